@@ -1,0 +1,157 @@
+"""ctypes binding of libfsamd.so (include/fenicssolver_amd.h).
+
+This is the only place that touches the C-ABI.  The reference has no FFI; the
+calls bound here stand in for the dolfin/PETSc calls made from
+FenicsSolver/SolverBase.py:592-672 (see the header for the per-function
+mapping).  There is NO CPU fallback: if the shared library is missing, or no
+gfx950 device is visible, every compute entry point raises ``BackendError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsamd.so")
+
+FS_OK = 0
+FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL = 0, 1, 2, 3, 4
+FS_KSP_CG = 0
+FS_PC_NONE, FS_PC_JACOBI = 0, 1
+FS_UNIQUE_ID_BYTES = 128
+
+c_i64 = C.c_int64
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class BackendError(RuntimeError):
+    """libfsamd.so is missing, no GPU is visible, or a call failed."""
+
+
+class fs_coef(C.Structure):
+    _fields_ = [("mode", C.c_int), ("value", C.c_double), ("data", c_f64p), ("tensor", C.c_double * 9)]
+
+
+class fs_bilinear_form(C.Structure):
+    _fields_ = [("stiffness", fs_coef), ("mass", fs_coef), ("lame_mu", C.c_double), ("lame_lambda", C.c_double)]
+
+
+class fs_linear_form(C.Structure):
+    _fields_ = [("source", fs_coef), ("vector_value", C.c_double * 3)]
+
+
+class fs_krylov_opts(C.Structure):
+    _fields_ = [("method", C.c_int), ("precond", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_iter", C.c_int), ("batch", C.c_int), ("nonzero_guess", C.c_int)]
+
+
+class fs_krylov_stats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("bnorm", C.c_double),
+                ("rel_residual", C.c_double), ("true_rel_residual", C.c_double), ("solve_ms", C.c_double),
+                ("spmv_ms", C.c_double), ("update_ms", C.c_double), ("spmv_bytes", c_i64)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/fenicssolver_amd.h
+_H = C.c_void_p
+SIGNATURES = {
+    "fs_init": (C.c_int, [C.c_int]),
+    "fs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "fs_device_synchronize": (C.c_int, []),
+    "fs_last_error": (C.c_char_p, []),
+    "fs_version": (C.c_char_p, []),
+    "fs_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
+    "fs_mesh_create": (C.c_int, [C.c_int, c_i64, c_f64p, c_i64, c_i32p, C.c_int, c_i64, C.POINTER(_H)]),
+    "fs_mesh_create_box": (C.c_int, [c_i64, c_i64, c_i64, c_f64p, c_f64p, c_i64, c_i64, C.POINTER(_H)]),
+    "fs_mesh_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p]),
+    "fs_mesh_get": (C.c_int, [_H, c_f64p, c_i32p, c_i64p]),
+    "fs_mesh_destroy": (C.c_int, [_H]),
+    "fs_space_create": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "fs_space_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p, c_i64p]),
+    "fs_space_destroy": (C.c_int, [_H]),
+    "fs_vector_create": (C.c_int, [c_i64, C.POINTER(_H)]),
+    "fs_vector_size": (C.c_int, [_H, c_i64p]),
+    "fs_vector_set": (C.c_int, [_H, c_f64p, c_i64]),
+    "fs_vector_get": (C.c_int, [_H, c_f64p, c_i64]),
+    "fs_vector_fill": (C.c_int, [_H, C.c_double]),
+    "fs_vector_axpy": (C.c_int, [_H, C.c_double, _H]),
+    "fs_vector_dot": (C.c_int, [_H, _H, c_f64p]),
+    "fs_vector_destroy": (C.c_int, [_H]),
+    "fs_matrix_create": (C.c_int, [_H, C.POINTER(_H)]),
+    "fs_matrix_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p]),
+    "fs_matrix_zero": (C.c_int, [_H]),
+    "fs_matrix_axpy": (C.c_int, [_H, C.c_double, _H]),
+    "fs_matrix_get_csr": (C.c_int, [_H, c_i32p, c_i32p, c_f64p]),
+    "fs_matrix_destroy": (C.c_int, [_H]),
+    "fs_assemble_matrix": (C.c_int, [_H, C.POINTER(fs_bilinear_form), C.c_int]),
+    "fs_assemble_vector": (C.c_int, [_H, C.POINTER(fs_linear_form), _H, C.c_int]),
+    "fs_assemble_facet_vector": (C.c_int, [_H, c_i64, c_i32p, c_f64p, _H]),
+    "fs_assemble_facet_matrix": (C.c_int, [_H, c_i64, c_i32p, c_f64p]),
+    "fs_apply_dirichlet": (C.c_int, [_H, _H, c_i64, c_i32p, c_f64p, C.c_int]),
+    "fs_spmv": (C.c_int, [_H, _H, _H]),
+    "fs_krylov_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
+    "fs_krylov_history": (C.c_int, [c_f64p, C.c_int, C.POINTER(C.c_int)]),
+    "fs_spmv_benchmark": (C.c_int, [_H, _H, _H, C.c_int, c_f64p]),
+    "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
+    "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+    "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fs_comm_allreduce_sum": (C.c_int, [c_f64p, C.c_int]),
+    "fs_comm_finalize": (C.c_int, []),
+    "fs_space_set_halo": (C.c_int, [_H, C.c_int, c_i32p, c_i64p, c_i32p, c_i64p]),
+    "fs_halo_exchange": (C.c_int, [_H, _H]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libfsamd.so and type every entry point.  Needs no GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). fenicssolver_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != FS_OK:
+        msg = load().fs_last_error()
+        raise BackendError("%s failed (code %d): %s" % (what or "libfsamd call", rc, (msg or b"").decode()))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def p_f64(a):
+    return a.ctypes.data_as(c_f64p) if a is not None else None
+
+
+def p_i32(a):
+    return a.ctypes.data_as(c_i32p) if a is not None else None
+
+
+def p_i64(a):
+    return a.ctypes.data_as(c_i64p) if a is not None else None

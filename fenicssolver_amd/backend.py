@@ -1,0 +1,315 @@
+"""Device objects over the C-ABI: meshes, function spaces, matrices, vectors
+and the Krylov solve, one GPU per process.
+
+These play the role of dolfin's Mesh/FunctionSpace/PETScMatrix/PETScVector/
+PETScKrylovSolver for the hot path of FenicsSolver/SolverBase.py:592-672.
+Everything here runs on the MI355X through libfsamd.so; nothing is computed
+on the host and nothing falls back to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from . import _lib as L
+from ._lib import BackendError  # noqa: F401  (re-export)
+
+
+def init(device_id=0):
+    L.check(L.load().fs_init(int(device_id)), "fs_init")
+
+
+def device_count():
+    n = C.c_int(0)
+    L.load().fs_device_count(C.byref(n))
+    return n.value
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_int64(0)
+    L.check(L.load().fs_device_info(name, 256, C.byref(cus), C.byref(mem)), "fs_device_info")
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+
+def synchronize():
+    L.check(L.load().fs_device_synchronize(), "fs_device_synchronize")
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self.h = C.c_void_p()
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            getattr(L.load(), self._destroy)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceMesh(_Handle):
+    """Tetrahedral mesh resident in HBM (dolfin.Mesh, SolverBase.py:203-258)."""
+    _destroy = "fs_mesh_destroy"
+
+    def __init__(self, coords=None, cells=None, n_owned=None):
+        super().__init__()
+        if coords is None:
+            return
+        coords = L.f64(coords)
+        cells = L.i32(cells)
+        if coords.ndim != 2 or cells.ndim != 2:
+            raise BackendError("DeviceMesh: coords must be [nv,gdim], cells [nc,verts]")
+        nv = coords.shape[0]
+        if n_owned is None:
+            n_owned = nv
+        self._keep = (coords, cells)
+        L.check(L.load().fs_mesh_create(coords.shape[1], nv, L.p_f64(coords), cells.shape[0], L.p_i32(cells),
+                                        cells.shape[1], int(n_owned), C.byref(self.h)), "fs_mesh_create")
+        self._keep = None
+
+    @classmethod
+    def box(cls, nx, ny, nz, p0=(0.0, 0.0, 0.0), p1=(1.0, 1.0, 1.0), zplanes=None):
+        """Slab [zplanes[0], zplanes[1]) of BoxMesh(p0,p1,nx,ny,nz) generated on the device."""
+        m = cls()
+        if zplanes is None:
+            zplanes = (0, nz + 1)
+        a = L.f64(p0)
+        b = L.f64(p1)
+        L.check(L.load().fs_mesh_create_box(int(nx), int(ny), int(nz), L.p_f64(a), L.p_f64(b), int(zplanes[0]),
+                                            int(zplanes[1]), C.byref(m.h)), "fs_mesh_create_box")
+        return m
+
+    def info(self):
+        nv, nc, no = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.load().fs_mesh_info(self.h, C.byref(nv), C.byref(nc), C.byref(no)), "fs_mesh_info")
+        return nv.value, nc.value, no.value
+
+    def get(self, want_coords=True, want_cells=True, want_gids=True):
+        nv, nc, _ = self.info()
+        xyz = np.empty((nv, 3)) if want_coords else None
+        cells = np.empty((nc, 4), dtype=np.int32) if want_cells else None
+        gid = np.empty(nv, dtype=np.int64) if want_gids else None
+        L.check(L.load().fs_mesh_get(self.h, L.p_f64(xyz), L.p_i32(cells), L.p_i64(gid)), "fs_mesh_get")
+        return xyz, cells, gid
+
+
+class DeviceSpace(_Handle):
+    """CG1 (scalar or 3-vector) space + sparsity (FunctionSpace, SolverBase.py:260-275)."""
+    _destroy = "fs_space_destroy"
+
+    def __init__(self, mesh, ncomp=1, degree=1):
+        super().__init__()
+        self.mesh = mesh
+        self.ncomp = int(ncomp)
+        L.check(L.load().fs_space_create(mesh.h, 0, int(degree), int(ncomp), C.byref(self.h)), "fs_space_create")
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.load().fs_space_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "fs_space_info")
+        self.n_local, self.n_owned, self.nnz, self.sell_entries = a.value, b.value, c.value, d.value
+
+    def set_halo(self, neighbors, send_lists, recv_counts):
+        """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour."""
+        nb = L.i32(neighbors)
+        sc = L.i64([len(s) for s in send_lists])
+        si = L.i32(np.concatenate([np.asarray(s, dtype=np.int32) for s in send_lists]) if len(send_lists) else [])
+        rc = L.i64(recv_counts)
+        L.check(L.load().fs_space_set_halo(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc)),
+                "fs_space_set_halo")
+
+
+class DeviceVector(_Handle):
+    _destroy = "fs_vector_destroy"
+
+    def __init__(self, n, values=None):
+        super().__init__()
+        self.n = int(n)
+        L.check(L.load().fs_vector_create(self.n, C.byref(self.h)), "fs_vector_create")
+        if values is not None:
+            self.set(values)
+
+    def set(self, values):
+        v = L.f64(values).ravel()
+        if v.size != self.n:
+            raise BackendError("DeviceVector.set: %d values for a vector of %d" % (v.size, self.n))
+        L.check(L.load().fs_vector_set(self.h, L.p_f64(v), self.n), "fs_vector_set")
+
+    def get(self, n=None):
+        n = self.n if n is None else int(n)
+        out = np.empty(n)
+        L.check(L.load().fs_vector_get(self.h, L.p_f64(out), n), "fs_vector_get")
+        return out
+
+    def fill(self, a):
+        L.check(L.load().fs_vector_fill(self.h, float(a)), "fs_vector_fill")
+
+    def axpy(self, a, x):
+        L.check(L.load().fs_vector_axpy(self.h, float(a), x.h), "fs_vector_axpy")
+
+    def dot(self, y):
+        r = C.c_double(0.0)
+        L.check(L.load().fs_vector_dot(self.h, y.h, C.byref(r)), "fs_vector_dot")
+        return r.value
+
+
+def _coef(spec, keep):
+    """spec: None | number | ('cell', array) | ('nodal', array) | ('tensor', 3x3)."""
+    c = L.fs_coef()
+    if spec is None:
+        c.mode = L.FS_COEF_NONE
+    elif isinstance(spec, tuple):
+        kind, arr = spec
+        if kind == "tensor":
+            c.mode = L.FS_COEF_TENSOR
+            t = L.f64(arr).reshape(9)
+            for i in range(9):
+                c.tensor[i] = t[i]
+        else:
+            a = L.f64(arr).ravel()
+            keep.append(a)
+            c.mode = L.FS_COEF_CELL if kind == "cell" else L.FS_COEF_NODAL
+            c.data = L.p_f64(a)
+    else:
+        c.mode = L.FS_COEF_CONST
+        c.value = float(spec)
+    return c
+
+
+class DeviceMatrix(_Handle):
+    """SELL-64 matrix on a space's pattern (PETSc AIJ behind dolfin.assemble)."""
+    _destroy = "fs_matrix_destroy"
+
+    def __init__(self, space):
+        super().__init__()
+        self.space = space
+        L.check(L.load().fs_matrix_create(space.h, C.byref(self.h)), "fs_matrix_create")
+
+    def assemble(self, stiffness=None, mass=None, lame=None, add=False):
+        keep = []
+        f = L.fs_bilinear_form()
+        f.stiffness = _coef(stiffness, keep)
+        f.mass = _coef(mass, keep)
+        if lame is not None:
+            f.lame_mu, f.lame_lambda = float(lame[0]), float(lame[1])
+        L.check(L.load().fs_assemble_matrix(self.h, C.byref(f), 1 if add else 0), "fs_assemble_matrix")
+
+    def add_facet_mass(self, tri, h):
+        tri = L.i32(tri).reshape(-1, 3)
+        h = L.f64(np.broadcast_to(h, (tri.shape[0],)))
+        L.check(L.load().fs_assemble_facet_matrix(self.h, tri.shape[0], L.p_i32(tri), L.p_f64(h)),
+                "fs_assemble_facet_matrix")
+
+    def axpy(self, a, X):
+        L.check(L.load().fs_matrix_axpy(self.h, float(a), X.h), "fs_matrix_axpy")
+
+    def zero(self):
+        L.check(L.load().fs_matrix_zero(self.h), "fs_matrix_zero")
+
+    def apply_dirichlet(self, b, dofs, vals, symmetric=True):
+        dofs = L.i32(dofs).ravel()
+        vals = L.f64(np.broadcast_to(vals, dofs.shape))
+        L.check(L.load().fs_apply_dirichlet(self.h, b.h if b is not None else None, dofs.size, L.p_i32(dofs),
+                                            L.p_f64(vals), 1 if symmetric else 0), "fs_apply_dirichlet")
+
+    def to_csr(self):
+        """(rowptr, colidx, vals) sorted-column CSR copy on the host."""
+        nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.load().fs_matrix_info(self.h, C.byref(nr), C.byref(ncol), C.byref(nnz)), "fs_matrix_info")
+        rp = np.empty(nr.value + 1, dtype=np.int32)
+        ci = np.empty(nnz.value, dtype=np.int32)
+        va = np.empty(nnz.value)
+        L.check(L.load().fs_matrix_get_csr(self.h, L.p_i32(rp), L.p_i32(ci), L.p_f64(va)), "fs_matrix_get_csr")
+        return rp, ci, va, (nr.value, ncol.value)
+
+    def spmv(self, x, y):
+        L.check(L.load().fs_spmv(self.h, x.h, y.h), "fs_spmv")
+
+    def spmv_benchmark(self, x, y, reps=20):
+        ms = C.c_double(0.0)
+        L.check(L.load().fs_spmv_benchmark(self.h, x.h, y.h, int(reps), C.byref(ms)), "fs_spmv_benchmark")
+        return ms.value
+
+
+def assemble_vector(space, b, source=None, vector_value=None, add=False):
+    keep = []
+    f = L.fs_linear_form()
+    f.source = _coef(source, keep)
+    if vector_value is not None:
+        for i in range(3):
+            f.vector_value[i] = float(vector_value[i])
+    L.check(L.load().fs_assemble_vector(space.h, C.byref(f), b.h, 1 if add else 0), "fs_assemble_vector")
+
+
+def assemble_facet_vector(space, b, tri, g):
+    """b_a += int g phi_a ds over the facets tri[nf,3]; g scalar, [ncomp], [nf] or [nf,ncomp]."""
+    tri = L.i32(tri).reshape(-1, 3)
+    nf, nc = tri.shape[0], space.ncomp
+    g = np.asarray(g, dtype=np.float64)
+    if g.ndim == 0:
+        g = np.full((nf, nc), float(g))
+    elif g.ndim == 1 and nc > 1 and g.size == nc:
+        g = np.broadcast_to(g[None, :], (nf, nc))
+    elif g.ndim == 1:
+        g = g.reshape(nf, 1) if nc == 1 else np.broadcast_to(g[:, None], (nf, nc))
+    g = L.f64(g)
+    if g.shape != (nf, nc):
+        raise BackendError("assemble_facet_vector: g has shape %s, expected (%d,%d)" % (g.shape, nf, nc))
+    L.check(L.load().fs_assemble_facet_vector(space.h, nf, L.p_i32(tri), L.p_f64(g), b.h),
+            "fs_assemble_facet_vector")
+
+
+def set_dirichlet_values(b, dofs, vals):
+    dofs = L.i32(dofs).ravel()
+    vals = L.f64(np.broadcast_to(vals, dofs.shape))
+    L.check(L.load().fs_apply_dirichlet(None, b.h, dofs.size, L.p_i32(dofs), L.p_f64(vals), 0), "fs_apply_dirichlet")
+
+
+def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False):
+    """CG on the device.  Returns a stats dict (iterations, converged, residuals, timings)."""
+    o = L.fs_krylov_opts()
+    o.method = L.FS_KSP_CG
+    o.precond = {"none": L.FS_PC_NONE, None: L.FS_PC_NONE, "jacobi": L.FS_PC_JACOBI}[precond]
+    o.rtol, o.atol, o.max_iter, o.batch = float(rtol), float(atol), int(max_iter), int(batch)
+    o.nonzero_guess = 1 if nonzero_guess else 0
+    st = L.fs_krylov_stats()
+    L.check(L.load().fs_krylov_solve(A.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_krylov_solve")
+    return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
+
+
+def krylov_history():
+    n = C.c_int(0)
+    L.load().fs_krylov_history(None, 0, C.byref(n))
+    out = np.empty(max(n.value, 1))
+    L.load().fs_krylov_history(L.p_f64(out), n.value, C.byref(n))
+    return out[: n.value]
+
+
+# ---- multi-GPU ------------------------------------------------------------------------------
+def comm_unique_id():
+    buf = C.create_string_buffer(L.FS_UNIQUE_ID_BYTES)
+    L.check(L.load().fs_comm_get_unique_id(buf), "fs_comm_get_unique_id")
+    return bytes(buf.raw)
+
+
+def comm_init(n_ranks, rank, uid):
+    L.check(L.load().fs_comm_init(int(n_ranks), int(rank), C.c_char_p(uid)), "fs_comm_init")
+
+
+def comm_finalize():
+    L.check(L.load().fs_comm_finalize(), "fs_comm_finalize")
+
+
+def comm_allreduce_sum(values):
+    v = L.f64(values).ravel().copy()
+    L.check(L.load().fs_comm_allreduce_sum(L.p_f64(v), v.size), "fs_comm_allreduce_sum")
+    return v
+
+
+def halo_exchange(space, v):
+    L.check(L.load().fs_halo_exchange(space.h, v.h), "fs_halo_exchange")

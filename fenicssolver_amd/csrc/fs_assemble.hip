@@ -1,0 +1,577 @@
+// Numeric assembly of libfsamd.so: per-cell quadrature + local tensors, scatter into
+// the SELL-64 matrix through the precomputed slot table, load vectors, boundary-facet
+// terms and Dirichlet application.
+//
+// Stands in for FFC's generated tabulate_tensor + DOLFIN's Assembler/SystemAssembler +
+// DirichletBC.apply reached from SolverBase.solve_linear_problem / solve_amg
+// (FenicsSolver/SolverBase.py:592-613, 643-672).  All kernels are HBM/L2-bound scatter
+// kernels: one thread per cell, 16-B coalesced loads of the cell's vertex ids and of the
+// slot column, hardware fp64 atomics (global_atomic_add_f64) for the scatter.
+#include "fs_common.h"
+#include <unordered_map>
+
+// ---- P1 geometry ---------------------------------------------------------------------------
+struct tet_geom {
+    double g[4][3];  // gradients of the barycentric basis
+    double adet;     // |det J|
+};
+
+__device__ __forceinline__ void load_vertex(const double* __restrict__ xyz4, int32_t v, double (&x)[3]) {
+    const double2 a = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)v];
+    const double2 b = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)v + 1];
+    x[0] = a.x; x[1] = a.y; x[2] = b.x;
+}
+
+__device__ __forceinline__ tet_geom tet_geometry(const double* __restrict__ xyz4, const int32_t (&v)[4]) {
+    double x0[3], x1[3], x2[3], x3[3];
+    load_vertex(xyz4, v[0], x0);
+    load_vertex(xyz4, v[1], x1);
+    load_vertex(xyz4, v[2], x2);
+    load_vertex(xyz4, v[3], x3);
+    const double e1[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    const double e2[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
+    const double e3[3] = {x3[0] - x0[0], x3[1] - x0[1], x3[2] - x0[2]};
+    // cofactors: grad lambda_1 = (e2 x e3)/det, grad lambda_2 = (e3 x e1)/det, grad lambda_3 = (e1 x e2)/det
+    const double c1[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    const double c2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    const double c3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = e1[0] * c1[0] + e1[1] * c1[1] + e1[2] * c1[2];
+    const double inv = 1.0 / det;
+    tet_geom t;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        t.g[1][d] = c1[d] * inv;
+        t.g[2][d] = c2[d] * inv;
+        t.g[3][d] = c3[d] * inv;
+        t.g[0][d] = -(t.g[1][d] + t.g[2][d] + t.g[3][d]);
+    }
+    t.adet = fabs(det);
+    return t;
+}
+
+struct coef_dev {
+    int mode;
+    double value;
+    const double* data;
+    double tensor[9];
+};
+
+// ---- scalar P1:  Ke = k vol grad_a.K.grad_b + m |J|/120 (1+delta_ab) ------------------------
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar(const int32_t* __restrict__ cells,
+                                                                 const double* __restrict__ xyz4,
+                                                                 const int32_t* __restrict__ slots, int64_t nc,
+                                                                 coef_dev kc, coef_dev mc,
+                                                                 double* __restrict__ val) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const tet_geom t = tet_geometry(xyz4, v);
+        const double vol = t.adet * (1.0 / 6.0);
+        double ke[4][4];
+        if (kc.mode == FS_COEF_TENSOR) {
+            double kg[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    kg[a][i] = kc.tensor[3 * i + 0] * t.g[a][0] + kc.tensor[3 * i + 1] * t.g[a][1] + kc.tensor[3 * i + 2] * t.g[a][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    ke[a][b] = vol * (t.g[a][0] * kg[b][0] + t.g[a][1] * kg[b][1] + t.g[a][2] * kg[b][2]);
+        } else {
+            double kk = 0.0;
+            if (kc.mode == FS_COEF_CONST) kk = kc.value;
+            else if (kc.mode == FS_COEF_CELL) kk = kc.data[c];
+            const double w = kk * vol;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) {
+                    const double x = w * (t.g[a][0] * t.g[b][0] + t.g[a][1] * t.g[b][1] + t.g[a][2] * t.g[b][2]);
+                    ke[a][b] = x;
+                    ke[b][a] = x;
+                }
+        }
+        if (mc.mode != FS_COEF_NONE) {
+            const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.adet * (1.0 / 120.0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ke[a][b] += (a == b ? 2.0 : 1.0) * mm;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int32_t slot = slots[(int64_t)(a * 4 + b) * nc + c];
+                if (slot >= 0) atomicAdd(&val[slot], ke[a][b]);
+            }
+    }
+}
+
+// ---- vector P1 elasticity: 3x3 block per node pair, plane (i*3+j) of the SELL value array ------
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32_t* __restrict__ cells,
+                                                                     const double* __restrict__ xyz4,
+                                                                     const int32_t* __restrict__ slots, int64_t nc,
+                                                                     double mu, double lambda, coef_dev mc,
+                                                                     int64_t plane, double* __restrict__ val) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const tet_geom t = tet_geometry(xyz4, v);
+        const double vol = t.adet * (1.0 / 6.0);
+        double mm = 0.0;
+        if (mc.mode != FS_COEF_NONE) mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.adet * (1.0 / 120.0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int32_t slot = slots[(int64_t)(a * 4 + b) * nc + c];
+                if (slot < 0) continue;
+                const double gg = t.g[a][0] * t.g[b][0] + t.g[a][1] * t.g[b][1] + t.g[a][2] * t.g[b][2];
+                const double ms = (a == b ? 2.0 : 1.0) * mm;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double x = vol * (lambda * t.g[a][i] * t.g[b][j] + mu * t.g[a][j] * t.g[b][i]);
+                        if (i == j) x += vol * mu * gg + ms;
+                        atomicAdd(&val[(int64_t)(i * 3 + j) * plane + slot], x);
+                    }
+            }
+    }
+}
+
+// ---- load vectors -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
+                                                                 const double* __restrict__ xyz4, int64_t nc,
+                                                                 int64_t n_rows, coef_dev f, int ncomp, double fx,
+                                                                 double fy, double fz, double* __restrict__ b) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const tet_geom t = tet_geometry(xyz4, v);
+        if (ncomp == 1) {
+            double be[4];
+            if (f.mode == FS_COEF_NODAL) {
+                // b_e = M_e f_e with the exact P1 mass matrix
+                const double fe[4] = {f.data[v[0]], f.data[v[1]], f.data[v[2]], f.data[v[3]]};
+                const double sum = (fe[0] + fe[1]) + (fe[2] + fe[3]);
+                const double m = t.adet * (1.0 / 120.0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) be[a] = m * (sum + fe[a]);
+            } else {
+                const double ff = f.mode == FS_COEF_CONST ? f.value : f.data[c];
+                const double w = ff * t.adet * (1.0 / 24.0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) be[a] = w;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (v[a] < n_rows) atomicAdd(&b[v[a]], be[a]);
+        } else {
+            const double w = t.adet * (1.0 / 24.0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (v[a] < n_rows) {
+                    atomicAdd(&b[3 * (int64_t)v[a] + 0], w * fx);
+                    atomicAdd(&b[3 * (int64_t)v[a] + 1], w * fy);
+                    atomicAdd(&b[3 * (int64_t)v[a] + 2], w * fz);
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ double tri_area(const double* __restrict__ xyz4, int32_t a, int32_t b, int32_t c) {
+    double x0[3], x1[3], x2[3];
+    load_vertex(xyz4, a, x0);
+    load_vertex(xyz4, b, x1);
+    load_vertex(xyz4, c, x2);
+    const double u[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    const double w[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
+    const double n[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+    return 0.5 * sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+}
+
+__global__ void k_facet_vector(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
+                               const double* __restrict__ g, int ncomp, int64_t n_rows, double* __restrict__ b) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t v[3] = {tri[3 * f], tri[3 * f + 1], tri[3 * f + 2]};
+        const double w = tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 3.0);
+        for (int a = 0; a < 3; ++a) {
+            if (v[a] >= n_rows) continue;
+            for (int i = 0; i < ncomp; ++i) atomicAdd(&b[(int64_t)v[a] * ncomp + i], w * g[f * ncomp + i]);
+        }
+    }
+}
+
+__global__ void k_facet_matrix(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
+                               const double* __restrict__ h, int64_t n_rows, const int32_t* __restrict__ rowptr,
+                               const int32_t* __restrict__ colidx, const int64_t* __restrict__ slice_ptr,
+                               double* __restrict__ val, int* __restrict__ err) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t v[3] = {tri[3 * f], tri[3 * f + 1], tri[3 * f + 2]};
+        const double w = h[f] * tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 12.0);
+        for (int a = 0; a < 3; ++a) {
+            const int32_t row = v[a];
+            if (row >= n_rows) continue;
+            const int32_t start = rowptr[row], end = rowptr[row + 1];
+            const int64_t base = slice_ptr[row >> 6] + (row & 63);
+            for (int b = 0; b < 3; ++b) {
+                int32_t lo = start, hi = end;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi) >> 1;
+                    if (colidx[mid] < v[b]) lo = mid + 1; else hi = mid;
+                }
+                if (lo < end && colidx[lo] == v[b]) atomicAdd(&val[base + (int64_t)(lo - start) * FS_SLICE], (a == b ? 2.0 : 1.0) * w);
+                else atomicAdd(err, 1);
+            }
+        }
+    }
+}
+
+// ---- Dirichlet ------------------------------------------------------------------------------------
+__global__ void k_bc_scatter(const int32_t* __restrict__ dofs, const double* __restrict__ vals, int64_t n,
+                             uint8_t* __restrict__ flag, double* __restrict__ g) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        flag[dofs[i]] = 1;
+        g[dofs[i]] = vals[i];
+    }
+}
+
+__global__ void k_bc_vector(const int32_t* __restrict__ dofs, const double* __restrict__ vals, int64_t n,
+                            int64_t n_rows_dofs, double* __restrict__ b) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        if (dofs[i] < n_rows_dofs) b[dofs[i]] = vals[i];
+}
+
+// one wavefront per SELL slice, lane = node row; rows of constrained dofs become identity,
+// (symmetric) constrained columns are folded into b and zeroed.
+template <int BS>
+__global__ void __launch_bounds__(FS_BLOCK) k_dirichlet_sell(int64_t n_rows, int64_t n_slices,
+                                                             const int64_t* __restrict__ slice_ptr,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ sell_col,
+                                                             double* __restrict__ val, int64_t plane,
+                                                             const uint8_t* __restrict__ flag,
+                                                             const double* __restrict__ g, double* __restrict__ b,
+                                                             int symmetric) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t r = s * FS_SLICE + lane;
+        if (r >= n_rows) continue;
+        const int64_t base = slice_ptr[s] + lane;
+        const int len = rowptr[r + 1] - rowptr[r];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            const int64_t dofr = r * BS + i;
+            const bool fr = flag[dofr] != 0;
+            double bacc = 0.0;
+            for (int k = 0; k < len; ++k) {
+                const int64_t e = base + (int64_t)k * FS_SLICE;
+                const int32_t c = sell_col[e];
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    const int64_t idx = (int64_t)(i * BS + j) * plane + e;
+                    if (fr) {
+                        val[idx] = (c == r && i == j) ? 1.0 : 0.0;
+                    } else if (symmetric && flag[(int64_t)c * BS + j]) {
+                        bacc += val[idx] * g[(int64_t)c * BS + j];
+                        val[idx] = 0.0;
+                    }
+                }
+            }
+            if (b) {
+                if (fr) b[dofr] = g[dofr];
+                else if (symmetric) b[dofr] -= bacc;
+            }
+        }
+    }
+}
+
+// ---- CSR export ---------------------------------------------------------------------------------------
+template <int BS>
+__global__ void k_export_csr(int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ rowptr,
+                             const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
+                             int32_t* __restrict__ out_rowptr, int32_t* __restrict__ out_col,
+                             double* __restrict__ out_val) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t base = slice_ptr[r >> 6] + (r & 63);
+        const int32_t start = rowptr[r];
+        const int len = rowptr[r + 1] - start;
+        for (int i = 0; i < BS; ++i) {
+            const int64_t o = (int64_t)BS * BS * start + (int64_t)i * BS * len;
+            if (out_rowptr) out_rowptr[r * BS + i] = (int32_t)o;
+            for (int k = 0; k < len; ++k) {
+                const int64_t e = base + (int64_t)k * FS_SLICE;
+                for (int j = 0; j < BS; ++j) {
+                    if (out_col) out_col[o + (int64_t)k * BS + j] = sell_col[e] * BS + j;
+                    if (out_val) out_val[o + (int64_t)k * BS + j] = val[(int64_t)(i * BS + j) * plane + e];
+                }
+            }
+        }
+        if (r == n_rows - 1 && out_rowptr) out_rowptr[n_rows * BS] = (int32_t)((int64_t)BS * BS * rowptr[n_rows]);
+    }
+}
+
+__global__ void k_mat_axpy(double* __restrict__ y, const double* __restrict__ x, int64_t n, double a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] += a * x[i];
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static int make_coef(const fs_coef& in, int64_t expect_len, dbuf<double>& store, coef_dev* out, const char* what) {
+    out->mode = in.mode;
+    out->value = in.value;
+    out->data = nullptr;
+    for (int i = 0; i < 9; ++i) out->tensor[i] = in.tensor[i];
+    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL) {
+        FS_REQUIRE(in.data, "%s: coefficient data pointer is null", what);
+        FS_CHECK(store.alloc(expect_len));
+        FS_CHECK(store.upload(in.data, expect_len, fs_rt().stream));
+        out->data = store.p;
+    } else if (in.mode != FS_COEF_NONE && in.mode != FS_COEF_CONST && in.mode != FS_COEF_TENSOR) {
+        fs_set_error("%s: unknown coefficient mode %d", what, in.mode);
+        return FS_ERR_INVALID;
+    }
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_create(fs_space_t space, fs_matrix_t* out) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(space && out, "fs_matrix_create: null pointer");
+    fs_matrix_s* A = new fs_matrix_s();
+    A->space = space;
+    A->bs = space->ncomp;
+    int rc = A->val.alloc(space->sell_entries * A->bs * A->bs);
+    if (rc == FS_OK) rc = A->val.zero(fs_rt().stream);
+    if (rc == FS_OK && hipStreamSynchronize(fs_rt().stream) != hipSuccess) rc = FS_ERR_HIP;
+    if (rc != FS_OK) {
+        delete A;
+        return rc;
+    }
+    *out = A;
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_info(fs_matrix_t A, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
+    FS_REQUIRE(A, "fs_matrix_info: null matrix");
+    if (n_rows) *n_rows = A->space->n_dofs_owned;
+    if (n_cols) *n_cols = A->space->n_dofs_local;
+    if (nnz) *nnz = A->space->nnz_nodes * A->bs * A->bs;
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_zero(fs_matrix_t A) {
+    FS_REQUIRE(A, "fs_matrix_zero: null matrix");
+    FS_CHECK(A->val.zero(fs_rt().stream));
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_axpy(fs_matrix_t Y, double a, fs_matrix_t X) {
+    FS_REQUIRE(X && Y && X->space == Y->space, "fs_matrix_axpy: matrices must share a function space");
+    hipLaunchKernelGGL(k_mat_axpy, dim3(fs_grid_for(Y->val.n)), dim3(FS_BLOCK), 0, fs_rt().stream, Y->val.p, X->val.p, Y->val.n, a);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_destroy(fs_matrix_t A) {
+    delete A;
+    return FS_OK;
+}
+
+extern "C" int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx, double* vals) {
+    FS_REQUIRE(A, "fs_matrix_get_csr: null matrix");
+    fs_space_s* sp = A->space;
+    hipStream_t s = fs_rt().stream;
+    const int bs = A->bs;
+    const int64_t n_rows = sp->n_nodes_owned, nnz = sp->nnz_nodes * bs * bs;
+    FS_REQUIRE(nnz < (int64_t)INT32_MAX, "fs_matrix_get_csr: nnz exceeds int32");
+    dbuf<int32_t> d_rp, d_ci;
+    dbuf<double> d_v;
+    if (rowptr) FS_CHECK(d_rp.alloc(n_rows * bs + 1));
+    if (colidx) FS_CHECK(d_ci.alloc(nnz));
+    if (vals) FS_CHECK(d_v.alloc(nnz));
+    if (bs == 1)
+        hipLaunchKernelGGL(k_export_csr<1>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
+    else
+        hipLaunchKernelGGL(k_export_csr<3>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
+    FS_KERNEL_CHECK();
+    if (rowptr) FS_CHECK(d_rp.download(rowptr, n_rows * bs + 1, s));
+    if (colidx) FS_CHECK(d_ci.download(colidx, nnz, s));
+    if (vals) FS_CHECK(d_v.download(vals, nnz, s));
+    return FS_OK;
+}
+
+extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, int add) {
+    FS_REQUIRE(A && form, "fs_assemble_matrix: null pointer");
+    fs_space_s* sp = A->space;
+    fs_mesh_s* m = sp->mesh;
+    hipStream_t s = fs_rt().stream;
+    if (!add) FS_CHECK(A->val.zero(s));
+    dbuf<double> kstore, mstore;
+    coef_dev kc, mc;
+    FS_CHECK(make_coef(form->mass, m->nc, mstore, &mc, "fs_assemble_matrix(mass)"));
+    FS_REQUIRE(mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL,
+               "fs_assemble_matrix: mass coefficient must be constant or per cell");
+    const int grid = fs_grid_for(m->nc, FS_BLOCK, 8192);
+    if (A->bs == 1) {
+        FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
+        FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
+        hipLaunchKernelGGL(k_assemble_p1_scalar, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, kc, mc, A->val.p);
+    } else {
+        hipLaunchKernelGGL(k_assemble_p1_elasticity, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+    }
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add) {
+    FS_REQUIRE(space && form && b, "fs_assemble_vector: null pointer");
+    FS_REQUIRE(b->d.n >= space->n_dofs_owned, "fs_assemble_vector: vector shorter than the owned dofs");
+    fs_mesh_s* m = space->mesh;
+    hipStream_t s = fs_rt().stream;
+    if (!add) FS_CHECK(b->d.zero(s));
+    dbuf<double> store;
+    coef_dev f;
+    const int64_t len = form->source.mode == FS_COEF_NODAL ? space->n_nodes_local : m->nc;
+    FS_CHECK(make_coef(form->source, len, store, &f, "fs_assemble_vector(source)"));
+    if (space->ncomp == 1 && f.mode == FS_COEF_NONE) {
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
+    FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor source is meaningless");
+    hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], b->d.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, const int32_t* tri, const double* g,
+                                        fs_vector_t b) {
+    FS_REQUIRE(space && b && (n_facets == 0 || (tri && g)), "fs_assemble_facet_vector: null pointer");
+    if (n_facets == 0) return FS_OK;
+    for (int64_t i = 0; i < 3 * n_facets; ++i)
+        FS_REQUIRE(tri[i] >= 0 && tri[i] < space->n_nodes_local, "fs_assemble_facet_vector: facet vertex %d out of range", tri[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> d_tri;
+    dbuf<double> d_g;
+    FS_CHECK(d_tri.alloc(3 * n_facets));
+    FS_CHECK(d_g.alloc(n_facets * space->ncomp));
+    FS_CHECK(d_tri.upload(tri, 3 * n_facets, s));
+    FS_CHECK(d_g.upload(g, n_facets * space->ncomp, s));
+    hipLaunchKernelGGL(k_facet_vector, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->ncomp, space->n_nodes_owned, b->d.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const int32_t* tri, const double* h) {
+    FS_REQUIRE(A && (n_facets == 0 || (tri && h)), "fs_assemble_facet_matrix: null pointer");
+    if (A->bs != 1) {
+        fs_set_error("fs_assemble_facet_matrix: only scalar spaces (Robin/HTC term) are supported");
+        return FS_ERR_UNSUPPORTED;
+    }
+    if (n_facets == 0) return FS_OK;
+    fs_space_s* sp = A->space;
+    for (int64_t i = 0; i < 3 * n_facets; ++i)
+        FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->n_nodes_local, "fs_assemble_facet_matrix: facet vertex %d out of range", tri[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> d_tri;
+    dbuf<double> d_h;
+    dbuf<int> d_err;
+    FS_CHECK(d_tri.alloc(3 * n_facets));
+    FS_CHECK(d_h.alloc(n_facets));
+    FS_CHECK(d_err.alloc(1));
+    FS_CHECK(d_err.zero(s));
+    FS_CHECK(d_tri.upload(tri, 3 * n_facets, s));
+    FS_CHECK(d_h.upload(h, n_facets, s));
+    hipLaunchKernelGGL(k_facet_matrix, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, sp->mesh->xyz.p, d_tri.p, n_facets, d_h.p, sp->n_nodes_owned, sp->rowptr.p, sp->colidx.p, sp->slice_ptr.p, A->val.p, d_err.p);
+    FS_KERNEL_CHECK();
+    int h_err = 0;
+    FS_CHECK(d_err.download(&h_err, 1, s));
+    FS_REQUIRE(h_err == 0, "fs_assemble_facet_matrix: %d facet vertex pairs are not mesh edges", h_err);
+    return FS_OK;
+}
+
+extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const int32_t* dofs, const double* vals,
+                                  int symmetric) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A || b, "fs_apply_dirichlet: both A and b are null");
+    FS_REQUIRE(n == 0 || (dofs && vals), "fs_apply_dirichlet: null dof list");
+    if (n == 0) return FS_OK;
+    hipStream_t s = fs_rt().stream;
+    // later entries win on duplicates (DOLFIN applies BCs in list order)
+    std::vector<int32_t> h_dofs;
+    std::vector<double> h_vals;
+    {
+        std::unordered_map<int32_t, int64_t> last;
+        last.reserve((size_t)n * 2);
+        for (int64_t i = 0; i < n; ++i) last[dofs[i]] = i;
+        h_dofs.reserve(last.size());
+        h_vals.reserve(last.size());
+        for (int64_t i = 0; i < n; ++i)
+            if (last[dofs[i]] == i) {
+                h_dofs.push_back(dofs[i]);
+                h_vals.push_back(vals[i]);
+            }
+    }
+    const int64_t nu = (int64_t)h_dofs.size();
+    dbuf<int32_t> d_dofs;
+    dbuf<double> d_vals;
+    FS_CHECK(d_dofs.alloc(nu));
+    FS_CHECK(d_vals.alloc(nu));
+    FS_CHECK(d_dofs.upload(h_dofs.data(), nu, s));
+    FS_CHECK(d_vals.upload(h_vals.data(), nu, s));
+    if (!A) {
+        hipLaunchKernelGGL(k_bc_vector, dim3(fs_grid_for(nu)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, nu, b->d.n, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
+    fs_space_s* sp = A->space;
+    for (int64_t i = 0; i < nu; ++i)
+        FS_REQUIRE(h_dofs[i] >= 0 && h_dofs[i] < sp->n_dofs_local, "fs_apply_dirichlet: dof %d outside [0,%lld)", h_dofs[i], (long long)sp->n_dofs_local);
+    FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_apply_dirichlet: b shorter than the owned dofs");
+    dbuf<uint8_t> flag;
+    dbuf<double> g;
+    FS_CHECK(flag.alloc(sp->n_dofs_local));
+    FS_CHECK(g.alloc(sp->n_dofs_local));
+    FS_CHECK(flag.zero(s));
+    FS_CHECK(g.zero(s));
+    hipLaunchKernelGGL(k_bc_scatter, dim3(fs_grid_for(nu)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, nu, flag.p, g.p);
+    FS_KERNEL_CHECK();
+    const int grid = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
+    double* bp = b ? b->d.p : nullptr;
+    if (A->bs == 1)
+        hipLaunchKernelGGL(k_dirichlet_sell<1>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+    else
+        hipLaunchKernelGGL(k_dirichlet_sell<3>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}

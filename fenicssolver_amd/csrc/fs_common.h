@@ -1,0 +1,164 @@
+// Internal definitions shared by the libfsamd.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+#include <string>
+
+#include "../../include/fenicssolver_amd.h"
+
+#define FS_WAVE 64            // CDNA wavefront
+#define FS_SLICE 64           // SELL slice height = one wavefront
+#define FS_BLOCK 256          // workgroup size of every kernel (4 waves)
+#define FS_MAX_PARTIAL_BLOCKS 1024
+
+// ---- error plumbing -----------------------------------------------------------
+void fs_set_error(const char* fmt, ...);
+
+#define FS_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            fs_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                         __LINE__);                                                       \
+            return FS_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define FS_CHECK(call)              \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != FS_OK) return rc__; \
+    } while (0)
+
+#define FS_REQUIRE(cond, ...)         \
+    do {                              \
+        if (!(cond)) {                \
+            fs_set_error(__VA_ARGS__); \
+            return FS_ERR_INVALID;    \
+        }                             \
+    } while (0)
+
+#define FS_KERNEL_CHECK() FS_HIP(hipGetLastError())
+
+// ---- runtime state -------------------------------------------------------------
+struct fs_runtime {
+    bool initialised = false;
+    int device = -1;
+    int compute_units = 0;
+    hipStream_t stream = nullptr;  // every kernel of the library runs on this stream
+    // communicator (RCCL), see fs_comm.hip
+    int n_ranks = 1;
+    int rank = 0;
+    void* comm = nullptr;
+};
+fs_runtime& fs_rt();
+int fs_require_init();
+
+// ---- device buffer -------------------------------------------------------------
+template <typename T>
+struct dbuf {
+    T* p = nullptr;
+    int64_t n = 0;
+    int alloc(int64_t count) {
+        release();
+        n = count;
+        if (count == 0) return FS_OK;
+        FS_HIP(hipMalloc((void**)&p, (size_t)count * sizeof(T)));
+        return FS_OK;
+    }
+    int zero(hipStream_t s) {
+        if (n) FS_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(T), s));
+        return FS_OK;
+    }
+    int upload(const T* host, int64_t count, hipStream_t s) {
+        if (count) {
+            FS_HIP(hipMemcpyAsync(p, host, (size_t)count * sizeof(T), hipMemcpyHostToDevice, s));
+            FS_HIP(hipStreamSynchronize(s));
+        }
+        return FS_OK;
+    }
+    int download(T* host, int64_t count, hipStream_t s) const {
+        if (count) {
+            FS_HIP(hipMemcpyAsync(host, p, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, s));
+            FS_HIP(hipStreamSynchronize(s));
+        }
+        return FS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~dbuf() { release(); }
+    dbuf() = default;
+    dbuf(const dbuf&) = delete;
+    dbuf& operator=(const dbuf&) = delete;
+};
+
+// ---- handles ---------------------------------------------------------------------
+struct fs_mesh_s {
+    int64_t nv = 0;       // local vertices (owned + ghost)
+    int64_t nc = 0;       // local cells
+    int64_t n_owned = 0;  // owned vertices (first n_owned local ids)
+    dbuf<double> xyz;     // [nv][4] padded (x,y,z,0): two 16-B loads per vertex
+    dbuf<int32_t> cells;  // [nc][4] local vertex ids
+    dbuf<int64_t> gid;    // [nv] global vertex ids
+};
+
+struct fs_halo_plan {
+    bool active = false;
+    std::vector<int> neighbors;
+    std::vector<int64_t> send_counts, send_offsets, recv_counts, recv_offsets;
+    std::vector<char> send_contiguous;     // send list of neighbour i is a contiguous range
+    std::vector<int64_t> send_first;       // first index of that range
+    dbuf<int32_t> send_idx;                // concatenated
+    dbuf<double> send_buf;                 // packed values (non-contiguous lists)
+    int64_t total_send = 0, total_recv = 0;
+};
+
+struct fs_space_s {
+    fs_mesh_s* mesh = nullptr;
+    int degree = 1;
+    int ncomp = 1;
+    int64_t n_nodes_local = 0, n_nodes_owned = 0;  // node level
+    int64_t n_dofs_local = 0, n_dofs_owned = 0;    // = nodes * ncomp
+    // node-level sparsity: CSR + SELL-64
+    int64_t nnz_nodes = 0;        // node-pair entries
+    int64_t n_slices = 0;
+    int64_t sell_entries = 0;     // padded node-pair entries (sum width*64)
+    int max_row = 0;
+    dbuf<int32_t> rowptr;         // [n_nodes_owned+1]
+    dbuf<int32_t> colidx;         // [nnz_nodes]
+    dbuf<int64_t> slice_ptr;      // [n_slices+1] offsets into sell arrays (entries)
+    dbuf<int32_t> sell_col;       // [sell_entries] node column, padding = own row
+    dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned
+    fs_halo_plan halo;
+};
+
+struct fs_matrix_s {
+    fs_space_s* space = nullptr;
+    int bs = 1;                   // block size (ncomp)
+    dbuf<double> val;             // [sell_entries * bs*bs]; block entry e, (i,j) at ((i*bs+j)*sell_entries + e)
+};
+
+struct fs_vector_s {
+    dbuf<double> d;
+};
+
+// grid for a grid-stride elementwise / per-row kernel
+static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int cap = 2048) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---- cross-TU internals ------------------------------------------------------------------
+// RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.
+int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
+int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s);

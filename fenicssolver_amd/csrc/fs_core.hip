@@ -1,0 +1,367 @@
+// Runtime, vectors and meshes of libfsamd.so (gfx950).
+#include "fs_common.h"
+#include "fs_kernels.h"
+
+// ---- errors / runtime --------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void fs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+fs_runtime& fs_rt() {
+    static fs_runtime rt;
+    return rt;
+}
+
+int fs_require_init() {
+    if (!fs_rt().initialised) {
+        // implicit init on device 0 keeps single-GPU callers short, but still fails
+        // loudly when there is no GPU: there is no CPU path in this library.
+        return fs_init(0);
+    }
+    return FS_OK;
+}
+
+extern "C" const char* fs_last_error(void) { return g_err; }
+extern "C" const char* fs_version(void) { return "fenicssolver_amd 0.1 (gfx950, fp64)"; }
+
+extern "C" int fs_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        n = 0;
+        (void)hipGetLastError();
+    }
+    *count = n;
+    return FS_OK;
+}
+
+extern "C" int fs_init(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        fs_set_error("no HIP device visible (hipGetDeviceCount: %s); libfsamd has no CPU fallback",
+                     e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return FS_ERR_NO_DEVICE;
+    }
+    FS_REQUIRE(device_id >= 0 && device_id < n, "fs_init: device %d out of range (0..%d)", device_id, n - 1);
+    fs_runtime& rt = fs_rt();
+    if (rt.initialised && rt.device == device_id) return FS_OK;
+    FS_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    FS_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (rt.stream) (void)hipStreamDestroy(rt.stream);
+    FS_HIP(hipStreamCreateWithFlags(&rt.stream, hipStreamNonBlocking));
+    rt.device = device_id;
+    rt.compute_units = prop.multiProcessorCount;
+    rt.initialised = true;
+    return FS_OK;
+}
+
+extern "C" int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes) {
+    FS_CHECK(fs_require_init());
+    hipDeviceProp_t prop;
+    FS_HIP(hipGetDeviceProperties(&prop, fs_rt().device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return FS_OK;
+}
+
+extern "C" int fs_device_synchronize(void) {
+    FS_CHECK(fs_require_init());
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    FS_HIP(hipDeviceSynchronize());
+    return FS_OK;
+}
+
+// ---- vectors ------------------------------------------------------------------------
+__global__ void k_fill(double* __restrict__ v, int64_t n, double a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] = a;
+}
+
+__global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, int64_t n, double a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] += a * x[i];
+}
+
+extern "C" int fs_vector_create(int64_t n, fs_vector_t* out) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(n >= 0 && out, "fs_vector_create: bad arguments");
+    fs_vector_s* v = new fs_vector_s();
+    int rc = v->d.alloc(n);
+    if (rc == FS_OK) rc = v->d.zero(fs_rt().stream);
+    if (rc == FS_OK && hipStreamSynchronize(fs_rt().stream) != hipSuccess) rc = FS_ERR_HIP;
+    if (rc != FS_OK) {
+        delete v;
+        return rc;
+    }
+    *out = v;
+    return FS_OK;
+}
+
+extern "C" int fs_vector_size(fs_vector_t v, int64_t* n) {
+    FS_REQUIRE(v && n, "fs_vector_size: null");
+    *n = v->d.n;
+    return FS_OK;
+}
+
+extern "C" int fs_vector_set(fs_vector_t v, const double* host, int64_t n) {
+    FS_REQUIRE(v && host && n == v->d.n, "fs_vector_set: size mismatch (%lld vs %lld)", (long long)n,
+               v ? (long long)v->d.n : -1LL);
+    return v->d.upload(host, n, fs_rt().stream);
+}
+
+extern "C" int fs_vector_get(fs_vector_t v, double* host, int64_t n) {
+    FS_REQUIRE(v && host && n <= v->d.n, "fs_vector_get: size mismatch");
+    return v->d.download(host, n, fs_rt().stream);
+}
+
+extern "C" int fs_vector_fill(fs_vector_t v, double value) {
+    FS_REQUIRE(v, "fs_vector_fill: null");
+    if (v->d.n == 0) return FS_OK;
+    hipLaunchKernelGGL(k_fill, dim3(fs_grid_for(v->d.n)), dim3(FS_BLOCK), 0, fs_rt().stream, v->d.p, v->d.n, value);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    return FS_OK;
+}
+
+extern "C" int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x) {
+    FS_REQUIRE(x && y && x->d.n == y->d.n, "fs_vector_axpy: size mismatch");
+    if (y->d.n == 0) return FS_OK;
+    hipLaunchKernelGGL(k_axpy, dim3(fs_grid_for(y->d.n)), dim3(FS_BLOCK), 0, fs_rt().stream, y->d.p, x->d.p, y->d.n, a);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    return FS_OK;
+}
+
+extern "C" int fs_vector_dot(fs_vector_t x, fs_vector_t y, double* result) {
+    FS_REQUIRE(x && y && result, "fs_vector_dot: null");
+    int64_t n = x->d.n < y->d.n ? x->d.n : y->d.n;
+    hipStream_t s = fs_rt().stream;
+    int grid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
+    dbuf<double> part;
+    FS_CHECK(part.alloc(grid + 1));
+    hipLaunchKernelGGL(k_dot_partial, dim3(grid), dim3(FS_BLOCK), 0, s, x->d.p, y->d.p, n, part.p);
+    FS_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, part.p, grid, 1, part.p + grid);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipMemcpyAsync(result, part.p + grid, sizeof(double), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_vector_destroy(fs_vector_t v) {
+    delete v;
+    return FS_OK;
+}
+
+// ---- meshes ---------------------------------------------------------------------------
+__global__ void k_pad_xyz(const double* __restrict__ xyz3, double* __restrict__ xyz4, int64_t nv) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nv; i += stride) {
+        xyz4[4 * i + 0] = xyz3[3 * i + 0];
+        xyz4[4 * i + 1] = xyz3[3 * i + 1];
+        xyz4[4 * i + 2] = xyz3[3 * i + 2];
+        xyz4[4 * i + 3] = 0.0;
+    }
+}
+
+__global__ void k_iota64(int64_t* __restrict__ v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] = i;
+}
+
+extern "C" int fs_mesh_create(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells,
+                              int verts_per_cell, int64_t n_owned, fs_mesh_t* out) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(out && xyz && cells, "fs_mesh_create: null pointer");
+    if (gdim != 3 || verts_per_cell != 4) {
+        fs_set_error("fs_mesh_create: only tetrahedral meshes in 3D are supported (gdim=%d, verts_per_cell=%d)",
+                     gdim, verts_per_cell);
+        return FS_ERR_UNSUPPORTED;
+    }
+    FS_REQUIRE(nv > 0 && nc > 0 && n_owned >= 0 && n_owned <= nv, "fs_mesh_create: bad sizes");
+    FS_REQUIRE(nv < (int64_t)INT32_MAX, "fs_mesh_create: vertex count exceeds int32");
+    for (int64_t i = 0; i < nc * 4; ++i) {
+        if (cells[i] < 0 || cells[i] >= nv) {
+            fs_set_error("fs_mesh_create: cell %lld references vertex %d outside [0,%lld)", (long long)(i / 4),
+                         cells[i], (long long)nv);
+            return FS_ERR_INVALID;
+        }
+    }
+    hipStream_t s = fs_rt().stream;
+    fs_mesh_s* m = new fs_mesh_s();
+    m->nv = nv;
+    m->nc = nc;
+    m->n_owned = n_owned;
+    dbuf<double> tmp;
+    int rc = FS_OK;
+    if ((rc = m->xyz.alloc(nv * 4)) != FS_OK || (rc = m->cells.alloc(nc * 4)) != FS_OK ||
+        (rc = m->gid.alloc(nv)) != FS_OK || (rc = tmp.alloc(nv * 3)) != FS_OK ||
+        (rc = tmp.upload(xyz, nv * 3, s)) != FS_OK || (rc = m->cells.upload(cells, nc * 4, s)) != FS_OK) {
+        delete m;
+        return rc;
+    }
+    hipLaunchKernelGGL(k_pad_xyz, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, tmp.p, m->xyz.p, nv);
+    hipLaunchKernelGGL(k_iota64, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, m->gid.p, nv);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        fs_set_error("fs_mesh_create: kernel launch failed");
+        delete m;
+        return FS_ERR_HIP;
+    }
+    *out = m;
+    return FS_OK;
+}
+
+// Slab of dolfin.BoxMesh generated on the device.  One thread per local vertex /
+// per local hexahedron (6 tets).
+struct box_desc {
+    int64_t nx, ny, nz;      // global cells per axis
+    double p0[3], p1[3];
+    int64_t zb, ze;          // owned vertex planes [zb, ze)
+    int64_t kz0, kz1;        // local cell layers [kz0, kz1)
+    int64_t plane;           // (nx+1)*(ny+1)
+    int64_t n_owned;
+    int has_lower, has_upper;
+};
+
+__device__ __forceinline__ int32_t box_local_id(const box_desc& d, int64_t ix, int64_t iy, int64_t iz) {
+    const int64_t inplane = iy * (d.nx + 1) + ix;
+    if (iz >= d.zb && iz < d.ze) return (int32_t)((iz - d.zb) * d.plane + inplane);
+    if (iz == d.zb - 1) return (int32_t)(d.n_owned + inplane);
+    return (int32_t)(d.n_owned + (d.has_lower ? d.plane : 0) + inplane);  // iz == ze
+}
+
+__global__ void k_box_vertices(box_desc d, int64_t nv, double* __restrict__ xyz4, int64_t* __restrict__ gid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nv; i += stride) {
+        int64_t iz, inplane;
+        if (i < d.n_owned) {
+            iz = d.zb + i / d.plane;
+            inplane = i % d.plane;
+        } else {
+            int64_t j = i - d.n_owned;
+            if (d.has_lower && j < d.plane) {
+                iz = d.zb - 1;
+                inplane = j;
+            } else {
+                iz = d.ze;
+                inplane = j - (d.has_lower ? d.plane : 0);
+            }
+        }
+        const int64_t iy = inplane / (d.nx + 1);
+        const int64_t ix = inplane % (d.nx + 1);
+        // same expression order as DOLFIN's BoxMesh: a + (i*(b-a))/n
+        xyz4[4 * i + 0] = d.p0[0] + ((double)ix * (d.p1[0] - d.p0[0])) / (double)d.nx;
+        xyz4[4 * i + 1] = d.p0[1] + ((double)iy * (d.p1[1] - d.p0[1])) / (double)d.ny;
+        xyz4[4 * i + 2] = d.p0[2] + ((double)iz * (d.p1[2] - d.p0[2])) / (double)d.nz;
+        xyz4[4 * i + 3] = 0.0;
+        gid[i] = iz * d.plane + inplane;
+    }
+}
+
+__global__ void k_box_cells(box_desc d, int64_t nhex, int32_t* __restrict__ cells) {
+    int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; h < nhex; h += stride) {
+        const int64_t ix = h % d.nx;
+        const int64_t iy = (h / d.nx) % d.ny;
+        const int64_t kz = d.kz0 + h / (d.nx * d.ny);
+        int32_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[c] = box_local_id(d, ix + (c & 1), iy + ((c >> 1) & 1), kz + ((c >> 2) & 1));
+        // six tets around the v0-v7 diagonal, vertices ascending by GLOBAL index
+        // (global order of the hex corners is v0<v1<...<v7)
+        const int t[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 4, 5, 7}, {0, 2, 3, 7}, {0, 4, 6, 7}, {0, 2, 6, 7}};
+        int4* out = reinterpret_cast<int4*>(cells) + h * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = make_int4(v[t[k][0]], v[t[k][1]], v[t[k][2]], v[t[k][3]]);
+    }
+}
+
+extern "C" int fs_mesh_create_box(int64_t nx, int64_t ny, int64_t nz, const double p0[3], const double p1[3],
+                                  int64_t zplane_begin, int64_t zplane_end, fs_mesh_t* out) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(out && p0 && p1, "fs_mesh_create_box: null pointer");
+    FS_REQUIRE(nx > 0 && ny > 0 && nz > 0, "fs_mesh_create_box: cell counts must be positive");
+    FS_REQUIRE(zplane_begin >= 0 && zplane_end <= nz + 1 && zplane_begin < zplane_end,
+               "fs_mesh_create_box: owned plane range [%lld,%lld) outside [0,%lld]", (long long)zplane_begin,
+               (long long)zplane_end, (long long)(nz + 1));
+    box_desc d;
+    d.nx = nx; d.ny = ny; d.nz = nz;
+    for (int i = 0; i < 3; ++i) { d.p0[i] = p0[i]; d.p1[i] = p1[i]; }
+    d.zb = zplane_begin; d.ze = zplane_end;
+    d.plane = (nx + 1) * (ny + 1);
+    d.has_lower = zplane_begin > 0;
+    d.has_upper = zplane_end < nz + 1;
+    d.n_owned = (zplane_end - zplane_begin) * d.plane;
+    d.kz0 = zplane_begin > 0 ? zplane_begin - 1 : 0;
+    d.kz1 = zplane_end < nz ? zplane_end : nz;
+    const int64_t nv = d.n_owned + (d.has_lower + d.has_upper) * d.plane;
+    const int64_t nhex = (d.kz1 - d.kz0) * nx * ny;
+    const int64_t nc = nhex * 6;
+    FS_REQUIRE(nv < (int64_t)INT32_MAX && nc < (int64_t)INT32_MAX, "fs_mesh_create_box: slab exceeds int32 indexing");
+    hipStream_t s = fs_rt().stream;
+    fs_mesh_s* m = new fs_mesh_s();
+    m->nv = nv; m->nc = nc; m->n_owned = d.n_owned;
+    int rc = FS_OK;
+    if ((rc = m->xyz.alloc(nv * 4)) != FS_OK || (rc = m->cells.alloc(nc * 4)) != FS_OK ||
+        (rc = m->gid.alloc(nv)) != FS_OK) {
+        delete m;
+        return rc;
+    }
+    hipLaunchKernelGGL(k_box_vertices, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, d, nv, m->xyz.p, m->gid.p);
+    hipLaunchKernelGGL(k_box_cells, dim3(fs_grid_for(nhex)), dim3(FS_BLOCK), 0, s, d, nhex, m->cells.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        fs_set_error("fs_mesh_create_box: kernel launch failed");
+        delete m;
+        return FS_ERR_HIP;
+    }
+    *out = m;
+    return FS_OK;
+}
+
+extern "C" int fs_mesh_info(fs_mesh_t mesh, int64_t* nv, int64_t* nc, int64_t* n_owned) {
+    FS_REQUIRE(mesh, "fs_mesh_info: null mesh");
+    if (nv) *nv = mesh->nv;
+    if (nc) *nc = mesh->nc;
+    if (n_owned) *n_owned = mesh->n_owned;
+    return FS_OK;
+}
+
+extern "C" int fs_mesh_get(fs_mesh_t mesh, double* xyz, int32_t* cells, int64_t* global_ids) {
+    FS_REQUIRE(mesh, "fs_mesh_get: null mesh");
+    hipStream_t s = fs_rt().stream;
+    if (xyz) {
+        std::vector<double> tmp((size_t)mesh->nv * 4);
+        FS_CHECK(mesh->xyz.download(tmp.data(), mesh->nv * 4, s));
+        for (int64_t i = 0; i < mesh->nv; ++i) {
+            xyz[3 * i + 0] = tmp[4 * i + 0];
+            xyz[3 * i + 1] = tmp[4 * i + 1];
+            xyz[3 * i + 2] = tmp[4 * i + 2];
+        }
+    }
+    if (cells) FS_CHECK(mesh->cells.download(cells, mesh->nc * 4, s));
+    if (global_ids) FS_CHECK(mesh->gid.download(global_ids, mesh->nv, s));
+    return FS_OK;
+}
+
+extern "C" int fs_mesh_destroy(fs_mesh_t mesh) {
+    delete mesh;
+    return FS_OK;
+}

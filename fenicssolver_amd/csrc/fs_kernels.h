@@ -1,0 +1,43 @@
+// Small device helpers and reduction kernels shared by the translation units of
+// libfsamd.so (each TU gets its own static copy; no relocatable device code needed).
+#pragma once
+#include "fs_common.h"
+
+// wave64 shuffle reduction -> one LDS slot per wave -> thread 0 holds the block sum.
+// Fixed order, so a given launch geometry always produces the same bits.
+__device__ __forceinline__ double fs_block_sum(double v, double* lds4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    __syncthreads();
+    return t;
+}
+
+static __global__ void __launch_bounds__(FS_BLOCK) k_dot_partial(const double* __restrict__ x,
+                                                                 const double* __restrict__ y, int64_t n,
+                                                                 double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) acc += x[i] * y[i];
+    const double t = fs_block_sum(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// fixed-order sum of nsums interleaved partial arrays (partial[j*count + i]) by one
+// workgroup -> out[j].
+static __global__ void __launch_bounds__(FS_BLOCK) k_sum_partials(const double* __restrict__ partial, int count,
+                                                                  int nsums, double* __restrict__ out) {
+    __shared__ double lds4[4];
+    for (int j = 0; j < nsums; ++j) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < count; i += FS_BLOCK) acc += partial[(int64_t)j * count + i];
+        const double t = fs_block_sum(acc, lds4);
+        if (threadIdx.x == 0) out[j] = t;
+    }
+}

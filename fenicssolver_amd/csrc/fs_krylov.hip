@@ -1,0 +1,526 @@
+// SpMV and Krylov solver of libfsamd.so (gfx950, fp64).
+//
+// Stands in for PETSc MatMult / VecDot / VecAXPY / KSPCG + PCJACOBI behind
+// PETScKrylovSolver("cg", pc).solve(x, b)  (FenicsSolver/SolverBase.py:663-670) and the
+// Krylov option of LinearVariationalSolver (SolverBase.py:608-612).
+//
+// Matrix layout: SELL-64.  One wavefront owns one slice of 64 consecutive rows; entry k
+// of the 64 rows is contiguous in memory, so every wave-level load of values (8 B/lane)
+// and column indices (4 B/lane) is one fully coalesced 512-B / 256-B transaction and the
+// row sum needs no cross-lane reduction.  The kernel is HBM-bound (0.17 flop/B):
+// algorithmic bytes per SpMV = nnz*(8+4) + n*(4+8+8)  (SURVEY.md section 8d).
+//
+// CG is the single-reduction (Chronopoulos-Gear) recurrence: per iteration ONE fused
+// SpMV+3-dots kernel, one 1-workgroup partial-sum kernel (+ one 3-double all-reduce on
+// >1 GPU) and ONE fused vector-update kernel.  alpha/beta/convergence live on the
+// device; the host only polls a status word every `batch` iterations, two batches in
+// flight, so the stream never drains.
+#include "fs_common.h"
+#include "fs_kernels.h"
+#include <chrono>
+#include <math.h>
+
+// ---- XCD-aware persistent chunk mapping -------------------------------------------------
+// Workgroup b is (observed) placed on XCD b % 8.  Give every XCD one contiguous 1/8 of the
+// chunk range so the x-vector lines gathered by neighbouring rows stay in that XCD's L2.
+// Correctness never depends on the placement.
+struct chunk_iter {
+    int64_t cur, end, step;
+};
+__device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
+    const int64_t per_xcd = (n_chunks + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int64_t j = blockIdx.x >> 3;
+    chunk_iter it;
+    it.step = gridDim.x >> 3;
+    it.cur = xcd * per_xcd + j;
+    const int64_t e = (xcd + 1) * per_xcd;
+    it.end = e < n_chunks ? e : n_chunks;
+    return it;
+}
+
+// ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
+template <int BS, bool DOTS>
+__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_slices,
+                                                        const int64_t* __restrict__ slice_ptr,
+                                                        const int32_t* __restrict__ sell_col,
+                                                        const double* __restrict__ val, int64_t plane,
+                                                        const double* __restrict__ x, double* __restrict__ y,
+                                                        const double* __restrict__ rvec,
+                                                        double* __restrict__ partials,
+                                                        const int* __restrict__ status) {
+    if (DOTS) {
+        if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
+    }
+    __shared__ double lds4[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
+    const int64_t n_chunks = (n_slices + 3) >> 2;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
+        if (s >= n_slices) continue;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t r = s * FS_SLICE + lane;
+        const int32_t* __restrict__ cp = sell_col + base + lane;
+        const double* __restrict__ vp = val + base + lane;
+        if (BS == 1) {
+            double acc = 0.0;
+            int k = 0;
+            for (; k + 4 <= width; k += 4) {
+                const int32_t c0 = cp[(int64_t)(k + 0) * FS_SLICE];
+                const int32_t c1 = cp[(int64_t)(k + 1) * FS_SLICE];
+                const int32_t c2 = cp[(int64_t)(k + 2) * FS_SLICE];
+                const int32_t c3 = cp[(int64_t)(k + 3) * FS_SLICE];
+                const double v0 = vp[(int64_t)(k + 0) * FS_SLICE];
+                const double v1 = vp[(int64_t)(k + 1) * FS_SLICE];
+                const double v2 = vp[(int64_t)(k + 2) * FS_SLICE];
+                const double v3 = vp[(int64_t)(k + 3) * FS_SLICE];
+                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+                acc += v0 * x0;
+                acc += v1 * x1;
+                acc += v2 * x2;
+                acc += v3 * x3;
+            }
+            for (; k < width; ++k) acc += vp[(int64_t)k * FS_SLICE] * x[cp[(int64_t)k * FS_SLICE]];
+            if (r < n_rows) {
+                y[r] = acc;
+                if (DOTS) {
+                    const double zi = x[r], ri = rvec[r];
+                    d_rz += ri * zi;
+                    d_wz += acc * zi;
+                    d_rr += ri * ri;
+                }
+            }
+        } else {
+            double acc[BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) acc[i] = 0.0;
+            for (int k = 0; k < width; ++k) {
+                const int64_t c = cp[(int64_t)k * FS_SLICE];
+                double xv[BS];
+#pragma unroll
+                for (int j = 0; j < BS; ++j) xv[j] = x[c * BS + j];
+#pragma unroll
+                for (int i = 0; i < BS; ++i)
+#pragma unroll
+                    for (int j = 0; j < BS; ++j) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xv[j];
+            }
+            if (r < n_rows) {
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    y[r * BS + i] = acc[i];
+                    if (DOTS) {
+                        const double zi = x[r * BS + i], ri = rvec[r * BS + i];
+                        d_rz += ri * zi;
+                        d_wz += acc[i] * zi;
+                        d_rr += ri * ri;
+                    }
+                }
+            }
+        }
+    }
+    if (DOTS) {
+        const double t0 = fs_block_sum(d_rz, lds4);
+        const double t1 = fs_block_sum(d_wz, lds4);
+        const double t2 = fs_block_sum(d_rr, lds4);
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x] = t0;
+            partials[gridDim.x + blockIdx.x] = t1;
+            partials[2 * gridDim.x + blockIdx.x] = t2;
+        }
+    }
+}
+
+// ---- CG scalar state on the device ---------------------------------------------------------
+// sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
+// ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b
+// scal[2][2] = (gamma, alpha) of the previous iteration, double-buffered by iteration parity
+// status[0] = 0 running / 1 converged / 2 breakdown / 3 max_iter, status[1] = iterations
+__global__ void k_set_threshold(const double* __restrict__ bb, double rtol, double atol, double* __restrict__ ctrl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double t = rtol * rtol * bb[0];
+        ctrl[0] = fmax(t, atol * atol);
+        ctrl[1] = bb[0];
+    }
+}
+
+__global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int check_only,
+                                                        const double* __restrict__ sums,
+                                                        const double* __restrict__ ctrl, double* __restrict__ scal,
+                                                        int* __restrict__ status, double* __restrict__ hist,
+                                                        const double* __restrict__ dinv, double* z,
+                                                        const double* __restrict__ w, double* __restrict__ p,
+                                                        double* __restrict__ sv, double* __restrict__ x,
+                                                        double* __restrict__ r) {
+    if (status[0] != 0) return;
+    const double gamma = sums[0], delta = sums[1], rho = sums[2];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (leader) hist[iter] = rho;
+    if (rho <= ctrl[0]) {  // every workgroup takes the same branch: inputs are identical
+        if (leader) { status[1] = iter; status[0] = 1; }
+        return;
+    }
+    if (check_only) {
+        if (leader) { status[1] = iter; status[0] = 3; }
+        return;
+    }
+    double beta = 0.0, alpha;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) {  // not SPD / NaN
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) {
+        scal[2 * (iter & 1) + 0] = gamma;
+        scal[2 * (iter & 1) + 1] = alpha;
+    }
+    // 16-B vectorised body; n even part as double2, tail scalar
+    const int64_t n2 = n >> 1;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double2* z2 = reinterpret_cast<double2*>(z);  // read and written in place: no restrict
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    const double2* __restrict__ d2 = reinterpret_cast<const double2*>(dinv);
+    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
+    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
+    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
+    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
+    for (; i < n2; i += stride) {
+        const double2 zz = z2[i], ww = w2[i], dd = d2[i];
+        double2 pp = p2[i], ss = s2[i], xx = x2[i], rr = r2[i];
+        pp.x = zz.x + beta * pp.x;  pp.y = zz.y + beta * pp.y;
+        ss.x = ww.x + beta * ss.x;  ss.y = ww.y + beta * ss.y;
+        xx.x += alpha * pp.x;       xx.y += alpha * pp.y;
+        rr.x -= alpha * ss.x;       rr.y -= alpha * ss.y;
+        p2[i] = pp; s2[i] = ss; x2[i] = xx; r2[i] = rr;
+        double2 zn; zn.x = dd.x * rr.x; zn.y = dd.y * rr.y;
+        z2[i] = zn;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t t = n - 1;
+        const double pp = z[t] + beta * p[t];
+        const double ss = w[t] + beta * sv[t];
+        p[t] = pp; sv[t] = ss;
+        x[t] += alpha * pp;
+        const double rr = r[t] - alpha * ss;
+        r[t] = rr;
+        z[t] = dinv[t] * rr;
+    }
+}
+
+template <int BS>
+__global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sell_col,
+                               const double* __restrict__ val, int64_t plane, int jacobi,
+                               double* __restrict__ dinv, int* __restrict__ err) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t base = slice_ptr[r >> 6] + (r & 63);
+        const int len = rowptr[r + 1] - rowptr[r];
+        int kd = -1;
+        for (int k = 0; k < len; ++k)
+            if (sell_col[base + (int64_t)k * FS_SLICE] == r) { kd = k; break; }
+        for (int i = 0; i < BS; ++i) {
+            double d = 1.0;
+            if (jacobi) {
+                d = kd >= 0 ? val[(int64_t)(i * BS + i) * plane + base + (int64_t)kd * FS_SLICE] : 0.0;
+                if (!(d != 0.0)) { atomicAdd(err, 1); d = 1.0; }
+                d = 1.0 / d;
+            }
+            dinv[r * BS + i] = d;
+        }
+    }
+}
+
+__global__ void k_pointwise_mul(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = a[i] * b[i];
+}
+
+// r = b - w ; partial of r.r
+__global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict__ b, const double* __restrict__ w,
+                                                       int64_t n, double* __restrict__ r,
+                                                       double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double d = b[i] - w[i];
+        if (r) r[i] = d;
+        acc += d * d;
+    }
+    const double t = fs_block_sum(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ---- host side --------------------------------------------------------------------------------
+static int spmv_grid(int64_t n_slices) {
+    const int64_t n_chunks = (n_slices + 3) / 4;
+    int64_t g = n_chunks < FS_MAX_PARTIAL_BLOCKS ? n_chunks : FS_MAX_PARTIAL_BLOCKS;
+    g = (g + 7) & ~(int64_t)7;  // multiple of 8 for the XCD mapping
+    return (int)g;
+}
+
+template <bool DOTS>
+static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
+                        const int* status, hipStream_t s) {
+    fs_space_s* sp = A->space;
+    const int grid = spmv_grid(sp->n_slices);
+    if (A->bs == 1)
+        hipLaunchKernelGGL((k_sell_spmv<1, DOTS>), dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status);
+    else
+        hipLaunchKernelGGL((k_sell_spmv<3, DOTS>), dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status);
+}
+
+extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
+    FS_REQUIRE(A && x && y, "fs_spmv: null pointer");
+    fs_space_s* sp = A->space;
+    FS_REQUIRE(x->d.n >= sp->n_dofs_local, "fs_spmv: x has %lld entries, needs %lld (owned + ghost)", (long long)x->d.n, (long long)sp->n_dofs_local);
+    FS_REQUIRE(y->d.n >= sp->n_dofs_owned, "fs_spmv: y too short");
+    hipStream_t s = fs_rt().stream;
+    FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
+    launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch) {
+    FS_REQUIRE(A && x && y && ms_per_launch && reps > 0, "fs_spmv_benchmark: bad arguments");
+    fs_space_s* sp = A->space;
+    FS_REQUIRE(x->d.n >= sp->n_dofs_local && y->d.n >= sp->n_dofs_owned, "fs_spmv_benchmark: vector too short");
+    hipStream_t s = fs_rt().stream;
+    hipEvent_t e0, e1;
+    FS_HIP(hipEventCreate(&e0));
+    FS_HIP(hipEventCreate(&e1));
+    launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);  // warm-up
+    FS_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    FS_HIP(hipEventRecord(e1, s));
+    FS_HIP(hipEventSynchronize(e1));
+    FS_KERNEL_CHECK();
+    float ms = 0.f;
+    FS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = (double)ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FS_OK;
+}
+
+// persistent Krylov workspace: allocation stays out of the timed solve
+struct krylov_ws {
+    int64_t n = 0, nl = 0;
+    int hist_cap = 0;
+    dbuf<double> dinv, r, z, w, p, s, partials, sums, ctrl, scal, hist;
+    dbuf<int> status;
+    int* h_status = nullptr;  // pinned, 2 x 4 ints
+    hipEvent_t poll[2] = {nullptr, nullptr};
+    static const int NSAMPLE = 64;
+    hipEvent_t ev[NSAMPLE][4];
+    bool events = false;
+    std::vector<double> last_hist;
+};
+static krylov_ws g_ws;
+
+static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
+    if (ws.n != n || ws.nl != nl) {
+        FS_CHECK(ws.dinv.alloc(n + 2));
+        FS_CHECK(ws.r.alloc(n + 2));
+        FS_CHECK(ws.z.alloc(nl + 2));
+        FS_CHECK(ws.w.alloc(n + 2));
+        FS_CHECK(ws.p.alloc(n + 2));
+        FS_CHECK(ws.s.alloc(n + 2));
+        ws.n = n;
+        ws.nl = nl;
+    }
+    if (!ws.partials.p) {
+        FS_CHECK(ws.partials.alloc(4 * (FS_MAX_PARTIAL_BLOCKS + 8)));
+        FS_CHECK(ws.sums.alloc(8));
+        FS_CHECK(ws.ctrl.alloc(4));
+        FS_CHECK(ws.scal.alloc(4));
+        FS_CHECK(ws.status.alloc(4));
+        FS_HIP(hipHostMalloc((void**)&ws.h_status, 8 * sizeof(int), hipHostMallocDefault));
+        FS_HIP(hipEventCreateWithFlags(&ws.poll[0], hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&ws.poll[1], hipEventDisableTiming));
+        for (int i = 0; i < krylov_ws::NSAMPLE; ++i)
+            for (int j = 0; j < 4; ++j) FS_HIP(hipEventCreate(&ws.ev[i][j]));
+        ws.events = true;
+    }
+    if (ws.hist_cap < max_iter + 2) {
+        FS_CHECK(ws.hist.alloc(max_iter + 2));
+        ws.hist_cap = max_iter + 2;
+    }
+    return FS_OK;
+}
+
+extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,
+                               fs_krylov_stats* stats) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A && b && x && opts, "fs_krylov_solve: null pointer");
+    if (opts->method != FS_KSP_CG) {
+        fs_set_error("fs_krylov_solve: only FS_KSP_CG is implemented (method=%d)", opts->method);
+        return FS_ERR_UNSUPPORTED;
+    }
+    FS_REQUIRE(opts->precond == FS_PC_NONE || opts->precond == FS_PC_JACOBI, "fs_krylov_solve: unknown preconditioner %d", opts->precond);
+    FS_REQUIRE(opts->max_iter > 0 && opts->rtol >= 0.0 && opts->atol >= 0.0, "fs_krylov_solve: bad tolerances");
+    fs_space_s* sp = A->space;
+    const int64_t n = sp->n_dofs_owned, nl = sp->n_dofs_local;
+    FS_REQUIRE(b->d.n >= n && x->d.n >= n, "fs_krylov_solve: b/x shorter than the owned dofs (%lld)", (long long)n);
+    hipStream_t s = fs_rt().stream;
+    krylov_ws& ws = g_ws;
+    FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
+    const int bs = A->bs;
+    const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, 2048);
+    const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
+    const int sgrid = spmv_grid(sp->n_slices);
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    // Jacobi diagonal
+    {
+        dbuf<int> d_err;
+        FS_CHECK(d_err.alloc(1));
+        FS_CHECK(d_err.zero(s));
+        const int g = fs_grid_for(sp->n_nodes_owned);
+        if (bs == 1)
+            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+        else
+            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+        FS_KERNEL_CHECK();
+        int h_err = 0;
+        FS_CHECK(d_err.download(&h_err, 1, s));
+        if (h_err) {
+            fs_set_error("fs_krylov_solve: %d zero diagonal entries (Jacobi preconditioner undefined)", h_err);
+            return FS_ERR_NUMERIC;
+        }
+    }
+    // ||b||^2 -> threshold
+    hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, b->d.p, n, ws.partials.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 4);
+    FS_KERNEL_CHECK();
+    FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 4, 1, s));
+    hipLaunchKernelGGL(k_set_threshold, dim3(1), dim3(64), 0, s, ws.sums.p + 4, opts->rtol, opts->atol, ws.ctrl.p);
+    // initial state
+    FS_CHECK(ws.status.zero(s));
+    FS_CHECK(ws.scal.zero(s));
+    FS_CHECK(ws.p.zero(s));
+    FS_CHECK(ws.s.zero(s));
+    FS_CHECK(ws.z.zero(s));
+    if (opts->nonzero_guess) {
+        FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+        launch_spmv<false>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
+        hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, ws.r.p, ws.partials.p);
+    } else {
+        FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
+        FS_HIP(hipMemcpyAsync(ws.r.p, b->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
+    FS_KERNEL_CHECK();
+
+    // iteration pipeline
+    const int batch = opts->batch > 0 ? opts->batch : 32;
+    const int max_iter = opts->max_iter;
+    int k = 0, slot = 0, pending = -1, n_samples = 0;
+    bool finished = false;
+    while (!finished) {
+        const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
+        for (; k < kend; ++k) {
+            const bool sample = (k % 4 == 1) && n_samples < krylov_ws::NSAMPLE;
+            FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+            if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
+            launch_spmv<true>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
+            if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
+            FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
+            if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+            hipLaunchKernelGGL(k_cg_update, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
+            if (sample) {
+                FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
+                ++n_samples;
+            }
+        }
+        FS_KERNEL_CHECK();
+        FS_HIP(hipMemcpyAsync(ws.h_status + 4 * slot, ws.status.p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        FS_HIP(hipEventRecord(ws.poll[slot], s));
+        if (pending >= 0) {
+            FS_HIP(hipEventSynchronize(ws.poll[pending]));
+            if (ws.h_status[4 * pending] != 0) finished = true;
+        }
+        pending = slot;
+        slot ^= 1;
+        if (k > max_iter) finished = true;
+    }
+    FS_HIP(hipStreamSynchronize(s));
+    int h_status[4] = {0, 0, 0, 0};
+    FS_CHECK(ws.status.download(h_status, 4, s));
+    const int iters = h_status[1];
+
+    // true residual b - A x
+    FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+    launch_spmv<false>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
+    hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 5);
+    FS_KERNEL_CHECK();
+    FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 5, 1, s));
+    double h_sums[8];
+    FS_CHECK(ws.sums.download(h_sums, 8, s));
+    double h_ctrl[4];
+    FS_CHECK(ws.ctrl.download(h_ctrl, 4, s));
+    ws.last_hist.resize((size_t)iters + 1);
+    FS_CHECK(ws.hist.download(ws.last_hist.data(), iters + 1, s));
+    const auto t_end = std::chrono::steady_clock::now();
+
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        const double bb = h_ctrl[1];
+        stats->iterations = iters;
+        stats->converged = h_status[0] == 1 ? 1 : (h_status[0] == 2 ? -1 : 0);
+        stats->bnorm = sqrt(bb);
+        stats->rel_residual = bb > 0.0 ? sqrt(ws.last_hist[iters] / bb) : 0.0;
+        stats->true_rel_residual = bb > 0.0 ? sqrt(h_sums[5] / bb) : sqrt(h_sums[5]);
+        stats->solve_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+        double t_spmv = 0.0, t_upd = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < n_samples; ++i) {
+            if (4 * i + 1 >= iters) break;  // launches after convergence are no-ops
+            float a = 0.f, c = 0.f;
+            if (hipEventElapsedTime(&a, ws.ev[i][0], ws.ev[i][1]) != hipSuccess) break;
+            if (hipEventElapsedTime(&c, ws.ev[i][2], ws.ev[i][3]) != hipSuccess) break;
+            t_spmv += a;
+            t_upd += c;
+            ++cnt;
+        }
+        if (cnt) {
+            stats->spmv_ms = t_spmv / cnt;
+            stats->update_ms = t_upd / cnt;
+        }
+        stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
+    }
+    if (h_status[0] == 2) {
+        fs_set_error("fs_krylov_solve: CG breakdown at iteration %d (operator not SPD or NaN)", iters);
+        return FS_ERR_NUMERIC;
+    }
+    return FS_OK;
+}
+
+extern "C" int fs_krylov_history(double* out, int capacity, int* count) {
+    const int n = (int)g_ws.last_hist.size();
+    if (count) *count = n;
+    if (out)
+        for (int i = 0; i < n && i < capacity; ++i) out[i] = g_ws.last_hist[i];
+    return FS_OK;
+}

@@ -1,0 +1,242 @@
+/*
+ * fenicssolver_amd.h — C-ABI of libfsamd.so, the MI355X (gfx950) replacement for
+ * the part of FenicsSolver that the reference delegates to DOLFIN/FFC/PETSc.
+ *
+ * The reference has no FFI of its own: the seam is the Python methods
+ *   SolverBase.solve_linear_problem(F, u, bcs)   FenicsSolver/SolverBase.py:592-613
+ *   SolverBase.solve_amg(F, u, bcs)              FenicsSolver/SolverBase.py:643-672
+ *   SolverBase.solve_nonlinear_problem(...)      FenicsSolver/SolverBase.py:615-626
+ * which call dolfin.assemble / assemble_system / DirichletBC.apply /
+ * LinearVariationalSolver / PETScKrylovSolver.  Each entry point below names the
+ * dolfin call (and the reference line that makes it) that it stands in for; the
+ * ctypes binding a maintainer would add is fenicssolver_amd/_lib.py (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no exceptions cross the boundary.
+ *   - every function returns 0 (FS_OK) or a negative FS_ERR_* code; the message is
+ *     available from fs_last_error() (thread-local).
+ *   - handles are opaque and own device (HBM) memory; host arrays passed in are
+ *     borrowed for the duration of the call only (C-contiguous, fp64 / int32 / int64).
+ *   - calls are synchronous at return unless stated otherwise.
+ *   - one process drives one GPU; N-GPU runs are N processes joined through
+ *     fs_comm_init (RCCL).  All field arithmetic is fp64, connectivity is int32.
+ */
+#ifndef FENICSSOLVER_AMD_H
+#define FENICSSOLVER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_OK 0
+#define FS_ERR_INVALID (-1)   /* bad argument / handle */
+#define FS_ERR_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define FS_ERR_NO_DEVICE (-3) /* no gfx950 device visible: the library never falls back to the CPU */
+#define FS_ERR_UNSUPPORTED (-4)
+#define FS_ERR_COMM (-5)      /* RCCL error */
+#define FS_ERR_NUMERIC (-6)   /* Krylov breakdown (non-SPD operator, NaN) */
+
+typedef struct fs_mesh_s* fs_mesh_t;
+typedef struct fs_space_s* fs_space_t;
+typedef struct fs_matrix_s* fs_matrix_t;
+typedef struct fs_vector_s* fs_vector_t;
+
+/* ---- runtime ---------------------------------------------------------------- */
+
+/* Select the HIP device this process drives (dolfin has no analogue; MPI rank ->
+ * device mapping replaces `mpirun`, SolverBase.py:102-118). */
+int fs_init(int device_id);
+int fs_device_count(int* count);
+int fs_device_synchronize(void);
+const char* fs_last_error(void);
+const char* fs_version(void);
+/* Name, CU count and HBM bytes of the selected device. */
+int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+
+/* ---- mesh  (dolfin.Mesh / BoxMesh, SolverBase.py:203-258) -------------------- */
+
+/* Upload a tetrahedral mesh.  xyz[nv][gdim] (gdim must be 3), cells[nc][4]
+ * vertex indices.  The first n_owned vertices are the rows this process owns
+ * (n_owned == nv on one GPU); the remainder are ghost vertices whose values
+ * arrive by halo exchange. */
+int fs_mesh_create(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells,
+                   int verts_per_cell, int64_t n_owned, fs_mesh_t* out);
+
+/* Generate on the device the slab of dolfin.BoxMesh(p0, p1, nx, ny, nz) whose
+ * owned vertex planes are [zplane_begin, zplane_end) (0 .. nz+1 for the whole
+ * mesh).  Vertex order x-fastest, six tets per hex around the v0-v7 diagonal,
+ * cells iz->iy->ix, each cell's vertices ascending by global index (SURVEY.md
+ * section 8d / Appendix D-8).  Local numbering: owned planes first, then the
+ * lower ghost plane, then the upper ghost plane. */
+int fs_mesh_create_box(int64_t nx, int64_t ny, int64_t nz, const double p0[3], const double p1[3],
+                       int64_t zplane_begin, int64_t zplane_end, fs_mesh_t* out);
+
+int fs_mesh_info(fs_mesh_t mesh, int64_t* nv, int64_t* nc, int64_t* n_owned);
+/* Copy back to host (any pointer may be NULL): xyz[nv][3], cells[nc][4],
+ * global vertex ids[nv] (identity for uploaded meshes). */
+int fs_mesh_get(fs_mesh_t mesh, double* xyz, int32_t* cells, int64_t* global_ids);
+int fs_mesh_destroy(fs_mesh_t mesh);
+
+/* ---- function space + sparsity (dolfin.FunctionSpace, SolverBase.py:260-275;
+ *      the sparsity pattern DOLFIN builds inside the first assemble()) --------- */
+
+#define FS_FAMILY_CG 0
+/* degree 1 only in this revision; ncomp = 1 (scalar) or 3 (vector, node-interleaved
+ * dofs as DOLFIN's VectorFunctionSpace lays them out). */
+int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
+int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
+                  int64_t* sell_entries);
+int fs_space_destroy(fs_space_t space);
+
+/* ---- vectors (dolfin.Function.vector(), PETScVector) ------------------------ */
+
+int fs_vector_create(int64_t n, fs_vector_t* out);
+int fs_vector_size(fs_vector_t v, int64_t* n);
+int fs_vector_set(fs_vector_t v, const double* host, int64_t n);
+int fs_vector_get(fs_vector_t v, double* host, int64_t n);
+int fs_vector_fill(fs_vector_t v, double value);
+int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x); /* y += a x */
+int fs_vector_dot(fs_vector_t x, fs_vector_t y, double* result); /* local (un-reduced) dot */
+int fs_vector_destroy(fs_vector_t v);
+
+/* ---- matrices (PETSc AIJ behind dolfin.assemble, SolverBase.py:595, 608-612, 644) */
+
+/* A matrix on the space's sparsity pattern, values zero.  Rows = owned dofs,
+ * columns = local (owned + ghost) dofs. */
+int fs_matrix_create(fs_space_t space, fs_matrix_t* out);
+int fs_matrix_info(fs_matrix_t A, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+int fs_matrix_zero(fs_matrix_t A);
+/* Y += a X (same space). Used for theta-scheme operators M/dt + theta K
+ * (ScalarTransportSolver.py:287-293). */
+int fs_matrix_axpy(fs_matrix_t Y, double a, fs_matrix_t X);
+/* Export as sorted-column CSR (any pointer may be NULL): rowptr[n_rows+1],
+ * colidx[nnz], vals[nnz]. */
+int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx, double* vals);
+int fs_matrix_destroy(fs_matrix_t A);
+
+/* Coefficient of a volume term: constant, one value per cell (DG0, e.g. a
+ * per-subdomain material, SolverBase.py:331-332) or a constant 3x3 tensor
+ * (as_matrix, SolverBase.py:327-330). */
+#define FS_COEF_NONE 0
+#define FS_COEF_CONST 1
+#define FS_COEF_CELL 2
+#define FS_COEF_TENSOR 3
+#define FS_COEF_NODAL 4 /* linear forms only: P1-interpolated coefficient */
+
+typedef struct fs_coef {
+    int mode;             /* FS_COEF_* */
+    double value;         /* FS_COEF_CONST */
+    const double* data;   /* FS_COEF_CELL: [n_cells]; FS_COEF_NODAL: [n_dofs_local] (host) */
+    double tensor[9];     /* FS_COEF_TENSOR, row-major */
+} fs_coef;
+
+/* Bilinear form  a(u,v) = int stiffness * grad u . grad v dx + int mass * u v dx
+ * (scalar space: ScalarTransportSolver.py:284-285 and the 1/dt capacity term
+ * :292), or for a vector space the isotropic elasticity operator
+ * int (2 mu sym grad u + lambda div u I) : grad v dx  (LinearElasticitySolver.py:62-69, 215)
+ * plus  mass * u . v. */
+typedef struct fs_bilinear_form {
+    fs_coef stiffness;   /* scalar spaces */
+    fs_coef mass;        /* both */
+    double lame_mu;      /* vector spaces */
+    double lame_lambda;  /* vector spaces */
+} fs_bilinear_form;
+
+/* Replaces dolfin.assemble(a) / the matrix half of assemble_system: numeric
+ * cell loop (tabulate_tensor + MatSetValues(ADD)).  add == 0 zeroes A first. */
+int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, int add);
+
+/* Linear form  L(v) = int source * v dx  (body source, ScalarTransportSolver.py:213-226;
+ * vector spaces: constant body force f, LinearElasticitySolver.py:227-228, in
+ * vector_value).  add == 0 zeroes b first. */
+typedef struct fs_linear_form {
+    fs_coef source;
+    double vector_value[3];
+} fs_linear_form;
+int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add);
+
+/* Boundary-facet integrals over an explicit facet list (the host resolves
+ * ds(id) to facets).  tri[n_facets][3] local vertex ids.
+ *   vector:  b_a += int g phi_a ds, g[n_facets][ncomp]  (flux / Neumann / traction,
+ *            ScalarTransportSolver.py:176-200, LinearElasticitySolver.py:165-196)
+ *   matrix:  A_ab += int h phi_a phi_b ds, h[n_facets]   (HTC / Robin, :201-208) */
+int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, const int32_t* tri,
+                             const double* g, fs_vector_t b);
+int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const int32_t* tri, const double* h);
+
+/* Replaces DirichletBC.apply(A, b) (symmetric == 0: rows -> identity, b_i = g;
+ * LinearVariationalSolver, SolverBase.py:608-612) and the elimination done by
+ * assemble_system (symmetric == 1: additionally b -= A[:,i] g, columns zeroed;
+ * SolverBase.py:644).  dofs are local dof indices (may include ghosts); later
+ * entries win on duplicates, as later BCs do in DOLFIN.  A may be NULL to set
+ * only b_i = g. */
+int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const int32_t* dofs,
+                       const double* vals, int symmetric);
+
+/* y = A x  (PETSc MatMult).  x has n_cols entries, y n_rows.  With a halo plan
+ * attached and a communicator up, ghosts of x are refreshed first. */
+int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y);
+
+/* ---- Krylov (PETScKrylovSolver("cg", pc).solve, SolverBase.py:663-670) -------- */
+
+#define FS_KSP_CG 0
+#define FS_PC_NONE 0
+#define FS_PC_JACOBI 1
+
+typedef struct fs_krylov_opts {
+    int method;          /* FS_KSP_CG */
+    int precond;         /* FS_PC_* */
+    double rtol;         /* stop when ||r||_2 <= max(rtol*||b||_2, atol) */
+    double atol;
+    int max_iter;
+    int batch;           /* iterations enqueued between host polls (0 = default 32) */
+    int nonzero_guess;   /* 0: x0 = 0 (PETSc default); 1: use x on entry */
+} fs_krylov_opts;
+
+typedef struct fs_krylov_stats {
+    int iterations;
+    int converged;          /* 1 converged, 0 max_iter reached, -1 breakdown */
+    double bnorm;           /* ||b||_2 (global) */
+    double rel_residual;    /* recurrence ||r||/||b|| at exit */
+    double true_rel_residual; /* ||b - A x||/||b|| recomputed at exit */
+    double solve_ms;        /* wall time of the solve (host clock, synchronised) */
+    double spmv_ms;         /* mean duration of the fused SpMV+dots kernel (HIP events) */
+    double update_ms;       /* mean duration of the fused vector-update kernel */
+    int64_t spmv_bytes;     /* algorithmic bytes of one SpMV: nnz*12 + n*20 */
+} fs_krylov_stats;
+
+int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,
+                    fs_krylov_stats* stats);
+/* ||r_k||_2^2 history of the last solve, k = 0..iterations. */
+int fs_krylov_history(double* out, int capacity, int* count);
+
+/* Time `reps` back-to-back launches of the bare SpMV kernel with HIP events on
+ * the library's stream; returns mean milliseconds per launch. */
+int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch);
+
+/* ---- multi-GPU (MPI inside PETSc/DOLFIN under mpirun; SolverBase.py:102-118, 634) */
+
+#define FS_UNIQUE_ID_BYTES 128
+int fs_comm_get_unique_id(char id[FS_UNIQUE_ID_BYTES]); /* rank 0, then broadcast out of band */
+int fs_comm_init(int n_ranks, int rank, const char id[FS_UNIQUE_ID_BYTES]);
+int fs_comm_info(int* n_ranks, int* rank);
+int fs_comm_allreduce_sum(double* host_inout, int n); /* utility: host scalars */
+int fs_comm_finalize(void);
+
+/* Halo plan of a space (PETSc VecScatter ghost update): for each neighbour the
+ * owned local dofs to send (concatenated in send_idx) and the number of ghosts
+ * received; ghosts are stored after the owned dofs, neighbour by neighbour in
+ * the order given. */
+int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks,
+                      const int64_t* send_counts, const int32_t* send_idx,
+                      const int64_t* recv_counts);
+/* Refresh the ghost entries of a local vector (n_dofs_local long). */
+int fs_halo_exchange(fs_space_t space, fs_vector_t v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FENICSSOLVER_AMD_H */

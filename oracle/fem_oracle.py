@@ -1,0 +1,558 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the FenicsSolver hot path.
+
+This module is a numpy/scipy restatement of what the reference delegates to
+DOLFIN/FFC/PETSc when ``SolverBase.solve()`` runs
+(/root/reference/FenicsSolver/SolverBase.py:484-490, 544-546, 592-672):
+mesh ingest, P1 dof tables, cell-by-cell assembly of the forms built in
+ScalarTransportSolver.generate_form (ScalarTransportSolver.py:228-359) and
+LinearElasticitySolver.generate_form (LinearElasticitySolver.py:206-245),
+Dirichlet application and the linear solve.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it.  It is never on the product path.
+
+PARITY PINNING.  The arithmetic of the reference path lives in un-vendored
+third-party code (DOLFIN/FFC/UFL/FIAT 2017.1-2019.1, PETSc; unpinned, see
+SURVEY.md section 8c) that cannot be built or imported here, and the
+reference's own example scripts assert no number.  The oracle is therefore
+pinned by the known-answer set-ups the reference ships:
+  * data/TestHeatTransfer.json + data/mesh*.xml  -> T = 350 - 2.5 z exactly
+    (tests/golden/data, tests/test_oracle_*.py),
+  * lexicographic facet numbering reproduces the 100+100 marked boundary
+    facets of data/mesh_facet_region.xml,
+  * exact reference-tet element matrices,
+  * patch tests / rigid-body null space / structure counts (Appendix C4-C7).
+Against DOLFIN itself parity is "unpinned" (stated in DESIGN.md).
+"""
+from __future__ import annotations
+
+import re
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+# --------------------------------------------------------------------------
+# mesh ingest  (SolverBase.py:223-258 -> dolfin.Mesh(xml), MeshFunction(xml))
+# --------------------------------------------------------------------------
+
+_VERT_RE = re.compile(
+    r'<vertex\s+index="(\d+)"\s+x="([^"]+)"\s+y="([^"]+)"(?:\s+z="([^"]+)")?')
+_TET_RE = re.compile(
+    r'<tetrahedron\s+index="(\d+)"\s+v0="(\d+)"\s+v1="(\d+)"\s+v2="(\d+)"\s+v3="(\d+)"')
+_TRI_RE = re.compile(
+    r'<triangle\s+index="(\d+)"\s+v0="(\d+)"\s+v1="(\d+)"\s+v2="(\d+)"')
+_ENT_RE = re.compile(r'<entity\s+index="(\d+)"\s+value="(-?\d+)"')
+_MF_RE = re.compile(r'<mesh_function\s+type="(\w+)"\s+dim="(\d+)"\s+size="(\d+)"')
+
+
+def read_dolfin_xml_mesh(path):
+    """DOLFIN-XML mesh reader.  Returns (coords[N,gdim] f64, cells[Nc,nv] i32).
+
+    Each cell's vertex list is sorted ascending, as ``dolfin.Mesh(xml)`` does
+    through ``mesh.order()``.
+    """
+    text = open(path, "r").read()
+    verts = _VERT_RE.findall(text)
+    has_z = any(v[3] != "" for v in verts)
+    gdim = 3 if has_z else 2
+    coords = np.zeros((len(verts), gdim), dtype=np.float64)
+    for idx, x, y, z in verts:
+        i = int(idx)
+        coords[i, 0] = float(x)
+        coords[i, 1] = float(y)
+        if gdim == 3:
+            coords[i, 2] = float(z)
+    tets = _TET_RE.findall(text)
+    if tets:
+        cells = np.zeros((len(tets), 4), dtype=np.int32)
+        for t in tets:
+            cells[int(t[0])] = [int(t[1]), int(t[2]), int(t[3]), int(t[4])]
+    else:
+        tris = _TRI_RE.findall(text)
+        cells = np.zeros((len(tris), 3), dtype=np.int32)
+        for t in tris:
+            cells[int(t[0])] = [int(t[1]), int(t[2]), int(t[3])]
+    cells.sort(axis=1)
+    return coords, cells
+
+
+def read_dolfin_xml_meshfunction(path):
+    """Old-style ``<mesh_function>`` reader -> (dim, values[int64])."""
+    text = open(path, "r").read()
+    m = _MF_RE.search(text)
+    dim, size = int(m.group(2)), int(m.group(3))
+    vals = np.zeros(size, dtype=np.int64)
+    for idx, v in _ENT_RE.findall(text):
+        vals[int(idx)] = int(v)
+    return dim, vals
+
+
+# --------------------------------------------------------------------------
+# structured generators (dolfin.BoxMesh / UnitCubeMesh ordering, Appendix D-8)
+# --------------------------------------------------------------------------
+
+def box_mesh(p0, p1, nx, ny, nz):
+    """``BoxMesh(Point(p0), Point(p1), nx, ny, nz)``: vertices x-fastest,
+    cells iz->iy->ix, six tets per hex around the v0-v7 diagonal, each cell's
+    vertices sorted ascending (examples/test_linear_elasticity.py:42)."""
+    # DOLFIN BoxMesh.cpp evaluates  a + (i*(b - a))/n  in this order; the device
+    # generator uses the same expression so coordinates are bit-identical.
+    x = p0[0] + (np.arange(nx + 1, dtype=np.float64) * (p1[0] - p0[0])) / float(nx)
+    y = p0[1] + (np.arange(ny + 1, dtype=np.float64) * (p1[1] - p0[1])) / float(ny)
+    z = p0[2] + (np.arange(nz + 1, dtype=np.float64) * (p1[2] - p0[2])) / float(nz)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (iz * (ny + 1) * (nx + 1) + iy * (nx + 1) + ix).ravel().astype(np.int64)
+    v1 = v0 + 1
+    v2 = v0 + (nx + 1)
+    v3 = v1 + (nx + 1)
+    v4 = v0 + (nx + 1) * (ny + 1)
+    v5 = v1 + (nx + 1) * (ny + 1)
+    v6 = v2 + (nx + 1) * (ny + 1)
+    v7 = v3 + (nx + 1) * (ny + 1)
+    tets = np.stack([
+        np.stack([v0, v1, v3, v7], 1),
+        np.stack([v0, v1, v7, v5], 1),
+        np.stack([v0, v5, v7, v4], 1),
+        np.stack([v0, v3, v2, v7], 1),
+        np.stack([v0, v6, v4, v7], 1),
+        np.stack([v0, v2, v6, v7], 1),
+    ], axis=1)  # [nhex, 6, 4]
+    cells = tets.reshape(-1, 4)
+    cells = np.sort(cells, axis=1).astype(np.int32)
+    return coords, cells
+
+
+def unit_cube_mesh(n):
+    return box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+
+
+# --------------------------------------------------------------------------
+# topology: facets / edges numbered lexicographically
+# --------------------------------------------------------------------------
+
+def facet_numbering(cells):
+    """Facets = sorted vertex triples ranked lexicographically.
+
+    Returns (facets[Nf,3], cell_facets[Nc,4], facet_cell_count[Nf]) where
+    local facet i of a cell is the one opposite local vertex i (UFC).
+    """
+    cells = np.asarray(cells, dtype=np.int64)
+    nc = cells.shape[0]
+    opp = [(1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2)]
+    tri = np.stack([cells[:, list(o)] for o in opp], axis=1).reshape(-1, 3)
+    tri = np.sort(tri, axis=1)
+    uniq, inv, cnt = np.unique(tri, axis=0, return_inverse=True, return_counts=True)
+    return uniq.astype(np.int32), inv.reshape(nc, 4).astype(np.int32), cnt.astype(np.int32)
+
+
+def edge_numbering(cells):
+    """Edges = sorted vertex pairs ranked lexicographically.
+
+    UFC local edges of a tet: e0=(v2,v3) e1=(v1,v3) e2=(v1,v2) e3=(v0,v3)
+    e4=(v0,v2) e5=(v0,v1).
+    """
+    cells = np.asarray(cells, dtype=np.int64)
+    nc = cells.shape[0]
+    loc = [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+    ed = np.stack([cells[:, list(e)] for e in loc], axis=1).reshape(-1, 2)
+    ed = np.sort(ed, axis=1)
+    uniq, inv = np.unique(ed, axis=0, return_inverse=True)
+    return uniq.astype(np.int32), inv.reshape(nc, 6).astype(np.int32)
+
+
+def boundary_facets(cells):
+    facets, cell_facets, cnt = facet_numbering(cells)
+    return np.nonzero(cnt == 1)[0].astype(np.int32), facets
+
+
+def mark_facets(coords, cells, inside, marker_id, markers=None, eps=3e-16):
+    """``SubDomain.mark(facets, id)`` (SolverBase.py:277-283): a facet is
+    marked when all its vertices and its midpoint satisfy ``inside(x,
+    on_boundary)`` (Appendix D-4).  ``inside`` receives (x[3] array, bool)."""
+    facets, _, cnt = facet_numbering(cells)
+    if markers is None:
+        markers = np.zeros(len(facets), dtype=np.int64)
+    on_b = cnt == 1
+    for f in range(len(facets)):
+        vs = facets[f]
+        ok = True
+        for v in vs:
+            if not inside(coords[v], bool(on_b[f])):
+                ok = False
+                break
+        if ok and inside(coords[vs].mean(axis=0), bool(on_b[f])):
+            markers[f] = marker_id
+    return markers
+
+
+def dirichlet_dofs_p1(facets, facet_markers, marker_id):
+    """Topological DirichletBC on P1: every vertex in the closure of the
+    facets carrying ``marker_id`` (ScalarTransportSolver.py:169-175,
+    Appendix D-3).  Sorted ascending."""
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    return np.unique(np.asarray(facets)[sel].ravel()).astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# P1 element geometry
+# --------------------------------------------------------------------------
+
+def p1_geometry(coords, cells):
+    """Returns (detJ[Nc], grads[Nc,4,3]) of the barycentric basis."""
+    c = np.asarray(coords, dtype=np.float64)[np.asarray(cells, dtype=np.int64)]
+    J = np.stack([c[:, 1] - c[:, 0], c[:, 2] - c[:, 0], c[:, 3] - c[:, 0]], axis=2)  # columns
+    detJ = np.linalg.det(J)
+    Jinv = np.linalg.inv(J)  # rows of Jinv are grads of lambda_1..3
+    g = np.zeros((c.shape[0], 4, 3))
+    g[:, 1:, :] = Jinv
+    g[:, 0, :] = -Jinv.sum(axis=1)
+    return detJ, g
+
+
+def p1_stiffness_local(coords, cells, k=1.0):
+    """Ke[a,b] = |detJ|/6 * grad_a . K . grad_b  for a(T,q)=int k grad T.grad q
+    (ScalarTransportSolver.py:284-285).  k: scalar, per-cell array or 3x3."""
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    k = np.asarray(k, dtype=np.float64)
+    if k.ndim == 2 and k.shape == (3, 3):
+        Kg = np.einsum("ij,caj->cai", k, g)
+        Ke = np.einsum("cai,cbi->cab", g, Kg)
+        return Ke * vol[:, None, None]
+    Ke = np.einsum("cai,cbi->cab", g, g)
+    if k.ndim == 0:
+        return Ke * (vol * float(k))[:, None, None]
+    return Ke * (vol * k)[:, None, None]
+
+
+def p1_mass_local(coords, cells, c=1.0):
+    """Me[a,b] = |detJ|/120 * (1+delta_ab) * c  (exact P1 mass matrix)."""
+    detJ, _ = p1_geometry(coords, cells)
+    base = (np.ones((4, 4)) + np.eye(4)) / 120.0
+    c = np.asarray(c, dtype=np.float64)
+    w = np.abs(detJ) * (float(c) if c.ndim == 0 else c)
+    return w[:, None, None] * base[None]
+
+
+# --------------------------------------------------------------------------
+# CSR pattern + assembly  (DOLFIN Assembler + PETSc AIJ, SolverBase.py:595,608-612)
+# --------------------------------------------------------------------------
+
+def csr_pattern(n, cells, ncomp=1):
+    """Sorted-column CSR pattern of the P1 (vector: node-interleaved) space."""
+    cells = np.asarray(cells, dtype=np.int64)
+    nv = cells.shape[1]
+    r = np.repeat(cells, nv, axis=1).ravel()
+    c = np.tile(cells, (1, nv)).ravel()
+    key = np.unique(r * n + c)
+    rows = key // n
+    cols = key % n
+    if ncomp > 1:
+        # expand every node pair to an ncomp x ncomp block, dof = node*ncomp+comp
+        rr = (rows[:, None, None] * ncomp + np.arange(ncomp)[None, :, None])
+        cc = (cols[:, None, None] * ncomp + np.arange(ncomp)[None, None, :])
+        rr = np.broadcast_to(rr, (len(rows), ncomp, ncomp)).ravel()
+        cc = np.broadcast_to(cc, (len(rows), ncomp, ncomp)).ravel()
+        nn = n * ncomp
+        key = np.unique(rr * nn + cc)
+        rows = key // nn
+        cols = key % nn
+        n = nn
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr.astype(np.int32), cols.astype(np.int32)
+
+
+def assemble_matrix(n, cells, Ke):
+    """Scatter-add local matrices (sum of duplicates) into sorted CSR."""
+    cells = np.asarray(cells, dtype=np.int64)
+    nv = cells.shape[1]
+    r = np.repeat(cells, nv, axis=1).ravel()
+    c = np.tile(cells, (1, nv)).ravel()
+    A = sp.coo_matrix((Ke.ravel(), (r, c)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def assemble_p1_scalar(coords, cells, k=1.0, mass_coef=None):
+    """A = K(k) [+ mass_coef * M]."""
+    n = len(coords)
+    Ke = p1_stiffness_local(coords, cells, k)
+    if mass_coef is not None:
+        Ke = Ke + p1_mass_local(coords, cells, mass_coef)
+    return assemble_matrix(n, cells, Ke)
+
+
+def assemble_p1_source(coords, cells, f=None, f_nodal=None, cell_markers=None, subdomain_id=None):
+    """b_a = int f phi_a dx.  Constant/per-cell f: |detJ|/24 each vertex
+    (ScalarTransportSolver.py:213-226 body source S*q*dx[(id)]).  Nodal f
+    (interpolated Expression/Function): b_e = M_e f_e."""
+    n = len(coords)
+    cells64 = np.asarray(cells, dtype=np.int64)
+    detJ, _ = p1_geometry(coords, cells)
+    b = np.zeros(n)
+    mask = np.ones(len(cells), dtype=bool)
+    if subdomain_id is not None:
+        mask = np.asarray(cell_markers) == subdomain_id
+    if f_nodal is not None:
+        Me = p1_mass_local(coords, cells, 1.0)
+        fe = np.asarray(f_nodal)[cells64]
+        be = np.einsum("cab,cb->ca", Me, fe)
+    else:
+        fv = np.asarray(f, dtype=np.float64)
+        w = np.abs(detJ) / 24.0 * (float(fv) if fv.ndim == 0 else fv)
+        be = np.repeat(w[:, None], 4, axis=1)
+    be = be * mask[:, None]
+    np.add.at(b, cells64.ravel(), be.ravel())
+    return b
+
+
+def facet_areas(coords, facets):
+    p = np.asarray(coords)[np.asarray(facets, dtype=np.int64)]
+    return 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
+
+
+def assemble_p1_facet_load(coords, facets, facet_markers, marker_id, g):
+    """b_a += int_{ds(id)} g phi_a ds = g*area/3 per facet vertex
+    (flux / Neumann terms, ScalarTransportSolver.py:176-200)."""
+    n = len(coords)
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    b = np.zeros(n)
+    if len(sel) == 0:
+        return b
+    ar = facet_areas(coords, np.asarray(facets)[sel])
+    np.add.at(b, np.asarray(facets, dtype=np.int64)[sel].ravel(),
+              np.repeat(g * ar / 3.0, 3))
+    return b
+
+
+def assemble_p1_facet_mass(coords, facets, facet_markers, marker_id, h):
+    """A_ab += int_{ds(id)} h phi_a phi_b ds = h*area/12*(1+delta_ab)
+    (HTC/Robin term  htc*(Ta-T)*q*ds, ScalarTransportSolver.py:201-208)."""
+    n = len(coords)
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    f = np.asarray(facets, dtype=np.int64)[sel]
+    ar = facet_areas(coords, f)
+    base = (np.ones((3, 3)) + np.eye(3)) / 12.0
+    Me = (h * ar)[:, None, None] * base[None]
+    r = np.repeat(f, 3, axis=1).ravel()
+    c = np.tile(f, (1, 3)).ravel()
+    A = sp.coo_matrix((Me.ravel(), (r, c)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    return A
+
+
+# --------------------------------------------------------------------------
+# linear elasticity, vector P1, node-interleaved dofs (LinearElasticitySolver.py:62-69, 215)
+# --------------------------------------------------------------------------
+
+def lame(E, nu):
+    mu = E / (2.0 * (1.0 + nu))
+    lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    return mu, lmbda
+
+
+def p1_elasticity_local(coords, cells, E, nu):
+    """Ke[(a,i),(b,j)] = vol * ( lmbda g_ai g_bj + mu g_aj g_bi + mu delta_ij g_a.g_b )
+    from inner(sigma(u), grad(v)) with sigma = 2 mu sym(grad u) + lmbda div u I."""
+    mu, lmbda = lame(E, nu)
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    gg = np.einsum("cak,cbk->cab", g, g)
+    Ke = (lmbda * np.einsum("cai,cbj->caibj", g, g)
+          + mu * np.einsum("caj,cbi->caibj", g, g)
+          + mu * np.einsum("cab,ij->caibj", gg, np.eye(3)))
+    Ke = Ke * vol[:, None, None, None, None]
+    return Ke.reshape(len(cells), 12, 12)
+
+
+def assemble_p1_elasticity(coords, cells, E, nu):
+    n = len(coords)
+    Ke = p1_elasticity_local(coords, cells, E, nu)
+    cells64 = np.asarray(cells, dtype=np.int64)
+    dofs = (cells64[:, :, None] * 3 + np.arange(3)[None, None, :]).reshape(len(cells), 12)
+    r = np.repeat(dofs, 12, axis=1).ravel()
+    c = np.tile(dofs, (1, 12)).ravel()
+    A = sp.coo_matrix((Ke.ravel(), (r, c)), shape=(3 * n, 3 * n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def assemble_p1_vector_source(coords, cells, f):
+    """b_(a,i) = int f_i phi_a dx for constant vector f (body force,
+    LinearElasticitySolver.py:227-228)."""
+    n = len(coords)
+    detJ, _ = p1_geometry(coords, cells)
+    w = np.abs(detJ) / 24.0
+    nodal = np.zeros(n)
+    np.add.at(nodal, np.asarray(cells, dtype=np.int64).ravel(), np.repeat(w, 4))
+    return (nodal[:, None] * np.asarray(f, dtype=np.float64)[None, :]).ravel()
+
+
+def rigid_body_modes(coords):
+    """The 6 vectors of SolverBase.build_nullspace (SolverBase.py:674-706),
+    before orthonormalisation, node-interleaved."""
+    n = len(coords)
+    x, y, z = coords[:, 0], coords[:, 1], coords[:, 2]
+    ns = np.zeros((6, n, 3))
+    ns[0, :, 0] = 1.0
+    ns[1, :, 1] = 1.0
+    ns[2, :, 2] = 1.0
+    ns[3, :, 0] = -y
+    ns[3, :, 1] = x
+    ns[4, :, 0] = z
+    ns[4, :, 2] = -x
+    ns[5, :, 2] = y
+    ns[5, :, 1] = -z
+    return ns.reshape(6, 3 * n)
+
+
+# --------------------------------------------------------------------------
+# Dirichlet  (DirichletBC.apply / assemble_system, SolverBase.py:598-602, 608-612, 644)
+# --------------------------------------------------------------------------
+
+def apply_dirichlet(A, b, dofs, vals, symmetric=True):
+    """symmetric=False: rows -> identity, b[i]=g (LinearVariationalSolver).
+    symmetric=True : additionally b -= A[:,i] g and columns zeroed
+    (assemble_system).  The CSR pattern is preserved (explicit zeros kept)."""
+    A = A.tocsr().copy()
+    b = np.array(b, dtype=np.float64, copy=True)
+    n = A.shape[0]
+    dofs = np.asarray(dofs, dtype=np.int64)
+    vals = np.broadcast_to(np.asarray(vals, dtype=np.float64), dofs.shape)
+    flag = np.zeros(n, dtype=bool)
+    g = np.zeros(n)
+    flag[dofs] = True
+    g[dofs] = vals  # later entries win on duplicates, as later BCs do in DOLFIN
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    cols = A.indices
+    data = A.data
+    if symmetric:
+        colmask = flag[cols] & ~flag[rows]
+        np.subtract.at(b, rows[colmask], data[colmask] * g[cols[colmask]])
+        data[colmask] = 0.0
+    rowmask = flag[rows]
+    data[rowmask] = 0.0
+    data[rowmask & (rows == cols)] = 1.0
+    b[flag] = g[flag]
+    return A, b
+
+
+# --------------------------------------------------------------------------
+# Krylov  (PETSc KSPCG + PCJACOBI behind SolverBase.py:663-670)
+# --------------------------------------------------------------------------
+
+def pcg_jacobi(A, b, rtol=1e-8, maxit=10000, x0=None):
+    """Textbook Jacobi-PCG from x0=0, stops when ||r||_2 <= rtol ||b||_2
+    (unpreconditioned norm: BASELINE.json 'CG solve to 1e-8').
+    Returns (x, iterations, residual_history)."""
+    n = A.shape[0]
+    dinv = 1.0 / A.diagonal()
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    r = b - A @ x
+    bb = float(b @ b)
+    thresh = rtol * rtol * bb
+    hist = [float(r @ r)]
+    if hist[0] <= thresh:
+        return x, 0, hist
+    z = dinv * r
+    p = z.copy()
+    rz = float(r @ z)
+    it = 0
+    while it < maxit:
+        q = A @ p
+        alpha = rz / float(p @ q)
+        x += alpha * p
+        r -= alpha * q
+        it += 1
+        rr = float(r @ r)
+        hist.append(rr)
+        if rr <= thresh:
+            break
+        z = dinv * r
+        rz_new = float(r @ z)
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x, it, hist
+
+
+def pcg_jacobi_single_reduction(A, b, rtol=1e-8, maxit=10000):
+    """Chronopoulos-Gear single-reduction Jacobi-PCG (PETSc
+    KSPCGUseSingleReduction): the recurrence the HIP solver runs.
+
+    iteration k:  w = A z_k ; gamma=r.z, delta=w.z, rho=r.r (one reduction)
+                  stop if rho <= rtol^2 b.b
+                  beta=gamma/gamma_old, alpha=gamma/(delta-beta*gamma/alpha_old)
+                  p=z+beta p ; s=w+beta s ; x+=alpha p ; r-=alpha s ; z=D^-1 r
+    """
+    n = A.shape[0]
+    dinv = 1.0 / A.diagonal()
+    x = np.zeros(n)
+    r = np.array(b, dtype=np.float64, copy=True)
+    z = dinv * r
+    p = np.zeros(n)
+    s = np.zeros(n)
+    bb = float(b @ b)
+    thresh = rtol * rtol * bb
+    gamma_old = 1.0
+    alpha_old = 1.0
+    hist = []
+    it = 0
+    while True:
+        w = A @ z
+        gamma = float(r @ z)
+        delta = float(w @ z)
+        rho = float(r @ r)
+        hist.append(rho)
+        if rho <= thresh or it >= maxit:
+            break
+        if it == 0:
+            beta = 0.0
+            alpha = gamma / delta
+        else:
+            beta = gamma / gamma_old
+            alpha = gamma / (delta - beta * gamma / alpha_old)
+        p = z + beta * p
+        s = w + beta * s
+        x += alpha * p
+        r -= alpha * s
+        z = dinv * r
+        gamma_old = gamma
+        alpha_old = alpha
+        it += 1
+    return x, it, hist
+
+
+def solve_direct(A, b):
+    """Sparse LU: the reference's *default* linear solve
+    (LinearVariationalSolver linear_solver='default')."""
+    return spla.spsolve(A.tocsc(), b)
+
+
+# --------------------------------------------------------------------------
+# whole-path helpers used by tests / bench cpu baseline
+# --------------------------------------------------------------------------
+
+def heat_box_problem(n, k=20.0, t_lo=350.0, t_hi=300.0, axis=2, dims=None, p1=None):
+    """Config-2 family: unit cube (or box) P1, T=t_lo on face axis=0, t_hi on
+    the opposite face, natural elsewhere, f=0.  Returns dict with A,b (BC
+    applied symmetrically), dofs, exact solution."""
+    if dims is None:
+        dims = (n, n, n)
+    if p1 is None:
+        p1 = (1.0, 1.0, 1.0)
+    coords, cells = box_mesh((0.0, 0.0, 0.0), p1, *dims)
+    A = assemble_p1_scalar(coords, cells, k)
+    b = np.zeros(len(coords))
+    lo = np.nonzero(coords[:, axis] == 0.0)[0]
+    hi = np.nonzero(coords[:, axis] == p1[axis])[0]
+    dofs = np.concatenate([lo, hi]).astype(np.int32)
+    vals = np.concatenate([np.full(len(lo), t_lo), np.full(len(hi), t_hi)])
+    Abc, bbc = apply_dirichlet(A, b, dofs, vals, symmetric=True)
+    exact = t_lo + (t_hi - t_lo) * coords[:, axis] / p1[axis]
+    return dict(coords=coords, cells=cells, A0=A, A=Abc, b=bbc, dofs=dofs, vals=vals, exact=exact)

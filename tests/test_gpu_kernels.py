@@ -1,0 +1,389 @@
+"""GPU parity tests of the HIP hot path against the CPU oracle, through the C-ABI.
+
+Bars: connectivity / CSR structure bit-exact; fp64 values within the tolerance
+written next to each assert (atomic scatter order and FMA contraction are the
+only differences from the oracle's arithmetic).
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fem_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+RTOL_ASSEMBLY = 1e-12   # relative to max |A_ij|
+RTOL_SPMV = 1e-13       # relative to |A| |x|
+RTOL_SOLUTION = 1e-9    # relative to max |u| at equal Krylov tolerance
+
+
+def _csr(A):
+    rp, ci, va, shape = A.to_csr()
+    return sp.csr_matrix((va, ci, rp), shape=shape)
+
+
+def _assert_same_pattern(M, R):
+    R = R.tocsr()
+    R.sort_indices()
+    assert M.shape == R.shape
+    assert np.array_equal(M.indptr, R.indptr)
+    assert np.array_equal(M.indices, R.indices)
+
+
+# ---------------------------------------------------------------------------------------
+def test_box_mesh_generator_matches_dolfin_order(gpu):
+    for dims, p1 in (((3, 4, 5), (1.0, 1.0, 1.0)), ((7, 2, 3), (10.0, 1.0, 1.0))):
+        m = gpu.DeviceMesh.box(*dims, p1=p1)
+        xyz, cells, gid = m.get()
+        co, ce = fo.box_mesh((0, 0, 0), p1, *dims)
+        assert np.array_equal(xyz, co)            # bit-exact coordinates
+        assert np.array_equal(cells, ce)          # bit-exact connectivity
+        assert np.array_equal(gid, np.arange(len(co)))
+
+
+def test_box_slab_has_owned_first_numbering(gpu):
+    nx, ny, nz = 3, 2, 6
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), nx, ny, nz)
+    plane = (nx + 1) * (ny + 1)
+    for zb, ze in ((0, 3), (2, 5), (4, 7)):
+        m = gpu.DeviceMesh.box(nx, ny, nz, zplanes=(zb, ze))
+        xyz, cells, gid = m.get()
+        nv, nc, n_owned = m.info()
+        assert n_owned == (ze - zb) * plane
+        assert np.array_equal(gid[:n_owned], np.arange(zb * plane, ze * plane))
+        assert np.array_equal(xyz, co[gid])
+        # local cells = every global cell touching an owned vertex, same relative order
+        glob = gid[cells]
+        owned_mask = (ce >= zb * plane) & (ce < ze * plane)
+        expect = ce[owned_mask.any(axis=1)]
+        assert np.array_equal(glob, expect)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 12])
+def test_p1_poisson_assembly_structured(gpu, n):
+    co, ce = fo.unit_cube_mesh(n)
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    M = _csr(A)
+    R = fo.assemble_p1_scalar(co, ce, 20.0)
+    _assert_same_pattern(M, R)
+    assert V.nnz == R.nnz
+    assert np.abs(M.data - R.data).max() <= RTOL_ASSEMBLY * np.abs(R.data).max()
+
+
+def test_p1_assembly_unstructured_data_mesh(gpu, data_dir):
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    assert V.nnz == 13315          # V + 2E
+    A = gpu.DeviceMatrix(V)
+    rng = np.random.default_rng(0)
+    kcell = rng.uniform(0.5, 1.5, len(ce))
+    ccell = rng.uniform(1.0, 2.0, len(ce))
+    for kw, ref in (
+        (dict(stiffness=20.0), fo.assemble_p1_scalar(co, ce, 20.0)),
+        (dict(stiffness=("cell", kcell)), fo.assemble_p1_scalar(co, ce, kcell)),
+        (dict(stiffness=2.0, mass=3.0), fo.assemble_p1_scalar(co, ce, 2.0, mass_coef=3.0)),
+        (dict(stiffness=None, mass=("cell", ccell)),
+         fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, ccell))),
+        (dict(stiffness=("tensor", [[2.0, 0.3, 0.0], [0.3, 1.0, 0.1], [0.0, 0.1, 4.0]])),
+         fo.assemble_p1_scalar(co, ce, np.array([[2.0, 0.3, 0.0], [0.3, 1.0, 0.1], [0.0, 0.1, 4.0]]))),
+    ):
+        A.assemble(**kw)
+        M = _csr(A)
+        _assert_same_pattern(M, ref)
+        assert np.abs(M.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max(), kw
+
+
+def test_matrix_add_and_axpy(gpu):
+    co, ce = fo.unit_cube_mesh(4)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    K = gpu.DeviceMatrix(V)
+    Mm = gpu.DeviceMatrix(V)
+    K.assemble(stiffness=1.5)
+    Mm.assemble(mass=2.0)
+    K.axpy(4.0, Mm)
+    ref = fo.assemble_p1_scalar(co, ce, 1.5, mass_coef=8.0)
+    got = _csr(K)
+    assert np.abs(got.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max()
+    K.assemble(stiffness=1.5)
+    K.assemble(mass=8.0, add=True)
+    got = _csr(K)
+    assert np.abs(got.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_dirichlet_matches_oracle(gpu, data_dir, symmetric):
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    d1 = fo.dirichlet_dofs_p1(facets, fm, 1)
+    d2 = fo.dirichlet_dofs_p1(facets, fm, 2)
+    dofs = np.concatenate([d1, d2])
+    vals = np.concatenate([np.full(len(d1), 350.0), np.full(len(d2), 300.0)])
+    rng = np.random.default_rng(1)
+    b0 = rng.standard_normal(len(co))
+    A0 = fo.assemble_p1_scalar(co, ce, 20.0)
+    Ar, br = fo.apply_dirichlet(A0, b0, dofs, vals, symmetric=symmetric)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    b = gpu.DeviceVector(V.n_owned, b0)
+    A.apply_dirichlet(b, dofs, vals, symmetric=symmetric)
+    M = _csr(A)
+    _assert_same_pattern(M, Ar)
+    assert np.abs(M.data - Ar.data).max() <= RTOL_ASSEMBLY * np.abs(Ar.data).max()
+    assert np.abs(b.get() - br).max() <= 1e-12 * np.abs(br).max()
+    # identity rows are exact
+    assert np.all(M.diagonal()[dofs] == 1.0)
+    assert np.all(b.get()[dofs] == vals)
+
+
+def test_dirichlet_later_entries_win(gpu):
+    co, ce = fo.unit_cube_mesh(2)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=1.0)
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, [0, 1, 0], [1.0, 2.0, 3.0], symmetric=False)
+    got = b.get()
+    assert got[0] == 3.0 and got[1] == 2.0
+
+
+def test_spmv_matches_oracle(gpu, data_dir):
+    rng = np.random.default_rng(2)
+    for co, ce in (fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml")), fo.unit_cube_mesh(9)):
+        mesh = gpu.DeviceMesh(co, ce)
+        V = gpu.DeviceSpace(mesh, 1)
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=3.0, mass=1.0)
+        R = _csr(A)   # use the device values so only the SpMV is under test
+        xh = rng.standard_normal(V.n_local)
+        x = gpu.DeviceVector(V.n_local, xh)
+        y = gpu.DeviceVector(V.n_owned)
+        A.spmv(x, y)
+        ref = R @ xh
+        scale = (abs(R) @ np.abs(xh)).max()
+        assert np.abs(y.get() - ref).max() <= RTOL_SPMV * scale
+
+
+def test_vector_ops(gpu):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(100003)
+    b = rng.standard_normal(100003)
+    x = gpu.DeviceVector(a.size, a)
+    y = gpu.DeviceVector(b.size, b)
+    assert abs(x.dot(y) - float(a @ b)) <= 1e-12 * float(np.abs(a) @ np.abs(b))
+    y.axpy(2.5, x)
+    assert np.allclose(y.get(), b + 2.5 * a, rtol=0, atol=1e-14 * 10)
+    y.fill(7.0)
+    assert np.all(y.get() == 7.0)
+
+
+def test_rhs_source_and_facet_terms(gpu, data_dir):
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    b = gpu.DeviceVector(V.n_owned)
+    rng = np.random.default_rng(4)
+    gpu.assemble_vector(V, b, source=2.5)
+    ref = fo.assemble_p1_source(co, ce, 2.5)
+    assert np.abs(b.get() - ref).max() <= 1e-12 * np.abs(ref).max()
+    fc = rng.uniform(0, 1, len(ce))
+    gpu.assemble_vector(V, b, source=("cell", fc))
+    ref = fo.assemble_p1_source(co, ce, fc)
+    assert np.abs(b.get() - ref).max() <= 1e-12 * np.abs(ref).max()
+    fn = rng.uniform(0, 1, len(co))
+    gpu.assemble_vector(V, b, source=("nodal", fn))
+    ref = fo.assemble_p1_source(co, ce, f_nodal=fn)
+    assert np.abs(b.get() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # facet load on marker 1, accumulated on top
+    tri = facets[fm == 1]
+    gpu.assemble_facet_vector(V, b, tri, 36.0)
+    ref = ref + fo.assemble_p1_facet_load(co, facets, fm, 1, 36.0)
+    assert np.abs(b.get() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # Robin matrix on marker 2
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=1.0)
+    A.add_facet_mass(facets[fm == 2], 100.0)
+    R = fo.assemble_p1_scalar(co, ce, 1.0) + fo.assemble_p1_facet_mass(co, facets, fm, 2, 100.0)
+    R = R.tocsr()
+    M = _csr(A)
+    assert abs(M - R).max() <= RTOL_ASSEMBLY * abs(R).max()
+
+
+# ---- the solve -------------------------------------------------------------------------------
+def _solve_heat(gpu, mesh, dofs, vals, k=20.0, rtol=1e-8, precond="jacobi"):
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=k)
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    x = gpu.DeviceVector(V.n_owned)
+    st = gpu.krylov_solve(A, b, x, rtol=rtol, max_iter=5000, precond=precond)
+    return x.get(), st
+
+
+def test_config1_heat_transfer_data_mesh(gpu, data_dir):
+    """data/TestHeatTransfer.json on data/mesh.xml: T = 350 - 2.5 z."""
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    d1 = fo.dirichlet_dofs_p1(facets, fm, 1)
+    d2 = fo.dirichlet_dofs_p1(facets, fm, 2)
+    dofs = np.concatenate([d1, d2])
+    vals = np.concatenate([np.full(len(d1), 350.0), np.full(len(d2), 300.0)])
+    T, st = _solve_heat(gpu, gpu.DeviceMesh(co, ce), dofs, vals, rtol=1e-8)
+    A0 = fo.assemble_p1_scalar(co, ce, 20.0)
+    Ab, bb = fo.apply_dirichlet(A0, np.zeros(len(co)), dofs, vals, True)
+    xo, ito, _ = fo.pcg_jacobi_single_reduction(Ab, bb, rtol=1e-8)
+    assert st["converged"] == 1
+    assert abs(st["iterations"] - ito) <= 1          # same recurrence, same count (93)
+    assert st["true_rel_residual"] <= 1.5e-8
+    assert np.abs(T - xo).max() <= 1e-7 * 350.0        # both stopped at 1e-8: agree far below that
+    assert np.abs(T - (350.0 - 2.5 * co[:, 2])).max() <= 1e-4
+    # tight tolerance reproduces the exact discrete solution (the reference's LU answer)
+    T, st = _solve_heat(gpu, gpu.DeviceMesh(co, ce), dofs, vals, rtol=1e-13)
+    assert np.abs(T - (350.0 - 2.5 * co[:, 2])).max() <= 1e-9
+
+
+@pytest.mark.parametrize("n,axis", [(12, 2), (24, 2), (24, 0)])
+def test_config2_family_cg_parity(gpu, n, axis):
+    P = fo.heat_box_problem(n, axis=axis)
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    T, st = _solve_heat(gpu, mesh, P["dofs"], P["vals"], rtol=1e-8)
+    xo, ito, hist = fo.pcg_jacobi_single_reduction(P["A"], P["b"], rtol=1e-8)
+    assert st["converged"] == 1
+    assert abs(st["iterations"] - ito) <= 1
+    assert np.abs(T - xo).max() <= RTOL_SOLUTION * 350.0 * 100
+    assert np.abs(T - P["exact"]).max() <= 1e-3
+    # residual history follows the oracle's while well above round-off
+    h = gpu.krylov_history()
+    m = min(len(h), len(hist), 20)
+    assert np.allclose(h[:m], hist[:m], rtol=1e-6)
+    # unpreconditioned CG also converges to the same answer
+    T2, st2 = _solve_heat(gpu, mesh, P["dofs"], P["vals"], rtol=1e-10, precond="none")
+    assert st2["converged"] == 1
+    assert np.abs(T2 - P["exact"]).max() <= 1e-5
+
+
+def test_manufactured_solution_converges_second_order(gpu):
+    """-k lap u = f with u = sin(pi x) sin(pi y) sin(pi z): L2-ish error ~ h^2 (Appendix C6)."""
+    errs = []
+    k = 20.0
+    for n in (8, 16, 32):
+        mesh = gpu.DeviceMesh.box(n, n, n)
+        xyz, cells, _ = mesh.get()
+        V = gpu.DeviceSpace(mesh, 1)
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=k)
+        u = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1]) * np.sin(np.pi * xyz[:, 2])
+        f = 3 * np.pi ** 2 * k * u
+        b = gpu.DeviceVector(V.n_owned)
+        gpu.assemble_vector(V, b, source=("nodal", f))
+        on_b = np.nonzero(((xyz == 0.0) | (xyz == 1.0)).any(axis=1))[0]
+        A.apply_dirichlet(b, on_b, 0.0, symmetric=True)
+        x = gpu.DeviceVector(V.n_owned)
+        st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+        assert st["converged"] == 1
+        errs.append(np.sqrt(np.mean((x.get() - u) ** 2)))
+    r1 = np.log2(errs[0] / errs[1])
+    r2 = np.log2(errs[1] / errs[2])
+    assert 1.7 <= r1 <= 2.3 and 1.7 <= r2 <= 2.3, (errs, r1, r2)
+
+
+def test_slab_rows_equal_global_rows(gpu):
+    """A slab (owned planes + ghost layer) assembles exactly the owned rows of the global matrix."""
+    nx, ny, nz = 4, 3, 8
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 2), nx, ny, nz)
+    G = fo.assemble_p1_scalar(co, ce, 20.0).tocsr()
+    plane = (nx + 1) * (ny + 1)
+    for zb, ze in ((0, 4), (4, 9), (3, 6)):
+        mesh = gpu.DeviceMesh.box(nx, ny, nz, p1=(1.0, 1.0, 2.0), zplanes=(zb, ze))
+        _, _, gid = mesh.get()
+        V = gpu.DeviceSpace(mesh, 1)
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=20.0)
+        M = _csr(A)
+        assert M.shape == ((ze - zb) * plane, len(gid))
+        # map local columns to global and compare row by row
+        Mg = sp.csr_matrix((M.data, gid[M.indices], M.indptr), shape=(M.shape[0], len(co)))
+        Mg.sort_indices()
+        ref = G[zb * plane:ze * plane]
+        ref.sort_indices()
+        assert np.array_equal(Mg.indptr, ref.indptr)
+        assert np.array_equal(Mg.indices, ref.indices)
+        assert np.abs(Mg.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max()
+
+
+# ---- vector P1 elasticity ----------------------------------------------------------------------
+def test_elasticity_assembly_and_nullspace(gpu):
+    E, nu = 2e11, 0.27
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 8, 2, 2)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=fo.lame(E, nu))
+    M = _csr(A)
+    R = fo.assemble_p1_elasticity(co, ce, E, nu)
+    # the device pattern is the full 3x3 block pattern (explicit zeros kept)
+    assert M.shape == R.shape
+    assert abs(M - R).max() <= RTOL_ASSEMBLY * abs(R).max()
+    # rigid-body modes span the null space: K r = 0 (Appendix C5)
+    ns = fo.rigid_body_modes(co)
+    x = gpu.DeviceVector(V.n_local)
+    y = gpu.DeviceVector(V.n_owned)
+    scale = abs(R).max()
+    for r in ns:
+        x.set(r)
+        A.spmv(x, y)
+        assert np.abs(y.get()).max() <= 1e-10 * scale * np.abs(r).max()
+
+
+def test_elasticity_cantilever_solve(gpu):
+    E, nu = 2e11, 0.27
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 10, 2, 2)
+    n = len(co)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=fo.lame(E, nu))
+    b = gpu.DeviceVector(V.n_owned)
+    f = (0.0, 0.0, -7800.0 * 10.0)
+    gpu.assemble_vector(V, b, vector_value=f)
+    left = np.nonzero(co[:, 0] == 0.0)[0]
+    dofs = (left[:, None] * 3 + np.arange(3)[None, :]).ravel()
+    A.apply_dirichlet(b, dofs, 0.0, symmetric=True)
+    x = gpu.DeviceVector(V.n_owned)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=20000)
+    assert st["converged"] == 1
+    R = fo.assemble_p1_elasticity(co, ce, E, nu)
+    rb = fo.assemble_p1_vector_source(co, ce, f)
+    Ab, bb = fo.apply_dirichlet(R, rb, dofs, 0.0, True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(x.get() - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert ref.reshape(n, 3)[:, 2].min() < 0.0
+
+
+def test_errors_are_reported_not_silent(gpu):
+    co, ce = fo.unit_cube_mesh(2)
+    bad = ce.copy()
+    bad[0, 0] = 10 ** 6
+    with pytest.raises(gpu.BackendError):
+        gpu.DeviceMesh(co, bad)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)       # all-zero matrix: Jacobi undefined
+    b = gpu.DeviceVector(V.n_owned, np.ones(V.n_owned))
+    x = gpu.DeviceVector(V.n_owned)
+    with pytest.raises(gpu.BackendError):
+        gpu.krylov_solve(A, b, x)
