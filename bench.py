@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — DOF/s (assemble + CG solve to 1e-8) on 3D P1 heat conduction.
+
+One "step" = one pass of the hot path over the synthetic mesh already resident in
+HBM: numeric assembly of A (5.8 M tets at N=1), Dirichlet elimination, Jacobi-PCG
+from x0 = 0 to ||b - A x|| <= 1e-8 ||b||  (what SolverBase.solve_linear_problem does
+through DOLFIN/PETSc, FenicsSolver/SolverBase.py:592-613).  Mesh generation and the
+sparsity pattern (DOLFIN builds it inside the first assemble) are set-up, timed and
+reported separately as `symbolic_ms`.
+
+  python bench.py                       # N=1: BASELINE.json configs[1], 1 M DOF unit cube
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU (RCCL)
+
+Multi-GPU: z-slab domain decomposition, halo exchange + one 3-double all-reduce per CG
+iteration (fenicssolver_amd/csrc/fs_comm.hip).  Default scaling is WEAK: every GPU
+owns 100 vertex planes of 100x100 (1 M DOF), the bar grows along z and the Dirichlet pair
+sits on the x-faces so the conditioning does not change with N.  `--scaling strong --n 215`
+splits the 10 M-DOF cube instead.
+
+torch is used only for process rendezvous (gloo broadcast of the RCCL unique id and the
+timing barrier); all compute is libfsamd.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fenicssolver_amd import backend as B  # noqa: E402  (loads libfsamd.so before torch)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=99, help="cells per axis of the (per-GPU) cube")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--bc-axis", type=int, default=None, help="axis of the Dirichlet face pair (default 2 at N=1, 0 at N>1)")
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-case", action="store_true", help="skip the extra 10 M-DOF roofline measurement")
+    return ap.parse_args()
+
+
+class Problem:
+    """One rank's share of the box heat problem, resident on the device."""
+
+    def __init__(self, nx, ny, nz, p1, zplanes, axis, rank, world):
+        P = (nx + 1) * (ny + 1)
+        zb, ze = zplanes
+        t0 = time.perf_counter()
+        self.mesh = B.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), p1, zplanes=zplanes)
+        B.synchronize()
+        t1 = time.perf_counter()
+        self.V = B.DeviceSpace(self.mesh, 1)
+        B.synchronize()
+        t2 = time.perf_counter()
+        self.mesh_ms = (t1 - t0) * 1e3
+        self.symbolic_ms = (t2 - t1) * 1e3
+        n_own = (ze - zb) * P
+        has_lo, has_hi = zb > 0, ze < nz + 1
+        assert self.V.n_owned == n_own and self.V.n_local == n_own + (has_lo + has_hi) * P
+        # Dirichlet dofs in local numbering (owned planes first, then lower, then upper ghost plane)
+        planes = list(range(zb, ze)) + ([zb - 1] if has_lo else []) + ([ze] if has_hi else [])
+        inplane = np.arange(P)
+        ix, iy = inplane % (nx + 1), inplane // (nx + 1)
+        dofs, vals = [], []
+        for lp, iz in enumerate(planes):
+            if axis == 2:
+                if iz == 0:
+                    sel, v = inplane, 350.0
+                elif iz == nz:
+                    sel, v = inplane, 300.0
+                else:
+                    continue
+                dofs.append(lp * P + sel)
+                vals.append(np.full(sel.size, v))
+            else:
+                c, m = (ix, nx) if axis == 0 else (iy, ny)
+                lo, hi = inplane[c == 0], inplane[c == m]
+                dofs += [lp * P + lo, lp * P + hi]
+                vals += [np.full(lo.size, 350.0), np.full(hi.size, 300.0)]
+        self.dofs = np.concatenate(dofs).astype(np.int32)
+        self.vals = np.concatenate(vals)
+        if world > 1:
+            nb, send, recv = [], [], []
+            if has_lo:
+                nb.append(rank - 1)
+                send.append(np.arange(0, P, dtype=np.int32))
+                recv.append(P)
+            if has_hi:
+                nb.append(rank + 1)
+                send.append(np.arange(n_own - P, n_own, dtype=np.int32))
+                recv.append(P)
+            self.V.set_halo(nb, send, recv)
+        self.A = B.DeviceMatrix(self.V)
+        self.b = B.DeviceVector(self.V.n_owned)
+        self.x = B.DeviceVector(self.V.n_owned)
+        self.n_owned = n_own
+
+    def step(self, rtol):
+        """assemble + Dirichlet + CG.  Returns (stats, t_assemble_ms)."""
+        t0 = time.perf_counter()
+        self.A.assemble(stiffness=20.0)
+        self.b.fill(0.0)
+        self.A.apply_dirichlet(self.b, self.dofs, self.vals, symmetric=True)
+        t1 = time.perf_counter()
+        st = B.krylov_solve(self.A, self.b, self.x, rtol=rtol, max_iter=20000, precond="jacobi")
+        if st["converged"] != 1:
+            raise RuntimeError("CG did not converge: %r" % (st,))
+        return st, (t1 - t0) * 1e3
+
+
+def roofline_of(st, traffic=None):
+    ms = st["spmv_ms"]
+    achieved = st["spmv_bytes"] / ms / 1e6 if ms > 0 else 0.0
+    return {"kernel": "k_sell_spmv<1,DOTS,4> (SELL-64 SpMV fused with the 3 CG dot products)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": st["spmv_bytes"], "avg_launch_ms": round(ms, 5)}
+
+
+def committed_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc.json, collected with tools/collect_pmc.sh on the same command)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as fh:
+            return json.load(fh).get(tag)
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+        a.gpus = world
+    B.init(local_rank if world > 1 else 0)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous only
+        dist.init_process_group("gloo")
+        uid = [B.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        B.comm_init(world, rank, uid[0])
+
+    def barrier():
+        B.synchronize()
+        if dist is not None:
+            dist.barrier()
+        B.synchronize()
+
+    n = a.n
+    axis = a.bc_axis if a.bc_axis is not None else (2 if world == 1 else 0)
+    if a.scaling == "weak":
+        planes_per_rank = n + 1
+        nz = world * planes_per_rank - 1
+        p1 = (1.0, 1.0, nz / float(n))
+        zplanes = (rank * planes_per_rank, (rank + 1) * planes_per_rank)
+    else:
+        nz = n
+        p1 = (1.0, 1.0, 1.0)
+        cuts = [(n + 1) * r // world for r in range(world + 1)]
+        zplanes = (cuts[rank], cuts[rank + 1])
+    if world > 1 and axis == 2 and a.scaling == "weak":
+        print("[bench] note: --bc-axis 2 with weak scaling lengthens the bar between the Dirichlet faces; "
+              "iteration counts will grow with N", file=sys.stderr)
+    prob = Problem(n, n, nz, p1, zplanes, axis, rank, world)
+    n_dof_total = (n + 1) * (n + 1) * (nz + 1)
+
+    for _ in range(a.warmup):
+        prob.step(a.rtol)
+    barrier()
+    t0 = time.perf_counter()
+    asm_ms, stats = 0.0, None
+    for _ in range(a.steps):
+        stats, t_asm = prob.step(a.rtol)
+        asm_ms += t_asm
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / a.steps
+
+    out = None
+    if rank == 0:
+        workload = ("P1 Poisson heat conduction, unit cube n=%d (BASELINE.json configs[1]: %d DOF, %d tets), "
+                    "k=20, T=350/300 on the %s-faces, Jacobi-PCG rtol %g" %
+                    (n, n_dof_total, 6 * n ** 3, "xyz"[axis], a.rtol)) if world == 1 else (
+            "P1 Poisson heat conduction, box %dx%dx%d cells (%d DOF), z-slabs over %d GPUs, "
+            "T=350/300 on the %s-faces, Jacobi-PCG rtol %g" % (n, n, nz, n_dof_total, world, "xyz"[axis], a.rtol))
+        out = {
+            "metric": "DOF/s (assemble+CG solve to 1e-8) on 3D heat transfer",
+            "value": round(n_dof_total / (ms_per_step * 1e-3), 1),
+            "unit": "DOF/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_dof": n_dof_total, "n_cells": 6 * n * n * nz,
+                       "parallelism": "1 GPU" if world == 1 else "z-slab domain decomposition x%d" % world,
+                       "cg_iterations": stats["iterations"], "true_rel_residual": stats["true_rel_residual"]},
+            "assemble_ms_per_step": round(asm_ms / a.steps, 4),
+            "solve_ms_per_step": round(ms_per_step - asm_ms / a.steps, 4),
+            "symbolic_ms": round(prob.symbolic_ms, 3), "mesh_ms": round(prob.mesh_ms, 3),
+            "update_kernel_ms": round(stats["update_ms"], 5),
+            "roofline": roofline_of(stats, committed_traffic("spmv_fused_n%d" % n) if world == 1 else None),
+        }
+
+    if world == 1:
+        x_gpu = prob.x.get()
+        # --- extra: the same path at 10 M DOF, where nothing fits the 256 MiB Infinity Cache ---
+        if not a.no_hbm_case and n < 200:
+            del prob
+            big = Problem(215, 215, 215, (1.0, 1.0, 1.0), (0, 216), axis, 0, 1)
+            big.step(a.rtol)
+            t0 = time.perf_counter()
+            st_big, asm_big = big.step(a.rtol)
+            B.synchronize()
+            t_big = time.perf_counter() - t0
+            r = roofline_of(st_big, committed_traffic("spmv_fused_n215"))
+            r.update({"workload": "same path, unit cube n=215, %d DOF (HBM-resident)" % big.n_owned,
+                      "dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
+                      "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3)})
+            out["roofline_hbm_resident"] = r
+            del big
+        # --- CPU baseline: the oracle's C restatement of the reference's CPU path, same workload ---
+        if not a.no_cpu_baseline:
+            from oracle import c_oracle
+            ref = c_oracle.heat_box_solve(n, n, n, axis=axis, rtol=a.rtol)
+            cpu_s = ref["t_assemble"] + ref["t_solve"]
+            scale = np.abs(ref["x"]).max()
+            out["cpu_baseline"] = {
+                "value": round(n_dof_total / cpu_s, 1), "unit": "DOF/s", "cores": ref["threads"], "kind": "port",
+                "sample": "the full step workload once (n=%d: assemble %.3f s + %d PCG iterations %.3f s; "
+                          "pattern build %.2f s excluded as on the GPU)" % (n, ref["t_assemble"], ref["iterations"],
+                                                                           ref["t_solve"], ref["t_symbolic"]),
+                "what": "oracle/fem_oracle_c.c: C/OpenMP restatement of DOLFIN cell-loop assembly + PETSc KSPCG/PCJACOBI "
+                        "(FEniCS itself cannot be installed here)",
+                "iterations": ref["iterations"]}
+            out["parity"] = {"iterations_gpu": stats["iterations"], "iterations_cpu": ref["iterations"],
+                             "max_rel_diff_solution": float(np.abs(x_gpu - ref["x"]).max() / scale)}
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        B.comm_finalize()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

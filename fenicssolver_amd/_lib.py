@@ -62,6 +62,7 @@ SIGNATURES = {
     "fs_device_synchronize": (C.c_int, []),
     "fs_last_error": (C.c_char_p, []),
     "fs_version": (C.c_char_p, []),
+    "fs_set_option": (C.c_int, [C.c_char_p, C.c_double]),
     "fs_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "fs_mesh_create": (C.c_int, [C.c_int, c_i64, c_f64p, c_i64, c_i32p, C.c_int, c_i64, C.POINTER(_H)]),
     "fs_mesh_create_box": (C.c_int, [c_i64, c_i64, c_i64, c_f64p, c_f64p, c_i64, c_i64, C.POINTER(_H)]),

@@ -313,3 +313,7 @@ def comm_allreduce_sum(values):
 
 def halo_exchange(space, v):
     L.check(L.load().fs_halo_exchange(space.h, v.h), "fs_halo_exchange")
+
+
+def set_option(name, value):
+    L.check(L.load().fs_set_option(name.encode(), float(value)), "fs_set_option")

@@ -557,10 +557,12 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
     for (int64_t i = 0; i < nu; ++i)
         FS_REQUIRE(h_dofs[i] >= 0 && h_dofs[i] < sp->n_dofs_local, "fs_apply_dirichlet: dof %d outside [0,%lld)", h_dofs[i], (long long)sp->n_dofs_local);
     FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_apply_dirichlet: b shorter than the owned dofs");
-    dbuf<uint8_t> flag;
-    dbuf<double> g;
-    FS_CHECK(flag.alloc(sp->n_dofs_local));
-    FS_CHECK(g.alloc(sp->n_dofs_local));
+    dbuf<uint8_t>& flag = sp->bc_flag;
+    dbuf<double>& g = sp->bc_g;
+    if (flag.n != sp->n_dofs_local) {
+        FS_CHECK(flag.alloc(sp->n_dofs_local));
+        FS_CHECK(g.alloc(sp->n_dofs_local));
+    }
     FS_CHECK(flag.zero(s));
     FS_CHECK(g.zero(s));
     hipLaunchKernelGGL(k_bc_scatter, dim3(fs_grid_for(nu)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, nu, flag.p, g.p);

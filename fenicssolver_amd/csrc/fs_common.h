@@ -14,7 +14,7 @@
 #define FS_WAVE 64            // CDNA wavefront
 #define FS_SLICE 64           // SELL slice height = one wavefront
 #define FS_BLOCK 256          // workgroup size of every kernel (4 waves)
-#define FS_MAX_PARTIAL_BLOCKS 1024
+#define FS_MAX_PARTIAL_BLOCKS 4096
 
 // ---- error plumbing -----------------------------------------------------------
 void fs_set_error(const char* fmt, ...);
@@ -138,6 +138,9 @@ struct fs_space_s {
     dbuf<int32_t> sell_col;       // [sell_entries] node column, padding = own row
     dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned
     fs_halo_plan halo;
+    // Dirichlet scratch kept across calls (re-assembly every time step must not hipMalloc)
+    dbuf<uint8_t> bc_flag;        // [n_dofs_local]
+    dbuf<double> bc_g;            // [n_dofs_local]
 };
 
 struct fs_matrix_s {

@@ -40,7 +40,7 @@ __device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
 }
 
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
-template <int BS, bool DOTS>
+template <int BS, bool DOTS, int UNROLL>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_slices,
                                                         const int64_t* __restrict__ slice_ptr,
                                                         const int32_t* __restrict__ sell_col,
@@ -63,37 +63,51 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t r = s * FS_SLICE + lane;
+        const bool live = r < n_rows;
         const int32_t* __restrict__ cp = sell_col + base + lane;
         const double* __restrict__ vp = val + base + lane;
         if (BS == 1) {
+            // operands of the fused dots are requested up front so their latency hides
+            // under the row loop instead of serialising after it
+            double zi = 0.0, ri = 0.0;
+            if (DOTS && live) {
+                zi = x[r];
+                ri = rvec[r];
+            }
             double acc = 0.0;
             int k = 0;
-            for (; k + 4 <= width; k += 4) {
-                const int32_t c0 = cp[(int64_t)(k + 0) * FS_SLICE];
-                const int32_t c1 = cp[(int64_t)(k + 1) * FS_SLICE];
-                const int32_t c2 = cp[(int64_t)(k + 2) * FS_SLICE];
-                const int32_t c3 = cp[(int64_t)(k + 3) * FS_SLICE];
-                const double v0 = vp[(int64_t)(k + 0) * FS_SLICE];
-                const double v1 = vp[(int64_t)(k + 1) * FS_SLICE];
-                const double v2 = vp[(int64_t)(k + 2) * FS_SLICE];
-                const double v3 = vp[(int64_t)(k + 3) * FS_SLICE];
-                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-                acc += v0 * x0;
-                acc += v1 * x1;
-                acc += v2 * x2;
-                acc += v3 * x3;
+            for (; k + UNROLL <= width; k += UNROLL) {
+                int32_t c[UNROLL];
+                double v[UNROLL], xv[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) c[u] = cp[(int64_t)(k + u) * FS_SLICE];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) acc += v[u] * xv[u];
             }
             for (; k < width; ++k) acc += vp[(int64_t)k * FS_SLICE] * x[cp[(int64_t)k * FS_SLICE]];
-            if (r < n_rows) {
+            if (live) {
                 y[r] = acc;
                 if (DOTS) {
-                    const double zi = x[r], ri = rvec[r];
                     d_rz += ri * zi;
                     d_wz += acc * zi;
                     d_rr += ri * ri;
                 }
             }
         } else {
+            double zi[BS], ri[BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                zi[i] = 0.0;
+                ri[i] = 0.0;
+                if (DOTS && live) {
+                    zi[i] = x[r * BS + i];
+                    ri[i] = rvec[r * BS + i];
+                }
+            }
             double acc[BS];
 #pragma unroll
             for (int i = 0; i < BS; ++i) acc[i] = 0.0;
@@ -107,15 +121,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
 #pragma unroll
                     for (int j = 0; j < BS; ++j) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xv[j];
             }
-            if (r < n_rows) {
+            if (live) {
 #pragma unroll
                 for (int i = 0; i < BS; ++i) {
                     y[r * BS + i] = acc[i];
                     if (DOTS) {
-                        const double zi = x[r * BS + i], ri = rvec[r * BS + i];
-                        d_rz += ri * zi;
-                        d_wz += acc[i] * zi;
-                        d_rr += ri * ri;
+                        d_rz += ri[i] * zi[i];
+                        d_wz += acc[i] * zi[i];
+                        d_rr += ri[i] * ri[i];
                     }
                 }
             }
@@ -267,9 +280,32 @@ __global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict_
 }
 
 // ---- host side --------------------------------------------------------------------------------
+// tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
+static int g_spmv_blocks = 2048;
+static int g_spmv_unroll = 4;
+static int g_cg_batch = 32;
+
+extern "C" int fs_set_option(const char* name, double value) {
+    FS_REQUIRE(name, "fs_set_option: null name");
+    if (!strcmp(name, "spmv_blocks")) {
+        FS_REQUIRE(value >= 8 && value <= FS_MAX_PARTIAL_BLOCKS, "spmv_blocks must be in [8,%d]", FS_MAX_PARTIAL_BLOCKS);
+        g_spmv_blocks = (int)value;
+    } else if (!strcmp(name, "spmv_unroll")) {
+        FS_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "spmv_unroll must be 2, 4, 8 or 16");
+        g_spmv_unroll = (int)value;
+    } else if (!strcmp(name, "cg_batch")) {
+        FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
+        g_cg_batch = (int)value;
+    } else {
+        fs_set_error("fs_set_option: unknown option '%s'", name);
+        return FS_ERR_INVALID;
+    }
+    return FS_OK;
+}
+
 static int spmv_grid(int64_t n_slices) {
     const int64_t n_chunks = (n_slices + 3) / 4;
-    int64_t g = n_chunks < FS_MAX_PARTIAL_BLOCKS ? n_chunks : FS_MAX_PARTIAL_BLOCKS;
+    int64_t g = n_chunks < g_spmv_blocks ? n_chunks : g_spmv_blocks;
     g = (g + 7) & ~(int64_t)7;  // multiple of 8 for the XCD mapping
     return (int)g;
 }
@@ -279,10 +315,18 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
                         const int* status, hipStream_t s) {
     fs_space_s* sp = A->space;
     const int grid = spmv_grid(sp->n_slices);
-    if (A->bs == 1)
-        hipLaunchKernelGGL((k_sell_spmv<1, DOTS>), dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status);
-    else
-        hipLaunchKernelGGL((k_sell_spmv<3, DOTS>), dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status);
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status
+    if (A->bs == 1) {
+        switch (g_spmv_unroll) {
+            case 2: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 2>), FS_SPMV_ARGS); break;
+            case 8: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 8>), FS_SPMV_ARGS); break;
+            case 16: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16>), FS_SPMV_ARGS); break;
+            default: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS); break;
+        }
+    } else {
+        hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 1>), FS_SPMV_ARGS);
+    }
+#undef FS_SPMV_ARGS
 }
 
 extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
@@ -299,16 +343,29 @@ extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
 }
 
 extern "C" int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch) {
-    FS_REQUIRE(A && x && y && ms_per_launch && reps > 0, "fs_spmv_benchmark: bad arguments");
+    FS_REQUIRE(A && x && y && ms_per_launch && reps != 0, "fs_spmv_benchmark: bad arguments");
+    // reps < 0: time the CG flavour (SpMV fused with the three dot products, r := y)
+    const bool fused = reps < 0;
+    if (fused) reps = -reps;
     fs_space_s* sp = A->space;
     FS_REQUIRE(x->d.n >= sp->n_dofs_local && y->d.n >= sp->n_dofs_owned, "fs_spmv_benchmark: vector too short");
     hipStream_t s = fs_rt().stream;
     hipEvent_t e0, e1;
     FS_HIP(hipEventCreate(&e0));
     FS_HIP(hipEventCreate(&e1));
-    launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);  // warm-up
+    dbuf<double> partials, w;
+    dbuf<int> status;
+    FS_CHECK(partials.alloc(4 * (FS_MAX_PARTIAL_BLOCKS + 8)));
+    FS_CHECK(status.alloc(4));
+    FS_CHECK(status.zero(s));
+    if (fused) FS_CHECK(w.alloc(sp->n_dofs_owned + 2));
+    auto go = [&]() {
+        if (fused) launch_spmv<true>(A, x->d.p, w.p, y->d.p, partials.p, status.p, s);
+        else launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    };
+    go();  // warm-up
     FS_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    for (int i = 0; i < reps; ++i) go();
     FS_HIP(hipEventRecord(e1, s));
     FS_HIP(hipEventSynchronize(e1));
     FS_KERNEL_CHECK();
@@ -431,7 +488,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     FS_KERNEL_CHECK();
 
     // iteration pipeline
-    const int batch = opts->batch > 0 ? opts->batch : 32;
+    const int batch = opts->batch > 0 ? opts->batch : g_cg_batch;
     const int max_iter = opts->max_iter;
     int k = 0, slot = 0, pending = -1, n_samples = 0;
     bool finished = false;

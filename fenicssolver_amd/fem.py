@@ -1,0 +1,735 @@
+"""Host-side data model the solver API exposes: the small subset of the dolfin
+namespace that FenicsSolver's settings dicts and example scripts use
+ — Mesh, BoxMesh, UnitCubeMesh, MeshFunction,
+SubDomain/AutoSubDomain, FunctionSpace/VectorFunctionSpace, Function, Constant,
+Expression, DirichletBC, interpolate, near, Point.
+
+These objects only describe the problem (topology, markers, coefficients,
+Dirichlet sets).  They do no assembly and no linear algebra: that is
+libfsamd.so's job (fenicssolver_amd.backend).  Semantics follow DOLFIN's as the
+reference relies on them:
+  * Mesh(xml) sorts each cell's vertices ascending; facets and edges are
+    numbered lexicographically by their sorted vertex tuples (Appendix C1);
+  * SubDomain.mark marks a facet when all its vertices and its midpoint are
+    inside (D-4); DirichletBC is topological: all dofs on marked facets (D-3);
+  * VectorFunctionSpace dofs are node-interleaved (D-7).
+"""
+from __future__ import annotations
+
+import math
+import numbers
+import os
+import re
+
+import numpy as np
+
+DOLFIN_EPS = 3.0e-16
+
+
+class SolverError(Exception):
+    pass
+
+
+def near(a, b, eps=DOLFIN_EPS):
+    """dolfin.near: |a-b| < eps.  Works on scalars and arrays."""
+    return np.abs(np.asarray(a) - b) < eps if isinstance(a, np.ndarray) else abs(a - b) < eps
+
+
+class Point:
+    def __init__(self, *xyz):
+        if len(xyz) == 1 and hasattr(xyz[0], "__len__"):
+            xyz = tuple(xyz[0])
+        self._x = np.zeros(3)
+        self._x[: len(xyz)] = xyz
+
+    def x(self):
+        return self._x[0]
+
+    def y(self):
+        return self._x[1]
+
+    def z(self):
+        return self._x[2]
+
+    def array(self):
+        return self._x.copy()
+
+    def __getitem__(self, i):
+        return self._x[i]
+
+
+# --------------------------------------------------------------------------------------------
+# mesh
+# --------------------------------------------------------------------------------------------
+_VERT_RE = re.compile(r'<vertex\s+index="(\d+)"\s+x="([^"]+)"\s+y="([^"]+)"(?:\s+z="([^"]+)")?')
+_TET_RE = re.compile(r'<tetrahedron\s+index="(\d+)"\s+v0="(\d+)"\s+v1="(\d+)"\s+v2="(\d+)"\s+v3="(\d+)"')
+_ENT_RE = re.compile(r'<entity\s+index="(\d+)"\s+value="(-?\d+)"')
+_MF_RE = re.compile(r'<mesh_function\s+type="(\w+)"\s+dim="(\d+)"\s+size="(\d+)"')
+_MVC_RE = re.compile(r'<value\s+cell_index="(\d+)"\s+local_entity="(\d+)"\s+value="(-?\d+)"')
+
+
+class _Geometry:
+    def __init__(self, mesh):
+        self._m = mesh
+
+    def dim(self):
+        return self._m._coords.shape[1]
+
+
+class _Topology:
+    def __init__(self, mesh):
+        self._m = mesh
+
+    def dim(self):
+        return self._m._cells.shape[1] - 1
+
+
+class Mesh:
+    """Tetrahedral mesh (dolfin.Mesh; SolverBase.py:203-258).  ``Mesh(path)`` reads DOLFIN XML."""
+
+    def __init__(self, filename=None, coords=None, cells=None):
+        if filename is not None:
+            coords, cells = self._read_xml(filename)
+        if coords is None or cells is None:
+            raise SolverError("Mesh needs a DOLFIN-XML file name or (coords, cells) arrays")
+        self._coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self._cells = np.sort(cells, axis=1)  # mesh.order()
+        if self._coords.shape[1] != 3 or self._cells.shape[1] != 4:
+            raise SolverError("only tetrahedral meshes in 3D are supported by fenicssolver_amd "
+                              "(got gdim=%d, %d vertices per cell)" % (self._coords.shape[1], self._cells.shape[1]))
+        self._topo = None
+        self._device = None
+
+    @staticmethod
+    def _read_xml(path):
+        if not os.path.exists(path):
+            raise SolverError('mesh file: {} , does not exist'.format(path))
+        text = open(path, "r").read()
+        verts = _VERT_RE.findall(text)
+        tets = _TET_RE.findall(text)
+        if not verts or not tets:
+            raise SolverError("{}: not a DOLFIN-XML tetrahedral mesh".format(path))
+        coords = np.zeros((len(verts), 3))
+        for idx, x, y, z in verts:
+            coords[int(idx)] = (float(x), float(y), float(z) if z != "" else 0.0)
+        cells = np.zeros((len(tets), 4), dtype=np.int32)
+        for t in tets:
+            cells[int(t[0])] = (int(t[1]), int(t[2]), int(t[3]), int(t[4]))
+        return coords, cells
+
+    # dolfin API -------------------------------------------------------------
+    def geometry(self):
+        return _Geometry(self)
+
+    def topology(self):
+        return _Topology(self)
+
+    def coordinates(self):
+        return self._coords
+
+    def cells(self):
+        return self._cells
+
+    def num_vertices(self):
+        return self._coords.shape[0]
+
+    def num_cells(self):
+        return self._cells.shape[0]
+
+    def num_entities(self, dim):
+        if dim == 0:
+            return self.num_vertices()
+        if dim == 3:
+            return self.num_cells()
+        if dim == 2:
+            return len(self.facets())
+        if dim == 1:
+            return len(self.edges())
+        raise SolverError("bad entity dimension %d" % dim)
+
+    def num_facets(self):
+        return len(self.facets())
+
+    def hmin(self):
+        c = self._coords[self._cells.astype(np.int64)]
+        e = [np.linalg.norm(c[:, i] - c[:, j], axis=1) for i in range(4) for j in range(i + 1, 4)]
+        return float(np.min(e))
+
+    # topology (lexicographic numbering) --------------------------------
+    def _build_topology(self):
+        if self._topo is not None:
+            return self._topo
+        cells = self._cells.astype(np.int64)
+        nv = self.num_vertices()
+        opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))  # facet i is opposite local vertex i
+        tri = np.stack([cells[:, list(o)] for o in opp], axis=1).reshape(-1, 3)  # already ascending
+        key = (tri[:, 0] * nv + tri[:, 1]) * nv + tri[:, 2]
+        ukey, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+        facets = np.stack([ukey // (nv * nv), (ukey // nv) % nv, ukey % nv], axis=1).astype(np.int32)
+        loc = ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+        ed = np.stack([cells[:, list(e)] for e in loc], axis=1).reshape(-1, 2)
+        ekey = ed[:, 0] * nv + ed[:, 1]
+        uekey, einv = np.unique(ekey, return_inverse=True)
+        edges = np.stack([uekey // nv, uekey % nv], axis=1).astype(np.int32)
+        self._topo = dict(facets=facets, cell_facets=inv.reshape(-1, 4).astype(np.int32),
+                          facet_count=cnt.astype(np.int32), edges=edges,
+                          cell_edges=einv.reshape(-1, 6).astype(np.int32))
+        return self._topo
+
+    def facets(self):
+        return self._build_topology()["facets"]
+
+    def edges(self):
+        return self._build_topology()["edges"]
+
+    def cell_facets(self):
+        return self._build_topology()["cell_facets"]
+
+    def exterior_facets(self):
+        """bool[num_facets]: facet belongs to exactly one cell."""
+        return self._build_topology()["facet_count"] == 1
+
+    def device(self):
+        """The mesh resident in HBM (created on first use)."""
+        if self._device is None:
+            from . import backend
+            self._device = self._make_device(backend)
+        return self._device
+
+    def _make_device(self, backend):
+        return backend.DeviceMesh(self._coords, self._cells)
+
+
+class BoxMesh(Mesh):
+    """dolfin.BoxMesh(Point, Point, nx, ny, nz) ordering (Appendix D-8;
+    examples/test_linear_elasticity.py:42).  The host copy is built with numpy; the
+    device copy is generated by a kernel, not uploaded."""
+
+    def __init__(self, p0, p1, nx, ny, nz):
+        a = p0.array() if isinstance(p0, Point) else np.asarray(p0, dtype=np.float64)
+        b = p1.array() if isinstance(p1, Point) else np.asarray(p1, dtype=np.float64)
+        nx, ny, nz = int(nx), int(ny), int(nz)
+        self._box = (nx, ny, nz, tuple(a), tuple(b))
+        x = a[0] + (np.arange(nx + 1, dtype=np.float64) * (b[0] - a[0])) / float(nx)
+        y = a[1] + (np.arange(ny + 1, dtype=np.float64) * (b[1] - a[1])) / float(ny)
+        z = a[2] + (np.arange(nz + 1, dtype=np.float64) * (b[2] - a[2])) / float(nz)
+        Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+        coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        v0 = (iz * (ny + 1) * (nx + 1) + iy * (nx + 1) + ix).ravel().astype(np.int64)
+        sx, sy, sz = 1, nx + 1, (nx + 1) * (ny + 1)
+        corner = [v0, v0 + sx, v0 + sy, v0 + sx + sy, v0 + sz, v0 + sx + sz, v0 + sy + sz, v0 + sx + sy + sz]
+        tets = ((0, 1, 3, 7), (0, 1, 5, 7), (0, 4, 5, 7), (0, 2, 3, 7), (0, 4, 6, 7), (0, 2, 6, 7))
+        cells = np.stack([np.stack([corner[i] for i in t], axis=1) for t in tets], axis=1).reshape(-1, 4)
+        Mesh.__init__(self, coords=coords, cells=cells)
+
+    def _make_device(self, backend):
+        nx, ny, nz, a, b = self._box
+        return backend.DeviceMesh.box(nx, ny, nz, a, b)
+
+
+class UnitCubeMesh(BoxMesh):
+    def __init__(self, nx, ny, nz):
+        BoxMesh.__init__(self, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), nx, ny, nz)
+
+
+class MeshFunction:
+    """dolfin.MeshFunction("size_t", mesh, dim | filename[, value])."""
+
+    def __init__(self, value_type, mesh, dim_or_file, value=None):
+        self._mesh = mesh
+        self._type = value_type
+        dt = np.float64 if value_type == "double" else np.int64
+        if isinstance(dim_or_file, str):
+            self._dim, self._a = self._read_xml(mesh, dim_or_file, dt)
+        else:
+            self._dim = int(dim_or_file)
+            self._a = np.zeros(mesh.num_entities(self._dim), dtype=dt)
+            if value is not None:
+                self._a[:] = value
+
+    @staticmethod
+    def _read_xml(mesh, path, dt):
+        text = open(path, "r").read()
+        m = _MF_RE.search(text)
+        if m:  # old style: entity index = lexicographic facet/cell index
+            dim, size = int(m.group(2)), int(m.group(3))
+            if size != mesh.num_entities(dim):
+                raise SolverError("{}: {} entities of dim {} but the mesh has {}".format(
+                    path, size, dim, mesh.num_entities(dim)))
+            a = np.zeros(size, dtype=dt)
+            for idx, v in _ENT_RE.findall(text):
+                a[int(idx)] = int(v)
+            return dim, a
+        vals = _MVC_RE.findall(text)
+        if vals:  # mesh_value_collection: (cell, local entity) pairs
+            dm = re.search(r'<mesh_value_collection[^>]*dim="(\d+)"', text)
+            dim = int(dm.group(1))
+            a = np.zeros(mesh.num_entities(dim), dtype=dt)
+            cf = mesh.cell_facets()
+            for c, le, v in vals:
+                if dim == 2:
+                    a[cf[int(c), int(le)]] = int(v)
+                elif dim == 3:
+                    a[int(c)] = int(v)
+            return dim, a
+        raise SolverError("{}: unknown DOLFIN-XML mesh function format".format(path))
+
+    def dim(self):
+        return self._dim
+
+    def mesh(self):
+        return self._mesh
+
+    def array(self):
+        return self._a
+
+    def set_all(self, v):
+        self._a[:] = v
+
+    def size(self):
+        return self._a.size
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+    def __setitem__(self, i, v):
+        self._a[i] = v
+
+
+class SubDomain:
+    """dolfin.SubDomain: override ``inside(x, on_boundary)``; ``mark(mf, id)``
+    marks facets (or cells) whose vertices AND midpoint are all inside."""
+
+    def inside(self, x, on_boundary):  # pragma: no cover - user supplied
+        raise NotImplementedError
+
+    def _inside_points(self, pts, on_boundary):
+        """Vectorised where the user's predicate allows it, per-point otherwise."""
+        ob = np.broadcast_to(np.asarray(on_boundary, dtype=bool), (pts.shape[0],))
+        try:
+            r = self.inside(pts.T, ob)
+            r = np.asarray(r)
+            if r.shape == (pts.shape[0],) and r.dtype == bool:
+                return r
+        except Exception:
+            pass
+        return np.fromiter((bool(self.inside(pts[i], bool(ob[i]))) for i in range(pts.shape[0])),
+                           dtype=bool, count=pts.shape[0])
+
+    def mark(self, mesh_function, marker_id):
+        mesh = mesh_function.mesh()
+        dim = mesh_function.dim()
+        co = mesh.coordinates()
+        if dim == 2:
+            ent = mesh.facets().astype(np.int64)
+            on_b = mesh.exterior_facets()
+        elif dim == 3:
+            ent = mesh.cells().astype(np.int64)
+            on_b = np.zeros(len(ent), dtype=bool)
+        else:
+            raise SolverError("SubDomain.mark: only facet (dim 2) and cell (dim 3) functions are supported")
+        vert_on_b = np.zeros(mesh.num_vertices(), dtype=bool)
+        vert_on_b[mesh.facets()[mesh.exterior_facets()].ravel()] = True
+        vin = self._inside_points(co, vert_on_b)
+        cand = np.nonzero(vin[ent].all(axis=1))[0]
+        if cand.size:
+            mid = co[ent[cand]].mean(axis=1)
+            ok = self._inside_points(mid, on_b[cand])
+            mesh_function.array()[cand[ok]] = marker_id
+
+
+class AutoSubDomain(SubDomain):
+    """dolfin.AutoSubDomain(lambda x[, on_boundary]: ...) (examples/test_heat_transfer.py:42-45)."""
+
+    def __init__(self, fn):
+        self._fn = fn
+        try:
+            self._nargs = fn.__code__.co_argcount
+        except AttributeError:
+            self._nargs = 2
+
+    def inside(self, x, on_boundary):
+        return self._fn(x) if self._nargs == 1 else self._fn(x, on_boundary)
+
+
+# --------------------------------------------------------------------------------------------
+# coefficients
+# --------------------------------------------------------------------------------------------
+class Constant:
+    def __init__(self, value):
+        self._v = np.asarray(value, dtype=np.float64)
+
+    def values(self):
+        return np.atleast_1d(self._v)
+
+    def ufl_shape(self):
+        return self._v.shape
+
+    def value_size(self):
+        return int(self._v.size)
+
+    def __float__(self):
+        return float(self._v)
+
+    def __call__(self, *x):
+        return self._v if self._v.ndim else float(self._v)
+
+
+_ALLOWED = {
+    "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log, "sqrt": np.sqrt,
+    "pow": np.power, "fabs": np.abs, "abs": np.abs, "atan": np.arctan, "atan2": np.arctan2,
+    "asin": np.arcsin, "acos": np.arccos, "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh,
+    "floor": np.floor, "ceil": np.ceil, "fmin": np.minimum, "fmax": np.maximum,
+    "pi": math.pi, "DOLFIN_PI": math.pi, "DOLFIN_EPS": DOLFIN_EPS, "M_PI": math.pi,
+}
+
+
+def _compile_cexpr(code):
+    """C-syntax scalar expression in x[0..2] (dolfin.Expression string) -> python code object."""
+    if not isinstance(code, str):
+        code = repr(float(code))
+    src = re.sub(r"x\s*\[\s*(\d)\s*\]", r"x\1", code)
+    src = src.replace("&&", " and ").replace("||", " or ")
+    if "?" in src:
+        raise SolverError("Expression '{}': the C ternary operator is not supported".format(code))
+    try:
+        return compile(src, "<Expression>", "eval")
+    except SyntaxError as e:
+        raise SolverError("Expression '{}' cannot be parsed: {}".format(code, e))
+
+
+class Expression:
+    """dolfin.Expression("C++ string" | tuple of strings, degree=.., **params)
+    (SolverBase.py:310-314, 364, 387; examples/test_linear_elasticity.py:68)."""
+
+    def __init__(self, code, degree=1, **params):
+        self._code = code
+        self.degree = degree
+        self.params = dict(params)
+        if isinstance(code, (tuple, list)):
+            if len(code) and isinstance(code[0], (tuple, list)):
+                self._shape = (len(code), len(code[0]))
+                flat = [c for row in code for c in row]
+            else:
+                self._shape = (len(code),)
+                flat = list(code)
+        else:
+            self._shape = ()
+            flat = [code]
+        self._objs = [_compile_cexpr(c) for c in flat]
+
+    def __setattr__(self, k, v):  # user parameters may be updated like dolfin: expr.t = ...
+        if not k.startswith("_") and k not in ("degree", "params") and hasattr(self, "params"):
+            self.params[k] = v
+        object.__setattr__(self, k, v)
+
+    def ufl_shape(self):
+        return self._shape
+
+    def value_size(self):
+        return int(np.prod(self._shape)) if self._shape else 1
+
+    def eval_points(self, pts):
+        """pts[n,3] -> values[n] (scalar) or [n, size]."""
+        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+        env = dict(_ALLOWED)
+        env.update(self.params)
+        env.update(x0=pts[:, 0], x1=pts[:, 1], x2=pts[:, 2])
+        cols = []
+        for o in self._objs:
+            try:
+                v = eval(o, {"__builtins__": {}}, env)
+            except NameError as e:
+                raise SolverError("Expression {}: {}".format(self._code, e))
+            cols.append(np.broadcast_to(np.asarray(v, dtype=np.float64), (pts.shape[0],)))
+        out = np.stack(cols, axis=1)
+        return out[:, 0] if not self._shape else out
+
+    def __call__(self, *x):
+        p = np.zeros(3)
+        xs = x[0] if len(x) == 1 and hasattr(x[0], "__len__") else x
+        p[: len(xs)] = xs
+        r = self.eval_points(p[None, :])
+        return r[0]
+
+
+# --------------------------------------------------------------------------------------------
+# function spaces / functions
+# --------------------------------------------------------------------------------------------
+class _Element:
+    def __init__(self, family, degree, ncomp):
+        self._f, self._d, self._n = family, degree, ncomp
+
+    def degree(self):
+        return self._d
+
+    def family(self):
+        return self._f
+
+    def value_size(self):
+        return self._n
+
+
+class FunctionSpace:
+    """dolfin.FunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
+    Only continuous P1 is built in this revision; the dof of vertex v (component i of an
+    ncomp-vector space) is v*ncomp + i."""
+
+    def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
+                 _parent=None):
+        if family not in ("CG", "P", "Lagrange"):
+            raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
+        if int(degree) != 1:
+            raise SolverError("fe_degree {} is not built yet in fenicssolver_amd (P1 only)".format(degree))
+        if constrained_domain is not None:
+            raise SolverError("periodic_boundary (constrained_domain) is not supported")
+        self._mesh = mesh
+        self._ufl_element = _Element("Lagrange", int(degree), _ncomp)
+        self._ncomp = _ncomp
+        self._component = _component
+        self._parent = _parent
+        self._device = None
+
+    def mesh(self):
+        return self._mesh
+
+    def ufl_element(self):
+        return self._ufl_element
+
+    def dim(self):
+        return self._mesh.num_vertices() * self._ncomp
+
+    def num_sub_spaces(self):
+        return self._ncomp if self._ncomp > 1 else 0
+
+    def sub(self, i):
+        if self._ncomp == 1:
+            raise SolverError("sub(): not a vector space")
+        return FunctionSpace(self._mesh, "CG", 1, _ncomp=self._ncomp, _component=int(i), _parent=self)
+
+    def component(self):
+        return self._component
+
+    def root(self):
+        return self._parent if self._parent is not None else self
+
+    def tabulate_dof_coordinates(self):
+        return np.repeat(self._mesh.coordinates(), self._ncomp, axis=0)
+
+    def device(self):
+        """Device space (sparsity + SELL slot table), built once per space."""
+        root = self.root()
+        if root._device is None:
+            from . import backend
+            root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, 1)
+        return root._device
+
+
+def VectorFunctionSpace(mesh, family="CG", degree=1, dim=None, constrained_domain=None):
+    return FunctionSpace(mesh, family, degree, constrained_domain, _ncomp=dim or mesh.geometry().dim())
+
+
+class _Vector:
+    """Minimal GenericVector: numpy storage with the calls the reference's users make."""
+
+    def __init__(self, n):
+        self._a = np.zeros(n)
+
+    def get_local(self):
+        return self._a.copy()
+
+    def set_local(self, v):
+        self._a[:] = v
+
+    def array(self):
+        return self._a
+
+    def copy(self):
+        v = _Vector(self._a.size)
+        v._a[:] = self._a
+        return v
+
+    def size(self):
+        return self._a.size
+
+    def norm(self, kind="l2"):
+        return float(np.linalg.norm(self._a, {"l2": 2, "linf": np.inf, "l1": 1}[kind]))
+
+    def apply(self, mode):
+        pass
+
+    def __len__(self):
+        return self._a.size
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+    def __setitem__(self, i, v):
+        self._a[i] = v
+
+
+class Function:
+    """dolfin.Function(V) (SolverBase.py:472-475)."""
+
+    def __init__(self, V, other=None):
+        if isinstance(V, Function):  # copy constructor Function(u)
+            other, V = V, V.function_space()
+        self._V = V
+        self._vec = _Vector(V.dim())
+        self._name = "f"
+        if isinstance(other, Function):
+            self._vec.set_local(other._vec.array())
+
+    def function_space(self):
+        return self._V
+
+    def vector(self):
+        return self._vec
+
+    def assign(self, other):
+        if isinstance(other, Function):
+            self._vec.set_local(other._vec.array())
+        elif isinstance(other, Constant):
+            self._vec.array().reshape(-1, self._V._ncomp)[:] = other.values()
+        else:
+            raise SolverError("Function.assign: unsupported source {}".format(type(other)))
+
+    def rename(self, name, label):
+        self._name = name
+
+    def name(self):
+        return self._name
+
+    def copy(self, deepcopy=True):
+        return Function(self._V, self)
+
+    def compute_vertex_values(self, mesh=None):
+        """dolfin layout: component-major [ncomp * num_vertices]."""
+        n = self._V._ncomp
+        a = self._vec.array()
+        return a.copy() if n == 1 else a.reshape(-1, n).T.ravel().copy()
+
+    def vertex_values(self):
+        """[num_vertices] (scalar) or [num_vertices, ncomp] view of the P1 dofs."""
+        n = self._V._ncomp
+        return self._vec.array() if n == 1 else self._vec.array().reshape(-1, n)
+
+    def ufl_shape(self):
+        return () if self._V._ncomp == 1 else (self._V._ncomp,)
+
+    def __call__(self, *x):
+        """Point evaluation by brute-force cell search (small meshes / post-processing only)."""
+        p = np.zeros(3)
+        xs = x[0] if len(x) == 1 and hasattr(x[0], "__len__") else x
+        if isinstance(xs, Point):
+            xs = xs.array()
+        p[: len(xs)] = xs
+        mesh = self._V.mesh()
+        co, ce = mesh.coordinates(), mesh.cells().astype(np.int64)
+        c = co[ce]
+        T = np.stack([c[:, 1] - c[:, 0], c[:, 2] - c[:, 0], c[:, 3] - c[:, 0]], axis=2)
+        lam = np.linalg.solve(T, (p - c[:, 0])[:, :, None])[:, :, 0]
+        l0 = 1.0 - lam.sum(axis=1)
+        bary = np.concatenate([l0[:, None], lam], axis=1)
+        i = int(np.argmax(bary.min(axis=1)))
+        if bary[i].min() < -1e-10:
+            raise SolverError("point {} is outside the mesh".format(p))
+        vals = self.vertex_values()[ce[i]]
+        return bary[i] @ vals
+
+
+def interpolate(v, V):
+    """dolfin.interpolate(Expression|Constant|Function, V) for P1: nodal evaluation."""
+    f = Function(V)
+    co = V.mesh().coordinates()
+    n = V._ncomp
+    if isinstance(v, Expression):
+        vals = v.eval_points(co)
+    elif isinstance(v, Constant):
+        vals = np.broadcast_to(v.values() if n > 1 else float(v), (co.shape[0], n) if n > 1 else (co.shape[0],))
+    elif isinstance(v, Function):
+        vals = v.vertex_values()
+    elif isinstance(v, numbers.Number):
+        vals = np.full(co.shape[0], float(v))
+    else:
+        raise SolverError("interpolate: unsupported source {}".format(type(v)))
+    vals = np.asarray(vals, dtype=np.float64)
+    if n > 1 and vals.shape != (co.shape[0], n):
+        raise SolverError("interpolate: value shape {} does not match a {}-vector space".format(vals.shape, n))
+    f.vector().set_local(vals.reshape(-1))
+    return f
+
+
+def project(v, V):
+    """For the P1 sources used here projection == interpolation of nodal data."""
+    return interpolate(v, V)
+
+
+def nodal_values(value, V):
+    """Values of a coefficient at the vertices: number/Constant/Expression/Function -> array."""
+    co = V.mesh().coordinates()
+    if isinstance(value, numbers.Number):
+        return np.full(co.shape[0], float(value))
+    if isinstance(value, Constant):
+        v = value.values()
+        return np.full(co.shape[0], float(v[0])) if v.size == 1 else np.broadcast_to(v, (co.shape[0], v.size)).copy()
+    if isinstance(value, Expression):
+        return value.eval_points(co)
+    if isinstance(value, Function):
+        return value.vertex_values()
+    raise SolverError("cannot evaluate {} at the mesh vertices".format(type(value)))
+
+
+def is_constant_value(value):
+    return isinstance(value, (numbers.Number, Constant))
+
+
+class DirichletBC:
+    """dolfin.DirichletBC(V | V.sub(i), value, facet_markers, id) — topological
+    (ScalarTransportSolver.py:169-175; LinearElasticitySolver.py:125-133)."""
+
+    def __init__(self, V, value, markers, marker_id):
+        self.function_space = V
+        self.value = value
+        self.marker_id = marker_id
+        mesh = V.mesh()
+        if isinstance(markers, MeshFunction):
+            if markers.dim() != 2:
+                raise SolverError("DirichletBC needs a facet MeshFunction")
+            sel = np.nonzero(markers.array() == marker_id)[0]
+        else:
+            raise SolverError("DirichletBC: markers must be a MeshFunction")
+        verts = np.unique(mesh.facets()[sel].ravel()).astype(np.int64)
+        n = V._ncomp
+        comp = V.component()
+        co = mesh.coordinates()[verts]
+        if n == 1:
+            self.dofs = verts.astype(np.int32)
+            self.values = self._eval(value, co, 1).reshape(-1)
+        elif comp is not None:
+            self.dofs = (verts * n + comp).astype(np.int32)
+            self.values = self._eval(value, co, 1).reshape(-1)
+        else:
+            self.dofs = (verts[:, None] * n + np.arange(n)[None, :]).ravel().astype(np.int32)
+            self.values = self._eval(value, co, n).reshape(-1)
+
+    @staticmethod
+    def _eval(value, pts, size):
+        if isinstance(value, numbers.Number):
+            v = np.full((pts.shape[0], 1), float(value))
+        elif isinstance(value, Constant):
+            v = np.broadcast_to(value.values().reshape(1, -1), (pts.shape[0], value.value_size())).copy()
+        elif isinstance(value, Expression):
+            v = value.eval_points(pts).reshape(pts.shape[0], -1)
+        elif isinstance(value, (tuple, list, np.ndarray)):
+            v = np.broadcast_to(np.asarray(value, dtype=np.float64).reshape(1, -1), (pts.shape[0], len(value))).copy()
+        else:
+            raise SolverError("DirichletBC value of type {} is not supported".format(type(value)))
+        if v.shape[1] != size:
+            raise SolverError("DirichletBC value has {} components, the (sub)space has {}".format(v.shape[1], size))
+        return v
+
+    def get_boundary_values(self):
+        return dict(zip(self.dofs.tolist(), self.values.tolist()))

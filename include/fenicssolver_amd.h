@@ -53,6 +53,9 @@ int fs_device_count(int* count);
 int fs_device_synchronize(void);
 const char* fs_last_error(void);
 const char* fs_version(void);
+/* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
+ * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll). */
+int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
 int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
 
@@ -213,8 +216,9 @@ int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov
 /* ||r_k||_2^2 history of the last solve, k = 0..iterations. */
 int fs_krylov_history(double* out, int capacity, int* count);
 
-/* Time `reps` back-to-back launches of the bare SpMV kernel with HIP events on
- * the library's stream; returns mean milliseconds per launch. */
+/* Time |reps| back-to-back launches of the SpMV kernel with HIP events on the
+ * library's stream; returns mean milliseconds per launch.  reps > 0: bare y = A x;
+ * reps < 0: the CG flavour fused with the three dot products (y plays r). */
 int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch);
 
 /* ---- multi-GPU (MPI inside PETSc/DOLFIN under mpirun; SolverBase.py:102-118, 634) */
