@@ -34,6 +34,8 @@ def load():
         _lib.orc_heat_box_solve.argtypes = [C.c_int64, C.c_int64, C.c_int64, _f64p, C.c_double, C.c_int, C.c_double,
                                             C.c_double, C.c_double, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64)]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        _lib.orc_set_num_threads(usable_cores())
         _lib.orc_csr_pattern.restype = C.c_int64
         _lib.orc_csr_pattern.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, C.POINTER(_i32p)]
         _lib.orc_free.argtypes = [C.c_void_p]
@@ -42,6 +44,31 @@ def load():
         _lib.orc_pcg_jacobi.restype = C.c_int
         _lib.orc_pcg_jacobi.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int, _f64p]
     return _lib
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU
+    quota (a 256-thread box with a 16-CPU quota must run 16 OpenMP threads, not 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(-(-int(quota) // int(period)))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, -(-q // p)))
+    except Exception:
+        pass
+    return n
+
+
+def set_num_threads(n):
+    load().orc_set_num_threads(int(n))
 
 
 def num_threads():

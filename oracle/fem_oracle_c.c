@@ -38,6 +38,14 @@ int orc_num_threads(void) {
 #endif
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* dolfin.BoxMesh ordering, see fem_oracle.box_mesh */
 void orc_box_mesh(int64_t nx, int64_t ny, int64_t nz, const double* p0, const double* p1, double* xyz,
                   int32_t* cells) {

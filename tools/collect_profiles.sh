@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): kernel-trace stats of the default bench command and
+# separate PMC passes (FETCH_SIZE / WRITE_SIZE never share a pass: TCC has 4 slots, they need 3+2).
+# Outputs land in gpurun_out/; tools/summarize_profiles.py condenses them into profiles/.
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+BENCH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
+tail -2 $OUT/stats.log
+for C in FETCH_SIZE WRITE_SIZE; do
+  echo "== pmc $C"; rocprofv3 --pmc $C -d $OUT/pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  tail -1 $OUT/pmc_$C.log
+done
+find $OUT -type f | head -40
+du -sh $OUT

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 rocpd databases written by tools/collect_profiles.sh
+(gpurun_out/prof/...) into the small tracked summaries under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   per (phase, kernel): calls, total/avg/min/max us, % of GPU time
+  profiles/<tag>_pmc_raw.json       per-launch FETCH_SIZE / WRITE_SIZE of the hot kernels as reported
+                                    (the gfx950 correction of the read side is applied in
+                                    profiles/<tag>_pmc.json, see profiles/README.md)
+
+The default bench command runs two problem sizes back to back; dispatches are attributed to a
+phase by time: before / after the second sparsity build (second k_pair_keys dispatch).
+"""
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+PHASES = ("n99_1M_dof", "n215_10M_dof")
+HOT = ("k_sell_spmv", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    if "rocprim" in name:
+        m = re.search(r"detail::(radix_sort_\w+|partition_impl|scan_\w+|lookback_scan\w*|init_\w+|\w+_kernel)", name)
+        return "rocprim::" + (m.group(1) if m else "kernel")
+    return name.split("(")[0]
+
+
+def phase_split(cur, table, name_col, start_col):
+    rows = cur.execute("select %s from %s where %s like 'k_pair_keys%%' order by %s"
+                       % (start_col, table, name_col, start_col)).fetchall()
+    return rows[1][0] if len(rows) > 1 else None
+
+
+def kernel_stats():
+    db = sqlite3.connect(os.path.join(SRC, "stats", "bench_results.db"))
+    cur = db.cursor()
+    split = phase_split(cur, "kernels", "name", "start")
+    agg = {}
+    for name, start, dur in cur.execute("select name, start, duration from kernels"):
+        ph = PHASES[0] if split is None or start < split else PHASES[1]
+        a = agg.setdefault((ph, short(name)), [0, 0.0, 1e30, 0.0, []])
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+        a[4].append(dur)
+    total = sum(a[1] for a in agg.values())
+    out = os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv")
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        # live_* exclude the no-op launches of a CG batch enqueued after convergence (< 10 % of the max)
+        w.writerow(["phase", "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct_of_gpu_time",
+                    "live_calls", "live_avg_us"])
+        for (ph, k), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            live = [d for d in a[4] if d >= 0.1 * a[3]]
+            w.writerow([ph, k, a[0], "%.1f" % (a[1] / 1e3), "%.3f" % (a[1] / a[0] / 1e3), "%.3f" % (a[2] / 1e3),
+                        "%.3f" % (a[3] / 1e3), "%.2f" % (100 * a[1] / total), len(live),
+                        "%.3f" % (sum(live) / len(live) / 1e3)])
+    print("wrote", out)
+
+
+def pmc(counter):
+    """Mean counter value per launch and phase.  Launches enqueued after CG converged are no-ops
+    (they return on the status word); they are dropped by discarding values < 1% of the maximum."""
+    db = sqlite3.connect(os.path.join(SRC, "pmc_" + counter, "bench_results.db"))
+    cur = db.cursor()
+    split = phase_split(cur, "counters_collection", "kernel_name", "start")
+    vals = {}
+    for name, start, val in cur.execute(
+            "select kernel_name, start, value from counters_collection where counter_name=?", (counter,)):
+        ph = PHASES[0] if split is None or start < split else PHASES[1]
+        vals.setdefault((ph, short(name)), []).append(val)
+    mean, cnt = {}, {}
+    for k, v in vals.items():
+        top = max(v)
+        live = [x for x in v if x >= 0.01 * top] if top > 0 else v
+        mean[k] = sum(live) / len(live)
+        cnt[k] = len(live)
+    return mean, cnt
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    kernel_stats()
+    fetch, nf = pmc("FETCH_SIZE")
+    write, _ = pmc("WRITE_SIZE")
+    raw = {"_doc": "per-launch means over live launches; FETCH_SIZE/WRITE_SIZE are KiB as reported by rocprofv3 "
+                   "(separate --pmc passes, no other trace domain)", "kernels": {}}
+    for key in sorted(fetch):
+        ph, k = key
+        if not k.startswith(HOT):
+            continue
+        raw["kernels"]["%s/%s" % (ph, k)] = {"launches": nf[key], "FETCH_SIZE_KiB": round(fetch[key], 1),
+                                              "WRITE_SIZE_KiB": round(write.get(key, 0.0), 1)}
+    json.dump(raw, open(os.path.join(ROOT, "profiles", TAG + "_pmc_raw.json"), "w"), indent=1)
+    # gfx950 correction (guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B.
+    # Calibrated in THIS run on kernels of known byte count (see profiles/README.md): reads x2, writes x1.
+    n_dof = {PHASES[0]: 100 ** 3, PHASES[1]: 216 ** 3}
+    cal = {}
+    for ph in PHASES:
+        n = n_dof[ph]
+        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_cg_update", 56 * n)):
+            if (ph, k) in fetch:
+                cal["%s/%s" % (ph, k)] = {"expected_read_bytes": expect,
+                                          "FETCH_SIZE_bytes": int(fetch[(ph, k)] * 1024),
+                                          "ratio": round(fetch[(ph, k)] * 1024 / expect, 4)}
+        if (ph, "k_cg_update") in write:
+            cal["%s/k_cg_update(write)" % ph] = {"expected_write_bytes": 40 * n,
+                                                "WRITE_SIZE_bytes": int(write[(ph, "k_cg_update")] * 1024),
+                                                "ratio": round(write[(ph, "k_cg_update")] * 1024 / (40 * n), 4)}
+    out = {"_doc": "HBM-side bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                   "(read side doubled per the gfx950 rule, confirmed by the calibration block). "
+                   "bench.py reports these as roofline.traffic.",
+           "calibration": cal}
+    for ph, tag in ((PHASES[0], "spmv_fused_n99"), (PHASES[1], "spmv_fused_n215")):
+        key = (ph, "k_sell_spmv<1, true, 4>")
+        if key in fetch:
+            out[tag] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+        key = (ph, "k_sell_spmv<1, false, 4>")
+        if key in fetch:
+            out[tag.replace("fused", "bare")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+        key = (ph, "k_assemble_p1_scalar")
+        if key in fetch:
+            out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+    json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
