@@ -1,0 +1,255 @@
+"""LinearElasticitySolver — small-strain isotropic elasticity on vector P1, GPU back end.
+
+Counterpart of FenicsSolver/LinearElasticitySolver.py: same class/constructor (forces
+vector_name='displacement', :55-60), sigma(u) = 2 mu sym(grad u) + lambda div(u) I
+(:62-69), boundary types displacement/Dirichlet (per-component with None = free,
+:122-131), force / pressure / stress (:165-196), body force (:227-228), thermal stress
+(:78-85, 231-238); 3D problems go through solve_amg (CG), as in the reference (:247-253).
+
+Reference quirk kept by default (Appendix B-Q3): body forces and tractions are ADDED to
+F (:227-228, 242-243), so they act with reversed sign; set
+``solver.reference_load_sign = False`` for the physical convention.  The thermal term has
+the conventional sign in both.  Modal analysis (:270-312, SLEPc) is out of scope.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+
+from .fem import Constant, Expression, Function, DirichletBC, nodal_values, is_constant_value
+from .SolverBase import SolverBase, SolverError
+from . import forms
+
+
+class LinearElasticitySolver(SolverBase):
+    def __init__(self, case_settings):
+        case_settings['vector_name'] = 'displacement'
+        SolverBase.__init__(self, case_settings)
+        self.solving_modal = False
+        self.solving_dynamics = False
+        self.reference_load_sign = True
+
+    def lame_parameters(self):
+        elasticity = self.material['elastic_modulus']
+        nu = self.material['poisson_ratio']
+        if not (isinstance(elasticity, numbers.Number) and isinstance(nu, numbers.Number)):
+            raise SolverError('elastic_modulus and poisson_ratio must be numbers (homogeneous material)')
+        mu = elasticity / (2.0 * (1.0 + nu))
+        lmbda = elasticity * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+        return mu, lmbda
+
+    def _cell_gradients(self, u):
+        """grad u per cell [nc,3,3] (component i, derivative j) of a P1 displacement."""
+        co = self.mesh.coordinates()
+        ce = self.mesh.cells().astype(np.int64)
+        X = co[ce]
+        J = np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2)
+        Ji = np.linalg.inv(J)
+        g = np.zeros((len(ce), 4, 3))
+        g[:, 1:, :] = Ji
+        g[:, 0, :] = -Ji.sum(axis=1)
+        U = u.vertex_values()[ce]                       # [nc,4,3]
+        return np.einsum("cai,caj->cij", U, g)
+
+    def sigma(self, u):
+        """Cell-wise (DG0) stress tensor [nc,3,3] of a displacement Function."""
+        mu, lmbda = self.lame_parameters()
+        G = self._cell_gradients(u)
+        eps = 0.5 * (G + np.transpose(G, (0, 2, 1)))
+        tr = np.trace(G, axis1=1, axis2=2)
+        return 2.0 * mu * eps + lmbda * tr[:, None, None] * np.eye(3)[None]
+
+    def von_Mises(self, u):
+        """project(sqrt(3/2 s:s), P1) (:71-76) with a lumped mass matrix: volume-weighted vertex average."""
+        from .fem import FunctionSpace
+        s = self.sigma(u)
+        dev = s - np.trace(s, axis1=1, axis2=2)[:, None, None] / 3.0 * np.eye(3)[None]
+        vm = np.sqrt(1.5 * np.einsum("cij,cij->c", dev, dev))
+        co = self.mesh.coordinates()
+        ce = self.mesh.cells().astype(np.int64)
+        X = co[ce]
+        vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))) / 6.0
+        num = np.zeros(len(co))
+        den = np.zeros(len(co))
+        np.add.at(num, ce.ravel(), np.repeat(vm * vol, 4))
+        np.add.at(den, ce.ravel(), np.repeat(vol, 4))
+        f = Function(FunctionSpace(self.mesh, 'P', 1))
+        f.vector().set_local(num / den)
+        return f
+
+    def thermal_stress_coefficient(self):
+        elasticity = self.material['elastic_modulus']
+        nu = self.material['poisson_ratio']
+        tec = self.material['thermal_expansion_coefficient']
+        return elasticity / (1.0 - 2.0 * nu) * tec
+
+    def get_flux(self, u, mag_vector):
+        return mag_vector
+
+    # ------------------------------------------------------------------ boundary conditions
+    def _facet_normals(self, marker_id):
+        """Outward unit normals and areas of the facets carrying marker_id."""
+        mesh = self.mesh
+        sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+        tri = mesh.facets()[sel].astype(np.int64)
+        co = mesh.coordinates()
+        p = co[tri]
+        n = 0.5 * np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+        area = np.linalg.norm(n, axis=1)
+        # orient away from the interior: use the centroid of the (single) adjacent cell
+        cf = mesh.cell_facets()
+        cells = mesh.cells().astype(np.int64)
+        owner = np.full(mesh.num_facets(), -1, dtype=np.int64)
+        owner[cf.ravel()] = np.repeat(np.arange(len(cells)), 4)
+        cc = co[cells[owner[sel]]].mean(axis=1)
+        flip = np.einsum("fi,fi->f", n, p.mean(axis=1) - cc) < 0
+        n[flip] *= -1.0
+        return tri, n / area[:, None], area
+
+    def _vector_of(self, value, what):
+        if isinstance(value, Constant):
+            v = value.values()
+        elif isinstance(value, (tuple, list, np.ndarray)):
+            v = np.asarray(value, dtype=np.float64)
+        else:
+            raise SolverError('{}: a constant vector is required, got {}'.format(what, type(value)))
+        if v.size != self.dimension:
+            raise SolverError('{}: vector of size {} in a {}D problem'.format(what, v.size, self.dimension))
+        return v
+
+    def update_boundary_conditions(self, time_iter_, u, v, ds):
+        V = self.function_space
+        bcs = []
+        integrals_N = []
+        if 'point_source' in self.settings and self.settings['point_source']:
+            raise SolverError('point_source is not supported')
+        if 'surface_source' in self.settings and self.settings['surface_source']:
+            raise SolverError('surface_source is not supported')
+
+        for name, bc_settings in self.boundary_conditions.items():
+            i = bc_settings['boundary_id']
+            bc = self.get_boundary_variable(bc_settings)
+            btype = bc['type']
+            if btype == 'Dirichlet' or btype == 'displacement':
+                bv = bc['value']
+                if isinstance(bv, (tuple, list)) and len(bv) == self.dimension and \
+                        any(c is None or isinstance(c, (Constant, Expression, str)) for c in bv):
+                    for axis_i, disp in enumerate(bv):
+                        if disp is not None:   # None = free; zero is a constraint
+                            val = self.translate_value(disp)
+                            bcs.append(DirichletBC(V.sub(axis_i), val, self.boundary_facets, i))
+                else:
+                    bcs.append(DirichletBC(V, self.translate_value(bv), self.boundary_facets, i))
+            elif btype == 'force':
+                val = bc['value']
+                if isinstance(val, (tuple, list, Constant)) and np.size(self._try_values(val)) == self.dimension:
+                    # the reference applies a vector-valued 'force' as a traction density (:166-167)
+                    g = self._vector_of(val, name)
+                    integrals_N.append(forms.FacetLoad(i, g, 'force(vector)'))
+                else:
+                    bc_force = self.translate_value(val)
+                    if not is_constant_value(bc_force):
+                        raise SolverError("boundary '{}': force magnitude must be a constant".format(name))
+                    tri, nrm, area = self._facet_normals(i)
+                    bc_area = float(area.sum())     # assemble(Constant(1)*ds(id)) (:171)
+                    self.logger.info('boundary area (m2) for force boundary is %g', bc_area)
+                    gmag = float(bc_force) / bc_area
+                    if 'direction' in bc and bc['direction']:
+                        integrals_N.append(forms.FacetLoad(i, self._vector_of(bc['direction'], name) * gmag,
+                                                           'force(direction)'))
+                    else:
+                        integrals_N.append(forms.FacetLoad(i, nrm * gmag, 'force(normal)'))
+            elif btype == 'pressure':
+                pval = self.translate_value(bc['value'])
+                if not is_constant_value(pval):
+                    raise SolverError("boundary '{}': pressure must be a constant".format(name))
+                if 'direction' in bc and bc['direction']:
+                    integrals_N.append(forms.FacetLoad(i, self._vector_of(bc['direction'], name) * float(pval),
+                                                       'pressure(direction)'))
+                else:
+                    tri, nrm, area = self._facet_normals(i)
+                    integrals_N.append(forms.FacetLoad(i, nrm * float(pval), 'pressure(normal)'))
+            elif btype == 'stress':
+                g = self.translate_value(bc['value'])
+                if isinstance(g, Constant) and g.value_size() == self.dimension:
+                    integrals_N.append(forms.FacetLoad(i, g.values(), 'stress(vector)'))
+                elif isinstance(g, Constant) and g.value_size() == self.dimension ** 2:
+                    tri, nrm, area = self._facet_normals(i)
+                    integrals_N.append(forms.FacetLoad(i, nrm @ g.values().reshape(3, 3).T, 'stress(tensor.n)'))
+                else:
+                    raise SolverError("boundary '{}': stress must be a constant vector or tensor".format(name))
+            elif btype == 'Neumann':
+                raise SolverError('Neumann boundary type`{}` is not supported'.format(btype))
+            elif btype == 'symmetry':
+                raise SolverError('symmetry boundary type`{}` is not supported'.format(btype))
+            else:
+                raise SolverError('boundary type`{}` is not supported'.format(btype))
+        return bcs, integrals_N
+
+    @staticmethod
+    def _try_values(val):
+        if isinstance(val, Constant):
+            return val.values()
+        try:
+            return np.asarray(val, dtype=np.float64)
+        except (TypeError, ValueError):
+            return np.zeros(0)
+
+    # ------------------------------------------------------------------ the form
+    def generate_form(self, time_iter_, u, v, u_current, u_prev):
+        if self.transient_settings['transient'] and self.solving_dynamics:
+            raise SolverError('elastodynamics (acceleration term) is not built yet')
+        F = forms.ElasticityForm(self.function_space)
+        F.mu, F.lmbda = self.lame_parameters()
+        F.load_sign = -1.0 if self.reference_load_sign else 1.0
+
+        bcs, integrals_F = self.update_boundary_conditions(time_iter_, u, v, None)
+        F.tractions.extend(integrals_F)
+
+        if self.body_source:
+            bs = self.body_source
+            if isinstance(bs, Expression):
+                vals = bs.eval_points(self.mesh.coordinates()[:1])   # constant body force expected
+                allv = bs.eval_points(self.mesh.coordinates())
+                if np.abs(allv - vals).max() > 1e-12 * max(1.0, np.abs(allv).max()):
+                    raise SolverError('body_source must be constant in space on the GPU back end')
+                F.body_force = tuple(float(x) for x in vals[0])
+            else:
+                F.body_force = tuple(float(x) for x in self._vector_of(bs, 'body_source'))
+
+        if not hasattr(self, 'temperature_distribution'):
+            if 'temperature_distribution' in self.settings and self.settings['temperature_distribution']:
+                self.temperature_distribution = self.translate_value(self.settings['temperature_distribution'])
+        if hasattr(self, 'temperature_distribution') and self.temperature_distribution:
+            T = self.temperature_distribution
+            T_ref = float(self.reference_values['temperature'])
+            if is_constant_value(T):
+                Tval = float(T)
+            else:
+                from .fem import FunctionSpace
+                nod = nodal_values(T, FunctionSpace(self.mesh, 'P', 1))
+                Tval = float(nod[0]) if np.ptp(nod) == 0.0 else nod
+            F.thermal = (self.thermal_stress_coefficient(), Tval, T_ref)
+        return F, bcs
+
+    def solve_form(self, F, u_, bcs):
+        if self.dimension == 3:
+            u_ = self.solve_amg(F, u_, bcs)
+        else:
+            u_ = self.solve_linear_problem(F, u_, bcs)
+        return u_
+
+    def displacement(self):
+        if self.is_mixed_function_space:
+            raise SolverError('subclass with mixed_function_space must override this function')
+        return self.w_current
+
+    def velocity(self):
+        dt = self.get_time_step(self.current_step)
+        out = Function(self.function_space)
+        out.vector().set_local((self.w_current.vector().array() - self.w_prev.vector().array()) / dt)
+        return out
+
+    def solve_modal(self):
+        raise SolverError('modal analysis (SLEPc) is out of scope of the GPU back end')

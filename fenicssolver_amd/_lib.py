@@ -40,7 +40,7 @@ class fs_bilinear_form(C.Structure):
 
 
 class fs_linear_form(C.Structure):
-    _fields_ = [("source", fs_coef), ("vector_value", C.c_double * 3)]
+    _fields_ = [("source", fs_coef), ("vector_value", C.c_double * 3), ("div_coef", fs_coef)]
 
 
 class fs_krylov_opts(C.Structure):

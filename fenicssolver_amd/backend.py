@@ -236,10 +236,12 @@ class DeviceMatrix(_Handle):
         return ms.value
 
 
-def assemble_vector(space, b, source=None, vector_value=None, add=False):
+def assemble_vector(space, b, source=None, vector_value=None, div_coef=None, add=False):
+    """b (+)= int source q dx [+ int f.v dx + int div_coef div v dx on vector spaces]."""
     keep = []
     f = L.fs_linear_form()
     f.source = _coef(source, keep)
+    f.div_coef = _coef(div_coef, keep)
     if vector_value is not None:
         for i in range(3):
             f.vector_value[i] = float(vector_value[i])

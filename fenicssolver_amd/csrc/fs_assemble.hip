@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
                                                                  int64_t n_rows, coef_dev f, int ncomp, double fx,
-                                                                 double fy, double fz, double* __restrict__ b) {
+                                                                 double fy, double fz, coef_dev dv,
+                                                                 double* __restrict__ b) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
@@ -179,12 +180,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* 
                 if (v[a] < n_rows) atomicAdd(&b[v[a]], be[a]);
         } else {
             const double w = t.adet * (1.0 / 24.0);
+            double cd = 0.0;  // int c div v dx = c_cell * vol * grad_a[i]
+            if (dv.mode == FS_COEF_CONST) cd = dv.value;
+            else if (dv.mode == FS_COEF_CELL) cd = dv.data[c];
+            else if (dv.mode == FS_COEF_NODAL) cd = 0.25 * ((dv.data[v[0]] + dv.data[v[1]]) + (dv.data[v[2]] + dv.data[v[3]]));
+            cd *= t.adet * (1.0 / 6.0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 if (v[a] < n_rows) {
-                    atomicAdd(&b[3 * (int64_t)v[a] + 0], w * fx);
-                    atomicAdd(&b[3 * (int64_t)v[a] + 1], w * fy);
-                    atomicAdd(&b[3 * (int64_t)v[a] + 2], w * fz);
+                    atomicAdd(&b[3 * (int64_t)v[a] + 0], w * fx + cd * t.g[a][0]);
+                    atomicAdd(&b[3 * (int64_t)v[a] + 1], w * fy + cd * t.g[a][1]);
+                    atomicAdd(&b[3 * (int64_t)v[a] + 2], w * fz + cd * t.g[a][2]);
                 }
         }
     }
@@ -460,12 +466,17 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     coef_dev f;
     const int64_t len = form->source.mode == FS_COEF_NODAL ? space->n_nodes_local : m->nc;
     FS_CHECK(make_coef(form->source, len, store, &f, "fs_assemble_vector(source)"));
+    dbuf<double> dstore;
+    coef_dev dv;
+    const int64_t dlen = form->div_coef.mode == FS_COEF_NODAL ? space->n_nodes_local : m->nc;
+    FS_CHECK(make_coef(form->div_coef, dlen, dstore, &dv, "fs_assemble_vector(div_coef)"));
+    FS_REQUIRE(dv.mode == FS_COEF_NONE || space->ncomp == 3, "fs_assemble_vector: div_coef needs a vector space");
     if (space->ncomp == 1 && f.mode == FS_COEF_NONE) {
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
-    FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor source is meaningless");
-    hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], b->d.p);
+    FS_REQUIRE(f.mode != FS_COEF_TENSOR && dv.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
+    hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -1,0 +1,122 @@
+"""Operator specifications: what ``generate_form`` returns in place of a UFL form.
+
+The reference builds a UFL expression tree and lets FFC turn it into
+tabulate_tensor code (ScalarTransportSolver.py:228-359,
+LinearElasticitySolver.py:206-245).  Here the solver classes *recognise* which
+integrals the settings ask for and record them, with their coefficients, in one
+of the small classes below; ``SolverBase.solve_linear_problem`` / ``solve_amg``
+hand them to the HIP kernels.  The classes are plain data — printable and
+comparable in tests — and contain no arithmetic.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class VolumeCoefficient:
+    """kind: 'const' (value float), 'cell' (value array[n_cells]), 'tensor' (value 3x3),
+    'nodal' (value array[n_vertices], linear forms only)."""
+
+    def __init__(self, kind, value):
+        self.kind = kind
+        self.value = value
+
+    def spec(self, scale=1.0):
+        """Argument for fenicssolver_amd.backend (None | number | (kind, array))."""
+        if self.kind == "const":
+            return float(self.value) * scale
+        return (self.kind, np.asarray(self.value, dtype=np.float64) * scale)
+
+    def describe(self):
+        if self.kind == "const":
+            return ("const", float(self.value))
+        a = np.asarray(self.value, dtype=np.float64)
+        return (self.kind, a.shape, float(a.min()), float(a.max()))
+
+    def __repr__(self):
+        return "VolumeCoefficient%r" % (self.describe(),)
+
+
+class FacetLoad:
+    """int g * q ds(marker_id) added to the load vector; g scalar or [ncomp]."""
+
+    def __init__(self, marker_id, g, origin=""):
+        self.marker_id = int(marker_id)
+        self.g = g
+        self.origin = origin
+
+    def __repr__(self):
+        return "FacetLoad(ds(%d), g=%r, %s)" % (self.marker_id, self.g, self.origin)
+
+
+class FacetRobin:
+    """htc*(Ta - T)*q*ds(i): +h int T q ds on the matrix, +h*Ta int q ds on the load."""
+
+    def __init__(self, marker_id, h, ambient):
+        self.marker_id = int(marker_id)
+        self.h = float(h)
+        self.ambient = float(ambient)
+
+    def __repr__(self):
+        return "FacetRobin(ds(%d), h=%g, Ta=%g)" % (self.marker_id, self.h, self.ambient)
+
+
+class ScalarForm:
+    """F = (1/dt) c (T-T_prev) q dx + theta a_k(T,q) + (1-theta) a_k(T_prev,q) - loads
+    with a_k = int k grad T . grad q dx  (ScalarTransportSolver.py:284-303)."""
+
+    def __init__(self, space):
+        self.space = space
+        self.conductivity = None      # VolumeCoefficient
+        self.capacity = None          # VolumeCoefficient (transient only)
+        self.transient = False
+        self.dt = None
+        self.theta = 1.0
+        self.T_prev = None            # Function
+        self.sources = []             # [VolumeCoefficient]  int S q dx
+        self.facet_loads = []         # [FacetLoad]
+        self.robin = []               # [FacetRobin]
+        self.symmetric = True
+
+    def describe(self):
+        """Canonical, order-stable description used by the golden-term tests."""
+        return {
+            "type": "scalar",
+            "conductivity": self.conductivity.describe() if self.conductivity else None,
+            "capacity": self.capacity.describe() if self.capacity else None,
+            "transient": self.transient, "dt": self.dt, "theta": self.theta,
+            "sources": [s.describe() for s in self.sources],
+            "facet_loads": [(f.marker_id, _plain(f.g), f.origin) for f in self.facet_loads],
+            "robin": [(r.marker_id, r.h, r.ambient) for r in self.robin],
+        }
+
+
+class ElasticityForm:
+    """F = int sigma(u):grad v dx  +/- loads  (LinearElasticitySolver.py:206-245)."""
+
+    def __init__(self, space):
+        self.space = space
+        self.mu = None
+        self.lmbda = None
+        self.body_force = None        # (fx, fy, fz) or None
+        self.tractions = []           # [FacetLoad] with vector g
+        self.thermal = None           # (coefficient E*alpha/(1-2nu), T nodal array or float, T_ref)
+        self.load_sign = -1.0         # reference adds the load terms to F => rhs = -loads (Appendix B-Q3)
+
+    def describe(self):
+        return {
+            "type": "elasticity", "mu": self.mu, "lambda": self.lmbda,
+            "body_force": None if self.body_force is None else tuple(float(x) for x in self.body_force),
+            "tractions": [(t.marker_id, _plain(t.g), t.origin) for t in self.tractions],
+            "thermal": None if self.thermal is None else (self.thermal[0], _plain(self.thermal[1]), self.thermal[2]),
+            "load_sign": self.load_sign,
+        }
+
+
+def _plain(v):
+    a = np.asarray(v, dtype=np.float64)
+    if a.ndim == 0:
+        return float(a)
+    if a.size <= 4:
+        return tuple(float(x) for x in a.ravel())
+    return ("array", a.shape, float(a.min()), float(a.max()))

@@ -154,10 +154,14 @@ int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, int add);
 
 /* Linear form  L(v) = int source * v dx  (body source, ScalarTransportSolver.py:213-226;
  * vector spaces: constant body force f, LinearElasticitySolver.py:227-228, in
- * vector_value).  add == 0 zeroes b first. */
+ * vector_value) + int div_coef * div v dx (vector spaces only: the thermal-stress load
+ * E alpha (T-T0)/(1-2nu) I : grad v, LinearElasticitySolver.py:78-85, 231-238; a nodal
+ * coefficient enters by its cell mean, which is what one-point quadrature of a P1 field gives).
+ * add == 0 zeroes b first. */
 typedef struct fs_linear_form {
     fs_coef source;
     double vector_value[3];
+    fs_coef div_coef;
 } fs_linear_form;
 int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add);
 

@@ -1,0 +1,240 @@
+"""GPU tests of the drop-in solver API (SolverBase / ScalarTransportSolver /
+LinearElasticitySolver with reference-style settings dicts), checked against the oracle
+and against the analytic answers the reference's cases imply."""
+import copy
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+
+
+def test_config1_json_case_end_to_end(gpu, data_dir):
+    """python main.py ../data/TestHeatTransfer.json  ->  T = 350 - 2.5 z  (SURVEY 3.1, 8d config 1)."""
+    from fenicssolver_amd.main import load_settings, main
+    s = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+    s["report_settings"] = dict(QUIET)
+    solver = main(s)
+    T = solver.result
+    assert T is solver.w_current
+    z = solver.mesh.coordinates()[:, 2]
+    gold = np.load(os.path.join(os.path.dirname(data_dir), "config1_solution.npy"))
+    assert np.abs(T.vector().array() - gold).max() <= 5e-5          # CG stopped at 1e-8 vs LU
+    assert np.abs(T.vector().array() - (350.0 - 2.5 * z)).max() <= 5e-5
+    assert solver.last_solve_stats["iterations"] in (92, 93, 94)   # C8: 93
+    assert solver.last_solve_stats["true_rel_residual"] <= 1.2e-8
+    # heat flux through the inlet: k * dT/dz * area = 20 * 2.5 * 50  (outward normal is -z)
+    assert abs(solver.boundary_flux(1) - 20 * 2.5 * 50) < 1e-2
+    # tighter Krylov tolerance reproduces the reference's direct solve
+    s2 = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+    s2["report_settings"] = dict(QUIET)
+    s2["solver_settings"]["solver_parameters"]["krylov_relative_tolerance"] = 1e-13
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    T2 = ScalarTransportSolver(s2).solve()
+    assert np.abs(T2.vector().array() - gold).max() <= 1e-9
+
+
+def _box_heat_settings(n=6, transient=False, **extra):
+    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, near
+    m = UnitCubeMesh(n, n, n)
+    Q = FunctionSpace(m, "CG", 1)
+    top = AutoSubDomain(lambda x: near(x[1], 1.0))
+    bottom = AutoSubDomain(lambda x: near(x[1], 0.0))
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': top, 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["cold"] = {'boundary': bottom, 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+         'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+         'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.6},
+         'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1,
+                                                    'ending_time': 0.3},
+                             'reference_values': {'temperature': 300},
+                             'solver_parameters': {'krylov_relative_tolerance': 1e-12}},
+         'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    s.update(extra)
+    return s, m
+
+
+def test_dirichlet_pair_gives_linear_profile_and_flux(gpu):
+    """examples/test_heat_transfer.py pure-conduction variant: analytic flux (T_hot-T_cold)/L*k."""
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(6)
+    solver = ScalarTransportSolver(s)
+    T = solver.solve()
+    y = m.coordinates()[:, 1]
+    assert np.abs(T.vector().array() - (300 + 60 * y)).max() < 1e-8
+    assert abs(solver.boundary_flux(2) - (-0.6 * 60)) < 1e-8       # outward at y=0 is -y
+    assert abs(solver.boundary_flux(1) - (0.6 * 60)) < 1e-8
+
+
+def test_flux_htc_source_case_matches_oracle(gpu):
+    """heatFlux on top, HTC on bottom, body source (examples/test_heat_transfer.py:156-161)."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(5, body_source=7.0)
+    s['boundary_conditions']["hot"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}
+    s['boundary_conditions']["cold"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}
+    solver = ScalarTransportSolver(s)
+    T = solver.solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    facets, _, cnt = fo.facet_numbering(ce)
+    fm = fo.mark_facets(co, ce, lambda x, ob: abs(x[1] - 1.0) < 3e-16, 1)
+    fm = fo.mark_facets(co, ce, lambda x, ob: abs(x[1]) < 3e-16, 2, fm)
+    assert np.array_equal(fm, solver.boundary_facets.array())
+    A = fo.assemble_p1_scalar(co, ce, 0.6) + fo.assemble_p1_facet_mass(co, facets, fm, 2, 100.0)
+    b = fo.assemble_p1_source(co, ce, 7.0) + fo.assemble_p1_facet_load(co, facets, fm, 1, 36.0) \
+        + fo.assemble_p1_facet_load(co, facets, fm, 2, 100.0 * 300.0)
+    ref = fo.solve_direct(A.tocsr(), b)
+    assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
+    # energy balance: flux in + source = convective loss
+    assert abs(36.0 + 7.0 - 100.0 * (T[co[:, 1] == 0].mean() - 300.0)) < 0.5
+
+
+def test_per_subdomain_material_and_source(gpu):
+    from fenicssolver_amd.fem import MeshFunction
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(4)
+    solver = ScalarTransportSolver(s)
+    co, ce = m.coordinates(), m.cells()
+    cen = co[ce.astype(np.int64)].mean(axis=1)
+    sub = MeshFunction("size_t", m, 3)
+    sub.array()[:] = np.where(cen[:, 1] < 0.5, 1, 2)
+    solver.subdomains = sub
+    solver.material['conductivity'] = {'lower': {'subdomain_id': 1, 'value': 0.6},
+                                       'upper': {'subdomain_id': 2, 'value': 6.0}}
+    solver.body_source = {'heater': {'subdomain_id': 2, 'value': 50.0}}
+    T = solver.solve().vector().array()
+    kc = np.where(cen[:, 1] < 0.5, 0.6, 6.0)
+    A = fo.assemble_p1_scalar(co, ce, kc)
+    b = fo.assemble_p1_source(co, ce, np.where(cen[:, 1] < 0.5, 0.0, 50.0))
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    Ab, bb = fo.apply_dirichlet(A, b, np.concatenate([top, bot]),
+                                np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)]), True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(T - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_transient_crank_nicolson_matches_oracle(gpu, tmp_path):
+    """Crank-Nicolson time loop (ScalarTransportSolver.py:287-293, SolverBase.py:492-542)."""
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(4, transient=True)
+    s['material'] = {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6}
+    s['report_settings'] = dict(QUIET, saving_freq=1, result_filename=str(tmp_path / "T.pvd"))
+    solver = ScalarTransportSolver(s)
+    T = solver.solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    K = fo.assemble_p1_scalar(co, ce, 0.6)
+    M = fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 20.0))
+    dt = 0.1
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    dofs = np.concatenate([top, bot])
+    vals = np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+    Tn = np.full(len(co), 300.0)
+    t, steps = 0.0, 0
+    while t < 0.3:                       # the reference's loop condition (float accumulation included)
+        A = (M / dt + 0.5 * K).tocsr()
+        b = (M / dt - 0.5 * K) @ Tn
+        Ab, bb = fo.apply_dirichlet(A, b, dofs, vals, True)
+        Tn = fo.solve_direct(Ab, bb)
+        t += dt
+        steps += 1
+    assert solver.current_step == steps
+    assert np.abs(T - Tn).max() <= 1e-8 * 360.0
+    assert np.all(np.isfinite(T)) and T.max() <= 360.0 + 1e-9
+    # save(): a PVD collection with one VTU per saved step
+    assert os.path.exists(str(tmp_path / "T.pvd"))
+    assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".vtu")]) == steps - 1
+
+
+def test_linear_elasticity_cases(gpu):
+    """examples/test_linear_elasticity.py boundary variants on a P1 cantilever, vs the oracle's LU."""
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, SubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    E, nu = 2e11, 0.27
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 10, 2, 2)
+    co, ce = mesh.coordinates(), mesh.cells()
+    n = len(co)
+
+    class Left(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0)
+
+    class Right(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 10)
+
+    def make(bcs, **extra):
+        s = copy.deepcopy(SB.default_case_settings)
+        s['material'] = {'name': 'steel', 'elastic_modulus': E, 'poisson_ratio': nu, 'density': 7800,
+                         'thermal_expansion_coefficient': 2e-6}
+        s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+        s['boundary_conditions'] = bcs
+        s['solver_settings']['reference_values'] = {'temperature': 293}
+        s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
+        s['report_settings'] = dict(QUIET)
+        s.update(extra)
+        return LinearElasticitySolver(s)
+
+    K = fo.assemble_p1_elasticity(co, ce, E, nu)
+    left = np.nonzero(co[:, 0] == 0)[0]
+    right = np.nonzero(co[:, 0] == 10)[0]
+    facets, _, cnt = fo.facet_numbering(ce)
+    fm = fo.mark_facets(co, ce, lambda x, ob: abs(x[0] - 10) < 3e-16, 2)
+
+    # (1) prescribed displacement on the right face, clamp on the left (boundary_type 1 with full clamp)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+    bcs["displ"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant((0, 0, 1e-3))}
+    u = make(bcs).solve().vector().array()
+    dofs = np.concatenate([(left[:, None] * 3 + np.arange(3)).ravel(), (right[:, None] * 3 + np.arange(3)).ravel()])
+    vals = np.concatenate([np.zeros(3 * len(left)), np.tile([0, 0, 1e-3], len(right))])
+    Ab, bb = fo.apply_dirichlet(K, np.zeros(3 * n), dofs, vals, True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(u - ref).max() <= 1e-7 * np.abs(ref).max()
+
+    # (2) normal stress on the right face + body force + thermal stress, reference sign convention (Q3)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+    bcs["tensile"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'stress', 'value': Constant((1e8, 0, 0))}
+    solver = make(bcs, body_source=Expression(("10*rho", "0", "0.0"), rho=7800, omega=100, degree=2),
+                  temperature_distribution=Expression("343", degree=1))
+    u = solver.solve().vector().array()
+    tri = facets[fm == 2].astype(np.int64)
+    area = fo.facet_areas(co, tri)
+    bt = np.zeros((n, 3))
+    np.add.at(bt[:, 0], tri.ravel(), np.repeat(1e8 * area / 3.0, 3))
+    bf = fo.assemble_p1_vector_source(co, ce, (78000.0, 0, 0))
+    detJ, g = fo.p1_geometry(co, ce)
+    cT = E / (1 - 2 * nu) * 2e-6 * (343.0 - 293.0)
+    bth = np.zeros((n, 3))
+    np.add.at(bth, ce.astype(np.int64).ravel(), (cT * (np.abs(detJ) / 6.0)[:, None, None] * g).reshape(-1, 3))
+    rhs = -(bt.ravel() + bf) + bth.ravel()          # loads added to F (reversed), thermal conventional
+    dofs = (left[:, None] * 3 + np.arange(3)).ravel()
+    Ab, bb = fo.apply_dirichlet(K, rhs, dofs, 0.0, True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(u - ref).max() <= 1e-7 * np.abs(ref).max()
+    # physical convention on request: the bar stretches under the tensile stress
+    solver2 = make(bcs)
+    solver2.reference_load_sign = False
+    u2 = solver2.solve().vertex_values()
+    assert u2[right, 0].mean() > 0 and abs(u2[right, 0].mean() - 1e8 * 10 / E) < 0.1 * 1e8 * 10 / E
+    vm = solver2.von_Mises(solver2.result).vector().array()
+    assert abs(np.median(vm) - 1e8) < 0.15e8
+
+    # (3) per-component constraint (Constant(0), None, None) + total force on the right face
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+    bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
+    u3 = make(bcs).solve().vertex_values()
+    assert u3[right, 1].mean() < 0      # reversed sign (Q3): pushes -y

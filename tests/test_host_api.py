@@ -1,0 +1,347 @@
+"""CPU tests (no GPU): the oracle against the reference's known answers, the host-side data
+model and form recognition, and the C-ABI surface of libfsamd.so."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- oracle vs known answers
+def test_facet_numbering_reproduces_reference_markers(data_dir):
+    """lexicographic facet numbering puts the 100+100 marked facets of
+    data/mesh_facet_region.xml exactly on z=0 (id 1) and z=20 (id 2)."""
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    dim, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, cell_facets, cnt = fo.facet_numbering(ce)
+    assert (len(co), len(ce), len(facets), dim) == (1069, 4355, 9410, 2)
+    assert int((cnt == 1).sum()) == 1400
+    assert np.bincount(fm).tolist() == [9210, 100, 100]
+    for mid, z in ((1, 0.0), (2, 20.0)):
+        sel = fm == mid
+        assert np.all(co[facets[sel]][:, :, 2] == z) and np.all(cnt[sel] == 1)
+    dimc, cm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_physical_region.xml"))
+    assert dimc == 3 and np.all(cm == 3) and len(cm) == 4355
+    # golden fixture: vertex triples of the marked facets
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "config1_marked_facets.npz"))
+    assert np.array_equal(facets[fm == 1], gold["id1"]) and np.array_equal(facets[fm == 2], gold["id2"])
+    # mesh sanity: volume 10*5*20, Euler characteristic 1
+    detJ, _ = fo.p1_geometry(co, ce)
+    assert np.all(detJ != 0) and abs(np.abs(detJ).sum() / 6 - 1000.0) < 1e-9
+    edges, _ = fo.edge_numbering(ce)
+    assert len(co) - len(edges) + len(facets) - len(ce) == 1
+
+
+def test_config1_exact_solution(data_dir):
+    """data/TestHeatTransfer.json: k=20, T=350 on id 1, 300 on id 2 -> T = 350 - 2.5 z (C2, C8)."""
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    A = fo.assemble_p1_scalar(co, ce, 20.0)
+    assert A.nnz == 13315 and abs(A - A.T).max() < 1e-12 and abs(A.sum(axis=1)).max() < 1e-11
+    d1, d2 = fo.dirichlet_dofs_p1(facets, fm, 1), fo.dirichlet_dofs_p1(facets, fm, 2)
+    assert len(d1) == 66 and len(d2) == 66
+    dofs = np.concatenate([d1, d2])
+    vals = np.concatenate([np.full(66, 350.0), np.full(66, 300.0)])
+    exact = 350.0 - 2.5 * co[:, 2]
+    for sym in (False, True):
+        Ab, bb = fo.apply_dirichlet(A, np.zeros(len(co)), dofs, vals, symmetric=sym)
+        assert np.abs(fo.solve_direct(Ab, bb) - exact).max() < 1e-9
+    Ab, bb = fo.apply_dirichlet(A, np.zeros(len(co)), dofs, vals, symmetric=True)
+    x, it, _ = fo.pcg_jacobi(Ab, bb, rtol=1e-8)
+    assert it == 93 and np.abs(x - exact).max() < 1e-4
+    x2, it2, _ = fo.pcg_jacobi_single_reduction(Ab, bb, rtol=1e-8)
+    assert abs(it2 - it) <= 1 and np.abs(x2 - x).max() < 1e-6
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "config1_solution.npy"))
+    assert np.abs(fo.solve_direct(Ab, bb) - gold).max() < 1e-9
+
+
+def test_reference_tet_element_matrices():
+    """Appendix C3: exact P1 stiffness and mass matrices on the reference tetrahedron."""
+    co = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+    ce = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    K = fo.p1_stiffness_local(co, ce, 1.0)[0]
+    assert np.allclose(K * 6, [[3, -1, -1, -1], [-1, 1, 0, 0], [-1, 0, 1, 0], [-1, 0, 0, 1]], atol=1e-15)
+    M = fo.p1_mass_local(co, ce, 1.0)[0]
+    assert np.allclose(M * 120, np.ones((4, 4)) + np.eye(4), atol=1e-15)
+
+
+def test_kuhn_cube_structure_counts():
+    """Appendix C7: nnz/row of the P1 pattern on dolfin.UnitCubeMesh(n,n,n)."""
+    for n, expect in ((8, 12.48), (16, 13.63)):
+        co, ce = fo.unit_cube_mesh(n)
+        rp, ci = fo.csr_pattern(len(co), ce)
+        assert abs(len(ci) / len(co) - expect) < 0.01 and np.diff(rp).max() == 15
+        assert len(ce) == 6 * n ** 3
+    co, ce = fo.unit_cube_mesh(3)
+    detJ, _ = fo.p1_geometry(co, ce)
+    assert abs(np.abs(detJ).sum() / 6 - 1.0) < 1e-14
+
+
+def test_patch_tests_and_nullspace():
+    """C4/C5: linear fields are reproduced exactly; rigid-body modes are in the elasticity kernel."""
+    co, ce = fo.box_mesh((0, 0, 0), (2.0, 1.0, 1.5), 3, 2, 2)
+    A = fo.assemble_p1_scalar(co, ce, 3.0)
+    lin = 1.0 + 2.0 * co[:, 0] - 0.5 * co[:, 1] + 0.25 * co[:, 2]
+    on_b = np.nonzero(((co == 0) | (co == np.array([2.0, 1.0, 1.5]))).any(axis=1))[0]
+    Ab, bb = fo.apply_dirichlet(A, np.zeros(len(co)), on_b, lin[on_b], True)
+    assert np.abs(fo.solve_direct(Ab, bb) - lin).max() < 1e-12
+    K = fo.assemble_p1_elasticity(co, ce, 2e11, 0.27)
+    for r in fo.rigid_body_modes(co):
+        assert np.abs(K @ r).max() < 1e-9 * abs(K).max() * np.abs(r).max()
+    assert abs(K - K.T).max() < 1e-6 * abs(K).max()
+
+
+def test_c_oracle_agrees_with_numpy_oracle():
+    from oracle import c_oracle as co_
+    xyz, cells = co_.box_mesh(5, 4, 3, (0, 0, 0), (1, 2, 3))
+    c2, e2 = fo.box_mesh((0, 0, 0), (1, 2, 3), 5, 4, 3)
+    assert np.array_equal(xyz, c2) and np.array_equal(cells, e2)
+    rp, ci = co_.csr_pattern(len(xyz), cells)
+    rp2, ci2 = fo.csr_pattern(len(c2), e2)
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    v = co_.assemble_p1(xyz, cells, 20.0, rp, ci)
+    A = fo.assemble_p1_scalar(c2, e2, 20.0)
+    assert np.abs(v - A.data).max() < 1e-13 * np.abs(A.data).max()
+    P = fo.heat_box_problem(16)
+    x, it, _ = fo.pcg_jacobi(P["A"], P["b"])
+    r = co_.heat_box_solve(16, 16, 16)
+    assert r["iterations"] == it and np.abs(r["x"] - x).max() < 1e-9
+
+
+# ---------------------------------------------------------------- C-ABI surface
+def test_library_exports_every_declared_symbol():
+    from fenicssolver_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "fenicssolver_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libfsamd.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in lib.fs_version()
+
+
+def test_product_fails_loudly_without_gpu(data_dir):
+    from fenicssolver_amd import backend
+    if backend.device_count() > 0:
+        pytest.skip("a GPU is visible: the loud-failure path cannot be exercised")
+    with pytest.raises(backend.BackendError):
+        backend.init(0)
+    from fenicssolver_amd.main import load_settings
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+    s["mesh"] = os.path.join(data_dir, "mesh.xml")
+    solver = ScalarTransportSolver(s)
+    with pytest.raises(backend.BackendError):
+        solver.solve()     # no CPU fallback anywhere on the product path
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under fenicssolver_amd/ may import, link or include it."""
+    pkg = os.path.join(ROOT, "fenicssolver_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                text = open(path).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), path
+                assert "liboracle" not in text, path
+            elif f.endswith((".hip", ".h", ".cpp", "Makefile")):
+                text = open(path).read()
+                assert not re.search(r"#include\s*[\"<][^\">]*oracle", text) and "liboracle" not in text, path
+
+
+# ---------------------------------------------------------------- host data model
+def test_load_settings_contract(data_dir, tmp_path):
+    from fenicssolver_amd.main import load_settings, main
+    d = {"solver_name": "x"}
+    assert load_settings(d) is d
+    s = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+    ref = json.load(open(os.path.join(data_dir, "TestHeatTransfer.json")))
+    assert s["solver_name"] == "ScalarTransportSolver" and s["material"] == ref["material"]
+    assert s["boundary_conditions"] == ref["boundary_conditions"]
+    with pytest.raises(TypeError):
+        load_settings(12345)
+    with pytest.raises(NameError):
+        main({"solver_name": "NoSuchSolver"})
+
+
+def test_mesh_and_markers_from_xml(data_dir):
+    from fenicssolver_amd.fem import Mesh, MeshFunction
+    m = Mesh(os.path.join(data_dir, "mesh.xml"))
+    assert (m.num_vertices(), m.num_cells(), m.num_facets(), m.num_entities(1)) == (1069, 4355, 9410, 6123)
+    assert np.all(np.diff(m.cells().astype(np.int64), axis=1) > 0)      # mesh.order()
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    facets, cf, cnt = fo.facet_numbering(ce)
+    assert np.array_equal(m.facets(), facets) and np.array_equal(m.cell_facets(), cf)
+    assert np.array_equal(m.exterior_facets(), cnt == 1)
+    mf = MeshFunction("size_t", m, os.path.join(data_dir, "mesh_facet_region.xml"))
+    assert mf.dim() == 2 and np.bincount(mf.array()).tolist() == [9210, 100, 100]
+
+
+def test_boxmesh_matches_oracle_and_subdomain_marking():
+    from fenicssolver_amd.fem import BoxMesh, Point, MeshFunction, AutoSubDomain, SubDomain, near
+    m = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 6, 2, 3)
+    co, ce = fo.box_mesh((0, 0, 0), (10, 1, 1), 6, 2, 3)
+    assert np.array_equal(m.coordinates(), co) and np.array_equal(m.cells(), ce)
+
+    class Left(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0.0)
+
+    mf = MeshFunction("size_t", m, 2)
+    mf.set_all(0)
+    Left().mark(mf, 1)
+    AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 10.0)).mark(mf, 2)
+    AutoSubDomain(lambda x: near(x[2], 1.0)).mark(mf, 3)
+    ref = fo.mark_facets(co, ce, lambda x, ob: abs(x[0]) < 3e-16, 1)
+    ref = fo.mark_facets(co, ce, lambda x, ob: ob and abs(x[0] - 10.0) < 3e-16, 2, ref)
+    ref = fo.mark_facets(co, ce, lambda x, ob: abs(x[2] - 1.0) < 3e-16, 3, ref)
+    assert np.array_equal(mf.array(), ref)
+    assert (mf.array() == 1).sum() == 2 * 2 * 3 and (mf.array() == 3).sum() == 2 * 6 * 2
+
+
+def test_expression_and_dirichlet():
+    from fenicssolver_amd.fem import (UnitCubeMesh, FunctionSpace, VectorFunctionSpace, Expression, Constant,
+                                      MeshFunction, AutoSubDomain, DirichletBC, interpolate, near, SolverError)
+    m = UnitCubeMesh(3, 3, 3)
+    V = FunctionSpace(m, "CG", 1)
+    f = interpolate(Expression("1 + x[0]*x[0] + 2*x[1] - pow(x[2], 3) + sin(pi*x[0])", degree=1), V)
+    co = m.coordinates()
+    assert np.allclose(f.vector().array(), 1 + co[:, 0] ** 2 + 2 * co[:, 1] - co[:, 2] ** 3 + np.sin(np.pi * co[:, 0]))
+    e = Expression(("10*rho", "0", "0.0"), rho=7800, omega=100, degree=2)   # examples/test_linear_elasticity.py:68
+    assert np.allclose(e.eval_points(co[:2]), [[78000.0, 0, 0]] * 2)
+    with pytest.raises(SolverError):
+        Expression("x[0] > 0 ? 1 : 2", degree=1)
+    mf = MeshFunction("size_t", m, 2)
+    AutoSubDomain(lambda x: near(x[0], 0.0)).mark(mf, 1)
+    bc = DirichletBC(V, Constant(350), mf, 1)
+    assert np.array_equal(bc.dofs, np.nonzero(co[:, 0] == 0)[0]) and np.all(bc.values == 350.0)
+    W = VectorFunctionSpace(m, "Lagrange", 1)
+    bcy = DirichletBC(W.sub(1), Constant(0.5), mf, 1)
+    assert np.array_equal(bcy.dofs, np.nonzero(co[:, 0] == 0)[0] * 3 + 1)
+    bcv = DirichletBC(W, Constant((0, 0, 1e-3)), mf, 1)
+    assert bcv.dofs.size == 3 * 16 and np.allclose(bcv.values.reshape(-1, 3), [0, 0, 1e-3])
+    with pytest.raises(SolverError):
+        FunctionSpace(m, "CG", 2)          # P2 not built yet: loud, not silent
+
+
+def test_scalar_form_recognition_config1(data_dir):
+    """Same settings dict in -> same Dirichlet sets and operator as the reference builds
+    (ScalarTransportSolver.py:228-359 for TestHeatTransfer.json)."""
+    from fenicssolver_amd.main import load_settings
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+    s["mesh"] = os.path.join(data_dir, "mesh.xml")
+    solver = ScalarTransportSolver(s)
+    assert solver.dimension == 3 and not solver.transient
+    solver.init_solver()
+    assert np.all(solver.w_current.vector().array() == 293.0)      # initial_values
+    solver.current_step = 0
+    F, bcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    d = F.describe()
+    assert d["conductivity"] == ("const", 20.0) and d["capacity"] is None and not d["transient"]
+    assert d["sources"] == [] and d["facet_loads"] == [] and d["robin"] == []
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    assert [b.marker_id for b in bcs] == [1, 2]
+    assert np.array_equal(bcs[0].dofs, fo.dirichlet_dofs_p1(facets, fm, 1)) and np.all(bcs[0].values == 350.0)
+    assert np.array_equal(bcs[1].dofs, fo.dirichlet_dofs_p1(facets, fm, 2)) and np.all(bcs[1].values == 300.0)
+    assert solver.capacity() == 1000 * 500
+    assert solver.set_solver_parameters()["relative_tolerance"] == 1e-8   # 1e-7 in the JSON is capped (Q2)
+
+
+def test_scalar_form_recognition_heat_flux_htc_transient():
+    """The BC vocabulary of examples/test_heat_transfer.py:42-71,136-161 on a 3D box."""
+    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    from fenicssolver_amd.SolverBase import SolverError
+    m = UnitCubeMesh(4, 4, 4)
+    Q = FunctionSpace(m, "CG", 1)
+    top = AutoSubDomain(lambda x: near(x[1], 1.0))
+    bottom = AutoSubDomain(lambda x: near(x[1], 0.0))
+    left = AutoSubDomain(lambda x: near(x[0], 0.0))
+    bcs = {"hot": {'boundary': top, 'boundary_id': 1, 'values': {
+               'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}},
+           "cold": {'boundary': bottom, 'boundary_id': 2, 'values': {
+               'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100),
+                               'ambient': Constant(300)}}},
+           "left": {'boundary': left, 'boundary_id': 3, 'values': {
+               'temperature': {'variable': 'temperature', 'type': 'symmetry', 'value': None}}}}
+    settings = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+                'boundary_conditions': bcs, 'body_source': 5.0, 'initial_values': {'temperature': 300},
+                'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.1},
+                'solver_settings': {'transient_settings': {'transient': True, 'starting_time': 0, 'time_step': 0.1,
+                                                           'ending_time': 1},
+                                    'reference_values': {'temperature': 300}, 'solver_parameters': {}},
+                'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    solver.material['conductivity'] = 0.6      # users patch the material after construction (:170)
+    solver.init_solver()
+    solver.current_step = 0
+    F, dbc = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    d = F.describe()
+    assert dbc == []
+    assert d["conductivity"] == ("const", 0.6) and d["capacity"] == ("const", 4200000.0)
+    assert d["transient"] and d["dt"] == 0.1 and d["theta"] == 0.5
+    assert d["facet_loads"] == [(1, 36.0, 'flux')] and d["robin"] == [(2, 100.0, 300.0)]
+    assert d["sources"] == [("const", 5.0)]
+    assert (solver.boundary_facets.array() == 1).sum() == 32
+    settings['convective_velocity'] = Constant((0.005, -0.005, 0.0))
+    with pytest.raises(SolverError):
+        ScalarTransportSolver(settings).generate_form(0, None, None, solver.w_current, solver.w_prev)
+
+
+def test_elasticity_form_recognition():
+    """examples/test_linear_elasticity.py:70-129 (P1 instead of P2)."""
+    import copy
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, SubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 8, 2, 2)
+
+    class Left(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0)
+
+    class Right(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 10)
+
+    from collections import OrderedDict
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), None, None)}
+    bcs["tensile"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'stress', 'value': Constant((1e8, 0, 0))}
+    s = copy.deepcopy(SB.default_case_settings)
+    s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                     'thermal_expansion_coefficient': 2e-6}
+    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    s['boundary_conditions'] = bcs
+    s['solver_settings']['reference_values'] = {'temperature': 293}
+    s['temperature_distribution'] = Expression("343", degree=1)
+    s['body_source'] = Expression(("10*rho", "0", "0.0"), omega=100, rho=7800, degree=2)
+    solver = LinearElasticitySolver(s)
+    assert solver.settings['vector_name'] == 'displacement'
+    solver.init_solver()
+    solver.current_step = 0
+    F, dbc = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    d = F.describe()
+    mu, lm = fo.lame(2e11, 0.27)
+    assert d["mu"] == mu and d["lambda"] == lm and d["load_sign"] == -1.0      # quirk Q3 kept
+    assert d["body_force"] == (78000.0, 0.0, 0.0)
+    assert d["tractions"] == [(2, (1e8, 0.0, 0.0), 'stress(vector)')]
+    assert d["thermal"] == (2e11 / (1 - 0.54) * 2e-6, 343.0, 293.0)
+    co = mesh.coordinates()
+    assert len(dbc) == 1 and np.array_equal(dbc[0].dofs, np.nonzero(co[:, 0] == 0)[0] * 3)
+    ns = solver.build_nullspace(solver.function_space)
+    assert ns.shape == (6, 3 * len(co)) and np.allclose(ns @ ns.T, np.eye(6), atol=1e-12)
+    K = fo.assemble_p1_elasticity(co, mesh.cells(), 2e11, 0.27)
+    assert np.abs(K @ ns.T).max() < 1e-9 * abs(K).max()
