@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from fenicssolver_amd import backend as B  # noqa: E402  (loads libfsamd.so before torch)
+from fenicssolver_amd import partition  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
@@ -66,42 +67,13 @@ class Problem:
         t2 = time.perf_counter()
         self.mesh_ms = (t1 - t0) * 1e3
         self.symbolic_ms = (t2 - t1) * 1e3
-        n_own = (ze - zb) * P
-        has_lo, has_hi = zb > 0, ze < nz + 1
-        assert self.V.n_owned == n_own and self.V.n_local == n_own + (has_lo + has_hi) * P
+        lay = partition.slab_layout(nx, ny, nz, zplanes, rank, world)
+        n_own = lay["n_owned"]
+        assert self.V.n_owned == n_own and self.V.n_local == lay["n_local"]
         # Dirichlet dofs in local numbering (owned planes first, then lower, then upper ghost plane)
-        planes = list(range(zb, ze)) + ([zb - 1] if has_lo else []) + ([ze] if has_hi else [])
-        inplane = np.arange(P)
-        ix, iy = inplane % (nx + 1), inplane // (nx + 1)
-        dofs, vals = [], []
-        for lp, iz in enumerate(planes):
-            if axis == 2:
-                if iz == 0:
-                    sel, v = inplane, 350.0
-                elif iz == nz:
-                    sel, v = inplane, 300.0
-                else:
-                    continue
-                dofs.append(lp * P + sel)
-                vals.append(np.full(sel.size, v))
-            else:
-                c, m = (ix, nx) if axis == 0 else (iy, ny)
-                lo, hi = inplane[c == 0], inplane[c == m]
-                dofs += [lp * P + lo, lp * P + hi]
-                vals += [np.full(lo.size, 350.0), np.full(hi.size, 300.0)]
-        self.dofs = np.concatenate(dofs).astype(np.int32)
-        self.vals = np.concatenate(vals)
+        self.dofs, self.vals = partition.slab_dirichlet(nx, ny, nz, lay, axis)
         if world > 1:
-            nb, send, recv = [], [], []
-            if has_lo:
-                nb.append(rank - 1)
-                send.append(np.arange(0, P, dtype=np.int32))
-                recv.append(P)
-            if has_hi:
-                nb.append(rank + 1)
-                send.append(np.arange(n_own - P, n_own, dtype=np.int32))
-                recv.append(P)
-            self.V.set_halo(nb, send, recv)
+            self.V.set_halo(lay["neighbors"], lay["send_lists"], lay["recv_counts"])
         self.A = B.DeviceMatrix(self.V)
         self.b = B.DeviceVector(self.V.n_owned)
         self.x = B.DeviceVector(self.V.n_owned)
@@ -166,15 +138,13 @@ def main():
     n = a.n
     axis = a.bc_axis if a.bc_axis is not None else (2 if world == 1 else 0)
     if a.scaling == "weak":
-        planes_per_rank = n + 1
-        nz = world * planes_per_rank - 1
+        nz = world * (n + 1) - 1
         p1 = (1.0, 1.0, nz / float(n))
-        zplanes = (rank * planes_per_rank, (rank + 1) * planes_per_rank)
+        zplanes = partition.slab_ranges(nz + 1, world, planes_per_rank=n + 1)[rank]
     else:
         nz = n
         p1 = (1.0, 1.0, 1.0)
-        cuts = [(n + 1) * r // world for r in range(world + 1)]
-        zplanes = (cuts[rank], cuts[rank + 1])
+        zplanes = partition.slab_ranges(nz + 1, world)[rank]
     if world > 1 and axis == 2 and a.scaling == "weak":
         print("[bench] note: --bc-axis 2 with weak scaling lengthens the bar between the Dirichlet faces; "
               "iteration counts will grow with N", file=sys.stderr)

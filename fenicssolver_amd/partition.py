@@ -1,0 +1,173 @@
+"""Domain decomposition plans for one-process-per-GPU runs (host logic, numpy only).
+
+DOLFIN partitions the mesh with SCOTCH under ``mpirun`` and PETSc builds the VecScatter
+that refreshes ghost values (the reference only inherits this: SolverBase.py:102-118, 634).
+Here the owner-computes plan is explicit:
+
+  * every vertex (P1 dof node) has one owner rank;
+  * a rank keeps every cell that touches one of its vertices (one ghost-cell layer), so
+    assembly of the rows it owns needs no communication;
+  * local numbering = owned vertices first (ascending global id), then ghosts grouped by
+    owner rank (ascending), each group ascending by global id;
+  * for every neighbour: the owned vertices it needs (send list, ascending global id — the
+    same order the neighbour stores them as ghosts) and the number of ghosts it provides.
+
+``slab_layout`` is the closed form of the same plan for the structured box meshes of
+bench.py (z-slabs of whole vertex planes: <= 2 neighbours, contiguous send ranges);
+``build_local_part`` handles any mesh/owner array and is what the tests compare it with.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def slab_owner(coords, n_parts, axis=2):
+    """Owner array for slabs of (nearly) equal vertex count along `axis`.  Vertices sharing a
+    coordinate stay together, so structured meshes split into whole planes."""
+    c = np.asarray(coords)[:, axis]
+    levels, inv = np.unique(c, return_inverse=True)
+    counts = np.bincount(inv)
+    cum = np.cumsum(counts)
+    total = cum[-1]
+    # plane p goes to the part whose share its midpoint falls in
+    mid = cum - counts / 2.0
+    owner_of_level = np.minimum((mid * n_parts / total).astype(np.int64), n_parts - 1)
+    return owner_of_level[inv].astype(np.int32)
+
+
+def rcb_owner(coords, n_parts):
+    """Recursive coordinate bisection of the vertices (unstructured meshes)."""
+    coords = np.asarray(coords)
+    owner = np.zeros(len(coords), dtype=np.int32)
+
+    def split(idx, lo, hi):
+        if hi - lo <= 1:
+            owner[idx] = lo
+            return
+        ext = coords[idx].max(axis=0) - coords[idx].min(axis=0)
+        ax = int(np.argmax(ext))
+        nl = (hi - lo) // 2
+        k = int(round(len(idx) * nl / float(hi - lo)))
+        order = idx[np.argsort(coords[idx, ax], kind="stable")]
+        split(order[:k], lo, lo + nl)
+        split(order[k:], lo + nl, hi)
+
+    split(np.arange(len(coords)), 0, n_parts)
+    return owner
+
+
+class LocalPart:
+    """One rank's share of a partitioned mesh (see module docstring for the numbering)."""
+
+    def __init__(self, rank, l2g, n_owned, cells_local, cell_gids, neighbors, send_lists, recv_counts):
+        self.rank = rank
+        self.l2g = l2g                      # [n_local] global vertex id of every local vertex
+        self.n_owned = n_owned
+        self.cells = cells_local            # [nc_local, 4] local vertex ids (vertex order of the global cell)
+        self.cell_gids = cell_gids          # [nc_local] global cell ids, ascending
+        self.neighbors = neighbors          # ranks, ascending
+        self.send_lists = send_lists        # per neighbour: owned local ids, ascending global id
+        self.recv_counts = recv_counts      # per neighbour: number of ghosts it owns
+
+    @property
+    def n_local(self):
+        return len(self.l2g)
+
+    def g2l(self, n_global):
+        m = np.full(n_global, -1, dtype=np.int64)
+        m[self.l2g] = np.arange(len(self.l2g))
+        return m
+
+    def dof_send_lists(self, ncomp):
+        if ncomp == 1:
+            return self.send_lists
+        return [(s[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel().astype(np.int32) for s in self.send_lists]
+
+
+def build_local_part(cells, owner, rank):
+    cells = np.asarray(cells, dtype=np.int64)
+    owner = np.asarray(owner)
+    n_global = len(owner)
+    cell_owned = owner[cells] == rank
+    keep = np.nonzero(cell_owned.any(axis=1))[0]
+    lc = cells[keep]
+    verts = np.unique(lc)
+    mine = verts[owner[verts] == rank]
+    ghosts = verts[owner[verts] != rank]
+    gorder = np.lexsort((ghosts, owner[ghosts]))          # by owner rank, then global id
+    ghosts = ghosts[gorder]
+    l2g = np.concatenate([mine, ghosts])
+    g2l = np.full(n_global, -1, dtype=np.int64)
+    g2l[l2g] = np.arange(len(l2g))
+    neighbors, recv_counts = np.unique(owner[ghosts], return_counts=True)
+    # what each neighbour q needs from me: my vertices in cells that touch a q-owned vertex
+    send_lists = []
+    nb_all = set(neighbors.tolist())
+    cand = cells[(owner[cells] == rank).any(axis=1)]
+    for q in sorted(nb_all | set(np.unique(owner[cand]).tolist()) - {rank}):
+        touch = cand[(owner[cand] == q).any(axis=1)]
+        v = np.unique(touch)
+        v = v[owner[v] == rank]
+        if q not in nb_all:
+            # q needs my vertices but I need none of q's: cannot happen for a one-layer overlap
+            raise AssertionError("asymmetric neighbourhood between ranks %d and %d" % (rank, q))
+        send_lists.append(g2l[v].astype(np.int32))
+    return LocalPart(rank, l2g, len(mine), g2l[lc].astype(np.int32), keep, [int(q) for q in neighbors],
+                     send_lists, [int(c) for c in recv_counts])
+
+
+def slab_ranges(n_planes, world, planes_per_rank=None):
+    """[zb, ze) owned vertex planes of every rank."""
+    if planes_per_rank is not None:
+        return [(r * planes_per_rank, (r + 1) * planes_per_rank) for r in range(world)]
+    cuts = [n_planes * r // world for r in range(world + 1)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def slab_layout(nx, ny, nz, zplanes, rank, world):
+    """Closed-form plan of the z-slab [zplanes) of BoxMesh(nx,ny,nz) as fs_mesh_create_box numbers it:
+    owned planes first (x-fastest), then the lower ghost plane, then the upper ghost plane.
+    Returns dict(n_owned, n_local, planes (global z index of every local plane), l2g, neighbors,
+    send_lists, recv_counts)."""
+    P = (nx + 1) * (ny + 1)
+    zb, ze = zplanes
+    has_lo, has_hi = zb > 0, ze < nz + 1
+    planes = list(range(zb, ze)) + ([zb - 1] if has_lo else []) + ([ze] if has_hi else [])
+    n_owned = (ze - zb) * P
+    l2g = np.concatenate([np.arange(iz * P, (iz + 1) * P, dtype=np.int64) for iz in planes])
+    neighbors, send_lists, recv_counts = [], [], []
+    if has_lo:
+        neighbors.append(rank - 1)
+        send_lists.append(np.arange(0, P, dtype=np.int32))
+        recv_counts.append(P)
+    if has_hi:
+        neighbors.append(rank + 1)
+        send_lists.append(np.arange(n_owned - P, n_owned, dtype=np.int32))
+        recv_counts.append(P)
+    return dict(n_owned=n_owned, n_local=n_owned + (has_lo + has_hi) * P, planes=planes, l2g=l2g,
+                neighbors=neighbors, send_lists=send_lists, recv_counts=recv_counts, plane_size=P)
+
+
+def slab_dirichlet(nx, ny, nz, layout, axis, lo_value=350.0, hi_value=300.0):
+    """Local dofs/values of the Dirichlet face pair of the box heat problem (axis = 0, 1 or 2),
+    ghosts included (the elimination needs the values of constrained ghost columns)."""
+    P = layout["plane_size"]
+    inplane = np.arange(P)
+    ix, iy = inplane % (nx + 1), inplane // (nx + 1)
+    dofs, vals = [], []
+    for lp, iz in enumerate(layout["planes"]):
+        if axis == 2:
+            if iz == 0:
+                dofs.append(lp * P + inplane)
+                vals.append(np.full(P, lo_value))
+            elif iz == nz:
+                dofs.append(lp * P + inplane)
+                vals.append(np.full(P, hi_value))
+        else:
+            c, m = (ix, nx) if axis == 0 else (iy, ny)
+            lo, hi = inplane[c == 0], inplane[c == m]
+            dofs += [lp * P + lo, lp * P + hi]
+            vals += [np.full(lo.size, lo_value), np.full(hi.size, hi_value)]
+    if not dofs:
+        return np.zeros(0, dtype=np.int32), np.zeros(0)
+    return np.concatenate(dofs).astype(np.int32), np.concatenate(vals)

@@ -1,0 +1,93 @@
+"""world_size-2/3 `gloo` tests of the N>1 path on CPU: partition plans + the distributed
+single-reduction CG sequence (halo -> SpMV+dots -> one all-reduce -> update) reproduce the
+single-rank solution; the closed-form slab plan equals the general plan."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from fenicssolver_amd import partition
+from oracle import fem_oracle as fo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_plan_equals_general_plan():
+    nx, ny, nz = 4, 3, 10
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 2), nx, ny, nz)
+    P = (nx + 1) * (ny + 1)
+    for world in (2, 3, 4):
+        ranges = partition.slab_ranges(nz + 1, world)
+        owner = np.zeros(len(co), dtype=np.int32)
+        for r, (zb, ze) in enumerate(ranges):
+            owner[zb * P:ze * P] = r
+        seen = np.zeros(len(co), dtype=int)
+        for r, zr in enumerate(ranges):
+            lay = partition.slab_layout(nx, ny, nz, zr, r, world)
+            part = partition.build_local_part(ce, owner, r)
+            assert np.array_equal(lay["l2g"], part.l2g) and lay["n_owned"] == part.n_owned
+            assert lay["neighbors"] == part.neighbors and lay["recv_counts"] == part.recv_counts
+            for a, b in zip(lay["send_lists"], part.send_lists):
+                assert np.array_equal(a, b)
+            seen[part.l2g[:part.n_owned]] += 1
+            # ghost order on the receiver == send order on the owner (ascending global id)
+            off = part.n_owned
+            for q, cnt in zip(part.neighbors, part.recv_counts):
+                other = partition.build_local_part(ce, owner, q)
+                sl = other.send_lists[other.neighbors.index(r)]
+                assert np.array_equal(other.l2g[sl], part.l2g[off:off + cnt])
+                off += cnt
+            # every cell touching an owned vertex is local, and only those
+            touch = (owner[ce.astype(np.int64)] == r).any(axis=1)
+            assert np.array_equal(part.cell_gids, np.nonzero(touch)[0])
+        assert np.all(seen == 1)
+
+
+def test_owner_functions_cover_all_vertices(data_dir):
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    for world in (2, 5, 8):
+        o = partition.rcb_owner(co, world)
+        cnt = np.bincount(o, minlength=world)
+        assert cnt.min() > 0 and cnt.max() - cnt.min() <= world
+        o2 = partition.slab_owner(co, world, axis=2)
+        assert set(np.unique(o2)) == set(range(world))
+    # unstructured plan: symmetric neighbourhoods, consistent orders
+    owner = partition.rcb_owner(co, 4)
+    parts = [partition.build_local_part(ce, owner, r) for r in range(4)]
+    for p in parts:
+        off = p.n_owned
+        for q, cnt in zip(p.neighbors, p.recv_counts):
+            sl = parts[q].send_lists[parts[q].neighbors.index(p.rank)]
+            assert np.array_equal(parts[q].l2g[sl], p.l2g[off:off + cnt])
+            off += cnt
+        assert off == p.n_local
+
+
+def _run(world, mode, tmp_path):
+    out = str(tmp_path / ("dist_%s_%d.npz" % (mode, world)))
+    port = 29500 + (os.getpid() % 2000) + world
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_worker.py"), mode, out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "slab"), (3, "slab"), (2, "rcb"), (3, "general_slab")])
+def test_distributed_cg_matches_single_rank(world, mode, tmp_path):
+    r = _run(world, mode, tmp_path)
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 1.8), 5, 4, 9)
+    A = fo.assemble_p1_scalar(co, ce, 20.0)
+    lo, hi = np.nonzero(co[:, 0] == 0.0)[0], np.nonzero(co[:, 0] == 1.0)[0]
+    Ab, bb = fo.apply_dirichlet(A, np.zeros(len(co)), np.concatenate([lo, hi]),
+                                np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), True)
+    x1, it1, _ = fo.pcg_jacobi_single_reduction(Ab, bb, rtol=1e-10)
+    assert not np.isnan(r["x"]).any()
+    assert abs(int(r["iterations"]) - it1) <= 1
+    # reduction order differs between 1 and N ranks: agreement to 1e-12 relative
+    assert np.abs(r["x"] - x1).max() <= 1e-10 * np.abs(x1).max()
+    assert np.abs(r["x"] - (350.0 - 50.0 * co[:, 0])).max() <= 1e-6
