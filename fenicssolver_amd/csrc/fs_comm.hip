@@ -12,6 +12,7 @@
 // librccl is dlopen()ed on first use, so single-GPU processes never depend on it.
 #include "fs_common.h"
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 struct rccl_api {
@@ -30,10 +31,13 @@ static rccl_api g_nccl;
 
 static int rccl_load() {
     if (g_nccl.handle) return FS_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // Prefer the RCCL of the ROCm install this library's HIP runtime comes from; a process that has
+    // imported torch also carries torch's bundled copy under the same SONAME.  FS_RCCL_PATH overrides.
+    const char* names[] = {getenv("FS_RCCL_PATH"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void* h = nullptr;
     for (const char* nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!nm || !*nm) continue;
+        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
     }
     if (!h) {
