@@ -8,7 +8,6 @@
 // kernels: one thread per cell, 16-B coalesced loads of the cell's vertex ids and of the
 // slot column, hardware fp64 atomics (global_atomic_add_f64) for the scatter.
 #include "fs_common.h"
-#include <unordered_map>
 
 // ---- P1 geometry ---------------------------------------------------------------------------
 struct tet_geom {
@@ -110,6 +109,83 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar(const int32_t* 
                 const int32_t slot = slots[(int64_t)(a * 4 + b) * nc + c];
                 if (slot >= 0) atomicAdd(&val[slot], ke[a][b]);
             }
+    }
+}
+
+// ---- scalar P1, row-gather form: owner computes, no atomics, deterministic -----------------------
+// One wavefront per SELL slice, lane = row.  Every row walks its (cell, local vertex) incidences
+// (SELL-laid-out tables built by fs_space_create), recomputes the cell geometry with its own vertex
+// rotated to local index 0 (so no register array is indexed dynamically), and accumulates the row of
+// the local matrix into a thread-private LDS column at the precomputed in-row positions.  The row is
+// then written with plain, fully coalesced stores.  Contributions are summed in ascending cell order,
+// so the assembled matrix is bit-reproducible.
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+    const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
+    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
+    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < n_slices; s += (int64_t)gridDim.x * wpb) {
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const uint32_t packed = inc_pos[ibase + (int64_t)j * FS_SLICE + lane];
+            const int c = q >> 2, a = q & 3;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            // rotate so that this row's vertex is local vertex 0 (gradients are orientation-free)
+            const int32_t w0 = a == 0 ? v4.x : a == 1 ? v4.y : a == 2 ? v4.z : v4.w;
+            const int32_t w1 = a == 0 ? v4.y : a == 1 ? v4.z : a == 2 ? v4.w : v4.x;
+            const int32_t w2 = a == 0 ? v4.z : a == 1 ? v4.w : a == 2 ? v4.x : v4.y;
+            const int32_t w3 = a == 0 ? v4.w : a == 1 ? v4.x : a == 2 ? v4.y : v4.z;
+            const uint32_t prot = a == 0 ? packed : ((packed >> (8 * a)) | (packed << (32 - 8 * a)));
+            const int32_t vv[4] = {w0, w1, w2, w3};
+            const tet_geom t = tet_geometry(xyz4, vv);
+            const double vol = t.adet * (1.0 / 6.0);
+            double row[4];
+            if (kc.mode == FS_COEF_TENSOR) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double kg[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        kg[i] = kc.tensor[3 * i + 0] * t.g[b][0] + kc.tensor[3 * i + 1] * t.g[b][1] + kc.tensor[3 * i + 2] * t.g[b][2];
+                    row[b] = vol * (t.g[0][0] * kg[0] + t.g[0][1] * kg[1] + t.g[0][2] * kg[2]);
+                }
+            } else {
+                double kk = 0.0;
+                if (kc.mode == FS_COEF_CONST) kk = kc.value;
+                else if (kc.mode == FS_COEF_CELL) kk = kc.data[c];
+                const double w = kk * vol;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    row[b] = w * (t.g[0][0] * t.g[b][0] + t.g[0][1] * t.g[b][1] + t.g[0][2] * t.g[b][2]);
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.adet * (1.0 / 120.0);
+                row[0] += 2.0 * mm;
+                row[1] += mm;
+                row[2] += mm;
+                row[3] += mm;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = (prot >> (8 * b)) & 255;
+                lds_acc[k * bd + tid] += row[b];
+            }
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
     }
 }
 
@@ -249,22 +325,33 @@ __global__ void k_facet_matrix(const double* __restrict__ xyz4, const int32_t* _
 }
 
 // ---- Dirichlet ------------------------------------------------------------------------------------
+// "later entries win" without a host pass: first the largest list index naming each dof ...
+__global__ void k_bc_last_index(const int32_t* __restrict__ dofs, int64_t n, int32_t* __restrict__ idx) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) atomicMax(&idx[dofs[i]], (int32_t)i);
+}
+
+// ... then only that entry writes flag and value (deterministic for any duplicate pattern)
 __global__ void k_bc_scatter(const int32_t* __restrict__ dofs, const double* __restrict__ vals, int64_t n,
-                             uint8_t* __restrict__ flag, double* __restrict__ g) {
+                             const int32_t* __restrict__ idx, uint8_t* __restrict__ flag, double* __restrict__ g) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        flag[dofs[i]] = 1;
-        g[dofs[i]] = vals[i];
+        const int32_t d = dofs[i];
+        if (idx[d] == (int32_t)i) {
+            flag[d] = 1;
+            g[d] = vals[i];
+        }
     }
 }
 
-__global__ void k_bc_vector(const int32_t* __restrict__ dofs, const double* __restrict__ vals, int64_t n,
-                            int64_t n_rows_dofs, double* __restrict__ b) {
+__global__ void k_bc_vector(const uint8_t* __restrict__ flag, const double* __restrict__ g, int64_t n_rows_dofs,
+                            double* __restrict__ b) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride)
-        if (dofs[i] < n_rows_dofs) b[dofs[i]] = vals[i];
+    for (; i < n_rows_dofs; i += stride)
+        if (flag[i]) b[i] = g[i];
 }
 
 // one wavefront per SELL slice, lane = node row; rows of constrained dofs become identity,
@@ -437,18 +524,34 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     fs_space_s* sp = A->space;
     fs_mesh_s* m = sp->mesh;
     hipStream_t s = fs_rt().stream;
-    if (!add) FS_CHECK(A->val.zero(s));
     dbuf<double> kstore, mstore;
     coef_dev kc, mc;
     FS_CHECK(make_coef(form->mass, m->nc, mstore, &mc, "fs_assemble_matrix(mass)"));
     FS_REQUIRE(mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL,
                "fs_assemble_matrix: mass coefficient must be constant or per cell");
     const int grid = fs_grid_for(m->nc, FS_BLOCK, 8192);
-    if (A->bs == 1) {
+    if (A->bs == 1 && sp->inc_cell.p) {
+        // row-gather path: every SELL entry (padding included) is written exactly once, no memset
+        FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
+        FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
+        // LDS: one accumulator column per thread; fall to one wave per workgroup for very long rows
+        const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
+        const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
+        FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
+        const int wpb = bd / 64;
+        const int g = fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 16384);
+        if (add)
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+    } else if (A->bs == 1) {
+        FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
+        if (!add) FS_CHECK(A->val.zero(s));
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
         hipLaunchKernelGGL(k_assemble_p1_scalar, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, kc, mc, A->val.p);
     } else {
+        if (!add) FS_CHECK(A->val.zero(s));
         hipLaunchKernelGGL(k_assemble_p1_elasticity, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
     }
     FS_KERNEL_CHECK();
@@ -534,50 +637,43 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A || b, "fs_apply_dirichlet: both A and b are null");
     FS_REQUIRE(n == 0 || (dofs && vals), "fs_apply_dirichlet: null dof list");
+    FS_REQUIRE(n < (int64_t)INT32_MAX, "fs_apply_dirichlet: list too long");
     if (n == 0) return FS_OK;
     hipStream_t s = fs_rt().stream;
-    // later entries win on duplicates (DOLFIN applies BCs in list order)
-    std::vector<int32_t> h_dofs;
-    std::vector<double> h_vals;
-    {
-        std::unordered_map<int32_t, int64_t> last;
-        last.reserve((size_t)n * 2);
-        for (int64_t i = 0; i < n; ++i) last[dofs[i]] = i;
-        h_dofs.reserve(last.size());
-        h_vals.reserve(last.size());
-        for (int64_t i = 0; i < n; ++i)
-            if (last[dofs[i]] == i) {
-                h_dofs.push_back(dofs[i]);
-                h_vals.push_back(vals[i]);
-            }
+    const int64_t n_dofs = A ? A->space->n_dofs_local : b->d.n;
+    for (int64_t i = 0; i < n; ++i)
+        FS_REQUIRE(dofs[i] >= 0 && dofs[i] < n_dofs, "fs_apply_dirichlet: dof %d outside [0,%lld)", dofs[i], (long long)n_dofs);
+    FS_REQUIRE(!A || !b || b->d.n >= A->space->n_dofs_owned, "fs_apply_dirichlet: b shorter than the owned dofs");
+    // scratch: kept on the space when there is one (re-assembly every time step must not hipMalloc)
+    dbuf<uint8_t> flag_local;
+    dbuf<double> g_local;
+    dbuf<int32_t> idx_local;
+    dbuf<uint8_t>& flag = A ? A->space->bc_flag : flag_local;
+    dbuf<double>& g = A ? A->space->bc_g : g_local;
+    dbuf<int32_t>& idx = A ? A->space->bc_idx : idx_local;
+    if (flag.n != n_dofs) {
+        FS_CHECK(flag.alloc(n_dofs));
+        FS_CHECK(g.alloc(n_dofs));
+        FS_CHECK(idx.alloc(n_dofs));
     }
-    const int64_t nu = (int64_t)h_dofs.size();
     dbuf<int32_t> d_dofs;
     dbuf<double> d_vals;
-    FS_CHECK(d_dofs.alloc(nu));
-    FS_CHECK(d_vals.alloc(nu));
-    FS_CHECK(d_dofs.upload(h_dofs.data(), nu, s));
-    FS_CHECK(d_vals.upload(h_vals.data(), nu, s));
+    FS_CHECK(d_dofs.alloc(n));
+    FS_CHECK(d_vals.alloc(n));
+    FS_HIP(hipMemcpyAsync(d_dofs.p, dofs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    FS_HIP(hipMemcpyAsync(d_vals.p, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    FS_CHECK(flag.zero(s));
+    FS_HIP(hipMemsetAsync(idx.p, 0xff, (size_t)n_dofs * sizeof(int32_t), s));  // -1
+    hipLaunchKernelGGL(k_bc_last_index, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, d_dofs.p, n, idx.p);
+    hipLaunchKernelGGL(k_bc_scatter, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, n, idx.p, flag.p, g.p);
+    FS_KERNEL_CHECK();
     if (!A) {
-        hipLaunchKernelGGL(k_bc_vector, dim3(fs_grid_for(nu)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, nu, b->d.n, b->d.p);
+        hipLaunchKernelGGL(k_bc_vector, dim3(fs_grid_for(n_dofs)), dim3(FS_BLOCK), 0, s, flag.p, g.p, n_dofs, b->d.p);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
     fs_space_s* sp = A->space;
-    for (int64_t i = 0; i < nu; ++i)
-        FS_REQUIRE(h_dofs[i] >= 0 && h_dofs[i] < sp->n_dofs_local, "fs_apply_dirichlet: dof %d outside [0,%lld)", h_dofs[i], (long long)sp->n_dofs_local);
-    FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_apply_dirichlet: b shorter than the owned dofs");
-    dbuf<uint8_t>& flag = sp->bc_flag;
-    dbuf<double>& g = sp->bc_g;
-    if (flag.n != sp->n_dofs_local) {
-        FS_CHECK(flag.alloc(sp->n_dofs_local));
-        FS_CHECK(g.alloc(sp->n_dofs_local));
-    }
-    FS_CHECK(flag.zero(s));
-    FS_CHECK(g.zero(s));
-    hipLaunchKernelGGL(k_bc_scatter, dim3(fs_grid_for(nu)), dim3(FS_BLOCK), 0, s, d_dofs.p, d_vals.p, nu, flag.p, g.p);
-    FS_KERNEL_CHECK();
     const int grid = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
     double* bp = b ? b->d.p : nullptr;
     if (A->bs == 1)

@@ -136,11 +136,19 @@ struct fs_space_s {
     dbuf<int32_t> colidx;         // [nnz_nodes]
     dbuf<int64_t> slice_ptr;      // [n_slices+1] offsets into sell arrays (entries)
     dbuf<int32_t> sell_col;       // [sell_entries] node column, padding = own row
-    dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned
+    dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned (vector spaces)
+    // row-gather assembly tables (scalar spaces): the (cell, local vertex) incidences of every owned
+    // row, SELL-64 laid out like the matrix; inc_pos packs the 4 in-row positions of the cell's vertices
+    int64_t inc_entries = 0;
+    int inc_max = 0;              // most incidences of any row
+    dbuf<int64_t> inc_slice_ptr;  // [n_slices+1]
+    dbuf<int32_t> inc_cell;       // [inc_entries] cell*4 + local vertex, -1 = padding
+    dbuf<uint32_t> inc_pos;       // [inc_entries] 4 x uint8 positions
     fs_halo_plan halo;
     // Dirichlet scratch kept across calls (re-assembly every time step must not hipMalloc)
     dbuf<uint8_t> bc_flag;        // [n_dofs_local]
     dbuf<double> bc_g;            // [n_dofs_local]
+    dbuf<int32_t> bc_idx;         // [n_dofs_local] index of the last list entry naming the dof
 };
 
 struct fs_matrix_s {

@@ -159,7 +159,12 @@ __global__ void k_set_threshold(const double* __restrict__ bb, double rtol, doub
     }
 }
 
+// FUSED: every workgroup first sums the SpMV's per-WG partials itself (same fixed order as
+// k_sum_partials, so all workgroups obtain bit-identical gamma/delta/rho) - saves one launch per
+// iteration on a single GPU; with a communicator the sums come from the all-reduced `sums`.
+template <bool FUSED>
 __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int check_only,
+                                                        const double* __restrict__ partials, int npart,
                                                         const double* __restrict__ sums,
                                                         const double* __restrict__ ctrl, double* __restrict__ scal,
                                                         int* __restrict__ status, double* __restrict__ hist,
@@ -168,7 +173,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int
                                                         double* __restrict__ sv, double* __restrict__ x,
                                                         double* __restrict__ r) {
     if (status[0] != 0) return;
-    const double gamma = sums[0], delta = sums[1], rho = sums[2];
+    double gamma, delta, rho;
+    if (FUSED) {
+        __shared__ double lds4[4];
+        __shared__ double sh[3];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int i = threadIdx.x; i < npart; i += FS_BLOCK) {
+            a0 += partials[i];
+            a1 += partials[npart + i];
+            a2 += partials[2 * npart + i];
+        }
+        const double t0 = fs_block_sum(a0, lds4);
+        const double t1 = fs_block_sum(a1, lds4);
+        const double t2 = fs_block_sum(a2, lds4);
+        if (threadIdx.x == 0) { sh[0] = t0; sh[1] = t1; sh[2] = t2; }
+        __syncthreads();
+        gamma = sh[0]; delta = sh[1]; rho = sh[2];
+    } else {
+        gamma = sums[0]; delta = sums[1]; rho = sums[2];
+    }
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     if (leader) hist[iter] = rho;
     if (rho <= ctrl[0]) {  // every workgroup takes the same branch: inputs are identical
@@ -281,9 +304,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict_
 
 // ---- host side --------------------------------------------------------------------------------
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
-static int g_spmv_blocks = 2048;
+static int g_spmv_blocks = 1024;
 static int g_spmv_unroll = 4;
 static int g_cg_batch = 32;
+static int g_cg_fuse_sums = 1;
+static int g_update_blocks = 512;
 
 extern "C" int fs_set_option(const char* name, double value) {
     FS_REQUIRE(name, "fs_set_option: null name");
@@ -293,6 +318,11 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "spmv_unroll")) {
         FS_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "spmv_unroll must be 2, 4, 8 or 16");
         g_spmv_unroll = (int)value;
+    } else if (!strcmp(name, "cg_fuse_sums")) {
+        g_cg_fuse_sums = value != 0.0;
+    } else if (!strcmp(name, "update_blocks")) {
+        FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
+        g_update_blocks = (int)value;
     } else if (!strcmp(name, "cg_batch")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
         g_cg_batch = (int)value;
@@ -440,7 +470,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     krylov_ws& ws = g_ws;
     FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
     const int bs = A->bs;
-    const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, 2048);
+    const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
+    const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
     const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
     const int sgrid = spmv_grid(sp->n_slices);
     const auto t_begin = std::chrono::steady_clock::now();
@@ -500,10 +531,15 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
             launch_spmv<true>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
             if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
-            FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
-            if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-            hipLaunchKernelGGL(k_cg_update, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
+            if (fuse_sums) {
+                if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                hipLaunchKernelGGL(k_cg_update<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
+            } else {
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
+                FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
+                if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                hipLaunchKernelGGL(k_cg_update<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
+            }
             if (sample) {
                 FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
                 ++n_samples;

@@ -148,6 +148,84 @@ __global__ void k_slots(const int32_t* __restrict__ cells, int64_t nc, int64_t n
     }
 }
 
+// ---- row-gather incidence tables ----------------------------------------------------------------
+// key = (vertex << 32) | (cell*4 + local vertex) for every owned (cell, vertex) incidence
+__global__ void k_inc_keys(const int32_t* __restrict__ cells, int64_t n_inc, int64_t n_rows,
+                           uint64_t* __restrict__ keys) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; q < n_inc; q += stride) {
+        const int32_t v = cells[q];
+        keys[q] = v < n_rows ? (((uint64_t)(uint32_t)v << 32) | (uint64_t)q) : ~0ULL;
+    }
+}
+
+// one wavefront per slice: width = most incidences of a row in the slice
+__global__ void __launch_bounds__(FS_BLOCK) k_inc_width(const int32_t* __restrict__ inc_ptr, int64_t n_rows,
+                                                        int64_t n_slices, int64_t* __restrict__ slice_entries,
+                                                        int* __restrict__ max_cnt) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t r = s * FS_SLICE + lane;
+        int cnt = 0;
+        if (r < n_rows) cnt = inc_ptr[r + 1] - inc_ptr[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
+        if (lane == 0) {
+            slice_entries[s] = (int64_t)cnt * FS_SLICE;
+            atomicMax(max_cnt, cnt);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restrict__ keys,
+                                                       const int32_t* __restrict__ inc_ptr,
+                                                       const int32_t* __restrict__ cells,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ colidx, int64_t n_rows,
+                                                       int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                       int32_t* __restrict__ inc_cell,
+                                                       uint32_t* __restrict__ inc_pos, int* __restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t base = inc_slice_ptr[s];
+        const int width = (int)((inc_slice_ptr[s + 1] - base) >> 6);
+        const int64_t r = s * FS_SLICE + lane;
+        int32_t first = 0, cnt = 0, rs = 0, re = 0;
+        if (r < n_rows) {
+            first = inc_ptr[r];
+            cnt = inc_ptr[r + 1] - first;
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+        }
+        for (int j = 0; j < width; ++j) {
+            int32_t q = -1;
+            uint32_t packed = 0;
+            if (j < cnt) {
+                q = (int32_t)(keys[first + j] & 0xffffffffULL);
+                const int4 v4 = reinterpret_cast<const int4*>(cells)[q >> 2];
+                const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int32_t lo = rs, hi = re;
+                    while (lo < hi) {
+                        const int32_t mid = (lo + hi) >> 1;
+                        if (colidx[mid] < v[b]) lo = mid + 1; else hi = mid;
+                    }
+                    if (!(lo < re && colidx[lo] == v[b]) || lo - rs > 255) atomicAdd(err, 1);
+                    packed |= (uint32_t)((lo - rs) & 255) << (8 * b);
+                }
+            }
+            inc_cell[base + (int64_t)j * FS_SLICE + lane] = q;
+            inc_pos[base + (int64_t)j * FS_SLICE + lane] = packed;
+        }
+    }
+}
+
 // ---- API -----------------------------------------------------------------------------------
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
     FS_CHECK(fs_require_init());
@@ -263,8 +341,58 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
     FS_SP(sp->sell_col.alloc(sp->sell_entries));
     hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, sp->slice_ptr.p, sp->sell_col.p);
     FS_SP_HIP(hipGetLastError());
-    // 5. slot table
-    {
+    if (ncomp == 1 && sp->max_row <= 255) {
+        // 5a. scalar spaces: row-gather incidence tables (deterministic, atomic-free assembly)
+        const int64_t n_inc = 4 * nc;
+        FS_REQUIRE(n_inc < (int64_t)INT32_MAX, "fs_space_create: cell-vertex incidences exceed int32");
+        dbuf<uint64_t> ka, kb;
+        dbuf<int32_t> inc_ptr;
+        dbuf<int64_t> entries;
+        dbuf<int> d_max, d_err;
+        FS_SP(ka.alloc(n_inc));
+        FS_SP(kb.alloc(n_inc));
+        FS_SP(inc_ptr.alloc(n_rows + 1));
+        FS_SP(entries.alloc(n_slices + 1));
+        FS_SP(entries.zero(s));
+        FS_SP(d_max.alloc(1));
+        FS_SP(d_max.zero(s));
+        FS_SP(d_err.alloc(1));
+        FS_SP(d_err.zero(s));
+        hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, n_inc, n_rows, ka.p);
+        FS_SP_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka.p, kb.p, (int)n_inc, 0, 64, s));
+        size_t tmp2 = 0;
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, entries.p, entries.p, (int)(n_slices + 1), s));
+        if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+        dbuf<char> tmp;
+        FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
+        size_t tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_inc, 0, 64, s));
+        // rows of other ranks (key ~0) sort to the end: count of valid keys = first index of the sentinel row
+        hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, kb.p, n_inc, n_rows, inc_ptr.p);
+        FS_SP(sp->inc_slice_ptr.alloc(n_slices + 1));
+        hipLaunchKernelGGL(k_inc_width, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, inc_ptr.p, n_rows, n_slices, entries.p, d_max.p);
+        FS_SP_HIP(hipGetLastError());
+        tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, entries.p, sp->inc_slice_ptr.p, (int)(n_slices + 1), s));
+        int64_t total = 0;
+        FS_SP_HIP(hipMemcpyAsync(&total, sp->inc_slice_ptr.p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        FS_SP(d_max.download(&sp->inc_max, 1, s));
+        sp->inc_entries = total;
+        FS_SP(sp->inc_cell.alloc(total));
+        FS_SP(sp->inc_pos.alloc(total));
+        hipLaunchKernelGGL(k_inc_fill, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, kb.p, inc_ptr.p, mesh->cells.p, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, d_err.p);
+        FS_SP_HIP(hipGetLastError());
+        int h_err = 0;
+        FS_SP(d_err.download(&h_err, 1, s));
+        if (h_err != 0) {
+            fs_set_error("fs_space_create: internal error, %d incidences missing from the sparsity pattern", h_err);
+            delete sp;
+            return FS_ERR_INVALID;
+        }
+    } else {
+        // 5b. vector spaces: slot table for the scatter assembly
         dbuf<int> d_err;
         FS_SP(d_err.alloc(1));
         FS_SP(d_err.zero(s));

@@ -54,7 +54,9 @@ int fs_device_synchronize(void);
 const char* fs_last_error(void);
 const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
- * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll). */
+ * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll),
+ * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
+ * "update_blocks" (grid of the fused vector-update kernel). */
 int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
 int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
