@@ -113,6 +113,8 @@ class DeviceSpace(_Handle):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.load().fs_space_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "fs_space_info")
         self.n_local, self.n_owned, self.nnz, self.sell_entries = a.value, b.value, c.value, d.value
+        L.check(L.load().fs_space_format_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "fs_space_format_info")
+        self.n_slices, self.n_dia_slices, self.spmv_matrix_bytes = a.value, b.value, c.value
 
     def set_halo(self, neighbors, send_lists, recv_counts):
         """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour."""

@@ -298,9 +298,9 @@ __global__ void k_facet_vector(const double* __restrict__ xyz4, const int32_t* _
 }
 
 __global__ void k_facet_matrix(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
-                               const double* __restrict__ h, int64_t n_rows, const int32_t* __restrict__ rowptr,
-                               const int32_t* __restrict__ colidx, const int64_t* __restrict__ slice_ptr,
-                               double* __restrict__ val, int* __restrict__ err) {
+                               const double* __restrict__ h, int64_t n_rows, const int32_t* __restrict__ sell_col,
+                               const int64_t* __restrict__ slice_ptr, double* __restrict__ val,
+                               int* __restrict__ err) {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; f < nf; f += stride) {
@@ -309,15 +309,14 @@ __global__ void k_facet_matrix(const double* __restrict__ xyz4, const int32_t* _
         for (int a = 0; a < 3; ++a) {
             const int32_t row = v[a];
             if (row >= n_rows) continue;
-            const int32_t start = rowptr[row], end = rowptr[row + 1];
-            const int64_t base = slice_ptr[row >> 6] + (row & 63);
+            const int64_t sp0 = slice_ptr[row >> 6];
+            const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            const int64_t base = sp0 + (row & 63);
             for (int b = 0; b < 3; ++b) {
-                int32_t lo = start, hi = end;
-                while (lo < hi) {
-                    const int32_t mid = (lo + hi) >> 1;
-                    if (colidx[mid] < v[b]) lo = mid + 1; else hi = mid;
-                }
-                if (lo < end && colidx[lo] == v[b]) atomicAdd(&val[base + (int64_t)(lo - start) * FS_SLICE], (a == b ? 2.0 : 1.0) * w);
+                int k = -1;
+                for (int kk = 0; kk < width; ++kk)
+                    if (sell_col[base + (int64_t)kk * FS_SLICE] == v[b]) { k = kk; break; }
+                if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], (a == b ? 2.0 : 1.0) * w);
                 else atomicAdd(err, 1);
             }
         }
@@ -354,12 +353,12 @@ __global__ void k_bc_vector(const uint8_t* __restrict__ flag, const double* __re
         if (flag[i]) b[i] = g[i];
 }
 
-// one wavefront per SELL slice, lane = node row; rows of constrained dofs become identity,
-// (symmetric) constrained columns are folded into b and zeroed.
+// one wavefront per slice, lane = node row; rows of constrained dofs become identity,
+// (symmetric) constrained columns are folded into b and zeroed.  Non-structural entries (negative
+// column) are left untouched: they are zero and stay zero.
 template <int BS>
 __global__ void __launch_bounds__(FS_BLOCK) k_dirichlet_sell(int64_t n_rows, int64_t n_slices,
                                                              const int64_t* __restrict__ slice_ptr,
-                                                             const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ sell_col,
                                                              double* __restrict__ val, int64_t plane,
                                                              const uint8_t* __restrict__ flag,
@@ -372,15 +371,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dirichlet_sell(int64_t n_rows, int
         const int64_t r = s * FS_SLICE + lane;
         if (r >= n_rows) continue;
         const int64_t base = slice_ptr[s] + lane;
-        const int len = rowptr[r + 1] - rowptr[r];
+        const int width = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
             const int64_t dofr = r * BS + i;
             const bool fr = flag[dofr] != 0;
             double bacc = 0.0;
-            for (int k = 0; k < len; ++k) {
+            for (int k = 0; k < width; ++k) {
                 const int64_t e = base + (int64_t)k * FS_SLICE;
                 const int32_t c = sell_col[e];
+                if (c < 0) continue;
 #pragma unroll
                 for (int j = 0; j < BS; ++j) {
                     const int64_t idx = (int64_t)(i * BS + j) * plane + e;
@@ -409,18 +409,24 @@ __global__ void k_export_csr(int64_t n_rows, const int64_t* __restrict__ slice_p
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; r < n_rows; r += stride) {
-        const int64_t base = slice_ptr[r >> 6] + (r & 63);
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
         const int32_t start = rowptr[r];
         const int len = rowptr[r + 1] - start;
         for (int i = 0; i < BS; ++i) {
             const int64_t o = (int64_t)BS * BS * start + (int64_t)i * BS * len;
             if (out_rowptr) out_rowptr[r * BS + i] = (int32_t)o;
-            for (int k = 0; k < len; ++k) {
+            int kk = 0;  // structural entries appear in ascending column order in both storage forms
+            for (int k = 0; k < width; ++k) {
                 const int64_t e = base + (int64_t)k * FS_SLICE;
+                const int32_t c = sell_col[e];
+                if (c < 0) continue;
                 for (int j = 0; j < BS; ++j) {
-                    if (out_col) out_col[o + (int64_t)k * BS + j] = sell_col[e] * BS + j;
-                    if (out_val) out_val[o + (int64_t)k * BS + j] = val[(int64_t)(i * BS + j) * plane + e];
+                    if (out_col) out_col[o + (int64_t)kk * BS + j] = c * BS + j;
+                    if (out_val) out_val[o + (int64_t)kk * BS + j] = val[(int64_t)(i * BS + j) * plane + e];
                 }
+                ++kk;
             }
         }
         if (r == n_rows - 1 && out_rowptr) out_rowptr[n_rows * BS] = (int32_t)((int64_t)BS * BS * rowptr[n_rows]);
@@ -624,7 +630,7 @@ extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const i
     FS_CHECK(d_err.zero(s));
     FS_CHECK(d_tri.upload(tri, 3 * n_facets, s));
     FS_CHECK(d_h.upload(h, n_facets, s));
-    hipLaunchKernelGGL(k_facet_matrix, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, sp->mesh->xyz.p, d_tri.p, n_facets, d_h.p, sp->n_nodes_owned, sp->rowptr.p, sp->colidx.p, sp->slice_ptr.p, A->val.p, d_err.p);
+    hipLaunchKernelGGL(k_facet_matrix, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, sp->mesh->xyz.p, d_tri.p, n_facets, d_h.p, sp->n_nodes_owned, sp->sell_col.p, sp->slice_ptr.p, A->val.p, d_err.p);
     FS_KERNEL_CHECK();
     int h_err = 0;
     FS_CHECK(d_err.download(&h_err, 1, s));
@@ -677,9 +683,9 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
     const int grid = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
     double* bp = b ? b->d.p : nullptr;
     if (A->bs == 1)
-        hipLaunchKernelGGL(k_dirichlet_sell<1>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+        hipLaunchKernelGGL(k_dirichlet_sell<1>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     else
-        hipLaunchKernelGGL(k_dirichlet_sell<3>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+        hipLaunchKernelGGL(k_dirichlet_sell<3>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -127,15 +127,24 @@ struct fs_space_s {
     int ncomp = 1;
     int64_t n_nodes_local = 0, n_nodes_owned = 0;  // node level
     int64_t n_dofs_local = 0, n_dofs_owned = 0;    // = nodes * ncomp
-    // node-level sparsity: CSR + SELL-64
+    // node-level sparsity: CSR + hybrid SELL-64 / per-slice DIA
     int64_t nnz_nodes = 0;        // node-pair entries
     int64_t n_slices = 0;
-    int64_t sell_entries = 0;     // padded node-pair entries (sum width*64)
-    int max_row = 0;
+    int64_t n_dia_slices = 0;     // slices stored in diagonal (offset) form
+    int64_t dia_entries = 0;      // stored entries that belong to DIA slices
+    int64_t sell_entries = 0;     // stored node-pair entries (sum width*64), padding included
+    int max_row = 0;              // largest slice width (storage positions per row)
     dbuf<int32_t> rowptr;         // [n_nodes_owned+1]
     dbuf<int32_t> colidx;         // [nnz_nodes]
-    dbuf<int64_t> slice_ptr;      // [n_slices+1] offsets into sell arrays (entries)
-    dbuf<int32_t> sell_col;       // [sell_entries] node column, padding = own row
+    dbuf<int64_t> slice_ptr;      // [n_slices+1] offsets into the value/column arrays (entries)
+    // column of every stored entry; NEGATIVE = not a structural entry (padding), value ~c is a safe
+    // column to read.  Always present (assembly tables, Dirichlet, export); the SpMV reads it only
+    // for SELL slices.
+    dbuf<int32_t> sell_col;       // [sell_entries]
+    // DIA slices: all 64 rows share one sorted list of (col - row) offsets, so the SpMV needs no
+    // per-entry column index: dia_ptr[s] >= 0 indexes dia_off, -1 = SELL slice
+    dbuf<int32_t> dia_ptr;        // [n_slices]
+    dbuf<int32_t> dia_off;        // [sum of offsets over DIA slices]
     dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned (vector spaces)
     // row-gather assembly tables (scalar spaces): the (cell, local vertex) incidences of every owned
     // row, SELL-64 laid out like the matrix; inc_pos packs the 4 in-row positions of the cell's vertices
@@ -160,6 +169,8 @@ struct fs_matrix_s {
 struct fs_vector_s {
     dbuf<double> d;
 };
+
+__host__ __device__ static inline int32_t fs_col_decode(int32_t c) { return c < 0 ? ~c : c; }
 
 // grid for a grid-stride elementwise / per-row kernel
 static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int cap = 2048) {

@@ -41,9 +41,11 @@ __device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
 
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
 template <int BS, bool DOTS, int UNROLL>
-__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_slices,
+__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                         const int64_t* __restrict__ slice_ptr,
                                                         const int32_t* __restrict__ sell_col,
+                                                        const int32_t* __restrict__ dia_ptr,
+                                                        const int32_t* __restrict__ dia_off,
                                                         const double* __restrict__ val, int64_t plane,
                                                         const double* __restrict__ x, double* __restrict__ y,
                                                         const double* __restrict__ rvec,
@@ -57,79 +59,94 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
     const int wave = threadIdx.x >> 6;
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
     const int64_t n_chunks = (n_slices + 3) >> 2;
+    const int32_t cmax = (int32_t)(n_cols - 1);
     for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
         const int64_t s = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
         if (s >= n_slices) continue;
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int32_t dp = dia_ptr[s];              // wave-uniform: >= 0 selects the DIA form
         const int64_t r = s * FS_SLICE + lane;
         const bool live = r < n_rows;
         const int32_t* __restrict__ cp = sell_col + base + lane;
         const double* __restrict__ vp = val + base + lane;
-        if (BS == 1) {
-            // operands of the fused dots are requested up front so their latency hides
-            // under the row loop instead of serialising after it
-            double zi = 0.0, ri = 0.0;
+        double zi[BS], ri[BS], acc[BS];
+        // operands of the fused dots are requested up front so their latency hides under the row loop
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            zi[i] = 0.0;
+            ri[i] = 0.0;
+            acc[i] = 0.0;
             if (DOTS && live) {
-                zi = x[r];
-                ri = rvec[r];
+                zi[i] = x[r * BS + i];
+                ri[i] = rvec[r * BS + i];
             }
-            double acc = 0.0;
+        }
+        if (dp >= 0) {
+            // DIA slice: column = row + offset[k] (one scalar per entry row), so the x gather of the wave
+            // is one contiguous 512-B read and no column index is streamed.  Entries a row does not have
+            // hold the value 0 and read a clamped, valid address.
+            const int32_t* __restrict__ op = dia_off + dp;
             int k = 0;
-            for (; k + UNROLL <= width; k += UNROLL) {
-                int32_t c[UNROLL];
-                double v[UNROLL], xv[UNROLL];
+            if (BS == 1) {
+                for (; k + UNROLL <= width; k += UNROLL) {
+                    double v[UNROLL], xv[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) c[u] = cp[(int64_t)(k + u) * FS_SLICE];
+                    for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+                    for (int u = 0; u < UNROLL; ++u) {
+                        int32_t c = (int32_t)r + op[k + u];
+                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
+                        xv[u] = x[c];
+                    }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) acc += v[u] * xv[u];
+                    for (int u = 0; u < UNROLL; ++u) acc[0] += v[u] * xv[u];
+                }
             }
-            for (; k < width; ++k) acc += vp[(int64_t)k * FS_SLICE] * x[cp[(int64_t)k * FS_SLICE]];
-            if (live) {
-                y[r] = acc;
-                if (DOTS) {
-                    d_rz += ri * zi;
-                    d_wz += acc * zi;
-                    d_rr += ri * ri;
+            for (; k < width; ++k) {
+                int64_t c = r + op[k];
+                c = c < 0 ? 0 : (c > cmax ? cmax : c);
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    const double xj = x[c * BS + j];
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xj;
                 }
             }
         } else {
-            double zi[BS], ri[BS];
+            int k = 0;
+            if (BS == 1) {
+                for (; k + UNROLL <= width; k += UNROLL) {
+                    int32_t c[UNROLL];
+                    double v[UNROLL], xv[UNROLL];
 #pragma unroll
-            for (int i = 0; i < BS; ++i) {
-                zi[i] = 0.0;
-                ri[i] = 0.0;
-                if (DOTS && live) {
-                    zi[i] = x[r * BS + i];
-                    ri[i] = rvec[r * BS + i];
+                    for (int u = 0; u < UNROLL; ++u) c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) acc[0] += v[u] * xv[u];
                 }
             }
-            double acc[BS];
+            for (; k < width; ++k) {
+                const int64_t c = fs_col_decode(cp[(int64_t)k * FS_SLICE]);
 #pragma unroll
-            for (int i = 0; i < BS; ++i) acc[i] = 0.0;
-            for (int k = 0; k < width; ++k) {
-                const int64_t c = cp[(int64_t)k * FS_SLICE];
-                double xv[BS];
+                for (int j = 0; j < BS; ++j) {
+                    const double xj = x[c * BS + j];
 #pragma unroll
-                for (int j = 0; j < BS; ++j) xv[j] = x[c * BS + j];
-#pragma unroll
-                for (int i = 0; i < BS; ++i)
-#pragma unroll
-                    for (int j = 0; j < BS; ++j) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xv[j];
+                    for (int i = 0; i < BS; ++i) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xj;
+                }
             }
-            if (live) {
+        }
+        if (live) {
 #pragma unroll
-                for (int i = 0; i < BS; ++i) {
-                    y[r * BS + i] = acc[i];
-                    if (DOTS) {
-                        d_rz += ri[i] * zi[i];
-                        d_wz += acc[i] * zi[i];
-                        d_rr += ri[i] * ri[i];
-                    }
+            for (int i = 0; i < BS; ++i) {
+                y[r * BS + i] = acc[i];
+                if (DOTS) {
+                    d_rz += ri[i] * zi[i];
+                    d_wz += acc[i] * zi[i];
+                    d_rr += ri[i] * ri[i];
                 }
             }
         }
@@ -255,16 +272,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int
 
 template <int BS>
 __global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
-                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sell_col,
-                               const double* __restrict__ val, int64_t plane, int jacobi,
-                               double* __restrict__ dinv, int* __restrict__ err) {
+                               const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
+                               int jacobi, double* __restrict__ dinv, int* __restrict__ err) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; r < n_rows; r += stride) {
-        const int64_t base = slice_ptr[r >> 6] + (r & 63);
-        const int len = rowptr[r + 1] - rowptr[r];
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
         int kd = -1;
-        for (int k = 0; k < len; ++k)
+        for (int k = 0; k < width; ++k)
             if (sell_col[base + (int64_t)k * FS_SLICE] == r) { kd = k; break; }
         for (int i = 0; i < BS; ++i) {
             double d = 1.0;
@@ -345,7 +362,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
                         const int* status, hipStream_t s) {
     fs_space_s* sp = A->space;
     const int grid = spmv_grid(sp->n_slices);
-#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status
     if (A->bs == 1) {
         switch (g_spmv_unroll) {
             case 2: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 2>), FS_SPMV_ARGS); break;
@@ -354,7 +371,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             default: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS); break;
         }
     } else {
-        hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 1>), FS_SPMV_ARGS);
+        hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
     }
 #undef FS_SPMV_ARGS
 }
@@ -483,9 +500,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_CHECK(d_err.zero(s));
         const int g = fs_grid_for(sp->n_nodes_owned);
         if (bs == 1)
-            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
         else
-            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
         FS_KERNEL_CHECK();
         int h_err = 0;
         FS_CHECK(d_err.download(&h_err, 1, s));

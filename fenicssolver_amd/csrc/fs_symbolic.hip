@@ -9,6 +9,7 @@
 //   numeric assembly is a pure scatter with no searching.
 #include "fs_common.h"
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 // ---- keys ------------------------------------------------------------------------------
 // 12 directed pairs per tet (a != b) + one diagonal key per owned row.
@@ -62,30 +63,82 @@ __global__ void k_rowptr(const uint64_t* __restrict__ keys, int64_t nnz, int64_t
     }
 }
 
-// one wavefront per slice: width = max row length in the slice
-__global__ void __launch_bounds__(FS_BLOCK) k_slice_width(const int32_t* __restrict__ rowptr, int64_t n_rows,
-                                                          int64_t n_slices, int64_t* __restrict__ slice_entries,
-                                                          int* __restrict__ max_row) {
+#define FS_DIA_CAP 48  // most distinct offsets a DIA slice may have
+
+// One wavefront per slice.  Computes the longest row and the sorted set of distinct (col - row)
+// offsets used by the 64 rows (each row's columns are sorted, so a per-lane cursor walks them).
+// A slice is stored in DIA form when that set is small and costs fewer bytes than SELL:
+// nd*8 B/row (values only) against len*12 B/row (values + 4-B columns).
+__global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ colidx, int64_t n_rows,
+                                                            int64_t n_slices, int allow_dia,
+                                                            int64_t* __restrict__ slice_entries,
+                                                            int32_t* __restrict__ dia_cnt,
+                                                            int32_t* __restrict__ tmp_off, int* __restrict__ max_w,
+                                                            int* __restrict__ n_dia) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (; s < n_slices; s += stride) {
         const int64_t r = s * FS_SLICE + lane;
-        int len = 0;
-        if (r < n_rows) len = rowptr[r + 1] - rowptr[r];
+        int32_t start = 0, len = 0;
+        if (r < n_rows) {
+            start = rowptr[r];
+            len = rowptr[r + 1] - start;
+        }
+        int maxlen = len;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+        for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+        int nd = 0;
+        if (allow_dia) {
+            int cur = 0;                       // cursor into this lane's row
+            const int64_t BIG = (int64_t)1 << 40;
+            while (true) {
+                int64_t mine = cur < len ? (int64_t)colidx[start + cur] - r : BIG;
+                int64_t m = mine;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int64_t o = __shfl_xor(m, off, 64);
+                    m = o < m ? o : m;
+                }
+                if (m == BIG) break;
+                if (nd < FS_DIA_CAP && lane == 0) tmp_off[s * FS_DIA_CAP + nd] = (int32_t)m;
+                ++nd;
+                if (mine == m) ++cur;
+                if (nd > FS_DIA_CAP) break;
+            }
+        }
+        const bool dia = allow_dia && nd > 0 && nd <= FS_DIA_CAP && nd <= 255 && (int64_t)nd * 8 * 10 <= (int64_t)maxlen * 12 * 9;
+        const int width = dia ? nd : maxlen;
         if (lane == 0) {
-            slice_entries[s] = (int64_t)len * FS_SLICE;
-            atomicMax(max_row, len);
+            slice_entries[s] = (int64_t)width * FS_SLICE;
+            dia_cnt[s] = dia ? nd : 0;
+            atomicMax(max_w, width);
+            if (dia) atomicAdd(n_dia, 1);
         }
     }
 }
 
-// sell_col[slice_ptr[s] + k*64 + lane] = column k of row, padding = the row itself
+__global__ void k_dia_ptr(const int32_t* __restrict__ dia_cnt, const int32_t* __restrict__ dia_scan, int64_t n_slices,
+                          const int32_t* __restrict__ tmp_off, int32_t* __restrict__ dia_ptr,
+                          int32_t* __restrict__ dia_off) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < n_slices; s += stride) {
+        const int nd = dia_cnt[s];
+        dia_ptr[s] = nd > 0 ? dia_scan[s] : -1;
+        for (int k = 0; k < nd; ++k) dia_off[dia_scan[s] + k] = tmp_off[s * FS_DIA_CAP + k];
+    }
+}
+
+// column of every stored entry.  SELL slice: entry k of the row, padding = ~row.  DIA slice:
+// row + offset k when the row really has that column, otherwise ~clamp(row + offset).
 __global__ void __launch_bounds__(FS_BLOCK) k_fill_sell(const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx, int64_t n_rows,
-                                                        int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+                                                        int64_t n_cols, int64_t n_slices,
+                                                        const int64_t* __restrict__ slice_ptr,
+                                                        const int32_t* __restrict__ dia_ptr,
+                                                        const int32_t* __restrict__ dia_off,
                                                         int32_t* __restrict__ sell_col) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -94,22 +147,45 @@ __global__ void __launch_bounds__(FS_BLOCK) k_fill_sell(const int32_t* __restric
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t r = s * FS_SLICE + lane;
-        int64_t start = 0;
-        int len = 0;
-        int32_t self = (int32_t)(r < n_rows ? r : n_rows - 1);
+        int32_t start = 0, len = 0;
         if (r < n_rows) {
             start = rowptr[r];
-            len = rowptr[r + 1] - (int32_t)start;
+            len = rowptr[r + 1] - start;
         }
-        for (int k = 0; k < width; ++k) sell_col[base + (int64_t)k * FS_SLICE + lane] = k < len ? colidx[start + k] : self;
+        const int32_t dp = dia_ptr[s];
+        if (dp < 0) {
+            const int32_t self = (int32_t)(r < n_rows ? r : n_rows - 1);
+            for (int k = 0; k < width; ++k)
+                sell_col[base + (int64_t)k * FS_SLICE + lane] = k < len ? colidx[start + k] : ~self;
+        } else {
+            int cur = 0;
+            for (int k = 0; k < width; ++k) {
+                int64_t c = r + (int64_t)dia_off[dp + k];
+                bool structural = false;
+                if (cur < len && (int64_t)colidx[start + cur] == c) {
+                    structural = true;
+                    ++cur;
+                }
+                if (c < 0) c = 0;
+                if (c > n_cols - 1) c = n_cols - 1;
+                sell_col[base + (int64_t)k * FS_SLICE + lane] = structural ? (int32_t)c : ~(int32_t)c;
+            }
+        }
     }
 }
 
-// slots[(a*4+b)*nc + c] = SELL entry of (cells[c][a], cells[c][b]) or -1 when the row is not owned
+// storage position of column `target` in the row of `lane` of the slice starting at `base`, -1 if absent
+__device__ __forceinline__ int fs_find_pos(const int32_t* __restrict__ sell_col, int64_t base_lane, int width,
+                                           int32_t target) {
+    for (int k = 0; k < width; ++k)
+        if (sell_col[base_lane + (int64_t)k * FS_SLICE] == target) return k;
+    return -1;
+}
+
+// slots[(a*4+b)*nc + c] = stored entry of (cells[c][a], cells[c][b]) or -1 when the row is not owned
 __global__ void k_slots(const int32_t* __restrict__ cells, int64_t nc, int64_t n_rows,
-                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                        const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ slots,
-                        int* __restrict__ err) {
+                        const int32_t* __restrict__ sell_col, const int64_t* __restrict__ slice_ptr,
+                        int32_t* __restrict__ slots, int* __restrict__ err) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
@@ -118,29 +194,21 @@ __global__ void k_slots(const int32_t* __restrict__ cells, int64_t nc, int64_t n
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int32_t row = v[a];
-            int32_t start = 0, end = 0;
-            int64_t base = 0;
             const bool owned = row < n_rows;
+            int64_t base = 0;
+            int width = 0;
             if (owned) {
-                start = rowptr[row];
-                end = rowptr[row + 1];
-                base = slice_ptr[row >> 6] + (row & 63);
+                const int64_t sp0 = slice_ptr[row >> 6];
+                width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+                base = sp0 + (row & 63);
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 int32_t slot = -1;
                 if (owned) {
-                    int32_t lo = start, hi = end;
-                    const int32_t target = v[b];
-                    while (lo < hi) {
-                        int32_t mid = (lo + hi) >> 1;
-                        if (colidx[mid] < target) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < end && colidx[lo] == target) {
-                        slot = (int32_t)(base + (int64_t)(lo - start) * FS_SLICE);
-                    } else {
-                        atomicAdd(err, 1);
-                    }
+                    const int k = fs_find_pos(sell_col, base, width, v[b]);
+                    if (k >= 0) slot = (int32_t)(base + (int64_t)k * FS_SLICE);
+                    else atomicAdd(err, 1);
                 }
                 slots[(int64_t)(a * 4 + b) * nc + c] = slot;
             }
@@ -183,8 +251,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_width(const int32_t* __restric
 __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restrict__ keys,
                                                        const int32_t* __restrict__ inc_ptr,
                                                        const int32_t* __restrict__ cells,
-                                                       const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ colidx, int64_t n_rows,
+                                                       const int32_t* __restrict__ sell_col,
+                                                       const int64_t* __restrict__ slice_ptr, int64_t n_rows,
                                                        int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
                                                        int32_t* __restrict__ inc_cell,
                                                        uint32_t* __restrict__ inc_pos, int* __restrict__ err) {
@@ -194,13 +262,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
     for (; s < n_slices; s += stride) {
         const int64_t base = inc_slice_ptr[s];
         const int width = (int)((inc_slice_ptr[s + 1] - base) >> 6);
+        const int64_t mbase = slice_ptr[s] + lane;
+        const int mwidth = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
         const int64_t r = s * FS_SLICE + lane;
-        int32_t first = 0, cnt = 0, rs = 0, re = 0;
+        int32_t first = 0, cnt = 0;
         if (r < n_rows) {
             first = inc_ptr[r];
             cnt = inc_ptr[r + 1] - first;
-            rs = rowptr[r];
-            re = rowptr[r + 1];
         }
         for (int j = 0; j < width; ++j) {
             int32_t q = -1;
@@ -211,13 +279,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
                 const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    int32_t lo = rs, hi = re;
-                    while (lo < hi) {
-                        const int32_t mid = (lo + hi) >> 1;
-                        if (colidx[mid] < v[b]) lo = mid + 1; else hi = mid;
-                    }
-                    if (!(lo < re && colidx[lo] == v[b]) || lo - rs > 255) atomicAdd(err, 1);
-                    packed |= (uint32_t)((lo - rs) & 255) << (8 * b);
+                    const int k = fs_find_pos(sell_col, mbase, mwidth, v[b]);
+                    if (k < 0 || k > 255) atomicAdd(err, 1);
+                    packed |= (uint32_t)(k & 255) << (8 * b);
                 }
             }
             inc_cell[base + (int64_t)j * FS_SLICE + lane] = q;
@@ -310,36 +374,61 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP_HIP(hipGetLastError());
         FS_SP_HIP(hipStreamSynchronize(s));
     }
-    // 4. SELL-64
+    // 4. hybrid SELL-64 / DIA storage
     const int64_t n_slices = (n_rows + FS_SLICE - 1) / FS_SLICE;
     sp->n_slices = n_slices;
     {
         dbuf<int64_t> entries;
-        dbuf<int> d_max;
+        dbuf<int32_t> dia_cnt, dia_scan, tmp_off;
+        dbuf<int> d_max, d_ndia;
         FS_SP(entries.alloc(n_slices + 1));
         FS_SP(entries.zero(s));
+        FS_SP(dia_cnt.alloc(n_slices + 1));
+        FS_SP(dia_cnt.zero(s));
+        FS_SP(dia_scan.alloc(n_slices + 1));
+        FS_SP(tmp_off.alloc(n_slices * FS_DIA_CAP));
         FS_SP(d_max.alloc(1));
         FS_SP(d_max.zero(s));
+        FS_SP(d_ndia.alloc(1));
+        FS_SP(d_ndia.zero(s));
         FS_SP(sp->slice_ptr.alloc(n_slices + 1));
-        hipLaunchKernelGGL(k_slice_width, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, n_rows, n_slices, entries.p, d_max.p);
+        FS_SP(sp->dia_ptr.alloc(n_slices));
+        const char* env = getenv("FS_DISABLE_DIA");
+        const int allow_dia = !(env && *env && *env != '0');
+        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, d_max.p, d_ndia.p);
         FS_SP_HIP(hipGetLastError());
-        size_t tmp_bytes = 0;
+        size_t tmp_bytes = 0, t2 = 0;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
+        if (t2 > tmp_bytes) tmp_bytes = t2;
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
-        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
+        size_t tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
+        tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
         int64_t total = 0;
+        int32_t total_off = 0;
+        int h_ndia = 0;
         FS_SP_HIP(hipMemcpyAsync(&total, sp->slice_ptr.p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        FS_SP_HIP(hipMemcpyAsync(&total_off, dia_scan.p + n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        FS_SP(d_ndia.download(&h_ndia, 1, s));
         FS_SP(d_max.download(&sp->max_row, 1, s));
         sp->sell_entries = total;
+        sp->n_dia_slices = h_ndia;
+        sp->dia_entries = (int64_t)total_off * FS_SLICE;
+        FS_SP(sp->dia_off.alloc(total_off > 0 ? total_off : 1));
+        hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, sp->dia_ptr.p, sp->dia_off.p);
+        FS_SP_HIP(hipGetLastError());
+        FS_SP_HIP(hipStreamSynchronize(s));
     }
     if (sp->sell_entries >= (int64_t)INT32_MAX) {
-        fs_set_error("fs_space_create: SELL storage of %lld entries exceeds int32 slot indexing", (long long)sp->sell_entries);
+        fs_set_error("fs_space_create: storage of %lld entries exceeds int32 slot indexing", (long long)sp->sell_entries);
         delete sp;
         return FS_ERR_UNSUPPORTED;
     }
     FS_SP(sp->sell_col.alloc(sp->sell_entries));
-    hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, sp->slice_ptr.p, sp->sell_col.p);
+    hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, sp->n_nodes_local, n_slices, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, sp->sell_col.p);
     FS_SP_HIP(hipGetLastError());
     if (ncomp == 1 && sp->max_row <= 255) {
         // 5a. scalar spaces: row-gather incidence tables (deterministic, atomic-free assembly)
@@ -382,7 +471,7 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         sp->inc_entries = total;
         FS_SP(sp->inc_cell.alloc(total));
         FS_SP(sp->inc_pos.alloc(total));
-        hipLaunchKernelGGL(k_inc_fill, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, kb.p, inc_ptr.p, mesh->cells.p, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, d_err.p);
+        hipLaunchKernelGGL(k_inc_fill, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, kb.p, inc_ptr.p, mesh->cells.p, sp->sell_col.p, sp->slice_ptr.p, n_rows, n_slices, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, d_err.p);
         FS_SP_HIP(hipGetLastError());
         int h_err = 0;
         FS_SP(d_err.download(&h_err, 1, s));
@@ -397,7 +486,7 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP(d_err.alloc(1));
         FS_SP(d_err.zero(s));
         FS_SP(sp->slots.alloc(16 * nc));
-        hipLaunchKernelGGL(k_slots, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, n_rows, sp->rowptr.p, sp->colidx.p, sp->slice_ptr.p, sp->slots.p, d_err.p);
+        hipLaunchKernelGGL(k_slots, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, n_rows, sp->sell_col.p, sp->slice_ptr.p, sp->slots.p, d_err.p);
         FS_SP_HIP(hipGetLastError());
         int h_err = 0;
         FS_SP(d_err.download(&h_err, 1, s));
@@ -425,5 +514,18 @@ extern "C" int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n
 
 extern "C" int fs_space_destroy(fs_space_t space) {
     delete space;
+    return FS_OK;
+}
+
+extern "C" int fs_space_format_info(fs_space_t space, int64_t* n_slices, int64_t* n_dia_slices, int64_t* spmv_bytes) {
+    FS_REQUIRE(space, "fs_space_format_info: null space");
+    if (n_slices) *n_slices = space->n_slices;
+    if (n_dia_slices) *n_dia_slices = space->n_dia_slices;
+    if (spmv_bytes) {
+        // bytes the SpMV actually streams for the matrix: 8 B per stored value (x block) + 4 B per stored
+        // column of SELL slices (DIA slices read one offset per entry row, negligible)
+        const int64_t bs2 = (int64_t)space->ncomp * space->ncomp;
+        *spmv_bytes = space->sell_entries * bs2 * 8 + (space->sell_entries - space->dia_entries) * 4;
+    }
     return FS_OK;
 }

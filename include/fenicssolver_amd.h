@@ -94,6 +94,9 @@ int fs_mesh_destroy(fs_mesh_t mesh);
 int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
 int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
                   int64_t* sell_entries);
+/* Storage form chosen per 64-row slice: SELL (values + 4-B columns) or DIA (values only, the
+ * 64 rows share one list of column offsets).  spmv_bytes = matrix bytes one SpMV streams. */
+int fs_space_format_info(fs_space_t space, int64_t* n_slices, int64_t* n_dia_slices, int64_t* spmv_matrix_bytes);
 int fs_space_destroy(fs_space_t space);
 
 /* ---- vectors (dolfin.Function.vector(), PETScVector) ------------------------ */
