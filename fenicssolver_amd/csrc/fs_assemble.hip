@@ -8,6 +8,7 @@
 // kernels: one thread per cell, 16-B coalesced loads of the cell's vertex ids and of the
 // slot column, hardware fp64 atomics (global_atomic_add_f64) for the scatter.
 #include "fs_common.h"
+#include "fs_kernels.h"
 
 // ---- P1 geometry ---------------------------------------------------------------------------
 struct tet_geom {
@@ -128,7 +129,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
-    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < n_slices; s += (int64_t)gridDim.x * wpb) {
+    // XCD-contiguous chunk map (see xcd_chunks): the rows an XCD assembles reference a narrow band of
+    // vertices, so their coordinates stay in that XCD's L2 instead of being re-fetched over the fabric
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = it.cur * wpb + wave;
+        if (s >= n_slices) continue;
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t ibase = inc_slice_ptr[s];
@@ -545,7 +551,7 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
-        const int g = fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 16384);
+        const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
             hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
         else

@@ -20,25 +20,6 @@
 #include <chrono>
 #include <math.h>
 
-// ---- XCD-aware persistent chunk mapping -------------------------------------------------
-// Workgroup b is (observed) placed on XCD b % 8.  Give every XCD one contiguous 1/8 of the
-// chunk range so the x-vector lines gathered by neighbouring rows stay in that XCD's L2.
-// Correctness never depends on the placement.
-struct chunk_iter {
-    int64_t cur, end, step;
-};
-__device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
-    const int64_t per_xcd = (n_chunks + 7) >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int64_t j = blockIdx.x >> 3;
-    chunk_iter it;
-    it.step = gridDim.x >> 3;
-    it.cur = xcd * per_xcd + j;
-    const int64_t e = (xcd + 1) * per_xcd;
-    it.end = e < n_chunks ? e : n_chunks;
-    return it;
-}
-
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
 template <int BS, bool DOTS, int UNROLL>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,

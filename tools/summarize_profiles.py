@@ -106,15 +106,15 @@ def main():
     cal = {}
     for ph in PHASES:
         n = n_dof[ph]
-        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_cg_update", 56 * n)):
+        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_cg_update<true>", 56 * n)):
             if (ph, k) in fetch:
                 cal["%s/%s" % (ph, k)] = {"expected_read_bytes": expect,
                                           "FETCH_SIZE_bytes": int(fetch[(ph, k)] * 1024),
                                           "ratio": round(fetch[(ph, k)] * 1024 / expect, 4)}
-        if (ph, "k_cg_update") in write:
+        if (ph, "k_cg_update<true>") in write:
             cal["%s/k_cg_update(write)" % ph] = {"expected_write_bytes": 40 * n,
-                                                "WRITE_SIZE_bytes": int(write[(ph, "k_cg_update")] * 1024),
-                                                "ratio": round(write[(ph, "k_cg_update")] * 1024 / (40 * n), 4)}
+                                                "WRITE_SIZE_bytes": int(write[(ph, "k_cg_update<true>")] * 1024),
+                                                "ratio": round(write[(ph, "k_cg_update<true>")] * 1024 / (40 * n), 4)}
     out = {"_doc": "HBM-side bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(read side doubled per the gfx950 rule, confirmed by the calibration block). "
                    "bench.py reports these as roofline.traffic.",
@@ -126,7 +126,7 @@ def main():
         key = (ph, "k_sell_spmv<1, false, 4>")
         if key in fetch:
             out[tag.replace("fused", "bare")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
-        key = (ph, "k_assemble_p1_scalar")
+        key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
     json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc.json"), "w"), indent=1)
