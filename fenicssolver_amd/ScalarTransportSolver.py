@@ -134,6 +134,31 @@ class ScalarTransportSolver(SolverBase):
             return nod[tri].mean(axis=1)
         raise SolverError('{}: boundary value of type {} is not supported'.format(what, type(value)))
 
+    def get_convective_velocity_function(self, convective_velocity):
+        """-> constant 3-vector or per-cell velocities [n_cells,3] (ScalarTransportSolver.py:131-140).
+        A spatially varying velocity is sampled at the vertices and enters cell-wise by its mean."""
+        v = convective_velocity
+        if isinstance(v, Constant):
+            vals = v.values()
+            if vals.size != self.dimension:
+                raise SolverError('convective_velocity must have {} components'.format(self.dimension))
+            return np.asarray(vals, dtype=np.float64)
+        if isinstance(v, (tuple, list, np.ndarray)) and len(v) == self.dimension and \
+                all(isinstance(c, numbers.Number) for c in v):
+            return np.asarray(v, dtype=np.float64)
+        if isinstance(v, (tuple, list)) and len(v) == self.dimension and all(isinstance(c, str) for c in v):
+            v = Expression(tuple(v), degree=self.settings['fe_degree'])
+        if isinstance(v, Expression):
+            nod = v.eval_points(self.mesh.coordinates())
+        elif isinstance(v, Function):
+            nod = v.vertex_values()
+        else:
+            raise SolverError('convective_velocity of type {} is not supported'.format(type(v)))
+        nod = np.asarray(nod, dtype=np.float64)
+        if nod.ndim != 2 or nod.shape[1] != self.dimension:
+            raise SolverError('convective_velocity must be a {}-vector field'.format(self.dimension))
+        return nod[self.mesh.cells().astype(np.int64)].mean(axis=1)
+
     # ------------------------------------------------------------------ boundary conditions
     def update_boundary_conditions(self, time_iter_, T, Tq, ds):
         """-> (Dirichlet bcs, list of FacetLoad / FacetRobin)  (ScalarTransportSolver.py:142-211)"""
@@ -217,9 +242,13 @@ class ScalarTransportSolver(SolverBase):
                 self.convective_velocity = self.settings['convective_velocity']
             else:
                 self.convective_velocity = None
+        velocity = None
         if self.convective_velocity:
-            raise SolverError('convective_velocity (advection, ScalarTransportSolver.py:305-328) needs a '
-                              'non-symmetric Krylov solver that is not built yet in fenicssolver_amd')
+            ads = self.settings.get('advection_settings') or {'stabilization_method': None}
+            if ads.get('stabilization_method'):
+                raise SolverError("advection stabilization '{}' (SUPG/IP, ScalarTransportSolver.py:259-328) is not "
+                                  "built yet; only the Galerkin term is".format(ads['stabilization_method']))
+            velocity = self.get_convective_velocity_function(self.convective_velocity)
         if self.nonlinear_material or self.nonlinear:
             raise SolverError('temperature-dependent material properties (Newton) are not built yet')
 
@@ -235,6 +264,11 @@ class ScalarTransportSolver(SolverBase):
             # keep the object, not a copy: solve_current_step assigns w_current to w_prev AFTER the form
             # is generated and BEFORE it is assembled (SolverBase.py:486-489), as UFL's late binding does
             F.T_prev = T_prev
+
+        if velocity is not None:
+            # F += inner(velocity, grad(T))*Tq*capacity*dx  (:311) - not theta-weighted in the reference either
+            F.advection = (velocity, self._scalar_capacity(self._volume_coefficient(capacity, 'capacity')))
+            F.symmetric = False
 
         bcs, integrals_N = self.update_boundary_conditions(time_iter_, T, T_test, None)
         for item in integrals_N:

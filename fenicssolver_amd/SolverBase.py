@@ -492,20 +492,20 @@ class SolverBase():
         return {'linear_solver': 'cg', 'preconditioner': pc, 'relative_tolerance': rtol,
                 'maximum_iterations': max_iter}
 
-    def _device_solve(self, A, b, u, label):
+    def _device_solve(self, A, b, u, label, method="cg"):
         from . import backend
         rtol, max_iter, pc = self._krylov_options()
         V = u.function_space().device()
         x = backend.DeviceVector(V.n_owned)
-        stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc)
+        stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method)
         self.last_solve_stats = stats
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         if sp.get('monitor_convergence'):
-            self.logger.info("%s: CG iterations=%d converged=%d ||r||/||b||=%.3e (true %.3e) solve %.2f ms",
+            self.logger.info("%s: Krylov iterations=%d converged=%d ||r||/||b||=%.3e (true %.3e) solve %.2f ms",
                              label, stats['iterations'], stats['converged'], stats['rel_residual'],
                              stats['true_rel_residual'], stats['solve_ms'])
         if stats['converged'] != 1:
-            raise SolverError('{}: CG did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
+            raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                 label, stats['iterations'], stats['true_rel_residual']))
         u.vector().set_local(x.get())
         return u
@@ -532,7 +532,8 @@ class SolverBase():
         if isinstance(F, forms.ScalarForm):
             theta = F.theta if F.transient else 1.0
             mass = F.capacity.spec(1.0 / F.dt) if F.transient else None
-            A.assemble(stiffness=F.conductivity.spec(theta), mass=mass)
+            adv, adv_scale = F.advection if F.advection is not None else (None, 1.0)
+            A.assemble(stiffness=F.conductivity.spec(theta), mass=mass, advection=adv, advection_scale=adv_scale)
             for r in F.robin:
                 A.add_facet_mass(self._facets_of(r.marker_id), r.h)
             first = True
@@ -577,7 +578,9 @@ class SolverBase():
         if 'point_source' in self.settings and self.settings['point_source']:
             raise SolverError('point_source is not supported by the GPU back end yet')
         A, b = self.assemble_system(F, Dirichlet_bcs, symmetric=True)
-        return self._device_solve(A, b, u, 'solve_linear_problem')
+        # advection makes the operator non-symmetric: BiCGStab (PETSc KSPBCGS) instead of CG
+        method = "cg" if getattr(F, "symmetric", True) else "bicgstab"
+        return self._device_solve(A, b, u, 'solve_linear_problem', method=method)
 
     def solve_nonlinear_problem(self, F, u_current, Dirichlet_bcs, J):
         raise SolverError('nonlinear problems (Newton, SolverBase.py:615-626) are not built yet in '

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libfsamd.so")
 FS_OK = 0
 FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL = 0, 1, 2, 3, 4
 FS_KSP_CG = 0
+FS_KSP_BICGSTAB = 1
 FS_PC_NONE, FS_PC_JACOBI = 0, 1
 FS_UNIQUE_ID_BYTES = 128
 
@@ -36,7 +37,8 @@ class fs_coef(C.Structure):
 
 
 class fs_bilinear_form(C.Structure):
-    _fields_ = [("stiffness", fs_coef), ("mass", fs_coef), ("lame_mu", C.c_double), ("lame_lambda", C.c_double)]
+    _fields_ = [("stiffness", fs_coef), ("mass", fs_coef), ("lame_mu", C.c_double), ("lame_lambda", C.c_double),
+                ("advection", fs_coef), ("advection_scale", C.c_double)]
 
 
 class fs_linear_form(C.Structure):

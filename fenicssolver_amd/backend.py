@@ -192,11 +192,24 @@ class DeviceMatrix(_Handle):
         self.space = space
         L.check(L.load().fs_matrix_create(space.h, C.byref(self.h)), "fs_matrix_create")
 
-    def assemble(self, stiffness=None, mass=None, lame=None, add=False):
+    def assemble(self, stiffness=None, mass=None, lame=None, advection=None, advection_scale=1.0, add=False):
+        """advection: constant velocity (3 numbers) or per-cell array [n_cells,3]."""
         keep = []
         f = L.fs_bilinear_form()
         f.stiffness = _coef(stiffness, keep)
         f.mass = _coef(mass, keep)
+        if advection is not None:
+            v = L.f64(advection)
+            if v.size == 3:
+                f.advection.mode = L.FS_COEF_CONST
+                for i in range(3):
+                    f.advection.tensor[i] = float(v.ravel()[i])
+            else:
+                v = L.f64(v.reshape(-1, 3))
+                keep.append(v)
+                f.advection.mode = L.FS_COEF_CELL
+                f.advection.data = L.p_f64(v)
+            f.advection_scale = float(advection_scale)
         if lame is not None:
             f.lame_mu, f.lame_lambda = float(lame[0]), float(lame[1])
         L.check(L.load().fs_assemble_matrix(self.h, C.byref(f), 1 if add else 0), "fs_assemble_matrix")
@@ -274,10 +287,11 @@ def set_dirichlet_values(b, dofs, vals):
     L.check(L.load().fs_apply_dirichlet(None, b.h, dofs.size, L.p_i32(dofs), L.p_f64(vals), 0), "fs_apply_dirichlet")
 
 
-def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False):
-    """CG on the device.  Returns a stats dict (iterations, converged, residuals, timings)."""
+def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False,
+                 method="cg"):
+    """CG (SPD) or BiCGStab (non-symmetric) on the device.  Returns a stats dict."""
     o = L.fs_krylov_opts()
-    o.method = L.FS_KSP_CG
+    o.method = {"cg": L.FS_KSP_CG, "bicgstab": L.FS_KSP_BICGSTAB}[method]
     o.precond = {"none": L.FS_PC_NONE, None: L.FS_PC_NONE, "jacobi": L.FS_PC_JACOBI}[precond]
     o.rtol, o.atol, o.max_iter, o.batch = float(rtol), float(atol), int(max_iter), int(batch)
     o.nonzero_guess = 1 if nonzero_guess else 0

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double* __restrict__ val) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -180,6 +180,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
                 row[1] += mm;
                 row[2] += mm;
                 row[3] += mm;
+            }
+            if (ac.mode != FS_COEF_NONE) {
+                // Galerkin advection: C_ab = scale * (vol/4) * (v . grad phi_b), the same for every row a
+                double vx, vy, vz;
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; vz = ac.tensor[2]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; vz = ac.data[3 * (int64_t)c + 2]; }
+                const double w4 = ascale * vol * 0.25;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) row[b] += w4 * (vx * t.g[b][0] + vy * t.g[b][1] + vz * t.g[b][2]);
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -546,6 +555,11 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         // row-gather path: every SELL entry (padding included) is written exactly once, no memset
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
+        dbuf<double> astore;
+        coef_dev ac;
+        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore, &ac, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE(ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: advection velocity must be constant or per cell");
         // LDS: one accumulator column per thread; fall to one wave per workgroup for very long rows
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
@@ -553,11 +567,12 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, A->val.p);
         else
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, A->val.p);
     } else if (A->bs == 1) {
         FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
+        FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
         if (!add) FS_CHECK(A->val.zero(s));
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");

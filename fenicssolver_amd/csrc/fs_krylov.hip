@@ -21,7 +21,7 @@
 #include <math.h>
 
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
-template <int BS, bool DOTS, int UNROLL>
+template <int BS, int DOTS, int UNROLL>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                         const int64_t* __restrict__ slice_ptr,
                                                         const int32_t* __restrict__ sell_col,
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             ri[i] = 0.0;
             acc[i] = 0.0;
             if (DOTS && live) {
-                zi[i] = x[r * BS + i];
+                if (DOTS == 1) zi[i] = x[r * BS + i];
                 ri[i] = rvec[r * BS + i];
             }
         }
@@ -124,9 +124,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
 #pragma unroll
             for (int i = 0; i < BS; ++i) {
                 y[r * BS + i] = acc[i];
-                if (DOTS) {
+                if (DOTS == 1) {          // CG: r.z, w.z, r.r
                     d_rz += ri[i] * zi[i];
                     d_wz += acc[i] * zi[i];
+                    d_rr += ri[i] * ri[i];
+                } else if (DOTS == 2) {   // generic: w.u, w.w, u.u with u = rvec
+                    d_rz += acc[i] * ri[i];
+                    d_wz += acc[i] * acc[i];
                     d_rr += ri[i] * ri[i];
                 }
             }
@@ -251,6 +255,165 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int
     }
 }
 
+// ---- BiCGStab (non-symmetric operators: advection, ScalarTransportSolver.py:305-311) --------------
+// Right-preconditioned (Jacobi) BiCGStab, PETSc KSPBCGS.  Per iteration: two fused SpMV+dots launches and
+// three fused vector kernels; rho/alpha/omega, the threshold and the status word live on the device,
+// exactly as for CG.  bscal = {rho[parity 0], rho[parity 1], alpha, omega}.
+template <int NS>
+__device__ __forceinline__ void wg_sum_partials(const double* __restrict__ partials, int npart, double (&out)[NS]) {
+    __shared__ double lds4[4];
+    __shared__ double sh[NS];
+    double a[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) a[j] = 0.0;
+    for (int i = threadIdx.x; i < npart; i += FS_BLOCK) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) a[j] += partials[(int64_t)j * npart + i];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const double t = fs_block_sum(a[j], lds4);
+        if (threadIdx.x == 0) sh[j] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NS; ++j) out[j] = sh[j];
+}
+
+static __global__ void __launch_bounds__(FS_BLOCK) k_dot2_partial(const double* __restrict__ a, const double* __restrict__ b,
+                                                                  const double* __restrict__ c, const double* __restrict__ d,
+                                                                  int64_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double s0 = 0.0, s1 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        s0 += a[i] * b[i];
+        s1 += c[i] * d[i];
+    }
+    const double t0 = fs_block_sum(s0, lds4);
+    const double t1 = fs_block_sum(s1, lds4);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = t0;
+        partial[gridDim.x + blockIdx.x] = t1;
+    }
+}
+
+// K1: (rho_new = rhat.r, rr = r.r) -> convergence test, beta, p = r + beta (p - omega v), y = D^-1 p
+template <bool FUSED>
+__global__ void __launch_bounds__(FS_BLOCK) k_bicg_p(int64_t n, int iter, int check_only,
+                                                     const double* __restrict__ partials, int npart,
+                                                     const double* __restrict__ sums, const double* __restrict__ ctrl,
+                                                     double* __restrict__ bscal, int* __restrict__ status,
+                                                     double* __restrict__ hist, const double* __restrict__ dinv,
+                                                     const double* __restrict__ r, double* __restrict__ p,
+                                                     const double* __restrict__ v, double* __restrict__ y) {
+    if (status[0] != 0) return;
+    double sm[2];
+    if (FUSED) wg_sum_partials<2>(partials, npart, sm);
+    else { sm[0] = sums[0]; sm[1] = sums[1]; }
+    const double rho_new = sm[0], rr = sm[1];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (leader) hist[iter] = rr;
+    if (rr <= ctrl[0]) {
+        if (leader) { status[1] = iter; status[0] = 1; }
+        return;
+    }
+    if (check_only) {
+        if (leader) { status[1] = iter; status[0] = 3; }
+        return;
+    }
+    double beta = 0.0, omega = 0.0;
+    if (iter > 0) {
+        const double rho_old = bscal[(iter - 1) & 1];
+        const double alpha = bscal[2];
+        omega = bscal[3];
+        beta = (rho_new / rho_old) * (alpha / omega);
+    }
+    if (!(rho_new == rho_new) || rho_new == 0.0 || !(beta == beta) || !(fabs(beta) < 1e300)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) bscal[iter & 1] = rho_new;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double pn = iter == 0 ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
+        p[i] = pn;
+        y[i] = dinv[i] * pn;
+    }
+}
+
+// K3: alpha = rho / (rhat.v); s = r - alpha v; z = D^-1 s
+template <bool FUSED>
+__global__ void __launch_bounds__(FS_BLOCK) k_bicg_s(int64_t n, int iter, const double* __restrict__ partials,
+                                                     int npart, const double* __restrict__ sums,
+                                                     double* __restrict__ bscal, int* __restrict__ status,
+                                                     const double* __restrict__ dinv, const double* __restrict__ r,
+                                                     const double* __restrict__ v, double* __restrict__ sv,
+                                                     double* __restrict__ z) {
+    if (status[0] != 0) return;
+    double sm[1];
+    if (FUSED) wg_sum_partials<1>(partials, npart, sm);
+    else sm[0] = sums[0];
+    const double rv = sm[0];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const double alpha = bscal[iter & 1] / rv;
+    if (rv == 0.0 || !(alpha == alpha) || !(fabs(alpha) < 1e300)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) bscal[2] = alpha;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double si = r[i] - alpha * v[i];
+        sv[i] = si;
+        z[i] = dinv[i] * si;
+    }
+}
+
+// K5: omega = (t.s)/(t.t); x += alpha y + omega z; r = s - omega t; partial dots (rhat.r, r.r)
+template <bool FUSED>
+__global__ void __launch_bounds__(FS_BLOCK) k_bicg_x(int64_t n, int iter, const double* __restrict__ partials,
+                                                     int npart, const double* __restrict__ sums,
+                                                     double* __restrict__ bscal, int* __restrict__ status,
+                                                     double* __restrict__ x, const double* __restrict__ y,
+                                                     const double* __restrict__ z, double* __restrict__ r,
+                                                     const double* __restrict__ sv, const double* __restrict__ t,
+                                                     const double* __restrict__ rhat, double* __restrict__ pout) {
+    if (status[0] != 0) return;
+    double sm[2];
+    if (FUSED) wg_sum_partials<2>(partials, npart, sm);
+    else { sm[0] = sums[0]; sm[1] = sums[1]; }
+    const double ts = sm[0], tt = sm[1];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    const double omega = tt > 0.0 ? ts / tt : 0.0;   // t = 0 only when s = 0: x + alpha y is already exact
+    const double alpha = bscal[2];
+    if (!(omega == omega)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) bscal[3] = omega;
+    __shared__ double lds4b[4];
+    double d0 = 0.0, d1 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        x[i] += alpha * y[i] + omega * z[i];
+        const double ri = sv[i] - omega * t[i];
+        r[i] = ri;
+        d0 += rhat[i] * ri;
+        d1 += ri * ri;
+    }
+    const double t0 = fs_block_sum(d0, lds4b);
+    const double t1 = fs_block_sum(d1, lds4b);
+    if (threadIdx.x == 0) {
+        pout[blockIdx.x] = t0;
+        pout[gridDim.x + blockIdx.x] = t1;
+    }
+}
+
 template <int BS>
 __global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
                                const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
@@ -338,7 +501,7 @@ static int spmv_grid(int64_t n_slices) {
     return (int)g;
 }
 
-template <bool DOTS>
+template <int DOTS>
 static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
                         const int* status, hipStream_t s) {
     fs_space_s* sp = A->space;
@@ -364,7 +527,7 @@ extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     FS_REQUIRE(y->d.n >= sp->n_dofs_owned, "fs_spmv: y too short");
     hipStream_t s = fs_rt().stream;
     FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
-    launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    launch_spmv<0>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;
@@ -388,8 +551,8 @@ extern "C" int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, in
     FS_CHECK(status.zero(s));
     if (fused) FS_CHECK(w.alloc(sp->n_dofs_owned + 2));
     auto go = [&]() {
-        if (fused) launch_spmv<true>(A, x->d.p, w.p, y->d.p, partials.p, status.p, s);
-        else launch_spmv<false>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+        if (fused) launch_spmv<1>(A, x->d.p, w.p, y->d.p, partials.p, status.p, s);
+        else launch_spmv<0>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
     };
     go();  // warm-up
     FS_HIP(hipEventRecord(e0, s));
@@ -410,6 +573,8 @@ struct krylov_ws {
     int64_t n = 0, nl = 0;
     int hist_cap = 0;
     dbuf<double> dinv, r, z, w, p, s, partials, sums, ctrl, scal, hist;
+    dbuf<double> rhat, t, y, partials2, bsums;   // BiCGStab only (allocated on first use)
+    int64_t bicg_n = -1;
     dbuf<int> status;
     int* h_status = nullptr;  // pinned, 2 x 4 ints
     hipEvent_t poll[2] = {nullptr, nullptr};
@@ -455,10 +620,11 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                                fs_krylov_stats* stats) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A && b && x && opts, "fs_krylov_solve: null pointer");
-    if (opts->method != FS_KSP_CG) {
-        fs_set_error("fs_krylov_solve: only FS_KSP_CG is implemented (method=%d)", opts->method);
+    if (opts->method != FS_KSP_CG && opts->method != FS_KSP_BICGSTAB) {
+        fs_set_error("fs_krylov_solve: unknown Krylov method %d", opts->method);
         return FS_ERR_UNSUPPORTED;
     }
+    const bool bicg = opts->method == FS_KSP_BICGSTAB;
     FS_REQUIRE(opts->precond == FS_PC_NONE || opts->precond == FS_PC_JACOBI, "fs_krylov_solve: unknown preconditioner %d", opts->precond);
     FS_REQUIRE(opts->max_iter > 0 && opts->rtol >= 0.0 && opts->atol >= 0.0, "fs_krylov_solve: bad tolerances");
     fs_space_s* sp = A->space;
@@ -467,6 +633,14 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     hipStream_t s = fs_rt().stream;
     krylov_ws& ws = g_ws;
     FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
+    if (bicg && (ws.bicg_n != n || ws.y.n != nl + 2)) {
+        FS_CHECK(ws.rhat.alloc(n + 2));
+        FS_CHECK(ws.t.alloc(n + 2));
+        FS_CHECK(ws.y.alloc(nl + 2));
+        FS_CHECK(ws.partials2.alloc(4 * (FS_MAX_PARTIAL_BLOCKS + 8)));
+        FS_CHECK(ws.bsums.alloc(16));
+        ws.bicg_n = n;
+    }
     const int bs = A->bs;
     const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
@@ -507,7 +681,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     if (opts->nonzero_guess) {
         FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
         FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-        launch_spmv<false>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
+        launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
         hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, ws.r.p, ws.partials.p);
     } else {
         FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
@@ -515,6 +689,14 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     }
     hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
     FS_KERNEL_CHECK();
+    if (bicg) {
+        // rhat = r0; first (rhat.r, r.r) partials; v = 0 (ws.w), p = 0, y = 0
+        FS_HIP(hipMemcpyAsync(ws.rhat.p, ws.r.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        FS_CHECK(ws.w.zero(s));
+        FS_CHECK(ws.y.zero(s));
+        hipLaunchKernelGGL(k_dot2_partial, dim3(vgrid), dim3(FS_BLOCK), 0, s, ws.rhat.p, ws.r.p, ws.r.p, ws.r.p, n, ws.partials2.p);
+        FS_KERNEL_CHECK();
+    }
 
     // iteration pipeline
     const int batch = opts->batch > 0 ? opts->batch : g_cg_batch;
@@ -525,9 +707,50 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
         for (; k < kend; ++k) {
             const bool sample = (k % 4 == 1) && n_samples < krylov_ws::NSAMPLE;
+            if (bicg) {
+                const int co = k == max_iter ? 1 : 0;
+                // K1: p, y
+                if (fuse_sums) {
+                    hipLaunchKernelGGL(k_bicg_p<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
+                } else {
+                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials2.p, vgrid, 2, ws.bsums.p);
+                    FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p, 2, s));
+                    hipLaunchKernelGGL(k_bicg_p<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.hist.p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
+                }
+                // K2: v = A y, rhat.v
+                FS_CHECK(fs_halo_exchange_dev(sp, ws.y.p, s));
+                if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
+                launch_spmv<2>(A, ws.y.p, ws.w.p, ws.rhat.p, ws.partials.p, ws.status.p, s);
+                if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
+                // K3: s, z
+                if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                if (fuse_sums) {
+                    hipLaunchKernelGGL(k_bicg_s<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
+                } else {
+                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 1, ws.bsums.p + 4);
+                    FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 4, 1, s));
+                    hipLaunchKernelGGL(k_bicg_s<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
+                }
+                if (sample) {
+                    FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
+                    ++n_samples;
+                }
+                // K4: t = A z, (t.s, t.t)
+                FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+                launch_spmv<2>(A, ws.z.p, ws.t.p, ws.s.p, ws.partials.p, ws.status.p, s);
+                // K5: x, r, next (rhat.r, r.r)
+                if (fuse_sums) {
+                    hipLaunchKernelGGL(k_bicg_x<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
+                } else {
+                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 2, ws.bsums.p + 8);
+                    FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 8, 2, s));
+                    hipLaunchKernelGGL(k_bicg_x<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
+                }
+                continue;
+            }
             FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
             if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
-            launch_spmv<true>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
+            launch_spmv<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
             if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
             if (fuse_sums) {
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
@@ -562,7 +785,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     // true residual b - A x
     FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-    launch_spmv<false>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
+    launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
     hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 5);
     FS_KERNEL_CHECK();
@@ -602,7 +825,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
     }
     if (h_status[0] == 2) {
-        fs_set_error("fs_krylov_solve: CG breakdown at iteration %d (operator not SPD or NaN)", iters);
+        fs_set_error("fs_krylov_solve: %s breakdown at iteration %d (operator not SPD / rho = 0 / NaN)", bicg ? "BiCGStab" : "CG", iters);
         return FS_ERR_NUMERIC;
     }
     return FS_OK;

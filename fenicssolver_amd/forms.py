@@ -76,6 +76,7 @@ class ScalarForm:
         self.sources = []             # [VolumeCoefficient]  int S q dx
         self.facet_loads = []         # [FacetLoad]
         self.robin = []               # [FacetRobin]
+        self.advection = None         # (velocity: 3-vector or array[n_cells,3], scale = capacity) -> non-symmetric
         self.symmetric = True
 
     def describe(self):
@@ -88,6 +89,7 @@ class ScalarForm:
             "sources": [s.describe() for s in self.sources],
             "facet_loads": [(f.marker_id, _plain(f.g), f.origin) for f in self.facet_loads],
             "robin": [(r.marker_id, r.h, r.ambient) for r in self.robin],
+            "advection": None if self.advection is None else (_plain(self.advection[0]), float(self.advection[1])),
         }
 
 

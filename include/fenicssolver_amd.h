@@ -151,6 +151,10 @@ typedef struct fs_bilinear_form {
     fs_coef mass;        /* both */
     double lame_mu;      /* vector spaces */
     double lame_lambda;  /* vector spaces */
+    /* scalar spaces: + advection_scale * int (v . grad u) q dx  (ScalarTransportSolver.py:311; Galerkin,
+     * non-symmetric).  v: FS_COEF_CONST -> tensor[0..2]; FS_COEF_CELL -> data[n_cells][3]. */
+    fs_coef advection;
+    double advection_scale;
 } fs_bilinear_form;
 
 /* Replaces dolfin.assemble(a) / the matrix half of assemble_system: numeric
@@ -195,11 +199,12 @@ int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y);
 /* ---- Krylov (PETScKrylovSolver("cg", pc).solve, SolverBase.py:663-670) -------- */
 
 #define FS_KSP_CG 0
+#define FS_KSP_BICGSTAB 1 /* non-symmetric operators (advection); PETSc KSPBCGS, right Jacobi */
 #define FS_PC_NONE 0
 #define FS_PC_JACOBI 1
 
 typedef struct fs_krylov_opts {
-    int method;          /* FS_KSP_CG */
+    int method;          /* FS_KSP_CG | FS_KSP_BICGSTAB */
     int precond;         /* FS_PC_* */
     double rtol;         /* stop when ||r||_2 <= max(rtol*||b||_2, atol) */
     double atol;

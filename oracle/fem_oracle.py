@@ -287,6 +287,18 @@ def assemble_p1_scalar(coords, cells, k=1.0, mass_coef=None):
     return assemble_matrix(n, cells, Ke)
 
 
+def p1_advection_local(coords, cells, velocity, scale=1.0):
+    """Ce[a,b] = scale * vol/4 * (v . grad phi_b): Galerkin  inner(velocity, grad(T))*Tq*capacity*dx
+    (ScalarTransportSolver.py:311) with a cell-wise constant velocity.  velocity: [3] or [nc,3]."""
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(cells), 3))
+    vg = np.einsum("ci,cbi->cb", v, g)                 # v . grad phi_b
+    return scale * 0.25 * vol[:, None, None] * np.broadcast_to(vg[:, None, :], (len(cells), 4, 4))
+
+
 def assemble_p1_source(coords, cells, f=None, f_nodal=None, cell_markers=None, subdomain_id=None):
     """b_a = int f phi_a dx.  Constant/per-cell f: |detJ|/24 each vertex
     (ScalarTransportSolver.py:213-226 body source S*q*dx[(id)]).  Nodal f

@@ -387,3 +387,50 @@ def test_errors_are_reported_not_silent(gpu):
     x = gpu.DeviceVector(V.n_owned)
     with pytest.raises(gpu.BackendError):
         gpu.krylov_solve(A, b, x)
+
+
+# ---- non-symmetric path: advection + BiCGStab ---------------------------------------------------
+def test_advection_assembly_and_bicgstab(gpu, data_dir):
+    rng = np.random.default_rng(5)
+    for co, ce in (fo.unit_cube_mesh(6), fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))):
+        mesh = gpu.DeviceMesh(co, ce)
+        V = gpu.DeviceSpace(mesh, 1)
+        A = gpu.DeviceMatrix(V)
+        vconst = np.array([0.3, -0.2, 0.5])
+        vcell = rng.uniform(-1, 1, (len(ce), 3))
+        for vel in (vconst, vcell):
+            A.assemble(stiffness=0.7, mass=0.1, advection=vel, advection_scale=2.5)
+            ref = fo.assemble_matrix(len(co), ce, fo.p1_stiffness_local(co, ce, 0.7) + fo.p1_mass_local(co, ce, 0.1)
+                                     + fo.p1_advection_local(co, ce, vel, 2.5))
+            M = _csr(A)
+            _assert_same_pattern(M, ref)
+            assert np.abs(M.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max()
+        # solve the (non-symmetric) system against the oracle's sparse LU
+        b0 = rng.standard_normal(len(co))
+        dofs = np.nonzero(co[:, 2] == co[:, 2].min())[0]
+        Ab, bb = fo.apply_dirichlet(ref, b0, dofs, 1.0, True)
+        xref = fo.solve_direct(Ab, bb)
+        b = gpu.DeviceVector(V.n_owned, b0)
+        A.apply_dirichlet(b, dofs, 1.0, symmetric=True)
+        x = gpu.DeviceVector(V.n_owned)
+        st = gpu.krylov_solve(A, b, x, rtol=1e-12, max_iter=5000, method="bicgstab")
+        assert st["converged"] == 1 and st["true_rel_residual"] <= 1e-11
+        assert np.abs(x.get() - xref).max() <= 1e-8 * np.abs(xref).max()
+
+
+def test_bicgstab_agrees_with_cg_on_spd(gpu):
+    n = 12
+    P = fo.heat_box_problem(n)
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, P["dofs"], P["vals"], symmetric=True)
+    x1, x2 = gpu.DeviceVector(V.n_owned), gpu.DeviceVector(V.n_owned)
+    s1 = gpu.krylov_solve(A, b, x1, rtol=1e-10, max_iter=3000, method="cg")
+    s2 = gpu.krylov_solve(A, b, x2, rtol=1e-10, max_iter=3000, method="bicgstab")
+    assert s1["converged"] == 1 and s2["converged"] == 1
+    assert s2["iterations"] <= s1["iterations"]            # two SpMVs per BiCGStab iteration
+    assert np.abs(x1.get() - x2.get()).max() <= 1e-7 * 350
+    assert np.abs(x2.get() - P["exact"]).max() <= 1e-5

@@ -238,3 +238,35 @@ def test_linear_elasticity_cases(gpu):
     bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
     u3 = make(bcs).solve().vertex_values()
     assert u3[right, 1].mean() < 0      # reversed sign (Q3): pushes -y
+
+
+def test_convective_velocity_case(gpu):
+    """examples/test_heat_transfer.py active case: convective velocity + heatFlux + HTC (:136-168, :224)."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(5)
+    s['boundary_conditions']["hot"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}
+    s['boundary_conditions']["cold"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}
+    s['convective_velocity'] = Constant((0.005, -0.005, 0.0))
+    s['material'] = {'density': 10.0, 'specific_heat_capacity': 20.0, 'thermal_conductivity': 0.6}
+    solver = ScalarTransportSolver(s)
+    T = solver.solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    facets, _, _ = fo.facet_numbering(ce)
+    fm = solver.boundary_facets.array()
+    A = fo.assemble_matrix(len(co), ce, fo.p1_stiffness_local(co, ce, 0.6)
+                           + fo.p1_advection_local(co, ce, (0.005, -0.005, 0.0), 200.0))
+    A = A + fo.assemble_p1_facet_mass(co, facets, fm, 2, 100.0)
+    b = fo.assemble_p1_facet_load(co, facets, fm, 1, 36.0) + fo.assemble_p1_facet_load(co, facets, fm, 2, 100.0 * 300.0)
+    ref = fo.solve_direct(A.tocsr(), b)
+    assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
+    assert solver.last_solve_stats["converged"] == 1
+    # the stabilised variants are refused loudly, not silently dropped
+    s2, _ = _box_heat_settings(3)
+    s2['convective_velocity'] = Constant((0.005, -0.005, 0.0))
+    s2['advection_settings'] = {'stabilization_method': 'SPUG', 'Pe': 10.0}
+    from fenicssolver_amd.SolverBase import SolverError
+    with pytest.raises(SolverError):
+        ScalarTransportSolver(s2).solve()

@@ -296,6 +296,12 @@ def test_scalar_form_recognition_heat_flux_htc_transient():
     assert d["sources"] == [("const", 5.0)]
     assert (solver.boundary_facets.array() == 1).sum() == 32
     settings['convective_velocity'] = Constant((0.005, -0.005, 0.0))
+    s2 = ScalarTransportSolver(settings)
+    s2.init_solver()
+    s2.current_step = 0
+    F2, _ = s2.generate_form(0, None, None, s2.w_current, s2.w_prev)
+    assert F2.describe()["advection"] == ((0.005, -0.005, 0.0), 4200000.0) and not F2.symmetric
+    settings['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}
     with pytest.raises(SolverError):
         ScalarTransportSolver(settings).generate_form(0, None, None, solver.w_current, solver.w_prev)
 
