@@ -143,10 +143,18 @@ class LinearElasticitySolver(SolverBase):
                     bcs.append(DirichletBC(V, self.translate_value(bv), self.boundary_facets, i))
             elif btype == 'force':
                 val = bc['value']
-                if isinstance(val, (tuple, list, Constant)) and np.size(self._try_values(val)) == self.dimension:
-                    # the reference applies a vector-valued 'force' as a traction density (:166-167)
+                if isinstance(val, (tuple, list)) and len(val) == self.dimension:
+                    # the reference applies a tuple-valued 'force' as a traction density (:166-167)
                     g = self._vector_of(val, name)
-                    integrals_N.append(forms.FacetLoad(i, g, 'force(vector)'))
+                    integrals_N.append(forms.FacetLoad(i, g, 'force(vector density)'))
+                elif isinstance(val, Constant) and val.value_size() == self.dimension:
+                    # Constant((Fx,Fy,Fz)) as in examples/test_linear_elasticity.py:86: the reference forms
+                    # n * (F / area), a vector-vector product UFL rejects; the evident intent - the total
+                    # force vector spread over the face - is what is applied here: traction = F / area
+                    tri, nrm, area = self._facet_normals(i)
+                    bc_area = float(area.sum())
+                    self.logger.info('boundary area (m2) for force boundary is %g', bc_area)
+                    integrals_N.append(forms.FacetLoad(i, val.values() / bc_area, 'force(vector / area)'))
                 else:
                     bc_force = self.translate_value(val)
                     if not is_constant_value(bc_force):

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Runs the REFERENCE's own solver classes (/root/reference/FenicsSolver, imported unchanged)
+against the recording `dolfin` stub of tests/refstub and writes what they hand to
+DOLFIN — Dirichlet sets and the integrals of the variational form — as JSON goldens:
+
+    tests/golden/reference_forms.json
+
+This pins the Python-side semantics of the reference ("partial-import
+option"): which settings produce which integrals, coefficients, signs and Dirichlet conditions,
+quirks included.  tests/test_reference_forms.py checks that fenicssolver_amd's generate_form
+recognises exactly the same terms from the same settings.  Only runs in the build container
+(needs /root/reference); the GPU box sees the JSON only.
+
+    python tests/golden/make_reference_form_goldens.py
+"""
+import collections
+import copy
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "tests", "refstub"))     # the stub named `dolfin` / `ufl`
+sys.path.insert(0, "/root/reference")
+sys.argv = [sys.argv[0]]                                         # FenicsSolver/__init__ runs main(argv) otherwise
+
+import dolfin                                                    # noqa: E402  (the stub)
+from dolfin import (Constant, Expression, AutoSubDomain, SubDomain, FunctionSpace, VectorFunctionSpace,  # noqa: E402
+                    UnitCubeMesh, BoxMesh, Point)
+from FenicsSolver import SolverBase, ScalarTransportSolver, LinearElasticitySolver                     # noqa: E402
+from FenicsSolver.main import load_settings                                                            # noqa: E402
+
+QUIET = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+out = collections.OrderedDict()
+
+
+def run(name, solver):
+    dolfin.RECORD["solves"] = []
+    dolfin.RECORD.pop("assembled", None)
+    solver.solve()
+    rec = {"solves": copy.deepcopy(dolfin.RECORD["solves"])}
+    if "assembled" in dolfin.RECORD:
+        rec["assembled"] = copy.deepcopy(dolfin.RECORD["assembled"])
+    if "nullspace_vectors" in dolfin.RECORD:
+        rec["nullspace_vectors"] = dolfin.RECORD.pop("nullspace_vectors")
+    out[name] = rec
+
+
+# --- case 1: data/TestHeatTransfer.json (config 1) -------------------------------------------------
+os.chdir("/root/reference/FenicsSolver")      # the JSON's mesh path is relative to the package folder
+s = load_settings("../data/TestHeatTransfer.json")
+s["report_settings"] = dict(QUIET)
+run("config1_json", ScalarTransportSolver.ScalarTransportSolver(s))
+
+
+def heat_settings(transient=False, **extra):
+    mesh = UnitCubeMesh(4, 4, 4)
+    Q = FunctionSpace(mesh, "CG", 1)
+    top = AutoSubDomain(lambda x: True)
+    bottom = AutoSubDomain(lambda x: True)
+    left = AutoSubDomain(lambda x: True)
+    bcs = collections.OrderedDict()
+    bcs["hot"] = {'boundary': top, 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
+    bcs["cold"] = {'boundary': bottom, 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    bcs["left"] = {'boundary': left, 'boundary_id': 3, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'symmetry', 'value': None}}}
+    st = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+          'boundary_conditions': bcs, 'body_source': 5.0, 'initial_values': {'temperature': 300},
+          'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.1},
+          'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1,
+                                                     'ending_time': 0.1},
+                              'reference_values': {'temperature': 300}, 'solver_parameters': {}},
+          'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    st.update(extra)
+    return st
+
+
+# --- case 2: heatFlux + HTC + symmetry + body source, conductivity patched after construction ---------
+sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings())
+sol.material['conductivity'] = 0.6
+run("heat_flux_htc_source", sol)
+
+# --- case 3: the same, transient (Crank-Nicolson) -------------------------------------------------------
+sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings(transient=True))
+sol.material['conductivity'] = 0.6
+run("heat_transient", sol)
+
+# --- case 4: convective velocity, no stabilisation (examples/test_heat_transfer.py active case) ---------
+sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings(convective_velocity=Constant((0.005, -0.005, 0.0))))
+sol.material['conductivity'] = 0.6
+run("heat_convection", sol)
+
+# --- case 5: Dirichlet + Neumann(fixedGradient) + Robin --------------------------------------------------
+st = heat_settings()
+st['body_source'] = None
+st['boundary_conditions']["hot"]['values']['temperature'] = {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}
+st['boundary_conditions']["cold"]['values']['temperature'] = {'variable': 'temperature', 'type': 'fixedGradient', 'value': Constant(2.0)}
+st['boundary_conditions']["left"]['values']['temperature'] = {'variable': 'temperature', 'type': 'Robin', 'value': Constant(310), 'gradient': Constant(1.5)}
+run("heat_dirichlet_neumann_robin", ScalarTransportSolver.ScalarTransportSolver(st))
+
+
+# --- case 6: linear elasticity (examples/test_linear_elasticity.py) ------------------------------------
+def elasticity_settings(bcs, **extra):
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 8, 2, 2)
+    st = copy.deepcopy(SolverBase.default_case_settings)
+    st['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    st['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    st['boundary_conditions'] = bcs
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = None
+    st.update(extra)
+    return st
+
+
+class Left(SubDomain):
+    pass
+
+
+class Right(SubDomain):
+    pass
+
+
+bcs = collections.OrderedDict()
+bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), None, None)}
+bcs["tensile"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'stress', 'value': Constant((1e8, 0, 0))}
+run("elasticity_stress_body_thermal", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(
+    bcs, body_source=Expression(("10*rho", "0", "0.0"), rho=7800, omega=100, degree=2),
+    temperature_distribution=Expression("343", degree=1))))
+
+bcs = collections.OrderedDict()
+bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+bcs["displ"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant((0, 0, 1e-3))}
+run("elasticity_displacement", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(
+    bcs, body_source=Expression(("10*rho", "0", "0.0"), rho=7800, omega=100, degree=2))))
+
+bcs = collections.OrderedDict()
+bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
+run("elasticity_force", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(bcs)))
+
+path = os.path.join(HERE, "reference_forms.json")
+with open(path, "w") as fh:
+    json.dump(out, fh, indent=1)
+print("wrote", path)
+for k, v in out.items():
+    print("==", k)
+    for sv in v["solves"][:1]:
+        print("  ", sv["kind"])
+        for b in sv["bcs"]:
+            print("     bc", b)
+        for t in sv["terms"]:
+            print("     %+d  %s * %s" % (t["sign"], t["integrand"], t["measure"]))
