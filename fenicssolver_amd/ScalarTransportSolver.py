@@ -113,7 +113,7 @@ class ScalarTransportSolver(SolverBase):
             if isinstance(value, Expression) and value.value_size() != 1:
                 raise SolverError('{}: tensor-valued Expression coefficients are not supported'.format(what))
             nod = nodal_values(value, self.function_space)
-            cells = self.mesh.cells().astype(np.int64)
+            cells = self.mesh.cells().astype(np.int64)      # vertex nodes come first in P1 and P2 alike
             return forms.VolumeCoefficient("cell", nod[cells].mean(axis=1))
         raise SolverError('{}: value of type {} is not supported'.format(what, type(value)))
 

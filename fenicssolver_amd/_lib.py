@@ -74,6 +74,7 @@ SIGNATURES = {
     "fs_space_create": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "fs_space_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p, c_i64p]),
     "fs_space_format_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p]),
+    "fs_space_get_edges": (C.c_int, [_H, c_i64p, c_i32p]),
     "fs_space_destroy": (C.c_int, [_H]),
     "fs_vector_create": (C.c_int, [c_i64, C.POINTER(_H)]),
     "fs_vector_size": (C.c_int, [_H, c_i64p]),

@@ -115,6 +115,16 @@ class DeviceSpace(_Handle):
         self.n_local, self.n_owned, self.nnz, self.sell_entries = a.value, b.value, c.value, d.value
         L.check(L.load().fs_space_format_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "fs_space_format_info")
         self.n_slices, self.n_dia_slices, self.spmv_matrix_bytes = a.value, b.value, c.value
+        self.degree = int(degree)
+
+    def edges(self):
+        """CG2: [n_edges,2] vertex pairs of the edge nodes (dof = n_vertices + row index)."""
+        ne = C.c_int64(0)
+        L.check(L.load().fs_space_get_edges(self.h, C.byref(ne), None), "fs_space_get_edges")
+        out = np.empty((ne.value, 2), dtype=np.int32)
+        if ne.value:
+            L.check(L.load().fs_space_get_edges(self.h, C.byref(ne), L.p_i32(out)), "fs_space_get_edges")
+        return out
 
     def set_halo(self, neighbors, send_lists, recv_counts):
         """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour."""

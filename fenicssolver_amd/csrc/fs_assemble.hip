@@ -49,6 +49,17 @@ __device__ __forceinline__ tet_geom tet_geometry(const double* __restrict__ xyz4
     return t;
 }
 
+__device__ __forceinline__ double tri_area(const double* __restrict__ xyz4, int32_t a, int32_t b, int32_t c) {
+    double x0[3], x1[3], x2[3];
+    load_vertex(xyz4, a, x0);
+    load_vertex(xyz4, b, x1);
+    load_vertex(xyz4, c, x2);
+    const double u[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    const double w[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
+    const double n[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+    return 0.5 * sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+}
+
 struct coef_dev {
     int mode;
     double value;
@@ -204,6 +215,157 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     }
 }
 
+// ---- scalar P2, row-gather form --------------------------------------------------------------------
+// Local dofs: 4 vertices, then the 6 UFC edges.  grad phi_vertex_i = (4 lambda_i - 1) grad lambda_i,
+// grad phi_edge_ij = 4 (lambda_i grad lambda_j + lambda_j grad lambda_i); the stiffness integrand is
+// quadratic, integrated exactly by the 4-point rule FFC picks for it.
+__device__ __constant__ double FS_P2_QP[4][4] = {
+    {0.5854101966249685, 0.1381966011250105, 0.1381966011250105, 0.1381966011250105},
+    {0.1381966011250105, 0.5854101966249685, 0.1381966011250105, 0.1381966011250105},
+    {0.1381966011250105, 0.1381966011250105, 0.5854101966249685, 0.1381966011250105},
+    {0.1381966011250105, 0.1381966011250105, 0.1381966011250105, 0.5854101966249685}};
+// exact P2 mass matrix of a unit-volume tetrahedron times 420
+__device__ __constant__ double FS_P2_MASS420[10][10] = {
+    {6, 1, 1, 1, -6, -6, -6, -4, -4, -4},   {1, 6, 1, 1, -6, -4, -4, -6, -6, -4},
+    {1, 1, 6, 1, -4, -6, -4, -6, -4, -6},   {1, 1, 1, 6, -4, -4, -6, -4, -6, -6},
+    {-6, -6, -4, -4, 32, 16, 16, 16, 16, 8}, {-6, -4, -6, -4, 16, 32, 16, 16, 8, 16},
+    {-6, -4, -4, -6, 16, 16, 32, 8, 16, 16}, {-4, -6, -6, -4, 16, 16, 8, 32, 16, 16},
+    {-4, -6, -4, -6, 16, 8, 16, 16, 32, 16}, {-4, -4, -6, -6, 8, 16, 16, 16, 16, 32}};
+
+__device__ __forceinline__ void p2_basis_grads(const tet_geom& t, const double (&lam)[4], double (&gp)[10][3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gp[i][d] = (4.0 * lam[i] - 1.0) * t.g[i][d];
+    // UFC edges: e0=(2,3) e1=(1,3) e2=(1,2) e3=(0,3) e4=(0,2) e5=(0,1)
+    const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gp[4 + e][d] = 4.0 * (lam[ei[e]] * t.g[ej[e]][d] + lam[ej[e]] * t.g[ei[e]][d]);
+}
+
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+    const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
+    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cell_dofs, const double* __restrict__ xyz4,
+    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = it.cur * wpb + wave;
+        if (s >= n_slices) continue;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int64_t e = ibase + (int64_t)j * FS_SLICE + lane;
+            const int32_t q = inc_cell[e];
+            if (q < 0) continue;
+            const int c = q / 10, a = q - 10 * c;
+            const uint32_t pw[3] = {inc_pos[e], inc_pos[inc_entries + e], inc_pos[2 * inc_entries + e]};
+            const int32_t vv[4] = {cell_dofs[(int64_t)c * 10], cell_dofs[(int64_t)c * 10 + 1],
+                                   cell_dofs[(int64_t)c * 10 + 2], cell_dofs[(int64_t)c * 10 + 3]};
+            const tet_geom t = tet_geometry(xyz4, vv);
+            const double vol = t.adet * (1.0 / 6.0);
+            double row[10];
+#pragma unroll
+            for (int b = 0; b < 10; ++b) row[b] = 0.0;
+            if (kc.mode != FS_COEF_NONE) {
+                double kk = kc.mode == FS_COEF_CONST ? kc.value : kc.data[c];
+#pragma unroll
+                for (int qp = 0; qp < 4; ++qp) {
+                    const double lam[4] = {FS_P2_QP[qp][0], FS_P2_QP[qp][1], FS_P2_QP[qp][2], FS_P2_QP[qp][3]};
+                    double gp[10][3];
+                    p2_basis_grads(t, lam, gp);
+                    double ga[3] = {0.0, 0.0, 0.0};   // gradient of this row's basis function, selected without
+#pragma unroll                                         // indexing the register array dynamically
+                    for (int b = 0; b < 10; ++b)
+                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; ga[2] = gp[b][2]; }
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] += 0.25 * (ga[0] * gp[b][0] + ga[1] * gp[b][1] + ga[2] * gp[b][2]);
+                }
+                const double w = kk * vol;
+#pragma unroll
+                for (int b = 0; b < 10; ++b) row[b] *= w;
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * vol * (1.0 / 420.0);
+#pragma unroll
+                for (int b = 0; b < 10; ++b) row[b] += mm * FS_P2_MASS420[a][b];
+            }
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+                const int k = (pw[b >> 2] >> (8 * (b & 3))) & 255;
+                lds_acc[k * bd + tid] += row[b];
+            }
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
+    }
+}
+
+// P2 load vector: int f phi_a dx; constant / per-cell f: V * (-1/20 vertex, 1/5 edge); nodal (P2) f: M_e f_e
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* __restrict__ cell_dofs,
+                                                                 const double* __restrict__ xyz4, int64_t nc,
+                                                                 coef_dev f, double* __restrict__ b) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        int32_t d[10];
+        for (int a = 0; a < 10; ++a) d[a] = cell_dofs[c * 10 + a];
+        const int32_t vv[4] = {d[0], d[1], d[2], d[3]};
+        const tet_geom t = tet_geometry(xyz4, vv);
+        const double vol = t.adet * (1.0 / 6.0);
+        if (f.mode == FS_COEF_NODAL) {
+            double fe[10];
+            for (int a = 0; a < 10; ++a) fe[a] = f.data[d[a]];
+            for (int a = 0; a < 10; ++a) {
+                double acc = 0.0;
+                for (int k = 0; k < 10; ++k) acc += FS_P2_MASS420[a][k] * fe[k];
+                atomicAdd(&b[d[a]], acc * vol * (1.0 / 420.0));
+            }
+        } else {
+            const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
+            for (int a = 0; a < 4; ++a) atomicAdd(&b[d[a]], -0.05 * ff);
+            for (int a = 4; a < 10; ++a) atomicAdd(&b[d[a]], 0.2 * ff);
+        }
+    }
+}
+
+// P2 boundary load: int g phi_a ds over a facet = g * area / 3 on each of its 3 edge nodes, 0 on the vertices
+__global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
+                                  const double* __restrict__ g, const int32_t* __restrict__ edges, int64_t ne,
+                                  int64_t nv, double* __restrict__ b, int* __restrict__ err) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t v[3] = {tri[3 * f], tri[3 * f + 1], tri[3 * f + 2]};
+        const double w = tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 3.0) * g[f];
+        const int pi[3] = {0, 0, 1}, pj[3] = {1, 2, 2};
+        for (int e = 0; e < 3; ++e) {
+            const int32_t a = v[pi[e]], bb = v[pj[e]];
+            const int32_t lo_v = a < bb ? a : bb, hi_v = a < bb ? bb : a;
+            int64_t lo = 0, hi = ne;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const int32_t e0 = edges[2 * mid], e1 = edges[2 * mid + 1];
+                if (e0 < lo_v || (e0 == lo_v && e1 < hi_v)) lo = mid + 1; else hi = mid;
+            }
+            if (lo < ne && edges[2 * lo] == lo_v && edges[2 * lo + 1] == hi_v) atomicAdd(&b[nv + lo], w);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- vector P1 elasticity: 3x3 block per node pair, plane (i*3+j) of the SELL value array ------
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32_t* __restrict__ cells,
                                                                      const double* __restrict__ xyz4,
@@ -285,17 +447,6 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* 
                 }
         }
     }
-}
-
-__device__ __forceinline__ double tri_area(const double* __restrict__ xyz4, int32_t a, int32_t b, int32_t c) {
-    double x0[3], x1[3], x2[3];
-    load_vertex(xyz4, a, x0);
-    load_vertex(xyz4, b, x1);
-    load_vertex(xyz4, c, x2);
-    const double u[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
-    const double w[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
-    const double n[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
-    return 0.5 * sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
 }
 
 __global__ void k_facet_vector(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
@@ -551,7 +702,22 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     FS_REQUIRE(mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL,
                "fs_assemble_matrix: mass coefficient must be constant or per cell");
     const int grid = fs_grid_for(m->nc, FS_BLOCK, 8192);
-    if (A->bs == 1 && sp->inc_cell.p) {
+    if (A->bs == 1 && sp->degree == 2) {
+        FS_REQUIRE(sp->inc_cell.p, "fs_assemble_matrix: CG2 space has no assembly tables");
+        FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
+        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
+        FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection is not built for CG2");
+        const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
+        const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
+        FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
+        const int wpb = bd / 64;
+        const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
+        if (add)
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, sp->cell_dofs, m->xyz.p, kc, mc, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, sp->cell_dofs, m->xyz.p, kc, mc, A->val.p);
+    } else if (A->bs == 1 && sp->inc_cell.p) {
         // row-gather path: every SELL entry (padding included) is written exactly once, no memset
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
@@ -605,6 +771,13 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
+    if (space->degree == 2) {
+        FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
+        hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->xyz.p, m->nc, f, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     FS_REQUIRE(f.mode != FS_COEF_TENSOR && dv.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
     hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, b->d.p);
     FS_KERNEL_CHECK();
@@ -625,6 +798,17 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
     FS_CHECK(d_g.alloc(n_facets * space->ncomp));
     FS_CHECK(d_tri.upload(tri, 3 * n_facets, s));
     FS_CHECK(d_g.upload(g, n_facets * space->ncomp, s));
+    if (space->degree == 2) {
+        dbuf<int> d_err;
+        FS_CHECK(d_err.alloc(1));
+        FS_CHECK(d_err.zero(s));
+        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edges.p, space->n_edges, space->mesh->nv, b->d.p, d_err.p);
+        FS_KERNEL_CHECK();
+        int h_err = 0;
+        FS_CHECK(d_err.download(&h_err, 1, s));
+        FS_REQUIRE(h_err == 0, "fs_assemble_facet_vector: %d facet edges are not mesh edges", h_err);
+        return FS_OK;
+    }
     hipLaunchKernelGGL(k_facet_vector, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->ncomp, space->n_nodes_owned, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
@@ -639,6 +823,10 @@ extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const i
     }
     if (n_facets == 0) return FS_OK;
     fs_space_s* sp = A->space;
+    if (sp->degree != 1) {
+        fs_set_error("fs_assemble_facet_matrix: the Robin/HTC boundary matrix is not built for CG2 yet");
+        return FS_ERR_UNSUPPORTED;
+    }
     for (int64_t i = 0; i < 3 * n_facets; ++i)
         FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->n_nodes_local, "fs_assemble_facet_matrix: facet vertex %d out of range", tri[i]);
     hipStream_t s = fs_rt().stream;

@@ -125,6 +125,13 @@ struct fs_space_s {
     fs_mesh_s* mesh = nullptr;
     int degree = 1;
     int ncomp = 1;
+    // cell -> node table: P1 aliases mesh->cells (4 vertices); P2 holds [nc][10] = 4 vertices + 6 edge
+    // nodes (nv + lexicographic edge index; UFC local edge order e0=(v2,v3) ... e5=(v0,v1))
+    int ndof_cell = 4;
+    const int32_t* cell_dofs = nullptr;
+    dbuf<int32_t> cell_dofs_store;
+    int64_t n_edges = 0;
+    dbuf<int32_t> edges;          // [n_edges][2] (P2 only), ascending vertex pairs, lexicographic order
     int64_t n_nodes_local = 0, n_nodes_owned = 0;  // node level
     int64_t n_dofs_local = 0, n_dofs_owned = 0;    // = nodes * ncomp
     // node-level sparsity: CSR + hybrid SELL-64 / per-slice DIA
@@ -152,7 +159,8 @@ struct fs_space_s {
     int inc_max = 0;              // most incidences of any row
     dbuf<int64_t> inc_slice_ptr;  // [n_slices+1]
     dbuf<int32_t> inc_cell;       // [inc_entries] cell*4 + local vertex, -1 = padding
-    dbuf<uint32_t> inc_pos;       // [inc_entries] 4 x uint8 positions
+    dbuf<uint32_t> inc_pos;       // [pos_words][inc_entries]: ndof_cell x uint8 in-row positions, 4 per word
+    int pos_words = 1;
     fs_halo_plan halo;
     // Dirichlet scratch kept across calls (re-assembly every time step must not hipMalloc)
     dbuf<uint8_t> bc_flag;        // [n_dofs_local]

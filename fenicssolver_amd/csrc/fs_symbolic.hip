@@ -12,25 +12,71 @@
 #include <stdlib.h>
 
 // ---- keys ------------------------------------------------------------------------------
-// 12 directed pairs per tet (a != b) + one diagonal key per owned row.
-__global__ void k_pair_keys(const int32_t* __restrict__ cells, int64_t nc, int64_t n_rows,
+// nd*(nd-1) directed pairs per cell (a != b) + one diagonal key per owned row.
+__global__ void k_pair_keys(const int32_t* __restrict__ cell_dofs, int nd, int64_t nc, int64_t n_rows,
                             uint64_t* __restrict__ keys) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
-        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
-        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        int32_t v[10];
+        for (int a = 0; a < nd; ++a) v[a] = cell_dofs[c * nd + a];
         int k = 0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
+        for (int a = 0; a < nd; ++a) {
+            for (int b = 0; b < nd; ++b) {
                 if (a == b) continue;
                 uint64_t key = ~0ULL;  // rows owned elsewhere sort to the end and are dropped
                 if (v[a] < n_rows) key = ((uint64_t)(uint32_t)v[a] << 32) | (uint32_t)v[b];
                 keys[(int64_t)k * nc + c] = key;
                 ++k;
             }
+        }
+    }
+}
+
+// ---- P2: edge nodes ---------------------------------------------------------------------------
+__device__ __constant__ int FS_EDGE_V[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};  // UFC
+
+__global__ void k_edge_keys(const int32_t* __restrict__ cells, int64_t nc, uint64_t* __restrict__ keys) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        for (int e = 0; e < 6; ++e) {
+            const int32_t a = v[FS_EDGE_V[e][0]], b = v[FS_EDGE_V[e][1]];
+            const uint32_t lo = (uint32_t)(a < b ? a : b), hi = (uint32_t)(a < b ? b : a);
+            keys[(int64_t)e * nc + c] = ((uint64_t)lo << 32) | hi;
+        }
+    }
+}
+
+__global__ void k_edge_table(const uint64_t* __restrict__ ukeys, int64_t ne, int32_t* __restrict__ edges) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < ne; i += stride) {
+        edges[2 * i] = (int32_t)(ukeys[i] >> 32);
+        edges[2 * i + 1] = (int32_t)(ukeys[i] & 0xffffffffULL);
+    }
+}
+
+// cell_dofs[c] = {4 vertices, nv + index of each of the 6 edges in the sorted unique edge keys}
+__global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, int64_t nv,
+                               const uint64_t* __restrict__ ukeys, int64_t ne, int32_t* __restrict__ cell_dofs) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        for (int a = 0; a < 4; ++a) cell_dofs[c * 10 + a] = v[a];
+        for (int e = 0; e < 6; ++e) {
+            const int32_t a = v[FS_EDGE_V[e][0]], b = v[FS_EDGE_V[e][1]];
+            const uint64_t key = ((uint64_t)(uint32_t)(a < b ? a : b) << 32) | (uint32_t)(a < b ? b : a);
+            int64_t lo = 0, hi = ne;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            cell_dofs[c * 10 + 4 + e] = (int32_t)(nv + lo);
         }
     }
 }
@@ -218,12 +264,12 @@ __global__ void k_slots(const int32_t* __restrict__ cells, int64_t nc, int64_t n
 
 // ---- row-gather incidence tables ----------------------------------------------------------------
 // key = (vertex << 32) | (cell*4 + local vertex) for every owned (cell, vertex) incidence
-__global__ void k_inc_keys(const int32_t* __restrict__ cells, int64_t n_inc, int64_t n_rows,
+__global__ void k_inc_keys(const int32_t* __restrict__ cell_dofs, int64_t n_inc, int64_t n_rows,
                            uint64_t* __restrict__ keys) {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; q < n_inc; q += stride) {
-        const int32_t v = cells[q];
+        const int32_t v = cell_dofs[q];
         keys[q] = v < n_rows ? (((uint64_t)(uint32_t)v << 32) | (uint64_t)q) : ~0ULL;
     }
 }
@@ -250,13 +296,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_width(const int32_t* __restric
 
 __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restrict__ keys,
                                                        const int32_t* __restrict__ inc_ptr,
-                                                       const int32_t* __restrict__ cells,
+                                                       const int32_t* __restrict__ cell_dofs, int nd,
                                                        const int32_t* __restrict__ sell_col,
                                                        const int64_t* __restrict__ slice_ptr, int64_t n_rows,
                                                        int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
-                                                       int32_t* __restrict__ inc_cell,
+                                                       int64_t inc_entries, int32_t* __restrict__ inc_cell,
                                                        uint32_t* __restrict__ inc_pos, int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
+    const int words = (nd + 3) >> 2;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (; s < n_slices; s += stride) {
@@ -272,20 +319,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
         }
         for (int j = 0; j < width; ++j) {
             int32_t q = -1;
-            uint32_t packed = 0;
+            uint32_t packed[3] = {0u, 0u, 0u};
             if (j < cnt) {
                 q = (int32_t)(keys[first + j] & 0xffffffffULL);
-                const int4 v4 = reinterpret_cast<const int4*>(cells)[q >> 2];
-                const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int k = fs_find_pos(sell_col, mbase, mwidth, v[b]);
+                const int64_t c = q / nd;
+                for (int b = 0; b < nd; ++b) {
+                    const int k = fs_find_pos(sell_col, mbase, mwidth, cell_dofs[c * nd + b]);
                     if (k < 0 || k > 255) atomicAdd(err, 1);
-                    packed |= (uint32_t)(k & 255) << (8 * b);
+                    packed[b >> 2] |= (uint32_t)(k & 255) << (8 * (b & 3));
                 }
             }
-            inc_cell[base + (int64_t)j * FS_SLICE + lane] = q;
-            inc_pos[base + (int64_t)j * FS_SLICE + lane] = packed;
+            const int64_t e = base + (int64_t)j * FS_SLICE + lane;
+            inc_cell[e] = q;
+            for (int w = 0; w < words; ++w) inc_pos[(int64_t)w * inc_entries + e] = packed[w];
         }
     }
 }
@@ -294,22 +340,26 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
-    if (family != FS_FAMILY_CG || degree != 1 || (ncomp != 1 && ncomp != 3)) {
-        fs_set_error("fs_space_create: only CG degree 1 with 1 or 3 components is supported (family=%d degree=%d ncomp=%d)",
+    if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3) || (degree == 2 && ncomp != 1)) {
+        fs_set_error("fs_space_create: supported spaces are CG1 with 1 or 3 components and scalar CG2 (family=%d degree=%d ncomp=%d)",
                      family, degree, ncomp);
         return FS_ERR_UNSUPPORTED;
     }
     hipStream_t s = fs_rt().stream;
-    const int64_t nc = mesh->nc, n_rows = mesh->n_owned;
-    FS_REQUIRE(n_rows > 0, "fs_space_create: process owns no vertices");
+    const int64_t nc = mesh->nc;
+    FS_REQUIRE(mesh->n_owned > 0, "fs_space_create: process owns no vertices");
+    if (degree == 2 && mesh->n_owned != mesh->nv) {
+        fs_set_error("fs_space_create: CG2 spaces are single-GPU for now (the mesh has ghost vertices)");
+        return FS_ERR_UNSUPPORTED;
+    }
     fs_space_s* sp = new fs_space_s();
     sp->mesh = mesh;
     sp->degree = degree;
     sp->ncomp = ncomp;
+    sp->ndof_cell = 4;
+    sp->cell_dofs = mesh->cells.p;
     sp->n_nodes_local = mesh->nv;
-    sp->n_nodes_owned = n_rows;
-    sp->n_dofs_local = mesh->nv * ncomp;
-    sp->n_dofs_owned = n_rows * ncomp;
+    sp->n_nodes_owned = mesh->n_owned;
 
 #define FS_SP(call)                \
     do {                           \
@@ -329,8 +379,51 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         }                                                                                     \
     } while (0)
 
+    if (degree == 2) {
+        // edge nodes: unique (min,max) vertex pairs in lexicographic order = oracle/DOLFIN-style edge numbering
+        const int64_t n_ek = 6 * nc;
+        FS_REQUIRE(n_ek < (int64_t)INT32_MAX, "fs_space_create: edge keys exceed int32");
+        dbuf<uint64_t> ka, kb;
+        dbuf<int> d_count;
+        FS_SP(ka.alloc(n_ek));
+        FS_SP(kb.alloc(n_ek));
+        FS_SP(d_count.alloc(1));
+        hipLaunchKernelGGL(k_edge_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, ka.p);
+        FS_SP_HIP(hipGetLastError());
+        size_t tb1 = 0, tb2 = 0;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, ka.p, kb.p, (int)n_ek, 0, 64, s));
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, kb.p, ka.p, d_count.p, (int)n_ek, s));
+        const size_t tbm = tb1 > tb2 ? tb1 : tb2;
+        dbuf<char> tmp;
+        FS_SP(tmp.alloc((int64_t)tbm + 16));
+        size_t tb = tbm;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_ek, 0, 64, s));
+        tb = tbm;
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, kb.p, ka.p, d_count.p, (int)n_ek, s));
+        int h_ne = 0;
+        FS_SP(d_count.download(&h_ne, 1, s));
+        sp->n_edges = h_ne;
+        FS_SP(sp->edges.alloc(2 * (int64_t)h_ne));
+        FS_SP(sp->cell_dofs_store.alloc(10 * nc));
+        hipLaunchKernelGGL(k_edge_table, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, sp->edges.p);
+        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->nv, ka.p, (int64_t)h_ne, sp->cell_dofs_store.p);
+        FS_SP_HIP(hipGetLastError());
+        FS_SP_HIP(hipStreamSynchronize(s));
+        sp->ndof_cell = 10;
+        sp->cell_dofs = sp->cell_dofs_store.p;
+        sp->n_nodes_local = mesh->nv + h_ne;
+        sp->n_nodes_owned = sp->n_nodes_local;
+        FS_REQUIRE(sp->n_nodes_local < (int64_t)INT32_MAX, "fs_space_create: CG2 dof count exceeds int32");
+    }
+    sp->n_dofs_local = sp->n_nodes_local * ncomp;
+    sp->n_dofs_owned = sp->n_nodes_owned * ncomp;
+    sp->pos_words = (sp->ndof_cell + 3) / 4;
+    const int nd = sp->ndof_cell;
+    const int64_t n_rows = sp->n_nodes_owned;
+
     // 1. keys
-    const int64_t n_keys = 12 * nc + n_rows;
+    const int64_t n_pairs = (int64_t)nd * (nd - 1);
+    const int64_t n_keys = n_pairs * nc + n_rows;
     FS_REQUIRE(n_keys < (int64_t)INT32_MAX, "fs_space_create: %lld pattern keys exceed int32 (mesh too large for one GPU pass)", (long long)n_keys);
     int64_t nnz = 0;
     {
@@ -339,8 +432,8 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP(keys_a.alloc(n_keys));
         FS_SP(keys_b.alloc(n_keys));
         FS_SP(d_count.alloc(1));
-        hipLaunchKernelGGL(k_pair_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, n_rows, keys_a.p);
-        hipLaunchKernelGGL(k_diag_keys, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, keys_a.p + 12 * nc);
+        hipLaunchKernelGGL(k_pair_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, nd, nc, n_rows, keys_a.p);
+        hipLaunchKernelGGL(k_diag_keys, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, keys_a.p + n_pairs * nc);
         FS_SP_HIP(hipGetLastError());
         // 2. sort + unique
         int end_bit = 64;
@@ -432,7 +525,7 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
     FS_SP_HIP(hipGetLastError());
     if (ncomp == 1 && sp->max_row <= 255) {
         // 5a. scalar spaces: row-gather incidence tables (deterministic, atomic-free assembly)
-        const int64_t n_inc = 4 * nc;
+        const int64_t n_inc = (int64_t)nd * nc;
         FS_REQUIRE(n_inc < (int64_t)INT32_MAX, "fs_space_create: cell-vertex incidences exceed int32");
         dbuf<uint64_t> ka, kb;
         dbuf<int32_t> inc_ptr;
@@ -447,7 +540,7 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP(d_max.zero(s));
         FS_SP(d_err.alloc(1));
         FS_SP(d_err.zero(s));
-        hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, n_inc, n_rows, ka.p);
+        hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, n_inc, n_rows, ka.p);
         FS_SP_HIP(hipGetLastError());
         size_t tmp_bytes = 0;
         FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka.p, kb.p, (int)n_inc, 0, 64, s));
@@ -470,8 +563,8 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP(d_max.download(&sp->inc_max, 1, s));
         sp->inc_entries = total;
         FS_SP(sp->inc_cell.alloc(total));
-        FS_SP(sp->inc_pos.alloc(total));
-        hipLaunchKernelGGL(k_inc_fill, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, kb.p, inc_ptr.p, mesh->cells.p, sp->sell_col.p, sp->slice_ptr.p, n_rows, n_slices, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, d_err.p);
+        FS_SP(sp->inc_pos.alloc(total * sp->pos_words));
+        hipLaunchKernelGGL(k_inc_fill, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, kb.p, inc_ptr.p, sp->cell_dofs, nd, sp->sell_col.p, sp->slice_ptr.p, n_rows, n_slices, sp->inc_slice_ptr.p, total, sp->inc_cell.p, sp->inc_pos.p, d_err.p);
         FS_SP_HIP(hipGetLastError());
         int h_err = 0;
         FS_SP(d_err.download(&h_err, 1, s));
@@ -527,5 +620,12 @@ extern "C" int fs_space_format_info(fs_space_t space, int64_t* n_slices, int64_t
         const int64_t bs2 = (int64_t)space->ncomp * space->ncomp;
         *spmv_bytes = space->sell_entries * bs2 * 8 + (space->sell_entries - space->dia_entries) * 4;
     }
+    return FS_OK;
+}
+
+extern "C" int fs_space_get_edges(fs_space_t space, int64_t* n_edges, int32_t* edges) {
+    FS_REQUIRE(space, "fs_space_get_edges: null space");
+    if (n_edges) *n_edges = space->n_edges;
+    if (edges && space->n_edges) FS_CHECK(space->edges.download(edges, 2 * space->n_edges, fs_rt().stream));
     return FS_OK;
 }

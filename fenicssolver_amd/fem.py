@@ -481,11 +481,14 @@ class FunctionSpace:
                  _parent=None):
         if family not in ("CG", "P", "Lagrange"):
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
-        if int(degree) != 1:
-            raise SolverError("fe_degree {} is not built yet in fenicssolver_amd (P1 only)".format(degree))
+        if int(degree) not in (1, 2):
+            raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and scalar P2 only)".format(degree))
+        if int(degree) == 2 and _ncomp != 1:
+            raise SolverError("vector P2 spaces are not built yet in fenicssolver_amd")
         if constrained_domain is not None:
             raise SolverError("periodic_boundary (constrained_domain) is not supported")
         self._mesh = mesh
+        self._degree = int(degree)
         self._ufl_element = _Element("Lagrange", int(degree), _ncomp)
         self._ncomp = _ncomp
         self._component = _component
@@ -498,8 +501,38 @@ class FunctionSpace:
     def ufl_element(self):
         return self._ufl_element
 
+    def degree(self):
+        return self._degree
+
+    def num_nodes(self):
+        """P1: vertices; P2: vertices + edges (edge node e is dof num_vertices + e, lexicographic edges)."""
+        n = self._mesh.num_vertices()
+        return n + len(self._mesh.edges()) if self._degree == 2 else n
+
     def dim(self):
-        return self._mesh.num_vertices() * self._ncomp
+        return self.num_nodes() * self._ncomp
+
+    def node_coordinates(self):
+        co = self._mesh.coordinates()
+        if self._degree == 1:
+            return co
+        ed = self._mesh.edges().astype(np.int64)
+        return np.concatenate([co, 0.5 * (co[ed[:, 0]] + co[ed[:, 1]])], axis=0)
+
+    def facet_nodes(self, facet_ids):
+        """Nodes in the closure of the given facets: their vertices (+ their edges for P2), ascending."""
+        mesh = self._mesh
+        f = mesh.facets()[facet_ids].astype(np.int64)
+        verts = np.unique(f.ravel())
+        if self._degree == 1:
+            return verts
+        nv = mesh.num_vertices()
+        ed = mesh.edges().astype(np.int64)
+        ekey = ed[:, 0] * nv + ed[:, 1]
+        fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facet vertices are ascending
+        fkey = np.unique(fe[:, 0] * nv + fe[:, 1])
+        eid = np.searchsorted(ekey, fkey)
+        return np.concatenate([verts, nv + eid])
 
     def num_sub_spaces(self):
         return self._ncomp if self._ncomp > 1 else 0
@@ -507,7 +540,7 @@ class FunctionSpace:
     def sub(self, i):
         if self._ncomp == 1:
             raise SolverError("sub(): not a vector space")
-        return FunctionSpace(self._mesh, "CG", 1, _ncomp=self._ncomp, _component=int(i), _parent=self)
+        return FunctionSpace(self._mesh, "CG", self._degree, _ncomp=self._ncomp, _component=int(i), _parent=self)
 
     def component(self):
         return self._component
@@ -516,14 +549,14 @@ class FunctionSpace:
         return self._parent if self._parent is not None else self
 
     def tabulate_dof_coordinates(self):
-        return np.repeat(self._mesh.coordinates(), self._ncomp, axis=0)
+        return np.repeat(self.node_coordinates(), self._ncomp, axis=0)
 
     def device(self):
         """Device space (sparsity + SELL slot table), built once per space."""
         root = self.root()
         if root._device is None:
             from . import backend
-            root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, 1)
+            root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree)
         return root._device
 
 
@@ -607,12 +640,17 @@ class Function:
 
     def compute_vertex_values(self, mesh=None):
         """dolfin layout: component-major [ncomp * num_vertices]."""
-        n = self._V._ncomp
-        a = self._vec.array()
-        return a.copy() if n == 1 else a.reshape(-1, n).T.ravel().copy()
+        v = self.vertex_values()
+        return v.copy() if v.ndim == 1 else v.T.ravel().copy()
 
     def vertex_values(self):
-        """[num_vertices] (scalar) or [num_vertices, ncomp] view of the P1 dofs."""
+        """[num_vertices] (scalar) or [num_vertices, ncomp]: the dofs that sit on mesh vertices."""
+        n = self._V._ncomp
+        nv = self._V.mesh().num_vertices()
+        return self._vec.array()[:nv] if n == 1 else self._vec.array().reshape(-1, n)[:nv]
+
+    def node_values(self):
+        """All nodal dofs: [num_nodes] or [num_nodes, ncomp] (P2: vertices then edge midpoints)."""
         n = self._V._ncomp
         return self._vec.array() if n == 1 else self._vec.array().reshape(-1, n)
 
@@ -643,14 +681,16 @@ class Function:
 def interpolate(v, V):
     """dolfin.interpolate(Expression|Constant|Function, V) for P1: nodal evaluation."""
     f = Function(V)
-    co = V.mesh().coordinates()
+    co = V.node_coordinates()
     n = V._ncomp
     if isinstance(v, Expression):
         vals = v.eval_points(co)
     elif isinstance(v, Constant):
         vals = np.broadcast_to(v.values() if n > 1 else float(v), (co.shape[0], n) if n > 1 else (co.shape[0],))
     elif isinstance(v, Function):
-        vals = v.vertex_values()
+        vals = v.node_values()
+        if len(vals) != co.shape[0]:
+            raise SolverError("interpolate: source and target function spaces differ")
     elif isinstance(v, numbers.Number):
         vals = np.full(co.shape[0], float(v))
     else:
@@ -669,7 +709,7 @@ def project(v, V):
 
 def nodal_values(value, V):
     """Values of a coefficient at the vertices: number/Constant/Expression/Function -> array."""
-    co = V.mesh().coordinates()
+    co = V.node_coordinates()
     if isinstance(value, numbers.Number):
         return np.full(co.shape[0], float(value))
     if isinstance(value, Constant):
@@ -678,8 +718,9 @@ def nodal_values(value, V):
     if isinstance(value, Expression):
         return value.eval_points(co)
     if isinstance(value, Function):
-        return value.vertex_values()
-    raise SolverError("cannot evaluate {} at the mesh vertices".format(type(value)))
+        vals = value.node_values()
+        return vals if len(vals) == co.shape[0] else value.vertex_values()
+    raise SolverError("cannot evaluate {} at the nodes of the space".format(type(value)))
 
 
 def is_constant_value(value):
@@ -701,10 +742,10 @@ class DirichletBC:
             sel = np.nonzero(markers.array() == marker_id)[0]
         else:
             raise SolverError("DirichletBC: markers must be a MeshFunction")
-        verts = np.unique(mesh.facets()[sel].ravel()).astype(np.int64)
+        verts = V.facet_nodes(sel).astype(np.int64)     # P2: vertices and edge nodes of the marked facets
         n = V._ncomp
         comp = V.component()
-        co = mesh.coordinates()[verts]
+        co = V.node_coordinates()[verts]
         if n == 1:
             self.dofs = verts.astype(np.int32)
             self.values = self._eval(value, co, 1).reshape(-1)

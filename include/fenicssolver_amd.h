@@ -89,14 +89,17 @@ int fs_mesh_destroy(fs_mesh_t mesh);
  *      the sparsity pattern DOLFIN builds inside the first assemble()) --------- */
 
 #define FS_FAMILY_CG 0
-/* degree 1 only in this revision; ncomp = 1 (scalar) or 3 (vector, node-interleaved
- * dofs as DOLFIN's VectorFunctionSpace lays them out). */
+/* degree 1 with ncomp = 1 (scalar) or 3 (vector, node-interleaved dofs as DOLFIN's
+ * VectorFunctionSpace lays them out); degree 2 scalar (single GPU): dofs = the vertices, then one
+ * node per edge, edges numbered lexicographically by their ascending vertex pair. */
 int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
 int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
                   int64_t* sell_entries);
 /* Storage form chosen per 64-row slice: SELL (values + 4-B columns) or DIA (values only, the
  * 64 rows share one list of column offsets).  spmv_bytes = matrix bytes one SpMV streams. */
 int fs_space_format_info(fs_space_t space, int64_t* n_slices, int64_t* n_dia_slices, int64_t* spmv_matrix_bytes);
+/* CG2: the edge table [n_edges][2] (edge node e is dof n_vertices + e); n_edges = 0 for CG1. */
+int fs_space_get_edges(fs_space_t space, int64_t* n_edges, int32_t* edges);
 int fs_space_destroy(fs_space_t space);
 
 /* ---- vectors (dolfin.Function.vector(), PETScVector) ------------------------ */

@@ -568,3 +568,111 @@ def heat_box_problem(n, k=20.0, t_lo=350.0, t_hi=300.0, axis=2, dims=None, p1=No
     Abc, bbc = apply_dirichlet(A, b, dofs, vals, symmetric=True)
     exact = t_lo + (t_hi - t_lo) * coords[:, axis] / p1[axis]
     return dict(coords=coords, cells=cells, A0=A, A=Abc, b=bbc, dofs=dofs, vals=vals, exact=exact)
+
+
+# --------------------------------------------------------------------------
+# P2 (quadratic Lagrange) tetrahedra: dofs = vertices, then edges (lexicographic edge numbering);
+# local order = 4 vertices, then UFC edges e0=(v2,v3) e1=(v1,v3) e2=(v1,v2) e3=(v0,v3) e4=(v0,v2) e5=(v0,v1)
+# (SURVEY Appendix C3).  FFC integrates grad.grad of P2 with the 4-point degree-2 rule (Appendix D-5).
+# --------------------------------------------------------------------------
+P2_EDGE_VERTS = ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+_QA = (5.0 - np.sqrt(5.0)) / 20.0
+_QB = (5.0 + 3.0 * np.sqrt(5.0)) / 20.0
+P2_QUAD_POINTS = np.array([[_QB, _QA, _QA, _QA], [_QA, _QB, _QA, _QA], [_QA, _QA, _QB, _QA], [_QA, _QA, _QA, _QB]])
+
+
+def p2_cell_dofs(n_vertices, cells):
+    """[nc,10] global dofs of every cell and the edge table [ne,2]."""
+    edges, cell_edges = edge_numbering(cells)
+    cd = np.concatenate([np.asarray(cells, dtype=np.int64), n_vertices + cell_edges.astype(np.int64)], axis=1)
+    return cd.astype(np.int32), edges
+
+
+def p2_dof_coordinates(coords, edges):
+    return np.concatenate([coords, 0.5 * (coords[edges[:, 0]] + coords[edges[:, 1]])], axis=0)
+
+
+def p2_basis_gradients(g, lam):
+    """grad of the 10 P2 basis functions at barycentric point lam[4]; g[nc,4,3] -> [nc,10,3]."""
+    out = np.zeros((g.shape[0], 10, 3))
+    for i in range(4):
+        out[:, i, :] = (4.0 * lam[i] - 1.0) * g[:, i, :]
+    for e, (i, j) in enumerate(P2_EDGE_VERTS):
+        out[:, 4 + e, :] = 4.0 * (lam[i] * g[:, j, :] + lam[j] * g[:, i, :])
+    return out
+
+
+def p2_stiffness_local(coords, cells, k=1.0):
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    Ke = np.zeros((len(cells), 10, 10))
+    for lam in P2_QUAD_POINTS:
+        gp = p2_basis_gradients(g, lam)
+        Ke += 0.25 * np.einsum("cai,cbi->cab", gp, gp)
+    kk = np.asarray(k, dtype=np.float64)
+    return Ke * (vol * (float(kk) if kk.ndim == 0 else kk))[:, None, None]
+
+
+def p2_mass_reference():
+    """Exact P2 mass matrix of a tetrahedron of unit volume (x V for any affine image): 1/420 *
+    {6 same vertex, 1 vertex-vertex, 32 same edge, 16 edges sharing a vertex, 8 opposite edges,
+    -4 vertex on the edge, -6 vertex off the edge}."""
+    M = np.zeros((10, 10))
+    for a in range(4):
+        for b in range(4):
+            M[a, b] = 6.0 if a == b else 1.0
+    for e, (i, j) in enumerate(P2_EDGE_VERTS):
+        for f, (k, l) in enumerate(P2_EDGE_VERTS):
+            shared = len({i, j} & {k, l})
+            M[4 + e, 4 + f] = 32.0 if shared == 2 else (16.0 if shared == 1 else 8.0)
+        for a in range(4):
+            M[a, 4 + e] = M[4 + e, a] = -4.0 if a in (i, j) else -6.0
+    return M / 420.0
+
+
+def p2_mass_local(coords, cells, c=1.0):
+    detJ, _ = p1_geometry(coords, cells)
+    cc = np.asarray(c, dtype=np.float64)
+    w = np.abs(detJ) / 6.0 * (float(cc) if cc.ndim == 0 else cc)
+    return w[:, None, None] * p2_mass_reference()[None]
+
+
+def p2_source_local(coords, cells, f=1.0):
+    """int f phi_a dx for constant f: -V/20 per vertex dof, V/5 per edge dof."""
+    detJ, _ = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    w = np.concatenate([np.full(4, -1.0 / 20.0), np.full(6, 1.0 / 5.0)])
+    ff = np.asarray(f, dtype=np.float64)
+    return (vol * (float(ff) if ff.ndim == 0 else ff))[:, None] * w[None, :]
+
+
+def assemble_generic(n_dofs, cell_dofs, Ke):
+    cd = np.asarray(cell_dofs, dtype=np.int64)
+    nd = cd.shape[1]
+    r = np.repeat(cd, nd, axis=1).ravel()
+    c = np.tile(cd, (1, nd)).ravel()
+    A = sp.coo_matrix((Ke.ravel(), (r, c)), shape=(n_dofs, n_dofs)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def assemble_generic_vector(n_dofs, cell_dofs, be):
+    b = np.zeros(n_dofs)
+    np.add.at(b, np.asarray(cell_dofs, dtype=np.int64).ravel(), be.ravel())
+    return b
+
+
+def p2_facet_dofs(n_vertices, edges, facets, facet_markers, marker_id):
+    """Topological DirichletBC on P2: vertices and edges in the closure of the marked facets (Appendix D-3)."""
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    f = np.asarray(facets, dtype=np.int64)[sel]
+    verts = np.unique(f.ravel())
+    nv = int(n_vertices)
+    ekey = np.asarray(edges, dtype=np.int64)
+    ekey = ekey[:, 0] * nv + ekey[:, 1]
+    fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facets hold ascending vertices
+    fkey = np.unique(fe[:, 0] * nv + fe[:, 1])
+    eid = np.searchsorted(ekey, fkey)
+    assert np.array_equal(ekey[eid], fkey)
+    return np.concatenate([verts, nv + eid]).astype(np.int32)
