@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* 
 
 // P2 boundary load: int g phi_a ds over a facet = g * area / 3 on each of its 3 edge nodes, 0 on the vertices
 __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
-                                  const double* __restrict__ g, const int32_t* __restrict__ edges, int64_t ne,
-                                  int64_t nv, double* __restrict__ b, int* __restrict__ err) {
+                                  const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne,
+                                  int grouped, int64_t nv, double* __restrict__ b, int* __restrict__ err) {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; f < nf; f += stride) {
@@ -353,14 +353,14 @@ __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t
         const int pi[3] = {0, 0, 1}, pj[3] = {1, 2, 2};
         for (int e = 0; e < 3; ++e) {
             const int32_t a = v[pi[e]], bb = v[pj[e]];
-            const int32_t lo_v = a < bb ? a : bb, hi_v = a < bb ? bb : a;
+            const uint32_t lo_v = (uint32_t)(a < bb ? a : bb), hi_v = (uint32_t)(a < bb ? bb : a);
+            const uint64_t key = grouped ? (((uint64_t)(hi_v - lo_v) << 32) | lo_v) : (((uint64_t)lo_v << 32) | hi_v);
             int64_t lo = 0, hi = ne;
             while (lo < hi) {
                 const int64_t mid = (lo + hi) >> 1;
-                const int32_t e0 = edges[2 * mid], e1 = edges[2 * mid + 1];
-                if (e0 < lo_v || (e0 == lo_v && e1 < hi_v)) lo = mid + 1; else hi = mid;
+                if (edge_keys[mid] < key) lo = mid + 1; else hi = mid;
             }
-            if (lo < ne && edges[2 * lo] == lo_v && edges[2 * lo + 1] == hi_v) atomicAdd(&b[nv + lo], w);
+            if (lo < ne && edge_keys[lo] == key) atomicAdd(&b[nv + lo], w);
             else atomicAdd(err, 1);
         }
     }
@@ -802,7 +802,7 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
         dbuf<int> d_err;
         FS_CHECK(d_err.alloc(1));
         FS_CHECK(d_err.zero(s));
-        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edges.p, space->n_edges, space->mesh->nv, b->d.p, d_err.p);
+        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->mesh->nv, b->d.p, d_err.p);
         FS_KERNEL_CHECK();
         int h_err = 0;
         FS_CHECK(d_err.download(&h_err, 1, s));

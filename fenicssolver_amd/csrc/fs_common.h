@@ -131,7 +131,9 @@ struct fs_space_s {
     const int32_t* cell_dofs = nullptr;
     dbuf<int32_t> cell_dofs_store;
     int64_t n_edges = 0;
-    dbuf<int32_t> edges;          // [n_edges][2] (P2 only), ascending vertex pairs, lexicographic order
+    dbuf<int32_t> edges;          // [n_edges][2] (P2 only), ascending vertex pairs, in edge-node order
+    dbuf<uint64_t> edge_keys;     // [n_edges] sorted search keys of the edge nodes
+    int edge_grouped = 0;         // 0: key = (v0<<32|v1); 1: key = ((v1-v0)<<32|v0)  (<= 16 distinct v1-v0)
     int64_t n_nodes_local = 0, n_nodes_owned = 0;  // node level
     int64_t n_dofs_local = 0, n_dofs_owned = 0;    // = nodes * ncomp
     // node-level sparsity: CSR + hybrid SELL-64 / per-slice DIA

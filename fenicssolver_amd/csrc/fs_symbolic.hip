@@ -36,32 +36,43 @@ __global__ void k_pair_keys(const int32_t* __restrict__ cell_dofs, int nd, int64
 // ---- P2: edge nodes ---------------------------------------------------------------------------
 __device__ __constant__ int FS_EDGE_V[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};  // UFC
 
-__global__ void k_edge_keys(const int32_t* __restrict__ cells, int64_t nc, uint64_t* __restrict__ keys) {
+__device__ __forceinline__ uint64_t fs_edge_key(int32_t a, int32_t b, int grouped) {
+    const uint32_t lo = (uint32_t)(a < b ? a : b), hi = (uint32_t)(a < b ? b : a);
+    return grouped ? (((uint64_t)(hi - lo) << 32) | lo) : (((uint64_t)lo << 32) | hi);
+}
+
+__global__ void k_edge_keys(const int32_t* __restrict__ cells, int64_t nc, int grouped, uint64_t* __restrict__ keys) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
         const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
         const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-        for (int e = 0; e < 6; ++e) {
-            const int32_t a = v[FS_EDGE_V[e][0]], b = v[FS_EDGE_V[e][1]];
-            const uint32_t lo = (uint32_t)(a < b ? a : b), hi = (uint32_t)(a < b ? b : a);
-            keys[(int64_t)e * nc + c] = ((uint64_t)lo << 32) | hi;
-        }
+        for (int e = 0; e < 6; ++e)
+            keys[(int64_t)e * nc + c] = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
     }
 }
 
-__global__ void k_edge_table(const uint64_t* __restrict__ ukeys, int64_t ne, int32_t* __restrict__ edges) {
+// v1 - v0 of every lexicographic unique edge, to count the distinct differences
+__global__ void k_edge_deltas(const uint64_t* __restrict__ ukeys, int64_t ne, uint32_t* __restrict__ delta) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < ne; i += stride) delta[i] = (uint32_t)(ukeys[i] & 0xffffffffULL) - (uint32_t)(ukeys[i] >> 32);
+}
+
+__global__ void k_edge_table(const uint64_t* __restrict__ ukeys, int64_t ne, int grouped, int32_t* __restrict__ edges) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < ne; i += stride) {
-        edges[2 * i] = (int32_t)(ukeys[i] >> 32);
-        edges[2 * i + 1] = (int32_t)(ukeys[i] & 0xffffffffULL);
+        const uint32_t hi32 = (uint32_t)(ukeys[i] >> 32), lo32 = (uint32_t)(ukeys[i] & 0xffffffffULL);
+        edges[2 * i] = (int32_t)(grouped ? lo32 : hi32);
+        edges[2 * i + 1] = (int32_t)(grouped ? lo32 + hi32 : lo32);
     }
 }
 
 // cell_dofs[c] = {4 vertices, nv + index of each of the 6 edges in the sorted unique edge keys}
 __global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, int64_t nv,
-                               const uint64_t* __restrict__ ukeys, int64_t ne, int32_t* __restrict__ cell_dofs) {
+                               const uint64_t* __restrict__ ukeys, int64_t ne, int grouped,
+                               int32_t* __restrict__ cell_dofs) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
@@ -69,8 +80,7 @@ __global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, in
         const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
         for (int a = 0; a < 4; ++a) cell_dofs[c * 10 + a] = v[a];
         for (int e = 0; e < 6; ++e) {
-            const int32_t a = v[FS_EDGE_V[e][0]], b = v[FS_EDGE_V[e][1]];
-            const uint64_t key = ((uint64_t)(uint32_t)(a < b ? a : b) << 32) | (uint32_t)(a < b ? b : a);
+            const uint64_t key = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
             int64_t lo = 0, hi = ne;
             while (lo < hi) {
                 const int64_t mid = (lo + hi) >> 1;
@@ -109,7 +119,7 @@ __global__ void k_rowptr(const uint64_t* __restrict__ keys, int64_t nnz, int64_t
     }
 }
 
-#define FS_DIA_CAP 48  // most distinct offsets a DIA slice may have
+#define FS_DIA_CAP 72  // most distinct offsets a DIA slice may have (P2 vertex rows of a Kuhn mesh: 65)
 
 // One wavefront per slice.  Computes the longest row and the sorted set of distinct (col - row)
 // offsets used by the 64 rows (each row's columns are sorted, so a per-lane cursor walks them).
@@ -388,25 +398,49 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         FS_SP(ka.alloc(n_ek));
         FS_SP(kb.alloc(n_ek));
         FS_SP(d_count.alloc(1));
-        hipLaunchKernelGGL(k_edge_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, ka.p);
-        FS_SP_HIP(hipGetLastError());
-        size_t tb1 = 0, tb2 = 0;
+        size_t tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
         FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, ka.p, kb.p, (int)n_ek, 0, 64, s));
         FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, kb.p, ka.p, d_count.p, (int)n_ek, s));
-        const size_t tbm = tb1 > tb2 ? tb1 : tb2;
+        dbuf<uint32_t> da, db;
+        FS_SP(da.alloc(n_ek));
+        FS_SP(db.alloc(n_ek));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb3, da.p, db.p, (int)n_ek, 0, 32, s));
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tb4, db.p, da.p, d_count.p, (int)n_ek, s));
+        size_t tbm = tb1 > tb2 ? tb1 : tb2;
+        if (tb3 > tbm) tbm = tb3;
+        if (tb4 > tbm) tbm = tb4;
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tbm + 16));
-        size_t tb = tbm;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_ek, 0, 64, s));
-        tb = tbm;
-        FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, kb.p, ka.p, d_count.p, (int)n_ek, s));
         int h_ne = 0;
-        FS_SP(d_count.download(&h_ne, 1, s));
+        // pass 0: lexicographic keys -> unique edges -> number of distinct v1 - v0; pass 1 (structured meshes
+        // only, <= 16 distinct differences): regroup the edges by that difference
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(k_edge_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, sp->edge_grouped, ka.p);
+            FS_SP_HIP(hipGetLastError());
+            size_t tb = tbm;
+            FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_ek, 0, 64, s));
+            tb = tbm;
+            FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, kb.p, ka.p, d_count.p, (int)n_ek, s));
+            FS_SP(d_count.download(&h_ne, 1, s));
+            if (pass == 1) break;
+            hipLaunchKernelGGL(k_edge_deltas, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, da.p);
+            FS_SP_HIP(hipGetLastError());
+            tb = tbm;
+            FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, da.p, db.p, h_ne, 0, 32, s));
+            tb = tbm;
+            FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, db.p, da.p, d_count.p, h_ne, s));
+            int h_nd = 0;
+            FS_SP(d_count.download(&h_nd, 1, s));
+            if (h_nd > 16) break;
+            sp->edge_grouped = 1;
+        }
         sp->n_edges = h_ne;
         FS_SP(sp->edges.alloc(2 * (int64_t)h_ne));
+        FS_SP(sp->edge_keys.alloc(h_ne));
         FS_SP(sp->cell_dofs_store.alloc(10 * nc));
-        hipLaunchKernelGGL(k_edge_table, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, sp->edges.p);
-        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->nv, ka.p, (int64_t)h_ne, sp->cell_dofs_store.p);
+        FS_SP_HIP(hipMemcpyAsync(sp->edge_keys.p, ka.p, (size_t)h_ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_edge_table, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->edges.p);
+        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->nv, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->cell_dofs_store.p);
         FS_SP_HIP(hipGetLastError());
         FS_SP_HIP(hipStreamSynchronize(s));
         sp->ndof_cell = 10;

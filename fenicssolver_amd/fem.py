@@ -504,10 +504,27 @@ class FunctionSpace:
     def degree(self):
         return self._degree
 
+    P2_MAX_EDGE_CLASSES = 16
+
+    def edge_nodes(self):
+        """P2: the edge table [ne,2] in edge-node order (edge node e is dof num_vertices + e).
+        DOLFIN's dof numbering is not reproducible, so the build fixes its own rule, the same as
+        libfsamd.so applies on the device: lexicographic (v0, v1) in general; meshes with at most 16
+        distinct index differences v1 - v0 (structured meshes) group their edges by that difference
+        first, so that consecutive matrix rows share their column offsets (DIA slices)."""
+        root = self.root()
+        if getattr(root, "_edge_nodes", None) is None:
+            ed = root._mesh.edges()
+            delta = ed[:, 1].astype(np.int64) - ed[:, 0]
+            if len(np.unique(delta)) <= self.P2_MAX_EDGE_CLASSES:
+                ed = ed[np.lexsort((ed[:, 0], delta))]
+            root._edge_nodes = ed
+        return root._edge_nodes
+
     def num_nodes(self):
-        """P1: vertices; P2: vertices + edges (edge node e is dof num_vertices + e, lexicographic edges)."""
+        """P1: vertices; P2: vertices + edge nodes."""
         n = self._mesh.num_vertices()
-        return n + len(self._mesh.edges()) if self._degree == 2 else n
+        return n + len(self.edge_nodes()) if self._degree == 2 else n
 
     def dim(self):
         return self.num_nodes() * self._ncomp
@@ -516,7 +533,7 @@ class FunctionSpace:
         co = self._mesh.coordinates()
         if self._degree == 1:
             return co
-        ed = self._mesh.edges().astype(np.int64)
+        ed = self.edge_nodes().astype(np.int64)
         return np.concatenate([co, 0.5 * (co[ed[:, 0]] + co[ed[:, 1]])], axis=0)
 
     def facet_nodes(self, facet_ids):
@@ -527,12 +544,13 @@ class FunctionSpace:
         if self._degree == 1:
             return verts
         nv = mesh.num_vertices()
-        ed = mesh.edges().astype(np.int64)
+        ed = self.edge_nodes().astype(np.int64)
         ekey = ed[:, 0] * nv + ed[:, 1]
+        sorter = np.argsort(ekey)
         fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facet vertices are ascending
         fkey = np.unique(fe[:, 0] * nv + fe[:, 1])
-        eid = np.searchsorted(ekey, fkey)
-        return np.concatenate([verts, nv + eid])
+        eid = sorter[np.searchsorted(ekey[sorter], fkey)]
+        return np.concatenate([verts, np.sort(nv + eid)])
 
     def num_sub_spaces(self):
         return self._ncomp if self._ncomp > 1 else 0

@@ -581,11 +581,29 @@ _QB = (5.0 + 3.0 * np.sqrt(5.0)) / 20.0
 P2_QUAD_POINTS = np.array([[_QB, _QA, _QA, _QA], [_QA, _QB, _QA, _QA], [_QA, _QA, _QB, _QA], [_QA, _QA, _QA, _QB]])
 
 
+P2_MAX_EDGE_CLASSES = 16
+
+
+def p2_edge_order(edges):
+    """Order of the edge nodes of a P2 space.  DOLFIN's dof numbering is not reproducible (Appendix D-7), so
+    the build fixes its own: lexicographic by (v0, v1) in general; when the mesh has at most 16 distinct
+    index differences v1 - v0 (structured meshes: 7) edges are grouped by that difference first, which makes
+    consecutive rows share their column offsets.  Returns the permutation of the lexicographic edge list."""
+    e = np.asarray(edges, dtype=np.int64)
+    delta = e[:, 1] - e[:, 0]
+    if len(np.unique(delta)) <= P2_MAX_EDGE_CLASSES:
+        return np.lexsort((e[:, 0], delta))
+    return np.arange(len(e))
+
+
 def p2_cell_dofs(n_vertices, cells):
-    """[nc,10] global dofs of every cell and the edge table [ne,2]."""
+    """[nc,10] global dofs of every cell and the edge table [ne,2] in edge-node order."""
     edges, cell_edges = edge_numbering(cells)
-    cd = np.concatenate([np.asarray(cells, dtype=np.int64), n_vertices + cell_edges.astype(np.int64)], axis=1)
-    return cd.astype(np.int32), edges
+    order = p2_edge_order(edges)
+    rank = np.empty(len(edges), dtype=np.int64)
+    rank[order] = np.arange(len(edges))
+    cd = np.concatenate([np.asarray(cells, dtype=np.int64), n_vertices + rank[cell_edges.astype(np.int64)]], axis=1)
+    return cd.astype(np.int32), edges[order]
 
 
 def p2_dof_coordinates(coords, edges):
@@ -671,8 +689,9 @@ def p2_facet_dofs(n_vertices, edges, facets, facet_markers, marker_id):
     nv = int(n_vertices)
     ekey = np.asarray(edges, dtype=np.int64)
     ekey = ekey[:, 0] * nv + ekey[:, 1]
+    sorter = np.argsort(ekey)
     fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facets hold ascending vertices
     fkey = np.unique(fe[:, 0] * nv + fe[:, 1])
-    eid = np.searchsorted(ekey, fkey)
+    eid = sorter[np.searchsorted(ekey[sorter], fkey)]
     assert np.array_equal(ekey[eid], fkey)
-    return np.concatenate([verts, nv + eid]).astype(np.int32)
+    return np.concatenate([verts, np.sort(nv + eid)]).astype(np.int32)

@@ -30,7 +30,10 @@ def test_p2_edges_pattern_and_matrices(gpu, data_dir):
         mesh, V, cd, edges = _p2(gpu, co, ce)
         n = len(co) + len(edges)
         assert V.n_owned == n
-        assert np.array_equal(V.edges(), edges)                    # bit-exact edge numbering
+        assert np.array_equal(V.edges(), edges)                    # bit-exact edge-node numbering (both rules)
+        lex = fo.edge_numbering(ce)[0]
+        grouped = len(np.unique(lex[:, 1].astype(np.int64) - lex[:, 0])) <= 16
+        assert grouped == (len(co) == 64)                          # the Kuhn cube is grouped, the Gmsh mesh is not
         A = gpu.DeviceMatrix(V)
         rng = np.random.default_rng(0)
         kc = rng.uniform(0.5, 2.0, len(ce))
@@ -144,8 +147,9 @@ def test_p2_solver_api_config1_and_box(gpu, data_dir):
     area = fo.facet_areas(co, tri)
     nv = len(co)
     ekey = edges[:, 0].astype(np.int64) * nv + edges[:, 1]
+    sorter = np.argsort(ekey)          # the structured cube groups its edge nodes by v1 - v0
     for (i, j) in ((0, 1), (0, 2), (1, 2)):
-        eid = np.searchsorted(ekey, tri[:, i] * nv + tri[:, j])
+        eid = sorter[np.searchsorted(ekey[sorter], tri[:, i] * nv + tri[:, j])]
         np.add.at(b, nv + eid, 12.0 * area / 3.0)
     dofs = fo.p2_facet_dofs(nv, edges, facets, fm, 1)
     Ab, bb = fo.apply_dirichlet(A, b, dofs, 360.0, True)

@@ -230,7 +230,9 @@ def test_expression_and_dirichlet():
     bcv = DirichletBC(W, Constant((0, 0, 1e-3)), mf, 1)
     assert bcv.dofs.size == 3 * 16 and np.allclose(bcv.values.reshape(-1, 3), [0, 0, 1e-3])
     with pytest.raises(SolverError):
-        FunctionSpace(m, "CG", 2)          # P2 not built yet: loud, not silent
+        FunctionSpace(m, "CG", 3)          # P3 is not built: loud, not silent
+    with pytest.raises(SolverError):
+        VectorFunctionSpace(m, "Lagrange", 2)
 
 
 def test_scalar_form_recognition_config1(data_dir):
@@ -351,3 +353,53 @@ def test_elasticity_form_recognition():
     assert ns.shape == (6, 3 * len(co)) and np.allclose(ns @ ns.T, np.eye(6), atol=1e-12)
     K = fo.assemble_p1_elasticity(co, mesh.cells(), 2e11, 0.27)
     assert np.abs(K @ ns.T).max() < 1e-9 * abs(K).max()
+
+
+# ---------------------------------------------------------------- P2
+def test_p2_oracle_known_answers():
+    """Appendix C3: exact P2 stiffness of the reference tetrahedron (x30), exact mass (row sums), loads."""
+    co = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+    ce = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    K = fo.p2_stiffness_local(co, ce, 1.0)[0] * 30
+    ref = np.array([[9, 1, 1, 1, 2, 2, 2, -6, -6, -6], [1, 3, 0, 0, 0, -1, -1, 1, 1, -4], [1, 0, 3, 0, -1, 0, -1, 1, -4, 1],
+                    [1, 0, 0, 3, -1, -1, 0, -4, 1, 1], [2, 0, -1, -1, 16, 4, 4, -8, -8, -8], [2, -1, 0, -1, 4, 16, 4, -8, -8, -8],
+                    [2, -1, -1, 0, 4, 4, 16, -8, -8, -8], [-6, 1, 1, -4, -8, -8, -8, 24, 4, 4], [-6, 1, -4, 1, -8, -8, -8, 4, 24, 4],
+                    [-6, -4, 1, 1, -8, -8, -8, 4, 4, 24]], dtype=float)
+    assert np.abs(K - ref).max() < 1e-13
+    M = fo.p2_mass_reference()
+    assert abs(M.sum() - 1.0) < 1e-15 and np.allclose(M, M.T)
+    assert np.allclose(M.sum(axis=1), [-1 / 20.0] * 4 + [1 / 5.0] * 6)       # = int phi_a
+    # quadratic patch test + structure counts (C7: P2 max 65 entries per row on Kuhn cubes)
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), 2, 2, 2)
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    X = fo.p2_dof_coordinates(co, edges)
+    n = len(X)
+    A = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 1.0))
+    assert np.diff(A.indptr).max() == 65
+    u = 1 + X[:, 0] ** 2 - 0.5 * X[:, 1] ** 2 + X[:, 0] * X[:, 2] + 2 * X[:, 1]
+    b = fo.assemble_generic_vector(n, cd, fo.p2_source_local(co, ce, -1.0))
+    onb = np.nonzero(((X == 0) | (X == 1)).any(axis=1))[0]
+    Ab, bb = fo.apply_dirichlet(A, b, onb, u[onb], True)
+    assert np.abs(fo.solve_direct(Ab, bb) - u).max() < 1e-12
+
+
+def test_p2_host_space_matches_oracle_numbering(data_dir):
+    from fenicssolver_amd.fem import Mesh, UnitCubeMesh, FunctionSpace, MeshFunction, AutoSubDomain, DirichletBC, Expression, near
+    for m in (UnitCubeMesh(3, 3, 3), Mesh(os.path.join(data_dir, "mesh.xml"))):
+        V = FunctionSpace(m, "CG", 2)
+        co, ce = m.coordinates(), m.cells()
+        cd, edges = fo.p2_cell_dofs(len(co), ce)
+        assert np.array_equal(V.edge_nodes(), edges) and V.dim() == len(co) + len(edges)
+        assert np.array_equal(V.node_coordinates(), fo.p2_dof_coordinates(co, edges))
+    m = UnitCubeMesh(3, 3, 3)
+    V = FunctionSpace(m, "CG", 2)
+    mf = MeshFunction("size_t", m, 2)
+    AutoSubDomain(lambda x: near(x[2], 0.0)).mark(mf, 1)
+    bc = DirichletBC(V, Expression("1+x[0]*x[1]", degree=2), mf, 1)
+    co, ce = m.coordinates(), m.cells()
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    facets, _, _ = fo.facet_numbering(ce)
+    ref = fo.p2_facet_dofs(len(co), edges, facets, mf.array(), 1)
+    assert np.array_equal(bc.dofs, ref) and len(ref) == 49
+    Xb = V.node_coordinates()[ref]
+    assert np.allclose(bc.values, 1 + Xb[:, 0] * Xb[:, 1])
