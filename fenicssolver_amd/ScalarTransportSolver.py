@@ -42,15 +42,22 @@ class ScalarTransportSolver(SolverBase):
         self.nonlinear_material = False
         for v in self.material.values():
             if callable(v) and not isinstance(v, (Function, Constant, Expression)):
-                self.nonlinear = True
+                self.nonlinear = True   # (re-checked in generate_form: users patch the material afterwards)
         if self.scalar_name == "electric_potential":
             assert self.settings['solver_settings']['transient_settings']['transient'] is False
 
     # ------------------------------------------------------------------ material
     def _finish_material(self, c, T):
+        """Material value; a python function of T (ScalarTransportSolver.py:88-91, 106-109, 125-128) makes the
+        problem nonlinear and is evaluated cell-wise at the mean of the current vertex values."""
         from inspect import isfunction
         if isfunction(c):
             self.nonlinear_material = True
+            if isinstance(T, Function):
+                Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)
+                return forms.VolumeCoefficient("cell", np.broadcast_to(np.asarray(c(Tbar), dtype=np.float64), Tbar.shape).copy())
+            if T is None:
+                raise SolverError('a temperature-dependent material property needs the current field')
             return c(T)
         return self.get_material_value(c)
 
@@ -249,11 +256,16 @@ class ScalarTransportSolver(SolverBase):
                 raise SolverError("advection stabilization '{}' (SUPG/IP, ScalarTransportSolver.py:259-328) is not "
                                   "built yet; only the Galerkin term is".format(ads['stabilization_method']))
             velocity = self.get_convective_velocity_function(self.convective_velocity)
-        if self.nonlinear_material or self.nonlinear:
-            raise SolverError('temperature-dependent material properties (Newton) are not built yet')
-
         F = forms.ScalarForm(self.function_space)
         F.conductivity = self._volume_coefficient(conductivity, 'conductivity')
+        from inspect import isfunction
+        kraw = self.material.get('conductivity', self.material.get('thermal_conductivity'))
+        if isfunction(kraw):
+            F.conductivity_fn = kraw
+        if self.nonlinear_material and F.conductivity_fn is None:
+            raise SolverError('only the conductivity may depend on the temperature on the GPU back end')
+        if (self.nonlinear_material or self.nonlinear) and self.function_space.degree() != 1:
+            raise SolverError('nonlinear problems are built for P1 spaces only')
         if self.transient_settings['transient']:
             F.transient = True
             F.dt = float(self.get_time_step(time_iter_))
@@ -278,11 +290,44 @@ class ScalarTransportSolver(SolverBase):
             F.sources.extend(bs_items)
 
         if self.scalar_name == "temperature":
-            if ('radiation_settings' in self.settings and self.settings['radiation_settings']) or \
-                    (hasattr(self, 'radiation_settings') and self.radiation_settings):
-                raise SolverError('radiation (nonlinear, ScalarTransportSolver.py:338-376) is not built yet')
-            self.has_radiation = False
+            if ('radiation_settings' in self.settings and self.settings['radiation_settings']):
+                self.radiation_settings = self.settings['radiation_settings']
+                self.has_radiation = True
+            elif hasattr(self, 'radiation_settings') and self.radiation_settings:
+                self.has_radiation = True
+            else:
+                self.has_radiation = False
+            if self.has_radiation:
+                if self.function_space.degree() != 1:
+                    raise SolverError('radiation is built for P1 spaces only')
+                self.nonlinear = True
+                F.radiation = self.radiation_coefficients()
+        if self.nonlinear_material:
+            self.nonlinear = True
+        F.nonlinear = bool(self.nonlinear)
         return F, bcs
+
+    def radiation_coefficients(self):
+        """(emissivity * Stefan-Boltzmann, ambient temperature) of  m (Ta^4 - T^4)  (:361-376)."""
+        Stefan_constant = 5.670367e-8
+        if 'emissivity' in self.material:
+            emissivity = self.material['emissivity']
+        elif 'emissivity' in self.radiation_settings:
+            emissivity = self.radiation_settings['emissivity']
+        else:
+            emissivity = 1.0
+        if 'ambient_temperature' in self.radiation_settings:
+            T_amb = self.radiation_settings['ambient_temperature']
+        else:
+            T_amb = self.reference_values['temperature']
+        return (float(emissivity) * Stefan_constant, float(T_amb))
+
+    def refresh_nonlinear_form(self, F, T):
+        """Re-evaluate the temperature-dependent coefficients of F at the Newton iterate T."""
+        if F.conductivity_fn is not None:
+            Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)
+            F.conductivity = forms.VolumeCoefficient(
+                "cell", np.broadcast_to(np.asarray(F.conductivity_fn(Tbar), dtype=np.float64), Tbar.shape).copy())
 
     def solve_form(self, F, T_current, bcs):
         if self.nonlinear:

@@ -583,8 +583,71 @@ class SolverBase():
         return self._device_solve(A, b, u, 'solve_linear_problem', method=method)
 
     def solve_nonlinear_problem(self, F, u_current, Dirichlet_bcs, J):
-        raise SolverError('nonlinear problems (Newton, SolverBase.py:615-626) are not built yet in '
-                          'fenicssolver_amd: callable material properties and radiation are unsupported')
+        """NonlinearVariationalSolver.solve() (SolverBase.py:615-626): Newton iteration with DOLFIN's
+        NewtonSolver defaults (relative 1e-9 / absolute 1e-10 on the residual norm, 50 iterations, no
+        relaxation).  Every linear step is assembled and solved on the GPU.  The radiation term is
+        linearised exactly per facet (facet-mean temperature); a temperature-dependent conductivity is
+        re-evaluated each iteration and its derivative left out of the Jacobian (quasi-Newton), as the
+        reference's own remark at ScalarTransportSolver.py:281-283 does."""
+        from . import backend
+        if not isinstance(F, forms.ScalarForm):
+            raise SolverError('nonlinear solves are built for scalar transport only')
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        newton = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
+        rtol = float(newton.get('relative_tolerance', 1e-9))
+        atol = float(newton.get('absolute_tolerance', 1e-10))
+        max_it = int(newton.get('maximum_iterations', 50))
+        V = F.space.device()
+        n = V.n_owned
+        dofs, vals = self._bc_arrays(Dirichlet_bcs)
+        T = u_current.vector().array().copy()
+        if dofs.size:
+            T[dofs] = vals                                  # the first iterate carries the boundary values
+        ext = self.mesh.facets()[self.mesh.exterior_facets()]
+        krtol, kmax, pc = self._krylov_options()
+        r0 = None
+        self.newton_iterations = 0
+        for it in range(max_it + 1):
+            u_current.vector().set_local(T)
+            if hasattr(self, 'refresh_nonlinear_form'):
+                self.refresh_nonlinear_form(F, u_current)
+            A, b = self.assemble_system(F, [], symmetric=True)      # operator and loads at the iterate, no BCs
+            if F.radiation is not None:
+                m_, T_amb = F.radiation
+                Tf = T[ext.astype(np.int64)].mean(axis=1)
+                backend.assemble_facet_vector(V, b, ext, m_ * (T_amb ** 4 - Tf ** 4))
+            Tdev = backend.DeviceVector(V.n_local, np.concatenate([T, np.zeros(V.n_local - n)]))
+            r = backend.DeviceVector(n)
+            A.spmv(Tdev, r)
+            r.axpy(-1.0, b)                                         # r = A(T) T - b(T)
+            if dofs.size:
+                backend.set_dirichlet_values(r, dofs, 0.0)          # residual of constrained rows is zero
+            rnorm = float(np.sqrt(r.dot(r)))
+            if r0 is None:
+                r0 = rnorm
+            if sp.get('monitor_convergence'):
+                self.logger.info("Newton iteration %d: r (abs) = %.3e (tol = %.3e) r (rel) = %.3e (tol = %.3e)",
+                                 it, rnorm, atol, rnorm / r0 if r0 > 0 else 0.0, rtol)
+            if rnorm < atol or (r0 > 0 and rnorm / r0 < rtol):
+                break
+            if it == max_it:
+                raise SolverError('Newton solver did not converge in {} iterations (residual {:.3e})'.format(max_it, rnorm))
+            if F.radiation is not None:
+                A.add_facet_mass(ext, 4.0 * m_ * Tf ** 3)            # d/dT of  + m T^4 q ds
+            rhs = backend.DeviceVector(n)
+            rhs.axpy(-1.0, r)
+            if dofs.size:
+                A.apply_dirichlet(rhs, dofs, 0.0, symmetric=True)   # delta = 0 on the Dirichlet boundary
+            delta = backend.DeviceVector(n)
+            stats = backend.krylov_solve(A, rhs, delta, rtol=min(krtol, 1e-10), max_iter=kmax, precond=pc,
+                                         method="cg" if F.symmetric else "bicgstab")
+            self.last_solve_stats = stats
+            if stats['converged'] != 1:
+                raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))
+            T = T + delta.get()
+            self.newton_iterations = it + 1
+        u_current.vector().set_local(T)
+        return u_current
 
     def solve_amg(self, F, u, bcs):
         """assemble_system + CG (SolverBase.py:643-672).  The reference preconditions with PETSc's

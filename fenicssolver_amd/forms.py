@@ -78,6 +78,11 @@ class ScalarForm:
         self.robin = []               # [FacetRobin]
         self.advection = None         # (velocity: 3-vector or array[n_cells,3], scale = capacity) -> non-symmetric
         self.symmetric = True
+        # nonlinear terms (Newton): radiation  - m (Ta^4 - T^4) q ds over the whole boundary, m = emissivity*sigma
+        # (ScalarTransportSolver.py:338-350, 361-376) and material callables re-evaluated every iteration
+        self.radiation = None         # (m, T_ambient)
+        self.conductivity_fn = None   # callable(T array) -> k
+        self.nonlinear = False
 
     def describe(self):
         """Canonical, order-stable description used by the golden-term tests."""
@@ -90,6 +95,7 @@ class ScalarForm:
             "facet_loads": [(f.marker_id, _plain(f.g), f.origin) for f in self.facet_loads],
             "robin": [(r.marker_id, r.h, r.ambient) for r in self.robin],
             "advection": None if self.advection is None else (_plain(self.advection[0]), float(self.advection[1])),
+            "radiation": self.radiation, "nonlinear": self.nonlinear,
         }
 
 

@@ -270,3 +270,53 @@ def test_convective_velocity_case(gpu):
     from fenicssolver_amd.SolverBase import SolverError
     with pytest.raises(SolverError):
         ScalarTransportSolver(s2).solve()
+
+
+def test_radiation_and_temperature_dependent_conductivity_newton(gpu):
+    """examples/test_heat_transfer.py:195-218 test_radiation(): nonlinear path through
+    solve_nonlinear_problem, checked against a Newton iteration written with the oracle."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(4)
+    s['boundary_conditions']["cold"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}
+    s['radiation_settings'] = {'ambient_temperature': 280.0, 'emissivity': 0.9}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-13}
+    solver = ScalarTransportSolver(s)
+    solver.material['conductivity'] = lambda T: 0.6 * (1.0 + 0.002 * (T - 300.0))
+    solver.material['emissivity'] = 0.9
+    T = solver.solve().vector().array()
+    assert solver.nonlinear and 2 <= solver.newton_iterations <= 30
+    co, ce = m.coordinates(), m.cells()
+    facets, _, cnt = fo.facet_numbering(ce)
+    ext = facets[cnt == 1].astype(np.int64)
+    area = fo.facet_areas(co, ext)
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    dofs = np.concatenate([top, bot])
+    vals = np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+    mrad, Ta = 0.9 * 5.670367e-8, 280.0
+    Tn = np.full(len(co), 300.0)
+    Tn[dofs] = vals
+    cells = ce.astype(np.int64)
+    for it in range(60):
+        k = 0.6 * (1.0 + 0.002 * (Tn[cells].mean(axis=1) - 300.0))
+        A = fo.assemble_p1_scalar(co, ce, k).tolil()
+        Tf = Tn[ext].mean(axis=1)
+        b = np.zeros(len(co))
+        np.add.at(b, ext.ravel(), np.repeat(mrad * (Ta ** 4 - Tf ** 4) * area / 3.0, 3))
+        r = A @ Tn - b
+        r[dofs] = 0.0
+        if np.linalg.norm(r) < 1e-10:
+            break
+        J = A.tocsr()
+        import scipy.sparse as sp
+        base = (np.ones((3, 3)) + np.eye(3)) / 12.0
+        Me = (4.0 * mrad * Tf ** 3 * area)[:, None, None] * base[None]
+        J = J + sp.coo_matrix((Me.ravel(), (np.repeat(ext, 3, axis=1).ravel(), np.tile(ext, (1, 3)).ravel())),
+                              shape=J.shape).tocsr()
+        Jb, rb = fo.apply_dirichlet(J, -r, dofs, 0.0, True)
+        Tn = Tn + fo.solve_direct(Jb, rb)
+    assert np.abs(T - Tn).max() <= 1e-6
+    # radiation to a colder ambient pulls the interior below the linear conduction profile
+    lin = 300.0 + 60.0 * co[:, 1]
+    assert (T - lin).min() < -1e-3 and T.max() <= 360.0 + 1e-9
