@@ -1,0 +1,106 @@
+"""BASELINE.json's configurations at FULL size, checked through size-independent properties
+(the oracle cannot assemble 10 M-DOF problems in seconds): exact discrete solutions the
+set-ups imply, linearity in the data, symmetry of the operator, true-residual convergence and
+the iteration anchors of SURVEY.md Appendix C8."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _heat_cube(gpu, n, degree=1, lo=350.0, hi=300.0, k=20.0, rtol=1e-8):
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    V = gpu.DeviceSpace(mesh, 1, degree=degree)
+    if degree == 1:
+        P = (n + 1) ** 2
+        dofs = np.concatenate([np.arange(P), np.arange(n * P, (n + 1) * P)])
+        vals = np.concatenate([np.full(P, lo), np.full(P, hi)])
+        z = None
+    else:
+        xyz, _, _ = mesh.get()
+        ed = V.edges().astype(np.int64)
+        z = np.concatenate([xyz[:, 2], 0.5 * (xyz[ed[:, 0], 2] + xyz[ed[:, 1], 2])])
+        b0, b1 = np.nonzero(z == 0.0)[0], np.nonzero(z == 1.0)[0]
+        dofs = np.concatenate([b0, b1])
+        vals = np.concatenate([np.full(len(b0), lo), np.full(len(b1), hi)])
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=k)
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    x = gpu.DeviceVector(V.n_owned)
+    st = gpu.krylov_solve(A, b, x, rtol=rtol, max_iter=50000)
+    return mesh, V, A, x, st, z
+
+
+def test_config2_p1_poisson_1m_dof(gpu):
+    """configs[1]: unit cube n=99, 1 000 000 DOF, 5 821 794 tets, 14 761 198 nnz."""
+    n = 99
+    mesh, V, A, x, st, _ = _heat_cube(gpu, n)
+    assert (V.n_owned, V.nnz) == (1000000, 14761198) and mesh.info()[1] == 5821794
+    assert st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
+    assert st["iterations"] == 293                     # == the C oracle's PCG count on the same problem
+    P = (n + 1) ** 2
+    zc = np.repeat(np.arange(n + 1) / n, P)
+    T = x.get()
+    assert np.abs(T - (350.0 - 50.0 * zc)).max() <= 5e-4      # exact discrete solution is linear in z
+    # linearity in the boundary data: doubling the Dirichlet values doubles the solution
+    _, _, _, x2, st2, _ = _heat_cube(gpu, n, lo=700.0, hi=600.0)
+    assert st2["iterations"] == st["iterations"]
+    assert np.abs(x2.get() - 2.0 * T).max() <= 1e-9 * 700.0
+    # symmetry of the assembled operator after symmetric elimination: <A u, v> == <u, A v>
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(V.n_owned), rng.standard_normal(V.n_owned)
+    du, dv, w = gpu.DeviceVector(V.n_local, u), gpu.DeviceVector(V.n_local, v), gpu.DeviceVector(V.n_owned)
+    A.spmv(du, w)
+    auv = float(w.get() @ v)
+    A.spmv(dv, w)
+    uav = float(w.get() @ u)
+    assert abs(auv - uav) <= 1e-10 * abs(auv)
+    # the solve is deterministic: same bits on a second run (fixed-order reductions, atomic-free assembly)
+    _, _, _, x3, _, _ = _heat_cube(gpu, n)
+    assert np.array_equal(x3.get(), T)
+
+
+def test_config2_family_10m_dof_hbm_resident(gpu):
+    n = 215
+    mesh, V, A, x, st, _ = _heat_cube(gpu, n)
+    assert V.n_owned == 216 ** 3 and st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
+    assert V.n_dia_slices == V.n_slices                 # every slice of the Kuhn cube is stored in DIA form
+    zc = np.repeat(np.arange(n + 1) / n, (n + 1) ** 2)
+    assert np.abs(x.get() - (350.0 - 50.0 * zc)).max() <= 2e-3
+
+
+def test_config3_elasticity_cantilever_5m_dof(gpu):
+    """configs[2]: BoxMesh((0,0,0),(10,1,1),472,59,59), vector P1, E=2e11, nu=0.27, clamped at x=0,
+    body force; 5 108 400 DOF.  Euler-Bernoulli tip deflection q L^4 / (8 E I)."""
+    nx, ny, nz = 472, 59, 59
+    E, nu = 2e11, 0.27
+    mu, lm = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0, 0, 0), (10.0, 1.0, 1.0))
+    V = gpu.DeviceSpace(mesh, 3)
+    assert V.n_owned == 5108400 and mesh.info()[1] == 9858192
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(mu, lm))
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, vector_value=(0.0, 0.0, -7800.0 * 10.0))
+    nodes = np.arange((nx + 1) * (ny + 1) * (nz + 1))
+    left = nodes[nodes % (nx + 1) == 0]
+    A.apply_dirichlet(b, (left[:, None] * 3 + np.arange(3)).ravel(), 0.0, symmetric=True)
+    x = gpu.DeviceVector(V.n_owned)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-8, max_iter=100000)
+    assert st["converged"] == 1 and st["true_rel_residual"] <= 2e-8
+    u = x.get().reshape(-1, 3)
+    beam = -7800.0 * 10.0 * 10.0 ** 4 / (8 * E * (1.0 / 12.0))
+    tip = u[nodes % (nx + 1) == nx, 2].mean()
+    assert abs(tip - beam) <= 0.01 * abs(beam)
+    assert np.abs(u[left]).max() == 0.0                     # clamped face
+    assert abs(u[:, 1].mean()) <= 1e-3 * abs(tip)           # no net sideways motion (the Kuhn split is not mirror-symmetric)
+
+
+def test_config4_p2_poisson_10m_dof_single_gpu(gpu):
+    """configs[3] on ONE GPU: unit cube n=107, P2, 215^3 = 9 938 375 DOF, 7 350 258 tets."""
+    n = 107
+    mesh, V, A, x, st, z = _heat_cube(gpu, n, degree=2)
+    assert V.n_owned == 215 ** 3 and mesh.info()[1] == 7350258
+    assert st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
+    assert np.abs(x.get() - (350.0 - 50.0 * z)).max() <= 3e-3   # P2 reproduces the linear profile
