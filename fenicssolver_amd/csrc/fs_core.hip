@@ -154,7 +154,7 @@ extern "C" int fs_vector_dot(fs_vector_t x, fs_vector_t y, double* result) {
     FS_CHECK(part.alloc(grid + 1));
     hipLaunchKernelGGL(k_dot_partial, dim3(grid), dim3(FS_BLOCK), 0, s, x->d.p, y->d.p, n, part.p);
     FS_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, part.p, grid, 1, part.p + grid);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, part.p, grid, 1, part.p + grid);
     FS_KERNEL_CHECK();
     FS_HIP(hipMemcpyAsync(result, part.p + grid, sizeof(double), hipMemcpyDeviceToHost, s));
     FS_HIP(hipStreamSynchronize(s));

@@ -48,15 +48,33 @@ static __global__ void __launch_bounds__(FS_BLOCK) k_dot_partial(const double* _
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// fixed-order sum of nsums interleaved partial arrays (partial[j*count + i]) by one
-// workgroup -> out[j].
-static __global__ void __launch_bounds__(FS_BLOCK) k_sum_partials(const double* __restrict__ partial, int count,
-                                                                  int nsums, double* __restrict__ out) {
-    __shared__ double lds4[4];
-    for (int j = 0; j < nsums; ++j) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < count; i += FS_BLOCK) acc += partial[(int64_t)j * count + i];
-        const double t = fs_block_sum(acc, lds4);
-        if (threadIdx.x == 0) out[j] = t;
+// fixed-order sum of nsums (<= 4) interleaved partial arrays (partial[j*count + i]) by ONE workgroup of
+// 1024 threads -> out[j].  Latency-bound (it sits between the SpMV and the all-reduce on N>1 GPUs), so
+// all loads of a thread are issued before the first reduction step.
+#define FS_SUM_BLOCK 1024
+static __global__ void __launch_bounds__(FS_SUM_BLOCK) k_sum_partials(const double* __restrict__ partial, int count,
+                                                                      int nsums, double* __restrict__ out) {
+    __shared__ double lds[16][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < count; i += FS_SUM_BLOCK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nsums) acc[j] += partial[(int64_t)j * count + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && (int)threadIdx.x < nsums) {
+        double t = 0.0;
+        for (int w = 0; w < FS_SUM_BLOCK / 64; ++w) t += lds[w][threadIdx.x];   // fixed order
+        out[threadIdx.x] = t;
     }
 }

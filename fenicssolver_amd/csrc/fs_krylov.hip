@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             ri[i] = 0.0;
             acc[i] = 0.0;
             if (DOTS && live) {
-                if (DOTS == 1) zi[i] = x[r * BS + i];
+                if (DOTS == 1 || DOTS == 3) zi[i] = x[r * BS + i];
                 ri[i] = rvec[r * BS + i];
             }
         }
@@ -133,6 +133,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                     d_rz += acc[i] * ri[i];
                     d_wz += acc[i] * acc[i];
                     d_rr += ri[i] * ri[i];
+                } else if (DOTS == 3) {   // diagonally scaled CG (z == r): r.r, w.r, sum d r^2 with d = rvec
+                    d_rz += zi[i] * zi[i];
+                    d_wz += acc[i] * zi[i];
+                    d_rr += ri[i] * zi[i] * zi[i];
                 }
             }
         }
@@ -415,10 +419,156 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bicg_x(int64_t n, int iter, const 
     }
 }
 
+// ---- CG on the symmetrically scaled system  D^-1/2 A D^-1/2 (PETSc KSPSetDiagonalScale) ------------
+// Jacobi-PCG on A is unpreconditioned CG on the scaled operator, for which z == r: the update kernel
+// drops the z and D^-1 streams (72 instead of 96 B/DOF per iteration).  rho stays the UNSCALED ||r||^2
+// (sum d r^2, computed in the SpMV), so the stopping test is unchanged.
+template <bool FUSED>
+__global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int iter, int check_only,
+                                                               const double* __restrict__ partials, int npart,
+                                                               const double* __restrict__ sums,
+                                                               const double* __restrict__ ctrl,
+                                                               double* __restrict__ scal, int* __restrict__ status,
+                                                               double* __restrict__ hist, double* __restrict__ r,
+                                                               const double* __restrict__ w, double* __restrict__ p,
+                                                               double* __restrict__ sv, double* __restrict__ x) {
+    if (status[0] != 0) return;
+    double gamma, delta, rho;
+    if (FUSED) {
+        double sm[3];
+        wg_sum_partials<3>(partials, npart, sm);
+        gamma = sm[0]; delta = sm[1]; rho = sm[2];
+    } else {
+        gamma = sums[0]; delta = sums[1]; rho = sums[2];
+    }
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (leader) hist[iter] = rho;
+    if (rho <= ctrl[0]) {
+        if (leader) { status[1] = iter; status[0] = 1; }
+        return;
+    }
+    if (check_only) {
+        if (leader) { status[1] = iter; status[0] = 3; }
+        return;
+    }
+    double beta = 0.0, alpha;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) {
+        scal[2 * (iter & 1) + 0] = gamma;
+        scal[2 * (iter & 1) + 1] = alpha;
+    }
+    const int64_t n2 = n >> 1;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
+    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
+    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
+    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
+    // two strided elements per trip: ten 16-B loads in flight per lane (the kernel is latency-bound at 1 M DOF)
+    for (; i + stride < n2; i += 2 * stride) {
+        const int64_t j = i + stride;
+        const double2 wa = w2[i], wb = w2[j];
+        double2 pa = p2[i], sa = s2[i], xa = x2[i], ra = r2[i];
+        double2 pb = p2[j], sb = s2[j], xb = x2[j], rb = r2[j];
+        pa.x = ra.x + beta * pa.x;  pa.y = ra.y + beta * pa.y;
+        pb.x = rb.x + beta * pb.x;  pb.y = rb.y + beta * pb.y;
+        sa.x = wa.x + beta * sa.x;  sa.y = wa.y + beta * sa.y;
+        sb.x = wb.x + beta * sb.x;  sb.y = wb.y + beta * sb.y;
+        xa.x += alpha * pa.x;       xa.y += alpha * pa.y;
+        xb.x += alpha * pb.x;       xb.y += alpha * pb.y;
+        ra.x -= alpha * sa.x;       ra.y -= alpha * sa.y;
+        rb.x -= alpha * sb.x;       rb.y -= alpha * sb.y;
+        p2[i] = pa; s2[i] = sa; x2[i] = xa; r2[i] = ra;
+        p2[j] = pb; s2[j] = sb; x2[j] = xb; r2[j] = rb;
+    }
+    for (; i < n2; i += stride) {
+        const double2 ww = w2[i];
+        double2 pp = p2[i], ss = s2[i], xx = x2[i], rr = r2[i];
+        pp.x = rr.x + beta * pp.x;  pp.y = rr.y + beta * pp.y;
+        ss.x = ww.x + beta * ss.x;  ss.y = ww.y + beta * ss.y;
+        xx.x += alpha * pp.x;       xx.y += alpha * pp.y;
+        rr.x -= alpha * ss.x;       rr.y -= alpha * ss.y;
+        p2[i] = pp; s2[i] = ss; x2[i] = xx; r2[i] = rr;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t t = n - 1;
+        const double pp = r[t] + beta * p[t];
+        const double ss = w[t] + beta * sv[t];
+        p[t] = pp; sv[t] = ss;
+        x[t] += alpha * pp;
+        r[t] -= alpha * ss;
+    }
+}
+
+// aval = D^-1/2 A D^-1/2 (copy; the caller's matrix is left untouched), sc = 1/sqrt(diag)
+template <int BS>
+__global__ void __launch_bounds__(FS_BLOCK) k_scale_copy(int64_t n_rows, int64_t n_slices,
+                                                         const int64_t* __restrict__ slice_ptr,
+                                                         const int32_t* __restrict__ sell_col,
+                                                         const double* __restrict__ val, int64_t plane,
+                                                         const double* __restrict__ sc, double* __restrict__ aval) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t r = s * FS_SLICE + lane;
+        const int64_t base = slice_ptr[s] + lane;
+        const int width = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            const int32_t c = sell_col[e];
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    const int64_t idx = (int64_t)(i * BS + j) * plane + e;
+                    aval[idx] = (c >= 0 && r < n_rows) ? val[idx] * sc[r * BS + i] * sc[(int64_t)c * BS + j] : 0.0;
+                }
+        }
+    }
+}
+
+__global__ void k_pointwise_div(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = a[i] / b[i];
+}
+
+// partial of sum d (b - w)^2 ; optionally r = b - w
+__global__ void __launch_bounds__(FS_BLOCK) k_residual_scaled(const double* __restrict__ b, const double* __restrict__ w,
+                                                              const double* __restrict__ d, int64_t n,
+                                                              double* __restrict__ r, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double x = b[i] - w[i];
+        if (r) r[i] = x;
+        acc += d[i] * x * x;
+    }
+    const double t = fs_block_sum(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 template <int BS>
 __global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
                                const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
-                               int jacobi, double* __restrict__ dinv, int* __restrict__ err) {
+                               int jacobi, double* __restrict__ dinv, int* __restrict__ err,
+                               double* __restrict__ dvec = nullptr) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; r < n_rows; r += stride) {
@@ -432,8 +582,9 @@ __global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice
             double d = 1.0;
             if (jacobi) {
                 d = kd >= 0 ? val[(int64_t)(i * BS + i) * plane + base + (int64_t)kd * FS_SLICE] : 0.0;
-                if (!(d != 0.0)) { atomicAdd(err, 1); d = 1.0; }
-                d = 1.0 / d;
+                if (!(d != 0.0) || (jacobi == 2 && !(d > 0.0))) { atomicAdd(err, 1); d = 1.0; }
+                if (dvec) dvec[r * BS + i] = d;
+                d = jacobi == 2 ? 1.0 / sqrt(d) : 1.0 / d;
             }
             dinv[r * BS + i] = d;
         }
@@ -504,10 +655,11 @@ static int spmv_grid(int64_t n_slices) {
 
 template <int DOTS>
 static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
-                        const int* status, hipStream_t s) {
+                        const int* status, hipStream_t s, const double* val_override = nullptr) {
+    const double* mat_val = val_override ? val_override : A->val.p;
     fs_space_s* sp = A->space;
     const int grid = spmv_grid(sp->n_slices);
-#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, rvec, partials, status
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status
     if (A->bs == 1) {
         switch (g_spmv_unroll) {
             case 2: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 2>), FS_SPMV_ARGS); break;
@@ -575,6 +727,7 @@ struct krylov_ws {
     int hist_cap = 0;
     dbuf<double> dinv, r, z, w, p, s, partials, sums, ctrl, scal, hist;
     dbuf<double> rhat, t, y, partials2, bsums;   // BiCGStab only (allocated on first use)
+    dbuf<double> aval, dvec, bhat;               // diagonally scaled CG only
     int64_t bicg_n = -1;
     dbuf<int> status;
     int* h_status = nullptr;  // pinned, 2 x 4 ints
@@ -643,6 +796,14 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         ws.bicg_n = n;
     }
     const int bs = A->bs;
+    const bool ds = !bicg && opts->precond == FS_PC_JACOBI && opts->diagonal_scale != 0;
+    if (ds) {
+        if (ws.aval.n != A->val.n) FS_CHECK(ws.aval.alloc(A->val.n));
+        if (ws.dvec.n != n + 2) {
+            FS_CHECK(ws.dvec.alloc(n + 2));
+            FS_CHECK(ws.bhat.alloc(n + 2));
+        }
+    }
     const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
     const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
@@ -655,24 +816,43 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_CHECK(d_err.alloc(1));
         FS_CHECK(d_err.zero(s));
         const int g = fs_grid_for(sp->n_nodes_owned);
+        const int jmode = ds ? 2 : (opts->precond == FS_PC_JACOBI ? 1 : 0);
+        double* dv = ds ? ws.dvec.p : nullptr;
         if (bs == 1)
-            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, d_err.p, dv);
         else
-            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, opts->precond == FS_PC_JACOBI, ws.dinv.p, d_err.p);
+            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, d_err.p, dv);
         FS_KERNEL_CHECK();
         int h_err = 0;
         FS_CHECK(d_err.download(&h_err, 1, s));
         if (h_err) {
-            fs_set_error("fs_krylov_solve: %d zero diagonal entries (Jacobi preconditioner undefined)", h_err);
+            fs_set_error("fs_krylov_solve: %d zero%s diagonal entries (Jacobi preconditioner undefined)", h_err, ds ? " or negative" : "");
             return FS_ERR_NUMERIC;
         }
     }
     // ||b||^2 -> threshold
     hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, b->d.p, n, ws.partials.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 4);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 4);
     FS_KERNEL_CHECK();
     FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 4, 1, s));
     hipLaunchKernelGGL(k_set_threshold, dim3(1), dim3(64), 0, s, ws.sums.p + 4, opts->rtol, opts->atol, ws.ctrl.p);
+    const double* aval = nullptr;
+    if (ds) {
+        // the scaled system needs ghost scale factors too: refresh them through the halo
+        dbuf<double> sc_local;
+        FS_CHECK(sc_local.alloc(nl + 2));
+        FS_HIP(hipMemcpyAsync(sc_local.p, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        FS_CHECK(fs_halo_exchange_dev(sp, sc_local.p, s));
+        const int g2 = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
+        if (bs == 1)
+            hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local.p, ws.aval.p);
+        else
+            hipLaunchKernelGGL(k_scale_copy<3>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local.p, ws.aval.p);
+        hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, b->d.p, n, ws.bhat.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));   // sc_local is released at the end of this scope
+        aval = ws.aval.p;
+    }
     // A pass = fresh recurrences from the current x.  The single-reduction recurrences drift on
     // ill-conditioned operators (the recurrence residual can reach the threshold while b - A x has not):
     // the true residual is recomputed after every pass and, if it misses the tolerance, the solve
@@ -689,16 +869,30 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_CHECK(ws.p.zero(s));
         FS_CHECK(ws.s.zero(s));
         FS_CHECK(ws.z.zero(s));
-        if (use_guess) {
-            FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-            FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-            launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
-            hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, ws.r.p, ws.partials.p);
+        if (ds) {
+            // scaled unknown xhat = D^1/2 x lives in the caller's x until the final un-scaling; rhat in ws.z
+            if (use_guess) {
+                if (n_pass == 0) hipLaunchKernelGGL(k_pointwise_div, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, x->d.p, ws.dinv.p, n, x->d.p);
+                FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+                FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+                launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
+                hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, n, ws.z.p, ws.partials.p);
+            } else {
+                FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
+                FS_HIP(hipMemcpyAsync(ws.z.p, ws.bhat.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
         } else {
-            FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
-            FS_HIP(hipMemcpyAsync(ws.r.p, b->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (use_guess) {
+                FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+                FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+                launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
+                hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, ws.r.p, ws.partials.p);
+            } else {
+                FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
+                FS_HIP(hipMemcpyAsync(ws.r.p, b->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
+            hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
         }
-        hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
         FS_KERNEL_CHECK();
         if (bicg) {
             // rhat = r0; first (rhat.r, r.r) partials; v = 0 (ws.w), p = 0, y = 0
@@ -724,7 +918,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_p<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials2.p, vgrid, 2, ws.bsums.p);
+                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials2.p, vgrid, 2, ws.bsums.p);
                         FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p, 2, s));
                         hipLaunchKernelGGL(k_bicg_p<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
                     }
@@ -738,7 +932,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_s<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 1, ws.bsums.p + 4);
+                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 1, ws.bsums.p + 4);
                         FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 4, 1, s));
                         hipLaunchKernelGGL(k_bicg_s<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
                     }
@@ -753,7 +947,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_x<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 2, ws.bsums.p + 8);
+                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 2, ws.bsums.p + 8);
                         FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 8, 2, s));
                         hipLaunchKernelGGL(k_bicg_x<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
                     }
@@ -761,13 +955,25 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 }
                 FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
-                launch_spmv<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
+                if (ds) launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
+                else launch_spmv<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
-                if (fuse_sums) {
+                if (ds) {
+                    const int co = k == max_iter ? 1 : 0;
+                    if (fuse_sums) {
+                        if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                        hipLaunchKernelGGL(k_cg_update_scaled<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                    } else {
+                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
+                        FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
+                        if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                        hipLaunchKernelGGL(k_cg_update_scaled<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                    }
+                } else if (fuse_sums) {
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     hipLaunchKernelGGL(k_cg_update<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
                 } else {
-                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
+                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
                     FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     hipLaunchKernelGGL(k_cg_update<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
@@ -794,12 +1000,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         const int iters = h_status[1];
         total_iters += iters;
 
-        // true residual b - A x
+        // true residual b - A x (scaled mode: sum d (bhat - Ahat xhat)^2, the same number)
         FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
         FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-        launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
-        hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 5);
+        launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
+        if (ds) hipLaunchKernelGGL(k_residual_scaled, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, ws.dvec.p, n, (double*)nullptr, ws.partials.p);
+        else hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 5);
         FS_KERNEL_CHECK();
         FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 5, 1, s));
 
@@ -818,6 +1025,11 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         if (true_rr > 0.7 * prev_true_rr) break;   // no longer improving: attainable accuracy of fp64 reached
         prev_true_rr = true_rr;
         use_guess = true;   // restart: r := b - A x exactly, then continue
+    }
+    if (ds) {   // x = D^-1/2 xhat
+        hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, x->d.p, n, x->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
     }
     const int iters = total_iters;
     ws.last_hist.resize((size_t)iters + 1);
