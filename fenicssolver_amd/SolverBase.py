@@ -497,7 +497,11 @@ class SolverBase():
         rtol, max_iter, pc = self._krylov_options()
         V = u.function_space().device()
         x = backend.DeviceVector(V.n_owned)
-        stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method)
+        sp_ = self.solver_settings.get('solver_parameters', {}) or {}
+        # PETSc's KSPCG default: convergence on the preconditioned residual norm; it is
+        # also what keeps badly scaled operators (e.g. permittivities of 1e-10 next to identity rows) honest
+        norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc == "jacobi") else 'unpreconditioned')
+        stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method, norm=norm)
         self.last_solve_stats = stats
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         if sp.get('monitor_convergence'):
@@ -640,7 +644,8 @@ class SolverBase():
                 A.apply_dirichlet(rhs, dofs, 0.0, symmetric=True)   # delta = 0 on the Dirichlet boundary
             delta = backend.DeviceVector(n)
             stats = backend.krylov_solve(A, rhs, delta, rtol=min(krtol, 1e-10), max_iter=kmax, precond=pc,
-                                         method="cg" if F.symmetric else "bicgstab")
+                                         method="cg" if F.symmetric else "bicgstab",
+                                         norm="preconditioned" if (F.symmetric and pc == "jacobi") else "unpreconditioned")
             self.last_solve_stats = stats
             if stats['converged'] != 1:
                 raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))

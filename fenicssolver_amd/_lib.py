@@ -20,6 +20,7 @@ FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL = 0, 1,
 FS_KSP_CG = 0
 FS_KSP_BICGSTAB = 1
 FS_PC_NONE, FS_PC_JACOBI = 0, 1
+FS_NORM_UNPRECONDITIONED, FS_NORM_PRECONDITIONED = 0, 1
 FS_UNIQUE_ID_BYTES = 128
 
 c_i64 = C.c_int64
@@ -47,7 +48,8 @@ class fs_linear_form(C.Structure):
 
 class fs_krylov_opts(C.Structure):
     _fields_ = [("method", C.c_int), ("precond", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
-                ("max_iter", C.c_int), ("batch", C.c_int), ("nonzero_guess", C.c_int), ("diagonal_scale", C.c_int)]
+                ("max_iter", C.c_int), ("batch", C.c_int), ("nonzero_guess", C.c_int), ("norm_type", C.c_int),
+                ("diagonal_scale", C.c_int)]
 
 
 class fs_krylov_stats(C.Structure):

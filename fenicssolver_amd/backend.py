@@ -298,7 +298,7 @@ def set_dirichlet_values(b, dofs, vals):
 
 
 def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False,
-                 method="cg", diagonal_scale=True):
+                 method="cg", diagonal_scale=True, norm="unpreconditioned"):
     """CG (SPD) or BiCGStab (non-symmetric) on the device.  Returns a stats dict."""
     o = L.fs_krylov_opts()
     o.method = {"cg": L.FS_KSP_CG, "bicgstab": L.FS_KSP_BICGSTAB}[method]
@@ -306,6 +306,7 @@ def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi",
     o.rtol, o.atol, o.max_iter, o.batch = float(rtol), float(atol), int(max_iter), int(batch)
     o.nonzero_guess = 1 if nonzero_guess else 0
     o.diagonal_scale = 1 if diagonal_scale else 0
+    o.norm_type = {"unpreconditioned": L.FS_NORM_UNPRECONDITIONED, "preconditioned": L.FS_NORM_PRECONDITIONED}[norm]
     st = L.fs_krylov_stats()
     L.check(L.load().fs_krylov_solve(A.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_krylov_solve")
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}

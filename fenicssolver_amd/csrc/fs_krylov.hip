@@ -830,7 +830,18 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             return FS_ERR_NUMERIC;
         }
     }
-    // ||b||^2 -> threshold
+    const bool pnorm = opts->norm_type == FS_NORM_PRECONDITIONED;
+    if (pnorm && !ds) {
+        fs_set_error("fs_krylov_solve: the preconditioned residual norm needs CG + Jacobi with diagonal_scale = 1");
+        return FS_ERR_UNSUPPORTED;
+    }
+    // ||b||^2 -> threshold.  Preconditioned norm (PETSc's KSPCG default): ||D^-1 b||^2 = sum (dinv_s^2 b)^2,
+    // where ws.dinv holds 1/sqrt(d) in scaled mode, and the residual weights become 1/d instead of d.
+    if (pnorm) {
+        hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.dinv.p, n, ws.dvec.p);  // 1/d
+        hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dvec.p, b->d.p, n, ws.bhat.p);    // b/d
+        hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.bhat.p, n, ws.partials.p);
+    } else
     hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, b->d.p, n, ws.partials.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 4);
     FS_KERNEL_CHECK();

@@ -205,6 +205,9 @@ int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y);
 #define FS_KSP_BICGSTAB 1 /* non-symmetric operators (advection); PETSc KSPBCGS, right Jacobi */
 #define FS_PC_NONE 0
 #define FS_PC_JACOBI 1
+#define FS_NORM_UNPRECONDITIONED 0 /* ||b - A x||_2 <= rtol ||b||_2 (BASELINE.json's definition) */
+#define FS_NORM_PRECONDITIONED 1   /* ||D^-1 (b - A x)||_2 <= rtol ||D^-1 b||_2: PETSc's KSPCG default, robust when
+                                    * constrained (identity) rows and physical rows differ by orders of magnitude */
 
 typedef struct fs_krylov_opts {
     int method;          /* FS_KSP_CG | FS_KSP_BICGSTAB */
@@ -214,6 +217,7 @@ typedef struct fs_krylov_opts {
     int max_iter;
     int batch;           /* iterations enqueued between host polls (0 = default 32) */
     int nonzero_guess;   /* 0: x0 = 0 (PETSc default); 1: use x on entry */
+    int norm_type;       /* FS_NORM_*; the preconditioned norm needs CG + Jacobi + diagonal_scale */
     int diagonal_scale;  /* CG + Jacobi only: run on D^-1/2 A D^-1/2 (PETSc KSPSetDiagonalScale): same iterates,
                           * 25 % less vector traffic; A itself is left untouched (a scaled copy is kept) */
 } fs_krylov_opts;
