@@ -511,7 +511,14 @@ class SolverBase():
         if stats['converged'] != 1:
             raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                 label, stats['iterations'], stats['true_rel_residual']))
-        u.vector().set_local(x.get())
+        loc = u.function_space().localizer()
+        if loc is None:
+            u.vector().set_local(x.get())
+        else:   # every rank ends with the full field, gathered by global vertex id
+            from . import parallel
+            ncomp = u.function_space()._ncomp
+            u.vector().set_local(parallel.gather_owned(x.get(), loc.part.l2g[:loc.part.n_owned],
+                                                       loc.n_global, ncomp))
         return u
 
     @staticmethod
@@ -526,34 +533,55 @@ class SolverBase():
         sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
         return self.mesh.facets()[sel]
 
+    def _device_facets(self, F, marker_id, per_facet=None):
+        """(vertex triples, per-facet values) of ds(marker_id) as this rank's device space needs them."""
+        tri = self._facets_of(marker_id)
+        loc = F.space.localizer()
+        if loc is None:
+            return tri, per_facet
+        ltri, mask = loc.facets(tri)
+        if per_facet is not None and np.ndim(per_facet) >= 1 and np.shape(per_facet)[0] == len(tri):
+            per_facet = np.asarray(per_facet)[mask]
+        return ltri, per_facet
+
     def assemble_system(self, F, bcs, symmetric=True):
         """(A, b) on the device for a ScalarForm / ElasticityForm, Dirichlet conditions applied
         (dolfin.assemble_system / assemble + bc.apply; SolverBase.py:594-602, 644)."""
         from . import backend
         V = F.space.device()
+        loc = F.space.localizer()
+        L_ = (lambda spec: spec) if loc is None else loc.spec
         A = backend.DeviceMatrix(V)
         b = backend.DeviceVector(V.n_owned)
         if isinstance(F, forms.ScalarForm):
             theta = F.theta if F.transient else 1.0
-            mass = F.capacity.spec(1.0 / F.dt) if F.transient else None
+            mass = L_(F.capacity.spec(1.0 / F.dt)) if F.transient else None
             adv, adv_scale = F.advection if F.advection is not None else (None, 1.0)
-            A.assemble(stiffness=F.conductivity.spec(theta), mass=mass, advection=adv, advection_scale=adv_scale)
+            if adv is not None and loc is not None and np.ndim(adv) == 2:
+                adv = loc.cells(adv)
+            A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale)
             for r in F.robin:
-                A.add_facet_mass(self._facets_of(r.marker_id), r.h)
+                tri, _ = self._device_facets(F, r.marker_id)
+                A.add_facet_mass(tri, r.h)
             first = True
             for s in F.sources:
-                backend.assemble_vector(V, b, source=s.spec(), add=not first)
+                backend.assemble_vector(V, b, source=L_(s.spec()), add=not first)
                 first = False
             for fl in F.facet_loads:
-                backend.assemble_facet_vector(V, b, self._facets_of(fl.marker_id), fl.g)
+                tri, g = self._device_facets(F, fl.marker_id, fl.g)
+                if len(tri):
+                    backend.assemble_facet_vector(V, b, tri, g)
             for r in F.robin:
-                backend.assemble_facet_vector(V, b, self._facets_of(r.marker_id), r.h * r.ambient)
+                tri, _ = self._device_facets(F, r.marker_id)
+                if len(tri):
+                    backend.assemble_facet_vector(V, b, tri, r.h * r.ambient)
             if F.transient:
                 # b += (M/dt - (1-theta) K) T_prev   (Crank-Nicolson old-step terms, :292-293)
                 B = backend.DeviceMatrix(V)
-                B.assemble(stiffness=F.conductivity.spec(-(1.0 - theta)), mass=F.capacity.spec(1.0 / F.dt))
-                tp = backend.DeviceVector(V.n_local, np.concatenate(
-                    [F.T_prev.vector().array(), np.zeros(V.n_local - V.n_owned)]))
+                B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)))
+                tp_host = F.T_prev.vector().array()
+                tp_host = tp_host if loc is None else loc.nodes(tp_host)
+                tp = backend.DeviceVector(V.n_local, np.concatenate([tp_host, np.zeros(V.n_local - len(tp_host))]))
                 tmp = backend.DeviceVector(V.n_owned)
                 B.spmv(tp, tmp)
                 b.axpy(1.0, tmp)
@@ -563,16 +591,21 @@ class SolverBase():
             if F.body_force is not None:
                 backend.assemble_vector(V, b, vector_value=[sgn * x for x in F.body_force])
             for t in F.tractions:
-                backend.assemble_facet_vector(V, b, self._facets_of(t.marker_id), sgn * np.asarray(t.g, float))
+                tri, g = self._device_facets(F, t.marker_id, t.g)
+                if len(tri):
+                    backend.assemble_facet_vector(V, b, tri, sgn * np.asarray(g, float))
             if F.thermal is not None:
                 coef, T, T_ref = F.thermal
                 if np.ndim(T) == 0:
                     backend.assemble_vector(V, b, div_coef=coef * (float(T) - T_ref), add=True)
                 else:
-                    backend.assemble_vector(V, b, div_coef=("nodal", coef * (np.asarray(T) - T_ref)), add=True)
+                    Tn = np.asarray(T) if loc is None else loc.nodes(np.asarray(T))
+                    backend.assemble_vector(V, b, div_coef=("nodal", coef * (Tn - T_ref)), add=True)
         else:
             raise SolverError('unknown form specification {}'.format(type(F)))
         dofs, vals = self._bc_arrays(bcs)
+        if loc is not None and dofs.size:
+            dofs, vals = loc.dofs(dofs, vals)       # local dofs, ghosts included (their columns are eliminated too)
         if dofs.size:
             A.apply_dirichlet(b, dofs, vals, symmetric=symmetric)
         return A, b
@@ -596,6 +629,8 @@ class SolverBase():
         from . import backend
         if not isinstance(F, forms.ScalarForm):
             raise SolverError('nonlinear solves are built for scalar transport only')
+        if F.space.device() is not None and F.space.localizer() is not None:
+            raise SolverError('nonlinear solves are single-GPU for now')
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         newton = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
         rtol = float(newton.get('relative_tolerance', 1e-9))

@@ -573,9 +573,36 @@ class FunctionSpace:
         """Device space (sparsity + SELL slot table), built once per space."""
         root = self.root()
         if root._device is None:
-            from . import backend
-            root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree)
+            from . import backend, parallel
+            if parallel.active():
+                root._device = self._make_parallel_device(root, backend, parallel)
+            else:
+                root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree)
         return root._device
+
+    @staticmethod
+    def _make_parallel_device(root, backend, parallel):
+        """This rank's share of the space: owner-computes vertex slabs along the longest axis,
+        one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
+        from . import partition
+        if root._degree != 1:
+            raise SolverError("multi-GPU decomposition is built for P1 spaces only (P2 is single-GPU for now)")
+        rank, size = parallel.ensure_comm()
+        mesh = root._mesh
+        co, ce = mesh.coordinates(), mesh.cells()
+        axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
+        owner = partition.slab_owner(co, size, axis=axis)
+        part = partition.build_local_part(ce, owner, rank)
+        dm = backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned)
+        ds = backend.DeviceSpace(dm, root._ncomp, 1)
+        if size > 1:
+            ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
+        root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
+        return ds
+
+    def localizer(self):
+        """None on one GPU; the global->local mapper of this rank's part otherwise (after device())."""
+        return getattr(self.root(), "_localizer", None)
 
 
 def VectorFunctionSpace(mesh, family="CG", degree=1, dim=None, constrained_domain=None):

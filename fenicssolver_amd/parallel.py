@@ -1,0 +1,114 @@
+"""One process per GPU: process-group plumbing for the solver API.
+
+The reference becomes parallel by being started under ``mpirun`` — DOLFIN partitions the mesh
+and PETSc communicates (SolverBase.py:102-118, 634).  Here a script that uses the solver
+classes is started with ``python -m torch.distributed.run --nproc-per-node N script.py``:
+every rank builds the same (global) host mesh, owns a slab of its vertices (partition.py),
+assembles and solves its rows on its own MI355X and exchanges halos / dot products over RCCL;
+the solution is gathered so that ``solver.result`` holds the full field on every rank, as
+DOLFIN's ``Function`` does for the part a rank can see.
+
+torch.distributed (gloo) is used for rendezvous and for the final gather only.
+FS_FORCE_PARALLEL_PATH=1 sends a single process through the same code (one part, no
+communicator) — that is how the 1-GPU tests exercise the mapping logic.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+_state = {"ready": False}
+
+
+def world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def active():
+    return world()[1] > 1 or os.environ.get("FS_FORCE_PARALLEL_PATH", "") not in ("", "0")
+
+
+def ensure_comm():
+    """Select this rank's GPU and bring up RCCL (idempotent)."""
+    from . import backend
+    rank, size, local_rank = world()
+    if _state["ready"]:
+        return rank, size
+    backend.init(local_rank if size > 1 else 0)
+    if size > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        uid = [backend.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        backend.comm_init(size, rank, uid[0])
+    _state["ready"] = True
+    return rank, size
+
+
+def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
+    """Owned dof values of every rank -> the full vector (on every rank)."""
+    rank, size, _ = world()
+    vals = np.asarray(values_owned, dtype=np.float64).reshape(-1, ncomp)
+    out = np.full((n_global, ncomp), np.nan)
+    if size == 1:
+        out[np.asarray(gids_owned)] = vals
+    else:
+        import torch.distributed as dist
+        parts = [None] * size
+        dist.all_gather_object(parts, (np.asarray(gids_owned), vals))
+        for g, v in parts:
+            out[g] = v
+    if np.isnan(out).any():
+        raise RuntimeError("gather_owned: some dofs are owned by no rank")
+    return out.reshape(-1) if ncomp == 1 else out.reshape(-1)
+
+
+class Localizer:
+    """Maps global host arrays (per cell / per node / dof lists / facet lists) to one rank's part."""
+
+    def __init__(self, part, n_global_nodes, ncomp):
+        self.part = part
+        self.ncomp = ncomp
+        self.n_global = n_global_nodes
+        self.g2l = part.g2l(n_global_nodes)
+
+    def cells(self, arr):
+        a = np.asarray(arr)
+        return a[self.part.cell_gids]
+
+    def nodes(self, arr):
+        """Nodal array [n_global] or dof array [n_global*ncomp] -> local (owned + ghost) order."""
+        a = np.asarray(arr)
+        if a.shape[0] == self.n_global:
+            return a[self.part.l2g]
+        return a.reshape(self.n_global, -1)[self.part.l2g].reshape(-1)
+
+    def dofs(self, dofs, vals):
+        d = np.asarray(dofs, dtype=np.int64)
+        node, comp = d // self.ncomp, d % self.ncomp
+        loc = self.g2l[node]
+        keep = loc >= 0
+        return (loc[keep] * self.ncomp + comp[keep]).astype(np.int32), np.asarray(vals, dtype=np.float64)[keep]
+
+    def facets(self, tri):
+        """Facets with at least one owned vertex (their cell is local, so all three vertices are);
+        returns (local vertex triples, mask into the input)."""
+        t = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+        loc = self.g2l[t]
+        mask = ((loc >= 0) & (loc < self.part.n_owned)).any(axis=1)
+        sel = loc[mask]
+        if (sel < 0).any():
+            raise RuntimeError("a boundary facet touching an owned vertex has a non-local vertex")
+        return sel.astype(np.int32), mask
+
+    def spec(self, spec):
+        """backend coefficient spec (None | number | (kind, array)) -> local."""
+        if isinstance(spec, tuple):
+            kind, arr = spec
+            if kind == "cell":
+                return (kind, self.cells(arr))
+            if kind == "nodal":
+                return (kind, self.nodes(arr))
+        return spec

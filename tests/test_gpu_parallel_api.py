@@ -1,0 +1,136 @@
+"""The solver API's domain-decomposed path (fenicssolver_amd/parallel.py + SolverBase.assemble_system
+localisation), checked on one GPU two ways:
+  * FS_FORCE_PARALLEL_PATH=1 sends the whole case through the partition/localise/gather code with
+    one part: results must equal the plain single-GPU path;
+  * three emulated ranks (no communicator): every rank's owned rows of (A, b), mapped back to
+    global numbering, must equal the single-GPU system - coefficients, facet terms, Crank-Nicolson
+    old-step terms and the symmetric Dirichlet elimination included.
+The RCCL exchange itself is covered by test_gpu_comm.py and the gloo tests of the partition."""
+import copy
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+
+
+def _heat_case(n=5, transient=False):
+    from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n)
+    Q = FunctionSpace(m, "CG", 1)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
+    bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+         'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+         'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
+         'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1,
+                                                    'ending_time': 0.3},
+                             'reference_values': {'temperature': 300},
+                             'solver_parameters': {'krylov_relative_tolerance': 1e-12}},
+         'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(s)
+    cen = m.coordinates()[m.cells().astype(np.int64)].mean(axis=1)
+    sub = MeshFunction("size_t", m, 3)
+    sub.array()[:] = np.where(cen[:, 2] < 0.9, 1, 2)
+    solver.subdomains = sub
+    solver.material['conductivity'] = {'lower': {'subdomain_id': 1, 'value': 0.6},
+                                       'upper': {'subdomain_id': 2, 'value': 6.0}}
+    solver.body_source = {'heater': {'subdomain_id': 2, 'value': 50.0}}
+    return solver
+
+
+def _elastic_case():
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 12, 2, 2)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
+                    'value': Constant((0, 0, 0))}
+    bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
+                      'value': Constant((1e8, 0, 0))}
+    s = copy.deepcopy(SB.default_case_settings)
+    s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                     'thermal_expansion_coefficient': 2e-6}
+    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    s['boundary_conditions'] = bcs
+    s['solver_settings']['reference_values'] = {'temperature': 293}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
+    s['report_settings'] = dict(QUIET)
+    s['body_source'] = Expression(("10*rho", "0", "0.0"), rho=7800, degree=2)
+    s['temperature_distribution'] = Expression("300+40*x[0]", degree=1)
+    return LinearElasticitySolver(s)
+
+
+CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_forced_single_part_equals_plain_path(gpu, monkeypatch, case):
+    from fenicssolver_amd import parallel
+    plain = CASES[case]().solve().vector().array()
+    monkeypatch.setenv("FS_FORCE_PARALLEL_PATH", "1")
+    assert parallel.active()
+    solver = CASES[case]()
+    forced = solver.solve().vector().array()
+    assert solver.function_space.localizer() is not None
+    assert np.abs(forced - plain).max() <= 1e-9 * np.abs(plain).max()
+
+
+class _Captured(Exception):
+    pass
+
+
+def _capture_system(monkeypatch, make, rank=None, world=1):
+    """Run make().solve() up to the first linear solve and return (A as global-numbered csr rows,
+    b, global row ids, ndof) of the rank."""
+    from fenicssolver_amd import parallel, backend, SolverBase as SB
+    got = {}
+
+    def fake_solve(self, A, b, u, label, method="cg"):
+        rp, ci, va, shape = A.to_csr()
+        got.update(A=sp.csr_matrix((va, ci, rp), shape=shape), b=b.get(), loc=u.function_space().localizer(),
+                   ncomp=u.function_space()._ncomp)
+        raise _Captured()
+
+    with monkeypatch.context() as mp:
+        mp.setattr(SB.SolverBase, "_device_solve", fake_solve)
+        if rank is not None:
+            mp.setattr(parallel, "world", lambda: (rank, world, 0))
+            mp.setattr(parallel, "ensure_comm", lambda: (rank, world))
+            mp.setattr(backend.DeviceSpace, "set_halo", lambda self, *a, **k: None)
+        with pytest.raises(_Captured):
+            make().solve()
+    return got
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_three_emulated_ranks_reproduce_the_global_system(gpu, monkeypatch, case):
+    ref = _capture_system(monkeypatch, CASES[case])
+    A, b = ref["A"].tocsr(), ref["b"]
+    ndof = A.shape[0]
+    covered = np.zeros(ndof, dtype=int)
+    for r in range(3):
+        got = _capture_system(monkeypatch, CASES[case], rank=r, world=3)
+        loc, nc = got["loc"], got["ncomp"]
+        part = loc.part
+        l2g_dof = (part.l2g[:, None].astype(np.int64) * nc + np.arange(nc)).ravel()
+        rows = l2g_dof[:part.n_owned * nc]
+        covered[rows] += 1
+        Al = got["A"].tocoo()
+        Ag = sp.csr_matrix((Al.data, (rows[Al.row], l2g_dof[Al.col])), shape=(ndof, ndof))
+        diff = abs(Ag[rows] - A[rows])
+        scale = abs(A).max()
+        assert (diff.max() if diff.nnz else 0.0) <= 1e-12 * scale, (case, r)
+        assert np.abs(got["b"] - b[rows]).max() <= 1e-11 * max(np.abs(b).max(), 1e-300), (case, r)
+    assert np.all(covered == 1)
