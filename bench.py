@@ -99,7 +99,7 @@ def roofline_of(st, V, traffic=None):
     ms = st["spmv_ms"]
     achieved = st["spmv_bytes"] / ms / 1e6 if ms > 0 else 0.0
     streamed = V.spmv_matrix_bytes + 24 * V.n_owned
-    return {"kernel": "k_sell_spmv<1,true,4> (hybrid SELL-64/DIA SpMV fused with the 3 CG dot products)",
+    return {"kernel": "k_sell_spmv<1,3,4> (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": st["spmv_bytes"], "avg_launch_ms": round(ms, 5),
@@ -109,7 +109,7 @@ def roofline_of(st, V, traffic=None):
 
 def committed_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc.json, collected with tools/collect_pmc.sh on the same command)."""
+    (profiles/r01_pmc.json, collected with tools/collect_profiles.sh on the same command)."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as fh:
             return json.load(fh).get(tag)

@@ -106,24 +106,32 @@ def main():
     cal = {}
     for ph in PHASES:
         n = n_dof[ph]
-        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_cg_update<true>", 56 * n)):
+        # streams of known size: dot (1 read), residuals (2 / 3 reads), CG updates (reads r,w,p,s,x [+z,dinv])
+        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_residual_scaled", 24 * n),
+                          ("k_cg_update<true>", 56 * n), ("k_cg_update_scaled<true>", 40 * n)):
             if (ph, k) in fetch:
                 cal["%s/%s" % (ph, k)] = {"expected_read_bytes": expect,
                                           "FETCH_SIZE_bytes": int(fetch[(ph, k)] * 1024),
                                           "ratio": round(fetch[(ph, k)] * 1024 / expect, 4)}
-        if (ph, "k_cg_update<true>") in write:
-            cal["%s/k_cg_update(write)" % ph] = {"expected_write_bytes": 40 * n,
-                                                "WRITE_SIZE_bytes": int(write[(ph, "k_cg_update<true>")] * 1024),
-                                                "ratio": round(write[(ph, "k_cg_update<true>")] * 1024 / (40 * n), 4)}
+        for k, expect in (("k_cg_update<true>", 40 * n), ("k_cg_update_scaled<true>", 32 * n)):
+            if (ph, k) in write:
+                cal["%s/%s(write)" % (ph, k)] = {"expected_write_bytes": expect,
+                                                 "WRITE_SIZE_bytes": int(write[(ph, k)] * 1024),
+                                                 "ratio": round(write[(ph, k)] * 1024 / expect, 4)}
     out = {"_doc": "HBM-side bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(read side doubled per the gfx950 rule, confirmed by the calibration block). "
                    "bench.py reports these as roofline.traffic.",
            "calibration": cal}
     for ph, tag in ((PHASES[0], "spmv_fused_n99"), (PHASES[1], "spmv_fused_n215")):
-        key = (ph, "k_sell_spmv<1, true, 4>")
-        if key in fetch:
-            out[tag] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
-        key = (ph, "k_sell_spmv<1, false, 4>")
+        # DOTS template argument: 3 = in-CG kernel of the diagonally scaled solve, 1 = unscaled CG /
+        # fs_spmv_benchmark(fused), 0 = bare SpMV
+        for dots in ("3", "1"):
+            key = (ph, "k_sell_spmv<1, %s, 4>" % dots)
+            if key in fetch:
+                out[tag + ("" if dots == "3" else "_dots1")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+        if tag not in out and tag + "_dots1" in out:
+            out[tag] = out[tag + "_dots1"]
+        key = (ph, "k_sell_spmv<1, 0, 4>")
         if key in fetch:
             out[tag.replace("fused", "bare")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
