@@ -58,6 +58,11 @@ class fs_krylov_stats(C.Structure):
                 ("spmv_ms", C.c_double), ("update_ms", C.c_double), ("spmv_bytes", c_i64)]
 
 
+class fs_amg_opts(C.Structure):
+    _fields_ = [("strength_threshold", C.c_double), ("max_levels", C.c_int), ("coarse_size", C.c_int),
+                ("smoother_steps", C.c_int), ("eig_steps", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/fenicssolver_amd.h
 _H = C.c_void_p
 SIGNATURES = {
@@ -101,6 +106,13 @@ SIGNATURES = {
     "fs_krylov_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
     "fs_krylov_history": (C.c_int, [c_f64p, C.c_int, C.POINTER(C.c_int)]),
     "fs_spmv_benchmark": (C.c_int, [_H, _H, _H, C.c_int, c_f64p]),
+    "fs_amg_setup": (C.c_int, [_H, C.c_int, c_f64p, C.POINTER(fs_amg_opts), C.POINTER(_H)]),
+    "fs_amg_destroy": (C.c_int, [_H]),
+    "fs_amg_info": (C.c_int, [_H, C.POINTER(C.c_int), c_f64p, c_f64p, c_f64p]),
+    "fs_amg_level_info": (C.c_int, [_H, C.c_int, c_i64p, C.POINTER(C.c_int), c_i64p, c_i64p, C.POINTER(C.c_int), c_f64p]),
+    "fs_amg_level_get": (C.c_int, [_H, C.c_int, C.c_int, c_i32p, c_i32p, c_f64p]),
+    "fs_amg_apply": (C.c_int, [_H, _H, _H]),
+    "fs_amg_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

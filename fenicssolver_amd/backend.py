@@ -312,6 +312,75 @@ def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi",
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 
 
+class AMG(_Handle):
+    """Smoothed-aggregation hierarchy of an assembled SPD matrix (PETSc GAMG behind
+    PETScPreconditioner("petsc_amg"), SolverBase.py:643-672).  nullspace: [nb, n_dofs] near-null-space
+    vectors (rigid-body modes) or None = constants per component."""
+    _destroy = "fs_amg_destroy"
+
+    def __init__(self, A, nullspace=None, strength_threshold=0.0, max_levels=0, coarse_size=0, smoother_steps=0,
+                 eig_steps=0):
+        super().__init__()
+        self.A = A                      # keeps the matrix alive
+        o = L.fs_amg_opts()
+        o.strength_threshold, o.max_levels, o.coarse_size = float(strength_threshold), int(max_levels), int(coarse_size)
+        o.smoother_steps, o.eig_steps = int(smoother_steps), int(eig_steps)
+        ns, nb = None, 0
+        if nullspace is not None:
+            ns = np.ascontiguousarray(np.asarray(nullspace, dtype=np.float64).reshape(len(nullspace), -1))
+            nb = ns.shape[0]
+            if ns.shape[1] != A.space.n_owned:
+                raise ValueError("near-null space has %d entries per vector, the matrix has %d rows" % (ns.shape[1], A.space.n_owned))
+        L.check(L.load().fs_amg_setup(A.h, nb, L.p_f64(ns), C.byref(o), C.byref(self.h)), "fs_amg_setup")
+
+    def info(self):
+        nl, oc, gc, ms = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        L.check(L.load().fs_amg_info(self.h, C.byref(nl), C.byref(oc), C.byref(gc), C.byref(ms)), "fs_amg_info")
+        return {"levels": nl.value, "operator_complexity": oc.value, "grid_complexity": gc.value, "setup_ms": ms.value}
+
+    def level_info(self, level):
+        nn, pn, bs, pc, nz, lm = C.c_int64(), C.c_int64(), C.c_int(), C.c_int(), C.c_int64(), C.c_double()
+        L.check(L.load().fs_amg_level_info(self.h, int(level), C.byref(nn), C.byref(bs), C.byref(nz), C.byref(pn),
+                                           C.byref(pc), C.byref(lm)), "fs_amg_level_info")
+        return {"n_nodes": nn.value, "block_size": bs.value, "nnz_blocks": nz.value, "p_nnz_blocks": pn.value,
+                "p_block_cols": pc.value, "lambda_max": lm.value}
+
+    def level_matrix(self, level, which="A"):
+        """scipy BSR copy of a level operator ('A') or of the prolongator from level+1 ('P')."""
+        import scipy.sparse as sp
+        li = self.level_info(level)
+        if which == "A":
+            nnz, br, bc, nrows = li["nnz_blocks"], li["block_size"], li["block_size"], li["n_nodes"]
+            ncols = nrows
+        else:
+            nnz, br, bc, nrows = li["p_nnz_blocks"], li["block_size"], li["p_block_cols"], li["n_nodes"]
+            ncols = self.level_info(level + 1)["n_nodes"]
+        rp = np.empty(nrows + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        va = np.empty(nnz * br * bc)
+        L.check(L.load().fs_amg_level_get(self.h, int(level), 0 if which == "A" else 1, L.p_i32(rp), L.p_i32(ci),
+                                          L.p_f64(va)), "fs_amg_level_get")
+        return sp.bsr_matrix((va.reshape(nnz, br, bc), ci, rp), shape=(nrows * br, ncols * bc)).tocsr()
+
+    def level_nullspace(self, level, nb):
+        li = self.level_info(level)
+        out = np.empty(li["n_nodes"] * li["block_size"] * nb)
+        L.check(L.load().fs_amg_level_get(self.h, int(level), 2, None, None, L.p_f64(out)), "fs_amg_level_get")
+        return out.reshape(-1, nb)
+
+    def apply(self, r, z):
+        L.check(L.load().fs_amg_apply(self.h, r.h, z.h), "fs_amg_apply")
+
+    def solve(self, b, x, rtol=1e-8, atol=0.0, max_iter=500, nonzero_guess=False, norm="unpreconditioned"):
+        o = L.fs_krylov_opts()
+        o.rtol, o.atol, o.max_iter = float(rtol), float(atol), int(max_iter)
+        o.nonzero_guess = 1 if nonzero_guess else 0
+        o.norm_type = {"unpreconditioned": L.FS_NORM_UNPRECONDITIONED, "preconditioned": L.FS_NORM_PRECONDITIONED}[norm]
+        st = L.fs_krylov_stats()
+        L.check(L.load().fs_amg_solve(self.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_amg_solve")
+        return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
+
+
 def krylov_history():
     n = C.c_int(0)
     L.load().fs_krylov_history(None, 0, C.byref(n))

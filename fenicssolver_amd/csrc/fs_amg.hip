@@ -1,0 +1,1173 @@
+// Smoothed-aggregation algebraic multigrid for libfsamd.so (gfx950).
+//
+// Replaces what SolverBase.solve_amg() asks of PETSc (FenicsSolver/SolverBase.py:643-672):
+//   PETScPreconditioner("petsc_amg")  = GAMG smoothed aggregation with the rigid-body near-null space
+//                                       of build_nullspace() (:674-706),
+//   mg_levels_ksp_type chebyshev + mg_levels_pc_type jacobi (2 steps, bounds 0.1/1.1 of the
+//   estimated largest eigenvalue of D^-1 A), CG outside.
+//
+// Everything but the final dense factorisation of the (<= a few hundred dof) coarsest operator runs
+// on the device:
+//   strength graph -> MIS(2) aggregation (Bell/Dalton/Olson: roots are a distance-2 maximal
+//   independent set found with hashed 64-bit keys, deterministic) -> per-aggregate QR of the near-null
+//   space (tentative prolongator T, coarse near-null space R) -> P = (I - 4/(3 lmax) D^-1 A) T ->
+//   A_c = P^T A P.
+// The two sparse products are row-wise SpGEMMs: one workgroup (or wave) per output row, the distinct
+// columns of a row found with an LDS hash, the numeric pass accumulating into an LDS-resident row
+// (this is where the 160 KB LDS of a CDNA4 CU pays: a 6x6-block coarse row of ~100 blocks is 29 KB).
+// Level matrices are block CSR (block = dofs of a node: 1, 3 on the fine level, nb = 6 on the
+// coarse levels of elasticity).  The fine level's SpMV is the tuned SELL/DIA kernel.
+#include "fs_kernels.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+
+// ---- block CSR -----------------------------------------------------------------------------------
+struct bcsr {
+    int64_t nrows = 0, ncols = 0;   // in blocks
+    int br = 1, bc = 1;
+    int64_t nnz = 0;                // blocks
+    dbuf<int32_t> rowptr, col;
+    dbuf<double> val;               // [nnz][br][bc]
+};
+
+struct amg_level {
+    int64_t nn = 0;       // nodes
+    int bs = 1;           // dofs per node
+    int64_t n = 0;        // dofs
+    int nb = 1;           // near-null-space vectors = dofs per node of the next level
+    bcsr A;
+    bcsr P;               // nn x n_agg, blocks bs x nb
+    int64_t n_agg = 0;
+    dbuf<int32_t> pt_ptr, pt_entry, pt_row;   // transpose index of P (entries sorted by column)
+    dbuf<double> dinv;    // [n]
+    dbuf<uint8_t> ident;  // [n] scalar row has no off-diagonal value (eliminated Dirichlet dof)
+    dbuf<double> B;       // near-null space [n][nb]
+    double lmax = 2.0;    // largest eigenvalue of D^-1 A (estimate)
+    double gersh = 2.0;   // Gershgorin bound of it
+    dbuf<double> x, b, r, d, t;   // work vectors (levels > 0 own x and b)
+};
+
+struct fs_amg_s {
+    fs_matrix_s* fine = nullptr;
+    std::vector<amg_level*> lv;
+    dbuf<double> cinv;          // dense inverse of the coarsest operator (row-major), empty = Chebyshev
+    int64_t nc = 0;
+    double setup_ms = 0.0;
+    double op_complexity = 1.0, grid_complexity = 1.0;
+    int smooth_steps = 2;
+    dbuf<double> partials, sums;
+    // PCG vectors
+    dbuf<double> pr, pz, pp, pw;
+    ~fs_amg_s() {
+        for (amg_level* l : lv) delete l;
+    }
+};
+
+#define FS_AMG_HIP(call) FS_HIP(call)
+
+// ---- small utilities --------------------------------------------------------------------------------
+static int scan_exclusive(int32_t* d_in, int32_t* d_out, int64_t count, hipStream_t s) {
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_in, d_out, (int)count, s));
+    dbuf<uint8_t> tmp;
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, d_in, d_out, (int)count, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+static int sort_pairs(int32_t* k_in, int32_t* k_out, int32_t* v_in, int32_t* v_out, int64_t count, hipStream_t s) {
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)count, 0, 32, s));
+    dbuf<uint8_t> tmp;
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in, k_out, v_in, v_out, (int)count, 0, 32, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+static int read_i32(const int32_t* d, int32_t* h, hipStream_t s) {
+    FS_HIP(hipMemcpyAsync(h, d, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+__global__ void k_iota(int32_t* v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] = (int32_t)i;
+}
+
+// out[a] = first position p in sorted keys[0..n) with keys[p] >= a, a = 0..n_bins
+__global__ void k_lower_bounds(const int32_t* __restrict__ keys, int64_t n, int64_t n_bins, int32_t* __restrict__ out) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; a <= n_bins; a += stride) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < (int32_t)a) lo = mid + 1; else hi = mid;
+        }
+        out[a] = (int32_t)lo;
+    }
+}
+
+__global__ void k_expand_rows(const int32_t* __restrict__ rowptr, int64_t nrows, int32_t* __restrict__ rowidx) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nrows; i += stride)
+        for (int32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) rowidx[e] = (int32_t)i;
+}
+
+__global__ void k_gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = src[idx[i]];
+}
+
+// ---- level 0: block CSR copy of the SELL/DIA matrix -------------------------------------------------
+template <int BS>
+__global__ void k_amg_extract(int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ rowptr,
+                              const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
+                              double* __restrict__ out) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        int64_t o = rowptr[r];
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] < 0) continue;     // structural entries come in ascending column order
+            for (int i = 0; i < BS; ++i)
+                for (int j = 0; j < BS; ++j) out[(o * BS + i) * BS + j] = val[(int64_t)(i * BS + j) * plane + e];
+            ++o;
+        }
+    }
+}
+
+// per node: 1/diag, identity-row flags, Gershgorin ratio (max over the block row, atomically maxed), block norm
+__global__ void k_amg_diag(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                           const double* __restrict__ val, double* __restrict__ dinv, uint8_t* __restrict__ ident,
+                           double* __restrict__ dnorm, unsigned long long* __restrict__ gersh_bits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double gmax = 0.0;
+    for (; i < nn; i += stride) {
+        double dn = 0.0;
+        for (int r = 0; r < bs; ++r) {
+            double d = 0.0, off = 0.0;
+            for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+                const double* blk = val + ((int64_t)e * bs + r) * bs;
+                const bool diag = ci[e] == (int32_t)i;
+                for (int c = 0; c < bs; ++c) {
+                    if (diag && c == r) d = blk[c]; else off += fabs(blk[c]);
+                    if (diag) dn += blk[c] * blk[c];
+                }
+            }
+            dinv[i * bs + r] = d != 0.0 ? 1.0 / d : 1.0;
+            ident[i * bs + r] = off == 0.0 ? 1 : 0;
+            if (d != 0.0) gmax = fmax(gmax, (fabs(d) + off) / fabs(d));
+        }
+        dnorm[i] = sqrt(dn);
+    }
+    // positive doubles order like their bit patterns
+    atomicMax(gersh_bits, (unsigned long long)__double_as_longlong(gmax));
+}
+
+// strength graph: j != i strong iff ||A_ij||_F^2 > theta^2 ||A_ii||_F ||A_jj||_F (and > 0)
+template <bool FILL>
+__global__ void k_strength(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                           const double* __restrict__ val, const double* __restrict__ dnorm, double theta2,
+                           int32_t* __restrict__ cnt, const int32_t* __restrict__ sptr, int32_t* __restrict__ scol,
+                           double* __restrict__ sw) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int bb = bs * bs;
+    for (; i < nn; i += stride) {
+        int32_t n = 0;
+        const int32_t o = FILL ? sptr[i] : 0;
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const int32_t j = ci[e];
+            if (j == (int32_t)i) continue;
+            double f = 0.0;
+            const double* blk = val + (int64_t)e * bb;
+            for (int q = 0; q < bb; ++q) f += blk[q] * blk[q];
+            if (f > 0.0 && f > theta2 * dnorm[i] * dnorm[j]) {
+                if (FILL) { scol[o + n] = j; sw[o + n] = f; }
+                ++n;
+            }
+        }
+        if (!FILL) cnt[i] = n;
+    }
+}
+
+// ---- MIS(2) ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t amg_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// key = state(2 bits: 2 root, 1 undecided, 0 out) | hash(30) | index(32)
+__global__ void k_mis_init(int64_t nn, const int32_t* __restrict__ sptr, unsigned long long* __restrict__ key) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        const unsigned long long st = sptr[i + 1] > sptr[i] ? 1ULL : 0ULL;
+        key[i] = (st << 62) | ((unsigned long long)(amg_hash((uint32_t)i) & 0x3fffffffU) << 32) | (unsigned long long)i;
+    }
+}
+__global__ void k_mis_max(int64_t nn, const int32_t* __restrict__ sptr, const int32_t* __restrict__ scol,
+                          const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        unsigned long long m = in[i];
+        for (int32_t e = sptr[i]; e < sptr[i + 1]; ++e) {
+            const unsigned long long v = in[scol[e]];
+            m = v > m ? v : m;
+        }
+        out[i] = m;
+    }
+}
+__global__ void k_mis_update(int64_t nn, unsigned long long* __restrict__ key, const unsigned long long* __restrict__ m2,
+                             int32_t* __restrict__ undecided) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int32_t left = 0;
+    for (; i < nn; i += stride) {
+        const unsigned long long k = key[i];
+        if ((k >> 62) != 1ULL) continue;
+        const unsigned long long m = m2[i];
+        if ((uint32_t)m == (uint32_t)i) key[i] = (k & ~(3ULL << 62)) | (2ULL << 62);
+        else if ((m >> 62) == 2ULL) key[i] = k & ~(3ULL << 62);
+        else ++left;
+    }
+    if (left) atomicAdd(undecided, left);
+}
+__global__ void k_agg_rootflag(int64_t nn, const unsigned long long* __restrict__ key, int32_t* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i <= nn; i += stride) flag[i] = (i < nn && (key[i] >> 62) == 2ULL) ? 1 : 0;
+}
+__global__ void k_agg_pass1(int64_t nn, const int32_t* __restrict__ sptr, const int32_t* __restrict__ scol,
+                            const unsigned long long* __restrict__ key, const int32_t* __restrict__ rootid,
+                            int32_t* __restrict__ agg1) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        int32_t a = -1;
+        if ((key[i] >> 62) == 2ULL) a = rootid[i];
+        else
+            for (int32_t e = sptr[i]; e < sptr[i + 1]; ++e) {
+                const int32_t j = scol[e];
+                if ((key[j] >> 62) == 2ULL) { a = rootid[j]; break; }   // at most one root neighbour
+            }
+        agg1[i] = a;
+    }
+}
+__global__ void k_agg_pass2(int64_t nn, const int32_t* __restrict__ sptr, const int32_t* __restrict__ scol,
+                            const double* __restrict__ sw, const int32_t* __restrict__ agg1, int32_t* __restrict__ agg) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        int32_t a = agg1[i];
+        if (a < 0) {
+            double best = -1.0;
+            for (int32_t e = sptr[i]; e < sptr[i + 1]; ++e) {   // ascending j: ties go to the smaller index
+                const int32_t aj = agg1[scol[e]];
+                if (aj >= 0 && sw[e] > best) { best = sw[e]; a = aj; }
+            }
+        }
+        agg[i] = a;
+    }
+}
+__global__ void k_agg_sortkey(int64_t nn, const int32_t* __restrict__ agg, int32_t n_agg, int32_t* __restrict__ key,
+                              int32_t* __restrict__ has) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i <= nn; i += stride) {
+        if (i < nn) key[i] = agg[i] >= 0 ? agg[i] : n_agg;
+        has[i] = (i < nn && agg[i] >= 0) ? 1 : 0;
+    }
+}
+
+// ---- tentative prolongator: QR of the near-null space over every aggregate ---------------------------
+// T [nn][bs][nb] (rows of isolated nodes stay 0), Bc [n_agg][nb][nb] = R
+__global__ void k_tentative(int64_t n_agg, int bs, int nb, const int32_t* __restrict__ agg_ptr,
+                            const int32_t* __restrict__ members, const double* __restrict__ B,
+                            const uint8_t* __restrict__ ident, double* __restrict__ T, double* __restrict__ Bc) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; a < n_agg; a += stride) {
+        const int32_t m0 = agg_ptr[a], m1 = agg_ptr[a + 1];
+        for (int32_t m = m0; m < m1; ++m) {
+            const int64_t i = members[m];
+            for (int r = 0; r < bs; ++r)
+                for (int c = 0; c < nb; ++c)
+                    T[(i * bs + r) * nb + c] = ident[i * bs + r] ? 0.0 : B[(i * bs + r) * nb + c];
+        }
+        double* R = Bc + a * nb * nb;
+        for (int q = 0; q < nb * nb; ++q) R[q] = 0.0;
+        for (int c = 0; c < nb; ++c) {
+            double orig = 0.0;
+            for (int32_t m = m0; m < m1; ++m) {
+                const int64_t i = members[m];
+                for (int r = 0; r < bs; ++r) { const double v = T[(i * bs + r) * nb + c]; orig += v * v; }
+            }
+            for (int k = 0; k < c; ++k) {
+                double dot = 0.0;
+                for (int32_t m = m0; m < m1; ++m) {
+                    const int64_t i = members[m];
+                    for (int r = 0; r < bs; ++r) dot += T[(i * bs + r) * nb + k] * T[(i * bs + r) * nb + c];
+                }
+                R[k * nb + c] = dot;
+                for (int32_t m = m0; m < m1; ++m) {
+                    const int64_t i = members[m];
+                    for (int r = 0; r < bs; ++r) T[(i * bs + r) * nb + c] -= dot * T[(i * bs + r) * nb + k];
+                }
+            }
+            double nrm = 0.0;
+            for (int32_t m = m0; m < m1; ++m) {
+                const int64_t i = members[m];
+                for (int r = 0; r < bs; ++r) { const double v = T[(i * bs + r) * nb + c]; nrm += v * v; }
+            }
+            const bool live = nrm > 1e-16 * orig && nrm > 0.0;   // (1e-8)^2: column not in the span of the others
+            nrm = sqrt(nrm);
+            R[c * nb + c] = live ? nrm : 0.0;
+            const double sc = live ? 1.0 / nrm : 0.0;
+            if (!live)
+                for (int k = 0; k < c; ++k) R[k * nb + c] = 0.0;
+            for (int32_t m = m0; m < m1; ++m) {
+                const int64_t i = members[m];
+                for (int r = 0; r < bs; ++r) T[(i * bs + r) * nb + c] *= sc;
+            }
+        }
+    }
+}
+
+// T as block CSR: one block per aggregated node
+__global__ void k_t_fill(int64_t nn, int bsnb, const int32_t* __restrict__ agg, const int32_t* __restrict__ tptr,
+                         const double* __restrict__ T, int32_t* __restrict__ tcol, double* __restrict__ tval) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        if (agg[i] < 0) continue;
+        const int64_t e = tptr[i];
+        tcol[e] = agg[i];
+        for (int q = 0; q < bsnb; ++q) tval[e * bsnb + q] = T[i * bsnb + q];
+    }
+}
+
+// P = T - omega D^-1 (A T), in place on the values of AT (pattern of AT contains agg(i): the diagonal is structural)
+__global__ void k_smooth_p(int64_t nn, int bs, int nb, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                           double* __restrict__ val, const double* __restrict__ dinv, const int32_t* __restrict__ agg,
+                           const double* __restrict__ T, double omega) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride) {
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const bool own = ci[e] == agg[i];
+            for (int r = 0; r < bs; ++r)
+                for (int c = 0; c < nb; ++c) {
+                    const int64_t q = ((int64_t)e * bs + r) * nb + c;
+                    double v = -omega * dinv[i * bs + r] * val[q];
+                    if (own) v += T[(i * bs + r) * nb + c];
+                    val[q] = v;
+                }
+        }
+    }
+}
+
+// ---- row-wise SpGEMM ----------------------------------------------------------------------------------
+// Output row I expands the rows lk[q] of the right matrix, q in [lptr[I], lptr[I+1]).
+// Symbolic: distinct columns through an LDS hash; COUNT writes the row length, otherwise the sorted columns.
+template <bool COUNT>
+__global__ void k_spgemm_symbolic(int64_t n_out, const int32_t* __restrict__ lptr, const int32_t* __restrict__ lk,
+                                  const int32_t* __restrict__ rptr, const int32_t* __restrict__ rcol, int cap,
+                                  int32_t* __restrict__ rowlen, const int32_t* __restrict__ optr,
+                                  int32_t* __restrict__ ocol, int32_t* __restrict__ overflow) {
+    extern __shared__ int32_t lds_i[];
+    int32_t* keys = lds_i;            // [cap]
+    int32_t* list = lds_i + cap;      // [cap]
+    __shared__ int32_t used;
+    const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
+    for (int64_t I = blockIdx.x; I < n_out; I += gridDim.x) {
+        for (int t = threadIdx.x; t < cap; t += blockDim.x) keys[t] = -1;
+        if (threadIdx.x == 0) used = 0;
+        __syncthreads();
+        for (int32_t q = lptr[I] + grp; q < lptr[I + 1]; q += ngrp) {
+            const int32_t k = lk[q];
+            for (int32_t p = rptr[k] + lane16; p < rptr[k + 1]; p += 16) {
+                const int32_t J = rcol[p];
+                uint32_t h = ((uint32_t)J * 2654435761U) % (uint32_t)cap;
+                int probes = 0;
+                while (true) {
+                    const int32_t old = atomicCAS(&keys[h], -1, J);
+                    if (old == -1 || old == J) break;
+                    h = h + 1 == (uint32_t)cap ? 0 : h + 1;
+                    if (++probes >= cap) { atomicExch(overflow, 1); break; }
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < cap; t += blockDim.x)
+            if (keys[t] >= 0) list[atomicAdd(&used, 1)] = keys[t];
+        __syncthreads();
+        const int n = used;
+        if (COUNT) {
+            if (threadIdx.x == 0) rowlen[I] = n;
+        } else {
+            const int32_t o = optr[I];
+            for (int t = threadIdx.x; t < n; t += blockDim.x) {
+                const int32_t key = list[t];
+                int rank = 0;
+                for (int u = 0; u < n; ++u) rank += list[u] < key ? 1 : 0;
+                ocol[o + rank] = key;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Numeric: C_row(I) = sum_q L_q * Rrow(lk[q]); L_q = left block lval[lidx[q]] (br x bk), used transposed when
+// TRANS (stored bk x br).  The row is accumulated in LDS ([len][br][bc]); within one q all items hit distinct
+// addresses, consecutive q are separated by a barrier: no atomics, fixed summation order.
+template <bool TRANS>
+__global__ void k_spgemm_numeric(int64_t n_out, int br, int bk, int bc, const int32_t* __restrict__ lptr,
+                                 const int32_t* __restrict__ lk, const int32_t* __restrict__ lidx,
+                                 const double* __restrict__ lval, const int32_t* __restrict__ rptr,
+                                 const int32_t* __restrict__ rcol, const double* __restrict__ rval,
+                                 const int32_t* __restrict__ optr, const int32_t* __restrict__ ocol,
+                                 double* __restrict__ oval) {
+    extern __shared__ double acc[];
+    const int rc = br * bc;
+    for (int64_t I = blockIdx.x; I < n_out; I += gridDim.x) {
+        const int32_t o0 = optr[I];
+        const int len = optr[I + 1] - o0;
+        for (int t = threadIdx.x; t < len * rc; t += blockDim.x) acc[t] = 0.0;
+        __syncthreads();
+        for (int32_t q = lptr[I]; q < lptr[I + 1]; ++q) {
+            const int32_t k = lk[q];
+            const double* L = lval + (int64_t)(lidx ? lidx[q] : q) * br * bk;
+            const int32_t r0 = rptr[k];
+            const int items = (rptr[k + 1] - r0) * rc;
+            for (int it = threadIdx.x; it < items; it += blockDim.x) {
+                const int p = it / rc, e = it - p * rc;
+                const int r = e / bc, c = e - r * bc;
+                const int32_t J = rcol[r0 + p];
+                int lo = 0, hi = len;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ocol[o0 + mid] < J) lo = mid + 1; else hi = mid;
+                }
+                const double* Rb = rval + (int64_t)(r0 + p) * bk * bc;
+                double v = 0.0;
+                for (int m = 0; m < bk; ++m) v += (TRANS ? L[m * br + r] : L[r * bk + m]) * Rb[m * bc + c];
+                acc[lo * rc + e] += v;
+            }
+            __syncthreads();
+        }
+        for (int t = threadIdx.x; t < len * rc; t += blockDim.x) oval[(int64_t)o0 * rc + t] = acc[t];
+        __syncthreads();
+    }
+}
+
+// dead coarse dofs (near-null-space column not representable on an aggregate): unit diagonal
+__global__ void k_fix_dead(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                           double* __restrict__ val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nn; i += stride)
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e)
+            if (ci[e] == (int32_t)i)
+                for (int r = 0; r < bs; ++r)
+                    if (val[((int64_t)e * bs + r) * bs + r] == 0.0) val[((int64_t)e * bs + r) * bs + r] = 1.0;
+}
+
+// ---- solve phase kernels ------------------------------------------------------------------------------
+// y = A x (MODE 0) or y = b - A x (MODE 1); thread per scalar row
+template <int BS, int MODE>
+__global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv(int64_t n, const int32_t* __restrict__ rp,
+                                                        const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                        const double* __restrict__ x, const double* __restrict__ b,
+                                                        double* __restrict__ y) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; row < n; row += stride) {
+        const int64_t i = row / BS;
+        const int r = (int)(row - i * BS);
+        double acc = 0.0;
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const double* blk = val + ((int64_t)e * BS + r) * BS;
+            const double* xj = x + (int64_t)ci[e] * BS;
+#pragma unroll
+            for (int c = 0; c < BS; ++c) acc += blk[c] * xj[c];
+        }
+        y[row] = MODE ? b[row] - acc : acc;
+    }
+}
+
+// xf += P xc ; thread per fine scalar row
+__global__ void k_prolong_add(int64_t n_f, int br, int bc, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                              const double* __restrict__ val, const double* __restrict__ xc, double* __restrict__ xf) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; row < n_f; row += stride) {
+        const int64_t i = row / br;
+        const int r = (int)(row - i * br);
+        double acc = 0.0;
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const double* blk = val + ((int64_t)e * br + r) * bc;
+            const double* xj = xc + (int64_t)ci[e] * bc;
+            for (int c = 0; c < bc; ++c) acc += blk[c] * xj[c];
+        }
+        xf[row] += acc;
+    }
+}
+
+// bc_ = P^T rf ; thread per coarse scalar row, entries of the column in ascending fine row (fixed order)
+__global__ void k_restrict(int64_t n_c, int br, int bc, const int32_t* __restrict__ pt_ptr,
+                           const int32_t* __restrict__ pt_entry, const int32_t* __restrict__ pt_row,
+                           const double* __restrict__ val, const double* __restrict__ rf, double* __restrict__ out) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; row < n_c; row += stride) {
+        const int64_t I = row / bc;
+        const int c = (int)(row - I * bc);
+        double acc = 0.0;
+        for (int32_t q = pt_ptr[I]; q < pt_ptr[I + 1]; ++q) {
+            const double* blk = val + (int64_t)pt_entry[q] * br * bc;
+            const double* rr = rf + (int64_t)pt_row[q] * br;
+            for (int r = 0; r < br; ++r) acc += blk[r * bc + c] * rr[r];
+        }
+        out[row] = acc;
+    }
+}
+
+// d = scale * dinv*r ; x = (ADD ? x : 0) + d
+template <bool ADD>
+__global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r,
+                             double* __restrict__ d, double* __restrict__ x, double scale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double v = scale * dinv[i] * r[i];
+        d[i] = v;
+        x[i] = ADD ? x[i] + v : v;
+    }
+}
+// d = c1 d + c2 dinv*r ; x += d
+__global__ void k_cheb_next(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r,
+                            double* __restrict__ d, double* __restrict__ x, double c1, double c2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double v = c1 * d[i] + c2 * dinv[i] * r[i];
+        d[i] = v;
+        x[i] += v;
+    }
+}
+__global__ void k_amg_sub(int64_t n, const double* __restrict__ b, const double* t, double* r) {   // r may alias t
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) r[i] = b[i] - t[i];
+}
+// y = a x + b y
+__global__ void k_amg_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+__global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ dinv, double* __restrict__ v, double s) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] *= s * (dinv ? dinv[i] : 1.0);
+}
+__global__ void k_amg_seed(int64_t n, double* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] = (double)(amg_hash((uint32_t)i * 2654435761U + 12345U) & 0xffffff) / 8388608.0 - 1.0;
+}
+// x = Cinv b, one wave per row
+__global__ void k_dense_apply(int64_t n, const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (; row < n; row += stride) {
+        double acc = 0.0;
+        for (int64_t c = lane; c < n; c += 64) acc += M[row * n + c] * b[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) x[row] = acc;
+    }
+}
+
+// ---- host: products ------------------------------------------------------------------------------------
+// C = L R with the left operand given as (lptr, lk, lidx, lval): plain block CSR (lidx = nullptr, TRANS=false)
+// or the transpose index of P (TRANS=true).  wg = threads per output row.
+static int spgemm(int64_t n_out, int64_t n_cols, int br, int bk, int bc, bool trans, const int32_t* lptr, const int32_t* lk,
+                  const int32_t* lidx, const double* lval, const bcsr& R, int wg, bcsr* C, hipStream_t s) {
+    C->nrows = n_out; C->ncols = n_cols; C->br = br; C->bc = bc;
+    FS_CHECK(C->rowptr.alloc(n_out + 1));
+    dbuf<int32_t> rowlen, flag;
+    FS_CHECK(rowlen.alloc(n_out + 1));
+    FS_CHECK(rowlen.zero(s));
+    FS_CHECK(flag.alloc(1));
+    const int grid = (int)std::min<int64_t>(n_out, 1 << 16);
+    int cap = wg == 64 ? 256 : 1024;
+    while (true) {
+        FS_CHECK(flag.zero(s));
+        hipLaunchKernelGGL(k_spgemm_symbolic<true>, dim3(grid), dim3(wg), (size_t)cap * 2 * sizeof(int32_t), s, n_out, lptr, lk, R.rowptr.p, R.col.p, cap, rowlen.p, (const int32_t*)nullptr, (int32_t*)nullptr, flag.p);
+        FS_KERNEL_CHECK();
+        int32_t of = 0;
+        FS_CHECK(read_i32(flag.p, &of, s));
+        if (!of) break;
+        cap *= 2;
+        FS_REQUIRE(cap <= 8192, "AMG setup: a product row has more than 8192 distinct columns");
+    }
+    FS_CHECK(scan_exclusive(rowlen.p, C->rowptr.p, n_out + 1, s));
+    int32_t nnz = 0;
+    FS_CHECK(read_i32(C->rowptr.p + n_out, &nnz, s));
+    C->nnz = nnz;
+    FS_CHECK(C->col.alloc(nnz));
+    FS_CHECK(C->val.alloc((int64_t)nnz * br * bc));
+    hipLaunchKernelGGL(k_spgemm_symbolic<false>, dim3(grid), dim3(wg), (size_t)cap * 2 * sizeof(int32_t), s, n_out, lptr, lk, R.rowptr.p, R.col.p, cap, (int32_t*)nullptr, C->rowptr.p, C->col.p, flag.p);
+    FS_KERNEL_CHECK();
+    // longest row -> LDS of the numeric pass
+    int32_t maxlen = 0;
+    {
+        size_t tb = 0;
+        dbuf<int32_t> mx;
+        FS_CHECK(mx.alloc(1));
+        FS_HIP(hipcub::DeviceReduce::Max(nullptr, tb, rowlen.p, mx.p, (int)n_out, s));
+        dbuf<uint8_t> tmp;
+        FS_CHECK(tmp.alloc((int64_t)tb + 16));
+        FS_HIP(hipcub::DeviceReduce::Max(tmp.p, tb, rowlen.p, mx.p, (int)n_out, s));
+        FS_CHECK(read_i32(mx.p, &maxlen, s));
+    }
+    const size_t lds = (size_t)std::max(1, maxlen) * br * bc * sizeof(double);
+    FS_REQUIRE(lds <= 160 * 1024 - 512, "AMG setup: a product row of %d blocks (%dx%d) exceeds the LDS accumulator", maxlen, br, bc);
+    if (lds > 64 * 1024) {
+        if (trans) FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (trans)
+        hipLaunchKernelGGL(k_spgemm_numeric<true>, dim3(grid), dim3(wg), lds, s, n_out, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+    else
+        hipLaunchKernelGGL(k_spgemm_numeric<false>, dim3(grid), dim3(wg), lds, s, n_out, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, double* y, int mode, hipStream_t s) {
+    amg_level* L = M->lv[l];
+    if (l == 0) {
+        if (mode == 0) return fs_spmv_dev(M->fine, x, y, s);
+        FS_CHECK(fs_spmv_dev(M->fine, x, L->t.p, s));
+        hipLaunchKernelGGL(k_amg_sub, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, b, L->t.p, y);
+        return FS_OK;
+    }
+    const int g = fs_grid_for(L->n, FS_BLOCK, 8192);
+#define FS_BCSR_ARGS dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y
+    if (L->bs == 1) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv<1, 1>), FS_BCSR_ARGS); else hipLaunchKernelGGL((k_bcsr_spmv<1, 0>), FS_BCSR_ARGS); }
+    else if (L->bs == 3) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv<3, 1>), FS_BCSR_ARGS); else hipLaunchKernelGGL((k_bcsr_spmv<3, 0>), FS_BCSR_ARGS); }
+    else if (L->bs == 6) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv<6, 1>), FS_BCSR_ARGS); else hipLaunchKernelGGL((k_bcsr_spmv<6, 0>), FS_BCSR_ARGS); }
+    else { fs_set_error("AMG: unsupported block size %d", L->bs); return FS_ERR_UNSUPPORTED; }
+#undef FS_BCSR_ARGS
+    return FS_OK;
+}
+
+// setup-time SpMV on the level's own block CSR (level 0 included)
+static int bcsr_spmv_setup(amg_level* L, const double* x, double* y, hipStream_t s) {
+    const int g = fs_grid_for(L->n, FS_BLOCK, 8192);
+#define FS_BCSR_ARGS dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, (const double*)nullptr, y
+    if (L->bs == 1) hipLaunchKernelGGL((k_bcsr_spmv<1, 0>), FS_BCSR_ARGS);
+    else if (L->bs == 3) hipLaunchKernelGGL((k_bcsr_spmv<3, 0>), FS_BCSR_ARGS);
+    else if (L->bs == 6) hipLaunchKernelGGL((k_bcsr_spmv<6, 0>), FS_BCSR_ARGS);
+    else { fs_set_error("AMG: unsupported block size %d", L->bs); return FS_ERR_UNSUPPORTED; }
+#undef FS_BCSR_ARGS
+    return FS_OK;
+}
+
+static int dot_host(fs_amg_s* M, const double* x, const double* y, int64_t n, double* out, hipStream_t s) {
+    const int g = fs_grid_for(n, FS_BLOCK, 1024);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(FS_BLOCK), 0, s, x, y, n, M->partials.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, M->partials.p, g, 1, M->sums.p);
+    FS_KERNEL_CHECK();
+    FS_CHECK(M->sums.download(out, 1, s));
+    return FS_OK;
+}
+
+// largest eigenvalue of D^-1 A by power iteration (deterministic start)
+static int estimate_lmax(fs_amg_s* M, amg_level* L, int steps, hipStream_t s) {
+    dbuf<double> v, w;
+    FS_CHECK(v.alloc(L->n));
+    FS_CHECK(w.alloc(L->n));
+    hipLaunchKernelGGL(k_amg_seed, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, v.p);
+    double nv = 0.0, lam = 0.0;
+    FS_CHECK(dot_host(M, v.p, v.p, L->n, &nv, s));
+    hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, (const double*)nullptr, v.p, 1.0 / sqrt(nv));
+    for (int it = 0; it < steps; ++it) {
+        FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
+        hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, w.p, 1.0);
+        double nw = 0.0;
+        FS_CHECK(dot_host(M, w.p, w.p, L->n, &nw, s));
+        nw = sqrt(nw);
+        if (!(nw > 0.0)) break;
+        lam = nw;
+        hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, (const double*)nullptr, w.p, 1.0 / nw);
+        std::swap(v.p, w.p);
+    }
+    L->lmax = lam > 0.0 ? std::min(1.1 * lam, L->gersh) : L->gersh;
+    return FS_OK;
+}
+
+// ---- host: one coarsening step.  Returns *stop = 1 when no useful coarse level results ------------------
+static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_level** out, hipStream_t s) {
+    *out = nullptr;
+    const int64_t nn = L->nn;
+    const int bs = L->bs, nb = L->nb;
+    const int g = fs_grid_for(nn, FS_BLOCK, 8192);
+    // diagonal quantities
+    dbuf<double> dnorm;
+    dbuf<unsigned long long> gbits;
+    FS_CHECK(dnorm.alloc(nn));
+    FS_CHECK(gbits.alloc(1));
+    FS_CHECK(gbits.zero(s));
+    FS_CHECK(L->dinv.alloc(L->n));
+    FS_CHECK(L->ident.alloc(L->n));
+    hipLaunchKernelGGL(k_amg_diag, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, L->ident.p, dnorm.p, gbits.p);
+    FS_KERNEL_CHECK();
+    unsigned long long hb = 0;
+    FS_HIP(hipMemcpyAsync(&hb, gbits.p, 8, hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    memcpy(&L->gersh, &hb, 8);
+    if (!(L->gersh > 0.0)) L->gersh = 2.0;
+    FS_CHECK(estimate_lmax(M, L, eig_steps, s));
+    if (nb <= 0) return FS_OK;   // coarsest level: only the smoother data
+
+    // strength graph
+    dbuf<int32_t> scnt, sptr, scol;
+    dbuf<double> sw;
+    FS_CHECK(scnt.alloc(nn + 1));
+    FS_CHECK(scnt.zero(s));
+    FS_CHECK(sptr.alloc(nn + 1));
+    hipLaunchKernelGGL(k_strength<false>, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, dnorm.p, theta * theta, scnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+    FS_KERNEL_CHECK();
+    FS_CHECK(scan_exclusive(scnt.p, sptr.p, nn + 1, s));
+    int32_t snnz = 0;
+    FS_CHECK(read_i32(sptr.p + nn, &snnz, s));
+    if (snnz == 0) return FS_OK;
+    FS_CHECK(scol.alloc(snnz));
+    FS_CHECK(sw.alloc(snnz));
+    hipLaunchKernelGGL(k_strength<true>, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, dnorm.p, theta * theta, (int32_t*)nullptr, sptr.p, scol.p, sw.p);
+    FS_KERNEL_CHECK();
+
+    // MIS(2)
+    dbuf<unsigned long long> key, m1, m2;
+    dbuf<int32_t> undecided;
+    FS_CHECK(key.alloc(nn)); FS_CHECK(m1.alloc(nn)); FS_CHECK(m2.alloc(nn));
+    FS_CHECK(undecided.alloc(1));
+    hipLaunchKernelGGL(k_mis_init, dim3(g), dim3(FS_BLOCK), 0, s, nn, sptr.p, key.p);
+    for (int round = 0;; ++round) {
+        FS_REQUIRE(round < 200, "AMG setup: MIS(2) did not terminate");
+        FS_CHECK(undecided.zero(s));
+        hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(FS_BLOCK), 0, s, nn, sptr.p, scol.p, key.p, m1.p);
+        hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(FS_BLOCK), 0, s, nn, sptr.p, scol.p, m1.p, m2.p);
+        hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(FS_BLOCK), 0, s, nn, key.p, m2.p, undecided.p);
+        FS_KERNEL_CHECK();
+        int32_t left = 0;
+        FS_CHECK(read_i32(undecided.p, &left, s));
+        if (left == 0) break;
+    }
+    // aggregates
+    dbuf<int32_t> flag, rootid, agg1, agg;
+    FS_CHECK(flag.alloc(nn + 1)); FS_CHECK(rootid.alloc(nn + 1)); FS_CHECK(agg1.alloc(nn)); FS_CHECK(agg.alloc(nn));
+    hipLaunchKernelGGL(k_agg_rootflag, dim3(g), dim3(FS_BLOCK), 0, s, nn, key.p, flag.p);
+    FS_CHECK(scan_exclusive(flag.p, rootid.p, nn + 1, s));
+    int32_t n_agg = 0;
+    FS_CHECK(read_i32(rootid.p + nn, &n_agg, s));
+    if (n_agg == 0 || (int64_t)n_agg * nb >= L->n) return FS_OK;   // no reduction
+    hipLaunchKernelGGL(k_agg_pass1, dim3(g), dim3(FS_BLOCK), 0, s, nn, sptr.p, scol.p, key.p, rootid.p, agg1.p);
+    hipLaunchKernelGGL(k_agg_pass2, dim3(g), dim3(FS_BLOCK), 0, s, nn, sptr.p, scol.p, sw.p, agg1.p, agg.p);
+    FS_KERNEL_CHECK();
+    // member lists
+    dbuf<int32_t> skey, skey2, sval, members, agg_ptr, has, tptr;
+    FS_CHECK(skey.alloc(nn)); FS_CHECK(skey2.alloc(nn)); FS_CHECK(sval.alloc(nn)); FS_CHECK(members.alloc(nn));
+    FS_CHECK(agg_ptr.alloc(n_agg + 1)); FS_CHECK(has.alloc(nn + 1)); FS_CHECK(tptr.alloc(nn + 1));
+    hipLaunchKernelGGL(k_agg_sortkey, dim3(g), dim3(FS_BLOCK), 0, s, nn, agg.p, n_agg, skey.p, has.p);
+    hipLaunchKernelGGL(k_iota, dim3(g), dim3(FS_BLOCK), 0, s, sval.p, nn);
+    FS_CHECK(sort_pairs(skey.p, skey2.p, sval.p, members.p, nn, s));
+    hipLaunchKernelGGL(k_lower_bounds, dim3(fs_grid_for(n_agg + 1)), dim3(FS_BLOCK), 0, s, skey2.p, nn, (int64_t)n_agg, agg_ptr.p);
+    FS_CHECK(scan_exclusive(has.p, tptr.p, nn + 1, s));
+    int32_t n_t = 0;
+    FS_CHECK(read_i32(tptr.p + nn, &n_t, s));
+
+    // tentative prolongator + coarse near-null space
+    amg_level* C = new amg_level();
+    C->nn = n_agg; C->bs = nb; C->n = (int64_t)n_agg * nb; C->nb = nb;
+    dbuf<double> T;
+    FS_CHECK(T.alloc(L->n * nb));
+    FS_CHECK(T.zero(s));
+    FS_CHECK(C->B.alloc(C->n * nb));
+    hipLaunchKernelGGL(k_tentative, dim3(fs_grid_for(n_agg, 64, 8192)), dim3(64), 0, s, (int64_t)n_agg, bs, nb, agg_ptr.p, members.p, L->B.p, L->ident.p, T.p, C->B.p);
+    FS_KERNEL_CHECK();
+    bcsr Tm;
+    Tm.nrows = nn; Tm.ncols = n_agg; Tm.br = bs; Tm.bc = nb; Tm.nnz = n_t;
+    FS_CHECK(Tm.col.alloc(n_t));
+    FS_CHECK(Tm.val.alloc((int64_t)n_t * bs * nb));
+    hipLaunchKernelGGL(k_t_fill, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs * nb, agg.p, tptr.p, T.p, Tm.col.p, Tm.val.p);
+    FS_KERNEL_CHECK();
+    std::swap(Tm.rowptr.p, tptr.p); std::swap(Tm.rowptr.n, tptr.n);
+
+    // P = (I - omega D^-1 A) T
+    FS_CHECK(spgemm(nn, n_agg, bs, bs, nb, false, L->A.rowptr.p, L->A.col.p, nullptr, L->A.val.p, Tm, 64, &L->P, s));
+    const double omega = 4.0 / (3.0 * L->lmax);
+    hipLaunchKernelGGL(k_smooth_p, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, nb, L->P.rowptr.p, L->P.col.p, L->P.val.p, L->dinv.p, agg.p, T.p, omega);
+    FS_KERNEL_CHECK();
+    L->n_agg = n_agg;
+    // transpose index of P
+    {
+        const int64_t pn = L->P.nnz;
+        dbuf<int32_t> k2, ids, prow;
+        FS_CHECK(k2.alloc(pn)); FS_CHECK(ids.alloc(pn)); FS_CHECK(prow.alloc(pn));
+        FS_CHECK(L->pt_entry.alloc(pn)); FS_CHECK(L->pt_row.alloc(pn)); FS_CHECK(L->pt_ptr.alloc(n_agg + 1));
+        hipLaunchKernelGGL(k_iota, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, ids.p, pn);
+        hipLaunchKernelGGL(k_expand_rows, dim3(g), dim3(FS_BLOCK), 0, s, L->P.rowptr.p, nn, prow.p);
+        FS_CHECK(sort_pairs(L->P.col.p, k2.p, ids.p, L->pt_entry.p, pn, s));    // stable: ascending fine row inside a column
+        hipLaunchKernelGGL(k_lower_bounds, dim3(fs_grid_for(n_agg + 1)), dim3(FS_BLOCK), 0, s, k2.p, pn, (int64_t)n_agg, L->pt_ptr.p);
+        hipLaunchKernelGGL(k_gather_i32, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, prow.p, L->pt_entry.p, pn, L->pt_row.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+    }
+    // A_c = P^T (A P)
+    {
+        bcsr AP;
+        FS_CHECK(spgemm(nn, n_agg, bs, bs, nb, false, L->A.rowptr.p, L->A.col.p, nullptr, L->A.val.p, L->P, 64, &AP, s));
+        FS_CHECK(spgemm(n_agg, n_agg, nb, bs, nb, true, L->pt_ptr.p, L->pt_row.p, L->pt_entry.p, L->P.val.p, AP, FS_BLOCK, &C->A, s));
+    }
+    hipLaunchKernelGGL(k_fix_dead, dim3(fs_grid_for(n_agg)), dim3(FS_BLOCK), 0, s, (int64_t)n_agg, nb, C->A.rowptr.p, C->A.col.p, C->A.val.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    *out = C;
+    return FS_OK;
+}
+
+// dense inverse of the coarsest operator on the host (Gauss-Jordan, partial pivoting)
+static int coarse_inverse(fs_amg_s* M, amg_level* L, hipStream_t s) {
+    const int64_t n = L->n, nn = L->nn;
+    const int bs = L->bs;
+    std::vector<int32_t> rp(nn + 1), ci(L->A.nnz);
+    std::vector<double> va((size_t)L->A.nnz * bs * bs);
+    FS_CHECK(L->A.rowptr.download(rp.data(), nn + 1, s));
+    FS_CHECK(L->A.col.download(ci.data(), L->A.nnz, s));
+    FS_CHECK(L->A.val.download(va.data(), (int64_t)va.size(), s));
+    std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
+    for (int64_t i = 0; i < nn; ++i)
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e)
+            for (int r = 0; r < bs; ++r)
+                for (int c = 0; c < bs; ++c) a[(size_t)(i * bs + r) * n + (size_t)ci[e] * bs + c] = va[((size_t)e * bs + r) * bs + c];
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+    for (int64_t k = 0; k < n; ++k) {
+        int64_t piv = k;
+        double best = fabs(a[(size_t)k * n + k]);
+        for (int64_t i = k + 1; i < n; ++i)
+            if (fabs(a[(size_t)i * n + k]) > best) { best = fabs(a[(size_t)i * n + k]); piv = i; }
+        if (!(best > 0.0)) { fs_set_error("AMG setup: coarsest operator is singular"); return FS_ERR_NUMERIC; }
+        if (piv != k)
+            for (int64_t c = 0; c < n; ++c) {
+                std::swap(a[(size_t)k * n + c], a[(size_t)piv * n + c]);
+                std::swap(inv[(size_t)k * n + c], inv[(size_t)piv * n + c]);
+            }
+        const double d = 1.0 / a[(size_t)k * n + k];
+        for (int64_t c = 0; c < n; ++c) { a[(size_t)k * n + c] *= d; inv[(size_t)k * n + c] *= d; }
+        for (int64_t i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double f = a[(size_t)i * n + k];
+            if (f == 0.0) continue;
+            for (int64_t c = 0; c < n; ++c) {
+                a[(size_t)i * n + c] -= f * a[(size_t)k * n + c];
+                inv[(size_t)i * n + c] -= f * inv[(size_t)k * n + c];
+            }
+        }
+    }
+    FS_CHECK(M->cinv.alloc(n * n));
+    FS_CHECK(M->cinv.upload(inv.data(), n * n, s));
+    M->nc = n;
+    return FS_OK;
+}
+
+// ---- C-ABI: setup ---------------------------------------------------------------------------------------
+extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullspace, const fs_amg_opts* opts,
+                            fs_amg_t* out) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A && out, "fs_amg_setup: null pointer");
+    fs_space_s* sp = A->space;
+    FS_REQUIRE(fs_rt().n_ranks == 1 && !sp->halo.active, "fs_amg_setup: the AMG hierarchy is single-GPU for now");
+    FS_REQUIRE(A->bs == 1 || A->bs == 3, "fs_amg_setup: block size %d", A->bs);
+    const int nb = nullspace ? n_nullspace : A->bs;
+    FS_REQUIRE(nb == 1 || nb == 3 || nb == 6, "fs_amg_setup: %d near-null-space vectors (1, 3 or 6 are built)", nb);
+    const double theta = opts ? opts->strength_threshold : 0.0;
+    const int max_levels = opts && opts->max_levels > 0 ? opts->max_levels : 10;
+    const int coarse_size = opts && opts->coarse_size > 0 ? opts->coarse_size : 500;
+    const int eig_steps = opts && opts->eig_steps > 0 ? opts->eig_steps : 30;
+    hipStream_t s = fs_rt().stream;
+    const auto t0 = std::chrono::steady_clock::now();
+
+    fs_amg_s* M = new fs_amg_s();
+    M->fine = A;
+    M->smooth_steps = opts && opts->smoother_steps > 0 ? opts->smoother_steps : 2;
+    int rc = FS_OK;
+    auto fail = [&](int code) { delete M; return code; };
+    if ((rc = M->partials.alloc(FS_MAX_PARTIAL_BLOCKS * 4)) != FS_OK) return fail(rc);
+    if ((rc = M->sums.alloc(8)) != FS_OK) return fail(rc);
+
+    amg_level* L0 = new amg_level();
+    M->lv.push_back(L0);
+    L0->nn = sp->n_nodes_owned; L0->bs = A->bs; L0->n = sp->n_dofs_owned; L0->nb = nb;
+    L0->A.nrows = L0->A.ncols = L0->nn; L0->A.br = L0->A.bc = A->bs; L0->A.nnz = sp->nnz_nodes;
+    if ((rc = L0->A.rowptr.alloc(L0->nn + 1)) != FS_OK) return fail(rc);
+    if ((rc = L0->A.col.alloc(sp->nnz_nodes)) != FS_OK) return fail(rc);
+    if ((rc = L0->A.val.alloc(sp->nnz_nodes * A->bs * A->bs)) != FS_OK) return fail(rc);
+    if (hipMemcpyAsync(L0->A.rowptr.p, sp->rowptr.p, (size_t)(L0->nn + 1) * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(L0->A.col.p, sp->colidx.p, (size_t)sp->nnz_nodes * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        fs_set_error("fs_amg_setup: device copy failed");
+        return fail(FS_ERR_HIP);
+    }
+    if (A->bs == 1)
+        hipLaunchKernelGGL(k_amg_extract<1>, dim3(fs_grid_for(L0->nn)), dim3(FS_BLOCK), 0, s, L0->nn, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, L0->A.val.p);
+    else
+        hipLaunchKernelGGL(k_amg_extract<3>, dim3(fs_grid_for(L0->nn)), dim3(FS_BLOCK), 0, s, L0->nn, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, L0->A.val.p);
+    // near-null space [n][nb]
+    {
+        std::vector<double> hB((size_t)L0->n * nb, 0.0);
+        if (nullspace) {
+            for (int c = 0; c < nb; ++c)
+                for (int64_t i = 0; i < L0->n; ++i) hB[(size_t)i * nb + c] = nullspace[(size_t)c * L0->n + i];
+        } else {
+            for (int64_t i = 0; i < L0->n; ++i) hB[(size_t)i * nb + (i % A->bs)] = 1.0;
+        }
+        if ((rc = L0->B.alloc(L0->n * nb)) != FS_OK) return fail(rc);
+        if ((rc = L0->B.upload(hB.data(), L0->n * nb, s)) != FS_OK) return fail(rc);
+    }
+    double nnz_scalar0 = (double)L0->A.nnz * A->bs * A->bs, nnz_total = nnz_scalar0, n_total = (double)L0->n;
+    while (true) {
+        amg_level* L = M->lv.back();
+        const bool last = (int)M->lv.size() >= max_levels || L->n <= coarse_size;
+        if (last) L->nb = 0;
+        amg_level* C = nullptr;
+        if ((rc = coarsen(M, L, theta, eig_steps, &C, s)) != FS_OK) return fail(rc);
+        if (!C) { L->nb = 0; break; }
+        M->lv.push_back(C);
+        nnz_total += (double)C->A.nnz * C->bs * C->bs;
+        n_total += (double)C->n;
+    }
+    M->op_complexity = nnz_total / nnz_scalar0;
+    M->grid_complexity = n_total / (double)L0->n;
+    // work vectors
+    for (size_t l = 0; l < M->lv.size(); ++l) {
+        amg_level* L = M->lv[l];
+        if ((rc = L->r.alloc(L->n)) != FS_OK || (rc = L->d.alloc(L->n)) != FS_OK || (rc = L->t.alloc(L->n)) != FS_OK) return fail(rc);
+        if (l > 0 && ((rc = L->x.alloc(L->n)) != FS_OK || (rc = L->b.alloc(L->n)) != FS_OK)) return fail(rc);
+    }
+    amg_level* Lc = M->lv.back();
+    if (Lc->n <= 2500 && M->lv.size() > 1) {
+        if ((rc = coarse_inverse(M, Lc, s)) != FS_OK) return fail(rc);
+    }
+    FS_HIP(hipStreamSynchronize(s));
+    M->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = M;
+    return FS_OK;
+}
+
+extern "C" int fs_amg_destroy(fs_amg_t M) {
+    delete M;
+    return FS_OK;
+}
+
+extern "C" int fs_amg_info(fs_amg_t M, int* n_levels, double* operator_complexity, double* grid_complexity, double* setup_ms) {
+    FS_REQUIRE(M, "fs_amg_info: null handle");
+    if (n_levels) *n_levels = (int)M->lv.size();
+    if (operator_complexity) *operator_complexity = M->op_complexity;
+    if (grid_complexity) *grid_complexity = M->grid_complexity;
+    if (setup_ms) *setup_ms = M->setup_ms;
+    return FS_OK;
+}
+
+extern "C" int fs_amg_level_info(fs_amg_t M, int level, int64_t* n_nodes, int* block_size, int64_t* nnz_blocks,
+                                 int64_t* p_nnz_blocks, int* p_block_cols, double* lambda_max) {
+    FS_REQUIRE(M && level >= 0 && level < (int)M->lv.size(), "fs_amg_level_info: bad level");
+    amg_level* L = M->lv[level];
+    if (n_nodes) *n_nodes = L->nn;
+    if (block_size) *block_size = L->bs;
+    if (nnz_blocks) *nnz_blocks = L->A.nnz;
+    if (p_nnz_blocks) *p_nnz_blocks = L->P.nnz;
+    if (p_block_cols) *p_block_cols = L->P.bc;
+    if (lambda_max) *lambda_max = L->lmax;
+    return FS_OK;
+}
+
+extern "C" int fs_amg_level_get(fs_amg_t M, int level, int which, int32_t* rowptr, int32_t* col, double* val) {
+    FS_REQUIRE(M && level >= 0 && level < (int)M->lv.size(), "fs_amg_level_get: bad level");
+    amg_level* L = M->lv[level];
+    const bcsr& X = which == 0 ? L->A : L->P;
+    hipStream_t s = fs_rt().stream;
+    if (which == 2) {
+        FS_REQUIRE(val, "fs_amg_level_get: null pointer");
+        return L->B.download(val, L->B.n, s);
+    }
+    FS_REQUIRE(X.nnz > 0, "fs_amg_level_get: level %d has no such operator", level);
+    if (rowptr) FS_CHECK(X.rowptr.download(rowptr, X.nrows + 1, s));
+    if (col) FS_CHECK(X.col.download(col, X.nnz, s));
+    if (val) FS_CHECK(X.val.download(val, X.nnz * X.br * X.bc, s));
+    return FS_OK;
+}
+
+// ---- V-cycle ----------------------------------------------------------------------------------------------
+static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_guess, hipStream_t s) {
+    amg_level* L = M->lv[l];
+    const double up = 1.1 * L->lmax, lo = 0.1 * L->lmax;
+    const double theta = 0.5 * (up + lo), delta = 0.5 * (up - lo), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    const int g = fs_grid_for(L->n, FS_BLOCK, 2048);
+    const double* r = b;
+    if (!zero_guess) {
+        FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
+        r = L->r.p;
+        hipLaunchKernelGGL(k_cheb_first<true>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, r, L->d.p, x, 1.0 / theta);
+    } else {
+        hipLaunchKernelGGL(k_cheb_first<false>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, r, L->d.p, x, 1.0 / theta);
+    }
+    for (int k = 1; k < M->smooth_steps; ++k) {
+        FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        hipLaunchKernelGGL(k_cheb_next, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, L->r.p, L->d.p, x, rho_new * rho, 2.0 * rho_new / delta);
+        rho = rho_new;
+    }
+    return FS_OK;
+}
+
+static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s) {
+    amg_level* L = M->lv[l];
+    const int last = (int)M->lv.size() - 1;
+    if (l == last) {
+        if (M->cinv.p && l > 0) {
+            hipLaunchKernelGGL(k_dense_apply, dim3(fs_grid_for(L->n, 4, 2048)), dim3(FS_BLOCK), 0, s, L->n, M->cinv.p, b, x);
+            return FS_OK;
+        }
+        FS_CHECK(smooth(M, l, x, b, true, s));
+        for (int k = 0; k < (l > 0 ? 4 : 0); ++k) FS_CHECK(smooth(M, l, x, b, false, s));
+        return FS_OK;
+    }
+    amg_level* C = M->lv[l + 1];
+    FS_CHECK(smooth(M, l, x, b, true, s));
+    FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
+    hipLaunchKernelGGL(k_restrict, dim3(fs_grid_for(C->n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, C->n, L->P.br, L->P.bc, L->pt_ptr.p, L->pt_entry.p, L->pt_row.p, L->P.val.p, L->r.p, C->b.p);
+    FS_CHECK(vcycle(M, l + 1, C->x.p, C->b.p, s));
+    hipLaunchKernelGGL(k_prolong_add, dim3(fs_grid_for(L->n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L->n, L->P.br, L->P.bc, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
+    FS_CHECK(smooth(M, l, x, b, false, s));
+    return FS_OK;
+}
+
+extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
+    FS_REQUIRE(M && r && z, "fs_amg_apply: null pointer");
+    amg_level* L0 = M->lv[0];
+    FS_REQUIRE(r->d.n >= L0->n && z->d.n >= M->fine->space->n_dofs_local, "fs_amg_apply: vector too short");
+    hipStream_t s = fs_rt().stream;
+    FS_CHECK(vcycle(M, 0, z->d.p, r->d.p, s));
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+// ---- PCG preconditioned by one V-cycle (PETSc KSPCG + PCGAMG) ------------------------------------------------
+extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats) {
+    FS_REQUIRE(M && b && x && opts && stats, "fs_amg_solve: null pointer");
+    amg_level* L0 = M->lv[0];
+    const int64_t n = L0->n;
+    fs_space_s* sp = M->fine->space;
+    FS_REQUIRE(b->d.n >= n && x->d.n >= sp->n_dofs_local, "fs_amg_solve: vector too short");
+    hipStream_t s = fs_rt().stream;
+    if (M->pr.n < n) {
+        FS_CHECK(M->pr.alloc(n));
+        FS_CHECK(M->pz.alloc(sp->n_dofs_local));
+        FS_CHECK(M->pp.alloc(sp->n_dofs_local));
+        FS_CHECK(M->pw.alloc(n));
+        FS_CHECK(M->pz.zero(s));
+        FS_CHECK(M->pp.zero(s));
+    }
+    memset(stats, 0, sizeof(*stats));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int g = fs_grid_for(n, FS_BLOCK, 2048);
+    const bool pnorm = opts->norm_type == FS_NORM_PRECONDITIONED;
+    double bb = 0.0;
+    FS_CHECK(dot_host(M, b->d.p, b->d.p, n, &bb, s));
+    stats->bnorm = sqrt(bb);
+    if (!opts->nonzero_guess) FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)n * sizeof(double), s));
+    // r = b - A x
+    if (opts->nonzero_guess) {
+        FS_CHECK(fs_spmv_dev(M->fine, x->d.p, M->pw.p, s));
+        hipLaunchKernelGGL(k_amg_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, M->pw.p, M->pr.p);
+    } else {
+        FS_HIP(hipMemcpyAsync(M->pr.p, b->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    double ref2 = bb;   // reference for the relative test
+    if (pnorm) {
+        FS_CHECK(vcycle(M, 0, M->pz.p, b->d.p, s));
+        FS_CHECK(dot_host(M, M->pz.p, M->pz.p, n, &ref2, s));
+    }
+    const double thr2 = std::max(opts->rtol * opts->rtol * ref2, opts->atol * opts->atol);
+    double rho = 0.0, rho_old = 1.0, res2 = 0.0;
+    int it = 0, conv = 0;
+    const int max_iter = opts->max_iter > 0 ? opts->max_iter : 1000;
+    for (;; ++it) {
+        if (!pnorm) {
+            FS_CHECK(dot_host(M, M->pr.p, M->pr.p, n, &res2, s));
+            if (!(res2 == res2)) { conv = -1; break; }
+            if (res2 <= thr2) { conv = 1; break; }
+            if (it >= max_iter) break;
+        }
+        FS_CHECK(vcycle(M, 0, M->pz.p, M->pr.p, s));
+        FS_CHECK(dot_host(M, M->pr.p, M->pz.p, n, &rho, s));
+        if (pnorm) {
+            FS_CHECK(dot_host(M, M->pz.p, M->pz.p, n, &res2, s));
+            if (!(res2 == res2)) { conv = -1; break; }
+            if (res2 <= thr2) { conv = 1; break; }
+            if (it >= max_iter) break;
+        }
+        if (!(rho > 0.0)) { conv = -1; break; }
+        const double beta = it == 0 ? 0.0 : rho / rho_old;
+        hipLaunchKernelGGL(k_amg_axpby, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0, M->pz.p, beta, M->pp.p);   // p = z + beta p
+        FS_CHECK(fs_spmv_dev(M->fine, M->pp.p, M->pw.p, s));
+        double pw = 0.0;
+        FS_CHECK(dot_host(M, M->pp.p, M->pw.p, n, &pw, s));
+        if (!(pw > 0.0)) { conv = -1; break; }
+        const double alpha = rho / pw;
+        hipLaunchKernelGGL(k_amg_axpby, dim3(g), dim3(FS_BLOCK), 0, s, n, alpha, M->pp.p, 1.0, x->d.p);     // x += alpha p
+        hipLaunchKernelGGL(k_amg_axpby, dim3(g), dim3(FS_BLOCK), 0, s, n, -alpha, M->pw.p, 1.0, M->pr.p);   // r -= alpha w
+        rho_old = rho;
+    }
+    FS_KERNEL_CHECK();
+    // true residual
+    FS_CHECK(fs_spmv_dev(M->fine, x->d.p, M->pw.p, s));
+    hipLaunchKernelGGL(k_amg_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, M->pw.p, M->pw.p);
+    double tr2 = 0.0;
+    FS_CHECK(dot_host(M, M->pw.p, M->pw.p, n, &tr2, s));
+    stats->iterations = it;
+    stats->converged = conv;
+    stats->rel_residual = ref2 > 0.0 ? sqrt(res2 / ref2) : 0.0;
+    stats->true_rel_residual = bb > 0.0 ? sqrt(tr2 / bb) : 0.0;
+    stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats->spmv_bytes = sp->nnz_nodes * M->fine->bs * M->fine->bs * 12 + n * 20;
+    if (conv < 0) {
+        fs_set_error("fs_amg_solve: breakdown at iteration %d (rho %g, residual^2 %g)", it, rho, res2);
+        return FS_ERR_NUMERIC;
+    }
+    return FS_OK;
+}

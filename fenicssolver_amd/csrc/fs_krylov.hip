@@ -673,6 +673,11 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 #undef FS_SPMV_ARGS
 }
 
+int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
+    launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, s);
+    return FS_OK;
+}
+
 extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     FS_REQUIRE(A && x && y, "fs_spmv: null pointer");
     fs_space_s* sp = A->space;

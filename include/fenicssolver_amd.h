@@ -244,6 +244,37 @@ int fs_krylov_history(double* out, int capacity, int* count);
  * reps < 0: the CG flavour fused with the three dot products (y plays r). */
 int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch);
 
+/* ---- smoothed-aggregation AMG (PETScPreconditioner("petsc_amg") + set_near_nullspace,
+ *      SolverBase.py:643-672; Chebyshev/Jacobi level smoother as the PETScOptions there ask) ---- */
+
+typedef struct fs_amg_s* fs_amg_t;
+
+typedef struct fs_amg_opts {
+    double strength_threshold; /* theta of |A_ij|^2 > theta^2 |A_ii||A_jj|; 0 = every non-zero coupling (GAMG default) */
+    int max_levels;            /* 0 = 10 */
+    int coarse_size;           /* stop coarsening at this many dofs; 0 = 500 */
+    int smoother_steps;        /* Chebyshev steps per pre/post smoothing; 0 = 2 (PETSc mg_levels_ksp_max_it) */
+    int eig_steps;             /* power-iteration steps of the eigenvalue estimate; 0 = 30 */
+} fs_amg_opts;
+
+/* Build the hierarchy for the assembled (Dirichlet-eliminated, SPD) matrix.  nullspace: host array
+ * [n_nullspace][n_dofs] of near-null-space vectors (the rigid-body modes of build_nullspace(),
+ * SolverBase.py:674-706), or NULL = one constant per component.  The matrix must outlive the
+ * hierarchy and keep its values.  Single GPU. */
+int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullspace, const fs_amg_opts* opts, fs_amg_t* out);
+int fs_amg_destroy(fs_amg_t amg);
+int fs_amg_info(fs_amg_t amg, int* n_levels, double* operator_complexity, double* grid_complexity, double* setup_ms);
+int fs_amg_level_info(fs_amg_t amg, int level, int64_t* n_nodes, int* block_size, int64_t* nnz_blocks,
+                      int64_t* p_nnz_blocks, int* p_block_cols, double* lambda_max);
+/* which: 0 = level operator A (block CSR, blocks row-major), 1 = prolongator to this level from the
+ * next, 2 = near-null space [n_dofs][nb] (val only).  Test/inspection hook. */
+int fs_amg_level_get(fs_amg_t amg, int level, int which, int32_t* rowptr, int32_t* col, double* val);
+/* z = M r: one V-cycle from a zero guess (PCApply). */
+int fs_amg_apply(fs_amg_t amg, fs_vector_t r, fs_vector_t z);
+/* CG preconditioned by the V-cycle (PETScKrylovSolver("cg", pc).solve, SolverBase.py:660-670);
+ * uses rtol, atol, max_iter, nonzero_guess and norm_type of the options. */
+int fs_amg_solve(fs_amg_t amg, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats);
+
 /* ---- multi-GPU (MPI inside PETSc/DOLFIN under mpirun; SolverBase.py:102-118, 634) */
 
 #define FS_UNIQUE_ID_BYTES 128

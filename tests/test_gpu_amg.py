@@ -1,0 +1,188 @@
+"""Smoothed-aggregation AMG (fs_amg_*; the PETSc GAMG role of SolverBase.solve_amg, SolverBase.py:643-672).
+
+There is no reference arithmetic to pin an AMG hierarchy to (aggregation in GAMG is itself
+implementation-defined), so the hierarchy is held to the properties that define the method, with
+scipy as the checker:
+  * Galerkin:    A_{l+1} == P_l^T A_l P_l                       (the two row-wise SpGEMMs)
+  * near-null space: P_l B_{l+1} == B_l wherever A_l B_l == 0    (tentative QR + prolongator smoothing)
+  * the V-cycle is a symmetric positive definite operator        (CG may be used outside)
+  * the preconditioned solve returns the oracle's direct solution; iteration counts are mesh independent
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fem_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _poisson(gpu, n, seed=0, variable=True):
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), n, n, n)
+    rng = np.random.default_rng(seed)
+    kc = rng.uniform(0.5, 1.5, len(ce)) if variable else 1.0
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=("cell", kc) if variable else 1.0)
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, source=1.0)
+    bot, top = np.nonzero(co[:, 2] == 0)[0], np.nonzero(co[:, 2] == 1)[0]
+    dofs = np.concatenate([bot, top]).astype(np.int32)
+    vals = np.concatenate([np.full(len(bot), 1.0), np.full(len(top), 2.0)])
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    K = fo.assemble_p1_scalar(co, ce, kc)
+    rhs = fo.assemble_p1_source(co, ce, 1.0)
+    Ab, bb = fo.apply_dirichlet(K, rhs, dofs, vals, True)
+    return V, A, b, Ab.tocsr(), bb
+
+
+def _elasticity(gpu, dims=(12, 3, 3), clamp_components=None):
+    co, ce = fo.box_mesh((0, 0, 0), (4.0, 1.0, 1.0), *dims)
+    E, nu = 2e11, 0.27
+    mu, lam = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, ncomp=3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(mu, lam))
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, vector_value=[0.0, -7.8e4, 0.0])
+    left = np.nonzero(co[:, 0] == 0)[0]
+    comps = np.arange(3) if clamp_components is None else np.asarray(clamp_components)
+    dofs = (left[:, None] * 3 + comps).ravel().astype(np.int32)
+    if clamp_components is not None:       # pin the remaining rigid-body modes (y, z translation, x rotation)
+        xm = co[:, 0].max()
+        na = np.nonzero((co[:, 0] == xm) & (co[:, 1] == 0) & (co[:, 2] == 0))[0][0]
+        nb_ = np.nonzero((co[:, 0] == xm) & (co[:, 1] == 1) & (co[:, 2] == 0))[0][0]
+        extra = np.array([na * 3 + 1, na * 3 + 2, nb_ * 3 + 2], dtype=np.int32)
+        dofs = np.unique(np.concatenate([dofs, extra])).astype(np.int32)
+    vals = np.zeros(len(dofs))
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    K = fo.assemble_p1_elasticity(co, ce, E, nu)
+    rhs = fo.assemble_p1_vector_source(co, ce, (0.0, -7.8e4, 0.0))
+    Ab, bb = fo.apply_dirichlet(K, rhs, dofs, vals, True)
+    return V, A, b, Ab.tocsr(), bb, fo.rigid_body_modes(co)
+
+
+def _check_hierarchy(amg, A0, B0, nb):
+    info = amg.info()
+    assert info["levels"] >= 2
+    A = A0
+    B = B0
+    for l in range(info["levels"] - 1):
+        Al = amg.level_matrix(l, "A")
+        scale = abs(Al).max()
+        assert abs(Al - A).max() <= 1e-12 * scale, l          # level 0: the assembled matrix itself
+        P = amg.level_matrix(l, "P")
+        Ac = amg.level_matrix(l + 1, "A")
+        ref = (P.T @ Al @ P).tocsr()
+        # dead coarse dofs get a unit diagonal; everything else is the Galerkin product
+        d = abs(Ac - ref)
+        dead = np.asarray(abs(ref).sum(axis=1)).ravel() == 0
+        d = d.tolil()
+        for k in np.nonzero(dead)[0]:
+            assert Ac[k, k] == 1.0
+            d[k, k] = 0.0
+        assert d.tocsr().max() <= 1e-11 * abs(ref).max(), l
+        assert abs(Ac - Ac.T).max() <= 1e-11 * abs(Ac).max(), l
+        # near-null space carried to the next level
+        Bl = amg.level_nullspace(l, nb)
+        if l == 0:
+            ident = np.asarray(abs(Al - sp.diags(Al.diagonal())).sum(axis=1)).ravel() == 0
+            assert np.allclose(Bl[~ident], B[~ident], rtol=0, atol=1e-13 * np.abs(B).max())
+        Bc = amg.level_nullspace(l + 1, nb)
+        resid = Al @ Bl
+        interp = P @ Bc
+        li = amg.level_info(l)
+        bs = li["block_size"]
+        # rows whose whole node sees A B == 0 (interior, away from eliminated dofs) and that are aggregated
+        ident_rows = np.asarray(abs(Al - sp.diags(Al.diagonal())).sum(axis=1)).ravel() == 0
+        ok = (np.abs(resid) <= 1e-9 * (abs(Al) @ np.abs(Bl)) + 1e-300).all(axis=1) & ~ident_rows
+        ok_node = ok.reshape(-1, bs).all(axis=1)
+        nbr = (abs(Al) > 0).astype(np.int8)
+        node_of = np.repeat(np.arange(len(ok_node)), bs)
+        G = sp.csr_matrix((np.ones(nbr.nnz), (node_of[nbr.tocoo().row], node_of[nbr.tocoo().col])),
+                          shape=(len(ok_node), len(ok_node)))
+        all_nbrs_ok = np.asarray(G @ (~ok_node).astype(float)).ravel() == 0
+        rows = np.repeat(ok_node & all_nbrs_ok, bs)
+        assert rows.sum() > 0 or l > 0
+        if rows.any():
+            assert np.abs(interp[rows] - Bl[rows]).max() <= 1e-8 * np.abs(Bl).max(), l
+        A = Ac
+    return info
+
+
+def test_amg_poisson_hierarchy_and_solve(gpu):
+    V, A, b, Ab, bb = _poisson(gpu, 14)
+    amg = gpu.AMG(A, coarse_size=20)
+    info = _check_hierarchy(amg, Ab, np.ones((V.n_owned, 1)), 1)
+    assert info["levels"] >= 3 and info["operator_complexity"] < 2.0
+    x = gpu.DeviceVector(V.n_local)
+    st = amg.solve(b, x, rtol=1e-10)
+    ref = fo.solve_direct(Ab, bb)
+    assert st["converged"] == 1 and st["iterations"] <= 25
+    assert st["true_rel_residual"] <= 2e-10
+    assert np.abs(x.get()[:V.n_owned] - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_amg_vcycle_is_symmetric_positive_definite(gpu):
+    V, A, b, Ab, bb = _poisson(gpu, 5)
+    amg = gpu.AMG(A, coarse_size=20)
+    n = V.n_owned
+    M = np.empty((n, n))
+    r = gpu.DeviceVector(n)
+    z = gpu.DeviceVector(V.n_local)
+    e = np.zeros(n)
+    for i in range(n):
+        e[:] = 0.0
+        e[i] = 1.0
+        r.set(e)
+        amg.apply(r, z)
+        M[:, i] = z.get()[:n]
+    assert np.abs(M - M.T).max() <= 1e-10 * np.abs(M).max()
+    w = np.linalg.eigvalsh(0.5 * (M + M.T))
+    assert w.min() > 0
+    # spectrum of the preconditioned operator: clustered well away from 0
+    ev = np.linalg.eigvals(M @ Ab.toarray()).real
+    assert ev.min() > 0.3 and ev.max() < 1.6
+
+
+def test_amg_iterations_do_not_grow_with_the_mesh(gpu):
+    its = []
+    for n in (8, 16, 32):
+        V, A, b, Ab, bb = _poisson(gpu, n, variable=False)
+        amg = gpu.AMG(A)
+        x = gpu.DeviceVector(V.n_local)
+        st = amg.solve(b, x, rtol=1e-8)
+        assert st["converged"] == 1 and st["true_rel_residual"] <= 2e-8
+        its.append(st["iterations"])
+        xj = gpu.DeviceVector(V.n_local)
+        sj = gpu.krylov_solve(A, b, xj, rtol=1e-8, max_iter=5000)
+        assert np.abs(x.get() - xj.get()).max() <= 1e-6 * np.abs(xj.get()).max()
+    assert max(its) <= 20 and its[-1] <= its[0] + 6, its
+
+
+@pytest.mark.parametrize("clamp", [None, (0,)])
+def test_amg_elasticity_rigid_body_modes(gpu, clamp):
+    V, A, b, Ab, bb, rbm = _elasticity(gpu, clamp_components=clamp)
+    amg = gpu.AMG(A, nullspace=rbm, coarse_size=100)
+    info = _check_hierarchy(amg, Ab, rbm.T.copy(), 6)
+    assert amg.level_info(1)["block_size"] == 6
+    x = gpu.DeviceVector(V.n_local)
+    st = amg.solve(b, x, rtol=1e-10)
+    ref = fo.solve_direct(Ab, bb)
+    assert st["converged"] == 1 and st["iterations"] <= 40, st
+    assert np.abs(x.get()[:V.n_owned] - ref).max() <= 1e-7 * np.abs(ref).max()
+    # the same solve with Jacobi needs an order of magnitude more iterations
+    xj = gpu.DeviceVector(V.n_local)
+    sj = gpu.krylov_solve(A, b, xj, rtol=1e-10, max_iter=20000)
+    assert sj["iterations"] > 5 * st["iterations"]
+
+
+def test_amg_rejects_bad_input(gpu):
+    from fenicssolver_amd._lib import BackendError
+    V, A, b, Ab, bb = _poisson(gpu, 4)
+    with pytest.raises(ValueError):
+        gpu.AMG(A, nullspace=np.ones((1, 3)))
+    with pytest.raises(BackendError):
+        gpu.AMG(A, nullspace=np.ones((2, V.n_owned)))      # 2 vectors: not 1, 3 or 6
