@@ -475,8 +475,10 @@ class SolverBase():
             rtol = min(float(sp.get('relative_tolerance', KRYLOV_RTOL_CAP)), KRYLOV_RTOL_CAP)
         max_iter = int(sp.get('krylov_maximum_iterations', max(int(sp.get('maximum_iterations', 500)), 20000)))
         pc = sp.get('preconditioner', 'jacobi')
-        if pc in ('default', 'jacobi', 'petsc_amg', 'amg', 'hypre_amg', 'sor', 'ilu', 'icc'):
-            pc = 'jacobi'     # the only preconditioner built so far; AMG is SURVEY section 8(f) rank 3
+        if pc in ('petsc_amg', 'amg', 'hypre_amg'):
+            pc = 'amg'        # smoothed aggregation on the device (fs_amg_*)
+        elif pc in ('default', 'jacobi', 'sor', 'ilu', 'icc'):
+            pc = 'jacobi'     # point preconditioners other than Jacobi are not built
         elif pc in ('none', None):
             pc = 'none'
         else:
@@ -492,16 +494,31 @@ class SolverBase():
         return {'linear_solver': 'cg', 'preconditioner': pc, 'relative_tolerance': rtol,
                 'maximum_iterations': max_iter}
 
-    def _device_solve(self, A, b, u, label, method="cg"):
+    def _device_solve(self, A, b, u, label, method="cg", amg=False, near_nullspace=None):
+        """amg=True: the caller is solve_amg (AMG unless solver_parameters name another preconditioner)."""
         from . import backend
         rtol, max_iter, pc = self._krylov_options()
         V = u.function_space().device()
         x = backend.DeviceVector(V.n_owned)
         sp_ = self.solver_settings.get('solver_parameters', {}) or {}
+        if amg and 'preconditioner' not in sp_:
+            pc = 'amg'
+        if pc == 'amg' and (method != "cg" or u.function_space().localizer() is not None
+                            or u.function_space()._degree != 1):
+            self.logger.warning('%s: the AMG hierarchy is built for symmetric P1 problems on one GPU; using Jacobi', label)
+            pc = 'jacobi'
         # PETSc's KSPCG default: convergence on the preconditioned residual norm (SURVEY Appendix D-6); it is
         # also what keeps badly scaled operators (e.g. permittivities of 1e-10 next to identity rows) honest
-        norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc == "jacobi") else 'unpreconditioned')
-        stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method, norm=norm)
+        norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc in ("jacobi", "amg")) else 'unpreconditioned')
+        if pc == 'amg':
+            hierarchy = backend.AMG(A, nullspace=near_nullspace,
+                                    strength_threshold=float(sp_.get('amg_strength_threshold', 0.0)))
+            stats = hierarchy.solve(b, x, rtol=rtol, max_iter=min(max_iter, int(sp_.get('maximum_iterations', 500))),
+                                    norm=norm)
+            stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
+            hierarchy.close()
+        else:
+            stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method, norm=norm)
         self.last_solve_stats = stats
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         if sp.get('monitor_convergence'):
@@ -690,15 +707,17 @@ class SolverBase():
         return u_current
 
     def solve_amg(self, F, u, bcs):
-        """assemble_system + CG (SolverBase.py:643-672).  The reference preconditions with PETSc's
-        smoothed-aggregation AMG; this revision uses Jacobi (more iterations, same solution)."""
+        """assemble_system + CG preconditioned by smoothed-aggregation AMG with the rigid-body near-null
+        space (SolverBase.py:643-672); solver_parameters['preconditioner'] = 'jacobi' selects Jacobi-CG."""
         if isinstance(F, forms.ElasticityForm) and F.body_force is None and not F.tractions \
                 and F.thermal is None and not any(np.any(bc.values != 0) for bc in bcs):
             # empty right-hand side: the reference fails in assemble_system here (Appendix B-Q11)
             self.logger.warning('solve_amg: zero load and homogeneous BCs, the solution is zero')
         A, b = self.assemble_system(F, bcs, symmetric=True)
-        self._near_nullspace = self.build_nullspace(self.function_space, u.vector())
-        return self._device_solve(A, b, u, 'solve_amg')
+        ns = None
+        if isinstance(F, forms.ElasticityForm):
+            self._near_nullspace = ns = self.build_nullspace(self.function_space, u.vector())
+        return self._device_solve(A, b, u, 'solve_amg', amg=True, near_nullspace=ns)
 
     def build_nullspace(self, V, x=None):
         """The rigid-body modes of SolverBase.py:674-706 (3 in 2D, 6 in 3D), orthonormalised."""

@@ -250,7 +250,8 @@ int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, dou
 typedef struct fs_amg_s* fs_amg_t;
 
 typedef struct fs_amg_opts {
-    double strength_threshold; /* theta of |A_ij|^2 > theta^2 |A_ii||A_jj|; 0 = every non-zero coupling (GAMG default) */
+    double strength_threshold; /* theta of |A_ij|^2 > theta^2 |A_ii||A_jj| (block Frobenius norms); 0 = 0.05,
+                                * negative = every coupling above rounding noise (1e-8) */
     int max_levels;            /* 0 = 10 */
     int coarse_size;           /* stop coarsening at this many dofs; 0 = 500 */
     int smoother_steps;        /* Chebyshev steps per pre/post smoothing; 0 = 2 (PETSc mg_levels_ksp_max_it) */

@@ -186,3 +186,36 @@ def test_amg_rejects_bad_input(gpu):
         gpu.AMG(A, nullspace=np.ones((1, 3)))
     with pytest.raises(BackendError):
         gpu.AMG(A, nullspace=np.ones((2, V.n_owned)))      # 2 vectors: not 1, 3 or 6
+
+
+def test_solve_amg_is_the_default_of_the_elasticity_solver(gpu):
+    """LinearElasticitySolver.solve_form -> solve_amg in 3D (LinearElasticitySolver.py:247-253): AMG with the
+    rigid-body modes of build_nullspace unless solver_parameters name another preconditioner."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 40, 4, 4)
+
+    def make(**params):
+        bcs = OrderedDict()
+        bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
+                        'value': Constant((0, 0, 0))}
+        bcs["tip"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
+                      'value': Constant((0, 0, 1e6))}
+        s = copy.deepcopy(SB.default_case_settings)
+        s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800}
+        s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+        s['boundary_conditions'] = bcs
+        s['solver_settings']['solver_parameters'] = dict({'krylov_relative_tolerance': 1e-10}, **params)
+        s['report_settings'] = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+        return LinearElasticitySolver(s)
+
+    a = make()
+    ua = a.solve().vector().array()
+    assert a.last_solve_stats['amg_levels'] >= 2 and a.last_solve_stats['iterations'] <= 60
+    j = make(preconditioner='jacobi')
+    uj = j.solve().vector().array()
+    assert 'amg_levels' not in j.last_solve_stats and j.last_solve_stats['iterations'] > 200
+    assert np.abs(ua - uj).max() <= 1e-6 * np.abs(uj).max()

@@ -97,7 +97,7 @@ def _capture_system(monkeypatch, make, rank=None, world=1):
     from fenicssolver_amd import parallel, backend, SolverBase as SB
     got = {}
 
-    def fake_solve(self, A, b, u, label, method="cg"):
+    def fake_solve(self, A, b, u, label, method="cg", **kwargs):
         rp, ci, va, shape = A.to_csr()
         got.update(A=sp.csr_matrix((va, ci, rp), shape=shape), b=b.get(), loc=u.function_space().localizer(),
                    ncomp=u.function_space()._ncomp)
