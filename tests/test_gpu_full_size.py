@@ -95,6 +95,22 @@ def test_config3_elasticity_cantilever_5m_dof(gpu):
     assert abs(tip - beam) <= 0.01 * abs(beam)
     assert np.abs(u[left]).max() == 0.0                     # clamped face
     assert abs(u[:, 1].mean()) <= 1e-3 * abs(tip)           # no net sideways motion (the Kuhn split is not mirror-symmetric)
+    # the solve_amg path (SolverBase.py:643-672): same system, smoothed-aggregation AMG with the six rigid-body modes
+    xyz = mesh.get(True, False, False)[0]
+    ns = np.zeros((6, len(xyz), 3))
+    ns[0, :, 0] = ns[1, :, 1] = ns[2, :, 2] = 1.0
+    ns[3, :, 0], ns[3, :, 1] = -xyz[:, 1], xyz[:, 0]
+    ns[4, :, 0], ns[4, :, 2] = xyz[:, 2], -xyz[:, 0]
+    ns[5, :, 2], ns[5, :, 1] = xyz[:, 1], -xyz[:, 2]
+    amg = gpu.AMG(A, nullspace=ns.reshape(6, -1))
+    xa = gpu.DeviceVector(V.n_owned)
+    sa = amg.solve(b, xa, rtol=1e-8)
+    assert sa["converged"] == 1 and sa["iterations"] <= 60 and sa["true_rel_residual"] <= 4e-8
+    assert sa["iterations"] * 50 < st["iterations"]          # two orders of magnitude fewer iterations than Jacobi-CG
+    ua = xa.get().reshape(-1, 3)
+    assert np.abs(ua - u).max() <= 2e-5 * np.abs(u).max()    # both solved to 1e-8 of a 1e9-conditioned system
+    info = amg.info()
+    assert info["levels"] >= 4 and info["operator_complexity"] < 1.8
 
 
 def test_config4_p2_poisson_10m_dof_single_gpu(gpu):

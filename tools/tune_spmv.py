@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fenicssolver_amd import backend as B
 B.init(0)
