@@ -1,0 +1,200 @@
+"""Drop-in counterpart of FenicsSolver/CoupledNavierStokesSolver.py (incompressible, laminar, Taylor-Hood),
+MI355X back end: the coupled velocity-pressure system is assembled and solved on the device
+(fs_assemble_navier_stokes / fs_saddle_solve) instead of DOLFIN + PETSc LU.
+
+Same settings dict as the reference: ``fe_degree`` = pressure degree (velocity is one
+higher, CoupledNavierStokesSolver.py:84-88), ``material`` with ``density`` and ``kinematic_viscosity``,
+``boundary_conditions`` whose ``values`` are a list/dict of {'variable': 'velocity'|'pressure', 'type': ..., 'value': ...},
+``initial_values`` {'velocity': (..), 'pressure': ..}, ``body_source`` (acceleration, e.g. gravity), transient_settings
+(backward Euler, :367-381).  ``solver.using_nonlinear_solver`` (default True) selects Newton, False the Picard loop
+with under-relaxation 0.7 of :492-528.
+
+Built: velocity Dirichlet conditions (constants, tuples, C-string Expressions, per-time-step lists are not),
+body force, steady and backward-Euler transient, Newton and Picard.  Raise: pressure / symmetry / farfield
+boundary types (their natural boundary integrals are not built yet), G2 stabilisation, ALE reference frames,
+non-Newtonian viscosity, the coupled temperature equation.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+
+from .SolverBase import SolverBase, SolverError
+from .fem import Function, Constant, Expression, DirichletBC
+from .mixed import TaylorHoodSpace, split
+from . import forms
+
+
+class CoupledNavierStokesSolver(SolverBase):
+    """incompressible and laminar flow (the reference's G2 stabilisation is not built)"""
+
+    def __init__(self, case_input):
+        self.solving_temperature = bool(case_input.get('solving_temperature', False)) if isinstance(case_input, dict) else False
+        if self.solving_temperature:
+            raise SolverError("solving_temperature (coupled energy equation) is not built; the reference marks it 'test not passed'")
+        SolverBase.__init__(self, case_input)
+        self.compressible = False
+        self.using_nonlinear_solver = True
+        self.settings['mixed_variable'] = ('velocity', 'pressure')
+
+    # ------------------------------------------------------------------ space
+    def generate_function_space(self, periodic_boundary):
+        self.vel_degree = self.settings['fe_degree'] + 1
+        self.pressure_degree = self.settings['fe_degree']
+        self.is_mixed_function_space = True
+        self._update_function_space(periodic_boundary)
+
+    def _update_function_space(self, periodic_boundary=None):
+        self.function_space = TaylorHoodSpace(self.mesh, self.settings['fe_family'], self.pressure_degree,
+                                              constrained_domain=periodic_boundary)
+        self.velocity_subfunction_space = self.function_space.sub(0)
+
+    def get_variable_name(self):
+        return "velocity_pressure"
+
+    # ------------------------------------------------------------------ values
+    def get_body_source(self):
+        """(CoupledNavierStokesSolver.py:114-123) default gravity along -z in 3D."""
+        bs = self.settings.get('body_source')
+        if bs:
+            return self._vector3(bs, 'body_source')
+        return np.array([0.0, 0.0, -9.8])
+
+    @staticmethod
+    def _vector3(value, what):
+        if isinstance(value, Constant):
+            value = value.values()
+        if isinstance(value, (tuple, list, np.ndarray)) and len(value) == 3 and \
+                all(isinstance(x, numbers.Number) for x in value):
+            return np.asarray(value, dtype=np.float64)
+        raise SolverError("{} must be 3 numbers (a Constant or a tuple) on this back end".format(what))
+
+    def get_initial_field(self):
+        W = self.function_space
+        iv = self.initial_values
+        up0 = Function(W)
+        if isinstance(iv, Function):
+            if iv.vector().size() != up0.vector().size():
+                raise SolverError("initial_values Function lives on a different space")
+            up0.assign(iv)
+            return up0
+        a = up0.vector().array().reshape(-1, 4)
+        vel = iv.get('velocity', (0.0, 0.0, 0.0)) if isinstance(iv, dict) else (0.0, 0.0, 0.0)
+        pre = iv.get('pressure', 0.0) if isinstance(iv, dict) else 0.0
+        co = W.node_coordinates()
+        expr = Expression(tuple(str(v) for v in list(vel) + [pre]), degree=self.settings['fe_degree'])
+        vals = expr.eval_points(co)
+        a[:, :3] = vals[:, :3]
+        a[:self.mesh.num_vertices(), 3] = vals[:self.mesh.num_vertices(), 3]
+        return up0
+
+    def viscosity(self, current_w=None):
+        if 'Newtonian' in self.material and (not self.material['Newtonian']):
+            raise SolverError("non-Newtonian viscosity is not built")
+        nu = self.material['kinematic_viscosity']
+        if isinstance(nu, Constant):
+            nu = float(nu)
+        if not isinstance(nu, numbers.Number):
+            raise SolverError("kinematic_viscosity must be a number on this back end")
+        return float(nu)
+
+    # ------------------------------------------------------------------ form
+    def generate_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
+        F = forms.NavierStokesForm(self.function_space)
+        F.nu = self.viscosity()
+        F.rho = float(self.material['density'])
+        F.w_current = up_current
+        F.w_prev = up_prev
+        F.newton = bool(self.using_nonlinear_solver)
+        if self.settings.get('body_source'):          # "just gravity, without * rho" (:315-316)
+            F.body_force = self.get_body_source()
+        if 'reference_frame_settings' in self.settings:
+            raise SolverError("reference_frame_settings (ALE) is not built")
+        ads = self.settings.get('advection_settings') or {}
+        if ads.get('stabilization_method'):
+            raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
+        if self.transient_settings['transient']:
+            F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:367-381)
+        bcs = self.update_boundary_conditions(time_iter_, trial_function, test_function, None)
+        self.J = F if self.using_nonlinear_solver else None
+        return F, bcs
+
+    def update_boundary_conditions(self, time_iter_, trial_function, test_function, ds):
+        W = self.function_space
+        bcs = []
+        for key, boundary in self.boundary_conditions.items():
+            if boundary.get('coupling') == 'FSI' and 'values' not in boundary:
+                boundary['values'] = [{'variable': "velocity", 'type': 'Dirichlet', 'value': self.dimension * (0.0,)}]
+            values = boundary.get('values')
+            if values is None:
+                raise SolverError("boundary '{}' has no 'values'".format(key))
+            bc_values = values if isinstance(values, list) else list(values.values())
+            for bc in bc_values:
+                var, typ = bc.get('variable'), bc.get('type')
+                if var == 'velocity':
+                    if typ == 'Dirichlet':
+                        value = bc['value']
+                        if isinstance(value, list):
+                            raise SolverError("per-time-step lists of velocity values are not built")
+                        if isinstance(value, (tuple, np.ndarray)):
+                            value = Constant(tuple(float(x) for x in value))
+                        bcs.append(DirichletBC(W.sub(0), value, self.boundary_facets, boundary['boundary_id']))
+                    else:
+                        raise SolverError("velocity boundary type `{}` is not built (Dirichlet only)".format(typ))
+                elif var == 'pressure':
+                    raise SolverError("pressure boundary conditions are not built yet: their boundary integrals "
+                                      "(p n.v and the viscous traction term, CoupledNavierStokesSolver.py:449-453) are missing")
+                elif var == 'temperature':
+                    continue      # "boundary setup is done in scalar transport for incompressible flow" (:483)
+                else:
+                    raise SolverError("boundary variable `{}` is not supported".format(var))
+        return bcs
+
+    def solve_form(self, F, up_, Dirichlet_bcs_up):
+        if self.using_nonlinear_solver:
+            return self.solve_nonlinear_problem(F, up_, Dirichlet_bcs_up, self.J)
+        # Picard iteration with under-relaxation (:497-528)
+        F.newton = False
+        iter_, max_iter, eps, tol, under_relax_ratio = 0, 50, 1.0, 1e-4, 0.7
+        while iter_ < max_iter and eps > tol:
+            old = up_.vector().get_local()
+            up_ = self.solve_linear_problem(F, up_, Dirichlet_bcs_up)
+            diff = up_.vector().get_local() - old
+            eps = float(np.linalg.norm(diff, ord=np.inf))
+            self.logger.info("iter = %d; eps_up = %e", iter_, eps)
+            up_.vector().set_local(old + diff * under_relax_ratio)
+            iter_ += 1
+        self.picard_iterations = iter_
+        return up_
+
+    def save(self, result_filename):
+        """PVD collection; each frame is a VTU with the velocity (vertex values) and the pressure."""
+        import os
+        from .SolverBase import write_vtu
+        assert result_filename[-4:] == '.pvd'
+        root = result_filename[:-4]
+        if not hasattr(self, '_saved_frames'):
+            self._saved_frames = []
+        u, p = split(self.w_current)
+        vtu = "%s%06d.vtu" % (root, len(self._saved_frames))
+        write_vtu(vtu, self.mesh, u, "velocity", extra=[(p, "pressure")])
+        self._saved_frames.append((getattr(self, 'current_time', 0.0), os.path.basename(vtu)))
+        with open(result_filename, "w") as fh:
+            fh.write('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n  <Collection>\n')
+            for t, f in self._saved_frames:
+                fh.write('    <DataSet timestep="%g" part="0" file="%s" />\n' % (t, f))
+            fh.write('  </Collection>\n</VTKFile>\n')
+
+    def plot(self):
+        self.logger.info("plot(): use save() and ParaView for velocity-pressure fields")
+
+    # ------------------------------------------------------------------ post-processing
+    def split(self, w=None):
+        return split(w if w is not None else self.w_current)
+
+    def viscous_stress(self, up, T_space=None):
+        raise SolverError("viscous_stress / boundary_traction / calc_drag_and_lift are not built on this back end")
+
+    boundary_traction = viscous_stress
+    calc_drag_and_lift = viscous_stress

@@ -631,6 +631,8 @@ class SolverBase():
         """LinearVariationalSolver.solve() on the GPU (SolverBase.py:592-613)."""
         if 'point_source' in self.settings and self.settings['point_source']:
             raise SolverError('point_source is not supported by the GPU back end yet')
+        if isinstance(F, forms.NavierStokesForm):
+            return self._navier_stokes_linear(F, u, Dirichlet_bcs)
         A, b = self.assemble_system(F, Dirichlet_bcs, symmetric=True)
         # advection makes the operator non-symmetric: BiCGStab (PETSc KSPBCGS) instead of CG
         method = "cg" if getattr(F, "symmetric", True) else "bicgstab"
@@ -644,8 +646,10 @@ class SolverBase():
         re-evaluated each iteration and its derivative left out of the Jacobian (quasi-Newton), as the
         reference's own remark at ScalarTransportSolver.py:281-283 does."""
         from . import backend
+        if isinstance(F, forms.NavierStokesForm):
+            return self._navier_stokes_newton(F, u_current, Dirichlet_bcs)
         if not isinstance(F, forms.ScalarForm):
-            raise SolverError('nonlinear solves are built for scalar transport only')
+            raise SolverError('nonlinear solves are built for scalar transport and Navier-Stokes only')
         if F.space.device() is not None and F.space.localizer() is not None:
             raise SolverError('nonlinear solves are single-GPU for now')
         sp = self.solver_settings.get('solver_parameters', {}) or {}
@@ -706,6 +710,123 @@ class SolverBase():
         u_current.vector().set_local(T)
         return u_current
 
+    # ---- Taylor-Hood Navier-Stokes (CoupledNavierStokesSolver) -----------------------------------------
+    def _navier_stokes_context(self, F, bcs):
+        """Device objects shared by the steps of one solve: mixed space, pressure operators, BC lists."""
+        from . import backend
+        W = F.space
+        V = W.device()
+        if W.localizer() is not None:
+            raise SolverError('the Navier-Stokes path is single-GPU for now')
+        dofs, vals = self._bc_arrays(bcs)
+        pre = dofs[(dofs % 4) == 3] if dofs.size else dofs
+        ctx = getattr(self, '_ns_ctx', None)
+        key = (id(V), tuple(np.sort(pre).tolist()))
+        if ctx is None or ctx['key'] != key:
+            Q = W.pressure_space().device()
+            pinned = (pre // 4).astype(np.int32)
+            if pinned.size == 0:
+                # no pressure condition: the pressure is defined up to a constant (the reference's LU hits a
+                # singular matrix here); fix it at vertex 0
+                self.logger.warning('no pressure boundary condition: pinning the pressure at vertex 0 to 0')
+                pinned = np.zeros(1, dtype=np.int32)
+            Kp = backend.DeviceMatrix(Q)
+            Kp.assemble(stiffness=1.0)
+            Kp.apply_dirichlet(None, pinned, np.zeros(len(pinned)), symmetric=True)
+            Mp = backend.DeviceMatrix(Q)
+            Mp.assemble(mass=1.0)
+            ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
+                   'auto_pin': pre.size == 0}
+            self._ns_ctx = ctx
+        if ctx['auto_pin']:
+            dofs = np.concatenate([dofs, np.array([3], dtype=np.int32)]).astype(np.int32)
+            vals = np.concatenate([vals, np.zeros(1)])
+        # "later wins" de-duplication happens on the device; dummy pressure slots stay at zero
+        return V, ctx, dofs.astype(np.int32), vals
+
+    def _navier_stokes_assemble(self, F, V, ctx, w, newton):
+        from . import backend
+        dw = backend.DeviceVector(V.n_local, w)
+        dp = backend.DeviceVector(V.n_local, F.w_prev.vector().array()) if F.inv_dt else None
+        g = backend.DeviceVector(V.n_owned)
+        backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
+                                       body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
+                                       convection=True, newton=newton)
+        return dw, g
+
+    def _navier_stokes_krylov(self, F, ctx, J, b, x, rtol, nonzero_guess):
+        from . import backend
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        st = backend.saddle_solve(J, ctx['Kp'] if F.inv_dt else None, ctx['Mp'], b, x, nu=F.nu, rho=F.rho,
+                                  inv_dt=F.inv_dt, rtol=rtol, max_iter=int(sp.get('krylov_maximum_iterations', 2000)),
+                                  restart=int(sp.get('gmres_restart', 0)),
+                                  velocity_sweeps=int(sp.get('velocity_sweeps', 0 if F.inv_dt else 3)),
+                                  nonzero_guess=nonzero_guess)
+        self.last_solve_stats = st
+        if st['converged'] != 1:
+            raise SolverError('Navier-Stokes: FGMRES did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
+                st['iterations'], st['rel_residual']))
+        return st
+
+    def _navier_stokes_newton(self, F, u_current, bcs):
+        """NonlinearVariationalSolver.solve() for the coupled system: DOLFIN NewtonSolver defaults (relative 1e-9 /
+        absolute 1e-10 on the residual 2-norm, 50 iterations, relaxation 1); each step solves J dw = -R on the GPU."""
+        from . import backend
+        V, ctx, dofs, vals = self._navier_stokes_context(F, bcs)
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        ns = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
+        rtol = float(ns.get('relative_tolerance', 1e-9))
+        atol = float(ns.get('absolute_tolerance', 1e-10))
+        max_it = int(ns.get('maximum_iterations', 50))
+        relax = float(ns.get('relaxation_parameter', 1.0))
+        lin_rtol = float(sp.get('krylov_relative_tolerance', 1e-6))
+        w = u_current.vector().get_local()
+        w[dofs] = vals
+        w[F.space.dummy_dofs()] = 0.0
+        history, krylov = [], 0
+        for it in range(max_it + 1):
+            dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=True)
+            r = backend.DeviceVector(V.n_owned)
+            ctx['J'].spmv(dw, r)
+            r.axpy(-1.0, g)                                   # R(w) = J w - g
+            res = r.get()
+            res[dofs] = 0.0
+            rn = float(np.linalg.norm(res))
+            history.append(rn)
+            self.logger.info("Newton iteration %d: r (abs) = %.3e (tol = %.3e) r (rel) = %.3e (tol = %.3e)", it, rn, atol,
+                             rn / max(history[0], 1e-300), rtol)
+            if rn <= atol or rn <= rtol * history[0]:
+                break
+            if it == max_it:
+                raise SolverError('Newton solver did not converge in {} iterations: {}'.format(max_it, history))
+            rhs = backend.DeviceVector(V.n_owned, -res)
+            ctx['J'].apply_dirichlet(rhs, dofs, np.zeros(len(dofs)), symmetric=False)
+            x = backend.DeviceVector(V.n_local)
+            st = self._navier_stokes_krylov(F, ctx, ctx['J'], rhs, x, lin_rtol, False)
+            krylov += st['iterations']
+            w = w + relax * x.get()
+        self.newton_history = history
+        self.newton_krylov_iterations = krylov
+        u_current.vector().set_local(w)
+        return u_current
+
+    def _navier_stokes_linear(self, F, u, bcs):
+        """One Picard step: LinearVariationalSolver on lhs(F) == rhs(F) with the advecting velocity frozen."""
+        from . import backend
+        V, ctx, dofs, vals = self._navier_stokes_context(F, bcs)
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        w = F.w_current.vector().get_local()
+        dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=False)
+        ctx['J'].apply_dirichlet(g, dofs, vals, symmetric=False)
+        w0 = w.copy()
+        w0[dofs] = vals
+        x = backend.DeviceVector(V.n_local, w0)
+        self._navier_stokes_krylov(F, ctx, ctx['J'], g, x, float(sp.get('krylov_relative_tolerance', 1e-8)), True)
+        out = x.get()
+        out[F.space.dummy_dofs()] = 0.0
+        u.vector().set_local(out)
+        return u
+
     def solve_amg(self, F, u, bcs):
         """assemble_system + CG preconditioned by smoothed-aggregation AMG with the rigid-body near-null
         space (SolverBase.py:643-672); solver_parameters['preconditioner'] = 'jacobi' selects Jacobi-CG."""
@@ -737,8 +858,8 @@ class SolverBase():
         return q.T.copy()
 
 
-def write_vtu(path, mesh, function, name):
-    """ASCII VTK unstructured grid of a P1 function on a tet mesh."""
+def write_vtu(path, mesh, function, name, extra=()):
+    """ASCII VTK unstructured grid of a nodal function on a tet mesh (vertex values); extra: [(Function, name)]."""
     co, ce = mesh.coordinates(), mesh.cells()
     vals = function.vertex_values()
     ncomp = 1 if vals.ndim == 1 else vals.shape[1]
@@ -757,4 +878,11 @@ def write_vtu(path, mesh, function, name):
         fh.write('<PointData %s="%s">\n' % ("Scalars" if ncomp == 1 else "Vectors", name))
         fh.write('<DataArray type="Float64" Name="%s" NumberOfComponents="%d" format="ascii">\n' % (name, ncomp))
         np.savetxt(fh, vals.reshape(len(co), -1), fmt="%.16e")
-        fh.write('</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')
+        fh.write('</DataArray>\n')
+        for f2, n2 in extra:
+            v2 = f2.vertex_values()
+            fh.write('<DataArray type="Float64" Name="%s" NumberOfComponents="%d" format="ascii">\n' % (
+                n2, 1 if v2.ndim == 1 else v2.shape[1]))
+            np.savetxt(fh, v2.reshape(len(co), -1), fmt="%.16e")
+            fh.write('</DataArray>\n')
+        fh.write('</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')

@@ -58,6 +58,17 @@ class fs_krylov_stats(C.Structure):
                 ("spmv_ms", C.c_double), ("update_ms", C.c_double), ("spmv_bytes", c_i64)]
 
 
+class fs_ns_form(C.Structure):
+    _fields_ = [("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
+                ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int)]
+
+
+class fs_saddle_opts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_iter", C.c_int), ("restart", C.c_int),
+                ("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
+                ("velocity_sweeps", C.c_int), ("inner_rtol", C.c_double), ("nonzero_guess", C.c_int)]
+
+
 class fs_amg_opts(C.Structure):
     _fields_ = [("strength_threshold", C.c_double), ("max_levels", C.c_int), ("coarse_size", C.c_int),
                 ("smoother_steps", C.c_int), ("eig_steps", C.c_int)]
@@ -113,6 +124,8 @@ SIGNATURES = {
     "fs_amg_level_get": (C.c_int, [_H, C.c_int, C.c_int, c_i32p, c_i32p, c_f64p]),
     "fs_amg_apply": (C.c_int, [_H, _H, _H]),
     "fs_amg_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
+    "fs_assemble_navier_stokes": (C.c_int, [_H, _H, _H, _H, C.POINTER(fs_ns_form)]),
+    "fs_saddle_solve": (C.c_int, [_H, _H, _H, _H, _H, C.POINTER(fs_saddle_opts), C.POINTER(fs_krylov_stats)]),
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

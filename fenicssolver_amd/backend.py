@@ -381,6 +381,32 @@ class AMG(_Handle):
         return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 
 
+def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, body_force=(0.0, 0.0, 0.0),
+                           convection=True, newton=True):
+    """Linearised Taylor-Hood system at the state w0 (J w_new = g), J on a DeviceSpace(mesh, ncomp=4, degree=2)."""
+    f = L.fs_ns_form()
+    f.kinematic_viscosity, f.density, f.inv_dt = float(nu), float(rho), float(inv_dt)
+    for i in range(3):
+        f.body_force[i] = float(body_force[i])
+    f.convection, f.newton = (1 if convection else 0), (1 if newton else 0)
+    L.check(L.load().fs_assemble_navier_stokes(J.h, g.h, w0.h if w0 is not None else None,
+                                               w_prev.h if w_prev is not None else None, C.byref(f)),
+            "fs_assemble_navier_stokes")
+
+
+def saddle_solve(J, Kp, Mp, b, x, nu, rho=1.0, inv_dt=0.0, rtol=1e-8, atol=0.0, max_iter=0, restart=0,
+                 velocity_sweeps=0, inner_rtol=0.0, nonzero_guess=False):
+    """FGMRES with the block-triangular Cahouet-Chabard preconditioner; Kp may be None for steady problems."""
+    o = L.fs_saddle_opts()
+    o.rtol, o.atol, o.max_iter, o.restart = float(rtol), float(atol), int(max_iter), int(restart)
+    o.kinematic_viscosity, o.density, o.inv_dt = float(nu), float(rho), float(inv_dt)
+    o.velocity_sweeps, o.inner_rtol, o.nonzero_guess = int(velocity_sweeps), float(inner_rtol), 1 if nonzero_guess else 0
+    st = L.fs_krylov_stats()
+    L.check(L.load().fs_saddle_solve(J.h, Kp.h if Kp is not None else None, Mp.h, b.h, x.h, C.byref(o), C.byref(st)),
+            "fs_saddle_solve")
+    return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
+
+
 def krylov_history():
     n = C.c_int(0)
     L.load().fs_krylov_history(None, 0, C.byref(n))

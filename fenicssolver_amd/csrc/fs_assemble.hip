@@ -682,8 +682,10 @@ extern "C" int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx
     if (vals) FS_CHECK(d_v.alloc(nnz));
     if (bs == 1)
         hipLaunchKernelGGL(k_export_csr<1>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
-    else
+    else if (bs == 3)
         hipLaunchKernelGGL(k_export_csr<3>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
+    else
+        hipLaunchKernelGGL(k_export_csr<4>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
     FS_KERNEL_CHECK();
     if (rowptr) FS_CHECK(d_rp.download(rowptr, n_rows * bs + 1, s));
     if (colidx) FS_CHECK(d_ci.download(colidx, nnz, s));
@@ -893,8 +895,10 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
     double* bp = b ? b->d.p : nullptr;
     if (A->bs == 1)
         hipLaunchKernelGGL(k_dirichlet_sell<1>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
-    else
+    else if (A->bs == 3)
         hipLaunchKernelGGL(k_dirichlet_sell<3>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+    else
+        hipLaunchKernelGGL(k_dirichlet_sell<4>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -667,8 +667,10 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             case 16: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16>), FS_SPMV_ARGS); break;
             default: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS); break;
         }
-    } else {
+    } else if (A->bs == 3) {
         hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
+    } else {
+        hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 4>), FS_SPMV_ARGS);
     }
 #undef FS_SPMV_ARGS
 }
@@ -784,6 +786,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         return FS_ERR_UNSUPPORTED;
     }
     const bool bicg = opts->method == FS_KSP_BICGSTAB;
+    FS_REQUIRE(A->bs != 4, "fs_krylov_solve: Taylor-Hood block systems are solved by fs_saddle_solve");
     FS_REQUIRE(opts->precond == FS_PC_NONE || opts->precond == FS_PC_JACOBI, "fs_krylov_solve: unknown preconditioner %d", opts->precond);
     FS_REQUIRE(opts->max_iter > 0 && opts->rtol >= 0.0 && opts->atol >= 0.0, "fs_krylov_solve: bad tolerances");
     fs_space_s* sp = A->space;

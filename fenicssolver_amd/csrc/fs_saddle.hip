@@ -1,0 +1,518 @@
+// Taylor-Hood Navier-Stokes for libfsamd.so (gfx950): assembly of the linearised coupled system and its
+// Krylov solve.  Replaces what CoupledNavierStokesSolver hands to DOLFIN/PETSc
+// (FenicsSolver/CoupledNavierStokesSolver.py:288-381 forms, :215-245 action/derivative, :492-528 solve,
+// SolverBase.py:615-626 NonlinearVariationalSolver):
+//   J(w0) w = g(w0)   with   J = 2 nu eps(u):eps(v) + (1/dt) u.v + (grad(u) u0).v [+ (grad(u0) u).v]
+//                                 - (p/rho) div v + (q/rho) div u
+//                            g = f.v + (1/dt) u_prev.v [+ (grad(u0) u0).v]
+// (the Newton step written for the new iterate, so Dirichlet values are applied directly).
+//
+// Layout: one block of 4 unknowns per P2 node (u_x, u_y, u_z, p), the matrix is a bs = 4 matrix on the CG2
+// node pattern (hybrid SELL/DIA like every other operator, so the tuned SpMV applies).  The pressure is P1:
+// only vertex nodes carry a pressure; the pressure slot of an edge node is a dummy unknown with a unit row.
+//
+// Assembly: one thread per (cell, test node a, trial node b): 14-point degree-5 rule (exact for the
+// P2*P2*P1 convection integrand), the 4x4 block accumulated in registers, fp64 hardware atomics into the
+// 16 value planes through the slot table.  Solve: restarted FGMRES, right preconditioner
+//   [A 0; D S]^-1  with  A^-1 ~ Jacobi sweeps,  S^-1 ~ rho^2 ( (1/dt) K_p^-1 + nu M_p^-1 )  (Cahouet-Chabard),
+// K_p, M_p = P1 pressure Laplacian / mass matrix solved by the library's own CG.
+#include "fs_kernels.h"
+#include <chrono>
+#include <stdlib.h>
+#include <cmath>
+#include <vector>
+
+// barycentric points / weights (sum 1) of the 14-point degree-5 rule
+__device__ const double NS_QP[14][4] = {
+    {0.0673422422100982, 0.3108859192633006, 0.3108859192633006, 0.3108859192633006},
+    {0.3108859192633006, 0.0673422422100982, 0.3108859192633006, 0.3108859192633006},
+    {0.3108859192633006, 0.3108859192633006, 0.0673422422100982, 0.3108859192633006},
+    {0.3108859192633006, 0.3108859192633006, 0.3108859192633006, 0.0673422422100982},
+    {0.7217942490673264, 0.0927352503108912, 0.0927352503108912, 0.0927352503108912},
+    {0.0927352503108912, 0.7217942490673264, 0.0927352503108912, 0.0927352503108912},
+    {0.0927352503108912, 0.0927352503108912, 0.7217942490673264, 0.0927352503108912},
+    {0.0927352503108912, 0.0927352503108912, 0.0927352503108912, 0.7217942490673264},
+    {0.0455037041256496, 0.0455037041256496, 0.4544962958743504, 0.4544962958743504},
+    {0.0455037041256496, 0.4544962958743504, 0.0455037041256496, 0.4544962958743504},
+    {0.0455037041256496, 0.4544962958743504, 0.4544962958743504, 0.0455037041256496},
+    {0.4544962958743504, 0.0455037041256496, 0.0455037041256496, 0.4544962958743504},
+    {0.4544962958743504, 0.0455037041256496, 0.4544962958743504, 0.0455037041256496},
+    {0.4544962958743504, 0.4544962958743504, 0.0455037041256496, 0.0455037041256496}};
+__device__ const double NS_QW[14] = {
+    0.1126879257180159, 0.1126879257180159, 0.1126879257180159, 0.1126879257180159,
+    0.0734930431163620, 0.0734930431163620, 0.0734930431163620, 0.0734930431163620,
+    0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815};
+// UFC edge -> vertex pairs of the P2 edge nodes 4..9: e0=(2,3) e1=(1,3) e2=(1,2) e3=(0,3) e4=(0,2) e5=(0,1)
+__device__ const int NS_EI[6] = {2, 1, 1, 0, 0, 0};
+__device__ const int NS_EJ[6] = {3, 3, 2, 3, 2, 1};
+
+__device__ __forceinline__ double sel4(int i, double a, double b, double c, double d) {
+    return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d));
+}
+
+// value and physical gradient of P2 basis function n (runtime index) at barycentric point l
+__device__ __forceinline__ void p2_eval(int n, const double l[4], const double gl[4][3], double* phi, double g[3]) {
+    if (n < 4) {
+        const double li = sel4(n, l[0], l[1], l[2], l[3]);
+        const double d = 4.0 * li - 1.0;
+        *phi = li * (2.0 * li - 1.0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = d * sel4(n, gl[0][k], gl[1][k], gl[2][k], gl[3][k]);
+    } else {
+        const int i = NS_EI[n - 4], j = NS_EJ[n - 4];
+        const double li = sel4(i, l[0], l[1], l[2], l[3]), lj = sel4(j, l[0], l[1], l[2], l[3]);
+        *phi = 4.0 * li * lj;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            g[k] = 4.0 * (li * sel4(j, gl[0][k], gl[1][k], gl[2][k], gl[3][k]) + lj * sel4(i, gl[0][k], gl[1][k], gl[2][k], gl[3][k]));
+    }
+}
+
+struct ns_params {
+    double nu, inv_rho, inv_dt;
+    double f[3];
+    int convection, newton;
+};
+
+// thread t = ab*nc + c : block (a, b) of cell c.  val planes [(i*4+j)*plane + slot], g [node*4 + i]
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restrict__ xyz, const int32_t* __restrict__ cell_dofs,
+                                                          int64_t nc, const int32_t* __restrict__ slots,
+                                                          const double* __restrict__ w0, const double* __restrict__ wprev,
+                                                          ns_params P, double* __restrict__ val, int64_t plane,
+                                                          double* __restrict__ g) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nc * 100; t += stride) {
+        const int ab = (int)(t / nc);
+        const int64_t c = t - (int64_t)ab * nc;
+        const int a = ab / 10, b = ab - a * 10;
+        const int32_t slot = slots[t];
+        if (slot < 0) continue;   // row not owned (single GPU: never)
+        int32_t nd[10];
+#pragma unroll
+        for (int n = 0; n < 10; ++n) nd[n] = cell_dofs[c * 10 + n];
+        // geometry: gradients of the barycentric coordinates
+        double X[4][3];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double2 p01 = reinterpret_cast<const double2*>(xyz)[2 * (int64_t)nd[v]];
+            X[v][0] = p01.x; X[v][1] = p01.y; X[v][2] = xyz[4 * (int64_t)nd[v] + 2];
+        }
+        const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
+        const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
+        const double e3[3] = {X[3][0] - X[0][0], X[3][1] - X[0][1], X[3][2] - X[0][2]};
+        const double c23[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+        const double c31[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+        const double c12[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double det = e1[0] * c23[0] + e1[1] * c23[1] + e1[2] * c23[2];
+        const double idet = 1.0 / det;
+        double gl[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gl[1][k] = c23[k] * idet;
+            gl[2][k] = c31[k] * idet;
+            gl[3][k] = c12[k] * idet;
+            gl[0][k] = -(gl[1][k] + gl[2][k] + gl[3][k]);
+        }
+        const double vol = fabs(det) * (1.0 / 6.0);
+        // state at the cell nodes
+        double U0[10][3];
+        if (P.convection) {
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                const double2 u01 = reinterpret_cast<const double2*>(w0)[2 * (int64_t)nd[n]];
+                U0[n][0] = u01.x; U0[n][1] = u01.y; U0[n][2] = w0[4 * (int64_t)nd[n] + 2];
+            }
+        }
+        double blk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[i][j] = 0.0;
+        double gv[3] = {0.0, 0.0, 0.0};
+        const bool do_rhs = b == 0;
+        for (int q = 0; q < 14; ++q) {
+            const double l[4] = {NS_QP[q][0], NS_QP[q][1], NS_QP[q][2], NS_QP[q][3]};
+            const double wv = NS_QW[q] * vol;
+            double pa, pb, ga[3], gb[3];
+            p2_eval(a, l, gl, &pa, ga);
+            p2_eval(b, l, gl, &pb, gb);
+            const double gg = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+            double diag = P.nu * gg + P.inv_dt * pa * pb;
+            double u0[3] = {0.0, 0.0, 0.0}, gu0[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (P.convection) {
+#pragma unroll
+                for (int n = 0; n < 10; ++n) {
+                    double pn, gn[3];
+                    p2_eval(n, l, gl, &pn, gn);      // n is a compile-time constant here: the selects fold away
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        u0[i] += pn * U0[n][i];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) gu0[i][j] += U0[n][i] * gn[j];
+                    }
+                }
+                diag += pa * (u0[0] * gb[0] + u0[1] * gb[1] + u0[2] * gb[2]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                blk[i][i] += wv * diag;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double v = P.nu * ga[j] * gb[i];
+                    if (P.convection && P.newton) v += pa * pb * gu0[i][j];
+                    blk[i][j] += wv * v;
+                }
+            }
+            if (b < 4) {   // pressure trial function psi_b = lambda_b
+                const double psi = sel4(b, l[0], l[1], l[2], l[3]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) blk[i][3] -= wv * P.inv_rho * psi * ga[i];
+            }
+            if (a < 4) {   // continuity test function psi_a
+                const double psi = sel4(a, l[0], l[1], l[2], l[3]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) blk[3][j] += wv * P.inv_rho * psi * gb[j];
+            }
+            if (do_rhs) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double v = P.f[i];
+                    if (P.convection && P.newton) v += gu0[i][0] * u0[0] + gu0[i][1] * u0[1] + gu0[i][2] * u0[2];
+                    gv[i] += wv * pa * v;
+                }
+                if (wprev && P.inv_dt != 0.0) {
+                    double up[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int n = 0; n < 10; ++n) {
+                        double pn, gn[3];
+                        p2_eval(n, l, gl, &pn, gn);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) up[i] += pn * wprev[4 * (int64_t)nd[n] + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) gv[i] += wv * P.inv_dt * pa * up[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i == 3 && j == 3) continue;
+                if (j == 3 && b >= 4) continue;
+                if (i == 3 && a >= 4) continue;
+                atomicAdd(&val[(int64_t)(i * 4 + j) * plane + slot], blk[i][j]);
+            }
+        if (do_rhs) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) atomicAdd(&g[4 * (int64_t)nd[a] + i], gv[i]);
+        }
+    }
+}
+
+// unit diagonal on the dummy pressure slot of edge nodes
+__global__ void k_ns_dummy_rows(int64_t nv, int64_t n_nodes, const int64_t* __restrict__ slice_ptr,
+                                const int32_t* __restrict__ sell_col, double* __restrict__ val, int64_t plane) {
+    int64_t r = nv + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_nodes; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] == (int32_t)r) { val[15 * plane + e] = 1.0; break; }
+        }
+    }
+}
+
+extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev,
+                                         const fs_ns_form* form) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(J && g && form, "fs_assemble_navier_stokes: null pointer");
+    fs_space_s* sp = J->space;
+    FS_REQUIRE(sp->degree == 2 && sp->ncomp == 4 && J->bs == 4, "fs_assemble_navier_stokes: the matrix must live on a 4-component CG2 space");
+    FS_REQUIRE(sp->slots.p, "fs_assemble_navier_stokes: the space has no slot table");
+    FS_REQUIRE(!form->convection || w0, "fs_assemble_navier_stokes: convection needs the state w0");
+    FS_REQUIRE(g->d.n >= sp->n_dofs_owned && (!w0 || w0->d.n >= sp->n_dofs_local) && (!w_prev || w_prev->d.n >= sp->n_dofs_local),
+               "fs_assemble_navier_stokes: vector too short");
+    FS_REQUIRE(form->density > 0.0 && form->inv_dt >= 0.0, "fs_assemble_navier_stokes: bad density / time step");
+    hipStream_t s = fs_rt().stream;
+    fs_mesh_s* m = sp->mesh;
+    ns_params P;
+    P.nu = form->kinematic_viscosity;
+    P.inv_rho = 1.0 / form->density;
+    P.inv_dt = form->inv_dt;
+    for (int i = 0; i < 3; ++i) P.f[i] = form->body_force[i];
+    P.convection = form->convection ? 1 : 0;
+    P.newton = form->newton ? 1 : 0;
+    FS_CHECK(J->val.zero(s));
+    FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
+    const int grid = fs_grid_for(m->nc * 100, FS_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_assemble_ns, dim3(grid), dim3(FS_BLOCK), 0, s, m->xyz.p, sp->cell_dofs, m->nc, sp->slots.p,
+                       w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries, g->d.p);
+    hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - m->nv)), dim3(FS_BLOCK), 0, s, m->nv,
+                       sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+// ---- FGMRES with the block-triangular preconditioner ---------------------------------------------------------
+__global__ void k_sd_diag(int64_t n_nodes, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                          const double* __restrict__ val, int64_t plane, double* __restrict__ dinv) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_nodes; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] != (int32_t)r) continue;
+            for (int i = 0; i < 4; ++i) {
+                const double d = val[(int64_t)(i * 4 + i) * plane + e];
+                dinv[r * 4 + i] = d != 0.0 ? 1.0 / d : 0.0;     // pressure rows have no diagonal: 0
+            }
+            break;
+        }
+    }
+}
+// zu = (ADD ? zu : 0) + dinv * (r - t) on velocity components; pressure components of zu are set to 0
+template <bool FIRST>
+__global__ void k_sd_vel_sweep(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r,
+                               const double* __restrict__ t, double* __restrict__ z) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if ((i & 3) == 3) { z[i] = 0.0; continue; }
+        z[i] = FIRST ? dinv[i] * r[i] : z[i] + dinv[i] * (r[i] - t[i]);
+    }
+}
+// rp[v] = r[4v+3] - t[4v+3]
+__global__ void k_sd_gather_p(int64_t nv, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ rp) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; v < nv; v += stride) rp[v] = r[4 * v + 3] - t[4 * v + 3];
+}
+// z[4v+3] = c1*p1[v] + c2*p2[v] for vertices; dummy pressure slots z = r; rows flagged as identity z = r
+__global__ void k_sd_scatter_p(int64_t n_nodes, int64_t nv, double c1, const double* __restrict__ p1, double c2,
+                               const double* __restrict__ p2, const double* __restrict__ r, const uint8_t* __restrict__ ident,
+                               double* __restrict__ z) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; v < n_nodes; v += stride) {
+        double out;
+        if (v >= nv || ident[v]) out = r[4 * v + 3];
+        else out = (p1 ? c1 * p1[v] : 0.0) + c2 * p2[v];
+        z[4 * v + 3] = out;
+    }
+}
+// pressure rows that are identity rows (Dirichlet pressure): the row has a unit (3,3) diagonal entry
+__global__ void k_sd_ident_p(int64_t nv, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                             const double* __restrict__ val, int64_t plane, uint8_t* __restrict__ ident) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < nv; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        uint8_t f = 0;
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] == (int32_t)r) { f = val[15 * plane + e] != 0.0 ? 1 : 0; break; }
+        }
+        ident[r] = f;
+    }
+}
+__global__ void k_sd_axpy(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] += a * x[i];
+}
+__global__ void k_sd_scale_to(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = a * x[i];
+}
+__global__ void k_sd_sub(int64_t n, const double* __restrict__ b, const double* t, double* r) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) r[i] = b[i] - t[i];
+}
+
+struct saddle_ws {
+    dbuf<double> partials, sums, dinv, t, r, w;
+    dbuf<uint8_t> ident;
+    fs_vector_s rp, p1, p2;
+    std::vector<dbuf<double>*> V, Z;
+    ~saddle_ws() {
+        for (auto* v : V) delete v;
+        for (auto* z : Z) delete z;
+    }
+};
+
+static int sd_dot(saddle_ws& W, const double* x, const double* y, int64_t n, double* out, hipStream_t s) {
+    const int g = fs_grid_for(n, FS_BLOCK, 1024);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(FS_BLOCK), 0, s, x, y, n, W.partials.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, W.partials.p, g, 1, W.sums.p);
+    FS_KERNEL_CHECK();
+    FS_CHECK(W.sums.download(out, 1, s));
+    return FS_OK;
+}
+
+// z = P^-1 r
+static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_matrix_s* Mp, const fs_saddle_opts* o, saddle_ws& W,
+                      const double* r, double* z, int* inner_its, hipStream_t s) {
+    fs_space_s* sp = J->space;
+    const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
+    const int g = fs_grid_for(n, FS_BLOCK, 4096);
+    hipLaunchKernelGGL(k_sd_vel_sweep<true>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, (const double*)nullptr, z);
+    const int sweeps = o->velocity_sweeps > 0 ? o->velocity_sweeps : 1;
+    for (int k = 1; k < sweeps; ++k) {
+        FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));
+        hipLaunchKernelGGL(k_sd_vel_sweep<false>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, W.t.p, z);
+    }
+    FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));     // pressure rows of t = D z_u
+    hipLaunchKernelGGL(k_sd_gather_p, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, r, W.t.p, W.rp.d.p);
+    FS_KERNEL_CHECK();
+    fs_krylov_opts ko;
+    memset(&ko, 0, sizeof(ko));
+    ko.method = FS_KSP_CG;
+    ko.precond = FS_PC_JACOBI;
+    ko.rtol = o->inner_rtol > 0.0 ? o->inner_rtol : 1e-2;
+    ko.max_iter = 500;
+    ko.diagonal_scale = 1;
+    ko.norm_type = FS_NORM_UNPRECONDITIONED;
+    fs_krylov_stats ks;
+    const bool transient = o->inv_dt > 0.0 && Kp;
+    if (transient) {
+        FS_CHECK(fs_krylov_solve(Kp, &W.rp, &W.p1, &ko, &ks));
+        *inner_its += ks.iterations;
+    }
+    FS_CHECK(fs_krylov_solve(Mp, &W.rp, &W.p2, &ko, &ks));
+    *inner_its += ks.iterations;
+    const double r2 = o->density * o->density;
+    hipLaunchKernelGGL(k_sd_scatter_p, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, nv,
+                       r2 * o->inv_dt, transient ? W.p1.d.p : (const double*)nullptr, r2 * o->kinematic_viscosity, W.p2.d.p, r,
+                       W.ident.p, z);
+    FS_KERNEL_CHECK();
+    return FS_OK;
+}
+
+extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
+                               const fs_saddle_opts* o, fs_krylov_stats* stats) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(J && Mp && b && x && o && stats, "fs_saddle_solve: null pointer");
+    fs_space_s* sp = J->space;
+    FS_REQUIRE(J->bs == 4 && sp->degree == 2, "fs_saddle_solve: the operator must be a Taylor-Hood block matrix");
+    FS_REQUIRE(fs_rt().n_ranks == 1 && !sp->halo.active, "fs_saddle_solve: single GPU for now");
+    const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
+    FS_REQUIRE(Mp->bs == 1 && Mp->space->n_dofs_owned == nv && (!Kp || (Kp->bs == 1 && Kp->space->n_dofs_owned == nv)),
+               "fs_saddle_solve: the pressure operators must live on the CG1 space of the same mesh");
+    FS_REQUIRE(b->d.n >= n && x->d.n >= sp->n_dofs_local, "fs_saddle_solve: vector too short");
+    hipStream_t s = fs_rt().stream;
+    const int m = o->restart > 0 ? o->restart : 60;
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 600;
+    memset(stats, 0, sizeof(*stats));
+    const auto t0 = std::chrono::steady_clock::now();
+
+    saddle_ws W;
+    FS_CHECK(W.partials.alloc(FS_MAX_PARTIAL_BLOCKS));
+    FS_CHECK(W.sums.alloc(8));
+    FS_CHECK(W.dinv.alloc(n));
+    FS_CHECK(W.t.alloc(n));
+    FS_CHECK(W.r.alloc(n));
+    FS_CHECK(W.w.alloc(n));
+    FS_CHECK(W.ident.alloc(nv));
+    FS_CHECK(W.rp.d.alloc(nv));
+    FS_CHECK(W.p1.d.alloc(Mp->space->n_dofs_local));
+    FS_CHECK(W.p2.d.alloc(Mp->space->n_dofs_local));
+    for (int k = 0; k <= m; ++k) {
+        W.V.push_back(new dbuf<double>());
+        FS_CHECK(W.V.back()->alloc(n));
+    }
+    for (int k = 0; k < m; ++k) {
+        W.Z.push_back(new dbuf<double>());
+        FS_CHECK(W.Z.back()->alloc(n));
+    }
+    hipLaunchKernelGGL(k_sd_diag, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries, W.dinv.p);
+    hipLaunchKernelGGL(k_sd_ident_p, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries, W.ident.p);
+    FS_KERNEL_CHECK();
+
+    const int g = fs_grid_for(n, FS_BLOCK, 4096);
+    double bb = 0.0;
+    FS_CHECK(sd_dot(W, b->d.p, b->d.p, n, &bb, s));
+    stats->bnorm = sqrt(bb);
+    if (!o->nonzero_guess) FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)sp->n_dofs_local * sizeof(double), s));
+    const double thr = std::max(o->rtol * stats->bnorm, o->atol);
+    int it = 0, conv = 0, inner = 0;
+    double res = 0.0;
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m);
+    while (true) {
+        // r = b - J x
+        FS_CHECK(fs_spmv_dev(J, x->d.p, W.t.p, s));
+        hipLaunchKernelGGL(k_sd_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, W.t.p, W.r.p);
+        double rr = 0.0;
+        FS_CHECK(sd_dot(W, W.r.p, W.r.p, n, &rr, s));
+        res = sqrt(rr);
+        if (!(res == res)) { conv = -1; break; }
+        if (res <= thr) { conv = 1; break; }
+        if (it >= max_iter) break;
+        hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / res, W.r.p, W.V[0]->p);
+        std::fill(gam.begin(), gam.end(), 0.0);
+        gam[0] = res;
+        int k = 0;
+        for (; k < m && it < max_iter; ++k, ++it) {
+            FS_CHECK(sd_precond(J, Kp, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
+            FS_CHECK(fs_spmv_dev(J, W.Z[k]->p, W.w.p, s));
+            for (int j = 0; j <= k; ++j) {       // modified Gram-Schmidt
+                double h = 0.0;
+                FS_CHECK(sd_dot(W, W.w.p, W.V[j]->p, n, &h, s));
+                H[(size_t)j * m + k] = h;
+                hipLaunchKernelGGL(k_sd_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, -h, W.V[j]->p, W.w.p);
+            }
+            double hh = 0.0;
+            FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));
+            hh = sqrt(hh);
+            H[(size_t)(k + 1) * m + k] = hh;
+            if (hh > 0.0) hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / hh, W.w.p, W.V[k + 1]->p);
+            for (int j = 0; j < k; ++j) {        // previous rotations
+                const double a = H[(size_t)j * m + k], c = H[(size_t)(j + 1) * m + k];
+                H[(size_t)j * m + k] = cs[j] * a + sn[j] * c;
+                H[(size_t)(j + 1) * m + k] = -sn[j] * a + cs[j] * c;
+            }
+            const double a = H[(size_t)k * m + k], c = H[(size_t)(k + 1) * m + k];
+            const double d = sqrt(a * a + c * c);
+            cs[k] = d > 0.0 ? a / d : 1.0;
+            sn[k] = d > 0.0 ? c / d : 0.0;
+            H[(size_t)k * m + k] = d;
+            H[(size_t)(k + 1) * m + k] = 0.0;
+            gam[k + 1] = -sn[k] * gam[k];
+            gam[k] = cs[k] * gam[k];
+            res = fabs(gam[k + 1]);
+            if (res <= thr || !(hh > 0.0)) { ++k; ++it; break; }
+        }
+        // y = H^-1 gamma ; x += Z y
+        for (int i = k - 1; i >= 0; --i) {
+            double v = gam[i];
+            for (int j = i + 1; j < k; ++j) v -= H[(size_t)i * m + j] * y[j];
+            y[i] = v / H[(size_t)i * m + i];
+        }
+        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(k_sd_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, y[i], W.Z[i]->p, x->d.p);
+        FS_KERNEL_CHECK();
+    }
+    stats->iterations = it;
+    stats->converged = conv;
+    stats->rel_residual = stats->bnorm > 0.0 ? res / stats->bnorm : 0.0;
+    stats->true_rel_residual = stats->rel_residual;
+    stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats->spmv_bytes = sp->nnz_nodes * 16 * 12 + n * 20;
+    if (getenv("FS_SADDLE_DEBUG")) fprintf(stderr, "[fs_saddle_solve] %d outer iterations, %d inner CG iterations, %.1f ms\n", it, inner, stats->solve_ms);
+    if (conv < 0) {
+        fs_set_error("fs_saddle_solve: breakdown at iteration %d", it);
+        return FS_ERR_NUMERIC;
+    }
+    return FS_OK;
+}

@@ -346,12 +346,44 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
     }
 }
 
+// generic element: slots[(a*nd+b)*nc + c] for the nd dofs of cell c (thread per (cell, a))
+__global__ void k_slots_generic(const int32_t* __restrict__ cell_dofs, int nd, int64_t nc, int64_t n_rows,
+                                const int32_t* __restrict__ sell_col, const int64_t* __restrict__ slice_ptr,
+                                int32_t* __restrict__ slots, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nc * nd; t += stride) {
+        const int64_t c = t / nd;
+        const int a = (int)(t - c * nd);
+        const int32_t row = cell_dofs[c * nd + a];
+        const bool owned = row < n_rows;
+        int64_t base = 0;
+        int width = 0;
+        if (owned) {
+            const int64_t sp0 = slice_ptr[row >> 6];
+            width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            base = sp0 + (row & 63);
+        }
+        for (int b = 0; b < nd; ++b) {
+            int32_t slot = -1;
+            if (owned) {
+                const int k = fs_find_pos(sell_col, base, width, cell_dofs[c * nd + b]);
+                if (k >= 0) slot = (int32_t)(base + (int64_t)k * FS_SLICE);
+                else atomicAdd(err, 1);
+            }
+            slots[(int64_t)(a * nd + b) * nc + c] = slot;
+        }
+    }
+}
+
 // ---- API -----------------------------------------------------------------------------------
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
-    if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3) || (degree == 2 && ncomp != 1)) {
-        fs_set_error("fs_space_create: supported spaces are CG1 with 1 or 3 components and scalar CG2 (family=%d degree=%d ncomp=%d)",
+    // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes
+    if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3 && ncomp != 4) ||
+        (degree == 2 && ncomp == 3) || (degree == 1 && ncomp == 4)) {
+        fs_set_error("fs_space_create: supported spaces are CG1 with 1 or 3 components, scalar CG2 and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d)",
                      family, degree, ncomp);
         return FS_ERR_UNSUPPORTED;
     }
@@ -612,8 +644,11 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         dbuf<int> d_err;
         FS_SP(d_err.alloc(1));
         FS_SP(d_err.zero(s));
-        FS_SP(sp->slots.alloc(16 * nc));
-        hipLaunchKernelGGL(k_slots, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, n_rows, sp->sell_col.p, sp->slice_ptr.p, sp->slots.p, d_err.p);
+        FS_SP(sp->slots.alloc((int64_t)nd * nd * nc));
+        if (nd == 4)
+            hipLaunchKernelGGL(k_slots, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, n_rows, sp->sell_col.p, sp->slice_ptr.p, sp->slots.p, d_err.p);
+        else
+            hipLaunchKernelGGL(k_slots_generic, dim3(fs_grid_for(nc * nd)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, nd, nc, n_rows, sp->sell_col.p, sp->slice_ptr.p, sp->slots.p, d_err.p);
         FS_SP_HIP(hipGetLastError());
         int h_err = 0;
         FS_SP(d_err.download(&h_err, 1, s));

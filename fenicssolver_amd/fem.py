@@ -478,13 +478,14 @@ class FunctionSpace:
     ncomp-vector space) is v*ncomp + i."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
-                 _parent=None):
+                 _parent=None, _holder=False):
         if family not in ("CG", "P", "Lagrange"):
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
         if int(degree) not in (1, 2):
             raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and scalar P2 only)".format(degree))
-        if int(degree) == 2 and _ncomp != 1:
-            raise SolverError("vector P2 spaces are not built yet in fenicssolver_amd")
+        if int(degree) == 2 and _ncomp != 1 and not _holder:
+            # _holder: host-side container of the velocity part of a Taylor-Hood solution (mixed.split)
+            raise SolverError("vector P2 spaces are not built in fenicssolver_amd (P2 is scalar)")
         if constrained_domain is not None:
             raise SolverError("periodic_boundary (constrained_domain) is not supported")
         self._mesh = mesh
@@ -787,6 +788,9 @@ class DirichletBC:
             sel = np.nonzero(markers.array() == marker_id)[0]
         else:
             raise SolverError("DirichletBC: markers must be a MeshFunction")
+        if hasattr(V, "dirichlet_dofs"):                # sub space of the velocity-pressure space (mixed.py)
+            self.dofs, self.values = V.dirichlet_dofs(sel, lambda pts, size: self._eval(value, pts, size))
+            return
         verts = V.facet_nodes(sel).astype(np.int64)     # P2: vertices and edge nodes of the marked facets
         n = V._ncomp
         comp = V.component()

@@ -128,3 +128,26 @@ def _plain(v):
     if a.size <= 4:
         return tuple(float(x) for x in a.ravel())
     return ("array", a.shape, float(a.min()), float(a.max()))
+
+
+class NavierStokesForm:
+    """F = 2 nu eps(u):eps(v) - (p/rho) div v + (q/rho) div u - f.v + (grad(u) u0).v [+ (1/dt)(u - u_prev).v]
+    with u0 = the velocity of ``w_current`` (CoupledNavierStokesSolver.py:288-381).  ``newton``: the reference's
+    action(F, w_current) + derivative (Newton); otherwise the Picard linearisation with u0 frozen."""
+
+    def __init__(self, space):
+        self.space = space
+        self.nu = None
+        self.rho = None
+        self.inv_dt = 0.0
+        self.body_force = None        # 3 numbers or None
+        self.w_current = None         # Function (late bound, like UFL coefficients)
+        self.w_prev = None
+        self.newton = True
+        self.symmetric = False
+        self.nonlinear = True
+
+    def describe(self):
+        return {"type": "navier_stokes", "nu": self.nu, "rho": self.rho, "inv_dt": self.inv_dt,
+                "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
+                "newton": bool(self.newton)}

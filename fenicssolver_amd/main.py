@@ -40,7 +40,7 @@ def main(case_input):
     elif solver_name == "LinearElasticitySolver":
         from .LinearElasticitySolver import LinearElasticitySolver as cls
     elif solver_name == "CoupledNavierStokesSolver":
-        raise NotImplementedError("CoupledNavierStokesSolver (Taylor-Hood) is not built yet in fenicssolver_amd")
+        from .CoupledNavierStokesSolver import CoupledNavierStokesSolver as cls
     else:
         raise NameError('Solver name : {} is not supported, choose one of {}'.format(solver_name, _SOLVERS))
     solver = cls(settings)

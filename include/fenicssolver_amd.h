@@ -276,6 +276,40 @@ int fs_amg_apply(fs_amg_t amg, fs_vector_t r, fs_vector_t z);
  * uses rtol, atol, max_iter, nonzero_guess and norm_type of the options. */
 int fs_amg_solve(fs_amg_t amg, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats);
 
+/* ---- Taylor-Hood Navier-Stokes (CoupledNavierStokesSolver.py:288-381, 215-245, 492-528) -------------
+ * Unknowns: one block (u_x, u_y, u_z, p) per CG2 node of fs_space_create(mesh, FS_FAMILY_CG, 2, 4); the
+ * pressure is CG1, the pressure slot of an edge node is a dummy unknown with a unit row. */
+
+typedef struct fs_ns_form {
+    double kinematic_viscosity; /* nu: 2 nu eps(u):eps(v) */
+    double density;             /* rho: -(p/rho) div v + (q/rho) div u */
+    double inv_dt;              /* 1/dt of the backward-Euler term (F_transient), 0 = steady */
+    double body_force[3];       /* f of -f.v (acceleration, "just gravity, without * rho") */
+    int convection;             /* (grad(u) u0).v with u0 = velocity part of w0 */
+    int newton;                 /* add (grad(u0) u).v to J and (grad(u0) u0).v to g: derivative(action(F, w0)) */
+} fs_ns_form;
+
+/* J <- linearised operator at w0, g <- right-hand side such that J w_new = g is the Newton (or Picard) step
+ * written for the new iterate.  w_prev: previous time step (may be NULL when inv_dt = 0). */
+int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev, const fs_ns_form* form);
+
+typedef struct fs_saddle_opts {
+    double rtol, atol;          /* on ||g - J w||_2 (relative to ||g||_2) */
+    int max_iter;               /* 0 = 600 */
+    int restart;                /* FGMRES restart length, 0 = 60 */
+    double kinematic_viscosity, density, inv_dt; /* of the Schur-complement approximation */
+    int velocity_sweeps;        /* Jacobi sweeps standing in for A^-1, 0 = 1 */
+    double inner_rtol;          /* of the pressure Laplacian / mass CG solves, 0 = 1e-2 */
+    int nonzero_guess;
+} fs_saddle_opts;
+
+/* Restarted FGMRES on the coupled system (the reference lets PETSc LU do this, SolverBase.py:615-626),
+ * right-preconditioned by [A 0; D S]^-1 with the Cahouet-Chabard Schur complement
+ * S^-1 = rho^2 ((1/dt) Kp^-1 + nu Mp^-1).  Kp: CG1 stiffness matrix (coefficient 1) with the pressure
+ * Dirichlet dofs eliminated, may be NULL when inv_dt = 0; Mp: CG1 mass matrix. */
+int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
+                    const fs_saddle_opts* opts, fs_krylov_stats* stats);
+
 /* ---- multi-GPU (MPI inside PETSc/DOLFIN under mpirun; SolverBase.py:102-118, 634) */
 
 #define FS_UNIQUE_ID_BYTES 128

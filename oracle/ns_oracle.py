@@ -1,0 +1,204 @@
+"""CPU oracle (TEST INFRASTRUCTURE, never imported by the product) for the Taylor-Hood path of
+CoupledNavierStokesSolver: P2 velocity / P1 pressure on tetrahedra.
+
+Parity unpinned against DOLFIN/FFC/PETSc themselves (not installable here, see fem_oracle.py); the
+restatement is pinned by known answers: quadrature exactness, exact reproduction of Poiseuille flow
+(quadratic velocity + linear pressure lie in the Taylor-Hood space), a finite-difference check of the
+Jacobian against the residual, and the form goldens recorded from the reference's Python layer.
+
+Forms restated (FenicsSolver/CoupledNavierStokesSolver.py):
+  F_static    :288-365  F = 2 nu eps(u):eps(v) - (p/rho) div v + div u (q/rho) - f.v + (grad(u) a).v
+  F_transient :367-381  F += (1/dt) (u - u_prev).v                      (backward Euler)
+  generate_form :215-245  F = action(F, w_current);  J = derivative(F, w_current)   (Newton)
+  solve_form  :492-528  Newton (NonlinearVariationalSolver) or Picard with under-relaxation 0.7
+
+Numbering used here and on the device: one block of 4 dofs per P2 node (vertices first, then edge
+mid-points in fem_oracle.p2_cell_dofs order): (u_x, u_y, u_z, p).  The pressure lives on vertex nodes only;
+the pressure slot of an edge node is a dummy unknown with an identity row.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import fem_oracle as fo
+
+# ---- quadrature on the reference tetrahedron (barycentric points, weights sum to 1) -------------
+def tet_quadrature(degree):
+    """Degree 2: 4 points; degree 5: the 14-point rule (Walkington / Grundmann-Moeller family)."""
+    if degree <= 2:
+        a, b = 0.5854101966249685, 0.1381966011250105
+        pts = np.full((4, 4), b)
+        np.fill_diagonal(pts, a)
+        return pts, np.full(4, 0.25)
+    pts, w = [], []
+    for a, wt in ((0.3108859192633006, 0.1126879257180159), (0.0927352503108912, 0.0734930431163620)):
+        for k in range(4):
+            p = [a, a, a, a]
+            p[k] = 1.0 - 3.0 * a
+            pts.append(p)
+            w.append(wt)
+    b, wt = 0.0455037041256496, 0.0425460207770815
+    c = 0.5 - b
+    for p in ((b, b, c, c), (b, c, b, c), (b, c, c, b), (c, b, b, c), (c, b, c, b), (c, c, b, b)):
+        pts.append(list(p))
+        w.append(wt)
+    return np.array(pts), np.array(w)
+
+
+def p2_shape(lam):
+    """P2 basis at barycentric point lam[4]: values [10] and d/d(lambda_k) [10,4] (UFC edge order)."""
+    phi = np.zeros(10)
+    dphi = np.zeros((10, 4))
+    for i in range(4):
+        phi[i] = lam[i] * (2.0 * lam[i] - 1.0)
+        dphi[i, i] = 4.0 * lam[i] - 1.0
+    for e, (i, j) in enumerate(fo.P2_EDGE_VERTS):
+        phi[4 + e] = 4.0 * lam[i] * lam[j]
+        dphi[4 + e, i] = 4.0 * lam[j]
+        dphi[4 + e, j] = 4.0 * lam[i]
+    return phi, dphi
+
+
+class TaylorHood:
+    """Mesh + P2/P1 numbering + cell geometry."""
+
+    def __init__(self, coords, cells):
+        self.coords = np.asarray(coords, dtype=np.float64)
+        self.cells = np.asarray(cells, dtype=np.int64)
+        self.nv = len(self.coords)
+        cd, edges = fo.p2_cell_dofs(self.nv, cells)
+        self.cell_nodes = cd.astype(np.int64)              # [nc,10]
+        self.edges = edges
+        self.node_coords = fo.p2_dof_coordinates(self.coords, edges.astype(np.int64))
+        self.n_nodes = len(self.node_coords)
+        self.n = 4 * self.n_nodes
+        detJ, g = fo.p1_geometry(self.coords, cells)       # g[nc,4,3] = grad lambda_k
+        self.vol = np.abs(detJ) / 6.0
+        self.glam = g
+
+    def velocity_dofs(self, nodes, comps=(0, 1, 2)):
+        nodes = np.asarray(nodes, dtype=np.int64)
+        return (nodes[:, None] * 4 + np.asarray(comps)[None, :]).ravel()
+
+    def pressure_dofs(self, vertices):
+        return np.asarray(vertices, dtype=np.int64) * 4 + 3
+
+    def dummy_dofs(self):
+        return np.arange(self.nv, self.n_nodes, dtype=np.int64) * 4 + 3
+
+    def boundary_nodes(self, inside):
+        """P2 nodes (vertices and edge mid-points) of the boundary facets whose mid-point satisfies inside(x)
+        (DirichletBC topological search on marked facets)."""
+        facets, _, cnt = fo.facet_numbering(self.cells)
+        bf = facets[cnt == 1].astype(np.int64)
+        mid = self.coords[bf].mean(axis=1)
+        sel = bf[np.array([bool(inside(x)) for x in mid])]
+        nodes = set(sel.ravel().tolist())
+        key = {(int(a), int(b)): self.nv + k for k, (a, b) in enumerate(self.edges.astype(np.int64))}
+        for t in sel:
+            for a, b in ((t[0], t[1]), (t[0], t[2]), (t[1], t[2])):
+                nodes.add(key[(min(a, b), max(a, b))])
+        return np.array(sorted(nodes), dtype=np.int64)
+
+
+def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, newton=True, convection=True,
+              quad_degree=5):
+    """Linearised system at the state w0:  J(w0) w_new = g(w0).
+
+    J = 2 nu eps:eps + (1/dt) mass + (grad(.) u0).v [+ (grad(u0) .).v if newton] - (p/rho) div v + (q/rho) div u
+    g = f.v + (1/dt) u_prev.v [+ (grad(u0) u0).v if newton]
+    so that the Newton update solves J (w_new - w0) = -R(w0) with R(w) = K(w) w - rhs.
+    Returns (J csr [n,n], g [n]); dummy pressure rows are identity / zero.
+    """
+    nc = len(th.cells)
+    pts, wq = tet_quadrature(quad_degree)
+    W0 = np.asarray(w0, dtype=np.float64).reshape(th.n_nodes, 4)
+    U0 = W0[th.cell_nodes][:, :, :3]                       # [nc,10,3]
+    Up = None if w_prev is None else np.asarray(w_prev, dtype=np.float64).reshape(th.n_nodes, 4)[th.cell_nodes][:, :, :3]
+    f = np.zeros(3) if body_force is None else np.asarray(body_force, dtype=np.float64)
+    Ke = np.zeros((nc, 10, 4, 10, 4))
+    ge = np.zeros((nc, 10, 4))
+    for lam, w in zip(pts, wq):
+        phi, dphi = p2_shape(lam)
+        gphi = np.einsum("ak,cki->cai", dphi, th.glam)     # [nc,10,3] physical gradients
+        psi = lam                                           # P1 basis = barycentric coordinates
+        wv = w * th.vol                                     # [nc]
+        u0 = np.einsum("a,cai->ci", phi, U0)                # [nc,3]
+        gu0 = np.einsum("cai,caj->cij", U0, gphi)           # [nc,3,3] d u0_i / d x_j
+        # viscous: nu (delta_ij grad phi_a . grad phi_b + d_j phi_a d_i phi_b)
+        gg = np.einsum("cak,cbk->cab", gphi, gphi)
+        for i in range(3):
+            Ke[:, :, i, :, i] += (nu * wv)[:, None, None] * gg
+        Ke[:, :, :3, :, :3] += (nu * wv)[:, None, None, None, None] * np.einsum("caj,cbi->caibj", gphi, gphi)
+        # mass
+        mm = np.einsum("a,b->ab", phi, phi)
+        for i in range(3):
+            Ke[:, :, i, :, i] += (inv_dt * wv)[:, None, None] * mm[None]
+        if convection:
+            adv = np.einsum("ck,cbk->cb", u0, gphi)         # u0 . grad phi_b
+            cc = np.einsum("a,cb->cab", phi, adv)
+            for i in range(3):
+                Ke[:, :, i, :, i] += wv[:, None, None] * cc
+            if newton:
+                Ke[:, :, :3, :, :3] += wv[:, None, None, None, None] * np.einsum("ab,cij->caibj", mm, gu0)
+                ge[:, :, :3] += wv[:, None, None] * np.einsum("a,ci->cai", phi, np.einsum("cij,cj->ci", gu0, u0))
+        # pressure gradient / continuity (pressure basis on the 4 vertex nodes = local nodes 0..3)
+        for m in range(4):
+            Ke[:, :, :3, m, 3] += (-(1.0 / rho) * wv * psi[m])[:, None, None] * gphi
+            Ke[:, m, 3, :, :3] += ((1.0 / rho) * wv * psi[m])[:, None, None] * gphi
+        # loads
+        ge[:, :, :3] += wv[:, None, None] * np.einsum("a,i->ai", phi, f)[None]
+        if Up is not None and inv_dt != 0.0:
+            up = np.einsum("a,cai->ci", phi, Up)
+            ge[:, :, :3] += (inv_dt * wv)[:, None, None] * np.einsum("a,ci->cai", phi, up)
+    dofs = (th.cell_nodes[:, :, None] * 4 + np.arange(4)[None, None, :]).reshape(nc, 40)
+    rows = np.repeat(dofs, 40, axis=1).ravel()
+    cols = np.tile(dofs, (1, 40)).ravel()
+    J = sp.coo_matrix((Ke.reshape(nc, 1600).ravel(), (rows, cols)), shape=(th.n, th.n)).tocsr()
+    g = np.zeros(th.n)
+    np.add.at(g, dofs.ravel(), ge.reshape(nc, 40).ravel())
+    dd = th.dummy_dofs()
+    J = J + sp.coo_matrix((np.ones(len(dd)), (dd, dd)), shape=(th.n, th.n)).tocsr()
+    return J, g
+
+
+def apply_dirichlet_rows(J, g, dofs, vals):
+    """DirichletBC.apply on a non-symmetric system: row -> identity, rhs -> value (columns kept)."""
+    J = J.tolil()
+    dofs = np.asarray(dofs, dtype=np.int64)
+    vals = np.broadcast_to(np.asarray(vals, dtype=np.float64), dofs.shape)
+    for d, v in zip(dofs, vals):
+        J.rows[d] = [int(d)]
+        J.data[d] = [1.0]
+        g[d] = v
+    return J.tocsr(), g
+
+
+def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None):
+    """R(w) = K(w) w - rhs  (the nonlinear residual F of the reference after action(F, w))."""
+    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False)
+    return K @ w - rhs
+
+
+def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None,
+                 rtol=1e-9, atol=1e-10, max_it=50, newton=True, relax=1.0):
+    """DOLFIN NewtonSolver semantics (relative 1e-9 / absolute 1e-10 on the residual 2-norm)."""
+    import scipy.sparse.linalg as spl
+    w = np.array(w_init, dtype=np.float64)
+    w[bc_dofs] = bc_vals
+    free = np.ones(th.n, dtype=bool)
+    free[bc_dofs] = False
+    r0 = None
+    history = []
+    for it in range(max_it + 1):
+        J, g = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=newton)
+        r = (J @ w - g)
+        r[~free] = 0.0
+        rn = np.linalg.norm(r)
+        history.append(rn)
+        r0 = rn if r0 is None else r0
+        if rn <= atol or rn <= rtol * r0:
+            return w, history
+        Jb, gb = apply_dirichlet_rows(J, g.copy(), bc_dofs, bc_vals)
+        w_new = spl.spsolve(Jb.tocsc(), gb)
+        w = w + relax * (w_new - w)
+    raise RuntimeError("Newton did not converge: %r" % history)
