@@ -736,7 +736,7 @@ class SolverBase():
             Mp = backend.DeviceMatrix(Q)
             Mp.assemble(mass=1.0)
             ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
-                   'auto_pin': pre.size == 0}
+                   'auto_pin': pre.size == 0, 'Kp_amg': backend.AMG(Kp)}
             self._ns_ctx = ctx
         if ctx['auto_pin']:
             dofs = np.concatenate([dofs, np.array([3], dtype=np.int32)]).astype(np.int32)
@@ -761,7 +761,7 @@ class SolverBase():
                                   inv_dt=F.inv_dt, rtol=rtol, max_iter=int(sp.get('krylov_maximum_iterations', 2000)),
                                   restart=int(sp.get('gmres_restart', 0)),
                                   velocity_sweeps=int(sp.get('velocity_sweeps', 0 if F.inv_dt else 3)),
-                                  nonzero_guess=nonzero_guess)
+                                  nonzero_guess=nonzero_guess, Kp_amg=ctx['Kp_amg'] if F.inv_dt else None)
         self.last_solve_stats = st
         if st['converged'] != 1:
             raise SolverError('Navier-Stokes: FGMRES did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(

@@ -395,14 +395,15 @@ def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, b
 
 
 def saddle_solve(J, Kp, Mp, b, x, nu, rho=1.0, inv_dt=0.0, rtol=1e-8, atol=0.0, max_iter=0, restart=0,
-                 velocity_sweeps=0, inner_rtol=0.0, nonzero_guess=False):
+                 velocity_sweeps=0, inner_rtol=0.0, nonzero_guess=False, Kp_amg=None):
     """FGMRES with the block-triangular Cahouet-Chabard preconditioner; Kp may be None for steady problems."""
     o = L.fs_saddle_opts()
     o.rtol, o.atol, o.max_iter, o.restart = float(rtol), float(atol), int(max_iter), int(restart)
     o.kinematic_viscosity, o.density, o.inv_dt = float(nu), float(rho), float(inv_dt)
     o.velocity_sweeps, o.inner_rtol, o.nonzero_guess = int(velocity_sweeps), float(inner_rtol), 1 if nonzero_guess else 0
     st = L.fs_krylov_stats()
-    L.check(L.load().fs_saddle_solve(J.h, Kp.h if Kp is not None else None, Mp.h, b.h, x.h, C.byref(o), C.byref(st)),
+    L.check(L.load().fs_saddle_solve(J.h, Kp.h if Kp is not None else None, Kp_amg.h if Kp_amg is not None else None,
+                                     Mp.h, b.h, x.h, C.byref(o), C.byref(st)),
             "fs_saddle_solve")
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 

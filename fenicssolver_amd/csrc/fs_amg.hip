@@ -1159,6 +1159,10 @@ static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s)
     return FS_OK;
 }
 
+int fs_amg_apply_dev(fs_amg_s* M, const double* r, double* z, hipStream_t s) {
+    return vcycle(M, 0, z, r, s);
+}
+
 extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
     FS_REQUIRE(M && r && z, "fs_amg_apply: null pointer");
     amg_level* L0 = M->lv[0];

@@ -196,3 +196,6 @@ int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
 int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s);
 // fs_krylov.hip: bare y = A x on the library stream, no halo exchange, no synchronisation.
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
+// fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.
+struct fs_amg_s;
+int fs_amg_apply_dev(fs_amg_s* amg, const double* r, double* z, hipStream_t s);

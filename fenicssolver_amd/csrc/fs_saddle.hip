@@ -342,8 +342,72 @@ __global__ void k_sd_sub(int64_t n, const double* __restrict__ b, const double* 
     for (; i < n; i += stride) r[i] = b[i] - t[i];
 }
 
+// Chebyshev step for M x = b with Jacobi: d = c2 d + c1 dinv (b - t), x += d   (FIRST: d = c1 dinv b, x = d)
+template <bool FIRST>
+__global__ void k_sd_cheb(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ t,
+                          double* __restrict__ d, double* __restrict__ x, double c1, double c2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double v = FIRST ? c1 * dinv[i] * b[i] : c2 * d[i] + c1 * dinv[i] * (b[i] - t[i]);
+        d[i] = v;
+        x[i] = FIRST ? v : x[i] + v;
+    }
+}
+// 1/diag of a scalar SELL matrix
+__global__ void k_sd_scalar_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                 const double* __restrict__ val, double* __restrict__ dinv) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        double d = 1.0;
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] == (int32_t)r) { d = val[e]; break; }
+        }
+        dinv[r] = d != 0.0 ? 1.0 / d : 1.0;
+    }
+}
+// dots[j] partials of w . V_j for j < nvec (one launch; block b writes partial[j*gridDim + b])
+__global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_dot(int64_t n, const double* __restrict__ w, const double* const* __restrict__ V,
+                                                           int nvec, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    for (int j = 0; j < nvec; ++j) {
+        const double* __restrict__ v = V[j];
+        double acc = 0.0;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (; i < n; i += stride) acc += w[i] * v[i];
+        const double t = fs_block_sum(acc, lds4);
+        if (threadIdx.x == 0) partial[(int64_t)j * gridDim.x + blockIdx.x] = t;
+    }
+}
+// sums[j] = sum_b partial[j*nblk + b]   (one workgroup per j, fixed order)
+__global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_sum(const double* __restrict__ partial, int nblk, double* __restrict__ sums) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc += partial[(int64_t)blockIdx.x * nblk + b];
+    const double t = fs_block_sum(acc, lds4);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+// w -= sum_j h[j] V_j
+__global__ void k_sd_multi_axpy(int64_t n, double* __restrict__ w, const double* const* __restrict__ V, const double* __restrict__ h,
+                                int nvec) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double acc = w[i];
+        for (int j = 0; j < nvec; ++j) acc -= h[j] * V[j][i];
+        w[i] = acc;
+    }
+}
+
 struct saddle_ws {
-    dbuf<double> partials, sums, dinv, t, r, w;
+    dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev;
+    dbuf<const double*> vptr;
     dbuf<uint8_t> ident;
     fs_vector_s rp, p1, p2;
     std::vector<dbuf<double>*> V, Z;
@@ -363,7 +427,7 @@ static int sd_dot(saddle_ws& W, const double* x, const double* y, int64_t n, dou
 }
 
 // z = P^-1 r
-static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_matrix_s* Mp, const fs_saddle_opts* o, saddle_ws& W,
+static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matrix_s* Mp, const fs_saddle_opts* o, saddle_ws& W,
                       const double* r, double* z, int* inner_its, hipStream_t s) {
     fs_space_s* sp = J->space;
     const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
@@ -388,11 +452,28 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_matrix_s* Mp, const fs
     fs_krylov_stats ks;
     const bool transient = o->inv_dt > 0.0 && Kp;
     if (transient) {
-        FS_CHECK(fs_krylov_solve(Kp, &W.rp, &W.p1, &ko, &ks));
-        *inner_its += ks.iterations;
+        if (Kp_amg) {          // one V-cycle: a fixed linear operator, spectrally equivalent to Kp^-1
+            FS_CHECK(fs_amg_apply_dev(Kp_amg, W.rp.d.p, W.p1.d.p, s));
+        } else {
+            FS_CHECK(fs_krylov_solve(Kp, &W.rp, &W.p1, &ko, &ks));
+            *inner_its += ks.iterations;
+        }
     }
-    FS_CHECK(fs_krylov_solve(Mp, &W.rp, &W.p2, &ko, &ks));
-    *inner_its += ks.iterations;
+    // Mp^-1: the Jacobi-scaled P1 mass matrix has its spectrum in [1/2, 5/2] (Wathen 1987), so 5 Chebyshev
+    // steps reduce the error by 1e-2 with no reduction and no host synchronisation: a fixed linear operator
+    {
+        const int gq = fs_grid_for(nv, FS_BLOCK, 2048);
+        const double lo = 0.5, up = 2.5, theta = 0.5 * (up + lo), delta = 0.5 * (up - lo), sigma = theta / delta;
+        double rho_c = 1.0 / sigma;
+        hipLaunchKernelGGL(k_sd_cheb<true>, dim3(gq), dim3(FS_BLOCK), 0, s, nv, W.mdinv.p, W.rp.d.p, (const double*)nullptr, W.md.p, W.p2.d.p, 1.0 / theta, 0.0);
+        for (int k = 1; k < 5; ++k) {
+            FS_CHECK(fs_spmv_dev(Mp, W.p2.d.p, W.mt.p, s));
+            const double rho_new = 1.0 / (2.0 * sigma - rho_c);
+            hipLaunchKernelGGL(k_sd_cheb<false>, dim3(gq), dim3(FS_BLOCK), 0, s, nv, W.mdinv.p, W.rp.d.p, W.mt.p, W.md.p, W.p2.d.p, 2.0 * rho_new / delta, rho_new * rho_c);
+            rho_c = rho_new;
+        }
+        (void)ks;
+    }
     const double r2 = o->density * o->density;
     hipLaunchKernelGGL(k_sd_scatter_p, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, nv,
                        r2 * o->inv_dt, transient ? W.p1.d.p : (const double*)nullptr, r2 * o->kinematic_viscosity, W.p2.d.p, r,
@@ -401,7 +482,7 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_matrix_s* Mp, const fs
     return FS_OK;
 }
 
-extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
+extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
                                const fs_saddle_opts* o, fs_krylov_stats* stats) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(J && Mp && b && x && o && stats, "fs_saddle_solve: null pointer");
@@ -418,14 +499,28 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs
     memset(stats, 0, sizeof(*stats));
     const auto t0 = std::chrono::steady_clock::now();
 
-    saddle_ws W;
-    FS_CHECK(W.partials.alloc(FS_MAX_PARTIAL_BLOCKS));
+    // the workspace (2m+1 Krylov vectors) is kept between calls: a Newton / time loop solves many systems of one size
+    static saddle_ws* g_ws = nullptr;
+    static int64_t g_ws_n = -1;
+    static int g_ws_m = -1;
+    const int dot_blocks = 512;
+    if (g_ws && (g_ws_n != n || g_ws_m != m)) { delete g_ws; g_ws = nullptr; }
+    const bool fresh = g_ws == nullptr;
+    if (fresh) { g_ws = new saddle_ws(); g_ws_n = n; g_ws_m = m; }
+    saddle_ws& W = *g_ws;
+    auto build_ws = [&]() -> int {
+    FS_CHECK(W.partials.alloc(std::max<int64_t>(FS_MAX_PARTIAL_BLOCKS, (int64_t)(m + 2) * dot_blocks)));
     FS_CHECK(W.sums.alloc(8));
     FS_CHECK(W.dinv.alloc(n));
     FS_CHECK(W.t.alloc(n));
     FS_CHECK(W.r.alloc(n));
     FS_CHECK(W.w.alloc(n));
     FS_CHECK(W.ident.alloc(nv));
+    FS_CHECK(W.mdinv.alloc(nv));
+    FS_CHECK(W.md.alloc(nv));
+    FS_CHECK(W.mt.alloc(nv));
+    FS_CHECK(W.hdev.alloc(m + 2));
+    FS_CHECK(W.vptr.alloc(m + 2));
     FS_CHECK(W.rp.d.alloc(nv));
     FS_CHECK(W.p1.d.alloc(Mp->space->n_dofs_local));
     FS_CHECK(W.p2.d.alloc(Mp->space->n_dofs_local));
@@ -436,6 +531,22 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs
     for (int k = 0; k < m; ++k) {
         W.Z.push_back(new dbuf<double>());
         FS_CHECK(W.Z.back()->alloc(n));
+    }
+    {
+        std::vector<const double*> hp(m + 1);
+        for (int k = 0; k <= m; ++k) hp[k] = W.V[k]->p;
+        FS_HIP(hipMemcpyAsync(W.vptr.p, hp.data(), (size_t)(m + 1) * sizeof(double*), hipMemcpyHostToDevice, s));
+        FS_HIP(hipStreamSynchronize(s));
+    }
+        return FS_OK;
+    };
+    if (fresh) {
+        const int rc_ws = build_ws();
+        if (rc_ws != FS_OK) { delete g_ws; g_ws = nullptr; return rc_ws; }
+    }
+    {
+        fs_space_s* q = Mp->space;
+        hipLaunchKernelGGL(k_sd_scalar_dinv, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, q->slice_ptr.p, q->sell_col.p, Mp->val.p, W.mdinv.p);
     }
     hipLaunchKernelGGL(k_sd_diag, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries, W.dinv.p);
     hipLaunchKernelGGL(k_sd_ident_p, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries, W.ident.p);
@@ -449,7 +560,7 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs
     const double thr = std::max(o->rtol * stats->bnorm, o->atol);
     int it = 0, conv = 0, inner = 0;
     double res = 0.0;
-    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m);
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m), hcol(m + 2);
     while (true) {
         // r = b - J x
         FS_CHECK(fs_spmv_dev(J, x->d.p, W.t.p, s));
@@ -465,13 +576,17 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs
         gam[0] = res;
         int k = 0;
         for (; k < m && it < max_iter; ++k, ++it) {
-            FS_CHECK(sd_precond(J, Kp, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
+            FS_CHECK(sd_precond(J, Kp, Kp_amg, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
             FS_CHECK(fs_spmv_dev(J, W.Z[k]->p, W.w.p, s));
-            for (int j = 0; j <= k; ++j) {       // modified Gram-Schmidt
-                double h = 0.0;
-                FS_CHECK(sd_dot(W, W.w.p, W.V[j]->p, n, &h, s));
-                H[(size_t)j * m + k] = h;
-                hipLaunchKernelGGL(k_sd_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, -h, W.V[j]->p, W.w.p);
+            // classical Gram-Schmidt, applied twice (CGS2): one fused multi-dot launch and one host read per pass
+            for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, W.partials.p);
+                hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 1), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p);
+                hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, W.hdev.p, k + 1);
+                FS_KERNEL_CHECK();
+                FS_CHECK(W.hdev.download(hcol.data(), k + 1, s));
+                for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] += hcol[j];
             }
             double hh = 0.0;
             FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));

@@ -306,8 +306,9 @@ typedef struct fs_saddle_opts {
 /* Restarted FGMRES on the coupled system (the reference lets PETSc LU do this, SolverBase.py:615-626),
  * right-preconditioned by [A 0; D S]^-1 with the Cahouet-Chabard Schur complement
  * S^-1 = rho^2 ((1/dt) Kp^-1 + nu Mp^-1).  Kp: CG1 stiffness matrix (coefficient 1) with the pressure
- * Dirichlet dofs eliminated, may be NULL when inv_dt = 0; Mp: CG1 mass matrix. */
-int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
+ * Dirichlet dofs eliminated, may be NULL when inv_dt = 0; Kp_amg: optional hierarchy of Kp (fs_amg_setup) - one
+ * V-cycle then stands in for Kp^-1 instead of an inner CG solve; Mp: CG1 mass matrix. */
+int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
                     const fs_saddle_opts* opts, fs_krylov_stats* stats);
 
 /* ---- multi-GPU (MPI inside PETSc/DOLFIN under mpirun; SolverBase.py:102-118, 634) */

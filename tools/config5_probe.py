@@ -1,0 +1,40 @@
+"""BASELINE.json configs[4]: lid-driven cavity, Taylor-Hood P2/P1, unit cube n=43 (1 975 509 velocity + 85 184 pressure
+dofs, 477 042 tets), nu = 0.01, rho = 1, dt = 0.01, backward Euler, Newton per step.  Timing of the pieces."""
+import sys, time, os, copy, logging
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from collections import OrderedDict
+import numpy as np
+from fenicssolver_amd import backend as B
+from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, near
+from fenicssolver_amd import SolverBase as SB
+from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 43
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+B.init(0)
+t0 = time.perf_counter()
+mesh = UnitCubeMesh(n, n, n)
+bcs = OrderedDict()
+bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 1.0)), 'boundary_id': 2,
+              'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+s = copy.deepcopy(SB.default_case_settings)
+s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+          'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+          'material': {'density': 1.0, 'kinematic_viscosity': 0.01}})
+s['solver_settings']['transient_settings'] = {'transient': True, 'starting_time': 0.0, 'time_step': 0.01, 'ending_time': 0.01 * steps - 1e-9}
+s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+s['report_settings'] = {"logging_level": logging.INFO, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+solver = CoupledNavierStokesSolver(s)
+t1 = time.perf_counter()
+print('mesh+solver construction %.2f s; cells %d' % (t1 - t0, mesh.num_cells()), flush=True)
+w = solver.solve()
+B.synchronize()
+t2 = time.perf_counter()
+W4 = w.vector().array().reshape(-1, 4)
+nv = mesh.num_vertices()
+print('n', n, 'velocity dofs', 3 * len(W4), 'pressure dofs', nv, 'steps', solver.current_step, 'solve %.2f s' % (t2 - t1))
+print('last newton history', solver.newton_history, 'krylov its in last step', solver.newton_krylov_iterations)
+print('|u|max %.4f  p range [%.4f, %.4f]  u_x at centre %.5f' % (np.abs(W4[:, :3]).max(), W4[:nv, 3].min(), W4[:nv, 3].max(), w.split_centre if hasattr(w, 'split_centre') else W4[(nv - 1) // 2, 0]))
+print('DOF/s (all steps): %.3g' % ((3 * len(W4) + nv) * solver.current_step / (t2 - t1)))
