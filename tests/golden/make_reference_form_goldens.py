@@ -143,6 +143,35 @@ bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'valu
 bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
 run("elasticity_force", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(bcs)))
 
+# --- Taylor-Hood Navier-Stokes (CoupledNavierStokesSolver.py) ---------------------------------------
+from FenicsSolver import CoupledNavierStokesSolver                                                     # noqa: E402
+
+
+def ns_settings(transient, body_source=None, nonlinear=True):
+    mesh = UnitCubeMesh(4, 4, 4)
+    walls = AutoSubDomain(lambda x, on_boundary: on_boundary)
+    lid = AutoSubDomain(lambda x, on_boundary: on_boundary)
+    bcs = collections.OrderedDict()
+    bcs["walls"] = {'boundary': walls, 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["lid"] = {'boundary': lid, 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    st = copy.deepcopy(SolverBase.default_case_settings)
+    st.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
+               'boundary_conditions': bcs, 'body_source': body_source,
+               'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+               'material': {'density': 2.0, 'kinematic_viscosity': 0.01}})
+    st['solver_settings']['transient_settings'] = {'transient': transient, 'starting_time': 0.0, 'time_step': 0.01,
+                                                   'ending_time': 0.01}
+    st['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    st['report_settings'] = dict(QUIET)
+    return st
+
+
+run("navier_stokes_steady", CoupledNavierStokesSolver.CoupledNavierStokesSolver(ns_settings(False)))
+run("navier_stokes_transient_gravity",
+    CoupledNavierStokesSolver.CoupledNavierStokesSolver(ns_settings(True, body_source=Constant((0, 0, -9.8)))))
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

@@ -87,6 +87,10 @@ class Expr(object):
     def ufl_shape(self):
         return getattr(self, "_shape", ())
 
+    @property
+    def T(self):
+        return Expr("transpose", self)
+
     def s(self):
         if self.op == "num":
             v = self.args[0]
@@ -194,6 +198,9 @@ class Mesh(object):
     def hmin(self):
         return 1.0
 
+    def ufl_cell(self):
+        return "tetrahedron"
+
 
 def BoxMesh(*a):
     return Mesh("BoxMesh%r" % (tuple(repr(x) for x in a),))
@@ -241,8 +248,42 @@ class _Element(object):
         return self._d
 
 
+class FiniteElement(object):
+    def __init__(self, family, cell, degree):
+        self.family, self.cell, self.degree_, self.kind = family, cell, degree, "scalar"
+
+    def __mul__(self, other):
+        return MixedElement([self, other])
+
+    def label(self):
+        return "%s%d" % (self.family, self.degree_)
+
+
+class VectorElement(FiniteElement):
+    def __init__(self, family, cell, degree):
+        FiniteElement.__init__(self, family, cell, degree)
+        self.kind = "vector"
+
+    def label(self):
+        return "Vector%s%d" % (self.family, self.degree_)
+
+
+class MixedElement(object):
+    def __init__(self, elements):
+        self.elements, self.kind = list(elements), "mixed"
+
+    def label(self):
+        return "Mixed(%s)" % " x ".join(e.label() for e in self.elements)
+
+
 class FunctionSpace(object):
-    def __init__(self, mesh, family, degree, constrained_domain=None, _kind="scalar", _label="V"):
+    def __init__(self, mesh, family, degree=None, constrained_domain=None, _kind="scalar", _label="V"):
+        if isinstance(family, (FiniteElement, MixedElement)):          # FunctionSpace(mesh, element)
+            element = family
+            self._mesh, self.family, self._degree = mesh, element.label(), getattr(element, "degree_", None)
+            self.kind, self.label, self.element = element.kind, "W" if element.kind == "mixed" else _label, element
+            self._ufl_element = _Element(self._degree)
+            return
         self._mesh, self.family, self._degree, self.kind, self.label = mesh, family, degree, _kind, _label
         self._ufl_element = _Element(degree)
 
@@ -250,6 +291,10 @@ class FunctionSpace(object):
         return self._mesh
 
     def sub(self, i):
+        if self.kind == "mixed":
+            e = self.element.elements[i]
+            V = FunctionSpace(self._mesh, e, _label="%s.sub(%d)" % (self.label, i))
+            return V
         return FunctionSpace(self._mesh, self.family, self._degree, _kind="component", _label="%s.sub(%d)" % (self.label, i))
 
     def dofmap(self):
@@ -308,6 +353,8 @@ class Function(Expr):
 
 def TrialFunction(V):
     f = Expr("symbol", "u_trial")
+    if getattr(V, "kind", "") == "mixed":
+        f._elements = V.element.elements
     if getattr(V, "kind", "") == "vector":
         f._len, f._shape = 3, (3,)
     return f
@@ -315,9 +362,29 @@ def TrialFunction(V):
 
 def TestFunction(V):
     f = Expr("symbol", "v_test")
+    if getattr(V, "kind", "") == "mixed":
+        f._elements = V.element.elements
     if getattr(V, "kind", "") == "vector":
         f._len, f._shape = 3, (3,)
     return f
+
+
+def split(f):
+    """Components of a function of a mixed space: symbols named after the function."""
+    V = getattr(f, "V", None)
+    name = f.args[0] if f.op == "symbol" else f.s()
+    elements = V.element.elements if V is not None and getattr(V, "kind", "") == "mixed" else getattr(f, "_elements", [])
+    out = []
+    for i, e in enumerate(elements):
+        c = Expr("symbol", "%s[%d]" % (name, i))
+        if e.kind == "vector":
+            c._len, c._shape = 3, (3,)
+        out.append(c)
+    return tuple(out)
+
+
+def TensorFunctionSpace(mesh, family, degree):
+    return FunctionSpace(mesh, family, degree, _kind="tensor", _label="T")
 
 
 def interpolate(expr, V):

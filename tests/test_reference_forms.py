@@ -309,3 +309,72 @@ def test_elasticity_terms():
     g = GOLD["elasticity_displacement"]["solves"][0]
     assert_same_poly(elasticity_form_poly(F), golden_poly(g))
     assert bc_list(dbc) == golden_bcs(g)
+
+
+# ------------------------------------------------------------------ Taylor-Hood Navier-Stokes
+def _ns_expected_terms(desc, state="W0", prev="WPREV"):
+    """The integrals the reference builds for a NavierStokesForm description (CoupledNavierStokesSolver.py:315-381),
+    in the recording stub's notation with the state / previous-step functions replaced by placeholders."""
+    eps = lambda f: "mul(0.5, add(grad(%s), transpose(grad(%s))))" % (f, f)   # noqa: E731
+    num = lambda x: repr(float(x)) if not float(x).is_integer() else "%d" % x  # noqa: E731
+    t = [(+1, "mul(%s, inner(%s, %s))" % (num(desc["nu"] * 2.0), eps("u_trial[0]"), eps("v_test[0]"))),
+         (-1, "mul(div(u_trial[1], %s), div(v_test[0]))" % num(desc["rho"])),
+         (+1, "mul(div(u_trial[0]), div(v_test[1], %s))" % num(desc["rho"]))]
+    if desc["body_force"] is not None:
+        t.append((-1, "inner(Constant(vec(%s)), v_test[0])" % ", ".join(num(x) for x in desc["body_force"])))
+    t.append((+1, "inner(dot(grad(u_trial[0]), %s[0]), v_test[0])" % state))
+    if desc["inv_dt"]:
+        t.append((+1, "mul(%s, inner(sub(u_trial[0], %s[0]), v_test[0]))" % (num(desc["inv_dt"]), prev)))
+    return t
+
+
+@pytest.mark.parametrize("case,transient,body", [("navier_stokes_steady", False, None),
+                                                 ("navier_stokes_transient_gravity", True, (0, 0, -9.8))])
+def test_navier_stokes_terms(case, transient, body):
+    """Same settings -> the same integrals (signs, the 2*nu, the 1/rho on both pressure terms, gravity without rho,
+    backward Euler) and the same Dirichlet conditions on W.sub(0) as the reference hands to NonlinearVariationalSolver."""
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = UnitCubeMesh(2, 2, 2)
+    bcs = collections.OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[2] - 1) < 1e-12), 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
+              'boundary_conditions': bcs, 'body_source': Constant(body) if body else None,
+              'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 2.0, 'kinematic_viscosity': 0.01}})
+    s['solver_settings']['transient_settings'] = {'transient': transient, 'starting_time': 0.0, 'time_step': 0.01,
+                                                  'ending_time': 0.01}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['report_settings'] = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = CoupledNavierStokesSolver(s)
+    solver.init_solver()
+    F, dbcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    desc = F.describe()
+    assert desc["newton"] is True              # using_nonlinear_solver: action(F, w) + derivative (:241-243)
+
+    gold = GOLD[case]["solves"][0]
+    assert gold["kind"] == "NonlinearVariationalSolver"
+    # strip the action(..., w_current) wrapper and name the state / previous-step functions
+    terms = []
+    state = None
+    for t in gold["terms"]:
+        m = re.match(r"^action\((.*), (interpolate\(Expression\(.*?\)\)\))\)$", t["integrand"])
+        assert m and t["measure"] == "dx"
+        state = state or m.group(2)
+        assert m.group(2) == state
+        body_ = m.group(1).replace(state, "W0")
+        body_ = re.sub(r"\bw\d+\b", "WPREV", body_)
+        terms.append((t["sign"], body_))
+    assert sorted(terms) == sorted(_ns_expected_terms(desc))
+    # Dirichlet conditions: both on the velocity sub space, in the same order with the same values
+    assert [(b["space"], b["marker"]) for b in gold["bcs"]] == [("W.sub(0)", 1), ("W.sub(0)", 2)]
+    assert [b.marker_id for b in dbcs] == [1, 2]
+    assert np.all(dbcs[0].values == 0.0)
+    v2 = dbcs[1].values.reshape(-1, 3)
+    assert np.all(v2[:, 0] == 1.0) and np.all(v2[:, 1:] == 0.0)
+    assert np.all(dbcs[1].dofs % 4 != 3)       # velocity components only
