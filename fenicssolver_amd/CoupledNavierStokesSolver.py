@@ -9,10 +9,11 @@ higher, CoupledNavierStokesSolver.py:84-88), ``material`` with ``density`` and `
 (backward Euler, :367-381).  ``solver.using_nonlinear_solver`` (default True) selects Newton, False the Picard loop
 with under-relaxation 0.7 of :492-528.
 
-Built: velocity Dirichlet conditions (constants, tuples, C-string Expressions, per-time-step lists are not),
-body force, steady and backward-Euler transient, Newton and Picard.  Raise: pressure / symmetry / farfield
-boundary types (their natural boundary integrals are not built yet), G2 stabilisation, ALE reference frames,
-non-Newtonian viscosity, the coupled temperature equation.
+Built: velocity Dirichlet conditions (constants, tuples, C-string Expressions; per-time-step lists are not),
+pressure Dirichlet (inlet / outlet, with the reference's boundary integrals p n.v ds - nu ((grad u + grad u^T) n).v ds)
+and pressure 'farfield' boundaries, body force, steady and backward-Euler transient, Newton and Picard.
+Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), G2 stabilisation,
+ALE reference frames, non-Newtonian viscosity, the coupled temperature equation.
 """
 from __future__ import annotations
 
@@ -116,13 +117,14 @@ class CoupledNavierStokesSolver(SolverBase):
             raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
         if self.transient_settings['transient']:
             F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:367-381)
-        bcs = self.update_boundary_conditions(time_iter_, trial_function, test_function, None)
+        bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function, None)
         self.J = F if self.using_nonlinear_solver else None
         return F, bcs
 
     def update_boundary_conditions(self, time_iter_, trial_function, test_function, ds):
+        """-> (Dirichlet conditions, pressure-boundary integrals) (CoupledNavierStokesSolver.py:383-490)."""
         W = self.function_space
-        bcs = []
+        bcs, pressure_terms = [], []
         for key, boundary in self.boundary_conditions.items():
             if boundary.get('coupling') == 'FSI' and 'values' not in boundary:
                 boundary['values'] = [{'variable': "velocity", 'type': 'Dirichlet', 'value': self.dimension * (0.0,)}]
@@ -130,6 +132,7 @@ class CoupledNavierStokesSolver(SolverBase):
             if values is None:
                 raise SolverError("boundary '{}' has no 'values'".format(key))
             bc_values = values if isinstance(values, list) else list(values.values())
+            bid = boundary['boundary_id']
             for bc in bc_values:
                 var, typ = bc.get('variable'), bc.get('type')
                 if var == 'velocity':
@@ -139,17 +142,36 @@ class CoupledNavierStokesSolver(SolverBase):
                             raise SolverError("per-time-step lists of velocity values are not built")
                         if isinstance(value, (tuple, np.ndarray)):
                             value = Constant(tuple(float(x) for x in value))
-                        bcs.append(DirichletBC(W.sub(0), value, self.boundary_facets, boundary['boundary_id']))
+                        bcs.append(DirichletBC(W.sub(0), value, self.boundary_facets, bid))
+                    elif typ == 'Neumann':
+                        # the reference builds a NotImplementedError without raising it (:431): a no-op
+                        self.logger.warning("velocity boundary type `Neumann` is a no-op, as in the reference")
+                    elif typ in ('symmetry', 'farfield'):
+                        raise SolverError("velocity boundary type `{}`: the reference's form for it is not valid UFL "
+                                          "(inner of a scalar and a vector, :434 / product of two vectors, :437); "
+                                          "not built".format(typ))
                     else:
-                        raise SolverError("velocity boundary type `{}` is not built (Dirichlet only)".format(typ))
+                        self.logger.warning('velocity boundary type`%s` is not supported', typ)
                 elif var == 'pressure':
-                    raise SolverError("pressure boundary conditions are not built yet: their boundary integrals "
-                                      "(p n.v and the viscous traction term, CoupledNavierStokesSolver.py:449-453) are missing")
+                    if typ == 'Dirichlet':      # pressure inlet or outlet (:445-453)
+                        value = bc['value']
+                        if isinstance(value, numbers.Number):
+                            value = Constant(float(value))
+                        bcs.append(DirichletBC(W.sub(1), value, self.boundary_facets, bid))
+                        pressure_terms.append((bid, value))
+                    elif typ == 'farfield':     # no viscous stress (:459-460)
+                        pressure_terms.append((bid, None))
+                    elif typ in ('symmetry',):
+                        pass
+                    elif typ == 'Neumann':
+                        self.logger.warning("pressure boundary type `Neumann` is a no-op, as in the reference")
+                    else:
+                        self.logger.warning('pressure boundary type`%s` is not supported thus ignored', typ)
                 elif var == 'temperature':
                     continue      # "boundary setup is done in scalar transport for incompressible flow" (:483)
                 else:
-                    raise SolverError("boundary variable `{}` is not supported".format(var))
-        return bcs
+                    self.logger.warning('boundary variable `%s` is not handled by the incompressible flow solver', var)
+        return bcs, pressure_terms
 
     def solve_form(self, F, up_, Dirichlet_bcs_up):
         if self.using_nonlinear_solver:

@@ -752,7 +752,24 @@ class SolverBase():
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
                                        convection=True, newton=newton)
+        for marker_id, value in F.pressure_boundaries:
+            cells, opp, centroids = self._marked_facet_cells(marker_id)
+            fv = None
+            if value is not None:
+                fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
+            backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv)
         return dw, g
+
+    def _marked_facet_cells(self, marker_id):
+        """(cell, local opposite vertex, centroid) of the facets carrying a boundary marker."""
+        cache = self.__dict__.setdefault('_facet_cell_cache', {})
+        if marker_id not in cache:
+            sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+            cf = self.mesh.cell_facets()
+            cells, opp = np.nonzero(np.isin(cf, sel))
+            tri = self.mesh.facets()[cf[cells, opp]].astype(np.int64)
+            cache[marker_id] = (cells.astype(np.int32), opp.astype(np.int32), self.mesh.coordinates()[tri].mean(axis=1))
+        return cache[marker_id]
 
     def _navier_stokes_krylov(self, F, ctx, J, b, x, rtol, nonzero_guess):
         from . import backend

@@ -394,6 +394,17 @@ def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, b
             "fs_assemble_navier_stokes")
 
 
+def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_value=None):
+    """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only)."""
+    fc = np.ascontiguousarray(facet_cell, dtype=np.int32)
+    fo_ = np.ascontiguousarray(facet_opposite, dtype=np.int32)
+    fv = None
+    if facet_value is not None:
+        fv = np.ascontiguousarray(np.broadcast_to(np.asarray(facet_value, dtype=np.float64), fc.shape))
+    L.check(L.load().fs_assemble_ns_pressure_boundary(J.h, g.h, len(fc), L.p_i32(fc), L.p_i32(fo_), L.p_f64(fv), float(nu)),
+            "fs_assemble_ns_pressure_boundary")
+
+
 def saddle_solve(J, Kp, Mp, b, x, nu, rho=1.0, inv_dt=0.0, rtol=1e-8, atol=0.0, max_iter=0, restart=0,
                  velocity_sweeps=0, inner_rtol=0.0, nonzero_guess=False, Kp_amg=None):
     """FGMRES with the block-triangular Cahouet-Chabard preconditioner; Kp may be None for steady problems."""

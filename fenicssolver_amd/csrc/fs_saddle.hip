@@ -259,6 +259,129 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     return FS_OK;
 }
 
+// ---- pressure boundaries: F += inner(p_b n, v) ds - nu inner((grad(u) + grad(u)^T) n, v) ds -----------------------
+// (CoupledNavierStokesSolver.py:449-453 pressure Dirichlet, :459-460 pressure 'farfield')
+// 6-point degree-4 triangle rule; the facet's P2 nodes as cell-local node indices, by opposite vertex
+__device__ const double NS_TQ[6][3] = {{0.108103018168070, 0.445948490915965, 0.445948490915965},
+                                       {0.445948490915965, 0.108103018168070, 0.445948490915965},
+                                       {0.445948490915965, 0.445948490915965, 0.108103018168070},
+                                       {0.816847572980459, 0.091576213509771, 0.091576213509771},
+                                       {0.091576213509771, 0.816847572980459, 0.091576213509771},
+                                       {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+__device__ const double NS_TW[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011,
+                                    0.109951743655322, 0.109951743655322, 0.109951743655322};
+__device__ const int NS_FACE_NODES[4][6] = {{1, 2, 3, 4, 5, 6}, {0, 2, 3, 4, 7, 8}, {0, 1, 3, 5, 7, 9}, {0, 1, 2, 6, 8, 9}};
+
+// thread t = (facet, facet node al, cell node b)
+__global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                                       const double* __restrict__ facet_value, double nu, const double* __restrict__ xyz,
+                                       const int32_t* __restrict__ cell_dofs, int64_t nc, const int32_t* __restrict__ slots,
+                                       double* __restrict__ val, int64_t plane, double* __restrict__ g) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 60; t += stride) {
+        const int64_t f = t / 60;
+        const int r = (int)(t - f * 60);
+        const int al = r / 10, b = r - al * 10;
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int a = NS_FACE_NODES[o][al];
+        int32_t nd[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) nd[v] = cell_dofs[c * 10 + v];
+        double X[4][3];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            X[v][0] = xyz[4 * (int64_t)nd[v]]; X[v][1] = xyz[4 * (int64_t)nd[v] + 1]; X[v][2] = xyz[4 * (int64_t)nd[v] + 2];
+        }
+        const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
+        const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
+        const double e3[3] = {X[3][0] - X[0][0], X[3][1] - X[0][1], X[3][2] - X[0][2]};
+        const double c23[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+        const double c31[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+        const double c12[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double det = e1[0] * c23[0] + e1[1] * c23[1] + e1[2] * c23[2];
+        const double idet = 1.0 / det;
+        double gl[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gl[1][k] = c23[k] * idet;
+            gl[2][k] = c31[k] * idet;
+            gl[3][k] = c12[k] * idet;
+            gl[0][k] = -(gl[1][k] + gl[2][k] + gl[3][k]);
+        }
+        const double vol = fabs(det) * (1.0 / 6.0);
+        double go[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) go[k] = sel4(o, gl[0][k], gl[1][k], gl[2][k], gl[3][k]);
+        const double gnorm = sqrt(go[0] * go[0] + go[1] * go[1] + go[2] * go[2]);
+        const double n[3] = {-go[0] / gnorm, -go[1] / gnorm, -go[2] / gnorm};   // outward
+        const double area = 3.0 * vol * gnorm;
+        double blk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        double gv[3] = {0.0, 0.0, 0.0};
+        const double pb = facet_value ? facet_value[f] : 0.0;
+        for (int q = 0; q < 6; ++q) {
+            double l[4];
+            int kk = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) l[v] = (v == o) ? 0.0 : NS_TQ[q][kk++];
+            const double wv = NS_TW[q] * area;
+            double pa, pbf, ga[3], gb[3];
+            p2_eval(a, l, gl, &pa, ga);
+            p2_eval(b, l, gl, &pbf, gb);
+            const double gn = gb[0] * n[0] + gb[1] * n[1] + gb[2] * n[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) blk[i][j] -= nu * wv * pa * ((i == j ? gn : 0.0) + gb[i] * n[j]);
+                gv[i] -= wv * pb * n[i] * pa;
+            }
+        }
+        const int32_t slot = slots[(int64_t)(a * 10 + b) * nc + c];
+        if (slot < 0) continue;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) atomicAdd(&val[(int64_t)(i * 4 + j) * plane + slot], blk[i][j]);
+        if (b == 0 && facet_value) {
+            const int32_t node = cell_dofs[c * 10 + a];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) atomicAdd(&g[4 * (int64_t)node + i], gv[i]);
+        }
+    }
+}
+
+extern "C" int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
+                                                const int32_t* facet_opposite, const double* facet_value,
+                                                double kinematic_viscosity) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(J && g && n_facets >= 0 && (n_facets == 0 || (facet_cell && facet_opposite)), "fs_assemble_ns_pressure_boundary: bad arguments");
+    fs_space_s* sp = J->space;
+    FS_REQUIRE(sp->degree == 2 && sp->ncomp == 4 && sp->slots.p, "fs_assemble_ns_pressure_boundary: not a Taylor-Hood block matrix");
+    if (n_facets == 0) return FS_OK;
+    fs_mesh_s* m = sp->mesh;
+    for (int64_t i = 0; i < n_facets; ++i)
+        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] < 4,
+                   "fs_assemble_ns_pressure_boundary: facet %lld names cell %d / local vertex %d", (long long)i, facet_cell[i], facet_opposite[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> dc, dop;
+    dbuf<double> dv;
+    FS_CHECK(dc.alloc(n_facets));
+    FS_CHECK(dop.alloc(n_facets));
+    FS_CHECK(dc.upload(facet_cell, n_facets, s));
+    FS_CHECK(dop.upload(facet_opposite, n_facets, s));
+    if (facet_value) {
+        FS_CHECK(dv.alloc(n_facets));
+        FS_CHECK(dv.upload(facet_value, n_facets, s));
+    }
+    hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
+                       facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, sp->cell_dofs, m->nc,
+                       sp->slots.p, J->val.p, sp->sell_entries, g->d.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 // ---- FGMRES with the block-triangular preconditioner ---------------------------------------------------------
 __global__ void k_sd_diag(int64_t n_nodes, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
                           const double* __restrict__ val, int64_t plane, double* __restrict__ dinv) {

@@ -146,8 +146,19 @@ class NavierStokesForm:
         self.newton = True
         self.symmetric = False
         self.nonlinear = True
+        # pressure boundaries: [(marker_id, value | None)]: + inner(value*n, v)*ds(id) (value given) and
+        # - nu*inner((grad(u) + grad(u).T)*n, v)*ds(id)   (CoupledNavierStokesSolver.py:449-453, 459-460)
+        self.pressure_boundaries = []
+
+    @staticmethod
+    def _value_name(v):
+        try:
+            return "Constant(%g)" % float(v)
+        except (TypeError, ValueError):
+            return type(v).__name__
 
     def describe(self):
         return {"type": "navier_stokes", "nu": self.nu, "rho": self.rho, "inv_dt": self.inv_dt,
+                "pressure_boundaries": [(int(m), None if v is None else self._value_name(v)) for m, v in self.pressure_boundaries],
                 "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
                 "newton": bool(self.newton)}

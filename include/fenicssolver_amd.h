@@ -293,6 +293,13 @@ typedef struct fs_ns_form {
  * written for the new iterate.  w_prev: previous time step (may be NULL when inv_dt = 0). */
 int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev, const fs_ns_form* form);
 
+/* Pressure boundaries, added to J and g after fs_assemble_navier_stokes and before the Dirichlet rows:
+ *   F += inner(p_b n, v) ds - nu inner((grad(u) + grad(u)^T) n, v) ds   (CoupledNavierStokesSolver.py:449-453)
+ * facet_cell / facet_opposite: the cell behind each boundary facet and the local vertex opposite to it;
+ * facet_value: p_b per facet, NULL = the pressure 'farfield' type (traction term only, :459-460). */
+int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
+                                     const int32_t* facet_opposite, const double* facet_value, double kinematic_viscosity);
+
 typedef struct fs_saddle_opts {
     double rtol, atol;          /* on ||g - J w||_2 (relative to ||g||_2) */
     int max_iter;               /* 0 = 600 */

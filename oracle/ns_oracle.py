@@ -202,3 +202,63 @@ def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=N
         w_new = spl.spsolve(Jb.tocsc(), gb)
         w = w + relax * (w_new - w)
     raise RuntimeError("Newton did not converge: %r" % history)
+
+
+# ---- pressure boundaries (CoupledNavierStokesSolver.py:449-453, 459-460) -----------------------------------
+# 6-point degree-4 rule on the triangle (barycentric, weights sum to 1)
+TRI_QP = np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965],
+                   [0.445948490915965, 0.108103018168070, 0.445948490915965],
+                   [0.445948490915965, 0.445948490915965, 0.108103018168070],
+                   [0.816847572980459, 0.091576213509771, 0.091576213509771],
+                   [0.091576213509771, 0.816847572980459, 0.091576213509771],
+                   [0.091576213509771, 0.091576213509771, 0.816847572980459]])
+TRI_QW = np.array([0.223381589678011] * 3 + [0.109951743655322] * 3)
+
+
+def boundary_facet_cells(th, inside):
+    """(cell, opposite local vertex) of the boundary facets whose mid-point satisfies inside(x)."""
+    out = []
+    opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))
+    facets, cf, cnt = fo.facet_numbering(th.cells)
+    for c in range(len(th.cells)):
+        for o in range(4):
+            if cnt[cf[c, o]] != 1:
+                continue
+            if inside(th.coords[th.cells[c, list(opp[o])]].mean(axis=0)):
+                out.append((c, o))
+    return np.array(out, dtype=np.int64).reshape(-1, 2)
+
+
+def pressure_boundary_terms(th, facet_cells, nu, bvalue=None):
+    """F += inner(bvalue*n, v)*ds - nu*inner((grad(u) + grad(u).T)*n, v)*ds on the given boundary facets.
+    Returns (dJ csr, dg): the matrix of the viscous traction term and the load (moved to the right-hand side).
+    bvalue None: the 'farfield' pressure type (traction term only)."""
+    nf = len(facet_cells)
+    Ke = np.zeros((nf, 10, 4, 10, 4))
+    ge = np.zeros((nf, 10, 4))
+    opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))
+    for k, (c, o) in enumerate(facet_cells):
+        gl = th.glam[c]
+        gnorm = np.linalg.norm(gl[o])
+        n = -gl[o] / gnorm
+        area = 3.0 * th.vol[c] * gnorm
+        for bary, w in zip(TRI_QP, TRI_QW):
+            lam = np.zeros(4)
+            lam[list(opp[o])] = bary
+            phi, dphi = p2_shape(lam)
+            gphi = dphi @ gl                          # [10,3]
+            wv = w * area
+            gn = gphi @ n                              # grad phi_b . n
+            for i in range(3):
+                Ke[k, :, i, :, i] += -nu * wv * np.outer(phi, gn)
+            Ke[k, :, :3, :, :3] += -nu * wv * np.einsum("a,bi,j->aibj", phi, gphi, n)
+            if bvalue is not None:
+                ge[k, :, :3] -= wv * float(bvalue) * np.outer(phi, n)
+    cells = facet_cells[:, 0]
+    dofs = (th.cell_nodes[cells][:, :, None] * 4 + np.arange(4)[None, None, :]).reshape(nf, 40)
+    rows = np.repeat(dofs, 40, axis=1).ravel()
+    cols = np.tile(dofs, (1, 40)).ravel()
+    dJ = sp.coo_matrix((Ke.reshape(nf, 1600).ravel(), (rows, cols)), shape=(th.n, th.n)).tocsr()
+    dg = np.zeros(th.n)
+    np.add.at(dg, dofs.ravel(), ge.reshape(nf, 40).ravel())
+    return dJ, dg

@@ -172,6 +172,13 @@ run("navier_stokes_steady", CoupledNavierStokesSolver.CoupledNavierStokesSolver(
 run("navier_stokes_transient_gravity",
     CoupledNavierStokesSolver.CoupledNavierStokesSolver(ns_settings(True, body_source=Constant((0, 0, -9.8)))))
 
+st = ns_settings(False)
+st['boundary_conditions']["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 3,
+                                       'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(5.0)}]}
+st['boundary_conditions']["far"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 4,
+                                    'values': [{'variable': "pressure", 'type': 'farfield', 'value': Constant(0.0)}]}
+run("navier_stokes_pressure_boundaries", CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

@@ -325,11 +325,18 @@ def _ns_expected_terms(desc, state="W0", prev="WPREV"):
     t.append((+1, "inner(dot(grad(u_trial[0]), %s[0]), v_test[0])" % state))
     if desc["inv_dt"]:
         t.append((+1, "mul(%s, inner(sub(u_trial[0], %s[0]), v_test[0]))" % (num(desc["inv_dt"]), prev)))
+    t = [(sg, body, "dx") for sg, body in t]
+    for marker, value in desc.get("pressure_boundaries", []):
+        if value is not None:
+            t.append((+1, "inner(mul(%s, n), v_test[0])" % value, "ds(%d)" % marker))
+        t.append((+1, "mul(%s, inner(mul(add(grad(u_trial[0]), transpose(grad(u_trial[0]))), n), v_test[0]))" % num(-desc["nu"]),
+                  "ds(%d)" % marker))
     return t
 
 
 @pytest.mark.parametrize("case,transient,body", [("navier_stokes_steady", False, None),
-                                                 ("navier_stokes_transient_gravity", True, (0, 0, -9.8))])
+                                                 ("navier_stokes_transient_gravity", True, (0, 0, -9.8)),
+                                                 ("navier_stokes_pressure_boundaries", False, None)])
 def test_navier_stokes_terms(case, transient, body):
     """Same settings -> the same integrals (signs, the 2*nu, the 1/rho on both pressure terms, gravity without rho,
     backward Euler) and the same Dirichlet conditions on W.sub(0) as the reference hands to NonlinearVariationalSolver."""
@@ -342,6 +349,12 @@ def test_navier_stokes_terms(case, transient, body):
                     'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
     bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[2] - 1) < 1e-12), 'boundary_id': 2,
                   'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    pressure = case.endswith("pressure_boundaries")
+    if pressure:
+        bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[0] - 1) < 1e-12), 'boundary_id': 3,
+                         'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(5.0)}]}
+        bcs["far"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[0]) < 1e-12), 'boundary_id': 4,
+                      'values': [{'variable': "pressure", 'type': 'farfield', 'value': Constant(0.0)}]}
     s = copy.deepcopy(SB.default_case_settings)
     s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
               'boundary_conditions': bcs, 'body_source': Constant(body) if body else None,
@@ -364,16 +377,19 @@ def test_navier_stokes_terms(case, transient, body):
     state = None
     for t in gold["terms"]:
         m = re.match(r"^action\((.*), (interpolate\(Expression\(.*?\)\)\))\)$", t["integrand"])
-        assert m and t["measure"] == "dx"
+        assert m
         state = state or m.group(2)
         assert m.group(2) == state
         body_ = m.group(1).replace(state, "W0")
         body_ = re.sub(r"\bw\d+\b", "WPREV", body_)
-        terms.append((t["sign"], body_))
+        terms.append((t["sign"], body_, t["measure"]))
     assert sorted(terms) == sorted(_ns_expected_terms(desc))
-    # Dirichlet conditions: both on the velocity sub space, in the same order with the same values
-    assert [(b["space"], b["marker"]) for b in gold["bcs"]] == [("W.sub(0)", 1), ("W.sub(0)", 2)]
-    assert [b.marker_id for b in dbcs] == [1, 2]
+    # Dirichlet conditions: velocity sub space (and the pressure sub space for a pressure outlet), same order and values
+    expect_bcs = [("W.sub(0)", 1), ("W.sub(0)", 2)] + ([("W.sub(1)", 3)] if pressure else [])
+    assert [(b["space"], b["marker"]) for b in gold["bcs"]] == expect_bcs
+    assert [b.marker_id for b in dbcs] == [m_ for _, m_ in expect_bcs]
+    if pressure:
+        assert np.all(dbcs[2].dofs % 4 == 3) and np.all(dbcs[2].values == 5.0)
     assert np.all(dbcs[0].values == 0.0)
     v2 = dbcs[1].values.reshape(-1, 3)
     assert np.all(v2[:, 0] == 1.0) and np.all(v2[:, 1:] == 0.0)
