@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict_
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
 static int g_spmv_blocks = 1024;
 static int g_spmv_unroll = 4;
+static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
 static int g_update_blocks = 512;
@@ -631,6 +632,9 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "spmv_unroll")) {
         FS_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "spmv_unroll must be 2, 4, 8 or 16");
         g_spmv_unroll = (int)value;
+    } else if (!strcmp(name, "spmv_unroll4")) {
+        FS_REQUIRE(value == 1 || value == 2 || value == 4, "spmv_unroll4 must be 1, 2 or 4");
+        g_spmv_unroll4 = (int)value;
     } else if (!strcmp(name, "cg_fuse_sums")) {
         g_cg_fuse_sums = value != 0.0;
     } else if (!strcmp(name, "update_blocks")) {
@@ -670,7 +674,11 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     } else if (A->bs == 3) {
         hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
     } else {
-        hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 4>), FS_SPMV_ARGS);
+        switch (g_spmv_unroll4) {
+            case 1: hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 1>), FS_SPMV_ARGS); break;
+            case 4: hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 4>), FS_SPMV_ARGS); break;
+            default: hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 2>), FS_SPMV_ARGS); break;
+        }
     }
 #undef FS_SPMV_ARGS
 }

@@ -413,6 +413,58 @@ __global__ void k_sd_vel_sweep(int64_t n, const double* __restrict__ dinv, const
         z[i] = FIRST ? dinv[i] * r[i] : z[i] + dinv[i] * (r[i] - t[i]);
     }
 }
+// Chebyshev step on the velocity block (Jacobi-scaled): d = c2 d + c1 dinv (r - t), z += d; FIRST: d = c1 dinv r, z = d.
+// Pressure components of z and d stay 0.
+template <bool FIRST>
+__global__ void k_sd_vel_cheb(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r,
+                              const double* __restrict__ t, double* __restrict__ d, double* __restrict__ z, double c1, double c2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if ((i & 3) == 3) { z[i] = 0.0; d[i] = 0.0; continue; }
+        const double v = FIRST ? c1 * dinv[i] * r[i] : c2 * d[i] + c1 * dinv[i] * (r[i] - t[i]);
+        d[i] = v;
+        z[i] = FIRST ? v : z[i] + v;
+    }
+}
+// v <- dinv * t on velocity components, 0 on pressure components (power iteration of D^-1 A)
+__global__ void k_sd_vel_scale(int64_t n, const double* __restrict__ dinv, const double* __restrict__ t, double* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[i] = (i & 3) == 3 ? 0.0 : dinv[i] * t[i];
+}
+__global__ void k_sd_seed(int64_t n, double* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761U + 12345U;
+        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+        v[i] = (i & 3) == 3 ? 0.0 : (double)(x & 0xffffff) / 8388608.0 - 1.0;
+    }
+}
+// rp[v] = r[4v+3] - (D z_u)[v]: only the continuity rows of the block matrix are needed here, i.e. the three value
+// planes (3,0..2) of the vertex-node rows (numbered first) - 2 % of the traffic of a full SpMV.  One thread per row.
+__global__ void __launch_bounds__(FS_BLOCK) k_sd_pressure_rows(int64_t nv, const int64_t* __restrict__ slice_ptr,
+                                                               const int32_t* __restrict__ sell_col, const double* __restrict__ val,
+                                                               int64_t plane, const double* __restrict__ z,
+                                                               const double* __restrict__ r, double* __restrict__ rp) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; v < nv; v += stride) {
+        const int64_t sp0 = slice_ptr[v >> 6];
+        const int width = (int)((slice_ptr[(v >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (v & 63);
+        double acc = 0.0;
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            const int32_t c = sell_col[e];
+            if (c < 0) continue;
+            const double* zc = z + 4 * (int64_t)c;
+            acc += val[12 * plane + e] * zc[0] + val[13 * plane + e] * zc[1] + val[14 * plane + e] * zc[2];
+        }
+        rp[v] = r[4 * v + 3] - acc;
+    }
+}
 // rp[v] = r[4v+3] - t[4v+3]
 __global__ void k_sd_gather_p(int64_t nv, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ rp) {
     int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,10 +548,10 @@ __global__ void k_sd_scalar_dinv(int64_t n_rows, const int64_t* __restrict__ sli
 }
 // dots[j] partials of w . V_j for j < nvec (one launch; block b writes partial[j*gridDim + b])
 __global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_dot(int64_t n, const double* __restrict__ w, const double* const* __restrict__ V,
-                                                           int nvec, double* __restrict__ partial) {
+                                                           int nvec, int with_self, double* __restrict__ partial) {
     __shared__ double lds4[4];
-    for (int j = 0; j < nvec; ++j) {
-        const double* __restrict__ v = V[j];
+    for (int j = 0; j < nvec + with_self; ++j) {
+        const double* v = j < nvec ? V[j] : w;      // the extra "vector" is w itself: ||w||^2
         double acc = 0.0;
         int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -529,7 +581,8 @@ __global__ void k_sd_multi_axpy(int64_t n, double* __restrict__ w, const double*
 }
 
 struct saddle_ws {
-    dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev;
+    dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev, cd;
+    double vel_lmax = 0.0;   // largest eigenvalue of D^-1 A on the velocity block (Chebyshev sweeps)
     dbuf<const double*> vptr;
     dbuf<uint8_t> ident;
     fs_vector_s rp, p1, p2;
@@ -555,14 +608,25 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
     fs_space_s* sp = J->space;
     const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
     const int g = fs_grid_for(n, FS_BLOCK, 4096);
-    hipLaunchKernelGGL(k_sd_vel_sweep<true>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, (const double*)nullptr, z);
     const int sweeps = o->velocity_sweeps > 0 ? o->velocity_sweeps : 1;
-    for (int k = 1; k < sweeps; ++k) {
-        FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));
-        hipLaunchKernelGGL(k_sd_vel_sweep<false>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, W.t.p, z);
+    if (sweeps == 1) {
+        hipLaunchKernelGGL(k_sd_vel_sweep<true>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, (const double*)nullptr, z);
+    } else {
+        // plain Jacobi sweeps are not a convergent iteration on P2 blocks (lambda_max(D^-1 A) > 2, an even number of
+        // sweeps is even indefinite): Chebyshev polynomial in D^-1 A on [lambda_max/8, 1.1 lambda_max] instead
+        const double up = 1.1 * W.vel_lmax, lo = W.vel_lmax / 8.0;
+        const double theta = 0.5 * (up + lo), delta = 0.5 * (up - lo), sigma = theta / delta;
+        double rho_c = 1.0 / sigma;
+        hipLaunchKernelGGL(k_sd_vel_cheb<true>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, (const double*)nullptr, W.cd.p, z, 1.0 / theta, 0.0);
+        for (int k = 1; k < sweeps; ++k) {
+            FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));
+            const double rho_new = 1.0 / (2.0 * sigma - rho_c);
+            hipLaunchKernelGGL(k_sd_vel_cheb<false>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, W.t.p, W.cd.p, z, 2.0 * rho_new / delta, rho_new * rho_c);
+            rho_c = rho_new;
+        }
     }
-    FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));     // pressure rows of t = D z_u
-    hipLaunchKernelGGL(k_sd_gather_p, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, r, W.t.p, W.rp.d.p);
+    hipLaunchKernelGGL(k_sd_pressure_rows, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p,
+                       J->val.p, sp->sell_entries, z, r, W.rp.d.p);
     FS_KERNEL_CHECK();
     fs_krylov_opts ko;
     memset(&ko, 0, sizeof(ko));
@@ -632,18 +696,19 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     if (fresh) { g_ws = new saddle_ws(); g_ws_n = n; g_ws_m = m; }
     saddle_ws& W = *g_ws;
     auto build_ws = [&]() -> int {
-    FS_CHECK(W.partials.alloc(std::max<int64_t>(FS_MAX_PARTIAL_BLOCKS, (int64_t)(m + 2) * dot_blocks)));
+    FS_CHECK(W.partials.alloc(std::max<int64_t>(FS_MAX_PARTIAL_BLOCKS, (int64_t)(m + 3) * dot_blocks)));
     FS_CHECK(W.sums.alloc(8));
     FS_CHECK(W.dinv.alloc(n));
     FS_CHECK(W.t.alloc(n));
     FS_CHECK(W.r.alloc(n));
     FS_CHECK(W.w.alloc(n));
+    FS_CHECK(W.cd.alloc(n));
     FS_CHECK(W.ident.alloc(nv));
     FS_CHECK(W.mdinv.alloc(nv));
     FS_CHECK(W.md.alloc(nv));
     FS_CHECK(W.mt.alloc(nv));
-    FS_CHECK(W.hdev.alloc(m + 2));
-    FS_CHECK(W.vptr.alloc(m + 2));
+    FS_CHECK(W.hdev.alloc(m + 3));
+    FS_CHECK(W.vptr.alloc(m + 3));
     FS_CHECK(W.rp.d.alloc(nv));
     FS_CHECK(W.p1.d.alloc(Mp->space->n_dofs_local));
     FS_CHECK(W.p2.d.alloc(Mp->space->n_dofs_local));
@@ -676,6 +741,22 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_KERNEL_CHECK();
 
     const int g = fs_grid_for(n, FS_BLOCK, 4096);
+    if (o->velocity_sweeps > 1) {
+        // lambda_max(D^-1 A) of the velocity block: 12 power iterations from a hashed start
+        hipLaunchKernelGGL(k_sd_seed, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p);
+        double lam = 1.0;
+        for (int it = 0; it < 12; ++it) {
+            double nn = 0.0;
+            FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &nn, s));
+            nn = sqrt(nn);
+            if (!(nn > 0.0)) break;
+            if (it > 0) lam = nn;
+            hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / nn, W.w.p, W.r.p);
+            FS_CHECK(fs_spmv_dev(J, W.r.p, W.t.p, s));
+            hipLaunchKernelGGL(k_sd_vel_scale, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, W.t.p, W.w.p);
+        }
+        W.vel_lmax = lam;
+    }
     double bb = 0.0;
     FS_CHECK(sd_dot(W, b->d.p, b->d.p, n, &bb, s));
     stats->bnorm = sqrt(bb);
@@ -683,7 +764,7 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     const double thr = std::max(o->rtol * stats->bnorm, o->atol);
     int it = 0, conv = 0, inner = 0;
     double res = 0.0;
-    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m), hcol(m + 2);
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m), hcol(m + 3);
     while (true) {
         // r = b - J x
         FS_CHECK(fs_spmv_dev(J, x->d.p, W.t.p, s));
@@ -702,17 +783,26 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
             FS_CHECK(sd_precond(J, Kp, Kp_amg, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
             FS_CHECK(fs_spmv_dev(J, W.Z[k]->p, W.w.p, s));
             // classical Gram-Schmidt, applied twice (CGS2): one fused multi-dot launch and one host read per pass
+            // classical Gram-Schmidt with one fused multi-dot launch and one host read per pass; the last pointer of the
+            // list is w itself, so the pass also returns ||w||^2 before the projection.  A second pass only when the
+            // projection removed most of w (DGKS-type criterion): orthogonality stays near working precision.
             for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = 0.0;
-            for (int pass = 0; pass < 2; ++pass) {
-                hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, W.partials.p);
-                hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 1), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p);
+            double hh = 0.0;
+            for (int pass = 0; pass < 3; ++pass) {
+                hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, 1, W.partials.p);
+                hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 2), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p);
                 hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, W.hdev.p, k + 1);
                 FS_KERNEL_CHECK();
-                FS_CHECK(W.hdev.download(hcol.data(), k + 1, s));
-                for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] += hcol[j];
+                FS_CHECK(W.hdev.download(hcol.data(), k + 2, s));
+                double removed = 0.0;
+                for (int j = 0; j <= k; ++j) { H[(size_t)j * m + k] += hcol[j]; removed += hcol[j] * hcol[j]; }
+                const double before = hcol[k + 1];
+                hh = before - removed;               // Pythagoras; recomputed exactly below when cancellation is severe
+                if (hh > 0.1 * before) break;        // eta^2 = 0.1: at most one digit lost to cancellation
+                FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));
+                if (pass >= 1) break;
             }
-            double hh = 0.0;
-            FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));
+            if (!(hh > 0.0)) hh = 0.0;
             hh = sqrt(hh);
             H[(size_t)(k + 1) * m + k] = hh;
             if (hh > 0.0) hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / hh, W.w.p, W.V[k + 1]->p);

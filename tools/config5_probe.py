@@ -25,6 +25,10 @@ s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree':
           'material': {'density': 1.0, 'kinematic_viscosity': 0.01}})
 s['solver_settings']['transient_settings'] = {'transient': True, 'starting_time': 0.0, 'time_step': 0.01, 'ending_time': 0.01 * steps - 1e-9}
 s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+if len(sys.argv) > 3:
+    s['solver_settings']['solver_parameters'] = dict(s['solver_settings'].get('solver_parameters') or {}, velocity_sweeps=int(sys.argv[3]))
+if len(sys.argv) > 4:
+    s['solver_settings']['solver_parameters']['krylov_relative_tolerance'] = float(sys.argv[4])
 s['report_settings'] = {"logging_level": logging.INFO, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
 solver = CoupledNavierStokesSolver(s)
 t1 = time.perf_counter()
