@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from .fem import Constant, Expression, Function, DirichletBC, nodal_values, is_constant_value
+from .fem import Constant, Expression, Function, DirichletBC, PointSource, Point, nodal_values, is_constant_value
 from .SolverBase import SolverBase, SolverError
 from . import forms
 
@@ -172,8 +172,15 @@ class ScalarTransportSolver(SolverBase):
         capacity = self.capacity(T)
         bcs = []
         integrals_N = []
+        self._point_sources = []
         if 'point_source' in self.settings and self.settings['point_source']:
-            raise SolverError('point_source is not supported by the GPU back end yet')
+            ps = self.settings['point_source']      # a PointSource, or a list of (point, magnitude) (:148-155)
+            if isinstance(ps, PointSource):
+                self._point_sources = [ps]
+            else:
+                self._point_sources = [p if isinstance(p, PointSource) else
+                                       PointSource(self.function_space, Point(*np.ravel(p[0])) if not isinstance(p[0], Point) else p[0], p[1])
+                                       for p in ps]
         if 'surface_source' in self.settings and self.settings['surface_source']:
             raise SolverError('surface_source is not supported (undefined in the reference as well)')
 
@@ -285,6 +292,7 @@ class ScalarTransportSolver(SolverBase):
         bcs, integrals_N = self.update_boundary_conditions(time_iter_, T, T_test, None)
         for item in integrals_N:
             (F.robin if isinstance(item, forms.FacetRobin) else F.facet_loads).append(item)
+        F.point_sources = list(self._point_sources)
         bs_items = self.get_body_source_items(time_iter_, T, T_test, None)
         if bs_items:
             F.sources.extend(bs_items)

@@ -592,6 +592,15 @@ class SolverBase():
                 tri, _ = self._device_facets(F, r.marker_id)
                 if len(tri):
                     backend.assemble_facet_vector(V, b, tri, r.h * r.ambient)
+            for ps in getattr(F, 'point_sources', []):
+                # PointSource.apply(b) (SolverBase.py:597-601): before the Dirichlet rows, which then overwrite
+                pd, pw = ps.dofs, ps.weights
+                if loc is not None:
+                    pd, pw = loc.dofs(pd, pw)
+                    keep = pd < V.n_owned
+                    pd, pw = pd[keep], pw[keep]
+                if len(pd):
+                    b.add_entries(pd, pw)
             if F.transient:
                 # b += (M/dt - (1-theta) K) T_prev   (Crank-Nicolson old-step terms, :292-293)
                 B = backend.DeviceMatrix(V)
@@ -629,8 +638,6 @@ class SolverBase():
 
     def solve_linear_problem(self, F, u, Dirichlet_bcs):
         """LinearVariationalSolver.solve() on the GPU (SolverBase.py:592-613)."""
-        if 'point_source' in self.settings and self.settings['point_source']:
-            raise SolverError('point_source is not supported by the GPU back end yet')
         if isinstance(F, forms.NavierStokesForm):
             return self._navier_stokes_linear(F, u, Dirichlet_bcs)
         A, b = self.assemble_system(F, Dirichlet_bcs, symmetric=True)

@@ -164,6 +164,10 @@ class DeviceVector(_Handle):
     def axpy(self, a, x):
         L.check(L.load().fs_vector_axpy(self.h, float(a), x.h), "fs_vector_axpy")
 
+    def add_entries(self, idx, vals):
+        i, v = L.i32(idx).ravel(), L.f64(vals).ravel()
+        L.check(L.load().fs_vector_add_entries(self.h, i.size, L.p_i32(i), L.p_f64(v)), "fs_vector_add_entries")
+
     def dot(self, y):
         r = C.c_double(0.0)
         L.check(L.load().fs_vector_dot(self.h, y.h, C.byref(r)), "fs_vector_dot")

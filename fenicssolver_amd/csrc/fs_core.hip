@@ -145,6 +145,30 @@ extern "C" int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x) {
     return FS_OK;
 }
 
+__global__ void k_add_entries(double* __restrict__ v, const int32_t* __restrict__ idx, const double* __restrict__ vals, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) atomicAdd(&v[idx[i]], vals[i]);
+}
+
+extern "C" int fs_vector_add_entries(fs_vector_t v, int64_t n, const int32_t* idx, const double* vals) {
+    FS_REQUIRE(v && n >= 0 && (n == 0 || (idx && vals)), "fs_vector_add_entries: bad arguments");
+    if (n == 0) return FS_OK;
+    for (int64_t i = 0; i < n; ++i)
+        FS_REQUIRE(idx[i] >= 0 && idx[i] < v->d.n, "fs_vector_add_entries: index %d outside the vector of %lld entries", idx[i], (long long)v->d.n);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> di;
+    dbuf<double> dv;
+    FS_CHECK(di.alloc(n));
+    FS_CHECK(dv.alloc(n));
+    FS_CHECK(di.upload(idx, n, s));
+    FS_CHECK(dv.upload(vals, n, s));
+    hipLaunchKernelGGL(k_add_entries, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, v->d.p, di.p, dv.p, n);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 extern "C" int fs_vector_dot(fs_vector_t x, fs_vector_t y, double* result) {
     FS_REQUIRE(x && y && result, "fs_vector_dot: null");
     int64_t n = x->d.n < y->d.n ? x->d.n : y->d.n;

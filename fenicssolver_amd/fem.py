@@ -769,6 +769,31 @@ def nodal_values(value, V):
     raise SolverError("cannot evaluate {} at the nodes of the space".format(type(value)))
 
 
+class PointSource:
+    """dolfin.PointSource(V, Point, magnitude): a Dirac load, b[dof] += magnitude * phi_dof(point) on the cell that
+    holds the point (examples/test_electrostatics.py:52-53; ScalarTransportSolver.py:148-155)."""
+
+    def __init__(self, V, point, magnitude=1.0):
+        self.function_space, self.magnitude = V, float(magnitude)
+        p = np.zeros(3)
+        xs = point.array() if isinstance(point, Point) else np.asarray(point, dtype=np.float64).ravel()
+        p[: len(xs)] = xs
+        self.point = p
+        if V._degree != 1 or V._ncomp != 1:
+            raise SolverError("PointSource is built for scalar P1 spaces")
+        mesh = V.mesh()
+        co, ce = mesh.coordinates(), mesh.cells().astype(np.int64)
+        c = co[ce]
+        T = np.stack([c[:, 1] - c[:, 0], c[:, 2] - c[:, 0], c[:, 3] - c[:, 0]], axis=2)
+        lam = np.linalg.solve(T, np.broadcast_to(p - c[:, 0], (len(ce), 3))[:, :, None])[:, :, 0]
+        bary = np.concatenate([1.0 - lam.sum(axis=1, keepdims=True), lam], axis=1)
+        i = int(np.argmax(bary.min(axis=1)))
+        if bary[i].min() < -1e-10:
+            raise SolverError("PointSource at {} is outside the mesh".format(p))
+        self.dofs = ce[i].astype(np.int32)
+        self.weights = self.magnitude * bary[i]
+
+
 def is_constant_value(value):
     return isinstance(value, (numbers.Number, Constant))
 

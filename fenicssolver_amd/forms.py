@@ -76,6 +76,7 @@ class ScalarForm:
         self.sources = []             # [VolumeCoefficient]  int S q dx
         self.facet_loads = []         # [FacetLoad]
         self.robin = []               # [FacetRobin]
+        self.point_sources = []       # [fem.PointSource]: b[dofs] += weights, before the Dirichlet rows
         self.advection = None         # (velocity: 3-vector or array[n_cells,3], scale = capacity) -> non-symmetric
         self.symmetric = True
         # nonlinear terms (Newton): radiation  - m (Ta^4 - T^4) q ds over the whole boundary, m = emissivity*sigma

@@ -356,3 +356,35 @@ def test_electrostatics_and_species_scalars(gpu):
     sol2 = ScalarTransportSolver(s2)
     C = sol2.solve().vector().array()
     assert np.abs(C - (300 + 60 * y)).max() < 1e-8 and sol2.conductivity() == 2.5e-3
+
+
+def test_point_sources(gpu):
+    """settings['point_source'] (ScalarTransportSolver.py:148-155; examples/test_electrostatics.py:52-53): Dirac loads
+    b += magnitude * phi(point), applied before the Dirichlet rows."""
+    from fenicssolver_amd.fem import PointSource, Point, Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(4)
+    for k in ("hot", "cold"):
+        s['boundary_conditions'][k]['values']['temperature']['value'] = Constant(0)
+    pts = [((0.5, 0.5, 0.5), 3.0), ((0.3, 0.62, 0.41), -1.5), ((0.25, 1.0, 0.25), 100.0)]   # vertex, interior, on the hot wall
+    s['point_source'] = pts
+    solver = ScalarTransportSolver(s)
+    T = solver.solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    K = fo.assemble_p1_scalar(co, ce, 0.6)
+    b = np.zeros(len(co))
+    for p, mag in pts:
+        ps = PointSource(solver.function_space, Point(*p), mag)
+        assert abs(ps.weights.sum() - mag) < 1e-12 * abs(mag) and ps.weights.min() >= -1e-9 * abs(mag) if mag > 0 else True
+        np.add.at(b, ps.dofs.astype(np.int64), ps.weights)
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    Ab, bb = fo.apply_dirichlet(K, b, np.concatenate([top, bot]), 0.0, True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(ref).max() > 0.1
+    assert np.abs(T - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.all(T[top] == 0.0)                      # the source on the Dirichlet wall is overwritten, as in DOLFIN
+    # a single PointSource object is accepted as well
+    s2, m2 = _box_heat_settings(4)
+    s2['point_source'] = PointSource(s2['function_space'], Point(0.5, 0.5, 0.5), 3.0)
+    T2 = ScalarTransportSolver(s2).solve().vector().array()
+    assert np.all(np.isfinite(T2)) and T2.max() > 360.0      # heated above the hot wall near the source
