@@ -16,6 +16,10 @@ from ._lib import BackendError  # noqa: F401  (re-export)
 
 
 def init(device_id=0):
+    # FS_DEVICE pins every rank to one device: test-only (several ranks sharing a GPU, if RCCL accepts it)
+    import os
+    if os.environ.get("FS_DEVICE", "") != "":
+        device_id = int(os.environ["FS_DEVICE"])
     L.check(L.load().fs_init(int(device_id)), "fs_init")
 
 

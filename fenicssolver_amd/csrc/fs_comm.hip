@@ -13,6 +13,12 @@
 #include "fs_common.h"
 #include <dlfcn.h>
 #include <stdlib.h>
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <rccl/rccl.h>
 
 struct rccl_api {
@@ -64,6 +70,57 @@ static int rccl_load() {
     return FS_OK;
 }
 
+// ---- test transport: host-staged exchange through POSIX shared memory ---------------------------------------
+// FS_COMM_TRANSPORT=shm replaces the RCCL calls by device<->host copies and a shared-memory mailbox, so that
+// SEVERAL RANKS CAN SHARE ONE GPU (RCCL refuses duplicate devices).  It exists to run the complete distributed
+// algorithm - partition, halo packing, ghost layout, fused dots + all-reduce, restarts - on the 1-GPU test
+// boxes; it is slow by construction and never selected unless the variable is set.
+struct shm_header {
+    std::atomic<int> arrive;
+    std::atomic<int> generation;
+};
+struct shm_comm {
+    int fd = -1;
+    char* base = nullptr;
+    size_t bytes = 0;
+    int n_ranks = 1, rank = 0;
+    char name[64] = {0};
+    static constexpr int64_t PAIR_CAP = 1 << 20;   // doubles per (src,dst) halo buffer
+    static constexpr int RED_CAP = 64;             // doubles per rank in the reduction mailbox
+    shm_header* hdr() { return (shm_header*)base; }
+    double* red(int r) { return (double*)(base + 4096) + (size_t)r * RED_CAP; }
+    double* pair(int src, int dst) {
+        return (double*)(base + 4096 + (size_t)n_ranks * RED_CAP * 8) + ((size_t)src * n_ranks + dst) * PAIR_CAP;
+    }
+    static size_t size_for(int n) { return 4096 + (size_t)n * RED_CAP * 8 + (size_t)n * n * PAIR_CAP * 8; }
+    void barrier() {
+        shm_header* h = hdr();
+        const int gen = h->generation.load(std::memory_order_acquire);
+        if (h->arrive.fetch_add(1, std::memory_order_acq_rel) == n_ranks - 1) {
+            h->arrive.store(0, std::memory_order_relaxed);
+            h->generation.store(gen + 1, std::memory_order_release);
+        } else {
+            while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
+        }
+    }
+};
+static bool g_use_shm() {
+    const char* t = getenv("FS_COMM_TRANSPORT");
+    return t && !strcmp(t, "shm");
+}
+static shm_comm* g_shm = nullptr;
+
+static int shm_open_segment(shm_comm* c, bool create) {
+    c->bytes = shm_comm::size_for(c->n_ranks);
+    c->fd = shm_open(c->name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (c->fd < 0) { fs_set_error("shm transport: shm_open(%s) failed", c->name); return FS_ERR_COMM; }
+    if (create && ftruncate(c->fd, (off_t)c->bytes) != 0) { fs_set_error("shm transport: ftruncate failed"); return FS_ERR_COMM; }
+    void* p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+    if (p == MAP_FAILED) { fs_set_error("shm transport: mmap of %zu bytes failed", c->bytes); return FS_ERR_COMM; }
+    c->base = (char*)p;
+    return FS_OK;
+}
+
 #define FS_NCCL(call)                                                                          \
     do {                                                                                       \
         ncclResult_t r__ = (call);                                                             \
@@ -77,6 +134,11 @@ static_assert(sizeof(ncclUniqueId) == FS_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
 extern "C" int fs_comm_get_unique_id(char id[FS_UNIQUE_ID_BYTES]) {
     FS_CHECK(fs_require_init());
+    if (g_use_shm()) {     // the id is the name of the segment; it is created by fs_comm_init of rank 0
+        memset(id, 0, FS_UNIQUE_ID_BYTES);
+        snprintf(id, 64, "/fsamd_%d_%ld", (int)getpid(), (long)time(nullptr));
+        return FS_OK;
+    }
     FS_CHECK(rccl_load());
     ncclUniqueId uid;
     FS_NCCL(g_nccl.GetUniqueId(&uid));
@@ -89,6 +151,41 @@ extern "C" int fs_comm_init(int n_ranks, int rank, const char id[FS_UNIQUE_ID_BY
     FS_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks && id, "fs_comm_init: bad rank %d of %d", rank, n_ranks);
     fs_runtime& rt = fs_rt();
     FS_REQUIRE(rt.comm == nullptr, "fs_comm_init: communicator already initialised");
+    if (g_use_shm()) {
+        FS_REQUIRE(n_ranks <= 4, "shm test transport: at most 4 ranks");
+        shm_comm* c = new shm_comm();
+        c->n_ranks = n_ranks; c->rank = rank;
+        strncpy(c->name, id, 63);
+        // rank 0 creates and zeroes the segment, the others wait until it exists with its full size
+        int rc = FS_ERR_COMM;
+        if (rank == 0) {
+            rc = shm_open_segment(c, true);
+            if (rc == FS_OK) { c->hdr()->arrive.store(0); c->hdr()->generation.store(1000); }
+        } else {
+            for (int tries = 0; tries < 20000 && rc != FS_OK; ++tries) {
+                c->fd = shm_open(c->name, O_RDWR, 0600);
+                if (c->fd >= 0) {
+                    struct stat st;
+                    if (fstat(c->fd, &st) == 0 && (size_t)st.st_size == shm_comm::size_for(n_ranks)) {
+                        close(c->fd);
+                        rc = shm_open_segment(c, false);
+                        if (rc == FS_OK)
+                            while (c->hdr()->generation.load() < 1000) usleep(100);
+                        break;
+                    }
+                    close(c->fd);
+                }
+                usleep(500);
+            }
+        }
+        if (rc != FS_OK) { delete c; if (rc == FS_ERR_COMM && !*fs_last_error()) fs_set_error("shm transport: rendezvous failed"); return rc; }
+        g_shm = c;
+        rt.comm = (void*)c;
+        rt.n_ranks = n_ranks;
+        rt.rank = rank;
+        c->barrier();
+        return FS_OK;
+    }
     FS_CHECK(rccl_load());
     ncclUniqueId uid;
     memcpy(&uid, id, FS_UNIQUE_ID_BYTES);
@@ -108,7 +205,16 @@ extern "C" int fs_comm_info(int* n_ranks, int* rank) {
 
 extern "C" int fs_comm_finalize(void) {
     fs_runtime& rt = fs_rt();
-    if (rt.comm) {
+    if (rt.comm && g_shm) {
+        (void)hipStreamSynchronize(rt.stream);
+        g_shm->barrier();
+        munmap(g_shm->base, g_shm->bytes);
+        close(g_shm->fd);
+        if (g_shm->rank == 0) shm_unlink(g_shm->name);
+        delete g_shm;
+        g_shm = nullptr;
+        rt.comm = nullptr;
+    } else if (rt.comm) {
         (void)hipStreamSynchronize(rt.stream);
         FS_NCCL(g_nccl.CommDestroy((ncclComm_t)rt.comm));
         rt.comm = nullptr;
@@ -121,6 +227,23 @@ extern "C" int fs_comm_finalize(void) {
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     if (!rt.comm) return FS_OK;  // one rank
+    if (g_shm) {
+        FS_REQUIRE(n <= shm_comm::RED_CAP, "shm test transport: reduction of %d values", n);
+        double h[shm_comm::RED_CAP];
+        FS_HIP(hipMemcpyAsync(h, d_inout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        FS_HIP(hipStreamSynchronize(s));
+        memcpy(g_shm->red(g_shm->rank), h, (size_t)n * sizeof(double));
+        g_shm->barrier();
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int r = 0; r < g_shm->n_ranks; ++r) acc += g_shm->red(r)[i];   // rank order: same bits everywhere
+            h[i] = acc;
+        }
+        g_shm->barrier();
+        FS_HIP(hipMemcpyAsync(d_inout, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     FS_NCCL(g_nccl.AllReduce(d_inout, d_inout, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)rt.comm, s));
     return FS_OK;
 }
@@ -206,6 +329,21 @@ int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
     }
     FS_KERNEL_CHECK();
     double* ghosts = d_vec + space->n_dofs_owned;
+    if (g_shm) {
+        FS_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nn; ++i) {
+            if (h.send_counts[i] == 0) continue;
+            FS_REQUIRE(h.send_counts[i] <= shm_comm::PAIR_CAP, "shm test transport: halo of %lld values", (long long)h.send_counts[i]);
+            const double* src = h.send_contiguous[i] ? d_vec + h.send_first[i] : h.send_buf.p + h.send_offsets[i];
+            FS_HIP(hipMemcpy(g_shm->pair(g_shm->rank, h.neighbors[i]), src, (size_t)h.send_counts[i] * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        g_shm->barrier();
+        for (int i = 0; i < nn; ++i)
+            if (h.recv_counts[i] > 0)
+                FS_HIP(hipMemcpy(ghosts + h.recv_offsets[i], g_shm->pair(h.neighbors[i], g_shm->rank), (size_t)h.recv_counts[i] * sizeof(double), hipMemcpyHostToDevice));
+        g_shm->barrier();
+        return FS_OK;
+    }
     FS_NCCL(g_nccl.GroupStart());
     for (int i = 0; i < nn; ++i) {
         if (h.send_counts[i] > 0) {

@@ -1,0 +1,58 @@
+"""Several ranks on ONE GPU: the complete distributed algorithm (owner-computes partition, ghost layout, halo packing,
+fused dots + all-reduce, restarts, result gather) with real device kernels in every rank.  RCCL refuses two ranks on
+one device, so the library's shared-memory test transport (FS_COMM_TRANSPORT=shm, fs_comm.hip) carries the halo and
+the reductions; the RCCL calls themselves are covered by test_gpu_comm.py with the 1-rank communicator."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PORT = [29610]
+
+
+def _run(world, case, tmp_path):
+    out = str(tmp_path / ("%s_%d.npz" % (case, world)))
+    env = dict(os.environ, FS_DEVICE="0", FS_COMM_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    PORT[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, case]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
+    nx, ny, nz, axis = 9, 7, 23, 0
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 2.0), nx, ny, nz)
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0))
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    b = gpu.DeviceVector(V.n_owned)
+    x = gpu.DeviceVector(V.n_local)
+    A.assemble(stiffness=20.0)
+    gpu.assemble_vector(V, b, source=3.0)
+    lo, hi = np.nonzero(co[:, axis] == 0)[0], np.nonzero(co[:, axis] == co[:, axis].max())[0]
+    A.apply_dirichlet(b, np.concatenate([lo, hi]).astype(np.int32),
+                      np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+    r = _run(world, "box", tmp_path)
+    assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10
+    assert abs(int(r["iterations"]) - st["iterations"]) <= 2          # reduction order differs, the recurrence does not
+    assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
+
+
+@pytest.mark.parametrize("case", ["heat", "heat_cn", "elasticity"])
+def test_solver_classes_under_two_ranks(gpu, tmp_path, case):
+    """`python -m torch.distributed.run --nproc-per-node 2 script.py` with the reference-style solver classes:
+    same field as the single-process run, gathered on every rank."""
+    import test_gpu_parallel_api as T
+    single = T.CASES[case]().solve().vector().get_local()
+    r = _run(2, case, tmp_path)
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
