@@ -22,6 +22,58 @@
 #include <stdlib.h>
 
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
+// One round of N entries of a scalar row: all 2N loads are issued before the first FMA, so the latency of a
+// round is one memory round trip whatever N is.  The remainder of a row (width % UNROLL entries) goes through
+// the same code with N = remainder (compile-time if-chain) instead of a serial tail loop - on the 15-wide
+// rows of a P1 Kuhn mesh a serial tail is 3 of the 6 round trips at UNROLL = 4.
+template <int N>
+__device__ __forceinline__ void dia_round(const double* __restrict__ vp, const int32_t* __restrict__ op, int k, int32_t r,
+                                          int32_t cmax, const double* __restrict__ x, double& acc) {
+    double v[N], xv[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        int32_t c = r + op[k + u];
+        c = c < 0 ? 0 : (c > cmax ? cmax : c);
+        xv[u] = x[c];
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
+}
+template <int N>
+__device__ __forceinline__ void sell_round(const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
+                                           const double* __restrict__ x, double& acc) {
+    int32_t c[N];
+    double v[N], xv[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+#pragma unroll
+    for (int u = 0; u < N; ++u) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
+}
+template <int N>
+struct row_tail {
+    static __device__ __forceinline__ void dia(int rem, const double* __restrict__ vp, const int32_t* __restrict__ op, int k,
+                                               int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
+        if (rem == N) dia_round<N>(vp, op, k, r, cmax, x, acc);
+        else row_tail<N - 1>::dia(rem, vp, op, k, r, cmax, x, acc);
+    }
+    static __device__ __forceinline__ void sell(int rem, const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
+                                                const double* __restrict__ x, double& acc) {
+        if (rem == N) sell_round<N>(vp, cp, k, x, acc);
+        else row_tail<N - 1>::sell(rem, vp, cp, k, x, acc);
+    }
+};
+template <>
+struct row_tail<0> {
+    static __device__ __forceinline__ void dia(int, const double*, const int32_t*, int, int32_t, int32_t, const double*, double&) {}
+    static __device__ __forceinline__ void sell(int, const double*, const int32_t*, int, const double*, double&) {}
+};
+
 template <int BS, int DOTS, int UNROLL>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                         const int64_t* __restrict__ slice_ptr,
@@ -71,19 +123,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             const int32_t* __restrict__ op = dia_off + dp;
             int k = 0;
             if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) {
-                    double v[UNROLL], xv[UNROLL];
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) {
-                        int32_t c = (int32_t)r + op[k + u];
-                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
-                        xv[u] = x[c];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) acc[0] += v[u] * xv[u];
-                }
+                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL>(vp, op, k, (int32_t)r, cmax, x, acc[0]);
+                row_tail<UNROLL - 1>::dia(width - k, vp, op, k, (int32_t)r, cmax, x, acc[0]);
+                k = width;
             }
             for (; k < width; ++k) {
                 int64_t c = r + op[k];
@@ -98,18 +140,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
         } else {
             int k = 0;
             if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) {
-                    int32_t c[UNROLL];
-                    double v[UNROLL], xv[UNROLL];
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) acc[0] += v[u] * xv[u];
-                }
+                for (; k + UNROLL <= width; k += UNROLL) sell_round<UNROLL>(vp, cp, k, x, acc[0]);
+                row_tail<UNROLL - 1>::sell(width - k, vp, cp, k, x, acc[0]);
+                k = width;
             }
             for (; k < width; ++k) {
                 const int64_t c = fs_col_decode(cp[(int64_t)k * FS_SLICE]);
@@ -619,6 +652,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict_
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
 static int g_spmv_blocks = 1024;
 static int g_spmv_unroll = 4;
+static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
@@ -629,9 +663,11 @@ extern "C" int fs_set_option(const char* name, double value) {
     if (!strcmp(name, "spmv_blocks")) {
         FS_REQUIRE(value >= 8 && value <= FS_MAX_PARTIAL_BLOCKS, "spmv_blocks must be in [8,%d]", FS_MAX_PARTIAL_BLOCKS);
         g_spmv_blocks = (int)value;
+        g_spmv_blocks_pinned = true;
     } else if (!strcmp(name, "spmv_unroll")) {
         FS_REQUIRE(value == 2 || value == 4 || value == 8 || value == 16, "spmv_unroll must be 2, 4, 8 or 16");
         g_spmv_unroll = (int)value;
+        g_spmv_unroll_pinned = true;
     } else if (!strcmp(name, "spmv_unroll4")) {
         FS_REQUIRE(value == 1 || value == 2 || value == 4, "spmv_unroll4 must be 1, 2 or 4");
         g_spmv_unroll4 = (int)value;
@@ -650,9 +686,22 @@ extern "C" int fs_set_option(const char* name, double value) {
     return FS_OK;
 }
 
+// Launch shape, unless fs_set_option pinned it (tools/tune_spmv.py + bench.py on MI355X, round 1): 1024 workgroups
+// with 4-entry rounds for the 1 M-DOF class that lives in the Infinity Cache (more workgroups make the SpMV 1 us
+// faster but the update kernel, which re-reduces the per-workgroup dot partials, 3 us slower); 512 workgroups
+// with 16-entry rounds for HBM-resident sizes (-3 % solve time at 10 M DOF).
+static int spmv_blocks_for(int64_t n_slices) {
+    if (g_spmv_blocks_pinned) return g_spmv_blocks;
+    return n_slices <= 32768 ? 1024 : 512;
+}
+static int spmv_unroll_for(int64_t n_slices) {
+    if (g_spmv_unroll_pinned) return g_spmv_unroll;
+    return n_slices <= 32768 ? 4 : 16;
+}
 static int spmv_grid(int64_t n_slices) {
     const int64_t n_chunks = (n_slices + 3) / 4;
-    int64_t g = n_chunks < g_spmv_blocks ? n_chunks : g_spmv_blocks;
+    const int64_t blocks = spmv_blocks_for(n_slices);
+    int64_t g = n_chunks < blocks ? n_chunks : blocks;
     g = (g + 7) & ~(int64_t)7;  // multiple of 8 for the XCD mapping
     return (int)g;
 }
@@ -665,7 +714,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int grid = spmv_grid(sp->n_slices);
 #define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status
     if (A->bs == 1) {
-        switch (g_spmv_unroll) {
+        switch (spmv_unroll_for(sp->n_slices)) {
             case 2: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 2>), FS_SPMV_ARGS); break;
             case 8: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 8>), FS_SPMV_ARGS); break;
             case 16: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16>), FS_SPMV_ARGS); break;
