@@ -534,8 +534,7 @@ class SolverBase():
         else:   # every rank ends with the full field, gathered by global vertex id
             from . import parallel
             ncomp = u.function_space()._ncomp
-            u.vector().set_local(parallel.gather_owned(x.get(), loc.part.l2g[:loc.part.n_owned],
-                                                       loc.n_global, ncomp))
+            u.vector().set_local(parallel.gather_owned(x.get(), loc.owned_gids(), loc.n_global, ncomp))
         return u
 
     @staticmethod
@@ -808,14 +807,22 @@ class SolverBase():
         w[dofs] = vals
         w[F.space.dummy_dofs()] = 0.0
         history, krylov = [], 0
+        timing = os.environ.get("FS_NS_TIMING") is not None
+        tm = {"assemble": 0.0, "residual": 0.0, "dirichlet": 0.0, "krylov": 0.0, "update": 0.0}
+        clock = time.perf_counter
         for it in range(max_it + 1):
+            t0 = clock()
             dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=True)
+            t1 = clock()
             r = backend.DeviceVector(V.n_owned)
             ctx['J'].spmv(dw, r)
             r.axpy(-1.0, g)                                   # R(w) = J w - g
             res = r.get()
             res[dofs] = 0.0
             rn = float(np.linalg.norm(res))
+            t2 = clock()
+            tm["assemble"] += t1 - t0
+            tm["residual"] += t2 - t1
             history.append(rn)
             self.logger.info("Newton iteration %d: r (abs) = %.3e (tol = %.3e) r (rel) = %.3e (tol = %.3e)", it, rn, atol,
                              rn / max(history[0], 1e-300), rtol)
@@ -823,12 +830,21 @@ class SolverBase():
                 break
             if it == max_it:
                 raise SolverError('Newton solver did not converge in {} iterations: {}'.format(max_it, history))
+            t3 = clock()
             rhs = backend.DeviceVector(V.n_owned, -res)
             ctx['J'].apply_dirichlet(rhs, dofs, np.zeros(len(dofs)), symmetric=False)
+            t4 = clock()
             x = backend.DeviceVector(V.n_local)
             st = self._navier_stokes_krylov(F, ctx, ctx['J'], rhs, x, lin_rtol, False)
             krylov += st['iterations']
+            t5 = clock()
             w = w + relax * x.get()
+            t6 = clock()
+            tm["dirichlet"] += t4 - t3
+            tm["krylov"] += t5 - t4
+            tm["update"] += t6 - t5
+        if timing:
+            self.logger.warning("Newton timing [s]: %s", {k: round(v, 4) for k, v in tm.items()})
         self.newton_history = history
         self.newton_krylov_iterations = krylov
         u_current.vector().set_local(w)

@@ -63,7 +63,7 @@ class DeviceMesh(_Handle):
     """Tetrahedral mesh resident in HBM (dolfin.Mesh, SolverBase.py:203-258)."""
     _destroy = "fs_mesh_destroy"
 
-    def __init__(self, coords=None, cells=None, n_owned=None):
+    def __init__(self, coords=None, cells=None, n_owned=None, global_ids=None):
         super().__init__()
         if coords is None:
             return
@@ -78,6 +78,11 @@ class DeviceMesh(_Handle):
         L.check(L.load().fs_mesh_create(coords.shape[1], nv, L.p_f64(coords), cells.shape[0], L.p_i32(cells),
                                         cells.shape[1], int(n_owned), C.byref(self.h)), "fs_mesh_create")
         self._keep = None
+        if global_ids is not None:
+            g = L.i64(global_ids)
+            if g.shape != (nv,):
+                raise BackendError("DeviceMesh: global_ids must have one entry per local vertex")
+            L.check(L.load().fs_mesh_set_global_ids(self.h, L.p_i64(g)), "fs_mesh_set_global_ids")
 
     @classmethod
     def box(cls, nx, ny, nz, p0=(0.0, 0.0, 0.0), p1=(1.0, 1.0, 1.0), zplanes=None):
@@ -130,14 +135,20 @@ class DeviceSpace(_Handle):
             L.check(L.load().fs_space_get_edges(self.h, C.byref(ne), L.p_i32(out)), "fs_space_get_edges")
         return out
 
-    def set_halo(self, neighbors, send_lists, recv_counts):
-        """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour."""
+    def set_halo(self, neighbors, send_lists, recv_counts, recv_lists=None):
+        """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour;
+        recv_lists: per neighbour the local ghost dof of every received value (None: ghosts grouped by neighbour)."""
         nb = L.i32(neighbors)
         sc = L.i64([len(s) for s in send_lists])
         si = L.i32(np.concatenate([np.asarray(s, dtype=np.int32) for s in send_lists]) if len(send_lists) else [])
         rc = L.i64(recv_counts)
-        L.check(L.load().fs_space_set_halo(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc)),
-                "fs_space_set_halo")
+        if recv_lists is None:
+            L.check(L.load().fs_space_set_halo(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc)),
+                    "fs_space_set_halo")
+        else:
+            ri = L.i32(np.concatenate([np.asarray(r, dtype=np.int32) for r in recv_lists]) if len(recv_lists) else [])
+            L.check(L.load().fs_space_set_halo_indexed(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc),
+                                                       L.p_i32(ri)), "fs_space_set_halo_indexed")
 
 
 class DeviceVector(_Handle):

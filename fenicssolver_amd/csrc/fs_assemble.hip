@@ -249,7 +249,7 @@ template <bool ADD>
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
-    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cell_dofs, const double* __restrict__ xyz4,
+    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
     coef_dev kc, coef_dev mc, double* __restrict__ val) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
             if (q < 0) continue;
             const int c = q / 10, a = q - 10 * c;
             const uint32_t pw[3] = {inc_pos[e], inc_pos[inc_entries + e], inc_pos[2 * inc_entries + e]};
-            const int32_t vv[4] = {cell_dofs[(int64_t)c * 10], cell_dofs[(int64_t)c * 10 + 1],
-                                   cell_dofs[(int64_t)c * 10 + 2], cell_dofs[(int64_t)c * 10 + 3]};
+            const int4 c4 = reinterpret_cast<const int4*>(cells)[c];      // vertex ids (node ids differ once ghosts exist)
+            const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
             const tet_geom t = tet_geometry(xyz4, vv);
             const double vol = t.adet * (1.0 / 6.0);
             double row[10];
@@ -315,28 +315,31 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
 
 // P2 load vector: int f phi_a dx; constant / per-cell f: V * (-1/20 vertex, 1/5 edge); nodal (P2) f: M_e f_e
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* __restrict__ cell_dofs,
+                                                                 const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
-                                                                 coef_dev f, double* __restrict__ b) {
+                                                                 int64_t n_rows, coef_dev f, double* __restrict__ b) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
         int32_t d[10];
         for (int a = 0; a < 10; ++a) d[a] = cell_dofs[c * 10 + a];
-        const int32_t vv[4] = {d[0], d[1], d[2], d[3]};
+        const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
         const tet_geom t = tet_geometry(xyz4, vv);
         const double vol = t.adet * (1.0 / 6.0);
         if (f.mode == FS_COEF_NODAL) {
             double fe[10];
             for (int a = 0; a < 10; ++a) fe[a] = f.data[d[a]];
             for (int a = 0; a < 10; ++a) {
+                if (d[a] >= n_rows) continue;          // rows of other ranks
                 double acc = 0.0;
                 for (int k = 0; k < 10; ++k) acc += FS_P2_MASS420[a][k] * fe[k];
                 atomicAdd(&b[d[a]], acc * vol * (1.0 / 420.0));
             }
         } else {
             const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
-            for (int a = 0; a < 4; ++a) atomicAdd(&b[d[a]], -0.05 * ff);
-            for (int a = 4; a < 10; ++a) atomicAdd(&b[d[a]], 0.2 * ff);
+            for (int a = 0; a < 4; ++a) if (d[a] < n_rows) atomicAdd(&b[d[a]], -0.05 * ff);
+            for (int a = 4; a < 10; ++a) if (d[a] < n_rows) atomicAdd(&b[d[a]], 0.2 * ff);
         }
     }
 }
@@ -344,7 +347,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* 
 // P2 boundary load: int g phi_a ds over a facet = g * area / 3 on each of its 3 edge nodes, 0 on the vertices
 __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
                                   const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne,
-                                  int grouped, int64_t nv, double* __restrict__ b, int* __restrict__ err) {
+                                  int grouped, const int32_t* __restrict__ edge_node, int64_t n_rows,
+                                  double* __restrict__ b, int* __restrict__ err) {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; f < nf; f += stride) {
@@ -360,8 +364,11 @@ __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t
                 const int64_t mid = (lo + hi) >> 1;
                 if (edge_keys[mid] < key) lo = mid + 1; else hi = mid;
             }
-            if (lo < ne && edge_keys[lo] == key) atomicAdd(&b[nv + lo], w);
-            else atomicAdd(err, 1);
+            if (lo < ne && edge_keys[lo] == key) {
+                if (edge_node[lo] < n_rows) atomicAdd(&b[edge_node[lo]], w);     // edge rows of other ranks: theirs to add
+            } else {
+                atomicAdd(err, 1);
+            }
         }
     }
 }
@@ -716,9 +723,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (add)
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, sp->cell_dofs, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
         else
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, sp->cell_dofs, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
     } else if (A->bs == 1 && sp->inc_cell.p) {
         // row-gather path: every SELL entry (padding included) is written exactly once, no memset
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
@@ -775,7 +782,7 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     }
     if (space->degree == 2) {
         FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
-        hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->xyz.p, m->nc, f, b->d.p);
+        hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
@@ -804,7 +811,7 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
         dbuf<int> d_err;
         FS_CHECK(d_err.alloc(1));
         FS_CHECK(d_err.zero(s));
-        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->mesh->nv, b->d.p, d_err.p);
+        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, b->d.p, d_err.p);
         FS_KERNEL_CHECK();
         int h_err = 0;
         FS_CHECK(d_err.download(&h_err, 1, s));

@@ -269,15 +269,36 @@ __global__ void k_pack(const double* __restrict__ v, const int32_t* __restrict__
     for (; i < n; i += stride) out[i] = v[idx[i]];
 }
 
+__global__ void k_unpack(double* __restrict__ v, const int32_t* __restrict__ idx, int64_t n, const double* __restrict__ in) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) v[idx[i]] = in[i];
+}
+
+static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
+                         const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
+
+extern "C" int fs_space_set_halo_indexed(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks,
+                                         const int64_t* send_counts, const int32_t* send_idx, const int64_t* recv_counts,
+                                         const int32_t* recv_idx) {
+    FS_REQUIRE(n_neighbors == 0 || recv_idx, "fs_space_set_halo_indexed: null scatter list");
+    return set_halo_impl(space, n_neighbors, neighbor_ranks, send_counts, send_idx, recv_counts, recv_idx);
+}
+
 extern "C" int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks,
                                  const int64_t* send_counts, const int32_t* send_idx, const int64_t* recv_counts) {
+    return set_halo_impl(space, n_neighbors, neighbor_ranks, send_counts, send_idx, recv_counts, nullptr);
+}
+
+static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks,
+                         const int64_t* send_counts, const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(space && n_neighbors >= 0, "fs_space_set_halo: bad arguments");
     fs_halo_plan& h = space->halo;
     h.active = false;
     h.neighbors.clear(); h.send_counts.clear(); h.send_offsets.clear(); h.recv_counts.clear();
     h.recv_offsets.clear(); h.send_contiguous.clear(); h.send_first.clear();
-    h.send_idx.release(); h.send_buf.release();
+    h.send_idx.release(); h.send_buf.release(); h.recv_idx.release(); h.recv_buf.release();
     h.total_send = h.total_recv = 0;
     if (n_neighbors == 0) return FS_OK;
     FS_REQUIRE(neighbor_ranks && send_counts && send_idx && recv_counts, "fs_space_set_halo: null pointer");
@@ -308,6 +329,14 @@ extern "C" int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_
     FS_CHECK(h.send_idx.alloc(so));
     FS_CHECK(h.send_buf.alloc(so));
     FS_CHECK(h.send_idx.upload(send_idx, so, fs_rt().stream));
+    if (recv_idx) {
+        for (int64_t k = 0; k < ro; ++k)
+            FS_REQUIRE(recv_idx[k] >= space->n_dofs_owned && recv_idx[k] < space->n_dofs_local,
+                       "fs_space_set_halo_indexed: scatter index %d is not a ghost dof", recv_idx[k]);
+        FS_CHECK(h.recv_idx.alloc(ro));
+        FS_CHECK(h.recv_buf.alloc(ro));
+        FS_CHECK(h.recv_idx.upload(recv_idx, ro, fs_rt().stream));
+    }
     h.active = true;
     return FS_OK;
 }
@@ -338,10 +367,15 @@ int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
             FS_HIP(hipMemcpy(g_shm->pair(g_shm->rank, h.neighbors[i]), src, (size_t)h.send_counts[i] * sizeof(double), hipMemcpyDeviceToHost));
         }
         g_shm->barrier();
+        double* rbase = h.recv_idx.p ? h.recv_buf.p : ghosts;
         for (int i = 0; i < nn; ++i)
             if (h.recv_counts[i] > 0)
-                FS_HIP(hipMemcpy(ghosts + h.recv_offsets[i], g_shm->pair(h.neighbors[i], g_shm->rank), (size_t)h.recv_counts[i] * sizeof(double), hipMemcpyHostToDevice));
+                FS_HIP(hipMemcpy(rbase + h.recv_offsets[i], g_shm->pair(h.neighbors[i], g_shm->rank), (size_t)h.recv_counts[i] * sizeof(double), hipMemcpyHostToDevice));
         g_shm->barrier();
+        if (h.recv_idx.p && h.total_recv > 0) {
+            hipLaunchKernelGGL(k_unpack, dim3(fs_grid_for(h.total_recv)), dim3(FS_BLOCK), 0, s, d_vec, h.recv_idx.p, h.total_recv, h.recv_buf.p);
+            FS_KERNEL_CHECK();
+        }
         return FS_OK;
     }
     FS_NCCL(g_nccl.GroupStart());
@@ -351,10 +385,14 @@ int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
             FS_NCCL(g_nccl.Send(src, (size_t)h.send_counts[i], ncclDouble, h.neighbors[i], (ncclComm_t)rt.comm, s));
         }
         if (h.recv_counts[i] > 0)
-            FS_NCCL(g_nccl.Recv(ghosts + h.recv_offsets[i], (size_t)h.recv_counts[i], ncclDouble, h.neighbors[i],
-                                (ncclComm_t)rt.comm, s));
+            FS_NCCL(g_nccl.Recv((h.recv_idx.p ? h.recv_buf.p : ghosts) + h.recv_offsets[i], (size_t)h.recv_counts[i], ncclDouble,
+                                h.neighbors[i], (ncclComm_t)rt.comm, s));
     }
     FS_NCCL(g_nccl.GroupEnd());
+    if (h.recv_idx.p && h.total_recv > 0) {
+        hipLaunchKernelGGL(k_unpack, dim3(fs_grid_for(h.total_recv)), dim3(FS_BLOCK), 0, s, d_vec, h.recv_idx.p, h.total_recv, h.recv_buf.p);
+        FS_KERNEL_CHECK();
+    }
     return FS_OK;
 }
 

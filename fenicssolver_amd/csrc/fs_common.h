@@ -118,6 +118,8 @@ struct fs_halo_plan {
     std::vector<int64_t> send_first;       // first index of that range
     dbuf<int32_t> send_idx;                // concatenated
     dbuf<double> send_buf;                 // packed values (non-contiguous lists)
+    dbuf<int32_t> recv_idx;                // optional scatter list (local dof of every received value)
+    dbuf<double> recv_buf;
     int64_t total_send = 0, total_recv = 0;
 };
 
@@ -134,6 +136,11 @@ struct fs_space_s {
     dbuf<int32_t> edges;          // [n_edges][2] (P2 only), ascending vertex pairs, in edge-node order
     dbuf<uint64_t> edge_keys;     // [n_edges] sorted search keys of the edge nodes
     int edge_grouped = 0;         // 0: key = (v0<<32|v1); 1: key = ((v1-v0)<<32|v0)  (<= 16 distinct v1-v0)
+    // P2 node numbering: [owned vertices | owned edges | ghost vertices | ghost edges].  An edge is owned by the
+    // rank that owns its endpoint of smaller GLOBAL id (that rank has every cell of the edge).  edge_node[i] =
+    // node id of the edge at position i of the sorted key table; one GPU: nv + i.
+    int64_t n_edges_owned = 0;
+    dbuf<int32_t> edge_node;      // [n_edges]
     int64_t n_nodes_local = 0, n_nodes_owned = 0;  // node level
     int64_t n_dofs_local = 0, n_dofs_owned = 0;    // = nodes * ncomp
     // node-level sparsity: CSR + hybrid SELL-64 / per-slice DIA

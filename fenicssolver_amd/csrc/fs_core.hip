@@ -360,6 +360,12 @@ extern "C" int fs_mesh_create_box(int64_t nx, int64_t ny, int64_t nz, const doub
     return FS_OK;
 }
 
+extern "C" int fs_mesh_set_global_ids(fs_mesh_t mesh, const int64_t* global_ids) {
+    FS_REQUIRE(mesh && global_ids, "fs_mesh_set_global_ids: null pointer");
+    FS_CHECK(mesh->gid.upload(global_ids, mesh->nv, fs_rt().stream));
+    return FS_OK;
+}
+
 extern "C" int fs_mesh_info(fs_mesh_t mesh, int64_t* nv, int64_t* nc, int64_t* n_owned) {
     FS_REQUIRE(mesh, "fs_mesh_info: null mesh");
     if (nv) *nv = mesh->nv;

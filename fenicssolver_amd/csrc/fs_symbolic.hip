@@ -69,16 +69,44 @@ __global__ void k_edge_table(const uint64_t* __restrict__ ukeys, int64_t ne, int
     }
 }
 
-// cell_dofs[c] = {4 vertices, nv + index of each of the 6 edges in the sorted unique edge keys}
-__global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, int64_t nv,
+// ghost flag of every unique edge: owned iff its endpoint of smaller global id is an owned vertex
+__global__ void k_edge_ghost_flag(const uint64_t* __restrict__ ukeys, int64_t ne, int grouped, const int64_t* __restrict__ gid,
+                                  int64_t n_owned, int32_t* __restrict__ flag, int32_t* __restrict__ index) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < ne; i += stride) {
+        const uint32_t hi32 = (uint32_t)(ukeys[i] >> 32), lo32 = (uint32_t)(ukeys[i] & 0xffffffffULL);
+        const int32_t v0 = (int32_t)(grouped ? lo32 : hi32), v1 = (int32_t)(grouped ? lo32 + hi32 : lo32);
+        const int32_t vmin = gid[v0] < gid[v1] ? v0 : v1;
+        flag[i] = vmin < n_owned ? 0 : 1;
+        index[i] = (int32_t)i;
+    }
+}
+// order[j] = sorted-key position of the j-th edge in node order (owned first) -> edge_node and the edge table
+__global__ void k_edge_nodes(const int32_t* __restrict__ order, int64_t ne, int64_t neo, int64_t nvo, int64_t nv,
+                             const uint64_t* __restrict__ ukeys, int grouped, int32_t* __restrict__ edge_node,
+                             int32_t* __restrict__ edges) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; j < ne; j += stride) {
+        const int32_t i = order[j];
+        edge_node[i] = (int32_t)(j < neo ? nvo + j : nv + j);     // ghost edges sit after the ghost vertices
+        const uint32_t hi32 = (uint32_t)(ukeys[i] >> 32), lo32 = (uint32_t)(ukeys[i] & 0xffffffffULL);
+        edges[2 * j] = (int32_t)(grouped ? lo32 : hi32);
+        edges[2 * j + 1] = (int32_t)(grouped ? lo32 + hi32 : lo32);
+    }
+}
+
+// cell_dofs[c] = {nodes of the 4 vertices, node of each of the 6 edges (edge_node of its sorted-key position)}
+__global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, int64_t nvo, int64_t neo,
                                const uint64_t* __restrict__ ukeys, int64_t ne, int grouped,
-                               int32_t* __restrict__ cell_dofs) {
+                               const int32_t* __restrict__ edge_node, int32_t* __restrict__ cell_dofs) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
         const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
         const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-        for (int a = 0; a < 4; ++a) cell_dofs[c * 10 + a] = v[a];
+        for (int a = 0; a < 4; ++a) cell_dofs[c * 10 + a] = v[a] < nvo ? v[a] : (int32_t)(v[a] + neo);
         for (int e = 0; e < 6; ++e) {
             const uint64_t key = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
             int64_t lo = 0, hi = ne;
@@ -86,7 +114,7 @@ __global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, in
                 const int64_t mid = (lo + hi) >> 1;
                 if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
             }
-            cell_dofs[c * 10 + 4 + e] = (int32_t)(nv + lo);
+            cell_dofs[c * 10 + 4 + e] = edge_node[lo];
         }
     }
 }
@@ -390,8 +418,8 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
     hipStream_t s = fs_rt().stream;
     const int64_t nc = mesh->nc;
     FS_REQUIRE(mesh->n_owned > 0, "fs_space_create: process owns no vertices");
-    if (degree == 2 && mesh->n_owned != mesh->nv) {
-        fs_set_error("fs_space_create: CG2 spaces are single-GPU for now (the mesh has ghost vertices)");
+    if (degree == 2 && ncomp != 1 && mesh->n_owned != mesh->nv) {
+        fs_set_error("fs_space_create: the Taylor-Hood block space is single-GPU for now (the mesh has ghost vertices)");
         return FS_ERR_UNSUPPORTED;
     }
     fs_space_s* sp = new fs_space_s();
@@ -469,16 +497,45 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         sp->n_edges = h_ne;
         FS_SP(sp->edges.alloc(2 * (int64_t)h_ne));
         FS_SP(sp->edge_keys.alloc(h_ne));
+        FS_SP(sp->edge_node.alloc(h_ne));
         FS_SP(sp->cell_dofs_store.alloc(10 * nc));
         FS_SP_HIP(hipMemcpyAsync(sp->edge_keys.p, ka.p, (size_t)h_ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_edge_table, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->edges.p);
-        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->nv, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->cell_dofs_store.p);
+        // owned edges first (stable: key order inside each class)
+        int h_neo = h_ne;
+        {
+            dbuf<int32_t> flag, flag2, idx, order;
+            FS_SP(flag.alloc(h_ne)); FS_SP(flag2.alloc(h_ne)); FS_SP(idx.alloc(h_ne)); FS_SP(order.alloc(h_ne));
+            hipLaunchKernelGGL(k_edge_ghost_flag, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, ka.p, (int64_t)h_ne, sp->edge_grouped, mesh->gid.p, mesh->n_owned, flag.p, idx.p);
+            FS_SP_HIP(hipGetLastError());
+            size_t tbs = 0;
+            FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tbs, flag.p, flag2.p, idx.p, order.p, h_ne, 0, 1, s));
+            dbuf<char> tmps;
+            FS_SP(tmps.alloc((int64_t)tbs + 16));
+            FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(tmps.p, tbs, flag.p, flag2.p, idx.p, order.p, h_ne, 0, 1, s));
+            if (mesh->n_owned != mesh->nv) {
+                size_t tbr = 0;
+                dbuf<int32_t> dsum;
+                FS_SP(dsum.alloc(1));
+                FS_SP_HIP(hipcub::DeviceReduce::Sum(nullptr, tbr, flag.p, dsum.p, h_ne, s));
+                dbuf<char> tmpr;
+                FS_SP(tmpr.alloc((int64_t)tbr + 16));
+                FS_SP_HIP(hipcub::DeviceReduce::Sum(tmpr.p, tbr, flag.p, dsum.p, h_ne, s));
+                int32_t h_ghost = 0;
+                FS_SP(dsum.download(&h_ghost, 1, s));
+                h_neo = h_ne - h_ghost;
+            }
+            hipLaunchKernelGGL(k_edge_nodes, dim3(fs_grid_for(h_ne)), dim3(FS_BLOCK), 0, s, order.p, (int64_t)h_ne, (int64_t)h_neo, mesh->n_owned, mesh->nv, ka.p, sp->edge_grouped, sp->edge_node.p, sp->edges.p);
+            FS_SP_HIP(hipGetLastError());
+            FS_SP_HIP(hipStreamSynchronize(s));
+        }
+        sp->n_edges_owned = h_neo;
+        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->n_owned, (int64_t)h_neo, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->edge_node.p, sp->cell_dofs_store.p);
         FS_SP_HIP(hipGetLastError());
         FS_SP_HIP(hipStreamSynchronize(s));
         sp->ndof_cell = 10;
         sp->cell_dofs = sp->cell_dofs_store.p;
         sp->n_nodes_local = mesh->nv + h_ne;
-        sp->n_nodes_owned = sp->n_nodes_local;
+        sp->n_nodes_owned = mesh->n_owned + h_neo;
         FS_REQUIRE(sp->n_nodes_local < (int64_t)INT32_MAX, "fs_space_create: CG2 dof count exceeds int32");
     }
     sp->n_dofs_local = sp->n_nodes_local * ncomp;

@@ -586,19 +586,27 @@ class FunctionSpace:
         """This rank's share of the space: owner-computes vertex slabs along the longest axis,
         one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
         from . import partition
-        if root._degree != 1:
-            raise SolverError("multi-GPU decomposition is built for P1 spaces only (P2 is single-GPU for now)")
+        if root._degree == 2 and root._ncomp != 1:
+            raise SolverError("multi-GPU decomposition is built for P1 spaces and scalar P2 spaces")
         rank, size = parallel.ensure_comm()
         mesh = root._mesh
         co, ce = mesh.coordinates(), mesh.cells()
         axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
         owner = partition.slab_owner(co, size, axis=axis)
         part = partition.build_local_part(ce, owner, rank)
-        dm = backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned)
-        ds = backend.DeviceSpace(dm, root._ncomp, 1)
-        if size > 1:
-            ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
-        root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
+        dm = backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g)
+        ds = backend.DeviceSpace(dm, root._ncomp, root._degree)
+        if root._degree == 1:
+            if size > 1:
+                ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
+            root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
+        else:
+            plan = partition.build_p2_plan(ce, owner, rank, part, ds.edges(), root.edge_nodes())
+            if plan.n_owned_nodes != ds.n_owned:
+                raise SolverError("internal error: host and device disagree on the owned P2 nodes")
+            if size > 1:
+                ds.set_halo(plan.neighbors, plan.send_lists, plan.recv_counts, recv_lists=plan.recv_lists)
+            root._localizer = parallel.Localizer(part, mesh.num_vertices(), 1, p2_plan=plan, n_global_nodes=root.num_nodes())
         return ds
 
     def localizer(self):

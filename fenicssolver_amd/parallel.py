@@ -68,11 +68,26 @@ def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
 class Localizer:
     """Maps global host arrays (per cell / per node / dof lists / facet lists) to one rank's part."""
 
-    def __init__(self, part, n_global_nodes, ncomp):
+    def __init__(self, part, n_global_vertices, ncomp, p2_plan=None, n_global_nodes=None):
+        """p2_plan: partition.P2Plan of a CG2 space (node-level maps); P1 spaces use the vertex maps of the part."""
         self.part = part
         self.ncomp = ncomp
-        self.n_global = n_global_nodes
-        self.g2l = part.g2l(n_global_nodes)
+        self.n_global_vertices = n_global_vertices
+        self.g2l_vertex = part.g2l(n_global_vertices)
+        if p2_plan is None:
+            self.n_global = n_global_vertices
+            self.l2g = part.l2g
+            self.n_owned = part.n_owned
+        else:
+            self.n_global = int(n_global_nodes)
+            self.l2g = p2_plan.l2g_nodes
+            self.n_owned = p2_plan.n_owned_nodes
+        self.g2l = np.full(self.n_global, -1, dtype=np.int64)
+        self.g2l[self.l2g] = np.arange(len(self.l2g))
+
+    def owned_gids(self):
+        """Global node ids of the rows this rank owns, in local order."""
+        return self.l2g[:self.n_owned]
 
     def cells(self, arr):
         a = np.asarray(arr)
@@ -82,8 +97,8 @@ class Localizer:
         """Nodal array [n_global] or dof array [n_global*ncomp] -> local (owned + ghost) order."""
         a = np.asarray(arr)
         if a.shape[0] == self.n_global:
-            return a[self.part.l2g]
-        return a.reshape(self.n_global, -1)[self.part.l2g].reshape(-1)
+            return a[self.l2g]
+        return a.reshape(self.n_global, -1)[self.l2g].reshape(-1)
 
     def dofs(self, dofs, vals):
         d = np.asarray(dofs, dtype=np.int64)
@@ -96,7 +111,7 @@ class Localizer:
         """Facets with at least one owned vertex (their cell is local, so all three vertices are);
         returns (local vertex triples, mask into the input)."""
         t = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
-        loc = self.g2l[t]
+        loc = self.g2l_vertex[t]              # facets are given, and handed to the device, as vertex triples
         mask = ((loc >= 0) & (loc < self.part.n_owned)).any(axis=1)
         sel = loc[mask]
         if (sel < 0).any():

@@ -171,3 +171,79 @@ def slab_dirichlet(nx, ny, nz, layout, axis, lo_value=350.0, hi_value=300.0):
     if not dofs:
         return np.zeros(0, dtype=np.int32), np.zeros(0)
     return np.concatenate(dofs).astype(np.int32), np.concatenate(vals)
+
+
+# ---- CG2 (P2) spaces on a decomposed mesh -------------------------------------------------------------------
+_TET_EDGES = ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+
+
+class P2Plan:
+    """Node-level plan of a CG2 space on one rank's part.  Local node order (libfsamd.so, fs_space_create):
+    [owned vertices | owned edges | ghost vertices | ghost edges]; an edge belongs to the rank owning its endpoint
+    of smaller global id."""
+
+    def __init__(self, n_owned_nodes, l2g_nodes, neighbors, send_lists, recv_lists):
+        self.n_owned_nodes = n_owned_nodes
+        self.l2g_nodes = l2g_nodes          # [n_local_nodes] global node id (vertices, then n_global_vertices + global edge index)
+        self.neighbors = neighbors
+        self.send_lists = send_lists        # per neighbour: local node ids (owned) in the agreed order
+        self.recv_lists = recv_lists        # per neighbour: local node ids (ghost) in the same order
+        self.recv_counts = [len(r) for r in recv_lists]
+
+
+def _edge_keys(g0, g1, n_global):
+    lo, hi = np.minimum(g0, g1), np.maximum(g0, g1)
+    return lo.astype(np.int64) * n_global + hi
+
+
+def build_p2_plan(cells, owner, rank, part, local_edges, global_edges):
+    """cells [nc,4] / owner [nv]: the GLOBAL mesh and vertex owners; part: this rank's LocalPart; local_edges [ne,2]: the
+    device's edge table in node order (local vertex ids, owned edges first); global_edges [ne_g,2]: the host's global
+    edge-node table (FunctionSpace.edge_nodes()).  No communication: every rank derives both sides of each exchange
+    from the global mesh, ordered by (vertices by global id, then edges by (g0, g1))."""
+    cells = np.asarray(cells, dtype=np.int64)
+    owner = np.asarray(owner)
+    n_global = len(owner)
+    nv, nvo = part.n_local, part.n_owned
+    le = np.asarray(local_edges, dtype=np.int64).reshape(-1, 2)
+    g0 = np.minimum(part.l2g[le[:, 0]], part.l2g[le[:, 1]])
+    g1 = np.maximum(part.l2g[le[:, 0]], part.l2g[le[:, 1]])
+    e_owner = owner[g0]
+    neo = int((e_owner == rank).sum())
+    if not (np.all(e_owner[:neo] == rank) and np.all(e_owner[neo:] != rank)):
+        raise AssertionError("device edge table is not ordered owned-first")
+    ne = len(le)
+    node_of_vertex = np.where(np.arange(nv) < nvo, np.arange(nv), np.arange(nv) + neo)
+    node_of_edge = np.where(np.arange(ne) < neo, nvo + np.arange(ne), nv + np.arange(ne))
+    # global node ids
+    gkey = _edge_keys(np.asarray(global_edges)[:, 0], np.asarray(global_edges)[:, 1], n_global)
+    gsort = np.argsort(gkey)
+    lkey = _edge_keys(g0, g1, n_global)
+    gpos = gsort[np.searchsorted(gkey[gsort], lkey)]
+    if not np.array_equal(gkey[gpos], lkey):
+        raise AssertionError("a local edge is missing from the global edge table")
+    l2g_nodes = np.empty(nv + ne, dtype=np.int64)
+    l2g_nodes[node_of_vertex] = part.l2g
+    l2g_nodes[node_of_edge] = n_global + gpos
+    # exchanges
+    lsort = np.argsort(lkey)
+    send_lists, recv_lists = [], []
+    mine_cells = cells[(owner[cells] == rank).any(axis=1)]
+    for qi, q in enumerate(part.neighbors):
+        # receive: ghost vertices owned by q (part order: by global id), then ghost edges owned by q by (g0, g1)
+        gv = np.nonzero(owner[part.l2g] == q)[0]
+        gv = gv[np.argsort(part.l2g[gv])]
+        ge = np.nonzero(e_owner == q)[0]
+        ge = ge[np.argsort(lkey[ge])]
+        recv_lists.append(np.concatenate([node_of_vertex[gv], node_of_edge[ge]]).astype(np.int32))
+        # send: my vertices (LocalPart order) and my edges that live in a cell local to q
+        touch = mine_cells[(owner[mine_cells] == q).any(axis=1)]
+        a = np.concatenate([touch[:, i] for i, _ in _TET_EDGES])
+        b = np.concatenate([touch[:, j] for _, j in _TET_EDGES])
+        k = np.unique(_edge_keys(a, b, n_global))
+        k = k[owner[k // n_global] == rank]                      # owner = owner of the smaller global id
+        pos = lsort[np.searchsorted(lkey[lsort], k)]
+        if not np.array_equal(lkey[pos], k):
+            raise AssertionError("an edge to send is not a local edge")
+        send_lists.append(np.concatenate([np.asarray(part.send_lists[qi], dtype=np.int64), node_of_edge[pos]]).astype(np.int32))
+    return P2Plan(nvo + neo, l2g_nodes, list(part.neighbors), send_lists, recv_lists)

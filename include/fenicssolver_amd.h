@@ -79,6 +79,9 @@ int fs_mesh_create(int gdim, int64_t nv, const double* xyz, int64_t nc, const in
 int fs_mesh_create_box(int64_t nx, int64_t ny, int64_t nz, const double p0[3], const double p1[3],
                        int64_t zplane_begin, int64_t zplane_end, fs_mesh_t* out);
 
+/* Global vertex ids of an uploaded mesh part (identity by default).  Needed for CG2 spaces on a decomposed mesh:
+ * an edge node is owned by the rank owning its endpoint of smaller global id. */
+int fs_mesh_set_global_ids(fs_mesh_t mesh, const int64_t* global_ids);
 int fs_mesh_info(fs_mesh_t mesh, int64_t* nv, int64_t* nc, int64_t* n_owned);
 /* Copy back to host (any pointer may be NULL): xyz[nv][3], cells[nc][4],
  * global vertex ids[nv] (identity for uploaded meshes). */
@@ -337,6 +340,11 @@ int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_t* neighbor
                       const int64_t* send_counts, const int32_t* send_idx,
                       const int64_t* recv_counts);
 /* Refresh the ghost entries of a local vector (n_dofs_local long). */
+/* The same with an explicit scatter list: the k-th value received from a neighbour goes to local dof recv_idx[k]
+ * (>= the owned dofs).  For layouts whose ghosts are not grouped by owner, e.g. CG2 nodes
+ * [owned vertices | owned edges | ghost vertices | ghost edges]. */
+int fs_space_set_halo_indexed(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
+                              const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
 int fs_halo_exchange(fs_space_t space, fs_vector_t v);
 
 #ifdef __cplusplus

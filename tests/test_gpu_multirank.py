@@ -48,11 +48,12 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
 
 
-@pytest.mark.parametrize("case", ["heat", "heat_cn", "elasticity"])
-def test_solver_classes_under_two_ranks(gpu, tmp_path, case):
-    """`python -m torch.distributed.run --nproc-per-node 2 script.py` with the reference-style solver classes:
-    same field as the single-process run, gathered on every rank."""
+@pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3)])
+def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
+    """`python -m torch.distributed.run --nproc-per-node N script.py` with the reference-style solver classes:
+    same field as the single-process run, gathered on every rank.  heat_p2: CG2 nodes decomposed as
+    [owned vertices | owned edges | ghost vertices | ghost edges] with the indexed halo."""
     import test_gpu_parallel_api as T
     single = T.CASES[case]().solve().vector().get_local()
-    r = _run(2, case, tmp_path)
+    r = _run(world, case, tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()

@@ -18,18 +18,28 @@ pytestmark = pytest.mark.gpu
 QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
 
 
-def _heat_case(n=5, transient=False):
+def _heat_p2_case(n=4):
+    """P2 heat: Dirichlet + flux + per-subdomain conductivity and source (degree 2 has no Robin facet matrix)."""
+    solver = _heat_case(n, degree=2)
+    return solver
+
+
+def _heat_case(n=5, transient=False, degree=1):
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n)
-    Q = FunctionSpace(m, "CG", 1)
+    Q = FunctionSpace(m, "CG", degree)
     bcs = OrderedDict()
     bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
         'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
     bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 2, 'values': {
         'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
-    bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
-        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    if degree == 1:
+        bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    else:
+        bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
     s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
          'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
          'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
@@ -72,7 +82,8 @@ def _elastic_case():
     return LinearElasticitySolver(s)
 
 
-CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case}
+CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
+         "heat_p2": _heat_p2_case}
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -123,9 +134,8 @@ def test_three_emulated_ranks_reproduce_the_global_system(gpu, monkeypatch, case
     for r in range(3):
         got = _capture_system(monkeypatch, CASES[case], rank=r, world=3)
         loc, nc = got["loc"], got["ncomp"]
-        part = loc.part
-        l2g_dof = (part.l2g[:, None].astype(np.int64) * nc + np.arange(nc)).ravel()
-        rows = l2g_dof[:part.n_owned * nc]
+        l2g_dof = (loc.l2g[:, None].astype(np.int64) * nc + np.arange(nc)).ravel()     # node-level (P2: vertices + edges)
+        rows = l2g_dof[:loc.n_owned * nc]
         covered[rows] += 1
         Al = got["A"].tocoo()
         Ag = sp.csr_matrix((Al.data, (rows[Al.row], l2g_dof[Al.col])), shape=(ndof, ndof))
