@@ -91,3 +91,46 @@ def test_distributed_cg_matches_single_rank(world, mode, tmp_path):
     # reduction order differs between 1 and N ranks: agreement to 1e-12 relative
     assert np.abs(r["x"] - x1).max() <= 1e-10 * np.abs(x1).max()
     assert np.abs(r["x"] - (350.0 - 50.0 * co[:, 0])).max() <= 1e-6
+
+
+def _device_like_edges(part, owner, rank):
+    """The edge table fs_space_create builds for a part: unique local vertex pairs in key order, owned edges first
+    (an edge belongs to the rank owning its endpoint of smaller global id)."""
+    c = part.cells.astype(np.int64)
+    pairs = np.concatenate([np.sort(c[:, [i, j]], axis=1) for i, j in partition._TET_EDGES])
+    pairs = np.unique(pairs, axis=0)                          # lexicographic (v0, v1) = the ungrouped key order
+    g = part.l2g[pairs]
+    vmin = np.where(g[:, 0] < g[:, 1], pairs[:, 0], pairs[:, 1])
+    ghost = vmin >= part.n_owned
+    return np.concatenate([pairs[~ghost], pairs[ghost]])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_p2_exchange_plan_is_consistent_between_ranks(world):
+    """partition.build_p2_plan derives both sides of every exchange without communication: what rank p sends to q
+    must be, value for value, what q expects from p - compared through global node ids - and every ghost node of
+    every rank must be covered exactly once."""
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.7, 2.0), 3, 4, 9)
+    nvg = len(co)
+    edges_g, _ = fo.edge_numbering(ce)
+    owner = partition.slab_owner(co, world, axis=2)
+    plans, parts = [], []
+    for r in range(world):
+        part = partition.build_local_part(ce, owner, r)
+        le = _device_like_edges(part, owner, r)
+        plans.append(partition.build_p2_plan(ce, owner, r, part, le, edges_g))
+        parts.append(part)
+    owned_total = 0
+    seen = np.zeros(nvg + len(edges_g), dtype=int)
+    for r, pl in enumerate(plans):
+        owned_total += pl.n_owned_nodes
+        seen[pl.l2g_nodes[:pl.n_owned_nodes]] += 1
+        ghosts = np.concatenate(pl.recv_lists) if pl.recv_lists else np.zeros(0, dtype=np.int64)
+        assert sorted(ghosts.tolist()) == list(range(pl.n_owned_nodes, len(pl.l2g_nodes)))      # each ghost exactly once
+        for qi, q in enumerate(pl.neighbors):
+            back = plans[q].neighbors.index(r)
+            sent_gids = plans[q].l2g_nodes[plans[q].send_lists[back]]
+            want_gids = pl.l2g_nodes[pl.recv_lists[qi]]
+            assert np.array_equal(sent_gids, want_gids)
+            assert np.all(plans[q].send_lists[back] < plans[q].n_owned_nodes)
+    assert owned_total == nvg + len(edges_g) and np.all(seen == 1)         # the owned sets partition the P2 nodes
