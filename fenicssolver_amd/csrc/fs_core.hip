@@ -1,6 +1,7 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
 #include "fs_kernels.h"
+#include <stdlib.h>
 
 // ---- errors / runtime --------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -53,6 +54,18 @@ extern "C" int fs_init(int device_id) {
     fs_runtime& rt = fs_rt();
     if (rt.initialised && rt.device == device_id) return FS_OK;
     FS_HIP(hipSetDevice(device_id));
+    // Host waits spin instead of sleeping on an interrupt: the Krylov loops read a few scalars per iteration and a
+    // blocked thread costs ~0.1-1 ms to wake up (measured: FGMRES iteration 2.6 -> see DESIGN.md).  FS_WAIT=yield|block
+    // selects the other modes (e.g. many ranks sharing few cores).
+    {
+        const char* w = getenv("FS_WAIT");
+        unsigned flags = hipDeviceScheduleSpin;
+        if (w && !strcmp(w, "yield")) flags = hipDeviceScheduleYield;
+        else if (w && !strcmp(w, "block")) flags = hipDeviceScheduleBlockingSync;
+        else if (w && !strcmp(w, "auto")) flags = hipDeviceScheduleAuto;
+        (void)hipSetDeviceFlags(flags);     // fails harmlessly when the context already exists (e.g. torch created it)
+        (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     FS_HIP(hipGetDeviceProperties(&prop, device_id));
     if (rt.stream) (void)hipStreamDestroy(rt.stream);

@@ -580,8 +580,11 @@ __global__ void k_sd_multi_axpy(int64_t n, double* __restrict__ w, const double*
     }
 }
 
+static bool g_sd_timing = false, g_sd_sync = false;
+static double g_sd_t[4];
+
 struct saddle_ws {
-    dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev, cd;
+    dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev, cd, gin, gout;
     double vel_lmax = 0.0;   // largest eigenvalue of D^-1 A on the velocity block (Chebyshev sweeps)
     dbuf<const double*> vptr;
     dbuf<uint8_t> ident;
@@ -681,6 +684,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
                "fs_saddle_solve: the pressure operators must live on the CG1 space of the same mesh");
     FS_REQUIRE(b->d.n >= n && x->d.n >= sp->n_dofs_local, "fs_saddle_solve: vector too short");
     hipStream_t s = fs_rt().stream;
+    g_sd_timing = getenv("FS_SADDLE_TIMING") != nullptr;
+    g_sd_sync = getenv("FS_SADDLE_SYNC") != nullptr;
+    g_sd_t[0] = g_sd_t[1] = g_sd_t[2] = g_sd_t[3] = 0.0;
     const int m = o->restart > 0 ? o->restart : 60;
     const int max_iter = o->max_iter > 0 ? o->max_iter : 600;
     memset(stats, 0, sizeof(*stats));
@@ -703,6 +709,8 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_CHECK(W.r.alloc(n));
     FS_CHECK(W.w.alloc(n));
     FS_CHECK(W.cd.alloc(n));
+    FS_CHECK(W.gin.alloc(n));
+    FS_CHECK(W.gout.alloc(n));
     FS_CHECK(W.ident.alloc(nv));
     FS_CHECK(W.mdinv.alloc(nv));
     FS_CHECK(W.md.alloc(nv));
@@ -741,6 +749,7 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_KERNEL_CHECK();
 
     const int g = fs_grid_for(n, FS_BLOCK, 4096);
+    const bool transient_kp = o->inv_dt > 0.0 && Kp != nullptr;     // an inner CG on Kp (no hierarchy given) cannot be captured
     if (o->velocity_sweeps > 1) {
         // lambda_max(D^-1 A) of the velocity block: 12 power iterations from a hashed start
         hipLaunchKernelGGL(k_sd_seed, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p);
@@ -765,6 +774,55 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     int it = 0, conv = 0, inner = 0;
     double res = 0.0;
     std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m), hcol(m + 3);
+    // The preconditioner is ~55 small launches (AMG V-cycle on the pressure Laplacian, Chebyshev mass solve): a fixed
+    // sequence on fixed buffers once its input/output are staged in gin/gout, so it can be captured into a hipGraph
+    // and replayed (FS_SADDLE_GRAPH=1).  Measured on MI355X / ROCm 7.2 (round 1): replay and direct launches both take
+    // 0.35 ms - the enqueue costs the host only 0.1 ms, it is not launch-bound - so direct launches stay the default.
+    hipGraph_t pgraph = nullptr;
+    hipGraphExec_t pexec = nullptr;
+    bool use_graph = getenv("FS_SADDLE_GRAPH") != nullptr && (!transient_kp || Kp_amg != nullptr);
+    if (use_graph) {
+        FS_HIP(hipStreamSynchronize(s));
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int dummy = 0;
+            const int rc_cap = sd_precond(J, Kp, Kp_amg, Mp, o, W, W.gin.p, W.gout.p, &dummy, s);
+            const hipError_t e_end = hipStreamEndCapture(s, &pgraph);
+            if (rc_cap != FS_OK || e_end != hipSuccess || !pgraph ||
+                hipGraphInstantiate(&pexec, pgraph, nullptr, nullptr, 0) != hipSuccess) {
+                if (pgraph) (void)hipGraphDestroy(pgraph);
+                pgraph = nullptr; pexec = nullptr; use_graph = false;
+                (void)hipGetLastError();
+            }
+        } else {
+            use_graph = false;
+            (void)hipGetLastError();
+        }
+    }
+    if (g_sd_timing) {      // back-to-back cost of the preconditioner, graph replay vs direct launches
+        int dummy = 0;
+        (void)hipStreamSynchronize(s);
+        auto t0g = std::chrono::steady_clock::now();
+        if (use_graph) for (int rep = 0; rep < 20; ++rep) (void)hipGraphLaunch(pexec, s);
+        (void)hipStreamSynchronize(s);
+        auto t1g = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < 20; ++rep) (void)sd_precond(J, Kp, Kp_amg, Mp, o, W, W.gin.p, W.gout.p, &dummy, s);
+        (void)hipStreamSynchronize(s);
+        auto t2g = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < 20; ++rep) (void)fs_spmv_dev(J, W.gin.p, W.w.p, s);
+        (void)hipStreamSynchronize(s);
+        auto t3g = std::chrono::steady_clock::now();
+        (void)fs_spmv_dev(J, W.gin.p, W.w.p, s);
+        (void)hipStreamSynchronize(s);
+        auto t4g = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fs_saddle_solve] block SpMV: %.3f ms each back to back (x20), %.3f ms for a single launch + sync\n",
+                std::chrono::duration<double, std::milli>(t3g - t2g).count() / 20, std::chrono::duration<double, std::milli>(t4g - t3g).count());
+        fprintf(stderr, "[fs_saddle_solve] preconditioner x20 back to back: graph %.3f ms each, direct %.3f ms each\n",
+                std::chrono::duration<double, std::milli>(t1g - t0g).count() / 20, std::chrono::duration<double, std::milli>(t2g - t1g).count() / 20);
+    }
+    struct graph_guard {
+        hipGraph_t& g; hipGraphExec_t& e;
+        ~graph_guard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
+    } guard{pgraph, pexec};
     while (true) {
         // r = b - J x
         FS_CHECK(fs_spmv_dev(J, x->d.p, W.t.p, s));
@@ -780,8 +838,21 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
         gam[0] = res;
         int k = 0;
         for (; k < m && it < max_iter; ++k, ++it) {
-            FS_CHECK(sd_precond(J, Kp, Kp_amg, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
+            const bool dbg = g_sd_timing || g_sd_sync;
+            auto tA = std::chrono::steady_clock::now();
+            if (use_graph) {
+                FS_HIP(hipMemcpyAsync(W.gin.p, W.V[k]->p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+                FS_HIP(hipGraphLaunch(pexec, s));
+                FS_HIP(hipMemcpyAsync(W.Z[k]->p, W.gout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            } else {
+                FS_CHECK(sd_precond(J, Kp, Kp_amg, Mp, o, W, W.V[k]->p, W.Z[k]->p, &inner, s));
+            }
+            auto tB = tA;
+            if (dbg) { tB = std::chrono::steady_clock::now(); (void)hipStreamSynchronize(s); }
+            auto tC = std::chrono::steady_clock::now();
             FS_CHECK(fs_spmv_dev(J, W.Z[k]->p, W.w.p, s));
+            if (dbg) (void)hipStreamSynchronize(s);
+            auto tD = std::chrono::steady_clock::now();
             // classical Gram-Schmidt, applied twice (CGS2): one fused multi-dot launch and one host read per pass
             // classical Gram-Schmidt with one fused multi-dot launch and one host read per pass; the last pointer of the
             // list is w itself, so the pass also returns ||w||^2 before the projection.  A second pass only when the
@@ -801,6 +872,13 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
                 if (hh > 0.1 * before) break;        // eta^2 = 0.1: at most one digit lost to cancellation
                 FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));
                 if (pass >= 1) break;
+            }
+            if (g_sd_timing) {
+                auto tE = std::chrono::steady_clock::now();
+                g_sd_t[0] += std::chrono::duration<double, std::milli>(tB - tA).count();   // enqueue of the preconditioner
+                g_sd_t[1] += std::chrono::duration<double, std::milli>(tC - tA).count();   // ... until it has run
+                g_sd_t[2] += std::chrono::duration<double, std::milli>(tD - tC).count();   // SpMV
+                g_sd_t[3] += std::chrono::duration<double, std::milli>(tE - tD).count();   // orthogonalisation
             }
             if (!(hh > 0.0)) hh = 0.0;
             hh = sqrt(hh);
@@ -837,7 +915,8 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     stats->true_rel_residual = stats->rel_residual;
     stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     stats->spmv_bytes = sp->nnz_nodes * 16 * 12 + n * 20;
-    if (getenv("FS_SADDLE_DEBUG")) fprintf(stderr, "[fs_saddle_solve] %d outer iterations, %d inner CG iterations, %.1f ms\n", it, inner, stats->solve_ms);
+    if (getenv("FS_SADDLE_DEBUG")) fprintf(stderr, "[fs_saddle_solve] %d outer iterations, %d inner CG iterations, %.1f ms%s\n", it, inner, stats->solve_ms, use_graph ? " (preconditioner as hipGraph)" : "");
+    if (g_sd_timing) fprintf(stderr, "[fs_saddle_solve] per iteration [ms]: precond enqueue %.3f, precond done %.3f, spmv %.3f, orthogonalisation %.3f\n", g_sd_t[0] / std::max(it, 1), g_sd_t[1] / std::max(it, 1), g_sd_t[2] / std::max(it, 1), g_sd_t[3] / std::max(it, 1));
     if (conv < 0) {
         fs_set_error("fs_saddle_solve: breakdown at iteration %d", it);
         return FS_ERR_NUMERIC;

@@ -11,8 +11,11 @@ J = B.DeviceMatrix(W); g = B.DeviceVector(W.n_owned)
 B.assemble_navier_stokes(J, g, None, None, nu=0.01, rho=1.0, inv_dt=100.0, convection=False, newton=False)
 x = B.DeviceVector(W.n_local, np.random.default_rng(0).standard_normal(W.n_local)); y = B.DeviceVector(W.n_owned)
 print('dofs', W.n_owned, 'nnz', W.nnz, 'stored bytes', W.spmv_matrix_bytes, 'dia slices', W.n_dia_slices, '/', W.n_slices)
-for blocks in (512, 1024, 2048, 4096):
-    for un in (1, 2, 4):
-        B.set_option('spmv_blocks', blocks); B.set_option('spmv_unroll4', un)
-        ms = min(J.spmv_benchmark(x, y, 20) for _ in range(3))
-        print('blocks %4d unroll %d  %.3f ms  %.0f GB/s stored' % (blocks, un, ms, W.spmv_matrix_bytes / ms / 1e6))
+import os
+for reps in (1, 2, 5, 20, 100):
+    ms = [J.spmv_benchmark(x, y, reps) for _ in range(4)]
+    print('row-split kernel, %3d back-to-back launches: %s ms each' % (reps, ['%.3f' % m for m in ms]))
+os.environ['FS_SPMV4_GENERIC'] = '1'
+for reps in (1, 20):
+    ms = [J.spmv_benchmark(x, y, reps) for _ in range(3)]
+    print('generic kernel,   %3d back-to-back launches: %s ms each' % (reps, ['%.3f' % m for m in ms]))
