@@ -54,16 +54,14 @@ extern "C" int fs_init(int device_id) {
     fs_runtime& rt = fs_rt();
     if (rt.initialised && rt.device == device_id) return FS_OK;
     FS_HIP(hipSetDevice(device_id));
-    // Host waits spin instead of sleeping on an interrupt: the Krylov loops read a few scalars per iteration and a
-    // blocked thread costs ~0.1-1 ms to wake up (measured: FGMRES iteration 2.6 -> see DESIGN.md).  FS_WAIT=yield|block
-    // selects the other modes (e.g. many ranks sharing few cores).
-    {
-        const char* w = getenv("FS_WAIT");
-        unsigned flags = hipDeviceScheduleSpin;
-        if (w && !strcmp(w, "yield")) flags = hipDeviceScheduleYield;
-        else if (w && !strcmp(w, "block")) flags = hipDeviceScheduleBlockingSync;
-        else if (w && !strcmp(w, "auto")) flags = hipDeviceScheduleAuto;
-        (void)hipSetDeviceFlags(flags);     // fails harmlessly when the context already exists (e.g. torch created it)
+    // FS_WAIT=spin|yield|block selects how the host waits for the device (default: the runtime's choice; spinning
+    // made no measurable difference to the Krylov loops on the MI355X test boxes)
+    if (const char* w = getenv("FS_WAIT")) {
+        unsigned flags = hipDeviceScheduleAuto;
+        if (!strcmp(w, "spin")) flags = hipDeviceScheduleSpin;
+        else if (!strcmp(w, "yield")) flags = hipDeviceScheduleYield;
+        else if (!strcmp(w, "block")) flags = hipDeviceScheduleBlockingSync;
+        (void)hipSetDeviceFlags(flags);     // fails harmlessly when the context already exists
         (void)hipGetLastError();
     }
     hipDeviceProp_t prop;
