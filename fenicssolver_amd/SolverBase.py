@@ -575,13 +575,20 @@ class SolverBase():
             adv, adv_scale = F.advection if F.advection is not None else (None, 1.0)
             if adv is not None and loc is not None and np.ndim(adv) == 2:
                 adv = loc.cells(adv)
-            A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale)
+            pe = getattr(F, 'supg_pe', 0.0) if adv is not None else 0.0
+            if pe and loc is not None:
+                raise SolverError('SUPG stabilisation is single-GPU for now')
+            A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
+                       supg_pe=pe)
             for r in F.robin:
                 tri, _ = self._device_facets(F, r.marker_id)
                 A.add_facet_mass(tri, r.h)
             first = True
             for s in F.sources:
-                backend.assemble_vector(V, b, source=L_(s.spec()), add=not first)
+                spec = L_(s.spec())
+                if pe and isinstance(spec, tuple) and spec[0] == 'nodal':
+                    raise SolverError('SUPG with a nodal (Function / Expression) source is not built')
+                backend.assemble_vector(V, b, source=spec, add=not first, supg=(adv, pe) if pe else None)
                 first = False
             for fl in F.facet_loads:
                 tri, g = self._device_facets(F, fl.marker_id, fl.g)
@@ -591,6 +598,14 @@ class SolverBase():
                 tri, _ = self._device_facets(F, r.marker_id)
                 if len(tri):
                     backend.assemble_facet_vector(V, b, tri, r.h * r.ambient)
+            if pe:
+                # the reference substitutes q + tau (v . grad q) in the boundary integrals as well (Tq, :296-298)
+                for fl in F.facet_loads:
+                    cells_, opp_, _ = self._marked_facet_cells(fl.marker_id)
+                    backend.assemble_facet_supg(V, None, b, cells_, opp_, adv, pe, g=fl.g)
+                for r in F.robin:
+                    cells_, opp_, _ = self._marked_facet_cells(r.marker_id)
+                    backend.assemble_facet_supg(V, A, b, cells_, opp_, adv, pe, g=r.h * r.ambient, h=r.h)
             for ps in getattr(F, 'point_sources', []):
                 # PointSource.apply(b) (SolverBase.py:597-601): before the Dirichlet rows, which then overwrite
                 pd, pw = ps.dofs, ps.weights
@@ -603,7 +618,8 @@ class SolverBase():
             if F.transient:
                 # b += (M/dt - (1-theta) K) T_prev   (Crank-Nicolson old-step terms, :292-293)
                 B = backend.DeviceMatrix(V)
-                B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)))
+                B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)),
+                           advection=adv if pe else None, advection_scale=0.0, supg_pe=pe)    # SUPG mass part only
                 tp_host = F.T_prev.vector().array()
                 tp_host = tp_host if loc is None else loc.nodes(tp_host)
                 tp = backend.DeviceVector(V.n_local, np.concatenate([tp_host, np.zeros(V.n_local - len(tp_host))]))
@@ -773,6 +789,8 @@ class SolverBase():
             sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
             cf = self.mesh.cell_facets()
             cells, opp = np.nonzero(np.isin(cf, sel))
+            order = np.argsort(cf[cells, opp], kind='stable')       # ascending facet id: the order of _facets_of()
+            cells, opp = cells[order], opp[order]
             tri = self.mesh.facets()[cf[cells, opp]].astype(np.int64)
             cache[marker_id] = (cells.astype(np.int32), opp.astype(np.int32), self.mesh.coordinates()[tri].mean(axis=1))
         return cache[marker_id]

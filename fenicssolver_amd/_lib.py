@@ -39,11 +39,12 @@ class fs_coef(C.Structure):
 
 class fs_bilinear_form(C.Structure):
     _fields_ = [("stiffness", fs_coef), ("mass", fs_coef), ("lame_mu", C.c_double), ("lame_lambda", C.c_double),
-                ("advection", fs_coef), ("advection_scale", C.c_double)]
+                ("advection", fs_coef), ("advection_scale", C.c_double), ("supg_pe", C.c_double)]
 
 
 class fs_linear_form(C.Structure):
-    _fields_ = [("source", fs_coef), ("vector_value", C.c_double * 3), ("div_coef", fs_coef)]
+    _fields_ = [("source", fs_coef), ("vector_value", C.c_double * 3), ("div_coef", fs_coef), ("supg_velocity", fs_coef),
+                ("supg_pe", C.c_double)]
 
 
 class fs_krylov_opts(C.Structure):
@@ -125,6 +126,7 @@ SIGNATURES = {
     "fs_amg_level_get": (C.c_int, [_H, C.c_int, C.c_int, c_i32p, c_i32p, c_f64p]),
     "fs_amg_apply": (C.c_int, [_H, _H, _H]),
     "fs_amg_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
+    "fs_assemble_facet_supg": (C.c_int, [_H, _H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, C.POINTER(fs_coef), C.c_double]),
     "fs_assemble_navier_stokes": (C.c_int, [_H, _H, _H, _H, C.POINTER(fs_ns_form)]),
     "fs_assemble_ns_pressure_boundary": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]),
     "fs_saddle_solve": (C.c_int, [_H, _H, _H, _H, _H, _H, C.POINTER(fs_saddle_opts), C.POINTER(fs_krylov_stats)]),

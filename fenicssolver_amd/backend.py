@@ -221,8 +221,9 @@ class DeviceMatrix(_Handle):
         self.space = space
         L.check(L.load().fs_matrix_create(space.h, C.byref(self.h)), "fs_matrix_create")
 
-    def assemble(self, stiffness=None, mass=None, lame=None, advection=None, advection_scale=1.0, add=False):
-        """advection: constant velocity (3 numbers) or per-cell array [n_cells,3]."""
+    def assemble(self, stiffness=None, mass=None, lame=None, advection=None, advection_scale=1.0, add=False, supg_pe=0.0):
+        """advection: constant velocity (3 numbers) or per-cell array [n_cells,3]; supg_pe > 0: SUPG test function
+        q + tau (v . grad q) on the advection and mass terms."""
         keep = []
         f = L.fs_bilinear_form()
         f.stiffness = _coef(stiffness, keep)
@@ -239,6 +240,7 @@ class DeviceMatrix(_Handle):
                 f.advection.mode = L.FS_COEF_CELL
                 f.advection.data = L.p_f64(v)
             f.advection_scale = float(advection_scale)
+            f.supg_pe = float(supg_pe)
         if lame is not None:
             f.lame_mu, f.lame_lambda = float(lame[0]), float(lame[1])
         L.check(L.load().fs_assemble_matrix(self.h, C.byref(f), 1 if add else 0), "fs_assemble_matrix")
@@ -280,12 +282,45 @@ class DeviceMatrix(_Handle):
         return ms.value
 
 
-def assemble_vector(space, b, source=None, vector_value=None, div_coef=None, add=False):
-    """b (+)= int source q dx [+ int f.v dx + int div_coef div v dx on vector spaces]."""
+def _velocity_coef(v, keep):
+    """Constant velocity (3 numbers) or per-cell array [n_cells,3] -> fs_coef."""
+    c = L.fs_coef()
+    v = L.f64(v)
+    if v.size == 3:
+        c.mode = L.FS_COEF_CONST
+        for i in range(3):
+            c.tensor[i] = float(v.ravel()[i])
+    else:
+        v = L.f64(v.reshape(-1, 3))
+        keep.append(v)
+        c.mode = L.FS_COEF_CELL
+        c.data = L.p_f64(v)
+    return c
+
+
+def assemble_facet_supg(space, A, b, facet_cell, facet_opposite, velocity, pe, g=None, h=None):
+    """SUPG part of ds(i) terms: b_a += g area w_a, A_ab += h (area/3) w_a (b on the facet), w_a = tau (v . grad phi_a)."""
+    fc = np.ascontiguousarray(facet_cell, dtype=np.int32)
+    fo_ = np.ascontiguousarray(facet_opposite, dtype=np.int32)
+    keep = []
+    vel = _velocity_coef(velocity, keep)
+    gg = None if g is None else np.ascontiguousarray(np.broadcast_to(np.asarray(g, dtype=np.float64), fc.shape))
+    hh = None if h is None else np.ascontiguousarray(np.broadcast_to(np.asarray(h, dtype=np.float64), fc.shape))
+    L.check(L.load().fs_assemble_facet_supg(space.h, A.h if A is not None else None, b.h if b is not None else None, len(fc),
+                                            L.p_i32(fc), L.p_i32(fo_), L.p_f64(gg), L.p_f64(hh), C.byref(vel), float(pe)),
+            "fs_assemble_facet_supg")
+
+
+def assemble_vector(space, b, source=None, vector_value=None, div_coef=None, add=False, supg=None):
+    """b (+)= int source q dx [+ int f.v dx + int div_coef div v dx on vector spaces]; supg = (velocity, Pe) adds
+    int source tau (v . grad q) dx."""
     keep = []
     f = L.fs_linear_form()
     f.source = _coef(source, keep)
     f.div_coef = _coef(div_coef, keep)
+    if supg is not None:
+        f.supg_velocity = _velocity_coef(supg[0], keep)
+        f.supg_pe = float(supg[1])
     if vector_value is not None:
         for i in range(3):
             f.vector_value[i] = float(vector_value[i])

@@ -10,6 +10,12 @@
 #include "fs_common.h"
 #include "fs_kernels.h"
 
+__device__ __forceinline__ int fs_find_pos_local(const int32_t* __restrict__ sell_col, int64_t base_lane, int width, int32_t target) {
+    for (int k = 0; k < width; ++k)
+        if (sell_col[base_lane + (int64_t)k * FS_SLICE] == target) return k;
+    return -1;
+}
+
 // ---- P1 geometry ---------------------------------------------------------------------------
 struct tet_geom {
     double g[4][3];  // gradients of the barycentric basis
@@ -47,6 +53,25 @@ __device__ __forceinline__ tet_geom tet_geometry(const double* __restrict__ xyz4
     }
     t.adet = fabs(det);
     return t;
+}
+
+// SUPG parameter of a cell (ScalarTransportSolver.py:262-266): tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 R with R the
+// circumradius: R = sqrt((aA+bB+cC)(aA+bB-cC)(aA-bB+cC)(-aA+bB+cC)) / (24 V), (a,A) (b,B) (c,C) opposite edge pairs
+__device__ __forceinline__ double supg_tau(const double* __restrict__ xyz4, const int32_t (&v)[4], double adet, double vnorm,
+                                           double pe) {
+    double x0[3], x1[3], x2[3], x3[3];
+    load_vertex(xyz4, v[0], x0);
+    load_vertex(xyz4, v[1], x1);
+    load_vertex(xyz4, v[2], x2);
+    load_vertex(xyz4, v[3], x3);
+    auto dist = [](const double (&p)[3], const double (&q)[3]) {
+        return sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
+    };
+    const double aA = dist(x0, x1) * dist(x2, x3), bB = dist(x0, x2) * dist(x1, x3), cC = dist(x0, x3) * dist(x1, x2);
+    const double prod = (aA + bB + cC) * (aA + bB - cC) * (aA - bB + cC) * (-aA + bB + cC);
+    const double R = sqrt(prod > 0.0 ? prod : 0.0) / (4.0 * adet);     // 24 V = 4 |det J|
+    const double h = 2.0 * R;
+    return 0.5 * h / (4.0 / (pe * h) + 2.0 * vnorm);
 }
 
 __device__ __forceinline__ double tri_area(const double* __restrict__ xyz4, int32_t a, int32_t b, int32_t c) {
@@ -136,7 +161,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double supg_pe, double* __restrict__ val) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -200,6 +225,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
                 const double w4 = ascale * vol * 0.25;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) row[b] += w4 * (vx * t.g[b][0] + vy * t.g[b][1] + vz * t.g[b][2]);
+                if (supg_pe > 0.0) {
+                    // test function q + tau (v . grad q): this row's vertex is local vertex 0 after the rotation
+                    const double tau = supg_tau(xyz4, vv, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    const double wa = tau * (vx * t.g[0][0] + vy * t.g[0][1] + vz * t.g[0][2]);
+                    const double mval = mc.mode == FS_COEF_NONE ? 0.0 : (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        row[b] += wa * vol * (ascale * (vx * t.g[b][0] + vy * t.g[b][1] + vz * t.g[b][2]) + 0.25 * mval);
+                }
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -412,8 +446,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
                                                                  int64_t n_rows, coef_dev f, int ncomp, double fx,
-                                                                 double fy, double fz, coef_dev dv,
-                                                                 double* __restrict__ b) {
+                                                                 double fy, double fz, coef_dev dv, coef_dev sv,
+                                                                 double supg_pe, double* __restrict__ b) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
@@ -434,6 +468,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* 
                 const double w = ff * t.adet * (1.0 / 24.0);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) be[a] = w;
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {     // + int S tau (v . grad phi_a) dx
+                    double vx, vy, vz;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; vz = sv.tensor[2]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; vz = sv.data[3 * (int64_t)c + 2]; }
+                    const double tau = supg_tau(xyz4, v, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    const double sw = ff * t.adet * (1.0 / 6.0) * tau;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) be[a] += sw * (vx * t.g[a][0] + vy * t.g[a][1] + vz * t.g[a][2]);
+                }
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -742,9 +785,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p);
         else
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p);
     } else if (A->bs == 1) {
         FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
         FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
@@ -788,9 +831,88 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         return FS_OK;
     }
     FS_REQUIRE(f.mode != FS_COEF_TENSOR && dv.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
-    hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, b->d.p);
+    dbuf<double> sstore;
+    coef_dev sv;
+    FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore, &sv, "fs_assemble_vector(supg_velocity)"));
+    FS_REQUIRE(!(form->supg_pe > 0.0) || sv.mode == FS_COEF_NONE || (space->ncomp == 1 && f.mode != FS_COEF_NODAL),
+               "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources on scalar CG1 spaces");
+    hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, sv, form->supg_pe, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+// SUPG part of the ds(i) terms: thread per (facet, cell vertex a)
+__global__ void k_facet_supg(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                             const double* __restrict__ g, const double* __restrict__ h, coef_dev vel, double pe,
+                             const int32_t* __restrict__ cells, const double* __restrict__ xyz4, int64_t n_rows,
+                             const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                             double* __restrict__ val, double* __restrict__ b, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 4; t += stride) {
+        const int64_t f = t >> 2;
+        const int a = (int)(t & 3);
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int32_t row = v[a];
+        if (row >= n_rows) continue;
+        const tet_geom tg = tet_geometry(xyz4, v);
+        double vx, vy, vz;
+        if (vel.mode == FS_COEF_CONST) { vx = vel.tensor[0]; vy = vel.tensor[1]; vz = vel.tensor[2]; }
+        else { vx = vel.data[3 * c]; vy = vel.data[3 * c + 1]; vz = vel.data[3 * c + 2]; }
+        const double tau = supg_tau(xyz4, v, tg.adet, sqrt(vx * vx + vy * vy + vz * vz), pe);
+        const double wa = tau * (vx * tg.g[a][0] + vy * tg.g[a][1] + vz * tg.g[a][2]);
+        const double gn = sqrt(tg.g[o][0] * tg.g[o][0] + tg.g[o][1] * tg.g[o][1] + tg.g[o][2] * tg.g[o][2]);
+        const double area = 0.5 * tg.adet * gn;          // 3 V |grad lambda_o|
+        if (b && g) atomicAdd(&b[row], g[f] * area * wa);
+        if (val && h) {
+            const int64_t sp0 = slice_ptr[row >> 6];
+            const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            const int64_t base = sp0 + (row & 63);
+            for (int bb = 0; bb < 4; ++bb) {
+                if (bb == o) continue;
+                const int k = fs_find_pos_local(sell_col, base, width, v[bb]);
+                if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], h[f] * area * (1.0 / 3.0) * wa);
+                else atomicAdd(err, 1);
+            }
+        }
+    }
+}
+
+extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector_t b, int64_t n_facets, const int32_t* facet_cell,
+                                      const int32_t* facet_opposite, const double* g, const double* h, const fs_coef* velocity,
+                                      double supg_pe) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(space && velocity && supg_pe > 0.0 && n_facets >= 0, "fs_assemble_facet_supg: bad arguments");
+    FS_REQUIRE(space->degree == 1 && space->ncomp == 1, "fs_assemble_facet_supg: scalar CG1 spaces only");
+    FS_REQUIRE((!A || A->space == space) && (!b || b->d.n >= space->n_dofs_owned), "fs_assemble_facet_supg: operand mismatch");
+    if (n_facets == 0 || ((!A || !h) && (!b || !g))) return FS_OK;
+    fs_mesh_s* m = space->mesh;
+    for (int64_t i = 0; i < n_facets; ++i)
+        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] < 4,
+                   "fs_assemble_facet_supg: facet %lld names cell %d / local vertex %d", (long long)i, facet_cell[i], facet_opposite[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> dc, dop;
+    dbuf<double> dg, dh, vstore;
+    dbuf<int> d_err;
+    coef_dev vel;
+    FS_CHECK(make_coef(*velocity, 3 * m->nc, vstore, &vel, "fs_assemble_facet_supg(velocity)"));
+    FS_REQUIRE(vel.mode == FS_COEF_CONST || vel.mode == FS_COEF_CELL, "fs_assemble_facet_supg: velocity must be constant or per cell");
+    FS_CHECK(dc.alloc(n_facets)); FS_CHECK(dop.alloc(n_facets)); FS_CHECK(d_err.alloc(1)); FS_CHECK(d_err.zero(s));
+    FS_CHECK(dc.upload(facet_cell, n_facets, s));
+    FS_CHECK(dop.upload(facet_opposite, n_facets, s));
+    if (g) { FS_CHECK(dg.alloc(n_facets)); FS_CHECK(dg.upload(g, n_facets, s)); }
+    if (h) { FS_CHECK(dh.alloc(n_facets)); FS_CHECK(dh.upload(h, n_facets, s)); }
+    hipLaunchKernelGGL(k_facet_supg, dim3(fs_grid_for(n_facets * 4)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
+                       h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
+                       space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
+    FS_KERNEL_CHECK();
+    int h_err = 0;
+    FS_CHECK(d_err.download(&h_err, 1, s));
+    FS_REQUIRE(h_err == 0, "fs_assemble_facet_supg: %d facet pairs missing from the sparsity pattern", h_err);
     return FS_OK;
 }
 

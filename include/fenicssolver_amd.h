@@ -163,6 +163,11 @@ typedef struct fs_bilinear_form {
      * non-symmetric).  v: FS_COEF_CONST -> tensor[0..2]; FS_COEF_CELL -> data[n_cells][3]. */
     fs_coef advection;
     double advection_scale;
+    /* SUPG ("SPUG" in the reference, ScalarTransportSolver.py:259-270): the test function becomes
+     * q + tau (v . grad q), tau = 0.5 h / (4/(Pe h) + 2|v|), h = 2 * circumradius of the cell.  supg_pe > 0 adds the
+     * tau-part to the advection term (streamline diffusion) and to the mass term; v is the advection velocity
+     * (set advection_scale = 0 to get the mass part only, e.g. for the old-step operator).  CG1 scalar spaces. */
+    double supg_pe;
 } fs_bilinear_form;
 
 /* Replaces dolfin.assemble(a) / the matrix half of assemble_system: numeric
@@ -179,8 +184,19 @@ typedef struct fs_linear_form {
     fs_coef source;
     double vector_value[3];
     fs_coef div_coef;
+    fs_coef supg_velocity;   /* with supg_pe > 0: + int source * tau (v . grad q) dx (constant / per-cell sources) */
+    double supg_pe;
 } fs_linear_form;
 int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add);
+
+/* SUPG part of the boundary integrals (the reference substitutes q + tau (v . grad q) in them too,
+ * ScalarTransportSolver.py:296-298 with Tq): for every listed boundary facet (cell behind it, local vertex opposite)
+ *   b_a += g_f * area * w_a                      (flux / Neumann / HTC ambient loads; g may be NULL)
+ *   A_ab += h_f * (area / 3) * w_a, b on the facet (HTC / Robin matrices; h may be NULL)
+ * for all four vertices a of the cell, w_a = tau (v . grad phi_a).  A or b may be NULL. */
+int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector_t b, int64_t n_facets, const int32_t* facet_cell,
+                           const int32_t* facet_opposite, const double* g, const double* h, const fs_coef* velocity,
+                           double supg_pe);
 
 /* Boundary-facet integrals over an explicit facet list (the host resolves
  * ds(id) to facets).  tri[n_facets][3] local vertex ids.

@@ -695,3 +695,71 @@ def p2_facet_dofs(n_vertices, edges, facets, facet_markers, marker_id):
     eid = sorter[np.searchsorted(ekey[sorter], fkey)]
     assert np.array_equal(ekey[eid], fkey)
     return np.concatenate([verts, np.sort(nv + eid)]).astype(np.int32)
+
+
+# ---- SUPG ("SPUG", ScalarTransportSolver.py:259-270): test function q + tau (v . grad q) --------------------
+def tet_circumradius(coords, cells):
+    """R of every tetrahedron by solving |x - p_i|^2 = R^2 for the circumcentre (independent of the edge-product
+    formula the device uses)."""
+    c = np.asarray(coords, dtype=np.float64)[np.asarray(cells, dtype=np.int64)]
+    A = 2.0 * (c[:, 1:] - c[:, :1])                                    # [nc,3,3]
+    rhs = (c[:, 1:] ** 2).sum(axis=2) - (c[:, :1] ** 2).sum(axis=2)    # [nc,3]
+    centre = np.linalg.solve(A, rhs[:, :, None])[:, :, 0]
+    return np.linalg.norm(centre - c[:, 0], axis=1)
+
+
+def supg_weights(coords, cells, velocity, pe):
+    """w[c,a] = tau_c (v_c . grad phi_a), tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 * Circumradius (:262-266)."""
+    detJ, g = p1_geometry(coords, cells)
+    v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(cells), 3))
+    h = 2.0 * tet_circumradius(coords, cells)
+    tau = 0.5 * h / (4.0 / (pe * h) + 2.0 * np.linalg.norm(v, axis=1))
+    return tau[:, None] * np.einsum("ci,cai->ca", v, g), v
+
+
+def p1_supg_local(coords, cells, velocity, pe, advection_scale=0.0, mass_coef=0.0):
+    """Extra element matrix of the SUPG test-function part: w_a * (scale (v . grad phi_b) vol + mass vol/4)."""
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    w, v = supg_weights(coords, cells, velocity, pe)
+    vg = np.einsum("ci,cbi->cb", v, g)
+    m = np.broadcast_to(np.asarray(mass_coef, dtype=np.float64), (len(cells),))
+    return w[:, :, None] * (advection_scale * vg[:, None, :] * vol[:, None, None] + (0.25 * m * vol)[:, None, None])
+
+
+def assemble_p1_supg_source(coords, cells, velocity, pe, f):
+    """int f tau (v . grad phi_a) dx for a constant / per-cell source f."""
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    w, _ = supg_weights(coords, cells, velocity, pe)
+    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
+    b = np.zeros(len(coords))
+    np.add.at(b, np.asarray(cells, dtype=np.int64).ravel(), (w * (ff * vol)[:, None]).ravel())
+    return b
+
+
+def supg_facet_terms(coords, cells, facet_cells, velocity, pe, g=None, h=None):
+    """(dA, db) of the SUPG part of ds terms over boundary facets given as (cell, opposite local vertex):
+    db[a] += g area w_a ;  dA[a, b on facet] += h (area/3) w_a   for the four vertices a of the cell."""
+    import scipy.sparse as sp
+    coords = np.asarray(coords, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.int64)
+    w, _ = supg_weights(coords, cells, velocity, pe)
+    n = len(coords)
+    db = np.zeros(n)
+    rows, cols, vals = [], [], []
+    opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))
+    for k, (c, o) in enumerate(np.asarray(facet_cells, dtype=np.int64)):
+        tri = cells[c, list(opp[o])]
+        p = coords[tri]
+        area = 0.5 * np.linalg.norm(np.cross(p[1] - p[0], p[2] - p[0]))
+        gk = 0.0 if g is None else float(np.broadcast_to(g, (len(facet_cells),))[k])
+        hk = 0.0 if h is None else float(np.broadcast_to(h, (len(facet_cells),))[k])
+        for a in range(4):
+            db[cells[c, a]] += gk * area * w[c, a]
+            for bnode in tri:
+                rows.append(cells[c, a]); cols.append(bnode); vals.append(hk * area / 3.0 * w[c, a])
+    dA = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    return dA, db

@@ -93,6 +93,14 @@ sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings(convective_veloc
 sol.material['conductivity'] = 0.6
 run("heat_convection", sol)
 
+# --- case 4b: the same with SUPG ("SPUG", method 2: the test function becomes q + tau (v . grad q) everywhere) ----
+for name, tr in (("heat_convection_supg", False), ("heat_convection_supg_transient", True)):
+    sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings(
+        transient=tr, convective_velocity=Constant((0.005, -0.005, 0.0)),
+        advection_settings={'stabilization_method': 'SPUG', 'Pe': 10.0}))
+    sol.material['conductivity'] = 0.6
+    run(name, sol)
+
 # --- case 5: Dirichlet + Neumann(fixedGradient) + Robin --------------------------------------------------
 st = heat_settings()
 st['body_source'] = None

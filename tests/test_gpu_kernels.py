@@ -434,3 +434,41 @@ def test_bicgstab_agrees_with_cg_on_spd(gpu):
     assert s2["iterations"] <= s1["iterations"]            # two SpMVs per BiCGStab iteration
     assert np.abs(x1.get() - x2.get()).max() <= 1e-7 * 350
     assert np.abs(x2.get() - P["exact"]).max() <= 1e-5
+
+
+def test_supg_terms_match_oracle(gpu):
+    """SUPG ("SPUG") test function q + tau (v . grad q): matrix (advection + mass), source and ds(i) extras."""
+    from oracle import ns_oracle as nso
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), 4, 3, 5)
+    rng = np.random.default_rng(5)
+    co = co + 0.02 * rng.standard_normal(co.shape) * (np.abs(co - 0.5).max(axis=1) < 0.4)[:, None]   # distort the interior
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh)
+    pe = 7.0
+    for vel in (np.array([0.3, -0.2, 0.5]), rng.standard_normal((len(ce), 3))):
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=0.6, mass=11.0, advection=vel, advection_scale=4.2, supg_pe=pe)
+        ref = fo.assemble_p1_scalar(co, ce, 0.6) + fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 11.0)) \
+            + fo.assemble_matrix(len(co), ce, fo.p1_advection_local(co, ce, vel, 4.2)) \
+            + fo.assemble_matrix(len(co), ce, fo.p1_supg_local(co, ce, vel, pe, 4.2, 11.0))
+        assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+        # mass part only (old-step operator of the time stepping): advection_scale = 0
+        A.assemble(mass=11.0, advection=vel, advection_scale=0.0, supg_pe=pe)
+        ref = fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 11.0)) \
+            + fo.assemble_matrix(len(co), ce, fo.p1_supg_local(co, ce, vel, pe, 0.0, 11.0))
+        assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+        b = gpu.DeviceVector(V.n_owned)
+        fc = rng.uniform(1, 2, len(ce))
+        gpu.assemble_vector(V, b, source=("cell", fc), supg=(vel, pe))
+        refb = fo.assemble_p1_source(co, ce, fc) + fo.assemble_p1_supg_source(co, ce, vel, pe, fc)
+        assert np.abs(b.get() - refb).max() <= 1e-12 * np.abs(refb).max()
+        th = nso.TaylorHood(co, ce)
+        fcells = nso.boundary_facet_cells(th, lambda x: x[2] < 0.05 or x[0] > 0.95)
+        gval, hval = rng.uniform(1, 3, len(fcells)), rng.uniform(50, 90, len(fcells))
+        A.assemble(stiffness=1.0)
+        base = _csr(A)
+        b.fill(0.0)
+        gpu.assemble_facet_supg(V, A, b, fcells[:, 0], fcells[:, 1], vel, pe, g=gval, h=hval)
+        dA, db = fo.supg_facet_terms(co, ce, fcells, vel, pe, gval, hval)
+        assert abs((_csr(A) - base) - dA).max() <= 1e-12 * abs(dA).max()
+        assert np.abs(b.get() - db).max() <= 1e-12 * np.abs(db).max()

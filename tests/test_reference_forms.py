@@ -394,3 +394,35 @@ def test_navier_stokes_terms(case, transient, body):
     v2 = dbcs[1].values.reshape(-1, 3)
     assert np.all(v2[:, 0] == 1.0) and np.all(v2[:, 1:] == 0.0)
     assert np.all(dbcs[1].dofs % 4 != 3)       # velocity components only
+
+
+# ------------------------------------------------------------------ SUPG ("SPUG")
+@pytest.mark.parametrize("transient", [False, True])
+def test_supg_is_the_plain_form_with_the_test_function_replaced(transient):
+    """What the reference builds for advection_settings = {'stabilization_method': 'SPUG', 'Pe': 10} is, integral by
+    integral, the unstabilised form with every test function q replaced by
+        q + tau (v . grad q),   tau = 0.5 h (4/(Pe h) + 2 |v|)^-1,   h = 2 Circumradius
+    (ScalarTransportSolver.py:259-270, SPUG_method == 2) - volume, source AND boundary integrals.  That substitution is
+    what forms.ScalarForm.supg_pe stands for (kernels: fs_assemble.hip supg_tau / k_facet_supg; oracle: supg_weights)."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    vel = "Constant(vec(0.005, -0.005, 0))"
+    h = "mul(2, Circumradius)"
+    tau = "mul(mul(0.5, %s), pow(add(div(4, mul(10, %s)), mul(2, sqrt(dot(%s, %s)))), -1))" % (h, h, vel, vel)
+    tq = "add(v_test, mul(%s, inner(%s, grad(v_test))))" % (tau, vel)
+    g = GOLD["heat_convection_supg_transient" if transient else "heat_convection_supg"]["solves"][0]
+    stripped = []
+    for t in g["terms"]:
+        assert tq in t["integrand"], t["integrand"]              # every integral carries the modified test function
+        stripped.append({"sign": t["sign"], "integrand": t["integrand"].replace(tq, "v_test"), "measure": t["measure"]})
+        assert "Circumradius" not in stripped[-1]["integrand"]   # ... and nothing else of the stabilisation
+    # our side: the same settings give the plain convection form + supg_pe = Pe
+    kw = {"convective_velocity": Constant((0.005, -0.005, 0.0)), "advection_settings": {'stabilization_method': 'SPUG', 'Pe': 10.0}}
+    if transient:
+        kw["transient"] = True
+    solver = ScalarTransportSolver(_heat_settings(**kw))
+    solver.material['conductivity'] = 0.6
+    F, bcs = _form_of(solver)
+    assert F.supg_pe == 10.0 and F.describe()["supg_pe"] == 10.0
+    assert_same_poly(scalar_form_poly(F), golden_poly({"terms": stripped}))
+    assert bc_list(bcs) == golden_bcs(g) == []
