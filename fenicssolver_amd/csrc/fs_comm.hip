@@ -85,7 +85,7 @@ struct shm_comm {
     size_t bytes = 0;
     int n_ranks = 1, rank = 0;
     char name[64] = {0};
-    static constexpr int64_t PAIR_CAP = 1 << 20;   // doubles per (src,dst) halo buffer
+    static constexpr int64_t PAIR_CAP = 1 << 18;   // doubles per (src,dst) halo buffer (pages are touched only when used)
     static constexpr int RED_CAP = 64;             // doubles per rank in the reduction mailbox
     shm_header* hdr() { return (shm_header*)base; }
     double* red(int r) { return (double*)(base + 4096) + (size_t)r * RED_CAP; }
