@@ -125,14 +125,21 @@ def main():
     for ph, tag in ((PHASES[0], "spmv_fused_n99"), (PHASES[1], "spmv_fused_n215")):
         # DOTS template argument: 3 = in-CG kernel of the diagonally scaled solve, 1 = unscaled CG /
         # fs_spmv_benchmark(fused), 0 = bare SpMV
+        # the launch shape (last template argument = entries per round) depends on the problem size
+        def find(dots):
+            for un in ("4", "16", "8", "2"):
+                k = (ph, "k_sell_spmv<1, %s, %s>" % (dots, un))
+                if k in fetch:
+                    return k
+            return None
         for dots in ("3", "1"):
-            key = (ph, "k_sell_spmv<1, %s, 4>" % dots)
-            if key in fetch:
+            key = find(dots)
+            if key is not None:
                 out[tag + ("" if dots == "3" else "_dots1")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
         if tag not in out and tag + "_dots1" in out:
             out[tag] = out[tag + "_dots1"]
-        key = (ph, "k_sell_spmv<1, 0, 4>")
-        if key in fetch:
+        key = find("0")
+        if key is not None:
             out[tag.replace("fused", "bare")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
