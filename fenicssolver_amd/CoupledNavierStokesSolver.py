@@ -211,6 +211,8 @@ class CoupledNavierStokesSolver(SolverBase):
     def plot(self):
         self.logger.info("plot(): use save() and ParaView for velocity-pressure fields")
 
+    plot_result = plot
+
     # ------------------------------------------------------------------ post-processing
     def split(self, w=None):
         return split(w if w is not None else self.w_current)

@@ -84,6 +84,19 @@ class LinearElasticitySolver(SolverBase):
         tec = self.material['thermal_expansion_coefficient']
         return elasticity / (1.0 - 2.0 * nu) * tec
 
+    def thermal_stress(self, T):
+        """The isotropic thermal stress  E/(1-2nu) * alpha * (T - T_ref)  (the multiplier of Identity(dim),
+        LinearElasticitySolver.py:78-85) for a number, an array of nodal temperatures or a Function."""
+        vals = T.vector().array() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
+        return self.thermal_stress_coefficient() * (vals - float(self.reference_values['temperature']))
+
+    def strain_energy(self, u):
+        raise SolverError("strain_energy: the reference's expression (LinearElasticitySolver.py:87-93) uses an undefined "
+                          "symbol and '^' on UFL objects; nothing to reproduce")
+
+    def solve_modal_form(self, F, bcs):
+        raise SolverError("modal analysis (SLEPc eigen-solver, LinearElasticitySolver.py:283-310) is not built")
+
     def get_flux(self, u, mag_vector):
         return mag_vector
 

@@ -339,6 +339,12 @@ class ScalarTransportSolver(SolverBase):
             T_amb = self.reference_values['temperature']
         return (float(emissivity) * Stefan_constant, float(T_amb))
 
+    def radiation_flux(self, T):
+        """m (Ta^4 - T^4) evaluated on numbers / arrays / a Function's nodal values (:361-376)."""
+        m, T_amb = self.radiation_coefficients()
+        vals = T.vector().array() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
+        return m * (T_amb ** 4 - vals ** 4)
+
     def refresh_nonlinear_form(self, F, T):
         """Re-evaluate the temperature-dependent coefficients of F at the Newton iterate T."""
         if F.conductivity_fn is not None:

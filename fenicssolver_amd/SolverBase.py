@@ -362,6 +362,20 @@ class SolverBase():
                 raise SolverError('time step can only be a sequence or scalar')
         return dt
 
+    def get_acceleration(self, time_iter_):
+        """(SolverBase.py:477-482) second difference of the last three steps, with the reference's own scaling
+        (it divides by 1/dt, "FIXME: does not work for non-uniform time step" there)."""
+        assert time_iter_ >= 1
+        dt, dt_prev = self.get_time_step(time_iter_), self.get_time_step(time_iter_ - 1)
+        vel = (self.w_current.vector().array() - self.w_prev.vector().array()) / dt
+        vel_prev = (self.w_prev.vector().array() - self.w_pp.vector().array()) / dt_prev
+        a = Function(self.function_space)
+        a.vector().set_local((vel - vel_prev) / (1.0 / dt))
+        return a
+
+    def _translate_dict_value_to_function(self, value):
+        raise NotImplementedError('not yet implemented')      # as in the reference (SolverBase.py:339-347)
+
     def get_current_time(self, time_iter_=None):
         if not time_iter_:
             time_iter_ = self.current_step
