@@ -246,7 +246,8 @@ class DeviceMatrix(_Handle):
         L.check(L.load().fs_assemble_matrix(self.h, C.byref(f), 1 if add else 0), "fs_assemble_matrix")
 
     def add_facet_mass(self, tri, h):
-        tri = L.i32(tri).reshape(-1, 3)
+        tri = L.i32(tri)
+        tri = tri.reshape(-1, 3) if tri.ndim == 1 else tri       # [nf,3] triangles (3-D) or [nf,2] edges (2-D)
         h = L.f64(np.broadcast_to(h, (tri.shape[0],)))
         L.check(L.load().fs_assemble_facet_matrix(self.h, tri.shape[0], L.p_i32(tri), L.p_f64(h)),
                 "fs_assemble_facet_matrix")
@@ -329,7 +330,8 @@ def assemble_vector(space, b, source=None, vector_value=None, div_coef=None, add
 
 def assemble_facet_vector(space, b, tri, g):
     """b_a += int g phi_a ds over the facets tri[nf,3]; g scalar, [ncomp], [nf] or [nf,ncomp]."""
-    tri = L.i32(tri).reshape(-1, 3)
+    tri = L.i32(tri)
+    tri = tri.reshape(-1, 3) if tri.ndim == 1 else tri           # [nf,3] triangles (3-D) or [nf,2] edges (2-D)
     nf, nc = tri.shape[0], space.ncomp
     g = np.asarray(g, dtype=np.float64)
     if g.ndim == 0:

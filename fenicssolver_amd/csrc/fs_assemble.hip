@@ -442,6 +442,156 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32
     }
 }
 
+// ---- 2-D: CG1 on triangles ------------------------------------------------------------------------
+// (the reference's runnable examples are 2-D: examples/test_heat_transfer.py:34, test_electrostatics.py:35)
+struct tri_geom {
+    double g[3][2];   // gradients of the barycentric basis
+    double area;
+};
+__device__ __forceinline__ tri_geom tri_geometry2(const double* __restrict__ xyz4, int32_t a, int32_t b, int32_t c) {
+    const double2 p0 = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)a];
+    const double2 p1 = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)b];
+    const double2 p2 = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)c];
+    const double e1x = p1.x - p0.x, e1y = p1.y - p0.y, e2x = p2.x - p0.x, e2y = p2.y - p0.y;
+    const double det = e1x * e2y - e1y * e2x;
+    const double inv = 1.0 / det;
+    tri_geom t;
+    t.g[1][0] = e2y * inv;  t.g[1][1] = -e2x * inv;
+    t.g[2][0] = -e1y * inv; t.g[2][1] = e1x * inv;
+    t.g[0][0] = -(t.g[1][0] + t.g[2][0]);
+    t.g[0][1] = -(t.g[1][1] + t.g[2][1]);
+    t.area = 0.5 * fabs(det);
+    return t;
+}
+
+// row-gather assembly, the triangle counterpart of k_assemble_p1_scalar_gather (lane = row, LDS row accumulator)
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+    const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
+    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
+    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = it.cur * wpb + wave;
+        if (s >= n_slices) continue;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const uint32_t packed = inc_pos[ibase + (int64_t)j * FS_SLICE + lane];
+            const int c = q / 3, a = q - 3 * c;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            double ga[2];
+            ga[0] = a == 0 ? t.g[0][0] : (a == 1 ? t.g[1][0] : t.g[2][0]);
+            ga[1] = a == 0 ? t.g[0][1] : (a == 1 ? t.g[1][1] : t.g[2][1]);
+            double row[3];
+            if (kc.mode == FS_COEF_TENSOR) {       // 2x2 tensor in the leading block of the 3x3 storage
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const double kx = kc.tensor[0] * t.g[b][0] + kc.tensor[1] * t.g[b][1];
+                    const double ky = kc.tensor[3] * t.g[b][0] + kc.tensor[4] * t.g[b][1];
+                    row[b] = t.area * (ga[0] * kx + ga[1] * ky);
+                }
+            } else {
+                double kk = 0.0;
+                if (kc.mode == FS_COEF_CONST) kk = kc.value;
+                else if (kc.mode == FS_COEF_CELL) kk = kc.data[c];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) row[b] = kk * t.area * (ga[0] * t.g[b][0] + ga[1] * t.g[b][1]);
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.area * (1.0 / 12.0);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) row[b] += (b == a ? 2.0 : 1.0) * mm;
+            }
+            if (ac.mode != FS_COEF_NONE) {         // Galerkin advection: scale * (area/3) * (v . grad phi_b)
+                double vx, vy;
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; }
+                const double w3 = ascale * t.area * (1.0 / 3.0);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) row[b] += w3 * (vx * t.g[b][0] + vy * t.g[b][1]);
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int k = (packed >> (8 * b)) & 255;
+                lds_acc[k * bd + tid] += row[b];
+            }
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_source(const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
+                                                                  int64_t nc, int64_t n_rows, coef_dev f, double* __restrict__ b) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[3] = {v4.x, v4.y, v4.z};
+        const tri_geom t = tri_geometry2(xyz4, v[0], v[1], v[2]);
+        double be[3];
+        if (f.mode == FS_COEF_NODAL) {
+            const double fe[3] = {f.data[v[0]], f.data[v[1]], f.data[v[2]]};
+            const double sum = fe[0] + fe[1] + fe[2];
+            for (int a = 0; a < 3; ++a) be[a] = t.area * (1.0 / 12.0) * (sum + fe[a]);
+        } else {
+            const double ff = f.mode == FS_COEF_CONST ? f.value : f.data[c];
+            for (int a = 0; a < 3; ++a) be[a] = ff * t.area * (1.0 / 3.0);
+        }
+        for (int a = 0; a < 3; ++a)
+            if (v[a] < n_rows) atomicAdd(&b[v[a]], be[a]);
+    }
+}
+
+// boundary edges: b_a += g len/2 ; A += h len/6 [[2,1],[1,2]]
+__global__ void k_edge_vector(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                              const double* __restrict__ g, int64_t n_rows, double* __restrict__ b) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = 0.5 * sqrt(dx * dx + dy * dy) * g[f];
+        if (a < n_rows) atomicAdd(&b[a], w);
+        if (c < n_rows) atomicAdd(&b[c], w);
+    }
+}
+__global__ void k_edge_matrix(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                              const double* __restrict__ h, int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                              const int32_t* __restrict__ sell_col, double* __restrict__ val, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 4; t += stride) {
+        const int64_t f = t >> 2;
+        const int i = (int)(t & 3) >> 1, j = (int)(t & 1);
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const int32_t row = i ? c : a, col = j ? c : a;
+        if (row >= n_rows) continue;
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = h[f] * sqrt(dx * dx + dy * dy) * (1.0 / 6.0) * (i == j ? 2.0 : 1.0);
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        const int k = fs_find_pos_local(sell_col, base, width, col);
+        if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], w);
+        else atomicAdd(err, 1);
+    }
+}
+
 // ---- load vectors -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
@@ -754,7 +904,26 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     FS_REQUIRE(mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL,
                "fs_assemble_matrix: mass coefficient must be constant or per cell");
     const int grid = fs_grid_for(m->nc, FS_BLOCK, 8192);
-    if (A->bs == 1 && sp->degree == 2) {
+    if (m->tdim == 2) {
+        FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
+        FS_REQUIRE(!(form->supg_pe > 0.0), "fs_assemble_matrix: SUPG is built for tetrahedral meshes");
+        FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
+        FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
+        dbuf<double> astore2;
+        coef_dev ac2;
+        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore2, &ac2, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE(ac2.mode == FS_COEF_NONE || ac2.mode == FS_COEF_CONST || ac2.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: advection velocity must be constant or per cell");
+        const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
+        const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
+        FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
+        const int wpb = bd / 64;
+        const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
+        if (add)
+            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p);
+    } else if (A->bs == 1 && sp->degree == 2) {
         FS_REQUIRE(sp->inc_cell.p, "fs_assemble_matrix: CG2 space has no assembly tables");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
@@ -820,6 +989,13 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     FS_CHECK(make_coef(form->div_coef, dlen, dstore, &dv, "fs_assemble_vector(div_coef)"));
     FS_REQUIRE(dv.mode == FS_COEF_NONE || space->ncomp == 3, "fs_assemble_vector: div_coef needs a vector space");
     if (space->ncomp == 1 && f.mode == FS_COEF_NONE) {
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
+    if (m->tdim == 2) {
+        FS_REQUIRE(f.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0), "fs_assemble_vector: unsupported option on a triangular mesh");
+        hipLaunchKernelGGL(k_assemble_tri_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
+        FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
@@ -920,6 +1096,21 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
                                         fs_vector_t b) {
     FS_REQUIRE(space && b && (n_facets == 0 || (tri && g)), "fs_assemble_facet_vector: null pointer");
     if (n_facets == 0) return FS_OK;
+    if (space->mesh->tdim == 2) {      // facets are edges: tri holds [n_facets][2] vertex pairs
+        for (int64_t i = 0; i < 2 * n_facets; ++i)
+            FS_REQUIRE(tri[i] >= 0 && tri[i] < space->n_nodes_local, "fs_assemble_facet_vector: edge vertex %d out of range", tri[i]);
+        hipStream_t s2 = fs_rt().stream;
+        dbuf<int32_t> d_ed;
+        dbuf<double> d_g2;
+        FS_CHECK(d_ed.alloc(2 * n_facets));
+        FS_CHECK(d_g2.alloc(n_facets));
+        FS_CHECK(d_ed.upload(tri, 2 * n_facets, s2));
+        FS_CHECK(d_g2.upload(g, n_facets, s2));
+        hipLaunchKernelGGL(k_edge_vector, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->n_nodes_owned, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s2));
+        return FS_OK;
+    }
     for (int64_t i = 0; i < 3 * n_facets; ++i)
         FS_REQUIRE(tri[i] >= 0 && tri[i] < space->n_nodes_local, "fs_assemble_facet_vector: facet vertex %d out of range", tri[i]);
     hipStream_t s = fs_rt().stream;
@@ -957,6 +1148,26 @@ extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const i
     if (sp->degree != 1) {
         fs_set_error("fs_assemble_facet_matrix: the Robin/HTC boundary matrix is not built for CG2 yet");
         return FS_ERR_UNSUPPORTED;
+    }
+    if (sp->mesh->tdim == 2) {
+        for (int64_t i = 0; i < 2 * n_facets; ++i)
+            FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->n_nodes_local, "fs_assemble_facet_matrix: edge vertex %d out of range", tri[i]);
+        hipStream_t s2 = fs_rt().stream;
+        dbuf<int32_t> d_ed;
+        dbuf<double> d_h2;
+        dbuf<int> d_err2;
+        FS_CHECK(d_ed.alloc(2 * n_facets));
+        FS_CHECK(d_h2.alloc(n_facets));
+        FS_CHECK(d_err2.alloc(1));
+        FS_CHECK(d_err2.zero(s2));
+        FS_CHECK(d_ed.upload(tri, 2 * n_facets, s2));
+        FS_CHECK(d_h2.upload(h, n_facets, s2));
+        hipLaunchKernelGGL(k_edge_matrix, dim3(fs_grid_for(4 * n_facets)), dim3(FS_BLOCK), 0, s2, sp->mesh->xyz.p, d_ed.p, n_facets, d_h2.p, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err2.p);
+        FS_KERNEL_CHECK();
+        int h_err2 = 0;
+        FS_CHECK(d_err2.download(&h_err2, 1, s2));
+        FS_REQUIRE(h_err2 == 0, "fs_assemble_facet_matrix: %d edge vertex pairs are not mesh edges", h_err2);
+        return FS_OK;
     }
     for (int64_t i = 0; i < 3 * n_facets; ++i)
         FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->n_nodes_local, "fs_assemble_facet_matrix: facet vertex %d out of range", tri[i]);

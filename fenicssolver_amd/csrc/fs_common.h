@@ -105,6 +105,7 @@ struct fs_mesh_s {
     int64_t nv = 0;       // local vertices (owned + ghost)
     int64_t nc = 0;       // local cells
     int64_t n_owned = 0;  // owned vertices (first n_owned local ids)
+    int tdim = 3;         // 3: tetrahedra; 2: triangles (xyz stores (x,y,0,0), cells (v0,v1,v2,-1))
     dbuf<double> xyz;     // [nv][4] padded (x,y,z,0): two 16-B loads per vertex
     dbuf<int32_t> cells;  // [nc][4] local vertex ids
     dbuf<int64_t> gid;    // [nv] global vertex ids

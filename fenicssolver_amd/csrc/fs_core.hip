@@ -1,6 +1,7 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
 #include "fs_kernels.h"
+#include <vector>
 #include <stdlib.h>
 
 // ---- errors / runtime --------------------------------------------------------------
@@ -223,27 +224,41 @@ extern "C" int fs_mesh_create(int gdim, int64_t nv, const double* xyz, int64_t n
                               int verts_per_cell, int64_t n_owned, fs_mesh_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(out && xyz && cells, "fs_mesh_create: null pointer");
-    if (gdim != 3 || verts_per_cell != 4) {
-        fs_set_error("fs_mesh_create: only tetrahedral meshes in 3D are supported (gdim=%d, verts_per_cell=%d)",
+    const bool tri = gdim == 2 && verts_per_cell == 3;
+    if (!tri && (gdim != 3 || verts_per_cell != 4)) {
+        fs_set_error("fs_mesh_create: tetrahedral meshes in 3D and triangular meshes in 2D are supported (gdim=%d, verts_per_cell=%d)",
                      gdim, verts_per_cell);
         return FS_ERR_UNSUPPORTED;
     }
     FS_REQUIRE(nv > 0 && nc > 0 && n_owned >= 0 && n_owned <= nv, "fs_mesh_create: bad sizes");
     FS_REQUIRE(nv < (int64_t)INT32_MAX, "fs_mesh_create: vertex count exceeds int32");
-    for (int64_t i = 0; i < nc * 4; ++i) {
+    for (int64_t i = 0; i < nc * verts_per_cell; ++i) {
         if (cells[i] < 0 || cells[i] >= nv) {
-            fs_set_error("fs_mesh_create: cell %lld references vertex %d outside [0,%lld)", (long long)(i / 4),
+            fs_set_error("fs_mesh_create: cell %lld references vertex %d outside [0,%lld)", (long long)(i / verts_per_cell),
                          cells[i], (long long)nv);
             return FS_ERR_INVALID;
         }
     }
+    FS_REQUIRE(!tri || n_owned == nv, "fs_mesh_create: triangular meshes are single-GPU for now");
     hipStream_t s = fs_rt().stream;
     fs_mesh_s* m = new fs_mesh_s();
     m->nv = nv;
     m->nc = nc;
     m->n_owned = n_owned;
+    m->tdim = tri ? 2 : 3;
     dbuf<double> tmp;
     int rc = FS_OK;
+    // triangles are stored in the same padded layout: (x, y, 0, 0) and (v0, v1, v2, -1)
+    std::vector<double> x3;
+    std::vector<int32_t> c4;
+    if (tri) {
+        x3.resize((size_t)nv * 3);
+        for (int64_t i = 0; i < nv; ++i) { x3[3 * i] = xyz[2 * i]; x3[3 * i + 1] = xyz[2 * i + 1]; x3[3 * i + 2] = 0.0; }
+        c4.resize((size_t)nc * 4);
+        for (int64_t c = 0; c < nc; ++c) { c4[4 * c] = cells[3 * c]; c4[4 * c + 1] = cells[3 * c + 1]; c4[4 * c + 2] = cells[3 * c + 2]; c4[4 * c + 3] = -1; }
+        xyz = x3.data();
+        cells = c4.data();
+    }
     if ((rc = m->xyz.alloc(nv * 4)) != FS_OK || (rc = m->cells.alloc(nc * 4)) != FS_OK ||
         (rc = m->gid.alloc(nv)) != FS_OK || (rc = tmp.alloc(nv * 3)) != FS_OK ||
         (rc = tmp.upload(xyz, nv * 3, s)) != FS_OK || (rc = m->cells.upload(cells, nc * 4, s)) != FS_OK) {

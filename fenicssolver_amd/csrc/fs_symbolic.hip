@@ -404,6 +404,16 @@ __global__ void k_slots_generic(const int32_t* __restrict__ cell_dofs, int nd, i
     }
 }
 
+__global__ void k_compact_tri_cells(const int32_t* __restrict__ cells4, int64_t nc, int32_t* __restrict__ cells3) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        cells3[3 * c] = cells4[4 * c];
+        cells3[3 * c + 1] = cells4[4 * c + 1];
+        cells3[3 * c + 2] = cells4[4 * c + 2];
+    }
+}
+
 // ---- API -----------------------------------------------------------------------------------
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
     FS_CHECK(fs_require_init());
@@ -449,6 +459,19 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         }                                                                                     \
     } while (0)
 
+    if (mesh->tdim == 2) {
+        // triangles: CG1 scalar spaces; the compact [nc][3] dof table feeds the generic pattern / incidence code
+        if (degree != 1 || ncomp != 1) {
+            fs_set_error("fs_space_create: triangular meshes carry scalar CG1 spaces only (degree=%d ncomp=%d)", degree, ncomp);
+            delete sp;
+            return FS_ERR_UNSUPPORTED;
+        }
+        FS_SP(sp->cell_dofs_store.alloc(3 * nc));
+        hipLaunchKernelGGL(k_compact_tri_cells, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, sp->cell_dofs_store.p);
+        FS_SP_HIP(hipGetLastError());
+        sp->ndof_cell = 3;
+        sp->cell_dofs = sp->cell_dofs_store.p;
+    }
     if (degree == 2) {
         // edge nodes: unique (min,max) vertex pairs in lexicographic order = oracle/DOLFIN-style edge numbering
         const int64_t n_ek = 6 * nc;

@@ -63,8 +63,9 @@ int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_by
 
 /* ---- mesh  (dolfin.Mesh / BoxMesh, SolverBase.py:203-258) -------------------- */
 
-/* Upload a tetrahedral mesh.  xyz[nv][gdim] (gdim must be 3), cells[nc][4]
- * vertex indices.  The first n_owned vertices are the rows this process owns
+/* Upload a tetrahedral mesh (gdim 3, 4 vertices per cell) or a triangular mesh (gdim 2, 3 vertices per
+ * cell: scalar CG1 spaces, one GPU; facet lists of the boundary calls are then [n_facets][2] edge vertex pairs).
+ * xyz[nv][gdim], cells[nc][verts_per_cell] vertex indices.  The first n_owned vertices are the rows this process owns
  * (n_owned == nv on one GPU); the remainder are ghost vertices whose values
  * arrive by halo exchange. */
 int fs_mesh_create(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells,

@@ -763,3 +763,111 @@ def supg_facet_terms(coords, cells, facet_cells, velocity, pe, g=None, h=None):
                 rows.append(cells[c, a]); cols.append(bnode); vals.append(hk * area / 3.0 * w[c, a])
     dA = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
     return dA, db
+
+
+# ---- 2-D P1 (triangles): the reference's runnable examples are 2-D (examples/test_heat_transfer.py:34,
+# test_electrostatics.py:35 use UnitSquareMesh(40, 40)) ---------------------------------------------------
+def rectangle_mesh(p0, p1, nx, ny):
+    """RectangleMesh(Point(p0), Point(p1), nx, ny) / UnitSquareMesh with the default "right" diagonal: vertices
+    x-fastest, per square (iy outer, ix inner) the cells (v0, v1, v3) and (v0, v2, v3) [upstream DOLFIN RectangleMesh]."""
+    xs = np.array([p0[0] + (i * (p1[0] - p0[0])) / nx for i in range(nx + 1)])
+    ys = np.array([p0[1] + (j * (p1[1] - p0[1])) / ny for j in range(ny + 1)])
+    coords = np.stack([np.tile(xs, ny + 1), np.repeat(ys, nx + 1)], axis=1)
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    v0 = (iy * (nx + 1) + ix).ravel()
+    v1, v2 = v0 + 1, v0 + (nx + 1)
+    v3 = v2 + 1
+    cells = np.stack([np.stack([v0, v1, v3], axis=1), np.stack([v0, v2, v3], axis=1)], axis=1).reshape(-1, 3)
+    return coords, np.sort(cells, axis=1).astype(np.int32)
+
+
+def tri_edge_numbering(cells):
+    """Facets of a triangle mesh = edges, ranked lexicographically; local facet i is opposite local vertex i.
+    Returns (edges [ne,2], cell_facets [nc,3], count [ne])."""
+    cells = np.asarray(cells, dtype=np.int64)
+    opp = [(1, 2), (0, 2), (0, 1)]
+    ed = np.sort(np.stack([cells[:, list(o)] for o in opp], axis=1).reshape(-1, 2), axis=1)
+    uniq, inv, cnt = np.unique(ed, axis=0, return_inverse=True, return_counts=True)
+    return uniq.astype(np.int32), inv.reshape(len(cells), 3).astype(np.int32), cnt.astype(np.int32)
+
+
+def tri_geometry(coords, cells):
+    """(area [nc], grad phi [nc,3,2]) of P1 on triangles."""
+    c = np.asarray(coords, dtype=np.float64)[np.asarray(cells, dtype=np.int64)]
+    e1, e2 = c[:, 1] - c[:, 0], c[:, 2] - c[:, 0]
+    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    g = np.zeros((len(c), 3, 2))
+    g[:, 1] = np.stack([e2[:, 1], -e2[:, 0]], axis=1) / det[:, None]
+    g[:, 2] = np.stack([-e1[:, 1], e1[:, 0]], axis=1) / det[:, None]
+    g[:, 0] = -(g[:, 1] + g[:, 2])
+    return 0.5 * np.abs(det), g
+
+
+def tri_stiffness_local(coords, cells, k=1.0):
+    area, g = tri_geometry(coords, cells)
+    kk = np.broadcast_to(np.asarray(k, dtype=np.float64), (len(area),))
+    return (kk * area)[:, None, None] * np.einsum("cai,cbi->cab", g, g)
+
+
+def tri_mass_local(coords, cells, c=1.0):
+    area, _ = tri_geometry(coords, cells)
+    cc = np.broadcast_to(np.asarray(c, dtype=np.float64), (len(area),))
+    return (cc * area / 12.0)[:, None, None] * (np.ones((3, 3)) + np.eye(3))[None]
+
+
+def tri_advection_local(coords, cells, velocity, scale=1.0):
+    area, g = tri_geometry(coords, cells)
+    v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(area), 2))
+    vg = np.einsum("ci,cbi->cb", v, g)
+    return scale * (area / 3.0)[:, None, None] * np.broadcast_to(vg[:, None, :], (len(area), 3, 3))
+
+
+def assemble_tri_source(coords, cells, f=1.0, f_nodal=None):
+    area, _ = tri_geometry(coords, cells)
+    cells = np.asarray(cells, dtype=np.int64)
+    b = np.zeros(len(coords))
+    if f_nodal is not None:
+        fe = np.asarray(f_nodal, dtype=np.float64)[cells]
+        be = (area / 12.0)[:, None] * (fe.sum(axis=1, keepdims=True) + fe)
+    else:
+        be = np.broadcast_to((np.broadcast_to(np.asarray(f, dtype=np.float64), area.shape) * area / 3.0)[:, None], (len(area), 3))
+    np.add.at(b, cells.ravel(), be.ravel())
+    return b
+
+
+def assemble_edge_load(coords, edges, markers, marker_id, g):
+    """int g phi_a ds over the marked boundary edges: g * length / 2 on both end points."""
+    e = np.asarray(edges, dtype=np.int64)[np.asarray(markers) == marker_id]
+    length = np.linalg.norm(np.asarray(coords)[e[:, 1]] - np.asarray(coords)[e[:, 0]], axis=1)
+    b = np.zeros(len(coords))
+    np.add.at(b, e.ravel(), np.repeat(np.broadcast_to(g, length.shape) * length / 2.0, 2))
+    return b
+
+
+def assemble_edge_mass(coords, edges, markers, marker_id, h):
+    """int h T q ds: h * length/6 * [[2,1],[1,2]] per marked edge."""
+    import scipy.sparse as sp
+    e = np.asarray(edges, dtype=np.int64)[np.asarray(markers) == marker_id]
+    length = np.linalg.norm(np.asarray(coords)[e[:, 1]] - np.asarray(coords)[e[:, 0]], axis=1)
+    w = np.broadcast_to(h, length.shape) * length / 6.0
+    rows = np.concatenate([e[:, 0], e[:, 0], e[:, 1], e[:, 1]])
+    cols = np.concatenate([e[:, 0], e[:, 1], e[:, 0], e[:, 1]])
+    vals = np.concatenate([2 * w, w, w, 2 * w])
+    n = len(coords)
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+
+
+def mark_edges(coords, cells, inside, marker_id, markers=None, eps=3e-16):
+    """SubDomain.mark on the facets (edges) of a triangle mesh: every vertex and the mid-point inside."""
+    edges, _, cnt = tri_edge_numbering(cells)
+    if markers is None:
+        markers = np.zeros(len(edges), dtype=np.int64)
+    co = np.asarray(coords, dtype=np.float64)
+    for i, (a, b) in enumerate(edges):
+        ob = cnt[i] == 1
+        pts = (co[a], co[b], 0.5 * (co[a] + co[b]))
+        if all(inside(p, ob) for p in pts):
+            markers[i] = marker_id
+    return markers

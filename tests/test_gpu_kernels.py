@@ -472,3 +472,53 @@ def test_supg_terms_match_oracle(gpu):
         dA, db = fo.supg_facet_terms(co, ce, fcells, vel, pe, gval, hval)
         assert abs((_csr(A) - base) - dA).max() <= 1e-12 * abs(dA).max()
         assert np.abs(b.get() - db).max() <= 1e-12 * np.abs(db).max()
+
+
+def test_triangle_mesh_kernels_match_oracle(gpu):
+    """2-D CG1 on triangles (the reference's runnable examples are 2-D): pattern, stiffness / mass / advection,
+    sources, boundary-edge loads and Robin matrices, Dirichlet + CG, against the numpy oracle."""
+    co, ce = fo.rectangle_mesh((0.0, 0.0), (1.0, 0.6), 7, 5)
+    rng = np.random.default_rng(2)
+    inner = (co[:, 0] > 0) & (co[:, 0] < 1) & (co[:, 1] > 0) & (co[:, 1] < 0.6)
+    co = co + 0.02 * rng.standard_normal(co.shape) * inner[:, None]
+    n = len(co)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh)
+    assert V.n_owned == n
+    kc = rng.uniform(0.5, 2.0, len(ce))
+    vel = rng.standard_normal((len(ce), 3))
+    vel[:, 2] = 0.0
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=("cell", kc), mass=3.0, advection=vel, advection_scale=1.7)
+    ref = fo.assemble_generic(n, ce, fo.tri_stiffness_local(co, ce, kc) + fo.tri_mass_local(co, ce, 3.0)
+                              + fo.tri_advection_local(co, ce, vel[:, :2], 1.7))
+    M = _csr(A)
+    _assert_same_pattern(M, fo.assemble_generic(n, ce, np.ones((len(ce), 3, 3))))
+    assert abs(M - ref).max() <= RTOL_ASSEMBLY * abs(ref).max()
+    b = gpu.DeviceVector(n)
+    fn = np.sin(3 * co[:, 0]) + co[:, 1]
+    gpu.assemble_vector(V, b, source=("nodal", fn))
+    assert np.abs(b.get() - fo.assemble_tri_source(co, ce, f_nodal=fn)).max() <= 1e-14
+    gpu.assemble_vector(V, b, source=("cell", kc))
+    assert np.abs(b.get() - fo.assemble_tri_source(co, ce, kc)).max() <= 1e-14
+    # boundary edges
+    edges, cf, cnt = fo.tri_edge_numbering(ce)
+    fm = fo.mark_edges(co, ce, lambda x, ob: ob and abs(x[0] - 1.0) < 1e-12, 1)
+    fm = fo.mark_edges(co, ce, lambda x, ob: ob and abs(x[1]) < 1e-12, 2, fm)
+    e1, e2 = edges[fm == 1], edges[fm == 2]
+    b.fill(0.0)
+    gpu.assemble_facet_vector(V, b, e1, 36.0)
+    assert np.abs(b.get() - fo.assemble_edge_load(co, edges, fm, 1, 36.0)).max() <= 1e-13
+    A.assemble(stiffness=1.0)
+    base = _csr(A)
+    A.add_facet_mass(e2, 100.0)
+    assert abs((_csr(A) - base) - fo.assemble_edge_mass(co, edges, fm, 2, 100.0)).max() <= 1e-12
+    # Dirichlet + CG: the linear function is reproduced exactly
+    A.assemble(stiffness=2.5)
+    b.fill(0.0)
+    bnd = np.nonzero(~inner)[0].astype(np.int32)
+    exact = 3.0 * co[:, 0] - 2.0 * co[:, 1] + 1.0
+    A.apply_dirichlet(b, bnd, exact[bnd], symmetric=True)
+    x = gpu.DeviceVector(V.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-13, max_iter=2000)
+    assert st["converged"] == 1 and np.abs(x.get() - exact).max() <= 1e-10
