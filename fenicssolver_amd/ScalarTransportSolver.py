@@ -15,6 +15,7 @@ capacity rho*cp, not the conductivity (B-Q8).
 """
 from __future__ import annotations
 
+import math
 import numbers
 import os
 
@@ -149,10 +150,10 @@ class ScalarTransportSolver(SolverBase):
             vals = v.values()
             if vals.size != self.dimension:
                 raise SolverError('convective_velocity must have {} components'.format(self.dimension))
-            return np.asarray(vals, dtype=np.float64)
+            return self._pad3(np.asarray(vals, dtype=np.float64))
         if isinstance(v, (tuple, list, np.ndarray)) and len(v) == self.dimension and \
                 all(isinstance(c, numbers.Number) for c in v):
-            return np.asarray(v, dtype=np.float64)
+            return self._pad3(np.asarray(v, dtype=np.float64))
         if isinstance(v, (tuple, list)) and len(v) == self.dimension and all(isinstance(c, str) for c in v):
             v = Expression(tuple(v), degree=self.settings['fe_degree'])
         if isinstance(v, Expression):
@@ -164,7 +165,15 @@ class ScalarTransportSolver(SolverBase):
         nod = np.asarray(nod, dtype=np.float64)
         if nod.ndim != 2 or nod.shape[1] != self.dimension:
             raise SolverError('convective_velocity must be a {}-vector field'.format(self.dimension))
-        return nod[self.mesh.cells().astype(np.int64)].mean(axis=1)
+        return self._pad3(nod[self.mesh.cells().astype(np.int64)].mean(axis=1))
+
+    @staticmethod
+    def _pad3(v):
+        """Velocities travel to the device as 3-vectors (2-D problems: v_z = 0)."""
+        v = np.asarray(v, dtype=np.float64)
+        if v.shape[-1] == 3:
+            return v
+        return np.concatenate([v, np.zeros(v.shape[:-1] + (3 - v.shape[-1],))], axis=-1)
 
     # ------------------------------------------------------------------ boundary conditions
     def update_boundary_conditions(self, time_iter_, T, Tq, ds):
@@ -370,27 +379,17 @@ class ScalarTransportSolver(SolverBase):
             raise SolverError('boundary_flux needs a constant conductivity')
         mesh = self.mesh
         co, cells = mesh.coordinates(), mesh.cells().astype(np.int64)
+        d = co.shape[1]                                   # 3: tetrahedra, 2: triangles
         sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
         cf = mesh.cell_facets()
+        c_idx, lf = np.nonzero(np.isin(cf, sel))          # boundary facets belong to exactly one cell
         T = self.result.vector().array()
-        total = 0.0
-        owner = {}
-        for c in range(len(cells)):
-            for lf in range(4):
-                owner.setdefault(int(cf[c, lf]), (c, lf))
-        for f in sel:
-            c, lf = owner[int(f)]
-            v = cells[c]
-            X = co[v]
-            J = np.stack([X[1] - X[0], X[2] - X[0], X[3] - X[0]], axis=1)
-            g = np.zeros((4, 3))
-            g[1:] = np.linalg.inv(J)
-            g[0] = -g[1:].sum(axis=0)
-            gradT = T[v] @ g
-            tri = [i for i in range(4) if i != lf]
-            p = X[tri]
-            nvec = 0.5 * np.cross(p[1] - p[0], p[2] - p[0])
-            if np.dot(nvec, p[0] - X[lf]) < 0:
-                nvec = -nvec    # outward: away from the opposite vertex
-            total += float(k) * float(gradT @ nvec)
-        return total
+        X = co[cells[c_idx]]                              # [nf, d+1, d]
+        J = np.stack([X[:, k + 1] - X[:, 0] for k in range(d)], axis=2)
+        ginv = np.linalg.inv(J)                           # rows: grad lambda_1..d
+        g = np.concatenate([-ginv.sum(axis=1, keepdims=True), ginv], axis=1)       # [nf, d+1, d] grad lambda_a
+        vol = np.abs(np.linalg.det(J)) / math.factorial(d)
+        gradT = np.einsum("fa,fad->fd", T[cells[c_idx]], g)
+        # outward normal times facet measure = - d * |cell| * grad lambda_(opposite vertex)
+        nmeas = -d * vol[:, None] * g[np.arange(len(c_idx)), lf]
+        return float(k) * float(np.einsum("fd,fd->", gradT, nmeas))

@@ -933,6 +933,9 @@ class SolverBase():
 def write_vtu(path, mesh, function, name, extra=()):
     """ASCII VTK unstructured grid of a nodal function on a tet mesh (vertex values); extra: [(Function, name)]."""
     co, ce = mesh.coordinates(), mesh.cells()
+    if co.shape[1] == 2:          # VTK points are 3-D
+        co = np.concatenate([co, np.zeros((len(co), 1))], axis=1)
+    nvc = ce.shape[1]             # 4: tetra (VTK type 10), 3: triangle (type 5)
     vals = function.vertex_values()
     ncomp = 1 if vals.ndim == 1 else vals.shape[1]
     with open(path, "w") as fh:
@@ -943,9 +946,9 @@ def write_vtu(path, mesh, function, name, extra=()):
         fh.write('</DataArray>\n</Points>\n<Cells>\n<DataArray type="Int32" Name="connectivity" format="ascii">\n')
         np.savetxt(fh, ce, fmt="%d")
         fh.write('</DataArray>\n<DataArray type="Int32" Name="offsets" format="ascii">\n')
-        np.savetxt(fh, (np.arange(len(ce)) + 1) * 4, fmt="%d")
+        np.savetxt(fh, (np.arange(len(ce)) + 1) * nvc, fmt="%d")
         fh.write('</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n')
-        np.savetxt(fh, np.full(len(ce), 10), fmt="%d")
+        np.savetxt(fh, np.full(len(ce), 10 if nvc == 4 else 5), fmt="%d")
         fh.write('</DataArray>\n</Cells>\n')
         fh.write('<PointData %s="%s">\n' % ("Scalars" if ncomp == 1 else "Vectors", name))
         fh.write('<DataArray type="Float64" Name="%s" NumberOfComponents="%d" format="ascii">\n' % (name, ncomp))

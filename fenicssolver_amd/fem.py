@@ -63,6 +63,7 @@ class Point:
 # --------------------------------------------------------------------------------------------
 _VERT_RE = re.compile(r'<vertex\s+index="(\d+)"\s+x="([^"]+)"\s+y="([^"]+)"(?:\s+z="([^"]+)")?')
 _TET_RE = re.compile(r'<tetrahedron\s+index="(\d+)"\s+v0="(\d+)"\s+v1="(\d+)"\s+v2="(\d+)"\s+v3="(\d+)"')
+_TRI_RE = re.compile(r'<triangle\s+index="(\d+)"\s+v0="(\d+)"\s+v1="(\d+)"\s+v2="(\d+)"')
 _ENT_RE = re.compile(r'<entity\s+index="(\d+)"\s+value="(-?\d+)"')
 _MF_RE = re.compile(r'<mesh_function\s+type="(\w+)"\s+dim="(\d+)"\s+size="(\d+)"')
 _MVC_RE = re.compile(r'<value\s+cell_index="(\d+)"\s+local_entity="(\d+)"\s+value="(-?\d+)"')
@@ -85,7 +86,8 @@ class _Topology:
 
 
 class Mesh:
-    """Tetrahedral mesh (dolfin.Mesh; SolverBase.py:203-258).  ``Mesh(path)`` reads DOLFIN XML."""
+    """Tetrahedral (3-D) or triangular (2-D) mesh (dolfin.Mesh; SolverBase.py:203-258).  ``Mesh(path)`` reads
+    DOLFIN XML.  Facets are the entities of dimension tdim - 1: triangles in 3-D, edges in 2-D."""
 
     def __init__(self, filename=None, coords=None, cells=None):
         if filename is not None:
@@ -95,8 +97,8 @@ class Mesh:
         self._coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         self._cells = np.sort(cells, axis=1)  # mesh.order()
-        if self._coords.shape[1] != 3 or self._cells.shape[1] != 4:
-            raise SolverError("only tetrahedral meshes in 3D are supported by fenicssolver_amd "
+        if (self._coords.shape[1], self._cells.shape[1]) not in ((3, 4), (2, 3)):
+            raise SolverError("tetrahedral meshes in 3D and triangular meshes in 2D are supported by fenicssolver_amd "
                               "(got gdim=%d, %d vertices per cell)" % (self._coords.shape[1], self._cells.shape[1]))
         self._topo = None
         self._device = None
@@ -108,8 +110,17 @@ class Mesh:
         text = open(path, "r").read()
         verts = _VERT_RE.findall(text)
         tets = _TET_RE.findall(text)
-        if not verts or not tets:
-            raise SolverError("{}: not a DOLFIN-XML tetrahedral mesh".format(path))
+        tris = _TRI_RE.findall(text) if not tets else []
+        if not verts or not (tets or tris):
+            raise SolverError("{}: not a DOLFIN-XML tetrahedral or triangular mesh".format(path))
+        if tris:
+            coords = np.zeros((len(verts), 2))
+            for idx, x, y, z in verts:
+                coords[int(idx)] = (float(x), float(y))
+            cells = np.zeros((len(tris), 3), dtype=np.int32)
+            for t in tris:
+                cells[int(t[0])] = (int(t[1]), int(t[2]), int(t[3]))
+            return coords, cells
         coords = np.zeros((len(verts), 3))
         for idx, x, y, z in verts:
             coords[int(idx)] = (float(x), float(y), float(z) if z != "" else 0.0)
@@ -138,11 +149,12 @@ class Mesh:
         return self._cells.shape[0]
 
     def num_entities(self, dim):
+        tdim = self._cells.shape[1] - 1
         if dim == 0:
             return self.num_vertices()
-        if dim == 3:
+        if dim == tdim:
             return self.num_cells()
-        if dim == 2:
+        if dim == tdim - 1:
             return len(self.facets())
         if dim == 1:
             return len(self.edges())
@@ -153,7 +165,8 @@ class Mesh:
 
     def hmin(self):
         c = self._coords[self._cells.astype(np.int64)]
-        e = [np.linalg.norm(c[:, i] - c[:, j], axis=1) for i in range(4) for j in range(i + 1, 4)]
+        nvc = self._cells.shape[1]
+        e = [np.linalg.norm(c[:, i] - c[:, j], axis=1) for i in range(nvc) for j in range(i + 1, nvc)]
         return float(np.min(e))
 
     # topology (lexicographic numbering) --------------------------------
@@ -162,6 +175,15 @@ class Mesh:
             return self._topo
         cells = self._cells.astype(np.int64)
         nv = self.num_vertices()
+        if cells.shape[1] == 3:      # triangles: facets are the edges, facet i opposite local vertex i
+            ed = np.stack([cells[:, [1, 2]], cells[:, [0, 2]], cells[:, [0, 1]]], axis=1).reshape(-1, 2)
+            ekey = ed[:, 0] * nv + ed[:, 1]
+            uekey, einv, cnt = np.unique(ekey, return_inverse=True, return_counts=True)
+            edges = np.stack([uekey // nv, uekey % nv], axis=1).astype(np.int32)
+            self._topo = dict(facets=edges, cell_facets=einv.reshape(-1, 3).astype(np.int32),
+                              facet_count=cnt.astype(np.int32), edges=edges,
+                              cell_edges=einv.reshape(-1, 3).astype(np.int32))
+            return self._topo
         opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))  # facet i is opposite local vertex i
         tri = np.stack([cells[:, list(o)] for o in opp], axis=1).reshape(-1, 3)  # already ascending
         key = (tri[:, 0] * nv + tri[:, 1]) * nv + tri[:, 2]
@@ -234,6 +256,33 @@ class UnitCubeMesh(BoxMesh):
         BoxMesh.__init__(self, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), nx, ny, nz)
 
 
+class RectangleMesh(Mesh):
+    """dolfin.RectangleMesh(Point, Point, nx, ny[, diagonal]): vertices x-fastest; per square (iy outer, ix inner) the
+    two triangles (v0, v1, v3), (v0, v2, v3) of the default "right" diagonal (examples/test_heat_transfer.py:34 uses
+    UnitSquareMesh(40, 40))."""
+
+    def __init__(self, p0, p1, nx, ny, diagonal="right"):
+        if diagonal != "right":
+            raise SolverError("RectangleMesh: only the default 'right' diagonal is built")
+        a = (p0.array() if isinstance(p0, Point) else np.asarray(p0, dtype=np.float64))[:2]
+        b = (p1.array() if isinstance(p1, Point) else np.asarray(p1, dtype=np.float64))[:2]
+        nx, ny = int(nx), int(ny)
+        x = a[0] + (np.arange(nx + 1, dtype=np.float64) * (b[0] - a[0])) / float(nx)
+        y = a[1] + (np.arange(ny + 1, dtype=np.float64) * (b[1] - a[1])) / float(ny)
+        coords = np.stack([np.tile(x, ny + 1), np.repeat(y, nx + 1)], axis=1)
+        ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+        v0 = (iy * (nx + 1) + ix).ravel().astype(np.int64)
+        v1, v2 = v0 + 1, v0 + (nx + 1)
+        v3 = v2 + 1
+        cells = np.stack([np.stack([v0, v1, v3], axis=1), np.stack([v0, v2, v3], axis=1)], axis=1).reshape(-1, 3)
+        Mesh.__init__(self, coords=coords, cells=cells)
+
+
+class UnitSquareMesh(RectangleMesh):
+    def __init__(self, nx, ny, diagonal="right"):
+        RectangleMesh.__init__(self, (0.0, 0.0), (1.0, 1.0), nx, ny, diagonal)
+
+
 class MeshFunction:
     """dolfin.MeshFunction("size_t", mesh, dim | filename[, value])."""
 
@@ -268,10 +317,11 @@ class MeshFunction:
             dim = int(dm.group(1))
             a = np.zeros(mesh.num_entities(dim), dtype=dt)
             cf = mesh.cell_facets()
+            tdim = mesh.topology().dim()
             for c, le, v in vals:
-                if dim == 2:
+                if dim == tdim - 1:
                     a[cf[int(c), int(le)]] = int(v)
-                elif dim == 3:
+                elif dim == tdim:
                     a[int(c)] = int(v)
             return dim, a
         raise SolverError("{}: unknown DOLFIN-XML mesh function format".format(path))
@@ -322,14 +372,15 @@ class SubDomain:
         mesh = mesh_function.mesh()
         dim = mesh_function.dim()
         co = mesh.coordinates()
-        if dim == 2:
+        tdim = mesh.topology().dim()
+        if dim == tdim - 1:
             ent = mesh.facets().astype(np.int64)
             on_b = mesh.exterior_facets()
-        elif dim == 3:
+        elif dim == tdim:
             ent = mesh.cells().astype(np.int64)
             on_b = np.zeros(len(ent), dtype=bool)
         else:
-            raise SolverError("SubDomain.mark: only facet (dim 2) and cell (dim 3) functions are supported")
+            raise SolverError("SubDomain.mark: only facet and cell functions are supported")
         vert_on_b = np.zeros(mesh.num_vertices(), dtype=bool)
         vert_on_b[mesh.facets()[mesh.exterior_facets()].ravel()] = True
         vin = self._inside_points(co, vert_on_b)
@@ -432,8 +483,12 @@ class Expression:
         return int(np.prod(self._shape)) if self._shape else 1
 
     def eval_points(self, pts):
-        """pts[n,3] -> values[n] (scalar) or [n, size]."""
-        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+        """pts[n,3] (or [n,2] on 2-D meshes) -> values[n] (scalar) or [n, size]."""
+        pts = np.asarray(pts, dtype=np.float64)
+        if pts.ndim == 1:
+            pts = pts.reshape(1, -1)
+        if pts.shape[1] < 3:
+            pts = np.concatenate([pts, np.zeros((pts.shape[0], 3 - pts.shape[1]))], axis=1)
         env = dict(_ALLOWED)
         env.update(self.params)
         env.update(x0=pts[:, 0], x1=pts[:, 1], x2=pts[:, 2])
@@ -488,6 +543,8 @@ class FunctionSpace:
             raise SolverError("vector P2 spaces are not built in fenicssolver_amd (P2 is scalar)")
         if constrained_domain is not None:
             raise SolverError("periodic_boundary (constrained_domain) is not supported")
+        if mesh.topology().dim() == 2 and (int(degree) != 1 or _ncomp != 1):
+            raise SolverError("2-D (triangular) meshes carry scalar P1 spaces only in fenicssolver_amd")
         self._mesh = mesh
         self._degree = int(degree)
         self._ufl_element = _Element("Lagrange", int(degree), _ncomp)
@@ -657,6 +714,20 @@ class _Vector:
         self._a[i] = v
 
 
+def locate_point(mesh, p):
+    """(cell index, barycentric coordinates) of the cell holding point p (brute force; post-processing sizes)."""
+    co, ce = mesh.coordinates(), mesh.cells().astype(np.int64)
+    gdim = co.shape[1]
+    c = co[ce]
+    T = np.stack([c[:, k + 1] - c[:, 0] for k in range(gdim)], axis=2)
+    lam = np.linalg.solve(T, np.broadcast_to(np.asarray(p, dtype=np.float64)[:gdim] - c[:, 0], (len(ce), gdim))[:, :, None])[:, :, 0]
+    bary = np.concatenate([1.0 - lam.sum(axis=1, keepdims=True), lam], axis=1)
+    i = int(np.argmax(bary.min(axis=1)))
+    if bary[i].min() < -1e-10:
+        raise SolverError("point {} is outside the mesh".format(p))
+    return i, bary[i]
+
+
 class Function:
     """dolfin.Function(V) (SolverBase.py:472-475)."""
 
@@ -719,17 +790,9 @@ class Function:
             xs = xs.array()
         p[: len(xs)] = xs
         mesh = self._V.mesh()
-        co, ce = mesh.coordinates(), mesh.cells().astype(np.int64)
-        c = co[ce]
-        T = np.stack([c[:, 1] - c[:, 0], c[:, 2] - c[:, 0], c[:, 3] - c[:, 0]], axis=2)
-        lam = np.linalg.solve(T, (p - c[:, 0])[:, :, None])[:, :, 0]
-        l0 = 1.0 - lam.sum(axis=1)
-        bary = np.concatenate([l0[:, None], lam], axis=1)
-        i = int(np.argmax(bary.min(axis=1)))
-        if bary[i].min() < -1e-10:
-            raise SolverError("point {} is outside the mesh".format(p))
-        vals = self.vertex_values()[ce[i]]
-        return bary[i] @ vals
+        i, bary = locate_point(mesh, p)
+        vals = self.vertex_values()[mesh.cells().astype(np.int64)[i]]
+        return bary @ vals
 
 
 def interpolate(v, V):
@@ -790,16 +853,9 @@ class PointSource:
         if V._degree != 1 or V._ncomp != 1:
             raise SolverError("PointSource is built for scalar P1 spaces")
         mesh = V.mesh()
-        co, ce = mesh.coordinates(), mesh.cells().astype(np.int64)
-        c = co[ce]
-        T = np.stack([c[:, 1] - c[:, 0], c[:, 2] - c[:, 0], c[:, 3] - c[:, 0]], axis=2)
-        lam = np.linalg.solve(T, np.broadcast_to(p - c[:, 0], (len(ce), 3))[:, :, None])[:, :, 0]
-        bary = np.concatenate([1.0 - lam.sum(axis=1, keepdims=True), lam], axis=1)
-        i = int(np.argmax(bary.min(axis=1)))
-        if bary[i].min() < -1e-10:
-            raise SolverError("PointSource at {} is outside the mesh".format(p))
-        self.dofs = ce[i].astype(np.int32)
-        self.weights = self.magnitude * bary[i]
+        i, bary = locate_point(mesh, p)
+        self.dofs = mesh.cells()[i].astype(np.int32)
+        self.weights = self.magnitude * bary
 
 
 def is_constant_value(value):
@@ -816,7 +872,7 @@ class DirichletBC:
         self.marker_id = marker_id
         mesh = V.mesh()
         if isinstance(markers, MeshFunction):
-            if markers.dim() != 2:
+            if markers.dim() != mesh.topology().dim() - 1:
                 raise SolverError("DirichletBC needs a facet MeshFunction")
             sel = np.nonzero(markers.array() == marker_id)[0]
         else:

@@ -403,3 +403,29 @@ def test_p2_host_space_matches_oracle_numbering(data_dir):
     assert np.array_equal(bc.dofs, ref) and len(ref) == 49
     Xb = V.node_coordinates()[ref]
     assert np.allclose(bc.values, 1 + Xb[:, 0] * Xb[:, 1])
+
+
+def test_2d_host_data_model_matches_oracle():
+    """UnitSquareMesh / RectangleMesh ('right' diagonal), edge = facet numbering, marking, DirichletBC, point evaluation."""
+    from fenicssolver_amd.fem import (UnitSquareMesh, RectangleMesh, Point, MeshFunction, AutoSubDomain, near, FunctionSpace,
+                                      DirichletBC, Constant, Expression, interpolate, PointSource)
+    m = RectangleMesh(Point(0, 0), Point(2.0, 1.0), 6, 4)
+    co, ce = fo.rectangle_mesh((0, 0), (2.0, 1.0), 6, 4)
+    assert np.array_equal(m.coordinates(), co) and np.array_equal(m.cells(), ce)
+    assert m.geometry().dim() == 2 and m.topology().dim() == 2
+    edges, cf, cnt = fo.tri_edge_numbering(ce)
+    assert np.array_equal(m.facets(), edges) and np.array_equal(m.cell_facets(), cf)
+    assert np.array_equal(m.exterior_facets(), cnt == 1) and m.num_entities(1) == len(edges) and m.num_entities(2) == len(ce)
+    mf = MeshFunction("size_t", m, 1)
+    AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 2.0)).mark(mf, 3)
+    ref = fo.mark_edges(co, ce, lambda x, ob: ob and abs(x[0] - 2.0) < 3e-16, 3)
+    assert np.array_equal(mf.array(), ref) and (ref == 3).sum() == 4
+    V = FunctionSpace(m, "CG", 1)
+    bc = DirichletBC(V, Expression("10*x[1]", degree=1), mf, 3)
+    right = np.nonzero(co[:, 0] == 2.0)[0]
+    assert np.array_equal(bc.dofs, right) and np.allclose(bc.values, 10 * co[right, 1])
+    f = interpolate(Expression("1+2*x[0]-x[1]", degree=1), V)
+    assert abs(f(1.3, 0.45) - (1 + 2.6 - 0.45)) < 1e-13
+    ps = PointSource(V, Point(1.3, 0.45), 2.0)
+    assert abs(ps.weights.sum() - 2.0) < 1e-13 and len(ps.dofs) == 3
+    assert UnitSquareMesh(40, 40).num_cells() == 3200
