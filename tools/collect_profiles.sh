@@ -15,5 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $C"; rocprofv3 --pmc $C -d $OUT/pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
   tail -1 $OUT/pmc_$C.log
 done
-find $OUT -type f | head -40
-du -sh $OUT
+# condense on the box: the rocpd databases are tens of MB, gpurun copies back at most 64 MiB
+python $R/tools/summarize_profiles.py ${1:-r01} $R/gpurun_out/summary > $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
+rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+ls -la $R/gpurun_out/summary

@@ -20,6 +20,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# second argument: output directory (default profiles/).  On the GPU box the summaries are written under gpurun_out/
+# and the multi-10-MB databases are deleted before gpurun copies the directory back.
+OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 PHASES = ("n99_1M_dof", "n215_10M_dof")
 HOT = ("k_sell_spmv", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
@@ -52,7 +55,7 @@ def kernel_stats():
         a[3] = max(a[3], dur)
         a[4].append(dur)
     total = sum(a[1] for a in agg.values())
-    out = os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv")
+    out = os.path.join(OUT, TAG + "_kernel_stats.csv")
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
         # live_* exclude the no-op launches of a CG batch enqueued after convergence (< 10 % of the max)
@@ -87,7 +90,7 @@ def pmc(counter):
 
 
 def main():
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    os.makedirs(OUT, exist_ok=True)
     kernel_stats()
     fetch, nf = pmc("FETCH_SIZE")
     write, _ = pmc("WRITE_SIZE")
@@ -99,7 +102,7 @@ def main():
             continue
         raw["kernels"]["%s/%s" % (ph, k)] = {"launches": nf[key], "FETCH_SIZE_KiB": round(fetch[key], 1),
                                               "WRITE_SIZE_KiB": round(write.get(key, 0.0), 1)}
-    json.dump(raw, open(os.path.join(ROOT, "profiles", TAG + "_pmc_raw.json"), "w"), indent=1)
+    json.dump(raw, open(os.path.join(OUT, TAG + "_pmc_raw.json"), "w"), indent=1)
     # gfx950 correction (guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B.
     # Calibrated in THIS run on kernels of known byte count (see profiles/README.md): reads x2, writes x1.
     n_dof = {PHASES[0]: 100 ** 3, PHASES[1]: 216 ** 3}
@@ -144,7 +147,7 @@ def main():
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
-    json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUT, TAG + "_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
