@@ -757,7 +757,7 @@ class SolverBase():
         dofs, vals = self._bc_arrays(bcs)
         pre = dofs[(dofs % 4) == 3] if dofs.size else dofs
         ctx = getattr(self, '_ns_ctx', None)
-        key = (id(V), tuple(np.sort(pre).tolist()))
+        key = (id(V), pre.size, np.sort(pre).tobytes())
         if ctx is None or ctx['key'] != key:
             Q = W.pressure_space().device()
             pinned = (pre // 4).astype(np.int32)

@@ -547,22 +547,52 @@ __global__ void k_sd_scalar_dinv(int64_t n_rows, const int64_t* __restrict__ sli
     }
 }
 // dots[j] partials of w . V_j for j < nvec (one launch; block b writes partial[j*gridDim + b])
+// gate (may be null): the launch is a no-op when *gate == 0 - the second Gram-Schmidt pass is enqueued unconditionally
+// and the device decides whether it runs, so the host never waits for the first pass.
+// Eight basis vectors per sweep over the rows: eight independent load streams per lane and one block reduction for
+// the eight sums (a sweep per vector is latency-bound: 20 rows per thread, then a barrier).
+#define SD_DOT_GROUP 8
 __global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_dot(int64_t n, const double* __restrict__ w, const double* const* __restrict__ V,
-                                                           int nvec, int with_self, double* __restrict__ partial) {
-    __shared__ double lds4[4];
-    for (int j = 0; j < nvec + with_self; ++j) {
-        const double* v = j < nvec ? V[j] : w;      // the extra "vector" is w itself: ||w||^2
-        double acc = 0.0;
-        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-        for (; i < n; i += stride) acc += w[i] * v[i];
-        const double t = fs_block_sum(acc, lds4);
-        if (threadIdx.x == 0) partial[(int64_t)j * gridDim.x + blockIdx.x] = t;
+                                                           int nvec, int with_self, double* __restrict__ partial,
+                                                           const double* __restrict__ gate) {
+    __shared__ double lds[SD_DOT_GROUP][FS_BLOCK / 64];
+    if (gate && *gate == 0.0) return;
+    const int total = nvec + with_self;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int j0 = 0; j0 < total; j0 += SD_DOT_GROUP) {
+        const double* vp[SD_DOT_GROUP];
+        double acc[SD_DOT_GROUP];
+#pragma unroll
+        for (int c = 0; c < SD_DOT_GROUP; ++c) {
+            vp[c] = j0 + c < nvec ? V[j0 + c] : w;      // the extra "vector" is w itself: ||w||^2
+            acc[c] = 0.0;
+        }
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const double wi = w[i];
+#pragma unroll
+            for (int c = 0; c < SD_DOT_GROUP; ++c) acc[c] += wi * vp[c][i];
+        }
+#pragma unroll
+        for (int c = 0; c < SD_DOT_GROUP; ++c) {
+            double t = acc[c];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) lds[c][wave] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < SD_DOT_GROUP && j0 + (int)threadIdx.x < total) {
+            double t = 0.0;
+            for (int q = 0; q < FS_BLOCK / 64; ++q) t += lds[threadIdx.x][q];
+            partial[(int64_t)(j0 + threadIdx.x) * gridDim.x + blockIdx.x] = t;
+        }
+        __syncthreads();
     }
 }
 // sums[j] = sum_b partial[j*nblk + b]   (one workgroup per j, fixed order)
-__global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_sum(const double* __restrict__ partial, int nblk, double* __restrict__ sums) {
+__global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_sum(const double* __restrict__ partial, int nblk, double* __restrict__ sums,
+                                                           const double* __restrict__ gate) {
     __shared__ double lds4[4];
+    if (gate && *gate == 0.0) return;
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc += partial[(int64_t)blockIdx.x * nblk + b];
     const double t = fs_block_sum(acc, lds4);
@@ -570,7 +600,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sd_multi_sum(const double* __restr
 }
 // w -= sum_j h[j] V_j
 __global__ void k_sd_multi_axpy(int64_t n, double* __restrict__ w, const double* const* __restrict__ V, const double* __restrict__ h,
-                                int nvec) {
+                                int nvec, const double* __restrict__ gate) {
+    if (gate && *gate == 0.0) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -580,17 +611,90 @@ __global__ void k_sd_multi_axpy(int64_t n, double* __restrict__ w, const double*
     }
 }
 
+// ---- Arnoldi bookkeeping on the device: the Hessenberg column, the Givens rotations and the residual recurrence are
+// advanced by single-thread kernels between the vector kernels, so one FGMRES iteration is a fixed launch sequence with
+// no host read in it.  ctl = {need second pass, hh^2, 1/hh, |gamma_{k+1}|, hh}.
+enum { SD_NEED2 = 0, SD_HH2 = 1, SD_SCALE = 2, SD_RES = 3, SD_HH = 4, SD_CTL = 8 };
+// column k of H (stride m) += the projections of this pass; Pythagoras for the new norm; DGKS-type criterion
+__global__ void k_sd_hess_pass(const double* __restrict__ hdev, int k, int m, double* __restrict__ H, double* __restrict__ ctl, int pass) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (pass > 0 && ctl[SD_NEED2] == 0.0) return;
+    double removed = 0.0;
+    for (int j = 0; j <= k; ++j) {
+        const double h = hdev[j];
+        H[(size_t)j * m + k] = (pass > 0 ? H[(size_t)j * m + k] : 0.0) + h;
+        removed += h * h;
+    }
+    const double before = hdev[k + 1];
+    const double hh2 = before - removed;
+    ctl[SD_HH2] = hh2;
+    if (pass == 0) ctl[SD_NEED2] = hh2 > 0.1 * before ? 0.0 : 1.0;      // eta^2 = 0.1: at most one digit lost to cancellation
+}
+// host_out (mapped, coherent host memory): {|gamma_{k+1}|, hh, serial}; the serial number is written last, after a
+// system-scope fence, and the host spins on it - no runtime call is involved in the hand-over
+__global__ void k_sd_givens(int k, int m, double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
+                            double* __restrict__ gam, double* __restrict__ ctl, volatile double* host_out, double serial) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double hh2 = ctl[SD_HH2];
+    const double hh = hh2 > 0.0 ? sqrt(hh2) : 0.0;
+    ctl[SD_HH] = hh;
+    ctl[SD_SCALE] = hh > 0.0 ? 1.0 / hh : 0.0;
+    H[(size_t)(k + 1) * m + k] = hh;
+    for (int j = 0; j < k; ++j) {
+        const double a = H[(size_t)j * m + k], c = H[(size_t)(j + 1) * m + k];
+        H[(size_t)j * m + k] = cs[j] * a + sn[j] * c;
+        H[(size_t)(j + 1) * m + k] = -sn[j] * a + cs[j] * c;
+    }
+    const double a = H[(size_t)k * m + k], c = H[(size_t)(k + 1) * m + k];
+    const double d = sqrt(a * a + c * c);
+    cs[k] = d > 0.0 ? a / d : 1.0;
+    sn[k] = d > 0.0 ? c / d : 0.0;
+    H[(size_t)k * m + k] = d;
+    H[(size_t)(k + 1) * m + k] = 0.0;
+    gam[k + 1] = -sn[k] * gam[k];
+    gam[k] = cs[k] * gam[k];
+    ctl[SD_RES] = fabs(gam[k + 1]);
+    host_out[0] = ctl[SD_RES];
+    host_out[1] = hh;
+    __threadfence_system();
+    host_out[2] = serial;
+}
+__global__ void k_sd_cycle_init(int m, double res, double* __restrict__ gam) {
+    for (int i = threadIdx.x; i <= m; i += blockDim.x) gam[i] = i == 0 ? res : 0.0;
+}
+// y = -(H(0:k,0:k))^-1 gamma   (the sign lets k_sd_multi_axpy, which subtracts, add Z y to x)
+__global__ void k_sd_backsolve(int k, int m, const double* __restrict__ H, const double* __restrict__ gam, double* __restrict__ y) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = k - 1; i >= 0; --i) {
+        double v = -gam[i];
+        for (int j = i + 1; j < k; ++j) v -= H[(size_t)i * m + j] * y[j];
+        const double d = H[(size_t)i * m + i];
+        y[i] = d != 0.0 ? v / d : 0.0;
+    }
+}
+__global__ void k_sd_scale_dev(int64_t n, const double* __restrict__ a, const double* __restrict__ x, double* __restrict__ y) {
+    const double f = *a;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = f * x[i];
+}
+
 static bool g_sd_timing = false, g_sd_sync = false;
 static double g_sd_t[4];
 
 struct saddle_ws {
     dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev, cd, gin, gout;
     double vel_lmax = 0.0;   // largest eigenvalue of D^-1 A on the velocity block (Chebyshev sweeps)
-    dbuf<const double*> vptr;
+    dbuf<const double*> vptr, zptr;
+    dbuf<double> hs;            // H | cs | sn | gamma | y | ctl  (device-side Arnoldi state)
+    double* h_poll = nullptr;   // pinned, mapped, coherent: 2 slots x {|gamma|, hh, serial, -}
+    double* d_poll = nullptr;   // the same memory as the device sees it
+    double serial = 0.0;
     dbuf<uint8_t> ident;
     fs_vector_s rp, p1, p2;
     std::vector<dbuf<double>*> V, Z;
     ~saddle_ws() {
+        if (h_poll) (void)hipHostFree(h_poll);
         for (auto* v : V) delete v;
         for (auto* z : Z) delete z;
     }
@@ -717,6 +821,11 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_CHECK(W.mt.alloc(nv));
     FS_CHECK(W.hdev.alloc(m + 3));
     FS_CHECK(W.vptr.alloc(m + 3));
+    FS_CHECK(W.zptr.alloc(m + 3));
+    FS_CHECK(W.hs.alloc((int64_t)(m + 1) * m + 4 * (int64_t)m + 1 + SD_CTL));
+    FS_HIP(hipHostMalloc((void**)&W.h_poll, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(W.h_poll, 0, 8 * sizeof(double));
+    FS_HIP(hipHostGetDevicePointer((void**)&W.d_poll, W.h_poll, 0));
     FS_CHECK(W.rp.d.alloc(nv));
     FS_CHECK(W.p1.d.alloc(Mp->space->n_dofs_local));
     FS_CHECK(W.p2.d.alloc(Mp->space->n_dofs_local));
@@ -732,6 +841,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
         std::vector<const double*> hp(m + 1);
         for (int k = 0; k <= m; ++k) hp[k] = W.V[k]->p;
         FS_HIP(hipMemcpyAsync(W.vptr.p, hp.data(), (size_t)(m + 1) * sizeof(double*), hipMemcpyHostToDevice, s));
+        FS_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < m; ++k) hp[k] = W.Z[k]->p;
+        FS_HIP(hipMemcpyAsync(W.zptr.p, hp.data(), (size_t)m * sizeof(double*), hipMemcpyHostToDevice, s));
         FS_HIP(hipStreamSynchronize(s));
     }
         return FS_OK;
@@ -773,7 +885,12 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     const double thr = std::max(o->rtol * stats->bnorm, o->atol);
     int it = 0, conv = 0, inner = 0;
     double res = 0.0;
-    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gam(m + 1), y(m), hcol(m + 3);
+    double* const dH = W.hs.p;
+    double* const dcs = dH + (size_t)(m + 1) * m;
+    double* const dsn = dcs + m;
+    double* const dgam = dsn + m;
+    double* const dy = dgam + m + 1;
+    double* const dctl = dy + m;
     // The preconditioner is ~55 small launches (AMG V-cycle on the pressure Laplacian, Chebyshev mass solve): a fixed
     // sequence on fixed buffers once its input/output are staged in gin/gout, so it can be captured into a hipGraph
     // and replayed (FS_SADDLE_GRAPH=1).  Measured on MI355X / ROCm 7.2 (round 1): replay and direct launches both take
@@ -834,10 +951,48 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
         if (res <= thr) { conv = 1; break; }
         if (it >= max_iter) break;
         hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / res, W.r.p, W.V[0]->p);
-        std::fill(gam.begin(), gam.end(), 0.0);
-        gam[0] = res;
-        int k = 0;
-        for (; k < m && it < max_iter; ++k, ++it) {
+        hipLaunchKernelGGL(k_sd_cycle_init, dim3(1), dim3(64), 0, s, m, res, dgam);
+        // One FGMRES iteration is a fixed launch sequence: the Hessenberg column, the rotations and the residual
+        // recurrence live on the device.  The host runs one iteration ahead of the GPU and reads |gamma| of iteration
+        // k-1 (pinned copy + event) after it has enqueued iteration k, so the queue never drains; the price is at
+        // most one iteration enqueued beyond convergence, whose column is simply not used in the update.
+        int k = 0, kuse = 0, slot = 0, pending = -1, pending_k = -1;
+        bool stop = false;
+        // FS_SADDLE_TRACE: per-iteration GPU time (events) beside the host's enqueue and wait times, without extra syncs
+        static const bool trace = getenv("FS_SADDLE_TRACE") != nullptr;
+        std::vector<hipEvent_t> tev;
+        std::vector<double> t_enq, t_wait;
+        if (trace) {
+            tev.resize(m + 1);
+            for (auto& e : tev) (void)hipEventCreate(&e);
+            (void)hipEventRecord(tev[0], s);
+        }
+        // hipEventSynchronize is not used for the hand-over: a wait of ~1 ms leaves the runtime's active-wait window and
+        // blocks on an interrupt, and that wake-up was measured to take 25-65 ms once or twice per solve (MI355X,
+        // ROCm 7.2; FS_SADDLE_TRACE) - the host spins on the serial number the kernel writes instead.
+        double expect[2] = {0.0, 0.0};
+        auto harvest = [&]() -> int {       // result of the iteration behind `pending`
+            volatile double* hp = W.h_poll + 4 * pending;
+            const auto t_spin = std::chrono::steady_clock::now();
+            for (uint64_t spin = 0; hp[2] != expect[pending]; ++spin) {
+                __builtin_ia32_pause();
+                if ((spin & 0xfffff) == 0xfffff) {          // every ~10 ms: a failed launch or a hung device must not spin for ever
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q != hipSuccess && q != hipErrorNotReady) FS_HIP(q);
+                    if (q == hipSuccess && hp[2] != expect[pending]) { fs_set_error("fs_saddle_solve: the iteration result never arrived"); return FS_ERR_HIP; }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 120.0) { fs_set_error("fs_saddle_solve: device timeout"); return FS_ERR_HIP; }
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            const double rk = hp[0], hk = hp[1];
+            res = rk;
+            kuse = pending_k + 1;
+            if (!(rk == rk)) { conv = -1; stop = true; }
+            else if (rk <= thr || !(hk > 0.0)) stop = true;
+            pending = -1;
+            return FS_OK;
+        };
+        for (; k < m && it + k < max_iter && !stop; ++k) {
             const bool dbg = g_sd_timing || g_sd_sync;
             auto tA = std::chrono::steady_clock::now();
             if (use_graph) {
@@ -853,61 +1008,55 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
             FS_CHECK(fs_spmv_dev(J, W.Z[k]->p, W.w.p, s));
             if (dbg) (void)hipStreamSynchronize(s);
             auto tD = std::chrono::steady_clock::now();
-            // classical Gram-Schmidt, applied twice (CGS2): one fused multi-dot launch and one host read per pass
-            // classical Gram-Schmidt with one fused multi-dot launch and one host read per pass; the last pointer of the
-            // list is w itself, so the pass also returns ||w||^2 before the projection.  A second pass only when the
-            // projection removed most of w (DGKS-type criterion): orthogonality stays near working precision.
-            for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = 0.0;
-            double hh = 0.0;
-            for (int pass = 0; pass < 3; ++pass) {
-                hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, 1, W.partials.p);
-                hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 2), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p);
-                hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, W.hdev.p, k + 1);
-                FS_KERNEL_CHECK();
-                FS_CHECK(W.hdev.download(hcol.data(), k + 2, s));
-                double removed = 0.0;
-                for (int j = 0; j <= k; ++j) { H[(size_t)j * m + k] += hcol[j]; removed += hcol[j] * hcol[j]; }
-                const double before = hcol[k + 1];
-                hh = before - removed;               // Pythagoras; recomputed exactly below when cancellation is severe
-                if (hh > 0.1 * before) break;        // eta^2 = 0.1: at most one digit lost to cancellation
-                FS_CHECK(sd_dot(W, W.w.p, W.w.p, n, &hh, s));
-                if (pass >= 1) break;
+            // classical Gram-Schmidt with one fused multi-dot launch per pass; the last pointer of the list is w itself,
+            // so the pass also returns ||w||^2 before the projection.  The second pass runs only when the projection
+            // removed most of w (DGKS-type criterion, decided on the device): orthogonality stays near working precision.
+            for (int pass = 0; pass < 2; ++pass) {
+                const double* gate = pass ? dctl + SD_NEED2 : nullptr;
+                hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, 1, W.partials.p, gate);
+                hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 2), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p, gate);
+                hipLaunchKernelGGL(k_sd_hess_pass, dim3(1), dim3(1), 0, s, W.hdev.p, k, m, dH, dctl, pass);
+                hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, W.hdev.p, k + 1, gate);
             }
+            W.serial += 1.0;
+            expect[slot] = W.serial;
+            hipLaunchKernelGGL(k_sd_givens, dim3(1), dim3(1), 0, s, k, m, dH, dcs, dsn, dgam, dctl, W.d_poll + 4 * slot, W.serial);
+            hipLaunchKernelGGL(k_sd_scale_dev, dim3(g), dim3(FS_BLOCK), 0, s, n, dctl + SD_SCALE, W.w.p, W.V[k + 1]->p);
+            FS_KERNEL_CHECK();
+            if (trace) (void)hipEventRecord(tev[k + 1], s);
+            auto tF = std::chrono::steady_clock::now();
             if (g_sd_timing) {
+                (void)hipStreamSynchronize(s);
                 auto tE = std::chrono::steady_clock::now();
                 g_sd_t[0] += std::chrono::duration<double, std::milli>(tB - tA).count();   // enqueue of the preconditioner
                 g_sd_t[1] += std::chrono::duration<double, std::milli>(tC - tA).count();   // ... until it has run
                 g_sd_t[2] += std::chrono::duration<double, std::milli>(tD - tC).count();   // SpMV
                 g_sd_t[3] += std::chrono::duration<double, std::milli>(tE - tD).count();   // orthogonalisation
             }
-            if (!(hh > 0.0)) hh = 0.0;
-            hh = sqrt(hh);
-            H[(size_t)(k + 1) * m + k] = hh;
-            if (hh > 0.0) hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / hh, W.w.p, W.V[k + 1]->p);
-            for (int j = 0; j < k; ++j) {        // previous rotations
-                const double a = H[(size_t)j * m + k], c = H[(size_t)(j + 1) * m + k];
-                H[(size_t)j * m + k] = cs[j] * a + sn[j] * c;
-                H[(size_t)(j + 1) * m + k] = -sn[j] * a + cs[j] * c;
+            if (pending >= 0) FS_CHECK(harvest());
+            if (trace) {
+                t_enq.push_back(std::chrono::duration<double, std::milli>(tF - tA).count());
+                t_wait.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tF).count());
             }
-            const double a = H[(size_t)k * m + k], c = H[(size_t)(k + 1) * m + k];
-            const double d = sqrt(a * a + c * c);
-            cs[k] = d > 0.0 ? a / d : 1.0;
-            sn[k] = d > 0.0 ? c / d : 0.0;
-            H[(size_t)k * m + k] = d;
-            H[(size_t)(k + 1) * m + k] = 0.0;
-            gam[k + 1] = -sn[k] * gam[k];
-            gam[k] = cs[k] * gam[k];
-            res = fabs(gam[k + 1]);
-            if (res <= thr || !(hh > 0.0)) { ++k; ++it; break; }
+            if (!stop) { pending = slot; pending_k = k; slot ^= 1; }
         }
-        // y = H^-1 gamma ; x += Z y
-        for (int i = k - 1; i >= 0; --i) {
-            double v = gam[i];
-            for (int j = i + 1; j < k; ++j) v -= H[(size_t)i * m + j] * y[j];
-            y[i] = v / H[(size_t)i * m + i];
+        if (trace) {
+            (void)hipStreamSynchronize(s);
+            for (size_t q = 0; q < t_enq.size(); ++q) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, tev[q], tev[q + 1]);
+                fprintf(stderr, "[fs_saddle_trace] k=%2zu gpu %.3f ms  host enqueue %.3f ms  host wait %.3f ms\n", q, ms, t_enq[q], t_wait[q]);
+            }
+            for (auto& e : tev) (void)hipEventDestroy(e);
         }
-        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(k_sd_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, y[i], W.Z[i]->p, x->d.p);
+        if (!stop && pending >= 0) FS_CHECK(harvest());
+        it += kuse;
+        if (conv < 0) break;
+        // y = H^-1 gamma ; x += Z y   (the first kuse columns)
+        hipLaunchKernelGGL(k_sd_backsolve, dim3(1), dim3(1), 0, s, kuse, m, dH, dgam, dy);
+        hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, x->d.p, W.zptr.p, dy, kuse, (const double*)nullptr);
         FS_KERNEL_CHECK();
+        if (kuse == 0) break;
     }
     stats->iterations = it;
     stats->converged = conv;

@@ -21,6 +21,8 @@ import numbers
 import os
 import re
 
+import zlib
+
 import numpy as np
 
 DOLFIN_EPS = 3.0e-16
@@ -591,8 +593,12 @@ class FunctionSpace:
         co = self._mesh.coordinates()
         if self._degree == 1:
             return co
-        ed = self.edge_nodes().astype(np.int64)
-        return np.concatenate([co, 0.5 * (co[ed[:, 0]] + co[ed[:, 1]])], axis=0)
+        root = self.root()
+        if getattr(root, "_node_co", None) is None:       # time loops rebuild their DirichletBCs every step
+            ed = self.edge_nodes().astype(np.int64)
+            root._node_co = np.concatenate([co, 0.5 * (co[ed[:, 0]] + co[ed[:, 1]])], axis=0)
+            root._node_co.setflags(write=False)
+        return root._node_co
 
     def facet_nodes(self, facet_ids):
         """Nodes in the closure of the given facets: their vertices (+ their edges for P2), ascending."""
@@ -601,6 +607,20 @@ class FunctionSpace:
         verts = np.unique(f.ravel())
         if self._degree == 1:
             return verts
+        root = self.root()
+        cache = root.__dict__.setdefault("_facet_node_cache", {})
+        ids = np.ascontiguousarray(facet_ids)
+        key = (ids.size, zlib.crc32(ids.tobytes()))
+        if key in cache:
+            return cache[key]
+        if len(cache) > 64:
+            cache.clear()
+        out = self._facet_nodes_p2(f, verts)
+        cache[key] = out
+        return out
+
+    def _facet_nodes_p2(self, f, verts):
+        mesh = self._mesh
         nv = mesh.num_vertices()
         ed = self.edge_nodes().astype(np.int64)
         ekey = ed[:, 0] * nv + ed[:, 1]
