@@ -26,12 +26,20 @@
 // round is one memory round trip whatever N is.  The remainder of a row (width % UNROLL entries) goes through
 // the same code with N = remainder (compile-time if-chain) instead of a serial tail loop - on the 15-wide
 // rows of a P1 Kuhn mesh a serial tail is 3 of the 6 round trips at UNROLL = 4.
-template <int N>
+// NT: matrix values and column indices are read once per product; when the matrix is larger than the caches
+// (Infinity Cache 256 MB) a non-temporal load keeps them from evicting the x window out of L2 (measured on MI355X,
+// 10 M DOF: P1 310 -> 290 us, P2 1095 -> 1016 us; at 1 M DOF, where the matrix stays cache-resident between
+// iterations, the hint costs 25 %, so it is chosen by size).
+template <bool NT, typename T>
+__device__ __forceinline__ T fs_ldv(const T* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <int N, bool NT>
 __device__ __forceinline__ void dia_round(const double* __restrict__ vp, const int32_t* __restrict__ op, int k, int32_t r,
                                           int32_t cmax, const double* __restrict__ x, double& acc) {
     double v[N], xv[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+    for (int u = 0; u < N; ++u) v[u] = fs_ldv<NT>(&vp[(int64_t)(k + u) * FS_SLICE]);
 #pragma unroll
     for (int u = 0; u < N; ++u) {
         int32_t c = r + op[k + u];
@@ -41,40 +49,40 @@ __device__ __forceinline__ void dia_round(const double* __restrict__ vp, const i
 #pragma unroll
     for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
 }
-template <int N>
+template <int N, bool NT>
 __device__ __forceinline__ void sell_round(const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
                                            const double* __restrict__ x, double& acc) {
     int32_t c[N];
     double v[N], xv[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
+    for (int u = 0; u < N; ++u) c[u] = fs_col_decode(fs_ldv<NT>(&cp[(int64_t)(k + u) * FS_SLICE]));
 #pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = vp[(int64_t)(k + u) * FS_SLICE];
+    for (int u = 0; u < N; ++u) v[u] = fs_ldv<NT>(&vp[(int64_t)(k + u) * FS_SLICE]);
 #pragma unroll
     for (int u = 0; u < N; ++u) xv[u] = x[c[u]];
 #pragma unroll
     for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
 }
-template <int N>
+template <int N, bool NT>
 struct row_tail {
     static __device__ __forceinline__ void dia(int rem, const double* __restrict__ vp, const int32_t* __restrict__ op, int k,
                                                int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
-        if (rem == N) dia_round<N>(vp, op, k, r, cmax, x, acc);
-        else row_tail<N - 1>::dia(rem, vp, op, k, r, cmax, x, acc);
+        if (rem == N) dia_round<N, NT>(vp, op, k, r, cmax, x, acc);
+        else row_tail<N - 1, NT>::dia(rem, vp, op, k, r, cmax, x, acc);
     }
     static __device__ __forceinline__ void sell(int rem, const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
                                                 const double* __restrict__ x, double& acc) {
-        if (rem == N) sell_round<N>(vp, cp, k, x, acc);
-        else row_tail<N - 1>::sell(rem, vp, cp, k, x, acc);
+        if (rem == N) sell_round<N, NT>(vp, cp, k, x, acc);
+        else row_tail<N - 1, NT>::sell(rem, vp, cp, k, x, acc);
     }
 };
-template <>
-struct row_tail<0> {
+template <bool NT>
+struct row_tail<0, NT> {
     static __device__ __forceinline__ void dia(int, const double*, const int32_t*, int, int32_t, int32_t, const double*, double&) {}
     static __device__ __forceinline__ void sell(int, const double*, const int32_t*, int, const double*, double&) {}
 };
 
-template <int BS, int DOTS, int UNROLL>
+template <int BS, int DOTS, int UNROLL, bool NT = false>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                         const int64_t* __restrict__ slice_ptr,
                                                         const int32_t* __restrict__ sell_col,
@@ -123,8 +131,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             const int32_t* __restrict__ op = dia_off + dp;
             int k = 0;
             if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL>(vp, op, k, (int32_t)r, cmax, x, acc[0]);
-                row_tail<UNROLL - 1>::dia(width - k, vp, op, k, (int32_t)r, cmax, x, acc[0]);
+                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL, NT>(vp, op, k, (int32_t)r, cmax, x, acc[0]);
+                row_tail<UNROLL - 1, NT>::dia(width - k, vp, op, k, (int32_t)r, cmax, x, acc[0]);
                 k = width;
             }
             for (; k < width; ++k) {
@@ -140,8 +148,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
         } else {
             int k = 0;
             if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) sell_round<UNROLL>(vp, cp, k, x, acc[0]);
-                row_tail<UNROLL - 1>::sell(width - k, vp, cp, k, x, acc[0]);
+                for (; k + UNROLL <= width; k += UNROLL) sell_round<UNROLL, NT>(vp, cp, k, x, acc[0]);
+                row_tail<UNROLL - 1, NT>::sell(width - k, vp, cp, k, x, acc[0]);
                 k = width;
             }
             for (; k < width; ++k) {
@@ -698,6 +706,12 @@ static int spmv_unroll_for(int64_t n_slices) {
     if (g_spmv_unroll_pinned) return g_spmv_unroll;
     return n_slices <= 32768 ? 4 : 16;
 }
+// the matrix does not stay in the 256 MB Infinity Cache between two products
+static bool spmv_nontemporal(const fs_space_s* sp, int bs) {
+    static const char* e = getenv("FS_SPMV_NT");       // 0 / 1 pins the choice (tools/tune_spmv.py)
+    if (e) return e[0] == '1';
+    return sp->sell_entries * (int64_t)bs * bs * 8 > (int64_t)192 << 20;
+}
 static int spmv_grid(int64_t n_slices) {
     const int64_t n_chunks = (n_slices + 3) / 4;
     const int64_t blocks = spmv_blocks_for(n_slices);
@@ -714,11 +728,21 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int grid = spmv_grid(sp->n_slices);
 #define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status
     if (A->bs == 1) {
+        const bool nt = spmv_nontemporal(sp, 1);
         switch (spmv_unroll_for(sp->n_slices)) {
             case 2: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 2>), FS_SPMV_ARGS); break;
-            case 8: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 8>), FS_SPMV_ARGS); break;
-            case 16: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16>), FS_SPMV_ARGS); break;
-            default: hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS); break;
+            case 8:
+                if (nt) hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 8, true>), FS_SPMV_ARGS);
+                else hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 8>), FS_SPMV_ARGS);
+                break;
+            case 16:
+                if (nt) hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16, true>), FS_SPMV_ARGS);
+                else hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 16>), FS_SPMV_ARGS);
+                break;
+            default:
+                if (nt) hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4, true>), FS_SPMV_ARGS);
+                else hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS);
+                break;
         }
     } else if (A->bs == 3) {
         hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
@@ -735,6 +759,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 // y = A x for 4x4-block matrices (Taylor-Hood): one workgroup per slice, wave i computes block-row i.  A slice of a
 // CG2 pattern holds 30-65 entries of 16 planes each; giving every block-row its own wave quarters the serial
 // chain of a wave and quadruples the loads in flight (the generic kernel walks all 16 planes in one wave).
+template <bool NT>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                               const int64_t* __restrict__ slice_ptr,
                                                               const int32_t* __restrict__ sell_col,
@@ -768,8 +793,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
             double v0[4], v1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v0[j] = vp[(int64_t)j * plane + (int64_t)k * FS_SLICE];
-                v1[j] = vp[(int64_t)j * plane + (int64_t)(k + 1) * FS_SLICE];
+                v0[j] = fs_ldv<NT>(&vp[(int64_t)j * plane + (int64_t)k * FS_SLICE]);
+                v1[j] = fs_ldv<NT>(&vp[(int64_t)j * plane + (int64_t)(k + 1) * FS_SLICE]);
             }
             const double2 xa0 = reinterpret_cast<const double2*>(x)[2 * c0], xb0 = reinterpret_cast<const double2*>(x)[2 * c0 + 1];
             const double2 xa1 = reinterpret_cast<const double2*>(x)[2 * c1], xb1 = reinterpret_cast<const double2*>(x)[2 * c1 + 1];
@@ -791,8 +816,12 @@ int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     if (A->bs == 4 && !getenv("FS_SPMV4_GENERIC")) {
         fs_space_s* sp = A->space;
         const int grid = (int)(sp->n_slices < 65535 ? sp->n_slices : 65535);
-        hipLaunchKernelGGL(k_sell_spmv4_rows, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
-                           sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
+        if (spmv_nontemporal(sp, 4))
+            hipLaunchKernelGGL(k_sell_spmv4_rows<true>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
+        else
+            hipLaunchKernelGGL(k_sell_spmv4_rows<false>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
         return FS_OK;
     }
     launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, s);

@@ -11,7 +11,7 @@ grep "solve\|DOF" $OUT/run.log
 python - <<PY
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("$OUT/*.db")[0]); c = db.cursor()
-rows = list(c.execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name order by 3 desc limit 22"))
+rows = list(c.execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name order by 3 desc limit 40"))
 for n, k, t, a in rows:
     print("%-72s %7d %10.1f ms %9.1f us" % (n[:72], k, t / 1e6, a / 1e3))
 # idle analysis: where does the GPU wait inside the FGMRES iterations?
