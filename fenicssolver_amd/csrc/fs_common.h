@@ -163,6 +163,11 @@ struct fs_space_s {
     dbuf<int32_t> dia_ptr;        // [n_slices]
     dbuf<int32_t> dia_off;        // [sum of offsets over DIA slices]
     dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned (vector spaces)
+    // two-pass assembly of block spaces with many dofs per cell (Taylor-Hood): element matrices are written to
+    // elem_buf [cell*nd*nd + ab][bs*bs] and summed per stored block through the inverse of the slot table
+    // (gmap_src[gmap_ptr[e] .. gmap_ptr[e+1]) = sources of entry e, ascending) - built on first use
+    dbuf<int32_t> gmap_ptr, gmap_src;
+    dbuf<double> elem_buf;
     // row-gather assembly tables (scalar spaces): the (cell, local vertex) incidences of every owned
     // row, SELL-64 laid out like the matrix; inc_pos packs the 4 in-row positions of the cell's vertices
     int64_t inc_entries = 0;

@@ -17,6 +17,7 @@
 //   [A 0; D S]^-1  with  A^-1 ~ Jacobi sweeps,  S^-1 ~ rho^2 ( (1/dt) K_p^-1 + nu M_p^-1 )  (Cahouet-Chabard),
 // K_p, M_p = P1 pressure Laplacian / mass matrix solved by the library's own CG.
 #include "fs_kernels.h"
+#include <hipcub/hipcub.hpp>
 #include <chrono>
 #include <stdlib.h>
 #include <cmath>
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
                                                                int64_t nc, const int32_t* __restrict__ slots,
                                                                const double* __restrict__ w0, const double* __restrict__ wprev,
                                                                ns_params P, double* __restrict__ val, int64_t plane,
-                                                               double* __restrict__ g) {
+                                                               double* __restrict__ ebuf, double* __restrict__ g) {
     __shared__ ns_cell_lds S[NS_WPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ns_cell_lds& L = S[wave];
@@ -313,7 +314,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
         if (act) {
             for (int ab = lane; ab < 100; ab += 64) {
                 const int a = ab / 10, b = ab - 10 * a;
-                const int32_t slot = slots[(int64_t)ab * nc + c];
+                // two-pass mode needs no slot: blocks of rows this rank does not own are simply never gathered
+                const int32_t slot = ebuf ? 0 : slots[(int64_t)ab * nc + c];
                 if (slot < 0) continue;   // row not owned
                 double blk[4][4];
 #pragma unroll
@@ -361,15 +363,24 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
                         }
                     }
                 }
+                if (ebuf) {      // element block -> buffer (128 B per lane, contiguous over the wave); summed by k_ns_gather
+                    double2* __restrict__ out = reinterpret_cast<double2*>(ebuf + ((int64_t)c * 100 + ab) * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (i == 3 && j == 3) continue;
-                        if (j == 3 && b >= 4) continue;
-                        if (i == 3 && a >= 4) continue;
-                        atomicAdd(&val[(int64_t)(i * 4 + j) * plane + slot], blk[i][j]);
+                    for (int i = 0; i < 4; ++i) {
+                        out[2 * i] = make_double2(blk[i][0], blk[i][1]);
+                        out[2 * i + 1] = make_double2(blk[i][2], blk[i][3]);
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (i == 3 && j == 3) continue;
+                            if (j == 3 && b >= 4) continue;
+                            if (i == 3 && a >= 4) continue;
+                            atomicAdd(&val[(int64_t)(i * 4 + j) * plane + slot], blk[i][j]);
+                        }
+                }
                 if (do_rhs) {
                     const int64_t node = L.nd[a];
 #pragma unroll
@@ -379,6 +390,75 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
         }
         __syncthreads();
     }
+}
+
+
+// ---- second pass: stored block e = sum of its element blocks (fixed order: deterministic, no atomics) -------------------
+__global__ void k_ns_pair_keys(const int32_t* __restrict__ slots, int64_t n, int32_t sentinel, int32_t* __restrict__ key,
+                               int32_t* __restrict__ src) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) {          // slots[ab*nc + c] -> source index c*100 + ab
+        const int64_t nc = n / 100;
+        const int64_t ab = t / nc, c = t - ab * nc;
+        const int32_t sl = slots[t];
+        key[t] = sl >= 0 ? sl : sentinel;
+        src[t] = (int32_t)(c * 100 + ab);
+    }
+}
+__global__ void k_ns_lower_bound(const int32_t* __restrict__ keys, int64_t n, int64_t n_entries, int32_t* __restrict__ ptr) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e <= n_entries; e += stride) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < (int32_t)e) lo = mid + 1; else hi = mid;
+        }
+        ptr[e] = (int32_t)lo;
+    }
+}
+__global__ void __launch_bounds__(FS_BLOCK) k_ns_gather(int64_t n_entries, const int32_t* __restrict__ ptr, const int32_t* __restrict__ src,
+                                                        const double* __restrict__ ebuf, double* __restrict__ val, int64_t plane) {
+    // 8 lanes per stored block: lane w reads the 16 bytes (values 2w, 2w+1) of every element block, so a block is one
+    // coalesced 128-byte read
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n_entries * 8; t += stride) {
+        const int64_t e = t >> 3;
+        const int w = (int)(t & 7);
+        double a0 = 0.0, a1 = 0.0;
+        const int32_t q1 = ptr[e + 1];
+        for (int32_t q = ptr[e]; q < q1; ++q) {
+            const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(ebuf + (int64_t)src[q] * 16) + w);   // read once
+            a0 += v.x;
+            a1 += v.y;
+        }
+        val[(int64_t)(2 * w) * plane + e] = a0;
+        val[(int64_t)(2 * w + 1) * plane + e] = a1;
+    }
+}
+static int ns_build_gather_map(fs_space_s* sp, hipStream_t s) {
+    const int64_t n = sp->mesh->nc * 100;
+    FS_REQUIRE(n < (int64_t)INT32_MAX && sp->sell_entries < (int64_t)INT32_MAX - 1, "fs_assemble_navier_stokes: mesh too large for 32-bit element indices");
+    dbuf<int32_t> k_in, k_out, v_in;
+    FS_CHECK(k_in.alloc(n));
+    FS_CHECK(k_out.alloc(n));
+    FS_CHECK(v_in.alloc(n));
+    FS_CHECK(sp->gmap_src.alloc(n));
+    FS_CHECK(sp->gmap_ptr.alloc(sp->sell_entries + 1));
+    hipLaunchKernelGGL(k_ns_pair_keys, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, sp->slots.p, n, (int32_t)INT32_MAX, k_in.p, v_in.p);
+    FS_KERNEL_CHECK();
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
+    dbuf<char> tmp;
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
+    hipLaunchKernelGGL(k_ns_lower_bound, dim3(fs_grid_for(sp->sell_entries + 1)), dim3(FS_BLOCK), 0, s, k_out.p, n, sp->sell_entries, sp->gmap_ptr.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
 }
 
 // unit diagonal on the dummy pressure slot of edge nodes
@@ -417,16 +497,30 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     for (int i = 0; i < 3; ++i) P.f[i] = form->body_force[i];
     P.convection = form->convection ? 1 : 0;
     P.newton = form->newton ? 1 : 0;
-    FS_CHECK(J->val.zero(s));
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
-    if (getenv("FS_NS_ASSEMBLE_OLD")) {
+    // Element blocks -> buffer -> one sum per stored block: 25 ms with 544 M device-scope fp64 atomics became 7 ms
+    // (MI355X, configs[4]) and the matrix is bit-reproducible.  FS_NS_ASSEMBLE=atomic / pair selects the one-pass
+    // kernels (no 6 GB element buffer).
+    static const char* mode_env = getenv("FS_NS_ASSEMBLE");
+    const bool two_pass = !mode_env || (mode_env[0] != 'a' && mode_env[0] != 'p');
+    if (two_pass) {
+        if (!sp->gmap_ptr.p) FS_CHECK(ns_build_gather_map(sp, s));
+        if (!sp->elem_buf.p) FS_CHECK(sp->elem_buf.alloc(m->nc * 1600));
+    } else {
+        FS_CHECK(J->val.zero(s));
+    }
+    if (!two_pass && mode_env[0] == 'p') {
         const int grid = fs_grid_for(m->nc * 100, FS_BLOCK, 1 << 16);
         hipLaunchKernelGGL(k_assemble_ns, dim3(grid), dim3(FS_BLOCK), 0, s, m->xyz.p, sp->cell_dofs, m->nc, sp->slots.p,
                            w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries, g->d.p);
     } else {
         const int grid = (int)std::min<int64_t>((m->nc + NS_WPB - 1) / NS_WPB, 1 << 16);
         hipLaunchKernelGGL(k_assemble_ns_wave, dim3(std::max(grid, 1)), dim3(FS_BLOCK), 0, s, m->xyz.p, sp->cell_dofs, m->nc, sp->slots.p,
-                           w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries, g->d.p);
+                           w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries,
+                           two_pass ? sp->elem_buf.p : nullptr, g->d.p);
+        if (two_pass)
+            hipLaunchKernelGGL(k_ns_gather, dim3(fs_grid_for(sp->sell_entries * 8, FS_BLOCK, 1 << 18)), dim3(FS_BLOCK), 0, s, sp->sell_entries,
+                               sp->gmap_ptr.p, sp->gmap_src.p, sp->elem_buf.p, J->val.p, sp->sell_entries);
     }
     hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - m->nv)), dim3(FS_BLOCK), 0, s, m->nv,
                        sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
