@@ -513,18 +513,21 @@ class SolverBase():
         from . import backend
         rtol, max_iter, pc = self._krylov_options()
         V = u.function_space().device()
-        x = backend.DeviceVector(V.n_owned)
+        x = backend.DeviceVector(V.n_local)            # owned + ghost entries: the input of operator products
         sp_ = self.solver_settings.get('solver_parameters', {}) or {}
         if amg and 'preconditioner' not in sp_:
             pc = 'amg'
-        if pc == 'amg' and (method != "cg" or u.function_space().localizer() is not None
-                            or u.function_space()._degree != 1):
-            self.logger.warning('%s: the AMG hierarchy is built for symmetric P1 problems on one GPU; using Jacobi', label)
+        if pc == 'amg' and (method != "cg" or u.function_space()._degree != 1):
+            self.logger.warning('%s: the AMG hierarchy is built for symmetric P1 problems; using Jacobi', label)
             pc = 'jacobi'
         # PETSc's KSPCG default: convergence on the preconditioned residual norm; it is
         # also what keeps badly scaled operators (e.g. permittivities of 1e-10 next to identity rows) honest
         norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc in ("jacobi", "amg")) else 'unpreconditioned')
+        loc = u.function_space().localizer()
         if pc == 'amg':
+            # several GPUs: every rank builds the hierarchy of its own diagonal block (additive Schwarz, no overlap)
+            if near_nullspace is not None and loc is not None:
+                near_nullspace = np.stack([loc.nodes(v)[:V.n_owned] for v in np.asarray(near_nullspace)])
             hierarchy = backend.AMG(A, nullspace=near_nullspace,
                                     strength_threshold=float(sp_.get('amg_strength_threshold', 0.0)))
             stats = hierarchy.solve(b, x, rtol=rtol, max_iter=min(max_iter, int(sp_.get('maximum_iterations', 500))),
@@ -542,13 +545,12 @@ class SolverBase():
         if stats['converged'] != 1:
             raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                 label, stats['iterations'], stats['true_rel_residual']))
-        loc = u.function_space().localizer()
         if loc is None:
-            u.vector().set_local(x.get())
+            u.vector().set_local(x.get()[:V.n_owned])
         else:   # every rank ends with the full field, gathered by global vertex id
             from . import parallel
             ncomp = u.function_space()._ncomp
-            u.vector().set_local(parallel.gather_owned(x.get(), loc.owned_gids(), loc.n_global, ncomp))
+            u.vector().set_local(parallel.gather_owned(x.get()[:V.n_owned], loc.owned_gids(), loc.n_global, ncomp))
         return u
 
     @staticmethod
@@ -748,48 +750,70 @@ class SolverBase():
 
     # ---- Taylor-Hood Navier-Stokes (CoupledNavierStokesSolver) -----------------------------------------
     def _navier_stokes_context(self, F, bcs):
-        """Device objects shared by the steps of one solve: mixed space, pressure operators, BC lists."""
+        """Device objects shared by the steps of one solve: mixed space, pressure operators, BC lists (local
+        numbering of this rank's part on several GPUs)."""
         from . import backend
         W = F.space
         V = W.device()
-        if W.localizer() is not None:
-            raise SolverError('the Navier-Stokes path is single-GPU for now')
-        dofs, vals = self._bc_arrays(bcs)
+        loc = W.localizer()
+        dofs, vals = self._bc_arrays(bcs)                      # global dofs
         pre = dofs[(dofs % 4) == 3] if dofs.size else dofs
         ctx = getattr(self, '_ns_ctx', None)
         key = (id(V), pre.size, np.sort(pre).tobytes())
         if ctx is None or ctx['key'] != key:
-            Q = W.pressure_space().device()
-            pinned = (pre // 4).astype(np.int32)
+            Qs = W.pressure_space()
+            Q = Qs.device()
+            qloc = Qs.localizer()
+            pinned = (pre // 4).astype(np.int64)
             if pinned.size == 0:
                 # no pressure condition: the pressure is defined up to a constant (the reference's LU hits a
                 # singular matrix here); fix it at vertex 0
                 self.logger.warning('no pressure boundary condition: pinning the pressure at vertex 0 to 0')
-                pinned = np.zeros(1, dtype=np.int32)
+                pinned = np.zeros(1, dtype=np.int64)
+            if qloc is not None:
+                pinned = qloc.dofs(pinned, np.zeros(len(pinned)))[0]
+            pinned = np.asarray(pinned, dtype=np.int32)
             Kp = backend.DeviceMatrix(Q)
             Kp.assemble(stiffness=1.0)
             Kp.apply_dirichlet(None, pinned, np.zeros(len(pinned)), symmetric=True)
             Mp = backend.DeviceMatrix(Q)
             Mp.assemble(mass=1.0)
+            cell_g2l = None
+            if loc is not None:
+                cell_g2l = np.full(self.mesh.num_cells(), -1, dtype=np.int64)
+                cell_g2l[loc.part.cell_gids] = np.arange(len(loc.part.cell_gids))
+            # several GPUs: the hierarchy of this rank's diagonal block of Kp (the Schur-complement solves of the
+            # preconditioner are subdomain solves, fs_saddle.hip)
             ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
-                   'auto_pin': pre.size == 0, 'Kp_amg': backend.AMG(Kp)}
+                   'auto_pin': pre.size == 0, 'Kp_amg': backend.AMG(Kp), 'cell_g2l': cell_g2l}
             self._ns_ctx = ctx
         if ctx['auto_pin']:
             dofs = np.concatenate([dofs, np.array([3], dtype=np.int32)]).astype(np.int32)
             vals = np.concatenate([vals, np.zeros(1)])
+        if loc is not None:
+            dofs, vals = loc.dofs(dofs, vals)
         # "later wins" de-duplication happens on the device; dummy pressure slots stay at zero
-        return V, ctx, dofs.astype(np.int32), vals
+        return V, ctx, dofs.astype(np.int32), vals, loc
 
-    def _navier_stokes_assemble(self, F, V, ctx, w, newton):
+    @staticmethod
+    def _ns_local(loc, w):
+        """global dof vector -> this rank's owned + ghost entries"""
+        return w if loc is None else loc.nodes(w)
+
+    def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None):
         from . import backend
-        dw = backend.DeviceVector(V.n_local, w)
-        dp = backend.DeviceVector(V.n_local, F.w_prev.vector().array()) if F.inv_dt else None
+        dw = backend.DeviceVector(V.n_local, self._ns_local(loc, w))
+        dp = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector().array())) if F.inv_dt else None
         g = backend.DeviceVector(V.n_owned)
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
                                        convection=True, newton=newton)
         for marker_id, value in F.pressure_boundaries:
             cells, opp, centroids = self._marked_facet_cells(marker_id)
+            if loc is not None:                 # facets whose cell is local; rows of other ranks are skipped on the device
+                lc = ctx['cell_g2l'][cells]
+                keep = lc >= 0
+                cells, opp, centroids = lc[keep].astype(np.int32), opp[keep], centroids[keep]
             fv = None
             if value is not None:
                 fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
@@ -825,9 +849,12 @@ class SolverBase():
 
     def _navier_stokes_newton(self, F, u_current, bcs):
         """NonlinearVariationalSolver.solve() for the coupled system: DOLFIN NewtonSolver defaults (relative 1e-9 /
-        absolute 1e-10 on the residual 2-norm, 50 iterations, relaxation 1); each step solves J dw = -R on the GPU."""
-        from . import backend
-        V, ctx, dofs, vals = self._navier_stokes_context(F, bcs)
+        absolute 1e-10 on the residual 2-norm, 50 iterations, relaxation 1); each step solves J dw = -R on the GPU(s).
+        On several GPUs every rank keeps the full iterate on the host (as every other path of this back end does),
+        assembles and solves its own rows and the update is gathered by global dof."""
+        from . import backend, parallel
+        V, ctx, dofs, vals, loc = self._navier_stokes_context(F, bcs)
+        gdofs, gvals = self._bc_arrays(bcs)
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         ns = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
         rtol = float(ns.get('relative_tolerance', 1e-9))
@@ -836,22 +863,28 @@ class SolverBase():
         relax = float(ns.get('relaxation_parameter', 1.0))
         lin_rtol = float(sp.get('krylov_relative_tolerance', 1e-6))
         w = u_current.vector().get_local()
-        w[dofs] = vals
+        w[gdofs] = gvals
+        if ctx['auto_pin']:
+            w[3] = 0.0
         w[F.space.dummy_dofs()] = 0.0
+        own = dofs[dofs < V.n_owned]               # constrained rows of this rank (the list also names ghost dofs)
         history, krylov = [], 0
         timing = os.environ.get("FS_NS_TIMING") is not None
         tm = {"assemble": 0.0, "residual": 0.0, "dirichlet": 0.0, "krylov": 0.0, "update": 0.0}
         clock = time.perf_counter
         for it in range(max_it + 1):
             t0 = clock()
-            dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=True)
+            dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=True, loc=loc)
             t1 = clock()
             r = backend.DeviceVector(V.n_owned)
             ctx['J'].spmv(dw, r)
             r.axpy(-1.0, g)                                   # R(w) = J w - g
             res = r.get()
-            res[dofs] = 0.0
-            rn = float(np.linalg.norm(res))
+            res[own] = 0.0
+            rn2 = float(np.dot(res, res))
+            if loc is not None and parallel.world()[1] > 1:
+                rn2 = float(backend.comm_allreduce_sum([rn2])[0])
+            rn = float(np.sqrt(rn2))
             t2 = clock()
             tm["assemble"] += t1 - t0
             tm["residual"] += t2 - t1
@@ -870,7 +903,10 @@ class SolverBase():
             st = self._navier_stokes_krylov(F, ctx, ctx['J'], rhs, x, lin_rtol, False)
             krylov += st['iterations']
             t5 = clock()
-            w = w + relax * x.get()
+            dx = x.get()[:V.n_owned]
+            if loc is not None:
+                dx = parallel.gather_owned(dx, loc.owned_gids(), loc.n_global, 4)
+            w = w + relax * dx
             t6 = clock()
             tm["dirichlet"] += t4 - t3
             tm["krylov"] += t5 - t4
@@ -884,17 +920,22 @@ class SolverBase():
 
     def _navier_stokes_linear(self, F, u, bcs):
         """One Picard step: LinearVariationalSolver on lhs(F) == rhs(F) with the advecting velocity frozen."""
-        from . import backend
-        V, ctx, dofs, vals = self._navier_stokes_context(F, bcs)
+        from . import backend, parallel
+        V, ctx, dofs, vals, loc = self._navier_stokes_context(F, bcs)
+        gdofs, gvals = self._bc_arrays(bcs)
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         w = F.w_current.vector().get_local()
-        dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=False)
+        dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=False, loc=loc)
         ctx['J'].apply_dirichlet(g, dofs, vals, symmetric=False)
         w0 = w.copy()
-        w0[dofs] = vals
-        x = backend.DeviceVector(V.n_local, w0)
+        w0[gdofs] = gvals
+        if ctx['auto_pin']:
+            w0[3] = 0.0
+        x = backend.DeviceVector(V.n_local, self._ns_local(loc, w0))
         self._navier_stokes_krylov(F, ctx, ctx['J'], g, x, float(sp.get('krylov_relative_tolerance', 1e-8)), True)
-        out = x.get()
+        out = x.get()[:V.n_owned]
+        if loc is not None:
+            out = parallel.gather_owned(out, loc.owned_gids(), loc.n_global, 4)
         out[F.space.dummy_dofs()] = 0.0
         u.vector().set_local(out)
         return u

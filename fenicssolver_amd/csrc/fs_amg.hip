@@ -164,6 +164,33 @@ __global__ void k_amg_extract(int64_t n_rows, const int64_t* __restrict__ slice_
     }
 }
 
+// rank-local block of a distributed matrix: entries whose column is a ghost node are dropped
+__global__ void k_count_owned_cols(int64_t nn, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, int32_t* __restrict__ cnt) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r <= nn; r += stride) {
+        int32_t c = 0;
+        if (r < nn)
+            for (int32_t e = rp[r]; e < rp[r + 1]; ++e) c += ci[e] < nn ? 1 : 0;
+        cnt[r] = c;
+    }
+}
+__global__ void k_compact_owned_cols(int64_t nn, int bs2, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                     const double* __restrict__ val, const int32_t* __restrict__ nrp, int32_t* __restrict__ nci,
+                                     double* __restrict__ nval) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < nn; r += stride) {
+        int64_t o = nrp[r];
+        for (int32_t e = rp[r]; e < rp[r + 1]; ++e) {
+            if (ci[e] >= nn) continue;
+            nci[o] = ci[e];
+            for (int q = 0; q < bs2; ++q) nval[o * bs2 + q] = val[(int64_t)e * bs2 + q];
+            ++o;
+        }
+    }
+}
+
 // per node: 1/diag, identity-row flags, Gershgorin ratio (max over the block row, atomically maxed), block norm
 __global__ void k_amg_diag(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                            const double* __restrict__ val, double* __restrict__ dinv, uint8_t* __restrict__ ident,
@@ -979,7 +1006,9 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A && out, "fs_amg_setup: null pointer");
     fs_space_s* sp = A->space;
-    FS_REQUIRE(fs_rt().n_ranks == 1 && !sp->halo.active, "fs_amg_setup: the AMG hierarchy is single-GPU for now");
+    // Multi-GPU: the hierarchy is built on this rank's diagonal block (ghost columns dropped) - the subdomain solver
+    // of a non-overlapping additive Schwarz preconditioner; fs_amg_apply then expects zero ghost entries in z.
+    const bool local_block = sp->n_nodes_local > sp->n_nodes_owned;
     FS_REQUIRE(A->bs == 1 || A->bs == 3, "fs_amg_setup: block size %d", A->bs);
     const int nb = nullspace ? n_nullspace : A->bs;
     FS_REQUIRE(nb == 1 || nb == 3 || nb == 6, "fs_amg_setup: %d near-null-space vectors (1, 3 or 6 are built)", nb);
@@ -1027,6 +1056,24 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
         }
         hipLaunchKernelGGL(k_nullspace_layout, dim3(fs_grid_for(L0->n * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->n, nb, A->bs, (const double*)raw.p, L0->B.p);
         if (hipStreamSynchronize(s) != hipSuccess) { fs_set_error("fs_amg_setup: near-null-space upload failed"); return fail(FS_ERR_HIP); }
+    }
+    if (local_block) {
+        const int bs2 = A->bs * A->bs;
+        dbuf<int32_t> cnt, nrp, nci;
+        dbuf<double> nval;
+        if ((rc = cnt.alloc(L0->nn + 1)) != FS_OK || (rc = nrp.alloc(L0->nn + 1)) != FS_OK) return fail(rc);
+        hipLaunchKernelGGL(k_count_owned_cols, dim3(fs_grid_for(L0->nn + 1)), dim3(FS_BLOCK), 0, s, L0->nn, L0->A.rowptr.p, L0->A.col.p, cnt.p);
+        if ((rc = scan_exclusive(cnt.p, nrp.p, L0->nn + 1, s)) != FS_OK) return fail(rc);
+        int32_t kept = 0;
+        if ((rc = read_i32(nrp.p + L0->nn, &kept, s)) != FS_OK) return fail(rc);
+        if ((rc = nci.alloc(std::max<int64_t>(kept, 1))) != FS_OK || (rc = nval.alloc(std::max<int64_t>(kept, 1) * bs2)) != FS_OK) return fail(rc);
+        hipLaunchKernelGGL(k_compact_owned_cols, dim3(fs_grid_for(L0->nn)), dim3(FS_BLOCK), 0, s, L0->nn, bs2, L0->A.rowptr.p, L0->A.col.p,
+                           L0->A.val.p, nrp.p, nci.p, nval.p);
+        if (hipStreamSynchronize(s) != hipSuccess) { fs_set_error("fs_amg_setup: compaction of the local block failed"); return fail(FS_ERR_HIP); }
+        L0->A.rowptr.swap(nrp);
+        L0->A.col.swap(nci);
+        L0->A.val.swap(nval);
+        L0->A.nnz = kept;
     }
     tick("extract+nullspace");
     double nnz_scalar0 = (double)L0->A.nnz * A->bs * A->bs, nnz_total = nnz_scalar0, n_total = (double)L0->n;
@@ -1193,6 +1240,17 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
     memset(stats, 0, sizeof(*stats));
     const auto t0 = std::chrono::steady_clock::now();
     const int g = fs_grid_for(n, FS_BLOCK, 2048);
+    // Multi-GPU: CG on the distributed operator (halo exchange before each product, dots reduced over the ranks),
+    // preconditioned by the rank-local hierarchies (additive Schwarz, no overlap)
+    auto dot_host = [&](fs_amg_s* Mm, const double* xx, const double* yy, int64_t nn, double* out, hipStream_t ss) -> int {
+        const int gg = fs_grid_for(nn, FS_BLOCK, 1024);
+        hipLaunchKernelGGL(k_dot_partial, dim3(gg), dim3(FS_BLOCK), 0, ss, xx, yy, nn, Mm->partials.p);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, ss, Mm->partials.p, gg, 1, Mm->sums.p);
+        FS_KERNEL_CHECK();
+        FS_CHECK(fs_comm_allreduce_dev(Mm->sums.p, 1, ss));
+        FS_CHECK(Mm->sums.download(out, 1, ss));
+        return FS_OK;
+    };
     const bool pnorm = opts->norm_type == FS_NORM_PRECONDITIONED;
     double bb = 0.0;
     FS_CHECK(dot_host(M, b->d.p, b->d.p, n, &bb, s));
@@ -1200,6 +1258,7 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
     if (!opts->nonzero_guess) FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)n * sizeof(double), s));
     // r = b - A x
     if (opts->nonzero_guess) {
+        FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
         FS_CHECK(fs_spmv_dev(M->fine, x->d.p, M->pw.p, s));
         hipLaunchKernelGGL(k_amg_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, M->pw.p, M->pr.p);
     } else {
@@ -1236,6 +1295,7 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
             const double beta = first ? 0.0 : rho / rho_old;
             first = false;
             hipLaunchKernelGGL(k_amg_axpby, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0, M->pz.p, beta, M->pp.p);   // p = z + beta p
+            FS_CHECK(fs_halo_exchange_dev(sp, M->pp.p, s));
             FS_CHECK(fs_spmv_dev(M->fine, M->pp.p, M->pw.p, s));
             double pw = 0.0;
             FS_CHECK(dot_host(M, M->pp.p, M->pw.p, n, &pw, s));
@@ -1251,6 +1311,7 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
         FS_CHECK(cg_pass());
         FS_KERNEL_CHECK();
         // true residual b - A x
+        FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
         FS_CHECK(fs_spmv_dev(M->fine, x->d.p, M->pw.p, s));
         hipLaunchKernelGGL(k_amg_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, M->pw.p, M->pw.p);
         FS_CHECK(dot_host(M, M->pw.p, M->pw.p, n, &tr2, s));

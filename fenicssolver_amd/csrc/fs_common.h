@@ -94,6 +94,10 @@ struct dbuf {
         p = nullptr;
         n = 0;
     }
+    void swap(dbuf& o) {
+        T* tp = p; p = o.p; o.p = tp;
+        const int64_t tn = n; n = o.n; o.n = tn;
+    }
     ~dbuf() { release(); }
     dbuf() = default;
     dbuf(const dbuf&) = delete;

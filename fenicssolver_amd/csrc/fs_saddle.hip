@@ -76,7 +76,8 @@ struct ns_params {
 };
 
 // thread t = ab*nc + c : block (a, b) of cell c.  val planes [(i*4+j)*plane + slot], g [node*4 + i]
-__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restrict__ xyz, const int32_t* __restrict__ cell_dofs,
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
+                                                          const int32_t* __restrict__ cell_dofs,
                                                           int64_t nc, const int32_t* __restrict__ slots,
                                                           const double* __restrict__ w0, const double* __restrict__ wprev,
                                                           ns_params P, double* __restrict__ val, int64_t plane,
@@ -92,12 +93,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
         int32_t nd[10];
 #pragma unroll
         for (int n = 0; n < 10; ++n) nd[n] = cell_dofs[c * 10 + n];
-        // geometry: gradients of the barycentric coordinates
+        // geometry: gradients of the barycentric coordinates (vertex ids: node ids differ once ghosts exist)
         double X[4][3];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const double2 p01 = reinterpret_cast<const double2*>(xyz)[2 * (int64_t)nd[v]];
-            X[v][0] = p01.x; X[v][1] = p01.y; X[v][2] = xyz[4 * (int64_t)nd[v] + 2];
+            const int64_t vx = cells[c * 4 + v];
+            const double2 p01 = reinterpret_cast<const double2*>(xyz)[2 * vx];
+            X[v][0] = p01.x; X[v][1] = p01.y; X[v][2] = xyz[4 * vx + 2];
         }
         const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
         const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
@@ -232,8 +234,9 @@ struct ns_cell_lds {
     int32_t nd[10];
     int32_t pad[2];
 };
-__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __restrict__ xyz, const int32_t* __restrict__ cell_dofs,
-                                                               int64_t nc, const int32_t* __restrict__ slots,
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
+                                                               const int32_t* __restrict__ cell_dofs,
+                                                               int64_t nc, int64_t n_rows, const int32_t* __restrict__ slots,
                                                                const double* __restrict__ w0, const double* __restrict__ wprev,
                                                                ns_params P, double* __restrict__ val, int64_t plane,
                                                                double* __restrict__ ebuf, double* __restrict__ g) {
@@ -257,9 +260,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
             double X[4][3];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int64_t node = cell_dofs[c * 10 + v];
-                const double2 p01 = reinterpret_cast<const double2*>(xyz)[2 * node];
-                X[v][0] = p01.x; X[v][1] = p01.y; X[v][2] = xyz[4 * node + 2];
+                const int64_t vx = cells[c * 4 + v];          // vertex ids: node ids differ once ghosts exist
+                const double2 p01 = reinterpret_cast<const double2*>(xyz)[2 * vx];
+                X[v][0] = p01.x; X[v][1] = p01.y; X[v][2] = xyz[4 * vx + 2];
             }
             const double e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
             const double e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
@@ -383,8 +386,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
                 }
                 if (do_rhs) {
                     const int64_t node = L.nd[a];
+                    if (node < n_rows) {      // owned row
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) atomicAdd(&g[4 * node + i], gv[i]);
+                        for (int i = 0; i < 3; ++i) atomicAdd(&g[4 * node + i], gv[i]);
+                    }
                 }
             }
         }
@@ -511,18 +516,19 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     }
     if (!two_pass && mode_env[0] == 'p') {
         const int grid = fs_grid_for(m->nc * 100, FS_BLOCK, 1 << 16);
-        hipLaunchKernelGGL(k_assemble_ns, dim3(grid), dim3(FS_BLOCK), 0, s, m->xyz.p, sp->cell_dofs, m->nc, sp->slots.p,
+        hipLaunchKernelGGL(k_assemble_ns, dim3(grid), dim3(FS_BLOCK), 0, s, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc, sp->slots.p,
                            w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries, g->d.p);
     } else {
         const int grid = (int)std::min<int64_t>((m->nc + NS_WPB - 1) / NS_WPB, 1 << 16);
-        hipLaunchKernelGGL(k_assemble_ns_wave, dim3(std::max(grid, 1)), dim3(FS_BLOCK), 0, s, m->xyz.p, sp->cell_dofs, m->nc, sp->slots.p,
+        hipLaunchKernelGGL(k_assemble_ns_wave, dim3(std::max(grid, 1)), dim3(FS_BLOCK), 0, s, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
+                           sp->n_nodes_owned, sp->slots.p,
                            w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P, J->val.p, sp->sell_entries,
                            two_pass ? sp->elem_buf.p : nullptr, g->d.p);
         if (two_pass)
             hipLaunchKernelGGL(k_ns_gather, dim3(fs_grid_for(sp->sell_entries * 8, FS_BLOCK, 1 << 18)), dim3(FS_BLOCK), 0, s, sp->sell_entries,
                                sp->gmap_ptr.p, sp->gmap_src.p, sp->elem_buf.p, J->val.p, sp->sell_entries);
     }
-    hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - m->nv)), dim3(FS_BLOCK), 0, s, m->nv,
+    hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - m->n_owned)), dim3(FS_BLOCK), 0, s, m->n_owned,
                        sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
@@ -545,7 +551,8 @@ __device__ const int NS_FACE_NODES[4][6] = {{1, 2, 3, 4, 5, 6}, {0, 2, 3, 4, 7, 
 // thread t = (facet, facet node al, cell node b)
 __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
                                        const double* __restrict__ facet_value, double nu, const double* __restrict__ xyz,
-                                       const int32_t* __restrict__ cell_dofs, int64_t nc, const int32_t* __restrict__ slots,
+                                       const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
+                                       const int32_t* __restrict__ slots,
                                        double* __restrict__ val, int64_t plane, double* __restrict__ g) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -558,7 +565,7 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
         const int a = NS_FACE_NODES[o][al];
         int32_t nd[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) nd[v] = cell_dofs[c * 10 + v];
+        for (int v = 0; v < 4; ++v) nd[v] = cells[c * 4 + v];     // vertex ids (geometry), not node ids
         double X[4][3];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -645,7 +652,7 @@ extern "C" int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, in
         FS_CHECK(dv.upload(facet_value, n_facets, s));
     }
     hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
-                       facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, sp->cell_dofs, m->nc,
+                       facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
                        sp->slots.p, J->val.p, sp->sell_entries, g->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
@@ -975,6 +982,7 @@ static int sd_dot(saddle_ws& W, const double* x, const double* y, int64_t n, dou
     hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(FS_BLOCK), 0, s, x, y, n, W.partials.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, W.partials.p, g, 1, W.sums.p);
     FS_KERNEL_CHECK();
+    FS_CHECK(fs_comm_allreduce_dev(W.sums.p, 1, s));      // no-op on one rank
     FS_CHECK(W.sums.download(out, 1, s));
     return FS_OK;
 }
@@ -983,7 +991,7 @@ static int sd_dot(saddle_ws& W, const double* x, const double* y, int64_t n, dou
 static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matrix_s* Mp, const fs_saddle_opts* o, saddle_ws& W,
                       const double* r, double* z, int* inner_its, hipStream_t s) {
     fs_space_s* sp = J->space;
-    const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
+    const int64_t n = sp->n_dofs_owned, nv = sp->mesh->n_owned;      // owned vertices = pressure unknowns of this rank
     const int g = fs_grid_for(n, FS_BLOCK, 4096);
     const int sweeps = o->velocity_sweeps > 0 ? o->velocity_sweeps : 1;
     if (sweeps == 1) {
@@ -996,12 +1004,17 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
         double rho_c = 1.0 / sigma;
         hipLaunchKernelGGL(k_sd_vel_cheb<true>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, (const double*)nullptr, W.cd.p, z, 1.0 / theta, 0.0);
         for (int k = 1; k < sweeps; ++k) {
+            FS_CHECK(fs_halo_exchange_dev(sp, z, s));
             FS_CHECK(fs_spmv_dev(J, z, W.t.p, s));
             const double rho_new = 1.0 / (2.0 * sigma - rho_c);
             hipLaunchKernelGGL(k_sd_vel_cheb<false>, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, r, W.t.p, W.cd.p, z, 2.0 * rho_new / delta, rho_new * rho_c);
             rho_c = rho_new;
         }
     }
+    // the continuity rows couple to the velocities of ghost nodes.  Multi-GPU: the two pressure solves below act on
+    // this rank's diagonal block (ghost columns see zeros) - a non-overlapping additive Schwarz step with the AMG
+    // V-cycle / Chebyshev iteration as subdomain solver, no communication inside
+    FS_CHECK(fs_halo_exchange_dev(sp, z, s));
     hipLaunchKernelGGL(k_sd_pressure_rows, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p,
                        J->val.p, sp->sell_entries, z, r, W.rp.d.p);
     FS_KERNEL_CHECK();
@@ -1043,6 +1056,7 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
                        r2 * o->inv_dt, transient ? W.p1.d.p : (const double*)nullptr, r2 * o->kinematic_viscosity, W.p2.d.p, r,
                        W.ident.p, z);
     FS_KERNEL_CHECK();
+    FS_CHECK(fs_halo_exchange_dev(sp, z, s));      // ghost pressures for the operator product that follows
     return FS_OK;
 }
 
@@ -1052,8 +1066,8 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_REQUIRE(J && Mp && b && x && o && stats, "fs_saddle_solve: null pointer");
     fs_space_s* sp = J->space;
     FS_REQUIRE(J->bs == 4 && sp->degree == 2, "fs_saddle_solve: the operator must be a Taylor-Hood block matrix");
-    FS_REQUIRE(fs_rt().n_ranks == 1 && !sp->halo.active, "fs_saddle_solve: single GPU for now");
-    const int64_t n = sp->n_dofs_owned, nv = sp->mesh->nv;
+    const bool multi = fs_rt().n_ranks > 1;
+    const int64_t n = sp->n_dofs_owned, nl = sp->n_dofs_local, nv = sp->mesh->n_owned;
     FS_REQUIRE(Mp->bs == 1 && Mp->space->n_dofs_owned == nv && (!Kp || (Kp->bs == 1 && Kp->space->n_dofs_owned == nv)),
                "fs_saddle_solve: the pressure operators must live on the CG1 space of the same mesh");
     FS_REQUIRE(b->d.n >= n && x->d.n >= sp->n_dofs_local, "fs_saddle_solve: vector too short");
@@ -1071,7 +1085,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     static int64_t g_ws_n = -1;
     static int g_ws_m = -1;
     const int dot_blocks = 512;
-    if (g_ws && (g_ws_n != n || g_ws_m != m)) { delete g_ws; g_ws = nullptr; }
+    static int64_t g_ws_nl = -1;
+    if (g_ws && (g_ws_n != n || g_ws_m != m || g_ws_nl != nl)) { delete g_ws; g_ws = nullptr; }
+    g_ws_nl = nl;
     const bool fresh = g_ws == nullptr;
     if (fresh) { g_ws = new saddle_ws(); g_ws_n = n; g_ws_m = m; }
     saddle_ws& W = *g_ws;
@@ -1084,7 +1100,8 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_CHECK(W.w.alloc(n));
     FS_CHECK(W.cd.alloc(n));
     FS_CHECK(W.gin.alloc(n));
-    FS_CHECK(W.gout.alloc(n));
+    FS_CHECK(W.gout.alloc(nl));
+    FS_CHECK(W.gout.zero(s));
     FS_CHECK(W.ident.alloc(nv));
     FS_CHECK(W.mdinv.alloc(nv));
     FS_CHECK(W.md.alloc(nv));
@@ -1099,13 +1116,16 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     FS_CHECK(W.rp.d.alloc(nv));
     FS_CHECK(W.p1.d.alloc(Mp->space->n_dofs_local));
     FS_CHECK(W.p2.d.alloc(Mp->space->n_dofs_local));
+    FS_CHECK(W.p1.d.zero(s));          // ghost entries stay zero: the pressure solves are rank-local blocks
+    FS_CHECK(W.p2.d.zero(s));
     for (int k = 0; k <= m; ++k) {
         W.V.push_back(new dbuf<double>());
         FS_CHECK(W.V.back()->alloc(n));
     }
-    for (int k = 0; k < m; ++k) {
+    for (int k = 0; k < m; ++k) {          // Z_k is the input of an operator product: owned + ghost entries
         W.Z.push_back(new dbuf<double>());
-        FS_CHECK(W.Z.back()->alloc(n));
+        FS_CHECK(W.Z.back()->alloc(nl));
+        FS_CHECK(W.Z.back()->zero(s));
     }
     {
         std::vector<const double*> hp(m + 1);
@@ -1142,8 +1162,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
             nn = sqrt(nn);
             if (!(nn > 0.0)) break;
             if (it > 0) lam = nn;
-            hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / nn, W.w.p, W.r.p);
-            FS_CHECK(fs_spmv_dev(J, W.r.p, W.t.p, s));
+            hipLaunchKernelGGL(k_sd_scale_to, dim3(g), dim3(FS_BLOCK), 0, s, n, 1.0 / nn, W.w.p, W.Z[0]->p);
+            FS_CHECK(fs_halo_exchange_dev(sp, W.Z[0]->p, s));
+            FS_CHECK(fs_spmv_dev(J, W.Z[0]->p, W.t.p, s));
             hipLaunchKernelGGL(k_sd_vel_scale, dim3(g), dim3(FS_BLOCK), 0, s, n, W.dinv.p, W.t.p, W.w.p);
         }
         W.vel_lmax = lam;
@@ -1167,7 +1188,7 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     // 0.35 ms - the enqueue costs the host only 0.1 ms, it is not launch-bound - so direct launches stay the default.
     hipGraph_t pgraph = nullptr;
     hipGraphExec_t pexec = nullptr;
-    bool use_graph = getenv("FS_SADDLE_GRAPH") != nullptr && (!transient_kp || Kp_amg != nullptr);
+    bool use_graph = getenv("FS_SADDLE_GRAPH") != nullptr && (!transient_kp || Kp_amg != nullptr) && !multi;
     if (use_graph) {
         FS_HIP(hipStreamSynchronize(s));
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -1212,6 +1233,7 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     } guard{pgraph, pexec};
     while (true) {
         // r = b - J x
+        FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
         FS_CHECK(fs_spmv_dev(J, x->d.p, W.t.p, s));
         hipLaunchKernelGGL(k_sd_sub, dim3(g), dim3(FS_BLOCK), 0, s, n, b->d.p, W.t.p, W.r.p);
         double rr = 0.0;
@@ -1285,6 +1307,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
                 const double* gate = pass ? dctl + SD_NEED2 : nullptr;
                 hipLaunchKernelGGL(k_sd_multi_dot, dim3(dot_blocks), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, k + 1, 1, W.partials.p, gate);
                 hipLaunchKernelGGL(k_sd_multi_sum, dim3(k + 2), dim3(FS_BLOCK), 0, s, W.partials.p, dot_blocks, W.hdev.p, gate);
+                // every rank issues the reduction of both passes: whether the second pass counts is decided on the
+                // device, from reduced numbers, hence identically on all ranks
+                if (multi) FS_CHECK(fs_comm_allreduce_dev(W.hdev.p, k + 2, s));
                 hipLaunchKernelGGL(k_sd_hess_pass, dim3(1), dim3(1), 0, s, W.hdev.p, k, m, dH, dctl, pass);
                 hipLaunchKernelGGL(k_sd_multi_axpy, dim3(g), dim3(FS_BLOCK), 0, s, n, W.w.p, W.vptr.p, W.hdev.p, k + 1, gate);
             }

@@ -428,10 +428,6 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
     hipStream_t s = fs_rt().stream;
     const int64_t nc = mesh->nc;
     FS_REQUIRE(mesh->n_owned > 0, "fs_space_create: process owns no vertices");
-    if (degree == 2 && ncomp != 1 && mesh->n_owned != mesh->nv) {
-        fs_set_error("fs_space_create: the Taylor-Hood block space is single-GPU for now (the mesh has ghost vertices)");
-        return FS_ERR_UNSUPPORTED;
-    }
     fs_space_s* sp = new fs_space_s();
     sp->mesh = mesh;
     sp->degree = degree;

@@ -663,8 +663,8 @@ class FunctionSpace:
         """This rank's share of the space: owner-computes vertex slabs along the longest axis,
         one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
         from . import partition
-        if root._degree == 2 and root._ncomp != 1:
-            raise SolverError("multi-GPU decomposition is built for P1 spaces and scalar P2 spaces")
+        if root._degree == 2 and root._ncomp not in (1, 4):
+            raise SolverError("multi-GPU decomposition is built for P1 spaces, scalar P2 spaces and the Taylor-Hood space")
         rank, size = parallel.ensure_comm()
         mesh = root._mesh
         co, ce = mesh.coordinates(), mesh.cells()
@@ -679,11 +679,18 @@ class FunctionSpace:
             root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
         else:
             plan = partition.build_p2_plan(ce, owner, rank, part, ds.edges(), root.edge_nodes())
-            if plan.n_owned_nodes != ds.n_owned:
+            nc_ = root._ncomp
+            if plan.n_owned_nodes * nc_ != ds.n_owned:
                 raise SolverError("internal error: host and device disagree on the owned P2 nodes")
             if size > 1:
-                ds.set_halo(plan.neighbors, plan.send_lists, plan.recv_counts, recv_lists=plan.recv_lists)
-            root._localizer = parallel.Localizer(part, mesh.num_vertices(), 1, p2_plan=plan, n_global_nodes=root.num_nodes())
+                def dof_lists(lists):      # node lists -> dof lists (block of ncomp unknowns per node)
+                    if nc_ == 1:
+                        return lists
+                    return [(np.asarray(l, dtype=np.int64)[:, None] * nc_ + np.arange(nc_)[None, :]).reshape(-1).astype(np.int32)
+                            for l in lists]
+                ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts],
+                            recv_lists=dof_lists(plan.recv_lists))
+            root._localizer = parallel.Localizer(part, mesh.num_vertices(), nc_, p2_plan=plan, n_global_nodes=root.num_nodes())
         return ds
 
     def localizer(self):

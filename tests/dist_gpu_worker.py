@@ -50,7 +50,7 @@ if case == "box":
 else:
     # the solver API under torch.distributed.run (parallel.py): every rank builds the global host mesh
     import test_gpu_parallel_api as T
-    solver = T.CASES[case]()
+    solver = (T.CASES.get(case) or T.NS_CASES[case])()
     u = solver.solve()
     assert solver.function_space.localizer() is not None and parallel.world()[1] == world
     if rank == 0:

@@ -57,3 +57,24 @@ def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     single = T.CASES[case]().solve().vector().get_local()
     r = _run(world, case, tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
+
+
+@pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2)])
+def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
+    """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,
+    FGMRES with reduced multi-dots, halo exchange of the iterate inside the preconditioner, Schur-complement solves on
+    the rank-local blocks (AMG hierarchy of the local pressure Laplacian), Newton residual norm reduced over the ranks."""
+    import test_gpu_parallel_api as T
+    single = T.NS_CASES[case]().solve().vector().get_local()
+    r = _run(world, case, tmp_path)
+    assert np.abs(r["x"] - single).max() <= 1e-6 * np.abs(single).max()
+
+
+def test_amg_pcg_under_two_ranks_is_an_additive_schwarz_solve(gpu, tmp_path):
+    """solve_amg on two ranks: CG on the distributed operator, preconditioned by the hierarchies of the rank-local
+    diagonal blocks; same displacement field as the single-GPU AMG-PCG."""
+    import test_gpu_parallel_api as T
+    single = T.CASES["elasticity"]().solve().vector().get_local()
+    r = _run(2, "elasticity", tmp_path)
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
+    assert int(r["iterations"]) < 200

@@ -82,20 +82,74 @@ def _elastic_case():
     return LinearElasticitySolver(s)
 
 
+def _cavity_case(n=4, transient=True):
+    """Lid-driven cavity, Taylor-Hood, two backward-Euler steps with Newton (configs[4] in small)."""
+    from fenicssolver_amd.fem import UnitCubeMesh, BoxMesh, Point, AutoSubDomain, Constant, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 1.5), n, n, n + 2)
+    bcs = OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 1.5)), 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+              'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 1.0, 'kinematic_viscosity': 0.01}})
+    s['solver_settings']['transient_settings'] = {'transient': transient, 'starting_time': 0.0, 'time_step': 0.01,
+                                                  'ending_time': 0.02 - 1e-9}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-10}
+    s['report_settings'] = dict(QUIET)
+    return CoupledNavierStokesSolver(s)
+
+
+def _channel_case():
+    """Pressure-driven channel along z (the partition axis): pressure Dirichlet + the reference's pressure-boundary
+    integrals on the inlet / outlet facets, which lie in the first and the last rank's parts."""
+    from fenicssolver_amd.fem import BoxMesh, Point, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    nu = 0.3
+    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 3, 3, 6)
+    prof = Expression(("0", "0", "x[0]*(1-x[0])"), degree=2)
+    bcs = OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[0], 0) or near(x[0], 1) or near(x[1], 0) or near(x[1], 1))),
+                    'boundary_id': 1, 'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': prof}]}
+    bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 0)), 'boundary_id': 2,
+                    'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(2 * nu * 2)}]}
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 2)), 'boundary_id': 3,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(0.0)}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+              'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 1.0, 'kinematic_viscosity': nu}})
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-10}
+    s['report_settings'] = dict(QUIET)
+    return CoupledNavierStokesSolver(s)
+
+
+# Navier-Stokes cases: solved through the saddle-point path, not through _device_solve (no captured (A, b) test)
+NS_CASES = {"cavity": _cavity_case, "channel": _channel_case}
+
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          "heat_p2": _heat_p2_case}
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("case", sorted(CASES) + sorted(NS_CASES))
 def test_forced_single_part_equals_plain_path(gpu, monkeypatch, case):
     from fenicssolver_amd import parallel
-    plain = CASES[case]().solve().vector().array()
+    make = CASES.get(case) or NS_CASES[case]
+    plain = make().solve().vector().array()
     monkeypatch.setenv("FS_FORCE_PARALLEL_PATH", "1")
     assert parallel.active()
-    solver = CASES[case]()
+    solver = make()
     forced = solver.solve().vector().array()
     assert solver.function_space.localizer() is not None
-    assert np.abs(forced - plain).max() <= 1e-9 * np.abs(plain).max()
+    tol = 1e-9 if case in CASES else 1e-7          # Newton + FGMRES to 1e-10 on the update
+    assert np.abs(forced - plain).max() <= tol * np.abs(plain).max()
 
 
 class _Captured(Exception):
