@@ -782,10 +782,21 @@ class SolverBase():
             if loc is not None:
                 cell_g2l = np.full(self.mesh.num_cells(), -1, dtype=np.int64)
                 cell_g2l[loc.part.cell_gids] = np.arange(len(loc.part.cell_gids))
-            # several GPUs: the hierarchy of this rank's diagonal block of Kp (the Schur-complement solves of the
-            # preconditioner are subdomain solves, fs_saddle.hip)
+            # several GPUs: the pressure space is small, so every rank holds the hierarchy of the GLOBAL pressure
+            # Laplacian (assembled on the global mesh) and the Schur-complement solve is replicated (fs_saddle.hip)
+            if loc is not None:
+                gm = backend.DeviceMesh(self.mesh.coordinates(), self.mesh.cells())
+                gQ = backend.DeviceSpace(gm, 1, 1)
+                gK = backend.DeviceMatrix(gQ)
+                gK.assemble(stiffness=1.0)
+                gpin = (pre // 4).astype(np.int32) if pre.size else np.zeros(1, dtype=np.int32)
+                gK.apply_dirichlet(None, gpin, np.zeros(len(gpin)), symmetric=True)
+                kp_amg = backend.AMG(gK)
+                keep = (gm, gQ, gK)
+            else:
+                kp_amg, keep = backend.AMG(Kp), None
             ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
-                   'auto_pin': pre.size == 0, 'Kp_amg': backend.AMG(Kp), 'cell_g2l': cell_g2l}
+                   'auto_pin': pre.size == 0, 'Kp_amg': kp_amg, 'cell_g2l': cell_g2l, 'global_pressure': keep}
             self._ns_ctx = ctx
         if ctx['auto_pin']:
             dofs = np.concatenate([dofs, np.array([3], dtype=np.int32)]).astype(np.int32)

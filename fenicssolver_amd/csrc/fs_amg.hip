@@ -1222,6 +1222,8 @@ extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
 }
 
 // ---- PCG preconditioned by one V-cycle (PETSc KSPCG + PCGAMG) ------------------------------------------------
+int64_t fs_amg_rows(const fs_amg_s* amg) { return amg && !amg->lv.empty() ? amg->lv[0]->n : 0; }
+
 extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats) {
     FS_REQUIRE(M && b && x && opts && stats, "fs_amg_solve: null pointer");
     amg_level* L0 = M->lv[0];

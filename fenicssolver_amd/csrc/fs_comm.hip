@@ -11,6 +11,8 @@
 //
 // librccl is dlopen()ed on first use, so single-GPU processes never depend on it.
 #include "fs_common.h"
+#include <vector>
+#include <algorithm>
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <atomic>
@@ -86,7 +88,7 @@ struct shm_comm {
     int n_ranks = 1, rank = 0;
     char name[64] = {0};
     static constexpr int64_t PAIR_CAP = 1 << 18;   // doubles per (src,dst) halo buffer (pages are touched only when used)
-    static constexpr int RED_CAP = 64;             // doubles per rank in the reduction mailbox
+    static constexpr int RED_CAP = 8192;           // doubles per rank in the reduction mailbox (longer vectors go in rounds)
     shm_header* hdr() { return (shm_header*)base; }
     double* red(int r) { return (double*)(base + 4096) + (size_t)r * RED_CAP; }
     double* pair(int src, int dst) {
@@ -228,19 +230,21 @@ int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     if (!rt.comm) return FS_OK;  // one rank
     if (g_shm) {
-        FS_REQUIRE(n <= shm_comm::RED_CAP, "shm test transport: reduction of %d values", n);
-        double h[shm_comm::RED_CAP];
-        FS_HIP(hipMemcpyAsync(h, d_inout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        std::vector<double> h((size_t)n);
+        FS_HIP(hipMemcpyAsync(h.data(), d_inout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
         FS_HIP(hipStreamSynchronize(s));
-        memcpy(g_shm->red(g_shm->rank), h, (size_t)n * sizeof(double));
-        g_shm->barrier();
-        for (int i = 0; i < n; ++i) {
-            double acc = 0.0;
-            for (int r = 0; r < g_shm->n_ranks; ++r) acc += g_shm->red(r)[i];   // rank order: same bits everywhere
-            h[i] = acc;
+        for (int64_t off = 0; off < n; off += shm_comm::RED_CAP) {
+            const int m = (int)std::min<int64_t>(shm_comm::RED_CAP, n - off);
+            memcpy(g_shm->red(g_shm->rank), h.data() + off, (size_t)m * sizeof(double));
+            g_shm->barrier();
+            for (int i = 0; i < m; ++i) {
+                double acc = 0.0;
+                for (int r = 0; r < g_shm->n_ranks; ++r) acc += g_shm->red(r)[i];   // rank order: same bits everywhere
+                h[off + i] = acc;
+            }
+            g_shm->barrier();
         }
-        g_shm->barrier();
-        FS_HIP(hipMemcpyAsync(d_inout, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        FS_HIP(hipMemcpyAsync(d_inout, h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }

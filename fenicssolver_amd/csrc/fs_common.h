@@ -216,3 +216,4 @@ int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 // fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.
 struct fs_amg_s;
 int fs_amg_apply_dev(fs_amg_s* amg, const double* r, double* z, hipStream_t s);
+int64_t fs_amg_rows(const fs_amg_s* amg);      // scalar rows of the finest level

@@ -956,11 +956,24 @@ __global__ void k_sd_scale_dev(int64_t n, const double* __restrict__ a, const do
     for (; i < n; i += stride) y[i] = f * x[i];
 }
 
+// replicated pressure problem: owned entries <-> the global vector by global vertex id
+__global__ void k_sd_to_global(int64_t nvo, const int64_t* __restrict__ gid, const double* __restrict__ local, double* __restrict__ global) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; v < nvo; v += stride) global[gid[v]] = local[v];
+}
+__global__ void k_sd_from_global(int64_t nvo, const int64_t* __restrict__ gid, const double* __restrict__ global, double* __restrict__ local) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; v < nvo; v += stride) local[v] = global[gid[v]];
+}
+
 static bool g_sd_timing = false, g_sd_sync = false;
 static double g_sd_t[4];
 
 struct saddle_ws {
     dbuf<double> partials, sums, dinv, t, r, w, mdinv, md, mt, hdev, cd, gin, gout;
+    dbuf<double> pg_in, pg_out;      // the replicated (global) pressure right-hand side / correction on several ranks
     double vel_lmax = 0.0;   // largest eigenvalue of D^-1 A on the velocity block (Chebyshev sweeps)
     dbuf<const double*> vptr, zptr;
     dbuf<double> hs;            // H | cs | sn | gamma | y | ctl  (device-side Arnoldi state)
@@ -1029,8 +1042,34 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
     fs_krylov_stats ks;
     const bool transient = o->inv_dt > 0.0 && Kp;
     if (transient) {
-        if (Kp_amg) {          // one V-cycle: a fixed linear operator, spectrally equivalent to Kp^-1
+        if (Kp_amg && fs_rt().n_ranks == 1) {          // one V-cycle: a fixed linear operator, spectrally equivalent to Kp^-1
             FS_CHECK(fs_amg_apply_dev(Kp_amg, W.rp.d.p, W.p1.d.p, s));
+        } else if (Kp_amg && fs_amg_rows(Kp_amg) != nv) {
+            // Several GPUs, hierarchy of the GLOBAL pressure Laplacian held by every rank: the pressure space is small
+            // (85 184 unknowns at configs[4]), so the Schur-complement solve is replicated - the owned residuals are
+            // summed into the global vector (one all-reduce, 0.7 MB), every rank applies the same V-cycle and keeps
+            // its own entries.  Same operator, hence same FGMRES iteration counts, as on one GPU; a block-Jacobi
+            // K_p^-1 (rank-local hierarchies) loses the smooth pressure modes that dominate at small dt and
+            // FGMRES(60) stagnates at 2e-5 with 2 and 4 ranks.
+            const int64_t ng = fs_amg_rows(Kp_amg);
+            FS_REQUIRE(sp->mesh->gid.p, "fs_saddle_solve: the mesh carries no global vertex ids (fs_mesh_set_global_ids)");
+            if (W.pg_in.n != ng) { FS_CHECK(W.pg_in.alloc(ng)); FS_CHECK(W.pg_out.alloc(ng)); }
+            FS_CHECK(W.pg_in.zero(s));
+            hipLaunchKernelGGL(k_sd_to_global, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->mesh->gid.p, W.rp.d.p, W.pg_in.p);
+            FS_CHECK(fs_comm_allreduce_dev(W.pg_in.p, (int)ng, s));
+            FS_CHECK(fs_amg_apply_dev(Kp_amg, W.pg_in.p, W.pg_out.p, s));
+            hipLaunchKernelGGL(k_sd_from_global, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, sp->mesh->gid.p, W.pg_out.p, W.p1.d.p);
+        } else if (Kp_amg) {
+            // several GPUs with a hierarchy of this rank's diagonal block only: K_p^-1 as a global solve - CG on the
+            // distributed operator with the local V-cycles as (additive Schwarz) preconditioner, to 1e-2; FGMRES
+            // tolerates the varying operator
+            fs_krylov_opts ao = ko;
+            ao.rtol = o->inner_rtol > 0.0 ? o->inner_rtol : 1e-2;
+            ao.max_iter = 60;
+            ao.norm_type = FS_NORM_UNPRECONDITIONED;
+            const int rc_in = fs_amg_solve(Kp_amg, &W.rp, &W.p1, &ao, &ks);
+            if (rc_in != FS_OK && rc_in != FS_ERR_NUMERIC) return rc_in;
+            *inner_its += ks.iterations;
         } else {
             FS_CHECK(fs_krylov_solve(Kp, &W.rp, &W.p1, &ko, &ks));
             *inner_its += ks.iterations;

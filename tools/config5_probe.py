@@ -11,7 +11,11 @@ from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 43
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-B.init(0)
+from fenicssolver_amd import parallel
+if parallel.world()[1] > 1:
+    parallel.ensure_comm()      # started under torch.distributed.run (FS_DEVICE / FS_COMM_TRANSPORT=shm: ranks share a GPU)
+else:
+    B.init(0)
 t0 = time.perf_counter()
 mesh = UnitCubeMesh(n, n, n)
 bcs = OrderedDict()
@@ -32,7 +36,7 @@ if len(sys.argv) > 4:
 s['report_settings'] = {"logging_level": logging.INFO, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
 solver = CoupledNavierStokesSolver(s)
 t1 = time.perf_counter()
-print('mesh+solver construction %.2f s; cells %d' % (t1 - t0, mesh.num_cells()), flush=True)
+if parallel.world()[0] == 0: print('mesh+solver construction %.2f s; cells %d' % (t1 - t0, mesh.num_cells()), flush=True)
 w = solver.solve()
 B.synchronize()
 t2 = time.perf_counter()
