@@ -688,20 +688,26 @@ class SolverBase():
             return self._navier_stokes_newton(F, u_current, Dirichlet_bcs)
         if not isinstance(F, forms.ScalarForm):
             raise SolverError('nonlinear solves are built for scalar transport and Navier-Stokes only')
-        if F.space.device() is not None and F.space.localizer() is not None:
-            raise SolverError('nonlinear solves are single-GPU for now')
+        from . import parallel
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         newton = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
         rtol = float(newton.get('relative_tolerance', 1e-9))
         atol = float(newton.get('absolute_tolerance', 1e-10))
         max_it = int(newton.get('maximum_iterations', 50))
         V = F.space.device()
+        loc = F.space.localizer()          # several GPUs: the iterate stays global on the host, rows are local
         n = V.n_owned
-        dofs, vals = self._bc_arrays(Dirichlet_bcs)
+        gdofs, gvals = self._bc_arrays(Dirichlet_bcs)
         T = u_current.vector().array().copy()
-        if dofs.size:
-            T[dofs] = vals                                  # the first iterate carries the boundary values
+        if gdofs.size:
+            T[gdofs] = gvals                                # the first iterate carries the boundary values
+        dofs = gdofs if loc is None else loc.dofs(gdofs, gvals)[0]
+        own = dofs[dofs < n]
         ext = self.mesh.facets()[self.mesh.exterior_facets()]
+        if loc is None:
+            ext_dev, ext_mask = ext, slice(None)
+        else:
+            ext_dev, ext_mask = loc.facets(ext)
         krtol, kmax, pc = self._krylov_options()
         r0 = None
         self.newton_iterations = 0
@@ -713,14 +719,17 @@ class SolverBase():
             if F.radiation is not None:
                 m_, T_amb = F.radiation
                 Tf = T[ext.astype(np.int64)].mean(axis=1)
-                backend.assemble_facet_vector(V, b, ext, m_ * (T_amb ** 4 - Tf ** 4))
-            Tdev = backend.DeviceVector(V.n_local, np.concatenate([T, np.zeros(V.n_local - n)]))
+                backend.assemble_facet_vector(V, b, ext_dev, (m_ * (T_amb ** 4 - Tf ** 4))[ext_mask])
+            Tdev = backend.DeviceVector(V.n_local, T if loc is None else loc.nodes(T))
             r = backend.DeviceVector(n)
             A.spmv(Tdev, r)
             r.axpy(-1.0, b)                                         # r = A(T) T - b(T)
-            if dofs.size:
-                backend.set_dirichlet_values(r, dofs, 0.0)          # residual of constrained rows is zero
-            rnorm = float(np.sqrt(r.dot(r)))
+            if own.size:
+                backend.set_dirichlet_values(r, own, 0.0)           # residual of constrained rows is zero
+            rn2 = float(r.dot(r))
+            if loc is not None and parallel.world()[1] > 1:
+                rn2 = float(backend.comm_allreduce_sum([rn2])[0])
+            rnorm = float(np.sqrt(rn2))
             if r0 is None:
                 r0 = rnorm
             if sp.get('monitor_convergence'):
@@ -731,19 +740,22 @@ class SolverBase():
             if it == max_it:
                 raise SolverError('Newton solver did not converge in {} iterations (residual {:.3e})'.format(max_it, rnorm))
             if F.radiation is not None:
-                A.add_facet_mass(ext, 4.0 * m_ * Tf ** 3)            # d/dT of  + m T^4 q ds
+                A.add_facet_mass(ext_dev, (4.0 * m_ * Tf ** 3)[ext_mask])   # d/dT of  + m T^4 q ds
             rhs = backend.DeviceVector(n)
             rhs.axpy(-1.0, r)
             if dofs.size:
                 A.apply_dirichlet(rhs, dofs, 0.0, symmetric=True)   # delta = 0 on the Dirichlet boundary
-            delta = backend.DeviceVector(n)
+            delta = backend.DeviceVector(V.n_local)
             stats = backend.krylov_solve(A, rhs, delta, rtol=min(krtol, 1e-10), max_iter=kmax, precond=pc,
                                          method="cg" if F.symmetric else "bicgstab",
                                          norm="preconditioned" if (F.symmetric and pc == "jacobi") else "unpreconditioned")
             self.last_solve_stats = stats
             if stats['converged'] != 1:
                 raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))
-            T = T + delta.get()
+            d = delta.get()[:n]
+            if loc is not None:
+                d = parallel.gather_owned(d, loc.owned_gids(), loc.n_global, 1)
+            T = T + d
             self.newton_iterations = it + 1
         u_current.vector().set_local(T)
         return u_current

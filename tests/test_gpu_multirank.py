@@ -59,11 +59,12 @@ def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
 
 
-@pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2)])
+@pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2), ("radiation", 2)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,
     FGMRES with reduced multi-dots, halo exchange of the iterate inside the preconditioner, Schur-complement solves on
-    the rank-local blocks (AMG hierarchy of the local pressure Laplacian), Newton residual norm reduced over the ranks."""
+    the replicated pressure space (every rank applies the V-cycle of the global pressure Laplacian), Newton residual norm
+    reduced over the ranks.  radiation: the scalar Newton loop (facet radiation terms + k(T)) on two ranks."""
     import test_gpu_parallel_api as T
     single = T.NS_CASES[case]().solve().vector().get_local()
     r = _run(world, case, tmp_path)

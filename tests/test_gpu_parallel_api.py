@@ -131,8 +131,34 @@ def _channel_case():
     return CoupledNavierStokesSolver(s)
 
 
-# Navier-Stokes cases: solved through the saddle-point path, not through _device_solve (no captured (A, b) test)
-NS_CASES = {"cavity": _cavity_case, "channel": _channel_case}
+def _radiation_case():
+    """examples/test_heat_transfer.py test_radiation(): radiation to the ambient on every exterior facet and a
+    temperature-dependent conductivity, Newton through solve_nonlinear_problem."""
+    from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 4, 4, 8)
+    Q = FunctionSpace(m, "CG", 1)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+         'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+         'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.6},
+         'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 0.3},
+                             'reference_values': {'temperature': 300},
+                             'solver_parameters': {'krylov_relative_tolerance': 1e-13}},
+         'radiation_settings': {'ambient_temperature': 280.0, 'emissivity': 0.9},
+         'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(s)
+    solver.material['conductivity'] = lambda T: 0.6 * (1.0 + 0.002 * (T - 300.0))
+    solver.material['emissivity'] = 0.9
+    return solver
+
+
+# cases that do not go through _device_solve (Newton loops, the saddle-point path): no captured (A, b) test
+NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case}
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          "heat_p2": _heat_p2_case}
