@@ -164,6 +164,11 @@ struct fs_space_s {
     dbuf<int32_t> sell_col;       // [sell_entries]
     // DIA slices: all 64 rows share one sorted list of (col - row) offsets, so the SpMV needs no
     // per-entry column index: dia_ptr[s] >= 0 indexes dia_off, -1 = SELL slice
+    // processing order of the slices in the SpMV (empty = identity).  CG2 spaces number their edge nodes class by class,
+    // so a contiguous eighth of the rows (what one XCD sweeps) is one edge class over the WHOLE mesh and every XCD
+    // pulls all of x through its L2; ordered by the position of the slice's first node instead, an XCD sweeps one
+    // slab of the mesh for all classes and x is fetched once
+    dbuf<int32_t> slice_order;    // [n_slices]
     dbuf<int32_t> dia_ptr;        // [n_slices]
     dbuf<int32_t> dia_off;        // [sum of offsets over DIA slices]
     dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned (vector spaces)

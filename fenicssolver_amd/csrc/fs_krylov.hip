@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                                                         const double* __restrict__ x, double* __restrict__ y,
                                                         const double* __restrict__ rvec,
                                                         double* __restrict__ partials,
-                                                        const int* __restrict__ status) {
+                                                        const int* __restrict__ status,
+                                                        const int32_t* __restrict__ order) {
     if (DOTS) {
         if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
     }
@@ -103,8 +104,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
     const int64_t n_chunks = (n_slices + 3) >> 2;
     const int32_t cmax = (int32_t)(n_cols - 1);
     for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
-        const int64_t s = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
-        if (s >= n_slices) continue;
+        const int64_t q = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
+        if (q >= n_slices) continue;
+        const int64_t s = order ? __builtin_amdgcn_readfirstlane(order[q]) : q;      // fs_space_s::slice_order
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int32_t dp = dia_ptr[s];              // wave-uniform: >= 0 selects the DIA form
@@ -726,7 +728,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const double* mat_val = val_override ? val_override : A->val.p;
     fs_space_s* sp = A->space;
     const int grid = spmv_grid(sp->n_slices);
-#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, sp->slice_order.p
     if (A->bs == 1) {
         const bool nt = spmv_nontemporal(sp, 1);
         switch (spmv_unroll_for(sp->n_slices)) {
@@ -766,11 +768,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
                                                               const int32_t* __restrict__ dia_ptr,
                                                               const int32_t* __restrict__ dia_off,
                                                               const double* __restrict__ val, int64_t plane,
-                                                              const double* __restrict__ x, double* __restrict__ y) {
+                                                              const double* __restrict__ x, double* __restrict__ y,
+                                                              const int32_t* __restrict__ order) {
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x >> 6;          // block-row of this wave
     const int64_t cmax = n_cols - 1;
-    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
+    // an XCD sweeps a contiguous eighth of the (spatially ordered) slices: x is fetched into one L2, once
+    for (chunk_iter it = xcd_chunks(n_slices); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = order ? order[it.cur] : it.cur;
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int32_t dp = dia_ptr[s];
@@ -815,13 +820,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     if (A->bs == 4 && !getenv("FS_SPMV4_GENERIC")) {
         fs_space_s* sp = A->space;
-        const int grid = (int)(sp->n_slices < 65535 ? sp->n_slices : 65535);
+        const int grid = (int)((std::min<int64_t>(sp->n_slices, 8192) + 7) & ~(int64_t)7);     // multiple of 8: the XCD mapping
         if (spmv_nontemporal(sp, 4))
             hipLaunchKernelGGL(k_sell_spmv4_rows<true>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
-                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, sp->slice_order.p);
         else
             hipLaunchKernelGGL(k_sell_spmv4_rows<false>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
-                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, sp->slice_order.p);
         return FS_OK;
     }
     launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, s);

@@ -414,6 +414,25 @@ __global__ void k_compact_tri_cells(const int32_t* __restrict__ cells4, int64_t 
     }
 }
 
+// spatial key of a slice = the vertex its first row sits at (an edge node: its endpoint of smaller id)
+__global__ void k_slice_keys(int64_t n_slices, int64_t nvo, int64_t n_rows, const int32_t* __restrict__ edges, uint32_t* __restrict__ key,
+                             int32_t* __restrict__ idx) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < n_slices; s += stride) {
+        const int64_t r = s * FS_SLICE;
+        uint32_t k;
+        if (r < nvo) k = (uint32_t)r;
+        else {
+            const int64_t j = r - nvo;
+            const int32_t a = edges[2 * j], b = edges[2 * j + 1];
+            k = (uint32_t)(a < b ? a : b);
+        }
+        key[s] = k;
+        idx[s] = (int32_t)s;
+    }
+}
+
 // ---- API -----------------------------------------------------------------------------------
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
     FS_CHECK(fs_require_init());
@@ -665,6 +684,23 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
     FS_SP(sp->sell_col.alloc(sp->sell_entries));
     hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, sp->n_nodes_local, n_slices, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, sp->sell_col.p);
     FS_SP_HIP(hipGetLastError());
+    if (degree == 2 && !getenv("FS_NO_SLICE_ORDER")) {
+        // processing order of the SpMV: slices sorted by the position of their first node (stable)
+        dbuf<uint32_t> k_in, k_out;
+        dbuf<int32_t> v_in;
+        FS_SP(k_in.alloc(n_slices));
+        FS_SP(k_out.alloc(n_slices));
+        FS_SP(v_in.alloc(n_slices));
+        FS_SP(sp->slice_order.alloc(n_slices));
+        hipLaunchKernelGGL(k_slice_keys, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, mesh->n_owned, n_rows, sp->edges.p, k_in.p, v_in.p);
+        FS_SP_HIP(hipGetLastError());
+        size_t tbs = 0;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tbs, k_in.p, k_out.p, v_in.p, sp->slice_order.p, (int)n_slices, 0, 32, s));
+        dbuf<char> tmps;
+        FS_SP(tmps.alloc((int64_t)tbs + 16));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(tmps.p, tbs, k_in.p, k_out.p, v_in.p, sp->slice_order.p, (int)n_slices, 0, 32, s));
+        FS_SP_HIP(hipStreamSynchronize(s));
+    }
     if (ncomp == 1 && sp->max_row <= 255) {
         // 5a. scalar spaces: row-gather incidence tables (deterministic, atomic-free assembly)
         const int64_t n_inc = (int64_t)nd * nc;
