@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double supg_pe, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double supg_pe, double* __restrict__ val,
+    const int32_t* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -169,8 +170,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
     // vertices, so their coordinates stay in that XCD's L2 instead of being re-fetched over the fabric
     const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
     for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
-        const int64_t s = it.cur * wpb + wave;
-        if (s >= n_slices) continue;
+        const int64_t q0 = it.cur * wpb + wave;
+        if (q0 >= n_slices) continue;
+        const int64_t s = order ? order[q0] : q0;      // spatial order of the slices (fs_space_s::slice_order)
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t ibase = inc_slice_ptr[s];
@@ -284,14 +286,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
     const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
     for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
-        const int64_t s = it.cur * wpb + wave;
-        if (s >= n_slices) continue;
+        const int64_t q = it.cur * wpb + wave;
+        if (q >= n_slices) continue;
+        const int64_t s = order ? order[q] : q;      // spatial order of the slices (fs_space_s::slice_order)
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t ibase = inc_slice_ptr[s];
@@ -935,9 +938,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (add)
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);
         else
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);
     } else if (A->bs == 1 && sp->inc_cell.p) {
         // row-gather path: every SELL entry (padding included) is written exactly once, no memset
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
@@ -954,9 +957,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
         else
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
     } else if (A->bs == 1) {
         FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
         FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
