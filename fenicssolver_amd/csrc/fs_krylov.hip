@@ -768,14 +768,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
                                                               const int32_t* __restrict__ dia_ptr,
                                                               const int32_t* __restrict__ dia_off,
                                                               const double* __restrict__ val, int64_t plane,
-                                                              const double* __restrict__ x, double* __restrict__ y,
-                                                              const int32_t* __restrict__ order) {
+                                                              const double* __restrict__ x, double* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x >> 6;          // block-row of this wave
     const int64_t cmax = n_cols - 1;
-    // an XCD sweeps a contiguous eighth of the (spatially ordered) slices: x is fetched into one L2, once
-    for (chunk_iter it = xcd_chunks(n_slices); it.cur < it.end; it.cur += it.step) {
-        const int64_t s = order ? order[it.cur] : it.cur;
+    // Slices are dealt round-robin (consecutive slices to different XCDs).  Measured on the configs[4] matrix: 443-490 us,
+    // with or without the spatial order of the slices; 567 us for XCD-contiguous eighths of the ordered slices and
+    // 878 us for contiguous eighths of the rows (vertex rows are 65 blocks wide, edge rows 20-30: unbalanced)
+    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int32_t dp = dia_ptr[s];
@@ -820,13 +820,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     if (A->bs == 4 && !getenv("FS_SPMV4_GENERIC")) {
         fs_space_s* sp = A->space;
-        const int grid = (int)((std::min<int64_t>(sp->n_slices, 8192) + 7) & ~(int64_t)7);     // multiple of 8: the XCD mapping
+        // one slice per workgroup while the grid allows it (dynamic balance)
+        const int grid = (int)std::min<int64_t>(sp->n_slices, 65535);
         if (spmv_nontemporal(sp, 4))
             hipLaunchKernelGGL(k_sell_spmv4_rows<true>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
-                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, sp->slice_order.p);
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
         else
             hipLaunchKernelGGL(k_sell_spmv4_rows<false>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices,
-                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, sp->slice_order.p);
+                               sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y);
         return FS_OK;
     }
     launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, s);
