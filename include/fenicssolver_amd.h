@@ -94,8 +94,11 @@ int fs_mesh_destroy(fs_mesh_t mesh);
 
 #define FS_FAMILY_CG 0
 /* degree 1 with ncomp = 1 (scalar) or 3 (vector, node-interleaved dofs as DOLFIN's
- * VectorFunctionSpace lays them out); degree 2 scalar (single GPU): dofs = the vertices, then one
- * node per edge, edges numbered lexicographically by their ascending vertex pair. */
+ * VectorFunctionSpace lays them out); degree 2 with ncomp = 1 (scalar) or 4 (Taylor-Hood block u_x,u_y,u_z,p):
+ * nodes = the vertices, then one node per edge, edges numbered lexicographically by their ascending vertex
+ * pair - grouped by index difference first on structured meshes.  With ghost vertices
+ * (n_owned < nv) the nodes are [owned vertices | owned edges | ghost vertices | ghost edges]; an edge belongs to
+ * the rank owning its endpoint of smaller global id (fs_mesh_set_global_ids). */
 int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
 int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
                   int64_t* sell_entries);
@@ -283,7 +286,9 @@ typedef struct fs_amg_opts {
 /* Build the hierarchy for the assembled (Dirichlet-eliminated, SPD) matrix.  nullspace: host array
  * [n_nullspace][n_dofs] of near-null-space vectors (the rigid-body modes of build_nullspace(),
  * SolverBase.py:674-706), or NULL = one constant per component.  The matrix must outlive the
- * hierarchy and keep its values.  Single GPU. */
+ * hierarchy and keep its values.  On a space with ghost nodes the hierarchy is built on this rank's diagonal
+ * block (ghost columns dropped): fs_amg_solve is then CG on the distributed operator with the rank-local
+ * V-cycles as non-overlapping additive Schwarz preconditioner. */
 int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullspace, const fs_amg_opts* opts, fs_amg_t* out);
 int fs_amg_destroy(fs_amg_t amg);
 int fs_amg_info(fs_amg_t amg, int* n_levels, double* operator_complexity, double* grid_complexity, double* setup_ms);
@@ -336,7 +341,12 @@ typedef struct fs_saddle_opts {
  * right-preconditioned by [A 0; D S]^-1 with the Cahouet-Chabard Schur complement
  * S^-1 = rho^2 ((1/dt) Kp^-1 + nu Mp^-1).  Kp: CG1 stiffness matrix (coefficient 1) with the pressure
  * Dirichlet dofs eliminated, may be NULL when inv_dt = 0; Kp_amg: optional hierarchy of Kp (fs_amg_setup) - one
- * V-cycle then stands in for Kp^-1 instead of an inner CG solve; Mp: CG1 mass matrix. */
+ * V-cycle then stands in for Kp^-1 instead of an inner CG solve; Mp: CG1 mass matrix.
+ * Several GPUs (J, Kp, Mp on decomposed spaces): the multi-dot sums are all-reduced, the halo of the preconditioned
+ * vector is exchanged twice per iteration, M_p^-1 acts on the rank-local block; Kp_amg is either the hierarchy of the
+ * GLOBAL pressure Laplacian held by every rank (its row count differs from the owned vertices: the pressure
+ * residual is all-reduced into the global vector and the V-cycle replicated - same operator as on one GPU) or a
+ * rank-local hierarchy (then an inner additive-Schwarz CG solve to inner_rtol). */
 int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
                     const fs_saddle_opts* opts, fs_krylov_stats* stats);
 
