@@ -269,19 +269,26 @@ class ScalarTransportSolver(SolverBase):
         if self.convective_velocity:
             ads = self.settings.get('advection_settings') or {'stabilization_method': None}
             method = ads.get('stabilization_method')
-            supg_pe = 0.0
-            if method == 'SPUG':      # the reference's spelling; its SPUG_method == 2 variant (:259-270)
+            supg_pe, ip_coef = 0.0, 0.0
+            if method == 'IP':        # interior penalty on the jump of the normal gradient (:312-315)
+                if self.function_space.degree() != 1 or self.dimension != 3:
+                    raise SolverError("IP stabilisation is built for P1 spaces on tetrahedral meshes")
+                cap = self.capacity()
+                if not isinstance(cap, numbers.Number):
+                    raise SolverError("IP stabilisation needs a constant capacity")
+                ip_coef = float(ads['alpha']) * float(cap)
+            elif method == 'SPUG':      # the reference's spelling; its SPUG_method == 2 variant (:259-270)
                 if self.function_space.degree() != 1:
                     raise SolverError("SUPG stabilisation is built for P1 spaces")
                 supg_pe = float(ads['Pe'])
                 if not supg_pe > 0.0:
                     raise SolverError("advection_settings['Pe'] must be positive")
             elif method:
-                raise SolverError("advection stabilization '{}' is not built (ScalarTransportSolver.py:312-316 needs "
-                                  "interior-facet integrals); 'SPUG' and the plain Galerkin term are".format(method))
+                raise SolverError("advection stabilization '{}' is not known ('SPUG', 'IP' or None)".format(method))
             velocity = self.get_convective_velocity_function(self.convective_velocity)
         F = forms.ScalarForm(self.function_space)
         F.supg_pe = supg_pe if self.convective_velocity else 0.0
+        F.ip_coefficient = ip_coef if self.convective_velocity else 0.0
         F.conductivity = self._volume_coefficient(conductivity, 'conductivity')
         from inspect import isfunction
         kraw = self.material.get('conductivity', self.material.get('thermal_conductivity'))

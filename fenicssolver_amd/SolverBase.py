@@ -580,7 +580,8 @@ class SolverBase():
         """(A, b) on the device for a ScalarForm / ElasticityForm, Dirichlet conditions applied
         (dolfin.assemble_system / assemble + bc.apply; SolverBase.py:594-602, 644)."""
         from . import backend
-        V = F.space.device()
+        ip = getattr(F, 'ip_coefficient', 0.0)
+        V = F.space.device(facet_coupling=True) if ip else F.space.device()
         loc = F.space.localizer()
         L_ = (lambda spec: spec) if loc is None else loc.spec
         A = backend.DeviceMatrix(V)
@@ -596,6 +597,8 @@ class SolverBase():
                 raise SolverError('SUPG stabilisation is single-GPU for now')
             A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
                        supg_pe=pe)
+            if ip:          # fully implicit, like the advection term it stabilises (ScalarTransportSolver.py:305-315)
+                A.add_interior_penalty(self.mesh.interior_facet_cells()[0], ip)
             for r in F.robin:
                 tri, _ = self._device_facets(F, r.marker_id)
                 A.add_facet_mass(tri, r.h)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "fs_mesh_get": (C.c_int, [_H, c_f64p, c_i32p, c_i64p]),
     "fs_mesh_destroy": (C.c_int, [_H]),
     "fs_space_create": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "fs_space_create_coupled": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, c_i64, c_i32p, C.POINTER(_H)]),
     "fs_space_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p, c_i64p]),
     "fs_space_format_info": (C.c_int, [_H, c_i64p, c_i64p, c_i64p]),
     "fs_space_get_edges": (C.c_int, [_H, c_i64p, c_i32p]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "fs_assemble_vector": (C.c_int, [_H, C.POINTER(fs_linear_form), _H, C.c_int]),
     "fs_assemble_facet_vector": (C.c_int, [_H, c_i64, c_i32p, c_f64p, _H]),
     "fs_assemble_facet_matrix": (C.c_int, [_H, c_i64, c_i32p, c_f64p]),
+    "fs_assemble_interior_penalty": (C.c_int, [_H, c_i64, c_i32p, C.c_double]),
     "fs_apply_dirichlet": (C.c_int, [_H, _H, c_i64, c_i32p, c_f64p, C.c_int]),
     "fs_spmv": (C.c_int, [_H, _H, _H]),
     "fs_krylov_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),

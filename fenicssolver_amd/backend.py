@@ -114,11 +114,18 @@ class DeviceSpace(_Handle):
     """CG1 (scalar or 3-vector) space + sparsity (FunctionSpace, SolverBase.py:260-275)."""
     _destroy = "fs_space_destroy"
 
-    def __init__(self, mesh, ncomp=1, degree=1):
+    def __init__(self, mesh, ncomp=1, degree=1, coupled_pairs=None):
+        """coupled_pairs [n,2]: extra node couplings of the sparsity pattern (interior-facet integrals)."""
         super().__init__()
         self.mesh = mesh
         self.ncomp = int(ncomp)
-        L.check(L.load().fs_space_create(mesh.h, 0, int(degree), int(ncomp), C.byref(self.h)), "fs_space_create")
+        if coupled_pairs is None:
+            L.check(L.load().fs_space_create(mesh.h, 0, int(degree), int(ncomp), C.byref(self.h)), "fs_space_create")
+        else:
+            pairs = L.i32(coupled_pairs).reshape(-1, 2)
+            L.check(L.load().fs_space_create_coupled(mesh.h, 0, int(degree), int(ncomp), pairs.shape[0], L.p_i32(pairs),
+                                                     C.byref(self.h)), "fs_space_create_coupled")
+        self.facet_coupled = coupled_pairs is not None
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.load().fs_space_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "fs_space_info")
         self.n_local, self.n_owned, self.nnz, self.sell_entries = a.value, b.value, c.value, d.value
@@ -251,6 +258,12 @@ class DeviceMatrix(_Handle):
         h = L.f64(np.broadcast_to(h, (tri.shape[0],)))
         L.check(L.load().fs_assemble_facet_matrix(self.h, tri.shape[0], L.p_i32(tri), L.p_f64(h)),
                 "fs_assemble_facet_matrix")
+
+    def add_interior_penalty(self, facet_cells, coefficient):
+        """+= coefficient * avg(h)^2 jump(grad u, n) jump(grad v, n) dS over the interior facets [nf,2] (cell pairs)."""
+        fc = L.i32(facet_cells).reshape(-1, 2)
+        L.check(L.load().fs_assemble_interior_penalty(self.h, fc.shape[0], L.p_i32(fc), float(coefficient)),
+                "fs_assemble_interior_penalty")
 
     def axpy(self, a, X):
         L.check(L.load().fs_matrix_axpy(self.h, float(a), X.h), "fs_matrix_axpy")

@@ -692,6 +692,79 @@ __global__ void k_facet_matrix(const double* __restrict__ xyz4, const int32_t* _
     }
 }
 
+// ---- interior penalty (ScalarTransportSolver.py:312-315) ----------------------------------------------------------
+//   + alpha avg(h)^2 jump(grad T, n) jump(grad q, n) capacity dS        over the interior facets, h = 2 circumradius.
+// CG1: the gradients are constant per cell, so a facet F = K+ n K- contributes  w J_i J_j  to the five nodes of the two
+// cells, J_i = grad phi_i^+ . n^+ + grad phi_i^- . n^-,  w = coef avg(h)^2 |F|.  The rows couple the two vertices
+// opposite the facet, which share no cell: the space must have been created with those pairs
+// (fs_space_create_coupled).  One thread per (facet, row node); fp64 atomics.
+__device__ __forceinline__ double tet_circum_h(const double* __restrict__ xyz4, const int32_t (&v)[4], double adet) {
+    double x0[3], x1[3], x2[3], x3[3];
+    load_vertex(xyz4, v[0], x0);
+    load_vertex(xyz4, v[1], x1);
+    load_vertex(xyz4, v[2], x2);
+    load_vertex(xyz4, v[3], x3);
+    auto dist = [](const double (&p)[3], const double (&q)[3]) {
+        return sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
+    };
+    const double aA = dist(x0, x1) * dist(x2, x3), bB = dist(x0, x2) * dist(x1, x3), cC = dist(x0, x3) * dist(x1, x2);
+    const double prod = (aA + bB + cC) * (aA + bB - cC) * (aA - bB + cC) * (-aA + bB + cC);
+    return 2.0 * sqrt(prod > 0.0 ? prod : 0.0) / (4.0 * adet);
+}
+__global__ void k_interior_penalty(int64_t nf, const int32_t* __restrict__ facet_cells, const int32_t* __restrict__ cells,
+                                   const double* __restrict__ xyz4, double coef, int64_t n_rows,
+                                   const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                   double* __restrict__ val, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 5; t += stride) {
+        const int64_t f = t / 5;
+        const int a = (int)(t - f * 5);
+        const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
+        const int4 p = reinterpret_cast<const int4*>(cells)[c0], q = reinterpret_cast<const int4*>(cells)[c1];
+        const int32_t v0[4] = {p.x, p.y, p.z, p.w}, v1[4] = {q.x, q.y, q.z, q.w};
+        int o0 = -1, o1 = -1;          // local index of the vertex opposite the facet in either cell
+        for (int i = 0; i < 4; ++i) {
+            bool in1 = false, in0 = false;
+            for (int j = 0; j < 4; ++j) { in1 |= v0[i] == v1[j]; in0 |= v1[i] == v0[j]; }
+            if (!in1) o0 = o0 < 0 ? i : 4;
+            if (!in0) o1 = o1 < 0 ? i : 4;
+        }
+        if (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3) { if (a == 0) atomicAdd(err, 1); continue; }   // not a shared facet
+        const tet_geom g0 = tet_geometry(xyz4, v0), g1 = tet_geometry(xyz4, v1);
+        // outward normal of K+ on the facet: -grad lambda_opposite / |grad lambda_opposite|;  |F| = 3 V |grad lambda_opp|
+        const double gn = sqrt(g0.g[o0][0] * g0.g[o0][0] + g0.g[o0][1] * g0.g[o0][1] + g0.g[o0][2] * g0.g[o0][2]);
+        const double n[3] = {-g0.g[o0][0] / gn, -g0.g[o0][1] / gn, -g0.g[o0][2] / gn};
+        const double area = 0.5 * g0.adet * gn;
+        const double hbar = 0.5 * (tet_circum_h(xyz4, v0, g0.adet) + tet_circum_h(xyz4, v1, g1.adet));
+        const double w = coef * hbar * hbar * area;
+        // the five nodes: the vertices of K+ and the vertex of K- opposite the facet
+        int32_t node[5];
+        double J[5];
+        for (int i = 0; i < 4; ++i) {
+            node[i] = v0[i];
+            double j = g0.g[i][0] * n[0] + g0.g[i][1] * n[1] + g0.g[i][2] * n[2];
+            for (int k = 0; k < 4; ++k)
+                if (v1[k] == v0[i]) j -= g1.g[k][0] * n[0] + g1.g[k][1] * n[1] + g1.g[k][2] * n[2];
+            J[i] = j;
+        }
+        node[4] = v1[o1];
+        J[4] = -(g1.g[o1][0] * n[0] + g1.g[o1][1] * n[1] + g1.g[o1][2] * n[2]);
+        const int32_t row = node[a];
+        if (row >= n_rows) continue;
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        for (int b = 0; b < 5; ++b) {
+            int k = -1;
+            for (int kk = 0; kk < width; ++kk)
+                if (sell_col[base + (int64_t)kk * FS_SLICE] == node[b]) { k = kk; break; }
+            if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], w * J[a] * J[b]);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- Dirichlet ------------------------------------------------------------------------------------
 // "later entries win" without a host pass: first the largest list index naming each dof ...
 __global__ void k_bc_last_index(const int32_t* __restrict__ dofs, int64_t n, int32_t* __restrict__ idx) {
@@ -1244,5 +1317,33 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
         hipLaunchKernelGGL(k_dirichlet_sell<4>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
+extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, const int32_t* facet_cells, double coefficient) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A && n_facets >= 0 && (n_facets == 0 || facet_cells), "fs_assemble_interior_penalty: bad arguments");
+    fs_space_s* sp = A->space;
+    if (A->bs != 1 || sp->degree != 1 || sp->mesh->tdim != 3) {
+        fs_set_error("fs_assemble_interior_penalty: built for scalar CG1 spaces on tetrahedra");
+        return FS_ERR_UNSUPPORTED;
+    }
+    if (n_facets == 0) return FS_OK;
+    for (int64_t i = 0; i < 2 * n_facets; ++i)
+        FS_REQUIRE(facet_cells[i] >= 0 && facet_cells[i] < sp->mesh->nc, "fs_assemble_interior_penalty: facet %lld names cell %d", (long long)(i / 2), facet_cells[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> dfc;
+    dbuf<int> d_err;
+    FS_CHECK(dfc.alloc(2 * n_facets));
+    FS_CHECK(d_err.alloc(1));
+    FS_CHECK(d_err.zero(s));
+    FS_CHECK(dfc.upload(facet_cells, 2 * n_facets, s));
+    hipLaunchKernelGGL(k_interior_penalty, dim3(fs_grid_for(5 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
+                       sp->mesh->cells.p, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
+    FS_KERNEL_CHECK();
+    int h_err = 0;
+    FS_CHECK(d_err.download(&h_err, 1, s));
+    FS_REQUIRE(h_err == 0, "fs_assemble_interior_penalty: %d entries are missing from the sparsity pattern or the cell pairs share no facet "
+               "(create the space with fs_space_create_coupled and the pairs of vertices opposite every interior facet)", h_err);
     return FS_OK;
 }

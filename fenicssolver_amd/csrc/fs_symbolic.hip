@@ -484,7 +484,33 @@ __global__ void k_slice_keys(int64_t n_slices, int64_t nvo, int64_t n_rows, cons
 }
 
 // ---- API -----------------------------------------------------------------------------------
+// extra node couplings (both directions) in the pattern: interior-facet integrals couple the two vertices opposite a facet
+__global__ void k_extra_pair_keys(const int32_t* __restrict__ pairs, int64_t n, int64_t n_rows, uint64_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int32_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        keys[2 * i] = a < n_rows ? (((uint64_t)(uint32_t)a << 32) | (uint32_t)b) : ~0ULL;
+        keys[2 * i + 1] = b < n_rows ? (((uint64_t)(uint32_t)b << 32) | (uint32_t)a) : ~0ULL;
+    }
+}
+
+static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_extra, const int32_t* extra_pairs,
+                             fs_space_t* out);
+
 extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out) {
+    return space_create_impl(mesh, family, degree, ncomp, 0, nullptr, out);
+}
+
+extern "C" int fs_space_create_coupled(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_pairs,
+                                       const int32_t* node_pairs, fs_space_t* out) {
+    FS_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || node_pairs), "fs_space_create_coupled: bad pair list");
+    FS_REQUIRE(degree == 1 || n_pairs == 0, "fs_space_create_coupled: extra couplings are built for CG1 spaces");
+    return space_create_impl(mesh, family, degree, ncomp, n_pairs, node_pairs, out);
+}
+
+static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_extra, const int32_t* extra_pairs,
+                             fs_space_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
     // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes
@@ -634,7 +660,13 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
 
     // 1. keys
     const int64_t n_pairs = (int64_t)nd * (nd - 1);
-    const int64_t n_keys = n_pairs * nc + n_rows;
+    const int64_t n_keys = n_pairs * nc + n_rows + 2 * n_extra;
+    for (int64_t i = 0; i < 2 * n_extra; ++i)
+        if (extra_pairs[i] < 0 || extra_pairs[i] >= sp->n_nodes_local) {
+            fs_set_error("fs_space_create_coupled: pair %lld names node %d", (long long)(i / 2), extra_pairs[i]);
+            delete sp;
+            return FS_ERR_INVALID;
+        }
     FS_REQUIRE(n_keys < (int64_t)INT32_MAX, "fs_space_create: %lld pattern keys exceed int32 (mesh too large for one GPU pass)", (long long)n_keys);
     int64_t nnz = 0;
     {
@@ -646,6 +678,14 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
         hipLaunchKernelGGL(k_pair_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, nd, nc, n_rows, keys_a.p);
         hipLaunchKernelGGL(k_diag_keys, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, keys_a.p + n_pairs * nc);
         FS_SP_HIP(hipGetLastError());
+        if (n_extra > 0) {
+            dbuf<int32_t> dp;
+            FS_SP(dp.alloc(2 * n_extra));
+            FS_SP(dp.upload(extra_pairs, 2 * n_extra, s));
+            hipLaunchKernelGGL(k_extra_pair_keys, dim3(fs_grid_for(n_extra)), dim3(FS_BLOCK), 0, s, dp.p, n_extra, n_rows, keys_a.p + n_pairs * nc + n_rows);
+            FS_SP_HIP(hipGetLastError());
+            FS_SP_HIP(hipStreamSynchronize(s));
+        }
         // 2. sort + unique
         int end_bit = 64;
         size_t tmp_bytes = 0;

@@ -214,6 +214,25 @@ class Mesh:
         """bool[num_facets]: facet belongs to exactly one cell."""
         return self._build_topology()["facet_count"] == 1
 
+    def interior_facet_cells(self):
+        """(cell pairs [nf,2], opposite-vertex pairs [nf,2]) of the facets shared by two cells (tetrahedra): what an
+        interior-facet (dS) integral runs over and the node couplings it adds to the sparsity pattern."""
+        if getattr(self, "_interior", None) is None:
+            if self._cells.shape[1] != 4:
+                raise SolverError("interior facets are built for tetrahedral meshes")
+            cf = self.cell_facets().astype(np.int64)                 # [nc,4], facet i opposite local vertex i
+            nc = cf.shape[0]
+            order = np.argsort(cf.ravel(), kind="stable")
+            fid = cf.ravel()[order]
+            dup = np.nonzero(fid[1:] == fid[:-1])[0]                  # consecutive equal ids = the two cells of a facet
+            a, b = order[dup], order[dup + 1]
+            ca, la, cb, lb = a // 4, a % 4, b // 4, b % 4
+            cells = self._cells.astype(np.int64)
+            self._interior = (np.stack([ca, cb], axis=1).astype(np.int32),
+                              np.stack([cells[ca, la], cells[cb, lb]], axis=1).astype(np.int32))
+            assert nc > 0
+        return self._interior
+
     def device(self):
         """The mesh resident in HBM (created on first use)."""
         if self._device is None:
@@ -647,15 +666,24 @@ class FunctionSpace:
     def tabulate_dof_coordinates(self):
         return np.repeat(self.node_coordinates(), self._ncomp, axis=0)
 
-    def device(self):
-        """Device space (sparsity + SELL slot table), built once per space."""
+    def device(self, facet_coupling=False):
+        """Device space (sparsity + SELL slot table), built once per space.  facet_coupling: the pattern also holds
+        the couplings of interior-facet integrals (the vertices opposite every interior facet); asking for it
+        rebuilds a space that was created without."""
         root = self.root()
+        if root._device is not None and facet_coupling and not getattr(root._device, "facet_coupled", False):
+            root._device = None
         if root._device is None:
             from . import backend, parallel
             if parallel.active():
+                if facet_coupling:
+                    raise SolverError("interior-facet (IP) terms are single-GPU for now")
                 root._device = self._make_parallel_device(root, backend, parallel)
             else:
-                root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree)
+                pairs = root._mesh.interior_facet_cells()[1] if facet_coupling else None
+                if facet_coupling and (root._degree != 1 or root._ncomp != 1):
+                    raise SolverError("interior-facet (IP) terms are built for scalar P1 spaces")
+                root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree, coupled_pairs=pairs)
         return root._device
 
     @staticmethod

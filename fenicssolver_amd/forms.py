@@ -78,6 +78,7 @@ class ScalarForm:
         self.robin = []               # [FacetRobin]
         self.point_sources = []       # [fem.PointSource]: b[dofs] += weights, before the Dirichlet rows
         self.supg_pe = 0.0            # > 0: every test function is q + tau (v . grad q) ("SPUG", :259-270)
+        self.ip_coefficient = 0.0     # alpha * capacity of + alpha avg(h)^2 jump(grad T,n) jump(grad q,n) capacity dS ("IP", :312-315)
         self.advection = None         # (velocity: 3-vector or array[n_cells,3], scale = capacity) -> non-symmetric
         self.symmetric = True
         # nonlinear terms (Newton): radiation  - m (Ta^4 - T^4) q ds over the whole boundary, m = emissivity*sigma
@@ -94,6 +95,7 @@ class ScalarForm:
             "capacity": self.capacity.describe() if self.capacity else None,
             "transient": self.transient, "dt": self.dt, "theta": self.theta,
             "supg_pe": self.supg_pe,
+            "ip_coefficient": self.ip_coefficient,
             "sources": [s.describe() for s in self.sources],
             "facet_loads": [(f.marker_id, _plain(f.g), f.origin) for f in self.facet_loads],
             "robin": [(r.marker_id, r.h, r.ambient) for r in self.robin],

@@ -100,8 +100,18 @@ int fs_mesh_destroy(fs_mesh_t mesh);
  * (n_owned < nv) the nodes are [owned vertices | owned edges | ghost vertices | ghost edges]; an edge belongs to
  * the rank owning its endpoint of smaller global id (fs_mesh_set_global_ids). */
 int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
+/* The same space with additional node couplings in the sparsity pattern (node_pairs [n_pairs][2], both directions are
+ * added): what DOLFIN's pattern builder does for a form with interior-facet (dS) integrals, where the two vertices
+ * opposite a facet couple although they share no cell (ScalarTransportSolver.py:312-315).  CG1 only. */
+int fs_space_create_coupled(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_pairs, const int32_t* node_pairs,
+                            fs_space_t* out);
 int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
                   int64_t* sell_entries);
+/* A += coefficient * avg(h)^2 jump(grad u, n) jump(grad v, n) dS over the listed interior facets, h = 2 circumradius
+ * (the 'IP' stabilisation of ScalarTransportSolver.py:312-315, coefficient = alpha * capacity).  facet_cells
+ * [n_facets][2]: the two local cells of every facet.  Scalar CG1 on tetrahedra, space from fs_space_create_coupled. */
+int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, const int32_t* facet_cells, double coefficient);
+
 /* Storage form chosen per 64-row slice: SELL (values + 4-B columns) or DIA (values only, the
  * 64 rows share one list of column offsets).  spmv_bytes = matrix bytes one SpMV streams. */
 int fs_space_format_info(fs_space_t space, int64_t* n_slices, int64_t* n_dia_slices, int64_t* spmv_matrix_bytes);

@@ -871,3 +871,41 @@ def mark_edges(coords, cells, inside, marker_id, markers=None, eps=3e-16):
         if all(inside(p, ob) for p in pts):
             markers[i] = marker_id
     return markers
+
+
+# ---- interior penalty (ScalarTransportSolver.py:312-315) --------------------------------------------------------
+def assemble_interior_penalty(coords, cells, coefficient):
+    """+ coefficient * avg(h)^2 * jump(grad T, n) * jump(grad q, n) dS over the interior facets, h = 2 * Circumradius,
+    jump(w, n) = w+ . n+ + w- . n-.  Written as UFL reads: per facet, per side, grad phi_i . n of the side; the facet
+    normal comes from the facet's own vertices (cross product, oriented away from the cell's opposite vertex) and
+    the facet area from the same cross product - independent of the barycentric-gradient shortcut of the device."""
+    import scipy.sparse as sp
+    co = np.asarray(coords, dtype=np.float64)
+    ce = np.asarray(cells, dtype=np.int64)
+    n = len(co)
+    _, g = p1_geometry(co, ce)
+    h = 2.0 * tet_circumradius(co, ce)
+    facets, cell_facets, cnt = facet_numbering(ce)
+    sides = {}
+    for c in range(len(ce)):
+        for i in range(4):
+            sides.setdefault(int(cell_facets[c, i]), []).append((c, i))
+    rows, cols, vals = [], [], []
+    for f, ss in sides.items():
+        if len(ss) != 2:
+            continue
+        tri = co[facets[f].astype(np.int64)]
+        nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+        area = 0.5 * np.linalg.norm(nrm)
+        nrm = nrm / np.linalg.norm(nrm)
+        J = {}
+        for c, i in ss:
+            outward = nrm if np.dot(nrm, tri[0] - co[ce[c, i]]) > 0 else -nrm     # away from the opposite vertex
+            for a in range(4):
+                J[int(ce[c, a])] = J.get(int(ce[c, a]), 0.0) + float(np.dot(g[c, a], outward))
+        w = coefficient * (0.5 * (h[ss[0][0]] + h[ss[1][0]])) ** 2 * area
+        nodes = list(J)
+        for a in nodes:
+            for b in nodes:
+                rows.append(a); cols.append(b); vals.append(w * J[a] * J[b])
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()

@@ -101,6 +101,12 @@ for name, tr in (("heat_convection_supg", False), ("heat_convection_supg_transie
     sol.material['conductivity'] = 0.6
     run(name, sol)
 
+# --- case 4c: interior-penalty stabilisation ("IP": an interior-facet integral added to the convection form) ------
+sol = ScalarTransportSolver.ScalarTransportSolver(heat_settings(
+    convective_velocity=Constant((0.005, -0.005, 0.0)), advection_settings={'stabilization_method': 'IP', 'alpha': 0.1}))
+sol.material['conductivity'] = 0.6
+run("heat_convection_ip", sol)
+
 # --- case 5: Dirichlet + Neumann(fixedGradient) + Robin --------------------------------------------------
 st = heat_settings()
 st['body_source'] = None

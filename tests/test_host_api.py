@@ -304,6 +304,9 @@ def test_scalar_form_recognition_heat_flux_htc_transient():
     F2, _ = s2.generate_form(0, None, None, s2.w_current, s2.w_prev)
     assert F2.describe()["advection"] == ((0.005, -0.005, 0.0), 4200000.0) and not F2.symmetric
     settings['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}
+    F3, _ = ScalarTransportSolver(settings).generate_form(0, None, None, solver.w_current, solver.w_prev)
+    assert F3.describe()["ip_coefficient"] == pytest.approx(0.1 * 4200000.0)      # alpha * capacity (:312-315)
+    settings['advection_settings'] = {'stabilization_method': 'G2'}
     with pytest.raises(SolverError):
         ScalarTransportSolver(settings).generate_form(0, None, None, solver.w_current, solver.w_prev)
 

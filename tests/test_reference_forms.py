@@ -426,3 +426,28 @@ def test_supg_is_the_plain_form_with_the_test_function_replaced(transient):
     assert F.supg_pe == 10.0 and F.describe()["supg_pe"] == 10.0
     assert_same_poly(scalar_form_poly(F), golden_poly({"terms": stripped}))
     assert bc_list(bcs) == golden_bcs(g) == []
+
+
+# ------------------------------------------------------------------ interior penalty ("IP")
+def test_ip_is_the_convection_form_plus_one_interior_facet_integral():
+    """advection_settings = {'stabilization_method': 'IP', 'alpha': 0.1}: the reference adds exactly one integral,
+        alpha avg(h)^2 inner(jump(grad T, n), jump(grad q, n)) capacity dS,   h = 2 Circumradius
+    (ScalarTransportSolver.py:312-315), to the unstabilised convection form.  forms.ScalarForm.ip_coefficient =
+    alpha * capacity stands for it (kernel: fs_assemble.hip k_interior_penalty; oracle: assemble_interior_penalty)."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    g = GOLD["heat_convection_ip"]["solves"][0]
+    facet = [t for t in g["terms"] if t["measure"] == "dS"]
+    rest = [t for t in g["terms"] if t["measure"] != "dS"]
+    assert len(facet) == 1 and facet[0]["sign"] == 1
+    assert facet[0]["integrand"] == ("mul(mul(mul(Constant(0.1), pow(avg(mul(2, Circumradius)), 2)), "
+                                     "inner(jump(grad(u_trial), n), jump(grad(v_test), n))), 4200000)")
+    plain = GOLD["heat_convection"]["solves"][0]
+    key = lambda ts: [(t["sign"], t["integrand"], t["measure"]) for t in ts]      # noqa: E731
+    assert key(rest) == key(plain["terms"])
+    kw = {"convective_velocity": Constant((0.005, -0.005, 0.0)), "advection_settings": {'stabilization_method': 'IP', 'alpha': 0.1}}
+    solver = ScalarTransportSolver(_heat_settings(**kw))
+    solver.material['conductivity'] = 0.6
+    F, bcs = _form_of(solver)
+    assert F.ip_coefficient == pytest.approx(0.1 * 4200000.0) and F.supg_pe == 0.0
+    assert_same_poly(scalar_form_poly(F), golden_poly({"terms": rest}))
