@@ -399,30 +399,6 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __r
 
 
 // ---- second pass: stored block e = sum of its element blocks (fixed order: deterministic, no atomics) -------------------
-__global__ void k_ns_pair_keys(const int32_t* __restrict__ slots, int64_t n, int32_t sentinel, int32_t* __restrict__ key,
-                               int32_t* __restrict__ src) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < n; t += stride) {          // slots[ab*nc + c] -> source index c*100 + ab
-        const int64_t nc = n / 100;
-        const int64_t ab = t / nc, c = t - ab * nc;
-        const int32_t sl = slots[t];
-        key[t] = sl >= 0 ? sl : sentinel;
-        src[t] = (int32_t)(c * 100 + ab);
-    }
-}
-__global__ void k_ns_lower_bound(const int32_t* __restrict__ keys, int64_t n, int64_t n_entries, int32_t* __restrict__ ptr) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; e <= n_entries; e += stride) {
-        int64_t lo = 0, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < (int32_t)e) lo = mid + 1; else hi = mid;
-        }
-        ptr[e] = (int32_t)lo;
-    }
-}
 __global__ void __launch_bounds__(FS_BLOCK) k_ns_gather(int64_t n_entries, const int32_t* __restrict__ ptr, const int32_t* __restrict__ src,
                                                         const double* __restrict__ ebuf, double* __restrict__ val, int64_t plane) {
     // 8 lanes per stored block: lane w reads the 16 bytes (values 2w, 2w+1) of every element block, so a block is one
@@ -444,28 +420,6 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ns_gather(int64_t n_entries, const
         val[(int64_t)(2 * w + 1) * plane + e] = a1;
     }
 }
-static int ns_build_gather_map(fs_space_s* sp, hipStream_t s) {
-    const int64_t n = sp->mesh->nc * 100;
-    FS_REQUIRE(n < (int64_t)INT32_MAX && sp->sell_entries < (int64_t)INT32_MAX - 1, "fs_assemble_navier_stokes: mesh too large for 32-bit element indices");
-    dbuf<int32_t> k_in, k_out, v_in;
-    FS_CHECK(k_in.alloc(n));
-    FS_CHECK(k_out.alloc(n));
-    FS_CHECK(v_in.alloc(n));
-    FS_CHECK(sp->gmap_src.alloc(n));
-    FS_CHECK(sp->gmap_ptr.alloc(sp->sell_entries + 1));
-    hipLaunchKernelGGL(k_ns_pair_keys, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, sp->slots.p, n, (int32_t)INT32_MAX, k_in.p, v_in.p);
-    FS_KERNEL_CHECK();
-    size_t tb = 0;
-    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
-    dbuf<char> tmp;
-    FS_CHECK(tmp.alloc((int64_t)tb + 16));
-    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
-    hipLaunchKernelGGL(k_ns_lower_bound, dim3(fs_grid_for(sp->sell_entries + 1)), dim3(FS_BLOCK), 0, s, k_out.p, n, sp->sell_entries, sp->gmap_ptr.p);
-    FS_KERNEL_CHECK();
-    FS_HIP(hipStreamSynchronize(s));
-    return FS_OK;
-}
-
 // unit diagonal on the dummy pressure slot of edge nodes
 __global__ void k_ns_dummy_rows(int64_t nv, int64_t n_nodes, const int64_t* __restrict__ slice_ptr,
                                 const int32_t* __restrict__ sell_col, double* __restrict__ val, int64_t plane) {
@@ -509,7 +463,7 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     static const char* mode_env = getenv("FS_NS_ASSEMBLE");
     const bool two_pass = !mode_env || (mode_env[0] != 'a' && mode_env[0] != 'p');
     if (two_pass) {
-        if (!sp->gmap_ptr.p) FS_CHECK(ns_build_gather_map(sp, s));
+        if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
         if (!sp->elem_buf.p) FS_CHECK(sp->elem_buf.alloc(m->nc * 1600));
     } else {
         FS_CHECK(J->val.zero(s));

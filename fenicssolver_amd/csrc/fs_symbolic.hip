@@ -414,6 +414,54 @@ __global__ void k_compact_tri_cells(const int32_t* __restrict__ cells4, int64_t 
     }
 }
 
+// ---- inverse of the slot table (two-pass / gather assembly of block spaces) -----------------------------------------
+__global__ void k_gmap_keys(const int32_t* __restrict__ slots, int64_t nc, int nd2, int32_t sentinel, int32_t* __restrict__ key,
+                            int32_t* __restrict__ src) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nc * nd2; t += stride) {          // slots[ab*nc + c] -> source index c*nd2 + ab
+        const int64_t ab = t / nc, c = t - ab * nc;
+        const int32_t sl = slots[t];
+        key[t] = sl >= 0 ? sl : sentinel;
+        src[t] = (int32_t)(c * nd2 + ab);
+    }
+}
+__global__ void k_gmap_lower_bound(const int32_t* __restrict__ keys, int64_t n, int64_t n_entries, int32_t* __restrict__ ptr) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e <= n_entries; e += stride) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < (int32_t)e) lo = mid + 1; else hi = mid;
+        }
+        ptr[e] = (int32_t)lo;
+    }
+}
+int fs_space_build_gather_map(fs_space_s* sp, hipStream_t s) {
+    FS_REQUIRE(sp->slots.p, "gather map: the space has no slot table");
+    const int nd2 = sp->ndof_cell * sp->ndof_cell;
+    const int64_t n = sp->mesh->nc * nd2;
+    FS_REQUIRE(n < (int64_t)INT32_MAX && sp->sell_entries < (int64_t)INT32_MAX - 1, "gather map: mesh too large for 32-bit element indices");
+    dbuf<int32_t> k_in, k_out, v_in;
+    FS_CHECK(k_in.alloc(n));
+    FS_CHECK(k_out.alloc(n));
+    FS_CHECK(v_in.alloc(n));
+    FS_CHECK(sp->gmap_src.alloc(n));
+    FS_CHECK(sp->gmap_ptr.alloc(sp->sell_entries + 1));
+    hipLaunchKernelGGL(k_gmap_keys, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, sp->slots.p, sp->mesh->nc, nd2, (int32_t)INT32_MAX, k_in.p, v_in.p);
+    FS_KERNEL_CHECK();
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
+    dbuf<char> tmp;
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sp->gmap_src.p, (int)n, 0, 32, s));
+    hipLaunchKernelGGL(k_gmap_lower_bound, dim3(fs_grid_for(sp->sell_entries + 1)), dim3(FS_BLOCK), 0, s, k_out.p, n, sp->sell_entries, sp->gmap_ptr.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 // bounding box of the vertices: one workgroup, grid-stride (set-up time)
 __global__ void __launch_bounds__(1024) k_bbox(const double* __restrict__ xyz4, int64_t nv, double* __restrict__ box) {
     __shared__ double lo[3][16], hi[3][16];

@@ -264,10 +264,10 @@ def test_convective_velocity_case(gpu):
     ref = fo.solve_direct(A.tocsr(), b)
     assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
     assert solver.last_solve_stats["converged"] == 1
-    # the interior-penalty variant is refused loudly, not silently dropped (SUPG is built, see below)
+    # an unknown stabilisation is refused loudly, not silently dropped ('SPUG' and 'IP' are built: below, test_gpu_ip.py)
     s2, _ = _box_heat_settings(3)
     s2['convective_velocity'] = Constant((0.005, -0.005, 0.0))
-    s2['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}     # interior-penalty: not built
+    s2['advection_settings'] = {'stabilization_method': 'G2'}
     from fenicssolver_amd.SolverBase import SolverError
     with pytest.raises(SolverError):
         ScalarTransportSolver(s2).solve()
