@@ -99,8 +99,10 @@ def roofline_of(st, V, traffic=None):
     ms = st["spmv_ms"]
     achieved = st["spmv_bytes"] / ms / 1e6 if ms > 0 else 0.0
     streamed = V.spmv_matrix_bytes + 24 * V.n_owned
-    return {"kernel": "k_sell_spmv<1,3,%d> (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; "
-                      "last template argument = entries per round, chosen by problem size)" % (4 if V.n_slices <= 32768 else 16),
+    nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
+    return {"kernel": "k_sell_spmv<1,3,%d,%s> (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; "
+                      "template arguments: block size, dot mode, entries per round and non-temporal matrix loads - the last two "
+                      "chosen by problem size)" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false"),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": st["spmv_bytes"], "avg_launch_ms": round(ms, 5),

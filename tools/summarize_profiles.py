@@ -130,10 +130,12 @@ def main():
         # fs_spmv_benchmark(fused), 0 = bare SpMV
         # the launch shape (last template argument = entries per round) depends on the problem size
         def find(dots):
+            # ... and so does the 4th one (non-temporal matrix loads when the matrix exceeds the caches)
             for un in ("4", "16", "8", "2"):
-                k = (ph, "k_sell_spmv<1, %s, %s>" % (dots, un))
-                if k in fetch:
-                    return k
+                for tail in ("", ", false", ", true"):
+                    k = (ph, "k_sell_spmv<1, %s, %s%s>" % (dots, un, tail))
+                    if k in fetch:
+                        return k
             return None
         for dots in ("3", "1"):
             key = find(dots)
