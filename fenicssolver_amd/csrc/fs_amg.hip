@@ -552,6 +552,32 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv(int64_t n, const int32_t
     }
 }
 
+// the same with G lanes per scalar row (coarse levels: few, long rows - a thread per row walks 30-250 entries one
+// dependent load after the other and fills a fraction of the chip: 39 us for a 4 K-row level, latency only)
+template <int BS, int MODE, int G>
+__global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_grp(int64_t n, const int32_t* __restrict__ rp,
+                                                            const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                            const double* __restrict__ x, const double* __restrict__ b,
+                                                            double* __restrict__ y) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = gid / G;
+    const int lg = (int)(gid - row * G);
+    double acc = 0.0;
+    if (row < n) {
+        const int64_t i = row / BS;
+        const int r = (int)(row - i * BS);
+        for (int32_t e = rp[i] + lg; e < rp[i + 1]; e += G) {
+            const double* blk = val + ((int64_t)e * BS + r) * BS;
+            const double* xj = x + (int64_t)ci[e] * BS;
+#pragma unroll
+            for (int c = 0; c < BS; ++c) acc += blk[c] * xj[c];
+        }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);      // fixed order: reproducible
+    if (lg == 0 && row < n) y[row] = MODE ? b[row] - acc : acc;
+}
+
 // xf += P xc ; thread per fine scalar row
 __global__ void k_prolong_add(int64_t n_f, int br, int bc, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                               const double* __restrict__ val, const double* __restrict__ xc, double* __restrict__ xf) {
@@ -748,6 +774,16 @@ static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, doub
         FS_CHECK(fs_spmv_dev(M->fine, x, L->t.p, s));
         hipLaunchKernelGGL(k_amg_sub, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, b, L->t.p, y);
         return FS_OK;
+    }
+    // long rows on few nodes: 16 lanes per scalar row
+    static const bool no_grp = getenv("FS_AMG_NO_ROW_GROUPS") != nullptr;
+    if (!no_grp && L->nn > 0 && L->A.nnz >= 8 * L->nn && L->n <= ((int64_t)1 << 22)) {
+        const int gg = (int)((L->n * 16 + FS_BLOCK - 1) / FS_BLOCK);
+#define FS_BCSR_GRP dim3(gg), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y
+        if (L->bs == 1) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv_grp<1, 1, 16>), FS_BCSR_GRP); else hipLaunchKernelGGL((k_bcsr_spmv_grp<1, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+        if (L->bs == 3) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv_grp<3, 1, 16>), FS_BCSR_GRP); else hipLaunchKernelGGL((k_bcsr_spmv_grp<3, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+        if (L->bs == 6) { if (mode) hipLaunchKernelGGL((k_bcsr_spmv_grp<6, 1, 16>), FS_BCSR_GRP); else hipLaunchKernelGGL((k_bcsr_spmv_grp<6, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+#undef FS_BCSR_GRP
     }
     const int g = fs_grid_for(L->n, FS_BLOCK, 8192);
 #define FS_BCSR_ARGS dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y
