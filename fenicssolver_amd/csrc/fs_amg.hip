@@ -478,7 +478,7 @@ __global__ void k_spgemm_symbolic(int64_t n_out, const int32_t* __restrict__ lpt
 // TRANS (stored bk x br).  The row is accumulated in LDS ([len][br][bc]); within one q all items hit distinct
 // addresses, consecutive q are separated by a barrier: no atomics, fixed summation order.
 template <bool TRANS>
-__global__ void k_spgemm_numeric(int64_t n_out, int br, int bk, int bc, const int32_t* __restrict__ lptr,
+__global__ void k_spgemm_numeric(int64_t n_out, int maxlen, int br, int bk, int bc, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lk, const int32_t* __restrict__ lidx,
                                  const double* __restrict__ lval, const int32_t* __restrict__ rptr,
                                  const int32_t* __restrict__ rcol, const double* __restrict__ rval,
@@ -486,10 +486,15 @@ __global__ void k_spgemm_numeric(int64_t n_out, int br, int bk, int bc, const in
                                  double* __restrict__ oval) {
     extern __shared__ double acc[];
     const int rc = br * bc;
+    // the row's output columns are staged once, so the binary search of every product runs in LDS.  (Staging the
+    // whole lookup - right rows, product positions - ahead of the accumulation rounds was tried: the 20 KB of extra
+    // LDS per workgroup cost more occupancy than the shorter dependency chains gained, 2x slower.)
+    int32_t* scol = reinterpret_cast<int32_t*>(acc + (size_t)maxlen * rc);
     for (int64_t I = blockIdx.x; I < n_out; I += gridDim.x) {
         const int32_t o0 = optr[I];
         const int len = optr[I + 1] - o0;
         for (int t = threadIdx.x; t < len * rc; t += blockDim.x) acc[t] = 0.0;
+        for (int t = threadIdx.x; t < len; t += blockDim.x) scol[t] = ocol[o0 + t];
         __syncthreads();
         for (int32_t q = lptr[I]; q < lptr[I + 1]; ++q) {
             const int32_t k = lk[q];
@@ -503,7 +508,7 @@ __global__ void k_spgemm_numeric(int64_t n_out, int br, int bk, int bc, const in
                 int lo = 0, hi = len;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (ocol[o0 + mid] < J) lo = mid + 1; else hi = mid;
+                    if (scol[mid] < J) lo = mid + 1; else hi = mid;
                 }
                 const double* Rb = rval + (int64_t)(r0 + p) * bk * bc;
                 double v = 0.0;
@@ -751,16 +756,16 @@ static int spgemm(int64_t n_out, int64_t n_cols, int br, int bk, int bc, bool tr
         FS_CHECK(read_i32(mx.p, &maxlen, s));
     }
     amg_tick("    spgemm maxlen");
-    const size_t lds = (size_t)std::max(1, maxlen) * br * bc * sizeof(double);
+    const size_t lds = (size_t)std::max(1, maxlen) * br * bc * sizeof(double) + (size_t)std::max(1, maxlen) * sizeof(int32_t);
     FS_REQUIRE(lds <= 160 * 1024 - 512, "AMG setup: a product row of %d blocks (%dx%d) exceeds the LDS accumulator", maxlen, br, bc);
     if (lds > 64 * 1024) {
         if (trans) FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         else FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (trans)
-        hipLaunchKernelGGL(k_spgemm_numeric<true>, dim3(grid), dim3(wg), lds, s, n_out, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+        hipLaunchKernelGGL(k_spgemm_numeric<true>, dim3(grid), dim3(wg), lds, s, n_out, std::max(1, maxlen), br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
     else
-        hipLaunchKernelGGL(k_spgemm_numeric<false>, dim3(grid), dim3(wg), lds, s, n_out, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+        hipLaunchKernelGGL(k_spgemm_numeric<false>, dim3(grid), dim3(wg), lds, s, n_out, std::max(1, maxlen), br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     amg_tick("    spgemm numeric");
@@ -818,15 +823,22 @@ static int dot_host(fs_amg_s* M, const double* x, const double* y, int64_t n, do
 
 // largest eigenvalue of D^-1 A by power iteration (deterministic start)
 static int estimate_lmax(fs_amg_s* M, amg_level* L, int steps, hipStream_t s) {
+    // level 0: the tuned SELL/DIA product of the fine matrix (332 us at configs[2]) instead of the block-CSR copy
+    // (607 us); its input carries the ghost entries of a decomposed space, which stay zero (rank-local block)
+    const bool fine = L == M->lv[0] && M->fine != nullptr;
+    const int64_t nloc = fine ? M->fine->space->n_dofs_local : L->n;
     dbuf<double> v, w;
-    FS_CHECK(v.alloc(L->n));
-    FS_CHECK(w.alloc(L->n));
+    FS_CHECK(v.alloc(nloc));
+    FS_CHECK(w.alloc(nloc));
+    FS_CHECK(v.zero(s));
+    FS_CHECK(w.zero(s));
     hipLaunchKernelGGL(k_amg_seed, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, v.p);
     double nv = 0.0, lam = 0.0;
     FS_CHECK(dot_host(M, v.p, v.p, L->n, &nv, s));
     hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, (const double*)nullptr, v.p, 1.0 / sqrt(nv));
     for (int it = 0; it < steps; ++it) {
-        FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
+        if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
+        else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
         hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, w.p, 1.0);
         double nw = 0.0;
         FS_CHECK(dot_host(M, w.p, w.p, L->n, &nw, s));
