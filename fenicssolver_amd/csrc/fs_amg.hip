@@ -802,6 +802,14 @@ static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, doub
 
 // setup-time SpMV on the level's own block CSR (level 0 included)
 static int bcsr_spmv_setup(amg_level* L, const double* x, double* y, hipStream_t s) {
+    if (L->nn > 0 && L->A.nnz >= 8 * L->nn && L->n <= ((int64_t)1 << 22)) {      // long rows: 16 lanes per scalar row
+        const int gg = (int)((L->n * 16 + FS_BLOCK - 1) / FS_BLOCK);
+#define FS_BCSR_GRP dim3(gg), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, (const double*)nullptr, y
+        if (L->bs == 1) { hipLaunchKernelGGL((k_bcsr_spmv_grp<1, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+        if (L->bs == 3) { hipLaunchKernelGGL((k_bcsr_spmv_grp<3, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+        if (L->bs == 6) { hipLaunchKernelGGL((k_bcsr_spmv_grp<6, 0, 16>), FS_BCSR_GRP); return FS_OK; }
+#undef FS_BCSR_GRP
+    }
     const int g = fs_grid_for(L->n, FS_BLOCK, 8192);
 #define FS_BCSR_ARGS dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, (const double*)nullptr, y
     if (L->bs == 1) hipLaunchKernelGGL((k_bcsr_spmv<1, 0>), FS_BCSR_ARGS);
