@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bicg_x(int64_t n, int iter, const 
 // Jacobi-PCG on A is unpreconditioned CG on the scaled operator, for which z == r: the update kernel
 // drops the z and D^-1 streams (72 instead of 96 B/DOF per iteration).  rho stays the UNSCALED ||r||^2
 // (sum d r^2, computed in the SpMV), so the stopping test is unchanged.
-template <bool FUSED>
+template <bool FUSED, bool NT = false>
 __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int iter, int check_only,
                                                                const double* __restrict__ partials, int npart,
                                                                const double* __restrict__ sums,
@@ -514,6 +514,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     const int64_t n2 = n >> 1;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // NT (vectors larger than the caches, 10 M DOF): non-temporal loads and stores - the probe in tools/probes streams
+    // 7.2 instead of 6.4 TB/s that way
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    struct io {
+        static __device__ __forceinline__ double2 ld(const double2* q) {
+            if (NT) { const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)); return make_double2(t.x, t.y); }
+            return *q;
+        }
+        static __device__ __forceinline__ void st(double2* q, const double2& v) {
+            if (NT) { v2d t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(q)); }
+            else *q = v;
+        }
+    };
     const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
     double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
     double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
@@ -522,9 +535,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     // two strided elements per trip: ten 16-B loads in flight per lane (the kernel is latency-bound at 1 M DOF)
     for (; i + stride < n2; i += 2 * stride) {
         const int64_t j = i + stride;
-        const double2 wa = w2[i], wb = w2[j];
-        double2 pa = p2[i], sa = s2[i], xa = x2[i], ra = r2[i];
-        double2 pb = p2[j], sb = s2[j], xb = x2[j], rb = r2[j];
+        const double2 wa = io::ld(&w2[i]), wb = io::ld(&w2[j]);
+        double2 pa = io::ld(&p2[i]), sa = io::ld(&s2[i]), xa = io::ld(&x2[i]), ra = io::ld(&r2[i]);
+        double2 pb = io::ld(&p2[j]), sb = io::ld(&s2[j]), xb = io::ld(&x2[j]), rb = io::ld(&r2[j]);
         pa.x = ra.x + beta * pa.x;  pa.y = ra.y + beta * pa.y;
         pb.x = rb.x + beta * pb.x;  pb.y = rb.y + beta * pb.y;
         sa.x = wa.x + beta * sa.x;  sa.y = wa.y + beta * sa.y;
@@ -533,8 +546,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         xb.x += alpha * pb.x;       xb.y += alpha * pb.y;
         ra.x -= alpha * sa.x;       ra.y -= alpha * sa.y;
         rb.x -= alpha * sb.x;       rb.y -= alpha * sb.y;
-        p2[i] = pa; s2[i] = sa; x2[i] = xa; r2[i] = ra;
-        p2[j] = pb; s2[j] = sb; x2[j] = xb; r2[j] = rb;
+        io::st(&p2[i], pa); io::st(&s2[i], sa); io::st(&x2[i], xa); io::st(&r2[i], ra);
+        io::st(&p2[j], pb); io::st(&s2[j], sb); io::st(&x2[j], xb); io::st(&r2[j], rb);
     }
     for (; i < n2; i += stride) {
         const double2 ww = w2[i];
@@ -1031,6 +1044,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     // the true residual is recomputed after every pass and, if it misses the tolerance, the solve
     // restarts from the current x (at most 8 passes, iteration budget shared).
     const int batch = opts->batch > 0 ? opts->batch : g_cg_batch;
+    static const char* upd_nt_env = getenv("FS_UPDATE_NT");
+    const bool upd_nt = upd_nt_env ? upd_nt_env[0] == '1' : (int64_t)sp->n_dofs_owned * 72 > ((int64_t)192 << 20);   // five vectors exceed the caches
     int total_iters = 0, n_samples = 0, n_pass = 0;
     int h_status[4] = {0, 0, 0, 0};
     bool use_guess = opts->nonzero_guess != 0;
@@ -1135,12 +1150,14 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const int co = k == max_iter ? 1 : 0;
                     if (fuse_sums) {
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                        hipLaunchKernelGGL(k_cg_update_scaled<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     } else {
                         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
                         FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                        hipLaunchKernelGGL(k_cg_update_scaled<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     }
                 } else if (fuse_sums) {
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
