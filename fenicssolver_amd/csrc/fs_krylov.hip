@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                 for (int j = 0; j < BS; ++j) {
                     const double xj = x[c * BS + j];
 #pragma unroll
-                    for (int i = 0; i < BS; ++i) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xj;
+                    for (int i = 0; i < BS; ++i) acc[i] += fs_ldv<NT>(&vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE]) * xj;
                 }
             }
         } else {
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                 for (int j = 0; j < BS; ++j) {
                     const double xj = x[c * BS + j];
 #pragma unroll
-                    for (int i = 0; i < BS; ++i) acc[i] += vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE] * xj;
+                    for (int i = 0; i < BS; ++i) acc[i] += fs_ldv<NT>(&vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE]) * xj;
                 }
             }
         }
@@ -760,7 +760,8 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
                 break;
         }
     } else if (A->bs == 3) {
-        hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
+        if (spmv_nontemporal(sp, 3)) hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4, true>), FS_SPMV_ARGS);
+        else hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
     } else {
         switch (g_spmv_unroll4) {
             case 1: hipLaunchKernelGGL((k_sell_spmv<4, DOTS, 1>), FS_SPMV_ARGS); break;
