@@ -826,9 +826,9 @@ class SolverBase():
         """global dof vector -> this rank's owned + ghost entries"""
         return w if loc is None else loc.nodes(w)
 
-    def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None):
+    def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None, w_is_local=False):
         from . import backend
-        dw = backend.DeviceVector(V.n_local, self._ns_local(loc, w))
+        dw = backend.DeviceVector(V.n_local, w if w_is_local else self._ns_local(loc, w))
         dp = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector().array())) if F.inv_dt else None
         g = backend.DeviceVector(V.n_owned)
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
@@ -895,13 +895,16 @@ class SolverBase():
             w[3] = 0.0
         w[F.space.dummy_dofs()] = 0.0
         own = dofs[dofs < V.n_owned]               # constrained rows of this rank (the list also names ghost dofs)
+        # several GPUs: the iterate lives in this rank's numbering (owned + ghost entries) during the iteration - the
+        # update of the ghosts comes with the halo of the Krylov solution - and is gathered once at the end
+        wl = self._ns_local(loc, w)
         history, krylov = [], 0
         timing = os.environ.get("FS_NS_TIMING") is not None
         tm = {"assemble": 0.0, "residual": 0.0, "dirichlet": 0.0, "krylov": 0.0, "update": 0.0}
         clock = time.perf_counter
         for it in range(max_it + 1):
             t0 = clock()
-            dw, g = self._navier_stokes_assemble(F, V, ctx, w, newton=True, loc=loc)
+            dw, g = self._navier_stokes_assemble(F, V, ctx, wl, newton=True, loc=loc, w_is_local=True)
             t1 = clock()
             r = backend.DeviceVector(V.n_owned)
             ctx['J'].spmv(dw, r)
@@ -941,14 +944,14 @@ class SolverBase():
             st = self._navier_stokes_krylov(F, ctx, ctx['J'], rhs, x, eta, False)
             krylov += st['iterations']
             t5 = clock()
-            dx = x.get()[:V.n_owned]
-            if loc is not None:
-                dx = parallel.gather_owned(dx, loc.owned_gids(), loc.n_global, 4)
-            w = w + relax * dx
+            if loc is not None and parallel.world()[1] > 1:
+                backend.halo_exchange(V, x)                   # ghost entries of the update
+            wl = wl + relax * x.get()
             t6 = clock()
             tm["dirichlet"] += t4 - t3
             tm["krylov"] += t5 - t4
             tm["update"] += t6 - t5
+        w = wl[:V.n_owned] if loc is None else parallel.gather_owned(wl[:V.n_owned], loc.owned_gids(), loc.n_global, 4)
         if timing:
             self.logger.warning("Newton timing [s]: %s", {k: round(v, 4) for k, v in tm.items()})
         self.newton_history = history

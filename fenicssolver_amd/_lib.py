@@ -136,6 +136,7 @@ SIGNATURES = {
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fs_comm_allreduce_sum": (C.c_int, [c_f64p, C.c_int]),
+    "fs_comm_allgather": (C.c_int, [c_f64p, c_i64, c_i64, c_f64p]),
     "fs_comm_finalize": (C.c_int, []),
     "fs_mesh_set_global_ids": (C.c_int, [_H, c_i64p]),
     "fs_space_set_halo_indexed": (C.c_int, [_H, C.c_int, c_i32p, c_i64p, c_i32p, c_i64p, c_i32p]),

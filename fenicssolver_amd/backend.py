@@ -9,6 +9,8 @@ on the host and nothing falls back to it.
 from __future__ import annotations
 
 import ctypes as C
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -515,6 +517,15 @@ def comm_allreduce_sum(values):
     v = L.f64(values).ravel().copy()
     L.check(L.load().fs_comm_allreduce_sum(L.p_f64(v), v.size), "fs_comm_allreduce_sum")
     return v
+
+
+def comm_allgather(values, n_max):
+    """[n_ranks, n_max]: every rank's values (padded to n_max), one ncclAllGather."""
+    v = L.f64(values).ravel()
+    n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
+    out = np.empty((n_ranks, int(n_max)))
+    L.check(L.load().fs_comm_allgather(L.p_f64(v), v.size, int(n_max), L.p_f64(out)), "fs_comm_allgather")
+    return out
 
 
 def halo_exchange(space, v):

@@ -29,6 +29,7 @@ struct rccl_api {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -62,6 +63,7 @@ static int rccl_load() {
     LOAD(CommInitRank, "ncclCommInitRank")
     LOAD(CommDestroy, "ncclCommDestroy")
     LOAD(AllReduce, "ncclAllReduce")
+    LOAD(AllGather, "ncclAllGather")
     LOAD(Send, "ncclSend")
     LOAD(Recv, "ncclRecv")
     LOAD(GroupStart, "ncclGroupStart")
@@ -262,6 +264,40 @@ extern "C" int fs_comm_allreduce_sum(double* host_inout, int n) {
     FS_CHECK(d.upload(host_inout, n, s));
     FS_CHECK(fs_comm_allreduce_dev(d.p, n, s));
     FS_CHECK(d.download(host_inout, n, s));
+    return FS_OK;
+}
+
+// Every rank contributes n_max doubles (its n_send values, padded); recv = [n_ranks][n_max] on every rank.  Used by the
+// solver API to gather the owned parts of a solution (fenicssolver_amd/parallel.py) - one ncclAllGather.
+extern "C" int fs_comm_allgather(const double* host_send, int64_t n_send, int64_t n_max, double* host_recv) {
+    FS_CHECK(fs_require_init());
+    fs_runtime& rt = fs_rt();
+    FS_REQUIRE(host_recv && n_send >= 0 && n_send <= n_max && (n_send == 0 || host_send), "fs_comm_allgather: bad arguments");
+    if (!rt.comm) {
+        memcpy(host_recv, host_send, (size_t)n_send * sizeof(double));
+        return FS_OK;
+    }
+    const int nr = rt.n_ranks;
+    if (g_shm) {
+        // test transport: rounds of RED_CAP doubles per rank through the reduction mailbox
+        for (int64_t off = 0; off < n_max; off += shm_comm::RED_CAP) {
+            const int64_t m = std::min<int64_t>(shm_comm::RED_CAP, n_max - off);
+            const int64_t mine = std::max<int64_t>(0, std::min<int64_t>(m, n_send - off));
+            if (mine > 0) memcpy(g_shm->red(g_shm->rank), host_send + off, (size_t)mine * sizeof(double));
+            g_shm->barrier();
+            for (int r = 0; r < nr; ++r) memcpy(host_recv + (int64_t)r * n_max + off, g_shm->red(r), (size_t)m * sizeof(double));
+            g_shm->barrier();
+        }
+        return FS_OK;
+    }
+    hipStream_t s = rt.stream;
+    dbuf<double> ds, dr;
+    FS_CHECK(ds.alloc(std::max<int64_t>(n_max, 1)));
+    FS_CHECK(dr.alloc(std::max<int64_t>(n_max, 1) * nr));
+    FS_CHECK(ds.zero(s));
+    FS_CHECK(ds.upload(host_send, n_send, s));
+    FS_NCCL(g_nccl.AllGather(ds.p, dr.p, (size_t)n_max, ncclDouble, (ncclComm_t)rt.comm, s));
+    FS_CHECK(dr.download(host_recv, n_max * nr, s));
     return FS_OK;
 }
 

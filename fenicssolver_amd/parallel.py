@@ -47,22 +47,36 @@ def ensure_comm():
     return rank, size
 
 
+_gid_cache = {}
+
+
 def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
-    """Owned dof values of every rank -> the full vector (on every rank)."""
+    """Owned dof values of every rank -> the full vector (on every rank).  The values travel in one all-gather of the
+    communicator (RCCL; fs_comm_allgather); the owners' global ids are exchanged once per layout and cached."""
     rank, size, _ = world()
     vals = np.asarray(values_owned, dtype=np.float64).reshape(-1, ncomp)
+    gids = np.asarray(gids_owned)
     out = np.full((n_global, ncomp), np.nan)
     if size == 1:
-        out[np.asarray(gids_owned)] = vals
+        out[gids] = vals
     else:
         import torch.distributed as dist
-        parts = [None] * size
-        dist.all_gather_object(parts, (np.asarray(gids_owned), vals))
-        for g, v in parts:
-            out[g] = v
+        from . import backend
+        key = (int(n_global), len(gids), int(gids[0]) if len(gids) else -1, int(gids[-1]) if len(gids) else -1)
+        if key not in _gid_cache:
+            parts = [None] * size
+            dist.all_gather_object(parts, gids)
+            if len(_gid_cache) > 16:
+                _gid_cache.clear()
+            _gid_cache[key] = parts
+        parts = _gid_cache[key]
+        n_max = max(len(g) for g in parts) * ncomp
+        got = backend.comm_allgather(vals.reshape(-1), n_max)
+        for r, g in enumerate(parts):
+            out[g] = got[r, :len(g) * ncomp].reshape(-1, ncomp)
     if np.isnan(out).any():
         raise RuntimeError("gather_owned: some dofs are owned by no rank")
-    return out.reshape(-1) if ncomp == 1 else out.reshape(-1)
+    return out.reshape(-1)
 
 
 class Localizer:

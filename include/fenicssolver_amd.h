@@ -367,6 +367,9 @@ int fs_comm_get_unique_id(char id[FS_UNIQUE_ID_BYTES]); /* rank 0, then broadcas
 int fs_comm_init(int n_ranks, int rank, const char id[FS_UNIQUE_ID_BYTES]);
 int fs_comm_info(int* n_ranks, int* rank);
 int fs_comm_allreduce_sum(double* host_inout, int n); /* utility: host scalars */
+/* All-gather of host arrays: every rank contributes n_send <= n_max doubles; recv [n_ranks][n_max] (padding undefined).
+ * One ncclAllGather; the solver API gathers the owned parts of a solution with it. */
+int fs_comm_allgather(const double* host_send, int64_t n_send, int64_t n_max, double* host_recv);
 int fs_comm_finalize(void);
 
 /* Halo plan of a space (PETSc VecScatter ghost update): for each neighbour the
