@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
 }
 
 // ---- the same element, one wave per cell ---------------------------------------------------------------------------
-// The kernel above (one thread per (cell, a, b), ordered pair-major; FS_NS_ASSEMBLE_OLD=1) recomputes the state at the
+// The kernel above (one thread per (cell, a, b), ordered pair-major; FS_NS_ASSEMBLE=pair) recomputes the state at the
 // 14 points in each of the 100 threads of a cell.  Here a wave owns a cell: basis functions and state at the quadrature
 // points are built once in LDS, lane ab accumulates block (a, b), and all atomics of a cell - and of its neighbours in
 // the cell order, which share its rows - are issued together.  Measured on MI355X (configs[4], 477 042 cells): 24.7 ms
