@@ -1045,6 +1045,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     // the true residual is recomputed after every pass and, if it misses the tolerance, the solve
     // restarts from the current x (at most 8 passes, iteration budget shared).
     const int batch = opts->batch > 0 ? opts->batch : g_cg_batch;
+    // kernel durations (stats->spmv_ms / update_ms: the roofline of bench.py) are sampled with HIP events every
+    // sample_every-th iteration, 4 events each.  The markers are not free: on the 1 M-DOF solve (293 iterations of 45 us)
+    // sampling every 4th iteration costs 0.87 ms per solve (6 %), every 16th 0.4 ms - the default
+    static const int sample_every = getenv("FS_CG_SAMPLE_EVERY") ? std::max(1, atoi(getenv("FS_CG_SAMPLE_EVERY"))) : 16;
     static const char* upd_nt_env = getenv("FS_UPDATE_NT");
     const bool upd_nt = upd_nt_env ? upd_nt_env[0] == '1' : (int64_t)sp->n_dofs_owned * 72 > ((int64_t)192 << 20);   // five vectors exceed the caches
     int total_iters = 0, n_samples = 0, n_pass = 0;
@@ -1100,7 +1104,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
             for (; k < kend; ++k) {
-                const bool sample = (k % 4 == 1) && n_samples < krylov_ws::NSAMPLE;
+                const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
                 if (bicg) {
                     const int co = k == max_iter ? 1 : 0;
                     // K1: p, y
