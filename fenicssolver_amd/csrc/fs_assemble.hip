@@ -1108,6 +1108,42 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     return FS_OK;
 }
 
+// scalar CG1 load vector without atomics: lane = row, its cell incidences summed in ascending cell order (the tables of the
+// row-gather matrix assembly).  1 M DOF: 0.85 ms (constant f) / 1.25 ms (nodal f) with 23 M device-scope fp64 atomics.
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source_gather(int64_t n_rows, int64_t n_slices,
+                                                                        const int64_t* __restrict__ inc_slice_ptr,
+                                                                        const int32_t* __restrict__ inc_cell,
+                                                                        const int32_t* __restrict__ cells,
+                                                                        const double* __restrict__ xyz4, coef_dev f,
+                                                                        double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q >> 2, a = q & 3;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const tet_geom t = tet_geometry(xyz4, v);
+            if (f.mode == FS_COEF_NODAL) {          // b_e = M_e f_e with the exact P1 mass matrix
+                const double fe[4] = {f.data[v[0]], f.data[v[1]], f.data[v[2]], f.data[v[3]]};
+                const double fa = a == 0 ? fe[0] : a == 1 ? fe[1] : a == 2 ? fe[2] : fe[3];
+                acc += t.adet * (1.0 / 120.0) * (((fe[0] + fe[1]) + (fe[2] + fe[3])) + fa);
+            } else {
+                acc += (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.adet * (1.0 / 24.0);
+            }
+        }
+        if (row < n_rows) b[row] = ADD ? b[row] + acc : acc;
+    }
+}
+
 extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add) {
     FS_REQUIRE(space && form && b, "fs_assemble_vector: null pointer");
     FS_REQUIRE(b->d.n >= space->n_dofs_owned, "fs_assemble_vector: vector shorter than the owned dofs");
@@ -1147,6 +1183,14 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore, &sv, "fs_assemble_vector(supg_velocity)"));
     FS_REQUIRE(!(form->supg_pe > 0.0) || sv.mode == FS_COEF_NONE || (space->ncomp == 1 && f.mode != FS_COEF_NODAL),
                "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources on scalar CG1 spaces");
+    if (space->ncomp == 1 && space->inc_cell.p && !(form->supg_pe > 0.0 && sv.mode != FS_COEF_NONE) && !getenv("FS_SOURCE_ATOMIC")) {
+        // b was zeroed above unless add: the gather kernel adds to what is there either way
+        hipLaunchKernelGGL(k_assemble_p1_source_gather<true>, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                           space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, m->cells.p, m->xyz.p, f, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     hipLaunchKernelGGL(k_assemble_p1_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, m->n_owned, f, space->ncomp, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, sv, form->supg_pe, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
