@@ -104,7 +104,7 @@ class LinearElasticitySolver(SolverBase):
     def _facet_normals(self, marker_id):
         """Outward unit normals and areas of the facets carrying marker_id."""
         mesh = self.mesh
-        sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+        sel = self.boundary_facets.where(marker_id)
         tri = mesh.facets()[sel].astype(np.int64)
         co = mesh.coordinates()
         p = co[tri]

@@ -387,7 +387,7 @@ class ScalarTransportSolver(SolverBase):
         mesh = self.mesh
         co, cells = mesh.coordinates(), mesh.cells().astype(np.int64)
         d = co.shape[1]                                   # 3: tetrahedra, 2: triangles
-        sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+        sel = self.boundary_facets.where(marker_id)
         cf = mesh.cell_facets()
         c_idx, lf = np.nonzero(np.isin(cf, sel))          # boundary facets belong to exactly one cell
         T = self.result.vector().array()

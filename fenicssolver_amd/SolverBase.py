@@ -562,7 +562,7 @@ class SolverBase():
         return np.concatenate(dofs).astype(np.int32), np.concatenate(vals).astype(np.float64)
 
     def _facets_of(self, marker_id):
-        sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+        sel = self.boundary_facets.where(marker_id)
         return self.mesh.facets()[sel]
 
     def _device_facets(self, F, marker_id, per_facet=None):
@@ -850,7 +850,7 @@ class SolverBase():
         """(cell, local opposite vertex, centroid) of the facets carrying a boundary marker."""
         cache = self.__dict__.setdefault('_facet_cell_cache', {})
         if marker_id not in cache:
-            sel = np.nonzero(self.boundary_facets.array() == marker_id)[0]
+            sel = self.boundary_facets.where(marker_id)
             cf = self.mesh.cell_facets()
             cells, opp = np.nonzero(np.isin(cf, sel))
             order = np.argsort(cf[cells, opp], kind='stable')       # ascending facet id: the order of _facets_of()

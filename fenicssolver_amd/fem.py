@@ -354,10 +354,23 @@ class MeshFunction:
         return self._mesh
 
     def array(self):
+        self._where = {}            # the caller may write through the returned array
         return self._a
 
     def set_all(self, v):
+        self._where = {}
         self._a[:] = v
+
+    def where(self, value):
+        """Indices of the entities carrying `value` (cached: a time loop rebuilds its boundary conditions every step and
+        a scan of 12 M facet markers takes milliseconds).  Every public accessor that can write - array(), set_all(),
+        mf[i] = v - drops the cache; write through an array obtained earlier and call array() again before relying on it."""
+        w = self.__dict__.setdefault("_where", {})
+        if value not in w:
+            if len(w) > 64:
+                w.clear()
+            w[value] = np.nonzero(self._a == value)[0]
+        return w[value]
 
     def size(self):
         return self._a.size
@@ -366,6 +379,7 @@ class MeshFunction:
         return self._a[i]
 
     def __setitem__(self, i, v):
+        self._where = {}
         self._a[i] = v
 
 
@@ -929,7 +943,7 @@ class DirichletBC:
         if isinstance(markers, MeshFunction):
             if markers.dim() != mesh.topology().dim() - 1:
                 raise SolverError("DirichletBC needs a facet MeshFunction")
-            sel = np.nonzero(markers.array() == marker_id)[0]
+            sel = markers.where(marker_id)
         else:
             raise SolverError("DirichletBC: markers must be a MeshFunction")
         if hasattr(V, "dirichlet_dofs"):                # sub space of the velocity-pressure space (mixed.py)
