@@ -107,7 +107,12 @@ def roofline_of(st, V, traffic=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": st["spmv_bytes"], "avg_launch_ms": round(ms, 5),
             "streamed_bytes_per_launch": streamed, "streamed_GBps": round(streamed / ms / 1e6, 1) if ms > 0 else 0.0,
-            "dia_slices": V.n_dia_slices, "slices": V.n_slices}
+            "dia_slices": V.n_dia_slices, "slices": V.n_slices,
+            "note": ("achieved = ALGORITHMIC CSR bytes / mean kernel time (HIP events, every 16th iteration of the timed solves). "
+                     + ("At this size the matrix and the vectors (streamed_bytes_per_launch) stay in the 256 MiB Infinity Cache "
+                        "between iterations and the DIA slices stream no column indices, so the figure is not an HBM rate and can "
+                        "exceed the HBM peak; roofline_hbm_resident is the same kernel on a 10 M-DOF problem."
+                        if streamed < (256 << 20) else "HBM-resident problem: the matrix is re-read from HBM every iteration."))}
 
 
 def committed_traffic(tag):
