@@ -410,6 +410,58 @@ __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t
     }
 }
 
+// CG2 Robin / HTC matrix  int_F h phi_a phi_b ds: the exact P2 mass matrix of the facet triangle (nodes: its three
+// vertices, then the edge nodes (0,1), (0,2), (1,2)), A/180 * [[6 -1 -1 0 0 -4], ...] - a vertex couples with -4 to the
+// opposite edge node, with 0 to the adjacent ones; edge nodes 32 / 16.  Thread per (facet, row node).
+__device__ const double FS_P2_TRI_MASS180[6][6] = {{6, -1, -1, 0, 0, -4}, {-1, 6, -1, 0, -4, 0}, {-1, -1, 6, -4, 0, 0},
+                                                  {0, 0, -4, 32, 16, 16}, {0, -4, 0, 16, 32, 16}, {-4, 0, 0, 16, 16, 32}};
+__global__ void k_facet_matrix_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
+                                  const double* __restrict__ h, const uint64_t* __restrict__ edge_keys, int64_t ne,
+                                  int grouped, const int32_t* __restrict__ edge_node, int64_t n_rows, int64_t nvo, int64_t neo,
+                                  const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                  double* __restrict__ val, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 6; t += stride) {
+        const int64_t f = t / 6;
+        const int a = (int)(t - f * 6);
+        const int32_t v[3] = {tri[3 * f], tri[3 * f + 1], tri[3 * f + 2]};
+        // node of a vertex: itself when owned, shifted behind the owned edge nodes when ghost
+        int32_t node[6] = {(int32_t)(v[0] < nvo ? v[0] : v[0] + neo), (int32_t)(v[1] < nvo ? v[1] : v[1] + neo),
+                           (int32_t)(v[2] < nvo ? v[2] : v[2] + neo), -1, -1, -1};
+        const int pi[3] = {0, 0, 1}, pj[3] = {1, 2, 2};
+        bool ok = true;
+        for (int e = 0; e < 3; ++e) {
+            const int32_t p = v[pi[e]], q = v[pj[e]];
+            const uint32_t lo_v = (uint32_t)(p < q ? p : q), hi_v = (uint32_t)(p < q ? q : p);
+            const uint64_t key = grouped ? (((uint64_t)(hi_v - lo_v) << 32) | lo_v) : (((uint64_t)lo_v << 32) | hi_v);
+            int64_t lo = 0, hi = ne;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (edge_keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < ne && edge_keys[lo] == key) node[3 + e] = edge_node[lo];
+            else ok = false;
+        }
+        if (!ok) { if (a == 0) atomicAdd(err, 1); continue; }
+        const int32_t row = node[a];
+        if (row >= n_rows) continue;
+        const double w = h[f] * tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 180.0);
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        for (int b = 0; b < 6; ++b) {
+            const double m = FS_P2_TRI_MASS180[a][b];
+            if (m == 0.0) continue;
+            int k = -1;
+            for (int kk = 0; kk < width; ++kk)
+                if (sell_col[base + (int64_t)kk * FS_SLICE] == node[b]) { k = kk; break; }
+            if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], w * m);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- vector P1 elasticity: 3x3 block per node pair, plane (i*3+j) of the SELL value array ------
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity(const int32_t* __restrict__ cells,
                                                                      const double* __restrict__ xyz4,
@@ -1324,9 +1376,28 @@ extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const i
     }
     if (n_facets == 0) return FS_OK;
     fs_space_s* sp = A->space;
-    if (sp->degree != 1) {
-        fs_set_error("fs_assemble_facet_matrix: the Robin/HTC boundary matrix is not built for CG2 yet");
-        return FS_ERR_UNSUPPORTED;
+    if (sp->degree == 2) {
+        FS_REQUIRE(sp->mesh->tdim == 3, "fs_assemble_facet_matrix: CG2 facet matrices are built for tetrahedral meshes");
+        for (int64_t i = 0; i < 3 * n_facets; ++i)
+            FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->mesh->nv, "fs_assemble_facet_matrix: facet vertex %d out of range", tri[i]);
+        hipStream_t s3 = fs_rt().stream;
+        dbuf<int32_t> d_t;
+        dbuf<double> d_h3;
+        dbuf<int> d_err3;
+        FS_CHECK(d_t.alloc(3 * n_facets));
+        FS_CHECK(d_h3.alloc(n_facets));
+        FS_CHECK(d_err3.alloc(1));
+        FS_CHECK(d_err3.zero(s3));
+        FS_CHECK(d_t.upload(tri, 3 * n_facets, s3));
+        FS_CHECK(d_h3.upload(h, n_facets, s3));
+        hipLaunchKernelGGL(k_facet_matrix_p2, dim3(fs_grid_for(6 * n_facets)), dim3(FS_BLOCK), 0, s3, sp->mesh->xyz.p, d_t.p, n_facets, d_h3.p,
+                           sp->edge_keys.p, sp->n_edges, sp->edge_grouped, sp->edge_node.p, sp->n_nodes_owned, sp->mesh->n_owned, sp->n_edges_owned,
+                           sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err3.p);
+        FS_KERNEL_CHECK();
+        int h_err3 = 0;
+        FS_CHECK(d_err3.download(&h_err3, 1, s3));
+        FS_REQUIRE(h_err3 == 0, "fs_assemble_facet_matrix: %d facet edges / entries are not in the space", h_err3);
+        return FS_OK;
     }
     if (sp->mesh->tdim == 2) {
         for (int64_t i = 0; i < 2 * n_facets; ++i)

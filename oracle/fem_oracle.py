@@ -909,3 +909,39 @@ def assemble_interior_penalty(coords, cells, coefficient):
             for b in nodes:
                 rows.append(a); cols.append(b); vals.append(w * J[a] * J[b])
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+
+
+# ---- P2 Robin / HTC facet matrix (ScalarTransportSolver.py:201-208 with fe_degree 2) ---------------------------------
+def assemble_p2_facet_mass(coords, edges, facets, facet_markers, marker_id, h):
+    """int_F h phi_a phi_b ds on the marked facets for the P2 basis: by quadrature (the 6-point degree-4 rule, exact for
+    the quartic integrand), not by the closed-form mass matrix the device uses.  Node of edge k = n_vertices + k."""
+    import scipy.sparse as sp
+    co = np.asarray(coords, dtype=np.float64)
+    nv = len(co)
+    ed = np.asarray(edges, dtype=np.int64)
+    emap = {(int(a), int(b)): nv + k for k, (a, b) in enumerate(ed)}
+    q = np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965],
+                  [0.445948490915965, 0.108103018168070, 0.445948490915965],
+                  [0.445948490915965, 0.445948490915965, 0.108103018168070],
+                  [0.816847572980459, 0.091576213509771, 0.091576213509771],
+                  [0.091576213509771, 0.816847572980459, 0.091576213509771],
+                  [0.091576213509771, 0.091576213509771, 0.816847572980459]])
+    w = np.array([0.223381589678011] * 3 + [0.109951743655322] * 3)
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    hh = np.broadcast_to(np.asarray(h, dtype=np.float64), (len(sel),))
+    rows, cols, vals = [], [], []
+    for idx, f in enumerate(sel):
+        v = [int(x) for x in facets[f]]
+        nodes = v + [emap[tuple(sorted((v[0], v[1])))], emap[tuple(sorted((v[0], v[2])))], emap[tuple(sorted((v[1], v[2])))]]
+        area = 0.5 * np.linalg.norm(np.cross(co[v[1]] - co[v[0]], co[v[2]] - co[v[0]]))
+        M = np.zeros((6, 6))
+        for lam, wq in zip(q, w):
+            phi = np.array([lam[0] * (2 * lam[0] - 1), lam[1] * (2 * lam[1] - 1), lam[2] * (2 * lam[2] - 1),
+                            4 * lam[0] * lam[1], 4 * lam[0] * lam[2], 4 * lam[1] * lam[2]])
+            M += wq * np.outer(phi, phi)
+        M *= area * hh[idx]
+        for a in range(6):
+            for b in range(6):
+                rows.append(nodes[a]); cols.append(nodes[b]); vals.append(M[a, b])
+    n = nv + len(ed)
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()

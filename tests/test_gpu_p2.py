@@ -155,3 +155,51 @@ def test_p2_solver_api_config1_and_box(gpu, data_dir):
     Ab, bb = fo.apply_dirichlet(A, b, dofs, 360.0, True)
     ref = fo.solve_direct(Ab, bb)
     assert np.abs(Tb - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_p2_htc_facet_matrix_and_solver_class(gpu):
+    """Robin / HTC on a CG2 space: int h T q ds with the exact P2 facet mass matrix against the oracle's quadrature, and
+    the solver class (fe_degree 2, HTC on one face, Dirichlet on the opposite one) against an oracle solve."""
+    from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 1.2), 3, 2, 3)
+    mesh, V, cd, edges = _p2(gpu, co, ce)
+    n = len(co) + len(edges)
+    facets, _, cnt = fo.facet_numbering(ce)
+    markers = fo.mark_facets(co, ce, lambda x, on_b: on_b and np.isclose(x[2], 0.0), 3)
+    sel = np.nonzero(markers == 3)[0]
+    hvals = np.linspace(50.0, 150.0, len(sel))
+    A = gpu.DeviceMatrix(V)
+    A.zero()
+    A.add_facet_mass(facets[sel], hvals)
+    ref = fo.assemble_p2_facet_mass(co, edges, facets, markers, 3, hvals)
+    got = _csr(A)
+    assert abs(got - ref).max() <= 1e-12 * abs(ref).max()
+    # through the solver class
+    m = BoxMesh(Point(0, 0, 0), Point(1.0, 0.8, 1.2), 3, 2, 3)
+    Q = FunctionSpace(m, "CG", 2)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 1.2)), 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+         'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+         'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
+         'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 0.3},
+                             'reference_values': {'temperature': 300}, 'solver_parameters': {'krylov_relative_tolerance': 1e-12}},
+         'report_settings': {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0},
+         'scalar_name': 'temperature'}
+    T = ScalarTransportSolver(s).solve().vector().array()
+    K = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.6))
+    R = fo.assemble_p2_facet_mass(co, edges, facets, markers, 3, 100.0)
+    b = R @ np.full(n, 300.0)                                   # int h Ta q ds = R * (Ta as a P2 function)
+    mk1 = fo.mark_facets(co, ce, lambda x, on_b: on_b and np.isclose(x[2], 1.2), 1)
+    dofs = fo.p2_facet_dofs(len(co), edges, facets, mk1, 1)
+    Ab, bb = fo.apply_dirichlet((K + R).tocsr(), b, dofs, np.full(len(dofs), 360.0), True)
+    ref_T = fo.solve_direct(Ab, bb)
+    assert np.abs(T - ref_T).max() <= 1e-8 * 360.0
+    # physical check: 1-D conduction with a Robin end, T(z) = 300 + q (1/h + z/k), q = (360 - 300)/(1/h + L/k)
+    X = fo.p2_dof_coordinates(co, edges)
+    q = 60.0 / (1.0 / 100.0 + 1.2 / 0.6)
+    assert np.abs(T - (300.0 + q * (1.0 / 100.0 + X[:, 2] / 0.6))).max() <= 1e-7

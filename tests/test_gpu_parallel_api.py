@@ -19,7 +19,8 @@ QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_
 
 
 def _heat_p2_case(n=4):
-    """P2 heat: Dirichlet + flux + per-subdomain conductivity and source (degree 2 has no Robin facet matrix)."""
+    """P2 heat: Dirichlet + flux + HTC (the CG2 facet mass matrix, ghost vertex nodes included) + per-subdomain
+    conductivity and source."""
     solver = _heat_case(n, degree=2)
     return solver
 
@@ -34,12 +35,8 @@ def _heat_case(n=5, transient=False, degree=1):
         'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
     bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 2, 'values': {
         'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
-    if degree == 1:
-        bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
-            'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
-    else:
-        bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
-            'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
     s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
          'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
          'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
