@@ -593,8 +593,6 @@ class SolverBase():
             if adv is not None and loc is not None and np.ndim(adv) == 2:
                 adv = loc.cells(adv)
             pe = getattr(F, 'supg_pe', 0.0) if adv is not None else 0.0
-            if pe and loc is not None:
-                raise SolverError('SUPG stabilisation is single-GPU for now')
             A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
                        supg_pe=pe)
             if ip:          # fully implicit, like the advection term it stabilises (ScalarTransportSolver.py:305-315)
@@ -619,12 +617,30 @@ class SolverBase():
                     backend.assemble_facet_vector(V, b, tri, r.h * r.ambient)
             if pe:
                 # the reference substitutes q + tau (v . grad q) in the boundary integrals as well (Tq, :296-298)
+                def local_facets(marker_id, per_facet):
+                    cells_, opp_, _ = self._marked_facet_cells(marker_id)
+                    if loc is None:
+                        return cells_, opp_, per_facet
+                    # several GPUs: the facets whose cell is in this rank's part (rows of other ranks are skipped on the
+                    # device); per-facet values follow the facets
+                    g2l = self.__dict__.setdefault('_cell_g2l', {}).get(id(loc))
+                    if g2l is None:
+                        g2l = np.full(self.mesh.num_cells(), -1, dtype=np.int64)
+                        g2l[loc.part.cell_gids] = np.arange(len(loc.part.cell_gids))
+                        self._cell_g2l[id(loc)] = g2l
+                    lc = g2l[cells_]
+                    keep = lc >= 0
+                    if per_facet is not None and np.ndim(per_facet) >= 1 and np.shape(per_facet)[0] == len(cells_):
+                        per_facet = np.asarray(per_facet)[keep]
+                    return lc[keep].astype(np.int32), opp_[keep], per_facet
                 for fl in F.facet_loads:
-                    cells_, opp_, _ = self._marked_facet_cells(fl.marker_id)
-                    backend.assemble_facet_supg(V, None, b, cells_, opp_, adv, pe, g=fl.g)
+                    cells_, opp_, gg = local_facets(fl.marker_id, fl.g)
+                    if len(cells_):
+                        backend.assemble_facet_supg(V, None, b, cells_, opp_, adv, pe, g=gg)
                 for r in F.robin:
-                    cells_, opp_, _ = self._marked_facet_cells(r.marker_id)
-                    backend.assemble_facet_supg(V, A, b, cells_, opp_, adv, pe, g=r.h * r.ambient, h=r.h)
+                    cells_, opp_, _ = local_facets(r.marker_id, None)
+                    if len(cells_):
+                        backend.assemble_facet_supg(V, A, b, cells_, opp_, adv, pe, g=r.h * r.ambient, h=r.h)
             for ps in getattr(F, 'point_sources', []):
                 # PointSource.apply(b) (SolverBase.py:597-601): before the Dirichlet rows, which then overwrite
                 pd, pw = ps.dofs, ps.weights

@@ -48,7 +48,7 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
 
 
-@pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3)])
+@pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     """`python -m torch.distributed.run --nproc-per-node N script.py` with the reference-style solver classes:
     same field as the single-process run, gathered on every rank.  heat_p2: CG2 nodes decomposed as

@@ -25,7 +25,7 @@ def _heat_p2_case(n=4):
     return solver
 
 
-def _heat_case(n=5, transient=False, degree=1):
+def _heat_case(n=5, transient=False, degree=1, supg=False):
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n)
@@ -45,6 +45,9 @@ def _heat_case(n=5, transient=False, degree=1):
                              'reference_values': {'temperature': 300},
                              'solver_parameters': {'krylov_relative_tolerance': 1e-12}},
          'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    if supg:        # advection with the 'SPUG' test function in the volume, source and boundary (flux, HTC) integrals
+        s['convective_velocity'] = Constant((0.02, -0.01, 0.03))
+        s['advection_settings'] = {'stabilization_method': 'SPUG', 'Pe': 10.0}
     solver = ScalarTransportSolver(s)
     cen = m.coordinates()[m.cells().astype(np.int64)].mean(axis=1)
     sub = MeshFunction("size_t", m, 3)
@@ -158,6 +161,7 @@ def _radiation_case():
 NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case}
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
+         "heat_supg": lambda: _heat_case(supg=True),
          "heat_p2": _heat_p2_case}
 
 
