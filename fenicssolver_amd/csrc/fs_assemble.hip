@@ -1196,6 +1196,54 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source_gather(int64_t 
     }
 }
 
+// vector CG1 load vector without atomics: thread per owned node; the cells holding the node are the sources of its
+// diagonal block in the inverse slot table (ascending cell order: the right-hand side - and with it the iteration
+// counts of the elasticity solves - is reproducible)
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_vector_source_gather(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                                                                               const int32_t* __restrict__ sell_col,
+                                                                               const int32_t* __restrict__ gptr,
+                                                                               const int32_t* __restrict__ gsrc,
+                                                                               const int32_t* __restrict__ cells,
+                                                                               const double* __restrict__ xyz4, double fx, double fy,
+                                                                               double fz, coef_dev dv, double* __restrict__ b) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        int64_t e = -1;
+        for (int k = 0; k < width; ++k)
+            if (sell_col[base + (int64_t)k * FS_SLICE] == (int32_t)r) { e = base + (int64_t)k * FS_SLICE; break; }
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (e >= 0) {
+            for (int32_t q = gptr[e]; q < gptr[e + 1]; ++q) {
+                const int32_t sidx = gsrc[q];
+                const int64_t c = sidx >> 4;
+                const int a = (sidx >> 2) & 3;
+                const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+                const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const tet_geom t = tet_geometry(xyz4, v);
+                const double w = t.adet * (1.0 / 24.0);
+                double cd = 0.0;  // int c div v dx = c_cell * vol * grad_a[i]
+                if (dv.mode == FS_COEF_CONST) cd = dv.value;
+                else if (dv.mode == FS_COEF_CELL) cd = dv.data[c];
+                else if (dv.mode == FS_COEF_NODAL) cd = 0.25 * ((dv.data[v[0]] + dv.data[v[1]]) + (dv.data[v[2]] + dv.data[v[3]]));
+                cd *= t.adet * (1.0 / 6.0);
+                const double ga[3] = {a == 0 ? t.g[0][0] : a == 1 ? t.g[1][0] : a == 2 ? t.g[2][0] : t.g[3][0],
+                                      a == 0 ? t.g[0][1] : a == 1 ? t.g[1][1] : a == 2 ? t.g[2][1] : t.g[3][1],
+                                      a == 0 ? t.g[0][2] : a == 1 ? t.g[1][2] : a == 2 ? t.g[2][2] : t.g[3][2]};
+                acc[0] += w * fx + cd * ga[0];
+                acc[1] += w * fy + cd * ga[1];
+                acc[2] += w * fz + cd * ga[2];
+            }
+        }
+        b[3 * r + 0] += acc[0];
+        b[3 * r + 1] += acc[1];
+        b[3 * r + 2] += acc[2];
+    }
+}
+
 extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add) {
     FS_REQUIRE(space && form && b, "fs_assemble_vector: null pointer");
     FS_REQUIRE(b->d.n >= space->n_dofs_owned, "fs_assemble_vector: vector shorter than the owned dofs");
@@ -1239,6 +1287,15 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         // b was zeroed above unless add: the gather kernel adds to what is there either way
         hipLaunchKernelGGL(k_assemble_p1_source_gather<true>, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                            space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, m->cells.p, m->xyz.p, f, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
+    if (space->ncomp == 3 && space->slots.p && !getenv("FS_SOURCE_ATOMIC")) {
+        if (!space->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(space, s));
+        hipLaunchKernelGGL(k_assemble_p1_vector_source_gather, dim3(fs_grid_for(space->n_nodes_owned, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                           space->n_nodes_owned, space->slice_ptr.p, space->sell_col.p, space->gmap_ptr.p, space->gmap_src.p, m->cells.p,
+                           m->xyz.p, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, b->d.p);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
