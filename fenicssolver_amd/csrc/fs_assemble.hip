@@ -381,6 +381,42 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* 
     }
 }
 
+// the same by row gather (lane = row, its cell incidences in ascending order: no atomics, reproducible)
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t n_rows, int64_t n_slices,
+                                                                        const int64_t* __restrict__ inc_slice_ptr,
+                                                                        const int32_t* __restrict__ inc_cell,
+                                                                        const int32_t* __restrict__ cell_dofs,
+                                                                        const int32_t* __restrict__ cells,
+                                                                        const double* __restrict__ xyz4, coef_dev f,
+                                                                        double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q / 10, a = q - 10 * c;
+            const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
+            const tet_geom t = tet_geometry(xyz4, vv);
+            const double vol = t.adet * (1.0 / 6.0);
+            if (f.mode == FS_COEF_NODAL) {
+                double m = 0.0;
+                for (int k = 0; k < 10; ++k) m += FS_P2_MASS420[a][k] * f.data[cell_dofs[(int64_t)c * 10 + k]];
+                acc += m * vol * (1.0 / 420.0);
+            } else {
+                acc += (a < 4 ? -0.05 : 0.2) * (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
+            }
+        }
+        if (row < n_rows) b[row] += acc;
+    }
+}
+
 // P2 boundary load: int g phi_a ds over a facet = g * area / 3 on each of its 3 edge nodes, 0 on the vertices
 __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
                                   const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne,
@@ -1272,7 +1308,12 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     }
     if (space->degree == 2) {
         FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
-        hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
+        if (space->ncomp == 1 && space->inc_cell.p && !getenv("FS_SOURCE_ATOMIC"))
+            hipLaunchKernelGGL(k_assemble_p2_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                               space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
+                               m->xyz.p, f, b->d.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
