@@ -195,6 +195,7 @@ struct fs_space_s {
 struct fs_matrix_s {
     fs_space_s* space = nullptr;
     int bs = 1;                   // block size (ncomp)
+    bool taylor_hood = false;     // bs = 4 values written by fs_assemble_navier_stokes: pressure only on vertex nodes
     dbuf<double> val;             // [sell_entries * bs*bs]; block entry e, (i,j) at ((i*bs+j)*sell_entries + e)
 };
 

@@ -482,6 +482,7 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
             hipLaunchKernelGGL(k_ns_gather, dim3(fs_grid_for(sp->sell_entries * 8, FS_BLOCK, 1 << 18)), dim3(FS_BLOCK), 0, s, sp->sell_entries,
                                sp->gmap_ptr.p, sp->gmap_src.p, sp->elem_buf.p, J->val.p, sp->sell_entries);
     }
+    J->taylor_hood = true;      // lets the operator product skip the structurally empty pressure planes
     hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - m->n_owned)), dim3(FS_BLOCK), 0, s, m->n_owned,
                        sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
     FS_KERNEL_CHECK();
