@@ -680,27 +680,31 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sd_pressure_rows(int64_t nv, const
                                                                const int32_t* __restrict__ sell_col, const double* __restrict__ val,
                                                                int64_t plane, const double* __restrict__ z,
                                                                const double* __restrict__ r, double* __restrict__ rp) {
-    // 16 lanes per row: vertex rows of the CG2 pattern are up to 65 blocks wide and there are few of them (85 184 at
-    // configs[4]) - a thread per row is a chain of 65 dependent loads on a third of the chip (75 us)
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t v = gid >> 4;
-    const int lg = (int)(gid & 15);
-    double acc = 0.0;
-    if (v < nv) {
-        const int64_t sp0 = slice_ptr[v >> 6];
-        const int width = (int)((slice_ptr[(v >> 6) + 1] - sp0) >> 6);
-        const int64_t base = sp0 + (v & 63);
-        for (int k = lg; k < width; k += 16) {
+    // One workgroup per slice of 64 vertex rows, lane = row (every load of a wave is one contiguous 512-byte line of
+    // the slice), the entries of the up to 65-block-wide rows dealt round-robin to the four waves, partial sums through
+    // LDS: a thread per row walks 65 dependent entries on a third of the chip (75 us at configs[4]), 16 lanes per row read
+    // 32 bytes per line (65 us).
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n_sl = (nv + 63) >> 6;
+    for (int64_t s = blockIdx.x; s < n_sl; s += gridDim.x) {
+        const int64_t v = s * 64 + lane;
+        const int64_t sp0 = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - sp0) >> 6);
+        const int64_t base = sp0 + lane;
+        double acc = 0.0;
+        for (int k = w; k < width; k += 4) {
             const int64_t e = base + (int64_t)k * FS_SLICE;
             const int32_t c = sell_col[e];
             if (c < 0) continue;
             const double* zc = z + 4 * (int64_t)c;
             acc += val[12 * plane + e] * zc[0] + val[13 * plane + e] * zc[1] + val[14 * plane + e] * zc[2];
         }
+        part[w][lane] = acc;
+        __syncthreads();
+        if (w == 0 && v < nv) rp[v] = r[4 * v + 3] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+        __syncthreads();
     }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
-    if (lg == 0 && v < nv) rp[v] = r[4 * v + 3] - acc;
 }
 // rp[v] = r[4v+3] - t[4v+3]
 __global__ void k_sd_gather_p(int64_t nv, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ rp) {
@@ -988,7 +992,7 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
     // this rank's diagonal block (ghost columns see zeros) - a non-overlapping additive Schwarz step with the AMG
     // V-cycle / Chebyshev iteration as subdomain solver, no communication inside
     FS_CHECK(fs_halo_exchange_dev(sp, z, s));
-    hipLaunchKernelGGL(k_sd_pressure_rows, dim3((unsigned)((nv * 16 + FS_BLOCK - 1) / FS_BLOCK)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p,
+    hipLaunchKernelGGL(k_sd_pressure_rows, dim3((unsigned)std::min<int64_t>((nv + 63) / 64, 65535)), dim3(FS_BLOCK), 0, s, nv, sp->slice_ptr.p, sp->sell_col.p,
                        J->val.p, sp->sell_entries, z, r, W.rp.d.p);
     FS_KERNEL_CHECK();
     fs_krylov_opts ko;
