@@ -222,6 +222,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
 // against 22.4 ms for the pair-major kernel - neither the redundant flops nor the locality of the lines is the
 // limit, the 544 M device-scope fp64 atomics are (22 G/s: they are resolved behind the per-XCD L2s).  The next
 // step is an owner-computes gather (one wave per matrix row, no atomics), as the P1 scalar path already does.
+// Occupancy: 4 waves per SIMD (127 VGPRs, 20 B of scratch) 5.9 ms; the compiler's own choice 3 waves (137 VGPRs) 6.9 ms;
+// 5 waves (96 VGPRs, 132 B of scratch) 7.2 ms - configs[4], 477 042 cells.
 #define NS_WPB (FS_BLOCK / 64)
 struct ns_cell_lds {
     double phi[14][10];
@@ -234,7 +236,7 @@ struct ns_cell_lds {
     int32_t nd[10];
     int32_t pad[2];
 };
-__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_wave(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
+__global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_assemble_ns_wave(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
                                                                const int32_t* __restrict__ cell_dofs,
                                                                int64_t nc, int64_t n_rows, const int32_t* __restrict__ slots,
                                                                const double* __restrict__ w0, const double* __restrict__ wprev,
