@@ -1004,7 +1004,7 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
         FS_CHECK(spgemm(nn, n_agg, bs, bs, nb, false, L->A.rowptr.p, L->A.col.p, nullptr, L->A.val.p, L->P, bs * nb >= 36 ? FS_BLOCK : 64, &AP, s));
         // few, long output rows on the coarser levels (4 192 rows of ~150 blocks of 6x6 at level 2 of configs[2]): a larger
         // workgroup shortens the serial loop over the products of a row
-        const int wg_rap = n_agg < 32768 ? 1024 : FS_BLOCK;
+        const int wg_rap = n_agg < 32768 ? 1024 : 512;
         FS_CHECK(spgemm(n_agg, n_agg, nb, bs, nb, true, L->pt_ptr.p, L->pt_row.p, L->pt_entry.p, L->P.val.p, AP, wg_rap, &C->A, s));
     }
     amg_tick("  RAP");
