@@ -1071,7 +1071,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     // ill-conditioned operators (the recurrence residual can reach the threshold while b - A x has not):
     // the true residual is recomputed after every pass and, if it misses the tolerance, the solve
     // restarts from the current x (at most 8 passes, iteration budget shared).
-    const int batch = opts->batch > 0 ? opts->batch : g_cg_batch;
+    static const int env_batch = getenv("FS_CG_BATCH") ? atoi(getenv("FS_CG_BATCH")) : 0;
+    const int batch = opts->batch > 0 ? opts->batch : (env_batch > 0 ? env_batch : g_cg_batch);
     // kernel durations (stats->spmv_ms / update_ms: the roofline of bench.py) are sampled with HIP events every
     // sample_every-th iteration, 4 events each.  The markers are not free: on the 1 M-DOF solve (293 iterations of 45 us)
     // sampling every 4th iteration costs 0.87 ms per solve (6 %), every 16th 0.4 ms - the default
