@@ -15,7 +15,7 @@ reported separately as `symbolic_ms`.
 Multi-GPU: z-slab domain decomposition, halo exchange + one 3-double all-reduce per CG
 iteration (fenicssolver_amd/csrc/fs_comm.hip).  Default scaling is WEAK: every GPU
 owns 100 vertex planes of 100x100 (1 M DOF), the bar grows along z and the Dirichlet pair
-sits on the x-faces so the conditioning does not change with N.  `--scaling strong --n 215`
+sits on the x-faces so the conditioning does not change with N.  `--scaling strong --cells 215`
 splits the 10 M-DOF cube instead.
 
 torch is used only for process rendezvous (gloo broadcast of the RCCL unique id and the
@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=99, help="cells per axis of the (per-GPU) cube")
+    # (--cells under torch.distributed.run: its own parser claims every abbreviation of --nnodes / --nproc-per-node)
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=99, help="cells per axis of the (per-GPU) cube")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--bc-axis", type=int, default=None, help="axis of the Dirichlet face pair (default 2 at N=1, 0 at N>1)")
     ap.add_argument("--rtol", type=float, default=1e-8)
