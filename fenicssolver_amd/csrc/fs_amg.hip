@@ -674,6 +674,28 @@ __global__ void k_cheb_next(int64_t n, const double* __restrict__ dinv, const do
         x[i] += v;
     }
 }
+// the same two with the residual r = b - t formed on the fly (level 0: t = A x comes from the SELL product)
+template <bool ADD>
+__global__ void k_cheb_first_bt(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ t,
+                                double* __restrict__ d, double* __restrict__ x, double scale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double v = scale * dinv[i] * (b[i] - t[i]);
+        d[i] = v;
+        x[i] = ADD ? x[i] + v : v;
+    }
+}
+__global__ void k_cheb_next_bt(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ t,
+                               double* __restrict__ d, double* __restrict__ x, double c1, double c2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double v = c1 * d[i] + c2 * dinv[i] * (b[i] - t[i]);
+        d[i] = v;
+        x[i] += v;
+    }
+}
 __global__ void k_amg_sub(int64_t n, const double* __restrict__ b, const double* t, double* r) {   // r may alias t
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1218,17 +1240,28 @@ static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_gues
     double rho = 1.0 / sigma;
     const int g = fs_grid_for(L->n, FS_BLOCK, 2048);
     const double* r = b;
+    const bool fine = l == 0;       // level 0: the product comes from the SELL kernel, b - A x is formed inside the update
     if (!zero_guess) {
-        FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
-        r = L->r.p;
-        hipLaunchKernelGGL(k_cheb_first<true>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, r, L->d.p, x, 1.0 / theta);
+        if (fine) {
+            FS_CHECK(level_spmv(M, l, x, b, L->t.p, 0, s));
+            hipLaunchKernelGGL(k_cheb_first_bt<true>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, b, L->t.p, L->d.p, x, 1.0 / theta);
+        } else {
+            FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
+            r = L->r.p;
+            hipLaunchKernelGGL(k_cheb_first<true>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, r, L->d.p, x, 1.0 / theta);
+        }
     } else {
         hipLaunchKernelGGL(k_cheb_first<false>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, r, L->d.p, x, 1.0 / theta);
     }
     for (int k = 1; k < M->smooth_steps; ++k) {
-        FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
         const double rho_new = 1.0 / (2.0 * sigma - rho);
-        hipLaunchKernelGGL(k_cheb_next, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, L->r.p, L->d.p, x, rho_new * rho, 2.0 * rho_new / delta);
+        if (fine) {
+            FS_CHECK(level_spmv(M, l, x, b, L->t.p, 0, s));
+            hipLaunchKernelGGL(k_cheb_next_bt, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, b, L->t.p, L->d.p, x, rho_new * rho, 2.0 * rho_new / delta);
+        } else {
+            FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
+            hipLaunchKernelGGL(k_cheb_next, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, L->r.p, L->d.p, x, rho_new * rho, 2.0 * rho_new / delta);
+        }
         rho = rho_new;
     }
     return FS_OK;
