@@ -432,3 +432,20 @@ def test_2d_host_data_model_matches_oracle():
     ps = PointSource(V, Point(1.3, 0.45), 2.0)
     assert abs(ps.weights.sum() - 2.0) < 1e-13 and len(ps.dofs) == 3
     assert UnitSquareMesh(40, 40).num_cells() == 3200
+
+
+def test_host_blas_pools_are_capped_under_the_cpu_quota():
+    """Importing the package caps the BLAS pools at half the CPUs the cgroup grants (an uncapped 64-thread OpenBLAS pool
+    spinning under a 16-CPU quota freezes the thread that feeds the GPU: DESIGN.md, Navier-Stokes section)."""
+    import os
+    import fenicssolver_amd
+    n = fenicssolver_amd.granted_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if any(os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")) and \\
+            fenicssolver_amd._thread_pool_limit is None:
+        return                                   # the user chose: nothing to check
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    import numpy  # noqa: F401
+    for pool in threadpoolctl.threadpool_info():
+        if pool.get("user_api") == "blas":
+            assert pool["num_threads"] <= max(1, n // 2)
