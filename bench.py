@@ -10,7 +10,8 @@ reported separately as `symbolic_ms`.
 
   python bench.py                       # N=1: BASELINE.json configs[1], 1 M DOF unit cube
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU (RCCL)
+         --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU (RCCL); the driver's launcher
+  python -m fenicssolver_amd.launch --nproc N bench.py --gpus N      # the package's own launcher, same environment
 
 Multi-GPU: z-slab domain decomposition, halo exchange + one 3-double all-reduce per CG
 iteration (fenicssolver_amd/csrc/fs_comm.hip).  Default scaling is WEAK: every GPU
@@ -18,8 +19,13 @@ owns 100 vertex planes of 100x100 (1 M DOF), the bar grows along z and the Diric
 sits on the x-faces so the conditioning does not change with N.  `--scaling strong --cells 215`
 splits the 10 M-DOF cube instead.
 
-torch is used only for process rendezvous (gloo broadcast of the RCCL unique id and the
-timing barrier); all compute is libfsamd.so.
+bench.py imports no torch: the launcher only has to export RANK / WORLD_SIZE / LOCAL_RANK; the RCCL unique id travels
+through fenicssolver_amd/rendezvous.py and the timing barrier / max-over-ranks run over the communicator itself.
+
+The JSON line's `roofline` is the dominant kernel (the SpMV fused with the CG dot products) measured on the
+HBM-RESIDENT 10 M-DOF problem of the same family; the same kernel on the 1 M-DOF step workload runs out of the
+256 MiB Infinity Cache, so its byte rate is reported separately (`dominant_kernel_on_step_workload`) and is not an
+HBM fraction.
 """
 import argparse
 import json
@@ -32,8 +38,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fenicssolver_amd import backend as B  # noqa: E402  (loads libfsamd.so before torch)
-from fenicssolver_amd import partition  # noqa: E402
+from fenicssolver_amd import backend as B  # noqa: E402
+from fenicssolver_amd import partition, parallel  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
@@ -93,61 +99,68 @@ class Problem:
         return st, (t1 - t0) * 1e3
 
 
-def roofline_of(st, V, traffic=None):
-    """Dominant kernel = the SpMV fused with the CG dots.  `achieved` uses the ALGORITHMIC bytes of a CSR
-    SpMV (nnz*12 + n*20); `streamed_bytes_per_launch` is what the hybrid SELL/DIA storage
-    really has to move (values + columns of SELL slices only + z, r reads + w write)."""
-    ms = st["spmv_ms"]
-    achieved = st["spmv_bytes"] / ms / 1e6 if ms > 0 else 0.0
-    streamed = V.spmv_matrix_bytes + 24 * V.n_owned
+def kernel_name(V):
     nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
-    return {"kernel": "k_sell_spmv<1,3,%d,%s> (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; "
-                      "template arguments: block size, dot mode, entries per round and non-temporal matrix loads - the last two "
-                      "chosen by problem size)" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false"),
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": st["spmv_bytes"], "avg_launch_ms": round(ms, 5),
-            "streamed_bytes_per_launch": streamed, "streamed_GBps": round(streamed / ms / 1e6, 1) if ms > 0 else 0.0,
-            "dia_slices": V.n_dia_slices, "slices": V.n_slices,
-            "note": ("achieved = ALGORITHMIC CSR bytes / mean kernel time (HIP events, every 16th iteration of the timed solves). "
-                     + ("At this size the matrix and the vectors (streamed_bytes_per_launch) stay in the 256 MiB Infinity Cache "
-                        "between iterations and the DIA slices stream no column indices, so the figure is not an HBM rate and can "
-                        "exceed the HBM peak; roofline_hbm_resident is the same kernel on a 10 M-DOF problem."
-                        if streamed < (256 << 20) else "HBM-resident problem: the matrix is re-read from HBM every iteration."))}
+    return "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
+
+
+def kernel_rates(st, V):
+    """Byte rates of the dominant kernel = the hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally
+    scaled CG.  ALGORITHMIC bytes are those of a CSR SpMV (nnz*12 + n*20); streamed bytes are what
+    the hybrid storage really has to move (values + column indices of SELL slices only + z, d reads + w write).
+    Time = mean duration of the live launches sampled with HIP events on the library's stream inside the timed solves."""
+    ms = st["spmv_ms"]
+    streamed = V.spmv_matrix_bytes + 24 * V.n_owned
+    return {"kernel": kernel_name(V), "avg_launch_ms": round(ms, 5),
+            "algorithmic_bytes_per_launch": st["spmv_bytes"],
+            "algorithmic_GBps": round(st["spmv_bytes"] / ms / 1e6, 1) if ms > 0 else 0.0,
+            "streamed_bytes_per_launch": streamed,
+            "streamed_GBps": round(streamed / ms / 1e6, 1) if ms > 0 else 0.0,
+            "dia_slices": V.n_dia_slices, "slices": V.n_slices}
 
 
 def committed_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc.json, collected with tools/collect_profiles.sh on the same command)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as fh:
-            return json.load(fh).get(tag)
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
+    newest round first; collected on the same command in separate --pmc runs).  Not measured in this run."""
+    for name in ("r02_pmc.json", "r01_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                v = json.load(fh).get(tag)
+            if v is not None:
+                return v, "profiles/" + name
+        except Exception:
+            pass
+    return None, None
+
+
+def make_roofline(k, workload, traffic, traffic_source):
+    frac = k["algorithmic_GBps"] / HBM_PEAK_GBS
+    r = {"kernel": k["kernel"] + " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template "
+                                 "arguments: block size, dot mode, entries per round, non-temporal matrix loads)",
+         "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 3),
+         "traffic": traffic,
+         "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; NOT measured in this run)" % traffic_source)
+                           if traffic is not None else None,
+         "workload": workload,
+         "note": "achieved = algorithmic CSR bytes (nnz*12 + n*20, SURVEY 8d) / avg_launch_ms; avg_launch_ms = mean of the LIVE "
+                 "launches sampled with HIP events (every 16th iteration of the timed solve) on the library's stream"}
+    r.update({kk: k[kk] for kk in ("avg_launch_ms", "algorithmic_bytes_per_launch", "streamed_bytes_per_launch", "streamed_GBps",
+                                   "dia_slices", "slices")})
+    return r
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, _ = parallel.world()
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+            sys.exit("bench.py --gpus %d needs one rank per GPU: python -m fenicssolver_amd.launch --nproc %d bench.py --gpus %d "
+                     "(or torch.distributed.run)" % (a.gpus, a.gpus, a.gpus))
         a.gpus = world
-    B.init(local_rank if world > 1 else 0)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # rendezvous only
-        dist.init_process_group("gloo")
-        uid = [B.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        B.comm_init(world, rank, uid[0])
+    parallel.ensure_comm()      # binds LOCAL_RANK's GPU; N>1: rendezvous of the RCCL id + ncclCommInitRank
 
     def barrier():
-        B.synchronize()
-        if dist is not None:
-            dist.barrier()
+        parallel.barrier()      # device sync + (N>1) a 1-double all-reduce over RCCL
         B.synchronize()
 
     n = a.n
@@ -175,12 +188,7 @@ def main():
         stats, t_asm = prob.step(a.rtol)
         asm_ms += t_asm
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed * 1e3 / a.steps
 
     out = None
@@ -203,13 +211,24 @@ def main():
             "solve_ms_per_step": round(ms_per_step - asm_ms / a.steps, 4),
             "symbolic_ms": round(prob.symbolic_ms, 3), "mesh_ms": round(prob.mesh_ms, 3),
             "update_kernel_ms": round(stats["update_ms"], 5),
-            "roofline": roofline_of(stats, prob.V, committed_traffic("spmv_fused_n%d" % n) if world == 1 else None),
         }
+        step_kernel = kernel_rates(stats, prob.V)
+        hbm_resident = step_kernel["streamed_bytes_per_launch"] > (256 << 20)
+        if hbm_resident:
+            out["roofline"] = make_roofline(step_kernel, "the step workload itself (rank 0's part)", None, None)
+        else:
+            step_kernel["note"] = ("the matrix and vectors this kernel streams (streamed_bytes_per_launch) stay in the 256 MiB "
+                                   "Infinity Cache between iterations: these are cache rates, not an HBM roofline fraction")
+            out["dominant_kernel_on_step_workload"] = step_kernel
+            if world > 1 or a.no_hbm_case:   # no HBM-resident side measurement: the part of a GPU is cache-resident by construction
+                out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                   "note": "1 M DOF per GPU stays in the Infinity Cache: see dominant_kernel_on_step_workload for the "
+                                           "cache rates; the HBM roofline of this kernel is measured by the default N=1 run (10 M DOF)"}
 
     if world == 1:
         x_gpu = prob.x.get()
-        # --- extra: the same path at 10 M DOF, where nothing fits the 256 MiB Infinity Cache ---
-        if not a.no_hbm_case and n < 200:
+        # --- the dominant kernel on an HBM-resident problem of the same family (10 M DOF): the roofline of the line ---
+        if not a.no_hbm_case and "roofline" not in out:
             del prob
             big = Problem(215, 215, 215, (1.0, 1.0, 1.0), (0, 216), axis, 0, 1)
             big.step(a.rtol)
@@ -217,17 +236,14 @@ def main():
             st_big, asm_big = big.step(a.rtol)
             B.synchronize()
             t_big = time.perf_counter() - t0
-            r = roofline_of(st_big, big.V, committed_traffic("spmv_fused_n215"))
-            # The events bracket single launches and let the stores of the preceding update kernel drain before the timed
-            # SpMV starts; inside the loop that drain is part of the SpMV (the rocprofv3 trace, without markers, shows it:
-            # ~8 % longer at this size).  in_loop_ms bounds the unperturbed duration from above with the solve time itself.
-            in_loop = st_big["solve_ms"] / max(st_big["iterations"], 1) - st_big["update_ms"] - 0.0042
-            r.update({"in_loop_ms_upper_bound": round(in_loop, 5),
-                      "in_loop_frac_lower_bound": round(st_big["spmv_bytes"] / in_loop / 1e6 / HBM_PEAK_GBS, 4)})
-            r.update({"workload": "same path, unit cube n=215, %d DOF (HBM-resident)" % big.n_owned,
-                      "dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
-                      "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3)})
-            out["roofline_hbm_resident"] = r
+            traffic, src = committed_traffic("spmv_fused_n215")
+            r = make_roofline(kernel_rates(st_big, big.V), "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per "
+                              "launch)" % (big.n_owned, (big.V.spmv_matrix_bytes + 24 * big.n_owned) / 1e9), traffic, src)
+            r.update({"dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
+                      "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3),
+                      "update_kernel_ms": round(st_big["update_ms"], 5),
+                      "iteration_ms": round(st_big["solve_ms"] / max(st_big["iterations"], 1), 5)})
+            out["roofline"] = r
             del big
         # --- CPU baseline: the oracle's C restatement of the reference's CPU path, same workload ---
         if not a.no_cpu_baseline:
@@ -257,10 +273,10 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
             # north_star target: >= 10x the host-CPU path on the 10 M-DOF solve.  Timed only when the
             # calibration says the pass stays within ~40 s of host time.
-            if "roofline_hbm_resident" in out and cpu_s * 10.1 * (451.0 / max(ref["iterations"], 1)) < 40.0:
+            if out["roofline"].get("dof_per_s") and cpu_s * 10.1 * (451.0 / max(ref["iterations"], 1)) < 40.0:
                 big_ref = c_oracle.heat_box_solve(215, 215, 215, axis=axis, rtol=a.rtol)
                 t_big_cpu = big_ref["t_assemble"] + big_ref["t_solve"]
-                hb = out["roofline_hbm_resident"]
+                hb = out["roofline"]
                 hb["cpu_baseline"] = {"value": round(216 ** 3 / t_big_cpu, 1), "unit": "DOF/s", "cores": big_ref["threads"],
                                       "kind": "port", "iterations": big_ref["iterations"],
                                       "sample": "the 10 M-DOF workload once (assemble %.2f s + PCG %.2f s)" % (
@@ -268,10 +284,8 @@ def main():
                 hb["speedup_vs_cpu_baseline"] = round(hb["dof_per_s"] / hb["cpu_baseline"]["value"], 2)
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        B.comm_finalize()
-        dist.destroy_process_group()
+    parallel.barrier()
+    parallel.finalize()
 
 
 if __name__ == "__main__":

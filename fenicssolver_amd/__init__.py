@@ -37,7 +37,7 @@ def _limit_host_thread_pools():
     pools are capped at half the granted CPUs unless the user has already chosen (OMP/OPENBLAS/MKL_NUM_THREADS)."""
     if any(_os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "FS_KEEP_THREAD_POOLS")):
         return None
-    # one process per GPU: the ranks of a node share the quota (torchrun exports LOCAL_WORLD_SIZE)
+    # one process per GPU: the ranks of a node share the quota (the launcher exports LOCAL_WORLD_SIZE)
     ranks = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
     limit = max(1, granted_cpus() // (2 * ranks))
     _os.environ.setdefault("OPENBLAS_NUM_THREADS", str(limit))     # BLAS libraries loaded from here on (scipy's own copy)

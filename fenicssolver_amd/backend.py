@@ -18,10 +18,6 @@ from ._lib import BackendError  # noqa: F401  (re-export)
 
 
 def init(device_id=0):
-    # FS_DEVICE pins every rank to one device: test-only (several ranks sharing a GPU, if RCCL accepts it)
-    import os
-    if os.environ.get("FS_DEVICE", "") != "":
-        device_id = int(os.environ["FS_DEVICE"])
     L.check(L.load().fs_init(int(device_id)), "fs_init")
 
 
@@ -509,6 +505,13 @@ def comm_init(n_ranks, rank, uid):
     L.check(L.load().fs_comm_init(int(n_ranks), int(rank), C.c_char_p(uid)), "fs_comm_init")
 
 
+def comm_info():
+    """(n_ranks, rank) of the communicator that is up ((1, 0) without one)."""
+    n, r = C.c_int(1), C.c_int(0)
+    L.check(L.load().fs_comm_info(C.byref(n), C.byref(r)), "fs_comm_info")
+    return n.value, r.value
+
+
 def comm_finalize():
     L.check(L.load().fs_comm_finalize(), "fs_comm_finalize")
 
@@ -522,7 +525,7 @@ def comm_allreduce_sum(values):
 def comm_allgather(values, n_max):
     """[n_ranks, n_max]: every rank's values (padded to n_max), one ncclAllGather."""
     v = L.f64(values).ravel()
-    n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
+    n_ranks = comm_info()[0]
     out = np.empty((n_ranks, int(n_max)))
     L.check(L.load().fs_comm_allgather(L.p_f64(v), v.size, int(n_max), L.p_f64(out)), "fs_comm_allgather")
     return out

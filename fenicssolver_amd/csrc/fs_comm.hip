@@ -15,12 +15,6 @@
 #include <algorithm>
 #include <dlfcn.h>
 #include <stdlib.h>
-#include <atomic>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <unistd.h>
-#include <sys/stat.h>
-#include <time.h>
 #include <rccl/rccl.h>
 
 struct rccl_api {
@@ -40,8 +34,9 @@ static rccl_api g_nccl;
 
 static int rccl_load() {
     if (g_nccl.handle) return FS_OK;
-    // Prefer the RCCL of the ROCm install this library's HIP runtime comes from; a process that has
-    // imported torch also carries torch's bundled copy under the same SONAME.  FS_RCCL_PATH overrides.
+    // Prefer the RCCL of the ROCm install this library's HIP runtime comes from (a host process may carry another
+    // copy under the same SONAME).  FS_RCCL_PATH names a specific library (a site build of RCCL; the test suite
+    // points it at tests/shim/libfakerccl.so to run several ranks on one GPU).
     const char* names[] = {getenv("FS_RCCL_PATH"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void* h = nullptr;
     for (const char* nm : names) {
@@ -74,57 +69,6 @@ static int rccl_load() {
     return FS_OK;
 }
 
-// ---- test transport: host-staged exchange through POSIX shared memory ---------------------------------------
-// FS_COMM_TRANSPORT=shm replaces the RCCL calls by device<->host copies and a shared-memory mailbox, so that
-// SEVERAL RANKS CAN SHARE ONE GPU (RCCL refuses duplicate devices).  It exists to run the complete distributed
-// algorithm - partition, halo packing, ghost layout, fused dots + all-reduce, restarts - on the 1-GPU test
-// boxes; it is slow by construction and never selected unless the variable is set.
-struct shm_header {
-    std::atomic<int> arrive;
-    std::atomic<int> generation;
-};
-struct shm_comm {
-    int fd = -1;
-    char* base = nullptr;
-    size_t bytes = 0;
-    int n_ranks = 1, rank = 0;
-    char name[64] = {0};
-    static constexpr int64_t PAIR_CAP = 1 << 18;   // doubles per (src,dst) halo buffer (pages are touched only when used)
-    static constexpr int RED_CAP = 8192;           // doubles per rank in the reduction mailbox (longer vectors go in rounds)
-    shm_header* hdr() { return (shm_header*)base; }
-    double* red(int r) { return (double*)(base + 4096) + (size_t)r * RED_CAP; }
-    double* pair(int src, int dst) {
-        return (double*)(base + 4096 + (size_t)n_ranks * RED_CAP * 8) + ((size_t)src * n_ranks + dst) * PAIR_CAP;
-    }
-    static size_t size_for(int n) { return 4096 + (size_t)n * RED_CAP * 8 + (size_t)n * n * PAIR_CAP * 8; }
-    void barrier() {
-        shm_header* h = hdr();
-        const int gen = h->generation.load(std::memory_order_acquire);
-        if (h->arrive.fetch_add(1, std::memory_order_acq_rel) == n_ranks - 1) {
-            h->arrive.store(0, std::memory_order_relaxed);
-            h->generation.store(gen + 1, std::memory_order_release);
-        } else {
-            while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
-        }
-    }
-};
-static bool g_use_shm() {
-    const char* t = getenv("FS_COMM_TRANSPORT");
-    return t && !strcmp(t, "shm");
-}
-static shm_comm* g_shm = nullptr;
-
-static int shm_open_segment(shm_comm* c, bool create) {
-    c->bytes = shm_comm::size_for(c->n_ranks);
-    c->fd = shm_open(c->name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
-    if (c->fd < 0) { fs_set_error("shm transport: shm_open(%s) failed", c->name); return FS_ERR_COMM; }
-    if (create && ftruncate(c->fd, (off_t)c->bytes) != 0) { fs_set_error("shm transport: ftruncate failed"); return FS_ERR_COMM; }
-    void* p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
-    if (p == MAP_FAILED) { fs_set_error("shm transport: mmap of %zu bytes failed", c->bytes); return FS_ERR_COMM; }
-    c->base = (char*)p;
-    return FS_OK;
-}
-
 #define FS_NCCL(call)                                                                          \
     do {                                                                                       \
         ncclResult_t r__ = (call);                                                             \
@@ -138,11 +82,6 @@ static_assert(sizeof(ncclUniqueId) == FS_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
 extern "C" int fs_comm_get_unique_id(char id[FS_UNIQUE_ID_BYTES]) {
     FS_CHECK(fs_require_init());
-    if (g_use_shm()) {     // the id is the name of the segment; it is created by fs_comm_init of rank 0
-        memset(id, 0, FS_UNIQUE_ID_BYTES);
-        snprintf(id, 64, "/fsamd_%d_%ld", (int)getpid(), (long)time(nullptr));
-        return FS_OK;
-    }
     FS_CHECK(rccl_load());
     ncclUniqueId uid;
     FS_NCCL(g_nccl.GetUniqueId(&uid));
@@ -155,41 +94,6 @@ extern "C" int fs_comm_init(int n_ranks, int rank, const char id[FS_UNIQUE_ID_BY
     FS_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks && id, "fs_comm_init: bad rank %d of %d", rank, n_ranks);
     fs_runtime& rt = fs_rt();
     FS_REQUIRE(rt.comm == nullptr, "fs_comm_init: communicator already initialised");
-    if (g_use_shm()) {
-        FS_REQUIRE(n_ranks <= 4, "shm test transport: at most 4 ranks");
-        shm_comm* c = new shm_comm();
-        c->n_ranks = n_ranks; c->rank = rank;
-        strncpy(c->name, id, 63);
-        // rank 0 creates and zeroes the segment, the others wait until it exists with its full size
-        int rc = FS_ERR_COMM;
-        if (rank == 0) {
-            rc = shm_open_segment(c, true);
-            if (rc == FS_OK) { c->hdr()->arrive.store(0); c->hdr()->generation.store(1000); }
-        } else {
-            for (int tries = 0; tries < 20000 && rc != FS_OK; ++tries) {
-                c->fd = shm_open(c->name, O_RDWR, 0600);
-                if (c->fd >= 0) {
-                    struct stat st;
-                    if (fstat(c->fd, &st) == 0 && (size_t)st.st_size == shm_comm::size_for(n_ranks)) {
-                        close(c->fd);
-                        rc = shm_open_segment(c, false);
-                        if (rc == FS_OK)
-                            while (c->hdr()->generation.load() < 1000) usleep(100);
-                        break;
-                    }
-                    close(c->fd);
-                }
-                usleep(500);
-            }
-        }
-        if (rc != FS_OK) { delete c; if (rc == FS_ERR_COMM && !*fs_last_error()) fs_set_error("shm transport: rendezvous failed"); return rc; }
-        g_shm = c;
-        rt.comm = (void*)c;
-        rt.n_ranks = n_ranks;
-        rt.rank = rank;
-        c->barrier();
-        return FS_OK;
-    }
     FS_CHECK(rccl_load());
     ncclUniqueId uid;
     memcpy(&uid, id, FS_UNIQUE_ID_BYTES);
@@ -209,16 +113,7 @@ extern "C" int fs_comm_info(int* n_ranks, int* rank) {
 
 extern "C" int fs_comm_finalize(void) {
     fs_runtime& rt = fs_rt();
-    if (rt.comm && g_shm) {
-        (void)hipStreamSynchronize(rt.stream);
-        g_shm->barrier();
-        munmap(g_shm->base, g_shm->bytes);
-        close(g_shm->fd);
-        if (g_shm->rank == 0) shm_unlink(g_shm->name);
-        delete g_shm;
-        g_shm = nullptr;
-        rt.comm = nullptr;
-    } else if (rt.comm) {
+    if (rt.comm) {
         (void)hipStreamSynchronize(rt.stream);
         FS_NCCL(g_nccl.CommDestroy((ncclComm_t)rt.comm));
         rt.comm = nullptr;
@@ -231,25 +126,6 @@ extern "C" int fs_comm_finalize(void) {
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     if (!rt.comm) return FS_OK;  // one rank
-    if (g_shm) {
-        std::vector<double> h((size_t)n);
-        FS_HIP(hipMemcpyAsync(h.data(), d_inout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-        FS_HIP(hipStreamSynchronize(s));
-        for (int64_t off = 0; off < n; off += shm_comm::RED_CAP) {
-            const int m = (int)std::min<int64_t>(shm_comm::RED_CAP, n - off);
-            memcpy(g_shm->red(g_shm->rank), h.data() + off, (size_t)m * sizeof(double));
-            g_shm->barrier();
-            for (int i = 0; i < m; ++i) {
-                double acc = 0.0;
-                for (int r = 0; r < g_shm->n_ranks; ++r) acc += g_shm->red(r)[i];   // rank order: same bits everywhere
-                h[off + i] = acc;
-            }
-            g_shm->barrier();
-        }
-        FS_HIP(hipMemcpyAsync(d_inout, h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-        FS_HIP(hipStreamSynchronize(s));
-        return FS_OK;
-    }
     FS_NCCL(g_nccl.AllReduce(d_inout, d_inout, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)rt.comm, s));
     return FS_OK;
 }
@@ -278,18 +154,6 @@ extern "C" int fs_comm_allgather(const double* host_send, int64_t n_send, int64_
         return FS_OK;
     }
     const int nr = rt.n_ranks;
-    if (g_shm) {
-        // test transport: rounds of RED_CAP doubles per rank through the reduction mailbox
-        for (int64_t off = 0; off < n_max; off += shm_comm::RED_CAP) {
-            const int64_t m = std::min<int64_t>(shm_comm::RED_CAP, n_max - off);
-            const int64_t mine = std::max<int64_t>(0, std::min<int64_t>(m, n_send - off));
-            if (mine > 0) memcpy(g_shm->red(g_shm->rank), host_send + off, (size_t)mine * sizeof(double));
-            g_shm->barrier();
-            for (int r = 0; r < nr; ++r) memcpy(host_recv + (int64_t)r * n_max + off, g_shm->red(r), (size_t)m * sizeof(double));
-            g_shm->barrier();
-        }
-        return FS_OK;
-    }
     hipStream_t s = rt.stream;
     dbuf<double> ds, dr;
     FS_CHECK(ds.alloc(std::max<int64_t>(n_max, 1)));
@@ -317,6 +181,59 @@ __global__ void k_unpack(double* __restrict__ v, const int32_t* __restrict__ idx
 
 static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
                          const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
+
+// Interior / boundary split of the owned rows, at the granularity the SpMV works at (slices of 64 rows): a slice is a
+// BOUNDARY slice if any of its structural entries names a ghost column.  Interior slices are multiplied while the
+// halo is in flight, boundary slices after it (fs_krylov.hip, spmv_overlapped).  Both lists keep the processing
+// order of the space (slice_order), so the XCD-contiguous sweep is unchanged.
+__global__ void __launch_bounds__(FS_BLOCK) k_slice_has_ghost(int64_t n_slices, int64_t n_owned_nodes,
+                                                              const int64_t* __restrict__ slice_ptr,
+                                                              const int32_t* __restrict__ sell_col, int32_t* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t base = slice_ptr[s] + lane;
+        const int width = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
+        int g = 0;
+        for (int k = 0; k < width; ++k) g |= sell_col[base + (int64_t)k * FS_SLICE] >= n_owned_nodes;
+        const unsigned long long any = __ballot(g);
+        if (lane == 0) flag[s] = any != 0ull;
+    }
+}
+
+static int build_slice_split(fs_space_s* sp) {
+    fs_halo_plan& h = sp->halo;
+    hipStream_t s = fs_rt().stream;
+    h.interior.release();
+    h.boundary.release();
+    h.n_interior = h.n_boundary = 0;
+    const int64_t ns = sp->n_slices;
+    if (ns == 0) return FS_OK;
+    dbuf<int32_t> flag;
+    FS_CHECK(flag.alloc(ns));
+    hipLaunchKernelGGL(k_slice_has_ghost, dim3(fs_grid_for(ns * 64)), dim3(FS_BLOCK), 0, s, ns, sp->n_nodes_owned,
+                       sp->slice_ptr.p, sp->sell_col.p, flag.p);
+    FS_KERNEL_CHECK();
+    std::vector<int32_t> hf((size_t)ns), order;
+    FS_CHECK(flag.download(hf.data(), ns, s));
+    if (sp->slice_order.p) {
+        order.resize((size_t)ns);
+        FS_CHECK(sp->slice_order.download(order.data(), ns, s));
+    }
+    std::vector<int32_t> in, bd;
+    for (int64_t q = 0; q < ns; ++q) {
+        const int32_t sl = order.empty() ? (int32_t)q : order[(size_t)q];
+        (hf[(size_t)sl] ? bd : in).push_back(sl);
+    }
+    h.n_interior = (int64_t)in.size();
+    h.n_boundary = (int64_t)bd.size();
+    FS_CHECK(h.interior.alloc(std::max<int64_t>(h.n_interior, 1)));
+    FS_CHECK(h.boundary.alloc(std::max<int64_t>(h.n_boundary, 1)));
+    FS_CHECK(h.interior.upload(in.data(), h.n_interior, s));
+    FS_CHECK(h.boundary.upload(bd.data(), h.n_boundary, s));
+    return FS_OK;
+}
 
 extern "C" int fs_space_set_halo_indexed(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks,
                                          const int64_t* send_counts, const int32_t* send_idx, const int64_t* recv_counts,
@@ -377,17 +294,27 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
         FS_CHECK(h.recv_buf.alloc(ro));
         FS_CHECK(h.recv_idx.upload(recv_idx, ro, fs_rt().stream));
     }
+    FS_CHECK(build_slice_split(space));
     h.active = true;
     return FS_OK;
 }
 
-int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
+// The exchange is split in two so that the rows that need no ghost value can be multiplied while it is in flight
+// (SURVEY section 8e):  begin = pack on the compute stream, then grouped ncclSend/ncclRecv (+ scatter of an indexed
+// halo) on the library's COMMUNICATION stream behind an event;  end = the compute stream waits for that stream.
+// Only device-side dependencies: the host never blocks.
+int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
     fs_halo_plan& h = space->halo;
     if (!h.active) return FS_OK;
     fs_runtime& rt = fs_rt();
     if (!rt.comm) {
         fs_set_error("halo exchange requested but no communicator is up (call fs_comm_init)");
         return FS_ERR_COMM;
+    }
+    if (!h.comm_stream) {
+        FS_HIP(hipStreamCreateWithFlags(&h.comm_stream, hipStreamNonBlocking));
+        FS_HIP(hipEventCreateWithFlags(&h.ev_ready, hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&h.ev_done, hipEventDisableTiming));
     }
     const int nn = (int)h.neighbors.size();
     for (int i = 0; i < nn; ++i) {
@@ -397,43 +324,39 @@ int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
         }
     }
     FS_KERNEL_CHECK();
+    hipStream_t cs = h.comm_stream;
+    FS_HIP(hipEventRecord(h.ev_ready, s));
+    FS_HIP(hipStreamWaitEvent(cs, h.ev_ready, 0));
     double* ghosts = d_vec + space->n_dofs_owned;
-    if (g_shm) {
-        FS_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < nn; ++i) {
-            if (h.send_counts[i] == 0) continue;
-            FS_REQUIRE(h.send_counts[i] <= shm_comm::PAIR_CAP, "shm test transport: halo of %lld values", (long long)h.send_counts[i]);
-            const double* src = h.send_contiguous[i] ? d_vec + h.send_first[i] : h.send_buf.p + h.send_offsets[i];
-            FS_HIP(hipMemcpy(g_shm->pair(g_shm->rank, h.neighbors[i]), src, (size_t)h.send_counts[i] * sizeof(double), hipMemcpyDeviceToHost));
-        }
-        g_shm->barrier();
-        double* rbase = h.recv_idx.p ? h.recv_buf.p : ghosts;
-        for (int i = 0; i < nn; ++i)
-            if (h.recv_counts[i] > 0)
-                FS_HIP(hipMemcpy(rbase + h.recv_offsets[i], g_shm->pair(h.neighbors[i], g_shm->rank), (size_t)h.recv_counts[i] * sizeof(double), hipMemcpyHostToDevice));
-        g_shm->barrier();
-        if (h.recv_idx.p && h.total_recv > 0) {
-            hipLaunchKernelGGL(k_unpack, dim3(fs_grid_for(h.total_recv)), dim3(FS_BLOCK), 0, s, d_vec, h.recv_idx.p, h.total_recv, h.recv_buf.p);
-            FS_KERNEL_CHECK();
-        }
-        return FS_OK;
-    }
     FS_NCCL(g_nccl.GroupStart());
     for (int i = 0; i < nn; ++i) {
         if (h.send_counts[i] > 0) {
             const double* src = h.send_contiguous[i] ? d_vec + h.send_first[i] : h.send_buf.p + h.send_offsets[i];
-            FS_NCCL(g_nccl.Send(src, (size_t)h.send_counts[i], ncclDouble, h.neighbors[i], (ncclComm_t)rt.comm, s));
+            FS_NCCL(g_nccl.Send(src, (size_t)h.send_counts[i], ncclDouble, h.neighbors[i], (ncclComm_t)rt.comm, cs));
         }
         if (h.recv_counts[i] > 0)
             FS_NCCL(g_nccl.Recv((h.recv_idx.p ? h.recv_buf.p : ghosts) + h.recv_offsets[i], (size_t)h.recv_counts[i], ncclDouble,
-                                h.neighbors[i], (ncclComm_t)rt.comm, s));
+                                h.neighbors[i], (ncclComm_t)rt.comm, cs));
     }
     FS_NCCL(g_nccl.GroupEnd());
     if (h.recv_idx.p && h.total_recv > 0) {
-        hipLaunchKernelGGL(k_unpack, dim3(fs_grid_for(h.total_recv)), dim3(FS_BLOCK), 0, s, d_vec, h.recv_idx.p, h.total_recv, h.recv_buf.p);
+        hipLaunchKernelGGL(k_unpack, dim3(fs_grid_for(h.total_recv)), dim3(FS_BLOCK), 0, cs, d_vec, h.recv_idx.p, h.total_recv, h.recv_buf.p);
         FS_KERNEL_CHECK();
     }
+    FS_HIP(hipEventRecord(h.ev_done, cs));
     return FS_OK;
+}
+
+int fs_halo_end_dev(fs_space_s* space, hipStream_t s) {
+    fs_halo_plan& h = space->halo;
+    if (!h.active) return FS_OK;
+    FS_HIP(hipStreamWaitEvent(s, h.ev_done, 0));
+    return FS_OK;
+}
+
+int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
+    FS_CHECK(fs_halo_begin_dev(space, d_vec, s));
+    return fs_halo_end_dev(space, s);
 }
 
 extern "C" int fs_halo_exchange(fs_space_t space, fs_vector_t v) {

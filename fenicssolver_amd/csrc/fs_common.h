@@ -126,6 +126,17 @@ struct fs_halo_plan {
     dbuf<int32_t> recv_idx;                // optional scatter list (local dof of every received value)
     dbuf<double> recv_buf;
     int64_t total_send = 0, total_recv = 0;
+    // overlap of the exchange with the interior rows: the grouped send/recv runs on comm_stream between two events
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    // slices (in processing order) without / with ghost columns
+    dbuf<int32_t> interior, boundary;
+    int64_t n_interior = 0, n_boundary = 0;
+    ~fs_halo_plan() {
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    }
 };
 
 struct fs_space_s {
@@ -219,6 +230,9 @@ int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
 // inverse of the slot table: sources (cell*nd*nd + ab) of every stored block, ascending (gmap_ptr / gmap_src)
 int fs_space_build_gather_map(fs_space_s* space, hipStream_t s);
 int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s);
+// the same in two halves: begin = pack + send/recv on the communication stream, end = compute stream waits for it
+int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s);
+int fs_halo_end_dev(fs_space_s* space, hipStream_t s);
 // fs_krylov.hip: bare y = A x on the library stream, no halo exchange, no synchronisation.
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 // fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.

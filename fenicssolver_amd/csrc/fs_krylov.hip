@@ -93,7 +93,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                                                         const double* __restrict__ rvec,
                                                         double* __restrict__ partials,
                                                         const int* __restrict__ status,
-                                                        const int32_t* __restrict__ order) {
+                                                        const int32_t* __restrict__ order,
+                                                        int part_base, int part_stride) {
+    // part_base / part_stride: where this launch's per-workgroup dot partials go (partials[j*stride + base + wg]);
+    // a product split into an interior and a boundary launch fills one array of stride = both grids
     if (DOTS) {
         if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
     }
@@ -189,9 +192,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
         const double t1 = fs_block_sum(d_wz, lds4);
         const double t2 = fs_block_sum(d_rr, lds4);
         if (threadIdx.x == 0) {
-            partials[blockIdx.x] = t0;
-            partials[gridDim.x + blockIdx.x] = t1;
-            partials[2 * gridDim.x + blockIdx.x] = t2;
+            partials[part_base + blockIdx.x] = t0;
+            partials[part_stride + part_base + blockIdx.x] = t1;
+            partials[2 * part_stride + part_base + blockIdx.x] = t2;
         }
     }
 }
@@ -727,21 +730,28 @@ static bool spmv_nontemporal(const fs_space_s* sp, int bs) {
     if (e) return e[0] == '1';
     return sp->sell_entries * (int64_t)bs * bs * 8 > (int64_t)192 << 20;
 }
-static int spmv_grid(int64_t n_slices) {
+static int spmv_grid(int64_t n_slices, int64_t n_slices_matrix) {
     const int64_t n_chunks = (n_slices + 3) / 4;
-    const int64_t blocks = spmv_blocks_for(n_slices);
+    const int64_t blocks = spmv_blocks_for(n_slices_matrix);
     int64_t g = n_chunks < blocks ? n_chunks : blocks;
     g = (g + 7) & ~(int64_t)7;  // multiple of 8 for the XCD mapping
     return (int)g;
 }
 
+// `list` / `n_list`: multiply only these slices (the interior or the boundary slices of a decomposed space, in
+// processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
 static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
-                        const int* status, hipStream_t s, const double* val_override = nullptr) {
+                        const int* status, hipStream_t s, const double* val_override = nullptr,
+                        const int32_t* list = nullptr, int64_t n_list = 0, int part_base = 0, int part_stride = 0) {
     const double* mat_val = val_override ? val_override : A->val.p;
     fs_space_s* sp = A->space;
-    const int grid = spmv_grid(sp->n_slices);
-#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, sp->slice_order.p
+    const int64_t ns = list ? n_list : sp->n_slices;
+    if (ns == 0) return;
+    const int32_t* order = list ? list : sp->slice_order.p;
+    const int grid = spmv_grid(ns, sp->n_slices);
+    if (part_stride == 0) part_stride = grid;
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride
     if (A->bs == 1) {
         const bool nt = spmv_nontemporal(sp, 1);
         switch (spmv_unroll_for(sp->n_slices)) {
@@ -770,6 +780,35 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
         }
     }
 #undef FS_SPMV_ARGS
+}
+
+// Number of per-workgroup dot partials one (possibly split) product writes.
+static bool spmv_is_split(const fs_space_s* sp) { return sp->halo.active && sp->halo.n_interior > 0; }
+static int spmv_partials(const fs_space_s* sp) {
+    if (!spmv_is_split(sp)) return spmv_grid(sp->n_slices, sp->n_slices);
+    return spmv_grid(sp->halo.n_interior, sp->n_slices) + (sp->halo.n_boundary ? spmv_grid(sp->halo.n_boundary, sp->n_slices) : 0);
+}
+
+// y = A x on a decomposed space with the ghost refresh of x hidden behind the interior rows:
+//   pack + grouped send/recv on the communication stream | interior slices on the compute stream
+//   compute stream waits for the halo                     | boundary slices
+// One GPU (no halo plan): the plain product.
+template <int DOTS>
+static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* rvec, double* partials, const int* status,
+                           hipStream_t s, const double* val_override = nullptr) {
+    fs_space_s* sp = A->space;
+    if (!spmv_is_split(sp)) {
+        FS_CHECK(fs_halo_exchange_dev(sp, x, s));
+        launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override);
+        return FS_OK;
+    }
+    const fs_halo_plan& h = sp->halo;
+    const int gi = spmv_grid(h.n_interior, sp->n_slices), total = spmv_partials(sp);
+    FS_CHECK(fs_halo_begin_dev(sp, x, s));
+    launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.interior.p, h.n_interior, 0, total);
+    FS_CHECK(fs_halo_end_dev(sp, s));
+    if (h.n_boundary) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.boundary.p, h.n_boundary, gi, total);
+    return FS_OK;
 }
 
 // y = A x for 4x4-block matrices (Taylor-Hood): one workgroup per slice, wave i computes block-row i.  A slice of a
@@ -929,13 +968,16 @@ struct krylov_ws {
     int hist_cap = 0;
     dbuf<double> dinv, r, z, w, p, s, partials, sums, ctrl, scal, hist;
     dbuf<double> rhat, t, y, partials2, bsums;   // BiCGStab only (allocated on first use)
-    dbuf<double> aval, dvec, bhat;               // diagonally scaled CG only
+    dbuf<double> aval, dvec, bhat, sc_local;     // diagonally scaled CG only
+    dbuf<int> d_err;                             // zero-diagonal counter of k_extract_dinv
     int64_t bicg_n = -1;
     dbuf<int> status;
-    int* h_status = nullptr;  // pinned, 2 x 4 ints
+    int* h_status = nullptr;  // pinned: 2 x 4 status ints (double-buffered polls) + [8] zero-diagonal count
     hipEvent_t poll[2] = {nullptr, nullptr};
     static const int NSAMPLE = 64;
     hipEvent_t ev[NSAMPLE][4];
+    int sample_iter[NSAMPLE];   // iteration (within its pass) a sample was taken at
+    bool sample_live[NSAMPLE];  // false: the sampled launches came after convergence (no-ops)
     bool events = false;
     std::vector<double> last_hist;
 };
@@ -958,7 +1000,8 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
         FS_CHECK(ws.ctrl.alloc(4));
         FS_CHECK(ws.scal.alloc(4));
         FS_CHECK(ws.status.alloc(4));
-        FS_HIP(hipHostMalloc((void**)&ws.h_status, 8 * sizeof(int), hipHostMallocDefault));
+        FS_CHECK(ws.d_err.alloc(1));
+        FS_HIP(hipHostMalloc((void**)&ws.h_status, 12 * sizeof(int), hipHostMallocDefault));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[0], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[1], hipEventDisableTiming));
         for (int i = 0; i < krylov_ws::NSAMPLE; ++i)
@@ -1006,32 +1049,26 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             FS_CHECK(ws.dvec.alloc(n + 2));
             FS_CHECK(ws.bhat.alloc(n + 2));
         }
+        if (ws.sc_local.n != nl + 2) FS_CHECK(ws.sc_local.alloc(nl + 2));
     }
     const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
     const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
-    const int sgrid = spmv_grid(sp->n_slices);
+    const int sgrid = spmv_partials(sp);     // dot partials per product (interior + boundary launch on a decomposed space)
     const auto t_begin = std::chrono::steady_clock::now();
 
-    // Jacobi diagonal
+    // Jacobi diagonal (the zero-diagonal counter is read back with the first status poll: no extra sync here)
     {
-        dbuf<int> d_err;
-        FS_CHECK(d_err.alloc(1));
-        FS_CHECK(d_err.zero(s));
+        FS_CHECK(ws.d_err.zero(s));
         const int g = fs_grid_for(sp->n_nodes_owned);
         const int jmode = ds ? 2 : (opts->precond == FS_PC_JACOBI ? 1 : 0);
         double* dv = ds ? ws.dvec.p : nullptr;
         if (bs == 1)
-            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, d_err.p, dv);
+            hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, ws.d_err.p, dv);
         else
-            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, d_err.p, dv);
+            hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, ws.d_err.p, dv);
         FS_KERNEL_CHECK();
-        int h_err = 0;
-        FS_CHECK(d_err.download(&h_err, 1, s));
-        if (h_err) {
-            fs_set_error("fs_krylov_solve: %d zero%s diagonal entries (Jacobi preconditioner undefined)", h_err, ds ? " or negative" : "");
-            return FS_ERR_NUMERIC;
-        }
+        FS_HIP(hipMemcpyAsync(ws.h_status + 8, ws.d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
     }
     const bool pnorm = opts->norm_type == FS_NORM_PRECONDITIONED;
     if (pnorm && !ds) {
@@ -1053,18 +1090,16 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const double* aval = nullptr;
     if (ds) {
         // the scaled system needs ghost scale factors too: refresh them through the halo
-        dbuf<double> sc_local;
-        FS_CHECK(sc_local.alloc(nl + 2));
-        FS_HIP(hipMemcpyAsync(sc_local.p, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        FS_CHECK(fs_halo_exchange_dev(sp, sc_local.p, s));
+        double* sc_local = ws.sc_local.p;
+        FS_HIP(hipMemcpyAsync(sc_local, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        FS_CHECK(fs_halo_exchange_dev(sp, sc_local, s));
         const int g2 = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
         if (bs == 1)
-            hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local.p, ws.aval.p);
+            hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
         else
-            hipLaunchKernelGGL(k_scale_copy<3>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local.p, ws.aval.p);
+            hipLaunchKernelGGL(k_scale_copy<3>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
         hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, b->d.p, n, ws.bhat.p);
         FS_KERNEL_CHECK();
-        FS_HIP(hipStreamSynchronize(s));   // sc_local is released at the end of this scope
         aval = ws.aval.p;
     }
     // A pass = fresh recurrences from the current x.  The single-reduction recurrences drift on
@@ -1129,10 +1164,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         double* const hist_p = ws.hist.p + total_iters;
         int k = 0, slot = 0, pending = -1;
         bool finished = false;
+        const int first_sample = n_samples;
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
             for (; k < kend; ++k) {
                 const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
+                if (sample) ws.sample_iter[n_samples] = k;
                 if (bicg) {
                     const int co = k == max_iter ? 1 : 0;
                     // K1: p, y
@@ -1144,9 +1181,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         hipLaunchKernelGGL(k_bicg_p<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
                     }
                     // K2: v = A y, rhat.v
-                    FS_CHECK(fs_halo_exchange_dev(sp, ws.y.p, s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
-                    launch_spmv<2>(A, ws.y.p, ws.w.p, ws.rhat.p, ws.partials.p, ws.status.p, s);
+                    FS_CHECK(spmv_overlapped<2>(A, ws.y.p, ws.w.p, ws.rhat.p, ws.partials.p, ws.status.p, s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
                     // K3: s, z
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
@@ -1162,8 +1198,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         ++n_samples;
                     }
                     // K4: t = A z, (t.s, t.t)
-                    FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-                    launch_spmv<2>(A, ws.z.p, ws.t.p, ws.s.p, ws.partials.p, ws.status.p, s);
+                    FS_CHECK(spmv_overlapped<2>(A, ws.z.p, ws.t.p, ws.s.p, ws.partials.p, ws.status.p, s));
                     // K5: x, r, next (rhat.r, r.r)
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_x<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
@@ -1174,10 +1209,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                     continue;
                 }
-                FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
-                if (ds) launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
-                else launch_spmv<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s);
+                if (ds) FS_CHECK(spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval));
+                else FS_CHECK(spmv_overlapped<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s));
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
                 if (ds) {
                     const int co = k == max_iter ? 1 : 0;
@@ -1222,6 +1256,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_CHECK(ws.status.download(h_status, 4, s));
         const int iters = h_status[1];
         total_iters += iters;
+        // launches enqueued after the recurrence stopped return on the status word: their samples time no-ops
+        for (int i = first_sample; i < n_samples; ++i) ws.sample_live[i] = ws.sample_iter[i] < iters;
+        if (ws.h_status[8] != 0) {
+            fs_set_error("fs_krylov_solve: %d zero%s diagonal entries (Jacobi preconditioner undefined)", ws.h_status[8], ds ? " or negative" : "");
+            return FS_ERR_NUMERIC;
+        }
 
         // true residual b - A x (scaled mode: sum d (bhat - Ahat xhat)^2, the same number)
         FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1273,7 +1313,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         double t_spmv = 0.0, t_upd = 0.0;
         int cnt = 0;
         for (int i = 0; i < n_samples; ++i) {
-            if (4 * i + 1 >= iters) break;  // launches after convergence are no-ops
+            if (!ws.sample_live[i]) continue;
             float a = 0.f, c = 0.f;
             if (hipEventElapsedTime(&a, ws.ev[i][0], ws.ev[i][1]) != hipSuccess) break;
             if (hipEventElapsedTime(&c, ws.ev[i][2], ws.ev[i][3]) != hipSuccess) break;

@@ -1,53 +1,84 @@
 """One process per GPU: process-group plumbing for the solver API.
 
-The reference becomes parallel by being started under ``mpirun`` — DOLFIN partitions the mesh
+The reference becomes parallel by being started under ``mpirun`` - DOLFIN partitions the mesh
 and PETSc communicates (SolverBase.py:102-118, 634).  Here a script that uses the solver
-classes is started with ``python -m torch.distributed.run --nproc-per-node N script.py``:
-every rank builds the same (global) host mesh, owns a slab of its vertices (partition.py),
-assembles and solves its rows on its own MI355X and exchanges halos / dot products over RCCL;
-the solution is gathered so that ``solver.result`` holds the full field on every rank, as
-DOLFIN's ``Function`` does for the part a rank can see.
+classes is started with ``python -m fenicssolver_amd.launch --nproc N script.py`` (or any
+launcher that exports RANK / WORLD_SIZE / LOCAL_RANK, e.g. the driver's elastic launcher, mpirun, srun):
+every rank owns a slab of the vertices (partition.py), assembles and solves its rows on its own
+MI355X and exchanges halos / dot products over RCCL; the solution is gathered so that
+``solver.result`` holds the full field on every rank, as DOLFIN's ``Function`` does for the
+part a rank can see.
 
-torch.distributed (gloo) is used for rendezvous and for the final gather only.
-FS_FORCE_PARALLEL_PATH=1 sends a single process through the same code (one part, no
-communicator) — that is how the 1-GPU tests exercise the mapping logic.
+No ML framework, no MPI: the RCCL unique id travels through rendezvous.py, everything after that
+(barrier, gathers) runs over the communicator itself.
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
+
+from . import rendezvous
 
 _state = {"ready": False}
 
+# Tests flip this to send a single process through the decomposition code (one part, no communicator).
+FORCE_DECOMPOSED_PATH = False
+
 
 def world():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    return rendezvous.world()
 
 
 def active():
-    return world()[1] > 1 or os.environ.get("FS_FORCE_PARALLEL_PATH", "") not in ("", "0")
+    return world()[1] > 1 or FORCE_DECOMPOSED_PATH
 
 
 def ensure_comm():
-    """Select this rank's GPU and bring up RCCL (idempotent)."""
+    """Select this rank's GPU (LOCAL_RANK) and bring up RCCL (idempotent)."""
     from . import backend
     rank, size, local_rank = world()
     if _state["ready"]:
         return rank, size
     backend.init(local_rank if size > 1 else 0)
     if size > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group("gloo")
-        uid = [backend.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        backend.comm_init(size, rank, uid[0])
+        uid = rendezvous.exchange_unique_id(rank, size, backend.comm_unique_id)
+        backend.comm_init(size, rank, uid)
+        rendezvous.cleanup(rank, size)
     _state["ready"] = True
     return rank, size
 
 
+def barrier():
+    from . import backend
+    backend.synchronize()
+    if world()[1] > 1:
+        backend.comm_allreduce_sum([0.0])
+
+
+def max_over_ranks(value):
+    from . import backend
+    if world()[1] == 1:
+        return float(value)
+    return float(backend.comm_allgather([float(value)], 1).max())
+
+
+def finalize():
+    from . import backend
+    if _state["ready"] and world()[1] > 1:
+        backend.comm_finalize()
+    _state["ready"] = False
+
+
 _gid_cache = {}
+
+
+def allgather_index_lists(ids):
+    """Every rank's integer list (exact below 2^53: they travel as doubles through fs_comm_allgather)."""
+    from . import backend
+    ids = np.asarray(ids, dtype=np.int64)
+    counts = backend.comm_allgather([float(len(ids))], 1)[:, 0].astype(np.int64)
+    n_max = max(int(counts.max()), 1)
+    got = backend.comm_allgather(ids.astype(np.float64), n_max)
+    return [got[r, :counts[r]].astype(np.int64) for r in range(len(counts))]
 
 
 def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
@@ -60,15 +91,12 @@ def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
     if size == 1:
         out[gids] = vals
     else:
-        import torch.distributed as dist
         from . import backend
         key = (int(n_global), len(gids), int(gids[0]) if len(gids) else -1, int(gids[-1]) if len(gids) else -1)
         if key not in _gid_cache:
-            parts = [None] * size
-            dist.all_gather_object(parts, gids)
             if len(_gid_cache) > 16:
                 _gid_cache.clear()
-            _gid_cache[key] = parts
+            _gid_cache[key] = allgather_index_lists(gids)
         parts = _gid_cache[key]
         n_max = max(len(g) for g in parts) * ncomp
         got = backend.comm_allgather(vals.reshape(-1), n_max)

@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_multirank.py: one rank of a multi-rank run that SHARES ONE GPU through the library's
-shared-memory test transport (FS_DEVICE=0, FS_COMM_TRANSPORT=shm).  Started by torch.distributed.run.
+"""Worker of tests/test_gpu_multirank.py: one rank of a multi-rank run whose ranks SHARE ONE GPU (launched with
+--devices 0,0,..; FS_RCCL_PATH = tests/shim/libfakerccl.so).  Started by fenicssolver_amd.launch.
 Writes what rank 0 gathered to the .npz named on the command line."""
 import os
 import sys
@@ -10,7 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import torch.distributed as dist                                   # noqa: E402
 from fenicssolver_amd import backend as B, partition, parallel    # noqa: E402
 
 out_path, case = sys.argv[1], sys.argv[2]
@@ -20,11 +19,7 @@ result = {}
 if case == "box":
     # the bench path: device box-slab generator, closed-form halo plan, Jacobi-CG
     nx, ny, nz, axis = 9, 7, 23, 0
-    B.init(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("gloo")
-    uid = [B.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    B.comm_init(world, rank, uid[0])
+    parallel.ensure_comm()
     zr = partition.slab_ranges(nz + 1, world)[rank]
     mesh = B.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0), zplanes=zr)
     V = B.DeviceSpace(mesh, 1)
@@ -38,25 +33,21 @@ if case == "box":
     B.assemble_vector(V, b, source=3.0)
     A.apply_dirichlet(b, dofs, vals, symmetric=True)
     st = B.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
-    parts = [None] * world
-    dist.all_gather_object(parts, (lay["l2g"][:lay["n_owned"]], x.get()[:lay["n_owned"]]))
+    full = parallel.gather_owned(x.get()[:lay["n_owned"]], lay["l2g"][:lay["n_owned"]], (nx + 1) * (ny + 1) * (nz + 1))
     if rank == 0:
-        full = np.empty((nx + 1) * (ny + 1) * (nz + 1))
-        for g, v in parts:
-            full[g] = v
         result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"])
-    dist.barrier()
-    B.comm_finalize()
+    parallel.barrier()
+    parallel.finalize()
 else:
-    # the solver API under torch.distributed.run (parallel.py): every rank builds the global host mesh
+    # the solver API on several ranks (parallel.py)
     import test_gpu_parallel_api as T
     solver = (T.CASES.get(case) or T.NS_CASES[case])()
     u = solver.solve()
     assert solver.function_space.localizer() is not None and parallel.world()[1] == world
     if rank == 0:
         result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"])
-    dist.barrier()
-    B.comm_finalize()
+    parallel.barrier()
+    parallel.finalize()
 
 if rank == 0:
     np.savez(out_path, **result)

@@ -1,7 +1,9 @@
 """Several ranks on ONE GPU: the complete distributed algorithm (owner-computes partition, ghost layout, halo packing,
-fused dots + all-reduce, restarts, result gather) with real device kernels in every rank.  RCCL refuses two ranks on
-one device, so the library's shared-memory test transport (FS_COMM_TRANSPORT=shm, fs_comm.hip) carries the halo and
-the reductions; the RCCL calls themselves are covered by test_gpu_comm.py with the 1-rank communicator."""
+interior/boundary overlap, fused dots + all-reduce, restarts, result gather) with real device kernels in every rank.
+RCCL refuses two ranks on one device, so FS_RCCL_PATH points libfsamd.so at tests/shim/libfakerccl.so - a stand-in
+that exports the nccl* entry points and moves the data through host shared memory.  The library runs exactly the
+ncclGroupStart/Send/Recv/GroupEnd, ncclAllReduce and ncclAllGather call sites it runs in production (there is no
+other transport in it); real RCCL is covered by test_gpu_comm.py with the 1-rank communicator a 1-GPU box allows."""
 import os
 import subprocess
 import sys
@@ -18,10 +20,12 @@ PORT = [29610]
 
 def _run(world, case, tmp_path):
     out = str(tmp_path / ("%s_%d.npz" % (case, world)))
-    env = dict(os.environ, FS_DEVICE="0", FS_COMM_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    shim = os.path.join(ROOT, "tests", "shim", "libfakerccl.so")
+    assert os.path.exists(shim), "build tests/shim first (make -C tests/shim; __graft_entry__.build() does it)"
+    env = dict(os.environ, FS_RCCL_PATH=shim)
     PORT[0] += 1
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, case]
+    cmd = [sys.executable, "-m", "fenicssolver_amd.launch", "--nproc", str(world), "--devices", ",".join(["0"] * world),
+           "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, case]
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     return np.load(out)
@@ -50,7 +54,7 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
 
 @pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
-    """`python -m torch.distributed.run --nproc-per-node N script.py` with the reference-style solver classes:
+    """`python -m fenicssolver_amd.launch --nproc N script.py` with the reference-style solver classes:
     same field as the single-process run, gathered on every rank.  heat_p2: CG2 nodes decomposed as
     [owned vertices | owned edges | ghost vertices | ghost edges] with the indexed halo."""
     import test_gpu_parallel_api as T

@@ -1,6 +1,6 @@
 """The solver API's domain-decomposed path (fenicssolver_amd/parallel.py + SolverBase.assemble_system
 localisation), checked on one GPU two ways:
-  * FS_FORCE_PARALLEL_PATH=1 sends the whole case through the partition/localise/gather code with
+  * parallel.FORCE_DECOMPOSED_PATH = True sends the whole case through the partition/localise/gather code with
     one part: results must equal the plain single-GPU path;
   * three emulated ranks (no communicator): every rank's owned rows of (A, b), mapped back to
     global numbering, must equal the single-GPU system - coefficients, facet terms, Crank-Nicolson
@@ -170,7 +170,7 @@ def test_forced_single_part_equals_plain_path(gpu, monkeypatch, case):
     from fenicssolver_amd import parallel
     make = CASES.get(case) or NS_CASES[case]
     plain = make().solve().vector().array()
-    monkeypatch.setenv("FS_FORCE_PARALLEL_PATH", "1")
+    monkeypatch.setattr(parallel, "FORCE_DECOMPOSED_PATH", True)
     assert parallel.active()
     solver = make()
     forced = solver.solve().vector().array()

@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 43
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 from fenicssolver_amd import parallel
 if parallel.world()[1] > 1:
-    parallel.ensure_comm()      # started under torch.distributed.run (FS_DEVICE / FS_COMM_TRANSPORT=shm: ranks share a GPU)
+    parallel.ensure_comm()      # started under fenicssolver_amd.launch
 else:
     B.init(0)
 t0 = time.perf_counter()
