@@ -143,7 +143,8 @@ def make_roofline(k, workload, traffic, traffic_source):
                            if traffic is not None else None,
          "workload": workload,
          "note": "achieved = algorithmic CSR bytes (nnz*12 + n*20, SURVEY 8d) / avg_launch_ms; avg_launch_ms = mean of the LIVE "
-                 "launches sampled with HIP events (every 16th iteration of the timed solve) on the library's stream"}
+                 "launches sampled with HIP events (every 16th iteration of the timed solve) on the library's stream; "
+                 "streamed_GBps = the bytes the hybrid storage really moves (DIA slices carry no column indices) / the same time"}
     r.update({kk: k[kk] for kk in ("avg_launch_ms", "algorithmic_bytes_per_launch", "streamed_bytes_per_launch", "streamed_GBps",
                                    "dia_slices", "slices")})
     return r
@@ -237,8 +238,8 @@ def main():
             B.synchronize()
             t_big = time.perf_counter() - t0
             traffic, src = committed_traffic("spmv_fused_n215")
-            r = make_roofline(kernel_rates(st_big, big.V), "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per "
-                              "launch)" % (big.n_owned, (big.V.spmv_matrix_bytes + 24 * big.n_owned) / 1e9), traffic, src)
+            r = make_roofline(kernel_rates(st_big, big.V), "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per launch)"
+                              % (big.n_owned, (big.V.spmv_matrix_bytes + 24 * big.n_owned) / 1e9), traffic, src)
             r.update({"dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
                       "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3),
                       "update_kernel_ms": round(st_big["update_ms"], 5),
