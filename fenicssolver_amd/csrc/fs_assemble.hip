@@ -420,13 +420,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t 
 // P2 boundary load: int g phi_a ds over a facet = g * area / 3 on each of its 3 edge nodes, 0 on the vertices
 __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ tri, int64_t nf,
                                   const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne,
-                                  int grouped, const int32_t* __restrict__ edge_node, int64_t n_rows,
+                                  int grouped, const int32_t* __restrict__ edge_node, int64_t n_rows, int ncomp,
                                   double* __restrict__ b, int* __restrict__ err) {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; f < nf; f += stride) {
         const int32_t v[3] = {tri[3 * f], tri[3 * f + 1], tri[3 * f + 2]};
-        const double w = tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 3.0) * g[f];
+        const double w = tri_area(xyz4, v[0], v[1], v[2]) * (1.0 / 3.0);      // g: [nf][ncomp]
         const int pi[3] = {0, 0, 1}, pj[3] = {1, 2, 2};
         for (int e = 0; e < 3; ++e) {
             const int32_t a = v[pi[e]], bb = v[pj[e]];
@@ -438,7 +438,8 @@ __global__ void k_facet_vector_p2(const double* __restrict__ xyz4, const int32_t
                 if (edge_keys[mid] < key) lo = mid + 1; else hi = mid;
             }
             if (lo < ne && edge_keys[lo] == key) {
-                if (edge_node[lo] < n_rows) atomicAdd(&b[edge_node[lo]], w);     // edge rows of other ranks: theirs to add
+                if (edge_node[lo] < n_rows)                                      // edge rows of other ranks: theirs to add
+                    for (int i = 0; i < ncomp; ++i) atomicAdd(&b[(int64_t)edge_node[lo] * ncomp + i], w * g[f * ncomp + i]);
             } else {
                 atomicAdd(err, 1);
             }
@@ -582,6 +583,144 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity_gather(int6
                 const int64_t idx = (int64_t)(i * 3 + j) * plane + e;
                 val[idx] = ADD ? val[idx] + acc[i][j] : acc[i][j];
             }
+    }
+}
+
+// ---- vector P2 elasticity (the reference's own example: VectorFunctionSpace(mesh, 'CG', 2),
+// examples/test_linear_elasticity.py:105-106; form LinearElasticitySolver.py:62-69, 215) --------------------------------
+// Same scheme as the P1 operator: one thread per STORED 3x3 block sums, in ascending order, the (cell, a, b) sources the
+// inverse slot table lists for it (source index = cell*100 + a*10 + b), recomputing the cell's barycentric gradients.
+// K_ab[i][j] = int lambda d_i phi_a d_j phi_b + mu d_j phi_a d_i phi_b + mu delta_ij grad phi_a . grad phi_b dx, quadratic
+// integrand, 4-point rule (exact; the rule FFC picks).  Local nodes: 4 vertices, then the 6 UFC edges.
+__device__ __constant__ int FS_P2_EI[6] = {2, 1, 1, 0, 0, 0};
+__device__ __constant__ int FS_P2_EJ[6] = {3, 3, 2, 3, 2, 1};
+__device__ __forceinline__ double tet_g(const tet_geom& t, int a, int d) {      // t.g[a][d] without dynamic register indexing
+    return a == 0 ? t.g[0][d] : a == 1 ? t.g[1][d] : a == 2 ? t.g[2][d] : t.g[3][d];
+}
+__device__ __forceinline__ void p2_grad_one(const tet_geom& t, int qp, int a, double (&ga)[3]) {
+    if (a < 4) {
+        const double w = 4.0 * FS_P2_QP[qp][a] - 1.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ga[d] = w * tet_g(t, a, d);
+    } else {
+        const int i = FS_P2_EI[a - 4], j = FS_P2_EJ[a - 4];
+        const double li = 4.0 * FS_P2_QP[qp][i], lj = 4.0 * FS_P2_QP[qp][j];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ga[d] = li * tet_g(t, j, d) + lj * tet_g(t, i, d);
+    }
+}
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_elasticity_gather(int64_t n_entries, const int32_t* __restrict__ ptr,
+                                                                            const int32_t* __restrict__ src,
+                                                                            const int32_t* __restrict__ cells,
+                                                                            const double* __restrict__ xyz4, double mu, double lambda,
+                                                                            coef_dev mc, int64_t plane, double* __restrict__ val) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < n_entries; e += stride) {
+        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        const int32_t q1 = ptr[e + 1];
+        for (int32_t q = ptr[e]; q < q1; ++q) {
+            const int32_t sidx = src[q];
+            const int64_t c = sidx / 100;
+            const int ab = sidx - (int32_t)c * 100, a = ab / 10, b = ab - 10 * a;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const tet_geom t = tet_geometry(xyz4, v);
+            const double w = t.adet * (1.0 / 24.0);            // volume * quadrature weight 1/4
+#pragma unroll
+            for (int qp = 0; qp < 4; ++qp) {
+                double ga[3], gb[3];
+                p2_grad_one(t, qp, a, ga);
+                p2_grad_one(t, qp, b, gb);
+                const double gg = mu * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double x = lambda * ga[i] * gb[j] + mu * ga[j] * gb[i];
+                        if (i == j) x += gg;
+                        acc[i][j] += w * x;
+                    }
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double ms = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.adet * (1.0 / 2520.0) * FS_P2_MASS420[a][b];
+                acc[0][0] += ms; acc[1][1] += ms; acc[2][2] += ms;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int64_t idx = (int64_t)(i * 3 + j) * plane + e;
+                val[idx] = ADD ? val[idx] + acc[i][j] : acc[i][j];
+            }
+    }
+}
+
+// Load vector of the vector P2 space: body force  int f . phi_a dx  (constant f: -V/20 on vertex nodes, V/5 on edge nodes)
+// and the thermal-stress load  int c div v dx = int c d_i phi_a dx  with c constant, per cell, or P1 through its VERTEX
+// values (nodal array over the space's nodes; exact for a P1 temperature):
+//   vertex a:      V g_a (c_a / 5 - S / 20)                          S = sum of the four vertex values
+//   edge (i, j):   V / 5 ((S + c_i) g_j + (S + c_j) g_i)             (constant c: 0 and c V (g_i + g_j))
+// One thread per owned node; its (cell, a) incidences are the sources of its diagonal block, ascending (reproducible).
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_vector_source_gather(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                                                                               const int32_t* __restrict__ sell_col,
+                                                                               const int32_t* __restrict__ gptr,
+                                                                               const int32_t* __restrict__ gsrc,
+                                                                               const int32_t* __restrict__ cells,
+                                                                               const double* __restrict__ xyz4, double fx, double fy,
+                                                                               double fz, coef_dev dv, int64_t nvo, int64_t neo,
+                                                                               double* __restrict__ b) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        int64_t e = -1;
+        for (int k = 0; k < width; ++k)
+            if (sell_col[base + (int64_t)k * FS_SLICE] == (int32_t)r) { e = base + (int64_t)k * FS_SLICE; break; }
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (e >= 0) {
+            for (int32_t q = gptr[e]; q < gptr[e + 1]; ++q) {
+                const int32_t sidx = gsrc[q];
+                const int64_t c = sidx / 100;
+                const int a = (sidx - (int32_t)c * 100) / 10;
+                const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+                const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const tet_geom t = tet_geometry(xyz4, v);
+                const double vol = t.adet * (1.0 / 6.0);
+                const double wf = vol * (a < 4 ? -0.05 : 0.2);
+                acc[0] += wf * fx; acc[1] += wf * fy; acc[2] += wf * fz;
+                if (dv.mode == FS_COEF_NONE) continue;
+                double cv[4];
+                if (dv.mode == FS_COEF_NODAL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cv[k] = dv.data[v[k] < nvo ? v[k] : v[k] + neo];
+                } else {
+                    const double cc = dv.mode == FS_COEF_CONST ? dv.value : dv.data[c];
+                    cv[0] = cv[1] = cv[2] = cv[3] = cc;
+                }
+                const double S = (cv[0] + cv[1]) + (cv[2] + cv[3]);
+                if (a < 4) {
+                    const double ca = a == 0 ? cv[0] : a == 1 ? cv[1] : a == 2 ? cv[2] : cv[3];
+                    const double w = vol * (0.2 * ca - 0.05 * S);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[d] += w * tet_g(t, a, d);
+                } else {
+                    const int i = FS_P2_EI[a - 4], j = FS_P2_EJ[a - 4];
+                    const double ci = i == 0 ? cv[0] : i == 1 ? cv[1] : i == 2 ? cv[2] : cv[3];
+                    const double cj = j == 0 ? cv[0] : j == 1 ? cv[1] : j == 2 ? cv[2] : cv[3];
+                    const double wi = 0.2 * vol * (S + ci), wj = 0.2 * vol * (S + cj);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[d] += wi * tet_g(t, j, d) + wj * tet_g(t, i, d);
+                }
+            }
+        }
+        b[3 * r + 0] += acc[0];
+        b[3 * r + 1] += acc[1];
+        b[3 * r + 2] += acc[2];
     }
 }
 
@@ -1180,10 +1319,18 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
         hipLaunchKernelGGL(k_assemble_p1_scalar, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, kc, mc, A->val.p);
-    } else if (getenv("FS_ELASTICITY_ATOMIC")) {
+    } else if (getenv("FS_ELASTICITY_ATOMIC") && sp->degree == 1 && A->bs == 3) {
         if (!add) FS_CHECK(A->val.zero(s));
         hipLaunchKernelGGL(k_assemble_p1_elasticity, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+    } else if (A->bs == 3 && sp->degree == 2) {
+        if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
+        const int gg = fs_grid_for(sp->sell_entries, FS_BLOCK, 1 << 16);
+        if (add)
+            hipLaunchKernelGGL(k_assemble_p2_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p2_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
     } else {
+        FS_REQUIRE(A->bs == 3 && sp->degree == 1, "fs_assemble_matrix: no operator for block size %d on CG%d nodes (Taylor-Hood systems: fs_assemble_navier_stokes)", A->bs, sp->degree);
         if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
         const int gg = fs_grid_for(sp->sell_entries, FS_BLOCK, 1 << 16);
         if (add)
@@ -1306,7 +1453,21 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
+    if (space->degree == 2 && space->ncomp == 3) {
+        FS_REQUIRE(f.mode == FS_COEF_NONE, "fs_assemble_vector: vector spaces take their body force in vector_value");
+        FS_REQUIRE(dv.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
+        FS_REQUIRE(space->slots.p, "fs_assemble_vector: vector CG2 space without slot table");
+        if (!space->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(space, s));
+        hipLaunchKernelGGL(k_assemble_p2_vector_source_gather, dim3(fs_grid_for(space->n_nodes_owned, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                           space->n_nodes_owned, space->slice_ptr.p, space->sell_col.p, space->gmap_ptr.p, space->gmap_src.p, m->cells.p,
+                           m->xyz.p, form->vector_value[0], form->vector_value[1], form->vector_value[2], dv, m->n_owned,
+                           space->n_edges_owned, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     if (space->degree == 2) {
+        FS_REQUIRE(space->ncomp == 1, "fs_assemble_vector: %d-component CG2 node blocks have no load-vector kernel", space->ncomp);
         FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
         if (space->ncomp == 1 && space->inc_cell.p && !getenv("FS_SOURCE_ATOMIC"))
             hipLaunchKernelGGL(k_assemble_p2_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
@@ -1453,7 +1614,7 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
         dbuf<int> d_err;
         FS_CHECK(d_err.alloc(1));
         FS_CHECK(d_err.zero(s));
-        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, b->d.p, d_err.p);
+        hipLaunchKernelGGL(k_facet_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s, space->mesh->xyz.p, d_tri.p, n_facets, d_g.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, space->ncomp, b->d.p, d_err.p);
         FS_KERNEL_CHECK();
         int h_err = 0;
         FS_CHECK(d_err.download(&h_err, 1, s));

@@ -563,8 +563,8 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
     // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes
     if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3 && ncomp != 4) ||
-        (degree == 2 && ncomp == 3) || (degree == 1 && ncomp == 4)) {
-        fs_set_error("fs_space_create: supported spaces are CG1 with 1 or 3 components, scalar CG2 and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d)",
+        (degree == 1 && ncomp == 4)) {
+        fs_set_error("fs_space_create: supported spaces are CG1 / CG2 with 1 or 3 components and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d)",
                      family, degree, ncomp);
         return FS_ERR_UNSUPPORTED;
     }

@@ -664,6 +664,76 @@ def p2_source_local(coords, cells, f=1.0):
     return (vol * (float(ff) if ff.ndim == 0 else ff))[:, None] * w[None, :]
 
 
+def p2_elasticity_local(coords, cells, E, nu):
+    """30x30 element matrix of inner(sigma(u), grad(v)) on P2 tetrahedra (the reference's elasticity example runs
+    VectorFunctionSpace(mesh, 'CG', 2): examples/test_linear_elasticity.py:105-106; form LinearElasticitySolver.py:62-69, 215).
+    Ke[(a,i),(b,j)] = int lmbda d_i phi_a d_j phi_b + mu d_j phi_a d_i phi_b + mu delta_ij grad phi_a . grad phi_b dx;
+    the integrand is quadratic: the 4-point rule FFC picks (Appendix C3, D-5) is exact.  Dof order per cell:
+    node-major (a = 4 vertices then 6 UFC edges), component-minor, as vector spaces interleave (Appendix D-7)."""
+    mu, lmbda = lame(E, nu)
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    Ke = np.zeros((len(cells), 10, 3, 10, 3))
+    eye = np.eye(3)
+    for lam in P2_QUAD_POINTS:
+        gp = p2_basis_gradients(g, lam)
+        gg = np.einsum("cak,cbk->cab", gp, gp)
+        Ke += 0.25 * (lmbda * np.einsum("cai,cbj->caibj", gp, gp) + mu * np.einsum("caj,cbi->caibj", gp, gp)
+                      + mu * np.einsum("cab,ij->caibj", gg, eye))
+    return (Ke * vol[:, None, None, None, None]).reshape(len(cells), 30, 30)
+
+
+def p2_vector_cell_dofs(cell_dofs):
+    """[nc,30] dofs of a 3-vector P2 space from the node table [nc,10]: dof = node*3 + component."""
+    cd = np.asarray(cell_dofs, dtype=np.int64)
+    return (cd[:, :, None] * 3 + np.arange(3)[None, None, :]).reshape(len(cd), 30)
+
+
+def assemble_p2_elasticity(coords, cells, E, nu):
+    cd, edges = p2_cell_dofs(len(coords), cells)
+    n_nodes = len(coords) + len(edges)
+    return assemble_generic(3 * n_nodes, p2_vector_cell_dofs(cd), p2_elasticity_local(coords, cells, E, nu)), cd, edges
+
+
+def assemble_p2_vector_source(coords, cells, f):
+    """b_(a,i) = int f_i phi_a dx for a constant vector f on the 3-vector P2 space (-V/20 per vertex, V/5 per edge node)."""
+    cd, edges = p2_cell_dofs(len(coords), cells)
+    nodal = assemble_generic_vector(len(coords) + len(edges), cd, p2_source_local(coords, cells, 1.0))
+    return (nodal[:, None] * np.asarray(f, dtype=np.float64)[None, :]).ravel()
+
+
+def p2_div_load_local(coords, cells, c_vertex=None, c_const=None):
+    """be[(a,i)] = int c d_i phi_a dx (the thermal-stress load E alpha (T - T0)/(1-2nu) I : grad v,
+    LinearElasticitySolver.py:78-85, 231-238) with c constant or P1 (given by its vertex values [nv]): the integrand is
+    at most quadratic, 4-point rule exact."""
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    ce = np.asarray(cells, dtype=np.int64)
+    be = np.zeros((len(cells), 10, 3))
+    for lam in P2_QUAD_POINTS:
+        gp = p2_basis_gradients(g, lam)
+        cq = np.full(len(cells), float(c_const)) if c_vertex is None else np.asarray(c_vertex)[ce] @ np.asarray(lam)
+        be += 0.25 * cq[:, None, None] * gp
+    return (be * vol[:, None, None]).reshape(len(cells), 30)
+
+
+def assemble_p2_facet_vector_load(coords, edges, facets, facet_markers, marker_id, g):
+    """b_(a,i) = int g_i phi_a ds(marker_id), constant vector g, 3-vector P2 space: g_i * area / 3 on the three edge
+    nodes of every marked facet, nothing on its vertices (LinearElasticitySolver.py:165-196 tractions)."""
+    nv = len(coords)
+    sel = np.nonzero(np.asarray(facet_markers) == marker_id)[0]
+    f = np.asarray(facets, dtype=np.int64)[sel]
+    area = facet_areas(coords, f)
+    ekey = np.asarray(edges, dtype=np.int64)
+    ekey = ekey[:, 0] * nv + ekey[:, 1]
+    sorter = np.argsort(ekey)
+    b = np.zeros((nv + len(edges), 3))
+    for i, j in ((0, 1), (0, 2), (1, 2)):
+        eid = sorter[np.searchsorted(ekey[sorter], f[:, i] * nv + f[:, j])]
+        np.add.at(b, nv + eid, (area / 3.0)[:, None] * np.asarray(g, dtype=np.float64)[None, :])
+    return b.ravel()
+
+
 def assemble_generic(n_dofs, cell_dofs, Ke):
     cd = np.asarray(cell_dofs, dtype=np.int64)
     nd = cd.shape[1]
