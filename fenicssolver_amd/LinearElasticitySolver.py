@@ -1,4 +1,4 @@
-"""LinearElasticitySolver — small-strain isotropic elasticity on vector P1, GPU back end.
+"""LinearElasticitySolver — small-strain isotropic elasticity on vector P1 / P2, GPU back end.
 
 Counterpart of FenicsSolver/LinearElasticitySolver.py: same class/constructor (forces
 vector_name='displacement', :55-60), sigma(u) = 2 mu sym(grad u) + lambda div(u) I
@@ -10,6 +10,12 @@ Reference quirk kept by default (Appendix B-Q3): body forces and tractions are A
 F (:227-228, 242-243), so they act with reversed sign; set
 ``solver.reference_load_sign = False`` for the physical convention.  The thermal term has
 the conventional sign in both.  Modal analysis (:270-312, SLEPc) is out of scope.
+
+Vector P2 (the reference's own example, examples/test_linear_elasticity.py:105-106) runs on one GPU; its solve_amg uses
+Jacobi-CG (the aggregation hierarchy is built on P1 node patterns).  ``von_Mises`` is the consistent L2 projection onto P1,
+assembled and solved on the device (fs_assemble_von_mises + P1 mass matrix + CG).  Elastodynamics
+(``solving_dynamics = True``, :216-220) subtracts rho * acceleration with the reference's own finite-difference
+acceleration (SolverBase.py:477-482, including its division by 1/dt).
 """
 from __future__ import annotations
 
@@ -40,7 +46,7 @@ class LinearElasticitySolver(SolverBase):
         return mu, lmbda
 
     def _cell_gradients(self, u):
-        """grad u per cell [nc,3,3] (component i, derivative j) of a P1 displacement."""
+        """grad u per cell [nc,3,3] (component i, derivative j); P2 displacements: at the cell centroid."""
         co = self.mesh.coordinates()
         ce = self.mesh.cells().astype(np.int64)
         X = co[ce]
@@ -49,11 +55,19 @@ class LinearElasticitySolver(SolverBase):
         g = np.zeros((len(ce), 4, 3))
         g[:, 1:, :] = Ji
         g[:, 0, :] = -Ji.sum(axis=1)
-        U = u.vertex_values()[ce]                       # [nc,4,3]
-        return np.einsum("cai,caj->cij", U, g)
+        V = u.function_space()
+        if V.degree() == 1:
+            return np.einsum("cai,caj->cij", u.vertex_values()[ce], g)
+        # P2 at the centroid (lambda = 1/4): vertex functions have zero gradient there, edge (i,j): g_i + g_j
+        ei, ej = [2, 1, 1, 0, 0, 0], [3, 3, 2, 3, 2, 1]
+        cd = V.cell_nodes()
+        U = u.node_values()[cd[:, 4:]]                  # [nc,6,3]
+        ge = g[:, ei, :] + g[:, ej, :]
+        return np.einsum("cai,caj->cij", U, ge)
 
     def sigma(self, u):
-        """Cell-wise (DG0) stress tensor [nc,3,3] of a displacement Function."""
+        """Cell-wise (DG0) stress tensor [nc,3,3] of a displacement Function (post-processing helper on the host; the
+        reference returns the UFL expression, LinearElasticitySolver.py:62-69)."""
         mu, lmbda = self.lame_parameters()
         G = self._cell_gradients(u)
         eps = 0.5 * (G + np.transpose(G, (0, 2, 1)))
@@ -61,21 +75,27 @@ class LinearElasticitySolver(SolverBase):
         return 2.0 * mu * eps + lmbda * tr[:, None, None] * np.eye(3)[None]
 
     def von_Mises(self, u):
-        """project(sqrt(3/2 s:s), P1) (:71-76) with a lumped mass matrix: volume-weighted vertex average."""
+        """project(sqrt(3/2 s:s), FunctionSpace(mesh, 'P', 1)) (:71-76): the consistent L2 projection, on the device -
+        right-hand side int vm phi_a dx (fs_assemble_von_mises), P1 mass matrix, Jacobi-CG to 1e-12."""
         from .fem import FunctionSpace
-        s = self.sigma(u)
-        dev = s - np.trace(s, axis1=1, axis2=2)[:, None, None] / 3.0 * np.eye(3)[None]
-        vm = np.sqrt(1.5 * np.einsum("cij,cij->c", dev, dev))
-        co = self.mesh.coordinates()
-        ce = self.mesh.cells().astype(np.int64)
-        X = co[ce]
-        vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))) / 6.0
-        num = np.zeros(len(co))
-        den = np.zeros(len(co))
-        np.add.at(num, ce.ravel(), np.repeat(vm * vol, 4))
-        np.add.at(den, ce.ravel(), np.repeat(vol, 4))
-        f = Function(FunctionSpace(self.mesh, 'P', 1))
-        f.vector().set_local(num / den)
+        from . import backend
+        V = u.function_space()
+        if V.localizer() is not None:
+            raise SolverError('von_Mises: the projection is built for one GPU')
+        P = FunctionSpace(self.mesh, 'P', 1)
+        dV, dP = V.device(), P.device()
+        mu, lmbda = self.lame_parameters()
+        ud = backend.DeviceVector(dV.n_local, u.vector().array())
+        b = backend.DeviceVector(dP.n_owned)
+        backend.assemble_von_mises(dV, ud, mu, lmbda, dP, b)
+        M = backend.DeviceMatrix(dP)
+        M.assemble(mass=1.0)
+        x = backend.DeviceVector(dP.n_local)
+        st = backend.krylov_solve(M, b, x, rtol=1e-12, max_iter=2000, precond="jacobi", norm="preconditioned")
+        if st['converged'] != 1:
+            raise SolverError('von_Mises: the mass-matrix solve did not converge')
+        f = Function(P)
+        f.vector().set_local(x.get()[:dP.n_owned])
         return f
 
     def thermal_stress_coefficient(self):
@@ -219,9 +239,10 @@ class LinearElasticitySolver(SolverBase):
 
     # ------------------------------------------------------------------ the form
     def generate_form(self, time_iter_, u, v, u_current, u_prev):
-        if self.transient_settings['transient'] and self.solving_dynamics:
-            raise SolverError('elastodynamics (acceleration term) is not built yet')
         F = forms.ElasticityForm(self.function_space)
+        if self.transient_settings['transient'] and self.solving_dynamics and time_iter_ >= 1:
+            # F -= density * inner(accel, v) * dx (:216-220) with the explicit acceleration of SolverBase.get_acceleration
+            F.inertia = (float(self.material['density']), self.get_acceleration(time_iter_))
         F.mu, F.lmbda = self.lame_parameters()
         F.load_sign = -1.0 if self.reference_load_sign else 1.0
 

@@ -675,8 +675,22 @@ class SolverBase():
                 if np.ndim(T) == 0:
                     backend.assemble_vector(V, b, div_coef=coef * (float(T) - T_ref), add=True)
                 else:
-                    Tn = np.asarray(T) if loc is None else loc.nodes(np.asarray(T))
+                    Tn = np.asarray(T)               # P1 temperature: its vertex values
+                    if F.space.degree() == 2:        # nodal array over the P2 nodes; the kernel reads the vertex entries
+                        Tn = np.concatenate([Tn, np.full(F.space.num_nodes() - len(Tn), T_ref)])
+                    Tn = Tn if loc is None else loc.nodes(Tn)
                     backend.assemble_vector(V, b, div_coef=("nodal", coef * (Tn - T_ref)), add=True)
+            if getattr(F, 'inertia', None) is not None:
+                # F -= rho inner(accel, v) dx with the known (explicit) acceleration: rhs += rho M accel
+                rho, accel = F.inertia
+                Mv = backend.DeviceMatrix(V)
+                Mv.assemble(lame=(0.0, 0.0), mass=L_(rho))
+                ah = accel.vector().array()
+                ah = ah if loc is None else loc.nodes(ah)
+                ad = backend.DeviceVector(V.n_local, np.concatenate([ah, np.zeros(V.n_local - len(ah))]))
+                tmp = backend.DeviceVector(V.n_owned)
+                Mv.spmv(ad, tmp)
+                b.axpy(1.0, tmp)
         else:
             raise SolverError('unknown form specification {}'.format(type(F)))
         dofs, vals = self._bc_arrays(bcs)

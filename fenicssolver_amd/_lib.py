@@ -134,6 +134,7 @@ SIGNATURES = {
     "fs_saddle_solve": (C.c_int, [_H, _H, _H, _H, _H, _H, C.POINTER(fs_saddle_opts), C.POINTER(fs_krylov_stats)]),
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+    "fs_assemble_von_mises": (C.c_int, [_H, _H, C.c_double, C.c_double, _H, _H]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fs_comm_allreduce_sum": (C.c_int, [c_f64p, C.c_int]),
     "fs_comm_allgather": (C.c_int, [c_f64p, c_i64, c_i64, c_f64p]),

@@ -358,6 +358,11 @@ def assemble_facet_vector(space, b, tri, g):
             "fs_assemble_facet_vector")
 
 
+def assemble_von_mises(disp_space, u, mu, lmbda, p1_space, b):
+    """b_a = int sqrt(3/2 s:s) phi_a dx, s the deviator of sigma(u), on the scalar CG1 space of the same mesh."""
+    L.check(L.load().fs_assemble_von_mises(disp_space.h, u.h, float(mu), float(lmbda), p1_space.h, b.h), "fs_assemble_von_mises")
+
+
 def set_dirichlet_values(b, dofs, vals):
     dofs = L.i32(dofs).ravel()
     vals = L.f64(np.broadcast_to(vals, dofs.shape))

@@ -1379,6 +1379,112 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source_gather(int64_t 
     }
 }
 
+// ---- von Mises stress, right-hand side of its L2 projection onto P1 (LinearElasticitySolver.py:71-76: project(von_Mises, V)
+// = solve  int w q dx = int sqrt(3/2 s:s) q dx) ---------------------------------------------------------------------------
+// b_a = int vm(x) lambda_a dx over the cells of vertex a (row gather on the scalar CG1 space of the mesh: lane = vertex, its
+// incidences in ascending cell order, no atomics).  s = dev(sigma(u)), sigma = 2 mu sym(grad u) + lambda div u I.
+// P1 displacement: grad u is constant per cell -> vm V / 4 exactly.  P2 displacement: grad u is linear, vm is not a
+// polynomial; it is integrated with the 4-point degree-2 rule against lambda_a (the same rule everywhere else on CG2).
+__device__ __forceinline__ double von_mises_of(const double (&G)[3][3], double mu, double lambda) {
+    const double tr = G[0][0] + G[1][1] + G[2][2];
+    double sg[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sg[i][j] = mu * (G[i][j] + G[j][i]) + (i == j ? lambda * tr : 0.0);
+    const double p = (sg[0][0] + sg[1][1] + sg[2][2]) * (1.0 / 3.0);
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double d = sg[i][j] - (i == j ? p : 0.0);
+            ss += d * d;
+        }
+    return sqrt(1.5 * ss);
+}
+template <int DEG>
+__global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                             const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
+                                                             const double* __restrict__ xyz4, const int32_t* __restrict__ u_dofs,
+                                                             const double* __restrict__ u, double mu, double lambda,
+                                                             double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q >> 2, a = q & 3;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const tet_geom t = tet_geometry(xyz4, v);
+            const double vol = t.adet * (1.0 / 6.0);
+            if (DEG == 1) {
+                double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int64_t d = (int64_t)u_dofs[(int64_t)c * 4 + n] * 3;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) G[i][k] += u[d + i] * t.g[n][k];
+                }
+                acc += 0.25 * vol * von_mises_of(G, mu, lambda);
+            } else {
+                double un[10][3];
+#pragma unroll
+                for (int n = 0; n < 10; ++n) {
+                    const int64_t d = (int64_t)u_dofs[(int64_t)c * 10 + n] * 3;
+                    un[n][0] = u[d]; un[n][1] = u[d + 1]; un[n][2] = u[d + 2];
+                }
+#pragma unroll
+                for (int qp = 0; qp < 4; ++qp) {
+                    const double lam[4] = {FS_P2_QP[qp][0], FS_P2_QP[qp][1], FS_P2_QP[qp][2], FS_P2_QP[qp][3]};
+                    double gp[10][3];
+                    p2_basis_grads(t, lam, gp);
+                    double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                    for (int n = 0; n < 10; ++n)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) G[i][k] += un[n][i] * gp[n][k];
+                    const double la = a == 0 ? lam[0] : a == 1 ? lam[1] : a == 2 ? lam[2] : lam[3];
+                    acc += 0.25 * vol * la * von_mises_of(G, mu, lambda);
+                }
+            }
+        }
+        if (row < n_rows) b[row] = acc;
+    }
+}
+
+extern "C" int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, double lambda, fs_space_t p1_space,
+                                     fs_vector_t b) {
+    FS_REQUIRE(disp_space && u && p1_space && b, "fs_assemble_von_mises: null pointer");
+    FS_REQUIRE(disp_space->mesh == p1_space->mesh, "fs_assemble_von_mises: the two spaces live on different meshes");
+    FS_REQUIRE(disp_space->ncomp == 3 && disp_space->mesh->tdim == 3, "fs_assemble_von_mises: needs a 3-vector displacement space on tetrahedra");
+    FS_REQUIRE(p1_space->ncomp == 1 && p1_space->degree == 1 && p1_space->inc_cell.p, "fs_assemble_von_mises: the target is the scalar CG1 space of the mesh");
+    FS_REQUIRE(u->d.n >= disp_space->n_dofs_local && b->d.n >= p1_space->n_dofs_owned, "fs_assemble_von_mises: vector too short");
+    hipStream_t s = fs_rt().stream;
+    fs_mesh_s* m = p1_space->mesh;
+    const int g = fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192);
+    if (disp_space->degree == 1)
+        hipLaunchKernelGGL(k_von_mises_load<1>, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
+                           p1_space->inc_cell.p, m->cells.p, m->xyz.p, disp_space->cell_dofs, u->d.p, mu, lambda, b->d.p);
+    else
+        hipLaunchKernelGGL(k_von_mises_load<2>, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
+                           p1_space->inc_cell.p, m->cells.p, m->xyz.p, disp_space->cell_dofs, u->d.p, mu, lambda, b->d.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 // vector CG1 load vector without atomics: thread per owned node; the cells holding the node are the sources of its
 // diagonal block in the inverse slot table (ascending cell order: the right-hand side - and with it the iteration
 // counts of the elasticity solves - is reproducible)

@@ -563,19 +563,17 @@ class _Element:
 
 
 class FunctionSpace:
-    """dolfin.FunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
-    Only continuous P1 is built in this revision; the dof of vertex v (component i of an
-    ncomp-vector space) is v*ncomp + i."""
+    """dolfin.FunctionSpace / VectorFunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
+    Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D scalar P1.
+    Component i of node n of an ncomp-vector space is dof n*ncomp + i (DOLFIN interleaves the same way).
+    Not built: periodic constraints (constrained_domain raises), 2-D vector / P2 spaces, degree > 2."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
                  _parent=None, _holder=False):
         if family not in ("CG", "P", "Lagrange"):
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
         if int(degree) not in (1, 2):
-            raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and scalar P2 only)".format(degree))
-        if int(degree) == 2 and _ncomp != 1 and not _holder:
-            # _holder: host-side container of the velocity part of a Taylor-Hood solution (mixed.split)
-            raise SolverError("vector P2 spaces are not built in fenicssolver_amd (P2 is scalar)")
+            raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and P2 only)".format(degree))
         if constrained_domain is not None:
             raise SolverError("periodic_boundary (constrained_domain) is not supported")
         if mesh.topology().dim() == 2 and (int(degree) != 1 or _ncomp != 1):
@@ -613,6 +611,25 @@ class FunctionSpace:
                 ed = ed[np.lexsort((ed[:, 0], delta))]
             root._edge_nodes = ed
         return root._edge_nodes
+
+    def cell_nodes(self):
+        """[num_cells, 4 | 10] node ids of every cell: its vertices, then (P2) the nodes of its 6 UFC edges
+        e0=(v2,v3) e1=(v1,v3) e2=(v1,v2) e3=(v0,v3) e4=(v0,v2) e5=(v0,v1)."""
+        ce = self._mesh.cells().astype(np.int64)
+        if self._degree == 1:
+            return ce
+        root = self.root()
+        if getattr(root, "_cell_nodes", None) is None:
+            nv = self._mesh.num_vertices()
+            ed = self.edge_nodes().astype(np.int64)
+            ekey = ed[:, 0] * nv + ed[:, 1]
+            sorter = np.argsort(ekey)
+            cols = [ce]
+            for i, j in ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)):
+                a, b = np.minimum(ce[:, i], ce[:, j]), np.maximum(ce[:, i], ce[:, j])
+                cols.append((nv + sorter[np.searchsorted(ekey[sorter], a * nv + b)])[:, None])
+            root._cell_nodes = np.concatenate(cols, axis=1)
+        return root._cell_nodes
 
     def num_nodes(self):
         """P1: vertices; P2: vertices + edge nodes."""
@@ -706,7 +723,8 @@ class FunctionSpace:
         one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
         from . import partition
         if root._degree == 2 and root._ncomp not in (1, 4):
-            raise SolverError("multi-GPU decomposition is built for P1 spaces, scalar P2 spaces and the Taylor-Hood space")
+            raise SolverError("multi-GPU decomposition is built for P1 spaces, scalar P2 spaces and the Taylor-Hood space; "
+                              "vector P2 runs on one GPU")
         rank, size = parallel.ensure_comm()
         mesh = root._mesh
         co, ce = mesh.coordinates(), mesh.cells()

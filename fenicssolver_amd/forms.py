@@ -115,6 +115,7 @@ class ElasticityForm:
         self.tractions = []           # [FacetLoad] with vector g
         self.thermal = None           # (coefficient E*alpha/(1-2nu), T nodal array or float, T_ref)
         self.load_sign = -1.0         # reference adds the load terms to F => rhs = -loads (Appendix B-Q3)
+        self.inertia = None           # (density, acceleration dof array): F -= rho a . v dx => rhs += rho M a (:216-220)
 
     def describe(self):
         return {

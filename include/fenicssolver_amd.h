@@ -203,6 +203,13 @@ typedef struct fs_linear_form {
 } fs_linear_form;
 int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add);
 
+/* Right-hand side of the L2 projection of the von Mises stress onto the scalar CG1 space of the mesh
+ * (LinearElasticitySolver.py:71-76, project(sqrt(3/2 s:s), FunctionSpace(mesh, 'P', 1))): b_a = int vm(u) phi_a dx with
+ * s = dev(2 mu sym(grad u) + lambda div u I).  disp_space: 3-vector CG1 or CG2 space, u its dof vector (owned + ghost);
+ * p1_space: scalar CG1 space on the SAME mesh.  The projection itself is fs_assemble_matrix(mass = 1) on p1_space +
+ * fs_krylov_solve.  CG1 displacement: exact; CG2: 4-point degree-2 rule. */
+int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, double lambda, fs_space_t p1_space, fs_vector_t b);
+
 /* SUPG part of the boundary integrals (the reference substitutes q + tau (v . grad q) in them too,
  * ScalarTransportSolver.py:296-298 with Tq): for every listed boundary facet (cell behind it, local vertex opposite)
  *   b_a += g_f * area * w_a                      (flux / Neumann / HTC ambient loads; g may be NULL)

@@ -734,6 +734,38 @@ def assemble_p2_facet_vector_load(coords, edges, facets, facet_markers, marker_i
     return b.ravel()
 
 
+def von_mises_at(G, E, nu):
+    """sqrt(3/2 s:s), s = dev(2 mu sym(G) + lmbda tr(G) I), for displacement gradients G[..., 3, 3]
+    (LinearElasticitySolver.py:62-76)."""
+    mu, lmbda = lame(E, nu)
+    tr = np.trace(G, axis1=-2, axis2=-1)
+    sg = mu * (G + np.swapaxes(G, -1, -2)) + lmbda * tr[..., None, None] * np.eye(3)
+    dev = sg - np.trace(sg, axis1=-2, axis2=-1)[..., None, None] / 3.0 * np.eye(3)
+    return np.sqrt(1.5 * np.einsum("...ij,...ij->...", dev, dev))
+
+
+def von_mises_projection(coords, cells, u, E, nu, degree=1, cell_dofs=None):
+    """project(von_Mises(u), FunctionSpace(mesh, 'P', 1)) (LinearElasticitySolver.py:71-76): solve M w = b with the
+    consistent P1 mass matrix, b_a = int vm lambda_a dx.  u: [n_nodes, 3].  P1 displacement: vm is constant per cell;
+    P2 (cell_dofs [nc,10]): 4-point degree-2 rule.  Returns (w, b)."""
+    ce = np.asarray(cells, dtype=np.int64)
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    be = np.zeros((len(ce), 4))
+    if degree == 1:
+        G = np.einsum("cni,cnk->cik", np.asarray(u)[ce], g)
+        be[:] = (0.25 * vol * von_mises_at(G, E, nu))[:, None]
+    else:
+        un = np.asarray(u)[np.asarray(cell_dofs, dtype=np.int64)]          # [nc,10,3]
+        for lam in P2_QUAD_POINTS:
+            gp = p2_basis_gradients(g, lam)
+            G = np.einsum("cni,cnk->cik", un, gp)
+            be += 0.25 * (vol * von_mises_at(G, E, nu))[:, None] * np.asarray(lam)[None, :]
+    b = assemble_generic_vector(len(coords), ce, be)
+    M = assemble_matrix(len(coords), cells, p1_mass_local(coords, cells, 1.0))
+    return solve_direct(M, b), b
+
+
 def assemble_generic(n_dofs, cell_dofs, Ke):
     cd = np.asarray(cell_dofs, dtype=np.int64)
     nd = cd.shape[1]

@@ -157,6 +157,30 @@ bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'valu
 bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
 run("elasticity_force", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(bcs)))
 
+# --- case 6b: the reference's own elasticity example, as its __main__ runs it (examples/test_linear_elasticity.py:42-129,
+# 170: BoxMesh 40x10x10, VectorFunctionSpace(mesh, "Lagrange", 2), left face (0, free, free), right face (0, 0, 1e-3),
+# body force, thermal stress at 343 K)
+def example_settings():
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 40, 10, 10)
+    st = copy.copy(SolverBase.default_case_settings)            # shallow, as the example does (Appendix B-Q12)
+    st['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    st['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 2)
+    bcs = collections.OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), None, None)}
+    bcs["displ"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant((0, 0, 1 * 1e-3))}
+    st['boundary_conditions'] = bcs
+    st['solver_settings'] = copy.deepcopy(st['solver_settings'])
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = Expression("343", degree=2)
+    st['body_source'] = Expression(("10*rho", "0", "0.0"), omega=100, rho=7800, degree=2)
+    return st
+
+
+run("elasticity_example_p2", LinearElasticitySolver.LinearElasticitySolver(example_settings()))
+out["elasticity_example_p2"]["function_space"] = {"family": "Lagrange", "degree": 2, "mesh": "BoxMesh((0,0,0),(10,1,1),40,10,10)"}
+
 # --- Taylor-Hood Navier-Stokes (CoupledNavierStokesSolver.py) ---------------------------------------
 from FenicsSolver import CoupledNavierStokesSolver                                                     # noqa: E402
 

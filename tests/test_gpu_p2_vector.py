@@ -80,7 +80,7 @@ def test_p2_vector_load_vectors_equal_oracle(gpu):
     ref = ref + fo.assemble_p2_vector_source(co, ce, f) + fo.assemble_generic_vector(3 * n, vd, fo.p2_div_load_local(co, ce, c_const=2.5))
     assert np.abs(b.get() - ref).max() <= 1e-12 * np.abs(ref).max()
     # traction int g . v ds on the face x = x_max
-    facets, _ = fo.facet_numbering(ce)
+    facets = fo.facet_numbering(ce)[0]
     fm = fo.mark_facets(co, ce, lambda x, on: on and abs(x[0] - 2.0) < 1e-12, 5)
     tri = facets[fm == 5]
     g = (1e3, 0.0, -4e3)
@@ -102,7 +102,7 @@ def test_p2_cantilever_solve_equals_oracle_direct_solve(gpu):
     b = gpu.DeviceVector(V.n_owned)
     f = (0.0, 0.0, -7800.0 * 10.0)
     gpu.assemble_vector(V, b, vector_value=f)
-    facets, _ = fo.facet_numbering(ce)
+    facets = fo.facet_numbering(ce)[0]
     fm = fo.mark_facets(co, ce, lambda x, on: on and abs(x[0]) < 1e-12, 1)
     fm = fo.mark_facets(co, ce, lambda x, on: on and abs(x[0] - 10.0) < 1e-12, 2, markers=fm)
     left = fo.p2_facet_dofs(len(co), edges, facets, fm, 1).astype(np.int64)
@@ -119,3 +119,150 @@ def test_p2_cantilever_solve_equals_oracle_direct_solve(gpu):
     ref = fo.solve_direct(Ab, bb)
     assert np.abs(x.get() - ref).max() <= 1e-7 * np.abs(ref).max()
     assert abs(x.get().reshape(n, 3)[right, 2] - 1e-3).max() <= 1e-15
+
+
+# ---- through the solver API ------------------------------------------------------------------------------------------
+QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+
+
+def _example_solver(nx, ny, nz, degree=2, thermal=True, body=True, **extra):
+    """examples/test_linear_elasticity.py:42-129 on an nx x ny x nz box."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, Constant, Expression, SubDomain, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+
+    class Left(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0)
+
+    class Right(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 10)
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), nx, ny, nz)
+    st = copy.deepcopy(SB.default_case_settings)
+    st['material'] = {'name': 'steel', 'elastic_modulus': E, 'poisson_ratio': NU, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    st['function_space'] = VectorFunctionSpace(mesh, "Lagrange", degree)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), None, None)}
+    bcs["displ"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant((0, 0, 1e-3))}
+    st['boundary_conditions'] = bcs
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['solver_settings']['solver_parameters'] = {'relative_tolerance': 1e-12, 'maximum_iterations': 100000}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = Expression("343", degree=degree) if thermal else None
+    if body:
+        st['body_source'] = Expression(("10*rho", "0", "0.0"), omega=100, rho=7800, degree=2)
+    st.update(extra)
+    return LinearElasticitySolver(st)
+
+
+def _oracle_example(co, ce, thermal=True, body=True):
+    """The same problem restated on the oracle: bug-compatible load sign (Appendix B-Q3), thermal term conventional."""
+    R, cd, edges = fo.assemble_p2_elasticity(co, ce, E, NU)
+    n = len(co) + len(edges)
+    b = np.zeros(3 * n)
+    if body:
+        b -= fo.assemble_p2_vector_source(co, ce, (78000.0, 0.0, 0.0))
+    if thermal:
+        c = E / (1 - 2 * NU) * 2e-6 * (343.0 - 293.0)
+        b += fo.assemble_generic_vector(3 * n, fo.p2_vector_cell_dofs(cd), fo.p2_div_load_local(co, ce, c_const=c))
+    facets = fo.facet_numbering(ce)[0]
+    fm = fo.mark_facets(co, ce, lambda x, on: abs(x[0]) < 1e-12, 1)
+    fm = fo.mark_facets(co, ce, lambda x, on: abs(x[0] - 10.0) < 1e-12, 2, markers=fm)
+    left = fo.p2_facet_dofs(len(co), edges, facets, fm, 1).astype(np.int64)
+    right = fo.p2_facet_dofs(len(co), edges, facets, fm, 2).astype(np.int64)
+    dofs = np.concatenate([left * 3, (right[:, None] * 3 + np.arange(3)).ravel()])
+    vals = np.concatenate([np.zeros(len(left)), np.tile([0.0, 0.0, 1e-3], len(right))])
+    Ab, bb = fo.apply_dirichlet(R, b, dofs, vals, True)
+    return fo.solve_direct(Ab, bb), cd, edges
+
+
+def test_reference_example_p2_small_equals_oracle(gpu):
+    solver = _example_solver(8, 2, 2)
+    u = solver.solve()
+    assert solver.function_space.degree() == 2 and u.vector().size() == solver.function_space.dim()
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 8, 2, 2)
+    ref, cd, edges = _oracle_example(co, ce)
+    assert np.array_equal(solver.function_space.edge_nodes(), edges)
+    assert np.abs(u.vector().array() - ref).max() <= 1e-6 * np.abs(ref).max()
+    # consistent L2 projection of the von Mises stress (LinearElasticitySolver.py:71-76) against the oracle's sparse LU
+    vm = solver.von_Mises(u).vector().array()
+    vm_ref, _ = fo.von_mises_projection(co, ce, u.vector().array().reshape(-1, 3), E, NU, degree=2, cell_dofs=cd)
+    assert np.abs(vm - vm_ref).max() <= 1e-8 * np.abs(vm_ref).max()
+    assert vm.shape == (len(co),) and vm.max() > 0
+
+
+def test_von_mises_projection_p1_equals_oracle(gpu):
+    solver = _example_solver(8, 2, 2, degree=1)
+    u = solver.solve()
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 8, 2, 2)
+    vm = solver.von_Mises(u).vector().array()
+    vm_ref, b_ref = fo.von_mises_projection(co, ce, u.vector().array().reshape(-1, 3), E, NU, degree=1)
+    assert np.abs(vm - vm_ref).max() <= 1e-9 * np.abs(vm_ref).max()
+    # a consistent projection is NOT the lumped vertex average round 1 computed
+    s = solver.sigma(u)
+    dev = s - np.trace(s, axis1=1, axis2=2)[:, None, None] / 3.0 * np.eye(3)
+    vmc = np.sqrt(1.5 * np.einsum("cij,cij->c", dev, dev))
+    X = co[ce.astype(np.int64)]
+    vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2))) / 6.0
+    num, den = np.zeros(len(co)), np.zeros(len(co))
+    np.add.at(num, ce.ravel(), np.repeat(vmc * vol, 4))
+    np.add.at(den, ce.ravel(), np.repeat(vol, 4))
+    assert np.abs(vm - num / den).max() > 1e-3 * np.abs(vm).max()
+    # ... but both conserve the integral of vm
+    M = fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 1.0))
+    assert abs((M @ vm).sum() - (vmc * vol).sum()) <= 1e-9 * (vmc * vol).sum()
+
+
+def test_reference_example_p2_full_size(gpu):
+    """The example's own mesh (40 x 10 x 10 cells, 41 x 11 x 11 vertices + 30 870... edge nodes): runs, meets its Dirichlet
+    data, and agrees with the oracle restated on the same mesh in the energy norm of the load-free part."""
+    solver = _example_solver(40, 10, 10, thermal=True, body=True)
+    u = solver.solve()
+    V = solver.function_space
+    X = V.node_coordinates()
+    U = u.node_values()
+    assert U.shape == (V.num_nodes(), 3) and V.num_nodes() == 81 * 21 * 21
+    assert np.abs(U[np.isclose(X[:, 0], 10.0)] - [0.0, 0.0, 1e-3]).max() <= 1e-15
+    assert np.abs(U[np.isclose(X[:, 0], 0.0), 0]).max() == 0.0
+    st = solver.last_solve_stats
+    assert st["converged"] == 1 and st["true_rel_residual"] <= 1e-8
+    # residual of the discrete equilibrium equations against the oracle's operator (free dofs)
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 40, 10, 10)
+    R, cd, edges = fo.assemble_p2_elasticity(co, ce, E, NU)
+    n = len(co) + len(edges)
+    b = -fo.assemble_p2_vector_source(co, ce, (78000.0, 0.0, 0.0))
+    b += fo.assemble_generic_vector(3 * n, fo.p2_vector_cell_dofs(cd), fo.p2_div_load_local(co, ce, c_const=E / (1 - 2 * NU) * 2e-6 * 50.0))
+    r = R @ u.vector().array() - b
+    free = np.ones(3 * n, dtype=bool)
+    free[3 * np.nonzero(np.isclose(X[:, 0], 0.0))[0]] = False
+    free[(3 * np.nonzero(np.isclose(X[:, 0], 10.0))[0][:, None] + np.arange(3)).ravel()] = False
+    assert np.linalg.norm(r[free]) <= 1e-7 * np.linalg.norm(b)
+
+
+def test_elastodynamics_inertia_term(gpu):
+    """solving_dynamics = True (LinearElasticitySolver.py:216-220): from the second step on the explicit acceleration of
+    SolverBase.get_acceleration enters the right-hand side as rho M a; checked against the oracle's consistent mass matrix."""
+    import scipy.sparse as sps
+    tr = {'transient': True, 'starting_time': 0.0, 'time_step': 1e-3, 'ending_time': 3e-3}
+    solver = _example_solver(6, 2, 2, degree=1, thermal=False, body=True)
+    solver.transient_settings = tr
+    solver.solving_dynamics = True
+    solver.init_solver()
+    rng = np.random.default_rng(5)
+    n = solver.function_space.dim()
+    for f in (solver.w_current, solver.w_prev, solver.w_pp):
+        f.vector().set_local(1e-4 * rng.standard_normal(n))
+    F, bcs = solver.generate_form(1, None, None, solver.w_current, solver.w_prev)
+    assert F.inertia is not None and F.inertia[0] == 7800.0
+    A, b = solver.assemble_system(F, [], symmetric=True)
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 6, 2, 2)
+    M = sps.kron(fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 7800.0)), sps.identity(3)).tocsr()
+    dt = 1e-3
+    w0, w1, w2 = solver.w_current.vector().array(), solver.w_prev.vector().array(), solver.w_pp.vector().array()
+    accel = ((w0 - w1) / dt - (w1 - w2) / dt) / (1.0 / dt)                 # the reference's own scaling (SolverBase.py:477-482)
+    ref = M @ accel - fo.assemble_p1_vector_source(co, ce, (78000.0, 0.0, 0.0))
+    assert np.abs(b.get() - ref).max() <= 1e-11 * np.abs(ref).max()

@@ -311,6 +311,44 @@ def test_elasticity_terms():
     assert bc_list(dbc) == golden_bcs(g)
 
 
+def test_reference_elasticity_example_on_vector_p2():
+    """examples/test_linear_elasticity.py as its __main__ runs it: BoxMesh 40x10x10, VectorFunctionSpace(mesh, 'Lagrange', 2),
+    left face clamped in x only, right face displaced by (0, 0, 1e-3), body force, thermal stress at 343 K."""
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, Constant, Expression
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    left, right = _sides()
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 40, 10, 10)
+    st = copy.deepcopy(SB.default_case_settings)
+    st['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    V = VectorFunctionSpace(mesh, "Lagrange", 2)
+    st['function_space'] = V
+    bcs = collections.OrderedDict()
+    bcs["fixed"] = {'boundary': left, 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), None, None)}
+    bcs["displ"] = {'boundary': right, 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant((0, 0, 1 * 1e-3))}
+    st['boundary_conditions'] = bcs
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = Expression("343", degree=2)
+    st['body_source'] = Expression(("10*rho", "0", "0.0"), omega=100, rho=7800, degree=2)
+    solver = LinearElasticitySolver(st)
+    gold = GOLD["elasticity_example_p2"]
+    assert gold["function_space"]["degree"] == V.degree() == 2 and solver.function_space.ufl_element().value_size() == 3
+    F, dbc = _form_of(solver)
+    g = gold["solves"][0]
+    assert_same_poly(elasticity_form_poly(F), golden_poly(g))
+    assert bc_list(dbc) == golden_bcs(g)
+    # topological Dirichlet sets on P2: vertices AND edge midpoints of the marked faces (Appendix D-3)
+    X = V.node_coordinates()
+    nv = mesh.num_vertices()
+    fixed, displ = dbc
+    assert len(fixed.dofs) == 21 * 21 and np.all(fixed.dofs % 3 == 0) and np.allclose(X[fixed.dofs // 3, 0], 0.0)
+    assert np.count_nonzero(fixed.dofs // 3 >= nv) == 21 * 21 - 11 * 11
+    assert len(displ.dofs) == 3 * 21 * 21 and np.allclose(X[displ.dofs // 3, 0], 10.0)
+    assert np.array_equal(displ.values.reshape(-1, 3), np.tile([0.0, 0.0, 1e-3], (21 * 21, 1)))
+
+
 # ------------------------------------------------------------------ Taylor-Hood Navier-Stokes
 def _ns_expected_terms(desc, state="W0", prev="WPREV"):
     """The integrals the reference builds for a NavierStokesForm description (CoupledNavierStokesSolver.py:315-381),
