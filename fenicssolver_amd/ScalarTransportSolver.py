@@ -6,10 +6,11 @@ keys, material look-ups (:73-129), boundary types (:142-211), body source (:213-
 and time scheme (Crank-Nicolson, :287-293).  ``generate_form`` returns a
 ``forms.ScalarForm`` (which integrals, which coefficients) instead of a UFL form.
 
-Not built yet (raise SolverError, never silently ignored): convective velocity and
-its SUPG/IP stabilisation (:244-276, 305-328; non-symmetric operator -> BiCGStab),
-radiation and temperature-dependent material (Newton, :338-357, 361-376), point and
-surface sources (broken in the reference as well, Appendix B-Q6).
+Built: steady and Crank-Nicolson transient diffusion on P1 and P2; Dirichlet / Neumann / Robin / flux / HTC boundaries;
+body and point sources; convective velocity (non-symmetric operator -> BiCGStab) with SUPG ('SPUG') and interior-penalty
+('IP') stabilisation (:244-276, 305-328; P1, IP on one GPU); surface radiation and temperature-dependent conductivity
+through Newton (:338-357, 361-376; P1).  Raises SolverError (never silently ignored): ``surface_source`` (undefined
+symbols in the reference as well, Appendix B-Q6), advection / nonlinear terms on P2, periodic boundaries.
 Reference quirks kept on purpose: Neumann ('fixedGradient') terms are scaled by the
 capacity rho*cp, not the conductivity (B-Q8).
 """

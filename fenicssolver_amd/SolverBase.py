@@ -742,6 +742,10 @@ class SolverBase():
         else:
             ext_dev, ext_mask = loc.facets(ext)
         krtol, kmax, pc = self._krylov_options()
+        if pc not in ('jacobi', 'none', None):
+            # 'amg' / 'petsc_amg' / 'hypre_amg' are accepted by _krylov_options; the Newton steps solve with Jacobi-CG
+            self.logger.warning("solve_nonlinear_problem: preconditioner '%s' is not built for the Newton steps; using Jacobi", pc)
+            pc = 'jacobi'
         r0 = None
         self.newton_iterations = 0
         for it in range(max_it + 1):

@@ -463,26 +463,12 @@ class Constant:
         return self._v if self._v.ndim else float(self._v)
 
 
-_ALLOWED = {
-    "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log, "sqrt": np.sqrt,
-    "pow": np.power, "fabs": np.abs, "abs": np.abs, "atan": np.arctan, "atan2": np.arctan2,
-    "asin": np.arcsin, "acos": np.arccos, "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh,
-    "floor": np.floor, "ceil": np.ceil, "fmin": np.minimum, "fmax": np.maximum,
-    "pi": math.pi, "DOLFIN_PI": math.pi, "DOLFIN_EPS": DOLFIN_EPS, "M_PI": math.pi,
-}
-
-
 def _compile_cexpr(code):
-    """C-syntax scalar expression in x[0..2] (dolfin.Expression string) -> python code object."""
-    if not isinstance(code, str):
-        code = repr(float(code))
-    src = re.sub(r"x\s*\[\s*(\d)\s*\]", r"x\1", code)
-    src = src.replace("&&", " and ").replace("||", " or ")
-    if "?" in src:
-        raise SolverError("Expression '{}': the C ternary operator is not supported".format(code))
+    """C++-syntax scalar expression in x[0..2] (dolfin.Expression string) -> cexpr.CExpr (parsed, never eval'ed)."""
+    from .cexpr import CExpr, CExprError
     try:
-        return compile(src, "<Expression>", "eval")
-    except SyntaxError as e:
+        return CExpr(code)
+    except CExprError as e:
         raise SolverError("Expression '{}' cannot be parsed: {}".format(code, e))
 
 
@@ -524,16 +510,13 @@ class Expression:
             pts = pts.reshape(1, -1)
         if pts.shape[1] < 3:
             pts = np.concatenate([pts, np.zeros((pts.shape[0], 3 - pts.shape[1]))], axis=1)
-        env = dict(_ALLOWED)
-        env.update(self.params)
-        env.update(x0=pts[:, 0], x1=pts[:, 1], x2=pts[:, 2])
+        from .cexpr import CExprError
         cols = []
         for o in self._objs:
             try:
-                v = eval(o, {"__builtins__": {}}, env)
-            except NameError as e:
+                cols.append(o(pts, self.params))
+            except CExprError as e:
                 raise SolverError("Expression {}: {}".format(self._code, e))
-            cols.append(np.broadcast_to(np.asarray(v, dtype=np.float64), (pts.shape[0],)))
         out = np.stack(cols, axis=1)
         return out[:, 0] if not self._shape else out
 
@@ -971,15 +954,31 @@ class DirichletBC:
         n = V._ncomp
         comp = V.component()
         co = V.node_coordinates()[verts]
+        if isinstance(value, Function):
+            # translate_value() turns strings / tuples of strings / file names into Functions (SolverBase.py:349-393);
+            # DOLFIN's DirichletBC takes their values at the constrained dofs
+            vals = value.node_values()
+            if vals.shape[0] != V.num_nodes():
+                raise SolverError("DirichletBC: the value Function lives on another space ({} nodes, the BC space has {})".format(
+                    vals.shape[0], V.num_nodes()))
+            vals = vals.reshape(V.num_nodes(), -1)[verts]
+            if comp is not None and vals.shape[1] == n:
+                vals = vals[:, [comp]]                  # vector Function on V.sub(i): its i-th component
+            size = 1 if (n == 1 or comp is not None) else n
+            if vals.shape[1] != size:
+                raise SolverError("DirichletBC value has {} components, the (sub)space has {}".format(vals.shape[1], size))
+            ev = lambda pts, sz: vals                   # noqa: E731
+        else:
+            ev = lambda pts, sz: self._eval(value, pts, sz)     # noqa: E731
         if n == 1:
             self.dofs = verts.astype(np.int32)
-            self.values = self._eval(value, co, 1).reshape(-1)
+            self.values = ev(co, 1).reshape(-1).astype(np.float64)
         elif comp is not None:
             self.dofs = (verts * n + comp).astype(np.int32)
-            self.values = self._eval(value, co, 1).reshape(-1)
+            self.values = ev(co, 1).reshape(-1).astype(np.float64)
         else:
             self.dofs = (verts[:, None] * n + np.arange(n)[None, :]).ravel().astype(np.int32)
-            self.values = self._eval(value, co, n).reshape(-1)
+            self.values = ev(co, n).reshape(-1).astype(np.float64)
 
     @staticmethod
     def _eval(value, pts, size):

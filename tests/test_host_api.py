@@ -218,8 +218,17 @@ def test_expression_and_dirichlet():
     assert np.allclose(f.vector().array(), 1 + co[:, 0] ** 2 + 2 * co[:, 1] - co[:, 2] ** 3 + np.sin(np.pi * co[:, 0]))
     e = Expression(("10*rho", "0", "0.0"), rho=7800, omega=100, degree=2)   # examples/test_linear_elasticity.py:68
     assert np.allclose(e.eval_points(co[:2]), [[78000.0, 0, 0]] * 2)
+    # C++ semantics, not Python's (fenicssolver_amd/cexpr.py): ternary, integer division, no eval of arbitrary code
+    assert np.array_equal(Expression("x[0] > 0.5 ? 1 : 2", degree=1).eval_points(co), np.where(co[:, 0] > 0.5, 1.0, 2.0))
+    assert np.array_equal(Expression("1/2*x[0] + 7/2", degree=1).eval_points(co), np.full(len(co), 3.0))
+    assert np.allclose(Expression("1./2*x[0]", degree=1).eval_points(co), 0.5 * co[:, 0])
+    assert np.array_equal(Expression("x[0] >= 1 && !(x[1] < 1) || x[2] == 0", degree=1).eval_points(co),
+                          (((co[:, 0] >= 1) & ~(co[:, 1] < 1)) | (co[:, 2] == 0)).astype(float))
+    for bad in ("x[0]^2", "().__class__.__subclasses__()", "__import__('os').system('true')", "open('x')", "x[3]", "1 +"):
+        with pytest.raises(SolverError):
+            Expression(bad, degree=1)
     with pytest.raises(SolverError):
-        Expression("x[0] > 0 ? 1 : 2", degree=1)
+        Expression("2*undefined_parameter", degree=1).eval_points(co)
     mf = MeshFunction("size_t", m, 2)
     AutoSubDomain(lambda x: near(x[0], 0.0)).mark(mf, 1)
     bc = DirichletBC(V, Constant(350), mf, 1)
@@ -231,8 +240,24 @@ def test_expression_and_dirichlet():
     assert bcv.dofs.size == 3 * 16 and np.allclose(bcv.values.reshape(-1, 3), [0, 0, 1e-3])
     with pytest.raises(SolverError):
         FunctionSpace(m, "CG", 3)          # P3 is not built: loud, not silent
-    with pytest.raises(SolverError):
-        VectorFunctionSpace(m, "Lagrange", 2)
+    # vector P2 (the reference's elasticity example): vertices + edge midpoints of the marked facets, 3 dofs per node
+    W2 = VectorFunctionSpace(m, "Lagrange", 2)
+    X2 = W2.node_coordinates()
+    on_face = np.nonzero(X2[:, 0] == 0)[0]
+    bc2 = DirichletBC(W2.sub(2), Constant(1.0), mf, 1)
+    assert W2.dim() == 3 * len(X2) and np.array_equal(bc2.dofs, on_face * 3 + 2) and len(on_face) == 7 * 7
+    assert np.array_equal(W2.cell_nodes()[:, :4], m.cells())
+    mid = 0.5 * (X2[W2.cell_nodes()[:, 2]] + X2[W2.cell_nodes()[:, 3]])
+    assert np.allclose(X2[W2.cell_nodes()[:, 4]], mid)                       # UFC edge 0 = (v2, v3)
+    # values given as strings / Functions (translate_value interpolates them into the space): evaluated at the BC nodes
+    g = interpolate(Expression("300 + x[1]", degree=1), V)
+    bcf = DirichletBC(V, g, mf, 1)
+    assert np.allclose(bcf.values, 300.0 + co[bcf.dofs, 1])
+    gv = interpolate(Expression(("x[0]", "2*x[1]", "3*x[2]"), degree=1), W)
+    bcfv = DirichletBC(W, gv, mf, 1)
+    assert np.allclose(bcfv.values.reshape(-1, 3), co[bcfv.dofs[::3] // 3] * [1, 2, 3])
+    bcfc = DirichletBC(W.sub(1), gv, mf, 1)                                      # a vector Function on a sub space: its component
+    assert np.allclose(bcfc.values, 2 * co[bcfc.dofs // 3, 1])
 
 
 def test_scalar_form_recognition_config1(data_dir):
