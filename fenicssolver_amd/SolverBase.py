@@ -31,7 +31,7 @@ import numpy as np
 
 from .fem import (SolverError, Mesh, MeshFunction, FunctionSpace, VectorFunctionSpace, Function, Constant,
                   Expression, DirichletBC, interpolate, project, nodal_values)
-from . import forms
+from . import forms, case
 
 __all__ = ["SolverError", "SolverBase", "default_report_settings", "default_solver_parameters",
            "default_case_settings"]
@@ -70,297 +70,139 @@ class SolverBase():
     """shared base class; generate_form() and update_boundary_conditions() come from the derived class"""
 
     def __init__(self, case_input):
-        if isinstance(case_input, (dict)):
-            self.settings = case_input
-            self.load_settings(case_input)
-        else:
+        if not isinstance(case_input, dict):
             raise SolverError('case setup data must be a python dict')
-        # one process per GPU; ranks are joined by fenicssolver_amd.backend.comm_init (RCCL),
-        # the counterpart of running the reference under mpirun (SolverBase.py:102-118)
-        self.parallel = int(os.environ.get("WORLD_SIZE", "1")) > 1
+        self.settings = case_input
         self.last_solve_stats = None
+        self.load_settings(case_input)
+        # one process per GPU (fenicssolver_amd.launch / mpirun export the rank): the counterpart of starting the
+        # reference under mpirun (SolverBase.py:102-118)
+        from . import parallel
+        self.parallel = parallel.world()[1] > 1
 
     def print(self):
         import pprint
         pprint.PrettyPrinter(indent=4).pprint(self.settings)
 
-    # ------------------------------------------------------------------ settings
+    # ------------------------------------------------------------------ settings (fenicssolver_amd/case.py does the work)
     def load_settings(self, s):
-        if 'periodic_boundary' not in s:
-            s['periodic_boundary'] = None
+        """Discretisation first (mesh + markers + space), then the physics blocks of the dict, then reporting."""
         self.boundary_conditions = s['boundary_conditions']
-        if ('mesh' in s) and s['mesh']:
-            if isinstance(s['mesh'], (str, bytes)):
-                self.read_mesh(s['mesh'])
-            elif isinstance(s['mesh'], (Mesh,)):
-                self.mesh = s['mesh']
-                self.generate_boundary_facets()
-            else:
-                raise SolverError('Error: mesh must be file path or Mesh object: {}'.format(type(s['mesh'])))
-            if 'fe_family' not in s:
-                s['fe_family'] = 'CG'
-            if 'fe_degree' not in s:
-                s['fe_degree'] = 1
+        bundle, space = case.MeshSource(s).resolve()
+        self._adopt_mesh(bundle)
+        if space is None:
             self.generate_function_space(s['periodic_boundary'])
-        elif ('mesh' not in s or s['mesh'] is None) and ('function_space' in s and s['function_space']):
-            self.function_space = s['function_space']
-            s['fe_degree'] = self.function_space._ufl_element.degree()
-            if 'fe_family' not in s:
-                s['fe_family'] = 'CG'
-            self.mesh = self.function_space.mesh()
-            self.generate_boundary_facets()
-            self.is_mixed_function_space = False
         else:
-            raise SolverError('mesh or function space must specified to construct solver object')
+            self.function_space = space
+            self.is_mixed_function_space = False
         self.dimension = self.mesh.geometry().dim()
         self.topo_dimension = self.mesh.topology().dim()
 
-        if not hasattr(self, 'subdomains'):
-            self.subdomains = MeshFunction("size_t", self.mesh, self.mesh.topology().dim())
-        if 'body_source' in s and s['body_source']:
-            self.body_source = s['body_source']
-        else:
-            self.body_source = None
-        if 'initial_values' in s:
-            self.initial_values = s['initial_values']
-        else:
-            self.initial_values = {}
-        self.reference_values = s['solver_settings']['reference_values']
+        solver_settings = s['solver_settings']
+        self.body_source = s.get('body_source') or None
+        self.initial_values = s.get('initial_values', {})
         self.material = s['material']
-        self.solver_settings = s['solver_settings']
-        self.transient_settings = s['solver_settings']['transient_settings']
+        self.solver_settings = solver_settings
+        self.reference_values = solver_settings['reference_values']
+        self.transient_settings = solver_settings['transient_settings']
         self.transient = self.transient_settings['transient']
+        self._values = case.ValueTranslator(self)
 
-        if 'report_settings' not in self.settings:
-            self.settings['report_settings'] = default_report_settings
-        self.report_settings = self.settings['report_settings']
-        self.set_logger(self.settings['report_settings'])
+        self.report_settings = self.settings.setdefault('report_settings', default_report_settings)
+        self.set_logger(self.report_settings)
+
+    def _adopt_mesh(self, bundle):
+        """mesh + its markers; facet markers a file does not carry come from the boundary conditions' SubDomains."""
+        self.mesh = bundle.mesh
+        if bundle.facet_markers is not None:
+            self.boundary_facets = bundle.facet_markers
+        else:
+            self.generate_boundary_facets()
+        if bundle.cell_markers is not None:
+            self.subdomains = bundle.cell_markers
+        elif not hasattr(self, 'subdomains'):
+            self.subdomains = MeshFunction("size_t", self.mesh, self.mesh.topology().dim())
 
     def set_logger(self, s):
+        level = s.get('logging_level', logging.DEBUG)
         logger = logging.getLogger(self.__class__.__name__)
         if not logger.handlers:
-            if ('logging_file' not in s) or (s['logging_file'] is None):
-                fh = logging.StreamHandler()
-            else:
-                fh = logging.FileHandler(s['logging_file'])
-            fh.setLevel(s['logging_level'] if 'logging_level' in s else logging.DEBUG)
-            fh.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s - %(message)s'))
-            logger.addHandler(fh)
-        logger.setLevel(s['logging_level'] if 'logging_level' in s else logging.DEBUG)
+            target = s.get('logging_file')
+            handler = logging.FileHandler(target) if target else logging.StreamHandler()
+            handler.setLevel(level)
+            handler.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s - %(message)s'))
+            logger.addHandler(handler)
+        logger.setLevel(level)
         self.logger = logger
 
+    def logger_or_print(self, msg):
+        self.logger.info(msg) if hasattr(self, 'logger') else print(msg)
+
     # ------------------------------------------------------------------ mesh ingest
-    def _read_hdf5_mesh(self, filename):
-        raise SolverError('HDF5 meshes need h5py, which is not available; convert {} to DOLFIN XML'.format(filename))
+    def read_mesh(self, filename):
+        """DOLFIN XML (+ _facet_region / _physical_region side files) or ASCII XDMF; HDF5 needs h5py (absent): raises."""
+        self._adopt_mesh(case.read_mesh_file(filename))
 
     def _read_xml_mesh(self, filename):
-        mesh = Mesh(filename)
-        bmeshfile = filename[:-4] + "_facet_region.xml"
-        self.mesh = mesh
-        if os.path.exists(bmeshfile):
-            self.boundary_facets = MeshFunction("size_t", mesh, bmeshfile)
-        else:
-            self.logger_or_print('Boundary facets are not provided by xml input file, '
-                                 'boundary will be marked from subdomain instance')
-            self.generate_boundary_facets()
-        subdomain_meshfile = filename[:-4] + "_physical_region.xml"
-        if os.path.exists(subdomain_meshfile):
-            self.subdomains = MeshFunction("size_t", mesh, subdomain_meshfile)
-        else:
-            self.subdomains = MeshFunction("size_t", mesh, mesh.topology().dim())
+        self._adopt_mesh(case.read_dolfin_xml(filename))
 
-    def logger_or_print(self, msg):
-        if hasattr(self, 'logger'):
-            self.logger.info(msg)
-        else:
-            print(msg)
-
-    def read_mesh(self, filename):
-        if isinstance(filename, bytes):
-            filename = filename.decode('utf-8')
-        if not os.path.exists(filename):
-            raise SolverError('mesh file: {} , does not exist'.format(filename))
-        if filename[-5:] == ".xdmf":
-            raise SolverError('XDMF meshes are not supported yet; convert {} to DOLFIN XML'.format(filename))
-        elif filename[-4:] == ".xml":
-            self._read_xml_mesh(filename)
-        elif filename[-3:] == ".h5" or filename[-5:] == ".hdf5":
-            self._read_hdf5_mesh(filename)
-        else:
-            raise SolverError('mesh or function space must specified to construct solver object')
+    def _read_hdf5_mesh(self, filename):
+        self._adopt_mesh(case.read_hdf5(filename))
 
     def generate_function_space(self, periodic_boundary):
         self.is_mixed_function_space = False
-        if "scalar_name" in self.settings:
-            self.function_space = FunctionSpace(self.mesh, self.settings['fe_family'], self.settings['fe_degree'],
-                                                constrained_domain=periodic_boundary)
-        elif "vector_name" in self.settings:
-            self.function_space = VectorFunctionSpace(self.mesh, self.settings['fe_family'],
-                                                      self.settings['fe_degree'],
-                                                      constrained_domain=periodic_boundary)
-        else:
-            raise SolverError('only scalar or vector solver has a base method of generate_function_space()')
+        self.settings['periodic_boundary'] = periodic_boundary
+        self.function_space = case.build_function_space(self.mesh, self.settings)
 
     def generate_boundary_facets(self):
-        boundary_facets = MeshFunction('size_t', self.mesh, self.mesh.topology().dim() - 1)
-        boundary_facets.set_all(0)
-        for name, bc in self.boundary_conditions.items():
-            if 'boundary' not in bc:
-                raise SolverError("boundary '{}' has no 'boundary' SubDomain and the mesh carries no facet "
-                                  "markers".format(name))
-            bc['boundary'].mark(boundary_facets, bc['boundary_id'])
-        self.boundary_facets = boundary_facets
+        self.boundary_facets = case.mark_boundaries(self.mesh, self.boundary_conditions)
 
     # ------------------------------------------------------------------ values
     def get_initial_field(self):
-        if not self.initial_values:
-            if self.is_mixed_function_space:
-                return Function(self.function_space)
-            elif 'vector_name' in self.settings:
-                v0 = (0,) * self.dimension
-            elif 'scalar_name' in self.settings:
-                v0 = 0
-            else:
-                raise SolverError('only vector and scalar equation can run this method')
-        else:
-            if self.is_mixed_function_space:
-                raise SolverError('only vector and scalar function can run this method')
-            elif 'vector_name' in self.settings:
-                v0 = self.initial_values[self.settings['vector_name']]
-            elif 'scalar_name' in self.settings:
-                v0 = self.initial_values[self.settings['scalar_name']]
-            else:
-                raise SolverError('only vector and scalar function can run this method')
-
-        if 'vector_name' in self.settings and isinstance(v0, (tuple, list)) and \
-                isinstance(v0[0], (str, numbers.Number)):
-            expr = Expression(tuple([str(v) for v in v0]), degree=self.settings['fe_degree'])
-            u0 = interpolate(expr, self.function_space)
-        elif 'scalar_name' in self.settings and isinstance(v0, (str, numbers.Number)):
-            u0 = interpolate(Expression(str(v0), degree=self.settings['fe_degree']), self.function_space)
-        elif isinstance(v0, (Function,)):
-            u0 = Function(v0) if v0.function_space().dim() == self.function_space.dim() \
-                else project(v0, self.function_space)
-        elif isinstance(v0, str) and os.path.exists(v0):
-            u0 = self._load_function(v0)   # the reference forgets to assign here (SolverBase.py:320-321)
-        else:
-            raise SolverError('only number, file, another function, str expr are supported as initial values')
-        return u0
+        return case.initial_field(self)
 
     def _load_function(self, filename):
-        data = np.load(filename) if filename.endswith(".npy") else np.loadtxt(filename)
-        f = Function(self.function_space)
-        if data.size != f.vector().size():
-            raise SolverError('{} holds {} values, the function space has {}'.format(filename, data.size,
-                                                                                     f.vector().size()))
-        f.vector().set_local(np.asarray(data, dtype=np.float64).ravel())
-        return f
+        return case.load_function_file(self.function_space, filename)
 
     def get_material_value(self, value):
-        if isinstance(value, (list, tuple, np.ndarray)) and len(value) == self.dimension \
-                and hasattr(value[0], '__len__') and len(value[0]) == self.dimension \
-                and isinstance(value[0][0], numbers.Number):
-            return np.asarray(value, dtype=np.float64)     # anisotropic tensor (as_matrix)
-        elif isinstance(value, dict):
+        """numbers pass through; dim x dim nested lists become a tensor (as_matrix); per-region dicts a cell-wise field."""
+        if case.is_square_matrix_of_numbers(value, self.dimension):
+            return np.asarray(value, dtype=np.float64)
+        if isinstance(value, dict):
             return self._translate_dict_value(value)
         return value
 
     def _translate_dict_value(self, value):
-        """{'region': {'subdomain_id': i, 'value': v}, ...} -> one value per cell (DG0)."""
-        cells = self.subdomains.array()
-        out = np.zeros(len(cells))
-        seen = np.zeros(len(cells), dtype=bool)
-        for name, item in value.items():
-            v = item['value'] if 'value' in item else item.get('material')
-            if not isinstance(v, numbers.Number):
-                raise SolverError("multi-region value '{}' must be a number".format(name))
-            sel = cells == item['subdomain_id']
-            out[sel] = float(v)
-            seen |= sel
-        if not seen.all():
-            raise SolverError('multi-region value does not cover every subdomain id of the mesh')
-        return forms.VolumeCoefficient("cell", out)
+        return forms.VolumeCoefficient("cell", case.cellwise_from_regions(value, self.subdomains))
+
+    def _translate_dict_value_to_function(self, value):
+        raise NotImplementedError('not yet implemented')      # as in the reference (SolverBase.py:339-347)
 
     def translate_value(self, value, function_space=None):
-        _degree = self.settings['fe_degree']
-        W = function_space if function_space else self.function_space
-        if isinstance(value, (tuple, list, np.ndarray)):
-            if len(value) == self.dimension and isinstance(value[0], (numbers.Number)):
-                values_0 = Constant(tuple(value))
-            elif len(value) == self.dimension and isinstance(value[0], (str)):
-                values_0 = interpolate(Expression(tuple(value), degree=_degree), W)
-            elif self.transient_settings['transient'] and len(value) > self.dimension:
-                values_0 = value[self.current_step]
-            else:
-                raise SolverError('{} is supplied, but only tuple of number and string expr of dim = len(v) '
-                                  'are supported'.format(type(value)))
-        elif isinstance(value, (numbers.Number)):
-            values_0 = Constant(value)
-        elif isinstance(value, (Constant, Function)):
-            values_0 = value
-        elif isinstance(value, (Expression,)):
-            values_0 = value
-        elif callable(value) and self.transient_settings['transient']:
-            values_0 = value(self.get_current_time())
-        elif isinstance(value, (str,)):
-            if os.path.exists(value):
-                values_0 = self._load_function(value)
-            else:
-                values_0 = interpolate(Expression(value, degree=_degree), W)
-        elif value is None:
-            raise TypeError('None type is supplied as value to be translated')
-        else:
-            self.logger_or_print('Warning: {} is supplied, not tuple, number, Constant,file name, '
-                                 'Expression'.format(type(value)))
-            values_0 = value
-        return values_0
+        return self._values(value, function_space)
 
     def get_variable_name(self):
-        if 'scalar_name' in self.settings:
-            return self.settings['scalar_name']
-        elif 'vector_name' in self.settings:
-            return self.settings['vector_name']
-        return 'unknown'
+        return self.settings.get('scalar_name') or self.settings.get('vector_name') or 'unknown'
 
     def get_boundary_variable(self, bc, variable=None):
-        if not variable:
-            variable = self.get_variable_name()
-        bvariable = bc
-        if 'values' in bc:
-            if isinstance(bc['values'], dict) and variable in bc['values']:
-                bvariable = bc['values'][variable]
-            if isinstance(bc['values'], list):
-                for vbc in bc['values']:
-                    if 'variable' in vbc and vbc['variable'] == variable:
-                        bvariable = vbc
-        return bvariable
+        return case.boundary_variable(bc, variable or self.get_variable_name())
 
     def get_boundary_value(self, bc, variable=None):
-        b = self.get_boundary_variable(bc, variable)
-        return self.translate_value(b['value'])   # the reference calls an undefined global here (B-Q5)
+        # the reference calls an undefined global here (Appendix B-Q5); the evident intent:
+        return self.translate_value(self.get_boundary_variable(bc, variable)['value'])
 
     def get_body_source(self):
-        if isinstance(self.body_source, (dict)):
-            vdict = copy.copy(self.body_source)
-            for k in vdict:
-                vdict[k] = dict(vdict[k])
-                vdict[k]['value'] = self.translate_value(self.body_source[k]['value'])
-            return vdict
-        if self.body_source:
-            return self.translate_value(self.body_source)
-        return None
+        src = self.body_source
+        if isinstance(src, dict):      # {'region': {'subdomain_id': i, 'value': v}}: translate every value, keep the ids
+            return {k: dict(item, value=self.translate_value(item['value'])) for k, item in src.items()}
+        return self.translate_value(src) if src else None
 
     # ------------------------------------------------------------------ time loop
     def get_time_step(self, time_iter_):
-        try:
-            dt = float(self.transient_settings['time_step'])
-        except (KeyError, TypeError, ValueError):
-            ts = self.transient_settings['time_series']
-            if len(ts) > time_iter_ + 1:
-                dt = ts[time_iter_ + 1] - ts[time_iter_]
-            else:
-                raise SolverError('time step can only be a sequence or scalar')
-        return dt
+        return case.TimeGrid(self.transient_settings).step(time_iter_)
+
+    def get_current_time(self, time_iter_=None):
+        return case.TimeGrid(self.transient_settings).time(time_iter_ or self.current_step)
 
     def get_acceleration(self, time_iter_):
         """(SolverBase.py:477-482) second difference of the last three steps, with the reference's own scaling
@@ -373,71 +215,48 @@ class SolverBase():
         a.vector().set_local((vel - vel_prev) / (1.0 / dt))
         return a
 
-    def _translate_dict_value_to_function(self, value):
-        raise NotImplementedError('not yet implemented')      # as in the reference (SolverBase.py:339-347)
-
-    def get_current_time(self, time_iter_=None):
-        if not time_iter_:
-            time_iter_ = self.current_step
-        try:
-            dt = float(self.transient_settings['time_step'])
-            tp = self.transient_settings['starting_time'] + dt * (time_iter_ - 1)
-        except (KeyError, TypeError, ValueError):
-            ts = self.transient_settings['time_series']
-            if len(ts) >= time_iter_:
-                tp = ts[time_iter_]
-            else:
-                raise SolverError('time point can only be a sequence of time series or derived from '
-                                  'constant time step')
-        return tp
-
     def init_solver(self):
-        self.trial_function = None   # no symbolic trial/test functions: forms are recognised, not compiled
-        self.test_function = None
+        """State of the time loop: current, previous and pre-previous fields, all starting from the initial field.
+        There are no symbolic trial / test functions here: forms are recognised, not compiled."""
+        self.trial_function = self.test_function = None
         self.w_current = self.get_initial_field()
-        self.w_prev = Function(self.function_space)
-        self.w_prev.assign(self.w_current)
-        self.w_pp = Function(self.function_space)
-        self.w_pp.assign(self.w_current)
+        self.w_prev, self.w_pp = (Function(self.function_space) for _ in range(2))
+        for w in (self.w_prev, self.w_pp):
+            w.assign(self.w_current)
 
     def solve_current_step(self):
-        F, Dirichlet_bcs_up = self.generate_form(self.current_step, self.trial_function, self.test_function,
-                                                 self.w_current, self.w_prev)
+        """The form is rebuilt every step from (current, previous); then the history rotates pp <- prev <- current and the
+        new current field is solved for (SolverBase.py:484-490)."""
+        F, bcs = self.generate_form(self.current_step, self.trial_function, self.test_function, self.w_current, self.w_prev)
         self.w_pp.assign(self.w_prev)
         self.w_prev.assign(self.w_current)
-        self.w_current = self.solve_form(F, self.w_current, Dirichlet_bcs_up)
-        self.result = self.w_current
+        self.result = self.w_current = self.solve_form(F, self.w_current, bcs)
+
+    def _due(self, freq_key):
+        """plot / save cadence of the reference: every freq-th step, never at step 0 (so steady runs never fire, B-Q14)."""
+        freq = self.report_settings.get(freq_key, 0)
+        return bool(freq) and freq > 0 and self.current_step > 0 and self.current_step % freq == 0
 
     def solve_transient(self):
         self.init_solver()
         ts = self.transient_settings
-        self.current_time = ts['starting_time']
-        self.current_step = 0
+        self.current_time, self.current_step = ts['starting_time'], 0
         t_end = ts['ending_time'] if ts['transient'] else self.current_time + 1
-
-        sf = self.report_settings.get('saving_freq', 0)
-        result_filename = 'result_file.pvd'
-        if sf and sf > 0 and self.report_settings.get('result_filename'):
-            result_filename = self.report_settings['result_filename']
-
-        t_start = time.perf_counter()
-        while (self.current_time < t_end):
-            dt = self.get_time_step(self.current_step) if ts['transient'] else 1
+        pvd = self.report_settings.get('result_filename') or 'result_file.pvd'
+        t0 = time.perf_counter()
+        while self.current_time < t_end:
             self.solve_current_step()
-            self.logger.info("Current step = %d time = %g TimerSolveAll = %.4f", self.current_step,
-                             self.current_time, time.perf_counter() - t_start)
-            pf = self.report_settings.get('plotting_freq', 0)
-            if pf and pf > 0 and self.current_step > 0 and (self.current_step % pf == 0):
+            self.logger.info("Current step = %d time = %g TimerSolveAll = %.4f", self.current_step, self.current_time,
+                             time.perf_counter() - t0)
+            if self._due('plotting_freq'):
                 self.plot()
-            if sf and sf > 0:
-                if self.current_step > 0 and (self.current_step % sf == 0):
-                    self.save(result_filename)
-                    self.logger.info("save data to file `%s` at step: %d , at time: %g", result_filename,
-                                     self.current_step, self.current_time)
-            if not self.transient_settings['transient']:
+            if self._due('saving_freq'):
+                self.save(pvd)
+                self.logger.info("save data to file `%s` at step: %d , at time: %g", pvd, self.current_step, self.current_time)
+            if not ts['transient']:
                 break
+            self.current_time += self.get_time_step(self.current_step)
             self.current_step += 1
-            self.current_time += dt
         return self.w_current
 
     def solve(self):

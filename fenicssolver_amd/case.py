@@ -1,0 +1,318 @@
+"""Case settings: what a settings dict means before any arithmetic happens.
+
+Counterpart of the set-up half of FenicsSolver/SolverBase.py (load_settings :125-182, mesh ingest :203-258,
+function space :260-275, boundary markers :277-283, value translation :285-438, time stepping :440-465).  The same
+settings keys produce the same objects; the organisation is this package's own:
+
+* ``MeshSource``        - one place that turns ``settings['mesh']`` / ``settings['function_space']`` into
+                          (mesh, facet markers, cell markers) through a table of file readers (DOLFIN XML, XDMF);
+* ``ValueTranslator``   - a rule table (type -> coefficient object) for boundary, source and initial values;
+* ``TimeGrid``          - the (time_step | time_series) arithmetic of the transient loop.
+
+SolverBase keeps the reference's method names and forwards to these.
+"""
+from __future__ import annotations
+
+import numbers
+import os
+import re
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from .fem import (SolverError, Mesh, MeshFunction, FunctionSpace, VectorFunctionSpace, Function, Constant, Expression,
+                  interpolate, project)
+
+
+# ------------------------------------------------------------------------------------------------ mesh files
+class MeshBundle:
+    """What a mesh file can carry: the mesh, optionally facet markers (dim tdim-1) and cell markers (dim tdim)."""
+
+    def __init__(self, mesh, facet_markers=None, cell_markers=None):
+        self.mesh, self.facet_markers, self.cell_markers = mesh, facet_markers, cell_markers
+
+
+def read_dolfin_xml(path):
+    """``mesh.xml`` plus, when they sit next to it, ``mesh_facet_region.xml`` / ``mesh_physical_region.xml``
+    (the dolfin-convert naming the reference relies on, SolverBase.py:223-238)."""
+    mesh = Mesh(path)
+    stem = path[:-len(".xml")]
+    side = {}
+    for key, suffix in (("facet_markers", "_facet_region.xml"), ("cell_markers", "_physical_region.xml")):
+        f = stem + suffix
+        side[key] = MeshFunction("size_t", mesh, f) if os.path.exists(f) else None
+    return MeshBundle(mesh, **side)
+
+
+_XDMF_CELLS = {"tetrahedron": 4, "tet": 4, "triangle": 3}
+
+
+def _xdmf_numbers(item, path, dtype):
+    """The numbers of a <DataItem>: inline text (Format="XML") only - heavy data in a side HDF5 file needs h5py."""
+    fmt = (item.get("Format") or "XML").upper()
+    if fmt != "XML":
+        raise SolverError("{}: DataItem Format=\"{}\" points into an HDF5 file; h5py is not available here - write the XDMF "
+                          "with ASCII encoding (XDMFFile.Encoding_ASCII / meshio --ascii) or convert to DOLFIN XML".format(
+                              path, item.get("Format")))
+    return np.array((item.text or "").split(), dtype=dtype)
+
+
+def read_xdmf(path):
+    """XDMF with inline (ASCII) DataItems, as DOLFIN writes with ASCII encoding (SolverBase.py:246-252 reads the mesh
+    only; cell / facet markers come from ``SubDomain.mark`` afterwards).  One uniform grid of tetrahedra or triangles.
+    A cell-centred integer <Attribute> (meshio / gmsh physical groups) is taken as the subdomain markers."""
+    try:
+        root = ET.parse(path).getroot()
+    except ET.ParseError as e:
+        raise SolverError("{}: not well-formed XML ({})".format(path, e))
+    grids = [g for g in root.iter("Grid") if (g.get("GridType") or "Uniform") == "Uniform"]
+    if not grids:
+        raise SolverError("{}: no uniform <Grid> found".format(path))
+    grid = grids[0]
+    topo, geom = grid.find("Topology"), grid.find("Geometry")
+    if topo is None or geom is None:
+        raise SolverError("{}: <Grid> lacks <Topology> or <Geometry>".format(path))
+    kind = (topo.get("TopologyType") or topo.get("Type") or "").lower()
+    if kind not in _XDMF_CELLS:
+        raise SolverError("{}: TopologyType '{}' is not supported (Tetrahedron / Triangle)".format(path, topo.get("TopologyType")))
+    nvc = _XDMF_CELLS[kind]
+    cells = _xdmf_numbers(topo.find("DataItem"), path, np.int64).reshape(-1, nvc)
+    gtype = (geom.get("GeometryType") or geom.get("Type") or "XYZ").upper()
+    gdim = {"XYZ": 3, "XY": 2}.get(gtype)
+    if gdim is None:
+        raise SolverError("{}: GeometryType '{}' is not supported (XYZ / XY)".format(path, gtype))
+    coords = _xdmf_numbers(geom.find("DataItem"), path, np.float64).reshape(-1, gdim)
+    if nvc == 3 and gdim == 3:
+        if np.ptp(coords[:, 2]) != 0.0:
+            raise SolverError("{}: triangles embedded in 3-D are not supported".format(path))
+        coords = coords[:, :2]
+    if cells.size and (cells.min() < 0 or cells.max() >= len(coords)):
+        raise SolverError("{}: connectivity names vertex {} of {}".format(path, int(cells.max()), len(coords)))
+    mesh = Mesh(coords=coords, cells=cells)
+    cell_markers = None
+    for att in grid.findall("Attribute"):
+        if (att.get("Center") or "").lower() == "cell" and (att.get("AttributeType") or "Scalar").lower() == "scalar":
+            vals = _xdmf_numbers(att.find("DataItem"), path, np.float64)
+            if len(vals) == len(cells) and np.all(vals == np.round(vals)) and vals.min() >= 0:
+                cell_markers = MeshFunction("size_t", mesh, mesh.topology().dim())
+                cell_markers.array()[:] = vals.astype(np.int64)
+                break
+    return MeshBundle(mesh, None, cell_markers)
+
+
+def read_hdf5(path):
+    raise SolverError("{}: DOLFIN HDF5 meshes (/mesh, /subdomains, /boundaries; SolverBase.py:203-221) need an HDF5 reader; "
+                      "h5py is not available in this environment - convert to DOLFIN XML or ASCII XDMF".format(path))
+
+
+MESH_READERS = ((".xdmf", read_xdmf), (".xml", read_dolfin_xml), (".h5", read_hdf5), (".hdf5", read_hdf5))
+
+
+def read_mesh_file(path):
+    if isinstance(path, bytes):
+        path = path.decode("utf-8")
+    if not os.path.exists(path):
+        raise SolverError("mesh file: {} , does not exist".format(path))
+    for ext, reader in MESH_READERS:
+        if path.lower().endswith(ext):
+            return reader(path)
+    raise SolverError("mesh file {}: unknown format (known: {})".format(path, ", ".join(e for e, _ in MESH_READERS)))
+
+
+def mark_boundaries(mesh, boundary_conditions):
+    """Facet markers from the ``boundary`` SubDomain of every boundary condition, in order (later ones overwrite),
+    0 elsewhere (SolverBase.py:277-283)."""
+    markers = MeshFunction("size_t", mesh, mesh.topology().dim() - 1)
+    markers.set_all(0)
+    for name, bc in (boundary_conditions or {}).items():
+        if "boundary" not in bc:
+            raise SolverError("boundary '{}' has no 'boundary' SubDomain and the mesh carries no facet markers".format(name))
+        bc["boundary"].mark(markers, bc["boundary_id"])
+    return markers
+
+
+class MeshSource:
+    """Resolves the two ways a case names its discretisation: ``mesh`` (file or Mesh; the space is then built from
+    fe_family / fe_degree / scalar_name | vector_name) or a ready ``function_space``."""
+
+    def __init__(self, settings):
+        self.s = settings
+        settings.setdefault("periodic_boundary", None)
+        settings.setdefault("fe_family", "CG")
+
+    def resolve(self):
+        """-> (MeshBundle, function space or None when the solver class has to build it)."""
+        s = self.s
+        given = s.get("mesh")
+        if given:
+            s.setdefault("fe_degree", 1)
+            if isinstance(given, (str, bytes)):
+                return read_mesh_file(given), None
+            if isinstance(given, Mesh):
+                return MeshBundle(given), None
+            raise SolverError("settings['mesh'] must be a file path or a Mesh, got {}".format(type(given)))
+        V = s.get("function_space")
+        if V:
+            s["fe_degree"] = V.ufl_element().degree()
+            return MeshBundle(V.mesh()), V
+        raise SolverError("a case needs settings['mesh'] or settings['function_space']")
+
+
+def build_function_space(mesh, settings):
+    """FunctionSpace for scalar_name cases, VectorFunctionSpace for vector_name cases (SolverBase.py:260-275);
+    ``periodic_boundary`` goes to the space, which refuses it loudly (periodic constraints are not built)."""
+    make = FunctionSpace if "scalar_name" in settings else VectorFunctionSpace if "vector_name" in settings else None
+    if make is None:
+        raise SolverError("the settings name neither 'scalar_name' nor 'vector_name': this solver class must build its own space")
+    return make(mesh, settings["fe_family"], settings["fe_degree"], constrained_domain=settings.get("periodic_boundary"))
+
+
+# ------------------------------------------------------------------------------------------------ values
+def load_function_file(V, filename):
+    """Dof values of a Function from .npy or whitespace text (the reference streams a DOLFIN File, SolverBase.py:318-321)."""
+    data = np.load(filename) if filename.endswith(".npy") else np.loadtxt(filename)
+    f = Function(V)
+    if data.size != f.vector().size():
+        raise SolverError("{} holds {} values, the function space has {}".format(filename, data.size, f.vector().size()))
+    f.vector().set_local(np.asarray(data, dtype=np.float64).ravel())
+    return f
+
+
+class ValueTranslator:
+    """settings value -> coefficient object, by a rule table (SolverBase.py:349-393):
+
+        number                      Constant
+        Constant / Function / Expression      themselves
+        sequence of dim numbers     vector Constant
+        sequence of dim strings     Expression interpolated into the space
+        longer sequence (transient) its entry for the current step
+        callable (transient)        value(current time)
+        string                      a file of dof values if it exists, else an Expression interpolated into the space
+    """
+
+    def __init__(self, solver):
+        self.solver = solver
+
+    def __call__(self, value, function_space=None):
+        sv = self.solver
+        V = function_space or sv.function_space
+        degree = sv.settings["fe_degree"]
+        transient = sv.transient_settings["transient"]
+        if value is None:
+            raise TypeError("None type is supplied as value to be translated")
+        if isinstance(value, (Constant, Function, Expression)):
+            return value
+        if isinstance(value, numbers.Number):
+            return Constant(value)
+        if isinstance(value, (tuple, list, np.ndarray)):
+            if len(value) == sv.dimension and isinstance(value[0], numbers.Number):
+                return Constant(tuple(value))
+            if len(value) == sv.dimension and isinstance(value[0], str):
+                return interpolate(Expression(tuple(value), degree=degree), V)
+            if transient and len(value) > sv.dimension:
+                return value[sv.current_step]
+            raise SolverError("a sequence value must hold {} numbers or {} expression strings (or one entry per time "
+                              "step), got {!r}".format(sv.dimension, sv.dimension, value))
+        if callable(value) and transient:
+            return value(sv.get_current_time())
+        if isinstance(value, str):
+            if os.path.exists(value):
+                return load_function_file(V, value)
+            return interpolate(Expression(value, degree=degree), V)
+        sv.logger_or_print("Warning: value of type {} is passed through untranslated".format(type(value)))
+        return value
+
+
+def initial_field(solver):
+    """The starting Function: zero unless ``initial_values[<variable name>]`` says otherwise (SolverBase.py:285-324)."""
+    s, V = solver.settings, solver.function_space
+    if solver.is_mixed_function_space:
+        if solver.initial_values:
+            raise SolverError("initial_values of a mixed function space are set by the solver class itself")
+        return Function(V)
+    name = solver.get_variable_name()
+    if name == "unknown":
+        raise SolverError("initial field: the settings name neither 'scalar_name' nor 'vector_name'")
+    vector = "vector_name" in s
+    v0 = solver.initial_values.get(name) if solver.initial_values else None
+    if not solver.initial_values:
+        v0 = (0,) * solver.dimension if vector else 0
+    elif name not in solver.initial_values:
+        raise KeyError(name)
+    degree = s["fe_degree"]
+    if vector and isinstance(v0, (tuple, list)) and isinstance(v0[0], (str, numbers.Number)):
+        return interpolate(Expression(tuple(str(c) for c in v0), degree=degree), V)
+    if not vector and isinstance(v0, (str, numbers.Number)) and not (isinstance(v0, str) and os.path.exists(v0)):
+        return interpolate(Expression(str(v0), degree=degree), V)
+    if isinstance(v0, Function):
+        return Function(v0) if v0.function_space().dim() == V.dim() else project(v0, V)
+    if isinstance(v0, str) and os.path.exists(v0):
+        return load_function_file(V, v0)          # the reference forgets to keep what it reads (SolverBase.py:320-321)
+    raise SolverError("initial value of '{}' must be a number, an expression string, a file of dof values or a Function".format(name))
+
+
+def boundary_variable(bc, variable):
+    """The sub-dict of a boundary condition that belongs to ``variable``: ``bc['values']`` may be a dict keyed by variable
+    name or a list of {'variable': ..} dicts; otherwise the boundary condition itself (SolverBase.py:403-415)."""
+    many = bc.get("values")
+    if isinstance(many, dict):
+        return many.get(variable, bc)
+    if isinstance(many, list):
+        hits = [item for item in many if item.get("variable") == variable]
+        return hits[-1] if hits else bc
+    return bc
+
+
+def cellwise_from_regions(regions, cell_markers):
+    """{'name': {'subdomain_id': i, 'value' | 'material': v}, ...} -> one number per cell."""
+    ids = cell_markers.array()
+    out = np.zeros(len(ids))
+    covered = np.zeros(len(ids), dtype=bool)
+    for name, item in regions.items():
+        v = item["value"] if "value" in item else item.get("material")
+        if not isinstance(v, numbers.Number):
+            raise SolverError("multi-region value '{}' must be a number".format(name))
+        here = ids == item["subdomain_id"]
+        out[here] = float(v)
+        covered |= here
+    if not covered.all():
+        raise SolverError("multi-region value does not cover every subdomain id of the mesh")
+    return out
+
+
+def is_square_matrix_of_numbers(value, dim):
+    return (isinstance(value, (list, tuple, np.ndarray)) and len(value) == dim and hasattr(value[0], "__len__")
+            and len(value[0]) == dim and isinstance(value[0][0], numbers.Number))
+
+
+# ------------------------------------------------------------------------------------------------ time
+class TimeGrid:
+    """``transient_settings``: constant ``time_step`` or a ``time_series`` of time points (SolverBase.py:440-465).
+    The reference's series branch subtracts t[i] from itself (Appendix B-Q4); here it is t[i+1] - t[i]."""
+
+    def __init__(self, transient_settings):
+        self.ts = transient_settings
+
+    def _constant_step(self):
+        try:
+            return float(self.ts["time_step"])
+        except (KeyError, TypeError, ValueError):
+            return None
+
+    def step(self, i):
+        dt = self._constant_step()
+        if dt is not None:
+            return dt
+        series = self.ts.get("time_series")
+        if series is None or len(series) <= i + 1:
+            raise SolverError("time step can only be a sequence or scalar")
+        return series[i + 1] - series[i]
+
+    def time(self, i):
+        dt = self._constant_step()
+        if dt is not None:
+            return self.ts["starting_time"] + dt * (i - 1)
+        series = self.ts.get("time_series")
+        if series is None or len(series) < i:
+            raise SolverError("time point can only be a sequence of time series or derived from constant time step")
+        return series[i]

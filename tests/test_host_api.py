@@ -474,3 +474,96 @@ def test_host_blas_pools_are_capped_under_the_cpu_quota():
     for pool in threadpoolctl.threadpool_info():
         if pool.get("user_api") == "blas":
             assert pool["num_threads"] <= max(1, n // 2)
+
+
+def _write_ascii_xdmf(path, co, ce, cell_attr=None, fmt="XML"):
+    """What dolfin.XDMFFile writes with XDMFFile.Encoding_ASCII (and meshio --ascii): inline DataItems."""
+    kind, g = ("Tetrahedron", "XYZ") if ce.shape[1] == 4 else ("Triangle", "XY")
+    with open(path, "w") as fh:
+        fh.write('<?xml version="1.0"?>\n<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">\n'
+                 '  <Domain>\n    <Grid Name="mesh" GridType="Uniform">\n')
+        fh.write('      <Topology NumberOfElements="%d" TopologyType="%s" NodesPerElement="%d">\n        <DataItem Dimensions="%d %d" '
+                 'NumberType="UInt" Format="%s">' % (len(ce), kind, ce.shape[1], len(ce), ce.shape[1], fmt))
+        fh.write("\n".join(" ".join(str(v) for v in row) for row in ce) if fmt == "XML" else "mesh.h5:/Mesh/mesh/topology")
+        fh.write('</DataItem>\n      </Topology>\n      <Geometry GeometryType="%s">\n        <DataItem Dimensions="%d %d" Format="%s">'
+                 % (g, len(co), co.shape[1], fmt))
+        fh.write("\n".join(" ".join(repr(float(v)) for v in row) for row in co) if fmt == "XML" else "mesh.h5:/Mesh/mesh/geometry")
+        fh.write('</DataItem>\n      </Geometry>\n')
+        if cell_attr is not None:
+            fh.write('      <Attribute Name="subdomains" AttributeType="Scalar" Center="Cell">\n        <DataItem Dimensions="%d 1" Format="XML">'
+                     % len(ce))
+            fh.write(" ".join(str(int(v)) for v in cell_attr))
+            fh.write('</DataItem>\n      </Attribute>\n')
+        fh.write('    </Grid>\n  </Domain>\n</Xdmf>\n')
+
+
+def test_xdmf_mesh_reader_and_settings_paths(tmp_path):
+    """settings['mesh'] = 'case.xdmf' (SolverBase.py:246-252): ASCII XDMF is read, markers come from the SubDomains;
+    HDF5-backed XDMF / .h5 files say what is missing instead of guessing; periodic boundaries are refused loudly."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd import SolverBase as SB, case
+    from fenicssolver_amd.fem import AutoSubDomain, Constant, near, SolverError
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 2.0, 3.0), 2, 3, 2)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(ce))
+    ids = (co[ce.astype(np.int64)].mean(axis=1)[:, 2] > 1.5).astype(int) + 1
+    path = str(tmp_path / "box.xdmf")
+    _write_ascii_xdmf(path, co, ce[perm][:, ::-1], cell_attr=ids[perm])          # cells shuffled, vertices unsorted
+    bundle = case.read_mesh_file(path)
+    m = bundle.mesh
+    assert np.array_equal(m.coordinates(), co) and m.num_cells() == len(ce)
+    assert np.array_equal(np.sort(m.cells(), axis=0), np.sort(np.sort(ce, axis=1), axis=0))      # same cells, mesh.order()ed
+    assert np.array_equal(np.sort(bundle.cell_markers.array()), np.sort(ids)) and bundle.facet_markers is None
+    # through the solver: markers from the SubDomains, k per region from the XDMF cell attribute
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update(mesh=path, scalar_name="temperature", report_settings=dict(logging_level=50, logging_file=None, plotting_freq=0, saving_freq=0))
+    bcs = OrderedDict()
+    bcs["bottom"] = {'boundary': AutoSubDomain(lambda x, on: on and near(x[2], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(350)}
+    bcs["top"] = {'boundary': AutoSubDomain(lambda x, on: on and near(x[2], 3.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': 300}
+    s['boundary_conditions'] = bcs
+    s['material'] = {'thermal_conductivity': 20.0, 'density': 1.0, 'specific_heat_capacity': 1.0}
+    solver = ScalarTransportSolver(s)
+    assert solver.mesh.num_vertices() == len(co) and solver.function_space.dim() == len(co)
+    assert np.count_nonzero(solver.boundary_facets.array() == 1) == 2 * 2 * 3 and np.count_nonzero(solver.boundary_facets.array() == 2) == 12
+    assert sorted(set(solver.subdomains.array().tolist())) == [1, 2]
+    F, dbc = solver.generate_form(0, None, None, None, None)
+    assert [len(b.dofs) for b in dbc] == [12, 12]
+    # 2-D triangles
+    co2, ce2 = fo.rectangle_mesh((0, 0), (1, 1), 3, 2)
+    p2 = str(tmp_path / "sq.xdmf")
+    _write_ascii_xdmf(p2, co2, ce2)
+    m2 = case.read_mesh_file(p2).mesh
+    assert m2.topology().dim() == 2 and np.array_equal(m2.coordinates(), co2)
+    # heavy data in HDF5: loud, with the way out
+    p3 = str(tmp_path / "h5.xdmf")
+    _write_ascii_xdmf(p3, co, ce, fmt="HDF")
+    for bad in (p3,):
+        with pytest.raises(SolverError, match="h5py"):
+            case.read_mesh_file(bad)
+    open(str(tmp_path / "m.h5"), "wb").write(b"\x89HDF\r\n\x1a\n")
+    with pytest.raises(SolverError, match="HDF5"):
+        case.read_mesh_file(str(tmp_path / "m.h5"))
+    with pytest.raises(SolverError):
+        case.read_mesh_file(str(tmp_path / "missing.xml"))
+    # periodic_boundary is not built: refused, not ignored (SolverBase.py:260-275)
+    s2 = copy.deepcopy(SB.default_case_settings)
+    s2.update(mesh=path, scalar_name="temperature", boundary_conditions=bcs, material=s['material'], report_settings=s['report_settings'],
+              periodic_boundary=AutoSubDomain(lambda x: near(x[0], 0.0)))
+    with pytest.raises(SolverError, match="periodic"):
+        ScalarTransportSolver(s2)
+
+
+def test_time_grid_and_value_rules():
+    from fenicssolver_amd import case
+    from fenicssolver_amd.fem import SolverError
+    g = case.TimeGrid({'transient': True, 'starting_time': 1.0, 'time_step': 0.25, 'ending_time': 2.0})
+    assert g.step(3) == 0.25 and g.time(3) == 1.5
+    g = case.TimeGrid({'transient': True, 'starting_time': 0.0, 'time_series': [0.0, 0.1, 0.3, 0.7], 'ending_time': 0.7})
+    assert abs(g.step(1) - 0.2) < 1e-15 and g.time(2) == 0.3          # t[i+1] - t[i], not the reference's t[i] - t[i] (B-Q4)
+    with pytest.raises(SolverError):
+        g.step(3)
+    assert case.boundary_variable({'type': 'a', 'values': {'temperature': {'type': 'b'}}}, 'temperature') == {'type': 'b'}
+    assert case.boundary_variable({'type': 'a', 'values': [{'variable': 'velocity', 'type': 'c'}]}, 'velocity')['type'] == 'c'
+    assert case.boundary_variable({'type': 'a', 'values': {'pressure': {}}}, 'temperature')['type'] == 'a'
