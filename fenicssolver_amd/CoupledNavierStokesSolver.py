@@ -12,8 +12,14 @@ with under-relaxation 0.7 of :492-528.
 Built: velocity Dirichlet conditions (constants, tuples, C-string Expressions; per-time-step lists are not),
 pressure Dirichlet (inlet / outlet, with the reference's boundary integrals p n.v ds - nu ((grad u + grad u^T) n).v ds)
 and pressure 'farfield' boundaries, body force, steady and backward-Euler transient, Newton and Picard.
-Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), G2 stabilisation,
-ALE reference frames, non-Newtonian viscosity, the coupled temperature equation.
+ALE reference frames with a constant ``mesh_velocity`` (:321-329), ``viscous_stress`` (the consistent L2 projection of
+nu (grad u + grad u^T) - p I onto CG1, nine mass-matrix solves on the device), ``boundary_traction`` and
+``calc_drag_and_lift`` (the reference's versions reference an undefined ``self.ds`` and index symbols, Appendix B-Q13;
+the evident intent is built: facet integrals of the projected stress over ``boundary_facets``).
+Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), G2 stabilisation
+(its transient branch reads an undefined ``time_iter_``, B-Q13, and its Newton linearisation would have to differentiate
+the stabilisation parameter), non-constant mesh velocities, non-Newtonian viscosity, the coupled temperature equation
+(marked "test not passed" in the reference).
 """
 from __future__ import annotations
 
@@ -110,8 +116,14 @@ class CoupledNavierStokesSolver(SolverBase):
         F.newton = bool(self.using_nonlinear_solver)
         if self.settings.get('body_source'):          # "just gravity, without * rho" (:315-316)
             F.body_force = self.get_body_source()
-        if 'reference_frame_settings' in self.settings:
-            raise SolverError("reference_frame_settings (ALE) is not built")
+        rfs = self.settings.get('reference_frame_settings')
+        if rfs:
+            if rfs.get('type') != 'ALE':
+                raise SolverError('reference_frame_settings type `{}` is not supported'.format(rfs.get('type')))
+            mv = rfs.get('mesh_velocity')
+            if callable(mv) and self.transient_settings['transient']:
+                mv = mv(self.get_current_time())
+            F.mesh_velocity = self._vector3(mv, "reference_frame_settings['mesh_velocity'] (a constant vector)")
         ads = self.settings.get('advection_settings') or {}
         if ads.get('stabilization_method'):
             raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
@@ -218,7 +230,84 @@ class CoupledNavierStokesSolver(SolverBase):
         return split(w if w is not None else self.w_current)
 
     def viscous_stress(self, up, T_space=None):
-        raise SolverError("viscous_stress / boundary_traction / calc_drag_and_lift are not built on this back end")
+        """project(nu (grad u + grad u^T) - p I, TensorFunctionSpace(mesh, 'CG', 1)) (:149-155).  Right-hand sides on the
+        device (fs_assemble_viscous_stress), then one CG1 mass-matrix solve per tensor component (Jacobi-CG, 1e-12).
+        Returns a Function on TensorFunctionSpace(mesh, 'CG', 1): node_values() is [num_vertices, 9], row-major."""
+        from . import backend
+        from .fem import FunctionSpace, TensorFunctionSpace
+        W = up.function_space()
+        if W.localizer() is not None:
+            raise SolverError('viscous_stress: the projection is built for one GPU')
+        if T_space is None:
+            T_space = TensorFunctionSpace(self.mesh, 'CG', 1)
+        elif T_space.degree() != 1 or T_space._ncomp != 9:
+            raise SolverError('viscous_stress: T_space must be TensorFunctionSpace(mesh, "CG", 1)')
+        P = W.pressure_space()
+        dW, dP = W.device(), P.device()
+        nv = self.mesh.num_vertices()
+        wd = backend.DeviceVector(dW.n_local, up.vector().array())
+        b9 = backend.DeviceVector(9 * dP.n_owned)
+        backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9)
+        rhs = b9.get().reshape(nv, 9)
+        M = backend.DeviceMatrix(dP)
+        M.assemble(mass=1.0)
+        b, x = backend.DeviceVector(dP.n_owned), backend.DeviceVector(dP.n_local)
+        out = np.zeros((nv, 9))
+        for k in range(9):
+            if k in (3, 6, 7):            # sigma is symmetric: (1,0) (2,0) (2,1) copy (0,1) (0,2) (1,2)
+                out[:, k] = out[:, {3: 1, 6: 2, 7: 5}[k]]
+                continue
+            b.set(rhs[:, k])
+            st = backend.krylov_solve(M, b, x, rtol=1e-12, max_iter=2000, precond="jacobi", norm="preconditioned")
+            if st['converged'] != 1:
+                raise SolverError('viscous_stress: the mass-matrix solve did not converge')
+            out[:, k] = x.get()[:nv]
+        sigma = Function(T_space)
+        sigma.vector().set_local(out.reshape(-1))
+        return sigma
 
-    boundary_traction = viscous_stress
-    calc_drag_and_lift = viscous_stress
+    def _facet_geometry(self, sel):
+        """(vertex triples [nf,3], outward normal * area [nf,3]) of the boundary facets with indices sel."""
+        mesh = self.mesh
+        tri = mesh.facets()[sel].astype(np.int64)
+        co = mesh.coordinates()
+        X = co[tri]
+        nrm = 0.5 * np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0])
+        owner = np.full(mesh.num_facets(), -1, dtype=np.int64)
+        owner[mesh.cell_facets().ravel()] = np.repeat(np.arange(mesh.num_cells()), 4)
+        inward = np.einsum("fi,fi->f", nrm, X.mean(axis=1) - co[mesh.cells().astype(np.int64)[owner[sel]]].mean(axis=1)) < 0
+        nrm[inward] *= -1.0
+        return tri, nrm
+
+    def boundary_traction(self, up, target_space=None):
+        """sigma . n on the boundary, as a CG1 vector Function (interior vertices 0): at a boundary vertex the area-weighted
+        mean of sigma(vertex) . n over its exterior facets.  (The reference's version, :157-170, calls viscous_stress
+        without its second argument and uses undefined index symbols; this is its stated intent: traction = dot(sigma, n).)"""
+        from .fem import VectorFunctionSpace
+        V = target_space or VectorFunctionSpace(self.mesh, 'CG', 1)
+        if V.degree() != 1 or V._ncomp != 3:
+            raise SolverError('boundary_traction: target_space must be VectorFunctionSpace(mesh, "CG", 1)')
+        sig = self.viscous_stress(up).node_values().reshape(-1, 3, 3)
+        tri, nrm = self._facet_geometry(np.nonzero(self.mesh.exterior_facets())[0])
+        nv = self.mesh.num_vertices()
+        num, den = np.zeros((nv, 3)), np.zeros(nv)
+        area = np.linalg.norm(nrm, axis=1)
+        for k in range(3):
+            np.add.at(num, tri[:, k], np.einsum("fij,fj->fi", sig[tri[:, k]], nrm))
+            np.add.at(den, tri[:, k], area)
+        vals = np.zeros_like(num)
+        on = den > 0
+        vals[on] = num[on] / den[on, None]
+        t = Function(V)
+        t.vector().set_local(vals.reshape(-1))
+        return t
+
+    def calc_drag_and_lift(self, up, drag_axis_index, lift_axis_index, boundary_index_list):
+        """(drag, lift) = -int T[axis, j] n_j ds over the listed boundaries (:172-192), T = viscous_stress(up), n outward.
+        With CG1 T the facet integral is area * mean of the three vertex tensors (exact)."""
+        if not (boundary_index_list and len(boundary_index_list)):
+            raise SolverError('Error: boundary_index_list must be specified to calc drag and lift forces')
+        T = self.viscous_stress(up).node_values().reshape(-1, 3, 3)
+        tri, nrm = self._facet_geometry(np.concatenate([self.boundary_facets.where(i) for i in boundary_index_list]))
+        force = -np.einsum("fij,fj->i", T[tri].mean(axis=1), nrm)
+        return float(force[drag_axis_index]), float(force[lift_axis_index])

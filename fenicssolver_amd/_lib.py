@@ -61,7 +61,7 @@ class fs_krylov_stats(C.Structure):
 
 class fs_ns_form(C.Structure):
     _fields_ = [("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
-                ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int)]
+                ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int), ("mesh_velocity", C.c_double * 3)]
 
 
 class fs_saddle_opts(C.Structure):
@@ -135,6 +135,7 @@ SIGNATURES = {
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "fs_assemble_von_mises": (C.c_int, [_H, _H, C.c_double, C.c_double, _H, _H]),
+    "fs_assemble_viscous_stress": (C.c_int, [_H, _H, C.c_double, _H, _H]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fs_comm_allreduce_sum": (C.c_int, [c_f64p, C.c_int]),
     "fs_comm_allgather": (C.c_int, [c_f64p, c_i64, c_i64, c_f64p]),

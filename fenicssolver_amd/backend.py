@@ -363,6 +363,11 @@ def assemble_von_mises(disp_space, u, mu, lmbda, p1_space, b):
     L.check(L.load().fs_assemble_von_mises(disp_space.h, u.h, float(mu), float(lmbda), p1_space.h, b.h), "fs_assemble_von_mises")
 
 
+def assemble_viscous_stress(th_space, w, nu, p1_space, b):
+    """b[vertex*9 + 3i + j] = int (nu (grad u + grad u^T) - p I)_ij phi_vertex dx for a Taylor-Hood iterate w."""
+    L.check(L.load().fs_assemble_viscous_stress(th_space.h, w.h, float(nu), p1_space.h, b.h), "fs_assemble_viscous_stress")
+
+
 def set_dirichlet_values(b, dofs, vals):
     dofs = L.i32(dofs).ravel()
     vals = L.f64(np.broadcast_to(vals, dofs.shape))
@@ -454,12 +459,13 @@ class AMG(_Handle):
 
 
 def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, body_force=(0.0, 0.0, 0.0),
-                           convection=True, newton=True):
+                           convection=True, newton=True, mesh_velocity=(0.0, 0.0, 0.0)):
     """Linearised Taylor-Hood system at the state w0 (J w_new = g), J on a DeviceSpace(mesh, ncomp=4, degree=2)."""
     f = L.fs_ns_form()
     f.kinematic_viscosity, f.density, f.inv_dt = float(nu), float(rho), float(inv_dt)
     for i in range(3):
         f.body_force[i] = float(body_force[i])
+        f.mesh_velocity[i] = float(mesh_velocity[i])
     f.convection, f.newton = (1 if convection else 0), (1 if newton else 0)
     L.check(L.load().fs_assemble_navier_stokes(J.h, g.h, w0.h if w0 is not None else None,
                                                w_prev.h if w_prev is not None else None, C.byref(f)),

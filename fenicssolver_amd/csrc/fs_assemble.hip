@@ -1464,6 +1464,78 @@ __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load(int64_t n_rows, int
     }
 }
 
+// Right-hand sides of the L2 projection of the fluid stress  sigma = nu (grad u + grad u^T) - p I  onto CG1, component by
+// component (CoupledNavierStokesSolver.py:149-155: project(..., TensorFunctionSpace(mesh, 'CG', 1))).  Taylor-Hood iterate:
+// block (u_x, u_y, u_z, p) per CG2 node, p on the vertex nodes.  grad u is linear and p is linear: the integrand against
+// lambda_a is quadratic, the 4-point rule exact.  b[row*9 + 3 i + j] = int sigma_ij lambda_row dx.
+__global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                                  const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
+                                                                  const double* __restrict__ xyz4, const int32_t* __restrict__ w_dofs,
+                                                                  const double* __restrict__ w, double nu, double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q >> 2, a = q & 3;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const tet_geom t = tet_geometry(xyz4, v);
+            const double wq = t.adet * (1.0 / 24.0);
+            double un[10][3], pv[4];
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                const int64_t d = (int64_t)w_dofs[(int64_t)c * 10 + n] * 4;
+                un[n][0] = w[d]; un[n][1] = w[d + 1]; un[n][2] = w[d + 2];
+                if (n < 4) pv[n] = w[d + 3];
+            }
+#pragma unroll
+            for (int qp = 0; qp < 4; ++qp) {
+                const double lam[4] = {FS_P2_QP[qp][0], FS_P2_QP[qp][1], FS_P2_QP[qp][2], FS_P2_QP[qp][3]};
+                double gp[10][3];
+                p2_basis_grads(t, lam, gp);
+                double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                for (int n = 0; n < 10; ++n)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) G[i][k] += un[n][i] * gp[n][k];
+                const double pq = (lam[0] * pv[0] + lam[1] * pv[1]) + (lam[2] * pv[2] + lam[3] * pv[3]);
+                const double la = wq * (a == 0 ? lam[0] : a == 1 ? lam[1] : a == 2 ? lam[2] : lam[3]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[3 * i + k] += la * (nu * (G[i][k] + G[k][i]) - (i == k ? pq : 0.0));
+            }
+        }
+        if (row < n_rows)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) b[row * 9 + k] = acc[k];
+    }
+}
+
+extern "C" int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b) {
+    FS_REQUIRE(th_space && w && p1_space && b, "fs_assemble_viscous_stress: null pointer");
+    FS_REQUIRE(th_space->mesh == p1_space->mesh, "fs_assemble_viscous_stress: the two spaces live on different meshes");
+    FS_REQUIRE(th_space->ncomp == 4 && th_space->degree == 2, "fs_assemble_viscous_stress: needs the Taylor-Hood node-block space");
+    FS_REQUIRE(p1_space->ncomp == 1 && p1_space->degree == 1 && p1_space->inc_cell.p, "fs_assemble_viscous_stress: the target is the scalar CG1 space of the mesh");
+    FS_REQUIRE(w->d.n >= th_space->n_dofs_local && b->d.n >= 9 * p1_space->n_dofs_owned, "fs_assemble_viscous_stress: vector too short");
+    hipStream_t s = fs_rt().stream;
+    fs_mesh_s* m = p1_space->mesh;
+    hipLaunchKernelGGL(k_viscous_stress_load, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
+                       p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, b->d.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 extern "C" int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, double lambda, fs_space_t p1_space,
                                      fs_vector_t b) {
     FS_REQUIRE(disp_space && u && p1_space && b, "fs_assemble_von_mises: null pointer");

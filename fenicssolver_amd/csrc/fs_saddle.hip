@@ -72,6 +72,7 @@ __device__ __forceinline__ void p2_eval(int n, const double l[4], const double g
 struct ns_params {
     double nu, inv_rho, inv_dt;
     double f[3];
+    double wm[3];      // ALE: the frame (mesh) velocity, subtracted from the ADVECTING velocity only (:321-329)
     int convection, newton;
 };
 
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
                         for (int j = 0; j < 3; ++j) gu0[i][j] += U0[n][i] * gn[j];
                     }
                 }
-                diag += pa * (u0[0] * gb[0] + u0[1] * gb[1] + u0[2] * gb[2]);
+                diag += pa * ((u0[0] - P.wm[0]) * gb[0] + (u0[1] - P.wm[1]) * gb[1] + (u0[2] - P.wm[2]) * gb[2]);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     const double gb[3] = {L.gphi[q][b][0], L.gphi[q][b][1], L.gphi[q][b][2]};
                     const double u0[3] = {L.u0[q][0], L.u0[q][1], L.u0[q][2]};
                     double diag = P.nu * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]) + P.inv_dt * pa * pb;
-                    if (P.convection) diag += pa * (u0[0] * gb[0] + u0[1] * gb[1] + u0[2] * gb[2]);
+                    if (P.convection) diag += pa * ((u0[0] - P.wm[0]) * gb[0] + (u0[1] - P.wm[1]) * gb[1] + (u0[2] - P.wm[2]) * gb[2]);
                     const bool full = P.convection && P.newton;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -456,6 +457,7 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     P.inv_rho = 1.0 / form->density;
     P.inv_dt = form->inv_dt;
     for (int i = 0; i < 3; ++i) P.f[i] = form->body_force[i];
+    for (int i = 0; i < 3; ++i) P.wm[i] = form->convection ? form->mesh_velocity[i] : 0.0;
     P.convection = form->convection ? 1 : 0;
     P.newton = form->newton ? 1 : 0;
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));

@@ -10,6 +10,7 @@
 #include "fs_common.h"
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
+#include <algorithm>
 
 // ---- keys ------------------------------------------------------------------------------
 // nd*(nd-1) directed pairs per cell (a != b) + one diagonal key per owned row.
@@ -489,6 +490,38 @@ __global__ void __launch_bounds__(1024) k_bbox(const double* __restrict__ xyz4, 
         box[3 + d] = b2;
     }
 }
+// How fast does each coordinate vary along the row numbering?  cnt[a] = number of consecutive owned rows whose
+// a-coordinates differ: a lexicographic box numbering gives n, n/N_fast, n/(N_fast N_mid) for its three axes.
+__global__ void __launch_bounds__(FS_BLOCK) k_axis_counts(const double* __restrict__ xyz4, int64_t n_rows, unsigned long long* __restrict__ cnt) {
+    unsigned long long c[3] = {0, 0, 0};
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i + 1 < n_rows; i += stride)
+        for (int d = 0; d < 3; ++d) c[d] += xyz4[4 * i + d] != xyz4[4 * (i + 1) + d];
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) c[d] += __shfl_down(c[d], off, 64);
+        if ((threadIdx.x & 63) == 0 && c[d]) atomicAdd(&cnt[d], c[d]);
+    }
+}
+// Pencil order of the slices of a lexicographically numbered box (fast / mid / slow axis): the mid axis is cut into
+// n_tiles bands; a band is swept plane by plane along the slow axis, inside a plane in row order.  Rows that are
+// neighbours across planes (offsets +-N_fast*N_mid and friends) are then one band-plane apart in the sweep instead of a
+// whole plane: what the mirrored reads of the symmetric product (fs_krylov.hip) and the x windows need to meet in L2.
+__global__ void k_slice_keys_pencil(int64_t n_slices, const double* __restrict__ xyz4, const double* __restrict__ box, int mid,
+                                    int slow, int n_tiles, int n_slow, uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < n_slices; s += stride) {
+        const int64_t v = s * FS_SLICE;
+        const double em = box[3 + mid] - box[mid], es = box[3 + slow] - box[slow];
+        double tm = em > 0.0 ? (xyz4[4 * v + mid] - box[mid]) / em * n_tiles : 0.0;
+        tm = tm < 0.0 ? 0.0 : (tm > n_tiles - 1.0 ? n_tiles - 1.0 : tm);
+        double ts = es > 0.0 ? (xyz4[4 * v + slow] - box[slow]) / es * (n_slow - 1) + 0.5 : 0.0;
+        ts = ts < 0.0 ? 0.0 : (ts > n_slow - 1.0 ? n_slow - 1.0 : ts);
+        key[s] = ((uint32_t)tm << 20) | (uint32_t)ts;
+        idx[s] = (int32_t)s;
+    }
+}
 __device__ __forceinline__ uint32_t fs_spread3(uint32_t v) {      // 10 bits -> every third bit
     v &= 0x3ff;
     v = (v | (v << 16)) & 0x030000ff;
@@ -825,9 +858,13 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     // processing order of the slices (SpMV, gather assembly).  CG2: by the vertex the slice's first node sits at, i.e.
     // the sweep order of the vertices with the edge classes interleaved (bits = -1).  Measured inside the CG solve on
     // MI355X (round 1): P2 10 M DOF 1071 us unordered, 703 us by vertex, 735-755 us in Morton order (4-7 bits per
-    // axis); P1 (already in sweep order) 328 us unordered, 342 us in Morton order - so CG1 spaces are left alone.
-    // FS_SLICE_ORDER = 0 | -1 | <Morton bits per axis> overrides.
-    int order_bits = degree == 2 ? -1 : 0;
+    // axis); P1 (already in sweep order) 328 us unordered, 342 us in Morton order.
+    // CG1 spaces too large for the caches (> 2 M rows) on a lexicographically numbered box: PENCIL order (-2; bands of
+    // ~4096 rows along the middle axis, each swept plane by plane).  Round 2, 10 M DOF: gather assembly 3.97 -> 2.91 ms (the
+    // cells and coordinates of the plane below / above are still in L2 when they are needed again), CG product unchanged
+    // within run-to-run noise (0.298-0.323 ms either way).  Anything else keeps its natural order.
+    // FS_SLICE_ORDER = 0 | -1 | -2 | <Morton bits per axis> overrides.
+    int order_bits = degree == 2 ? -1 : (n_slices > 32768 && mesh->tdim == 3 ? -2 : 0);
     if (const char* e = getenv("FS_SLICE_ORDER")) order_bits = atoi(e);
     if (getenv("FS_NO_SLICE_ORDER")) order_bits = 0;
     if (order_bits > 10) order_bits = 10;
@@ -841,15 +878,47 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP(k_out.alloc(n_slices));
         FS_SP(v_in.alloc(n_slices));
         FS_SP(sp->slice_order.alloc(n_slices));
-        hipLaunchKernelGGL(k_slice_keys, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, mesh->n_owned, n_rows,
-                           degree == 2 ? sp->edges.p : (const int32_t*)nullptr, mesh->xyz.p, box.p, order_bits, k_in.p, v_in.p);
+        bool pencil = false, skip = false;
+        if (order_bits == -2) {
+            // pencil order: needs the numbering to be lexicographic on a box (axis speeds well separated)
+            dbuf<unsigned long long> cnt;
+            FS_SP(cnt.alloc(3));
+            FS_SP(cnt.zero(s));
+            hipLaunchKernelGGL(k_axis_counts, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, mesh->xyz.p, n_rows, cnt.p);
+            unsigned long long hc[3] = {0, 0, 0};
+            FS_SP(cnt.download(hc, 3, s));
+            int ax[3] = {0, 1, 2};
+            std::sort(ax, ax + 3, [&](int a, int b2) { return hc[a] > hc[b2]; });
+            const int mid = ax[1], slow = ax[2];
+            const double n_slow = (double)hc[slow] + 1.0, n_mid = ((double)hc[mid] + 1.0) / n_slow;
+            const double n_fast = (double)n_rows / (n_mid * n_slow);
+            static const double tile_rows = getenv("FS_TILE_ROWS") ? atof(getenv("FS_TILE_ROWS")) : 4096.0;
+            if (mesh->tdim == 3 && hc[ax[0]] > 4 * hc[mid] && hc[mid] > 4 * hc[slow] && n_slow >= 4 && n_slow < (1 << 20) && n_mid >= 2) {
+                double lines = tile_rows / n_fast;
+                lines = lines < 1.0 ? 1.0 : lines;
+                int n_tiles = (int)(n_mid / lines + 0.5);
+                n_tiles = n_tiles < 1 ? 1 : (n_tiles > 4000 ? 4000 : n_tiles);
+                hipLaunchKernelGGL(k_slice_keys_pencil, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, mesh->xyz.p, box.p, mid, slow,
+                                   n_tiles, (int)n_slow, k_in.p, v_in.p);
+                pencil = true;
+                if (getenv("FS_SPACE_DEBUG"))
+                    fprintf(stderr, "[fs_space] pencil order: axes fast %d mid %d slow %d, %g x %g x %g nodes, %d bands\n", ax[0], mid, slow, n_fast, n_mid, n_slow, n_tiles);
+            }
+        }
+        if (!pencil && order_bits == -2 && degree == 1) skip = true;     // no box numbering found: CG1 rows keep their order
+        if (skip) sp->slice_order.release();
+        else if (!pencil)
+            hipLaunchKernelGGL(k_slice_keys, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, mesh->n_owned, n_rows,
+                               degree == 2 ? sp->edges.p : (const int32_t*)nullptr, mesh->xyz.p, box.p, order_bits == -2 ? -1 : order_bits, k_in.p, v_in.p);
         FS_SP_HIP(hipGetLastError());
         size_t tbs = 0;
+        if (!skip) {
         FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tbs, k_in.p, k_out.p, v_in.p, sp->slice_order.p, (int)n_slices, 0, 32, s));
         dbuf<char> tmps;
         FS_SP(tmps.alloc((int64_t)tbs + 16));
         FS_SP_HIP(hipcub::DeviceRadixSort::SortPairs(tmps.p, tbs, k_in.p, k_out.p, v_in.p, sp->slice_order.p, (int)n_slices, 0, 32, s));
         FS_SP_HIP(hipStreamSynchronize(s));
+        }
     }
     if (ncomp == 1 && sp->max_row <= 255) {
         // 5a. scalar spaces: row-gather incidence tables (deterministic, atomic-free assembly)

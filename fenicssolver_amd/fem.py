@@ -745,6 +745,14 @@ def VectorFunctionSpace(mesh, family="CG", degree=1, dim=None, constrained_domai
     return FunctionSpace(mesh, family, degree, constrained_domain, _ncomp=dim or mesh.geometry().dim())
 
 
+def TensorFunctionSpace(mesh, family="CG", degree=1, shape=None):
+    """Host-side container of a nodal tensor field (dim x dim values per node, row-major): what viscous_stress /
+    project(sigma, T) return (CoupledNavierStokesSolver.py:149-155).  Never assembled on: no device space behind it."""
+    d = mesh.geometry().dim()
+    n = int(np.prod(shape)) if shape else d * d
+    return FunctionSpace(mesh, family, degree, _ncomp=n, _holder=True)
+
+
 class _Vector:
     """Minimal GenericVector: numpy storage with the calls the reference's users make."""
 

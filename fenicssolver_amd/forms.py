@@ -155,6 +155,8 @@ class NavierStokesForm:
         # pressure boundaries: [(marker_id, value | None)]: + inner(value*n, v)*ds(id) (value given) and
         # - nu*inner((grad(u) + grad(u).T)*n, v)*ds(id)   (CoupledNavierStokesSolver.py:449-453, 459-460)
         self.pressure_boundaries = []
+        # ALE frame (reference_frame_settings {'type': 'ALE', 'mesh_velocity': ..}, :321-329): advecting velocity u0 - w
+        self.mesh_velocity = None     # 3 numbers or None
 
     @staticmethod
     def _value_name(v):
@@ -167,4 +169,5 @@ class NavierStokesForm:
         return {"type": "navier_stokes", "nu": self.nu, "rho": self.rho, "inv_dt": self.inv_dt,
                 "pressure_boundaries": [(int(m), None if v is None else self._value_name(v)) for m, v in self.pressure_boundaries],
                 "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
+                "mesh_velocity": None if self.mesh_velocity is None else [float(x) for x in self.mesh_velocity],
                 "newton": bool(self.newton)}

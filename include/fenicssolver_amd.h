@@ -210,6 +210,12 @@ int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t
  * fs_krylov_solve.  CG1 displacement: exact; CG2: 4-point degree-2 rule. */
 int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, double lambda, fs_space_t p1_space, fs_vector_t b);
 
+/* Right-hand sides of the L2 projection of the fluid stress  nu (grad u + grad u^T) - p I  onto CG1
+ * (CoupledNavierStokesSolver.py:149-155, viscous_stress): b[vertex*9 + 3 i + j] = int sigma_ij phi_vertex dx for a
+ * Taylor-Hood iterate w (block (u_x,u_y,u_z,p) per CG2 node).  Each of the 9 components is then one CG1 mass-matrix
+ * solve (fs_assemble_matrix(mass = 1) on p1_space + fs_krylov_solve). */
+int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b);
+
 /* SUPG part of the boundary integrals (the reference substitutes q + tau (v . grad q) in them too,
  * ScalarTransportSolver.py:296-298 with Tq): for every listed boundary facet (cell behind it, local vertex opposite)
  *   b_a += g_f * area * w_a                      (flux / Neumann / HTC ambient loads; g may be NULL)
@@ -331,6 +337,9 @@ typedef struct fs_ns_form {
     double body_force[3];       /* f of -f.v (acceleration, "just gravity, without * rho") */
     int convection;             /* (grad(u) u0).v with u0 = velocity part of w0 */
     int newton;                 /* add (grad(u0) u).v to J and (grad(u0) u0).v to g: derivative(action(F, w0)) */
+    double mesh_velocity[3];    /* ALE frame (reference_frame_settings, CoupledNavierStokesSolver.py:321-329): the advecting
+                                 * velocity is u0 - mesh_velocity, i.e. the term is (grad(u) (u0 - w)).v; constant vector.
+                                 * Written for the new iterate, the Newton right-hand side keeps (grad(u0) u0).v. */
 } fs_ns_form;
 
 /* J <- linearised operator at w0, g <- right-hand side such that J w_new = g is the Newton (or Picard) step

@@ -101,12 +101,15 @@ class TaylorHood:
 
 
 def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, newton=True, convection=True,
-              quad_degree=5):
+              quad_degree=5, mesh_velocity=None):
     """Linearised system at the state w0:  J(w0) w_new = g(w0).
 
     J = 2 nu eps:eps + (1/dt) mass + (grad(.) u0).v [+ (grad(u0) .).v if newton] - (p/rho) div v + (q/rho) div u
     g = f.v + (1/dt) u_prev.v [+ (grad(u0) u0).v if newton]
     so that the Newton update solves J (w_new - w0) = -R(w0) with R(w) = K(w) w - rhs.
+    mesh_velocity (constant 3-vector): the ALE frame of CoupledNavierStokesSolver.py:321-329 - the ADVECTING velocity is
+    u0 - w_mesh: (grad(.) (u0 - w)).v in J; the Newton terms (grad(u0) .).v and (grad(u0) u0).v are unchanged
+    (J w_new = J w0 - F(w0) with F's convective part (grad(u0) (u0 - w)).v).
     Returns (J csr [n,n], g [n]); dummy pressure rows are identity / zero.
     """
     nc = len(th.cells)
@@ -134,7 +137,8 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
         for i in range(3):
             Ke[:, :, i, :, i] += (inv_dt * wv)[:, None, None] * mm[None]
         if convection:
-            adv = np.einsum("ck,cbk->cb", u0, gphi)         # u0 . grad phi_b
+            ua = u0 if mesh_velocity is None else u0 - np.asarray(mesh_velocity, dtype=np.float64)[None, :]
+            adv = np.einsum("ck,cbk->cb", ua, gphi)         # (u0 - w_mesh) . grad phi_b
             cc = np.einsum("a,cb->cab", phi, adv)
             for i in range(3):
                 Ke[:, :, i, :, i] += wv[:, None, None] * cc
@@ -173,10 +177,52 @@ def apply_dirichlet_rows(J, g, dofs, vals):
     return J.tocsr(), g
 
 
-def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None):
+def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, mesh_velocity=None):
     """R(w) = K(w) w - rhs  (the nonlinear residual F of the reference after action(F, w))."""
-    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False)
+    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False, mesh_velocity=mesh_velocity)
     return K @ w - rhs
+
+
+def viscous_stress_projection(th, w, nu):
+    """project(nu (grad u + grad u^T) - p I, TensorFunctionSpace(mesh, 'CG', 1)) (CoupledNavierStokesSolver.py:149-155):
+    consistent P1 mass matrix, 4-point rule (integrand quadratic).  Returns sigma [nv, 3, 3]."""
+    W = np.asarray(w, dtype=np.float64).reshape(th.n_nodes, 4)
+    U = W[th.cell_nodes][:, :, :3]
+    Pv = W[th.cells][:, :, 3]
+    be = np.zeros((len(th.cells), 4, 9))
+    pts, wq = tet_quadrature(2)
+    for lam, wt in zip(pts, wq):
+        _, dphi = p2_shape(lam)
+        gphi = np.einsum("ak,cki->cai", dphi, th.glam)
+        G = np.einsum("cai,caj->cij", U, gphi)
+        pq = Pv @ lam
+        sig = nu * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(3)
+        be += (wt * th.vol)[:, None, None] * lam[None, :, None] * sig.reshape(-1, 1, 9)
+    M = fo.assemble_matrix(th.nv, th.cells, fo.p1_mass_local(th.coords, th.cells, 1.0))
+    out = np.zeros((th.nv, 9))
+    for k in range(9):
+        out[:, k] = fo.solve_direct(M, fo.assemble_generic_vector(th.nv, th.cells, be[:, :, k]))
+    return out.reshape(th.nv, 3, 3)
+
+
+def boundary_force(th, sigma, inside):
+    """-int sigma n ds over the boundary facets whose mid-point satisfies inside(x) (calc_drag_and_lift, :166-183; n the
+    outward normal): with P1 sigma the facet integral is area * mean of the three vertex tensors."""
+    facets, cell_facets, cnt = fo.facet_numbering(th.cells)
+    bf = np.nonzero(cnt == 1)[0]
+    owner = np.zeros(len(facets), dtype=np.int64)
+    owner[cell_facets.ravel()] = np.repeat(np.arange(len(th.cells)), 4)
+    F = np.zeros(3)
+    for f in bf:
+        tri = facets[f].astype(np.int64)
+        X = th.coords[tri]
+        if not inside(X.mean(axis=0)):
+            continue
+        nrm = 0.5 * np.cross(X[1] - X[0], X[2] - X[0])
+        if nrm @ (X.mean(axis=0) - th.coords[th.cells[owner[f]]].mean(axis=0)) < 0:
+            nrm = -nrm
+        F -= sigma[tri].mean(axis=0) @ nrm
+    return F
 
 
 def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None,

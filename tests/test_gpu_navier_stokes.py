@@ -334,3 +334,117 @@ def test_channel_flow_with_pressure_inlet_and_outlet_through_the_solver_class(gp
     assert np.abs(u.node_values()[:, 1:]).max() <= 1e-6
     co = mesh.coordinates()
     assert np.abs(p.vector().array() - dp * (1 - co[:, 0])).max() <= 1e-5
+
+
+def test_ale_mesh_velocity_shifts_the_advecting_velocity_only(gpu):
+    """reference_frame_settings {'type': 'ALE', 'mesh_velocity': w} (CoupledNavierStokesSolver.py:321-329): J gets
+    (grad(.) (u0 - w)).v, the Newton terms keep u0; checked for Newton and Picard against the oracle."""
+    co, ce, th, mesh, W, Q = _setup(gpu, 3, (1.0, 0.8, 1.3))
+    rng = np.random.default_rng(2)
+    w0 = 0.3 * rng.standard_normal(th.n)
+    w0[th.dummy_dofs()] = 0.0
+    nu, rho, wm = 0.05, 1.3, (0.4, -0.7, 0.25)
+    J = gpu.DeviceMatrix(W)
+    g = gpu.DeviceVector(W.n_owned)
+    for newton in (True, False):
+        gpu.assemble_navier_stokes(J, g, gpu.DeviceVector(W.n_local, w0), None, nu=nu, rho=rho, convection=True, newton=newton,
+                                   mesh_velocity=wm)
+        Jr, gr = ns.ns_system(th, w0, nu, rho, 0.0, None, None, newton=newton, mesh_velocity=wm)
+        assert abs(_csr(J) - Jr).max() <= 1e-11 * abs(Jr).max()
+        assert np.abs(g.get() - gr).max() <= 1e-11 * max(np.abs(gr).max(), 1.0)
+        J0, _ = ns.ns_system(th, w0, nu, rho, 0.0, None, None, newton=newton)
+        assert abs(Jr - J0).max() > 1e-3 * abs(Jr).max()            # the frame velocity does change the operator
+    # J w0 - g is the residual of the ALE form: K w0 + (grad(u0) (u0 - w)).v
+    gpu.assemble_navier_stokes(J, g, gpu.DeviceVector(W.n_local, w0), None, nu=nu, rho=rho, convection=True, newton=True, mesh_velocity=wm)
+    r = _csr(J) @ w0 - g.get()
+    rr = ns.residual(th, w0, nu, rho, mesh_velocity=wm)
+    assert np.abs(r - rr).max() <= 1e-10 * np.abs(rr).max()
+
+
+def _channel_solver(ale=None):
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import BoxMesh, Point, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    nu = 0.3
+    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 3, 3, 6)
+    prof = Expression(("0", "0", "x[0]*(1-x[0])"), degree=2)
+    bcs = OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[0], 0) or near(x[0], 1) or near(x[1], 0) or near(x[1], 1))),
+                    'boundary_id': 1, 'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': prof}]}
+    bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 0)), 'boundary_id': 2,
+                    'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(2 * nu * 2)}]}
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 2)), 'boundary_id': 3,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(0.0)}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+              'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 1.0, 'kinematic_viscosity': nu}})
+    if ale is not None:
+        s['reference_frame_settings'] = {'type': 'ALE', 'mesh_velocity': ale}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-10}
+    s['report_settings'] = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    return CoupledNavierStokesSolver(s), nu
+
+
+def test_viscous_stress_projection_and_drag_lift(gpu):
+    """viscous_stress = project(nu (grad u + grad u^T) - p I, CG1 tensors) (:149-155) against the oracle's sparse-LU
+    projection; calc_drag_and_lift (:172-192, with the undefined self.ds read as the boundary markers) against the
+    oracle's facet sums and against the analytic wall shear of the plane channel flow."""
+    solver, nu = _channel_solver()
+    w = solver.solve()
+    co, ce = solver.mesh.coordinates(), solver.mesh.cells()
+    th = ns.TaylorHood(co, ce)
+    assert np.array_equal(solver.function_space.edge_nodes().astype(np.int64), th.edges.astype(np.int64))
+    sig = solver.viscous_stress(w)
+    ref = ns.viscous_stress_projection(th, w.vector().array(), nu)
+    got = sig.node_values().reshape(-1, 3, 3)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-8 * np.abs(ref).max()
+    assert np.abs(got - np.swapaxes(got, 1, 2)).max() == 0.0
+    # the flow is u_z = x(1-x), p = 4 nu (1 - z/2): sigma_zx = nu (1 - 2x), sigma_ii = -p  (P1-representable: exact)
+    X = co
+    assert np.abs(got[:, 2, 0] - nu * (1 - 2 * X[:, 0])).max() <= 1e-6
+    assert np.abs(got[:, 0, 0] + 4 * nu * (1 - X[:, 2] / 2)).max() <= 1e-6
+    # forces on the walls (marker 1): drag along z, lift along x
+    drag, lift = solver.calc_drag_and_lift(w, 2, 0, [1])
+    F = ns.boundary_force(th, ref, lambda x: min(abs(x[0]), abs(x[0] - 1), abs(x[1]), abs(x[1] - 1)) < 1e-12)
+    assert abs(drag - F[2]) <= 1e-9 * abs(F[2]) and abs(lift - F[0]) <= 1e-9 * max(abs(F[0]), abs(F[2]))
+    # analytic: -int sigma n ds on x = 0 and x = 1 walls: -(sigma_zx * (-1))|x=0 * 2 - (sigma_zx * 1)|x=1 * 2 = 2 nu + 2 nu
+    assert abs(drag - 4 * nu) <= 1e-6 and abs(lift) <= 1e-6
+    with pytest.raises(Exception):
+        solver.calc_drag_and_lift(w, 2, 0, [])
+    # traction on the boundary vertices: sigma . n; on the wall x = 0 (n = -e_x) its z-component is -nu
+    t = solver.boundary_traction(w).node_values()
+    wall0 = np.nonzero((X[:, 0] == 0) & (X[:, 1] > 0) & (X[:, 1] < 1) & (X[:, 2] > 0) & (X[:, 2] < 2))[0]
+    interior = np.nonzero((X[:, 0] > 0) & (X[:, 0] < 1) & (X[:, 1] > 0) & (X[:, 1] < 1) & (X[:, 2] > 0) & (X[:, 2] < 2))[0]
+    assert np.abs(t[wall0, 2] + nu).max() <= 1e-6 and np.abs(t[interior]).max() == 0.0
+
+
+def test_ale_frame_through_the_solver_api(gpu):
+    """A frame moving along the channel axis changes nothing for a z-independent flow ((grad u) w = 0 for w = (0,0,c)),
+    a frame moving across it does; both go through reference_frame_settings."""
+    base, _ = _channel_solver()
+    u0 = base.solve().vector().array().copy()
+    along, _ = _channel_solver(ale=(0.0, 0.0, 0.8))
+    u1 = along.solve().vector().array()
+    assert np.abs(u1 - u0).max() <= 1e-7 * np.abs(u0).max()
+    F, _ = along.generate_form(0, None, None, along.w_current, along.w_prev)
+    assert F.describe()["mesh_velocity"] == [0.0, 0.0, 0.8]
+    across, _ = _channel_solver(ale=(0.5, 0.0, 0.0))
+    u2 = across.solve().vector().array()
+    assert np.abs(u2 - u0).max() >= 1e-4 * np.abs(u0).max()
+    th = ns.TaylorHood(base.mesh.coordinates(), base.mesh.cells())
+    r = ns.residual(th, u2, 0.3, 1.0, mesh_velocity=(0.5, 0.0, 0.0))
+    free = np.ones(th.n, dtype=bool)
+    X = th.node_coords
+    bn = th.boundary_nodes(lambda x: min(abs(x[0]), abs(x[0] - 1), abs(x[1]), abs(x[1] - 1)) < 1e-12)
+    free[th.velocity_dofs(bn)] = False
+    free[3::4] = True
+    # momentum residual on the free velocity dofs of the interior (pressure-boundary integrals live on inlet / outlet nodes)
+    inner = free.copy()
+    io = th.boundary_nodes(lambda x: abs(x[2]) < 1e-12 or abs(x[2] - 2) < 1e-12)
+    inner[th.velocity_dofs(io)] = False
+    inner[3::4] = False
+    assert np.abs(r[inner]).max() <= 1e-7 * max(np.abs(r).max(), 1e-3)
