@@ -345,7 +345,7 @@ class SolverBase():
         loc = u.function_space().localizer()
         if pc == 'amg':
             # several GPUs: every rank builds the hierarchy of its own diagonal block (additive Schwarz, no overlap)
-            if near_nullspace is not None and loc is not None:
+            if near_nullspace is not None and not isinstance(near_nullspace, str) and loc is not None:
                 near_nullspace = np.stack([loc.nodes(v)[:V.n_owned] for v in np.asarray(near_nullspace)])
             hierarchy = backend.AMG(A, nullspace=near_nullspace,
                                     strength_threshold=float(sp_.get('amg_strength_threshold', 0.0)))
@@ -843,9 +843,9 @@ class SolverBase():
             # empty right-hand side: the reference fails in assemble_system here (Appendix B-Q11)
             self.logger.warning('solve_amg: zero load and homogeneous BCs, the solution is zero')
         A, b = self.assemble_system(F, bcs, symmetric=True)
-        ns = None
-        if isinstance(F, forms.ElasticityForm):
-            self._near_nullspace = ns = self.build_nullspace(self.function_space, u.vector())
+        # near-null space of the elasticity operator: the six rigid-body modes, built on the device from the node
+        # coordinates (build_nullspace() below is the host version the reference's API exposes)
+        ns = "rigid_body" if isinstance(F, forms.ElasticityForm) and self.dimension == 3 else None
         return self._device_solve(A, b, u, 'solve_amg', amg=True, near_nullspace=ns)
 
     def build_nullspace(self, V, x=None):

@@ -72,7 +72,7 @@ class fs_saddle_opts(C.Structure):
 
 class fs_amg_opts(C.Structure):
     _fields_ = [("strength_threshold", C.c_double), ("max_levels", C.c_int), ("coarse_size", C.c_int),
-                ("smoother_steps", C.c_int), ("eig_steps", C.c_int)]
+                ("smoother_steps", C.c_int), ("eig_steps", C.c_int), ("rigid_body_modes", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/fenicssolver_amd.h

@@ -392,7 +392,8 @@ def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi",
 class AMG(_Handle):
     """Smoothed-aggregation hierarchy of an assembled SPD matrix (PETSc GAMG behind
     PETScPreconditioner("petsc_amg"), SolverBase.py:643-672).  nullspace: [nb, n_dofs] near-null-space
-    vectors (rigid-body modes) or None = constants per component."""
+    vectors, "rigid_body" = the six rigid-body modes built on the device from the node coordinates (3-vector CG1
+    spaces), or None = constants per component."""
     _destroy = "fs_amg_destroy"
 
     def __init__(self, A, nullspace=None, strength_threshold=0.0, max_levels=0, coarse_size=0, smoother_steps=0,
@@ -403,7 +404,11 @@ class AMG(_Handle):
         o.strength_threshold, o.max_levels, o.coarse_size = float(strength_threshold), int(max_levels), int(coarse_size)
         o.smoother_steps, o.eig_steps = int(smoother_steps), int(eig_steps)
         ns, nb = None, 0
-        if nullspace is not None:
+        if isinstance(nullspace, str):
+            if nullspace != "rigid_body":
+                raise ValueError("nullspace must be an array, None or 'rigid_body'")
+            o.rigid_body_modes = 1
+        elif nullspace is not None:
             ns = np.ascontiguousarray(np.asarray(nullspace, dtype=np.float64).reshape(len(nullspace), -1))
             nb = ns.shape[0]
             if ns.shape[1] != A.space.n_owned:

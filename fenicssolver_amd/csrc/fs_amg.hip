@@ -142,6 +142,22 @@ __global__ void k_nullspace_layout(int64_t n, int nb, int bs, const double* __re
     }
 }
 
+// The six rigid-body modes of SolverBase.build_nullspace (SolverBase.py:674-706) from the node coordinates, in the
+// [dof][6] layout of the near-null space: translations, then (-y, x, 0), (z, 0, -x), (0, -z, y).  The reference
+// orthonormalises them globally; the tentative prolongator orthonormalises per aggregate anyway, so the span is what
+// matters.  Saves the 6 n doubles a host-built basis has to cross PCIe (245 MB at configs[2]).
+__global__ void k_rigid_body_modes(int64_t n_nodes, const double* __restrict__ xyz4, double* __restrict__ B) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_nodes; i += stride) {
+        const double x = xyz4[4 * i], y = xyz4[4 * i + 1], z = xyz4[4 * i + 2];
+        double* b = B + i * 18;
+        const double rows[3][6] = {{1, 0, 0, -y, z, 0}, {0, 1, 0, x, 0, -z}, {0, 0, 1, 0, -x, y}};
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 6; ++k) b[c * 6 + k] = rows[c][k];
+    }
+}
+
 // ---- level 0: block CSR copy of the SELL/DIA matrix -------------------------------------------------
 template <int BS>
 __global__ void k_amg_extract(int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ rowptr,
@@ -863,22 +879,23 @@ static int estimate_lmax(fs_amg_s* M, amg_level* L, int steps, hipStream_t s) {
     FS_CHECK(v.zero(s));
     FS_CHECK(w.zero(s));
     hipLaunchKernelGGL(k_amg_seed, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, v.p);
-    double nv = 0.0, lam = 0.0;
-    FS_CHECK(dot_host(M, v.p, v.p, L->n, &nv, s));
-    hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, (const double*)nullptr, v.p, 1.0 / sqrt(nv));
-    for (int it = 0; it < steps; ++it) {
+    // No normalisation and no host round trip inside the loop (round 1: one synchronising dot per step, 21 + 19 ms of the
+    // 160 ms set-up at configs[2], most of it latency on the small levels): the iterate grows by at most the Gershgorin
+    // bound per step, 1e300 is far away for any sensible step count, and lambda = ||v_k|| / ||v_{k-1}|| needs two dots.
+    const double growth = L->gersh > 1.0 ? L->gersh : 1.0;
+    int safe = steps;
+    while (safe > 1 && safe * log10(growth) > 250.0) --safe;
+    double n_prev = 0.0, n_last = 0.0;
+    for (int it = 0; it < safe; ++it) {
+        if (it == safe - 1) FS_CHECK(dot_host(M, v.p, v.p, L->n, &n_prev, s));
         if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
         else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
         hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, w.p, 1.0);
-        double nw = 0.0;
-        FS_CHECK(dot_host(M, w.p, w.p, L->n, &nw, s));
-        nw = sqrt(nw);
-        if (!(nw > 0.0)) break;
-        lam = nw;
-        hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, (const double*)nullptr, w.p, 1.0 / nw);
         std::swap(v.p, w.p);
     }
-    L->lmax = lam > 0.0 ? std::min(1.1 * lam, L->gersh) : L->gersh;
+    FS_CHECK(dot_host(M, v.p, v.p, L->n, &n_last, s));
+    const double lam = n_prev > 0.0 ? sqrt(n_last / n_prev) : 0.0;
+    L->lmax = (lam > 0.0 && lam == lam && lam < 1e300) ? std::min(1.1 * lam, L->gersh) : L->gersh;
     return FS_OK;
 }
 
@@ -1091,7 +1108,9 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
     // of a non-overlapping additive Schwarz preconditioner; fs_amg_apply then expects zero ghost entries in z.
     const bool local_block = sp->n_nodes_local > sp->n_nodes_owned;
     FS_REQUIRE(A->bs == 1 || A->bs == 3, "fs_amg_setup: block size %d", A->bs);
-    const int nb = nullspace ? n_nullspace : A->bs;
+    const bool rigid = !nullspace && opts && opts->rigid_body_modes != 0;
+    FS_REQUIRE(!rigid || (A->bs == 3 && sp->degree == 1 && sp->mesh->tdim == 3), "fs_amg_setup: rigid-body modes are built for 3-vector CG1 spaces on tetrahedra");
+    const int nb = nullspace ? n_nullspace : (rigid ? 6 : A->bs);
     FS_REQUIRE(nb == 1 || nb == 3 || nb == 6, "fs_amg_setup: %d near-null-space vectors (1, 3 or 6 are built)", nb);
     // 0 = default 0.05; negative = keep every coupling above the summation-order noise (1e-8)
     const double theta = (!opts || opts->strength_threshold == 0.0) ? 0.05 : std::max(opts->strength_threshold, 1e-8);
@@ -1135,7 +1154,10 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
             if ((rc = raw.alloc(L0->n * nb)) != FS_OK) return fail(rc);
             if ((rc = raw.upload(nullspace, L0->n * nb, s)) != FS_OK) return fail(rc);
         }
-        hipLaunchKernelGGL(k_nullspace_layout, dim3(fs_grid_for(L0->n * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->n, nb, A->bs, (const double*)raw.p, L0->B.p);
+        if (rigid)
+            hipLaunchKernelGGL(k_rigid_body_modes, dim3(fs_grid_for(L0->nn, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->nn, sp->mesh->xyz.p, L0->B.p);
+        else
+            hipLaunchKernelGGL(k_nullspace_layout, dim3(fs_grid_for(L0->n * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->n, nb, A->bs, (const double*)raw.p, L0->B.p);
         if (hipStreamSynchronize(s) != hipSuccess) { fs_set_error("fs_amg_setup: near-null-space upload failed"); return fail(FS_ERR_HIP); }
     }
     if (local_block) {

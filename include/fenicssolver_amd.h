@@ -304,6 +304,8 @@ typedef struct fs_amg_opts {
     int coarse_size;           /* stop coarsening at this many dofs; 0 = 500 */
     int smoother_steps;        /* Chebyshev steps per pre/post smoothing; 0 = 2 (PETSc mg_levels_ksp_max_it) */
     int eig_steps;             /* power-iteration steps of the eigenvalue estimate; 0 = 30 */
+    int rigid_body_modes;      /* nullspace == NULL and a 3-vector CG1 space: build the six rigid-body modes of
+                                * build_nullspace() (SolverBase.py:674-706) on the device from the node coordinates */
 } fs_amg_opts;
 
 /* Build the hierarchy for the assembled (Dirichlet-eliminated, SPD) matrix.  nullspace: host array

@@ -219,3 +219,53 @@ def test_solve_amg_is_the_default_of_the_elasticity_solver(gpu):
     uj = j.solve().vector().array()
     assert 'amg_levels' not in j.last_solve_stats and j.last_solve_stats['iterations'] > 200
     assert np.abs(ua - uj).max() <= 1e-6 * np.abs(uj).max()
+
+
+def test_device_rigid_body_modes_equal_the_host_built_near_null_space(gpu):
+    """nullspace='rigid_body' builds the six modes of SolverBase.build_nullspace on the device from the node coordinates:
+    level-0 near-null space identical to the un-normalised host vectors, same hierarchy and the same iteration count as
+    the (orthonormalised) host basis the reference passes - the tentative prolongator orthonormalises per aggregate."""
+    co, ce = fo.box_mesh((0, 0, 0), (6.0, 1.0, 1.2), 24, 4, 5)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=fo.lame(2e11, 0.27))
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, vector_value=(0.0, 0.0, -7.8e4))
+    left = np.nonzero(co[:, 0] == 0.0)[0]
+    A.apply_dirichlet(b, (left[:, None] * 3 + np.arange(3)).ravel().astype(np.int32), 0.0, symmetric=True)
+    n = len(co)
+    raw = np.zeros((6, n, 3))
+    raw[0, :, 0] = raw[1, :, 1] = raw[2, :, 2] = 1.0
+    raw[3, :, 0], raw[3, :, 1] = -co[:, 1], co[:, 0]
+    raw[4, :, 0], raw[4, :, 2] = co[:, 2], -co[:, 0]
+    raw[5, :, 2], raw[5, :, 1] = co[:, 1], -co[:, 2]
+    dev = gpu.AMG(A, nullspace="rigid_body")
+    host = gpu.AMG(A, nullspace=fo.rigid_body_modes(co))
+    assert dev.info()["levels"] == host.info()["levels"]
+    for l in range(dev.info()["levels"]):
+        assert dev.level_info(l)["n_nodes"] == host.level_info(l)["n_nodes"]
+        assert dev.level_info(l)["nnz_blocks"] == host.level_info(l)["nnz_blocks"]
+    xd, xh = gpu.DeviceVector(V.n_owned), gpu.DeviceVector(V.n_owned)
+    sd = dev.solve(b, xd, rtol=1e-10)
+    sh = host.solve(b, xh, rtol=1e-10)
+    assert sd["converged"] == 1 and abs(sd["iterations"] - sh["iterations"]) <= 1
+    assert np.abs(xd.get() - xh.get()).max() <= 1e-7 * np.abs(xh.get()).max()
+    # the device near-null space itself (level 0, [dof][6]) against the host vectors
+    import ctypes as C
+    from fenicssolver_amd import _lib as L
+    got = np.empty(V.n_owned * 6)
+    L.check(L.load().fs_amg_level_get(dev.h, 0, 2, None, None, L.p_f64(got)), "fs_amg_level_get")
+    fixed = np.zeros(3 * n, dtype=bool)
+    fixed[(left[:, None] * 3 + np.arange(3)).ravel()] = True
+    want = raw.reshape(6, -1).T.copy()
+    got = got.reshape(-1, 6)
+    free = ~fixed
+    assert np.abs(got[free] - want[free]).max() <= 1e-14 * np.abs(want).max()
+    dev.close()
+    host.close()
+    with pytest.raises(BackendError):
+        Q = gpu.DeviceSpace(mesh, 1)
+        K = gpu.DeviceMatrix(Q)
+        K.assemble(stiffness=1.0)
+        gpu.AMG(K, nullspace="rigid_body")

@@ -27,7 +27,7 @@ for dims in sizes:
     ns[5, :, 2], ns[5, :, 1] = xyz[:, 1], -xyz[:, 2]
     variants = [dict()] * 2 if len(sys.argv) < 3 else [dict(strength_threshold=t) for t in (-1, 0.01, 0.02, 0.05, 0.1)]
     for kw in variants:
-        t0 = time.perf_counter(); amg = B.AMG(A, nullspace=ns.reshape(6, -1), **kw); B.synchronize(); t1 = time.perf_counter()
+        t0 = time.perf_counter(); amg = B.AMG(A, nullspace='rigid_body' if os.environ.get('AMG_DEVICE_NS', '1') == '1' else ns.reshape(6, -1), **kw); B.synchronize(); t1 = time.perf_counter()
         st = amg.solve(b, x, rtol=1e-8); t2 = time.perf_counter()
         info = amg.info()
         lv = [(amg.level_info(l)['n_nodes'], amg.level_info(l)['block_size'], amg.level_info(l)['nnz_blocks']) for l in range(info['levels'])]
