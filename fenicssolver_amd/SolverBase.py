@@ -347,12 +347,28 @@ class SolverBase():
             # several GPUs: every rank builds the hierarchy of its own diagonal block (additive Schwarz, no overlap)
             if near_nullspace is not None and not isinstance(near_nullspace, str) and loc is not None:
                 near_nullspace = np.stack([loc.nodes(v)[:V.n_owned] for v in np.asarray(near_nullspace)])
-            hierarchy = backend.AMG(A, nullspace=near_nullspace,
-                                    strength_threshold=float(sp_.get('amg_strength_threshold', 0.0)))
+            # The hierarchy depends on the operator only: time steps / load cases that re-assemble the SAME matrix (quasi-static
+            # elasticity with time-dependent loads, LinearElasticitySolver.py:216-220 with solving_dynamics False) reuse it -
+            # at configs[2] the set-up (0.15 s) costs more than the solve (0.12 s).  The key holds everything the matrix
+            # values depend on; the cached hierarchy keeps its own (identical) fine matrix alive.
+            key = getattr(self, '_operator_key', None)
+            cached = getattr(self, '_amg_cache', None)
+            if key is not None and cached is not None and cached[0] == key:
+                hierarchy, reused = cached[1], True
+            else:
+                if cached is not None:
+                    cached[1].close()
+                    self._amg_cache = None
+                hierarchy, reused = backend.AMG(A, nullspace=near_nullspace,
+                                                strength_threshold=float(sp_.get('amg_strength_threshold', 0.0))), False
+                if key is not None:
+                    self._amg_cache = (key, hierarchy)
             stats = hierarchy.solve(b, x, rtol=rtol, max_iter=min(max_iter, int(sp_.get('maximum_iterations', 500))),
                                     norm=norm)
             stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
-            hierarchy.close()
+            stats['amg_reused'] = reused
+            if key is None:
+                hierarchy.close()
         else:
             stats = backend.krylov_solve(A, b, x, rtol=rtol, max_iter=max_iter, precond=pc, method=method, norm=norm)
         self.last_solve_stats = stats
@@ -843,10 +859,19 @@ class SolverBase():
             # empty right-hand side: the reference fails in assemble_system here (Appendix B-Q11)
             self.logger.warning('solve_amg: zero load and homogeneous BCs, the solution is zero')
         A, b = self.assemble_system(F, bcs, symmetric=True)
+        self._operator_key = self._amg_operator_key(F, bcs)
         # near-null space of the elasticity operator: the six rigid-body modes, built on the device from the node
         # coordinates (build_nullspace() below is the host version the reference's API exposes)
         ns = "rigid_body" if isinstance(F, forms.ElasticityForm) and self.dimension == 3 else None
         return self._device_solve(A, b, u, 'solve_amg', amg=True, near_nullspace=ns)
+
+    def _amg_operator_key(self, F, bcs):
+        """Everything the assembled matrix depends on, or None when that cannot be told cheaply (no hierarchy reuse)."""
+        import zlib
+        if not isinstance(F, forms.ElasticityForm):
+            return None
+        dofs = np.concatenate([np.asarray(bc.dofs, dtype=np.int64) for bc in bcs]) if bcs else np.zeros(0, dtype=np.int64)
+        return ('elasticity', id(F.space.root()), float(F.mu), float(F.lmbda), len(dofs), zlib.crc32(np.ascontiguousarray(dofs).tobytes()))
 
     def build_nullspace(self, V, x=None):
         """The rigid-body modes of SolverBase.py:674-706 (3 in 2D, 6 in 3D), orthonormalised."""

@@ -270,3 +270,39 @@ def test_device_rigid_body_modes_equal_the_host_built_near_null_space(gpu):
         K = gpu.DeviceMatrix(Q)
         K.assemble(stiffness=1.0)
         gpu.AMG(K, nullspace="rigid_body")
+
+
+def test_hierarchy_is_reused_across_quasi_static_time_steps(gpu):
+    """Transient elasticity with solving_dynamics False re-solves the static problem with time-dependent loads
+    (LinearElasticitySolver.py:216-220, examples/test_linear_elasticity.py:118-121): same operator every step, so the AMG
+    hierarchy of the first step serves the others; a changed Dirichlet set rebuilds it."""
+    import copy
+    import math
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 30, 3, 3)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+    bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
+                      'value': lambda t: Constant((1e8 * math.sin(100 * math.pi * 2 * t), 0, 0))}
+    s = copy.deepcopy(SB.default_case_settings)
+    s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800}
+    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    s['boundary_conditions'] = bcs
+    s['solver_settings']['transient_settings'] = {'transient': True, 'starting_time': 0.0, 'time_step': 0.001, 'ending_time': 0.0035}
+    s['report_settings'] = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = LinearElasticitySolver(s)
+    seen = []
+    orig = solver._device_solve
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        seen.append((solver.last_solve_stats['amg_reused'], solver.last_solve_stats['iterations'], float(np.abs(out.vector().array()).max())))
+        return out
+    solver._device_solve = spy
+    solver.solve()
+    assert [r for r, _, _ in seen] == [False, True, True, True]
+    assert all(it <= 60 for _, it, _ in seen) and seen[1][2] > 0          # step 1 (t = 0): zero load; later steps move
+    assert len({round(v, 12) for _, _, v in seen[1:]}) == 3               # the load really changes from step to step
