@@ -101,7 +101,10 @@ class Problem:
 
 def kernel_name(V):
     nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
-    return "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
+    one = "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
+    if V.n_slices > 32768 and V.degree == 1:       # spmv_use_pairs(): paired DIA slices, two rows per lane
+        return "k_dia_pair_spmv<3,%s> + %s on the unpaired slices (one launch each per product)" % ("true" if nt else "false", one)
+    return one
 
 
 def kernel_rates(st, V):
@@ -136,14 +139,16 @@ def committed_traffic(tag):
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["algorithmic_GBps"] / HBM_PEAK_GBS
     r = {"kernel": k["kernel"] + " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template "
-                                 "arguments: block size, dot mode, entries per round, non-temporal matrix loads)",
+                                 "arguments of k_sell_spmv: block size, dot mode, entries per round, non-temporal matrix loads; of "
+                                 "k_dia_pair_spmv: dot mode, non-temporal matrix loads)",
          "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 3),
          "traffic": traffic,
          "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; NOT measured in this run)" % traffic_source)
                            if traffic is not None else None,
          "workload": workload,
          "note": "achieved = algorithmic CSR bytes (nnz*12 + n*20, SURVEY 8d) / avg_launch_ms; avg_launch_ms = mean of the LIVE "
-                 "launches sampled with HIP events (every 16th iteration of the timed solve) on the library's stream; "
+                 "products sampled with HIP events (every 16th iteration of the timed solve; a product = the launches the kernel "
+                 "field names) on the library's stream; "
                  "streamed_GBps = the bytes the hybrid storage really moves (DIA slices carry no column indices) / the same time"}
     r.update({kk: k[kk] for kk in ("avg_launch_ms", "algorithmic_bytes_per_launch", "streamed_bytes_per_launch", "streamed_GBps",
                                    "dia_slices", "slices")})

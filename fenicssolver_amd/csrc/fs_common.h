@@ -182,6 +182,11 @@ struct fs_space_s {
     dbuf<int32_t> slice_order;    // [n_slices]
     dbuf<int32_t> dia_ptr;        // [n_slices]
     dbuf<int32_t> dia_off;        // [sum of offsets over DIA slices]
+    // two-rows-per-lane product (k_dia_pair_spmv): pairs of slices, consecutive in processing order, both complete DIA
+    // slices with identical offset lists; pair_singles = every other slice, in processing order.  Built on first use.
+    dbuf<int32_t> pair_list;      // [2 * n_pairs]
+    dbuf<int32_t> pair_singles;   // [n_pair_singles]
+    int64_t n_pairs = -1, n_pair_singles = 0;      // -1: not built yet
     dbuf<int32_t> slots;          // [16][nc] SELL entry index of (a,b) of each cell, -1 = not owned (vector spaces)
     // two-pass assembly of block spaces with many dofs per cell (Taylor-Hood): element matrices are written to
     // elem_buf [cell*nd*nd + ab][bs*bs] and summed per stored block through the inverse of the slot table

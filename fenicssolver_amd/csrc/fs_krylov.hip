@@ -199,6 +199,120 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
     }
 }
 
+// ---- DIA slices, two rows per lane ------------------------------------------------------------------------------------
+// PMC on the one-row-per-lane kernel at 10 M DOF (round 2: TA busy 70 %, 31 % of the wave cycles issue stalls, time
+// proportional to the L1 accesses and insensitive to the HBM byte count) says the per-CU address / L1 path is the limit,
+// not HBM.  This kernel halves the vector-memory instructions per row: a wave takes TWO slices with the same offset list
+// (lanes 0-31 the first, 32-63 the second), every lane two consecutive rows, so the value planes are read as 16-byte
+// lane loads, and inside a run of consecutive offsets (..., o, o+1, ...) the x value a lane needs for its second row at
+// offset o is the one it needs for its first row at offset o+1: one new 8-byte load per further offset of a run.
+// P1 Kuhn mesh (15 offsets in 7 runs): 15 + 22 + 2 loads per two rows instead of 64.
+// Pairs are formed on the host (fs_space_s::pair_list: consecutive slices in processing order, both DIA, both complete,
+// identical offset lists); everything else goes through k_sell_spmv as before.  Same per-row summation order.
+template <int DOTS, bool NT>
+__global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int64_t n_pairs, const int32_t* __restrict__ pairs,
+                                                            const int64_t* __restrict__ slice_ptr,
+                                                            const int32_t* __restrict__ dia_ptr,
+                                                            const int32_t* __restrict__ dia_off,
+                                                            const double* __restrict__ val,
+                                                            const double* __restrict__ x, double* __restrict__ y,
+                                                            const double* __restrict__ rvec,
+                                                            double* __restrict__ partials,
+                                                            const int* __restrict__ status, int part_base, int part_stride) {
+    if (DOTS) {
+        if (status[0] != 0) return;
+    }
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    __shared__ double lds4[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l2 = (lane & 31) * 2;
+    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
+    const int64_t n_chunks = (n_pairs + 3) >> 2;
+    const int32_t cmax = (int32_t)(n_cols - 1);
+    constexpr int U = 16;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t q = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
+        if (q >= n_pairs) continue;
+        const int32_t sa = __builtin_amdgcn_readfirstlane(pairs[2 * q]), sb = __builtin_amdgcn_readfirstlane(pairs[2 * q + 1]);
+        const int64_t s = half ? sb : sa;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[sa + 1] - slice_ptr[sa]) >> 6);       // same for both slices of a pair
+        const int32_t* __restrict__ op = dia_off + dia_ptr[sa];                   // the shared offset list
+        const int32_t r = (int32_t)(s * FS_SLICE + l2);
+        const double* __restrict__ vp = val + base + l2;
+        v2d zi = {0.0, 0.0}, ri = {0.0, 0.0};
+        if (DOTS) {
+            if (DOTS == 1 || DOTS == 3) zi = *reinterpret_cast<const v2d*>(&x[r]);
+            ri = *reinterpret_cast<const v2d*>(&rvec[r]);
+        }
+        double a0 = 0.0, a1 = 0.0, prev_hi = 0.0;
+        int32_t prev_o = INT32_MIN;
+        for (int k0 = 0; k0 < width; k0 += U) {
+            v2d t[U];
+            double lo[U], hi[U];
+            bool cont[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < width) t[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(&vp[(int64_t)(k0 + u) * FS_SLICE]))
+                                              : *reinterpret_cast<const v2d*>(&vp[(int64_t)(k0 + u) * FS_SLICE]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < width) {
+                    const int32_t o = op[k0 + u];
+                    cont[u] = o == (u == 0 ? prev_o : op[k0 + u - 1]) + 1;     // wave-uniform
+                    int32_t c1 = r + o + 1;
+                    c1 = c1 < 0 ? 0 : (c1 > cmax ? cmax : c1);
+                    hi[u] = x[c1];
+                    if (!cont[u]) {
+                        int32_t c0 = r + o;
+                        c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
+                        lo[u] = x[c0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < width) {
+                    const double l = cont[u] ? (u == 0 ? prev_hi : hi[u - 1]) : lo[u];
+                    a0 += t[u].x * l;
+                    a1 += t[u].y * hi[u];
+                }
+            }
+            const int last = (width - k0 < U ? width - k0 : U) - 1;
+            prev_o = op[k0 + last];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u == last) prev_hi = hi[u];
+        }
+        v2d out;
+        out.x = a0; out.y = a1;
+        *reinterpret_cast<v2d*>(&y[r]) = out;
+        if (DOTS == 1) {
+            d_rz += ri.x * zi.x + ri.y * zi.y;
+            d_wz += a0 * zi.x + a1 * zi.y;
+            d_rr += ri.x * ri.x + ri.y * ri.y;
+        } else if (DOTS == 2) {
+            d_rz += a0 * ri.x + a1 * ri.y;
+            d_wz += a0 * a0 + a1 * a1;
+            d_rr += ri.x * ri.x + ri.y * ri.y;
+        } else if (DOTS == 3) {
+            d_rz += zi.x * zi.x + zi.y * zi.y;
+            d_wz += a0 * zi.x + a1 * zi.y;
+            d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
+        }
+    }
+    if (DOTS) {
+        const double t0 = fs_block_sum(d_rz, lds4);
+        const double t1 = fs_block_sum(d_wz, lds4);
+        const double t2 = fs_block_sum(d_rr, lds4);
+        if (threadIdx.x == 0) {
+            partials[part_base + blockIdx.x] = t0;
+            partials[part_stride + part_base + blockIdx.x] = t1;
+            partials[2 * part_stride + part_base + blockIdx.x] = t2;
+        }
+    }
+}
+
 // ---- CG scalar state on the device ---------------------------------------------------------
 // sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
 // ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b
@@ -738,6 +852,65 @@ static int spmv_grid(int64_t n_slices, int64_t n_slices_matrix) {
     return (int)g;
 }
 
+// Pair / single split of the slices of a scalar space for k_dia_pair_spmv (host pass over four small arrays, once).
+static int build_pair_lists(fs_space_s* sp, hipStream_t s) {
+    const int64_t ns = sp->n_slices;
+    std::vector<int32_t> dp((size_t)ns), off((size_t)std::max<int64_t>(sp->dia_off.n, 1)), order;
+    std::vector<int64_t> ptr((size_t)ns + 1);
+    FS_CHECK(sp->dia_ptr.download(dp.data(), ns, s));
+    FS_CHECK(sp->dia_off.download(off.data(), sp->dia_off.n, s));
+    FS_CHECK(sp->slice_ptr.download(ptr.data(), ns + 1, s));
+    if (sp->slice_order.p) {
+        order.resize((size_t)ns);
+        FS_CHECK(sp->slice_order.download(order.data(), ns, s));
+    }
+    auto slice_at = [&](int64_t q) { return order.empty() ? (int32_t)q : order[(size_t)q]; };
+    auto width = [&](int32_t sl) { return (int)((ptr[(size_t)sl + 1] - ptr[(size_t)sl]) >> 6); };
+    auto pairable = [&](int32_t a, int32_t b) {
+        if (dp[(size_t)a] < 0 || dp[(size_t)b] < 0) return false;
+        if ((int64_t)(a + 1) * FS_SLICE > sp->n_nodes_owned || (int64_t)(b + 1) * FS_SLICE > sp->n_nodes_owned) return false;
+        const int w = width(a);
+        if (w != width(b) || w == 0) return false;
+        for (int k = 0; k < w; ++k)
+            if (off[(size_t)dp[(size_t)a] + k] != off[(size_t)dp[(size_t)b] + k]) return false;
+        return true;
+    };
+    std::vector<int32_t> pairs, singles;
+    for (int64_t q = 0; q < ns;) {
+        if (q + 1 < ns && pairable(slice_at(q), slice_at(q + 1))) {
+            pairs.push_back(slice_at(q));
+            pairs.push_back(slice_at(q + 1));
+            q += 2;
+        } else {
+            singles.push_back(slice_at(q));
+            q += 1;
+        }
+    }
+    sp->n_pairs = (int64_t)pairs.size() / 2;
+    sp->n_pair_singles = (int64_t)singles.size();
+    if (getenv("FS_SPACE_DEBUG")) fprintf(stderr, "[fs_space] two-rows-per-lane product: %lld pairs, %lld single slices\n", (long long)sp->n_pairs, (long long)sp->n_pair_singles);
+    FS_CHECK(sp->pair_list.alloc(std::max<int64_t>((int64_t)pairs.size(), 1)));
+    FS_CHECK(sp->pair_singles.alloc(std::max<int64_t>(sp->n_pair_singles, 1)));
+    FS_CHECK(sp->pair_list.upload(pairs.data(), (int64_t)pairs.size(), s));
+    FS_CHECK(sp->pair_singles.upload(singles.data(), sp->n_pair_singles, s));
+    return FS_OK;
+}
+// The pair kernel pays a second (small) launch for the unpaired slices: used where launches are long (matrix larger than
+// the caches).  FS_SPMV_PAIRS = 0 / 1 pins the choice.
+static bool spmv_use_pairs(const fs_space_s* sp, int bs) {
+    if (bs != 1) return false;
+    static const char* e = getenv("FS_SPMV_PAIRS");
+    if (e) return e[0] == '1';
+    return sp->n_slices > 32768;
+}
+static int spmv_pair_grid(const fs_space_s* sp) {
+    const int64_t n_chunks = (sp->n_pairs + 3) / 4;
+    static const int env_blocks = getenv("FS_PAIR_BLOCKS") ? atoi(getenv("FS_PAIR_BLOCKS")) : 0;
+    int64_t g = std::min<int64_t>(n_chunks, env_blocks > 0 ? env_blocks : spmv_blocks_for(sp->n_slices));
+    g = (g + 7) & ~(int64_t)7;
+    return (int)std::max<int64_t>(g, 8);
+}
+
 // `list` / `n_list`: multiply only these slices (the interior or the boundary slices of a decomposed space, in
 // processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
@@ -752,6 +925,19 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int grid = spmv_grid(ns, sp->n_slices);
     if (part_stride == 0) part_stride = grid;
 #define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride
+    if (A->bs == 1 && !list && sp->n_pairs > 0 && spmv_use_pairs(sp, 1)) {
+        // two launches: the paired slices (two rows per lane), then the rest through the one-row-per-lane kernel
+        const bool nt = spmv_nontemporal(sp, 1);
+        const int gp = spmv_pair_grid(sp);
+        const int gs = sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0;
+        const int stride = gp + gs;
+#define FS_PAIR_ARGS dim3(gp), dim3(FS_BLOCK), 0, s, sp->n_nodes_local, sp->n_pairs, sp->pair_list.p, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, x, y, rvec, partials, status, 0, stride
+        if (nt) hipLaunchKernelGGL((k_dia_pair_spmv<DOTS, true>), FS_PAIR_ARGS);
+        else hipLaunchKernelGGL((k_dia_pair_spmv<DOTS, false>), FS_PAIR_ARGS);
+#undef FS_PAIR_ARGS
+        if (gs) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, sp->pair_singles.p, sp->n_pair_singles, gp, stride);
+        return;
+    }
     if (A->bs == 1) {
         const bool nt = spmv_nontemporal(sp, 1);
         switch (spmv_unroll_for(sp->n_slices)) {
@@ -784,7 +970,9 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 
 // Number of per-workgroup dot partials one (possibly split) product writes.
 static bool spmv_is_split(const fs_space_s* sp) { return sp->halo.active && sp->halo.n_interior > 0; }
-static int spmv_partials(const fs_space_s* sp) {
+static int spmv_partials(const fs_space_s* sp, int bs = 0) {
+    if (!spmv_is_split(sp) && bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
+        return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
     if (!spmv_is_split(sp)) return spmv_grid(sp->n_slices, sp->n_slices);
     return spmv_grid(sp->halo.n_interior, sp->n_slices) + (sp->halo.n_boundary ? spmv_grid(sp->halo.n_boundary, sp->n_slices) : 0);
 }
@@ -920,6 +1108,7 @@ extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     FS_REQUIRE(x->d.n >= sp->n_dofs_local, "fs_spmv: x has %lld entries, needs %lld (owned + ghost)", (long long)x->d.n, (long long)sp->n_dofs_local);
     FS_REQUIRE(y->d.n >= sp->n_dofs_owned, "fs_spmv: y too short");
     hipStream_t s = fs_rt().stream;
+    if (A->bs == 1 && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
     FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
     launch_spmv<0>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
     FS_KERNEL_CHECK();
@@ -935,6 +1124,7 @@ extern "C" int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, in
     fs_space_s* sp = A->space;
     FS_REQUIRE(x->d.n >= sp->n_dofs_local && y->d.n >= sp->n_dofs_owned, "fs_spmv_benchmark: vector too short");
     hipStream_t s = fs_rt().stream;
+    if (A->bs == 1 && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
     hipEvent_t e0, e1;
     FS_HIP(hipEventCreate(&e0));
     FS_HIP(hipEventCreate(&e1));
@@ -1054,7 +1244,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
     const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
-    const int sgrid = spmv_partials(sp);     // dot partials per product (interior + boundary launch on a decomposed space)
+    if (A->bs == 1 && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
+    const int sgrid = spmv_partials(sp, A->bs);     // dot partials per product (pairs + singles, or interior + boundary on a decomposed space)
     const auto t_begin = std::chrono::steady_clock::now();
 
     // Jacobi diagonal (the zero-diagonal counter is read back with the first status poll: no extra sync here)

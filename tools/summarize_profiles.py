@@ -24,7 +24,7 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 # and the multi-10-MB databases are deleted before gpurun copies the directory back.
 OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 PHASES = ("n99_1M_dof", "n215_10M_dof")
-HOT = ("k_sell_spmv", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
+HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
 
 def short(name):
@@ -141,6 +141,16 @@ def main():
             key = find(dots)
             if key is not None:
                 out[tag + ("" if dots == "3" else "_dots1")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+            # HBM-resident sizes: the product is k_dia_pair_spmv (paired DIA slices, two rows per lane) + k_sell_spmv on the
+            # few unpaired slices - one product = one launch of each
+            for nt in ("true", "false"):
+                pk = (ph, "k_dia_pair_spmv<%s, %s>" % (dots, nt))
+                if pk in fetch:
+                    total = (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
+                    if key is not None:
+                        total += (2 * fetch[key] + write.get(key, 0.0)) * 1024
+                    out[tag + ("" if dots == "3" else "_dots1")] = int(total)
+                    out[tag + ("" if dots == "3" else "_dots1") + "_kernels"] = [pk[1]] + ([key[1]] if key is not None else [])
         if tag not in out and tag + "_dots1" in out:
             out[tag] = out[tag + "_dots1"]
         key = find("0")
