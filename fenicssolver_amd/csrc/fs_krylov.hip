@@ -875,16 +875,21 @@ static int build_pair_lists(fs_space_s* sp, hipStream_t s) {
             if (off[(size_t)dp[(size_t)a] + k] != off[(size_t)dp[(size_t)b] + k]) return false;
         return true;
     };
+    // units are formed in the NATURAL numbering (rows of consecutive slices continue each other: same edge class on CG2
+    // spaces, same mesh line on CG1) and then sorted into the processing order of the space by their first slice
+    std::vector<int32_t> rank((size_t)ns);
+    for (int64_t q = 0; q < ns; ++q) rank[(size_t)slice_at(q)] = (int32_t)q;
+    struct unit { int32_t key, a, b; };
+    std::vector<unit> units;
+    for (int32_t sl = 0; sl < ns;) {
+        if (sl + 1 < ns && pairable(sl, sl + 1)) { units.push_back({rank[(size_t)sl], sl, sl + 1}); sl += 2; }
+        else { units.push_back({rank[(size_t)sl], sl, -1}); sl += 1; }
+    }
+    std::sort(units.begin(), units.end(), [](const unit& u, const unit& v) { return u.key < v.key; });
     std::vector<int32_t> pairs, singles;
-    for (int64_t q = 0; q < ns;) {
-        if (q + 1 < ns && pairable(slice_at(q), slice_at(q + 1))) {
-            pairs.push_back(slice_at(q));
-            pairs.push_back(slice_at(q + 1));
-            q += 2;
-        } else {
-            singles.push_back(slice_at(q));
-            q += 1;
-        }
+    for (const unit& u : units) {
+        if (u.b >= 0) { pairs.push_back(u.a); pairs.push_back(u.b); }
+        else singles.push_back(u.a);
     }
     sp->n_pairs = (int64_t)pairs.size() / 2;
     sp->n_pair_singles = (int64_t)singles.size();

@@ -83,3 +83,25 @@ def test_amg_pcg_under_two_ranks_is_an_additive_schwarz_solve(gpu, tmp_path):
     r = _run(2, "elasticity", tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
     assert int(r["iterations"]) < 200
+
+
+def test_bench_under_the_drivers_launcher(gpu, tmp_path):
+    """bench.py exactly as the driver starts it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N): env rendezvous of the RCCL id through fenicssolver_amd/rendezvous.py (no torch import in bench.py), barrier
+    and max-over-ranks over the communicator, one JSON line from rank 0.  One GPU here: tests/shim/on_device0.py pins every
+    rank to device 0 and libfakerccl.so stands in for RCCL."""
+    import json
+    shim = os.path.join(ROOT, "tests", "shim", "libfakerccl.so")
+    PORT[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "shim", "on_device0.py"), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "23"]
+    p = subprocess.run(cmd, env=dict(os.environ, FS_RCCL_PATH=shim), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "DOF/s"
+    assert d["config"]["n_dof"] == 24 * 24 * 48 and d["config"]["true_rel_residual"] <= 1.1e-8
+    assert "roofline" in d and d["value"] > 0
+    assert "torch" not in open(os.path.join(ROOT, "bench.py")).read().replace("torch.distributed.run", "")

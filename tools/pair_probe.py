@@ -27,8 +27,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                       "xsum": float(xs.sum()), "x_mid": float(xs[len(xs) // 2])}), flush=True)
 else:
     for n, deg in ((215, 1), (107, 2)):
-        subprocess.run([sys.executable, __file__, "child", str(n), str(deg)], env=dict(os.environ, FS_SPMV_PAIRS="0"))
-        for blocks in ("256", "512", "1024", "2048"):
-            for nt in ("0", "1"):
-                print("blocks", blocks, "nt", nt, flush=True)
-                subprocess.run([sys.executable, __file__, "child", str(n), str(deg)], env=dict(os.environ, FS_SPMV_PAIRS="1", FS_PAIR_BLOCKS=blocks, FS_SPMV_NT=nt, FS_SPACE_DEBUG="1"))
+        for pairs in ("0", "1"):
+            subprocess.run([sys.executable, __file__, "child", str(n), str(deg)], env=dict(os.environ, FS_SPMV_PAIRS=pairs, FS_SPACE_DEBUG="1"))
