@@ -154,8 +154,13 @@ def main():
         if tag not in out and tag + "_dots1" in out:
             out[tag] = out[tag + "_dots1"]
         key = find("0")
-        if key is not None:
-            out[tag.replace("fused", "bare")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+        bare = 0.0 if key is None else (2 * fetch[key] + write.get(key, 0.0)) * 1024
+        for nt in ("true", "false"):
+            pk = (ph, "k_dia_pair_spmv<0, %s>" % nt)
+            if pk in fetch:
+                bare += (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
+        if bare > 0.0:
+            out[tag.replace("fused", "bare")] = int(bare)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
