@@ -140,6 +140,18 @@ class LinearElasticitySolver(SolverBase):
         n[flip] *= -1.0
         return tri, n / area[:, None], area
 
+    def _total_area(self, tri, area):
+        """assemble(Constant(1)*ds(id)): on a distributed mesh every facet is counted once - by the rank owning its vertex
+        of smallest global id - and the ranks' sums are added."""
+        mesh = self.mesh
+        if not (hasattr(mesh, 'is_distributed') and mesh.is_distributed()):
+            return float(area.sum())
+        from . import backend
+        gid = mesh.global_vertex_ids()[tri]
+        first = np.take_along_axis(tri, np.argmin(gid, axis=1)[:, None], axis=1)[:, 0]
+        mine = first < mesh.num_owned_vertices()
+        return float(backend.comm_allreduce_sum([float(area[mine].sum())])[0])
+
     def _vector_of(self, value, what):
         if isinstance(value, Constant):
             v = value.values()
@@ -185,7 +197,7 @@ class LinearElasticitySolver(SolverBase):
                     # n * (F / area), a vector-vector product UFL rejects; the evident intent - the total
                     # force vector spread over the face - is what is applied here: traction = F / area
                     tri, nrm, area = self._facet_normals(i)
-                    bc_area = float(area.sum())
+                    bc_area = self._total_area(tri, area)
                     self.logger.info('boundary area (m2) for force boundary is %g', bc_area)
                     integrals_N.append(forms.FacetLoad(i, val.values() / bc_area, 'force(vector / area)'))
                 else:
@@ -193,7 +205,7 @@ class LinearElasticitySolver(SolverBase):
                     if not is_constant_value(bc_force):
                         raise SolverError("boundary '{}': force magnitude must be a constant".format(name))
                     tri, nrm, area = self._facet_normals(i)
-                    bc_area = float(area.sum())     # assemble(Constant(1)*ds(id)) (:171)
+                    bc_area = self._total_area(tri, area)     # assemble(Constant(1)*ds(id)) (:171)
                     self.logger.info('boundary area (m2) for force boundary is %g', bc_area)
                     gmag = float(bc_force) / bc_area
                     if 'direction' in bc and bc['direction']:

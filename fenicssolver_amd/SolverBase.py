@@ -382,6 +382,13 @@ class SolverBase():
                 label, stats['iterations'], stats['true_rel_residual']))
         if loc is None:
             u.vector().set_local(x.get()[:V.n_owned])
+        elif getattr(loc, 'is_local_view', False):
+            # distributed mesh: the Function holds this rank's part, owned values and refreshed ghosts (what a DOLFIN
+            # Function holds under MPI); parallel.gather_function(u) builds the global array when wanted
+            from . import parallel
+            if parallel.world()[1] > 1:
+                backend.halo_exchange(V, x)
+            u.vector().set_local(x.get())
         else:   # every rank ends with the full field, gathered by global vertex id
             from . import parallel
             ncomp = u.function_space()._ncomp

@@ -91,14 +91,16 @@ class Mesh:
     """Tetrahedral (3-D) or triangular (2-D) mesh (dolfin.Mesh; SolverBase.py:203-258).  ``Mesh(path)`` reads
     DOLFIN XML.  Facets are the entities of dimension tdim - 1: triangles in 3-D, edges in 2-D."""
 
-    def __init__(self, filename=None, coords=None, cells=None):
+    def __init__(self, filename=None, coords=None, cells=None, _ordered=False):
         if filename is not None:
             coords, cells = self._read_xml(filename)
         if coords is None or cells is None:
             raise SolverError("Mesh needs a DOLFIN-XML file name or (coords, cells) arrays")
         self._coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
-        self._cells = np.sort(cells, axis=1)  # mesh.order()
+        # mesh.order(): vertices of a cell ascending by GLOBAL id (_ordered: the caller already did that - the local
+        # numbering of a distributed mesh is not monotone in the global one)
+        self._cells = cells if _ordered else np.sort(cells, axis=1)
         if (self._coords.shape[1], self._cells.shape[1]) not in ((3, 4), (2, 3)):
             raise SolverError("tetrahedral meshes in 3D and triangular meshes in 2D are supported by fenicssolver_amd "
                               "(got gdim=%d, %d vertices per cell)" % (self._coords.shape[1], self._cells.shape[1]))
@@ -247,34 +249,85 @@ class Mesh:
 class BoxMesh(Mesh):
     """dolfin.BoxMesh(Point, Point, nx, ny, nz) ordering (Appendix D-8;
     examples/test_linear_elasticity.py:42).  The host copy is built with numpy; the
-    device copy is generated by a kernel, not uploaded."""
+    device copy is generated by a kernel, not uploaded.
 
-    def __init__(self, p0, p1, nx, ny, nz):
+    ``distributed=True`` under several ranks (DOLFIN's BoxMesh is distributed under mpirun): every rank holds ONLY its
+    z-slab - the vertex planes it owns plus one ghost plane on either side and the cell layers touching owned planes -
+    numbered as libfsamd.so numbers a slab: owned planes first (x fastest), then the lower, then the upper ghost plane.
+    Nothing of global size is ever built on the host; global vertex ids are arithmetic (``global_vertex_ids()``).
+    Boundary markers, Dirichlet sets, coefficients and the result live on the local mesh (the part of the field a rank can
+    see, as with DOLFIN); ``parallel.gather_function(u)`` assembles the global nodal array when one is wanted.
+    Built for P1 spaces (scalar / vector); P2 and Taylor-Hood spaces use the default replicated mesh."""
+
+    def __init__(self, p0, p1, nx, ny, nz, distributed=False):
         a = p0.array() if isinstance(p0, Point) else np.asarray(p0, dtype=np.float64)
         b = p1.array() if isinstance(p1, Point) else np.asarray(p1, dtype=np.float64)
         nx, ny, nz = int(nx), int(ny), int(nz)
         self._box = (nx, ny, nz, tuple(a), tuple(b))
+        self._slab = None
+        planes = np.arange(nz + 1)
+        layers = np.arange(nz)
+        if distributed:
+            from . import parallel, partition
+            rank, size, _ = parallel.world()
+            if size > 1:
+                zb, ze = partition.slab_ranges(nz + 1, size)[rank]
+                if ze - zb < 1:
+                    raise SolverError("BoxMesh(distributed=True): rank {} would own no vertex plane ({} planes, {} ranks)".format(rank, nz + 1, size))
+                lay = partition.slab_layout(nx, ny, nz, (zb, ze), rank, size)
+                planes = np.asarray(lay["planes"])                          # owned planes, lower ghost, upper ghost
+                layers = np.arange(max(zb - 1, 0), min(ze, nz))              # cell layers touching an owned plane
+                self._slab = dict(lay, zplanes=(zb, ze), rank=rank, size=size, n_global=(nx + 1) * (ny + 1) * (nz + 1))
         x = a[0] + (np.arange(nx + 1, dtype=np.float64) * (b[0] - a[0])) / float(nx)
         y = a[1] + (np.arange(ny + 1, dtype=np.float64) * (b[1] - a[1])) / float(ny)
-        z = a[2] + (np.arange(nz + 1, dtype=np.float64) * (b[2] - a[2])) / float(nz)
+        z = a[2] + (planes.astype(np.float64) * (b[2] - a[2])) / float(nz)
         Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
         coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
-        iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-        v0 = (iz * (ny + 1) * (nx + 1) + iy * (nx + 1) + ix).ravel().astype(np.int64)
-        sx, sy, sz = 1, nx + 1, (nx + 1) * (ny + 1)
-        corner = [v0, v0 + sx, v0 + sy, v0 + sx + sy, v0 + sz, v0 + sx + sz, v0 + sy + sz, v0 + sx + sy + sz]
+        P = (nx + 1) * (ny + 1)
+        local_plane = np.full(nz + 1, -1, dtype=np.int64)                    # global z index -> local plane position
+        local_plane[planes] = np.arange(len(planes))
+        iz, iy, ix = np.meshgrid(layers, np.arange(ny), np.arange(nx), indexing="ij")
+        inplane = (iy * (nx + 1) + ix).ravel().astype(np.int64)
+        lo, hi = local_plane[iz.ravel()] * P + inplane, local_plane[iz.ravel() + 1] * P + inplane
+        sx, sy = 1, nx + 1
+        # corners in GLOBAL order v0..v7 (v4..v7 one plane up): a cell's vertices stay in ascending global order
+        corner = [lo, lo + sx, lo + sy, lo + sx + sy, hi, hi + sx, hi + sy, hi + sx + sy]
         tets = ((0, 1, 3, 7), (0, 1, 5, 7), (0, 4, 5, 7), (0, 2, 3, 7), (0, 4, 6, 7), (0, 2, 6, 7))
         cells = np.stack([np.stack([corner[i] for i in t], axis=1) for t in tets], axis=1).reshape(-1, 4)
-        Mesh.__init__(self, coords=coords, cells=cells)
+        Mesh.__init__(self, coords=coords, cells=cells, _ordered=self._slab is not None)
+
+    def is_distributed(self):
+        return self._slab is not None
+
+    def global_vertex_ids(self):
+        """Global id of every local vertex (the mesh's own numbering when it is not distributed)."""
+        return self._slab["l2g"] if self._slab is not None else np.arange(self.num_vertices(), dtype=np.int64)
+
+    def num_owned_vertices(self):
+        return self._slab["n_owned"] if self._slab is not None else self.num_vertices()
+
+    def exterior_facets(self):
+        """Facets of the DOMAIN boundary: on a distributed slab the cut faces through the ghost planes have one cell too,
+        but they are interior facets of the global mesh."""
+        ext = Mesh.exterior_facets(self)
+        if self._slab is None:
+            return ext
+        nx, ny, nz = self._box[:3]
+        P = (nx + 1) * (ny + 1)
+        gz = np.asarray(self._slab["planes"])[self.facets().astype(np.int64) // P]      # global z index of the facet's vertices
+        flat = (gz[:, 0] == gz[:, 1]) & (gz[:, 1] == gz[:, 2])
+        return ext & ~(flat & (gz[:, 0] != 0) & (gz[:, 0] != nz))
 
     def _make_device(self, backend):
         nx, ny, nz, a, b = self._box
+        if self._slab is not None:
+            return backend.DeviceMesh.box(nx, ny, nz, a, b, zplanes=self._slab["zplanes"])
         return backend.DeviceMesh.box(nx, ny, nz, a, b)
 
 
 class UnitCubeMesh(BoxMesh):
-    def __init__(self, nx, ny, nz):
-        BoxMesh.__init__(self, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), nx, ny, nz)
+    def __init__(self, nx, ny, nz, distributed=False):
+        BoxMesh.__init__(self, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), nx, ny, nz, distributed=distributed)
 
 
 class RectangleMesh(Mesh):
@@ -710,6 +763,20 @@ class FunctionSpace:
                               "vector P2 runs on one GPU")
         rank, size = parallel.ensure_comm()
         mesh = root._mesh
+        if getattr(mesh, "_slab", None) is not None:
+            # distributed box: the host mesh already IS this rank's part, numbered as the device numbers a slab
+            if root._degree != 1:
+                raise SolverError("BoxMesh(distributed=True) carries P1 spaces; P2 / Taylor-Hood use the replicated mesh (distributed=False)")
+            lay = mesh._slab
+            ds = backend.DeviceSpace(mesh.device(), root._ncomp, 1)
+            if ds.n_owned != lay["n_owned"] * root._ncomp or ds.n_local != lay["n_local"] * root._ncomp:
+                raise SolverError("internal error: host and device disagree on the slab layout")
+            nc_ = root._ncomp
+            sends = lay["send_lists"] if nc_ == 1 else [
+                (np.asarray(l, dtype=np.int64)[:, None] * nc_ + np.arange(nc_)[None, :]).reshape(-1).astype(np.int32) for l in lay["send_lists"]]
+            ds.set_halo(lay["neighbors"], sends, [c * nc_ for c in lay["recv_counts"]])
+            root._localizer = parallel.LocalView(lay["n_owned"], lay["n_local"], mesh.num_cells(), lay["l2g"], lay["n_global"], nc_)
+            return ds
         co, ce = mesh.coordinates(), mesh.cells()
         axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
         owner = partition.slab_owner(co, size, axis=axis)

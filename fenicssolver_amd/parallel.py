@@ -107,6 +107,56 @@ def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
     return out.reshape(-1)
 
 
+class _Part:
+    pass
+
+
+class LocalView:
+    """The Localizer of a DISTRIBUTED mesh (fem.BoxMesh(distributed=True)): host arrays are already this rank's - owned
+    entries first, ghosts after - so every map is the identity; what remains is to know which entries are owned."""
+    is_local_view = True
+
+    def __init__(self, n_owned, n_local, n_cells, l2g, n_global, ncomp):
+        self.n_owned, self.n_local, self.ncomp = int(n_owned), int(n_local), int(ncomp)
+        self.l2g, self.n_global = np.asarray(l2g, dtype=np.int64), int(n_global)
+        self.part = _Part()
+        self.part.n_owned = self.n_owned
+        self.part.cell_gids = np.arange(int(n_cells))        # "global" cell ids of the host mesh = its own (local) ids
+
+    def owned_gids(self):
+        return self.l2g[:self.n_owned]
+
+    def cells(self, arr):
+        return np.asarray(arr)
+
+    def nodes(self, arr):
+        return np.asarray(arr)
+
+    def dofs(self, dofs, vals):
+        return np.asarray(dofs, dtype=np.int32), np.asarray(vals, dtype=np.float64)
+
+    def facets(self, tri):
+        t = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+        mask = (t < self.n_owned).any(axis=1)                  # facets that touch a row of this rank
+        return t[mask].astype(np.int32), mask
+
+    def spec(self, spec):
+        return spec
+
+
+def gather_function(u):
+    """The global nodal array [n_global (, ncomp)] of a Function on a distributed mesh, on every rank (one all-gather);
+    on a replicated mesh the Function already is global."""
+    V = u.function_space()
+    loc = V.localizer()
+    vals = u.node_values()
+    if loc is None or not getattr(loc, "is_local_view", False):
+        return vals.copy()
+    n = V._ncomp
+    out = gather_owned(np.asarray(vals).reshape(-1, n)[:loc.n_owned].reshape(-1), loc.owned_gids(), loc.n_global, n)
+    return out if n == 1 else out.reshape(-1, n)
+
+
 class Localizer:
     """Maps global host arrays (per cell / per node / dof lists / facet lists) to one rank's part."""
 

@@ -41,10 +41,19 @@ if case == "box":
 else:
     # the solver API on several ranks (parallel.py)
     import test_gpu_parallel_api as T
-    solver = (T.CASES.get(case) or T.NS_CASES[case])()
+    solver = (T.CASES.get(case) or T.DIST_CASES.get(case) or T.NS_CASES[case])()
     u = solver.solve()
     assert solver.function_space.localizer() is not None and parallel.world()[1] == world
-    if rank == 0:
+    if case in T.DIST_CASES:
+        mesh = solver.mesh
+        assert mesh.is_distributed() and mesh.num_vertices() < (mesh._box[0] + 1) * (mesh._box[1] + 1) * (mesh._box[2] + 1)
+        # the host mesh of this rank is exactly what the device generated for its slab
+        xyz, cells, gid = mesh.device().get(True, True, True)
+        assert np.array_equal(xyz, mesh.coordinates()) and np.array_equal(cells, mesh.cells()) and np.array_equal(gid, mesh.global_vertex_ids())
+        full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
+        if rank == 0:
+            result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices())
+    elif rank == 0:
         result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"])
     parallel.barrier()
     parallel.finalize()

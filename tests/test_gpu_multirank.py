@@ -63,6 +63,18 @@ def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
 
 
+@pytest.mark.parametrize("case,world", [("heat_dist", 2), ("heat_dist", 3), ("heat_cn_dist", 2), ("elasticity_dist", 2), ("elasticity_dist", 3)])
+def test_distributed_box_mesh_no_global_host_mesh(gpu, tmp_path, case, world):
+    """BoxMesh(distributed=True): every rank builds only its slab on the host (vertex planes it owns + one ghost plane each
+    side), marks boundaries, evaluates coefficients and Dirichlet sets on it and keeps the local part of the result; the
+    global field gathered from the ranks equals the single-process solve on the full mesh."""
+    import test_gpu_parallel_api as T
+    single = T.DIST_CASES[case]().solve().vector().get_local()       # one process: the slab is the whole box
+    r = _run(world, case, tmp_path)
+    assert int(r["n_local"]) < len(single) // (3 if "elasticity" in case else 1)
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
+
+
 @pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2), ("radiation", 2)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,

@@ -25,10 +25,10 @@ def _heat_p2_case(n=4):
     return solver
 
 
-def _heat_case(n=5, transient=False, degree=1, supg=False):
+def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False):
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
-    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n)
+    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n, distributed=distributed)
     Q = FunctionSpace(m, "CG", degree)
     bcs = OrderedDict()
     bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
@@ -59,16 +59,23 @@ def _heat_case(n=5, transient=False, degree=1, supg=False):
     return solver
 
 
-def _elastic_case():
+def _elastic_case(distributed=False):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
-    mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 12, 2, 2)
     bcs = OrderedDict()
-    bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
-                    'value': Constant((0, 0, 0))}
-    bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
-                      'value': Constant((1e8, 0, 0))}
+    if distributed:     # slabs are cut along z: the beam lies along z
+        mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 10), 2, 2, 12, distributed=True)
+        bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
+                        'value': Constant((0, 0, 0))}
+        bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 10)), 'boundary_id': 2, 'type': 'stress',
+                          'value': Constant((0, 1e6, 1e8))}
+    else:
+        mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 12, 2, 2)
+        bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
+                        'value': Constant((0, 0, 0))}
+        bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
+                          'value': Constant((1e8, 0, 0))}
     s = copy.deepcopy(SB.default_case_settings)
     s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
                      'thermal_expansion_coefficient': 2e-6}
@@ -78,7 +85,7 @@ def _elastic_case():
     s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
     s['report_settings'] = dict(QUIET)
     s['body_source'] = Expression(("10*rho", "0", "0.0"), rho=7800, degree=2)
-    s['temperature_distribution'] = Expression("300+40*x[0]", degree=1)
+    s['temperature_distribution'] = Expression("300+40*x[2]" if distributed else "300+40*x[0]", degree=1)
     return LinearElasticitySolver(s)
 
 
@@ -159,6 +166,10 @@ def _radiation_case():
 
 # cases that do not go through _device_solve (Newton loops, the saddle-point path): no captured (A, b) test
 NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case}
+
+# BoxMesh(distributed=True): every rank builds only its z-slab on the host (one rank: the same mesh as the replicated one)
+DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist": lambda: _heat_case(transient=True, distributed=True),
+              "elasticity_dist": lambda: _elastic_case(distributed=True)}
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          "heat_supg": lambda: _heat_case(supg=True),
