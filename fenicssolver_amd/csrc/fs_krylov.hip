@@ -92,13 +92,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                                                         const double* __restrict__ x, double* __restrict__ y,
                                                         const double* __restrict__ rvec,
                                                         double* __restrict__ partials,
-                                                        const int* __restrict__ status,
+                                                        int* __restrict__ status,
                                                         const int32_t* __restrict__ order,
-                                                        int part_base, int part_stride) {
+                                                        int part_base, int part_stride, int bump) {
     // part_base / part_stride: where this launch's per-workgroup dot partials go (partials[j*stride + base + wg]);
     // a product split into an interior and a boundary launch fills one array of stride = both grids
     if (DOTS) {
         if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
+        // status[2] = number of in-loop products launched so far: the update kernel of a captured batch (hipGraph: same
+        // arguments every iteration) reads its iteration index from it.  Nobody else touches the word while we run.
+        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;
     }
     __shared__ double lds4[4];
     const int lane = threadIdx.x & 63;
@@ -218,9 +221,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
                                                             const double* __restrict__ x, double* __restrict__ y,
                                                             const double* __restrict__ rvec,
                                                             double* __restrict__ partials,
-                                                            const int* __restrict__ status, int part_base, int part_stride) {
+                                                            int* __restrict__ status, int part_base, int part_stride, int bump) {
     if (DOTS) {
         if (status[0] != 0) return;
+        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
     }
     typedef double v2d __attribute__((ext_vector_type(2)));
     __shared__ double lds4[4];
@@ -593,6 +597,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
                                                                const double* __restrict__ w, double* __restrict__ p,
                                                                double* __restrict__ sv, double* __restrict__ x) {
     if (status[0] != 0) return;
+    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
+        iter = status[2] - 1;
+        check_only = iter >= check_only ? 1 : 0;       // the argument carries max_iter in this mode
+    }
     double gamma, delta, rho;
     if (FUSED) {
         double sm[3];
@@ -796,6 +804,7 @@ static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
+static int g_cg_graph = -1;      // -1: by size (cache-resident problems, where the launch gaps are ~10 % of an iteration)
 static int g_update_blocks = 512;
 
 extern "C" int fs_set_option(const char* name, double value) {
@@ -813,6 +822,8 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_spmv_unroll4 = (int)value;
     } else if (!strcmp(name, "cg_fuse_sums")) {
         g_cg_fuse_sums = value != 0.0;
+    } else if (!strcmp(name, "cg_graph")) {
+        g_cg_graph = value < 0.0 ? -1 : (value != 0.0);
     } else if (!strcmp(name, "update_blocks")) {
         FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
         g_update_blocks = (int)value;
@@ -920,8 +931,8 @@ static int spmv_pair_grid(const fs_space_s* sp) {
 // processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
 static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
-                        const int* status, hipStream_t s, const double* val_override = nullptr,
-                        const int32_t* list = nullptr, int64_t n_list = 0, int part_base = 0, int part_stride = 0) {
+                        int* status, hipStream_t s, const double* val_override = nullptr,
+                        const int32_t* list = nullptr, int64_t n_list = 0, int part_base = 0, int part_stride = 0, int bump = 1) {
     const double* mat_val = val_override ? val_override : A->val.p;
     fs_space_s* sp = A->space;
     const int64_t ns = list ? n_list : sp->n_slices;
@@ -929,18 +940,18 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int32_t* order = list ? list : sp->slice_order.p;
     const int grid = spmv_grid(ns, sp->n_slices);
     if (part_stride == 0) part_stride = grid;
-#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride
+#define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride, bump
     if (A->bs == 1 && !list && sp->n_pairs > 0 && spmv_use_pairs(sp, 1)) {
         // two launches: the paired slices (two rows per lane), then the rest through the one-row-per-lane kernel
         const bool nt = spmv_nontemporal(sp, 1);
         const int gp = spmv_pair_grid(sp);
         const int gs = sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0;
         const int stride = gp + gs;
-#define FS_PAIR_ARGS dim3(gp), dim3(FS_BLOCK), 0, s, sp->n_nodes_local, sp->n_pairs, sp->pair_list.p, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, x, y, rvec, partials, status, 0, stride
+#define FS_PAIR_ARGS dim3(gp), dim3(FS_BLOCK), 0, s, sp->n_nodes_local, sp->n_pairs, sp->pair_list.p, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, x, y, rvec, partials, status, 0, stride, bump
         if (nt) hipLaunchKernelGGL((k_dia_pair_spmv<DOTS, true>), FS_PAIR_ARGS);
         else hipLaunchKernelGGL((k_dia_pair_spmv<DOTS, false>), FS_PAIR_ARGS);
 #undef FS_PAIR_ARGS
-        if (gs) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, sp->pair_singles.p, sp->n_pair_singles, gp, stride);
+        if (gs) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, sp->pair_singles.p, sp->n_pair_singles, gp, stride, 0);
         return;
     }
     if (A->bs == 1) {
@@ -987,7 +998,7 @@ static int spmv_partials(const fs_space_s* sp, int bs = 0) {
 //   compute stream waits for the halo                     | boundary slices
 // One GPU (no halo plan): the plain product.
 template <int DOTS>
-static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* rvec, double* partials, const int* status,
+static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* rvec, double* partials, int* status,
                            hipStream_t s, const double* val_override = nullptr) {
     fs_space_s* sp = A->space;
     if (!spmv_is_split(sp)) {
@@ -1000,7 +1011,7 @@ static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* r
     FS_CHECK(fs_halo_begin_dev(sp, x, s));
     launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.interior.p, h.n_interior, 0, total);
     FS_CHECK(fs_halo_end_dev(sp, s));
-    if (h.n_boundary) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.boundary.p, h.n_boundary, gi, total);
+    if (h.n_boundary) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.boundary.p, h.n_boundary, gi, total, 0);
     return FS_OK;
 }
 
@@ -1175,6 +1186,11 @@ struct krylov_ws {
     bool sample_live[NSAMPLE];  // false: the sampled launches came after convergence (no-ops)
     bool events = false;
     std::vector<double> last_hist;
+    // one batch of CG iterations captured as a hipGraph (same arguments every iteration: the update kernel reads its
+    // iteration index from the device).  Re-instantiated when anything it bakes in changes.
+    hipGraphExec_t cg_graph = nullptr;
+    const void* cg_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t cg_key_i[6] = {0, 0, 0, 0, 0, 0};
 };
 static krylov_ws g_ws;
 
@@ -1361,8 +1377,40 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         int k = 0, slot = 0, pending = -1;
         bool finished = false;
         const int first_sample = n_samples;
+        // Batches after the first (which carries the event samples) go out as ONE hipGraphLaunch of 2 x batch kernel nodes
+        // on cache-resident problems: the gaps between consecutive launches (2 x 2.1 us of a 44 us iteration at 1 M DOF)
+        // shrink to the graph's own node-to-node latency.
+        static const char* graph_env = getenv("FS_CG_GRAPH");
+        const int graph_mode = graph_env ? atoi(graph_env) : g_cg_graph;
+        const bool use_graph = ds && fuse_sums && !bicg && !sp->halo.active && bs == 1 &&
+                               (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
+            if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
+                const void* key[8] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p};
+                const int64_t key_i[6] = {n, max_iter, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1)};
+                if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
+                    if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
+                    hipGraph_t graph = nullptr;
+                    FS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    int rc_cap = FS_OK;
+                    for (int i = 0; i < batch && rc_cap == FS_OK; ++i) {
+                        rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
+                        // iteration index from the device (iter = -1), check_only carries max_iter
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, max_iter, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, max_iter, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                    }
+                    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+                    FS_CHECK(rc_cap);
+                    FS_HIP(e_end);
+                    FS_HIP(hipGraphInstantiate(&ws.cg_graph, graph, nullptr, nullptr, 0));
+                    (void)hipGraphDestroy(graph);
+                    memcpy(ws.cg_key, key, sizeof(key));
+                    memcpy(ws.cg_key_i, key_i, sizeof(key_i));
+                }
+                FS_HIP(hipGraphLaunch(ws.cg_graph, s));
+                k = kend;
+            }
             for (; k < kend; ++k) {
                 const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
                 if (sample) ws.sample_iter[n_samples] = k;
