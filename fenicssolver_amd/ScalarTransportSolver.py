@@ -27,7 +27,8 @@ from .SolverBase import SolverBase, SolverError
 from . import forms
 
 supported_scalars = {'temperature', 'electric_potential', 'species_concentration'}
-electric_permittivity_in_vacumm = 8.854187817e-12
+VACUUM_PERMITTIVITY = 8.854187817e-12
+electric_permittivity_in_vacumm = VACUUM_PERMITTIVITY      # the reference's (misspelt) module-level name, kept for importers
 
 
 class ScalarTransportSolver(SolverBase):
@@ -63,42 +64,45 @@ class ScalarTransportSolver(SolverBase):
             return c(T)
         return self.get_material_value(c)
 
-    def capacity(self, T=None):
-        if 'capacity' in self.material:
-            c = self.material['capacity']
-        elif self.scalar_name == "temperature":
-            c = self.material['density'] * self.material['specific_heat_capacity']
-        elif self.scalar_name == "electric_potential":
-            c = electric_permittivity_in_vacumm
-        elif self.scalar_name == "species_concentration":
-            c = 1
+    # Which material entry (or combination) a transport coefficient comes from, per scalar: an explicit generic key wins,
+    # then the scalar's own physical properties (ScalarTransportSolver.py:73-129).  Entries are functions of the material dict.
+    _COEFFICIENT_RULES = {
+        'capacity': {
+            'temperature': lambda m, self: m['density'] * m['specific_heat_capacity'],
+            'electric_potential': lambda m, self: VACUUM_PERMITTIVITY,
+            'species_concentration': lambda m, self: 1,
+        },
+        'diffusivity': {
+            'temperature': lambda m, self: m['thermal_conductivity'] / self.capacity(),
+            'electric_potential': lambda m, self: m['relative_electric_permittivity'],
+        },
+        'conductivity': {
+            'temperature': lambda m, self: m['thermal_conductivity'],
+            'electric_potential': lambda m, self: m['relative_electric_permittivity'] * VACUUM_PERMITTIVITY,
+            'species_concentration': lambda m, self: m['diffusivity'],
+        },
+    }
+
+    def _coefficient(self, kind, T):
+        m = self.material
+        if kind in m:
+            c = m[kind]
+        elif self.scalar_name in self._COEFFICIENT_RULES[kind]:
+            c = self._COEFFICIENT_RULES[kind][self.scalar_name](m, self)
+        elif kind == 'conductivity':
+            c = self.diffusivity() * self.capacity()
         else:
-            raise SolverError('material capacity property is not found for {}'.format(self.scalar_name))
+            raise SolverError('material {} property is not found for {}'.format(kind, self.scalar_name))
         return self._finish_material(c, T)
+
+    def capacity(self, T=None):
+        return self._coefficient('capacity', T)
 
     def diffusivity(self, T=None):
-        if 'diffusivity' in self.material:
-            c = self.material['diffusivity']
-        elif self.scalar_name == "temperature":
-            c = self.material['thermal_conductivity'] / self.capacity()
-        elif self.scalar_name == "electric_potential":
-            c = self.material['relative_electric_permittivity']
-        else:
-            raise SolverError('conductivity material property is not found for {}'.format(self.scalar_name))
-        return self._finish_material(c, T)
+        return self._coefficient('diffusivity', T)
 
     def conductivity(self, T=None):
-        if 'conductivity' in self.material:
-            c = self.material['conductivity']
-        elif self.scalar_name == "temperature":
-            c = self.material['thermal_conductivity']
-        elif self.scalar_name == "electric_potential":
-            c = self.material['relative_electric_permittivity'] * electric_permittivity_in_vacumm
-        elif self.scalar_name == "species_concentration":
-            c = self.material['diffusivity']
-        else:
-            c = self.diffusivity() * self.capacity()
-        return self._finish_material(c, T)
+        return self._coefficient('conductivity', T)
 
     # ------------------------------------------------------------------ coefficients
     def _volume_coefficient(self, value, what):
@@ -323,19 +327,15 @@ class ScalarTransportSolver(SolverBase):
         if bs_items:
             F.sources.extend(bs_items)
 
-        if self.scalar_name == "temperature":
-            if ('radiation_settings' in self.settings and self.settings['radiation_settings']):
-                self.radiation_settings = self.settings['radiation_settings']
-                self.has_radiation = True
-            elif hasattr(self, 'radiation_settings') and self.radiation_settings:
-                self.has_radiation = True
-            else:
-                self.has_radiation = False
-            if self.has_radiation:
-                if self.function_space.degree() != 1:
-                    raise SolverError('radiation is built for P1 spaces only')
-                self.nonlinear = True
-                F.radiation = self.radiation_coefficients()
+        # surface radiation to the ambient (heat only): settings key, or an attribute the user set after construction
+        rs = self.settings.get('radiation_settings') or getattr(self, 'radiation_settings', None)
+        self.has_radiation = self.scalar_name == "temperature" and bool(rs)
+        if self.has_radiation:
+            self.radiation_settings = rs
+            if self.function_space.degree() != 1:
+                raise SolverError('radiation is built for P1 spaces only')
+            self.nonlinear = True
+            F.radiation = self.radiation_coefficients()
         if self.nonlinear_material:
             self.nonlinear = True
         F.nonlinear = bool(self.nonlinear)
@@ -343,18 +343,13 @@ class ScalarTransportSolver(SolverBase):
 
     def radiation_coefficients(self):
         """(emissivity * Stefan-Boltzmann, ambient temperature) of  m (Ta^4 - T^4)  (:361-376)."""
-        Stefan_constant = 5.670367e-8
-        if 'emissivity' in self.material:
-            emissivity = self.material['emissivity']
-        elif 'emissivity' in self.radiation_settings:
-            emissivity = self.radiation_settings['emissivity']
-        else:
-            emissivity = 1.0
-        if 'ambient_temperature' in self.radiation_settings:
-            T_amb = self.radiation_settings['ambient_temperature']
-        else:
-            T_amb = self.reference_values['temperature']
-        return (float(emissivity) * Stefan_constant, float(T_amb))
+        sigma_sb = 5.670367e-8                                   # W / (m^2 K^4)
+        rs = self.radiation_settings
+        emissivity = self.material.get('emissivity', rs.get('emissivity', 1.0))          # the material wins over the settings
+        T_amb = rs.get('ambient_temperature', self.reference_values.get('temperature'))
+        if T_amb is None:
+            raise SolverError("radiation needs 'ambient_temperature' or a reference temperature")
+        return (float(emissivity) * sigma_sb, float(T_amb))
 
     def radiation_flux(self, T):
         """m (Ta^4 - T^4) evaluated on numbers / arrays / a Function's nodal values (:361-376)."""
