@@ -245,7 +245,7 @@ class CoupledNavierStokesSolver(SolverBase):
         P = W.pressure_space()
         dW, dP = W.device(), P.device()
         nv = self.mesh.num_vertices()
-        wd = backend.DeviceVector(dW.n_local, up.vector().array())
+        wd = backend.DeviceVector(dW.n_local, up.vector()._values())
         b9 = backend.DeviceVector(9 * dP.n_owned)
         backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9)
         rhs = b9.get().reshape(nv, 9)

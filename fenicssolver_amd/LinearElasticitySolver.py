@@ -85,7 +85,7 @@ class LinearElasticitySolver(SolverBase):
         P = FunctionSpace(self.mesh, 'P', 1)
         dV, dP = V.device(), P.device()
         mu, lmbda = self.lame_parameters()
-        ud = backend.DeviceVector(dV.n_local, u.vector().array())
+        ud = backend.DeviceVector(dV.n_local, u.vector()._values())
         b = backend.DeviceVector(dP.n_owned)
         backend.assemble_von_mises(dV, ud, mu, lmbda, dP, b)
         M = backend.DeviceMatrix(dP)
@@ -107,7 +107,7 @@ class LinearElasticitySolver(SolverBase):
     def thermal_stress(self, T):
         """The isotropic thermal stress  E/(1-2nu) * alpha * (T - T_ref)  (the multiplier of Identity(dim),
         LinearElasticitySolver.py:78-85) for a number, an array of nodal temperatures or a Function."""
-        vals = T.vector().array() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
+        vals = T.vector()._values() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
         return self.thermal_stress_coefficient() * (vals - float(self.reference_values['temperature']))
 
     def strain_energy(self, u):
@@ -302,7 +302,7 @@ class LinearElasticitySolver(SolverBase):
     def velocity(self):
         dt = self.get_time_step(self.current_step)
         out = Function(self.function_space)
-        out.vector().set_local((self.w_current.vector().array() - self.w_prev.vector().array()) / dt)
+        out.vector().set_local((self.w_current.vector()._values() - self.w_prev.vector()._values()) / dt)
         return out
 
     def solve_modal(self):

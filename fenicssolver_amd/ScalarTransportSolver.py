@@ -354,7 +354,7 @@ class ScalarTransportSolver(SolverBase):
     def radiation_flux(self, T):
         """m (Ta^4 - T^4) evaluated on numbers / arrays / a Function's nodal values (:361-376)."""
         m, T_amb = self.radiation_coefficients()
-        vals = T.vector().array() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
+        vals = T.vector()._values() if isinstance(T, Function) else np.asarray(T, dtype=np.float64)
         return m * (T_amb ** 4 - vals ** 4)
 
     def refresh_nonlinear_form(self, F, T):
@@ -386,7 +386,7 @@ class ScalarTransportSolver(SolverBase):
         sel = self.boundary_facets.where(marker_id)
         cf = mesh.cell_facets()
         c_idx, lf = np.nonzero(np.isin(cf, sel))          # boundary facets belong to exactly one cell
-        T = self.result.vector().array()
+        T = self.result.vector()._values()
         X = co[cells[c_idx]]                              # [nf, d+1, d]
         J = np.stack([X[:, k + 1] - X[:, 0] for k in range(d)], axis=2)
         ginv = np.linalg.inv(J)                           # rows: grad lambda_1..d

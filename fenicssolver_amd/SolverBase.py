@@ -209,8 +209,8 @@ class SolverBase():
         (it divides by 1/dt, "FIXME: does not work for non-uniform time step" there)."""
         assert time_iter_ >= 1
         dt, dt_prev = self.get_time_step(time_iter_), self.get_time_step(time_iter_ - 1)
-        vel = (self.w_current.vector().array() - self.w_prev.vector().array()) / dt
-        vel_prev = (self.w_prev.vector().array() - self.w_pp.vector().array()) / dt_prev
+        vel = (self.w_current.vector()._values() - self.w_prev.vector()._values()) / dt
+        vel_prev = (self.w_prev.vector()._values() - self.w_pp.vector()._values()) / dt_prev
         a = Function(self.function_space)
         a.vector().set_local((vel - vel_prev) / (1.0 / dt))
         return a
@@ -381,14 +381,14 @@ class SolverBase():
             raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                 label, stats['iterations'], stats['true_rel_residual']))
         if loc is None:
-            u.vector().set_local(x.get()[:V.n_owned])
+            u.vector()._adopt_device(x)         # stays in HBM; the host copy is fetched when somebody looks at it
         elif getattr(loc, 'is_local_view', False):
             # distributed mesh: the Function holds this rank's part, owned values and refreshed ghosts (what a DOLFIN
             # Function holds under MPI); parallel.gather_function(u) builds the global array when wanted
             from . import parallel
             if parallel.world()[1] > 1:
                 backend.halo_exchange(V, x)
-            u.vector().set_local(x.get())
+            u.vector()._adopt_device(x)
         else:   # every rank ends with the full field, gathered by global vertex id
             from . import parallel
             ncomp = u.function_space()._ncomp
@@ -497,9 +497,11 @@ class SolverBase():
                 B = backend.DeviceMatrix(V)
                 B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)),
                            advection=adv if pe else None, advection_scale=0.0, supg_pe=pe)    # SUPG mass part only
-                tp_host = F.T_prev.vector().array()
-                tp_host = tp_host if loc is None else loc.nodes(tp_host)
-                tp = backend.DeviceVector(V.n_local, np.concatenate([tp_host, np.zeros(V.n_local - len(tp_host))]))
+                if loc is None or getattr(loc, 'is_local_view', False):
+                    tp = F.T_prev.vector()._device(V.n_local)          # the previous solve left it in HBM
+                else:
+                    tp_host = loc.nodes(F.T_prev.vector()._values())
+                    tp = backend.DeviceVector(V.n_local, np.concatenate([tp_host, np.zeros(V.n_local - len(tp_host))]))
                 tmp = backend.DeviceVector(V.n_owned)
                 B.spmv(tp, tmp)
                 b.axpy(1.0, tmp)
@@ -527,7 +529,7 @@ class SolverBase():
                 rho, accel = F.inertia
                 Mv = backend.DeviceMatrix(V)
                 Mv.assemble(lame=(0.0, 0.0), mass=L_(rho))
-                ah = accel.vector().array()
+                ah = accel.vector()._values()
                 ah = ah if loc is None else loc.nodes(ah)
                 ad = backend.DeviceVector(V.n_local, np.concatenate([ah, np.zeros(V.n_local - len(ah))]))
                 tmp = backend.DeviceVector(V.n_owned)
@@ -573,7 +575,7 @@ class SolverBase():
         loc = F.space.localizer()          # several GPUs: the iterate stays global on the host, rows are local
         n = V.n_owned
         gdofs, gvals = self._bc_arrays(Dirichlet_bcs)
-        T = u_current.vector().array().copy()
+        T = u_current.vector()._values().copy()
         if gdofs.size:
             T[gdofs] = gvals                                # the first iterate carries the boundary values
         dofs = gdofs if loc is None else loc.dofs(gdofs, gvals)[0]
@@ -705,7 +707,7 @@ class SolverBase():
     def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None, w_is_local=False):
         from . import backend
         dw = backend.DeviceVector(V.n_local, w if w_is_local else self._ns_local(loc, w))
-        dp = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector().array())) if F.inv_dt else None
+        dp = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector()._values())) if F.inv_dt else None
         g = backend.DeviceVector(V.n_owned)
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),

@@ -102,6 +102,7 @@ SIGNATURES = {
     "fs_vector_get": (C.c_int, [_H, c_f64p, c_i64]),
     "fs_vector_fill": (C.c_int, [_H, C.c_double]),
     "fs_vector_add_entries": (C.c_int, [_H, C.c_int64, c_i32p, c_f64p]),
+    "fs_vector_copy": (C.c_int, [_H, _H, c_i64]),
     "fs_vector_axpy": (C.c_int, [_H, C.c_double, _H]),
     "fs_vector_dot": (C.c_int, [_H, _H, c_f64p]),
     "fs_vector_destroy": (C.c_int, [_H]),

@@ -181,6 +181,10 @@ class DeviceVector(_Handle):
     def fill(self, a):
         L.check(L.load().fs_vector_fill(self.h, float(a)), "fs_vector_fill")
 
+    def copy_from(self, src, n=None):
+        n = min(self.n, src.n) if n is None else int(n)
+        L.check(L.load().fs_vector_copy(self.h, src.h, n), "fs_vector_copy")
+
     def axpy(self, a, x):
         L.check(L.load().fs_vector_axpy(self.h, float(a), x.h), "fs_vector_axpy")
 

@@ -148,6 +148,14 @@ extern "C" int fs_vector_fill(fs_vector_t v, double value) {
     return FS_OK;
 }
 
+extern "C" int fs_vector_copy(fs_vector_t dst, fs_vector_t src, int64_t n) {
+    FS_REQUIRE(dst && src && n >= 0 && n <= dst->d.n && n <= src->d.n, "fs_vector_copy: bad arguments");
+    if (n == 0) return FS_OK;
+    FS_HIP(hipMemcpyAsync(dst->d.p, src->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, fs_rt().stream));
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    return FS_OK;
+}
+
 extern "C" int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x) {
     FS_REQUIRE(x && y && x->d.n == y->d.n, "fs_vector_axpy: size mismatch");
     if (y->d.n == 0) return FS_OK;

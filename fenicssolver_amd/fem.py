@@ -821,30 +821,79 @@ def TensorFunctionSpace(mesh, family="CG", degree=1, shape=None):
 
 
 class _Vector:
-    """Minimal GenericVector: numpy storage with the calls the reference's users make."""
+    """Minimal GenericVector: numpy storage with the calls the reference's users make.
+
+    The values may also live in a device vector (the solution a solve just produced stays in HBM: the next time step reads
+    its previous field from there, no PCIe round trip).  Exactly one side may be stale: ``array()`` (a writable view) and
+    ``set_local`` make the host side the truth, ``_adopt_device`` the device side; ``get_local`` / ``_values`` only read."""
 
     def __init__(self, n):
         self._a = np.zeros(n)
+        self._dev = None          # backend.DeviceVector holding (at least) the first len(_a) entries
+        self._host_ok = True
+        self._dev_ok = False
+
+    def _sync_host(self):
+        if not self._host_ok:
+            self._a[:] = self._dev.get(self._a.size)
+            self._host_ok = True
+
+    def _values(self):
+        """Read-only access for the library itself: the device copy, if any, stays valid."""
+        self._sync_host()
+        return self._a
+
+    def _adopt_device(self, dev):
+        """dev (length >= len(self)) now IS this vector; the host copy is refreshed on first use."""
+        self._dev, self._dev_ok, self._host_ok = dev, True, False
+
+    def _device(self, n=None):
+        """A device vector with these values (n entries, default len(self); the rest - ghost slots - zero)."""
+        from . import backend
+        n = self._a.size if n is None else int(n)
+        if self._dev_ok and self._dev is not None and self._dev.n >= n:
+            return self._dev
+        self._sync_host()
+        host = self._a if n == self._a.size else np.concatenate([self._a, np.zeros(n - self._a.size)])
+        if self._dev is None or self._dev.n != n:
+            self._dev = backend.DeviceVector(n)
+        self._dev.set(host)
+        self._dev_ok = True
+        return self._dev
 
     def get_local(self):
-        return self._a.copy()
+        return self._values().copy()
 
     def set_local(self, v):
         self._a[:] = v
+        self._host_ok, self._dev_ok = True, False
 
     def array(self):
+        self._sync_host()
+        self._dev_ok = False      # the caller may write through the view
         return self._a
+
+    def assign_from(self, other):
+        """Copy of another vector of the same size: device to device when the source lives there."""
+        if other._dev_ok and other._dev is not None and not other._host_ok:
+            from . import backend
+            if self._dev is None or self._dev.n != other._dev.n:
+                self._dev = backend.DeviceVector(other._dev.n)
+            self._dev.copy_from(other._dev)
+            self._dev_ok, self._host_ok = True, False
+        else:
+            self.set_local(other._values())
 
     def copy(self):
         v = _Vector(self._a.size)
-        v._a[:] = self._a
+        v.assign_from(self)
         return v
 
     def size(self):
         return self._a.size
 
     def norm(self, kind="l2"):
-        return float(np.linalg.norm(self._a, {"l2": 2, "linf": np.inf, "l1": 1}[kind]))
+        return float(np.linalg.norm(self._values(), {"l2": 2, "linf": np.inf, "l1": 1}[kind]))
 
     def apply(self, mode):
         pass
@@ -853,10 +902,10 @@ class _Vector:
         return self._a.size
 
     def __getitem__(self, i):
-        return self._a[i]
+        return self._values()[i]
 
     def __setitem__(self, i, v):
-        self._a[i] = v
+        self.array()[i] = v
 
 
 def locate_point(mesh, p):
@@ -883,7 +932,7 @@ class Function:
         self._vec = _Vector(V.dim())
         self._name = "f"
         if isinstance(other, Function):
-            self._vec.set_local(other._vec.array())
+            self._vec.assign_from(other._vec)
 
     def function_space(self):
         return self._V
@@ -893,7 +942,7 @@ class Function:
 
     def assign(self, other):
         if isinstance(other, Function):
-            self._vec.set_local(other._vec.array())
+            self._vec.assign_from(other._vec)
         elif isinstance(other, Constant):
             self._vec.array().reshape(-1, self._V._ncomp)[:] = other.values()
         else:
@@ -917,12 +966,12 @@ class Function:
         """[num_vertices] (scalar) or [num_vertices, ncomp]: the dofs that sit on mesh vertices."""
         n = self._V._ncomp
         nv = self._V.mesh().num_vertices()
-        return self._vec.array()[:nv] if n == 1 else self._vec.array().reshape(-1, n)[:nv]
+        return self._vec._values()[:nv] if n == 1 else self._vec._values().reshape(-1, n)[:nv]
 
     def node_values(self):
         """All nodal dofs: [num_nodes] or [num_nodes, ncomp] (P2: vertices then edge midpoints)."""
         n = self._V._ncomp
-        return self._vec.array() if n == 1 else self._vec.array().reshape(-1, n)
+        return self._vec._values() if n == 1 else self._vec._values().reshape(-1, n)
 
     def ufl_shape(self):
         return () if self._V._ncomp == 1 else (self._V._ncomp,)

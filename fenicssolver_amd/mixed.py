@@ -92,7 +92,7 @@ def split(w):
     W = w.function_space()
     if not isinstance(W, TaylorHoodSpace):
         raise SolverError("split(): not a velocity-pressure function")
-    a = w.vector().array().reshape(-1, 4)
+    a = w.vector()._values().reshape(-1, 4)
     u = Function(W.velocity_space())
     u.vector().set_local(a[:, :3].reshape(-1))
     p = Function(W.pressure_space())

@@ -127,6 +127,7 @@ int fs_vector_set(fs_vector_t v, const double* host, int64_t n);
 int fs_vector_get(fs_vector_t v, double* host, int64_t n);
 int fs_vector_fill(fs_vector_t v, double value);
 int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x); /* y += a x */
+int fs_vector_copy(fs_vector_t dst, fs_vector_t src, int64_t n); /* first n entries, device to device (Function.assign) */
 /* v[idx[k]] += vals[k] (repeated indices accumulate): dolfin.PointSource.apply(b), SolverBase.py:597-601 */
 int fs_vector_add_entries(fs_vector_t v, int64_t n, const int32_t* idx, const double* vals);
 int fs_vector_dot(fs_vector_t x, fs_vector_t y, double* result); /* local (un-reduced) dot */
