@@ -236,6 +236,61 @@ __global__ void k_amg_diag(int64_t nn, int bs, const int32_t* __restrict__ rp, c
     atomicMax(gersh_bits, (unsigned long long)__double_as_longlong(gmax));
 }
 
+// the same with 16 lanes per node striding over the values of its block row (contiguous in memory); bs <= 6
+__global__ void __launch_bounds__(FS_BLOCK) k_amg_diag_grp(int64_t nn, int bs, const int32_t* __restrict__ rp,
+                                                           const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                           double* __restrict__ dinv, uint8_t* __restrict__ ident,
+                                                           double* __restrict__ dnorm, unsigned long long* __restrict__ gersh_bits) {
+    const int sub = threadIdx.x & 15;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int bb = bs * bs;
+    double gmax = 0.0;
+    for (; i < nn; i += stride) {
+        const int32_t e0 = rp[i];
+        const int total = (rp[i + 1] - e0) * bb;
+        const double* row = val + (int64_t)e0 * bb;
+        double d[6] = {0, 0, 0, 0, 0, 0}, off[6] = {0, 0, 0, 0, 0, 0}, dn = 0.0;
+        for (int idx = sub; idx < total; idx += 16) {
+            const int e = idx / bb, rem = idx - e * bb;
+            const int r = rem / bs, c = rem - r * bs;
+            const double v = row[idx];
+            const bool diag = ci[e0 + e] == (int32_t)i;
+            const bool on_diag = diag && c == r;
+            const double a = on_diag ? 0.0 : fabs(v);
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) {
+                if (rr == r) {
+                    off[rr] += a;
+                    if (on_diag) d[rr] = v;
+                }
+            }
+            if (diag) dn += v * v;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                d[rr] += __shfl_xor(d[rr], o, 16);        // one lane holds the entry, the others 0
+                off[rr] += __shfl_xor(off[rr], o, 16);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dn += __shfl_xor(dn, o, 16);
+        double dm = 0.0, om = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+            if (rr == sub) { dm = d[rr]; om = off[rr]; }
+        if (sub < bs) {
+            dinv[i * bs + sub] = dm != 0.0 ? 1.0 / dm : 1.0;
+            ident[i * bs + sub] = om == 0.0 ? 1 : 0;
+            if (dm != 0.0) gmax = fmax(gmax, (fabs(dm) + om) / fabs(dm));
+        }
+        if (sub == 0) dnorm[i] = sqrt(dn);
+    }
+    atomicMax(gersh_bits, (unsigned long long)__double_as_longlong(gmax));
+}
+
 // strength graph: j != i strong iff ||A_ij||_F^2 > theta^2 ||A_ii||_F ||A_jj||_F (and > 0)
 template <bool FILL>
 __global__ void k_strength(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
@@ -406,6 +461,72 @@ __global__ void k_tentative(int64_t n_agg, int bs, int nb, const int32_t* __rest
     }
 }
 
+// the same with one wave per aggregate: a lane owns the rows lane, lane + 64, ... of the aggregate (nobody else
+// touches them), the column products are butterfly sums over the wave - every lane holds the same bits
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_tentative_wave(int64_t n_agg, int bs, int nb, const int32_t* __restrict__ agg_ptr,
+                                                       const int32_t* __restrict__ members, const double* __restrict__ B,
+                                                       const uint8_t* __restrict__ ident, double* __restrict__ T,
+                                                       double* __restrict__ Bc) {
+    const int lane = threadIdx.x;
+    for (int64_t a = blockIdx.x; a < n_agg; a += gridDim.x) {
+        const int32_t m0 = agg_ptr[a];
+        const int n_rows = (agg_ptr[a + 1] - m0) * bs;
+        double* R = Bc + a * nb * nb;
+        for (int q = lane; q < nb * nb; q += 64) R[q] = 0.0;
+        for (int t = lane; t < n_rows; t += 64) {
+            const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+            for (int c = 0; c < nb; ++c) T[row * nb + c] = ident[row] ? 0.0 : B[row * nb + c];
+        }
+        for (int c = 0; c < nb; ++c) {
+            double part = 0.0;
+            for (int t = lane; t < n_rows; t += 64) {
+                const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+                const double v = T[row * nb + c];
+                part += v * v;
+            }
+            const double orig = wave_sum_all(part);
+            for (int k = 0; k < c; ++k) {
+                part = 0.0;
+                for (int t = lane; t < n_rows; t += 64) {
+                    const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+                    part += T[row * nb + k] * T[row * nb + c];
+                }
+                const double dot = wave_sum_all(part);
+                if (lane == 0) R[k * nb + c] = dot;
+                for (int t = lane; t < n_rows; t += 64) {
+                    const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+                    T[row * nb + c] -= dot * T[row * nb + k];
+                }
+            }
+            part = 0.0;
+            for (int t = lane; t < n_rows; t += 64) {
+                const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+                const double v = T[row * nb + c];
+                part += v * v;
+            }
+            double nrm = wave_sum_all(part);
+            const bool live = nrm > 1e-16 * orig && nrm > 0.0;   // (1e-8)^2: column not in the span of the others
+            nrm = sqrt(nrm);
+            const double sc = live ? 1.0 / nrm : 0.0;
+            if (lane == 0) {
+                R[c * nb + c] = live ? nrm : 0.0;
+                if (!live)
+                    for (int k = 0; k < c; ++k) R[k * nb + c] = 0.0;
+            }
+            for (int t = lane; t < n_rows; t += 64) {
+                const int64_t row = (int64_t)members[m0 + t / bs] * bs + t % bs;
+                T[row * nb + c] *= sc;
+            }
+        }
+    }
+}
+
 // T as block CSR: one block per aggregated node
 __global__ void k_t_fill(int64_t nn, int bsnb, const int32_t* __restrict__ agg, const int32_t* __restrict__ tptr,
                          const double* __restrict__ T, int32_t* __restrict__ tcol, double* __restrict__ tval) {
@@ -493,6 +614,7 @@ __global__ void k_spgemm_symbolic(int64_t n_out, const int32_t* __restrict__ lpt
 // Numeric: C_row(I) = sum_q L_q * Rrow(lk[q]); L_q = left block lval[lidx[q]] (br x bk), used transposed when
 // TRANS (stored bk x br).  The row is accumulated in LDS ([len][br][bc]); within one q all items hit distinct
 // addresses, consecutive q are separated by a barrier: no atomics, fixed summation order.
+#define FS_SPGEMM_STAGE 64
 template <bool TRANS>
 __global__ void k_spgemm_numeric(int64_t n_out, int maxlen, int br, int bk, int bc, const int32_t* __restrict__ lptr,
                                  const int32_t* __restrict__ lk, const int32_t* __restrict__ lidx,
@@ -506,36 +628,150 @@ __global__ void k_spgemm_numeric(int64_t n_out, int maxlen, int br, int bk, int 
     // whole lookup - right rows, product positions - ahead of the accumulation rounds was tried: the 20 KB of extra
     // LDS per workgroup cost more occupancy than the shorter dependency chains gained, 2x slower.)
     int32_t* scol = reinterpret_cast<int32_t*>(acc + (size_t)maxlen * rc);
+    // (right row, its start, its length, left block) of the next FS_SPGEMM_STAGE products, fetched by as many lanes
+    // at once: the three dependent loads lk -> rptr -> row would otherwise sit in front of every accumulation round
+    int32_t* stage = scol + maxlen;
     for (int64_t I = blockIdx.x; I < n_out; I += gridDim.x) {
         const int32_t o0 = optr[I];
         const int len = optr[I + 1] - o0;
         for (int t = threadIdx.x; t < len * rc; t += blockDim.x) acc[t] = 0.0;
         for (int t = threadIdx.x; t < len; t += blockDim.x) scol[t] = ocol[o0 + t];
-        __syncthreads();
-        for (int32_t q = lptr[I]; q < lptr[I + 1]; ++q) {
-            const int32_t k = lk[q];
-            const double* L = lval + (int64_t)(lidx ? lidx[q] : q) * br * bk;
-            const int32_t r0 = rptr[k];
-            const int items = (rptr[k + 1] - r0) * rc;
-            for (int it = threadIdx.x; it < items; it += blockDim.x) {
-                const int p = it / rc, e = it - p * rc;
-                const int r = e / bc, c = e - r * bc;
-                const int32_t J = rcol[r0 + p];
-                int lo = 0, hi = len;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (scol[mid] < J) lo = mid + 1; else hi = mid;
-                }
-                const double* Rb = rval + (int64_t)(r0 + p) * bk * bc;
-                double v = 0.0;
-                for (int m = 0; m < bk; ++m) v += (TRANS ? L[m * br + r] : L[r * bk + m]) * Rb[m * bc + c];
-                acc[lo * rc + e] += v;
+        const int32_t q_end = lptr[I + 1];
+        for (int32_t q0 = lptr[I]; q0 < q_end; q0 += FS_SPGEMM_STAGE) {
+            const int nq = min(FS_SPGEMM_STAGE, q_end - q0);
+            __syncthreads();
+            if ((int)threadIdx.x < nq) {
+                const int32_t q = q0 + threadIdx.x;
+                const int32_t k = lk[q];
+                const int32_t r0 = rptr[k];
+                stage[4 * threadIdx.x + 0] = r0;
+                stage[4 * threadIdx.x + 1] = rptr[k + 1] - r0;
+                stage[4 * threadIdx.x + 2] = lidx ? lidx[q] : q;
             }
             __syncthreads();
+            for (int j = 0; j < nq; ++j) {
+                const int32_t r0 = stage[4 * j + 0];
+                const int items = stage[4 * j + 1] * rc;
+                const double* L = lval + (int64_t)stage[4 * j + 2] * br * bk;
+                for (int it = threadIdx.x; it < items; it += blockDim.x) {
+                    const int p = it / rc, e = it - p * rc;
+                    const int r = e / bc, c = e - r * bc;
+                    const int32_t J = rcol[r0 + p];
+                    const double* Rb = rval + (int64_t)(r0 + p) * bk * bc;
+                    double v = 0.0;
+                    for (int m = 0; m < bk; ++m) v += (TRANS ? L[m * br + r] : L[r * bk + m]) * Rb[m * bc + c];
+                    int lo = 0, hi = len;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (scol[mid] < J) lo = mid + 1; else hi = mid;
+                    }
+                    acc[lo * rc + e] += v;
+                }
+                if (j + 1 < nq) __syncthreads();
+            }
         }
+        __syncthreads();
         for (int t = threadIdx.x; t < len * rc; t += blockDim.x) oval[(int64_t)o0 * rc + t] = acc[t];
         __syncthreads();
     }
+}
+
+// The same product with one wave per output row and the block shape known at compile time.  The wave is cut into
+// G = 64 >> gl_log2 groups of lanes; group g takes the products q = g, g + G, ... of the row and accumulates them in
+// its own copy of the row (LDS), a lane owning one column c of one right block and running over the BR rows itself:
+// one column search, BK right values and BR*BK left values (the same addresses over the group) per BR results.  No
+// barrier separates the products: a group sits inside one wave, whose LDS accesses complete in issue order.  The
+// copies are added in the order g = 0..G-1 at the end, so the summation order is a function of the operands alone.
+template <bool TRANS, int BR, int BK, int BC>
+__global__ void __launch_bounds__(64) k_spgemm_numeric_wave(int64_t n_out, int maxlen, int gl_log2,
+                                                            const int32_t* __restrict__ lptr, const int32_t* __restrict__ lk,
+                                                            const int32_t* __restrict__ lidx, const double* __restrict__ lval,
+                                                            const int32_t* __restrict__ rptr, const int32_t* __restrict__ rcol,
+                                                            const double* __restrict__ rval, const int32_t* __restrict__ optr,
+                                                            const int32_t* __restrict__ ocol, double* __restrict__ oval) {
+    extern __shared__ double acc[];
+    constexpr int RC = BR * BC;
+    const int G = 64 >> gl_log2, gl = 1 << gl_log2;
+    const int lane = threadIdx.x, g = lane >> gl_log2, sub = lane & (gl - 1);
+    const size_t copy = (size_t)maxlen * RC;
+    int32_t* scol = reinterpret_cast<int32_t*>(acc + (size_t)G * copy);
+    int32_t* stage = scol + maxlen;
+    double* mine = acc + (size_t)g * copy;
+    for (int64_t I = blockIdx.x; I < n_out; I += gridDim.x) {
+        const int32_t o0 = optr[I];
+        const int len = optr[I + 1] - o0;
+        for (int k = 0; k < G; ++k)
+            for (int t = lane; t < len * RC; t += 64) acc[k * copy + t] = 0.0;
+        for (int t = lane; t < len; t += 64) scol[t] = ocol[o0 + t];
+        const int32_t q_end = lptr[I + 1];
+        for (int32_t q0 = lptr[I]; q0 < q_end; q0 += 64) {
+            const int nq = min(64, q_end - q0);
+            __syncthreads();
+            if (lane < nq) {
+                const int32_t q = q0 + lane;
+                const int32_t k = lk[q];
+                const int32_t r0 = rptr[k];
+                stage[4 * lane + 0] = r0;
+                stage[4 * lane + 1] = rptr[k + 1] - r0;
+                stage[4 * lane + 2] = lidx ? lidx[q] : q;
+            }
+            __syncthreads();
+            for (int j = g; j < nq; j += G) {
+                const int32_t r0 = stage[4 * j + 0];
+                const int items = stage[4 * j + 1] * BC;
+                const double* L = lval + (int64_t)stage[4 * j + 2] * BR * BK;
+                double Lr[BR * BK];
+#pragma unroll
+                for (int t = 0; t < BR * BK; ++t) Lr[t] = L[t];
+                for (int it = sub; it < items; it += gl) {
+                    const int p = it / BC, c = it - p * BC;
+                    const int32_t J = rcol[r0 + p];
+                    const double* Rb = rval + (int64_t)(r0 + p) * BK * BC + c;
+                    double rv[BK];
+#pragma unroll
+                    for (int m = 0; m < BK; ++m) rv[m] = Rb[m * BC];
+                    int lo = 0, hi = len;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (scol[mid] < J) lo = mid + 1; else hi = mid;
+                    }
+                    double* a = mine + lo * RC + c;
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < BK; ++m) v += (TRANS ? Lr[m * BR + r] : Lr[r * BK + m]) * rv[m];
+                        a[r * BC] += v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = lane; t < len * RC; t += 64) {
+            double v = acc[t];
+            for (int k = 1; k < G; ++k) v += acc[k * copy + t];
+            oval[(int64_t)o0 * RC + t] = v;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool TRANS, int BR, int BK, int BC>
+static int launch_spgemm_wave(int64_t n_out, int maxlen, double items_per_product, const int32_t* lptr, const int32_t* lk,
+                              const int32_t* lidx, const double* lval, const bcsr& R, bcsr* C, hipStream_t s) {
+    int gl_log2 = 3;                                            // 8 lanes per product at least
+    while (gl_log2 < 6 && (1 << gl_log2) < items_per_product) ++gl_log2;
+    const size_t copy = (size_t)maxlen * BR * BC * sizeof(double);
+    while (gl_log2 < 6 && (64 >> gl_log2) * copy > 24 * 1024) ++gl_log2;   // keep several waves per CU resident
+    const size_t lds = (size_t)(64 >> gl_log2) * copy + (size_t)maxlen * sizeof(int32_t) + 64 * 4 * sizeof(int32_t);
+    FS_REQUIRE(lds <= 160 * 1024 - 512, "AMG setup: a product row of %d blocks (%dx%d) exceeds the LDS accumulator", maxlen, BR, BC);
+    auto kern = k_spgemm_numeric_wave<TRANS, BR, BK, BC>;
+    if (lds > 64 * 1024) FS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (int)std::min<int64_t>(n_out, 1 << 20);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, n_out, maxlen, gl_log2, lptr, lk, lidx, lval, R.rowptr.p, R.col.p,
+                       R.val.p, C->rowptr.p, C->col.p, C->val.p);
+    FS_KERNEL_CHECK();
+    return FS_OK;
 }
 
 // dead coarse dofs (near-null-space column not representable on an aggregate): unit diagonal
@@ -614,6 +850,41 @@ __global__ void k_prolong_add(int64_t n_f, int br, int bc, const int32_t* __rest
             for (int c = 0; c < bc; ++c) acc += blk[c] * xj[c];
         }
         xf[row] += acc;
+    }
+}
+
+// the same for a known block shape: 16 lanes per fine node stride over the values of its block row
+template <int BR, int BC>
+__global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, const int32_t* __restrict__ rp,
+                                                              const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                              const double* __restrict__ xc, double* __restrict__ xf) {
+    constexpr int BB = BR * BC;
+    const int sub = threadIdx.x & 15;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (; i < nn_f; i += stride) {
+        const int32_t e0 = rp[i];
+        const int total = (rp[i + 1] - e0) * BB;
+        const double* row = val + (int64_t)e0 * BB;
+        double acc[BR];
+#pragma unroll
+        for (int r = 0; r < BR; ++r) acc[r] = 0.0;
+        for (int idx = sub; idx < total; idx += 16) {
+            const int e = idx / BB, rem = idx - e * BB;
+            const int r = rem / BC, c = rem - r * BC;
+            const double v = row[idx] * xc[(int64_t)ci[e0 + e] * BC + c];
+#pragma unroll
+            for (int rr = 0; rr < BR; ++rr)
+                if (rr == r) acc[rr] += v;
+        }
+        double mine = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < BR; ++rr) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[rr] += __shfl_xor(acc[rr], o, 16);
+            if (rr == sub) mine = acc[rr];
+        }
+        if (sub < BR) xf[i * BR + sub] += mine;
     }
 }
 
@@ -728,6 +999,12 @@ __global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ dinv, dou
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) v[i] *= s * (dinv ? dinv[i] : 1.0);
 }
+__global__ void k_amg_div_dinv(int64_t n, const double* __restrict__ dinv, const double* __restrict__ v, double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = v[i] / dinv[i];
+}
+
 __global__ void k_amg_seed(int64_t n, double* __restrict__ v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -794,17 +1071,34 @@ static int spgemm(int64_t n_out, int64_t n_cols, int br, int bk, int bc, bool tr
         FS_CHECK(read_i32(mx.p, &maxlen, s));
     }
     amg_tick("    spgemm maxlen");
-    const size_t lds = (size_t)std::max(1, maxlen) * br * bc * sizeof(double) + (size_t)std::max(1, maxlen) * sizeof(int32_t);
-    FS_REQUIRE(lds <= 160 * 1024 - 512, "AMG setup: a product row of %d blocks (%dx%d) exceeds the LDS accumulator", maxlen, br, bc);
-    if (lds > 64 * 1024) {
-        if (trans) FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    maxlen = std::max(1, maxlen);
+    const double items = (double)R.nnz / (double)std::max<int64_t>(1, R.nrows) * bc;   // lanes one product can use
+    bool done = false;
+#define FS_SPGEMM_SHAPE(T, BR_, BK_, BC_)                                                                          \
+    if (!done && trans == T && br == BR_ && bk == BK_ && bc == BC_) {                                              \
+        FS_CHECK((launch_spgemm_wave<T, BR_, BK_, BC_>(n_out, maxlen, items, lptr, lk, lidx, lval, R, C, s)));      \
+        done = true;                                                                                                \
     }
-    if (trans)
-        hipLaunchKernelGGL(k_spgemm_numeric<true>, dim3(grid), dim3(wg), lds, s, n_out, std::max(1, maxlen), br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
-    else
-        hipLaunchKernelGGL(k_spgemm_numeric<false>, dim3(grid), dim3(wg), lds, s, n_out, std::max(1, maxlen), br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
-    FS_KERNEL_CHECK();
+    static const bool old_numeric = getenv("FS_AMG_SPGEMM_BLOCK") != nullptr;
+    if (!old_numeric) {
+        FS_SPGEMM_SHAPE(false, 3, 3, 6) FS_SPGEMM_SHAPE(true, 6, 3, 6) FS_SPGEMM_SHAPE(false, 6, 6, 6) FS_SPGEMM_SHAPE(true, 6, 6, 6)
+        FS_SPGEMM_SHAPE(false, 1, 1, 1) FS_SPGEMM_SHAPE(true, 1, 1, 1) FS_SPGEMM_SHAPE(false, 3, 3, 3) FS_SPGEMM_SHAPE(true, 3, 3, 3)
+    }
+#undef FS_SPGEMM_SHAPE
+    if (!done) {       // any other block shape: a workgroup per row, shapes at run time
+        const size_t lds = (size_t)maxlen * br * bc * sizeof(double) + (size_t)maxlen * sizeof(int32_t) +
+                           (size_t)FS_SPGEMM_STAGE * 4 * sizeof(int32_t);
+        FS_REQUIRE(lds <= 160 * 1024 - 512, "AMG setup: a product row of %d blocks (%dx%d) exceeds the LDS accumulator", maxlen, br, bc);
+        if (lds > 64 * 1024) {
+            if (trans) FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            else FS_HIP(hipFuncSetAttribute((const void*)k_spgemm_numeric<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (trans)
+            hipLaunchKernelGGL(k_spgemm_numeric<true>, dim3(grid), dim3(wg), lds, s, n_out, maxlen, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+        else
+            hipLaunchKernelGGL(k_spgemm_numeric<false>, dim3(grid), dim3(wg), lds, s, n_out, maxlen, br, bk, bc, lptr, lk, lidx, lval, R.rowptr.p, R.col.p, R.val.p, C->rowptr.p, C->col.p, C->val.p);
+        FS_KERNEL_CHECK();
+    }
     FS_HIP(hipStreamSynchronize(s));
     amg_tick("    spgemm numeric");
     return FS_OK;
@@ -881,21 +1175,27 @@ static int estimate_lmax(fs_amg_s* M, amg_level* L, int steps, hipStream_t s) {
     hipLaunchKernelGGL(k_amg_seed, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, v.p);
     // No normalisation and no host round trip inside the loop (round 1: one synchronising dot per step, 21 + 19 ms of the
     // 160 ms set-up at configs[2], most of it latency on the small levels): the iterate grows by at most the Gershgorin
-    // bound per step, 1e300 is far away for any sensible step count, and lambda = ||v_k|| / ||v_{k-1}|| needs two dots.
+    // bound per step, 1e300 is far away for any sensible step count.  The estimate is the Rayleigh quotient of the
+    // last iterate, (v, A v) / (v, D v) - that of D^-1/2 A D^-1/2 at D^1/2 v - whose error is the square of the
+    // iterate's, so half the steps of a norm ratio do (two dots and one scaling, once).
     const double growth = L->gersh > 1.0 ? L->gersh : 1.0;
     int safe = steps;
     while (safe > 1 && safe * log10(growth) > 250.0) --safe;
-    double n_prev = 0.0, n_last = 0.0;
-    for (int it = 0; it < safe; ++it) {
-        if (it == safe - 1) FS_CHECK(dot_host(M, v.p, v.p, L->n, &n_prev, s));
+    for (int it = 0; it + 1 < safe; ++it) {
         if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
         else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
         hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, w.p, 1.0);
         std::swap(v.p, w.p);
     }
-    FS_CHECK(dot_host(M, v.p, v.p, L->n, &n_last, s));
-    const double lam = n_prev > 0.0 ? sqrt(n_last / n_prev) : 0.0;
+    if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
+    else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
+    double num = 0.0, den = 0.0;
+    FS_CHECK(dot_host(M, v.p, w.p, L->n, &num, s));
+    hipLaunchKernelGGL(k_amg_div_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, v.p, w.p);
+    FS_CHECK(dot_host(M, v.p, w.p, L->n, &den, s));
+    const double lam = den > 0.0 ? num / den : 0.0;
     L->lmax = (lam > 0.0 && lam == lam && lam < 1e300) ? std::min(1.1 * lam, L->gersh) : L->gersh;
+    if (getenv("FS_AMG_DEBUG")) fprintf(stderr, "[fs_amg_setup]   lambda_max(D^-1 A) ~ %.6f after %d steps (Gershgorin %.4f)\n", lam, safe, L->gersh);
     return FS_OK;
 }
 
@@ -924,7 +1224,10 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     FS_CHECK(gbits.zero(s));
     FS_CHECK(L->dinv.alloc(L->n));
     FS_CHECK(L->ident.alloc(L->n));
-    hipLaunchKernelGGL(k_amg_diag, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, L->ident.p, dnorm.p, gbits.p);
+    if (bs <= 6)
+        hipLaunchKernelGGL(k_amg_diag_grp, dim3(fs_grid_for(nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, L->ident.p, dnorm.p, gbits.p);
+    else
+        hipLaunchKernelGGL(k_amg_diag, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, L->ident.p, dnorm.p, gbits.p);
     FS_KERNEL_CHECK();
     unsigned long long hb = 0;
     FS_HIP(hipMemcpyAsync(&hb, gbits.p, 8, hipMemcpyDeviceToHost, s));
@@ -1002,7 +1305,11 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     FS_CHECK(T.alloc(L->n * nb));
     FS_CHECK(T.zero(s));
     FS_CHECK(C->B.alloc(C->n * nb));
-    hipLaunchKernelGGL(k_tentative, dim3(fs_grid_for(n_agg, 64, 8192)), dim3(64), 0, s, (int64_t)n_agg, bs, nb, agg_ptr.p, members.p, L->B.p, L->ident.p, T.p, C->B.p);
+    static const bool serial_qr = getenv("FS_AMG_SERIAL_QR") != nullptr;
+    if (serial_qr)
+        hipLaunchKernelGGL(k_tentative, dim3(fs_grid_for(n_agg, 64, 8192)), dim3(64), 0, s, (int64_t)n_agg, bs, nb, agg_ptr.p, members.p, L->B.p, L->ident.p, T.p, C->B.p);
+    else
+        hipLaunchKernelGGL(k_tentative_wave, dim3((unsigned)std::min<int64_t>(n_agg, 1 << 20)), dim3(64), 0, s, (int64_t)n_agg, bs, nb, agg_ptr.p, members.p, L->B.p, L->ident.p, T.p, C->B.p);
     FS_KERNEL_CHECK();
     bcsr Tm;
     Tm.nrows = nn; Tm.ncols = n_agg; Tm.br = bs; Tm.bc = nb; Tm.nnz = n_t;
@@ -1116,7 +1423,7 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
     const double theta = (!opts || opts->strength_threshold == 0.0) ? 0.05 : std::max(opts->strength_threshold, 1e-8);
     const int max_levels = opts && opts->max_levels > 0 ? opts->max_levels : 10;
     const int coarse_size = opts && opts->coarse_size > 0 ? opts->coarse_size : 500;
-    const int eig_steps = opts && opts->eig_steps > 0 ? opts->eig_steps : 30;
+    const int eig_steps = opts && opts->eig_steps > 0 ? opts->eig_steps : 15;
     hipStream_t s = fs_rt().stream;
     const auto t0 = std::chrono::steady_clock::now();
     amg_tick(nullptr);
@@ -1315,7 +1622,12 @@ static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s)
 #undef FS_RESTRICT_ARGS
     }
     FS_CHECK(vcycle(M, l + 1, C->x.p, C->b.p, s));
-    hipLaunchKernelGGL(k_prolong_add, dim3(fs_grid_for(L->n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L->n, L->P.br, L->P.bc, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
+    if (L->P.br == 3 && L->P.bc == 6)
+        hipLaunchKernelGGL((k_prolong_add_grp<3, 6>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
+    else if (L->P.br == 6 && L->P.bc == 6)
+        hipLaunchKernelGGL((k_prolong_add_grp<6, 6>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
+    else
+        hipLaunchKernelGGL(k_prolong_add, dim3(fs_grid_for(L->n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L->n, L->P.br, L->P.bc, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
     FS_CHECK(smooth(M, l, x, b, false, s));
     return FS_OK;
 }

@@ -304,7 +304,7 @@ typedef struct fs_amg_opts {
     int max_levels;            /* 0 = 10 */
     int coarse_size;           /* stop coarsening at this many dofs; 0 = 500 */
     int smoother_steps;        /* Chebyshev steps per pre/post smoothing; 0 = 2 (PETSc mg_levels_ksp_max_it) */
-    int eig_steps;             /* power-iteration steps of the eigenvalue estimate; 0 = 30 */
+    int eig_steps;             /* power-iteration steps before the Rayleigh quotient of the eigenvalue estimate; 0 = 15 */
     int rigid_body_modes;      /* nullspace == NULL and a 3-vector CG1 space: build the six rigid-body modes of
                                 * build_nullspace() (SolverBase.py:674-706) on the device from the node coordinates */
 } fs_amg_opts;

@@ -42,3 +42,4 @@ t2 = time.perf_counter()
 print("n %d: %d DOF, set-up %.2f s, %d steps in %.3f s = %.1f ms per step, last solve %d iterations" % (
     n, Q.dim(), t1 - t0, steps, t2 - t1, (t2 - t1) / steps * 1e3, solver.last_solve_stats["iterations"]))
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(22)
