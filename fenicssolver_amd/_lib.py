@@ -81,6 +81,8 @@ SIGNATURES = {
     "fs_init": (C.c_int, [C.c_int]),
     "fs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fs_device_synchronize": (C.c_int, []),
+    "fs_memory_info": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "fs_memory_trim": (C.c_int, []),
     "fs_last_error": (C.c_char_p, []),
     "fs_version": (C.c_char_p, []),
     "fs_set_option": (C.c_int, [C.c_char_p, C.c_double]),

@@ -39,6 +39,18 @@ def synchronize():
     L.check(L.load().fs_device_synchronize(), "fs_device_synchronize")
 
 
+def memory_info():
+    """Bytes of device memory the library holds: in use by live objects / idle in its block cache."""
+    live, cached = C.c_int64(0), C.c_int64(0)
+    L.check(L.load().fs_memory_info(C.byref(live), C.byref(cached)), "fs_memory_info")
+    return {"live_bytes": live.value, "cached_bytes": cached.value}
+
+
+def trim_memory():
+    """Return the idle blocks of the cache to the driver."""
+    L.check(L.load().fs_memory_trim(), "fs_memory_trim")
+
+
 class _Handle:
     _destroy = None
 

@@ -59,6 +59,16 @@ struct fs_runtime {
 fs_runtime& fs_rt();
 int fs_require_init();
 
+// ---- device memory -------------------------------------------------------------
+// Blocks released by the library are kept (up to FS_POOL_MAX_MB, default 16384) and handed out again for requests of
+// about their size: hipFree synchronises the device and hipMalloc of a large block takes 0.1-1 ms, which a time loop
+// re-assembling its operators and an AMG set-up with its dozens of temporaries pay every time.  Every kernel and copy
+// of the library is ordered on the one stream of fs_runtime, so a block can be re-used as soon as it is released.
+void* fs_pool_alloc(size_t bytes);   // nullptr (error message set) when the device is out of memory
+void fs_pool_free(void* p);
+void fs_pool_trim(size_t keep_bytes);   // give cached blocks back to the driver until at most keep_bytes stay
+void fs_pool_stats(size_t* live_bytes, size_t* cached_bytes);
+
 // ---- device buffer -------------------------------------------------------------
 template <typename T>
 struct dbuf {
@@ -68,7 +78,8 @@ struct dbuf {
         release();
         n = count;
         if (count == 0) return FS_OK;
-        FS_HIP(hipMalloc((void**)&p, (size_t)count * sizeof(T)));
+        p = static_cast<T*>(fs_pool_alloc((size_t)count * sizeof(T)));
+        if (!p) { n = 0; return FS_ERR_HIP; }
         return FS_OK;
     }
     int zero(hipStream_t s) {
@@ -90,7 +101,7 @@ struct dbuf {
         return FS_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) fs_pool_free(p);
         p = nullptr;
         n = 0;
     }

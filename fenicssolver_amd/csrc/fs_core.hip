@@ -1,6 +1,8 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
 #include "fs_kernels.h"
+#include <map>
+#include <unordered_map>
 #include <vector>
 #include <stdlib.h>
 
@@ -17,6 +19,107 @@ void fs_set_error(const char* fmt, ...) {
 fs_runtime& fs_rt() {
     static fs_runtime rt;
     return rt;
+}
+
+// ---- block cache (see fs_common.h) ----------------------------------------------------
+namespace {
+struct block_pool {
+    std::multimap<size_t, void*> idle;               // size -> block
+    std::unordered_map<void*, size_t> size_of;       // every block handed out or idle
+    size_t live = 0, cached = 0;
+    size_t limit() {
+        static size_t v = [] {
+            const char* e = getenv("FS_POOL_MAX_MB");
+            return (size_t)(e ? strtoull(e, nullptr, 10) : 16384ull) << 20;
+        }();
+        return v;
+    }
+};
+block_pool& pool() {
+    static block_pool* p = new block_pool;   // never destroyed: buffers of static objects are released at exit, after
+    return *p;                               // function-local statics of this file would be gone
+}
+}  // namespace
+
+void fs_pool_trim(size_t keep_bytes) {
+    block_pool& P = pool();
+    while (P.cached > keep_bytes && !P.idle.empty()) {
+        auto it = std::prev(P.idle.end());           // largest first
+        (void)hipFree(it->second);
+        P.size_of.erase(it->second);
+        P.cached -= it->first;
+        P.idle.erase(it);
+    }
+}
+
+void* fs_pool_alloc(size_t bytes) {
+    block_pool& P = pool();
+    if (bytes == 0) return nullptr;
+    // the smallest idle block that holds the request and wastes at most a quarter of itself (small blocks: half)
+    auto it = P.idle.lower_bound(bytes);
+    if (it != P.idle.end() && it->first - bytes <= (it->first < (1u << 20) ? it->first / 2 : it->first / 4)) {
+        void* p = it->second;
+        P.cached -= it->first;
+        P.live += it->first;
+        P.idle.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                           // give the cache back and try once more
+        (void)hipGetLastError();
+        fs_pool_trim(0);
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fs_set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    P.size_of[p] = bytes;
+    P.live += bytes;
+    return p;
+}
+
+void fs_pool_free(void* p) {
+    block_pool& P = pool();
+    auto it = P.size_of.find(p);
+    if (it == P.size_of.end()) {                     // not ours (cannot happen): hand it to the driver
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second;
+    P.live -= bytes;
+    if (bytes > P.limit()) {
+        (void)hipFree(p);
+        P.size_of.erase(it);
+        return;
+    }
+    P.idle.emplace(bytes, p);
+    P.cached += bytes;
+    if (P.cached > P.limit()) {                      // over the limit: drop the largest idle blocks
+        fs_pool_trim(P.limit());
+    }
+}
+
+void fs_pool_stats(size_t* live_bytes, size_t* cached_bytes) {
+    if (live_bytes) *live_bytes = pool().live;
+    if (cached_bytes) *cached_bytes = pool().cached;
+}
+
+extern "C" int fs_memory_trim(void) {
+    FS_CHECK(fs_require_init());
+    FS_HIP(hipStreamSynchronize(fs_rt().stream));
+    fs_pool_trim(0);
+    return FS_OK;
+}
+
+extern "C" int fs_memory_info(int64_t* live_bytes, int64_t* cached_bytes) {
+    size_t l = 0, c = 0;
+    fs_pool_stats(&l, &c);
+    if (live_bytes) *live_bytes = (int64_t)l;
+    if (cached_bytes) *cached_bytes = (int64_t)c;
+    return FS_OK;
 }
 
 int fs_require_init() {
@@ -54,6 +157,7 @@ extern "C" int fs_init(int device_id) {
     FS_REQUIRE(device_id >= 0 && device_id < n, "fs_init: device %d out of range (0..%d)", device_id, n - 1);
     fs_runtime& rt = fs_rt();
     if (rt.initialised && rt.device == device_id) return FS_OK;
+    if (rt.initialised) fs_pool_trim(0);          // idle blocks of the device this process used before
     FS_HIP(hipSetDevice(device_id));
     // FS_WAIT=spin|yield|block selects how the host waits for the device (default: the runtime's choice; spinning
     // made no measurable difference to the Krylov loops on the MI355X test boxes)

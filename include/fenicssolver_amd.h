@@ -51,6 +51,12 @@ typedef struct fs_vector_s* fs_vector_t;
 int fs_init(int device_id);
 int fs_device_count(int* count);
 int fs_device_synchronize(void);
+/* Device blocks released by the library are cached for re-use (hipFree synchronises the device, a time loop that
+ * re-assembles its operators must not pay it every step): fs_memory_info reports the bytes in use / idle in the
+ * cache, fs_memory_trim returns the idle ones to the driver.  FS_POOL_MAX_MB (environment, default 16384) caps the
+ * idle bytes; 0 turns the cache off. */
+int fs_memory_info(int64_t* live_bytes, int64_t* cached_bytes);
+int fs_memory_trim(void);
 const char* fs_last_error(void);
 const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"

@@ -113,3 +113,40 @@ def test_bad_meshes_are_rejected(gpu):
         gpu.DeviceMesh(co, np.zeros((0, 4), dtype=np.int32))                 # no cells
     with pytest.raises(BackendError):
         gpu.DeviceSpace(gpu.DeviceMesh(co, np.array([[0, 1, 2, 3]], dtype=np.int32)), ncomp=2)   # 2-vectors are not built
+
+
+def test_released_blocks_are_reused_and_can_be_trimmed(gpu):
+    """The block cache of the library (include/fenicssolver_amd.h, fs_memory_info): a released vector's block serves
+    the next request of its size, the results of work in re-used blocks are those of fresh ones, trim empties it."""
+    gpu.trim_memory()
+    base = gpu.memory_info()
+    n = 1 << 20
+    a = gpu.DeviceVector(n)
+    a.set(np.arange(n, dtype=np.float64))
+    assert gpu.memory_info()["live_bytes"] - base["live_bytes"] >= 8 * n
+    a.close()
+    after_close = gpu.memory_info()
+    assert after_close["cached_bytes"] - base["cached_bytes"] >= 8 * n
+    b = gpu.DeviceVector(n)                       # same size: comes out of the cache
+    assert gpu.memory_info()["cached_bytes"] <= after_close["cached_bytes"] - 8 * n
+    b.fill(2.5)
+    assert np.all(b.get() == 2.5)
+    # a solve whose temporaries live in re-used blocks equals the first one bit for bit
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), 6, 5, 4)
+    sols = []
+    for _ in range(3):
+        mesh = gpu.DeviceMesh(co, ce)
+        V = gpu.DeviceSpace(mesh)
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=1.0, mass=1.0)
+        rhs = gpu.DeviceVector(V.n_owned)
+        gpu.assemble_vector(V, rhs, source=1.0)
+        x = gpu.DeviceVector(V.n_owned)
+        gpu.krylov_solve(A, rhs, x, rtol=1e-12)
+        sols.append(x.get())
+        for h in (x, rhs, A, V, mesh):
+            h.close()
+    assert np.array_equal(sols[0], sols[1]) and np.array_equal(sols[0], sols[2])
+    b.close()
+    gpu.trim_memory()
+    assert gpu.memory_info()["cached_bytes"] == 0
