@@ -292,29 +292,63 @@ __global__ void __launch_bounds__(FS_BLOCK) k_amg_diag_grp(int64_t nn, int bs, c
 }
 
 // strength graph: j != i strong iff ||A_ij||_F^2 > theta^2 ||A_ii||_F ||A_jj||_F (and > 0)
-template <bool FILL>
-__global__ void k_strength(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                           const double* __restrict__ val, const double* __restrict__ dnorm, double theta2,
-                           int32_t* __restrict__ cnt, const int32_t* __restrict__ sptr, int32_t* __restrict__ scol,
-                           double* __restrict__ sw) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// 16 lanes per node.  Small blocks (COOP = false): a lane per entry of the block row, the strong entries keep their
+// order through the ballot of the group.  Large blocks (6x6): the group sums one block after the other together
+// (butterfly: every lane holds the same bits) and its first lane writes.
+template <bool FILL, bool COOP>
+__global__ void __launch_bounds__(FS_BLOCK) k_strength_grp(int64_t nn, int bs, const int32_t* __restrict__ rp,
+                                                           const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                           const double* __restrict__ dnorm, double theta2,
+                                                           int32_t* __restrict__ cnt, const int32_t* __restrict__ sptr,
+                                                           int32_t* __restrict__ scol, double* __restrict__ sw) {
+    const int sub = threadIdx.x & 15;
+    const int shift = threadIdx.x & 48;                    // first lane of the group inside its wave
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int bb = bs * bs;
     for (; i < nn; i += stride) {
-        int32_t n = 0;
+        const int32_t e0 = rp[i], e1 = rp[i + 1];
         const int32_t o = FILL ? sptr[i] : 0;
-        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
-            const int32_t j = ci[e];
-            if (j == (int32_t)i) continue;
-            double f = 0.0;
-            const double* blk = val + (int64_t)e * bb;
-            for (int q = 0; q < bb; ++q) f += blk[q] * blk[q];
-            if (f > 0.0 && f > theta2 * dnorm[i] * dnorm[j]) {   // theta2 >= 1e-16: summation-order noise is no coupling
-                if (FILL) { scol[o + n] = j; sw[o + n] = f; }
-                ++n;
+        const double di = dnorm[i];
+        int32_t n = 0;
+        if (COOP) {
+            for (int32_t e = e0; e < e1; ++e) {
+                const int32_t j = ci[e];
+                if (j == (int32_t)i) continue;
+                const double* blk = val + (int64_t)e * bb;
+                double f = 0.0;
+                for (int q = sub; q < bb; q += 16) f += blk[q] * blk[q];
+#pragma unroll
+                for (int w = 8; w > 0; w >>= 1) f += __shfl_xor(f, w, 16);
+                if (f > 0.0 && f > theta2 * di * dnorm[j]) {
+                    if (FILL && sub == 0) { scol[o + n] = j; sw[o + n] = f; }
+                    ++n;
+                }
+            }
+        } else {
+            for (int32_t base = e0; base < e1; base += 16) {
+                const int32_t e = base + sub;
+                bool strong = false;
+                int32_t j = 0;
+                double f = 0.0;
+                if (e < e1) {
+                    j = ci[e];
+                    if (j != (int32_t)i) {
+                        const double* blk = val + (int64_t)e * bb;
+                        for (int q = 0; q < bb; ++q) f += blk[q] * blk[q];
+                        strong = f > 0.0 && f > theta2 * di * dnorm[j];
+                    }
+                }
+                const unsigned m = (unsigned)((__ballot(strong) >> shift) & 0xffffull);
+                if (FILL && strong) {
+                    const int at = o + n + __popc(m & ((1u << sub) - 1u));
+                    scol[at] = j;
+                    sw[at] = f;
+                }
+                n += __popc(m);
             }
         }
-        if (!FILL) cnt[i] = n;
+        if (!FILL && sub == 0) cnt[i] = n;
     }
 }
 
@@ -541,21 +575,26 @@ __global__ void k_t_fill(int64_t nn, int bsnb, const int32_t* __restrict__ agg, 
 }
 
 // P = T - omega D^-1 (A T), in place on the values of AT (pattern of AT contains agg(i): the diagonal is structural)
-__global__ void k_smooth_p(int64_t nn, int bs, int nb, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                           double* __restrict__ val, const double* __restrict__ dinv, const int32_t* __restrict__ agg,
-                           const double* __restrict__ T, double omega) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// 16 lanes per node over the values of its row of P
+__global__ void __launch_bounds__(FS_BLOCK) k_smooth_p_grp(int64_t nn, int bs, int nb, const int32_t* __restrict__ rp,
+                                                           const int32_t* __restrict__ ci, double* __restrict__ val,
+                                                           const double* __restrict__ dinv, const int32_t* __restrict__ agg,
+                                                           const double* __restrict__ T, double omega) {
+    const int sub = threadIdx.x & 15;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int bb = bs * nb;
     for (; i < nn; i += stride) {
-        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
-            const bool own = ci[e] == agg[i];
-            for (int r = 0; r < bs; ++r)
-                for (int c = 0; c < nb; ++c) {
-                    const int64_t q = ((int64_t)e * bs + r) * nb + c;
-                    double v = -omega * dinv[i * bs + r] * val[q];
-                    if (own) v += T[(i * bs + r) * nb + c];
-                    val[q] = v;
-                }
+        const int32_t e0 = rp[i];
+        const int total = (rp[i + 1] - e0) * bb;
+        double* row = val + (int64_t)e0 * bb;
+        const int32_t mine = agg[i];
+        for (int idx = sub; idx < total; idx += 16) {
+            const int e = idx / bb, rem = idx - e * bb;
+            const int r = rem / nb;
+            double v = -omega * dinv[i * bs + r] * row[idx];
+            if (ci[e0 + e] == mine) v += T[i * bb + rem];
+            row[idx] = v;
         }
     }
 }
@@ -1244,7 +1283,9 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     FS_CHECK(scnt.alloc(nn + 1));
     FS_CHECK(scnt.zero(s));
     FS_CHECK(sptr.alloc(nn + 1));
-    hipLaunchKernelGGL(k_strength<false>, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, dnorm.p, theta * theta, scnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+#define FS_STRENGTH_ARGS dim3(fs_grid_for(nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, dnorm.p, theta * theta
+    if (bs >= 4) hipLaunchKernelGGL((k_strength_grp<false, true>), FS_STRENGTH_ARGS, scnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+    else hipLaunchKernelGGL((k_strength_grp<false, false>), FS_STRENGTH_ARGS, scnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
     FS_KERNEL_CHECK();
     FS_CHECK(scan_exclusive(scnt.p, sptr.p, nn + 1, s));
     int32_t snnz = 0;
@@ -1252,7 +1293,9 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     if (snnz == 0) return FS_OK;
     FS_CHECK(scol.alloc(snnz));
     FS_CHECK(sw.alloc(snnz));
-    hipLaunchKernelGGL(k_strength<true>, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, L->A.rowptr.p, L->A.col.p, L->A.val.p, dnorm.p, theta * theta, (int32_t*)nullptr, sptr.p, scol.p, sw.p);
+    if (bs >= 4) hipLaunchKernelGGL((k_strength_grp<true, true>), FS_STRENGTH_ARGS, (int32_t*)nullptr, sptr.p, scol.p, sw.p);
+    else hipLaunchKernelGGL((k_strength_grp<true, false>), FS_STRENGTH_ARGS, (int32_t*)nullptr, sptr.p, scol.p, sw.p);
+#undef FS_STRENGTH_ARGS
     FS_KERNEL_CHECK();
 
     amg_tick("  strength");
@@ -1323,7 +1366,7 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     // P = (I - omega D^-1 A) T
     FS_CHECK(spgemm(nn, n_agg, bs, bs, nb, false, L->A.rowptr.p, L->A.col.p, nullptr, L->A.val.p, Tm, 64, &L->P, s));
     const double omega = 4.0 / (3.0 * L->lmax);
-    hipLaunchKernelGGL(k_smooth_p, dim3(g), dim3(FS_BLOCK), 0, s, nn, bs, nb, L->P.rowptr.p, L->P.col.p, L->P.val.p, L->dinv.p, agg.p, T.p, omega);
+    hipLaunchKernelGGL(k_smooth_p_grp, dim3(fs_grid_for(nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, nn, bs, nb, L->P.rowptr.p, L->P.col.p, L->P.val.p, L->dinv.p, agg.p, T.p, omega);
     FS_KERNEL_CHECK();
     L->n_agg = n_agg;
     amg_tick("  smoothed P");

@@ -25,7 +25,7 @@ for dims in sizes:
     ns[3, :, 0], ns[3, :, 1] = -xyz[:, 1], xyz[:, 0]
     ns[4, :, 0], ns[4, :, 2] = xyz[:, 2], -xyz[:, 0]
     ns[5, :, 2], ns[5, :, 1] = xyz[:, 1], -xyz[:, 2]
-    variants = [dict(eig_steps=int(k)) for k in os.environ['AMG_EIG_STEPS'].split(',')] if 'AMG_EIG_STEPS' in os.environ else [dict()] * 2 if len(sys.argv) < 3 else [dict(strength_threshold=t) for t in (-1, 0.01, 0.02, 0.05, 0.1)]
+    variants = __import__('json').loads(os.environ['AMG_KW']) if 'AMG_KW' in os.environ else [dict(eig_steps=int(k)) for k in os.environ['AMG_EIG_STEPS'].split(',')] if 'AMG_EIG_STEPS' in os.environ else [dict()] * 2 if len(sys.argv) < 3 else [dict(strength_threshold=t) for t in (-1, 0.01, 0.02, 0.05, 0.1)]
     for kw in variants:
         t0 = time.perf_counter(); amg = B.AMG(A, nullspace='rigid_body' if os.environ.get('AMG_DEVICE_NS', '1') == '1' else ns.reshape(6, -1), **kw); B.synchronize(); t1 = time.perf_counter()
         st = amg.solve(b, x, rtol=1e-8); t2 = time.perf_counter()
