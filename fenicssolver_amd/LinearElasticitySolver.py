@@ -50,9 +50,10 @@ class LinearElasticitySolver(SolverBase):
         co = self.mesh.coordinates()
         ce = self.mesh.cells().astype(np.int64)
         X = co[ce]
-        J = np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=2)
+        d = ce.shape[1] - 1                 # 3: tetrahedra, 2: triangles ([nc,2,2] gradients)
+        J = np.stack([X[:, k] - X[:, 0] for k in range(1, d + 1)], axis=2)
         Ji = np.linalg.inv(J)
-        g = np.zeros((len(ce), 4, 3))
+        g = np.zeros((len(ce), d + 1, d))
         g[:, 1:, :] = Ji
         g[:, 0, :] = -Ji.sum(axis=1)
         V = u.function_space()
@@ -72,7 +73,7 @@ class LinearElasticitySolver(SolverBase):
         G = self._cell_gradients(u)
         eps = 0.5 * (G + np.transpose(G, (0, 2, 1)))
         tr = np.trace(G, axis1=1, axis2=2)
-        return 2.0 * mu * eps + lmbda * tr[:, None, None] * np.eye(3)[None]
+        return 2.0 * mu * eps + lmbda * tr[:, None, None] * np.eye(G.shape[1])[None]
 
     def von_Mises(self, u):
         """project(sqrt(3/2 s:s), FunctionSpace(mesh, 'P', 1)) (:71-76): the consistent L2 projection, on the device -
@@ -122,19 +123,23 @@ class LinearElasticitySolver(SolverBase):
 
     # ------------------------------------------------------------------ boundary conditions
     def _facet_normals(self, marker_id):
-        """Outward unit normals and areas of the facets carrying marker_id."""
+        """Outward unit normals and areas (lengths in 2-D) of the facets carrying marker_id."""
         mesh = self.mesh
         sel = self.boundary_facets.where(marker_id)
         tri = mesh.facets()[sel].astype(np.int64)
         co = mesh.coordinates()
         p = co[tri]
-        n = 0.5 * np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+        if tri.shape[1] == 2:          # boundary edges of a triangular mesh: the tangent turned by -90 degrees
+            t = p[:, 1] - p[:, 0]
+            n = np.stack([t[:, 1], -t[:, 0]], axis=1)
+        else:
+            n = 0.5 * np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
         area = np.linalg.norm(n, axis=1)
         # orient away from the interior: use the centroid of the (single) adjacent cell
         cf = mesh.cell_facets()
         cells = mesh.cells().astype(np.int64)
         owner = np.full(mesh.num_facets(), -1, dtype=np.int64)
-        owner[cf.ravel()] = np.repeat(np.arange(len(cells)), 4)
+        owner[cf.ravel()] = np.repeat(np.arange(len(cells)), cells.shape[1])
         cc = co[cells[owner[sel]]].mean(axis=1)
         flip = np.einsum("fi,fi->f", n, p.mean(axis=1) - cc) < 0
         n[flip] *= -1.0
@@ -229,7 +234,7 @@ class LinearElasticitySolver(SolverBase):
                     integrals_N.append(forms.FacetLoad(i, g.values(), 'stress(vector)'))
                 elif isinstance(g, Constant) and g.value_size() == self.dimension ** 2:
                     tri, nrm, area = self._facet_normals(i)
-                    integrals_N.append(forms.FacetLoad(i, nrm @ g.values().reshape(3, 3).T, 'stress(tensor.n)'))
+                    integrals_N.append(forms.FacetLoad(i, nrm @ g.values().reshape(self.dimension, self.dimension).T, 'stress(tensor.n)'))
                 else:
                     raise SolverError("boundary '{}': stress must be a constant vector or tensor".format(name))
             elif btype == 'Neumann':

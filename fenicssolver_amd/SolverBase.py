@@ -886,16 +886,21 @@ class SolverBase():
         """The rigid-body modes of SolverBase.py:674-706 (3 in 2D, 6 in 3D), orthonormalised."""
         co = V.mesh().coordinates()
         n = co.shape[0]
-        if self.dimension != 3:
-            raise SolverError('only 3D is supported by nullspace on this back end')
-        ns = np.zeros((6, n, 3))
-        ns[0, :, 0] = 1.0
-        ns[1, :, 1] = 1.0
-        ns[2, :, 2] = 1.0
-        ns[3, :, 0], ns[3, :, 1] = -co[:, 1], co[:, 0]
-        ns[4, :, 0], ns[4, :, 2] = co[:, 2], -co[:, 0]
-        ns[5, :, 2], ns[5, :, 1] = co[:, 1], -co[:, 2]
-        basis = ns.reshape(6, 3 * n)
+        if self.dimension == 2:
+            ns = np.zeros((3, n, 2))
+            ns[0, :, 0] = 1.0
+            ns[1, :, 1] = 1.0
+            ns[2, :, 0], ns[2, :, 1] = -co[:, 1], co[:, 0]
+            basis = ns.reshape(3, 2 * n)
+        else:
+            ns = np.zeros((6, n, 3))
+            ns[0, :, 0] = 1.0
+            ns[1, :, 1] = 1.0
+            ns[2, :, 2] = 1.0
+            ns[3, :, 0], ns[3, :, 1] = -co[:, 1], co[:, 0]
+            ns[4, :, 0], ns[4, :, 2] = co[:, 2], -co[:, 0]
+            ns[5, :, 2], ns[5, :, 1] = co[:, 1], -co[:, 2]
+            basis = ns.reshape(6, 3 * n)
         q, _ = np.linalg.qr(basis.T)
         return q.T.copy()
 

@@ -350,8 +350,8 @@ def assemble_vector(space, b, source=None, vector_value=None, div_coef=None, add
         f.supg_velocity = _velocity_coef(supg[0], keep)
         f.supg_pe = float(supg[1])
     if vector_value is not None:
-        for i in range(3):
-            f.vector_value[i] = float(vector_value[i])
+        for i, x in enumerate(vector_value):         # 3 components (2 on triangular meshes)
+            f.vector_value[i] = float(x)
     L.check(L.load().fs_assemble_vector(space.h, C.byref(f), b.h, 1 if add else 0), "fs_assemble_vector")
 
 

@@ -746,6 +746,111 @@ __device__ __forceinline__ tri_geom tri_geometry2(const double* __restrict__ xyz
     return t;
 }
 
+// ---- plane-strain elasticity on triangles (LinearElasticitySolver.py:62-69 with dimension 2; the reference sends 2D
+// problems to solve_linear_problem, :247-253) ------------------------------------------------------------------------------
+// One thread per stored 2x2 block sums, in ascending order, the (cell, a, b) sources of the inverse slot table
+// (source index = cell*9 + a*3 + b): K_ab[i][j] = A (lambda d_i phi_a d_j phi_b + mu d_j phi_a d_i phi_b + mu delta_ij
+// grad phi_a . grad phi_b) [+ mass (1 + delta_ab) A / 12 delta_ij].
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_elasticity_gather(int64_t n_entries, const int32_t* __restrict__ ptr,
+                                                                             const int32_t* __restrict__ src,
+                                                                             const int32_t* __restrict__ cells,
+                                                                             const double* __restrict__ xyz4, double mu, double lambda,
+                                                                             coef_dev mc, int64_t plane, double* __restrict__ val) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < n_entries; e += stride) {
+        double acc[2][2] = {{0, 0}, {0, 0}};
+        const int32_t q1 = ptr[e + 1];
+        for (int32_t q = ptr[e]; q < q1; ++q) {
+            const int32_t sidx = src[q];
+            const int64_t c = sidx / 9;
+            const int ab = sidx - (int32_t)(c * 9);
+            const int a = ab / 3, b = ab - 3 * a;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            const double ga[2] = {a == 0 ? t.g[0][0] : (a == 1 ? t.g[1][0] : t.g[2][0]), a == 0 ? t.g[0][1] : (a == 1 ? t.g[1][1] : t.g[2][1])};
+            const double gb[2] = {b == 0 ? t.g[0][0] : (b == 1 ? t.g[1][0] : t.g[2][0]), b == 0 ? t.g[0][1] : (b == 1 ? t.g[1][1] : t.g[2][1])};
+            double ms = 0.0;
+            if (mc.mode != FS_COEF_NONE)
+                ms = (a == b ? 2.0 : 1.0) * (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.area * (1.0 / 12.0);
+            const double gg = ga[0] * gb[0] + ga[1] * gb[1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double x = t.area * (lambda * ga[i] * gb[j] + mu * ga[j] * gb[i]);
+                    if (i == j) x += t.area * mu * gg + ms;
+                    acc[i][j] += x;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t idx = (int64_t)(i * 2 + j) * plane + e;
+                val[idx] = ADD ? val[idx] + acc[i][j] : acc[i][j];
+            }
+    }
+}
+
+// b_(a,i) += int f_i phi_a dx + int c d_i phi_a dx over the triangles of vertex a, listed by the diagonal block of the
+// inverse slot table in ascending cell order
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_vector_source_gather(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                                                                                const int32_t* __restrict__ sell_col,
+                                                                                const int32_t* __restrict__ gptr,
+                                                                                const int32_t* __restrict__ gsrc,
+                                                                                const int32_t* __restrict__ cells,
+                                                                                const double* __restrict__ xyz4, double fx, double fy,
+                                                                                coef_dev dv, double* __restrict__ b) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        int64_t e = -1;
+        for (int k = 0; k < width; ++k)
+            if (sell_col[base + (int64_t)k * FS_SLICE] == (int32_t)r) { e = base + (int64_t)k * FS_SLICE; break; }
+        double acc[2] = {0.0, 0.0};
+        if (e >= 0) {
+            for (int32_t q = gptr[e]; q < gptr[e + 1]; ++q) {
+                const int32_t sidx = gsrc[q];
+                const int64_t c = sidx / 9;
+                const int a = (sidx - (int32_t)(c * 9)) / 3;
+                const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+                const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+                const double w = t.area * (1.0 / 3.0);
+                double cd = 0.0;
+                if (dv.mode == FS_COEF_CONST) cd = dv.value;
+                else if (dv.mode == FS_COEF_CELL) cd = dv.data[c];
+                else if (dv.mode == FS_COEF_NODAL) cd = ((dv.data[v4.x] + dv.data[v4.y]) + dv.data[v4.z]) * (1.0 / 3.0);
+                cd *= t.area;
+                acc[0] += w * fx + cd * (a == 0 ? t.g[0][0] : (a == 1 ? t.g[1][0] : t.g[2][0]));
+                acc[1] += w * fy + cd * (a == 0 ? t.g[0][1] : (a == 1 ? t.g[1][1] : t.g[2][1]));
+            }
+        }
+        b[2 * r + 0] += acc[0];
+        b[2 * r + 1] += acc[1];
+    }
+}
+
+// traction on boundary edges of a 2-vector space: b_(v,i) += g_i |edge| / 2 for both end points
+__global__ void k_edge_vector2(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                               const double* __restrict__ g, int64_t n_rows, double* __restrict__ b) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = 0.5 * sqrt(dx * dx + dy * dy);
+        for (int i = 0; i < 2; ++i) {
+            if (a < n_rows) atomicAdd(&b[2 * (int64_t)a + i], w * g[2 * f + i]);
+            if (c < n_rows) atomicAdd(&b[2 * (int64_t)c + i], w * g[2 * f + i]);
+        }
+    }
+}
+
 // row-gather assembly, the triangle counterpart of k_assemble_p1_scalar_gather (lane = row, LDS row accumulator)
 template <bool ADD>
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
@@ -1237,6 +1342,8 @@ extern "C" int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx
     if (vals) FS_CHECK(d_v.alloc(nnz));
     if (bs == 1)
         hipLaunchKernelGGL(k_export_csr<1>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
+    else if (bs == 2)
+        hipLaunchKernelGGL(k_export_csr<2>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
     else if (bs == 3)
         hipLaunchKernelGGL(k_export_csr<3>, dim3(fs_grid_for(n_rows)), dim3(FS_BLOCK), 0, s, n_rows, sp->slice_ptr.p, sp->rowptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, d_rp.p, d_ci.p, d_v.p);
     else
@@ -1259,7 +1366,17 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     FS_REQUIRE(mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL,
                "fs_assemble_matrix: mass coefficient must be constant or per cell");
     const int grid = fs_grid_for(m->nc, FS_BLOCK, 8192);
-    if (m->tdim == 2) {
+    if (m->tdim == 2 && A->bs == 2) {
+        FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: 2-vector space without slot table");
+        FS_REQUIRE(form->stiffness.mode == FS_COEF_NONE && form->advection.mode == FS_COEF_NONE && !(form->supg_pe > 0.0),
+                   "fs_assemble_matrix: a 2-vector space takes the Lame parameters (plane-strain elasticity) and a mass coefficient");
+        if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
+        const int gg = fs_grid_for(sp->sell_entries, FS_BLOCK, 1 << 16);
+        if (add)
+            hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+    } else if (m->tdim == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
         FS_REQUIRE(!(form->supg_pe > 0.0), "fs_assemble_matrix: SUPG is built for tetrahedral meshes");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
@@ -1464,6 +1581,45 @@ __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load(int64_t n_rows, int
     }
 }
 
+// 2-D (plane strain, P1 on triangles): the reference's expression with dimension 2 - sigma the 2x2 tensor, the deviator
+// s = sigma - tr(sigma)/3 Identity(2) (LinearElasticitySolver.py:71-73 keeps the 1/3) - constant per cell: vm A / 3.
+__global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load_tri(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                                 const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
+                                                                 const double* __restrict__ xyz4, const double* __restrict__ u, double mu,
+                                                                 double lambda, double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q / 3;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int32_t v[3] = {v4.x, v4.y, v4.z};
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            double G[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) G[i][k] += u[2 * (int64_t)v[n] + i] * t.g[n][k];
+            const double tr = G[0][0] + G[1][1];
+            const double s00 = 2.0 * mu * G[0][0] + lambda * tr, s11 = 2.0 * mu * G[1][1] + lambda * tr;
+            const double s01 = mu * (G[0][1] + G[1][0]);
+            const double pm = (s00 + s11) * (1.0 / 3.0);
+            const double ss = (s00 - pm) * (s00 - pm) + (s11 - pm) * (s11 - pm) + 2.0 * s01 * s01;
+            acc += t.area * (1.0 / 3.0) * sqrt(1.5 * ss);
+        }
+        if (row < n_rows) b[row] = acc;
+    }
+}
+
 // Right-hand sides of the L2 projection of the fluid stress  sigma = nu (grad u + grad u^T) - p I  onto CG1, component by
 // component (CoupledNavierStokesSolver.py:149-155: project(..., TensorFunctionSpace(mesh, 'CG', 1))).  Taylor-Hood iterate:
 // block (u_x, u_y, u_z, p) per CG2 node, p on the vertex nodes.  grad u is linear and p is linear: the integrand against
@@ -1540,13 +1696,17 @@ extern "C" int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, doubl
                                      fs_vector_t b) {
     FS_REQUIRE(disp_space && u && p1_space && b, "fs_assemble_von_mises: null pointer");
     FS_REQUIRE(disp_space->mesh == p1_space->mesh, "fs_assemble_von_mises: the two spaces live on different meshes");
-    FS_REQUIRE(disp_space->ncomp == 3 && disp_space->mesh->tdim == 3, "fs_assemble_von_mises: needs a 3-vector displacement space on tetrahedra");
+    FS_REQUIRE((disp_space->ncomp == 3 && disp_space->mesh->tdim == 3) || (disp_space->ncomp == 2 && disp_space->mesh->tdim == 2),
+               "fs_assemble_von_mises: needs a 3-vector displacement space on tetrahedra or a 2-vector space on triangles");
     FS_REQUIRE(p1_space->ncomp == 1 && p1_space->degree == 1 && p1_space->inc_cell.p, "fs_assemble_von_mises: the target is the scalar CG1 space of the mesh");
     FS_REQUIRE(u->d.n >= disp_space->n_dofs_local && b->d.n >= p1_space->n_dofs_owned, "fs_assemble_von_mises: vector too short");
     hipStream_t s = fs_rt().stream;
     fs_mesh_s* m = p1_space->mesh;
     const int g = fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192);
-    if (disp_space->degree == 1)
+    if (m->tdim == 2)
+        hipLaunchKernelGGL(k_von_mises_load_tri, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
+                           p1_space->inc_cell.p, m->cells.p, m->xyz.p, u->d.p, mu, lambda, b->d.p);
+    else if (disp_space->degree == 1)
         hipLaunchKernelGGL(k_von_mises_load<1>, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
                            p1_space->inc_cell.p, m->cells.p, m->xyz.p, disp_space->cell_dofs, u->d.p, mu, lambda, b->d.p);
     else
@@ -1619,8 +1779,20 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     coef_dev dv;
     const int64_t dlen = form->div_coef.mode == FS_COEF_NODAL ? space->n_nodes_local : m->nc;
     FS_CHECK(make_coef(form->div_coef, dlen, dstore, &dv, "fs_assemble_vector(div_coef)"));
-    FS_REQUIRE(dv.mode == FS_COEF_NONE || space->ncomp == 3, "fs_assemble_vector: div_coef needs a vector space");
+    FS_REQUIRE(dv.mode == FS_COEF_NONE || space->ncomp == 3 || space->ncomp == 2, "fs_assemble_vector: div_coef needs a vector space");
     if (space->ncomp == 1 && f.mode == FS_COEF_NONE) {
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
+    if (m->tdim == 2 && space->ncomp == 2) {
+        FS_REQUIRE(f.mode == FS_COEF_NONE, "fs_assemble_vector: vector spaces take their body force in vector_value");
+        FS_REQUIRE(dv.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0), "fs_assemble_vector: unsupported option on a 2-vector space");
+        FS_REQUIRE(space->slots.p, "fs_assemble_vector: 2-vector space without slot table");
+        if (!space->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(space, s));
+        hipLaunchKernelGGL(k_assemble_tri_vector_source_gather, dim3(fs_grid_for(space->n_nodes_owned, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                           space->n_nodes_owned, space->slice_ptr.p, space->sell_col.p, space->gmap_ptr.p, space->gmap_src.p, m->cells.p,
+                           m->xyz.p, form->vector_value[0], form->vector_value[1], dv, b->d.p);
+        FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
@@ -1771,10 +1943,13 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
         dbuf<int32_t> d_ed;
         dbuf<double> d_g2;
         FS_CHECK(d_ed.alloc(2 * n_facets));
-        FS_CHECK(d_g2.alloc(n_facets));
+        FS_CHECK(d_g2.alloc(n_facets * space->ncomp));
         FS_CHECK(d_ed.upload(tri, 2 * n_facets, s2));
-        FS_CHECK(d_g2.upload(g, n_facets, s2));
-        hipLaunchKernelGGL(k_edge_vector, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->n_nodes_owned, b->d.p);
+        FS_CHECK(d_g2.upload(g, n_facets * space->ncomp, s2));
+        if (space->ncomp == 2)
+            hipLaunchKernelGGL(k_edge_vector2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->n_nodes_owned, b->d.p);
+        else
+            hipLaunchKernelGGL(k_edge_vector, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->n_nodes_owned, b->d.p);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s2));
         return FS_OK;
@@ -1922,6 +2097,8 @@ extern "C" int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const
     double* bp = b ? b->d.p : nullptr;
     if (A->bs == 1)
         hipLaunchKernelGGL(k_dirichlet_sell<1>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
+    else if (A->bs == 2)
+        hipLaunchKernelGGL(k_dirichlet_sell<2>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     else if (A->bs == 3)
         hipLaunchKernelGGL(k_dirichlet_sell<3>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, flag.p, g.p, bp, symmetric);
     else

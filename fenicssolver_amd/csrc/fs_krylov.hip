@@ -971,6 +971,8 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
                 else hipLaunchKernelGGL((k_sell_spmv<1, DOTS, 4>), FS_SPMV_ARGS);
                 break;
         }
+    } else if (A->bs == 2) {
+        hipLaunchKernelGGL((k_sell_spmv<2, DOTS, 4>), FS_SPMV_ARGS);
     } else if (A->bs == 3) {
         if (spmv_nontemporal(sp, 3)) hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4, true>), FS_SPMV_ARGS);
         else hipLaunchKernelGGL((k_sell_spmv<3, DOTS, 4>), FS_SPMV_ARGS);
@@ -1275,7 +1277,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         const int g = fs_grid_for(sp->n_nodes_owned);
         const int jmode = ds ? 2 : (opts->precond == FS_PC_JACOBI ? 1 : 0);
         double* dv = ds ? ws.dvec.p : nullptr;
-        if (bs == 1)
+        if (bs == 2)
+            hipLaunchKernelGGL(k_extract_dinv<2>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, ws.d_err.p, dv);
+        else if (bs == 1)
             hipLaunchKernelGGL(k_extract_dinv<1>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, ws.d_err.p, dv);
         else
             hipLaunchKernelGGL(k_extract_dinv<3>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, jmode, ws.dinv.p, ws.d_err.p, dv);
@@ -1306,7 +1310,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_HIP(hipMemcpyAsync(sc_local, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
         FS_CHECK(fs_halo_exchange_dev(sp, sc_local, s));
         const int g2 = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
-        if (bs == 1)
+        if (bs == 2)
+            hipLaunchKernelGGL(k_scale_copy<2>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
+        else if (bs == 1)
             hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
         else
             hipLaunchKernelGGL(k_scale_copy<3>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);

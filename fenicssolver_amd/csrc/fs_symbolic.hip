@@ -595,10 +595,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     FS_CHECK(fs_require_init());
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
     // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes
-    if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3 && ncomp != 4) ||
-        (degree == 1 && ncomp == 4)) {
-        fs_set_error("fs_space_create: supported spaces are CG1 / CG2 with 1 or 3 components and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d)",
-                     family, degree, ncomp);
+    if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3 && ncomp != 4 && ncomp != 2) ||
+        (degree == 1 && ncomp == 4) || (ncomp == 2 && mesh->tdim != 2) || (ncomp > 2 && mesh->tdim == 2)) {
+        fs_set_error("fs_space_create: supported spaces are CG1 / CG2 with 1 or 3 components on tetrahedra, CG1 with 1 or 2 components on triangles and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d on a %dD mesh)",
+                     family, degree, ncomp, mesh->tdim);
         return FS_ERR_UNSUPPORTED;
     }
     hipStream_t s = fs_rt().stream;
@@ -632,9 +632,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     } while (0)
 
     if (mesh->tdim == 2) {
-        // triangles: CG1 scalar spaces; the compact [nc][3] dof table feeds the generic pattern / incidence code
-        if (degree != 1 || ncomp != 1) {
-            fs_set_error("fs_space_create: triangular meshes carry scalar CG1 spaces only (degree=%d ncomp=%d)", degree, ncomp);
+        // triangles: CG1 scalar and 2-vector spaces; the compact [nc][3] dof table feeds the generic pattern / incidence /
+        // slot-table code
+        if (degree != 1) {
+            fs_set_error("fs_space_create: triangular meshes carry CG1 spaces only (degree=%d ncomp=%d)", degree, ncomp);
             delete sp;
             return FS_ERR_UNSUPPORTED;
         }

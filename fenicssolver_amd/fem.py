@@ -600,9 +600,10 @@ class _Element:
 
 class FunctionSpace:
     """dolfin.FunctionSpace / VectorFunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
-    Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D scalar P1.
+    Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D P1, scalar or
+    2-vector.
     Component i of node n of an ncomp-vector space is dof n*ncomp + i (DOLFIN interleaves the same way).
-    Not built: periodic constraints (constrained_domain raises), 2-D vector / P2 spaces, degree > 2."""
+    Not built: periodic constraints (constrained_domain raises), 2-D P2 spaces, degree > 2."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
                  _parent=None, _holder=False):
@@ -612,8 +613,8 @@ class FunctionSpace:
             raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and P2 only)".format(degree))
         if constrained_domain is not None:
             raise SolverError("periodic_boundary (constrained_domain) is not supported")
-        if mesh.topology().dim() == 2 and (int(degree) != 1 or _ncomp != 1):
-            raise SolverError("2-D (triangular) meshes carry scalar P1 spaces only in fenicssolver_amd")
+        if mesh.topology().dim() == 2 and (int(degree) != 1 or (_ncomp not in (1, 2) and not _holder)):
+            raise SolverError("2-D (triangular) meshes carry P1 spaces (scalar or 2-vector) only in fenicssolver_amd")
         self._mesh = mesh
         self._degree = int(degree)
         self._ufl_element = _Element("Lagrange", int(degree), _ncomp)

@@ -1047,3 +1047,74 @@ def assemble_p2_facet_mass(coords, edges, facets, facet_markers, marker_id, h):
                 rows.append(nodes[a]); cols.append(nodes[b]); vals.append(M[a, b])
     n = nv + len(ed)
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+
+
+# ---- 2-D vector P1 (plane-strain elasticity; LinearElasticitySolver.py:62-69 with dimension 2, which the reference
+# hands to solve_linear_problem, :247-253) -------------------------------------------------------------------------
+def tri_elasticity_local(coords, cells, E, nu):
+    """Ke[(a,i),(b,j)] = area * (lmbda g_ai g_bj + mu g_aj g_bi + mu delta_ij g_a.g_b): inner(sigma(u), grad(v)) dx with
+    sigma = 2 mu sym(grad u) + lmbda div u I on P1 triangles (constant gradients, exact)."""
+    mu, lmbda = lame(E, nu)
+    area, g = tri_geometry(coords, cells)
+    gg = np.einsum("cak,cbk->cab", g, g)
+    Ke = (lmbda * np.einsum("cai,cbj->caibj", g, g)
+          + mu * np.einsum("caj,cbi->caibj", g, g)
+          + mu * np.einsum("cab,ij->caibj", gg, np.eye(2)))
+    return (Ke * area[:, None, None, None, None]).reshape(len(area), 6, 6)
+
+
+def tri_vector_cell_dofs(cells):
+    c = np.asarray(cells, dtype=np.int64)
+    return (c[:, :, None] * 2 + np.arange(2)[None, None, :]).reshape(len(c), 6)
+
+
+def assemble_tri_elasticity(coords, cells, E, nu, mass_coef=None):
+    """Plane-strain stiffness (+ mass_coef * vector mass matrix: the inertia term of the dynamic form)."""
+    Ke = tri_elasticity_local(coords, cells, E, nu)
+    if mass_coef is not None:
+        Me = tri_mass_local(coords, cells, mass_coef)                      # [nc,3,3]
+        Ke = Ke + np.einsum("cab,ij->caibj", Me, np.eye(2)).reshape(len(Me), 6, 6)
+    return assemble_generic(2 * len(coords), tri_vector_cell_dofs(cells), Ke)
+
+
+def assemble_tri_vector_source(coords, cells, f, div_coef=None):
+    """b_(a,i) = int f_i phi_a dx [+ int c d_i phi_a dx, c constant, per cell or nodal (averaged over the cell's
+    vertices: one-point rule, as the 3-D thermal-stress load)]."""
+    area, g = tri_geometry(coords, cells)
+    c = np.asarray(cells, dtype=np.int64)
+    be = np.broadcast_to((area / 3.0)[:, None, None] * np.asarray(f, dtype=np.float64)[None, None, :], (len(area), 3, 2)).copy()
+    if div_coef is not None:
+        dc = np.asarray(div_coef, dtype=np.float64)
+        if dc.ndim == 0:
+            cc = np.full(len(area), float(dc))
+        elif len(dc) == len(area) and len(dc) != len(coords):
+            cc = dc
+        else:
+            cc = dc[c].sum(axis=1) / 3.0
+        be += (cc * area)[:, None, None] * g
+    return assemble_generic_vector(2 * len(coords), tri_vector_cell_dofs(cells), be.reshape(len(area), 6))
+
+
+def assemble_edge_vector_load(coords, edges, markers, marker_id, g):
+    """int g . v ds over the marked boundary edges, g a constant 2-vector: g_i * length / 2 on both end points."""
+    e = np.asarray(edges, dtype=np.int64)[np.asarray(markers) == marker_id]
+    length = np.linalg.norm(np.asarray(coords)[e[:, 1]] - np.asarray(coords)[e[:, 0]], axis=1)
+    b = np.zeros((len(coords), 2))
+    for i in range(2):
+        np.add.at(b[:, i], e.ravel(), np.repeat(g[i] * length / 2.0, 2))
+    return b.ravel()
+
+
+def tri_von_mises_projection(coords, cells, u, E, nu):
+    """The 2-D case of von_mises_projection: LinearElasticitySolver.py:71-76 with dimension 2 - sigma the 2x2 tensor,
+    s = sigma - tr(sigma)/3 Identity(2) (the reference keeps 1/3 in 2-D), vm constant per P1 triangle.  u: [n, 2]."""
+    mu, lmbda = lame(E, nu)
+    ce = np.asarray(cells, dtype=np.int64)
+    area, g = tri_geometry(coords, cells)
+    G = np.einsum("cni,cnk->cik", np.asarray(u)[ce], g)
+    sg = mu * (G + np.swapaxes(G, -1, -2)) + lmbda * np.trace(G, axis1=-2, axis2=-1)[:, None, None] * np.eye(2)
+    dev = sg - np.trace(sg, axis1=-2, axis2=-1)[:, None, None] / 3.0 * np.eye(2)
+    vm = np.sqrt(1.5 * np.einsum("cij,cij->c", dev, dev))
+    b = assemble_generic_vector(len(coords), ce, np.repeat((area / 3.0 * vm)[:, None], 3, axis=1))
+    M = assemble_generic(len(coords), ce, tri_mass_local(coords, cells, 1.0))
+    return solve_direct(M, b), b
