@@ -874,6 +874,64 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_grp(int64_t n, const int
     if (lg == 0 && row < n) y[row] = MODE ? b[row] - acc : acc;
 }
 
+// the same with one wave per NODE (block row) of a level with large blocks: the lanes stride over the contiguous values
+// of the block row (coalesced 8-byte loads; the per-scalar-row kernels read 48-byte pieces 288 bytes apart and lean on
+// the caches for the rest of the line: 3.5 TB/s on the 0.9 GB level-1 operator of configs[2]), every lane keeps BS
+// partial sums, butterfly reduction, lanes 0..BS-1 write
+template <int BS, int MODE>
+__global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const int32_t* __restrict__ rp,
+                                                             const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                             const double* __restrict__ x, const double* __restrict__ b,
+                                                             double* __restrict__ y) {
+    constexpr int BB = BS * BS;
+    const int lane = threadIdx.x & 63;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; i < nn; i += stride) {
+        const int32_t e0 = rp[i];
+        const int total = (rp[i + 1] - e0) * BB;
+        const double* row = val + (int64_t)e0 * BB;
+        double acc[BS];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) acc[r] = 0.0;
+        if (BS % 2 == 0) {           // a lane takes one row of one block: BS/2 16-byte loads of values and of x
+            constexpr int HP = BS / 2;
+            const double2* row2 = reinterpret_cast<const double2*>(row);
+            const int parts = (rp[i + 1] - e0) * BS;
+            for (int idx = lane; idx < parts; idx += 64) {
+                const int e = idx / BS, r = idx - e * BS;
+                const double2* xv = reinterpret_cast<const double2*>(x + (int64_t)ci[e0 + e] * BS);
+                double v = 0.0;
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    const double2 a = row2[(int64_t)idx * HP + h], xx = xv[h];
+                    v += a.x * xx.x + a.y * xx.y;
+                }
+#pragma unroll
+                for (int rr = 0; rr < BS; ++rr)
+                    if (rr == r) acc[rr] += v;
+            }
+        } else {
+            for (int idx = lane; idx < total; idx += 64) {
+                const int e = idx / BB, rem = idx - e * BB;
+                const int r = rem / BS, c = rem - r * BS;
+                const double v = row[idx] * x[(int64_t)ci[e0 + e] * BS + c];
+#pragma unroll
+                for (int rr = 0; rr < BS; ++rr)
+                    if (rr == r) acc[rr] += v;
+            }
+        }
+        double mine = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < BS; ++rr) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[rr] += __shfl_xor(acc[rr], o, 64);
+            if (rr == lane) mine = acc[rr];
+        }
+        if (lane < BS) y[i * BS + lane] = MODE ? b[i * BS + lane] - mine : mine;
+    }
+}
+
 // xf += P xc ; thread per fine scalar row
 __global__ void k_prolong_add(int64_t n_f, int br, int bc, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                               const double* __restrict__ val, const double* __restrict__ xc, double* __restrict__ xf) {
@@ -908,13 +966,32 @@ __global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, cons
         double acc[BR];
 #pragma unroll
         for (int r = 0; r < BR; ++r) acc[r] = 0.0;
-        for (int idx = sub; idx < total; idx += 16) {
-            const int e = idx / BB, rem = idx - e * BB;
-            const int r = rem / BC, c = rem - r * BC;
-            const double v = row[idx] * xc[(int64_t)ci[e0 + e] * BC + c];
+        if (BC % 2 == 0) {           // a lane takes one row of one block: BC/2 16-byte loads of values and of xc
+            constexpr int HP = BC / 2;
+            const double2* row2 = reinterpret_cast<const double2*>(row);
+            const int parts = (rp[i + 1] - e0) * BR;
+            for (int idx = sub; idx < parts; idx += 16) {
+                const int e = idx / BR, r = idx - e * BR;
+                const double2* xv = reinterpret_cast<const double2*>(xc + (int64_t)ci[e0 + e] * BC);
+                double v = 0.0;
 #pragma unroll
-            for (int rr = 0; rr < BR; ++rr)
-                if (rr == r) acc[rr] += v;
+                for (int h = 0; h < HP; ++h) {
+                    const double2 a = row2[(int64_t)idx * HP + h], xx = xv[h];
+                    v += a.x * xx.x + a.y * xx.y;
+                }
+#pragma unroll
+                for (int rr = 0; rr < BR; ++rr)
+                    if (rr == r) acc[rr] += v;
+            }
+        } else {
+            for (int idx = sub; idx < total; idx += 16) {
+                const int e = idx / BB, rem = idx - e * BB;
+                const int r = rem / BC, c = rem - r * BC;
+                const double v = row[idx] * xc[(int64_t)ci[e0 + e] * BC + c];
+#pragma unroll
+                for (int rr = 0; rr < BR; ++rr)
+                    if (rr == r) acc[rr] += v;
+            }
         }
         double mine = 0.0;
 #pragma unroll
@@ -955,11 +1032,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_restrict(int64_t nn_c, const int32
 #pragma unroll
         for (int c = 0; c < BC; ++c) acc[c] = 0.0;
         for (int32_t q = pt_ptr[I] + lane; q < pt_ptr[I + 1]; q += 64) {
-            const double* blk = rt + (int64_t)q * BR * BC;
             const double* rr = rf + (int64_t)pt_row[q] * BR;
             double rv[BR];
 #pragma unroll
             for (int r = 0; r < BR; ++r) rv[r] = rr[r];
+            double blk[BR * BC];
+            if ((BR * BC) % 2 == 0) {     // blocks are 16-byte aligned
+                const double2* b2 = reinterpret_cast<const double2*>(rt + (int64_t)q * BR * BC);
+#pragma unroll
+                for (int h = 0; h < BR * BC / 2; ++h) { const double2 t = b2[h]; blk[2 * h] = t.x; blk[2 * h + 1] = t.y; }
+            } else {
+#pragma unroll
+                for (int h = 0; h < BR * BC; ++h) blk[h] = rt[(int64_t)q * BR * BC + h];
+            }
 #pragma unroll
             for (int c = 0; c < BC; ++c)
 #pragma unroll
@@ -1149,6 +1234,14 @@ static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, doub
         if (mode == 0) return fs_spmv_dev(M->fine, x, y, s);
         FS_CHECK(fs_spmv_dev(M->fine, x, L->t.p, s));
         hipLaunchKernelGGL(k_amg_sub, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, b, L->t.p, y);
+        return FS_OK;
+    }
+    // 6x6 blocks: a wave per node over the contiguous block row
+    static const bool no_node = getenv("FS_AMG_NO_NODE_WAVES") != nullptr;
+    if (!no_node && L->bs == 6 && L->nn > 0 && L->A.nnz >= 4 * L->nn) {
+        const int gg = fs_grid_for(L->nn * 64, FS_BLOCK, 1 << 20);
+        if (mode) hipLaunchKernelGGL((k_bcsr_spmv_node<6, 1>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
+        else hipLaunchKernelGGL((k_bcsr_spmv_node<6, 0>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
         return FS_OK;
     }
     // long rows on few nodes: 16 lanes per scalar row
