@@ -435,13 +435,24 @@ class SolverBase():
             if adv is not None and loc is not None and np.ndim(adv) == 2:
                 adv = loc.cells(adv)
             pe = getattr(F, 'supg_pe', 0.0) if adv is not None else 0.0
-            A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
-                       supg_pe=pe)
-            if ip:          # fully implicit, like the advection term it stabilises (ScalarTransportSolver.py:305-315)
-                A.add_interior_penalty(self.mesh.interior_facet_cells()[0], ip)
-            for r in F.robin:
-                tri, _ = self._device_facets(F, r.marker_id)
-                A.add_facet_mass(tri, r.h)
+            # Constant coefficients in a time loop: the unconstrained operators are the same every step - kept on the
+            # device and copied (DOLFIN re-assembles them, SolverBase.py:592-602; the copy is a third of the assembly).
+            const_ops = F.transient and adv is None and not ip and F.conductivity.kind == "const" and \
+                F.capacity.kind == "const" and all(np.ndim(r.h) == 0 for r in F.robin)
+            op_key = (id(V), theta, float(F.conductivity.value), float(F.capacity.value), float(F.dt),
+                      tuple((r.marker_id, float(r.h)) for r in F.robin)) if const_ops else None
+            kept = self.__dict__.get('_kept_operators')
+            if op_key is not None and kept is not None and kept[0] == op_key:
+                A.copy_from(kept[1])
+            else:
+                A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
+                           supg_pe=pe)
+                if ip:          # fully implicit, like the advection term it stabilises (ScalarTransportSolver.py:305-315)
+                    A.add_interior_penalty(self.mesh.interior_facet_cells()[0], ip)
+                for r in F.robin:
+                    tri, _ = self._device_facets(F, r.marker_id)
+                    A.add_facet_mass(tri, r.h)
+                kept = None
             first = True
             for s in F.sources:
                 spec = L_(s.spec())
@@ -494,9 +505,20 @@ class SolverBase():
                     b.add_entries(pd, pw)
             if F.transient:
                 # b += (M/dt - (1-theta) K) T_prev   (Crank-Nicolson old-step terms, :292-293)
-                B = backend.DeviceMatrix(V)
-                B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)),
-                           advection=adv if pe else None, advection_scale=0.0, supg_pe=pe)    # SUPG mass part only
+                if kept is not None:
+                    B = kept[2]
+                else:
+                    B = backend.DeviceMatrix(V)
+                    B.assemble(stiffness=L_(F.conductivity.spec(-(1.0 - theta))), mass=L_(F.capacity.spec(1.0 / F.dt)),
+                               advection=adv if pe else None, advection_scale=0.0, supg_pe=pe)    # SUPG mass part only
+                    if op_key is not None:
+                        Au = backend.DeviceMatrix(V)
+                        Au.copy_from(A)              # A is still unconstrained here: the Dirichlet rows come last
+                        old_kept = self.__dict__.get('_kept_operators')
+                        if old_kept is not None:
+                            old_kept[1].close()
+                            old_kept[2].close()
+                        self._kept_operators = (op_key, Au, B)
                 if loc is None or getattr(loc, 'is_local_view', False):
                     tp = F.T_prev.vector()._device(V.n_local)          # the previous solve left it in HBM
                 else:

@@ -282,6 +282,10 @@ class DeviceMatrix(_Handle):
     def axpy(self, a, X):
         L.check(L.load().fs_matrix_axpy(self.h, float(a), X.h), "fs_matrix_axpy")
 
+    def copy_from(self, src):
+        """self = src (same space), on the library's stream."""
+        L.check(L.load().fs_matrix_copy(self.h, src.h), "fs_matrix_copy")
+
     def zero(self):
         L.check(L.load().fs_matrix_zero(self.h), "fs_matrix_zero")
 

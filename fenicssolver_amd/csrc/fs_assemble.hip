@@ -1323,6 +1323,12 @@ extern "C" int fs_matrix_axpy(fs_matrix_t Y, double a, fs_matrix_t X) {
     return FS_OK;
 }
 
+extern "C" int fs_matrix_copy(fs_matrix_t dst, fs_matrix_t src) {
+    FS_REQUIRE(dst && src && dst->space == src->space && dst->val.n == src->val.n, "fs_matrix_copy: matrices must share a function space");
+    FS_HIP(hipMemcpyAsync(dst->val.p, src->val.p, (size_t)src->val.n * sizeof(double), hipMemcpyDeviceToDevice, fs_rt().stream));
+    return FS_OK;
+}
+
 extern "C" int fs_matrix_destroy(fs_matrix_t A) {
     delete A;
     return FS_OK;

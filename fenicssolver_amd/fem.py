@@ -690,19 +690,18 @@ class FunctionSpace:
     def facet_nodes(self, facet_ids):
         """Nodes in the closure of the given facets: their vertices (+ their edges for P2), ascending."""
         mesh = self._mesh
-        f = mesh.facets()[facet_ids].astype(np.int64)
-        verts = np.unique(f.ravel())
-        if self._degree == 1:
-            return verts
         root = self.root()
-        cache = root.__dict__.setdefault("_facet_node_cache", {})
+        cache = root.__dict__.setdefault("_facet_node_cache", {})    # a time loop rebuilds its DirichletBCs every step
         ids = np.ascontiguousarray(facet_ids)
         key = (ids.size, zlib.crc32(ids.tobytes()))
         if key in cache:
             return cache[key]
         if len(cache) > 64:
             cache.clear()
-        out = self._facet_nodes_p2(f, verts)
+        f = mesh.facets()[facet_ids].astype(np.int64)
+        verts = np.unique(f.ravel())
+        out = verts if self._degree == 1 else self._facet_nodes_p2(f, verts)
+        out.setflags(write=False)
         cache[key] = out
         return out
 

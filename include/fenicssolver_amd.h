@@ -149,6 +149,9 @@ int fs_matrix_zero(fs_matrix_t A);
 /* Y += a X (same space). Used for theta-scheme operators M/dt + theta K
  * (ScalarTransportSolver.py:287-293). */
 int fs_matrix_axpy(fs_matrix_t Y, double a, fs_matrix_t X);
+/* dst = src (same space), enqueued on the library's stream: a time loop with constant coefficients keeps its
+ * unconstrained operator and starts every step from a copy (DOLFIN re-assembles, SolverBase.py:592-602). */
+int fs_matrix_copy(fs_matrix_t dst, fs_matrix_t src);
 /* Export as sorted-column CSR (any pointer may be NULL): rowptr[n_rows+1],
  * colidx[nnz], vals[nnz]. */
 int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx, double* vals);
