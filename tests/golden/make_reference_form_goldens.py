@@ -157,6 +157,33 @@ bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'valu
 bcs["bending"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'force', 'value': Constant((0, 1e6, 0))}
 run("elasticity_force", LinearElasticitySolver.LinearElasticitySolver(elasticity_settings(bcs)))
 
+# --- case 6a2: a 2-D (plane strain) problem: the reference sends it to solve_linear_problem, not solve_amg
+# (LinearElasticitySolver.py:247-253); per-component clamp, pressure on the top edge, body force
+def elasticity_2d_settings():
+    from dolfin import RectangleMesh
+    mesh = RectangleMesh(Point(0, 0), Point(4, 1), 8, 2)
+    st = copy.deepcopy(SolverBase.default_case_settings)
+    st['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    st['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    bcs = collections.OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), Constant(0))}
+    bcs["roller"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'displacement', 'value': (Constant(1e-3), None)}
+    bcs["load"] = {'boundary': Top(), 'boundary_id': 3, 'type': 'stress', 'value': Constant((0, -5e6))}
+    st['boundary_conditions'] = bcs
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = None
+    st['body_source'] = Constant((0, -76440.0))
+    return st
+
+
+class Top(SubDomain):
+    pass
+
+
+run("elasticity_2d", LinearElasticitySolver.LinearElasticitySolver(elasticity_2d_settings()))
+
 # --- case 6b: the reference's own elasticity example, as its __main__ runs it (examples/test_linear_elasticity.py:42-129,
 # 170: BoxMesh 40x10x10, VectorFunctionSpace(mesh, "Lagrange", 2), left face (0, free, free), right face (0, 0, 1e-3),
 # body force, thermal stress at 343 K)

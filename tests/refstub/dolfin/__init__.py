@@ -183,14 +183,15 @@ class _Geometry(object):
 
 
 class Mesh(object):
-    def __init__(self, filename=None):
+    def __init__(self, filename=None, dim=3):
         self.filename = filename
+        self._dim = dim
 
     def geometry(self):
-        return _Geometry(3)
+        return _Geometry(self._dim)
 
     def topology(self):
-        return _Geometry(3)
+        return _Geometry(self._dim)
 
     def mpi_comm(self):
         return None
@@ -199,7 +200,7 @@ class Mesh(object):
         return 1.0
 
     def ufl_cell(self):
-        return "tetrahedron"
+        return "tetrahedron" if self._dim == 3 else "triangle"
 
 
 def BoxMesh(*a):
@@ -208,6 +209,14 @@ def BoxMesh(*a):
 
 def UnitCubeMesh(*a):
     return Mesh("UnitCubeMesh%r" % (a,))
+
+
+def UnitSquareMesh(*a):
+    return Mesh("UnitSquareMesh%r" % (a,), dim=2)
+
+
+def RectangleMesh(*a):
+    return Mesh("RectangleMesh%r" % (tuple(repr(x) for x in a),), dim=2)
 
 
 class Point(object):
@@ -336,7 +345,8 @@ class Function(Expr):
         Expr.__init__(self, "symbol", self.name_)
         self.V = V
         if getattr(V, "kind", "") == "vector":
-            self._len, self._shape = 3, (3,)
+            d = _vdim(V)
+            self._len, self._shape = d, (d,)
 
     def assign(self, other):
         pass
@@ -356,7 +366,7 @@ def TrialFunction(V):
     if getattr(V, "kind", "") == "mixed":
         f._elements = V.element.elements
     if getattr(V, "kind", "") == "vector":
-        f._len, f._shape = 3, (3,)
+        f._len, f._shape = _vdim(V), (_vdim(V),)
     return f
 
 
@@ -365,8 +375,14 @@ def TestFunction(V):
     if getattr(V, "kind", "") == "mixed":
         f._elements = V.element.elements
     if getattr(V, "kind", "") == "vector":
-        f._len, f._shape = 3, (3,)
+        f._len, f._shape = _vdim(V), (_vdim(V),)
     return f
+
+
+def _vdim(V):
+    """components of a VectorFunctionSpace = the geometric dimension of its mesh"""
+    m = getattr(V, "mesh_", None) or (V.mesh() if hasattr(V, "mesh") and callable(V.mesh) else None)
+    return m.geometry().dim() if m is not None else 3
 
 
 def split(f):

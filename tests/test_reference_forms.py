@@ -145,14 +145,14 @@ def scalar_form_poly(F):
     return {k: v for k, v in out.items() if v != 0.0}
 
 
-def elasticity_form_poly(F, mu2_name="sym grad u_trial"):
+def elasticity_form_poly(F, mu2_name="sym grad u_trial", body_symbol="c:expr(10*rho,0,0.0)"):
     d = F.describe()
     out = collections.defaultdict(float)
     out[("dx", tuple(sorted([mu2_name, "grad v_test"])))] += 2.0 * d["mu"]
     out[("dx", tuple(sorted(["c:I", "div u_trial", "grad v_test"])))] += d["lambda"]
     sgn = -d["load_sign"]            # F = a(u,v) + sum(loads) in the reference  <=>  load_sign = -1
     if d["body_force"] is not None:
-        out[("dx", tuple(sorted(["c:expr(10*rho,0,0.0)", "v_test"])))] += sgn * 1.0
+        out[("dx", tuple(sorted([body_symbol, "v_test"])))] += sgn * 1.0
     for (i, g, origin) in d["tractions"]:
         out[("ds(%d)" % i, tuple(sorted(["c:vec(%s)" % ",".join("%g" % x for x in g), "v_test"])))] += sgn * 1.0
     if d["thermal"] is not None:
@@ -309,6 +309,53 @@ def test_elasticity_terms():
     g = GOLD["elasticity_displacement"]["solves"][0]
     assert_same_poly(elasticity_form_poly(F), golden_poly(g))
     assert bc_list(dbc) == golden_bcs(g)
+
+
+def test_elasticity_2d_goes_through_solve_linear_problem():
+    """A plane-strain case: the reference solves 2-D problems with solve_linear_problem (LinearVariationalSolver), not
+    solve_amg (LinearElasticitySolver.py:247-253); same integrals, per-component Dirichlet sets, Identity(2)."""
+    from fenicssolver_amd.fem import RectangleMesh, Point, VectorFunctionSpace, Constant, SubDomain, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+
+    class Left(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0)
+
+    class Right(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 4)
+
+    class Top(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[1], 1)
+    mesh = RectangleMesh(Point(0, 0), Point(4, 1), 8, 2)
+    st = copy.deepcopy(SB.default_case_settings)
+    st['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
+                      'thermal_expansion_coefficient': 2e-6}
+    st['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    bcs = collections.OrderedDict()
+    bcs["fixed"] = {'boundary': Left(), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0), Constant(0))}
+    bcs["roller"] = {'boundary': Right(), 'boundary_id': 2, 'type': 'displacement', 'value': (Constant(1e-3), None)}
+    bcs["load"] = {'boundary': Top(), 'boundary_id': 3, 'type': 'stress', 'value': Constant((0, -5e6))}
+    st['boundary_conditions'] = bcs
+    st['solver_settings']['reference_values'] = {'temperature': 293}
+    st['report_settings'] = dict(QUIET)
+    st['temperature_distribution'] = None
+    st['body_source'] = Constant((0, -76440.0))
+    solver = LinearElasticitySolver(st)
+    assert solver.dimension == 2 and solver.function_space.ufl_element().value_size() == 2
+    F, dbc = _form_of(solver)
+    g = GOLD["elasticity_2d"]["solves"][0]
+    assert g["kind"] == "LinearVariationalSolver" and "Identity(2)" in g["terms"][0]["integrand"]
+    assert_same_poly(elasticity_form_poly(F, body_symbol="c:vec(0,-76440)"), golden_poly(g))
+    assert bc_list(dbc) == golden_bcs(g)
+    # the class takes the same branch: solve_form -> solve_linear_problem for dimension 2
+    called = []
+    solver.solve_linear_problem = lambda F_, u_, b_: called.append("linear") or u_
+    solver.solve_amg = lambda F_, u_, b_: called.append("amg") or u_
+    solver.solve_form(F, solver.w_current, dbc)
+    assert called == ["linear"]
 
 
 def test_reference_elasticity_example_on_vector_p2():
