@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
 
 // ---- CG scalar state on the device ---------------------------------------------------------
 // sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
-// ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b
+// ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b, ctrl[2] = max_iter (read by the update kernels of a
+// captured batch, so that one instantiated graph serves solves with different iteration limits)
 // scal[2][2] = (gamma, alpha) of the previous iteration, double-buffered by iteration parity
 // status[0] = 0 running / 1 converged / 2 breakdown / 3 max_iter, status[1] = iterations
 __global__ void k_set_threshold(const double* __restrict__ bb, double rtol, double atol, double* __restrict__ ctrl) {
@@ -328,6 +329,9 @@ __global__ void k_set_threshold(const double* __restrict__ bb, double rtol, doub
         ctrl[0] = fmax(t, atol * atol);
         ctrl[1] = bb[0];
     }
+}
+__global__ void k_set_iteration_limit(double* __restrict__ ctrl, int max_iter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctrl[2] = (double)max_iter;
 }
 
 // FUSED: every workgroup first sums the SpMV's per-WG partials itself (same fixed order as
@@ -599,7 +603,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     if (status[0] != 0) return;
     if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
         iter = status[2] - 1;
-        check_only = iter >= check_only ? 1 : 0;       // the argument carries max_iter in this mode
+        check_only = iter >= (int)ctrl[2] ? 1 : 0;
     }
     double gamma, delta, rho;
     if (FUSED) {
@@ -1379,6 +1383,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
 
         // iteration pipeline
         const int max_iter = opts->max_iter - total_iters > 0 ? opts->max_iter - total_iters : 1;
+        hipLaunchKernelGGL(k_set_iteration_limit, dim3(1), dim3(64), 0, s, ws.ctrl.p, max_iter);
         double* const hist_p = ws.hist.p + total_iters;
         int k = 0, slot = 0, pending = -1;
         bool finished = false;
@@ -1387,14 +1392,26 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // on cache-resident problems: the gaps between consecutive launches (2 x 2.1 us of a 44 us iteration at 1 M DOF)
         // shrink to the graph's own node-to-node latency.
         static const char* graph_env = getenv("FS_CG_GRAPH");
-        const int graph_mode = graph_env ? atoi(graph_env) : g_cg_graph;
+        // rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch once about 10 500 kernel nodes have been replayed under
+        // --kernel-trace (168 launches of this 64-node graph; nothing to do with the graph's contents or age - renewing
+        // the executable does not help, plain launches of the same kernels trace fine).  With the profiler's tool library
+        // in the process the automatic mode therefore falls back to plain launches: the kernels and their durations are
+        // the same, only the 2 x 2 us of launch gap per iteration come back.  FS_CG_GRAPH=1 still forces graphs.
+        static const bool profiler_attached = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+        int graph_mode = graph_env ? atoi(graph_env) : g_cg_graph;
+        if (graph_mode < 0 && profiler_attached) {
+            static bool told = false;
+            if (!told) fprintf(stderr, "[libfsamd] rocprofiler tool library detected: CG batches go out as plain launches, not hipGraphs\n");
+            told = true;
+            graph_mode = 0;
+        }
         const bool use_graph = ds && fuse_sums && !bicg && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
             if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
                 const void* key[8] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p};
-                const int64_t key_i[6] = {n, max_iter, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1)};
+                const int64_t key_i[6] = {n, 0, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1)};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
                     if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
                     hipGraph_t graph = nullptr;
@@ -1402,9 +1419,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     int rc_cap = FS_OK;
                     for (int i = 0; i < batch && rc_cap == FS_OK; ++i) {
                         rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
-                        // iteration index from the device (iter = -1), check_only carries max_iter
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, max_iter, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, max_iter, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        // iteration index (status[2]) and iteration limit (ctrl[2]) from the device: iter = -1
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     }
                     const hipError_t e_end = hipStreamEndCapture(s, &graph);
                     FS_CHECK(rc_cap);
