@@ -28,7 +28,7 @@ import numbers
 import numpy as np
 
 from .SolverBase import SolverBase, SolverError
-from .fem import Function, Constant, Expression, DirichletBC
+from .fem import Measure, Function, Constant, Expression, DirichletBC
 from .mixed import TaylorHoodSpace, split
 from . import forms
 
@@ -129,7 +129,8 @@ class CoupledNavierStokesSolver(SolverBase):
             raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
         if self.transient_settings['transient']:
             F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:367-381)
-        bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function, None)
+        bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function,
+                                                                                  Measure("ds", subdomain_data=self.boundary_facets))
         self.J = F if self.using_nonlinear_solver else None
         return F, bcs
 

@@ -23,7 +23,7 @@ import numbers
 
 import numpy as np
 
-from .fem import Constant, Expression, Function, DirichletBC, nodal_values, is_constant_value
+from .fem import Measure, Constant, Expression, Function, DirichletBC, nodal_values, is_constant_value
 from .SolverBase import SolverBase, SolverError
 from . import forms
 
@@ -263,7 +263,7 @@ class LinearElasticitySolver(SolverBase):
         F.mu, F.lmbda = self.lame_parameters()
         F.load_sign = -1.0 if self.reference_load_sign else 1.0
 
-        bcs, integrals_F = self.update_boundary_conditions(time_iter_, u, v, None)
+        bcs, integrals_F = self.update_boundary_conditions(time_iter_, u, v, Measure("ds", subdomain_data=self.boundary_facets))
         F.tractions.extend(integrals_F)
 
         if self.body_source:

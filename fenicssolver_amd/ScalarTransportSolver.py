@@ -22,7 +22,7 @@ import os
 
 import numpy as np
 
-from .fem import Constant, Expression, Function, DirichletBC, PointSource, Point, nodal_values, is_constant_value
+from .fem import Measure, Constant, Expression, Function, DirichletBC, PointSource, Point, nodal_values, is_constant_value
 from .SolverBase import SolverBase, SolverError
 from . import forms
 
@@ -319,7 +319,7 @@ class ScalarTransportSolver(SolverBase):
             F.advection = (velocity, self._scalar_capacity(self._volume_coefficient(capacity, 'capacity')))
             F.symmetric = False
 
-        bcs, integrals_N = self.update_boundary_conditions(time_iter_, T, T_test, None)
+        bcs, integrals_N = self.update_boundary_conditions(time_iter_, T, T_test, Measure("ds", subdomain_data=self.boundary_facets))
         for item in integrals_N:
             (F.robin if isinstance(item, forms.FacetRobin) else F.facet_loads).append(item)
         F.point_sources = list(self._point_sources)

@@ -380,6 +380,9 @@ class SolverBase():
         if stats['converged'] != 1:
             raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                 label, stats['iterations'], stats['true_rel_residual']))
+        per = u.function_space().periodic_pairs() if hasattr(u.function_space(), 'periodic_pairs') else None
+        if per is not None:
+            x.assign_entries(per[0], per[1], block=u.function_space()._ncomp)
         if loc is None:
             u.vector()._adopt_device(x)         # stays in HBM; the host copy is fetched when somebody looks at it
         elif getattr(loc, 'is_local_view', False):
@@ -559,6 +562,9 @@ class SolverBase():
                 b.axpy(1.0, tmp)
         else:
             raise SolverError('unknown form specification {}'.format(type(F)))
+        per = F.space.periodic_pairs() if hasattr(F.space, 'periodic_pairs') else None
+        if per is not None:
+            A.tie_nodes(b, per[0], per[1])          # before the Dirichlet rows, as DOLFIN's dofmap has no slave dofs at all
         dofs, vals = self._bc_arrays(bcs)
         if loc is not None and dofs.size:
             dofs, vals = loc.dofs(dofs, vals)       # local dofs, ghosts included (their columns are eliminated too)
@@ -587,6 +593,8 @@ class SolverBase():
             return self._navier_stokes_newton(F, u_current, Dirichlet_bcs)
         if not isinstance(F, forms.ScalarForm):
             raise SolverError('nonlinear solves are built for scalar transport and Navier-Stokes only')
+        if F.space.periodic_pairs() is not None:
+            raise SolverError('periodic_boundary is built for linear problems (the Newton loop does not fold its residual)')
         from . import parallel
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         newton = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}

@@ -113,6 +113,8 @@ SIGNATURES = {
     "fs_matrix_zero": (C.c_int, [_H]),
     "fs_matrix_axpy": (C.c_int, [_H, C.c_double, _H]),
     "fs_matrix_copy": (C.c_int, [_H, _H]),
+    "fs_matrix_tie_nodes": (C.c_int, [_H, _H, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "fs_vector_assign_entries": (C.c_int, [_H, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "fs_matrix_get_csr": (C.c_int, [_H, c_i32p, c_i32p, c_f64p]),
     "fs_matrix_destroy": (C.c_int, [_H]),
     "fs_assemble_matrix": (C.c_int, [_H, C.POINTER(fs_bilinear_form), C.c_int]),

@@ -204,6 +204,11 @@ class DeviceVector(_Handle):
         i, v = L.i32(idx).ravel(), L.f64(vals).ravel()
         L.check(L.load().fs_vector_add_entries(self.h, i.size, L.p_i32(i), L.p_f64(v)), "fs_vector_add_entries")
 
+    def assign_entries(self, dst_nodes, src_nodes, block=1):
+        """self[dst*block + c] = self[src*block + c] (the slaves of a periodic constraint take their masters' values)."""
+        d, sr = L.i32(dst_nodes).ravel(), L.i32(src_nodes).ravel()
+        L.check(L.load().fs_vector_assign_entries(self.h, d.size, L.p_i32(d), L.p_i32(sr), int(block)), "fs_vector_assign_entries")
+
     def dot(self, y):
         r = C.c_double(0.0)
         L.check(L.load().fs_vector_dot(self.h, y.h, C.byref(r)), "fs_vector_dot")
@@ -281,6 +286,12 @@ class DeviceMatrix(_Handle):
 
     def axpy(self, a, X):
         L.check(L.load().fs_matrix_axpy(self.h, float(a), X.h), "fs_matrix_axpy")
+
+    def tie_nodes(self, b, slaves, masters):
+        """Fold the periodic constraint u[slaves] = u[masters] into the assembled system (and b, which may be None)."""
+        sl, ma = L.i32(slaves).ravel(), L.i32(masters).ravel()
+        L.check(L.load().fs_matrix_tie_nodes(self.h, b.h if b is not None else None, sl.size, L.p_i32(sl), L.p_i32(ma)),
+                "fs_matrix_tie_nodes")
 
     def copy_from(self, src):
         """self = src (same space), on the library's stream."""

@@ -160,7 +160,7 @@ class MeshSource:
 
 def build_function_space(mesh, settings):
     """FunctionSpace for scalar_name cases, VectorFunctionSpace for vector_name cases (SolverBase.py:260-275);
-    ``periodic_boundary`` goes to the space, which refuses it loudly (periodic constraints are not built)."""
+    ``periodic_boundary`` goes to the space as its constrained_domain (P1 spaces on one GPU)."""
     make = FunctionSpace if "scalar_name" in settings else VectorFunctionSpace if "vector_name" in settings else None
     if make is None:
         raise SolverError("the settings name neither 'scalar_name' nor 'vector_name': this solver class must build its own space")

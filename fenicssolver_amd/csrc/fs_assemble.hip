@@ -1226,6 +1226,137 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dirichlet_sell(int64_t n_rows, int
     }
 }
 
+// ---- tied nodes (periodic constraints: FunctionSpace(..., constrained_domain=pb), SolverBase.py:260-275) ---------------
+// DOLFIN removes the slave dofs; here they stay in the vectors and the assembled system is folded instead: with P the
+// matrix that copies every master value to its slaves, A <- P^T A P + (unit diagonal on the slave rows), b <- P^T b (0 on
+// the slaves); the solution of the folded system carries the masters' values, which fs_vector_assign_entries then copies
+// to the slaves.  The sparsity pattern has to hold (master, fold(j)) for every neighbour j of a slave:
+// fs_space_create_coupled with those pairs.
+// Pass 1, lane = node row: the columns of slave nodes move to their masters' columns (one lane owns the row: no atomics).
+template <int BS>
+__global__ void __launch_bounds__(FS_BLOCK) k_tie_columns(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+                                                          const int32_t* __restrict__ sell_col, double* __restrict__ val,
+                                                          int64_t plane, const int32_t* __restrict__ master_of,
+                                                          int* __restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t r = s * FS_SLICE + lane;
+        if (r >= n_rows) continue;
+        const int64_t base = slice_ptr[s] + lane;
+        const int width = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            const int32_t c = sell_col[e];
+            if (c < 0) continue;
+            const int32_t m = master_of[c];
+            if (m < 0) continue;
+            int64_t em = -1;
+            for (int kk = 0; kk < width; ++kk)
+                if (sell_col[base + (int64_t)kk * FS_SLICE] == m) { em = base + (int64_t)kk * FS_SLICE; break; }
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < BS * BS; ++q) any = any || val[(int64_t)q * plane + e] != 0.0;
+            if (em < 0) {
+                if (any) atomicAdd(err, 1);
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < BS * BS; ++q) {
+                val[(int64_t)q * plane + em] += val[(int64_t)q * plane + e];
+                val[(int64_t)q * plane + e] = 0.0;
+            }
+        }
+    }
+}
+// Pass 2, thread = tied pair: the slave's row is added to its master's row (several slaves may share a master: atomics;
+// a handful of rows), the slave keeps a unit diagonal and a zero right-hand side.
+template <int BS>
+__global__ void k_tie_rows(int64_t n_pairs, const int32_t* __restrict__ slaves, const int32_t* __restrict__ masters,
+                           int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                           double* __restrict__ val, int64_t plane, double* __restrict__ b, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n_pairs; t += stride) {
+        const int64_t sl = slaves[t], ma = masters[t];
+        if (sl >= n_rows || ma >= n_rows) { atomicAdd(err, 1); continue; }
+        const int64_t sp_s = slice_ptr[sl >> 6], sp_m = slice_ptr[ma >> 6];
+        const int w_s = (int)((slice_ptr[(sl >> 6) + 1] - sp_s) >> 6), w_m = (int)((slice_ptr[(ma >> 6) + 1] - sp_m) >> 6);
+        const int64_t base_s = sp_s + (sl & 63), base_m = sp_m + (ma & 63);
+        for (int k = 0; k < w_s; ++k) {
+            const int64_t e = base_s + (int64_t)k * FS_SLICE;
+            const int32_t c = sell_col[e];
+            if (c < 0) continue;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < BS * BS; ++q) any = any || val[(int64_t)q * plane + e] != 0.0;
+            if (any) {
+                int64_t em = -1;
+                for (int kk = 0; kk < w_m; ++kk)
+                    if (sell_col[base_m + (int64_t)kk * FS_SLICE] == c) { em = base_m + (int64_t)kk * FS_SLICE; break; }
+                if (em < 0) { atomicAdd(err, 1); continue; }
+#pragma unroll
+                for (int q = 0; q < BS * BS; ++q) atomicAdd(&val[(int64_t)q * plane + em], val[(int64_t)q * plane + e]);
+            }
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) val[(int64_t)(i * BS + j) * plane + e] = (c == (int32_t)sl && i == j) ? 1.0 : 0.0;
+        }
+        if (b) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                atomicAdd(&b[ma * BS + i], b[sl * BS + i]);
+                b[sl * BS + i] = 0.0;
+            }
+        }
+    }
+}
+__global__ void k_fill_master_of(int64_t n_pairs, const int32_t* __restrict__ slaves, const int32_t* __restrict__ masters,
+                                 int32_t* __restrict__ master_of) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n_pairs; t += stride) master_of[slaves[t]] = masters[t];
+}
+
+extern "C" int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs, const int32_t* slaves, const int32_t* masters) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A && (n_pairs == 0 || (slaves && masters)), "fs_matrix_tie_nodes: null pointer");
+    if (n_pairs == 0) return FS_OK;
+    fs_space_s* sp = A->space;
+    FS_REQUIRE(!sp->halo.active, "fs_matrix_tie_nodes: tied nodes are built for one GPU");
+    FS_REQUIRE(A->bs >= 1 && A->bs <= 3, "fs_matrix_tie_nodes: block size %d", A->bs);
+    FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_matrix_tie_nodes: right-hand side too short");
+    for (int64_t i = 0; i < n_pairs; ++i)
+        FS_REQUIRE(slaves[i] >= 0 && slaves[i] < sp->n_nodes_owned && masters[i] >= 0 && masters[i] < sp->n_nodes_owned && slaves[i] != masters[i],
+                   "fs_matrix_tie_nodes: pair %lld (%d -> %d) out of range", (long long)i, slaves[i], masters[i]);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> d_s, d_m, master_of;
+    dbuf<int> d_err;
+    FS_CHECK(d_s.alloc(n_pairs)); FS_CHECK(d_m.alloc(n_pairs)); FS_CHECK(master_of.alloc(sp->n_nodes_local)); FS_CHECK(d_err.alloc(1));
+    FS_CHECK(d_s.upload(slaves, n_pairs, s)); FS_CHECK(d_m.upload(masters, n_pairs, s));
+    FS_CHECK(d_err.zero(s));
+    FS_HIP(hipMemsetAsync(master_of.p, 0xff, (size_t)sp->n_nodes_local * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_fill_master_of, dim3(fs_grid_for(n_pairs)), dim3(FS_BLOCK), 0, s, n_pairs, d_s.p, d_m.p, master_of.p);
+    const int grid = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192), gp = fs_grid_for(n_pairs);
+    double* bp = b ? b->d.p : nullptr;
+#define FS_TIE(BS_)                                                                                                                       \
+    {                                                                                                                                     \
+        hipLaunchKernelGGL(k_tie_columns<BS_>, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,        \
+                           sp->sell_col.p, A->val.p, sp->sell_entries, master_of.p, d_err.p);                                             \
+        hipLaunchKernelGGL(k_tie_rows<BS_>, dim3(gp), dim3(FS_BLOCK), 0, s, n_pairs, d_s.p, d_m.p, sp->n_nodes_owned, sp->slice_ptr.p,    \
+                           sp->sell_col.p, A->val.p, sp->sell_entries, bp, d_err.p);                                                      \
+    }
+    if (A->bs == 1) FS_TIE(1) else if (A->bs == 2) FS_TIE(2) else FS_TIE(3)
+#undef FS_TIE
+    FS_KERNEL_CHECK();
+    int h_err = 0;
+    FS_CHECK(d_err.download(&h_err, 1, s));
+    FS_REQUIRE(h_err == 0, "fs_matrix_tie_nodes: %d folded entries have no place in the sparsity pattern (create the space with fs_space_create_coupled and the (master, neighbour-of-slave) pairs)", h_err);
+    return FS_OK;
+}
+
 // ---- CSR export ---------------------------------------------------------------------------------------
 template <int BS>
 __global__ void k_export_csr(int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ rowptr,

@@ -211,6 +211,33 @@ __global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, int
     for (; i < n; i += stride) y[i] += a * x[i];
 }
 
+__global__ void k_assign_entries(double* __restrict__ v, int64_t n, const int32_t* __restrict__ dst, const int32_t* __restrict__ src, int bs) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n * bs; t += stride) {
+        const int64_t i = t / bs;
+        const int c = (int)(t - i * bs);
+        v[(int64_t)dst[i] * bs + c] = v[(int64_t)src[i] * bs + c];
+    }
+}
+
+extern "C" int fs_vector_assign_entries(fs_vector_t v, int64_t n, const int32_t* dst_nodes, const int32_t* src_nodes, int block) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(v && block >= 1 && (n == 0 || (dst_nodes && src_nodes)), "fs_vector_assign_entries: bad arguments");
+    if (n == 0) return FS_OK;
+    for (int64_t i = 0; i < n; ++i)
+        FS_REQUIRE(dst_nodes[i] >= 0 && src_nodes[i] >= 0 && ((int64_t)dst_nodes[i] + 1) * block <= v->d.n && ((int64_t)src_nodes[i] + 1) * block <= v->d.n,
+                   "fs_vector_assign_entries: pair %lld out of range", (long long)i);
+    hipStream_t s = fs_rt().stream;
+    dbuf<int32_t> d_d, d_s;
+    FS_CHECK(d_d.alloc(n)); FS_CHECK(d_s.alloc(n));
+    FS_CHECK(d_d.upload(dst_nodes, n, s)); FS_CHECK(d_s.upload(src_nodes, n, s));
+    hipLaunchKernelGGL(k_assign_entries, dim3(fs_grid_for(n * block)), dim3(FS_BLOCK), 0, s, v->d.p, n, d_d.p, d_s.p, block);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));      // the index buffers go back to the block cache
+    return FS_OK;
+}
+
 extern "C" int fs_vector_create(int64_t n, fs_vector_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(n >= 0 && out, "fs_vector_create: bad arguments");

@@ -598,12 +598,50 @@ class _Element:
         return self._n
 
 
+def periodic_vertex_pairs(mesh, pb):
+    """Slave / master vertex pairs of a periodic SubDomain, DOLFIN's rule (PeriodicBoundaryComputation): a boundary vertex
+    x with pb.inside(x, True) is a master; any other boundary vertex is a slave when y = pb.map(x, y) lands inside, tied
+    to the master vertex at y.  Chains (a master that is itself mapped, corners of doubly periodic domains) are followed
+    to their end."""
+    from scipy.spatial import cKDTree
+    if not hasattr(pb, "map"):
+        raise SolverError("periodic_boundary must be a SubDomain with inside(x, on_boundary) and map(x, y)")
+    co = mesh.coordinates()
+    bverts = np.unique(mesh.facets()[mesh.exterior_facets()].astype(np.int64).ravel())
+    inside = pb._inside_points(co[bverts], True)
+    masters_all, cand = bverts[inside], bverts[~inside]
+    if len(masters_all) == 0:
+        raise SolverError("periodic_boundary: inside() selects no boundary vertex")
+    y = co[cand].copy()
+    for i in range(len(cand)):
+        pb.map(co[cand[i]], y[i])
+    ok = pb._inside_points(y, True)
+    slaves, targets = cand[ok], y[ok]
+    if len(slaves) == 0:
+        raise SolverError("periodic_boundary: map() sends no boundary vertex onto the master part")
+    span = float(np.ptp(co, axis=0).max())
+    dist, idx = cKDTree(co[masters_all]).query(targets)
+    if dist.max() > 1e-8 * span:
+        raise SolverError("periodic_boundary: the meshes of the two sides do not match ({} slave vertices have no master "
+                          "within {:g})".format(int(np.count_nonzero(dist > 1e-8 * span)), 1e-8 * span))
+    masters = masters_all[idx]
+    fold = np.arange(mesh.num_vertices(), dtype=np.int64)
+    fold[slaves] = masters
+    for _ in range(8):                       # follow chains
+        nxt = fold[fold]
+        if np.array_equal(nxt, fold):
+            break
+        fold = nxt
+    return slaves.astype(np.int32), fold[slaves].astype(np.int32)
+
+
 class FunctionSpace:
     """dolfin.FunctionSpace / VectorFunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
     Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D P1, scalar or
     2-vector.
     Component i of node n of an ncomp-vector space is dof n*ncomp + i (DOLFIN interleaves the same way).
-    Not built: periodic constraints (constrained_domain raises), 2-D P2 spaces, degree > 2."""
+    Periodic constraints (constrained_domain): P1, one GPU, slave dofs kept and tied (see periodic_pairs()).
+    Not built: 2-D P2 spaces, degree > 2."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
                  _parent=None, _holder=False):
@@ -611,8 +649,11 @@ class FunctionSpace:
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
         if int(degree) not in (1, 2):
             raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and P2 only)".format(degree))
+        self._periodic = None
         if constrained_domain is not None:
-            raise SolverError("periodic_boundary (constrained_domain) is not supported")
+            if int(degree) != 1 or _holder:
+                raise SolverError("periodic_boundary (constrained_domain) is built for P1 spaces")
+            self._periodic = periodic_vertex_pairs(mesh, constrained_domain)
         if mesh.topology().dim() == 2 and (int(degree) != 1 or (_ncomp not in (1, 2) and not _holder)):
             raise SolverError("2-D (triangular) meshes carry P1 spaces (scalar or 2-vector) only in fenicssolver_amd")
         self._mesh = mesh
@@ -625,6 +666,32 @@ class FunctionSpace:
 
     def mesh(self):
         return self._mesh
+
+    def periodic_pairs(self):
+        """(slave vertices, master vertices) of the constrained_domain the space was built with, or None.  DOLFIN removes
+        the slave dofs from the space; here they stay (dim() is unchanged), the assembled system is folded onto the masters
+        on the device (fs_matrix_tie_nodes) and the slaves receive their masters' values after the solve."""
+        return self.root()._periodic
+
+    def _periodic_couplings(self):
+        """Node pairs the sparsity pattern needs for the folded system: (master, j) and (master, fold(j)) for every vertex
+        j sharing a cell with a slave of that master, the slave itself included."""
+        sl, ma = self.root()._periodic
+        nv = self._mesh.num_vertices()
+        fold = np.arange(nv, dtype=np.int64)
+        fold[sl] = ma
+        ce = self._mesh.cells().astype(np.int64)
+        is_slave = np.zeros(nv, dtype=bool)
+        is_slave[sl] = True
+        touched = ce[is_slave[ce].any(axis=1)]
+        k = touched.shape[1]
+        a = np.repeat(touched, k, axis=1).ravel()
+        b = np.tile(touched, (1, k)).ravel()
+        keep = is_slave[a]                       # b == a too: the slave's diagonal moves to (slave, master) first
+        m = fold[a[keep]]
+        pairs = np.concatenate([np.stack([m, b[keep]], axis=1), np.stack([m, fold[b[keep]]], axis=1)])
+        pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+        return np.unique(pairs, axis=0).astype(np.int32)
 
     def ufl_element(self):
         return self._ufl_element
@@ -745,11 +812,16 @@ class FunctionSpace:
             if parallel.active():
                 if facet_coupling:
                     raise SolverError("interior-facet (IP) terms are single-GPU for now")
+                if root._periodic is not None:
+                    raise SolverError("periodic_boundary (constrained_domain) is built for one GPU")
                 root._device = self._make_parallel_device(root, backend, parallel)
             else:
                 pairs = root._mesh.interior_facet_cells()[1] if facet_coupling else None
                 if facet_coupling and (root._degree != 1 or root._ncomp != 1):
                     raise SolverError("interior-facet (IP) terms are built for scalar P1 spaces")
+                if root._periodic is not None:
+                    extra = root._periodic_couplings()
+                    pairs = extra if pairs is None else np.concatenate([np.asarray(pairs, dtype=np.int32).reshape(-1, 2), extra])
                 root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree, coupled_pairs=pairs)
         return root._device
 
@@ -1032,6 +1104,34 @@ def nodal_values(value, V):
         vals = value.node_values()
         return vals if len(vals) == co.shape[0] else value.vertex_values()
     raise SolverError("cannot evaluate {} at the nodes of the space".format(type(value)))
+
+
+class Measure:
+    """dolfin.Measure("ds" | "dx" | "dS", subdomain_data=markers[, domain=mesh]): the integration measure the reference
+    builds for its boundary terms (ScalarTransportSolver.py:262, LinearElasticitySolver.py:210) and hands to
+    update_boundary_conditions.  ``ds(3)`` names the part marked 3: a (kind, marker_id, markers) record - what the
+    term descriptions of forms.py carry instead of UFL integrals; ``ds(3).facets()`` lists the marked entities."""
+
+    def __init__(self, kind, subdomain_data=None, domain=None, subdomain_id=None):
+        if kind not in ("dx", "ds", "dS"):
+            raise SolverError("Measure: integral type '{}' is not one of dx, ds, dS".format(kind))
+        self.kind, self.subdomain_data, self.domain, self.subdomain_id = kind, subdomain_data, domain, subdomain_id
+
+    def __call__(self, subdomain_id=None, domain=None, subdomain_data=None):
+        return Measure(self.kind, subdomain_data if subdomain_data is not None else self.subdomain_data,
+                       domain if domain is not None else self.domain, subdomain_id)
+
+    def integral_type(self):
+        return {"dx": "cell", "ds": "exterior_facet", "dS": "interior_facet"}[self.kind]
+
+    def facets(self):
+        """Indices of the marked entities (all of them for an unrestricted measure without markers)."""
+        if self.subdomain_data is None or self.subdomain_id is None:
+            raise SolverError("Measure.facets(): needs subdomain_data and a subdomain id")
+        return self.subdomain_data.where(self.subdomain_id)
+
+    def __repr__(self):
+        return "%s(%s)" % (self.kind, "" if self.subdomain_id is None else self.subdomain_id)
 
 
 class PointSource:

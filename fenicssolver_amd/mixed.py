@@ -30,6 +30,7 @@ class TaylorHoodSpace(FunctionSpace):
         self._component = None
         self._parent = None
         self._device = None
+        self._periodic = None
 
     def num_sub_spaces(self):
         return 2

@@ -152,6 +152,15 @@ int fs_matrix_axpy(fs_matrix_t Y, double a, fs_matrix_t X);
 /* dst = src (same space), enqueued on the library's stream: a time loop with constant coefficients keeps its
  * unconstrained operator and starts every step from a copy (DOLFIN re-assembles, SolverBase.py:592-602). */
 int fs_matrix_copy(fs_matrix_t dst, fs_matrix_t src);
+/* Periodic constraints (FunctionSpace(..., constrained_domain=pb), SolverBase.py:260-275): node slaves[i] takes the
+ * value of node masters[i] (chains resolved by the caller, a master is never a slave).  DOLFIN removes the slave dofs;
+ * here the assembled system is folded in place - A <- P^T A P with a unit diagonal on the slave rows, b <- P^T b with 0
+ * on the slaves (b may be NULL) - and after the solve fs_vector_assign_entries copies the masters' values to the
+ * slaves.  The pattern must hold (master, j) and (master, fold(j)) for every neighbour j of a slave: create the space
+ * with fs_space_create_coupled.  Apply before fs_apply_dirichlet.  One GPU. */
+int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs, const int32_t* slaves, const int32_t* masters);
+/* v[dst_nodes[i]*block + c] = v[src_nodes[i]*block + c], c < block. */
+int fs_vector_assign_entries(fs_vector_t v, int64_t n, const int32_t* dst_nodes, const int32_t* src_nodes, int block);
 /* Export as sorted-column CSR (any pointer may be NULL): rowptr[n_rows+1],
  * colidx[nnz], vals[nnz]. */
 int fs_matrix_get_csr(fs_matrix_t A, int32_t* rowptr, int32_t* colidx, double* vals);

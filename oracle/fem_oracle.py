@@ -1118,3 +1118,30 @@ def tri_von_mises_projection(coords, cells, u, E, nu):
     b = assemble_generic_vector(len(coords), ce, np.repeat((area / 3.0 * vm)[:, None], 3, axis=1))
     M = assemble_generic(len(coords), ce, tri_mass_local(coords, cells, 1.0))
     return solve_direct(M, b), b
+
+
+# ---- periodic constraints (FunctionSpace(..., constrained_domain=pb), SolverBase.py:260-275) ----------------------------
+def periodic_fold(A, b, slaves, masters, ncomp=1):
+    """The system DOLFIN assembles on a space without the slave dofs, written on the full dof set: with P copying every
+    master value to its slaves, (P^T A P + unit diagonal on the slave rows, P^T b with 0 on the slaves).  Solve it and
+    call periodic_expand.  slaves / masters are node indices; dof = node*ncomp + component."""
+    n = A.shape[0]
+    sl = (np.asarray(slaves, dtype=np.int64)[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel()
+    ma = (np.asarray(masters, dtype=np.int64)[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel()
+    target = np.arange(n)
+    target[sl] = ma
+    keep = np.ones(n)
+    keep[sl] = 0.0
+    P = sp.csr_matrix((np.ones(n), (np.arange(n), target)), shape=(n, n))      # u_full = P u_folded
+    Af = (P.T @ sp.csr_matrix(A) @ P + sp.diags(1.0 - keep)).tocsr()
+    bf = P.T @ np.asarray(b, dtype=np.float64)
+    bf[sl] = 0.0
+    Af.sum_duplicates()
+    Af.sort_indices()
+    return Af, bf
+
+
+def periodic_expand(u, slaves, masters, ncomp=1):
+    u = np.array(u, dtype=np.float64).reshape(-1, ncomp)
+    u[np.asarray(slaves, dtype=np.int64)] = u[np.asarray(masters, dtype=np.int64)]
+    return u.reshape(-1)

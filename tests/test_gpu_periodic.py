@@ -1,0 +1,166 @@
+"""Periodic constraints: FunctionSpace(mesh, ..., constrained_domain=pb) as SolverBase.generate_function_space builds it
+from settings['periodic_boundary'] (reference SolverBase.py:260-275).  DOLFIN removes the slave dofs; the GPU path folds
+the assembled system onto the masters (fs_matrix_tie_nodes) - checked against the same fold in scipy and a direct solve."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fem_oracle as fo
+
+pytestmark = pytest.mark.gpu
+QUIET = {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+
+
+def _csr(A):
+    rp, ci, va, shape = A.to_csr()
+    return sp.csr_matrix((va, ci, rp), shape=shape)
+
+
+def _periodic_x(length=1.0):
+    from fenicssolver_amd.fem import SubDomain, near
+
+    class PeriodicX(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0.0) and on_boundary
+
+        def map(self, x, y):
+            y[0] = x[0] - length
+            for i in range(1, len(x)):
+                y[i] = x[i]
+    return PeriodicX()
+
+
+@pytest.mark.parametrize("ncomp", [1, 3])
+def test_folded_system_matches_the_oracle_fold(gpu, ncomp):
+    from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, VectorFunctionSpace
+    mesh = BoxMesh(Point(0, 0, 0), Point(1.0, 0.8, 0.6), 6, 5, 4)
+    pb = _periodic_x()
+    V = FunctionSpace(mesh, "CG", 1, constrained_domain=pb) if ncomp == 1 else VectorFunctionSpace(mesh, "CG", 1, constrained_domain=pb)
+    sl, ma = V.periodic_pairs()
+    co, ce = mesh.coordinates(), mesh.cells()
+    assert len(sl) == 6 * 5 and np.allclose(co[sl, 0], 1.0) and np.allclose(co[ma, 0], 0.0) and np.allclose(co[sl, 1:], co[ma, 1:])
+    dV = V.device()
+    A = gpu.DeviceMatrix(dV)
+    b = gpu.DeviceVector(dV.n_owned)
+    rng = np.random.default_rng(3)
+    if ncomp == 1:
+        A.assemble(stiffness=2.0, mass=0.7)
+        ref = fo.assemble_p1_scalar(co, ce, 2.0, mass_coef=0.7)
+        fn = np.sin(2 * np.pi * co[:, 0]) * (1 + co[:, 1])
+        gpu.assemble_vector(dV, b, source=("nodal", fn))
+        rhs = fo.assemble_p1_source(co, ce, f_nodal=fn)
+    else:
+        mu, lm = fo.lame(10.0, 0.3)
+        A.assemble(lame=(mu, lm), mass=0.5)
+        M = fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 0.5))
+        ref = fo.assemble_p1_elasticity(co, ce, 10.0, 0.3) + sp.kron(M, sp.identity(3), format="csr")
+        gpu.assemble_vector(dV, b, vector_value=(0.2, -1.0, 0.4))
+        rhs = fo.assemble_p1_vector_source(co, ce, (0.2, -1.0, 0.4))
+    assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+    A.tie_nodes(b, sl, ma)
+    Af, bf = fo.periodic_fold(ref, rhs, sl, ma, ncomp)
+    got = _csr(A)
+    assert abs(got - Af).max() <= 1e-12 * abs(ref).max()
+    assert np.abs(b.get() - bf).max() <= 1e-12 * np.abs(rhs).max()
+    assert abs(got - got.T).max() <= 1e-12 * abs(ref).max()
+    x = gpu.DeviceVector(dV.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-12, max_iter=5000)
+    assert st["converged"] == 1
+    x.assign_entries(sl, ma, block=ncomp)
+    want = fo.periodic_expand(fo.solve_direct(Af, bf), sl, ma, ncomp)
+    assert np.abs(x.get() - want).max() <= 1e-8 * np.abs(want).max()
+    u = x.get().reshape(-1, ncomp)
+    assert np.array_equal(u[sl], u[ma])
+
+
+def test_tie_nodes_needs_the_coupled_pattern(gpu):
+    """Without the (master, neighbour-of-slave) couplings the fold has nowhere to put its entries: loud failure."""
+    co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), 3, 3, 3)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=1.0)
+    sl = np.nonzero(np.abs(co[:, 0] - 1.0) < 1e-12)[0]
+    ma = np.array([np.nonzero((np.abs(co[:, 0]) < 1e-12) & (np.abs(co[:, 1:] - co[s, 1:]).max(axis=1) < 1e-12))[0][0] for s in sl])
+    with pytest.raises(gpu.BackendError, match="sparsity pattern"):
+        A.tie_nodes(None, sl, ma)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_scalar_solver_with_periodic_boundary(gpu, dim):
+    """settings['periodic_boundary'] through ScalarTransportSolver: a source that is periodic in x, walls held at fixed
+    temperatures in y; the solution equals the oracle's (same fold, direct solve) and is periodic."""
+    from fenicssolver_amd.fem import UnitSquareMesh, UnitCubeMesh, AutoSubDomain, Expression, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh = UnitSquareMesh(12, 10) if dim == 2 else UnitCubeMesh(8, 6, 5)
+    pb = _periodic_x()
+    src = Expression("100*sin(2*pi*x[0])*x[1]", degree=1)
+    bcs = OrderedDict()
+    bcs["bottom"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(300.0)}
+    bcs["top"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant(310.0)}
+    settings = {'solver_name': 'ScalarTransportSolver', 'mesh': mesh, 'function_space': None, 'periodic_boundary': pb,
+                'fe_family': 'CG', 'fe_degree': 1, 'boundary_conditions': bcs, 'body_source': src,
+                'initial_values': {'temperature': 300}, 'material': {'density': 1.0, 'specific_heat_capacity': 1.0, 'thermal_conductivity': 0.5},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'relative_tolerance': 1e-9, 'maximum_iterations': 5000, 'krylov_relative_tolerance': 1e-12}},
+                'report_settings': QUIET, 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    sl, ma = solver.function_space.periodic_pairs()
+    T = solver.solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    n = len(co)
+    fn = 100 * np.sin(2 * np.pi * co[:, 0]) * co[:, 1]
+    if dim == 2:
+        K = fo.assemble_generic(n, ce, fo.tri_stiffness_local(co, ce, 0.5))
+        rhs = fo.assemble_tri_source(co, ce, f_nodal=fn)
+    else:
+        K = fo.assemble_p1_scalar(co, ce, 0.5)
+        rhs = fo.assemble_p1_source(co, ce, f_nodal=fn)
+    Af, bf = fo.periodic_fold(K, rhs, sl, ma)
+    lo, hi = np.nonzero(np.abs(co[:, 1]) < 1e-12)[0], np.nonzero(np.abs(co[:, 1] - 1.0) < 1e-12)[0]
+    Ab, bb = fo.apply_dirichlet(Af, bf, np.concatenate([lo, hi]), np.concatenate([np.full(len(lo), 300.0), np.full(len(hi), 310.0)]), symmetric=True)
+    want = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma)
+    assert np.abs(T - want).max() <= 1e-7 * np.abs(want).max()
+    assert np.array_equal(T[sl], T[ma])
+    # the constraint matters: without it the x-faces are insulated and the answer is different
+    free = fo.apply_dirichlet(K, rhs, np.concatenate([lo, hi]), np.concatenate([np.full(len(lo), 300.0), np.full(len(hi), 310.0)]), symmetric=True)
+    assert np.abs(fo.solve_direct(*free) - want).max() > 1e-3
+
+
+def test_transient_periodic_matches_oracle_time_stepping(gpu):
+    """Crank-Nicolson with a periodic x direction (the kept-operator path of the time loop folds a fresh copy every step):
+    three steps against the same recurrence in scipy."""
+    from fenicssolver_amd.fem import UnitSquareMesh, AutoSubDomain, Expression, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh = UnitSquareMesh(10, 8)
+    pb = _periodic_x()
+    bcs = OrderedDict()
+    bcs["bottom"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(300.0)}
+    k, rho_c, dt, steps = 0.5, 2.0, 0.05, 3
+    settings = {'solver_name': 'ScalarTransportSolver', 'mesh': mesh, 'function_space': None, 'periodic_boundary': pb,
+                'fe_family': 'CG', 'fe_degree': 1, 'boundary_conditions': bcs,
+                'body_source': Expression("50*cos(2*pi*x[0])", degree=1),
+                'initial_values': {'temperature': 300}, 'material': {'density': rho_c, 'specific_heat_capacity': 1.0, 'thermal_conductivity': k},
+                'solver_settings': {'transient_settings': {'transient': True, 'starting_time': 0, 'time_step': dt, 'ending_time': dt * steps - 1e-9},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'relative_tolerance': 1e-9, 'maximum_iterations': 5000, 'krylov_relative_tolerance': 1e-13}},
+                'report_settings': QUIET, 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    sl, ma = solver.function_space.periodic_pairs()
+    T = solver.solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    n = len(co)
+    K = fo.assemble_generic(n, ce, fo.tri_stiffness_local(co, ce, k))
+    M = fo.assemble_generic(n, ce, fo.tri_mass_local(co, ce, rho_c / dt))
+    f = fo.assemble_tri_source(co, ce, f_nodal=50 * np.cos(2 * np.pi * co[:, 0]))
+    lo = np.nonzero(np.abs(co[:, 1]) < 1e-12)[0]
+    Tn = np.full(n, 300.0)
+    for _ in range(steps):
+        Af, bf = fo.periodic_fold(M + 0.5 * K, f + (M - 0.5 * K) @ Tn, sl, ma)
+        Ab, bb = fo.apply_dirichlet(Af, bf, lo, np.full(len(lo), 300.0), symmetric=True)
+        Tn = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma)
+    assert np.abs(T - Tn).max() <= 1e-8 * 300.0 and np.array_equal(T[sl], T[ma])
+    assert np.abs(Tn - 300.0).max() > 0.05

@@ -567,3 +567,67 @@ def test_time_grid_and_value_rules():
     assert case.boundary_variable({'type': 'a', 'values': {'temperature': {'type': 'b'}}}, 'temperature') == {'type': 'b'}
     assert case.boundary_variable({'type': 'a', 'values': [{'variable': 'velocity', 'type': 'c'}]}, 'velocity')['type'] == 'c'
     assert case.boundary_variable({'type': 'a', 'values': {'pressure': {}}}, 'temperature')['type'] == 'a'
+
+
+def test_measure_names_marked_boundary_parts():
+    """dolfin.Measure as the reference uses it: ds = Measure("ds", subdomain_data=boundary_facets); ds(i) (SolverBase users
+    get it as the 4th argument of update_boundary_conditions)."""
+    from fenicssolver_amd.fem import UnitCubeMesh, MeshFunction, AutoSubDomain, Measure, SolverError, near
+    mesh = UnitCubeMesh(2, 2, 2)
+    mf = MeshFunction("size_t", mesh, 2)
+    mf.set_all(0)
+    AutoSubDomain(lambda x: near(x[0], 0.0)).mark(mf, 4)
+    ds = Measure("ds", subdomain_data=mf)
+    part = ds(4)
+    assert part.subdomain_id == 4 and part.integral_type() == "exterior_facet" and repr(part) == "ds(4)"
+    assert len(part.facets()) == 8 and np.array_equal(part.facets(), mf.where(4))
+    assert ds.subdomain_id is None and Measure("dx", domain=mesh)(1).integral_type() == "cell"
+    with pytest.raises(SolverError):
+        Measure("dq")
+    with pytest.raises(SolverError):
+        ds.facets()
+
+
+def test_periodic_vertex_pairs_follow_dolfins_rule():
+    """constrained_domain: masters = boundary vertices inside(); a slave is a boundary vertex whose map() lands inside;
+    doubly periodic corners fold onto one master; unmatched meshes and empty selections are errors."""
+    from fenicssolver_amd.fem import UnitSquareMesh, FunctionSpace, SubDomain, SolverError, near, periodic_vertex_pairs
+
+    class PX(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[0], 0.0) and on_boundary
+
+        def map(self, x, y):
+            y[0], y[1] = x[0] - 1.0, x[1]
+
+    class PXY(SubDomain):          # the doubly periodic square of the DOLFIN demos: left and bottom edges are masters
+        def inside(self, x, on_boundary):
+            return bool((near(x[0], 0) or near(x[1], 0)) and not ((near(x[0], 0) and near(x[1], 1)) or (near(x[0], 1) and near(x[1], 0))) and on_boundary)
+
+        def map(self, x, y):
+            if near(x[0], 1) and near(x[1], 1):
+                y[0], y[1] = x[0] - 1.0, x[1] - 1.0
+            elif near(x[0], 1):
+                y[0], y[1] = x[0] - 1.0, x[1]
+            else:
+                y[0], y[1] = x[0], x[1] - 1.0
+    mesh = UnitSquareMesh(4, 3)
+    co = mesh.coordinates()
+    sl, ma = periodic_vertex_pairs(mesh, PX())
+    assert len(sl) == 4 and np.allclose(co[sl, 0], 1.0) and np.allclose(co[ma, 0], 0.0) and np.allclose(co[sl, 1], co[ma, 1])
+    sl2, ma2 = periodic_vertex_pairs(mesh, PXY())
+    assert len(sl2) == 4 + 5 - 1 and not set(sl2) & set(ma2)      # right edge + top edge, the corner (1, 1) once
+    corner = {tuple(co[s]): tuple(co[m]) for s, m in zip(sl2, ma2)}
+    assert corner[(1.0, 1.0)] == (0.0, 0.0) and corner[(1.0, 0.0)] == (0.0, 0.0) and corner[(0.0, 1.0)] == (0.0, 0.0)
+    V = FunctionSpace(mesh, "CG", 1, constrained_domain=PX())
+    assert V.dim() == mesh.num_vertices() and np.array_equal(V.periodic_pairs()[0], sl)
+    pairs = V._periodic_couplings()
+    assert pairs.shape[1] == 2 and set(pairs[:, 0]) <= set(ma)
+    with pytest.raises(SolverError):
+        FunctionSpace(mesh, "CG", 2, constrained_domain=PX())
+
+    class Shifted(PX):
+        def map(self, x, y):
+            y[0], y[1] = x[0] - 1.0, x[1] + 0.01
+    with pytest.raises(SolverError):
+        periodic_vertex_pairs(mesh, Shifted())
