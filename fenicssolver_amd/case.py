@@ -48,18 +48,20 @@ _XDMF_CELLS = {"tetrahedron": 4, "tet": 4, "triangle": 3}
 
 
 def _xdmf_numbers(item, path, dtype):
-    """The numbers of a <DataItem>: inline text (Format="XML") only - heavy data in a side HDF5 file needs h5py."""
+    """The numbers of a <DataItem>: inline text (Format="XML") or a dataset of a side HDF5 file (Format="HDF",
+    text ``file.h5:/dataset``, read through libhdf5 - fenicssolver_amd/hdf5io.py)."""
     fmt = (item.get("Format") or "XML").upper()
+    if fmt in ("HDF", "HDF5"):
+        from . import hdf5io
+        return hdf5io.read_dataset(item.text or "", relative_to=os.path.dirname(os.path.abspath(path))).astype(dtype).ravel()
     if fmt != "XML":
-        raise SolverError("{}: DataItem Format=\"{}\" points into an HDF5 file; h5py is not available here - write the XDMF "
-                          "with ASCII encoding (XDMFFile.Encoding_ASCII / meshio --ascii) or convert to DOLFIN XML".format(
-                              path, item.get("Format")))
+        raise SolverError("{}: DataItem Format=\"{}\" is not supported (XML or HDF)".format(path, item.get("Format")))
     return np.array((item.text or "").split(), dtype=dtype)
 
 
 def read_xdmf(path):
-    """XDMF with inline (ASCII) DataItems, as DOLFIN writes with ASCII encoding (SolverBase.py:246-252 reads the mesh
-    only; cell / facet markers come from ``SubDomain.mark`` afterwards).  One uniform grid of tetrahedra or triangles.
+    """XDMF (SolverBase.py:246-252 reads the mesh only; cell / facet markers come from ``SubDomain.mark`` afterwards):
+    DataItems inline (ASCII encoding) or in the side HDF5 file DOLFIN / meshio write by default.  One uniform grid of tetrahedra or triangles.
     A cell-centred integer <Attribute> (meshio / gmsh physical groups) is taken as the subdomain markers."""
     try:
         root = ET.parse(path).getroot()
@@ -101,8 +103,21 @@ def read_xdmf(path):
 
 
 def read_hdf5(path):
-    raise SolverError("{}: DOLFIN HDF5 meshes (/mesh, /subdomains, /boundaries; SolverBase.py:203-221) need an HDF5 reader; "
-                      "h5py is not available in this environment - convert to DOLFIN XML or ASCII XDMF".format(path))
+    """DOLFIN's HDF5File layout (SolverBase._read_hdf5_mesh, :203-221): /mesh, and the mesh functions /subdomains (cells)
+    and /boundaries (facets) when present - matched to this build's entity numbering by their vertex tuples."""
+    from . import hdf5io
+    coords, cells, facet_values, cell_values = hdf5io.read_dolfin_mesh(path)
+    if cells.size and (cells.min() < 0 or cells.max() >= len(coords)):
+        raise SolverError("{}: /mesh/topology names vertex {} of {}".format(path, int(cells.max()), len(coords)))
+    mesh = Mesh(coords=coords, cells=cells)
+    fm = cm = None
+    if facet_values is not None:
+        fm = MeshFunction("size_t", mesh, mesh.topology().dim() - 1)
+        fm.array()[:] = facet_values(mesh.facets())
+    if cell_values is not None:
+        cm = MeshFunction("size_t", mesh, mesh.topology().dim())
+        cm.array()[:] = cell_values(mesh.cells())
+    return MeshBundle(mesh, fm, cm)
 
 
 MESH_READERS = ((".xdmf", read_xdmf), (".xml", read_dolfin_xml), (".h5", read_hdf5), (".hdf5", read_hdf5))

@@ -499,7 +499,7 @@ def _write_ascii_xdmf(path, co, ce, cell_attr=None, fmt="XML"):
 
 def test_xdmf_mesh_reader_and_settings_paths(tmp_path):
     """settings['mesh'] = 'case.xdmf' (SolverBase.py:246-252): ASCII XDMF is read, markers come from the SubDomains;
-    HDF5-backed XDMF / .h5 files say what is missing instead of guessing; periodic boundaries are refused loudly."""
+    HDF5-backed XDMF goes through libhdf5; broken files and a periodic_boundary without map() are refused loudly."""
     import copy
     from collections import OrderedDict
     from fenicssolver_amd import SolverBase as SB, case
@@ -536,18 +536,24 @@ def test_xdmf_mesh_reader_and_settings_paths(tmp_path):
     _write_ascii_xdmf(p2, co2, ce2)
     m2 = case.read_mesh_file(p2).mesh
     assert m2.topology().dim() == 2 and np.array_equal(m2.coordinates(), co2)
-    # heavy data in HDF5: loud, with the way out
+    # heavy data in a side HDF5 file (what DOLFIN and meshio write by default): read through libhdf5
+    from fenicssolver_amd import hdf5io
+    with hdf5io.H5File(str(tmp_path / "mesh.h5"), "w") as h5:
+        h5.write("/Mesh/mesh/topology", ce[perm][:, ::-1])
+        h5.write("/Mesh/mesh/geometry", co)
     p3 = str(tmp_path / "h5.xdmf")
     _write_ascii_xdmf(p3, co, ce, fmt="HDF")
-    for bad in (p3,):
-        with pytest.raises(SolverError, match="h5py"):
-            case.read_mesh_file(bad)
+    m3 = case.read_mesh_file(p3).mesh
+    assert np.array_equal(m3.coordinates(), co) and np.array_equal(m3.cells(), m.cells())
+    os.remove(str(tmp_path / "mesh.h5"))
+    with pytest.raises(SolverError, match="mesh.h5"):
+        case.read_mesh_file(p3)
     open(str(tmp_path / "m.h5"), "wb").write(b"\x89HDF\r\n\x1a\n")
     with pytest.raises(SolverError, match="HDF5"):
         case.read_mesh_file(str(tmp_path / "m.h5"))
     with pytest.raises(SolverError):
         case.read_mesh_file(str(tmp_path / "missing.xml"))
-    # periodic_boundary is not built: refused, not ignored (SolverBase.py:260-275)
+    # a periodic_boundary must be able to map slaves onto masters (SolverBase.py:260-275)
     s2 = copy.deepcopy(SB.default_case_settings)
     s2.update(mesh=path, scalar_name="temperature", boundary_conditions=bcs, material=s['material'], report_settings=s['report_settings'],
               periodic_boundary=AutoSubDomain(lambda x: near(x[0], 0.0)))
@@ -631,3 +637,62 @@ def test_periodic_vertex_pairs_follow_dolfins_rule():
             y[0], y[1] = x[0] - 1.0, x[1] + 0.01
     with pytest.raises(SolverError):
         periodic_vertex_pairs(mesh, Shifted())
+
+
+def test_dolfin_hdf5_mesh_files(tmp_path):
+    """settings['mesh'] = 'case.h5' (SolverBase._read_hdf5_mesh, :203-221): /mesh, /boundaries, /subdomains in DOLFIN's
+    HDF5File layout, written here through the same libhdf5 and read back; markers are matched by vertex tuples, so a file
+    whose entities are listed in another order (and with their vertices permuted) gives the same MeshFunctions."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd import SolverBase as SB, case, hdf5io
+    from fenicssolver_amd.fem import UnitCubeMesh, UnitSquareMesh, MeshFunction, AutoSubDomain, Constant, SolverError, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    for mesh in (UnitCubeMesh(3, 2, 2), UnitSquareMesh(4, 3)):
+        td = mesh.topology().dim()
+        fm = MeshFunction("size_t", mesh, td - 1)
+        fm.set_all(0)
+        AutoSubDomain(lambda x: near(x[0], 0.0)).mark(fm, 5)
+        AutoSubDomain(lambda x: near(x[1], 1.0)).mark(fm, 7)
+        cm = MeshFunction("size_t", mesh, td)
+        cm.set_all(0)
+        cm.array()[::3] = 2
+        path = str(tmp_path / ("m%d.h5" % td))
+        hdf5io.write_dolfin_mesh(path, mesh, fm, cm)
+        with hdf5io.H5File(path) as f:
+            assert sorted(f.keys("/")) == ["boundaries", "mesh", "subdomains"] and f.has("/mesh/topology") and not f.has("/mesh/nope")
+            assert f.read("/mesh/coordinates").shape == mesh.coordinates().shape
+        b = case.read_mesh_file(path)
+        assert np.array_equal(b.mesh.coordinates(), mesh.coordinates()) and np.array_equal(b.mesh.cells(), mesh.cells())
+        assert np.array_equal(b.facet_markers.array(), fm.array()) and np.array_equal(b.cell_markers.array(), cm.array())
+        # the same content, entities shuffled and their vertices reversed
+        rng = np.random.default_rng(1)
+        sel = np.nonzero(fm.array())[0]
+        pf = rng.permutation(len(sel))
+        with hdf5io.H5File(path, "w") as f:
+            f.write("/mesh/coordinates", mesh.coordinates())
+            f.write("/mesh/topology", mesh.cells())
+            f.write("/boundaries/topology", mesh.facets()[sel][pf][:, ::-1])
+            f.write("/boundaries/values", fm.array()[sel][pf])
+        b2 = case.read_mesh_file(path)
+        assert np.array_equal(b2.facet_markers.array(), fm.array()) and b2.cell_markers is None
+    # through the solver class: markers come from the file, not from the SubDomains
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update(mesh=str(tmp_path / "m3.h5"), scalar_name="temperature", report_settings=dict(logging_level=50, logging_file=None, plotting_freq=0, saving_freq=0))
+    bcs = OrderedDict()
+    bcs["left"] = {'boundary_id': 5, 'type': 'Dirichlet', 'value': Constant(350)}
+    bcs["back"] = {'boundary_id': 7, 'type': 'Dirichlet', 'value': 300}
+    s['boundary_conditions'] = bcs
+    s['material'] = {'thermal_conductivity': 20.0, 'density': 1.0, 'specific_heat_capacity': 1.0}
+    solver = ScalarTransportSolver(s)
+    assert np.count_nonzero(solver.boundary_facets.array() == 5) == 2 * 2 * 2
+    F, dbc = solver.generate_form(0, None, None, None, None)
+    assert [len(b.dofs) for b in dbc] == [9, 12]
+    # a marker entity that is not in the mesh is an error, not a silent drop
+    with hdf5io.H5File(str(tmp_path / "bad.h5"), "w") as f:
+        f.write("/mesh/coordinates", mesh.coordinates())
+        f.write("/mesh/topology", mesh.cells())
+        f.write("/boundaries/topology", np.array([[0, 19]]))
+        f.write("/boundaries/values", np.array([3]))
+    with pytest.raises(SolverError, match="not facets"):
+        case.read_mesh_file(str(tmp_path / "bad.h5"))
