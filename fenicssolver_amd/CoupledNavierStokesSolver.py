@@ -16,10 +16,13 @@ ALE reference frames with a constant ``mesh_velocity`` (:321-329), ``viscous_str
 nu (grad u + grad u^T) - p I onto CG1, nine mass-matrix solves on the device), ``boundary_traction`` and
 ``calc_drag_and_lift`` (the reference's versions reference an undefined ``self.ds`` and index symbols, Appendix B-Q13;
 the evident intent is built: facet integrals of the projected stress over ``boundary_facets``).
-Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), G2 stabilisation
-(its transient branch reads an undefined ``time_iter_``, B-Q13, and its Newton linearisation would have to differentiate
-the stabilisation parameter), non-constant mesh velocities, non-Newtonian viscosity, the coupled temperature equation
-(marked "test not passed" in the reference).
+G2 stabilisation (``advection_settings = {'stabilization_method': 'G2', 'Re':, 'kappa1':, 'kappa2':}``, :334-363):
+F -= delta1 (a.grad u).(a.grad v) dx with the reference's sign and its delta1 (kappa1 h^2 for Re <= 1, kappa1/2 h/|a|
+otherwise; the transient branch, where the reference reads an undefined ``time_iter_`` and raises NameError, uses the
+step's dt in its formula).  The term enters the Jacobian with the advecting velocity frozen at the iterate; the system is
+written for the new iterate, so the Newton residual is the exact one and the fixed point is the reference's.
+Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
+velocities, non-Newtonian viscosity, the coupled temperature equation (marked "test not passed" in the reference).
 """
 from __future__ import annotations
 
@@ -34,7 +37,7 @@ from . import forms
 
 
 class CoupledNavierStokesSolver(SolverBase):
-    """incompressible and laminar flow (the reference's G2 stabilisation is not built)"""
+    """incompressible and laminar flow"""
 
     def __init__(self, case_input):
         self.solving_temperature = bool(case_input.get('solving_temperature', False)) if isinstance(case_input, dict) else False
@@ -125,7 +128,14 @@ class CoupledNavierStokesSolver(SolverBase):
                 mv = mv(self.get_current_time())
             F.mesh_velocity = self._vector3(mv, "reference_frame_settings['mesh_velocity'] (a constant vector)")
         ads = self.settings.get('advection_settings') or {}
-        if ads.get('stabilization_method'):
+        if ads.get('stabilization_method') == 'G2':
+            # F -= delta1 inner(dot(a, grad(u)), dot(a, grad(v))) dx (:334-363); delta2 / kappa2 only enter the density
+            # term the reference leaves commented out
+            for key in ('Re', 'kappa1'):
+                if key not in ads:
+                    raise SolverError("advection_settings for G2 need '{}' (the reference reads Re, kappa1, kappa2)".format(key))
+            F.g2 = (1 if float(ads['Re']) <= 1 else 2, float(ads['kappa1']))
+        elif ads.get('stabilization_method'):
             raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
         if self.transient_settings['transient']:
             F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:367-381)

@@ -742,7 +742,8 @@ class SolverBase():
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
                                        convection=True, newton=newton,
-                                       mesh_velocity=F.mesh_velocity if F.mesh_velocity is not None else (0.0, 0.0, 0.0))
+                                       mesh_velocity=F.mesh_velocity if F.mesh_velocity is not None else (0.0, 0.0, 0.0),
+                                       g2=getattr(F, 'g2', None))
         for marker_id, value in F.pressure_boundaries:
             cells, opp, centroids = self._marked_facet_cells(marker_id)
             if loc is not None:                 # facets whose cell is local; rows of other ranks are skipped on the device

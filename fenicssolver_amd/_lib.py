@@ -61,7 +61,8 @@ class fs_krylov_stats(C.Structure):
 
 class fs_ns_form(C.Structure):
     _fields_ = [("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
-                ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int), ("mesh_velocity", C.c_double * 3)]
+                ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int), ("mesh_velocity", C.c_double * 3),
+                ("g2_mode", C.c_int), ("g2_kappa1", C.c_double)]
 
 
 class fs_saddle_opts(C.Structure):

@@ -495,14 +495,17 @@ class AMG(_Handle):
 
 
 def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, body_force=(0.0, 0.0, 0.0),
-                           convection=True, newton=True, mesh_velocity=(0.0, 0.0, 0.0)):
-    """Linearised Taylor-Hood system at the state w0 (J w_new = g), J on a DeviceSpace(mesh, ncomp=4, degree=2)."""
+                           convection=True, newton=True, mesh_velocity=(0.0, 0.0, 0.0), g2=None):
+    """Linearised Taylor-Hood system at the state w0 (J w_new = g), J on a DeviceSpace(mesh, ncomp=4, degree=2).
+    g2 = (mode, kappa1): the G2 streamline term (mode 1: Re <= 1, 2: convection dominated)."""
     f = L.fs_ns_form()
     f.kinematic_viscosity, f.density, f.inv_dt = float(nu), float(rho), float(inv_dt)
     for i in range(3):
         f.body_force[i] = float(body_force[i])
         f.mesh_velocity[i] = float(mesh_velocity[i])
     f.convection, f.newton = (1 if convection else 0), (1 if newton else 0)
+    if g2 is not None:
+        f.g2_mode, f.g2_kappa1 = int(g2[0]), float(g2[1])
     L.check(L.load().fs_assemble_navier_stokes(J.h, g.h, w0.h if w0 is not None else None,
                                                w_prev.h if w_prev is not None else None, C.byref(f)),
             "fs_assemble_navier_stokes")

@@ -74,7 +74,30 @@ struct ns_params {
     double f[3];
     double wm[3];      // ALE: the frame (mesh) velocity, subtracted from the ADVECTING velocity only (:321-329)
     int convection, newton;
+    int g2;            // G2 streamline term (:334-363): 0 off, 1 delta1 = kappa1 h^2 (Re <= 1), 2 delta1 from |a|, h (and dt)
+    double g2_kappa;
 };
+
+// h = 2 * circumradius of the tetrahedron X (UFL's 2*Circumradius(mesh), :343):
+// R = sqrt((aA+bB+cC)(aA+bB-cC)(aA-bB+cC)(-aA+bB+cC)) / (24 V), (a,A) (b,B) (c,C) the opposite edge pairs
+__device__ __forceinline__ double ns_cell_h(const double (&X)[4][3], double vol) {
+    auto dist = [&](int p, int q) {
+        const double dx = X[p][0] - X[q][0], dy = X[p][1] - X[q][1], dz = X[p][2] - X[q][2];
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    const double aA = dist(0, 1) * dist(2, 3), bB = dist(0, 2) * dist(1, 3), cC = dist(0, 3) * dist(1, 2);
+    const double prod = (aA + bB + cC) * (aA + bB - cC) * (aA - bB + cC) * (-aA + bB + cC);
+    return 2.0 * sqrt(prod > 0.0 ? prod : 0.0) / (24.0 * vol);
+}
+// delta1 of the reference's G2 term at a point with advecting velocity a (|a|^2 = U2): kappa1 h^2 for Re <= 1, otherwise
+// kappa1/2 * h/|a| (steady) or kappa1/2 / sqrt(1/dt^2 + 1/(|a|^2 h^2)) (transient, as the reference writes it).  The
+// term delta1 (a.grad u)(a.grad v) vanishes with |a|: delta1 = 0 where a = 0 (UFL would divide by zero there).
+__device__ __forceinline__ double ns_g2_delta(const ns_params& P, double h, double U2) {
+    if (P.g2 == 1) return P.g2_kappa * h * h;
+    if (U2 <= 0.0) return 0.0;
+    if (P.inv_dt != 0.0) return 0.5 * P.g2_kappa / sqrt(P.inv_dt * P.inv_dt + 1.0 / (U2 * h * h));
+    return 0.5 * P.g2_kappa * h / sqrt(U2);
+}
 
 // thread t = ab*nc + c : block (a, b) of cell c.  val planes [(i*4+j)*plane + slot], g [node*4 + i]
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
@@ -119,6 +142,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
             gl[0][k] = -(gl[1][k] + gl[2][k] + gl[3][k]);
         }
         const double vol = fabs(det) * (1.0 / 6.0);
+        const double hcell = P.g2 ? ns_cell_h(X, vol) : 0.0;
         // state at the cell nodes
         double U0[10][3];
         if (P.convection) {
@@ -156,7 +180,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
                         for (int j = 0; j < 3; ++j) gu0[i][j] += U0[n][i] * gn[j];
                     }
                 }
-                diag += pa * ((u0[0] - P.wm[0]) * gb[0] + (u0[1] - P.wm[1]) * gb[1] + (u0[2] - P.wm[2]) * gb[2]);
+                const double av[3] = {u0[0] - P.wm[0], u0[1] - P.wm[1], u0[2] - P.wm[2]};
+                const double agb = av[0] * gb[0] + av[1] * gb[1] + av[2] * gb[2];
+                diag += pa * agb;
+                if (P.g2) {      // F -= delta1 (a.grad u).(a.grad v) dx, the sign as the reference has it (:360-362)
+                    const double aga = av[0] * ga[0] + av[1] * ga[1] + av[2] * ga[2];
+                    diag -= ns_g2_delta(P, hcell, av[0] * av[0] + av[1] * av[1] + av[2] * av[2]) * aga * agb;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -250,7 +280,7 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     for (int64_t cbase = (int64_t)blockIdx.x * NS_WPB; cbase < nc; cbase += (int64_t)gridDim.x * NS_WPB) {
         const int64_t c = cbase + wave;
         const bool act = c < nc;
-        double gl[4][3], vol = 0.0;
+        double gl[4][3], vol = 0.0, hcell = 0.0;
         if (act) {
             // node ids and nodal state -> LDS; geometry in registers (every lane, broadcast loads)
             if (lane < 10) L.nd[lane] = cell_dofs[c * 10 + lane];
@@ -283,6 +313,7 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 gl[0][k] = -(gl[1][k] + gl[2][k] + gl[3][k]);
             }
             vol = fabs(det) * (1.0 / 6.0);
+            if (P.g2) hcell = ns_cell_h(X, vol);
             // basis functions and gradients at the 14 points
             for (int item = lane; item < 140; item += 64) {
                 const int q = item / 10, n = item - 10 * q;
@@ -337,7 +368,15 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     const double gb[3] = {L.gphi[q][b][0], L.gphi[q][b][1], L.gphi[q][b][2]};
                     const double u0[3] = {L.u0[q][0], L.u0[q][1], L.u0[q][2]};
                     double diag = P.nu * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]) + P.inv_dt * pa * pb;
-                    if (P.convection) diag += pa * ((u0[0] - P.wm[0]) * gb[0] + (u0[1] - P.wm[1]) * gb[1] + (u0[2] - P.wm[2]) * gb[2]);
+                    if (P.convection) {
+                        const double av[3] = {u0[0] - P.wm[0], u0[1] - P.wm[1], u0[2] - P.wm[2]};
+                        const double agb = av[0] * gb[0] + av[1] * gb[1] + av[2] * gb[2];
+                        diag += pa * agb;
+                        if (P.g2) {
+                            const double aga = av[0] * ga[0] + av[1] * ga[1] + av[2] * ga[2];
+                            diag -= ns_g2_delta(P, hcell, av[0] * av[0] + av[1] * av[1] + av[2] * av[2]) * aga * agb;
+                        }
+                    }
                     const bool full = P.convection && P.newton;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -460,6 +499,9 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     for (int i = 0; i < 3; ++i) P.wm[i] = form->convection ? form->mesh_velocity[i] : 0.0;
     P.convection = form->convection ? 1 : 0;
     P.newton = form->newton ? 1 : 0;
+    FS_REQUIRE(form->g2_mode >= 0 && form->g2_mode <= 2 && (form->g2_mode == 0 || form->convection), "fs_assemble_navier_stokes: bad G2 mode");
+    P.g2 = form->g2_mode;
+    P.g2_kappa = form->g2_kappa1;
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
     // Element blocks -> buffer -> one sum per stored block: 25 ms with 544 M device-scope fp64 atomics became 7 ms
     // (MI355X, configs[4]) and the matrix is bit-reproducible.  FS_NS_ASSEMBLE=atomic / pair selects the one-pass

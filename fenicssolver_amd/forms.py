@@ -157,6 +157,9 @@ class NavierStokesForm:
         self.pressure_boundaries = []
         # ALE frame (reference_frame_settings {'type': 'ALE', 'mesh_velocity': ..}, :321-329): advecting velocity u0 - w
         self.mesh_velocity = None     # 3 numbers or None
+        # G2 stabilisation (advection_settings {'stabilization_method': 'G2', 'Re':, 'kappa1':, 'kappa2':}, :334-363):
+        # (mode, kappa1) with mode 1 for Re <= 1 (delta1 = kappa1 h^2), 2 otherwise; None = off
+        self.g2 = None
 
     @staticmethod
     def _value_name(v):
@@ -170,4 +173,5 @@ class NavierStokesForm:
                 "pressure_boundaries": [(int(m), None if v is None else self._value_name(v)) for m, v in self.pressure_boundaries],
                 "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
                 "mesh_velocity": None if self.mesh_velocity is None else [float(x) for x in self.mesh_velocity],
+                "g2": None if self.g2 is None else [int(self.g2[0]), float(self.g2[1])],
                 "newton": bool(self.newton)}

@@ -361,6 +361,12 @@ typedef struct fs_ns_form {
     double mesh_velocity[3];    /* ALE frame (reference_frame_settings, CoupledNavierStokesSolver.py:321-329): the advecting
                                  * velocity is u0 - mesh_velocity, i.e. the term is (grad(u) (u0 - w)).v; constant vector.
                                  * Written for the new iterate, the Newton right-hand side keeps (grad(u0) u0).v. */
+    int g2_mode;                /* G2 streamline term of advection_settings (CoupledNavierStokesSolver.py:334-363):
+                                 * F -= delta1 (a.grad u).(a.grad v) dx, a the advecting velocity, h = 2 circumradius;
+                                 * 0 off, 1: delta1 = kappa1 h^2 (Re <= 1), 2: kappa1/2 h/|a| (steady) or
+                                 * kappa1/2 / sqrt(1/dt^2 + 1/(|a|^2 h^2)) (inv_dt > 0).  Enters J with a frozen at w0 (the
+                                 * system is written for the new iterate, so g is unchanged and J w - g is the exact residual). */
+    double g2_kappa1;
 } fs_ns_form;
 
 /* J <- linearised operator at w0, g <- right-hand side such that J w_new = g is the Newton (or Picard) step

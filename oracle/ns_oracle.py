@@ -100,8 +100,33 @@ class TaylorHood:
         return np.array(sorted(nodes), dtype=np.int64)
 
 
+def cell_h(coords, cells):
+    """2 * Circumradius per tetrahedron (UFL's cell size in the G2 term, CoupledNavierStokesSolver.py:343)."""
+    X = np.asarray(coords, dtype=np.float64)[np.asarray(cells, dtype=np.int64)]
+    d = lambda p, q: np.linalg.norm(X[:, p] - X[:, q], axis=1)          # noqa: E731
+    aA, bB, cC = d(0, 1) * d(2, 3), d(0, 2) * d(1, 3), d(0, 3) * d(1, 2)
+    vol = np.abs(np.linalg.det(np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]], axis=1))) / 6.0
+    prod = (aA + bB + cC) * (aA + bB - cC) * (aA - bB + cC) * (-aA + bB + cC)
+    return 2.0 * np.sqrt(np.maximum(prod, 0.0)) / (24.0 * vol)
+
+
+def g2_delta1(g2, h, U2, inv_dt):
+    """delta1 of the reference's G2 term (:344-355): kappa1 h^2 for Re <= 1 (mode 1); otherwise kappa1/2 h/|a| (steady) or
+    kappa1/2 / sqrt(1/dt^2 + 1/(|a|^2 h^2)) (transient); 0 where the advecting velocity vanishes (the term does)."""
+    mode, kappa1 = g2
+    if mode == 1:
+        return kappa1 * h * h
+    out = np.zeros_like(U2)
+    ok = U2 > 0
+    if inv_dt != 0.0:
+        out[ok] = 0.5 * kappa1 / np.sqrt(inv_dt ** 2 + 1.0 / (U2[ok] * h[ok] ** 2))
+    else:
+        out[ok] = 0.5 * kappa1 * h[ok] / np.sqrt(U2[ok])
+    return out
+
+
 def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, newton=True, convection=True,
-              quad_degree=5, mesh_velocity=None):
+              quad_degree=5, mesh_velocity=None, g2=None):
     """Linearised system at the state w0:  J(w0) w_new = g(w0).
 
     J = 2 nu eps:eps + (1/dt) mass + (grad(.) u0).v [+ (grad(u0) .).v if newton] - (p/rho) div v + (q/rho) div u
@@ -120,6 +145,7 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
     f = np.zeros(3) if body_force is None else np.asarray(body_force, dtype=np.float64)
     Ke = np.zeros((nc, 10, 4, 10, 4))
     ge = np.zeros((nc, 10, 4))
+    h_cell = cell_h(th.coords, th.cells) if g2 is not None else None
     for lam, w in zip(pts, wq):
         phi, dphi = p2_shape(lam)
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)     # [nc,10,3] physical gradients
@@ -142,6 +168,13 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
             cc = np.einsum("a,cb->cab", phi, adv)
             for i in range(3):
                 Ke[:, :, i, :, i] += wv[:, None, None] * cc
+            if g2 is not None:
+                # F -= delta1 (a.grad u).(a.grad v) dx with a frozen at w0: the system is written for the new iterate, so the
+                # right-hand side does not change and K(w) w - rhs is the exact residual of the term
+                d1 = g2_delta1(g2, h_cell, np.einsum("ck,ck->c", ua, ua), inv_dt)
+                ss = np.einsum("ca,cb->cab", adv, adv)
+                for i in range(3):
+                    Ke[:, :, i, :, i] -= (wv * d1)[:, None, None] * ss
             if newton:
                 Ke[:, :, :3, :, :3] += wv[:, None, None, None, None] * np.einsum("ab,cij->caibj", mm, gu0)
                 ge[:, :, :3] += wv[:, None, None] * np.einsum("a,ci->cai", phi, np.einsum("cij,cj->ci", gu0, u0))
@@ -177,9 +210,9 @@ def apply_dirichlet_rows(J, g, dofs, vals):
     return J.tocsr(), g
 
 
-def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, mesh_velocity=None):
+def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, mesh_velocity=None, g2=None):
     """R(w) = K(w) w - rhs  (the nonlinear residual F of the reference after action(F, w))."""
-    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False, mesh_velocity=mesh_velocity)
+    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False, mesh_velocity=mesh_velocity, g2=g2)
     return K @ w - rhs
 
 
@@ -226,7 +259,7 @@ def boundary_force(th, sigma, inside):
 
 
 def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None,
-                 rtol=1e-9, atol=1e-10, max_it=50, newton=True, relax=1.0):
+                 rtol=1e-9, atol=1e-10, max_it=50, newton=True, relax=1.0, g2=None):
     """DOLFIN NewtonSolver semantics (relative 1e-9 / absolute 1e-10 on the residual 2-norm)."""
     import scipy.sparse.linalg as spl
     w = np.array(w_init, dtype=np.float64)
@@ -236,7 +269,7 @@ def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=N
     r0 = None
     history = []
     for it in range(max_it + 1):
-        J, g = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=newton)
+        J, g = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=newton, g2=g2)
         r = (J @ w - g)
         r[~free] = 0.0
         rn = np.linalg.norm(r)

@@ -244,12 +244,26 @@ st['boundary_conditions']["far"] = {'boundary': AutoSubDomain(lambda x, on_bound
                                     'values': [{'variable': "pressure", 'type': 'farfield', 'value': Constant(0.0)}]}
 run("navier_stokes_pressure_boundaries", CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
 
+# G2 streamline term (advection_settings, CoupledNavierStokesSolver.py:334-363): convection dominated (Re > 1), steady and
+# transient, and the Re <= 1 branch
+for name, transient, re_ in (("navier_stokes_g2_steady", False, 100), ("navier_stokes_g2_transient", True, 100),
+                             ("navier_stokes_g2_low_re", False, 0.5)):
+    st = ns_settings(transient)
+    st['advection_settings'] = {'stabilization_method': 'G2', 'Re': re_, 'kappa1': 4, 'kappa2': 2}
+    try:
+        run(name, CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
+    except Exception as e:            # the reference's own failure is what gets pinned then
+        out[name] = {"reference_raises": "%s: %s" % (type(e).__name__, e)}
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)
 print("wrote", path)
 for k, v in out.items():
     print("==", k)
+    if "reference_raises" in v:
+        print("   reference raises", v["reference_raises"])
+        continue
     for sv in v["solves"][:1]:
         print("  ", sv["kind"])
         for b in sv["bcs"]:

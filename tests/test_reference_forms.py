@@ -410,6 +410,14 @@ def _ns_expected_terms(desc, state="W0", prev="WPREV"):
     t.append((+1, "inner(dot(grad(u_trial[0]), %s[0]), v_test[0])" % state))
     if desc["inv_dt"]:
         t.append((+1, "mul(%s, inner(sub(u_trial[0], %s[0]), v_test[0]))" % (num(desc["inv_dt"]), prev)))
+    if desc.get("g2"):
+        mode, kappa1 = desc["g2"]
+        h = "mul(2, Circumradius)"
+        stream = "inner(dot(%s[0], grad(u_trial[0])), dot(%s[0], grad(v_test[0])))" % (state, state)
+        if mode == 1:          # Re <= 1: delta1 = kappa1 h h
+            t.append((-1, "mul(mul(mul(%s, %s), %s), %s)" % (num(kappa1), h, h, stream)))
+        else:                  # steady, convection dominated: delta1 = kappa1/2 h / sqrt(a.a)
+            t.append((-1, "mul(div(mul(%s, %s), sqrt(dot(%s[0], %s[0]))), %s)" % (num(kappa1 / 2.0), h, state, state, stream)))
     t = [(sg, body, "dx") for sg, body in t]
     for marker, value in desc.get("pressure_boundaries", []):
         if value is not None:
@@ -421,7 +429,9 @@ def _ns_expected_terms(desc, state="W0", prev="WPREV"):
 
 @pytest.mark.parametrize("case,transient,body", [("navier_stokes_steady", False, None),
                                                  ("navier_stokes_transient_gravity", True, (0, 0, -9.8)),
-                                                 ("navier_stokes_pressure_boundaries", False, None)])
+                                                 ("navier_stokes_pressure_boundaries", False, None),
+                                                 ("navier_stokes_g2_steady", False, None),
+                                                 ("navier_stokes_g2_low_re", False, None)])
 def test_navier_stokes_terms(case, transient, body):
     """Same settings -> the same integrals (signs, the 2*nu, the 1/rho on both pressure terms, gravity without rho,
     backward Euler) and the same Dirichlet conditions on W.sub(0) as the reference hands to NonlinearVariationalSolver."""
@@ -449,10 +459,13 @@ def test_navier_stokes_terms(case, transient, body):
                                                   'ending_time': 0.01}
     s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
     s['report_settings'] = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    if "g2" in case:           # the G2 streamline term (CoupledNavierStokesSolver.py:334-363), subtracted as the reference does
+        s['advection_settings'] = {'stabilization_method': 'G2', 'Re': 0.5 if case.endswith("low_re") else 100, 'kappa1': 4, 'kappa2': 2}
     solver = CoupledNavierStokesSolver(s)
     solver.init_solver()
     F, dbcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
     desc = F.describe()
+    assert desc["g2"] == ([1 if case.endswith("low_re") else 2, 4.0] if "g2" in case else None)
     assert desc["newton"] is True              # using_nonlinear_solver: action(F, w) + derivative (:241-243)
 
     gold = GOLD[case]["solves"][0]
@@ -479,6 +492,12 @@ def test_navier_stokes_terms(case, transient, body):
     v2 = dbcs[1].values.reshape(-1, 3)
     assert np.all(v2[:, 0] == 1.0) and np.all(v2[:, 1:] == 0.0)
     assert np.all(dbcs[1].dofs % 4 != 3)       # velocity components only
+
+
+def test_reference_g2_transient_branch_is_broken_upstream():
+    """F_static reads an undefined time_iter_ in the transient, convection-dominated G2 branch (:354-355): the reference
+    raises NameError there.  The GPU path uses the step's dt in that formula (the evident intent) - see fs_ns_form.g2_mode."""
+    assert GOLD["navier_stokes_g2_transient"]["reference_raises"].startswith("NameError")
 
 
 # ------------------------------------------------------------------ SUPG ("SPUG")
