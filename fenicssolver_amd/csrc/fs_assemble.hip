@@ -22,18 +22,25 @@ struct tet_geom {
     double adet;     // |det J|
 };
 
+// 16 + 8 bytes: the pad of the 32-byte record is not fetched (the gather kernels are bound by the bytes their lanes pull
+// through the per-CU address path, not by HBM)
 __device__ __forceinline__ void load_vertex(const double* __restrict__ xyz4, int32_t v, double (&x)[3]) {
     const double2 a = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)v];
-    const double2 b = reinterpret_cast<const double2*>(xyz4)[2 * (int64_t)v + 1];
-    x[0] = a.x; x[1] = a.y; x[2] = b.x;
+    x[0] = a.x; x[1] = a.y; x[2] = xyz4[4 * (int64_t)v + 2];
 }
 
+__device__ __forceinline__ tet_geom tet_geometry_x(const double (&x0)[3], const double (&x1)[3], const double (&x2)[3],
+                                                   const double (&x3)[3]);
 __device__ __forceinline__ tet_geom tet_geometry(const double* __restrict__ xyz4, const int32_t (&v)[4]) {
     double x0[3], x1[3], x2[3], x3[3];
     load_vertex(xyz4, v[0], x0);
     load_vertex(xyz4, v[1], x1);
     load_vertex(xyz4, v[2], x2);
     load_vertex(xyz4, v[3], x3);
+    return tet_geometry_x(x0, x1, x2, x3);
+}
+__device__ __forceinline__ tet_geom tet_geometry_x(const double (&x0)[3], const double (&x1)[3], const double (&x2)[3],
+                                                   const double (&x3)[3]) {
     const double e1[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
     const double e2[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
     const double e3[3] = {x3[0] - x0[0], x3[1] - x0[1], x3[2] - x0[2]};
@@ -156,8 +163,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar(const int32_t* 
 // the local matrix into a thread-private LDS column at the precomputed in-row positions.  The row is
 // then written with plain, fully coalesced stores.  Contributions are summed in ascending cell order,
 // so the assembled matrix is bit-reproducible.
+// Loads are issued ahead of their use: the incidence records of the next eight rounds while the current eight are worked
+// on, the cell records of a group before its first coordinate load; the row's own vertex is read once, coordinates as
+// 16 + 8 bytes.  10 M DOF: 2.94 -> 2.06 ms, 1 M DOF: 0.326 -> 0.241 ms (occupancy 3 waves per SIMD at 167 VGPRs; what was
+// waited for were the three dependent loads record -> cell -> coordinates of every incidence).  Staging the coordinates
+// of the row's columns in LDS instead (a fifth of the bytes through the address path) was SLOWER, 3.4 ms: 30 KB of
+// LDS per wave leave one wave per SIMD (tools/experiments/r02_assemble_xlds.patch).
 template <bool ADD>
-__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
+__global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_assemble_p1_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
@@ -178,20 +191,52 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
         const int64_t ibase = inc_slice_ptr[s];
         const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
         for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
-        for (int j = 0; j < iwidth; ++j) {
-            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+        double xown[3] = {0.0, 0.0, 0.0};
+        if (s * FS_SLICE + lane < n_rows) load_vertex(xyz4, (int32_t)(s * FS_SLICE + lane), xown);
+        // the incidence records of the next rounds are fetched ahead
+        constexpr int PF = 8;
+        int32_t qn[PF];
+        uint32_t pn[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            qn[u] = u < iwidth ? inc_cell[ibase + (int64_t)u * FS_SLICE + lane] : -1;
+            pn[u] = (u < iwidth) ? inc_pos[ibase + (int64_t)u * FS_SLICE + lane] : 0u;
+        }
+        for (int j0 = 0; j0 < iwidth; j0 += PF) {
+          int32_t qc[PF];
+          uint32_t pc[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u) { qc[u] = qn[u]; pc[u] = pn[u]; }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+              const int jn = j0 + PF + u;
+              qn[u] = jn < iwidth ? inc_cell[ibase + (int64_t)jn * FS_SLICE + lane] : -1;
+              pn[u] = jn < iwidth ? inc_pos[ibase + (int64_t)jn * FS_SLICE + lane] : 0u;
+          }
+          int4 vc[PF];
+          // the cell records of the whole group go out before the first coordinate load
+#pragma unroll
+          for (int u = 0; u < PF; ++u) vc[u] = qc[u] >= 0 ? reinterpret_cast<const int4*>(cells)[qc[u] >> 2] : make_int4(0, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            if (j0 + u >= iwidth) break;          // (also keeps the compiler from hoisting all eight rounds' coordinate loads)
+            const int32_t q = qc[u];
             if (q < 0) continue;
-            const uint32_t packed = inc_pos[ibase + (int64_t)j * FS_SLICE + lane];
+            const uint32_t packed = pc[u];
             const int c = q >> 2, a = q & 3;
-            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
             // rotate so that this row's vertex is local vertex 0 (gradients are orientation-free)
-            const int32_t w0 = a == 0 ? v4.x : a == 1 ? v4.y : a == 2 ? v4.z : v4.w;
-            const int32_t w1 = a == 0 ? v4.y : a == 1 ? v4.z : a == 2 ? v4.w : v4.x;
-            const int32_t w2 = a == 0 ? v4.z : a == 1 ? v4.w : a == 2 ? v4.x : v4.y;
-            const int32_t w3 = a == 0 ? v4.w : a == 1 ? v4.x : a == 2 ? v4.y : v4.z;
             const uint32_t prot = a == 0 ? packed : ((packed >> (8 * a)) | (packed << (32 - 8 * a)));
-            const int32_t vv[4] = {w0, w1, w2, w3};
-            const tet_geom t = tet_geometry(xyz4, vv);
+            const int4 v4 = vc[u];
+            int32_t vv[4];
+            vv[0] = a == 0 ? v4.x : a == 1 ? v4.y : a == 2 ? v4.z : v4.w;      // = this row's vertex
+            vv[1] = a == 0 ? v4.y : a == 1 ? v4.z : a == 2 ? v4.w : v4.x;
+            vv[2] = a == 0 ? v4.z : a == 1 ? v4.w : a == 2 ? v4.x : v4.y;
+            vv[3] = a == 0 ? v4.w : a == 1 ? v4.x : a == 2 ? v4.y : v4.z;
+            double x1[3], x2[3], x3[3];
+            load_vertex(xyz4, vv[1], x1);
+            load_vertex(xyz4, vv[2], x2);
+            load_vertex(xyz4, vv[3], x3);
+            const tet_geom t = tet_geometry_x(xown, x1, x2, x3);          // the row's own coordinates were loaded once
             const double vol = t.adet * (1.0 / 6.0);
             double row[4];
             if (kc.mode == FS_COEF_TENSOR) {
@@ -242,6 +287,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar_gather(
                 const int k = (prot >> (8 * b)) & 255;
                 lds_acc[k * bd + tid] += row[b];
             }
+          }
         }
         for (int k = 0; k < width; ++k) {
             const int64_t e = base + (int64_t)k * FS_SLICE + lane;
