@@ -1025,6 +1025,180 @@ __global__ void k_edge_matrix(const double* __restrict__ xyz4, const int32_t* __
     }
 }
 
+// ---- scalar P2 on triangles (2-D meshes with fe_degree 2) --------------------------------------------------------------
+// Local nodes: 3 vertices, then the 3 UFC edges (edge i opposite vertex i).  grad phi_vertex_i = (4 lambda_i - 1) grad
+// lambda_i, grad phi_edge_(i,j) = 4 (lambda_i grad lambda_j + lambda_j grad lambda_i): the stiffness integrand is quadratic,
+// the 3-point edge-midpoint rule exact; exact mass matrix A/180 * FS_P2_TRI_UFC_MASS180.
+__device__ __constant__ double FS_P2_TRI_UFC_MASS180[6][6] = {{6, -1, -1, -4, 0, 0}, {-1, 6, -1, 0, -4, 0}, {-1, -1, 6, 0, 0, -4},
+                                                               {-4, 0, 0, 32, 16, 16}, {0, -4, 0, 16, 32, 16}, {0, 0, -4, 16, 16, 32}};
+__device__ __forceinline__ void p2tri_basis_grads(const tri_geom& t, const double (&lam)[3], double (&gp)[6][2]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) gp[i][d] = (4.0 * lam[i] - 1.0) * t.g[i][d];
+    const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) gp[3 + e][d] = 4.0 * (lam[ei[e]] * t.g[ej[e]][d] + lam[ej[e]] * t.g[ei[e]][d]);
+}
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+    const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
+    const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
+    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t s = it.cur * wpb + wave;
+        if (s >= n_slices) continue;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int64_t e = ibase + (int64_t)j * FS_SLICE + lane;
+            const int32_t q = inc_cell[e];
+            if (q < 0) continue;
+            const int c = q / 6, a = q - 6 * c;
+            const uint32_t pw[2] = {inc_pos[e], inc_pos[inc_entries + e]};
+            const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, c4.x, c4.y, c4.z);
+            double row[6] = {0, 0, 0, 0, 0, 0};
+            if (kc.mode != FS_COEF_NONE) {
+                const double kk = kc.mode == FS_COEF_CONST ? kc.value : kc.data[c];
+#pragma unroll
+                for (int qp = 0; qp < 3; ++qp) {
+                    const double lam[3] = {qp == 0 ? 0.0 : 0.5, qp == 1 ? 0.0 : 0.5, qp == 2 ? 0.0 : 0.5};
+                    double gp[6][2];
+                    p2tri_basis_grads(t, lam, gp);
+                    double ga[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; }
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) row[b] += (1.0 / 3.0) * (ga[0] * gp[b][0] + ga[1] * gp[b][1]);
+                }
+                const double w = kk * t.area;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) row[b] *= w;
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.area * (1.0 / 180.0);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) row[b] += mm * FS_P2_TRI_UFC_MASS180[a][b];
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int k = (pw[b >> 2] >> (8 * (b & 3))) & 255;
+                lds_acc[k * bd + tid] += row[b];
+            }
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
+    }
+}
+
+// load vector: constant / per-cell f: A/3 on the edge nodes, 0 on the vertices; nodal (P2) f: M_e f_e
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_source_gather(int64_t n_rows, int64_t n_slices,
+                                                                           const int64_t* __restrict__ inc_slice_ptr,
+                                                                           const int32_t* __restrict__ inc_cell,
+                                                                           const int32_t* __restrict__ cell_dofs,
+                                                                           const int32_t* __restrict__ cells,
+                                                                           const double* __restrict__ xyz4, coef_dev f,
+                                                                           double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q / 6, a = q - 6 * c;
+            const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, c4.x, c4.y, c4.z);
+            if (f.mode == FS_COEF_NODAL) {
+                double m = 0.0;
+                for (int k = 0; k < 6; ++k) m += FS_P2_TRI_UFC_MASS180[a][k] * f.data[cell_dofs[(int64_t)c * 6 + k]];
+                acc += m * t.area * (1.0 / 180.0);
+            } else {
+                acc += (a < 3 ? 0.0 : 1.0 / 3.0) * (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.area;
+            }
+        }
+        if (row < n_rows) b[row] += acc;
+    }
+}
+
+// node of the P2 edge (a, c) through the sorted edge keys
+__device__ __forceinline__ int32_t p2_edge_node_of(int32_t a, int32_t c, const uint64_t* __restrict__ edge_keys, int64_t ne, int grouped,
+                                                   const int32_t* __restrict__ edge_node) {
+    const uint32_t lo_v = (uint32_t)(a < c ? a : c), hi_v = (uint32_t)(a < c ? c : a);
+    const uint64_t key = grouped ? (((uint64_t)(hi_v - lo_v) << 32) | lo_v) : (((uint64_t)lo_v << 32) | hi_v);
+    int64_t lo = 0, hi = ne;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (edge_keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < ne && edge_keys[lo] == key) ? edge_node[lo] : -1;
+}
+// P2 boundary load on an edge: g |e| (1/6, 1/6, 4/6) on its two vertices and its mid node (Simpson, exact for P2)
+__global__ void k_edge_vector_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                                 const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne, int grouped,
+                                 const int32_t* __restrict__ edge_node, int64_t n_rows, double* __restrict__ b, int* __restrict__ err) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = sqrt(dx * dx + dy * dy) * g[f] * (1.0 / 6.0);
+        const int32_t m = p2_edge_node_of(a, c, edge_keys, ne, grouped, edge_node);
+        if (m < 0) { atomicAdd(err, 1); continue; }
+        if (a < n_rows) atomicAdd(&b[a], w);
+        if (c < n_rows) atomicAdd(&b[c], w);
+        if (m < n_rows) atomicAdd(&b[m], 4.0 * w);
+    }
+}
+// P2 Robin matrix on an edge: h |e| / 30 * [[4 -1 2], [-1 4 2], [2 2 16]] on (a, c, mid).  Thread per (edge, row node).
+__global__ void k_edge_matrix_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                                 const double* __restrict__ h, const uint64_t* __restrict__ edge_keys, int64_t ne, int grouped,
+                                 const int32_t* __restrict__ edge_node, int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                                 const int32_t* __restrict__ sell_col, double* __restrict__ val, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 3; t += stride) {
+        const int64_t f = t / 3;
+        const int i = (int)(t - 3 * f);
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const int32_t m = p2_edge_node_of(a, c, edge_keys, ne, grouped, edge_node);
+        if (m < 0) { atomicAdd(err, 1); continue; }
+        const int32_t node[3] = {a, c, m};
+        const int32_t row = node[i];
+        if (row >= n_rows) continue;
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = h[f] * sqrt(dx * dx + dy * dy) * (1.0 / 30.0);
+        const double M3[3][3] = {{4, -1, 2}, {-1, 4, 2}, {2, 2, 16}};
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        for (int j = 0; j < 3; ++j) {
+            const int k = fs_find_pos_local(sell_col, base, width, node[j]);
+            if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], w * M3[i][j]);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- load vectors -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
@@ -1559,6 +1733,21 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
             hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
         else
             hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+    } else if (m->tdim == 2 && sp->degree == 2) {
+        FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: CG2 space on triangles without assembly tables");
+        FS_REQUIRE(form->advection.mode == FS_COEF_NONE && !(form->supg_pe > 0.0), "fs_assemble_matrix: advection is not built for CG2");
+        FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
+        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
+        const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
+        const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
+        FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
+        const int wpb = bd / 64;
+        const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
+        if (add)
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
     } else if (m->tdim == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
         FS_REQUIRE(!(form->supg_pe > 0.0), "fs_assemble_matrix: SUPG is built for tetrahedral meshes");
@@ -1979,6 +2168,15 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
     }
+    if (m->tdim == 2 && space->degree == 2) {
+        FS_REQUIRE(f.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0) && space->inc_cell.p, "fs_assemble_vector: unsupported option on a CG2 space on triangles");
+        hipLaunchKernelGGL(k_assemble_p2tri_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                           space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
+                           m->xyz.p, f, b->d.p);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     if (m->tdim == 2) {
         FS_REQUIRE(f.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0), "fs_assemble_vector: unsupported option on a triangular mesh");
         hipLaunchKernelGGL(k_assemble_tri_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
@@ -2129,6 +2327,17 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
         FS_CHECK(d_g2.alloc(n_facets * space->ncomp));
         FS_CHECK(d_ed.upload(tri, 2 * n_facets, s2));
         FS_CHECK(d_g2.upload(g, n_facets * space->ncomp, s2));
+        if (space->degree == 2) {
+            dbuf<int> d_e2;
+            FS_CHECK(d_e2.alloc(1));
+            FS_CHECK(d_e2.zero(s2));
+            hipLaunchKernelGGL(k_edge_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, b->d.p, d_e2.p);
+            FS_KERNEL_CHECK();
+            int h_e2 = 0;
+            FS_CHECK(d_e2.download(&h_e2, 1, s2));
+            FS_REQUIRE(h_e2 == 0, "fs_assemble_facet_vector: %d boundary edges are not mesh edges", h_e2);
+            return FS_OK;
+        }
         if (space->ncomp == 2)
             hipLaunchKernelGGL(k_edge_vector2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->n_nodes_owned, b->d.p);
         else
@@ -2171,6 +2380,28 @@ extern "C" int fs_assemble_facet_matrix(fs_matrix_t A, int64_t n_facets, const i
     }
     if (n_facets == 0) return FS_OK;
     fs_space_s* sp = A->space;
+    if (sp->degree == 2 && sp->mesh->tdim == 2) {
+        for (int64_t i = 0; i < 2 * n_facets; ++i)
+            FS_REQUIRE(tri[i] >= 0 && tri[i] < sp->mesh->nv, "fs_assemble_facet_matrix: edge vertex %d out of range", tri[i]);
+        hipStream_t s4 = fs_rt().stream;
+        dbuf<int32_t> d_e;
+        dbuf<double> d_h4;
+        dbuf<int> d_err4;
+        FS_CHECK(d_e.alloc(2 * n_facets));
+        FS_CHECK(d_h4.alloc(n_facets));
+        FS_CHECK(d_err4.alloc(1));
+        FS_CHECK(d_err4.zero(s4));
+        FS_CHECK(d_e.upload(tri, 2 * n_facets, s4));
+        FS_CHECK(d_h4.upload(h, n_facets, s4));
+        hipLaunchKernelGGL(k_edge_matrix_p2, dim3(fs_grid_for(3 * n_facets)), dim3(FS_BLOCK), 0, s4, sp->mesh->xyz.p, d_e.p, n_facets, d_h4.p,
+                           sp->edge_keys.p, sp->n_edges, sp->edge_grouped, sp->edge_node.p, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p,
+                           A->val.p, d_err4.p);
+        FS_KERNEL_CHECK();
+        int h_err4 = 0;
+        FS_CHECK(d_err4.download(&h_err4, 1, s4));
+        FS_REQUIRE(h_err4 == 0, "fs_assemble_facet_matrix: %d boundary edges / entries are not in the space", h_err4);
+        return FS_OK;
+    }
     if (sp->degree == 2) {
         FS_REQUIRE(sp->mesh->tdim == 3, "fs_assemble_facet_matrix: CG2 facet matrices are built for tetrahedral meshes");
         for (int64_t i = 0; i < 3 * n_facets; ++i)

@@ -42,14 +42,22 @@ __device__ __forceinline__ uint64_t fs_edge_key(int32_t a, int32_t b, int groupe
     return grouped ? (((uint64_t)(hi - lo) << 32) | lo) : (((uint64_t)lo << 32) | hi);
 }
 
-__global__ void k_edge_keys(const int32_t* __restrict__ cells, int64_t nc, int grouped, uint64_t* __restrict__ keys) {
+// UFC edges of a triangle: edge i lies opposite vertex i
+__device__ __constant__ int FS_TRI_EDGE_V[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+
+__global__ void k_edge_keys(const int32_t* __restrict__ cells, int64_t nc, int grouped, uint64_t* __restrict__ keys, int tdim = 3) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
         const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
         const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-        for (int e = 0; e < 6; ++e)
-            keys[(int64_t)e * nc + c] = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
+        if (tdim == 2) {
+            for (int e = 0; e < 3; ++e)
+                keys[(int64_t)e * nc + c] = fs_edge_key(v[FS_TRI_EDGE_V[e][0]], v[FS_TRI_EDGE_V[e][1]], grouped);
+        } else {
+            for (int e = 0; e < 6; ++e)
+                keys[(int64_t)e * nc + c] = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
+        }
     }
 }
 
@@ -101,12 +109,25 @@ __global__ void k_edge_nodes(const int32_t* __restrict__ order, int64_t ne, int6
 // cell_dofs[c] = {nodes of the 4 vertices, node of each of the 6 edges (edge_node of its sorted-key position)}
 __global__ void k_p2_cell_dofs(const int32_t* __restrict__ cells, int64_t nc, int64_t nvo, int64_t neo,
                                const uint64_t* __restrict__ ukeys, int64_t ne, int grouped,
-                               const int32_t* __restrict__ edge_node, int32_t* __restrict__ cell_dofs) {
+                               const int32_t* __restrict__ edge_node, int32_t* __restrict__ cell_dofs, int tdim = 3) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
         const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
         const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (tdim == 2) {          // 3 vertices, then the 3 UFC edges
+            for (int a = 0; a < 3; ++a) cell_dofs[c * 6 + a] = v[a] < nvo ? v[a] : (int32_t)(v[a] + neo);
+            for (int e = 0; e < 3; ++e) {
+                const uint64_t key = fs_edge_key(v[FS_TRI_EDGE_V[e][0]], v[FS_TRI_EDGE_V[e][1]], grouped);
+                int64_t lo = 0, hi = ne;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                cell_dofs[c * 6 + 3 + e] = edge_node[lo];
+            }
+            continue;
+        }
         for (int a = 0; a < 4; ++a) cell_dofs[c * 10 + a] = v[a] < nvo ? v[a] : (int32_t)(v[a] + neo);
         for (int e = 0; e < 6; ++e) {
             const uint64_t key = fs_edge_key(v[FS_EDGE_V[e][0]], v[FS_EDGE_V[e][1]], grouped);
@@ -634,8 +655,8 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     if (mesh->tdim == 2) {
         // triangles: CG1 scalar and 2-vector spaces; the compact [nc][3] dof table feeds the generic pattern / incidence /
         // slot-table code
-        if (degree != 1) {
-            fs_set_error("fs_space_create: triangular meshes carry CG1 spaces only (degree=%d ncomp=%d)", degree, ncomp);
+        if (degree == 2 && ncomp != 1) {
+            fs_set_error("fs_space_create: CG2 spaces on triangular meshes are scalar (ncomp=%d)", ncomp);
             delete sp;
             return FS_ERR_UNSUPPORTED;
         }
@@ -647,7 +668,9 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     }
     if (degree == 2) {
         // edge nodes: unique (min,max) vertex pairs in lexicographic order = oracle/DOLFIN-style edge numbering
-        const int64_t n_ek = 6 * nc;
+        const int tdim = mesh->tdim;
+        const int n_cell_edges = tdim == 2 ? 3 : 6, n_cell_nodes = tdim == 2 ? 6 : 10;
+        const int64_t n_ek = (int64_t)n_cell_edges * nc;
         FS_REQUIRE(n_ek < (int64_t)INT32_MAX, "fs_space_create: edge keys exceed int32");
         dbuf<uint64_t> ka, kb;
         dbuf<int> d_count;
@@ -671,7 +694,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         // pass 0: lexicographic keys -> unique edges -> number of distinct v1 - v0; pass 1 (structured meshes
         // only, <= 16 distinct differences): regroup the edges by that difference
         for (int pass = 0; pass < 2; ++pass) {
-            hipLaunchKernelGGL(k_edge_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, sp->edge_grouped, ka.p);
+            hipLaunchKernelGGL(k_edge_keys, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, sp->edge_grouped, ka.p, tdim);
             FS_SP_HIP(hipGetLastError());
             size_t tb = tbm;
             FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_ek, 0, 64, s));
@@ -694,7 +717,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP(sp->edges.alloc(2 * (int64_t)h_ne));
         FS_SP(sp->edge_keys.alloc(h_ne));
         FS_SP(sp->edge_node.alloc(h_ne));
-        FS_SP(sp->cell_dofs_store.alloc(10 * nc));
+        FS_SP(sp->cell_dofs_store.alloc((int64_t)n_cell_nodes * nc));
         FS_SP_HIP(hipMemcpyAsync(sp->edge_keys.p, ka.p, (size_t)h_ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
         // owned edges first (stable: key order inside each class)
         int h_neo = h_ne;
@@ -725,10 +748,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
             FS_SP_HIP(hipStreamSynchronize(s));
         }
         sp->n_edges_owned = h_neo;
-        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->n_owned, (int64_t)h_neo, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->edge_node.p, sp->cell_dofs_store.p);
+        hipLaunchKernelGGL(k_p2_cell_dofs, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, mesh->n_owned, (int64_t)h_neo, ka.p, (int64_t)h_ne, sp->edge_grouped, sp->edge_node.p, sp->cell_dofs_store.p, tdim);
         FS_SP_HIP(hipGetLastError());
         FS_SP_HIP(hipStreamSynchronize(s));
-        sp->ndof_cell = 10;
+        sp->ndof_cell = n_cell_nodes;
         sp->cell_dofs = sp->cell_dofs_store.p;
         sp->n_nodes_local = mesh->nv + h_ne;
         sp->n_nodes_owned = mesh->n_owned + h_neo;
@@ -865,7 +888,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     // cells and coordinates of the plane below / above are still in L2 when they are needed again), CG product unchanged
     // within run-to-run noise (0.298-0.323 ms either way).  Anything else keeps its natural order.
     // FS_SLICE_ORDER = 0 | -1 | -2 | <Morton bits per axis> overrides.
-    int order_bits = degree == 2 ? -1 : (n_slices > 32768 && mesh->tdim == 3 ? -2 : 0);
+    int order_bits = (degree == 2 && mesh->tdim == 3) ? -1 : (n_slices > 32768 && mesh->tdim == 3 ? -2 : 0);
     if (const char* e = getenv("FS_SLICE_ORDER")) order_bits = atoi(e);
     if (getenv("FS_NO_SLICE_ORDER")) order_bits = 0;
     if (order_bits > 10) order_bits = 10;

@@ -638,10 +638,10 @@ def periodic_vertex_pairs(mesh, pb):
 class FunctionSpace:
     """dolfin.FunctionSpace / VectorFunctionSpace(mesh, "CG"|"P"|"Lagrange", degree) (SolverBase.py:260-275).
     Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D P1, scalar or
-    2-vector.
+    2-vector, and scalar P2.
     Component i of node n of an ncomp-vector space is dof n*ncomp + i (DOLFIN interleaves the same way).
     Periodic constraints (constrained_domain): P1, one GPU, slave dofs kept and tied (see periodic_pairs()).
-    Not built: 2-D P2 spaces, degree > 2."""
+    Not built: vector P2 on 2-D meshes, degree > 2."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
                  _parent=None, _holder=False):
@@ -654,8 +654,8 @@ class FunctionSpace:
             if int(degree) != 1 or _holder:
                 raise SolverError("periodic_boundary (constrained_domain) is built for P1 spaces")
             self._periodic = periodic_vertex_pairs(mesh, constrained_domain)
-        if mesh.topology().dim() == 2 and (int(degree) != 1 or (_ncomp not in (1, 2) and not _holder)):
-            raise SolverError("2-D (triangular) meshes carry P1 spaces (scalar or 2-vector) only in fenicssolver_amd")
+        if mesh.topology().dim() == 2 and not _holder and not ((int(degree) == 1 and _ncomp in (1, 2)) or (int(degree) == 2 and _ncomp == 1)):
+            raise SolverError("2-D (triangular) meshes carry P1 spaces (scalar or 2-vector) and scalar P2 spaces in fenicssolver_amd")
         self._mesh = mesh
         self._degree = int(degree)
         self._ufl_element = _Element("Lagrange", int(degree), _ncomp)
@@ -718,7 +718,8 @@ class FunctionSpace:
 
     def cell_nodes(self):
         """[num_cells, 4 | 10] node ids of every cell: its vertices, then (P2) the nodes of its 6 UFC edges
-        e0=(v2,v3) e1=(v1,v3) e2=(v1,v2) e3=(v0,v3) e4=(v0,v2) e5=(v0,v1)."""
+        e0=(v2,v3) e1=(v1,v3) e2=(v1,v2) e3=(v0,v3) e4=(v0,v2) e5=(v0,v1); triangles: [num_cells, 3 | 6] with the UFC
+        edges e0=(v1,v2) e1=(v0,v2) e2=(v0,v1)."""
         ce = self._mesh.cells().astype(np.int64)
         if self._degree == 1:
             return ce
@@ -729,7 +730,8 @@ class FunctionSpace:
             ekey = ed[:, 0] * nv + ed[:, 1]
             sorter = np.argsort(ekey)
             cols = [ce]
-            for i, j in ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)):
+            local_edges = ((1, 2), (0, 2), (0, 1)) if ce.shape[1] == 3 else ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+            for i, j in local_edges:
                 a, b = np.minimum(ce[:, i], ce[:, j]), np.maximum(ce[:, i], ce[:, j])
                 cols.append((nv + sorter[np.searchsorted(ekey[sorter], a * nv + b)])[:, None])
             root._cell_nodes = np.concatenate(cols, axis=1)
@@ -778,7 +780,10 @@ class FunctionSpace:
         ed = self.edge_nodes().astype(np.int64)
         ekey = ed[:, 0] * nv + ed[:, 1]
         sorter = np.argsort(ekey)
-        fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facet vertices are ascending
+        if f.shape[1] == 2:            # 2-D: a facet is an edge, its closure the two vertices and the edge's own node
+            fe = f
+        else:
+            fe = np.concatenate([f[:, [0, 1]], f[:, [0, 2]], f[:, [1, 2]]], axis=0)   # facet vertices are ascending
         fkey = np.unique(fe[:, 0] * nv + fe[:, 1])
         eid = sorter[np.searchsorted(ekey[sorter], fkey)]
         return np.concatenate([verts, np.sort(nv + eid)])

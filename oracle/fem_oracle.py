@@ -1145,3 +1145,104 @@ def periodic_expand(u, slaves, masters, ncomp=1):
     u = np.array(u, dtype=np.float64).reshape(-1, ncomp)
     u[np.asarray(slaves, dtype=np.int64)] = u[np.asarray(masters, dtype=np.int64)]
     return u.reshape(-1)
+
+
+# ---- scalar P2 on triangles (2-D meshes with fe_degree 2) ---------------------------------------------------------------
+def tri_p2_cell_dofs(n_vertices, cells):
+    """[nc,6] global dofs of every triangle (3 vertices, then the 3 UFC edges: edge i opposite vertex i) and the edge table
+    [ne,2] in edge-node order (p2_edge_order: lexicographic, or grouped by index difference on structured meshes)."""
+    edges, cell_edges, _ = tri_edge_numbering(cells)
+    order = p2_edge_order(edges)
+    rank = np.empty(len(edges), dtype=np.int64)
+    rank[order] = np.arange(len(edges))
+    cd = np.concatenate([np.asarray(cells, dtype=np.int64), n_vertices + rank[cell_edges.astype(np.int64)]], axis=1)
+    return cd.astype(np.int32), edges[order]
+
+
+TRI_P2_EDGES = ((1, 2), (0, 2), (0, 1))
+
+
+def tri_p2_shape(lam):
+    """(phi [6], dphi/dlambda [6,3]) of the P2 triangle at barycentric lam."""
+    lam = np.asarray(lam, dtype=np.float64)
+    phi = np.zeros(6)
+    d = np.zeros((6, 3))
+    for i in range(3):
+        phi[i] = lam[i] * (2 * lam[i] - 1)
+        d[i, i] = 4 * lam[i] - 1
+    for e, (i, j) in enumerate(TRI_P2_EDGES):
+        phi[3 + e] = 4 * lam[i] * lam[j]
+        d[3 + e, i] = 4 * lam[j]
+        d[3 + e, j] = 4 * lam[i]
+    return phi, d
+
+
+# degree-4 rule on the triangle (6 points, weights sum to 1): exact for the P2 mass matrix
+_TRI_Q4 = (np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965], [0.445948490915965, 0.108103018168070, 0.445948490915965],
+                     [0.445948490915965, 0.445948490915965, 0.108103018168070], [0.816847572980459, 0.091576213509771, 0.091576213509771],
+                     [0.091576213509771, 0.816847572980459, 0.091576213509771], [0.091576213509771, 0.091576213509771, 0.816847572980459]]),
+           np.array([0.223381589678011] * 3 + [0.109951743655322] * 3))
+
+
+def tri_p2_stiffness_local(coords, cells, k=1.0):
+    """Ke[a,b] = k int grad phi_a . grad phi_b dx; quadratic integrand, the degree-4 rule is exact."""
+    area, g = tri_geometry(coords, cells)                       # g [nc,3,2] = grad lambda
+    kk = np.broadcast_to(np.asarray(k, dtype=np.float64), (len(area),))
+    Ke = np.zeros((len(area), 6, 6))
+    for lam, w in zip(*_TRI_Q4):
+        _, d = tri_p2_shape(lam)
+        gp = np.einsum("ak,cki->cai", d, g)                     # [nc,6,2]
+        Ke += w * np.einsum("cai,cbi->cab", gp, gp)
+    return Ke * (kk * area)[:, None, None]
+
+
+def tri_p2_mass_reference():
+    """int phi_a phi_b over the unit-area triangle (= the 1/180 table of the device kernels), by the degree-4 rule."""
+    M = np.zeros((6, 6))
+    for lam, w in zip(*_TRI_Q4):
+        phi, _ = tri_p2_shape(lam)
+        M += w * np.outer(phi, phi)
+    return M
+
+
+def tri_p2_mass_local(coords, cells, c=1.0):
+    area, _ = tri_geometry(coords, cells)
+    cc = np.broadcast_to(np.asarray(c, dtype=np.float64), (len(area),))
+    return (cc * area)[:, None, None] * tri_p2_mass_reference()[None]
+
+
+def tri_p2_source_local(coords, cells, f=1.0):
+    """int f phi_a dx for constant / per-cell f: 0 on the vertices, A/3 on the edge nodes."""
+    area, _ = tri_geometry(coords, cells)
+    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(area),))
+    return (ff * area)[:, None] * np.array([0.0, 0.0, 0.0, 1.0 / 3, 1.0 / 3, 1.0 / 3])[None, :]
+
+
+def tri_p2_edge_nodes(n_vertices, p2_edges, boundary_edges):
+    """For boundary edges [n,2] (vertex pairs): their (a, c, mid) P2 nodes."""
+    e = np.sort(np.asarray(boundary_edges, dtype=np.int64), axis=1)
+    table = {(int(a), int(b)): i for i, (a, b) in enumerate(np.asarray(p2_edges, dtype=np.int64))}
+    mid = np.array([n_vertices + table[(int(a), int(b))] for a, b in e], dtype=np.int64)
+    be = np.asarray(boundary_edges, dtype=np.int64)
+    return np.stack([be[:, 0], be[:, 1], mid], axis=1)
+
+
+def assemble_tri_p2_edge_load(n_dofs, coords, nodes3, g):
+    """int g phi ds over boundary edges given by their (a, c, mid) nodes: g |e| (1/6, 1/6, 4/6)."""
+    co = np.asarray(coords, dtype=np.float64)
+    length = np.linalg.norm(co[nodes3[:, 1]] - co[nodes3[:, 0]], axis=1)
+    b = np.zeros(n_dofs)
+    w = np.broadcast_to(g, length.shape) * length / 6.0
+    np.add.at(b, nodes3[:, 0], w)
+    np.add.at(b, nodes3[:, 1], w)
+    np.add.at(b, nodes3[:, 2], 4.0 * w)
+    return b
+
+
+def assemble_tri_p2_edge_mass(n_dofs, coords, nodes3, h):
+    """int h T q ds over boundary edges: h |e| / 30 [[4,-1,2],[-1,4,2],[2,2,16]] on (a, c, mid)."""
+    co = np.asarray(coords, dtype=np.float64)
+    length = np.linalg.norm(co[nodes3[:, 1]] - co[nodes3[:, 0]], axis=1)
+    M3 = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0
+    Ke = (np.broadcast_to(h, length.shape) * length)[:, None, None] * M3[None]
+    return assemble_generic(n_dofs, nodes3, Ke)
