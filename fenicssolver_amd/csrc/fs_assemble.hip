@@ -346,13 +346,46 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
         const int64_t ibase = inc_slice_ptr[s];
         const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
         for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
-        for (int j = 0; j < iwidth; ++j) {
-            const int64_t e = ibase + (int64_t)j * FS_SLICE + lane;
-            const int32_t q = inc_cell[e];
+        // loads issued ahead of their use, as in the P1 kernel: the records of the next group while this one is worked on,
+        // the cell records of a group before its first coordinate load
+        constexpr int PF = 4;
+        int32_t qn[PF];
+        uint32_t pn[PF][3];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int64_t e = ibase + (int64_t)u * FS_SLICE + lane;
+            qn[u] = u < iwidth ? inc_cell[e] : -1;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) pn[u][w] = u < iwidth ? inc_pos[w * inc_entries + e] : 0u;
+        }
+        for (int j0 = 0; j0 < iwidth; j0 += PF) {
+          int32_t qc[PF];
+          uint32_t pc[PF][3];
+          int4 vc[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+              qc[u] = qn[u];
+#pragma unroll
+              for (int w = 0; w < 3; ++w) pc[u][w] = pn[u][w];
+          }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+              const int jn = j0 + PF + u;
+              const int64_t e = ibase + (int64_t)jn * FS_SLICE + lane;
+              qn[u] = jn < iwidth ? inc_cell[e] : -1;
+#pragma unroll
+              for (int w = 0; w < 3; ++w) pn[u][w] = jn < iwidth ? inc_pos[w * inc_entries + e] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) vc[u] = qc[u] >= 0 ? reinterpret_cast<const int4*>(cells)[qc[u] / 10] : make_int4(0, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            if (j0 + u >= iwidth) break;
+            const int32_t q = qc[u];
             if (q < 0) continue;
             const int c = q / 10, a = q - 10 * c;
-            const uint32_t pw[3] = {inc_pos[e], inc_pos[inc_entries + e], inc_pos[2 * inc_entries + e]};
-            const int4 c4 = reinterpret_cast<const int4*>(cells)[c];      // vertex ids (node ids differ once ghosts exist)
+            const uint32_t pw[3] = {pc[u][0], pc[u][1], pc[u][2]};
+            const int4 c4 = vc[u];      // vertex ids (node ids differ once ghosts exist)
             const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
             const tet_geom t = tet_geometry(xyz4, vv);
             const double vol = t.adet * (1.0 / 6.0);
@@ -387,6 +420,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
                 const int k = (pw[b >> 2] >> (8 * (b & 3))) & 255;
                 lds_acc[k * bd + tid] += row[b];
             }
+          }
         }
         for (int k = 0; k < width; ++k) {
             const int64_t e = base + (int64_t)k * FS_SLICE + lane;
@@ -595,11 +629,22 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity_gather(int6
     for (; e < n_entries; e += stride) {
         double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         const int32_t q1 = ptr[e + 1];
-        for (int32_t q = ptr[e]; q < q1; ++q) {
-            const int32_t sidx = src[q];
+        // sources in groups of four: their indices, then their cell records, go out before the first coordinate load
+        constexpr int PF = 4;
+        for (int32_t q0 = ptr[e]; q0 < q1; q0 += PF) {
+          int32_t sc[PF];
+          int4 vc[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u) sc[u] = q0 + u < q1 ? src[q0 + u] : -1;
+#pragma unroll
+          for (int u = 0; u < PF; ++u) vc[u] = sc[u] >= 0 ? reinterpret_cast<const int4*>(cells)[sc[u] >> 4] : make_int4(0, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            if (q0 + u >= q1) break;
+            const int32_t sidx = sc[u];
             const int64_t c = sidx >> 4;
             const int a = (sidx >> 2) & 3, b = sidx & 3;
-            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int4 v4 = vc[u];
             const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
             const tet_geom t = tet_geometry(xyz4, v);
             const double vol = t.adet * (1.0 / 6.0);
@@ -621,6 +666,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity_gather(int6
                     if (i == j) x += vol * mu * gg + ms;
                     acc[i][j] += x;
                 }
+          }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -1849,11 +1895,21 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source_gather(int64_t 
         const int64_t ibase = inc_slice_ptr[s];
         const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
         double acc = 0.0;
-        for (int j = 0; j < iwidth; ++j) {
-            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+        constexpr int PF = 4;          // incidence records, then cell records, ahead of the coordinate loads
+        for (int j0 = 0; j0 < iwidth; j0 += PF) {
+          int32_t qc[PF];
+          int4 vc[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u) qc[u] = j0 + u < iwidth ? inc_cell[ibase + (int64_t)(j0 + u) * FS_SLICE + lane] : -1;
+#pragma unroll
+          for (int u = 0; u < PF; ++u) vc[u] = qc[u] >= 0 ? reinterpret_cast<const int4*>(cells)[qc[u] >> 2] : make_int4(0, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            if (j0 + u >= iwidth) break;
+            const int32_t q = qc[u];
             if (q < 0) continue;
             const int c = q >> 2, a = q & 3;
-            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const int4 v4 = vc[u];
             const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
             const tet_geom t = tet_geometry(xyz4, v);
             if (f.mode == FS_COEF_NODAL) {          // b_e = M_e f_e with the exact P1 mass matrix
@@ -1863,6 +1919,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source_gather(int64_t 
             } else {
                 acc += (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.adet * (1.0 / 24.0);
             }
+          }
         }
         if (row < n_rows) b[row] = ADD ? b[row] + acc : acc;
     }
@@ -2110,11 +2167,22 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_vector_source_gather(i
             if (sell_col[base + (int64_t)k * FS_SLICE] == (int32_t)r) { e = base + (int64_t)k * FS_SLICE; break; }
         double acc[3] = {0.0, 0.0, 0.0};
         if (e >= 0) {
-            for (int32_t q = gptr[e]; q < gptr[e + 1]; ++q) {
-                const int32_t sidx = gsrc[q];
+            constexpr int PF = 4;      // sources in groups: indices, then cell records, ahead of the coordinate loads
+            const int32_t q1 = gptr[e + 1];
+            for (int32_t q0 = gptr[e]; q0 < q1; q0 += PF) {
+              int32_t sc[PF];
+              int4 vc[PF];
+#pragma unroll
+              for (int u = 0; u < PF; ++u) sc[u] = q0 + u < q1 ? gsrc[q0 + u] : -1;
+#pragma unroll
+              for (int u = 0; u < PF; ++u) vc[u] = sc[u] >= 0 ? reinterpret_cast<const int4*>(cells)[sc[u] >> 4] : make_int4(0, 0, 0, 0);
+#pragma unroll
+              for (int u = 0; u < PF; ++u) {
+                if (q0 + u >= q1) break;
+                const int32_t sidx = sc[u];
                 const int64_t c = sidx >> 4;
                 const int a = (sidx >> 2) & 3;
-                const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+                const int4 v4 = vc[u];
                 const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
                 const tet_geom t = tet_geometry(xyz4, v);
                 const double w = t.adet * (1.0 / 24.0);
@@ -2129,6 +2197,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_vector_source_gather(i
                 acc[0] += w * fx + cd * ga[0];
                 acc[1] += w * fy + cd * ga[1];
                 acc[2] += w * fz + cd * ga[2];
+              }
             }
         }
         b[3 * r + 0] += acc[0];
