@@ -59,9 +59,15 @@ class LinearElasticitySolver(SolverBase):
         V = u.function_space()
         if V.degree() == 1:
             return np.einsum("cai,caj->cij", u.vertex_values()[ce], g)
-        # P2 at the centroid (lambda = 1/4): vertex functions have zero gradient there, edge (i,j): g_i + g_j
-        ei, ej = [2, 1, 1, 0, 0, 0], [3, 3, 2, 3, 2, 1]
         cd = V.cell_nodes()
+        if d == 2:
+            # triangles at the centroid (lambda = 1/3): vertex i (4/3 - 1) g_i, edge (i,j): 4/3 (g_i + g_j)
+            ei, ej = [1, 0, 0], [2, 2, 1]
+            gv = g / 3.0
+            ge = (4.0 / 3.0) * (g[:, ei, :] + g[:, ej, :])
+            return np.einsum("cai,caj->cij", u.node_values()[cd], np.concatenate([gv, ge], axis=1))
+        # tetrahedra at the centroid (lambda = 1/4): vertex functions have zero gradient there, edge (i,j): g_i + g_j
+        ei, ej = [2, 1, 1, 0, 0, 0], [3, 3, 2, 3, 2, 1]
         U = u.node_values()[cd[:, 4:]]                  # [nc,6,3]
         ge = g[:, ei, :] + g[:, ej, :]
         return np.einsum("cai,caj->cij", U, ge)

@@ -1245,6 +1245,145 @@ __global__ void k_edge_matrix_p2(const double* __restrict__ xyz4, const int32_t*
     }
 }
 
+// ---- 2-vector P2 on triangles (plane-strain elasticity with fe_degree 2) ---------------------------------------------------
+// gradient of local basis function a (0..2 vertices, 3..5 UFC edges) at edge-midpoint quadrature point qp
+__device__ __forceinline__ void p2tri_grad_one(const tri_geom& t, int qp, int a, double (&ga)[2]) {
+    const double lam[3] = {qp == 0 ? 0.0 : 0.5, qp == 1 ? 0.0 : 0.5, qp == 2 ? 0.0 : 0.5};
+    auto g = [&](int n, int d) { return n == 0 ? t.g[0][d] : (n == 1 ? t.g[1][d] : t.g[2][d]); };
+    auto l = [&](int n) { return n == 0 ? lam[0] : (n == 1 ? lam[1] : lam[2]); };
+    if (a < 3) {
+        const double w = 4.0 * l(a) - 1.0;
+        ga[0] = w * g(a, 0); ga[1] = w * g(a, 1);
+    } else {
+        const int i = a == 3 ? 1 : 0, j = a == 5 ? 1 : 2;          // e0=(1,2) e1=(0,2) e2=(0,1)
+        ga[0] = 4.0 * (l(i) * g(j, 0) + l(j) * g(i, 0));
+        ga[1] = 4.0 * (l(i) * g(j, 1) + l(j) * g(i, 1));
+    }
+}
+// one thread per stored 2x2 block: the (cell, a, b) sources of the inverse slot table (source = cell*36 + a*6 + b), the
+// quadratic integrand by the 3-point edge-midpoint rule (exact)
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_elasticity_gather(int64_t n_entries, const int32_t* __restrict__ ptr,
+                                                                               const int32_t* __restrict__ src,
+                                                                               const int32_t* __restrict__ cells,
+                                                                               const double* __restrict__ xyz4, double mu, double lambda,
+                                                                               coef_dev mc, int64_t plane, double* __restrict__ val) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < n_entries; e += stride) {
+        double acc[2][2] = {{0, 0}, {0, 0}};
+        const int32_t q1 = ptr[e + 1];
+        for (int32_t q = ptr[e]; q < q1; ++q) {
+            const int32_t sidx = src[q];
+            const int64_t c = sidx / 36;
+            const int ab = sidx - (int32_t)c * 36, a = ab / 6, b = ab - 6 * a;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            const double w = t.area * (1.0 / 3.0);
+#pragma unroll
+            for (int qp = 0; qp < 3; ++qp) {
+                double ga[2], gb[2];
+                p2tri_grad_one(t, qp, a, ga);
+                p2tri_grad_one(t, qp, b, gb);
+                const double gg = mu * (ga[0] * gb[0] + ga[1] * gb[1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        double x = lambda * ga[i] * gb[j] + mu * ga[j] * gb[i];
+                        if (i == j) x += gg;
+                        acc[i][j] += w * x;
+                    }
+            }
+            if (mc.mode != FS_COEF_NONE) {
+                const double ms = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.area * (1.0 / 180.0) * FS_P2_TRI_UFC_MASS180[a][b];
+                acc[0][0] += ms; acc[1][1] += ms;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t idx = (int64_t)(i * 2 + j) * plane + e;
+                val[idx] = ADD ? val[idx] + acc[i][j] : acc[i][j];
+            }
+    }
+}
+// load vector: body force int f . phi_a dx (A/3 on edge nodes) + int c d_i phi_a dx with c constant, per cell or P1 through
+// its vertex values (nodal array over the space's nodes); c linear x grad phi linear: the 3-point rule is exact
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_vector_source_gather(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
+                                                                                  const int32_t* __restrict__ sell_col,
+                                                                                  const int32_t* __restrict__ gptr,
+                                                                                  const int32_t* __restrict__ gsrc,
+                                                                                  const int32_t* __restrict__ cells,
+                                                                                  const double* __restrict__ xyz4, double fx, double fy,
+                                                                                  coef_dev dv, int64_t nvo, int64_t neo,
+                                                                                  double* __restrict__ b) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        int64_t e = -1;
+        for (int k = 0; k < width; ++k)
+            if (sell_col[base + (int64_t)k * FS_SLICE] == (int32_t)r) { e = base + (int64_t)k * FS_SLICE; break; }
+        double acc[2] = {0.0, 0.0};
+        if (e >= 0) {
+            for (int32_t q = gptr[e]; q < gptr[e + 1]; ++q) {
+                const int32_t sidx = gsrc[q];
+                const int64_t c = sidx / 36;
+                const int a = (sidx - (int32_t)c * 36) / 6;
+                const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+                const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+                const double wf = a < 3 ? 0.0 : t.area * (1.0 / 3.0);
+                acc[0] += wf * fx;
+                acc[1] += wf * fy;
+                if (dv.mode != FS_COEF_NONE) {
+                    double cv[3] = {0.0, 0.0, 0.0};          // c at the three vertices of the cell
+                    if (dv.mode == FS_COEF_CONST) cv[0] = cv[1] = cv[2] = dv.value;
+                    else if (dv.mode == FS_COEF_CELL) cv[0] = cv[1] = cv[2] = dv.data[c];
+                    else {
+                        const int32_t vx[3] = {v4.x, v4.y, v4.z};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) cv[k] = dv.data[vx[k] < nvo ? vx[k] : vx[k] + neo];      // node of the vertex
+                    }
+#pragma unroll
+                    for (int qp = 0; qp < 3; ++qp) {
+                        const double cq = 0.5 * ((qp == 0 ? 0.0 : cv[0]) + (qp == 1 ? 0.0 : cv[1]) + (qp == 2 ? 0.0 : cv[2]));
+                        double ga[2];
+                        p2tri_grad_one(t, qp, a, ga);
+                        acc[0] += t.area * (1.0 / 3.0) * cq * ga[0];
+                        acc[1] += t.area * (1.0 / 3.0) * cq * ga[1];
+                    }
+                }
+            }
+        }
+        b[2 * r + 0] += acc[0];
+        b[2 * r + 1] += acc[1];
+    }
+}
+// traction on boundary edges of a 2-vector P2 space: g_i |e| (1/6, 1/6, 4/6) on (a, c, mid)
+__global__ void k_edge_vector2_p2(const double* __restrict__ xyz4, const int32_t* __restrict__ ed, int64_t nf,
+                                  const double* __restrict__ g, const uint64_t* __restrict__ edge_keys, int64_t ne, int grouped,
+                                  const int32_t* __restrict__ edge_node, int64_t n_rows, double* __restrict__ b, int* __restrict__ err) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; f < nf; f += stride) {
+        const int32_t a = ed[2 * f], c = ed[2 * f + 1];
+        const double dx = xyz4[4 * (int64_t)c] - xyz4[4 * (int64_t)a], dy = xyz4[4 * (int64_t)c + 1] - xyz4[4 * (int64_t)a + 1];
+        const double w = sqrt(dx * dx + dy * dy) * (1.0 / 6.0);
+        const int32_t m = p2_edge_node_of(a, c, edge_keys, ne, grouped, edge_node);
+        if (m < 0) { atomicAdd(err, 1); continue; }
+        for (int i = 0; i < 2; ++i) {
+            const double gi = g[2 * f + i];
+            if (a < n_rows) atomicAdd(&b[2 * (int64_t)a + i], w * gi);
+            if (c < n_rows) atomicAdd(&b[2 * (int64_t)c + i], w * gi);
+            if (m < n_rows) atomicAdd(&b[2 * (int64_t)m + i], 4.0 * w * gi);
+        }
+    }
+}
+
 // ---- load vectors -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, int64_t nc,
@@ -1775,7 +1914,12 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
                    "fs_assemble_matrix: a 2-vector space takes the Lame parameters (plane-strain elasticity) and a mass coefficient");
         if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
         const int gg = fs_grid_for(sp->sell_entries, FS_BLOCK, 1 << 16);
-        if (add)
+        if (sp->degree == 2) {
+            if (add)
+                hipLaunchKernelGGL(k_assemble_p2tri_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+            else
+                hipLaunchKernelGGL(k_assemble_p2tri_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+        } else if (add)
             hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
         else
             hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
@@ -2012,6 +2156,58 @@ __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load(int64_t n_rows, int
 
 // 2-D (plane strain, P1 on triangles): the reference's expression with dimension 2 - sigma the 2x2 tensor, the deviator
 // s = sigma - tr(sigma)/3 Identity(2) (LinearElasticitySolver.py:71-73 keeps the 1/3) - constant per cell: vm A / 3.
+__device__ __forceinline__ double von_mises_2d(const double (&G)[2][2], double mu, double lambda) {
+    const double tr = G[0][0] + G[1][1];
+    const double s00 = 2.0 * mu * G[0][0] + lambda * tr, s11 = 2.0 * mu * G[1][1] + lambda * tr;
+    const double s01 = mu * (G[0][1] + G[1][0]);
+    const double pm = (s00 + s11) * (1.0 / 3.0);
+    return sqrt(1.5 * ((s00 - pm) * (s00 - pm) + (s11 - pm) * (s11 - pm) + 2.0 * s01 * s01));
+}
+// P2 displacement on triangles: grad u is linear, vm is not a polynomial; 3-point edge-midpoint rule against lambda_a
+__global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load_tri_p2(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                                    const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
+                                                                    const double* __restrict__ xyz4, const int32_t* __restrict__ u_dofs,
+                                                                    const double* __restrict__ u, double mu, double lambda,
+                                                                    double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc = 0.0;
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q / 3, a = q - 3 * c;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            double un[6][2];
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                const int64_t d = (int64_t)u_dofs[(int64_t)c * 6 + n] * 2;
+                un[n][0] = u[d]; un[n][1] = u[d + 1];
+            }
+#pragma unroll
+            for (int qp = 0; qp < 3; ++qp) {
+                double G[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+                for (int n = 0; n < 6; ++n) {
+                    double gn[2];
+                    p2tri_grad_one(t, qp, n, gn);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) G[i][k] += un[n][i] * gn[k];
+                }
+                const double la = a == qp ? 0.0 : 0.5;
+                acc += t.area * (1.0 / 3.0) * la * von_mises_2d(G, mu, lambda);
+            }
+        }
+        if (row < n_rows) b[row] = acc;
+    }
+}
 __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load_tri(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
                                                                  const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
                                                                  const double* __restrict__ xyz4, const double* __restrict__ u, double mu,
@@ -2132,7 +2328,10 @@ extern "C" int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, doubl
     hipStream_t s = fs_rt().stream;
     fs_mesh_s* m = p1_space->mesh;
     const int g = fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192);
-    if (m->tdim == 2)
+    if (m->tdim == 2 && disp_space->degree == 2)
+        hipLaunchKernelGGL(k_von_mises_load_tri_p2, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
+                           p1_space->inc_cell.p, m->cells.p, m->xyz.p, disp_space->cell_dofs, u->d.p, mu, lambda, b->d.p);
+    else if (m->tdim == 2)
         hipLaunchKernelGGL(k_von_mises_load_tri, dim3(g), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned, p1_space->n_slices, p1_space->inc_slice_ptr.p,
                            p1_space->inc_cell.p, m->cells.p, m->xyz.p, u->d.p, mu, lambda, b->d.p);
     else if (disp_space->degree == 1)
@@ -2230,6 +2429,11 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         FS_REQUIRE(dv.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0), "fs_assemble_vector: unsupported option on a 2-vector space");
         FS_REQUIRE(space->slots.p, "fs_assemble_vector: 2-vector space without slot table");
         if (!space->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(space, s));
+        if (space->degree == 2)
+            hipLaunchKernelGGL(k_assemble_p2tri_vector_source_gather, dim3(fs_grid_for(space->n_nodes_owned, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
+                               space->n_nodes_owned, space->slice_ptr.p, space->sell_col.p, space->gmap_ptr.p, space->gmap_src.p, m->cells.p,
+                               m->xyz.p, form->vector_value[0], form->vector_value[1], dv, m->n_owned, space->n_edges_owned, b->d.p);
+        else
         hipLaunchKernelGGL(k_assemble_tri_vector_source_gather, dim3(fs_grid_for(space->n_nodes_owned, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                            space->n_nodes_owned, space->slice_ptr.p, space->sell_col.p, space->gmap_ptr.p, space->gmap_src.p, m->cells.p,
                            m->xyz.p, form->vector_value[0], form->vector_value[1], dv, b->d.p);
@@ -2400,6 +2604,9 @@ extern "C" int fs_assemble_facet_vector(fs_space_t space, int64_t n_facets, cons
             dbuf<int> d_e2;
             FS_CHECK(d_e2.alloc(1));
             FS_CHECK(d_e2.zero(s2));
+            if (space->ncomp == 2)
+                hipLaunchKernelGGL(k_edge_vector2_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, b->d.p, d_e2.p);
+            else
             hipLaunchKernelGGL(k_edge_vector_p2, dim3(fs_grid_for(n_facets)), dim3(FS_BLOCK), 0, s2, space->mesh->xyz.p, d_ed.p, n_facets, d_g2.p, space->edge_keys.p, space->n_edges, space->edge_grouped, space->edge_node.p, space->n_nodes_owned, b->d.p, d_e2.p);
             FS_KERNEL_CHECK();
             int h_e2 = 0;

@@ -655,11 +655,6 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     if (mesh->tdim == 2) {
         // triangles: CG1 scalar and 2-vector spaces; the compact [nc][3] dof table feeds the generic pattern / incidence /
         // slot-table code
-        if (degree == 2 && ncomp != 1) {
-            fs_set_error("fs_space_create: CG2 spaces on triangular meshes are scalar (ncomp=%d)", ncomp);
-            delete sp;
-            return FS_ERR_UNSUPPORTED;
-        }
         FS_SP(sp->cell_dofs_store.alloc(3 * nc));
         hipLaunchKernelGGL(k_compact_tri_cells, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, mesh->cells.p, nc, sp->cell_dofs_store.p);
         FS_SP_HIP(hipGetLastError());

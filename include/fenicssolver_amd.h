@@ -101,7 +101,7 @@ int fs_mesh_destroy(fs_mesh_t mesh);
 #define FS_FAMILY_CG 0
 /* degree 1 with ncomp = 1 (scalar) or 3 (vector, node-interleaved dofs as DOLFIN's
  * VectorFunctionSpace lays them out; 2 on triangular meshes: plane-strain elasticity); triangular meshes also carry
- * scalar degree-2 spaces (3 vertices + 3 edge nodes per cell, UFC edge i opposite vertex i); degree 2 with ncomp = 1 (scalar) or 4 (Taylor-Hood block u_x,u_y,u_z,p):
+ * degree-2 spaces, scalar or 2-vector (3 vertices + 3 edge nodes per cell, UFC edge i opposite vertex i); degree 2 with ncomp = 1 (scalar) or 4 (Taylor-Hood block u_x,u_y,u_z,p):
  * nodes = the vertices, then one node per edge, edges numbered lexicographically by their ascending vertex
  * pair - grouped by index difference first on structured meshes.  With ghost vertices
  * (n_owned < nv) the nodes are [owned vertices | owned edges | ghost vertices | ghost edges]; an edge belongs to

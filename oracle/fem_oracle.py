@@ -1246,3 +1246,90 @@ def assemble_tri_p2_edge_mass(n_dofs, coords, nodes3, h):
     M3 = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0
     Ke = (np.broadcast_to(h, length.shape) * length)[:, None, None] * M3[None]
     return assemble_generic(n_dofs, nodes3, Ke)
+
+
+# ---- 2-vector P2 on triangles (plane strain with fe_degree 2) --------------------------------------------------------------
+_TRI_MID = (np.array([[0.0, 0.5, 0.5], [0.5, 0.0, 0.5], [0.5, 0.5, 0.0]]), np.array([1.0 / 3] * 3))      # edge-midpoint rule, degree 2
+
+
+def tri_p2_vector_cell_dofs(cell_dofs):
+    cd = np.asarray(cell_dofs, dtype=np.int64)
+    return (cd[:, :, None] * 2 + np.arange(2)[None, None, :]).reshape(len(cd), 12)
+
+
+def tri_p2_elasticity_local(coords, cells, E, nu):
+    """Ke[(a,i),(b,j)] = int lmbda d_i phi_a d_j phi_b + mu d_j phi_a d_i phi_b + mu delta_ij grad phi_a . grad phi_b dx on P2
+    triangles; quadratic integrand, degree-4 rule."""
+    mu, lmbda = lame(E, nu)
+    area, g = tri_geometry(coords, cells)
+    Ke = np.zeros((len(area), 6, 2, 6, 2))
+    for lam, w in zip(*_TRI_Q4):
+        _, d = tri_p2_shape(lam)
+        gp = np.einsum("ak,cki->cai", d, g)
+        gg = np.einsum("cak,cbk->cab", gp, gp)
+        Ke += w * (lmbda * np.einsum("cai,cbj->caibj", gp, gp) + mu * np.einsum("caj,cbi->caibj", gp, gp)
+                   + mu * np.einsum("cab,ij->caibj", gg, np.eye(2)))
+    return (Ke * area[:, None, None, None, None]).reshape(len(area), 12, 12)
+
+
+def assemble_tri_p2_elasticity(coords, cells, cell_dofs, n_nodes, E, nu, mass_coef=None):
+    Ke = tri_p2_elasticity_local(coords, cells, E, nu)
+    if mass_coef is not None:
+        Me = tri_p2_mass_local(coords, cells, mass_coef)
+        Ke = Ke + np.einsum("cab,ij->caibj", Me, np.eye(2)).reshape(len(Me), 12, 12)
+    return assemble_generic(2 * n_nodes, tri_p2_vector_cell_dofs(cell_dofs), Ke)
+
+
+def assemble_tri_p2_vector_source(coords, cells, cell_dofs, n_nodes, f, div_coef=None):
+    """b_(a,i) = int f_i phi_a dx [+ int c d_i phi_a dx; c a number, per cell, or P1 given by its vertex values]."""
+    area, g = tri_geometry(coords, cells)
+    ce = np.asarray(cells, dtype=np.int64)
+    be = np.zeros((len(area), 6, 2))
+    be[:, 3:, :] = (area / 3.0)[:, None, None] * np.asarray(f, dtype=np.float64)[None, None, :]
+    if div_coef is not None:
+        dc = np.asarray(div_coef, dtype=np.float64)
+        if dc.ndim == 0:
+            cv = np.full((len(area), 3), float(dc))
+        elif len(dc) == len(area) and len(dc) != len(coords):
+            cv = np.repeat(dc[:, None], 3, axis=1)
+        else:
+            cv = dc[ce]
+        for lam, w in zip(*_TRI_MID):
+            _, d = tri_p2_shape(lam)
+            gp = np.einsum("ak,cki->cai", d, g)
+            be += (w * area * (cv @ lam))[:, None, None] * gp
+    return assemble_generic_vector(2 * n_nodes, tri_p2_vector_cell_dofs(cell_dofs), be.reshape(len(area), 12))
+
+
+def assemble_tri_p2_edge_vector_load(n_nodes, coords, nodes3, g):
+    """int g . v ds over boundary edges given by their (a, c, mid) nodes, g a constant 2-vector."""
+    co = np.asarray(coords, dtype=np.float64)
+    length = np.linalg.norm(co[nodes3[:, 1]] - co[nodes3[:, 0]], axis=1)
+    b = np.zeros((n_nodes, 2))
+    for i in range(2):
+        w = g[i] * length / 6.0
+        np.add.at(b[:, i], nodes3[:, 0], w)
+        np.add.at(b[:, i], nodes3[:, 1], w)
+        np.add.at(b[:, i], nodes3[:, 2], 4.0 * w)
+    return b.ravel()
+
+
+def tri_p2_von_mises_projection(coords, cells, cell_dofs, u, E, nu):
+    """project(von_Mises(u), P1) for a P2 displacement on triangles (u [n_nodes, 2]): the reference's 2-D expression (2x2
+    tensor, deviator with 1/3) integrated against lambda_a with the 3-point edge-midpoint rule.  Returns (w, b)."""
+    mu, lmbda = lame(E, nu)
+    ce = np.asarray(cells, dtype=np.int64)
+    area, g = tri_geometry(coords, cells)
+    un = np.asarray(u)[np.asarray(cell_dofs, dtype=np.int64)]                 # [nc,6,2]
+    be = np.zeros((len(ce), 3))
+    for lam, w in zip(*_TRI_MID):
+        _, d = tri_p2_shape(lam)
+        gp = np.einsum("ak,cki->cai", d, g)
+        G = np.einsum("cni,cnk->cik", un, gp)
+        sg = mu * (G + np.swapaxes(G, -1, -2)) + lmbda * np.trace(G, axis1=-2, axis2=-1)[:, None, None] * np.eye(2)
+        dev = sg - np.trace(sg, axis1=-2, axis2=-1)[:, None, None] / 3.0 * np.eye(2)
+        vm = np.sqrt(1.5 * np.einsum("cij,cij->c", dev, dev))
+        be += (w * area * vm)[:, None] * np.asarray(lam)[None, :]
+    b = assemble_generic_vector(len(coords), ce, be)
+    M = assemble_generic(len(coords), ce, tri_mass_local(coords, cells, 1.0))
+    return solve_direct(M, b), b

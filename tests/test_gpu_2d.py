@@ -148,7 +148,7 @@ def test_2d_restrictions_are_loud(gpu):
     with pytest.raises(SolverError):
         FunctionSpace(m, "CG", 3)
     with pytest.raises(SolverError):
-        VectorFunctionSpace(m, "CG", 2)
+        VectorFunctionSpace(m, "CG", 1, dim=3)
     with pytest.raises(gpu.BackendError):
         gpu.DeviceSpace(m.device(), ncomp=3)           # 3 components belong to tetrahedra
 
@@ -444,3 +444,87 @@ def test_p2_heat_conduction_on_a_2d_mesh_through_the_solver_class(gpu):
         'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Expression("300 + 10*(x[0]*x[0] - x[1]*x[1])", degree=2)}}}
     T2 = ScalarTransportSolver(settings(bcs)).solve().vector().get_local()
     assert np.abs(T2 - (300.0 + 10.0 * (X[:, 0] ** 2 - X[:, 1] ** 2))).max() <= 1e-8
+
+
+def test_plane_strain_p2_kernels_and_solver_class(gpu):
+    """2-vector CG2 on triangles: stiffness (+ mass), body force + thermal load, edge traction, von Mises load against the
+    oracle; LinearElasticitySolver with VectorFunctionSpace(mesh, 'CG', 2) on a 2-D mesh against a direct solve."""
+    from fenicssolver_amd.fem import RectangleMesh, Point, VectorFunctionSpace, AutoSubDomain, near, Constant
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+    co, ce = fo.rectangle_mesh((0.0, 0.0), (2.0, 0.5), 7, 3)
+    rng = np.random.default_rng(9)
+    inner = (co[:, 0] > 0) & (co[:, 0] < 2) & (co[:, 1] > 0) & (co[:, 1] < 0.5)
+    co = co + 0.015 * rng.standard_normal(co.shape) * inner[:, None]
+    nv = len(co)
+    cd, p2_edges = fo.tri_p2_cell_dofs(nv, ce)
+    nn = nv + len(p2_edges)
+    E, nu = 3.0e3, 0.3
+    mu, lm = fo.lame(E, nu)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, ncomp=2, degree=2)
+    assert V.n_owned == 2 * nn
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(mu, lm), mass=3.0)
+    ref = fo.assemble_tri_p2_elasticity(co, ce, cd, nn, E, nu, mass_coef=3.0)
+    assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+    A.assemble(lame=(mu, lm))
+    K = fo.assemble_tri_p2_elasticity(co, ce, cd, nn, E, nu)
+    X = fo.p2_dof_coordinates(co, p2_edges.astype(np.int64))
+    rot = np.stack([-X[:, 1], X[:, 0]], axis=1).ravel()
+    assert abs(_csr(A) - K).max() <= 1e-12 * abs(K).max() and np.abs(K @ rot).max() <= 1e-9 * abs(K).max()
+    b = gpu.DeviceVector(V.n_owned)
+    Tn = np.concatenate([300.0 + 40.0 * co[:, 0] - 25.0 * co[:, 1] ** 2, np.zeros(len(p2_edges))])     # P1 temperature at the vertex nodes
+    gpu.assemble_vector(V, b, vector_value=(0.3, -9.81), div_coef=("nodal", Tn))
+    want = fo.assemble_tri_p2_vector_source(co, ce, cd, nn, (0.3, -9.81), div_coef=Tn[:nv])
+    assert np.abs(b.get() - want).max() <= 1e-12 * np.abs(want).max()
+    gpu.assemble_vector(V, b, vector_value=(0.0, 0.0), div_coef=2.5)
+    want = fo.assemble_tri_p2_vector_source(co, ce, cd, nn, (0.0, 0.0), div_coef=2.5)
+    assert np.abs(b.get() - want).max() <= 1e-12
+    edges, cf, cnt = fo.tri_edge_numbering(ce)
+    fm = fo.mark_edges(co, ce, lambda x, ob: ob and abs(x[0] - 2.0) < 1e-12, 1)
+    nodes3 = fo.tri_p2_edge_nodes(nv, p2_edges, edges[fm == 1])
+    b.fill(0.0)
+    gpu.assemble_facet_vector(V, b, edges[fm == 1], np.array([5.0, -3.0]))
+    assert np.abs(b.get() - fo.assemble_tri_p2_edge_vector_load(nn, co, nodes3, (5.0, -3.0))).max() <= 1e-13
+    u = 1e-3 * rng.standard_normal((nn, 2))
+    P = gpu.DeviceSpace(mesh)
+    bv = gpu.DeviceVector(P.n_owned)
+    gpu.assemble_von_mises(V, gpu.DeviceVector(V.n_local, u.ravel()), mu, lm, P, bv)
+    w, bref = fo.tri_p2_von_mises_projection(co, ce, cd, u, E, nu)
+    assert np.abs(bv.get() - bref).max() <= 1e-12 * np.abs(bref).max()
+    # the solver class
+    m2 = RectangleMesh(Point(0.0, 0.0), Point(4.0, 1.0), 12, 4)
+    W = VectorFunctionSpace(m2, "CG", 2)
+    bcs = OrderedDict()
+    bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': (Constant(0.0), Constant(0.0))}
+    bcs["top"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 3, 'type': 'pressure', 'value': Constant(-12.0)}
+    settings = {'solver_name': 'LinearElasticitySolver', 'mesh': None, 'function_space': W, 'periodic_boundary': None,
+                'boundary_conditions': bcs, 'body_source': (0.0, -76.0), 'initial_values': {'displacement': (0.0, 0.0)},
+                'material': {'name': 'steel', 'elastic_modulus': 2.0e5, 'poisson_ratio': 0.25, 'density': 7.8},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 293},
+                                    'solver_parameters': {'relative_tolerance': 1e-9, 'maximum_iterations': 20000, 'krylov_relative_tolerance': 1e-12}},
+                'report_settings': QUIET, 'vector_name': 'displacement'}
+    solver = LinearElasticitySolver(settings)
+    got = solver.solve().vector().get_local()
+    c2, e2 = m2.coordinates(), m2.cells()
+    cd2, pe2 = fo.tri_p2_cell_dofs(len(c2), e2)
+    n2 = len(c2) + len(pe2)
+    assert np.array_equal(W.cell_nodes(), cd2) and W.dim() == 2 * n2
+    K2 = fo.assemble_tri_p2_elasticity(c2, e2, cd2, n2, 2.0e5, 0.25)
+    ed2, _, _ = fo.tri_edge_numbering(e2)
+    fm2 = fo.mark_edges(c2, e2, lambda x, ob: ob and abs(x[1] - 1.0) < 1e-12, 3)
+    sign = -1.0 if solver.reference_load_sign else 1.0
+    rhs = sign * (fo.assemble_tri_p2_vector_source(c2, e2, cd2, n2, (0.0, -76.0))
+                  + fo.assemble_tri_p2_edge_vector_load(n2, c2, fo.tri_p2_edge_nodes(len(c2), pe2, ed2[fm2 == 3]), (0.0, -12.0)))
+    X2 = fo.p2_dof_coordinates(c2, pe2.astype(np.int64))
+    left = np.nonzero(np.abs(X2[:, 0]) < 1e-12)[0]
+    dofs = np.concatenate([2 * left, 2 * left + 1])
+    Ab, bb = fo.apply_dirichlet(K2, rhs, dofs, np.zeros(len(dofs)), symmetric=True)
+    want = fo.solve_direct(Ab, bb)
+    assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
+    vm = solver.von_Mises(solver.w_current).vector().get_local()
+    wv, _ = fo.tri_p2_von_mises_projection(c2, e2, cd2, want.reshape(-1, 2), 2.0e5, 0.25)
+    assert np.abs(vm - wv).max() <= 1e-5 * np.abs(wv).max()
+    sg = solver.sigma(solver.w_current)
+    assert sg.shape == (len(e2), 2, 2) and np.all(np.isfinite(sg))
