@@ -734,10 +734,17 @@ class SolverBase():
         """global dof vector -> this rank's owned + ghost entries"""
         return w if loc is None else loc.nodes(w)
 
-    def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None, w_is_local=False):
+    def _navier_stokes_assemble(self, F, V, ctx, w, newton, loc=None, w_is_local=False, prev=None):
+        """(device iterate, right-hand side) with ctx['J'] assembled at w: w a host array (global, or this rank's entries
+        with w_is_local) or a DeviceVector that is used as it is; prev: the previous time step already on the device."""
         from . import backend
-        dw = backend.DeviceVector(V.n_local, w if w_is_local else self._ns_local(loc, w))
-        dp = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector()._values())) if F.inv_dt else None
+        if isinstance(w, backend.DeviceVector):
+            dw = w
+        else:
+            dw = backend.DeviceVector(V.n_local, w if w_is_local else self._ns_local(loc, w))
+        dp = None
+        if F.inv_dt:
+            dp = prev if prev is not None else backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector()._values()))
         g = backend.DeviceVector(V.n_owned)
         backend.assemble_navier_stokes(ctx['J'], g, dw, dp, nu=F.nu, rho=F.rho, inv_dt=F.inv_dt,
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
@@ -807,21 +814,24 @@ class SolverBase():
         own = dofs[dofs < V.n_owned]               # constrained rows of this rank (the list also names ghost dofs)
         # several GPUs: the iterate lives in this rank's numbering (owned + ghost entries) during the iteration - the
         # update of the ghosts comes with the halo of the Krylov solution - and is gathered once at the end
-        wl = self._ns_local(loc, w)
+        # the iterate, the residual and the update stay in HBM for the whole Newton iteration (one upload, one download)
+        dw = backend.DeviceVector(V.n_local, self._ns_local(loc, w))
+        dprev = backend.DeviceVector(V.n_local, self._ns_local(loc, F.w_prev.vector()._values())) if F.inv_dt else None
+        zeros_own = np.zeros(len(own))
         history, krylov = [], 0
         timing = os.environ.get("FS_NS_TIMING") is not None
         tm = {"assemble": 0.0, "residual": 0.0, "dirichlet": 0.0, "krylov": 0.0, "update": 0.0}
         clock = time.perf_counter
         for it in range(max_it + 1):
             t0 = clock()
-            dw, g = self._navier_stokes_assemble(F, V, ctx, wl, newton=True, loc=loc, w_is_local=True)
+            dw, g = self._navier_stokes_assemble(F, V, ctx, dw, newton=True, loc=loc, prev=dprev)
             t1 = clock()
             r = backend.DeviceVector(V.n_owned)
             ctx['J'].spmv(dw, r)
             r.axpy(-1.0, g)                                   # R(w) = J w - g
-            res = r.get()
-            res[own] = 0.0
-            rn2 = float(np.dot(res, res))
+            if len(own):
+                backend.set_dirichlet_values(r, own, zeros_own)   # constrained rows carry no residual
+            rn2 = float(r.dot(r))
             if loc is not None and parallel.world()[1] > 1:
                 rn2 = float(backend.comm_allreduce_sum([rn2])[0])
             rn = float(np.sqrt(rn2))
@@ -836,7 +846,9 @@ class SolverBase():
             if it == max_it:
                 raise SolverError('Newton solver did not converge in {} iterations: {}'.format(max_it, history))
             t3 = clock()
-            rhs = backend.DeviceVector(V.n_owned, -res)
+            rhs = backend.DeviceVector(V.n_owned)
+            rhs.fill(0.0)
+            rhs.axpy(-1.0, r)
             ctx['J'].apply_dirichlet(rhs, dofs, np.zeros(len(dofs)), symmetric=False)
             t4 = clock()
             x = backend.DeviceVector(V.n_local)
@@ -856,11 +868,12 @@ class SolverBase():
             t5 = clock()
             if loc is not None and parallel.world()[1] > 1:
                 backend.halo_exchange(V, x)                   # ghost entries of the update
-            wl = wl + relax * x.get()
+            dw.axpy(relax, x)
             t6 = clock()
             tm["dirichlet"] += t4 - t3
             tm["krylov"] += t5 - t4
             tm["update"] += t6 - t5
+        wl = dw.get()
         w = wl[:V.n_owned] if loc is None else parallel.gather_owned(wl[:V.n_owned], loc.owned_gids(), loc.n_global, 4)
         if timing:
             self.logger.warning("Newton timing [s]: %s", {k: round(v, 4) for k, v in tm.items()})

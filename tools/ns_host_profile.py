@@ -4,4 +4,4 @@ sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'),
 pr = cProfile.Profile(); pr.enable()
 exec(open(os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'tools', 'config5_probe.py')).read())
 pr.disable()
-pstats.Stats(pr).sort_stats('cumtime').print_stats(38)
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
