@@ -119,9 +119,13 @@ class ScalarTransportSolver(SolverBase):
                 return forms.VolumeCoefficient("const", float(v[0]))
             if v.size == 9:
                 return forms.VolumeCoefficient("tensor", v.reshape(3, 3))
-            raise SolverError('{}: Constant of size {} is not a scalar or 3x3 tensor'.format(what, v.size))
+            if v.size == 4 and self.dimension == 2:
+                return forms.VolumeCoefficient("tensor", self._embed_2x2(v.reshape(2, 2)))
+            raise SolverError('{}: Constant of size {} is not a scalar or a dim x dim tensor'.format(what, v.size))
         if isinstance(value, np.ndarray) and value.shape == (3, 3):
             return forms.VolumeCoefficient("tensor", value)
+        if isinstance(value, np.ndarray) and value.shape == (2, 2) and self.dimension == 2:
+            return forms.VolumeCoefficient("tensor", self._embed_2x2(value))
         if isinstance(value, (Expression, Function)):
             if isinstance(value, Expression) and value.value_size() != 1:
                 raise SolverError('{}: tensor-valued Expression coefficients are not supported'.format(what))
@@ -129,6 +133,15 @@ class ScalarTransportSolver(SolverBase):
             cells = self.mesh.cells().astype(np.int64)      # vertex nodes come first in P1 and P2 alike
             return forms.VolumeCoefficient("cell", nod[cells].mean(axis=1))
         raise SolverError('{}: value of type {} is not supported'.format(what, type(value)))
+
+    @staticmethod
+    def _embed_2x2(k):
+        """2-D anisotropic tensor (examples/test_heat_transfer.py: K_anisotropic) in the leading block of the 3x3 the
+        device kernels take."""
+        out = np.zeros((3, 3))
+        out[:2, :2] = np.asarray(k, dtype=np.float64)
+        out[2, 2] = 1.0
+        return out
 
     def _source_coefficient(self, value):
         if isinstance(value, numbers.Number) or (isinstance(value, Constant) and value.value_size() == 1):

@@ -528,3 +528,37 @@ def test_plane_strain_p2_kernels_and_solver_class(gpu):
     assert np.abs(vm - wv).max() <= 1e-5 * np.abs(wv).max()
     sg = solver.sigma(solver.w_current)
     assert sg.shape == (len(e2), 2, 2) and np.all(np.isfinite(sg))
+
+
+def test_anisotropic_conductivity_in_2d(gpu):
+    """examples/test_heat_transfer.py's anisotropic variant (K a 2x2 matrix): material 'thermal_conductivity' as a nested
+    list on a 2-D mesh, against the oracle's  area * grad phi_a . K grad phi_b."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh, Q, sd = _square(16)
+    Kt = np.array([[0.6, 0.25], [0.25, 1.4]])
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': sd['top'], 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["left"] = {'boundary': sd['left'], 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    settings = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+                'boundary_conditions': bcs, 'body_source': 50.0, 'initial_values': {'temperature': 300},
+                'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': Kt.tolist()},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'krylov_relative_tolerance': 1e-13}},
+                'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    T = ScalarTransportSolver(settings).solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    n = len(co)
+    area, g = fo.tri_geometry(co, ce)
+    Ke = area[:, None, None] * np.einsum("cai,ij,cbj->cab", g, Kt, g)
+    K = fo.assemble_generic(n, ce, Ke)
+    rhs = fo.assemble_tri_source(co, ce, 50.0)
+    top, left = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 0] == 0.0)[0]
+    dofs = np.concatenate([top, left])
+    vals = np.concatenate([np.full(len(top), 360.0), np.full(len(left), 300.0)])     # later entries win, as in the solver
+    Ab, bb = fo.apply_dirichlet(K.tocsr(), rhs, dofs, vals, symmetric=True)
+    ref = fo.solve_direct(Ab, bb)
+    assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
