@@ -296,6 +296,8 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
     }
     FS_CHECK(build_slice_split(space));
     h.active = true;
+    h.early = -1;          // a new plan: the ranks agree again on the early start of the exchange (fs_krylov.hip)
+    h.begun = false;
     return FS_OK;
 }
 

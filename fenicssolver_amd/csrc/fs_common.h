@@ -140,6 +140,9 @@ struct fs_halo_plan {
     // overlap of the exchange with the interior rows: the grouped send/recv runs on comm_stream between two events
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool begun = false;                    // an exchange was started ahead of the product that will wait for it (fs_krylov.hip)
+    int early = -1;                        // 1: EVERY rank sends a prefix / suffix of its rows (agreed by an all-reduce), 0: no, -1: not asked yet
+    int64_t early_a = 0, early_b = 0;
     // slices (in processing order) without / with ghost columns
     dbuf<int32_t> interior, boundary;
     int64_t n_interior = 0, n_boundary = 0;

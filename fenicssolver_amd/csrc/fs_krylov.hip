@@ -697,6 +697,41 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     }
 }
 
+// The same update on the rows [0, a) and [b, n) only - the rows a slab sends to its neighbours - so that the halo
+// exchange of the new r can start before the bulk of the update and the interior product are even launched (several
+// GPUs: sums from the all-reduce).  No side effects: status, history and the scalars are written by the launch on the
+// remaining rows, which comes later in the stream and takes the same decisions from the same inputs.
+__global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, int64_t b, int64_t n, int iter, int check_only,
+                                                                    const double* __restrict__ sums, const double* __restrict__ ctrl,
+                                                                    const double* __restrict__ scal, const int* __restrict__ status,
+                                                                    double* __restrict__ r, const double* __restrict__ w,
+                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x) {
+    if (status[0] != 0) return;
+    const double gamma = sums[0], delta = sums[1], rho = sums[2];
+    if (rho <= ctrl[0] || check_only) return;
+    double beta = 0.0, alpha;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) return;
+    const int64_t total = a + (n - b);
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const int64_t i = t < a ? t : b + (t - a);
+        const double pp = r[i] + beta * p[i];
+        const double ss = w[i] + beta * sv[i];
+        p[i] = pp; sv[i] = ss;
+        x[i] += alpha * pp;
+        r[i] -= alpha * ss;
+    }
+}
+
 // aval = D^-1/2 A D^-1/2 (copy; the caller's matrix is left untouched), sc = 1/sqrt(diag)
 template <int BS>
 __global__ void __launch_bounds__(FS_BLOCK) k_scale_copy(int64_t n_rows, int64_t n_slices,
@@ -1014,9 +1049,10 @@ static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* r
     }
     const fs_halo_plan& h = sp->halo;
     const int gi = spmv_grid(h.n_interior, sp->n_slices), total = spmv_partials(sp);
-    FS_CHECK(fs_halo_begin_dev(sp, x, s));
+    if (!sp->halo.begun) FS_CHECK(fs_halo_begin_dev(sp, x, s));     // (begun: started right after the rows it sends were updated)
     launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.interior.p, h.n_interior, 0, total);
     FS_CHECK(fs_halo_end_dev(sp, s));
+    sp->halo.begun = false;
     if (h.n_boundary) launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override, h.boundary.p, h.n_boundary, gi, total, 0);
     return FS_OK;
 }
@@ -1250,6 +1286,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     hipStream_t s = fs_rt().stream;
     krylov_ws& ws = g_ws;
     FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
+    if (sp->halo.begun) {              // left over from a solve that ended in an error
+        FS_CHECK(fs_halo_end_dev(sp, fs_rt().stream));
+        sp->halo.begun = false;
+    }
     if (bicg && (ws.bicg_n != n || ws.y.n != nl + 2)) {
         FS_CHECK(ws.rhat.alloc(n + 2));
         FS_CHECK(ws.t.alloc(n + 2));
@@ -1405,6 +1445,40 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             told = true;
             graph_mode = 0;
         }
+        // rows sent to the neighbours as a prefix [0, early_a) and / or a suffix [early_b, n) of the owned rows (z-slabs): see
+        // the update below.  FS_HALO_EARLY=0 keeps the exchange inside the product.
+        int64_t early_a = 0, early_b = n;
+        if (ds && !bicg && !fuse_sums && sp->halo.active && fs_rt().n_ranks > 1) {     // (a condition every rank evaluates alike)
+            static const bool no_early = getenv("FS_HALO_EARLY") && getenv("FS_HALO_EARLY")[0] == '0';
+            fs_halo_plan& hp = sp->halo;
+            if (hp.early < 0) {
+                bool ok = !no_early && spmv_is_split(sp);
+                int64_t a = 0, b2 = n;
+                for (size_t i = 0; ok && i < hp.neighbors.size(); ++i) {
+                    if (hp.send_counts[i] <= 0) continue;
+                    const int64_t first = hp.send_first[i], last = first + hp.send_counts[i];
+                    if (!hp.send_contiguous[i]) ok = false;
+                    else if (first == 0) a = std::max(a, last);
+                    else if (last == n) b2 = std::min(b2, first);
+                    else ok = false;
+                }
+                a = (a + 1) & ~(int64_t)1;          // the bulk update works on 16-byte pairs
+                ok = ok && a < b2 && (a > 0 || b2 < n);
+                // every rank has to take the same path: an exchange begun by one side only would never be matched
+                double flag = ok ? 1.0 : 0.0;
+                FS_HIP(hipMemcpyAsync(ws.sums.p + 6, &flag, sizeof(double), hipMemcpyHostToDevice, s));
+                FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 6, 1, s));
+                FS_HIP(hipMemcpyAsync(&flag, ws.sums.p + 6, sizeof(double), hipMemcpyDeviceToHost, s));
+                FS_HIP(hipStreamSynchronize(s));
+                hp.early = flag > fs_rt().n_ranks - 0.5 ? 1 : 0;
+                hp.early_a = a;
+                hp.early_b = b2;
+                if (getenv("FS_KRYLOV_DEBUG"))
+                    fprintf(stderr, "[fs_krylov] rank %d: rows [0,%lld) and [%lld,%lld) are sent; early start of the exchange: %s\n", fs_rt().rank,
+                            (long long)a, (long long)b2, (long long)n, hp.early == 1 ? "yes" : "no");
+            }
+            if (hp.early == 1) { early_a = hp.early_a; early_b = hp.early_b; }
+        }
         const bool use_graph = ds && fuse_sums && !bicg && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
         while (!finished) {
@@ -1490,8 +1564,20 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
                         FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        // Slabs send a prefix and / or a suffix of their rows: those are updated first and their exchange is
+                        // started, so that it runs under the rest of the update AND the interior product of the next iteration
+                        // (the exchange alone used to start only with that product).
+                        int64_t m0 = 0, m1 = n;
+                        if (early_a > 0 || early_b < n) {
+                            hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 256)), dim3(FS_BLOCK), 0, s,
+                                               early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                            FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
+                            sp->halo.begun = true;
+                            m0 = early_a; m1 = early_b;
+                        }
+                        const int64_t nm = m1 - m0;
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
                     }
                 } else if (fuse_sums) {
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
@@ -1517,6 +1603,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             pending = slot;
             slot ^= 1;
             if (k > max_iter) finished = true;
+        }
+        if (sp->halo.begun) {          // the exchange started for a product that is not coming any more
+            FS_CHECK(fs_halo_end_dev(sp, s));
+            sp->halo.begun = false;
         }
         FS_HIP(hipStreamSynchronize(s));
         h_status[0] = h_status[1] = h_status[2] = h_status[3] = 0;
