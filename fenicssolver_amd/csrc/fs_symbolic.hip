@@ -607,7 +607,7 @@ extern "C" int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp
 extern "C" int fs_space_create_coupled(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_pairs,
                                        const int32_t* node_pairs, fs_space_t* out) {
     FS_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || node_pairs), "fs_space_create_coupled: bad pair list");
-    FS_REQUIRE(degree == 1 || n_pairs == 0, "fs_space_create_coupled: extra couplings are built for CG1 spaces");
+    FS_REQUIRE(degree == 1 || degree == 2 || n_pairs == 0, "fs_space_create_coupled: extra couplings are built for CG1 / CG2 spaces");
     return space_create_impl(mesh, family, degree, ncomp, n_pairs, node_pairs, out);
 }
 

@@ -640,7 +640,7 @@ class FunctionSpace:
     Built: 3-D continuous P1 and P2, scalar or 3-vector (P2 nodes = vertices, then edge midpoints); 2-D P1 and P2, scalar or
     2-vector.
     Component i of node n of an ncomp-vector space is dof n*ncomp + i (DOLFIN interleaves the same way).
-    Periodic constraints (constrained_domain): P1, one GPU, slave dofs kept and tied (see periodic_pairs()).
+    Periodic constraints (constrained_domain): P1 and P2, one GPU, slave dofs kept and tied (see periodic_pairs()).
     Not built: degree > 2."""
 
     def __init__(self, mesh, family="CG", degree=1, constrained_domain=None, _ncomp=1, _component=None,
@@ -651,9 +651,9 @@ class FunctionSpace:
             raise SolverError("fe_degree {} is not built in fenicssolver_amd (P1 and P2 only)".format(degree))
         self._periodic = None
         if constrained_domain is not None:
-            if int(degree) != 1 or _holder:
-                raise SolverError("periodic_boundary (constrained_domain) is built for P1 spaces")
-            self._periodic = periodic_vertex_pairs(mesh, constrained_domain)
+            if _holder:
+                raise SolverError("periodic_boundary (constrained_domain) is not meaningful for a container space")
+            self._periodic = periodic_vertex_pairs(mesh, constrained_domain)      # vertices; periodic_pairs() adds P2 edge nodes
         if mesh.topology().dim() == 2 and not _holder and _ncomp not in (1, 2):
             raise SolverError("2-D (triangular) meshes carry scalar and 2-vector spaces (P1 or P2) in fenicssolver_amd")
         self._mesh = mesh
@@ -671,16 +671,38 @@ class FunctionSpace:
         """(slave vertices, master vertices) of the constrained_domain the space was built with, or None.  DOLFIN removes
         the slave dofs from the space; here they stay (dim() is unchanged), the assembled system is folded onto the masters
         on the device (fs_matrix_tie_nodes) and the slaves receive their masters' values after the solve."""
-        return self.root()._periodic
+        root = self.root()
+        if root._periodic is None or root._degree == 1:
+            return root._periodic
+        if getattr(root, "_periodic_nodes", None) is None:
+            # P2: an edge whose two end points fold onto the end points of another edge is tied to that edge
+            sl, ma = root._periodic
+            nv = root._mesh.num_vertices()
+            fold = np.arange(nv, dtype=np.int64)
+            fold[sl] = ma
+            ed = root.edge_nodes().astype(np.int64)
+            fe = np.sort(fold[ed], axis=1)
+            moved = (fe != ed).any(axis=1) & (fe[:, 0] != fe[:, 1])
+            key = ed[:, 0] * nv + ed[:, 1]
+            sorter = np.argsort(key)
+            fk = fe[moved, 0] * nv + fe[moved, 1]
+            pos = np.searchsorted(key[sorter], fk)
+            pos[pos >= len(key)] = 0
+            hit = key[sorter][pos] == fk
+            slave_e = np.nonzero(moved)[0][hit]
+            master_e = sorter[pos[hit]]
+            root._periodic_nodes = (np.concatenate([sl, nv + slave_e]).astype(np.int32),
+                                    np.concatenate([ma, nv + master_e]).astype(np.int32))
+        return root._periodic_nodes
 
     def _periodic_couplings(self):
-        """Node pairs the sparsity pattern needs for the folded system: (master, j) and (master, fold(j)) for every vertex
+        """Node pairs the sparsity pattern needs for the folded system: (master, j) and (master, fold(j)) for every node
         j sharing a cell with a slave of that master, the slave itself included."""
-        sl, ma = self.root()._periodic
-        nv = self._mesh.num_vertices()
+        sl, ma = self.periodic_pairs()
+        nv = self.num_nodes()
         fold = np.arange(nv, dtype=np.int64)
         fold[sl] = ma
-        ce = self._mesh.cells().astype(np.int64)
+        ce = self.cell_nodes().astype(np.int64)
         is_slave = np.zeros(nv, dtype=bool)
         is_slave[sl] = True
         touched = ce[is_slave[ce].any(axis=1)]

@@ -164,3 +164,48 @@ def test_transient_periodic_matches_oracle_time_stepping(gpu):
         Tn = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma)
     assert np.abs(T - Tn).max() <= 1e-8 * 300.0 and np.array_equal(T[sl], T[ma])
     assert np.abs(Tn - 300.0).max() > 0.05
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_p2_space_with_periodic_boundary(gpu, dim):
+    """fe_degree 2 with a periodic_boundary: the edge nodes of the slave face are tied to the edge nodes of the master face
+    (an edge whose end points fold onto those of another edge), vertices as for P1."""
+    from fenicssolver_amd.fem import UnitSquareMesh, UnitCubeMesh, FunctionSpace, AutoSubDomain, Expression, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh = UnitSquareMesh(8, 6) if dim == 2 else UnitCubeMesh(5, 4, 3)
+    pb = _periodic_x()
+    bcs = OrderedDict()
+    bcs["bottom"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(300.0)}
+    bcs["top"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant(310.0)}
+    settings = {'solver_name': 'ScalarTransportSolver', 'mesh': mesh, 'function_space': None, 'periodic_boundary': pb,
+                'fe_family': 'CG', 'fe_degree': 2, 'boundary_conditions': bcs, 'body_source': Expression("100*sin(2*pi*x[0])*x[1]", degree=2),
+                'initial_values': {'temperature': 300}, 'material': {'density': 1.0, 'specific_heat_capacity': 1.0, 'thermal_conductivity': 0.5},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'relative_tolerance': 1e-9, 'maximum_iterations': 20000, 'krylov_relative_tolerance': 1e-12}},
+                'report_settings': QUIET, 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    V = solver.function_space
+    sl, ma = V.periodic_pairs()
+    X = V.node_coordinates()
+    assert V.degree() == 2 and np.allclose(X[sl, 0], 1.0) and np.allclose(X[ma, 0], 0.0) and np.allclose(X[sl, 1:], X[ma, 1:])
+    nv = mesh.num_vertices()
+    n_face_nodes = (2 * 6 + 1) if dim == 2 else (2 * 4 + 1) * (2 * 3 + 1)
+    assert len(sl) == n_face_nodes and np.count_nonzero(sl >= nv) == n_face_nodes - ((6 + 1) if dim == 2 else (4 + 1) * (3 + 1))
+    T = solver.solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    cd = V.cell_nodes()
+    n = V.dim()
+    fn = 100 * np.sin(2 * np.pi * X[:, 0]) * X[:, 1]
+    if dim == 2:
+        K = fo.assemble_generic(n, cd, fo.tri_p2_stiffness_local(co, ce, 0.5))
+        M = fo.assemble_generic(n, cd, fo.tri_p2_mass_local(co, ce, 1.0))
+    else:
+        K = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.5))
+        M = fo.assemble_generic(n, cd, fo.p2_mass_local(co, ce, 1.0))
+    Af, bf = fo.periodic_fold(K, M @ fn, sl, ma)
+    lo, hi = np.nonzero(np.abs(X[:, 1]) < 1e-12)[0], np.nonzero(np.abs(X[:, 1] - 1.0) < 1e-12)[0]
+    Ab, bb = fo.apply_dirichlet(Af, bf, np.concatenate([lo, hi]), np.concatenate([np.full(len(lo), 300.0), np.full(len(hi), 310.0)]), symmetric=True)
+    want = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma)
+    assert np.abs(T - want).max() <= 1e-7 * np.abs(want).max()
+    assert np.array_equal(T[sl], T[ma])

@@ -629,8 +629,10 @@ def test_periodic_vertex_pairs_follow_dolfins_rule():
     assert V.dim() == mesh.num_vertices() and np.array_equal(V.periodic_pairs()[0], sl)
     pairs = V._periodic_couplings()
     assert pairs.shape[1] == 2 and set(pairs[:, 0]) <= set(ma)
-    with pytest.raises(SolverError):
-        FunctionSpace(mesh, "CG", 2, constrained_domain=PX())
+    V2 = FunctionSpace(mesh, "CG", 2, constrained_domain=PX())          # P2: the edge nodes of the slave side are tied as well
+    s2, m2 = V2.periodic_pairs()
+    X2 = V2.node_coordinates()
+    assert len(s2) == 4 + 3 and np.allclose(X2[s2, 0], 1.0) and np.allclose(X2[m2, 0], 0.0) and np.allclose(X2[s2, 1], X2[m2, 1])
 
     class Shifted(PX):
         def map(self, x, y):
