@@ -119,6 +119,7 @@ SIGNATURES = {
     "fs_matrix_get_csr": (C.c_int, [_H, c_i32p, c_i32p, c_f64p]),
     "fs_matrix_destroy": (C.c_int, [_H]),
     "fs_assemble_matrix": (C.c_int, [_H, C.POINTER(fs_bilinear_form), C.c_int]),
+    "fs_operator_apply": (C.c_int, [_H, C.POINTER(fs_bilinear_form), _H, _H, C.c_int, C.POINTER(C.c_double)]),
     "fs_assemble_vector": (C.c_int, [_H, C.POINTER(fs_linear_form), _H, C.c_int]),
     "fs_assemble_facet_vector": (C.c_int, [_H, c_i64, c_i32p, c_f64p, _H]),
     "fs_assemble_facet_matrix": (C.c_int, [_H, c_i64, c_i32p, c_f64p]),

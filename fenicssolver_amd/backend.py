@@ -238,6 +238,38 @@ def _coef(spec, keep):
     return c
 
 
+def _bilinear_form(keep, stiffness=None, mass=None, lame=None, advection=None, advection_scale=1.0, supg_pe=0.0):
+    f = L.fs_bilinear_form()
+    f.stiffness = _coef(stiffness, keep)
+    f.mass = _coef(mass, keep)
+    if advection is not None:
+        v = L.f64(advection)
+        if v.size == 3:
+            f.advection.mode = L.FS_COEF_CONST
+            for i in range(3):
+                f.advection.tensor[i] = float(v.ravel()[i])
+        else:
+            v = L.f64(v.reshape(-1, 3))
+            keep.append(v)
+            f.advection.mode = L.FS_COEF_CELL
+            f.advection.data = L.p_f64(v)
+        f.advection_scale = float(advection_scale)
+        f.supg_pe = float(supg_pe)
+    if lame is not None:
+        f.lame_mu, f.lame_lambda = float(lame[0]), float(lame[1])
+    return f
+
+
+def apply_operator(space, x, y, stiffness=None, mass=None, advection=None, advection_scale=1.0, supg_pe=0.0, reps=0):
+    """Matrix-free y = K(form) x on a scalar CG1 space over tetrahedra (no matrix is formed, no Dirichlet rows).
+    reps > 1: also returns the mean milliseconds of reps products timed with HIP events."""
+    keep = []
+    f = _bilinear_form(keep, stiffness, mass, None, advection, advection_scale, supg_pe)
+    ms = C.c_double(0.0)
+    L.check(L.load().fs_operator_apply(space.h, C.byref(f), x.h, y.h, int(reps), C.byref(ms)), "fs_operator_apply")
+    return ms.value if reps > 1 else None
+
+
 class DeviceMatrix(_Handle):
     """SELL-64 matrix on a space's pattern (PETSc AIJ behind dolfin.assemble)."""
     _destroy = "fs_matrix_destroy"
@@ -251,24 +283,7 @@ class DeviceMatrix(_Handle):
         """advection: constant velocity (3 numbers) or per-cell array [n_cells,3]; supg_pe > 0: SUPG test function
         q + tau (v . grad q) on the advection and mass terms."""
         keep = []
-        f = L.fs_bilinear_form()
-        f.stiffness = _coef(stiffness, keep)
-        f.mass = _coef(mass, keep)
-        if advection is not None:
-            v = L.f64(advection)
-            if v.size == 3:
-                f.advection.mode = L.FS_COEF_CONST
-                for i in range(3):
-                    f.advection.tensor[i] = float(v.ravel()[i])
-            else:
-                v = L.f64(v.reshape(-1, 3))
-                keep.append(v)
-                f.advection.mode = L.FS_COEF_CELL
-                f.advection.data = L.p_f64(v)
-            f.advection_scale = float(advection_scale)
-            f.supg_pe = float(supg_pe)
-        if lame is not None:
-            f.lame_mu, f.lame_lambda = float(lame[0]), float(lame[1])
+        f = _bilinear_form(keep, stiffness, mass, lame, advection, advection_scale, supg_pe)
         L.check(L.load().fs_assemble_matrix(self.h, C.byref(f), 1 if add else 0), "fs_assemble_matrix")
 
     def add_facet_mass(self, tri, h):

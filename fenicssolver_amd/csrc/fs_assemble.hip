@@ -169,13 +169,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_scalar(const int32_t* 
 // waited for were the three dependent loads record -> cell -> coordinates of every incidence).  Staging the coordinates
 // of the row's columns in LDS instead (a fifth of the bytes through the address path) was SLOWER, 3.4 ms: 30 KB of
 // LDS per wave leave one wave per SIMD (tools/experiments/r02_assemble_xlds.patch).
-template <bool ADD>
+// MODE 0: A = form, 1: A += form, 2: matrix-free product val[row] = (form x)[row] - the same walk with the row of the
+// local matrix multiplied into x instead of stored (fs_operator_apply; the operator is never formed, no LDS).
+template <int MODE>
 __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_assemble_p1_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
     coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double supg_pe, double* __restrict__ val,
-    const int32_t* __restrict__ order) {
+    const int32_t* __restrict__ order, const double* __restrict__ xvec = nullptr) {
+    constexpr bool ADD = MODE == 1, APPLY = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -190,9 +193,14 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t ibase = inc_slice_ptr[s];
         const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
-        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        if (!APPLY)
+            for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
         double xown[3] = {0.0, 0.0, 0.0};
-        if (s * FS_SLICE + lane < n_rows) load_vertex(xyz4, (int32_t)(s * FS_SLICE + lane), xown);
+        double yacc = 0.0, x_own = 0.0;
+        if (s * FS_SLICE + lane < n_rows) {
+            load_vertex(xyz4, (int32_t)(s * FS_SLICE + lane), xown);
+            if (APPLY) x_own = xvec[s * FS_SLICE + lane];
+        }
         // the incidence records of the next rounds are fetched ahead
         constexpr int PF = 8;
         int32_t qn[PF];
@@ -236,6 +244,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
             load_vertex(xyz4, vv[1], x1);
             load_vertex(xyz4, vv[2], x2);
             load_vertex(xyz4, vv[3], x3);
+            double xb[3] = {0.0, 0.0, 0.0};
+            if (APPLY) { xb[0] = xvec[vv[1]]; xb[1] = xvec[vv[2]]; xb[2] = xvec[vv[3]]; }
             const tet_geom t = tet_geometry_x(xown, x1, x2, x3);          // the row's own coordinates were loaded once
             const double vol = t.adet * (1.0 / 6.0);
             double row[4];
@@ -282,12 +292,20 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
                         row[b] += wa * vol * (ascale * (vx * t.g[b][0] + vy * t.g[b][1] + vz * t.g[b][2]) + 0.25 * mval);
                 }
             }
+            if (APPLY) {
+                yacc += row[0] * x_own + row[1] * xb[0] + row[2] * xb[1] + row[3] * xb[2];
+            } else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = (prot >> (8 * b)) & 255;
-                lds_acc[k * bd + tid] += row[b];
+                for (int b = 0; b < 4; ++b) {
+                    const int k = (prot >> (8 * b)) & 255;
+                    lds_acc[k * bd + tid] += row[b];
+                }
             }
           }
+        }
+        if (APPLY) {
+            if (s * FS_SLICE + lane < n_rows) val[s * FS_SLICE + lane] = yacc;
+            continue;
         }
         for (int k = 0; k < width; ++k) {
             const int64_t e = base + (int64_t)k * FS_SLICE + lane;
@@ -1988,9 +2006,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<1>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
         else
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<0>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
     } else if (A->bs == 1) {
         FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
         FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
@@ -2300,6 +2318,56 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
 #pragma unroll
             for (int k = 0; k < 9; ++k) b[row * 9 + k] = acc[k];
     }
+}
+
+
+// Matrix-free product y = K(form) x on a scalar CG1 space over tetrahedra: the walk of the row-gather assembly with every
+// local row multiplied into x on the fly (north_star's "matrix-free CG").  No Dirichlet rows: callers mask.
+// Measured against the assembled hybrid SELL/DIA product in DESIGN.md section 3 (it re-reads connectivity and
+// coordinates and recomputes 24 cell geometries per row for every product, the assembled form streams 15 doubles per row).
+extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_vector_t x, fs_vector_t y, int reps,
+                                 double* ms_per_launch) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(V && form && x && y, "fs_operator_apply: null pointer");
+    fs_space_s* sp = V;
+    fs_mesh_s* m = sp->mesh;
+    FS_REQUIRE(m->tdim == 3 && sp->degree == 1 && sp->ncomp == 1 && sp->inc_cell.p,
+               "fs_operator_apply: built for scalar CG1 spaces on tetrahedra");
+    FS_REQUIRE(x->d.n >= sp->n_dofs_local && y->d.n >= sp->n_dofs_owned && x != y, "fs_operator_apply: vector too short (or x is y)");
+    hipStream_t s = fs_rt().stream;
+    dbuf<double> kstore, mstore, astore;
+    coef_dev kc, mc, ac;
+    FS_CHECK(make_coef(form->mass, m->nc, mstore, &mc, "fs_operator_apply(mass)"));
+    FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_operator_apply(stiffness)"));
+    FS_CHECK(make_coef(form->advection, 3 * m->nc, astore, &ac, "fs_operator_apply(advection)"));
+    FS_REQUIRE((mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL) && kc.mode != FS_COEF_NODAL &&
+               (ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL),
+               "fs_operator_apply: coefficients must be constant or per cell");
+    const int wpb = FS_BLOCK / 64;
+    const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
+    auto go = [&]() {
+        hipLaunchKernelGGL(k_assemble_p1_scalar_gather<2>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                           sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale,
+                           form->supg_pe, y->d.p, sp->slice_order.p, x->d.p);
+    };
+    go();
+    if (reps > 1 && ms_per_launch) {      // HIP events around reps further launches on the library's stream
+        hipEvent_t e0, e1;
+        FS_HIP(hipEventCreate(&e0));
+        FS_HIP(hipEventCreate(&e1));
+        FS_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) go();
+        FS_HIP(hipEventRecord(e1, s));
+        FS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_launch = (double)ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
 }
 
 extern "C" int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b) {
