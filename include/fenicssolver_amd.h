@@ -21,6 +21,10 @@
  *   - calls are synchronous at return unless stated otherwise.
  *   - one process drives one GPU; N-GPU runs are N processes joined through
  *     fs_comm_init (RCCL).  All field arithmetic is fp64, connectivity is int32.
+ *   - threading: one thread at a time per process, as for the PETSc objects of one communicator.  All work is
+ *     ordered on the library's single HIP stream, the device block cache and the Krylov / AMG / saddle-point work
+ *     spaces (and fs_krylov_history) belong to the process: callers with several threads serialise their calls;
+ *     concurrency comes from running one process per GPU.
  */
 #ifndef FENICSSOLVER_AMD_H
 #define FENICSSOLVER_AMD_H
