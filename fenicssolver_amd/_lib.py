@@ -166,6 +166,9 @@ def load():
         raise BackendError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). fenicssolver_amd has no CPU fallback." % LIB_PATH)
+    # RCCL between the processes of a node needs dmabuf IPC on hosts whose driver has no legacy IPC (hipIpcGetMemHandle
+    # fails otherwise); the HSA runtime reads this when the first HIP call initialises it, i.e. after this dlopen
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:  # pragma: no cover
