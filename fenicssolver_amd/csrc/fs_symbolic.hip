@@ -767,11 +767,17 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
             delete sp;
             return FS_ERR_INVALID;
         }
-    FS_REQUIRE(n_keys < (int64_t)INT32_MAX, "fs_space_create: %lld pattern keys exceed int32 (mesh too large for one GPU pass)", (long long)n_keys);
+    if (ncomp == 1 && (int64_t)nd * nc >= (int64_t)INT32_MAX) {      // the assembly tables name (cell, local dof) in 32 bits
+        fs_set_error("fs_space_create: %lld cell-dof incidences exceed the 32-bit assembly tables (largest P1 cube: n = 447)",
+                     (long long)((int64_t)nd * nc));
+        delete sp;
+        return FS_ERR_UNSUPPORTED;
+    }
+    // (the sort and the unique pass take 64-bit item counts: a P1 space of 80 M dofs has 6.4e9 keys, 2 x 51 GB for a moment)
     int64_t nnz = 0;
     {
         dbuf<uint64_t> keys_a, keys_b;
-        dbuf<int> d_count;
+        dbuf<int64_t> d_count;
         FS_SP(keys_a.alloc(n_keys));
         FS_SP(keys_b.alloc(n_keys));
         FS_SP(d_count.alloc(1));
@@ -789,19 +795,24 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         // 2. sort + unique
         int end_bit = 64;
         size_t tmp_bytes = 0;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a.p, keys_b.p, (int)n_keys, 0, end_bit, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a.p, keys_b.p, n_keys, 0, end_bit, s));
         size_t tmp2 = 0;
-        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2, keys_b.p, keys_a.p, d_count.p, (int)n_keys, s));
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2, keys_b.p, keys_a.p, d_count.p, n_keys, s));
         if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
         size_t tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_a.p, keys_b.p, (int)n_keys, 0, end_bit, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_a.p, keys_b.p, n_keys, 0, end_bit, s));
         tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, keys_b.p, keys_a.p, d_count.p, (int)n_keys, s));
-        int h_count = 0;
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, keys_b.p, keys_a.p, d_count.p, n_keys, s));
+        int64_t h_count = 0;
         FS_SP(d_count.download(&h_count, 1, s));
         nnz = h_count;
+        if (nnz >= (int64_t)INT32_MAX) {
+            fs_set_error("fs_space_create: %lld coupled node pairs exceed the 32-bit row pointers", (long long)nnz);
+            delete sp;
+            return FS_ERR_UNSUPPORTED;
+        }
         // the sentinel (rows owned by other ranks) is the last unique key when present
         if (nnz > 0) {
             uint64_t last = 0;

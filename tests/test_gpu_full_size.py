@@ -73,6 +73,28 @@ def test_config2_family_10m_dof_hbm_resident(gpu):
     assert np.abs(x.get() - (350.0 - 50.0 * zc)).max() <= 2e-3
 
 
+def test_largest_single_gpu_p1_problem_86m_dof(gpu):
+    """Maximum size of the 32-bit connectivity (cell-vertex incidences < 2^31): unit cube n=440, 85.8 M DOF, 511 M tets,
+    6.2e9 pattern keys through the 64-bit sort - about a third of the 288 GB of one MI355X for a moment.  One size
+    further the space constructor must refuse loudly."""
+    n = 440
+    mesh, V, A, x, st, _ = _heat_cube(gpu, n)
+    assert V.n_owned == 441 ** 3 and mesh.info()[1] == 6 * n ** 3
+    assert st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
+    T = x.get()
+    P = (n + 1) ** 2
+    zmean = T.reshape(n + 1, P).mean(axis=1)
+    assert np.abs(zmean - (350.0 - 50.0 * np.arange(n + 1) / n)).max() <= 5e-3     # linear in z, plane by plane
+    assert T.min() >= 300.0 - 1e-6 and T.max() <= 350.0 + 1e-6                       # discrete maximum principle
+    del A, x, V, mesh
+    gpu.trim_memory()
+    big = gpu.DeviceMesh.box(480, 480, 480)                                           # 663 M tets: 4 nc >= 2^31
+    with pytest.raises(gpu.BackendError):
+        gpu.DeviceSpace(big, 1)
+    del big
+    gpu.trim_memory()
+
+
 def test_config3_elasticity_cantilever_5m_dof(gpu):
     """configs[2]: BoxMesh((0,0,0),(10,1,1),472,59,59), vector P1, E=2e11, nu=0.27, clamped at x=0,
     body force; 5 108 400 DOF.  Euler-Bernoulli tip deflection q L^4 / (8 E I)."""

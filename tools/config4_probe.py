@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from fenicssolver_amd import backend as B
 B.init(0)
-for n in (26, 53, 107):
+for n in ([int(a) for a in sys.argv[1:]] or (26, 53, 107)):
     t0=time.perf_counter(); mesh = B.DeviceMesh.box(n,n,n); V = B.DeviceSpace(mesh,1,degree=2); B.synchronize(); t1=time.perf_counter()
     A = B.DeviceMatrix(V); b = B.DeviceVector(V.n_owned); x = B.DeviceVector(V.n_owned)
     xyz,_,_ = mesh.get(); edges = V.edges().astype(np.int64)
