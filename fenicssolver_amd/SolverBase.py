@@ -336,8 +336,8 @@ class SolverBase():
         sp_ = self.solver_settings.get('solver_parameters', {}) or {}
         if amg and 'preconditioner' not in sp_:
             pc = 'amg'
-        if pc == 'amg' and (method != "cg" or u.function_space()._degree != 1):
-            self.logger.warning('%s: the AMG hierarchy is built for symmetric P1 problems; using Jacobi', label)
+        if pc == 'amg' and method != "cg":
+            self.logger.warning('%s: the AMG hierarchy is built for symmetric problems; using Jacobi', label)
             pc = 'jacobi'
         # PETSc's KSPCG default: convergence on the preconditioned residual norm; it is
         # also what keeps badly scaled operators (e.g. permittivities of 1e-10 next to identity rows) honest
@@ -928,7 +928,7 @@ class SolverBase():
 
     def build_nullspace(self, V, x=None):
         """The rigid-body modes of SolverBase.py:674-706 (3 in 2D, 6 in 3D), orthonormalised."""
-        co = V.mesh().coordinates()
+        co = V.node_coordinates() if hasattr(V, 'node_coordinates') else V.mesh().coordinates()   # P2: edge mid-points too
         n = co.shape[0]
         if self.dimension == 2:
             ns = np.zeros((3, n, 2))

@@ -439,7 +439,7 @@ class AMG(_Handle):
     """Smoothed-aggregation hierarchy of an assembled SPD matrix (PETSc GAMG behind
     PETScPreconditioner("petsc_amg"), SolverBase.py:643-672).  nullspace: [nb, n_dofs] near-null-space
     vectors, "rigid_body" = the six rigid-body modes built on the device from the node coordinates (3-vector CG1
-    spaces), or None = constants per component."""
+    / CG2 spaces: vertices and edge mid-points), or None = constants per component."""
     _destroy = "fs_amg_destroy"
 
     def __init__(self, A, nullspace=None, strength_threshold=0.0, max_levels=0, coarse_size=0, smoother_steps=0,

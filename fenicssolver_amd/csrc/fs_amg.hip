@@ -146,11 +146,19 @@ __global__ void k_nullspace_layout(int64_t n, int nb, int bs, const double* __re
 // [dof][6] layout of the near-null space: translations, then (-y, x, 0), (z, 0, -x), (0, -z, y).  The reference
 // orthonormalises them globally; the tentative prolongator orthonormalises per aggregate anyway, so the span is what
 // matters.  Saves the 6 n doubles a host-built basis has to cross PCIe (245 MB at configs[2]).
-__global__ void k_rigid_body_modes(int64_t n_nodes, const double* __restrict__ xyz4, double* __restrict__ B) {
+// CG2 spaces: node i >= nv is the mid-point of edge i - nv (owned vertices first, then the owned edges in table order).
+__global__ void k_rigid_body_modes(int64_t n_nodes, int64_t nv, const int32_t* __restrict__ edges, const double* __restrict__ xyz4,
+                                   double* __restrict__ B) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n_nodes; i += stride) {
-        const double x = xyz4[4 * i], y = xyz4[4 * i + 1], z = xyz4[4 * i + 2];
+        double x, y, z;
+        if (i < nv) {
+            x = xyz4[4 * i]; y = xyz4[4 * i + 1]; z = xyz4[4 * i + 2];
+        } else {
+            const int64_t a = edges[2 * (i - nv)], b = edges[2 * (i - nv) + 1];
+            x = 0.5 * (xyz4[4 * a] + xyz4[4 * b]); y = 0.5 * (xyz4[4 * a + 1] + xyz4[4 * b + 1]); z = 0.5 * (xyz4[4 * a + 2] + xyz4[4 * b + 2]);
+        }
         double* b = B + i * 18;
         const double rows[3][6] = {{1, 0, 0, -y, z, 0}, {0, 1, 0, x, 0, -z}, {0, 0, 1, 0, -x, y}};
         for (int c = 0; c < 3; ++c)
@@ -1552,7 +1560,8 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
     const bool local_block = sp->n_nodes_local > sp->n_nodes_owned;
     FS_REQUIRE(A->bs == 1 || A->bs == 3, "fs_amg_setup: block size %d", A->bs);
     const bool rigid = !nullspace && opts && opts->rigid_body_modes != 0;
-    FS_REQUIRE(!rigid || (A->bs == 3 && sp->degree == 1 && sp->mesh->tdim == 3), "fs_amg_setup: rigid-body modes are built for 3-vector CG1 spaces on tetrahedra");
+    FS_REQUIRE(!rigid || (A->bs == 3 && sp->mesh->tdim == 3 && (sp->degree == 1 || sp->edges.p)),
+               "fs_amg_setup: rigid-body modes are built for 3-vector CG1 / CG2 spaces on tetrahedra");
     const int nb = nullspace ? n_nullspace : (rigid ? 6 : A->bs);
     FS_REQUIRE(nb == 1 || nb == 3 || nb == 6, "fs_amg_setup: %d near-null-space vectors (1, 3 or 6 are built)", nb);
     // 0 = default 0.05; negative = keep every coupling above the summation-order noise (1e-8)
@@ -1598,7 +1607,9 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
             if ((rc = raw.upload(nullspace, L0->n * nb, s)) != FS_OK) return fail(rc);
         }
         if (rigid)
-            hipLaunchKernelGGL(k_rigid_body_modes, dim3(fs_grid_for(L0->nn, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->nn, sp->mesh->xyz.p, L0->B.p);
+            hipLaunchKernelGGL(k_rigid_body_modes, dim3(fs_grid_for(L0->nn, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->nn,
+                               sp->degree == 1 ? L0->nn : sp->mesh->n_owned, sp->degree == 1 ? (const int32_t*)nullptr : sp->edges.p,
+                               sp->mesh->xyz.p, L0->B.p);
         else
             hipLaunchKernelGGL(k_nullspace_layout, dim3(fs_grid_for(L0->n * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, L0->n, nb, A->bs, (const double*)raw.p, L0->B.p);
         if (hipStreamSynchronize(s) != hipSuccess) { fs_set_error("fs_amg_setup: near-null-space upload failed"); return fail(FS_ERR_HIP); }

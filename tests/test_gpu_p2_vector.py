@@ -230,6 +230,9 @@ def test_reference_example_p2_full_size(gpu):
     assert np.abs(U[np.isclose(X[:, 0], 0.0), 0]).max() == 0.0
     st = solver.last_solve_stats
     assert st["converged"] == 1 and st["true_rel_residual"] <= 1e-8
+    # solve_amg as in the reference (LinearElasticitySolver.py:247-250): CG + smoothed aggregation on the P2 operator, rigid-body
+    # modes evaluated at the vertices AND the edge mid-points; Jacobi-CG needs about 3 000 iterations on this mesh
+    assert st["amg_levels"] >= 2 and st["iterations"] <= 80
     # residual of the discrete equilibrium equations against the oracle's operator (free dofs)
     co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 40, 10, 10)
     R, cd, edges = fo.assemble_p2_elasticity(co, ce, E, NU)
@@ -266,3 +269,31 @@ def test_elastodynamics_inertia_term(gpu):
     accel = ((w0 - w1) / dt - (w1 - w2) / dt) / (1.0 / dt)                 # the reference's own scaling (SolverBase.py:477-482)
     ref = M @ accel - fo.assemble_p1_vector_source(co, ce, (78000.0, 0.0, 0.0))
     assert np.abs(b.get() - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_p2_amg_device_modes_equal_the_host_near_null_space(gpu):
+    """The six rigid-body modes built on the device for a CG2 space (vertices + edge mid-points) span what
+    SolverBase.build_nullspace returns; both hierarchies solve the cantilever in the same number of iterations, and the
+    operator annihilates the modes on the interior rows."""
+    solver = _example_solver(12, 3, 3, thermal=False, body=True)
+    solver.init_solver()
+    F, bcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    A, b = solver.assemble_system(F, bcs, symmetric=True)
+    V = solver.function_space
+    ns = solver.build_nullspace(V)
+    assert ns.shape == (6, V.dim())
+    assert np.abs(ns @ ns.T - np.eye(6)).max() <= 1e-12
+    its = []
+    for near in ("rigid_body", ns):
+        H = gpu.AMG(A, nullspace=near)
+        x = gpu.DeviceVector(V.device().n_local)
+        st = H.solve(b, x, rtol=1e-10, max_iter=200)
+        assert st["converged"] == 1 and H.info()["levels"] >= 2
+        its.append(st["iterations"])
+        H.close()
+    assert abs(its[0] - its[1]) <= 2 and its[0] <= 60
+    A0, _ = solver.assemble_system(F, [], symmetric=True)           # no Dirichlet rows: K B = 0
+    y = gpu.DeviceVector(V.dim())
+    for k in range(6):
+        A0.spmv(gpu.DeviceVector(V.dim(), ns[k]), y)
+        assert np.abs(y.get()).max() <= 1e-9 * 2e11 * np.abs(ns[k]).max()
