@@ -75,6 +75,44 @@ def test_folded_system_matches_the_oracle_fold(gpu, ncomp):
     assert np.array_equal(u[sl], u[ma])
 
 
+def test_vector_p2_fold_matches_the_oracle_fold(gpu):
+    """The fold on the vector CG2 operator (3 x 3 node blocks, vertex AND edge-node ties) - the elasticity solver with a
+    periodic_boundary and fe_degree 2."""
+    from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace
+    mesh = BoxMesh(Point(0, 0, 0), Point(1.0, 0.8, 0.6), 4, 3, 2)
+    V = VectorFunctionSpace(mesh, "CG", 2, constrained_domain=_periodic_x())
+    sl, ma = V.periodic_pairs()
+    X = V.node_coordinates()
+    assert len(sl) == (2 * 3 + 1) * (2 * 2 + 1) and np.allclose(X[sl, 0], 1.0) and np.allclose(X[ma, 0], 0.0) and np.allclose(X[sl, 1:], X[ma, 1:])
+    co, ce = mesh.coordinates(), mesh.cells()
+    dV = V.device()
+    A = gpu.DeviceMatrix(dV)
+    b = gpu.DeviceVector(dV.n_owned)
+    mu, lm = fo.lame(10.0, 0.3)
+    A.assemble(lame=(mu, lm))
+    ref, cd, edges = fo.assemble_p2_elasticity(co, ce, 10.0, 0.3)
+    assert np.array_equal(V.edge_nodes(), edges)
+    gpu.assemble_vector(dV, b, vector_value=(0.2, -1.0, 0.4))
+    rhs = fo.assemble_p2_vector_source(co, ce, (0.2, -1.0, 0.4))
+    assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+    A.tie_nodes(b, sl, ma)
+    Af, bf = fo.periodic_fold(ref, rhs, sl, ma, 3)
+    got = _csr(A)
+    assert abs(got - Af).max() <= 1e-12 * abs(ref).max()
+    assert np.abs(b.get() - bf).max() <= 1e-12 * np.abs(rhs).max()
+    # clamp the bottom face and solve
+    nodes = np.nonzero(np.abs(X[:, 2]) < 1e-12)[0]
+    dofs = (nodes[:, None] * 3 + np.arange(3)).ravel()
+    A.apply_dirichlet(b, dofs, 0.0, symmetric=True)
+    Ab, bb = fo.apply_dirichlet(Af, bf, dofs, 0.0, True)
+    x = gpu.DeviceVector(dV.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-12, max_iter=20000)
+    assert st["converged"] == 1
+    x.assign_entries(sl, ma, block=3)
+    want = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma, 3)
+    assert np.abs(x.get() - want).max() <= 1e-7 * np.abs(want).max()
+
+
 def test_tie_nodes_needs_the_coupled_pattern(gpu):
     """Without the (master, neighbour-of-slave) couplings the fold has nowhere to put its entries: loud failure."""
     co, ce = fo.box_mesh((0, 0, 0), (1, 1, 1), 3, 3, 3)
