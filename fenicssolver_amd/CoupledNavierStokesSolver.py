@@ -21,8 +21,10 @@ F -= delta1 (a.grad u).(a.grad v) dx with the reference's sign and its delta1 (k
 otherwise; the transient branch, where the reference reads an undefined ``time_iter_`` and raises NameError, uses the
 step's dt in its formula).  The term enters the Jacobian with the advecting velocity frozen at the iterate; the system is
 written for the new iterate, so the Newton residual is the exact one and the fixed point is the reference's.
+Non-Newtonian material (``material['Newtonian'] = False``, ``viscosity`` :194-213 without a temperature): nu (p / p_ref)^0.1
+with the pressure of the current iterate, evaluated at the quadrature points on the device (``viscosity_law``).
 Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
-velocities, non-Newtonian viscosity, the coupled temperature equation (marked "test not passed" in the reference).
+velocities, the coupled temperature equation (marked "test not passed" in the reference).
 """
 from __future__ import annotations
 
@@ -99,9 +101,20 @@ class CoupledNavierStokesSolver(SolverBase):
         a[:self.mesh.num_vertices(), 3] = vals[:self.mesh.num_vertices(), 3]
         return up0
 
-    def viscosity(self, current_w=None):
+    def viscosity_law(self):
+        """None (Newtonian) or (p_ref, exponent) of the reference's non-Newtonian law (:194-213, the branch without a
+        temperature): nu(p) = nu * pow(p / reference_values['pressure'], 0.1), evaluated on the current iterate as the
+        reference does (F_static :306 takes up_0, the boundary terms :401 w_current)."""
         if 'Newtonian' in self.material and (not self.material['Newtonian']):
-            raise SolverError("non-Newtonian viscosity is not built")
+            pref = (getattr(self, 'reference_values', None) or {}).get('pressure')
+            if pref is None or not float(pref) > 0.0:
+                raise SolverError("non-Newtonian viscosity needs a positive reference_values['pressure']")
+            return (float(pref), 0.1)
+        return None
+
+    def viscosity(self, current_w=None):
+        """The constant kinematic viscosity nu0; a non-Newtonian material multiplies it by (p / p_ref)^0.1 inside the device
+        kernels (viscosity_law)."""
         nu = self.material['kinematic_viscosity']
         if isinstance(nu, Constant):
             nu = float(nu)
@@ -113,6 +126,7 @@ class CoupledNavierStokesSolver(SolverBase):
     def generate_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
         F = forms.NavierStokesForm(self.function_space)
         F.nu = self.viscosity()
+        F.viscosity_law = self.viscosity_law()
         F.rho = float(self.material['density'])
         F.w_current = up_current
         F.w_prev = up_prev
@@ -258,7 +272,7 @@ class CoupledNavierStokesSolver(SolverBase):
         nv = self.mesh.num_vertices()
         wd = backend.DeviceVector(dW.n_local, up.vector()._values())
         b9 = backend.DeviceVector(9 * dP.n_owned)
-        backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9)
+        backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9, viscosity_law=self.viscosity_law())
         rhs = b9.get().reshape(nv, 9)
         M = backend.DeviceMatrix(dP)
         M.assemble(mass=1.0)

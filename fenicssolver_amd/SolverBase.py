@@ -750,7 +750,7 @@ class SolverBase():
                                        body_force=F.body_force if F.body_force is not None else (0.0, 0.0, 0.0),
                                        convection=True, newton=newton,
                                        mesh_velocity=F.mesh_velocity if F.mesh_velocity is not None else (0.0, 0.0, 0.0),
-                                       g2=getattr(F, 'g2', None))
+                                       g2=getattr(F, 'g2', None), viscosity_law=getattr(F, 'viscosity_law', None))
         for marker_id, value in F.pressure_boundaries:
             cells, opp, centroids = self._marked_facet_cells(marker_id)
             if loc is not None:                 # facets whose cell is local; rows of other ranks are skipped on the device
@@ -760,7 +760,7 @@ class SolverBase():
             fv = None
             if value is not None:
                 fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
-            backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv)
+            backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv, viscosity_law=getattr(F, 'viscosity_law', None), w0=dw)
         return dw, g
 
     def _marked_facet_cells(self, marker_id):

@@ -62,7 +62,8 @@ class fs_krylov_stats(C.Structure):
 class fs_ns_form(C.Structure):
     _fields_ = [("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
                 ("body_force", C.c_double * 3), ("convection", C.c_int), ("newton", C.c_int), ("mesh_velocity", C.c_double * 3),
-                ("g2_mode", C.c_int), ("g2_kappa1", C.c_double)]
+                ("g2_mode", C.c_int), ("g2_kappa1", C.c_double),
+                ("viscosity_pressure_ref", C.c_double), ("viscosity_pressure_exponent", C.c_double)]
 
 
 class fs_saddle_opts(C.Structure):
@@ -139,11 +140,13 @@ SIGNATURES = {
     "fs_assemble_facet_supg": (C.c_int, [_H, _H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, C.POINTER(fs_coef), C.c_double]),
     "fs_assemble_navier_stokes": (C.c_int, [_H, _H, _H, _H, C.POINTER(fs_ns_form)]),
     "fs_assemble_ns_pressure_boundary": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]),
+    "fs_assemble_ns_pressure_boundary_nn": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double, _H, C.c_double, C.c_double]),
     "fs_saddle_solve": (C.c_int, [_H, _H, _H, _H, _H, _H, C.POINTER(fs_saddle_opts), C.POINTER(fs_krylov_stats)]),
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "fs_assemble_von_mises": (C.c_int, [_H, _H, C.c_double, C.c_double, _H, _H]),
     "fs_assemble_viscous_stress": (C.c_int, [_H, _H, C.c_double, _H, _H]),
+    "fs_assemble_viscous_stress_nn": (C.c_int, [_H, _H, C.c_double, _H, _H, C.c_double, C.c_double]),
     "fs_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fs_comm_allreduce_sum": (C.c_int, [c_f64p, C.c_int]),
     "fs_comm_allgather": (C.c_int, [c_f64p, c_i64, c_i64, c_f64p]),

@@ -409,9 +409,11 @@ def assemble_von_mises(disp_space, u, mu, lmbda, p1_space, b):
     L.check(L.load().fs_assemble_von_mises(disp_space.h, u.h, float(mu), float(lmbda), p1_space.h, b.h), "fs_assemble_von_mises")
 
 
-def assemble_viscous_stress(th_space, w, nu, p1_space, b):
-    """b[vertex*9 + 3i + j] = int (nu (grad u + grad u^T) - p I)_ij phi_vertex dx for a Taylor-Hood iterate w."""
-    L.check(L.load().fs_assemble_viscous_stress(th_space.h, w.h, float(nu), p1_space.h, b.h), "fs_assemble_viscous_stress")
+def assemble_viscous_stress(th_space, w, nu, p1_space, b, viscosity_law=None):
+    """b[vertex*9 + 3i + j] = int (nu (grad u + grad u^T) - p I)_ij phi_vertex dx for a Taylor-Hood iterate w.
+    viscosity_law = (p_ref, exponent): nu (p / p_ref)^exponent."""
+    pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))
+    L.check(L.load().fs_assemble_viscous_stress_nn(th_space.h, w.h, float(nu), p1_space.h, b.h, pref, ex), "fs_assemble_viscous_stress")
 
 
 def set_dirichlet_values(b, dofs, vals):
@@ -510,9 +512,10 @@ class AMG(_Handle):
 
 
 def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, body_force=(0.0, 0.0, 0.0),
-                           convection=True, newton=True, mesh_velocity=(0.0, 0.0, 0.0), g2=None):
+                           convection=True, newton=True, mesh_velocity=(0.0, 0.0, 0.0), g2=None, viscosity_law=None):
     """Linearised Taylor-Hood system at the state w0 (J w_new = g), J on a DeviceSpace(mesh, ncomp=4, degree=2).
-    g2 = (mode, kappa1): the G2 streamline term (mode 1: Re <= 1, 2: convection dominated)."""
+    g2 = (mode, kappa1): the G2 streamline term (mode 1: Re <= 1, 2: convection dominated).
+    viscosity_law = (p_ref, exponent): nu (p0 / p_ref)^exponent with the pressure of w0 (the reference's non-Newtonian law)."""
     f = L.fs_ns_form()
     f.kinematic_viscosity, f.density, f.inv_dt = float(nu), float(rho), float(inv_dt)
     for i in range(3):
@@ -521,19 +524,24 @@ def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, b
     f.convection, f.newton = (1 if convection else 0), (1 if newton else 0)
     if g2 is not None:
         f.g2_mode, f.g2_kappa1 = int(g2[0]), float(g2[1])
+    if viscosity_law is not None:
+        f.viscosity_pressure_ref, f.viscosity_pressure_exponent = float(viscosity_law[0]), float(viscosity_law[1])
     L.check(L.load().fs_assemble_navier_stokes(J.h, g.h, w0.h if w0 is not None else None,
                                                w_prev.h if w_prev is not None else None, C.byref(f)),
             "fs_assemble_navier_stokes")
 
 
-def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_value=None):
-    """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only)."""
+def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_value=None, viscosity_law=None, w0=None):
+    """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only).
+    viscosity_law = (p_ref, exponent) with the state w0: nu (p0 / p_ref)^exponent."""
     fc = np.ascontiguousarray(facet_cell, dtype=np.int32)
     fo_ = np.ascontiguousarray(facet_opposite, dtype=np.int32)
     fv = None
     if facet_value is not None:
         fv = np.ascontiguousarray(np.broadcast_to(np.asarray(facet_value, dtype=np.float64), fc.shape))
-    L.check(L.load().fs_assemble_ns_pressure_boundary(J.h, g.h, len(fc), L.p_i32(fc), L.p_i32(fo_), L.p_f64(fv), float(nu)),
+    pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))
+    L.check(L.load().fs_assemble_ns_pressure_boundary_nn(J.h, g.h, len(fc), L.p_i32(fc), L.p_i32(fo_), L.p_f64(fv), float(nu),
+                                                         w0.h if (w0 is not None and viscosity_law is not None) else None, pref, ex),
             "fs_assemble_ns_pressure_boundary")
 
 

@@ -2270,7 +2270,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load_tri(int64_t n_rows,
 __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
                                                                   const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
                                                                   const double* __restrict__ xyz4, const int32_t* __restrict__ w_dofs,
-                                                                  const double* __restrict__ w, double nu, double* __restrict__ b) {
+                                                                  const double* __restrict__ w, double nu0, double nn_pref, double nn_exp, double* __restrict__ b) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -2307,6 +2307,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
 #pragma unroll
                         for (int k = 0; k < 3; ++k) G[i][k] += un[n][i] * gp[n][k];
                 const double pq = (lam[0] * pv[0] + lam[1] * pv[1]) + (lam[2] * pv[2] + lam[3] * pv[3]);
+                const double nu = nn_pref > 0.0 ? nu0 * pow(pq / nn_pref, nn_exp) : nu0;     // CoupledNavierStokesSolver.viscosity
                 const double la = wq * (a == 0 ? lam[0] : a == 1 ? lam[1] : a == 2 ? lam[2] : lam[3]);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -2370,8 +2371,14 @@ extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_
     return FS_OK;
 }
 
+extern "C" int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b,
+                                             double nn_pref, double nn_exp);
 extern "C" int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b) {
-    FS_REQUIRE(th_space && w && p1_space && b, "fs_assemble_viscous_stress: null pointer");
+    return fs_assemble_viscous_stress_nn(th_space, w, nu, p1_space, b, 0.0, 0.0);
+}
+extern "C" int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b,
+                                             double nn_pref, double nn_exp) {
+    FS_REQUIRE(th_space && w && p1_space && b && nn_pref >= 0.0, "fs_assemble_viscous_stress: null pointer / negative reference pressure");
     FS_REQUIRE(th_space->mesh == p1_space->mesh, "fs_assemble_viscous_stress: the two spaces live on different meshes");
     FS_REQUIRE(th_space->ncomp == 4 && th_space->degree == 2, "fs_assemble_viscous_stress: needs the Taylor-Hood node-block space");
     FS_REQUIRE(p1_space->ncomp == 1 && p1_space->degree == 1 && p1_space->inc_cell.p, "fs_assemble_viscous_stress: the target is the scalar CG1 space of the mesh");
@@ -2379,7 +2386,7 @@ extern "C" int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, do
     hipStream_t s = fs_rt().stream;
     fs_mesh_s* m = p1_space->mesh;
     hipLaunchKernelGGL(k_viscous_stress_load, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
-                       p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, b->d.p);
+                       p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, nn_pref, nn_exp, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -76,7 +76,11 @@ struct ns_params {
     int convection, newton;
     int g2;            // G2 streamline term (:334-363): 0 off, 1 delta1 = kappa1 h^2 (Re <= 1), 2 delta1 from |a|, h (and dt)
     double g2_kappa;
+    double nn_pref, nn_exp;   // non-Newtonian law (:194-213): nu (p0 / nn_pref)^nn_exp at every quadrature point; nn_pref = 0: off
 };
+__device__ __forceinline__ double ns_viscosity(double nu, double pref, double ex, double p) {
+    return pref > 0.0 ? nu * pow(p / pref, ex) : nu;
+}
 
 // h = 2 * circumradius of the tetrahedron X (UFL's 2*Circumradius(mesh), :343):
 // R = sqrt((aA+bB+cC)(aA+bB-cC)(aA-bB+cC)(-aA+bB+cC)) / (24 V), (a,A) (b,B) (c,C) the opposite edge pairs
@@ -159,14 +163,20 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
             for (int j = 0; j < 4; ++j) blk[i][j] = 0.0;
         double gv[3] = {0.0, 0.0, 0.0};
         const bool do_rhs = b == 0;
+        double P0[4] = {0.0, 0.0, 0.0, 0.0};
+        if (P.nn_pref > 0.0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P0[v] = w0[4 * (int64_t)nd[v] + 3];
+        }
         for (int q = 0; q < 14; ++q) {
             const double l[4] = {NS_QP[q][0], NS_QP[q][1], NS_QP[q][2], NS_QP[q][3]};
             const double wv = NS_QW[q] * vol;
+            const double nuq = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3]);
             double pa, pb, ga[3], gb[3];
             p2_eval(a, l, gl, &pa, ga);
             p2_eval(b, l, gl, &pb, gb);
             const double gg = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
-            double diag = P.nu * gg + P.inv_dt * pa * pb;
+            double diag = nuq * gg + P.inv_dt * pa * pb;
             double u0[3] = {0.0, 0.0, 0.0}, gu0[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             if (P.convection) {
 #pragma unroll
@@ -193,7 +203,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
                 blk[i][i] += wv * diag;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    double v = P.nu * ga[j] * gb[i];
+                    double v = nuq * ga[j] * gb[i];
                     if (P.convection && P.newton) v += pa * pb * gu0[i][j];
                     blk[i][j] += wv * v;
                 }
@@ -264,6 +274,8 @@ struct ns_cell_lds {
     double up[14][3];
     double U0[10][3];
     double UP[10][3];
+    double nuq[14];
+    double P0[4];
     int32_t nd[10];
     int32_t pad[2];
 };
@@ -289,6 +301,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 const int64_t node = cell_dofs[c * 10 + n];
                 L.U0[n][i] = P.convection ? w0[4 * node + i] : 0.0;
                 L.UP[n][i] = has_prev ? wprev[4 * node + i] : 0.0;
+            } else if (lane < 34) {
+                L.P0[lane - 30] = P.nn_pref > 0.0 ? w0[4 * (int64_t)cell_dofs[c * 10 + (lane - 30)] + 3] : 0.0;
             }
             double X[4][3];
 #pragma unroll
@@ -327,6 +341,9 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         __syncthreads();
         if (act) {
             // state, its gradient and the previous velocity at the 14 points
+            if (lane < 14)
+                L.nuq[lane] = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, NS_QP[lane][0] * L.P0[0] + NS_QP[lane][1] * L.P0[1] +
+                                                                      NS_QP[lane][2] * L.P0[2] + NS_QP[lane][3] * L.P0[3]);
             for (int item = lane; item < 210; item += 64) {
                 double acc = 0.0;
                 if (item < 42) {
@@ -367,7 +384,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     const double ga[3] = {L.gphi[q][a][0], L.gphi[q][a][1], L.gphi[q][a][2]};
                     const double gb[3] = {L.gphi[q][b][0], L.gphi[q][b][1], L.gphi[q][b][2]};
                     const double u0[3] = {L.u0[q][0], L.u0[q][1], L.u0[q][2]};
-                    double diag = P.nu * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]) + P.inv_dt * pa * pb;
+                    const double nuq = L.nuq[q];
+                    double diag = nuq * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]) + P.inv_dt * pa * pb;
                     if (P.convection) {
                         const double av[3] = {u0[0] - P.wm[0], u0[1] - P.wm[1], u0[2] - P.wm[2]};
                         const double agb = av[0] * gb[0] + av[1] * gb[1] + av[2] * gb[2];
@@ -383,7 +401,7 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         blk[i][i] += wv * diag;
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
-                            double v = P.nu * ga[j] * gb[i];
+                            double v = nuq * ga[j] * gb[i];
                             if (full) v += pa * pb * L.gu0[q][3 * i + j];
                             blk[i][j] += wv * v;
                         }
@@ -502,6 +520,10 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     FS_REQUIRE(form->g2_mode >= 0 && form->g2_mode <= 2 && (form->g2_mode == 0 || form->convection), "fs_assemble_navier_stokes: bad G2 mode");
     P.g2 = form->g2_mode;
     P.g2_kappa = form->g2_kappa1;
+    FS_REQUIRE(form->viscosity_pressure_ref >= 0.0 && (form->viscosity_pressure_ref == 0.0 || w0),
+               "fs_assemble_navier_stokes: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
+    P.nn_pref = form->viscosity_pressure_ref;
+    P.nn_exp = form->viscosity_pressure_exponent;
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
     // Element blocks -> buffer -> one sum per stored block: 25 ms with 544 M device-scope fp64 atomics became 7 ms
     // (MI355X, configs[4]) and the matrix is bit-reproducible.  FS_NS_ASSEMBLE=atomic / pair selects the one-pass
@@ -551,10 +573,11 @@ __device__ const int NS_FACE_NODES[4][6] = {{1, 2, 3, 4, 5, 6}, {0, 2, 3, 4, 7, 
 
 // thread t = (facet, facet node al, cell node b)
 __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
-                                       const double* __restrict__ facet_value, double nu, const double* __restrict__ xyz,
+                                       const double* __restrict__ facet_value, double nu0, const double* __restrict__ xyz,
                                        const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
                                        const int32_t* __restrict__ slots,
-                                       double* __restrict__ val, int64_t plane, double* __restrict__ g) {
+                                       double* __restrict__ val, int64_t plane, double* __restrict__ g,
+                                       const double* __restrict__ w0, double nn_pref, double nn_exp) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nf * 60; t += stride) {
@@ -598,12 +621,18 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
         double blk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         double gv[3] = {0.0, 0.0, 0.0};
         const double pb = facet_value ? facet_value[f] : 0.0;
+        double P0[4] = {0.0, 0.0, 0.0, 0.0};
+        if (nn_pref > 0.0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P0[v] = w0[4 * (int64_t)cell_dofs[c * 10 + v] + 3];
+        }
         for (int q = 0; q < 6; ++q) {
             double l[4];
             int kk = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) l[v] = (v == o) ? 0.0 : NS_TQ[q][kk++];
             const double wv = NS_TW[q] * area;
+            const double nu = ns_viscosity(nu0, nn_pref, nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3]);
             double pa, pbf, ga[3], gb[3];
             p2_eval(a, l, gl, &pa, ga);
             p2_eval(b, l, gl, &pbf, gb);
@@ -629,10 +658,20 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
     }
 }
 
+extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
+                                                   const int32_t* facet_opposite, const double* facet_value,
+                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp);
 extern "C" int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                                 const int32_t* facet_opposite, const double* facet_value,
                                                 double kinematic_viscosity) {
+    return fs_assemble_ns_pressure_boundary_nn(J, g, n_facets, facet_cell, facet_opposite, facet_value, kinematic_viscosity, nullptr, 0.0, 0.0);
+}
+extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
+                                                   const int32_t* facet_opposite, const double* facet_value,
+                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp) {
     FS_CHECK(fs_require_init());
+    FS_REQUIRE(nn_pref >= 0.0 && (nn_pref == 0.0 || (w0 && J && w0->d.n >= J->space->n_dofs_local)),
+               "fs_assemble_ns_pressure_boundary: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
     FS_REQUIRE(J && g && n_facets >= 0 && (n_facets == 0 || (facet_cell && facet_opposite)), "fs_assemble_ns_pressure_boundary: bad arguments");
     fs_space_s* sp = J->space;
     FS_REQUIRE(sp->degree == 2 && sp->ncomp == 4 && sp->slots.p, "fs_assemble_ns_pressure_boundary: not a Taylor-Hood block matrix");
@@ -654,7 +693,8 @@ extern "C" int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, in
     }
     hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
                        facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
-                       sp->slots.p, J->val.p, sp->sell_entries, g->d.p);
+                       sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,
+                       nn_pref, nn_exp);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -160,6 +160,8 @@ class NavierStokesForm:
         # G2 stabilisation (advection_settings {'stabilization_method': 'G2', 'Re':, 'kappa1':, 'kappa2':}, :334-363):
         # (mode, kappa1) with mode 1 for Re <= 1 (delta1 = kappa1 h^2), 2 otherwise; None = off
         self.g2 = None
+        # non-Newtonian law (material 'Newtonian': False, :194-213): (p_ref, exponent) -> nu (p / p_ref)^exponent; None = off
+        self.viscosity_law = None
 
     @staticmethod
     def _value_name(v):
@@ -174,4 +176,5 @@ class NavierStokesForm:
                 "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
                 "mesh_velocity": None if self.mesh_velocity is None else [float(x) for x in self.mesh_velocity],
                 "g2": None if self.g2 is None else [int(self.g2[0]), float(self.g2[1])],
+                "viscosity_law": None if self.viscosity_law is None else [float(self.viscosity_law[0]), float(self.viscosity_law[1])],
                 "newton": bool(self.newton)}

@@ -239,6 +239,9 @@ int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, doubl
  * Taylor-Hood iterate w (block (u_x,u_y,u_z,p) per CG2 node).  Each of the 9 components is then one CG1 mass-matrix
  * solve (fs_assemble_matrix(mass = 1) on p1_space + fs_krylov_solve). */
 int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b);
+/* The same with nu(p) = nu (p / p_ref)^exponent (fs_ns_form.viscosity_pressure_ref / _exponent). */
+int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b,
+                                  double viscosity_pressure_ref, double viscosity_pressure_exponent);
 
 /* SUPG part of the boundary integrals (the reference substitutes q + tau (v . grad q) in them too,
  * ScalarTransportSolver.py:296-298 with Tq): for every listed boundary facet (cell behind it, local vertex opposite)
@@ -379,6 +382,9 @@ typedef struct fs_ns_form {
                                  * kappa1/2 / sqrt(1/dt^2 + 1/(|a|^2 h^2)) (inv_dt > 0).  Enters J with a frozen at w0 (the
                                  * system is written for the new iterate, so g is unchanged and J w - g is the exact residual). */
     double g2_kappa1;
+    double viscosity_pressure_ref;      /* > 0: the non-Newtonian law of CoupledNavierStokesSolver.viscosity (:194-213, the branch */
+    double viscosity_pressure_exponent; /* without a temperature): nu(p) = nu (p / p_ref)^exponent with the pressure of w0 (needs
+                                         * w0; Picard in the viscosity - J w - g stays the exact residual).  0: Newtonian. */
 } fs_ns_form;
 
 /* J <- linearised operator at w0, g <- right-hand side such that J w_new = g is the Newton (or Picard) step
@@ -391,6 +397,10 @@ int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_v
  * facet_value: p_b per facet, NULL = the pressure 'farfield' type (traction term only, :459-460). */
 int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                      const int32_t* facet_opposite, const double* facet_value, double kinematic_viscosity);
+/* The same with the pressure-dependent viscosity of fs_ns_form (w0: the state whose pressure enters nu). */
+int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
+                                        const int32_t* facet_opposite, const double* facet_value, double kinematic_viscosity,
+                                        fs_vector_t w0, double viscosity_pressure_ref, double viscosity_pressure_exponent);
 
 typedef struct fs_saddle_opts {
     double rtol, atol;          /* on ||g - J w||_2 (relative to ||g||_2) */

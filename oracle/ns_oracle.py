@@ -125,8 +125,17 @@ def g2_delta1(g2, h, U2, inv_dt):
     return out
 
 
+def viscosity_at(nu, law, p_q):
+    """CoupledNavierStokesSolver.viscosity (:194-213), the branch without a temperature: Newtonian -> nu; otherwise
+    nu * pow(p / p_ref, 0.1) with the CURRENT pressure (the reference evaluates it on up_0 / w_current, :306 and :401).
+    law = None or (p_ref, exponent); p_q: pressure at the quadrature points."""
+    if law is None:
+        return np.full(np.shape(p_q), float(nu))
+    return float(nu) * np.power(np.asarray(p_q, dtype=np.float64) / float(law[0]), float(law[1]))
+
+
 def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, newton=True, convection=True,
-              quad_degree=5, mesh_velocity=None, g2=None):
+              quad_degree=5, mesh_velocity=None, g2=None, viscosity_law=None):
     """Linearised system at the state w0:  J(w0) w_new = g(w0).
 
     J = 2 nu eps:eps + (1/dt) mass + (grad(.) u0).v [+ (grad(u0) .).v if newton] - (p/rho) div v + (q/rho) div u
@@ -135,6 +144,8 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
     mesh_velocity (constant 3-vector): the ALE frame of CoupledNavierStokesSolver.py:321-329 - the ADVECTING velocity is
     u0 - w_mesh: (grad(.) (u0 - w)).v in J; the Newton terms (grad(u0) .).v and (grad(u0) u0).v are unchanged
     (J w_new = J w0 - F(w0) with F's convective part (grad(u0) (u0 - w)).v).
+    viscosity_law (p_ref, e): nu(p0) = nu (p0 / p_ref)^e frozen at the state w0 - Picard in the viscosity; K(w) w - rhs
+    is still the exact residual, the reference's Newton (derivative of the form) converges to the same root.
     Returns (J csr [n,n], g [n]); dummy pressure rows are identity / zero.
     """
     nc = len(th.cells)
@@ -146,7 +157,10 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
     Ke = np.zeros((nc, 10, 4, 10, 4))
     ge = np.zeros((nc, 10, 4))
     h_cell = cell_h(th.coords, th.cells) if g2 is not None else None
+    P0 = W0[th.cells][:, :, 3]                              # [nc,4] pressure at the cell vertices
+    nu_const = nu
     for lam, w in zip(pts, wq):
+        nu = viscosity_at(nu_const, viscosity_law, P0 @ np.asarray(lam))     # [nc]
         phi, dphi = p2_shape(lam)
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)     # [nc,10,3] physical gradients
         psi = lam                                           # P1 basis = barycentric coordinates
@@ -210,13 +224,14 @@ def apply_dirichlet_rows(J, g, dofs, vals):
     return J.tocsr(), g
 
 
-def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, mesh_velocity=None, g2=None):
+def residual(th, w, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, mesh_velocity=None, g2=None, viscosity_law=None):
     """R(w) = K(w) w - rhs  (the nonlinear residual F of the reference after action(F, w))."""
-    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False, mesh_velocity=mesh_velocity, g2=g2)
+    K, rhs = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=False, mesh_velocity=mesh_velocity, g2=g2,
+                       viscosity_law=viscosity_law)
     return K @ w - rhs
 
 
-def viscous_stress_projection(th, w, nu):
+def viscous_stress_projection(th, w, nu, viscosity_law=None):
     """project(nu (grad u + grad u^T) - p I, TensorFunctionSpace(mesh, 'CG', 1)) (CoupledNavierStokesSolver.py:149-155):
     consistent P1 mass matrix, 4-point rule (integrand quadratic).  Returns sigma [nv, 3, 3]."""
     W = np.asarray(w, dtype=np.float64).reshape(th.n_nodes, 4)
@@ -229,7 +244,7 @@ def viscous_stress_projection(th, w, nu):
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)
         G = np.einsum("cai,caj->cij", U, gphi)
         pq = Pv @ lam
-        sig = nu * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(3)
+        sig = viscosity_at(nu, viscosity_law, pq)[:, None, None] * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(3)
         be += (wt * th.vol)[:, None, None] * lam[None, :, None] * sig.reshape(-1, 1, 9)
     M = fo.assemble_matrix(th.nv, th.cells, fo.p1_mass_local(th.coords, th.cells, 1.0))
     out = np.zeros((th.nv, 9))
@@ -259,7 +274,7 @@ def boundary_force(th, sigma, inside):
 
 
 def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None,
-                 rtol=1e-9, atol=1e-10, max_it=50, newton=True, relax=1.0, g2=None):
+                 rtol=1e-9, atol=1e-10, max_it=50, newton=True, relax=1.0, g2=None, viscosity_law=None):
     """DOLFIN NewtonSolver semantics (relative 1e-9 / absolute 1e-10 on the residual 2-norm)."""
     import scipy.sparse.linalg as spl
     w = np.array(w_init, dtype=np.float64)
@@ -269,7 +284,7 @@ def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=N
     r0 = None
     history = []
     for it in range(max_it + 1):
-        J, g = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=newton, g2=g2)
+        J, g = ns_system(th, w, nu, rho, inv_dt, w_prev, body_force, newton=newton, g2=g2, viscosity_law=viscosity_law)
         r = (J @ w - g)
         r[~free] = 0.0
         rn = np.linalg.norm(r)
@@ -308,7 +323,7 @@ def boundary_facet_cells(th, inside):
     return np.array(out, dtype=np.int64).reshape(-1, 2)
 
 
-def pressure_boundary_terms(th, facet_cells, nu, bvalue=None):
+def pressure_boundary_terms(th, facet_cells, nu, bvalue=None, viscosity_law=None, w0=None):
     """F += inner(bvalue*n, v)*ds - nu*inner((grad(u) + grad(u).T)*n, v)*ds on the given boundary facets.
     Returns (dJ csr, dg): the matrix of the viscous traction term and the load (moved to the right-hand side).
     bvalue None: the 'farfield' pressure type (traction term only)."""
@@ -316,6 +331,8 @@ def pressure_boundary_terms(th, facet_cells, nu, bvalue=None):
     Ke = np.zeros((nf, 10, 4, 10, 4))
     ge = np.zeros((nf, 10, 4))
     opp = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))
+    nu_const = nu
+    P0 = None if viscosity_law is None else np.asarray(w0, dtype=np.float64).reshape(th.n_nodes, 4)[th.cells][:, :, 3]
     for k, (c, o) in enumerate(facet_cells):
         gl = th.glam[c]
         gnorm = np.linalg.norm(gl[o])
@@ -324,6 +341,7 @@ def pressure_boundary_terms(th, facet_cells, nu, bvalue=None):
         for bary, w in zip(TRI_QP, TRI_QW):
             lam = np.zeros(4)
             lam[list(opp[o])] = bary
+            nu = nu_const if viscosity_law is None else float(viscosity_at(nu_const, viscosity_law, P0[c] @ lam))
             phi, dphi = p2_shape(lam)
             gphi = dphi @ gl                          # [10,3]
             wv = w * area

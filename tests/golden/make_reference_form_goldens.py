@@ -255,6 +255,19 @@ for name, transient, re_ in (("navier_stokes_g2_steady", False, 100), ("navier_s
     except Exception as e:            # the reference's own failure is what gets pinned then
         out[name] = {"reference_raises": "%s: %s" % (type(e).__name__, e)}
 
+# non-Newtonian material (CoupledNavierStokesSolver.viscosity :194-213, the branch without a temperature), with a pressure outlet
+# so that the viscosity of the boundary term (:401) is recorded as well
+st = ns_settings(False)
+st['material'] = {'density': 2.0, 'kinematic_viscosity': 0.01, 'Newtonian': False}
+st['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 1.0e5}
+st['initial_values'] = {'velocity': (0, 0, 0), 'pressure': 1.0e5}
+st['boundary_conditions']["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 3,
+                                       'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(1.0e5)}]}
+try:
+    run("navier_stokes_non_newtonian", CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
+except Exception as e:
+    out["navier_stokes_non_newtonian"] = {"reference_raises": "%s: %s" % (type(e).__name__, e)}
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

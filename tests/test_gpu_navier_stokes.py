@@ -504,3 +504,107 @@ def test_g2_through_the_solver_class(gpu):
     W4, R4 = w.reshape(-1, 4), ref.reshape(-1, 4)
     assert np.abs(W4[:, :3] - R4[:, :3]).max() <= 1e-6
     assert np.abs(R4[:, :3] - plain.reshape(-1, 4)[:, :3]).max() > 1e-4       # and it changes the flow
+
+
+@pytest.mark.parametrize("newton,inv_dt", [(True, 0.0), (False, 5.0)])
+def test_pressure_dependent_viscosity_matches_oracle(gpu, newton, inv_dt):
+    """material 'Newtonian': False (CoupledNavierStokesSolver.viscosity :194-213, the branch without a temperature):
+    nu(p) = nu0 (p / p_ref)^0.1 with the pressure of the current iterate, in the cell terms, the pressure-boundary terms
+    and the stress projection.  Both element kernels, device vs oracle."""
+    import os
+    co, ce, th, mesh, W, Q = _setup(gpu, 3, (1.0, 0.8, 1.3))
+    rng = np.random.default_rng(4)
+    w0 = 0.3 * rng.standard_normal(th.n)
+    w0.reshape(-1, 4)[:th.nv, 3] = 1.0e5 * (1.0 + 0.3 * rng.uniform(-1, 1, th.nv))       # absolute pressures around p_ref
+    w0[th.dummy_dofs()] = 0.0
+    wp = 0.3 * rng.standard_normal(th.n)
+    nu, rho, f, law = 0.07, 1.7, (0.1, -0.2, -9.8), (1.0e5, 0.1)
+    Jr, gr = ns.ns_system(th, w0, nu, rho, inv_dt, wp, f, newton=newton, viscosity_law=law)
+    Jn, _ = ns.ns_system(th, w0, nu, rho, inv_dt, wp, f, newton=newton)
+    assert abs(Jr - Jn).max() > 1e-3 * abs(Jn).max()          # the law matters at these pressures
+    J = gpu.DeviceMatrix(W)
+    g = gpu.DeviceVector(W.n_owned)
+    dw = gpu.DeviceVector(W.n_local, w0)
+    for mode in (None, "pair"):
+        if mode:
+            os.environ["FS_NS_ASSEMBLE"] = mode
+        try:
+            gpu.assemble_navier_stokes(J, g, dw, gpu.DeviceVector(W.n_local, wp), nu=nu, rho=rho, inv_dt=inv_dt,
+                                       body_force=f, convection=True, newton=newton, viscosity_law=law)
+        finally:
+            os.environ.pop("FS_NS_ASSEMBLE", None)
+        assert abs(_csr(J) - Jr).max() <= 1e-11 * abs(Jr).max()
+        assert np.abs(g.get() - gr).max() <= 1e-11 * np.abs(gr).max()
+        if mode is None and os.environ.get("FS_NS_ASSEMBLE"):
+            break
+    # pressure boundaries
+    fin = ns.boundary_facet_cells(th, lambda x: abs(x[0]) < 1e-12)
+    base, gbase = _csr(J), g.get()
+    gpu.assemble_ns_pressure_boundary(J, g, fin[:, 0], fin[:, 1], nu, 5.0, viscosity_law=law, w0=dw)
+    dJ, dg = ns.pressure_boundary_terms(th, fin, nu, 5.0, viscosity_law=law, w0=w0)
+    dJn, _ = ns.pressure_boundary_terms(th, fin, nu, 5.0)
+    assert abs(dJ - dJn).max() > 1e-3 * abs(dJn).max()
+    assert abs((_csr(J) - base) - dJ).max() <= 1e-12 * abs(base).max()
+    assert np.abs((g.get() - gbase) - dg).max() <= 1e-12 * np.abs(gbase).max()
+    # stress projection: right-hand sides against the oracle's
+    b9 = gpu.DeviceVector(9 * Q.n_owned)
+    gpu.assemble_viscous_stress(W, dw, nu, Q, b9, viscosity_law=law)
+    sig = ns.viscous_stress_projection(th, w0, nu, viscosity_law=law)
+    M = fo.assemble_matrix(th.nv, th.cells, fo.p1_mass_local(th.coords, th.cells, 1.0))
+    want = M @ sig.reshape(th.nv, 9)
+    assert np.abs(b9.get().reshape(th.nv, 9) - want).max() <= 1e-10 * np.abs(want).max()
+    with pytest.raises(gpu.BackendError):
+        gpu.assemble_navier_stokes(J, g, None, None, nu=nu, rho=rho, convection=False, newton=False, viscosity_law=law)
+
+
+def test_non_newtonian_channel_through_the_solver_class(gpu):
+    """The solver class with material['Newtonian'] = False: pressure-driven channel at absolute pressures around p_ref;
+    the converged iterate is a root of the ORACLE's residual with the same law, and differs from the Newtonian one."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, Expression, near, SolverError
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    nu, pref = 0.3, 10.0
+
+    def run(newtonian, ref_pressure=pref):
+        mesh = UnitCubeMesh(3, 3, 3)
+        bcs = OrderedDict()
+        bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[2], 0) or near(x[2], 1) or near(x[1], 0) or near(x[1], 1))),
+                        'boundary_id': 1, 'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+        bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 0)), 'boundary_id': 2,
+                        'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(14.0)}]}
+        bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 1)), 'boundary_id': 3,
+                         'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(8.0)}]}
+        s = copy.deepcopy(SB.default_case_settings)
+        s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+                  'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 10.0},
+                  'material': {'density': 1.0, 'kinematic_viscosity': nu, 'Newtonian': newtonian}})
+        s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': ref_pressure}
+        s['report_settings'] = dict(QUIET)
+        solver = CoupledNavierStokesSolver(s)
+        w = solver.solve()
+        return solver, mesh, w.vector().array().copy()
+
+    solver, mesh, w_nn = run(False)
+    _, _, w_n = run(True)
+    assert solver.viscosity_law() == (pref, 0.1) and solver.viscosity() == nu
+    U_nn, U_n = w_nn.reshape(-1, 4)[:, 0], w_n.reshape(-1, 4)[:, 0]
+    assert U_n.max() > 0.05 and np.abs(U_nn - U_n).max() > 2e-3 * U_n.max()
+    # root of the oracle's residual (cell terms + pressure-boundary terms) on the free dofs
+    th = ns.TaylorHood(mesh.coordinates(), mesh.cells())
+    law = (pref, 0.1)
+    K, rhs = ns.ns_system(th, w_nn, nu, 1.0, 0.0, None, None, newton=False, viscosity_law=law)
+    for inside, val in ((lambda x: abs(x[0]) < 1e-12, 14.0), (lambda x: abs(x[0] - 1) < 1e-12, 8.0)):
+        dJ, dg = ns.pressure_boundary_terms(th, ns.boundary_facet_cells(th, inside), nu, val, viscosity_law=law, w0=w_nn)
+        K, rhs = K + dJ, rhs + dg
+    r = K @ w_nn - rhs
+    X = th.node_coords
+    walls = th.boundary_nodes(lambda x: min(abs(x[1]), abs(x[1] - 1), abs(x[2]), abs(x[2] - 1)) < 1e-12)
+    co = mesh.coordinates()
+    fixed = np.concatenate([th.velocity_dofs(walls), th.pressure_dofs(np.nonzero(co[:, 0] == 0)[0]), th.pressure_dofs(np.nonzero(co[:, 0] == 1)[0]),
+                            th.dummy_dofs()])
+    r[fixed] = 0.0
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(rhs)
+    with pytest.raises(SolverError):
+        run(False, ref_pressure=0)

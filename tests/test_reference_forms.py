@@ -402,7 +402,10 @@ def _ns_expected_terms(desc, state="W0", prev="WPREV"):
     in the recording stub's notation with the state / previous-step functions replaced by placeholders."""
     eps = lambda f: "mul(0.5, add(grad(%s), transpose(grad(%s))))" % (f, f)   # noqa: E731
     num = lambda x: repr(float(x)) if not float(x).is_integer() else "%d" % x  # noqa: E731
-    t = [(+1, "mul(%s, inner(%s, %s))" % (num(desc["nu"] * 2.0), eps("u_trial[0]"), eps("v_test[0]"))),
+    law = desc.get("viscosity_law")
+    nu_expr = None if not law else "mul(%s, pow(div(%s[1], %s), %s))" % (num(desc["nu"]), state, num(law[0]), num(law[1]))
+    visc = "mul(%s, inner(%s, %s))" % (num(desc["nu"] * 2.0) if not law else "mul(%s, 2)" % nu_expr, eps("u_trial[0]"), eps("v_test[0]"))
+    t = [(+1, visc),
          (-1, "mul(div(u_trial[1], %s), div(v_test[0]))" % num(desc["rho"])),
          (+1, "mul(div(u_trial[0]), div(v_test[1], %s))" % num(desc["rho"]))]
     if desc["body_force"] is not None:
@@ -422,8 +425,8 @@ def _ns_expected_terms(desc, state="W0", prev="WPREV"):
     for marker, value in desc.get("pressure_boundaries", []):
         if value is not None:
             t.append((+1, "inner(mul(%s, n), v_test[0])" % value, "ds(%d)" % marker))
-        t.append((+1, "mul(%s, inner(mul(add(grad(u_trial[0]), transpose(grad(u_trial[0]))), n), v_test[0]))" % num(-desc["nu"]),
-                  "ds(%d)" % marker))
+        t.append((+1, "mul(%s, inner(mul(add(grad(u_trial[0]), transpose(grad(u_trial[0]))), n), v_test[0]))"
+                  % (num(-desc["nu"]) if not law else "neg(%s)" % nu_expr), "ds(%d)" % marker))
     return t
 
 
@@ -492,6 +495,46 @@ def test_navier_stokes_terms(case, transient, body):
     v2 = dbcs[1].values.reshape(-1, 3)
     assert np.all(v2[:, 0] == 1.0) and np.all(v2[:, 1:] == 0.0)
     assert np.all(dbcs[1].dofs % 4 != 3)       # velocity components only
+
+
+def test_navier_stokes_non_newtonian_terms():
+    """material['Newtonian'] = False (CoupledNavierStokesSolver.viscosity :194-213): the reference multiplies nu by
+    pow(p / reference pressure, 0.1) with the pressure of the CURRENT iterate, in the cell term (:306) and in the boundary
+    term of a pressure outlet (:401).  The form description of this package says the same."""
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = UnitCubeMesh(2, 2, 2)
+    bcs = collections.OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[2] - 1) < 1e-12), 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[0] - 1) < 1e-12), 'boundary_id': 3,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(1.0e5)}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
+              'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 1.0e5},
+              'material': {'density': 2.0, 'kinematic_viscosity': 0.01, 'Newtonian': False}})
+    s['solver_settings']['transient_settings'] = {'transient': False, 'starting_time': 0.0, 'time_step': 0.01, 'ending_time': 0.01}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 1.0e5}
+    s['report_settings'] = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = CoupledNavierStokesSolver(s)
+    solver.init_solver()
+    F, dbcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    desc = F.describe()
+    assert desc["viscosity_law"] == [1.0e5, 0.1] and desc["nu"] == 0.01
+    gold = GOLD["navier_stokes_non_newtonian"]["solves"][0]
+    terms, state = [], None
+    for t in gold["terms"]:
+        m = re.match(r"^action\((.*), (interpolate\(Expression\(.*?\)\)\))\)$", t["integrand"])
+        assert m
+        state = state or m.group(2)
+        assert m.group(2) == state
+        terms.append((t["sign"], m.group(1).replace(state, "W0"), t["measure"]))
+    assert sorted(terms) == sorted(_ns_expected_terms(desc))
+    assert [(b["space"], b["marker"]) for b in gold["bcs"]] == [("W.sub(0)", 1), ("W.sub(0)", 2), ("W.sub(1)", 3)]
+    assert [b.marker_id for b in dbcs] == [1, 2, 3]
 
 
 def test_reference_g2_transient_branch_is_broken_upstream():
