@@ -421,9 +421,10 @@ class SolverBase():
             per_facet = np.asarray(per_facet)[mask]
         return ltri, per_facet
 
-    def assemble_system(self, F, bcs, symmetric=True):
+    def assemble_system(self, F, bcs, symmetric=True, tie=True):
         """(A, b) on the device for a ScalarForm / ElasticityForm, Dirichlet conditions applied
-        (dolfin.assemble_system / assemble + bc.apply; SolverBase.py:594-602, 644)."""
+        (dolfin.assemble_system / assemble + bc.apply; SolverBase.py:594-602, 644).  tie=False leaves a periodic
+        constraint unfolded (the Newton loop adds its boundary terms first and folds then)."""
         from . import backend
         ip = getattr(F, 'ip_coefficient', 0.0)
         V = F.space.device(facet_coupling=True) if ip else F.space.device()
@@ -563,7 +564,7 @@ class SolverBase():
         else:
             raise SolverError('unknown form specification {}'.format(type(F)))
         per = F.space.periodic_pairs() if hasattr(F.space, 'periodic_pairs') else None
-        if per is not None:
+        if per is not None and tie:
             A.tie_nodes(b, per[0], per[1])          # before the Dirichlet rows, as DOLFIN's dofmap has no slave dofs at all
         dofs, vals = self._bc_arrays(bcs)
         if loc is not None and dofs.size:
@@ -593,8 +594,7 @@ class SolverBase():
             return self._navier_stokes_newton(F, u_current, Dirichlet_bcs)
         if not isinstance(F, forms.ScalarForm):
             raise SolverError('nonlinear solves are built for scalar transport and Navier-Stokes only')
-        if F.space.periodic_pairs() is not None:
-            raise SolverError('periodic_boundary is built for linear problems (the Newton loop does not fold its residual)')
+        per = F.space.periodic_pairs()
         from . import parallel
         sp = self.solver_settings.get('solver_parameters', {}) or {}
         newton = sp.get('newton_solver', {}) if isinstance(sp.get('newton_solver', {}), dict) else {}
@@ -608,6 +608,8 @@ class SolverBase():
         T = u_current.vector()._values().copy()
         if gdofs.size:
             T[gdofs] = gvals                                # the first iterate carries the boundary values
+        if per is not None:
+            T[per[0]] = T[per[1]]                           # ... and is periodic
         dofs = gdofs if loc is None else loc.dofs(gdofs, gvals)[0]
         own = dofs[dofs < n]
         ext = self.mesh.facets()[self.mesh.exterior_facets()]
@@ -626,7 +628,7 @@ class SolverBase():
             u_current.vector().set_local(T)
             if hasattr(self, 'refresh_nonlinear_form'):
                 self.refresh_nonlinear_form(F, u_current)
-            A, b = self.assemble_system(F, [], symmetric=True)      # operator and loads at the iterate, no BCs
+            A, b = self.assemble_system(F, [], symmetric=True, tie=False)   # operator and loads at the iterate, no BCs
             if F.radiation is not None:
                 m_, T_amb = F.radiation
                 Tf = T[ext.astype(np.int64)].mean(axis=1)
@@ -635,6 +637,12 @@ class SolverBase():
             r = backend.DeviceVector(n)
             A.spmv(Tdev, r)
             r.axpy(-1.0, b)                                         # r = A(T) T - b(T)
+            if per is not None:
+                # periodic constraint: Jacobian and residual are folded onto the masters together (A <- P^T A P + unit
+                # slave rows, r <- P^T r with zeros on the slaves), so the Jacobian's boundary term goes in first
+                if F.radiation is not None:
+                    A.add_facet_mass(ext_dev, (4.0 * m_ * Tf ** 3)[ext_mask])
+                A.tie_nodes(r, per[0], per[1])
             if own.size:
                 backend.set_dirichlet_values(r, own, 0.0)           # residual of constrained rows is zero
             rn2 = float(r.dot(r))
@@ -650,7 +658,7 @@ class SolverBase():
                 break
             if it == max_it:
                 raise SolverError('Newton solver did not converge in {} iterations (residual {:.3e})'.format(max_it, rnorm))
-            if F.radiation is not None:
+            if F.radiation is not None and per is None:
                 A.add_facet_mass(ext_dev, (4.0 * m_ * Tf ** 3)[ext_mask])   # d/dT of  + m T^4 q ds
             rhs = backend.DeviceVector(n)
             rhs.axpy(-1.0, r)
@@ -663,6 +671,8 @@ class SolverBase():
             self.last_solve_stats = stats
             if stats['converged'] != 1:
                 raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))
+            if per is not None:
+                delta.assign_entries(per[0], per[1])                # the slaves move with their masters
             d = delta.get()[:n]
             if loc is not None:
                 d = parallel.gather_owned(d, loc.owned_gids(), loc.n_global, 1)

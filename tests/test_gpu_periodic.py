@@ -247,3 +247,56 @@ def test_p2_space_with_periodic_boundary(gpu, dim):
     want = fo.periodic_expand(fo.solve_direct(Ab, bb), sl, ma)
     assert np.abs(T - want).max() <= 1e-7 * np.abs(want).max()
     assert np.array_equal(T[sl], T[ma])
+
+
+def test_radiation_newton_with_periodic_boundary(gpu):
+    """Nonlinear path (solve_nonlinear_problem) on a periodic space: Jacobian and residual of every Newton step are folded
+    together; checked against the same Newton iteration written with the oracle and its fold."""
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh = UnitCubeMesh(5, 4, 3)
+    bcs = OrderedDict()
+    bcs["bottom"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(300.0)}
+    bcs["top"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant(360.0)}
+    settings = {'solver_name': 'ScalarTransportSolver', 'mesh': mesh, 'function_space': None, 'periodic_boundary': _periodic_x(),
+                'fe_family': 'CG', 'fe_degree': 1, 'boundary_conditions': bcs, 'body_source': None,
+                'initial_values': {'temperature': 300}, 'material': {'density': 1.0, 'specific_heat_capacity': 1.0, 'thermal_conductivity': 0.6,
+                                                                      'emissivity': 0.9},
+                'radiation_settings': {'ambient_temperature': 280.0, 'emissivity': 0.9},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'relative_tolerance': 1e-9, 'maximum_iterations': 5000, 'krylov_relative_tolerance': 1e-13}},
+                'report_settings': QUIET, 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    T = solver.solve().vector().get_local()
+    assert solver.nonlinear and 2 <= solver.newton_iterations <= 30
+    sl, ma = solver.function_space.periodic_pairs()
+    co, ce = mesh.coordinates(), mesh.cells()
+    facets, _, cnt = fo.facet_numbering(ce)
+    ext = facets[cnt == 1].astype(np.int64)              # every exterior facet radiates, the periodic faces included (ds is ds)
+    area = fo.facet_areas(co, ext)
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    dofs = np.concatenate([top, bot])
+    vals = np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+    mrad, Ta = 0.9 * 5.670367e-8, 280.0
+    Tn = np.full(len(co), 300.0)
+    Tn[dofs] = vals
+    Tn[sl] = Tn[ma]
+    K = fo.assemble_p1_scalar(co, ce, 0.6)
+    base = (np.ones((3, 3)) + np.eye(3)) / 12.0
+    for it in range(60):
+        Tf = Tn[ext].mean(axis=1)
+        b = np.zeros(len(co))
+        np.add.at(b, ext.ravel(), np.repeat(mrad * (Ta ** 4 - Tf ** 4) * area / 3.0, 3))
+        r = K @ Tn - b
+        Me = (4.0 * mrad * Tf ** 3 * area)[:, None, None] * base[None]
+        J = K + sp.coo_matrix((Me.ravel(), (np.repeat(ext, 3, axis=1).ravel(), np.tile(ext, (1, 3)).ravel())), shape=K.shape).tocsr()
+        Jf, rf = fo.periodic_fold(J, -r, sl, ma)
+        Jb, rb = fo.apply_dirichlet(Jf, rf, dofs, 0.0, True)
+        chk = rb.copy()
+        chk[dofs] = 0.0
+        if np.linalg.norm(chk) < 1e-10:
+            break
+        Tn = Tn + fo.periodic_expand(fo.solve_direct(Jb, rb), sl, ma)
+    assert np.abs(T - Tn).max() <= 1e-6 and np.array_equal(T[sl], T[ma])
+    assert np.abs(T - (300.0 + 60.0 * co[:, 1])).max() > 1e-3              # radiation matters
