@@ -698,19 +698,28 @@ class SolverBase():
             Q = Qs.device()
             qloc = Qs.localizer()
             pinned = (pre // 4).astype(np.int64)
+            per = W.periodic_pairs()                 # (slave, master) P2 nodes of a periodic_boundary, or None
+            qper = Qs.periodic_pairs()
+            pin_vertex = 0
+            if qper is not None and 0 in set(qper[0].tolist()):
+                pin_vertex = int(qper[1][list(qper[0]).index(0)])      # a slave has no equation of its own: pin its master
             if pinned.size == 0:
                 # no pressure condition: the pressure is defined up to a constant (the reference's LU hits a
                 # singular matrix here); fix it at vertex 0
-                self.logger.warning('no pressure boundary condition: pinning the pressure at vertex 0 to 0')
-                pinned = np.zeros(1, dtype=np.int64)
+                self.logger.warning('no pressure boundary condition: pinning the pressure at vertex %d to 0', pin_vertex)
+                pinned = np.full(1, pin_vertex, dtype=np.int64)
             if qloc is not None:
                 pinned = qloc.dofs(pinned, np.zeros(len(pinned)))[0]
             pinned = np.asarray(pinned, dtype=np.int32)
             Kp = backend.DeviceMatrix(Q)
             Kp.assemble(stiffness=1.0)
+            if qper is not None:
+                Kp.tie_nodes(None, qper[0], qper[1])
             Kp.apply_dirichlet(None, pinned, np.zeros(len(pinned)), symmetric=True)
             Mp = backend.DeviceMatrix(Q)
             Mp.assemble(mass=1.0)
+            if qper is not None:
+                Mp.tie_nodes(None, qper[0], qper[1])
             cell_g2l = None
             if loc is not None:
                 cell_g2l = np.full(self.mesh.num_cells(), -1, dtype=np.int64)
@@ -729,10 +738,12 @@ class SolverBase():
             else:
                 kp_amg, keep = backend.AMG(Kp), None
             ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
-                   'auto_pin': pre.size == 0, 'Kp_amg': kp_amg, 'cell_g2l': cell_g2l, 'global_pressure': keep}
+                   'auto_pin': pre.size == 0, 'Kp_amg': kp_amg, 'cell_g2l': cell_g2l, 'global_pressure': keep,
+                   'per': per, 'pin_dof': 4 * pin_vertex + 3,
+                   'slave_dofs': None if per is None else (per[0].astype(np.int64)[:, None] * 4 + np.arange(4)).ravel().astype(np.int32)}
             self._ns_ctx = ctx
         if ctx['auto_pin']:
-            dofs = np.concatenate([dofs, np.array([3], dtype=np.int32)]).astype(np.int32)
+            dofs = np.concatenate([dofs, np.array([ctx['pin_dof']], dtype=np.int32)]).astype(np.int32)
             vals = np.concatenate([vals, np.zeros(1)])
         if loc is not None:
             dofs, vals = loc.dofs(dofs, vals)
@@ -771,6 +782,9 @@ class SolverBase():
             if value is not None:
                 fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
             backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv, viscosity_law=getattr(F, 'viscosity_law', None), w0=dw)
+        if ctx.get('per') is not None:
+            # periodic_boundary: J <- P^T J P + unit slave rows, g <- P^T g (zeros on the slaves), all four unknowns of a node
+            ctx['J'].tie_nodes(g, ctx['per'][0], ctx['per'][1])
         return dw, g
 
     def _marked_facet_cells(self, marker_id):
@@ -819,9 +833,15 @@ class SolverBase():
         w = u_current.vector().get_local()
         w[gdofs] = gvals
         if ctx['auto_pin']:
-            w[3] = 0.0
+            w[ctx['pin_dof']] = 0.0
         w[F.space.dummy_dofs()] = 0.0
+        per = ctx.get('per')
+        if per is not None:
+            w4 = w.reshape(-1, 4)
+            w4[per[0]] = w4[per[1]]                # the iterate is periodic from the start
         own = dofs[dofs < V.n_owned]               # constrained rows of this rank (the list also names ghost dofs)
+        if per is not None:
+            own = np.unique(np.concatenate([own, ctx['slave_dofs']]))      # slave rows are unit rows: no residual there
         # several GPUs: the iterate lives in this rank's numbering (owned + ghost entries) during the iteration - the
         # update of the ghosts comes with the halo of the Krylov solution - and is gathered once at the end
         # the iterate, the residual and the update stay in HBM for the whole Newton iteration (one upload, one download)
@@ -878,6 +898,8 @@ class SolverBase():
             t5 = clock()
             if loc is not None and parallel.world()[1] > 1:
                 backend.halo_exchange(V, x)                   # ghost entries of the update
+            if per is not None:
+                x.assign_entries(per[0], per[1], block=4)     # the slaves move with their masters
             dw.axpy(relax, x)
             t6 = clock()
             tm["dirichlet"] += t4 - t3
@@ -904,9 +926,15 @@ class SolverBase():
         w0 = w.copy()
         w0[gdofs] = gvals
         if ctx['auto_pin']:
-            w0[3] = 0.0
+            w0[ctx['pin_dof']] = 0.0
+        per = ctx.get('per')
+        if per is not None:
+            w04 = w0.reshape(-1, 4)
+            w04[per[0]] = 0.0                                  # slave rows are unit rows with a zero right-hand side
         x = backend.DeviceVector(V.n_local, self._ns_local(loc, w0))
         self._navier_stokes_krylov(F, ctx, ctx['J'], g, x, float(sp.get('krylov_relative_tolerance', 1e-8)), True)
+        if per is not None:
+            x.assign_entries(per[0], per[1], block=4)
         out = x.get()[:V.n_owned]
         if loc is not None:
             out = parallel.gather_owned(out, loc.owned_gids(), loc.n_global, 4)

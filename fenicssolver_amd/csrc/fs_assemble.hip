@@ -1749,7 +1749,7 @@ extern "C" int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs
     if (n_pairs == 0) return FS_OK;
     fs_space_s* sp = A->space;
     FS_REQUIRE(!sp->halo.active, "fs_matrix_tie_nodes: tied nodes are built for one GPU");
-    FS_REQUIRE(A->bs >= 1 && A->bs <= 3, "fs_matrix_tie_nodes: block size %d", A->bs);
+    FS_REQUIRE(A->bs >= 1 && A->bs <= 4, "fs_matrix_tie_nodes: block size %d", A->bs);
     FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_matrix_tie_nodes: right-hand side too short");
     for (int64_t i = 0; i < n_pairs; ++i)
         FS_REQUIRE(slaves[i] >= 0 && slaves[i] < sp->n_nodes_owned && masters[i] >= 0 && masters[i] < sp->n_nodes_owned && slaves[i] != masters[i],
@@ -1771,8 +1771,9 @@ extern "C" int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs
         hipLaunchKernelGGL(k_tie_rows<BS_>, dim3(gp), dim3(FS_BLOCK), 0, s, n_pairs, d_s.p, d_m.p, sp->n_nodes_owned, sp->slice_ptr.p,    \
                            sp->sell_col.p, A->val.p, sp->sell_entries, bp, d_err.p);                                                      \
     }
-    if (A->bs == 1) FS_TIE(1) else if (A->bs == 2) FS_TIE(2) else FS_TIE(3)
+    if (A->bs == 1) FS_TIE(1) else if (A->bs == 2) FS_TIE(2) else if (A->bs == 3) FS_TIE(3) else FS_TIE(4)
 #undef FS_TIE
+    if (A->bs == 4 && A->taylor_hood) fs_ns_reset_dummy_rows(A, s);     // the folded dummy diagonals of edge masters: 2 -> 1
     FS_KERNEL_CHECK();
     int h_err = 0;
     FS_CHECK(d_err.download(&h_err, 1, s));

@@ -57,6 +57,8 @@ struct fs_runtime {
     void* comm = nullptr;
 };
 fs_runtime& fs_rt();
+struct fs_matrix_s;
+void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s);   // fs_saddle.hip: unit diagonal on the dummy pressure slots
 int fs_require_init();
 
 // ---- device memory -------------------------------------------------------------

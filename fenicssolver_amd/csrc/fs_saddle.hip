@@ -496,6 +496,16 @@ __global__ void k_ns_dummy_rows(int64_t nv, int64_t n_nodes, const int64_t* __re
     }
 }
 
+// After a periodic fold (fs_matrix_tie_nodes) the dummy pressure slot of a master edge node holds 2 (its own unit
+// diagonal plus the slave's); the operator product treats those rows as the identity, so the stored value follows.
+void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s) {
+    fs_space_s* sp = J->space;
+    const int64_t nv = sp->mesh->n_owned;
+    if (sp->n_nodes_owned <= nv) return;
+    hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - nv)), dim3(FS_BLOCK), 0, s, nv, sp->n_nodes_owned,
+                       sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
+}
+
 extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev,
                                          const fs_ns_form* form) {
     FS_CHECK(fs_require_init());

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .fem import FunctionSpace, Function, SolverError, DirichletBC, _Element   # noqa: F401
+from .fem import FunctionSpace, Function, SolverError, DirichletBC, _Element, periodic_vertex_pairs   # noqa: F401
 
 
 class TaylorHoodSpace(FunctionSpace):
@@ -19,8 +19,6 @@ class TaylorHoodSpace(FunctionSpace):
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
         if int(pressure_degree) != 1:
             raise SolverError("Taylor-Hood is built for fe_degree 1 (P2 velocity / P1 pressure) only")
-        if constrained_domain is not None:
-            raise SolverError("periodic_boundary (constrained_domain) is not supported")
         if mesh.geometry().dim() != 3:
             raise SolverError("the Navier-Stokes path is built for 3D tetrahedral meshes")
         self._mesh = mesh
@@ -30,7 +28,10 @@ class TaylorHoodSpace(FunctionSpace):
         self._component = None
         self._parent = None
         self._device = None
-        self._periodic = None
+        # periodic_boundary (CoupledNavierStokesSolver.py:97-100): vertex and edge nodes of the slave side are tied to the
+        # master side, all four unknowns of a node together; the pressure space carries the same constraint
+        self._constrained_domain = constrained_domain
+        self._periodic = None if constrained_domain is None else periodic_vertex_pairs(mesh, constrained_domain)
 
     def num_sub_spaces(self):
         return 2
@@ -48,7 +49,7 @@ class TaylorHoodSpace(FunctionSpace):
 
     def pressure_space(self):
         if getattr(self, "_q", None) is None:
-            self._q = FunctionSpace(self._mesh, "CG", 1)
+            self._q = FunctionSpace(self._mesh, "CG", 1, constrained_domain=self._constrained_domain)
         return self._q
 
     def velocity_space(self):

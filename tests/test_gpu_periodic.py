@@ -300,3 +300,77 @@ def test_radiation_newton_with_periodic_boundary(gpu):
         Tn = Tn + fo.periodic_expand(fo.solve_direct(Jb, rb), sl, ma)
     assert np.abs(T - Tn).max() <= 1e-6 and np.array_equal(T[sl], T[ma])
     assert np.abs(T - (300.0 + 60.0 * co[:, 1])).max() > 1e-3              # radiation matters
+
+
+def test_taylor_hood_fold_and_periodic_channel(gpu):
+    """periodic_boundary on the velocity-pressure space (CoupledNavierStokesSolver.py:97-100): all four unknowns of a P2 node
+    are tied.  (1) the folded linearised system equals the oracle's fold; (2) a body-force driven channel, periodic in x,
+    lands on Poiseuille flow (exact in P2) through the solver class, Newton and Picard."""
+    import copy
+    from oracle import ns_oracle as ns
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd.mixed import TaylorHoodSpace
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = UnitCubeMesh(3, 3, 3)
+    W = TaylorHoodSpace(mesh, "CG", 1, constrained_domain=_periodic_x())
+    sl, ma = W.periodic_pairs()
+    X = W.node_coordinates()
+    assert len(sl) == 7 * 7 and np.allclose(X[sl, 0], 1.0) and np.allclose(X[ma, 0], 0.0) and np.allclose(X[sl, 1:], X[ma, 1:])
+    th = ns.TaylorHood(mesh.coordinates(), mesh.cells())
+    dW = W.device()
+    assert np.array_equal(dW.edges().astype(np.int64), th.edges.astype(np.int64))
+    rng = np.random.default_rng(8)
+    w0 = 0.3 * rng.standard_normal(th.n)
+    w0[th.dummy_dofs()] = 0.0
+    J, g = gpu.DeviceMatrix(dW), gpu.DeviceVector(dW.n_owned)
+    gpu.assemble_navier_stokes(J, g, gpu.DeviceVector(dW.n_local, w0), None, nu=0.07, rho=1.3, body_force=(0.2, 0.0, -1.0))
+    J.tie_nodes(g, sl, ma)
+    Jr, gr = ns.ns_system(th, w0, 0.07, 1.3, 0.0, None, (0.2, 0.0, -1.0))
+    Jf, gf = fo.periodic_fold(Jr, gr, sl, ma, 4)
+    # the dummy pressure slot of an edge node stays a unit row on the device (the fold would make it 2 on the masters)
+    dd = th.dummy_dofs()
+    Jf = Jf.tolil()
+    Jf[dd, dd] = 1.0
+    Jf = Jf.tocsr()
+    assert abs(_csr(J) - Jf).max() <= 1e-11 * abs(Jr).max()
+    assert np.abs(g.get() - gf).max() <= 1e-11 * np.abs(gr).max()
+    # operator product on the folded matrix (the Taylor-Hood kernel skips the structurally empty pressure planes)
+    xh = rng.standard_normal(th.n)
+    y = gpu.DeviceVector(dW.n_owned)
+    J.spmv(gpu.DeviceVector(dW.n_local, xh), y)
+    assert np.abs(y.get() - Jf @ xh).max() <= 1e-11 * (abs(Jf) @ np.abs(xh)).max()
+
+    nu = 0.3
+    prof = Expression(("x[2]*(1-x[2])", "0", "0"), degree=2)
+
+    def run(nonlinear):
+        bcs = OrderedDict()
+        bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[2], 0) or near(x[2], 1) or near(x[1], 0) or near(x[1], 1))),
+                        'boundary_id': 1, 'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': prof}]}
+        s = copy.deepcopy(SB.default_case_settings)
+        s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': UnitCubeMesh(3, 3, 3), 'fe_degree': 1, 'boundary_conditions': bcs,
+                  'periodic_boundary': _periodic_x(), 'body_source': Constant((2 * nu, 0.0, 0.0)),
+                  'initial_values': {'velocity': (0, 0, 0), 'pressure': 0}, 'material': {'density': 1.0, 'kinematic_viscosity': nu}})
+        s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+        # the mean flow is the smoothest mode of the system: tight Krylov / Newton tolerances to see the exact profile
+        s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-11,
+                                                     'newton_solver': {'relative_tolerance': 1e-12, 'absolute_tolerance': 1e-13}}
+        s['report_settings'] = dict(QUIET)
+        solver = CoupledNavierStokesSolver(s)
+        solver.using_nonlinear_solver = nonlinear
+        solver.solve()
+        return solver
+
+    for nonlinear in (True, False):
+        solver = run(nonlinear)
+        Ws = solver.function_space
+        u, p = solver.split()
+        Xn = Ws.node_coordinates()
+        U = u.node_values()
+        tol = 1e-9 if nonlinear else 1e-4          # the Picard loop (relaxation 0.7) stops at its own, looser criterion
+        assert np.abs(U[:, 0] - Xn[:, 2] * (1 - Xn[:, 2])).max() <= tol and np.abs(U[:, 1:]).max() <= tol
+        assert np.abs(p.vector().array()).max() <= 10 * tol       # the body force drives the flow, no pressure drop
+        s2, m2 = Ws.periodic_pairs()
+        a = solver.w_current.vector().array().reshape(-1, 4)
+        assert np.array_equal(a[s2], a[m2])
