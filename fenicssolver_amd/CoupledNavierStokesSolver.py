@@ -124,6 +124,13 @@ class CoupledNavierStokesSolver(SolverBase):
 
     # ------------------------------------------------------------------ form
     def generate_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
+        F = self._cell_form(time_iter_, up_current, up_prev)
+        bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function,
+                                                                                  Measure("ds", subdomain_data=self.boundary_facets))
+        self.J = F if self.using_nonlinear_solver else None
+        return F, bcs
+
+    def _cell_form(self, time_iter_, up_current, up_prev):
         F = forms.NavierStokesForm(self.function_space)
         F.nu = self.viscosity()
         F.viscosity_law = self.viscosity_law()
@@ -153,10 +160,50 @@ class CoupledNavierStokesSolver(SolverBase):
             raise SolverError("advection stabilisation '{}' is not built".format(ads['stabilization_method']))
         if self.transient_settings['transient']:
             F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:367-381)
-        bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function,
-                                                                                  Measure("ds", subdomain_data=self.boundary_facets))
-        self.J = F if self.using_nonlinear_solver else None
-        return F, bcs
+        return F
+
+    def _boundary_value(self, value):
+        """The time-dependent forms translate_value accepts (SolverBase.py:365-366, 376-377): one entry per time step (a
+        sequence longer than the dimension, as examples/test_cfd_solver.py:127-129 passes for its inlet) or a callable
+        of the time; everything else goes to DirichletBC as it is."""
+        if not self.transient_settings['transient']:
+            return value
+        if isinstance(value, (list, tuple)) and len(value) > self.dimension:
+            if self.current_step >= len(value):
+                raise SolverError("boundary value list has {} entries, time step {} asked".format(len(value), self.current_step))
+            return value[self.current_step]
+        if callable(value) and not isinstance(value, (Constant, Function)) and not hasattr(value, 'eval_points'):
+            return value(self.get_current_time())
+        return value
+
+    # The reference splits its form into F_static / F_transient (:288-365, 367-381), which subclasses and the FSI solver call;
+    # here both return the form description generate_form builds (without / with the backward-Euler term).
+    def F_static(self, trial_function, test_function, up_0):
+        saved = self.transient_settings
+        try:
+            self.transient_settings = dict(saved, transient=False)
+            return self._cell_form(0, up_0, None)
+        finally:
+            self.transient_settings = saved
+
+    def F_transient(self, time_iter_, trial_function, test_function, up_current, up_prev):
+        F = self.F_static(trial_function, test_function, up_current)
+        F.w_prev = up_prev
+        F.inv_dt = 1.0 / self.get_time_step(time_iter_)      # backward Euler (:381)
+        return F
+
+    def update_solver_function_space(self, periodic_boundary=None):
+        """After a mesh update (FSI, :104-117): rebuild the mixed space and carry the iterates over (same topology)."""
+        old_c, old_p = self.w_current.vector().get_local(), self.w_prev.vector().get_local()
+        self._update_function_space(periodic_boundary)
+        self.trial_function = self.test_function = None
+        self.w_current, self.w_prev = Function(self.function_space), Function(self.function_space)
+        self.w_current.vector().set_local(old_c)
+        self.w_prev.vector().set_local(old_p)
+        self._ns_ctx = None
+
+    def plot_result(self):
+        self.plot()
 
     def update_boundary_conditions(self, time_iter_, trial_function, test_function, ds):
         """-> (Dirichlet conditions, pressure-boundary integrals) (CoupledNavierStokesSolver.py:383-490)."""
@@ -174,10 +221,8 @@ class CoupledNavierStokesSolver(SolverBase):
                 var, typ = bc.get('variable'), bc.get('type')
                 if var == 'velocity':
                     if typ == 'Dirichlet':
-                        value = bc['value']
-                        if isinstance(value, list):
-                            raise SolverError("per-time-step lists of velocity values are not built")
-                        if isinstance(value, (tuple, np.ndarray)):
+                        value = self._boundary_value(bc['value'])
+                        if isinstance(value, (tuple, list, np.ndarray)):
                             value = Constant(tuple(float(x) for x in value))
                         bcs.append(DirichletBC(W.sub(0), value, self.boundary_facets, bid))
                     elif typ == 'Neumann':
@@ -191,7 +236,7 @@ class CoupledNavierStokesSolver(SolverBase):
                         self.logger.warning('velocity boundary type`%s` is not supported', typ)
                 elif var == 'pressure':
                     if typ == 'Dirichlet':      # pressure inlet or outlet (:445-453)
-                        value = bc['value']
+                        value = self._boundary_value(bc['value'])
                         if isinstance(value, numbers.Number):
                             value = Constant(float(value))
                         bcs.append(DirichletBC(W.sub(1), value, self.boundary_facets, bid))

@@ -608,3 +608,42 @@ def test_non_newtonian_channel_through_the_solver_class(gpu):
     assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(rhs)
     with pytest.raises(SolverError):
         run(False, ref_pressure=0)
+
+
+def test_time_dependent_boundary_values_and_form_parts(gpu):
+    """translate_value's time-dependent forms on a velocity boundary (SolverBase.py:365-366 a sequence with one entry per time
+    step, :376-377 a callable of the time), as examples/test_cfd_solver.py:127-129 passes them; and the reference's
+    F_static / F_transient entry points (:288-381)."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+
+    def run(lid_value):
+        s, mesh = _cavity_settings(3, transient=True, nu=0.05, t_end=0.03)
+        s['boundary_conditions']['lid']['values'][0]['value'] = lid_value
+        solver = CoupledNavierStokesSolver(s)
+        return solver, mesh, solver.solve().vector().array().copy()
+
+    ramp = [0.25, 0.5, 0.75, 1.0, 1.0]
+    _, mesh, w_list = run([Constant((a, 0, 0)) for a in ramp])
+    # get_current_time() of step k is starting_time + dt (k - 1), as in the reference (SolverBase.py:453-465)
+    solver, _, w_call = run(lambda t: Constant((ramp[int(round(t / 0.01)) + 1], 0, 0)))
+    assert np.abs(w_list - w_call).max() <= 1e-12
+    _, _, w_const = run(Constant((1.0, 0, 0)))
+    assert np.abs(w_list - w_const).reshape(-1, 4)[:, :3].max() > 1e-2           # the ramp is a different problem
+    # oracle: the same ramp, step by step
+    th = ns.TaylorHood(mesh.coordinates(), mesh.cells())
+    X = th.node_coords
+    bn = th.boundary_nodes(lambda x: True)
+    top = bn[X[bn, 2] == 1.0]
+    bc_dofs = np.concatenate([th.velocity_dofs(bn), th.pressure_dofs([0])])
+    w = np.zeros(th.n)
+    for k in range(solver.current_step):
+        vals = np.zeros((th.n_nodes, 4))
+        vals[top, 0] = ramp[k]
+        w, _ = ns.newton_solve(th, w, bc_dofs, vals.ravel()[bc_dofs], 0.05, 1.0, 100.0, w.copy(), None)
+    assert np.abs(w_list - w).reshape(-1, 4)[:, :3].max() <= 2e-6
+    # form parts
+    Fs = solver.F_static(None, None, solver.w_current)
+    Ft = solver.F_transient(1, None, None, solver.w_current, solver.w_prev)
+    assert Fs.inv_dt == 0.0 and Ft.inv_dt == pytest.approx(100.0) and Ft.w_prev is solver.w_prev
+    assert Fs.describe()["nu"] == 0.05 and solver.transient_settings['transient'] is True
