@@ -205,6 +205,14 @@ class CoupledNavierStokesSolver(SolverBase):
     def plot_result(self):
         self.plot()
 
+    def generate_thermal_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
+        raise SolverError("solving_temperature (the coupled energy equation, :247-286) is not built; the reference marks it "
+                          "'test not passed' (:236)")
+
+    def viscous_heat(self, u, p):
+        raise SolverError("viscous_heat: the reference projects a scalar, inner(sigma, grad(u)), onto the VECTOR velocity space "
+                          "(:187-192, 'not tested code'): there is no such projection; sigma is available from viscous_stress()")
+
     def update_boundary_conditions(self, time_iter_, trial_function, test_function, ds):
         """-> (Dirichlet conditions, pressure-boundary integrals) (CoupledNavierStokesSolver.py:383-490)."""
         W = self.function_space
