@@ -160,9 +160,16 @@ class ScalarTransportSolver(SolverBase):
             return nod[tri].mean(axis=1)
         raise SolverError('{}: boundary value of type {} is not supported'.format(what, type(value)))
 
-    def get_convective_velocity_function(self, convective_velocity):
-        """-> constant 3-vector or per-cell velocities [n_cells,3] (ScalarTransportSolver.py:131-140).
-        A spatially varying velocity is sampled at the vertices and enters cell-wise by its mean."""
+    # int phi^P2_n phi^P1_a dx on a tetrahedron of unit volume (n: 4 vertices, 6 UFC edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1))
+    _P2_P1_MASS = np.array([[0.0 if n == a else -1.0 / 60.0 for a in range(4)] for n in range(4)] +
+                           [[1.0 / 15.0 if a in e else 1.0 / 30.0 for a in range(4)]
+                            for e in ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))])
+
+    def get_convective_velocity_function(self, convective_velocity, per_test_function=True):
+        """-> constant 3-vector, or the velocities of a field (ScalarTransportSolver.py:131-140, 305-311).
+        per_test_function: [n_cells, d+1, 3] with V_a = (d+1)/|K| int_K u phi_a dx, the weights that integrate
+        inner(u, grad(T)) * q * dx exactly for a P1 field (Expression / Function sampled at the vertices) or a P2 vector
+        Function (its vertex and edge values); False (SUPG, whose tau needs one |u| per cell): the cell mean [n_cells, 3]."""
         v = convective_velocity
         if isinstance(v, Constant):
             vals = v.values()
@@ -183,7 +190,14 @@ class ScalarTransportSolver(SolverBase):
         nod = np.asarray(nod, dtype=np.float64)
         if nod.ndim != 2 or nod.shape[1] != self.dimension:
             raise SolverError('convective_velocity must be a {}-vector field'.format(self.dimension))
-        return self._pad3(nod[self.mesh.cells().astype(np.int64)].mean(axis=1))
+        cells = self.mesh.cells().astype(np.int64)
+        if not per_test_function:
+            return self._pad3(nod[cells].mean(axis=1))
+        if isinstance(v, Function) and v.function_space().degree() == 2 and self.dimension == 3:
+            Uc = v.node_values()[v.function_space().cell_nodes().astype(np.int64)]            # [nc,10,3]
+            return self._pad3(4.0 * np.einsum("na,cni->cai", self._P2_P1_MASS, Uc))
+        Uc = nod[cells]                                                                          # [nc,d+1,dim]
+        return self._pad3((Uc.sum(axis=1, keepdims=True) + Uc) / (cells.shape[1] + 1.0))
 
     @staticmethod
     def _pad3(v):
@@ -303,7 +317,7 @@ class ScalarTransportSolver(SolverBase):
                     raise SolverError("advection_settings['Pe'] must be positive")
             elif method:
                 raise SolverError("advection stabilization '{}' is not known ('SPUG', 'IP' or None)".format(method))
-            velocity = self.get_convective_velocity_function(self.convective_velocity)
+            velocity = self.get_convective_velocity_function(self.convective_velocity, per_test_function=not supg_pe > 0.0)
         F = forms.ScalarForm(self.function_space)
         F.supg_pe = supg_pe if self.convective_velocity else 0.0
         F.ip_coefficient = ip_coef if self.convective_velocity else 0.0

@@ -436,7 +436,7 @@ class SolverBase():
             theta = F.theta if F.transient else 1.0
             mass = L_(F.capacity.spec(1.0 / F.dt)) if F.transient else None
             adv, adv_scale = F.advection if F.advection is not None else (None, 1.0)
-            if adv is not None and loc is not None and np.ndim(adv) == 2:
+            if adv is not None and loc is not None and np.ndim(adv) >= 2:
                 adv = loc.cells(adv)
             pe = getattr(F, 'supg_pe', 0.0) if adv is not None else 0.0
             # Constant coefficients in a time loop: the unconstrained operators are the same every step - kept on the

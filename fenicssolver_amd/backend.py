@@ -248,6 +248,11 @@ def _bilinear_form(keep, stiffness=None, mass=None, lame=None, advection=None, a
             f.advection.mode = L.FS_COEF_CONST
             for i in range(3):
                 f.advection.tensor[i] = float(v.ravel()[i])
+        elif v.ndim == 3:           # [n_cells, d+1, 3]: one velocity per cell and test function (fem.row_velocities)
+            v = L.f64(np.ascontiguousarray(v).reshape(-1, 3))
+            keep.append(v)
+            f.advection.mode = L.FS_COEF_CELL_ROW
+            f.advection.data = L.p_f64(v)
         else:
             v = L.f64(v.reshape(-1, 3))
             keep.append(v)

@@ -278,7 +278,10 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
                 // Galerkin advection: C_ab = scale * (vol/4) * (v . grad phi_b), the same for every row a
                 double vx, vy, vz;
                 if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; vz = ac.tensor[2]; }
-                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; vz = ac.data[3 * (int64_t)c + 2]; }
+                else {      // per cell, or per (cell, test function a) - the exact weights of a finite-element velocity
+                    const int64_t o = ac.mode == FS_COEF_CELL_ROW ? 3 * (4 * (int64_t)c + a) : 3 * (int64_t)c;
+                    vx = ac.data[o]; vy = ac.data[o + 1]; vz = ac.data[o + 2];
+                }
                 const double w4 = ascale * vol * 0.25;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) row[b] += w4 * (vx * t.g[b][0] + vy * t.g[b][1] + vz * t.g[b][2]);
@@ -1013,7 +1016,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
             if (ac.mode != FS_COEF_NONE) {         // Galerkin advection: scale * (area/3) * (v . grad phi_b)
                 double vx, vy;
                 if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; }
-                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; }
+                else {
+                    const int64_t o = ac.mode == FS_COEF_CELL_ROW ? 3 * (3 * (int64_t)c + a) : 3 * (int64_t)c;
+                    vx = ac.data[o]; vy = ac.data[o + 1];
+                }
                 const double w3 = ascale * t.area * (1.0 / 3.0);
 #pragma unroll
                 for (int b = 0; b < 3; ++b) row[b] += w3 * (vx * t.g[b][0] + vy * t.g[b][1]);
@@ -1826,7 +1832,7 @@ static int make_coef(const fs_coef& in, int64_t expect_len, dbuf<double>& store,
     out->value = in.value;
     out->data = nullptr;
     for (int i = 0; i < 9; ++i) out->tensor[i] = in.tensor[i];
-    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL) {
+    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL || in.mode == FS_COEF_CELL_ROW) {
         FS_REQUIRE(in.data, "%s: coefficient data pointer is null", what);
         FS_CHECK(store.alloc(expect_len));
         FS_CHECK(store.upload(in.data, expect_len, fs_rt().stream));
@@ -1964,9 +1970,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
         dbuf<double> astore2;
         coef_dev ac2;
-        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore2, &ac2, "fs_assemble_matrix(advection)"));
-        FS_REQUIRE(ac2.mode == FS_COEF_NONE || ac2.mode == FS_COEF_CONST || ac2.mode == FS_COEF_CELL,
-                   "fs_assemble_matrix: advection velocity must be constant or per cell");
+        FS_CHECK(make_coef(form->advection, (form->advection.mode == FS_COEF_CELL_ROW ? 9 : 3) * m->nc, astore2, &ac2, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE(ac2.mode == FS_COEF_NONE || ac2.mode == FS_COEF_CONST || ac2.mode == FS_COEF_CELL || ac2.mode == FS_COEF_CELL_ROW,
+                   "fs_assemble_matrix: advection velocity must be constant, per cell or per (cell, test function)");
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
@@ -1997,9 +2003,10 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
         dbuf<double> astore;
         coef_dev ac;
-        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore, &ac, "fs_assemble_matrix(advection)"));
-        FS_REQUIRE(ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL,
-                   "fs_assemble_matrix: advection velocity must be constant or per cell");
+        FS_CHECK(make_coef(form->advection, (form->advection.mode == FS_COEF_CELL_ROW ? 12 : 3) * m->nc, astore, &ac, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE(ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL || ac.mode == FS_COEF_CELL_ROW,
+                   "fs_assemble_matrix: advection velocity must be constant, per cell or per (cell, test function)");
+        FS_REQUIRE(!(ac.mode == FS_COEF_CELL_ROW && form->supg_pe > 0.0), "fs_assemble_matrix: SUPG takes a constant or per-cell velocity");
         // LDS: one accumulator column per thread; fall to one wave per workgroup for very long rows
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
@@ -2341,9 +2348,10 @@ extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_
     coef_dev kc, mc, ac;
     FS_CHECK(make_coef(form->mass, m->nc, mstore, &mc, "fs_operator_apply(mass)"));
     FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_operator_apply(stiffness)"));
-    FS_CHECK(make_coef(form->advection, 3 * m->nc, astore, &ac, "fs_operator_apply(advection)"));
+    FS_CHECK(make_coef(form->advection, (form->advection.mode == FS_COEF_CELL_ROW ? 12 : 3) * m->nc, astore, &ac, "fs_operator_apply(advection)"));
     FS_REQUIRE((mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL) && kc.mode != FS_COEF_NODAL &&
-               (ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL),
+               (ac.mode == FS_COEF_NONE || ac.mode == FS_COEF_CONST || ac.mode == FS_COEF_CELL || ac.mode == FS_COEF_CELL_ROW) &&
+               !(ac.mode == FS_COEF_CELL_ROW && form->supg_pe > 0.0),
                "fs_operator_apply: coefficients must be constant or per cell");
     const int wpb = FS_BLOCK / 64;
     const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;

@@ -179,6 +179,8 @@ int fs_matrix_destroy(fs_matrix_t A);
 #define FS_COEF_CELL 2
 #define FS_COEF_TENSOR 3
 #define FS_COEF_NODAL 4 /* linear forms only: P1-interpolated coefficient */
+#define FS_COEF_CELL_ROW 5 /* advection velocity only: data[n_cells][d+1][3], V_a = (d+1)/|K| int_K u phi_a dx per cell and test
+                            * function - integrates inner(u, grad T) q dx exactly for a finite-element velocity u */
 
 typedef struct fs_coef {
     int mode;             /* FS_COEF_* */
@@ -198,7 +200,7 @@ typedef struct fs_bilinear_form {
     double lame_mu;      /* vector spaces */
     double lame_lambda;  /* vector spaces */
     /* scalar spaces: + advection_scale * int (v . grad u) q dx  (ScalarTransportSolver.py:311; Galerkin,
-     * non-symmetric).  v: FS_COEF_CONST -> tensor[0..2]; FS_COEF_CELL -> data[n_cells][3]. */
+     * non-symmetric).  v: FS_COEF_CONST -> tensor[0..2]; FS_COEF_CELL -> data[n_cells][3]; FS_COEF_CELL_ROW -> data[n_cells][d+1][3]. */
     fs_coef advection;
     double advection_scale;
     /* SUPG ("SPUG" in the reference, ScalarTransportSolver.py:259-270): the test function becomes

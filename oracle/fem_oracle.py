@@ -293,10 +293,39 @@ def p1_advection_local(coords, cells, velocity, scale=1.0):
     detJ, g = p1_geometry(coords, cells)
     vol = np.abs(detJ) / 6.0
     v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 3:                                    # row velocities [nc,4,3]: V_a = (4/vol) int v phi_a dx (exact for a field)
+        vg = np.einsum("cai,cbi->cab", v, g)
+        return scale * 0.25 * vol[:, None, None] * vg
     if v.ndim == 1:
         v = np.broadcast_to(v, (len(cells), 3))
     vg = np.einsum("ci,cbi->cb", v, g)                 # v . grad phi_b
     return scale * 0.25 * vol[:, None, None] * np.broadcast_to(vg[:, None, :], (len(cells), 4, 4))
+
+
+# int phi^P2_n phi^P1_a dx on a tetrahedron of unit volume (n: 4 vertices, then the 6 UFC edges; a: vertex)
+def _p2_p1_mass_unit():
+    M = np.zeros((10, 4))
+    for n in range(4):
+        for a in range(4):
+            M[n, a] = 0.0 if n == a else -1.0 / 60.0
+    for e, (i, j) in enumerate(P2_EDGE_VERTS):
+        for a in range(4):
+            M[4 + e, a] = 1.0 / 15.0 if a in (i, j) else 1.0 / 30.0
+    return M
+
+
+def row_velocities(cells, nodal_velocity, cell_dofs=None):
+    """V[c,a,:] = (d+1)/|K| int_K u phi_a dx for a P1 (nodal values at the vertices) or P2 (cell_dofs [nc,10] given) velocity
+    field u on tetrahedra, or a P1 field on triangles: the weights with which  inner(u, grad(T)) * q * dx
+    (ScalarTransportSolver.py:305-311) is integrated EXACTLY for a finite-element velocity; a constant u gives V = u."""
+    U = np.asarray(nodal_velocity, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.int64)
+    if cell_dofs is not None:
+        Uc = U[np.asarray(cell_dofs, dtype=np.int64)]                    # [nc,10,dim]
+        return 4.0 * np.einsum("na,cni->cai", _p2_p1_mass_unit(), Uc)
+    Uc = U[cells]                                                        # [nc,d+1,dim]
+    nv = cells.shape[1]
+    return (Uc.sum(axis=1, keepdims=True) + Uc) / (nv + 1.0)
 
 
 def assemble_p1_source(coords, cells, f=None, f_nodal=None, cell_markers=None, subdomain_id=None):
@@ -920,6 +949,8 @@ def tri_mass_local(coords, cells, c=1.0):
 def tri_advection_local(coords, cells, velocity, scale=1.0):
     area, g = tri_geometry(coords, cells)
     v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 3:                                    # row velocities [nc,3,2] (row_velocities)
+        return scale * (area / 3.0)[:, None, None] * np.einsum("cai,cbi->cab", v[:, :, :2], g)
     if v.ndim == 1:
         v = np.broadcast_to(v, (len(area), 2))
     vg = np.einsum("ci,cbi->cb", v, g)

@@ -265,6 +265,26 @@ def test_convective_velocity_case(gpu):
     assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
     assert solver.last_solve_stats["converged"] == 1
     # an unknown stabilisation is refused loudly, not silently dropped ('SPUG' and 'IP' are built: below, test_gpu_ip.py)
+    # a velocity FIELD (Expression -> P1 interpolant): inner(u, grad(T)) * q * dx is integrated exactly, with one velocity
+    # per cell and test function (fs_coef FS_COEF_CELL_ROW) - not by a cell mean
+    from fenicssolver_amd.fem import Expression
+    s3, m3 = _box_heat_settings(4)
+    s3['material'] = {'density': 10.0, 'specific_heat_capacity': 20.0, 'thermal_conductivity': 0.6}
+    s3['convective_velocity'] = Expression(("0.5*x[1]", "-0.5*x[0]*x[2]", "0.2*x[0]"), degree=1)
+    T3 = ScalarTransportSolver(s3).solve().vector().array()
+    co3, ce3 = m3.coordinates(), m3.cells()
+    U = np.stack([0.5 * co3[:, 1], -0.5 * co3[:, 0] * co3[:, 2], 0.2 * co3[:, 0]], axis=1)
+    K3 = fo.p1_stiffness_local(co3, ce3, 0.6)
+    top, bot = np.nonzero(co3[:, 1] == 1.0)[0], np.nonzero(co3[:, 1] == 0.0)[0]
+    dofs3 = np.concatenate([top, bot])
+    vals3 = np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+
+    def direct(vel):
+        A3 = fo.assemble_matrix(len(co3), ce3, K3 + fo.p1_advection_local(co3, ce3, vel, 200.0))
+        return fo.solve_direct(*fo.apply_dirichlet(A3, np.zeros(len(co3)), dofs3, vals3, True))
+    exact3 = direct(fo.row_velocities(ce3, U))
+    assert np.abs(T3 - exact3).max() <= 1e-7 * np.abs(exact3).max()
+    assert np.abs(direct(U[ce3.astype(np.int64)].mean(axis=1)) - exact3).max() > 1e-4     # the cell mean is another matrix
     s2, _ = _box_heat_settings(3)
     s2['convective_velocity'] = Constant((0.005, -0.005, 0.0))
     s2['advection_settings'] = {'stabilization_method': 'G2'}

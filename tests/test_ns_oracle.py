@@ -79,3 +79,47 @@ def test_jacobian_is_the_derivative_of_the_residual():
     K0, _ = ns.ns_system(th, np.zeros(th.n), *args, newton=False)
     J0, _ = ns.ns_system(th, np.zeros(th.n), *args, newton=True)
     assert abs(K0 - J0).max() == 0
+
+
+def test_row_velocity_advection_is_the_exact_integral_for_p1_and_p2_fields():
+    """fo.row_velocities / p1_advection_local with [nc,4,3] velocities: C_ab = int (u . grad phi_b) phi_a dx integrated EXACTLY for
+    a P1 or a P2 velocity field (what FFC's quadrature does for ScalarTransportSolver.py:305-311 and for the temperature
+    equation of the coupled flow solver, whose convective velocity is the P2 iterate) - pinned with the degree-5 rule."""
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.7, 1.2), 2, 2, 2)
+    rng = np.random.default_rng(12)
+    th = ns.TaylorHood(co, ce)
+    pts, wq = ns.tet_quadrature(5)
+    detJ, g = fo.p1_geometry(co, ce)
+    vol = np.abs(detJ) / 6.0
+    # P2 field
+    U2 = rng.standard_normal((th.n_nodes, 3))
+    want = np.zeros((len(ce), 4, 4))
+    for lam, w in zip(pts, wq):
+        phi, _ = ns.p2_shape(lam)
+        u = np.einsum("n,cni->ci", phi, U2[th.cell_nodes])
+        want += (w * vol)[:, None, None] * np.einsum("a,cb->cab", lam, np.einsum("ci,cbi->cb", u, g))
+    got = fo.p1_advection_local(co, ce, fo.row_velocities(ce, U2, cell_dofs=th.cell_nodes), 1.0)
+    assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()
+    # P1 field
+    U1 = rng.standard_normal((len(co), 3))
+    want = np.zeros((len(ce), 4, 4))
+    for lam, w in zip(pts, wq):
+        u = np.einsum("v,cvi->ci", lam, U1[ce.astype(np.int64)])
+        want += (w * vol)[:, None, None] * np.einsum("a,cb->cab", lam, np.einsum("ci,cbi->cb", u, g))
+    got = fo.p1_advection_local(co, ce, fo.row_velocities(ce, U1), 1.0)
+    assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()
+    # a constant field gives back the cell-wise formula
+    const = np.tile([0.3, -0.2, 0.5], (len(co), 1))
+    assert np.abs(fo.p1_advection_local(co, ce, fo.row_velocities(ce, const), 2.0) - fo.p1_advection_local(co, ce, (0.3, -0.2, 0.5), 2.0)).max() <= 1e-15
+    # triangles, P1 field, 3-point edge-midpoint rule (exact for quadratics)
+    c2, t2 = fo.rectangle_mesh((0, 0), (1.0, 0.8), 3, 2) if hasattr(fo, "rectangle_mesh") else (None, None)
+    if c2 is not None:
+        U = rng.standard_normal((len(c2), 2))
+        area, g2 = fo.tri_geometry(c2, t2)
+        want = np.zeros((len(t2), 3, 3))
+        for lam in ((0.5, 0.5, 0.0), (0.0, 0.5, 0.5), (0.5, 0.0, 0.5)):
+            lam = np.asarray(lam)
+            u = np.einsum("v,cvi->ci", lam, U[t2.astype(np.int64)])
+            want += (area / 3.0)[:, None, None] * np.einsum("a,cb->cab", lam, np.einsum("ci,cbi->cb", u, g2))
+        got = fo.tri_advection_local(c2, t2, fo.row_velocities(t2, U), 1.0)
+        assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max()
