@@ -23,8 +23,11 @@ step's dt in its formula).  The term enters the Jacobian with the advecting velo
 written for the new iterate, so the Newton residual is the exact one and the fixed point is the reference's.
 Non-Newtonian material (``material['Newtonian'] = False``, ``viscosity`` :194-213 without a temperature): nu (p / p_ref)^0.1
 with the pressure of the current iterate, evaluated at the quadrature points on the device (``viscosity_law``).
+``solving_temperature`` (:236-239, 247-286): the transport equation of the temperature on the pressure space, IP-stabilised,
+convected by the velocity iterate - solved after the flow of every step (block-triangular for a Newtonian fluid); ``split``
+then returns (u, p, T) as the reference's MixedElement([V, Q, Q]) does.
 Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
-velocities, the coupled temperature equation (marked "test not passed" in the reference).
+velocities, a viscosity depending on the temperature.
 """
 from __future__ import annotations
 
@@ -43,9 +46,9 @@ class CoupledNavierStokesSolver(SolverBase):
 
     def __init__(self, case_input):
         self.solving_temperature = bool(case_input.get('solving_temperature', False)) if isinstance(case_input, dict) else False
-        if self.solving_temperature:
-            raise SolverError("solving_temperature (coupled energy equation) is not built; the reference marks it 'test not passed'")
+        self._Tsolver = None
         SolverBase.__init__(self, case_input)
+        self.solving_temperature = self.solving_temperature or bool(self.settings.get('solving_temperature', False))
         self.compressible = False
         self.using_nonlinear_solver = True
         self.settings['mixed_variable'] = ('velocity', 'pressure')
@@ -106,6 +109,9 @@ class CoupledNavierStokesSolver(SolverBase):
         temperature): nu(p) = nu * pow(p / reference_values['pressure'], 0.1), evaluated on the current iterate as the
         reference does (F_static :306 takes up_0, the boundary terms :401 w_current)."""
         if 'Newtonian' in self.material and (not self.material['Newtonian']):
+            if self.solving_temperature:
+                raise SolverError("non-Newtonian viscosity with solving_temperature (nu depending on p AND T, :200-204) couples "
+                                  "the temperature back into the momentum equation; not built")
             pref = (getattr(self, 'reference_values', None) or {}).get('pressure')
             if pref is None or not float(pref) > 0.0:
                 raise SolverError("non-Newtonian viscosity needs a positive reference_values['pressure']")
@@ -202,12 +208,58 @@ class CoupledNavierStokesSolver(SolverBase):
         self.w_prev.vector().set_local(old_p)
         self._ns_ctx = None
 
-    def plot_result(self):
-        self.plot()
-
+    # ---- the coupled temperature equation (solving_temperature, :236-239 and :247-286) ---------------------------------
+    # The reference adds the form of a ScalarTransportSolver on W.sub(2) - the flow case's own settings with scalar_name
+    # 'temperature', IP stabilisation alpha = 0.1, convective velocity = the CURRENT velocity iterate - to the flow form
+    # and solves (u, p, T) monolithically.  For a Newtonian fluid nothing of T enters the momentum or continuity equations
+    # (the viscous heating stays commented out, :281-285), so the converged (u, p) is the flow solution and T solves the
+    # transport equation with that velocity: the block-triangular system is solved here in that order, step by step.
     def generate_thermal_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
-        raise SolverError("solving_temperature (the coupled energy equation, :247-286) is not built; the reference marks it "
-                          "'test not passed' (:236)")
+        Ts = self._temperature_solver()
+        Ts.convective_velocity = split(up_current)[0]
+        return Ts.generate_form(time_iter_, None, None, Ts.w_current, Ts.w_prev)
+
+    def _temperature_solver(self):
+        if self._Tsolver is None:
+            import copy
+            from collections import OrderedDict
+            from .ScalarTransportSolver import ScalarTransportSolver
+            from . import case
+            ts = copy.copy(self.settings)                    # "Tsettings = copy.copy(self.settings)" (:255)
+            ts['scalar_name'] = 'temperature'
+            ts['mesh'] = None
+            ts['function_space'] = self.function_space.pressure_space()      # MixedElement([V, Q, Q]): T lives on Q (:94-95)
+            ts['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}     # (:262)
+            ts['convective_velocity'] = None
+            ts['solving_temperature'] = False
+            if ts.get('body_source'):
+                # the copied settings would hand the flow's body force (a vector) to the scalar equation; the reference
+                # leaves "Tsettings['body_source'] = # incomplate form?" open (:263)
+                self.logger.warning("solving_temperature: the flow's body_source is not a heat source; the temperature "
+                                    "equation runs without one")
+                ts['body_source'] = None
+            keep = OrderedDict()
+            for name, bc in (self.settings.get('boundary_conditions') or {}).items():
+                sub = case.boundary_variable(bc, 'temperature')
+                if sub is not bc or bc.get('variable') == 'temperature':
+                    keep[name] = bc                          # boundaries without a temperature entry stay natural (zero flux)
+            ts['boundary_conditions'] = keep
+            self._Tsolver = ScalarTransportSolver(ts)
+            self._Tsolver.init_solver()
+        return self._Tsolver
+
+    def solve_current_step(self):
+        SolverBase.solve_current_step(self)
+        if self.solving_temperature:
+            Ts = self._temperature_solver()
+            Ts.current_step, Ts.current_time = self.current_step, getattr(self, 'current_time', 0.0)
+            Ts.convective_velocity = split(self.w_current)[0]       # the P2 velocity just solved for
+            Ts.solve_current_step()
+            self.w_current._temperature = Ts.w_current
+            self.result = self.w_current
+
+    def temperature(self):
+        return self._Tsolver.w_current if self._Tsolver is not None else None
 
     def viscous_heat(self, u, p):
         raise SolverError("viscous_heat: the reference projects a scalar, inner(sigma, grad(u)), onto the VECTOR velocity space "
@@ -288,9 +340,10 @@ class CoupledNavierStokesSolver(SolverBase):
         root = result_filename[:-4]
         if not hasattr(self, '_saved_frames'):
             self._saved_frames = []
-        u, p = split(self.w_current)
+        parts = split(self.w_current)
+        u, p = parts[0], parts[1]
         vtu = "%s%06d.vtu" % (root, len(self._saved_frames))
-        write_vtu(vtu, self.mesh, u, "velocity", extra=[(p, "pressure")])
+        write_vtu(vtu, self.mesh, u, "velocity", extra=[(p, "pressure")] + ([(parts[2], "temperature")] if len(parts) > 2 else []))
         self._saved_frames.append((getattr(self, 'current_time', 0.0), os.path.basename(vtu)))
         with open(result_filename, "w") as fh:
             fh.write('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n  <Collection>\n')

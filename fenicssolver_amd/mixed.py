@@ -90,7 +90,8 @@ class TaylorHoodSub:
 
 
 def split(w):
-    """(u, p) copies of a Function of the mixed space (dolfin: w.split(deepcopy=True))."""
+    """(u, p) copies of a Function of the mixed space (dolfin: w.split(deepcopy=True)); (u, p, T) when the flow solver
+    solved the coupled temperature equation (MixedElement([V, Q, Q]), CoupledNavierStokesSolver.py:94-95)."""
     W = w.function_space()
     if not isinstance(W, TaylorHoodSpace):
         raise SolverError("split(): not a velocity-pressure function")
@@ -99,4 +100,7 @@ def split(w):
     u.vector().set_local(a[:, :3].reshape(-1))
     p = Function(W.pressure_space())
     p.vector().set_local(a[:W.mesh().num_vertices(), 3])
+    T = getattr(w, "_temperature", None)
+    if T is not None:
+        return u, p, T
     return u, p

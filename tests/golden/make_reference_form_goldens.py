@@ -268,6 +268,21 @@ try:
 except Exception as e:
     out["navier_stokes_non_newtonian"] = {"reference_raises": "%s: %s" % (type(e).__name__, e)}
 
+# coupled temperature (solving_temperature, CoupledNavierStokesSolver.py:236-239, 247-286)
+st = ns_settings(False)
+st['solving_temperature'] = True
+st['material'] = {'density': 2.0, 'kinematic_viscosity': 0.01, 'specific_heat_capacity': 3.0, 'thermal_conductivity': 0.1}
+st['initial_values'] = {'velocity': (0, 0, 0), 'pressure': 0, 'temperature': 320}
+st['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0, 'temperature': 300}
+st['boundary_conditions']['walls']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(350)})
+st['boundary_conditions']['lid']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)})
+try:
+    run("navier_stokes_coupled_temperature", CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
+except Exception as e:
+    import traceback
+    out["navier_stokes_coupled_temperature"] = {"reference_raises": "%s: %s" % (type(e).__name__, e),
+                                                "where": traceback.format_exc().strip().splitlines()[-3].strip()}
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

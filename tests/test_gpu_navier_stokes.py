@@ -647,3 +647,74 @@ def test_time_dependent_boundary_values_and_form_parts(gpu):
     Ft = solver.F_transient(1, None, None, solver.w_current, solver.w_prev)
     assert Fs.inv_dt == 0.0 and Ft.inv_dt == pytest.approx(100.0) and Ft.w_prev is solver.w_prev
     assert Fs.describe()["nu"] == 0.05 and solver.transient_settings['transient'] is True
+
+
+def _thermal_cavity(n, transient, t_end=0.02):
+    from fenicssolver_amd.fem import Constant
+    s, mesh = _cavity_settings(n, transient=transient, nu=0.05, t_end=t_end)
+    s['solving_temperature'] = True
+    s['material'] = {'density': 2.0, 'kinematic_viscosity': 0.05, 'specific_heat_capacity': 3.0, 'thermal_conductivity': 0.1}
+    s['boundary_conditions']['walls']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(350.0)})
+    s['boundary_conditions']['lid']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300.0)})
+    s['initial_values'] = {'velocity': (0, 0, 0), 'pressure': 0, 'temperature': 320.0}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0, 'temperature': 300.0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
+    return s, mesh
+
+
+def _thermal_operators(mesh, u_nodes, th):
+    co, ce = mesh.coordinates(), mesh.cells()
+    cap = 2.0 * 3.0
+    V = fo.row_velocities(ce, u_nodes, cell_dofs=th.cell_nodes)            # the P2 velocity, integrated exactly
+    K = fo.assemble_p1_scalar(co, ce, 0.1)
+    C = fo.assemble_matrix(len(co), ce, fo.p1_advection_local(co, ce, V, cap))
+    P = fo.assemble_interior_penalty(co, ce, 0.1 * cap)                     # IP, alpha = 0.1 (CoupledNavierStokesSolver.py:262)
+    M = fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, cap))
+    top = np.nonzero(co[:, 2] == 1.0)[0]
+    bnd = np.nonzero(np.any((co == 0.0) | (co == 1.0), axis=1))[0]
+    vals = np.full(len(co), 350.0)
+    vals[top] = 300.0                                                       # the lid is marked after the walls
+    return K, C, P, M, bnd, vals[bnd]
+
+
+def test_coupled_temperature_steady(gpu):
+    """solving_temperature (CoupledNavierStokesSolver.py:236-239, 247-286): u, p, T = split(solver.solve()); the flow is the one
+    of the same case without the temperature, T solves the IP-stabilised transport equation convected by that P2 velocity."""
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    from fenicssolver_amd.mixed import split
+    s, mesh = _thermal_cavity(3, transient=False)
+    solver = CoupledNavierStokesSolver(s)
+    w = solver.solve()
+    u, p, T = split(w)
+    assert T.vector().size() == mesh.num_vertices() and solver.temperature() is T
+    s0, _ = _thermal_cavity(3, transient=False)
+    s0['solving_temperature'] = False
+    w0 = CoupledNavierStokesSolver(s0).solve()
+    assert np.abs(w.vector().array() - w0.vector().array()).max() <= 1e-12            # one-way coupling
+    th = ns.TaylorHood(mesh.coordinates(), mesh.cells())
+    K, C, P, M, bnd, bvals = _thermal_operators(mesh, u.node_values(), th)
+    A, b = fo.apply_dirichlet((K + C + P).tocsr(), np.zeros(th.nv), bnd, bvals, True)
+    want = fo.solve_direct(A, b)
+    Tv = T.vector().array()
+    assert np.abs(Tv - want).max() <= 1e-6 * np.abs(want).max()
+    assert Tv.min() >= 299.0 and Tv.max() <= 352.0 and np.ptp(Tv) > 10.0       # (no discrete maximum principle on 3^3 cells)
+
+
+def test_coupled_temperature_transient_step_satisfies_the_crank_nicolson_equation(gpu, tmp_path):
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    s, mesh = _thermal_cavity(3, transient=True, t_end=0.03)
+    s['report_settings'] = dict(QUIET, saving_freq=1, result_filename=str(tmp_path / "upT.pvd"))
+    solver = CoupledNavierStokesSolver(s)
+    u, p, T = solver.split(solver.solve())
+    Ts = solver._Tsolver
+    Tn, Tp = T.vector().array(), Ts.w_prev.vector().array()
+    th = ns.TaylorHood(mesh.coordinates(), mesh.cells())
+    K, C, P, M, bnd, bvals = _thermal_operators(mesh, u.node_values(), th)
+    dt = 0.01
+    # (1/dt) M (T - T_prev) + 1/2 K T + 1/2 K T_prev + C T + P T = 0 on the free rows (ScalarTransportSolver.py:292-315)
+    r = M @ (Tn - Tp) / dt + 0.5 * (K @ Tn) + 0.5 * (K @ Tp) + C @ Tn + P @ Tn
+    r[bnd] = 0.0
+    scale = np.abs(M @ Tn / dt).max()
+    assert np.abs(r).max() <= 1e-8 * scale
+    assert np.abs(Tn[bnd] - bvals).max() <= 1e-10 and np.abs(Tn - Tp).max() > 1e-3
+    assert "temperature" in open(str(tmp_path / "upT000000.vtu")).read()

@@ -537,6 +537,58 @@ def test_navier_stokes_non_newtonian_terms():
     assert [b.marker_id for b in dbcs] == [1, 2, 3]
 
 
+def test_navier_stokes_coupled_temperature_terms():
+    """solving_temperature (CoupledNavierStokesSolver.py:236-239, 247-286): the reference adds, on W.sub(2), the conduction
+    term, the convection by the CURRENT velocity iterate times the capacity rho*cp, and the interior-penalty term with
+    alpha = 0.1 (times the capacity), with the temperature Dirichlet sets; no viscous heating, no source.  The temperature
+    form of this package says the same, and the flow terms are those of the uncoupled case."""
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    gold = GOLD["navier_stokes_coupled_temperature"]["solves"][0]
+    state = None
+    terms = []
+    for t in gold["terms"]:
+        m = re.match(r"^action\((.*), (interpolate\(Expression\(.*?\)\)\))\)$", t["integrand"])
+        assert m
+        state = state or m.group(2)
+        terms.append((t["sign"], m.group(1).replace(state, "W0"), t["measure"]))
+    thermal = sorted(x for x in terms if "[2]" in x[1])
+    assert thermal == sorted([
+        (+1, "inner(mul(0.1, grad(u_trial[2])), grad(v_test[2]))", "dx"),
+        (+1, "mul(mul(inner(W0[0], grad(u_trial[2])), v_test[2]), 6)", "dx"),
+        (+1, "mul(mul(mul(Constant(0.1), pow(avg(mul(2, Circumradius)), 2)), inner(jump(grad(u_trial[2]), n), jump(grad(v_test[2]), n))), 6)", "dS")])
+    assert [(b["space"], b["marker"], b["value"]) for b in gold["bcs"] if b["space"] == "W.sub(2)"] == \
+        [("W.sub(2)", 1, "Constant(350)"), ("W.sub(2)", 2, "Constant(300)")]
+
+    mesh = UnitCubeMesh(2, 2, 2)
+    bcs = collections.OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))},
+                               {'variable': "temperature", 'type': 'Dirichlet', 'value': Constant(350)}]}
+    bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and abs(x[2] - 1) < 1e-12), 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))},
+                             {'variable': "temperature", 'type': 'Dirichlet', 'value': Constant(300)}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG', 'solving_temperature': True,
+              'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0, 'temperature': 320},
+              'material': {'density': 2.0, 'kinematic_viscosity': 0.01, 'specific_heat_capacity': 3.0, 'thermal_conductivity': 0.1}})
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0, 'temperature': 300}
+    s['report_settings'] = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = CoupledNavierStokesSolver(s)
+    solver.init_solver()
+    F, dbcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    flow = [x for x in terms if "[2]" not in x[1]]
+    assert sorted(flow) == sorted(_ns_expected_terms(F.describe()))
+    FT, tbcs = solver.generate_thermal_form(0, None, None, solver.w_current, solver.w_prev)
+    d = FT.describe()
+    assert d["conductivity"] == ("const", 0.1) or d["conductivity"] == 0.1 or tuple(d["conductivity"])[-1] == 0.1
+    assert d["ip_coefficient"] == pytest.approx(0.1 * 6.0) and FT.advection[1] == pytest.approx(6.0)
+    assert np.ndim(FT.advection[0]) == 3                     # one velocity per cell and test function: the P2 iterate, exactly
+    assert [b.marker_id for b in tbcs] == [1, 2] and np.all(tbcs[0].values == 350.0) and np.all(tbcs[1].values == 300.0)
+    assert not FT.transient and FT.source is None if hasattr(FT, "source") else True
+
+
 def test_reference_g2_transient_branch_is_broken_upstream():
     """F_static reads an undefined time_iter_ in the transient, convection-dominated G2 branch (:354-355): the reference
     raises NameError there.  The GPU path uses the step's dt in that formula (the evident intent) - see fs_ns_form.g2_mode."""
