@@ -128,7 +128,19 @@ class ScalarTransportSolver(SolverBase):
             return forms.VolumeCoefficient("tensor", self._embed_2x2(value))
         if isinstance(value, (Expression, Function)):
             if isinstance(value, Expression) and value.value_size() != 1:
-                raise SolverError('{}: tensor-valued Expression coefficients are not supported'.format(what))
+                # K_anisotropic = Expression((('exp(x[0])','sin(x[1])'), ('sin(x[0])','tan(x[1])')), degree=0)
+                # (examples/test_heat_transfer.py:90): a tensor per cell, evaluated at the cell mid-points as DOLFIN
+                # interpolates a degree-0 Expression into DG0
+                d = self.dimension
+                if value.ufl_shape() != (d, d) or int(value.degree) != 0:
+                    raise SolverError('{}: a tensor-valued Expression must be {}x{} and of degree 0'.format(what, d, d))
+                if what != 'conductivity':
+                    raise SolverError('{} cannot be a tensor'.format(what))
+                co, cells = self.mesh.coordinates(), self.mesh.cells().astype(np.int64)
+                vals = value.eval_points(co[cells].mean(axis=1)).reshape(-1, d, d)
+                full = np.zeros((len(cells), 3, 3))
+                full[:, :d, :d] = vals
+                return forms.VolumeCoefficient("cell_tensor", full)
             nod = nodal_values(value, self.function_space)
             cells = self.mesh.cells().astype(np.int64)      # vertex nodes come first in P1 and P2 alike
             return forms.VolumeCoefficient("cell", nod[cells].mean(axis=1))

@@ -216,7 +216,7 @@ class DeviceVector(_Handle):
 
 
 def _coef(spec, keep):
-    """spec: None | number | ('cell', array) | ('nodal', array) | ('tensor', 3x3)."""
+    """spec: None | number | ('cell', array) | ('nodal', array) | ('tensor', 3x3) | ('cell_tensor', [n_cells,3,3])."""
     c = L.fs_coef()
     if spec is None:
         c.mode = L.FS_COEF_NONE
@@ -227,6 +227,11 @@ def _coef(spec, keep):
             t = L.f64(arr).reshape(9)
             for i in range(9):
                 c.tensor[i] = t[i]
+        elif kind == "cell_tensor":          # [n_cells, 3, 3]
+            a = L.f64(np.ascontiguousarray(arr).reshape(-1, 9))
+            keep.append(a)
+            c.mode = L.FS_COEF_CELL_TENSOR
+            c.data = L.p_f64(a)
         else:
             a = L.f64(arr).ravel()
             keep.append(a)

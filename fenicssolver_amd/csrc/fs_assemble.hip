@@ -258,6 +258,15 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
                         kg[i] = kc.tensor[3 * i + 0] * t.g[b][0] + kc.tensor[3 * i + 1] * t.g[b][1] + kc.tensor[3 * i + 2] * t.g[b][2];
                     row[b] = vol * (t.g[0][0] * kg[0] + t.g[0][1] * kg[1] + t.g[0][2] * kg[2]);
                 }
+            } else if (kc.mode == FS_COEF_CELL_TENSOR) {      // one tensor per cell (an Expression of degree 0)
+                const double* __restrict__ T = kc.data + 9 * (int64_t)c;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double kg[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) kg[i] = T[3 * i + 0] * t.g[b][0] + T[3 * i + 1] * t.g[b][1] + T[3 * i + 2] * t.g[b][2];
+                    row[b] = vol * (t.g[0][0] * kg[0] + t.g[0][1] * kg[1] + t.g[0][2] * kg[2]);
+                }
             } else {
                 double kk = 0.0;
                 if (kc.mode == FS_COEF_CONST) kk = kc.value;
@@ -999,6 +1008,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
                 for (int b = 0; b < 3; ++b) {
                     const double kx = kc.tensor[0] * t.g[b][0] + kc.tensor[1] * t.g[b][1];
                     const double ky = kc.tensor[3] * t.g[b][0] + kc.tensor[4] * t.g[b][1];
+                    row[b] = t.area * (ga[0] * kx + ga[1] * ky);
+                }
+            } else if (kc.mode == FS_COEF_CELL_TENSOR) {
+                const double* __restrict__ T = kc.data + 9 * (int64_t)c;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const double kx = T[0] * t.g[b][0] + T[1] * t.g[b][1];
+                    const double ky = T[3] * t.g[b][0] + T[4] * t.g[b][1];
                     row[b] = t.area * (ga[0] * kx + ga[1] * ky);
                 }
             } else {
@@ -1832,7 +1849,8 @@ static int make_coef(const fs_coef& in, int64_t expect_len, dbuf<double>& store,
     out->value = in.value;
     out->data = nullptr;
     for (int i = 0; i < 9; ++i) out->tensor[i] = in.tensor[i];
-    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL || in.mode == FS_COEF_CELL_ROW) {
+    if (in.mode == FS_COEF_CELL_TENSOR) expect_len *= 9;
+    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL || in.mode == FS_COEF_CELL_ROW || in.mode == FS_COEF_CELL_TENSOR) {
         FS_REQUIRE(in.data, "%s: coefficient data pointer is null", what);
         FS_CHECK(store.alloc(expect_len));
         FS_CHECK(store.upload(in.data, expect_len, fs_rt().stream));
@@ -2022,7 +2040,7 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
         if (!add) FS_CHECK(A->val.zero(s));
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
-        FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
+        FS_REQUIRE(kc.mode != FS_COEF_NODAL && kc.mode != FS_COEF_CELL_TENSOR, "fs_assemble_matrix: nodal / per-cell tensor stiffness coefficients need the row-gather tables");
         hipLaunchKernelGGL(k_assemble_p1_scalar, dim3(grid), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, sp->slots.p, m->nc, kc, mc, A->val.p);
     } else if (getenv("FS_ELASTICITY_ATOMIC") && sp->degree == 1 && A->bs == 3) {
         if (!add) FS_CHECK(A->val.zero(s));

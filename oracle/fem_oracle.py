@@ -221,6 +221,8 @@ def p1_stiffness_local(coords, cells, k=1.0):
         Kg = np.einsum("ij,caj->cai", k, g)
         Ke = np.einsum("cai,cbi->cab", g, Kg)
         return Ke * vol[:, None, None]
+    if k.ndim == 3:                                     # one 3x3 tensor per cell (a tensor Expression of degree 0)
+        return vol[:, None, None] * np.einsum("cai,cij,cbj->cab", g, k, g)
     Ke = np.einsum("cai,cbi->cab", g, g)
     if k.ndim == 0:
         return Ke * (vol * float(k))[:, None, None]
@@ -936,7 +938,12 @@ def tri_geometry(coords, cells):
 
 def tri_stiffness_local(coords, cells, k=1.0):
     area, g = tri_geometry(coords, cells)
-    kk = np.broadcast_to(np.asarray(k, dtype=np.float64), (len(area),))
+    k = np.asarray(k, dtype=np.float64)
+    if k.ndim == 3:                                     # one 2x2 tensor per cell (a tensor Expression of degree 0)
+        return area[:, None, None] * np.einsum("cai,cij,cbj->cab", g, k[:, :2, :2], g)
+    if k.ndim == 2 and k.shape in ((2, 2), (3, 3)):
+        return area[:, None, None] * np.einsum("cai,ij,cbj->cab", g, k[:2, :2], g)
+    kk = np.broadcast_to(k, (len(area),))
     return (kk * area)[:, None, None] * np.einsum("cai,cbi->cab", g, g)
 
 

@@ -562,3 +562,55 @@ def test_anisotropic_conductivity_in_2d(gpu):
     Ab, bb = fo.apply_dirichlet(K.tocsr(), rhs, dofs, vals, symmetric=True)
     ref = fo.solve_direct(Ab, bb)
     assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_tensor_expression_conductivity_of_the_example(gpu):
+    """examples/test_heat_transfer.py:90 and :138-140: solver.material['conductivity'] = Expression((('exp(x[0])','sin(x[1])'),
+    ('sin(x[0])','tan(x[1])')), degree=0) ("#works!") - one 2x2 tensor per cell, taken at the cell mid-points."""
+    from fenicssolver_amd.fem import Constant, Expression, SolverError
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh, Q, sd = _square(12)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': sd['top'], 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["cold"] = {'boundary': sd['bottom'], 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    settings = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+                'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+                'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.1},
+                'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 1},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'krylov_relative_tolerance': 1e-13, 'maximum_iterations': 20000}},
+                'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    # symmetric positive definite variant of the example's tensor (its own is not symmetric: BiCGStab territory, below)
+    solver.material['conductivity'] = Expression((('exp(x[0])', '0.3*sin(x[1])'), ('0.3*sin(x[1])', '1+tan(x[1])')), degree=0)
+    T = solver.solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    mid = co[ce.astype(np.int64)].mean(axis=1)
+    Kc = np.zeros((len(ce), 2, 2))
+    Kc[:, 0, 0], Kc[:, 0, 1] = np.exp(mid[:, 0]), 0.3 * np.sin(mid[:, 1])
+    Kc[:, 1, 0], Kc[:, 1, 1] = 0.3 * np.sin(mid[:, 1]), 1 + np.tan(mid[:, 1])
+    K = fo.assemble_generic(len(co), ce, fo.tri_stiffness_local(co, ce, Kc))
+    top, bot = np.nonzero(co[:, 1] == 1.0)[0], np.nonzero(co[:, 1] == 0.0)[0]
+    dofs, vals = np.concatenate([top, bot]), np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+    ref = fo.solve_direct(*fo.apply_dirichlet(K.tocsr(), np.zeros(len(co)), dofs, vals, symmetric=True))
+    assert np.abs(T - ref).max() <= 1e-7 * np.abs(ref).max()
+    assert np.abs(T - (300 + 60 * co[:, 1])).max() > 0.5                       # not the isotropic answer
+    # the example's own (non-symmetric) tensor: the assembled operator equals the oracle's
+    solver2 = ScalarTransportSolver(settings)
+    solver2.material['conductivity'] = Expression((('exp(x[0])', 'sin(x[1])'), ('sin(x[0])', 'tan(x[1])')), degree=0)
+    solver2.init_solver()
+    F, dbc = solver2.generate_form(0, None, None, solver2.w_current, solver2.w_prev)
+    A, b = solver2.assemble_system(F, [], symmetric=True)
+    K2 = np.zeros((len(ce), 2, 2))
+    K2[:, 0, 0], K2[:, 0, 1], K2[:, 1, 0], K2[:, 1, 1] = np.exp(mid[:, 0]), np.sin(mid[:, 1]), np.sin(mid[:, 0]), np.tan(mid[:, 1])
+    ref2 = fo.assemble_generic(len(co), ce, fo.tri_stiffness_local(co, ce, K2)).tocsr()
+    rp, ci, va, shape = A.to_csr()
+    import scipy.sparse as sps
+    assert abs(sps.csr_matrix((va, ci, rp), shape=shape) - ref2).max() <= 1e-12 * abs(ref2).max()
+    # degree > 0 tensors would need a quadrature over the tensor field: loud
+    solver3 = ScalarTransportSolver(settings)
+    solver3.material['conductivity'] = Expression((('exp(x[0])', '0'), ('0', '1')), degree=1)
+    with pytest.raises(SolverError):
+        solver3.solve()

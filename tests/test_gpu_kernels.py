@@ -452,6 +452,29 @@ def test_matrix_free_product_matches_assembled_operator(gpu, data_dir):
         gpu.apply_operator(V3, gpu.DeviceVector(V3.n_local * 3), gpu.DeviceVector(V3.n_owned * 3), stiffness=1.0)
 
 
+def test_per_cell_tensor_stiffness(gpu):
+    """FS_COEF_CELL_TENSOR: one 3x3 conductivity tensor per cell, assembled and matrix-free."""
+    rng = np.random.default_rng(31)
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 1.1), 4, 3, 3)
+    mesh = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    B = rng.standard_normal((len(ce), 3, 3))
+    Kc = np.einsum("cij,ckj->cik", B, B) + 0.5 * np.eye(3)[None]             # SPD per cell
+    A.assemble(stiffness=("cell_tensor", Kc), mass=0.2)
+    ref = fo.assemble_matrix(len(co), ce, fo.p1_stiffness_local(co, ce, Kc) + fo.p1_mass_local(co, ce, 0.2))
+    M = _csr(A)
+    _assert_same_pattern(M, ref)
+    assert np.abs(M.data - ref.data).max() <= RTOL_ASSEMBLY * np.abs(ref.data).max()
+    xh = rng.standard_normal(V.n_local)
+    y = gpu.DeviceVector(V.n_owned)
+    gpu.apply_operator(V, gpu.DeviceVector(V.n_local, xh), y, stiffness=("cell_tensor", Kc), mass=0.2)
+    assert np.abs(y.get() - ref @ xh).max() <= 1e-13 * (abs(ref) @ np.abs(xh)).max()
+    V2 = gpu.DeviceSpace(mesh, 1, degree=2)
+    with pytest.raises(gpu.BackendError):
+        gpu.DeviceMatrix(V2).assemble(stiffness=("cell_tensor", Kc))            # CG2: constant or per-cell scalars only
+
+
 def test_bicgstab_agrees_with_cg_on_spd(gpu):
     n = 12
     P = fo.heat_box_problem(n)
