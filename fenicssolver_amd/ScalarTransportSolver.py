@@ -315,8 +315,8 @@ class ScalarTransportSolver(SolverBase):
             method = ads.get('stabilization_method')
             supg_pe, ip_coef = 0.0, 0.0
             if method == 'IP':        # interior penalty on the jump of the normal gradient (:312-315)
-                if self.function_space.degree() != 1 or self.dimension != 3:
-                    raise SolverError("IP stabilisation is built for P1 spaces on tetrahedral meshes")
+                if self.function_space.degree() != 1:
+                    raise SolverError("IP stabilisation is built for P1 spaces")
                 cap = self.capacity()
                 if not isinstance(cap, numbers.Number):
                     raise SolverError("IP stabilisation needs a constant capacity")

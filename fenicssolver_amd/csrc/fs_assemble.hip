@@ -1595,6 +1595,66 @@ __global__ void k_interior_penalty(int64_t nf, const int32_t* __restrict__ facet
     }
 }
 
+// The same on triangles: an interior edge E = K+ n K- and the four nodes of the two cells; h = 2 circumradius = abc / (2 A).
+__device__ __forceinline__ double tri_circum_h(const double* __restrict__ xyz4, const int32_t (&v)[3], double area) {
+    double x[3][2];
+    for (int i = 0; i < 3; ++i) { x[i][0] = xyz4[4 * (int64_t)v[i]]; x[i][1] = xyz4[4 * (int64_t)v[i] + 1]; }
+    auto dist = [&](int p, int q) { return sqrt((x[p][0] - x[q][0]) * (x[p][0] - x[q][0]) + (x[p][1] - x[q][1]) * (x[p][1] - x[q][1])); };
+    return dist(0, 1) * dist(1, 2) * dist(2, 0) / (2.0 * area);
+}
+__global__ void k_interior_penalty_tri(int64_t nf, const int32_t* __restrict__ facet_cells, const int32_t* __restrict__ cells,
+                                       const double* __restrict__ xyz4, double coef, int64_t n_rows,
+                                       const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                       double* __restrict__ val, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 4; t += stride) {
+        const int64_t f = t >> 2;
+        const int a = (int)(t & 3);
+        const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
+        const int4 p = reinterpret_cast<const int4*>(cells)[c0], q = reinterpret_cast<const int4*>(cells)[c1];
+        const int32_t v0[3] = {p.x, p.y, p.z}, v1[3] = {q.x, q.y, q.z};
+        int o0 = -1, o1 = -1;          // local index of the vertex opposite the shared edge in either cell
+        for (int i = 0; i < 3; ++i) {
+            bool in1 = false, in0 = false;
+            for (int j = 0; j < 3; ++j) { in1 |= v0[i] == v1[j]; in0 |= v1[i] == v0[j]; }
+            if (!in1) o0 = o0 < 0 ? i : 3;
+            if (!in0) o1 = o1 < 0 ? i : 3;
+        }
+        if (o0 < 0 || o0 > 2 || o1 < 0 || o1 > 2) { if (a == 0) atomicAdd(err, 1); continue; }
+        const tri_geom g0 = tri_geometry2(xyz4, v0[0], v0[1], v0[2]), g1 = tri_geometry2(xyz4, v1[0], v1[1], v1[2]);
+        // outward normal of K+ on the edge: -grad lambda_opposite / |grad lambda_opposite|;  |E| = 2 A |grad lambda_opp|
+        const double gn = sqrt(g0.g[o0][0] * g0.g[o0][0] + g0.g[o0][1] * g0.g[o0][1]);
+        const double n[2] = {-g0.g[o0][0] / gn, -g0.g[o0][1] / gn};
+        const double len = 2.0 * g0.area * gn;
+        const double hbar = 0.5 * (tri_circum_h(xyz4, v0, g0.area) + tri_circum_h(xyz4, v1, g1.area));
+        const double w = coef * hbar * hbar * len;
+        int32_t node[4];
+        double J[4];
+        for (int i = 0; i < 3; ++i) {
+            node[i] = v0[i];
+            double j = g0.g[i][0] * n[0] + g0.g[i][1] * n[1];
+            for (int k = 0; k < 3; ++k)
+                if (v1[k] == v0[i]) j -= g1.g[k][0] * n[0] + g1.g[k][1] * n[1];
+            J[i] = j;
+        }
+        node[3] = v1[o1];
+        J[3] = -(g1.g[o1][0] * n[0] + g1.g[o1][1] * n[1]);
+        const int32_t row = node[a];
+        if (row >= n_rows) continue;
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        for (int b = 0; b < 4; ++b) {
+            int k = -1;
+            for (int kk = 0; kk < width; ++kk)
+                if (sell_col[base + (int64_t)kk * FS_SLICE] == node[b]) { k = kk; break; }
+            if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], w * J[a] * J[b]);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- Dirichlet ------------------------------------------------------------------------------------
 // "later entries win" without a host pass: first the largest list index naming each dof ...
 __global__ void k_bc_last_index(const int32_t* __restrict__ dofs, int64_t n, int32_t* __restrict__ idx) {
@@ -2904,8 +2964,8 @@ extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, con
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A && n_facets >= 0 && (n_facets == 0 || facet_cells), "fs_assemble_interior_penalty: bad arguments");
     fs_space_s* sp = A->space;
-    if (A->bs != 1 || sp->degree != 1 || sp->mesh->tdim != 3) {
-        fs_set_error("fs_assemble_interior_penalty: built for scalar CG1 spaces on tetrahedra");
+    if (A->bs != 1 || sp->degree != 1) {
+        fs_set_error("fs_assemble_interior_penalty: built for scalar CG1 spaces");
         return FS_ERR_UNSUPPORTED;
     }
     if (n_facets == 0) return FS_OK;
@@ -2918,8 +2978,12 @@ extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, con
     FS_CHECK(d_err.alloc(1));
     FS_CHECK(d_err.zero(s));
     FS_CHECK(dfc.upload(facet_cells, 2 * n_facets, s));
-    hipLaunchKernelGGL(k_interior_penalty, dim3(fs_grid_for(5 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
-                       sp->mesh->cells.p, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
+    if (sp->mesh->tdim == 2)
+        hipLaunchKernelGGL(k_interior_penalty_tri, dim3(fs_grid_for(4 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
+                           sp->mesh->cells.p, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
+    else
+        hipLaunchKernelGGL(k_interior_penalty, dim3(fs_grid_for(5 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
+                           sp->mesh->cells.p, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
     FS_KERNEL_CHECK();
     int h_err = 0;
     FS_CHECK(d_err.download(&h_err, 1, s));

@@ -217,18 +217,16 @@ class Mesh:
         return self._build_topology()["facet_count"] == 1
 
     def interior_facet_cells(self):
-        """(cell pairs [nf,2], opposite-vertex pairs [nf,2]) of the facets shared by two cells (tetrahedra): what an
+        """(cell pairs [nf,2], opposite-vertex pairs [nf,2]) of the facets shared by two cells (tetrahedra / triangles): what an
         interior-facet (dS) integral runs over and the node couplings it adds to the sparsity pattern."""
         if getattr(self, "_interior", None) is None:
-            if self._cells.shape[1] != 4:
-                raise SolverError("interior facets are built for tetrahedral meshes")
-            cf = self.cell_facets().astype(np.int64)                 # [nc,4], facet i opposite local vertex i
-            nc = cf.shape[0]
+            cf = self.cell_facets().astype(np.int64)                 # [nc,d+1], facet i opposite local vertex i
+            nc, nl = cf.shape
             order = np.argsort(cf.ravel(), kind="stable")
             fid = cf.ravel()[order]
             dup = np.nonzero(fid[1:] == fid[:-1])[0]                  # consecutive equal ids = the two cells of a facet
             a, b = order[dup], order[dup + 1]
-            ca, la, cb, lb = a // 4, a % 4, b // 4, b % 4
+            ca, la, cb, lb = a // nl, a % nl, b // nl, b % nl
             cells = self._cells.astype(np.int64)
             self._interior = (np.stack([ca, cb], axis=1).astype(np.int32),
                               np.stack([cells[ca, la], cells[cb, lb]], axis=1).astype(np.int32))

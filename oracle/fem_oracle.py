@@ -1051,6 +1051,41 @@ def assemble_interior_penalty(coords, cells, coefficient):
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
 
 
+def assemble_tri_interior_penalty(coords, cells, coefficient):
+    """The same term on a triangle mesh: interior EDGES, normal = the edge direction turned by 90 degrees (oriented away from
+    the cell's opposite vertex), |E| the edge length, h = 2 * Circumradius from the circumcentre."""
+    import scipy.sparse as sp
+    co = np.asarray(coords, dtype=np.float64)[:, :2]
+    ce = np.asarray(cells, dtype=np.int64)
+    n = len(co)
+    _, g = tri_geometry(co, ce)
+    h = 2.0 * tet_circumradius(co, ce)                   # (the circumcentre solve is dimension-free)
+    edges, cell_edges, cnt = tri_edge_numbering(ce)
+    sides = {}
+    for c in range(len(ce)):
+        for i in range(3):
+            sides.setdefault(int(cell_edges[c, i]), []).append((c, i))
+    rows, cols, vals = [], [], []
+    for f, ss in sides.items():
+        if len(ss) != 2:
+            continue
+        e = co[edges[f].astype(np.int64)]
+        tvec = e[1] - e[0]
+        length = np.linalg.norm(tvec)
+        nrm = np.array([tvec[1], -tvec[0]]) / length
+        J = {}
+        for c, i in ss:
+            outward = nrm if np.dot(nrm, e[0] - co[ce[c, i]]) > 0 else -nrm
+            for a in range(3):
+                J[int(ce[c, a])] = J.get(int(ce[c, a]), 0.0) + float(np.dot(g[c, a], outward))
+        w = coefficient * (0.5 * (h[ss[0][0]] + h[ss[1][0]])) ** 2 * length
+        nodes = list(J)
+        for a in nodes:
+            for b in nodes:
+                rows.append(a); cols.append(b); vals.append(w * J[a] * J[b])
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+
+
 # ---- P2 Robin / HTC facet matrix (ScalarTransportSolver.py:201-208 with fe_degree 2) ---------------------------------
 def assemble_p2_facet_mass(coords, edges, facets, facet_markers, marker_id, h):
     """int_F h phi_a phi_b ds on the marked facets for the P2 basis: by quadrature (the 6-point degree-4 rule, exact for

@@ -101,3 +101,59 @@ def test_ip_stabilised_advection_through_the_solver_class(gpu):
     galerkin = fo.solve_direct(A0, b0)
     overshoot = lambda T: max(T.max() - 360.0, 300.0 - T.min())           # noqa: E731
     assert overshoot(galerkin) > 1.0 and overshoot(T_ip) < 0.5 * overshoot(galerkin)
+
+
+def test_interior_penalty_on_triangles(gpu):
+    """The same term over the interior EDGES of a 2-D mesh (advection_settings 'IP' on a triangular mesh): kernel against the
+    oracle, linear fields in the kernel, and the solver class against the oracle's direct solve."""
+    from fenicssolver_amd.fem import Mesh, RectangleMesh, Point, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    rng = np.random.default_rng(3)
+    co, ce = fo.rectangle_mesh((0, 0), (1.0, 0.8), 6, 5)
+    interior = np.all((co > 1e-12) & (co < np.array([1.0, 0.8]) - 1e-12), axis=1)
+    co = co + interior[:, None] * rng.uniform(-0.03, 0.03, co.shape)
+    m = Mesh(coords=co, cells=ce)
+    ce = m.cells()
+    fcells, pairs = m.interior_facet_cells()
+    _, _, cnt = fo.tri_edge_numbering(ce)
+    assert len(fcells) == int((cnt == 2).sum())
+    dm = gpu.DeviceMesh(co, ce)
+    V = gpu.DeviceSpace(dm, 1, 1, coupled_pairs=pairs)
+    A = gpu.DeviceMatrix(V)
+    A.zero()
+    A.add_interior_penalty(fcells, 0.37)
+    ref = fo.assemble_tri_interior_penalty(co, ce, 0.37)
+    got = _csr(A)
+    assert abs(got - ref).max() <= 1e-12 * abs(ref).max()
+    lin = 3.0 + co @ np.array([0.7, -1.1])
+    assert np.abs(got @ lin).max() <= 1e-11 * abs(ref).max() * np.abs(lin).max()
+    v = rng.standard_normal(len(co))
+    assert v @ (got @ v) >= -1e-12 * abs(ref).max()
+
+    mesh = RectangleMesh(Point(0, 0), Point(1, 1), 10, 10)
+    Q = FunctionSpace(mesh, "CG", 1)
+    bcs = OrderedDict()
+    bcs["in"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)}}}
+    bcs["out"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 1.0)), 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+         'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
+         'material': {'density': 1.0, 'specific_heat_capacity': 1.0, 'thermal_conductivity': 0.002},
+         'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 0.3},
+                             'reference_values': {'temperature': 300},
+                             'solver_parameters': {'krylov_relative_tolerance': 1e-12}},
+         'convective_velocity': Constant((1.0, 0.0)), 'advection_settings': {'stabilization_method': 'IP', 'alpha': 0.1},
+         'report_settings': {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0},
+         'scalar_name': 'temperature'}
+    T = ScalarTransportSolver(s).solve().vector().array()
+    c2, t2 = mesh.coordinates(), mesh.cells()
+    K = fo.assemble_generic(len(c2), t2, fo.tri_stiffness_local(c2, t2, 0.002) + fo.tri_advection_local(c2, t2, (1.0, 0.0), 1.0))
+    P = fo.assemble_tri_interior_penalty(c2, t2, 0.1)
+    lo, hi = np.nonzero(c2[:, 0] == 0.0)[0], np.nonzero(c2[:, 0] == 1.0)[0]
+    dofs, vals = np.concatenate([lo, hi]), np.concatenate([np.full(len(lo), 300.0), np.full(len(hi), 360.0)])
+    ref = fo.solve_direct(*fo.apply_dirichlet((K + P).tocsr(), np.zeros(len(c2)), dofs, vals, False))
+    assert np.abs(T - ref).max() <= 1e-7 * 360.0
+    gal = fo.solve_direct(*fo.apply_dirichlet(K.tocsr(), np.zeros(len(c2)), dofs, vals, False))
+    overshoot = lambda X: max(X.max() - 360.0, 300.0 - X.min())           # noqa: E731
+    assert overshoot(gal) > 1.0 and overshoot(T) < 0.6 * overshoot(gal)
