@@ -278,8 +278,12 @@ class LinearElasticitySolver(SolverBase):
                 vals = bs.eval_points(self.mesh.coordinates()[:1])   # constant body force expected
                 allv = bs.eval_points(self.mesh.coordinates())
                 if np.abs(allv - vals).max() > 1e-12 * max(1.0, np.abs(allv).max()):
-                    raise SolverError('body_source must be constant in space on the GPU back end')
-                F.body_force = tuple(float(x) for x in vals[0])
+                    # a field (e.g. a centrifugal load): its interpolant in the displacement space, integrated with the
+                    # consistent mass matrix - what FFC's quadrature gives for an Expression of the element's degree
+                    F.body_force_nodal = bs.eval_points(self.function_space.node_coordinates())[:, :self.dimension]
+                    F.body_force = None
+                else:
+                    F.body_force = tuple(float(x) for x in vals[0])
             else:
                 F.body_force = tuple(float(x) for x in self._vector_of(bs, 'body_source'))
 

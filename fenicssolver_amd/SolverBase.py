@@ -536,6 +536,15 @@ class SolverBase():
             sgn = F.load_sign
             if F.body_force is not None:
                 backend.assemble_vector(V, b, vector_value=[sgn * x for x in F.body_force])
+            if getattr(F, 'body_force_nodal', None) is not None:
+                Mb = backend.DeviceMatrix(V)
+                Mb.assemble(lame=(0.0, 0.0), mass=1.0)
+                fh = np.ascontiguousarray(F.body_force_nodal, dtype=np.float64).reshape(-1)
+                fh = fh if loc is None else loc.nodes(fh)
+                fd = backend.DeviceVector(V.n_local, np.concatenate([fh, np.zeros(V.n_local - len(fh))]))
+                tmpb = backend.DeviceVector(V.n_owned)
+                Mb.spmv(fd, tmpb)
+                b.axpy(sgn, tmpb)
             for t in F.tractions:
                 tri, g = self._device_facets(F, t.marker_id, t.g)
                 if len(tri):
@@ -945,8 +954,8 @@ class SolverBase():
     def solve_amg(self, F, u, bcs):
         """assemble_system + CG preconditioned by smoothed-aggregation AMG with the rigid-body near-null
         space (SolverBase.py:643-672); solver_parameters['preconditioner'] = 'jacobi' selects Jacobi-CG."""
-        if isinstance(F, forms.ElasticityForm) and F.body_force is None and not F.tractions \
-                and F.thermal is None and not any(np.any(bc.values != 0) for bc in bcs):
+        if isinstance(F, forms.ElasticityForm) and F.body_force is None and getattr(F, 'body_force_nodal', None) is None \
+                and not F.tractions and F.thermal is None and not any(np.any(bc.values != 0) for bc in bcs):
             # empty right-hand side: the reference fails in assemble_system here (Appendix B-Q11)
             self.logger.warning('solve_amg: zero load and homogeneous BCs, the solution is zero')
         A, b = self.assemble_system(F, bcs, symmetric=True)

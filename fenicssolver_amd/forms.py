@@ -112,6 +112,7 @@ class ElasticityForm:
         self.mu = None
         self.lmbda = None
         self.body_force = None        # (fx, fy, fz) or None
+        self.body_force_nodal = None  # [n_nodes, dim]: a body force FIELD by its nodal values (consistent-mass load)
         self.tractions = []           # [FacetLoad] with vector g
         self.thermal = None           # (coefficient E*alpha/(1-2nu), T nodal array or float, T_ref)
         self.load_sign = -1.0         # reference adds the load terms to F => rhs = -loads (Appendix B-Q3)

@@ -297,3 +297,35 @@ def test_p2_amg_device_modes_equal_the_host_near_null_space(gpu):
     for k in range(6):
         A0.spmv(gpu.DeviceVector(V.dim(), ns[k]), y)
         assert np.abs(y.get()).max() <= 1e-9 * 2e11 * np.abs(ns[k]).max()
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_spatially_varying_body_force(gpu, degree):
+    """A body_source Expression that varies in space (a centrifugal load): its interpolant in the displacement space times the
+    consistent mass matrix - FFC's quadrature for an Expression of the element's degree - against the oracle's direct solve."""
+    import scipy.sparse as sps
+    from fenicssolver_amd.fem import Expression
+    solver = _example_solver(8, 2, 2, degree=degree, thermal=False, body=False)
+    solver.settings['body_source'] = Expression(("rho*omega*omega*x[0]", "rho*omega*omega*x[1]", "-9.8*rho"), rho=7800.0, omega=30.0, degree=degree)
+    solver.body_source = solver.settings['body_source']
+    u = solver.solve().vector().array()
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 8, 2, 2)
+    V = solver.function_space
+    X = V.node_coordinates()
+    f = np.stack([7800.0 * 900.0 * X[:, 0], 7800.0 * 900.0 * X[:, 1], np.full(len(X), -9.8 * 7800.0)], axis=1)
+    if degree == 1:
+        R = fo.assemble_p1_elasticity(co, ce, E, NU)
+        M = sps.kron(fo.assemble_matrix(len(co), ce, fo.p1_mass_local(co, ce, 1.0)), sps.identity(3), format="csr")
+        left = np.nonzero(np.isclose(co[:, 0], 0.0))[0]
+        right = np.nonzero(np.isclose(co[:, 0], 10.0))[0]
+    else:
+        R, cd, edges = fo.assemble_p2_elasticity(co, ce, E, NU)
+        M = sps.kron(fo.assemble_generic(len(X), cd, fo.p2_mass_local(co, ce, 1.0)), sps.identity(3), format="csr")
+        left = np.nonzero(np.isclose(X[:, 0], 0.0))[0]
+        right = np.nonzero(np.isclose(X[:, 0], 10.0))[0]
+    b = -(M @ f.reshape(-1))                                         # the reference ADDS its loads to F (Appendix B-Q3)
+    dofs = np.concatenate([left * 3, (right[:, None] * 3 + np.arange(3)).ravel()])
+    vals = np.concatenate([np.zeros(len(left)), np.tile([0.0, 0.0, 1e-3], len(right))])
+    ref = fo.solve_direct(*fo.apply_dirichlet(R, b, dofs, vals, True))
+    assert np.abs(u - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert np.abs(ref).max() > 2e-3                                  # the load matters next to the 1 mm end displacement
