@@ -594,8 +594,8 @@ class SolverBase():
     def solve_nonlinear_problem(self, F, u_current, Dirichlet_bcs, J):
         """NonlinearVariationalSolver.solve() (SolverBase.py:615-626): Newton iteration with DOLFIN's
         NewtonSolver defaults (relative 1e-9 / absolute 1e-10 on the residual norm, 50 iterations, no
-        relaxation).  Every linear step is assembled and solved on the GPU.  The radiation term is
-        linearised exactly per facet (facet-mean temperature); a temperature-dependent conductivity is
+        relaxation).  Every linear step is assembled and solved on the GPU.  The radiation term enters the residual
+        exactly (degree-5 facet quadrature of m T_h^4 q) and the Jacobian by its facet-mean linearisation; a temperature-dependent conductivity is
         re-evaluated each iteration and its derivative left out of the Jacobian (quasi-Newton), as the
         reference's own remark at ScalarTransportSolver.py:281-283 does."""
         from . import backend
@@ -641,7 +641,13 @@ class SolverBase():
             if F.radiation is not None:
                 m_, T_amb = F.radiation
                 Tf = T[ext.astype(np.int64)].mean(axis=1)
-                backend.assemble_facet_vector(V, b, ext_dev, (m_ * (T_amb ** 4 - Tf ** 4))[ext_mask])
+                # residual: int m (T_amb^4 - T_h^4) q ds with T_h the P1 iterate, integrated exactly (degree 5) as FFC does
+                # for m*(pow(T, 4) - pow(T_amb, 4))*Tq*ds (ScalarTransportSolver.py:186-190); the Jacobian below keeps the
+                # facet-mean linearisation - it only steers the iteration
+                loads = _radiation_loads(self.mesh.coordinates(), ext.astype(np.int64), T, m_, T_amb)[ext_mask]
+                rows = np.asarray(ext_dev, dtype=np.int64)
+                own_rows = rows < n
+                b.add_entries(rows[own_rows], loads[own_rows])
             Tdev = backend.DeviceVector(V.n_local, T if loc is None else loc.nodes(T))
             r = backend.DeviceVector(n)
             A.spmv(Tdev, r)
@@ -994,6 +1000,31 @@ class SolverBase():
             basis = ns.reshape(6, 3 * n)
         q, _ = np.linalg.qr(basis.T)
         return q.T.copy()
+
+
+# degree-5 rules: Radon's 7 points on the triangle (barycentric), 3 Gauss points on the segment
+_S15 = np.sqrt(15.0)
+_TRI7 = np.array([[1 / 3, 1 / 3, 1 / 3]] +
+                 [p for a in ((6 - _S15) / 21, (6 + _S15) / 21) for p in ([1 - 2 * a, a, a], [a, 1 - 2 * a, a], [a, a, 1 - 2 * a])])
+_TRI7_W = np.array([9 / 40] + [(155 - _S15) / 1200] * 3 + [(155 + _S15) / 1200] * 3)
+_SEG3 = np.array([[0.5 - 0.5 * np.sqrt(0.6), 0.5 + 0.5 * np.sqrt(0.6)], [0.5, 0.5], [0.5 + 0.5 * np.sqrt(0.6), 0.5 - 0.5 * np.sqrt(0.6)]])
+_SEG3_W = np.array([5 / 18, 8 / 18, 5 / 18])
+
+
+def _radiation_loads(coords, facets, T, m, T_amb):
+    """[n_facets, d] vertex loads  int_F m (T_amb^4 - T_h^4) lambda_a ds  of the P1 field T on boundary triangles (3-D) or
+    edges (2-D): quintic integrand, integrated exactly."""
+    X = coords[facets]
+    if facets.shape[1] == 3:
+        e1, e2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        measure = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+        pts, w = _TRI7, _TRI7_W
+    else:
+        measure = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+        pts, w = _SEG3, _SEG3_W
+    Tq = T[facets] @ pts.T                                   # [nf, nq]
+    g = m * (T_amb ** 4 - Tq ** 4) * w[None, :]              # [nf, nq]
+    return measure[:, None] * (g @ pts)                      # [nf, d]
 
 
 def write_vtu(path, mesh, function, name, extra=()):

@@ -1051,6 +1051,44 @@ def assemble_interior_penalty(coords, cells, coefficient):
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
 
 
+def radiation_facet_loads(coords, facets, T, m, T_amb):
+    """[nf, d] vertex loads int_F m (T_amb^4 - T_h^4) lambda_a ds of a P1 field T on boundary triangles / edges, for the
+    reference's  m*(pow(T, 4) - pow(T_amb, 4))*Tq*ds  (ScalarTransportSolver.py:186-190): exact, by expanding T_h^4 in the
+    barycentric monomials and  int lambda^alpha = |F| (d-1)! alpha! / (|alpha| + d - 1)!  - no quadrature involved."""
+    from math import factorial
+    from itertools import product
+    co = np.asarray(coords, dtype=np.float64)
+    fa = np.asarray(facets, dtype=np.int64)
+    d = fa.shape[1]
+    X = co[fa]
+    if d == 3:
+        e1, e2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        c = np.cross(e1, e2) if X.shape[2] == 3 else (e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])[:, None]
+        measure = 0.5 * np.linalg.norm(c, axis=1)
+    else:
+        measure = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+    Tv = np.asarray(T, dtype=np.float64)[fa]                                  # [nf,d]
+    out = np.zeros((len(fa), d))
+    for a in range(d):
+        acc = np.zeros(len(fa))
+        for alpha in product(range(5), repeat=d):
+            if sum(alpha) != 4:
+                continue
+            multinom = factorial(4)
+            term = np.ones(len(fa))
+            for k in range(d):
+                multinom //= factorial(alpha[k])
+                term = term * Tv[:, k] ** alpha[k]
+            beta = list(alpha)
+            beta[a] += 1
+            integ = factorial(d - 1)
+            for k in range(d):
+                integ *= factorial(beta[k])
+            acc += multinom * term * integ / factorial(sum(beta) + d - 1)
+        out[:, a] = m * (T_amb ** 4 / d - acc) * measure                     # int lambda_a = |F| / d
+    return out
+
+
 def assemble_tri_interior_penalty(coords, cells, coefficient):
     """The same term on a triangle mesh: interior EDGES, normal = the edge direction turned by 90 degrees (oriented away from
     the cell's opposite vertex), |E| the edge length, h = 2 * Circumradius from the circumcentre."""

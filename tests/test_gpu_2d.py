@@ -317,7 +317,7 @@ def test_radiation_example_in_2d(gpu):
     for it in range(60):
         Tf = Tn[ext].mean(axis=1)
         b = np.zeros(n)
-        np.add.at(b, ext.ravel(), np.repeat(mrad * (Ta ** 4 - Tf ** 4) * length / 2.0, 2))
+        np.add.at(b, ext.ravel(), fo.radiation_facet_loads(co, ext, Tn, mrad, Ta).ravel())      # exact: m (Ta^4 - T_h^4) q ds
         r = K @ Tn - b
         r[dofs] = 0.0
         if np.linalg.norm(r) < 1e-10:

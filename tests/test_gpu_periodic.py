@@ -287,7 +287,7 @@ def test_radiation_newton_with_periodic_boundary(gpu):
     for it in range(60):
         Tf = Tn[ext].mean(axis=1)
         b = np.zeros(len(co))
-        np.add.at(b, ext.ravel(), np.repeat(mrad * (Ta ** 4 - Tf ** 4) * area / 3.0, 3))
+        np.add.at(b, ext.ravel(), fo.radiation_facet_loads(co, ext, Tn, mrad, Ta).ravel())      # exact: m (Ta^4 - T_h^4) q ds
         r = K @ Tn - b
         Me = (4.0 * mrad * Tf ** 3 * area)[:, None, None] * base[None]
         J = K + sp.coo_matrix((Me.ravel(), (np.repeat(ext, 3, axis=1).ravel(), np.tile(ext, (1, 3)).ravel())), shape=K.shape).tocsr()

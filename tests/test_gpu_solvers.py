@@ -324,7 +324,7 @@ def test_radiation_and_temperature_dependent_conductivity_newton(gpu):
         A = fo.assemble_p1_scalar(co, ce, k).tolil()
         Tf = Tn[ext].mean(axis=1)
         b = np.zeros(len(co))
-        np.add.at(b, ext.ravel(), np.repeat(mrad * (Ta ** 4 - Tf ** 4) * area / 3.0, 3))
+        np.add.at(b, ext.ravel(), fo.radiation_facet_loads(co, ext, Tn, mrad, Ta).ravel())      # exact: m (Ta^4 - T_h^4) q ds
         r = A @ Tn - b
         r[dofs] = 0.0
         if np.linalg.norm(r) < 1e-10:
