@@ -163,12 +163,16 @@ class ScalarTransportSolver(SolverBase):
         raise SolverError('body source of type {} is not supported'.format(type(value)))
 
     def _facet_value(self, value, marker_id, what):
-        """Constant over the boundary, or the per-facet mean of a varying value."""
+        """Constant over the boundary; a varying value (Expression / Function) by its values at the vertices of every facet,
+        [n_facets, d]: int g q ds is then integrated exactly for the P1 interpolant of g (SolverBase._facet_nodal_loads).
+        P2 spaces take the per-facet mean."""
         if is_constant_value(value):
             return float(value)
         if isinstance(value, (Expression, Function)):
             nod = nodal_values(value, self.function_space)
             tri = self._facets_of(marker_id).astype(np.int64)
+            if self.function_space.degree() == 1:
+                return nod[tri]
             return nod[tri].mean(axis=1)
         raise SolverError('{}: boundary value of type {} is not supported'.format(what, type(value)))
 

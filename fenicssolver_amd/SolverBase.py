@@ -465,6 +465,17 @@ class SolverBase():
                 backend.assemble_vector(V, b, source=spec, add=not first, supg=(adv, pe) if pe else None)
                 first = False
             for fl in F.facet_loads:
+                if np.ndim(fl.g) == 2:
+                    # a varying flux by its vertex values: int g_h lambda_a ds = |F| / (d (d + 1)) (sum_b g_b + g_a), exact for
+                    # the P1 interpolant (FFC: quadrature degree 2 for a degree-1 Expression times the test function)
+                    gtri = self._facets_of(fl.marker_id).astype(np.int64)
+                    loads = _facet_nodal_loads(self.mesh.coordinates(), gtri, np.asarray(fl.g, dtype=np.float64))
+                    tri, loads = self._device_facets(F, fl.marker_id, loads)
+                    rows = np.asarray(tri, dtype=np.int64)
+                    own_rows = rows < V.n_owned
+                    if own_rows.any():
+                        b.add_entries(rows[own_rows], loads[own_rows])
+                    continue
                 tri, g = self._device_facets(F, fl.marker_id, fl.g)
                 if len(tri):
                     backend.assemble_facet_vector(V, b, tri, g)
@@ -491,7 +502,7 @@ class SolverBase():
                         per_facet = np.asarray(per_facet)[keep]
                     return lc[keep].astype(np.int32), opp_[keep], per_facet
                 for fl in F.facet_loads:
-                    cells_, opp_, gg = local_facets(fl.marker_id, fl.g)
+                    cells_, opp_, gg = local_facets(fl.marker_id, fl.g if np.ndim(fl.g) < 2 else np.asarray(fl.g).mean(axis=1))
                     if len(cells_):
                         backend.assemble_facet_supg(V, None, b, cells_, opp_, adv, pe, g=gg)
                 for r in F.robin:
@@ -1009,6 +1020,19 @@ _TRI7 = np.array([[1 / 3, 1 / 3, 1 / 3]] +
 _TRI7_W = np.array([9 / 40] + [(155 - _S15) / 1200] * 3 + [(155 + _S15) / 1200] * 3)
 _SEG3 = np.array([[0.5 - 0.5 * np.sqrt(0.6), 0.5 + 0.5 * np.sqrt(0.6)], [0.5, 0.5], [0.5 + 0.5 * np.sqrt(0.6), 0.5 - 0.5 * np.sqrt(0.6)]])
 _SEG3_W = np.array([5 / 18, 8 / 18, 5 / 18])
+
+
+def _facet_nodal_loads(coords, facets, g):
+    """[n_facets, d] vertex loads int_F g_h lambda_a ds for g given at the facet vertices (triangles or edges)."""
+    X = coords[facets]
+    d = facets.shape[1]
+    if d == 3:
+        e1, e2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        c = np.cross(e1, e2) if X.shape[2] == 3 else (e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])[:, None]
+        measure = 0.5 * np.linalg.norm(np.atleast_2d(c), axis=1)
+    else:
+        measure = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+    return (measure / (d * (d + 1.0)))[:, None] * (g.sum(axis=1, keepdims=True) + g)
 
 
 def _radiation_loads(coords, facets, T, m, T_amb):
