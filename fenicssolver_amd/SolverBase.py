@@ -30,7 +30,7 @@ import time
 import numpy as np
 
 from .fem import (SolverError, Mesh, MeshFunction, FunctionSpace, VectorFunctionSpace, Function, Constant,
-                  Expression, DirichletBC, interpolate, project, nodal_values)
+                  Expression, DirichletBC, interpolate, project, nodal_values, is_constant_value)
 from . import forms, case
 
 __all__ = ["SolverError", "SolverBase", "default_report_settings", "default_solver_parameters",
@@ -806,7 +806,16 @@ class SolverBase():
                 cells, opp, centroids = lc[keep].astype(np.int32), opp[keep], centroids[keep]
             fv = None
             if value is not None:
-                fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
+                if is_constant_value(value):
+                    fv = DirichletBC._eval(value, centroids, 1).reshape(-1)
+                else:
+                    # a boundary pressure that varies (e.g. hydrostatic): its values at the facet's vertices, in the cell's local
+                    # order with the opposite vertex left out - DOLFIN's P1 interpolant of a degree-1 Expression
+                    gcells = self.mesh.cells().astype(np.int64)
+                    cg = cells if loc is None else loc.part.cell_gids[cells]
+                    keepv = np.arange(4)[None, :] != opp[:, None]
+                    fverts = gcells[cg][keepv].reshape(-1, 3)
+                    fv = DirichletBC._eval(value, self.mesh.coordinates()[fverts.ravel()], 1).reshape(-1, 3)
             backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv, viscosity_law=getattr(F, 'viscosity_law', None), w0=dw)
         if ctx.get('per') is not None:
             # periodic_boundary: J <- P^T J P + unit slave rows, g <- P^T g (zeros on the slaves), all four unknowns of a node

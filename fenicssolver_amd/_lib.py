@@ -140,7 +140,8 @@ SIGNATURES = {
     "fs_assemble_facet_supg": (C.c_int, [_H, _H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, C.POINTER(fs_coef), C.c_double]),
     "fs_assemble_navier_stokes": (C.c_int, [_H, _H, _H, _H, C.POINTER(fs_ns_form)]),
     "fs_assemble_ns_pressure_boundary": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]),
-    "fs_assemble_ns_pressure_boundary_nn": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double, _H, C.c_double, C.c_double]),
+    "fs_assemble_ns_pressure_boundary_nn": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double, _H, C.c_double, C.c_double,
+                                                    C.c_int]),
     "fs_saddle_solve": (C.c_int, [_H, _H, _H, _H, _H, _H, C.POINTER(fs_saddle_opts), C.POINTER(fs_krylov_stats)]),
     "fs_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "fs_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),

@@ -542,16 +542,21 @@ def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, b
 
 
 def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_value=None, viscosity_law=None, w0=None):
-    """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only).
+    """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only;
+    a number, one value per facet, or [n_facets, 3] values at the facet's vertices in the cell's local order).
     viscosity_law = (p_ref, exponent) with the state w0: nu (p0 / p_ref)^exponent."""
     fc = np.ascontiguousarray(facet_cell, dtype=np.int32)
     fo_ = np.ascontiguousarray(facet_opposite, dtype=np.int32)
-    fv = None
+    fv, per = None, 1
     if facet_value is not None:
-        fv = np.ascontiguousarray(np.broadcast_to(np.asarray(facet_value, dtype=np.float64), fc.shape))
+        a = np.asarray(facet_value, dtype=np.float64)
+        if a.ndim == 2 and a.shape == (len(fc), 3):       # values at the three vertices of every facet
+            fv, per = np.ascontiguousarray(a), 3
+        else:
+            fv = np.ascontiguousarray(np.broadcast_to(a, fc.shape))
     pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))
     L.check(L.load().fs_assemble_ns_pressure_boundary_nn(J.h, g.h, len(fc), L.p_i32(fc), L.p_i32(fo_), L.p_f64(fv), float(nu),
-                                                         w0.h if (w0 is not None and viscosity_law is not None) else None, pref, ex),
+                                                         w0.h if (w0 is not None and viscosity_law is not None) else None, pref, ex, per),
             "fs_assemble_ns_pressure_boundary")
 
 

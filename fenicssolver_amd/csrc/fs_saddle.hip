@@ -587,7 +587,7 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
                                        const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
                                        const int32_t* __restrict__ slots,
                                        double* __restrict__ val, int64_t plane, double* __restrict__ g,
-                                       const double* __restrict__ w0, double nn_pref, double nn_exp) {
+                                       const double* __restrict__ w0, double nn_pref, double nn_exp, int vstride) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nf * 60; t += stride) {
@@ -630,7 +630,13 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
         const double area = 3.0 * vol * gnorm;
         double blk[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         double gv[3] = {0.0, 0.0, 0.0};
-        const double pb = facet_value ? facet_value[f] : 0.0;
+        // boundary pressure: one value per facet, or (vstride 3) its values at the facet's vertices - the P1 interpolant DOLFIN
+        // evaluates a degree-1 Expression with - in the order of the cell's local vertices
+        double pbv[3] = {0.0, 0.0, 0.0};
+        if (facet_value) {
+            if (vstride == 3) { pbv[0] = facet_value[3 * f]; pbv[1] = facet_value[3 * f + 1]; pbv[2] = facet_value[3 * f + 2]; }
+            else pbv[0] = pbv[1] = pbv[2] = facet_value[f];
+        }
         double P0[4] = {0.0, 0.0, 0.0, 0.0};
         if (nn_pref > 0.0) {
 #pragma unroll
@@ -642,6 +648,7 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
 #pragma unroll
             for (int v = 0; v < 4; ++v) l[v] = (v == o) ? 0.0 : NS_TQ[q][kk++];
             const double wv = NS_TW[q] * area;
+            const double pb = NS_TQ[q][0] * pbv[0] + NS_TQ[q][1] * pbv[1] + NS_TQ[q][2] * pbv[2];
             const double nu = ns_viscosity(nu0, nn_pref, nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3]);
             double pa, pbf, ga[3], gb[3];
             p2_eval(a, l, gl, &pa, ga);
@@ -670,16 +677,19 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
 
 extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                                    const int32_t* facet_opposite, const double* facet_value,
-                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp);
+                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp,
+                                                   int values_per_facet);
 extern "C" int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                                 const int32_t* facet_opposite, const double* facet_value,
                                                 double kinematic_viscosity) {
-    return fs_assemble_ns_pressure_boundary_nn(J, g, n_facets, facet_cell, facet_opposite, facet_value, kinematic_viscosity, nullptr, 0.0, 0.0);
+    return fs_assemble_ns_pressure_boundary_nn(J, g, n_facets, facet_cell, facet_opposite, facet_value, kinematic_viscosity, nullptr, 0.0, 0.0, 1);
 }
 extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                                    const int32_t* facet_opposite, const double* facet_value,
-                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp) {
+                                                   double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp,
+                                                   int values_per_facet) {
     FS_CHECK(fs_require_init());
+    FS_REQUIRE(values_per_facet == 1 || values_per_facet == 3, "fs_assemble_ns_pressure_boundary: values_per_facet must be 1 or 3");
     FS_REQUIRE(nn_pref >= 0.0 && (nn_pref == 0.0 || (w0 && J && w0->d.n >= J->space->n_dofs_local)),
                "fs_assemble_ns_pressure_boundary: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
     FS_REQUIRE(J && g && n_facets >= 0 && (n_facets == 0 || (facet_cell && facet_opposite)), "fs_assemble_ns_pressure_boundary: bad arguments");
@@ -698,13 +708,13 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
     FS_CHECK(dc.upload(facet_cell, n_facets, s));
     FS_CHECK(dop.upload(facet_opposite, n_facets, s));
     if (facet_value) {
-        FS_CHECK(dv.alloc(n_facets));
-        FS_CHECK(dv.upload(facet_value, n_facets, s));
+        FS_CHECK(dv.alloc(n_facets * values_per_facet));
+        FS_CHECK(dv.upload(facet_value, n_facets * values_per_facet, s));
     }
     hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
                        facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
                        sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,
-                       nn_pref, nn_exp);
+                       nn_pref, nn_exp, values_per_facet);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

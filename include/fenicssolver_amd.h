@@ -401,10 +401,14 @@ int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_v
  * facet_value: p_b per facet, NULL = the pressure 'farfield' type (traction term only, :459-460). */
 int fs_assemble_ns_pressure_boundary(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                      const int32_t* facet_opposite, const double* facet_value, double kinematic_viscosity);
-/* The same with the pressure-dependent viscosity of fs_ns_form (w0: the state whose pressure enters nu). */
+/* The same with the pressure-dependent viscosity of fs_ns_form (w0: the state whose pressure enters nu; ref 0 = off) and,
+ * with values_per_facet = 3, a boundary pressure that varies over the facet: facet_value[f][k] = p_b at the facet's k-th
+ * vertex in the order of the cell's local vertices (the opposite one left out) - the P1 interpolant DOLFIN evaluates a
+ * degree-1 Expression with; values_per_facet = 1: one value per facet. */
 int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                         const int32_t* facet_opposite, const double* facet_value, double kinematic_viscosity,
-                                        fs_vector_t w0, double viscosity_pressure_ref, double viscosity_pressure_exponent);
+                                        fs_vector_t w0, double viscosity_pressure_ref, double viscosity_pressure_exponent,
+                                        int values_per_facet);
 
 typedef struct fs_saddle_opts {
     double rtol, atol;          /* on ||g - J w||_2 (relative to ||g||_2) */

@@ -350,7 +350,14 @@ def pressure_boundary_terms(th, facet_cells, nu, bvalue=None, viscosity_law=None
                 Ke[k, :, i, :, i] += -nu * wv * np.outer(phi, gn)
             Ke[k, :, :3, :, :3] += -nu * wv * np.einsum("a,bi,j->aibj", phi, gphi, n)
             if bvalue is not None:
-                ge[k, :, :3] -= wv * float(bvalue) * np.outer(phi, n)
+                # a number, or a function of the point (a boundary pressure that varies: evaluated through its P1 interpolant
+                # on the facet, i.e. from its values at the facet's vertices - what DOLFIN does with a degree-1 Expression)
+                if callable(bvalue):
+                    pv = np.array([bvalue(th.coords[th.cells[c, v]]) for v in opp[o]])
+                    pb = float(pv @ bary)
+                else:
+                    pb = float(bvalue)
+                ge[k, :, :3] -= wv * pb * np.outer(phi, n)
     cells = facet_cells[:, 0]
     dofs = (th.cell_nodes[cells][:, :, None] * 4 + np.arange(4)[None, None, :]).reshape(nf, 40)
     rows = np.repeat(dofs, 40, axis=1).ravel()

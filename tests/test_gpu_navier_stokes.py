@@ -718,3 +718,50 @@ def test_coupled_temperature_transient_step_satisfies_the_crank_nicolson_equatio
     assert np.abs(r).max() <= 1e-8 * scale
     assert np.abs(Tn[bnd] - bvals).max() <= 1e-10 and np.abs(Tn - Tp).max() > 1e-3
     assert "temperature" in open(str(tmp_path / "upT000000.vtu")).read()
+
+
+def test_boundary_pressure_that_varies_over_the_facets(gpu):
+    """A pressure boundary value given as an Expression (hydrostatic outlet): the load inner(p_b n, v) ds with p_b through its P1
+    interpolant on every facet (values at the facet's vertices), kernel against the oracle and through the solver class."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    co, ce, th, mesh, W, Q = _setup(gpu, 3)
+    nu = 0.3
+    fout = ns.boundary_facet_cells(th, lambda x: abs(x[0] - 1) < 1e-12)
+    pfun = lambda x: 5.0 - 9.8 * x[2] + 0.5 * x[1]                              # noqa: E731
+    J = gpu.DeviceMatrix(W)
+    g = gpu.DeviceVector(W.n_owned)
+    gpu.assemble_navier_stokes(J, g, None, None, nu=nu, rho=1.0, convection=False, newton=False)
+    gbase = g.get()
+    cells = ce.astype(np.int64)
+    fv = np.array([[pfun(co[cells[c, v]]) for v in range(4) if v != o] for c, o in fout])
+    gpu.assemble_ns_pressure_boundary(J, g, fout[:, 0], fout[:, 1], nu, fv)
+    dJ, dg = ns.pressure_boundary_terms(th, fout, nu, pfun)
+    assert np.abs((g.get() - gbase) - dg).max() <= 1e-12 * np.abs(dg).max()
+    _, dg_c = ns.pressure_boundary_terms(th, fout, nu, 5.0 - 4.9 + 0.25)
+    assert np.abs(dg - dg_c).max() > 1e-2 * np.abs(dg).max()                     # not the load of the mean pressure
+
+    # solver class: fluid at rest under gravity, closed box except a hydrostatic outlet: u = 0, p = p0 - g z exactly
+    m = UnitCubeMesh(3, 3, 3)
+    bcs = OrderedDict()
+    # every boundary facet is a wall first; the outlet re-marks its own facets afterwards (a facet is marked when ALL its
+    # vertices are inside, so "on_boundary and not near(x[0], 1)" would leave the wall facets along the outlet rim unmarked)
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 1.0)), 'boundary_id': 2,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Expression("5.0 - 9.8*x[2]", degree=1)}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': m, 'fe_degree': 1, 'boundary_conditions': bcs,
+              'body_source': Constant((0.0, 0.0, -9.8)), 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 1.0, 'kinematic_viscosity': nu}})
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-11}
+    s['report_settings'] = dict(QUIET)
+    solver = CoupledNavierStokesSolver(s)
+    solver.solve()
+    u, p = solver.split()
+    assert np.abs(u.node_values()).max() <= 1e-8
+    assert np.abs(p.vector().array() - (5.0 - 9.8 * m.coordinates()[:, 2])).max() <= 1e-6
