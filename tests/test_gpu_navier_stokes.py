@@ -627,7 +627,7 @@ def test_time_dependent_boundary_values_and_form_parts(gpu):
     _, mesh, w_list = run([Constant((a, 0, 0)) for a in ramp])
     # get_current_time() of step k is starting_time + dt (k - 1), as in the reference (SolverBase.py:453-465)
     solver, _, w_call = run(lambda t: Constant((ramp[int(round(t / 0.01)) + 1], 0, 0)))
-    assert np.abs(w_list - w_call).max() <= 1e-12
+    assert np.abs(w_list - w_call).max() <= 1e-9          # (the right-hand side is summed with atomics: not bit-reproducible)
     _, _, w_const = run(Constant((1.0, 0, 0)))
     assert np.abs(w_list - w_const).reshape(-1, 4)[:, :3].max() > 1e-2           # the ramp is a different problem
     # oracle: the same ramp, step by step
