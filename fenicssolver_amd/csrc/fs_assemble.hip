@@ -868,6 +868,17 @@ __device__ __forceinline__ tri_geom tri_geometry2(const double* __restrict__ xyz
     return t;
 }
 
+// SUPG parameter on a triangle: tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 Circumradius = a b c / (2 A)
+__device__ __forceinline__ double supg_tau_tri(const double* __restrict__ xyz4, int32_t v0, int32_t v1, int32_t v2, double area,
+                                               double vnorm, double pe) {
+    const double x0 = xyz4[4 * (int64_t)v0], y0 = xyz4[4 * (int64_t)v0 + 1], x1 = xyz4[4 * (int64_t)v1], y1 = xyz4[4 * (int64_t)v1 + 1];
+    const double x2 = xyz4[4 * (int64_t)v2], y2 = xyz4[4 * (int64_t)v2 + 1];
+    const double a = sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0)), b = sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+    const double c = sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2));
+    const double h = a * b * c / (2.0 * area);
+    return 0.5 * h / (4.0 / (pe * h) + 2.0 * vnorm);
+}
+
 // ---- plane-strain elasticity on triangles (LinearElasticitySolver.py:62-69 with dimension 2; the reference sends 2D
 // problems to solve_linear_problem, :247-253) ------------------------------------------------------------------------------
 // One thread per stored 2x2 block sums, in ascending order, the (cell, a, b) sources of the inverse slot table
@@ -979,7 +990,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double* __restrict__ val, double supg_pe = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -1040,6 +1051,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
                 const double w3 = ascale * t.area * (1.0 / 3.0);
 #pragma unroll
                 for (int b = 0; b < 3; ++b) row[b] += w3 * (vx * t.g[b][0] + vy * t.g[b][1]);
+                if (supg_pe > 0.0) {      // test function q + tau (v . grad q) on the advection and mass terms (:259-270)
+                    const double tau = supg_tau_tri(xyz4, v4.x, v4.y, v4.z, t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                    const double wa = tau * (vx * ga[0] + vy * ga[1]);
+                    const double mval = mc.mode == FS_COEF_NONE ? 0.0 : (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) row[b] += wa * t.area * (ascale * (vx * t.g[b][0] + vy * t.g[b][1]) + mval * (1.0 / 3.0));
+                }
             }
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
@@ -1056,7 +1074,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_scalar_gather(
 }
 
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_source(const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-                                                                  int64_t nc, int64_t n_rows, coef_dev f, double* __restrict__ b) {
+                                                                  int64_t nc, int64_t n_rows, coef_dev f, double* __restrict__ b,
+                                                                  coef_dev sv, double supg_pe) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; c < nc; c += stride) {
@@ -1071,6 +1090,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_source(const int32_t*
         } else {
             const double ff = f.mode == FS_COEF_CONST ? f.value : f.data[c];
             for (int a = 0; a < 3; ++a) be[a] = ff * t.area * (1.0 / 3.0);
+            if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {     // + int S tau (v . grad phi_a) dx
+                double vx, vy;
+                if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; }
+                else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; }
+                const double tau = supg_tau_tri(xyz4, v[0], v[1], v[2], t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                for (int a = 0; a < 3; ++a) be[a] += ff * t.area * tau * (vx * t.g[a][0] + vy * t.g[a][1]);
+            }
         }
         for (int a = 0; a < 3; ++a)
             if (v[a] < n_rows) atomicAdd(&b[v[a]], be[a]);
@@ -2043,7 +2069,6 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
             hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
     } else if (m->tdim == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
-        FS_REQUIRE(!(form->supg_pe > 0.0), "fs_assemble_matrix: SUPG is built for tetrahedral meshes");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode != FS_COEF_NODAL, "fs_assemble_matrix: nodal stiffness coefficient is not supported");
         dbuf<double> astore2;
@@ -2051,15 +2076,16 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_CHECK(make_coef(form->advection, (form->advection.mode == FS_COEF_CELL_ROW ? 9 : 3) * m->nc, astore2, &ac2, "fs_assemble_matrix(advection)"));
         FS_REQUIRE(ac2.mode == FS_COEF_NONE || ac2.mode == FS_COEF_CONST || ac2.mode == FS_COEF_CELL || ac2.mode == FS_COEF_CELL_ROW,
                    "fs_assemble_matrix: advection velocity must be constant, per cell or per (cell, test function)");
+        FS_REQUIRE(!(ac2.mode == FS_COEF_CELL_ROW && form->supg_pe > 0.0), "fs_assemble_matrix: SUPG takes a constant or per-cell velocity");
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (add)
-            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p);
+            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p, form->supg_pe);
         else
-            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p);
+            hipLaunchKernelGGL(k_assemble_tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac2, form->advection_scale, A->val.p, form->supg_pe);
     } else if (A->bs == 1 && sp->degree == 2) {
         FS_REQUIRE(sp->inc_cell.p, "fs_assemble_matrix: CG2 space has no assembly tables");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
@@ -2613,8 +2639,14 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         return FS_OK;
     }
     if (m->tdim == 2) {
-        FS_REQUIRE(f.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0), "fs_assemble_vector: unsupported option on a triangular mesh");
-        hipLaunchKernelGGL(k_assemble_tri_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
+        FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: unsupported option on a triangular mesh");
+        dbuf<double> sstore2;
+        coef_dev sv2;
+        FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore2, &sv2, "fs_assemble_vector(supg_velocity)"));
+        FS_REQUIRE(!(form->supg_pe > 0.0) || sv2.mode == FS_COEF_NONE || ((sv2.mode == FS_COEF_CONST || sv2.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL),
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
+        hipLaunchKernelGGL(k_assemble_tri_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p,
+                           sv2, form->supg_pe);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
@@ -2714,6 +2746,45 @@ __global__ void k_facet_supg(int64_t nf, const int32_t* __restrict__ facet_cell,
     }
 }
 
+// the same on the boundary EDGES of a triangular mesh: |E| = 2 A |grad lambda_o|, the Robin matrix couples w_a with the two edge vertices
+__global__ void k_facet_supg_tri(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                                 const double* __restrict__ g, const double* __restrict__ h, coef_dev vel, double pe,
+                                 const int32_t* __restrict__ cells, const double* __restrict__ xyz4, int64_t n_rows,
+                                 const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                 double* __restrict__ val, double* __restrict__ b, int* __restrict__ err) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 3; t += stride) {
+        const int64_t f = t / 3;
+        const int a = (int)(t - 3 * f);
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[3] = {v4.x, v4.y, v4.z};
+        const int32_t row = v[a];
+        if (row >= n_rows) continue;
+        const tri_geom tg = tri_geometry2(xyz4, v[0], v[1], v[2]);
+        double vx, vy;
+        if (vel.mode == FS_COEF_CONST) { vx = vel.tensor[0]; vy = vel.tensor[1]; }
+        else { vx = vel.data[3 * c]; vy = vel.data[3 * c + 1]; }
+        const double tau = supg_tau_tri(xyz4, v[0], v[1], v[2], tg.area, sqrt(vx * vx + vy * vy), pe);
+        const double wa = tau * (vx * tg.g[a][0] + vy * tg.g[a][1]);
+        const double len = 2.0 * tg.area * sqrt(tg.g[o][0] * tg.g[o][0] + tg.g[o][1] * tg.g[o][1]);
+        if (b && g) atomicAdd(&b[row], g[f] * len * wa);
+        if (val && h) {
+            const int64_t sp0 = slice_ptr[row >> 6];
+            const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            const int64_t base = sp0 + (row & 63);
+            for (int bb = 0; bb < 3; ++bb) {
+                if (bb == o) continue;
+                const int k = fs_find_pos_local(sell_col, base, width, v[bb]);
+                if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], h[f] * len * 0.5 * wa);
+                else atomicAdd(err, 1);
+            }
+        }
+    }
+}
+
 extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector_t b, int64_t n_facets, const int32_t* facet_cell,
                                       const int32_t* facet_opposite, const double* g, const double* h, const fs_coef* velocity,
                                       double supg_pe) {
@@ -2724,7 +2795,7 @@ extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector
     if (n_facets == 0 || ((!A || !h) && (!b || !g))) return FS_OK;
     fs_mesh_s* m = space->mesh;
     for (int64_t i = 0; i < n_facets; ++i)
-        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] < 4,
+        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] <= m->tdim,
                    "fs_assemble_facet_supg: facet %lld names cell %d / local vertex %d", (long long)i, facet_cell[i], facet_opposite[i]);
     hipStream_t s = fs_rt().stream;
     dbuf<int32_t> dc, dop;
@@ -2738,9 +2809,14 @@ extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector
     FS_CHECK(dop.upload(facet_opposite, n_facets, s));
     if (g) { FS_CHECK(dg.alloc(n_facets)); FS_CHECK(dg.upload(g, n_facets, s)); }
     if (h) { FS_CHECK(dh.alloc(n_facets)); FS_CHECK(dh.upload(h, n_facets, s)); }
-    hipLaunchKernelGGL(k_facet_supg, dim3(fs_grid_for(n_facets * 4)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
-                       h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
-                       space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
+    if (m->tdim == 2)
+        hipLaunchKernelGGL(k_facet_supg_tri, dim3(fs_grid_for(n_facets * 3)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
+                           h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
+                           space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
+    else
+        hipLaunchKernelGGL(k_facet_supg, dim3(fs_grid_for(n_facets * 4)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
+                           h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
+                           space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
     FS_KERNEL_CHECK();
     int h_err = 0;
     FS_CHECK(d_err.download(&h_err, 1, s));

@@ -1051,6 +1051,57 @@ def assemble_interior_penalty(coords, cells, coefficient):
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
 
 
+# ---- SUPG on triangles (the same substitutions as on tetrahedra, ScalarTransportSolver.py:259-270) -----------------------
+def tri_supg_weights(coords, cells, velocity, pe):
+    """w[c,a] = tau_c (v_c . grad phi_a), tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 * Circumradius."""
+    area, g = tri_geometry(coords, cells)
+    v = np.asarray(velocity, dtype=np.float64)[..., :2]
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(area), 2))
+    h = 2.0 * tet_circumradius(np.asarray(coords, dtype=np.float64)[:, :2], cells)
+    tau = 0.5 * h / (4.0 / (pe * h) + 2.0 * np.linalg.norm(v, axis=1))
+    return tau[:, None] * np.einsum("ci,cai->ca", v, g), v
+
+
+def tri_supg_local(coords, cells, velocity, pe, advection_scale=0.0, mass_coef=0.0):
+    area, g = tri_geometry(coords, cells)
+    w, v = tri_supg_weights(coords, cells, velocity, pe)
+    vg = np.einsum("ci,cbi->cb", v, g)
+    m = np.broadcast_to(np.asarray(mass_coef, dtype=np.float64), (len(area),))
+    return w[:, :, None] * (advection_scale * vg[:, None, :] * area[:, None, None] + (m * area / 3.0)[:, None, None])
+
+
+def assemble_tri_supg_source(coords, cells, velocity, pe, f):
+    area, _ = tri_geometry(coords, cells)
+    w, _ = tri_supg_weights(coords, cells, velocity, pe)
+    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(area),))
+    b = np.zeros(len(coords))
+    np.add.at(b, np.asarray(cells, dtype=np.int64).ravel(), (w * (ff * area)[:, None]).ravel())
+    return b
+
+
+def tri_supg_facet_terms(coords, cells, facet_cells, velocity, pe, g=None, h=None):
+    """db[a] += g |E| w_a ;  dA[a, b on the edge] += h (|E|/2) w_a  for the three vertices a of the cell behind each boundary edge."""
+    import scipy.sparse as sp
+    co = np.asarray(coords, dtype=np.float64)[:, :2]
+    ce = np.asarray(cells, dtype=np.int64)
+    w, _ = tri_supg_weights(co, ce, velocity, pe)
+    n = len(co)
+    db = np.zeros(n)
+    rows, cols, vals = [], [], []
+    opp = ((1, 2), (0, 2), (0, 1))
+    for k, (c, o) in enumerate(np.asarray(facet_cells, dtype=np.int64)):
+        ed = ce[c, list(opp[o])]
+        length = np.linalg.norm(co[ed[1]] - co[ed[0]])
+        gk = 0.0 if g is None else float(np.broadcast_to(g, (len(facet_cells),))[k])
+        hk = 0.0 if h is None else float(np.broadcast_to(h, (len(facet_cells),))[k])
+        for a in range(3):
+            db[ce[c, a]] += gk * length * w[c, a]
+            for bnode in ed:
+                rows.append(ce[c, a]); cols.append(bnode); vals.append(hk * length / 2.0 * w[c, a])
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr(), db
+
+
 def radiation_facet_loads(coords, facets, T, m, T_amb):
     """[nf, d] vertex loads int_F m (T_amb^4 - T_h^4) lambda_a ds of a P1 field T on boundary triangles / edges, for the
     reference's  m*(pow(T, 4) - pow(T_amb, 4))*Tq*ds  (ScalarTransportSolver.py:186-190): exact, by expanding T_h^4 in the
