@@ -151,6 +151,43 @@ class LinearElasticitySolver(SolverBase):
         n[flip] *= -1.0
         return tri, n / area[:, None], area
 
+    # int phi_node lambda_b ds / |F| on a boundary facet: P2 nodes (vertices, then edge mid-points) against the P1 weights
+    _W_TRI_P2 = np.array([[1 / 30 if b == v else -1 / 60 for b in range(3)] for v in range(3)] +
+                         [[2 / 15 if b in e else 1 / 15 for b in range(3)] for e in ((0, 1), (0, 2), (1, 2))])
+    _W_SEG_P2 = np.array([[1 / 6, 0.0], [0.0, 1 / 6], [1 / 3, 1 / 3]])
+
+    def _varying_pressure_load(self, marker_id, pval, direction, name):
+        from .fem import nodal_values, FunctionSpace
+        V = self.function_space
+        if V.localizer() is not None:
+            raise SolverError("boundary '{}': a varying pressure is built for one GPU".format(name))
+        tri, nrm, area = self._facet_normals(marker_id)
+        if direction:
+            nrm = np.tile(self._vector_of(direction, name), (len(tri), 1))
+        pv = nodal_values(pval, FunctionSpace(self.mesh, 'P', 1))[tri]              # [nf, d]: p at the facet's vertices
+        d = tri.shape[1]
+        nv = self.mesh.num_vertices()
+        if V.degree() == 1:
+            nodes = tri
+            w = (pv.sum(axis=1, keepdims=True) + pv) / (d * (d + 1.0))              # [nf, d]
+        else:
+            ed = V.edge_nodes().astype(np.int64)
+            ekey = ed[:, 0] * nv + ed[:, 1]
+            sorter = np.argsort(ekey)
+            pairs = ((0, 1), (0, 2), (1, 2)) if d == 3 else ((0, 1),)
+            enodes = []
+            for a, b in pairs:
+                lo, hi = np.minimum(tri[:, a], tri[:, b]), np.maximum(tri[:, a], tri[:, b])
+                enodes.append(nv + sorter[np.searchsorted(ekey[sorter], lo * nv + hi)])
+            nodes = np.concatenate([tri, np.stack(enodes, axis=1)], axis=1)         # [nf, 6] or [nf, 3]
+            w = pv @ (self._W_TRI_P2 if d == 3 else self._W_SEG_P2).T               # [nf, n_nodes]
+        loads = self.load_sign_for_tractions() * area[:, None, None] * w[:, :, None] * nrm[:, None, :]     # [nf, nn, dim]
+        dofs = nodes[:, :, None] * self.dimension + np.arange(self.dimension)[None, None, :]
+        return forms.NodalLoad(dofs, loads, 'pressure(field) ds(%d)' % marker_id)
+
+    def load_sign_for_tractions(self):
+        return -1.0 if self.reference_load_sign else 1.0
+
     def _total_area(self, tri, area):
         """assemble(Constant(1)*ds(id)): on a distributed mesh every facet is counted once - by the rank owning its vertex
         of smallest global id - and the ranks' sums are added."""
@@ -227,7 +264,10 @@ class LinearElasticitySolver(SolverBase):
             elif btype == 'pressure':
                 pval = self.translate_value(bc['value'])
                 if not is_constant_value(pval):
-                    raise SolverError("boundary '{}': pressure must be a constant".format(name))
+                    # a pressure that varies over the boundary (hydrostatic load on a wall): n * p with p through its P1
+                    # interpolant on every facet, integrated exactly against the P1 / P2 test functions
+                    integrals_N.append(self._varying_pressure_load(i, pval, bc.get('direction'), name))
+                    continue
                 if 'direction' in bc and bc['direction']:
                     integrals_N.append(forms.FacetLoad(i, self._vector_of(bc['direction'], name) * float(pval),
                                                        'pressure(direction)'))

@@ -557,6 +557,9 @@ class SolverBase():
                 Mb.spmv(fd, tmpb)
                 b.axpy(sgn, tmpb)
             for t in F.tractions:
+                if isinstance(t, forms.NodalLoad):          # worked out per node on the host (sign included)
+                    b.add_entries(t.dofs, t.values)
+                    continue
                 tri, g = self._device_facets(F, t.marker_id, t.g)
                 if len(tri):
                     backend.assemble_facet_vector(V, b, tri, sgn * np.asarray(g, float))

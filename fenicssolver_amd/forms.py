@@ -49,6 +49,19 @@ class FacetLoad:
         return "FacetLoad(ds(%d), g=%r, %s)" % (self.marker_id, self.g, self.origin)
 
 
+class NodalLoad:
+    """b[dofs] += values: load contributions worked out per node on the host (boundary terms with a varying magnitude,
+    integrated exactly for its P1 interpolant)."""
+
+    def __init__(self, dofs, values, origin=""):
+        self.dofs = np.asarray(dofs, dtype=np.int64).ravel()
+        self.values = np.asarray(values, dtype=np.float64).ravel()
+        self.origin = origin
+
+    def __repr__(self):
+        return "NodalLoad(%d entries, %s)" % (len(self.dofs), self.origin)
+
+
 class FacetRobin:
     """htc*(Ta - T)*q*ds(i): +h int T q ds on the matrix, +h*Ta int q ds on the load."""
 
@@ -122,7 +135,8 @@ class ElasticityForm:
         return {
             "type": "elasticity", "mu": self.mu, "lambda": self.lmbda,
             "body_force": None if self.body_force is None else tuple(float(x) for x in self.body_force),
-            "tractions": [(t.marker_id, _plain(t.g), t.origin) for t in self.tractions],
+            "tractions": [(t.marker_id, _plain(t.g), t.origin) if isinstance(t, FacetLoad) else ("nodal", len(t.dofs), t.origin)
+                          for t in self.tractions],
             "thermal": None if self.thermal is None else (self.thermal[0], _plain(self.thermal[1]), self.thermal[2]),
             "load_sign": self.load_sign,
         }

@@ -329,3 +329,52 @@ def test_spatially_varying_body_force(gpu, degree):
     ref = fo.solve_direct(*fo.apply_dirichlet(R, b, dofs, vals, True))
     assert np.abs(u - ref).max() <= 1e-6 * np.abs(ref).max()
     assert np.abs(ref).max() > 2e-3                                  # the load matters next to the 1 mm end displacement
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_pressure_boundary_that_varies_in_space(gpu, degree):
+    """'pressure' with an Expression value (a hydrostatic load on the top face): n * p with p through its P1 interpolant on
+    every facet, integrated against the P1 / P2 test functions - checked with the 6-point degree-4 rule on every facet."""
+    from fenicssolver_amd.fem import Expression, SubDomain, near
+    from oracle import ns_oracle as nso
+
+    class Top(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[2], 1.0)
+    solver = _example_solver(6, 2, 2, degree=degree, thermal=False, body=False)
+    solver.boundary_conditions["load"] = {'boundary': Top(), 'boundary_id': 3, 'type': 'pressure', 'value': Expression("1e6*(1+0.3*x[0])", degree=1)}
+    solver.settings['boundary_conditions'] = solver.boundary_conditions
+    solver.generate_boundary_facets() if hasattr(solver, 'generate_boundary_facets') else None
+    u = solver.solve().vector().array()
+    co, ce = fo.box_mesh((0, 0, 0), (10.0, 1.0, 1.0), 6, 2, 2)
+    V = solver.function_space
+    X = V.node_coordinates()
+    n = len(X)
+    facets, _, cnt = fo.facet_numbering(ce)
+    top = facets[(cnt == 1) & np.all(co[facets.astype(np.int64)][:, :, 2] == 1.0, axis=1)].astype(np.int64)
+    area = fo.facet_areas(co, top)
+    pvert = 1e6 * (1 + 0.3 * co[:, 0])
+    b = np.zeros(3 * n)
+    if degree == 2:
+        edges = V.edge_nodes().astype(np.int64)
+        emap = {(int(a), int(c)): len(co) + k for k, (a, c) in enumerate(edges)}
+    for f, tri in enumerate(top):
+        nodes = list(tri) + ([emap[tuple(sorted((int(tri[i]), int(tri[j]))))] for i, j in ((0, 1), (0, 2), (1, 2))] if degree == 2 else [])
+        for bary, w in zip(nso.TRI_QP, nso.TRI_QW):
+            pq = pvert[tri] @ bary
+            if degree == 1:
+                phi = bary
+            else:
+                phi = np.concatenate([bary * (2 * bary - 1), [4 * bary[0] * bary[1], 4 * bary[0] * bary[2], 4 * bary[1] * bary[2]]])
+            for a, node in enumerate(nodes):
+                b[3 * node + 2] += -1.0 * w * area[f] * pq * phi[a] * 1.0          # outward normal (0,0,1); loads are ADDED to F (B-Q3)
+    if degree == 1:
+        R = fo.assemble_p1_elasticity(co, ce, E, NU)
+    else:
+        R, cd, _ = fo.assemble_p2_elasticity(co, ce, E, NU)
+    left = np.nonzero(np.isclose(X[:, 0], 0.0))[0]
+    right = np.nonzero(np.isclose(X[:, 0], 10.0))[0]
+    dofs = np.concatenate([left * 3, (right[:, None] * 3 + np.arange(3)).ravel()])
+    vals = np.concatenate([np.zeros(len(left)), np.tile([0.0, 0.0, 1e-3], len(right))])
+    ref = fo.solve_direct(*fo.apply_dirichlet(R, b, dofs, vals, True))
+    assert np.abs(u - ref).max() <= 1e-6 * np.abs(ref).max()
