@@ -271,10 +271,11 @@ class ScalarTransportSolver(SolverBase):
             elif btype == 'HTC':
                 Ta = self.translate_value(bc['ambient'])
                 htc = self.translate_value(bc['value'])
-                if not (is_constant_value(Ta) and is_constant_value(htc)):
-                    raise SolverError("boundary '{}': HTC value and ambient must be constants".format(name))
+                if not is_constant_value(htc):
+                    raise SolverError("boundary '{}': the HTC value must be a constant".format(name))
                 h = float(htc) / (self._scalar_capacity(capacity) if self.using_diffusion_form else 1.0)
-                integrals_N.append(forms.FacetRobin(i, h, float(Ta)))
+                # an ambient temperature that varies over the boundary enters the load h * Ta * q * ds by its vertex values
+                integrals_N.append(forms.FacetRobin(i, h, float(Ta) if is_constant_value(Ta) else self._facet_value(Ta, i, name)))
             else:
                 raise SolverError('boundary type`{}` is not supported'.format(btype))
         return bcs, integrals_N

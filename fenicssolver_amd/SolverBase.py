@@ -480,9 +480,18 @@ class SolverBase():
                 if len(tri):
                     backend.assemble_facet_vector(V, b, tri, g)
             for r in F.robin:
-                tri, _ = self._device_facets(F, r.marker_id)
+                if np.ndim(r.ambient) == 2:         # ambient given at the facet vertices: exact load of its P1 interpolant
+                    gtri = self._facets_of(r.marker_id).astype(np.int64)
+                    loads = _facet_nodal_loads(self.mesh.coordinates(), gtri, r.h * np.asarray(r.ambient, dtype=np.float64))
+                    tri, loads = self._device_facets(F, r.marker_id, loads)
+                    rows = np.asarray(tri, dtype=np.int64)
+                    own_rows = rows < V.n_owned
+                    if own_rows.any():
+                        b.add_entries(rows[own_rows], loads[own_rows])
+                    continue
+                tri, amb = self._device_facets(F, r.marker_id, r.ambient if np.ndim(r.ambient) == 1 else None)
                 if len(tri):
-                    backend.assemble_facet_vector(V, b, tri, r.h * r.ambient)
+                    backend.assemble_facet_vector(V, b, tri, r.h * (amb if amb is not None else r.ambient))
             if pe:
                 # the reference substitutes q + tau (v . grad q) in the boundary integrals as well (Tq, :296-298)
                 def local_facets(marker_id, per_facet):
@@ -506,9 +515,10 @@ class SolverBase():
                     if len(cells_):
                         backend.assemble_facet_supg(V, None, b, cells_, opp_, adv, pe, g=gg)
                 for r in F.robin:
-                    cells_, opp_, _ = local_facets(r.marker_id, None)
+                    amb = r.ambient if np.ndim(r.ambient) == 0 else (np.asarray(r.ambient).mean(axis=1) if np.ndim(r.ambient) == 2 else np.asarray(r.ambient))
+                    cells_, opp_, amb_l = local_facets(r.marker_id, amb if np.ndim(amb) == 1 else None)
                     if len(cells_):
-                        backend.assemble_facet_supg(V, A, b, cells_, opp_, adv, pe, g=r.h * r.ambient, h=r.h)
+                        backend.assemble_facet_supg(V, A, b, cells_, opp_, adv, pe, g=r.h * (amb_l if amb_l is not None else amb), h=r.h)
             for ps in getattr(F, 'point_sources', []):
                 # PointSource.apply(b) (SolverBase.py:597-601): before the Dirichlet rows, which then overwrite
                 pd, pw = ps.dofs, ps.weights

@@ -68,10 +68,10 @@ class FacetRobin:
     def __init__(self, marker_id, h, ambient):
         self.marker_id = int(marker_id)
         self.h = float(h)
-        self.ambient = float(ambient)
+        self.ambient = float(ambient) if np.ndim(ambient) == 0 else np.asarray(ambient, dtype=np.float64)   # [nf, d]: vertex values
 
     def __repr__(self):
-        return "FacetRobin(ds(%d), h=%g, Ta=%g)" % (self.marker_id, self.h, self.ambient)
+        return "FacetRobin(ds(%d), h=%g, Ta=%s)" % (self.marker_id, self.h, _plain(self.ambient))
 
 
 class ScalarForm:
@@ -111,7 +111,7 @@ class ScalarForm:
             "ip_coefficient": self.ip_coefficient,
             "sources": [s.describe() for s in self.sources],
             "facet_loads": [(f.marker_id, _plain(f.g), f.origin) for f in self.facet_loads],
-            "robin": [(r.marker_id, r.h, r.ambient) for r in self.robin],
+            "robin": [(r.marker_id, r.h, _plain(r.ambient)) for r in self.robin],
             "advection": None if self.advection is None else (_plain(self.advection[0]), float(self.advection[1])),
             "radiation": self.radiation, "nonlinear": self.nonlinear,
         }

@@ -504,3 +504,30 @@ def test_flux_boundary_given_as_a_field(gpu):
     np.add.at(bm, top.ravel(), np.repeat(gv[top].mean(axis=1) * area / 3.0, 3))
     mean = fo.solve_direct(*fo.apply_dirichlet(K, bm, bot, 300.0, True))
     assert np.abs(mean - ref).max() > 1e-3                                      # the facet mean is a different load
+
+
+def test_htc_with_an_ambient_temperature_field(gpu):
+    """HTC boundary whose ambient temperature varies over the boundary (an Expression): h * (Ta - T) * q * ds with Ta through
+    its P1 interpolant, the load integrated exactly (edge-midpoint rule on every boundary triangle as the check)."""
+    from fenicssolver_amd.fem import Constant, Expression
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    s, m = _box_heat_settings(4)
+    s['boundary_conditions']["cold"]['values']['temperature'] = {
+        'variable': 'temperature', 'type': 'HTC', 'value': Constant(100.0), 'ambient': Expression("300 + 40*x[0]*x[2]", degree=1)}
+    T = ScalarTransportSolver(s).solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    facets, _, cnt = fo.facet_numbering(ce)
+    fm = fo.mark_facets(co, ce, lambda x, ob: abs(x[1] - 1.0) < 3e-16, 1)
+    fm = fo.mark_facets(co, ce, lambda x, ob: abs(x[1]) < 3e-16, 2, fm)
+    bot = facets[fm == 2].astype(np.int64)
+    Ta = 300 + 40 * co[:, 0] * co[:, 2]
+    area = fo.facet_areas(co, bot)
+    b = np.zeros(len(co))
+    for lam in ((0.5, 0.5, 0.0), (0.0, 0.5, 0.5), (0.5, 0.0, 0.5)):
+        lam = np.asarray(lam)
+        np.add.at(b, bot.ravel(), ((area / 3.0 * 100.0 * (Ta[bot] @ lam))[:, None] * lam[None, :]).ravel())
+    A = fo.assemble_p1_scalar(co, ce, 0.6) + fo.assemble_p1_facet_mass(co, facets, fm, 2, 100.0)
+    top = np.nonzero(co[:, 1] == 1.0)[0]
+    ref = fo.solve_direct(*fo.apply_dirichlet(A.tocsr(), b, top, 360.0, True))
+    assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
+    assert np.ptp(T[co[:, 1] == 0.0]) > 5.0                     # the bottom follows the ambient field
