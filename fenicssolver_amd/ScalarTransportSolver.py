@@ -334,7 +334,9 @@ class ScalarTransportSolver(SolverBase):
                     raise SolverError("advection_settings['Pe'] must be positive")
             elif method:
                 raise SolverError("advection stabilization '{}' is not known ('SPUG', 'IP' or None)".format(method))
-            velocity = self.get_convective_velocity_function(self.convective_velocity, per_test_function=not supg_pe > 0.0)
+            # P2 spaces: a constant velocity is exact (degree-3 rule); a field enters by its cell mean
+            velocity = self.get_convective_velocity_function(
+                self.convective_velocity, per_test_function=(not supg_pe > 0.0) and self.function_space.degree() == 1)
         F = forms.ScalarForm(self.function_space)
         F.supg_pe = supg_pe if self.convective_velocity else 0.0
         F.ip_coefficient = ip_coef if self.convective_velocity else 0.0

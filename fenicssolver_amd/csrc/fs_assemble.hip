@@ -357,12 +357,21 @@ __device__ __forceinline__ void p2_basis_grads(const tet_geom& t, const double (
         for (int d = 0; d < 3; ++d) gp[4 + e][d] = 4.0 * (lam[ei[e]] * t.g[ej[e]][d] + lam[ej[e]] * t.g[ei[e]][d]);
 }
 
-template <bool ADD>
+// degree-3 rule for the cubic integrand of the CG2 advection term phi_a (v . grad phi_b): Keast's 5 points (one negative weight)
+__device__ __constant__ double FS_TET5_QP[5][4] = {{0.25, 0.25, 0.25, 0.25},
+                                                   {0.5, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0}, {1.0 / 6.0, 0.5, 1.0 / 6.0, 1.0 / 6.0},
+                                                   {1.0 / 6.0, 1.0 / 6.0, 0.5, 1.0 / 6.0}, {1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 0.5}};
+__device__ __constant__ double FS_TET5_QW[5] = {-0.8, 0.45, 0.45, 0.45, 0.45};
+
+// ADV: + scale * int phi_a (v . grad phi_b) dx with a constant or per-cell velocity (inner(velocity, grad(T))*Tq*capacity*dx,
+// ScalarTransportSolver.py:305-311, with fe_degree 2); a separate instantiation, the symmetric kernel keeps its registers
+template <bool ADD, bool ADV = false>
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order) {
+    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order,
+    coef_dev ac = coef_dev(), double ascale = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -444,6 +453,28 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
                 const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * vol * (1.0 / 420.0);
 #pragma unroll
                 for (int b = 0; b < 10; ++b) row[b] += mm * FS_P2_MASS420[a][b];
+            }
+            if (ADV && ac.mode != FS_COEF_NONE) {
+                double vx, vy, vz;
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; vz = ac.tensor[2]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; vz = ac.data[3 * (int64_t)c + 2]; }
+                for (int qp = 0; qp < 5; ++qp) {
+                    const double lam[4] = {FS_TET5_QP[qp][0], FS_TET5_QP[qp][1], FS_TET5_QP[qp][2], FS_TET5_QP[qp][3]};
+                    double gp[10][3];
+                    p2_basis_grads(t, lam, gp);
+                    // value of this row's basis function: vertex lambda (2 lambda - 1), edge 4 lambda_i lambda_j (UFC edges)
+                    const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
+                    double pa = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (b == a) pa = lam[b] * (2.0 * lam[b] - 1.0);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        if (4 + e == a) pa = 4.0 * lam[ei[e]] * lam[ej[e]];
+                    const double w = ascale * FS_TET5_QW[qp] * vol * pa;
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1] + vz * gp[b][2]);
+                }
             }
 #pragma unroll
             for (int b = 0; b < 10; ++b) {
@@ -2091,13 +2122,22 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
                    "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
-        FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection is not built for CG2");
+        dbuf<double> astore3;
+        coef_dev ac3;
+        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore3, &ac3, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE((ac3.mode == FS_COEF_NONE || ac3.mode == FS_COEF_CONST || ac3.mode == FS_COEF_CELL) && !(form->supg_pe > 0.0),
+                   "fs_assemble_matrix: CG2 advection takes a constant or per-cell velocity, without SUPG");
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
-        if (add)
+        if (ac3.mode != FS_COEF_NONE) {
+            if (add)
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, ac3, form->advection_scale);
+            else
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, ac3, form->advection_scale);
+        } else if (add)
             hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);
         else
             hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);

@@ -651,6 +651,25 @@ def p2_basis_gradients(g, lam):
     return out
 
 
+def p2_advection_local(coords, cells, velocity, scale=1.0):
+    """Ce[a,b] = scale * int phi_a (v . grad phi_b) dx for the P2 basis and a constant or per-cell velocity
+    (inner(velocity, grad(T))*Tq*capacity*dx, ScalarTransportSolver.py:305-311 with fe_degree 2): cubic integrand, integrated
+    with the 14-point degree-5 rule of the Navier-Stokes oracle (the device uses Keast's 5-point degree-3 rule)."""
+    from oracle import ns_oracle as nso
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    v = np.asarray(velocity, dtype=np.float64)
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(vol), 3))
+    pts, wq = nso.tet_quadrature(5)
+    Ce = np.zeros((len(vol), 10, 10))
+    for lam, w in zip(pts, wq):
+        phi, dphi = nso.p2_shape(lam)                       # [10], [10,4] (derivatives w.r.t. the barycentric coordinates)
+        gphi = np.einsum("ak,cki->cai", dphi, g)            # physical gradients
+        Ce += (scale * w * vol)[:, None, None] * np.einsum("a,cb->cab", phi, np.einsum("ci,cbi->cb", v, gphi))
+    return Ce
+
+
 def p2_stiffness_local(coords, cells, k=1.0):
     detJ, g = p1_geometry(coords, cells)
     vol = np.abs(detJ) / 6.0

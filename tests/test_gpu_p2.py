@@ -203,3 +203,53 @@ def test_p2_htc_facet_matrix_and_solver_class(gpu):
     X = fo.p2_dof_coordinates(co, edges)
     q = 60.0 / (1.0 / 100.0 + 1.2 / 0.6)
     assert np.abs(T - (300.0 + q * (1.0 / 100.0 + X[:, 2] / 0.6))).max() <= 1e-7
+
+
+def test_p2_advection_kernel_and_solver_class(gpu, data_dir):
+    """fe_degree 2 with a convective velocity (ScalarTransportSolver.py:305-311): C_ab = capacity * int phi_a (v . grad phi_b) dx
+    on the CG2 basis - kernel (Keast's 5-point degree-3 rule) against the oracle (14-point degree-5 rule) for constant and
+    per-cell velocities on an unstructured and a structured mesh, then the solver class (BiCGStab) against a direct solve."""
+    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    import scipy.sparse as sps
+    rng = np.random.default_rng(9)
+    for co, ce in (fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml")), fo.unit_cube_mesh(4)):
+        mesh = gpu.DeviceMesh(co, ce)
+        V = gpu.DeviceSpace(mesh, 1, degree=2)
+        cd, edges = fo.p2_cell_dofs(len(co), ce)
+        assert np.array_equal(V.edges().astype(np.int64), edges.astype(np.int64))
+        n = len(co) + len(edges)
+        A = gpu.DeviceMatrix(V)
+        for vel in (np.array([0.3, -0.2, 0.5]), rng.uniform(-1, 1, (len(ce), 3))):
+            A.assemble(stiffness=0.7, mass=0.1, advection=vel, advection_scale=2.5)
+            ref = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.7) + fo.p2_mass_local(co, ce, 0.1)
+                                      + fo.p2_advection_local(co, ce, vel, 2.5)).tocsr()
+            rp, ci, va, shape = A.to_csr()
+            got = sps.csr_matrix((va, ci, rp), shape=shape)
+            assert abs(got - ref).max() <= 1e-12 * abs(ref).max()
+        with pytest.raises(gpu.BackendError):
+            A.assemble(stiffness=0.7, advection=np.array([0.3, -0.2, 0.5]), supg_pe=2.0)
+    m = UnitCubeMesh(3, 3, 3)
+    Q = FunctionSpace(m, "CG", 2)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(360)}
+    bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant(300)}
+    st = {'solver_name': 'x', 'mesh': None, 'function_space': Q, 'periodic_boundary': None, 'boundary_conditions': bcs,
+          'body_source': 5.0, 'initial_values': {'temperature': 300}, 'convective_velocity': Constant((0.05, -0.08, 0.02)),
+          'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
+          'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 1},
+                              'reference_values': {'temperature': 300},
+                              'solver_parameters': {'krylov_relative_tolerance': 1e-12, 'maximum_iterations': 20000}},
+          'report_settings': {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}, 'scalar_name': 'temperature'}
+    T = ScalarTransportSolver(st).solve().vector().array()
+    co, ce = m.coordinates(), m.cells()
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    n = len(co) + len(edges)
+    A = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.6) + fo.p2_advection_local(co, ce, (0.05, -0.08, 0.02), 20.0))
+    b = fo.assemble_generic_vector(n, cd, fo.p2_source_local(co, ce, 5.0))
+    X = Q.node_coordinates()
+    top, bot = np.nonzero(X[:, 1] == 1.0)[0], np.nonzero(X[:, 1] == 0.0)[0]
+    ref = fo.solve_direct(*fo.apply_dirichlet(A.tocsr(), b, np.concatenate([top, bot]),
+                                              np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)]), False))
+    assert np.abs(T - ref).max() <= 1e-7 * np.abs(ref).max()
+    assert np.abs(T - (300 + 60 * X[:, 1])).max() > 0.5              # the convection bends the profile
