@@ -1186,12 +1186,15 @@ __device__ __forceinline__ void p2tri_basis_grads(const tri_geom& t, const doubl
 #pragma unroll
         for (int d = 0; d < 2; ++d) gp[3 + e][d] = 4.0 * (lam[ei[e]] * t.g[ej[e]][d] + lam[ej[e]] * t.g[ei[e]][d]);
 }
+// degree-3 rule on the triangle (Strang-Fix 4 points, one negative weight) for the cubic advection integrand
+__device__ __constant__ double FS_TRI4_QP[4][3] = {{1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0}, {0.6, 0.2, 0.2}, {0.2, 0.6, 0.2}, {0.2, 0.2, 0.6}};
+__device__ __constant__ double FS_TRI4_QW[4] = {-0.5625, 25.0 / 48.0, 25.0 / 48.0, 25.0 / 48.0};
 template <bool ADD>
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val) {
+    coef_dev kc, coef_dev mc, double* __restrict__ val, coef_dev ac = coef_dev(), double ascale = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -1235,6 +1238,27 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
                 const double mm = (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) * t.area * (1.0 / 180.0);
 #pragma unroll
                 for (int b = 0; b < 6; ++b) row[b] += mm * FS_P2_TRI_UFC_MASS180[a][b];
+            }
+            if (ac.mode != FS_COEF_NONE) {      // + scale int phi_a (v . grad phi_b) dx, constant or per-cell velocity
+                double vx, vy;
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; }
+                for (int qp = 0; qp < 4; ++qp) {
+                    const double lam[3] = {FS_TRI4_QP[qp][0], FS_TRI4_QP[qp][1], FS_TRI4_QP[qp][2]};
+                    double gp[6][2];
+                    p2tri_basis_grads(t, lam, gp);
+                    const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
+                    double pa = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        if (b == a) pa = lam[b] * (2.0 * lam[b] - 1.0);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (3 + e == a) pa = 4.0 * lam[ei[e]] * lam[ej[e]];
+                    const double w = ascale * FS_TRI4_QW[qp] * t.area * pa;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1]);
+                }
             }
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
@@ -2085,7 +2109,11 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
             hipLaunchKernelGGL(k_assemble_tri_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
     } else if (m->tdim == 2 && sp->degree == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: CG2 space on triangles without assembly tables");
-        FS_REQUIRE(form->advection.mode == FS_COEF_NONE && !(form->supg_pe > 0.0), "fs_assemble_matrix: advection is not built for CG2");
+        dbuf<double> astore4;
+        coef_dev ac4;
+        FS_CHECK(make_coef(form->advection, 3 * m->nc, astore4, &ac4, "fs_assemble_matrix(advection)"));
+        FS_REQUIRE((ac4.mode == FS_COEF_NONE || ac4.mode == FS_COEF_CONST || ac4.mode == FS_COEF_CELL) && !(form->supg_pe > 0.0),
+                   "fs_assemble_matrix: CG2 advection takes a constant or per-cell velocity, without SUPG");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
                    "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
@@ -2095,9 +2123,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (add)
-            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale);
         else
-            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale);
     } else if (m->tdim == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));

@@ -1365,6 +1365,22 @@ _TRI_Q4 = (np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965], 
            np.array([0.223381589678011] * 3 + [0.109951743655322] * 3))
 
 
+def tri_p2_advection_local(coords, cells, velocity, scale=1.0):
+    """Ce[a,b] = scale * int phi_a (v . grad phi_b) dx for the P2 basis on triangles (constant or per-cell velocity), with the
+    degree-4 rule _TRI_Q4 (the device uses the 4-point degree-3 rule)."""
+    area, g = tri_geometry(coords, cells)
+    v = np.asarray(velocity, dtype=np.float64)[..., :2]
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(area), 2))
+    pts, wq = _TRI_Q4
+    Ce = np.zeros((len(area), 6, 6))
+    for lam, w in zip(pts, wq):
+        phi, dphi = tri_p2_shape(np.asarray(lam))
+        gphi = np.einsum("ak,cki->cai", dphi, g)
+        Ce += (scale * w * area)[:, None, None] * np.einsum("a,cb->cab", phi, np.einsum("ci,cbi->cb", v, gphi))
+    return Ce
+
+
 def tri_p2_stiffness_local(coords, cells, k=1.0):
     """Ke[a,b] = k int grad phi_a . grad phi_b dx; quadratic integrand, the degree-4 rule is exact."""
     area, g = tri_geometry(coords, cells)                       # g [nc,3,2] = grad lambda

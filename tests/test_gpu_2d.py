@@ -356,6 +356,11 @@ def test_p2_triangle_kernels_match_oracle(gpu):
     A.assemble(stiffness=1.0)
     K = fo.assemble_generic(n, cd, fo.tri_p2_stiffness_local(co, ce, 1.0))
     assert abs(_csr(A) - K).max() <= 1e-12 * abs(K).max() and np.abs(K @ np.ones(n)).max() <= 1e-11
+    # advection (fe_degree 2 with a convective velocity): constant and per-cell velocities
+    for vel in (np.array([0.4, -0.7, 0.0]), np.concatenate([rng.uniform(-1, 1, (len(ce), 2)), np.zeros((len(ce), 1))], axis=1)):
+        A.assemble(stiffness=0.3, advection=vel, advection_scale=1.7)
+        refa = fo.assemble_generic(n, cd, fo.tri_p2_stiffness_local(co, ce, 0.3) + fo.tri_p2_advection_local(co, ce, vel, 1.7))
+        assert abs(_csr(A) - refa).max() <= 1e-12 * abs(refa).max()
     # sources
     b = gpu.DeviceVector(n)
     gpu.assemble_vector(V, b, source=3.0)
