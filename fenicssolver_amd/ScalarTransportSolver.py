@@ -347,8 +347,8 @@ class ScalarTransportSolver(SolverBase):
             F.conductivity_fn = kraw
         if self.nonlinear_material and F.conductivity_fn is None:
             raise SolverError('only the conductivity may depend on the temperature on the GPU back end')
-        if (self.nonlinear_material or self.nonlinear) and self.function_space.degree() != 1:
-            raise SolverError('nonlinear problems are built for P1 spaces only')
+        if self.nonlinear_material and self.function_space.degree() != 1:
+            raise SolverError('a temperature-dependent conductivity is built for P1 spaces only')
         if self.transient_settings['transient']:
             F.transient = True
             F.dt = float(self.get_time_step(time_iter_))
@@ -378,8 +378,6 @@ class ScalarTransportSolver(SolverBase):
         self.has_radiation = self.scalar_name == "temperature" and bool(rs)
         if self.has_radiation:
             self.radiation_settings = rs
-            if self.function_space.degree() != 1:
-                raise SolverError('radiation is built for P1 spaces only')
             self.nonlinear = True
             F.radiation = self.radiation_coefficients()
         if self.nonlinear_material:

@@ -668,10 +668,19 @@ class SolverBase():
                 # residual: int m (T_amb^4 - T_h^4) q ds with T_h the P1 iterate, integrated exactly (degree 5) as FFC does
                 # for m*(pow(T, 4) - pow(T_amb, 4))*Tq*ds (ScalarTransportSolver.py:186-190); the Jacobian below keeps the
                 # facet-mean linearisation - it only steers the iteration
-                loads = _radiation_loads(self.mesh.coordinates(), ext.astype(np.int64), T, m_, T_amb)[ext_mask]
-                rows = np.asarray(ext_dev, dtype=np.int64)
-                own_rows = rows < n
-                b.add_entries(rows[own_rows], loads[own_rows])
+                if F.space.degree() == 2:
+                    if loc is not None:
+                        raise SolverError('radiation on P2 spaces is built for one GPU')
+                    ftab = F.space.facet_node_table(ext.astype(np.int64))
+                    loads = _radiation_loads_p2(self.mesh.coordinates(), ext.astype(np.int64), ftab, T, m_, T_amb)
+                    b.add_entries(ftab, loads)
+                    en = T[ftab[:, ext.shape[1]:]]                          # edge-node values: the facet mean of a P2 field
+                    Tf = en.mean(axis=1) if ext.shape[1] == 3 else (T[ftab[:, 0]] + 4.0 * en[:, 0] + T[ftab[:, 1]]) / 6.0
+                else:
+                    loads = _radiation_loads(self.mesh.coordinates(), ext.astype(np.int64), T, m_, T_amb)[ext_mask]
+                    rows = np.asarray(ext_dev, dtype=np.int64)
+                    own_rows = rows < n
+                    b.add_entries(rows[own_rows], loads[own_rows])
             Tdev = backend.DeviceVector(V.n_local, T if loc is None else loc.nodes(T))
             r = backend.DeviceVector(n)
             A.spmv(Tdev, r)
@@ -1055,6 +1064,37 @@ def _facet_nodal_loads(coords, facets, g):
     else:
         measure = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
     return (measure / (d * (d + 1.0)))[:, None] * (g.sum(axis=1, keepdims=True) + g)
+
+
+def _p2_facet_shape(pts):
+    """[nq, n] values of the P2 facet basis (vertices, then edges (0,1), (0,2), (1,2) - or the one mid-point) at barycentric pts."""
+    d = pts.shape[1]
+    cols = [pts[:, i] * (2.0 * pts[:, i] - 1.0) for i in range(d)]
+    for a, b in (((0, 1), (0, 2), (1, 2)) if d == 3 else ((0, 1),)):
+        cols.append(4.0 * pts[:, a] * pts[:, b])
+    return np.stack(cols, axis=1)
+
+
+def _radiation_loads_p2(coords, facets, node_table, T, m, T_amb):
+    """[n_facets, n] loads int_F m (T_amb^4 - T_h^4) phi_a ds of a P2 field on boundary triangles / edges: degree-10
+    integrand (FFC: 4 * 2 + 2), integrated with Gauss-Legendre points (collapsed onto the triangle)."""
+    X = coords[facets]
+    g, w = np.polynomial.legendre.leggauss(6)
+    g, w = 0.5 * (g + 1.0), 0.5 * w
+    if facets.shape[1] == 3:
+        e1, e2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        measure = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+        # Duffy: (u, v) in the unit square -> lambda = (1 - u, u (1 - v), u v), weight u (times 2 for the unit-area normalisation)
+        U, Vv = np.meshgrid(g, g, indexing="ij")
+        WW = np.outer(w, w) * U * 2.0
+        pts = np.stack([1.0 - U.ravel(), (U * (1.0 - Vv)).ravel(), (U * Vv).ravel()], axis=1)
+        wq = WW.ravel()
+    else:
+        measure = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+        pts, wq = np.stack([1.0 - g, g], axis=1), w
+    phi = _p2_facet_shape(pts)                               # [nq, n]
+    Tq = T[node_table] @ phi.T                               # [nf, nq]
+    return measure[:, None] * ((m * (T_amb ** 4 - Tq ** 4) * wq[None, :]) @ phi)
 
 
 def _radiation_loads(coords, facets, T, m, T_amb):

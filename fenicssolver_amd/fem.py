@@ -794,6 +794,23 @@ class FunctionSpace:
         cache[key] = out
         return out
 
+    def facet_node_table(self, facet_vertices):
+        """[n_facets, n] nodes of every facet in a fixed local order: its vertices, then (P2) the nodes of its edges
+        (0,1), (0,2), (1,2) - or the one edge node of a boundary edge in 2-D."""
+        f = np.asarray(facet_vertices, dtype=np.int64)
+        if self._degree == 1:
+            return f
+        nv = self._mesh.num_vertices()
+        ed = self.edge_nodes().astype(np.int64)
+        ekey = ed[:, 0] * nv + ed[:, 1]
+        sorter = np.argsort(ekey)
+        pairs = ((0, 1), (0, 2), (1, 2)) if f.shape[1] == 3 else ((0, 1),)
+        cols = []
+        for a, b in pairs:
+            lo, hi = np.minimum(f[:, a], f[:, b]), np.maximum(f[:, a], f[:, b])
+            cols.append(nv + sorter[np.searchsorted(ekey[sorter], lo * nv + hi)])
+        return np.concatenate([f, np.stack(cols, axis=1)], axis=1)
+
     def _facet_nodes_p2(self, f, verts):
         mesh = self._mesh
         nv = mesh.num_vertices()
