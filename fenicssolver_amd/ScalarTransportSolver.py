@@ -31,6 +31,23 @@ VACUUM_PERMITTIVITY = 8.854187817e-12
 electric_permittivity_in_vacumm = VACUUM_PERMITTIVITY      # the reference's (misspelt) module-level name, kept for importers
 
 
+_A1, _B1, _A2, _B2, _A3, _B3 = 0.0673422422100982, 0.3108859192633006, 0.7217942490673264, 0.0927352503108912, \
+    0.0455037041256496, 0.4544962958743504
+# the 14 points of the degree-5 rule on the tetrahedron, in the order of the device table FS_TET14_QP
+_TET14_POINTS = np.array([[_A1, _B1, _B1, _B1], [_B1, _A1, _B1, _B1], [_B1, _B1, _A1, _B1], [_B1, _B1, _B1, _A1],
+                          [_A2, _B2, _B2, _B2], [_B2, _A2, _B2, _B2], [_B2, _B2, _A2, _B2], [_B2, _B2, _B2, _A2],
+                          [_A3, _A3, _B3, _B3], [_A3, _B3, _A3, _B3], [_A3, _B3, _B3, _A3], [_B3, _A3, _A3, _B3],
+                          [_B3, _A3, _B3, _A3], [_B3, _B3, _A3, _A3]])
+
+
+def _p2_shape_at(pts):
+    """[nq, 10] P2 basis on the tetrahedron at barycentric points: vertices, then the UFC edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1)."""
+    cols = [pts[:, i] * (2.0 * pts[:, i] - 1.0) for i in range(4)]
+    for i, j in ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)):
+        cols.append(4.0 * pts[:, i] * pts[:, j])
+    return np.stack(cols, axis=1)
+
+
 class ScalarTransportSolver(SolverBase):
     """general scalar transportation (diffusion) solver, exampled by heat transfer"""
 
@@ -347,8 +364,8 @@ class ScalarTransportSolver(SolverBase):
             F.conductivity_fn = kraw
         if self.nonlinear_material and F.conductivity_fn is None:
             raise SolverError('only the conductivity may depend on the temperature on the GPU back end')
-        if self.nonlinear_material and self.function_space.degree() != 1:
-            raise SolverError('a temperature-dependent conductivity is built for P1 spaces only')
+        if self.nonlinear_material and self.function_space.degree() != 1 and self.dimension != 3:
+            raise SolverError('a temperature-dependent conductivity on P2 spaces is built for tetrahedral meshes')
         if self.transient_settings['transient']:
             F.transient = True
             F.dt = float(self.get_time_step(time_iter_))
@@ -403,6 +420,13 @@ class ScalarTransportSolver(SolverBase):
 
     def refresh_nonlinear_form(self, F, T):
         """Re-evaluate the temperature-dependent coefficients of F at the Newton iterate T."""
+        if F.conductivity_fn is not None and self.function_space.degree() == 2:
+            # P2 iterate: k(T_h) at the 14 points of the degree-5 rule, where the integrand k grad T . grad q is evaluated
+            # (exact for a conductivity that is linear in T, e.g. examples/test_heat_transfer.py:53)
+            Tc = T.vector()._values()[self.function_space.cell_nodes().astype(np.int64)]          # [nc,10]
+            Tq = Tc @ _p2_shape_at(_TET14_POINTS).T                                                # [nc,14]
+            F.conductivity = forms.VolumeCoefficient("cell_qp", np.asarray(F.conductivity_fn(Tq), dtype=np.float64) * np.ones_like(Tq))
+            return
         if F.conductivity_fn is not None:
             Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)
             F.conductivity = forms.VolumeCoefficient(

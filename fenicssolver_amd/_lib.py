@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsamd.so")
 
 FS_OK = 0
-FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL, FS_COEF_CELL_ROW, FS_COEF_CELL_TENSOR = 0, 1, 2, 3, 4, 5, 6
+FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL, FS_COEF_CELL_ROW, FS_COEF_CELL_TENSOR, FS_COEF_CELL_QP = 0, 1, 2, 3, 4, 5, 6, 7
 FS_KSP_CG = 0
 FS_KSP_BICGSTAB = 1
 FS_PC_NONE, FS_PC_JACOBI = 0, 1

@@ -227,6 +227,11 @@ def _coef(spec, keep):
             t = L.f64(arr).reshape(9)
             for i in range(9):
                 c.tensor[i] = t[i]
+        elif kind == "cell_qp":              # [n_cells, 14]: the coefficient at the points of the degree-5 rule (CG2 spaces)
+            a = L.f64(np.ascontiguousarray(arr).reshape(-1, 14))
+            keep.append(a)
+            c.mode = L.FS_COEF_CELL_QP
+            c.data = L.p_f64(a)
         elif kind == "cell_tensor":          # [n_cells, 3, 3]
             a = L.f64(np.ascontiguousarray(arr).reshape(-1, 9))
             keep.append(a)

@@ -363,6 +363,27 @@ __device__ __constant__ double FS_TET5_QP[5][4] = {{0.25, 0.25, 0.25, 0.25},
                                                    {1.0 / 6.0, 1.0 / 6.0, 0.5, 1.0 / 6.0}, {1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 0.5}};
 __device__ __constant__ double FS_TET5_QW[5] = {-0.8, 0.45, 0.45, 0.45, 0.45};
 
+// the 14-point degree-5 rule (the one the Taylor-Hood element uses): for a coefficient given at its points (FS_COEF_CELL_QP)
+__device__ __constant__ double FS_TET14_QP[14][4] = {
+    {0.0673422422100982, 0.3108859192633006, 0.3108859192633006, 0.3108859192633006},
+    {0.3108859192633006, 0.0673422422100982, 0.3108859192633006, 0.3108859192633006},
+    {0.3108859192633006, 0.3108859192633006, 0.0673422422100982, 0.3108859192633006},
+    {0.3108859192633006, 0.3108859192633006, 0.3108859192633006, 0.0673422422100982},
+    {0.7217942490673264, 0.0927352503108912, 0.0927352503108912, 0.0927352503108912},
+    {0.0927352503108912, 0.7217942490673264, 0.0927352503108912, 0.0927352503108912},
+    {0.0927352503108912, 0.0927352503108912, 0.7217942490673264, 0.0927352503108912},
+    {0.0927352503108912, 0.0927352503108912, 0.0927352503108912, 0.7217942490673264},
+    {0.0455037041256496, 0.0455037041256496, 0.4544962958743504, 0.4544962958743504},
+    {0.0455037041256496, 0.4544962958743504, 0.0455037041256496, 0.4544962958743504},
+    {0.0455037041256496, 0.4544962958743504, 0.4544962958743504, 0.0455037041256496},
+    {0.4544962958743504, 0.0455037041256496, 0.0455037041256496, 0.4544962958743504},
+    {0.4544962958743504, 0.0455037041256496, 0.4544962958743504, 0.0455037041256496},
+    {0.4544962958743504, 0.4544962958743504, 0.0455037041256496, 0.0455037041256496}};
+__device__ __constant__ double FS_TET14_QW[14] = {
+    0.1126879257180159, 0.1126879257180159, 0.1126879257180159, 0.1126879257180159,
+    0.0734930431163620, 0.0734930431163620, 0.0734930431163620, 0.0734930431163620,
+    0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815, 0.0425460207770815};
+
 // ADV: + scale * int phi_a (v . grad phi_b) dx with a constant or per-cell velocity (inner(velocity, grad(T))*Tq*capacity*dx,
 // ScalarTransportSolver.py:305-311, with fe_degree 2); a separate instantiation, the symmetric kernel keeps its registers
 template <bool ADD, bool ADV = false>
@@ -431,7 +452,20 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
             double row[10];
 #pragma unroll
             for (int b = 0; b < 10; ++b) row[b] = 0.0;
-            if (kc.mode != FS_COEF_NONE) {
+            if (ADV && kc.mode == FS_COEF_CELL_QP) {      // (the non-symmetric instantiation also carries the rarely used modes)
+                for (int qp = 0; qp < 14; ++qp) {
+                    const double lam[4] = {FS_TET14_QP[qp][0], FS_TET14_QP[qp][1], FS_TET14_QP[qp][2], FS_TET14_QP[qp][3]};
+                    double gp[10][3];
+                    p2_basis_grads(t, lam, gp);
+                    double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int b = 0; b < 10; ++b)
+                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; ga[2] = gp[b][2]; }
+                    const double w = FS_TET14_QW[qp] * vol * kc.data[14 * (int64_t)c + qp];
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] += w * (ga[0] * gp[b][0] + ga[1] * gp[b][1] + ga[2] * gp[b][2]);
+                }
+            } else if (kc.mode != FS_COEF_NONE) {
                 double kk = kc.mode == FS_COEF_CONST ? kc.value : kc.data[c];
 #pragma unroll
                 for (int qp = 0; qp < 4; ++qp) {
@@ -1991,7 +2025,9 @@ static int make_coef(const fs_coef& in, int64_t expect_len, dbuf<double>& store,
     out->data = nullptr;
     for (int i = 0; i < 9; ++i) out->tensor[i] = in.tensor[i];
     if (in.mode == FS_COEF_CELL_TENSOR) expect_len *= 9;
-    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL || in.mode == FS_COEF_CELL_ROW || in.mode == FS_COEF_CELL_TENSOR) {
+    if (in.mode == FS_COEF_CELL_QP) expect_len *= 14;
+    if (in.mode == FS_COEF_CELL || in.mode == FS_COEF_NODAL || in.mode == FS_COEF_CELL_ROW || in.mode == FS_COEF_CELL_TENSOR ||
+        in.mode == FS_COEF_CELL_QP) {
         FS_REQUIRE(in.data, "%s: coefficient data pointer is null", what);
         FS_CHECK(store.alloc(expect_len));
         FS_CHECK(store.upload(in.data, expect_len, fs_rt().stream));
@@ -2148,8 +2184,8 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
     } else if (A->bs == 1 && sp->degree == 2) {
         FS_REQUIRE(sp->inc_cell.p, "fs_assemble_matrix: CG2 space has no assembly tables");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
-        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
-                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
+        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL || kc.mode == FS_COEF_CELL_QP,
+                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant, per cell or per quadrature point");
         dbuf<double> astore3;
         coef_dev ac3;
         FS_CHECK(make_coef(form->advection, 3 * m->nc, astore3, &ac3, "fs_assemble_matrix(advection)"));
@@ -2160,7 +2196,7 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
-        if (ac3.mode != FS_COEF_NONE) {
+        if (ac3.mode != FS_COEF_NONE || kc.mode == FS_COEF_CELL_QP) {
             if (add)
                 hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, ac3, form->advection_scale);
             else

@@ -214,7 +214,7 @@ class Localizer:
         """backend coefficient spec (None | number | (kind, array)) -> local."""
         if isinstance(spec, tuple):
             kind, arr = spec
-            if kind in ("cell", "cell_tensor"):
+            if kind in ("cell", "cell_tensor", "cell_qp"):
                 return (kind, self.cells(arr))
             if kind == "nodal":
                 return (kind, self.nodes(arr))

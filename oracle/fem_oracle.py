@@ -670,6 +670,21 @@ def p2_advection_local(coords, cells, velocity, scale=1.0):
     return Ce
 
 
+def p2_stiffness_local_qp(coords, cells, k_of_point):
+    """Ke[a,b] = int k(x) grad phi_a . grad phi_b dx with k given by a function of the barycentric point -> [nc] values
+    (a conductivity depending on the P2 temperature iterate, evaluated at the quadrature points): 14-point degree-5 rule."""
+    from oracle import ns_oracle as nso
+    detJ, g = p1_geometry(coords, cells)
+    vol = np.abs(detJ) / 6.0
+    pts, wq = nso.tet_quadrature(5)
+    Ke = np.zeros((len(vol), 10, 10))
+    for lam, w in zip(pts, wq):
+        _, dphi = nso.p2_shape(lam)
+        gphi = np.einsum("ak,cki->cai", dphi, g)
+        Ke += (w * vol * k_of_point(np.asarray(lam)))[:, None, None] * np.einsum("cai,cbi->cab", gphi, gphi)
+    return Ke
+
+
 def p2_stiffness_local(coords, cells, k=1.0):
     detJ, g = p1_geometry(coords, cells)
     vol = np.abs(detJ) / 6.0

@@ -315,3 +315,51 @@ def test_p2_radiation_newton(gpu):
     assert it < 199
     assert np.abs(T - Tn).max() <= 1e-6
     assert np.abs(T - (300 + 60 * X[:, 1])).max() > 1e-3
+
+
+def test_p2_temperature_dependent_conductivity(gpu):
+    """material['conductivity'] = lambda T: ... with fe_degree 2 (the nonlinear variant of examples/test_heat_transfer.py:50-54):
+    k(T_h) evaluated at the quadrature points of the stiffness integrand (FS_COEF_CELL_QP); Newton (Picard Jacobian) on the
+    device against the same fixed-point iteration written with the oracle."""
+    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    from oracle import ns_oracle as nso
+    m = UnitCubeMesh(3, 3, 2)
+    Q = FunctionSpace(m, "CG", 2)
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1.0)), 'boundary_id': 1, 'type': 'Dirichlet', 'value': Constant(360)}
+    bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 2, 'type': 'Dirichlet', 'value': Constant(300)}
+    st = {'solver_name': 'x', 'mesh': None, 'function_space': Q, 'periodic_boundary': None, 'boundary_conditions': bcs,
+          'body_source': 40.0, 'initial_values': {'temperature': 300},
+          'material': {'density': 1000, 'specific_heat_capacity': 4200, 'thermal_conductivity': 0.6},
+          'solver_settings': {'transient_settings': {'transient': False, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 1},
+                              'reference_values': {'temperature': 300},
+                              'solver_parameters': {'krylov_relative_tolerance': 1e-13, 'maximum_iterations': 20000}},
+          'report_settings': {"logging_level": 40, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}, 'scalar_name': 'temperature'}
+    kfun = lambda T: 0.6 * (1.0 + 0.01 * (T - 300.0))                      # noqa: E731  (linear in T: the integrand is a quartic)
+    solver = ScalarTransportSolver(st)
+    solver.material['conductivity'] = kfun
+    T = solver.solve().vector().array()
+    assert solver.nonlinear and 2 <= solver.newton_iterations <= 40
+    co, ce = m.coordinates(), m.cells()
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    n = len(co) + len(edges)
+    X = Q.node_coordinates()
+    b = fo.assemble_generic_vector(n, cd, fo.p2_source_local(co, ce, 40.0))
+    top, bot = np.nonzero(X[:, 1] == 1.0)[0], np.nonzero(X[:, 1] == 0.0)[0]
+    dofs = np.concatenate([top, bot])
+    vals = np.concatenate([np.full(len(top), 360.0), np.full(len(bot), 300.0)])
+    Tn = np.full(n, 300.0)
+    Tn[dofs] = vals
+    for it in range(100):
+        Tc = Tn[cd.astype(np.int64)]
+        K = fo.assemble_generic(n, cd, fo.p2_stiffness_local_qp(co, ce, lambda lam: kfun(Tc @ nso.p2_shape(lam)[0]))).tocsr()
+        r = K @ Tn - b
+        r[dofs] = 0.0
+        if np.linalg.norm(r) < 1e-9:
+            break
+        Tn = Tn + fo.solve_direct(*fo.apply_dirichlet(K, -r, dofs, 0.0, True))
+    assert it < 99
+    assert np.abs(T - Tn).max() <= 1e-6
+    lin = fo.solve_direct(*fo.apply_dirichlet(fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.6)).tocsr(), b, dofs, vals, True))
+    assert np.abs(T - lin).max() > 0.1                                     # the nonlinearity matters
