@@ -40,6 +40,11 @@ _TET14_POINTS = np.array([[_A1, _B1, _B1, _B1], [_B1, _A1, _B1, _B1], [_B1, _B1,
                           [_B3, _A3, _B3, _A3], [_B3, _B3, _A3, _A3]])
 
 
+_TRI6_POINTS = np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965], [0.445948490915965, 0.108103018168070, 0.445948490915965],
+                         [0.445948490915965, 0.445948490915965, 0.108103018168070], [0.816847572980459, 0.091576213509771, 0.091576213509771],
+                         [0.091576213509771, 0.816847572980459, 0.091576213509771], [0.091576213509771, 0.091576213509771, 0.816847572980459]])
+
+
 def _p2_shape_at(pts):
     """[nq, 10] P2 basis on the tetrahedron at barycentric points: vertices, then the UFC edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1)."""
     cols = [pts[:, i] * (2.0 * pts[:, i] - 1.0) for i in range(4)]
@@ -364,8 +369,7 @@ class ScalarTransportSolver(SolverBase):
             F.conductivity_fn = kraw
         if self.nonlinear_material and F.conductivity_fn is None:
             raise SolverError('only the conductivity may depend on the temperature on the GPU back end')
-        if self.nonlinear_material and self.function_space.degree() != 1 and self.dimension != 3:
-            raise SolverError('a temperature-dependent conductivity on P2 spaces is built for tetrahedral meshes')
+
         if self.transient_settings['transient']:
             F.transient = True
             F.dt = float(self.get_time_step(time_iter_))
@@ -423,9 +427,18 @@ class ScalarTransportSolver(SolverBase):
         if F.conductivity_fn is not None and self.function_space.degree() == 2:
             # P2 iterate: k(T_h) at the 14 points of the degree-5 rule, where the integrand k grad T . grad q is evaluated
             # (exact for a conductivity that is linear in T, e.g. examples/test_heat_transfer.py:53)
-            Tc = T.vector()._values()[self.function_space.cell_nodes().astype(np.int64)]          # [nc,10]
-            Tq = Tc @ _p2_shape_at(_TET14_POINTS).T                                                # [nc,14]
-            F.conductivity = forms.VolumeCoefficient("cell_qp", np.asarray(F.conductivity_fn(Tq), dtype=np.float64) * np.ones_like(Tq))
+            Tc = T.vector()._values()[self.function_space.cell_nodes().astype(np.int64)]          # [nc,10] or [nc,6]
+            if self.dimension == 3:
+                Tq = Tc @ _p2_shape_at(_TET14_POINTS).T                                            # [nc,14]
+                kq = np.asarray(F.conductivity_fn(Tq), dtype=np.float64) * np.ones_like(Tq)
+            else:       # triangles: the 6 points of the degree-4 rule, padded to the 14 columns of the device layout
+                p = _TRI6_POINTS
+                shape = np.stack([p[:, i] * (2.0 * p[:, i] - 1.0) for i in range(3)] +
+                                 [4.0 * p[:, i] * p[:, j] for i, j in ((1, 2), (0, 2), (0, 1))], axis=1)       # UFC edges of a triangle
+                Tq = Tc @ shape.T
+                kq = np.zeros((len(Tc), 14))
+                kq[:, :6] = np.asarray(F.conductivity_fn(Tq), dtype=np.float64) * np.ones_like(Tq)
+            F.conductivity = forms.VolumeCoefficient("cell_qp", kq)
             return
         if F.conductivity_fn is not None:
             Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)

@@ -1250,7 +1250,24 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
             const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
             const tri_geom t = tri_geometry2(xyz4, c4.x, c4.y, c4.z);
             double row[6] = {0, 0, 0, 0, 0, 0};
-            if (kc.mode != FS_COEF_NONE) {
+            if (kc.mode == FS_COEF_CELL_QP) {      // k at the 6 points of the degree-4 rule (data[c][14], the first 6 used)
+                const double TQ[6][3] = {{0.108103018168070, 0.445948490915965, 0.445948490915965}, {0.445948490915965, 0.108103018168070, 0.445948490915965},
+                                         {0.445948490915965, 0.445948490915965, 0.108103018168070}, {0.816847572980459, 0.091576213509771, 0.091576213509771},
+                                         {0.091576213509771, 0.816847572980459, 0.091576213509771}, {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+                const double TW[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011, 0.109951743655322, 0.109951743655322, 0.109951743655322};
+                for (int qp = 0; qp < 6; ++qp) {
+                    const double lam[3] = {TQ[qp][0], TQ[qp][1], TQ[qp][2]};
+                    double gp[6][2];
+                    p2tri_basis_grads(t, lam, gp);
+                    double ga[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; }
+                    const double w = TW[qp] * t.area * kc.data[14 * (int64_t)c + qp];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) row[b] += w * (ga[0] * gp[b][0] + ga[1] * gp[b][1]);
+                }
+            } else if (kc.mode != FS_COEF_NONE) {
                 const double kk = kc.mode == FS_COEF_CONST ? kc.value : kc.data[c];
 #pragma unroll
                 for (int qp = 0; qp < 3; ++qp) {
@@ -2151,8 +2168,8 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE((ac4.mode == FS_COEF_NONE || ac4.mode == FS_COEF_CONST || ac4.mode == FS_COEF_CELL) && !(form->supg_pe > 0.0),
                    "fs_assemble_matrix: CG2 advection takes a constant or per-cell velocity, without SUPG");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
-        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL,
-                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant or per cell");
+        FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL || kc.mode == FS_COEF_CELL_QP,
+                   "fs_assemble_matrix: CG2 stiffness coefficient must be constant, per cell or per quadrature point");
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);

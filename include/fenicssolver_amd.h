@@ -181,9 +181,9 @@ int fs_matrix_destroy(fs_matrix_t A);
 #define FS_COEF_NODAL 4 /* linear forms only: P1-interpolated coefficient */
 #define FS_COEF_CELL_TENSOR 6 /* stiffness only: data[n_cells][9], one row-major 3x3 tensor per cell (2-D: leading 2x2 block) -
                                * an Expression of degree 0 with a tensor value, examples/test_heat_transfer.py:90 */
-#define FS_COEF_CELL_QP 7 /* stiffness on CG2 tetrahedral spaces only: data[n_cells][14], the coefficient at the 14 points of the
-                           * degree-5 rule (a conductivity that depends on the P2 temperature iterate, evaluated where the
-                           * integrand is) */
+#define FS_COEF_CELL_QP 7 /* stiffness on CG2 spaces only: data[n_cells][14], the coefficient at the 14 points of the degree-5 rule on
+                           * tetrahedra / at the 6 points of the degree-4 rule on triangles (entries 0..5; the rest unused): a
+                           * conductivity that depends on the P2 temperature iterate, evaluated where the integrand is */
 #define FS_COEF_CELL_ROW 5 /* advection velocity only: data[n_cells][d+1][3], V_a = (d+1)/|K| int_K u phi_a dx per cell and test
                             * function - integrates inner(u, grad T) q dx exactly for a finite-element velocity u */
 
