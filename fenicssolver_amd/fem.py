@@ -872,9 +872,9 @@ class FunctionSpace:
         """This rank's share of the space: owner-computes vertex slabs along the longest axis,
         one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
         from . import partition
-        if root._degree == 2 and root._ncomp not in (1, 4):
-            raise SolverError("multi-GPU decomposition is built for P1 spaces, scalar P2 spaces and the Taylor-Hood space; "
-                              "vector P2 runs on one GPU")
+        if root._degree == 2 and (root._ncomp not in (1, 3, 4) or mesh_dim(root) != 3):
+            raise SolverError("multi-GPU decomposition is built for P1 spaces and, on tetrahedra, scalar / vector P2 spaces and the "
+                              "Taylor-Hood space")
         rank, size = parallel.ensure_comm()
         mesh = root._mesh
         if getattr(mesh, "_slab", None) is not None:
@@ -920,6 +920,10 @@ class FunctionSpace:
     def localizer(self):
         """None on one GPU; the global->local mapper of this rank's part otherwise (after device())."""
         return getattr(self.root(), "_localizer", None)
+
+
+def mesh_dim(space):
+    return space._mesh.geometry().dim()
 
 
 def VectorFunctionSpace(mesh, family="CG", degree=1, dim=None, constrained_domain=None):

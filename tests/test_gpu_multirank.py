@@ -97,6 +97,16 @@ def test_amg_pcg_under_two_ranks_is_an_additive_schwarz_solve(gpu, tmp_path):
     assert int(r["iterations"]) < 200
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_vector_p2_elasticity_under_several_ranks(gpu, tmp_path, world):
+    """The reference's elasticity example space (vector P2) decomposed: block-3 matrix on the decomposed CG2 nodes, indexed halo
+    of vertex and edge nodes, additive-Schwarz AMG-CG; same displacement field as one GPU."""
+    import test_gpu_parallel_api as T
+    single = T.CASES["elasticity_p2"]().solve().vector().get_local()
+    r = _run(world, "elasticity_p2", tmp_path)
+    assert np.abs(r["x"] - single).max() <= 1e-7 * np.abs(single).max()
+
+
 def test_bench_under_the_drivers_launcher(gpu, tmp_path):
     """bench.py exactly as the driver starts it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py
     --gpus N): env rendezvous of the RCCL id through fenicssolver_amd/rendezvous.py (no torch import in bench.py), barrier

@@ -59,7 +59,12 @@ def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False):
     return solver
 
 
-def _elastic_case(distributed=False):
+def _elastic_p2_case():
+    solver = _elastic_case(degree=2)
+    return solver
+
+
+def _elastic_case(distributed=False, degree=1):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
@@ -79,7 +84,7 @@ def _elastic_case(distributed=False):
     s = copy.deepcopy(SB.default_case_settings)
     s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
                      'thermal_expansion_coefficient': 2e-6}
-    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", 1)
+    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", degree)
     s['boundary_conditions'] = bcs
     s['solver_settings']['reference_values'] = {'temperature': 293}
     s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
@@ -173,7 +178,7 @@ DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist":
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          "heat_supg": lambda: _heat_case(supg=True),
-         "heat_p2": _heat_p2_case}
+         "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
 
 
 @pytest.mark.parametrize("case", sorted(CASES) + sorted(NS_CASES))
