@@ -87,12 +87,14 @@ class LinearElasticitySolver(SolverBase):
         from .fem import FunctionSpace
         from . import backend
         V = u.function_space()
-        if V.localizer() is not None:
-            raise SolverError('von_Mises: the projection is built for one GPU')
         P = FunctionSpace(self.mesh, 'P', 1)
         dV, dP = V.device(), P.device()
         mu, lmbda = self.lame_parameters()
-        ud = backend.DeviceVector(dV.n_local, u.vector()._values())
+        loc, ploc = V.localizer(), P.localizer()
+        uh = u.vector()._values()
+        if loc is not None and not getattr(loc, 'is_local_view', False):
+            uh = loc.nodes(uh)                       # replicated host field -> this rank's owned + ghost entries
+        ud = backend.DeviceVector(dV.n_local, uh)
         b = backend.DeviceVector(dP.n_owned)
         backend.assemble_von_mises(dV, ud, mu, lmbda, dP, b)
         M = backend.DeviceMatrix(dP)
@@ -102,7 +104,16 @@ class LinearElasticitySolver(SolverBase):
         if st['converged'] != 1:
             raise SolverError('von_Mises: the mass-matrix solve did not converge')
         f = Function(P)
-        f.vector().set_local(x.get()[:dP.n_owned])
+        if ploc is None:
+            f.vector().set_local(x.get()[:dP.n_owned])
+        elif getattr(ploc, 'is_local_view', False):
+            from . import parallel
+            if parallel.world()[1] > 1:
+                backend.halo_exchange(dP, x)
+            f.vector()._adopt_device(x)
+        else:
+            from . import parallel
+            f.vector().set_local(parallel.gather_owned(x.get()[:dP.n_owned], ploc.owned_gids(), ploc.n_global, 1))
         return f
 
     def thermal_stress_coefficient(self):

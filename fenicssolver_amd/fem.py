@@ -892,10 +892,15 @@ class FunctionSpace:
             root._localizer = parallel.LocalView(lay["n_owned"], lay["n_local"], mesh.num_cells(), lay["l2g"], lay["n_global"], nc_)
             return ds
         co, ce = mesh.coordinates(), mesh.cells()
-        axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
-        owner = partition.slab_owner(co, size, axis=axis)
-        part = partition.build_local_part(ce, owner, rank)
-        dm = backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g)
+        # one partition and ONE device mesh per host mesh: spaces on the same mesh share it (the stress projections assemble a
+        # load on the P1 space from a field of another space and need both on the same device mesh)
+        cache = mesh.__dict__.setdefault("_parallel_parts", {})
+        if (rank, size) not in cache:
+            axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
+            owner = partition.slab_owner(co, size, axis=axis)
+            part = partition.build_local_part(ce, owner, rank)
+            cache[(rank, size)] = (owner, part, backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g))
+        owner, part, dm = cache[(rank, size)]
         ds = backend.DeviceSpace(dm, root._ncomp, root._degree)
         if root._degree == 1:
             if size > 1:

@@ -53,8 +53,14 @@ else:
         full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
         if rank == 0:
             result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices())
-    elif rank == 0:
-        result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"])
+    else:
+        extra = {}
+        if case.startswith("elasticity") and hasattr(solver, "von_Mises"):
+            its = solver.last_solve_stats["iterations"]
+            extra["von_mises"] = solver.von_Mises(u).vector().get_local()       # the L2 projection on the decomposed P1 space
+            solver.last_solve_stats["iterations"] = its
+        if rank == 0:
+            result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"], **extra)
     parallel.barrier()
     parallel.finalize()
 

@@ -91,10 +91,13 @@ def test_amg_pcg_under_two_ranks_is_an_additive_schwarz_solve(gpu, tmp_path):
     """solve_amg on two ranks: CG on the distributed operator, preconditioned by the hierarchies of the rank-local
     diagonal blocks; same displacement field as the single-GPU AMG-PCG."""
     import test_gpu_parallel_api as T
-    single = T.CASES["elasticity"]().solve().vector().get_local()
+    one = T.CASES["elasticity"]()
+    single = one.solve().vector().get_local()
     r = _run(2, "elasticity", tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
     assert int(r["iterations"]) < 200
+    vm = one.von_Mises(one.w_current).vector().get_local()
+    assert np.abs(r["von_mises"] - vm).max() <= 1e-7 * np.abs(vm).max()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -102,9 +105,12 @@ def test_vector_p2_elasticity_under_several_ranks(gpu, tmp_path, world):
     """The reference's elasticity example space (vector P2) decomposed: block-3 matrix on the decomposed CG2 nodes, indexed halo
     of vertex and edge nodes, additive-Schwarz AMG-CG; same displacement field as one GPU."""
     import test_gpu_parallel_api as T
-    single = T.CASES["elasticity_p2"]().solve().vector().get_local()
+    one = T.CASES["elasticity_p2"]()
+    single = one.solve().vector().get_local()
     r = _run(world, "elasticity_p2", tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-7 * np.abs(single).max()
+    vm = one.von_Mises(one.w_current).vector().get_local()                       # the projection runs decomposed as well
+    assert np.abs(r["von_mises"] - vm).max() <= 1e-6 * np.abs(vm).max()
 
 
 def test_bench_under_the_drivers_launcher(gpu, tmp_path):
