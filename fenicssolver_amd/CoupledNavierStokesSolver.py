@@ -367,8 +367,6 @@ class CoupledNavierStokesSolver(SolverBase):
         from . import backend
         from .fem import FunctionSpace, TensorFunctionSpace
         W = up.function_space()
-        if W.localizer() is not None:
-            raise SolverError('viscous_stress: the projection is built for one GPU')
         if T_space is None:
             T_space = TensorFunctionSpace(self.mesh, 'CG', 1)
         elif T_space.degree() != 1 or T_space._ncomp != 9:
@@ -376,10 +374,12 @@ class CoupledNavierStokesSolver(SolverBase):
         P = W.pressure_space()
         dW, dP = W.device(), P.device()
         nv = self.mesh.num_vertices()
-        wd = backend.DeviceVector(dW.n_local, up.vector()._values())
+        loc, ploc = W.localizer(), P.localizer()      # several GPUs: this rank's rows of the nine mass-matrix solves, gathered at the end
+        wh = up.vector()._values()
+        wd = backend.DeviceVector(dW.n_local, wh if loc is None else loc.nodes(wh))
         b9 = backend.DeviceVector(9 * dP.n_owned)
         backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9, viscosity_law=self.viscosity_law())
-        rhs = b9.get().reshape(nv, 9)
+        rhs = b9.get().reshape(dP.n_owned, 9)
         M = backend.DeviceMatrix(dP)
         M.assemble(mass=1.0)
         b, x = backend.DeviceVector(dP.n_owned), backend.DeviceVector(dP.n_local)
@@ -392,7 +392,11 @@ class CoupledNavierStokesSolver(SolverBase):
             st = backend.krylov_solve(M, b, x, rtol=1e-12, max_iter=2000, precond="jacobi", norm="preconditioned")
             if st['converged'] != 1:
                 raise SolverError('viscous_stress: the mass-matrix solve did not converge')
-            out[:, k] = x.get()[:nv]
+            xo = x.get()[:dP.n_owned]
+            if ploc is not None:
+                from . import parallel
+                xo = parallel.gather_owned(xo, ploc.owned_gids(), ploc.n_global, 1)
+            out[:, k] = xo
         sigma = Function(T_space)
         sigma.vector().set_local(out.reshape(-1))
         return sigma

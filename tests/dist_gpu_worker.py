@@ -59,6 +59,10 @@ else:
             its = solver.last_solve_stats["iterations"]
             extra["von_mises"] = solver.von_Mises(u).vector().get_local()       # the L2 projection on the decomposed P1 space
             solver.last_solve_stats["iterations"] = its
+        if case == "channel":                                    # the fluid-stress projection on the decomposed pressure space
+            its = solver.last_solve_stats["iterations"]
+            extra["sigma"] = solver.viscous_stress(u).vector().get_local()
+            solver.last_solve_stats["iterations"] = its
         if rank == 0:
             result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"], **extra)
     parallel.barrier()

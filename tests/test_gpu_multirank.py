@@ -82,9 +82,13 @@ def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
     the replicated pressure space (every rank applies the V-cycle of the global pressure Laplacian), Newton residual norm
     reduced over the ranks.  radiation: the scalar Newton loop (facet radiation terms + k(T)) on two ranks."""
     import test_gpu_parallel_api as T
-    single = T.NS_CASES[case]().solve().vector().get_local()
+    one = T.NS_CASES[case]()
+    single = one.solve().vector().get_local()
     r = _run(world, case, tmp_path)
     assert np.abs(r["x"] - single).max() <= 1e-6 * np.abs(single).max()
+    if case == "channel":                 # viscous_stress on several ranks: nine decomposed mass-matrix solves
+        sig = one.viscous_stress(one.w_current).vector().get_local()
+        assert np.abs(r["sigma"] - sig).max() <= 1e-5 * np.abs(sig).max()
 
 
 def test_amg_pcg_under_two_ranks_is_an_additive_schwarz_solve(gpu, tmp_path):
