@@ -113,7 +113,8 @@ int fs_mesh_destroy(fs_mesh_t mesh);
 int fs_space_create(fs_mesh_t mesh, int family, int degree, int ncomp, fs_space_t* out);
 /* The same space with additional node couplings in the sparsity pattern (node_pairs [n_pairs][2], both directions are
  * added): what DOLFIN's pattern builder does for a form with interior-facet (dS) integrals, where the two vertices
- * opposite a facet couple although they share no cell (ScalarTransportSolver.py:312-315).  CG1 only. */
+ * opposite a facet couple although they share no cell (ScalarTransportSolver.py:312-315), and for a periodic space, whose
+ * folded system (fs_matrix_tie_nodes) couples every master with the neighbours of its slave.  CG1 and CG2. */
 int fs_space_create_coupled(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_pairs, const int32_t* node_pairs,
                             fs_space_t* out);
 int fs_space_info(fs_space_t space, int64_t* n_dofs_local, int64_t* n_dofs_owned, int64_t* nnz,
