@@ -50,7 +50,7 @@ class fs_linear_form(C.Structure):
 class fs_krylov_opts(C.Structure):
     _fields_ = [("method", C.c_int), ("precond", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_iter", C.c_int), ("batch", C.c_int), ("nonzero_guess", C.c_int), ("norm_type", C.c_int),
-                ("diagonal_scale", C.c_int)]
+                ("diagonal_scale", C.c_int), ("pipelined", C.c_int)]
 
 
 class fs_krylov_stats(C.Structure):

@@ -438,14 +438,19 @@ def set_dirichlet_values(b, dofs, vals):
 
 
 def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False,
-                 method="cg", diagonal_scale=True, norm="unpreconditioned"):
-    """CG (SPD) or BiCGStab (non-symmetric) on the device.  Returns a stats dict."""
+                 method="cg", diagonal_scale=True, norm="unpreconditioned", pipelined=None):
+    """CG (SPD) or BiCGStab (non-symmetric) on the device.  Returns a stats dict.
+    pipelined: True / False select the Ghysels-Vanroose or the single-reduction CG recurrence; None (default) = pipelined
+    exactly when the sums cross GPUs (more than one rank), where the all-reduce then hides under the product."""
     o = L.fs_krylov_opts()
     o.method = {"cg": L.FS_KSP_CG, "bicgstab": L.FS_KSP_BICGSTAB}[method]
     o.precond = {"none": L.FS_PC_NONE, None: L.FS_PC_NONE, "jacobi": L.FS_PC_JACOBI}[precond]
     o.rtol, o.atol, o.max_iter, o.batch = float(rtol), float(atol), int(max_iter), int(batch)
     o.nonzero_guess = 1 if nonzero_guess else 0
     o.diagonal_scale = 1 if diagonal_scale else 0
+    o.pipelined = -1 if pipelined is None else (1 if pipelined else 0)
+    if o.pipelined < 0 and not (method == "cg" and o.precond == L.FS_PC_JACOBI and diagonal_scale):
+        o.pipelined = 0
     o.norm_type = {"unpreconditioned": L.FS_NORM_UNPRECONDITIONED, "preconditioned": L.FS_NORM_PRECONDITIONED}[norm]
     st = L.fs_krylov_stats()
     L.check(L.load().fs_krylov_solve(A.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_krylov_solve")

@@ -305,6 +305,17 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
 // (SURVEY section 8e):  begin = pack on the compute stream, then grouped ncclSend/ncclRecv (+ scatter of an indexed
 // halo) on the library's COMMUNICATION stream behind an event;  end = the compute stream waits for that stream.
 // Only device-side dependencies: the host never blocks.
+int fs_halo_comm_stream(fs_space_s* space, hipStream_t* out) {
+    fs_halo_plan& h = space->halo;
+    if (!h.comm_stream) {
+        FS_HIP(hipStreamCreateWithFlags(&h.comm_stream, hipStreamNonBlocking));
+        FS_HIP(hipEventCreateWithFlags(&h.ev_ready, hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&h.ev_done, hipEventDisableTiming));
+    }
+    *out = h.comm_stream;
+    return FS_OK;
+}
+
 int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
     fs_halo_plan& h = space->halo;
     if (!h.active) return FS_OK;
@@ -313,11 +324,8 @@ int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
         fs_set_error("halo exchange requested but no communicator is up (call fs_comm_init)");
         return FS_ERR_COMM;
     }
-    if (!h.comm_stream) {
-        FS_HIP(hipStreamCreateWithFlags(&h.comm_stream, hipStreamNonBlocking));
-        FS_HIP(hipEventCreateWithFlags(&h.ev_ready, hipEventDisableTiming));
-        FS_HIP(hipEventCreateWithFlags(&h.ev_done, hipEventDisableTiming));
-    }
+    hipStream_t cs = nullptr;
+    FS_CHECK(fs_halo_comm_stream(space, &cs));
     const int nn = (int)h.neighbors.size();
     for (int i = 0; i < nn; ++i) {
         if (!h.send_contiguous[i] && h.send_counts[i] > 0) {
@@ -326,7 +334,6 @@ int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
         }
     }
     FS_KERNEL_CHECK();
-    hipStream_t cs = h.comm_stream;
     FS_HIP(hipEventRecord(h.ev_ready, s));
     FS_HIP(hipStreamWaitEvent(cs, h.ev_ready, 0));
     double* ghosts = d_vec + space->n_dofs_owned;

@@ -57,6 +57,9 @@ struct fs_runtime {
     void* comm = nullptr;
 };
 fs_runtime& fs_rt();
+// Serial numbers of spaces and matrices: heap and pool addresses are recycled after a destroy, so anything cached per
+// operator (the captured CG batch of fs_krylov.hip) is keyed on these, never on addresses alone.
+uint64_t fs_next_serial();
 struct fs_matrix_s;
 void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s);   // fs_saddle.hip: unit diagonal on the dummy pressure slots
 int fs_require_init();
@@ -64,8 +67,12 @@ int fs_require_init();
 // ---- device memory -------------------------------------------------------------
 // Blocks released by the library are kept (up to FS_POOL_MAX_MB, default 16384) and handed out again for requests of
 // about their size: hipFree synchronises the device and hipMalloc of a large block takes 0.1-1 ms, which a time loop
-// re-assembling its operators and an AMG set-up with its dozens of temporaries pay every time.  Every kernel and copy
-// of the library is ordered on the one stream of fs_runtime, so a block can be re-used as soon as it is released.
+// re-assembling its operators and an AMG set-up with its dozens of temporaries pay every time.  A released block is
+// re-used at once, which rests on this invariant: every kernel and copy that touches a pooled block is ordered on the
+// one stream of fs_runtime - EXCEPT the halo send / recv / unpack and the overlapped all-reduce on the communication
+// stream, and for those no buffer may be released between fs_halo_begin_dev and the fs_halo_end_dev that makes the
+// compute stream wait for them (the only blocks they touch are the vector being exchanged, the plan's own send / recv
+// buffers and the solver workspace, all of which outlive the solve).  The pool's book-keeping is guarded by a mutex.
 void* fs_pool_alloc(size_t bytes);   // nullptr (error message set) when the device is out of memory
 void fs_pool_free(void* p);
 void fs_pool_trim(size_t keep_bytes);   // give cached blocks back to the driver until at most keep_bytes stay
@@ -156,6 +163,7 @@ struct fs_halo_plan {
 };
 
 struct fs_space_s {
+    const uint64_t serial = fs_next_serial();
     fs_mesh_s* mesh = nullptr;
     int degree = 1;
     int ncomp = 1;
@@ -225,6 +233,7 @@ struct fs_space_s {
 };
 
 struct fs_matrix_s {
+    const uint64_t serial = fs_next_serial();
     fs_space_s* space = nullptr;
     int bs = 1;                   // block size (ncomp)
     bool taylor_hood = false;     // bs = 4 values written by fs_assemble_navier_stokes: pressure only on vertex nodes
@@ -254,6 +263,9 @@ int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s);
 // the same in two halves: begin = pack + send/recv on the communication stream, end = compute stream waits for it
 int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s);
 int fs_halo_end_dev(fs_space_s* space, hipStream_t s);
+// the communication stream of the space's halo plan (created on first use): collectives that are to overlap with the
+// compute stream are issued there, in the same order on every rank
+int fs_halo_comm_stream(fs_space_s* space, hipStream_t* out);
 // fs_krylov.hip: bare y = A x on the library stream, no halo exchange, no synchronisation.
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 // fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.

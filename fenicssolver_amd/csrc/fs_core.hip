@@ -1,5 +1,7 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
+#include <atomic>
+#include <mutex>
 #include "fs_kernels.h"
 #include <map>
 #include <unordered_map>
@@ -27,6 +29,8 @@ struct block_pool {
     std::multimap<size_t, void*> idle;               // size -> block
     std::unordered_map<void*, size_t> size_of;       // every block handed out or idle
     size_t live = 0, cached = 0;
+    std::recursive_mutex mu;                         // ctypes releases the GIL: a handle destroyed by one Python thread
+                                                     // (_Handle.__del__) may race an allocation made by another
     size_t limit() {
         static size_t v = [] {
             const char* e = getenv("FS_POOL_MAX_MB");
@@ -43,6 +47,7 @@ block_pool& pool() {
 
 void fs_pool_trim(size_t keep_bytes) {
     block_pool& P = pool();
+    std::lock_guard<std::recursive_mutex> lock(P.mu);
     while (P.cached > keep_bytes && !P.idle.empty()) {
         auto it = std::prev(P.idle.end());           // largest first
         (void)hipFree(it->second);
@@ -55,6 +60,7 @@ void fs_pool_trim(size_t keep_bytes) {
 void* fs_pool_alloc(size_t bytes) {
     block_pool& P = pool();
     if (bytes == 0) return nullptr;
+    std::lock_guard<std::recursive_mutex> lock(P.mu);
     // the smallest idle block that holds the request and wastes at most a quarter of itself (small blocks: half)
     auto it = P.idle.lower_bound(bytes);
     if (it != P.idle.end() && it->first - bytes <= (it->first < (1u << 20) ? it->first / 2 : it->first / 4)) {
@@ -83,6 +89,7 @@ void* fs_pool_alloc(size_t bytes) {
 
 void fs_pool_free(void* p) {
     block_pool& P = pool();
+    std::lock_guard<std::recursive_mutex> lock(P.mu);
     auto it = P.size_of.find(p);
     if (it == P.size_of.end()) {                     // not ours (cannot happen): hand it to the driver
         (void)hipFree(p);
@@ -103,6 +110,7 @@ void fs_pool_free(void* p) {
 }
 
 void fs_pool_stats(size_t* live_bytes, size_t* cached_bytes) {
+    std::lock_guard<std::recursive_mutex> lock(pool().mu);
     if (live_bytes) *live_bytes = pool().live;
     if (cached_bytes) *cached_bytes = pool().cached;
 }
@@ -129,6 +137,11 @@ int fs_require_init() {
         return fs_init(0);
     }
     return FS_OK;
+}
+
+uint64_t fs_next_serial() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
 }
 
 extern "C" const char* fs_last_error(void) { return g_err; }

@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                                                         int part_base, int part_stride, int bump) {
     // part_base / part_stride: where this launch's per-workgroup dot partials go (partials[j*stride + base + wg]);
     // a product split into an interior and a boundary launch fills one array of stride = both grids
+    // DOTS == 4: no dot products, but the launch is gated by the status word like the fused ones (the product of the
+    // pipelined CG, whose dots are computed by its update kernel)
     if (DOTS) {
         if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
         // status[2] = number of in-loop products launched so far: the update kernel of a captured batch (hipGraph: same
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             zi[i] = 0.0;
             ri[i] = 0.0;
             acc[i] = 0.0;
-            if (DOTS && live) {
+            if (DOTS && DOTS != 4 && live) {
                 if (DOTS == 1 || DOTS == 3) zi[i] = x[r * BS + i];
                 ri[i] = rvec[r * BS + i];
             }
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             }
         }
     }
-    if (DOTS) {
+    if (DOTS && DOTS != 4) {
         const double t0 = fs_block_sum(d_rz, lds4);
         const double t1 = fs_block_sum(d_wz, lds4);
         const double t2 = fs_block_sum(d_rr, lds4);
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
         const int32_t r = (int32_t)(s * FS_SLICE + l2);
         const double* __restrict__ vp = val + base + l2;
         v2d zi = {0.0, 0.0}, ri = {0.0, 0.0};
-        if (DOTS) {
+        if (DOTS && DOTS != 4) {
             if (DOTS == 1 || DOTS == 3) zi = *reinterpret_cast<const v2d*>(&x[r]);
             ri = *reinterpret_cast<const v2d*>(&rvec[r]);
         }
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
             d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
         }
     }
-    if (DOTS) {
+    if (DOTS && DOTS != 4) {
         const double t0 = fs_block_sum(d_rz, lds4);
         const double t1 = fs_block_sum(d_wz, lds4);
         const double t2 = fs_block_sum(d_rr, lds4);
@@ -729,6 +731,174 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
         p[i] = pp; sv[i] = ss;
         x[i] += alpha * pp;
         r[i] -= alpha * ss;
+    }
+}
+
+// ---- pipelined CG (Ghysels & Vanroose, Parallel Computing 40 (2014)) on the scaled system --------------------------
+// The single-reduction recurrence above still has the global sums between the product and the update: on several GPUs the
+// 3-double all-reduce (latency, not bandwidth) is paid in full every iteration.  The pipelined recurrence carries two more
+// vectors (w = A r, z = A s) so that the sums of iteration i - (r.r, w.r, sum d r^2) of r_i, w_i - are known BEFORE the
+// product n_i = A w_i starts and are reduced while it runs:
+//      beta = gamma_i / gamma_{i-1},  alpha = gamma_i / (delta_i - beta gamma_i / alpha_{i-1})
+//      z = n + beta z;  s = w + beta s;  p = r + beta p;   x += alpha p;  r -= alpha s;  w -= alpha z
+// In exact arithmetic the iterates are those of CG.  The update kernel computes the sums of the NEW r, w as it writes
+// them (per-workgroup partials, double-buffered by iteration parity because the next launch reads one set while it writes
+// the other).  112 instead of 72 B/DOF of vector traffic per iteration: it only pays where a collective is hidden.
+// Rows [m0, m1) are updated by this launch; rows [0, m0) and [m1, n) - what a slab sends to its neighbours - were already
+// updated by k_pcg_update_rows (so that their exchange could start) and only enter the sums here.
+__device__ __forceinline__ bool pcg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
+                                            double& alpha, double& beta) {
+    beta = 0.0;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    return (alpha > 0.0) && (alpha < 1e300) && (rho == rho);
+}
+
+template <bool FUSED, bool NT>
+__global__ void __launch_bounds__(FS_BLOCK) k_pcg_update(int64_t n, int64_t m0, int64_t m1, int iter, int check_only,
+                                                         double* __restrict__ partials, int npart,
+                                                         const double* __restrict__ sums, const double* __restrict__ ctrl,
+                                                         double* __restrict__ scal, int* __restrict__ status,
+                                                         double* __restrict__ hist, const double* __restrict__ dvec,
+                                                         double* __restrict__ r, double* __restrict__ w,
+                                                         const double* __restrict__ nv, double* __restrict__ p,
+                                                         double* __restrict__ sv, double* __restrict__ z,
+                                                         double* __restrict__ x) {
+    if (status[0] != 0) return;
+    double gamma, delta, rho;
+    if (FUSED) {
+        double sm[3];
+        wg_sum_partials<3>(partials + (int64_t)(iter & 1) * 3 * npart, npart, sm);
+        gamma = sm[0]; delta = sm[1]; rho = sm[2];
+    } else {
+        gamma = sums[0]; delta = sums[1]; rho = sums[2];
+    }
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (leader) hist[iter] = rho;
+    if (rho <= ctrl[0]) {
+        if (leader) { status[1] = iter; status[0] = 1; }
+        return;
+    }
+    if (check_only) {
+        if (leader) { status[1] = iter; status[0] = 3; }
+        return;
+    }
+    double alpha, beta;
+    if (!pcg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) {
+        scal[2 * (iter & 1) + 0] = gamma;
+        scal[2 * (iter & 1) + 1] = alpha;
+    }
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    struct io {
+        static __device__ __forceinline__ v2d ld(const double* q) {
+            return NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)) : *reinterpret_cast<const v2d*>(q);
+        }
+        static __device__ __forceinline__ void st(double* q, const v2d& v) {
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(q));
+            else *reinterpret_cast<v2d*>(q) = v;
+        }
+    };
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t npair = (m1 - m0) >> 1;              // m0 is even
+    for (int64_t q = tid; q < npair; q += stride) {
+        const int64_t i = m0 + 2 * q;
+        const v2d nn = io::ld(nv + i), dd = io::ld(dvec + i);
+        v2d zz = io::ld(z + i), ss = io::ld(sv + i), pp = io::ld(p + i), ww = io::ld(w + i), rr = io::ld(r + i), xx = io::ld(x + i);
+        zz = nn + beta * zz;
+        ss = ww + beta * ss;
+        pp = rr + beta * pp;
+        xx += alpha * pp;
+        rr -= alpha * ss;
+        ww -= alpha * zz;
+        io::st(z + i, zz); io::st(sv + i, ss); io::st(p + i, pp); io::st(x + i, xx); io::st(r + i, rr); io::st(w + i, ww);
+        a0 += rr.x * rr.x + rr.y * rr.y;
+        a1 += ww.x * rr.x + ww.y * rr.y;
+        a2 += dd.x * rr.x * rr.x + dd.y * rr.y * rr.y;
+    }
+    if (((m1 - m0) & 1) && tid == 0) {
+        const int64_t i = m1 - 1;
+        const double zz = nv[i] + beta * z[i], ss = w[i] + beta * sv[i], pp = r[i] + beta * p[i];
+        z[i] = zz; sv[i] = ss; p[i] = pp;
+        x[i] += alpha * pp;
+        const double rr = r[i] - alpha * ss, ww = w[i] - alpha * zz;
+        r[i] = rr; w[i] = ww;
+        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
+    }
+    // rows already updated by k_pcg_update_rows
+    const int64_t extra = m0 + (n - m1);
+    for (int64_t t = tid; t < extra; t += stride) {
+        const int64_t i = t < m0 ? t : m1 + (t - m0);
+        const double rr = r[i], ww = w[i];
+        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
+    }
+    __shared__ double lds4[4];
+    const double t0 = fs_block_sum(a0, lds4);
+    const double t1 = fs_block_sum(a1, lds4);
+    const double t2 = fs_block_sum(a2, lds4);
+    if (threadIdx.x == 0) {
+        double* out = partials + (int64_t)((iter + 1) & 1) * 3 * npart;
+        out[blockIdx.x] = t0;
+        out[npart + blockIdx.x] = t1;
+        out[2 * npart + blockIdx.x] = t2;
+    }
+}
+
+// The pipelined update on the rows [0, a) and [b, n) only (sums from the all-reduce): no side effects, the launch on
+// the remaining rows takes the same decisions from the same inputs and writes status / history / scalars.
+__global__ void __launch_bounds__(FS_BLOCK) k_pcg_update_rows(int64_t a, int64_t b, int64_t n, int iter, int check_only,
+                                                              const double* __restrict__ sums, const double* __restrict__ ctrl,
+                                                              const double* __restrict__ scal, const int* __restrict__ status,
+                                                              double* __restrict__ r, double* __restrict__ w,
+                                                              const double* __restrict__ nv, double* __restrict__ p,
+                                                              double* __restrict__ sv, double* __restrict__ z, double* __restrict__ x) {
+    if (status[0] != 0) return;
+    const double gamma = sums[0], delta = sums[1], rho = sums[2];
+    if (rho <= ctrl[0] || check_only) return;
+    double alpha, beta;
+    if (!pcg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
+    const int64_t total = a + (n - b);
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const int64_t i = t < a ? t : b + (t - a);
+        const double zz = nv[i] + beta * z[i], ss = w[i] + beta * sv[i], pp = r[i] + beta * p[i];
+        z[i] = zz; sv[i] = ss; p[i] = pp;
+        x[i] += alpha * pp;
+        r[i] -= alpha * ss;
+        w[i] -= alpha * zz;
+    }
+}
+
+// sums of the first iterate of a pass: partials (parity 0) of (r.r, w.r, sum d r^2)
+__global__ void __launch_bounds__(FS_BLOCK) k_pcg_dots(int64_t n, const double* __restrict__ r, const double* __restrict__ w,
+                                                       const double* __restrict__ dvec, double* __restrict__ partials, int npart) {
+    __shared__ double lds4[4];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double rr = r[i], ww = w[i];
+        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
+    }
+    const double t0 = fs_block_sum(a0, lds4);
+    const double t1 = fs_block_sum(a1, lds4);
+    const double t2 = fs_block_sum(a2, lds4);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t0;
+        partials[npart + blockIdx.x] = t1;
+        partials[2 * npart + blockIdx.x] = t2;
     }
 }
 
@@ -1217,6 +1387,8 @@ struct krylov_ws {
     dbuf<double> dinv, r, z, w, p, s, partials, sums, ctrl, scal, hist;
     dbuf<double> rhat, t, y, partials2, bsums;   // BiCGStab only (allocated on first use)
     dbuf<double> aval, dvec, bhat, sc_local;     // diagonally scaled CG only
+    dbuf<double> pw, pz;                         // pipelined CG only: w = A r (with ghost room: it is the exchanged vector), z = A s
+    hipEvent_t ev_upd = nullptr, ev_red = nullptr;   // pipelined CG: update done -> all-reduce on the communication stream -> sums ready
     dbuf<int> d_err;                             // zero-diagonal counter of k_extract_dinv
     int64_t bicg_n = -1;
     dbuf<int> status;
@@ -1231,8 +1403,8 @@ struct krylov_ws {
     // one batch of CG iterations captured as a hipGraph (same arguments every iteration: the update kernel reads its
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
     hipGraphExec_t cg_graph = nullptr;
-    const void* cg_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int64_t cg_key_i[6] = {0, 0, 0, 0, 0, 0};
+    const void* cg_key[12] = {};
+    int64_t cg_key_i[8] = {};
 };
 static krylov_ws g_ws;
 
@@ -1257,6 +1429,8 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
         FS_HIP(hipHostMalloc((void**)&ws.h_status, 12 * sizeof(int), hipHostMallocDefault));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[0], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[1], hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&ws.ev_upd, hipEventDisableTiming));
+        FS_HIP(hipEventCreateWithFlags(&ws.ev_red, hipEventDisableTiming));
         for (int i = 0; i < krylov_ws::NSAMPLE; ++i)
             for (int j = 0; j < 4; ++j) FS_HIP(hipEventCreate(&ws.ev[i][j]));
         ws.events = true;
@@ -1307,6 +1481,19 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             FS_CHECK(ws.bhat.alloc(n + 2));
         }
         if (ws.sc_local.n != nl + 2) FS_CHECK(ws.sc_local.alloc(nl + 2));
+    }
+    // Pipelined recurrence (k_pcg_update): asked for explicitly (> 0), or chosen automatically (< 0) when the sums have to
+    // cross GPUs - on one GPU nothing hides behind the product and the classic recurrence moves 40 B/DOF less.
+    static const char* pipe_env = getenv("FS_CG_PIPELINED");
+    const int pipe_opt = pipe_env ? atoi(pipe_env) : opts->pipelined;
+    if (pipe_opt > 0 && !ds) {
+        fs_set_error("fs_krylov_solve: the pipelined recurrence needs CG + Jacobi with diagonal_scale = 1");
+        return FS_ERR_UNSUPPORTED;
+    }
+    const bool pipelined = ds && (pipe_opt > 0 || (pipe_opt < 0 && fs_rt().comm != nullptr && fs_rt().n_ranks > 1));
+    if (pipelined) {
+        if (ws.pw.n != nl + 2) FS_CHECK(ws.pw.alloc(nl + 2));
+        if (ws.pz.n != n + 2) FS_CHECK(ws.pz.alloc(n + 2));
     }
     const bool fuse_sums = g_cg_fuse_sums && fs_rt().comm == nullptr;
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
@@ -1412,6 +1599,32 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
         }
         FS_KERNEL_CHECK();
+        // pipelined CG: the all-reduce of the sums runs on the communication stream of the halo plan, behind ev_upd, and the
+        // compute stream waits for ev_red only when the next update needs the sums - the product sits in between.  Without
+        // a halo plan (a replicated operator) the collective stays in-stream.
+        hipStream_t red_stream = nullptr;
+        if (pipelined && !fuse_sums && sp->halo.active) FS_CHECK(fs_halo_comm_stream(sp, &red_stream));
+        auto pcg_reduce = [&](int parity) -> int {
+            hipStream_t q = red_stream ? red_stream : s;
+            if (red_stream) {
+                FS_HIP(hipEventRecord(ws.ev_upd, s));
+                FS_HIP(hipStreamWaitEvent(red_stream, ws.ev_upd, 0));
+            }
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, q, ws.partials.p + (int64_t)parity * 3 * vgrid, vgrid, 3, ws.sums.p);
+            FS_KERNEL_CHECK();
+            FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, q));
+            if (red_stream) FS_HIP(hipEventRecord(ws.ev_red, red_stream));
+            return FS_OK;
+        };
+        if (pipelined) {
+            // r0 sits in ws.z; w0 = A r0, z = 0 (p, s are zero already), sums of (r0, w0)
+            FS_CHECK(ws.pz.zero(s));
+            FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+            launch_spmv<0>(A, ws.z.p, ws.pw.p, nullptr, nullptr, nullptr, s, aval);
+            hipLaunchKernelGGL(k_pcg_dots, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, ws.z.p, ws.pw.p, ws.dvec.p, ws.partials.p, vgrid);
+            FS_KERNEL_CHECK();
+            if (!fuse_sums) FS_CHECK(pcg_reduce(0));
+        }
         if (bicg) {
             // rhat = r0; first (rhat.r, r.r) partials; v = 0 (ws.w), p = 0, y = 0
             FS_HIP(hipMemcpyAsync(ws.rhat.p, ws.r.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1479,13 +1692,19 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             }
             if (hp.early == 1) { early_a = hp.early_a; early_b = hp.early_b; }
         }
-        const bool use_graph = ds && fuse_sums && !bicg && !sp->halo.active && bs == 1 &&
+        const bool use_graph = ds && fuse_sums && !bicg && !pipelined && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
             if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
-                const void* key[8] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p};
-                const int64_t key_i[6] = {n, 0, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1)};
+                // everything the captured launches bake in: the vectors of the workspace, the operator's value and
+                // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
+                // and pool addresses are handed out again (another mesh with the same row count would otherwise replay
+                // this graph over column arrays that no longer exist)
+                const void* key[12] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
+                                       ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p};
+                const int64_t key_i[8] = {n, 0, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1),
+                                          (int64_t)A->serial, (int64_t)sp->serial};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
                     if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
                     hipGraph_t graph = nullptr;
@@ -1547,6 +1766,46 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 2, ws.bsums.p + 8);
                         FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 8, 2, s));
                         hipLaunchKernelGGL(k_bicg_x<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
+                    }
+                    continue;
+                }
+                if (pipelined) {
+                    const int co = k == max_iter ? 1 : 0;
+                    // n = A w (its halo was begun behind the previous update), under which the sums of (r, w) are reduced
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
+                    FS_CHECK(spmv_overlapped<4>(A, ws.pw.p, ws.w.p, nullptr, nullptr, ws.status.p, s, aval));
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
+                    if (red_stream) FS_HIP(hipStreamWaitEvent(s, ws.ev_red, 0));
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                    int64_t m0 = 0, m1 = n;
+                    if (early_a > 0 || early_b < n) {
+                        hipLaunchKernelGGL(k_pcg_update_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 256)), dim3(FS_BLOCK), 0, s,
+                                           early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.pw.p, ws.w.p, ws.p.p, ws.s.p, ws.pz.p, x->d.p);
+                        FS_CHECK(fs_halo_begin_dev(sp, ws.pw.p, s));
+                        sp->halo.begun = true;
+                        m0 = early_a; m1 = early_b;
+                    }
+#define FS_PCG_ARGS dim3(vgrid), dim3(FS_BLOCK), 0, s, n, m0, m1, k, co, ws.partials.p, vgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dvec.p, ws.z.p, ws.pw.p, ws.w.p, ws.p.p, ws.s.p, ws.pz.p, x->d.p
+                    if (fuse_sums) {
+                        if (upd_nt) hipLaunchKernelGGL((k_pcg_update<true, true>), FS_PCG_ARGS);
+                        else hipLaunchKernelGGL((k_pcg_update<true, false>), FS_PCG_ARGS);
+                    } else {
+                        if (upd_nt) hipLaunchKernelGGL((k_pcg_update<false, true>), FS_PCG_ARGS);
+                        else hipLaunchKernelGGL((k_pcg_update<false, false>), FS_PCG_ARGS);
+                    }
+#undef FS_PCG_ARGS
+                    if (sample) {
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
+                        ++n_samples;
+                    }
+                    if (!fuse_sums) {
+                        // the halo of the new w goes first on the communication stream (the boundary rows of the next
+                        // product wait for it), the reduction of the new sums behind it
+                        if (!sp->halo.begun && spmv_is_split(sp)) {
+                            FS_CHECK(fs_halo_begin_dev(sp, ws.pw.p, s));
+                            sp->halo.begun = true;
+                        }
+                        FS_CHECK(pcg_reduce((k + 1) & 1));
                     }
                     continue;
                 }

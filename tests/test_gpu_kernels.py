@@ -276,6 +276,54 @@ def test_config2_family_cg_parity(gpu, n, axis):
     assert np.abs(T2 - P["exact"]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("n,axis,rtol", [(12, 2, 1e-8), (24, 0, 1e-8), (24, 2, 1e-12), (40, 2, 1e-10)])
+def test_pipelined_cg_follows_the_single_reduction_recurrence(gpu, n, axis, rtol):
+    """fs_krylov_opts.pipelined = 1 (Ghysels-Vanroose): in exact arithmetic the iterates of CG - same count within +2,
+    same residual history while well above round-off, same solution <= 1e-9 relative, and the oracle's answer."""
+    P = fo.heat_box_problem(n, axis=axis)
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, P["dofs"], P["vals"], symmetric=True)
+    x0, x1 = gpu.DeviceVector(V.n_owned), gpu.DeviceVector(V.n_owned)
+    s0 = gpu.krylov_solve(A, b, x0, rtol=rtol, max_iter=5000, pipelined=False)
+    h0 = gpu.krylov_history()
+    s1 = gpu.krylov_solve(A, b, x1, rtol=rtol, max_iter=5000, pipelined=True)
+    h1 = gpu.krylov_history()
+    assert s0["converged"] == 1 and s1["converged"] == 1
+    assert -1 <= s1["iterations"] - s0["iterations"] <= 2, (s0["iterations"], s1["iterations"])
+    assert s1["true_rel_residual"] <= 1.5 * rtol
+    m = min(len(h0), len(h1), 25)
+    assert np.allclose(h0[:m], h1[:m], rtol=1e-6)
+    scale = np.abs(x0.get()).max()
+    assert np.abs(x1.get() - x0.get()).max() <= max(RTOL_SOLUTION, 30 * rtol) * scale
+    xo, ito, _ = fo.pcg_jacobi_single_reduction(P["A"], P["b"], rtol=rtol)       # the oracle's recurrence and answer
+    assert -1 <= s1["iterations"] - ito <= 2
+    assert np.abs(x1.get() - xo).max() <= max(RTOL_SOLUTION, 30 * rtol) * scale
+    if rtol <= 1e-10:            # the linear profile is the exact discrete solution
+        assert np.abs(x1.get() - P["exact"]).max() <= 1e-6 * scale
+    # a nonzero initial guess and the preconditioned norm go through the same pass set-up
+    x2 = gpu.DeviceVector(V.n_owned)
+    x2.set(np.full(V.n_owned, 320.0))
+    s2 = gpu.krylov_solve(A, b, x2, rtol=rtol, max_iter=5000, pipelined=True, nonzero_guess=True, norm="preconditioned")
+    assert s2["converged"] == 1
+    assert np.abs(x2.get() - x0.get()).max() <= max(RTOL_SOLUTION, 300 * rtol) * scale
+
+
+def test_pipelined_cg_needs_the_scaled_jacobi_recurrence(gpu):
+    mesh = gpu.DeviceMesh.box(3, 3, 3)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=1.0, mass=1.0)
+    b = gpu.DeviceVector(V.n_owned)
+    b.fill(1.0)
+    x = gpu.DeviceVector(V.n_owned)
+    with pytest.raises(gpu.BackendError):
+        gpu.krylov_solve(A, b, x, precond="none", pipelined=True)
+
+
 def test_manufactured_solution_converges_second_order(gpu):
     """-k lap u = f with u = sin(pi x) sin(pi y) sin(pi z): L2-ish error ~ h^2 (Appendix C6)."""
     errs = []

@@ -18,11 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PORT = [29610]
 
 
-def _run(world, case, tmp_path):
+def _run(world, case, tmp_path, **extra_env):
     out = str(tmp_path / ("%s_%d.npz" % (case, world)))
     shim = os.path.join(ROOT, "tests", "shim", "libfakerccl.so")
     assert os.path.exists(shim), "build tests/shim first (make -C tests/shim; __graft_entry__.build() does it)"
-    env = dict(os.environ, FS_RCCL_PATH=shim)
+    env = dict(os.environ, FS_RCCL_PATH=shim, **extra_env)
     PORT[0] += 1
     cmd = [sys.executable, "-m", "fenicssolver_amd.launch", "--nproc", str(world), "--devices", ",".join(["0"] * world),
            "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, case]
@@ -31,8 +31,11 @@ def _run(world, case, tmp_path):
     return np.load(out)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
+@pytest.mark.parametrize("world,recurrence", [(2, "pipelined"), (3, "pipelined"), (2, "single_reduction"), (3, "single_reduction"),
+                                              (3, "pipelined_no_early_halo")])
+def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, recurrence):
+    """Both CG recurrences on several ranks (several ranks default to the pipelined one, whose all-reduce runs on the
+    communication stream under the product): same solution as one GPU <= 1e-9, iteration count within +2."""
     nx, ny, nz, axis = 9, 7, 23, 0
     co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 2.0), nx, ny, nz)
     mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0))
@@ -46,7 +49,9 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world):
     A.apply_dirichlet(b, np.concatenate([lo, hi]).astype(np.int32),
                       np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
     st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
-    r = _run(world, "box", tmp_path)
+    env = {"single_reduction": dict(FS_CG_PIPELINED="0"), "pipelined": {},
+           "pipelined_no_early_halo": dict(FS_HALO_EARLY="0")}[recurrence]
+    r = _run(world, "box", tmp_path, **env)
     assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10
     assert abs(int(r["iterations"]) - st["iterations"]) <= 2          # reduction order differs, the recurrence does not
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
