@@ -19,6 +19,16 @@ owns 100 vertex planes of 100x100 (1 M DOF), the bar grows along z and the Diric
 sits on the x-faces so the conditioning does not change with N.  `--scaling strong --cells 215`
 splits the 10 M-DOF cube instead.
 
+At N > 1 the SAME command also runs, after the timed weak leg and outside its timing, the legs the north_star
+is stated on, and adds them to the one JSON line:
+  "comm"    latency of the two collectives of an iteration (3-double all-reduce, ghost refresh) as the solver issues them
+  "strong"  the 10 M-DOF cube (n = 215) SPLIT over the N GPUs, with both CG recurrences (single-reduction and
+            pipelined); the strong-scaling anchor is the N = 1 line's roofline.dof_per_s (same cube on one GPU)
+  "configs3_p2" (N = 8, or --extra p2)  BASELINE configs[3]: P2 heat conduction, unit cube n = 107, 9.94 M DOF, z-slabs
+  "configs4_th" (N = 4, or --extra th)  BASELINE configs[4]: Taylor-Hood lid-driven cavity n = 43, 10 backward-Euler steps
+`--workload p2 | th` makes one of those the timed leg itself (any N).  The extra legs run under a watchdog: if one of
+them does not finish in its time budget the line is printed with what has been measured (`extra_legs_timed_out`).
+
 bench.py imports no torch: the launcher only has to export RANK / WORLD_SIZE / LOCAL_RANK; the RCCL unique id travels
 through fenicssolver_amd/rendezvous.py and the timing barrier / max-over-ranks run over the communicator itself.
 
@@ -54,6 +64,18 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--bc-axis", type=int, default=None, help="axis of the Dirichlet face pair (default 2 at N=1, 0 at N>1)")
     ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--workload", choices=("p1", "p2", "th"), default="p1",
+                    help="p1: BASELINE configs[1] family (default); p2: configs[3] (P2, n=107); th: configs[4] (Taylor-Hood cavity n=43)")
+    ap.add_argument("--extra", default="auto", help="extra legs at N>1: auto | none | comma list of strong,p2,th")
+    ap.add_argument("--extra-budget", type=float, default=240.0, help="seconds the extra legs may take before the watchdog prints the line")
+    ap.add_argument("--recurrence", choices=("auto", "single_reduction", "pipelined"), default="auto",
+                    help="CG recurrence of the timed leg at N>1 (auto: the faster of the two in a warm-up trial, agreed over the ranks)")
+    ap.add_argument("--mesh", choices=("structured", "shuffled", "renumbered"), default="structured",
+                    help="N=1 only: shuffled = random vertex + cell permutation of the cube uploaded as a file mesh would be, "
+                         "renumbering disabled; renumbered = the same upload with the library's locality renumbering")
+    ap.add_argument("--strong-n", type=int, default=215, help="cube of the strong extra leg (tests shrink it)")
+    ap.add_argument("--p2-n", type=int, default=107, help="cube of the configs[3] extra leg")
+    ap.add_argument("--th-n", type=int, default=43, help="cube of the configs[4] extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-case", action="store_true", help="skip the extra 10 M-DOF roofline measurement")
     return ap.parse_args()
@@ -86,6 +108,8 @@ class Problem:
         self.x = B.DeviceVector(self.V.n_owned)
         self.n_owned = n_own
 
+    pipelined = None     # None: the library's rule (pipelined exactly when the sums cross GPUs)
+
     def step(self, rtol):
         """assemble + Dirichlet + CG.  Returns (stats, t_assemble_ms)."""
         t0 = time.perf_counter()
@@ -93,10 +117,267 @@ class Problem:
         self.b.fill(0.0)
         self.A.apply_dirichlet(self.b, self.dofs, self.vals, symmetric=True)
         t1 = time.perf_counter()
-        st = B.krylov_solve(self.A, self.b, self.x, rtol=rtol, max_iter=20000, precond="jacobi")
+        st = B.krylov_solve(self.A, self.b, self.x, rtol=rtol, max_iter=20000, precond="jacobi", pipelined=self.pipelined)
         if st["converged"] != 1:
             raise RuntimeError("CG did not converge: %r" % (st,))
         return st, (t1 - t0) * 1e3
+
+
+class ShuffledProblem:
+    """The cube of BASELINE configs[1] as a mesh FILE would deliver it: vertices and cells in random order, uploaded through
+    fs_mesh_create (no structure for the DIA slices to find, no locality in the numbering).  renumber: the upload goes through
+    the library's locality order first (fs_mesh_locality_order: Morton order of the vertices, cells by their first vertex) -
+    what fem.Mesh does for file meshes; results are compared in the ORIGINAL numbering either way."""
+
+    pipelined = False
+
+    def __init__(self, n, axis, renumber, seed=0):
+        xyz, cells, _ = B.DeviceMesh.box(n, n, n).get()
+        nv = len(xyz)
+        rng = np.random.default_rng(seed)
+        new_of_old = rng.permutation(nv).astype(np.int64)            # the "file" numbering
+        co = np.empty_like(xyz)
+        co[new_of_old] = xyz
+        ce = np.sort(new_of_old[cells], axis=1)[rng.permutation(len(cells))].astype(np.int32)
+        del cells
+        self.file_of_structured = new_of_old
+        t0 = time.perf_counter()
+        if renumber:
+            vorder, corder = B.locality_order(co, ce)                # vorder[new] = file id
+            dev_of_file = np.empty(nv, dtype=np.int64)
+            dev_of_file[vorder] = np.arange(nv)
+            self.dev_of_file = dev_of_file
+            self.mesh = B.DeviceMesh(co[vorder], np.sort(dev_of_file[ce[corder]], axis=1).astype(np.int32))
+        else:
+            self.dev_of_file = np.arange(nv)
+            self.mesh = B.DeviceMesh(co, ce)
+        B.synchronize()
+        t1 = time.perf_counter()
+        self.V = B.DeviceSpace(self.mesh, 1)
+        B.synchronize()
+        t2 = time.perf_counter()
+        self.mesh_ms, self.symbolic_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        c = co[:, axis]
+        lo, hi = np.nonzero(c == 0.0)[0], np.nonzero(c == 1.0)[0]
+        self.dofs = self.dev_of_file[np.concatenate([lo, hi])].astype(np.int32)
+        self.vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+        self.A = B.DeviceMatrix(self.V)
+        self.b = B.DeviceVector(self.V.n_owned)
+        self.x = B.DeviceVector(self.V.n_owned)
+        self.n_owned = self.V.n_owned
+
+    step = Problem.step
+
+    def to_structured(self, x_dev):
+        """device numbering -> the lexicographic numbering of the structured cube (what the CPU leg solves in)."""
+        return np.asarray(x_dev)[self.dev_of_file[self.file_of_structured]]
+
+
+class P2Problem:
+    """One rank's z-slab of BASELINE configs[3]: P2 heat conduction on the unit cube, CG2 nodes numbered on the device as
+    [owned vertices | owned edges | ghost vertices | ghost edges]; the node-level halo plan comes from this rank's cells
+    alone (partition.build_p2_plan_local) - nothing of global size is built on any rank."""
+
+    pipelined = None
+
+    def __init__(self, n, zplanes, axis, rank, world):
+        t0 = time.perf_counter()
+        self.mesh = B.DeviceMesh.box(n, n, n, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), zplanes=zplanes)
+        B.synchronize()
+        t1 = time.perf_counter()
+        self.V = B.DeviceSpace(self.mesh, 1, degree=2)
+        B.synchronize()
+        t2 = time.perf_counter()
+        self.mesh_ms, self.symbolic_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        xyz, cells, gid = self.mesh.get()
+        edges = self.V.edges().astype(np.int64)
+        nv = len(xyz)
+        if world > 1:
+            lay = partition.slab_layout(n, n, n, zplanes, rank, world)
+            P = lay["plane_size"]
+            owner = np.full(nv, rank, dtype=np.int32)
+            off = lay["n_owned"]
+            for q in lay["neighbors"]:               # ghost planes follow the owned ones: lower neighbour first
+                owner[off:off + P] = q
+                off += P
+            assert np.array_equal(gid, lay["l2g"])
+            plan = partition.build_p2_plan_local(cells, gid, owner, rank, lay["neighbors"], edges, (n + 1) ** 3)
+            assert plan.n_owned_nodes == self.V.n_owned
+            self.V.set_halo(plan.neighbors, plan.send_lists, plan.recv_counts, recv_lists=plan.recv_lists)
+            nov, noe = plan.node_of_vertex, plan.node_of_edge
+        else:
+            nov, noe = np.arange(nv), nv + np.arange(len(edges))
+        # Dirichlet nodes (ghosts included): vertices and edge mid-points on the two faces normal to `axis`
+        cv = xyz[:, axis]
+        ce = 0.5 * (xyz[edges[:, 0], axis] + xyz[edges[:, 1], axis])
+        lo = np.concatenate([nov[cv == 0.0], noe[ce == 0.0]])
+        hi = np.concatenate([nov[cv == 1.0], noe[ce == 1.0]])
+        self.dofs = np.concatenate([lo, hi]).astype(np.int32)
+        self.vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+        self.A = B.DeviceMatrix(self.V)
+        self.b = B.DeviceVector(self.V.n_owned)
+        self.x = B.DeviceVector(self.V.n_owned)
+        self.n_owned = self.V.n_owned
+        # exact solution at the owned nodes (the linear profile is in the P2 space): the parity check of the leg
+        co = np.empty(self.V.n_local)
+        co[nov], co[noe] = cv, ce
+        self.exact_owned = 350.0 - 50.0 * co[:self.n_owned]
+
+    step = Problem.step
+
+
+def p2_global_dofs(n):
+    return (n + 1) ** 3 + 3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3      # vertices + axis, face-diagonal and body-diagonal edges
+
+
+def timed_steps(prob, rtol, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    asm_ms, stats = 0.0, None
+    for _ in range(steps):
+        stats, t_asm = prob.step(rtol)
+        asm_ms += t_asm
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    return elapsed, asm_ms / steps, stats
+
+
+def choose_recurrence(prob, rtol, world, requested, barrier):
+    """At N > 1 both CG recurrences are run once warm in the warm-up phase and the faster one (max over the ranks, so
+    every rank decides alike) carries the timed steps.  Returns (name, {name: seconds per step})."""
+    if world == 1:
+        prob.pipelined = False
+        return "single_reduction", {}
+    if requested != "auto":
+        prob.pipelined = requested == "pipelined"
+        return requested, {}
+    trial = {}
+    for name, flag in (("single_reduction", False), ("pipelined", True)):
+        prob.pipelined = flag
+        prob.step(rtol)
+        trial[name] = timed_steps(prob, rtol, 2, barrier)[0] / 2
+    best = min(trial, key=trial.get)
+    prob.pipelined = best == "pipelined"
+    return best, {k: round(v * 1e3, 4) for k, v in trial.items()}
+
+
+def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
+    """The n^3 cube SPLIT over the ranks (strong scaling), both recurrences; per-iteration time of the solve."""
+    zplanes = partition.slab_ranges(n + 1, world)[rank]
+    prob = Problem(n, n, n, (1.0, 1.0, 1.0), zplanes, axis, rank, world)
+    res = {"workload": "unit cube n=%d (%d DOF, %d tets) split into %d z-slabs, T=350/300 on the %s-faces" % (n, (n + 1) ** 3, 6 * n ** 3, world, "xyz"[axis]),
+           "anchor": "strong-scaling speed-up = dof_per_s / (roofline.dof_per_s of the N=1 line: the same cube on one GPU)"}
+    for name, flag in (("single_reduction", False), ("pipelined", True)):
+        prob.pipelined = flag
+        prob.step(rtol)
+        elapsed, asm_ms, st = timed_steps(prob, rtol, steps, barrier)
+        ms = elapsed * 1e3 / steps
+        res[name] = {"dof_per_s": round((n + 1) ** 3 / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "iterations": st["iterations"],
+                     "assemble_ms": round(asm_ms, 4), "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
+                     "spmv_kernel_ms": round(st["spmv_ms"], 5), "update_kernel_ms": round(st["update_ms"], 5),
+                     "true_rel_residual": st["true_rel_residual"]}
+    best = min(("single_reduction", "pipelined"), key=lambda k: res[k]["ms_per_step"])
+    res.update({"recurrence": best, "dof_per_s": res[best]["dof_per_s"], "iterations": res[best]["iterations"],
+                "ms_per_iteration": res[best]["ms_per_iteration"]})
+    a_ms, h_ms = B.comm_benchmark(prob.V, 200)
+    res.update({"allreduce_ms": round(a_ms, 5), "halo_ms": round(h_ms, 5)})
+    k = kernel_rates(st, prob.V)
+    res["spmv_algorithmic_GBps_rank0"] = k["algorithmic_GBps"]
+    return res
+
+
+def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="auto"):
+    """BASELINE configs[3]: P2 heat conduction, unit cube n (107 -> 9 938 375 DOF), z-slabs over the ranks."""
+    zplanes = partition.slab_ranges(n + 1, world)[rank]
+    t0 = time.perf_counter()
+    prob = P2Problem(n, zplanes, axis, rank, world)
+    setup_s = time.perf_counter() - t0
+    name, trial = choose_recurrence(prob, rtol, world, recurrence, barrier)
+    for _ in range(warmup):
+        prob.step(rtol)
+    elapsed, asm_ms, st = timed_steps(prob, rtol, steps, barrier)
+    ms = elapsed * 1e3 / steps
+    err = float(np.abs(prob.x.get()[:prob.n_owned] - prob.exact_owned).max())
+    err = parallel.max_over_ranks(err)
+    n_dof = p2_global_dofs(n)
+    k = kernel_rates(st, prob.V)
+    return {"workload": "BASELINE configs[3]: P2 heat conduction, unit cube n=%d (%d DOF, %d tets), k=20, T=350/300 on the %s-faces, "
+                        "Jacobi-PCG rtol %g, %s" % (n, n_dof, 6 * n ** 3, "xyz"[axis], rtol, "1 GPU" if world == 1 else "%d z-slabs" % world),
+            "n_dof": n_dof, "dof_per_s": round(n_dof / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
+            "assemble_ms": round(asm_ms, 4), "cg_iterations": st["iterations"], "true_rel_residual": st["true_rel_residual"],
+            "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
+            "max_abs_error_vs_exact_profile": err, "recurrence": name, "recurrence_trial_ms_per_step": trial,
+            "symbolic_ms": round(prob.symbolic_ms, 2), "setup_s": round(setup_s, 2),
+            "spmv": {"kernel": kernel_name(prob.V), "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
+                     "algorithmic_GBps": k["algorithmic_GBps"], "frac_of_8TBps": round(k["algorithmic_GBps"] / HBM_PEAK_GBS, 3),
+                     "streamed_GBps": k["streamed_GBps"], "dia_slices": k["dia_slices"], "slices": k["slices"], "rows_rank0": prob.n_owned}}
+
+
+def th_leg(n, n_steps, rank, world):
+    """BASELINE configs[4]: lid-driven cavity, Taylor-Hood P2/P1 on the unit cube n (43 -> 1 975 509 velocity + 85 184 pressure
+    dofs), nu = 0.01, rho = 1, dt = 0.01, backward Euler, Newton per step - through the solver class, as a user runs it."""
+    import copy
+    import logging
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    t0 = time.perf_counter()
+    mesh = UnitCubeMesh(n, n, n)
+    bcs = OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
+    bcs["lid"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 1.0)), 'boundary_id': 2,
+                  'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((1, 0, 0))}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'boundary_conditions': bcs,
+              'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
+              'material': {'density': 1.0, 'kinematic_viscosity': 0.01}})
+    s['solver_settings']['transient_settings'] = {'transient': True, 'starting_time': 0.0, 'time_step': 0.01,
+                                                  'ending_time': 0.01 * n_steps - 1e-9}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
+    s['report_settings'] = {"logging_level": logging.ERROR, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = CoupledNavierStokesSolver(s)
+    parallel.barrier()
+    t1 = time.perf_counter()
+    w = solver.solve()
+    parallel.barrier()
+    t2 = parallel.max_over_ranks(time.perf_counter() - t1)
+    W4 = w.vector().array().reshape(-1, 4)
+    nv = mesh.num_vertices()
+    n_dof = 3 * len(W4) + nv
+    return {"workload": "BASELINE configs[4]: lid-driven cavity, Taylor-Hood P2/P1, unit cube n=%d (%d velocity + %d pressure dofs, %d tets), "
+                        "nu=0.01, dt=0.01, %d backward-Euler steps, Newton per step, FGMRES + block preconditioner, %s"
+                        % (n, 3 * len(W4), nv, mesh.num_cells(), n_steps, "1 GPU" if world == 1 else "%d parts" % world),
+            "n_dof": n_dof, "time_steps": int(solver.current_step), "solve_s": round(t2, 4),
+            "dof_per_s": round(n_dof * solver.current_step / t2, 1), "setup_s": round(t1 - t0, 2),
+            "newton_residuals_last_step": [float(v) for v in solver.newton_history],
+            "krylov_iterations_last_step": int(solver.newton_krylov_iterations),
+            "max_speed": float(np.abs(W4[:, :3]).max()), "pressure_range": [float(W4[:nv, 3].min()), float(W4[:nv, 3].max())]}
+
+
+class Watchdog:
+    """The extra legs must never cost the line: if they overrun their budget (a collective that never completes would be the
+    reason), rank 0 prints what has been measured and every rank leaves."""
+
+    def __init__(self, out, rank, budget_s):
+        import threading
+        self.out, self.rank, self.done = out, rank, threading.Event()
+        self.t = threading.Thread(target=self._run, args=(budget_s,), daemon=True)
+        self.t.start()
+
+    def _run(self, budget_s):
+        if self.done.wait(budget_s):
+            return
+        if self.rank == 0 and self.out is not None:
+            self.out["extra_legs_timed_out"] = True
+            print(json.dumps(self.out), flush=True)
+        else:
+            time.sleep(2.0)
+        os._exit(0)
+
+    def stop(self):
+        self.done.set()
 
 
 def kernel_name(V):
@@ -169,6 +450,48 @@ def main():
         parallel.barrier()      # device sync + (N>1) a 1-double all-reduce over RCCL
         B.synchronize()
 
+    base = {"metric": "DOF/s (assemble+CG solve to 1e-8) on 3D heat transfer", "unit": "DOF/s", "n_gpus": world,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    par = "1 GPU" if world == 1 else "z-slab domain decomposition x%d" % world
+
+    if a.workload == "p2":      # BASELINE configs[3] as the timed leg: the fixed 9.94 M-DOF problem over the ranks (strong)
+        n = a.n if a.n != 99 else 107
+        axis = a.bc_axis if a.bc_axis is not None else 2
+        r = p2_leg(n, axis, rank, world, a.rtol, barrier, steps=a.steps, warmup=a.warmup, recurrence=a.recurrence)
+        if rank == 0:
+            out = dict(base, value=r["dof_per_s"], steps=a.steps, warmup=a.warmup, ms_per_step=r["ms_per_step"], scaling="strong",
+                       config={"workload": r["workload"], "n_dof": r["n_dof"], "n_cells": 6 * n ** 3, "parallelism": par,
+                               "cg_iterations": r["cg_iterations"], "true_rel_residual": r["true_rel_residual"], "recurrence": r["recurrence"]},
+                       assemble_ms_per_step=r["assemble_ms"], symbolic_ms=r["symbolic_ms"],
+                       parity={"max_abs_error_vs_exact_profile": r["max_abs_error_vs_exact_profile"]})
+            k = r["spmv"]
+            hbm = k["algorithmic_bytes_per_launch"] > (256 << 20)
+            out["roofline"] = {"kernel": k["kernel"] + " (hybrid SELL-64/DIA SpMV of the CG2 operator fused with the 3 CG dot products)",
+                               "bound": "hbm", "achieved": k["algorithmic_GBps"] if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": k["frac_of_8TBps"] if hbm else None, "traffic": None, "workload": "rank 0's part of the step workload",
+                               "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
+                               "streamed_GBps": k["streamed_GBps"], "dia_slices": k["dia_slices"], "slices": k["slices"],
+                               "note": "achieved = CSR-equivalent bytes (nnz*12 + n*20) / mean duration of the live launches (HIP events on the "
+                                       "library's stream)" + ("" if hbm else "; this rank's part is cache-resident: no HBM fraction claimed")}
+            print(json.dumps(out))
+        parallel.barrier()
+        parallel.finalize()
+        return
+    if a.workload == "th":      # BASELINE configs[4] as the timed leg (a "step" = one backward-Euler time step with its Newton solves)
+        n = a.n if a.n != 99 else 43
+        r = th_leg(n, a.steps if a.steps != 20 else 10, rank, world)
+        if rank == 0:
+            out = dict(base, metric="DOF/s (Taylor-Hood Navier-Stokes time steps, assemble + Newton/FGMRES solve)", value=r["dof_per_s"],
+                       steps=r["time_steps"], warmup=0, ms_per_step=round(r["solve_s"] * 1e3 / max(r["time_steps"], 1), 3), scaling="strong",
+                       config={"workload": r["workload"], "n_dof": r["n_dof"], "parallelism": par if world == 1 else "node-plan decomposition x%d" % world},
+                       detail={k: r[k] for k in ("newton_residuals_last_step", "krylov_iterations_last_step", "max_speed", "pressure_range", "setup_s")},
+                       roofline={"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                 "note": "kernel rates of this configuration: profiles/*_ns_kernel_stats.csv (rocprofv3 of tools/prof_ns.sh)"})
+            print(json.dumps(out))
+        parallel.barrier()
+        parallel.finalize()
+        return
+
     n = a.n
     axis = a.bc_axis if a.bc_axis is not None else (2 if world == 1 else 0)
     if a.scaling == "weak":
@@ -182,19 +505,18 @@ def main():
     if world > 1 and axis == 2 and a.scaling == "weak":
         print("[bench] note: --bc-axis 2 with weak scaling lengthens the bar between the Dirichlet faces; "
               "iteration counts will grow with N", file=sys.stderr)
-    prob = Problem(n, n, nz, p1, zplanes, axis, rank, world)
+    if a.mesh != "structured":
+        if world != 1:
+            sys.exit("bench.py --mesh %s is a one-GPU measurement" % a.mesh)
+        prob = ShuffledProblem(n, axis, renumber=a.mesh == "renumbered")
+    else:
+        prob = Problem(n, n, nz, p1, zplanes, axis, rank, world)
     n_dof_total = (n + 1) * (n + 1) * (nz + 1)
 
+    recurrence, trial = choose_recurrence(prob, a.rtol, world, a.recurrence, barrier)
     for _ in range(a.warmup):
         prob.step(a.rtol)
-    barrier()
-    t0 = time.perf_counter()
-    asm_ms, stats = 0.0, None
-    for _ in range(a.steps):
-        stats, t_asm = prob.step(a.rtol)
-        asm_ms += t_asm
-    barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    elapsed, asm_ms_step, stats = timed_steps(prob, a.rtol, a.steps, barrier)
     ms_per_step = elapsed * 1e3 / a.steps
 
     out = None
@@ -204,20 +526,23 @@ def main():
                     (n, n_dof_total, 6 * n ** 3, "xyz"[axis], a.rtol)) if world == 1 else (
             "P1 Poisson heat conduction, box %dx%dx%d cells (%d DOF), z-slabs over %d GPUs, "
             "T=350/300 on the %s-faces, Jacobi-PCG rtol %g" % (n, n, nz, n_dof_total, world, "xyz"[axis], a.rtol))
-        out = {
-            "metric": "DOF/s (assemble+CG solve to 1e-8) on 3D heat transfer",
-            "value": round(n_dof_total / (ms_per_step * 1e-3), 1),
-            "unit": "DOF/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "n_dof": n_dof_total, "n_cells": 6 * n * n * nz,
-                       "parallelism": "1 GPU" if world == 1 else "z-slab domain decomposition x%d" % world,
-                       "cg_iterations": stats["iterations"], "true_rel_residual": stats["true_rel_residual"]},
-            "assemble_ms_per_step": round(asm_ms / a.steps, 4),
-            "solve_ms_per_step": round(ms_per_step - asm_ms / a.steps, 4),
-            "symbolic_ms": round(prob.symbolic_ms, 3), "mesh_ms": round(prob.mesh_ms, 3),
-            "update_kernel_ms": round(stats["update_ms"], 5),
-        }
+        if a.mesh != "structured":
+            workload += "; mesh uploaded with RANDOMLY PERMUTED vertices and cells (%s)" % (
+                "the library's locality renumbering on" if a.mesh == "renumbered" else "renumbering off: FS_RENUMBER=0")
+        out = dict(base, value=round(n_dof_total / (ms_per_step * 1e-3), 1), steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(ms_per_step, 4), scaling=a.scaling,
+                   config={"workload": workload, "n_dof": n_dof_total, "n_cells": 6 * n * n * nz, "parallelism": par,
+                           "cg_iterations": stats["iterations"], "true_rel_residual": stats["true_rel_residual"],
+                           "recurrence": recurrence},
+                   assemble_ms_per_step=round(asm_ms_step, 4), solve_ms_per_step=round(ms_per_step - asm_ms_step, 4),
+                   symbolic_ms=round(prob.symbolic_ms, 3), mesh_ms=round(prob.mesh_ms, 3),
+                   update_kernel_ms=round(stats["update_ms"], 5))
+        # key order of the round-1/2 lines: metric, value, unit, ...
+        out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data", "config", "assemble_ms_per_step", "solve_ms_per_step", "symbolic_ms",
+                                   "mesh_ms", "update_kernel_ms")}
+        if trial:
+            out["config"]["recurrence_trial_ms_per_step"] = trial
         step_kernel = kernel_rates(stats, prob.V)
         hbm_resident = step_kernel["streamed_bytes_per_launch"] > (256 << 20)
         if hbm_resident:
@@ -231,8 +556,42 @@ def main():
                                    "note": "1 M DOF per GPU stays in the Infinity Cache: see dominant_kernel_on_step_workload for the "
                                            "cache rates; the HBM roofline of this kernel is measured by the default N=1 run (10 M DOF)"}
 
+    # ---- N > 1: the legs the north_star is stated on, outside the timed region, under a watchdog ----
+    if world > 1 and a.extra != "none":
+        legs = ["strong"] + (["p2"] if world == 8 else []) + (["th"] if world == 4 else []) if a.extra == "auto" else a.extra.split(",")
+        dog = Watchdog(out, rank, a.extra_budget)
+        t_extra = time.perf_counter()
+        try:
+            a_ms, h_ms = B.comm_benchmark(prob.V, 200)
+            if rank == 0:
+                out["comm"] = {"allreduce_3_doubles_ms": round(a_ms, 5), "halo_exchange_ms": round(h_ms, 5),
+                               "halo_bytes_per_neighbour": 8 * (n + 1) * (n + 1),
+                               "what": "mean of 200 back-to-back in-stream calls (HIP events), as a CG iteration issues them"}
+            del prob
+            if "strong" in legs:
+                r = strong_leg(a.strong_n, axis, rank, world, a.rtol, barrier)
+                if rank == 0:
+                    out["strong"] = r
+            if "p2" in legs:
+                r = p2_leg(a.p2_n, 2, rank, world, a.rtol, barrier)
+                if rank == 0:
+                    out["configs3_p2"] = r
+            if "th" in legs:
+                r = th_leg(a.th_n, 10, rank, world)
+                if rank == 0:
+                    out["configs4_th"] = r
+        except Exception as e:          # an extra leg must not cost the line
+            if rank == 0:
+                out["extra_legs_error"] = repr(e)[:400]
+        if rank == 0:
+            out["extra_legs_s"] = round(time.perf_counter() - t_extra, 2)
+        dog.stop()
+        prob = None
+
     if world == 1:
         x_gpu = prob.x.get()
+        if a.mesh != "structured":
+            x_gpu = prob.to_structured(x_gpu)
         # --- the dominant kernel on an HBM-resident problem of the same family (10 M DOF): the roofline of the line ---
         if not a.no_hbm_case and "roofline" not in out:
             del prob

@@ -120,6 +120,18 @@ class DeviceMesh(_Handle):
         return xyz, cells, gid
 
 
+def locality_order(coords, cells):
+    """(vertex_order, cell_order): the order in which to upload the vertices and cells of a mesh that arrives in file order
+    (Morton curve of the coordinates, computed on the device; fs_mesh_locality_order).  vertex_order[k] = old id of new
+    vertex k."""
+    co, ce = L.f64(coords), L.i32(cells)
+    vo = np.empty(co.shape[0], dtype=np.int32)
+    cord = np.empty(ce.shape[0], dtype=np.int32)
+    L.check(L.load().fs_mesh_locality_order(co.shape[1], co.shape[0], L.p_f64(co), ce.shape[0], L.p_i32(ce), ce.shape[1],
+                                            L.p_i32(vo), L.p_i32(cord)), "fs_mesh_locality_order")
+    return vo, cord
+
+
 class DeviceSpace(_Handle):
     """CG1 (scalar or 3-vector) space + sparsity (FunctionSpace, SolverBase.py:260-275)."""
     _destroy = "fs_space_destroy"
@@ -631,6 +643,14 @@ def comm_allgather(values, n_max):
 
 def halo_exchange(space, v):
     L.check(L.load().fs_halo_exchange(space.h, v.h), "fs_halo_exchange")
+
+
+def comm_benchmark(space, reps=200):
+    """(allreduce_ms, halo_ms): mean latency of the 3-double all-reduce and of this space's ghost refresh, as a CG
+    iteration issues them.  Collective (every rank calls it); zeros on one rank."""
+    a, h = C.c_double(), C.c_double()
+    L.check(L.load().fs_comm_benchmark(space.h, int(reps), C.byref(a), C.byref(h)), "fs_comm_benchmark")
+    return a.value, h.value
 
 
 def set_option(name, value):

@@ -375,3 +375,46 @@ extern "C" int fs_halo_exchange(fs_space_t space, fs_vector_t v) {
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;
 }
+
+// Latency of the two collectives of a CG iteration, as the solver issues them: `reps` back-to-back 3-double all-reduces
+// in the compute stream, and `reps` ghost refreshes of a scratch vector of this space (pack, grouped send / recv on the
+// communication stream, wait), each timed with HIP events on the compute stream.  Collective: every rank calls it.
+extern "C" int fs_comm_benchmark(fs_space_t space, int reps, double* allreduce_ms, double* halo_ms) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(reps > 0, "fs_comm_benchmark: reps must be positive");
+    if (allreduce_ms) *allreduce_ms = 0.0;
+    if (halo_ms) *halo_ms = 0.0;
+    fs_runtime& rt = fs_rt();
+    if (!rt.comm) return FS_OK;
+    hipStream_t s = rt.stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FS_HIP(hipEventCreate(&e0));
+    FS_HIP(hipEventCreate(&e1));
+    int rc = FS_OK;
+    float ms = 0.f;
+    dbuf<double> three, v;
+    if ((rc = three.alloc(4)) == FS_OK && (rc = three.zero(s)) == FS_OK) {
+        for (int pass = 0; pass < 2 && rc == FS_OK; ++pass) {        // pass 0 warms the collective up
+            (void)hipEventRecord(e0, s);
+            for (int i = 0; i < reps && rc == FS_OK; ++i) rc = fs_comm_allreduce_dev(three.p, 3, s);
+            (void)hipEventRecord(e1, s);
+            (void)hipEventSynchronize(e1);
+        }
+        if (rc == FS_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && allreduce_ms) *allreduce_ms = (double)ms / reps;
+    }
+    if (rc == FS_OK && space && space->halo.active && halo_ms) {
+        if ((rc = v.alloc(space->n_dofs_local + 2)) == FS_OK && (rc = v.zero(s)) == FS_OK) {
+            for (int pass = 0; pass < 2 && rc == FS_OK; ++pass) {
+                (void)hipEventRecord(e0, s);
+                for (int i = 0; i < reps && rc == FS_OK; ++i) rc = fs_halo_exchange_dev(space, v.p, s);
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+            }
+            if (rc == FS_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *halo_ms = (double)ms / reps;
+        }
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

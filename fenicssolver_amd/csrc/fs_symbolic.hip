@@ -1059,3 +1059,110 @@ extern "C" int fs_space_get_edges(fs_space_t space, int64_t* n_edges, int32_t* e
     if (edges && space->n_edges) FS_CHECK(space->edges.download(edges, 2 * space->n_edges, fs_rt().stream));
     return FS_OK;
 }
+
+// ---- locality order of an uploaded mesh -------------------------------------------------------------------------------
+// DOLFIN renumbers the dofs of every FunctionSpace for locality when it builds the dofmap (reorder_dofs_serial behind
+// FunctionSpace(...), SolverBase.py:260-275): a mesh file's vertex order says nothing about which vertices are neighbours.
+// The equivalent here is an order of the VERTICES (the dof nodes of CG1; CG2 edge nodes follow their end points) along the
+// Morton curve of their coordinates - 21 bits per axis, one 64-bit radix sort on the device - and of the CELLS by the
+// smallest new index of their vertices (a stable 32-bit sort, so cells keep their file order among equals).  Rows 64 by 64
+// (a SELL slice, one wavefront) then gather x from a few nearby cache lines, and the contiguous eighth of the rows one XCD
+// sweeps is one compact region of the mesh whose x entries stay in that XCD's L2.  The caller applies the two
+// permutations when it uploads the mesh (fenicssolver_amd/fem.py does, for file meshes) and maps results back: the
+// numbering the user sees never changes.
+__device__ __forceinline__ uint64_t fs_spread21(uint64_t v) {      // ...abc -> ...a00b00c
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ void k_morton_keys(int64_t nv, int gdim, const double* __restrict__ xyz, double x0, double y0, double z0,
+                              double sx, double sy, double sz, uint64_t* __restrict__ key, int32_t* __restrict__ idx) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nv; i += stride) {
+        const double* p = xyz + i * gdim;
+        const uint64_t a = (uint64_t)fmin(fmax((p[0] - x0) * sx, 0.0), 2097151.0);
+        const uint64_t b = (uint64_t)fmin(fmax((p[1] - y0) * sy, 0.0), 2097151.0);
+        const uint64_t c = gdim == 3 ? (uint64_t)fmin(fmax((p[2] - z0) * sz, 0.0), 2097151.0) : 0ull;
+        key[i] = fs_spread21(a) | fs_spread21(b) << 1 | fs_spread21(c) << 2;
+        idx[i] = (int32_t)i;
+    }
+}
+
+__global__ void k_invert_order(int64_t n, const int32_t* __restrict__ order, int32_t* __restrict__ rank) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) rank[order[i]] = (int32_t)i;
+}
+
+__global__ void k_cell_first_vertex(int64_t nc, int vpc, const int32_t* __restrict__ cells, const int32_t* __restrict__ rank,
+                                    uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        int32_t m = INT32_MAX;
+        for (int j = 0; j < vpc; ++j) {
+            const int32_t r = rank[cells[c * vpc + j]];
+            m = r < m ? r : m;
+        }
+        key[c] = (uint32_t)m;
+        idx[c] = (int32_t)c;
+    }
+}
+
+extern "C" int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
+                                      int32_t* vertex_order, int32_t* cell_order) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(xyz && cells && vertex_order && cell_order, "fs_mesh_locality_order: null pointer");
+    FS_REQUIRE((gdim == 3 && verts_per_cell == 4) || (gdim == 2 && verts_per_cell == 3), "fs_mesh_locality_order: tetrahedra in 3-D or triangles in 2-D");
+    FS_REQUIRE(nv > 0 && nc > 0 && nv < (int64_t)INT32_MAX && nc < (int64_t)INT32_MAX, "fs_mesh_locality_order: bad sizes");
+    hipStream_t s = fs_rt().stream;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < nv; ++i)
+        for (int d = 0; d < gdim; ++d) {
+            const double v = xyz[i * gdim + d];
+            lo[d] = v < lo[d] ? v : lo[d];
+            hi[d] = v > hi[d] ? v : hi[d];
+        }
+    // one cell size for all axes (the curve then visits cubes, not bricks, of an elongated domain)
+    double ext = 0.0;
+    for (int d = 0; d < gdim; ++d) ext = hi[d] - lo[d] > ext ? hi[d] - lo[d] : ext;
+    const double sc = ext > 0.0 ? 2097151.0 / ext : 0.0;
+    for (int64_t i = 0; i < nc * verts_per_cell; ++i)
+        FS_REQUIRE(cells[i] >= 0 && cells[i] < nv, "fs_mesh_locality_order: cell %lld references vertex %d outside [0,%lld)",
+                   (long long)(i / verts_per_cell), cells[i], (long long)nv);
+    dbuf<double> dx;
+    dbuf<uint64_t> k_in, k_out;
+    dbuf<int32_t> v_in, v_out, rank, dc, c_in, c_out;
+    dbuf<uint32_t> ck_in, ck_out;
+    dbuf<char> tmp;
+    FS_CHECK(dx.alloc(nv * gdim));
+    FS_CHECK(dx.upload(xyz, nv * gdim, s));
+    FS_CHECK(k_in.alloc(nv)); FS_CHECK(k_out.alloc(nv)); FS_CHECK(v_in.alloc(nv)); FS_CHECK(v_out.alloc(nv)); FS_CHECK(rank.alloc(nv));
+    hipLaunchKernelGGL(k_morton_keys, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, gdim, dx.p, lo[0], lo[1], gdim == 3 ? lo[2] : 0.0,
+                       sc, sc, sc, k_in.p, v_in.p);
+    FS_KERNEL_CHECK();
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)nv, 0, 63, s));
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)nv, 0, 63, s));
+    hipLaunchKernelGGL(k_invert_order, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, v_out.p, rank.p);
+    FS_KERNEL_CHECK();
+    FS_CHECK(v_out.download(vertex_order, nv, s));
+    FS_CHECK(dc.alloc(nc * verts_per_cell));
+    FS_CHECK(dc.upload(cells, nc * verts_per_cell, s));
+    FS_CHECK(ck_in.alloc(nc)); FS_CHECK(ck_out.alloc(nc)); FS_CHECK(c_in.alloc(nc)); FS_CHECK(c_out.alloc(nc));
+    hipLaunchKernelGGL(k_cell_first_vertex, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, nc, verts_per_cell, dc.p, rank.p, ck_in.p, c_in.p);
+    FS_KERNEL_CHECK();
+    size_t tb2 = 0;
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, ck_in.p, ck_out.p, c_in.p, c_out.p, (int)nc, 0, 32, s));
+    if ((int64_t)tb2 + 16 > tmp.n) FS_CHECK(tmp.alloc((int64_t)tb2 + 16));
+    FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, ck_in.p, ck_out.p, c_in.p, c_out.p, (int)nc, 0, 32, s));
+    FS_CHECK(c_out.download(cell_order, nc, s));
+    return FS_OK;
+}

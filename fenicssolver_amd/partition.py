@@ -247,3 +247,67 @@ def build_p2_plan(cells, owner, rank, part, local_edges, global_edges):
             raise AssertionError("an edge to send is not a local edge")
         send_lists.append(np.concatenate([np.asarray(part.send_lists[qi], dtype=np.int64), node_of_edge[pos]]).astype(np.int32))
     return P2Plan(nvo + neo, l2g_nodes, list(part.neighbors), send_lists, recv_lists)
+
+
+def build_p2_plan_local(cells, gid, owner, rank, neighbors, device_edges, n_global_vertices):
+    """The CG2 node plan of one rank from ITS OWN part only - nothing of global size is touched (what DOLFIN's distributed
+    dofmap builds from the local mesh and the shared-entity tables under mpirun).
+
+    cells [nc,4]: this rank's cells as LOCAL vertex ids (every cell touching an owned vertex: one ghost-cell layer);
+    gid [nv] / owner [nv]: global id and owning rank of every local vertex (owned vertices first); neighbors: the ranks
+    owning ghost vertices; device_edges [ne,2]: the device's edge table in node order (local vertex ids, owned edges first;
+    an edge belongs to the rank owning its endpoint of smaller GLOBAL id - fs_space_create applies the same rule).
+
+    Why local data suffices: an edge this rank owns has its smaller endpoint here, so every cell holding it touches an owned
+    vertex and is a local cell; the neighbour q stores that edge as a ghost exactly when one of those cells also touches a
+    q-owned vertex - a property of local cells.  Both sides of an exchange order its nodes the same way: vertices by global id,
+    then edges by the global ids (g0, g1) of their end points."""
+    cells = np.asarray(cells, dtype=np.int64)
+    gid = np.asarray(gid, dtype=np.int64)
+    owner = np.asarray(owner)
+    nv = len(gid)
+    nvo = int((owner == rank).sum())
+    if not np.all(owner[:nvo] == rank):
+        raise AssertionError("local vertices are not numbered owned-first")
+    le = np.asarray(device_edges, dtype=np.int64).reshape(-1, 2)
+    ga, gb = gid[le[:, 0]], gid[le[:, 1]]
+    first_is_small = ga < gb
+    g0, g1 = np.where(first_is_small, ga, gb), np.where(first_is_small, gb, ga)
+    e_owner = np.where(first_is_small, owner[le[:, 0]], owner[le[:, 1]])
+    neo = int((e_owner == rank).sum())
+    if not (np.all(e_owner[:neo] == rank) and np.all(e_owner[neo:] != rank)):
+        raise AssertionError("device edge table is not ordered owned-first")
+    ne = len(le)
+    node_of_vertex = np.where(np.arange(nv) < nvo, np.arange(nv), np.arange(nv) + neo)
+    node_of_edge = np.where(np.arange(ne) < neo, nvo + np.arange(ne), nv + np.arange(ne))
+    ng = int(n_global_vertices)
+    lkey = g0 * ng + g1
+    lsort = np.argsort(lkey)
+    cell_owner = owner[cells]
+    mine_in_cell = cell_owner == rank
+    send_lists, recv_lists = [], []
+    for q in neighbors:
+        gv = np.nonzero(owner == q)[0]
+        gv = gv[np.argsort(gid[gv])]
+        ge = np.nonzero(e_owner == q)[0]
+        ge = ge[np.argsort(lkey[ge])]
+        recv_lists.append(np.concatenate([node_of_vertex[gv], node_of_edge[ge]]).astype(np.int32))
+        sel = (cell_owner == q).any(axis=1)
+        touch, tmine = cells[sel], mine_in_cell[sel]
+        sv = np.unique(touch[tmine])                               # my vertices in cells that are local to q as well
+        sv = sv[np.argsort(gid[sv])]
+        a = np.concatenate([touch[:, i] for i, _ in _TET_EDGES])
+        b = np.concatenate([touch[:, j] for _, j in _TET_EDGES])
+        ka, kb = gid[a], gid[b]
+        small_a = ka < kb
+        own = np.where(small_a, owner[a], owner[b]) == rank
+        k = np.unique(np.where(small_a, ka, kb)[own] * ng + np.where(small_a, kb, ka)[own])
+        pos = lsort[np.searchsorted(lkey[lsort], k)] if len(k) else np.zeros(0, dtype=np.int64)
+        if len(k) and not np.array_equal(lkey[pos], k):
+            raise AssertionError("an edge to send is not in the device's edge table")
+        send_lists.append(np.concatenate([node_of_vertex[sv], node_of_edge[pos]]).astype(np.int32))
+    plan = P2Plan(nvo + neo, None, [int(q) for q in neighbors], send_lists, recv_lists)
+    plan.node_of_vertex, plan.node_of_edge = node_of_vertex, node_of_edge
+    plan.edge_gid_pairs = (g0, g1)          # global end points of every local edge, in device edge order
+    plan.n_owned_vertices, plan.n_owned_edges = nvo, neo
+    return plan

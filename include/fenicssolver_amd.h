@@ -98,6 +98,13 @@ int fs_mesh_info(fs_mesh_t mesh, int64_t* nv, int64_t* nc, int64_t* n_owned);
  * global vertex ids[nv] (identity for uploaded meshes). */
 int fs_mesh_get(fs_mesh_t mesh, double* xyz, int32_t* cells, int64_t* global_ids);
 int fs_mesh_destroy(fs_mesh_t mesh);
+/* Locality order of a mesh that arrives in file order (DOLFIN reorders the dofs of every FunctionSpace when it builds
+ * the dofmap, SolverBase.py:260-275): vertex_order[k] = the vertex to upload k-th (Morton curve of the coordinates),
+ * cell_order[k] = the cell to upload k-th (by the smallest new index of its vertices, file order among equals).  Computed
+ * on the device; host arrays in, host arrays out; nothing is created.  The caller uploads xyz[vertex_order] and the
+ * re-indexed cells[cell_order] through fs_mesh_create and keeps the permutation to translate indices and results. */
+int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
+                           int32_t* vertex_order, int32_t* cell_order);
 
 /* ---- function space + sparsity (dolfin.FunctionSpace, SolverBase.py:260-275;
  *      the sparsity pattern DOLFIN builds inside the first assemble()) --------- */
@@ -468,6 +475,10 @@ int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_t* neighbor
 int fs_space_set_halo_indexed(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
                               const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
 int fs_halo_exchange(fs_space_t space, fs_vector_t v);
+/* Mean latency (ms) of the two collectives of a distributed CG iteration as the solver issues them - the 3-double
+ * ncclAllReduce behind VecDot (SolverBase.py:634 under mpirun) and the ghost refresh of this space's halo plan behind
+ * MatMult's VecScatter - over `reps` back-to-back calls (HIP events).  Collective; zeros on one rank. */
+int fs_comm_benchmark(fs_space_t space, int reps, double* allreduce_ms, double* halo_ms);
 
 #ifdef __cplusplus
 }

@@ -134,3 +134,50 @@ def test_p2_exchange_plan_is_consistent_between_ranks(world):
             assert np.array_equal(sent_gids, want_gids)
             assert np.all(plans[q].send_lists[back] < plans[q].n_owned_nodes)
     assert owned_total == nvg + len(edges_g) and np.all(seen == 1)         # the owned sets partition the P2 nodes
+
+
+def _emulated_device_edges(part, owner, n_global):
+    """What fs_space_create numbers on a part: the edges of the local cells, owned ones first (owner = owner of the end point
+    of smaller global id), each group ascending by (local v0, local v1)."""
+    c = part.cells.astype(np.int64)
+    pairs = np.concatenate([np.sort(c[:, [i, j]], axis=1) for i, j in partition._TET_EDGES])
+    pairs = np.unique(pairs, axis=0)
+    g = part.l2g[pairs]
+    small = np.where(g[:, 0] < g[:, 1], pairs[:, 0], pairs[:, 1])
+    mine = owner[part.l2g[small]] == part.rank
+    return np.concatenate([pairs[mine], pairs[~mine]]).astype(np.int32)
+
+
+@pytest.mark.parametrize("mesh_kind,world", [("box", 2), ("box", 3), ("data", 4)])
+def test_local_p2_plan_equals_the_plan_from_the_global_mesh(data_dir, mesh_kind, world):
+    """partition.build_p2_plan_local sees only one rank's cells; it must produce the exchanges build_p2_plan derives from the
+    global mesh, and sender and receiver must agree on the order of every exchange."""
+    if mesh_kind == "box":
+        co, ce = fo.box_mesh((0, 0, 0), (1, 1, 2), 3, 4, 9)
+        owner = partition.slab_owner(co, world, axis=2)
+    else:
+        co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+        owner = partition.rcb_owner(co, world)
+    ce = np.sort(ce, axis=1)
+    ng = len(co)
+    ge = np.unique(np.concatenate([ce[:, [i, j]] for i, j in partition._TET_EDGES]), axis=0)      # global edge table (v0 < v1)
+    plans, parts = [], []
+    for r in range(world):
+        part = partition.build_local_part(ce, owner, r)
+        dev_edges = _emulated_device_edges(part, owner, ng)
+        ref = partition.build_p2_plan(ce, owner, r, part, dev_edges, ge)
+        loc = partition.build_p2_plan_local(part.cells, part.l2g, owner[part.l2g], r, part.neighbors, dev_edges, ng)
+        assert loc.n_owned_nodes == ref.n_owned_nodes and loc.neighbors == ref.neighbors
+        for a, b in zip(loc.send_lists, ref.send_lists):
+            assert np.array_equal(a, b)
+        for a, b in zip(loc.recv_lists, ref.recv_lists):
+            assert np.array_equal(a, b)
+        plans.append((loc, ref))
+        parts.append(part)
+    # the k-th node a rank sends is the k-th node its neighbour receives (compared through global node ids)
+    for r in range(world):
+        loc, ref = plans[r]
+        for qi, q in enumerate(loc.neighbors):
+            other, oref = plans[q]
+            back = other.neighbors.index(r)
+            assert np.array_equal(ref.l2g_nodes[loc.send_lists[qi]], oref.l2g_nodes[other.recv_lists[back]])

@@ -627,3 +627,45 @@ def test_triangle_mesh_kernels_match_oracle(gpu):
     x = gpu.DeviceVector(V.n_local)
     st = gpu.krylov_solve(A, b, x, rtol=1e-13, max_iter=2000)
     assert st["converged"] == 1 and np.abs(x.get() - exact).max() <= 1e-10
+
+
+def test_locality_order_of_a_shuffled_mesh(gpu, data_dir):
+    """fs_mesh_locality_order: both outputs are permutations; uploading the mesh in that order and un-permuting gives the SAME
+    operator bit for bit in structure and <= 1e-12 in value, and the same solution (parity on the permuted data/mesh.xml)."""
+    co, ce = fo.read_dolfin_xml_mesh(os.path.join(data_dir, "mesh.xml"))
+    rng = np.random.default_rng(3)
+    p = rng.permutation(len(co))                      # file id of every original vertex
+    co_f = np.empty_like(co)
+    co_f[p] = co
+    ce_f = np.sort(p[ce], axis=1)[rng.permutation(len(ce))].astype(np.int32)
+    vo, cord = gpu.locality_order(co_f, ce_f)
+    assert np.array_equal(np.sort(vo), np.arange(len(co))) and np.array_equal(np.sort(cord), np.arange(len(ce)))
+    dev_of_file = np.empty(len(co), dtype=np.int64)
+    dev_of_file[vo] = np.arange(len(co))
+    # locality: consecutive vertices are close (the file order has mean distance ~ domain size)
+    d_new = np.linalg.norm(np.diff(co_f[vo], axis=0), axis=1).mean()
+    d_old = np.linalg.norm(np.diff(co_f, axis=0), axis=1).mean()
+    assert d_new < 0.25 * d_old
+    mesh = gpu.DeviceMesh(co_f[vo], np.sort(dev_of_file[ce_f[cord]], axis=1).astype(np.int32))
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    M = _csr(A)
+    q = dev_of_file[p]                                # device id of every original vertex
+    Mo = M[q][:, q].tocsr()
+    Mo.sort_indices()
+    R = fo.assemble_p1_scalar(co, ce, 20.0)
+    _assert_same_pattern(Mo, R)
+    assert np.abs(Mo.data - R.tocsr().data).max() <= RTOL_ASSEMBLY * np.abs(R.data).max()
+    # config 1 on the renumbered upload: T = 350 - 2.5 z in the original numbering
+    _, fm = fo.read_dolfin_xml_meshfunction(os.path.join(data_dir, "mesh_facet_region.xml"))
+    facets, _, _ = fo.facet_numbering(ce)
+    d1, d2 = fo.dirichlet_dofs_p1(facets, fm, 1), fo.dirichlet_dofs_p1(facets, fm, 2)
+    dofs = q[np.concatenate([d1, d2])].astype(np.int32)
+    vals = np.concatenate([np.full(len(d1), 350.0), np.full(len(d2), 300.0)])
+    b = gpu.DeviceVector(V.n_owned)
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    x = gpu.DeviceVector(V.n_owned)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-13, max_iter=5000)
+    assert st["converged"] == 1
+    assert np.abs(x.get()[q] - (350.0 - 2.5 * co[:, 2])).max() <= 1e-9
