@@ -53,9 +53,12 @@ def trim_memory():
 
 class _Handle:
     _destroy = None
+    _serials = [0]
 
     def __init__(self):
         self.h = C.c_void_p()
+        _Handle._serials[0] += 1
+        self.serial = _Handle._serials[0]      # never reused (id() is): what caches keyed on a device object compare
 
     def close(self):
         if self.h is not None and self.h.value:

@@ -328,6 +328,6 @@ class TimeGrid:
         if dt is not None:
             return self.ts["starting_time"] + dt * (i - 1)
         series = self.ts.get("time_series")
-        if series is None or len(series) < i:
+        if series is None or len(series) <= i:          # (the reference tests `<` and then indexes past the end)
             raise SolverError("time point can only be a sequence of time series or derived from constant time step")
         return series[i]

@@ -1213,7 +1213,11 @@ static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* r
                            hipStream_t s, const double* val_override = nullptr) {
     fs_space_s* sp = A->space;
     if (!spmv_is_split(sp)) {
-        FS_CHECK(fs_halo_exchange_dev(sp, x, s));
+        if (sp->halo.begun) {           // started by the caller ahead of this product (pipelined CG)
+            FS_CHECK(fs_halo_end_dev(sp, s));
+            sp->halo.begun = false;
+        } else
+            FS_CHECK(fs_halo_exchange_dev(sp, x, s));
         launch_spmv<DOTS>(A, x, y, rvec, partials, status, s, val_override);
         return FS_OK;
     }
@@ -1801,7 +1805,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (!fuse_sums) {
                         // the halo of the new w goes first on the communication stream (the boundary rows of the next
                         // product wait for it), the reduction of the new sums behind it
-                        if (!sp->halo.begun && spmv_is_split(sp)) {
+                        // (whether a rank's product is split is a LOCAL property - a thin part may have no interior slice -
+                        // while the order of halo and reduction on the communicator must be the same everywhere: the
+                        // exchange is begun here on every rank with a plan, split or not)
+                        if (!sp->halo.begun && sp->halo.active) {
                             FS_CHECK(fs_halo_begin_dev(sp, ws.pw.p, s));
                             sp->halo.begun = true;
                         }

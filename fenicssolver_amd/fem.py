@@ -661,6 +661,15 @@ class FunctionSpace:
         self._component = _component
         self._parent = _parent
         self._device = None
+        FunctionSpace._next_serial += 1
+        self._serial = FunctionSpace._next_serial
+
+    _next_serial = 0
+
+    def serial(self):
+        """A number no other FunctionSpace of this process ever had (id() is recycled after garbage collection: caches keyed
+        on a space use this)."""
+        return self._serial
 
     def mesh(self):
         return self._mesh

@@ -92,8 +92,13 @@ def library():
         "H5Gopen2": (_hid, [_hid, C.c_char_p, _hid]),
         "H5Gclose": (C.c_int, [_hid]),
     }
+    optional = ("H5Gget_num_objs", "H5Gget_objname_by_idx")     # deprecated API: absent from a libhdf5 built without it
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if name in optional:
+                continue
+            raise SolverError("libhdf5 lacks {}: cannot read HDF5 / HDF5-backed XDMF meshes".format(name))
         fn.restype, fn.argtypes = res, args
     if lib.H5open() < 0:
         raise SolverError("H5open() failed")
@@ -161,6 +166,9 @@ class H5File:
         if g < 0:
             raise SolverError("{}: no group '{}'".format(self.path, group))
         n = C.c_uint64(0)
+        if not hasattr(self.lib, "H5Gget_num_objs") or not hasattr(self.lib, "H5Gget_objname_by_idx"):
+            self.lib.H5Gclose(g)
+            raise SolverError("{}: this libhdf5 was built without the group-listing calls (H5Gget_num_objs)".format(self.path))
         self.lib.H5Gget_num_objs(g, C.byref(n))
         out = []
         for i in range(n.value):

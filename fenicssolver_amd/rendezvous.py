@@ -35,6 +35,9 @@ def world():
     return 0, 1, 0
 
 
+_published = {}      # rank 0: the id and nonces it published (cleanup() republishes when a hello turns out to have been stale)
+
+
 def _directory():
     d = os.environ.get("FS_RDZV_DIR")
     if d:
@@ -46,12 +49,23 @@ def _key():
     k = os.environ.get("FS_RDZV_KEY")
     if k:
         return k
+    if os.environ.get("FS_RDZV_DIR"):
+        # a shared directory is the multi-node set-up: the parent pid differs from node to node, so the key is made of what the
+        # launcher gives EVERY rank alike - address, port and the job / run id when there is one
+        job = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("PMI_JOBID") or "0"
+        return "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "local").replace("/", "_"), os.environ.get("MASTER_PORT", "0"), job)
     return "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
 
 
 def _write_atomic(path, data: bytes):
     tmp = "%s.tmp.%d" % (path, os.getpid())
-    with open(tmp, "wb") as fh:
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    # the directory may be world-writable (/dev/shm): never follow a link somebody planted, never leave the file readable
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "wb") as fh:
         fh.write(data)
     os.replace(tmp, path)
 
@@ -86,6 +100,7 @@ def exchange_unique_id(rank: int, size: int, make_id, id_bytes: int = 128) -> by
         uid = bytes(make_id())
         assert len(uid) == id_bytes
         _write_atomic(id_path, uid + b"".join(nonces))
+        _published.update(uid=uid, nonces=nonces)
         return uid
     nonce = os.urandom(16)
     _write_atomic("%s.hello.%d" % (base, rank), nonce)
@@ -110,7 +125,20 @@ def cleanup(rank: int, size: int):
     base = os.path.join(_directory(), "fsamd_" + _key())
     deadline = time.monotonic() + 30.0
     while any(os.path.exists("%s.hello.%d" % (base, r)) for r in range(1, size)) and time.monotonic() < deadline:
+        # A hello file left by a crashed run (fixed FS_RDZV_KEY) may have been read before its rank rewrote it: that rank is
+        # still waiting for ITS nonce.  Publish the same id again with the nonces as they are now.
+        nonces = _published.get("nonces")
+        if nonces is not None:
+            changed = False
+            for r in range(1, size):
+                got = _read("%s.hello.%d" % (base, r))
+                if got is not None and len(got) == 16 and got != nonces[r - 1]:
+                    nonces[r - 1] = got
+                    changed = True
+            if changed:
+                _write_atomic(base + ".id", _published["uid"] + b"".join(nonces))
         time.sleep(0.002)
+    _published.clear()
     for p in [base + ".id"] + ["%s.hello.%d" % (base, r) for r in range(1, size)]:
         try:
             os.unlink(p)

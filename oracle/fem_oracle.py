@@ -571,6 +571,50 @@ def pcg_jacobi_single_reduction(A, b, rtol=1e-8, maxit=10000):
     return x, it, hist
 
 
+def pcg_jacobi_pipelined(A, b, rtol=1e-8, maxit=10000):
+    """The pipelined recurrence of fs_krylov.hip (k_pcg_update; Ghysels & Vanroose 2014) on the symmetrically scaled
+    system Ah = D^-1/2 A D^-1/2 - what fs_krylov_opts.pipelined = 1 runs.  PETSc's counterpart is KSPPIPECG
+    (the reference reaches PETSc through SolverBase.py:663-670).
+
+    iteration i:  gamma = r.r, delta = w.r, rho = sum d r^2 (= the unscaled ||r||^2) of r_i, w_i = Ah r_i - reduced WHILE
+                  n = Ah w runs;  stop if rho <= rtol^2 b.b
+                  beta = gamma/gamma_old, alpha = gamma/(delta - beta*gamma/alpha_old)
+                  z = n + beta z ; s = w + beta s ; p = r + beta p ; x += alpha p ; r -= alpha s ; w -= alpha z
+    Returns (x, iterations, history of rho)."""
+    d = A.diagonal()
+    sc = 1.0 / np.sqrt(d)
+    Ah = sp.diags(sc) @ A @ sp.diags(sc)
+    n = A.shape[0]
+    bh = sc * np.asarray(b, dtype=np.float64)
+    x = np.zeros(n)
+    r = bh.copy()
+    w = Ah @ r
+    z = np.zeros(n)
+    s = np.zeros(n)
+    p = np.zeros(n)
+    thresh = rtol * rtol * float(b @ b)
+    gamma_old = alpha_old = 1.0
+    hist = []
+    it = 0
+    while True:
+        gamma, delta, rho = float(r @ r), float(w @ r), float(d @ (r * r))
+        hist.append(rho)
+        if rho <= thresh or it >= maxit:
+            break
+        nv = Ah @ w
+        beta = 0.0 if it == 0 else gamma / gamma_old
+        alpha = gamma / delta if it == 0 else gamma / (delta - beta * gamma / alpha_old)
+        z = nv + beta * z
+        s = w + beta * s
+        p = r + beta * p
+        x += alpha * p
+        r -= alpha * s
+        w -= alpha * z
+        gamma_old, alpha_old = gamma, alpha
+        it += 1
+    return sc * x, it, np.array(hist)
+
+
 def solve_direct(A, b):
     """Sparse LU: the reference's *default* linear solve
     (LinearVariationalSolver linear_solver='default')."""

@@ -81,6 +81,47 @@ def main():
 
     bb = allreduce([float(b @ b)])[0]
     thresh = (1e-10) ** 2 * bb
+    if len(sys.argv) > 3 and sys.argv[3] == "pipelined":
+        # fs_krylov_opts.pipelined: the sums of (r, w) are all-reduced asynchronously while n = Ah w (halo of w + local
+        # product) runs; scaled system, the exchanged vector is w.  The ghost scale factors travel through the halo once.
+        dfull = np.zeros(n_local)
+        dfull[:n_owned] = A.diagonal()
+        halo_exchange(dfull, n_owned, neighbors, send_lists, recv_counts)
+        scl = 1.0 / np.sqrt(dfull)
+        Ah = sp.diags(scl[:n_owned]) @ A @ sp.diags(scl)
+        dv = dfull[:n_owned]
+        x = np.zeros(n_owned)
+        r = np.zeros(n_local)
+        r[:n_owned] = scl[:n_owned] * b
+        halo_exchange(r, n_owned, neighbors, send_lists, recv_counts)
+        w = np.zeros(n_local)
+        w[:n_owned] = Ah @ r
+        r = r[:n_owned].copy()
+        z, s, p = np.zeros(n_owned), np.zeros(n_owned), np.zeros(n_owned)
+        gamma_old = alpha_old = 1.0
+        it = 0
+        while True:
+            ro, wo = r, w[:n_owned]
+            t = torch.tensor([float(ro @ ro), float(wo @ ro), float(dv @ (ro * ro))], dtype=torch.float64)
+            work = dist.all_reduce(t, async_op=True)                   # ... in flight while the product runs
+            halo_exchange(w, n_owned, neighbors, send_lists, recv_counts)
+            nv = Ah @ w
+            work.wait()
+            g, d, rho = t.numpy()
+            if rho <= thresh or it >= 2000:
+                break
+            beta = 0.0 if it == 0 else g / gamma_old
+            alpha = g / d if it == 0 else g / (d - beta * g / alpha_old)
+            z = nv + beta * z
+            s = wo + beta * s
+            p = ro + beta * p
+            x += alpha * p
+            r = ro - alpha * s
+            w[:n_owned] = wo - alpha * z
+            gamma_old, alpha_old = g, alpha
+            it += 1
+        x = scl[:n_owned] * x
+        return finish(co, l2g, n_owned, x, it, n_local, send_lists, rank, world, out)
     x = np.zeros(n_owned)
     r = b.copy()
     z = np.zeros(n_local)
@@ -104,6 +145,10 @@ def main():
         z[:n_owned] = dinv * r
         gamma_old, alpha_old = g, alpha
         it += 1
+    return finish(co, l2g, n_owned, x, it, n_local, send_lists, rank, world, out)
+
+
+def finish(co, l2g, n_owned, x, it, n_local, send_lists, rank, world, out):
     gathered = [None] * world
     dist.all_gather_object(gathered, (l2g[:n_owned], x, it, n_local, [len(sl) for sl in send_lists]))
     if rank == 0:

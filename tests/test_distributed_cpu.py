@@ -65,13 +65,13 @@ def test_owner_functions_cover_all_vertices(data_dir):
         assert off == p.n_local
 
 
-def _run(world, mode, tmp_path):
-    out = str(tmp_path / ("dist_%s_%d.npz" % (mode, world)))
+def _run(world, mode, tmp_path, recurrence="single_reduction"):
+    out = str(tmp_path / ("dist_%s_%s_%d.npz" % (mode, recurrence, world)))
     port = 29500 + (os.getpid() % 2000) + world
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), mode, out]
+           os.path.join(ROOT, "tests", "dist_worker.py"), mode, out, recurrence]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     return np.load(out)
@@ -91,6 +91,27 @@ def test_distributed_cg_matches_single_rank(world, mode, tmp_path):
     # reduction order differs between 1 and N ranks: agreement to 1e-12 relative
     assert np.abs(r["x"] - x1).max() <= 1e-10 * np.abs(x1).max()
     assert np.abs(r["x"] - (350.0 - 50.0 * co[:, 0])).max() <= 1e-6
+
+
+@pytest.mark.parametrize("world,mode", [(2, "slab"), (3, "slab"), (3, "rcb")])
+def test_distributed_pipelined_cg_matches_single_rank(world, mode, tmp_path):
+    """The pipelined recurrence (all-reduce in flight under the product) on 2-3 gloo ranks: the single-rank oracle's solution
+    <= 1e-9 relative, its iteration count within +2 - and the oracle's own restatement of the pipelined recurrence agrees
+    with its single-reduction one."""
+    r = _run(world, mode, tmp_path, recurrence="pipelined")
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 1.8), 5, 4, 9)
+    A = fo.assemble_p1_scalar(co, ce, 20.0)
+    lo, hi = np.nonzero(co[:, 0] == 0.0)[0], np.nonzero(co[:, 0] == 1.0)[0]
+    Ab, bb = fo.apply_dirichlet(A, np.zeros(len(co)), np.concatenate([lo, hi]),
+                                np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), True)
+    x1, it1, h1 = fo.pcg_jacobi_single_reduction(Ab, bb, rtol=1e-10)
+    x2, it2, h2 = fo.pcg_jacobi_pipelined(Ab, bb, rtol=1e-10)
+    assert -1 <= it2 - it1 <= 2 and np.abs(x2 - x1).max() <= 1e-9 * np.abs(x1).max()
+    m = min(len(h1), len(h2), 15)
+    assert np.allclose(h1[:m], h2[:m], rtol=1e-8)
+    assert not np.isnan(r["x"]).any()
+    assert -1 <= int(r["iterations"]) - it1 <= 2
+    assert np.abs(r["x"] - x1).max() <= 1e-9 * np.abs(x1).max()
 
 
 def _device_like_edges(part, owner, rank):

@@ -301,6 +301,10 @@ def test_pipelined_cg_follows_the_single_reduction_recurrence(gpu, n, axis, rtol
     assert np.abs(x1.get() - x0.get()).max() <= max(RTOL_SOLUTION, 30 * rtol) * scale
     xo, ito, _ = fo.pcg_jacobi_single_reduction(P["A"], P["b"], rtol=rtol)       # the oracle's recurrence and answer
     assert -1 <= s1["iterations"] - ito <= 2
+    xp, itp, hp = fo.pcg_jacobi_pipelined(P["A"], P["b"], rtol=rtol)             # the oracle's restatement of k_pcg_update
+    assert abs(s1["iterations"] - itp) <= 1
+    mp = min(len(h1), len(hp), 25)
+    assert np.allclose(h1[:mp], hp[:mp], rtol=1e-6)
     assert np.abs(x1.get() - xo).max() <= max(RTOL_SOLUTION, 30 * rtol) * scale
     if rtol <= 1e-10:            # the linear profile is the exact discrete solution
         assert np.abs(x1.get() - P["exact"]).max() <= 1e-6 * scale
