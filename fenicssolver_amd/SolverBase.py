@@ -330,8 +330,10 @@ class SolverBase():
         return {'linear_solver': 'cg', 'preconditioner': pc, 'relative_tolerance': rtol,
                 'maximum_iterations': max_iter}
 
-    def _device_solve(self, A, b, u, label, method="cg", amg=False, near_nullspace=None, operator_key=None):
+    def _device_solve(self, A, b, u, label, method="cg", amg=False, near_nullspace=None, operator_key=None, global_operator=None):
         """amg=True: the caller is solve_amg (AMG unless solver_parameters name another preconditioner).
+        global_operator: a callable returning the UNDECOMPOSED operator on this rank's GPU (several ranks + AMG: see
+        _replicated_amg_solve).
         operator_key: everything the values of A depend on (None: unknown) - an AMG hierarchy is reused only for a call
         that names the same key; a call without one always builds its own."""
         from . import backend
@@ -348,8 +350,17 @@ class SolverBase():
         # also what keeps badly scaled operators (e.g. permittivities of 1e-10 next to identity rows) honest
         norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc in ("jacobi", "amg")) else 'unpreconditioned')
         loc = u.function_space().localizer()
-        if pc == 'amg':
-            # several GPUs: every rank builds the hierarchy of its own diagonal block (additive Schwarz, no overlap)
+        from . import parallel as _par
+        replicated = (pc == 'amg' and loc is not None and _par.world()[1] > 1 and global_operator is not None
+                      and isinstance(near_nullspace, (str, type(None)))
+                      and sp_.get('amg_decomposition', 'replicated') == 'replicated')
+        if replicated:
+            stats = self._replicated_amg_solve(b, x, V, loc, u.function_space()._ncomp, global_operator, operator_key,
+                                               near_nullspace, rtol, min(max_iter, int(sp_.get('maximum_iterations', 500))), norm,
+                                               float(sp_.get('amg_strength_threshold', 0.0)))
+        elif pc == 'amg':
+            # several GPUs, solver_parameters['amg_decomposition'] = 'schwarz': every rank builds the hierarchy of its own
+            # diagonal block (additive Schwarz, no overlap, no coarse space: the iteration count grows with the number of parts)
             if near_nullspace is not None and not isinstance(near_nullspace, str) and loc is not None:
                 near_nullspace = np.stack([loc.nodes(v)[:V.n_owned] for v in np.asarray(near_nullspace)])
             # The hierarchy depends on the operator only: time steps / load cases that re-assemble the SAME matrix (quasi-static
@@ -402,6 +413,43 @@ class SolverBase():
             ncomp = u.function_space()._ncomp
             u.vector().set_local(parallel.gather_owned(x.get()[:V.n_owned], loc.owned_gids(), loc.n_global, ncomp))
         return u
+
+    def _replicated_amg_solve(self, b, x, V, loc, ncomp, global_operator, key, near_nullspace, rtol, max_iter, norm, theta):
+        """solve_amg on several GPUs.  A hierarchy of the rank-local diagonal blocks (additive Schwarz) has no coarse space that
+        couples the parts: on the cantilever of BASELINE configs[2] cut into 2 / 4 / 8 slabs across its length the 24
+        iterations of one GPU become 166 / 321 / 495 (tools/amg_schwarz_probe.py).  What multigrid needs is the GLOBAL
+        coarse problem, and a 5 M-DOF operator with its hierarchy is a few GB of the 288 GB every MI355X has: so every rank
+        assembles the undecomposed operator as well (assembly is 2 ms, cheaper than any exchange of it), builds the same
+        hierarchy, solves the gathered right-hand side and keeps its own entries - the iteration count of one GPU at any
+        number of parts, no communication inside the solve, the speed of one GPU (not more: the preconditioner is not
+        distributed; 'amg_decomposition': 'schwarz' selects the rank-local hierarchies).  The pressure Laplacian of the
+        Navier-Stokes Schur complement is treated the same way (fs_saddle.hip)."""
+        from . import backend, parallel
+        cached = getattr(self, '_amg_cache', None)
+        if key is not None and cached is not None and cached[0] == ('replicated', key):
+            hierarchy, reused = cached[1], True
+        else:
+            if cached is not None:
+                cached[1].close()
+                self._amg_cache = None
+            Ag = global_operator()
+            hierarchy, reused = backend.AMG(Ag, nullspace=near_nullspace, strength_threshold=theta), False
+            if key is not None:
+                self._amg_cache = (('replicated', key), hierarchy)
+        Vg = hierarchy.A.space
+        bg = parallel.gather_owned(b.get()[:V.n_owned], loc.owned_gids(), loc.n_global, ncomp)
+        if bg.size != Vg.n_owned:
+            raise SolverError('internal error: the undecomposed operator has {} rows, the gathered right-hand side {}'.format(Vg.n_owned, bg.size))
+        bgd = backend.DeviceVector(Vg.n_owned, bg)
+        xg = backend.DeviceVector(Vg.n_local)
+        stats = hierarchy.solve(bgd, xg, rtol=rtol, max_iter=max_iter, norm=norm)
+        stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
+        stats['amg_reused'], stats['amg_decomposition'] = reused, 'replicated'
+        xl = xg.get()[:Vg.n_owned].reshape(loc.n_global, ncomp)[np.asarray(loc.l2g)].reshape(-1)      # owned + ghost entries
+        x.set(np.concatenate([xl, np.zeros(V.n_local - xl.size)]))
+        if key is None:
+            hierarchy.close()
+        return stats
 
     @staticmethod
     def _bc_arrays(bcs):
@@ -1016,7 +1064,39 @@ class SolverBase():
         # near-null space of the elasticity operator: the six rigid-body modes, built on the device from the node
         # coordinates (build_nullspace() below is the host version the reference's API exposes)
         ns = "rigid_body" if isinstance(F, forms.ElasticityForm) and self.dimension == 3 else None
-        return self._device_solve(A, b, u, 'solve_amg', amg=True, near_nullspace=ns, operator_key=key)
+        glob = (lambda: self._undecomposed_elasticity_operator(F, bcs)) if isinstance(F, forms.ElasticityForm) else None
+        return self._device_solve(A, b, u, 'solve_amg', amg=True, near_nullspace=ns, operator_key=key, global_operator=glob)
+
+    def _undecomposed_elasticity_operator(self, F, bcs):
+        """The Dirichlet-eliminated elasticity operator of the WHOLE mesh on this rank's GPU (several ranks, replicated AMG)."""
+        from . import backend, parallel
+        W = F.space.root() if hasattr(F.space, 'root') else F.space
+        mesh, loc, nc = W.mesh(), W.localizer(), W._ncomp
+        cache = mesh.__dict__.setdefault('_undecomposed_device', {})
+        if 'mesh' not in cache:
+            if getattr(mesh, '_slab', None) is not None:          # distributed box: the device generates the whole box
+                nx, ny, nz, p0, p1 = mesh._box
+                cache['mesh'] = backend.DeviceMesh.box(nx, ny, nz, p0, p1)
+            else:
+                cache['mesh'] = backend.DeviceMesh(mesh.coordinates(), mesh.cells())
+        skey = ('space', nc, W.degree())
+        if skey not in cache:
+            cache[skey] = backend.DeviceSpace(cache['mesh'], nc, W.degree())
+        Vg = cache[skey]
+        Ag = backend.DeviceMatrix(Vg)
+        Ag.assemble(lame=(F.mu, F.lmbda))
+        dofs, vals = self._bc_arrays(bcs)
+        if getattr(loc, 'is_local_view', False):
+            # the Dirichlet lists of a distributed mesh are local: owned entries -> global dofs, gathered over the ranks
+            node, comp = dofs // nc, dofs % nc
+            own = node < loc.n_owned
+            gd = np.asarray(loc.l2g)[node[own]] * nc + comp[own]
+            parts = parallel.allgather_index_lists(gd)
+            vparts = parallel.allgather_values(vals[own])
+            dofs, vals = np.concatenate(parts), np.concatenate(vparts)
+        if dofs.size:
+            Ag.apply_dirichlet(backend.DeviceVector(Vg.n_owned), dofs.astype(np.int32), vals, symmetric=True)
+        return Ag
 
     def _amg_operator_key(self, F, bcs):
         """Everything the assembled matrix depends on, or None when that cannot be told cheaply (no hierarchy reuse)."""

@@ -81,6 +81,15 @@ def allgather_index_lists(ids):
     return [got[r, :counts[r]].astype(np.int64) for r in range(len(counts))]
 
 
+def allgather_values(values):
+    """Every rank's float list (one all-gather of the padded lists)."""
+    from . import backend
+    v = np.asarray(values, dtype=np.float64).ravel()
+    counts = backend.comm_allgather([float(len(v))], 1)[:, 0].astype(np.int64)
+    got = backend.comm_allgather(v, max(int(counts.max()), 1))
+    return [got[r, :counts[r]].copy() for r in range(len(counts))]
+
+
 def gather_owned(values_owned, gids_owned, n_global, ncomp=1):
     """Owned dof values of every rank -> the full vector (on every rank).  The values travel in one all-gather of the
     communicator (RCCL; fs_comm_allgather); the owners' global ids are exchanged once per layout and cached."""

@@ -42,6 +42,10 @@ else:
     # the solver API on several ranks (parallel.py)
     import test_gpu_parallel_api as T
     solver = (T.CASES.get(case) or T.DIST_CASES.get(case) or T.NS_CASES[case])()
+    if os.environ.get("FS_TEST_AMG_DECOMPOSITION"):
+        sp = solver.solver_settings.setdefault('solver_parameters', {}) or {}
+        sp['amg_decomposition'] = os.environ["FS_TEST_AMG_DECOMPOSITION"]
+        solver.solver_settings['solver_parameters'] = sp
     u = solver.solve()
     assert solver.function_space.localizer() is not None and parallel.world()[1] == world
     if case in T.DIST_CASES:
