@@ -860,7 +860,10 @@ class FunctionSpace:
             root._device = None
         if root._device is None:
             from . import backend, parallel
-            if parallel.active():
+            if not parallel.active() and not facet_coupling and root._periodic is None and self._wants_renumbering(root):
+                # a mesh in FILE order on one GPU: the same machinery with one part whose numbering is the locality order
+                root._device = self._make_parallel_device(root, backend, parallel, renumber=True)
+            elif parallel.active():
                 if facet_coupling:
                     raise SolverError("interior-facet (IP) terms are single-GPU for now")
                 if root._periodic is not None:
@@ -876,15 +879,35 @@ class FunctionSpace:
                 root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree, coupled_pairs=pairs)
         return root._device
 
+    RENUMBER_MIN_VERTICES = 50000
+
     @staticmethod
-    def _make_parallel_device(root, backend, parallel):
+    def _wants_renumbering(root):
+        """DOLFIN renumbers the dofs of every FunctionSpace for locality (reorder_dofs_serial behind FunctionSpace(...),
+        SolverBase.py:260-275); a mesh FILE's vertex order says nothing about which vertices are neighbours, and the SELL
+        slices of the operator (64 consecutive rows = one wavefront) then gather x from all over the vector: on the 10 M-DOF
+        cube with shuffled vertices the CG product runs at 0.76 instead of 4.9 TB/s, the assembly takes 19 instead of 3.3 ms
+        (bench.py --mesh shuffled / renumbered).  So meshes that do not come from a generator are uploaded in the locality
+        order of fs_mesh_locality_order (Morton curve of the coordinates, computed on the device) - through the Localizer
+        that also serves domain decomposition, with one part: host arrays, dof numbers and results keep the file numbering.
+        FS_RENUMBER = 0 / 1 pins the choice; automatic for tetrahedral file meshes of RENUMBER_MIN_VERTICES vertices or more."""
+        mesh = root._mesh
+        env = os.environ.get("FS_RENUMBER", "")
+        if env == "0" or mesh.topology().dim() != 3 or getattr(mesh, "_box", None) is not None:
+            return False
+        if root._degree == 2 and root._ncomp not in (1, 3, 4):
+            return False
+        return env == "1" or mesh.num_vertices() >= FunctionSpace.RENUMBER_MIN_VERTICES
+
+    @staticmethod
+    def _make_parallel_device(root, backend, parallel, renumber=False):
         """This rank's share of the space: owner-computes vertex slabs along the longest axis,
         one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
         from . import partition
         if root._degree == 2 and (root._ncomp not in (1, 3, 4) or mesh_dim(root) != 3):
             raise SolverError("multi-GPU decomposition is built for P1 spaces and, on tetrahedra, scalar / vector P2 spaces and the "
                               "Taylor-Hood space")
-        rank, size = parallel.ensure_comm()
+        rank, size = (0, 1) if renumber else parallel.ensure_comm()
         mesh = root._mesh
         if getattr(mesh, "_slab", None) is not None:
             # distributed box: the host mesh already IS this rank's part, numbered as the device numbers a slab
@@ -907,7 +930,12 @@ class FunctionSpace:
         if (rank, size) not in cache:
             axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
             owner = partition.slab_owner(co, size, axis=axis)
-            part = partition.build_local_part(ce, owner, rank)
+            vrank = crank = None
+            if FunctionSpace._wants_renumbering(root):          # (file meshes on several ranks: the owned part in locality order too)
+                vo, cord = backend.locality_order(co, ce)
+                vrank, crank = np.empty(len(vo), dtype=np.int64), np.empty(len(cord), dtype=np.int64)
+                vrank[vo], crank[cord] = np.arange(len(vo)), np.arange(len(cord))
+            part = partition.build_local_part(ce, owner, rank, vrank, crank)
             cache[(rank, size)] = (owner, part, backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g))
         owner, part, dm = cache[(rank, size)]
         ds = backend.DeviceSpace(dm, root._ncomp, root._degree)

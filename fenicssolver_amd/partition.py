@@ -64,7 +64,7 @@ class LocalPart:
         self.l2g = l2g                      # [n_local] global vertex id of every local vertex
         self.n_owned = n_owned
         self.cells = cells_local            # [nc_local, 4] local vertex ids (vertex order of the global cell)
-        self.cell_gids = cell_gids          # [nc_local] global cell ids, ascending
+        self.cell_gids = cell_gids          # [nc_local] global cell ids (ascending unless a locality order was given)
         self.neighbors = neighbors          # ranks, ascending
         self.send_lists = send_lists        # per neighbour: owned local ids, ascending global id
         self.recv_counts = recv_counts      # per neighbour: number of ghosts it owns
@@ -84,15 +84,21 @@ class LocalPart:
         return [(s[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel().astype(np.int32) for s in self.send_lists]
 
 
-def build_local_part(cells, owner, rank):
+def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None):
+    """vertex_rank / cell_rank (optional, [n_global] each): a locality order (backend.locality_order) - the owned vertices
+    and the local cells are then numbered by it instead of by their global ids (the order a mesh file happens to have)."""
     cells = np.asarray(cells, dtype=np.int64)
     owner = np.asarray(owner)
     n_global = len(owner)
     cell_owned = owner[cells] == rank
     keep = np.nonzero(cell_owned.any(axis=1))[0]
+    if cell_rank is not None:
+        keep = keep[np.argsort(np.asarray(cell_rank)[keep], kind="stable")]
     lc = cells[keep]
     verts = np.unique(lc)
     mine = verts[owner[verts] == rank]
+    if vertex_rank is not None:
+        mine = mine[np.argsort(np.asarray(vertex_rank)[mine], kind="stable")]
     ghosts = verts[owner[verts] != rank]
     gorder = np.lexsort((ghosts, owner[ghosts]))          # by owner rank, then global id
     ghosts = ghosts[gorder]

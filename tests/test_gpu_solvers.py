@@ -542,3 +542,67 @@ def test_htc_with_an_ambient_temperature_field(gpu):
     ref = fo.solve_direct(*fo.apply_dirichlet(A.tocsr(), b, top, 360.0, True))
     assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
     assert np.ptp(T[co[:, 1] == 0.0]) > 5.0                     # the bottom follows the ambient field
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_file_mesh_is_renumbered_for_locality_behind_the_api(gpu, data_dir, monkeypatch, degree):
+    """FS_RENUMBER=1 (automatic for file meshes of 50 000 vertices or more): data/mesh.xml is uploaded in the Morton order of
+    fs_mesh_locality_order through the one-part Localizer; dof numbers, Dirichlet sets and the result stay in FILE numbering
+    and equal the plain upload to solver accuracy (VERDICT r2 next #2; DOLFIN reorders dofs too, SolverBase.py:260-275)."""
+    from fenicssolver_amd.main import load_settings
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+
+    def run():
+        s = load_settings(os.path.join(data_dir, "TestHeatTransfer.json"))
+        s["report_settings"] = dict(QUIET)
+        s["fe_degree"] = degree
+        solver = ScalarTransportSolver(s)
+        return solver, solver.solve().vector().get_local().copy()
+
+    monkeypatch.setenv("FS_RENUMBER", "0")
+    plain_solver, plain = run()
+    assert plain_solver.function_space.localizer() is None
+    monkeypatch.setenv("FS_RENUMBER", "1")
+    solver, renum = run()
+    loc = solver.function_space.localizer()
+    assert loc is not None and not np.array_equal(loc.l2g[:len(plain_solver.mesh.coordinates())], np.arange(len(plain_solver.mesh.coordinates())))
+    assert np.abs(renum - plain).max() <= 1e-9 * np.abs(plain).max()
+    X = solver.function_space.node_coordinates()
+    assert np.abs(renum - (350.0 - 2.5 * X[:, 2])).max() <= 1e-8
+    # consecutive device rows are neighbours in space: mean distance of consecutive vertices well below the file order's
+    co = plain_solver.mesh.coordinates()
+    nv = len(co)
+    order = loc.l2g[:nv] if degree == 1 else loc.part.l2g[:nv]
+    assert np.linalg.norm(np.diff(co[order], axis=0), axis=1).mean() < 0.5 * np.linalg.norm(np.diff(co, axis=0), axis=1).mean()
+
+
+def test_renumbered_file_mesh_elasticity_and_boundary_flux(gpu, data_dir, monkeypatch):
+    """The vector path and a boundary functional on the renumbered upload of data/mesh.xml."""
+    import copy
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.fem import Mesh, AutoSubDomain, Constant, near
+    from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
+
+    def run():
+        mesh = Mesh(os.path.join(data_dir, "mesh.xml"))
+        bcs = OrderedDict()
+        bcs["fixed"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 0.0)), 'boundary_id': 1,
+                        'type': 'Dirichlet', 'value': Constant((0, 0, 0))}
+        bcs["pull"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[2], 20.0)), 'boundary_id': 2,
+                       'type': 'force', 'value': Constant((1e3, 0, 2e3))}
+        s = copy.deepcopy(SB.default_case_settings)
+        s.update({'solver_name': 'LinearElasticitySolver', 'mesh': mesh, 'fe_degree': 1, 'vector_name': 'displacement',
+                  'boundary_conditions': bcs, 'body_source': (0, 0, -9.8 * 7800), 'initial_values': {'displacement': (0, 0, 0)},
+                  'material': {'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800}})
+        s['report_settings'] = dict(QUIET)
+        solver = LinearElasticitySolver(s)
+        u = solver.solve().vector().get_local().copy()
+        return solver, u, solver.von_Mises(solver.w_current).vector().get_local().copy()
+
+    monkeypatch.setenv("FS_RENUMBER", "0")
+    _, u0, vm0 = run()
+    monkeypatch.setenv("FS_RENUMBER", "1")
+    solver, u1, vm1 = run()
+    assert solver.function_space.localizer() is not None
+    assert np.abs(u1 - u0).max() <= 1e-8 * np.abs(u0).max()
+    assert np.abs(vm1 - vm0).max() <= 1e-6 * np.abs(vm0).max()
