@@ -383,7 +383,7 @@ class Watchdog:
 def kernel_name(V):
     nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
     one = "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
-    if V.n_slices > 32768 and V.degree == 1:       # spmv_use_pairs(): paired DIA slices, two rows per lane
+    if V.n_slices > 32768 and V.degree == 1 and V.n_dia_slices > 0:       # spmv_use_pairs(): paired DIA slices, two rows per lane
         return "k_dia_pair_spmv<3,%s> + %s on the unpaired slices (one launch each per product)" % ("true" if nt else "false", one)
     return one
 
@@ -406,7 +406,7 @@ def kernel_rates(st, V):
 def committed_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
     newest round first; collected on the same command in separate --pmc runs).  Not measured in this run."""
-    for name in ("r02_pmc.json", "r01_pmc.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 v = json.load(fh).get(tag)

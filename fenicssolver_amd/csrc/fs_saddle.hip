@@ -458,6 +458,197 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
 }
 
 
+// ---- Taylor-Hood on TRIANGLES (the reference's own CFD example is 2-D: examples/test_cfd_solver.py:83) -------------------
+// The class is dimension-free upstream (CoupledNavierStokesSolver.py:84-102, 288-381).  Here the 2-D system keeps the block-4
+// layout: (u_x, u_y, -, p) per CG2 node with the third slot a dummy unknown (unit row, zero coupling), so the operator product,
+// the block preconditioner and FGMRES above serve it unchanged; a 2-D mesh is small, the unused planes cost nothing that matters.
+// Element: 6 P2 nodes (3 vertices, then the UFC edges e0=(1,2) e1=(0,2) e2=(0,1)), Radon's 7-point degree-5 rule (exact for
+// the P2*P2*P1 convection integrand), one thread per (cell, a, b); the 4x4 element block goes to the element buffer and the
+// stored blocks are summed by k_ns_gather in a fixed order (no atomics on the matrix).
+__device__ const double NS_TRI_QP[7][3] = {
+    {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
+    {0.797426985353087, 0.101286507323456, 0.101286507323456},
+    {0.101286507323456, 0.797426985353087, 0.101286507323456},
+    {0.101286507323456, 0.101286507323456, 0.797426985353087},
+    {0.059715871789770, 0.470142064105115, 0.470142064105115},
+    {0.470142064105115, 0.059715871789770, 0.470142064105115},
+    {0.470142064105115, 0.470142064105115, 0.059715871789770}};
+__device__ const double NS_TRI_QW[7] = {0.225, 0.125939180544827, 0.125939180544827, 0.125939180544827,
+                                        0.132394152788506, 0.132394152788506, 0.132394152788506};
+__device__ const int NS_TRI_EI[3] = {1, 0, 0};
+__device__ const int NS_TRI_EJ[3] = {2, 2, 1};
+
+__device__ __forceinline__ double sel3(int i, double a, double b, double c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// value and physical gradient of P2 basis function n of a triangle at barycentric point l
+__device__ __forceinline__ void p2tri_eval(int n, const double l[3], const double gl[3][2], double* phi, double g[2]) {
+    if (n < 3) {
+        const double li = sel3(n, l[0], l[1], l[2]);
+        const double d = 4.0 * li - 1.0;
+        *phi = li * (2.0 * li - 1.0);
+        g[0] = d * sel3(n, gl[0][0], gl[1][0], gl[2][0]);
+        g[1] = d * sel3(n, gl[0][1], gl[1][1], gl[2][1]);
+    } else {
+        const int i = NS_TRI_EI[n - 3], j = NS_TRI_EJ[n - 3];
+        const double li = sel3(i, l[0], l[1], l[2]), lj = sel3(j, l[0], l[1], l[2]);
+        *phi = 4.0 * li * lj;
+        g[0] = 4.0 * (li * sel3(j, gl[0][0], gl[1][0], gl[2][0]) + lj * sel3(i, gl[0][0], gl[1][0], gl[2][0]));
+        g[1] = 4.0 * (li * sel3(j, gl[0][1], gl[1][1], gl[2][1]) + lj * sel3(i, gl[0][1], gl[1][1], gl[2][1]));
+    }
+}
+
+// gradients of the barycentric coordinates of triangle c, its area and (G2) h = 2 * circumradius = |e0||e1||e2| / (2 area)
+__device__ __forceinline__ void ns_tri_geometry(const double* __restrict__ xyz, const int32_t* __restrict__ cells, int64_t c,
+                                                double gl[3][2], double* area, double* hcell) {
+    double X[3][2];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const int64_t vx = cells[c * 4 + v];
+        X[v][0] = xyz[4 * vx]; X[v][1] = xyz[4 * vx + 1];
+    }
+    const double ax = X[1][0] - X[0][0], ay = X[1][1] - X[0][1], bx = X[2][0] - X[0][0], by = X[2][1] - X[0][1];
+    const double det = ax * by - bx * ay;
+    const double idet = 1.0 / det;
+    gl[1][0] = by * idet;  gl[1][1] = -bx * idet;
+    gl[2][0] = -ay * idet; gl[2][1] = ax * idet;
+    gl[0][0] = -(gl[1][0] + gl[2][0]); gl[0][1] = -(gl[1][1] + gl[2][1]);
+    *area = 0.5 * fabs(det);
+    if (hcell) {
+        const double cx = X[2][0] - X[1][0], cy = X[2][1] - X[1][1];
+        *hcell = sqrt((ax * ax + ay * ay) * (bx * bx + by * by) * (cx * cx + cy * cy)) / (2.0 * *area);
+    }
+}
+
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_tri(const double* __restrict__ xyz, const int32_t* __restrict__ cells,
+                                                              const int32_t* __restrict__ cell_dofs, int64_t nc, int64_t n_rows,
+                                                              const double* __restrict__ w0, const double* __restrict__ wprev,
+                                                              ns_params P, double* __restrict__ ebuf, double* __restrict__ g) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool has_prev = wprev != nullptr && P.inv_dt != 0.0;
+    for (; t < nc * 36; t += stride) {
+        const int64_t c = t / 36;
+        const int ab = (int)(t - c * 36);
+        const int a = ab / 6, b = ab - a * 6;
+        int32_t nd[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) nd[n] = cell_dofs[c * 6 + n];
+        double gl[3][2], area, hcell = 0.0;
+        ns_tri_geometry(xyz, cells, c, gl, &area, P.g2 ? &hcell : nullptr);
+        double U0[6][2], UP[6][2];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            U0[n][0] = P.convection ? w0[4 * (int64_t)nd[n]] : 0.0;
+            U0[n][1] = P.convection ? w0[4 * (int64_t)nd[n] + 1] : 0.0;
+            UP[n][0] = has_prev ? wprev[4 * (int64_t)nd[n]] : 0.0;
+            UP[n][1] = has_prev ? wprev[4 * (int64_t)nd[n] + 1] : 0.0;
+        }
+        double P0[3] = {0.0, 0.0, 0.0};
+        if (P.nn_pref > 0.0) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) P0[v] = w0[4 * (int64_t)nd[v] + 3];
+        }
+        double blk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[i][j] = 0.0;
+        double gv[2] = {0.0, 0.0};
+        const bool do_rhs = b == 0;
+        const bool full = P.convection && P.newton;
+        for (int q = 0; q < 7; ++q) {
+            const double l[3] = {NS_TRI_QP[q][0], NS_TRI_QP[q][1], NS_TRI_QP[q][2]};
+            const double wv = NS_TRI_QW[q] * area;
+            const double nuq = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2]);
+            double pa, pb, ga[2], gb[2];
+            p2tri_eval(a, l, gl, &pa, ga);
+            p2tri_eval(b, l, gl, &pb, gb);
+            double diag = nuq * (ga[0] * gb[0] + ga[1] * gb[1]) + P.inv_dt * pa * pb;
+            double u0[2] = {0.0, 0.0}, gu0[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, up[2] = {0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                double pn, gn[2];
+                p2tri_eval(n, l, gl, &pn, gn);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    u0[i] += pn * U0[n][i];
+                    up[i] += pn * UP[n][i];
+                    gu0[i][0] += U0[n][i] * gn[0];
+                    gu0[i][1] += U0[n][i] * gn[1];
+                }
+            }
+            if (P.convection) {
+                const double av[2] = {u0[0] - P.wm[0], u0[1] - P.wm[1]};
+                const double agb = av[0] * gb[0] + av[1] * gb[1];
+                diag += pa * agb;
+                if (P.g2) {
+                    const double aga = av[0] * ga[0] + av[1] * ga[1];
+                    diag -= ns_g2_delta(P, hcell, av[0] * av[0] + av[1] * av[1]) * aga * agb;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                blk[i][i] += wv * diag;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double v = nuq * ga[j] * gb[i];
+                    if (full) v += pa * pb * gu0[i][j];
+                    blk[i][j] += wv * v;
+                }
+            }
+            if (b < 3) {   // pressure trial function psi_b = lambda_b
+                const double psi = sel3(b, l[0], l[1], l[2]);
+                blk[0][3] -= wv * P.inv_rho * psi * ga[0];
+                blk[1][3] -= wv * P.inv_rho * psi * ga[1];
+            }
+            if (a < 3) {   // continuity test function psi_a
+                const double psi = sel3(a, l[0], l[1], l[2]);
+                blk[3][0] += wv * P.inv_rho * psi * gb[0];
+                blk[3][1] += wv * P.inv_rho * psi * gb[1];
+            }
+            if (do_rhs) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    double v = P.f[i];
+                    if (full) v += gu0[i][0] * u0[0] + gu0[i][1] * u0[1];
+                    if (has_prev) v += P.inv_dt * up[i];
+                    gv[i] += wv * pa * v;
+                }
+            }
+        }
+        double2* __restrict__ out = reinterpret_cast<double2*>(ebuf + t * 16);       // source index c*36 + ab = t
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[2 * i] = make_double2(blk[i][0], blk[i][1]);
+            out[2 * i + 1] = make_double2(blk[i][2], blk[i][3]);
+        }
+        if (do_rhs && nd[a] < n_rows) {
+            atomicAdd(&g[4 * (int64_t)nd[a]], gv[0]);
+            atomicAdd(&g[4 * (int64_t)nd[a] + 1], gv[1]);
+        }
+    }
+}
+
+// unit diagonal on the dummy slots of the 2-D layout: u_z of every node, the pressure of edge nodes
+__global__ void k_ns_dummy_rows_2d(int64_t nv, int64_t n_nodes, const int64_t* __restrict__ slice_ptr,
+                                   const int32_t* __restrict__ sell_col, double* __restrict__ val, int64_t plane) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_nodes; r += stride) {
+        const int64_t sp0 = slice_ptr[r >> 6];
+        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (r & 63);
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE;
+            if (sell_col[e] == (int32_t)r) {
+                val[10 * plane + e] = 1.0;
+                if (r >= nv) val[15 * plane + e] = 1.0;
+                break;
+            }
+        }
+    }
+}
+
 // ---- second pass: stored block e = sum of its element blocks (fixed order: deterministic, no atomics) -------------------
 __global__ void __launch_bounds__(FS_BLOCK) k_ns_gather(int64_t n_entries, const int32_t* __restrict__ ptr, const int32_t* __restrict__ src,
                                                         const double* __restrict__ ebuf, double* __restrict__ val, int64_t plane) {
@@ -501,6 +692,11 @@ __global__ void k_ns_dummy_rows(int64_t nv, int64_t n_nodes, const int64_t* __re
 void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s) {
     fs_space_s* sp = J->space;
     const int64_t nv = sp->mesh->n_owned;
+    if (sp->mesh->tdim == 2) {
+        hipLaunchKernelGGL(k_ns_dummy_rows_2d, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, nv, sp->n_nodes_owned,
+                           sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
+        return;
+    }
     if (sp->n_nodes_owned <= nv) return;
     hipLaunchKernelGGL(k_ns_dummy_rows, dim3(fs_grid_for(sp->n_nodes_owned - nv)), dim3(FS_BLOCK), 0, s, nv, sp->n_nodes_owned,
                        sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
@@ -535,6 +731,22 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     P.nn_pref = form->viscosity_pressure_ref;
     P.nn_exp = form->viscosity_pressure_exponent;
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
+    if (m->tdim == 2) {
+        // triangles: element blocks -> buffer -> one sum per stored block (always two-pass), dummy u_z / edge-pressure rows
+        if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
+        if (sp->elem_buf.n != m->nc * 36 * 16) FS_CHECK(sp->elem_buf.alloc(m->nc * 36 * 16));
+        hipLaunchKernelGGL(k_assemble_ns_tri, dim3(fs_grid_for(m->nc * 36, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, m->xyz.p, m->cells.p,
+                           sp->cell_dofs, m->nc, sp->n_nodes_owned, w0 ? w0->d.p : nullptr, w_prev ? w_prev->d.p : nullptr, P,
+                           sp->elem_buf.p, g->d.p);
+        hipLaunchKernelGGL(k_ns_gather, dim3(fs_grid_for(sp->sell_entries * 8, FS_BLOCK, 1 << 18)), dim3(FS_BLOCK), 0, s, sp->sell_entries,
+                           sp->gmap_ptr.p, sp->gmap_src.p, sp->elem_buf.p, J->val.p, sp->sell_entries);
+        J->taylor_hood = true;
+        hipLaunchKernelGGL(k_ns_dummy_rows_2d, dim3(fs_grid_for(sp->n_nodes_owned)), dim3(FS_BLOCK), 0, s, m->n_owned, sp->n_nodes_owned,
+                           sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
+        FS_KERNEL_CHECK();
+        FS_HIP(hipStreamSynchronize(s));
+        return FS_OK;
+    }
     // Element blocks -> buffer -> one sum per stored block: 25 ms with 544 M device-scope fp64 atomics became 7 ms
     // (MI355X, configs[4]) and the matrix is bit-reproducible.  FS_NS_ASSEMBLE=atomic / pair selects the one-pass
     // kernels (no 6 GB element buffer).
@@ -675,6 +887,75 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
     }
 }
 
+// the same on boundary EDGES of a triangle mesh: the edge opposite local vertex o carries the P2 nodes (i, j, 3 + o) with
+// i < j the other two vertices; 3-point Gauss-Legendre rule (degree 5); thread t = (facet, facet node al, cell node b)
+__global__ void k_ns_pressure_boundary_tri(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                                           const double* __restrict__ facet_value, double nu0, const double* __restrict__ xyz,
+                                           const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
+                                           const int32_t* __restrict__ slots, double* __restrict__ val, int64_t plane,
+                                           double* __restrict__ g, const double* __restrict__ w0, double nn_pref, double nn_exp,
+                                           int vstride) {
+    const double GS[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+    const double GW[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 18; t += stride) {
+        const int64_t f = t / 18;
+        const int r = (int)(t - f * 18);
+        const int al = r / 6, b = r - al * 6;
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int vi = o == 0 ? 1 : 0, vj = o == 2 ? 1 : 2;          // the edge's vertices, ascending local index
+        const int a = al == 0 ? vi : (al == 1 ? vj : 3 + o);
+        double gl[3][2], area;
+        ns_tri_geometry(xyz, cells, c, gl, &area, nullptr);
+        const double gnorm = sqrt(gl[o][0] * gl[o][0] + gl[o][1] * gl[o][1]);
+        const double n[2] = {-gl[o][0] / gnorm, -gl[o][1] / gnorm};     // outward
+        const double len = 2.0 * area * gnorm;
+        double pbv[2] = {0.0, 0.0};
+        if (facet_value) {
+            if (vstride == 2) { pbv[0] = facet_value[2 * f]; pbv[1] = facet_value[2 * f + 1]; }
+            else pbv[0] = pbv[1] = facet_value[f];
+        }
+        double P0[3] = {0.0, 0.0, 0.0};
+        if (nn_pref > 0.0) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) P0[v] = w0[4 * (int64_t)cell_dofs[c * 6 + v] + 3];
+        }
+        double blk[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        double gv[2] = {0.0, 0.0};
+        for (int q = 0; q < 3; ++q) {
+            double l[3] = {0.0, 0.0, 0.0};
+            l[vi] = 1.0 - GS[q];
+            l[vj] = GS[q];
+            const double wv = GW[q] * len;
+            const double pb = (1.0 - GS[q]) * pbv[0] + GS[q] * pbv[1];
+            const double nu = ns_viscosity(nu0, nn_pref, nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2]);
+            double pa, pbf, ga[2], gb[2];
+            p2tri_eval(a, l, gl, &pa, ga);
+            p2tri_eval(b, l, gl, &pbf, gb);
+            const double gn = gb[0] * n[0] + gb[1] * n[1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) blk[i][j] -= nu * wv * pa * ((i == j ? gn : 0.0) + gb[i] * n[j]);
+                gv[i] -= wv * pb * n[i] * pa;
+            }
+        }
+        const int32_t slot = slots[(int64_t)(a * 6 + b) * nc + c];
+        if (slot < 0) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) atomicAdd(&val[(int64_t)(i * 4 + j) * plane + slot], blk[i][j]);
+        if (b == 0 && facet_value) {
+            const int32_t node = cell_dofs[c * 6 + a];
+            atomicAdd(&g[4 * (int64_t)node], gv[0]);
+            atomicAdd(&g[4 * (int64_t)node + 1], gv[1]);
+        }
+    }
+}
+
 extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g, int64_t n_facets, const int32_t* facet_cell,
                                                    const int32_t* facet_opposite, const double* facet_value,
                                                    double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp,
@@ -689,7 +970,9 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
                                                    double kinematic_viscosity, fs_vector_t w0, double nn_pref, double nn_exp,
                                                    int values_per_facet) {
     FS_CHECK(fs_require_init());
-    FS_REQUIRE(values_per_facet == 1 || values_per_facet == 3, "fs_assemble_ns_pressure_boundary: values_per_facet must be 1 or 3");
+    FS_REQUIRE(J && J->space && J->space->mesh, "fs_assemble_ns_pressure_boundary: null matrix");
+    const int fverts = J->space->mesh->tdim;      // vertices of a boundary facet: 3 (triangle) or 2 (edge of a 2-D mesh)
+    FS_REQUIRE(values_per_facet == 1 || values_per_facet == fverts, "fs_assemble_ns_pressure_boundary: values_per_facet must be 1 or %d", fverts);
     FS_REQUIRE(nn_pref >= 0.0 && (nn_pref == 0.0 || (w0 && J && w0->d.n >= J->space->n_dofs_local)),
                "fs_assemble_ns_pressure_boundary: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
     FS_REQUIRE(J && g && n_facets >= 0 && (n_facets == 0 || (facet_cell && facet_opposite)), "fs_assemble_ns_pressure_boundary: bad arguments");
@@ -698,7 +981,7 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
     if (n_facets == 0) return FS_OK;
     fs_mesh_s* m = sp->mesh;
     for (int64_t i = 0; i < n_facets; ++i)
-        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] < 4,
+        FS_REQUIRE(facet_cell[i] >= 0 && facet_cell[i] < m->nc && facet_opposite[i] >= 0 && facet_opposite[i] <= fverts,
                    "fs_assemble_ns_pressure_boundary: facet %lld names cell %d / local vertex %d", (long long)i, facet_cell[i], facet_opposite[i]);
     hipStream_t s = fs_rt().stream;
     dbuf<int32_t> dc, dop;
@@ -711,6 +994,12 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
         FS_CHECK(dv.alloc(n_facets * values_per_facet));
         FS_CHECK(dv.upload(facet_value, n_facets * values_per_facet, s));
     }
+    if (fverts == 2)
+        hipLaunchKernelGGL(k_ns_pressure_boundary_tri, dim3(fs_grid_for(n_facets * 18)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
+                           facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
+                           sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,
+                           nn_pref, nn_exp, values_per_facet);
+    else
     hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
                        facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
                        sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,

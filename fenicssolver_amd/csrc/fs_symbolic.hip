@@ -615,9 +615,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
                              fs_space_t* out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(mesh && out, "fs_space_create: null pointer");
-    // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes
+    // ncomp = 4 on CG2 nodes is the Taylor-Hood block layout (u_x, u_y, u_z, p) of fs_assemble_navier_stokes; on triangles the
+    // u_z slot is a dummy unknown (unit row) so that the 2-D system runs through the same block-4 operator and solver
     if (family != FS_FAMILY_CG || (degree != 1 && degree != 2) || (ncomp != 1 && ncomp != 3 && ncomp != 4 && ncomp != 2) ||
-        (degree == 1 && ncomp == 4) || (ncomp == 2 && mesh->tdim != 2) || (ncomp > 2 && mesh->tdim == 2)) {
+        (degree == 1 && ncomp == 4) || (ncomp == 2 && mesh->tdim != 2) || (ncomp == 3 && mesh->tdim == 2)) {
         fs_set_error("fs_space_create: supported spaces are CG1 / CG2 with 1 or 3 components on tetrahedra, CG1 with 1 or 2 components on triangles and the 4-component CG2 node blocks of Taylor-Hood (family=%d degree=%d ncomp=%d on a %dD mesh)",
                      family, degree, ncomp, mesh->tdim);
         return FS_ERR_UNSUPPORTED;
