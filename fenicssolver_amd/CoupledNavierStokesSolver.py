@@ -26,6 +26,10 @@ with the pressure of the current iterate, evaluated at the quadrature points on 
 ``solving_temperature`` (:236-239, 247-286): the transport equation of the temperature on the pressure space, IP-stabilised,
 convected by the velocity iterate - solved after the flow of every step (block-triangular for a Newtonian fluid); ``split``
 then returns (u, p, T) as the reference's MixedElement([V, Q, Q]) does.
+2-D (triangles; the reference's own CFD example runs on UnitSquareMesh(40, 100), examples/test_cfd_solver.py:83): the same
+block layout with a dummy third velocity slot (mixed.py), 6-node element kernel with Radon's 7-point rule, edge integrals of
+the pressure boundaries, the same FGMRES / block preconditioner; G2, ALE, the non-Newtonian law and solving_temperature
+included, the stress post-processing (viscous_stress, drag / lift) is 3-D only.
 Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
 velocities, a viscosity depending on the temperature.
 """
@@ -70,20 +74,21 @@ class CoupledNavierStokesSolver(SolverBase):
 
     # ------------------------------------------------------------------ values
     def get_body_source(self):
-        """(CoupledNavierStokesSolver.py:114-123) default gravity along -z in 3D."""
+        """(CoupledNavierStokesSolver.py:114-123) default gravity along -z in 3D, along -y in 2D."""
         bs = self.settings.get('body_source')
         if bs:
             return self._vector3(bs, 'body_source')
-        return np.array([0.0, 0.0, -9.8])
+        return np.array([0.0, 0.0, -9.8]) if self.dimension == 3 else np.array([0.0, -9.8, 0.0])
 
-    @staticmethod
-    def _vector3(value, what):
+    def _vector3(self, value, what):
+        """A constant vector of the mesh dimension, padded to the three slots the device forms carry."""
         if isinstance(value, Constant):
             value = value.values()
-        if isinstance(value, (tuple, list, np.ndarray)) and len(value) == 3 and \
+        d = getattr(self, 'dimension', 3)
+        if isinstance(value, (tuple, list, np.ndarray)) and len(value) == d and \
                 all(isinstance(x, numbers.Number) for x in value):
-            return np.asarray(value, dtype=np.float64)
-        raise SolverError("{} must be 3 numbers (a Constant or a tuple) on this back end".format(what))
+            return np.concatenate([np.asarray(value, dtype=np.float64), np.zeros(3 - d)])
+        raise SolverError("{} must be {} numbers (a Constant or a tuple) on this back end".format(what, d))
 
     def get_initial_field(self):
         W = self.function_space
@@ -95,13 +100,16 @@ class CoupledNavierStokesSolver(SolverBase):
             up0.assign(iv)
             return up0
         a = up0.vector().array().reshape(-1, 4)
-        vel = iv.get('velocity', (0.0, 0.0, 0.0)) if isinstance(iv, dict) else (0.0, 0.0, 0.0)
+        d = self.dimension
+        vel = iv.get('velocity', d * (0.0,)) if isinstance(iv, dict) else d * (0.0,)
         pre = iv.get('pressure', 0.0) if isinstance(iv, dict) else 0.0
+        if len(vel) != d:
+            raise SolverError("initial_values['velocity'] must have {} components".format(d))
         co = W.node_coordinates()
         expr = Expression(tuple(str(v) for v in list(vel) + [pre]), degree=self.settings['fe_degree'])
         vals = expr.eval_points(co)
-        a[:, :3] = vals[:, :3]
-        a[:self.mesh.num_vertices(), 3] = vals[:self.mesh.num_vertices(), 3]
+        a[:, :d] = vals[:, :d]
+        a[:self.mesh.num_vertices(), 3] = vals[:self.mesh.num_vertices(), d]
         return up0
 
     def viscosity_law(self):
@@ -367,6 +375,8 @@ class CoupledNavierStokesSolver(SolverBase):
         from . import backend
         from .fem import FunctionSpace, TensorFunctionSpace
         W = up.function_space()
+        if self.dimension != 3:
+            raise SolverError("viscous_stress / boundary_traction / calc_drag_and_lift are built for 3-D flows")
         if T_space is None:
             T_space = TensorFunctionSpace(self.mesh, 'CG', 1)
         elif T_space.degree() != 1 or T_space._ncomp != 9:

@@ -888,9 +888,10 @@ class SolverBase():
                     # order with the opposite vertex left out - DOLFIN's P1 interpolant of a degree-1 Expression
                     gcells = self.mesh.cells().astype(np.int64)
                     cg = cells if loc is None else loc.part.cell_gids[cells]
-                    keepv = np.arange(4)[None, :] != opp[:, None]
-                    fverts = gcells[cg][keepv].reshape(-1, 3)
-                    fv = DirichletBC._eval(value, self.mesh.coordinates()[fverts.ravel()], 1).reshape(-1, 3)
+                    nvc = gcells.shape[1]                  # 4 (tetrahedra: facets are triangles) or 3 (triangles: edges)
+                    keepv = np.arange(nvc)[None, :] != opp[:, None]
+                    fverts = gcells[cg][keepv].reshape(-1, nvc - 1)
+                    fv = DirichletBC._eval(value, self.mesh.coordinates()[fverts.ravel()], 1).reshape(-1, nvc - 1)
             backend.assemble_ns_pressure_boundary(ctx['J'], g, cells, opp, F.nu, fv, viscosity_law=getattr(F, 'viscosity_law', None), w0=dw)
         if ctx.get('per') is not None:
             # periodic_boundary: J <- P^T J P + unit slave rows, g <- P^T g (zeros on the slaves), all four unknowns of a node

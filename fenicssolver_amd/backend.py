@@ -575,8 +575,8 @@ def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_va
     fv, per = None, 1
     if facet_value is not None:
         a = np.asarray(facet_value, dtype=np.float64)
-        if a.ndim == 2 and a.shape == (len(fc), 3):       # values at the three vertices of every facet
-            fv, per = np.ascontiguousarray(a), 3
+        if a.ndim == 2 and a.shape[0] == len(fc) and a.shape[1] in (2, 3):       # values at the vertices of every facet (edge: 2)
+            fv, per = np.ascontiguousarray(a), a.shape[1]
         else:
             fv = np.ascontiguousarray(np.broadcast_to(a, fc.shape))
     pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))

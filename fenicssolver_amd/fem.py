@@ -579,6 +579,45 @@ class Expression:
         return r[0]
 
 
+class UserExpression:
+    """dolfin.UserExpression: a Python subclass overrides ``eval(self, value, x)`` (and ``value_shape()`` for vector values),
+    as the reference's CFD example does for its inlet profile (examples/test_cfd_solver.py:118-135).  Evaluated point by
+    point on the host (boundary nodes, quadrature-free uses only)."""
+
+    def __init__(self, degree=1, **kwargs):
+        self.degree = degree
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def value_shape(self):
+        return ()
+
+    def ufl_shape(self):
+        return tuple(self.value_shape())
+
+    def value_size(self):
+        sh = tuple(self.value_shape())
+        return int(np.prod(sh)) if sh else 1
+
+    def eval(self, value, x):
+        raise SolverError("UserExpression subclasses must override eval(self, value, x)")
+
+    def eval_points(self, pts):
+        pts = np.asarray(pts, dtype=np.float64)
+        if pts.ndim == 1:
+            pts = pts.reshape(1, -1)
+        n = self.value_size()
+        out = np.zeros((pts.shape[0], n))
+        for k in range(pts.shape[0]):
+            self.eval(out[k], pts[k])
+        return out[:, 0] if not tuple(self.value_shape()) else out
+
+    def __call__(self, *x):
+        xs = x[0] if len(x) == 1 and hasattr(x[0], "__len__") else x
+        r = self.eval_points(np.asarray(xs, dtype=np.float64)[None, :])
+        return r[0]
+
+
 # --------------------------------------------------------------------------------------------
 # function spaces / functions
 # --------------------------------------------------------------------------------------------
@@ -652,7 +691,7 @@ class FunctionSpace:
             if _holder:
                 raise SolverError("periodic_boundary (constrained_domain) is not meaningful for a container space")
             self._periodic = periodic_vertex_pairs(mesh, constrained_domain)      # vertices; periodic_pairs() adds P2 edge nodes
-        if mesh.topology().dim() == 2 and not _holder and _ncomp not in (1, 2):
+        if mesh.topology().dim() == 2 and not _holder and _ncomp not in (1, 2) and not (_ncomp == 4 and int(degree) == 2):
             raise SolverError("2-D (triangular) meshes carry scalar and 2-vector spaces (P1 or P2) in fenicssolver_amd")
         self._mesh = mesh
         self._degree = int(degree)
@@ -1298,7 +1337,7 @@ class DirichletBC:
             v = np.full((pts.shape[0], 1), float(value))
         elif isinstance(value, Constant):
             v = np.broadcast_to(value.values().reshape(1, -1), (pts.shape[0], value.value_size())).copy()
-        elif isinstance(value, Expression):
+        elif isinstance(value, (Expression, UserExpression)):
             v = value.eval_points(pts).reshape(pts.shape[0], -1)
         elif isinstance(value, (tuple, list, np.ndarray)):
             v = np.broadcast_to(np.asarray(value, dtype=np.float64).reshape(1, -1), (pts.shape[0], len(value))).copy()

@@ -186,10 +186,11 @@ class NavierStokesForm:
             return type(v).__name__
 
     def describe(self):
+        d = self.space.velocity_dim() if hasattr(self.space, "velocity_dim") else 3      # vectors are stored padded to 3 slots
         return {"type": "navier_stokes", "nu": self.nu, "rho": self.rho, "inv_dt": self.inv_dt,
                 "pressure_boundaries": [(int(m), None if v is None else self._value_name(v)) for m, v in self.pressure_boundaries],
-                "body_force": None if self.body_force is None else [float(x) for x in self.body_force],
-                "mesh_velocity": None if self.mesh_velocity is None else [float(x) for x in self.mesh_velocity],
+                "body_force": None if self.body_force is None else [float(x) for x in self.body_force][:d],
+                "mesh_velocity": None if self.mesh_velocity is None else [float(x) for x in self.mesh_velocity][:d],
                 "g2": None if self.g2 is None else [int(self.g2[0]), float(self.g2[1])],
                 "viscosity_law": None if self.viscosity_law is None else [float(self.viscosity_law[0]), float(self.viscosity_law[1])],
                 "newton": bool(self.newton)}

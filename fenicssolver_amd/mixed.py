@@ -5,6 +5,9 @@ FiniteElement(family, cell, fe_degree))`` (CoupledNavierStokesSolver.py:84-102).
 numbering is not reproducible outside DOLFIN; the layout fixed here - and used by libfsamd.so - is one block
 of four unknowns (u_x, u_y, u_z, p) per P2 node (vertices first, then edge mid-points); the pressure is P1,
 so only vertex nodes carry one: the pressure slot of an edge node is a dummy unknown that stays 0.
+On triangles (the reference's own CFD example is 2-D, examples/test_cfd_solver.py:83) the block stays four wide -
+(u_x, u_y, -, p) with the third slot one more dummy unknown - so that one operator layout and one solver serve both
+dimensions; ``split`` hands back a 2-vector velocity.
 """
 from __future__ import annotations
 
@@ -19,8 +22,9 @@ class TaylorHoodSpace(FunctionSpace):
             raise SolverError("fe_family '{}' is not supported (CG/P/Lagrange only)".format(family))
         if int(pressure_degree) != 1:
             raise SolverError("Taylor-Hood is built for fe_degree 1 (P2 velocity / P1 pressure) only")
-        if mesh.geometry().dim() != 3:
-            raise SolverError("the Navier-Stokes path is built for 3D tetrahedral meshes")
+        if mesh.geometry().dim() not in (2, 3):
+            raise SolverError("the Navier-Stokes path is built for triangular and tetrahedral meshes")
+        self._gdim = mesh.geometry().dim()
         self._mesh = mesh
         self._degree = 2
         self._ufl_element = _Element("Mixed(P2^3 x P1)", 2, 4)
@@ -31,7 +35,14 @@ class TaylorHoodSpace(FunctionSpace):
         # periodic_boundary (CoupledNavierStokesSolver.py:97-100): vertex and edge nodes of the slave side are tied to the
         # master side, all four unknowns of a node together; the pressure space carries the same constraint
         self._constrained_domain = constrained_domain
+        if constrained_domain is not None and self._gdim == 2:
+            raise SolverError("periodic_boundary on the 2-D velocity-pressure space is not built")
         self._periodic = None if constrained_domain is None else periodic_vertex_pairs(mesh, constrained_domain)
+        FunctionSpace._next_serial += 1
+        self._serial = FunctionSpace._next_serial
+
+    def velocity_dim(self):
+        return self._gdim
 
     def num_sub_spaces(self):
         return 2
@@ -45,7 +56,11 @@ class TaylorHoodSpace(FunctionSpace):
         return np.arange(self._mesh.num_vertices(), dtype=np.int64) * 4 + 3
 
     def dummy_dofs(self):
-        return np.arange(self._mesh.num_vertices(), self.num_nodes(), dtype=np.int64) * 4 + 3
+        """Unknowns that are not unknowns: the pressure slot of the edge nodes and, on triangles, the third velocity slot."""
+        edge_p = np.arange(self._mesh.num_vertices(), self.num_nodes(), dtype=np.int64) * 4 + 3
+        if self._gdim == 3:
+            return edge_p
+        return np.concatenate([np.arange(self.num_nodes(), dtype=np.int64) * 4 + 2, edge_p])
 
     def pressure_space(self):
         if getattr(self, "_q", None) is None:
@@ -54,7 +69,7 @@ class TaylorHoodSpace(FunctionSpace):
 
     def velocity_space(self):
         if getattr(self, "_v", None) is None:
-            self._v = FunctionSpace(self._mesh, "CG", 2, _ncomp=3, _holder=True)
+            self._v = FunctionSpace(self._mesh, "CG", 2, _ncomp=self._gdim, _holder=True)
         return self._v
 
 
@@ -81,9 +96,12 @@ class TaylorHoodSub:
         if self._index == 0:
             nodes = W.facet_nodes(facet_ids).astype(np.int64)
             co = W.node_coordinates()[nodes]
+            d = W.velocity_dim()
             if self._comp is None:
-                vals = evaluate(co, 3)
-                return (nodes[:, None] * 4 + np.arange(3)[None, :]).ravel().astype(np.int32), vals.reshape(-1)
+                vals = evaluate(co, d)
+                return (nodes[:, None] * 4 + np.arange(d)[None, :]).ravel().astype(np.int32), vals.reshape(-1)
+            if self._comp >= d:
+                raise SolverError("the velocity has {} components".format(d))
             return (nodes * 4 + self._comp).astype(np.int32), evaluate(co, 1).reshape(-1)
         verts = np.unique(W.mesh().facets()[facet_ids].astype(np.int64).ravel())
         return (verts * 4 + 3).astype(np.int32), evaluate(W.mesh().coordinates()[verts], 1).reshape(-1)
@@ -97,7 +115,7 @@ def split(w):
         raise SolverError("split(): not a velocity-pressure function")
     a = w.vector()._values().reshape(-1, 4)
     u = Function(W.velocity_space())
-    u.vector().set_local(a[:, :3].reshape(-1))
+    u.vector().set_local(np.ascontiguousarray(a[:, :W.velocity_dim()]).reshape(-1))
     p = Function(W.pressure_space())
     p.vector().set_local(a[:W.mesh().num_vertices(), 3])
     T = getattr(w, "_temperature", None)

@@ -283,6 +283,39 @@ except Exception as e:
     out["navier_stokes_coupled_temperature"] = {"reference_raises": "%s: %s" % (type(e).__name__, e),
                                                 "where": traceback.format_exc().strip().splitlines()[-3].strip()}
 
+# 2-D Taylor-Hood: the set-up of the reference's own CFD example (examples/test_cfd_solver.py:83-170, UnitSquareMesh channel:
+# no-slip side walls, velocity inlet at the bottom, pressure outlet at the top), steady and transient with gravity
+from dolfin import UnitSquareMesh                                                                      # noqa: E402
+
+
+def ns2d_settings(transient, body_source=None):
+    mesh = UnitSquareMesh(4, 6)
+    bcs = collections.OrderedDict()
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 3,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(2.0)}]}
+    bcs["static"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
+                     'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0))}]}
+    bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 2,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 1))}]}
+    st = copy.deepcopy(SolverBase.default_case_settings)
+    st.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
+               'boundary_conditions': bcs, 'body_source': body_source,
+               'initial_values': {'velocity': (0, 0.2), 'pressure': 0},
+               'material': {'density': 1.5, 'kinematic_viscosity': 0.1}})
+    st['solver_settings']['transient_settings'] = {'transient': transient, 'starting_time': 0.0, 'time_step': 0.01,
+                                                   'ending_time': 0.01}
+    st['solver_settings']['reference_values'] = {'velocity': (1, 1), 'pressure': 0}
+    st['report_settings'] = dict(QUIET)
+    return st
+
+
+for name, transient, body in (("navier_stokes_2d_steady", False, None), ("navier_stokes_2d_transient_gravity", True, Constant((0, -9.8)))):
+    try:
+        run(name, CoupledNavierStokesSolver.CoupledNavierStokesSolver(ns2d_settings(transient, body)))
+    except Exception as e:
+        import traceback
+        out[name] = {"reference_raises": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc().strip().splitlines()[-3].strip()}
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

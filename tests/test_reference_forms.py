@@ -497,6 +497,61 @@ def test_navier_stokes_terms(case, transient, body):
     assert np.all(dbcs[1].dofs % 4 != 3)       # velocity components only
 
 
+@pytest.mark.parametrize("case,transient,body", [("navier_stokes_2d_steady", False, None),
+                                                 ("navier_stokes_2d_transient_gravity", True, (0, -9.8))])
+def test_navier_stokes_2d_terms(case, transient, body):
+    """The 2-D set-up of the reference's own CFD example (examples/test_cfd_solver.py:83-170: UnitSquareMesh channel, no-slip side
+    walls, velocity inlet, pressure outlet): the reference - imported unchanged on the recording stub - and this package build
+    the same integrals and the same Dirichlet conditions; the class is dimension-free upstream (:84-102)."""
+    from fenicssolver_amd.fem import UnitSquareMesh, AutoSubDomain, Constant, near
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = UnitSquareMesh(4, 6)
+    bcs = collections.OrderedDict()
+    bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[1], 1.0)), 'boundary_id': 3,
+                     'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(2.0)}]}
+    bcs["static"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[0], 0.0) or near(x[0], 1.0))), 'boundary_id': 1,
+                     'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0))}]}
+    bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[1], 0.0)), 'boundary_id': 2,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 1))}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': mesh, 'fe_degree': 1, 'fe_family': 'CG',
+              'boundary_conditions': bcs, 'body_source': Constant(body) if body else None,
+              'initial_values': {'velocity': (0, 0.2), 'pressure': 0},
+              'material': {'density': 1.5, 'kinematic_viscosity': 0.1}})
+    s['solver_settings']['transient_settings'] = {'transient': transient, 'starting_time': 0.0, 'time_step': 0.01, 'ending_time': 0.01}
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1), 'pressure': 0}
+    s['report_settings'] = {"logging_level": 50, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
+    solver = CoupledNavierStokesSolver(s)
+    solver.init_solver()
+    assert solver.dimension == 2 and solver.function_space.velocity_dim() == 2
+    F, dbcs = solver.generate_form(0, None, None, solver.w_current, solver.w_prev)
+    desc = F.describe()
+    gold = GOLD[case]["solves"][0]
+    assert gold["kind"] == "NonlinearVariationalSolver"
+    terms, state = [], None
+    for t in gold["terms"]:
+        m = re.match(r"^action\((.*), (interpolate\(Expression\(.*?\)\)\))\)$", t["integrand"])
+        assert m
+        state = state or m.group(2)
+        body_ = re.sub(r"\bw\d+\b", "WPREV", m.group(1).replace(state, "W0"))
+        terms.append((t["sign"], body_, t["measure"]))
+    assert sorted(terms) == sorted(_ns_expected_terms(desc))
+    assert [(b["space"], b["marker"]) for b in gold["bcs"]] == [("W.sub(1)", 3), ("W.sub(0)", 1), ("W.sub(0)", 2)]
+    assert [b.marker_id for b in dbcs] == [3, 1, 2]
+    # Dirichlet sets in the block-4 layout: pressure slots of the outlet vertices; both velocity components (never the dummy third
+    # slot) of the wall / inlet nodes, vertices and edge mid-points
+    X = solver.function_space.node_coordinates()
+    assert np.all(dbcs[0].dofs % 4 == 3) and np.all(dbcs[0].values == 2.0) and np.allclose(X[dbcs[0].dofs // 4, 1], 1.0)
+    assert set(np.unique(dbcs[1].dofs % 4)) == {0, 1} and np.all(dbcs[1].values == 0.0)
+    v2 = dbcs[2].values.reshape(-1, 2)
+    assert np.all(v2[:, 0] == 0.0) and np.all(v2[:, 1] == 1.0) and np.allclose(X[dbcs[2].dofs[::2] // 4, 1], 0.0)
+    assert len(dbcs[2].dofs) == 2 * (5 + 4)          # 5 vertices + 4 edge mid-points on the inlet
+    # the initial field the reference interpolates (Expression(('0', '0.2', '0'))): velocity (0, 0.2), pressure 0
+    a = solver.w_current.vector().get_local().reshape(-1, 4)
+    assert np.all(a[:, 0] == 0.0) and np.all(a[:, 1] == 0.2) and np.all(a[:, 2:] == 0.0)
+
+
 def test_navier_stokes_non_newtonian_terms():
     """material['Newtonian'] = False (CoupledNavierStokesSolver.viscosity :194-213): the reference multiplies nu by
     pow(p / reference pressure, 0.1) with the pressure of the CURRENT iterate, in the cell term (:306) and in the boundary
