@@ -270,3 +270,43 @@ def test_transient_channel_and_picard_2d(gpu):
     pic.using_nonlinear_solver = False
     wp = pic.solve().vector().get_local()
     assert np.abs(wp - newton).max() <= 2e-3 * np.abs(newton).max()
+
+
+def test_coupled_temperature_2d_as_the_reference_example_runs_it(gpu):
+    """examples/test_cfd_solver.py:165-182 runs its 2-D channel with solving_temperature: (u, p, T) = split(solver.solve()).  The
+    temperature equation lives on the P1 pressure space (IP-stabilised, convected by the P2 velocity iterate) and is solved after
+    the flow of every step; its 2-D kernels have their own oracle tests (test_gpu_2d.py), here the coupling through the solver
+    class: T takes the wall / inlet values, stays between them (the scheme is monotone at this cell Peclet number) and equals a
+    stand-alone ScalarTransportSolver run with the converged velocity as its convective field."""
+    from fenicssolver_amd.fem import Constant
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    from fenicssolver_amd.mixed import split
+    s = _channel_settings(nx=6, ny=10, nu=0.1)
+    s['solving_temperature'] = True
+    s['material'].update({'specific_heat_capacity': 420, 'thermal_conductivity': 0.1})
+    s['initial_values']['temperature'] = 300
+    s['solver_settings']['reference_values']['temperature'] = 300
+    s['boundary_conditions']['static']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(350)})
+    s['boundary_conditions']['inlet']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)})
+    solver = CoupledNavierStokesSolver(s)
+    u, p, T = split(solver.solve())
+    Tv = T.vector().get_local()
+    co = solver.mesh.coordinates()
+    assert Tv.min() >= 300.0 - 1e-6 and Tv.max() <= 350.0 + 1e-6
+    walls = ((co[:, 0] == 0.0) | (co[:, 0] == 1.0)) & (co[:, 1] > 0.0)
+    assert np.allclose(Tv[walls], 350.0)
+    assert np.allclose(Tv[co[:, 1] == 0.0], 300.0)         # the inlet comes later in the dict: it wins the two corners (DOLFIN's order)
+    # stand-alone scalar solver with the same settings the flow solver derives (:255-262) and the converged velocity
+    ts = {k: v for k, v in s.items() if k not in ('solving_temperature',)}
+    ts = dict(ts, scalar_name='temperature', mesh=None, function_space=solver.function_space.pressure_space(), body_source=None,
+              advection_settings={'stabilization_method': 'IP', 'alpha': 0.1}, convective_velocity=u)
+    keep = OrderedDict()
+    for name, bc in s['boundary_conditions'].items():
+        tv = [v for v in bc['values'] if v.get('variable') == 'temperature']
+        if tv:
+            keep[name] = dict(bc, values=tv)
+    ts['boundary_conditions'] = keep
+    alone = ScalarTransportSolver(ts)
+    Ta = alone.solve().vector().get_local()
+    assert np.abs(Ta - Tv).max() <= 1e-7 * 350.0
