@@ -205,7 +205,8 @@ struct fs_space_s {
     // slab of the mesh for all classes and x is fetched once
     dbuf<int32_t> slice_order;    // [n_slices]
     dbuf<int32_t> dia_ptr;        // [n_slices]
-    dbuf<int32_t> dia_off;        // [sum of offsets over DIA slices]
+    dbuf<int32_t> dia_off;        // per DIA slice: [split][offset list A: width][offset list B: width, only if split < 64] -
+                                  // rows [split, 64) of a SPLIT slice use list B (fs_symbolic.hip, k_slice_analyze)
     // two-rows-per-lane product (k_dia_pair_spmv): pairs of slices, consecutive in processing order, both complete DIA
     // slices with identical offset lists; pair_singles = every other slice, in processing order.  Built on first use.
     dbuf<int32_t> pair_list;      // [2 * n_pairs]

@@ -34,15 +34,17 @@ template <bool NT, typename T>
 __device__ __forceinline__ T fs_ldv(const T* p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
+// op / op2: the offset lists of the two pieces of a DIA slice (fs_symbolic.hip, "SPLIT slices"; op2 == op when the slice is
+// not split), hi: this lane belongs to the second piece - two scalar loads and one select per entry, no column stream
 template <int N, bool NT>
-__device__ __forceinline__ void dia_round(const double* __restrict__ vp, const int32_t* __restrict__ op, int k, int32_t r,
-                                          int32_t cmax, const double* __restrict__ x, double& acc) {
+__device__ __forceinline__ void dia_round(const double* __restrict__ vp, const int32_t* __restrict__ op, const int32_t* __restrict__ op2,
+                                          bool hi, int k, int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
     double v[N], xv[N];
 #pragma unroll
     for (int u = 0; u < N; ++u) v[u] = fs_ldv<NT>(&vp[(int64_t)(k + u) * FS_SLICE]);
 #pragma unroll
     for (int u = 0; u < N; ++u) {
-        int32_t c = r + op[k + u];
+        int32_t c = r + (hi ? op2[k + u] : op[k + u]);
         c = c < 0 ? 0 : (c > cmax ? cmax : c);
         xv[u] = x[c];
     }
@@ -65,10 +67,11 @@ __device__ __forceinline__ void sell_round(const double* __restrict__ vp, const 
 }
 template <int N, bool NT>
 struct row_tail {
-    static __device__ __forceinline__ void dia(int rem, const double* __restrict__ vp, const int32_t* __restrict__ op, int k,
+    static __device__ __forceinline__ void dia(int rem, const double* __restrict__ vp, const int32_t* __restrict__ op,
+                                               const int32_t* __restrict__ op2, bool hi, int k,
                                                int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
-        if (rem == N) dia_round<N, NT>(vp, op, k, r, cmax, x, acc);
-        else row_tail<N - 1, NT>::dia(rem, vp, op, k, r, cmax, x, acc);
+        if (rem == N) dia_round<N, NT>(vp, op, op2, hi, k, r, cmax, x, acc);
+        else row_tail<N - 1, NT>::dia(rem, vp, op, op2, hi, k, r, cmax, x, acc);
     }
     static __device__ __forceinline__ void sell(int rem, const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
                                                 const double* __restrict__ x, double& acc) {
@@ -78,7 +81,7 @@ struct row_tail {
 };
 template <bool NT>
 struct row_tail<0, NT> {
-    static __device__ __forceinline__ void dia(int, const double*, const int32_t*, int, int32_t, int32_t, const double*, double&) {}
+    static __device__ __forceinline__ void dia(int, const double*, const int32_t*, const int32_t*, bool, int, int32_t, int32_t, const double*, double&) {}
     static __device__ __forceinline__ void sell(int, const double*, const int32_t*, int, const double*, double&) {}
 };
 
@@ -138,15 +141,18 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
             // DIA slice: column = row + offset[k] (one scalar per entry row), so the x gather of the wave
             // is one contiguous 512-B read and no column index is streamed.  Entries a row does not have
             // hold the value 0 and read a clamped, valid address.
-            const int32_t* __restrict__ op = dia_off + dp;
+            const int split = dia_off[dp];                                  // rows [split, 64) use the second offset list
+            const int32_t* __restrict__ op = dia_off + dp + 1;
+            const int32_t* __restrict__ op2 = op + (split < FS_SLICE ? width : 0);
+            const bool hi = lane >= split;
             int k = 0;
             if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL, NT>(vp, op, k, (int32_t)r, cmax, x, acc[0]);
-                row_tail<UNROLL - 1, NT>::dia(width - k, vp, op, k, (int32_t)r, cmax, x, acc[0]);
+                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL, NT>(vp, op, op2, hi, k, (int32_t)r, cmax, x, acc[0]);
+                row_tail<UNROLL - 1, NT>::dia(width - k, vp, op, op2, hi, k, (int32_t)r, cmax, x, acc[0]);
                 k = width;
             }
             for (; k < width; ++k) {
-                int64_t c = r + op[k];
+                int64_t c = r + (hi ? op2[k] : op[k]);
                 c = c < 0 ? 0 : (c > cmax ? cmax : c);
 #pragma unroll
                 for (int j = 0; j < BS; ++j) {
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
         const int64_t s = half ? sb : sa;
         const int64_t base = slice_ptr[s];
         const int width = (int)((slice_ptr[sa + 1] - slice_ptr[sa]) >> 6);       // same for both slices of a pair
-        const int32_t* __restrict__ op = dia_off + dia_ptr[sa];                   // the shared offset list
+        const int32_t* __restrict__ op = dia_off + dia_ptr[sa] + 1;               // the shared offset list (pairs are never split slices)
         const int32_t r = (int32_t)(s * FS_SLICE + l2);
         const double* __restrict__ vp = val + base + l2;
         v2d zi = {0.0, 0.0}, ri = {0.0, 0.0};
@@ -1088,11 +1094,12 @@ static int build_pair_lists(fs_space_s* sp, hipStream_t s) {
     auto width = [&](int32_t sl) { return (int)((ptr[(size_t)sl + 1] - ptr[(size_t)sl]) >> 6); };
     auto pairable = [&](int32_t a, int32_t b) {
         if (dp[(size_t)a] < 0 || dp[(size_t)b] < 0) return false;
+        if (off[(size_t)dp[(size_t)a]] < FS_SLICE || off[(size_t)dp[(size_t)b]] < FS_SLICE) return false;      // split slices: two lists each
         if ((int64_t)(a + 1) * FS_SLICE > sp->n_nodes_owned || (int64_t)(b + 1) * FS_SLICE > sp->n_nodes_owned) return false;
         const int w = width(a);
         if (w != width(b) || w == 0) return false;
         for (int k = 0; k < w; ++k)
-            if (off[(size_t)dp[(size_t)a] + k] != off[(size_t)dp[(size_t)b] + k]) return false;
+            if (off[(size_t)dp[(size_t)a] + 1 + k] != off[(size_t)dp[(size_t)b] + 1 + k]) return false;
         return true;
     };
     // units are formed in the NATURAL numbering (rows of consecutive slices continue each other: same edge class on CG2
@@ -1265,7 +1272,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
         const int32_t dp = dia_ptr[s];
         const double* __restrict__ vp = val + (int64_t)(i * 4) * plane + base + lane;
         const int32_t* __restrict__ cp = sell_col + base + lane;
-        const int32_t* __restrict__ op = dia_off + (dp >= 0 ? dp : 0);
+        // DIA slice: [split][list A][list B if split < 64] (fs_symbolic.hip, "SPLIT slices"); this lane's list
+        const int split = dp >= 0 ? dia_off[dp] : FS_SLICE;
+        const int32_t* __restrict__ opa = dia_off + (dp >= 0 ? dp + 1 : 0);
+        const int32_t* __restrict__ opb = opa + (split < FS_SLICE ? width : 0);
+        const bool hi = lane >= split;
         double acc = 0.0;
         int k = 0;
         constexpr int U = 4;       // entries per round (2: 391 us, 4: 374 us, 8: 476 us on the configs[4] matrix - register pressure)
@@ -1275,7 +1286,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (dp >= 0) {
-                    c[u] = r + op[k + u];
+                    c[u] = r + (hi ? opb[k + u] : opa[k + u]);
                     c[u] = c[u] < 0 ? 0 : (c[u] > cmax ? cmax : c[u]);
                 } else {
                     c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
@@ -1299,7 +1310,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
             for (int u = 0; u < U; ++u) acc += v[u][0] * xa[u].x + v[u][1] * xa[u].y + v[u][2] * xb[u].x + v[u][3] * xb[u].y;
         }
         for (; k < width; ++k) {
-            int64_t c = dp >= 0 ? r + op[k] : (int64_t)fs_col_decode(cp[(int64_t)k * FS_SLICE]);
+            int64_t c = dp >= 0 ? r + (hi ? opb[k] : opa[k]) : (int64_t)fs_col_decode(cp[(int64_t)k * FS_SLICE]);
             c = c < 0 ? 0 : (c > cmax ? cmax : c);
             const bool pc = !TH || c < nvo || (c >= gv0 && c < gv1);
             const double2 xa = reinterpret_cast<const double2*>(x)[2 * c], xb = reinterpret_cast<const double2*>(x)[2 * c + 1];

@@ -175,13 +175,45 @@ __global__ void k_rowptr(const uint64_t* __restrict__ keys, int64_t nnz, int64_t
 // offsets used by the 64 rows (each row's columns are sorted, so a per-lane cursor walks them).
 // A slice is stored in DIA form when that set is small and costs fewer bytes than SELL:
 // nd*8 B/row (values only) against len*12 B/row (values + 4-B columns).
+//
+// SPLIT slices.  On a CG2 space of a structured mesh the rows of an edge class are numbered line by line, and where a slice
+// runs over the end of a mesh line every offset shifts by the rows the line end skips: the union over the 64 rows is then
+// twice the size and the slice used to fall back to SELL (36 % of the slices of the unit cube at any n > 64, measured).
+// Such a slice is two DIA pieces: rows [0, split) share one offset list, rows [split, 64) another.  Both lists are kept
+// (dia_off layout per DIA slice: [split][list A: width][list B: width, only if split < 64]); the product picks the list by
+// lane, still without streaming a column index.  The split is searched among the rows whose first column offset or length
+// differs from the row before (at most FS_SPLIT_TRIES candidates), keeping the narrowest admissible width.
+#define FS_SPLIT_TRIES 12
+// distinct offsets of the rows of the lanes with `active`, ascending; stops counting beyond cap + 1.  out (lane 0 writes) may be null.
+__device__ __forceinline__ int fs_union_offsets(bool active, const int32_t* __restrict__ colidx, int32_t start, int32_t len,
+                                                int64_t r, int lane, int cap, int32_t* __restrict__ out) {
+    int cur = 0, nd = 0;
+    const int64_t BIG = (int64_t)1 << 40;
+    while (true) {
+        const int64_t mine = (active && cur < len) ? (int64_t)colidx[start + cur] - r : BIG;
+        int64_t m = mine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int64_t o = __shfl_xor(m, off, 64);
+            m = o < m ? o : m;
+        }
+        if (m == BIG) break;
+        if (out && nd < cap && lane == 0) out[nd] = (int32_t)m;
+        ++nd;
+        if (mine == m) ++cur;
+        if (nd > cap) break;
+    }
+    return nd;
+}
+
 __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ colidx, int64_t n_rows,
                                                             int64_t n_slices, int allow_dia,
                                                             int64_t* __restrict__ slice_entries,
                                                             int32_t* __restrict__ dia_cnt,
-                                                            int32_t* __restrict__ tmp_off, int* __restrict__ max_w,
-                                                            int* __restrict__ n_dia) {
+                                                            int32_t* __restrict__ tmp_off, int32_t* __restrict__ split_at,
+                                                            int* __restrict__ max_w,
+                                                            int* __restrict__ n_dia, unsigned long long* __restrict__ dia_entries) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -195,45 +227,75 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
         int maxlen = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-        int nd = 0;
+        int32_t* const offA = tmp_off + s * (2 * FS_DIA_CAP);
+        int32_t* const offB = offA + FS_DIA_CAP;
+        auto admissible = [&](int nd) { return nd > 0 && nd <= FS_DIA_CAP && nd <= 255 && (int64_t)nd * 8 * 10 <= (int64_t)maxlen * 12 * 9; };
+        int nd = 0, split = FS_SLICE;
+        bool dia = false;
         if (allow_dia) {
-            int cur = 0;                       // cursor into this lane's row
-            const int64_t BIG = (int64_t)1 << 40;
-            while (true) {
-                int64_t mine = cur < len ? (int64_t)colidx[start + cur] - r : BIG;
-                int64_t m = mine;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const int64_t o = __shfl_xor(m, off, 64);
-                    m = o < m ? o : m;
+            nd = fs_union_offsets(true, colidx, start, len, r, lane, FS_DIA_CAP, offA);
+            dia = admissible(nd);
+            if (!dia && allow_dia > 1) {
+                // candidate split rows: the pattern of a row differs from the row before it
+                const int64_t first = len > 0 ? (int64_t)colidx[start] - r : 0;
+                const int64_t pf = __shfl_up(first, 1, 64);
+                const int pl = __shfl_up(len, 1, 64);
+                unsigned long long cand = __ballot(lane > 0 && r < n_rows && (first != pf || len != pl));
+                int best = 0, best_w = FS_DIA_CAP + 1;
+                for (int t = 0; t < FS_SPLIT_TRIES && cand; ++t) {
+                    const int sp = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const int na = fs_union_offsets(lane < sp, colidx, start, len, r, lane, FS_DIA_CAP, nullptr);
+                    if (na > FS_DIA_CAP) continue;
+                    const int nb = fs_union_offsets(lane >= sp, colidx, start, len, r, lane, FS_DIA_CAP, nullptr);
+                    const int w = na > nb ? na : nb;
+                    if (admissible(w) && w < best_w) { best_w = w; best = sp; }
                 }
-                if (m == BIG) break;
-                if (nd < FS_DIA_CAP && lane == 0) tmp_off[s * FS_DIA_CAP + nd] = (int32_t)m;
-                ++nd;
-                if (mine == m) ++cur;
-                if (nd > FS_DIA_CAP) break;
+                if (best > 0) {
+                    const int na = fs_union_offsets(lane < best, colidx, start, len, r, lane, FS_DIA_CAP, offA);
+                    const int nb = fs_union_offsets(lane >= best, colidx, start, len, r, lane, FS_DIA_CAP, offB);
+                    // the shorter list is padded with its own last offset: those entries hold the value 0 and are marked
+                    // non-structural by k_fill_sell (its cursor has passed the column by then)
+                    if (lane == 0) {
+                        for (int k = na; k < best_w; ++k) offA[k] = offA[na - 1];
+                        for (int k = nb; k < best_w; ++k) offB[k] = offB[nb - 1];
+                    }
+                    nd = best_w;
+                    split = best;
+                    dia = true;
+                }
             }
         }
-        const bool dia = allow_dia && nd > 0 && nd <= FS_DIA_CAP && nd <= 255 && (int64_t)nd * 8 * 10 <= (int64_t)maxlen * 12 * 9;
         const int width = dia ? nd : maxlen;
         if (lane == 0) {
             slice_entries[s] = (int64_t)width * FS_SLICE;
-            dia_cnt[s] = dia ? nd : 0;
+            dia_cnt[s] = dia ? 1 + nd * (split < FS_SLICE ? 2 : 1) : 0;      // ints this slice takes in dia_off
+            split_at[s] = split;
             atomicMax(max_w, width);
-            if (dia) atomicAdd(n_dia, 1);
+            if (dia) {
+                atomicAdd(n_dia, 1);
+                atomicAdd(dia_entries, (unsigned long long)width * FS_SLICE);
+            }
         }
     }
 }
 
 __global__ void k_dia_ptr(const int32_t* __restrict__ dia_cnt, const int32_t* __restrict__ dia_scan, int64_t n_slices,
-                          const int32_t* __restrict__ tmp_off, int32_t* __restrict__ dia_ptr,
+                          const int32_t* __restrict__ tmp_off, const int32_t* __restrict__ split_at, int32_t* __restrict__ dia_ptr,
                           int32_t* __restrict__ dia_off) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; s < n_slices; s += stride) {
-        const int nd = dia_cnt[s];
-        dia_ptr[s] = nd > 0 ? dia_scan[s] : -1;
-        for (int k = 0; k < nd; ++k) dia_off[dia_scan[s] + k] = tmp_off[s * FS_DIA_CAP + k];
+        const int cnt = dia_cnt[s];
+        dia_ptr[s] = cnt > 0 ? dia_scan[s] : -1;
+        if (cnt == 0) continue;
+        const int split = split_at[s];
+        const int nd = split < FS_SLICE ? (cnt - 1) / 2 : cnt - 1;
+        int32_t* out = dia_off + dia_scan[s];
+        out[0] = split;
+        for (int k = 0; k < nd; ++k) out[1 + k] = tmp_off[s * (2 * FS_DIA_CAP) + k];
+        if (split < FS_SLICE)
+            for (int k = 0; k < nd; ++k) out[1 + nd + k] = tmp_off[s * (2 * FS_DIA_CAP) + FS_DIA_CAP + k];
     }
 }
 
@@ -265,8 +327,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_fill_sell(const int32_t* __restric
                 sell_col[base + (int64_t)k * FS_SLICE + lane] = k < len ? colidx[start + k] : ~self;
         } else {
             int cur = 0;
+            const int split = dia_off[dp];
+            const int32_t* __restrict__ op = dia_off + dp + 1 + (lane >= split ? width : 0);      // this lane's offset list
             for (int k = 0; k < width; ++k) {
-                int64_t c = r + (int64_t)dia_off[dp + k];
+                int64_t c = r + (int64_t)op[k];
                 bool structural = false;
                 if (cur < len && (int64_t)colidx[start + cur] == c) {
                     structural = true;
@@ -835,14 +899,18 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     sp->n_slices = n_slices;
     {
         dbuf<int64_t> entries;
-        dbuf<int32_t> dia_cnt, dia_scan, tmp_off;
+        dbuf<int32_t> dia_cnt, dia_scan, tmp_off, split_at;
         dbuf<int> d_max, d_ndia;
+        dbuf<unsigned long long> d_dia_entries;
         FS_SP(entries.alloc(n_slices + 1));
         FS_SP(entries.zero(s));
         FS_SP(dia_cnt.alloc(n_slices + 1));
         FS_SP(dia_cnt.zero(s));
         FS_SP(dia_scan.alloc(n_slices + 1));
-        FS_SP(tmp_off.alloc(n_slices * FS_DIA_CAP));
+        FS_SP(tmp_off.alloc(n_slices * 2 * FS_DIA_CAP));
+        FS_SP(split_at.alloc(n_slices));
+        FS_SP(d_dia_entries.alloc(1));
+        FS_SP(d_dia_entries.zero(s));
         FS_SP(d_max.alloc(1));
         FS_SP(d_max.zero(s));
         FS_SP(d_ndia.alloc(1));
@@ -850,8 +918,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP(sp->slice_ptr.alloc(n_slices + 1));
         FS_SP(sp->dia_ptr.alloc(n_slices));
         const char* env = getenv("FS_DISABLE_DIA");
-        const int allow_dia = !(env && *env && *env != '0');
-        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, d_max.p, d_ndia.p);
+        const char* env_split = getenv("FS_DISABLE_DIA_SPLIT");
+        // 0: SELL only, 1: whole-slice DIA only, 2: DIA with split slices (default)
+        const int allow_dia = (env && *env && *env != '0') ? 0 : ((env_split && *env_split && *env_split != '0') ? 1 : 2);
+        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, split_at.p, d_max.p, d_ndia.p, d_dia_entries.p);
         FS_SP_HIP(hipGetLastError());
         size_t tmp_bytes = 0, t2 = 0;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
@@ -872,9 +942,11 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP(d_max.download(&sp->max_row, 1, s));
         sp->sell_entries = total;
         sp->n_dia_slices = h_ndia;
-        sp->dia_entries = (int64_t)total_off * FS_SLICE;
+        unsigned long long h_dia_entries = 0;
+        FS_SP(d_dia_entries.download(&h_dia_entries, 1, s));
+        sp->dia_entries = (int64_t)h_dia_entries;
         FS_SP(sp->dia_off.alloc(total_off > 0 ? total_off : 1));
-        hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, sp->dia_ptr.p, sp->dia_off.p);
+        hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, split_at.p, sp->dia_ptr.p, sp->dia_off.p);
         FS_SP_HIP(hipGetLastError());
         FS_SP_HIP(hipStreamSynchronize(s));
     }
