@@ -92,8 +92,8 @@ class LinearElasticitySolver(SolverBase):
         mu, lmbda = self.lame_parameters()
         loc, ploc = V.localizer(), P.localizer()
         uh = u.vector()._values()
-        if loc is not None and not getattr(loc, 'is_local_view', False):
-            uh = loc.nodes(uh)                       # replicated host field -> this rank's owned + ghost entries
+        if loc is not None and not getattr(loc, 'is_identity', False):
+            uh = loc.nodes(uh)                       # host field -> this rank's owned + ghost entries in device order
         ud = backend.DeviceVector(dV.n_local, uh)
         b = backend.DeviceVector(dP.n_owned)
         backend.assemble_von_mises(dV, ud, mu, lmbda, dP, b)

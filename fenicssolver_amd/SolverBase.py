@@ -352,6 +352,7 @@ class SolverBase():
         loc = u.function_space().localizer()
         from . import parallel as _par
         replicated = (pc == 'amg' and loc is not None and _par.world()[1] > 1 and global_operator is not None
+                      and hasattr(loc, 'l2g')            # (a CG2 space on a distributed mesh has no global node numbering: Schwarz)
                       and isinstance(near_nullspace, (str, type(None)))
                       and sp_.get('amg_decomposition', 'replicated') == 'replicated')
         if replicated:
@@ -407,7 +408,10 @@ class SolverBase():
             from . import parallel
             if parallel.world()[1] > 1:
                 backend.halo_exchange(V, x)
-            u.vector()._adopt_device(x)
+            if getattr(loc, 'is_identity', True):
+                u.vector()._adopt_device(x)
+            else:                                   # CG2 on a distributed mesh: device order -> the host's node order
+                u.vector().set_local(loc.to_host(x.get()))
         else:   # every rank ends with the full field, gathered by global vertex id
             from . import parallel
             ncomp = u.function_space()._ncomp
@@ -597,7 +601,7 @@ class SolverBase():
                             old_kept[1].close()
                             old_kept[2].close()
                         self._kept_operators = (op_key, Au, B)
-                if loc is None or getattr(loc, 'is_local_view', False):
+                if loc is None or getattr(loc, 'is_identity', False):
                     tp = F.T_prev.vector()._device(V.n_local)          # the previous solve left it in HBM
                 else:
                     tp_host = loc.nodes(F.T_prev.vector()._values())

@@ -255,7 +255,8 @@ class BoxMesh(Mesh):
     Nothing of global size is ever built on the host; global vertex ids are arithmetic (``global_vertex_ids()``).
     Boundary markers, Dirichlet sets, coefficients and the result live on the local mesh (the part of the field a rank can
     see, as with DOLFIN); ``parallel.gather_function(u)`` assembles the global nodal array when one is wanted.
-    Built for P1 spaces (scalar / vector); P2 and Taylor-Hood spaces use the default replicated mesh."""
+    Built for P1 and P2 spaces (scalar / vector; the P2 node plan comes from the local cells alone,
+    partition.build_p2_plan_local); the Taylor-Hood space uses the default replicated mesh."""
 
     def __init__(self, p0, p1, nx, ny, nz, distributed=False):
         a = p0.array() if isinstance(p0, Point) else np.asarray(p0, dtype=np.float64)
@@ -950,9 +951,12 @@ class FunctionSpace:
         mesh = root._mesh
         if getattr(mesh, "_slab", None) is not None:
             # distributed box: the host mesh already IS this rank's part, numbered as the device numbers a slab
-            if root._degree != 1:
-                raise SolverError("BoxMesh(distributed=True) carries P1 spaces; P2 / Taylor-Hood use the replicated mesh (distributed=False)")
             lay = mesh._slab
+            if root._degree == 2:
+                if root._ncomp == 4:
+                    raise SolverError("BoxMesh(distributed=True) carries P1 and P2 scalar / vector spaces; the Taylor-Hood space uses "
+                                      "the replicated mesh (distributed=False)")
+                return FunctionSpace._make_distributed_p2_device(root, backend, parallel, partition, mesh, lay, rank)
             ds = backend.DeviceSpace(mesh.device(), root._ncomp, 1)
             if ds.n_owned != lay["n_owned"] * root._ncomp or ds.n_local != lay["n_local"] * root._ncomp:
                 raise SolverError("internal error: host and device disagree on the slab layout")
@@ -996,6 +1000,44 @@ class FunctionSpace:
                 ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts],
                             recv_lists=dof_lists(plan.recv_lists))
             root._localizer = parallel.Localizer(part, mesh.num_vertices(), nc_, p2_plan=plan, n_global_nodes=root.num_nodes())
+        return ds
+
+    @staticmethod
+    def _make_distributed_p2_device(root, backend, parallel, partition, mesh, lay, rank):
+        """CG2 space on a distributed box: the node plan comes from this rank's cells alone (partition.build_p2_plan_local), the
+        host keeps its own node order and talks to the device through a permutation of LOCAL data (parallel.LocalNodeView)."""
+        nc_ = root._ncomp
+        ds = backend.DeviceSpace(mesh.device(), nc_, 2)
+        nv = mesh.num_vertices()
+        P = lay["plane_size"]
+        owner = np.full(nv, rank, dtype=np.int32)
+        off = lay["n_owned"]
+        for q in lay["neighbors"]:                     # ghost planes follow the owned ones: lower neighbour first
+            owner[off:off + P] = q
+            off += P
+        dev_edges = ds.edges().astype(np.int64)
+        plan = partition.build_p2_plan_local(mesh.cells(), lay["l2g"], owner, rank, lay["neighbors"], dev_edges, lay["n_global"])
+        if plan.n_owned_nodes * nc_ != ds.n_owned:
+            raise SolverError("internal error: host and device disagree on the owned P2 nodes")
+        # device node -> host node: vertices keep their (local) vertex id, an edge is looked up by its end points
+        he = root.edge_nodes().astype(np.int64)
+        hkey = np.minimum(he[:, 0], he[:, 1]) * nv + np.maximum(he[:, 0], he[:, 1])
+        hsort = np.argsort(hkey)
+        dkey = np.minimum(dev_edges[:, 0], dev_edges[:, 1]) * nv + np.maximum(dev_edges[:, 0], dev_edges[:, 1])
+        pos = hsort[np.searchsorted(hkey[hsort], dkey)]
+        if len(he) != len(dev_edges) or not np.array_equal(hkey[pos], dkey):
+            raise SolverError("internal error: host and device disagree on the edges of the local mesh")
+        l2h = np.empty(nv + len(dev_edges), dtype=np.int64)
+        l2h[plan.node_of_vertex] = np.arange(nv)
+        l2h[plan.node_of_edge] = nv + pos
+
+        def dof_lists(lists):
+            if nc_ == 1:
+                return lists
+            return [(np.asarray(l, dtype=np.int64)[:, None] * nc_ + np.arange(nc_)[None, :]).reshape(-1).astype(np.int32) for l in lists]
+        ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts], recv_lists=dof_lists(plan.recv_lists))
+        root._localizer = parallel.LocalNodeView(plan.n_owned_nodes, l2h, mesh.num_cells(), lay["n_owned"], nc_, lay["l2g"],
+                                                 lay["n_global"], plan.edge_gid_pairs)
         return ds
 
     def localizer(self):

@@ -124,6 +124,7 @@ class LocalView:
     """The Localizer of a DISTRIBUTED mesh (fem.BoxMesh(distributed=True)): host arrays are already this rank's - owned
     entries first, ghosts after - so every map is the identity; what remains is to know which entries are owned."""
     is_local_view = True
+    is_identity = True       # host order == device order (P1 on a distributed box); LocalNodeView (CG2) permutes
 
     def __init__(self, n_owned, n_local, n_cells, l2g, n_global, ncomp):
         self.n_owned, self.n_local, self.ncomp = int(n_owned), int(n_local), int(ncomp)
@@ -151,6 +152,81 @@ class LocalView:
 
     def spec(self, spec):
         return spec
+
+
+class LocalNodeView(LocalView):
+    """The view of a CG2 space on a DISTRIBUTED mesh.  Host arrays are this rank's (local vertices, then the edges of the
+    local cells in the host's edge order); the device numbers the same nodes [owned vertices | owned edges | ghost vertices |
+    ghost edges] (fs_space_create), so every map is a permutation of local data - l2h[device node] = host node - and still
+    nothing of global size exists on any rank.  Vertex ids (facet lists, cells) are the same on both sides."""
+    is_identity = False
+
+    def __init__(self, n_owned_nodes, l2h, n_cells, n_owned_vertices, ncomp, vertex_gids, n_global_vertices, edge_gid_pairs):
+        self.l2h = np.asarray(l2h, dtype=np.int64)
+        self.h2l = np.empty(len(self.l2h), dtype=np.int64)
+        self.h2l[self.l2h] = np.arange(len(self.l2h))
+        self.n_owned, self.n_local, self.ncomp = int(n_owned_nodes), len(self.l2h), int(ncomp)
+        self.n_owned_vertices = int(n_owned_vertices)
+        self.vertex_gids, self.n_global_vertices = np.asarray(vertex_gids, dtype=np.int64), int(n_global_vertices)
+        self.edge_gid_pairs = edge_gid_pairs           # (g0, g1) of every local edge, in DEVICE edge order
+        self.part = _Part()
+        self.part.n_owned = self.n_owned_vertices
+        self.part.cell_gids = np.arange(int(n_cells))
+
+    def owned_gids(self):
+        raise RuntimeError("a CG2 space on a distributed mesh has no global node numbering: use parallel.gather_nodes(u)")
+
+    def nodes(self, arr):
+        a = np.asarray(arr)
+        if a.shape[0] == self.n_local:
+            return a[self.l2h]
+        return a.reshape(self.n_local, -1)[self.l2h].reshape(-1)
+
+    def to_host(self, device_values):
+        """device order (owned + ghost entries, ncomp per node) -> the host's node order"""
+        a = np.asarray(device_values)[:self.n_local * self.ncomp].reshape(self.n_local, -1)
+        return a[self.h2l].reshape(-1)
+
+    def dofs(self, dofs, vals):
+        d = np.asarray(dofs, dtype=np.int64)
+        return (self.h2l[d // self.ncomp] * self.ncomp + d % self.ncomp).astype(np.int32), np.asarray(vals, dtype=np.float64)
+
+    def facets(self, tri):
+        t = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+        mask = (t < self.n_owned_vertices).any(axis=1)
+        return t[mask].astype(np.int32), mask
+
+    def spec(self, spec):
+        if isinstance(spec, tuple) and spec[0] == "nodal":
+            return (spec[0], self.nodes(spec[1]))
+        return spec
+
+
+def gather_nodes(u):
+    """The owned nodal values of a Function on a distributed mesh from every rank, with keys that name the nodes globally:
+    (vertex_gids [n], vertex_values [n, ncomp], edge_keys [m, 2] = global end points (g0 < g1), edge_values [m, ncomp]).
+    P1 spaces return empty edge arrays."""
+    V = u.function_space()
+    loc = V.localizer()
+    nc = V._ncomp
+    vals = np.asarray(u.vector().get_local()).reshape(-1, nc)
+    if not isinstance(loc, LocalNodeView):
+        if loc is None or not getattr(loc, "is_local_view", False):
+            nv = V.mesh().num_vertices()
+            ed = V.edge_nodes().astype(np.int64) if V.degree() == 2 else np.zeros((0, 2), dtype=np.int64)
+            return np.arange(nv), vals[:nv], ed, vals[nv:]
+        g = gather_owned(vals[:loc.n_owned].reshape(-1), loc.owned_gids(), loc.n_global, nc).reshape(-1, nc)
+        return np.arange(loc.n_global), g, np.zeros((0, 2), dtype=np.int64), np.zeros((0, nc))
+    dev = vals[loc.l2h]                                    # device order: [owned vertices | owned edges | ghosts]
+    nvo = loc.n_owned_vertices
+    neo = loc.n_owned - nvo
+    vg = allgather_index_lists(loc.vertex_gids[:nvo])
+    vv = allgather_values(dev[:nvo].reshape(-1))
+    g0, g1 = loc.edge_gid_pairs
+    e0, e1 = allgather_index_lists(g0[:neo]), allgather_index_lists(g1[:neo])
+    ev = allgather_values(dev[nvo:nvo + neo].reshape(-1))
+    return (np.concatenate(vg), np.concatenate(vv).reshape(-1, nc), np.stack([np.concatenate(e0), np.concatenate(e1)], axis=1),
+            np.concatenate(ev).reshape(-1, nc))
 
 
 def gather_function(u):

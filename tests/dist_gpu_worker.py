@@ -54,9 +54,16 @@ else:
         # the host mesh of this rank is exactly what the device generated for its slab
         xyz, cells, gid = mesh.device().get(True, True, True)
         assert np.array_equal(xyz, mesh.coordinates()) and np.array_equal(cells, mesh.cells()) and np.array_equal(gid, mesh.global_vertex_ids())
-        full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
-        if rank == 0:
-            result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices())
+        if solver.function_space.degree() == 2:
+            # CG2: nodes are named by global keys (vertex id / the two global end points of an edge); no global numbering exists
+            vg, vv, ek, ev = parallel.gather_nodes(u)
+            if rank == 0:
+                result = dict(vertex_gids=vg, vertex_values=vv, edge_keys=ek, edge_values=ev, iterations=solver.last_solve_stats["iterations"],
+                              n_local=solver.function_space.num_nodes())
+        else:
+            full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
+            if rank == 0:
+                result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices())
     else:
         extra = {}
         if case.startswith("elasticity") and hasattr(solver, "von_Mises"):

@@ -80,6 +80,34 @@ def test_distributed_box_mesh_no_global_host_mesh(gpu, tmp_path, case, world):
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
 
 
+@pytest.mark.parametrize("case,world", [("heat_p2_dist", 2), ("heat_p2_dist", 3), ("heat_p2_cn_dist", 2), ("elasticity_p2_dist", 2),
+                                        ("elasticity_p2_dist", 3)])
+def test_distributed_box_mesh_with_p2_spaces(gpu, tmp_path, case, world):
+    """CG2 spaces on BoxMesh(distributed=True): the node plan is derived from this rank's cells alone
+    (partition.build_p2_plan_local), the host keeps only its slab - its node count stays below 1.3 / world of the global one plus
+    the ghost layers - and the field gathered by global keys (vertex id, end points of an edge) equals the one-process solve."""
+    import test_gpu_parallel_api as T
+    one = T.DIST_CASES[case]()
+    single = one.solve().vector().get_local()
+    V = one.function_space
+    nc = V._ncomp
+    nv = one.mesh.num_vertices()
+    ed = V.edge_nodes().astype(np.int64)
+    r = _run(world, case, tmp_path)
+    S = single.reshape(-1, nc)
+    scale = np.abs(S).max()
+    assert len(r["vertex_gids"]) == nv and len(r["edge_keys"]) == len(ed)            # every node owned exactly once
+    assert np.abs(r["vertex_values"] - S[r["vertex_gids"]]).max() <= 1e-8 * scale
+    key = {(int(a), int(b)): k for k, (a, b) in enumerate(ed)}
+    idx = np.array([key[(int(a), int(b))] for a, b in r["edge_keys"]])
+    assert len(np.unique(idx)) == len(ed)
+    assert np.abs(r["edge_values"] - S[nv + idx]).max() <= 1e-8 * scale
+    # nothing of global size on a rank: owned slab + two ghost planes' worth of nodes
+    nx, ny, nz = one.mesh._box[:3]
+    ghost_layers = 2.0 * (V.num_nodes() / (nz + 1.0)) * 2.0
+    assert int(r["n_local"]) <= V.num_nodes() / world * 1.3 + ghost_layers
+
+
 @pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2), ("radiation", 2)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,

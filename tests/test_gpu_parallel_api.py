@@ -174,7 +174,11 @@ NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radi
 
 # BoxMesh(distributed=True): every rank builds only its z-slab on the host (one rank: the same mesh as the replicated one)
 DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist": lambda: _heat_case(transient=True, distributed=True),
-              "elasticity_dist": lambda: _elastic_case(distributed=True)}
+              "elasticity_dist": lambda: _elastic_case(distributed=True),
+              # CG2 spaces on the distributed box: node plan from local cells only, host <-> device through a local permutation
+              "heat_p2_dist": lambda: _heat_case(4, degree=2, distributed=True),
+              "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
+              "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2)}
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          "heat_supg": lambda: _heat_case(supg=True),
