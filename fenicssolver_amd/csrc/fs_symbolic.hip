@@ -1153,8 +1153,31 @@ __device__ __forceinline__ uint64_t fs_spread21(uint64_t v) {      // ...abc -> 
     return v;
 }
 
+// Hilbert index of a point with 21-bit integer coordinates (Skilling, "Programming the Hilbert curve", 2004: the transpose
+// form, then the bits interleaved).  Unlike the Morton curve the Hilbert curve never jumps: consecutive indices are always
+// neighbouring cells of the lattice, so the rows of a SELL slice and of the contiguous chunk an XCD sweeps form compact blobs.
+__device__ __forceinline__ uint64_t fs_hilbert_key(uint32_t X0, uint32_t X1, uint32_t X2, int n) {
+    uint32_t X[3] = {X0, X1, X2};
+    const uint32_t M = 1u << 20;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {         // inverse undo
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < n; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    for (int i = 1; i < n; ++i) X[i] ^= X[i - 1];   // Gray encode
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[n - 1] & Q) t ^= Q - 1;
+    for (int i = 0; i < n; ++i) X[i] ^= t;
+    // interleave: bit b of X[0] is the most significant of the three at level b
+    if (n == 3) return fs_spread21(X[0]) << 2 | fs_spread21(X[1]) << 1 | fs_spread21(X[2]);
+    return fs_spread21(X[0]) << 1 | fs_spread21(X[1]);      // (2-D: 3-way spread of two words still orders correctly)
+}
+
 __global__ void k_morton_keys(int64_t nv, int gdim, const double* __restrict__ xyz, double x0, double y0, double z0,
-                              double sx, double sy, double sz, uint64_t* __restrict__ key, int32_t* __restrict__ idx) {
+                              double sx, double sy, double sz, int curve, uint64_t* __restrict__ key, int32_t* __restrict__ idx) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < nv; i += stride) {
@@ -1162,7 +1185,8 @@ __global__ void k_morton_keys(int64_t nv, int gdim, const double* __restrict__ x
         const uint64_t a = (uint64_t)fmin(fmax((p[0] - x0) * sx, 0.0), 2097151.0);
         const uint64_t b = (uint64_t)fmin(fmax((p[1] - y0) * sy, 0.0), 2097151.0);
         const uint64_t c = gdim == 3 ? (uint64_t)fmin(fmax((p[2] - z0) * sz, 0.0), 2097151.0) : 0ull;
-        key[i] = fs_spread21(a) | fs_spread21(b) << 1 | fs_spread21(c) << 2;
+        key[i] = curve == 1 ? fs_hilbert_key((uint32_t)a, (uint32_t)b, (uint32_t)c, gdim)
+                            : (fs_spread21(a) | fs_spread21(b) << 1 | fs_spread21(c) << 2);
         idx[i] = (int32_t)i;
     }
 }
@@ -1217,8 +1241,10 @@ extern "C" int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, i
     FS_CHECK(dx.alloc(nv * gdim));
     FS_CHECK(dx.upload(xyz, nv * gdim, s));
     FS_CHECK(k_in.alloc(nv)); FS_CHECK(k_out.alloc(nv)); FS_CHECK(v_in.alloc(nv)); FS_CHECK(v_out.alloc(nv)); FS_CHECK(rank.alloc(nv));
+    static const char* curve_env = getenv("FS_LOCALITY_CURVE");          // "morton" | "hilbert" (default)
+    const int curve = (curve_env && curve_env[0] == 'm') ? 0 : 1;
     hipLaunchKernelGGL(k_morton_keys, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, gdim, dx.p, lo[0], lo[1], gdim == 3 ? lo[2] : 0.0,
-                       sc, sc, sc, k_in.p, v_in.p);
+                       sc, sc, sc, curve, k_in.p, v_in.p);
     FS_KERNEL_CHECK();
     size_t tb = 0;
     FS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)nv, 0, 63, s));
