@@ -341,9 +341,7 @@ class ScalarTransportSolver(SolverBase):
             ads = self.settings.get('advection_settings') or {'stabilization_method': None}
             method = ads.get('stabilization_method')
             supg_pe, ip_coef = 0.0, 0.0
-            if method == 'IP':        # interior penalty on the jump of the normal gradient (:312-315)
-                if self.function_space.degree() != 1:
-                    raise SolverError("IP stabilisation is built for P1 spaces")
+            if method == 'IP':        # interior penalty on the jump of the normal gradient (:312-315), P1 and P2
                 cap = self.capacity()
                 if not isinstance(cap, numbers.Number):
                     raise SolverError("IP stabilisation needs a constant capacity")

@@ -1787,6 +1787,125 @@ __global__ void k_interior_penalty_tri(int64_t nf, const int32_t* __restrict__ f
     }
 }
 
+// ---- interior penalty on CG2 spaces (the reference's term is degree-agnostic, ScalarTransportSolver.py:312-315) -------------
+// jump(grad phi_a, n) of a P2 basis function is LINEAR along the facet, the integrand quadratic: the 3 edge mid-points of the
+// facet (weights 1/3) on tetrahedra, 2-point Gauss-Legendre on the shared edge of two triangles - both exact.  Nodes of a facet
+// patch: the NK nodes of K+ and the NK - NF nodes K- does not share (its opposite vertex and the edges from it): 14 / 9.
+// Thread (facet, a): all jumps at the quadrature points (shared-node contributions of K- found by node id), then row a.
+template <int TD>
+__device__ __forceinline__ void ip_p2_grad_n(int n, const double* lam, const double (*gl)[3], const double* nrm, double* out) {
+    // grad phi_n . nrm at barycentric lam (TD+1 coordinates), UFC edge order of the cell type
+    constexpr int NV = TD + 1;
+    const int EI3[6] = {2, 1, 1, 0, 0, 0}, EJ3[6] = {3, 3, 2, 3, 2, 1}, EI2[3] = {1, 0, 0}, EJ2[3] = {2, 2, 1};
+    double g[3] = {0.0, 0.0, 0.0};
+    if (n < NV) {
+        const double d = 4.0 * lam[n] - 1.0;
+        for (int k = 0; k < TD; ++k) g[k] = d * gl[n][k];
+    } else {
+        const int i = TD == 3 ? EI3[n - NV] : EI2[n - NV], j = TD == 3 ? EJ3[n - NV] : EJ2[n - NV];
+        for (int k = 0; k < TD; ++k) g[k] = 4.0 * (lam[i] * gl[j][k] + lam[j] * gl[i][k]);
+    }
+    double r = 0.0;
+    for (int k = 0; k < TD; ++k) r += g[k] * nrm[k];
+    *out = r;
+}
+
+template <int TD>
+__global__ void k_interior_penalty_p2(int64_t nf, const int32_t* __restrict__ facet_cells, const int32_t* __restrict__ cells,
+                                      const int32_t* __restrict__ cell_dofs, const double* __restrict__ xyz4, double coef,
+                                      int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                      double* __restrict__ val, int* __restrict__ err) {
+    constexpr int NV = TD + 1, NK = TD == 3 ? 10 : 6, NF = TD == 3 ? 6 : 3, NP = 2 * NK - NF, NQ = TD == 3 ? 3 : 2;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * NP; t += stride) {
+        const int64_t f = t / NP;
+        const int a = (int)(t - f * NP);
+        const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
+        int32_t v0[4], v1[4];
+        for (int i = 0; i < NV; ++i) { v0[i] = cells[c0 * 4 + i]; v1[i] = cells[c1 * 4 + i]; }
+        int o0 = -1, o1 = -1;
+        for (int i = 0; i < NV; ++i) {
+            bool in1 = false, in0 = false;
+            for (int j = 0; j < NV; ++j) { in1 |= v0[i] == v1[j]; in0 |= v1[i] == v0[j]; }
+            if (!in1) o0 = o0 < 0 ? i : NV;
+            if (!in0) o1 = o1 < 0 ? i : NV;
+        }
+        if (o0 < 0 || o0 >= NV || o1 < 0 || o1 >= NV) { if (a == 0) atomicAdd(err, 1); continue; }
+        double g0[4][3], g1[4][3], h0, h1, meas, nrm[3] = {0.0, 0.0, 0.0};
+        if (TD == 3) {
+            const int32_t w0[4] = {v0[0], v0[1], v0[2], v0[3]}, w1[4] = {v1[0], v1[1], v1[2], v1[3]};
+            const tet_geom G0 = tet_geometry(xyz4, w0), G1 = tet_geometry(xyz4, w1);
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) { g0[i][k] = G0.g[i][k]; g1[i][k] = G1.g[i][k]; }
+            h0 = tet_circum_h(xyz4, w0, G0.adet);
+            h1 = tet_circum_h(xyz4, w1, G1.adet);
+            const double gn = sqrt(g0[o0][0] * g0[o0][0] + g0[o0][1] * g0[o0][1] + g0[o0][2] * g0[o0][2]);
+            for (int k = 0; k < 3; ++k) nrm[k] = -g0[o0][k] / gn;
+            meas = 0.5 * G0.adet * gn;
+        } else {
+            const int32_t w0[3] = {v0[0], v0[1], v0[2]}, w1[3] = {v1[0], v1[1], v1[2]};
+            const tri_geom G0 = tri_geometry2(xyz4, w0[0], w0[1], w0[2]), G1 = tri_geometry2(xyz4, w1[0], w1[1], w1[2]);
+            for (int i = 0; i < 3; ++i) for (int k = 0; k < 2; ++k) { g0[i][k] = G0.g[i][k]; g1[i][k] = G1.g[i][k]; }
+            h0 = tri_circum_h(xyz4, w0, G0.area);
+            h1 = tri_circum_h(xyz4, w1, G1.area);
+            const double gn = sqrt(g0[o0][0] * g0[o0][0] + g0[o0][1] * g0[o0][1]);
+            nrm[0] = -g0[o0][0] / gn; nrm[1] = -g0[o0][1] / gn;
+            meas = 2.0 * G0.area * gn;
+        }
+        const double hbar = 0.5 * (h0 + h1);
+        const double wf = coef * hbar * hbar * meas;
+        // patch nodes: the NK nodes of K+, then the nodes of K- that K+ does not have
+        int32_t node[NP];
+        int loc1[NP];                  // local index of the patch node in K-, -1 if absent
+        for (int i = 0; i < NK; ++i) { node[i] = cell_dofs[c0 * NK + i]; loc1[i] = -1; }
+        int np = NK;
+        for (int j = 0; j < NK; ++j) {
+            const int32_t nd = cell_dofs[c1 * NK + j];
+            int hit = -1;
+            for (int i = 0; i < NK; ++i) if (node[i] == nd) hit = i;
+            if (hit >= 0) loc1[hit] = j;
+            else if (np < NP) { node[np] = nd; loc1[np] = j; ++np; }
+        }
+        if (np != NP) { if (a == 0) atomicAdd(err, 1); continue; }
+        // quadrature points on the facet in the barycentric coordinates of either cell
+        double J[NQ][NP];
+        for (int q = 0; q < NQ; ++q) {
+            double bary[3];               // weights of the facet's vertices, in the order they appear in K+
+            if (TD == 3) { bary[0] = bary[1] = bary[2] = 0.5; bary[q] = 0.0; }
+            else { const double s_ = q == 0 ? 0.21132486540518713 : 0.7886751345948129; bary[0] = 1.0 - s_; bary[1] = s_; bary[2] = 0.0; }
+            double l0[4] = {0.0, 0.0, 0.0, 0.0}, l1[4] = {0.0, 0.0, 0.0, 0.0};
+            int kf = 0;
+            for (int i = 0; i < NV; ++i) {
+                if (i == o0) continue;
+                l0[i] = bary[kf];
+                for (int j = 0; j < NV; ++j) if (v1[j] == v0[i]) l1[j] = bary[kf];
+                ++kf;
+            }
+            for (int m = 0; m < NP; ++m) {
+                double jv = 0.0, tmp;
+                if (m < NK) { ip_p2_grad_n<TD>(m, l0, g0, nrm, &tmp); jv += tmp; }
+                if (loc1[m] >= 0) { ip_p2_grad_n<TD>(loc1[m], l1, g1, nrm, &tmp); jv -= tmp; }
+                J[q][m] = jv;
+            }
+        }
+        const int32_t row = node[a];
+        if (row >= n_rows) continue;
+        const int64_t sp0 = slice_ptr[row >> 6];
+        const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+        const int64_t base = sp0 + (row & 63);
+        for (int b = 0; b < NP; ++b) {
+            double e = 0.0;
+            for (int q = 0; q < NQ; ++q) e += J[q][a] * J[q][b];
+            e *= wf / NQ;                  // equal weights: 1/3 (edge mid-points of the triangle), 1/2 (2-point Gauss)
+            int k = -1;
+            for (int kk = 0; kk < width; ++kk)
+                if (sell_col[base + (int64_t)kk * FS_SLICE] == node[b]) { k = kk; break; }
+            if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], e);
+            else atomicAdd(err, 1);
+        }
+    }
+}
+
 // ---- Dirichlet ------------------------------------------------------------------------------------
 // "later entries win" without a host pass: first the largest list index naming each dof ...
 __global__ void k_bc_last_index(const int32_t* __restrict__ dofs, int64_t n, int32_t* __restrict__ idx) {
@@ -3161,8 +3280,8 @@ extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, con
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A && n_facets >= 0 && (n_facets == 0 || facet_cells), "fs_assemble_interior_penalty: bad arguments");
     fs_space_s* sp = A->space;
-    if (A->bs != 1 || sp->degree != 1) {
-        fs_set_error("fs_assemble_interior_penalty: built for scalar CG1 spaces");
+    if (A->bs != 1 || (sp->degree != 1 && sp->degree != 2)) {
+        fs_set_error("fs_assemble_interior_penalty: built for scalar CG1 / CG2 spaces");
         return FS_ERR_UNSUPPORTED;
     }
     if (n_facets == 0) return FS_OK;
@@ -3175,7 +3294,13 @@ extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, con
     FS_CHECK(d_err.alloc(1));
     FS_CHECK(d_err.zero(s));
     FS_CHECK(dfc.upload(facet_cells, 2 * n_facets, s));
-    if (sp->mesh->tdim == 2)
+    if (sp->degree == 2 && sp->mesh->tdim == 2)
+        hipLaunchKernelGGL(k_interior_penalty_p2<2>, dim3(fs_grid_for(9 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
+                           sp->mesh->cells.p, sp->cell_dofs, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
+    else if (sp->degree == 2)
+        hipLaunchKernelGGL(k_interior_penalty_p2<3>, dim3(fs_grid_for(14 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
+                           sp->mesh->cells.p, sp->cell_dofs, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
+    else if (sp->mesh->tdim == 2)
         hipLaunchKernelGGL(k_interior_penalty_tri, dim3(fs_grid_for(4 * n_facets, FS_BLOCK, 1 << 16)), dim3(FS_BLOCK), 0, s, n_facets, dfc.p,
                            sp->mesh->cells.p, sp->mesh->xyz.p, coefficient, sp->n_nodes_owned, sp->slice_ptr.p, sp->sell_col.p, A->val.p, d_err.p);
     else

@@ -762,6 +762,20 @@ class FunctionSpace:
         pairs = pairs[pairs[:, 0] != pairs[:, 1]]
         return np.unique(pairs, axis=0).astype(np.int32)
 
+    def _interior_facet_node_pairs(self):
+        """CG2: the node couplings an interior-facet integral adds to the sparsity pattern - every node of K+ that K- does not
+        share (its vertex opposite the facet and the edges from it) with every such node of K-."""
+        ca, cb = self._mesh.interior_facet_cells()[0].astype(np.int64).T
+        cn = self.cell_nodes().astype(np.int64)
+        A, B = cn[ca], cn[cb]
+        eq = A[:, :, None] == B[:, None, :]
+        only_a, only_b = ~eq.any(axis=2), ~eq.any(axis=1)
+        k = int(only_a[0].sum()) if len(A) else 0
+        if len(A) and not (np.all(only_a.sum(axis=1) == k) and np.all(only_b.sum(axis=1) == k)):
+            raise SolverError("internal error: interior facets do not share a full facet's nodes")
+        pa, pb = A[only_a].reshape(-1, k), B[only_b].reshape(-1, k)
+        return np.stack([np.repeat(pa, k, axis=1).ravel(), np.tile(pb, (1, k)).ravel()], axis=1).astype(np.int32)
+
     def ufl_element(self):
         return self._ufl_element
 
@@ -910,9 +924,11 @@ class FunctionSpace:
                     raise SolverError("periodic_boundary (constrained_domain) is built for one GPU")
                 root._device = self._make_parallel_device(root, backend, parallel)
             else:
-                pairs = root._mesh.interior_facet_cells()[1] if facet_coupling else None
-                if facet_coupling and (root._degree != 1 or root._ncomp != 1):
-                    raise SolverError("interior-facet (IP) terms are built for scalar P1 spaces")
+                pairs = None
+                if facet_coupling:
+                    if root._ncomp != 1:
+                        raise SolverError("interior-facet (IP) terms are built for scalar spaces")
+                    pairs = root._mesh.interior_facet_cells()[1] if root._degree == 1 else root._interior_facet_node_pairs()
                 if root._periodic is not None:
                     extra = root._periodic_couplings()
                     pairs = extra if pairs is None else np.concatenate([np.asarray(pairs, dtype=np.int32).reshape(-1, 2), extra])

@@ -1589,3 +1589,82 @@ def tri_p2_von_mises_projection(coords, cells, cell_dofs, u, E, nu):
     b = assemble_generic_vector(len(coords), ce, be)
     M = assemble_generic(len(coords), ce, tri_mass_local(coords, cells, 1.0))
     return solve_direct(M, b), b
+
+
+# ---- interior penalty on P2 spaces (ScalarTransportSolver.py:312-315 is degree-agnostic) ---------------------------------
+def assemble_p2_interior_penalty(coords, cells, coefficient, n_quad=4):
+    """+ coefficient * avg(h)^2 * jump(grad T, n) * jump(grad q, n) dS for the P2 basis, tetrahedra (4-column cells) or
+    triangles (3-column cells).  grad phi . n is linear along the facet, the integrand quadratic: integrated here with MORE
+    points than needed (tets: the 6-point degree-4 rule; triangles: n_quad-point Gauss-Legendre) - the device uses the minimal
+    exact rules.  Dofs as p2_cell_dofs / tri_p2_cell_dofs number them."""
+    import scipy.sparse as sp
+    co = np.asarray(coords, dtype=np.float64)
+    ce = np.asarray(cells, dtype=np.int64)
+    tdim = ce.shape[1] - 1
+    if tdim == 3:
+        cd, edges = p2_cell_dofs(len(co), ce)
+        _, g = p1_geometry(co, ce)
+        h = 2.0 * tet_circumradius(co, ce)
+        facets, cell_facets, _ = facet_numbering(ce)
+        loc_edges = P2_EDGE_VERTS
+        qp = np.array([[0.108103018168070, 0.445948490915965, 0.445948490915965], [0.445948490915965, 0.108103018168070, 0.445948490915965],
+                       [0.445948490915965, 0.445948490915965, 0.108103018168070], [0.816847572980459, 0.091576213509771, 0.091576213509771],
+                       [0.091576213509771, 0.816847572980459, 0.091576213509771], [0.091576213509771, 0.091576213509771, 0.816847572980459]])
+        qw = np.array([0.223381589678011] * 3 + [0.109951743655322] * 3)
+    else:
+        cd, edges = tri_p2_cell_dofs(len(co), ce)
+        area_c, g = tri_geometry(co, ce)
+        X = co[ce]
+        d = lambda p, q: np.linalg.norm(X[:, p] - X[:, q], axis=1)          # noqa: E731
+        h = d(0, 1) * d(1, 2) * d(2, 0) / (2.0 * area_c)
+        facets, cell_facets, _ = tri_edge_numbering(ce)
+        loc_edges = TRI_P2_EDGES
+        xg, wg = np.polynomial.legendre.leggauss(n_quad)
+        qp = np.stack([0.5 * (1.0 - xg), 0.5 * (1.0 + xg)], axis=1)
+        qw = 0.5 * wg
+    cd = cd.astype(np.int64)
+    n = len(co) + len(edges)
+    nvc = tdim + 1
+    sides = {}
+    for c in range(len(ce)):
+        for i in range(nvc):
+            sides.setdefault(int(cell_facets[c, i]), []).append((c, i))
+    rows, cols, vals = [], [], []
+    for f, ss in sides.items():
+        if len(ss) != 2:
+            continue
+        fv = facets[f].astype(np.int64)
+        P = co[fv]
+        if tdim == 3:
+            nrm = np.cross(P[1] - P[0], P[2] - P[0])
+            meas = 0.5 * np.linalg.norm(nrm)
+        else:
+            t = P[1] - P[0]
+            nrm = np.array([t[1], -t[0]])
+            meas = np.linalg.norm(t)
+        nrm = nrm / np.linalg.norm(nrm)
+        w0 = coefficient * (0.5 * (h[ss[0][0]] + h[ss[1][0]])) ** 2 * meas
+        Jq = []
+        for bary in qp:
+            J = {}
+            for c, i in ss:
+                outward = nrm if np.dot(nrm, P[0] - co[ce[c, i]]) > 0 else -nrm
+                lam = np.zeros(nvc)
+                for k, v in enumerate(fv):
+                    lam[list(ce[c]).index(v)] = bary[k]
+                dphi = np.zeros((len(cd[c]), nvc))
+                for a in range(nvc):
+                    dphi[a, a] = 4.0 * lam[a] - 1.0
+                for e, (p_, q_) in enumerate(loc_edges):
+                    dphi[nvc + e, p_] = 4.0 * lam[q_]
+                    dphi[nvc + e, q_] = 4.0 * lam[p_]
+                gphi = dphi @ g[c]
+                for a in range(len(cd[c])):
+                    J[int(cd[c, a])] = J.get(int(cd[c, a]), 0.0) + float(gphi[a] @ outward)
+            Jq.append(J)
+        nodes = list(Jq[0])
+        for a in nodes:
+            for b in nodes:
+                rows.append(a); cols.append(b)
+                vals.append(w0 * sum(wq * J[a] * J[b] for wq, J in zip(qw, Jq)))
+    return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
