@@ -1798,6 +1798,7 @@ extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
 int64_t fs_amg_rows(const fs_amg_s* amg) { return amg && !amg->lv.empty() ? amg->lv[0]->n : 0; }
 
 extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats) {
+    std::lock_guard<std::recursive_mutex> solve_lock(fs_solve_mutex());
     FS_REQUIRE(M && b && x && opts && stats, "fs_amg_solve: null pointer");
     amg_level* L0 = M->lv[0];
     const int64_t n = L0->n;

@@ -60,6 +60,10 @@ fs_runtime& fs_rt();
 // Serial numbers of spaces and matrices: heap and pool addresses are recycled after a destroy, so anything cached per
 // operator (the captured CG batch of fs_krylov.hip) is keyed on these, never on addresses alone.
 uint64_t fs_next_serial();
+// The solver workspaces (fs_krylov.hip, fs_saddle.hip) and the one compute stream belong to the process: solves are serialised
+// by this lock, so that concurrent calls from several host threads are slow rather than wrong.
+#include <mutex>
+std::recursive_mutex& fs_solve_mutex();
 struct fs_matrix_s;
 void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s);   // fs_saddle.hip: unit diagonal on the dummy pressure slots
 int fs_require_init();

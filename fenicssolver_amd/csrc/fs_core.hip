@@ -139,6 +139,11 @@ int fs_require_init() {
     return FS_OK;
 }
 
+std::recursive_mutex& fs_solve_mutex() {
+    static std::recursive_mutex* m = new std::recursive_mutex;      // never destroyed (static-destruction order)
+    return *m;
+}
+
 uint64_t fs_next_serial() {
     static std::atomic<uint64_t> next{1};
     return next.fetch_add(1);

@@ -1459,6 +1459,7 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
 
 extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,
                                fs_krylov_stats* stats) {
+    std::lock_guard<std::recursive_mutex> solve_lock(fs_solve_mutex());
     FS_CHECK(fs_require_init());
     FS_REQUIRE(A && b && x && opts, "fs_krylov_solve: null pointer");
     if (opts->method != FS_KSP_CG && opts->method != FS_KSP_BICGSTAB) {

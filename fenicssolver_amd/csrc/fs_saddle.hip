@@ -1460,6 +1460,7 @@ static int sd_precond(fs_matrix_s* J, fs_matrix_s* Kp, fs_amg_s* Kp_amg, fs_matr
 
 extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, fs_matrix_t Mp, fs_vector_t b, fs_vector_t x,
                                const fs_saddle_opts* o, fs_krylov_stats* stats) {
+    std::lock_guard<std::recursive_mutex> solve_lock(fs_solve_mutex());
     FS_CHECK(fs_require_init());
     FS_REQUIRE(J && Mp && b && x && o && stats, "fs_saddle_solve: null pointer");
     fs_space_s* sp = J->space;

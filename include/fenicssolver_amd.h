@@ -23,8 +23,10 @@
  *     fs_comm_init (RCCL).  All field arithmetic is fp64, connectivity is int32.
  *   - threading: one thread at a time per process, as for the PETSc objects of one communicator.  All work is
  *     ordered on the library's single HIP stream, the device block cache and the Krylov / AMG / saddle-point work
- *     spaces (and fs_krylov_history) belong to the process: callers with several threads serialise their calls;
- *     concurrency comes from running one process per GPU.
+ *     spaces (and fs_krylov_history) belong to the process.  The three solve entry points (fs_krylov_solve, fs_amg_solve,
+ *     fs_saddle_solve) take a process-wide lock and the block cache its own, so concurrent calls from several threads are
+ *     serialised, not undefined; assembly calls on DIFFERENT handles may overlap on the host but still share the stream.
+ *     Concurrency comes from running one process per GPU.
  */
 #ifndef FENICSSOLVER_AMD_H
 #define FENICSSOLVER_AMD_H
