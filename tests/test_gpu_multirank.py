@@ -68,6 +68,20 @@ def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
 
 
+@pytest.mark.parametrize("case,world,renumber", [("heat_file", 2, "1"), ("heat_file", 3, "0"), ("heat_file_p2", 2, "1")])
+def test_file_mesh_under_several_ranks(gpu, tmp_path, monkeypatch, case, world, renumber):
+    """An unstructured mesh FILE (data/mesh.xml) decomposed over the ranks, each part numbered in locality order (FS_RENUMBER=1)
+    or in file order: T = 350 - 2.5 z as on one GPU."""
+    import test_gpu_parallel_api as T
+    monkeypatch.setenv("FS_RENUMBER", "0")
+    one = T.CASES[case]()
+    single = one.solve().vector().get_local()
+    r = _run(world, case, tmp_path, FS_RENUMBER=renumber)
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
+    X = one.function_space.node_coordinates()
+    assert np.abs(r["x"] - (350.0 - 2.5 * X[:, 2])).max() <= 1e-7
+
+
 @pytest.mark.parametrize("case,world", [("heat_dist", 2), ("heat_dist", 3), ("heat_cn_dist", 2), ("elasticity_dist", 2), ("elasticity_dist", 3)])
 def test_distributed_box_mesh_no_global_host_mesh(gpu, tmp_path, case, world):
     """BoxMesh(distributed=True): every rank builds only its slab on the host (vertex planes it owns + one ghost plane each

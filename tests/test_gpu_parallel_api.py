@@ -7,6 +7,7 @@ localisation), checked on one GPU two ways:
     old-step terms and the symmetric Dirichlet elimination included.
 The RCCL exchange itself is covered by test_gpu_comm.py and the gloo tests of the partition."""
 import copy
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -180,7 +181,21 @@ DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist":
               "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
               "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2)}
 
+def _file_mesh_case(degree=1):
+    """data/TestHeatTransfer.json on data/mesh.xml (a Gmsh mesh in file order): decomposed by RCB-free coordinate slabs, every part
+    numbered in the locality order of fs_mesh_locality_order when FS_RENUMBER=1."""
+    from fenicssolver_amd.main import load_settings
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    s = load_settings(os.path.join(data, "TestHeatTransfer.json"))
+    s["mesh"] = os.path.join(data, "mesh.xml")
+    s["report_settings"] = dict(QUIET)
+    s["fe_degree"] = degree
+    return ScalarTransportSolver(s)
+
+
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
+         "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
          "heat_supg": lambda: _heat_case(supg=True),
          "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
 
