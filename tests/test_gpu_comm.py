@@ -70,3 +70,57 @@ def test_rccl_single_rank_allreduce_and_self_halo(gpu):
         Vs.set_halo([0], [send2], [pl])
         gpu.halo_exchange(Vs, v)          # plan without communicator: loud
     Vs.set_halo([], [], [])
+
+
+@pytest.mark.parametrize("layout", ["two_neighbours_contiguous", "one_neighbour_packed"])
+def test_rccl_single_rank_pipelined_cg_with_self_halo(gpu, layout):
+    """REAL RCCL (the 1-rank communicator a 1-GPU box allows) under the pipelined CG: the all-reduce of the sums is enqueued on
+    the communication stream behind the grouped send / recv of the halo, the compute stream waits for both through events -
+    the stream / event interplay production runs, with the rank as its own neighbour.  A z-periodic slab: the lower ghost plane
+    receives the top owned plane, the upper ghost plane the bottom owned plane, so the operator (stiffness + mass) is the SPD
+    operator of the periodic problem.  Both recurrences must agree, with the early start of the exchange (contiguous prefix /
+    suffix sends) and with packed sends."""
+    uid = gpu.comm_unique_id()
+    gpu.comm_init(1, 0, uid)
+    try:
+        nx, ny, nz = 6, 5, 9
+        pl = (nx + 1) * (ny + 1)
+        slab = gpu.DeviceMesh.box(nx, ny, nz, zplanes=(1, nz))          # owned planes 1 .. nz-1, ghosts: plane 0 then plane nz
+        V = gpu.DeviceSpace(slab, 1)
+        n_own = (nz - 1) * pl
+        assert V.n_owned == n_own and V.n_local == n_own + 2 * pl
+        top = np.arange(n_own - pl, n_own, dtype=np.int32)               # feeds the LOWER ghost plane
+        bottom = np.arange(0, pl, dtype=np.int32)                        # feeds the UPPER ghost plane
+        if layout == "two_neighbours_contiguous":
+            V.set_halo([0, 0], [top, bottom], [pl, pl])
+        else:
+            V.set_halo([0], [np.concatenate([top, bottom])], [2 * pl])
+        A = gpu.DeviceMatrix(V)
+        A.assemble(stiffness=3.0, mass=5.0)
+        rng = np.random.default_rng(2)
+        b = gpu.DeviceVector(V.n_owned, rng.standard_normal(V.n_owned))
+        sols = []
+        for pipelined in (False, True):
+            x = gpu.DeviceVector(V.n_local)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-11, max_iter=2000, pipelined=pipelined)
+            assert st["converged"] == 1 and st["true_rel_residual"] <= 5e-11, (pipelined, st)
+            sols.append((x.get()[:V.n_owned].copy(), st["iterations"]))
+        (x0, it0), (x1, it1) = sols
+        assert -1 <= it1 - it0 <= 2
+        assert np.abs(x1 - x0).max() <= 1e-9 * np.abs(x0).max()
+        # and the answer is the periodic problem's: rows of the local matrix with the ghost columns folded onto the owned planes
+        rp, ci, va, shape = A.to_csr()
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        M = sp.csr_matrix((va, ci, rp), shape=shape).tocoo()
+        col = M.col.copy()
+        lower = (col >= n_own) & (col < n_own + pl)
+        upper = col >= n_own + pl
+        col[lower] = top[col[lower] - n_own]
+        col[upper] = bottom[col[upper] - n_own - pl]
+        Mp = sp.coo_matrix((M.data, (M.row, col)), shape=(n_own, n_own)).tocsr()
+        assert abs(Mp - Mp.T).max() <= 1e-12 * abs(Mp).max()
+        ref = spl.spsolve(Mp.tocsc(), b.get())
+        assert np.abs(x1 - ref).max() <= 1e-8 * np.abs(ref).max()
+    finally:
+        gpu.comm_finalize()
