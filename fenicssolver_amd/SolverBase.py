@@ -395,8 +395,15 @@ class SolverBase():
                              label, stats['iterations'], stats['converged'], stats['rel_residual'],
                              stats['true_rel_residual'], stats['solve_ms'])
         if stats['converged'] != 1:
-            raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
-                label, stats['iterations'], stats['true_rel_residual']))
+            # The LU-equivalent default (1e-12) may lie below what fp64 attains on a badly conditioned operator: a solve that
+            # stopped short of it but reached the accuracy this back end promised before (1e-8) is a result, with a warning -
+            # not an error; a tolerance the user asked for explicitly stays binding.
+            user_tol = 'krylov_relative_tolerance' in (self.solver_settings.get('solver_parameters', {}) or {})
+            if user_tol or stats['converged'] < 0 or not (stats['true_rel_residual'] <= 1e-8):
+                raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
+                    label, stats['iterations'], stats['true_rel_residual']))
+            self.logger.warning('%s: stopped at ||r||/||b|| = %.3e after %d iterations (default tolerance %.0e not attained)',
+                                label, stats['true_rel_residual'], stats['iterations'], rtol)
         per = u.function_space().periodic_pairs() if hasattr(u.function_space(), 'periodic_pairs') else None
         if per is not None:
             x.assign_entries(per[0], per[1], block=u.function_space()._ncomp)
