@@ -21,6 +21,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifndef FS_BLOCK_ROUND
+#define FS_BLOCK_ROUND 3      // 3x3 blocks per round of the vector-space product (measured: see DESIGN.md section 3)
+#endif
+
 // ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
 // One round of N entries of a scalar row: all 2N loads are issued before the first FMA, so the latency of a
 // round is one memory round trip whatever N is.  The remainder of a row (width % UNROLL entries) goes through
@@ -84,6 +88,29 @@ struct row_tail<0, NT> {
     static __device__ __forceinline__ void dia(int, const double*, const int32_t*, const int32_t*, bool, int, int32_t, int32_t, const double*, double&) {}
     static __device__ __forceinline__ void sell(int, const double*, const int32_t*, int, const double*, double&) {}
 };
+
+// One round of R block entries (BS x BS values each, vector spaces): all R * (BS*BS + BS) loads are issued before the first FMA,
+// as the scalar rounds above do - the serial loop it replaces had the 12 loads of ONE 3x3 block in flight per lane and was
+// latency-bound (fine-level product of the elasticity AMG, configs[2]).
+template <int BS, int R, bool NT>
+__device__ __forceinline__ void block_round(const double* __restrict__ vp, int64_t plane, const int64_t (&c)[R], int k,
+                                            const double* __restrict__ x, double (&acc)[BS]) {
+    double v[R][BS * BS], xv[R][BS];
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int q = 0; q < BS * BS; ++q) v[u][q] = fs_ldv<NT>(&vp[(int64_t)q * plane + (int64_t)(k + u) * FS_SLICE]);
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) xv[u][j] = x[c[u] * BS + j];
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int j = 0; j < BS; ++j)
+#pragma unroll
+            for (int i = 0; i < BS; ++i) acc[i] += v[u][i * BS + j] * xv[u][j];
+}
 
 template <int BS, int DOTS, int UNROLL, bool NT = false>
 __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
@@ -151,6 +178,18 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                 row_tail<UNROLL - 1, NT>::dia(width - k, vp, op, op2, hi, k, (int32_t)r, cmax, x, acc[0]);
                 k = width;
             }
+            if (BS > 1) {
+                constexpr int R = BS == 3 ? FS_BLOCK_ROUND : 2;
+                for (; k + R <= width; k += R) {
+                    int64_t c[R];
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        c[u] = r + (hi ? op2[k + u] : op[k + u]);
+                        c[u] = c[u] < 0 ? 0 : (c[u] > cmax ? cmax : c[u]);
+                    }
+                    block_round<BS, R, NT>(vp, plane, c, k, x, acc);
+                }
+            }
             for (; k < width; ++k) {
                 int64_t c = r + (hi ? op2[k] : op[k]);
                 c = c < 0 ? 0 : (c > cmax ? cmax : c);
@@ -167,6 +206,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t 
                 for (; k + UNROLL <= width; k += UNROLL) sell_round<UNROLL, NT>(vp, cp, k, x, acc[0]);
                 row_tail<UNROLL - 1, NT>::sell(width - k, vp, cp, k, x, acc[0]);
                 k = width;
+            }
+            if (BS > 1) {
+                constexpr int R = BS == 3 ? FS_BLOCK_ROUND : 2;
+                for (; k + R <= width; k += R) {
+                    int64_t c[R];
+#pragma unroll
+                    for (int u = 0; u < R; ++u) c[u] = fs_col_decode(fs_ldv<NT>(&cp[(int64_t)(k + u) * FS_SLICE]));
+                    block_round<BS, R, NT>(vp, plane, c, k, x, acc);
+                }
             }
             for (; k < width; ++k) {
                 const int64_t c = fs_col_decode(cp[(int64_t)k * FS_SLICE]);
