@@ -23,7 +23,13 @@ run_case() {   # tag, filter for the PMC average, command...
   rm -rf $OUT
 }
 P="python $R/bench.py --no-cpu-baseline --no-hbm-case"
-run_case p2 k_ $P --workload p2 --steps 2 --warmup 1
-run_case sell_unstructured_shuffled k_ $P --cells 215 --mesh shuffled --steps 1 --warmup 1
-run_case sell_unstructured_renumbered k_ $P --cells 215 --mesh renumbered --steps 1 --warmup 1
+CASES=${1:-p2 shuffled renumbered}
+for CASE in $CASES; do
+  case $CASE in
+    p2) run_case p2 k_ $P --workload p2 --steps 2 --warmup 1 ;;
+    p2_split) run_case p2_split_slices k_ $P --workload p2 --steps 2 --warmup 1 ;;
+    shuffled) run_case sell_unstructured_shuffled k_ $P --cells 215 --mesh shuffled --steps 1 --warmup 1 ;;
+    renumbered) run_case sell_unstructured_renumbered k_ $P --cells 215 --mesh renumbered --steps 1 --warmup 1 ;;
+  esac
+done
 ls -la $S
