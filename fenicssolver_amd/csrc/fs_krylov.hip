@@ -1934,6 +1934,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             FS_CHECK(fs_halo_end_dev(sp, s));
             sp->halo.begun = false;
         }
+        // pipelined: the reduction enqueued behind the last update still reads the partial sums on the communication stream;
+        // nothing of the workspace is touched again before it is through
+        if (red_stream) FS_HIP(hipStreamWaitEvent(s, ws.ev_red, 0));
         FS_HIP(hipStreamSynchronize(s));
         h_status[0] = h_status[1] = h_status[2] = h_status[3] = 0;
         FS_CHECK(ws.status.download(h_status, 4, s));

@@ -257,8 +257,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
                     // the shorter list is padded with its own last offset: those entries hold the value 0 and are marked
                     // non-structural by k_fill_sell (its cursor has passed the column by then)
                     if (lane == 0) {
-                        for (int k = na; k < best_w; ++k) offA[k] = offA[na - 1];
-                        for (int k = nb; k < best_w; ++k) offB[k] = offB[nb - 1];
+                        for (int k = na; k < best_w; ++k) offA[k] = na > 0 ? offA[na - 1] : 0;
+                        for (int k = nb; k < best_w; ++k) offB[k] = nb > 0 ? offB[nb - 1] : 0;      // (a piece of rows beyond n_rows is empty)
                     }
                     nd = best_w;
                     split = best;

@@ -933,6 +933,7 @@ class FunctionSpace:
                     extra = root._periodic_couplings()
                     pairs = extra if pairs is None else np.concatenate([np.asarray(pairs, dtype=np.int32).reshape(-1, 2), extra])
                 root._device = backend.DeviceSpace(root._mesh.device(), root._ncomp, root._degree, coupled_pairs=pairs)
+                root._localizer = None      # (a renumbered upload built earlier for this space had one: this device space is in file order)
         return root._device
 
     RENUMBER_MIN_VERTICES = 50000
