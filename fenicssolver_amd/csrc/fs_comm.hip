@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <rccl/rccl.h>
+#include <chrono>
 
 struct rccl_api {
     void* handle = nullptr;
@@ -123,9 +124,27 @@ extern "C" int fs_comm_finalize(void) {
     return FS_OK;
 }
 
+// host time spent inside the RCCL enqueue calls (FS_COMM_TIMING=1 prints it per solve: the distributed CG loop is bound by it
+// when the kernels of an iteration are shorter than the enqueue of its collectives)
+static double g_host_us[2] = {0.0, 0.0};
+static long g_host_calls[2] = {0, 0};
+struct host_timer {
+    int k; std::chrono::steady_clock::time_point t0;
+    explicit host_timer(int kind) : k(kind), t0(std::chrono::steady_clock::now()) {}
+    ~host_timer() { g_host_us[k] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++g_host_calls[k]; }
+};
+void fs_comm_host_time(double* allreduce_us, long* allreduce_calls, double* halo_us, long* halo_calls, bool reset) {
+    if (allreduce_us) *allreduce_us = g_host_us[0];
+    if (allreduce_calls) *allreduce_calls = g_host_calls[0];
+    if (halo_us) *halo_us = g_host_us[1];
+    if (halo_calls) *halo_calls = g_host_calls[1];
+    if (reset) { g_host_us[0] = g_host_us[1] = 0.0; g_host_calls[0] = g_host_calls[1] = 0; }
+}
+
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     if (!rt.comm) return FS_OK;  // one rank
+    host_timer timer(0);
     FS_NCCL(g_nccl.AllReduce(d_inout, d_inout, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)rt.comm, s));
     return FS_OK;
 }
@@ -308,6 +327,8 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
 int fs_halo_comm_stream(fs_space_s* space, hipStream_t* out) {
     fs_halo_plan& h = space->halo;
     if (!h.comm_stream) {
+        // (default priority on purpose: with the highest stream priority the grouped send / recv of a 1-rank RCCL communicator took
+        // 162 instead of 31 us and an iteration 303 instead of 66 us on MI355X / ROCm 7.2 - tools/probes/rccl_self_halo_probe.py)
         FS_HIP(hipStreamCreateWithFlags(&h.comm_stream, hipStreamNonBlocking));
         FS_HIP(hipEventCreateWithFlags(&h.ev_ready, hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&h.ev_done, hipEventDisableTiming));
@@ -337,6 +358,7 @@ int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
     FS_HIP(hipEventRecord(h.ev_ready, s));
     FS_HIP(hipStreamWaitEvent(cs, h.ev_ready, 0));
     double* ghosts = d_vec + space->n_dofs_owned;
+    host_timer timer(1);
     FS_NCCL(g_nccl.GroupStart());
     for (int i = 0; i < nn; ++i) {
         if (h.send_counts[i] > 0) {

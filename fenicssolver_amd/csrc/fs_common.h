@@ -262,6 +262,7 @@ static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int 
 // ---- cross-TU internals ------------------------------------------------------------------
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
+void fs_comm_host_time(double* allreduce_us, long* allreduce_calls, double* halo_us, long* halo_calls, bool reset);
 // inverse of the slot table: sources (cell*nd*nd + ab) of every stored block, ascending (gmap_ptr / gmap_src)
 int fs_space_build_gather_map(fs_space_s* space, hipStream_t s);
 int fs_halo_exchange_dev(fs_space_s* space, double* d_vec, hipStream_t s);

@@ -1981,6 +1981,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_HIP(hipStreamSynchronize(s));
     }
     const int iters = total_iters;
+    if (fs_rt().comm && getenv("FS_COMM_TIMING")) {
+        double au, hu; long ac, hc;
+        fs_comm_host_time(&au, &ac, &hu, &hc, true);
+        fprintf(stderr, "[fs_krylov] host time inside RCCL enqueue calls: all-reduce %.1f us x %ld, grouped send/recv %.1f us x %ld; %d iterations in %.1f ms\n",
+                ac ? au / ac : 0.0, ac, hc ? hu / hc : 0.0, hc, iters,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    }
     ws.last_hist.resize((size_t)iters + 1);
     FS_CHECK(ws.hist.download(ws.last_hist.data(), iters + 1, s));
     const auto t_end = std::chrono::steady_clock::now();
