@@ -54,6 +54,9 @@ from fenicssolver_amd import partition, parallel  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
+VARIANTS = ("single_reduction", "pipelined", "single_reduction+p2p")
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +71,7 @@ def parse():
                     help="p1: BASELINE configs[1] family (default); p2: configs[3] (P2, n=107); th: configs[4] (Taylor-Hood cavity n=43)")
     ap.add_argument("--extra", default="auto", help="extra legs at N>1: auto | none | comma list of strong,p2,th")
     ap.add_argument("--extra-budget", type=float, default=240.0, help="seconds the extra legs may take before the watchdog prints the line")
-    ap.add_argument("--recurrence", choices=("auto", "single_reduction", "pipelined"), default="auto",
+    ap.add_argument("--recurrence", choices=("auto",) + VARIANTS, default="auto",
                     help="CG recurrence of the timed leg at N>1 (auto: the faster of the two in a warm-up trial, agreed over the ranks)")
     ap.add_argument("--mesh", choices=("structured", "shuffled", "renumbered"), default="structured",
                     help="N=1 only: shuffled = random vertex + cell permutation of the cube uploaded as a file mesh would be, "
@@ -230,7 +233,7 @@ def p2_global_dofs(n):
     return (n + 1) ** 3 + 3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3      # vertices + axis, face-diagonal and body-diagonal edges
 
 
-def timed_steps(prob, rtol, steps, barrier):
+def timed_steps(prob, rtol, steps, barrier, reduce=True):
     barrier()
     t0 = time.perf_counter()
     asm_ms, stats = 0.0, None
@@ -238,27 +241,64 @@ def timed_steps(prob, rtol, steps, barrier):
         stats, t_asm = prob.step(rtol)
         asm_ms += t_asm
     barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    elapsed = time.perf_counter() - t0
+    if reduce:
+        elapsed = parallel.max_over_ranks(elapsed)
     return elapsed, asm_ms / steps, stats
 
 
-def choose_recurrence(prob, rtol, world, requested, barrier):
-    """At N > 1 both CG recurrences are run once warm in the warm-up phase and the faster one (max over the ranks, so
-    every rank decides alike) carries the timed steps.  Returns (name, {name: seconds per step})."""
+def set_variant(prob, name):
+    """CG recurrence (+ transport of the ghost refresh / all-reduce) of the next steps.  '+p2p': the peer-to-peer exchange
+    (fs_space_enable_p2p_halo: stores into the neighbours' hipIpc-mapped buffers, four kernels per iteration on one stream);
+    otherwise RCCL send / recv + ncclAllReduce.  Collective: every rank calls it alike."""
+    want = name.endswith("+p2p")
+    if want != getattr(prob, "p2p", False):
+        prob.V.enable_p2p_halo(want)         # raises on every rank alike when a mapping failed (the ranks agree inside)
+        prob.p2p = want
+    prob.pipelined = name.startswith("pipelined")
+
+
+def all_ranks_ok(ok):
+    """Agreement over RCCL proper (ncclAllGather), never over the transport under test."""
+    flags = B.comm_allgather([0.0 if ok else 1.0], 1)
+    return float(np.sum(flags)) == 0.0
+
+
+def choose_recurrence(prob, rtol, world, requested, barrier, steps=2):
+    """At N > 1 the variants are run warm in the warm-up phase and the fastest (max over the ranks, so every rank decides
+    alike) carries the timed steps.  A variant that fails on any rank (hipIpc mapping refused, a peer-to-peer wait timed
+    out) is dropped on all of them.  Returns (name, {name: ms per step | error})."""
     if world == 1:
         prob.pipelined = False
         return "single_reduction", {}
     if requested != "auto":
-        prob.pipelined = requested == "pipelined"
+        set_variant(prob, requested)
         return requested, {}
-    trial = {}
-    for name, flag in (("single_reduction", False), ("pipelined", True)):
-        prob.pipelined = flag
-        prob.step(rtol)
-        trial[name] = timed_steps(prob, rtol, 2, barrier)[0] / 2
+    os.environ.setdefault("FS_P2P_TIMEOUT_MS", "4000")
+    trial, report = {}, {}
+    for name in VARIANTS:
+        err = None
+        try:
+            set_variant(prob, name)
+        except B.BackendError as e:          # agreed inside the library: every rank is here
+            report[name] = "unavailable: " + str(e)[:200]
+            prob.p2p = False
+            continue
+        try:
+            prob.step(rtol)
+            t = timed_steps(prob, rtol, steps, barrier, reduce=False)[0] / steps
+        except Exception as e:               # this rank only, perhaps: the ranks compare notes below
+            err, t = repr(e)[:200], 0.0
+        if not all_ranks_ok(err is None):
+            report[name] = "failed: " + (err or "on another rank")
+            if getattr(prob, "p2p", False):
+                set_variant(prob, "single_reduction")
+            continue
+        trial[name] = float(np.max(B.comm_allgather([t], 1)))
+        report[name] = round(trial[name] * 1e3, 4)
     best = min(trial, key=trial.get)
-    prob.pipelined = best == "pipelined"
-    return best, {k: round(v * 1e3, 4) for k, v in trial.items()}
+    set_variant(prob, best)
+    return best, report
 
 
 def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
@@ -267,21 +307,44 @@ def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
     prob = Problem(n, n, n, (1.0, 1.0, 1.0), zplanes, axis, rank, world)
     res = {"workload": "unit cube n=%d (%d DOF, %d tets) split into %d z-slabs, T=350/300 on the %s-faces" % (n, (n + 1) ** 3, 6 * n ** 3, world, "xyz"[axis]),
            "anchor": "strong-scaling speed-up = dof_per_s / (roofline.dof_per_s of the N=1 line: the same cube on one GPU)"}
-    for name, flag in (("single_reduction", False), ("pipelined", True)):
-        prob.pipelined = flag
-        prob.step(rtol)
-        elapsed, asm_ms, st = timed_steps(prob, rtol, steps, barrier)
+    os.environ.setdefault("FS_P2P_TIMEOUT_MS", "4000")
+    done = []
+    for name in VARIANTS:
+        err, st, elapsed, asm_ms = None, None, 0.0, 0.0
+        try:
+            set_variant(prob, name)
+        except B.BackendError as e:
+            res[name] = {"unavailable": str(e)[:200]}
+            prob.p2p = False
+            continue
+        try:
+            prob.step(rtol)
+            elapsed, asm_ms, st = timed_steps(prob, rtol, steps, barrier, reduce=False)
+        except Exception as e:
+            err = repr(e)[:200]
+        if not all_ranks_ok(err is None):
+            res[name] = {"failed": err or "on another rank"}
+            if getattr(prob, "p2p", False):
+                set_variant(prob, "single_reduction")
+            continue
+        elapsed = float(np.max(B.comm_allgather([elapsed], 1)))
         ms = elapsed * 1e3 / steps
         res[name] = {"dof_per_s": round((n + 1) ** 3 / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "iterations": st["iterations"],
                      "assemble_ms": round(asm_ms, 4), "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
                      "spmv_kernel_ms": round(st["spmv_ms"], 5), "update_kernel_ms": round(st["update_ms"], 5),
                      "true_rel_residual": st["true_rel_residual"]}
-    best = min(("single_reduction", "pipelined"), key=lambda k: res[k]["ms_per_step"])
+        done.append(name)
+        last_st = st
+        if name.endswith("+p2p"):
+            _, h_ms = B.comm_benchmark(prob.V, 200)
+            res[name]["halo_ms"] = round(h_ms, 5)
+    best = min(done, key=lambda k: res[k]["ms_per_step"])
     res.update({"recurrence": best, "dof_per_s": res[best]["dof_per_s"], "iterations": res[best]["iterations"],
                 "ms_per_iteration": res[best]["ms_per_iteration"]})
+    set_variant(prob, "single_reduction")
     a_ms, h_ms = B.comm_benchmark(prob.V, 200)
     res.update({"allreduce_ms": round(a_ms, 5), "halo_ms": round(h_ms, 5)})
-    k = kernel_rates(st, prob.V)
+    k = kernel_rates(last_st, prob.V)
     res["spmv_algorithmic_GBps_rank0"] = k["algorithmic_GBps"]
     return res
 

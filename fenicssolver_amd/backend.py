@@ -170,6 +170,8 @@ class DeviceSpace(_Handle):
     def set_halo(self, neighbors, send_lists, recv_counts, recv_lists=None):
         """neighbors: ranks; send_lists: per neighbour array of owned local dofs; recv_counts: ghosts per neighbour;
         recv_lists: per neighbour the local ghost dof of every received value (None: ghosts grouped by neighbour)."""
+        if getattr(self, "_p2p", False):
+            self.enable_p2p_halo(False)
         nb = L.i32(neighbors)
         sc = L.i64([len(s) for s in send_lists])
         si = L.i32(np.concatenate([np.asarray(s, dtype=np.int32) for s in send_lists]) if len(send_lists) else [])
@@ -181,6 +183,15 @@ class DeviceSpace(_Handle):
             ri = L.i32(np.concatenate([np.asarray(r, dtype=np.int32) for r in recv_lists]) if len(recv_lists) else [])
             L.check(L.load().fs_space_set_halo_indexed(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc),
                                                        L.p_i32(ri)), "fs_space_set_halo_indexed")
+        if _comm_up and os.environ.get("FS_HALO_P2P", "0") == "1":
+            self.enable_p2p_halo(True)
+
+    def enable_p2p_halo(self, on=True):
+        """Ghost refresh by direct stores into the neighbours' memory (hipIpc mappings, one node) instead of RCCL send / recv.
+        COLLECTIVE: every rank of the communicator calls it for its space, in the same order (also to turn it off).
+        FS_HALO_P2P=1 turns it on for every halo plan set while a communicator is up."""
+        L.check(L.load().fs_space_enable_p2p_halo(self.h, 1 if on else 0), "fs_space_enable_p2p_halo")
+        self._p2p = bool(on)
 
 
 class DeviceVector(_Handle):
@@ -614,8 +625,13 @@ def comm_unique_id():
     return bytes(buf.raw)
 
 
+_comm_up = False
+
+
 def comm_init(n_ranks, rank, uid):
+    global _comm_up
     L.check(L.load().fs_comm_init(int(n_ranks), int(rank), C.c_char_p(uid)), "fs_comm_init")
+    _comm_up = True
 
 
 def comm_info():
@@ -626,7 +642,9 @@ def comm_info():
 
 
 def comm_finalize():
+    global _comm_up
     L.check(L.load().fs_comm_finalize(), "fs_comm_finalize")
+    _comm_up = False
 
 
 def comm_allreduce_sum(values):

@@ -11,6 +11,7 @@
 //
 // librccl is dlopen()ed on first use, so single-GPU processes never depend on it.
 #include "fs_common.h"
+#include "fs_kernels.h"
 #include <vector>
 #include <algorithm>
 #include <dlfcn.h>
@@ -114,6 +115,7 @@ extern "C" int fs_comm_info(int* n_ranks, int* rank) {
 
 extern "C" int fs_comm_finalize(void) {
     fs_runtime& rt = fs_rt();
+    fs_p2p_reduce_teardown();
     if (rt.comm) {
         (void)hipStreamSynchronize(rt.stream);
         FS_NCCL(g_nccl.CommDestroy((ncclComm_t)rt.comm));
@@ -144,9 +146,17 @@ void fs_comm_host_time(double* allreduce_us, long* allreduce_calls, double* halo
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     if (!rt.comm) return FS_OK;  // one rank
+    if (fs_p2p_reduce_enabled() && n <= 8) return fs_p2p_allreduce_dev(nullptr, 0, d_inout, n, s);
     host_timer timer(0);
     FS_NCCL(g_nccl.AllReduce(d_inout, d_inout, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)rt.comm, s));
     return FS_OK;
+}
+
+int fs_comm_sum_allreduce_dev(const double* partials, int npart, int nv, double* out, hipStream_t s) {
+    if (fs_rt().comm && fs_p2p_reduce_enabled() && nv <= 4) return fs_p2p_allreduce_dev(partials, npart, out, nv, s);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, partials, npart, nv, out);
+    FS_KERNEL_CHECK();
+    return fs_comm_allreduce_dev(out, nv, s);
 }
 
 extern "C" int fs_comm_allreduce_sum(double* host_inout, int n) {
@@ -200,6 +210,459 @@ __global__ void k_unpack(double* __restrict__ v, const int32_t* __restrict__ idx
 
 static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
                          const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
+
+// ---- peer-to-peer ghost refresh and all-reduce ----------------------------------------------------
+// Nothing but kernels of the compute stream: no library call, no second stream, no event.  (Measured on MI355X: the
+// grouped ncclSend / ncclRecv of two 80 KB planes on the communication stream costs 31 us per refresh, of which most is
+// the two cross-stream event hops - the same two kernels below behind the same events took 36 us.)
+//
+// Send: `groups` workgroups per neighbour gather the values that neighbour needs and store them straight into ITS receive
+// buffer (mapped through hipIpc, fine-grained memory: the stores travel over xGMI), the last one to finish publishes the
+// sequence number of the exchange with a system-scope release.  Fire and forget: the rows that need no ghost value are
+// multiplied behind it while the data is in flight.  Two slots alternate: a rank cannot start exchange q+2 before its
+// neighbour consumed exchange q, because its own receive of q+1 completes only after the neighbour sent q+1, which the
+// neighbour's stream orders after its receive of q.
+static int* g_p2p_err = nullptr;                 // device flag: a wait timed out (peer died / mapping not coherent)
+static long long g_p2p_timeout_ticks = 0;        // wall_clock64 ticks (100 MHz)
+
+__global__ void __launch_bounds__(FS_BLOCK) k_p2p_send(const fs_p2p_peer* __restrict__ peers, int groups, uint32_t* done,
+                                                       const double* __restrict__ vec, const int32_t* __restrict__ send_idx,
+                                                       int slot, unsigned long long seq) {
+    const int nb = blockIdx.x / groups, g = blockIdx.x - nb * groups;
+    const fs_p2p_peer p = peers[nb];
+    double* dst = p.recv + (int64_t)slot * p.peer_total + p.recv_offset;
+    const int32_t* idx = send_idx + p.send_offset;
+    for (int64_t k = (int64_t)g * FS_BLOCK + threadIdx.x; k < p.send_count; k += (int64_t)groups * FS_BLOCK) fs_p2p_store(dst + k, vec[idx[k]]);
+    fs_p2p_stores_done();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (groups > 1) {
+            last = atomicAdd(done + nb, 1u) == (uint32_t)(groups - 1);
+            if (last) __hip_atomic_store(done + nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) fs_p2p_publish(p.flags + (int64_t)slot * p.peer_nn + p.peer_slot, seq);
+    }
+}
+
+// Receive: wait until every neighbour delivered exchange `seq`, then move the values to the ghost entries.
+__global__ void __launch_bounds__(FS_BLOCK) k_p2p_recv(int nn, const unsigned long long* flags, unsigned long long seq,
+                                                       const double* recv, int64_t total, const int32_t* __restrict__ recv_idx,
+                                                       double* __restrict__ vec, int64_t n_owned, long long timeout, int* err,
+                                                       const int* __restrict__ gate) {
+    if (gate && gate[0] != 0) return;          // status word of a solver: the send this receive pairs with was gated off too
+    if ((int)threadIdx.x < nn) fs_p2p_wait(flags + threadIdx.x, seq, timeout, err);
+    __syncthreads();
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < total; k += stride) {
+        const double v = fs_p2p_load(recv + k);
+        vec[recv_idx ? (int64_t)recv_idx[k] : n_owned + k] = v;
+    }
+}
+
+// All-reduce (sum) of up to 8 doubles: every rank stores its values into slot [me] of every rank's buffer and releases a
+// sequence number there, waits for the sequence numbers of all ranks in its own buffer and adds the values up IN RANK ORDER -
+// every rank obtains bit-identical sums (the convergence decision taken from them is the same everywhere).  With
+// npart > 0 the values are first summed from the per-workgroup partials [nv][npart] (fixed order), which saves the separate
+// launch.  The two-slot argument of the halo holds here too.
+struct fs_p2p_reduce {
+    bool enabled = false;
+    double* buf = nullptr;                     // fine-grained [2][n_ranks][8]
+    unsigned long long* flags = nullptr;       // fine-grained [2][n_ranks]
+    std::vector<void*> opened;
+    dbuf<double*> peer_buf;
+    dbuf<unsigned long long*> peer_flags;
+    unsigned long long seq = 0;
+    void release() {
+        if (buf || flags || !opened.empty()) (void)hipDeviceSynchronize();
+        for (void* q : opened) (void)hipIpcCloseMemHandle(q);
+        opened.clear();
+        if (buf) (void)hipFree(buf);
+        if (flags) (void)hipFree(flags);
+        buf = nullptr; flags = nullptr;
+        peer_buf.release(); peer_flags.release();
+        enabled = false; seq = 0;
+    }
+};
+static fs_p2p_reduce g_p2p_red;
+static int g_p2p_spaces = 0;           // spaces whose exchange was turned on (and not off again) through the API
+
+__global__ void __launch_bounds__(FS_SUM_BLOCK) k_p2p_allreduce(int nr, int me, int nv, const double* __restrict__ partials, int npart,
+                                                                double* const* __restrict__ peer_buf,
+                                                                unsigned long long* const* __restrict__ peer_flags,
+                                                                const double* own_buf, const unsigned long long* own_flags,
+                                                                int slot, unsigned long long seq, double* inout,
+                                                                long long timeout, int* err) {
+    __shared__ double lds[FS_SUM_BLOCK / 64][4];
+    __shared__ double mine[8];
+    if (npart > 0) {                                     // the reduction of k_sum_partials (fs_kernels.h), same order, same bits
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < npart; i += FS_SUM_BLOCK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) acc[j] += partials[(int64_t)j * npart + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off, 64);
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[wave][j] = acc[j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nv) {
+            double t = 0.0;
+            for (int w = 0; w < FS_SUM_BLOCK / 64; ++w) t += lds[w][threadIdx.x];
+            mine[threadIdx.x] = t;
+        }
+    } else if ((int)threadIdx.x < nv) mine[threadIdx.x] = inout[threadIdx.x];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nr) {
+        double* dst = peer_buf[t] + ((int64_t)slot * nr + me) * 8;
+        for (int v = 0; v < nv; ++v) fs_p2p_store(dst + v, mine[v]);
+        fs_p2p_stores_done();
+        fs_p2p_publish(peer_flags[t] + (int64_t)slot * nr + me, seq);
+        fs_p2p_wait(own_flags + (int64_t)slot * nr + t, seq, timeout, err);
+    }
+    __syncthreads();
+    if (t < nv) {
+        double a = 0.0;
+        for (int r = 0; r < nr; ++r) a += fs_p2p_load(own_buf + ((int64_t)slot * nr + r) * 8 + t);
+        inout[t] = a;
+    }
+}
+
+void fs_p2p_halo::release() {
+    if (recv || flags || !opened.empty()) (void)hipDeviceSynchronize();
+    for (void* q : opened) (void)hipIpcCloseMemHandle(q);
+    opened.clear();
+    if (recv) (void)hipFree(recv);
+    if (flags) (void)hipFree(flags);
+    recv = nullptr; flags = nullptr;
+    peers.release();
+    done.release();
+    counter.release();
+    pending = nullptr;
+    enabled = false;
+    seq = 0;
+}
+
+static int p2p_barrier() {               // host-level: an all-gather of one double
+    fs_runtime& rt = fs_rt();
+    if (!rt.comm) return FS_OK;
+    double one = 1.0;
+    std::vector<double> all((size_t)rt.n_ranks);
+    return fs_comm_allgather(&one, 1, 1, all.data());
+}
+
+static constexpr int P2P_HANDLE_DOUBLES = (int)(sizeof(hipIpcMemHandle_t) / sizeof(double));
+
+// every rank's verdict on a collective set-up step: all succeed or all back out (a rank waiting for stores that a failed
+// neighbour will never issue would hang the device)
+static int p2p_agree(bool ok, const char* what, const char* why = "") {
+    fs_runtime& rt = fs_rt();
+    double mine = ok ? 0.0 : 1.0;
+    std::vector<double> all((size_t)rt.n_ranks, 0.0);
+    FS_CHECK(fs_comm_allgather(&mine, 1, 1, all.data()));
+    for (int r = 0; r < rt.n_ranks; ++r)
+        if (all[(size_t)r] != 0.0) {
+            if (ok || !*why) fs_set_error("%s: rank %d could not map its neighbours' buffers (hipIpc: one node, peer access)", what, r);
+            else fs_set_error("%s: %s", what, why);
+            return FS_ERR_COMM;
+        }
+    return FS_OK;
+}
+
+// FS_P2P_TEST (tests only): "openfail" - rank 0 pretends hipIpcOpenMemHandle failed; "lost" - receives wait for a sequence
+// number that never comes.  Both failure paths must end in an error every rank agrees on, never in a hang.
+static int p2p_test_mode() {
+    const char* e = getenv("FS_P2P_TEST");
+    if (!e) return 0;
+    return !strcmp(e, "openfail") ? 1 : (!strcmp(e, "lost") ? 2 : 0);
+}
+
+static int p2p_common_setup() {
+    if (!g_p2p_err) {
+        FS_HIP(hipMalloc((void**)&g_p2p_err, sizeof(int)));
+        FS_HIP(hipMemset(g_p2p_err, 0, sizeof(int)));
+    }
+    const char* e = getenv("FS_P2P_TIMEOUT_MS");
+    const double ms = e ? atof(e) : 10000.0;
+    g_p2p_timeout_ticks = (long long)(ms * 1e5);          // wall_clock64: 100 MHz
+    return FS_OK;
+}
+
+// The all-reduce side, set up once per communicator (collective).
+static int p2p_reduce_setup() {
+    fs_runtime& rt = fs_rt();
+    fs_p2p_reduce& R = g_p2p_red;
+    if (R.enabled) return FS_OK;
+    const int nr = rt.n_ranks;
+    FS_REQUIRE(nr <= 64, "peer-to-peer all-reduce: %d ranks, at most 64", nr);
+    FS_HIP(hipExtMallocWithFlags((void**)&R.buf, (size_t)(2 * nr * 8) * sizeof(double), hipDeviceMallocFinegrained));
+    FS_HIP(hipExtMallocWithFlags((void**)&R.flags, (size_t)(2 * nr) * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+    FS_HIP(hipMemset(R.buf, 0, (size_t)(2 * nr * 8) * sizeof(double)));
+    FS_HIP(hipMemset(R.flags, 0, (size_t)(2 * nr) * sizeof(unsigned long long)));
+    FS_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t hv[2];
+    FS_HIP(hipIpcGetMemHandle(&hv[0], R.buf));
+    FS_HIP(hipIpcGetMemHandle(&hv[1], R.flags));
+    const int rec_n = 2 * P2P_HANDLE_DOUBLES;
+    std::vector<double> rec((size_t)rec_n), all((size_t)rec_n * nr);
+    memcpy(rec.data(), hv, sizeof(hv));
+    FS_CHECK(fs_comm_allgather(rec.data(), rec_n, rec_n, all.data()));
+    std::vector<double*> pb((size_t)nr);
+    std::vector<unsigned long long*> pf((size_t)nr);
+    bool ok = true;
+    for (int r = 0; r < nr && ok; ++r) {
+        if (r == rt.rank) { pb[(size_t)r] = R.buf; pf[(size_t)r] = R.flags; continue; }
+        hipIpcMemHandle_t qh[2];
+        memcpy(qh, all.data() + (size_t)r * rec_n, sizeof(qh));
+        void *a = nullptr, *b = nullptr;
+        ok = hipIpcOpenMemHandle(&a, qh[0], hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+        if (ok) { R.opened.push_back(a); ok = hipIpcOpenMemHandle(&b, qh[1], hipIpcMemLazyEnablePeerAccess) == hipSuccess; }
+        if (ok) R.opened.push_back(b);
+        pb[(size_t)r] = (double*)a; pf[(size_t)r] = (unsigned long long*)b;
+    }
+    if (!ok) (void)hipGetLastError();
+    if (p2p_test_mode() == 1 && rt.rank == 0) ok = false;
+    const int rc = p2p_agree(ok, "peer-to-peer all-reduce");
+    if (rc != FS_OK) { R.release(); return rc; }
+    FS_CHECK(R.peer_buf.alloc(nr));
+    FS_CHECK(R.peer_flags.alloc(nr));
+    FS_CHECK(R.peer_buf.upload(pb.data(), nr, rt.stream));
+    FS_CHECK(R.peer_flags.upload(pf.data(), nr, rt.stream));
+    FS_HIP(hipStreamSynchronize(rt.stream));
+    R.seq = 0;
+    R.enabled = true;
+    return FS_OK;
+}
+
+void fs_p2p_reduce_teardown() {          // fs_comm_finalize
+    g_p2p_spaces = 0;
+    g_p2p_red.release();
+}
+
+// 1 if the all-reduces of this process go through the peer-to-peer kernel (the solver then keeps them in the compute stream)
+int fs_p2p_reduce_enabled() { return g_p2p_red.enabled ? 1 : 0; }
+
+// sums of the per-workgroup partials [nv][npart] (npart > 0) or of inout itself (npart = 0) over all ranks -> inout
+int fs_p2p_allreduce_dev(const double* partials, int npart, double* inout, int nv, hipStream_t s) {
+    fs_runtime& rt = fs_rt();
+    fs_p2p_reduce& R = g_p2p_red;
+    const unsigned long long seq = ++R.seq;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(FS_SUM_BLOCK), 0, s, rt.n_ranks, rt.rank, nv, partials, npart,
+                       (double* const*)R.peer_buf.p, (unsigned long long* const*)R.peer_flags.p, R.buf, R.flags, (int)(seq & 1ull), seq,
+                       inout, g_p2p_timeout_ticks, g_p2p_err);
+    FS_KERNEL_CHECK();
+    return FS_OK;
+}
+
+// a wait of a peer-to-peer kernel timed out since the last call?  (synchronises the stream; the solvers ask once per solve)
+int fs_p2p_check(hipStream_t s) {
+    if (!g_p2p_err) return FS_OK;
+    int e = 0;
+    FS_HIP(hipMemcpyAsync(&e, g_p2p_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    if (e) {
+        FS_HIP(hipMemsetAsync(g_p2p_err, 0, sizeof(int), s));
+        fs_set_error("peer-to-peer exchange: a neighbour's data did not arrive within FS_P2P_TIMEOUT_MS (peer process gone, or stores over hipIpc mappings not visible on this system) - results of this solve are invalid");
+        return FS_ERR_COMM;
+    }
+    return FS_OK;
+}
+
+// Collective over the communicator (every rank calls it for its space, in the same order): allocate the receive side,
+// publish its hipIpc handles and the neighbour table with one all-gather, map every neighbour's buffers; the all-reduce
+// side is set up with the first space.  One node only (hipIpc); the RCCL exchange stays the default.  enable = 0 tears the
+// space's side down (also collective: nobody frees memory a neighbour may still write).
+static constexpr int P2P_MAX_NB = 16;
+static constexpr int P2P_REC = 4 + 3 * P2P_MAX_NB + 2 * P2P_HANDLE_DOUBLES;
+extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(space, "fs_space_enable_p2p_halo: null space");
+    static_assert(sizeof(hipIpcMemHandle_t) % sizeof(double) == 0, "handle size");
+    fs_runtime& rt = fs_rt();
+    fs_halo_plan& h = space->halo;
+    hipStream_t s = rt.stream;
+    FS_HIP(hipStreamSynchronize(s));
+    if (h.comm_stream) FS_HIP(hipStreamSynchronize(h.comm_stream));
+    if (h.p2p.enabled || h.p2p.recv) {
+        FS_CHECK(p2p_barrier());
+        if (h.p2p.enabled && g_p2p_spaces > 0) --g_p2p_spaces;
+        h.p2p.release();
+        h.early = -1;
+    }
+    if (!enable) {
+        // the last space turned off by hand takes the all-reduce back to RCCL (every rank is here: nobody writes into the buffers
+        // being freed); spaces destroyed with the exchange on leave it as it is
+        if (g_p2p_spaces == 0 && g_p2p_red.enabled) g_p2p_red.release();
+        return FS_OK;
+    }
+    if (!rt.comm) {
+        fs_set_error("fs_space_enable_p2p_halo: no communicator is up (call fs_comm_init)");
+        return FS_ERR_COMM;
+    }
+    FS_CHECK(p2p_common_setup());
+    FS_CHECK(p2p_reduce_setup());
+    const int nn = h.active ? (int)h.neighbors.size() : 0;
+    FS_REQUIRE(nn <= P2P_MAX_NB, "fs_space_enable_p2p_halo: %d neighbours, at most %d", nn, P2P_MAX_NB);
+    fs_p2p_halo& pp = h.p2p;
+    const int64_t total = std::max<int64_t>(h.total_recv, 1);
+    FS_HIP(hipExtMallocWithFlags((void**)&pp.recv, (size_t)(2 * total) * sizeof(double), hipDeviceMallocFinegrained));
+    FS_HIP(hipExtMallocWithFlags((void**)&pp.flags, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+    FS_HIP(hipMemset(pp.flags, 0, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long)));
+    FS_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t hv[2];
+    FS_HIP(hipIpcGetMemHandle(&hv[0], pp.recv));
+    FS_HIP(hipIpcGetMemHandle(&hv[1], pp.flags));
+    std::vector<double> rec((size_t)P2P_REC, 0.0), all((size_t)P2P_REC * rt.n_ranks, 0.0);
+    rec[0] = nn; rec[1] = (double)total;
+    for (int i = 0; i < nn; ++i) {
+        rec[(size_t)(4 + 3 * i)] = h.neighbors[(size_t)i];
+        rec[(size_t)(5 + 3 * i)] = (double)h.recv_offsets[(size_t)i];
+        rec[(size_t)(6 + 3 * i)] = (double)h.recv_counts[(size_t)i];
+    }
+    memcpy(rec.data() + 4 + 3 * P2P_MAX_NB, hv, sizeof(hv));
+    FS_CHECK(fs_comm_allgather(rec.data(), P2P_REC, P2P_REC, all.data()));
+    std::vector<fs_p2p_peer> peers((size_t)std::max(nn, 1));
+    std::vector<std::pair<double*, unsigned long long*>> mapped((size_t)rt.n_ranks, {nullptr, nullptr});
+    bool ok = true;
+    char why[256] = "";
+    int64_t max_send = 0;
+    for (int i = 0; i < nn && ok; ++i) {
+        const int q = h.neighbors[(size_t)i];
+        int occ = 0;
+        for (int j = 0; j < i; ++j) occ += h.neighbors[(size_t)j] == q;
+        const double* qr = q >= 0 && q < rt.n_ranks ? all.data() + (size_t)q * P2P_REC : nullptr;
+        const int qnn = qr ? (int)qr[0] : 0;
+        int slot = -1;
+        for (int j = 0, seen = 0; j < qnn; ++j)
+            if ((int)qr[4 + 3 * j] == rt.rank && seen++ == occ) { slot = j; break; }
+        if (slot < 0) { ok = false; snprintf(why, sizeof(why), "rank %d does not list rank %d as a neighbour", q, rt.rank); break; }
+        if ((int64_t)qr[6 + 3 * slot] != h.send_counts[(size_t)i]) {
+            ok = false;
+            snprintf(why, sizeof(why), "rank %d expects %lld values from rank %d, which sends %lld", q, (long long)qr[6 + 3 * slot], rt.rank,
+                     (long long)h.send_counts[(size_t)i]);
+            break;
+        }
+        if (q == rt.rank) mapped[(size_t)q] = {pp.recv, pp.flags};
+        else if (!mapped[(size_t)q].first) {
+            hipIpcMemHandle_t qh[2];
+            memcpy(qh, qr + 4 + 3 * P2P_MAX_NB, sizeof(qh));
+            void *a = nullptr, *b = nullptr;
+            ok = hipIpcOpenMemHandle(&a, qh[0], hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+            if (ok) { pp.opened.push_back(a); ok = hipIpcOpenMemHandle(&b, qh[1], hipIpcMemLazyEnablePeerAccess) == hipSuccess; }
+            if (ok) pp.opened.push_back(b);
+            if (!ok) { (void)hipGetLastError(); snprintf(why, sizeof(why), "hipIpcOpenMemHandle of rank %d's buffers failed", q); break; }
+            mapped[(size_t)q] = {(double*)a, (unsigned long long*)b};
+        }
+        fs_p2p_peer& e = peers[(size_t)i];
+        e.recv = mapped[(size_t)q].first;
+        e.flags = mapped[(size_t)q].second;
+        e.recv_offset = (int64_t)qr[5 + 3 * slot];
+        e.peer_total = (int64_t)qr[1];
+        e.send_offset = h.send_offsets[(size_t)i];
+        e.send_count = h.send_counts[(size_t)i];
+        e.send_first = h.send_contiguous[(size_t)i] ? h.send_first[(size_t)i] : -1;
+        e.peer_slot = slot;
+        e.peer_nn = std::max(qnn, 1);
+        max_send = std::max(max_send, e.send_count);
+    }
+    const int rc = p2p_agree(ok, "fs_space_enable_p2p_halo", why);
+    if (rc != FS_OK) {
+        pp.release();
+        if (g_p2p_spaces == 0) g_p2p_red.release();
+        return rc;
+    }
+    pp.send_groups = (int)std::min<int64_t>(16, std::max<int64_t>(1, (max_send + 8 * FS_BLOCK - 1) / (8 * FS_BLOCK)));
+    FS_CHECK(pp.peers.alloc((int64_t)peers.size()));
+    FS_CHECK(pp.peers.upload(peers.data(), (int64_t)peers.size(), s));
+    FS_CHECK(pp.done.alloc((int64_t)peers.size()));
+    FS_CHECK(pp.done.zero(s));
+    FS_CHECK(pp.counter.alloc(2));
+    FS_CHECK(pp.counter.zero(s));
+    FS_HIP(hipStreamSynchronize(s));
+    pp.seq = 0;
+    pp.pending = nullptr;
+    pp.enabled = true;
+    ++g_p2p_spaces;
+    h.early = -1;              // the solver asks the ranks again which iteration they can all run
+    return FS_OK;
+}
+
+static int p2p_exchange_begin(fs_space_s* space, double* d_vec, hipStream_t s) {
+    fs_halo_plan& h = space->halo;
+    fs_p2p_halo& pp = h.p2p;
+    FS_REQUIRE(!pp.pending, "peer-to-peer halo: an exchange was begun and never received");
+    const int nn = (int)h.neighbors.size();
+    const unsigned long long seq = ++pp.seq;
+    hipLaunchKernelGGL(k_p2p_send, dim3(nn * pp.send_groups), dim3(FS_BLOCK), 0, s, pp.peers.p, pp.send_groups, pp.done.p, d_vec,
+                       h.send_idx.p, (int)(seq & 1ull), seq);
+    FS_KERNEL_CHECK();
+    pp.pending = d_vec;
+    return FS_OK;
+}
+
+static int p2p_exchange_end(fs_space_s* space, hipStream_t s, const int* gate = nullptr) {
+    fs_halo_plan& h = space->halo;
+    fs_p2p_halo& pp = h.p2p;
+    FS_REQUIRE(pp.pending, "peer-to-peer halo: receive without a send");
+    const int nn = (int)h.neighbors.size();
+    const unsigned long long seq = pp.seq;
+    const int slot = (int)(seq & 1ull);
+    static const unsigned long long never = p2p_test_mode() == 2 ? 1000000000ull : 0ull;
+    const int grid = (int)std::min<int64_t>(16, std::max<int64_t>(1, (h.total_recv + FS_BLOCK * 8 - 1) / (FS_BLOCK * 8)));
+    hipLaunchKernelGGL(k_p2p_recv, dim3(grid), dim3(FS_BLOCK), 0, s, nn, pp.flags + (int64_t)slot * nn, seq + never,
+                       pp.recv + (int64_t)slot * std::max<int64_t>(h.total_recv, 1), h.total_recv, h.recv_idx.p, pp.pending,
+                       space->n_dofs_owned, g_p2p_timeout_ticks, g_p2p_err, gate);
+    FS_KERNEL_CHECK();
+    pp.pending = nullptr;
+    return FS_OK;
+}
+
+bool fs_p2p_fusable(const fs_space_s* space) {
+    const fs_halo_plan& h = space->halo;
+    return h.active && h.p2p.enabled && !h.recv_idx.p && g_p2p_red.enabled && fs_rt().comm != nullptr;
+}
+
+int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out) {
+    fs_p2p_halo& pp = space->halo.p2p;
+    FS_REQUIRE(!pp.pending, "peer-to-peer halo: an exchange was begun and never received");
+    const unsigned long long seq = ++pp.seq;
+    out->peers = pp.peers.p;
+    out->counter = pp.counter.p;
+    out->seq = seq;
+    out->nn = (int)space->halo.neighbors.size();
+    out->slot = (int)(seq & 1ull);
+    pp.pending = d_vec;
+    return FS_OK;
+}
+
+int fs_p2p_recv_gated(fs_space_s* space, const int* status, hipStream_t s) { return p2p_exchange_end(space, s, status); }
+
+void fs_p2p_drop_pending(fs_space_s* space) { space->halo.p2p.pending = nullptr; }
+
+int fs_p2p_next_reduce(const double* partials, int npart, double* sums_out, fs_p2p_rowsred* out) {
+    fs_runtime& rt = fs_rt();
+    fs_p2p_reduce& R = g_p2p_red;
+    const unsigned long long seq = ++R.seq;
+    out->partials = partials; out->npart = npart; out->sums_out = sums_out;
+    out->peer_buf = (double* const*)R.peer_buf.p;
+    out->peer_flags = (unsigned long long* const*)R.peer_flags.p;
+    out->own_buf = R.buf;
+    out->own_flags = R.flags;
+    out->seq = seq;
+    out->timeout = g_p2p_timeout_ticks;
+    out->err = g_p2p_err;
+    out->nr = rt.n_ranks; out->me = rt.rank; out->slot = (int)(seq & 1ull); out->on = 1;
+    return FS_OK;
+}
 
 // Interior / boundary split of the owned rows, at the granularity the SpMV works at (slices of 64 rows): a slice is a
 // BOUNDARY slice if any of its structural entries names a ghost column.  Interior slices are multiplied while the
@@ -271,6 +734,7 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
     FS_CHECK(fs_require_init());
     FS_REQUIRE(space && n_neighbors >= 0, "fs_space_set_halo: bad arguments");
     fs_halo_plan& h = space->halo;
+    FS_REQUIRE(!h.p2p.enabled, "fs_space_set_halo: the peer-to-peer exchange of this space is on; turn it off first (fs_space_enable_p2p_halo(space, 0), collective)");
     h.active = false;
     h.neighbors.clear(); h.send_counts.clear(); h.send_offsets.clear(); h.recv_counts.clear();
     h.recv_offsets.clear(); h.send_contiguous.clear(); h.send_first.clear();
@@ -345,6 +809,7 @@ int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
         fs_set_error("halo exchange requested but no communicator is up (call fs_comm_init)");
         return FS_ERR_COMM;
     }
+    if (h.p2p.enabled) return p2p_exchange_begin(space, d_vec, s);
     hipStream_t cs = nullptr;
     FS_CHECK(fs_halo_comm_stream(space, &cs));
     const int nn = (int)h.neighbors.size();
@@ -381,6 +846,7 @@ int fs_halo_begin_dev(fs_space_s* space, double* d_vec, hipStream_t s) {
 int fs_halo_end_dev(fs_space_s* space, hipStream_t s) {
     fs_halo_plan& h = space->halo;
     if (!h.active) return FS_OK;
+    if (h.p2p.enabled) return p2p_exchange_end(space, s);
     FS_HIP(hipStreamWaitEvent(s, h.ev_done, 0));
     return FS_OK;
 }

@@ -139,8 +139,34 @@ struct fs_mesh_s {
     dbuf<int64_t> gid;    // [nv] global vertex ids
 };
 
+// Peer-to-peer ghost refresh (opt-in, one node): every rank owns a fine-grained receive buffer + arrival flags that its
+// neighbours map through hipIpc and WRITE INTO from a kernel; the receiver's kernel waits for the flags (fs_comm.hip).
+struct fs_p2p_peer {
+    double* recv;                   // the neighbour's receive buffer (mapped), [2][peer_total]
+    unsigned long long* flags;      // the neighbour's arrival flags (mapped), [2][peer_nn]
+    int64_t recv_offset, peer_total;
+    int64_t send_offset, send_count;
+    int64_t send_first;             // first row of a contiguous send list (-1: not contiguous)
+    int32_t peer_slot, peer_nn;
+};
+struct fs_p2p_halo {
+    bool enabled = false;
+    double* recv = nullptr;
+    unsigned long long* flags = nullptr;
+    std::vector<void*> opened;
+    dbuf<fs_p2p_peer> peers;
+    dbuf<uint32_t> done;            // per neighbour: workgroups of the running send that have stored their share
+    int send_groups = 1;            // workgroups per neighbour
+    double* pending = nullptr;      // vector of the exchange begun and not yet received
+    dbuf<uint32_t> counter;         // [2]: last-workgroup counters of the fused kernels (rows update + send, product + post)
+    unsigned long long seq = 0;
+    void release();
+    ~fs_p2p_halo() { release(); }
+};
+
 struct fs_halo_plan {
     bool active = false;
+    fs_p2p_halo p2p;
     std::vector<int> neighbors;
     std::vector<int64_t> send_counts, send_offsets, recv_counts, recv_offsets;
     std::vector<char> send_contiguous;     // send list of neighbour i is a contiguous range
@@ -156,6 +182,7 @@ struct fs_halo_plan {
     bool begun = false;                    // an exchange was started ahead of the product that will wait for it (fs_krylov.hip)
     int early = -1;                        // 1: EVERY rank sends a prefix / suffix of its rows (agreed by an all-reduce), 0: no, -1: not asked yet
     int64_t early_a = 0, early_b = 0;
+    int fuse = 0;                          // 1: every rank can run the fused peer-to-peer iteration (agreed with `early`)
     // slices (in processing order) without / with ghost columns
     dbuf<int32_t> interior, boundary;
     int64_t n_interior = 0, n_boundary = 0;
@@ -262,6 +289,20 @@ static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int 
 // ---- cross-TU internals ------------------------------------------------------------------
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
+// sums over all ranks of the per-workgroup partials [nv][npart] (the k_sum_partials order) -> out[nv]: one kernel when the
+// peer-to-peer all-reduce is on, k_sum_partials + ncclAllReduce otherwise
+int fs_comm_sum_allreduce_dev(const double* partials, int npart, int nv, double* out, hipStream_t s);
+int fs_p2p_allreduce_dev(const double* partials, int npart, double* inout, int nv, hipStream_t s);
+int fs_p2p_reduce_enabled();
+// fused peer-to-peer CG iteration (fs_krylov.hip): the structures the kernels take, with the sequence numbers advanced
+struct fs_p2p_sendrows; struct fs_p2p_rowsred;
+bool fs_p2p_fusable(const fs_space_s* space);                                   // peer-to-peer halo on, ghosts grouped by neighbour
+int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out);    // the exchange the rows kernel will issue
+int fs_p2p_recv_gated(fs_space_s* space, const int* status, hipStream_t s);      // receive of the pending exchange unless status[0] != 0
+void fs_p2p_drop_pending(fs_space_s* space);                                    // a status-gated exchange that was never issued
+int fs_p2p_next_reduce(const double* partials, int npart, double* sums_out, fs_p2p_rowsred* out);
+int fs_p2p_check(hipStream_t s);
+void fs_p2p_reduce_teardown();
 void fs_comm_host_time(double* allreduce_us, long* allreduce_calls, double* halo_us, long* halo_calls, bool reset);
 // inverse of the slot table: sources (cell*nd*nd + ab) of every stored block, ascending (gmap_ptr / gmap_src)
 int fs_space_build_gather_map(fs_space_s* space, hipStream_t s);

@@ -22,6 +22,62 @@ __device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
     return it;
 }
 
+// ---- peer-to-peer exchange between the ranks of a node (fs_comm.hip sets it up, fs_krylov.hip fuses it into the CG kernels) ----
+// Memory-ordering discipline of these kernels.  A system-scope release fence on gfx950 is `buffer_wbl2` - it writes back EVERY
+// dirty line of the XCD's L2, and in the middle of a CG iteration that is the 4 MB per XCD the update and the product just wrote
+// (measured: + 10 us on a 20 000-row kernel).  The exchanged data therefore never becomes a dirty cached line in the first place:
+//   writer: every store into a peer's buffer is a system-scope (write-through, sc0 sc1) store;  s_waitcnt vmcnt(0) - all of
+//           them acknowledged - by a workgroup-scope release fence, workgroup barrier, then the sequence number, again a
+//           system-scope store;
+//   reader: spins on the sequence number with system-scope loads, then reads the data with system-scope loads (the buffers are
+//           fine-grained allocations: nothing of them is held in a cache).
+__device__ __forceinline__ void fs_p2p_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double fs_p2p_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void fs_p2p_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void fs_p2p_publish(unsigned long long* flag, unsigned long long seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Wait until *flag >= seq.  A wait that times out raises *err and every later wait returns at once: a solve over a broken
+// mapping finishes quickly with an error instead of hanging the device.
+__device__ __forceinline__ bool fs_p2p_wait(const unsigned long long* flag, unsigned long long seq, long long timeout, int* err) {
+    bool ok = true;
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((long long)wall_clock64() - t0 > timeout) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
+
+// what the update kernel on the rows a slab sends needs to store them into the neighbours' receive buffers itself
+struct fs_p2p_sendrows {
+    const fs_p2p_peer* peers;
+    uint32_t* counter;              // workgroups of this launch that are through (the last one releases the sequence numbers)
+    unsigned long long seq;
+    int nn, slot;
+};
+// all-reduce of the three dot sums inside the rows kernel (k_cg_update_scaled_rows, fs_krylov.hip)
+struct fs_p2p_rowsred {
+    const double* partials;         // [3][npart] of the product
+    double* sums_out;               // [3]: the reduced sums for the kernels that follow
+    double* const* peer_buf;
+    unsigned long long* const* peer_flags;
+    const double* own_buf;
+    const unsigned long long* own_flags;
+    unsigned long long seq;
+    long long timeout;
+    int* err;
+    int npart, nr, me, slot, on;
+};
+
 // wave64 shuffle reduction -> one LDS slot per wave -> thread 0 holds the block sum.
 // Fixed order, so a given launch geometry always produces the same bits.
 __device__ __forceinline__ double fs_block_sum(double v, double* lds4) {

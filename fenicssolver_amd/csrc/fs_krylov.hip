@@ -761,9 +761,39 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
                                                                     const double* __restrict__ sums, const double* __restrict__ ctrl,
                                                                     const double* __restrict__ scal, const int* __restrict__ status,
                                                                     double* __restrict__ r, const double* __restrict__ w,
-                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x) {
+                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x,
+                                                                    const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
     if (status[0] != 0) return;
-    const double gamma = sums[0], delta = sums[1], rho = sums[2];
+    double gamma, delta, rho;
+    if (red.on) {
+        // the all-reduce of the three dot sums happens HERE (peer-to-peer iteration, see the host loop): every workgroup sums the
+        // product's partials itself (same bits everywhere), workgroup 0 stores them into slot [me] of the other ranks' buffers,
+        // every workgroup waits for the other ranks' sums and adds all up in rank order; workgroup 0 leaves the result in `sums`
+        // for the update of the remaining rows
+        double sm[3];
+        wg_sum_partials<3>(red.partials, red.npart, sm);
+        const int t = threadIdx.x;
+        if (blockIdx.x == 0 && t < red.nr && t != red.me) {
+            double* dst = red.peer_buf[t] + ((int64_t)red.slot * red.nr + red.me) * 8;
+            fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
+            fs_p2p_stores_done();
+            fs_p2p_publish(red.peer_flags[t] + (int64_t)red.slot * red.nr + red.me, red.seq);
+        }
+        if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)red.slot * red.nr + t, red.seq, red.timeout, red.err);
+        __syncthreads();
+        __shared__ double tot[3];
+        if (t < 3) {
+            double a = 0.0;
+            for (int r = 0; r < red.nr; ++r)
+                a += r == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)red.slot * red.nr + r) * 8 + t);
+            tot[t] = a;
+            if (blockIdx.x == 0) red.sums_out[t] = a;
+        }
+        __syncthreads();
+        gamma = tot[0]; delta = tot[1]; rho = tot[2];
+    } else {
+        gamma = sums[0]; delta = sums[1]; rho = sums[2];
+    }
     if (rho <= ctrl[0] || check_only) return;
     double beta = 0.0, alpha;
     if (iter == 0) {
@@ -784,7 +814,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
         const double ss = w[i] + beta * sv[i];
         p[i] = pp; sv[i] = ss;
         x[i] += alpha * pp;
-        r[i] -= alpha * ss;
+        const double rn = r[i] - alpha * ss;
+        r[i] = rn;
+        // peer-to-peer exchange: the new value goes straight into the receive buffer of every neighbour that needs this row
+        for (int j = 0; j < snd.nn; ++j) {
+            const fs_p2p_peer q = snd.peers[j];
+            const int64_t k = i - q.send_first;
+            if (k >= 0 && k < q.send_count) fs_p2p_store(q.recv + (int64_t)snd.slot * q.peer_total + q.recv_offset + k, rn);
+        }
+    }
+    if (snd.nn > 0) {               // the last workgroup through publishes the sequence number at every neighbour (fs_kernels.h)
+        fs_p2p_stores_done();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < snd.nn; ++j) {
+                const fs_p2p_peer q = snd.peers[j];
+                fs_p2p_publish(q.flags + (int64_t)snd.slot * q.peer_nn + q.peer_slot, snd.seq);
+            }
+        }
     }
 }
 
@@ -1252,6 +1300,11 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 
 // Number of per-workgroup dot partials one (possibly split) product writes.
 static bool spmv_is_split(const fs_space_s* sp) { return sp->halo.active && sp->halo.n_interior > 0; }
+static int spmv_partials_unsplit(const fs_space_s* sp, int bs) {
+    if (bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
+        return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
+    return spmv_grid(sp->n_slices, sp->n_slices);
+}
 static int spmv_partials(const fs_space_s* sp, int bs = 0) {
     if (!spmv_is_split(sp) && bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
         return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
@@ -1554,7 +1607,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         fs_set_error("fs_krylov_solve: the pipelined recurrence needs CG + Jacobi with diagonal_scale = 1");
         return FS_ERR_UNSUPPORTED;
     }
-    const bool pipelined = ds && (pipe_opt > 0 || (pipe_opt < 0 && fs_rt().comm != nullptr && fs_rt().n_ranks > 1));
+    // several ranks default to the pipelined recurrence, whose all-reduce hides under the product - unless the all-reduce is the
+    // peer-to-peer kernel, which is cheaper than the extra vector traffic of that recurrence
+    const bool pipelined = ds && (pipe_opt > 0 || (pipe_opt < 0 && fs_rt().comm != nullptr && fs_rt().n_ranks > 1 && !fs_p2p_reduce_enabled()));
     if (pipelined) {
         if (ws.pw.n != nl + 2) FS_CHECK(ws.pw.alloc(nl + 2));
         if (ws.pz.n != n + 2) FS_CHECK(ws.pz.alloc(n + 2));
@@ -1594,9 +1649,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.bhat.p, n, ws.partials.p);
     } else
     hipLaunchKernelGGL(k_dot_partial, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, b->d.p, n, ws.partials.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 4);
-    FS_KERNEL_CHECK();
-    FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 4, 1, s));
+    FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, pgrid, 1, ws.sums.p + 4, s));
     hipLaunchKernelGGL(k_set_threshold, dim3(1), dim3(64), 0, s, ws.sums.p + 4, opts->rtol, opts->atol, ws.ctrl.p);
     const double* aval = nullptr;
     if (ds) {
@@ -1667,16 +1720,16 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // compute stream waits for ev_red only when the next update needs the sums - the product sits in between.  Without
         // a halo plan (a replicated operator) the collective stays in-stream.
         hipStream_t red_stream = nullptr;
-        if (pipelined && !fuse_sums && sp->halo.active) FS_CHECK(fs_halo_comm_stream(sp, &red_stream));
+        // (the peer-to-peer all-reduce is a kernel of a few microseconds: it stays in the compute stream, a second stream's two event
+        // hops cost more than it hides)
+        if (pipelined && !fuse_sums && sp->halo.active && !fs_p2p_reduce_enabled()) FS_CHECK(fs_halo_comm_stream(sp, &red_stream));
         auto pcg_reduce = [&](int parity) -> int {
             hipStream_t q = red_stream ? red_stream : s;
             if (red_stream) {
                 FS_HIP(hipEventRecord(ws.ev_upd, s));
                 FS_HIP(hipStreamWaitEvent(red_stream, ws.ev_upd, 0));
             }
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, q, ws.partials.p + (int64_t)parity * 3 * vgrid, vgrid, 3, ws.sums.p);
-            FS_KERNEL_CHECK();
-            FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, q));
+            FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p + (int64_t)parity * 3 * vgrid, vgrid, 3, ws.sums.p, q));
             if (red_stream) FS_HIP(hipEventRecord(ws.ev_red, red_stream));
             return FS_OK;
         };
@@ -1725,7 +1778,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // rows sent to the neighbours as a prefix [0, early_a) and / or a suffix [early_b, n) of the owned rows (z-slabs): see
         // the update below.  FS_HALO_EARLY=0 keeps the exchange inside the product.
         int64_t early_a = 0, early_b = n;
-        if (ds && !bicg && !fuse_sums && sp->halo.active && fs_rt().n_ranks > 1) {     // (a condition every rank evaluates alike)
+        int p2p_fuse = 0;
+        if (ds && !bicg && !fuse_sums && sp->halo.active) {     // (a condition every rank evaluates alike; !fuse_sums: a communicator is up)
             static const bool no_early = getenv("FS_HALO_EARLY") && getenv("FS_HALO_EARLY")[0] == '0';
             fs_halo_plan& hp = sp->halo;
             if (hp.early < 0) {
@@ -1742,12 +1796,16 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 a = (a + 1) & ~(int64_t)1;          // the bulk update works on 16-byte pairs
                 ok = ok && a < b2 && (a > 0 || b2 < n);
                 // every rank has to take the same path: an exchange begun by one side only would never be matched
-                double flag = ok ? 1.0 : 0.0;
+                // (+ 1024 per rank whose plan allows the fused peer-to-peer iteration below: its kernels are gated by the status
+                // word, the separate send / receive kernels are not - a mix would leave one side waiting)
+                double flag = (ok ? 1.0 : 0.0) + (bs == 1 && fs_p2p_fusable(sp) ? 1024.0 : 0.0);
                 FS_HIP(hipMemcpyAsync(ws.sums.p + 6, &flag, sizeof(double), hipMemcpyHostToDevice, s));
                 FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 6, 1, s));
                 FS_HIP(hipMemcpyAsync(&flag, ws.sums.p + 6, sizeof(double), hipMemcpyDeviceToHost, s));
                 FS_HIP(hipStreamSynchronize(s));
-                hp.early = flag > fs_rt().n_ranks - 0.5 ? 1 : 0;
+                const int nr_all = fs_rt().n_ranks, agreed = (int)(flag + 0.5);
+                hp.early = agreed % 1024 == nr_all ? 1 : 0;
+                hp.fuse = hp.early == 1 && agreed / 1024 == nr_all ? 1 : 0;
                 hp.early_a = a;
                 hp.early_b = b2;
                 if (getenv("FS_KRYLOV_DEBUG"))
@@ -1755,6 +1813,15 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             (long long)a, (long long)b2, (long long)n, hp.early == 1 ? "yes" : "no");
             }
             if (hp.early == 1) { early_a = hp.early_a; early_b = hp.early_b; }
+            // Peer-to-peer exchange on every rank: the iteration is FOUR kernels of the compute stream instead of seven launches on two
+            // streams (below).  FS_P2P_FUSE: bit 1 the four-kernel iteration at all, bit 0 the send inside the rows kernel, bit 2 the
+            // all-reduce inside the rows kernel (default 7; 0 keeps the separate send / receive / all-reduce kernels around a split
+            // product).  Measured alternatives that lost on MI355X: ghost columns read straight from the (uncached, fine-grained)
+            // receive buffer by the boundary rows of one merged product (67 instead of 39 us per product at 1 M rows), and the
+            // sums posted by the last workgroup of the product (its agent-scope fence in every workgroup writes back the whole
+            // L2 of the XCD: + 26 us).
+            static const int fuse_env = getenv("FS_P2P_FUSE") ? atoi(getenv("FS_P2P_FUSE")) : 7;
+            if (hp.fuse == 1 && !pipelined && (fuse_env & 2)) p2p_fuse = fuse_env & 7;
         }
         const bool use_graph = ds && fuse_sums && !bicg && !pipelined && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
@@ -1800,8 +1867,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_p<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials2.p, vgrid, 2, ws.bsums.p);
-                        FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p, 2, s));
+                        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials2.p, vgrid, 2, ws.bsums.p, s));
                         hipLaunchKernelGGL(k_bicg_p<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials2.p, vgrid, ws.bsums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.r.p, ws.p.p, ws.w.p, ws.y.p);
                     }
                     // K2: v = A y, rhat.v
@@ -1813,8 +1879,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_s<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 1, ws.bsums.p + 4);
-                        FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 4, 1, s));
+                        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 1, ws.bsums.p + 4, s));
                         hipLaunchKernelGGL(k_bicg_s<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 4, ws.scal.p, ws.status.p, ws.dinv.p, ws.r.p, ws.w.p, ws.s.p, ws.z.p);
                     }
                     if (sample) {
@@ -1827,8 +1892,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (fuse_sums) {
                         hipLaunchKernelGGL(k_bicg_x<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 2, ws.bsums.p + 8);
-                        FS_CHECK(fs_comm_allreduce_dev(ws.bsums.p + 8, 2, s));
+                        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 2, ws.bsums.p + 8, s));
                         hipLaunchKernelGGL(k_bicg_x<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, ws.partials.p, sgrid, ws.bsums.p + 8, ws.scal.p, ws.status.p, x->d.p, ws.y.p, ws.z.p, ws.r.p, ws.s.p, ws.t.p, ws.rhat.p, ws.partials2.p);
                     }
                     continue;
@@ -1876,6 +1940,37 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                     continue;
                 }
+                if (p2p_fuse) {
+                    // K_R ghosts in (the neighbours stored them during THEIR rows update, a whole bulk update ago), K_A the plain
+                    // product over all slices, K_B sums + all-reduce + update of the rows the neighbours need + their store into the
+                    // neighbours' buffers, K_C update of the rest
+                    const int co = k == max_iter ? 1 : 0;
+                    fs_p2p_rowsred red = {};
+                    fs_p2p_sendrows snd = {};
+                    if (!sp->halo.begun) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));          // first iteration: the plain send kernel
+                    FS_CHECK(fs_p2p_recv_gated(sp, ws.status.p, s));
+                    sp->halo.begun = false;
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
+                    launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
+                    if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                    const int fgrid = spmv_partials_unsplit(sp, 1);
+                    if (p2p_fuse & 4) FS_CHECK(fs_p2p_next_reduce(ws.partials.p, fgrid, ws.sums.p, &red));
+                    else FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, fgrid, 3, ws.sums.p, s));
+                    if (p2p_fuse & 1) FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, &snd));
+                    hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 64)), dim3(FS_BLOCK), 0, s,
+                                       early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, red, snd);
+                    if (!(p2p_fuse & 1)) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
+                    sp->halo.begun = true;
+                    const int64_t m0 = early_a, nm = early_b - early_a;
+                    if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
+                    else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
+                    if (sample) {
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
+                        ++n_samples;
+                    }
+                    continue;
+                }
                 if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
                 if (ds) FS_CHECK(spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval));
                 else FS_CHECK(spmv_overlapped<1>(A, ws.z.p, ws.w.p, ws.r.p, ws.partials.p, ws.status.p, s));
@@ -1887,8 +1982,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                         else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     } else {
-                        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
-                        FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
+                        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 3, ws.sums.p, s));
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                         // Slabs send a prefix and / or a suffix of their rows: those are updated first and their exchange is
                         // started, so that it runs under the rest of the update AND the interior product of the next iteration
@@ -1896,7 +1990,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         int64_t m0 = 0, m1 = n;
                         if (early_a > 0 || early_b < n) {
                             hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 256)), dim3(FS_BLOCK), 0, s,
-                                               early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                                               early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, fs_p2p_rowsred{}, fs_p2p_sendrows{});
                             FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
                             sp->halo.begun = true;
                             m0 = early_a; m1 = early_b;
@@ -1909,8 +2003,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     hipLaunchKernelGGL(k_cg_update<true>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
                 } else {
-                    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, sgrid, 3, ws.sums.p);
-                    FS_CHECK(fs_comm_allreduce_dev(ws.sums.p, 3, s));
+                    FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 3, ws.sums.p, s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     hipLaunchKernelGGL(k_cg_update<false>, dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, k == max_iter ? 1 : 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.dinv.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, ws.r.p);
                 }
@@ -1930,6 +2023,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             slot ^= 1;
             if (k > max_iter) finished = true;
         }
+        if (sp->halo.begun && p2p_fuse) {          // fused peer-to-peer iteration: the loop ends with a non-zero status word, under
+            fs_p2p_drop_pending(sp);               // which the rows kernel stored nothing, or what it stored is never read
+            sp->halo.begun = false;
+        }
         if (sp->halo.begun) {          // the exchange started for a product that is not coming any more
             FS_CHECK(fs_halo_end_dev(sp, s));
             sp->halo.begun = false;
@@ -1938,6 +2035,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // nothing of the workspace is touched again before it is through
         if (red_stream) FS_HIP(hipStreamWaitEvent(s, ws.ev_red, 0));
         FS_HIP(hipStreamSynchronize(s));
+        if (fs_p2p_reduce_enabled()) FS_CHECK(fs_p2p_check(s));
         h_status[0] = h_status[1] = h_status[2] = h_status[3] = 0;
         FS_CHECK(ws.status.download(h_status, 4, s));
         const int iters = h_status[1];
@@ -1955,9 +2053,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
         if (ds) hipLaunchKernelGGL(k_residual_scaled, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, ws.dvec.p, n, (double*)nullptr, ws.partials.p);
         else hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(FS_SUM_BLOCK), 0, s, ws.partials.p, pgrid, 1, ws.sums.p + 5);
-        FS_KERNEL_CHECK();
-        FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 5, 1, s));
+        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, pgrid, 1, ws.sums.p + 5, s));
 
         double h_pass[8], h_ctrl2[4];
         FS_CHECK(ws.sums.download(h_pass, 8, s));

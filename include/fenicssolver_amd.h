@@ -477,6 +477,15 @@ int fs_space_set_halo(fs_space_t space, int n_neighbors, const int32_t* neighbor
 int fs_space_set_halo_indexed(fs_space_t space, int n_neighbors, const int32_t* neighbor_ranks, const int64_t* send_counts,
                               const int32_t* send_idx, const int64_t* recv_counts, const int32_t* recv_idx);
 int fs_halo_exchange(fs_space_t space, fs_vector_t v);
+/* Opt-in ghost refresh WITHOUT the library in the data path, for the ranks of one node: every rank owns a fine-grained
+ * receive buffer and arrival flags, its neighbours map them through hipIpc, a kernel gathers the values a neighbour
+ * needs and stores them straight into that neighbour's buffer (over xGMI), then releases a sequence number; the
+ * receiver's kernel waits for the sequence numbers of all its neighbours and fills the ghost entries.  Same place in
+ * the iteration as the grouped ncclSend / ncclRecv it replaces (PETSc's VecScatter behind MatMult,
+ * SolverBase.py:634 under mpirun), about a third of its latency on MI355X.
+ * COLLECTIVE over the communicator: every rank calls it for its space in the same order; enable = 0 turns it off
+ * (required before fs_space_set_halo replaces the plan).  FS_ERR_COMM without a communicator. */
+int fs_space_enable_p2p_halo(fs_space_t space, int enable);
 /* Mean latency (ms) of the two collectives of a distributed CG iteration as the solver issues them - the 3-double
  * ncclAllReduce behind VecDot (SolverBase.py:634 under mpirun) and the ghost refresh of this space's halo plan behind
  * MatMult's VecScatter - over `reps` back-to-back calls (HIP events).  Collective; zeros on one rank. */

@@ -72,7 +72,7 @@ def test_rccl_single_rank_allreduce_and_self_halo(gpu):
     Vs.set_halo([], [], [])
 
 
-@pytest.mark.parametrize("layout", ["two_neighbours_contiguous", "one_neighbour_packed"])
+@pytest.mark.parametrize("layout", ["two_neighbours_contiguous", "one_neighbour_packed", "two_neighbours_p2p", "one_neighbour_p2p"])
 def test_rccl_single_rank_pipelined_cg_with_self_halo(gpu, layout):
     """REAL RCCL (the 1-rank communicator a 1-GPU box allows) under the pipelined CG: the all-reduce of the sums is enqueued on
     the communication stream behind the grouped send / recv of the halo, the compute stream waits for both through events -
@@ -91,10 +91,12 @@ def test_rccl_single_rank_pipelined_cg_with_self_halo(gpu, layout):
         assert V.n_owned == n_own and V.n_local == n_own + 2 * pl
         top = np.arange(n_own - pl, n_own, dtype=np.int32)               # feeds the LOWER ghost plane
         bottom = np.arange(0, pl, dtype=np.int32)                        # feeds the UPPER ghost plane
-        if layout == "two_neighbours_contiguous":
+        if layout.startswith("two_neighbours"):
             V.set_halo([0, 0], [top, bottom], [pl, pl])
         else:
             V.set_halo([0], [np.concatenate([top, bottom])], [2 * pl])
+        if layout.endswith("p2p"):          # the kernels of the peer-to-peer exchange, the rank writing into its own buffer
+            V.enable_p2p_halo(True)
         A = gpu.DeviceMatrix(V)
         A.assemble(stiffness=3.0, mass=5.0)
         rng = np.random.default_rng(2)
@@ -122,5 +124,10 @@ def test_rccl_single_rank_pipelined_cg_with_self_halo(gpu, layout):
         assert abs(Mp - Mp.T).max() <= 1e-12 * abs(Mp).max()
         ref = spl.spsolve(Mp.tocsc(), b.get())
         assert np.abs(x1 - ref).max() <= 1e-8 * np.abs(ref).max()
+        if layout.endswith("p2p"):
+            from fenicssolver_amd import _lib as L
+            assert L.load().fs_space_set_halo(V.h, 0, None, None, None, None) != 0       # plan replaced with the exchange on: refused
+            V.enable_p2p_halo(False)
+            assert L.load().fs_space_set_halo(V.h, 0, None, None, None, None) == 0
     finally:
         gpu.comm_finalize()

@@ -32,7 +32,8 @@ def _run(world, case, tmp_path, **extra_env):
 
 
 @pytest.mark.parametrize("world,recurrence", [(2, "pipelined"), (3, "pipelined"), (2, "single_reduction"), (3, "single_reduction"),
-                                              (3, "pipelined_no_early_halo")])
+                                              (3, "pipelined_no_early_halo"), (2, "pipelined_p2p"), (3, "pipelined_p2p"),
+                                              (3, "single_reduction_p2p")])
 def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, recurrence):
     """Both CG recurrences on several ranks (several ranks default to the pipelined one, whose all-reduce runs on the
     communication stream under the product): same solution as one GPU <= 1e-9, iteration count within +2."""
@@ -50,7 +51,9 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
                       np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
     st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
     env = {"single_reduction": dict(FS_CG_PIPELINED="0"), "pipelined": {},
-           "pipelined_no_early_halo": dict(FS_HALO_EARLY="0")}[recurrence]
+           "pipelined_no_early_halo": dict(FS_HALO_EARLY="0"),
+           # ghost refresh by stores into the neighbour PROCESS's memory (hipIpc) instead of send / recv: real on one GPU too
+           "pipelined_p2p": dict(FS_HALO_P2P="1"), "single_reduction_p2p": dict(FS_HALO_P2P="1", FS_CG_PIPELINED="0")}[recurrence]
     r = _run(world, "box", tmp_path, **env)
     assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10
     assert abs(int(r["iterations"]) - st["iterations"]) <= 2          # reduction order differs, the recurrence does not
@@ -59,12 +62,23 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
 
 @pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
+    _solver_classes_case(gpu, tmp_path, case, world)
+
+
+@pytest.mark.parametrize("case,world", [("heat", 3), ("elasticity", 2), ("heat_p2", 3)])
+def test_solver_classes_with_the_peer_to_peer_halo(gpu, tmp_path, case, world):
+    """FS_HALO_P2P=1: every halo plan of the run (P1, the 3-component one, the indexed CG2 one) refreshes its ghosts by stores
+    into the neighbour's hipIpc-mapped buffer."""
+    _solver_classes_case(gpu, tmp_path, case, world, FS_HALO_P2P="1")
+
+
+def _solver_classes_case(gpu, tmp_path, case, world, **env):
     """`python -m fenicssolver_amd.launch --nproc N script.py` with the reference-style solver classes:
     same field as the single-process run, gathered on every rank.  heat_p2: CG2 nodes decomposed as
     [owned vertices | owned edges | ghost vertices | ghost edges] with the indexed halo."""
     import test_gpu_parallel_api as T
     single = T.CASES[case]().solve().vector().get_local()
-    r = _run(world, case, tmp_path)
+    r = _run(world, case, tmp_path, **env)
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
 
 
@@ -172,18 +186,24 @@ def test_vector_p2_elasticity_under_several_ranks(gpu, tmp_path, world):
     assert np.abs(r["von_mises"] - vm).max() <= 1e-6 * np.abs(vm).max()
 
 
-def test_bench_under_the_drivers_launcher(gpu, tmp_path):
+@pytest.mark.parametrize("p2p", ["works", "openfail", "lost"])
+def test_bench_under_the_drivers_launcher(gpu, tmp_path, p2p):
     """bench.py exactly as the driver starts it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py
     --gpus N): env rendezvous of the RCCL id through fenicssolver_amd/rendezvous.py (no torch import in bench.py), barrier
     and max-over-ranks over the communicator, one JSON line from rank 0.  One GPU here: tests/shim/on_device0.py pins every
-    rank to device 0 and libfakerccl.so stands in for RCCL."""
+    rank to device 0 and libfakerccl.so stands in for RCCL.  The warm-up tries the three variants (two recurrences over RCCL,
+    the peer-to-peer exchange); when the peer-to-peer exchange cannot be set up (openfail) or its data never arrives (lost: every
+    wait times out) the line still comes, from an RCCL variant, with the reason recorded."""
     import json
     shim = os.path.join(ROOT, "tests", "shim", "libfakerccl.so")
     PORT[0] += 1
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "shim", "on_device0.py"), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "23"]
-    p = subprocess.run(cmd, env=dict(os.environ, FS_RCCL_PATH=shim), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "23", "--extra", "strong", "--strong-n", "23"]
+    env = dict(os.environ, FS_RCCL_PATH=shim)
+    if p2p != "works":
+        env.update(FS_P2P_TEST=p2p, FS_P2P_TIMEOUT_MS="100")
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -191,5 +211,15 @@ def test_bench_under_the_drivers_launcher(gpu, tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "DOF/s"
     assert d["config"]["n_dof"] == 24 * 24 * 48 and d["config"]["true_rel_residual"] <= 1.1e-8
     assert "roofline" in d and d["value"] > 0
+    trial = d["config"]["recurrence_trial_ms_per_step"]
+    assert set(trial) == {"single_reduction", "pipelined", "single_reduction+p2p"}
+    assert all(isinstance(trial[k], float) for k in ("single_reduction", "pipelined"))
+    if p2p == "works":
+        assert isinstance(trial["single_reduction+p2p"], float)
+        assert "dof_per_s" in d["strong"]["single_reduction+p2p"] and d["strong"]["single_reduction+p2p"]["true_rel_residual"] <= 1.1e-8
+    else:
+        assert trial["single_reduction+p2p"].startswith("unavailable" if p2p == "openfail" else "failed"), trial
+        assert d["config"]["recurrence"] in ("single_reduction", "pipelined")
+        assert ("unavailable" if p2p == "openfail" else "failed") in d["strong"]["single_reduction+p2p"]
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src and "from torch" not in src

@@ -46,4 +46,10 @@ run("RCCL 1 rank, self-halo, single-reduction", V2, A2, b2, pipelined=False)
 run("RCCL 1 rank, self-halo, pipelined", V2, A2, b2, pipelined=True)
 a_ms, h_ms = B.comm_benchmark(V2, 200)
 print("in-stream all-reduce of 3 doubles %.1f us, ghost refresh (2 planes of %d doubles to self) %.1f us" % (a_ms * 1e3, pl, h_ms * 1e3))
+V2.enable_p2p_halo(True)
+run("peer-to-peer halo (to self), single-reduction", V2, A2, b2, pipelined=False)
+run("peer-to-peer halo (to self), pipelined", V2, A2, b2, pipelined=True)
+a_ms, h_ms = B.comm_benchmark(V2, 200)
+print("peer-to-peer ghost refresh %.1f us" % (h_ms * 1e3))
+V2.enable_p2p_halo(False)
 B.comm_finalize()
