@@ -275,7 +275,7 @@ def choose_recurrence(prob, rtol, world, requested, barrier, steps=2):
         set_variant(prob, requested)
         return requested, {}
     os.environ.setdefault("FS_P2P_TIMEOUT_MS", "4000")
-    trial, report = {}, {}
+    trial, report, x_ref, first = {}, {}, None, None
     for name in VARIANTS:
         err = None
         try:
@@ -289,11 +289,18 @@ def choose_recurrence(prob, rtol, world, requested, barrier, steps=2):
             t = timed_steps(prob, rtol, steps, barrier, reduce=False)[0] / steps
         except Exception as e:               # this rank only, perhaps: the ranks compare notes below
             err, t = repr(e)[:200], 0.0
+        if err is None:                      # every variant must reproduce the first one's field (a transport that delivers stale
+            x = prob.x.get()[:prob.n_owned]  # ghost values may still "converge")
+            if x_ref is None:
+                x_ref = x
+            elif not np.abs(x - x_ref).max() <= 1e-5 * np.abs(x_ref).max():
+                err = "solution differs from the %s run by %.3g" % (first, float(np.abs(x - x_ref).max()))
         if not all_ranks_ok(err is None):
             report[name] = "failed: " + (err or "on another rank")
             if getattr(prob, "p2p", False):
                 set_variant(prob, "single_reduction")
             continue
+        first = first or name
         trial[name] = float(np.max(B.comm_allgather([t], 1)))
         report[name] = round(trial[name] * 1e3, 4)
     best = min(trial, key=trial.get)

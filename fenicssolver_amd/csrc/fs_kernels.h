@@ -63,6 +63,15 @@ struct fs_p2p_sendrows {
     uint32_t* counter;              // workgroups of this launch that are through (the last one releases the sequence numbers)
     unsigned long long seq;
     int nn, slot;
+    // the receive of the SAME exchange, by the same kernel (recv_on): after its own stores are out every workgroup waits for
+    // the neighbours' sequence numbers and moves its share of the receive buffer to the ghost entries of the vector
+    const unsigned long long* own_flags;
+    const double* own_recv;
+    double* ghosts;
+    int64_t total_recv;
+    long long timeout;
+    int* err;
+    int recv_on;
 };
 // all-reduce of the three dot sums inside the rows kernel (k_cg_update_scaled_rows, fs_krylov.hip)
 struct fs_p2p_rowsred {

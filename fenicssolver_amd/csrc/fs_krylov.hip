@@ -833,6 +833,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
                 fs_p2p_publish(q.flags + (int64_t)snd.slot * q.peer_nn + q.peer_slot, snd.seq);
             }
         }
+        if (snd.recv_on) {          // (no workgroup waits before its own stores are counted: the neighbours wait for those)
+            if ((int)threadIdx.x < snd.nn) fs_p2p_wait(snd.own_flags + threadIdx.x, snd.seq, snd.timeout, snd.err);
+            __syncthreads();
+            int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            for (; k < snd.total_recv; k += stride) snd.ghosts[k] = fs_p2p_load(snd.own_recv + k);
+        }
     }
 }
 
@@ -1779,6 +1785,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // the update below.  FS_HALO_EARLY=0 keeps the exchange inside the product.
         int64_t early_a = 0, early_b = n;
         int p2p_fuse = 0;
+        bool p2p_ghosts_in = false;      // fused peer-to-peer iteration: the ghosts of the next product were received by the rows kernel
         if (ds && !bicg && !fuse_sums && sp->halo.active) {     // (a condition every rank evaluates alike; !fuse_sums: a communicator is up)
             static const bool no_early = getenv("FS_HALO_EARLY") && getenv("FS_HALO_EARLY")[0] == '0';
             fs_halo_plan& hp = sp->halo;
@@ -1798,7 +1805,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 // every rank has to take the same path: an exchange begun by one side only would never be matched
                 // (+ 1024 per rank whose plan allows the fused peer-to-peer iteration below: its kernels are gated by the status
                 // word, the separate send / receive kernels are not - a mix would leave one side waiting)
-                double flag = (ok ? 1.0 : 0.0) + (bs == 1 && fs_p2p_fusable(sp) ? 1024.0 : 0.0);
+                double flag = (ok ? 1.0 : 0.0) + (fs_p2p_fusable(sp) ? 1024.0 : 0.0);
                 FS_HIP(hipMemcpyAsync(ws.sums.p + 6, &flag, sizeof(double), hipMemcpyHostToDevice, s));
                 FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 6, 1, s));
                 FS_HIP(hipMemcpyAsync(&flag, ws.sums.p + 6, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1813,15 +1820,16 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             (long long)a, (long long)b2, (long long)n, hp.early == 1 ? "yes" : "no");
             }
             if (hp.early == 1) { early_a = hp.early_a; early_b = hp.early_b; }
-            // Peer-to-peer exchange on every rank: the iteration is FOUR kernels of the compute stream instead of seven launches on two
-            // streams (below).  FS_P2P_FUSE: bit 1 the four-kernel iteration at all, bit 0 the send inside the rows kernel, bit 2 the
-            // all-reduce inside the rows kernel (default 7; 0 keeps the separate send / receive / all-reduce kernels around a split
-            // product).  Measured alternatives that lost on MI355X: ghost columns read straight from the (uncached, fine-grained)
+            // Peer-to-peer exchange on every rank: the iteration is THREE kernels of the compute stream instead of seven launches on
+            // two streams (below): the plain product, the rows kernel (all-reduce of the sums, update of the rows the neighbours need,
+            // their store into the neighbours' buffers, receive of the neighbours' rows), the update of the rest.  FS_P2P_FUSE: bit 1
+            // this iteration at all, bit 0 the send, bit 2 the all-reduce, bit 3 the receive inside the rows kernel (default 15; 0
+            // keeps the separate send / receive / all-reduce kernels around a split product).  Measured alternatives that lost on MI355X: ghost columns read straight from the (uncached, fine-grained)
             // receive buffer by the boundary rows of one merged product (67 instead of 39 us per product at 1 M rows), and the
             // sums posted by the last workgroup of the product (its agent-scope fence in every workgroup writes back the whole
             // L2 of the XCD: + 26 us).
-            static const int fuse_env = getenv("FS_P2P_FUSE") ? atoi(getenv("FS_P2P_FUSE")) : 7;
-            if (hp.fuse == 1 && !pipelined && (fuse_env & 2)) p2p_fuse = fuse_env & 7;
+            static const int fuse_env = getenv("FS_P2P_FUSE") ? atoi(getenv("FS_P2P_FUSE")) : 15;
+            if (hp.fuse == 1 && !pipelined && (fuse_env & 2)) p2p_fuse = fuse_env & 15;
         }
         const bool use_graph = ds && fuse_sums && !bicg && !pipelined && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
@@ -1947,21 +1955,25 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const int co = k == max_iter ? 1 : 0;
                     fs_p2p_rowsred red = {};
                     fs_p2p_sendrows snd = {};
-                    if (!sp->halo.begun) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));          // first iteration: the plain send kernel
-                    FS_CHECK(fs_p2p_recv_gated(sp, ws.status.p, s));
-                    sp->halo.begun = false;
+                    const bool recv_in_rows = (p2p_fuse & 9) == 9;
+                    if (!recv_in_rows || !p2p_ghosts_in) {
+                        if (!sp->halo.begun) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));      // first iteration: the plain send kernel
+                        FS_CHECK(fs_p2p_recv_gated(sp, ws.status.p, s));
+                        sp->halo.begun = false;
+                        p2p_ghosts_in = true;
+                    }
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
                     launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                    const int fgrid = spmv_partials_unsplit(sp, 1);
+                    const int fgrid = spmv_partials_unsplit(sp, bs);
                     if (p2p_fuse & 4) FS_CHECK(fs_p2p_next_reduce(ws.partials.p, fgrid, ws.sums.p, &red));
                     else FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, fgrid, 3, ws.sums.p, s));
-                    if (p2p_fuse & 1) FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, &snd));
+                    if (p2p_fuse & 1) FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, recv_in_rows ? 1 : 0, &snd));
                     hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 64)), dim3(FS_BLOCK), 0, s,
                                        early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, red, snd);
                     if (!(p2p_fuse & 1)) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
-                    sp->halo.begun = true;
+                    sp->halo.begun = !recv_in_rows;
                     const int64_t m0 = early_a, nm = early_b - early_a;
                     if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
                     else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);

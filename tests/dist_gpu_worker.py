@@ -38,6 +38,28 @@ if case == "box":
         result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"])
     parallel.barrier()
     parallel.finalize()
+elif case == "box3":
+    # three components per node (3x3-block operator of linear elasticity + mass), Jacobi-CG: the dof-level halo of a vector space
+    nx, ny, nz = 6, 5, 17
+    parallel.ensure_comm()
+    zr = partition.slab_ranges(nz + 1, world)[rank]
+    mesh = B.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0), zplanes=zr)
+    V = B.DeviceSpace(mesh, 3)
+    lay = partition.slab_layout(nx, ny, nz, zr, rank, world)
+    sends = [(3 * np.asarray(sl, dtype=np.int64)[:, None] + np.arange(3)).ravel().astype(np.int32) for sl in lay["send_lists"]]
+    V.set_halo(lay["neighbors"], sends, [3 * c for c in lay["recv_counts"]])
+    A = B.DeviceMatrix(V)
+    A.assemble(lame=(1.0, 1.5), mass=4.0)
+    g = np.repeat(lay["l2g"][:lay["n_owned"]], 3) * 3 + np.tile(np.arange(3), lay["n_owned"])
+    rhs = np.sin(0.37 * g) + 0.2
+    b = B.DeviceVector(V.n_owned, rhs)
+    x = B.DeviceVector(V.n_local)
+    st = B.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+    full = parallel.gather_owned(x.get()[:V.n_owned], g, 3 * (nx + 1) * (ny + 1) * (nz + 1))
+    if rank == 0:
+        result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"])
+    parallel.barrier()
+    parallel.finalize()
 else:
     # the solver API on several ranks (parallel.py)
     import test_gpu_parallel_api as T

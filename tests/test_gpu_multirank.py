@@ -33,7 +33,7 @@ def _run(world, case, tmp_path, **extra_env):
 
 @pytest.mark.parametrize("world,recurrence", [(2, "pipelined"), (3, "pipelined"), (2, "single_reduction"), (3, "single_reduction"),
                                               (3, "pipelined_no_early_halo"), (2, "pipelined_p2p"), (3, "pipelined_p2p"),
-                                              (3, "single_reduction_p2p")])
+                                              (3, "single_reduction_p2p"), (3, "p2p_unfused"), (2, "p2p_send_recv_kernels")])
 def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, recurrence):
     """Both CG recurrences on several ranks (several ranks default to the pipelined one, whose all-reduce runs on the
     communication stream under the product): same solution as one GPU <= 1e-9, iteration count within +2."""
@@ -53,11 +53,34 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
     env = {"single_reduction": dict(FS_CG_PIPELINED="0"), "pipelined": {},
            "pipelined_no_early_halo": dict(FS_HALO_EARLY="0"),
            # ghost refresh by stores into the neighbour PROCESS's memory (hipIpc) instead of send / recv: real on one GPU too
-           "pipelined_p2p": dict(FS_HALO_P2P="1"), "single_reduction_p2p": dict(FS_HALO_P2P="1", FS_CG_PIPELINED="0")}[recurrence]
+           "pipelined_p2p": dict(FS_HALO_P2P="1", FS_CG_PIPELINED="1"), "single_reduction_p2p": dict(FS_HALO_P2P="1"),
+           # FS_P2P_FUSE: 0 = the separate send / receive / all-reduce kernels around a split product, 6 = the fused iteration with
+           # its send and receive still kernels of their own
+           "p2p_unfused": dict(FS_HALO_P2P="1", FS_P2P_FUSE="0"), "p2p_send_recv_kernels": dict(FS_HALO_P2P="1", FS_P2P_FUSE="6")}[recurrence]
     r = _run(world, "box", tmp_path, **env)
     assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10
     assert abs(int(r["iterations"]) - st["iterations"]) <= 2          # reduction order differs, the recurrence does not
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "rccl"), (3, "p2p"), (2, "p2p_unfused")])
+def test_vector_space_slabs_over_ranks(gpu, tmp_path, world, mode):
+    """Three dofs per node (elasticity + mass operator), Jacobi-CG: the dof-level halo of a vector space over RCCL, over the fused
+    peer-to-peer iteration and over the separate peer-to-peer kernels - same solution as one GPU."""
+    nx, ny, nz = 6, 5, 17
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0))
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(1.0, 1.5), mass=4.0)
+    g = np.arange(V.n_owned)
+    b = gpu.DeviceVector(V.n_owned, np.sin(0.37 * g) + 0.2)
+    x = gpu.DeviceVector(V.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+    env = {"rccl": {}, "p2p": dict(FS_HALO_P2P="1"), "p2p_unfused": dict(FS_HALO_P2P="1", FS_P2P_FUSE="0")}[mode]
+    r = _run(world, "box3", tmp_path, **env)
+    assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10
+    assert abs(int(r["iterations"]) - st["iterations"]) <= 2
+    assert np.abs(r["x"] - x.get()[:V.n_owned]).max() <= 1e-9 * np.abs(x.get()).max()
 
 
 @pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2)])

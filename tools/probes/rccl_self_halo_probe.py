@@ -35,21 +35,28 @@ def run(tag, V, A, b, **kw):
         tag, st["iterations"], (t1 - t0) * 1e6 / max(st["iterations"], 1), st["spmv_ms"] * 1e3, st["update_ms"] * 1e3), flush=True)
 
 
-V, A, b = problem(False)
-print("rows", V.n_owned)
-run("no communicator (hipGraph batches)", V, A, b)
+what = sys.argv[2] if len(sys.argv) > 2 else "all"          # all | one | rccl | p2p  (one variant alone: for a kernel trace)
+if what in ("all", "one"):
+    V, A, b = problem(False)
+    print("rows", V.n_owned)
+    run("no communicator (hipGraph batches)", V, A, b)
 os.environ["FS_CG_GRAPH"] = "0"
 uid = B.comm_unique_id()
 B.comm_init(1, 0, uid)
 V2, A2, b2 = problem(True)
-run("RCCL 1 rank, self-halo, single-reduction", V2, A2, b2, pipelined=False)
-run("RCCL 1 rank, self-halo, pipelined", V2, A2, b2, pipelined=True)
-a_ms, h_ms = B.comm_benchmark(V2, 200)
-print("in-stream all-reduce of 3 doubles %.1f us, ghost refresh (2 planes of %d doubles to self) %.1f us" % (a_ms * 1e3, pl, h_ms * 1e3))
-V2.enable_p2p_halo(True)
-run("peer-to-peer halo (to self), single-reduction", V2, A2, b2, pipelined=False)
-run("peer-to-peer halo (to self), pipelined", V2, A2, b2, pipelined=True)
-a_ms, h_ms = B.comm_benchmark(V2, 200)
-print("peer-to-peer ghost refresh %.1f us" % (h_ms * 1e3))
-V2.enable_p2p_halo(False)
+if what in ("all", "rccl"):
+    run("RCCL 1 rank, self-halo, single-reduction", V2, A2, b2, pipelined=False)
+if what == "all":
+    run("RCCL 1 rank, self-halo, pipelined", V2, A2, b2, pipelined=True)
+    a_ms, h_ms = B.comm_benchmark(V2, 200)
+    print("in-stream all-reduce of 3 doubles %.1f us, ghost refresh (2 planes of %d doubles to self) %.1f us" % (a_ms * 1e3, pl, h_ms * 1e3))
+if what in ("all", "p2p"):
+    V2.enable_p2p_halo(True)
+    run("peer-to-peer halo (to self), single-reduction", V2, A2, b2, pipelined=False)
+if what == "all":
+    run("peer-to-peer halo (to self), pipelined", V2, A2, b2, pipelined=True)
+    a_ms, h_ms = B.comm_benchmark(V2, 200)
+    print("peer-to-peer ghost refresh %.1f us" % (h_ms * 1e3))
+if what in ("all", "p2p"):
+    V2.enable_p2p_halo(False)
 B.comm_finalize()
