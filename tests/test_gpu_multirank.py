@@ -88,7 +88,7 @@ def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     _solver_classes_case(gpu, tmp_path, case, world)
 
 
-@pytest.mark.parametrize("case,world", [("heat", 3), ("elasticity", 2), ("heat_p2", 3)])
+@pytest.mark.parametrize("case,world", [("heat", 3), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 3), ("heat_supg", 2)])
 def test_solver_classes_with_the_peer_to_peer_halo(gpu, tmp_path, case, world):
     """FS_HALO_P2P=1: every halo plan of the run (P1, the 3-component one, the indexed CG2 one) refreshes its ghosts by stores
     into the neighbour's hipIpc-mapped buffer."""
@@ -159,8 +159,9 @@ def test_distributed_box_mesh_with_p2_spaces(gpu, tmp_path, case, world):
     assert int(r["n_local"]) <= V.num_nodes() / world * 1.3 + ghost_layers
 
 
-@pytest.mark.parametrize("case,world", [("cavity", 2), ("cavity", 3), ("channel", 2), ("radiation", 2)])
-def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
+@pytest.mark.parametrize("case,world,p2p", [("cavity", 2, False), ("cavity", 3, False), ("channel", 2, False), ("radiation", 2, False),
+                                            ("cavity", 3, True), ("channel", 2, True)])
+def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world, p2p):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,
     FGMRES with reduced multi-dots, halo exchange of the iterate inside the preconditioner, Schur-complement solves on
     the replicated pressure space (every rank applies the V-cycle of the global pressure Laplacian), Newton residual norm
@@ -168,7 +169,9 @@ def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world):
     import test_gpu_parallel_api as T
     one = T.NS_CASES[case]()
     single = one.solve().vector().get_local()
-    r = _run(world, case, tmp_path)
+    # p2p: every halo (block-4 indexed, pressure space, mass-matrix solves) and every all-reduce of up to 8 doubles through the
+    # peer-to-peer kernels; the longer multi-dot reductions of FGMRES stay on ncclAllReduce
+    r = _run(world, case, tmp_path, **(dict(FS_HALO_P2P="1") if p2p else {}))
     assert np.abs(r["x"] - single).max() <= 1e-6 * np.abs(single).max()
     if case == "channel":                 # viscous_stress on several ranks: nine decomposed mass-matrix solves
         sig = one.viscous_stress(one.w_current).vector().get_local()
