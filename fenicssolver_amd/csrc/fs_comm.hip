@@ -628,28 +628,30 @@ static int p2p_exchange_end(fs_space_s* space, hipStream_t s, const int* gate = 
 
 bool fs_p2p_fusable(const fs_space_s* space) {
     const fs_halo_plan& h = space->halo;
-    return h.active && h.p2p.enabled && !h.recv_idx.p && g_p2p_red.enabled && fs_rt().comm != nullptr;
+    return h.active && h.p2p.enabled && g_p2p_red.enabled && fs_rt().comm != nullptr;
 }
 
-int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, int recv_too, fs_p2p_sendrows* out) {
+int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out) {
     fs_halo_plan& h = space->halo;
     fs_p2p_halo& pp = h.p2p;
     FS_REQUIRE(!pp.pending, "peer-to-peer halo: an exchange was begun and never received");
+    (void)d_vec;
     const unsigned long long seq = ++pp.seq;
     const int nn = (int)h.neighbors.size(), slot = (int)(seq & 1ull);
     out->peers = pp.peers.p;
+    out->send_idx = h.send_idx.p;
+    out->total_send = h.total_send;
     out->counter = pp.counter.p;
     out->seq = seq;
     out->nn = nn;
     out->slot = slot;
     out->own_flags = pp.flags + (int64_t)slot * nn;
     out->own_recv = pp.recv + (int64_t)slot * std::max<int64_t>(h.total_recv, 1);
-    out->ghosts = d_vec + space->n_dofs_owned;
+    out->recv_idx = h.recv_idx.p;
     out->total_recv = h.total_recv;
+    out->n_owned = space->n_dofs_owned;
     out->timeout = g_p2p_timeout_ticks;
     out->err = g_p2p_err;
-    out->recv_on = recv_too;
-    pp.pending = recv_too ? nullptr : d_vec;
     return FS_OK;
 }
 

@@ -296,8 +296,8 @@ int fs_p2p_allreduce_dev(const double* partials, int npart, double* inout, int n
 int fs_p2p_reduce_enabled();
 // fused peer-to-peer CG iteration (fs_krylov.hip): the structures the kernels take, with the sequence numbers advanced
 struct fs_p2p_sendrows; struct fs_p2p_rowsred;
-bool fs_p2p_fusable(const fs_space_s* space);                                   // peer-to-peer halo on, ghosts grouped by neighbour
-int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, int recv_too, fs_p2p_sendrows* out);    // the exchange the rows kernel will issue (and receive)
+bool fs_p2p_fusable(const fs_space_s* space);                                   // peer-to-peer halo and all-reduce on
+int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out);    // the exchange the exchange kernel will issue and receive
 int fs_p2p_recv_gated(fs_space_s* space, const int* status, hipStream_t s);      // receive of the pending exchange unless status[0] != 0
 void fs_p2p_drop_pending(fs_space_s* space);                                    // a status-gated exchange that was never issued
 int fs_p2p_next_reduce(const double* partials, int npart, double* sums_out, fs_p2p_rowsred* out);

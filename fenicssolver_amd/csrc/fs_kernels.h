@@ -57,23 +57,23 @@ __device__ __forceinline__ bool fs_p2p_wait(const unsigned long long* flag, unsi
     return ok;
 }
 
-// what the update kernel on the rows a slab sends needs to store them into the neighbours' receive buffers itself
+// halo part of the exchange kernel of the peer-to-peer CG iteration (k_cg_p2p_exchange, fs_krylov.hip)
 struct fs_p2p_sendrows {
-    const fs_p2p_peer* peers;
-    uint32_t* counter;              // workgroups of this launch that are through (the last one releases the sequence numbers)
+    const fs_p2p_peer* peers;       // per neighbour: where its part of the send list goes
+    const int32_t* send_idx;        // concatenated send lists (owned dofs)
+    int64_t total_send;
+    uint32_t* counter;              // workgroups of this launch whose stores are out (the last one publishes the sequence numbers)
     unsigned long long seq;
     int nn, slot;
-    // the receive of the SAME exchange, by the same kernel (recv_on): after its own stores are out every workgroup waits for
-    // the neighbours' sequence numbers and moves its share of the receive buffer to the ghost entries of the vector
+    // the receive of the same exchange: this rank's flags and buffer slot, the scatter list (nullptr: ghosts in arrival order)
     const unsigned long long* own_flags;
     const double* own_recv;
-    double* ghosts;
-    int64_t total_recv;
+    const int32_t* recv_idx;
+    int64_t total_recv, n_owned;
     long long timeout;
     int* err;
-    int recv_on;
 };
-// all-reduce of the three dot sums inside the rows kernel (k_cg_update_scaled_rows, fs_krylov.hip)
+// all-reduce part of the same kernel
 struct fs_p2p_rowsred {
     const double* partials;         // [3][npart] of the product
     double* sums_out;               // [3]: the reduced sums for the kernels that follow

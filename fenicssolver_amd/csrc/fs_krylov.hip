@@ -761,39 +761,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
                                                                     const double* __restrict__ sums, const double* __restrict__ ctrl,
                                                                     const double* __restrict__ scal, const int* __restrict__ status,
                                                                     double* __restrict__ r, const double* __restrict__ w,
-                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x,
-                                                                    const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
+                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x) {
     if (status[0] != 0) return;
-    double gamma, delta, rho;
-    if (red.on) {
-        // the all-reduce of the three dot sums happens HERE (peer-to-peer iteration, see the host loop): every workgroup sums the
-        // product's partials itself (same bits everywhere), workgroup 0 stores them into slot [me] of the other ranks' buffers,
-        // every workgroup waits for the other ranks' sums and adds all up in rank order; workgroup 0 leaves the result in `sums`
-        // for the update of the remaining rows
-        double sm[3];
-        wg_sum_partials<3>(red.partials, red.npart, sm);
-        const int t = threadIdx.x;
-        if (blockIdx.x == 0 && t < red.nr && t != red.me) {
-            double* dst = red.peer_buf[t] + ((int64_t)red.slot * red.nr + red.me) * 8;
-            fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
-            fs_p2p_stores_done();
-            fs_p2p_publish(red.peer_flags[t] + (int64_t)red.slot * red.nr + red.me, red.seq);
-        }
-        if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)red.slot * red.nr + t, red.seq, red.timeout, red.err);
-        __syncthreads();
-        __shared__ double tot[3];
-        if (t < 3) {
-            double a = 0.0;
-            for (int r = 0; r < red.nr; ++r)
-                a += r == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)red.slot * red.nr + r) * 8 + t);
-            tot[t] = a;
-            if (blockIdx.x == 0) red.sums_out[t] = a;
-        }
-        __syncthreads();
-        gamma = tot[0]; delta = tot[1]; rho = tot[2];
-    } else {
-        gamma = sums[0]; delta = sums[1]; rho = sums[2];
-    }
+    const double gamma = sums[0], delta = sums[1], rho = sums[2];
     if (rho <= ctrl[0] || check_only) return;
     double beta = 0.0, alpha;
     if (iter == 0) {
@@ -814,32 +784,97 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
         const double ss = w[i] + beta * sv[i];
         p[i] = pp; sv[i] = ss;
         x[i] += alpha * pp;
-        const double rn = r[i] - alpha * ss;
-        r[i] = rn;
-        // peer-to-peer exchange: the new value goes straight into the receive buffer of every neighbour that needs this row
+        r[i] -= alpha * ss;
+    }
+}
+
+// ---- the exchange kernel of the peer-to-peer iteration (fs_comm.hip: hipIpc-mapped buffers; protocol in fs_kernels.h) -----------
+// Everything of a CG iteration that crosses GPUs, in ONE launch between the product and the update:
+//   1. every workgroup sums the product's dot partials itself (same bits everywhere); workgroup 0 stores the three sums into slot
+//      [me] of the other ranks' all-reduce buffers; every workgroup waits for the other ranks' sums and adds all up in rank order;
+//      workgroup 0 leaves the result in `sums` for the update kernel that follows;
+//   2. the NEW residual of every row some neighbour needs, r - alpha (w + beta s), is computed (not stored here: the update
+//      kernel computes the same number with the same operations a moment later) and stored straight into that neighbour's
+//      receive buffer; the last workgroup through publishes the sequence number of the exchange at every neighbour;
+//   3. every workgroup waits for the neighbours' sequence numbers and moves its share of the own receive buffer to the ghost
+//      entries of r.  (No workgroup waits before its own stores are counted, so two ranks never wait for each other.)
+// Any halo plan (send lists need not be contiguous, ghosts may be scattered), any block size: rows are dofs here.  Gated by the
+// status word and by the same convergence test as the update kernel: every rank stops sending and waiting at the same iteration.
+__global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int check_only, const double* __restrict__ ctrl,
+                                                              const double* __restrict__ scal, const int* __restrict__ status,
+                                                              double* r, const double* __restrict__ w, const double* __restrict__ sv,
+                                                              const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
+    if (status[0] != 0) return;
+    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
+        iter = status[2] - 1;
+        check_only = iter >= (int)ctrl[2] ? 1 : 0;
+    }
+    // the operands of this thread's first entry are requested before the sums are reduced and exchanged: their latency hides there
+    const int64_t e_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int32_t i_f = 0;
+    double r_f = 0.0, w_f = 0.0, s_f = 0.0;
+    if (e_first < snd.total_send) {
+        i_f = snd.send_idx[e_first];
+        r_f = r[i_f]; w_f = w[i_f]; s_f = sv[i_f];
+    }
+    double sm[3];
+    wg_sum_partials<3>(red.partials, red.npart, sm);
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t < red.nr && t != red.me) {
+        double* dst = red.peer_buf[t] + ((int64_t)red.slot * red.nr + red.me) * 8;
+        fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
+        fs_p2p_stores_done();
+        fs_p2p_publish(red.peer_flags[t] + (int64_t)red.slot * red.nr + red.me, red.seq);
+    }
+    if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)red.slot * red.nr + t, red.seq, red.timeout, red.err);
+    __syncthreads();
+    __shared__ double tot[3];
+    if (t < 3) {
+        double a = 0.0;
+        for (int q = 0; q < red.nr; ++q)
+            a += q == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)red.slot * red.nr + q) * 8 + t);
+        tot[t] = a;
+        if (blockIdx.x == 0) red.sums_out[t] = a;
+    }
+    __syncthreads();
+    const double gamma = tot[0], delta = tot[1], rho = tot[2];
+    if (rho <= ctrl[0] || check_only) return;
+    double beta = 0.0, alpha;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) return;
+    for (int64_t e = e_first; e < snd.total_send; e += stride) {
+        if (e != e_first) {
+            i_f = snd.send_idx[e];
+            r_f = r[i_f]; w_f = w[i_f]; s_f = sv[i_f];
+        }
+        const double ss = w_f + beta * s_f;             // (the two lines of the update kernel)
+        const double rn = r_f - alpha * ss;
+        int j = 0;
+        while (j + 1 < snd.nn && e >= snd.peers[j + 1].send_offset) ++j;
+        const fs_p2p_peer q = snd.peers[j];
+        fs_p2p_store(q.recv + (int64_t)snd.slot * q.peer_total + q.recv_offset + (e - q.send_offset), rn);
+    }
+    fs_p2p_stores_done();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int j = 0; j < snd.nn; ++j) {
             const fs_p2p_peer q = snd.peers[j];
-            const int64_t k = i - q.send_first;
-            if (k >= 0 && k < q.send_count) fs_p2p_store(q.recv + (int64_t)snd.slot * q.peer_total + q.recv_offset + k, rn);
+            fs_p2p_publish(q.flags + (int64_t)snd.slot * q.peer_nn + q.peer_slot, snd.seq);
         }
     }
-    if (snd.nn > 0) {               // the last workgroup through publishes the sequence number at every neighbour (fs_kernels.h)
-        fs_p2p_stores_done();
-        __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
-            __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int j = 0; j < snd.nn; ++j) {
-                const fs_p2p_peer q = snd.peers[j];
-                fs_p2p_publish(q.flags + (int64_t)snd.slot * q.peer_nn + q.peer_slot, snd.seq);
-            }
-        }
-        if (snd.recv_on) {          // (no workgroup waits before its own stores are counted: the neighbours wait for those)
-            if ((int)threadIdx.x < snd.nn) fs_p2p_wait(snd.own_flags + threadIdx.x, snd.seq, snd.timeout, snd.err);
-            __syncthreads();
-            int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-            for (; k < snd.total_recv; k += stride) snd.ghosts[k] = fs_p2p_load(snd.own_recv + k);
-        }
-    }
+    if (t < snd.nn) fs_p2p_wait(snd.own_flags + t, snd.seq, snd.timeout, snd.err);
+    __syncthreads();
+    for (int64_t k = e_first; k < snd.total_recv; k += stride)
+        r[snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k] = fs_p2p_load(snd.own_recv + k);
 }
 
 // ---- pipelined CG (Ghysels & Vanroose, Parallel Computing 40 (2014)) on the scaled system --------------------------
@@ -1784,7 +1819,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // rows sent to the neighbours as a prefix [0, early_a) and / or a suffix [early_b, n) of the owned rows (z-slabs): see
         // the update below.  FS_HALO_EARLY=0 keeps the exchange inside the product.
         int64_t early_a = 0, early_b = n;
-        int p2p_fuse = 0;
+        int p2p_fuse = 0, p2p_rows_cap = 128;
         bool p2p_ghosts_in = false;      // fused peer-to-peer iteration: the ghosts of the next product were received by the rows kernel
         if (ds && !bicg && !fuse_sums && sp->halo.active) {     // (a condition every rank evaluates alike; !fuse_sums: a communicator is up)
             static const bool no_early = getenv("FS_HALO_EARLY") && getenv("FS_HALO_EARLY")[0] == '0';
@@ -1803,8 +1838,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 a = (a + 1) & ~(int64_t)1;          // the bulk update works on 16-byte pairs
                 ok = ok && a < b2 && (a > 0 || b2 < n);
                 // every rank has to take the same path: an exchange begun by one side only would never be matched
-                // (+ 1024 per rank whose plan allows the fused peer-to-peer iteration below: its kernels are gated by the status
-                // word, the separate send / receive kernels are not - a mix would leave one side waiting)
+                // (+ 1024 per rank with the peer-to-peer exchange on: the kernel of the iteration below is gated by the status word,
+                // the separate send / receive kernels are not - a mix would leave one side waiting)
                 double flag = (ok ? 1.0 : 0.0) + (fs_p2p_fusable(sp) ? 1024.0 : 0.0);
                 FS_HIP(hipMemcpyAsync(ws.sums.p + 6, &flag, sizeof(double), hipMemcpyHostToDevice, s));
                 FS_CHECK(fs_comm_allreduce_dev(ws.sums.p + 6, 1, s));
@@ -1812,7 +1847,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 FS_HIP(hipStreamSynchronize(s));
                 const int nr_all = fs_rt().n_ranks, agreed = (int)(flag + 0.5);
                 hp.early = agreed % 1024 == nr_all ? 1 : 0;
-                hp.fuse = hp.early == 1 && agreed / 1024 == nr_all ? 1 : 0;
+                hp.fuse = agreed / 1024 == nr_all ? 1 : 0;
                 hp.early_a = a;
                 hp.early_b = b2;
                 if (getenv("FS_KRYLOV_DEBUG"))
@@ -1820,16 +1855,17 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             (long long)a, (long long)b2, (long long)n, hp.early == 1 ? "yes" : "no");
             }
             if (hp.early == 1) { early_a = hp.early_a; early_b = hp.early_b; }
-            // Peer-to-peer exchange on every rank: the iteration is THREE kernels of the compute stream instead of seven launches on
-            // two streams (below): the plain product, the rows kernel (all-reduce of the sums, update of the rows the neighbours need,
-            // their store into the neighbours' buffers, receive of the neighbours' rows), the update of the rest.  FS_P2P_FUSE: bit 1
-            // this iteration at all, bit 0 the send, bit 2 the all-reduce, bit 3 the receive inside the rows kernel (default 15; 0
-            // keeps the separate send / receive / all-reduce kernels around a split product).  Measured alternatives that lost on MI355X: ghost columns read straight from the (uncached, fine-grained)
-            // receive buffer by the boundary rows of one merged product (67 instead of 39 us per product at 1 M rows), and the
-            // sums posted by the last workgroup of the product (its agent-scope fence in every workgroup writes back the whole
-            // L2 of the XCD: + 26 us).
-            static const int fuse_env = getenv("FS_P2P_FUSE") ? atoi(getenv("FS_P2P_FUSE")) : 15;
-            if (hp.fuse == 1 && !pipelined && (fuse_env & 2)) p2p_fuse = fuse_env & 15;
+            // Peer-to-peer exchange on every rank: the iteration is THREE kernels of the compute stream - the plain product, the
+            // exchange kernel (k_cg_p2p_exchange: all-reduce, send, receive), the plain update - instead of seven launches on two
+            // streams (below).  FS_P2P_FUSE=0 keeps the separate send / receive / all-reduce kernels of the same transport around a
+            // split product.  Measured alternatives that lost on MI355X: ghost columns read straight from the (uncached,
+            // fine-grained) receive buffer by the boundary rows of one merged product (67 instead of 39 us per product at 1 M rows),
+            // and the sums posted by the last workgroup of the product (its agent-scope fence in every workgroup writes back the
+            // whole L2 of the XCD: + 26 us).
+            static const int fuse_env = getenv("FS_P2P_FUSE") ? atoi(getenv("FS_P2P_FUSE")) : 1;
+            static const int rows_env = getenv("FS_P2P_ROWS_BLOCKS") ? atoi(getenv("FS_P2P_ROWS_BLOCKS")) : 128;
+            p2p_rows_cap = rows_env > 0 ? rows_env : 128;
+            if (hp.fuse == 1 && !pipelined && fuse_env) p2p_fuse = 1;
         }
         const bool use_graph = ds && fuse_sums && !bicg && !pipelined && !sp->halo.active && bs == 1 &&
                                (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
@@ -1949,17 +1985,11 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     continue;
                 }
                 if (p2p_fuse) {
-                    // K_R ghosts in (the neighbours stored them during THEIR rows update, a whole bulk update ago), K_A the plain
-                    // product over all slices, K_B sums + all-reduce + update of the rows the neighbours need + their store into the
-                    // neighbours' buffers, K_C update of the rest
                     const int co = k == max_iter ? 1 : 0;
                     fs_p2p_rowsred red = {};
                     fs_p2p_sendrows snd = {};
-                    const bool recv_in_rows = (p2p_fuse & 9) == 9;
-                    if (!recv_in_rows || !p2p_ghosts_in) {
-                        if (!sp->halo.begun) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));      // first iteration: the plain send kernel
-                        FS_CHECK(fs_p2p_recv_gated(sp, ws.status.p, s));
-                        sp->halo.begun = false;
+                    if (!p2p_ghosts_in) {          // first iteration of a pass: the plain send and receive kernels
+                        FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
                         p2p_ghosts_in = true;
                     }
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
@@ -1967,16 +1997,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     const int fgrid = spmv_partials_unsplit(sp, bs);
-                    if (p2p_fuse & 4) FS_CHECK(fs_p2p_next_reduce(ws.partials.p, fgrid, ws.sums.p, &red));
-                    else FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, fgrid, 3, ws.sums.p, s));
-                    if (p2p_fuse & 1) FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, recv_in_rows ? 1 : 0, &snd));
-                    hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 64)), dim3(FS_BLOCK), 0, s,
-                                       early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, red, snd);
-                    if (!(p2p_fuse & 1)) FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
-                    sp->halo.begun = !recv_in_rows;
-                    const int64_t m0 = early_a, nm = early_b - early_a;
-                    if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
-                    else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, nm, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p + m0, ws.w.p + m0, ws.p.p + m0, ws.s.p + m0, x->d.p + m0);
+                    FS_CHECK(fs_p2p_next_reduce(ws.partials.p, fgrid, ws.sums.p, &red));
+                    FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, &snd));
+                    const int64_t work = std::max(snd.total_send, snd.total_recv);
+                    hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
+                                       k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.s.p, red, snd);
+                    if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                    else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     if (sample) {
                         FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
                         ++n_samples;
@@ -2002,7 +2029,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         int64_t m0 = 0, m1 = n;
                         if (early_a > 0 || early_b < n) {
                             hipLaunchKernelGGL(k_cg_update_scaled_rows, dim3(fs_grid_for(early_a + (n - early_b), FS_BLOCK, 256)), dim3(FS_BLOCK), 0, s,
-                                               early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, fs_p2p_rowsred{}, fs_p2p_sendrows{});
+                                               early_a, early_b, n, k, co, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                             FS_CHECK(fs_halo_begin_dev(sp, ws.z.p, s));
                             sp->halo.begun = true;
                             m0 = early_a; m1 = early_b;
@@ -2034,10 +2061,6 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             pending = slot;
             slot ^= 1;
             if (k > max_iter) finished = true;
-        }
-        if (sp->halo.begun && p2p_fuse) {          // fused peer-to-peer iteration: the loop ends with a non-zero status word, under
-            fs_p2p_drop_pending(sp);               // which the rows kernel stored nothing, or what it stored is never read
-            sp->halo.begun = false;
         }
         if (sp->halo.begun) {          // the exchange started for a product that is not coming any more
             FS_CHECK(fs_halo_end_dev(sp, s));
