@@ -225,9 +225,15 @@ static int set_halo_impl(fs_space_t space, int n_neighbors, const int32_t* neigh
 static int* g_p2p_err = nullptr;                 // device flag: a wait timed out (peer died / mapping not coherent)
 static long long g_p2p_timeout_ticks = 0;        // wall_clock64 ticks (100 MHz)
 
-__global__ void __launch_bounds__(FS_BLOCK) k_p2p_send(const fs_p2p_peer* __restrict__ peers, int groups, uint32_t* done,
-                                                       const double* __restrict__ vec, const int32_t* __restrict__ send_idx,
-                                                       int slot, unsigned long long seq) {
+// Sequence numbers live ON THE DEVICE (one counter per halo plan, one for the all-reduce) and advance only when an exchange is
+// really executed: kernels gated off by a solver's status word consume none, so consecutive executed exchanges always alternate
+// between the two slots - which is what the no-overwrite argument above rests on - and a captured hipGraph can replay them.
+// Every workgroup reads the counter when it starts; the LAST workgroup through (an atomic count) writes it back incremented.
+__global__ void __launch_bounds__(FS_BLOCK) k_p2p_send(const fs_p2p_peer* __restrict__ peers, int groups, uint32_t* done, uint32_t* all_done,
+                                                       unsigned long long* d_seq, const double* __restrict__ vec,
+                                                       const int32_t* __restrict__ send_idx) {
+    const unsigned long long seq = *d_seq + 1ull;
+    const int slot = (int)(seq & 1ull);
     const int nb = blockIdx.x / groups, g = blockIdx.x - nb * groups;
     const fs_p2p_peer p = peers[nb];
     double* dst = p.recv + (int64_t)slot * p.peer_total + p.recv_offset;
@@ -242,17 +248,24 @@ __global__ void __launch_bounds__(FS_BLOCK) k_p2p_send(const fs_p2p_peer* __rest
             if (last) __hip_atomic_store(done + nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (last) fs_p2p_publish(p.flags + (int64_t)slot * p.peer_nn + p.peer_slot, seq);
+        if (atomicAdd(all_done, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(all_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
-// Receive: wait until every neighbour delivered exchange `seq`, then move the values to the ghost entries.
-__global__ void __launch_bounds__(FS_BLOCK) k_p2p_recv(int nn, const unsigned long long* flags, unsigned long long seq,
-                                                       const double* recv, int64_t total, const int32_t* __restrict__ recv_idx,
-                                                       double* __restrict__ vec, int64_t n_owned, long long timeout, int* err,
-                                                       const int* __restrict__ gate) {
-    if (gate && gate[0] != 0) return;          // status word of a solver: the send this receive pairs with was gated off too
-    if ((int)threadIdx.x < nn) fs_p2p_wait(flags + threadIdx.x, seq, timeout, err);
+// Receive of the exchange the last send kernel issued (*d_seq): wait until every neighbour delivered it, then move the values
+// to the ghost entries.  `never`: test hook (FS_P2P_TEST=lost).
+__global__ void __launch_bounds__(FS_BLOCK) k_p2p_recv(int nn, const unsigned long long* flags_base, const unsigned long long* d_seq,
+                                                       unsigned long long never, const double* recv_base, int64_t slot_stride,
+                                                       int64_t total, const int32_t* __restrict__ recv_idx,
+                                                       double* __restrict__ vec, int64_t n_owned, long long timeout, int* err) {
+    const unsigned long long seq = *d_seq;
+    const int slot = (int)(seq & 1ull);
+    if ((int)threadIdx.x < nn) fs_p2p_wait(flags_base + (int64_t)slot * nn + threadIdx.x, seq + never, timeout, err);
     __syncthreads();
+    const double* recv = recv_base + (int64_t)slot * slot_stride;
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; k < total; k += stride) {
@@ -273,7 +286,8 @@ struct fs_p2p_reduce {
     std::vector<void*> opened;
     dbuf<double*> peer_buf;
     dbuf<unsigned long long*> peer_flags;
-    unsigned long long seq = 0;
+    dbuf<unsigned long long> d_seq;            // device-side sequence number of the last executed all-reduce
+    dbuf<uint32_t> counter;                    // workgroups of the exchange kernel through their all-reduce part
     void release() {
         if (buf || flags || !opened.empty()) (void)hipDeviceSynchronize();
         for (void* q : opened) (void)hipIpcCloseMemHandle(q);
@@ -282,7 +296,8 @@ struct fs_p2p_reduce {
         if (flags) (void)hipFree(flags);
         buf = nullptr; flags = nullptr;
         peer_buf.release(); peer_flags.release();
-        enabled = false; seq = 0;
+        d_seq.release(); counter.release();
+        enabled = false;
     }
 };
 static fs_p2p_reduce g_p2p_red;
@@ -292,8 +307,10 @@ __global__ void __launch_bounds__(FS_SUM_BLOCK) k_p2p_allreduce(int nr, int me, 
                                                                 double* const* __restrict__ peer_buf,
                                                                 unsigned long long* const* __restrict__ peer_flags,
                                                                 const double* own_buf, const unsigned long long* own_flags,
-                                                                int slot, unsigned long long seq, double* inout,
+                                                                unsigned long long* d_seq, double* inout,
                                                                 long long timeout, int* err) {
+    const unsigned long long seq = *d_seq + 1ull;
+    const int slot = (int)(seq & 1ull);
     __shared__ double lds[FS_SUM_BLOCK / 64][4];
     __shared__ double mine[8];
     if (npart > 0) {                                     // the reduction of k_sum_partials (fs_kernels.h), same order, same bits
@@ -335,6 +352,7 @@ __global__ void __launch_bounds__(FS_SUM_BLOCK) k_p2p_allreduce(int nr, int me, 
         for (int r = 0; r < nr; ++r) a += fs_p2p_load(own_buf + ((int64_t)slot * nr + r) * 8 + t);
         inout[t] = a;
     }
+    if (t == 0) *d_seq = seq;              // (every thread read it before the first barrier)
 }
 
 void fs_p2p_halo::release() {
@@ -347,9 +365,9 @@ void fs_p2p_halo::release() {
     peers.release();
     done.release();
     counter.release();
+    d_seq.release();
     pending = nullptr;
     enabled = false;
-    seq = 0;
 }
 
 static int p2p_barrier() {               // host-level: an all-gather of one double
@@ -437,8 +455,11 @@ static int p2p_reduce_setup() {
     FS_CHECK(R.peer_flags.alloc(nr));
     FS_CHECK(R.peer_buf.upload(pb.data(), nr, rt.stream));
     FS_CHECK(R.peer_flags.upload(pf.data(), nr, rt.stream));
+    FS_CHECK(R.d_seq.alloc(1));
+    FS_CHECK(R.d_seq.zero(rt.stream));
+    FS_CHECK(R.counter.alloc(1));
+    FS_CHECK(R.counter.zero(rt.stream));
     FS_HIP(hipStreamSynchronize(rt.stream));
-    R.seq = 0;
     R.enabled = true;
     return FS_OK;
 }
@@ -455,9 +476,8 @@ int fs_p2p_reduce_enabled() { return g_p2p_red.enabled ? 1 : 0; }
 int fs_p2p_allreduce_dev(const double* partials, int npart, double* inout, int nv, hipStream_t s) {
     fs_runtime& rt = fs_rt();
     fs_p2p_reduce& R = g_p2p_red;
-    const unsigned long long seq = ++R.seq;
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(FS_SUM_BLOCK), 0, s, rt.n_ranks, rt.rank, nv, partials, npart,
-                       (double* const*)R.peer_buf.p, (unsigned long long* const*)R.peer_flags.p, R.buf, R.flags, (int)(seq & 1ull), seq,
+                       (double* const*)R.peer_buf.p, (unsigned long long* const*)R.peer_flags.p, R.buf, R.flags, R.d_seq.p,
                        inout, g_p2p_timeout_ticks, g_p2p_err);
     FS_KERNEL_CHECK();
     return FS_OK;
@@ -587,8 +607,9 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
     FS_CHECK(pp.done.zero(s));
     FS_CHECK(pp.counter.alloc(2));
     FS_CHECK(pp.counter.zero(s));
+    FS_CHECK(pp.d_seq.alloc(1));
+    FS_CHECK(pp.d_seq.zero(s));
     FS_HIP(hipStreamSynchronize(s));
-    pp.seq = 0;
     pp.pending = nullptr;
     pp.enabled = true;
     ++g_p2p_spaces;
@@ -601,26 +622,23 @@ static int p2p_exchange_begin(fs_space_s* space, double* d_vec, hipStream_t s) {
     fs_p2p_halo& pp = h.p2p;
     FS_REQUIRE(!pp.pending, "peer-to-peer halo: an exchange was begun and never received");
     const int nn = (int)h.neighbors.size();
-    const unsigned long long seq = ++pp.seq;
-    hipLaunchKernelGGL(k_p2p_send, dim3(nn * pp.send_groups), dim3(FS_BLOCK), 0, s, pp.peers.p, pp.send_groups, pp.done.p, d_vec,
-                       h.send_idx.p, (int)(seq & 1ull), seq);
+    hipLaunchKernelGGL(k_p2p_send, dim3(nn * pp.send_groups), dim3(FS_BLOCK), 0, s, pp.peers.p, pp.send_groups, pp.done.p, pp.counter.p,
+                       pp.d_seq.p, d_vec, h.send_idx.p);
     FS_KERNEL_CHECK();
     pp.pending = d_vec;
     return FS_OK;
 }
 
-static int p2p_exchange_end(fs_space_s* space, hipStream_t s, const int* gate = nullptr) {
+static int p2p_exchange_end(fs_space_s* space, hipStream_t s) {
     fs_halo_plan& h = space->halo;
     fs_p2p_halo& pp = h.p2p;
     FS_REQUIRE(pp.pending, "peer-to-peer halo: receive without a send");
     const int nn = (int)h.neighbors.size();
-    const unsigned long long seq = pp.seq;
-    const int slot = (int)(seq & 1ull);
     static const unsigned long long never = p2p_test_mode() == 2 ? 1000000000ull : 0ull;
     const int grid = (int)std::min<int64_t>(16, std::max<int64_t>(1, (h.total_recv + FS_BLOCK * 8 - 1) / (FS_BLOCK * 8)));
-    hipLaunchKernelGGL(k_p2p_recv, dim3(grid), dim3(FS_BLOCK), 0, s, nn, pp.flags + (int64_t)slot * nn, seq + never,
-                       pp.recv + (int64_t)slot * std::max<int64_t>(h.total_recv, 1), h.total_recv, h.recv_idx.p, pp.pending,
-                       space->n_dofs_owned, g_p2p_timeout_ticks, g_p2p_err, gate);
+    hipLaunchKernelGGL(k_p2p_recv, dim3(grid), dim3(FS_BLOCK), 0, s, nn, pp.flags, pp.d_seq.p, never, pp.recv,
+                       std::max<int64_t>(h.total_recv, 1), h.total_recv, h.recv_idx.p, pp.pending, space->n_dofs_owned,
+                       g_p2p_timeout_ticks, g_p2p_err);
     FS_KERNEL_CHECK();
     pp.pending = nullptr;
     return FS_OK;
@@ -631,47 +649,36 @@ bool fs_p2p_fusable(const fs_space_s* space) {
     return h.active && h.p2p.enabled && g_p2p_red.enabled && fs_rt().comm != nullptr;
 }
 
-int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out) {
+int fs_p2p_exchange_args(fs_space_s* space, const double* partials, int npart, double* sums_out, fs_p2p_rowsred* red, fs_p2p_sendrows* out) {
+    fs_runtime& rt = fs_rt();
     fs_halo_plan& h = space->halo;
     fs_p2p_halo& pp = h.p2p;
+    fs_p2p_reduce& R = g_p2p_red;
     FS_REQUIRE(!pp.pending, "peer-to-peer halo: an exchange was begun and never received");
-    (void)d_vec;
-    const unsigned long long seq = ++pp.seq;
-    const int nn = (int)h.neighbors.size(), slot = (int)(seq & 1ull);
     out->peers = pp.peers.p;
     out->send_idx = h.send_idx.p;
     out->total_send = h.total_send;
-    out->counter = pp.counter.p;
-    out->seq = seq;
-    out->nn = nn;
-    out->slot = slot;
-    out->own_flags = pp.flags + (int64_t)slot * nn;
-    out->own_recv = pp.recv + (int64_t)slot * std::max<int64_t>(h.total_recv, 1);
+    out->counter = pp.counter.p + 1;
+    out->d_seq = pp.d_seq.p;
+    out->nn = (int)h.neighbors.size();
+    out->own_flags = pp.flags;
+    out->own_recv = pp.recv;
+    out->recv_stride = std::max<int64_t>(h.total_recv, 1);
     out->recv_idx = h.recv_idx.p;
     out->total_recv = h.total_recv;
     out->n_owned = space->n_dofs_owned;
     out->timeout = g_p2p_timeout_ticks;
     out->err = g_p2p_err;
-    return FS_OK;
-}
-
-int fs_p2p_recv_gated(fs_space_s* space, const int* status, hipStream_t s) { return p2p_exchange_end(space, s, status); }
-
-void fs_p2p_drop_pending(fs_space_s* space) { space->halo.p2p.pending = nullptr; }
-
-int fs_p2p_next_reduce(const double* partials, int npart, double* sums_out, fs_p2p_rowsred* out) {
-    fs_runtime& rt = fs_rt();
-    fs_p2p_reduce& R = g_p2p_red;
-    const unsigned long long seq = ++R.seq;
-    out->partials = partials; out->npart = npart; out->sums_out = sums_out;
-    out->peer_buf = (double* const*)R.peer_buf.p;
-    out->peer_flags = (unsigned long long* const*)R.peer_flags.p;
-    out->own_buf = R.buf;
-    out->own_flags = R.flags;
-    out->seq = seq;
-    out->timeout = g_p2p_timeout_ticks;
-    out->err = g_p2p_err;
-    out->nr = rt.n_ranks; out->me = rt.rank; out->slot = (int)(seq & 1ull); out->on = 1;
+    red->partials = partials; red->npart = npart; red->sums_out = sums_out;
+    red->peer_buf = (double* const*)R.peer_buf.p;
+    red->peer_flags = (unsigned long long* const*)R.peer_flags.p;
+    red->own_buf = R.buf;
+    red->own_flags = R.flags;
+    red->d_seq = R.d_seq.p;
+    red->counter = R.counter.p;
+    red->timeout = g_p2p_timeout_ticks;
+    red->err = g_p2p_err;
+    red->nr = rt.n_ranks; red->me = rt.rank;
     return FS_OK;
 }
 

@@ -157,9 +157,9 @@ struct fs_p2p_halo {
     dbuf<fs_p2p_peer> peers;
     dbuf<uint32_t> done;            // per neighbour: workgroups of the running send that have stored their share
     int send_groups = 1;            // workgroups per neighbour
-    double* pending = nullptr;      // vector of the exchange begun and not yet received
-    dbuf<uint32_t> counter;         // [2]: last-workgroup counters of the fused kernels (rows update + send, product + post)
-    unsigned long long seq = 0;
+    double* pending = nullptr;      // vector of the exchange begun (plain send kernel) and not yet received
+    dbuf<uint32_t> counter;         // [2]: workgroups through - of the plain send kernel, of the exchange kernel's send part
+    dbuf<unsigned long long> d_seq; // device-side sequence number of the last executed exchange (fs_comm.hip)
     void release();
     ~fs_p2p_halo() { release(); }
 };
@@ -297,10 +297,8 @@ int fs_p2p_reduce_enabled();
 // fused peer-to-peer CG iteration (fs_krylov.hip): the structures the kernels take, with the sequence numbers advanced
 struct fs_p2p_sendrows; struct fs_p2p_rowsred;
 bool fs_p2p_fusable(const fs_space_s* space);                                   // peer-to-peer halo and all-reduce on
-int fs_p2p_begin_sendrows(fs_space_s* space, double* d_vec, fs_p2p_sendrows* out);    // the exchange the exchange kernel will issue and receive
-int fs_p2p_recv_gated(fs_space_s* space, const int* status, hipStream_t s);      // receive of the pending exchange unless status[0] != 0
-void fs_p2p_drop_pending(fs_space_s* space);                                    // a status-gated exchange that was never issued
-int fs_p2p_next_reduce(const double* partials, int npart, double* sums_out, fs_p2p_rowsred* out);
+// arguments of k_cg_p2p_exchange for this space (nothing is advanced on the host: the sequence numbers live on the device)
+int fs_p2p_exchange_args(fs_space_s* space, const double* partials, int npart, double* sums_out, fs_p2p_rowsred* red, fs_p2p_sendrows* snd);
 int fs_p2p_check(hipStream_t s);
 void fs_p2p_reduce_teardown();
 void fs_comm_host_time(double* allreduce_us, long* allreduce_calls, double* halo_us, long* halo_calls, bool reset);

@@ -63,28 +63,30 @@ struct fs_p2p_sendrows {
     const int32_t* send_idx;        // concatenated send lists (owned dofs)
     int64_t total_send;
     uint32_t* counter;              // workgroups of this launch whose stores are out (the last one publishes the sequence numbers)
-    unsigned long long seq;
-    int nn, slot;
-    // the receive of the same exchange: this rank's flags and buffer slot, the scatter list (nullptr: ghosts in arrival order)
+    unsigned long long* d_seq;      // sequence number of the last executed exchange of this plan
+    int nn;
+    // the receive of the same exchange: this rank's flags [2][nn] and buffer [2][recv_stride], the scatter list (nullptr: ghosts in
+    // arrival order)
     const unsigned long long* own_flags;
     const double* own_recv;
     const int32_t* recv_idx;
-    int64_t total_recv, n_owned;
+    int64_t recv_stride, total_recv, n_owned;
     long long timeout;
     int* err;
 };
 // all-reduce part of the same kernel
 struct fs_p2p_rowsred {
     const double* partials;         // [3][npart] of the product
-    double* sums_out;               // [3]: the reduced sums for the kernels that follow
+    double* sums_out;               // [3]: the reduced sums for the update kernel that follows
     double* const* peer_buf;
     unsigned long long* const* peer_flags;
     const double* own_buf;
     const unsigned long long* own_flags;
-    unsigned long long seq;
+    unsigned long long* d_seq;      // sequence number of the last executed all-reduce
+    uint32_t* counter;              // workgroups through their all-reduce part (the last one advances d_seq)
     long long timeout;
     int* err;
-    int npart, nr, me, slot, on;
+    int npart, nr, me;
 };
 
 // wave64 shuffle reduction -> one LDS slot per wave -> thread 0 holds the block sum.

@@ -809,6 +809,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
         iter = status[2] - 1;
         check_only = iter >= (int)ctrl[2] ? 1 : 0;
     }
+    // sequence numbers of THIS exchange: one past the last executed ones (fs_comm.hip); read by every workgroup at its start,
+    // advanced by the last workgroup through each part
+    const unsigned long long rseq = *red.d_seq + 1ull, hseq = *snd.d_seq + 1ull;
+    const int rslot = (int)(rseq & 1ull), hslot = (int)(hseq & 1ull);
     // the operands of this thread's first entry are requested before the sums are reduced and exchanged: their latency hides there
     const int64_t e_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -822,20 +826,24 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     wg_sum_partials<3>(red.partials, red.npart, sm);
     const int t = threadIdx.x;
     if (blockIdx.x == 0 && t < red.nr && t != red.me) {
-        double* dst = red.peer_buf[t] + ((int64_t)red.slot * red.nr + red.me) * 8;
+        double* dst = red.peer_buf[t] + ((int64_t)rslot * red.nr + red.me) * 8;
         fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
         fs_p2p_stores_done();
-        fs_p2p_publish(red.peer_flags[t] + (int64_t)red.slot * red.nr + red.me, red.seq);
+        fs_p2p_publish(red.peer_flags[t] + (int64_t)rslot * red.nr + red.me, rseq);
     }
-    if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)red.slot * red.nr + t, red.seq, red.timeout, red.err);
+    if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)rslot * red.nr + t, rseq, red.timeout, red.err);
     __syncthreads();
     __shared__ double tot[3];
     if (t < 3) {
         double a = 0.0;
         for (int q = 0; q < red.nr; ++q)
-            a += q == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)red.slot * red.nr + q) * 8 + t);
+            a += q == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)rslot * red.nr + q) * 8 + t);
         tot[t] = a;
         if (blockIdx.x == 0) red.sums_out[t] = a;
+    }
+    if (t == 0 && atomicAdd(red.counter, 1u) == gridDim.x - 1) {          // every workgroup has read d_seq and the other ranks' sums
+        __hip_atomic_store(red.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(red.d_seq, rseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const double gamma = tot[0], delta = tot[1], rho = tot[2];
@@ -860,21 +868,23 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
         int j = 0;
         while (j + 1 < snd.nn && e >= snd.peers[j + 1].send_offset) ++j;
         const fs_p2p_peer q = snd.peers[j];
-        fs_p2p_store(q.recv + (int64_t)snd.slot * q.peer_total + q.recv_offset + (e - q.send_offset), rn);
+        fs_p2p_store(q.recv + (int64_t)hslot * q.peer_total + q.recv_offset + (e - q.send_offset), rn);
     }
     fs_p2p_stores_done();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
         __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(snd.d_seq, hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int j = 0; j < snd.nn; ++j) {
             const fs_p2p_peer q = snd.peers[j];
-            fs_p2p_publish(q.flags + (int64_t)snd.slot * q.peer_nn + q.peer_slot, snd.seq);
+            fs_p2p_publish(q.flags + (int64_t)hslot * q.peer_nn + q.peer_slot, hseq);
         }
     }
-    if (t < snd.nn) fs_p2p_wait(snd.own_flags + t, snd.seq, snd.timeout, snd.err);
+    if (t < snd.nn) fs_p2p_wait(snd.own_flags + (int64_t)hslot * snd.nn + t, hseq, snd.timeout, snd.err);
     __syncthreads();
+    const double* own_recv = snd.own_recv + (int64_t)hslot * snd.recv_stride;
     for (int64_t k = e_first; k < snd.total_recv; k += stride)
-        r[snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k] = fs_p2p_load(snd.own_recv + k);
+        r[snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k] = fs_p2p_load(own_recv + k);
 }
 
 // ---- pipelined CG (Ghysels & Vanroose, Parallel Computing 40 (2014)) on the scaled system --------------------------
@@ -1997,8 +2007,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
                     if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
                     const int fgrid = spmv_partials_unsplit(sp, bs);
-                    FS_CHECK(fs_p2p_next_reduce(ws.partials.p, fgrid, ws.sums.p, &red));
-                    FS_CHECK(fs_p2p_begin_sendrows(sp, ws.z.p, &snd));
+                    FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                     const int64_t work = std::max(snd.total_send, snd.total_recv);
                     hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
                                        k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.s.p, red, snd);
