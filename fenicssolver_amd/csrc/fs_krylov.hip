@@ -1570,7 +1570,7 @@ struct krylov_ws {
     // one batch of CG iterations captured as a hipGraph (same arguments every iteration: the update kernel reads its
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
     hipGraphExec_t cg_graph = nullptr;
-    const void* cg_key[12] = {};
+    const void* cg_key[16] = {};
     int64_t cg_key_i[8] = {};
 };
 static krylov_ws g_ws;
@@ -1877,8 +1877,11 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             p2p_rows_cap = rows_env > 0 ? rows_env : 128;
             if (hp.fuse == 1 && !pipelined && fuse_env) p2p_fuse = 1;
         }
-        const bool use_graph = ds && fuse_sums && !bicg && !pipelined && !sp->halo.active && bs == 1 &&
-                               (graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768));
+        // (the peer-to-peer iteration is three kernels and no library call, with its sequence numbers on the device: it is captured the
+        // same way; the RCCL iteration is not - ncclSend / ncclRecv / ncclAllReduce are host calls)
+        const bool graph_sized = graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768);
+        const bool use_graph = ds && !bicg && !pipelined && graph_sized &&
+                               ((fuse_sums && !sp->halo.active && bs == 1) || p2p_fuse);
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
             if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
@@ -1886,9 +1889,14 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
                 // and pool addresses are handed out again (another mesh with the same row count would otherwise replay
                 // this graph over column arrays that no longer exist)
-                const void* key[12] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
-                                       ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p};
-                const int64_t key_i[8] = {n, 0, batch, sgrid, vgrid, (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, 1),
+                fs_p2p_rowsred red = {};
+                fs_p2p_sendrows snd = {};
+                const int fgrid = p2p_fuse ? spmv_partials_unsplit(sp, bs) : sgrid;
+                if (p2p_fuse) FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
+                const void* key[16] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
+                                       ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf};
+                const int64_t key_i[8] = {n, p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0, batch, fgrid, vgrid,
+                                          (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs),
                                           (int64_t)A->serial, (int64_t)sp->serial};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
                     if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
@@ -1896,8 +1904,17 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     FS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                     int rc_cap = FS_OK;
                     for (int i = 0; i < batch && rc_cap == FS_OK; ++i) {
-                        rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
                         // iteration index (status[2]) and iteration limit (ctrl[2]) from the device: iter = -1
+                        if (p2p_fuse) {
+                            launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
+                            const int64_t work = std::max(snd.total_send, snd.total_recv);
+                            hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
+                                               -1, 0, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.s.p, red, snd);
+                            if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                            else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                            continue;
+                        }
+                        rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
                         if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                         else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     }

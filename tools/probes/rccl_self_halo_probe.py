@@ -40,7 +40,6 @@ if what in ("all", "one"):
     V, A, b = problem(False)
     print("rows", V.n_owned)
     run("no communicator (hipGraph batches)", V, A, b)
-os.environ["FS_CG_GRAPH"] = "0"
 uid = B.comm_unique_id()
 B.comm_init(1, 0, uid)
 V2, A2, b2 = problem(True)
