@@ -397,10 +397,13 @@ static int p2p_agree(bool ok, const char* what, const char* why = "") {
 }
 
 // FS_P2P_TEST (tests only): "openfail" - rank 0 pretends hipIpcOpenMemHandle failed; "lost" - receives wait for a sequence
-// number that never comes.  Both failure paths must end in an error every rank agrees on, never in a hang.
+// number that never comes; "late:K" - the same from the K-th receive on (a transport that breaks after it was chosen).  All
+// failure paths must end in an error every rank agrees on, never in a hang.
+static int g_p2p_test_late = -1;
 static int p2p_test_mode() {
     const char* e = getenv("FS_P2P_TEST");
     if (!e) return 0;
+    if (!strncmp(e, "late:", 5)) { g_p2p_test_late = atoi(e + 5); return 3; }
     return !strcmp(e, "openfail") ? 1 : (!strcmp(e, "lost") ? 2 : 0);
 }
 
@@ -634,7 +637,10 @@ static int p2p_exchange_end(fs_space_s* space, hipStream_t s) {
     fs_p2p_halo& pp = h.p2p;
     FS_REQUIRE(pp.pending, "peer-to-peer halo: receive without a send");
     const int nn = (int)h.neighbors.size();
-    static const unsigned long long never = p2p_test_mode() == 2 ? 1000000000ull : 0ull;
+    static const int test_mode = p2p_test_mode();
+    static int n_receives = 0;
+    ++n_receives;
+    const unsigned long long never = test_mode == 2 || (test_mode == 3 && n_receives > g_p2p_test_late) ? 1000000000ull : 0ull;
     const int grid = (int)std::min<int64_t>(16, std::max<int64_t>(1, (h.total_recv + FS_BLOCK * 8 - 1) / (FS_BLOCK * 8)));
     hipLaunchKernelGGL(k_p2p_recv, dim3(grid), dim3(FS_BLOCK), 0, s, nn, pp.flags, pp.d_seq.p, never, pp.recv,
                        std::max<int64_t>(h.total_recv, 1), h.total_recv, h.recv_idx.p, pp.pending, space->n_dofs_owned,
