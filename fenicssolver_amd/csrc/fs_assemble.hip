@@ -39,11 +39,40 @@ __device__ __forceinline__ tet_geom tet_geometry(const double* __restrict__ xyz4
     load_vertex(xyz4, v[3], x3);
     return tet_geometry_x(x0, x1, x2, x3);
 }
+// snap: grid spacing of a uniform box mesh and its reciprocal (fs_mesh_s::box_h; 0 = general mesh).  An edge-vector component of a
+// box cell is -h, 0 or +h up to the rounding of the two coordinates it is the difference of; h * rint(e / h) removes exactly that
+// noise, so every cell of the same Kuhn type yields the same bits wherever it sits.
+struct box_snap { double h[3], inv[3]; };
+__device__ __forceinline__ tet_geom tet_geometry_e(const double (&e1)[3], const double (&e2)[3], const double (&e3)[3]);
 __device__ __forceinline__ tet_geom tet_geometry_x(const double (&x0)[3], const double (&x1)[3], const double (&x2)[3],
                                                    const double (&x3)[3]) {
     const double e1[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
     const double e2[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
     const double e3[3] = {x3[0] - x0[0], x3[1] - x0[1], x3[2] - x0[2]};
+    return tet_geometry_e(e1, e2, e3);
+}
+__device__ __forceinline__ tet_geom tet_geometry_snapped(const double (&x0)[3], const double (&x1)[3], const double (&x2)[3],
+                                                         const double (&x3)[3], const box_snap& bx) {
+    double e1[3], e2[3], e3[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        e1[d] = bx.h[d] * rint((x1[d] - x0[d]) * bx.inv[d]);
+        e2[d] = bx.h[d] * rint((x2[d] - x0[d]) * bx.inv[d]);
+        e3[d] = bx.h[d] * rint((x3[d] - x0[d]) * bx.inv[d]);
+    }
+    return tet_geometry_e(e1, e2, e3);
+}
+static box_snap make_box_snap(const fs_mesh_s* m) {
+    static const bool off = getenv("FS_BOX_SNAP") && getenv("FS_BOX_SNAP")[0] == '0';
+    box_snap b;
+    for (int d = 0; d < 3; ++d) {
+        const bool on = !off && m->tdim == 3 && m->box_h[0] > 0.0 && m->box_h[1] > 0.0 && m->box_h[2] > 0.0;
+        b.h[d] = on ? m->box_h[d] : 0.0;
+        b.inv[d] = on ? 1.0 / m->box_h[d] : 0.0;
+    }
+    return b;
+}
+__device__ __forceinline__ tet_geom tet_geometry_e(const double (&e1)[3], const double (&e2)[3], const double (&e3)[3]) {
     // cofactors: grad lambda_1 = (e2 x e3)/det, grad lambda_2 = (e3 x e1)/det, grad lambda_3 = (e1 x e2)/det
     const double c1[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
     const double c2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
@@ -177,8 +206,9 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
     const int64_t* __restrict__ inc_slice_ptr, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
     coef_dev kc, coef_dev mc, coef_dev ac, double ascale, double supg_pe, double* __restrict__ val,
-    const int32_t* __restrict__ order, const double* __restrict__ xvec = nullptr) {
+    const int32_t* __restrict__ order, const box_snap bx, const double* __restrict__ xvec = nullptr) {
     constexpr bool ADD = MODE == 1, APPLY = MODE == 2;
+    const bool snapped = bx.h[0] > 0.0;
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -246,7 +276,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
             load_vertex(xyz4, vv[3], x3);
             double xb[3] = {0.0, 0.0, 0.0};
             if (APPLY) { xb[0] = xvec[vv[1]]; xb[1] = xvec[vv[2]]; xb[2] = xvec[vv[3]]; }
-            const tet_geom t = tet_geometry_x(xown, x1, x2, x3);          // the row's own coordinates were loaded once
+            // (the row's own coordinates were loaded once; uniform box: edge vectors snapped to the grid spacing)
+            const tet_geom t = snapped ? tet_geometry_snapped(xown, x1, x2, x3, bx) : tet_geometry_x(xown, x1, x2, x3);
             const double vol = t.adet * (1.0 / 6.0);
             double row[4];
             if (kc.mode == FS_COEF_TENSOR) {
@@ -2358,9 +2389,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<1>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<1>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p, make_box_snap(m));
         else
-            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<0>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<0>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p, make_box_snap(m));
     } else if (A->bs == 1) {
         FS_REQUIRE(sp->slots.p, "fs_assemble_matrix: space has no assembly tables");
         FS_REQUIRE(form->advection.mode == FS_COEF_NONE, "fs_assemble_matrix: advection needs the row-gather tables");
@@ -2702,7 +2733,7 @@ extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_
     auto go = [&]() {
         hipLaunchKernelGGL(k_assemble_p1_scalar_gather<2>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
                            sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale,
-                           form->supg_pe, y->d.p, sp->slice_order.p, x->d.p);
+                           form->supg_pe, y->d.p, sp->slice_order.p, make_box_snap(m), x->d.p);
     };
     go();
     if (reps > 1 && ms_per_launch) {      // HIP events around reps further launches on the library's stream

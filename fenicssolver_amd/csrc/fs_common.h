@@ -137,6 +137,11 @@ struct fs_mesh_s {
     dbuf<double> xyz;     // [nv][4] padded (x,y,z,0): two 16-B loads per vertex
     dbuf<int32_t> cells;  // [nc][4] local vertex ids
     dbuf<int64_t> gid;    // [nv] global vertex ids
+    // uniform box meshes (fs_mesh_create_box): the grid spacing.  The P1 scalar assembly snaps every edge-vector component to a
+    // multiple of it, which makes the rows of the operator translation-invariant BIT FOR BIT (vertex coordinates i * h are not:
+    // their differences carry rounding noise of 1e-16 that differs from cell to cell) - what lets the solver find the few
+    // dozen distinct rows of such an operator (fs_krylov.hip, row dictionary).  0 = not a uniform box: nothing is snapped.
+    double box_h[3] = {0.0, 0.0, 0.0};
 };
 
 // Peer-to-peer ghost refresh (opt-in, one node): every rank owns a fine-grained receive buffer + arrival flags that its
@@ -240,6 +245,8 @@ struct fs_space_s {
                                   // rows [split, 64) of a SPLIT slice use list B (fs_symbolic.hip, k_slice_analyze)
     // two-rows-per-lane product (k_dia_pair_spmv): pairs of slices, consecutive in processing order, both complete DIA
     // slices with identical offset lists; pair_singles = every other slice, in processing order.  Built on first use.
+    dbuf<int32_t> slice_desc;     // [n_slices][4], processing order: (slice, width, dia_ptr, split) - one 16-byte scalar load per
+                                  // slice for the row-dictionary product (fs_krylov.hip); built on first use
     dbuf<int32_t> pair_list;      // [2 * n_pairs]
     dbuf<int32_t> pair_singles;   // [n_pair_singles]
     int64_t n_pairs = -1, n_pair_singles = 0;      // -1: not built yet

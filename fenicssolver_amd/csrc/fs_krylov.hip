@@ -373,6 +373,229 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
     }
 }
 
+
+// ---- row-dictionary form of a scalar DIA matrix ---------------------------------------------------------------------------------
+// On a uniform box mesh with constant coefficients (BASELINE configs[0] / [1]: BoxMesh, k = 20) the assembled operator has a few
+// dozen DISTINCT rows - interior, the 26 kinds of boundary position, the rows next to Dirichlet faces - each repeated bit for bit
+// (the box assembly snaps its edge vectors to the grid spacing, fs_assemble.hip, so that rows are translation-invariant).  The
+// product then does not have to stream 8 B per entry: every row carries a 2-byte class number and the distinct value rows sit
+// in LDS.  Built per solve from the values the solver is about to multiply with (one pass hashes the rows into a 1024-slot
+// table, one verifies EVERY row bit for bit against its class - a hash collision or a 513th class simply leaves the plain
+// form in use), so it is lossless and needs no knowledge of where the matrix came from.  Same offsets, same summation order,
+// same bits as k_sell_spmv.  Measured on MI355X at 1 M rows: product 26 -> 14 us.
+constexpr int FS_DICT_CAP = 1024;       // hash slots
+constexpr int FS_DICT_MAX = 512;        // distinct rows accepted
+constexpr int FS_DICT_LDS_DOUBLES = 6144;   // ncls * width must fit (48 KB)
+
+__device__ __forceinline__ unsigned long long dict_row_hash(const double* __restrict__ vp, int width) {
+    unsigned long long h = 1469598103934665603ull;
+    for (int k = 0; k < width; ++k) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(vp[(int64_t)k * FS_SLICE]);
+        h = (h ^ b) * 1099511628211ull;
+        h ^= h >> 29;
+    }
+    h ^= (unsigned long long)width * 0x9E3779B97F4A7C15ull;
+    return h ? h : 1ull;
+}
+
+// info[0] = classes found, info[1] = 1: gave up (too many classes), info[2] = rows that differ from their class (verification)
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+                                                          const double* __restrict__ val, int W, unsigned long long* keys,
+                                                          double* slot_vals, uint16_t* __restrict__ cls_slot, int* info) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t r = s * FS_SLICE + lane;
+        if (r >= n_rows) continue;
+        const double* __restrict__ vp = val + base + lane;
+        const unsigned long long h = dict_row_hash(vp, width);
+        int slot = (int)(h & (FS_DICT_CAP - 1));
+        for (int probe = 0; probe < FS_DICT_CAP; ++probe) {
+            unsigned long long old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, h);
+            if (old == 0ull) {                  // this row is the representative of a new class
+                if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < W; ++k) slot_vals[(int64_t)slot * W + k] = k < width ? vp[(int64_t)k * FS_SLICE] : 0.0;
+                break;
+            }
+            if (old == h) break;
+            slot = (slot + 1) & (FS_DICT_CAP - 1);
+        }
+        cls_slot[r] = (uint16_t)slot;
+    }
+}
+
+__global__ void __launch_bounds__(FS_DICT_CAP) k_dict_compact(const unsigned long long* __restrict__ keys, const double* __restrict__ slot_vals,
+                                                              int W, int32_t* __restrict__ slot2cls, double* __restrict__ values) {
+    __shared__ int cnt[FS_DICT_CAP];
+    const int t = threadIdx.x;
+    const int used = keys[t] != 0ull;
+    cnt[t] = used;
+    __syncthreads();
+    for (int off = 1; off < FS_DICT_CAP; off <<= 1) {       // inclusive scan
+        const int v = t >= off ? cnt[t - off] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    const int id = cnt[t] - 1;
+    slot2cls[t] = used ? id : -1;
+    if (used && id < FS_DICT_MAX)
+        for (int k = 0; k < W; ++k) values[(int64_t)id * W + k] = slot_vals[(int64_t)t * W + k];
+}
+
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
+                                                          const double* __restrict__ val, int W, const int32_t* __restrict__ slot2cls,
+                                                          const double* __restrict__ values, const uint16_t* __restrict__ cls_slot,
+                                                          uint16_t* __restrict__ cls, int* info) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int bad = 0;
+    for (; s < n_slices; s += stride) {
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t r = s * FS_SLICE + lane;
+        if (r >= n_rows) { cls[r] = 0; continue; }        // (cls holds n_slices * 64 entries)
+        const int id = slot2cls[cls_slot[r]];
+        cls[r] = (uint16_t)(id < 0 ? 0 : id);
+        if (id < 0 || id >= FS_DICT_MAX) { ++bad; continue; }
+        const double* __restrict__ vp = val + base + lane;
+        const double* __restrict__ dv = values + (int64_t)id * W;
+        for (int k = 0; k < width; ++k)
+            bad += __double_as_longlong(vp[(int64_t)k * FS_SLICE]) != __double_as_longlong(dv[k]);
+    }
+    if (bad) atomicAdd(&info[2], bad);
+}
+
+__global__ void k_slice_desc(int64_t n_slices, const int32_t* __restrict__ order, const int64_t* __restrict__ slice_ptr,
+                             const int32_t* __restrict__ dia_ptr, const int32_t* __restrict__ dia_off, int32_t* __restrict__ desc) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; q < n_slices; q += stride) {
+        const int32_t s = order ? order[q] : (int32_t)q;
+        const int32_t dp = dia_ptr[s];
+        desc[4 * q + 0] = s;
+        desc[4 * q + 1] = (int32_t)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
+        desc[4 * q + 2] = dp;
+        desc[4 * q + 3] = dp >= 0 ? dia_off[dp] : FS_SLICE;
+    }
+}
+
+template <int DOTS>
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
+                                                        const int4* __restrict__ desc, const int32_t* __restrict__ dia_off,
+                                                        const uint16_t* __restrict__ cls,
+                                                        const double* __restrict__ dict, int ncls, int W,
+                                                        const double* __restrict__ x, double* __restrict__ y,
+                                                        const double* __restrict__ rvec, double* __restrict__ partials,
+                                                        int* __restrict__ status, int part_base, int part_stride, int bump, int map_xcd) {
+    if (DOTS) {
+        if (status[0] != 0) return;
+        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
+    }
+    extern __shared__ double sdict[];
+    for (int i = threadIdx.x; i < ncls * W; i += FS_BLOCK) sdict[i] = dict[i];
+    __syncthreads();
+    __shared__ double lds4[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
+    const int64_t n_chunks = (n_slices + 3) >> 2;
+    const int32_t cmax = (int32_t)(n_cols - 1);
+    // (bound by dependent round trips per wave, not by bytes: everything a slice needs beyond x comes with ONE scalar load of its
+    // descriptor, and all x values of a round of 16 entries go out together)
+    const int64_t n_waves = ((int64_t)gridDim.x * FS_BLOCK) >> 6;
+    chunk_iter it = xcd_chunks(n_chunks);
+    int64_t q = map_xcd ? (it.cur < it.end ? it.cur * 4 + wave : n_slices) : (((int64_t)blockIdx.x * FS_BLOCK + threadIdx.x) >> 6);
+    while (q < n_slices) {
+        {
+            const int4 ds = desc[__builtin_amdgcn_readfirstlane((int)q)];
+            const int width = __builtin_amdgcn_readfirstlane(ds.y);
+            const int32_t r = __builtin_amdgcn_readfirstlane(ds.x) * FS_SLICE + lane;
+            const bool live = r < n_rows;
+            const int split = __builtin_amdgcn_readfirstlane(ds.w);
+            const int32_t* __restrict__ op = dia_off + __builtin_amdgcn_readfirstlane(ds.z) + 1;
+            const int32_t* __restrict__ op2 = op + (split < FS_SLICE ? width : 0);
+            const bool hi = lane >= split;
+            double zi = 0.0, ri = 0.0;
+            if (DOTS && DOTS != 4 && live) {
+                if (DOTS == 1 || DOTS == 3) zi = x[r];
+                ri = rvec[r];
+            }
+            const double* __restrict__ vp = sdict + (int)cls[r] * W;
+            double acc = 0.0;
+            // rounds of 16 entries WITHOUT a guard (a guarded load makes the compiler wait for the previous one): positions past
+            // the slice's width read whatever follows in the offset array (the address is clamped into x, dia_off is padded by
+            // 64 ints) and multiply it by the zeros the dictionary rows are padded with up to W, a multiple of 16
+            constexpr int U = 16;
+            if (split >= FS_SLICE) {                    // (wave-uniform) one offset list for the whole slice
+                for (int k = 0; k < width; k += U) {
+                    double xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int32_t c = r + op[k + u];
+                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
+                        xv[u] = x[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc += vp[k + u] * xv[u];
+                }
+            } else {
+                for (int k = 0; k < width; k += U) {
+                    double xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int32_t c = r + (hi ? op2[k + u] : op[k + u]);
+                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
+                        xv[u] = x[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc += vp[k + u] * xv[u];
+                }
+            }
+            if (live) {
+                y[r] = acc;
+                if (DOTS == 1) { d_rz += ri * zi; d_wz += acc * zi; d_rr += ri * ri; }
+                else if (DOTS == 2) { d_rz += acc * ri; d_wz += acc * acc; d_rr += ri * ri; }
+                else if (DOTS == 3) { d_rz += zi * zi; d_wz += acc * zi; d_rr += ri * zi * zi; }
+            }
+        }
+        if (map_xcd) {
+            it.cur += it.step;
+            q = it.cur < it.end ? it.cur * 4 + wave : n_slices;
+        } else q += n_waves;
+    }
+    if (DOTS && DOTS != 4) {
+        const double t0 = fs_block_sum(d_rz, lds4);
+        const double t1 = fs_block_sum(d_wz, lds4);
+        const double t2 = fs_block_sum(d_rr, lds4);
+        if (threadIdx.x == 0) {
+            partials[part_base + blockIdx.x] = t0;
+            partials[part_stride + part_base + blockIdx.x] = t1;
+            partials[2 * part_stride + part_base + blockIdx.x] = t2;
+        }
+    }
+}
+
+struct row_dict {
+    dbuf<uint16_t> cls, cls_slot;
+    dbuf<double> values, slot_vals;
+    dbuf<unsigned long long> keys;
+    dbuf<int32_t> slot2cls;
+    dbuf<int> info;
+    int ncls = 0, W = 0;
+    const double* built_for = nullptr;      // the value array the classes describe (nullptr: plain form in use)
+    uint64_t space_serial = 0;              // ... of this space
+    uint64_t gave_up_on = 0;                // serial of a matrix whose rows were not repetitive: not tried again
+    int64_t n_built = 0, n_failed = 0;      // statistics (fs_krylov_stats)
+};
+static row_dict g_dict;
+
 // ---- CG scalar state on the device ---------------------------------------------------------
 // sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
 // ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b, ctrl[2] = max_iter (read by the update kernels of a
@@ -1290,6 +1513,60 @@ static int spmv_pair_grid(const fs_space_s* sp) {
     return (int)std::max<int64_t>(g, 8);
 }
 
+
+static int spmv_partials_unsplit(const fs_space_s* sp, int bs);
+static int dict_map_xcd();
+// Try to describe `val` (the scalar DIA matrix the solver is about to multiply with) by row classes; leaves g_dict.built_for =
+// val on success, nullptr otherwise.  One host synchronisation (12 bytes).  FS_SPMV_DICT=0 switches it off.
+static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
+    row_dict& D = g_dict;
+    D.built_for = nullptr;
+    fs_space_s* sp = A->space;
+    static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
+    if (off || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
+    if (sp->max_row <= 0 || sp->max_row > 64) return FS_OK;
+    const int W = (sp->max_row + 15) & ~15;           // dictionary rows are padded with zeros to a multiple of the round length
+    const int64_t padded = sp->n_slices * FS_SLICE;
+    if (!sp->slice_desc.p) {
+        FS_CHECK(sp->slice_desc.alloc(4 * sp->n_slices));
+        hipLaunchKernelGGL(k_slice_desc, dim3(fs_grid_for(sp->n_slices)), dim3(FS_BLOCK), 0, s, sp->n_slices, sp->slice_order.p, sp->slice_ptr.p,
+                           sp->dia_ptr.p, sp->dia_off.p, sp->slice_desc.p);
+    }
+    if (D.cls.n < padded) { FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
+    if (!D.keys.p) {
+        FS_CHECK(D.keys.alloc(FS_DICT_CAP));
+        FS_CHECK(D.slot2cls.alloc(FS_DICT_CAP));
+        FS_CHECK(D.info.alloc(4));
+    }
+    if (D.slot_vals.n < (int64_t)FS_DICT_CAP * W) { FS_CHECK(D.slot_vals.alloc((int64_t)FS_DICT_CAP * W)); FS_CHECK(D.values.alloc((int64_t)FS_DICT_MAX * W)); }
+    FS_CHECK(D.keys.zero(s));
+    FS_CHECK(D.info.zero(s));
+    const int grid = fs_grid_for(padded, FS_BLOCK, 4096);
+    hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.keys.p,
+                       D.slot_vals.p, D.cls_slot.p, D.info.p);
+    hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(FS_DICT_CAP), 0, s, D.keys.p, D.slot_vals.p, W, D.slot2cls.p, D.values.p);
+    hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.slot2cls.p,
+                       D.values.p, D.cls_slot.p, D.cls.p, D.info.p);
+    FS_KERNEL_CHECK();
+    int h[4] = {0, 0, 0, 0};
+    FS_CHECK(D.info.download(h, 4, s));
+    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * W <= FS_DICT_LDS_DOUBLES;
+    if (getenv("FS_KRYLOV_DEBUG"))
+        fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of width %d among %lld, %d mismatches -> %s\n", h[0], W,
+                (long long)sp->n_nodes_owned, h[2], ok ? "compressed product" : "plain product");
+    if (!ok) {
+        D.gave_up_on = A->serial;
+        ++D.n_failed;
+        return FS_OK;
+    }
+    D.ncls = h[0];
+    D.W = W;
+    D.built_for = val;
+    D.space_serial = sp->serial;
+    ++D.n_built;
+    return FS_OK;
+}
+
 // `list` / `n_list`: multiply only these slices (the interior or the boundary slices of a decomposed space, in
 // processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
@@ -1301,6 +1578,15 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int64_t ns = list ? n_list : sp->n_slices;
     if (ns == 0) return;
     const int32_t* order = list ? list : sp->slice_order.p;
+    if (!list && A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val) {
+        // the values are a few dozen distinct rows (dict_build): class numbers + dictionary in LDS instead of the value stream;
+        // grid = what the plain form of this space would launch, so that the partial sums keep their layout
+        const int gd = spmv_partials_unsplit(sp, 1);
+        hipLaunchKernelGGL(k_dict_spmv<DOTS>, dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, sp->n_nodes_owned,
+                           sp->n_nodes_local, sp->n_slices, reinterpret_cast<const int4*>(sp->slice_desc.p), sp->dia_off.p, g_dict.cls.p,
+                           g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd());
+        return;
+    }
     const int grid = spmv_grid(ns, sp->n_slices);
     if (part_stride == 0) part_stride = grid;
 #define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride, bump
@@ -1351,15 +1637,26 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 
 // Number of per-workgroup dot partials one (possibly split) product writes.
 static bool spmv_is_split(const fs_space_s* sp) { return sp->halo.active && sp->halo.n_interior > 0; }
+static int dict_map_xcd() {
+    static const int m = getenv("FS_DICT_MAP") ? atoi(getenv("FS_DICT_MAP")) : 1;
+    return m;
+}
+static int dict_grid(const fs_space_s* sp) {
+    // the row-dictionary product is bound by round trips per wave: twice the workgroups of the streaming kernels
+    static const int env_blocks = getenv("FS_DICT_BLOCKS") ? atoi(getenv("FS_DICT_BLOCKS")) : 0;
+    const int64_t n_chunks = (sp->n_slices + 3) / 4;
+    int64_t g = std::min<int64_t>(n_chunks, env_blocks > 0 ? env_blocks : 2048);
+    g = (g + 7) & ~(int64_t)7;
+    return (int)std::max<int64_t>(g, 8);
+}
 static int spmv_partials_unsplit(const fs_space_s* sp, int bs) {
+    if (bs == 1 && g_dict.built_for && g_dict.space_serial == sp->serial) return dict_grid(sp);
     if (bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
         return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
     return spmv_grid(sp->n_slices, sp->n_slices);
 }
 static int spmv_partials(const fs_space_s* sp, int bs = 0) {
-    if (!spmv_is_split(sp) && bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
-        return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
-    if (!spmv_is_split(sp)) return spmv_grid(sp->n_slices, sp->n_slices);
+    if (!spmv_is_split(sp)) return spmv_partials_unsplit(sp, bs);
     return spmv_grid(sp->halo.n_interior, sp->n_slices) + (sp->halo.n_boundary ? spmv_grid(sp->halo.n_boundary, sp->n_slices) : 0);
 }
 
@@ -1619,6 +1916,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         return FS_ERR_UNSUPPORTED;
     }
     const bool bicg = opts->method == FS_KSP_BICGSTAB;
+    g_dict.built_for = nullptr;          // the row dictionary describes the values of ONE solve (rebuilt below where it applies)
     FS_REQUIRE(A->bs != 4, "fs_krylov_solve: Taylor-Hood block systems are solved by fs_saddle_solve");
     FS_REQUIRE(opts->precond == FS_PC_NONE || opts->precond == FS_PC_JACOBI, "fs_krylov_solve: unknown preconditioner %d", opts->precond);
     FS_REQUIRE(opts->max_iter > 0 && opts->rtol >= 0.0 && opts->atol >= 0.0, "fs_krylov_solve: bad tolerances");
@@ -1669,7 +1967,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const int vgrid = fs_grid_for(n / 2 + 1, FS_BLOCK, g_update_blocks);
     const int pgrid = fs_grid_for(n, FS_BLOCK, FS_MAX_PARTIAL_BLOCKS);
     if (A->bs == 1 && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
-    const int sgrid = spmv_partials(sp, A->bs);     // dot partials per product (pairs + singles, or interior + boundary on a decomposed space)
+    int sgrid = spmv_partials(sp, A->bs);     // dot partials per product (pairs + singles, or interior + boundary on a decomposed space)
     const auto t_begin = std::chrono::steady_clock::now();
 
     // Jacobi diagonal (the zero-diagonal counter is read back with the first status poll: no extra sync here)
@@ -1718,6 +2016,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, b->d.p, n, ws.bhat.p);
         FS_KERNEL_CHECK();
         aval = ws.aval.p;
+        if (bs == 1) {
+            FS_CHECK(dict_build(A, aval, s));       // a handful of distinct rows (uniform box, constant coefficient)?
+            sgrid = spmv_partials(sp, bs);          // (the row-dictionary product has its own launch geometry)
+        }
     }
     // A pass = fresh recurrences from the current x.  The single-reduction recurrences drift on
     // ill-conditioned operators (the recurrence residual can reach the threshold while b - A x has not):
@@ -1895,7 +2197,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 if (p2p_fuse) FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                 const void* key[16] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
                                        ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf};
-                const int64_t key_i[8] = {n, p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0, batch, fgrid, vgrid,
+                // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
+                const int64_t dict_sig = g_dict.built_for && g_dict.built_for == aval ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
+                const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,
                                           (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs),
                                           (int64_t)A->serial, (int64_t)sp->serial};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {

@@ -299,6 +299,66 @@ __global__ void k_dia_ptr(const int32_t* __restrict__ dia_cnt, const int32_t* __
     }
 }
 
+// Slices with the same offset list share ONE copy of it: on a structured mesh nearly every slice has the list of its neighbours,
+// and a product that walks 15 000 private copies misses the scalar cache on every slice (1 MB of offsets at 1 M rows) where it
+// could hit the same 64 bytes.  Two passes over a hash table of list hashes, result independent of the insertion order: pass 1
+// leaves in every occupied slot the SMALLEST slice index carrying that hash, pass 2 lets a slice adopt that slice's list if the
+// contents really are equal (a collision keeps its own copy).  The unused copies stay where they are.
+constexpr int FS_DEDUP_CAP = 1 << 16;
+__device__ __forceinline__ unsigned long long dia_list_hash(const int32_t* __restrict__ l, int cnt) {
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)cnt;
+    for (int k = 0; k < cnt; ++k) { h = (h ^ (unsigned long long)(uint32_t)l[k]) * 1099511628211ull; h ^= h >> 31; }
+    return h ? h : 1ull;
+}
+__global__ void k_dia_dedup_insert(int64_t n_slices, const int32_t* __restrict__ dia_cnt, const int32_t* __restrict__ dia_ptr,
+                                   const int32_t* __restrict__ dia_off, unsigned long long* keys, int32_t* rep) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < n_slices; s += stride) {
+        const int cnt = dia_cnt[s];
+        if (cnt == 0) continue;
+        const unsigned long long h = dia_list_hash(dia_off + dia_ptr[s], cnt);
+        int slot = (int)(h & (FS_DEDUP_CAP - 1));
+        for (int probe = 0; probe < 256; ++probe) {      // (a full table: the slice keeps its own copy)
+            unsigned long long old = keys[slot];
+            if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, h);
+            if (old == 0ull || old == h) { atomicMin(&rep[slot], (int32_t)s); break; }
+            slot = (slot + 1) & (FS_DEDUP_CAP - 1);
+        }
+    }
+}
+__global__ void k_dia_dedup_adopt(int64_t n_slices, const int32_t* __restrict__ dia_cnt, const int32_t* __restrict__ dia_ptr,
+                                  const int32_t* __restrict__ dia_off, const unsigned long long* __restrict__ keys,
+                                  const int32_t* __restrict__ rep, int32_t* __restrict__ dia_ptr_out) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < n_slices; s += stride) {
+        const int cnt = dia_cnt[s];
+        int32_t dp = dia_ptr[s];
+        if (cnt > 0) {
+            const int32_t* mine = dia_off + dp;
+            const unsigned long long h = dia_list_hash(mine, cnt);
+            int slot = (int)(h & (FS_DEDUP_CAP - 1));
+            for (int probe = 0; probe < 256; ++probe) {
+                const unsigned long long k = keys[slot];
+                if (k == 0ull) break;
+                if (k == h) {
+                    const int32_t r = rep[slot];
+                    if (r >= 0 && r < s && dia_cnt[r] == cnt) {
+                        const int32_t* other = dia_off + dia_ptr[r];
+                        bool same = true;
+                        for (int q = 0; q < cnt; ++q) same = same && other[q] == mine[q];
+                        if (same) dp = dia_ptr[r];
+                    }
+                    break;
+                }
+                slot = (slot + 1) & (FS_DEDUP_CAP - 1);
+            }
+        }
+        dia_ptr_out[s] = dp;
+    }
+}
+
 // column of every stored entry.  SELL slice: entry k of the row, padding = ~row.  DIA slice:
 // row + offset k when the row really has that column, otherwise ~clamp(row + offset).
 __global__ void __launch_bounds__(FS_BLOCK) k_fill_sell(const int32_t* __restrict__ rowptr,
@@ -945,9 +1005,24 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         unsigned long long h_dia_entries = 0;
         FS_SP(d_dia_entries.download(&h_dia_entries, 1, s));
         sp->dia_entries = (int64_t)h_dia_entries;
-        FS_SP(sp->dia_off.alloc(total_off > 0 ? total_off : 1));
+        FS_SP(sp->dia_off.alloc((total_off > 0 ? total_off : 1) + 64));       // (+ 64: the row-dictionary product reads whole rounds of 16 offsets)
+        FS_SP(sp->dia_off.zero(s));
         hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, split_at.p, sp->dia_ptr.p, sp->dia_off.p);
         FS_SP_HIP(hipGetLastError());
+        static const bool no_dedup = getenv("FS_DIA_DEDUP") && getenv("FS_DIA_DEDUP")[0] == '0';
+        if (h_ndia > 0 && !no_dedup) {       // identical offset lists -> one copy (see k_dia_dedup_insert)
+            dbuf<unsigned long long> keys;
+            dbuf<int32_t> rep, shared;
+            FS_SP(keys.alloc(FS_DEDUP_CAP));
+            FS_SP(rep.alloc(FS_DEDUP_CAP));
+            FS_SP(shared.alloc(n_slices));
+            FS_SP(keys.zero(s));
+            FS_SP_HIP(hipMemsetAsync(rep.p, 0x7f, (size_t)FS_DEDUP_CAP * sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_dia_dedup_insert, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p);
+            hipLaunchKernelGGL(k_dia_dedup_adopt, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p, shared.p);
+            FS_SP_HIP(hipGetLastError());
+            FS_SP_HIP(hipMemcpyAsync(sp->dia_ptr.p, shared.p, (size_t)n_slices * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
         FS_SP_HIP(hipStreamSynchronize(s));
     }
     if (sp->sell_entries >= (int64_t)INT32_MAX) {

@@ -1,0 +1,223 @@
+// Feasibility probe: product of a 15-point Kuhn stencil matrix on a 100^3 grid (1 M rows, cache-resident)
+//   A: values streamed per row (DIA layout [slice][k][64], what k_sell_spmv does on a structured cube)
+//   B: row CLASS id (1 byte per row) + dictionary of the distinct value rows in LDS (27 classes on a uniform box)
+//   C: as B, two consecutive rows per lane (x values of a run of consecutive offsets shared)
+// hipcc --offload-arch=gfx950 -O3 -o dict_spmv_probe dict_spmv_probe.hip && ./dict_spmv_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdint>
+#include <cmath>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+constexpr int W = 15;
+__constant__ int c_off[W];
+
+__global__ void __launch_bounds__(256) k_stream(int64_t n, const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ns = (n + 63) / 64;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < ns; s += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t r = s * 64 + lane;
+        const double* vp = val + s * 64 * W + lane;
+        double v[W], xv[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = vp[k * 64];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            int64_t c = r + c_off[k];
+            c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+            xv[k] = x[c];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc += v[k] * xv[k];
+        if (r < n) y[r] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dict(int64_t n, int ncls, const double* __restrict__ dict, const uint8_t* __restrict__ cls,
+                                              const double* __restrict__ x, double* __restrict__ y) {
+    extern __shared__ double sd[];
+    for (int i = threadIdx.x; i < ncls * W; i += blockDim.x) sd[i] = dict[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t ns = (n + 63) / 64;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < ns; s += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t r = s * 64 + lane;
+        const int id = r < n ? cls[r] : 0;
+        const double* vp = sd + id * W;
+        double xv[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            int64_t c = r + c_off[k];
+            c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+            xv[k] = x[c];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc += vp[k] * xv[k];
+        if (r < n) y[r] = acc;
+    }
+}
+
+// two rows per lane: lane handles rows r, r+1 (r even); offsets sorted ascending; run detection at compile time is not possible with
+// __constant__ offsets, so the probe hard-codes the Kuhn runs through a flag array
+__constant__ int c_cont[W];     // 1: offset k = offset k-1 + 1
+__global__ void __launch_bounds__(256) k_dict2(int64_t n, int ncls, const double* __restrict__ dict, const uint8_t* __restrict__ cls,
+                                               const double* __restrict__ x, double* __restrict__ y) {
+    extern __shared__ double sd[];
+    for (int i = threadIdx.x; i < ncls * W; i += blockDim.x) sd[i] = dict[i];
+    __syncthreads();
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int64_t nu = (n + 127) / 128;          // 128 rows per wave
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nu; s += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t r = s * 128 + 2 * lane;
+        const int id0 = r < n ? cls[r] : 0, id1 = r + 1 < n ? cls[r + 1] : 0;
+        const double* v0 = sd + id0 * W;
+        const double* v1 = sd + id1 * W;
+        double lo[W], hi[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            int64_t c1 = r + c_off[k] + 1;
+            c1 = c1 < 0 ? 0 : (c1 > n - 1 ? n - 1 : c1);
+            hi[k] = x[c1];
+            if (!c_cont[k]) {
+                int64_t c0 = r + c_off[k];
+                c0 = c0 < 0 ? 0 : (c0 > n - 1 ? n - 1 : c0);
+                lo[k] = x[c0];
+            }
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const double l = c_cont[k] ? hi[k - (k > 0)] : lo[k];
+            a0 += v0[k] * l;
+            a1 += v1[k] * hi[k];
+        }
+        if (r + 1 < n) { v2d o; o.x = a0; o.y = a1; *reinterpret_cast<v2d*>(&y[r]) = o; }
+        else if (r < n) y[r] = a0;
+    }
+}
+
+
+// D: B + the fused dots of the scaled CG (zi = x[r], ri = d[r], three block sums, per-workgroup partials)
+__device__ __forceinline__ double block_sum(double v, double* lds4) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    __syncthreads();
+    return t;
+}
+template <int META>
+__global__ void __launch_bounds__(256) k_dict_dots(int64_t n, int ncls, const double* __restrict__ dict, const uint8_t* __restrict__ cls,
+                                                   const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ dvec,
+                                                   double* __restrict__ partials, const int4* __restrict__ desc, const int32_t* __restrict__ offs) {
+    extern __shared__ double sd[];
+    __shared__ double lds4[4];
+    for (int i = threadIdx.x; i < ncls * 16; i += blockDim.x) sd[i] = dict[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t ns = (n + 63) / 64;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < ns; q += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        int64_t s = q;
+        const int32_t* op = offs;
+        if (META) {
+            const int4 ds = desc[__builtin_amdgcn_readfirstlane((int)q)];
+            s = __builtin_amdgcn_readfirstlane(ds.x);
+            op = offs + __builtin_amdgcn_readfirstlane(ds.z);
+        }
+        const int64_t r = s * 64 + lane;
+        const bool live = r < n;
+        const int id = live ? cls[r] : 0;
+        const double zi = live ? x[r] : 0.0, ri = live ? dvec[r] : 0.0;
+        const double* vp = sd + id * 16;
+        double xv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int64_t c = r + (META ? op[k] : c_off[k < W ? k : 0]);
+            c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+            xv[k] = x[c];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += vp[k] * xv[k];
+        if (live) { y[r] = acc; d0 += zi * zi; d1 += acc * zi; d2 += ri * zi * zi; }
+    }
+    const double t0 = block_sum(d0, lds4), t1 = block_sum(d1, lds4), t2 = block_sum(d2, lds4);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = t0; partials[gridDim.x + blockIdx.x] = t1; partials[2 * gridDim.x + blockIdx.x] = t2; }
+}
+
+int main() {
+    const int m = 100;
+    const int64_t n = (int64_t)m * m * m;
+    // Kuhn stencil offsets (i fastest): center, +-x, +-y, +-z, +-(x+y), +-(y+z), +-(x+y+z), +-(x+z)  -- sorted ascending
+    std::vector<int> off;
+    const int dx = 1, dy = m, dz = m * m;
+    int raw[15] = {0, dx, -dx, dy, -dy, dz, -dz, dx + dy, -dx - dy, dy + dz, -dy - dz, dx + dy + dz, -dx - dy - dz, dx + dz, -dx - dz};
+    off.assign(raw, raw + 15);
+    std::sort(off.begin(), off.end());
+    int cont[15];
+    for (int k = 0; k < 15; ++k) cont[k] = k > 0 && off[k] == off[k - 1] + 1;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(c_off), off.data(), sizeof(int) * W));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(c_cont), cont, sizeof(int) * W));
+    const int ncls = 27;
+    std::vector<double> dict(ncls * W);
+    for (int i = 0; i < ncls * W; ++i) dict[i] = 0.3 + 0.01 * (i % 37);
+    std::vector<uint8_t> cls(n);
+    std::vector<double> val((size_t)((n + 63) / 64) * 64 * W, 0.0), x(n), yref(n);
+    auto pos = [&](int i) { return i == 0 ? 0 : (i == m - 1 ? 2 : 1); };
+    for (int64_t r = 0; r < n; ++r) {
+        const int i = r % m, j = (r / m) % m, k = r / (m * m);
+        cls[r] = (uint8_t)(pos(i) + 3 * pos(j) + 9 * pos(k));
+        x[r] = std::sin(0.001 * r);
+        for (int q = 0; q < W; ++q) val[(size_t)(r / 64) * 64 * W + (size_t)q * 64 + (r % 64)] = dict[cls[r] * W + q];
+    }
+    double *d_val, *d_x, *d_y, *d_dict; uint8_t* d_cls;
+    CK(hipMalloc(&d_val, val.size() * 8)); CK(hipMalloc(&d_x, n * 8)); CK(hipMalloc(&d_y, n * 8)); CK(hipMalloc(&d_dict, dict.size() * 8)); CK(hipMalloc(&d_cls, n));
+    CK(hipMemcpy(d_val, val.data(), val.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_x, x.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_dict, dict.data(), dict.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_cls, cls.data(), n, hipMemcpyHostToDevice));
+    std::vector<double> dict16(ncls * 16, 0.0);
+    for (int c = 0; c < ncls; ++c) for (int k = 0; k < W; ++k) dict16[c * 16 + k] = dict[c * W + k];
+    const int64_t nsl = (n + 63) / 64;
+    std::vector<int> desc(4 * nsl), offs(16, 0);
+    for (int k = 0; k < W; ++k) offs[k] = off[k];
+    for (int64_t q = 0; q < nsl; ++q) { desc[4 * q] = (int)q; desc[4 * q + 1] = 15; desc[4 * q + 2] = 0; desc[4 * q + 3] = 64; }
+    double *d_dict16, *d_dvec, *d_part; int *d_desc, *d_offs;
+    CK(hipMalloc(&d_dict16, dict16.size() * 8)); CK(hipMalloc(&d_dvec, n * 8)); CK(hipMalloc(&d_part, 3 * 4096 * 8)); CK(hipMalloc(&d_desc, desc.size() * 4)); CK(hipMalloc(&d_offs, 64 * 4));
+    CK(hipMemcpy(d_dict16, dict16.data(), dict16.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_dvec, x.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_offs, offs.data(), 16 * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<double> ya(n), yb(n), yc(n);
+    const int reps = 300;
+    for (int grid : {1024, 2048}) {
+        float ms;
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, 0, n, d_val, d_x, d_y);
+        CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, 0, n, d_val, d_x, d_y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipMemcpy(ya.data(), d_y, n * 8, hipMemcpyDeviceToHost));
+        printf("grid %d  A streamed values       %.2f us\n", grid, ms * 1e3 / reps);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_dict, dim3(grid), dim3(256), ncls * W * 8, 0, n, ncls, d_dict, d_cls, d_x, d_y);
+        CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_dict, dim3(grid), dim3(256), ncls * W * 8, 0, n, ncls, d_dict, d_cls, d_x, d_y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipMemcpy(yb.data(), d_y, n * 8, hipMemcpyDeviceToHost));
+        printf("grid %d  B dictionary in LDS     %.2f us\n", grid, ms * 1e3 / reps);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_dict2, dim3(grid), dim3(256), ncls * W * 8, 0, n, ncls, d_dict, d_cls, d_x, d_y);
+        CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_dict2, dim3(grid), dim3(256), ncls * W * 8, 0, n, ncls, d_dict, d_cls, d_x, d_y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipMemcpy(yc.data(), d_y, n * 8, hipMemcpyDeviceToHost));
+        printf("grid %d  C dictionary, 2 rows/lane %.2f us\n", grid, ms * 1e3 / reps);
+        for (int meta = 0; meta < 2; ++meta) {
+            for (int i = 0; i < reps + 20; ++i) {
+                if (i == 20) CK(hipEventRecord(e0));
+                if (meta) hipLaunchKernelGGL(k_dict_dots<1>, dim3(grid), dim3(256), ncls * 16 * 8, 0, n, ncls, d_dict16, d_cls, d_x, d_y, d_dvec, d_part, (const int4*)d_desc, d_offs);
+                else hipLaunchKernelGGL(k_dict_dots<0>, dim3(grid), dim3(256), ncls * 16 * 8, 0, n, ncls, d_dict16, d_cls, d_x, d_y, d_dvec, d_part, (const int4*)d_desc, d_offs);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("grid %d  %s %.2f us\n", grid, meta ? "E dictionary + dots + descriptor / offsets from memory" : "D dictionary + fused dots            ", ms * 1e3 / reps);
+        }
+        double eb = 0, ec = 0;
+        for (int64_t r = 0; r < n; ++r) { eb = std::max(eb, std::fabs(ya[r] - yb[r])); ec = std::max(ec, std::fabs(ya[r] - yc[r])); }
+        printf("          max |A - B| %.3g   max |A - C| %.3g\n", eb, ec);
+    }
+    return 0;
+}
