@@ -1391,6 +1391,7 @@ static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
 static int g_cg_graph = -1;      // -1: by size (cache-resident problems, where the launch gaps are ~10 % of an iteration)
 static int g_update_blocks = 512;
+static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
 
 extern "C" int fs_set_option(const char* name, double value) {
     FS_REQUIRE(name, "fs_set_option: null name");
@@ -1412,6 +1413,8 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "update_blocks")) {
         FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
         g_update_blocks = (int)value;
+    } else if (!strcmp(name, "row_dictionary")) {
+        g_row_dictionary = value != 0.0;
     } else if (!strcmp(name, "cg_batch")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
         g_cg_batch = (int)value;
@@ -1523,7 +1526,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     D.built_for = nullptr;
     fs_space_s* sp = A->space;
     static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
-    if (off || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
+    if (off || !g_row_dictionary || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
     if (sp->max_row <= 0 || sp->max_row > 64) return FS_OK;
     const int W = (sp->max_row + 15) & ~15;           // dictionary rows are padded with zeros to a multiple of the round length
     const int64_t padded = sp->n_slices * FS_SLICE;
@@ -2480,6 +2483,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             stats->update_ms = t_upd / cnt;
         }
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
+        stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
     }
     if (h_status[0] == 2) {
         fs_set_error("fs_krylov_solve: %s breakdown at iteration %d (operator not SPD / rho = 0 / NaN)", bicg ? "BiCGStab" : "CG", iters);

@@ -68,7 +68,8 @@ const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
  * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll),
  * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
- * "update_blocks" (grid of the fused vector-update kernel). */
+ * "update_blocks" (grid of the fused vector-update kernel), "cg_graph" (-1 / 0 / 1: CG batches as hipGraphs by size /
+ * never / always), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes). */
 int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
 int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
@@ -336,6 +337,9 @@ typedef struct fs_krylov_stats {
     double spmv_ms;         /* mean duration of the fused SpMV+dots kernel (HIP events) */
     double update_ms;       /* mean duration of the fused vector-update kernel */
     int64_t spmv_bytes;     /* algorithmic bytes of one SpMV: nnz*12 + n*20 */
+    int row_classes;        /* > 0: the product ran in row-dictionary form with this many distinct rows (the operator of a uniform
+                             * box mesh with constant coefficients: class numbers + the distinct rows in LDS instead of the value
+                             * stream, verified bit for bit against the assembled values); 0: the streaming kernels */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,

@@ -673,3 +673,98 @@ def test_locality_order_of_a_shuffled_mesh(gpu, data_dir):
     st = gpu.krylov_solve(A, b, x, rtol=1e-13, max_iter=5000)
     assert st["converged"] == 1
     assert np.abs(x.get()[q] - (350.0 - 2.5 * co[:, 2])).max() <= 1e-9
+
+
+def _box_system(gpu, mesh, n, conductivity=20.0, mass=None):
+    """Heat-box operator and load with the Dirichlet pair on the z-faces, on the given device mesh of the n^3 cube."""
+    P = fo.heat_box_problem(n)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=conductivity, mass=mass)
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, source=3.0)
+    A.apply_dirichlet(b, P["dofs"], P["vals"], symmetric=True)
+    return P, V, A, b
+
+
+@pytest.mark.parametrize("n,pipelined", [(20, False), (33, False), (20, True)])
+def test_row_dictionary_product_is_the_streaming_product(gpu, n, pipelined):
+    """Uniform box + constant coefficients: the scaled operator has a few dozen DISTINCT rows (the box assembly snaps its edge
+    vectors to the grid spacing, so equal stencils are equal bit for bit) and the CG product runs from class numbers + a dictionary
+    in LDS (fs_krylov_stats.row_classes).  Same offsets, same summation order: iteration count, residual history and solution
+    are those of the streaming kernel, exactly."""
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    P, V, A, b = _box_system(gpu, mesh, n, mass=0.7)
+    runs = []
+    try:
+        for on in (1, 0):
+            gpu.set_option("row_dictionary", on)
+            x = gpu.DeviceVector(V.n_local)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000, pipelined=pipelined)
+            runs.append((st, x.get()[:V.n_owned].copy(), gpu.krylov_history().copy()))
+    finally:
+        gpu.set_option("row_dictionary", 1)
+    (s1, x1, h1), (s0, x0, h0) = runs
+    assert 0 < s1["row_classes"] <= 512 and s0["row_classes"] == 0
+    assert s1["converged"] == 1 and s0["converged"] == 1 and s1["iterations"] == s0["iterations"]
+    assert np.array_equal(h1, h0)
+    assert np.array_equal(x1, x0)
+    assert s1["true_rel_residual"] <= 2e-10
+
+
+def test_row_dictionary_is_not_used_where_rows_do_not_repeat(gpu):
+    """The form is found from the VALUES of every solve and verified row by row: a per-cell coefficient, or the same cube uploaded
+    as a general mesh (no snapping: equal stencils differ in the last bits), leaves the streaming kernels in use; an operator
+    that changes from one kind to the other between two solves is followed."""
+    n = 16
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    rng = np.random.default_rng(3)
+    nc = 6 * n ** 3
+    P, V, A, b = _box_system(gpu, mesh, n, conductivity=("cell", 1.0 + rng.random(nc)))
+    x = gpu.DeviceVector(V.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-9, max_iter=5000)
+    assert st["converged"] == 1 and st["row_classes"] == 0
+    # the same matrix object re-assembled with a constant coefficient: a new matrix is needed for the form to be tried again
+    # (a matrix whose rows did not repeat is not hashed again), a fresh one gets it
+    A2 = gpu.DeviceMatrix(V)
+    A2.assemble(stiffness=20.0)
+    b2 = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b2, source=3.0)
+    A2.apply_dirichlet(b2, P["dofs"], P["vals"], symmetric=True)
+    st2 = gpu.krylov_solve(A2, b2, x, rtol=1e-9, max_iter=5000)
+    assert st2["converged"] == 1 and st2["row_classes"] > 0
+    # general upload of a box whose spacings are not dyadic: coordinates i * h carry rounding noise and nothing snaps it away
+    # (with h = 1/16 the differences are exact and the rows repeat anyway)
+    dims = (1.0, 0.7, 1.3)
+    co, ce = fo.box_mesh((0, 0, 0), dims, n, n, n)
+    gm = gpu.DeviceMesh(co, ce)
+    P3, V3, A3, b3 = _box_system(gpu, gm, n)
+    x3 = gpu.DeviceVector(V3.n_local)
+    st3 = gpu.krylov_solve(A3, b3, x3, rtol=1e-9, max_iter=5000)
+    assert st3["converged"] == 1 and st3["row_classes"] == 0
+    # the device generator of the same box: snapped, repeated rows - and the same solution to rounding
+    bm = gpu.DeviceMesh.box(n, n, n, (0.0, 0.0, 0.0), dims)
+    P4, V4, A4, b4 = _box_system(gpu, bm, n)
+    x4 = gpu.DeviceVector(V4.n_local)
+    st4 = gpu.krylov_solve(A4, b4, x4, rtol=1e-9, max_iter=5000)
+    assert st4["converged"] == 1 and st4["row_classes"] > 0
+    assert np.abs(x4.get()[:V4.n_owned] - x3.get()[:V3.n_owned]).max() <= 1e-8 * np.abs(x3.get()).max()
+
+
+def test_box_assembly_is_translation_invariant_and_matches_the_oracle(gpu):
+    """fs_mesh_create_box meshes: interior rows of the P1 operator are identical BIT FOR BIT (edge vectors snapped to the grid
+    spacing), and the values are the oracle's to rounding."""
+    n = 12
+    mesh = gpu.DeviceMesh.box(n, n, n, (0.0, 0.0, 0.0), (1.0, 0.7, 1.3))
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0, mass=2.0)
+    rp, ci, va, shape = A.to_csr()
+    M = sp.csr_matrix((va, ci, rp), shape=shape)
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), n, n, n)
+    Ao = fo.assemble_p1_scalar(co, ce, k=20.0, mass_coef=2.0)
+    assert abs(M - Ao).max() <= 1e-12 * abs(Ao).max()
+    cnt = np.diff(rp)
+    rows = np.nonzero(cnt == 15)[0]
+    vals = va[rp[rows][:, None] + np.arange(15)]
+    assert len(rows) == (n - 1) ** 3 and len(np.unique(vals, axis=0)) == 1
