@@ -713,6 +713,8 @@ static int build_slice_split(fs_space_s* sp) {
     hipStream_t s = fs_rt().stream;
     h.interior.release();
     h.boundary.release();
+    h.desc_interior.release();
+    h.desc_boundary.release();
     h.n_interior = h.n_boundary = 0;
     const int64_t ns = sp->n_slices;
     if (ns == 0) return FS_OK;

@@ -190,6 +190,7 @@ struct fs_halo_plan {
     int fuse = 0;                          // 1: every rank can run the fused peer-to-peer iteration (agreed with `early`)
     // slices (in processing order) without / with ghost columns
     dbuf<int32_t> interior, boundary;
+    dbuf<int32_t> desc_interior, desc_boundary;     // slice descriptors of the two lists for the row-dictionary product (built on first use)
     int64_t n_interior = 0, n_boundary = 0;
     ~fs_halo_plan() {
         if (ev_ready) (void)hipEventDestroy(ev_ready);

@@ -884,6 +884,37 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         iter = status[2] - 1;
         check_only = iter >= (int)ctrl[2] ? 1 : 0;
     }
+    // NT (vectors larger than the caches, 10 M DOF): non-temporal loads and stores - the probe in tools/probes streams
+    // 7.2 instead of 6.4 TB/s that way
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    struct io {
+        static __device__ __forceinline__ double2 ld(const double2* q) {
+            if (NT) { const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)); return make_double2(t.x, t.y); }
+            return *q;
+        }
+        static __device__ __forceinline__ void st(double2* q, const double2& v) {
+            if (NT) { v2d t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(q)); }
+            else *q = v;
+        }
+    };
+    const int64_t n2 = n >> 1;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
+    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
+    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
+    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
+    // the operands of the first trip are requested BEFORE the sums are reduced (at 1 M rows a thread makes two trips and the
+    // kernel is latency-bound: the reduction of 3 x 1024 partials and the ten loads of the trip used to be two round trips in a row)
+    const bool first_trip = i + stride < n2;
+    double2 wa0 = {0.0, 0.0}, wb0 = wa0, pa0 = wa0, sa0 = wa0, xa0 = wa0, ra0 = wa0, pb0 = wa0, sb0 = wa0, xb0 = wa0, rb0 = wa0;
+    if (first_trip) {
+        const int64_t j = i + stride;
+        wa0 = io::ld(&w2[i]); wb0 = io::ld(&w2[j]);
+        pa0 = io::ld(&p2[i]); sa0 = io::ld(&s2[i]); xa0 = io::ld(&x2[i]); ra0 = io::ld(&r2[i]);
+        pb0 = io::ld(&p2[j]); sb0 = io::ld(&s2[j]); xb0 = io::ld(&x2[j]); rb0 = io::ld(&r2[j]);
+    }
     double gamma, delta, rho;
     if (FUSED) {
         double sm[3];
@@ -919,33 +950,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         scal[2 * (iter & 1) + 0] = gamma;
         scal[2 * (iter & 1) + 1] = alpha;
     }
-    const int64_t n2 = n >> 1;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // NT (vectors larger than the caches, 10 M DOF): non-temporal loads and stores - the probe in tools/probes streams
-    // 7.2 instead of 6.4 TB/s that way
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    struct io {
-        static __device__ __forceinline__ double2 ld(const double2* q) {
-            if (NT) { const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)); return make_double2(t.x, t.y); }
-            return *q;
-        }
-        static __device__ __forceinline__ void st(double2* q, const double2& v) {
-            if (NT) { v2d t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(q)); }
-            else *q = v;
-        }
-    };
-    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
-    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
-    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
-    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
-    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
     // two strided elements per trip: ten 16-B loads in flight per lane (the kernel is latency-bound at 1 M DOF)
+    bool prefetched = first_trip;
     for (; i + stride < n2; i += 2 * stride) {
         const int64_t j = i + stride;
-        const double2 wa = io::ld(&w2[i]), wb = io::ld(&w2[j]);
-        double2 pa = io::ld(&p2[i]), sa = io::ld(&s2[i]), xa = io::ld(&x2[i]), ra = io::ld(&r2[i]);
-        double2 pb = io::ld(&p2[j]), sb = io::ld(&s2[j]), xb = io::ld(&x2[j]), rb = io::ld(&r2[j]);
+        double2 wa, wb, pa, sa, xa, ra, pb, sb, xb, rb;
+        if (prefetched) {
+            wa = wa0; wb = wb0; pa = pa0; sa = sa0; xa = xa0; ra = ra0; pb = pb0; sb = sb0; xb = xb0; rb = rb0;
+            prefetched = false;
+        } else {
+            wa = io::ld(&w2[i]); wb = io::ld(&w2[j]);
+            pa = io::ld(&p2[i]); sa = io::ld(&s2[i]); xa = io::ld(&x2[i]); ra = io::ld(&r2[i]);
+            pb = io::ld(&p2[j]); sb = io::ld(&s2[j]); xb = io::ld(&x2[j]); rb = io::ld(&r2[j]);
+        }
         pa.x = ra.x + beta * pa.x;  pa.y = ra.y + beta * pa.y;
         pb.x = rb.x + beta * pb.x;  pb.y = rb.y + beta * pb.y;
         sa.x = wa.x + beta * sa.x;  sa.y = wa.y + beta * sa.y;
@@ -1581,14 +1598,26 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int64_t ns = list ? n_list : sp->n_slices;
     if (ns == 0) return;
     const int32_t* order = list ? list : sp->slice_order.p;
-    if (!list && A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val) {
-        // the values are a few dozen distinct rows (dict_build): class numbers + dictionary in LDS instead of the value stream;
-        // grid = what the plain form of this space would launch, so that the partial sums keep their layout
-        const int gd = spmv_partials_unsplit(sp, 1);
-        hipLaunchKernelGGL(k_dict_spmv<DOTS>, dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, sp->n_nodes_owned,
-                           sp->n_nodes_local, sp->n_slices, reinterpret_cast<const int4*>(sp->slice_desc.p), sp->dia_off.p, g_dict.cls.p,
-                           g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd());
-        return;
+    if (A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val) {
+        // the values are a few dozen distinct rows (dict_build): class numbers + dictionary in LDS instead of the value stream.
+        // Whole space: its own launch geometry (spmv_partials_unsplit); a list of a decomposed space (interior / boundary slices):
+        // the geometry of the streaming kernel, so that the two launches keep filling one partial array.
+        const int32_t* desc = sp->slice_desc.p;
+        int gd = spmv_partials_unsplit(sp, 1);
+        if (list) {
+            fs_halo_plan& h = sp->halo;
+            dbuf<int32_t>& dl = list == h.interior.p ? h.desc_interior : h.desc_boundary;
+            if (!dl.p && dl.alloc(4 * std::max<int64_t>(ns, 1)) == FS_OK)
+                hipLaunchKernelGGL(k_slice_desc, dim3(fs_grid_for(ns)), dim3(FS_BLOCK), 0, s, ns, list, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, dl.p);
+            desc = dl.p;
+            gd = spmv_grid(ns, sp->n_slices);
+        }
+        if (desc && (!list || list == sp->halo.interior.p || list == sp->halo.boundary.p)) {
+            hipLaunchKernelGGL(k_dict_spmv<DOTS>, dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, sp->n_nodes_owned,
+                               sp->n_nodes_local, ns, reinterpret_cast<const int4*>(desc), sp->dia_off.p, g_dict.cls.p,
+                               g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd());
+            return;
+        }
     }
     const int grid = spmv_grid(ns, sp->n_slices);
     if (part_stride == 0) part_stride = grid;
@@ -1645,10 +1674,11 @@ static int dict_map_xcd() {
     return m;
 }
 static int dict_grid(const fs_space_s* sp) {
-    // the row-dictionary product is bound by round trips per wave: twice the workgroups of the streaming kernels
+    // (measured at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 31 / 21 / 19 / 19 / 18.5 us, the update kernel that sums the
+    // partials + 0 / 0.5 / 1 / 1 / 3 us)
     static const int env_blocks = getenv("FS_DICT_BLOCKS") ? atoi(getenv("FS_DICT_BLOCKS")) : 0;
     const int64_t n_chunks = (sp->n_slices + 3) / 4;
-    int64_t g = std::min<int64_t>(n_chunks, env_blocks > 0 ? env_blocks : 2048);
+    int64_t g = std::min<int64_t>(n_chunks, env_blocks > 0 ? env_blocks : 1024);
     g = (g + 7) & ~(int64_t)7;
     return (int)std::max<int64_t>(g, 8);
 }
