@@ -515,9 +515,11 @@ def committed_traffic(tag):
 
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["algorithmic_GBps"] / HBM_PEAK_GBS
-    r = {"kernel": k["kernel"] + " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template "
-                                 "arguments of k_sell_spmv: block size, dot mode, entries per round, non-temporal matrix loads; of "
-                                 "k_dia_pair_spmv: dot mode, non-temporal matrix loads)",
+    what = (" (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
+            "LDS; template argument: dot mode)") if k.get("row_classes", 0) > 0 else (
+        " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template arguments of k_sell_spmv: block "
+        "size, dot mode, entries per round, non-temporal matrix loads; of k_dia_pair_spmv: dot mode, non-temporal matrix loads)")
+    r = {"kernel": k["kernel"] + what,
          "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 3),
          "traffic": traffic,
          "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; NOT measured in this run)" % traffic_source)
@@ -696,8 +698,9 @@ def main():
             B.synchronize()
             t_big = time.perf_counter() - t0
             traffic, src = committed_traffic("spmv_fused_n215")
-            r = make_roofline(kernel_rates(st_big, big.V), "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per launch)"
-                              % (big.n_owned, (big.V.spmv_matrix_bytes + 24 * big.n_owned) / 1e9), traffic, src)
+            k_big = kernel_rates(st_big, big.V)
+            r = make_roofline(k_big, "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per launch)"
+                              % (big.n_owned, k_big["streamed_bytes_per_launch"] / 1e9), traffic, src)
             r.update({"dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
                       "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3),
                       "update_kernel_ms": round(st_big["update_ms"], 5),
