@@ -1429,7 +1429,7 @@ static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
 static int g_cg_graph = -1;      // -1: by size (cache-resident problems, where the launch gaps are ~10 % of an iteration)
-static int g_update_blocks = 512;
+static int g_update_blocks = 1024;  // (round 3, with the 16 us row-dictionary product at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 10.59 / 10.42 / 10.20 / 10.12 / 11.22 ms per step; 10 M rows: flat)
 static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
 
 extern "C" int fs_set_option(const char* name, double value) {
