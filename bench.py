@@ -400,7 +400,7 @@ def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="a
             "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
             "max_abs_error_vs_exact_profile": err, "recurrence": name, "recurrence_trial_ms_per_step": trial,
             "symbolic_ms": round(prob.symbolic_ms, 2), "setup_s": round(setup_s, 2),
-            "spmv": {"kernel": kernel_name(prob.V), "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
+            "spmv": {"kernel": kernel_name(prob.V, st), "row_classes": st.get("row_classes", 0), "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
                      "algorithmic_GBps": k["algorithmic_GBps"], "frac_of_8TBps": round(k["algorithmic_GBps"] / HBM_PEAK_GBS, 3),
                      "streamed_GBps": k["streamed_GBps"], "dia_slices": k["dia_slices"], "slices": k["slices"], "rows_rank0": prob.n_owned}}
 

@@ -62,6 +62,7 @@ __device__ __forceinline__ tet_geom tet_geometry_snapped(const double (&x0)[3], 
     }
     return tet_geometry_e(e1, e2, e3);
 }
+__device__ __forceinline__ tet_geom tet_geometry_box(const double* __restrict__ xyz4, const int32_t (&v)[4], const box_snap& bx);
 static box_snap make_box_snap(const fs_mesh_s* m) {
     static const bool off = getenv("FS_BOX_SNAP") && getenv("FS_BOX_SNAP")[0] == '0';
     box_snap b;
@@ -89,6 +90,16 @@ __device__ __forceinline__ tet_geom tet_geometry_e(const double (&e1)[3], const 
     }
     t.adet = fabs(det);
     return t;
+}
+
+// general mesh: the plain geometry; uniform box (bx.h > 0): edge vectors snapped to the grid spacing
+__device__ __forceinline__ tet_geom tet_geometry_box(const double* __restrict__ xyz4, const int32_t (&v)[4], const box_snap& bx) {
+    double x0[3], x1[3], x2[3], x3[3];
+    load_vertex(xyz4, v[0], x0);
+    load_vertex(xyz4, v[1], x1);
+    load_vertex(xyz4, v[2], x2);
+    load_vertex(xyz4, v[3], x3);
+    return bx.h[0] > 0.0 ? tet_geometry_snapped(x0, x1, x2, x3, bx) : tet_geometry_x(x0, x1, x2, x3);
 }
 
 // SUPG parameter of a cell (ScalarTransportSolver.py:262-266): tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 R with R the
@@ -422,7 +433,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order,
+    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order, const box_snap bx,
     coef_dev ac = coef_dev(), double ascale = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
@@ -478,7 +489,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
             const uint32_t pw[3] = {pc[u][0], pc[u][1], pc[u][2]};
             const int4 c4 = vc[u];      // vertex ids (node ids differ once ghosts exist)
             const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
-            const tet_geom t = tet_geometry(xyz4, vv);
+            const tet_geom t = tet_geometry_box(xyz4, vv, bx);
             const double vol = t.adet * (1.0 / 6.0);
             double row[10];
 #pragma unroll
@@ -2365,13 +2376,13 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (ac3.mode != FS_COEF_NONE || kc.mode == FS_COEF_CELL_QP) {
             if (add)
-                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, ac3, form->advection_scale);
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale);
             else
-                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, ac3, form->advection_scale);
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale);
         } else if (add)
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m));
         else
-            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p);
+            hipLaunchKernelGGL(k_assemble_p2_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m));
     } else if (A->bs == 1 && sp->inc_cell.p) {
         // row-gather path: every SELL entry (padding included) is written exactly once, no memset
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));

@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
 // table, one verifies EVERY row bit for bit against its class - a hash collision or a 513th class simply leaves the plain
 // form in use), so it is lossless and needs no knowledge of where the matrix came from.  Same offsets, same summation order,
 // same bits as k_sell_spmv.  Measured on MI355X at 1 M rows: product 26 -> 14 us.
-constexpr int FS_DICT_CAP = 1024;       // hash slots
-constexpr int FS_DICT_MAX = 512;        // distinct rows accepted
+constexpr int FS_DICT_CAP = 8192;       // hash slots
+constexpr int FS_DICT_MAX = 4096;       // distinct rows accepted
 constexpr int FS_DICT_LDS_DOUBLES = 6144;   // ncls * width must fit (48 KB)
 
 __device__ __forceinline__ unsigned long long dict_row_hash(const double* __restrict__ vp, int width) {
@@ -451,23 +451,30 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_rows, int64_
     }
 }
 
-__global__ void __launch_bounds__(FS_DICT_CAP) k_dict_compact(const unsigned long long* __restrict__ keys, const double* __restrict__ slot_vals,
-                                                              int W, int32_t* __restrict__ slot2cls, double* __restrict__ values) {
-    __shared__ int cnt[FS_DICT_CAP];
+__global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long* __restrict__ keys, const double* __restrict__ slot_vals,
+                                                       int W, int32_t* __restrict__ slot2cls, double* __restrict__ values) {
+    constexpr int PER = FS_DICT_CAP / 1024;       // consecutive slots per thread
+    __shared__ int cnt[1024];
     const int t = threadIdx.x;
-    const int used = keys[t] != 0ull;
-    cnt[t] = used;
+    int mine = 0;
+    for (int q = 0; q < PER; ++q) mine += keys[t * PER + q] != 0ull;
+    cnt[t] = mine;
     __syncthreads();
-    for (int off = 1; off < FS_DICT_CAP; off <<= 1) {       // inclusive scan
+    for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan
         const int v = t >= off ? cnt[t - off] : 0;
         __syncthreads();
         cnt[t] += v;
         __syncthreads();
     }
-    const int id = cnt[t] - 1;
-    slot2cls[t] = used ? id : -1;
-    if (used && id < FS_DICT_MAX)
-        for (int k = 0; k < W; ++k) values[(int64_t)id * W + k] = slot_vals[(int64_t)t * W + k];
+    int id = cnt[t] - mine;
+    for (int q = 0; q < PER; ++q) {
+        const int slot = t * PER + q;
+        const bool used = keys[slot] != 0ull;
+        slot2cls[slot] = used ? id : -1;
+        if (used && id < FS_DICT_MAX)
+            for (int k = 0; k < W; ++k) values[(int64_t)id * W + k] = slot_vals[(int64_t)slot * W + k];
+        id += used;
+    }
 }
 
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
@@ -508,7 +515,9 @@ __global__ void k_slice_desc(int64_t n_slices, const int32_t* __restrict__ order
     }
 }
 
-template <int DOTS>
+// LDSD: the dictionary fits LDS (P1: 86 rows of 16); otherwise (CG2: 492 rows of 80 = 315 KB) it is read from memory - it
+// stays in L2, and the lanes of a wave mostly ask for the same class, so that a load is one broadcast line
+template <int DOTS, bool LDSD>
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
                                                         const int4* __restrict__ desc, const int32_t* __restrict__ dia_off,
                                                         const uint16_t* __restrict__ cls,
@@ -521,8 +530,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
         if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
     }
     extern __shared__ double sdict[];
-    for (int i = threadIdx.x; i < ncls * W; i += FS_BLOCK) sdict[i] = dict[i];
-    __syncthreads();
+    if (LDSD) {
+        for (int i = threadIdx.x; i < ncls * W; i += FS_BLOCK) sdict[i] = dict[i];
+        __syncthreads();
+    }
     __shared__ double lds4[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -549,7 +560,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
                 if (DOTS == 1 || DOTS == 3) zi = x[r];
                 ri = rvec[r];
             }
-            const double* __restrict__ vp = sdict + (int)cls[r] * W;
+            const double* __restrict__ vp = (LDSD ? sdict : dict) + (int)cls[r] * W;
             double acc = 0.0;
             // rounds of 16 entries WITHOUT a guard (a guarded load makes the compiler wait for the previous one): positions past
             // the slice's width read whatever follows in the offset array (the address is clamped into x, dia_off is padded by
@@ -1566,7 +1577,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     fs_space_s* sp = A->space;
     static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
     if (off || !g_row_dictionary || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
-    if (sp->max_row <= 0 || sp->max_row > 64) return FS_OK;
+    if (sp->max_row <= 0 || sp->max_row > 96) return FS_OK;
     const int W = (sp->max_row + 15) & ~15;           // dictionary rows are padded with zeros to a multiple of the round length
     const int64_t padded = sp->n_slices * FS_SLICE;
     if (!sp->slice_desc.p) {
@@ -1586,13 +1597,13 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     const int grid = fs_grid_for(padded, FS_BLOCK, 4096);
     hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.keys.p, D.keys.p,
                        D.slot_vals.p, D.cls_slot.p, D.info.p);
-    hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(FS_DICT_CAP), 0, s, D.keys.p, D.slot_vals.p, W, D.slot2cls.p, D.values.p);
+    hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, W, D.slot2cls.p, D.values.p);
     hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.slot2cls.p,
                        D.values.p, D.cls_slot.p, D.cls.p, D.info.p);
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
-    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * W <= FS_DICT_LDS_DOUBLES;
+    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX;
     if (getenv("FS_KRYLOV_DEBUG"))
         fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of width %d among %lld, %d mismatches -> %s\n", h[0], W,
                 (long long)sp->n_nodes_owned, h[2], ok ? "compressed product" : "plain product");
@@ -1635,9 +1646,13 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             gd = spmv_grid(ns, sp->n_slices);
         }
         if (desc && (!list || list == sp->halo.interior.p || list == sp->halo.boundary.p)) {
-            hipLaunchKernelGGL(k_dict_spmv<DOTS>, dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, sp->n_nodes_owned,
-                               sp->n_nodes_local, ns, reinterpret_cast<const int4*>(desc), sp->dia_off.p, g_dict.cls.p,
-                               g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd());
+#define FS_DICT_ARGS sp->n_nodes_owned, sp->n_nodes_local, ns, reinterpret_cast<const int4*>(desc), sp->dia_off.p, g_dict.cls.p, \
+                     g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd()
+            if ((int64_t)g_dict.ncls * g_dict.W <= FS_DICT_LDS_DOUBLES)
+                hipLaunchKernelGGL((k_dict_spmv<DOTS, true>), dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, FS_DICT_ARGS);
+            else
+                hipLaunchKernelGGL((k_dict_spmv<DOTS, false>), dim3(gd), dim3(FS_BLOCK), 0, s, FS_DICT_ARGS);
+#undef FS_DICT_ARGS
             return;
         }
     }

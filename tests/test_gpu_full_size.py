@@ -145,6 +145,28 @@ def test_config4_p2_poisson_10m_dof_single_gpu(gpu):
     assert V.n_owned == 215 ** 3 and mesh.info()[1] == 7350258
     assert st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
     assert np.abs(x.get() - (350.0 - 50.0 * z)).max() <= 3e-3   # P2 reproduces the linear profile
+    # the CG2 operator of the uniform cube has a few hundred distinct rows (every slice is in DIA form at this size): the product
+    # ran from class numbers + a dictionary (too large for LDS: read through the caches) - and follows the streaming product
+    assert 0 < st["row_classes"] <= 4096
+    x1, h1, it1 = x.get().copy(), gpu.krylov_history().copy(), st["iterations"]
+    try:
+        gpu.set_option("row_dictionary", 0)
+        b = gpu.DeviceVector(V.n_owned)
+        dofs = np.nonzero((z == 0.0) | (z == 1.0))[0]
+        A.assemble(stiffness=20.0)
+        A.apply_dirichlet(b, dofs, np.where(z[dofs] == 0.0, 350.0, 300.0), symmetric=True)
+        x0 = gpu.DeviceVector(V.n_owned)
+        st0 = gpu.krylov_solve(A, b, x0, rtol=1e-8, max_iter=50000)
+    finally:
+        gpu.set_option("row_dictionary", 1)
+    # (same per-row arithmetic; the dot products are partitioned over a different number of workgroups at this size - the
+    # streaming product is the two-launch pair kernel here -, so the recurrences agree to rounding, not to the bit as they
+    # do where both forms use one launch geometry: tests/test_gpu_kernels.py::test_row_dictionary_product_is_the_streaming_product)
+    assert st0["row_classes"] == 0 and abs(st0["iterations"] - it1) <= 1
+    h0 = gpu.krylov_history()
+    m = min(len(h0), len(h1), 200)
+    assert np.allclose(h0[:m], h1[:m], rtol=1e-8)
+    assert np.abs(x0.get() - x1).max() <= 1e-6
 
 
 def test_config5_taylor_hood_cavity_2m_velocity_dofs(gpu):
