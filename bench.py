@@ -474,7 +474,9 @@ class Watchdog:
 
 def kernel_name(V, st=None):
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, dictionary in LDS
-        return "k_dict_spmv<3> (row-dictionary form: %d distinct rows)" % st["row_classes"]
+        lds = st["row_classes"] * (16 if V.degree == 1 else 80) <= 6144       # fs_krylov.hip FS_DICT_LDS_DOUBLES (rows padded to 16s)
+        return "k_dict_spmv<3,%s> (row-dictionary form: %d distinct rows, dictionary %s)" % (
+            "true" if lds else "false", st["row_classes"], "in LDS" if lds else "read through the caches")
     nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
     one = "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
     if V.n_slices > 32768 and V.degree == 1 and V.n_dia_slices > 0:       # spmv_use_pairs(): paired DIA slices, two rows per lane

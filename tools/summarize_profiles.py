@@ -161,9 +161,9 @@ def main():
                 bare += (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
         if bare > 0.0:
             out[tag.replace("fused", "bare")] = int(bare)
-        dk = (ph, "k_dict_spmv<3>")       # row-dictionary form of the same product (uniform box, constant coefficient)
-        if dk in fetch:
-            out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
+        for dk in ((ph, "k_dict_spmv<3, true>"), (ph, "k_dict_spmv<3, false>")):       # row-dictionary form of the same product
+            if dk in fetch:                                                              # (dictionary in LDS / read through the caches)
+                out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
