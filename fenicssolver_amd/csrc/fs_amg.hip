@@ -1896,8 +1896,10 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
         if (conv != 1 || pnorm || tr2 <= 4.0 * thr2 || pass >= 2 || it >= max_iter) break;
         FS_HIP(hipMemcpyAsync(M->pr.p, M->pw.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
+    if (fs_p2p_reduce_enabled()) FS_CHECK(fs_p2p_check(s));      // a peer-to-peer wait timed out: the numbers below mean nothing
     stats->iterations = it;
     stats->converged = conv;
+    stats->row_classes = 0;
     stats->rel_residual = ref2 > 0.0 ? sqrt(res2 / ref2) : 0.0;
     stats->true_rel_residual = bb > 0.0 ? sqrt(tr2 / bb) : 0.0;
     stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

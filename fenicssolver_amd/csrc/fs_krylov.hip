@@ -1603,7 +1603,8 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
-    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX;
+    // (worth it only where rows really repeat: at most one class per 16 rows)
+    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * 16 <= sp->n_nodes_owned;
     if (getenv("FS_KRYLOV_DEBUG"))
         fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of width %d among %lld, %d mismatches -> %s\n", h[0], W,
                 (long long)sp->n_nodes_owned, h[2], ok ? "compressed product" : "plain product");
@@ -1937,7 +1938,7 @@ struct krylov_ws {
     // one batch of CG iterations captured as a hipGraph (same arguments every iteration: the update kernel reads its
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
     hipGraphExec_t cg_graph = nullptr;
-    const void* cg_key[16] = {};
+    const void* cg_key[20] = {};
     int64_t cg_key_i[8] = {};
 };
 static krylov_ws g_ws;
@@ -2265,10 +2266,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 fs_p2p_sendrows snd = {};
                 const int fgrid = p2p_fuse ? spmv_partials_unsplit(sp, bs) : sgrid;
                 if (p2p_fuse) FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
-                const void* key[16] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
-                                       ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf};
+                const bool dict_on = g_dict.built_for && g_dict.built_for == aval;
+                const void* key[20] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
+                                       ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf,
+                                       dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
+                                       dict_on ? (const void*)sp->slice_desc.p : nullptr, nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
-                const int64_t dict_sig = g_dict.built_for && g_dict.built_for == aval ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
+                const int64_t dict_sig = dict_on ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,
                                           (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs),
                                           (int64_t)A->serial, (int64_t)sp->serial};

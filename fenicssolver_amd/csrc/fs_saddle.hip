@@ -1754,6 +1754,8 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     }
     stats->iterations = it;
     stats->converged = conv;
+    if (fs_p2p_reduce_enabled()) FS_CHECK(fs_p2p_check(s));      // a peer-to-peer wait timed out: the numbers below mean nothing
+    stats->row_classes = 0;
     stats->rel_residual = stats->bnorm > 0.0 ? res / stats->bnorm : 0.0;
     stats->true_rel_residual = stats->rel_residual;
     stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
