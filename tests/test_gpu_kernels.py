@@ -768,3 +768,21 @@ def test_box_assembly_is_translation_invariant_and_matches_the_oracle(gpu):
     rows = np.nonzero(cnt == 15)[0]
     vals = va[rp[rows][:, None] + np.arange(15)]
     assert len(rows) == (n - 1) ** 3 and len(np.unique(vals, axis=0)) == 1
+
+
+def test_row_dictionary_buffers_may_move_between_solves(gpu):
+    """The captured CG batches bake the dictionary's buffers in: a larger space in between re-allocates them, and the batches of the
+    first space must be captured again (they are keyed on those buffers) - same solution before and after."""
+    def solve(n):
+        mesh = gpu.DeviceMesh.box(n, n, n)
+        P, V, A, b = _box_system(gpu, mesh, n)
+        x = gpu.DeviceVector(V.n_local)
+        st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+        assert st["converged"] == 1 and st["row_classes"] > 0 and st["iterations"] > 64      # beyond the first (uncaptured) batch
+        return (mesh, V, A, b), x.get()[:V.n_owned].copy(), st
+    keep, x_small, st_small = solve(24)
+    _, x_big, _ = solve(40)                      # larger class / descriptor arrays
+    mesh, V, A, b = keep
+    x = gpu.DeviceVector(V.n_local)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+    assert st["iterations"] == st_small["iterations"] and np.array_equal(x.get()[:V.n_owned], x_small)
