@@ -38,6 +38,34 @@ if case == "box":
         result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"])
     parallel.barrier()
     parallel.finalize()
+elif case == "box_stress":
+    # many solves back to back on one decomposed space: the sequence numbers, slots and captured batches of the peer-to-peer
+    # iteration over hundreds of exchanges, with a changing right-hand side (iteration counts differ from solve to solve)
+    nx, ny, nz, axis = 9, 7, 23, 0
+    parallel.ensure_comm()
+    zr = partition.slab_ranges(nz + 1, world)[rank]
+    mesh = B.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0), zplanes=zr)
+    V = B.DeviceSpace(mesh, 1)
+    lay = partition.slab_layout(nx, ny, nz, zr, rank, world)
+    dofs, vals = partition.slab_dirichlet(nx, ny, nz, lay, axis)
+    V.set_halo(lay["neighbors"], lay["send_lists"], lay["recv_counts"])
+    A = B.DeviceMatrix(V)
+    b = B.DeviceVector(V.n_owned)
+    x = B.DeviceVector(V.n_local)
+    its, res = [], []
+    for k in range(40):
+        A.assemble(stiffness=20.0, mass=0.1 * (k % 3))
+        B.assemble_vector(V, b, source=3.0 + k)
+        A.apply_dirichlet(b, dofs, vals * (1.0 + 0.01 * k), symmetric=True)
+        st = B.krylov_solve(A, b, x, rtol=10.0 ** -(6 + k % 6), max_iter=5000)
+        assert st["converged"] == 1, st
+        its.append(st["iterations"])
+        res.append(st["true_rel_residual"])
+    full = parallel.gather_owned(x.get()[:lay["n_owned"]], lay["l2g"][:lay["n_owned"]], (nx + 1) * (ny + 1) * (nz + 1))
+    if rank == 0:
+        result = dict(x=full, iterations=np.array(its), true_res=np.array(res))
+    parallel.barrier()
+    parallel.finalize()
 elif case == "box3":
     # three components per node (3x3-block operator of linear elasticity + mass), Jacobi-CG: the dof-level halo of a vector space
     nx, ny, nz = 6, 5, 17

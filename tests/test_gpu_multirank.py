@@ -63,6 +63,32 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
 
 
+@pytest.mark.parametrize("world,mode", [(3, "p2p"), (2, "p2p"), (3, "rccl")])
+def test_forty_solves_back_to_back_over_ranks(gpu, tmp_path, world, mode):
+    """40 solves in a row on one decomposed space (operator, load and tolerance change from solve to solve): hundreds of exchanges
+    through the two slots, sequence numbers that advance only with executed exchanges, captured batches re-used - every solve
+    converges to its tolerance, and the last field is the one-GPU field."""
+    nx, ny, nz, axis = 9, 7, 23, 0
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 2.0), nx, ny, nz)
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0))
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    b = gpu.DeviceVector(V.n_owned)
+    x = gpu.DeviceVector(V.n_local)
+    lo, hi = np.nonzero(co[:, axis] == 0)[0], np.nonzero(co[:, axis] == co[:, axis].max())[0]
+    dofs = np.concatenate([lo, hi]).astype(np.int32)
+    vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+    k = 39
+    A.assemble(stiffness=20.0, mass=0.1 * (k % 3))
+    gpu.assemble_vector(V, b, source=3.0 + k)
+    A.apply_dirichlet(b, dofs, vals * (1.0 + 0.01 * k), symmetric=True)
+    gpu.krylov_solve(A, b, x, rtol=10.0 ** -(6 + k % 6), max_iter=5000)
+    r = _run(world, "box_stress", tmp_path, **(dict(FS_HALO_P2P="1", FS_P2P_TIMEOUT_MS="3000") if mode == "p2p" else {}))
+    assert len(r["iterations"]) == 40
+    assert all(float(t) <= 1.5 * 10.0 ** -(6 + i % 6) for i, t in enumerate(r["true_res"]))
+    assert np.abs(r["x"] - x.get()[:V.n_owned]).max() <= 1e-8 * np.abs(x.get()).max()
+
+
 @pytest.mark.parametrize("world,mode", [(2, "rccl"), (3, "p2p"), (2, "p2p_unfused")])
 def test_vector_space_slabs_over_ranks(gpu, tmp_path, world, mode):
     """Three dofs per node (elasticity + mass operator), Jacobi-CG: the dof-level halo of a vector space over RCCL, over the fused
