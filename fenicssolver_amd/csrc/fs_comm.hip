@@ -617,6 +617,42 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
     pp.enabled = true;
     ++g_p2p_spaces;
     h.early = -1;              // the solver asks the ranks again which iteration they can all run
+    // Self-test on the hardware at hand, before any solver trusts the transport: an all-reduce of (rank + 1) and a ghost refresh of
+    // a vector holding (rank + 1) everywhere - every ghost must then read (its owner's rank + 1) - with a short time-out.  The
+    // verdict is agreed over the library's all-gather: a mapping that opens but does not deliver backs out on every rank.
+    {
+        const long long keep_timeout = g_p2p_timeout_ticks;
+        g_p2p_timeout_ticks = 50000000ll;       // 0.5 s
+        bool good = true;
+        const int64_t nl = space->n_dofs_local, no = space->n_dofs_owned;
+        dbuf<double> v;
+        std::vector<double> hv2((size_t)std::max<int64_t>(nl, 1) + 2, (double)(rt.rank + 1));
+        int rc2 = v.alloc(nl + 2);
+        if (rc2 == FS_OK) rc2 = v.upload(hv2.data(), nl + 2, s);
+        if (rc2 == FS_OK) rc2 = fs_p2p_allreduce_dev(nullptr, 0, v.p + nl, 1, s);       // (the spare entry behind the local dofs)
+        if (rc2 == FS_OK && nn > 0) rc2 = fs_halo_exchange_dev(space, v.p, s);
+        if (rc2 == FS_OK) rc2 = v.download(hv2.data(), nl + 2, s);
+        if (rc2 == FS_OK) rc2 = fs_p2p_check(s);
+        good = rc2 == FS_OK && hv2[(size_t)nl] == 0.5 * rt.n_ranks * (rt.n_ranks + 1.0);
+        if (good && nn > 0) {
+            std::vector<int32_t> ridx;
+            if (h.recv_idx.p) { ridx.resize((size_t)h.total_recv); good = h.recv_idx.download(ridx.data(), h.total_recv, s) == FS_OK; }
+            for (int i = 0; i < nn && good; ++i)
+                for (int64_t k2 = 0; k2 < h.recv_counts[(size_t)i] && good; ++k2) {
+                    const int64_t pos = h.recv_offsets[(size_t)i] + k2;
+                    const int64_t dof = ridx.empty() ? no + pos : (int64_t)ridx[(size_t)pos];
+                    good = hv2[(size_t)dof] == (double)(h.neighbors[(size_t)i] + 1);
+                }
+        }
+        g_p2p_timeout_ticks = keep_timeout;
+        const int rc3 = p2p_agree(good, "fs_space_enable_p2p_halo", "the self-test of the mapped buffers failed on this rank (sums or ghost values wrong, or a wait timed out)");
+        if (rc3 != FS_OK) {
+            --g_p2p_spaces;
+            pp.release();
+            if (g_p2p_spaces == 0) g_p2p_red.release();
+            return rc3;
+        }
+    }
     return FS_OK;
 }
 

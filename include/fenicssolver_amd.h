@@ -487,6 +487,8 @@ int fs_halo_exchange(fs_space_t space, fs_vector_t v);
  * receiver's kernel waits for the sequence numbers of all its neighbours and fills the ghost entries.  Same place in
  * the iteration as the grouped ncclSend / ncclRecv it replaces (PETSc's VecScatter behind MatMult,
  * SolverBase.py:634 under mpirun), about a third of its latency on MI355X.
+ * The call ends with a self-test of the mapped buffers (an all-reduce and a ghost refresh of known values, 0.5 s time-out)
+ * whose outcome the ranks agree on: FS_ERR_COMM on every rank if any of them saw a wrong or missing value.
  * COLLECTIVE over the communicator: every rank calls it for its space in the same order; enable = 0 turns it off
  * (required before fs_space_set_halo replaces the plan).  FS_ERR_COMM without a communicator. */
 int fs_space_enable_p2p_halo(fs_space_t space, int enable);

@@ -238,7 +238,7 @@ def test_vector_p2_elasticity_under_several_ranks(gpu, tmp_path, world):
     assert np.abs(r["von_mises"] - vm).max() <= 1e-6 * np.abs(vm).max()
 
 
-@pytest.mark.parametrize("p2p", ["works", "openfail", "lost", "late:9"])
+@pytest.mark.parametrize("p2p", ["works", "openfail", "lost", "late:12"])
 def test_bench_under_the_drivers_launcher(gpu, tmp_path, p2p):
     """bench.py exactly as the driver starts it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py
     --gpus N): env rendezvous of the RCCL id through fenicssolver_amd/rendezvous.py (no torch import in bench.py), barrier
@@ -275,8 +275,10 @@ def test_bench_under_the_drivers_launcher(gpu, tmp_path, p2p):
             assert trial["single_reduction+p2p (timed steps)"].startswith("failed")
         assert d["config"]["recurrence"] in ("single_reduction", "pipelined")
     else:
-        assert trial["single_reduction+p2p"].startswith("unavailable" if p2p == "openfail" else "failed"), trial
+        # (openfail: a mapping is refused; lost: the mappings open but nothing arrives - caught by the self-test of
+        # fs_space_enable_p2p_halo, so both end as "unavailable" before any solve runs on the transport)
+        assert trial["single_reduction+p2p"].startswith("unavailable"), trial
         assert d["config"]["recurrence"] in ("single_reduction", "pipelined")
-        assert ("unavailable" if p2p == "openfail" else "failed") in d["strong"]["single_reduction+p2p"]
+        assert "unavailable" in d["strong"]["single_reduction+p2p"]
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src and "from torch" not in src
