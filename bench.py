@@ -337,7 +337,9 @@ def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
     zplanes = partition.slab_ranges(n + 1, world)[rank]
     prob = Problem(n, n, n, (1.0, 1.0, 1.0), zplanes, axis, rank, world)
     res = {"workload": "unit cube n=%d (%d DOF, %d tets) split into %d z-slabs, T=350/300 on the %s-faces" % (n, (n + 1) ** 3, 6 * n ** 3, world, "xyz"[axis]),
-           "anchor": "strong-scaling speed-up = dof_per_s / (roofline.dof_per_s of the N=1 line: the same cube on one GPU)"}
+           "anchor": "strong-scaling speed-up = dof_per_s / (roofline.dof_per_s of the N=1 line: the same cube on one GPU, which runs the "
+                     "row-dictionary product there as the slabs do here; roofline.streaming_kernel.dof_per_s is the same cube with the "
+                     "streaming product)"}
     os.environ.setdefault("FS_P2P_TIMEOUT_MS", "4000")
     done = []
     for name in VARIANTS:
