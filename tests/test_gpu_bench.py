@@ -1,0 +1,54 @@
+"""bench.py on one GPU: the JSON line the driver parses (contract of the task: metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config + roofline + cpu_baseline), for the default command
+and for the side workloads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=900):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_command_prints_the_contract_line(gpu):
+    d = _bench()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["unit"] == "DOF/s" and d["dtype"] == "f64" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["n_dof"] == 1000000 and d["config"]["cg_iterations"] == 293
+    assert d["config"]["true_rel_residual"] <= 1.01e-8
+    assert abs(d["value"] - 1e6 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-3
+    # the BASELINE operator has repeated rows: the line says so and carries the streaming kernel's roofline beside it
+    assert "k_dict_spmv" in r["kernel"] and "note_row_dictionary" in r
+    s = r["streaming_kernel"]
+    assert "k_dia_pair_spmv" in s["kernel"] and 0.5 <= s["frac"] <= 1.0 and s["cg_iterations"] == r["cg_iterations"] == 451
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "DOF/s" and c["sample"]
+    assert d["parity"]["iterations_gpu"] == d["parity"]["iterations_cpu"] and d["parity"]["max_rel_diff_solution"] <= 1e-9
+
+
+@pytest.mark.parametrize("args,expect", [
+    (("--cells", "23", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-case"), "P1 Poisson"),
+    (("--workload", "p2", "--cells", "15", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"), "configs[3]"),
+    (("--cells", "15", "--mesh", "renumbered", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-case"), "RANDOMLY PERMUTED"),
+])
+def test_side_workloads_print_a_line(gpu, args, expect):
+    d = _bench(*args)
+    assert expect in d["config"]["workload"] and d["value"] > 0 and d["config"]["true_rel_residual"] <= 1.1e-8
+    assert "roofline" in d and d["n_gpus"] == 1
