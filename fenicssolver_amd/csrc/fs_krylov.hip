@@ -1439,7 +1439,7 @@ static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
-static int g_cg_graph = -1;      // -1: by size (cache-resident problems, where the launch gaps are ~10 % of an iteration)
+static int g_cg_graph = -1;      // -1: automatic (graphs, unless a profiler's tool library is in the process)
 static int g_update_blocks = 1024;  // (round 3, with the 16 us row-dictionary product at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 10.59 / 10.42 / 10.20 / 10.12 / 11.22 ms per step; 10 M rows: flat)
 static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
 
@@ -2252,7 +2252,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         }
         // (the peer-to-peer iteration is three kernels and no library call, with its sequence numbers on the device: it is captured the
         // same way; the RCCL iteration is not - ncclSend / ncclRecv / ncclAllReduce are host calls)
-        const bool graph_sized = graph_mode > 0 || (graph_mode < 0 && sp->n_slices <= 32768);
+        // (automatic mode: every size - the launch gaps are 10 % of an iteration at 1 M rows and still 1.5 % at 10 M)
+        const bool graph_sized = graph_mode != 0;
         const bool use_graph = ds && !bicg && !pipelined && graph_sized &&
                                ((fuse_sums && !sp->halo.active && bs == 1) || p2p_fuse);
         while (!finished) {

@@ -150,6 +150,66 @@ __global__ void __launch_bounds__(256) k_dict_dots(int64_t n, int ncls, const do
     if (threadIdx.x == 0) { partials[blockIdx.x] = t0; partials[gridDim.x + blockIdx.x] = t1; partials[2 * gridDim.x + blockIdx.x] = t2; }
 }
 
+// F: as E (dictionary + dots + descriptor / offsets from memory), TWO consecutive rows per lane: a wave takes two slices (128 rows),
+// lane l rows 2l, 2l+1; inside a run of consecutive offsets the x value of the second row at offset o is the first row's at o+1
+__global__ void __launch_bounds__(256) k_dict_dots2(int64_t n, int ncls, const double* __restrict__ dict, const uint8_t* __restrict__ cls,
+                                                    const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ dvec,
+                                                    double* __restrict__ partials, const int4* __restrict__ desc, const int32_t* __restrict__ offs) {
+    extern __shared__ double sd[];
+    __shared__ double lds4[4];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (int i = threadIdx.x; i < ncls * 16; i += blockDim.x) sd[i] = dict[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nu = (n + 127) / 128;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nu; q += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int4 ds = desc[__builtin_amdgcn_readfirstlane((int)(2 * q))];
+        const int64_t s = __builtin_amdgcn_readfirstlane(ds.x);
+        const int32_t* op = offs + __builtin_amdgcn_readfirstlane(ds.z);
+        const int64_t r = s * 64 + 2 * lane;
+        const bool live = r + 1 < n;
+        v2d zi = {0.0, 0.0}, ri = {0.0, 0.0};
+        int id0 = 0, id1 = 0;
+        if (live) {
+            zi = *reinterpret_cast<const v2d*>(&x[r]); ri = *reinterpret_cast<const v2d*>(&dvec[r]);
+            const unsigned short two = *reinterpret_cast<const unsigned short*>(&cls[r]);
+            id0 = two & 255; id1 = two >> 8;
+        }
+        const double* v0 = sd + id0 * 16;
+        const double* v1 = sd + id1 * 16;
+        double hi[16], lo[16];
+        bool cont[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int o = op[k];
+            cont[k] = k > 0 && o == op[k - 1] + 1;
+            int64_t c1 = r + o + 1;
+            c1 = c1 < 0 ? 0 : (c1 > n - 1 ? n - 1 : c1);
+            hi[k] = x[c1];
+            if (!cont[k]) {
+                int64_t c0 = r + o;
+                c0 = c0 < 0 ? 0 : (c0 > n - 1 ? n - 1 : c0);
+                lo[k] = x[c0];
+            }
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const double l = cont[k] ? hi[k > 0 ? k - 1 : 0] : lo[k];
+            a0 += v0[k] * l;
+            a1 += v1[k] * hi[k];
+        }
+        if (live) {
+            v2d o2; o2.x = a0; o2.y = a1;
+            *reinterpret_cast<v2d*>(&y[r]) = o2;
+            d0 += zi.x * zi.x + zi.y * zi.y; d1 += a0 * zi.x + a1 * zi.y; d2 += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
+        }
+    }
+    const double t0 = block_sum(d0, lds4), t1 = block_sum(d1, lds4), t2 = block_sum(d2, lds4);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = t0; partials[gridDim.x + blockIdx.x] = t1; partials[2 * gridDim.x + blockIdx.x] = t2; }
+}
+
 int main() {
     const int m = 100;
     const int64_t n = (int64_t)m * m * m;
@@ -184,6 +244,7 @@ int main() {
     const int64_t nsl = (n + 63) / 64;
     std::vector<int> desc(4 * nsl), offs(16, 0);
     for (int k = 0; k < W; ++k) offs[k] = off[k];
+    offs[15] = 0;
     for (int64_t q = 0; q < nsl; ++q) { desc[4 * q] = (int)q; desc[4 * q + 1] = 15; desc[4 * q + 2] = 0; desc[4 * q + 3] = 64; }
     double *d_dict16, *d_dvec, *d_part; int *d_desc, *d_offs;
     CK(hipMalloc(&d_dict16, dict16.size() * 8)); CK(hipMalloc(&d_dvec, n * 8)); CK(hipMalloc(&d_part, 3 * 4096 * 8)); CK(hipMalloc(&d_desc, desc.size() * 4)); CK(hipMalloc(&d_offs, 64 * 4));
@@ -214,6 +275,16 @@ int main() {
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             printf("grid %d  %s %.2f us\n", grid, meta ? "E dictionary + dots + descriptor / offsets from memory" : "D dictionary + fused dots            ", ms * 1e3 / reps);
+        }
+        {
+            for (int i = 0; i < reps + 20; ++i) {
+                if (i == 20) CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_dict_dots2, dim3(grid), dim3(256), ncls * 16 * 8, 0, n, ncls, d_dict16, d_cls, d_x, d_y, d_dvec, d_part, (const int4*)d_desc, d_offs);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<double> yf(n); CK(hipMemcpy(yf.data(), d_y, n * 8, hipMemcpyDeviceToHost));
+            double ef = 0; for (int64_t r = 0; r < n; ++r) ef = std::max(ef, std::fabs(ya[r] - yf[r]));
+            printf("grid %d  F as E, two rows per lane                      %.2f us   max |A - F| %.3g\n", grid, ms * 1e3 / reps, ef);
         }
         double eb = 0, ec = 0;
         for (int64_t r = 0; r < n; ++r) { eb = std::max(eb, std::fabs(ya[r] - yb[r])); ec = std::max(ec, std::fabs(ya[r] - yc[r])); }
