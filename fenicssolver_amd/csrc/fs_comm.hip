@@ -425,21 +425,26 @@ static int p2p_reduce_setup() {
     if (R.enabled) return FS_OK;
     const int nr = rt.n_ranks;
     FS_REQUIRE(nr <= 64, "peer-to-peer all-reduce: %d ranks, at most 64", nr);
-    FS_HIP(hipExtMallocWithFlags((void**)&R.buf, (size_t)(2 * nr * 8) * sizeof(double), hipDeviceMallocFinegrained));
-    FS_HIP(hipExtMallocWithFlags((void**)&R.flags, (size_t)(2 * nr) * sizeof(unsigned long long), hipDeviceMallocFinegrained));
-    FS_HIP(hipMemset(R.buf, 0, (size_t)(2 * nr * 8) * sizeof(double)));
-    FS_HIP(hipMemset(R.flags, 0, (size_t)(2 * nr) * sizeof(unsigned long long)));
-    FS_HIP(hipDeviceSynchronize());
+    // (a step that fails on ONE rank - an allocation, hipIpcGetMemHandle without dmabuf IPC - must not make that rank leave before
+    // the collective the others are heading for: every rank reaches the all-gather and the agreement, whatever happened locally)
+    bool ok = hipExtMallocWithFlags((void**)&R.buf, (size_t)(2 * nr * 8) * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess &&
+              hipExtMallocWithFlags((void**)&R.flags, (size_t)(2 * nr) * sizeof(unsigned long long), hipDeviceMallocFinegrained) == hipSuccess &&
+              hipMemset(R.buf, 0, (size_t)(2 * nr * 8) * sizeof(double)) == hipSuccess &&
+              hipMemset(R.flags, 0, (size_t)(2 * nr) * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     hipIpcMemHandle_t hv[2];
-    FS_HIP(hipIpcGetMemHandle(&hv[0], R.buf));
-    FS_HIP(hipIpcGetMemHandle(&hv[1], R.flags));
+    memset(hv, 0, sizeof(hv));
+    ok = ok && hipIpcGetMemHandle(&hv[0], R.buf) == hipSuccess && hipIpcGetMemHandle(&hv[1], R.flags) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
     const int rec_n = 2 * P2P_HANDLE_DOUBLES;
     std::vector<double> rec((size_t)rec_n), all((size_t)rec_n * nr);
     memcpy(rec.data(), hv, sizeof(hv));
     FS_CHECK(fs_comm_allgather(rec.data(), rec_n, rec_n, all.data()));
     std::vector<double*> pb((size_t)nr);
     std::vector<unsigned long long*> pf((size_t)nr);
-    bool ok = true;
+    if (p2p_agree(ok, "peer-to-peer all-reduce", "the buffers could not be allocated or exported (hipIpcGetMemHandle)") != FS_OK) {
+        R.release();
+        return FS_ERR_COMM;
+    }
     for (int r = 0; r < nr && ok; ++r) {
         if (r == rt.rank) { pb[(size_t)r] = R.buf; pf[(size_t)r] = R.flags; continue; }
         hipIpcMemHandle_t qh[2];
@@ -537,13 +542,16 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
     FS_REQUIRE(nn <= P2P_MAX_NB, "fs_space_enable_p2p_halo: %d neighbours, at most %d", nn, P2P_MAX_NB);
     fs_p2p_halo& pp = h.p2p;
     const int64_t total = std::max<int64_t>(h.total_recv, 1);
-    FS_HIP(hipExtMallocWithFlags((void**)&pp.recv, (size_t)(2 * total) * sizeof(double), hipDeviceMallocFinegrained));
-    FS_HIP(hipExtMallocWithFlags((void**)&pp.flags, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long), hipDeviceMallocFinegrained));
-    FS_HIP(hipMemset(pp.flags, 0, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long)));
-    FS_HIP(hipDeviceSynchronize());
+    // (local failures are carried to the agreement below, never returned before the all-gather: see p2p_reduce_setup)
+    bool ok = hipExtMallocWithFlags((void**)&pp.recv, (size_t)(2 * total) * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess &&
+              hipExtMallocWithFlags((void**)&pp.flags, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long), hipDeviceMallocFinegrained) == hipSuccess &&
+              hipMemset(pp.flags, 0, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long)) == hipSuccess &&
+              hipDeviceSynchronize() == hipSuccess;
+    char why[256] = "";
     hipIpcMemHandle_t hv[2];
-    FS_HIP(hipIpcGetMemHandle(&hv[0], pp.recv));
-    FS_HIP(hipIpcGetMemHandle(&hv[1], pp.flags));
+    memset(hv, 0, sizeof(hv));
+    ok = ok && hipIpcGetMemHandle(&hv[0], pp.recv) == hipSuccess && hipIpcGetMemHandle(&hv[1], pp.flags) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); snprintf(why, sizeof(why), "the receive buffers could not be allocated or exported (hipIpcGetMemHandle)"); }
     std::vector<double> rec((size_t)P2P_REC, 0.0), all((size_t)P2P_REC * rt.n_ranks, 0.0);
     rec[0] = nn; rec[1] = (double)total;
     for (int i = 0; i < nn; ++i) {
@@ -555,8 +563,6 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
     FS_CHECK(fs_comm_allgather(rec.data(), P2P_REC, P2P_REC, all.data()));
     std::vector<fs_p2p_peer> peers((size_t)std::max(nn, 1));
     std::vector<std::pair<double*, unsigned long long*>> mapped((size_t)rt.n_ranks, {nullptr, nullptr});
-    bool ok = true;
-    char why[256] = "";
     int64_t max_send = 0;
     for (int i = 0; i < nn && ok; ++i) {
         const int q = h.neighbors[(size_t)i];
