@@ -371,32 +371,34 @@ class CoupledNavierStokesSolver(SolverBase):
     def viscous_stress(self, up, T_space=None):
         """project(nu (grad u + grad u^T) - p I, TensorFunctionSpace(mesh, 'CG', 1)) (:149-155).  Right-hand sides on the
         device (fs_assemble_viscous_stress), then one CG1 mass-matrix solve per tensor component (Jacobi-CG, 1e-12).
-        Returns a Function on TensorFunctionSpace(mesh, 'CG', 1): node_values() is [num_vertices, 9], row-major."""
+        Returns a Function on TensorFunctionSpace(mesh, 'CG', 1): node_values() is [num_vertices, d * d], row-major
+        (d = 3 on tetrahedra, 2 on triangles)."""
         from . import backend
         from .fem import FunctionSpace, TensorFunctionSpace
         W = up.function_space()
-        if self.dimension != 3:
-            raise SolverError("viscous_stress / boundary_traction / calc_drag_and_lift are built for 3-D flows")
+        d = self.dimension
+        nt = d * d
         if T_space is None:
             T_space = TensorFunctionSpace(self.mesh, 'CG', 1)
-        elif T_space.degree() != 1 or T_space._ncomp != 9:
+        elif T_space.degree() != 1 or T_space._ncomp != nt:
             raise SolverError('viscous_stress: T_space must be TensorFunctionSpace(mesh, "CG", 1)')
         P = W.pressure_space()
         dW, dP = W.device(), P.device()
         nv = self.mesh.num_vertices()
-        loc, ploc = W.localizer(), P.localizer()      # several GPUs: this rank's rows of the nine mass-matrix solves, gathered at the end
+        loc, ploc = W.localizer(), P.localizer()      # several GPUs: this rank's rows of the mass-matrix solves, gathered at the end
         wh = up.vector()._values()
         wd = backend.DeviceVector(dW.n_local, wh if loc is None else loc.nodes(wh))
-        b9 = backend.DeviceVector(9 * dP.n_owned)
-        backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, b9, viscosity_law=self.viscosity_law())
-        rhs = b9.get().reshape(dP.n_owned, 9)
+        bt = backend.DeviceVector(nt * dP.n_owned)
+        backend.assemble_viscous_stress(dW, wd, self.viscosity(), dP, bt, viscosity_law=self.viscosity_law())
+        rhs = bt.get().reshape(dP.n_owned, nt)
         M = backend.DeviceMatrix(dP)
         M.assemble(mass=1.0)
         b, x = backend.DeviceVector(dP.n_owned), backend.DeviceVector(dP.n_local)
-        out = np.zeros((nv, 9))
-        for k in range(9):
-            if k in (3, 6, 7):            # sigma is symmetric: (1,0) (2,0) (2,1) copy (0,1) (0,2) (1,2)
-                out[:, k] = out[:, {3: 1, 6: 2, 7: 5}[k]]
+        out = np.zeros((nv, nt))
+        for k in range(nt):
+            i, j = divmod(k, d)
+            if i > j:                     # sigma is symmetric: the lower triangle copies the upper one
+                out[:, k] = out[:, j * d + i]
                 continue
             b.set(rhs[:, k])
             st = backend.krylov_solve(M, b, x, rtol=1e-12, max_iter=2000, precond="jacobi", norm="preconditioned")
@@ -412,34 +414,40 @@ class CoupledNavierStokesSolver(SolverBase):
         return sigma
 
     def _facet_geometry(self, sel):
-        """(vertex triples [nf,3], outward normal * area [nf,3]) of the boundary facets with indices sel."""
+        """(vertices [nf, d] of the boundary facets with indices sel, outward normal * area (length in 2-D) [nf, d])."""
         mesh = self.mesh
-        tri = mesh.facets()[sel].astype(np.int64)
-        co = mesh.coordinates()
-        X = co[tri]
-        nrm = 0.5 * np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0])
+        d = self.dimension
+        fv = mesh.facets()[sel].astype(np.int64)
+        co = mesh.coordinates()[:, :d]
+        X = co[fv]
+        if d == 3:
+            nrm = 0.5 * np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0])
+        else:
+            t = X[:, 1] - X[:, 0]
+            nrm = np.stack([t[:, 1], -t[:, 0]], axis=1)
         owner = np.full(mesh.num_facets(), -1, dtype=np.int64)
-        owner[mesh.cell_facets().ravel()] = np.repeat(np.arange(mesh.num_cells()), 4)
+        owner[mesh.cell_facets().ravel()] = np.repeat(np.arange(mesh.num_cells()), d + 1)
         inward = np.einsum("fi,fi->f", nrm, X.mean(axis=1) - co[mesh.cells().astype(np.int64)[owner[sel]]].mean(axis=1)) < 0
         nrm[inward] *= -1.0
-        return tri, nrm
+        return fv, nrm
 
     def boundary_traction(self, up, target_space=None):
         """sigma . n on the boundary, as a CG1 vector Function (interior vertices 0): at a boundary vertex the area-weighted
         mean of sigma(vertex) . n over its exterior facets.  (The reference's version, :157-170, calls viscous_stress
         without its second argument and uses undefined index symbols; this is its stated intent: traction = dot(sigma, n).)"""
         from .fem import VectorFunctionSpace
+        d = self.dimension
         V = target_space or VectorFunctionSpace(self.mesh, 'CG', 1)
-        if V.degree() != 1 or V._ncomp != 3:
+        if V.degree() != 1 or V._ncomp != d:
             raise SolverError('boundary_traction: target_space must be VectorFunctionSpace(mesh, "CG", 1)')
-        sig = self.viscous_stress(up).node_values().reshape(-1, 3, 3)
-        tri, nrm = self._facet_geometry(np.nonzero(self.mesh.exterior_facets())[0])
+        sig = self.viscous_stress(up).node_values().reshape(-1, d, d)
+        fv, nrm = self._facet_geometry(np.nonzero(self.mesh.exterior_facets())[0])
         nv = self.mesh.num_vertices()
-        num, den = np.zeros((nv, 3)), np.zeros(nv)
+        num, den = np.zeros((nv, d)), np.zeros(nv)
         area = np.linalg.norm(nrm, axis=1)
-        for k in range(3):
-            np.add.at(num, tri[:, k], np.einsum("fij,fj->fi", sig[tri[:, k]], nrm))
-            np.add.at(den, tri[:, k], area)
+        for k in range(d):
+            np.add.at(num, fv[:, k], np.einsum("fij,fj->fi", sig[fv[:, k]], nrm))
+            np.add.at(den, fv[:, k], area)
         vals = np.zeros_like(num)
         on = den > 0
         vals[on] = num[on] / den[on, None]
@@ -449,10 +457,11 @@ class CoupledNavierStokesSolver(SolverBase):
 
     def calc_drag_and_lift(self, up, drag_axis_index, lift_axis_index, boundary_index_list):
         """(drag, lift) = -int T[axis, j] n_j ds over the listed boundaries (:172-192), T = viscous_stress(up), n outward.
-        With CG1 T the facet integral is area * mean of the three vertex tensors (exact)."""
+        With CG1 T the facet integral is area * mean of the facet's vertex tensors (exact)."""
         if not (boundary_index_list and len(boundary_index_list)):
             raise SolverError('Error: boundary_index_list must be specified to calc drag and lift forces')
-        T = self.viscous_stress(up).node_values().reshape(-1, 3, 3)
-        tri, nrm = self._facet_geometry(np.concatenate([self.boundary_facets.where(i) for i in boundary_index_list]))
-        force = -np.einsum("fij,fj->i", T[tri].mean(axis=1), nrm)
+        d = self.dimension
+        T = self.viscous_stress(up).node_values().reshape(-1, d, d)
+        fv, nrm = self._facet_geometry(np.concatenate([self.boundary_facets.where(i) for i in boundary_index_list]))
+        force = -np.einsum("fij,fj->i", T[fv].mean(axis=1), nrm)
         return float(force[drag_axis_index]), float(force[lift_axis_index])

@@ -2716,6 +2716,61 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
 }
 
 
+// The same on TRIANGLES (2-D Taylor-Hood: block (u_x, u_y, -, p) per CG2 node, cell_dofs [nc][6]): b[row*4 + 2 i + k] = int sigma_ik lambda_row dx,
+// edge-midpoint rule (the integrand is quadratic for a constant viscosity).
+__global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load_tri(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
+                                                                      const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
+                                                                      const double* __restrict__ xyz4, const int32_t* __restrict__ w_dofs,
+                                                                      const double* __restrict__ w, double nu0, double nn_pref, double nn_exp,
+                                                                      double* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; s < n_slices; s += stride) {
+        const int64_t row = s * FS_SLICE + lane;
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        double acc[4] = {0, 0, 0, 0};
+        for (int j = 0; j < iwidth; ++j) {
+            const int32_t q = inc_cell[ibase + (int64_t)j * FS_SLICE + lane];
+            if (q < 0) continue;
+            const int c = q / 3, a = q - 3 * c;
+            const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+            const tri_geom t = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+            double un[6][2], pv[3];
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                const int64_t d = (int64_t)w_dofs[(int64_t)c * 6 + n] * 4;
+                un[n][0] = w[d]; un[n][1] = w[d + 1];
+                if (n < 3) pv[n] = w[d + 3];
+            }
+#pragma unroll
+            for (int qp = 0; qp < 3; ++qp) {         // mid-point of the edge opposite to vertex qp: lambda_qp = 0, the others 1/2
+                double G[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+                for (int n = 0; n < 6; ++n) {
+                    double gn[2];
+                    p2tri_grad_one(t, qp, n, gn);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) G[i][k] += un[n][i] * gn[k];
+                }
+                const double pq = 0.5 * ((qp == 0 ? 0.0 : pv[0]) + (qp == 1 ? 0.0 : pv[1]) + (qp == 2 ? 0.0 : pv[2]));
+                const double nu = nn_pref > 0.0 ? nu0 * pow(pq / nn_pref, nn_exp) : nu0;
+                const double la = t.area * (1.0 / 3.0) * (a == qp ? 0.0 : 0.5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) acc[2 * i + k] += la * (nu * (G[i][k] + G[k][i]) - (i == k ? pq : 0.0));
+            }
+        }
+        if (row < n_rows)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[row * 4 + k] = acc[k];
+    }
+}
+
 // Matrix-free product y = K(form) x on a scalar CG1 space over tetrahedra: the walk of the row-gather assembly with every
 // local row multiplied into x on the fly (north_star's "matrix-free CG").  No Dirichlet rows: callers mask.
 // Measured against the assembled hybrid SELL/DIA product in DESIGN.md section 3 (it re-reads connectivity and
@@ -2777,9 +2832,14 @@ extern "C" int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w,
     FS_REQUIRE(th_space->mesh == p1_space->mesh, "fs_assemble_viscous_stress: the two spaces live on different meshes");
     FS_REQUIRE(th_space->ncomp == 4 && th_space->degree == 2, "fs_assemble_viscous_stress: needs the Taylor-Hood node-block space");
     FS_REQUIRE(p1_space->ncomp == 1 && p1_space->degree == 1 && p1_space->inc_cell.p, "fs_assemble_viscous_stress: the target is the scalar CG1 space of the mesh");
-    FS_REQUIRE(w->d.n >= th_space->n_dofs_local && b->d.n >= 9 * p1_space->n_dofs_owned, "fs_assemble_viscous_stress: vector too short");
-    hipStream_t s = fs_rt().stream;
     fs_mesh_s* m = p1_space->mesh;
+    const int nt = m->tdim * m->tdim;           // tensor components per vertex: 9 (tetrahedra) or 4 (triangles)
+    FS_REQUIRE(w->d.n >= th_space->n_dofs_local && b->d.n >= nt * p1_space->n_dofs_owned, "fs_assemble_viscous_stress: vector too short");
+    hipStream_t s = fs_rt().stream;
+    if (m->tdim == 2)
+        hipLaunchKernelGGL(k_viscous_stress_load_tri, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
+                           p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, nn_pref, nn_exp, b->d.p);
+    else
     hipLaunchKernelGGL(k_viscous_stress_load, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
                        p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, nn_pref, nn_exp, b->d.p);
     FS_KERNEL_CHECK();

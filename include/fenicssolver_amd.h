@@ -255,7 +255,8 @@ int fs_assemble_von_mises(fs_space_t disp_space, fs_vector_t u, double mu, doubl
 /* Right-hand sides of the L2 projection of the fluid stress  nu (grad u + grad u^T) - p I  onto CG1
  * (CoupledNavierStokesSolver.py:149-155, viscous_stress): b[vertex*9 + 3 i + j] = int sigma_ij phi_vertex dx for a
  * Taylor-Hood iterate w (block (u_x,u_y,u_z,p) per CG2 node).  Each of the 9 components is then one CG1 mass-matrix
- * solve (fs_assemble_matrix(mass = 1) on p1_space + fs_krylov_solve). */
+ * solve (fs_assemble_matrix(mass = 1) on p1_space + fs_krylov_solve).  On triangles (2-D Taylor-Hood, third slot of the
+ * block unused): b[vertex*4 + 2 i + j], four components. */
 int fs_assemble_viscous_stress(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b);
 /* The same with nu(p) = nu (p / p_ref)^exponent (fs_ns_form.viscosity_pressure_ref / _exponent). */
 int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w, double nu, fs_space_t p1_space, fs_vector_t b,

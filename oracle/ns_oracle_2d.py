@@ -237,3 +237,46 @@ def newton_solve(th, w_init, bc_dofs, bc_vals, nu, rho=1.0, inv_dt=0.0, w_prev=N
         Jb, gb = apply_dirichlet_rows(J, g.copy(), bc_dofs, bc_vals)
         w = w + relax * (spl.spsolve(Jb.tocsc(), gb) - w)
     raise RuntimeError("Newton did not converge: %r" % history)
+
+
+def viscous_stress_projection(th, w, nu, viscosity_law=None):
+    """project(nu (grad u + grad u^T) - p I, TensorFunctionSpace(mesh, 'CG', 1)) (CoupledNavierStokesSolver.py:149-155) on
+    triangles: consistent P1 mass matrix, loads by the 12-point rule.  Returns sigma [nv, 2, 2]."""
+    W = np.asarray(w, dtype=np.float64).reshape(th.n_nodes, 4)
+    U = W[th.cell_nodes][:, :, :2]
+    Pv = W[th.cells][:, :, 3]
+    be = np.zeros((len(th.cells), 3, 4))
+    pts, wq = tri_quadrature("dunavant12")
+    for lam, wt in zip(pts, wq):
+        lam = np.asarray(lam)
+        _, dphi = fo.tri_p2_shape(lam)
+        gphi = np.einsum("ak,cki->cai", dphi, th.glam)
+        G = np.einsum("cai,caj->cij", U, gphi)
+        pq = Pv @ lam
+        sig = viscosity_at(nu, viscosity_law, pq)[:, None, None] * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(2)
+        be += (wt * th.area)[:, None, None] * lam[None, :, None] * sig.reshape(-1, 1, 4)
+    M = fo.assemble_matrix(th.nv, th.cells, fo.tri_mass_local(th.coords, th.cells, 1.0))
+    out = np.zeros((th.nv, 4))
+    for k in range(4):
+        out[:, k] = fo.solve_direct(M, fo.assemble_generic_vector(th.nv, th.cells, be[:, :, k]))
+    return out.reshape(th.nv, 2, 2)
+
+
+def boundary_force(th, sigma, inside):
+    """-int sigma n ds over the boundary edges whose mid-point satisfies inside(x) (calc_drag_and_lift, :166-183; n the outward
+    normal): with P1 sigma the edge integral is length * mean of the two vertex tensors."""
+    edges, cell_edges, cnt = fo.tri_edge_numbering(th.cells)
+    owner = np.zeros(len(edges), dtype=np.int64)
+    owner[cell_edges.ravel()] = np.repeat(np.arange(len(th.cells)), 3)
+    F = np.zeros(2)
+    for e in np.nonzero(cnt == 1)[0]:
+        ed = edges[e].astype(np.int64)
+        X = th.coords[ed]
+        if not inside(X.mean(axis=0)):
+            continue
+        t = X[1] - X[0]
+        nrm = np.array([t[1], -t[0]])
+        if nrm @ (X.mean(axis=0) - th.coords[th.cells[owner[e]]].mean(axis=0)) < 0:
+            nrm = -nrm
+        F -= sigma[ed].mean(axis=0) @ nrm
+    return F

@@ -310,3 +310,40 @@ def test_coupled_temperature_2d_as_the_reference_example_runs_it(gpu):
     alone = ScalarTransportSolver(ts)
     Ta = alone.solve().vector().get_local()
     assert np.abs(Ta - Tv).max() <= 1e-7 * 350.0
+
+
+def test_stress_post_processing_2d(gpu):
+    """viscous_stress / boundary_traction / calc_drag_and_lift on triangles (CoupledNavierStokesSolver.py:149-192).  On the
+    Poiseuille channel the stress is linear in x - sigma_xy = 4 nu (1 - 2x), sigma_xx = sigma_yy = -p - so its CG1 projection is
+    exact, the walls carry 4 nu each along the flow, and an arbitrary Taylor-Hood field must match the oracle's projection."""
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    from fenicssolver_amd.fem import Function
+    nu = 0.3
+    solver = CoupledNavierStokesSolver(_channel_settings(nu=nu))
+    w = solver.solve()
+    co = solver.mesh.coordinates()[:, :2]
+    sig = solver.viscous_stress(w).node_values().reshape(-1, 2, 2)
+    p = 8.0 * nu * (1.0 - co[:, 1])
+    assert np.abs(sig[:, 0, 1] - 4.0 * nu * (1.0 - 2.0 * co[:, 0])).max() <= 1e-6
+    assert np.abs(sig[:, 1, 0] - sig[:, 0, 1]).max() == 0.0
+    assert np.abs(sig[:, 0, 0] + p).max() <= 1e-5 and np.abs(sig[:, 1, 1] + p).max() <= 1e-5
+    drag, lift = solver.calc_drag_and_lift(w, 1, 0, [1])            # walls (boundary_id 1): along the flow, across it
+    assert abs(drag - 8.0 * nu) <= 1e-6
+    # across the flow the two walls carry the pressure with opposite signs: int p dy over x = 0 minus over x = 1
+    assert abs(lift) <= 1e-6
+    t = solver.boundary_traction(w).vector().get_local().reshape(-1, 2)
+    left = np.nonzero((co[:, 0] == 0.0) & (co[:, 1] > 0.0) & (co[:, 1] < 1.0))[0]
+    assert np.abs(t[left, 1] + 4.0 * nu).max() <= 1e-6            # sigma . n with n = (-1, 0): (-sigma_xx, -sigma_yx)
+    # an arbitrary field against the oracle's projection (and its force integral)
+    th = ns.TaylorHood2D(solver.mesh.coordinates(), solver.mesh.cells())
+    rng = np.random.default_rng(11)
+    wr = Function(solver.function_space)
+    vals = rng.standard_normal(th.n)
+    vals[th.dummy_dofs()] = 0.0
+    wr.vector().set_local(vals)
+    s_dev = solver.viscous_stress(wr).node_values().reshape(-1, 2, 2)
+    s_ora = ns.viscous_stress_projection(th, vals, nu)
+    assert np.abs(s_dev - s_ora).max() <= 1e-9 * np.abs(s_ora).max()
+    F = ns.boundary_force(th, s_ora, lambda x: x[0] == 0.0 or x[0] == 1.0)
+    d2, l2 = solver.calc_drag_and_lift(wr, 1, 0, [1])
+    assert abs(d2 - F[1]) <= 1e-8 * np.abs(F).max() and abs(l2 - F[0]) <= 1e-8 * np.abs(F).max()
