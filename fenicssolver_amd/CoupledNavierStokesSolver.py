@@ -29,7 +29,7 @@ then returns (u, p, T) as the reference's MixedElement([V, Q, Q]) does.
 2-D (triangles; the reference's own CFD example runs on UnitSquareMesh(40, 100), examples/test_cfd_solver.py:83): the same
 block layout with a dummy third velocity slot (mixed.py), 6-node element kernel with Radon's 7-point rule, edge integrals of
 the pressure boundaries, the same FGMRES / block preconditioner; G2, ALE, the non-Newtonian law and solving_temperature
-included, the stress post-processing (viscous_stress, drag / lift) is 3-D only.
+and the stress post-processing (viscous_stress, boundary_traction, drag / lift) included.
 Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
 velocities, a viscosity depending on the temperature.
 """
