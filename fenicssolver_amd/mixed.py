@@ -35,8 +35,6 @@ class TaylorHoodSpace(FunctionSpace):
         # periodic_boundary (CoupledNavierStokesSolver.py:97-100): vertex and edge nodes of the slave side are tied to the
         # master side, all four unknowns of a node together; the pressure space carries the same constraint
         self._constrained_domain = constrained_domain
-        if constrained_domain is not None and self._gdim == 2:
-            raise SolverError("periodic_boundary on the 2-D velocity-pressure space is not built")
         self._periodic = None if constrained_domain is None else periodic_vertex_pairs(mesh, constrained_domain)
         FunctionSpace._next_serial += 1
         self._serial = FunctionSpace._next_serial

@@ -374,3 +374,59 @@ def test_taylor_hood_fold_and_periodic_channel(gpu):
         s2, m2 = Ws.periodic_pairs()
         a = solver.w_current.vector().array().reshape(-1, 4)
         assert np.array_equal(a[s2], a[m2])
+
+
+def test_taylor_hood_periodic_channel_2d(gpu):
+    """The same on triangles (block layout with the dummy third velocity slot): the folded system equals the oracle's fold, and
+    the body-force driven channel periodic in x lands on u = (y (1 - y), 0), p = 0."""
+    import copy
+    from oracle import ns_oracle_2d as ns2
+    from fenicssolver_amd.fem import UnitSquareMesh, AutoSubDomain, Constant, Expression, near
+    from fenicssolver_amd.mixed import TaylorHoodSpace
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    mesh = UnitSquareMesh(4, 5)
+    W = TaylorHoodSpace(mesh, "CG", 1, constrained_domain=_periodic_x())
+    sl, ma = W.periodic_pairs()
+    X = W.node_coordinates()
+    assert len(sl) == 11 and np.allclose(X[sl, 0], 1.0) and np.allclose(X[ma, 0], 0.0) and np.allclose(X[sl, 1], X[ma, 1])
+    th = ns2.TaylorHood2D(mesh.coordinates(), mesh.cells())
+    dW = W.device()
+    rng = np.random.default_rng(18)
+    w0 = 0.3 * rng.standard_normal(th.n)
+    w0[th.dummy_dofs()] = 0.0
+    J, g = gpu.DeviceMatrix(dW), gpu.DeviceVector(dW.n_owned)
+    gpu.assemble_navier_stokes(J, g, gpu.DeviceVector(dW.n_local, w0), None, nu=0.07, rho=1.3, body_force=(0.2, -1.0, 0.0))
+    J.tie_nodes(g, sl, ma)
+    Jr, gr = ns2.ns_system(th, w0, 0.07, 1.3, 0.0, None, (0.2, -1.0))
+    Jf, gf = fo.periodic_fold(Jr, gr, sl, ma, 4)
+    dd = th.dummy_dofs()                 # unit rows on the device (the fold would make them 2 on the masters)
+    Jf = Jf.tolil()
+    Jf[dd, dd] = 1.0
+    Jf = Jf.tocsr()
+    assert abs(_csr(J) - Jf).max() <= 1e-11 * abs(Jr).max()
+    assert np.abs(g.get() - gf).max() <= 1e-11 * np.abs(gr).max()
+
+    nu = 0.3
+    bcs = OrderedDict()
+    bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[1], 0) or near(x[1], 1))), 'boundary_id': 1,
+                    'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0))}]}
+    s = copy.deepcopy(SB.default_case_settings)
+    s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': UnitSquareMesh(4, 5), 'fe_degree': 1, 'boundary_conditions': bcs,
+              'periodic_boundary': _periodic_x(), 'body_source': Constant((2 * nu, 0.0)),
+              'initial_values': {'velocity': (0, 0), 'pressure': 0}, 'material': {'density': 1.0, 'kinematic_viscosity': nu}})
+    s['solver_settings']['reference_values'] = {'velocity': (1, 1), 'pressure': 0}
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-11,
+                                                 'newton_solver': {'relative_tolerance': 1e-12, 'absolute_tolerance': 1e-13}}
+    s['report_settings'] = dict(QUIET)
+    solver = CoupledNavierStokesSolver(s)
+    solver.solve()
+    Ws = solver.function_space
+    u, p = solver.split()
+    Xn = Ws.node_coordinates()
+    U = u.node_values()
+    assert np.abs(U[:, 0] - Xn[:, 1] * (1 - Xn[:, 1])).max() <= 1e-8 and np.abs(U[:, 1]).max() <= 1e-8
+    assert np.abs(p.vector().array()).max() <= 1e-7
+    s2, m2 = Ws.periodic_pairs()
+    a = solver.w_current.vector().array().reshape(-1, 4)
+    assert np.array_equal(a[s2], a[m2])
