@@ -1062,20 +1062,22 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
 }
 
 // ---- the exchange kernel of the peer-to-peer iteration (fs_comm.hip: hipIpc-mapped buffers; protocol in fs_kernels.h) -----------
-// Everything of a CG iteration that crosses GPUs, in ONE launch between the product and the update:
-//   1. every workgroup sums the product's dot partials itself (same bits everywhere); workgroup 0 stores the three sums into slot
-//      [me] of the other ranks' all-reduce buffers; every workgroup waits for the other ranks' sums and adds all up in rank order;
-//      workgroup 0 leaves the result in `sums` for the update kernel that follows;
-//   2. the NEW residual of every row some neighbour needs, r - alpha (w + beta s), is computed (not stored here: the update
-//      kernel computes the same number with the same operations a moment later) and stored straight into that neighbour's
-//      receive buffer; the last workgroup through publishes the sequence number of the exchange at every neighbour;
-//   3. every workgroup waits for the neighbours' sequence numbers and moves its share of the own receive buffer to the ghost
-//      entries of r.  (No workgroup waits before its own stores are counted, so two ranks never wait for each other.)
-// Any halo plan (send lists need not be contiguous, ghosts may be scattered), any block size: rows are dofs here.  Gated by the
-// status word and by the same convergence test as the update kernel: every rank stops sending and waiting at the same iteration.
+// Everything of a CG iteration that crosses GPUs, in ONE launch between the product and the update.  What travels is w = A r on
+// the rows some neighbour needs - known as soon as the product is through, with no dependence on the sums - and NOT the new
+// residual: a rank advances the ghost copies of r and s itself (s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g are row-local and it
+// knows alpha, beta), with the operations the owner's update kernel applies to the same rows.
+//   1. every workgroup stores its share of w[send rows] straight into the neighbours' receive buffers, the last one through
+//      publishes the sequence number of the exchange at every neighbour;
+//   2. (meanwhile on the wire) every workgroup sums the product's dot partials itself (same bits everywhere); workgroup 0
+//      stores the three sums into slot [me] of the other ranks' all-reduce buffers; every workgroup waits for the other ranks'
+//      sums and adds all up in rank order; workgroup 0 leaves the result in `sums` for the update kernel that follows;
+//   3. every workgroup waits for the neighbours' sequence numbers and advances its share of the ghost rows with the received w.
+// (No workgroup waits before its own stores are counted, so two ranks never wait for each other.)  Any halo plan (send lists
+// need not be contiguous, ghosts may be scattered), any block size: rows are dofs here.  Gated by the status word; steps 1 and
+// 2 always run together, step 3 only if the iteration goes on - decided from the reduced sums, hence alike on every rank.
 __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int check_only, const double* __restrict__ ctrl,
                                                               const double* __restrict__ scal, const int* __restrict__ status,
-                                                              double* r, const double* __restrict__ w, const double* __restrict__ sv,
+                                                              double* r, const double* __restrict__ w, double* __restrict__ s_ghost,
                                                               const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
     if (status[0] != 0) return;
     if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
@@ -1086,18 +1088,30 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     // advanced by the last workgroup through each part
     const unsigned long long rseq = *red.d_seq + 1ull, hseq = *snd.d_seq + 1ull;
     const int rslot = (int)(rseq & 1ull), hslot = (int)(hseq & 1ull);
-    // the operands of this thread's first entry are requested before the sums are reduced and exchanged: their latency hides there
     const int64_t e_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int32_t i_f = 0;
-    double r_f = 0.0, w_f = 0.0, s_f = 0.0;
-    if (e_first < snd.total_send) {
-        i_f = snd.send_idx[e_first];
-        r_f = r[i_f]; w_f = w[i_f]; s_f = sv[i_f];
+    const int t = threadIdx.x;
+    // 1. w on the interface rows -> the neighbours
+    for (int64_t e = e_first; e < snd.total_send; e += stride) {
+        const double wv = w[snd.send_idx[e]];
+        int j = 0;
+        while (j + 1 < snd.nn && e >= snd.peers[j + 1].send_offset) ++j;
+        const fs_p2p_peer q = snd.peers[j];
+        fs_p2p_store(q.recv + (int64_t)hslot * q.peer_total + q.recv_offset + (e - q.send_offset), wv);
     }
+    fs_p2p_stores_done();
+    __syncthreads();
+    if (t == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(snd.d_seq, hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < snd.nn; ++j) {
+            const fs_p2p_peer q = snd.peers[j];
+            fs_p2p_publish(q.flags + (int64_t)hslot * q.peer_nn + q.peer_slot, hseq);
+        }
+    }
+    // 2. the sums of all ranks
     double sm[3];
     wg_sum_partials<3>(red.partials, red.npart, sm);
-    const int t = threadIdx.x;
     if (blockIdx.x == 0 && t < red.nr && t != red.me) {
         double* dst = red.peer_buf[t] + ((int64_t)rslot * red.nr + red.me) * 8;
         fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
@@ -1131,33 +1145,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
         alpha = gamma / (delta - beta * gamma / alpha_old);
     }
     if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) return;
-    for (int64_t e = e_first; e < snd.total_send; e += stride) {
-        if (e != e_first) {
-            i_f = snd.send_idx[e];
-            r_f = r[i_f]; w_f = w[i_f]; s_f = sv[i_f];
-        }
-        const double ss = w_f + beta * s_f;             // (the two lines of the update kernel)
-        const double rn = r_f - alpha * ss;
-        int j = 0;
-        while (j + 1 < snd.nn && e >= snd.peers[j + 1].send_offset) ++j;
-        const fs_p2p_peer q = snd.peers[j];
-        fs_p2p_store(q.recv + (int64_t)hslot * q.peer_total + q.recv_offset + (e - q.send_offset), rn);
-    }
-    fs_p2p_stores_done();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
-        __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(snd.d_seq, hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int j = 0; j < snd.nn; ++j) {
-            const fs_p2p_peer q = snd.peers[j];
-            fs_p2p_publish(q.flags + (int64_t)hslot * q.peer_nn + q.peer_slot, hseq);
-        }
-    }
+    // 3. ghost rows: s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g (the two lines of the update kernel)
     if (t < snd.nn) fs_p2p_wait(snd.own_flags + (int64_t)hslot * snd.nn + t, hseq, snd.timeout, snd.err);
     __syncthreads();
     const double* own_recv = snd.own_recv + (int64_t)hslot * snd.recv_stride;
-    for (int64_t k = e_first; k < snd.total_recv; k += stride)
-        r[snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k] = fs_p2p_load(own_recv + k);
+    for (int64_t k = e_first; k < snd.total_recv; k += stride) {
+        const int64_t gi = snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k;
+        const double ss = fs_p2p_load(own_recv + k) + beta * s_ghost[k];
+        s_ghost[k] = ss;
+        r[gi] -= alpha * ss;
+    }
 }
 
 // ---- pipelined CG (Ghysels & Vanroose, Parallel Computing 40 (2014)) on the scaled system --------------------------
@@ -1937,6 +1934,7 @@ struct krylov_ws {
     std::vector<double> last_hist;
     // one batch of CG iterations captured as a hipGraph (same arguments every iteration: the update kernel reads its
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
+    dbuf<double> sg;            // s on the ghost rows, in arrival order (peer-to-peer iteration: a rank advances its ghost r, s itself)
     hipGraphExec_t cg_graph = nullptr;
     const void* cg_key[20] = {};
     int64_t cg_key_i[8] = {};
@@ -2114,6 +2112,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_CHECK(ws.scal.zero(s));
         FS_CHECK(ws.p.zero(s));
         FS_CHECK(ws.s.zero(s));
+        if (sp->halo.active) {          // s on the ghost rows (k_cg_p2p_exchange)
+            if (ws.sg.n < nl - n + 2) FS_CHECK(ws.sg.alloc(nl - n + 2));
+            FS_CHECK(ws.sg.zero(s));
+        }
         FS_CHECK(ws.z.zero(s));
         if (ds) {
             // scaled unknown xhat = D^1/2 x lives in the caller's x until the final un-scaling; rhat in ws.z
@@ -2271,7 +2273,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 const void* key[20] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
                                        ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf,
                                        dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
-                                       dict_on ? (const void*)sp->slice_desc.p : nullptr, nullptr};
+                                       dict_on ? (const void*)sp->slice_desc.p : nullptr, p2p_fuse ? (const void*)ws.sg.p : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,
@@ -2288,7 +2290,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
                             const int64_t work = std::max(snd.total_send, snd.total_recv);
                             hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
-                                               -1, 0, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.s.p, red, snd);
+                                               -1, 0, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd);
                             if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                             else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                             continue;
@@ -2406,7 +2408,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                     const int64_t work = std::max(snd.total_send, snd.total_recv);
                     hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
-                                       k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.s.p, red, snd);
+                                       k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd);
                     if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     if (sample) {
