@@ -130,6 +130,7 @@ SIGNATURES = {
     "fs_krylov_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
     "fs_krylov_history": (C.c_int, [c_f64p, C.c_int, C.POINTER(C.c_int)]),
     "fs_spmv_benchmark": (C.c_int, [_H, _H, _H, C.c_int, c_f64p]),
+    "fs_spmv_dictionary": (C.c_int, [_H, _H, _H, C.POINTER(C.c_int)]),
     "fs_amg_setup": (C.c_int, [_H, C.c_int, c_f64p, C.POINTER(fs_amg_opts), C.POINTER(_H)]),
     "fs_amg_destroy": (C.c_int, [_H]),
     "fs_amg_info": (C.c_int, [_H, C.POINTER(C.c_int), c_f64p, c_f64p, c_f64p]),

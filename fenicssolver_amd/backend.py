@@ -375,6 +375,12 @@ class DeviceMatrix(_Handle):
     def spmv(self, x, y):
         L.check(L.load().fs_spmv(self.h, x.h, y.h), "fs_spmv")
 
+    def spmv_dictionary(self, x, y):
+        """y = A x through the row-dictionary product where the rows repeat; returns the number of distinct rows used (0: streaming)."""
+        nc = C.c_int(0)
+        L.check(L.load().fs_spmv_dictionary(self.h, x.h, y.h, C.byref(nc)), "fs_spmv_dictionary")
+        return nc.value
+
     def spmv_benchmark(self, x, y, reps=20):
         ms = C.c_double(0.0)
         L.check(L.load().fs_spmv_benchmark(self.h, x.h, y.h, int(reps), C.byref(ms)), "fs_spmv_benchmark")

@@ -63,8 +63,11 @@ __device__ __forceinline__ tet_geom tet_geometry_snapped(const double (&x0)[3], 
     return tet_geometry_e(e1, e2, e3);
 }
 __device__ __forceinline__ tet_geom tet_geometry_box(const double* __restrict__ xyz4, const int32_t (&v)[4], const box_snap& bx);
+static int g_box_snap = -1;          // -1: not set (environment FS_BOX_SNAP, default on)
+void fs_set_box_snap(bool on) { g_box_snap = on; }
 static box_snap make_box_snap(const fs_mesh_s* m) {
-    static const bool off = getenv("FS_BOX_SNAP") && getenv("FS_BOX_SNAP")[0] == '0';
+    static const bool env_off = getenv("FS_BOX_SNAP") && getenv("FS_BOX_SNAP")[0] == '0';
+    const bool off = g_box_snap < 0 ? env_off : g_box_snap == 0;
     box_snap b;
     for (int d = 0; d < 3; ++d) {
         const bool on = !off && m->tdim == 3 && m->box_h[0] > 0.0 && m->box_h[1] > 0.0 && m->box_h[2] > 0.0;

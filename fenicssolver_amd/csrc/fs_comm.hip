@@ -755,8 +755,9 @@ static int build_slice_split(fs_space_s* sp) {
     hipStream_t s = fs_rt().stream;
     h.interior.release();
     h.boundary.release();
-    h.desc_interior.release();
-    h.desc_boundary.release();
+    h.items_interior.release();
+    h.items_boundary.release();
+    h.n_items_interior = h.n_items_boundary = -1;
     h.n_interior = h.n_boundary = 0;
     const int64_t ns = sp->n_slices;
     if (ns == 0) return FS_OK;

@@ -190,7 +190,8 @@ struct fs_halo_plan {
     int fuse = 0;                          // 1: every rank can run the fused peer-to-peer iteration (agreed with `early`)
     // slices (in processing order) without / with ghost columns
     dbuf<int32_t> interior, boundary;
-    dbuf<int32_t> desc_interior, desc_boundary;     // slice descriptors of the two lists for the row-dictionary product (built on first use)
+    dbuf<int32_t> items_interior, items_boundary;   // work items of the two lists for the row-dictionary product (fs_space_s::dict_items)
+    int64_t n_items_interior = -1, n_items_boundary = -1;      // -1: not built yet
     int64_t n_interior = 0, n_boundary = 0;
     ~fs_halo_plan() {
         if (ev_ready) (void)hipEventDestroy(ev_ready);
@@ -246,8 +247,13 @@ struct fs_space_s {
                                   // rows [split, 64) of a SPLIT slice use list B (fs_symbolic.hip, k_slice_analyze)
     // two-rows-per-lane product (k_dia_pair_spmv): pairs of slices, consecutive in processing order, both complete DIA
     // slices with identical offset lists; pair_singles = every other slice, in processing order.  Built on first use.
-    dbuf<int32_t> slice_desc;     // [n_slices][4], processing order: (slice, width, dia_ptr, split) - one 16-byte scalar load per
-                                  // slice for the row-dictionary product (fs_krylov.hip); built on first use
+    // row-dictionary product (fs_krylov.hip, k_dict_pair_spmv): work items in processing order, one 16-byte scalar load each -
+    //   pair of consecutive complete DIA slices with one offset list, every access in range: (first slice, -rounds, first plan round, 0)
+    //   single slice:                                                                          (slice, width, dia_ptr, split)
+    // dict_plans: run plans of the distinct offset lists, 16 ints per round (fs_krylov.hip, dict_plan_round).  Built on first use.
+    dbuf<int32_t> dict_items;     // [n_dict_items][4]
+    dbuf<int32_t> dict_plans;
+    int64_t n_dict_items = -1;    // -1: not built yet
     dbuf<int32_t> pair_list;      // [2 * n_pairs]
     dbuf<int32_t> pair_singles;   // [n_pair_singles]
     int64_t n_pairs = -1, n_pair_singles = 0;      // -1: not built yet
@@ -295,6 +301,8 @@ static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int 
 }
 
 // ---- cross-TU internals ------------------------------------------------------------------
+// fs_assemble.hip: box meshes snap their edge vectors to the grid spacing (fs_set_option "box_snap", FS_BOX_SNAP=0: off)
+void fs_set_box_snap(bool on);
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
 // sums over all ranks of the per-workgroup partials [nv][npart] (the k_sum_partials order) -> out[nv]: one kernel when the

@@ -501,25 +501,41 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_rows, int64_
     if (bad) atomicAdd(&info[2], bad);
 }
 
-__global__ void k_slice_desc(int64_t n_slices, const int32_t* __restrict__ order, const int64_t* __restrict__ slice_ptr,
-                             const int32_t* __restrict__ dia_ptr, const int32_t* __restrict__ dia_off, int32_t* __restrict__ desc) {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; q < n_slices; q += stride) {
-        const int32_t s = order ? order[q] : (int32_t)q;
-        const int32_t dp = dia_ptr[s];
-        desc[4 * q + 0] = s;
-        desc[4 * q + 1] = (int32_t)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
-        desc[4 * q + 2] = dp;
-        desc[4 * q + 3] = dp >= 0 ? dia_off[dp] : FS_SLICE;
-    }
+// ---- the product: pairs of slices, two rows per lane, runs of consecutive offsets -----------------------------------------------
+// Round 3 (one row per lane, 16 clamped 8-byte gathers + class + z + d = 19 vector-memory instructions per row) ran at 0.27 of the
+// HBM peak on the 26 bytes a row has to move: the per-CU address path was the limit, as for the streaming kernels.  This form
+// issues 3.5 such instructions per row.  A wave takes a PAIR of consecutive complete DIA slices that share one offset list (128
+// rows, lane l rows 2l and 2l + 1).  The offset list is cut into RUNS of up to three consecutive offsets (o, o + 1, o + 2; the
+// Kuhn stencil: 7 runs for 15 offsets); for a run starting at o the two rows of a lane need x[r + o .. r + o + 3]: ONE 16-byte load
+// x[r + o], x[r + o + 1] per lane, the other two values are the NEXT lane's load (DPP wave shift, no LDS), and lane 63's come
+// from one 16-byte scalar load x[base + 128 + o ..] (the scalar data cache is invalidated at every kernel boundary like the vector
+// L1; the bit-for-bit comparisons with the streaming product over hundreds of dependent iterations would show a stale line).
+// A `run plan` per distinct offset list says, per round of 8 runs, where each run starts and which position of the class row
+// holds its three coefficients (the zero slot W - 1 past its length) - so the summation order is the streaming kernels' (ascending
+// position, one fma each; the extra terms add +0 * x).  Slot 7 of round 0 is the run (0; no coefficients): its load IS z = x[r],
+// x[r + 1] for the fused dots.  Pairs whose loads could leave [0, n_cols) (first / last mesh plane), split slices and slices without
+// a partner go through the one-row-per-lane code as single items.  Measured (tools/probes/dict_pair_probe.hip, 10 M rows):
+// 116 -> 62 us = 4.2 TB/s on 26 B/row; bpermute instead of DPP 80 us; dictionary re-laid out in plan order, descriptor
+// prefetch, one coefficient set when both rows share a class: 61-63 us (not kept).
+struct dict_plan_round {
+    int32_t start[8];
+    uint8_t kidx[8][4];
+};
+static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round");
+
+// the next lane's value; lane 63 takes `tail` (wave_shl:1 leaves the destination of a lane without a source untouched)
+__device__ __forceinline__ double fs_from_next_lane(double v, double tail) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(tail), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(tail), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 
 // LDSD: the dictionary fits LDS (P1: 86 rows of 16); otherwise (CG2: 492 rows of 80 = 315 KB) it is read from memory - it
 // stays in L2, and the lanes of a wave mostly ask for the same class, so that a load is one broadcast line
 template <int DOTS, bool LDSD>
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
-                                                        const int4* __restrict__ desc, const int32_t* __restrict__ dia_off,
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t n_cols, int64_t n_items,
+                                                        const int4* __restrict__ items, const int32_t* __restrict__ dia_off,
+                                                        const dict_plan_round* __restrict__ plans,
                                                         const uint16_t* __restrict__ cls,
                                                         const double* __restrict__ dict, int ncls, int W,
                                                         const double* __restrict__ x, double* __restrict__ y,
@@ -529,6 +545,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
         if (status[0] != 0) return;
         if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
     }
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
     extern __shared__ double sdict[];
     if (LDSD) {
         for (int i = threadIdx.x; i < ncls * W; i += FS_BLOCK) sdict[i] = dict[i];
@@ -538,18 +556,63 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    const int64_t n_chunks = (n_slices + 3) >> 2;
+    const int64_t n_chunks = (n_items + 3) >> 2;
     const int32_t cmax = (int32_t)(n_cols - 1);
-    // (bound by dependent round trips per wave, not by bytes: everything a slice needs beyond x comes with ONE scalar load of its
-    // descriptor, and all x values of a round of 16 entries go out together)
     const int64_t n_waves = ((int64_t)gridDim.x * FS_BLOCK) >> 6;
     chunk_iter it = xcd_chunks(n_chunks);
-    int64_t q = map_xcd ? (it.cur < it.end ? it.cur * 4 + wave : n_slices) : (((int64_t)blockIdx.x * FS_BLOCK + threadIdx.x) >> 6);
-    while (q < n_slices) {
-        {
-            const int4 ds = desc[__builtin_amdgcn_readfirstlane((int)q)];
-            const int width = __builtin_amdgcn_readfirstlane(ds.y);
-            const int32_t r = __builtin_amdgcn_readfirstlane(ds.x) * FS_SLICE + lane;
+    int64_t q = map_xcd ? (it.cur < it.end ? it.cur * 4 + wave : n_items) : (((int64_t)blockIdx.x * FS_BLOCK + threadIdx.x) >> 6);
+    const double* __restrict__ dbase = LDSD ? sdict : dict;
+    while (q < n_items) {
+        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
+        const int32_t sl = __builtin_amdgcn_readfirstlane(ds.x);
+        const int rounds = -__builtin_amdgcn_readfirstlane(ds.y);
+        if (rounds > 0) {
+            // ---- a pair of slices, two rows per lane ----
+            const int32_t base = sl * FS_SLICE;
+            const int32_t r = base + 2 * lane;
+            const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
+            v2d ri = {0.0, 0.0}, zi = {0.0, 0.0};
+            if (DOTS && DOTS != 4) ri = *reinterpret_cast<const v2d*>(&rvec[r]);
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
+            const double* __restrict__ v0 = dbase + (int)(two & 0xffffu) * W;
+            const double* __restrict__ v1 = dbase + (int)(two >> 16) * W;
+            const double* __restrict__ xr = x + r;
+            const double* __restrict__ xt = x + base + 2 * FS_SLICE;
+            double a0 = 0.0, a1 = 0.0;
+            for (int rd = 0; rd < rounds; ++rd) {
+                const dict_plan_round* __restrict__ p = pl + rd;
+                v2d A[8], T[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int32_t st = p->start[j];
+                    A[j] = *reinterpret_cast<const v2du*>(xr + st);
+                    T[j] = *reinterpret_cast<const v2du*>(xt + st);       // wave-uniform address: a scalar load
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double e0 = A[j].x, e1 = A[j].y;
+                    const double e2 = fs_from_next_lane(A[j].x, T[j].x), e3 = fs_from_next_lane(A[j].y, T[j].y);
+                    const int k0 = p->kidx[j][0], k1 = p->kidx[j][1], k2 = p->kidx[j][2];
+                    a0 = fma(v0[k0], e0, a0); a1 = fma(v1[k0], e1, a1);
+                    a0 = fma(v0[k1], e1, a0); a1 = fma(v1[k1], e2, a1);
+                    a0 = fma(v0[k2], e2, a0); a1 = fma(v1[k2], e3, a1);
+                }
+                if (rd == 0) zi = A[7];
+            }
+            v2d out;
+            out.x = a0; out.y = a1;
+            *reinterpret_cast<v2d*>(&y[r]) = out;
+            if (DOTS == 1) {
+                d_rz += ri.x * zi.x + ri.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * ri.x + ri.y * ri.y;
+            } else if (DOTS == 2) {
+                d_rz += a0 * ri.x + a1 * ri.y; d_wz += a0 * a0 + a1 * a1; d_rr += ri.x * ri.x + ri.y * ri.y;
+            } else if (DOTS == 3) {
+                d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
+            }
+        } else {
+            // ---- a single slice, one row per lane (round 3) ----
+            const int width = -rounds;
+            const int32_t r = sl * FS_SLICE + lane;
             const bool live = r < n_rows;
             const int split = __builtin_amdgcn_readfirstlane(ds.w);
             const int32_t* __restrict__ op = dia_off + __builtin_amdgcn_readfirstlane(ds.z) + 1;
@@ -560,7 +623,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
                 if (DOTS == 1 || DOTS == 3) zi = x[r];
                 ri = rvec[r];
             }
-            const double* __restrict__ vp = (LDSD ? sdict : dict) + (int)cls[r] * W;
+            const double* __restrict__ vp = dbase + (int)cls[r] * W;
             double acc = 0.0;
             // rounds of 16 entries WITHOUT a guard (a guarded load makes the compiler wait for the previous one): positions past
             // the slice's width read whatever follows in the offset array (the address is clamped into x, dia_off is padded by
@@ -600,7 +663,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
         }
         if (map_xcd) {
             it.cur += it.step;
-            q = it.cur < it.end ? it.cur * 4 + wave : n_slices;
+            q = it.cur < it.end ? it.cur * 4 + wave : n_items;
         } else q += n_waves;
     }
     if (DOTS && DOTS != 4) {
@@ -624,10 +687,17 @@ struct row_dict {
     int ncls = 0, W = 0;
     const double* built_for = nullptr;      // the value array the classes describe (nullptr: plain form in use)
     uint64_t space_serial = 0;              // ... of this space
+    uint64_t matrix_serial = 0;             // ... of this matrix (addresses are handed out again after a free: the pointer alone is no identity)
     uint64_t gave_up_on = 0;                // serial of a matrix whose rows were not repetitive: not tried again
     int64_t n_built = 0, n_failed = 0;      // statistics (fs_krylov_stats)
 };
 static row_dict g_dict;
+// The dictionary describes the values of ONE call (a solve, fs_spmv_dictionary): whoever builds it drops it on the way out, so that no
+// later product - another matrix whose values land on a freed address, the same matrix re-assembled - can meet a stale class table.
+struct row_dict_scope {
+    row_dict_scope() { g_dict.built_for = nullptr; }
+    ~row_dict_scope() { g_dict.built_for = nullptr; }
+};
 
 // ---- CG scalar state on the device ---------------------------------------------------------
 // sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
@@ -1462,6 +1532,8 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_update_blocks = (int)value;
     } else if (!strcmp(name, "row_dictionary")) {
         g_row_dictionary = value != 0.0;
+    } else if (!strcmp(name, "box_snap")) {
+        fs_set_box_snap(value != 0.0);
     } else if (!strcmp(name, "cg_batch")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
         g_cg_batch = (int)value;
@@ -1566,6 +1638,169 @@ static int spmv_pair_grid(const fs_space_s* sp) {
 
 static int spmv_partials_unsplit(const fs_space_s* sp, int bs);
 static int dict_map_xcd();
+// dictionary rows are padded with zeros to a multiple of the single-slice round length, with at least ONE zero behind the widest
+// row: position W - 1 is the coefficient of the empty slots of a run plan
+static int dict_width(const fs_space_s* sp) { return (sp->max_row + 16) & ~15; }
+
+// Work items of the row-dictionary product (fs_space_s::dict_items) for the whole space and, on a decomposed space, for its
+// interior / boundary lists; run plans of the distinct offset lists.  Host pass over four small arrays, once per space (and
+// again when the halo plan changes).
+namespace {
+struct dict_plan_info { int32_t first = -1, rounds = 0, min_start = 0, max_start = 0; };
+struct dict_item_builder {
+    fs_space_s* sp;
+    std::vector<int32_t> dp, off;
+    std::vector<int64_t> ptr;
+    std::vector<dict_plan_round> rounds;
+    std::vector<std::pair<std::pair<int32_t, int>, dict_plan_info>> plans;       // (dia_ptr, width) -> plan (a handful of lists: linear search)
+    int width(int32_t sl) const { return (int)((ptr[(size_t)sl + 1] - ptr[(size_t)sl]) >> 6); }
+    const dict_plan_info& plan_for(int32_t d, int w) {
+        for (auto& e : plans)
+            if (e.first.first == d && e.first.second == w) return e.second;
+        dict_plan_info info;
+        const int32_t* o = off.data() + d + 1;
+        const int zero = dict_width(sp) - 1;
+        info.first = (int32_t)rounds.size();
+        int slot = 0, k = 0;
+        dict_plan_round cur;
+        auto fresh = [&](dict_plan_round& r) {
+            for (int j = 0; j < 8; ++j) {
+                r.start[j] = 0;
+                for (int t = 0; t < 4; ++t) r.kidx[j][t] = (uint8_t)zero;
+            }
+        };
+        fresh(cur);
+        bool first = true;
+        while (k < w || first) {
+            const int cap = first ? 7 : 8;          // slot 7 of round 0 stays (0; no coefficients): its load is z
+            if (slot == cap || k >= w) {
+                rounds.push_back(cur);
+                fresh(cur);
+                slot = 0;
+                first = false;
+                continue;
+            }
+            int len = 1;
+            while (k + len < w && len < 3 && o[k + len] == o[k + len - 1] + 1) ++len;
+            cur.start[slot] = o[k];
+            for (int t = 0; t < len; ++t) cur.kidx[slot][t] = (uint8_t)(k + t);
+            info.min_start = std::min(info.min_start, o[k]);
+            info.max_start = std::max(info.max_start, o[k]);
+            ++slot;
+            k += len;
+        }
+        if (slot > 0) rounds.push_back(cur);
+        info.rounds = (int32_t)rounds.size() - info.first;
+        plans.push_back({{d, w}, info});
+        return plans.back().second;
+    }
+    // seq: the slices to multiply, in processing order
+    void make_items(const std::vector<int32_t>& seq, std::vector<int32_t>& items, int64_t& n_pairs) {
+        const int64_t ns = sp->n_slices;
+        std::vector<int32_t> rank((size_t)ns, -1);
+        for (size_t q = 0; q < seq.size(); ++q) rank[(size_t)seq[q]] = (int32_t)q;
+        struct unit { int32_t key, a, rounds, first; };
+        std::vector<unit> units;
+        units.reserve(seq.size());
+        const int64_t n_cols = sp->n_nodes_local;
+        for (int32_t sl = 0; sl < ns;) {
+            if (rank[(size_t)sl] < 0) { ++sl; continue; }
+            bool pair = sl + 1 < ns && rank[(size_t)sl + 1] >= 0 && dp[(size_t)sl] >= 0 && dp[(size_t)sl + 1] >= 0 &&
+                        (int64_t)(sl + 2) * FS_SLICE <= sp->n_nodes_owned;
+            const int w = width(sl);
+            if (pair) {
+                const int32_t da = dp[(size_t)sl], db = dp[(size_t)sl + 1];
+                pair = w > 0 && w == width(sl + 1) && off[(size_t)da] >= FS_SLICE && off[(size_t)db] >= FS_SLICE;
+                if (pair && da != db)
+                    for (int k = 0; k < w && pair; ++k) pair = off[(size_t)da + 1 + k] == off[(size_t)db + 1 + k];
+                if (pair) {
+                    const dict_plan_info& pi = plan_for(da, w);
+                    const int64_t base = (int64_t)sl * FS_SLICE;
+                    pair = base + pi.min_start >= 0 && base + 2 * FS_SLICE + 1 + pi.max_start <= n_cols - 1;
+                    if (pair) units.push_back({rank[(size_t)sl], sl, pi.rounds, pi.first});
+                }
+            }
+            if (pair) sl += 2;
+            else { units.push_back({rank[(size_t)sl], sl, 0, 0}); sl += 1; }
+        }
+        std::sort(units.begin(), units.end(), [](const unit& u, const unit& v) { return u.key < v.key; });
+        items.clear();
+        items.reserve(units.size() * 4);
+        n_pairs = 0;
+        for (const unit& u : units) {
+            if (u.rounds > 0) { items.insert(items.end(), {u.a, -u.rounds, u.first, 0}); ++n_pairs; }
+            else {
+                const int32_t d = dp[(size_t)u.a];
+                items.insert(items.end(), {u.a, width(u.a), d, d >= 0 ? off[(size_t)d] : FS_SLICE});
+            }
+        }
+    }
+};
+}
+static int dict_build_items(fs_space_s* sp, hipStream_t s) {
+    fs_halo_plan& h = sp->halo;
+    const bool split = h.active && h.n_interior > 0;
+    const bool need_space = sp->n_dict_items < 0, need_lists = split && (h.n_items_interior < 0 || h.n_items_boundary < 0);
+    if (!need_space && !need_lists) return FS_OK;
+    const int64_t ns = sp->n_slices;
+    dict_item_builder B;
+    B.sp = sp;
+    B.dp.resize((size_t)ns);
+    B.off.resize((size_t)std::max<int64_t>(sp->dia_off.n, 1));
+    B.ptr.resize((size_t)ns + 1);
+    FS_CHECK(sp->dia_ptr.download(B.dp.data(), ns, s));
+    FS_CHECK(sp->dia_off.download(B.off.data(), sp->dia_off.n, s));
+    FS_CHECK(sp->slice_ptr.download(B.ptr.data(), ns + 1, s));
+    // (the plans of a space are made in one go - every list below is walked before the upload - so that the array a captured
+    // batch points to never moves: an earlier build's rounds come first, in the same order)
+    if (!need_space) {
+        std::vector<int32_t> seq((size_t)ns), items;
+        if (sp->slice_order.p) FS_CHECK(sp->slice_order.download(seq.data(), ns, s));
+        else for (int64_t q = 0; q < ns; ++q) seq[(size_t)q] = (int32_t)q;
+        int64_t np = 0;
+        B.make_items(seq, items, np);
+    }
+    std::vector<int32_t> items_space, items_in, items_bd;
+    int64_t np_space = 0, np_in = 0, np_bd = 0;
+    if (need_space) {
+        std::vector<int32_t> seq((size_t)ns);
+        if (sp->slice_order.p) FS_CHECK(sp->slice_order.download(seq.data(), ns, s));
+        else for (int64_t q = 0; q < ns; ++q) seq[(size_t)q] = (int32_t)q;
+        B.make_items(seq, items_space, np_space);
+    }
+    if (need_lists) {
+        std::vector<int32_t> seq((size_t)h.n_interior);
+        FS_CHECK(h.interior.download(seq.data(), h.n_interior, s));
+        B.make_items(seq, items_in, np_in);
+        seq.resize((size_t)h.n_boundary);
+        if (h.n_boundary) FS_CHECK(h.boundary.download(seq.data(), h.n_boundary, s));
+        B.make_items(seq, items_bd, np_bd);
+    }
+    const int64_t plan_ints = (int64_t)B.rounds.size() * 16;
+    if (sp->dict_plans.n < plan_ints) {
+        if (sp->dict_plans.p && getenv("FS_KRYLOV_DEBUG")) fprintf(stderr, "[fs_krylov] run plans of space %llu grow: re-allocated\n", (unsigned long long)sp->serial);
+        FS_CHECK(sp->dict_plans.alloc(std::max<int64_t>(plan_ints, 16)));
+    }
+    if (plan_ints) FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(B.rounds.data()), plan_ints, s));
+    if (need_space) {
+        sp->n_dict_items = (int64_t)items_space.size() / 4;
+        FS_CHECK(sp->dict_items.alloc(std::max<int64_t>((int64_t)items_space.size(), 4)));
+        FS_CHECK(sp->dict_items.upload(items_space.data(), (int64_t)items_space.size(), s));
+    }
+    if (need_lists) {
+        h.n_items_interior = (int64_t)items_in.size() / 4;
+        h.n_items_boundary = (int64_t)items_bd.size() / 4;
+        FS_CHECK(h.items_interior.alloc(std::max<int64_t>((int64_t)items_in.size(), 4)));
+        FS_CHECK(h.items_boundary.alloc(std::max<int64_t>((int64_t)items_bd.size(), 4)));
+        FS_CHECK(h.items_interior.upload(items_in.data(), (int64_t)items_in.size(), s));
+        FS_CHECK(h.items_boundary.upload(items_bd.data(), (int64_t)items_bd.size(), s));
+    }
+    if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
+        fprintf(stderr, "[fs_krylov] row-dictionary work items: space %lld (%lld pairs) of %lld slices, interior %lld (%lld pairs), boundary %lld (%lld pairs), %zu plan rounds for %zu offset lists\n",
+                (long long)sp->n_dict_items, (long long)np_space, (long long)ns, (long long)h.n_items_interior, (long long)np_in,
+                (long long)h.n_items_boundary, (long long)np_bd, B.rounds.size(), B.plans.size());
+    return FS_OK;
+}
 // Try to describe `val` (the scalar DIA matrix the solver is about to multiply with) by row classes; leaves g_dict.built_for =
 // val on success, nullptr otherwise.  One host synchronisation (12 bytes).  FS_SPMV_DICT=0 switches it off.
 static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
@@ -1575,13 +1810,9 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
     if (off || !g_row_dictionary || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
     if (sp->max_row <= 0 || sp->max_row > 96) return FS_OK;
-    const int W = (sp->max_row + 15) & ~15;           // dictionary rows are padded with zeros to a multiple of the round length
+    const int W = dict_width(sp);
     const int64_t padded = sp->n_slices * FS_SLICE;
-    if (!sp->slice_desc.p) {
-        FS_CHECK(sp->slice_desc.alloc(4 * sp->n_slices));
-        hipLaunchKernelGGL(k_slice_desc, dim3(fs_grid_for(sp->n_slices)), dim3(FS_BLOCK), 0, s, sp->n_slices, sp->slice_order.p, sp->slice_ptr.p,
-                           sp->dia_ptr.p, sp->dia_off.p, sp->slice_desc.p);
-    }
+    FS_CHECK(dict_build_items(sp, s));
     if (D.cls.n < padded) { FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
     if (!D.keys.p) {
         FS_CHECK(D.keys.alloc(FS_DICT_CAP));
@@ -1614,6 +1845,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     D.W = W;
     D.built_for = val;
     D.space_serial = sp->serial;
+    D.matrix_serial = A->serial;
     ++D.n_built;
     return FS_OK;
 }
@@ -1629,22 +1861,25 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int64_t ns = list ? n_list : sp->n_slices;
     if (ns == 0) return;
     const int32_t* order = list ? list : sp->slice_order.p;
-    if (A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val) {
+    if (A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val && g_dict.matrix_serial == A->serial && g_dict.space_serial == sp->serial) {
         // the values are a few dozen distinct rows (dict_build): class numbers + dictionary in LDS instead of the value stream.
         // Whole space: its own launch geometry (spmv_partials_unsplit); a list of a decomposed space (interior / boundary slices):
         // the geometry of the streaming kernel, so that the two launches keep filling one partial array.
-        const int32_t* desc = sp->slice_desc.p;
+        const int32_t* items = sp->dict_items.p;
+        int64_t n_items = sp->n_dict_items;
         int gd = spmv_partials_unsplit(sp, 1);
         if (list) {
             fs_halo_plan& h = sp->halo;
-            dbuf<int32_t>& dl = list == h.interior.p ? h.desc_interior : h.desc_boundary;
-            if (!dl.p && dl.alloc(4 * std::max<int64_t>(ns, 1)) == FS_OK)
-                hipLaunchKernelGGL(k_slice_desc, dim3(fs_grid_for(ns)), dim3(FS_BLOCK), 0, s, ns, list, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, dl.p);
-            desc = dl.p;
+            const bool in = list == h.interior.p;
+            items = in ? h.items_interior.p : (list == h.boundary.p ? h.items_boundary.p : nullptr);
+            n_items = in ? h.n_items_interior : h.n_items_boundary;
             gd = spmv_grid(ns, sp->n_slices);
         }
-        if (desc && (!list || list == sp->halo.interior.p || list == sp->halo.boundary.p)) {
-#define FS_DICT_ARGS sp->n_nodes_owned, sp->n_nodes_local, ns, reinterpret_cast<const int4*>(desc), sp->dia_off.p, g_dict.cls.p, \
+        // (the two-rows-per-lane loads and stores are 16-byte accesses of y and d at even rows)
+        const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(rvec)) & 15) == 0;
+        if (items && n_items >= 0 && aligned) {
+#define FS_DICT_ARGS sp->n_nodes_owned, sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), sp->dia_off.p, \
+                     reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, \
                      g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd()
             if ((int64_t)g_dict.ncls * g_dict.W <= FS_DICT_LDS_DOUBLES)
                 hipLaunchKernelGGL((k_dict_spmv<DOTS, true>), dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, FS_DICT_ARGS);
@@ -1876,6 +2111,29 @@ extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     return FS_OK;
 }
 
+// y = A x through the row-dictionary product where the rows of A repeat (classes found from A's values in this call and dropped
+// at its end), else the streaming product; *row_classes = number of distinct rows used (0: streaming).  The two products agree bit
+// for bit (same offsets, same order of summation) - this entry point exists so that tests and users can check exactly that.
+extern "C" int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_classes) {
+    std::lock_guard<std::recursive_mutex> solve_lock(fs_solve_mutex());
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(A && x && y, "fs_spmv_dictionary: null pointer");
+    fs_space_s* sp = A->space;
+    FS_REQUIRE(x->d.n >= sp->n_dofs_local, "fs_spmv_dictionary: x has %lld entries, needs %lld (owned + ghost)", (long long)x->d.n, (long long)sp->n_dofs_local);
+    FS_REQUIRE(y->d.n >= sp->n_dofs_owned, "fs_spmv_dictionary: y too short");
+    hipStream_t s = fs_rt().stream;
+    row_dict_scope dict_scope;
+    if (A->bs == 1) FS_CHECK(dict_build(A, A->val.p, s));
+    if (A->bs == 1 && !g_dict.built_for && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
+    FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
+    if (g_dict.built_for) launch_spmv<0>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);
+    else FS_CHECK(fs_spmv_dev(A, x->d.p, y->d.p, s));
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    if (row_classes) *row_classes = g_dict.built_for ? g_dict.ncls : 0;
+    return FS_OK;
+}
+
 extern "C" int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch) {
     FS_REQUIRE(A && x && y && ms_per_launch && reps != 0, "fs_spmv_benchmark: bad arguments");
     // reps < 0: time the CG flavour (SpMV fused with the three dot products, r := y)
@@ -1936,7 +2194,7 @@ struct krylov_ws {
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
     dbuf<double> sg;            // s on the ghost rows, in arrival order (peer-to-peer iteration: a rank advances its ghost r, s itself)
     hipGraphExec_t cg_graph = nullptr;
-    const void* cg_key[20] = {};
+    const void* cg_key[24] = {};
     int64_t cg_key_i[8] = {};
 };
 static krylov_ws g_ws;
@@ -1985,7 +2243,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         return FS_ERR_UNSUPPORTED;
     }
     const bool bicg = opts->method == FS_KSP_BICGSTAB;
-    g_dict.built_for = nullptr;          // the row dictionary describes the values of ONE solve (rebuilt below where it applies)
+    row_dict_scope dict_scope;           // the row dictionary describes the values of ONE solve (built below where it applies)
     FS_REQUIRE(A->bs != 4, "fs_krylov_solve: Taylor-Hood block systems are solved by fs_saddle_solve");
     FS_REQUIRE(opts->precond == FS_PC_NONE || opts->precond == FS_PC_JACOBI, "fs_krylov_solve: unknown preconditioner %d", opts->precond);
     FS_REQUIRE(opts->max_iter > 0 && opts->rtol >= 0.0 && opts->atol >= 0.0, "fs_krylov_solve: bad tolerances");
@@ -2270,10 +2528,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 const int fgrid = p2p_fuse ? spmv_partials_unsplit(sp, bs) : sgrid;
                 if (p2p_fuse) FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                 const bool dict_on = g_dict.built_for && g_dict.built_for == aval;
-                const void* key[20] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
+                const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
                                        ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf,
                                        dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
-                                       dict_on ? (const void*)sp->slice_desc.p : nullptr, p2p_fuse ? (const void*)ws.sg.p : nullptr};
+                                       dict_on ? (const void*)sp->dict_items.p : nullptr, p2p_fuse ? (const void*)ws.sg.p : nullptr,
+                                       dict_on ? (const void*)sp->dict_plans.p : nullptr, dict_on ? (const void*)sp->halo.items_interior.p : nullptr,
+                                       dict_on ? (const void*)sp->halo.items_boundary.p : nullptr, nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,

@@ -69,7 +69,8 @@ const char* fs_version(void);
  * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll),
  * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
  * "update_blocks" (grid of the fused vector-update kernel), "cg_graph" (-1 / 0 / 1: CG batches as hipGraphs by size /
- * never / always), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes). */
+ * never / always), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes),
+ * "box_snap" (0 / 1: box meshes snap their edge vectors to the grid spacing so that equal stencils are equal bit for bit). */
 int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
 int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
@@ -352,6 +353,12 @@ int fs_krylov_history(double* out, int capacity, int* count);
  * library's stream; returns mean milliseconds per launch.  reps > 0: bare y = A x;
  * reps < 0: the CG flavour fused with the three dot products (y plays r). */
 int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch);
+
+/* y = A x (MatMult, behind KSPSolve at SolverBase.py:663-670) through the ROW-DICTIONARY form of the product where the rows of A
+ * repeat (a uniform box mesh with constant coefficients): the classes are found from A's current values inside this call,
+ * every row is verified against its class, and the table is dropped when the call returns.  *row_classes = number of distinct
+ * rows used, 0 = the rows do not repeat and the streaming product ran.  Both forms give the same bits as fs_spmv. */
+int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_classes);
 
 /* ---- smoothed-aggregation AMG (PETScPreconditioner("petsc_amg") + set_near_nullspace,
  *      SolverBase.py:643-672; Chebyshev/Jacobi level smoother as the PETScOptions there ask) ---- */
