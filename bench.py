@@ -378,7 +378,8 @@ def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
     a_ms, h_ms = B.comm_benchmark(prob.V, 200)
     res.update({"allreduce_ms": round(a_ms, 5), "halo_ms": round(h_ms, 5)})
     k = kernel_rates(last_st, prob.V)
-    res["spmv_algorithmic_GBps_rank0"] = k["algorithmic_GBps"]
+    res["spmv_required_GBps_rank0"] = k["required_GBps"]
+    res["spmv_csr_equivalent_GBps_rank0"] = k["csr_equivalent_GBps"]
     return res
 
 
@@ -402,9 +403,8 @@ def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="a
             "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
             "max_abs_error_vs_exact_profile": err, "recurrence": name, "recurrence_trial_ms_per_step": trial,
             "symbolic_ms": round(prob.symbolic_ms, 2), "setup_s": round(setup_s, 2),
-            "spmv": {"kernel": kernel_name(prob.V, st), "row_classes": st.get("row_classes", 0), "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
-                     "algorithmic_GBps": k["algorithmic_GBps"], "frac_of_8TBps": round(k["algorithmic_GBps"] / HBM_PEAK_GBS, 3),
-                     "streamed_GBps": k["streamed_GBps"], "dia_slices": k["dia_slices"], "slices": k["slices"], "rows_rank0": prob.n_owned}}
+            "spmv": dict(k, rows_rank0=prob.n_owned, frac_of_8TBps=round(k["required_GBps"] / HBM_PEAK_GBS, 3)),
+            "update": update_rates(st, prob.n_owned), "iteration": iteration_rates(st, k, prob.n_owned)}
 
 
 def th_leg(n, n_steps, rank, world):
@@ -486,27 +486,53 @@ def kernel_name(V, st=None):
     return one
 
 
+UPDATE_BYTES_PER_DOF = 72      # k_cg_update_scaled, single-reduction scaled CG: reads r, w, p, s, x and writes r, p, s, x
+DICT_BYTES_PER_ROW = 26        # k_dict_spmv: z read (its x gathers are the same array), d read, w written, 2-byte class number
+
+
 def kernel_rates(st, V):
-    """Byte rates of the dominant kernel = the hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally
-    scaled CG.  ALGORITHMIC bytes are those of a CSR SpMV (nnz*12 + n*20); streamed bytes are what
-    the hybrid storage really has to move (values + column indices of SELL slices only + z, d reads + w write).
+    """Byte rates of the product kernel (the hybrid SELL-64/DIA SpMV or its row-dictionary form, fused with the 3 dot products of the
+    diagonally scaled CG).  REQUIRED bytes = what the kernel's own storage form has to move per launch:
+    streaming form: stored values + the column indices of SELL slices + z, d reads + w write; row-dictionary form: 26 B per row.
+    They are the numerator of every roofline fraction this bench prints.  The CSR-equivalent bytes of SURVEY section 8d
+    (nnz*12 + n*20) are reported beside them as a rate a CSR kernel would need to match the duration - not as a fraction of anything:
+    a kernel that does not move those bytes can exceed the HBM peak on them.
     Time = mean duration of the live launches sampled with HIP events on the library's stream inside the timed solves."""
     ms = st["spmv_ms"]
-    streamed = V.spmv_matrix_bytes + 24 * V.n_owned
-    if st.get("row_classes", 0) > 0:      # class number (2 B) instead of the value stream: z, d reads + w write + class numbers
-        streamed = 26 * V.n_owned
+    dict_on = st.get("row_classes", 0) > 0
+    required = DICT_BYTES_PER_ROW * V.n_owned if dict_on else V.spmv_matrix_bytes + 24 * V.n_owned
+    rate = lambda nbytes: round(nbytes / ms / 1e6, 1) if ms > 0 else 0.0
     return {"kernel": kernel_name(V, st), "avg_launch_ms": round(ms, 5), "row_classes": st.get("row_classes", 0),
-            "algorithmic_bytes_per_launch": st["spmv_bytes"],
-            "algorithmic_GBps": round(st["spmv_bytes"] / ms / 1e6, 1) if ms > 0 else 0.0,
-            "streamed_bytes_per_launch": streamed,
-            "streamed_GBps": round(streamed / ms / 1e6, 1) if ms > 0 else 0.0,
+            "required_bytes_per_launch": required, "required_GBps": rate(required),
+            "required_bytes_model": ("26 B/row: z, d reads + w write + 2-byte class number (the distinct value rows sit in LDS / L2)" if dict_on else
+                                     "stored values + column indices of SELL slices + 24 B/row (z, d reads + w write); DIA slices carry no column indices"),
+            "csr_equivalent_bytes_per_launch": st["spmv_bytes"], "csr_equivalent_GBps": rate(st["spmv_bytes"]),
             "dia_slices": V.n_dia_slices, "slices": V.n_slices}
+
+
+def update_rates(st, n_rows):
+    """The fused vector update of the CG iteration: 72 B per row, nothing to compress."""
+    ms = st["update_ms"]
+    nbytes = UPDATE_BYTES_PER_DOF * n_rows
+    gbps = nbytes / ms / 1e6 if ms > 0 else 0.0
+    return {"kernel": "k_cg_update_scaled (x, r, p, s updated; the dot partials of the product summed)", "avg_launch_ms": round(ms, 5),
+            "required_bytes_per_launch": nbytes, "required_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 3)}
+
+
+def iteration_rates(st, k, n_rows):
+    """One whole CG iteration (product + update + launch gaps) against the bytes its two kernels have to move."""
+    ms = st["solve_ms"] / max(st["iterations"], 1)
+    nbytes = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * n_rows
+    gbps = nbytes / ms / 1e6 if ms > 0 else 0.0
+    return {"required_bytes": nbytes, "bytes_per_dof": round(nbytes / float(n_rows), 1), "ms": round(ms, 5), "GBps": round(gbps, 1),
+            "frac": round(gbps / HBM_PEAK_GBS, 3), "what": "solve_ms / iterations (host clock around the whole solve: products, updates, "
+            "launch gaps, convergence polls) against required bytes of the product + 72 B/row of the update"}
 
 
 def committed_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
     newest round first; collected on the same command in separate --pmc runs).  Not measured in this run."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 v = json.load(fh).get(tag)
@@ -518,23 +544,23 @@ def committed_traffic(tag):
 
 
 def make_roofline(k, workload, traffic, traffic_source):
-    frac = k["algorithmic_GBps"] / HBM_PEAK_GBS
+    frac = k["required_GBps"] / HBM_PEAK_GBS
     what = (" (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
-            "LDS; template argument: dot mode)") if k.get("row_classes", 0) > 0 else (
+            "LDS, two rows per lane over pairs of slices; template arguments: dot mode, dictionary in LDS)") if k.get("row_classes", 0) > 0 else (
         " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template arguments of k_sell_spmv: block "
         "size, dot mode, entries per round, non-temporal matrix loads; of k_dia_pair_spmv: dot mode, non-temporal matrix loads)")
     r = {"kernel": k["kernel"] + what,
-         "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 3),
+         "bound": "hbm", "achieved": k["required_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 3),
          "traffic": traffic,
          "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; NOT measured in this run)" % traffic_source)
                            if traffic is not None else None,
          "workload": workload,
-         "note": "achieved = algorithmic CSR bytes (nnz*12 + n*20, SURVEY 8d) / avg_launch_ms; avg_launch_ms = mean of the LIVE "
-                 "products sampled with HIP events (every 16th iteration of the timed solve; a product = the launches the kernel "
-                 "field names) on the library's stream; "
-                 "streamed_GBps = the bytes the hybrid storage really moves (DIA slices carry no column indices) / the same time"}
-    r.update({kk: k[kk] for kk in ("avg_launch_ms", "algorithmic_bytes_per_launch", "streamed_bytes_per_launch", "streamed_GBps",
-                                   "dia_slices", "slices")})
+         "note": "achieved = REQUIRED bytes of the kernel's storage form (required_bytes_model) / avg_launch_ms; avg_launch_ms = mean "
+                 "of the LIVE products sampled with HIP events (every 16th iteration of the timed solve; a product = the launches the "
+                 "kernel field names) on the library's stream; csr_equivalent_GBps = the SURVEY 8d CSR bytes (nnz*12 + n*20) over the "
+                 "same time: a comparison with a CSR kernel, not a fraction of the peak"}
+    r.update({kk: k[kk] for kk in ("avg_launch_ms", "required_bytes_per_launch", "required_bytes_model", "csr_equivalent_bytes_per_launch",
+                                   "csr_equivalent_GBps", "dia_slices", "slices")})
     return r
 
 
@@ -567,14 +593,12 @@ def main():
                        assemble_ms_per_step=r["assemble_ms"], symbolic_ms=r["symbolic_ms"],
                        parity={"max_abs_error_vs_exact_profile": r["max_abs_error_vs_exact_profile"]})
             k = r["spmv"]
-            hbm = k["algorithmic_bytes_per_launch"] > (256 << 20)
-            out["roofline"] = {"kernel": k["kernel"] + " (hybrid SELL-64/DIA SpMV of the CG2 operator fused with the 3 CG dot products)",
-                               "bound": "hbm", "achieved": k["algorithmic_GBps"] if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": k["frac_of_8TBps"] if hbm else None, "traffic": None, "workload": "rank 0's part of the step workload",
-                               "avg_launch_ms": k["avg_launch_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
-                               "streamed_GBps": k["streamed_GBps"], "dia_slices": k["dia_slices"], "slices": k["slices"],
-                               "note": "achieved = CSR-equivalent bytes (nnz*12 + n*20) / mean duration of the live launches (HIP events on the "
-                                       "library's stream)" + ("" if hbm else "; this rank's part is cache-resident: no HBM fraction claimed")}
+            hbm = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * k["rows_rank0"] > (256 << 20)
+            out["roofline"] = dict(make_roofline(k, "rank 0's part of the step workload", None, None),
+                                   update_kernel=r["update"], iteration=r["iteration"])
+            out["roofline"]["kernel"] = k["kernel"] + " (product of the CG2 operator fused with the 3 CG dot products)"
+            if not hbm:
+                out["roofline"].update(achieved=None, frac=None, note="this rank's part is cache-resident: no HBM fraction claimed")
             print(json.dumps(out))
         parallel.barrier()
         parallel.finalize()
@@ -643,13 +667,19 @@ def main():
                                    "mesh_ms", "update_kernel_ms")}
         if trial:
             out["config"]["recurrence_trial_ms_per_step"] = trial
+        # what ONE steady solve() of the reference API pays on this workload: mesh + sparsity pattern + assemble + solve
+        out["one_shot_dof_per_s"] = round(n_dof_total / (1e-3 * (prob.mesh_ms + prob.symbolic_ms + ms_per_step)), 1)
         step_kernel = kernel_rates(stats, prob.V)
-        hbm_resident = step_kernel["streamed_bytes_per_launch"] > (256 << 20)
+        step_kernel["update_kernel"] = update_rates(stats, prob.n_owned)
+        step_kernel["iteration"] = iteration_rates(stats, step_kernel, prob.n_owned)
+        # (what an iteration touches: the product's bytes + the five vectors of the update)
+        hbm_resident = step_kernel["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * prob.n_owned > (256 << 20)
         if hbm_resident:
-            out["roofline"] = make_roofline(step_kernel, "the step workload itself (rank 0's part)", None, None)
+            out["roofline"] = dict(make_roofline(step_kernel, "the step workload itself (rank 0's part)", None, None),
+                                   update_kernel=step_kernel["update_kernel"], iteration=step_kernel["iteration"])
         else:
-            step_kernel["note"] = ("the matrix and vectors this kernel streams (streamed_bytes_per_launch) stay in the 256 MiB "
-                                   "Infinity Cache between iterations: these are cache rates, not an HBM roofline fraction")
+            step_kernel["note"] = ("everything an iteration touches (required bytes of the product + 72 B/row of the update) stays in the "
+                                   "256 MiB Infinity Cache between iterations: these are cache rates, not an HBM roofline fraction")
             out["dominant_kernel_on_step_workload"] = step_kernel
             if world > 1 or a.no_hbm_case:   # no HBM-resident side measurement: the part of a GPU is cache-resident by construction
                 out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
@@ -703,27 +733,24 @@ def main():
             t_big = time.perf_counter() - t0
             traffic, src = committed_traffic("spmv_fused_n215")
             k_big = kernel_rates(st_big, big.V)
-            r = make_roofline(k_big, "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB streamed per launch)"
-                              % (big.n_owned, k_big["streamed_bytes_per_launch"] / 1e9), traffic, src)
+            r = make_roofline(k_big, "same path, unit cube n=215, %d DOF (HBM-resident: %.2f GB required per product, %.2f GB per iteration)"
+                              % (big.n_owned, k_big["required_bytes_per_launch"] / 1e9,
+                                 (k_big["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * big.n_owned) / 1e9), traffic, src)
             r.update({"dof_per_s": round(big.n_owned / t_big, 1), "cg_iterations": st_big["iterations"],
                       "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3),
-                      "update_kernel_ms": round(st_big["update_ms"], 5),
-                      "iteration_ms": round(st_big["solve_ms"] / max(st_big["iterations"], 1), 5)})
+                      "update_kernel": update_rates(st_big, big.n_owned), "iteration": iteration_rates(st_big, k_big, big.n_owned),
+                      "one_shot": {"mesh_ms": round(big.mesh_ms, 2), "symbolic_ms": round(big.symbolic_ms, 2),
+                                   "dof_per_s": round(big.n_owned / (1e-3 * (big.mesh_ms + big.symbolic_ms) + t_big), 1),
+                                   "what": "mesh + sparsity pattern + assemble + solve: what ONE steady solve() of the reference API pays"}})
             if st_big.get("row_classes", 0) > 0:
-                # The operator of a uniform box with a constant coefficient has a few dozen distinct rows: the product ran in
-                # row-dictionary form and does not stream the matrix at all, so "algorithmic bytes / time" exceeds the HBM peak.
-                # Both are reported: the kernel the path really runs here, and - same problem, option row_dictionary = 0 - the
-                # streaming kernel every other operator takes, whose HBM roofline fraction is the one to judge the kernel by.
-                kd = kernel_rates(st_big, big.V)
-                own = 26 * big.n_owned
+                # The operator of a uniform box with a constant coefficient has a few dozen distinct rows: the product runs in
+                # row-dictionary form and does not stream the matrix at all.  Both are reported: the kernel the path really runs
+                # here, and - same problem, option row_dictionary = 0 - the streaming kernels every other operator takes.
                 r["note_row_dictionary"] = (
                     "k_dict_spmv reads a 2-byte class number per row and keeps the %d distinct value rows in LDS instead of streaming "
-                    "8 B per entry (built per solve, every row verified bit for bit; same offsets, same summation order, same bits): "
-                    "achieved / frac are the CSR-equivalent bytes over its duration and exceed the peak because those bytes are not "
-                    "moved; on the bytes it has to move (%d B/row: z, d, class numbers, w) it runs at %.1f GB/s = %.2f of peak - the "
-                    "kernel is bound by its 19 memory instructions per row, not by HBM" % (
-                        st_big["row_classes"], 26, own / kd["avg_launch_ms"] / 1e6, own / kd["avg_launch_ms"] / 1e6 / HBM_PEAK_GBS))
-                r["own_bytes_per_launch"] = own
+                    "8 B per entry (built per solve, every row verified bit for bit; same offsets, same summation order, same bits as "
+                    "the streaming product): its roofline is on the 26 B/row it has to move; csr_equivalent_GBps exceeds the peak because "
+                    "those bytes are not moved" % st_big["row_classes"])
                 B.set_option("row_dictionary", 0)
                 try:
                     big.step(a.rtol)
@@ -733,9 +760,9 @@ def main():
                     t_s = time.perf_counter() - t0
                     rs = make_roofline(kernel_rates(st_s, big.V), "the same problem with option row_dictionary = 0: the streaming kernels "
                                        "every operator without repeated rows takes", traffic, src)
+                    ks = kernel_rates(st_s, big.V)
                     rs.update({"dof_per_s": round(big.n_owned / t_s, 1), "cg_iterations": st_s["iterations"],
-                               "update_kernel_ms": round(st_s["update_ms"], 5),
-                               "iteration_ms": round(st_s["solve_ms"] / max(st_s["iterations"], 1), 5)})
+                               "update_kernel": update_rates(st_s, big.n_owned), "iteration": iteration_rates(st_s, ks, big.n_owned)})
                     r["traffic"], r["traffic_source"] = committed_traffic("spmv_dict_n215")
                     if r["traffic"] is not None:
                         r["traffic_source"] = "%s (rocprofv3 --pmc passes of this command, committed; NOT measured in this run)" % r["traffic_source"]

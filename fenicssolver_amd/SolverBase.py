@@ -319,10 +319,31 @@ class SolverBase():
             pc = 'none'
         else:
             raise SolverError("preconditioner '{}' is not supported".format(pc))
-        ls = sp.get('linear_solver', 'cg')
-        if ls not in ('default', 'cg', 'lu', 'mumps', 'petsc', 'umfpack'):
-            raise SolverError("linear_solver '{}' is not supported on the GPU back end (cg only)".format(ls))
+        self._krylov_method(None)          # (rejects an unknown solver name here, where the parameters are read)
         return rtol, max_iter, pc
+
+    # names DOLFIN's LinearVariationalSolver / KrylovSolver accept for 'linear_solver' (the reference forwards any key the dolfin
+    # solver knows, SolverBase.py:638-641) -> the Krylov kernel of this back end (fs_krylov_solve: CG, BiCGStab)
+    _DIRECT_SOLVERS = ('default', 'lu', 'mumps', 'petsc', 'umfpack', 'superlu', 'superlu_dist', 'pastix')
+    _SYMMETRIC_KRYLOV = ('cg', 'minres')
+    _GENERAL_KRYLOV = ('bicgstab', 'gmres', 'tfqmr', 'richardson')
+
+    def _krylov_method(self, automatic):
+        """The Krylov kernel for this solve.  automatic: what the operator calls for ('cg' symmetric / 'bicgstab' not).  A direct
+        solver name keeps that choice (run to the LU-equivalent tolerance); 'cg' / 'minres' too (CG on a non-symmetric operator
+        would break down: the automatic BiCGStab stays); 'bicgstab' / 'gmres' / 'tfqmr' / 'richardson' select the method for
+        general operators - BiCGStab, the one this back end has for scalar and vector spaces (it is also valid on symmetric ones)."""
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        ls = sp.get('linear_solver', 'default')
+        if ls in self._DIRECT_SOLVERS or ls in self._SYMMETRIC_KRYLOV:
+            return automatic
+        if ls in self._GENERAL_KRYLOV:
+            if ls != 'bicgstab' and automatic is not None and not getattr(self, '_warned_krylov_alias', False):
+                self.logger.info("linear_solver '%s': solved with the BiCGStab kernel of the GPU back end", ls)
+                self._warned_krylov_alias = True
+            return 'bicgstab'
+        raise SolverError("linear_solver '{}' is not a solver name DOLFIN knows ({})".format(
+            ls, ', '.join(self._DIRECT_SOLVERS + self._SYMMETRIC_KRYLOV + self._GENERAL_KRYLOV)))
 
     def set_solver_parameters(self, solver=None):
         """Kept for API parity (SolverBase.py:628-641): returns the Krylov options this back end will use."""
@@ -338,11 +359,14 @@ class SolverBase():
         that names the same key; a call without one always builds its own."""
         from . import backend
         rtol, max_iter, pc = self._krylov_options()
+        automatic = method
+        method = self._krylov_method(method)
         V = u.function_space().device()
         x = backend.DeviceVector(V.n_local)            # owned + ghost entries: the input of operator products
         sp_ = self.solver_settings.get('solver_parameters', {}) or {}
         if amg and 'preconditioner' not in sp_:
             pc = 'amg'
+            method = automatic         # solve_amg is the reference's CG + AMG path (SolverBase.py:643-672): a general-solver name does not undo it
         if pc == 'amg' and method != "cg":
             self.logger.warning('%s: the AMG hierarchy is built for symmetric problems; using Jacobi', label)
             pc = 'jacobi'
@@ -398,7 +422,8 @@ class SolverBase():
             # The LU-equivalent default (1e-12) may lie below what fp64 attains on a badly conditioned operator: a solve that
             # stopped short of it but reached the accuracy this back end promised before (1e-8) is a result, with a warning -
             # not an error; a tolerance the user asked for explicitly stays binding.
-            user_tol = 'krylov_relative_tolerance' in (self.solver_settings.get('solver_parameters', {}) or {})
+            # (that is 'krylov_relative_tolerance', or the reference's own key 'relative_tolerance' below the 1e-8 of the fallback)
+            user_tol = 'krylov_relative_tolerance' in sp or float(sp.get('relative_tolerance', 1.0)) < 1e-8
             if user_tol or stats['converged'] < 0 or not (stats['true_rel_residual'] <= 1e-8):
                 raise SolverError('{}: Krylov solver did not converge in {} iterations (||r||/||b|| = {:.3e})'.format(
                     label, stats['iterations'], stats['true_rel_residual']))
@@ -777,9 +802,9 @@ class SolverBase():
             if dofs.size:
                 A.apply_dirichlet(rhs, dofs, 0.0, symmetric=True)   # delta = 0 on the Dirichlet boundary
             delta = backend.DeviceVector(V.n_local)
-            stats = backend.krylov_solve(A, rhs, delta, rtol=min(krtol, 1e-10), max_iter=kmax, precond=pc,
-                                         method="cg" if F.symmetric else "bicgstab",
-                                         norm="preconditioned" if (F.symmetric and pc == "jacobi") else "unpreconditioned")
+            kmethod = self._krylov_method("cg" if F.symmetric else "bicgstab")
+            stats = backend.krylov_solve(A, rhs, delta, rtol=min(krtol, 1e-10), max_iter=kmax, precond=pc, method=kmethod,
+                                         norm="preconditioned" if (kmethod == "cg" and pc == "jacobi") else "unpreconditioned")
             self.last_solve_stats = stats
             if stats['converged'] != 1:
                 raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))

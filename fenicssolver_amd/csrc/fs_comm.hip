@@ -355,7 +355,13 @@ __global__ void __launch_bounds__(FS_SUM_BLOCK) k_p2p_allreduce(int nr, int me, 
     if (t == 0) *d_seq = seq;              // (every thread read it before the first barrier)
 }
 
+// Also the destructor's path (fs_space_destroy with the exchange still on).  That is safe only when every rank is past its last
+// exchange with this one - true after any solve returned, whose closing residual check is a collective behind the last exchange -
+// and it is documented as a requirement in include/fenicssolver_amd.h: turn the exchange off (a collective) or destroy the
+// space on all ranks at the same point of the program.  The count of live peer-to-peer spaces follows, so that the all-reduce
+// does not stay on the peer-to-peer path for nobody (its buffers are freed by the next collective enable / disable or finalize).
 void fs_p2p_halo::release() {
+    if (enabled && g_p2p_spaces > 0) --g_p2p_spaces;
     if (recv || flags || !opened.empty()) (void)hipDeviceSynchronize();
     for (void* q : opened) (void)hipIpcCloseMemHandle(q);
     opened.clear();
@@ -409,8 +415,11 @@ static int p2p_test_mode() {
 
 static int p2p_common_setup() {
     if (!g_p2p_err) {
-        FS_HIP(hipMalloc((void**)&g_p2p_err, sizeof(int)));
-        FS_HIP(hipMemset(g_p2p_err, 0, sizeof(int)));
+        if (hipMalloc((void**)&g_p2p_err, sizeof(int)) != hipSuccess || hipMemset(g_p2p_err, 0, sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            g_p2p_err = nullptr;
+            return FS_ERR_HIP;         // (carried to the next agreement by the callers, not returned before a collective)
+        }
     }
     const char* e = getenv("FS_P2P_TIMEOUT_MS");
     const double ms = e ? atof(e) : 10000.0;
@@ -457,17 +466,14 @@ static int p2p_reduce_setup() {
     }
     if (!ok) (void)hipGetLastError();
     if (p2p_test_mode() == 1 && rt.rank == 0) ok = false;
+    // (the device-side tables too BEFORE the last agreement: a local out-of-memory here must back every rank out, not leave the
+    // others waiting for this one in the self-test all-reduce)
+    ok = ok && R.peer_buf.alloc(nr) == FS_OK && R.peer_flags.alloc(nr) == FS_OK &&
+         R.peer_buf.upload(pb.data(), nr, rt.stream) == FS_OK && R.peer_flags.upload(pf.data(), nr, rt.stream) == FS_OK &&
+         R.d_seq.alloc(1) == FS_OK && R.d_seq.zero(rt.stream) == FS_OK && R.counter.alloc(1) == FS_OK && R.counter.zero(rt.stream) == FS_OK &&
+         hipStreamSynchronize(rt.stream) == hipSuccess;
     const int rc = p2p_agree(ok, "peer-to-peer all-reduce");
     if (rc != FS_OK) { R.release(); return rc; }
-    FS_CHECK(R.peer_buf.alloc(nr));
-    FS_CHECK(R.peer_flags.alloc(nr));
-    FS_CHECK(R.peer_buf.upload(pb.data(), nr, rt.stream));
-    FS_CHECK(R.peer_flags.upload(pf.data(), nr, rt.stream));
-    FS_CHECK(R.d_seq.alloc(1));
-    FS_CHECK(R.d_seq.zero(rt.stream));
-    FS_CHECK(R.counter.alloc(1));
-    FS_CHECK(R.counter.zero(rt.stream));
-    FS_HIP(hipStreamSynchronize(rt.stream));
     R.enabled = true;
     return FS_OK;
 }
@@ -520,9 +526,10 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
     hipStream_t s = rt.stream;
     FS_HIP(hipStreamSynchronize(s));
     if (h.comm_stream) FS_HIP(hipStreamSynchronize(h.comm_stream));
+    // (unconditional: every rank is in this call, whatever the state of ITS side - a barrier that depended on local state would
+    // leave the ranks that still hold buffers waiting for those that do not)
+    FS_CHECK(p2p_barrier());
     if (h.p2p.enabled || h.p2p.recv) {
-        FS_CHECK(p2p_barrier());
-        if (h.p2p.enabled && g_p2p_spaces > 0) --g_p2p_spaces;
         h.p2p.release();
         h.early = -1;
     }
@@ -536,22 +543,26 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
         fs_set_error("fs_space_enable_p2p_halo: no communicator is up (call fs_comm_init)");
         return FS_ERR_COMM;
     }
-    FS_CHECK(p2p_common_setup());
+    // (local failures - an allocation, too many neighbours - are carried to the agreement below, never returned before the
+    // collectives the other ranks are heading for: see p2p_reduce_setup, whose own verdict is agreed and alike on every rank)
+    char why[256] = "";
+    const bool common_ok = p2p_common_setup() == FS_OK;
     FS_CHECK(p2p_reduce_setup());
-    const int nn = h.active ? (int)h.neighbors.size() : 0;
-    FS_REQUIRE(nn <= P2P_MAX_NB, "fs_space_enable_p2p_halo: %d neighbours, at most %d", nn, P2P_MAX_NB);
+    const int nn_plan = h.active ? (int)h.neighbors.size() : 0;
+    const int nn = std::min(nn_plan, P2P_MAX_NB);
     fs_p2p_halo& pp = h.p2p;
     const int64_t total = std::max<int64_t>(h.total_recv, 1);
-    // (local failures are carried to the agreement below, never returned before the all-gather: see p2p_reduce_setup)
-    bool ok = hipExtMallocWithFlags((void**)&pp.recv, (size_t)(2 * total) * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess &&
+    bool ok = common_ok && nn_plan <= P2P_MAX_NB;
+    if (!common_ok) snprintf(why, sizeof(why), "the error flag of the exchange kernels could not be allocated");
+    else if (!ok) snprintf(why, sizeof(why), "%d neighbours, at most %d", nn_plan, P2P_MAX_NB);
+    ok = ok && hipExtMallocWithFlags((void**)&pp.recv, (size_t)(2 * total) * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess &&
               hipExtMallocWithFlags((void**)&pp.flags, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long), hipDeviceMallocFinegrained) == hipSuccess &&
               hipMemset(pp.flags, 0, (size_t)(2 * std::max(nn, 1)) * sizeof(unsigned long long)) == hipSuccess &&
               hipDeviceSynchronize() == hipSuccess;
-    char why[256] = "";
     hipIpcMemHandle_t hv[2];
     memset(hv, 0, sizeof(hv));
     ok = ok && hipIpcGetMemHandle(&hv[0], pp.recv) == hipSuccess && hipIpcGetMemHandle(&hv[1], pp.flags) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); snprintf(why, sizeof(why), "the receive buffers could not be allocated or exported (hipIpcGetMemHandle)"); }
+    if (!ok) { (void)hipGetLastError(); if (!why[0]) snprintf(why, sizeof(why), "the receive buffers could not be allocated or exported (hipIpcGetMemHandle)"); }
     std::vector<double> rec((size_t)P2P_REC, 0.0), all((size_t)P2P_REC * rt.n_ranks, 0.0);
     rec[0] = nn; rec[1] = (double)total;
     for (int i = 0; i < nn; ++i) {
@@ -603,6 +614,12 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
         e.peer_nn = std::max(qnn, 1);
         max_send = std::max(max_send, e.send_count);
     }
+    if (ok) {
+        ok = pp.peers.alloc((int64_t)peers.size()) == FS_OK && pp.peers.upload(peers.data(), (int64_t)peers.size(), s) == FS_OK &&
+             pp.done.alloc((int64_t)peers.size()) == FS_OK && pp.done.zero(s) == FS_OK && pp.counter.alloc(2) == FS_OK && pp.counter.zero(s) == FS_OK &&
+             pp.d_seq.alloc(1) == FS_OK && pp.d_seq.zero(s) == FS_OK && hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) snprintf(why, sizeof(why), "the device tables of the exchange could not be allocated");
+    }
     const int rc = p2p_agree(ok, "fs_space_enable_p2p_halo", why);
     if (rc != FS_OK) {
         pp.release();
@@ -610,17 +627,10 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
         return rc;
     }
     pp.send_groups = (int)std::min<int64_t>(16, std::max<int64_t>(1, (max_send + 8 * FS_BLOCK - 1) / (8 * FS_BLOCK)));
-    FS_CHECK(pp.peers.alloc((int64_t)peers.size()));
-    FS_CHECK(pp.peers.upload(peers.data(), (int64_t)peers.size(), s));
-    FS_CHECK(pp.done.alloc((int64_t)peers.size()));
-    FS_CHECK(pp.done.zero(s));
-    FS_CHECK(pp.counter.alloc(2));
-    FS_CHECK(pp.counter.zero(s));
-    FS_CHECK(pp.d_seq.alloc(1));
-    FS_CHECK(pp.d_seq.zero(s));
-    FS_HIP(hipStreamSynchronize(s));
     pp.pending = nullptr;
     pp.enabled = true;
+    static uint64_t generation = 0;
+    pp.generation = ++generation;
     ++g_p2p_spaces;
     h.early = -1;              // the solver asks the ranks again which iteration they can all run
     // Self-test on the hardware at hand, before any solver trusts the transport: an all-reduce of (rank + 1) and a ghost refresh of
@@ -653,7 +663,6 @@ extern "C" int fs_space_enable_p2p_halo(fs_space_t space, int enable) {
         g_p2p_timeout_ticks = keep_timeout;
         const int rc3 = p2p_agree(good, "fs_space_enable_p2p_halo", "the self-test of the mapped buffers failed on this rank (sums or ghost values wrong, or a wait timed out)");
         if (rc3 != FS_OK) {
-            --g_p2p_spaces;
             pp.release();
             if (g_p2p_spaces == 0) g_p2p_red.release();
             return rc3;

@@ -165,6 +165,8 @@ struct fs_p2p_halo {
     double* pending = nullptr;      // vector of the exchange begun (plain send kernel) and not yet received
     dbuf<uint32_t> counter;         // [2]: workgroups through - of the plain send kernel, of the exchange kernel's send part
     dbuf<unsigned long long> d_seq; // device-side sequence number of the last executed exchange (fs_comm.hip)
+    uint64_t generation = 0;        // which enable of the process this is: everything a captured batch bakes in (flags, counters,
+                                    // index lists, mapped peers) is new after a disable / enable of the same space
     void release();
     ~fs_p2p_halo() { release(); }
 };

@@ -26,14 +26,21 @@ __device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
 // Memory-ordering discipline of these kernels.  A system-scope release fence on gfx950 is `buffer_wbl2` - it writes back EVERY
 // dirty line of the XCD's L2, and in the middle of a CG iteration that is the 4 MB per XCD the update and the product just wrote
 // (measured: + 10 us on a 20 000-row kernel).  The exchanged data therefore never becomes a dirty cached line in the first place:
-//   writer: every store into a peer's buffer is a system-scope (write-through, sc0 sc1) store;  s_waitcnt vmcnt(0) - all of
-//           them acknowledged - by a workgroup-scope release fence, workgroup barrier, then the sequence number, again a
-//           system-scope store;
+//   writer: every store into a peer's buffer is a system-scope (write-through, sc0 sc1) store; EVERY wave then waits for the
+//           acknowledgement of its own stores with an explicit `s_waitcnt vmcnt(0)` (fs_p2p_stores_done - inline assembly: a
+//           workgroup-scope release fence compiles to `s_waitcnt lgkmcnt(0)` only on gfx950 and leaves the data stores in
+//           flight; the compiler cannot drop or move the asm), workgroup barrier, then the sequence number, again a
+//           system-scope store.  Where several workgroups share one sequence number each of them does the above before its
+//           (relaxed, agent-scope) count: the workgroup that sees the last count publishes for all, and every other
+//           workgroup's stores were acknowledged before it counted;
 //   reader: spins on the sequence number with system-scope loads, then reads the data with system-scope loads (the buffers are
 //           fine-grained allocations: nothing of them is held in a cache).
 __device__ __forceinline__ void fs_p2p_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double fs_p2p_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void fs_p2p_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void fs_p2p_stores_done() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's remote stores are acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (and the compiler keeps later accesses behind this point)
+}
 __device__ __forceinline__ void fs_p2p_publish(unsigned long long* flag, unsigned long long seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -719,6 +719,24 @@ __global__ void k_set_iteration_limit(double* __restrict__ ctrl, int max_iter) {
 // FUSED: every workgroup first sums the SpMV's per-WG partials itself (same fixed order as
 // k_sum_partials, so all workgroups obtain bit-identical gamma/delta/rho) - saves one launch per
 // iteration on a single GPU; with a communicator the sums come from the all-reduced `sums`.
+// alpha, beta of the single-reduction recurrences from the reduced sums and the previous iteration's (gamma, alpha).  ONE definition
+// for every kernel that needs them - the update kernels, the peer-to-peer exchange kernel that advances the ghost rows of r and
+// s on its own, the pipelined recurrence: the ghost copies stay bit-identical to the owner's rows only if all of them apply the
+// same bits.  false: not SPD / NaN.
+__device__ __forceinline__ bool cg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
+                                            double& alpha, double& beta) {
+    beta = 0.0;
+    if (iter == 0) {
+        alpha = gamma / delta;
+    } else {
+        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+        beta = gamma / gamma_old;
+        alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    return (alpha > 0.0) && (alpha < 1e300) && (rho == rho);
+}
+
 template <bool FUSED>
 __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int check_only,
                                                         const double* __restrict__ partials, int npart,
@@ -759,16 +777,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int
         if (leader) { status[1] = iter; status[0] = 3; }
         return;
     }
-    double beta = 0.0, alpha;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) {  // not SPD / NaN
+    double beta, alpha;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {  // not SPD / NaN
         if (leader) { status[1] = iter; status[0] = 2; }
         return;
     }
@@ -1036,16 +1046,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         if (leader) { status[1] = iter; status[0] = 3; }
         return;
     }
-    double beta = 0.0, alpha;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) {
+    double beta, alpha;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
         if (leader) { status[1] = iter; status[0] = 2; }
         return;
     }
@@ -1108,16 +1110,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
     if (status[0] != 0) return;
     const double gamma = sums[0], delta = sums[1], rho = sums[2];
     if (rho <= ctrl[0] || check_only) return;
-    double beta = 0.0, alpha;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) return;
+    double beta, alpha;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
     const int64_t total = a + (n - b);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1205,16 +1199,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     __syncthreads();
     const double gamma = tot[0], delta = tot[1], rho = tot[2];
     if (rho <= ctrl[0] || check_only) return;
-    double beta = 0.0, alpha;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    if (!(alpha > 0.0) || !(alpha < 1e300) || !(rho == rho)) return;
+    double beta, alpha;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
     // 3. ghost rows: s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g (the two lines of the update kernel)
     if (t < snd.nn) fs_p2p_wait(snd.own_flags + (int64_t)hslot * snd.nn + t, hseq, snd.timeout, snd.err);
     __syncthreads();
@@ -1239,20 +1225,6 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
 // the other).  112 instead of 72 B/DOF of vector traffic per iteration: it only pays where a collective is hidden.
 // Rows [m0, m1) are updated by this launch; rows [0, m0) and [m1, n) - what a slab sends to its neighbours - were already
 // updated by k_pcg_update_rows (so that their exchange could start) and only enter the sums here.
-__device__ __forceinline__ bool pcg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
-                                            double& alpha, double& beta) {
-    beta = 0.0;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    return (alpha > 0.0) && (alpha < 1e300) && (rho == rho);
-}
-
 template <bool FUSED, bool NT>
 __global__ void __launch_bounds__(FS_BLOCK) k_pcg_update(int64_t n, int64_t m0, int64_t m1, int iter, int check_only,
                                                          double* __restrict__ partials, int npart,
@@ -1283,7 +1255,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_pcg_update(int64_t n, int64_t m0, 
         return;
     }
     double alpha, beta;
-    if (!pcg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
         if (leader) { status[1] = iter; status[0] = 2; }
         return;
     }
@@ -1360,7 +1332,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_pcg_update_rows(int64_t a, int64_t
     const double gamma = sums[0], delta = sums[1], rho = sums[2];
     if (rho <= ctrl[0] || check_only) return;
     double alpha, beta;
-    if (!pcg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
     const int64_t total = a + (n - b);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2533,7 +2505,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                                        dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
                                        dict_on ? (const void*)sp->dict_items.p : nullptr, p2p_fuse ? (const void*)ws.sg.p : nullptr,
                                        dict_on ? (const void*)sp->dict_plans.p : nullptr, dict_on ? (const void*)sp->halo.items_interior.p : nullptr,
-                                       dict_on ? (const void*)sp->halo.items_boundary.p : nullptr, nullptr};
+                                       dict_on ? (const void*)sp->halo.items_boundary.p : nullptr,
+                                       p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,

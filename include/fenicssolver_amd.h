@@ -498,7 +498,9 @@ int fs_halo_exchange(fs_space_t space, fs_vector_t v);
  * The call ends with a self-test of the mapped buffers (an all-reduce and a ghost refresh of known values, 0.5 s time-out)
  * whose outcome the ranks agree on: FS_ERR_COMM on every rank if any of them saw a wrong or missing value.
  * COLLECTIVE over the communicator: every rank calls it for its space in the same order; enable = 0 turns it off
- * (required before fs_space_set_halo replaces the plan).  FS_ERR_COMM without a communicator. */
+ * (required before fs_space_set_halo replaces the plan).  FS_ERR_COMM without a communicator.
+ * Destroying a space with the exchange still on frees buffers its neighbours have mapped: do it on every rank at the same
+ * point of the program (after a solve returned no rank has a store in flight), or turn the exchange off first. */
 int fs_space_enable_p2p_halo(fs_space_t space, int enable);
 /* Mean latency (ms) of the two collectives of a distributed CG iteration as the solver issues them - the 3-double
  * ncclAllReduce behind VecDot (SolverBase.py:634 under mpirun) and the ghost refresh of this space's halo plan behind

@@ -34,6 +34,10 @@ def test_default_command_prints_the_contract_line(gpu):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-3
+    # a roofline fraction: the bytes the kernel's storage form has to move over its duration, never above the peak
+    assert 0.3 <= r["frac"] <= 1.0 and abs(r["achieved"] - r["required_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) <= 1e-3 * r["achieved"]
+    assert r["csr_equivalent_GBps"] > r["achieved"] and 0.3 <= r["iteration"]["frac"] <= 1.0 and 0.5 <= r["update_kernel"]["frac"] <= 1.0
+    assert d["one_shot_dof_per_s"] < d["value"] and r["one_shot"]["dof_per_s"] < r["dof_per_s"]
     # the BASELINE operator has repeated rows: the line says so and carries the streaming kernel's roofline beside it
     assert "k_dict_spmv" in r["kernel"] and "note_row_dictionary" in r
     s = r["streaming_kernel"]
