@@ -1675,26 +1675,36 @@ struct dict_item_builder {
         std::vector<unit> units;
         units.reserve(seq.size());
         const int64_t n_cols = sp->n_nodes_local;
+        long long why[5] = {0, 0, 0, 0, 0};
         for (int32_t sl = 0; sl < ns;) {
             if (rank[(size_t)sl] < 0) { ++sl; continue; }
             bool pair = sl + 1 < ns && rank[(size_t)sl + 1] >= 0 && dp[(size_t)sl] >= 0 && dp[(size_t)sl + 1] >= 0 &&
                         (int64_t)(sl + 2) * FS_SLICE <= sp->n_nodes_owned;
             const int w = width(sl);
+            if (!pair) ++why[0];
             if (pair) {
                 const int32_t da = dp[(size_t)sl], db = dp[(size_t)sl + 1];
-                pair = w > 0 && w == width(sl + 1) && off[(size_t)da] >= FS_SLICE && off[(size_t)db] >= FS_SLICE;
-                if (pair && da != db)
+                pair = w > 0 && w == width(sl + 1);
+                if (!pair) ++why[1];
+                if (pair) { pair = off[(size_t)da] >= FS_SLICE && off[(size_t)db] >= FS_SLICE; if (!pair) ++why[2]; }
+                if (pair && da != db) {
                     for (int k = 0; k < w && pair; ++k) pair = off[(size_t)da + 1 + k] == off[(size_t)db + 1 + k];
+                    if (!pair) ++why[3];
+                }
                 if (pair) {
                     const dict_plan_info& pi = plan_for(da, w);
                     const int64_t base = (int64_t)sl * FS_SLICE;
                     pair = base + pi.min_start >= 0 && base + 2 * FS_SLICE + 1 + pi.max_start <= n_cols - 1;
+                    if (!pair) ++why[4];
                     if (pair) units.push_back({rank[(size_t)sl], sl, pi.rounds, pi.first});
                 }
             }
             if (pair) sl += 2;
             else { units.push_back({rank[(size_t)sl], sl, 0, 0}); sl += 1; }
         }
+        if (getenv("FS_KRYLOV_DEBUG"))
+            fprintf(stderr, "[fs_krylov] slices left single: no partner / incomplete %lld, widths differ %lld, split slice %lld, offset lists differ %lld, accesses out of range %lld\n",
+                    why[0], why[1], why[2], why[3], why[4]);
         std::sort(units.begin(), units.end(), [](const unit& u, const unit& v) { return u.key < v.key; });
         items.clear();
         items.reserve(units.size() * 4);
