@@ -475,10 +475,13 @@ class Watchdog:
 
 
 def kernel_name(V, st=None):
-    if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, dictionary in LDS
-        lds = st["row_classes"] * (16 if V.degree == 1 else 80) <= 6144       # fs_krylov.hip FS_DICT_LDS_DOUBLES (rows padded to 16s)
-        return "k_dict_spmv<3,%s> (row-dictionary form: %d distinct rows, dictionary %s)" % (
-            "true" if lds else "false", st["row_classes"], "in LDS" if lds else "read through the caches")
+    if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
+        # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
+        # class rows are 24 doubles per round of the longest run plan: 1 round on P1, 5 on CG2 Kuhn meshes) / per-item class rows
+        whole = st["row_classes"] * (24 if V.degree == 1 else 120) * 8 <= (32 << 10)
+        return "k_dict_spmv<3,%s> (row-dictionary form: %d distinct rows, %s)" % (
+            "true" if whole else "false", st["row_classes"],
+            "whole dictionary in LDS" if whole else "the class rows of each work item copied into its wave's LDS region")
     nt = V.sell_entries * 8 > (192 << 20)          # fs_krylov.hip spmv_nontemporal(): matrix larger than the caches
     one = "k_sell_spmv<1,3,%d,%s>" % (4 if V.n_slices <= 32768 else 16, "true" if nt else "false")
     if V.n_slices > 32768 and V.degree == 1 and V.n_dia_slices > 0:       # spmv_use_pairs(): paired DIA slices, two rows per lane
@@ -546,7 +549,8 @@ def committed_traffic(tag):
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["required_GBps"] / HBM_PEAK_GBS
     what = (" (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
-            "LDS, two rows per lane over pairs of slices; template arguments: dot mode, dictionary in LDS)") if k.get("row_classes", 0) > 0 else (
+            "LDS, work items of 126 rows - two per lane -, one 16-byte load per run of consecutive offsets; template arguments: dot mode, "
+            "whole dictionary in LDS)") if k.get("row_classes", 0) > 0 else (
         " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template arguments of k_sell_spmv: block "
         "size, dot mode, entries per round, non-temporal matrix loads; of k_dia_pair_spmv: dot mode, non-temporal matrix loads)")
     r = {"kernel": k["kernel"] + what,

@@ -249,13 +249,13 @@ struct fs_space_s {
                                   // rows [split, 64) of a SPLIT slice use list B (fs_symbolic.hip, k_slice_analyze)
     // two-rows-per-lane product (k_dia_pair_spmv): pairs of slices, consecutive in processing order, both complete DIA
     // slices with identical offset lists; pair_singles = every other slice, in processing order.  Built on first use.
-    // row-dictionary product (fs_krylov.hip, k_dict_pair_spmv): work items in processing order, one 16-byte scalar load each -
-    //   pair of consecutive complete DIA slices with one offset list, every access in range: (first slice, -rounds, first plan round, 0)
-    //   single slice:                                                                          (slice, width, dia_ptr, split)
-    // dict_plans: run plans of the distinct offset lists, 16 ints per round (fs_krylov.hip, dict_plan_round).  Built on first use.
+    // row-dictionary product (fs_krylov.hip, k_dict_spmv): work items of <= 128 consecutive rows with one offset list, in processing
+    // order, one 16-byte scalar load each: (first row, rows | edge << 16, first plan round, rounds); dict_plans: the run plans, 16
+    // ints per round (dict_plan_round); dict_slots: doubles per class row in plan layout.  Built on first use (dict_structure_build).
     dbuf<int32_t> dict_items;     // [n_dict_items][4]
     dbuf<int32_t> dict_plans;
-    int64_t n_dict_items = -1;    // -1: not built yet
+    int dict_slots = 0;
+    int64_t n_dict_items = -1;    // -1: not built yet, 0: the pattern does not lend itself to the form
     dbuf<int32_t> pair_list;      // [2 * n_pairs]
     dbuf<int32_t> pair_singles;   // [n_pair_singles]
     int64_t n_pairs = -1, n_pair_singles = 0;      // -1: not built yet

@@ -18,6 +18,8 @@
 #include "fs_common.h"
 #include "fs_kernels.h"
 #include <chrono>
+#include <string>
+#include <unordered_map>
 #include <math.h>
 #include <stdlib.h>
 
@@ -375,84 +377,157 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int6
 
 
 // ---- row-dictionary form of a scalar DIA matrix ---------------------------------------------------------------------------------
-// On a uniform box mesh with constant coefficients (BASELINE configs[0] / [1]: BoxMesh, k = 20) the assembled operator has a few
-// dozen DISTINCT rows - interior, the 26 kinds of boundary position, the rows next to Dirichlet faces - each repeated bit for bit
-// (the box assembly snaps its edge vectors to the grid spacing, fs_assemble.hip, so that rows are translation-invariant).  The
-// product then does not have to stream 8 B per entry: every row carries a 2-byte class number and the distinct value rows sit
-// in LDS.  Built per solve from the values the solver is about to multiply with (one pass hashes the rows into a 1024-slot
-// table, one verifies EVERY row bit for bit against its class - a hash collision or a 513th class simply leaves the plain
-// form in use), so it is lossless and needs no knowledge of where the matrix came from.  Same offsets, same summation order,
-// same bits as k_sell_spmv.  Measured on MI355X at 1 M rows: product 26 -> 14 us.
+// On a uniform box mesh with constant coefficients (BASELINE configs[0] / [1] / [3]: BoxMesh, k = 20) the assembled operator has a
+// few dozen (P1) to a few hundred (CG2) DISTINCT rows - interior, the 26 kinds of boundary position, the rows next to Dirichlet
+// faces - each repeated bit for bit (the box assembly snaps its edge vectors to the grid spacing, fs_assemble.hip, so that rows are
+// translation-invariant).  The product then does not have to stream 8 B per entry: every row carries a 2-byte class number and
+// the distinct coefficient rows are fetched per work item.  Built per solve from the values the solver is about to multiply with,
+// every row verified bit for bit against its class, so it is lossless and needs no knowledge of where the matrix came from.
+//
+// Round 4: the product is organised by ROWS, not by the 64-row slices of the value storage it no longer reads.
+//   * SEGMENTS (once per space, dict_structure_build): maximal runs of consecutive rows whose (col - row) offset sets are nested in
+//     one list - on a box mesh a mesh line (CG2: 107 / 108 rows, every line its own list because the edge classes are numbered with
+//     different line lengths) or, where all lines share one list (P1), the whole mesh.  Cut into WORK ITEMS of <= 128 rows.
+//   * the segment's offset list is cut into RUNS of up to three consecutive offsets (o, o + 1, o + 2).  A lane holds TWO consecutive
+//     rows; for a run starting at o its rows need x[r + o .. r + o + 3]: ONE 16-byte load x[r + o], x[r + o + 1] per lane, the
+//     other two values are the NEXT lane's load (DPP wave shift, no LDS); lane 63 has no rows of its own - an item is 126 rows -
+//     and loads what lane 62 needs (tests/test_gpu_kernels.py multiplies chains of dependent vectors bit for bit against the
+//     streaming product).  3.5 vector-memory instructions per row on the Kuhn stencil
+//     instead of the 19 of round 3, whose per-CU address path - not HBM - was the limit (0.27 of the peak on 26 B/row).
+//   * a RUN PLAN per segment: rounds of 8 runs (start offset, length); slot 0 of round 0 is the run (0; no coefficients) whose
+//     load IS z = x[r], x[r + 1] for the fused dots.  A class row holds its coefficients IN PLAN LAYOUT, [round][run][3], zero where
+//     a run is shorter or the row has no such entry: the kernel reads them at fixed positions.  Ascending offsets = the storage
+//     order of the streaming kernels, one fma each: same summation order, same bits (the extra terms add +0 * x).
+//   * per item, the distinct classes of its rows (a mesh line: interior + the two ends) are copied into the wave's own LDS
+//     region (sized for the item with the most classes, counted when the classes are found; at most 64 KB per workgroup) - the
+//     dictionary itself may have any size (CG2: 350 KB).
+//   * items whose loads could leave [0, n_cols) (first / last mesh plane) gather their four values per run one by one, clamped.
+// Measured (tools/probes/dict_pair_probe.hip and profiles/r04_*): P1, 10 M rows: 123 -> 64 us.
 constexpr int FS_DICT_CAP = 8192;       // hash slots
 constexpr int FS_DICT_MAX = 4096;       // distinct rows accepted
-constexpr int FS_DICT_LDS_DOUBLES = 6144;   // ncls * width must fit (48 KB)
+constexpr int FS_DICT_ITEM_ROWS = 126;  // rows per work item: two per lane for lanes 0 .. 62; lane 63 only loads (its pair is what lane 62
+                                        // needs from `the next lane`: no separate tail loads)
+constexpr int FS_DICT_WHOLE_LDS_BYTES = 32 << 10;   // a dictionary up to this size is held whole by every workgroup
+constexpr int FS_DICT_LDS_BYTES = 64 << 10;   // per workgroup: 4 waves x (most distinct classes of any item) x (doubles per class row)
+constexpr int FS_DICT_ITEMS_PER_WAVE = 4;   // consecutive items a wave takes when it fetches class rows per item
+constexpr int FS_DICT_MAX_ROUNDS = 8;   // rounds of 8 runs per plan (192 coefficient positions)
 
-__device__ __forceinline__ unsigned long long dict_row_hash(const double* __restrict__ vp, int width) {
-    unsigned long long h = 1469598103934665603ull;
-    for (int k = 0; k < width; ++k) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(vp[(int64_t)k * FS_SLICE]);
-        h = (h ^ b) * 1099511628211ull;
-        h ^= h >> 29;
+struct dict_plan_round {
+    int32_t start[8];       // first offset of each run (0 for an empty slot: a harmless load of x[r], x[r + 1])
+    uint8_t len[8];         // 0 .. 3
+    uint8_t pad[24];
+};
+static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round");
+
+// Coefficient position (plan layout) of the stored entry with offset o, walking the runs of a plan in ascending order from run g on
+// (the entries of a row come in ascending offsets, as the runs do): -1 = the plan has no such offset.
+__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int& g, int32_t o) {
+    while (g < n_runs) {
+        const dict_plan_round& pr = pl[g >> 3];
+        const int32_t st = pr.start[g & 7];
+        const int ln = pr.len[g & 7];
+        if (ln > 0 && o < st + ln) return o >= st ? 3 * g + (o - st) : -1;
+        ++g;
     }
-    h ^= (unsigned long long)width * 0x9E3779B97F4A7C15ull;
-    return h ? h : 1ull;
+    return -1;
 }
 
-// info[0] = classes found, info[1] = 1: gave up (too many classes), info[2] = rows that differ from their class (verification)
+// One row's stored entries (DIA slice storage: value plane k, offset list of the row's piece of its slice), nonzero ones only:
+// f(slot, value).  Returns false when an entry has no position in the plan.
+template <typename F>
+__device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
+                                              const int32_t* __restrict__ dia_off, const double* __restrict__ val,
+                                              const dict_plan_round* __restrict__ pl, int n_runs, F f) {
+    const int32_t sl = r >> 6, ln = r & 63;
+    const int64_t base = slice_ptr[sl];
+    const int width = (int)((slice_ptr[sl + 1] - base) >> 6);
+    const int32_t dp = dia_ptr[sl];
+    const int32_t* __restrict__ op = dia_off + dp + 1 + (ln >= dia_off[dp] ? width : 0);
+    const double* __restrict__ vp = val + base + ln;
+    int g = 1;                  // run 0 is the z run
+    bool ok = true;
+    for (int k = 0; k < width; ++k) {
+        const double v = vp[(int64_t)k * FS_SLICE];
+        if (v == 0.0) continue;
+        const int slot = dict_slot_of(pl, n_runs, g, op[k]);
+        if (slot < 0) { ok = false; break; }
+        f(slot, v);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ unsigned long long dict_mix(unsigned long long h, int slot, double v) {
+    h = (h ^ (unsigned long long)__double_as_longlong(v)) * 1099511628211ull;
+    h = (h ^ (unsigned long long)(unsigned)slot) * 1099511628211ull;
+    return h ^ (h >> 29);
+}
+
+// info[0] = classes found, info[1] = 1: gave up (too many classes), info[2] = rows that differ from their class or do not fit their
+// plan (verification), info[3] = most distinct classes in any item
 // Nearly all rows of such an operator carry the SAME hash, so the table is hit where it hurts: the lanes of a wave are first grouped
 // by hash (a wave of interior rows is one group) and only the group's first lane goes to memory, and it looks at the slot with an
 // ordinary cached load before any atomic (a slot goes from 0 to its final key once: a key seen there is final, a stale 0 merely
-// sends the lane to the compare-and-swap, which returns the truth).  First version, every lane with agent-scope loads of the one
-// hot slot: 0.5 ms per solve at 1 M rows.
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
-                                                          const double* __restrict__ val, int W, unsigned long long* keys,
-                                                          const unsigned long long* keys_cached, double* slot_vals,
+// sends the lane to the compare-and-swap, which returns the truth).
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
+                                                          const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S,
+                                                          unsigned long long* keys, const unsigned long long* keys_cached, double* slot_vals,
                                                           uint16_t* __restrict__ cls_slot, int* info) {
     const int lane = threadIdx.x & 63;
-    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (; s < n_slices; s += stride) {
+    for (; q < n_items; q += stride) {
         if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-        const int64_t r = s * FS_SLICE + lane;
-        const bool live = r < n_rows;
-        const double* __restrict__ vp = val + base + lane;
-        const unsigned long long h = live ? dict_row_hash(vp, width) : 0ull;
-        int my_slot = 0;
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const unsigned long long hl = ((unsigned long long)(unsigned)__shfl((int)(h >> 32), leader, 64) << 32) |
-                                          (unsigned long long)(unsigned)__shfl((int)(h & 0xffffffffull), leader, 64);
-            const bool mine = live && h == hl;
-            int slot = (int)(hl & (FS_DICT_CAP - 1));
-            if (lane == leader) {
-                for (int probe = 0; probe < FS_DICT_CAP; ++probe) {
-                    unsigned long long old = keys_cached[slot];
-                    if (old != hl) {
-                        old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, hl);
-                        if (old == 0ull) {                  // this row is the representative of a new class
-                            if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            for (int k = 0; k < W; ++k) slot_vals[(int64_t)slot * W + k] = k < width ? vp[(int64_t)k * FS_SLICE] : 0.0;
-                            break;
+        const int4 it = items[q];
+        const int32_t first = it.x, nr = it.y & 0xffff;
+        const dict_plan_round* __restrict__ pl = plans + it.z;
+        const int n_runs = 8 * it.w;
+        for (int half = 0; half < 2; ++half) {
+            const int i = half * 64 + lane;
+            const bool live = i < nr;
+            const int32_t r = first + i;
+            unsigned long long h = 1469598103934665603ull;
+            bool fits = true;
+            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int slot, double v) { h = dict_mix(h, slot, v); });
+            if (!h) h = 1ull;
+            if (live && !fits) atomicAdd(&info[2], 1);
+            int my_slot = 0;
+            unsigned long long todo = __ballot(live);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const unsigned long long hl = ((unsigned long long)(unsigned)__shfl((int)(h >> 32), leader, 64) << 32) |
+                                              (unsigned long long)(unsigned)__shfl((int)(h & 0xffffffffull), leader, 64);
+                const bool mine = live && h == hl;
+                int slot = (int)(hl & (FS_DICT_CAP - 1));
+                if (lane == leader) {
+                    for (int probe = 0; probe < FS_DICT_CAP; ++probe) {
+                        unsigned long long old = keys_cached[slot];
+                        if (old != hl) {
+                            old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, hl);
+                            if (old == 0ull) {                  // this row is the representative of a new class
+                                if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                double* __restrict__ dst = slot_vals + (int64_t)slot * S;       // (zero-filled by the host before the launch)
+                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
+                                break;
+                            }
                         }
+                        if (old == hl) break;
+                        slot = (slot + 1) & (FS_DICT_CAP - 1);
                     }
-                    if (old == hl) break;
-                    slot = (slot + 1) & (FS_DICT_CAP - 1);
                 }
+                slot = __shfl(slot, leader, 64);
+                if (mine) my_slot = slot;
+                todo &= ~__ballot(mine);
             }
-            slot = __shfl(slot, leader, 64);
-            if (mine) my_slot = slot;
-            todo &= ~__ballot(mine);
+            if (live) cls_slot[r] = (uint16_t)my_slot;
         }
-        if (live) cls_slot[r] = (uint16_t)my_slot;
     }
 }
 
+// number the occupied slots; values[id][S] = the class rows in plan layout, nnz[id] = their nonzero positions
 __global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long* __restrict__ keys, const double* __restrict__ slot_vals,
-                                                       int W, int32_t* __restrict__ slot2cls, double* __restrict__ values) {
+                                                       int S, int32_t* __restrict__ slot2cls, double* __restrict__ values, int32_t* __restrict__ nnz) {
     constexpr int PER = FS_DICT_CAP / 1024;       // consecutive slots per thread
     __shared__ int cnt[1024];
     const int t = threadIdx.x;
@@ -471,73 +546,84 @@ __global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long*
         const int slot = t * PER + q;
         const bool used = keys[slot] != 0ull;
         slot2cls[slot] = used ? id : -1;
-        if (used && id < FS_DICT_MAX)
-            for (int k = 0; k < W; ++k) values[(int64_t)id * W + k] = slot_vals[(int64_t)slot * W + k];
+        if (used && id < FS_DICT_MAX) {
+            int nz = 0;
+            for (int k = 0; k < S; ++k) {
+                const double v = slot_vals[(int64_t)slot * S + k];
+                values[(int64_t)id * S + k] = v;
+                nz += v != 0.0;
+            }
+            nnz[id] = nz;
+        }
         id += used;
     }
 }
 
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
-                                                          const double* __restrict__ val, int W, const int32_t* __restrict__ slot2cls,
-                                                          const double* __restrict__ values, const uint16_t* __restrict__ cls_slot,
+// class numbers; EVERY row against its class, bit for bit (a hash collision ends here); the distinct classes of every item counted
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
+                                                          const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S,
+                                                          const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
+                                                          const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
                                                           uint16_t* __restrict__ cls, int* info) {
     const int lane = threadIdx.x & 63;
-    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    int bad = 0;
-    for (; s < n_slices; s += stride) {
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-        const int64_t r = s * FS_SLICE + lane;
-        if (r >= n_rows) { cls[r] = 0; continue; }        // (cls holds n_slices * 64 entries)
-        const int id = slot2cls[cls_slot[r]];
-        cls[r] = (uint16_t)(id < 0 ? 0 : id);
-        if (id < 0 || id >= FS_DICT_MAX) { ++bad; continue; }
-        const double* __restrict__ vp = val + base + lane;
-        const double* __restrict__ dv = values + (int64_t)id * W;
-        for (int k = 0; k < width; ++k)
-            bad += __double_as_longlong(vp[(int64_t)k * FS_SLICE]) != __double_as_longlong(dv[k]);
+    int bad = 0, crowded = 0;       // (crowded: most distinct classes of an item so far)
+    for (; q < n_items; q += stride) {
+        const int4 it = items[q];
+        const int32_t first = it.x, nr = it.y & 0xffff;
+        const dict_plan_round* __restrict__ pl = plans + it.z;
+        const int n_runs = 8 * it.w;
+        int id2[2] = {-1, -1};
+        for (int half = 0; half < 2; ++half) {
+            const int i = half * 64 + lane;
+            if (i >= nr) continue;
+            const int32_t r = first + i;
+            const int id = slot2cls[cls_slot[r]];
+            cls[r] = (uint16_t)(id < 0 ? 0 : id);
+            if (id < 0 || id >= FS_DICT_MAX) { ++bad; continue; }
+            id2[half] = id;
+            const double* __restrict__ dv = values + (int64_t)id * S;
+            int nz = 0, diff = 0;
+            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int slot, double v) {
+                ++nz;
+                diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
+            });
+            bad += !fits || diff != 0 || nz != nnz[id];
+        }
+        // distinct classes among the item's rows (what its wave will have to hold in LDS)
+        int distinct = 0;
+        unsigned long long m0 = __ballot(id2[0] >= 0), m1 = __ballot(id2[1] >= 0);
+        while (m0 | m1) {
+            const bool from0 = m0 != 0ull;
+            const int src = __ffsll((long long)(from0 ? m0 : m1)) - 1;
+            const int cv = __shfl(from0 ? id2[0] : id2[1], src, 64);
+            m0 &= ~__ballot(id2[0] == cv);
+            m1 &= ~__ballot(id2[1] == cv);
+            ++distinct;
+        }
+        crowded = distinct > crowded ? distinct : crowded;
     }
     if (bad) atomicAdd(&info[2], bad);
+    if (crowded && lane == 0) atomicMax(&info[3], crowded);
 }
 
-// ---- the product: pairs of slices, two rows per lane, runs of consecutive offsets -----------------------------------------------
-// Round 3 (one row per lane, 16 clamped 8-byte gathers + class + z + d = 19 vector-memory instructions per row) ran at 0.27 of the
-// HBM peak on the 26 bytes a row has to move: the per-CU address path was the limit, as for the streaming kernels.  This form
-// issues 3.5 such instructions per row.  A wave takes a PAIR of consecutive complete DIA slices that share one offset list (128
-// rows, lane l rows 2l and 2l + 1).  The offset list is cut into RUNS of up to three consecutive offsets (o, o + 1, o + 2; the
-// Kuhn stencil: 7 runs for 15 offsets); for a run starting at o the two rows of a lane need x[r + o .. r + o + 3]: ONE 16-byte load
-// x[r + o], x[r + o + 1] per lane, the other two values are the NEXT lane's load (DPP wave shift, no LDS), and lane 63's come
-// from one 16-byte scalar load x[base + 128 + o ..] (the scalar data cache is invalidated at every kernel boundary like the vector
-// L1; the bit-for-bit comparisons with the streaming product over hundreds of dependent iterations would show a stale line).
-// A `run plan` per distinct offset list says, per round of 8 runs, where each run starts and which position of the class row
-// holds its three coefficients (the zero slot W - 1 past its length) - so the summation order is the streaming kernels' (ascending
-// position, one fma each; the extra terms add +0 * x).  Slot 7 of round 0 is the run (0; no coefficients): its load IS z = x[r],
-// x[r + 1] for the fused dots.  Pairs whose loads could leave [0, n_cols) (first / last mesh plane), split slices and slices without
-// a partner go through the one-row-per-lane code as single items.  Measured (tools/probes/dict_pair_probe.hip, 10 M rows):
-// 116 -> 62 us = 4.2 TB/s on 26 B/row; bpermute instead of DPP 80 us; dictionary re-laid out in plan order, descriptor
-// prefetch, one coefficient set when both rows share a class: 61-63 us (not kept).
-struct dict_plan_round {
-    int32_t start[8];
-    uint8_t kidx[8][4];
-};
-static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round");
-
-// the next lane's value; lane 63 takes `tail` (wave_shl:1 leaves the destination of a lane without a source untouched)
-__device__ __forceinline__ double fs_from_next_lane(double v, double tail) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(tail), __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(tail), __double2hiint(v), 0x130, 0xf, 0xf, false);
+// the next lane's value (DPP wave shift, no LDS); lane 63, which has no next lane, owns no rows
+__device__ __forceinline__ double fs_from_next_lane(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
-// LDSD: the dictionary fits LDS (P1: 86 rows of 16); otherwise (CG2: 492 rows of 80 = 315 KB) it is read from memory - it
-// stays in L2, and the lanes of a wave mostly ask for the same class, so that a load is one broadcast line
+// item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (24 per round
+// of the longest plan of the space), C = class rows a wave's LDS region holds.  Dynamic LDS: 4 waves x C x S doubles.
+// LDSD: the whole dictionary fits the workgroup's LDS (P1: 78 class rows of 24 doubles) - loaded once per workgroup, a row's
+// coefficients sit at class * S; otherwise (CG2: 361 rows of 120) each item's classes are copied into its wave's region.
 template <int DOTS, bool LDSD>
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t n_cols, int64_t n_items,
-                                                        const int4* __restrict__ items, const int32_t* __restrict__ dia_off,
-                                                        const dict_plan_round* __restrict__ plans,
-                                                        const uint16_t* __restrict__ cls,
-                                                        const double* __restrict__ dict, int ncls, int W,
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
+                                                        const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
+                                                        const double* __restrict__ dict, int S, int C,
                                                         const double* __restrict__ x, double* __restrict__ y,
                                                         const double* __restrict__ rvec, double* __restrict__ partials,
                                                         int* __restrict__ status, int part_base, int part_stride, int bump, int map_xcd) {
@@ -548,123 +634,144 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_rows, int64_t 
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
     extern __shared__ double sdict[];
-    if (LDSD) {
-        for (int i = threadIdx.x; i < ncls * W; i += FS_BLOCK) sdict[i] = dict[i];
-        __syncthreads();
-    }
     __shared__ double lds4[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    double* __restrict__ wl = LDSD ? sdict : sdict + (int64_t)wave * C * S;
+    if (LDSD) {
+        for (int i = threadIdx.x; i < C * S; i += FS_BLOCK) sdict[i] = dict[i];      // (C = number of classes here)
+        __syncthreads();
+    }
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    const int64_t n_chunks = (n_items + 3) >> 2;
+    // A wave takes K CONSECUTIVE items of a chunk of 4 K: with per-item class rows (!LDSD) neighbouring mesh lines hold the same
+    // classes, and a class row already in the wave's region (tagv: lane k knows which class slot k holds) is not fetched again.
+    constexpr int K = LDSD ? 1 : FS_DICT_ITEMS_PER_WAVE;
+    const int64_t n_chunks = (n_items + 4 * K - 1) / (4 * K);
     const int32_t cmax = (int32_t)(n_cols - 1);
-    const int64_t n_waves = ((int64_t)gridDim.x * FS_BLOCK) >> 6;
     chunk_iter it = xcd_chunks(n_chunks);
-    int64_t q = map_xcd ? (it.cur < it.end ? it.cur * 4 + wave : n_items) : (((int64_t)blockIdx.x * FS_BLOCK + threadIdx.x) >> 6);
-    const double* __restrict__ dbase = LDSD ? sdict : dict;
-    while (q < n_items) {
+    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
+    int tagv = -1, rr = 0;
+    const unsigned long long cmask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+    for (; it.cur < it.end; it.cur += it.step)
+    for (int kk = 0; kk < K; ++kk) {
+        const int64_t q = (it.cur * 4 + wave) * K + kk;
+        if (q >= n_items) break;
         const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
-        const int32_t sl = __builtin_amdgcn_readfirstlane(ds.x);
-        const int rounds = -__builtin_amdgcn_readfirstlane(ds.y);
-        if (rounds > 0) {
-            // ---- a pair of slices, two rows per lane ----
-            const int32_t base = sl * FS_SLICE;
-            const int32_t r = base + 2 * lane;
-            const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
-            v2d ri = {0.0, 0.0}, zi = {0.0, 0.0};
-            if (DOTS && DOTS != 4) ri = *reinterpret_cast<const v2d*>(&rvec[r]);
-            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
-            const double* __restrict__ v0 = dbase + (int)(two & 0xffffu) * W;
-            const double* __restrict__ v1 = dbase + (int)(two >> 16) * W;
-            const double* __restrict__ xr = x + r;
-            const double* __restrict__ xt = x + base + 2 * FS_SLICE;
-            double a0 = 0.0, a1 = 0.0;
-            for (int rd = 0; rd < rounds; ++rd) {
-                const dict_plan_round* __restrict__ p = pl + rd;
-                v2d A[8], T[8];
+        const int32_t first = __builtin_amdgcn_readfirstlane(ds.x);
+        const int nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
+        const int edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
+        const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
+        const int rounds = __builtin_amdgcn_readfirstlane(ds.w);
+        const int32_t r = first + 2 * lane;
+        const bool ok0 = 2 * lane < nr, ok1 = 2 * lane + 1 < nr;
+        v2d ri = {0.0, 0.0};
+        if (DOTS && DOTS != 4) {
+            if (ok1) ri = *reinterpret_cast<const v2du*>(&rvec[r]);
+            else if (ok0) ri.x = rvec[r];
+        }
+        const int c0 = ok0 ? (int)cls[r] : -1, c1 = ok1 ? (int)cls[r + 1] : -1;
+        // the x values of the first round are asked for before anything waits for the class numbers.  Items whose accesses could leave
+        // [0, n_cols) (first / last rows of the vector) load the two values of a pair one by one, each clamped into x: a column
+        // outside the vector has no entry, hence a zero coefficient, and every value inside it is the right one.
+        const double* __restrict__ xr = x + r;
+        v2d A[8];
+        auto load_round = [&](v2d (&buf)[8], const dict_plan_round* __restrict__ p) {
+            if (!edge) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int32_t st = p->start[j];
-                    A[j] = *reinterpret_cast<const v2du*>(xr + st);
-                    T[j] = *reinterpret_cast<const v2du*>(xt + st);       // wave-uniform address: a scalar load
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double e0 = A[j].x, e1 = A[j].y;
-                    const double e2 = fs_from_next_lane(A[j].x, T[j].x), e3 = fs_from_next_lane(A[j].y, T[j].y);
-                    const int k0 = p->kidx[j][0], k1 = p->kidx[j][1], k2 = p->kidx[j][2];
-                    a0 = fma(v0[k0], e0, a0); a1 = fma(v1[k0], e1, a1);
-                    a0 = fma(v0[k1], e1, a0); a1 = fma(v1[k1], e2, a1);
-                    a0 = fma(v0[k2], e2, a0); a1 = fma(v1[k2], e3, a1);
-                }
-                if (rd == 0) zi = A[7];
-            }
-            v2d out;
-            out.x = a0; out.y = a1;
-            *reinterpret_cast<v2d*>(&y[r]) = out;
-            if (DOTS == 1) {
-                d_rz += ri.x * zi.x + ri.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * ri.x + ri.y * ri.y;
-            } else if (DOTS == 2) {
-                d_rz += a0 * ri.x + a1 * ri.y; d_wz += a0 * a0 + a1 * a1; d_rr += ri.x * ri.x + ri.y * ri.y;
-            } else if (DOTS == 3) {
-                d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
-            }
-        } else {
-            // ---- a single slice, one row per lane (round 3) ----
-            const int width = -rounds;
-            const int32_t r = sl * FS_SLICE + lane;
-            const bool live = r < n_rows;
-            const int split = __builtin_amdgcn_readfirstlane(ds.w);
-            const int32_t* __restrict__ op = dia_off + __builtin_amdgcn_readfirstlane(ds.z) + 1;
-            const int32_t* __restrict__ op2 = op + (split < FS_SLICE ? width : 0);
-            const bool hi = lane >= split;
-            double zi = 0.0, ri = 0.0;
-            if (DOTS && DOTS != 4 && live) {
-                if (DOTS == 1 || DOTS == 3) zi = x[r];
-                ri = rvec[r];
-            }
-            const double* __restrict__ vp = dbase + (int)cls[r] * W;
-            double acc = 0.0;
-            // rounds of 16 entries WITHOUT a guard (a guarded load makes the compiler wait for the previous one): positions past
-            // the slice's width read whatever follows in the offset array (the address is clamped into x, dia_off is padded by
-            // 64 ints) and multiply it by the zeros the dictionary rows are padded with up to W, a multiple of 16
-            constexpr int U = 16;
-            if (split >= FS_SLICE) {                    // (wave-uniform) one offset list for the whole slice
-                for (int k = 0; k < width; k += U) {
-                    double xv[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        int32_t c = r + op[k + u];
-                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
-                        xv[u] = x[c];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc += vp[k + u] * xv[u];
-                }
+                for (int j = 0; j < 8; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + p->start[j]);
             } else {
-                for (int k = 0; k < width; k += U) {
-                    double xv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        int32_t c = r + (hi ? op2[k + u] : op[k + u]);
-                        c = c < 0 ? 0 : (c > cmax ? cmax : c);
-                        xv[u] = x[c];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc += vp[k + u] * xv[u];
+                for (int j = 0; j < 8; ++j) {
+                    const int32_t c = r + p->start[j];
+                    buf[j].x = x[c < 0 ? 0 : (c > cmax ? cmax : c)];
+                    buf[j].y = x[c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1)];
                 }
             }
-            if (live) {
-                y[r] = acc;
-                if (DOTS == 1) { d_rz += ri * zi; d_wz += acc * zi; d_rr += ri * ri; }
-                else if (DOTS == 2) { d_rz += acc * ri; d_wz += acc * acc; d_rr += ri * ri; }
-                else if (DOTS == 3) { d_rz += zi * zi; d_wz += acc * zi; d_rr += ri * zi * zi; }
+        };
+        load_round(A, pl);
+        int b0 = 0, b1 = 0;
+        if (LDSD) {
+            b0 = ok0 ? c0 * S : 0;
+            b1 = ok1 ? c1 * S : 0;
+        } else {
+            // ---- the classes of this item's rows -> the wave's LDS region (C slots), unless they are there already ----
+            unsigned long long inuse = 0ull;
+            bool copied = false;
+            unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+            while (m0 | m1) {
+                const bool from0 = m0 != 0ull;
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(from0 ? m0 : m1)) - 1);
+                const int cv = __builtin_amdgcn_readlane(from0 ? c0 : c1, src);
+                const unsigned long long hit = __ballot(tagv == cv) & cmask;
+                int slot;
+                if (hit) slot = __ffsll((long long)hit) - 1;
+                else {
+                    // victim: the first slot from the round-robin pointer on that this item does not use (there is one: C is the
+                    // largest number of classes any item has)
+                    const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
+                    slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
+                    rr = slot + 1 == C ? 0 : slot + 1;
+                    const v2d* __restrict__ src_row = reinterpret_cast<const v2d*>(dict + (int64_t)cv * S);
+                    v2d* __restrict__ dst_row = reinterpret_cast<v2d*>(wl + slot * S);
+                    for (int i = lane; i < (S >> 1); i += 64) dst_row[i] = src_row[i];
+                    if (lane == slot) tagv = cv;
+                    copied = true;
+                }
+                inuse |= 1ull << slot;
+                const bool h0 = c0 == cv, h1 = c1 == cv;
+                if (h0) b0 = slot * S;
+                if (h1) b1 = slot * S;
+                m0 &= ~__ballot(h0);
+                m1 &= ~__ballot(h1);
+            }
+            if (copied) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        if (map_xcd) {
-            it.cur += it.step;
-            q = it.cur < it.end ? it.cur * 4 + wave : n_items;
-        } else q += n_waves;
+        const double* __restrict__ v0 = wl + b0;
+        const double* __restrict__ v1 = wl + b1;
+        double a0 = 0.0, a1 = 0.0;
+        v2d zi = {0.0, 0.0};
+        // (measured and not kept, CG2 n = 107, product 204 us: the next round's loads in flight while this one is multiplied - a
+        // second register set, 138 VGPRs, 3 waves per SIMD: 270 us; only the terms a run's length calls for, by wave-uniform branches
+        // - most CG2 runs are one or two offsets long - : 339 us, the branches keep the coefficient reads from being batched)
+        auto compute_round = [&](const v2d (&buf)[8], int rd) {
+            const double* __restrict__ w0 = v0 + 24 * rd;
+            const double* __restrict__ w1 = v1 + 24 * rd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double e0 = buf[j].x, e1 = buf[j].y;
+                const double e2 = fs_from_next_lane(buf[j].x), e3 = fs_from_next_lane(buf[j].y);
+                a0 = fma(w0[3 * j], e0, a0);     a1 = fma(w1[3 * j], e1, a1);
+                a0 = fma(w0[3 * j + 1], e1, a0); a1 = fma(w1[3 * j + 1], e2, a1);
+                a0 = fma(w0[3 * j + 2], e2, a0); a1 = fma(w1[3 * j + 2], e3, a1);
+                // (the coefficient positions are compile-time constants: left alone the compiler reads all 48 of a round
+                // ahead of the first fma - 150 VGPRs, 3 waves per SIMD; a compiler barrier per run keeps it at the run's six)
+                asm volatile("" ::: "memory");
+            }
+        };
+        for (int rd = 0; rd < rounds; ++rd) {
+            if (rd > 0) load_round(A, pl + rd);
+            compute_round(A, rd);
+            if (rd == 0) zi = A[0];
+        }
+        if (ok1) {
+            v2d out;
+            out.x = a0; out.y = a1;
+            *reinterpret_cast<v2du*>(&y[r]) = out;
+        } else if (ok0) y[r] = a0;
+        if (!ok0) { a0 = 0.0; zi.x = 0.0; }
+        if (!ok1) { a1 = 0.0; zi.y = 0.0; }
+        if (DOTS == 1) {
+            d_rz += ri.x * zi.x + ri.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * ri.x + ri.y * ri.y;
+        } else if (DOTS == 2) {
+            d_rz += a0 * ri.x + a1 * ri.y; d_wz += a0 * a0 + a1 * a1; d_rr += ri.x * ri.x + ri.y * ri.y;
+        } else if (DOTS == 3) {
+            d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
+        }
+        if (!LDSD) __builtin_amdgcn_wave_barrier();            // (the next item's class rows may overwrite this one's)
     }
     if (DOTS && DOTS != 4) {
         const double t0 = fs_block_sum(d_rz, lds4);
@@ -682,9 +789,9 @@ struct row_dict {
     dbuf<uint16_t> cls, cls_slot;
     dbuf<double> values, slot_vals;
     dbuf<unsigned long long> keys;
-    dbuf<int32_t> slot2cls;
+    dbuf<int32_t> slot2cls, nnz;
     dbuf<int> info;
-    int ncls = 0, W = 0;
+    int ncls = 0, S = 0, C = 0;             // classes, doubles per class row, most classes of any item
     const double* built_for = nullptr;      // the value array the classes describe (nullptr: plain form in use)
     uint64_t space_serial = 0;              // ... of this space
     uint64_t matrix_serial = 0;             // ... of this matrix (addresses are handed out again after a free: the pointer alone is no identity)
@@ -1610,221 +1717,276 @@ static int spmv_pair_grid(const fs_space_s* sp) {
 
 static int spmv_partials_unsplit(const fs_space_s* sp, int bs);
 static int dict_map_xcd();
-// dictionary rows are padded with zeros to a multiple of the single-slice round length, with at least ONE zero behind the widest
-// row: position W - 1 is the coefficient of the empty slots of a run plan
-static int dict_width(const fs_space_s* sp) { return (sp->max_row + 16) & ~15; }
-
-// Work items of the row-dictionary product (fs_space_s::dict_items) for the whole space and, on a decomposed space, for its
-// interior / boundary lists; run plans of the distinct offset lists.  Host pass over four small arrays, once per space (and
-// again when the halo plan changes).
-namespace {
-struct dict_plan_info { int32_t first = -1, rounds = 0, min_start = 0, max_start = 0; };
-struct dict_item_builder {
-    fs_space_s* sp;
-    std::vector<int32_t> dp, off;
-    std::vector<int64_t> ptr;
-    std::vector<dict_plan_round> rounds;
-    std::vector<std::pair<std::pair<int32_t, int>, dict_plan_info>> plans;       // (dia_ptr, width) -> plan (a handful of lists: linear search)
-    int width(int32_t sl) const { return (int)((ptr[(size_t)sl + 1] - ptr[(size_t)sl]) >> 6); }
-    const dict_plan_info& plan_for(int32_t d, int w) {
-        for (auto& e : plans)
-            if (e.first.first == d && e.first.second == w) return e.second;
-        dict_plan_info info;
-        const int32_t* o = off.data() + d + 1;
-        const int zero = dict_width(sp) - 1;
-        info.first = (int32_t)rounds.size();
-        int slot = 0, k = 0;
-        dict_plan_round cur;
-        auto fresh = [&](dict_plan_round& r) {
-            for (int j = 0; j < 8; ++j) {
-                r.start[j] = 0;
-                for (int t = 0; t < 4; ++t) r.kidx[j][t] = (uint8_t)zero;
+// ---- structure of the row-dictionary product: segments, work items, run plans (once per space) ---------------------------------
+// chg[r] = 1: the (col - row) offset set of row r differs from row r - 1's (compared through a 64-bit hash of both: a collision
+// merges two rows into one segment whose plan then misses an entry - caught by the verification of every row in dict_build)
+__global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, uint8_t* __restrict__ chg) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        unsigned long long h[2] = {0ull, 1ull};
+        for (int w = 0; w < 2; ++w) {
+            const int64_t q = r - w;
+            if (q < 0) break;
+            const int32_t s0 = rowptr[q], s1 = rowptr[q + 1];
+            unsigned long long hh = 1469598103934665603ull ^ (unsigned long long)(s1 - s0);
+            for (int32_t e = s0; e < s1; ++e) {
+                hh = (hh ^ (unsigned long long)(unsigned)(colidx[e] - (int32_t)q)) * 1099511628211ull;
+                hh ^= hh >> 29;
             }
-        };
-        fresh(cur);
-        bool first = true;
-        while (k < w || first) {
-            const int cap = first ? 7 : 8;          // slot 7 of round 0 stays (0; no coefficients): its load is z
-            if (slot == cap || k >= w) {
-                rounds.push_back(cur);
-                fresh(cur);
-                slot = 0;
-                first = false;
-                continue;
-            }
-            int len = 1;
-            while (k + len < w && len < 3 && o[k + len] == o[k + len - 1] + 1) ++len;
-            cur.start[slot] = o[k];
-            for (int t = 0; t < len; ++t) cur.kidx[slot][t] = (uint8_t)(k + t);
-            info.min_start = std::min(info.min_start, o[k]);
-            info.max_start = std::max(info.max_start, o[k]);
-            ++slot;
-            k += len;
+            h[w] = hh;
         }
-        if (slot > 0) rounds.push_back(cur);
-        info.rounds = (int32_t)rounds.size() - info.first;
-        plans.push_back({{d, w}, info});
-        return plans.back().second;
+        chg[r] = r == 0 || h[0] != h[1];
     }
-    // seq: the slices to multiply, in processing order
-    void make_items(const std::vector<int32_t>& seq, std::vector<int32_t>& items, int64_t& n_pairs) {
-        const int64_t ns = sp->n_slices;
-        std::vector<int32_t> rank((size_t)ns, -1);
-        for (size_t q = 0; q < seq.size(); ++q) rank[(size_t)seq[q]] = (int32_t)q;
-        struct unit { int32_t key, a, rounds, first; };
-        std::vector<unit> units;
-        units.reserve(seq.size());
-        const int64_t n_cols = sp->n_nodes_local;
-        long long why[5] = {0, 0, 0, 0, 0};
-        for (int32_t sl = 0; sl < ns;) {
-            if (rank[(size_t)sl] < 0) { ++sl; continue; }
-            bool pair = sl + 1 < ns && rank[(size_t)sl + 1] >= 0 && dp[(size_t)sl] >= 0 && dp[(size_t)sl + 1] >= 0 &&
-                        (int64_t)(sl + 2) * FS_SLICE <= sp->n_nodes_owned;
-            const int w = width(sl);
-            if (!pair) ++why[0];
-            if (pair) {
-                const int32_t da = dp[(size_t)sl], db = dp[(size_t)sl + 1];
-                pair = w > 0 && w == width(sl + 1);
-                if (!pair) ++why[1];
-                if (pair) { pair = off[(size_t)da] >= FS_SLICE && off[(size_t)db] >= FS_SLICE; if (!pair) ++why[2]; }
-                if (pair && da != db) {
-                    for (int k = 0; k < w && pair; ++k) pair = off[(size_t)da + 1 + k] == off[(size_t)db + 1 + k];
-                    if (!pair) ++why[3];
-                }
-                if (pair) {
-                    const dict_plan_info& pi = plan_for(da, w);
-                    const int64_t base = (int64_t)sl * FS_SLICE;
-                    pair = base + pi.min_start >= 0 && base + 2 * FS_SLICE + 1 + pi.max_start <= n_cols - 1;
-                    if (!pair) ++why[4];
-                    if (pair) units.push_back({rank[(size_t)sl], sl, pi.rounds, pi.first});
-                }
-            }
-            if (pair) sl += 2;
-            else { units.push_back({rank[(size_t)sl], sl, 0, 0}); sl += 1; }
-        }
-        if (getenv("FS_KRYLOV_DEBUG"))
-            fprintf(stderr, "[fs_krylov] slices left single: no partner / incomplete %lld, widths differ %lld, split slice %lld, offset lists differ %lld, accesses out of range %lld\n",
-                    why[0], why[1], why[2], why[3], why[4]);
-        std::sort(units.begin(), units.end(), [](const unit& u, const unit& v) { return u.key < v.key; });
-        items.clear();
-        items.reserve(units.size() * 4);
-        n_pairs = 0;
-        for (const unit& u : units) {
-            if (u.rounds > 0) { items.insert(items.end(), {u.a, -u.rounds, u.first, 0}); ++n_pairs; }
-            else {
-                const int32_t d = dp[(size_t)u.a];
-                items.insert(items.end(), {u.a, width(u.a), d, d >= 0 ? off[(size_t)d] : FS_SLICE});
-            }
-        }
-    }
-};
 }
-static int dict_build_items(fs_space_s* sp, hipStream_t s) {
+// offsets of the listed rows, concatenated (ptr = exclusive scan of their lengths)
+__global__ void k_gather_offsets(int64_t n_list, const int32_t* __restrict__ list, const int64_t* __restrict__ ptr, const int32_t* __restrict__ rowptr,
+                                 const int32_t* __restrict__ colidx, int32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_list; i += stride) {
+        const int32_t r = list[i];
+        const int32_t s0 = rowptr[r], s1 = rowptr[r + 1];
+        int32_t* __restrict__ o = out + ptr[i];
+        for (int32_t e = s0; e < s1; ++e) o[e - s0] = colidx[e] - r;
+    }
+}
+__global__ void k_gather_lengths(int64_t n_list, const int32_t* __restrict__ list, const int32_t* __restrict__ rowptr, int32_t* __restrict__ len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_list; i += stride) len[i] = rowptr[list[i] + 1] - rowptr[list[i]];
+}
+
+// Segments, work items and run plans of the row-dictionary product (comment at k_dict_spmv) for the whole space and, on a
+// decomposed space, for its interior / boundary slices.  One pass over the pattern on the device (which rows change the offset
+// set), the few rows that do are looked at on the host.  sp->n_dict_items = 0: the pattern does not lend itself to the form.
+static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
     fs_halo_plan& h = sp->halo;
     const bool split = h.active && h.n_interior > 0;
     const bool need_space = sp->n_dict_items < 0, need_lists = split && (h.n_items_interior < 0 || h.n_items_boundary < 0);
     if (!need_space && !need_lists) return FS_OK;
-    const int64_t ns = sp->n_slices;
-    dict_item_builder B;
-    B.sp = sp;
-    B.dp.resize((size_t)ns);
-    B.off.resize((size_t)std::max<int64_t>(sp->dia_off.n, 1));
-    B.ptr.resize((size_t)ns + 1);
-    FS_CHECK(sp->dia_ptr.download(B.dp.data(), ns, s));
-    FS_CHECK(sp->dia_off.download(B.off.data(), sp->dia_off.n, s));
-    FS_CHECK(sp->slice_ptr.download(B.ptr.data(), ns + 1, s));
-    // (the plans of a space are made in one go - every list below is walked before the upload - so that the array a captured
-    // batch points to never moves: an earlier build's rounds come first, in the same order)
-    if (!need_space) {
-        std::vector<int32_t> seq((size_t)ns), items;
-        if (sp->slice_order.p) FS_CHECK(sp->slice_order.download(seq.data(), ns, s));
-        else for (int64_t q = 0; q < ns; ++q) seq[(size_t)q] = (int32_t)q;
-        int64_t np = 0;
-        B.make_items(seq, items, np);
+    const int64_t n = sp->n_nodes_owned, ns = sp->n_slices, n_cols = sp->n_nodes_local;
+    auto give_up = [&](const char* why) {
+        if (getenv("FS_KRYLOV_DEBUG")) fprintf(stderr, "[fs_krylov] row-dictionary structure of space %llu: %s - not used\n", (unsigned long long)sp->serial, why);
+        sp->n_dict_items = 0;
+        h.n_items_interior = h.n_items_boundary = 0;
+        return FS_OK;
+    };
+    if (n < 2 || !sp->rowptr.p || !sp->colidx.p) return give_up("no pattern");
+    // 1. rows whose offset set differs from the previous row's
+    std::vector<uint8_t> chg((size_t)n);
+    {
+        dbuf<uint8_t> d_chg;
+        FS_CHECK(d_chg.alloc(n));
+        hipLaunchKernelGGL(k_row_change, dim3(fs_grid_for(n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, d_chg.p);
+        FS_KERNEL_CHECK();
+        FS_CHECK(d_chg.download(chg.data(), n, s));
     }
-    std::vector<int32_t> items_space, items_in, items_bd;
-    int64_t np_space = 0, np_in = 0, np_bd = 0;
+    std::vector<int32_t> crow;
+    for (int64_t r = 0; r < n; ++r)
+        if (chg[(size_t)r]) crow.push_back((int32_t)r);
+    const int64_t nc = (int64_t)crow.size();
+    if (nc * 2 > n) return give_up("rows change their offset set too often");     // (an unstructured mesh)
+    // 2. ... and their offset lists
+    std::vector<int32_t> clen((size_t)nc), coff;
+    std::vector<int64_t> cptr((size_t)nc + 1, 0);
+    {
+        dbuf<int32_t> d_list, d_len, d_off;
+        dbuf<int64_t> d_ptr;
+        FS_CHECK(d_list.alloc(nc));
+        FS_CHECK(d_len.alloc(nc));
+        FS_CHECK(d_list.upload(crow.data(), nc, s));
+        hipLaunchKernelGGL(k_gather_lengths, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, nc, d_list.p, sp->rowptr.p, d_len.p);
+        FS_CHECK(d_len.download(clen.data(), nc, s));
+        for (int64_t i = 0; i < nc; ++i) cptr[(size_t)i + 1] = cptr[(size_t)i] + clen[(size_t)i];
+        coff.resize((size_t)std::max<int64_t>(cptr[(size_t)nc], 1));
+        FS_CHECK(d_ptr.alloc(nc + 1));
+        FS_CHECK(d_ptr.upload(cptr.data(), nc + 1, s));
+        FS_CHECK(d_off.alloc(std::max<int64_t>(cptr[(size_t)nc], 1)));
+        hipLaunchKernelGGL(k_gather_offsets, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, nc, d_list.p, d_ptr.p, sp->rowptr.p, sp->colidx.p, d_off.p);
+        FS_KERNEL_CHECK();
+        FS_CHECK(d_off.download(coff.data(), cptr[(size_t)nc], s));
+    }
+    // 3. segments: a row joins while its set is nested with the segment's list (which grows to the larger one)
+    struct segment { int32_t first, end, list; };      // list = index of the change row whose offsets are the segment's list
+    std::vector<segment> segs;
+    {
+        auto set_of = [&](int64_t i) { return std::make_pair(coff.data() + cptr[(size_t)i], coff.data() + cptr[(size_t)i + 1]); };
+        int64_t cur = 0;
+        segs.push_back({0, 0, 0});
+        for (int64_t i = 1; i < nc; ++i) {
+            const auto M = set_of(cur), o = set_of(i);
+            if (std::includes(M.first, M.second, o.first, o.second)) continue;
+            if (std::includes(o.first, o.second, M.first, M.second)) { cur = i; segs.back().list = (int32_t)i; continue; }
+            segs.back().end = crow[(size_t)i];
+            segs.push_back({crow[(size_t)i], 0, (int32_t)i});
+            cur = i;
+        }
+        segs.back().end = (int32_t)n;
+    }
+    // 4. run plans (identical lists share one) and items
+    std::vector<dict_plan_round> rounds;
+    struct plan_info { int32_t first, rounds, min_start, max_start; };
+    std::vector<plan_info> seg_plan(segs.size());
+    int max_rounds = 0;
+    {
+        std::unordered_map<std::string, int32_t> seen;      // offset list -> index into `infos`
+        std::vector<plan_info> infos;
+        for (size_t g = 0; g < segs.size(); ++g) {
+            const int32_t* o = coff.data() + cptr[(size_t)segs[g].list];
+            const int w = clen[(size_t)segs[g].list];
+            std::string key(reinterpret_cast<const char*>(o), (size_t)w * sizeof(int32_t));
+            auto f = seen.find(key);
+            if (f != seen.end()) { seg_plan[g] = infos[(size_t)f->second]; continue; }
+            plan_info pi = {(int32_t)rounds.size(), 0, 0, 0};
+            dict_plan_round cur;
+            memset(&cur, 0, sizeof(cur));
+            int slot = 1;                               // slot 0 of round 0 is the z run
+            for (int k = 0; k < w;) {
+                int len = 1;
+                while (k + len < w && len < 3 && o[k + len] == o[k + len - 1] + 1) ++len;
+                if (slot == 8) { rounds.push_back(cur); memset(&cur, 0, sizeof(cur)); slot = 0; }
+                cur.start[slot] = o[k];
+                cur.len[slot] = (uint8_t)len;
+                pi.min_start = std::min(pi.min_start, o[k]);
+                pi.max_start = std::max(pi.max_start, o[k]);
+                ++slot;
+                k += len;
+            }
+            rounds.push_back(cur);
+            pi.rounds = (int32_t)rounds.size() - pi.first;
+            max_rounds = std::max(max_rounds, (int)pi.rounds);
+            seen.emplace(std::move(key), (int32_t)infos.size());
+            infos.push_back(pi);
+            seg_plan[g] = pi;
+        }
+        if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
+            fprintf(stderr, "[fs_krylov] row-dictionary structure: %lld rows, %lld change their offset set, %zu segments, %zu distinct plans, %zu rounds (longest plan %d)\n",
+                    (long long)n, (long long)nc, segs.size(), infos.size(), rounds.size(), max_rounds);
+    }
+    if (max_rounds > FS_DICT_MAX_ROUNDS) return give_up("a row has more runs of offsets than a plan holds");
+    // processing order: by the position of the item's first row in the slice order of the space (an XCD then sweeps one slab of
+    // the mesh for all node classes of a CG2 space, as the streaming kernels do)
+    std::vector<int32_t> rank;
+    if (sp->slice_order.p) {
+        std::vector<int32_t> order((size_t)ns);
+        FS_CHECK(sp->slice_order.download(order.data(), ns, s));
+        rank.resize((size_t)ns);
+        for (int64_t q = 0; q < ns; ++q) rank[(size_t)order[(size_t)q]] = (int32_t)q;
+    }
+    std::vector<uint8_t> bslice;        // slices with ghost columns (decomposed space)
+    if (split) {
+        bslice.assign((size_t)ns, 0);
+        std::vector<int32_t> bl((size_t)h.n_boundary);
+        if (h.n_boundary) FS_CHECK(h.boundary.download(bl.data(), h.n_boundary, s));
+        for (int32_t sl : bl) bslice[(size_t)sl] = 1;
+    }
+    struct item { int64_t key; int32_t v[4]; uint8_t boundary; };
+    std::vector<item> all;
+    for (size_t g = 0; g < segs.size(); ++g) {
+        const plan_info& pi = seg_plan[g];
+        // (a segment longer than one item is cut at multiples of 126 rows - even rows: the 16-byte accesses of w and d are aligned
+        // there; a shorter one - a mesh line of a CG2 space - is one item wherever it starts)
+        for (int32_t a = segs[g].first, e; a < segs[g].end; a = e) {
+            e = segs[g].end - a <= FS_DICT_ITEM_ROWS ? segs[g].end : (a / FS_DICT_ITEM_ROWS + 1) * FS_DICT_ITEM_ROWS;
+            // (all 64 lanes load, also those past the item's last row: in range means in range for 128 rows)
+            const bool edge = (int64_t)a + pi.min_start < 0 || (int64_t)a + 127 + pi.max_start > n_cols - 1;      // (64 lanes x 2 values)
+            item it;
+            it.key = rank.empty() ? (int64_t)a : (int64_t)rank[(size_t)(a >> 6)] * FS_SLICE + (a & 63);
+            it.v[0] = a; it.v[1] = (e - a) | ((int32_t)edge << 16); it.v[2] = pi.first; it.v[3] = pi.rounds;
+            it.boundary = 0;
+            if (split)
+                for (int32_t sl = a >> 6; sl <= (e - 1) >> 6; ++sl) it.boundary |= bslice[(size_t)sl];
+            all.push_back(it);
+        }
+    }
+    if ((int64_t)all.size() * 8 > n) return give_up("segments of fewer than 8 rows");
+    if (!rank.empty()) {
+        std::sort(all.begin(), all.end(), [](const item& u, const item& v) { return u.key < v.key; });
+        // ... and inside windows of 2048 items (about what one XCD has in flight) by row number again: the lines of ONE node class
+        // of a CG2 space follow each other there, so that the items a wave takes in a row hold the same coefficient classes
+        constexpr size_t WINDOW = 2048;
+        for (size_t w0 = 0; w0 < all.size(); w0 += WINDOW)
+            std::sort(all.begin() + w0, all.begin() + std::min(w0 + WINDOW, all.size()), [](const item& u, const item& v) { return u.v[0] < v.v[0]; });
+    }
+    auto upload_items = [&](dbuf<int32_t>& dst, int64_t& count, int which) {     // which: -1 all, 0 interior, 1 boundary
+        std::vector<int32_t> flat;
+        flat.reserve(all.size() * 4);
+        for (const item& it : all)
+            if (which < 0 || it.boundary == which) flat.insert(flat.end(), it.v, it.v + 4);
+        count = (int64_t)flat.size() / 4;
+        int rc = dst.alloc(std::max<int64_t>((int64_t)flat.size(), 4));
+        if (rc == FS_OK && !flat.empty()) rc = dst.upload(flat.data(), (int64_t)flat.size(), s);
+        return rc;
+    };
+    const int64_t plan_ints = (int64_t)rounds.size() * 16;
     if (need_space) {
-        std::vector<int32_t> seq((size_t)ns);
-        if (sp->slice_order.p) FS_CHECK(sp->slice_order.download(seq.data(), ns, s));
-        else for (int64_t q = 0; q < ns; ++q) seq[(size_t)q] = (int32_t)q;
-        B.make_items(seq, items_space, np_space);
-    }
-    if (need_lists) {
-        std::vector<int32_t> seq((size_t)h.n_interior);
-        FS_CHECK(h.interior.download(seq.data(), h.n_interior, s));
-        B.make_items(seq, items_in, np_in);
-        seq.resize((size_t)h.n_boundary);
-        if (h.n_boundary) FS_CHECK(h.boundary.download(seq.data(), h.n_boundary, s));
-        B.make_items(seq, items_bd, np_bd);
-    }
-    const int64_t plan_ints = (int64_t)B.rounds.size() * 16;
-    if (sp->dict_plans.n < plan_ints) {
-        if (sp->dict_plans.p && getenv("FS_KRYLOV_DEBUG")) fprintf(stderr, "[fs_krylov] run plans of space %llu grow: re-allocated\n", (unsigned long long)sp->serial);
+        // (the plans depend on the pattern only: a later build for new halo lists finds the same array in place)
         FS_CHECK(sp->dict_plans.alloc(std::max<int64_t>(plan_ints, 16)));
-    }
-    if (plan_ints) FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(B.rounds.data()), plan_ints, s));
-    if (need_space) {
-        sp->n_dict_items = (int64_t)items_space.size() / 4;
-        FS_CHECK(sp->dict_items.alloc(std::max<int64_t>((int64_t)items_space.size(), 4)));
-        FS_CHECK(sp->dict_items.upload(items_space.data(), (int64_t)items_space.size(), s));
+        FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(rounds.data()), plan_ints, s));
+        sp->dict_slots = 24 * std::max(max_rounds, 1);
+        FS_CHECK(upload_items(sp->dict_items, sp->n_dict_items, -1));
     }
     if (need_lists) {
-        h.n_items_interior = (int64_t)items_in.size() / 4;
-        h.n_items_boundary = (int64_t)items_bd.size() / 4;
-        FS_CHECK(h.items_interior.alloc(std::max<int64_t>((int64_t)items_in.size(), 4)));
-        FS_CHECK(h.items_boundary.alloc(std::max<int64_t>((int64_t)items_bd.size(), 4)));
-        FS_CHECK(h.items_interior.upload(items_in.data(), (int64_t)items_in.size(), s));
-        FS_CHECK(h.items_boundary.upload(items_bd.data(), (int64_t)items_bd.size(), s));
+        FS_CHECK(upload_items(h.items_interior, h.n_items_interior, 0));
+        FS_CHECK(upload_items(h.items_boundary, h.n_items_boundary, 1));
     }
+    FS_HIP(hipStreamSynchronize(s));
     if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
-        fprintf(stderr, "[fs_krylov] row-dictionary work items: space %lld (%lld pairs) of %lld slices, interior %lld (%lld pairs), boundary %lld (%lld pairs), %zu plan rounds for %zu offset lists\n",
-                (long long)sp->n_dict_items, (long long)np_space, (long long)ns, (long long)h.n_items_interior, (long long)np_in,
-                (long long)h.n_items_boundary, (long long)np_bd, B.rounds.size(), B.plans.size());
+        fprintf(stderr, "[fs_krylov] row-dictionary work items: %lld for the space (%.1f rows each), interior %lld, boundary %lld; %d coefficient positions per class row\n",
+                (long long)sp->n_dict_items, sp->n_dict_items ? (double)n / sp->n_dict_items : 0.0, (long long)h.n_items_interior,
+                (long long)h.n_items_boundary, sp->dict_slots);
     return FS_OK;
 }
+
 // Try to describe `val` (the scalar DIA matrix the solver is about to multiply with) by row classes; leaves g_dict.built_for =
-// val on success, nullptr otherwise.  One host synchronisation (12 bytes).  FS_SPMV_DICT=0 switches it off.
+// val on success, nullptr otherwise.  One host synchronisation (16 bytes).  FS_SPMV_DICT=0 switches it off.
 static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     row_dict& D = g_dict;
     D.built_for = nullptr;
     fs_space_s* sp = A->space;
     static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
     if (off || !g_row_dictionary || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
-    if (sp->max_row <= 0 || sp->max_row > 96) return FS_OK;
-    const int W = dict_width(sp);
-    const int64_t padded = sp->n_slices * FS_SLICE;
-    FS_CHECK(dict_build_items(sp, s));
+    FS_CHECK(dict_structure_build(sp, s));
+    if (sp->n_dict_items <= 0) return FS_OK;
+    const int S = sp->dict_slots;
+    const int64_t padded = sp->n_nodes_owned + 2 * FS_DICT_ITEM_ROWS;
     if (D.cls.n < padded) { FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
     if (!D.keys.p) {
         FS_CHECK(D.keys.alloc(FS_DICT_CAP));
         FS_CHECK(D.slot2cls.alloc(FS_DICT_CAP));
+        FS_CHECK(D.nnz.alloc(FS_DICT_MAX));
         FS_CHECK(D.info.alloc(4));
     }
-    if (D.slot_vals.n < (int64_t)FS_DICT_CAP * W) { FS_CHECK(D.slot_vals.alloc((int64_t)FS_DICT_CAP * W)); FS_CHECK(D.values.alloc((int64_t)FS_DICT_MAX * W)); }
+    if (D.slot_vals.n < (int64_t)FS_DICT_CAP * S) { FS_CHECK(D.slot_vals.alloc((int64_t)FS_DICT_CAP * S)); FS_CHECK(D.values.alloc((int64_t)FS_DICT_MAX * S)); }
     FS_CHECK(D.keys.zero(s));
     FS_CHECK(D.info.zero(s));
-    const int grid = fs_grid_for(padded, FS_BLOCK, 4096);
-    hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.keys.p, D.keys.p,
-                       D.slot_vals.p, D.cls_slot.p, D.info.p);
-    hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, W, D.slot2cls.p, D.values.p);
-    hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, val, W, D.slot2cls.p,
-                       D.values.p, D.cls_slot.p, D.cls.p, D.info.p);
+    FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
+    const int4* items = reinterpret_cast<const int4*>(sp->dict_items.p);
+    const dict_plan_round* plans = reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p);
+    const int grid = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
+    hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
+                       val, S, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
+    hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, S, D.slot2cls.p, D.values.p, D.nnz.p);
+    hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
+                       val, S, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
     // (worth it only where rows really repeat: at most one class per 16 rows)
-    const bool ok = h[1] == 0 && h[2] == 0 && h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * 16 <= sp->n_nodes_owned;
+    const bool ok = h[1] == 0 && h[2] == 0 && h[3] > 0 && (int64_t)(FS_BLOCK / 64) * h[3] * S * (int64_t)sizeof(double) <= FS_DICT_LDS_BYTES &&
+                    h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * 16 <= sp->n_nodes_owned;
     if (getenv("FS_KRYLOV_DEBUG"))
-        fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of width %d among %lld, %d mismatches -> %s\n", h[0], W,
-                (long long)sp->n_nodes_owned, h[2], ok ? "compressed product" : "plain product");
+        fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of %d positions among %lld, %d mismatches, at most %d classes per item -> %s\n", h[0], S,
+                (long long)sp->n_nodes_owned, h[2], h[3], ok ? "compressed product" : "plain product");
     if (!ok) {
         D.gave_up_on = A->serial;
         ++D.n_failed;
         return FS_OK;
     }
     D.ncls = h[0];
-    D.W = W;
+    D.S = S;
+    D.C = h[3];
     D.built_for = val;
     D.space_serial = sp->serial;
     D.matrix_serial = A->serial;
@@ -1857,16 +2019,15 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             n_items = in ? h.n_items_interior : h.n_items_boundary;
             gd = spmv_grid(ns, sp->n_slices);
         }
-        // (the two-rows-per-lane loads and stores are 16-byte accesses of y and d at even rows)
-        const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(rvec)) & 15) == 0;
-        if (items && n_items >= 0 && aligned) {
-#define FS_DICT_ARGS sp->n_nodes_owned, sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), sp->dia_off.p, \
-                     reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, \
-                     g_dict.values.p, g_dict.ncls, g_dict.W, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd()
-            if ((int64_t)g_dict.ncls * g_dict.W <= FS_DICT_LDS_DOUBLES)
-                hipLaunchKernelGGL((k_dict_spmv<DOTS, true>), dim3(gd), dim3(FS_BLOCK), (size_t)g_dict.ncls * g_dict.W * sizeof(double), s, FS_DICT_ARGS);
+        if (items && n_items >= 0) {
+#define FS_DICT_ARGS(CC) sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), \
+                         g_dict.cls.p, g_dict.values.p, g_dict.S, CC, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd()
+            const size_t whole = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
+            if (whole <= (size_t)FS_DICT_WHOLE_LDS_BYTES)
+                hipLaunchKernelGGL((k_dict_spmv<DOTS, true>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
             else
-                hipLaunchKernelGGL((k_dict_spmv<DOTS, false>), dim3(gd), dim3(FS_BLOCK), 0, s, FS_DICT_ARGS);
+                hipLaunchKernelGGL((k_dict_spmv<DOTS, false>), dim3(gd), dim3(FS_BLOCK), (size_t)(FS_BLOCK / 64) * g_dict.C * g_dict.S * sizeof(double), s,
+                                   FS_DICT_ARGS(g_dict.C));
 #undef FS_DICT_ARGS
             return;
         }
@@ -1926,10 +2087,12 @@ static int dict_map_xcd() {
     return m;
 }
 static int dict_grid(const fs_space_s* sp) {
-    // (measured at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 31 / 21 / 19 / 19 / 18.5 us, the update kernel that sums the
-    // partials + 0 / 0.5 / 1 / 1 / 3 us)
+    // (measured at 1 M rows, round 3: 256 / 512 / 768 / 1024 / 2048 workgroups: 31 / 21 / 19 / 19 / 18.5 us, the update kernel that sums
+    // the partials + 0 / 0.5 / 1 / 1 / 3 us)
     static const int env_blocks = getenv("FS_DICT_BLOCKS") ? atoi(getenv("FS_DICT_BLOCKS")) : 0;
-    const int64_t n_chunks = (sp->n_slices + 3) / 4;
+    const bool whole = (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES;
+    const int per_chunk = 4 * (whole ? 1 : FS_DICT_ITEMS_PER_WAVE);
+    const int64_t n_chunks = (std::max<int64_t>(sp->n_dict_items, 1) + per_chunk - 1) / per_chunk;
     int64_t g = std::min<int64_t>(n_chunks, env_blocks > 0 ? env_blocks : 1024);
     g = (g + 7) & ~(int64_t)7;
     return (int)std::max<int64_t>(g, 8);
@@ -2518,7 +2681,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                                        dict_on ? (const void*)sp->halo.items_boundary.p : nullptr,
                                        p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
-                const int64_t dict_sig = dict_on ? (int64_t)g_dict.ncls * 128 + g_dict.W : 0;
+                const int64_t dict_sig = dict_on ? ((int64_t)g_dict.ncls * 256 + g_dict.S) * 256 + g_dict.C : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,
                                           (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs),
                                           (int64_t)A->serial, (int64_t)sp->serial};
