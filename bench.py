@@ -287,6 +287,8 @@ def choose_recurrence(prob, rtol, world, requested, barrier, steps=2):
         try:
             prob.step(rtol)
             t = timed_steps(prob, rtol, steps, barrier, reduce=False)[0] / steps
+            if name.endswith("+p2p") and not getattr(prob.V, "_p2p", False):
+                err, prob.p2p = "a peer-to-peer wait timed out: the library fell back to RCCL mid-solve", False
         except Exception as e:               # this rank only, perhaps: the ranks compare notes below
             err, t = repr(e)[:200], 0.0
         if err is None:                      # every variant must reproduce the first one's field (a transport that delivers stale
@@ -320,6 +322,9 @@ def timed_steps_with_fallback(prob, rtol, steps, barrier, name, report, world, w
         for _ in range(warmup):
             prob.step(rtol)
         out = timed_steps(prob, rtol, steps, barrier, reduce=False)
+        if not getattr(prob.V, "_p2p", False):      # backend._with_p2p_fallback: the ranks agreed to leave the transport mid-solve
+            err = "a peer-to-peer wait timed out during a solve: the library turned the exchange off and solved again over RCCL"
+            prob.p2p = False
     except Exception as e:
         err = repr(e)[:200]
     if all_ranks_ok(err is None):
@@ -353,6 +358,8 @@ def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
         try:
             prob.step(rtol)
             elapsed, asm_ms, st = timed_steps(prob, rtol, steps, barrier, reduce=False)
+            if name.endswith("+p2p") and not getattr(prob.V, "_p2p", False):
+                err, prob.p2p = "a peer-to-peer wait timed out: the library fell back to RCCL mid-solve", False
         except Exception as e:
             err = repr(e)[:200]
         if not all_ranks_ok(err is None):
@@ -570,6 +577,9 @@ def make_roofline(k, workload, traffic, traffic_source):
 
 def main():
     a = parse()
+    # the library turns the peer-to-peer halo exchange on by default; here every transport / recurrence variant is set, tried and
+    # timed explicitly (choose_recurrence), so the halo plans start on RCCL
+    os.environ["FS_HALO_P2P"] = "0"
     rank, world, _ = parallel.world()
     if world != a.gpus:
         if world == 1 and a.gpus > 1:

@@ -183,13 +183,25 @@ class DeviceSpace(_Handle):
             ri = L.i32(np.concatenate([np.asarray(r, dtype=np.int32) for r in recv_lists]) if len(recv_lists) else [])
             L.check(L.load().fs_space_set_halo_indexed(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc),
                                                        L.p_i32(ri)), "fs_space_set_halo_indexed")
-        if _comm_up and os.environ.get("FS_HALO_P2P", "0") == "1":
-            self.enable_p2p_halo(True)
+        # The peer-to-peer exchange is the DEFAULT transport of a halo plan (round 4): 38 instead of 57 us per CG iteration at
+        # 1 M rows per rank (profiles/r03_p2p_self_halo_timings.txt), and the set-up ends with a self-test whose verdict all
+        # ranks agree on - a node where the mappings cannot be made (several nodes, no peer access) falls back to RCCL on EVERY
+        # rank, here.  FS_HALO_P2P=0: RCCL only; FS_HALO_P2P=1: a failed set-up is an error instead of a fall-back.
+        mode = os.environ.get("FS_HALO_P2P", "auto")
+        if _comm_up and mode != "0" and comm_info()[0] > 1:
+            try:
+                self.enable_p2p_halo(True)
+            except L.BackendError as e:
+                if mode == "1":
+                    raise
+                import logging
+                logging.getLogger("fenicssolver_amd").info("peer-to-peer halo exchange not available (%s): RCCL send / recv", str(e)[:160])
 
     def enable_p2p_halo(self, on=True):
         """Ghost refresh by direct stores into the neighbours' memory (hipIpc mappings, one node) instead of RCCL send / recv.
         COLLECTIVE: every rank of the communicator calls it for its space, in the same order (also to turn it off).
-        FS_HALO_P2P=1 turns it on for every halo plan set while a communicator is up."""
+        On by default for every halo plan set while a communicator of more than one rank is up (FS_HALO_P2P=0: off)."""
+        self._p2p = False
         L.check(L.load().fs_space_enable_p2p_halo(self.h, 1 if on else 0), "fs_space_enable_p2p_halo")
         self._p2p = bool(on)
 
@@ -472,8 +484,9 @@ def set_dirichlet_values(b, dofs, vals):
 def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi", batch=0, nonzero_guess=False,
                  method="cg", diagonal_scale=True, norm="unpreconditioned", pipelined=None):
     """CG (SPD) or BiCGStab (non-symmetric) on the device.  Returns a stats dict.
-    pipelined: True / False select the Ghysels-Vanroose or the single-reduction CG recurrence; None (default) = pipelined
-    exactly when the sums cross GPUs (more than one rank), where the all-reduce then hides under the product."""
+    pipelined: True selects the Ghysels-Vanroose recurrence (the all-reduce of the sums hidden under the product, 112 instead
+    of 72 B/DOF of vector traffic); None / False (default) the single-reduction recurrence - in every measurement so far the
+    pipelined one was slower, so it is opt-in."""
     o = L.fs_krylov_opts()
     o.method = {"cg": L.FS_KSP_CG, "bicgstab": L.FS_KSP_BICGSTAB}[method]
     o.precond = {"none": L.FS_PC_NONE, None: L.FS_PC_NONE, "jacobi": L.FS_PC_JACOBI}[precond]
@@ -485,8 +498,38 @@ def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi",
         o.pipelined = 0
     o.norm_type = {"unpreconditioned": L.FS_NORM_UNPRECONDITIONED, "preconditioned": L.FS_NORM_PRECONDITIONED}[norm]
     st = L.fs_krylov_stats()
-    L.check(L.load().fs_krylov_solve(A.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_krylov_solve")
+
+    def solve():
+        L.check(L.load().fs_krylov_solve(A.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_krylov_solve")
+    _with_p2p_fallback(A.space, solve, x if nonzero_guess else None)
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
+
+
+def _with_p2p_fallback(space, solve, x_guess=None):
+    """Run a solve over a space whose ghost refresh is the peer-to-peer exchange.  A wait of that transport that times out
+    (peer process gone, stores over the mappings not visible on this system) fails the solve on the rank that saw it; the ranks
+    compare notes over RCCL proper (never over the transport in doubt), and if ANY of them failed all of them turn the exchange
+    of this space off and solve again over RCCL send / recv.  One host all-gather per solve, only while the exchange is on."""
+    if not getattr(space, "_p2p", False) or not _comm_up:
+        return solve()
+    keep = None
+    if x_guess is not None:
+        keep = DeviceVector(x_guess.n)
+        keep.copy_from(x_guess)
+    err = None
+    try:
+        solve()
+    except L.BackendError as e:
+        err = e
+    if float(np.sum(comm_allgather([0.0 if err is None else 1.0], 1))) == 0.0:
+        return None
+    import logging
+    logging.getLogger("fenicssolver_amd").warning("peer-to-peer halo exchange failed during a solve (%s): turned off, solving again over RCCL",
+                                                  str(err)[:160] if err else "on another rank")
+    space.enable_p2p_halo(False)
+    if keep is not None:
+        x_guess.copy_from(keep)
+    return solve()
 
 
 class AMG(_Handle):

@@ -2420,17 +2420,19 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         }
         if (ws.sc_local.n != nl + 2) FS_CHECK(ws.sc_local.alloc(nl + 2));
     }
-    // Pipelined recurrence (k_pcg_update): asked for explicitly (> 0), or chosen automatically (< 0) when the sums have to
-    // cross GPUs - on one GPU nothing hides behind the product and the classic recurrence moves 40 B/DOF less.
+    // Pipelined recurrence (k_pcg_update): only when asked for explicitly (> 0).
     static const char* pipe_env = getenv("FS_CG_PIPELINED");
     const int pipe_opt = pipe_env ? atoi(pipe_env) : opts->pipelined;
     if (pipe_opt > 0 && !ds) {
         fs_set_error("fs_krylov_solve: the pipelined recurrence needs CG + Jacobi with diagonal_scale = 1");
         return FS_ERR_UNSUPPORTED;
     }
-    // several ranks default to the pipelined recurrence, whose all-reduce hides under the product - unless the all-reduce is the
-    // peer-to-peer kernel, which is cheaper than the extra vector traffic of that recurrence
-    const bool pipelined = ds && (pipe_opt > 0 || (pipe_opt < 0 && fs_rt().comm != nullptr && fs_rt().n_ranks > 1 && !fs_p2p_reduce_enabled()));
+    // OPT-IN since round 4 (opts->pipelined = 1, FS_CG_PIPELINED=1): in every measurement available the recurrence lost - 69.3
+    // against 57.1 us per iteration over RCCL, 58.8 against 38.0 us over the peer-to-peer exchange at 1 M rows per rank
+    // (profiles/r03_p2p_self_halo_timings.txt): its 40 B/DOF of extra vector traffic and two more launches cost more than the
+    // 3-double all-reduce it hides.  It would pay from an all-reduce latency of about 20 us per iteration upwards (DESIGN.md
+    // section 5) - a multi-node communicator, which this library does not target.
+    const bool pipelined = ds && pipe_opt > 0;
     if (pipelined) {
         if (ws.pw.n != nl + 2) FS_CHECK(ws.pw.alloc(nl + 2));
         if (ws.pz.n != n + 2) FS_CHECK(ws.pz.alloc(n + 2));

@@ -325,8 +325,9 @@ typedef struct fs_krylov_opts {
     int pipelined;       /* CG + Jacobi + diagonal_scale only.  1: the pipelined recurrence of Ghysels & Vanroose - the sums
                           * of an iteration are all-reduced WHILE its product runs instead of between product and update
                           * (same iterates in exact arithmetic, 112 instead of 72 B/DOF of vector traffic, attainable
-                          * accuracy guarded by the same true-residual restarts); 0: the single-reduction recurrence;
-                          * -1: pipelined exactly when the communicator has more than one rank */
+                          * accuracy guarded by the same true-residual restarts); 0 / -1: the single-reduction recurrence
+                          * (the default: measured on MI355X the pipelined one is the slower of the two at every size and
+                          * transport tried, DESIGN.md section 5 - it is kept for communicators with a slow all-reduce) */
 } fs_krylov_opts;
 
 typedef struct fs_krylov_stats {
