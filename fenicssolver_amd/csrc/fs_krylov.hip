@@ -669,7 +669,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
             if (ok1) ri = *reinterpret_cast<const v2du*>(&rvec[r]);
             else if (ok0) ri.x = rvec[r];
         }
-        const int c0 = ok0 ? (int)cls[r] : -1, c1 = ok1 ? (int)cls[r + 1] : -1;
+        int c0 = -1, c1 = -1;
+        if ((first & 1) == 0) {        // (wave-uniform) the two class numbers of a lane in one 4-byte load (the array is padded)
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
+            if (ok0) c0 = (int)(two & 0xffffu);
+            if (ok1) c1 = (int)(two >> 16);
+        } else {
+            if (ok0) c0 = (int)cls[r];
+            if (ok1) c1 = (int)cls[r + 1];
+        }
         // the x values of the first round are asked for before anything waits for the class numbers.  Items whose accesses could leave
         // [0, n_cols) (first / last rows of the vector) load the two values of a pair one by one, each clamped into x: a column
         // outside the vector has no entry, hence a zero coefficient, and every value inside it is the right one.

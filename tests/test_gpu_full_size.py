@@ -146,7 +146,8 @@ def test_config4_p2_poisson_10m_dof_single_gpu(gpu):
     assert st["converged"] == 1 and st["true_rel_residual"] <= 1.02e-8
     assert np.abs(x.get() - (350.0 - 50.0 * z)).max() <= 3e-3   # P2 reproduces the linear profile
     # the CG2 operator of the uniform cube has a few hundred distinct rows (every slice is in DIA form at this size): the product
-    # ran from class numbers + a dictionary (too large for LDS: read through the caches) - and follows the streaming product
+    # ran from class numbers + a dictionary (too large for LDS as a whole: every work item - a mesh line - brings its classes
+    # into its wave's region) - and follows the streaming product
     assert 0 < st["row_classes"] <= 4096
     x1, h1, it1 = x.get().copy(), gpu.krylov_history().copy(), st["iterations"]
     try:
@@ -171,9 +172,10 @@ def test_config4_p2_poisson_10m_dof_single_gpu(gpu):
 
 def test_config5_taylor_hood_cavity_2m_velocity_dofs(gpu):
     """configs[4]: lid-driven cavity, unit cube n=43, P2/P1: 1 975 509 velocity + 85 184 pressure dofs, 477 042 tets,
-    nu=0.01, rho=1, dt=0.01, backward Euler, Newton per step.  Three of the ten steps; properties:
-    Newton converges quadratically to DOLFIN's tolerances (the residual includes the discrete continuity rows),
-    boundary values are exact, the flow spins up (kinetic energy grows, the core moves with the lid)."""
+    nu=0.01, rho=1, dt=0.01, backward Euler, Newton per step.  ALL ten steps of the configuration; properties:
+    Newton converges quadratically to DOLFIN's tolerances in every step (the residual includes the discrete continuity rows),
+    boundary values are exact, the flow spins up monotonically (kinetic energy grows step by step, ever more slowly; the core
+    moves with the lid)."""
     import copy
     import logging
     from collections import OrderedDict
@@ -192,7 +194,7 @@ def test_config5_taylor_hood_cavity_2m_velocity_dofs(gpu):
               'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 0},
               'material': {'density': 1.0, 'kinematic_viscosity': 0.01}})
     s['solver_settings']['transient_settings'] = {'transient': True, 'starting_time': 0.0, 'time_step': 0.01,
-                                                  'ending_time': 0.03 - 1e-9}
+                                                  'ending_time': 0.1 - 1e-9}
     s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
     s['report_settings'] = {"logging_level": logging.ERROR, "logging_file": None, "plotting_freq": 0, "saving_freq": 0}
     solver = CoupledNavierStokesSolver(s)
@@ -201,7 +203,7 @@ def test_config5_taylor_hood_cavity_2m_velocity_dofs(gpu):
     energies = []
     solver.init_solver()
     solver.current_time, solver.current_step = 0.0, 0
-    for step in range(3):
+    for step in range(10):
         solver.solve_current_step()
         h = solver.newton_history
         assert h[-1] <= max(1e-9 * h[0], 1e-10) and len(h) <= 5
@@ -215,7 +217,9 @@ def test_config5_taylor_hood_cavity_2m_velocity_dofs(gpu):
     lid = co[:, 2] == 1.0
     wall = ((co[:, 0] == 0) | (co[:, 0] == 1) | (co[:, 1] == 0) | (co[:, 1] == 1) | (co[:, 2] == 0)) & ~lid
     assert np.all(a[lid, 0] == 1.0) and np.all(a[lid, 1:3] == 0.0) and np.all(a[wall, :3] == 0.0)
-    assert energies[0] < energies[1] < energies[2]
+    assert all(e1 > e0 for e0, e1 in zip(energies, energies[1:]))
+    growth = np.diff(energies)
+    assert all(g1 < g0 for g0, g1 in zip(growth[1:], growth[2:]))       # the spin-up slows down towards the steady state
     near_lid = (co[:, 2] > 0.9) & (co[:, 2] < 1.0) & (np.abs(co[:, 0] - 0.5) < 0.2) & (np.abs(co[:, 1] - 0.5) < 0.2)
     assert a[near_lid, 0].mean() > 0.05            # fluid under the lid is dragged along +x
     assert np.abs(a[W.mesh().num_vertices():, 3]).max() == 0.0   # dummy pressure slots stay zero
