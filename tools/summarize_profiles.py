@@ -8,7 +8,7 @@
                                     profiles/<tag>_pmc.json, see profiles/README.md)
 
 The default bench command runs two problem sizes back to back; dispatches are attributed to a
-phase by time: before / after the second sparsity build (second k_pair_keys dispatch).
+phase by time: before / after the last sparsity build (last k_pair_keys dispatch).
 """
 import csv
 import json
@@ -38,7 +38,8 @@ def short(name):
 def phase_split(cur, table, name_col, start_col):
     rows = cur.execute("select %s from %s where %s like 'k_pair_keys%%' order by %s"
                        % (start_col, table, name_col, start_col)).fetchall()
-    return rows[1][0] if len(rows) > 1 else None
+    # (round 4: bench.py builds the 1 M-DOF pattern twice - cold and warm - so the 10 M-DOF phase starts at the LAST build)
+    return rows[-1][0] if len(rows) > 1 else None
 
 
 def kernel_stats():
