@@ -404,10 +404,16 @@ class CoupledNavierStokesSolver(SolverBase):
             st = backend.krylov_solve(M, b, x, rtol=1e-12, max_iter=2000, precond="jacobi", norm="preconditioned")
             if st['converged'] != 1:
                 raise SolverError('viscous_stress: the mass-matrix solve did not converge')
-            xo = x.get()[:dP.n_owned]
-            if ploc is not None:
-                from . import parallel
-                xo = parallel.gather_owned(xo, ploc.owned_gids(), ploc.n_global, 1)
+            if ploc is not None and getattr(ploc, 'is_local_view', False):
+                from . import parallel          # distributed mesh: this rank's vertices, ghosts refreshed
+                if parallel.world()[1] > 1:
+                    backend.halo_exchange(dP, x)
+                xo = x.get()[:nv]
+            else:
+                xo = x.get()[:dP.n_owned]
+                if ploc is not None:
+                    from . import parallel
+                    xo = parallel.gather_owned(xo, ploc.owned_gids(), ploc.n_global, 1)
             out[:, k] = xo
         sigma = Function(T_space)
         sigma.vector().set_local(out.reshape(-1))
@@ -463,5 +469,17 @@ class CoupledNavierStokesSolver(SolverBase):
         d = self.dimension
         T = self.viscous_stress(up).node_values().reshape(-1, d, d)
         fv, nrm = self._facet_geometry(np.concatenate([self.boundary_facets.where(i) for i in boundary_index_list]))
+        ploc = up.function_space().pressure_space().localizer()
+        if ploc is not None and getattr(ploc, 'is_local_view', False):
+            # distributed mesh: the cells between an owned and a ghost vertex plane exist on two ranks - a facet counts on the rank
+            # that owns its vertex of smallest global id - and the force is summed over the ranks
+            from . import backend, parallel
+            g = np.asarray(ploc.l2g)[fv]
+            first = fv[np.arange(len(fv)), np.argmin(g, axis=1)]
+            mine = first < ploc.n_owned
+            force = -np.einsum("fij,fj->i", T[fv[mine]].mean(axis=1), nrm[mine]) if mine.any() else np.zeros(d)
+            if parallel.world()[1] > 1:
+                force = np.asarray(backend.comm_allreduce_sum(force), dtype=np.float64)
+            return float(force[drag_axis_index]), float(force[lift_axis_index])
         force = -np.einsum("fij,fj->i", T[fv].mean(axis=1), nrm)
         return float(force[drag_axis_index]), float(force[lift_axis_index])

@@ -826,25 +826,39 @@ class SolverBase():
         W = F.space
         V = W.device()
         loc = W.localizer()
-        dofs, vals = self._bc_arrays(bcs)                      # global dofs
+        dofs, vals = self._bc_arrays(bcs)                      # global dofs (a distributed mesh: this rank's host numbering)
         pre = dofs[(dofs % 4) == 3] if dofs.size else dofs
         ctx = getattr(self, '_ns_ctx', None)
         key = (V.serial, pre.size, np.sort(pre).tobytes())
         if ctx is None or ctx['key'] != key:
+            from . import parallel
             Qs = W.pressure_space()
             Q = Qs.device()
             qloc = Qs.localizer()
             pinned = (pre // 4).astype(np.int64)
+            local_view = getattr(loc, 'is_local_view', False)
+            # distributed mesh: the host lists name this rank's vertices only - whether ANY pressure condition exists, and the
+            # global vertices it names, are agreed over the ranks (every rank builds the same global pressure hierarchy below)
+            gpre = None
+            if local_view:
+                own = pinned < qloc.n_owned
+                gpre = np.concatenate(parallel.allgather_index_lists(np.asarray(qloc.l2g)[pinned[own]])) if parallel.world()[1] > 1 \
+                    else np.asarray(qloc.l2g)[pinned[own]]
+            n_pre_global = pre.size if gpre is None else gpre.size
             per = W.periodic_pairs()                 # (slave, master) P2 nodes of a periodic_boundary, or None
             qper = Qs.periodic_pairs()
             pin_vertex = 0
             if qper is not None and 0 in set(qper[0].tolist()):
                 pin_vertex = int(qper[1][list(qper[0]).index(0)])      # a slave has no equation of its own: pin its master
-            if pinned.size == 0:
+            pin_local = pin_vertex           # host vertex that carries the pin (None: the pinned vertex is not on this rank)
+            if n_pre_global == 0:
                 # no pressure condition: the pressure is defined up to a constant (the reference's LU hits a
                 # singular matrix here); fix it at vertex 0
                 self.logger.warning('no pressure boundary condition: pinning the pressure at vertex %d to 0', pin_vertex)
-                pinned = np.full(1, pin_vertex, dtype=np.int64)
+                if local_view:                # global vertex 0: on the rank(s) whose slab holds it, owned or ghost
+                    hit = np.nonzero(np.asarray(qloc.l2g) == pin_vertex)[0]
+                    pin_local = int(hit[0]) if hit.size else None
+                pinned = np.full(1, pin_local, dtype=np.int64) if pin_local is not None else np.zeros(0, dtype=np.int64)
             if qloc is not None:
                 pinned = qloc.dofs(pinned, np.zeros(len(pinned)))[0]
             pinned = np.asarray(pinned, dtype=np.int32)
@@ -864,19 +878,26 @@ class SolverBase():
             # several GPUs: the pressure space is small, so every rank holds the hierarchy of the GLOBAL pressure
             # Laplacian (assembled on the global mesh) and the Schur-complement solve is replicated (fs_saddle.hip)
             if loc is not None:
-                gm = backend.DeviceMesh(self.mesh.coordinates(), self.mesh.cells())
+                if getattr(self.mesh, '_slab', None) is not None:      # distributed box: the device generates the whole box
+                    nx_, ny_, nz_, p0_, p1_ = self.mesh._box
+                    gm = backend.DeviceMesh.box(nx_, ny_, nz_, p0_, p1_)
+                else:
+                    gm = backend.DeviceMesh(self.mesh.coordinates(), self.mesh.cells())
                 gQ = backend.DeviceSpace(gm, 1, 1)
                 gK = backend.DeviceMatrix(gQ)
                 gK.assemble(stiffness=1.0)
-                gpin = (pre // 4).astype(np.int32) if pre.size else np.zeros(1, dtype=np.int32)
+                if gpre is not None:
+                    gpin = np.unique(gpre).astype(np.int32) if gpre.size else np.full(1, pin_vertex, dtype=np.int32)
+                else:
+                    gpin = (pre // 4).astype(np.int32) if pre.size else np.zeros(1, dtype=np.int32)
                 gK.apply_dirichlet(None, gpin, np.zeros(len(gpin)), symmetric=True)
                 kp_amg = backend.AMG(gK)
                 keep = (gm, gQ, gK)
             else:
                 kp_amg, keep = backend.AMG(Kp), None
             ctx = {'key': key, 'Kp': Kp, 'Mp': Mp, 'J': backend.DeviceMatrix(V), 'pinned': pinned,
-                   'auto_pin': pre.size == 0, 'Kp_amg': kp_amg, 'cell_g2l': cell_g2l, 'global_pressure': keep,
-                   'per': per, 'pin_dof': 4 * pin_vertex + 3,
+                   'auto_pin': n_pre_global == 0 and pin_local is not None, 'Kp_amg': kp_amg, 'cell_g2l': cell_g2l, 'global_pressure': keep,
+                   'per': per, 'pin_dof': 4 * (pin_local if pin_local is not None else 0) + 3,
                    'slave_dofs': None if per is None else (per[0].astype(np.int64)[:, None] * 4 + np.arange(4)).ravel().astype(np.int32)}
             self._ns_ctx = ctx
         if ctx['auto_pin']:
@@ -1053,7 +1074,14 @@ class SolverBase():
             tm["krylov"] += t5 - t4
             tm["update"] += t6 - t5
         wl = dw.get()
-        w = wl[:V.n_owned] if loc is None else parallel.gather_owned(wl[:V.n_owned], loc.owned_gids(), loc.n_global, 4)
+        if loc is None:
+            w = wl[:V.n_owned]
+        elif getattr(loc, 'is_local_view', False):
+            # distributed mesh: the Function keeps this rank's part - owned values and the ghosts the last halo refreshed - in
+            # the host's node order (what a DOLFIN Function holds under MPI); parallel.gather_nodes(u) names the nodes globally
+            w = loc.to_host(wl) if not getattr(loc, 'is_identity', True) else wl[:loc.n_local * 4]
+        else:
+            w = parallel.gather_owned(wl[:V.n_owned], loc.owned_gids(), loc.n_global, 4)
         if timing:
             self.logger.warning("Newton timing [s]: %s", {k: round(v, 4) for k, v in tm.items()})
         self.newton_history = history
@@ -1082,9 +1110,14 @@ class SolverBase():
         self._navier_stokes_krylov(F, ctx, ctx['J'], g, x, float(sp.get('krylov_relative_tolerance', 1e-8)), True)
         if per is not None:
             x.assign_entries(per[0], per[1], block=4)
-        out = x.get()[:V.n_owned]
-        if loc is not None:
-            out = parallel.gather_owned(out, loc.owned_gids(), loc.n_global, 4)
+        if loc is not None and getattr(loc, 'is_local_view', False):
+            if parallel.world()[1] > 1:
+                backend.halo_exchange(V, x)
+            out = loc.to_host(x.get()) if not getattr(loc, 'is_identity', True) else x.get()[:loc.n_local * 4]
+        else:
+            out = x.get()[:V.n_owned]
+            if loc is not None:
+                out = parallel.gather_owned(out, loc.owned_gids(), loc.n_global, 4)
         out[F.space.dummy_dofs()] = 0.0
         u.vector().set_local(out)
         return u

@@ -969,10 +969,7 @@ class FunctionSpace:
         if getattr(mesh, "_slab", None) is not None:
             # distributed box: the host mesh already IS this rank's part, numbered as the device numbers a slab
             lay = mesh._slab
-            if root._degree == 2:
-                if root._ncomp == 4:
-                    raise SolverError("BoxMesh(distributed=True) carries P1 and P2 scalar / vector spaces; the Taylor-Hood space uses "
-                                      "the replicated mesh (distributed=False)")
+            if root._degree == 2:      # (scalar, vector and - round 4 - the four-unknown Taylor-Hood node blocks)
                 return FunctionSpace._make_distributed_p2_device(root, backend, parallel, partition, mesh, lay, rank)
             ds = backend.DeviceSpace(mesh.device(), root._ncomp, 1)
             if ds.n_owned != lay["n_owned"] * root._ncomp or ds.n_local != lay["n_local"] * root._ncomp:

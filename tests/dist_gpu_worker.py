@@ -107,9 +107,15 @@ else:
         if solver.function_space.degree() == 2:
             # CG2: nodes are named by global keys (vertex id / the two global end points of an edge); no global numbering exists
             vg, vv, ek, ev = parallel.gather_nodes(u)
+            extra = {}
+            if case == "channel_dist":        # the stress projection and the boundary force on the distributed pressure space
+                ploc = solver.function_space.pressure_space().localizer()
+                sig = solver.viscous_stress(u).node_values().reshape(-1, 9)
+                extra["sigma"] = parallel.gather_owned(sig[:ploc.n_owned].reshape(-1), ploc.owned_gids(), ploc.n_global, 9)
+                extra["force"] = np.array(solver.calc_drag_and_lift(u, 2, 0, [1]))
             if rank == 0:
                 result = dict(vertex_gids=vg, vertex_values=vv, edge_keys=ek, edge_values=ev, iterations=solver.last_solve_stats["iterations"],
-                              n_local=solver.function_space.num_nodes())
+                              n_local=solver.function_space.num_nodes(), **extra)
         else:
             full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
             if rank == 0:

@@ -189,6 +189,38 @@ def test_distributed_box_mesh_with_p2_spaces(gpu, tmp_path, case, world):
     assert int(r["n_local"]) <= V.num_nodes() / world * 1.3 + ghost_layers
 
 
+@pytest.mark.parametrize("case,world", [("cavity_dist", 2), ("cavity_dist", 3), ("channel_dist", 2), ("channel_dist", 3)])
+def test_navier_stokes_on_the_distributed_box_mesh(gpu, tmp_path, case, world):
+    """Taylor-Hood on BoxMesh(distributed=True) (BASELINE configs[4] is a 4-GPU configuration): every rank
+    builds only its slab on the host; the Newton loop, the boundary lists, the pressure pin, the pressure hierarchy (the device
+    generates the whole box for the replicated pressure Laplacian, the pressure conditions are agreed over the ranks), the
+    stress projection and the boundary force work on that slab; the Function keeps this rank's nodes.  Same field as the
+    one-process solve, node by node through global keys; nothing of global size on a rank."""
+    import test_gpu_parallel_api as T
+    one = T.DIST_CASES[case]()
+    single = one.solve().vector().get_local()
+    W = one.function_space
+    nv = one.mesh.num_vertices()
+    ed = W.edge_nodes().astype(np.int64)
+    r = _run(world, case, tmp_path)
+    S = single.reshape(-1, 4)
+    scale = np.abs(S).max()
+    assert len(r["vertex_gids"]) == nv and len(r["edge_keys"]) == len(ed)            # every node owned exactly once
+    assert np.abs(r["vertex_values"] - S[r["vertex_gids"]]).max() <= 1e-6 * scale
+    key = {(int(a), int(b)): k for k, (a, b) in enumerate(ed)}
+    idx = np.array([key[(int(a), int(b))] for a, b in r["edge_keys"]])
+    assert len(np.unique(idx)) == len(ed)
+    assert np.abs(r["edge_values"] - S[nv + idx]).max() <= 1e-6 * scale
+    nx, ny, nz = one.mesh._box[:3]
+    ghost_layers = 2.0 * (W.num_nodes() / (nz + 1.0)) * 2.0
+    assert int(r["n_local"]) <= W.num_nodes() / world * 1.3 + ghost_layers
+    if case == "channel_dist":
+        sig = one.viscous_stress(one.w_current).node_values().reshape(-1)
+        assert np.abs(r["sigma"] - sig).max() <= 1e-5 * np.abs(sig).max()
+        force = np.array(one.calc_drag_and_lift(one.w_current, 2, 0, [1]))
+        assert np.abs(r["force"] - force).max() <= 1e-6 * np.abs(force).max()
+
+
 @pytest.mark.parametrize("case,world,p2p", [("cavity", 2, False), ("cavity", 3, False), ("channel", 2, False), ("radiation", 2, False),
                                             ("cavity", 3, True), ("channel", 2, True)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world, p2p):
@@ -286,3 +318,24 @@ def test_bench_under_the_drivers_launcher(gpu, tmp_path, p2p):
         assert "unavailable" in d["strong"]["single_reduction+p2p"]
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src and "from torch" not in src
+
+
+def test_bench_taylor_hood_leg_runs_on_the_distributed_mesh(gpu, tmp_path):
+    """`bench.py --gpus N` adds BASELINE configs[4] (`configs4_th`, automatic at N = 4): since round 4 on BoxMesh(distributed=True) -
+    rank 0's host holds its slab of the nodes only (VERDICT r3 next #2).  Two ranks on one GPU through the stand-in, a small cube."""
+    import json
+    shim = os.path.join(ROOT, "tests", "shim", "libfakerccl.so")
+    PORT[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(PORT[0]), os.path.join(ROOT, "tests", "shim", "on_device0.py"), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--cells", "15", "--extra", "th", "--th-n", "6", "--recurrence", "single_reduction"]
+    p = subprocess.run(cmd, env=dict(os.environ, FS_RCCL_PATH=shim), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert "extra_legs_error" not in d, d.get("extra_legs_error")
+    th = d["configs4_th"]
+    n_nodes = 13 ** 3
+    assert th["time_steps"] == 10 and th["n_dof"] == 3 * n_nodes + 7 ** 3
+    assert th["host_nodes_rank0"] < 0.75 * n_nodes and "distributed box mesh" in th["workload"]
+    assert th["newton_residuals_last_step"][-1] <= 1e-9 * max(th["newton_residuals_last_step"][0], 1e-300) or th["newton_residuals_last_step"][-1] <= 1e-10
+    assert 0.0 < th["max_speed"] <= 1.0 + 1e-12

@@ -95,12 +95,12 @@ def _elastic_case(distributed=False, degree=1):
     return LinearElasticitySolver(s)
 
 
-def _cavity_case(n=4, transient=True):
+def _cavity_case(n=4, transient=True, distributed=False):
     """Lid-driven cavity, Taylor-Hood, two backward-Euler steps with Newton (configs[4] in small)."""
     from fenicssolver_amd.fem import UnitCubeMesh, BoxMesh, Point, AutoSubDomain, Constant, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
-    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 1.5), n, n, n + 2)
+    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 1.5), n, n, n + 2, distributed=distributed)
     bcs = OrderedDict()
     bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 1,
                     'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))}]}
@@ -118,14 +118,14 @@ def _cavity_case(n=4, transient=True):
     return CoupledNavierStokesSolver(s)
 
 
-def _channel_case():
+def _channel_case(distributed=False):
     """Pressure-driven channel along z (the partition axis): pressure Dirichlet + the reference's pressure-boundary
     integrals on the inlet / outlet facets, which lie in the first and the last rank's parts."""
     from fenicssolver_amd.fem import BoxMesh, Point, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
     nu = 0.3
-    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 3, 3, 6)
+    mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 3, 3, 6, distributed=distributed)
     prof = Expression(("0", "0", "x[0]*(1-x[0])"), degree=2)
     bcs = OrderedDict()
     bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[0], 0) or near(x[0], 1) or near(x[1], 0) or near(x[1], 1))),
@@ -179,7 +179,9 @@ DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist":
               # CG2 spaces on the distributed box: node plan from local cells only, host <-> device through a local permutation
               "heat_p2_dist": lambda: _heat_case(4, degree=2, distributed=True),
               "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
-              "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2)}
+              "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2),
+              # Taylor-Hood on the distributed box (round 4): Newton loop, pressure hierarchy and projections on this rank's slab only
+              "cavity_dist": lambda: _cavity_case(distributed=True), "channel_dist": lambda: _channel_case(distributed=True)}
 
 def _file_mesh_case(degree=1):
     """data/TestHeatTransfer.json on data/mesh.xml (a Gmsh mesh in file order): decomposed by RCB-free coordinate slabs, every part
