@@ -375,14 +375,18 @@ class SolverBase():
         norm = sp_.get('norm_type', 'preconditioned' if (method == "cg" and pc in ("jacobi", "amg")) else 'unpreconditioned')
         loc = u.function_space().localizer()
         from . import parallel as _par
+        # several GPUs: 'distributed' (default since round 4) - the hierarchy of the undecomposed operator on every rank, its fine
+        # level working on this rank's rows; 'replicated' - every rank solves the whole gathered system (round 3: the iteration
+        # count of one GPU, no speed-up); 'schwarz' - rank-local hierarchies
+        mode = sp_.get('amg_decomposition', 'distributed')
         replicated = (pc == 'amg' and loc is not None and _par.world()[1] > 1 and global_operator is not None
                       and hasattr(loc, 'l2g')            # (a CG2 space on a distributed mesh has no global node numbering: Schwarz)
                       and isinstance(near_nullspace, (str, type(None)))
-                      and sp_.get('amg_decomposition', 'replicated') == 'replicated')
+                      and mode in ('replicated', 'distributed'))
         if replicated:
             stats = self._replicated_amg_solve(b, x, V, loc, u.function_space()._ncomp, global_operator, operator_key,
                                                near_nullspace, rtol, min(max_iter, int(sp_.get('maximum_iterations', 500))), norm,
-                                               float(sp_.get('amg_strength_threshold', 0.0)))
+                                               float(sp_.get('amg_strength_threshold', 0.0)), A_local=A if mode == 'distributed' else None)
         elif pc == 'amg':
             # several GPUs, solver_parameters['amg_decomposition'] = 'schwarz': every rank builds the hierarchy of its own
             # diagonal block (additive Schwarz, no overlap, no coarse space: the iteration count grows with the number of parts)
@@ -450,7 +454,7 @@ class SolverBase():
             u.vector().set_local(parallel.gather_owned(x.get()[:V.n_owned], loc.owned_gids(), loc.n_global, ncomp))
         return u
 
-    def _replicated_amg_solve(self, b, x, V, loc, ncomp, global_operator, key, near_nullspace, rtol, max_iter, norm, theta):
+    def _replicated_amg_solve(self, b, x, V, loc, ncomp, global_operator, key, near_nullspace, rtol, max_iter, norm, theta, A_local=None):
         """solve_amg on several GPUs.  A hierarchy of the rank-local diagonal blocks (additive Schwarz) has no coarse space that
         couples the parts: on the cantilever of BASELINE configs[2] cut into 2 / 4 / 8 slabs across its length the 24
         iterations of one GPU become 166 / 321 / 495 (tools/amg_schwarz_probe.py).  What multigrid needs is the GLOBAL
@@ -462,7 +466,8 @@ class SolverBase():
         Navier-Stokes Schur complement is treated the same way (fs_saddle.hip)."""
         from . import backend, parallel
         cached = getattr(self, '_amg_cache', None)
-        if key is not None and cached is not None and cached[0] == ('replicated', key):
+        tag = 'replicated' if A_local is None else 'distributed'
+        if key is not None and cached is not None and cached[0] == (tag, key):
             hierarchy, reused = cached[1], True
         else:
             if cached is not None:
@@ -470,8 +475,24 @@ class SolverBase():
                 self._amg_cache = None
             Ag = global_operator()
             hierarchy, reused = backend.AMG(Ag, nullspace=near_nullspace, strength_threshold=theta), False
+            hierarchy._distributed = False
+            if A_local is not None and hierarchy.info()['levels'] >= 2:
+                # the fine level on this rank's rows of the decomposed operator; levels >= 1 replicated (fs_amg_attach_distributed_fine)
+                # (a problem so small that the hierarchy is one level is solved replicated, as in round 3)
+                hierarchy.attach_distributed_fine(A_local, loc.owned_gids())
+                hierarchy._distributed = True
             if key is not None:
-                self._amg_cache = (('replicated', key), hierarchy)
+                self._amg_cache = ((tag, key), hierarchy)
+        if hierarchy._distributed:
+            # CG on the decomposed operator (halo + reduced dots), one V-cycle per iteration whose fine level is distributed
+            stats = hierarchy.solve(b, x, rtol=rtol, max_iter=max_iter, norm=norm)
+            stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
+            stats['amg_reused'], stats['amg_decomposition'] = reused, 'distributed'
+            if parallel.world()[1] > 1:
+                backend.halo_exchange(V, x)
+            if key is None:
+                hierarchy.close()
+            return stats
         Vg = hierarchy.A.space
         bg = parallel.gather_owned(b.get()[:V.n_owned], loc.owned_gids(), loc.n_global, ncomp)
         if bg.size != Vg.n_owned:

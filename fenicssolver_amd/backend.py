@@ -558,6 +558,13 @@ class AMG(_Handle):
                 raise ValueError("near-null space has %d entries per vector, the matrix has %d rows" % (ns.shape[1], A.space.n_owned))
         L.check(L.load().fs_amg_setup(A.h, nb, L.p_f64(ns), C.byref(o), C.byref(self.h)), "fs_amg_setup")
 
+    def attach_distributed_fine(self, A_local, owned_global_nodes):
+        """The hierarchy was built on the undecomposed operator: from now on level 0 works on A_local, this rank's rows of the
+        decomposed operator (owned_global_nodes[i] = undecomposed node of local owned node i); levels >= 1 stay replicated."""
+        g = L.i32(owned_global_nodes)
+        L.check(L.load().fs_amg_attach_distributed_fine(self.h, A_local.h, len(g), L.p_i32(g)), "fs_amg_attach_distributed_fine")
+        self.A_local = A_local          # keeps the decomposed operator alive
+
     def info(self):
         nl, oc, gc, ms = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         L.check(L.load().fs_amg_info(self.h, C.byref(nl), C.byref(oc), C.byref(gc), C.byref(ms)), "fs_amg_info")

@@ -64,8 +64,13 @@ struct fs_amg_s {
     dbuf<double> partials, sums;
     // PCG vectors
     dbuf<double> pr, pz, pp, pw;
+    // DISTRIBUTED fine level under replicated coarse levels (fs_amg_attach_distributed_fine): the hierarchy was built on the
+    // undecomposed operator (every rank the same), `fine` is swapped for this rank's rows of the decomposed operator and dist0
+    // holds the level-0 pieces for those rows - P rows + transpose index, dinv, work vectors; level 1 and below stay replicated
+    amg_level* dist0 = nullptr;
     ~fs_amg_s() {
         for (amg_level* l : lv) delete l;
+        delete dist0;
     }
 };
 
@@ -1237,7 +1242,7 @@ static int spgemm(int64_t n_out, int64_t n_cols, int br, int bk, int bc, bool tr
 }
 
 static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, double* y, int mode, hipStream_t s) {
-    amg_level* L = M->lv[l];
+    amg_level* L = (l == 0 && M->dist0) ? M->dist0 : M->lv[l];
     if (l == 0) {
         if (mode == 0) return fs_spmv_dev(M->fine, x, y, s);
         FS_CHECK(fs_spmv_dev(M->fine, x, L->t.p, s));
@@ -1351,6 +1356,26 @@ static void amg_tick(const char* what) {
 }
 
 // ---- host: one coarsening step.  Returns *stop = 1 when no useful coarse level results ------------------
+// transpose index of L->P (nn x n_agg blocks): entries sorted by column (stable: ascending fine row inside a column), R = P^T
+// blocks in that order
+static int build_p_transpose(amg_level* L, int64_t nn, int64_t n_agg, int bs, int nb, hipStream_t s) {
+    const int64_t pn = L->P.nnz;
+    const int g = fs_grid_for(nn);
+    dbuf<int32_t> k2, ids, prow;
+    FS_CHECK(k2.alloc(std::max<int64_t>(pn, 1))); FS_CHECK(ids.alloc(std::max<int64_t>(pn, 1))); FS_CHECK(prow.alloc(std::max<int64_t>(pn, 1)));
+    FS_CHECK(L->pt_entry.alloc(std::max<int64_t>(pn, 1))); FS_CHECK(L->pt_row.alloc(std::max<int64_t>(pn, 1))); FS_CHECK(L->pt_ptr.alloc(n_agg + 1));
+    hipLaunchKernelGGL(k_iota, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, ids.p, pn);
+    hipLaunchKernelGGL(k_expand_rows, dim3(g), dim3(FS_BLOCK), 0, s, L->P.rowptr.p, nn, prow.p);
+    if (pn > 0) FS_CHECK(sort_pairs(L->P.col.p, k2.p, ids.p, L->pt_entry.p, pn, s));
+    hipLaunchKernelGGL(k_lower_bounds, dim3(fs_grid_for(n_agg + 1)), dim3(FS_BLOCK), 0, s, k2.p, pn, (int64_t)n_agg, L->pt_ptr.p);
+    hipLaunchKernelGGL(k_gather_i32, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, prow.p, L->pt_entry.p, pn, L->pt_row.p);
+    FS_CHECK(L->rt_val.alloc(std::max<int64_t>(pn * bs * nb, 1)));
+    hipLaunchKernelGGL(k_transpose_blocks, dim3(fs_grid_for(pn * bs * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, pn, bs, nb, L->pt_entry.p, L->P.val.p, L->rt_val.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_level** out, hipStream_t s) {
     *out = nullptr;
     const int64_t nn = L->nn;
@@ -1472,21 +1497,7 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     L->n_agg = n_agg;
     amg_tick("  smoothed P");
     // transpose index of P
-    {
-        const int64_t pn = L->P.nnz;
-        dbuf<int32_t> k2, ids, prow;
-        FS_CHECK(k2.alloc(pn)); FS_CHECK(ids.alloc(pn)); FS_CHECK(prow.alloc(pn));
-        FS_CHECK(L->pt_entry.alloc(pn)); FS_CHECK(L->pt_row.alloc(pn)); FS_CHECK(L->pt_ptr.alloc(n_agg + 1));
-        hipLaunchKernelGGL(k_iota, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, ids.p, pn);
-        hipLaunchKernelGGL(k_expand_rows, dim3(g), dim3(FS_BLOCK), 0, s, L->P.rowptr.p, nn, prow.p);
-        FS_CHECK(sort_pairs(L->P.col.p, k2.p, ids.p, L->pt_entry.p, pn, s));    // stable: ascending fine row inside a column
-        hipLaunchKernelGGL(k_lower_bounds, dim3(fs_grid_for(n_agg + 1)), dim3(FS_BLOCK), 0, s, k2.p, pn, (int64_t)n_agg, L->pt_ptr.p);
-        hipLaunchKernelGGL(k_gather_i32, dim3(fs_grid_for(pn)), dim3(FS_BLOCK), 0, s, prow.p, L->pt_entry.p, pn, L->pt_row.p);
-        FS_CHECK(L->rt_val.alloc(pn * bs * nb));
-        hipLaunchKernelGGL(k_transpose_blocks, dim3(fs_grid_for(pn * bs * nb, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, pn, bs, nb, L->pt_entry.p, L->P.val.p, L->rt_val.p);
-        FS_KERNEL_CHECK();
-        FS_HIP(hipStreamSynchronize(s));
-    }
+    FS_CHECK(build_p_transpose(L, nn, n_agg, bs, nb, s));
     amg_tick("  transpose");
     // A_c = P^T (A P)
     {
@@ -1665,6 +1676,84 @@ extern "C" int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullsp
     return FS_OK;
 }
 
+// ---- distributed fine level under the replicated hierarchy ----------------------------------------------------------------
+__global__ void k_sel_row_lengths(int64_t n_sel, const int32_t* __restrict__ sel, const int32_t* __restrict__ rowptr, int32_t* __restrict__ len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i <= n_sel; i += stride) len[i] = i < n_sel ? rowptr[sel[i] + 1] - rowptr[sel[i]] : 0;
+}
+__global__ void k_sel_copy_rows(int64_t n_sel, const int32_t* __restrict__ sel, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                const double* __restrict__ val, int bb, const int32_t* __restrict__ new_ptr, int32_t* __restrict__ new_col,
+                                double* __restrict__ new_val) {
+    const int lane = threadIdx.x & 63;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (; i < n_sel; i += stride) {
+        const int32_t s0 = rowptr[sel[i]], len = rowptr[sel[i] + 1] - s0, d0 = new_ptr[i];
+        for (int32_t e = lane; e < len; e += 64) new_col[d0 + e] = col[s0 + e];
+        for (int64_t e = lane; e < (int64_t)len * bb; e += 64) new_val[(int64_t)d0 * bb + e] = val[(int64_t)s0 * bb + e];
+    }
+}
+__global__ void k_sel_gather_dofs(int64_t n_sel, const int32_t* __restrict__ sel, int bs, const double* __restrict__ src, double* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_sel * bs; i += stride) dst[i] = src[(int64_t)sel[i / bs] * bs + i % bs];
+}
+
+// M was set up on the UNDECOMPOSED operator (the same on every rank).  A_local holds this rank's rows of the decomposed operator
+// (halo plan on its space); owned_global_nodes[i] = number, in the undecomposed space, of local owned node i.  From now on the
+// V-cycle smooths, restricts and prolongs level 0 on this rank's rows only - ghost entries refreshed before every fine product,
+// the restricted right-hand side summed over the ranks - and applies levels >= 1 as they are: the preconditioner of one GPU,
+// with the fine-level work divided by the number of ranks.  fs_amg_solve then runs CG on the decomposed operator.
+extern "C" int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, int64_t n_owned_nodes, const int32_t* owned_global_nodes) {
+    FS_CHECK(fs_require_init());
+    FS_REQUIRE(M && A_local && owned_global_nodes, "fs_amg_attach_distributed_fine: null pointer");
+    FS_REQUIRE(M->lv.size() >= 2, "fs_amg_attach_distributed_fine: the hierarchy has a single level");
+    FS_REQUIRE(!M->dist0, "fs_amg_attach_distributed_fine: a distributed fine level is attached already");
+    amg_level* G = M->lv[0];
+    fs_space_s* sp = A_local->space;
+    FS_REQUIRE(A_local->bs == G->bs && n_owned_nodes == sp->n_nodes_owned, "fs_amg_attach_distributed_fine: %lld owned nodes of block size %d do not match the space (%lld, %d)",
+               (long long)n_owned_nodes, A_local->bs, (long long)sp->n_nodes_owned, G->bs);
+    hipStream_t s = fs_rt().stream;
+    const int bs = G->bs, nb = G->P.bc, bb = bs * nb;
+    const int64_t nn = n_owned_nodes;
+    amg_level* D = new amg_level();
+    int rc = FS_OK;
+    auto fail = [&](int code) { delete D; return code; };
+    D->nn = nn; D->bs = bs; D->n = nn * bs; D->nb = G->nb; D->lmax = G->lmax; D->gersh = G->gersh; D->n_agg = G->n_agg;
+    dbuf<int32_t> sel, len;
+    if ((rc = sel.alloc(std::max<int64_t>(nn, 1))) != FS_OK || (rc = len.alloc(nn + 1)) != FS_OK) return fail(rc);
+    if ((rc = sel.upload(owned_global_nodes, nn, s)) != FS_OK) return fail(rc);
+    for (int64_t i = 0; i < nn; ++i)
+        if (owned_global_nodes[i] < 0 || owned_global_nodes[i] >= G->nn) {
+            fs_set_error("fs_amg_attach_distributed_fine: node %lld names global node %d of %lld", (long long)i, owned_global_nodes[i], (long long)G->nn);
+            return fail(FS_ERR_INVALID);
+        }
+    // this rank's rows of P
+    D->P.nrows = nn; D->P.ncols = G->P.ncols; D->P.br = G->P.br; D->P.bc = G->P.bc;
+    if ((rc = D->P.rowptr.alloc(nn + 1)) != FS_OK) return fail(rc);
+    hipLaunchKernelGGL(k_sel_row_lengths, dim3(fs_grid_for(nn + 1)), dim3(FS_BLOCK), 0, s, nn, sel.p, G->P.rowptr.p, len.p);
+    if ((rc = scan_exclusive(len.p, D->P.rowptr.p, nn + 1, s)) != FS_OK) return fail(rc);
+    int32_t pn = 0;
+    if ((rc = read_i32(D->P.rowptr.p + nn, &pn, s)) != FS_OK) return fail(rc);
+    D->P.nnz = pn;
+    if ((rc = D->P.col.alloc(std::max<int64_t>(pn, 1))) != FS_OK || (rc = D->P.val.alloc(std::max<int64_t>((int64_t)pn * bb, 1))) != FS_OK) return fail(rc);
+    hipLaunchKernelGGL(k_sel_copy_rows, dim3(fs_grid_for(nn * 64, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, nn, sel.p, G->P.rowptr.p, G->P.col.p, G->P.val.p, bb,
+                       D->P.rowptr.p, D->P.col.p, D->P.val.p);
+    if ((rc = build_p_transpose(D, nn, G->n_agg, bs, nb, s)) != FS_OK) return fail(rc);
+    // diagonal and work vectors of the local rows
+    if ((rc = D->dinv.alloc(std::max<int64_t>(D->n, 1))) != FS_OK || (rc = D->r.alloc(std::max<int64_t>(D->n, 1))) != FS_OK ||
+        (rc = D->d.alloc(std::max<int64_t>(D->n, 1))) != FS_OK || (rc = D->t.alloc(std::max<int64_t>(D->n, 1))) != FS_OK) return fail(rc);
+    hipLaunchKernelGGL(k_sel_gather_dofs, dim3(fs_grid_for(D->n)), dim3(FS_BLOCK), 0, s, nn, sel.p, bs, G->dinv.p, D->dinv.p);
+    FS_KERNEL_CHECK();
+    FS_HIP(hipStreamSynchronize(s));
+    M->dist0 = D;
+    M->fine = A_local;
+    // (the CG vectors are sized for the space they multiply with: re-allocated by the next fs_amg_solve)
+    M->pr.release(); M->pz.release(); M->pp.release(); M->pw.release();
+    return FS_OK;
+}
+
 extern "C" int fs_amg_destroy(fs_amg_t M) {
     delete M;
     return FS_OK;
@@ -1710,7 +1799,10 @@ extern "C" int fs_amg_level_get(fs_amg_t M, int level, int which, int32_t* rowpt
 
 // ---- V-cycle ----------------------------------------------------------------------------------------------
 static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_guess, hipStream_t s) {
-    amg_level* L = M->lv[l];
+    // distributed fine level: this rank's rows, the ghost entries of x refreshed before every product - the smoother IS the
+    // undecomposed one (same operator, same diagonal, same eigenvalue bound)
+    const bool dist = l == 0 && M->dist0 != nullptr;
+    amg_level* L = dist ? M->dist0 : M->lv[l];
     const double up = 1.1 * L->lmax, lo = 0.1 * L->lmax;
     const double theta = 0.5 * (up + lo), delta = 0.5 * (up - lo), sigma = theta / delta;
     double rho = 1.0 / sigma;
@@ -1719,6 +1811,7 @@ static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_gues
     const bool fine = l == 0;       // level 0: the product comes from the SELL kernel, b - A x is formed inside the update
     if (!zero_guess) {
         if (fine) {
+            if (dist) FS_CHECK(fs_halo_exchange_dev(M->fine->space, x, s));
             FS_CHECK(level_spmv(M, l, x, b, L->t.p, 0, s));
             hipLaunchKernelGGL(k_cheb_first_bt<true>, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, b, L->t.p, L->d.p, x, 1.0 / theta);
         } else {
@@ -1732,6 +1825,7 @@ static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_gues
     for (int k = 1; k < M->smooth_steps; ++k) {
         const double rho_new = 1.0 / (2.0 * sigma - rho);
         if (fine) {
+            if (dist) FS_CHECK(fs_halo_exchange_dev(M->fine->space, x, s));
             FS_CHECK(level_spmv(M, l, x, b, L->t.p, 0, s));
             hipLaunchKernelGGL(k_cheb_next_bt, dim3(g), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, b, L->t.p, L->d.p, x, rho_new * rho, 2.0 * rho_new / delta);
         } else {
@@ -1744,7 +1838,8 @@ static int smooth(fs_amg_s* M, int l, double* x, const double* b, bool zero_gues
 }
 
 static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s) {
-    amg_level* L = M->lv[l];
+    const bool dist = l == 0 && M->dist0 != nullptr;
+    amg_level* L = dist ? M->dist0 : M->lv[l];
     const int last = (int)M->lv.size() - 1;
     if (l == last) {
         if (M->cinv.p && l > 0) {
@@ -1757,6 +1852,7 @@ static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s)
     }
     amg_level* C = M->lv[l + 1];
     FS_CHECK(smooth(M, l, x, b, true, s));
+    if (dist) FS_CHECK(fs_halo_exchange_dev(M->fine->space, x, s));
     FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
     {
         const int rg = fs_grid_for(C->nn, FS_BLOCK / 64, 16384);
@@ -1768,6 +1864,8 @@ static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s)
         else { fs_set_error("AMG: restriction for %dx%d blocks is not built", L->P.br, L->P.bc); return FS_ERR_UNSUPPORTED; }
 #undef FS_RESTRICT_ARGS
     }
+    // distributed fine level: every rank restricted its own rows; the coarse right-hand side is their sum, on every rank
+    if (dist) FS_CHECK(fs_comm_allreduce_dev(C->b.p, (int)C->n, s));
     FS_CHECK(vcycle(M, l + 1, C->x.p, C->b.p, s));
     if (L->P.br == 3 && L->P.bc == 6)
         hipLaunchKernelGGL((k_prolong_add_grp<3, 6>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
@@ -1785,7 +1883,7 @@ int fs_amg_apply_dev(fs_amg_s* M, const double* r, double* z, hipStream_t s) {
 
 extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
     FS_REQUIRE(M && r && z, "fs_amg_apply: null pointer");
-    amg_level* L0 = M->lv[0];
+    amg_level* L0 = M->dist0 ? M->dist0 : M->lv[0];
     FS_REQUIRE(r->d.n >= L0->n && z->d.n >= M->fine->space->n_dofs_local, "fs_amg_apply: vector too short");
     hipStream_t s = fs_rt().stream;
     FS_CHECK(vcycle(M, 0, z->d.p, r->d.p, s));
@@ -1795,12 +1893,12 @@ extern "C" int fs_amg_apply(fs_amg_t M, fs_vector_t r, fs_vector_t z) {
 }
 
 // ---- PCG preconditioned by one V-cycle (PETSc KSPCG + PCGAMG) ------------------------------------------------
-int64_t fs_amg_rows(const fs_amg_s* amg) { return amg && !amg->lv.empty() ? amg->lv[0]->n : 0; }
+int64_t fs_amg_rows(const fs_amg_s* amg) { return amg && !amg->lv.empty() ? (amg->dist0 ? amg->dist0->n : amg->lv[0]->n) : 0; }
 
 extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts, fs_krylov_stats* stats) {
     std::lock_guard<std::recursive_mutex> solve_lock(fs_solve_mutex());
     FS_REQUIRE(M && b && x && opts && stats, "fs_amg_solve: null pointer");
-    amg_level* L0 = M->lv[0];
+    amg_level* L0 = M->dist0 ? M->dist0 : M->lv[0];
     const int64_t n = L0->n;
     fs_space_s* sp = M->fine->space;
     FS_REQUIRE(b->d.n >= n && x->d.n >= sp->n_dofs_local, "fs_amg_solve: vector too short");

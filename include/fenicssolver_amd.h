@@ -384,6 +384,14 @@ typedef struct fs_amg_opts {
  * block (ghost columns dropped): fs_amg_solve is then CG on the distributed operator with the rank-local
  * V-cycles as non-overlapping additive Schwarz preconditioner. */
 int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullspace, const fs_amg_opts* opts, fs_amg_t* out);
+/* Distributed fine level under a replicated hierarchy (several GPUs; PETSc's GAMG under mpirun keeps the fine level distributed
+ * and agglomerates the coarse ones, SolverBase.py:643-672 + :634).  M was set up on the UNDECOMPOSED operator, identically on
+ * every rank; A_local holds this rank's rows of the decomposed operator (halo plan on its space); owned_global_nodes[i] = the
+ * node, in the undecomposed space, of local owned node i.  Afterwards fs_amg_apply / fs_amg_solve smooth, restrict and prolong
+ * level 0 on this rank's rows (ghost refresh before every fine product, the restricted right-hand side summed over the ranks)
+ * and apply levels >= 1 as they are: the preconditioner - and the iteration count - of one GPU, with the fine-level work
+ * divided by the number of ranks.  COLLECTIVE in its use (every rank attaches its part before the first solve). */
+int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, int64_t n_owned_nodes, const int32_t* owned_global_nodes);
 int fs_amg_destroy(fs_amg_t amg);
 int fs_amg_info(fs_amg_t amg, int* n_levels, double* operator_complexity, double* grid_complexity, double* setup_ms);
 int fs_amg_level_info(fs_amg_t amg, int level, int64_t* n_nodes, int* block_size, int64_t* nnz_blocks,

@@ -118,8 +118,12 @@ else:
                               n_local=solver.function_space.num_nodes(), **extra)
         else:
             full = parallel.gather_function(u)          # [n_global (, 3)] on every rank
+            extra = {}
+            if "amg_decomposition" in solver.last_solve_stats:
+                extra["amg_decomposition"] = np.array(solver.last_solve_stats["amg_decomposition"])
+                extra["amg_levels"] = np.array(solver.last_solve_stats.get("amg_levels", 0))
             if rank == 0:
-                result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices())
+                result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices(), **extra)
     else:
         extra = {}
         if case.startswith("elasticity") and hasattr(solver, "von_Mises"):
@@ -130,6 +134,9 @@ else:
             its = solver.last_solve_stats["iterations"]
             extra["sigma"] = solver.viscous_stress(u).vector().get_local()
             solver.last_solve_stats["iterations"] = its
+        if "amg_decomposition" in solver.last_solve_stats:
+            extra["amg_decomposition"] = np.array(solver.last_solve_stats["amg_decomposition"])
+            extra["amg_levels"] = np.array(solver.last_solve_stats.get("amg_levels", 0))
         if rank == 0:
             result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"], **extra)
     parallel.barrier()

@@ -240,20 +240,23 @@ def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world, p2p):
         assert np.abs(r["sigma"] - sig).max() <= 1e-5 * np.abs(sig).max()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "replicated"), (3, "replicated"), (2, "schwarz")])
+@pytest.mark.parametrize("world,mode", [(2, "distributed"), (3, "distributed"), (2, "replicated"), (3, "replicated"), (2, "schwarz")])
 def test_amg_pcg_under_several_ranks(gpu, tmp_path, world, mode):
-    """solve_amg on several ranks.  Default ('replicated'): every rank holds the hierarchy of the UNDECOMPOSED operator and
-    solves the gathered right-hand side - the iteration count of one GPU whatever the number of parts (rank-local
-    hierarchies have no coarse space coupling the parts: tools/amg_schwarz_probe.py counts 24 / 166 / 321 / 495 iterations
-    at 1 / 2 / 4 / 8 slabs of BASELINE configs[2]).  'schwarz': CG on the distributed operator preconditioned by the
-    rank-local hierarchies.  Same displacement field as the single-GPU AMG-PCG either way."""
+    """solve_amg on several ranks.  Default since round 4 ('distributed'): every rank builds the hierarchy of the UNDECOMPOSED
+    operator, then attaches its own rows of the decomposed operator as the fine level (fs_amg_attach_distributed_fine): smoothing,
+    residual, restriction and prolongation of level 0 on this rank's rows - ghost refresh before every fine product, the coarse
+    right-hand side summed over the ranks -, levels >= 1 replicated; CG runs on the decomposed operator.  The V-cycle is the
+    one-GPU V-cycle: the iteration count of one GPU whatever the number of parts, with the fine-level work divided by it
+    (rank-local hierarchies have no coarse space coupling the parts: tools/amg_schwarz_probe.py counts 24 / 166 / 321 / 495
+    iterations at 1 / 2 / 4 / 8 slabs of BASELINE configs[2]).  'replicated' (round 3): every rank solves the whole gathered
+    system.  'schwarz': rank-local hierarchies.  Same displacement field as the single-GPU AMG-PCG every way."""
     import test_gpu_parallel_api as T
     one = T.CASES["elasticity"]()
     single = one.solve().vector().get_local()
     its = one.last_solve_stats["iterations"]
-    r = _run(world, "elasticity", tmp_path, **({"FS_TEST_AMG_DECOMPOSITION": "schwarz"} if mode == "schwarz" else {}))
+    r = _run(world, "elasticity", tmp_path, **({} if mode == "distributed" else {"FS_TEST_AMG_DECOMPOSITION": mode}))
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
-    if mode == "replicated":
+    if mode in ("replicated", "distributed"):
         assert abs(int(r["iterations"]) - its) <= 1
     else:
         assert its <= int(r["iterations"]) < 200
@@ -339,3 +342,19 @@ def test_bench_taylor_hood_leg_runs_on_the_distributed_mesh(gpu, tmp_path):
     assert th["host_nodes_rank0"] < 0.75 * n_nodes and "distributed box mesh" in th["workload"]
     assert th["newton_residuals_last_step"][-1] <= 1e-9 * max(th["newton_residuals_last_step"][0], 1e-300) or th["newton_residuals_last_step"][-1] <= 1e-10
     assert 0.0 < th["max_speed"] <= 1.0 + 1e-12
+
+
+@pytest.mark.parametrize("case,world", [("elasticity_fine", 2), ("elasticity_fine", 3), ("elasticity_fine_dist", 2), ("elasticity_fine_dist", 4)])
+def test_amg_with_a_distributed_fine_level(gpu, tmp_path, case, world):
+    """solve_amg on several ranks with a hierarchy of SEVERAL levels (37 x 7 x 7 nodes) - the fine level
+    works on each rank's rows (fs_amg_attach_distributed_fine), the coarse levels are replicated; replicated host mesh and
+    BoxMesh(distributed=True).  The V-cycle is the one-GPU V-cycle: same iteration count (+-1), same displacement."""
+    import test_gpu_parallel_api as T
+    one = (T.DIST_CASES if case.endswith("_dist") else T.CASES)[case]()
+    single = one.solve().vector().get_local()
+    its = one.last_solve_stats["iterations"]
+    assert one.last_solve_stats["amg_levels"] >= 2
+    r = _run(world, case, tmp_path)
+    assert str(r["amg_decomposition"]) == "distributed" and int(r["amg_levels"]) >= 2
+    assert abs(int(r["iterations"]) - its) <= 1
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()

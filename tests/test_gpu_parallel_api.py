@@ -65,19 +65,19 @@ def _elastic_p2_case():
     return solver
 
 
-def _elastic_case(distributed=False, degree=1):
+def _elastic_case(distributed=False, degree=1, fine=1):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
     bcs = OrderedDict()
     if distributed:     # slabs are cut along z: the beam lies along z
-        mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 10), 2, 2, 12, distributed=True)
+        mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 10), 2 * fine, 2 * fine, 12 * fine, distributed=True)
         bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
                         'value': Constant((0, 0, 0))}
         bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 10)), 'boundary_id': 2, 'type': 'stress',
                           'value': Constant((0, 1e6, 1e8))}
     else:
-        mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 12, 2, 2)
+        mesh = BoxMesh(Point(0, 0, 0), Point(10, 1, 1), 12 * fine, 2 * fine, 2 * fine)
         bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
                         'value': Constant((0, 0, 0))}
         bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
@@ -175,7 +175,7 @@ NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radi
 
 # BoxMesh(distributed=True): every rank builds only its z-slab on the host (one rank: the same mesh as the replicated one)
 DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist": lambda: _heat_case(transient=True, distributed=True),
-              "elasticity_dist": lambda: _elastic_case(distributed=True),
+              "elasticity_dist": lambda: _elastic_case(distributed=True), "elasticity_fine_dist": lambda: _elastic_case(distributed=True, fine=3),
               # CG2 spaces on the distributed box: node plan from local cells only, host <-> device through a local permutation
               "heat_p2_dist": lambda: _heat_case(4, degree=2, distributed=True),
               "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
@@ -197,6 +197,8 @@ def _file_mesh_case(degree=1):
 
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
+         # 37 x 7 x 7 nodes: a hierarchy of several levels (the 12 x 2 x 2 beam is a single level)
+         "elasticity_fine": lambda: _elastic_case(fine=3),
          "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
          "heat_supg": lambda: _heat_case(supg=True),
          "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
