@@ -157,11 +157,10 @@ class ShuffledProblem:
         self.file_of_structured = new_of_old
         t0 = time.perf_counter()
         if renumber:
-            vorder, corder = B.locality_order(co, ce)                # vorder[new] = file id
+            self.mesh, vorder, corder = B.DeviceMesh.renumbered(co, ce)      # vorder[new] = file id; ordered and built on the device
             dev_of_file = np.empty(nv, dtype=np.int64)
             dev_of_file[vorder] = np.arange(nv)
             self.dev_of_file = dev_of_file
-            self.mesh = B.DeviceMesh(co[vorder], np.sort(dev_of_file[ce[corder]], axis=1).astype(np.int32))
         else:
             self.dev_of_file = np.arange(nv)
             self.mesh = B.DeviceMesh(co, ce)

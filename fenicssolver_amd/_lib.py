@@ -159,6 +159,7 @@ SIGNATURES = {
     "fs_space_set_halo": (C.c_int, [_H, C.c_int, c_i32p, c_i64p, c_i32p, c_i64p]),
     "fs_halo_exchange": (C.c_int, [_H, _H]),
     "fs_mesh_locality_order": (C.c_int, [C.c_int, c_i64, c_f64p, c_i64, c_i32p, C.c_int, c_i32p, c_i32p]),
+    "fs_mesh_create_renumbered": (C.c_int, [c_i64, c_f64p, c_i64, c_i32p, c_i32p, c_i32p, C.POINTER(_H)]),
     "fs_space_enable_p2p_halo": (C.c_int, [_H, C.c_int]),
     "fs_comm_benchmark": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

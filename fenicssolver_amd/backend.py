@@ -109,6 +109,21 @@ class DeviceMesh(_Handle):
                                             int(zplanes[1]), C.byref(m.h)), "fs_mesh_create_box")
         return m
 
+    @classmethod
+    def renumbered(cls, coords, cells):
+        """A tetrahedral mesh that arrives in FILE order, uploaded once and built on the device in the locality order of
+        fs_mesh_locality_order (global vertex ids = the file's numbers).  Returns (mesh, vertex_order, cell_order):
+        vertex_order[k] / cell_order[c] = file number of device vertex k / device cell c."""
+        co, ce = L.f64(coords), L.i32(cells)
+        if co.ndim != 2 or co.shape[1] != 3 or ce.ndim != 2 or ce.shape[1] != 4:
+            raise BackendError("DeviceMesh.renumbered: coords [nv,3] and cells [nc,4]")
+        m = cls()
+        vo = np.empty(co.shape[0], dtype=np.int32)
+        cord = np.empty(ce.shape[0], dtype=np.int32)
+        L.check(L.load().fs_mesh_create_renumbered(co.shape[0], L.p_f64(co), ce.shape[0], L.p_i32(ce), L.p_i32(vo), L.p_i32(cord),
+                                                   C.byref(m.h)), "fs_mesh_create_renumbered")
+        return m, vo, cord
+
     def info(self):
         nv, nc, no = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.load().fs_mesh_info(self.h, C.byref(nv), C.byref(nc), C.byref(no)), "fs_mesh_info")

@@ -1287,11 +1287,35 @@ __global__ void k_cell_first_vertex(int64_t nc, int vpc, const int32_t* __restri
     }
 }
 
-extern "C" int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
-                                      int32_t* vertex_order, int32_t* cell_order) {
+__global__ void k_renumbered_xyz(int64_t nv, const int32_t* __restrict__ order, const double* __restrict__ xyz3, double* __restrict__ xyz4,
+                                 int64_t* __restrict__ gid) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nv; k += stride) {
+        const int64_t o = order[k];
+        xyz4[4 * k] = xyz3[3 * o]; xyz4[4 * k + 1] = xyz3[3 * o + 1]; xyz4[4 * k + 2] = xyz3[3 * o + 2]; xyz4[4 * k + 3] = 0.0;
+        gid[k] = o;
+    }
+}
+__global__ void k_renumbered_cells(int64_t nc, const int32_t* __restrict__ cell_order, const int32_t* __restrict__ cells_in,
+                                   const int32_t* __restrict__ rank, int32_t* __restrict__ cells_out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; c < nc; c += stride) {
+        const int4 v = reinterpret_cast<const int4*>(cells_in)[cell_order[c]];
+        reinterpret_cast<int4*>(cells_out)[c] = make_int4(rank[v.x], rank[v.y], rank[v.z], rank[v.w]);     // the cell's own vertex order is kept
+    }
+}
+
+// vertex_order[k] = old id of new vertex k, cell_order[c] = old id of new cell c.  mesh_out (optional): the mesh in that order,
+// built on the device from the arrays already uploaded for the ordering - coordinates gathered, cells gathered and renamed, global
+// ids = the old vertex ids (fs_mesh_create_renumbered; round 4: the host used to re-index 58 M cells with numpy, 6.7 s at 10 M DOF)
+static int locality_order_impl(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
+                               int32_t* vertex_order, int32_t* cell_order, fs_mesh_t* mesh_out) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(xyz && cells && vertex_order && cell_order, "fs_mesh_locality_order: null pointer");
     FS_REQUIRE((gdim == 3 && verts_per_cell == 4) || (gdim == 2 && verts_per_cell == 3), "fs_mesh_locality_order: tetrahedra in 3-D or triangles in 2-D");
+    FS_REQUIRE(!mesh_out || gdim == 3, "fs_mesh_create_renumbered: tetrahedral meshes");
     FS_REQUIRE(nv > 0 && nc > 0 && nv < (int64_t)INT32_MAX && nc < (int64_t)INT32_MAX, "fs_mesh_locality_order: bad sizes");
     hipStream_t s = fs_rt().stream;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -1338,5 +1362,33 @@ extern "C" int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, i
     if ((int64_t)tb2 + 16 > tmp.n) FS_CHECK(tmp.alloc((int64_t)tb2 + 16));
     FS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, ck_in.p, ck_out.p, c_in.p, c_out.p, (int)nc, 0, 32, s));
     FS_CHECK(c_out.download(cell_order, nc, s));
+    if (mesh_out) {
+        fs_mesh_s* m = new fs_mesh_s();
+        m->nv = nv; m->nc = nc; m->n_owned = nv; m->tdim = 3;
+        int rc = FS_OK;
+        if ((rc = m->xyz.alloc(nv * 4)) != FS_OK || (rc = m->cells.alloc(nc * 4)) != FS_OK || (rc = m->gid.alloc(nv)) != FS_OK) {
+            delete m;
+            return rc;
+        }
+        hipLaunchKernelGGL(k_renumbered_xyz, dim3(fs_grid_for(nv)), dim3(FS_BLOCK), 0, s, nv, v_out.p, dx.p, m->xyz.p, m->gid.p);
+        hipLaunchKernelGGL(k_renumbered_cells, dim3(fs_grid_for(nc)), dim3(FS_BLOCK), 0, s, nc, c_out.p, dc.p, rank.p, m->cells.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            fs_set_error("fs_mesh_create_renumbered: kernel launch failed");
+            delete m;
+            return FS_ERR_HIP;
+        }
+        *mesh_out = m;
+    }
     return FS_OK;
+}
+
+extern "C" int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
+                                      int32_t* vertex_order, int32_t* cell_order) {
+    return locality_order_impl(gdim, nv, xyz, nc, cells, verts_per_cell, vertex_order, cell_order, nullptr);
+}
+
+extern "C" int fs_mesh_create_renumbered(int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int32_t* vertex_order,
+                                         int32_t* cell_order, fs_mesh_t* out) {
+    FS_REQUIRE(out, "fs_mesh_create_renumbered: null pointer");
+    return locality_order_impl(3, nv, xyz, nc, cells, 4, vertex_order, cell_order, out);
 }

@@ -109,6 +109,12 @@ int fs_mesh_destroy(fs_mesh_t mesh);
  * re-indexed cells[cell_order] through fs_mesh_create and keeps the permutation to translate indices and results. */
 int fs_mesh_locality_order(int gdim, int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int verts_per_cell,
                            int32_t* vertex_order, int32_t* cell_order);
+/* fs_mesh_locality_order + fs_mesh_create in one: the tetrahedral mesh of a FILE (Mesh(filename), SolverBase.py:203-258) uploaded
+ * once, ordered on the device, and built there in that order - coordinates gathered, cells gathered and renamed, the vertices'
+ * global ids = their numbers in the file.  vertex_order[k] / cell_order[c] = file number of new vertex k / new cell c, for the
+ * host's maps between file numbering (what the API speaks) and device numbering. */
+int fs_mesh_create_renumbered(int64_t nv, const double* xyz, int64_t nc, const int32_t* cells, int32_t* vertex_order,
+                              int32_t* cell_order, fs_mesh_t* out);
 
 /* ---- function space + sparsity (dolfin.FunctionSpace, SolverBase.py:260-275;
  *      the sparsity pattern DOLFIN builds inside the first assemble()) --------- */
