@@ -502,7 +502,7 @@ def kernel_name(V, st=None):
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
         # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
         # class rows are 24 doubles per round of the longest run plan: 1 round on P1, 5 on CG2 Kuhn meshes) / per-item class rows
-        whole = st["row_classes"] * (24 if V.degree == 1 else 120) * 8 <= (32 << 10)
+        whole = st["row_classes"] * (24 if V.degree == 1 else 80) * 8 <= (32 << 10)
         return "k_dict_spmv<3,%s> (row-dictionary form: %d distinct rows, %s)" % (
             "true" if whole else "false", st["row_classes"],
             "whole dictionary in LDS" if whole else "the class rows of each work item copied into its wave's LDS region")

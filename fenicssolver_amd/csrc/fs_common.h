@@ -255,6 +255,7 @@ struct fs_space_s {
     dbuf<int32_t> dict_items;     // [n_dict_items][4]
     dbuf<int32_t> dict_plans;
     int dict_slots = 0;
+    int dict_run_len = 3;         // coefficient positions per run (2: CG2 spaces, where runs of three offsets are rare)
     int64_t n_dict_items = -1;    // -1: not built yet, 0: the pattern does not lend itself to the form
     dbuf<int32_t> pair_list;      // [2 * n_pairs]
     dbuf<int32_t> pair_singles;   // [n_pair_singles]

@@ -421,12 +421,12 @@ static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round"
 
 // Coefficient position (plan layout) of the stored entry with offset o, walking the runs of a plan in ascending order from run g on
 // (the entries of a row come in ascending offsets, as the runs do): -1 = the plan has no such offset.
-__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int& g, int32_t o) {
+__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int RL, int& g, int32_t o) {
     while (g < n_runs) {
         const dict_plan_round& pr = pl[g >> 3];
         const int32_t st = pr.start[g & 7];
         const int ln = pr.len[g & 7];
-        if (ln > 0 && o < st + ln) return o >= st ? 3 * g + (o - st) : -1;
+        if (ln > 0 && o < st + ln) return o >= st ? RL * g + (o - st) : -1;
         ++g;
     }
     return -1;
@@ -437,7 +437,7 @@ __device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ 
 template <typename F>
 __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
                                               const int32_t* __restrict__ dia_off, const double* __restrict__ val,
-                                              const dict_plan_round* __restrict__ pl, int n_runs, F f) {
+                                              const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f) {
     const int32_t sl = r >> 6, ln = r & 63;
     const int64_t base = slice_ptr[sl];
     const int width = (int)((slice_ptr[sl + 1] - base) >> 6);
@@ -449,7 +449,7 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
     for (int k = 0; k < width; ++k) {
         const double v = vp[(int64_t)k * FS_SLICE];
         if (v == 0.0) continue;
-        const int slot = dict_slot_of(pl, n_runs, g, op[k]);
+        const int slot = dict_slot_of(pl, n_runs, RL, g, op[k]);
         if (slot < 0) { ok = false; break; }
         f(slot, v);
     }
@@ -470,7 +470,7 @@ __device__ __forceinline__ unsigned long long dict_mix(unsigned long long h, int
 // sends the lane to the compare-and-swap, which returns the truth).
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
                                                           const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S, int RL,
                                                           unsigned long long* keys, const unsigned long long* keys_cached, double* slot_vals,
                                                           uint16_t* __restrict__ cls_slot, int* info) {
     const int lane = threadIdx.x & 63;
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
             const int32_t r = first + i;
             unsigned long long h = 1469598103934665603ull;
             bool fits = true;
-            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int slot, double v) { h = dict_mix(h, slot, v); });
+            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); });
             if (!h) h = 1ull;
             if (live && !fits) atomicAdd(&info[2], 1);
             int my_slot = 0;
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
                             if (old == 0ull) {                  // this row is the representative of a new class
                                 if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 double* __restrict__ dst = slot_vals + (int64_t)slot * S;       // (zero-filled by the host before the launch)
-                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
+                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
                                 break;
                             }
                         }
@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long*
 // class numbers; EVERY row against its class, bit for bit (a hash collision ends here); the distinct classes of every item counted
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
                                                           const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S, int RL,
                                                           const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
                                                           const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
                                                           uint16_t* __restrict__ cls, int* info) {
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
             id2[half] = id;
             const double* __restrict__ dv = values + (int64_t)id * S;
             int nz = 0, diff = 0;
-            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, [&](int slot, double v) {
+            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int slot, double v) {
                 ++nz;
                 diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
             });
@@ -616,11 +616,14 @@ __device__ __forceinline__ double fs_from_next_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (24 per round
+// item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (8 RL per round
 // of the longest plan of the space), C = class rows a wave's LDS region holds.  Dynamic LDS: 4 waves x C x S doubles.
 // LDSD: the whole dictionary fits the workgroup's LDS (P1: 78 class rows of 24 doubles) - loaded once per workgroup, a row's
 // coefficients sit at class * S; otherwise (CG2: 361 rows of 120) each item's classes are copied into its wave's region.
-template <int DOTS, bool LDSD>
+// RL: longest run of the space's plans (coefficient positions per run): 3 on P1 Kuhn meshes (runs of 2, 2, 2, 3, 2, 2, 2), 2 on CG2
+// spaces, where 67 % of the runs are one offset long, 32 % two and 0.5 % three (those are cut in two): a third fewer fmas and LDS
+// reads on padded positions, one DPP shift per run instead of two.
+template <int DOTS, bool LDSD, int RL>
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
                                                         const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
                                                         const double* __restrict__ dict, int S, int C,
@@ -683,20 +686,32 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
         // outside the vector has no entry, hence a zero coefficient, and every value inside it is the right one.
         const double* __restrict__ xr = x + r;
         v2d A[8];
-        auto load_round = [&](v2d (&buf)[8], const dict_plan_round* __restrict__ p) {
+        struct starts8 { int32_t v[8]; };
+        auto read_starts = [&](const dict_plan_round* __restrict__ p) {       // (wave-uniform: one 32-byte scalar load)
+            starts8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.v[j] = __builtin_amdgcn_readfirstlane(p->start[j]);
+            return t;
+        };
+        auto load_round = [&](v2d (&buf)[8], const starts8& st) {
             if (!edge) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + p->start[j]);
+                for (int j = 0; j < 8; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + st.v[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int32_t c = r + p->start[j];
+                    const int32_t c = r + st.v[j];
                     buf[j].x = x[c < 0 ? 0 : (c > cmax ? cmax : c)];
                     buf[j].y = x[c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1)];
                 }
             }
         };
-        load_round(A, pl);
+        load_round(A, read_starts(pl));
+        // (per-item class rows = CG2: the run starts of a plan are the line's own - 20 MB of plans streamed once per product - and
+        // the NEXT round's are asked for a round ahead, so that a round's loads wait for one memory round trip, not two: 196 ->
+        // 187 us.  It costs 20 VGPRs (the compiler forms the next round's addresses early): not done where the dictionary sits whole
+        // in LDS - P1, one round -, which it took from 6 to 4 waves per SIMD, 68 -> 78 us)
+        starts8 st_next = read_starts(pl + ((!LDSD && rounds > 1) ? 1 : 0));
         int b0 = 0, b1 = 0;
         if (LDSD) {
             b0 = ok0 ? c0 * S : 0;
@@ -746,22 +761,31 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
         // second register set, 138 VGPRs, 3 waves per SIMD: 270 us; only the terms a run's length calls for, by wave-uniform branches
         // - most CG2 runs are one or two offsets long - : 339 us, the branches keep the coefficient reads from being batched)
         auto compute_round = [&](const v2d (&buf)[8], int rd) {
-            const double* __restrict__ w0 = v0 + 24 * rd;
-            const double* __restrict__ w1 = v1 + 24 * rd;
+            const double* __restrict__ w0 = v0 + 8 * RL * rd;
+            const double* __restrict__ w1 = v1 + 8 * RL * rd;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const double e0 = buf[j].x, e1 = buf[j].y;
-                const double e2 = fs_from_next_lane(buf[j].x), e3 = fs_from_next_lane(buf[j].y);
-                a0 = fma(w0[3 * j], e0, a0);     a1 = fma(w1[3 * j], e1, a1);
-                a0 = fma(w0[3 * j + 1], e1, a0); a1 = fma(w1[3 * j + 1], e2, a1);
-                a0 = fma(w0[3 * j + 2], e2, a0); a1 = fma(w1[3 * j + 2], e3, a1);
+                const double e2 = fs_from_next_lane(buf[j].x);
+                a0 = fma(w0[RL * j], e0, a0);     a1 = fma(w1[RL * j], e1, a1);
+                a0 = fma(w0[RL * j + 1], e1, a0); a1 = fma(w1[RL * j + 1], e2, a1);
+                if (RL == 3) {
+                    const double e3 = fs_from_next_lane(buf[j].y);
+                    a0 = fma(w0[RL * j + 2], e2, a0); a1 = fma(w1[RL * j + 2], e3, a1);
+                }
                 // (the coefficient positions are compile-time constants: left alone the compiler reads all 48 of a round
                 // ahead of the first fma - 150 VGPRs, 3 waves per SIMD; a compiler barrier per run keeps it at the run's six)
                 asm volatile("" ::: "memory");
             }
         };
         for (int rd = 0; rd < rounds; ++rd) {
-            if (rd > 0) load_round(A, pl + rd);
+            if (rd > 0) {
+                if (LDSD) load_round(A, read_starts(pl + rd));
+                else {
+                    load_round(A, st_next);
+                    st_next = read_starts(pl + (rd + 1 < rounds ? rd + 1 : rd));
+                }
+            }
             compute_round(A, rd);
             if (rd == 0) zi = A[0];
         }
@@ -1832,7 +1856,26 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         }
         segs.back().end = (int32_t)n;
     }
-    // 4. run plans (identical lists share one) and items
+    // 4. run plans (identical lists share one) and items.  Runs of up to three consecutive offsets - or of up to two where longer
+    // ones are rare (CG2: 0.5 % of the runs): a class row then has two coefficient positions per run instead of three
+    int RL = 3;
+    {
+        int64_t n_runs3 = 0, n_long = 0;
+        for (size_t g = 0; g < segs.size(); g += std::max<size_t>(segs.size() / 4096, 1)) {       // (a sample of the segments)
+            const int32_t* o = coff.data() + cptr[(size_t)segs[g].list];
+            const int w = clen[(size_t)segs[g].list];
+            for (int k = 0; k < w;) {
+                int len = 1;
+                while (k + len < w && len < 3 && o[k + len] == o[k + len - 1] + 1) ++len;
+                ++n_runs3;
+                n_long += len == 3;
+                k += len;
+            }
+        }
+        if (n_long * 20 < n_runs3) RL = 2;
+        static const char* rl_env = getenv("FS_DICT_RUN_LENGTH");
+        if (rl_env && (rl_env[0] == '2' || rl_env[0] == '3')) RL = rl_env[0] - '0';
+    }
     std::vector<dict_plan_round> rounds;
     struct plan_info { int32_t first, rounds, min_start, max_start; };
     std::vector<plan_info> seg_plan(segs.size());
@@ -1852,7 +1895,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
             int slot = 1;                               // slot 0 of round 0 is the z run
             for (int k = 0; k < w;) {
                 int len = 1;
-                while (k + len < w && len < 3 && o[k + len] == o[k + len - 1] + 1) ++len;
+                while (k + len < w && len < RL && o[k + len] == o[k + len - 1] + 1) ++len;
                 if (slot == 8) { rounds.push_back(cur); memset(&cur, 0, sizeof(cur)); slot = 0; }
                 cur.start[slot] = o[k];
                 cur.len[slot] = (uint8_t)len;
@@ -1869,8 +1912,8 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
             seg_plan[g] = pi;
         }
         if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
-            fprintf(stderr, "[fs_krylov] row-dictionary structure: %lld rows, %lld change their offset set, %zu segments, %zu distinct plans, %zu rounds (longest plan %d)\n",
-                    (long long)n, (long long)nc, segs.size(), infos.size(), rounds.size(), max_rounds);
+            fprintf(stderr, "[fs_krylov] row-dictionary structure: %lld rows, %lld change their offset set, %zu segments, %zu distinct plans of runs <= %d, %zu rounds (longest plan %d)\n",
+                    (long long)n, (long long)nc, segs.size(), infos.size(), RL, rounds.size(), max_rounds);
     }
     if (max_rounds > FS_DICT_MAX_ROUNDS) return give_up("a row has more runs of offsets than a plan holds");
     // processing order: by the position of the item's first row in the slice order of the space (an XCD then sweeps one slab of
@@ -1932,7 +1975,8 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         // (the plans depend on the pattern only: a later build for new halo lists finds the same array in place)
         FS_CHECK(sp->dict_plans.alloc(std::max<int64_t>(plan_ints, 16)));
         FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(rounds.data()), plan_ints, s));
-        sp->dict_slots = 24 * std::max(max_rounds, 1);
+        sp->dict_slots = 8 * RL * std::max(max_rounds, 1);
+        sp->dict_run_len = RL;
         FS_CHECK(upload_items(sp->dict_items, sp->n_dict_items, -1));
     }
     if (need_lists) {
@@ -1974,10 +2018,10 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     const dict_plan_round* plans = reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p);
     const int grid = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
     hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, S, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
+                       val, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
     hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, S, D.slot2cls.p, D.values.p, D.nnz.p);
     hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, S, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
+                       val, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
@@ -2031,11 +2075,15 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
 #define FS_DICT_ARGS(CC) sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), \
                          g_dict.cls.p, g_dict.values.p, g_dict.S, CC, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump, dict_map_xcd()
             const size_t whole = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
-            if (whole <= (size_t)FS_DICT_WHOLE_LDS_BYTES)
-                hipLaunchKernelGGL((k_dict_spmv<DOTS, true>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
-            else
-                hipLaunchKernelGGL((k_dict_spmv<DOTS, false>), dim3(gd), dim3(FS_BLOCK), (size_t)(FS_BLOCK / 64) * g_dict.C * g_dict.S * sizeof(double), s,
-                                   FS_DICT_ARGS(g_dict.C));
+            const size_t per_wave = (size_t)(FS_BLOCK / 64) * g_dict.C * g_dict.S * sizeof(double);
+            const bool rl2 = sp->dict_run_len == 2;
+            if (whole <= (size_t)FS_DICT_WHOLE_LDS_BYTES) {
+                if (rl2) hipLaunchKernelGGL((k_dict_spmv<DOTS, true, 2>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
+                else hipLaunchKernelGGL((k_dict_spmv<DOTS, true, 3>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
+            } else {
+                if (rl2) hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 2>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
+                else hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 3>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
+            }
 #undef FS_DICT_ARGS
             return;
         }
