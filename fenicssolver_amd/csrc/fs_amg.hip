@@ -1914,6 +1914,12 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
     memset(stats, 0, sizeof(*stats));
     const auto t0 = std::chrono::steady_clock::now();
     const int g = fs_grid_for(n, FS_BLOCK, 2048);
+    // the fine operator of a uniform box has a few dozen distinct (block) rows: its products - four per V-cycle and one per CG
+    // iteration - then run from class numbers + class rows instead of streaming 72 B per stored block (fs_krylov.hip, k_dict_spmv3);
+    // found from the values, every row verified, dropped when this solve returns
+    struct dict_guard { ~dict_guard() { fs_dict_end(); } } dict_scope;
+    FS_CHECK(fs_dict_begin(M->fine, s));
+    stats->row_classes = 0;
     // Multi-GPU: CG on the distributed operator (halo exchange before each product, dots reduced over the ranks),
     // preconditioned by the rank-local hierarchies (additive Schwarz, no overlap)
     auto dot_host = [&](fs_amg_s* Mm, const double* xx, const double* yy, int64_t nn, double* out, hipStream_t ss) -> int {
@@ -1997,7 +2003,7 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
     if (fs_p2p_reduce_enabled()) FS_CHECK(fs_p2p_check(s));      // a peer-to-peer wait timed out: the numbers below mean nothing
     stats->iterations = it;
     stats->converged = conv;
-    stats->row_classes = 0;
+    stats->row_classes = fs_dict_classes();
     stats->rel_residual = ref2 > 0.0 ? sqrt(res2 / ref2) : 0.0;
     stats->true_rel_residual = bb > 0.0 ? sqrt(tr2 / bb) : 0.0;
     stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity_gather(int6
                                                                             const int32_t* __restrict__ src,
                                                                             const int32_t* __restrict__ cells,
                                                                             const double* __restrict__ xyz4, double mu, double lambda,
-                                                                            coef_dev mc, int64_t plane, double* __restrict__ val) {
+                                                                            coef_dev mc, int64_t plane, double* __restrict__ val, const box_snap bx) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; e < n_entries; e += stride) {
@@ -786,7 +786,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_elasticity_gather(int6
             const int a = (sidx >> 2) & 3, b = sidx & 3;
             const int4 v4 = vc[u];
             const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-            const tet_geom t = tet_geometry(xyz4, v);
+            // (box meshes: edge vectors snapped to the grid spacing, as the scalar kernels do - equal stencils become equal block rows
+            // bit for bit, which the row-dictionary product of the AMG fine level lives on)
+            const tet_geom t = tet_geometry_box(xyz4, v, bx);
             const double vol = t.adet * (1.0 / 6.0);
             double ga[3], gb[3];
 #pragma unroll
@@ -2428,9 +2430,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         if (!sp->gmap_ptr.p) FS_CHECK(fs_space_build_gather_map(sp, s));
         const int gg = fs_grid_for(sp->sell_entries, FS_BLOCK, 1 << 16);
         if (add)
-            hipLaunchKernelGGL(k_assemble_p1_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_elasticity_gather<true>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p, make_box_snap(m));
         else
-            hipLaunchKernelGGL(k_assemble_p1_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p);
+            hipLaunchKernelGGL(k_assemble_p1_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p, make_box_snap(m));
     }
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));

@@ -330,6 +330,10 @@ int fs_halo_end_dev(fs_space_s* space, hipStream_t s);
 // the communication stream of the space's halo plan (created on first use): collectives that are to overlap with the
 // compute stream are issued there, in the same order on every rank
 int fs_halo_comm_stream(fs_space_s* space, hipStream_t* out);
+// fs_krylov.hip: the row dictionary of A's current values for the products that follow (fs_spmv_dev), and its end
+int fs_dict_begin(fs_matrix_s* A, hipStream_t s);
+void fs_dict_end();
+int fs_dict_classes();
 // fs_krylov.hip: bare y = A x on the library stream, no halo exchange, no synchronisation.
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 // fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.

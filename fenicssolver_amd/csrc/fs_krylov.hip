@@ -410,6 +410,7 @@ constexpr int FS_DICT_ITEM_ROWS = 126;  // rows per work item: two per lane for 
 constexpr int FS_DICT_WHOLE_LDS_BYTES = 32 << 10;   // a dictionary up to this size is held whole by every workgroup
 constexpr int FS_DICT_LDS_BYTES = 64 << 10;   // per workgroup: 4 waves x (most distinct classes of any item) x (doubles per class row)
 constexpr int FS_DICT_ITEMS_PER_WAVE = 4;   // consecutive items a wave takes when it fetches class rows per item
+constexpr int FS_DICT3_RUNS = 4;          // runs whose loads the block-row kernel has in flight at a time
 constexpr int FS_DICT_MAX_ROUNDS = 8;   // rounds of 8 runs per plan (192 coefficient positions)
 
 struct dict_plan_round {
@@ -432,11 +433,12 @@ __device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ 
     return -1;
 }
 
-// One row's stored entries (DIA slice storage: value plane k, offset list of the row's piece of its slice), nonzero ones only:
-// f(slot, value).  Returns false when an entry has no position in the plan.
+// One row's stored entries (DIA slice storage: value plane k, offset list of the row's piece of its slice), nonzero values only:
+// f(position, value), position = slot * nq + q for component q of an entry's nq = bs * bs values (block entry e, component q at
+// q * plane + e).  Returns false when an entry has no position in the plan.
 template <typename F>
 __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                              const int32_t* __restrict__ dia_off, const double* __restrict__ val,
+                                              const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane,
                                               const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f) {
     const int32_t sl = r >> 6, ln = r & 63;
     const int64_t base = slice_ptr[sl];
@@ -446,12 +448,15 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
     const double* __restrict__ vp = val + base + ln;
     int g = 1;                  // run 0 is the z run
     bool ok = true;
-    for (int k = 0; k < width; ++k) {
-        const double v = vp[(int64_t)k * FS_SLICE];
-        if (v == 0.0) continue;
-        const int slot = dict_slot_of(pl, n_runs, RL, g, op[k]);
-        if (slot < 0) { ok = false; break; }
-        f(slot, v);
+    for (int k = 0; k < width && ok; ++k) {
+        int slot = -2;          // not looked up yet
+        for (int q = 0; q < nq; ++q) {
+            const double v = vp[(int64_t)k * FS_SLICE + (int64_t)q * plane];
+            if (v == 0.0) continue;
+            if (slot == -2) slot = dict_slot_of(pl, n_runs, RL, g, op[k]);
+            if (slot < 0) { ok = false; break; }
+            f(slot * nq + q, v);
+        }
     }
     return ok;
 }
@@ -470,7 +475,7 @@ __device__ __forceinline__ unsigned long long dict_mix(unsigned long long h, int
 // sends the lane to the compare-and-swap, which returns the truth).
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
                                                           const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S, int RL,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
                                                           unsigned long long* keys, const unsigned long long* keys_cached, double* slot_vals,
                                                           uint16_t* __restrict__ cls_slot, int* info) {
     const int lane = threadIdx.x & 63;
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
             const int32_t r = first + i;
             unsigned long long h = 1469598103934665603ull;
             bool fits = true;
-            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); });
+            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); });
             if (!h) h = 1ull;
             if (live && !fits) atomicAdd(&info[2], 1);
             int my_slot = 0;
@@ -508,7 +513,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
                             if (old == 0ull) {                  // this row is the representative of a new class
                                 if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 double* __restrict__ dst = slot_vals + (int64_t)slot * S;       // (zero-filled by the host before the launch)
-                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
+                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
                                 break;
                             }
                         }
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long*
 // class numbers; EVERY row against its class, bit for bit (a hash collision ends here); the distinct classes of every item counted
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
                                                           const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int S, int RL,
+                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
                                                           const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
                                                           const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
                                                           uint16_t* __restrict__ cls, int* info) {
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
             id2[half] = id;
             const double* __restrict__ dv = values + (int64_t)id * S;
             int nz = 0, diff = 0;
-            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, pl, n_runs, RL, [&](int slot, double v) {
+            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) {
                 ++nz;
                 diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
             });
@@ -817,13 +822,148 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
     }
 }
 
+// ---- the same product for 3 x 3 block rows (vector P1 spaces: the elasticity operator of a uniform box; the fine level of its AMG) --
+// A lane holds two consecutive NODES (six rows); a run's load is the six values x[3 (r + o)] .. x[3 (r + o) + 5] (three 16-byte
+// loads), the next two nodes come from the next lane; class rows are [position][9].  Per stored block the terms are added in the
+// streaming kernel's order (k_sell_spmv<3, ..>: column component outer, row component inner): same bits.  Rounds are taken in two
+// halves of four runs (a round's 48 doubles of x per lane would not leave room for anything else).  No fused dots: this is the
+// product of fs_spmv_dev - the AMG V-cycle's fine level and its CG.
+template <int RL>
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv3(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
+                                                         const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
+                                                         const double* __restrict__ dict, int S, int C,
+                                                         const double* __restrict__ x, double* __restrict__ y, int map_xcd) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
+    extern __shared__ double sdict[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double* __restrict__ wl = sdict + (int64_t)wave * C * S;
+    constexpr int K = FS_DICT_ITEMS_PER_WAVE;
+    const int64_t n_chunks = (n_items + 4 * K - 1) / (4 * K);
+    const int32_t cmax = (int32_t)(n_cols - 1);
+    chunk_iter it = xcd_chunks(n_chunks);
+    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
+    int tagv = -1, rr = 0;
+    const unsigned long long cmask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+    for (; it.cur < it.end; it.cur += it.step)
+    for (int kk = 0; kk < K; ++kk) {
+        const int64_t q = (it.cur * 4 + wave) * K + kk;
+        if (q >= n_items) break;
+        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
+        const int32_t first = __builtin_amdgcn_readfirstlane(ds.x);
+        const int nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
+        const int edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
+        const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
+        const int rounds = __builtin_amdgcn_readfirstlane(ds.w);
+        const int32_t r = first + 2 * lane;
+        const bool ok0 = 2 * lane < nr, ok1 = 2 * lane + 1 < nr;
+        const int c0 = ok0 ? (int)cls[r] : -1, c1 = ok1 ? (int)cls[r + 1] : -1;
+        // ---- the classes of this item's nodes -> the wave's LDS region, unless they are there already (k_dict_spmv) ----
+        int b0 = 0, b1 = 0;
+        {
+            unsigned long long inuse = 0ull;
+            bool copied = false;
+            unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+            while (m0 | m1) {
+                const bool from0 = m0 != 0ull;
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(from0 ? m0 : m1)) - 1);
+                const int cv = __builtin_amdgcn_readlane(from0 ? c0 : c1, src);
+                const unsigned long long hit = __ballot(tagv == cv) & cmask;
+                int slot;
+                if (hit) slot = __ffsll((long long)hit) - 1;
+                else {
+                    const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
+                    slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
+                    rr = slot + 1 == C ? 0 : slot + 1;
+                    const v2d* __restrict__ src_row = reinterpret_cast<const v2d*>(dict + (int64_t)cv * S);
+                    v2d* __restrict__ dst_row = reinterpret_cast<v2d*>(wl + slot * S);
+                    for (int i = lane; i < (S >> 1); i += 64) dst_row[i] = src_row[i];
+                    if (lane == slot) tagv = cv;
+                    copied = true;
+                }
+                inuse |= 1ull << slot;
+                const bool h0 = c0 == cv, h1 = c1 == cv;
+                if (h0) b0 = slot * S;
+                if (h1) b1 = slot * S;
+                m0 &= ~__ballot(h0);
+                m1 &= ~__ballot(h1);
+            }
+            if (copied) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        const double* __restrict__ v0 = wl + b0;
+        const double* __restrict__ v1 = wl + b1;
+        double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
+        for (int rd = 0; rd < rounds; ++rd) {
+            const dict_plan_round* __restrict__ p = pl + rd;
+#pragma unroll 1
+            for (int h4 = 0; h4 < 8; h4 += FS_DICT3_RUNS) {
+                v2d A[FS_DICT3_RUNS][3];
+                if (!edge) {
+#pragma unroll
+                    for (int j = 0; j < FS_DICT3_RUNS; ++j) {
+                        const double* __restrict__ xp = x + 3 * ((int64_t)r + p->start[h4 + j]);
+                        A[j][0] = *reinterpret_cast<const v2du*>(xp);
+                        A[j][1] = *reinterpret_cast<const v2du*>(xp + 2);
+                        A[j][2] = *reinterpret_cast<const v2du*>(xp + 4);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FS_DICT3_RUNS; ++j) {
+                        int32_t ca = r + p->start[h4 + j], cb = ca + 1;
+                        ca = ca < 0 ? 0 : (ca > cmax ? cmax : ca);
+                        cb = cb < 0 ? 0 : (cb > cmax ? cmax : cb);
+                        const double* __restrict__ pa = x + 3 * (int64_t)ca;
+                        const double* __restrict__ pb = x + 3 * (int64_t)cb;
+                        A[j][0].x = pa[0]; A[j][0].y = pa[1]; A[j][1].x = pa[2];
+                        A[j][1].y = pb[0]; A[j][2].x = pb[1]; A[j][2].y = pb[2];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FS_DICT3_RUNS; ++j) {
+                    const double e0[3] = {A[j][0].x, A[j][0].y, A[j][1].x}, e1[3] = {A[j][1].y, A[j][2].x, A[j][2].y};
+                    const double* __restrict__ w0 = v0 + (8 * RL * rd + RL * (h4 + j)) * 9;
+                    const double* __restrict__ w1 = v1 + (8 * RL * rd + RL * (h4 + j)) * 9;
+                    // (a compiler barrier after every 3 x 3 block: left alone the compiler reads a run's 54 coefficients - and the next
+                    // runs' - ahead of the first fma: 256 VGPRs and spills, one wave per SIMD, 219 us)
+                    auto block_terms = [&](const double* __restrict__ cb, const double (&e)[3], double (&acc)[3]) {
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) acc[i] = fma(cb[i * 3 + jj], e[jj], acc[i]);
+                        asm volatile("" ::: "memory");
+                    };
+                    block_terms(w0, e0, a0);      block_terms(w1, e1, a1);
+                    const double e2[3] = {fs_from_next_lane(e0[0]), fs_from_next_lane(e0[1]), fs_from_next_lane(e0[2])};
+                    block_terms(w0 + 9, e1, a0);  block_terms(w1 + 9, e2, a1);
+                    if (RL == 3) {
+                        const double e3[3] = {fs_from_next_lane(e1[0]), fs_from_next_lane(e1[1]), fs_from_next_lane(e1[2])};
+                        block_terms(w0 + 18, e2, a0); block_terms(w1 + 18, e3, a1);
+                    }
+                }
+            }
+        }
+        double* __restrict__ yp = y + 3 * (int64_t)r;
+        if (ok1) {
+            v2d o0, o1, o2;
+            o0.x = a0[0]; o0.y = a0[1]; o1.x = a0[2]; o1.y = a1[0]; o2.x = a1[1]; o2.y = a1[2];
+            *reinterpret_cast<v2du*>(yp) = o0; *reinterpret_cast<v2du*>(yp + 2) = o1; *reinterpret_cast<v2du*>(yp + 4) = o2;
+        } else if (ok0) { yp[0] = a0[0]; yp[1] = a0[1]; yp[2] = a0[2]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct row_dict {
     dbuf<uint16_t> cls, cls_slot;
     dbuf<double> values, slot_vals;
     dbuf<unsigned long long> keys;
     dbuf<int32_t> slot2cls, nnz;
     dbuf<int> info;
-    int ncls = 0, S = 0, C = 0;             // classes, doubles per class row, most classes of any item
+    int ncls = 0, S = 0, C = 0, bs = 1;     // classes, doubles per class row, most classes of any item, block size of the matrix
     const double* built_for = nullptr;      // the value array the classes describe (nullptr: plain form in use)
     uint64_t space_serial = 0;              // ... of this space
     uint64_t matrix_serial = 0;             // ... of this matrix (addresses are handed out again after a free: the pointer alone is no identity)
@@ -1998,10 +2138,14 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     D.built_for = nullptr;
     fs_space_s* sp = A->space;
     static const bool off = getenv("FS_SPMV_DICT") && getenv("FS_SPMV_DICT")[0] == '0';
-    if (off || !g_row_dictionary || A->bs != 1 || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
+    if (off || !g_row_dictionary || (A->bs != 1 && A->bs != 3) || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
+    // (block rows: finding and verifying the classes costs about 3 ms a solve and the item kernel has a latency floor - measured
+    // on the AMG-PCG solve of the cantilever: 91 k DOF 6.5 -> 9.5 ms, 683 k DOF 14.0 -> 12.4 ms, 5.1 M DOF 100 -> 61 ms)
+    if (A->bs == 3 && sp->n_nodes_owned < 150000) return FS_OK;
     FS_CHECK(dict_structure_build(sp, s));
     if (sp->n_dict_items <= 0) return FS_OK;
-    const int S = sp->dict_slots;
+    const int nq = A->bs * A->bs;               // values per stored entry (3 x 3 blocks of a vector space: the class rows are [position][9])
+    const int S = sp->dict_slots * nq;
     const int64_t padded = sp->n_nodes_owned + 2 * FS_DICT_ITEM_ROWS;
     if (D.cls.n < padded) { FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
     if (!D.keys.p) {
@@ -2018,10 +2162,10 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     const dict_plan_round* plans = reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p);
     const int grid = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
     hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
+                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
     hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, S, D.slot2cls.p, D.values.p, D.nnz.p);
     hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
+                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
@@ -2039,6 +2183,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     D.ncls = h[0];
     D.S = S;
     D.C = h[3];
+    D.bs = A->bs;
     D.built_for = val;
     D.space_serial = sp->serial;
     D.matrix_serial = A->serial;
@@ -2057,7 +2202,20 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
     const int64_t ns = list ? n_list : sp->n_slices;
     if (ns == 0) return;
     const int32_t* order = list ? list : sp->slice_order.p;
-    if (A->bs == 1 && g_dict.built_for && g_dict.built_for == mat_val && g_dict.matrix_serial == A->serial && g_dict.space_serial == sp->serial) {
+    if (A->bs == 3 && DOTS == 0 && !list && g_dict.bs == 3 && g_dict.built_for && g_dict.built_for == mat_val && g_dict.matrix_serial == A->serial &&
+        g_dict.space_serial == sp->serial && sp->n_dict_items > 0) {
+        // 3 x 3 block rows from class numbers + class rows (the fine-level product of the elasticity AMG on a uniform box)
+        const int64_t n_chunks = (sp->n_dict_items + 4 * FS_DICT_ITEMS_PER_WAVE - 1) / (4 * FS_DICT_ITEMS_PER_WAVE);
+        const int gd = (int)std::max<int64_t>((std::min<int64_t>(n_chunks, 1024) + 7) & ~(int64_t)7, 8);
+        const size_t lds = (size_t)(FS_BLOCK / 64) * g_dict.C * g_dict.S * sizeof(double);
+#define FS_DICT3_ARGS dim3(gd), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
+                      reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.C, x, y, dict_map_xcd()
+        if (sp->dict_run_len == 2) hipLaunchKernelGGL((k_dict_spmv3<2>), FS_DICT3_ARGS);
+        else hipLaunchKernelGGL((k_dict_spmv3<3>), FS_DICT3_ARGS);
+#undef FS_DICT3_ARGS
+        return;
+    }
+    if (A->bs == 1 && g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == mat_val && g_dict.matrix_serial == A->serial && g_dict.space_serial == sp->serial) {
         // the values are a few dozen distinct rows (dict_build): class numbers + dictionary in LDS instead of the value stream.
         // Whole space: its own launch geometry (spmv_partials_unsplit); a list of a decomposed space (interior / boundary slices):
         // the geometry of the streaming kernel, so that the two launches keep filling one partial array.
@@ -2298,6 +2456,15 @@ int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     return FS_OK;
 }
 
+// fs_amg.hip: the products of one fs_amg_solve through the row dictionary where the fine operator's rows repeat (scalar and
+// 3 x 3 block operators of uniform boxes); fs_dict_end drops the table (row_dict_scope by hand: the call sites are in another file)
+int fs_dict_begin(fs_matrix_s* A, hipStream_t s) {
+    g_dict.built_for = nullptr;
+    return dict_build(A, A->val.p, s);
+}
+void fs_dict_end() { g_dict.built_for = nullptr; }
+int fs_dict_classes() { return g_dict.built_for ? g_dict.ncls : 0; }
+
 extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     FS_REQUIRE(A && x && y, "fs_spmv: null pointer");
     fs_space_s* sp = A->space;
@@ -2324,7 +2491,7 @@ extern "C" int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, i
     FS_REQUIRE(y->d.n >= sp->n_dofs_owned, "fs_spmv_dictionary: y too short");
     hipStream_t s = fs_rt().stream;
     row_dict_scope dict_scope;
-    if (A->bs == 1) FS_CHECK(dict_build(A, A->val.p, s));
+    if (A->bs == 1 || A->bs == 3) FS_CHECK(dict_build(A, A->val.p, s));
     if (A->bs == 1 && !g_dict.built_for && sp->n_pairs < 0 && spmv_use_pairs(sp, 1)) FS_CHECK(build_pair_lists(sp, s));
     FS_CHECK(fs_halo_exchange_dev(sp, x->d.p, s));
     if (g_dict.built_for) launch_spmv<0>(A, x->d.p, y->d.p, nullptr, nullptr, nullptr, s);

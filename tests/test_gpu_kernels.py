@@ -745,6 +745,54 @@ def test_row_dictionary_product_bits(gpu, dims, mass):
         xb.set(nxt)
 
 
+def test_block_row_dictionary_product_bits_and_the_amg_solve(gpu):
+    """Vector P1 space on a uniform box (round 4): the 3 x 3 block rows of the elasticity operator repeat (33 classes at any size;
+    the elasticity kernel snaps its edge vectors like the scalar ones) and the products of fs_amg_solve - four per V-cycle on the
+    fine level, one per CG iteration - run from class numbers + class rows (k_dict_spmv3).  fs_spmv_dictionary = fs_spmv bit
+    for bit over a chain of dependent vectors; the AMG-PCG solve with and without it: same iteration count, same solution."""
+    nx, ny, nz = 70, 46, 46                      # 156 839 nodes: above the size from which the block form is used
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (2.0, 1.0, 1.0))
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(1.0, 1.5))
+    nodes = np.arange((nx + 1) * (ny + 1) * (nz + 1))
+    left = nodes[nodes % (nx + 1) == 0]
+    dofs = (left[:, None] * 3 + np.arange(3)).ravel().astype(np.int32)
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, vector_value=(0.0, 0.0, -1.0))
+    A.apply_dirichlet(b, dofs, 0.0, True)
+    rng = np.random.default_rng(9)
+    xa, xb = gpu.DeviceVector(V.n_local), gpu.DeviceVector(V.n_local)
+    ya, yb = gpu.DeviceVector(V.n_owned), gpu.DeviceVector(V.n_owned)
+    x0 = rng.standard_normal(V.n_local)
+    xa.set(x0)
+    xb.set(x0)
+    for it in range(6):
+        nc = A.spmv_dictionary(xa, ya)
+        assert 0 < nc <= 64
+        A.spmv(xb, yb)
+        a, bb = ya.get(), yb.get()
+        assert np.array_equal(a, bb), (it, np.abs(a - bb).max())
+        nxt = a / np.abs(a).max()
+        xa.set(nxt)
+        xb.set(nxt)
+    runs = []
+    try:
+        for on in (1, 0):
+            gpu.set_option("row_dictionary", on)
+            amg = gpu.AMG(A, nullspace="rigid_body")
+            x = gpu.DeviceVector(V.n_local)
+            st = amg.solve(b, x, rtol=1e-9)
+            runs.append((st, x.get()[:V.n_owned].copy()))
+            amg.close()
+    finally:
+        gpu.set_option("row_dictionary", 1)
+    (s1, x1), (s0, x0_) = runs
+    assert s1["converged"] == 1 and s0["converged"] == 1 and s1["iterations"] == s0["iterations"]
+    assert s1["row_classes"] > 0 and s0["row_classes"] == 0
+    assert np.abs(x1 - x0_).max() <= 1e-10 * np.abs(x0_).max()
+
+
 def test_row_dictionary_state_does_not_outlive_its_call(gpu):
     """the class table is keyed on (value pointer, matrix, space) and dropped when the solve returns - a solve,
     a trim of the pool, then ANOTHER space of the same row count whose arrays land on the freed addresses multiplies through the
