@@ -346,9 +346,7 @@ class ScalarTransportSolver(SolverBase):
                 if not isinstance(cap, numbers.Number):
                     raise SolverError("IP stabilisation needs a constant capacity")
                 ip_coef = float(ads['alpha']) * float(cap)
-            elif method == 'SPUG':      # the reference's spelling; its SPUG_method == 2 variant (:259-270)
-                if self.function_space.degree() != 1:
-                    raise SolverError("SUPG stabilisation is built for P1 spaces")
+            elif method == 'SPUG':      # the reference's spelling; its SPUG_method == 2 variant (:259-270), P1 and P2
                 supg_pe = float(ads['Pe'])
                 if not supg_pe > 0.0:
                     raise SolverError("advection_settings['Pe'] must be positive")

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
     coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order, const box_snap bx,
-    coef_dev ac = coef_dev(), double ascale = 0.0) {
+    coef_dev ac = coef_dev(), double ascale = 0.0, double supg_pe = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -497,6 +497,31 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
             double row[10];
 #pragma unroll
             for (int b = 0; b < 10; ++b) row[b] = 0.0;
+            // SUPG (supg_pe > 0, ScalarTransportSolver.py:259-270): this row's test function is q_a + tau (v . grad q_a) in every
+            // term; its gradient is grad q_a + tau H_a v with the constant Hessian H_a of the quadratic q_a (vertex i:
+            // 4 g_i g_i^T, edge ij: 4 (g_i g_j^T + g_j g_i^T)), v and tau constant on the cell
+            double vx = 0.0, vy = 0.0, vz = 0.0, tau = 0.0, hv[3] = {0.0, 0.0, 0.0};
+            if (ADV && ac.mode != FS_COEF_NONE) {
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; vz = ac.tensor[2]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; vz = ac.data[3 * (int64_t)c + 2]; }
+                if (supg_pe > 0.0) {
+                    tau = supg_tau(xyz4, vv, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    double gv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[i] = t.g[i][0] * vx + t.g[i][1] * vy + t.g[i][2] * vz;
+                    const int hi[6] = {2, 1, 1, 0, 0, 0}, hj[6] = {3, 3, 2, 3, 2, 1};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (b == a)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) hv[d] = 4.0 * tau * gv[b] * t.g[b][d];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        if (4 + e == a)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) hv[d] = 4.0 * tau * (gv[hj[e]] * t.g[hi[e]][d] + gv[hi[e]] * t.g[hj[e]][d]);
+                }
+            }
             if (ADV && kc.mode == FS_COEF_CELL_QP) {      // (the non-symmetric instantiation also carries the rarely used modes)
                 for (int qp = 0; qp < 14; ++qp) {
                     const double lam[4] = {FS_TET14_QP[qp][0], FS_TET14_QP[qp][1], FS_TET14_QP[qp][2], FS_TET14_QP[qp][3]};
@@ -505,7 +530,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
                     double ga[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                     for (int b = 0; b < 10; ++b)
-                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; ga[2] = gp[b][2]; }
+                        if (b == a) { ga[0] = gp[b][0] + hv[0]; ga[1] = gp[b][1] + hv[1]; ga[2] = gp[b][2] + hv[2]; }
                     const double w = FS_TET14_QW[qp] * vol * kc.data[14 * (int64_t)c + qp];
 #pragma unroll
                     for (int b = 0; b < 10; ++b) row[b] += w * (ga[0] * gp[b][0] + ga[1] * gp[b][1] + ga[2] * gp[b][2]);
@@ -521,6 +546,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
 #pragma unroll                                         // indexing the register array dynamically
                     for (int b = 0; b < 10; ++b)
                         if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; ga[2] = gp[b][2]; }
+                    if (ADV) { ga[0] += hv[0]; ga[1] += hv[1]; ga[2] += hv[2]; }
 #pragma unroll
                     for (int b = 0; b < 10; ++b) row[b] += 0.25 * (ga[0] * gp[b][0] + ga[1] * gp[b][1] + ga[2] * gp[b][2]);
                 }
@@ -534,25 +560,27 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
                 for (int b = 0; b < 10; ++b) row[b] += mm * FS_P2_MASS420[a][b];
             }
             if (ADV && ac.mode != FS_COEF_NONE) {
-                double vx, vy, vz;
-                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; vz = ac.tensor[2]; }
-                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; vz = ac.data[3 * (int64_t)c + 2]; }
+                const double msupg = (tau != 0.0 && mc.mode != FS_COEF_NONE) ? tau * (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) : 0.0;
                 for (int qp = 0; qp < 5; ++qp) {
                     const double lam[4] = {FS_TET5_QP[qp][0], FS_TET5_QP[qp][1], FS_TET5_QP[qp][2], FS_TET5_QP[qp][3]};
                     double gp[10][3];
                     p2_basis_grads(t, lam, gp);
-                    // value of this row's basis function: vertex lambda (2 lambda - 1), edge 4 lambda_i lambda_j (UFC edges)
+                    // values of the basis functions: vertex lambda (2 lambda - 1), edge 4 lambda_i lambda_j (UFC edges)
                     const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
-                    double pa = 0.0;
+                    double pb[10];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (b == a) pa = lam[b] * (2.0 * lam[b] - 1.0);
+                    for (int b = 0; b < 4; ++b) pb[b] = lam[b] * (2.0 * lam[b] - 1.0);
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
-                        if (4 + e == a) pa = 4.0 * lam[ei[e]] * lam[ej[e]];
-                    const double w = ascale * FS_TET5_QW[qp] * vol * pa;
+                    for (int e = 0; e < 6; ++e) pb[4 + e] = 4.0 * lam[ei[e]] * lam[ej[e]];
+                    double pa = 0.0, va = 0.0;      // this row's q_a and v . grad q_a at the point
 #pragma unroll
-                    for (int b = 0; b < 10; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1] + vz * gp[b][2]);
+                    for (int b = 0; b < 10; ++b)
+                        if (b == a) { pa = pb[b]; va = vx * gp[b][0] + vy * gp[b][1] + vz * gp[b][2]; }
+                    const double wq = FS_TET5_QW[qp] * vol;
+                    const double w = ascale * wq * (pa + tau * va);
+                    const double wm = msupg * wq * va;          // mass term against tau (v . grad q_a): cubic, this rule is exact
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1] + vz * gp[b][2]) + wm * pb[b];
                 }
             }
 #pragma unroll
@@ -608,7 +636,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t 
                                                                         const int32_t* __restrict__ cell_dofs,
                                                                         const int32_t* __restrict__ cells,
                                                                         const double* __restrict__ xyz4, coef_dev f,
-                                                                        double* __restrict__ b) {
+                                                                        double* __restrict__ b, coef_dev sv = coef_dev(),
+                                                                        double supg_pe = 0.0) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -630,7 +659,18 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t 
                 for (int k = 0; k < 10; ++k) m += FS_P2_MASS420[a][k] * f.data[cell_dofs[(int64_t)c * 10 + k]];
                 acc += m * vol * (1.0 / 420.0);
             } else {
-                acc += (a < 4 ? -0.05 : 0.2) * (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
+                const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
+                acc += (a < 4 ? -0.05 : 0.2) * ff;
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE && a >= 4) {
+                    // + int S tau (v . grad q_a) dx: the mean gradient of a vertex function vanishes, of the edge function ij it is g_i + g_j
+                    double vx, vy, vz;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; vz = sv.tensor[2]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; vz = sv.data[3 * (int64_t)c + 2]; }
+                    const double tau = supg_tau(xyz4, vv, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
+                    const int i = ei[a - 4], jj = ej[a - 4];
+                    acc += ff * tau * ((t.g[i][0] + t.g[jj][0]) * vx + (t.g[i][1] + t.g[jj][1]) * vy + (t.g[i][2] + t.g[jj][2]) * vz);
+                }
             }
         }
         if (row < n_rows) b[row] += acc;
@@ -1275,7 +1315,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
-    coef_dev kc, coef_dev mc, double* __restrict__ val, coef_dev ac = coef_dev(), double ascale = 0.0) {
+    coef_dev kc, coef_dev mc, double* __restrict__ val, coef_dev ac = coef_dev(), double ascale = 0.0, double supg_pe = 0.0) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -1297,6 +1337,26 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
             const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
             const tri_geom t = tri_geometry2(xyz4, c4.x, c4.y, c4.z);
             double row[6] = {0, 0, 0, 0, 0, 0};
+            // SUPG: test function q_a + tau (v . grad q_a), its gradient grad q_a + tau H_a v (as in the kernel for tetrahedra)
+            double vx = 0.0, vy = 0.0, tau = 0.0, hv[2] = {0.0, 0.0};
+            if (ac.mode != FS_COEF_NONE) {
+                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; }
+                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; }
+                if (supg_pe > 0.0) {
+                    tau = supg_tau_tri(xyz4, c4.x, c4.y, c4.z, t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                    const double gv[3] = {t.g[0][0] * vx + t.g[0][1] * vy, t.g[1][0] * vx + t.g[1][1] * vy, t.g[2][0] * vx + t.g[2][1] * vy};
+                    const int hi[3] = {1, 0, 0}, hj[3] = {2, 2, 1};
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        if (b == a) { hv[0] = 4.0 * tau * gv[b] * t.g[b][0]; hv[1] = 4.0 * tau * gv[b] * t.g[b][1]; }
+#pragma unroll
+                    for (int e2 = 0; e2 < 3; ++e2)
+                        if (3 + e2 == a) {
+                            hv[0] = 4.0 * tau * (gv[hj[e2]] * t.g[hi[e2]][0] + gv[hi[e2]] * t.g[hj[e2]][0]);
+                            hv[1] = 4.0 * tau * (gv[hj[e2]] * t.g[hi[e2]][1] + gv[hi[e2]] * t.g[hj[e2]][1]);
+                        }
+                }
+            }
             if (kc.mode == FS_COEF_CELL_QP) {      // k at the 6 points of the degree-4 rule (data[c][14], the first 6 used)
                 const double TQ[6][3] = {{0.108103018168070, 0.445948490915965, 0.445948490915965}, {0.445948490915965, 0.108103018168070, 0.445948490915965},
                                          {0.445948490915965, 0.445948490915965, 0.108103018168070}, {0.816847572980459, 0.091576213509771, 0.091576213509771},
@@ -1309,7 +1369,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
                     double ga[2] = {0.0, 0.0};
 #pragma unroll
                     for (int b = 0; b < 6; ++b)
-                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; }
+                        if (b == a) { ga[0] = gp[b][0] + hv[0]; ga[1] = gp[b][1] + hv[1]; }
                     const double w = TW[qp] * t.area * kc.data[14 * (int64_t)c + qp];
 #pragma unroll
                     for (int b = 0; b < 6; ++b) row[b] += w * (ga[0] * gp[b][0] + ga[1] * gp[b][1]);
@@ -1324,7 +1384,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
                     double ga[2] = {0.0, 0.0};
 #pragma unroll
                     for (int b = 0; b < 6; ++b)
-                        if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; }
+                        if (b == a) { ga[0] = gp[b][0] + hv[0]; ga[1] = gp[b][1] + hv[1]; }
 #pragma unroll
                     for (int b = 0; b < 6; ++b) row[b] += (1.0 / 3.0) * (ga[0] * gp[b][0] + ga[1] * gp[b][1]);
                 }
@@ -1337,25 +1397,27 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_scalar_gather(
 #pragma unroll
                 for (int b = 0; b < 6; ++b) row[b] += mm * FS_P2_TRI_UFC_MASS180[a][b];
             }
-            if (ac.mode != FS_COEF_NONE) {      // + scale int phi_a (v . grad phi_b) dx, constant or per-cell velocity
-                double vx, vy;
-                if (ac.mode == FS_COEF_CONST) { vx = ac.tensor[0]; vy = ac.tensor[1]; }
-                else { vx = ac.data[3 * (int64_t)c]; vy = ac.data[3 * (int64_t)c + 1]; }
+            if (ac.mode != FS_COEF_NONE) {      // + scale int q_a (v . grad phi_b) dx, constant or per-cell velocity
+                const double msupg = (tau != 0.0 && mc.mode != FS_COEF_NONE) ? tau * (mc.mode == FS_COEF_CONST ? mc.value : mc.data[c]) : 0.0;
                 for (int qp = 0; qp < 4; ++qp) {
                     const double lam[3] = {FS_TRI4_QP[qp][0], FS_TRI4_QP[qp][1], FS_TRI4_QP[qp][2]};
                     double gp[6][2];
                     p2tri_basis_grads(t, lam, gp);
                     const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
-                    double pa = 0.0;
+                    double pb[6];
 #pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        if (b == a) pa = lam[b] * (2.0 * lam[b] - 1.0);
+                    for (int b = 0; b < 3; ++b) pb[b] = lam[b] * (2.0 * lam[b] - 1.0);
 #pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (3 + e == a) pa = 4.0 * lam[ei[e]] * lam[ej[e]];
-                    const double w = ascale * FS_TRI4_QW[qp] * t.area * pa;
+                    for (int e2 = 0; e2 < 3; ++e2) pb[3 + e2] = 4.0 * lam[ei[e2]] * lam[ej[e2]];
+                    double pa = 0.0, va = 0.0;
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1]);
+                    for (int b = 0; b < 6; ++b)
+                        if (b == a) { pa = pb[b]; va = vx * gp[b][0] + vy * gp[b][1]; }
+                    const double wq = FS_TRI4_QW[qp] * t.area;
+                    const double w = ascale * wq * (pa + tau * va);
+                    const double wm = msupg * wq * va;      // SUPG part of the mass term (cubic: this rule is exact)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1]) + wm * pb[b];
                 }
             }
 #pragma unroll
@@ -1379,7 +1441,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_source_gather(int64
                                                                            const int32_t* __restrict__ cell_dofs,
                                                                            const int32_t* __restrict__ cells,
                                                                            const double* __restrict__ xyz4, coef_dev f,
-                                                                           double* __restrict__ b) {
+                                                                           double* __restrict__ b, coef_dev sv = coef_dev(),
+                                                                           double supg_pe = 0.0) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1399,7 +1462,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_source_gather(int64
                 for (int k = 0; k < 6; ++k) m += FS_P2_TRI_UFC_MASS180[a][k] * f.data[cell_dofs[(int64_t)c * 6 + k]];
                 acc += m * t.area * (1.0 / 180.0);
             } else {
-                acc += (a < 3 ? 0.0 : 1.0 / 3.0) * (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.area;
+                const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.area;
+                acc += (a < 3 ? 0.0 : 1.0 / 3.0) * ff;
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {
+                    // + int S tau (v . grad q_a) dx: the mean gradient over a triangle (lambda = 1/3) is g_a / 3 for a vertex
+                    // function, 4/3 (g_i + g_j) for the edge function ij
+                    double vx, vy;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; }
+                    const double tau = supg_tau_tri(xyz4, c4.x, c4.y, c4.z, t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                    const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
+                    double gx, gy;
+                    if (a < 3) { gx = t.g[a][0] * (1.0 / 3.0); gy = t.g[a][1] * (1.0 / 3.0); }
+                    else {
+                        const int i = ei[a - 3], jj = ej[a - 3];
+                        gx = (4.0 / 3.0) * (t.g[i][0] + t.g[jj][0]);
+                        gy = (4.0 / 3.0) * (t.g[i][1] + t.g[jj][1]);
+                    }
+                    acc += ff * tau * (gx * vx + gy * vy);
+                }
             }
         }
         if (row < n_rows) b[row] += acc;
@@ -2331,8 +2412,8 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         dbuf<double> astore4;
         coef_dev ac4;
         FS_CHECK(make_coef(form->advection, 3 * m->nc, astore4, &ac4, "fs_assemble_matrix(advection)"));
-        FS_REQUIRE((ac4.mode == FS_COEF_NONE || ac4.mode == FS_COEF_CONST || ac4.mode == FS_COEF_CELL) && !(form->supg_pe > 0.0),
-                   "fs_assemble_matrix: CG2 advection takes a constant or per-cell velocity, without SUPG");
+        FS_REQUIRE(ac4.mode == FS_COEF_NONE || ac4.mode == FS_COEF_CONST || ac4.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: CG2 advection (and its SUPG test function) takes a constant or per-cell velocity");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
         FS_REQUIRE(kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL || kc.mode == FS_COEF_CELL_QP,
                    "fs_assemble_matrix: CG2 stiffness coefficient must be constant, per cell or per quadrature point");
@@ -2342,9 +2423,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (add)
-            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale);
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale, form->supg_pe);
         else
-            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale);
+            hipLaunchKernelGGL(k_assemble_p2tri_scalar_gather<false>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, ac4, form->advection_scale, form->supg_pe);
     } else if (m->tdim == 2) {
         FS_REQUIRE(A->bs == 1 && sp->inc_cell.p, "fs_assemble_matrix: triangular meshes carry scalar CG1 spaces");
         FS_CHECK(make_coef(form->stiffness, m->nc, kstore, &kc, "fs_assemble_matrix(stiffness)"));
@@ -2372,8 +2453,8 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         dbuf<double> astore3;
         coef_dev ac3;
         FS_CHECK(make_coef(form->advection, 3 * m->nc, astore3, &ac3, "fs_assemble_matrix(advection)"));
-        FS_REQUIRE((ac3.mode == FS_COEF_NONE || ac3.mode == FS_COEF_CONST || ac3.mode == FS_COEF_CELL) && !(form->supg_pe > 0.0),
-                   "fs_assemble_matrix: CG2 advection takes a constant or per-cell velocity, without SUPG");
+        FS_REQUIRE(ac3.mode == FS_COEF_NONE || ac3.mode == FS_COEF_CONST || ac3.mode == FS_COEF_CELL,
+                   "fs_assemble_matrix: CG2 advection (and its SUPG test function) takes a constant or per-cell velocity");
         const int bd = (int64_t)sp->max_row * FS_BLOCK * 8 <= 64 * 1024 ? FS_BLOCK : 64;
         const size_t lds = (size_t)sp->max_row * bd * sizeof(double);
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
@@ -2381,9 +2462,9 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
         if (ac3.mode != FS_COEF_NONE || kc.mode == FS_COEF_CELL_QP) {
             if (add)
-                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale);
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale, form->supg_pe);
             else
-                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale);
+                hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale, form->supg_pe);
         } else if (add)
             hipLaunchKernelGGL(k_assemble_p2_scalar_gather<true>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m));
         else
@@ -2977,10 +3058,15 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         return FS_OK;
     }
     if (m->tdim == 2 && space->degree == 2) {
-        FS_REQUIRE(f.mode != FS_COEF_TENSOR && !(form->supg_pe > 0.0) && space->inc_cell.p, "fs_assemble_vector: unsupported option on a CG2 space on triangles");
+        FS_REQUIRE(f.mode != FS_COEF_TENSOR && space->inc_cell.p, "fs_assemble_vector: unsupported option on a CG2 space on triangles");
+        dbuf<double> sstore4;
+        coef_dev sv4;
+        FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore4, &sv4, "fs_assemble_vector(supg_velocity)"));
+        FS_REQUIRE(!(form->supg_pe > 0.0) || sv4.mode == FS_COEF_NONE || ((sv4.mode == FS_COEF_CONST || sv4.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL),
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
         hipLaunchKernelGGL(k_assemble_p2tri_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                            space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
-                           m->xyz.p, f, b->d.p);
+                           m->xyz.p, f, b->d.p, sv4, form->supg_pe);
         FS_KERNEL_CHECK();
         FS_HIP(hipStreamSynchronize(s));
         return FS_OK;
@@ -3014,10 +3100,16 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     if (space->degree == 2) {
         FS_REQUIRE(space->ncomp == 1, "fs_assemble_vector: %d-component CG2 node blocks have no load-vector kernel", space->ncomp);
         FS_REQUIRE(f.mode != FS_COEF_TENSOR, "fs_assemble_vector: tensor coefficient is meaningless here");
-        if (space->ncomp == 1 && space->inc_cell.p && !getenv("FS_SOURCE_ATOMIC"))
+        dbuf<double> sstore3;
+        coef_dev sv3;
+        FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore3, &sv3, "fs_assemble_vector(supg_velocity)"));
+        const bool supg3 = form->supg_pe > 0.0 && sv3.mode != FS_COEF_NONE;
+        FS_REQUIRE(!supg3 || ((sv3.mode == FS_COEF_CONST || sv3.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL && space->inc_cell.p),
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
+        if (space->ncomp == 1 && space->inc_cell.p && (supg3 || !getenv("FS_SOURCE_ATOMIC")))
             hipLaunchKernelGGL(k_assemble_p2_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                                space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
-                               m->xyz.p, f, b->d.p);
+                               m->xyz.p, f, b->d.p, sv3, form->supg_pe);
         else
             hipLaunchKernelGGL(k_assemble_p2_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, space->cell_dofs, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p);
         FS_KERNEL_CHECK();
@@ -3132,12 +3224,129 @@ __global__ void k_facet_supg_tri(int64_t nf, const int32_t* __restrict__ facet_c
     }
 }
 
+// CG2 spaces: thread per (facet, cell dof a).  Load: g |F| tau (v . grad q_a) at the facet centroid (the gradient is linear);
+// Robin matrix: h tau int_F phi_b (v . grad q_a) ds over the six facet dofs b, cubic on the facet: 6-point degree-4 rule
+__global__ void k_facet_supg_p2(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                                const double* __restrict__ g, const double* __restrict__ h, coef_dev vel, double pe,
+                                const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, const double* __restrict__ xyz4,
+                                int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                double* __restrict__ val, double* __restrict__ b, int* __restrict__ err) {
+    const double TQ[6][3] = {{0.108103018168070, 0.445948490915965, 0.445948490915965}, {0.445948490915965, 0.108103018168070, 0.445948490915965},
+                             {0.445948490915965, 0.445948490915965, 0.108103018168070}, {0.816847572980459, 0.091576213509771, 0.091576213509771},
+                             {0.091576213509771, 0.816847572980459, 0.091576213509771}, {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+    const double TW[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011, 0.109951743655322, 0.109951743655322, 0.109951743655322};
+    const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 10; t += stride) {
+        const int64_t f = t / 10;
+        const int a = (int)(t - 10 * f);
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int32_t row = cell_dofs[c * 10 + a];
+        if (row >= n_rows) continue;
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const tet_geom tg = tet_geometry(xyz4, v);
+        double vx, vy, vz;
+        if (vel.mode == FS_COEF_CONST) { vx = vel.tensor[0]; vy = vel.tensor[1]; vz = vel.tensor[2]; }
+        else { vx = vel.data[3 * c]; vy = vel.data[3 * c + 1]; vz = vel.data[3 * c + 2]; }
+        const double tau = supg_tau(xyz4, v, tg.adet, sqrt(vx * vx + vy * vy + vz * vz), pe);
+        const double gn = sqrt(tg.g[o][0] * tg.g[o][0] + tg.g[o][1] * tg.g[o][1] + tg.g[o][2] * tg.g[o][2]);
+        const double area = 0.5 * tg.adet * gn;          // 3 V |grad lambda_o|
+        if (b && g) {
+            double lam[4];
+            for (int i = 0; i < 4; ++i) lam[i] = i == o ? 0.0 : 1.0 / 3.0;
+            double gp[10][3];
+            p2_basis_grads(tg, lam, gp);
+            atomicAdd(&b[row], g[f] * area * tau * (vx * gp[a][0] + vy * gp[a][1] + vz * gp[a][2]));
+        }
+        if (val && h) {
+            double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int qp = 0; qp < 6; ++qp) {
+                double lam[4];
+                for (int i = 0, k = 0; i < 4; ++i) lam[i] = i == o ? 0.0 : TQ[qp][k++];
+                double gp[10][3];
+                p2_basis_grads(tg, lam, gp);
+                const double w = TW[qp] * area * tau * (vx * gp[a][0] + vy * gp[a][1] + vz * gp[a][2]);
+                for (int bb = 0; bb < 4; ++bb) acc[bb] += w * lam[bb] * (2.0 * lam[bb] - 1.0);
+                for (int e = 0; e < 6; ++e) acc[4 + e] += w * 4.0 * lam[ei[e]] * lam[ej[e]];
+            }
+            const int64_t sp0 = slice_ptr[row >> 6];
+            const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            const int64_t base = sp0 + (row & 63);
+            for (int bb = 0; bb < 10; ++bb) {
+                if (bb < 4 ? bb == o : (ei[bb - 4] == o || ej[bb - 4] == o)) continue;      // functions that vanish on the facet
+                const int k = fs_find_pos_local(sell_col, base, width, cell_dofs[c * 10 + bb]);
+                if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], h[f] * acc[bb]);
+                else atomicAdd(err, 1);
+            }
+        }
+    }
+}
+
+// CG2 on triangles: thread per (boundary edge, cell dof a); 3-point Gauss rule along the edge
+__global__ void k_facet_supg_p2tri(int64_t nf, const int32_t* __restrict__ facet_cell, const int32_t* __restrict__ facet_opp,
+                                   const double* __restrict__ g, const double* __restrict__ h, coef_dev vel, double pe,
+                                   const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, const double* __restrict__ xyz4,
+                                   int64_t n_rows, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ sell_col,
+                                   double* __restrict__ val, double* __restrict__ b, int* __restrict__ err) {
+    const double GQ[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+    const double GW[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+    const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nf * 6; t += stride) {
+        const int64_t f = t / 6;
+        const int a = (int)(t - 6 * f);
+        const int64_t c = facet_cell[f];
+        const int o = facet_opp[f];
+        const int32_t row = cell_dofs[c * 6 + a];
+        if (row >= n_rows) continue;
+        const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
+        const tri_geom tg = tri_geometry2(xyz4, v4.x, v4.y, v4.z);
+        double vx, vy;
+        if (vel.mode == FS_COEF_CONST) { vx = vel.tensor[0]; vy = vel.tensor[1]; }
+        else { vx = vel.data[3 * c]; vy = vel.data[3 * c + 1]; }
+        const double tau = supg_tau_tri(xyz4, v4.x, v4.y, v4.z, tg.area, sqrt(vx * vx + vy * vy), pe);
+        const double len = 2.0 * tg.area * sqrt(tg.g[o][0] * tg.g[o][0] + tg.g[o][1] * tg.g[o][1]);
+        if (b && g) {
+            double lam[3];
+            for (int i = 0; i < 3; ++i) lam[i] = i == o ? 0.0 : 0.5;
+            double gp[6][2];
+            p2tri_basis_grads(tg, lam, gp);
+            atomicAdd(&b[row], g[f] * len * tau * (vx * gp[a][0] + vy * gp[a][1]));
+        }
+        if (val && h) {
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int qp = 0; qp < 3; ++qp) {
+                double lam[3];
+                for (int i = 0, k = 0; i < 3; ++i) lam[i] = i == o ? 0.0 : (k++ == 0 ? GQ[qp] : 1.0 - GQ[qp]);
+                double gp[6][2];
+                p2tri_basis_grads(tg, lam, gp);
+                const double w = GW[qp] * len * tau * (vx * gp[a][0] + vy * gp[a][1]);
+                for (int bb = 0; bb < 3; ++bb) acc[bb] += w * lam[bb] * (2.0 * lam[bb] - 1.0);
+                for (int e = 0; e < 3; ++e) acc[3 + e] += w * 4.0 * lam[ei[e]] * lam[ej[e]];
+            }
+            const int64_t sp0 = slice_ptr[row >> 6];
+            const int width = (int)((slice_ptr[(row >> 6) + 1] - sp0) >> 6);
+            const int64_t base = sp0 + (row & 63);
+            for (int bb = 0; bb < 6; ++bb) {
+                if (bb < 3 ? bb == o : (ei[bb - 3] == o || ej[bb - 3] == o)) continue;
+                const int k = fs_find_pos_local(sell_col, base, width, cell_dofs[c * 6 + bb]);
+                if (k >= 0) atomicAdd(&val[base + (int64_t)k * FS_SLICE], h[f] * acc[bb]);
+                else atomicAdd(err, 1);
+            }
+        }
+    }
+}
+
 extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector_t b, int64_t n_facets, const int32_t* facet_cell,
                                       const int32_t* facet_opposite, const double* g, const double* h, const fs_coef* velocity,
                                       double supg_pe) {
     FS_CHECK(fs_require_init());
     FS_REQUIRE(space && velocity && supg_pe > 0.0 && n_facets >= 0, "fs_assemble_facet_supg: bad arguments");
-    FS_REQUIRE(space->degree == 1 && space->ncomp == 1, "fs_assemble_facet_supg: scalar CG1 spaces only");
+    FS_REQUIRE(space->ncomp == 1 && (space->degree == 1 || space->cell_dofs), "fs_assemble_facet_supg: scalar CG1 / CG2 spaces only");
     FS_REQUIRE((!A || A->space == space) && (!b || b->d.n >= space->n_dofs_owned), "fs_assemble_facet_supg: operand mismatch");
     if (n_facets == 0 || ((!A || !h) && (!b || !g))) return FS_OK;
     fs_mesh_s* m = space->mesh;
@@ -3156,7 +3365,15 @@ extern "C" int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector
     FS_CHECK(dop.upload(facet_opposite, n_facets, s));
     if (g) { FS_CHECK(dg.alloc(n_facets)); FS_CHECK(dg.upload(g, n_facets, s)); }
     if (h) { FS_CHECK(dh.alloc(n_facets)); FS_CHECK(dh.upload(h, n_facets, s)); }
-    if (m->tdim == 2)
+    if (space->degree == 2 && m->tdim == 2)
+        hipLaunchKernelGGL(k_facet_supg_p2tri, dim3(fs_grid_for(n_facets * 6)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
+                           h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, space->cell_dofs, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
+                           space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
+    else if (space->degree == 2)
+        hipLaunchKernelGGL(k_facet_supg_p2, dim3(fs_grid_for(n_facets * 10)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
+                           h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, space->cell_dofs, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
+                           space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);
+    else if (m->tdim == 2)
         hipLaunchKernelGGL(k_facet_supg_tri, dim3(fs_grid_for(n_facets * 3)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p, g ? dg.p : (const double*)nullptr,
                            h ? dh.p : (const double*)nullptr, vel, supg_pe, m->cells.p, m->xyz.p, space->n_nodes_owned, space->slice_ptr.p,
                            space->sell_col.p, A ? A->val.p : (double*)nullptr, b ? b->d.p : (double*)nullptr, d_err.p);

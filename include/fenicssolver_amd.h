@@ -229,7 +229,8 @@ typedef struct fs_bilinear_form {
     /* SUPG ("SPUG" in the reference, ScalarTransportSolver.py:259-270): the test function becomes
      * q + tau (v . grad q), tau = 0.5 h / (4/(Pe h) + 2|v|), h = 2 * circumradius of the cell.  supg_pe > 0 adds the
      * tau-part to the advection term (streamline diffusion) and to the mass term; v is the advection velocity
-     * (set advection_scale = 0 to get the mass part only, e.g. for the old-step operator).  CG1 scalar spaces. */
+     * (set advection_scale = 0 to get the mass part only, e.g. for the old-step operator).  CG1 and CG2 scalar spaces; on CG2 the
+     * diffusion term changes too: grad(q + tau v . grad q) = grad q + tau H_q v with the cell-wise constant Hessian of q. */
     double supg_pe;
 } fs_bilinear_form;
 
@@ -273,7 +274,8 @@ int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w, double nu,
  * ScalarTransportSolver.py:296-298 with Tq): for every listed boundary facet (cell behind it, local vertex opposite)
  *   b_a += g_f * area * w_a                      (flux / Neumann / HTC ambient loads; g may be NULL)
  *   A_ab += h_f * (area / 3) * w_a, b on the facet (HTC / Robin matrices; h may be NULL)
- * for all four vertices a of the cell, w_a = tau (v . grad phi_a).  A or b may be NULL. */
+ * for all four vertices a of the cell, w_a = tau (v . grad phi_a).  A or b may be NULL.  CG2 spaces: a runs over all dofs of
+ * the cell, the load takes v . grad q_a at the facet centroid, the matrix  h tau int_F phi_b (v . grad q_a) ds  by quadrature. */
 int fs_assemble_facet_supg(fs_space_t space, fs_matrix_t A, fs_vector_t b, int64_t n_facets, const int32_t* facet_cell,
                            const int32_t* facet_opposite, const double* g, const double* h, const fs_coef* velocity,
                            double supg_pe);

@@ -1668,3 +1668,127 @@ def assemble_p2_interior_penalty(coords, cells, coefficient, n_quad=4):
                 rows.append(a); cols.append(b)
                 vals.append(w0 * sum(wq * J[a] * J[b] for wq, J in zip(qw, Jq)))
     return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+
+
+# ---- SUPG on P2 spaces (ScalarTransportSolver.py:259-270 with fe_degree 2): Tq = q + tau (v . grad q) replaces the test function
+# in EVERY term of the form (:278-311), so grad(Tq) = grad q + tau H_q v with the (cell-wise constant) Hessian H_q of the quadratic
+# q.  Dimension-generic: simplices with nv = 3 or 4 vertices; quadrature of degree 4 (triangles) / 5 (tetrahedra), exact for all
+# integrands below (the highest is the cubic  phi_b (v . grad q_a)).
+def _p2_simplex_tools(coords, cells):
+    from oracle import ns_oracle as nso
+    cells = np.asarray(cells, dtype=np.int64)
+    if cells.shape[1] == 4:
+        detJ, g = p1_geometry(coords, cells)
+        size = np.abs(detJ) / 6.0
+        pts, wq = nso.tet_quadrature(5)
+        shape = nso.p2_shape
+        edges = P2_EDGE_VERTS
+    else:
+        size, g = tri_geometry(coords, cells)
+        pts, wq = _TRI_Q4
+        shape = tri_p2_shape
+        edges = TRI_P2_EDGES
+    return cells, size, g, pts, wq, shape, edges
+
+
+def p2_hessians(g, edges):
+    """H[c,a] = sum_kl d2 phi_a / d lambda_k d lambda_l  g_k g_l^T: vertex i: 4 g_i g_i^T, edge ij: 4 (g_i g_j^T + g_j g_i^T)."""
+    nc, nv, d = g.shape
+    H = np.zeros((nc, nv + len(edges), d, d))
+    for i in range(nv):
+        H[:, i] = 4.0 * np.einsum("ci,cj->cij", g[:, i], g[:, i])
+    for e, (i, j) in enumerate(edges):
+        H[:, nv + e] = 4.0 * (np.einsum("ci,cj->cij", g[:, i], g[:, j]) + np.einsum("ci,cj->cij", g[:, j], g[:, i]))
+    return H
+
+
+def p2_supg_tau(coords, cells, velocity, pe):
+    """(tau [nc], v [nc,d]): tau = 0.5 h / (4/(Pe h) + 2 |v|), h = 2 * Circumradius (:262-266), constant or per-cell velocity."""
+    cells = np.asarray(cells, dtype=np.int64)
+    d = cells.shape[1] - 1
+    v = np.asarray(velocity, dtype=np.float64)[..., :d]
+    if v.ndim == 1:
+        v = np.broadcast_to(v, (len(cells), d))
+    h = 2.0 * tet_circumradius(np.asarray(coords, dtype=np.float64)[:, :d], cells)
+    return 0.5 * h / (4.0 / (pe * h) + 2.0 * np.linalg.norm(v, axis=1)), v
+
+
+def p2_supg_system_local(coords, cells, velocity, pe, stiffness=0.0, advection_scale=0.0, mass_coef=0.0):
+    """Ke[a,b] = int  k grad phi_b . grad(Tq_a) + scale (v . grad phi_b) Tq_a + m phi_b Tq_a  dx,  Tq_a = q_a + tau (v . grad q_a);
+    rows = test functions (k, m constant or per cell).  With pe = None the plain Galerkin matrix (tau = 0)."""
+    cells, size, g, pts, wq, shape, edges = _p2_simplex_tools(coords, cells)
+    nc = len(cells)
+    if pe is None:
+        d = cells.shape[1] - 1
+        v = np.asarray(velocity, dtype=np.float64)[..., :d]
+        v = np.broadcast_to(v, (nc, d)) if v.ndim == 1 else v
+        tau = np.zeros(nc)
+    else:
+        tau, v = p2_supg_tau(coords, cells, velocity, pe)
+    Hv = np.einsum("caij,cj->cai", p2_hessians(g, edges), v)                  # H_a v
+    k = np.broadcast_to(np.asarray(stiffness, dtype=np.float64), (nc,))
+    m = np.broadcast_to(np.asarray(mass_coef, dtype=np.float64), (nc,))
+    nd = cells.shape[1] + len(edges)
+    Ke = np.zeros((nc, nd, nd))
+    for lam, w in zip(pts, wq):
+        phi, dphi = shape(np.asarray(lam))
+        gphi = np.einsum("ak,cki->cai", dphi, g)
+        vg = np.einsum("ci,cai->ca", v, gphi)
+        Tq = phi[None, :] + tau[:, None] * vg                                 # [nc, a]
+        gTq = gphi + tau[:, None, None] * Hv                                  # [nc, a, d]
+        Ke += (w * size * k)[:, None, None] * np.einsum("cai,cbi->cab", gTq, gphi)
+        Ke += (w * size * advection_scale)[:, None, None] * Tq[:, :, None] * vg[:, None, :]
+        Ke += (w * size * m)[:, None, None] * Tq[:, :, None] * phi[None, None, :]
+    return Ke
+
+
+def p2_supg_source_local(coords, cells, velocity, pe, f):
+    """be[a] = int f Tq_a dx for a constant / per-cell source f."""
+    cells, size, g, pts, wq, shape, edges = _p2_simplex_tools(coords, cells)
+    tau, v = p2_supg_tau(coords, cells, velocity, pe)
+    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
+    be = np.zeros((len(cells), cells.shape[1] + len(edges)))
+    for lam, w in zip(pts, wq):
+        phi, dphi = shape(np.asarray(lam))
+        vg = np.einsum("ci,cai->ca", v, np.einsum("ak,cki->cai", dphi, g))
+        be += (w * size * ff)[:, None] * (phi[None, :] + tau[:, None] * vg)
+    return be
+
+
+def p2_supg_facet_terms(coords, cells, cell_dofs, n_dofs, facet_cells, velocity, pe, g=None, h=None):
+    """(dA, db) of the SUPG part tau (v . grad q_a) of the boundary integrals  g Tq ds  and  h T Tq ds  over boundary facets given as
+    (cell, opposite local vertex); a runs over ALL dofs of the cell behind the facet.  Facet quadrature: a Gauss rule along an edge,
+    the degree-4 rule on a triangle (integrands are cubic)."""
+    import scipy.sparse as sp
+    cells, size, gg, _, _, shape, edges = _p2_simplex_tools(coords, cells)
+    tau, v = p2_supg_tau(coords, cells, velocity, pe)
+    nv = cells.shape[1]
+    co = np.asarray(coords, dtype=np.float64)[:, :nv - 1]
+    if nv == 4:
+        fpts, fw = _TRI_Q4
+    else:
+        x, wg = np.polynomial.legendre.leggauss(4)
+        fpts, fw = np.stack([0.5 * (1 - x), 0.5 * (1 + x)], axis=1), 0.5 * wg
+    db = np.zeros(n_dofs)
+    rows, cols, vals = [], [], []
+    fc = np.asarray(facet_cells, dtype=np.int64)
+    for kf, (c, o) in enumerate(fc):
+        others = [i for i in range(nv) if i != o]
+        p = co[cells[c, others]]
+        meas = np.linalg.norm(p[1] - p[0]) if nv == 3 else 0.5 * np.linalg.norm(np.cross(p[1] - p[0], p[2] - p[0]))
+        gk = 0.0 if g is None else float(np.broadcast_to(g, (len(fc),))[kf])
+        hk = 0.0 if h is None else float(np.broadcast_to(h, (len(fc),))[kf])
+        for mu, w in zip(fpts, fw):
+            lam = np.zeros(nv)
+            lam[others] = mu
+            phi, dphi = shape(lam)
+            vg = (dphi @ gg[c]) @ v[c]                                        # v . grad q_a at the point, [nd]
+            wa = w * meas * tau[c] * vg
+            db[cell_dofs[c]] += gk * wa
+            if hk:
+                for a in range(len(phi)):
+                    for bdof in range(len(phi)):
+                        if phi[bdof] != 0.0:
+                            rows.append(cell_dofs[c, a]); cols.append(cell_dofs[c, bdof]); vals.append(hk * wa[a] * phi[bdof])
+    dA = sp.coo_matrix((vals, (rows, cols)), shape=(n_dofs, n_dofs)).tocsr()
+    return dA, db

@@ -727,3 +727,101 @@ def test_p2_temperature_dependent_conductivity_in_2d(gpu):
             break
         Tn = Tn + fo.solve_direct(*fo.apply_dirichlet(K, -r, dofs, 0.0, True))
     assert it < 99 and np.abs(T - Tn).max() <= 1e-6
+
+
+@pytest.mark.parametrize("transient", [False, True])
+def test_p2_supg_stabilised_convection_in_2d(gpu, transient):
+    """'SPUG' with fe_degree 2 on triangles (round 4): the test function q + tau (v . grad q) - with the Hessian of q in the diffusion
+    term - in the operator, the old-step matrix, the body source and the HTC / flux edge integrals, against the oracle."""
+    from fenicssolver_amd.fem import UnitSquareMesh, FunctionSpace, AutoSubDomain, Constant, near
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    mesh = UnitSquareMesh(6, 5)
+    Q = FunctionSpace(mesh, "CG", 2)
+    vel, pe, rho_cp, k = (0.8, -0.5), 5.0, 2.0 * 3.0, 0.6
+    sd = dict(top=AutoSubDomain(lambda x: near(x[1], 1)), bottom=AutoSubDomain(lambda x: near(x[1], 0)), right=AutoSubDomain(lambda x: near(x[0], 1)))
+    bcs = OrderedDict()
+    bcs["hot"] = {'boundary': sd['top'], 'boundary_id': 1, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+    bcs["cold"] = {'boundary': sd['bottom'], 'boundary_id': 2, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    bcs["side"] = {'boundary': sd['right'], 'boundary_id': 3, 'values': {
+        'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
+    settings = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+                'boundary_conditions': bcs, 'body_source': 7.0, 'initial_values': {'temperature': 300},
+                'material': {'density': 2.0, 'specific_heat_capacity': 3.0, 'thermal_conductivity': k},
+                'convective_velocity': Constant(vel), 'advection_settings': {'stabilization_method': 'SPUG', 'Pe': pe},
+                'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 0.3},
+                                    'reference_values': {'temperature': 300},
+                                    'solver_parameters': {'krylov_relative_tolerance': 1e-13, 'maximum_iterations': 20000}},
+                'report_settings': dict(QUIET), 'scalar_name': 'temperature'}
+    solver = ScalarTransportSolver(settings)
+    T = solver.solve().vector().get_local()
+    co, ce = mesh.coordinates(), mesh.cells()
+    nv = len(co)
+    cd, p2_edges = fo.tri_p2_cell_dofs(nv, ce)
+    cdl = cd.astype(np.int64)
+    n = nv + len(p2_edges)
+    edges, cell_edges, cnt = fo.tri_edge_numbering(ce)
+    fm = solver.boundary_facets.array()
+
+    def marked_cells(mid):
+        sel = set(np.nonzero(fm == mid)[0].tolist())
+        return np.array([(c, o) for c in range(len(ce)) for o in range(3) if int(cell_edges[c, o]) in sel]).reshape(-1, 2)
+    n2 = fo.tri_p2_edge_nodes(nv, p2_edges, edges[fm == 2])
+    n3 = fo.tri_p2_edge_nodes(nv, p2_edges, edges[fm == 3])
+    dt = 0.1
+    A = fo.assemble_generic(n, cd, fo.p2_supg_system_local(co, ce, vel, pe, k * (0.5 if transient else 1.0), rho_cp,
+                                                           rho_cp / dt if transient else 0.0)).tocsr()
+    dA2, db2 = fo.p2_supg_facet_terms(co, ce, cdl, n, marked_cells(2), vel, pe, g=100.0 * 300.0, h=100.0)
+    _, db3 = fo.p2_supg_facet_terms(co, ce, cdl, n, marked_cells(3), vel, pe, g=36.0)
+    A = (A + fo.assemble_tri_p2_edge_mass(n, co, n2, 100.0) + dA2).tocsr()
+    load = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, pe, 7.0)) \
+        + fo.assemble_tri_p2_edge_load(n, co, n2, 100.0 * 300.0) + fo.assemble_tri_p2_edge_load(n, co, n3, 36.0) + db2 + db3
+    X = Q.node_coordinates()
+    top = np.nonzero(np.abs(X[:, 1] - 1.0) < 1e-12)[0]
+    if not transient:
+        ref = fo.solve_direct(*fo.apply_dirichlet(A, load, top, 360.0, False))
+    else:
+        B = fo.assemble_generic(n, cd, fo.p2_supg_system_local(co, ce, vel, pe, -0.5 * k, 0.0, rho_cp / dt)).tocsr()
+        ref = np.full(n, 300.0)
+        t = 0.0
+        while t < 0.3:
+            ref = fo.solve_direct(*fo.apply_dirichlet(A, B @ ref + load, top, 360.0, False))
+            t += dt
+    assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
+    if not transient:
+        gal = fo.assemble_generic(n, cd, fo.p2_supg_system_local(co, ce, vel, None, k, rho_cp, 0.0)).tocsr()
+        gload = fo.assemble_generic_vector(n, cd, fo.tri_p2_source_local(co, ce, 7.0)) \
+            + fo.assemble_tri_p2_edge_load(n, co, n2, 3.0e4) + fo.assemble_tri_p2_edge_load(n, co, n3, 36.0)
+        g = fo.solve_direct(*fo.apply_dirichlet((gal + fo.assemble_tri_p2_edge_mass(n, co, n2, 100.0)).tocsr(), gload, top, 360.0, False))
+        assert np.abs(g - ref).max() > 1e-4 * np.abs(ref).max()            # the stabilisation is not a no-op here
+
+
+def test_p2_triangle_supg_kernels_match_oracle(gpu):
+    """The SUPG pieces on CG2 / triangles one by one: operator parts (diffusion with the Hessian term, advection, capacity), the body
+    source (the mean gradient of a VERTEX function does not vanish on a triangle), the edge load and the Robin edge matrix."""
+    rng = np.random.default_rng(4)
+    co, ce = fo.rectangle_mesh((0, 0), (1.0, 0.8), 6, 5)
+    V = gpu.DeviceSpace(gpu.DeviceMesh(co, ce), 1, degree=2)
+    cd, edges = fo.tri_p2_cell_dofs(len(co), ce)
+    n = len(co) + len(edges)
+    A = gpu.DeviceMatrix(V)
+    for vel in (np.array([0.8, -0.5, 0.0]), np.concatenate([rng.uniform(-1, 1, (len(ce), 2)), np.zeros((len(ce), 1))], axis=1)):
+        for kk, mm, sc in ((0.7, 0.0, 0.0), (0.0, 0.0, 2.5), (0.0, 11.0, 0.0), (0.7, 0.1, 2.5)):
+            A.assemble(stiffness=kk if kk else None, mass=mm if mm else None, advection=vel, advection_scale=sc, supg_pe=5.0)
+            ref = fo.assemble_generic(n, cd, fo.p2_supg_system_local(co, ce, vel, 5.0, kk, sc, mm)).tocsr()
+            assert abs(_csr(A) - ref).max() <= 1e-12 * abs(ref).max()
+        b = gpu.DeviceVector(V.n_owned)
+        gpu.assemble_vector(V, b, source=7.0, supg=(vel, 5.0))
+        refb = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 5.0, 7.0))
+        assert np.abs(b.get() - refb).max() <= 1e-13 * np.abs(refb).max() * 10
+        _, cell_edges, cnt = fo.tri_edge_numbering(ce)
+        fc = np.array([(c, o) for c in range(len(ce)) for o in range(3) if cnt[cell_edges[c, o]] == 1]).reshape(-1, 2)
+        A.assemble(stiffness=0.7)
+        base = _csr(A)
+        b = gpu.DeviceVector(V.n_owned)
+        g, h = rng.uniform(1.0, 3.0, len(fc)), rng.uniform(50.0, 100.0, len(fc))
+        gpu.assemble_facet_supg(V, A, b, fc[:, 0], fc[:, 1], vel, 5.0, g=g, h=h)
+        dA, db = fo.p2_supg_facet_terms(co, ce, cd.astype(np.int64), n, fc, vel, 5.0, g, h)
+        assert abs((_csr(A) - base) - dA).max() <= 1e-12 * abs(dA).max()
+        assert np.abs(b.get() - db).max() <= 1e-12 * np.abs(db).max()
