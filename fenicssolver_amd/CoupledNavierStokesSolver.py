@@ -30,8 +30,9 @@ then returns (u, p, T) as the reference's MixedElement([V, Q, Q]) does.
 block layout with a dummy third velocity slot (mixed.py), 6-node element kernel with Radon's 7-point rule, edge integrals of
 the pressure boundaries, the same FGMRES / block preconditioner; G2, ALE, the non-Newtonian law and solving_temperature
 and the stress post-processing (viscous_stress, boundary_traction, drag / lift) included.
-Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh
-velocities, a viscosity depending on the temperature.
+With solving_temperature the non-Newtonian law is nu (1 + 0.1 p/p_ref)(1 - 0.2 T/T_ref) (:199-203): the temperature enters the
+momentum equation, and the step is solved as the fixed point of flow(T) -> T(u) (temperature_law, _solve_coupled_step).
+Raise: velocity 'symmetry' / 'farfield' (the reference's own forms for them are not valid UFL), non-constant mesh velocities.
 """
 from __future__ import annotations
 
@@ -118,13 +119,45 @@ class CoupledNavierStokesSolver(SolverBase):
         reference does (F_static :306 takes up_0, the boundary terms :401 w_current)."""
         if 'Newtonian' in self.material and (not self.material['Newtonian']):
             if self.solving_temperature:
-                raise SolverError("non-Newtonian viscosity with solving_temperature (nu depending on p AND T, :200-204) couples "
-                                  "the temperature back into the momentum equation; not built")
+                return None          # nu(p, T): attached to the device space together with the temperature (temperature_law)
             pref = (getattr(self, 'reference_values', None) or {}).get('pressure')
             if pref is None or not float(pref) > 0.0:
                 raise SolverError("non-Newtonian viscosity needs a positive reference_values['pressure']")
             return (float(pref), 0.1)
         return None
+
+    def temperature_law(self):
+        """None, or ('pT', p_ref, 0.1, T_ref, 0.2): the reference's non-Newtonian law with solving_temperature (:199-203),
+        nu (1 + (p/p_ref) 0.1) (1 - (T/T_ref) 0.2) on the current iterate (u, p, T).  The temperature then enters the momentum
+        equation: the monolithic (u, p, T) system of the reference is solved here as the fixed point of  flow with T frozen ->
+        temperature with the new velocity  (solve_current_step); at convergence both residuals of the reference's form vanish."""
+        if not (self.solving_temperature and 'Newtonian' in self.material and not self.material['Newtonian']):
+            return None
+        rv = getattr(self, 'reference_values', None) or {}
+        pref, tref = rv.get('pressure'), rv.get('temperature')
+        if pref is None or not float(pref) > 0.0 or tref is None or float(tref) == 0.0:
+            raise SolverError("non-Newtonian viscosity with solving_temperature needs reference_values['pressure'] > 0 and "
+                              "a non-zero reference_values['temperature']")
+        return ('pT', float(pref), 0.1, float(tref), 0.2)
+
+    def _attach_temperature_law(self):
+        """Hand the law and the CURRENT temperature (vertex values in the device space's local numbering) to the Taylor-Hood
+        device space: every routine that evaluates nu on it - cell terms, pressure-boundary traction, stress projection - uses it."""
+        from . import backend
+        law = self.temperature_law()
+        if law is None:
+            return
+        Ts = self._temperature_solver()
+        dW = self.function_space.device()
+        ploc = self.function_space.pressure_space().localizer()
+        vals = Ts.w_current.vector()._values()
+        if ploc is not None:
+            vals = ploc.nodes(vals)
+        vec = self.__dict__.get('_law_T')
+        if vec is None or vec.n != len(vals):
+            vec = self._law_T = backend.DeviceVector(len(vals))
+        vec.set(vals)
+        backend.set_viscosity_law(dW, law, vec)
 
     def viscosity(self, current_w=None):
         """The constant kinematic viscosity nu0; a non-Newtonian material multiplies it by (p / p_ref)^0.1 inside the device
@@ -257,6 +290,8 @@ class CoupledNavierStokesSolver(SolverBase):
         return self._Tsolver
 
     def solve_current_step(self):
+        if self.solving_temperature and self.temperature_law() is not None:
+            return self._solve_coupled_step()
         SolverBase.solve_current_step(self)
         if self.solving_temperature:
             Ts = self._temperature_solver()
@@ -265,6 +300,41 @@ class CoupledNavierStokesSolver(SolverBase):
             Ts.solve_current_step()
             self.w_current._temperature = Ts.w_current
             self.result = self.w_current
+
+    def _solve_coupled_step(self):
+        """nu(p, T) (temperature_law): the step's (u, p, T) as the fixed point of  flow(T) -> T(u).  The history rotates once, in
+        the first pass (SolverBase.solve_current_step); later passes re-generate the forms from the current iterates and the same
+        previous step.  Stops when the temperature changes by less than coupling_relative_tolerance (default 1e-10) of its range."""
+        sp = self.solver_settings.get('solver_parameters', {}) or {}
+        tol = float(sp.get('coupling_relative_tolerance', 1e-10))
+        max_it = int(sp.get('coupling_maximum_iterations', 50))
+        Ts = self._temperature_solver()
+        Ts.current_step, Ts.current_time = self.current_step, getattr(self, 'current_time', 0.0)
+        self.coupling_iterations = 0
+        for k in range(max_it):
+            self._attach_temperature_law()
+            if k == 0:
+                SolverBase.solve_current_step(self)
+            else:
+                F, bcs = self.generate_form(self.current_step, self.trial_function, self.test_function, self.w_current, self.w_prev)
+                self.w_current = self.solve_form(F, self.w_current, bcs)
+            T_old = Ts.w_current.vector()._values().copy()
+            Ts.convective_velocity = split(self.w_current)[0]
+            if k == 0:
+                Ts.solve_current_step()
+            else:
+                Ft, bct = Ts.generate_form(Ts.current_step, Ts.trial_function, Ts.test_function, Ts.w_current, Ts.w_prev)
+                Ts.w_current = Ts.solve_form(Ft, Ts.w_current, bct)
+            T_new = Ts.w_current.vector()._values()
+            self.coupling_iterations = k + 1
+            change = np.abs(T_new - T_old).max() / max(np.abs(T_new).max(), 1e-300)
+            if k > 0 and change <= tol:
+                break
+        else:
+            raise SolverError("flow / temperature coupling did not converge in {} passes (last change {:.3e})".format(max_it, change))
+        self._attach_temperature_law()           # post-processing (viscous_stress, drag / lift) sees the converged temperature
+        self.w_current._temperature = Ts.w_current
+        self.result = self.w_current
 
     def temperature(self):
         return self._Tsolver.w_current if self._Tsolver is not None else None

@@ -66,6 +66,11 @@ class fs_ns_form(C.Structure):
                 ("viscosity_pressure_ref", C.c_double), ("viscosity_pressure_exponent", C.c_double)]
 
 
+class fs_viscosity_law(C.Structure):
+    _fields_ = [("kind", C.c_int), ("pressure_ref", C.c_double), ("pressure_exponent", C.c_double), ("pressure_coef", C.c_double),
+                ("temperature_coef", C.c_double), ("temperature_ref", C.c_double), ("temperature", C.c_void_p)]
+
+
 class fs_saddle_opts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_iter", C.c_int), ("restart", C.c_int),
                 ("kinematic_viscosity", C.c_double), ("density", C.c_double), ("inv_dt", C.c_double),
@@ -141,6 +146,7 @@ SIGNATURES = {
     "fs_amg_solve": (C.c_int, [_H, _H, _H, C.POINTER(fs_krylov_opts), C.POINTER(fs_krylov_stats)]),
     "fs_assemble_facet_supg": (C.c_int, [_H, _H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, C.POINTER(fs_coef), C.c_double]),
     "fs_assemble_navier_stokes": (C.c_int, [_H, _H, _H, _H, C.POINTER(fs_ns_form)]),
+    "fs_space_set_viscosity_law": (C.c_int, [_H, C.POINTER(fs_viscosity_law)]),
     "fs_assemble_ns_pressure_boundary": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]),
     "fs_assemble_ns_pressure_boundary_nn": (C.c_int, [_H, _H, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double, _H, C.c_double, C.c_double,
                                                     C.c_int]),

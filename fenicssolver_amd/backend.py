@@ -648,6 +648,24 @@ def assemble_navier_stokes(J, g, w0, w_prev=None, nu=1.0, rho=1.0, inv_dt=0.0, b
             "fs_assemble_navier_stokes")
 
 
+def set_viscosity_law(th_space, law=None, temperature=None):
+    """Attach a non-Newtonian law to a Taylor-Hood space (fs_space_set_viscosity_law): law = None detaches; (p_ref, exponent):
+    nu (p / p_ref)^exponent; ('pT', p_ref, c_p, T_ref, c_T) with temperature = DeviceVector of the CG1 vertex values (local
+    numbering; read at every assembly, so the caller keeps it alive and current): nu (1 + c_p p/p_ref)(1 - c_T T/T_ref)."""
+    f = L.fs_viscosity_law()
+    if law is not None and law[0] == 'pT':
+        if temperature is None:
+            raise BackendError("set_viscosity_law: the 'pT' law needs the temperature vector")
+        f.kind, f.pressure_ref, f.pressure_coef, f.temperature_ref, f.temperature_coef = 2, float(law[1]), float(law[2]), float(law[3]), float(law[4])
+        f.temperature = temperature.h.value
+        th_space._law_temperature = temperature
+    elif law is not None:
+        f.kind, f.pressure_ref, f.pressure_exponent = 1, float(law[0]), float(law[1])
+    L.check(L.load().fs_space_set_viscosity_law(th_space.h, C.byref(f) if law is not None else None), "fs_space_set_viscosity_law")
+    if law is None or law[0] != 'pT':
+        th_space._law_temperature = None
+
+
 def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_value=None, viscosity_law=None, w0=None):
     """J, g += p_b n.v ds - nu ((grad u + grad u^T) n).v ds on the listed boundary facets (value None: traction term only;
     a number, one value per facet, or [n_facets, 3] values at the facet's vertices in the cell's local order).
@@ -663,7 +681,7 @@ def assemble_ns_pressure_boundary(J, g, facet_cell, facet_opposite, nu, facet_va
             fv = np.ascontiguousarray(np.broadcast_to(a, fc.shape))
     pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))
     L.check(L.load().fs_assemble_ns_pressure_boundary_nn(J.h, g.h, len(fc), L.p_i32(fc), L.p_i32(fo_), L.p_f64(fv), float(nu),
-                                                         w0.h if (w0 is not None and viscosity_law is not None) else None, pref, ex, per),
+                                                         w0.h if w0 is not None else None, pref, ex, per),
             "fs_assemble_ns_pressure_boundary")
 
 

@@ -2750,7 +2750,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_von_mises_load_tri(int64_t n_rows,
 __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
                                                                   const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
                                                                   const double* __restrict__ xyz4, const int32_t* __restrict__ w_dofs,
-                                                                  const double* __restrict__ w, double nu0, double nn_pref, double nn_exp, double* __restrict__ b) {
+                                                                  const double* __restrict__ w, double nu0, fs_visc_dev VL, double* __restrict__ b) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -2766,7 +2766,6 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
             const int4 v4 = reinterpret_cast<const int4*>(cells)[c];
             const int32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
             const tet_geom t = tet_geometry(xyz4, v);
-            const double wq = t.adet * (1.0 / 24.0);
             double un[10][3], pv[4];
 #pragma unroll
             for (int n = 0; n < 10; ++n) {
@@ -2774,9 +2773,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
                 un[n][0] = w[d]; un[n][1] = w[d + 1]; un[n][2] = w[d + 2];
                 if (n < 4) pv[n] = w[d + 3];
             }
+            double tv[4] = {0.0, 0.0, 0.0, 0.0};
+            if (VL.kind == 2)
 #pragma unroll
-            for (int qp = 0; qp < 4; ++qp) {
-                const double lam[4] = {FS_P2_QP[qp][0], FS_P2_QP[qp][1], FS_P2_QP[qp][2], FS_P2_QP[qp][3]};
+                for (int n = 0; n < 4; ++n) tv[n] = VL.T[w_dofs[(int64_t)c * 10 + n]];
+            // 4-point rule (exact for the quadratic integrand of a constant nu); nu(p, T) makes it quartic: the 14-point degree-5 rule
+            const int nq = VL.kind == 2 ? 14 : 4;
+            for (int qp = 0; qp < nq; ++qp) {
+                double lam[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lam[i] = VL.kind == 2 ? FS_TET14_QP[qp][i] : FS_P2_QP[qp][i];
+                const double wq = t.adet * (1.0 / 6.0) * (VL.kind == 2 ? FS_TET14_QW[qp] : 0.25);
                 double gp[10][3];
                 p2_basis_grads(t, lam, gp);
                 double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -2787,7 +2794,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
 #pragma unroll
                         for (int k = 0; k < 3; ++k) G[i][k] += un[n][i] * gp[n][k];
                 const double pq = (lam[0] * pv[0] + lam[1] * pv[1]) + (lam[2] * pv[2] + lam[3] * pv[3]);
-                const double nu = nn_pref > 0.0 ? nu0 * pow(pq / nn_pref, nn_exp) : nu0;     // CoupledNavierStokesSolver.viscosity
+                const double nu = fs_viscosity(VL, nu0, pq, (lam[0] * tv[0] + lam[1] * tv[1]) + (lam[2] * tv[2] + lam[3] * tv[3]));     // CoupledNavierStokesSolver.viscosity
                 const double la = wq * (a == 0 ? lam[0] : a == 1 ? lam[1] : a == 2 ? lam[2] : lam[3]);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -2807,7 +2814,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load(int64_t n_rows
 __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load_tri(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ inc_slice_ptr,
                                                                       const int32_t* __restrict__ inc_cell, const int32_t* __restrict__ cells,
                                                                       const double* __restrict__ xyz4, const int32_t* __restrict__ w_dofs,
-                                                                      const double* __restrict__ w, double nu0, double nn_pref, double nn_exp,
+                                                                      const double* __restrict__ w, double nu0, fs_visc_dev VL,
                                                                       double* __restrict__ b) {
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -2830,6 +2837,36 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load_tri(int64_t n_
                 un[n][0] = w[d]; un[n][1] = w[d + 1];
                 if (n < 3) pv[n] = w[d + 3];
             }
+            double tv[3] = {0.0, 0.0, 0.0};
+            if (VL.kind == 2)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) tv[n] = VL.T[w_dofs[(int64_t)c * 6 + n]];
+            if (VL.kind == 2) {      // nu(p, T): quartic integrand, the 6-point degree-4 rule
+                const double TQ[6][3] = {{0.108103018168070, 0.445948490915965, 0.445948490915965}, {0.445948490915965, 0.108103018168070, 0.445948490915965},
+                                         {0.445948490915965, 0.445948490915965, 0.108103018168070}, {0.816847572980459, 0.091576213509771, 0.091576213509771},
+                                         {0.091576213509771, 0.816847572980459, 0.091576213509771}, {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+                const double TW[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011, 0.109951743655322, 0.109951743655322, 0.109951743655322};
+                for (int qp = 0; qp < 6; ++qp) {
+                    const double lam[3] = {TQ[qp][0], TQ[qp][1], TQ[qp][2]};
+                    double gp[6][2];
+                    p2tri_basis_grads(t, lam, gp);
+                    double G[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+                    for (int n = 0; n < 6; ++n)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) G[i][k] += un[n][i] * gp[n][k];
+                    const double pq = lam[0] * pv[0] + lam[1] * pv[1] + lam[2] * pv[2];
+                    const double nu = fs_viscosity(VL, nu0, pq, lam[0] * tv[0] + lam[1] * tv[1] + lam[2] * tv[2]);
+                    const double la = t.area * TW[qp] * (a == 0 ? lam[0] : a == 1 ? lam[1] : lam[2]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) acc[2 * i + k] += la * (nu * (G[i][k] + G[k][i]) - (i == k ? pq : 0.0));
+                }
+                continue;
+            }
 #pragma unroll
             for (int qp = 0; qp < 3; ++qp) {         // mid-point of the edge opposite to vertex qp: lambda_qp = 0, the others 1/2
                 double G[2][2] = {{0, 0}, {0, 0}};
@@ -2843,7 +2880,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_viscous_stress_load_tri(int64_t n_
                         for (int k = 0; k < 2; ++k) G[i][k] += un[n][i] * gn[k];
                 }
                 const double pq = 0.5 * ((qp == 0 ? 0.0 : pv[0]) + (qp == 1 ? 0.0 : pv[1]) + (qp == 2 ? 0.0 : pv[2]));
-                const double nu = nn_pref > 0.0 ? nu0 * pow(pq / nn_pref, nn_exp) : nu0;
+                const double tq = 0.5 * ((qp == 0 ? 0.0 : tv[0]) + (qp == 1 ? 0.0 : tv[1]) + (qp == 2 ? 0.0 : tv[2]));
+                const double nu = fs_viscosity(VL, nu0, pq, tq);
                 const double la = t.area * (1.0 / 3.0) * (a == qp ? 0.0 : 0.5);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -2922,12 +2960,13 @@ extern "C" int fs_assemble_viscous_stress_nn(fs_space_t th_space, fs_vector_t w,
     const int nt = m->tdim * m->tdim;           // tensor components per vertex: 9 (tetrahedra) or 4 (triangles)
     FS_REQUIRE(w->d.n >= th_space->n_dofs_local && b->d.n >= nt * p1_space->n_dofs_owned, "fs_assemble_viscous_stress: vector too short");
     hipStream_t s = fs_rt().stream;
+    const fs_visc_dev VL = fs_space_viscosity(th_space, nn_pref, nn_exp);
     if (m->tdim == 2)
         hipLaunchKernelGGL(k_viscous_stress_load_tri, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
-                           p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, nn_pref, nn_exp, b->d.p);
+                           p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, VL, b->d.p);
     else
     hipLaunchKernelGGL(k_viscous_stress_load, dim3(fs_grid_for(p1_space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, p1_space->n_nodes_owned,
-                       p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, nn_pref, nn_exp, b->d.p);
+                       p1_space->n_slices, p1_space->inc_slice_ptr.p, p1_space->inc_cell.p, m->cells.p, m->xyz.p, th_space->cell_dofs, w->d.p, nu, VL, b->d.p);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

@@ -171,6 +171,22 @@ struct fs_p2p_halo {
     ~fs_p2p_halo() { release(); }
 };
 
+// Non-Newtonian viscosity law of CoupledNavierStokesSolver.viscosity (:194-213) as the kernels take it: kind 0 Newtonian;
+// 1: nu (p / pref)^ex (the branch without a temperature); 2: nu (1 + cp p/pref)(1 - ct T/tref) with the CG1 temperature T
+// (vertex values, local numbering of the Taylor-Hood space = of its mesh) - the solving_temperature branch (:199-203)
+struct fs_visc_dev {
+    int kind = 0;
+    double pref = 0.0, ex = 0.0, cp = 0.0, ct = 0.0, tref = 1.0;
+    const double* T = nullptr;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ double fs_viscosity(const fs_visc_dev& V, double nu, double p, double T) {
+    if (V.kind == 1) return nu * pow(p / V.pref, V.ex);
+    if (V.kind == 2) return (nu * (1.0 + (p / V.pref) * V.cp)) * (1.0 - (T / V.tref) * V.ct);
+    return nu;
+}
+#endif
+
 struct fs_halo_plan {
     bool active = false;
     fs_p2p_halo p2p;
@@ -205,6 +221,7 @@ struct fs_halo_plan {
 struct fs_space_s {
     const uint64_t serial = fs_next_serial();
     fs_mesh_s* mesh = nullptr;
+    fs_visc_dev visc;             // Taylor-Hood spaces: the law attached by fs_space_set_viscosity_law (kind 0: the form's own fields)
     int degree = 1;
     int ncomp = 1;
     // cell -> node table: P1 aliases mesh->cells (4 vertices); P2 holds [nc][10] = 4 vertices + 6 edge
@@ -340,3 +357,6 @@ int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 struct fs_amg_s;
 int fs_amg_apply_dev(fs_amg_s* amg, const double* r, double* z, hipStream_t s);
 int64_t fs_amg_rows(const fs_amg_s* amg);      // scalar rows of the finest level
+
+// fs_saddle.hip: the law a Taylor-Hood space carries, else kind 1 from (p_ref, exponent) > 0, else Newtonian
+fs_visc_dev fs_space_viscosity(const fs_space_s* sp, double legacy_pref, double legacy_exp);

@@ -76,11 +76,8 @@ struct ns_params {
     int convection, newton;
     int g2;            // G2 streamline term (:334-363): 0 off, 1 delta1 = kappa1 h^2 (Re <= 1), 2 delta1 from |a|, h (and dt)
     double g2_kappa;
-    double nn_pref, nn_exp;   // non-Newtonian law (:194-213): nu (p0 / nn_pref)^nn_exp at every quadrature point; nn_pref = 0: off
+    fs_visc_dev V;     // non-Newtonian law (:194-213) evaluated at every quadrature point on the state w0 (fs_common.h); kind 0: off
 };
-__device__ __forceinline__ double ns_viscosity(double nu, double pref, double ex, double p) {
-    return pref > 0.0 ? nu * pow(p / pref, ex) : nu;
-}
 
 // h = 2 * circumradius of the tetrahedron X (UFL's 2*Circumradius(mesh), :343):
 // R = sqrt((aA+bB+cC)(aA+bB-cC)(aA-bB+cC)(-aA+bB+cC)) / (24 V), (a,A) (b,B) (c,C) the opposite edge pairs
@@ -163,15 +160,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns(const double* __restri
             for (int j = 0; j < 4; ++j) blk[i][j] = 0.0;
         double gv[3] = {0.0, 0.0, 0.0};
         const bool do_rhs = b == 0;
-        double P0[4] = {0.0, 0.0, 0.0, 0.0};
-        if (P.nn_pref > 0.0) {
+        double P0[4] = {0.0, 0.0, 0.0, 0.0}, T0[4] = {0.0, 0.0, 0.0, 0.0};
+        if (P.V.kind) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) P0[v] = w0[4 * (int64_t)nd[v] + 3];
+            if (P.V.kind == 2)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) T0[v] = P.V.T[nd[v]];
         }
         for (int q = 0; q < 14; ++q) {
             const double l[4] = {NS_QP[q][0], NS_QP[q][1], NS_QP[q][2], NS_QP[q][3]};
             const double wv = NS_QW[q] * vol;
-            const double nuq = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3]);
+            const double nuq = fs_viscosity(P.V, P.nu, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3],
+                                            l[0] * T0[0] + l[1] * T0[1] + l[2] * T0[2] + l[3] * T0[3]);
             double pa, pb, ga[3], gb[3];
             p2_eval(a, l, gl, &pa, ga);
             p2_eval(b, l, gl, &pb, gb);
@@ -275,7 +276,7 @@ struct ns_cell_lds {
     double U0[10][3];
     double UP[10][3];
     double nuq[14];
-    double P0[4];
+    double P0[4], T0[4];
     int32_t nd[10];
     int32_t pad[2];
 };
@@ -302,7 +303,9 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 L.U0[n][i] = P.convection ? w0[4 * node + i] : 0.0;
                 L.UP[n][i] = has_prev ? wprev[4 * node + i] : 0.0;
             } else if (lane < 34) {
-                L.P0[lane - 30] = P.nn_pref > 0.0 ? w0[4 * (int64_t)cell_dofs[c * 10 + (lane - 30)] + 3] : 0.0;
+                L.P0[lane - 30] = P.V.kind ? w0[4 * (int64_t)cell_dofs[c * 10 + (lane - 30)] + 3] : 0.0;
+            } else if (lane < 38) {
+                L.T0[lane - 34] = P.V.kind == 2 ? P.V.T[cell_dofs[c * 10 + (lane - 34)]] : 0.0;
             }
             double X[4][3];
 #pragma unroll
@@ -342,8 +345,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         if (act) {
             // state, its gradient and the previous velocity at the 14 points
             if (lane < 14)
-                L.nuq[lane] = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, NS_QP[lane][0] * L.P0[0] + NS_QP[lane][1] * L.P0[1] +
-                                                                      NS_QP[lane][2] * L.P0[2] + NS_QP[lane][3] * L.P0[3]);
+                L.nuq[lane] = fs_viscosity(P.V, P.nu, NS_QP[lane][0] * L.P0[0] + NS_QP[lane][1] * L.P0[1] + NS_QP[lane][2] * L.P0[2] + NS_QP[lane][3] * L.P0[3],
+                                           NS_QP[lane][0] * L.T0[0] + NS_QP[lane][1] * L.T0[1] + NS_QP[lane][2] * L.T0[2] + NS_QP[lane][3] * L.T0[3]);
             for (int item = lane; item < 210; item += 64) {
                 double acc = 0.0;
                 if (item < 42) {
@@ -543,10 +546,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_tri(const double* __re
             UP[n][0] = has_prev ? wprev[4 * (int64_t)nd[n]] : 0.0;
             UP[n][1] = has_prev ? wprev[4 * (int64_t)nd[n] + 1] : 0.0;
         }
-        double P0[3] = {0.0, 0.0, 0.0};
-        if (P.nn_pref > 0.0) {
+        double P0[3] = {0.0, 0.0, 0.0}, T0[3] = {0.0, 0.0, 0.0};
+        if (P.V.kind) {
 #pragma unroll
             for (int v = 0; v < 3; ++v) P0[v] = w0[4 * (int64_t)nd[v] + 3];
+            if (P.V.kind == 2)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) T0[v] = P.V.T[nd[v]];
         }
         double blk[4][4];
 #pragma unroll
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_ns_tri(const double* __re
         for (int q = 0; q < 7; ++q) {
             const double l[3] = {NS_TRI_QP[q][0], NS_TRI_QP[q][1], NS_TRI_QP[q][2]};
             const double wv = NS_TRI_QW[q] * area;
-            const double nuq = ns_viscosity(P.nu, P.nn_pref, P.nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2]);
+            const double nuq = fs_viscosity(P.V, P.nu, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2], l[0] * T0[0] + l[1] * T0[1] + l[2] * T0[2]);
             double pa, pb, ga[2], gb[2];
             p2tri_eval(a, l, gl, &pa, ga);
             p2tri_eval(b, l, gl, &pb, gb);
@@ -702,6 +708,36 @@ void fs_ns_reset_dummy_rows(fs_matrix_s* J, hipStream_t s) {
                        sp->slice_ptr.p, sp->sell_col.p, J->val.p, sp->sell_entries);
 }
 
+// The law a Taylor-Hood space carries (fs_space_set_viscosity_law), else the (p_ref, exponent) pair of the call
+fs_visc_dev fs_space_viscosity(const fs_space_s* sp, double legacy_pref, double legacy_exp) {
+    if (sp && sp->visc.kind) return sp->visc;
+    fs_visc_dev V;
+    if (legacy_pref > 0.0) { V.kind = 1; V.pref = legacy_pref; V.ex = legacy_exp; }
+    return V;
+}
+
+extern "C" int fs_space_set_viscosity_law(fs_space_t th_space, const fs_viscosity_law* law) {
+    FS_REQUIRE(th_space, "fs_space_set_viscosity_law: null space");
+    fs_visc_dev V;
+    if (law && law->kind) {
+        FS_REQUIRE(th_space->degree == 2 && th_space->ncomp == 4, "fs_space_set_viscosity_law: not a Taylor-Hood space");
+        FS_REQUIRE((law->kind == 1 || law->kind == 2) && law->pressure_ref > 0.0, "fs_space_set_viscosity_law: kind 1 or 2 with a positive reference pressure");
+        V.kind = law->kind;
+        V.pref = law->pressure_ref;
+        V.ex = law->pressure_exponent;
+        if (law->kind == 2) {
+            FS_REQUIRE(law->temperature && law->temperature_ref != 0.0 && law->temperature->d.n >= th_space->mesh->nv,
+                       "fs_space_set_viscosity_law: kind 2 needs the CG1 temperature (one value per local vertex) and its reference");
+            V.cp = law->pressure_coef;
+            V.ct = law->temperature_coef;
+            V.tref = law->temperature_ref;
+            V.T = law->temperature->d.p;
+        }
+    }
+    th_space->visc = V;
+    return FS_OK;
+}
+
 extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev,
                                          const fs_ns_form* form) {
     FS_CHECK(fs_require_init());
@@ -728,8 +764,8 @@ extern "C" int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector
     P.g2_kappa = form->g2_kappa1;
     FS_REQUIRE(form->viscosity_pressure_ref >= 0.0 && (form->viscosity_pressure_ref == 0.0 || w0),
                "fs_assemble_navier_stokes: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
-    P.nn_pref = form->viscosity_pressure_ref;
-    P.nn_exp = form->viscosity_pressure_exponent;
+    P.V = fs_space_viscosity(sp, form->viscosity_pressure_ref, form->viscosity_pressure_exponent);
+    FS_REQUIRE(P.V.kind == 0 || w0, "fs_assemble_navier_stokes: a non-Newtonian law needs the state w0");
     FS_HIP(hipMemsetAsync(g->d.p, 0, (size_t)sp->n_dofs_owned * sizeof(double), s));
     if (m->tdim == 2) {
         // triangles: element blocks -> buffer -> one sum per stored block (always two-pass), dummy u_z / edge-pressure rows
@@ -799,7 +835,7 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
                                        const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
                                        const int32_t* __restrict__ slots,
                                        double* __restrict__ val, int64_t plane, double* __restrict__ g,
-                                       const double* __restrict__ w0, double nn_pref, double nn_exp, int vstride) {
+                                       const double* __restrict__ w0, fs_visc_dev V, int vstride) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nf * 60; t += stride) {
@@ -849,10 +885,13 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
             if (vstride == 3) { pbv[0] = facet_value[3 * f]; pbv[1] = facet_value[3 * f + 1]; pbv[2] = facet_value[3 * f + 2]; }
             else pbv[0] = pbv[1] = pbv[2] = facet_value[f];
         }
-        double P0[4] = {0.0, 0.0, 0.0, 0.0};
-        if (nn_pref > 0.0) {
+        double P0[4] = {0.0, 0.0, 0.0, 0.0}, T0[4] = {0.0, 0.0, 0.0, 0.0};
+        if (V.kind) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) P0[v] = w0[4 * (int64_t)cell_dofs[c * 10 + v] + 3];
+            if (V.kind == 2)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) T0[v] = V.T[cell_dofs[c * 10 + v]];
         }
         for (int q = 0; q < 6; ++q) {
             double l[4];
@@ -861,7 +900,8 @@ __global__ void k_ns_pressure_boundary(int64_t nf, const int32_t* __restrict__ f
             for (int v = 0; v < 4; ++v) l[v] = (v == o) ? 0.0 : NS_TQ[q][kk++];
             const double wv = NS_TW[q] * area;
             const double pb = NS_TQ[q][0] * pbv[0] + NS_TQ[q][1] * pbv[1] + NS_TQ[q][2] * pbv[2];
-            const double nu = ns_viscosity(nu0, nn_pref, nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3]);
+            const double nu = fs_viscosity(V, nu0, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2] + l[3] * P0[3],
+                                           l[0] * T0[0] + l[1] * T0[1] + l[2] * T0[2] + l[3] * T0[3]);
             double pa, pbf, ga[3], gb[3];
             p2_eval(a, l, gl, &pa, ga);
             p2_eval(b, l, gl, &pbf, gb);
@@ -893,7 +933,7 @@ __global__ void k_ns_pressure_boundary_tri(int64_t nf, const int32_t* __restrict
                                            const double* __restrict__ facet_value, double nu0, const double* __restrict__ xyz,
                                            const int32_t* __restrict__ cells, const int32_t* __restrict__ cell_dofs, int64_t nc,
                                            const int32_t* __restrict__ slots, double* __restrict__ val, int64_t plane,
-                                           double* __restrict__ g, const double* __restrict__ w0, double nn_pref, double nn_exp,
+                                           double* __restrict__ g, const double* __restrict__ w0, fs_visc_dev V,
                                            int vstride) {
     const double GS[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
     const double GW[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
@@ -917,10 +957,13 @@ __global__ void k_ns_pressure_boundary_tri(int64_t nf, const int32_t* __restrict
             if (vstride == 2) { pbv[0] = facet_value[2 * f]; pbv[1] = facet_value[2 * f + 1]; }
             else pbv[0] = pbv[1] = facet_value[f];
         }
-        double P0[3] = {0.0, 0.0, 0.0};
-        if (nn_pref > 0.0) {
+        double P0[3] = {0.0, 0.0, 0.0}, T0[3] = {0.0, 0.0, 0.0};
+        if (V.kind) {
 #pragma unroll
             for (int v = 0; v < 3; ++v) P0[v] = w0[4 * (int64_t)cell_dofs[c * 6 + v] + 3];
+            if (V.kind == 2)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) T0[v] = V.T[cell_dofs[c * 6 + v]];
         }
         double blk[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
         double gv[2] = {0.0, 0.0};
@@ -930,7 +973,7 @@ __global__ void k_ns_pressure_boundary_tri(int64_t nf, const int32_t* __restrict
             l[vj] = GS[q];
             const double wv = GW[q] * len;
             const double pb = (1.0 - GS[q]) * pbv[0] + GS[q] * pbv[1];
-            const double nu = ns_viscosity(nu0, nn_pref, nn_exp, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2]);
+            const double nu = fs_viscosity(V, nu0, l[0] * P0[0] + l[1] * P0[1] + l[2] * P0[2], l[0] * T0[0] + l[1] * T0[1] + l[2] * T0[2]);
             double pa, pbf, ga[2], gb[2];
             p2tri_eval(a, l, gl, &pa, ga);
             p2tri_eval(b, l, gl, &pbf, gb);
@@ -973,7 +1016,8 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
     FS_REQUIRE(J && J->space && J->space->mesh, "fs_assemble_ns_pressure_boundary: null matrix");
     const int fverts = J->space->mesh->tdim;      // vertices of a boundary facet: 3 (triangle) or 2 (edge of a 2-D mesh)
     FS_REQUIRE(values_per_facet == 1 || values_per_facet == fverts, "fs_assemble_ns_pressure_boundary: values_per_facet must be 1 or %d", fverts);
-    FS_REQUIRE(nn_pref >= 0.0 && (nn_pref == 0.0 || (w0 && J && w0->d.n >= J->space->n_dofs_local)),
+    const fs_visc_dev V = fs_space_viscosity(J->space, nn_pref, nn_exp);
+    FS_REQUIRE(nn_pref >= 0.0 && (V.kind == 0 || (w0 && J && w0->d.n >= J->space->n_dofs_local)),
                "fs_assemble_ns_pressure_boundary: the pressure-dependent viscosity needs a positive reference pressure and the state w0");
     FS_REQUIRE(J && g && n_facets >= 0 && (n_facets == 0 || (facet_cell && facet_opposite)), "fs_assemble_ns_pressure_boundary: bad arguments");
     fs_space_s* sp = J->space;
@@ -997,13 +1041,13 @@ extern "C" int fs_assemble_ns_pressure_boundary_nn(fs_matrix_t J, fs_vector_t g,
     if (fverts == 2)
         hipLaunchKernelGGL(k_ns_pressure_boundary_tri, dim3(fs_grid_for(n_facets * 18)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
                            facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
-                           sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,
-                           nn_pref, nn_exp, values_per_facet);
+                           sp->slots.p, J->val.p, sp->sell_entries, g->d.p, V.kind ? (const double*)w0->d.p : (const double*)nullptr,
+                           V, values_per_facet);
     else
     hipLaunchKernelGGL(k_ns_pressure_boundary, dim3(fs_grid_for(n_facets * 60)), dim3(FS_BLOCK), 0, s, n_facets, dc.p, dop.p,
                        facet_value ? dv.p : (const double*)nullptr, kinematic_viscosity, m->xyz.p, m->cells.p, sp->cell_dofs, m->nc,
-                       sp->slots.p, J->val.p, sp->sell_entries, g->d.p, nn_pref > 0.0 ? (const double*)w0->d.p : (const double*)nullptr,
-                       nn_pref, nn_exp, values_per_facet);
+                       sp->slots.p, J->val.p, sp->sell_entries, g->d.p, V.kind ? (const double*)w0->d.p : (const double*)nullptr,
+                       V, values_per_facet);
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     return FS_OK;

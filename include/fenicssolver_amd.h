@@ -438,6 +438,21 @@ typedef struct fs_ns_form {
                                          * w0; Picard in the viscosity - J w - g stays the exact residual).  0: Newtonian. */
 } fs_ns_form;
 
+/* The non-Newtonian laws of CoupledNavierStokesSolver.viscosity (CoupledNavierStokesSolver.py:194-213), attached to the
+ * Taylor-Hood space and used by every routine that evaluates nu on it (fs_assemble_navier_stokes, the pressure-boundary traction
+ * term, fs_assemble_viscous_stress*), in place of the (p_ref, exponent) pair those calls carry:
+ *   kind 1  nu (p / pressure_ref)^pressure_exponent                                          (:205-207, no temperature)
+ *   kind 2  nu (1 + pressure_coef p / pressure_ref) (1 - temperature_coef T / temperature_ref)   (:199-203, solving_temperature)
+ * p: the pressure of the state w0 the call linearises at; temperature: CG1 field, one value per LOCAL vertex of the space's mesh
+ * (the vector is read at assembly time - keep it alive and current; nothing is copied).  law = NULL or kind 0 detaches. */
+typedef struct fs_viscosity_law {
+    int kind;
+    double pressure_ref, pressure_exponent;
+    double pressure_coef, temperature_coef, temperature_ref;
+    fs_vector_t temperature;
+} fs_viscosity_law;
+int fs_space_set_viscosity_law(fs_space_t th_space, const fs_viscosity_law* law);
+
 /* J <- linearised operator at w0, g <- right-hand side such that J w_new = g is the Newton (or Picard) step
  * written for the new iterate.  w_prev: previous time step (may be NULL when inv_dt = 0). */
 int fs_assemble_navier_stokes(fs_matrix_t J, fs_vector_t g, fs_vector_t w0, fs_vector_t w_prev, const fs_ns_form* form);

@@ -125,13 +125,24 @@ def g2_delta1(g2, h, U2, inv_dt):
     return out
 
 
-def viscosity_at(nu, law, p_q):
-    """CoupledNavierStokesSolver.viscosity (:194-213), the branch without a temperature: Newtonian -> nu; otherwise
-    nu * pow(p / p_ref, 0.1) with the CURRENT pressure (the reference evaluates it on up_0 / w_current, :306 and :401).
-    law = None or (p_ref, exponent); p_q: pressure at the quadrature points."""
+def viscosity_at(nu, law, p_q, T_q=None):
+    """CoupledNavierStokesSolver.viscosity (:194-213): Newtonian -> nu; without a temperature nu * pow(p / p_ref, 0.1) with the
+    CURRENT pressure (the reference evaluates it on up_0 / w_current, :306 and :401), law = (p_ref, exponent); with
+    solving_temperature (:199-203) nu (1 + (p/p_ref) 0.1) (1 - (T/T_ref) 0.2), law = ('pT', p_ref, c_p, T_ref, c_T, T_vertices).
+    p_q, T_q: pressure / temperature at the quadrature points."""
     if law is None:
         return np.full(np.shape(p_q), float(nu))
+    if law[0] == 'pT':
+        _, pref, cp, tref, ct = law[:5]
+        return float(nu) * (1.0 + (np.asarray(p_q, dtype=np.float64) / float(pref)) * cp) * (1.0 - (np.asarray(T_q, dtype=np.float64) / float(tref)) * ct)
     return float(nu) * np.power(np.asarray(p_q, dtype=np.float64) / float(law[0]), float(law[1]))
+
+
+def law_temperature(th, law):
+    """[nc,4] vertex temperatures of every cell for the 'pT' law, None otherwise."""
+    if law is None or law[0] != 'pT':
+        return None
+    return np.asarray(law[5], dtype=np.float64)[th.cells]
 
 
 def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, newton=True, convection=True,
@@ -159,8 +170,9 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
     h_cell = cell_h(th.coords, th.cells) if g2 is not None else None
     P0 = W0[th.cells][:, :, 3]                              # [nc,4] pressure at the cell vertices
     nu_const = nu
+    T0 = law_temperature(th, viscosity_law)
     for lam, w in zip(pts, wq):
-        nu = viscosity_at(nu_const, viscosity_law, P0 @ np.asarray(lam))     # [nc]
+        nu = viscosity_at(nu_const, viscosity_law, P0 @ np.asarray(lam), None if T0 is None else T0 @ np.asarray(lam))     # [nc]
         phi, dphi = p2_shape(lam)
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)     # [nc,10,3] physical gradients
         psi = lam                                           # P1 basis = barycentric coordinates
@@ -238,13 +250,16 @@ def viscous_stress_projection(th, w, nu, viscosity_law=None):
     U = W[th.cell_nodes][:, :, :3]
     Pv = W[th.cells][:, :, 3]
     be = np.zeros((len(th.cells), 4, 9))
-    pts, wq = tet_quadrature(2)
+    pts, wq = tet_quadrature(5 if (viscosity_law is not None and viscosity_law[0] == 'pT') else 2)     # nu(p, T): quartic integrand
     for lam, wt in zip(pts, wq):
+        lam = np.asarray(lam)
         _, dphi = p2_shape(lam)
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)
         G = np.einsum("cai,caj->cij", U, gphi)
         pq = Pv @ lam
-        sig = viscosity_at(nu, viscosity_law, pq)[:, None, None] * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(3)
+        T0 = law_temperature(th, viscosity_law)
+        sig = viscosity_at(nu, viscosity_law, pq, None if T0 is None else T0 @ lam)[:, None, None] * (G + np.swapaxes(G, 1, 2)) \
+            - pq[:, None, None] * np.eye(3)
         be += (wt * th.vol)[:, None, None] * lam[None, :, None] * sig.reshape(-1, 1, 9)
     M = fo.assemble_matrix(th.nv, th.cells, fo.p1_mass_local(th.coords, th.cells, 1.0))
     out = np.zeros((th.nv, 9))
@@ -341,7 +356,9 @@ def pressure_boundary_terms(th, facet_cells, nu, bvalue=None, viscosity_law=None
         for bary, w in zip(TRI_QP, TRI_QW):
             lam = np.zeros(4)
             lam[list(opp[o])] = bary
-            nu = nu_const if viscosity_law is None else float(viscosity_at(nu_const, viscosity_law, P0[c] @ lam))
+            T0 = law_temperature(th, viscosity_law)
+            nu = nu_const if viscosity_law is None else float(viscosity_at(nu_const, viscosity_law, P0[c] @ lam,
+                                                                             None if T0 is None else T0[c] @ lam))
             phi, dphi = p2_shape(lam)
             gphi = dphi @ gl                          # [10,3]
             wv = w * area

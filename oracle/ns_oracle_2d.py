@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import fem_oracle as fo
-from .ns_oracle import apply_dirichlet_rows, g2_delta1, viscosity_at   # noqa: F401  (shared, dimension-free helpers)
+from .ns_oracle import apply_dirichlet_rows, g2_delta1, viscosity_at, law_temperature   # noqa: F401  (shared, dimension-free helpers)
 
 
 def tri_quadrature(name="dunavant12"):
@@ -107,7 +107,8 @@ def ns_system(th, w0, nu, rho=1.0, inv_dt=0.0, w_prev=None, body_force=None, new
     P0 = W0[th.cells][:, :, 3]
     nu_const = nu
     for lam, w in zip(pts, wq):
-        nu = viscosity_at(nu_const, viscosity_law, P0 @ np.asarray(lam))
+        T0 = law_temperature(th, viscosity_law)
+        nu = viscosity_at(nu_const, viscosity_law, P0 @ np.asarray(lam), None if T0 is None else T0 @ np.asarray(lam))
         phi, dphi = fo.tri_p2_shape(lam)
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)              # [nc,6,2]
         wv = w * th.area
@@ -188,7 +189,9 @@ def pressure_boundary_terms(th, facet_cells, nu, bvalue=None, viscosity_law=None
         for s, w in zip(sg, wg):
             lam = np.zeros(3)
             lam[vi], lam[vj] = 1.0 - s, s
-            nu = nu_const if viscosity_law is None else float(viscosity_at(nu_const, viscosity_law, P0[c] @ lam))
+            T0 = law_temperature(th, viscosity_law)
+            nu = nu_const if viscosity_law is None else float(viscosity_at(nu_const, viscosity_law, P0[c] @ lam,
+                                                                             None if T0 is None else T0[c] @ lam))
             phi, dphi = fo.tri_p2_shape(lam)
             gphi = dphi @ gl
             wv = w * length
@@ -253,7 +256,9 @@ def viscous_stress_projection(th, w, nu, viscosity_law=None):
         gphi = np.einsum("ak,cki->cai", dphi, th.glam)
         G = np.einsum("cai,caj->cij", U, gphi)
         pq = Pv @ lam
-        sig = viscosity_at(nu, viscosity_law, pq)[:, None, None] * (G + np.swapaxes(G, 1, 2)) - pq[:, None, None] * np.eye(2)
+        T0 = law_temperature(th, viscosity_law)
+        sig = viscosity_at(nu, viscosity_law, pq, None if T0 is None else T0 @ np.asarray(lam))[:, None, None] * (G + np.swapaxes(G, 1, 2)) \
+            - pq[:, None, None] * np.eye(2)
         be += (wt * th.area)[:, None, None] * lam[None, :, None] * sig.reshape(-1, 1, 4)
     M = fo.assemble_matrix(th.nv, th.cells, fo.tri_mass_local(th.coords, th.cells, 1.0))
     out = np.zeros((th.nv, 4))

@@ -765,3 +765,110 @@ def test_boundary_pressure_that_varies_over_the_facets(gpu):
     u, p = solver.split()
     assert np.abs(u.node_values()).max() <= 1e-8
     assert np.abs(p.vector().array() - (5.0 - 9.8 * m.coordinates()[:, 2])).max() <= 1e-6
+
+
+def test_viscosity_depending_on_pressure_and_temperature(gpu):
+    """material['Newtonian'] = False WITH solving_temperature (CoupledNavierStokesSolver.viscosity :199-203, round 4):
+    nu (1 + 0.1 p/p_ref)(1 - 0.2 T/T_ref) on the current (u, p, T).  Kernels: cell terms, pressure-boundary traction and the stress
+    projection with the law attached to the space, against the oracle.  Solver class: the converged (u, p, T) is a root of the ORACLE's
+    flow residual with that law AND of the transport equation convected by that velocity - the reference's monolithic system."""
+    import copy
+    from collections import OrderedDict
+    from fenicssolver_amd.fem import UnitCubeMesh, AutoSubDomain, Constant, near, SolverError
+    from fenicssolver_amd import SolverBase as SB
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    from fenicssolver_amd.mixed import split
+    co, ce, th, mesh, W, Q = _setup(gpu, 3)
+    nu, rho, pref, tref = 0.3, 1.3, 10.0, 300.0
+    rng = np.random.default_rng(5)
+    Tv = 300.0 + 80.0 * rng.random(th.nv)
+    w0 = 0.1 * rng.standard_normal(th.n)
+    w0.reshape(-1, 4)[:th.nv, 3] = 10.0 + 4.0 * rng.random(th.nv)
+    w0[th.dummy_dofs()] = 0.0
+    law = ('pT', pref, 0.1, tref, 0.2, Tv)
+    dT = gpu.DeviceVector(th.nv, Tv)
+    gpu.set_viscosity_law(W, law[:5], dT)
+    J = gpu.DeviceMatrix(W)
+    g = gpu.DeviceVector(W.n_owned)
+    dw = gpu.DeviceVector(W.n_local, w0)
+    gpu.assemble_navier_stokes(J, g, dw, None, nu=nu, rho=rho, convection=True, newton=True)
+    fin = ns.boundary_facet_cells(th, lambda x: abs(x[0]) < 1e-12)
+    gpu.assemble_ns_pressure_boundary(J, g, fin[:, 0] if hasattr(fin, 'shape') else np.array(fin)[:, 0], np.array(fin)[:, 1], nu,
+                                      np.full(len(fin), 14.0), w0=dw)
+    Kref, gref = ns.ns_system(th, w0, nu, rho, 0.0, None, None, newton=True, viscosity_law=law)
+    dJ, dg = ns.pressure_boundary_terms(th, fin, nu, 14.0, viscosity_law=law, w0=w0)
+    Kref, gref = (Kref + dJ).tocsr(), gref + dg
+    rp, ci, va, shape = J.to_csr()
+    import scipy.sparse as sps
+    got = sps.csr_matrix((va, ci, rp), shape=shape)
+    assert abs(got - Kref).max() <= 1e-11 * abs(Kref).max()
+    assert np.abs(g.get() - gref).max() <= 1e-11 * np.abs(gref).max()
+    Knewt, _ = ns.ns_system(th, w0, nu, rho, 0.0, None, None, newton=True)
+    assert abs(Kref - Knewt).max() > 1e-2 * abs(Knewt).max()                 # the law is not a no-op
+    bt = gpu.DeviceVector(9 * Q.n_owned)
+    gpu.assemble_viscous_stress(W, dw, nu, Q, bt)
+    sig = ns.viscous_stress_projection(th, w0, nu, viscosity_law=law)
+    Mq = fo.assemble_matrix(th.nv, ce, fo.p1_mass_local(co, ce, 1.0))
+    want = np.stack([Mq @ sig.reshape(th.nv, 9)[:, k] for k in range(9)], axis=1)
+    assert np.abs(bt.get().reshape(th.nv, 9) - want).max() <= 1e-10 * np.abs(want).max()
+    gpu.set_viscosity_law(W, None)
+    gpu.assemble_navier_stokes(J, g, dw, None, nu=nu, rho=rho, convection=True, newton=True)
+    rp, ci, va, shape = J.to_csr()
+    assert abs(sps.csr_matrix((va, ci, rp), shape=shape) - Knewt).max() <= 1e-11 * abs(Knewt).max()      # detached again
+
+    # ---- the solver class: heated channel driven by a pressure drop
+    def run(newtonian):
+        m = UnitCubeMesh(3, 3, 3)
+        bcs = OrderedDict()
+        bcs["walls"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and (near(x[2], 0) or near(x[2], 1) or near(x[1], 0) or near(x[1], 1))),
+                        'boundary_id': 1, 'values': [{'variable': "velocity", 'type': 'Dirichlet', 'value': Constant((0, 0, 0))},
+                                                     {'variable': "temperature", 'type': 'Dirichlet', 'value': Constant(420.0)}]}
+        bcs["inlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 0)), 'boundary_id': 2,
+                        'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(14.0)},
+                                   {'variable': "temperature", 'type': 'Dirichlet', 'value': Constant(300.0)}]}
+        bcs["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary and near(x[0], 1)), 'boundary_id': 3,
+                         'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(8.0)}]}
+        s = copy.deepcopy(SB.default_case_settings)
+        s.update({'solver_name': "CoupledNavierStokesSolver", 'mesh': m, 'fe_degree': 1, 'boundary_conditions': bcs, 'solving_temperature': True,
+                  'body_source': None, 'initial_values': {'velocity': (0, 0, 0), 'pressure': 10.0, 'temperature': 300.0},
+                  'material': {'density': 1.0, 'kinematic_viscosity': nu, 'Newtonian': newtonian, 'specific_heat_capacity': 3.0,
+                               'thermal_conductivity': 0.1}})
+        s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': pref, 'temperature': tref}
+        s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
+        s['report_settings'] = dict(QUIET)
+        solver = CoupledNavierStokesSolver(s)
+        return solver, m, solver.solve()
+
+    solver, m, w = run(False)
+    u, p, T = split(w)
+    assert solver.temperature_law() == ('pT', pref, 0.1, tref, 0.2) and 2 <= solver.coupling_iterations <= 40
+    wv, Tn = w.vector().array().copy(), T.vector().array().copy()
+    _, _, w_n = run(True)
+    assert np.abs(wv - w_n.vector().array()).reshape(-1, 4)[:, 0].max() > 2e-3 * np.abs(w_n.vector().array()).reshape(-1, 4)[:, 0].max()
+    th2 = ns.TaylorHood(m.coordinates(), m.cells())
+    law2 = ('pT', pref, 0.1, tref, 0.2, Tn)
+    K, rhs = ns.ns_system(th2, wv, nu, 1.0, 0.0, None, None, newton=False, viscosity_law=law2)
+    for inside, val in ((lambda x: abs(x[0]) < 1e-12, 14.0), (lambda x: abs(x[0] - 1) < 1e-12, 8.0)):
+        dJ, dg = ns.pressure_boundary_terms(th2, ns.boundary_facet_cells(th2, inside), nu, val, viscosity_law=law2, w0=wv)
+        K, rhs = K + dJ, rhs + dg
+    r = K @ wv - rhs
+    walls = th2.boundary_nodes(lambda x: min(abs(x[1]), abs(x[1] - 1), abs(x[2]), abs(x[2] - 1)) < 1e-12)
+    mc = m.coordinates()
+    fixed = np.concatenate([th2.velocity_dofs(walls), th2.pressure_dofs(np.nonzero(mc[:, 0] == 0)[0]), th2.pressure_dofs(np.nonzero(mc[:, 0] == 1)[0]),
+                            th2.dummy_dofs()])
+    r[fixed] = 0.0
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(rhs)
+    # the temperature solves the IP-stabilised transport equation convected by THIS velocity
+    cap = 1.0 * 3.0
+    V = fo.row_velocities(m.cells(), u.node_values(), cell_dofs=th2.cell_nodes)
+    A = (fo.assemble_p1_scalar(mc, m.cells(), 0.1) + fo.assemble_matrix(len(mc), m.cells(), fo.p1_advection_local(mc, m.cells(), V, cap))
+         + fo.assemble_interior_penalty(mc, m.cells(), 0.1 * cap)).tocsr()
+    wall_v = np.nonzero((mc[:, 1] == 0) | (mc[:, 1] == 1) | (mc[:, 2] == 0) | (mc[:, 2] == 1))[0]
+    inlet_v = np.nonzero(mc[:, 0] == 0)[0]
+    vals = np.full(len(mc), np.nan)
+    vals[wall_v] = 420.0
+    vals[inlet_v] = 300.0                                                   # the inlet is marked after the walls
+    bnd = np.nonzero(~np.isnan(vals))[0]
+    want = fo.solve_direct(*fo.apply_dirichlet(A, np.zeros(len(mc)), bnd, vals[bnd], False))
+    assert np.abs(Tn - want).max() <= 1e-6 * np.abs(want).max()
+    assert np.ptp(Tn) > 50.0
