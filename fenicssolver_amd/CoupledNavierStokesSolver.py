@@ -41,7 +41,7 @@ import numbers
 import numpy as np
 
 from .SolverBase import SolverBase, SolverError
-from .fem import Measure, Function, Constant, Expression, DirichletBC
+from .fem import Measure, Function, Constant, Expression, DirichletBC, FunctionSpace
 from .mixed import TaylorHoodSpace, split
 from . import forms
 
@@ -149,10 +149,22 @@ class CoupledNavierStokesSolver(SolverBase):
             return
         Ts = self._temperature_solver()
         dW = self.function_space.device()
-        ploc = self.function_space.pressure_space().localizer()
         vals = Ts.w_current.vector()._values()
-        if ploc is not None:
-            vals = ploc.nodes(vals)
+        loc = self.function_space.localizer()
+        # one value per LOCAL NODE of the flow space (read at the vertex nodes): on one GPU the vertices are the first nodes; a
+        # decomposed CG2 space orders [owned vertices | owned edges | ghost vertices | ghost edges]
+        if loc is None:
+            arr = np.zeros(dW.n_local // 4)
+            arr[:len(vals)] = vals
+        elif hasattr(loc, 'l2h'):                     # distributed box: host vectors are local, host nodes = vertices, then edges
+            arr = np.zeros(len(loc.l2h))
+            m = loc.l2h < len(vals)
+            arr[m] = vals[loc.l2h[m]]
+        else:                                         # replicated host mesh: global node ids, the vertices first
+            arr = np.zeros(len(loc.l2g))
+            m = loc.l2g < loc.n_global_vertices
+            arr[m] = vals[loc.l2g[m]]
+        vals = arr
         vec = self.__dict__.get('_law_T')
         if vec is None or vec.n != len(vals):
             vec = self._law_T = backend.DeviceVector(len(vals))
@@ -269,7 +281,10 @@ class CoupledNavierStokesSolver(SolverBase):
             ts = copy.copy(self.settings)                    # "Tsettings = copy.copy(self.settings)" (:255)
             ts['scalar_name'] = 'temperature'
             ts['mesh'] = None
-            ts['function_space'] = self.function_space.pressure_space()      # MixedElement([V, Q, Q]): T lives on Q (:94-95)
+            from . import parallel
+            # MixedElement([V, Q, Q]): T lives on Q (:94-95).  Several GPUs: a space of its own - its interior-penalty term cuts a
+            # two-layer part with its own device mesh, the flow's pressure space stays on the mesh the stress projections share
+            ts['function_space'] = FunctionSpace(self.mesh, "CG", 1) if parallel.active() else self.function_space.pressure_space()
             ts['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}     # (:262)
             ts['convective_velocity'] = None
             ts['solving_temperature'] = False

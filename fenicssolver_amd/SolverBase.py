@@ -562,7 +562,7 @@ class SolverBase():
                 A.assemble(stiffness=L_(F.conductivity.spec(theta)), mass=mass, advection=adv, advection_scale=adv_scale,
                            supg_pe=pe)
                 if ip:          # fully implicit, like the advection term it stabilises (ScalarTransportSolver.py:305-315)
-                    A.add_interior_penalty(self.mesh.interior_facet_cells()[0], ip)
+                    A.add_interior_penalty(self.mesh.interior_facet_cells()[0] if loc is None else loc.interior_facet_cells, ip)
                 for r in F.robin:
                     tri, _ = self._device_facets(F, r.marker_id)
                     A.add_facet_mass(tri, r.h)

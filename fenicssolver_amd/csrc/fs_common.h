@@ -173,7 +173,7 @@ struct fs_p2p_halo {
 
 // Non-Newtonian viscosity law of CoupledNavierStokesSolver.viscosity (:194-213) as the kernels take it: kind 0 Newtonian;
 // 1: nu (p / pref)^ex (the branch without a temperature); 2: nu (1 + cp p/pref)(1 - ct T/tref) with the CG1 temperature T
-// (vertex values, local numbering of the Taylor-Hood space = of its mesh) - the solving_temperature branch (:199-203)
+// (one value per local NODE of the Taylor-Hood space, read at the vertex nodes) - the solving_temperature branch (:199-203)
 struct fs_visc_dev {
     int kind = 0;
     double pref = 0.0, ex = 0.0, cp = 0.0, ct = 0.0, tref = 1.0;

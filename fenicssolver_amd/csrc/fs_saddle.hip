@@ -726,8 +726,8 @@ extern "C" int fs_space_set_viscosity_law(fs_space_t th_space, const fs_viscosit
         V.pref = law->pressure_ref;
         V.ex = law->pressure_exponent;
         if (law->kind == 2) {
-            FS_REQUIRE(law->temperature && law->temperature_ref != 0.0 && law->temperature->d.n >= th_space->mesh->nv,
-                       "fs_space_set_viscosity_law: kind 2 needs the CG1 temperature (one value per local vertex) and its reference");
+            FS_REQUIRE(law->temperature && law->temperature_ref != 0.0 && law->temperature->d.n >= th_space->n_nodes_local,
+                       "fs_space_set_viscosity_law: kind 2 needs the CG1 temperature (one value per local node, read at the vertex nodes) and its reference");
             V.cp = law->pressure_coef;
             V.ct = law->temperature_coef;
             V.tref = law->temperature_ref;

@@ -918,11 +918,9 @@ class FunctionSpace:
                 # a mesh in FILE order on one GPU: the same machinery with one part whose numbering is the locality order
                 root._device = self._make_parallel_device(root, backend, parallel, renumber=True)
             elif parallel.active():
-                if facet_coupling:
-                    raise SolverError("interior-facet (IP) terms are single-GPU for now")
                 if root._periodic is not None:
                     raise SolverError("periodic_boundary (constrained_domain) is built for one GPU")
-                root._device = self._make_parallel_device(root, backend, parallel)
+                root._device = self._make_parallel_device(root, backend, parallel, facet_coupling=facet_coupling)
             else:
                 pairs = None
                 if facet_coupling:
@@ -957,10 +955,14 @@ class FunctionSpace:
         return env == "1" or mesh.num_vertices() >= FunctionSpace.RENUMBER_MIN_VERTICES
 
     @staticmethod
-    def _make_parallel_device(root, backend, parallel, renumber=False):
+    def _make_parallel_device(root, backend, parallel, renumber=False, facet_coupling=False):
         """This rank's share of the space: owner-computes vertex slabs along the longest axis,
-        one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py)."""
+        one ghost-cell layer, halo plan on the device space (fenicssolver_amd/partition.py).
+        facet_coupling (scalar P1 spaces): interior-facet (dS) integrals - the part takes a SECOND cell layer (the cell across a
+        facet of a cell around an owned vertex), its own device mesh, and the pattern the couplings across the local facets."""
         from . import partition
+        if facet_coupling:
+            return FunctionSpace._make_parallel_facet_device(root, backend, parallel, partition)
         if root._degree == 2 and (root._ncomp not in (1, 3, 4) or mesh_dim(root) != 3):
             raise SolverError("multi-GPU decomposition is built for P1 spaces and, on tetrahedra, scalar / vector P2 spaces and the "
                               "Taylor-Hood space")
@@ -1020,6 +1022,39 @@ class FunctionSpace:
                 ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts],
                             recv_lists=dof_lists(plan.recv_lists))
             root._localizer = parallel.Localizer(part, mesh.num_vertices(), nc_, p2_plan=plan, n_global_nodes=root.num_nodes())
+        return ds
+
+    @staticmethod
+    def _make_parallel_facet_device(root, backend, parallel, partition):
+        mesh = root._mesh
+        if root._degree != 1 or root._ncomp != 1:
+            raise SolverError("interior-facet (IP) terms under domain decomposition are built for scalar P1 spaces")
+        if getattr(mesh, "_slab", None) is not None:
+            raise SolverError("interior-facet (IP) terms need two ghost-cell layers: BoxMesh(distributed=True) carries one - use the "
+                              "replicated BoxMesh (every rank then cuts its own two-layer part)")
+        rank, size = parallel.ensure_comm()
+        co, ce = mesh.coordinates(), mesh.cells()
+        cache = mesh.__dict__.setdefault("_parallel_parts", {})
+        key = (rank, size, "facets")
+        if key not in cache:
+            axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
+            owner = partition.slab_owner(co, size, axis=axis)
+            fcells, fopp = mesh.interior_facet_cells()
+            part = partition.build_local_part(ce, owner, rank, face_pairs=fcells)
+            # the interior facets both of whose cells are local, in local cell / vertex numbers
+            cg2l = np.full(len(ce), -1, dtype=np.int64)
+            cg2l[part.cell_gids] = np.arange(len(part.cell_gids))
+            lf = cg2l[fcells.astype(np.int64)]
+            sel = (lf >= 0).all(axis=1)
+            g2l = part.g2l(mesh.num_vertices())
+            cache[key] = (owner, part, backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g),
+                          lf[sel].astype(np.int32), g2l[fopp.astype(np.int64)[sel]].astype(np.int32))
+        owner, part, dm, lfacets, lpairs = cache[key]
+        ds = backend.DeviceSpace(dm, 1, 1, coupled_pairs=lpairs)
+        if size > 1:
+            ds.set_halo(part.neighbors, part.dof_send_lists(1), list(part.recv_counts))
+        root._localizer = parallel.Localizer(part, mesh.num_vertices(), 1)
+        root._localizer.interior_facet_cells = lfacets
         return ds
 
     @staticmethod

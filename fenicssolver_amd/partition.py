@@ -84,14 +84,30 @@ class LocalPart:
         return [(s[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel().astype(np.int32) for s in self.send_lists]
 
 
-def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None):
+def _local_cell_mask(cells, owner, q, face_pairs):
+    """Cells of rank q's part: those holding a q-owned vertex and - with face_pairs, the (cell, cell) pairs of the interior
+    facets - their neighbours across a facet (the second layer interior-facet integrals need: a row of an owned vertex a takes
+    contributions from every facet of the cells around a, and the cell on the far side need not touch any owned vertex)."""
+    m = (owner[cells] == q).any(axis=1)
+    if face_pairs is not None:
+        a, b = face_pairs[:, 0], face_pairs[:, 1]
+        m2 = m.copy()
+        m2[b[m[a]]] = True
+        m2[a[m[b]]] = True
+        m = m2
+    return m
+
+
+def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_pairs=None):
     """vertex_rank / cell_rank (optional, [n_global] each): a locality order (backend.locality_order) - the owned vertices
-    and the local cells are then numbered by it instead of by their global ids (the order a mesh file happens to have)."""
+    and the local cells are then numbered by it instead of by their global ids (the order a mesh file happens to have).
+    face_pairs [nf,2] (optional, global cell ids of the two cells of every interior facet): two cell layers instead of one."""
     cells = np.asarray(cells, dtype=np.int64)
     owner = np.asarray(owner)
+    if face_pairs is not None:
+        face_pairs = np.asarray(face_pairs, dtype=np.int64).reshape(-1, 2)
     n_global = len(owner)
-    cell_owned = owner[cells] == rank
-    keep = np.nonzero(cell_owned.any(axis=1))[0]
+    keep = np.nonzero(_local_cell_mask(cells, owner, rank, face_pairs))[0]
     if cell_rank is not None:
         keep = keep[np.argsort(np.asarray(cell_rank)[keep], kind="stable")]
     lc = cells[keep]
@@ -106,16 +122,25 @@ def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None):
     g2l = np.full(n_global, -1, dtype=np.int64)
     g2l[l2g] = np.arange(len(l2g))
     neighbors, recv_counts = np.unique(owner[ghosts], return_counts=True)
-    # what each neighbour q needs from me: my vertices in cells that touch a q-owned vertex
+    # what each neighbour q needs from me: my vertices in the cells of q's part (ascending global id = q's ghost order)
     send_lists = []
     nb_all = set(neighbors.tolist())
-    cand = cells[(owner[cells] == rank).any(axis=1)]
-    for q in sorted(nb_all | set(np.unique(owner[cand]).tolist()) - {rank}):
-        touch = cand[(owner[cand] == q).any(axis=1)]
+    if face_pairs is None:
+        cand = cells[(owner[cells] == rank).any(axis=1)]
+        others = sorted(nb_all | set(np.unique(owner[cand]).tolist()) - {rank})
+    else:
+        others = [q for q in range(int(owner.max()) + 1) if q != rank]
+    for q in others:
+        if face_pairs is None:
+            touch = cand[(owner[cand] == q).any(axis=1)]
+        else:
+            touch = cells[_local_cell_mask(cells, owner, q, face_pairs)]
         v = np.unique(touch)
         v = v[owner[v] == rank]
-        if q not in nb_all:
-            # q needs my vertices but I need none of q's: cannot happen for a one-layer overlap
+        if face_pairs is not None and len(v) == 0 and q not in nb_all:
+            continue
+        if q not in nb_all or (face_pairs is not None and len(v) == 0):
+            # q needs my vertices but I need none of q's (or the reverse): cannot happen, the overlap is symmetric
             raise AssertionError("asymmetric neighbourhood between ranks %d and %d" % (rank, q))
         send_lists.append(g2l[v].astype(np.int32))
     return LocalPart(rank, l2g, len(mine), g2l[lc].astype(np.int32), keep, [int(q) for q in neighbors],

@@ -443,8 +443,10 @@ typedef struct fs_ns_form {
  * term, fs_assemble_viscous_stress*), in place of the (p_ref, exponent) pair those calls carry:
  *   kind 1  nu (p / pressure_ref)^pressure_exponent                                          (:205-207, no temperature)
  *   kind 2  nu (1 + pressure_coef p / pressure_ref) (1 - temperature_coef T / temperature_ref)   (:199-203, solving_temperature)
- * p: the pressure of the state w0 the call linearises at; temperature: CG1 field, one value per LOCAL vertex of the space's mesh
- * (the vector is read at assembly time - keep it alive and current; nothing is copied).  law = NULL or kind 0 detaches. */
+ * p: the pressure of the state w0 the call linearises at; temperature: CG1 field stored like the pressure inside w0 - one value per
+ * LOCAL NODE of the Taylor-Hood space, read at the vertex nodes only (one GPU: the vertices are the first nodes; a decomposed space
+ * orders owned vertices, owned edges, ghost vertices, ghost edges).  The vector is read at assembly time - keep it alive and current;
+ * nothing is copied.  law = NULL or kind 0 detaches. */
 typedef struct fs_viscosity_law {
     int kind;
     double pressure_ref, pressure_exponent;

@@ -202,3 +202,37 @@ def test_local_p2_plan_equals_the_plan_from_the_global_mesh(data_dir, mesh_kind,
             other, oref = plans[q]
             back = other.neighbors.index(r)
             assert np.array_equal(ref.l2g_nodes[loc.send_lists[qi]], oref.l2g_nodes[other.recv_lists[back]])
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_two_layer_parts_for_interior_facet_integrals(world):
+    """partition.build_local_part(face_pairs=...) (round 4: the interior-penalty term under decomposition).  For every rank: (1) every
+    interior facet one of whose two cells holds an owned vertex has BOTH cells in the part - the rows of the owned vertices then get
+    all their dS contributions from local data; (2) the exchange plan is consistent: what rank r sends to q is exactly q's ghosts
+    owned by r, in q's ghost order."""
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 3.0), 3, 2, 9)
+    ce = ce.astype(np.int64)
+    _, cf, _ = fo.facet_numbering(ce)
+    order = np.argsort(cf.ravel(), kind="stable")
+    fid = cf.ravel()[order]
+    dup = np.nonzero(fid[1:] == fid[:-1])[0]
+    pairs = np.stack([order[dup] // 4, order[dup + 1] // 4], axis=1)
+    owner = partition.slab_owner(co, world, axis=2)
+    parts = [partition.build_local_part(ce, owner, r, face_pairs=pairs) for r in range(world)]
+    one_layer = [partition.build_local_part(ce, owner, r) for r in range(world)]
+    for r, part in enumerate(parts):
+        local = np.zeros(len(ce), dtype=bool)
+        local[part.cell_gids] = True
+        touches = (owner[ce] == r).any(axis=1)
+        need = touches[pairs[:, 0]] | touches[pairs[:, 1]]
+        assert local[pairs[need]].all()
+        assert len(part.cell_gids) > len(one_layer[r].cell_gids) or world == 1
+        assert np.array_equal(part.l2g[:part.n_owned], one_layer[r].l2g[:one_layer[r].n_owned])      # the owned rows do not change
+        off = part.n_owned
+        for q, cnt in zip(part.neighbors, part.recv_counts):
+            ghosts_from_q = part.l2g[off:off + cnt]
+            off += cnt
+            pq = parts[q]
+            k = pq.neighbors.index(r)
+            assert np.array_equal(pq.l2g[pq.send_lists[k]], ghosts_from_q)
+        assert off == part.n_local

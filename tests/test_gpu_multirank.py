@@ -113,7 +113,8 @@ def test_vector_space_slabs_over_ranks(gpu, tmp_path, world, mode):
     assert np.abs(r["x"] - x.get()[:V.n_owned]).max() <= 1e-9 * np.abs(x.get()).max()
 
 
-@pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2)])
+@pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2),
+                                        ("heat_ip", 2), ("heat_ip", 3)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     _solver_classes_case(gpu, tmp_path, case, world)
 
@@ -222,7 +223,7 @@ def test_navier_stokes_on_the_distributed_box_mesh(gpu, tmp_path, case, world):
 
 
 @pytest.mark.parametrize("case,world,p2p", [("cavity", 2, False), ("cavity", 3, False), ("channel", 2, False), ("radiation", 2, False),
-                                            ("cavity", 3, True), ("channel", 2, True)])
+                                            ("cavity", 3, True), ("channel", 2, True), ("cavity_thermal", 2, False)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world, p2p):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,
     FGMRES with reduced multi-dots, halo exchange of the iterate inside the preconditioner, Schur-complement solves on

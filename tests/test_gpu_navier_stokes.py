@@ -786,7 +786,7 @@ def test_viscosity_depending_on_pressure_and_temperature(gpu):
     w0.reshape(-1, 4)[:th.nv, 3] = 10.0 + 4.0 * rng.random(th.nv)
     w0[th.dummy_dofs()] = 0.0
     law = ('pT', pref, 0.1, tref, 0.2, Tv)
-    dT = gpu.DeviceVector(th.nv, Tv)
+    dT = gpu.DeviceVector(th.n_nodes, np.concatenate([Tv, np.zeros(th.n_nodes - th.nv)]))      # per node, read at the vertex nodes
     gpu.set_viscosity_law(W, law[:5], dT)
     J = gpu.DeviceMatrix(W)
     g = gpu.DeviceVector(W.n_owned)

@@ -363,7 +363,7 @@ def test_viscosity_depending_on_pressure_and_temperature_2d(gpu):
     w0.reshape(-1, 4)[:th.nv, 3] = 10.0 + 4.0 * rng.random(th.nv)
     Tv = 300.0 + 90.0 * rng.random(th.nv)
     law = ('pT', pref, 0.1, tref, 0.2, Tv)
-    dT = gpu.DeviceVector(th.nv, Tv)
+    dT = gpu.DeviceVector(th.n_nodes, np.concatenate([Tv, np.zeros(th.n_nodes - th.nv)]))      # per node, read at the vertex nodes
     gpu.set_viscosity_law(W, law[:5], dT)
     J = gpu.DeviceMatrix(W)
     g = gpu.DeviceVector(W.n_owned)

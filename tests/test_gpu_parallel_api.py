@@ -26,7 +26,7 @@ def _heat_p2_case(n=4):
     return solver
 
 
-def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False):
+def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip=False):
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n, distributed=distributed)
@@ -49,6 +49,9 @@ def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False):
     if supg:        # advection with the 'SPUG' test function in the volume, source and boundary (flux, HTC) integrals
         s['convective_velocity'] = Constant((0.02, -0.01, 0.03))
         s['advection_settings'] = {'stabilization_method': 'SPUG', 'Pe': 10.0}
+    if ip:          # interior-penalty stabilisation: a dS integral - under decomposition the part takes a second cell layer
+        s['convective_velocity'] = Constant((0.02, -0.01, 0.03))
+        s['advection_settings'] = {'stabilization_method': 'IP', 'alpha': 0.1}
     solver = ScalarTransportSolver(s)
     cen = m.coordinates()[m.cells().astype(np.int64)].mean(axis=1)
     sub = MeshFunction("size_t", m, 3)
@@ -95,7 +98,7 @@ def _elastic_case(distributed=False, degree=1, fine=1):
     return LinearElasticitySolver(s)
 
 
-def _cavity_case(n=4, transient=True, distributed=False):
+def _cavity_case(n=4, transient=True, distributed=False, thermal=False):
     """Lid-driven cavity, Taylor-Hood, two backward-Euler steps with Newton (configs[4] in small)."""
     from fenicssolver_amd.fem import UnitCubeMesh, BoxMesh, Point, AutoSubDomain, Constant, near
     from fenicssolver_amd import SolverBase as SB
@@ -115,6 +118,16 @@ def _cavity_case(n=4, transient=True, distributed=False):
     s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 0}
     s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-10}
     s['report_settings'] = dict(QUIET)
+    if thermal:
+        # solving_temperature with the non-Newtonian law nu (1 + 0.1 p/p_ref)(1 - 0.2 T/T_ref): the temperature (its own P1 space with
+        # the interior-penalty term, i.e. a two-layer part under decomposition) feeds back into the momentum equation
+        s['solving_temperature'] = True
+        s['material'] = {'density': 1.0, 'kinematic_viscosity': 0.05, 'Newtonian': False, 'specific_heat_capacity': 3.0,
+                         'thermal_conductivity': 0.1}
+        s['boundary_conditions']['walls']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(420.0)})
+        s['boundary_conditions']['lid']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300.0)})
+        s['initial_values'] = {'velocity': (0, 0, 0), 'pressure': 0, 'temperature': 320.0}
+        s['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 10.0, 'temperature': 300.0}
     return CoupledNavierStokesSolver(s)
 
 
@@ -171,7 +184,8 @@ def _radiation_case():
 
 
 # cases that do not go through _device_solve (Newton loops, the saddle-point path): no captured (A, b) test
-NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case}
+NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case,
+            "cavity_thermal": lambda: _cavity_case(transient=False, thermal=True)}
 
 # BoxMesh(distributed=True): every rank builds only its z-slab on the host (one rank: the same mesh as the replicated one)
 DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist": lambda: _heat_case(transient=True, distributed=True),
@@ -200,7 +214,7 @@ CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=T
          # 37 x 7 x 7 nodes: a hierarchy of several levels (the 12 x 2 x 2 beam is a single level)
          "elasticity_fine": lambda: _elastic_case(fine=3),
          "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
-         "heat_supg": lambda: _heat_case(supg=True),
+         "heat_supg": lambda: _heat_case(supg=True), "heat_ip": lambda: _heat_case(ip=True), "heat_ip_cn": lambda: _heat_case(ip=True, transient=True),
          "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
 
 
