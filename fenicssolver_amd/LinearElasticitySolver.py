@@ -170,8 +170,6 @@ class LinearElasticitySolver(SolverBase):
     def _varying_pressure_load(self, marker_id, pval, direction, name):
         from .fem import nodal_values, FunctionSpace
         V = self.function_space
-        if V.localizer() is not None:
-            raise SolverError("boundary '{}': a varying pressure is built for one GPU".format(name))
         tri, nrm, area = self._facet_normals(marker_id)
         if direction:
             nrm = np.tile(self._vector_of(direction, name), (len(tri), 1))

@@ -678,7 +678,13 @@ class SolverBase():
                 b.axpy(sgn, tmpb)
             for t in F.tractions:
                 if isinstance(t, forms.NodalLoad):          # worked out per node on the host (sign included)
-                    b.add_entries(t.dofs, t.values)
+                    nd_, nv_ = np.asarray(t.dofs).ravel(), np.asarray(t.values, dtype=np.float64).ravel()
+                    if loc is not None:                     # several GPUs: this rank's rows of the load
+                        nd_, nv_ = loc.dofs(nd_, nv_)
+                        keep_ = nd_ < V.n_owned
+                        nd_, nv_ = nd_[keep_], nv_[keep_]
+                    if len(nd_):
+                        b.add_entries(nd_, nv_)
                     continue
                 tri, g = self._device_facets(F, t.marker_id, t.g)
                 if len(tri):
@@ -779,11 +785,15 @@ class SolverBase():
                 # for m*(pow(T, 4) - pow(T_amb, 4))*Tq*ds (ScalarTransportSolver.py:186-190); the Jacobian below keeps the
                 # facet-mean linearisation - it only steers the iteration
                 if F.space.degree() == 2:
-                    if loc is not None:
-                        raise SolverError('radiation on P2 spaces is built for one GPU')
                     ftab = F.space.facet_node_table(ext.astype(np.int64))
                     loads = _radiation_loads_p2(self.mesh.coordinates(), ext.astype(np.int64), ftab, T, m_, T_amb)
-                    b.add_entries(ftab, loads)
+                    if loc is None:
+                        b.add_entries(ftab, loads)
+                    else:                                   # several GPUs: this rank's rows of the facet loads
+                        rd_, rv_ = loc.dofs(np.asarray(ftab).ravel(), np.asarray(loads, dtype=np.float64).ravel())
+                        keep_ = rd_ < n
+                        if keep_.any():
+                            b.add_entries(rd_[keep_], rv_[keep_])
                     en = T[ftab[:, ext.shape[1]:]]                          # edge-node values: the facet mean of a P2 field
                     Tf = en.mean(axis=1) if ext.shape[1] == 3 else (T[ftab[:, 0]] + 4.0 * en[:, 0] + T[ftab[:, 1]]) / 6.0
                 else:

@@ -114,7 +114,7 @@ def test_vector_space_slabs_over_ranks(gpu, tmp_path, world, mode):
 
 
 @pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2),
-                                        ("heat_ip", 2), ("heat_ip", 3)])
+                                        ("heat_ip", 2), ("heat_ip", 3), ("elasticity_pfield", 2), ("elasticity_p2_pfield", 2)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     _solver_classes_case(gpu, tmp_path, case, world)
 
@@ -150,7 +150,8 @@ def test_file_mesh_under_several_ranks(gpu, tmp_path, monkeypatch, case, world, 
     assert np.abs(r["x"] - (350.0 - 2.5 * X[:, 2])).max() <= 1e-7
 
 
-@pytest.mark.parametrize("case,world", [("heat_dist", 2), ("heat_dist", 3), ("heat_cn_dist", 2), ("elasticity_dist", 2), ("elasticity_dist", 3)])
+@pytest.mark.parametrize("case,world", [("heat_dist", 2), ("heat_dist", 3), ("heat_cn_dist", 2), ("elasticity_dist", 2), ("elasticity_dist", 3),
+                                        ("elasticity_pfield_dist", 2)])
 def test_distributed_box_mesh_no_global_host_mesh(gpu, tmp_path, case, world):
     """BoxMesh(distributed=True): every rank builds only its slab on the host (vertex planes it owns + one ghost plane each
     side), marks boundaries, evaluates coefficients and Dirichlet sets on it and keeps the local part of the result; the
@@ -223,7 +224,7 @@ def test_navier_stokes_on_the_distributed_box_mesh(gpu, tmp_path, case, world):
 
 
 @pytest.mark.parametrize("case,world,p2p", [("cavity", 2, False), ("cavity", 3, False), ("channel", 2, False), ("radiation", 2, False),
-                                            ("cavity", 3, True), ("channel", 2, True), ("cavity_thermal", 2, False)])
+                                            ("cavity", 3, True), ("channel", 2, True), ("cavity_thermal", 2, False), ("radiation_p2", 2, False)])
 def test_navier_stokes_under_several_ranks(gpu, tmp_path, case, world, p2p):
     """Taylor-Hood on several ranks: block-4 matrix on the decomposed CG2 nodes, two-pass assembly of the owned rows,
     FGMRES with reduced multi-dots, halo exchange of the iterate inside the preconditioner, Schur-complement solves on

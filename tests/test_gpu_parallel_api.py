@@ -68,7 +68,7 @@ def _elastic_p2_case():
     return solver
 
 
-def _elastic_case(distributed=False, degree=1, fine=1):
+def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
@@ -85,6 +85,10 @@ def _elastic_case(distributed=False, degree=1, fine=1):
                         'value': Constant((0, 0, 0))}
         bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 10)), 'boundary_id': 2, 'type': 'stress',
                           'value': Constant((1e8, 0, 0))}
+    if pressure_field:      # a pressure that varies over the face (hydrostatic-like): nodal loads worked out on the host
+        ax = 2 if distributed else 0
+        bcs["side"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 1)), 'boundary_id': 3, 'type': 'pressure',
+                       'value': Expression("1e6*(1+0.3*x[%d])" % ax, degree=1)}
     s = copy.deepcopy(SB.default_case_settings)
     s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
                      'thermal_expansion_coefficient': 2e-6}
@@ -157,13 +161,13 @@ def _channel_case(distributed=False):
     return CoupledNavierStokesSolver(s)
 
 
-def _radiation_case():
+def _radiation_case(degree=1):
     """examples/test_heat_transfer.py test_radiation(): radiation to the ambient on every exterior facet and a
     temperature-dependent conductivity, Newton through solve_nonlinear_problem."""
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
-    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 4, 4, 8)
-    Q = FunctionSpace(m, "CG", 1)
+    m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 4, 4, 8) if degree == 1 else BoxMesh(Point(0, 0, 0), Point(1, 1, 2), 3, 3, 6)
+    Q = FunctionSpace(m, "CG", degree)
     bcs = OrderedDict()
     bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
         'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
@@ -184,7 +188,7 @@ def _radiation_case():
 
 
 # cases that do not go through _device_solve (Newton loops, the saddle-point path): no captured (A, b) test
-NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case,
+NS_CASES = {"cavity": _cavity_case, "channel": _channel_case, "radiation": _radiation_case, "radiation_p2": lambda: _radiation_case(2),
             "cavity_thermal": lambda: _cavity_case(transient=False, thermal=True)}
 
 # BoxMesh(distributed=True): every rank builds only its z-slab on the host (one rank: the same mesh as the replicated one)
@@ -194,6 +198,7 @@ DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist":
               "heat_p2_dist": lambda: _heat_case(4, degree=2, distributed=True),
               "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
               "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2),
+              "elasticity_pfield_dist": lambda: _elastic_case(distributed=True, pressure_field=True),
               # Taylor-Hood on the distributed box (round 4): Newton loop, pressure hierarchy and projections on this rank's slab only
               "cavity_dist": lambda: _cavity_case(distributed=True), "channel_dist": lambda: _channel_case(distributed=True)}
 
@@ -212,7 +217,8 @@ def _file_mesh_case(degree=1):
 
 CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=True), "elasticity": _elastic_case,
          # 37 x 7 x 7 nodes: a hierarchy of several levels (the 12 x 2 x 2 beam is a single level)
-         "elasticity_fine": lambda: _elastic_case(fine=3),
+         "elasticity_fine": lambda: _elastic_case(fine=3), "elasticity_pfield": lambda: _elastic_case(pressure_field=True),
+         "elasticity_p2_pfield": lambda: _elastic_case(degree=2, pressure_field=True),
          "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
          "heat_supg": lambda: _heat_case(supg=True), "heat_ip": lambda: _heat_case(ip=True), "heat_ip_cn": lambda: _heat_case(ip=True, transient=True),
          "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
