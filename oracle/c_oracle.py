@@ -41,6 +41,10 @@ def load():
         _lib.orc_free.argtypes = [C.c_void_p]
         _lib.orc_box_mesh.argtypes = [C.c_int64, C.c_int64, C.c_int64, _f64p, _f64p, _f64p, _i32p]
         _lib.orc_assemble_p1.argtypes = [C.c_int64, C.c_int64, _f64p, _i32p, C.c_double, _f64p, _i32p, _i32p, _f64p]
+        _lib.orc_csr_pattern_generic.restype = C.c_int64
+        _lib.orc_csr_pattern_generic.argtypes = [C.c_int64, C.c_int64, C.c_int, _i32p, _i32p, C.POINTER(_i32p)]
+        _lib.orc_assemble_p2.argtypes = [C.c_int64, C.c_int64, _f64p, _i32p, _i32p, C.c_double, _i32p, _i32p, _f64p]
+        _lib.orc_assemble_p1_elasticity.argtypes = [C.c_int64, C.c_int64, _f64p, _i32p, C.c_double, C.c_double, _i32p, _i32p, _f64p]
         _lib.orc_pcg_jacobi.restype = C.c_int
         _lib.orc_pcg_jacobi.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int, _f64p]
     return _lib
@@ -94,6 +98,38 @@ def csr_pattern(n, cells):
     colidx = np.ctypeslib.as_array(out, shape=(nnz,)).copy()
     load().orc_free(out)
     return rowptr, colidx
+
+
+def csr_pattern_generic(n, cell_dofs):
+    """(rowptr, colidx) of a space with cell_dofs [nc, nd] (CG2: 10 nodes; vector CG1: the 12 scalar dofs 3 v + i)."""
+    cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    rowptr = np.empty(n + 1, dtype=np.int32)
+    out = _i32p()
+    nnz = load().orc_csr_pattern_generic(n, cd.shape[0], cd.shape[1], cd.ctypes.data_as(_i32p), rowptr.ctypes.data_as(_i32p), C.byref(out))
+    if nnz < 0:
+        raise ValueError("pattern exceeds 32-bit row pointers")
+    colidx = np.ctypeslib.as_array(out, shape=(nnz,)).copy()
+    load().orc_free(out)
+    return rowptr, colidx
+
+
+def assemble_p2(coords, cells, cell_dofs, k, rowptr, colidx):
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    vals = np.empty(len(colidx))
+    load().orc_assemble_p2(len(rowptr) - 1, len(cells), coords.ctypes.data_as(_f64p), cells.ctypes.data_as(_i32p), cd.ctypes.data_as(_i32p),
+                           float(k), rowptr.ctypes.data_as(_i32p), colidx.ctypes.data_as(_i32p), vals.ctypes.data_as(_f64p))
+    return vals
+
+
+def assemble_p1_elasticity(coords, cells, mu, lmbda, rowptr, colidx):
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    vals = np.empty(len(colidx))
+    load().orc_assemble_p1_elasticity(len(rowptr) - 1, len(cells), coords.ctypes.data_as(_f64p), cells.ctypes.data_as(_i32p), float(mu),
+                                      float(lmbda), rowptr.ctypes.data_as(_i32p), colidx.ctypes.data_as(_i32p), vals.ctypes.data_as(_f64p))
+    return vals
 
 
 def assemble_p1(coords, cells, k, rowptr, colidx):

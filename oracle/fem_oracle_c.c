@@ -120,6 +120,136 @@ int64_t orc_csr_pattern(int64_t n, int64_t nc, const int32_t* cells, int32_t* ro
 
 void orc_free(void* p) { free(p); }
 
+/* The same for a space with nd dofs per cell (cell_dofs[nc][nd]: CG2 = 10 nodes, vector CG1 = 12 scalar dofs): what
+ * DOLFIN's SparsityPatternBuilder gives any dofmap (SolverBase.py:595). */
+int64_t orc_csr_pattern_generic(int64_t n, int64_t nc, int nd, const int32_t* cell_dofs, int32_t* rowptr, int32_t** colidx_out) {
+    int64_t* cnt = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+    for (int64_t c = 0; c < nc; ++c)
+        for (int a = 0; a < nd; ++a) cnt[cell_dofs[nd * c + a] + 1] += nd;
+    for (int64_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    int32_t* tmp = (int32_t*)malloc((size_t)cnt[n] * sizeof(int32_t));
+    int64_t* fill = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+    memcpy(fill, cnt, (size_t)n * sizeof(int64_t));
+    for (int64_t c = 0; c < nc; ++c)
+        for (int a = 0; a < nd; ++a) {
+            const int32_t r = cell_dofs[nd * c + a];
+            for (int b = 0; b < nd; ++b) tmp[fill[r]++] = cell_dofs[nd * c + b];
+        }
+    int64_t* len = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t* row = tmp + cnt[i];
+        const int64_t m = cnt[i + 1] - cnt[i];
+        qsort(row, (size_t)m, sizeof(int32_t), cmp_i32);
+        int64_t u = 0;
+        for (int64_t k = 0; k < m; ++k)
+            if (k == 0 || row[k] != row[k - 1]) row[u++] = row[k];
+        len[i] = u;
+    }
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) total += len[i];
+    if (total >= (int64_t)INT32_MAX) { free(tmp); free(fill); free(len); free(cnt); return -1; }
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) rowptr[i + 1] = rowptr[i] + (int32_t)len[i];
+    const int64_t nnz = rowptr[n];
+    int32_t* colidx = (int32_t*)malloc((size_t)nnz * sizeof(int32_t));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) memcpy(colidx + rowptr[i], tmp + cnt[i], (size_t)len[i] * sizeof(int32_t));
+    free(tmp);
+    free(fill);
+    free(len);
+    free(cnt);
+    *colidx_out = colidx;
+    return nnz;
+}
+
+/* barycentric gradients and volume of one tetrahedron */
+static double tet_gradients(const double* xyz, const int32_t* v, double g[4][3]) {
+    const double* x0 = xyz + 3 * (int64_t)v[0];
+    const double* x1 = xyz + 3 * (int64_t)v[1];
+    const double* x2 = xyz + 3 * (int64_t)v[2];
+    const double* x3 = xyz + 3 * (int64_t)v[3];
+    const double e1[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    const double e2[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
+    const double e3[3] = {x3[0] - x0[0], x3[1] - x0[1], x3[2] - x0[2]};
+    const double c1[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    const double c2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    const double c3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = e1[0] * c1[0] + e1[1] * c1[1] + e1[2] * c1[2];
+    for (int d = 0; d < 3; ++d) {
+        g[1][d] = c1[d] / det;
+        g[2][d] = c2[d] / det;
+        g[3][d] = c3[d] / det;
+        g[0][d] = -(g[1][d] + g[2][d] + g[3][d]);
+    }
+    return fabs(det) / 6.0;
+}
+
+static void add_to_row(const int32_t* rowptr, const int32_t* colidx, double* vals, int32_t r, int32_t col, double v) {
+    int32_t lo = rowptr[r], hi = rowptr[r + 1];
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (colidx[mid] < col) lo = mid + 1; else hi = mid;
+    }
+#pragma omp atomic
+    vals[lo] += v;
+}
+
+/* CG2 stiffness  k inner(grad T, grad q) dx  (ScalarTransportSolver.py:278-281 with fe_degree 2): tabulate_tensor with the
+ * 4-point degree-2 rule FFC picks for the quadratic integrand; local dofs = 4 vertices, then the UFC edges
+ * e0=(2,3) e1=(1,3) e2=(1,2) e3=(0,3) e4=(0,2) e5=(0,1); grad phi_vertex = (4 l - 1) g, grad phi_edge = 4 (l_i g_j + l_j g_i). */
+void orc_assemble_p2(int64_t n, int64_t nc, const double* xyz, const int32_t* cells, const int32_t* cell_dofs, double k,
+                     const int32_t* rowptr, const int32_t* colidx, double* vals) {
+    static const int EI[6] = {2, 1, 1, 0, 0, 0}, EJ[6] = {3, 3, 2, 3, 2, 1};
+    const double qa = 0.5854101966249685, qb = 0.1381966011250105;
+    memset(vals, 0, (size_t)rowptr[n] * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nc; ++c) {
+        double g[4][3];
+        const double vol = tet_gradients(xyz, cells + 4 * c, g);
+        double ke[10][10];
+        memset(ke, 0, sizeof(ke));
+        for (int q = 0; q < 4; ++q) {
+            double l[4] = {qb, qb, qb, qb};
+            l[q] = qa;
+            double gp[10][3];
+            for (int i = 0; i < 4; ++i)
+                for (int d = 0; d < 3; ++d) gp[i][d] = (4.0 * l[i] - 1.0) * g[i][d];
+            for (int e = 0; e < 6; ++e)
+                for (int d = 0; d < 3; ++d) gp[4 + e][d] = 4.0 * (l[EI[e]] * g[EJ[e]][d] + l[EJ[e]] * g[EI[e]][d]);
+            for (int a = 0; a < 10; ++a)
+                for (int b = 0; b < 10; ++b)
+                    ke[a][b] += 0.25 * vol * k * (gp[a][0] * gp[b][0] + gp[a][1] * gp[b][1] + gp[a][2] * gp[b][2]);
+        }
+        const int32_t* d = cell_dofs + 10 * c;
+        for (int a = 0; a < 10; ++a)
+            for (int b = 0; b < 10; ++b) add_to_row(rowptr, colidx, vals, d[a], d[b], ke[a][b]);
+    }
+}
+
+/* Vector CG1 elasticity  inner(sigma(u), eps(v)) dx, sigma = 2 mu eps + lambda tr(eps) I (LinearElasticitySolver.py:152-167):
+ * Ke[(a,i),(b,j)] = V (lambda g_a[i] g_b[j] + mu g_a[j] g_b[i] + mu delta_ij g_a . g_b); scalar dof = 3 * vertex + component. */
+void orc_assemble_p1_elasticity(int64_t n_dofs, int64_t nc, const double* xyz, const int32_t* cells, double mu, double lambda,
+                                const int32_t* rowptr, const int32_t* colidx, double* vals) {
+    memset(vals, 0, (size_t)rowptr[n_dofs] * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nc; ++c) {
+        double g[4][3];
+        const int32_t* v = cells + 4 * c;
+        const double vol = tet_gradients(xyz, v, g);
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const double gg = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) {
+                        const double kij = vol * (lambda * g[a][i] * g[b][j] + mu * g[a][j] * g[b][i] + (i == j ? mu * gg : 0.0));
+                        add_to_row(rowptr, colidx, vals, 3 * v[a] + i, 3 * v[b] + j, kij);
+                    }
+            }
+    }
+}
+
+
 /* tabulate_tensor of  k * inner(grad T, grad q) * dx  on one P1 tetrahedron */
 static void p1_stiffness(const double* xyz, const int32_t* v, double k, double ke[4][4]) {
     const double* x0 = xyz + 3 * (int64_t)v[0];

@@ -316,3 +316,81 @@ def test_config4_p2_against_the_oracle_at_118k_dof(gpu):
     assert np.abs(xd - xo).max() <= 1e-9 * np.abs(xo).max()
     assert np.linalg.norm(Ab @ xd - bb) <= 2e-12 * np.linalg.norm(bb)
     assert np.abs(xd - (350.0 - 50.0 * z)).max() <= 1e-8
+
+
+def test_config3_operator_at_full_size_against_the_c_oracle(gpu):
+    """configs[2] at its FULL size (472 x 59 x 59 box, 5 108 400 DOF, 9.86 M tets) against the C oracle's restatement of DOLFIN's cell
+    loop for inner(sigma(u), eps(v)) dx (oracle/fem_oracle_c.c orc_assemble_p1_elasticity, itself checked against the numpy oracle
+    in the CPU suite): sparsity bit-exact, every stored value <= 1e-12 of the largest; the AMG-PCG solution of the solver path
+    satisfies the ORACLE's constrained system."""
+    from oracle import c_oracle
+    nx, ny, nz = 472, 59, 59
+    E, nu = 2e11, 0.27
+    mu, lm = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+    co, ce = c_oracle.box_mesh(nx, ny, nz, (0, 0, 0), (10.0, 1.0, 1.0))
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0, 0, 0), (10.0, 1.0, 1.0))
+    V = gpu.DeviceSpace(mesh, 3)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(lame=(mu, lm))
+    M = _device_csr(A)
+    cd12 = (ce.astype(np.int64)[:, :, None] * 3 + np.arange(3)).reshape(len(ce), 12).astype(np.int32)
+    rp, ci = c_oracle.csr_pattern_generic(3 * len(co), cd12)
+    assert M.shape[0] == 5108400 and np.array_equal(M.indptr, rp) and np.array_equal(M.indices, ci)
+    vals = c_oracle.assemble_p1_elasticity(co, ce, mu, lm, rp, ci)
+    assert np.abs(M.data - vals).max() <= 1e-12 * np.abs(vals).max()
+    del M
+    # the solve of the solver path against the oracle's operator: clamp x = 0, body force, AMG-PCG
+    b = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b, vector_value=(0.0, 0.0, -7800.0 * 10.0))
+    bo = b.get().copy()
+    nodes = np.arange(len(co))
+    left = nodes[nodes % (nx + 1) == 0]
+    dofs = (left[:, None] * 3 + np.arange(3)).ravel()
+    A.apply_dirichlet(b, dofs, 0.0, symmetric=True)
+    x = gpu.DeviceVector(V.n_local)
+    amg = gpu.AMG(A, nullspace="rigid_body")
+    st = amg.solve(b, x, rtol=1e-10, max_iter=200)
+    assert st["converged"] == 1
+    import scipy.sparse as sp
+    R = sp.csr_matrix((vals, ci, rp), shape=(3 * len(co), 3 * len(co)))
+    xd = x.get()[:V.n_owned]
+    r = R @ xd - bo                      # the unconstrained residual vanishes on the free rows (x = 0 on the clamped ones)
+    r[dofs] = 0.0
+    assert np.abs(xd[dofs]).max() == 0.0
+    # (round-off floor of this residual: entries of 1e11 against displacements of 6e-3 - |A| |x| eps is 7e-8 per row, 0.118 being the
+    # load of a row; measured 3.8e-8 of ||b||)
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(bo)
+    amg.close()
+
+
+def test_config4_operator_at_full_size_against_the_c_oracle(gpu):
+    """configs[3] at its FULL size (unit cube n = 107, CG2, 9 938 375 DOF, 7.35 M tets) against the C oracle's CG2 cell loop (4-point rule,
+    UFC edge order; orc_assemble_p2): node numbering and sparsity bit-exact, every stored value <= 1e-12 of the largest; the Jacobi-PCG
+    solution of the timed path satisfies the oracle's constrained system to the solver's tolerance."""
+    from oracle import c_oracle, fem_oracle as fo
+    n = 107
+    mesh, V, A0, x, st, z = _heat_cube(gpu, n, degree=2, rtol=1e-8)
+    co, ce = c_oracle.box_mesh(n, n, n)
+    # the oracle's own CG2 numbering (edges grouped by index difference, fem_oracle.p2_edge_order), from the connectivity alone
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    assert np.array_equal(V.edges().astype(np.int64), edges.astype(np.int64))
+    ndof = len(co) + len(edges)
+    assert ndof == V.n_owned == (2 * n + 1) ** 3
+    rp, ci = c_oracle.csr_pattern_generic(ndof, cd)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0)
+    M = _device_csr(A)
+    assert np.array_equal(M.indptr, rp) and np.array_equal(M.indices, ci)
+    vals = c_oracle.assemble_p2(co, ce, cd, 20.0, rp, ci)
+    assert np.abs(M.data - vals).max() <= 1e-12 * np.abs(vals).max()
+    del M
+    import scipy.sparse as sp
+    R = sp.csr_matrix((vals, ci, rp), shape=(ndof, ndof))
+    T = x.get()
+    r = R @ T                            # no load: the residual of the free rows is K T
+    fixed = (z == 0.0) | (z == 1.0)
+    r[fixed] = 0.0
+    # ||b|| of the constrained system the solver stopped on: the load the eliminated columns put on the free rows + the Dirichlet rows
+    bnorm = np.sqrt(np.linalg.norm(R[:, np.nonzero(fixed)[0]] @ T[fixed]) ** 2 + (T[fixed] ** 2).sum())
+    assert st["converged"] == 1 and np.linalg.norm(r) <= 2e-8 * bnorm
+    assert np.abs(T - (350.0 - 50.0 * z)).max() <= 2e-3

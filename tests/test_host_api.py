@@ -114,6 +114,28 @@ def test_c_oracle_agrees_with_numpy_oracle():
     assert r["iterations"] == it and np.abs(r["x"] - x).max() < 1e-9
 
 
+def test_c_oracle_p2_and_elasticity_agree_with_numpy_oracle():
+    """The C cell loops the full-size parity tests of configs[2] / configs[3] lean on (orc_assemble_p1_elasticity, orc_assemble_p2,
+    orc_csr_pattern_generic) against the numpy oracle - an independent statement of the same forms (vectorised, other data layout)."""
+    from oracle import c_oracle as co_
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 1.2), 5, 4, 6)
+    cd, edges = fo.p2_cell_dofs(len(co), ce)
+    n = len(co) + len(edges)
+    rp, ci = co_.csr_pattern_generic(n, cd)
+    R = fo.assemble_generic(n, cd, fo.p2_stiffness_local(co, ce, 0.7)).tocsr()
+    R.sort_indices()
+    assert np.array_equal(R.indptr, rp) and np.array_equal(R.indices, ci)
+    assert np.abs(R.data - co_.assemble_p2(co, ce, cd, 0.7, rp, ci)).max() <= 1e-13 * np.abs(R.data).max()
+    E, nu = 2e11, 0.27
+    mu, lam = fo.lame(E, nu)
+    cd12 = (ce.astype(np.int64)[:, :, None] * 3 + np.arange(3)).reshape(len(ce), 12)
+    rp, ci = co_.csr_pattern_generic(3 * len(co), cd12)
+    R = fo.assemble_p1_elasticity(co, ce, E, nu).tocsr()
+    R.sort_indices()
+    assert np.array_equal(R.indptr, rp) and np.array_equal(R.indices, ci)
+    assert np.abs(R.data - co_.assemble_p1_elasticity(co, ce, mu, lam, rp, ci)).max() <= 1e-13 * np.abs(R.data).max()
+
+
 # ---------------------------------------------------------------- C-ABI surface
 def test_library_exports_every_declared_symbol():
     from fenicssolver_amd import _lib
