@@ -872,3 +872,24 @@ def test_viscosity_depending_on_pressure_and_temperature(gpu):
     want = fo.solve_direct(*fo.apply_dirichlet(A, np.zeros(len(mc)), bnd, vals[bnd], False))
     assert np.abs(Tn - want).max() <= 1e-6 * np.abs(want).max()
     assert np.ptp(Tn) > 50.0
+
+
+def test_cavity_first_time_step_against_the_oracle_newton_at_n8(gpu):
+    """BASELINE configs[4] parameters (lid-driven cavity, nu = 0.01, rho = 1, dt = 0.01, backward Euler, Newton) at the largest size the
+    numpy oracle's Newton loop (sparse LU of the 19 652-unknown saddle system per iteration) finishes in about half a minute: n = 8,
+    one time step through the solver class against the oracle's own Newton iteration from the same start."""
+    from fenicssolver_amd.CoupledNavierStokesSolver import CoupledNavierStokesSolver
+    s, mesh = _cavity_settings(8, transient=True, nu=0.01, t_end=0.01 - 1e-9)
+    s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-11}
+    solver = CoupledNavierStokesSolver(s)
+    w = solver.solve().vector().array()
+    assert solver.current_step == 1
+    th, ref, hist = _oracle_cavity(mesh, 0.01, (1.0, 0.0, 0.0), 1, 0.01)
+    assert th.n == 19652 and len(solver.newton_history) <= len(hist) + 1
+    W4, R4 = w.reshape(-1, 4), ref.reshape(-1, 4)
+    assert np.abs(W4[:, :3] - R4[:, :3]).max() <= 1e-6
+    assert np.abs(W4[:th.nv, 3] - R4[:th.nv, 3]).max() <= 1e-4 * max(np.abs(R4[:th.nv, 3]).max(), 1.0)
+    r = ns.residual(th, w, 0.01, 1.0, 100.0, np.zeros(th.n))
+    bn = th.boundary_nodes(lambda x: True)
+    r[np.concatenate([th.velocity_dofs(bn), th.pressure_dofs([0]), th.dummy_dofs()])] = 0.0
+    assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(ns.ns_system(th, w, 0.01, 1.0, 100.0, np.zeros(th.n), None, newton=False)[0] @ w)
