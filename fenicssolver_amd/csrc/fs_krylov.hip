@@ -2141,7 +2141,8 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     if (off || !g_row_dictionary || (A->bs != 1 && A->bs != 3) || sp->n_slices == 0 || sp->n_dia_slices != sp->n_slices || D.gave_up_on == A->serial) return FS_OK;
     // (block rows: finding and verifying the classes costs about 3 ms a solve and the item kernel has a latency floor - measured
     // on the AMG-PCG solve of the cantilever: 91 k DOF 6.5 -> 9.5 ms, 683 k DOF 14.0 -> 12.4 ms, 5.1 M DOF 100 -> 61 ms)
-    if (A->bs == 3 && sp->n_nodes_owned < 150000) return FS_OK;
+    static const int64_t min_nodes3 = getenv("FS_DICT3_MIN_NODES") ? atoll(getenv("FS_DICT3_MIN_NODES")) : 150000;      // (tests lower it)
+    if (A->bs == 3 && sp->n_nodes_owned < min_nodes3) return FS_OK;
     FS_CHECK(dict_structure_build(sp, s));
     if (sp->n_dict_items <= 0) return FS_OK;
     const int nq = A->bs * A->bs;               // values per stored entry (3 x 3 blocks of a vector space: the class rows are [position][9])

@@ -122,6 +122,7 @@ else:
             if "amg_decomposition" in solver.last_solve_stats:
                 extra["amg_decomposition"] = np.array(solver.last_solve_stats["amg_decomposition"])
                 extra["amg_levels"] = np.array(solver.last_solve_stats.get("amg_levels", 0))
+                extra["row_classes"] = np.array(solver.last_solve_stats.get("row_classes", 0))
             if rank == 0:
                 result = dict(x=np.asarray(full).reshape(-1), iterations=solver.last_solve_stats["iterations"], n_local=mesh.num_vertices(), **extra)
     else:
@@ -137,6 +138,7 @@ else:
         if "amg_decomposition" in solver.last_solve_stats:
             extra["amg_decomposition"] = np.array(solver.last_solve_stats["amg_decomposition"])
             extra["amg_levels"] = np.array(solver.last_solve_stats.get("amg_levels", 0))
+            extra["row_classes"] = np.array(solver.last_solve_stats.get("row_classes", 0))
         if rank == 0:
             result = dict(x=u.vector().get_local(), iterations=solver.last_solve_stats["iterations"], **extra)
     parallel.barrier()

@@ -360,3 +360,20 @@ def test_amg_with_a_distributed_fine_level(gpu, tmp_path, case, world):
     assert str(r["amg_decomposition"]) == "distributed" and int(r["amg_levels"]) >= 2
     assert abs(int(r["iterations"]) - its) <= 1
     assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()
+
+
+@pytest.mark.parametrize("case,world", [("elasticity_wide_dist", 2), ("elasticity_wide_dist", 3)])
+def test_block_row_dictionary_on_a_decomposed_fine_level(gpu, tmp_path, case, world):
+    """The 3 x 3 block-row dictionary (k_dict_spmv3) on the rank-local fine level of the distributed AMG: the rows next to a slab's
+    cut reach into the ghost planes behind the owned nodes - other offsets, other plans, same classes machinery.  The size limit
+    of the block form is lifted (FS_DICT3_MIN_NODES=0) so that this small cantilever takes it: same iteration count and
+    displacement as one GPU on the streaming product."""
+    import test_gpu_parallel_api as T
+    one = (T.DIST_CASES if case.endswith("_dist") else T.CASES)[case]()
+    single = one.solve().vector().get_local()
+    its = one.last_solve_stats["iterations"]
+    assert one.last_solve_stats.get("row_classes", 0) == 0
+    r = _run(world, case, tmp_path, FS_DICT3_MIN_NODES="0")
+    assert str(r["amg_decomposition"]) == "distributed" and int(r["row_classes"]) > 0
+    assert abs(int(r["iterations"]) - its) <= 1
+    assert np.abs(r["x"] - single).max() <= 1e-8 * np.abs(single).max()

@@ -68,13 +68,16 @@ def _elastic_p2_case():
     return solver
 
 
-def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False):
+def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False, wide=False):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
     bcs = OrderedDict()
     if distributed:     # slabs are cut along z: the beam lies along z
-        mesh = BoxMesh(Point(0, 0, 0), Point(1, 1, 10), 2 * fine, 2 * fine, 12 * fine, distributed=True)
+        # (wide: mesh lines of 71 nodes, so that every 64-row slice of the operator holds at most one line end - the DIA form the
+        # row dictionary needs)
+        mesh = BoxMesh(Point(0, 0, 0), Point(3, 1, 10), 70, 8, 24, distributed=True) if wide else \
+            BoxMesh(Point(0, 0, 0), Point(1, 1, 10), 2 * fine, 2 * fine, 12 * fine, distributed=True)
         bcs["fixed"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0)), 'boundary_id': 1, 'type': 'Dirichlet',
                         'value': Constant((0, 0, 0))}
         bcs["tensile"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 10)), 'boundary_id': 2, 'type': 'stress',
@@ -199,6 +202,7 @@ DIST_CASES = {"heat_dist": lambda: _heat_case(distributed=True), "heat_cn_dist":
               "heat_p2_cn_dist": lambda: _heat_case(4, transient=True, degree=2, distributed=True),
               "elasticity_p2_dist": lambda: _elastic_case(distributed=True, degree=2),
               "elasticity_pfield_dist": lambda: _elastic_case(distributed=True, pressure_field=True),
+              "elasticity_wide_dist": lambda: _elastic_case(distributed=True, wide=True),
               # Taylor-Hood on the distributed box (round 4): Newton loop, pressure hierarchy and projections on this rank's slab only
               "cavity_dist": lambda: _cavity_case(distributed=True), "channel_dist": lambda: _channel_case(distributed=True)}
 
