@@ -499,6 +499,9 @@ class Watchdog:
 
 
 def kernel_name(V, st=None):
+    if st is not None and st.get("fused_iteration", 0):          # fs_krylov.hip k_dict_cg_iter: one launch per CG iteration
+        return ("k_dict_cg_iter<3> (ONE launch per CG iteration: update of iteration k + row-dictionary product of iteration k + 1, "
+                "%d distinct rows in LDS; the new residual on the neighbour columns recomputed from the old r, w, s)" % st["row_classes"])
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
         # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
         # class rows are 24 doubles per round of the longest run plan: 1 round on P1, 5 on CG2 Kuhn meshes) / per-item class rows
@@ -515,6 +518,7 @@ def kernel_name(V, st=None):
 
 UPDATE_BYTES_PER_DOF = 72      # k_cg_update_scaled, single-reduction scaled CG: reads r, w, p, s, x and writes r, p, s, x
 DICT_BYTES_PER_ROW = 26        # k_dict_spmv: z read (its x gathers are the same array), d read, w written, 2-byte class number
+FUSED_BYTES_PER_ROW = 90       # k_dict_cg_iter: reads r, w, s, p, x, d + 2-byte class number, writes r, w, s, p, x (one launch per iteration)
 
 
 def kernel_rates(st, V):
@@ -527,11 +531,14 @@ def kernel_rates(st, V):
     Time = mean duration of the live launches sampled with HIP events on the library's stream inside the timed solves."""
     ms = st["spmv_ms"]
     dict_on = st.get("row_classes", 0) > 0
-    required = DICT_BYTES_PER_ROW * V.n_owned if dict_on else V.spmv_matrix_bytes + 24 * V.n_owned
+    fused = bool(st.get("fused_iteration", 0))
+    required = (FUSED_BYTES_PER_ROW if fused else DICT_BYTES_PER_ROW) * V.n_owned if dict_on else V.spmv_matrix_bytes + 24 * V.n_owned
     rate = lambda nbytes: round(nbytes / ms / 1e6, 1) if ms > 0 else 0.0
-    return {"kernel": kernel_name(V, st), "avg_launch_ms": round(ms, 5), "row_classes": st.get("row_classes", 0),
+    return {"kernel": kernel_name(V, st), "avg_launch_ms": round(ms, 5), "row_classes": st.get("row_classes", 0), "fused_iteration": int(fused),
             "required_bytes_per_launch": required, "required_GBps": rate(required),
-            "required_bytes_model": ("26 B/row: z, d reads + w write + 2-byte class number (the distinct value rows sit in LDS / L2)" if dict_on else
+            "required_bytes_model": ("90 B/row: the whole iteration in one launch - r, w, s, p, x, d reads + 2-byte class number, r, w, s, p, x writes"
+                                     if fused else
+                                     "26 B/row: z, d reads + w write + 2-byte class number (the distinct value rows sit in LDS / L2)" if dict_on else
                                      "stored values + column indices of SELL slices + 24 B/row (z, d reads + w write); DIA slices carry no column indices"),
             "csr_equivalent_bytes_per_launch": st["spmv_bytes"], "csr_equivalent_GBps": rate(st["spmv_bytes"]),
             "dia_slices": V.n_dia_slices, "slices": V.n_slices}
@@ -539,6 +546,9 @@ def kernel_rates(st, V):
 
 def update_rates(st, n_rows):
     """The fused vector update of the CG iteration: 72 B per row, nothing to compress."""
+    if st.get("fused_iteration", 0):
+        return {"kernel": "none: the update is part of k_dict_cg_iter (one launch per iteration)", "avg_launch_ms": 0.0,
+                "required_bytes_per_launch": 0, "required_GBps": 0.0, "frac": None}
     ms = st["update_ms"]
     nbytes = UPDATE_BYTES_PER_DOF * n_rows
     gbps = nbytes / ms / 1e6 if ms > 0 else 0.0
@@ -549,11 +559,13 @@ def update_rates(st, n_rows):
 def iteration_rates(st, k, n_rows):
     """One whole CG iteration (product + update + launch gaps) against the bytes its two kernels have to move."""
     ms = st["solve_ms"] / max(st["iterations"], 1)
-    nbytes = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * n_rows
+    fused = bool(k.get("fused_iteration", 0))
+    nbytes = k["required_bytes_per_launch"] + (0 if fused else UPDATE_BYTES_PER_DOF * n_rows)
     gbps = nbytes / ms / 1e6 if ms > 0 else 0.0
     return {"required_bytes": nbytes, "bytes_per_dof": round(nbytes / float(n_rows), 1), "ms": round(ms, 5), "GBps": round(gbps, 1),
             "frac": round(gbps / HBM_PEAK_GBS, 3), "what": "solve_ms / iterations (host clock around the whole solve: products, updates, "
-            "launch gaps, convergence polls) against required bytes of the product + 72 B/row of the update"}
+            "launch gaps, convergence polls) against " + ("the 90 B/row of the one-launch iteration" if fused else
+                                                          "required bytes of the product + 72 B/row of the update")}
 
 
 def committed_traffic(tag):

@@ -1377,6 +1377,232 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     }
 }
 
+// ---- ONE launch per CG iteration (row-dictionary operators, one GPU) ------------------------------------------------------------
+// Launch k does the update of iteration k AND the product of iteration k + 1:
+//      s_k = w_k + beta_k s_{k-1};   r_{k+1} = r_k - alpha_k s_k;   p_k = r_k + beta_k p_{k-1};   x_{k+1} = x_k + alpha_k p_k
+//      w_{k+1} = A r_{k+1}   with the three sums (r.r, w.r, sum d r^2) of the new pair
+// The product needs r_{k+1} on the NEIGHBOUR rows, which other workgroups own: instead of waiting for them (a device-wide barrier
+// costs 8 us on the 8 XCDs of gfx950, DESIGN history) every lane recomputes r_{k+1}[j] = r_k[j] - alpha (w_k[j] + beta s_{k-1}[j])
+// for the columns its runs touch - the same two fmas the owner applies, hence the same bits - from the OLD r, w, s, which are
+// read-only during the launch: r, w, s are double-buffered by iteration parity, p and x are row-local and stay in place.  alpha_k,
+// beta_k come from the dot partials launch k - 1 left (summed by every workgroup, as k_cg_update_scaled does).
+// Per row: reads r, w, s (neighbour values from L1 / L2), p, x, d, the 2-byte class; writes r, w, s, p, x = 90 B instead of the
+// 98 B and two launches of k_dict_spmv + k_cg_update_scaled; 3 x 3.5 vector loads per row for the runs instead of 3.5.
+// The iteration number travels on the device (it_ctr[par] read by everybody, it_ctr[par ^ 1] = iter + 1 written by one lane) so
+// that a captured batch replays with constant arguments; par = parity of the launch = which buffers are `old`.
+// Whole dictionary in LDS only (P1 boxes: the operators whose iteration is launch-bound).
+// Measured on MI355X (tools/probes/fused_iter_probe.py, hipGraph batches): 1 M rows: 27.4 us per iteration against 29.9 us for
+// the two launches, iterates BIT-IDENTICAL (the same fmas on the same operands, the same partial-sum geometry); 10 M rows: 285 us
+// against 187 us - with ONE neighbour vector instead of three (timing ablation, wrong numerics) still 220 us: the row-local
+// streams (5 loads, 5 stores per row) reach 4.1 TB/s inside an item-by-item kernel against the 6.5 TB/s of the grid-stride update
+// kernel, and three vectors x three mesh planes no longer fit the 4 MB L2 of an XCD.  Hence automatic only where the vectors
+// stay in the Infinity Cache (FS_CG_FUSED_MAX_ROWS, default 3 M rows).
+template <int RL>
+__global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
+                                                           const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
+                                                           const double* __restrict__ dict, int S, int C,
+                                                           const double* __restrict__ r_in, const double* __restrict__ w_in,
+                                                           const double* __restrict__ s_in, double* __restrict__ r_out,
+                                                           double* __restrict__ w_out, double* __restrict__ s_out,
+                                                           double* __restrict__ pv, double* __restrict__ xv, const double* __restrict__ dvec,
+                                                           const double* __restrict__ part_in, double* __restrict__ part_out, int npart,
+                                                           const double* __restrict__ ctrl, double* __restrict__ scal, int* __restrict__ status,
+                                                           int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd) {
+    if (status[0] != 0) return;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
+    extern __shared__ double sdict[];
+    __shared__ double lds4[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int iter = it_ctr[par];
+    const int64_t n_chunks = (n_items + 3) / 4;
+    const int32_t cmax = (int32_t)(n_cols - 1);
+    chunk_iter it = xcd_chunks(n_chunks);
+    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
+    struct item_hdr { int32_t first; int nr, edge, rounds; const dict_plan_round* pl; };
+    auto decode = [&](int64_t q) {
+        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
+        item_hdr H;
+        H.first = __builtin_amdgcn_readfirstlane(ds.x);
+        H.nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
+        H.edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
+        H.pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
+        H.rounds = __builtin_amdgcn_readfirstlane(ds.w);
+        return H;
+    };
+    // loads of runs [4 h, 4 h + 4) of round rd: scalar base (vector + run start) + one 32-bit byte offset per lane - the `saddr` form
+    // of the load, no 64-bit address arithmetic or address registers per load (rows < 2^29)
+    auto load_half = [&](const item_hdr& H, int rd, int h, uint32_t boff, v2d (&A)[4], v2d (&Wb)[4], v2d (&Sb)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t st = __builtin_amdgcn_readfirstlane(H.pl[rd].start[4 * h + j]);
+            A[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(r_in + st) + boff);
+            Wb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(w_in + st) + boff);
+            Sb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(s_in + st) + boff);
+        }
+    };
+    auto load_own = [&](const item_hdr& H, v2d& pp, v2d& xx, v2d& dd) {
+        const int32_t r = H.first + 2 * lane;
+        pp = xx = dd = v2d{0.0, 0.0};
+        if (2 * lane + 1 < H.nr) {
+            pp = *reinterpret_cast<const v2du*>(&pv[r]);
+            xx = *reinterpret_cast<const v2du*>(&xv[r]);
+            dd = *reinterpret_cast<const v2du*>(&dvec[r]);
+        } else if (2 * lane < H.nr) { pp.x = pv[r]; xx.x = xv[r]; dd.x = dvec[r]; }
+    };
+    // Nothing the first item LOADS depends on alpha, beta: its first twelve run loads and its row-local operands are asked for
+    // before the partial sums are reduced (a wave has about two items at 1 M rows; 35.3 -> 27.4 us per iteration with 1024 workgroups)
+    item_hdr H0 = {};
+    v2d PA[4], PW[4], PS[4], Ppp = {0.0, 0.0}, Pxx = {0.0, 0.0}, Pdd = {0.0, 0.0};
+    const bool have0 = it.cur < it.end && it.cur * 4 + wave < n_items;
+    if (have0) {
+        H0 = decode(it.cur * 4 + wave);
+        if (!H0.edge) load_half(H0, 0, 0, (uint32_t)(H0.first + 2 * lane) * 8u, PA, PW, PS);
+        load_own(H0, Ppp, Pxx, Pdd);
+    }
+    for (int i = threadIdx.x; i < C * S; i += FS_BLOCK) sdict[i] = dict[i];      // (visible after the barriers of the sum below)
+    double sm[3];
+    wg_sum_partials<3>(part_in, npart, sm);
+    const double gamma = sm[0], delta = sm[1], rho = sm[2];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    if (leader) hist[iter] = rho;
+    if (rho <= ctrl[0]) {                       // every workgroup takes the same branch: the inputs are identical
+        if (leader) { status[1] = iter; status[0] = 1; }
+        return;
+    }
+    if (iter >= (int)ctrl[2]) {
+        if (leader) { status[1] = iter; status[0] = 3; }
+        return;
+    }
+    double beta, alpha;
+    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
+        if (leader) { status[1] = iter; status[0] = 2; }
+        return;
+    }
+    if (leader) {
+        scal[2 * (iter & 1) + 0] = gamma;
+        scal[2 * (iter & 1) + 1] = alpha;
+        it_ctr[par ^ 1] = iter + 1;
+    }
+    const double nalpha = -alpha;
+    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
+    // PRE: this item's first half round and row-local operands were loaded before the prologue
+    auto do_item = [&](const item_hdr& H, auto pre_tag) {
+        constexpr bool PRE = decltype(pre_tag)::value;
+        const int32_t r = H.first + 2 * lane;
+        const bool ok0 = 2 * lane < H.nr, ok1 = 2 * lane + 1 < H.nr;
+        int c0 = -1, c1 = -1;
+        if ((H.first & 1) == 0) {
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
+            if (ok0) c0 = (int)(two & 0xffffu);
+            if (ok1) c1 = (int)(two >> 16);
+        } else {
+            if (ok0) c0 = (int)cls[r];
+            if (ok1) c1 = (int)cls[r + 1];
+        }
+        v2d sn0 = {0.0, 0.0}, ro0 = {0.0, 0.0};
+        v2d pp, xx, dd;
+        if (PRE) { pp = Ppp; xx = Pxx; dd = Pdd; }
+        else load_own(H, pp, xx, dd);
+        const double* __restrict__ v0 = sdict + (ok0 ? c0 * S : 0);
+        const double* __restrict__ v1 = sdict + (ok1 ? c1 * S : 0);
+        double a0 = 0.0, a1 = 0.0;
+        v2d zi = {0.0, 0.0};
+        // one run: its terms in ascending offsets, one fma each (the order and the bits of k_dict_spmv)
+        auto run_terms = [&](v2d rn, const double* __restrict__ w0, const double* __restrict__ w1) {
+            const double e0 = rn.x, e1 = rn.y;
+            const double e2 = fs_from_next_lane(rn.x);
+            a0 = fma(w0[0], e0, a0); a1 = fma(w1[0], e1, a1);
+            a0 = fma(w0[1], e1, a0); a1 = fma(w1[1], e2, a1);
+            if (RL == 3) {
+                const double e3 = fs_from_next_lane(rn.y);
+                a0 = fma(w0[2], e2, a0); a1 = fma(w1[2], e3, a1);
+            }
+        };
+        if (!H.edge) {
+            const uint32_t boff = (uint32_t)r * 8u;
+            for (int rd = 0; rd < H.rounds; ++rd) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v2d A[4], Wb[4], Sb[4];
+                    if (PRE && h == 0) {
+                        if (rd == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { A[j] = PA[j]; Wb[j] = PW[j]; Sb[j] = PS[j]; }
+                        } else load_half(H, rd, h, boff, A, Wb, Sb);
+                    } else load_half(H, rd, h, boff, A, Wb, Sb);
+                    // the new r on these columns: r - alpha (w + beta s), two fmas per value - the owner's operations, the owner's bits
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2d sn;
+                        sn.x = fma(beta, Sb[j].x, Wb[j].x); sn.y = fma(beta, Sb[j].y, Wb[j].y);
+                        if (h == 0 && j == 0 && rd == 0) { sn0 = sn; ro0 = A[0]; }
+                        A[j].x = fma(nalpha, sn.x, A[j].x); A[j].y = fma(nalpha, sn.y, A[j].y);
+                    }
+                    if (h == 0 && rd == 0) zi = A[0];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        run_terms(A[j], v0 + RL * (8 * rd + 4 * h + j), v1 + RL * (8 * rd + 4 * h + j));
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+        } else {
+            // items whose loads could leave [0, n_cols) (first / last mesh plane; 1.4 % of the rows at 10 M): run by run, each value
+            // clamped into the vector (a column outside it has a zero coefficient)
+            const int n_runs = 8 * H.rounds;
+#pragma unroll 1
+            for (int g = 0; g < n_runs; ++g) {
+                const int32_t c = r + __builtin_amdgcn_readfirstlane(H.pl[g >> 3].start[g & 7]);
+                const int32_t ca = c < 0 ? 0 : (c > cmax ? cmax : c), cb = c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1);
+                v2d rn, sn;
+                sn.x = fma(beta, s_in[ca], w_in[ca]); sn.y = fma(beta, s_in[cb], w_in[cb]);
+                const double ra = r_in[ca], rb = r_in[cb];
+                if (g == 0) { sn0 = sn; ro0.x = ra; ro0.y = rb; }
+                rn.x = fma(nalpha, sn.x, ra); rn.y = fma(nalpha, sn.y, rb);
+                if (g == 0) zi = rn;
+                run_terms(rn, v0 + RL * g, v1 + RL * g);
+            }
+        }
+        // own rows: p, x, and the new s, r, w
+        v2d pn, xn;
+        pn.x = fma(beta, pp.x, ro0.x); pn.y = fma(beta, pp.y, ro0.y);
+        xn.x = fma(alpha, pn.x, xx.x); xn.y = fma(alpha, pn.y, xx.y);
+        if (ok1) {
+            v2d out;
+            out.x = a0; out.y = a1;
+            *reinterpret_cast<v2du*>(&w_out[r]) = out;
+            *reinterpret_cast<v2du*>(&r_out[r]) = zi;
+            *reinterpret_cast<v2du*>(&s_out[r]) = sn0;
+            *reinterpret_cast<v2du*>(&pv[r]) = pn;
+            *reinterpret_cast<v2du*>(&xv[r]) = xn;
+        } else if (ok0) {
+            w_out[r] = a0; r_out[r] = zi.x; s_out[r] = sn0.x; pv[r] = pn.x; xv[r] = xn.x;
+        }
+        if (!ok0) { a0 = 0.0; zi.x = 0.0; }
+        if (!ok1) { a1 = 0.0; zi.y = 0.0; }
+        d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += dd.x * zi.x * zi.x + dd.y * zi.y * zi.y;
+    };
+    if (have0) {
+        do_item(H0, std::true_type{});
+        it.cur += it.step;
+    }
+    for (; it.cur < it.end; it.cur += it.step) {
+        const int64_t q = it.cur * 4 + wave;
+        if (q >= n_items) break;
+        do_item(decode(q), std::false_type{});
+    }
+    const double t0 = fs_block_sum(d_rz, lds4);
+    const double t1 = fs_block_sum(d_wz, lds4);
+    const double t2 = fs_block_sum(d_rr, lds4);
+    if (threadIdx.x == 0) {
+        part_out[blockIdx.x] = t0;
+        part_out[npart + blockIdx.x] = t1;
+        part_out[2 * npart + blockIdx.x] = t2;
+    }
+}
+
 // The same update on the rows [0, a) and [b, n) only - the rows a slab sends to its neighbours - so that the halo
 // exchange of the new r can start before the bulk of the update and the interior product are even launched (several
 // GPUs: sums from the all-reduce).  No side effects: status, history and the scalars are written by the launch on the
@@ -1759,6 +1985,7 @@ static int g_cg_batch = 32;
 static int g_cg_fuse_sums = 1;
 static int g_cg_graph = -1;      // -1: automatic (graphs, unless a profiler's tool library is in the process)
 static int g_update_blocks = 1024;  // (round 3, with the 16 us row-dictionary product at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 10.59 / 10.42 / 10.20 / 10.12 / 11.22 ms per step; 10 M rows: flat)
+static int g_cg_fused = -1;      // one launch per CG iteration on row-dictionary operators: -1 automatic, 0 never, 1 wherever it applies
 static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
 
 extern "C" int fs_set_option(const char* name, double value) {
@@ -1778,6 +2005,8 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_cg_fuse_sums = value != 0.0;
     } else if (!strcmp(name, "cg_graph")) {
         g_cg_graph = value < 0.0 ? -1 : (value != 0.0);
+    } else if (!strcmp(name, "cg_fused")) {
+        g_cg_fused = value < 0.0 ? -1 : (value != 0.0);
     } else if (!strcmp(name, "update_blocks")) {
         FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
         g_update_blocks = (int)value;
@@ -2565,6 +2794,13 @@ struct krylov_ws {
     hipGraphExec_t cg_graph = nullptr;
     const void* cg_key[24] = {};
     int64_t cg_key_i[8] = {};
+    // one-launch iteration (k_dict_cg_iter): the second set of r, w, s (double-buffered by iteration parity), the iteration
+    // counters of the device, its own captured batch
+    dbuf<double> z2, w2, s2;
+    dbuf<int> it_ctr;
+    hipGraphExec_t cgf_graph = nullptr;
+    const void* cgf_key[24] = {};
+    int64_t cgf_key_i[8] = {};
 };
 static krylov_ws g_ws;
 
@@ -2718,6 +2954,24 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             FS_CHECK(dict_build(A, aval, s));       // a handful of distinct rows (uniform box, constant coefficient)?
             sgrid = spmv_partials(sp, bs);          // (the row-dictionary product has its own launch geometry)
         }
+    }
+    // One launch per iteration (k_dict_cg_iter) where the product is the row-dictionary kernel with the whole dictionary in LDS,
+    // on one GPU.  Automatic mode: FS_CG_FUSED_MAX_ROWS rows at most (the neighbour values of three vectors instead of one have
+    // to stay in the L2 of an XCD; measured crossover in DESIGN.md section 3).
+    static const char* fused_env = getenv("FS_CG_FUSED");
+    static const int64_t fused_max_rows = getenv("FS_CG_FUSED_MAX_ROWS") ? atoll(getenv("FS_CG_FUSED_MAX_ROWS")) : (int64_t)3000000;
+    const int fused_opt = fused_env ? atoi(fused_env) : g_cg_fused;
+    const bool fused = ds && !pipelined && fuse_sums && !sp->halo.active && bs == 1 && fused_opt != 0 &&
+                       g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
+                       (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
+                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && nl < ((int64_t)1 << 29) && (fused_opt > 0 || n <= fused_max_rows);
+    if (fused) {
+        if (ws.z2.n != nl + 2) FS_CHECK(ws.z2.alloc(nl + 2));
+        if (ws.w2.n != n + 2) {
+            FS_CHECK(ws.w2.alloc(n + 2));
+            FS_CHECK(ws.s2.alloc(n + 2));
+        }
+        if (!ws.it_ctr.p) FS_CHECK(ws.it_ctr.alloc(2));
     }
     // A pass = fresh recurrences from the current x.  The single-reduction recurrences drift on
     // ill-conditioned operators (the recurrence residual can reach the threshold while b - A x has not):
@@ -2885,10 +3139,67 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // same way; the RCCL iteration is not - ncclSend / ncclRecv / ncclAllReduce are host calls)
         // (automatic mode: every size - the launch gaps are 10 % of an iteration at 1 M rows and still 1.5 % at 10 M)
         const bool graph_sized = graph_mode != 0;
-        const bool use_graph = ds && !bicg && !pipelined && graph_sized &&
+        const bool use_graph = ds && !bicg && !pipelined && graph_sized && !fused &&
                                ((fuse_sums && !sp->halo.active && bs == 1) || p2p_fuse);
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
+            if (fused) {
+                // launch k = update k + product k + 1; buffers [k & 1] are read, [(k + 1) & 1] written
+                double* const Z[2] = {ws.z.p, ws.z2.p};
+                double* const W[2] = {ws.w.p, ws.w2.p};
+                double* const SV[2] = {ws.s.p, ws.s2.p};
+                double* const PT[2] = {ws.partials.p, ws.partials.p + 3 * (int64_t)sgrid};
+                const size_t lds = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
+                const bool rl2 = sp->dict_run_len == 2;
+                auto launch_iter = [&](int par) {
+#define FS_ITER_ARGS dim3(sgrid), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
+                     reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.ncls, \
+                     Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], sgrid, \
+                     ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd()
+                    if (rl2) hipLaunchKernelGGL((k_dict_cg_iter<2>), FS_ITER_ARGS);
+                    else hipLaunchKernelGGL((k_dict_cg_iter<3>), FS_ITER_ARGS);
+#undef FS_ITER_ARGS
+                };
+                if (k == 0) {
+                    // product 0 (w_0 = A r_0 and its sums) by the plain product kernel; s_{-1} = p_{-1} = 0 were set above
+                    FS_CHECK(ws.it_ctr.zero(s));
+                    launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
+                }
+                if (graph_sized && k >= batch && kend - k == batch && kend <= max_iter && (batch & 1) == 0 && (k & 1) == 0) {
+                    const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
+                                           ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
+                                           ws.ctrl.p, ws.scal.p};
+                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (rl2 ? 1 : 0), batch, sgrid, (int64_t)dict_map_xcd(),
+                                              (int64_t)sp->n_dict_items, (int64_t)A->serial, (int64_t)sp->serial};
+                    if (!ws.cgf_graph || memcmp(key, ws.cgf_key, sizeof(key)) || memcmp(key_i, ws.cgf_key_i, sizeof(key_i))) {
+                        if (ws.cgf_graph) { (void)hipGraphExecDestroy(ws.cgf_graph); ws.cgf_graph = nullptr; }
+                        hipGraph_t graph = nullptr;
+                        FS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                        for (int i = 0; i < batch; ++i) launch_iter(i & 1);
+                        FS_HIP(hipStreamEndCapture(s, &graph));
+                        FS_HIP(hipGraphInstantiate(&ws.cgf_graph, graph, nullptr, nullptr, 0));
+                        (void)hipGraphDestroy(graph);
+                        memcpy(ws.cgf_key, key, sizeof(key));
+                        memcpy(ws.cgf_key_i, key_i, sizeof(key_i));
+                    }
+                    FS_HIP(hipGraphLaunch(ws.cgf_graph, s));
+                    k = kend;
+                }
+                for (; k < kend; ++k) {
+                    const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
+                    if (sample) {
+                        ws.sample_iter[n_samples] = k;
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
+                    }
+                    launch_iter(k & 1);
+                    if (sample) {
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][1], s));
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
+                        FS_HIP(hipEventRecord(ws.ev[n_samples][3], s));
+                        ++n_samples;
+                    }
+                }
+            }
             if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
                 // everything the captured launches bake in: the vectors of the workspace, the operator's value and
                 // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
@@ -3190,6 +3501,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         }
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
         stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
+        stats->fused_iteration = fused ? 1 : 0;
+        if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {
         fs_set_error("fs_krylov_solve: %s breakdown at iteration %d (operator not SPD / rho = 0 / NaN)", bicg ? "BiCGStab" : "CG", iters);

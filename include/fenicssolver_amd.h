@@ -69,7 +69,8 @@ const char* fs_version(void);
  * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll),
  * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
  * "update_blocks" (grid of the fused vector-update kernel), "cg_graph" (-1 / 0 / 1: CG batches as hipGraphs by size /
- * never / always), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes),
+ * never / always), "cg_fused" (-1 / 0 / 1: ONE launch per CG iteration on row-dictionary operators - up to 3 M rows /
+ * never / wherever it applies; fs_krylov_stats.fused_iteration), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes),
  * "box_snap" (0 / 1: box meshes snap their edge vectors to the grid spacing so that equal stencils are equal bit for bit). */
 int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
@@ -351,6 +352,8 @@ typedef struct fs_krylov_stats {
     int row_classes;        /* > 0: the product ran in row-dictionary form with this many distinct rows (the operator of a uniform
                              * box mesh with constant coefficients: class numbers + the distinct rows in LDS instead of the value
                              * stream, verified bit for bit against the assembled values); 0: the streaming kernels */
+    int fused_iteration;    /* 1: every CG iteration was ONE launch (update of iteration k + product of iteration k + 1 on a
+                             * row-dictionary operator; spmv_ms is then the duration of that launch and update_ms 0) */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,

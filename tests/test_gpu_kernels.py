@@ -924,3 +924,39 @@ def test_row_dictionary_buffers_may_move_between_solves(gpu):
     x = gpu.DeviceVector(V.n_local)
     st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
     assert st["iterations"] == st_small["iterations"] and np.array_equal(x.get()[:V.n_owned], x_small)
+
+
+@pytest.mark.parametrize("n,rtol", [(12, 1e-8), (24, 1e-10), (40, 1e-12)])
+def test_one_launch_cg_iteration_is_the_two_launch_iteration_bit_for_bit(gpu, n, rtol):
+    """k_dict_cg_iter (fs_krylov.hip): launch k = update of iteration k + product of iteration k + 1, the new residual on the
+    neighbour columns recomputed from the old r, w, s with the owner's two fmas.  Same operations on the same operands, same
+    partial-sum geometry: iteration count, residual history and solution EQUAL the two-launch iteration's, bit for bit - through
+    the plain launches of the first batch, the captured batches after it (n = 40: more than 64 iterations), and a restart from a
+    nonzero guess; and both are the oracle's Jacobi-PCG."""
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    P, V, A, b = _box_system(gpu, mesh, n, mass=0.7 if n == 24 else None)
+    got = {}
+    try:
+        for fused in (1, 0):
+            gpu.set_option("cg_fused", fused)
+            x = gpu.DeviceVector(V.n_local)
+            st = gpu.krylov_solve(A, b, x, rtol=rtol, max_iter=5000)
+            hist = gpu.krylov_history()
+            # continue from a perturbed solution (nonzero guess: the first product of the pass is the plain kernel's)
+            x1 = x.get().copy()
+            x1[:V.n_owned] *= 1.0 + 1e-3 * np.cos(np.arange(V.n_owned))
+            xg = gpu.DeviceVector(V.n_local)
+            xg.set(x1)
+            st2 = gpu.krylov_solve(A, b, xg, rtol=rtol, max_iter=5000, nonzero_guess=True)
+            got[fused] = (st, x.get()[:V.n_owned].copy(), np.array(hist), st2, xg.get()[:V.n_owned].copy())
+    finally:
+        gpu.set_option("cg_fused", -1)
+    (s1, x1, h1, r1, y1), (s0, x0, h0, r0, y0) = got[1], got[0]
+    assert s1["fused_iteration"] == 1 and s0["fused_iteration"] == 0 and s1["row_classes"] > 0
+    assert s1["converged"] == 1 and s1["iterations"] == s0["iterations"] and (n < 40 or s1["iterations"] > 64)
+    assert np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    assert r1["iterations"] == r0["iterations"] and np.array_equal(y1, y0) and r1["fused_iteration"] == 1
+    rp, ci, va, shape = A.to_csr()                  # (the constrained operator the solves ran on)
+    xo, ito, _ = fo.pcg_jacobi_single_reduction(sp.csr_matrix((va, ci, rp), shape=shape), b.get()[:shape[0]], rtol=rtol)
+    assert abs(s1["iterations"] - ito) <= 1
+    assert np.abs(x1 - xo).max() <= 1e-7 * np.abs(xo).max()
