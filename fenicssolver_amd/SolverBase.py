@@ -435,6 +435,8 @@ class SolverBase():
                                 label, stats['true_rel_residual'], stats['iterations'], rtol)
         per = u.function_space().periodic_pairs() if hasattr(u.function_space(), 'periodic_pairs') else None
         if per is not None:
+            if loc is not None and hasattr(loc, 'tied_pairs'):      # decomposed: the local pairs (the slave rows live with their masters)
+                per = loc.tied_pairs(per[0], per[1])
             x.assign_entries(per[0], per[1], block=u.function_space()._ncomp)
         if loc is None:
             u.vector()._adopt_device(x)         # stays in HBM; the host copy is fetched when somebody looks at it
@@ -714,6 +716,8 @@ class SolverBase():
             raise SolverError('unknown form specification {}'.format(type(F)))
         per = F.space.periodic_pairs() if hasattr(F.space, 'periodic_pairs') else None
         if per is not None and tie:
+            if loc is not None and hasattr(loc, 'tied_pairs'):
+                per = loc.tied_pairs(per[0], per[1])
             A.tie_nodes(b, per[0], per[1])          # before the Dirichlet rows, as DOLFIN's dofmap has no slave dofs at all
         dofs, vals = self._bc_arrays(bcs)
         if loc is not None and dofs.size:
@@ -759,6 +763,8 @@ class SolverBase():
             T[gdofs] = gvals                                # the first iterate carries the boundary values
         if per is not None:
             T[per[0]] = T[per[1]]                           # ... and is periodic
+        # (several GPUs: the iterate above is the global host array; the device works on this rank's pairs)
+        per_dev = per if per is None or loc is None or not hasattr(loc, 'tied_pairs') else loc.tied_pairs(per[0], per[1])
         dofs = gdofs if loc is None else loc.dofs(gdofs, gvals)[0]
         own = dofs[dofs < n]
         ext = self.mesh.facets()[self.mesh.exterior_facets()]
@@ -810,7 +816,7 @@ class SolverBase():
                 # slave rows, r <- P^T r with zeros on the slaves), so the Jacobian's boundary term goes in first
                 if F.radiation is not None:
                     A.add_facet_mass(ext_dev, (4.0 * m_ * Tf ** 3)[ext_mask])
-                A.tie_nodes(r, per[0], per[1])
+                A.tie_nodes(r, per_dev[0], per_dev[1])
             if own.size:
                 backend.set_dirichlet_values(r, own, 0.0)           # residual of constrained rows is zero
             rn2 = float(r.dot(r))
@@ -840,7 +846,7 @@ class SolverBase():
             if stats['converged'] != 1:
                 raise SolverError('Newton step {}: Krylov solver did not converge'.format(it))
             if per is not None:
-                delta.assign_entries(per[0], per[1])                # the slaves move with their masters
+                delta.assign_entries(per_dev[0], per_dev[1])        # the slaves move with their masters
             d = delta.get()[:n]
             if loc is not None:
                 d = parallel.gather_owned(d, loc.owned_gids(), loc.n_global, 1)
@@ -1180,12 +1186,16 @@ class SolverBase():
                 cache['mesh'] = backend.DeviceMesh.box(nx, ny, nz, p0, p1)
             else:
                 cache['mesh'] = backend.DeviceMesh(mesh.coordinates(), mesh.cells())
-        skey = ('space', nc, W.degree())
+        per = W.periodic_pairs() if hasattr(W, 'periodic_pairs') else None
+        skey = ('space', nc, W.degree(), per is not None)
         if skey not in cache:
-            cache[skey] = backend.DeviceSpace(cache['mesh'], nc, W.degree())
+            # (a periodic space: the hierarchy is the FOLDED operator's - pattern with the master / neighbour-of-slave couplings)
+            cache[skey] = backend.DeviceSpace(cache['mesh'], nc, W.degree(), coupled_pairs=None if per is None else W._periodic_couplings())
         Vg = cache[skey]
         Ag = backend.DeviceMatrix(Vg)
         Ag.assemble(lame=(F.mu, F.lmbda))
+        if per is not None:
+            Ag.tie_nodes(None, per[0], per[1])
         dofs, vals = self._bc_arrays(bcs)
         if getattr(loc, 'is_local_view', False):
             # the Dirichlet lists of a distributed mesh are local: owned entries -> global dofs, gathered over the ranks

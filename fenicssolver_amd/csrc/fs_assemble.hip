@@ -2165,7 +2165,8 @@ __global__ void k_tie_rows(int64_t n_pairs, const int32_t* __restrict__ slaves, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < n_pairs; t += stride) {
         const int64_t sl = slaves[t], ma = masters[t];
-        if (sl >= n_rows || ma >= n_rows) { atomicAdd(err, 1); continue; }
+        if (sl >= n_rows) continue;           // a ghost slave (decomposed space): its row lives with its master, on another rank
+        if (ma >= n_rows) { atomicAdd(err, 1); continue; }
         const int64_t sp_s = slice_ptr[sl >> 6], sp_m = slice_ptr[ma >> 6];
         const int w_s = (int)((slice_ptr[(sl >> 6) + 1] - sp_s) >> 6), w_m = (int)((slice_ptr[(ma >> 6) + 1] - sp_m) >> 6);
         const int64_t base_s = sp_s + (sl & 63), base_m = sp_m + (ma & 63);
@@ -2210,12 +2211,15 @@ extern "C" int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs
     FS_REQUIRE(A && (n_pairs == 0 || (slaves && masters)), "fs_matrix_tie_nodes: null pointer");
     if (n_pairs == 0) return FS_OK;
     fs_space_s* sp = A->space;
-    FS_REQUIRE(!sp->halo.active, "fs_matrix_tie_nodes: tied nodes are built for one GPU");
     FS_REQUIRE(A->bs >= 1 && A->bs <= 4, "fs_matrix_tie_nodes: block size %d", A->bs);
     FS_REQUIRE(!b || b->d.n >= sp->n_dofs_owned, "fs_matrix_tie_nodes: right-hand side too short");
+    // Decomposed spaces: local node numbers, ghosts included.  The COLUMNS of every local slave fold onto its (local) master in
+    // the rows this rank owns; the ROW of a slave folds where the slave is owned - its master must be owned by the same rank
+    // (the partition gives a slave its master's rank, partition.build_local_part(tied=...)).
     for (int64_t i = 0; i < n_pairs; ++i)
-        FS_REQUIRE(slaves[i] >= 0 && slaves[i] < sp->n_nodes_owned && masters[i] >= 0 && masters[i] < sp->n_nodes_owned && slaves[i] != masters[i],
-                   "fs_matrix_tie_nodes: pair %lld (%d -> %d) out of range", (long long)i, slaves[i], masters[i]);
+        FS_REQUIRE(slaves[i] >= 0 && slaves[i] < sp->n_nodes_local && masters[i] >= 0 && masters[i] < sp->n_nodes_local && slaves[i] != masters[i] &&
+                   (slaves[i] >= sp->n_nodes_owned || masters[i] < sp->n_nodes_owned),
+                   "fs_matrix_tie_nodes: pair %lld (%d -> %d) out of range (a slave this rank owns needs its master on this rank too)", (long long)i, slaves[i], masters[i]);
     hipStream_t s = fs_rt().stream;
     dbuf<int32_t> d_s, d_m, master_of;
     dbuf<int> d_err;

@@ -918,8 +918,9 @@ class FunctionSpace:
                 # a mesh in FILE order on one GPU: the same machinery with one part whose numbering is the locality order
                 root._device = self._make_parallel_device(root, backend, parallel, renumber=True)
             elif parallel.active():
-                if root._periodic is not None:
-                    raise SolverError("periodic_boundary (constrained_domain) is built for one GPU")
+                if root._periodic is not None and (root._degree != 1 or facet_coupling or getattr(root._mesh, "_slab", None) is not None):
+                    raise SolverError("periodic_boundary (constrained_domain) under domain decomposition is built for P1 spaces on a "
+                                      "replicated host mesh (no interior-facet terms); CG2 / Taylor-Hood spaces: one GPU")
                 root._device = self._make_parallel_device(root, backend, parallel, facet_coupling=facet_coupling)
             else:
                 pairs = None
@@ -986,6 +987,14 @@ class FunctionSpace:
         # one partition and ONE device mesh per host mesh: spaces on the same mesh share it (the stress projections assemble a
         # load on the P1 space from a field of another space and need both on the same device mesh)
         cache = mesh.__dict__.setdefault("_parallel_parts", {})
+        if root._periodic is not None:
+            return FunctionSpace._make_parallel_periodic_device(root, backend, parallel, partition, rank, size, cache)
+        if (rank, size) not in cache:
+            # an unconstrained space on a mesh that already carries a periodic space (the P1 space a stress is projected onto): the
+            # same part and device mesh - its extra ghost vertices are columns nobody couples with here
+            pk = next((k for k in cache if len(k) == 4 and k[:3] == (rank, size, "periodic")), None)
+            if pk is not None:
+                cache[(rank, size)] = cache[pk]
         if (rank, size) not in cache and size == 1 and FunctionSpace._wants_renumbering(root):
             # one part in locality order (a mesh FILE on one GPU): ordered, re-indexed and built on the device in one upload
             # (fs_mesh_create_renumbered; the numpy re-indexing of the general path below took 6.7 s at 10 M vertices)
@@ -1022,6 +1031,36 @@ class FunctionSpace:
                 ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts],
                             recv_lists=dof_lists(plan.recv_lists))
             root._localizer = parallel.Localizer(part, mesh.num_vertices(), nc_, p2_plan=plan, n_global_nodes=root.num_nodes())
+        return ds
+
+    @staticmethod
+    def _make_parallel_periodic_device(root, backend, parallel, partition, rank, size, cache):
+        """A P1 space with a periodic constraint on several ranks (SolverBase.py:260-275 under mpirun).  DOLFIN's dofmap has no
+        slave dofs: a cell at the slave side couples its vertices with the MASTER, wherever that lives.  Here the slaves stay
+        nodes and the assembled system is folded (fs_matrix_tie_nodes), so
+          * a slave is owned by its master's rank (the row fold slave -> master is then rank-local),
+          * a part holds the master of every slave among its vertices, as an extra ghost without cells where need be (the column
+            fold (i, slave) -> (i, master) of a row i at the far side of the domain),
+          * the pattern holds the (master, neighbour-of-slave) couplings that touch a local row.
+        The part gets its own device mesh (its ghost list differs from the unconstrained part of the same host mesh)."""
+        mesh = root._mesh
+        co, ce = mesh.coordinates(), mesh.cells()
+        sl, ma = (np.asarray(a, dtype=np.int64) for a in root._periodic)
+        key = (rank, size, "periodic", hash(sl.tobytes()) ^ hash(ma.tobytes()))
+        if key not in cache:
+            axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
+            owner = np.array(partition.slab_owner(co, size, axis=axis))
+            owner[sl] = owner[ma]
+            part = partition.build_local_part(ce, owner, rank, tied=(sl, ma))
+            cache[key] = (owner, part, backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=part.l2g))
+        owner, part, dm = cache[key]
+        g2l = part.g2l(mesh.num_vertices())
+        pairs = g2l[root._periodic_couplings().astype(np.int64)]
+        pairs = pairs[(pairs >= 0).all(axis=1) & (pairs < part.n_owned).any(axis=1)]
+        ds = backend.DeviceSpace(dm, root._ncomp, 1, coupled_pairs=pairs.astype(np.int32))
+        if size > 1:
+            ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
+        root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
         return ds
 
     @staticmethod

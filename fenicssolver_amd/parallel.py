@@ -284,6 +284,15 @@ class Localizer:
         keep = loc >= 0
         return (loc[keep] * self.ncomp + comp[keep]).astype(np.int32), np.asarray(vals, dtype=np.float64)[keep]
 
+    def tied_pairs(self, slaves, masters):
+        """(slave, master) NODE pairs of a periodic constraint -> the pairs whose slave is local (owned or ghost), in local
+        node numbers (the part holds the master of every local slave, partition.build_local_part(tied=...))."""
+        sl, ma = self.g2l[np.asarray(slaves, dtype=np.int64)], self.g2l[np.asarray(masters, dtype=np.int64)]
+        keep = sl >= 0
+        if (ma[keep] < 0).any():
+            raise RuntimeError("a local slave node's master is not in the part")
+        return sl[keep].astype(np.int32), ma[keep].astype(np.int32)
+
     def facets(self, tri):
         """Facets with at least one owned vertex (their cell is local, so all three vertices are);
         returns (local vertex triples, mask into the input)."""

@@ -98,20 +98,38 @@ def _local_cell_mask(cells, owner, q, face_pairs):
     return m
 
 
-def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_pairs=None):
+def _with_masters(verts, master_of):
+    """verts plus the masters of the slaves among them (tied vertex pairs of a periodic constraint), ascending."""
+    m = master_of[verts]
+    return np.union1d(verts, m[m >= 0])
+
+
+def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_pairs=None, tied=None):
     """vertex_rank / cell_rank (optional, [n_global] each): a locality order (backend.locality_order) - the owned vertices
     and the local cells are then numbered by it instead of by their global ids (the order a mesh file happens to have).
-    face_pairs [nf,2] (optional, global cell ids of the two cells of every interior facet): two cell layers instead of one."""
+    face_pairs [nf,2] (optional, global cell ids of the two cells of every interior facet): two cell layers instead of one.
+    tied (optional, (slaves, masters) global vertex ids of a periodic constraint; `owner` must give a slave its master's rank):
+    the folded operator P^T A P moves every column of a slave onto its master, so a part holds the master of every slave among
+    its vertices as well - as an extra ghost vertex without cells where the master is no mesh neighbour of anything local (the
+    far side of the domain)."""
     cells = np.asarray(cells, dtype=np.int64)
     owner = np.asarray(owner)
     if face_pairs is not None:
         face_pairs = np.asarray(face_pairs, dtype=np.int64).reshape(-1, 2)
     n_global = len(owner)
+    master_of = None
+    if tied is not None:
+        master_of = np.full(n_global, -1, dtype=np.int64)
+        master_of[np.asarray(tied[0], dtype=np.int64)] = np.asarray(tied[1], dtype=np.int64)
+        if not np.array_equal(owner[np.asarray(tied[0], dtype=np.int64)], owner[np.asarray(tied[1], dtype=np.int64)]):
+            raise ValueError("build_local_part: a tied (slave, master) pair must live on one rank")
     keep = np.nonzero(_local_cell_mask(cells, owner, rank, face_pairs))[0]
     if cell_rank is not None:
         keep = keep[np.argsort(np.asarray(cell_rank)[keep], kind="stable")]
     lc = cells[keep]
     verts = np.unique(lc)
+    if master_of is not None:
+        verts = _with_masters(verts, master_of)
     mine = verts[owner[verts] == rank]
     if vertex_rank is not None:
         mine = mine[np.argsort(np.asarray(vertex_rank)[mine], kind="stable")]
@@ -125,21 +143,24 @@ def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_
     # what each neighbour q needs from me: my vertices in the cells of q's part (ascending global id = q's ghost order)
     send_lists = []
     nb_all = set(neighbors.tolist())
-    if face_pairs is None:
+    general = face_pairs is not None or master_of is not None      # (q's whole part is worked out, not only its cells around my vertices)
+    if not general:
         cand = cells[(owner[cells] == rank).any(axis=1)]
         others = sorted(nb_all | set(np.unique(owner[cand]).tolist()) - {rank})
     else:
         others = [q for q in range(int(owner.max()) + 1) if q != rank]
     for q in others:
-        if face_pairs is None:
+        if not general:
             touch = cand[(owner[cand] == q).any(axis=1)]
         else:
             touch = cells[_local_cell_mask(cells, owner, q, face_pairs)]
         v = np.unique(touch)
+        if master_of is not None:
+            v = _with_masters(v, master_of)
         v = v[owner[v] == rank]
-        if face_pairs is not None and len(v) == 0 and q not in nb_all:
+        if general and len(v) == 0 and q not in nb_all:
             continue
-        if q not in nb_all or (face_pairs is not None and len(v) == 0):
+        if q not in nb_all or (general and len(v) == 0):
             # q needs my vertices but I need none of q's (or the reverse): cannot happen, the overlap is symmetric
             raise AssertionError("asymmetric neighbourhood between ranks %d and %d" % (rank, q))
         send_lists.append(g2l[v].astype(np.int32))

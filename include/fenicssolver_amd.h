@@ -181,7 +181,9 @@ int fs_matrix_copy(fs_matrix_t dst, fs_matrix_t src);
  * here the assembled system is folded in place - A <- P^T A P with a unit diagonal on the slave rows, b <- P^T b with 0
  * on the slaves (b may be NULL) - and after the solve fs_vector_assign_entries copies the masters' values to the
  * slaves.  The pattern must hold (master, j) and (master, fold(j)) for every neighbour j of a slave: create the space
- * with fs_space_create_coupled.  Apply before fs_apply_dirichlet.  One GPU. */
+ * with fs_space_create_coupled.  Apply before fs_apply_dirichlet.  Decomposed spaces: local node numbers, ghosts included -
+ * the columns of every local slave fold onto its master in the rows this rank owns, the row of a slave folds on the rank that
+ * owns it, which must own its master too. */
 int fs_matrix_tie_nodes(fs_matrix_t A, fs_vector_t b, int64_t n_pairs, const int32_t* slaves, const int32_t* masters);
 /* v[dst_nodes[i]*block + c] = v[src_nodes[i]*block + c], c < block. */
 int fs_vector_assign_entries(fs_vector_t v, int64_t n, const int32_t* dst_nodes, const int32_t* src_nodes, int block);

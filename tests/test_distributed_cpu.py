@@ -236,3 +236,42 @@ def test_two_layer_parts_for_interior_facet_integrals(world):
             k = pq.neighbors.index(r)
             assert np.array_equal(pq.l2g[pq.send_lists[k]], ghosts_from_q)
         assert off == part.n_local
+
+
+@pytest.mark.parametrize("world,axis", [(2, 2), (3, 2), (4, 2), (3, 0)])
+def test_parts_of_a_periodic_space_hold_the_masters_of_their_slaves(world, axis):
+    """partition.build_local_part(tied=...) (round 4: periodic_boundary under decomposition).  Slaves are owned by their masters'
+    rank; every part holds the master of every slave among its vertices (as a ghost without cells where the master is at the far
+    side of the domain); the exchange plan stays consistent (what r sends to q is q's ghosts owned by r, in q's ghost order); and
+    the FOLDED global operator, restricted to the rows a rank owns, only has columns that are local to that rank."""
+    nx, ny, nz = 3, 2, 9
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 3.0), nx, ny, nz)
+    ce = ce.astype(np.int64)
+    length = (1.0, 0.8, 3.0)[axis]
+    slaves = np.nonzero(np.isclose(co[:, axis], length))[0]
+    key = lambda idx: [tuple(np.round(np.delete(co[i], axis), 9)) for i in idx]
+    lookup = {k: i for k, i in zip(key(np.nonzero(np.isclose(co[:, axis], 0.0))[0]), np.nonzero(np.isclose(co[:, axis], 0.0))[0])}
+    masters = np.array([lookup[k] for k in key(slaves)])
+    owner = np.array(partition.slab_owner(co, world, axis=2))
+    owner[slaves] = owner[masters]
+    parts = [partition.build_local_part(ce, owner, r, tied=(slaves, masters)) for r in range(world)]
+    A = fo.assemble_p1_scalar(co, ce, 1.0, mass_coef=1.0)
+    Af, _ = fo.periodic_fold(A, np.zeros(len(co)), slaves, masters, 1)
+    Af = Af.tocsr()
+    covered = np.zeros(len(co), dtype=int)
+    for r, part in enumerate(parts):
+        g2l = part.g2l(len(co))
+        covered[part.l2g[:part.n_owned]] += 1
+        loc_slaves = np.intersect1d(part.l2g, slaves)
+        assert (g2l[masters[np.searchsorted(slaves, loc_slaves)]] >= 0).all()
+        rows = part.l2g[:part.n_owned]
+        cols = np.unique(Af[rows].indices)
+        assert (g2l[cols] >= 0).all(), "a folded row of rank %d couples with a vertex outside its part" % r
+        off = part.n_owned
+        for q, cnt in zip(part.neighbors, part.recv_counts):
+            ghosts_from_q = part.l2g[off:off + cnt]
+            off += cnt
+            pq = parts[q]
+            assert np.array_equal(pq.l2g[pq.send_lists[pq.neighbors.index(r)]], ghosts_from_q)
+        assert off == part.n_local
+    assert np.all(covered == 1)

@@ -26,19 +26,44 @@ def _heat_p2_case(n=4):
     return solver
 
 
-def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip=False):
+def _periodic_subdomain(axis, length):
+    from fenicssolver_amd.fem import SubDomain, near
+
+    class Periodic(SubDomain):
+        def inside(self, x, on_boundary):
+            return near(x[axis], 0.0) and on_boundary
+
+        def map(self, x, y):
+            for i in range(len(x)):
+                y[i] = x[i] - (length if i == axis else 0.0)
+    return Periodic()
+
+
+def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip=False, periodic=None):
+    """periodic: axis of a periodic_boundary (reference SolverBase.py:260-275) - 1: across the slabs a decomposition cuts (slave
+    and master on one rank), 2: ALONG the decomposition axis (the first and the last rank become neighbours; the hot / HTC faces
+    then move to x)."""
     from fenicssolver_amd.fem import BoxMesh, Point, FunctionSpace, AutoSubDomain, Constant, MeshFunction, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     m = BoxMesh(Point(0, 0, 0), Point(1, 1, 2), n, n, 2 * n, distributed=distributed)
-    Q = FunctionSpace(m, "CG", degree)
+    pb = None if periodic is None else _periodic_subdomain(periodic, (1.0, 1.0, 2.0)[periodic])
+    Q = FunctionSpace(m, "CG", degree) if pb is None else FunctionSpace(m, "CG", degree, constrained_domain=pb)
     bcs = OrderedDict()
-    bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
-        'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
-    bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 2, 'values': {
-        'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
-    bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
-        'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
-    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': None,
+    if periodic == 2:
+        bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 1.0)), 'boundary_id': 1, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+        bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 2, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
+        bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 3, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    else:
+        bcs["hot"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 2.0)), 'boundary_id': 1, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(360)}}}
+        bcs["flux"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 0.0)), 'boundary_id': 2, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'heatFlux', 'value': Constant(36.0)}}}
+        bcs["htc"] = {'boundary': AutoSubDomain(lambda x: near(x[2], 0.0)), 'boundary_id': 3, 'values': {
+            'temperature': {'variable': 'temperature', 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}}}
+    s = {'solver_name': 'ScalarEquationSolver', 'mesh': None, 'function_space': Q, 'periodic_boundary': pb,
          'boundary_conditions': bcs, 'body_source': None, 'initial_values': {'temperature': 300},
          'material': {'density': 10.0, 'specific_heat_capacity': 2.0, 'thermal_conductivity': 0.6},
          'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1,
@@ -68,7 +93,7 @@ def _elastic_p2_case():
     return solver
 
 
-def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False, wide=False):
+def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False, wide=False, periodic=None):
     from fenicssolver_amd.fem import BoxMesh, Point, VectorFunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd import SolverBase as SB
     from fenicssolver_amd.LinearElasticitySolver import LinearElasticitySolver
@@ -95,7 +120,9 @@ def _elastic_case(distributed=False, degree=1, fine=1, pressure_field=False, wid
     s = copy.deepcopy(SB.default_case_settings)
     s['material'] = {'name': 'steel', 'elastic_modulus': 2e11, 'poisson_ratio': 0.27, 'density': 7800,
                      'thermal_expansion_coefficient': 2e-6}
-    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", degree)
+    pb = None if periodic is None else _periodic_subdomain(periodic, 1.0)     # (the beam's cross-section is the unit square)
+    s['function_space'] = VectorFunctionSpace(mesh, "Lagrange", degree, constrained_domain=pb)
+    s['periodic_boundary'] = pb
     s['boundary_conditions'] = bcs
     s['solver_settings']['reference_values'] = {'temperature': 293}
     s['solver_settings']['solver_parameters'] = {'krylov_relative_tolerance': 1e-12}
@@ -225,7 +252,11 @@ CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=T
          "elasticity_p2_pfield": lambda: _elastic_case(degree=2, pressure_field=True),
          "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
          "heat_supg": lambda: _heat_case(supg=True), "heat_ip": lambda: _heat_case(ip=True), "heat_ip_cn": lambda: _heat_case(ip=True, transient=True),
-         "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case}
+         "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case,
+         # periodic_boundary under decomposition (round 4): slaves owned by their masters' rank, masters as extra ghosts
+         "heat_periodic_y": lambda: _heat_case(periodic=1), "heat_periodic_z": lambda: _heat_case(periodic=2),
+         "heat_periodic_z_cn": lambda: _heat_case(periodic=2, transient=True),
+         "elasticity_periodic": lambda: _elastic_case(periodic=1)}
 
 
 @pytest.mark.parametrize("case", sorted(CASES) + sorted(NS_CASES))
