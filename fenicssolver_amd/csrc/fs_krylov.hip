@@ -621,6 +621,29 @@ __device__ __forceinline__ double fs_from_next_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// n doubles (n even, both 16-byte aligned) global -> LDS by the whole workgroup: batches of four 16-byte loads per thread, all four
+// in flight before the first LDS store (the plain loop `for i: lds[i] = g[i]` compiles to one load - wait - store per trip:
+// eight dependent round trips for the 15 KB dictionary of a P1 box, about 4 us at the head of every launch)
+__device__ __forceinline__ void fs_fill_lds(double* __restrict__ lds, const double* __restrict__ g, int n) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int n2 = n >> 1;
+    const v2d* __restrict__ g2 = reinterpret_cast<const v2d*>(g);
+    v2d* __restrict__ l2 = reinterpret_cast<v2d*>(lds);
+    for (int base = 0; base < n2; base += 4 * FS_BLOCK) {
+        v2d t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * FS_BLOCK + (int)threadIdx.x;
+            t[u] = g2[i < n2 ? i : n2 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * FS_BLOCK + (int)threadIdx.x;
+            if (i < n2) l2[i] = t[u];
+        }
+    }
+}
+
 // item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (8 RL per round
 // of the longest plan of the space), C = class rows a wave's LDS region holds.  Dynamic LDS: 4 waves x C x S doubles.
 // LDSD: the whole dictionary fits the workgroup's LDS (P1: 78 class rows of 24 doubles) - loaded once per workgroup, a row's
@@ -641,13 +664,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
     }
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ double sdict[];
+    extern __shared__ __attribute__((aligned(16))) double sdict[];
     __shared__ double lds4[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double* __restrict__ wl = LDSD ? sdict : sdict + (int64_t)wave * C * S;
     if (LDSD) {
-        for (int i = threadIdx.x; i < C * S; i += FS_BLOCK) sdict[i] = dict[i];      // (C = number of classes here)
+        fs_fill_lds(sdict, dict, C * S);      // (C = number of classes here)
         __syncthreads();
     }
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
@@ -835,7 +858,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv3(int64_t n_cols, int64_t
                                                          const double* __restrict__ x, double* __restrict__ y, int map_xcd) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ double sdict[];
+    extern __shared__ __attribute__((aligned(16))) double sdict[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double* __restrict__ wl = sdict + (int64_t)wave * C * S;
@@ -1002,18 +1025,25 @@ __global__ void k_set_iteration_limit(double* __restrict__ ctrl, int max_iter) {
 // for every kernel that needs them - the update kernels, the peer-to-peer exchange kernel that advances the ghost rows of r and
 // s on its own, the pipelined recurrence: the ghost copies stay bit-identical to the owner's rows only if all of them apply the
 // same bits.  false: not SPD / NaN.
-__device__ __forceinline__ bool cg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
-                                            double& alpha, double& beta) {
+__device__ __forceinline__ bool cg_scalars_from(int iter, double gamma, double delta, double rho, double gamma_old, double alpha_old,
+                                                 double& alpha, double& beta) {
     beta = 0.0;
     if (iter == 0) {
         alpha = gamma / delta;
     } else {
-        const double gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        const double alpha_old = scal[2 * ((iter - 1) & 1) + 1];
         beta = gamma / gamma_old;
         alpha = gamma / (delta - beta * gamma / alpha_old);
     }
     return (alpha > 0.0) && (alpha < 1e300) && (rho == rho);
+}
+__device__ __forceinline__ bool cg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
+                                            double& alpha, double& beta) {
+    double gamma_old = 0.0, alpha_old = 0.0;
+    if (iter != 0) {
+        gamma_old = scal[2 * ((iter - 1) & 1) + 0];
+        alpha_old = scal[2 * ((iter - 1) & 1) + 1];
+    }
+    return cg_scalars_from(iter, gamma, delta, rho, gamma_old, alpha_old, alpha, beta);
 }
 
 template <bool FUSED>
@@ -1110,9 +1140,23 @@ __device__ __forceinline__ void wg_sum_partials(const double* __restrict__ parti
     double a[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) a[j] = 0.0;
-    for (int i = threadIdx.x; i < npart; i += FS_BLOCK) {
+    // four trips at a time, their 4 NS loads in flight together (the plain loop waits for every trip's loads before the next
+    // trip's go out: four dependent round trips for 1024 partials, and the partials were written by the previous launch on other
+    // XCDs - about 0.7 us each); a thread's partials are still added in ascending index: same bits
+    for (int i0 = threadIdx.x; i0 < npart; i0 += 4 * FS_BLOCK) {
+        double v[4][NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) a[j] += partials[(int64_t)j * npart + i];
+        for (int t = 0; t < 4; ++t) {
+            const int i = i0 + t * FS_BLOCK;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) v[t][j] = partials[(int64_t)j * npart + (i < npart ? i : npart - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (i0 + t * FS_BLOCK < npart) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) a[j] += v[t][j];
+            }
     }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -1271,11 +1315,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
                                                                double* __restrict__ hist, double* __restrict__ r,
                                                                const double* __restrict__ w, double* __restrict__ p,
                                                                double* __restrict__ sv, double* __restrict__ x) {
-    if (status[0] != 0) return;
-    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
-        iter = status[2] - 1;
-        check_only = iter >= (int)ctrl[2] ? 1 : 0;
-    }
+    // (the status word is looked at AFTER the first trip's loads have gone out - everything a launch reads first was written by the
+    // previous launch on other XCDs, and each dependent load is a round trip of about a microsecond)
+    const int st0 = status[0];
+    const int st2 = status[2];
+    const double it_max = ctrl[2], thresh = ctrl[0];
+    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];      // (gamma, alpha) of the two iteration parities
     // NT (vectors larger than the caches, 10 M DOF): non-temporal loads and stores - the probe in tools/probes streams
     // 7.2 instead of 6.4 TB/s that way
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -1307,6 +1352,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         pa0 = io::ld(&p2[i]); sa0 = io::ld(&s2[i]); xa0 = io::ld(&x2[i]); ra0 = io::ld(&r2[i]);
         pb0 = io::ld(&p2[j]); sb0 = io::ld(&s2[j]); xb0 = io::ld(&x2[j]); rb0 = io::ld(&r2[j]);
     }
+    if (st0 != 0) return;
+    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
+        iter = st2 - 1;
+        check_only = iter >= (int)it_max ? 1 : 0;
+    }
     double gamma, delta, rho;
     if (FUSED) {
         double sm[3];
@@ -1317,7 +1367,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     }
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     if (leader) hist[iter] = rho;
-    if (rho <= ctrl[0]) {
+    if (rho <= thresh) {
         if (leader) { status[1] = iter; status[0] = 1; }
         return;
     }
@@ -1326,7 +1376,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         return;
     }
     double beta, alpha;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
+    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) {
         if (leader) { status[1] = iter; status[0] = 2; }
         return;
     }
@@ -1397,6 +1447,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
 // streams (5 loads, 5 stores per row) reach 4.1 TB/s inside an item-by-item kernel against the 6.5 TB/s of the grid-stride update
 // kernel, and three vectors x three mesh planes no longer fit the 4 MB L2 of an XCD.  Hence automatic only where the vectors
 // stay in the Infinity Cache (FS_CG_FUSED_MAX_ROWS, default 3 M rows).
+#ifdef FS_ITER_TIMING
+__device__ long long g_iter_dbg[8 * 4096];
+#define FS_STAMP(k) do { if (threadIdx.x == 0 && it_ctr[par] == 100) g_iter_dbg[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)
+#endif
 template <int RL>
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
                                                            const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
@@ -1408,14 +1464,30 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
                                                            const double* __restrict__ part_in, double* __restrict__ part_out, int npart,
                                                            const double* __restrict__ ctrl, double* __restrict__ scal, int* __restrict__ status,
                                                            int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd) {
-    if (status[0] != 0) return;
+    FS_STAMP(0);
+    // The launch is latency-bound at the sizes it is used for (a wave has two work items at 1 M rows), and what it reads first was
+    // written by the previous launch on other XCDs - every dependent load is a round trip to the Infinity Cache (1 - 2 us).  So
+    // everything the prologue needs goes out BEFORE anything is waited for: status word, iteration number, threshold, both parities
+    // of the previous (gamma, alpha), the twelve dot partials of this thread, the first item's header -> run starts -> first
+    // twelve run loads, the dictionary.  (Timeline of the first version, tools/probes: 8.8 of 22.7 us were the prologue.)
+    const int st0 = status[0];
+    const int iter = it_ctr[par];
+    const double thresh = ctrl[0], it_max = ctrl[2];
+    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];
+    double pl[3][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = threadIdx.x + t * FS_BLOCK;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pl[j][t] = part_in[(int64_t)j * npart + (i < npart ? i : npart - 1)];      // (no branch: twelve loads in flight)
+    }
+    FS_STAMP(1);
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ double sdict[];
-    __shared__ double lds4[4];
+    extern __shared__ __attribute__((aligned(16))) double sdict[];
+    __shared__ double lds34[3][4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int iter = it_ctr[par];
     const int64_t n_chunks = (n_items + 3) / 4;
     const int32_t cmax = (int32_t)(n_cols - 1);
     chunk_iter it = xcd_chunks(n_chunks);
@@ -1434,9 +1506,16 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
     // loads of runs [4 h, 4 h + 4) of round rd: scalar base (vector + run start) + one 32-bit byte offset per lane - the `saddr` form
     // of the load, no 64-bit address arithmetic or address registers per load (rows < 2^29)
     auto load_half = [&](const item_hdr& H, int rd, int h, uint32_t boff, v2d (&A)[4], v2d (&Wb)[4], v2d (&Sb)[4]) {
+        // (measured and not kept: run starts that need no load - kernel arguments for the plan most items have, or a per-item copy beside
+        // the header - and the next item's header asked for an item ahead: with nothing left between header and run loads the
+        // compiler schedules 164 - 177 VGPRs (and spills SGPRs into them), two or three waves per SIMD instead of four, and the
+        // launch gets slower: 22.9 against 19.0 us at 1 M rows)
+        int32_t sts[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sts[j] = __builtin_amdgcn_readfirstlane(H.pl[rd].start[4 * h + j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int32_t st = __builtin_amdgcn_readfirstlane(H.pl[rd].start[4 * h + j]);
+            const int32_t st = sts[j];
             A[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(r_in + st) + boff);
             Wb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(w_in + st) + boff);
             Sb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(s_in + st) + boff);
@@ -1461,22 +1540,46 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
         if (!H0.edge) load_half(H0, 0, 0, (uint32_t)(H0.first + 2 * lane) * 8u, PA, PW, PS);
         load_own(H0, Ppp, Pxx, Pdd);
     }
-    for (int i = threadIdx.x; i < C * S; i += FS_BLOCK) sdict[i] = dict[i];      // (visible after the barriers of the sum below)
+    FS_STAMP(2);
+    fs_fill_lds(sdict, dict, C * S);             // (visible after the barrier of the sum below)
+    if (st0 != 0) return;
+    // the three sums of the previous launch's partials, in the order of wg_sum_partials / fs_block_sum (same bits as the update
+    // kernel of the two-launch iteration computes), with ONE barrier: a thread's partials in ascending index, the wave's by the
+    // shuffle tree, the four waves as (0 + 1) + (2 + 3) by every thread
     double sm[3];
-    wg_sum_partials<3>(part_in, npart, sm);
+    {                                           // (npart <= 4 x 256: the host launches this kernel with at most 1024 workgroups)
+        double a[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if ((int)threadIdx.x + t * FS_BLOCK < npart) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[j] += pl[j][t];
+            }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a[j] += __shfl_down(a[j], off, 64);
+            if (lane == 0) lds34[j][wave] = a[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sm[j] = (lds34[j][0] + lds34[j][1]) + (lds34[j][2] + lds34[j][3]);
+        __syncthreads();                        // (lds34 is written again at the end)
+    }
+    FS_STAMP(3);
     const double gamma = sm[0], delta = sm[1], rho = sm[2];
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     if (leader) hist[iter] = rho;
-    if (rho <= ctrl[0]) {                       // every workgroup takes the same branch: the inputs are identical
+    if (rho <= thresh) {                        // every workgroup takes the same branch: the inputs are identical
         if (leader) { status[1] = iter; status[0] = 1; }
         return;
     }
-    if (iter >= (int)ctrl[2]) {
+    if (iter >= (int)it_max) {
         if (leader) { status[1] = iter; status[0] = 3; }
         return;
     }
     double beta, alpha;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
+    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) {
         if (leader) { status[1] = iter; status[0] = 2; }
         return;
     }
@@ -1486,6 +1589,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
         it_ctr[par ^ 1] = iter + 1;
     }
     const double nalpha = -alpha;
+    FS_STAMP(4);
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
     // PRE: this item's first half round and row-local operands were loaded before the prologue
     auto do_item = [&](const item_hdr& H, auto pre_tag) {
@@ -1588,19 +1692,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
         do_item(H0, std::true_type{});
         it.cur += it.step;
     }
+    FS_STAMP(5);
     for (; it.cur < it.end; it.cur += it.step) {
         const int64_t q = it.cur * 4 + wave;
         if (q >= n_items) break;
         do_item(decode(q), std::false_type{});
     }
-    const double t0 = fs_block_sum(d_rz, lds4);
-    const double t1 = fs_block_sum(d_wz, lds4);
-    const double t2 = fs_block_sum(d_rr, lds4);
-    if (threadIdx.x == 0) {
-        part_out[blockIdx.x] = t0;
-        part_out[npart + blockIdx.x] = t1;
-        part_out[2 * npart + blockIdx.x] = t2;
+    FS_STAMP(6);
+    // this workgroup's three dot partials: fs_block_sum's order (shuffle tree, then (0 + 1) + (2 + 3)), one barrier for the three
+    double dsum[3] = {d_rz, d_wz, d_rr};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum[j] += __shfl_down(dsum[j], off, 64);
+        if (lane == 0) lds34[j][wave] = dsum[j];
     }
+    __syncthreads();
+    FS_STAMP(7);
+    if (threadIdx.x < 3) part_out[(int64_t)threadIdx.x * npart + blockIdx.x] =
+        (lds34[threadIdx.x][0] + lds34[threadIdx.x][1]) + (lds34[threadIdx.x][2] + lds34[threadIdx.x][3]);
 }
 
 // The same update on the rows [0, a) and [b, n) only - the rows a slab sends to its neighbours - so that the halo
@@ -2964,7 +3074,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const bool fused = ds && !pipelined && fuse_sums && !sp->halo.active && bs == 1 && fused_opt != 0 &&
                        g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
                        (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
-                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && nl < ((int64_t)1 << 29) && (fused_opt > 0 || n <= fused_max_rows);
+                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && sgrid <= 4 * FS_BLOCK && nl < ((int64_t)1 << 29) && (fused_opt > 0 || n <= fused_max_rows);
     if (fused) {
         if (ws.z2.n != nl + 2) FS_CHECK(ws.z2.alloc(nl + 2));
         if (ws.w2.n != n + 2) {
@@ -3469,6 +3579,20 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 ac ? au / ac : 0.0, ac, hc ? hu / hc : 0.0, hc, iters,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     }
+#ifdef FS_ITER_TIMING
+    if (fused && getenv("FS_ITER_TIMING")) {
+        std::vector<long long> h(8 * 4096);
+        FS_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_iter_dbg), h.size() * sizeof(long long)));
+        long long first = h[0], last = 0;
+        for (int b = 0; b < sgrid; ++b) { first = std::min(first, h[8 * b]); last = std::max(last, h[8 * b + 7]); }
+        double mean[8] = {0}, mx[8] = {0};
+        for (int b = 0; b < sgrid; ++b)
+            for (int k2 = 0; k2 < 8; ++k2) { const double v = (h[8 * b + k2] - first) * 0.01; mean[k2] += v / sgrid; mx[k2] = std::max(mx[k2], v); }
+        fprintf(stderr, "[iter timing, last launch, us from the first workgroup's start] span %.2f;", (last - first) * 0.01);
+        for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, " s%d mean %.2f max %.2f;", k2, mean[k2], mx[k2]);
+        fprintf(stderr, "\n");
+    }
+#endif
     ws.last_hist.resize((size_t)iters + 1);
     FS_CHECK(ws.hist.download(ws.last_hist.data(), iters + 1, s));
     const auto t_end = std::chrono::steady_clock::now();

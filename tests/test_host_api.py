@@ -720,3 +720,32 @@ def test_dolfin_hdf5_mesh_files(tmp_path):
         f.write("/boundaries/values", np.array([3]))
     with pytest.raises(SolverError, match="not facets"):
         case.read_mesh_file(str(tmp_path / "bad.h5"))
+
+
+def test_one_launch_iteration_kernel_keeps_four_waves_per_simd(tmp_path):
+    """k_dict_cg_iter (fs_krylov.hip) is latency-bound: all of its 1024 workgroups have to be resident at once, which takes four
+    waves per SIMD = at most 128 VGPRs.  The compiler's schedule for it is touchy (a cold fallback path inside the kernel once took
+    it to 174 VGPRs and the launch from 19 to 25 us without any change to the hot path), so the register count is pinned here:
+    cross-compiled for gfx950 with the Makefile's flags, resource usage from the compiler's own remarks."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(ROOT, "fenicssolver_amd", "csrc", "fs_krylov.hip")
+    p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-function",
+                        "-c", src, "-o", str(tmp_path / "k.o"), "-Rpass-analysis=kernel-resource-usage"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=os.path.dirname(src), timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out)
+    seen = 0
+    for b in blocks:
+        if "k_dict_cg_iter" not in b.split("\n", 1)[0]:
+            continue
+        seen += 1
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert occ >= 4 and vgprs <= 128 and spill == 0, (vgprs, spill, occ)
+    assert seen >= 2          # both run lengths
