@@ -658,10 +658,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
                                                         const double* __restrict__ x, double* __restrict__ y,
                                                         const double* __restrict__ rvec, double* __restrict__ partials,
                                                         int* __restrict__ status, int part_base, int part_stride, int bump, int map_xcd) {
-    if (DOTS) {
-        if (status[0] != 0) return;
-        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
-    }
+    // (the status word is asked for now and looked at after the dictionary's loads have gone out: one round trip instead of two)
+    const int st0 = DOTS ? status[0] : 0;
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
     extern __shared__ __attribute__((aligned(16))) double sdict[];
@@ -669,10 +667,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double* __restrict__ wl = LDSD ? sdict : sdict + (int64_t)wave * C * S;
-    if (LDSD) {
-        fs_fill_lds(sdict, dict, C * S);      // (C = number of classes here)
-        __syncthreads();
+    if (LDSD) fs_fill_lds(sdict, dict, C * S);      // (C = number of classes here)
+    if (DOTS) {
+        if (st0 != 0) return;
+        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
     }
+    if (LDSD) __syncthreads();
     double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
     // A wave takes K CONSECUTIVE items of a chunk of 4 K: with per-item class rows (!LDSD) neighbouring mesh lines hold the same
     // classes, and a class row already in the wave's region (tagv: lane k knows which class slot k holds) is not fetched again.
@@ -2916,6 +2916,9 @@ static krylov_ws g_ws;
 
 static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
     if (ws.n != n || ws.nl != nl) {
+        // (measured and not kept: the vectors of the update set apart by 256 B ... 1 MB so that equal
+        // indices fall on different memory channels - no effect; the 100 - 117 us spread of the update kernel at 10 M rows is
+        // the box's, not the addresses')
         FS_CHECK(ws.dinv.alloc(n + 2));
         FS_CHECK(ws.r.alloc(n + 2));
         FS_CHECK(ws.z.alloc(nl + 2));
