@@ -3077,7 +3077,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const bool fused = ds && !pipelined && fuse_sums && !sp->halo.active && bs == 1 && fused_opt != 0 &&
                        g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
                        (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
-                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && sgrid <= 4 * FS_BLOCK && nl < ((int64_t)1 << 29) && (fused_opt > 0 || n <= fused_max_rows);
+                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && sgrid <= 4 * FS_BLOCK && nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && (fused_opt > 0 || n <= fused_max_rows);
     if (fused) {
         if (ws.z2.n != nl + 2) FS_CHECK(ws.z2.alloc(nl + 2));
         if (ws.w2.n != n + 2) {
@@ -3263,14 +3263,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 double* const SV[2] = {ws.s.p, ws.s2.p};
                 double* const PT[2] = {ws.partials.p, ws.partials.p + 3 * (int64_t)sgrid};
                 const size_t lds = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
-                const bool rl2 = sp->dict_run_len == 2;
                 auto launch_iter = [&](int par) {
 #define FS_ITER_ARGS dim3(sgrid), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
                      reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.ncls, \
                      Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], sgrid, \
                      ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd()
-                    if (rl2) hipLaunchKernelGGL((k_dict_cg_iter<2>), FS_ITER_ARGS);
-                    else hipLaunchKernelGGL((k_dict_cg_iter<3>), FS_ITER_ARGS);
+                    hipLaunchKernelGGL((k_dict_cg_iter<3>), FS_ITER_ARGS);
 #undef FS_ITER_ARGS
                 };
                 if (k == 0) {
@@ -3282,7 +3280,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
                                            ws.ctrl.p, ws.scal.p};
-                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (rl2 ? 1 : 0), batch, sgrid, (int64_t)dict_map_xcd(),
+                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4, batch, sgrid, (int64_t)dict_map_xcd(),
                                               (int64_t)sp->n_dict_items, (int64_t)A->serial, (int64_t)sp->serial};
                     if (!ws.cgf_graph || memcmp(key, ws.cgf_key, sizeof(key)) || memcmp(key_i, ws.cgf_key_i, sizeof(key_i))) {
                         if (ws.cgf_graph) { (void)hipGraphExecDestroy(ws.cgf_graph); ws.cgf_graph = nullptr; }

@@ -960,3 +960,28 @@ def test_one_launch_cg_iteration_is_the_two_launch_iteration_bit_for_bit(gpu, n,
     xo, ito, _ = fo.pcg_jacobi_single_reduction(sp.csr_matrix((va, ci, rp), shape=shape), b.get()[:shape[0]], rtol=rtol)
     assert abs(s1["iterations"] - ito) <= 1
     assert np.abs(x1 - xo).max() <= 1e-7 * np.abs(xo).max()
+
+
+def test_one_launch_cg_iteration_stops_at_the_iteration_limit_like_the_two_launch_one(gpu):
+    """max_iter below what the tolerance needs: both iterations stop after exactly max_iter steps with the same iterate (status 3
+    path of k_dict_cg_iter: the launch that sees iter == limit only checks); and a solve that is converged from the start
+    (zero right-hand side rows apart from the boundary lift, tolerance 1) takes zero iterations on both paths."""
+    n = 20
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    P, V, A, b = _box_system(gpu, mesh, n)
+    got = {}
+    try:
+        for fused in (1, 0):
+            gpu.set_option("cg_fused", fused)
+            x = gpu.DeviceVector(V.n_local)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-14, max_iter=37)
+            y = gpu.DeviceVector(V.n_local)
+            st0 = gpu.krylov_solve(A, b, y, rtol=1.0, max_iter=50)
+            got[fused] = (st, x.get()[:V.n_owned].copy(), st0)
+    finally:
+        gpu.set_option("cg_fused", -1)
+    (s1, x1, z1), (s0, x0, z0) = got[1], got[0]
+    assert s1["fused_iteration"] == 1 and s0["fused_iteration"] == 0
+    assert s1["iterations"] == s0["iterations"] == 37 and s1["converged"] == s0["converged"] == 0
+    assert np.array_equal(x1, x0)
+    assert z1["iterations"] == z0["iterations"] == 0 and z1["converged"] == z0["converged"] == 1
