@@ -571,7 +571,7 @@ def iteration_rates(st, k, n_rows):
 def committed_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
     newest round first; collected on the same command in separate --pmc runs).  Not measured in this run."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):      # (newest round first)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 v = json.load(fh).get(tag)
@@ -720,13 +720,15 @@ def main():
         step_kernel["update_kernel"] = update_rates(stats, prob.n_owned)
         step_kernel["iteration"] = iteration_rates(stats, step_kernel, prob.n_owned)
         # (what an iteration touches: the product's bytes + the five vectors of the update)
-        hbm_resident = step_kernel["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * prob.n_owned > (256 << 20)
+        hbm_resident = step_kernel["required_bytes_per_launch"] + (0 if step_kernel.get("fused_iteration") else UPDATE_BYTES_PER_DOF * prob.n_owned) > (256 << 20)
         if hbm_resident:
             out["roofline"] = dict(make_roofline(step_kernel, "the step workload itself (rank 0's part)", None, None),
                                    update_kernel=step_kernel["update_kernel"], iteration=step_kernel["iteration"])
         else:
-            step_kernel["note"] = ("everything an iteration touches (required bytes of the product + 72 B/row of the update) stays in the "
-                                   "256 MiB Infinity Cache between iterations: these are cache rates, not an HBM roofline fraction")
+            step_kernel["note"] = ("everything an iteration touches (%s) stays in the "
+                                   "256 MiB Infinity Cache between iterations: these are cache rates, not an HBM roofline fraction"
+                                   % ("the 90 B/row of the one-launch iteration" if step_kernel.get("fused_iteration") else
+                                      "required bytes of the product + 72 B/row of the update"))
             out["dominant_kernel_on_step_workload"] = step_kernel
             if world > 1 or a.no_hbm_case:   # no HBM-resident side measurement: the part of a GPU is cache-resident by construction
                 out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,

@@ -1758,14 +1758,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
                                                               const double* __restrict__ scal, const int* __restrict__ status,
                                                               double* r, const double* __restrict__ w, double* __restrict__ s_ghost,
                                                               const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
-    if (status[0] != 0) return;
-    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
-        iter = status[2] - 1;
-        check_only = iter >= (int)ctrl[2] ? 1 : 0;
-    }
+    // (every scalar the launch needs is asked for before the first of them is looked at: each was written by the previous launch,
+    // a dependent load is a round trip of about a microsecond, and this kernel sits on the critical path of every iteration)
+    const int st0 = status[0], st2 = status[2];
+    const double it_max = ctrl[2], thresh = ctrl[0];
+    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];
     // sequence numbers of THIS exchange: one past the last executed ones (fs_comm.hip); read by every workgroup at its start,
     // advanced by the last workgroup through each part
     const unsigned long long rseq = *red.d_seq + 1ull, hseq = *snd.d_seq + 1ull;
+    if (st0 != 0) return;
+    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
+        iter = st2 - 1;
+        check_only = iter >= (int)it_max ? 1 : 0;
+    }
     const int rslot = (int)(rseq & 1ull), hslot = (int)(hseq & 1ull);
     const int64_t e_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1813,9 +1818,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     }
     __syncthreads();
     const double gamma = tot[0], delta = tot[1], rho = tot[2];
-    if (rho <= ctrl[0] || check_only) return;
+    if (rho <= thresh || check_only) return;
     double beta, alpha;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
+    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) return;
     // 3. ghost rows: s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g (the two lines of the update kernel)
     if (t < snd.nn) fs_p2p_wait(snd.own_flags + (int64_t)hslot * snd.nn + t, hseq, snd.timeout, snd.err);
     __syncthreads();

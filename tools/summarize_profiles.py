@@ -24,7 +24,7 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 # and the multi-10-MB databases are deleted before gpurun copies the directory back.
 OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 PHASES = ("n99_1M_dof", "n215_10M_dof")
-HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
+HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
 
 def short(name):
@@ -165,6 +165,9 @@ def main():
         for dk in ((ph, "k_dict_spmv<3, true>"), (ph, "k_dict_spmv<3, false>")):       # row-dictionary form of the same product
             if dk in fetch:                                                              # (dictionary in LDS / read through the caches)
                 out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
+        ik = (ph, "k_dict_cg_iter<3>")                    # the one-launch CG iteration (update k + product k + 1; up to 3 M rows)
+        if ik in fetch:
+            out[tag.replace("spmv_fused", "cg_iter")] = int((2 * fetch[ik] + write.get(ik, 0.0)) * 1024)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
