@@ -644,6 +644,26 @@ __device__ __forceinline__ void fs_fill_lds(double* __restrict__ lds, const doub
     }
 }
 
+// the same by ONE wave (a class row of n2 16-byte pairs into the wave's LDS region): four loads in flight per lane and batch
+__device__ __forceinline__ void fs_wave_copy_pairs(double* __restrict__ lds, const double* __restrict__ g, int n2, int lane) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d* __restrict__ g2 = reinterpret_cast<const v2d*>(g);
+    v2d* __restrict__ l2 = reinterpret_cast<v2d*>(lds);
+    for (int base = 0; base < n2; base += 256) {
+        v2d t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 64 + lane;
+            t[u] = g2[i < n2 ? i : n2 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 64 + lane;
+            if (i < n2) l2[i] = t[u];
+        }
+    }
+}
+
 // item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (8 RL per round
 // of the longest plan of the space), C = class rows a wave's LDS region holds.  Dynamic LDS: 4 waves x C x S doubles.
 // LDSD: the whole dictionary fits the workgroup's LDS (P1: 78 class rows of 24 doubles) - loaded once per workgroup, a row's
@@ -762,9 +782,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
                     const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
                     slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
                     rr = slot + 1 == C ? 0 : slot + 1;
-                    const v2d* __restrict__ src_row = reinterpret_cast<const v2d*>(dict + (int64_t)cv * S);
-                    v2d* __restrict__ dst_row = reinterpret_cast<v2d*>(wl + slot * S);
-                    for (int i = lane; i < (S >> 1); i += 64) dst_row[i] = src_row[i];
+                    fs_wave_copy_pairs(wl + slot * S, dict + (int64_t)cv * S, S >> 1, lane);
                     if (lane == slot) tagv = cv;
                     copied = true;
                 }
@@ -899,9 +917,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv3(int64_t n_cols, int64_t
                     const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
                     slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
                     rr = slot + 1 == C ? 0 : slot + 1;
-                    const v2d* __restrict__ src_row = reinterpret_cast<const v2d*>(dict + (int64_t)cv * S);
-                    v2d* __restrict__ dst_row = reinterpret_cast<v2d*>(wl + slot * S);
-                    for (int i = lane; i < (S >> 1); i += 64) dst_row[i] = src_row[i];
+                    fs_wave_copy_pairs(wl + slot * S, dict + (int64_t)cv * S, S >> 1, lane);
                     if (lane == slot) tagv = cv;
                     copied = true;
                 }

@@ -162,8 +162,8 @@ def main():
                 bare += (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
         if bare > 0.0:
             out[tag.replace("fused", "bare")] = int(bare)
-        for dk in ((ph, "k_dict_spmv<3, true>"), (ph, "k_dict_spmv<3, false>")):       # row-dictionary form of the same product
-            if dk in fetch:                                                              # (dictionary in LDS / read through the caches)
+        for dk in sorted(fetch):              # row-dictionary form of the same product (dictionary in LDS / class rows per work item;
+            if dk[0] == ph and (dk[1].startswith("k_dict_spmv<3, true") or dk[1].startswith("k_dict_spmv<3, false")):    # last argument: run length)
                 out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
         ik = (ph, "k_dict_cg_iter<3>")                    # the one-launch CG iteration (update k + product k + 1; up to 3 M rows)
         if ik in fetch:
