@@ -11,6 +11,8 @@ cd /tmp
 BENCH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
 tail -2 $OUT/stats.log
+mkdir -p $R/gpurun_out/summary
+grep -a "^{" $OUT/stats.log | tail -1 > $R/gpurun_out/summary/${1:-r01}_bench_line_under_rocprof.json      # the line printed INSIDE the traced run
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $C"; rocprofv3 --pmc $C -d $OUT/pmc_$C -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
   tail -1 $OUT/pmc_$C.log
