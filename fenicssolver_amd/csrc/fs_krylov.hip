@@ -1469,7 +1469,10 @@ __device__ long long g_iter_dbg[8 * 4096];
 #else
 #define FS_STAMP(k) do { } while (0)
 #endif
-template <int RL>
+// COMM: a decomposed space - the three sums come reduced over the ranks from `sums` (k_cg_p2p_exchange<true> before this launch put
+// them there, stored the neighbours' w into the ghost rows of w_in and advanced the ghost rows of r_out / s_out); the neighbour
+// columns of an item may then be ghost columns: n_cols counts them.
+template <int RL, bool COMM>
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
                                                            const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
                                                            const double* __restrict__ dict, int S, int C,
@@ -1479,7 +1482,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
                                                            double* __restrict__ pv, double* __restrict__ xv, const double* __restrict__ dvec,
                                                            const double* __restrict__ part_in, double* __restrict__ part_out, int npart,
                                                            const double* __restrict__ ctrl, double* __restrict__ scal, int* __restrict__ status,
-                                                           int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd) {
+                                                           int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd,
+                                                           const double* __restrict__ sums) {
     FS_STAMP(0);
     // The launch is latency-bound at the sizes it is used for (a wave has two work items at 1 M rows), and what it reads first was
     // written by the previous launch on other XCDs - every dependent load is a round trip to the Infinity Cache (1 - 2 us).  So
@@ -1491,11 +1495,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
     const double thresh = ctrl[0], it_max = ctrl[2];
     const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];
     double pl[3][4];
+    double sum_g = 0.0, sum_d = 0.0, sum_r = 0.0;
+    if (COMM) { sum_g = sums[0]; sum_d = sums[1]; sum_r = sums[2]; }
+    else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = threadIdx.x + t * FS_BLOCK;
+        for (int t = 0; t < 4; ++t) {
+            const int i = threadIdx.x + t * FS_BLOCK;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) pl[j][t] = part_in[(int64_t)j * npart + (i < npart ? i : npart - 1)];      // (no branch: twelve loads in flight)
+            for (int j = 0; j < 3; ++j) pl[j][t] = part_in[(int64_t)j * npart + (i < npart ? i : npart - 1)];      // (no branch: twelve loads in flight)
+        }
     }
     FS_STAMP(1);
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -1563,7 +1571,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
     // kernel of the two-launch iteration computes), with ONE barrier: a thread's partials in ascending index, the wave's by the
     // shuffle tree, the four waves as (0 + 1) + (2 + 3) by every thread
     double sm[3];
-    {                                           // (npart <= 4 x 256: the host launches this kernel with at most 1024 workgroups)
+    if (COMM) {
+        sm[0] = sum_g; sm[1] = sum_d; sm[2] = sum_r;
+        __syncthreads();                        // (the dictionary is in LDS)
+    } else {                                    // (npart <= 4 x 256: the host launches this kernel with at most 1024 workgroups)
         double a[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1770,10 +1781,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, i
 // (No workgroup waits before its own stores are counted, so two ranks never wait for each other.)  Any halo plan (send lists
 // need not be contiguous, ghosts may be scattered), any block size: rows are dofs here.  Gated by the status word; steps 1 and
 // 2 always run together, step 3 only if the iteration goes on - decided from the reduced sums, hence alike on every rank.
+// PP: the exchange of the ONE-LAUNCH iteration on a decomposed space (k_dict_cg_iter<3, true> follows): r, w, s are double-buffered by
+// iteration parity and that kernel recomputes the new residual on its neighbour columns - ghost columns included - from the OLD r, w,
+// s.  So the received w goes into the ghost rows of the current w (pp.w_cur), and the ghost rows of s and r are advanced from the
+// current buffers into the next ones (pp.s_cur -> pp.s_nxt, pp.r_cur -> pp.r_nxt): the two fmas of the owner.  The iteration number
+// comes from it_ctr[par] (written by the previous iteration kernel).
+struct fs_pp_ghosts {
+    double* w_cur;
+    const double* s_cur;
+    double* s_nxt;
+    const double* r_cur;
+    double* r_nxt;
+    const int* it_ctr;
+    int par;
+};
+template <bool PP>
 __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int check_only, const double* __restrict__ ctrl,
                                                               const double* __restrict__ scal, const int* __restrict__ status,
                                                               double* r, const double* __restrict__ w, double* __restrict__ s_ghost,
-                                                              const fs_p2p_rowsred red, const fs_p2p_sendrows snd) {
+                                                              const fs_p2p_rowsred red, const fs_p2p_sendrows snd, const fs_pp_ghosts pp) {
     // (every scalar the launch needs is asked for before the first of them is looked at: each was written by the previous launch,
     // a dependent load is a round trip of about a microsecond, and this kernel sits on the critical path of every iteration)
     const int st0 = status[0], st2 = status[2];
@@ -1782,8 +1808,12 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     // sequence numbers of THIS exchange: one past the last executed ones (fs_comm.hip); read by every workgroup at its start,
     // advanced by the last workgroup through each part
     const unsigned long long rseq = *red.d_seq + 1ull, hseq = *snd.d_seq + 1ull;
+    const int it_dev = PP ? pp.it_ctr[pp.par] : 0;
     if (st0 != 0) return;
-    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
+    if (PP) {
+        iter = it_dev;
+        check_only = iter >= (int)it_max ? 1 : 0;
+    } else if (iter < 0) {          // captured batch: the index of the product that preceded this launch
         iter = st2 - 1;
         check_only = iter >= (int)it_max ? 1 : 0;
     }
@@ -1843,9 +1873,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int chec
     const double* own_recv = snd.own_recv + (int64_t)hslot * snd.recv_stride;
     for (int64_t k = e_first; k < snd.total_recv; k += stride) {
         const int64_t gi = snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k;
-        const double ss = fs_p2p_load(own_recv + k) + beta * s_ghost[k];
-        s_ghost[k] = ss;
-        r[gi] -= alpha * ss;
+        if (PP) {
+            const double wv = fs_p2p_load(own_recv + k);
+            pp.w_cur[gi] = wv;
+            const double ss = fma(beta, pp.s_cur[gi], wv);
+            pp.s_nxt[gi] = ss;
+            pp.r_nxt[gi] = fma(-alpha, ss, pp.r_cur[gi]);
+        } else {
+            const double ss = fs_p2p_load(own_recv + k) + beta * s_ghost[k];
+            s_ghost[k] = ss;
+            r[gi] -= alpha * ss;
+        }
     }
 }
 
@@ -2943,9 +2981,9 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
         FS_CHECK(ws.dinv.alloc(n + 2));
         FS_CHECK(ws.r.alloc(n + 2));
         FS_CHECK(ws.z.alloc(nl + 2));
-        FS_CHECK(ws.w.alloc(n + 2));
+        FS_CHECK(ws.w.alloc(nl + 2));        // (ghost room: the one-launch iteration on a decomposed space reads w and s on ghost columns)
         FS_CHECK(ws.p.alloc(n + 2));
-        FS_CHECK(ws.s.alloc(n + 2));
+        FS_CHECK(ws.s.alloc(nl + 2));
         ws.n = n;
         ws.nl = nl;
     }
@@ -3095,15 +3133,22 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     static const char* fused_env = getenv("FS_CG_FUSED");
     static const int64_t fused_max_rows = getenv("FS_CG_FUSED_MAX_ROWS") ? atoll(getenv("FS_CG_FUSED_MAX_ROWS")) : (int64_t)3000000;
     const int fused_opt = fused_env ? atoi(fused_env) : g_cg_fused;
-    const bool fused = ds && !pipelined && fuse_sums && !sp->halo.active && bs == 1 && fused_opt != 0 &&
-                       g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
-                       (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
-                       3 * (int64_t)sgrid * 2 <= (int64_t)ws.partials.n && sgrid <= 4 * FS_BLOCK && nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && (fused_opt > 0 || n <= fused_max_rows);
-    if (fused) {
+    const bool fused_common = ds && !pipelined && bs == 1 && fused_opt != 0 &&
+                              g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
+                              (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
+                              nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && (fused_opt > 0 || n <= fused_max_rows);
+    const int igrid = fused_common ? spmv_partials_unsplit(sp, bs) : 0;        // workgroups (= dot partials) of the iteration kernel
+    const bool fused_sized = fused_common && 3 * (int64_t)igrid * 2 <= (int64_t)ws.partials.n && igrid <= 4 * FS_BLOCK;
+    const bool fused = fused_sized && fuse_sums && !sp->halo.active;
+    // a decomposed space: the same kernel after the peer-to-peer exchange kernel (two launches per iteration instead of three) - where
+    // that exchange is what the iteration uses (decided per pass below: p2p_fuse); a rank-local choice, the exchange protocol is the same
+    static const bool fused_p2p_on = !(getenv("FS_CG_FUSED_P2P") && getenv("FS_CG_FUSED_P2P")[0] == '0');
+    const bool fusedp_ok = fused_sized && !fuse_sums && sp->halo.active && fused_p2p_on;
+    if (fused || fusedp_ok) {
         if (ws.z2.n != nl + 2) FS_CHECK(ws.z2.alloc(nl + 2));
-        if (ws.w2.n != n + 2) {
-            FS_CHECK(ws.w2.alloc(n + 2));
-            FS_CHECK(ws.s2.alloc(n + 2));
+        if (ws.w2.n != nl + 2) {
+            FS_CHECK(ws.w2.alloc(nl + 2));
+            FS_CHECK(ws.s2.alloc(nl + 2));
         }
         if (!ws.it_ctr.p) FS_CHECK(ws.it_ctr.alloc(2));
     }
@@ -3120,6 +3165,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     static const char* upd_nt_env = getenv("FS_UPDATE_NT");
     const bool upd_nt = upd_nt_env ? upd_nt_env[0] == '1' : (int64_t)sp->n_dofs_owned * 72 > ((int64_t)192 << 20);   // five vectors exceed the caches
     int total_iters = 0, n_samples = 0, n_pass = 0;
+    bool fusedp_used = false;
     int h_status[4] = {0, 0, 0, 0};
     bool use_guess = opts->nonzero_guess != 0;
     double true_rr = 0.0, thresh = 0.0, bb_host = 0.0, prev_true_rr = 1e300;
@@ -3273,35 +3319,58 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // same way; the RCCL iteration is not - ncclSend / ncclRecv / ncclAllReduce are host calls)
         // (automatic mode: every size - the launch gaps are 10 % of an iteration at 1 M rows and still 1.5 % at 10 M)
         const bool graph_sized = graph_mode != 0;
-        const bool use_graph = ds && !bicg && !pipelined && graph_sized && !fused &&
+        const bool fusedp = fusedp_ok && p2p_fuse && !bicg;
+        if (fusedp) fusedp_used = true;
+        const bool use_graph = ds && !bicg && !pipelined && graph_sized && !fused && !fusedp &&
                                ((fuse_sums && !sp->halo.active && bs == 1) || p2p_fuse);
         while (!finished) {
             const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
-            if (fused) {
-                // launch k = update k + product k + 1; buffers [k & 1] are read, [(k + 1) & 1] written
+            if (fused || fusedp) {
+                // launch k = update k + product k + 1; buffers [k & 1] are read, [(k + 1) & 1] written.  Decomposed space (fusedp):
+                // the exchange kernel goes first - it reduces the sums of the previous launch's partials over the ranks, stores the
+                // neighbours' w into the ghost rows of the current w and advances the ghost rows of r and s into the next buffers
                 double* const Z[2] = {ws.z.p, ws.z2.p};
                 double* const W[2] = {ws.w.p, ws.w2.p};
                 double* const SV[2] = {ws.s.p, ws.s2.p};
-                double* const PT[2] = {ws.partials.p, ws.partials.p + 3 * (int64_t)sgrid};
+                double* const PT[2] = {ws.partials.p, ws.partials.p + 3 * (int64_t)igrid};
                 const size_t lds = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
+                fs_p2p_rowsred red2[2] = {};
+                fs_p2p_sendrows snd2[2] = {};
+                if (fusedp)
+                    for (int c = 0; c < 2; ++c) FS_CHECK(fs_p2p_exchange_args(sp, PT[c], igrid, ws.sums.p, &red2[c], &snd2[c]));
+                auto launch_exchange = [&](int par) {
+                    const int64_t work = std::max(snd2[par].total_send, snd2[par].total_recv);
+                    const fs_pp_ghosts pp = {W[par], SV[par], SV[par ^ 1], Z[par], Z[par ^ 1], ws.it_ctr.p, par};
+                    hipLaunchKernelGGL((k_cg_p2p_exchange<true>), dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
+                                       0, 0, ws.ctrl.p, ws.scal.p, ws.status.p, (double*)nullptr, W[par], (double*)nullptr, red2[par], snd2[par], pp);
+                };
                 auto launch_iter = [&](int par) {
-#define FS_ITER_ARGS dim3(sgrid), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
+#define FS_ITER_ARGS dim3(igrid), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
                      reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.ncls, \
-                     Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], sgrid, \
-                     ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd()
-                    hipLaunchKernelGGL((k_dict_cg_iter<3>), FS_ITER_ARGS);
+                     Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], igrid, \
+                     ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd(), ws.sums.p
+                    if (fusedp) {
+                        launch_exchange(par);
+                        hipLaunchKernelGGL((k_dict_cg_iter<3, true>), FS_ITER_ARGS);
+                    } else hipLaunchKernelGGL((k_dict_cg_iter<3, false>), FS_ITER_ARGS);
 #undef FS_ITER_ARGS
                 };
                 if (k == 0) {
                     // product 0 (w_0 = A r_0 and its sums) by the plain product kernel; s_{-1} = p_{-1} = 0 were set above
                     FS_CHECK(ws.it_ctr.zero(s));
+                    if (fusedp && !p2p_ghosts_in) {          // the ghost rows of r_0: the plain send and receive kernels
+                        FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+                        p2p_ghosts_in = true;
+                    }
                     launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
                 }
                 if (graph_sized && k >= batch && kend - k == batch && kend <= max_iter && (batch & 1) == 0 && (k & 1) == 0) {
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
-                                           ws.ctrl.p, ws.scal.p};
-                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4, batch, sgrid, (int64_t)dict_map_xcd(),
+                                           ws.ctrl.p, ws.scal.p, snd2[0].own_recv, red2[0].own_buf,
+                                           fusedp ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation + 1) : nullptr};
+                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (fusedp ? 1 : 0), batch, igrid,
+                                              (int64_t)dict_map_xcd() + 16 * (int64_t)p2p_rows_cap,
                                               (int64_t)sp->n_dict_items, (int64_t)A->serial, (int64_t)sp->serial};
                     if (!ws.cgf_graph || memcmp(key, ws.cgf_key, sizeof(key)) || memcmp(key_i, ws.cgf_key_i, sizeof(key_i))) {
                         if (ws.cgf_graph) { (void)hipGraphExecDestroy(ws.cgf_graph); ws.cgf_graph = nullptr; }
@@ -3364,8 +3433,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         if (p2p_fuse) {
                             launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
                             const int64_t work = std::max(snd.total_send, snd.total_recv);
-                            hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
-                                               -1, 0, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd);
+                            hipLaunchKernelGGL((k_cg_p2p_exchange<false>), dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
+                                               -1, 0, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd, fs_pp_ghosts{});
                             if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                             else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                             continue;
@@ -3482,8 +3551,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const int fgrid = spmv_partials_unsplit(sp, bs);
                     FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                     const int64_t work = std::max(snd.total_send, snd.total_recv);
-                    hipLaunchKernelGGL(k_cg_p2p_exchange, dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
-                                       k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd);
+                    hipLaunchKernelGGL((k_cg_p2p_exchange<false>), dim3(fs_grid_for(std::max<int64_t>(work, 1), FS_BLOCK, p2p_rows_cap)), dim3(FS_BLOCK), 0, s,
+                                       k, co, ws.ctrl.p, ws.scal.p, ws.status.p, ws.z.p, ws.w.p, ws.sg.p, red, snd, fs_pp_ghosts{});
                     if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<false, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     else hipLaunchKernelGGL((k_cg_update_scaled<false, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, fgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
                     if (sample) {
@@ -3647,7 +3716,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         }
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
         stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
-        stats->fused_iteration = fused ? 1 : 0;
+        stats->fused_iteration = (fused || fusedp_used) ? 1 : 0;
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -18,7 +18,7 @@ result = {}
 
 if case == "box":
     # the bench path: device box-slab generator, closed-form halo plan, Jacobi-CG
-    nx, ny, nz, axis = 9, 7, 23, 0
+    nx, ny, nz, axis = [int(v) for v in os.environ.get("FS_TEST_BOX", "9,7,23,0").split(",")]
     parallel.ensure_comm()
     zr = partition.slab_ranges(nz + 1, world)[rank]
     mesh = B.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0), zplanes=zr)
@@ -33,9 +33,20 @@ if case == "box":
     B.assemble_vector(V, b, source=3.0)
     A.apply_dirichlet(b, dofs, vals, symmetric=True)
     st = B.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
-    full = parallel.gather_owned(x.get()[:lay["n_owned"]], lay["l2g"][:lay["n_owned"]], (nx + 1) * (ny + 1) * (nz + 1))
+    x1 = x.get()[:lay["n_owned"]].copy()
+    # a second solve on the same space from a perturbed iterate (restart path, captured batches re-used)
+    xg = x.get().copy()
+    xg[:lay["n_owned"]] *= 1.0 + 1e-3 * np.cos(np.asarray(lay["l2g"][:lay["n_owned"]], dtype=float))
+    x.set(xg)
+    st2 = B.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000, nonzero_guess=True)
+    n_glob = (nx + 1) * (ny + 1) * (nz + 1)
+    full = parallel.gather_owned(x1, lay["l2g"][:lay["n_owned"]], n_glob)
+    full2 = parallel.gather_owned(x.get()[:lay["n_owned"]], lay["l2g"][:lay["n_owned"]], n_glob)
+    flags = parallel.allgather_values(np.array([float(st["fused_iteration"]), float(st["row_classes"] > 0), float(st2["fused_iteration"])]))
     if rank == 0:
-        result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"])
+        result = dict(x=full, iterations=st["iterations"], converged=st["converged"], true_res=st["true_rel_residual"],
+                      x2=full2, iterations2=st2["iterations"], true_res2=st2["true_rel_residual"],
+                      fused=np.array([f[0] for f in flags]), dictionary=np.array([f[1] for f in flags]), fused2=np.array([f[2] for f in flags]))
     parallel.barrier()
     parallel.finalize()
 elif case == "box_stress":

@@ -67,6 +67,42 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
     assert np.abs(r["x"] - x.get()).max() <= 1e-9 * np.abs(x.get()).max()
 
 
+@pytest.mark.parametrize("world,mode", [(2, "default"), (3, "default"), (2, "two_launch_kernels"), (3, "breaks_mid_run")])
+def test_one_launch_iteration_on_a_decomposed_space(gpu, tmp_path, world, mode):
+    """The one-launch CG iteration under decomposition (k_cg_p2p_exchange<true> + k_dict_cg_iter<3, true>: two launches per iteration
+    instead of three).  A box whose mesh lines are wide enough for the row dictionary (72 vertices per line): every rank reports the
+    one-launch iteration, the field is the one-GPU field, a second solve from a perturbed iterate (restart, captured batches re-used)
+    as well; FS_CG_FUSED_P2P=0 keeps the three-launch iteration - same field; a transport that breaks in the middle of the run is
+    left by all ranks together and the solve repeated over RCCL."""
+    nx, ny, nz, axis = 71, 9, 23, 0
+    co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 2.0), nx, ny, nz)
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 0.8, 2.0))
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    b = gpu.DeviceVector(V.n_owned)
+    x = gpu.DeviceVector(V.n_local)
+    A.assemble(stiffness=20.0)
+    gpu.assemble_vector(V, b, source=3.0)
+    lo, hi = np.nonzero(co[:, axis] == 0)[0], np.nonzero(co[:, axis] == co[:, axis].max())[0]
+    A.apply_dirichlet(b, np.concatenate([lo, hi]).astype(np.int32),
+                      np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
+    st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+    assert st["row_classes"] > 0 and st["iterations"] > 64
+    env = {"default": {}, "two_launch_kernels": dict(FS_CG_FUSED_P2P="0"),
+           "breaks_mid_run": dict(FS_P2P_TEST="late:6", FS_P2P_TIMEOUT_MS="100")}[mode]
+    r = _run(world, "box", tmp_path, FS_TEST_BOX="%d,%d,%d,%d" % (nx, ny, nz, axis), **env)
+    assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10 and float(r["true_res2"]) <= 2e-10
+    assert abs(int(r["iterations"]) - st["iterations"]) <= 2
+    xs = x.get()
+    # (the second solve takes another Krylov path to the same tolerance: its error is the tolerance times the condition number)
+    assert np.abs(r["x"] - xs).max() <= 1e-9 * np.abs(xs).max() and np.abs(r["x2"] - xs).max() <= 2e-8 * np.abs(xs).max()
+    assert np.all(r["dictionary"] == 1)
+    if mode == "default":
+        assert np.all(r["fused"] == 1) and np.all(r["fused2"] == 1)
+    if mode == "two_launch_kernels":
+        assert np.all(r["fused"] == 0)
+
+
 @pytest.mark.parametrize("world,mode", [(3, "p2p"), (2, "p2p"), (3, "rccl")])
 def test_forty_solves_back_to_back_over_ranks(gpu, tmp_path, world, mode):
     """40 solves in a row on one decomposed space (operator, load and tolerance change from solve to solve): hundreds of exchanges
