@@ -499,6 +499,10 @@ class Watchdog:
 
 
 def kernel_name(V, st=None):
+    if st is not None and st.get("fused_iteration", 0) == 2:     # decomposed space: exchange kernel + iteration kernel
+        return ("k_cg_p2p_exchange<true> + k_dict_cg_iter<3,true> (TWO launches per CG iteration on a decomposed space: peer-to-peer "
+                "exchange - all-reduce, w to the neighbours, ghost rows of r and s advanced - then update of iteration k + row-dictionary "
+                "product of iteration k + 1, %d distinct rows in LDS)" % st["row_classes"])
     if st is not None and st.get("fused_iteration", 0):          # fs_krylov.hip k_dict_cg_iter: one launch per CG iteration
         return ("k_dict_cg_iter<3> (ONE launch per CG iteration: update of iteration k + row-dictionary product of iteration k + 1, "
                 "%d distinct rows in LDS; the new residual on the neighbour columns recomputed from the old r, w, s)" % st["row_classes"])

@@ -3716,7 +3716,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         }
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
         stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
-        stats->fused_iteration = (fused || fusedp_used) ? 1 : 0;
+        stats->fused_iteration = fusedp_used ? 2 : (fused ? 1 : 0);
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -355,7 +355,9 @@ typedef struct fs_krylov_stats {
                              * box mesh with constant coefficients: class numbers + the distinct rows in LDS instead of the value
                              * stream, verified bit for bit against the assembled values); 0: the streaming kernels */
     int fused_iteration;    /* 1: every CG iteration was ONE launch (update of iteration k + product of iteration k + 1 on a
-                             * row-dictionary operator; spmv_ms is then the duration of that launch and update_ms 0) */
+                             * row-dictionary operator; spmv_ms is then the duration of that launch and update_ms 0); 2: a decomposed
+                             * space - that launch preceded by the peer-to-peer exchange kernel (two launches per iteration;
+                             * spmv_ms is the pair) */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,

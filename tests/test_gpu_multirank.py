@@ -98,7 +98,7 @@ def test_one_launch_iteration_on_a_decomposed_space(gpu, tmp_path, world, mode):
     assert np.abs(r["x"] - xs).max() <= 1e-9 * np.abs(xs).max() and np.abs(r["x2"] - xs).max() <= 2e-8 * np.abs(xs).max()
     assert np.all(r["dictionary"] == 1)
     if mode == "default":
-        assert np.all(r["fused"] == 1) and np.all(r["fused2"] == 1)
+        assert np.all(r["fused"] == 2) and np.all(r["fused2"] == 2)      # (2: exchange kernel + iteration kernel)
     if mode == "two_launch_kernels":
         assert np.all(r["fused"] == 0)
 
