@@ -165,9 +165,9 @@ def main():
         for dk in sorted(fetch):              # row-dictionary form of the same product (dictionary in LDS / class rows per work item;
             if dk[0] == ph and (dk[1].startswith("k_dict_spmv<3, true") or dk[1].startswith("k_dict_spmv<3, false")):    # last argument: run length)
                 out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
-        ik = (ph, "k_dict_cg_iter<3>")                    # the one-launch CG iteration (update k + product k + 1; up to 3 M rows)
-        if ik in fetch:
-            out[tag.replace("spmv_fused", "cg_iter")] = int((2 * fetch[ik] + write.get(ik, 0.0)) * 1024)
+        for ik in sorted(fetch):                          # the one-launch CG iteration (update k + product k + 1; up to 3 M rows;
+            if ik[0] == ph and ik[1].startswith("k_dict_cg_iter<3"):      # second template argument: decomposed space)
+                out[tag.replace("spmv_fused", "cg_iter")] = int((2 * fetch[ik] + write.get(ik, 0.0)) * 1024)
         key = (ph, "k_assemble_p1_scalar_gather<false>")
         if key in fetch:
             out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
