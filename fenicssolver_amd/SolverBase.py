@@ -311,10 +311,11 @@ class SolverBase():
             rtol = min(float(sp.get('relative_tolerance', KRYLOV_RTOL_CAP)), KRYLOV_RTOL_CAP)
         max_iter = int(sp.get('krylov_maximum_iterations', max(int(sp.get('maximum_iterations', 500)), 20000)))
         pc = sp.get('preconditioner', 'jacobi')
-        if pc in ('petsc_amg', 'amg', 'hypre_amg'):
+        # every name DOLFIN's krylov_solver_preconditioners() lists (the reference forwards the key, SolverBase.py:638-641)
+        if pc in ('petsc_amg', 'amg', 'hypre_amg', 'ml_amg'):
             pc = 'amg'        # smoothed aggregation on the device (fs_amg_*)
-        elif pc in ('default', 'jacobi', 'sor', 'ilu', 'icc'):
-            pc = 'jacobi'     # point preconditioners other than Jacobi are not built
+        elif pc in ('default', 'jacobi', 'bjacobi', 'sor', 'ilu', 'icc', 'additive_schwarz', 'hypre_euclid', 'hypre_parasails'):
+            pc = 'jacobi'     # point / block / incomplete-factorisation preconditioners other than Jacobi are not built
         elif pc in ('none', None):
             pc = 'none'
         else:

@@ -120,6 +120,25 @@ def test_linear_solver_names_dolfin_knows_are_accepted(gpu, name):
             ScalarTransportSolver(s4).solve()
 
 
+@pytest.mark.parametrize("pc", ["bjacobi", "additive_schwarz", "hypre_euclid", "ilu", "ml_amg", "none"])
+def test_preconditioner_names_dolfin_knows_are_accepted(gpu, pc):
+    """Likewise 'preconditioner': every name of DOLFIN's krylov_solver_preconditioners() runs (point / block / incomplete
+    factorisations on the Jacobi kernel, the algebraic multigrids on the device's smoothed aggregation); an unknown one is refused."""
+    from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
+    from fenicssolver_amd.SolverBase import SolverError
+    s, m = _box_heat_settings(6)
+    s['solver_settings']['solver_parameters'] = {'linear_solver': 'cg', 'preconditioner': pc}
+    solver = ScalarTransportSolver(s)
+    T = solver.solve()
+    y = m.coordinates()[:, 1]
+    assert np.abs(T.vector().array() - (300 + 60 * y)).max() < 1e-7
+    if pc == "none":
+        s4, _ = _box_heat_settings(3)
+        s4['solver_settings']['solver_parameters'] = {'preconditioner': 'magic'}
+        with pytest.raises(SolverError):
+            ScalarTransportSolver(s4).solve()
+
+
 def test_reference_tolerance_key_below_the_fallback_is_binding(gpu):
     """'relative_tolerance' (the reference's key) tighter than the 1e-8 of the softened default is a request, not a hint:
     a solve that cannot reach it within the iteration limit raises instead of returning a 1e-8-accurate field."""
