@@ -1,10 +1,10 @@
 #!/bin/bash
 # ON THE GPU BOX: kernel-trace durations of the CG kernels of tools/probes/fused_iter_probe.py (arguments passed on); works for
-# timing ablations whose solves break down (the launches before the breakdown are in the trace)
+# timing ablations whose solves break down (the launches before the breakdown are in the trace); PROBE=p2_iter_probe.py: configs[3]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 rm -rf /tmp/fs_tr; mkdir -p /tmp/fs_tr; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/fs_tr -o run -- python $R/tools/probes/fused_iter_probe.py "$@" > /tmp/fs_tr/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/fs_tr -o run -- python $R/tools/probes/${PROBE:-fused_iter_probe.py} "$@" > /tmp/fs_tr/log 2>&1
 tail -2 /tmp/fs_tr/log
 F=$(find /tmp/fs_tr -name "*kernel_trace.csv" | head -1)
 python - "$F" <<'P'
