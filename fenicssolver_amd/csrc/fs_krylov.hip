@@ -3675,10 +3675,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         std::vector<long long> h(8 * 4096);
         FS_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_iter_dbg), h.size() * sizeof(long long)));
         long long first = h[0], last = 0;
-        for (int b = 0; b < sgrid; ++b) { first = std::min(first, h[8 * b]); last = std::max(last, h[8 * b + 7]); }
+        for (int b = 0; b < igrid; ++b) { first = std::min(first, h[8 * b]); last = std::max(last, h[8 * b + 7]); }
         double mean[8] = {0}, mx[8] = {0};
-        for (int b = 0; b < sgrid; ++b)
-            for (int k2 = 0; k2 < 8; ++k2) { const double v = (h[8 * b + k2] - first) * 0.01; mean[k2] += v / sgrid; mx[k2] = std::max(mx[k2], v); }
+        for (int b = 0; b < igrid; ++b)
+            for (int k2 = 0; k2 < 8; ++k2) { const double v = (h[8 * b + k2] - first) * 0.01; mean[k2] += v / igrid; mx[k2] = std::max(mx[k2], v); }
         fprintf(stderr, "[iter timing, last launch, us from the first workgroup's start] span %.2f;", (last - first) * 0.01);
         for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, " s%d mean %.2f max %.2f;", k2, mean[k2], mx[k2]);
         fprintf(stderr, "\n");
