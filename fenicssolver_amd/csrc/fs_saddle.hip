@@ -399,25 +399,30 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         }
                     }
                     const bool full = P.convection && P.newton;
+                    // (the kernel is instruction-bound - counters in DESIGN.md section 3 -: the weight goes into the factors once,
+                    // the nine viscous terms are 3 + 9 operations instead of 27, the Newton term 2 + 9)
+                    const double wd = wv * diag, wn = wv * nuq;
+                    const double wga[3] = {wn * ga[0], wn * ga[1], wn * ga[2]};
+                    const double wpp = full ? wv * pa * pb : 0.0;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        blk[i][i] += wv * diag;
+                        blk[i][i] += wd;
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
-                            double v = nuq * ga[j] * gb[i];
-                            if (full) v += pa * pb * L.gu0[q][3 * i + j];
-                            blk[i][j] += wv * v;
+                            blk[i][j] = fma(wga[j], gb[i], blk[i][j]);
+                            if (full) blk[i][j] = fma(wpp, L.gu0[q][3 * i + j], blk[i][j]);
                         }
                     }
+                    const double wr = wv * P.inv_rho;
                     if (b < 4) {   // pressure trial function psi_b = lambda_b
-                        const double psi = NS_QP[q][b];
+                        const double wpsi = wr * NS_QP[q][b];
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) blk[i][3] -= wv * P.inv_rho * psi * ga[i];
+                        for (int i = 0; i < 3; ++i) blk[i][3] = fma(-wpsi, ga[i], blk[i][3]);
                     }
                     if (a < 4) {   // continuity test function psi_a
-                        const double psi = NS_QP[q][a];
+                        const double wpsi = wr * NS_QP[q][a];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) blk[3][j] += wv * P.inv_rho * psi * gb[j];
+                        for (int j = 0; j < 3; ++j) blk[3][j] = fma(wpsi, gb[j], blk[3][j]);
                     }
                     if (do_rhs) {
 #pragma unroll
