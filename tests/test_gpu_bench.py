@@ -42,6 +42,11 @@ def test_default_command_prints_the_contract_line(gpu):
     assert "k_dict_spmv" in r["kernel"] and "note_row_dictionary" in r
     s = r["streaming_kernel"]
     assert "k_dia_pair_spmv" in s["kernel"] and 0.5 <= s["frac"] <= 1.0 and s["cg_iterations"] == r["cg_iterations"] == 451
+    # the step workload itself (1 M rows, cache-resident): ONE launch per CG iteration, priced on the 90 B/row that launch moves
+    k = d["dominant_kernel_on_step_workload"]
+    assert "k_dict_cg_iter" in k["kernel"] and k["fused_iteration"] == 1 and k["required_bytes_per_launch"] == 90 * 1000000
+    assert k["update_kernel"]["frac"] is None and k["iteration"]["required_bytes"] == 90 * 1000000 and 0.0 < k["iteration"]["frac"] <= 1.0
+    assert d["update_kernel_ms"] == 0.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "DOF/s" and c["sample"]
     assert d["parity"]["iterations_gpu"] == d["parity"]["iterations_cpu"] and d["parity"]["max_rel_diff_solution"] <= 1e-9
