@@ -381,6 +381,8 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     for (int j = 0; j < 4; ++j) blk[i][j] = 0.0;
                 double gv[3] = {0.0, 0.0, 0.0};
                 const bool do_rhs = b == 0;
+                const int bsel = b < 4 ? b : 0, asel = a < 4 ? a : 0;
+                const double bmask = b < 4 ? 1.0 : 0.0, amask = a < 4 ? 1.0 : 0.0;
                 for (int q = 0; q < 14; ++q) {
                     const double wv = NS_QW[q] * vol;
                     const double pa = L.phi[q][a], pb = L.phi[q][b];
@@ -413,17 +415,15 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                             if (full) blk[i][j] = fma(wpp, L.gu0[q][3 * i + j], blk[i][j]);
                         }
                     }
+                    // pressure trial function psi_b = lambda_b (b < 4) and continuity test function psi_a (a < 4): branch-free (a
+                    // zero factor for the edge nodes) - every lane-divergent branch inside this loop is an exec-mask sequence of
+                    // scalar instructions, 14 times per block
                     const double wr = wv * P.inv_rho;
-                    if (b < 4) {   // pressure trial function psi_b = lambda_b
-                        const double wpsi = wr * NS_QP[q][b];
+                    const double wpb = wr * (NS_QP[q][bsel] * bmask), wpa = wr * (NS_QP[q][asel] * amask);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) blk[i][3] = fma(-wpsi, ga[i], blk[i][3]);
-                    }
-                    if (a < 4) {   // continuity test function psi_a
-                        const double wpsi = wr * NS_QP[q][a];
+                    for (int i = 0; i < 3; ++i) blk[i][3] = fma(-wpb, ga[i], blk[i][3]);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) blk[3][j] = fma(wpsi, gb[j], blk[3][j]);
-                    }
+                    for (int j = 0; j < 3; ++j) blk[3][j] = fma(wpa, gb[j], blk[3][j]);
                     if (do_rhs) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
