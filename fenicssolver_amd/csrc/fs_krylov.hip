@@ -2144,6 +2144,23 @@ __global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// up to four vectors zeroed by ONE launch (the start of a CG pass: p, s, z and x - four memsets of 8 MB each at 1 M rows were four
+// launches with their gaps)
+__global__ void __launch_bounds__(FS_BLOCK) k_zero4(double* __restrict__ a, int64_t na, double* __restrict__ b, int64_t nb,
+                                                    double* __restrict__ c, int64_t nc, double* __restrict__ d, int64_t nd) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double* const ptr[4] = {a, b, c, d};
+    const int64_t len[4] = {na, nb, nc, nd};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double* __restrict__ v = ptr[q];
+        const int64_t n2 = len[q] >> 1;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) reinterpret_cast<v2d*>(v)[i] = v2d{0.0, 0.0};
+        if ((len[q] & 1) && blockIdx.x == 0 && threadIdx.x == 0) v[len[q] - 1] = 0.0;
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
 static int g_spmv_blocks = 1024;
@@ -2950,6 +2967,7 @@ struct krylov_ws {
     int64_t bicg_n = -1;
     dbuf<int> status;
     int* h_status = nullptr;  // pinned: 2 x 4 status ints (double-buffered polls) + [8] zero-diagonal count
+    double* h_vals = nullptr; // pinned: the sums [0 .. 8) and the control block [8 .. 12) at the end of a pass
     hipEvent_t poll[2] = {nullptr, nullptr};
     static const int NSAMPLE = 64;
     hipEvent_t ev[NSAMPLE][4];
@@ -2994,7 +3012,8 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
         FS_CHECK(ws.scal.alloc(4));
         FS_CHECK(ws.status.alloc(4));
         FS_CHECK(ws.d_err.alloc(1));
-        FS_HIP(hipHostMalloc((void**)&ws.h_status, 12 * sizeof(int), hipHostMallocDefault));
+        FS_HIP(hipHostMalloc((void**)&ws.h_status, 16 * sizeof(int), hipHostMallocDefault));     // ([12 .. 16): the status word at the end of a pass)
+        FS_HIP(hipHostMalloc((void**)&ws.h_vals, 16 * sizeof(double), hipHostMallocDefault));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[0], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[1], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.ev_upd, hipEventDisableTiming));
@@ -3173,13 +3192,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // initial state
         FS_CHECK(ws.status.zero(s));
         FS_CHECK(ws.scal.zero(s));
-        FS_CHECK(ws.p.zero(s));
-        FS_CHECK(ws.s.zero(s));
+        // p, s, z and - from a zero guess - x in one launch
+        hipLaunchKernelGGL(k_zero4, dim3(fs_grid_for(std::max<int64_t>(nl / 2, 1), FS_BLOCK, 1024)), dim3(FS_BLOCK), 0, s, ws.p.p, ws.p.n, ws.s.p, ws.s.n,
+                           ws.z.p, ws.z.n, x->d.p, use_guess ? (int64_t)0 : x->d.n);
         if (sp->halo.active) {          // s on the ghost rows (k_cg_p2p_exchange)
             if (ws.sg.n < nl - n + 2) FS_CHECK(ws.sg.alloc(nl - n + 2));
             FS_CHECK(ws.sg.zero(s));
         }
-        FS_CHECK(ws.z.zero(s));
         if (ds) {
             // scaled unknown xhat = D^1/2 x lives in the caller's x until the final un-scaling; rhat in ws.z
             if (use_guess) {
@@ -3189,7 +3208,6 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
                 hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, n, ws.z.p, ws.partials.p);
             } else {
-                FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
                 FS_HIP(hipMemcpyAsync(ws.z.p, ws.bhat.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
             }
         } else {
@@ -3199,7 +3217,6 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s);
                 hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, ws.r.p, ws.partials.p);
             } else {
-                FS_HIP(hipMemsetAsync(x->d.p, 0, (size_t)x->d.n * sizeof(double), s));
                 FS_HIP(hipMemcpyAsync(ws.r.p, b->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
             }
             hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, ws.r.p, n, ws.z.p);
@@ -3620,10 +3637,23 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // pipelined: the reduction enqueued behind the last update still reads the partial sums on the communication stream;
         // nothing of the workspace is touched again before it is through
         if (red_stream) FS_HIP(hipStreamWaitEvent(s, ws.ev_red, 0));
+        // The end of a pass used to be six host synchronisations (stream, status word, sums, control block, the un-scaling of x,
+        // the history): 0.68 ms of fixed cost per solve at 1 M rows, a tenth of the whole solve.  Nothing of the true-residual
+        // computation depends on what the host learns from the status word, so it is enqueued first and status, sums and control
+        // block come back in ONE synchronisation.
+        // true residual b - A x (scaled mode: sum d (bhat - Ahat xhat)^2, the same number)
+        FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
+        launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
+        if (ds) hipLaunchKernelGGL(k_residual_scaled, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, ws.dvec.p, n, (double*)nullptr, ws.partials.p);
+        else hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
+        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, pgrid, 1, ws.sums.p + 5, s));
+        FS_HIP(hipMemcpyAsync(ws.h_status + 12, ws.status.p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        FS_HIP(hipMemcpyAsync(ws.h_vals, ws.sums.p, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FS_HIP(hipMemcpyAsync(ws.h_vals + 8, ws.ctrl.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         FS_HIP(hipStreamSynchronize(s));
         if (fs_p2p_reduce_enabled()) FS_CHECK(fs_p2p_check(s));
-        h_status[0] = h_status[1] = h_status[2] = h_status[3] = 0;
-        FS_CHECK(ws.status.download(h_status, 4, s));
+        for (int q = 0; q < 4; ++q) h_status[q] = ws.h_status[12 + q];
         const int iters = h_status[1];
         total_iters += iters;
         // launches enqueued after the recurrence stopped return on the status word: their samples time no-ops
@@ -3632,18 +3662,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             fs_set_error("fs_krylov_solve: %d zero%s diagonal entries (Jacobi preconditioner undefined)", ws.h_status[8], ds ? " or negative" : "");
             return FS_ERR_NUMERIC;
         }
-
-        // true residual b - A x (scaled mode: sum d (bhat - Ahat xhat)^2, the same number)
-        FS_HIP(hipMemcpyAsync(ws.z.p, x->d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
-        launch_spmv<0>(A, ws.z.p, ws.w.p, nullptr, nullptr, nullptr, s, aval);
-        if (ds) hipLaunchKernelGGL(k_residual_scaled, dim3(pgrid), dim3(FS_BLOCK), 0, s, ws.bhat.p, ws.w.p, ws.dvec.p, n, (double*)nullptr, ws.partials.p);
-        else hipLaunchKernelGGL(k_residual, dim3(pgrid), dim3(FS_BLOCK), 0, s, b->d.p, ws.w.p, n, (double*)nullptr, ws.partials.p);
-        FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, pgrid, 1, ws.sums.p + 5, s));
-
-        double h_pass[8], h_ctrl2[4];
-        FS_CHECK(ws.sums.download(h_pass, 8, s));
-        FS_CHECK(ws.ctrl.download(h_ctrl2, 4, s));
+        const double* h_pass = ws.h_vals;
+        const double* h_ctrl2 = ws.h_vals + 8;
         true_rr = h_pass[5];
         thresh = h_ctrl2[0];
         bb_host = h_ctrl2[1];
@@ -3657,10 +3677,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         prev_true_rr = true_rr;
         use_guess = true;   // restart: r := b - A x exactly, then continue
     }
-    if (ds) {   // x = D^-1/2 xhat
+    if (ds) {   // x = D^-1/2 xhat (no synchronisation of its own: the download of the history below waits for it)
         hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, x->d.p, n, x->d.p);
         FS_KERNEL_CHECK();
-        FS_HIP(hipStreamSynchronize(s));
     }
     const int iters = total_iters;
     if (fs_rt().comm && getenv("FS_COMM_TIMING")) {
