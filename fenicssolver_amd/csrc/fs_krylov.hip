@@ -446,8 +446,45 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
     const int32_t dp = dia_ptr[sl];
     const int32_t* __restrict__ op = dia_off + dp + 1 + (ln >= dia_off[dp] ? width : 0);
     const double* __restrict__ vp = val + base + ln;
-    int g = 1;                  // run 0 is the z run
     bool ok = true;
+    if (n_runs == 8 && nq == 1) {
+        // one-round plans of scalar operators (P1): the eight run starts and lengths are wave-uniform - in scalar registers, an
+        // entry's position is found by comparing its offset with all of them - and the row is taken eight entries at a time,
+        // offsets and values of a batch (and whatever f loads) in flight together; the walk below goes entry by entry, two loads
+        // and a branch per step of the plan, each waited for
+        int32_t st[8], le[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            st[j] = __builtin_amdgcn_readfirstlane(pl->start[j]);
+            le[j] = __builtin_amdgcn_readfirstlane((int)pl->len[j]);
+        }
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int32_t o[8];
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u < width ? k0 + u : width - 1;        // (clamped: the loads of a short batch stay inside the row)
+                o[u] = op[k];
+                v[u] = vp[(int64_t)k * FS_SLICE];
+            }
+            int slot[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                slot[u] = -1;
+#pragma unroll
+                for (int j = 1; j < 8; ++j)              // (run 0 is the z run: no coefficients)
+                    if (le[j] > 0 && o[u] >= st[j] && o[u] < st[j] + le[j]) slot[u] = RL * j + (o[u] - st[j]);
+                if (k0 + u >= width || v[u] == 0.0) slot[u] = -3;         // nothing stored there
+                if (slot[u] == -1) ok = false;                           // a value outside the plan
+            }
+            if (!ok) return false;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (slot[u] >= 0) f(slot[u], v[u]);
+        }
+        return true;
+    }
+    int g = 1;                  // run 0 is the z run
     for (int k = 0; k < width && ok; ++k) {
         int slot = -2;          // not looked up yet
         for (int q = 0; q < nq; ++q) {
@@ -611,7 +648,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
         crowded = distinct > crowded ? distinct : crowded;
     }
     if (bad) atomicAdd(&info[2], bad);
-    if (crowded && lane == 0) atomicMax(&info[3], crowded);
+    // (a look before the atomic: nearly every wave holds the same maximum, and 8 000 atomics on one address were most of this
+    // kernel's time at 1 M rows)
+    if (crowded && lane == 0 && crowded > __hip_atomic_load(&info[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[3], crowded);
 }
 
 // the next lane's value (DPP wave shift, no LDS); lane 63, which has no next lane, owns no rows
