@@ -1047,6 +1047,16 @@ struct row_dict {
     uint64_t matrix_serial = 0;             // ... of this matrix (addresses are handed out again after a free: the pointer alone is no identity)
     uint64_t gave_up_on = 0;                // serial of a matrix whose rows were not repetitive: not tried again
     int64_t n_built = 0, n_failed = 0;      // statistics (fs_krylov_stats)
+    // The tables of the last successful build (cls_slot, slot2cls, values, nnz) outlive the call they were built in: the next call
+    // on the same space first has EVERY row of its matrix compared with the row's old class, bit for bit (k_dict_finish alone,
+    // one pass over the values instead of three) - the matrix of a steady problem solved again, of a transient one with a constant
+    // step.  A matrix that differs anywhere fails the comparison and is described from scratch; after a failure the next
+    // attempts are skipped (1, 2, 4 .. 64 calls: Newton and Picard loops change their matrix every time).
+    uint64_t tables_space = 0;              // serial of the space the tables describe (0: none)
+    int tables_bs = 0, tables_S = 0, tables_ncls = 0;
+    int reuse_backoff = 0, reuse_skip = 0;
+    int64_t n_reused = 0;
+    bool kept = false;                      // the tables in use were kept from the previous call
 };
 static row_dict g_dict;
 // The dictionary describes the values of ONE call (a solve, fs_spmv_dictionary): whoever builds it drops it on the way out, so that no
@@ -2602,20 +2612,60 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     const int nq = A->bs * A->bs;               // values per stored entry (3 x 3 blocks of a vector space: the class rows are [position][9])
     const int S = sp->dict_slots * nq;
     const int64_t padded = sp->n_nodes_owned + 2 * FS_DICT_ITEM_ROWS;
-    if (D.cls.n < padded) { FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
+    if (D.cls.n < padded) { D.tables_space = 0; FS_CHECK(D.cls.alloc(padded)); FS_CHECK(D.cls_slot.alloc(padded)); }
     if (!D.keys.p) {
         FS_CHECK(D.keys.alloc(FS_DICT_CAP));
         FS_CHECK(D.slot2cls.alloc(FS_DICT_CAP));
         FS_CHECK(D.nnz.alloc(FS_DICT_MAX));
         FS_CHECK(D.info.alloc(4));
     }
-    if (D.slot_vals.n < (int64_t)FS_DICT_CAP * S) { FS_CHECK(D.slot_vals.alloc((int64_t)FS_DICT_CAP * S)); FS_CHECK(D.values.alloc((int64_t)FS_DICT_MAX * S)); }
-    FS_CHECK(D.keys.zero(s));
-    FS_CHECK(D.info.zero(s));
-    FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
+    if (D.slot_vals.n < (int64_t)FS_DICT_CAP * S) { D.tables_space = 0; FS_CHECK(D.slot_vals.alloc((int64_t)FS_DICT_CAP * S)); FS_CHECK(D.values.alloc((int64_t)FS_DICT_MAX * S)); }
     const int4* items = reinterpret_cast<const int4*>(sp->dict_items.p);
     const dict_plan_round* plans = reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p);
     const int grid = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
+    const auto usable = [&](const int* h, int ncls) {
+        // (worth it only where rows really repeat: at most one class per 16 rows)
+        return h[1] == 0 && h[2] == 0 && h[3] > 0 && (int64_t)(FS_BLOCK / 64) * h[3] * S * (int64_t)sizeof(double) <= FS_DICT_LDS_BYTES &&
+               ncls > 0 && ncls <= FS_DICT_MAX && (int64_t)ncls * 16 <= sp->n_nodes_owned;
+    };
+    const auto adopt = [&](const int* h, int ncls) {
+        D.ncls = ncls;
+        D.S = S;
+        D.C = h[3];
+        D.bs = A->bs;
+        D.built_for = val;
+        D.space_serial = sp->serial;
+        D.matrix_serial = A->serial;
+    };
+    static const bool no_reuse = getenv("FS_DICT_REUSE") && getenv("FS_DICT_REUSE")[0] == '0';
+    if (!no_reuse && D.tables_space == sp->serial && D.tables_bs == A->bs && D.tables_S == S && D.tables_ncls > 0) {
+        if (D.reuse_skip > 0) --D.reuse_skip;
+        else {
+            FS_CHECK(D.info.zero(s));
+            hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
+                               val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
+            FS_KERNEL_CHECK();
+            int h[4] = {0, 0, 0, 0};
+            FS_CHECK(D.info.download(h, 4, s));
+            const bool same = usable(h, D.tables_ncls);
+            if (getenv("FS_KRYLOV_DEBUG"))
+                fprintf(stderr, "[fs_krylov] row dictionary: the %d classes of the last call against the %lld rows of this one: %d mismatches -> %s\n",
+                        D.tables_ncls, (long long)sp->n_nodes_owned, h[2], same ? "kept" : "built again");
+            if (same) {
+                adopt(h, D.tables_ncls);
+                D.kept = true;
+                D.reuse_backoff = 0;
+                ++D.n_reused;
+                return FS_OK;
+            }
+            D.reuse_backoff = D.reuse_backoff ? (D.reuse_backoff < 64 ? 2 * D.reuse_backoff : 64) : 1;
+            D.reuse_skip = D.reuse_backoff;
+        }
+    }
+    D.tables_space = 0;
+    FS_CHECK(D.keys.zero(s));
+    FS_CHECK(D.info.zero(s));
+    FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
     hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
                        val, nq, sp->sell_entries, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
     hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, S, D.slot2cls.p, D.values.p, D.nnz.p);
@@ -2624,9 +2674,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
-    // (worth it only where rows really repeat: at most one class per 16 rows)
-    const bool ok = h[1] == 0 && h[2] == 0 && h[3] > 0 && (int64_t)(FS_BLOCK / 64) * h[3] * S * (int64_t)sizeof(double) <= FS_DICT_LDS_BYTES &&
-                    h[0] > 0 && h[0] <= FS_DICT_MAX && (int64_t)h[0] * 16 <= sp->n_nodes_owned;
+    const bool ok = usable(h, h[0]);
     if (getenv("FS_KRYLOV_DEBUG"))
         fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of %d positions among %lld, %d mismatches, at most %d classes per item -> %s\n", h[0], S,
                 (long long)sp->n_nodes_owned, h[2], h[3], ok ? "compressed product" : "plain product");
@@ -2635,13 +2683,12 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
         ++D.n_failed;
         return FS_OK;
     }
-    D.ncls = h[0];
-    D.S = S;
-    D.C = h[3];
-    D.bs = A->bs;
-    D.built_for = val;
-    D.space_serial = sp->serial;
-    D.matrix_serial = A->serial;
+    adopt(h, h[0]);
+    D.kept = false;
+    D.tables_space = sp->serial;
+    D.tables_bs = A->bs;
+    D.tables_S = S;
+    D.tables_ncls = h[0];
     ++D.n_built;
     return FS_OK;
 }
@@ -3775,6 +3822,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         stats->spmv_bytes = sp->nnz_nodes * bs * bs * 12 + n * 20;
         stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
         stats->fused_iteration = fusedp_used ? 2 : (fused ? 1 : 0);
+        stats->classes_kept = g_dict.built_for && g_dict.kept ? 1 : 0;
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -358,6 +358,10 @@ typedef struct fs_krylov_stats {
                              * row-dictionary operator; spmv_ms is then the duration of that launch and update_ms 0); 2: a decomposed
                              * space - that launch preceded by the peer-to-peer exchange kernel (two launches per iteration;
                              * spmv_ms is the pair) */
+    int classes_kept;       /* 1: the class table of the previous call on this space was kept - every row of THIS matrix was
+                             * compared with its old class, bit for bit, and none differed (a steady problem solved again, a
+                             * transient one with a constant step: one pass over the values instead of three); 0: the classes
+                             * were found from scratch (or the streaming kernels ran) */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,
@@ -371,7 +375,8 @@ int fs_krylov_history(double* out, int capacity, int* count);
 int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, double* ms_per_launch);
 
 /* y = A x (MatMult, behind KSPSolve at SolverBase.py:663-670) through the ROW-DICTIONARY form of the product where the rows of A
- * repeat (a uniform box mesh with constant coefficients): the classes are found from A's current values inside this call,
+ * repeat (a uniform box mesh with constant coefficients): the classes are found from A's current values inside this call (or
+ * kept from the previous call on the same space, where every row of A still equals its old class),
  * every row is verified against its class, and the table is dropped when the call returns.  *row_classes = number of distinct
  * rows used, 0 = the rows do not repeat and the streaming product ran.  Both forms give the same bits as fs_spmv. */
 int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_classes);

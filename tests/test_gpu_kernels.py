@@ -889,6 +889,67 @@ def test_row_dictionary_is_not_used_where_rows_do_not_repeat(gpu):
     assert np.abs(x4.get()[:V4.n_owned] - x3.get()[:V3.n_owned]).max() <= 1e-8 * np.abs(x3.get()).max()
 
 
+def test_class_table_is_kept_only_for_a_matrix_that_still_equals_it_row_for_row(gpu):
+    """The class table of a call outlives it, and the next call on the same space first compares EVERY row of its matrix with
+    the row's old class, bit for bit (fs_krylov_stats.classes_kept): the same system solved again keeps the table - same bits
+    of the solution; one more Dirichlet row (15 rows of a million-entry operator change), or another coefficient (all of them),
+    fails the comparison, the classes are found from scratch and the result is that of the streaming kernels."""
+    n = 24
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    P, V, A, b = _box_system(gpu, mesh, n)
+
+    def solve(AA, bb):
+        x = gpu.DeviceVector(V.n_local)
+        st = gpu.krylov_solve(AA, bb, x, rtol=1e-10, max_iter=5000)
+        assert st["converged"] == 1
+        return st, x.get()[:V.n_owned].copy()
+
+    def streaming(AA, bb):
+        gpu.set_option("row_dictionary", 0)
+        try:
+            st, x = solve(AA, bb)
+        finally:
+            gpu.set_option("row_dictionary", 1)
+        assert st["row_classes"] == 0
+        return x
+
+    s1, x1 = solve(A, b)
+    assert s1["row_classes"] > 0 and s1["classes_kept"] == 0           # a space never seen before
+    s2, x2 = solve(A, b)
+    assert s2["classes_kept"] == 1 and s2["row_classes"] == s1["row_classes"] and s2["iterations"] == s1["iterations"]
+    assert np.array_equal(x2, x1)
+    # one interior node pinned: its row and its neighbours' change, nothing else
+    node = np.array([(n + 1) ** 2 * (n // 2) + (n + 1) * (n // 2) + n // 2], dtype=P["dofs"].dtype)
+    A.apply_dirichlet(b, node, np.array([400.0]), symmetric=True)
+    s3, x3 = solve(A, b)
+    assert s3["row_classes"] > s1["row_classes"] and s3["classes_kept"] == 0
+    assert abs(x3[node[0]] - 400.0) <= 1e-9 * 400.0
+    ref = streaming(A, b)
+    assert np.abs(x3 - ref).max() <= 1e-9 * np.abs(ref).max()
+    # ... and the product on the changed matrix, bit for bit (a stale table would be off in those 15 rows)
+    xv = gpu.DeviceVector(V.n_local)
+    ya = gpu.DeviceVector(V.n_owned)
+    yb = gpu.DeviceVector(V.n_owned)
+    xv.set(np.random.default_rng(11).standard_normal(V.n_local))
+    assert A.spmv_dictionary(xv, ya) > 0
+    A.spmv(xv, yb)
+    assert np.array_equal(ya.get(), yb.get())
+    # another coefficient on the same space: every row differs
+    A.assemble(stiffness=23.0)
+    b5 = gpu.DeviceVector(V.n_owned)
+    gpu.assemble_vector(V, b5, source=3.0)
+    A.apply_dirichlet(b5, P["dofs"], P["vals"], symmetric=True)
+    kept = []
+    for rep in range(4):                # (after a failed comparison the next attempts are skipped: 1, 2, 4 ... calls)
+        s5, x5 = solve(A, b5)
+        kept.append(s5["classes_kept"])
+        assert s5["row_classes"] == s1["row_classes"]
+        if rep == 0:
+            ref5 = streaming(A, b5)
+        assert np.abs(x5 - ref5).max() <= 1e-9 * np.abs(ref5).max()
+    assert kept[0] == 0 and kept[-1] == 1
+
+
 def test_box_assembly_is_translation_invariant_and_matches_the_oracle(gpu):
     """fs_mesh_create_box meshes: interior rows of the P1 operator are identical BIT FOR BIT (edge vectors snapped to the grid
     spacing), and the values are the oracle's to rounding."""
