@@ -2520,7 +2520,8 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
             hipLaunchKernelGGL(k_assemble_p1_elasticity_gather<false>, dim3(gg), dim3(FS_BLOCK), 0, s, sp->sell_entries, sp->gmap_ptr.p, sp->gmap_src.p, m->cells.p, m->xyz.p, form->lame_mu, form->lame_lambda, mc, sp->sell_entries, A->val.p, make_box_snap(m));
     }
     FS_KERNEL_CHECK();
-    FS_HIP(hipStreamSynchronize(s));
+    // (no wait here: host arrays were consumed by make_coef's uploads, the coefficient stores go back to the pool in stream order,
+    // and whatever the caller enqueues next - the load vector, the Dirichlet rows - is prepared while the assembly runs)
     return FS_OK;
 }
 

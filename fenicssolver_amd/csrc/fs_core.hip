@@ -293,7 +293,6 @@ extern "C" int fs_vector_fill(fs_vector_t v, double value) {
     if (v->d.n == 0) return FS_OK;
     hipLaunchKernelGGL(k_fill, dim3(fs_grid_for(v->d.n)), dim3(FS_BLOCK), 0, fs_rt().stream, v->d.p, v->d.n, value);
     FS_KERNEL_CHECK();
-    FS_HIP(hipStreamSynchronize(fs_rt().stream));
     return FS_OK;
 }
 
