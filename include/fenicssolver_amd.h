@@ -155,7 +155,7 @@ int fs_vector_create(int64_t n, fs_vector_t* out);
 int fs_vector_size(fs_vector_t v, int64_t* n);
 int fs_vector_set(fs_vector_t v, const double* host, int64_t n);
 int fs_vector_get(fs_vector_t v, double* host, int64_t n);
-int fs_vector_fill(fs_vector_t v, double value);
+int fs_vector_fill(fs_vector_t v, double value);      /* enqueued on the library's stream: returns without waiting for the kernel */
 int fs_vector_axpy(fs_vector_t y, double a, fs_vector_t x); /* y += a x */
 int fs_vector_copy(fs_vector_t dst, fs_vector_t src, int64_t n); /* first n entries, device to device (Function.assign) */
 /* v[idx[k]] += vals[k] (repeated indices accumulate): dolfin.PointSource.apply(b), SolverBase.py:597-601 */
@@ -238,7 +238,9 @@ typedef struct fs_bilinear_form {
 } fs_bilinear_form;
 
 /* Replaces dolfin.assemble(a) / the matrix half of assemble_system: numeric
- * cell loop (tabulate_tensor + MatSetValues(ADD)).  add == 0 zeroes A first. */
+ * cell loop (tabulate_tensor + MatSetValues(ADD)).  add == 0 zeroes A first.  The host arrays of the form have been consumed
+ * when the call returns; the cell loop itself is enqueued on the library's stream and the call does NOT wait for it (what the
+ * caller does next - the load vector, the Dirichlet rows - is prepared meanwhile; every call that hands data back waits). */
 int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, int add);
 
 /* Linear form  L(v) = int source * v dx  (body source, ScalarTransportSolver.py:213-226;
