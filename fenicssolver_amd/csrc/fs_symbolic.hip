@@ -14,6 +14,13 @@
 
 // ---- keys ------------------------------------------------------------------------------
 // nd*(nd-1) directed pairs per cell (a != b) + one diagonal key per owned row.
+// bits needed to write m itself (not m - 1): fields of sort keys whose all-ones value has to stay above every real entry
+static int fs_bits_for(uint64_t m) {
+    int b = 1;
+    while (b < 32 && (m >> b) != 0) ++b;
+    return b;
+}
+
 __global__ void k_pair_keys(const int32_t* __restrict__ cell_dofs, int nd, int64_t nc, int64_t n_rows,
                             uint64_t* __restrict__ keys) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,6 +152,24 @@ __global__ void k_diag_keys(int64_t n_rows, uint64_t* __restrict__ keys) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n_rows; i += stride) keys[i] = ((uint64_t)i << 32) | (uint64_t)i;
+}
+
+// unique keys of a sorted list: flag = first of its run; after the exclusive sum of the flags, pos[i] = where key i goes
+__global__ void k_unique_flags(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+__global__ void k_unique_scatter(const uint64_t* __restrict__ keys, const int32_t* __restrict__ pos, int64_t n,
+                                 uint64_t* __restrict__ out, int64_t* __restrict__ count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint64_t k = keys[i];
+        const bool first = i == 0 || k != keys[i - 1];
+        if (first) out[pos[i]] = k;
+        if (i == n - 1) count[0] = (int64_t)pos[i] + (first ? 1 : 0);
+    }
 }
 
 __global__ void k_split_keys(const uint64_t* __restrict__ keys, int64_t nnz, int32_t* __restrict__ colidx) {
@@ -501,22 +526,43 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
             first = inc_ptr[r];
             cnt = inc_ptr[r + 1] - first;
         }
-        for (int j = 0; j < width; ++j) {
-            int32_t q = -1;
-            uint32_t packed[3] = {0u, 0u, 0u};
-            if (j < cnt) {
-                q = (int32_t)(keys[first + j] & 0xffffffffULL);
-                const int64_t c = q / nd;
-                for (int b = 0; b < nd; ++b) {
-                    const int k = fs_find_pos(sell_col, mbase, mwidth, cell_dofs[c * nd + b]);
-                    if (k < 0 || k > 255) atomicAdd(err, 1);
-                    packed[b >> 2] |= (uint32_t)(k & 255) << (8 * (b & 3));
-                }
+        // Rows of at most 16 / 32 stored entries (CG1: 15 on a box, about 30 at most on a file mesh): the row's columns are read
+        // ONCE into registers and every cell dof is looked up there - the search through memory (fs_find_pos: up to `mwidth`
+        // dependent loads for each of the nd dofs of each of the row's cells) was 20 ms of the set-up at 10 M rows.
+        const auto fill = [&](auto cw_tag) {
+            constexpr int CW = decltype(cw_tag)::value;
+            int32_t cols[CW > 0 ? CW : 1];
+            if (CW > 0) {
+#pragma unroll
+                for (int k = 0; k < CW; ++k) cols[k] = k < mwidth ? sell_col[mbase + (int64_t)k * FS_SLICE] : -1;
             }
-            const int64_t e = base + (int64_t)j * FS_SLICE + lane;
-            inc_cell[e] = q;
-            for (int w = 0; w < words; ++w) inc_pos[(int64_t)w * inc_entries + e] = packed[w];
-        }
+            for (int j = 0; j < width; ++j) {
+                int32_t q = -1;
+                uint32_t packed[3] = {0u, 0u, 0u};
+                if (j < cnt) {
+                    q = (int32_t)(keys[first + j] & 0xffffffffULL);
+                    const int64_t c = q / nd;
+                    for (int b = 0; b < nd; ++b) {
+                        const int32_t target = cell_dofs[c * nd + b];
+                        int k = -1;
+                        if (CW > 0) {
+#pragma unroll
+                            for (int t = CW - 1; t >= 0; --t) k = cols[t] == target ? t : k;      // (the first match, as the search finds it)
+                        } else {
+                            k = fs_find_pos(sell_col, mbase, mwidth, target);
+                        }
+                        if (k < 0 || k > 255) atomicAdd(err, 1);
+                        packed[b >> 2] |= (uint32_t)(k & 255) << (8 * (b & 3));
+                    }
+                }
+                const int64_t e = base + (int64_t)j * FS_SLICE + lane;
+                inc_cell[e] = q;
+                for (int w = 0; w < words; ++w) inc_pos[(int64_t)w * inc_entries + e] = packed[w];
+            }
+        };
+        if (mwidth <= 16) fill(std::integral_constant<int, 16>{});
+        else if (mwidth <= 32) fill(std::integral_constant<int, 32>{});
+        else fill(std::integral_constant<int, 0>{});
     }
 }
 
@@ -609,14 +655,17 @@ int fs_space_build_gather_map(fs_space_s* sp, hipStream_t s) {
 }
 
 // bounding box of the vertices: one workgroup, grid-stride (set-up time)
-__global__ void __launch_bounds__(1024) k_bbox(const double* __restrict__ xyz4, int64_t nv, double* __restrict__ box) {
+// bounding box of the vertices: partial boxes per workgroup (part[b][6]), the last stage by one workgroup over the partials
+// (one workgroup over all the vertices took 6 ms at 10 M of them)
+__global__ void __launch_bounds__(1024) k_bbox(const double* __restrict__ xyz4, int64_t nv, int stride4, double* __restrict__ out) {
     __shared__ double lo[3][16], hi[3][16];
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-    for (int64_t i = threadIdx.x; i < nv; i += blockDim.x)
+    // stride4 = 4: vertices (x, y, z, pad), min and max of each coordinate; stride4 = 6: partial boxes (3 minima, 3 maxima)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x)
         for (int d = 0; d < 3; ++d) {
-            const double v = xyz4[4 * i + d];
-            mn[d] = v < mn[d] ? v : mn[d];
-            mx[d] = v > mx[d] ? v : mx[d];
+            const double a = xyz4[stride4 * i + d], b2 = xyz4[stride4 * i + (stride4 == 6 ? 3 + d : d)];
+            mn[d] = a < mn[d] ? a : mn[d];
+            mx[d] = b2 > mx[d] ? b2 : mx[d];
         }
     for (int d = 0; d < 3; ++d) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -631,8 +680,8 @@ __global__ void __launch_bounds__(1024) k_bbox(const double* __restrict__ xyz4, 
         const int d = threadIdx.x;
         double a = lo[d][0], b2 = hi[d][0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { a = lo[d][w] < a ? lo[d][w] : a; b2 = hi[d][w] > b2 ? hi[d][w] : b2; }
-        box[d] = a;
-        box[3 + d] = b2;
+        out[6 * (int64_t)blockIdx.x + d] = a;
+        out[6 * (int64_t)blockIdx.x + 3 + d] = b2;
     }
 }
 // How fast does each coordinate vary along the row numbering?  cnt[a] = number of consecutive owned rows whose
@@ -917,19 +966,42 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
             FS_SP_HIP(hipGetLastError());
             FS_SP_HIP(hipStreamSynchronize(s));
         }
-        // 2. sort + unique
-        int end_bit = 64;
-        size_t tmp_bytes = 0;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a.p, keys_b.p, n_keys, 0, end_bit, s));
+        // 2. sort + unique.  A key is (row << 32) | column with zero bits between the column's and the row's: two stable sorts over
+        // the bits that can differ - the columns' [0, bc), then the rows' [32, 32 + br) - are 6 radix passes at 1 M and 10 M rows
+        // where the sort over all 64 bits was 8 (each pass streams the 12 keys per cell twice).  br counts the bits of n_rows itself:
+        // the sentinel's row bits, all ones, then stay above every owned row and it still sorts to the end.
+        const int bc = fs_bits_for((uint64_t)sp->n_nodes_local), br = fs_bits_for((uint64_t)n_rows);
+        size_t tmp_bytes = 0, tmp1 = 0;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a.p, keys_b.p, n_keys, 0, bc, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp1, keys_b.p, keys_a.p, n_keys, 32, 32 + br, s));
+        if (tmp1 > tmp_bytes) tmp_bytes = tmp1;
         size_t tmp2 = 0;
-        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2, keys_b.p, keys_a.p, d_count.p, n_keys, s));
+        FS_SP_HIP(hipcub::DeviceSelect::Unique(nullptr, tmp2, keys_a.p, keys_b.p, d_count.p, n_keys, s));
         if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
         size_t tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_a.p, keys_b.p, n_keys, 0, end_bit, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_a.p, keys_b.p, n_keys, 0, bc, s));
         tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, keys_b.p, keys_a.p, d_count.p, n_keys, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_b.p, keys_a.p, n_keys, 32, 32 + br, s));
+        if (n_keys < (int64_t)INT32_MAX) {
+            // first-of-its-run flags, their exclusive sum, a scatter: 0.5 ms for the 71 M keys of a 1 M-row CG1 space where
+            // DeviceSelect::Unique took 1.7 ms (its look-back partition runs at 75 GB/s on 8-byte items)
+            dbuf<int32_t> upos;
+            FS_SP(upos.alloc(n_keys));
+            size_t tb3 = 0;
+            FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, upos.p, upos.p, (int)n_keys, s));
+            dbuf<char> tmp3;
+            FS_SP(tmp3.alloc((int64_t)tb3 + 16));
+            hipLaunchKernelGGL(k_unique_flags, dim3(fs_grid_for(n_keys)), dim3(FS_BLOCK), 0, s, keys_a.p, n_keys, upos.p);
+            FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, upos.p, upos.p, (int)n_keys, s));
+            hipLaunchKernelGGL(k_unique_scatter, dim3(fs_grid_for(n_keys)), dim3(FS_BLOCK), 0, s, keys_a.p, upos.p, n_keys, keys_b.p, d_count.p);
+            FS_SP_HIP(hipGetLastError());
+        } else {
+            tb = tmp_bytes;
+            FS_SP_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, keys_a.p, keys_b.p, d_count.p, n_keys, s));
+        }
+        keys_a.swap(keys_b);            // (the unique keys are what follows reads from keys_a)
         int64_t h_count = 0;
         FS_SP(d_count.download(&h_count, 1, s));
         nnz = h_count;
@@ -1049,9 +1121,16 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     if (order_bits != 0) {
         dbuf<uint32_t> k_in, k_out;
         dbuf<int32_t> v_in;
-        dbuf<double> box;
+        dbuf<double> box, box_parts;
         FS_SP(box.alloc(6));
-        hipLaunchKernelGGL(k_bbox, dim3(1), dim3(1024), 0, s, mesh->xyz.p, mesh->nv, box.p);
+        const int bbox_grid = (int)std::min<int64_t>(512, (mesh->nv + 1023) / 1024);
+        if (bbox_grid > 1) {
+            FS_SP(box_parts.alloc(6 * (int64_t)bbox_grid));
+            hipLaunchKernelGGL(k_bbox, dim3(bbox_grid), dim3(1024), 0, s, mesh->xyz.p, mesh->nv, 4, box_parts.p);
+            hipLaunchKernelGGL(k_bbox, dim3(1), dim3(1024), 0, s, box_parts.p, (int64_t)bbox_grid, 6, box.p);
+        } else {
+            hipLaunchKernelGGL(k_bbox, dim3(1), dim3(1024), 0, s, mesh->xyz.p, mesh->nv, 4, box.p);
+        }
         FS_SP(k_in.alloc(n_slices));
         FS_SP(k_out.alloc(n_slices));
         FS_SP(v_in.alloc(n_slices));
@@ -1118,14 +1197,17 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, n_inc, n_rows, ka.p);
         FS_SP_HIP(hipGetLastError());
         size_t tmp_bytes = 0;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka.p, kb.p, (int)n_inc, 0, 64, s));
+        // (the low half of a key is the incidence's own index, ascending as generated: a STABLE sort over the row bits alone leaves
+        // the incidences of a row in that order - 3 radix passes instead of 8; br as above keeps the sentinel last)
+        const int br_inc = fs_bits_for((uint64_t)n_rows);
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka.p, kb.p, (int)n_inc, 32, 32 + br_inc, s));
         size_t tmp2 = 0;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, entries.p, entries.p, (int)(n_slices + 1), s));
         if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
         size_t tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_inc, 0, 64, s));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_inc, 32, 32 + br_inc, s));
         // rows of other ranks (key ~0) sort to the end: count of valid keys = first index of the sentinel row
         hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, kb.p, n_inc, n_rows, inc_ptr.p);
         FS_SP(sp->inc_slice_ptr.alloc(n_slices + 1));
