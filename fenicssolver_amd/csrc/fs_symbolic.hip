@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
             slice_entries[s] = (int64_t)width * FS_SLICE;
             dia_cnt[s] = dia ? 1 + nd * (split < FS_SLICE ? 2 : 1) : 0;      // ints this slice takes in dia_off
             split_at[s] = split;
-            atomicMax(max_w, width);
+            if (width > __hip_atomic_load(max_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_w, width);      // (a look first: thousands of equal maxima on one address)
             if (dia) {
                 atomicAdd(n_dia, 1);
                 atomicAdd(dia_entries, (unsigned long long)width * FS_SLICE);
@@ -347,7 +347,12 @@ __global__ void k_dia_dedup_insert(int64_t n_slices, const int32_t* __restrict__
         for (int probe = 0; probe < 256; ++probe) {      // (a full table: the slice keeps its own copy)
             unsigned long long old = keys[slot];
             if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, h);
-            if (old == 0ull || old == h) { atomicMin(&rep[slot], (int32_t)s); break; }
+            if (old == 0ull || old == h) {
+                // (the minimum only falls: a value read without the atomic that is already below s settles it - nearly every
+                // slice of a box carries the same list)
+                if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)s) atomicMin(&rep[slot], (int32_t)s);
+                break;
+            }
             slot = (slot + 1) & (FS_DEDUP_CAP - 1);
         }
     }
@@ -498,7 +503,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_width(const int32_t* __restric
         for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
         if (lane == 0) {
             slice_entries[s] = (int64_t)cnt * FS_SLICE;
-            atomicMax(max_cnt, cnt);
+            if (cnt > __hip_atomic_load(max_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_cnt, cnt);
         }
     }
 }
@@ -535,6 +540,38 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restric
             if (CW > 0) {
 #pragma unroll
                 for (int k = 0; k < CW; ++k) cols[k] = k < mwidth ? sell_col[mbase + (int64_t)k * FS_SLICE] : -1;
+            }
+            if (CW > 0 && nd == 4) {
+                // tetrahedra / CG1: four incidences at a time - their keys, then the four vertices of each cell as ONE 16-byte
+                // load, all in flight together (incidence by incidence every row waited for two dependent loads per step)
+                for (int j0 = 0; j0 < width; j0 += 4) {
+                    int32_t q[4];
+                    int4 v4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = j0 + u < cnt ? (int32_t)(keys[first + j0 + u] & 0xffffffffULL) : -1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v4[u] = reinterpret_cast<const int4*>(cell_dofs)[q[u] >= 0 ? (q[u] >> 2) : 0];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j0 + u >= width) break;
+                        uint32_t packed0 = 0u;
+                        if (q[u] >= 0) {
+                            const int32_t tg[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                int k = -1;
+#pragma unroll
+                                for (int t = CW - 1; t >= 0; --t) k = cols[t] == tg[b] ? t : k;
+                                if (k < 0) atomicAdd(err, 1);
+                                packed0 |= (uint32_t)(k & 255) << (8 * b);
+                            }
+                        }
+                        const int64_t e = base + (int64_t)(j0 + u) * FS_SLICE + lane;
+                        inc_cell[e] = q[u];
+                        inc_pos[e] = packed0;
+                    }
+                }
+                return;
             }
             for (int j = 0; j < width; ++j) {
                 int32_t q = -1;
