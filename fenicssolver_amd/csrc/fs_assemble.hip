@@ -3681,3 +3681,9 @@ extern "C" int fs_assemble_interior_penalty(fs_matrix_t A, int64_t n_facets, con
                "(create the space with fs_space_create_coupled and the pairs of vertices opposite every interior facet)", h_err);
     return FS_OK;
 }
+
+void fs_assemble_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_bc_last_index));
+    (void)hipGetLastError();
+}

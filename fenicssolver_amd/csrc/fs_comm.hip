@@ -984,3 +984,9 @@ extern "C" int fs_comm_benchmark(fs_space_t space, int reps, double* allreduce_m
     (void)hipEventDestroy(e1);
     return rc;
 }
+
+void fs_comm_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_pack));
+    (void)hipGetLastError();
+}

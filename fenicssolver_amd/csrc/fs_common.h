@@ -348,6 +348,13 @@ int fs_halo_end_dev(fs_space_s* space, hipStream_t s);
 // compute stream are issued there, in the same order on every rank
 int fs_halo_comm_stream(fs_space_s* space, hipStream_t* out);
 // fs_krylov.hip: the row dictionary of A's current values for the products that follow (fs_spmv_dev), and its end
+// each asks the runtime for the attributes of one of the file's kernels: that loads the file's code object (fs_init)
+void fs_symbolic_preload();
+void fs_assemble_preload();
+void fs_krylov_preload();
+void fs_amg_preload();
+void fs_saddle_preload();
+void fs_comm_preload();
 int fs_dict_begin(fs_matrix_s* A, hipStream_t s);
 void fs_dict_end();
 int fs_dict_classes();

@@ -194,6 +194,18 @@ extern "C" int fs_init(int device_id) {
     rt.device = device_id;
     rt.compute_units = prop.multiProcessorCount;
     rt.initialised = true;
+    // The code objects of the library are loaded here, not at the first launch out of each of them: the object of the set-up
+    // kernels holds 3 300 rocPRIM instantiations (every algorithm for 13 architectures) and takes 35 ms to load - it used to be
+    // seven eighths of the first sparsity pattern of a process.  FS_PRELOAD=0: load on first use, as the runtime does by itself.
+    static const bool preload = !(getenv("FS_PRELOAD") && getenv("FS_PRELOAD")[0] == '0');
+    if (preload) {
+        fs_symbolic_preload();
+        fs_assemble_preload();
+        fs_krylov_preload();
+        fs_amg_preload();
+        fs_saddle_preload();
+        fs_comm_preload();
+    }
     return FS_OK;
 }
 

@@ -3839,3 +3839,9 @@ extern "C" int fs_krylov_history(double* out, int capacity, int* count) {
         for (int i = 0; i < n && i < capacity; ++i) out[i] = g_ws.last_hist[i];
     return FS_OK;
 }
+
+void fs_krylov_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_set_threshold));
+    (void)hipGetLastError();
+}

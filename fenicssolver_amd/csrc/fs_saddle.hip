@@ -1817,3 +1817,9 @@ extern "C" int fs_saddle_solve(fs_matrix_t J, fs_matrix_t Kp, fs_amg_t Kp_amg, f
     }
     return FS_OK;
 }
+
+void fs_saddle_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_ns_dummy_rows));
+    (void)hipGetLastError();
+}

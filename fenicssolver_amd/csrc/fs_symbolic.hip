@@ -1511,3 +1511,9 @@ extern "C" int fs_mesh_create_renumbered(int64_t nv, const double* xyz, int64_t 
     FS_REQUIRE(out, "fs_mesh_create_renumbered: null pointer");
     return locality_order_impl(3, nv, xyz, nc, cells, 4, vertex_order, cell_order, out);
 }
+
+void fs_symbolic_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_diag_keys));
+    (void)hipGetLastError();
+}
