@@ -154,6 +154,80 @@ __global__ void k_diag_keys(int64_t n_rows, uint64_t* __restrict__ keys) {
     for (; i < n_rows; i += stride) keys[i] = ((uint64_t)i << 32) | (uint64_t)i;
 }
 
+// ---- the sparsity pattern row by row (CG1) -------------------------------------------------------------------------------
+// The columns of row r are the vertices of the cells around r.  With the (vertex, cell) incidences sorted by vertex - which the
+// gather assembly needs anyway - a lane collects them for its row in a small set in LDS (set[slot][thread]: no bank conflicts),
+// sorts the set and writes it slot-major; an exclusive sum of the counts gives the row pointers and a second kernel packs the
+// columns.  This replaces sorting 12 keys per cell (71 M at 1 M rows: 6 radix passes of 1.1 GB) and the unique pass over them.
+// A row with more than FS_ROWCOL_CAP neighbours sends the whole space back to the sorted-keys path.
+constexpr int FS_ROWCOL_CAP = 32;
+__global__ void __launch_bounds__(FS_BLOCK) k_row_columns(const uint64_t* __restrict__ keys, const int32_t* __restrict__ inc_ptr,
+                                                          const int32_t* __restrict__ cell_dofs, int nd, int64_t n_rows,
+                                                          int32_t* __restrict__ cnt, int32_t* __restrict__ cols, int* __restrict__ overflow) {
+    __shared__ int32_t set[FS_ROWCOL_CAP * FS_BLOCK];
+    const int t = threadIdx.x;
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + t;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        int n = 1;
+        set[t] = (int32_t)r;                  // the diagonal, cells or not
+        bool over = false;
+        const int32_t first = inc_ptr[r], last = inc_ptr[r + 1];
+        const auto insert = [&](int32_t v) {
+            bool found = false;
+            for (int k = 0; k < n; ++k) found |= set[k * FS_BLOCK + t] == v;
+            if (!found) {
+                if (n < FS_ROWCOL_CAP) { set[n * FS_BLOCK + t] = v; ++n; }
+                else over = true;
+            }
+        };
+        if (nd == 4) {
+            // four cells at a time: their keys, then the four vertices of each as one 16-byte load, all in flight together
+            for (int32_t j0 = first; j0 < last; j0 += 4) {
+                int32_t q[4];
+                int4 v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = j0 + u < last ? (int32_t)(keys[j0 + u] & 0xffffffffULL) : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v4[u] = reinterpret_cast<const int4*>(cell_dofs)[q[u] >= 0 ? (q[u] >> 2) : 0];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q[u] < 0) continue;
+                    insert(v4[u].x); insert(v4[u].y); insert(v4[u].z); insert(v4[u].w);
+                }
+            }
+        } else {
+            for (int32_t j = first; j < last; ++j) {
+                const int32_t q = (int32_t)(keys[j] & 0xffffffffULL);
+                const int64_t c = q / nd;
+                for (int b = 0; b < nd; ++b) insert(cell_dofs[c * nd + b]);
+            }
+        }
+        if (over) {
+            atomicAdd(overflow, 1);
+            cnt[r] = 0;
+            continue;
+        }
+        for (int i = 1; i < n; ++i) {         // ascending, as the sorted keys delivered them
+            const int32_t x = set[i * FS_BLOCK + t];
+            int k = i - 1;
+            while (k >= 0 && set[k * FS_BLOCK + t] > x) { set[(k + 1) * FS_BLOCK + t] = set[k * FS_BLOCK + t]; --k; }
+            set[(k + 1) * FS_BLOCK + t] = x;
+        }
+        cnt[r] = n;
+        for (int k = 0; k < n; ++k) cols[(int64_t)k * n_rows + r] = set[k * FS_BLOCK + t];
+    }
+}
+__global__ void k_row_columns_pack(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols, int64_t n_rows,
+                                   int32_t* __restrict__ colidx) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n_rows; r += stride) {
+        const int32_t p0 = rowptr[r], n = rowptr[r + 1] - p0;
+        for (int k = 0; k < n; ++k) colidx[p0 + k] = cols[(int64_t)k * n_rows + r];
+    }
+}
+
 // unique keys of a sorted list: flag = first of its run; after the exclusive sum of the flags, pos[i] = where key i goes
 __global__ void k_unique_flags(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -986,7 +1060,65 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     }
     // (the sort and the unique pass take 64-bit item counts: a P1 space of 80 M dofs has 6.4e9 keys, 2 x 51 GB for a moment)
     int64_t nnz = 0;
-    {
+    // CG1 without extra couplings: the pattern row by row from the sorted (vertex, cell) incidences (k_row_columns); the sorted
+    // incidences are kept for the assembly tables of step 5a.  FS_PATTERN_BY_ROWS=0: the sorted-keys path below.
+    dbuf<uint64_t> inc_sorted;
+    dbuf<int32_t> inc_ptr_pre;
+    bool have_inc = false, by_rows = false;
+    static const bool by_rows_off = getenv("FS_PATTERN_BY_ROWS") && getenv("FS_PATTERN_BY_ROWS")[0] == '0';
+    if (!by_rows_off && n_extra == 0 && nd <= 4 && (int64_t)nd * nc < (int64_t)INT32_MAX && n_rows > 0) {
+        const int64_t n_inc = (int64_t)nd * nc;
+        dbuf<uint64_t> ka;
+        FS_SP(ka.alloc(n_inc));
+        FS_SP(inc_sorted.alloc(n_inc));
+        FS_SP(inc_ptr_pre.alloc(n_rows + 1));
+        hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, n_inc, n_rows, ka.p);
+        FS_SP_HIP(hipGetLastError());
+        // (the low half of a key is the incidence's own index, ascending as generated: a STABLE sort over the row bits alone leaves
+        // the incidences of a row in that order - 3 radix passes instead of 8; the bits of n_rows itself keep the sentinel last)
+        const int br_inc = fs_bits_for((uint64_t)n_rows);
+        size_t tmp_bytes = 0, tmp2 = 0;
+        dbuf<int32_t> cnt, cols;
+        dbuf<int> d_over;
+        FS_SP(cnt.alloc(n_rows + 1));
+        FS_SP(cols.alloc((int64_t)FS_ROWCOL_CAP * n_rows));
+        FS_SP(d_over.alloc(1));
+        FS_SP(d_over.zero(s));
+        FS_SP(sp->rowptr.alloc(n_rows + 1));
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka.p, inc_sorted.p, (int)n_inc, 32, 32 + br_inc, s));
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, cnt.p, sp->rowptr.p, (int)(n_rows + 1), s));
+        if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+        dbuf<char> tmp;
+        FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
+        size_t tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, inc_sorted.p, (int)n_inc, 32, 32 + br_inc, s));
+        // rows of other ranks (key ~0) sort to the end: count of valid keys = first index of the sentinel row
+        hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, inc_sorted.p, n_inc, n_rows, inc_ptr_pre.p);
+        have_inc = true;
+        FS_SP_HIP(hipMemsetAsync(cnt.p + n_rows, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_row_columns, dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, inc_sorted.p, inc_ptr_pre.p, sp->cell_dofs, nd, n_rows,
+                           cnt.p, cols.p, d_over.p);
+        FS_SP_HIP(hipGetLastError());
+        tb = tmp_bytes;
+        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.p, sp->rowptr.p, (int)(n_rows + 1), s));
+        int h_over = 0;
+        int32_t h_nnz = 0;
+        FS_SP_HIP(hipMemcpyAsync(&h_nnz, sp->rowptr.p + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        FS_SP(d_over.download(&h_over, 1, s));
+        if (h_over == 0) {
+            nnz = h_nnz;
+            sp->nnz_nodes = nnz;
+            FS_SP(sp->colidx.alloc(nnz));
+            hipLaunchKernelGGL(k_row_columns_pack, dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, cols.p, n_rows, sp->colidx.p);
+            FS_SP_HIP(hipGetLastError());
+            FS_SP_HIP(hipStreamSynchronize(s));
+            by_rows = true;
+        }
+        if (getenv("FS_SPACE_DEBUG"))
+            fprintf(stderr, "[fs_symbolic] sparsity pattern row by row: %s (%lld rows, %lld node pairs)\n",
+                    by_rows ? "yes" : "no, a row has more than 32 neighbours: sorted keys", (long long)n_rows, (long long)nnz);
+    }
+    if (!by_rows) {
         dbuf<uint64_t> keys_a, keys_b;
         dbuf<int64_t> d_count;
         FS_SP(keys_a.alloc(n_keys));
@@ -1222,17 +1354,24 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         dbuf<int32_t> inc_ptr;
         dbuf<int64_t> entries;
         dbuf<int> d_max, d_err;
-        FS_SP(ka.alloc(n_inc));
-        FS_SP(kb.alloc(n_inc));
-        FS_SP(inc_ptr.alloc(n_rows + 1));
+        if (have_inc) {             // (sorted for the pattern already)
+            kb.swap(inc_sorted);
+            inc_ptr.swap(inc_ptr_pre);
+        } else {
+            FS_SP(ka.alloc(n_inc));
+            FS_SP(kb.alloc(n_inc));
+            FS_SP(inc_ptr.alloc(n_rows + 1));
+        }
         FS_SP(entries.alloc(n_slices + 1));
         FS_SP(entries.zero(s));
         FS_SP(d_max.alloc(1));
         FS_SP(d_max.zero(s));
         FS_SP(d_err.alloc(1));
         FS_SP(d_err.zero(s));
-        hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, n_inc, n_rows, ka.p);
-        FS_SP_HIP(hipGetLastError());
+        if (!have_inc) {
+            hipLaunchKernelGGL(k_inc_keys, dim3(fs_grid_for(n_inc)), dim3(FS_BLOCK), 0, s, sp->cell_dofs, n_inc, n_rows, ka.p);
+            FS_SP_HIP(hipGetLastError());
+        }
         size_t tmp_bytes = 0;
         // (the low half of a key is the incidence's own index, ascending as generated: a STABLE sort over the row bits alone leaves
         // the incidences of a row in that order - 3 radix passes instead of 8; br as above keeps the sentinel last)
@@ -1244,9 +1383,11 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         dbuf<char> tmp;
         FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
         size_t tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_inc, 32, 32 + br_inc, s));
-        // rows of other ranks (key ~0) sort to the end: count of valid keys = first index of the sentinel row
-        hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, kb.p, n_inc, n_rows, inc_ptr.p);
+        if (!have_inc) {
+            FS_SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, ka.p, kb.p, (int)n_inc, 32, 32 + br_inc, s));
+            // rows of other ranks (key ~0) sort to the end: count of valid keys = first index of the sentinel row
+            hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, kb.p, n_inc, n_rows, inc_ptr.p);
+        }
         FS_SP(sp->inc_slice_ptr.alloc(n_slices + 1));
         hipLaunchKernelGGL(k_inc_width, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, inc_ptr.p, n_rows, n_slices, entries.p, d_max.p);
         FS_SP_HIP(hipGetLastError());

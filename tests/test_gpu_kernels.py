@@ -950,6 +950,29 @@ def test_class_table_is_kept_only_for_a_matrix_that_still_equals_it_row_for_row(
     assert kept[0] == 0 and kept[-1] == 1
 
 
+def test_pattern_built_row_by_row_is_the_pattern_of_the_sorted_keys(gpu, tmp_path):
+    """CG1 spaces get their sparsity pattern row by row from the sorted (vertex, cell) incidences (k_row_columns: a small set per
+    row in LDS) instead of from 12 sorted keys per cell; FS_PATTERN_BY_ROWS=0 keeps the sorted-keys path.  Two processes, one per
+    path: row pointers, column indices, assembled values and a product of a box, a vector space, a shuffled (file-like) cube and
+    a triangle mesh are the same arrays, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for tag, env in (("rows", {}), ("keys", {"FS_PATTERN_BY_ROWS": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "pattern_worker.py"), f], env=dict(os.environ, FS_SPACE_DEBUG="1", **env),
+                           cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        log = p.stdout.decode()
+        assert p.returncode == 0, log[-2000:]
+        assert log.count("sparsity pattern row by row: yes") == (4 if tag == "rows" else 0), log[-2000:]
+        files.append(np.load(f))
+    a, b = files
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 16
+    for k in a.files:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+
+
 def test_box_assembly_is_translation_invariant_and_matches_the_oracle(gpu):
     """fs_mesh_create_box meshes: interior rows of the P1 operator are identical BIT FOR BIT (edge vectors snapped to the grid
     spacing), and the values are the oracle's to rounding."""
