@@ -53,7 +53,13 @@ typedef struct fs_vector_s* fs_vector_t;
 /* ---- runtime ---------------------------------------------------------------- */
 
 /* Select the HIP device this process drives (dolfin has no analogue; MPI rank ->
- * device mapping replaces `mpirun`, SolverBase.py:102-118). */
+ * device mapping replaces `mpirun`, SolverBase.py:102-118).  Also loads the library's code objects onto the device (about 70 ms,
+ * half of it the set-up kernels' object with its rocPRIM sorts) so that the first mesh, space and solve of the process do not pay
+ * for it; environment FS_PRELOAD=0 leaves the loading to the first launch out of each object.
+ * Other environment switches read once per process (A/B and fall-backs, not needed for normal use): FS_PATTERN_BY_ROWS=0 (CG1
+ * sparsity patterns through sorted node-pair keys instead of row by row), FS_DICT_REUSE=0 (row classes found from scratch at every
+ * solve instead of compared with the kept table), FS_CG_FUSED / FS_CG_FUSED_MAX_ROWS / FS_CG_FUSED_P2P (the one-launch CG
+ * iteration: option "cg_fused"), FS_SPMV_DICT=0 (no row-dictionary product: option "row_dictionary"). */
 int fs_init(int device_id);
 int fs_device_count(int* count);
 int fs_device_synchronize(void);
