@@ -807,7 +807,7 @@ def main():
                 # here, and - same problem, option row_dictionary = 0 - the streaming kernels every other operator takes.
                 r["note_row_dictionary"] = (
                     "k_dict_spmv reads a 2-byte class number per row and keeps the %d distinct value rows in LDS instead of streaming "
-                    "8 B per entry (built per solve, every row verified bit for bit; same offsets, same summation order, same bits as "
+                    "8 B per entry (every row of every solve's matrix verified against its class bit for bit; same offsets, same summation order, same bits as "
                     "the streaming product): its roofline is on the 26 B/row it has to move; csr_equivalent_GBps exceeds the peak because "
                     "those bytes are not moved" % st_big["row_classes"])
                 B.set_option("row_dictionary", 0)

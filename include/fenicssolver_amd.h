@@ -385,7 +385,7 @@ int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, dou
 /* y = A x (MatMult, behind KSPSolve at SolverBase.py:663-670) through the ROW-DICTIONARY form of the product where the rows of A
  * repeat (a uniform box mesh with constant coefficients): the classes are found from A's current values inside this call (or
  * kept from the previous call on the same space, where every row of A still equals its old class),
- * every row is verified against its class, and the table is dropped when the call returns.  *row_classes = number of distinct
+ * every row is verified against its class, and no later call multiplies from the table without verifying its own matrix against it.  *row_classes = number of distinct
  * rows used, 0 = the rows do not repeat and the streaming product ran.  Both forms give the same bits as fs_spmv. */
 int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_classes);
 
