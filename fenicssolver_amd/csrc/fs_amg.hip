@@ -220,6 +220,15 @@ __global__ void k_compact_owned_cols(int64_t nn, int bs2, const int32_t* __restr
     }
 }
 
+// maximum of a non-negative double over all threads into one word (positive doubles order like their bit patterns): the wave's
+// maximum first, and a look at the word before the atomic - one atomic per THREAD on one address was half a million of them
+__device__ __forceinline__ void fs_atomic_max_positive(unsigned long long* word, double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+}
+
 // per node: 1/diag, identity-row flags, Gershgorin ratio (max over the block row, atomically maxed), block norm
 __global__ void k_amg_diag(int64_t nn, int bs, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                            const double* __restrict__ val, double* __restrict__ dinv, uint8_t* __restrict__ ident,
@@ -246,7 +255,7 @@ __global__ void k_amg_diag(int64_t nn, int bs, const int32_t* __restrict__ rp, c
         dnorm[i] = sqrt(dn);
     }
     // positive doubles order like their bit patterns
-    atomicMax(gersh_bits, (unsigned long long)__double_as_longlong(gmax));
+    fs_atomic_max_positive(gersh_bits, gmax);
 }
 
 // the same with 16 lanes per node striding over the values of its block row (contiguous in memory); bs <= 6
@@ -301,7 +310,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_amg_diag_grp(int64_t nn, int bs, c
         }
         if (sub == 0) dnorm[i] = sqrt(dn);
     }
-    atomicMax(gersh_bits, (unsigned long long)__double_as_longlong(gmax));
+    fs_atomic_max_positive(gersh_bits, gmax);
 }
 
 // strength graph: j != i strong iff ||A_ij||_F^2 > theta^2 ||A_ii||_F ||A_jj||_F (and > 0)
@@ -405,7 +414,10 @@ __global__ void k_mis_update(int64_t nn, unsigned long long* __restrict__ key, c
         else if ((m >> 62) == 2ULL) key[i] = k & ~(3ULL << 62);
         else ++left;
     }
-    if (left) atomicAdd(undecided, left);
+    // (the wave's count first: one atomic per thread on one word is half a million of them per round)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) left += __shfl_xor(left, off, 64);
+    if (left && (threadIdx.x & 63) == 0) atomicAdd(undecided, left);
 }
 __global__ void k_agg_rootflag(int64_t nn, const unsigned long long* __restrict__ key, int32_t* __restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
