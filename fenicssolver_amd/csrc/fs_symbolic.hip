@@ -316,6 +316,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int my_max_w = 0, my_n_dia = 0;             // (lane 0: the wave's slices together, one round of atomics after the loop)
+    unsigned long long my_dia_entries = 0ull;
     for (; s < n_slices; s += stride) {
         const int64_t r = s * FS_SLICE + lane;
         int32_t start = 0, len = 0;
@@ -370,11 +372,18 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
             slice_entries[s] = (int64_t)width * FS_SLICE;
             dia_cnt[s] = dia ? 1 + nd * (split < FS_SLICE ? 2 : 1) : 0;      // ints this slice takes in dia_off
             split_at[s] = split;
-            if (width > __hip_atomic_load(max_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_w, width);      // (a look first: thousands of equal maxima on one address)
+            my_max_w = width > my_max_w ? width : my_max_w;
             if (dia) {
-                atomicAdd(n_dia, 1);
-                atomicAdd(dia_entries, (unsigned long long)width * FS_SLICE);
+                ++my_n_dia;
+                my_dia_entries += (unsigned long long)width * FS_SLICE;
             }
+        }
+    }
+    if (lane == 0) {
+        if (my_max_w > __hip_atomic_load(max_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_w, my_max_w);      // (a look first: thousands of equal maxima on one address)
+        if (my_n_dia) {
+            atomicAdd(n_dia, my_n_dia);
+            atomicAdd(dia_entries, my_dia_entries);
         }
     }
 }
