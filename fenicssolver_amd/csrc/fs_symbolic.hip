@@ -578,17 +578,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_inc_width(const int32_t* __restric
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int my_max = 0;         // (the wave's slices together: one atomic per wave after the loop)
     for (; s < n_slices; s += stride) {
         const int64_t r = s * FS_SLICE + lane;
         int cnt = 0;
         if (r < n_rows) cnt = inc_ptr[r + 1] - inc_ptr[r];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cnt = max(cnt, __shfl_xor(cnt, off, 64));
-        if (lane == 0) {
-            slice_entries[s] = (int64_t)cnt * FS_SLICE;
-            if (cnt > __hip_atomic_load(max_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_cnt, cnt);
-        }
+        if (lane == 0) slice_entries[s] = (int64_t)cnt * FS_SLICE;
+        my_max = cnt > my_max ? cnt : my_max;
     }
+    if (lane == 0 && my_max > 0) atomicMax(max_cnt, my_max);
 }
 
 __global__ void __launch_bounds__(FS_BLOCK) k_inc_fill(const uint64_t* __restrict__ keys,
@@ -1231,7 +1231,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         const char* env_split = getenv("FS_DISABLE_DIA_SPLIT");
         // 0: SELL only, 1: whole-slice DIA only, 2: DIA with split slices (default)
         const int allow_dia = (env && *env && *env != '0') ? 0 : ((env_split && *env_split && *env_split != '0') ? 1 : 2);
-        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, split_at.p, d_max.p, d_ndia.p, d_dia_entries.p);
+        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64, FS_BLOCK, 1024)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, split_at.p, d_max.p, d_ndia.p, d_dia_entries.p);
         FS_SP_HIP(hipGetLastError());
         size_t tmp_bytes = 0, t2 = 0;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
@@ -1398,7 +1398,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
             hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, kb.p, n_inc, n_rows, inc_ptr.p);
         }
         FS_SP(sp->inc_slice_ptr.alloc(n_slices + 1));
-        hipLaunchKernelGGL(k_inc_width, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, inc_ptr.p, n_rows, n_slices, entries.p, d_max.p);
+        hipLaunchKernelGGL(k_inc_width, dim3(fs_grid_for(n_slices * 64, FS_BLOCK, 512)), dim3(FS_BLOCK), 0, s, inc_ptr.p, n_rows, n_slices, entries.p, d_max.p);
         FS_SP_HIP(hipGetLastError());
         tb = tmp_bytes;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, entries.p, sp->inc_slice_ptr.p, (int)(n_slices + 1), s));
