@@ -159,12 +159,15 @@ __global__ void k_diag_keys(int64_t n_rows, uint64_t* __restrict__ keys) {
 // gather assembly needs anyway - a lane collects them for its row in a small set in LDS (set[slot][thread]: no bank conflicts),
 // sorts the set and writes it slot-major; an exclusive sum of the counts gives the row pointers and a second kernel packs the
 // columns.  This replaces sorting 12 keys per cell (71 M at 1 M rows: 6 radix passes of 1.1 GB) and the unique pass over them.
-// A row with more than FS_ROWCOL_CAP neighbours sends the whole space back to the sorted-keys path.
-constexpr int FS_ROWCOL_CAP = 32;
-__global__ void __launch_bounds__(FS_BLOCK) k_row_columns(const uint64_t* __restrict__ keys, const int32_t* __restrict__ inc_ptr,
-                                                          const int32_t* __restrict__ cell_dofs, int nd, int64_t n_rows,
-                                                          int32_t* __restrict__ cnt, int32_t* __restrict__ cols, int* __restrict__ overflow) {
-    __shared__ int32_t set[FS_ROWCOL_CAP * FS_BLOCK];
+// A row with more neighbours than the set holds sends the whole space back to the sorted-keys path.
+// CAP / BLOCK: 32 entries x 256 rows per workgroup for CG1, 160 x 64 for CG2 (a vertex row of a tetrahedral CG2 space couples to
+// about 65 nodes, an edge row to about 27): 32 / 40 KB of LDS.
+template <int FS_ROWCOL_CAP, int FS_BLOCK_T>
+__global__ void __launch_bounds__(FS_BLOCK_T) k_row_columns(const uint64_t* __restrict__ keys, const int32_t* __restrict__ inc_ptr,
+                                                            const int32_t* __restrict__ cell_dofs, int nd, int64_t n_rows,
+                                                            int32_t* __restrict__ cnt, int32_t* __restrict__ cols, int* __restrict__ overflow) {
+    constexpr int RB = FS_BLOCK_T;       // rows per workgroup = the set's stride
+    __shared__ int32_t set[FS_ROWCOL_CAP * RB];
     const int t = threadIdx.x;
     int64_t r = (int64_t)blockIdx.x * blockDim.x + t;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -175,9 +178,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_row_columns(const uint64_t* __rest
         const int32_t first = inc_ptr[r], last = inc_ptr[r + 1];
         const auto insert = [&](int32_t v) {
             bool found = false;
-            for (int k = 0; k < n; ++k) found |= set[k * FS_BLOCK + t] == v;
+            for (int k = 0; k < n; ++k) found |= set[k * RB + t] == v;
             if (!found) {
-                if (n < FS_ROWCOL_CAP) { set[n * FS_BLOCK + t] = v; ++n; }
+                if (n < FS_ROWCOL_CAP) { set[n * RB + t] = v; ++n; }
                 else over = true;
             }
         };
@@ -209,13 +212,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_row_columns(const uint64_t* __rest
             continue;
         }
         for (int i = 1; i < n; ++i) {         // ascending, as the sorted keys delivered them
-            const int32_t x = set[i * FS_BLOCK + t];
+            const int32_t x = set[i * RB + t];
             int k = i - 1;
-            while (k >= 0 && set[k * FS_BLOCK + t] > x) { set[(k + 1) * FS_BLOCK + t] = set[k * FS_BLOCK + t]; --k; }
-            set[(k + 1) * FS_BLOCK + t] = x;
+            while (k >= 0 && set[k * RB + t] > x) { set[(k + 1) * RB + t] = set[k * RB + t]; --k; }
+            set[(k + 1) * RB + t] = x;
         }
         cnt[r] = n;
-        for (int k = 0; k < n; ++k) cols[(int64_t)k * n_rows + r] = set[k * FS_BLOCK + t];
+        for (int k = 0; k < n; ++k) cols[(int64_t)k * n_rows + r] = set[k * RB + t];
     }
 }
 __global__ void k_row_columns_pack(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols, int64_t n_rows,
@@ -1069,13 +1072,14 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
     }
     // (the sort and the unique pass take 64-bit item counts: a P1 space of 80 M dofs has 6.4e9 keys, 2 x 51 GB for a moment)
     int64_t nnz = 0;
-    // CG1 without extra couplings: the pattern row by row from the sorted (vertex, cell) incidences (k_row_columns); the sorted
+    // CG1 / CG2 without extra couplings: the pattern row by row from the sorted (vertex, cell) incidences (k_row_columns); the sorted
     // incidences are kept for the assembly tables of step 5a.  FS_PATTERN_BY_ROWS=0: the sorted-keys path below.
     dbuf<uint64_t> inc_sorted;
     dbuf<int32_t> inc_ptr_pre;
     bool have_inc = false, by_rows = false;
     static const bool by_rows_off = getenv("FS_PATTERN_BY_ROWS") && getenv("FS_PATTERN_BY_ROWS")[0] == '0';
-    if (!by_rows_off && n_extra == 0 && nd <= 4 && (int64_t)nd * nc < (int64_t)INT32_MAX && n_rows > 0) {
+    if (!by_rows_off && n_extra == 0 && nd <= 10 && (int64_t)nd * nc < (int64_t)INT32_MAX && n_rows > 0) {
+        const int rc_cap = nd <= 4 ? 32 : 160;
         const int64_t n_inc = (int64_t)nd * nc;
         dbuf<uint64_t> ka;
         FS_SP(ka.alloc(n_inc));
@@ -1090,7 +1094,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         dbuf<int32_t> cnt, cols;
         dbuf<int> d_over;
         FS_SP(cnt.alloc(n_rows + 1));
-        FS_SP(cols.alloc((int64_t)FS_ROWCOL_CAP * n_rows));
+        FS_SP(cols.alloc((int64_t)rc_cap * n_rows));
         FS_SP(d_over.alloc(1));
         FS_SP(d_over.zero(s));
         FS_SP(sp->rowptr.alloc(n_rows + 1));
@@ -1105,8 +1109,12 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         hipLaunchKernelGGL(k_rowptr, dim3(fs_grid_for(n_rows + 1)), dim3(FS_BLOCK), 0, s, inc_sorted.p, n_inc, n_rows, inc_ptr_pre.p);
         have_inc = true;
         FS_SP_HIP(hipMemsetAsync(cnt.p + n_rows, 0, sizeof(int32_t), s));
-        hipLaunchKernelGGL(k_row_columns, dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, inc_sorted.p, inc_ptr_pre.p, sp->cell_dofs, nd, n_rows,
-                           cnt.p, cols.p, d_over.p);
+        if (nd <= 4)
+            hipLaunchKernelGGL((k_row_columns<32, FS_BLOCK>), dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, inc_sorted.p, inc_ptr_pre.p,
+                               sp->cell_dofs, nd, n_rows, cnt.p, cols.p, d_over.p);
+        else
+            hipLaunchKernelGGL((k_row_columns<160, 64>), dim3(fs_grid_for(n_rows, 64, 32768)), dim3(64), 0, s, inc_sorted.p, inc_ptr_pre.p,
+                               sp->cell_dofs, nd, n_rows, cnt.p, cols.p, d_over.p);
         FS_SP_HIP(hipGetLastError());
         tb = tmp_bytes;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.p, sp->rowptr.p, (int)(n_rows + 1), s));
@@ -1125,7 +1133,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         }
         if (getenv("FS_SPACE_DEBUG"))
             fprintf(stderr, "[fs_symbolic] sparsity pattern row by row: %s (%lld rows, %lld node pairs)\n",
-                    by_rows ? "yes" : "no, a row has more than 32 neighbours: sorted keys", (long long)n_rows, (long long)nnz);
+                    by_rows ? "yes" : "no, a row has more neighbours than the set holds: sorted keys", (long long)n_rows, (long long)nnz);
     }
     if (!by_rows) {
         dbuf<uint64_t> keys_a, keys_b;

@@ -14,8 +14,8 @@ B.init(0)
 out = {}
 
 
-def record(name, mesh, ncomp, **form):
-    V = B.DeviceSpace(mesh, ncomp)
+def record(name, mesh, ncomp, degree=1, **form):
+    V = B.DeviceSpace(mesh, ncomp, degree)
     A = B.DeviceMatrix(V)
     A.assemble(**form)
     rp, ci, va, shape = A.to_csr()
@@ -40,5 +40,8 @@ record("shuffled", B.DeviceMesh(co[perm], ce2.astype(np.int32)), 1, stiffness=1.
 # triangles
 co2, ce2d = fo.rectangle_mesh((0.0, 0.0), (2.0, 1.0), 17, 11)
 record("rectangle", B.DeviceMesh(co2, ce2d.astype(np.int32)), 1, stiffness=3.0, mass=1.0)
+# CG2 (10 / 6 nodes per cell: the larger per-row set)
+record("box_p2", B.DeviceMesh.box(6, 5, 4), 1, 2, stiffness=1.5, mass=0.25)
+record("rectangle_p2", B.DeviceMesh(co2, ce2d.astype(np.int32)), 1, 2, stiffness=1.0)
 np.savez(sys.argv[1], **out)
 print("ok")

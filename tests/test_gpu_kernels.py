@@ -953,8 +953,8 @@ def test_class_table_is_kept_only_for_a_matrix_that_still_equals_it_row_for_row(
 def test_pattern_built_row_by_row_is_the_pattern_of_the_sorted_keys(gpu, tmp_path):
     """CG1 spaces get their sparsity pattern row by row from the sorted (vertex, cell) incidences (k_row_columns: a small set per
     row in LDS) instead of from 12 sorted keys per cell; FS_PATTERN_BY_ROWS=0 keeps the sorted-keys path.  Two processes, one per
-    path: row pointers, column indices, assembled values and a product of a box, a vector space, a shuffled (file-like) cube and
-    a triangle mesh are the same arrays, bit for bit."""
+    path: row pointers, column indices, assembled values and a product of a box, a vector space, a shuffled (file-like) cube,
+    a triangle mesh and the CG2 spaces of a box and of the triangles are the same arrays, bit for bit."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -965,10 +965,10 @@ def test_pattern_built_row_by_row_is_the_pattern_of_the_sorted_keys(gpu, tmp_pat
                            cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         log = p.stdout.decode()
         assert p.returncode == 0, log[-2000:]
-        assert log.count("sparsity pattern row by row: yes") == (4 if tag == "rows" else 0), log[-2000:]
+        assert log.count("sparsity pattern row by row: yes") == (6 if tag == "rows" else 0), log[-2000:]
         files.append(np.load(f))
     a, b = files
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 16
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 24
     for k in a.files:
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
 
