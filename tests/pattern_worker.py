@@ -43,5 +43,12 @@ record("rectangle", B.DeviceMesh(co2, ce2d.astype(np.int32)), 1, stiffness=3.0, 
 # CG2 (10 / 6 nodes per cell: the larger per-row set)
 record("box_p2", B.DeviceMesh.box(6, 5, 4), 1, 2, stiffness=1.5, mass=0.25)
 record("rectangle_p2", B.DeviceMesh(co2, ce2d.astype(np.int32)), 1, 2, stiffness=1.0)
+# a triangle fan: the centre has 40 neighbours, more than the per-row set of a CG1 space holds - the whole space goes back to the
+# sorted-keys path (and says so)
+m = 40
+ang = 2.0 * np.pi * np.arange(m) / m
+cof = np.vstack([[0.0, 0.0], np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+cef = np.stack([np.zeros(m, dtype=np.int32), 1 + np.arange(m, dtype=np.int32), 1 + (np.arange(m, dtype=np.int32) + 1) % m], axis=1)
+record("fan", B.DeviceMesh(cof, np.sort(cef, axis=1).astype(np.int32)), 1, stiffness=1.0)
 np.savez(sys.argv[1], **out)
 print("ok")

@@ -954,7 +954,8 @@ def test_pattern_built_row_by_row_is_the_pattern_of_the_sorted_keys(gpu, tmp_pat
     """CG1 spaces get their sparsity pattern row by row from the sorted (vertex, cell) incidences (k_row_columns: a small set per
     row in LDS) instead of from 12 sorted keys per cell; FS_PATTERN_BY_ROWS=0 keeps the sorted-keys path.  Two processes, one per
     path: row pointers, column indices, assembled values and a product of a box, a vector space, a shuffled (file-like) cube,
-    a triangle mesh and the CG2 spaces of a box and of the triangles are the same arrays, bit for bit."""
+    a triangle mesh and the CG2 spaces of a box and of the triangles are the same arrays, bit for bit; a triangle fan whose centre
+    has more neighbours than the per-row set holds falls back to the sorted keys."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -966,9 +967,10 @@ def test_pattern_built_row_by_row_is_the_pattern_of_the_sorted_keys(gpu, tmp_pat
         log = p.stdout.decode()
         assert p.returncode == 0, log[-2000:]
         assert log.count("sparsity pattern row by row: yes") == (6 if tag == "rows" else 0), log[-2000:]
+        assert log.count("sparsity pattern row by row: no") == (1 if tag == "rows" else 0), log[-2000:]       # (the fan)
         files.append(np.load(f))
     a, b = files
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 24
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 28
     for k in a.files:
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
 
