@@ -176,13 +176,18 @@ __global__ void __launch_bounds__(FS_BLOCK_T) k_row_columns(const uint64_t* __re
         set[t] = (int32_t)r;                  // the diagonal, cells or not
         bool over = false;
         const int32_t first = inc_ptr[r], last = inc_ptr[r + 1];
+        // the set is kept ascending (as the sorted keys delivered the columns): binary search, and a new entry shifts the tail up
         const auto insert = [&](int32_t v) {
-            bool found = false;
-            for (int k = 0; k < n; ++k) found |= set[k * RB + t] == v;
-            if (!found) {
-                if (n < FS_ROWCOL_CAP) { set[n * RB + t] = v; ++n; }
-                else over = true;
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (set[mid * RB + t] < v) lo = mid + 1; else hi = mid;
             }
+            if (lo < n && set[lo * RB + t] == v) return;
+            if (n >= FS_ROWCOL_CAP) { over = true; return; }
+            for (int k = n; k > lo; --k) set[k * RB + t] = set[(k - 1) * RB + t];
+            set[lo * RB + t] = v;
+            ++n;
         };
         if (nd == 4) {
             // four cells at a time: their keys, then the four vertices of each as one 16-byte load, all in flight together
@@ -200,22 +205,23 @@ __global__ void __launch_bounds__(FS_BLOCK_T) k_row_columns(const uint64_t* __re
                 }
             }
         } else {
+            // (the dofs of a cell asked for together, the next cell's key already under way)
+            int32_t q = first < last ? (int32_t)(keys[first] & 0xffffffffULL) : 0;
             for (int32_t j = first; j < last; ++j) {
-                const int32_t q = (int32_t)(keys[j] & 0xffffffffULL);
                 const int64_t c = q / nd;
-                for (int b = 0; b < nd; ++b) insert(cell_dofs[c * nd + b]);
+                if (j + 1 < last) q = (int32_t)(keys[j + 1] & 0xffffffffULL);
+                int32_t v[10];
+#pragma unroll
+                for (int b = 0; b < 10; ++b) v[b] = cell_dofs[c * nd + (b < nd ? b : 0)];
+#pragma unroll
+                for (int b = 0; b < 10; ++b)
+                    if (b < nd) insert(v[b]);
             }
         }
         if (over) {
             atomicAdd(overflow, 1);
             cnt[r] = 0;
             continue;
-        }
-        for (int i = 1; i < n; ++i) {         // ascending, as the sorted keys delivered them
-            const int32_t x = set[i * RB + t];
-            int k = i - 1;
-            while (k >= 0 && set[k * RB + t] > x) { set[(k + 1) * RB + t] = set[k * RB + t]; --k; }
-            set[(k + 1) * RB + t] = x;
         }
         cnt[r] = n;
         for (int k = 0; k < n; ++k) cols[(int64_t)k * n_rows + r] = set[k * RB + t];
