@@ -1100,7 +1100,11 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         dbuf<int32_t> cnt, cols;
         dbuf<int> d_over;
         FS_SP(cnt.alloc(n_rows + 1));
-        FS_SP(cols.alloc((int64_t)rc_cap * n_rows));
+        // (the unsorted keys are dead once the sort has run: the per-row sets are written over them where they fit - one
+        // allocation of 11 GB less at 86 M rows, where the set-up is mostly hipMalloc / hipFree of such blocks)
+        const bool cols_in_ka = (int64_t)rc_cap * n_rows * (int64_t)sizeof(int32_t) <= n_inc * (int64_t)sizeof(uint64_t);
+        if (!cols_in_ka) FS_SP(cols.alloc((int64_t)rc_cap * n_rows));
+        int32_t* const cols_p = cols_in_ka ? reinterpret_cast<int32_t*>(ka.p) : cols.p;
         FS_SP(d_over.alloc(1));
         FS_SP(d_over.zero(s));
         FS_SP(sp->rowptr.alloc(n_rows + 1));
@@ -1117,10 +1121,10 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP_HIP(hipMemsetAsync(cnt.p + n_rows, 0, sizeof(int32_t), s));
         if (nd <= 4)
             hipLaunchKernelGGL((k_row_columns<32, FS_BLOCK>), dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, inc_sorted.p, inc_ptr_pre.p,
-                               sp->cell_dofs, nd, n_rows, cnt.p, cols.p, d_over.p);
+                               sp->cell_dofs, nd, n_rows, cnt.p, cols_p, d_over.p);
         else
             hipLaunchKernelGGL((k_row_columns<160, 64>), dim3(fs_grid_for(n_rows, 64, 32768)), dim3(64), 0, s, inc_sorted.p, inc_ptr_pre.p,
-                               sp->cell_dofs, nd, n_rows, cnt.p, cols.p, d_over.p);
+                               sp->cell_dofs, nd, n_rows, cnt.p, cols_p, d_over.p);
         FS_SP_HIP(hipGetLastError());
         tb = tmp_bytes;
         FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.p, sp->rowptr.p, (int)(n_rows + 1), s));
@@ -1132,7 +1136,7 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
             nnz = h_nnz;
             sp->nnz_nodes = nnz;
             FS_SP(sp->colidx.alloc(nnz));
-            hipLaunchKernelGGL(k_row_columns_pack, dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, cols.p, n_rows, sp->colidx.p);
+            hipLaunchKernelGGL(k_row_columns_pack, dim3(fs_grid_for(n_rows, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, cols_p, n_rows, sp->colidx.p);
             FS_SP_HIP(hipGetLastError());
             FS_SP_HIP(hipStreamSynchronize(s));
             by_rows = true;
