@@ -154,10 +154,10 @@ __global__ void k_diag_keys(int64_t n_rows, uint64_t* __restrict__ keys) {
     for (; i < n_rows; i += stride) keys[i] = ((uint64_t)i << 32) | (uint64_t)i;
 }
 
-// ---- the sparsity pattern row by row (CG1) -------------------------------------------------------------------------------
-// The columns of row r are the vertices of the cells around r.  With the (vertex, cell) incidences sorted by vertex - which the
-// gather assembly needs anyway - a lane collects them for its row in a small set in LDS (set[slot][thread]: no bank conflicts),
-// sorts the set and writes it slot-major; an exclusive sum of the counts gives the row pointers and a second kernel packs the
+// ---- the sparsity pattern row by row (CG1, CG2) --------------------------------------------------------------------------
+// The columns of row r are the nodes of the cells around r.  With the (node, cell) incidences sorted by node - which the
+// gather assembly needs anyway - a lane collects them for its row in a small ascending set in LDS (set[slot][thread]: no bank
+// conflicts; binary search, a new entry shifts the tail) and writes it slot-major; an exclusive sum of the counts gives the row pointers and a second kernel packs the
 // columns.  This replaces sorting 12 keys per cell (71 M at 1 M rows: 6 radix passes of 1.1 GB) and the unique pass over them.
 // A row with more neighbours than the set holds sends the whole space back to the sorted-keys path.
 // CAP / BLOCK: 32 entries x 256 rows per workgroup for CG1, 160 x 64 for CG2 (a vertex row of a tetrahedral CG2 space couples to
