@@ -572,18 +572,20 @@ def iteration_rates(st, k, n_rows):
                                                           "required bytes of the product + 72 B/row of the update")}
 
 
+PROFILE_ROUND = "r05"          # the round whose committed PMC passes (profiles/<round>_pmc.json) belong to THIS tree's kernels
+
+
 def committed_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
-    newest round first; collected on the same command in separate --pmc runs).  Not measured in this run."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):      # (newest round first)
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                v = json.load(fh).get(tag)
-            if v is not None:
-                return v, "profiles/" + name
-        except Exception:
-            pass
-    return None, None
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round (profiles/r05_pmc.json;
+    collected on the same command in separate --pmc runs by tools/collect_profiles.sh).  Not measured in this run.  A missing file
+    or key gives None: an older round's file describes an older kernel and is never used."""
+    name = PROFILE_ROUND + "_pmc.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            v = json.load(fh).get(tag)
+    except (OSError, ValueError):
+        return None, None
+    return (v, "profiles/" + name) if v is not None else (None, None)
 
 
 def make_roofline(k, workload, traffic, traffic_source):
@@ -680,6 +682,7 @@ def main():
     if world > 1 and axis == 2 and a.scaling == "weak":
         print("[bench] note: --bc-axis 2 with weak scaling lengthens the bar between the Dirichlet faces; "
               "iteration counts will grow with N", file=sys.stderr)
+    B.profile_marker(1)         # phase 1 of a traced run: the step workload (tools/summarize_profiles.py)
     if a.mesh != "structured":
         if world != 1:
             sys.exit("bench.py --mesh %s is a one-GPU measurement" % a.mesh)
@@ -689,7 +692,14 @@ def main():
     n_dof_total = (n + 1) * (n + 1) * (nz + 1)
 
     recurrence, trial = choose_recurrence(prob, a.rtol, world, a.recurrence, barrier)
-    elapsed, asm_ms_step, stats, recurrence = timed_steps_with_fallback(prob, a.rtol, a.steps, barrier, recurrence, trial, world, a.warmup)
+    first_step_ms, warmup_left = None, a.warmup
+    if world == 1 and a.warmup > 0:      # the COLD step of the process (row classes found from scratch, graphs instantiated): one of the warm-ups
+        B.synchronize()
+        t0 = time.perf_counter()
+        prob.step(a.rtol)
+        B.synchronize()
+        first_step_ms, warmup_left = (time.perf_counter() - t0) * 1e3, a.warmup - 1
+    elapsed, asm_ms_step, stats, recurrence = timed_steps_with_fallback(prob, a.rtol, a.steps, barrier, recurrence, trial, world, warmup_left)
     ms_per_step = elapsed * 1e3 / a.steps
 
     out = None
@@ -716,16 +726,19 @@ def main():
                                    "mesh_ms", "update_kernel_ms")}
         if trial:
             out["config"]["recurrence_trial_ms_per_step"] = trial
-        # what ONE steady solve() of the reference API pays on this workload: mesh + sparsity pattern + assemble + solve
-        out["one_shot_dof_per_s"] = round(n_dof_total / (1e-3 * (prob.mesh_ms + prob.symbolic_ms + ms_per_step)), 1)
+        # what ONE solve() of the reference API pays on this workload, from the FIRST step of the process (nothing kept, nothing
+        # instantiated): mesh + sparsity pattern + first assemble + first solve; cold_one_shot adds fs_init (device context, code objects)
+        one = first_step_ms if first_step_ms is not None else ms_per_step
+        out["first_step_ms"] = None if first_step_ms is None else round(first_step_ms, 3)
+        out["one_shot_dof_per_s"] = round(n_dof_total / (1e-3 * (prob.mesh_ms + prob.symbolic_ms + one)), 1)
+        out["cold_one_shot_dof_per_s"] = round(n_dof_total / (1e-3 * (init_ms + prob.mesh_ms + prob.symbolic_ms + one)), 1)
+        out["init_ms"] = round(init_ms, 1)
         if getattr(prob, "symbolic_warm_ms", None) is not None:
             out["symbolic_warm_ms"] = round(prob.symbolic_warm_ms, 3)
-            out["init_ms"] = round(init_ms, 1)
             out["symbolic_note"] = ("symbolic_ms is the first pattern build of the process, symbolic_warm_ms a second build of the same pattern. "
-                                    "The library's code objects (the set-up kernels' alone: 3 300 rocPRIM instantiations, about 35 ms) are loaded "
-                                    "by fs_init, once per process - init_ms, not part of one_shot_dof_per_s, as `import dolfin` is not part of a "
-                                    "solve() of the reference; FS_PRELOAD=0 loads them at the first launch out of each file instead "
-                                    "(symbolic_ms was 48 ms that way)")
+                                    "one_shot_dof_per_s = n / (mesh_ms + symbolic_ms + first_step_ms): the first step of the process, not the "
+                                    "steady one; cold_one_shot_dof_per_s adds init_ms (fs_init: device context + the library's code objects, "
+                                    "once per process - what `import dolfin` is to the reference)")
         step_kernel = kernel_rates(stats, prob.V)
         step_kernel["update_kernel"] = update_rates(stats, prob.n_owned)
         step_kernel["iteration"] = iteration_rates(stats, step_kernel, prob.n_owned)
@@ -784,8 +797,13 @@ def main():
         # --- the dominant kernel on an HBM-resident problem of the same family (10 M DOF): the roofline of the line ---
         if not a.no_hbm_case and "roofline" not in out:
             del prob
+            B.profile_marker(2)     # phase 2: the HBM-resident sibling, row-dictionary product
             big = Problem(215, 215, 215, (1.0, 1.0, 1.0), (0, 216), axis, 0, 1)
+            B.synchronize()
+            t0 = time.perf_counter()
             big.step(a.rtol)
+            B.synchronize()
+            t_big_first = time.perf_counter() - t0
             t0 = time.perf_counter()
             st_big, asm_big = big.step(a.rtol)
             B.synchronize()
@@ -799,8 +817,9 @@ def main():
                       "assemble_ms": round(asm_big, 3), "solve_ms": round(st_big["solve_ms"], 3),
                       "update_kernel": update_rates(st_big, big.n_owned), "iteration": iteration_rates(st_big, k_big, big.n_owned),
                       "one_shot": {"mesh_ms": round(big.mesh_ms, 2), "symbolic_ms": round(big.symbolic_ms, 2),
-                                   "dof_per_s": round(big.n_owned / (1e-3 * (big.mesh_ms + big.symbolic_ms) + t_big), 1),
-                                   "what": "mesh + sparsity pattern + assemble + solve: what ONE steady solve() of the reference API pays"}})
+                                   "first_step_ms": round(t_big_first * 1e3, 2),
+                                   "dof_per_s": round(big.n_owned / (1e-3 * (big.mesh_ms + big.symbolic_ms) + t_big_first), 1),
+                                   "what": "mesh + sparsity pattern + FIRST assemble + solve on this mesh: what ONE solve() of the reference API pays"}})
             if st_big.get("row_classes", 0) > 0:
                 # The operator of a uniform box with a constant coefficient has a few dozen distinct rows: the product runs in
                 # row-dictionary form and does not stream the matrix at all.  Both are reported: the kernel the path really runs
@@ -810,6 +829,7 @@ def main():
                     "8 B per entry (every row of every solve's matrix verified against its class bit for bit; same offsets, same summation order, same bits as "
                     "the streaming product): its roofline is on the 26 B/row it has to move; csr_equivalent_GBps exceeds the peak because "
                     "those bytes are not moved" % st_big["row_classes"])
+                B.profile_marker(3)     # phase 3: the same cube, streaming product
                 B.set_option("row_dictionary", 0)
                 try:
                     big.step(a.rtol)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "fs_init": (C.c_int, [C.c_int]),
     "fs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fs_device_synchronize": (C.c_int, []),
+    "fs_profile_marker": (C.c_int, [C.c_int]),
     "fs_memory_info": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "fs_memory_trim": (C.c_int, []),
     "fs_last_error": (C.c_char_p, []),

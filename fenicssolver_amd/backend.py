@@ -39,6 +39,12 @@ def synchronize():
     L.check(L.load().fs_device_synchronize(), "fs_device_synchronize")
 
 
+def profile_marker(phase):
+    """An empty, named launch (k_profile_marker) between the legs of a traced command: the n-th one opens phase n of
+    tools/summarize_profiles.py."""
+    L.check(L.load().fs_profile_marker(int(phase)), "fs_profile_marker")
+
+
 def memory_info():
     """Bytes of device memory the library holds: in use by live objects / idle in its block cache."""
     live, cached = C.c_int64(0), C.c_int64(0)

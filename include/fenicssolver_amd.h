@@ -63,6 +63,10 @@ typedef struct fs_vector_s* fs_vector_t;
 int fs_init(int device_id);
 int fs_device_count(int* count);
 int fs_device_synchronize(void);
+/* Enqueues an empty kernel named k_profile_marker on the library's stream (no dolfin analogue; the reference's only timing is the
+ * wall clock around solve(), SolverBase.py:514-525).  A traced command (rocprofv3 --kernel-trace / --pmc) that runs several problem
+ * sizes or kernel variants back to back calls it between them; the n-th marker opens phase n of tools/summarize_profiles.py. */
+int fs_profile_marker(int phase);
 /* Device blocks released by the library are cached for re-use (hipFree synchronises the device, a time loop that
  * re-assembles its operators must not pay it every step): fs_memory_info reports the bytes in use / idle in the
  * cache, fs_memory_trim returns the idle ones to the driver.  FS_POOL_MAX_MB (environment, default 16384) caps the

@@ -7,8 +7,11 @@
                                     (the gfx950 correction of the read side is applied in
                                     profiles/<tag>_pmc.json, see profiles/README.md)
 
-The default bench command runs two problem sizes back to back; dispatches are attributed to a
-phase by time: before / after the last sparsity build (last k_pair_keys dispatch).
+The default bench command runs three legs back to back (configs[1] at 1 M DOF; the 10 M-DOF cube with the
+row-dictionary product; the same cube with the streaming product).  bench.py enqueues an empty kernel named
+k_profile_marker (fs_profile_marker) before each leg; a dispatch belongs to the phase whose marker is the last
+one before it.  A trace WITHOUT the markers is refused: splitting on the name of a set-up kernel went wrong once
+a round removed that kernel (round 4: every launch of both sizes under one phase, calibration 4.13).
 """
 import csv
 import json
@@ -23,7 +26,10 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 # second argument: output directory (default profiles/).  On the GPU box the summaries are written under gpurun_out/
 # and the multi-10-MB databases are deleted before gpurun copies the directory back.
 OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
-PHASES = ("n99_1M_dof", "n215_10M_dof")
+# phase 0 = before the first marker (fs_init, code-object loading); then one phase per marker, in bench.py's order
+PHASES = ("init", "n99_1M_dof", "n215_10M_dof", "n215_10M_dof_streaming")
+N_DOF = {"n99_1M_dof": 100 ** 3, "n215_10M_dof": 216 ** 3, "n215_10M_dof_streaming": 216 ** 3}
+MARKER = "k_profile_marker"
 HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
 
@@ -36,10 +42,21 @@ def short(name):
 
 
 def phase_split(cur, table, name_col, start_col):
-    rows = cur.execute("select %s from %s where %s like 'k_pair_keys%%' order by %s"
-                       % (start_col, table, name_col, start_col)).fetchall()
-    # (round 4: bench.py builds the 1 M-DOF pattern twice - cold and warm - so the 10 M-DOF phase starts at the LAST build)
-    return rows[-1][0] if len(rows) > 1 else None
+    """Start times of the marker launches, in order.  Exactly len(PHASES) - 1 of them, or the trace is not one of bench.py's."""
+    rows = [r[0] for r in cur.execute("select %s from %s where %s like '%%%s%%' order by %s"
+                                      % (start_col, table, name_col, MARKER, start_col)).fetchall()]
+    rows = sorted(set(rows))            # (a counter pass lists a dispatch once per counter instance)
+    if len(rows) != len(PHASES) - 1:
+        sys.exit("summarize_profiles: %d %s launches in %s, expected %d (one per leg of the default bench command) - "
+                 "refusing to attribute kernels to phases" % (len(rows), MARKER, table, len(PHASES) - 1))
+    return rows
+
+
+def phase_of(marks, start):
+    i = 0
+    while i < len(marks) and start >= marks[i]:
+        i += 1
+    return PHASES[i]
 
 
 def kernel_stats():
@@ -48,7 +65,9 @@ def kernel_stats():
     split = phase_split(cur, "kernels", "name", "start")
     agg = {}
     for name, start, dur in cur.execute("select name, start, duration from kernels"):
-        ph = PHASES[0] if split is None or start < split else PHASES[1]
+        if MARKER in name:
+            continue
+        ph = phase_of(split, start)
         a = agg.setdefault((ph, short(name)), [0, 0.0, 1e30, 0.0, []])
         a[0] += 1
         a[1] += dur
@@ -79,8 +98,9 @@ def pmc(counter):
     vals = {}
     for name, start, val in cur.execute(
             "select kernel_name, start, value from counters_collection where counter_name=?", (counter,)):
-        ph = PHASES[0] if split is None or start < split else PHASES[1]
-        vals.setdefault((ph, short(name)), []).append(val)
+        if MARKER in name:
+            continue
+        vals.setdefault((phase_of(split, start), short(name)), []).append(val)
     mean, cnt = {}, {}
     for k, v in vals.items():
         top = max(v)
@@ -106,71 +126,62 @@ def main():
     json.dump(raw, open(os.path.join(OUT, TAG + "_pmc_raw.json"), "w"), indent=1)
     # gfx950 correction (guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B.
     # Calibrated in THIS run on kernels of known byte count (see profiles/README.md): reads x2, writes x1.
-    n_dof = {PHASES[0]: 100 ** 3, PHASES[1]: 216 ** 3}
     cal = {}
-    for ph in PHASES:
-        n = n_dof[ph]
-        # streams of known size: dot (1 read), residuals (2 / 3 reads), CG updates (reads r,w,p,s,x [+z,dinv])
-        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_residual_scaled", 24 * n),
-                          ("k_cg_update<true>", 56 * n), ("k_cg_update_scaled<true>", 40 * n)):
+    for ph in PHASES[1:]:
+        n = N_DOF[ph]
+        # streams of known size: dot (1 read), residuals (2 / 3 reads).  The CG update kernel (reads r, w, p, s, x; writes r, p, s, x)
+        # calibrates the WRITE side only: the tail of w, written by the product just before it, is still in the L2s (its reads come
+        # out at 0.447 instead of 0.500 of the bytes at 10 M rows)
+        for k, expect in (("k_dot_partial", 8 * n), ("k_residual", 16 * n), ("k_residual_scaled", 24 * n)):
             if (ph, k) in fetch:
                 cal["%s/%s" % (ph, k)] = {"expected_read_bytes": expect,
                                           "FETCH_SIZE_bytes": int(fetch[(ph, k)] * 1024),
                                           "ratio": round(fetch[(ph, k)] * 1024 / expect, 4)}
-        for k, expect in (("k_cg_update<true>", 40 * n), ("k_cg_update_scaled<true>", 32 * n)):
+        for k, expect in (("k_cg_update<true>", 40 * n), ("k_cg_update_scaled<true, true>", 32 * n)):
             if (ph, k) in write:
                 cal["%s/%s(write)" % (ph, k)] = {"expected_write_bytes": expect,
                                                  "WRITE_SIZE_bytes": int(write[(ph, k)] * 1024),
                                                  "ratio": round(write[(ph, k)] * 1024 / expect, 4)}
     out = {"_doc": "HBM-side bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                   "(read side doubled per the gfx950 rule, confirmed by the calibration block). "
-                   "bench.py reports these as roofline.traffic.",
+                   "(read side doubled per the gfx950 rule, confirmed by the calibration block: read ratios 0.50, write ratios 1.0). "
+                   "bench.py reports these as roofline.traffic.  Phases = the legs of the default bench command, split at its "
+                   "k_profile_marker launches.",
+           "phases": sorted({ph for ph, _ in fetch}, key=PHASES.index),
            "calibration": cal}
-    for ph, tag in ((PHASES[0], "spmv_fused_n99"), (PHASES[1], "spmv_fused_n215")):
-        # DOTS template argument: 3 = in-CG kernel of the diagonally scaled solve, 1 = unscaled CG /
-        # fs_spmv_benchmark(fused), 0 = bare SpMV
-        # the launch shape (last template argument = entries per round) depends on the problem size
-        def find(dots):
-            # ... and so does the 4th one (non-temporal matrix loads when the matrix exceeds the caches)
-            for un in ("4", "16", "8", "2"):
-                for tail in ("", ", false", ", true"):
-                    k = (ph, "k_sell_spmv<1, %s, %s%s>" % (dots, un, tail))
-                    if k in fetch:
-                        return k
-            return None
-        for dots in ("3", "1"):
-            key = find(dots)
+
+    def hbm(key):
+        return (2 * fetch[key] + write.get(key, 0.0)) * 1024
+
+    def first(ph, *prefixes):
+        for pre in prefixes:
+            for key in sorted(fetch):
+                if key[0] == ph and key[1].startswith(pre):
+                    return key
+        return None
+
+    for ph, size in (("n99_1M_dof", "n99"), ("n215_10M_dof", "n215"), ("n215_10M_dof_streaming", "n215")):
+        # streaming product, DOTS template argument 3 (in-CG kernel of the diagonally scaled solve) / 0 (bare): at HBM-resident
+        # sizes one product = k_dia_pair_spmv on the paired DIA slices + k_sell_spmv on the rest, one launch of each
+        for dots, tag in (("3", "spmv_fused_"), ("0", "spmv_bare_")):
+            keys = [k for k in (first(ph, "k_dia_pair_spmv<%s," % dots), first(ph, "k_sell_spmv<1, %s," % dots)) if k is not None]
+            if keys:                                   # (the streaming leg comes last and owns the n215 keys)
+                out[tag + size] = int(sum(hbm(k) for k in keys))
+                out[tag + size + "_kernels"] = [k[1] for k in keys]
+        if ph.endswith("streaming"):
+            key = first(ph, "k_cg_update_scaled<true, true>")
             if key is not None:
-                out[tag + ("" if dots == "3" else "_dots1")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
-            # HBM-resident sizes: the product is k_dia_pair_spmv (paired DIA slices, two rows per lane) + k_sell_spmv on the
-            # few unpaired slices - one product = one launch of each
-            for nt in ("true", "false"):
-                pk = (ph, "k_dia_pair_spmv<%s, %s>" % (dots, nt))
-                if pk in fetch:
-                    total = (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
-                    if key is not None:
-                        total += (2 * fetch[key] + write.get(key, 0.0)) * 1024
-                    out[tag + ("" if dots == "3" else "_dots1")] = int(total)
-                    out[tag + ("" if dots == "3" else "_dots1") + "_kernels"] = [pk[1]] + ([key[1]] if key is not None else [])
-        if tag not in out and tag + "_dots1" in out:
-            out[tag] = out[tag + "_dots1"]
-        key = find("0")
-        bare = 0.0 if key is None else (2 * fetch[key] + write.get(key, 0.0)) * 1024
-        for nt in ("true", "false"):
-            pk = (ph, "k_dia_pair_spmv<0, %s>" % nt)
-            if pk in fetch:
-                bare += (2 * fetch[pk] + write.get(pk, 0.0)) * 1024
-        if bare > 0.0:
-            out[tag.replace("fused", "bare")] = int(bare)
-        for dk in sorted(fetch):              # row-dictionary form of the same product (dictionary in LDS / class rows per work item;
-            if dk[0] == ph and (dk[1].startswith("k_dict_spmv<3, true") or dk[1].startswith("k_dict_spmv<3, false")):    # last argument: run length)
-                out[tag.replace("spmv_fused", "spmv_dict")] = int((2 * fetch[dk] + write.get(dk, 0.0)) * 1024)
-        for ik in sorted(fetch):                          # the one-launch CG iteration (update k + product k + 1; up to 3 M rows;
-            if ik[0] == ph and ik[1].startswith("k_dict_cg_iter<3"):      # second template argument: decomposed space)
-                out[tag.replace("spmv_fused", "cg_iter")] = int((2 * fetch[ik] + write.get(ik, 0.0)) * 1024)
-        key = (ph, "k_assemble_p1_scalar_gather<false>")
-        if key in fetch:
-            out[tag.replace("spmv_fused", "assemble")] = int((2 * fetch[key] + write.get(key, 0.0)) * 1024)
+                out["update_" + size] = int(hbm(key))
+            continue
+        key = first(ph, "k_dict_spmv<3,")          # row-dictionary form of the product (dictionary in LDS / class rows per work item)
+        if key is not None:
+            out["spmv_dict_" + size] = int(hbm(key))
+            out["spmv_dict_" + size + "_kernel"] = key[1]
+        key = first(ph, "k_dict_cg_iter<3")         # the one-launch CG iteration (update k + product k + 1; up to 3 M rows)
+        if key is not None:
+            out["cg_iter_" + size] = int(hbm(key))
+        key = first(ph, "k_assemble_p1_scalar_gather")
+        if key is not None:
+            out["assemble_" + size] = int(hbm(key))
     json.dump(out, open(os.path.join(OUT, TAG + "_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
