@@ -146,9 +146,16 @@ class CoupledNavierStokesSolver(SolverBase):
         from . import backend
         law = self.temperature_law()
         if law is None:
+            # the law lives on the (shared) device space: a solver without one - another solver on the same function_space, or this
+            # one after its material went back to Newtonian / pressure-only - must not assemble with what was attached before
+            root = self.function_space.root() if hasattr(self.function_space, 'root') else self.function_space
+            dW = getattr(root, '_device', None)           # (no device space yet: nothing can be attached to it)
+            if dW is not None and (getattr(dW, '_law_temperature', None) is not None or self.__dict__.get('_law_T') is not None):
+                backend.set_viscosity_law(dW, None)
+                self._law_T = None
             return
-        Ts = self._temperature_solver()
         dW = self.function_space.device()
+        Ts = self._temperature_solver()
         vals = Ts.w_current.vector()._values()
         loc = self.function_space.localizer()
         # one value per LOCAL NODE of the flow space (read at the vertex nodes): on one GPU the vertices are the first nodes; a
@@ -183,6 +190,7 @@ class CoupledNavierStokesSolver(SolverBase):
 
     # ------------------------------------------------------------------ form
     def generate_form(self, time_iter_, trial_function, test_function, up_current, up_prev):
+        self._attach_temperature_law()      # nu(p, T) belongs to the form: attached (or detached) where the form is made, not only in the coupled step
         F = self._cell_form(time_iter_, up_current, up_prev)
         bcs, F.pressure_boundaries = self.update_boundary_conditions(time_iter_, trial_function, test_function,
                                                                                   Measure("ds", subdomain_data=self.boundary_facets))
@@ -461,6 +469,8 @@ class CoupledNavierStokesSolver(SolverBase):
         from . import backend
         from .fem import FunctionSpace, TensorFunctionSpace
         W = up.function_space()
+        if W is self.function_space:
+            self._attach_temperature_law()      # this solver's law (or none), whatever was assembled on the space last
         d = self.dimension
         nt = d * d
         if T_space is None:

@@ -225,7 +225,12 @@ class LinearElasticitySolver(SolverBase):
         bcs = []
         integrals_N = []
         if 'point_source' in self.settings and self.settings['point_source']:
-            raise SolverError('point_source is not supported')
+            # The reference reads the WRONG key here - settings['surface_source'] (LinearElasticitySolver.py:105-108) - and appends that
+            # dict to the Dirichlet list, which assemble_system (:643-650 of SolverBase.py) then rejects: no elasticity case with a
+            # point_source runs upstream.  Kept as an error ("refusals"); a point load is a 'force' boundary
+            # condition on a small marked facet patch, or a PointSource of the scalar solver for scalar problems.
+            raise SolverError("point_source is not supported by LinearElasticitySolver (the reference's own branch reads "
+                              "settings['surface_source'] and fails in assemble_system); use a 'force' boundary condition")
         if 'surface_source' in self.settings and self.settings['surface_source']:
             raise SolverError('surface_source is not supported')
 

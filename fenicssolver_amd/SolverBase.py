@@ -368,6 +368,11 @@ class SolverBase():
         if amg and 'preconditioner' not in sp_:
             pc = 'amg'
             method = automatic         # solve_amg is the reference's CG + AMG path (SolverBase.py:643-672): a general-solver name does not undo it
+        if pc == 'amg' and method != "cg" and automatic == "cg":
+            # 'gmres' / 'bicgstab' / 'tfqmr' + an AMG preconditioner on a SYMMETRIC operator: the reference would run that Krylov
+            # method with GAMG; here the preconditioner is kept and the method is CG, which the operator allows
+            self.logger.info("%s: linear_solver '%s' with an AMG preconditioner on a symmetric operator: CG + AMG", label, sp_.get('linear_solver'))
+            method = "cg"
         if pc == 'amg' and method != "cg":
             self.logger.warning('%s: the AMG hierarchy is built for symmetric problems; using Jacobi', label)
             pc = 'jacobi'
@@ -472,6 +477,9 @@ class SolverBase():
         tag = 'replicated' if A_local is None else 'distributed'
         if key is not None and cached is not None and cached[0] == (tag, key):
             hierarchy, reused = cached[1], True
+            if getattr(hierarchy, '_distributed', False) and hierarchy.A_local is not A_local:
+                # same operator key, another matrix object: CG multiplies with the caller's CURRENT matrix
+                hierarchy.attach_distributed_fine(A_local, loc.owned_gids())
         else:
             if cached is not None:
                 cached[1].close()
@@ -491,6 +499,16 @@ class SolverBase():
             stats = hierarchy.solve(b, x, rtol=rtol, max_iter=max_iter, norm=norm)
             stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
             stats['amg_reused'], stats['amg_decomposition'] = reused, 'distributed'
+            if stats['converged'] != 1 and stats['converged'] >= 0:
+                # The distributed fine level has not run on more than one physical GPU yet: a solve that
+                # does not reach its tolerance - the status is the same on every rank, it comes from reduced sums - is repeated
+                # with the replicated hierarchy of round 3 (no communication inside the solve) instead of being reported.
+                self.logger.warning('solve_amg: %d iterations with the distributed fine level without convergence; solving again replicated',
+                                    stats['iterations'])
+                hierarchy.close()
+                self._amg_cache = None
+                x.fill(0.0)
+                return self._replicated_amg_solve(b, x, V, loc, ncomp, global_operator, key, near_nullspace, rtol, max_iter, norm, theta)
             if parallel.world()[1] > 1:
                 backend.halo_exchange(V, x)
             if key is None:
@@ -573,8 +591,6 @@ class SolverBase():
             first = True
             for s in F.sources:
                 spec = L_(s.spec())
-                if pe and isinstance(spec, tuple) and spec[0] == 'nodal':
-                    raise SolverError('SUPG with a nodal (Function / Expression) source is not built')
                 backend.assemble_vector(V, b, source=spec, add=not first, supg=(adv, pe) if pe else None)
                 first = False
             for fl in F.facet_loads:

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsamd.so")
 
 FS_OK = 0
+FS_ERR_COMM, FS_ERR_NUMERIC, FS_ERR_P2P_TIMEOUT = -5, -6, -7      # include/fenicssolver_amd.h
 FS_COEF_NONE, FS_COEF_CONST, FS_COEF_CELL, FS_COEF_TENSOR, FS_COEF_NODAL, FS_COEF_CELL_ROW, FS_COEF_CELL_TENSOR, FS_COEF_CELL_QP = 0, 1, 2, 3, 4, 5, 6, 7
 FS_KSP_CG = 0
 FS_KSP_BICGSTAB = 1
@@ -30,7 +31,8 @@ c_i64p = C.POINTER(C.c_int64)
 
 
 class BackendError(RuntimeError):
-    """libfsamd.so is missing, no GPU is visible, or a call failed."""
+    """libfsamd.so is missing, no GPU is visible, or a call failed (rc = the FS_ERR_* code of the call, None otherwise)."""
+    rc = None
 
 
 class fs_coef(C.Structure):
@@ -202,7 +204,9 @@ def load():
 def check(rc, what=""):
     if rc != FS_OK:
         msg = load().fs_last_error()
-        raise BackendError("%s failed (code %d): %s" % (what or "libfsamd call", rc, (msg or b"").decode()))
+        err = BackendError("%s failed (code %d): %s" % (what or "libfsamd call", rc, (msg or b"").decode()))
+        err.rc = int(rc)
+        raise err
 
 
 def f64(a):

@@ -204,11 +204,13 @@ class DeviceSpace(_Handle):
             ri = L.i32(np.concatenate([np.asarray(r, dtype=np.int32) for r in recv_lists]) if len(recv_lists) else [])
             L.check(L.load().fs_space_set_halo_indexed(self.h, len(nb), L.p_i32(nb), L.p_i64(sc), L.p_i32(si), L.p_i64(rc),
                                                        L.p_i32(ri)), "fs_space_set_halo_indexed")
-        # The peer-to-peer exchange is the DEFAULT transport of a halo plan (round 4): 38 instead of 57 us per CG iteration at
-        # 1 M rows per rank (profiles/r03_p2p_self_halo_timings.txt), and the set-up ends with a self-test whose verdict all
-        # ranks agree on - a node where the mappings cannot be made (several nodes, no peer access) falls back to RCCL on EVERY
-        # rank, here.  FS_HALO_P2P=0: RCCL only; FS_HALO_P2P=1: a failed set-up is an error instead of a fall-back.
-        mode = os.environ.get("FS_HALO_P2P", "auto")
+        # The peer-to-peer exchange (29 instead of 55 us per CG iteration at 1 M rows per rank with the rank its own neighbour,
+        # profiles/*_p2p_self_halo_timings.txt) is OPT-IN until it has crossed a device boundary on hardware (round 5):
+        # FS_HALO_P2P=auto tries it - the set-up ends with a self-test whose verdict all ranks agree on, and a node where the
+        # mappings cannot be made falls back to RCCL on EVERY rank, here; FS_HALO_P2P=1: a failed set-up is an error instead of a
+        # fall-back; unset / 0: RCCL send / recv.  bench.py tries every transport explicitly and times the fastest that reproduces
+        # the RCCL field.
+        mode = os.environ.get("FS_HALO_P2P", "0")
         if _comm_up and mode != "0" and comm_info()[0] > 1:
             try:
                 self.enable_p2p_halo(True)
@@ -221,7 +223,7 @@ class DeviceSpace(_Handle):
     def enable_p2p_halo(self, on=True):
         """Ghost refresh by direct stores into the neighbours' memory (hipIpc mappings, one node) instead of RCCL send / recv.
         COLLECTIVE: every rank of the communicator calls it for its space, in the same order (also to turn it off).
-        On by default for every halo plan set while a communicator of more than one rank is up (FS_HALO_P2P=0: off)."""
+        Environment FS_HALO_P2P=auto / 1 turns it on for every halo plan set while a communicator of more than one rank is up."""
         self._p2p = False
         L.check(L.load().fs_space_enable_p2p_halo(self.h, 1 if on else 0), "fs_space_enable_p2p_halo")
         self._p2p = bool(on)
@@ -484,8 +486,18 @@ def assemble_facet_vector(space, b, tri, g):
             "fs_assemble_facet_vector")
 
 
+def _same_device_mesh(field_space, p1_space, what):
+    """A projection reads a field of one space cell by cell and loads another: both on ONE device mesh.  On several ranks a periodic
+    space cuts its own part (its masters are extra ghosts), and an unconstrained space made BEFORE it on the same host mesh sits on
+    another one (fem.FunctionSpace._make_parallel_device shares the periodic part only with spaces made after it)."""
+    if field_space.mesh is not p1_space.mesh:
+        raise BackendError("%s: the two spaces live on different device meshes (parts) of the same host mesh - on several ranks create "
+                           "the periodic function space BEFORE the unconstrained spaces that share its mesh" % what)
+
+
 def assemble_von_mises(disp_space, u, mu, lmbda, p1_space, b):
     """b_a = int sqrt(3/2 s:s) phi_a dx, s the deviator of sigma(u), on the scalar CG1 space of the same mesh."""
+    _same_device_mesh(disp_space, p1_space, "assemble_von_mises")
     L.check(L.load().fs_assemble_von_mises(disp_space.h, u.h, float(mu), float(lmbda), p1_space.h, b.h), "fs_assemble_von_mises")
 
 
@@ -493,6 +505,7 @@ def assemble_viscous_stress(th_space, w, nu, p1_space, b, viscosity_law=None):
     """b[vertex*9 + 3i + j] = int (nu (grad u + grad u^T) - p I)_ij phi_vertex dx for a Taylor-Hood iterate w.
     viscosity_law = (p_ref, exponent): nu (p / p_ref)^exponent."""
     pref, ex = (0.0, 0.0) if viscosity_law is None else (float(viscosity_law[0]), float(viscosity_law[1]))
+    _same_device_mesh(th_space, p1_space, "assemble_viscous_stress")
     L.check(L.load().fs_assemble_viscous_stress_nn(th_space.h, w.h, float(nu), p1_space.h, b.h, pref, ex), "fs_assemble_viscous_stress")
 
 
@@ -526,12 +539,22 @@ def krylov_solve(A, b, x, rtol=1e-8, atol=0.0, max_iter=10000, precond="jacobi",
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 
 
-def _with_p2p_fallback(space, solve, x_guess=None):
-    """Run a solve over a space whose ghost refresh is the peer-to-peer exchange.  A wait of that transport that times out
-    (peer process gone, stores over the mappings not visible on this system) fails the solve on the rank that saw it; the ranks
-    compare notes over RCCL proper (never over the transport in doubt), and if ANY of them failed all of them turn the exchange
-    of this space off and solve again over RCCL send / recv.  One host all-gather per solve, only while the exchange is on."""
-    if not getattr(space, "_p2p", False) or not _comm_up:
+def _with_p2p_fallback(spaces, solve, x_guess=None):
+    """Run a solve over space(s) whose ghost refresh is the peer-to-peer exchange.  A wait of that transport that times out (peer
+    process gone, stores over the mappings not visible on this system) fails the solve with FS_ERR_P2P_TIMEOUT on the rank that
+    saw it.  The ranks then compare notes over RCCL proper (never over the transport in doubt) on THAT code only, and if any of
+    them saw it all of them turn the exchange of the space(s) off and solve again over RCCL send / recv.  Any other failure - a
+    Krylov breakdown, a zero diagonal, a bad argument - is not the transport's: it is raised as it is (after the agreement, so that
+    the ranks stay paired), nothing is turned off and nothing is repeated.  One small RCCL all-gather per solve, only while the
+    exchange is on: a rank can finish its last wait while a neighbour times out on its own, so success on this rank says nothing
+    about the others."""
+    if not isinstance(spaces, (list, tuple)):
+        spaces = [spaces]
+    live = []
+    for sp in spaces:
+        if sp is not None and getattr(sp, "_p2p", False) and not any(sp is q for q in live):
+            live.append(sp)
+    if not live or not _comm_up:
         return solve()
     keep = None
     if x_guess is not None:
@@ -542,12 +565,18 @@ def _with_p2p_fallback(space, solve, x_guess=None):
         solve()
     except L.BackendError as e:
         err = e
-    if float(np.sum(comm_allgather([0.0 if err is None else 1.0], 1))) == 0.0:
+    timed_out = err is not None and err.rc == L.FS_ERR_P2P_TIMEOUT
+    if float(np.sum(comm_allgather([1.0 if timed_out else 0.0], 1))) == 0.0:
+        if err is not None:
+            raise err
         return None
     import logging
-    logging.getLogger("fenicssolver_amd").warning("peer-to-peer halo exchange failed during a solve (%s): turned off, solving again over RCCL",
-                                                  str(err)[:160] if err else "on another rank")
-    space.enable_p2p_halo(False)
+    logging.getLogger("fenicssolver_amd").warning("peer-to-peer halo exchange timed out during a solve (%s): turned off, solving again over RCCL",
+                                                  "on this rank" if timed_out else "on another rank")
+    for sp in live:
+        sp.enable_p2p_halo(False)
+    if err is not None and not timed_out:
+        raise err
     if keep is not None:
         x_guess.copy_from(keep)
     return solve()
@@ -630,7 +659,11 @@ class AMG(_Handle):
         o.nonzero_guess = 1 if nonzero_guess else 0
         o.norm_type = {"unpreconditioned": L.FS_NORM_UNPRECONDITIONED, "preconditioned": L.FS_NORM_PRECONDITIONED}[norm]
         st = L.fs_krylov_stats()
-        L.check(L.load().fs_amg_solve(self.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_amg_solve")
+
+        def solve():
+            L.check(L.load().fs_amg_solve(self.h, b.h, x.h, C.byref(o), C.byref(st)), "fs_amg_solve")
+        fine = getattr(self, "A_local", None) or self.A
+        _with_p2p_fallback(fine.space, solve, x if nonzero_guess else None)
         return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 
 
@@ -699,9 +732,12 @@ def saddle_solve(J, Kp, Mp, b, x, nu, rho=1.0, inv_dt=0.0, rtol=1e-8, atol=0.0, 
     o.kinematic_viscosity, o.density, o.inv_dt = float(nu), float(rho), float(inv_dt)
     o.velocity_sweeps, o.inner_rtol, o.nonzero_guess = int(velocity_sweeps), float(inner_rtol), 1 if nonzero_guess else 0
     st = L.fs_krylov_stats()
-    L.check(L.load().fs_saddle_solve(J.h, Kp.h if Kp is not None else None, Kp_amg.h if Kp_amg is not None else None,
-                                     Mp.h, b.h, x.h, C.byref(o), C.byref(st)),
-            "fs_saddle_solve")
+
+    def solve():
+        L.check(L.load().fs_saddle_solve(J.h, Kp.h if Kp is not None else None, Kp_amg.h if Kp_amg is not None else None,
+                                         Mp.h, b.h, x.h, C.byref(o), C.byref(st)),
+                "fs_saddle_solve")
+    _with_p2p_fallback([M.space for M in (J, Kp, Mp) if M is not None], solve, x if nonzero_guess else None)
     return {k: getattr(st, k) for k, _ in L.fs_krylov_stats._fields_}
 
 

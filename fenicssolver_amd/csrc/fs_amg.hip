@@ -68,6 +68,7 @@ struct fs_amg_s {
     // undecomposed operator (every rank the same), `fine` is swapped for this rank's rows of the decomposed operator and dist0
     // holds the level-0 pieces for those rows - P rows + transpose index, dinv, work vectors; level 1 and below stay replicated
     amg_level* dist0 = nullptr;
+    fs_space_s* dist_space = nullptr;      // the decomposed space dist0 was built for (a later matrix on it may be re-attached)
     ~fs_amg_s() {
         for (amg_level* l : lv) delete l;
         delete dist0;
@@ -1721,9 +1722,16 @@ extern "C" int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, i
     FS_CHECK(fs_require_init());
     FS_REQUIRE(M && A_local && owned_global_nodes, "fs_amg_attach_distributed_fine: null pointer");
     FS_REQUIRE(M->lv.size() >= 2, "fs_amg_attach_distributed_fine: the hierarchy has a single level");
-    FS_REQUIRE(!M->dist0, "fs_amg_attach_distributed_fine: a distributed fine level is attached already");
     amg_level* G = M->lv[0];
     fs_space_s* sp = A_local->space;
+    if (M->dist0) {
+        // a hierarchy kept over several solves (same operator key): the caller's CURRENT matrix on the same decomposed space takes
+        // the place of the one attached first - the level-0 pieces (P rows, diagonal) belong to the hierarchy, not to that matrix
+        FS_REQUIRE(sp == M->dist_space && A_local->bs == G->bs && n_owned_nodes == sp->n_nodes_owned,
+                   "fs_amg_attach_distributed_fine: a distributed fine level is attached already, on another space");
+        M->fine = A_local;
+        return FS_OK;
+    }
     FS_REQUIRE(A_local->bs == G->bs && n_owned_nodes == sp->n_nodes_owned, "fs_amg_attach_distributed_fine: %lld owned nodes of block size %d do not match the space (%lld, %d)",
                (long long)n_owned_nodes, A_local->bs, (long long)sp->n_nodes_owned, G->bs);
     hipStream_t s = fs_rt().stream;
@@ -1760,6 +1768,7 @@ extern "C" int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, i
     FS_KERNEL_CHECK();
     FS_HIP(hipStreamSynchronize(s));
     M->dist0 = D;
+    M->dist_space = sp;
     M->fine = A_local;
     // (the CG vectors are sized for the space they multiply with: re-allocated by the next fs_amg_solve)
     M->pr.release(); M->pz.release(); M->pp.release(); M->pw.release();

@@ -630,6 +630,43 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* 
 }
 
 // the same by row gather (lane = row, its cell incidences in ascending order: no atomics, reproducible)
+// SUPG load of a NODAL (Function / Expression) source on CG2:  int S_h (v . grad q_a) dx / |K|  for the P2 interpolant S_h = sum_k S_k psi_k
+// (ScalarTransportSolver.py:213-226 with Tq of :259-276).  grad q_a is linear in the barycentric coordinates - vertex a: (4 lambda_a - 1) g_a,
+// edge ij: 4 (lambda_i g_j + lambda_j g_i) - so all that is needed are the first moments  L_m = int psi_k lambda_m dx / |K|  summed with S_k,
+// exact monomial integrals: tetrahedron - vertex k: 0 (m = k), -1/60; edge ij: 1/15 (m in ij), 1/30;  triangle - vertex k: 1/30 (m = k),
+// -1/60; edge ij: 2/15 (m in ij), 1/15.  vg[m] = v . g_m.  Local dof order: vertices, then the edges ei / ej of the caller.
+template <int NV>
+__device__ __forceinline__ double p2_supg_nodal_load(const double* __restrict__ S, const double* __restrict__ vg, int a,
+                                                     const int* __restrict__ ei, const int* __restrict__ ej) {
+    constexpr int NE = NV == 4 ? 6 : 3;
+    constexpr double V_SAME = NV == 4 ? 0.0 : 1.0 / 30.0, V_OTHER = -1.0 / 60.0;
+    constexpr double E_IN = NV == 4 ? 1.0 / 15.0 : 2.0 / 15.0, E_OUT = NV == 4 ? 1.0 / 30.0 : 1.0 / 15.0;
+    double L[NV], total = 0.0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        double l = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) l += (k == m ? V_SAME : V_OTHER) * S[k];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) l += ((ei[e] == m || ej[e] == m) ? E_IN : E_OUT) * S[NV + e];
+        L[m] = l;
+        total += l;
+    }
+    if (a < NV) {
+        double la = 0.0, va = 0.0;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) if (m == a) { la = L[m]; va = vg[m]; }
+        return va * (4.0 * la - total);
+    }
+    double li = 0.0, lj = 0.0, vi = 0.0, vj = 0.0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        if (m == ei[a - NV]) { li = L[m]; vi = vg[m]; }
+        if (m == ej[a - NV]) { lj = L[m]; vj = vg[m]; }
+    }
+    return 4.0 * (vj * li + vi * lj);
+}
+
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t n_rows, int64_t n_slices,
                                                                         const int64_t* __restrict__ inc_slice_ptr,
                                                                         const int32_t* __restrict__ inc_cell,
@@ -655,9 +692,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source_gather(int64_t 
             const tet_geom t = tet_geometry(xyz4, vv);
             const double vol = t.adet * (1.0 / 6.0);
             if (f.mode == FS_COEF_NODAL) {
-                double m = 0.0;
-                for (int k = 0; k < 10; ++k) m += FS_P2_MASS420[a][k] * f.data[cell_dofs[(int64_t)c * 10 + k]];
+                double m = 0.0, S[10];
+                for (int k = 0; k < 10; ++k) { S[k] = f.data[cell_dofs[(int64_t)c * 10 + k]]; m += FS_P2_MASS420[a][k] * S[k]; }
                 acc += m * vol * (1.0 / 420.0);
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {      // + int S_h tau (v . grad q_a) dx, exactly
+                    double vx, vy, vz;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; vz = sv.tensor[2]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; vz = sv.data[3 * (int64_t)c + 2]; }
+                    const double tau = supg_tau(xyz4, vv, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    const int ei[6] = {2, 1, 1, 0, 0, 0}, ej[6] = {3, 3, 2, 3, 2, 1};
+                    double vg[4];
+                    for (int k = 0; k < 4; ++k) vg[k] = vx * t.g[k][0] + vy * t.g[k][1] + vz * t.g[k][2];
+                    acc += vol * tau * p2_supg_nodal_load<4>(S, vg, a, ei, ej);
+                }
             } else {
                 const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * vol;
                 acc += (a < 4 ? -0.05 : 0.2) * ff;
@@ -1239,6 +1286,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_tri_source(const int32_t*
             const double fe[3] = {f.data[v[0]], f.data[v[1]], f.data[v[2]]};
             const double sum = fe[0] + fe[1] + fe[2];
             for (int a = 0; a < 3; ++a) be[a] = t.area * (1.0 / 12.0) * (sum + fe[a]);
+            if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {     // + int S_h tau (v . grad phi_a) dx = tau (v . g_a) |K| mean(S): exact
+                double vx, vy;
+                if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; }
+                else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; }
+                const double tau = supg_tau_tri(xyz4, v[0], v[1], v[2], t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                for (int a = 0; a < 3; ++a) be[a] += sum * (1.0 / 3.0) * t.area * tau * (vx * t.g[a][0] + vy * t.g[a][1]);
+            }
         } else {
             const double ff = f.mode == FS_COEF_CONST ? f.value : f.data[c];
             for (int a = 0; a < 3; ++a) be[a] = ff * t.area * (1.0 / 3.0);
@@ -1458,9 +1512,19 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2tri_source_gather(int64
             const int4 c4 = reinterpret_cast<const int4*>(cells)[c];
             const tri_geom t = tri_geometry2(xyz4, c4.x, c4.y, c4.z);
             if (f.mode == FS_COEF_NODAL) {
-                double m = 0.0;
-                for (int k = 0; k < 6; ++k) m += FS_P2_TRI_UFC_MASS180[a][k] * f.data[cell_dofs[(int64_t)c * 6 + k]];
+                double m = 0.0, S[6];
+                for (int k = 0; k < 6; ++k) { S[k] = f.data[cell_dofs[(int64_t)c * 6 + k]]; m += FS_P2_TRI_UFC_MASS180[a][k] * S[k]; }
                 acc += m * t.area * (1.0 / 180.0);
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {      // + int S_h tau (v . grad q_a) dx, exactly
+                    double vx, vy;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; }
+                    const double tau = supg_tau_tri(xyz4, c4.x, c4.y, c4.z, t.area, sqrt(vx * vx + vy * vy), supg_pe);
+                    const int ei[3] = {1, 0, 0}, ej[3] = {2, 2, 1};
+                    double vg[3];
+                    for (int k = 0; k < 3; ++k) vg[k] = vx * t.g[k][0] + vy * t.g[k][1];
+                    acc += t.area * tau * p2_supg_nodal_load<3>(S, vg, a, ei, ej);
+                }
             } else {
                 const double ff = (f.mode == FS_COEF_CONST ? f.value : f.data[c]) * t.area;
                 acc += (a < 3 ? 0.0 : 1.0 / 3.0) * ff;
@@ -1706,6 +1770,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_source(const int32_t* 
                 const double m = t.adet * (1.0 / 120.0);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) be[a] = m * (sum + fe[a]);
+                if (supg_pe > 0.0 && sv.mode != FS_COEF_NONE) {     // + int S_h tau (v . grad phi_a) dx = tau (v . g_a) |K| mean(S): exact
+                    double vx, vy, vz;
+                    if (sv.mode == FS_COEF_CONST) { vx = sv.tensor[0]; vy = sv.tensor[1]; vz = sv.tensor[2]; }
+                    else { vx = sv.data[3 * (int64_t)c]; vy = sv.data[3 * (int64_t)c + 1]; vz = sv.data[3 * (int64_t)c + 2]; }
+                    const double tau = supg_tau(xyz4, v, t.adet, sqrt(vx * vx + vy * vy + vz * vz), supg_pe);
+                    const double sw = 0.25 * sum * t.adet * (1.0 / 6.0) * tau;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) be[a] += sw * (vx * t.g[a][0] + vy * t.g[a][1] + vz * t.g[a][2]);
+                }
             } else {
                 const double ff = f.mode == FS_COEF_CONST ? f.value : f.data[c];
                 const double w = ff * t.adet * (1.0 / 24.0);
@@ -3106,8 +3179,8 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         dbuf<double> sstore4;
         coef_dev sv4;
         FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore4, &sv4, "fs_assemble_vector(supg_velocity)"));
-        FS_REQUIRE(!(form->supg_pe > 0.0) || sv4.mode == FS_COEF_NONE || ((sv4.mode == FS_COEF_CONST || sv4.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL),
-                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
+        FS_REQUIRE(!(form->supg_pe > 0.0) || sv4.mode == FS_COEF_NONE || sv4.mode == FS_COEF_CONST || sv4.mode == FS_COEF_CELL,
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell velocities");
         hipLaunchKernelGGL(k_assemble_p2tri_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                            space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
                            m->xyz.p, f, b->d.p, sv4, form->supg_pe);
@@ -3120,8 +3193,8 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         dbuf<double> sstore2;
         coef_dev sv2;
         FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore2, &sv2, "fs_assemble_vector(supg_velocity)"));
-        FS_REQUIRE(!(form->supg_pe > 0.0) || sv2.mode == FS_COEF_NONE || ((sv2.mode == FS_COEF_CONST || sv2.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL),
-                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
+        FS_REQUIRE(!(form->supg_pe > 0.0) || sv2.mode == FS_COEF_NONE || sv2.mode == FS_COEF_CONST || sv2.mode == FS_COEF_CELL,
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell velocities");
         hipLaunchKernelGGL(k_assemble_tri_source, dim3(fs_grid_for(m->nc, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, m->cells.p, m->xyz.p, m->nc, space->n_nodes_owned, f, b->d.p,
                            sv2, form->supg_pe);
         FS_KERNEL_CHECK();
@@ -3148,8 +3221,8 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
         coef_dev sv3;
         FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore3, &sv3, "fs_assemble_vector(supg_velocity)"));
         const bool supg3 = form->supg_pe > 0.0 && sv3.mode != FS_COEF_NONE;
-        FS_REQUIRE(!supg3 || ((sv3.mode == FS_COEF_CONST || sv3.mode == FS_COEF_CELL) && f.mode != FS_COEF_NODAL && space->inc_cell.p),
-                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources and velocities");
+        FS_REQUIRE(!supg3 || ((sv3.mode == FS_COEF_CONST || sv3.mode == FS_COEF_CELL) && space->inc_cell.p),
+                   "fs_assemble_vector: the SUPG source term is built for constant / per-cell velocities");
         if (space->ncomp == 1 && space->inc_cell.p && (supg3 || !getenv("FS_SOURCE_ATOMIC")))
             hipLaunchKernelGGL(k_assemble_p2_source_gather, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,
                                space->n_nodes_owned, space->n_slices, space->inc_slice_ptr.p, space->inc_cell.p, space->cell_dofs, m->cells.p,
@@ -3164,8 +3237,8 @@ extern "C" int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, 
     dbuf<double> sstore;
     coef_dev sv;
     FS_CHECK(make_coef(form->supg_velocity, 3 * m->nc, sstore, &sv, "fs_assemble_vector(supg_velocity)"));
-    FS_REQUIRE(!(form->supg_pe > 0.0) || sv.mode == FS_COEF_NONE || (space->ncomp == 1 && f.mode != FS_COEF_NODAL),
-               "fs_assemble_vector: the SUPG source term is built for constant / per-cell sources on scalar CG1 spaces");
+    FS_REQUIRE(!(form->supg_pe > 0.0) || sv.mode == FS_COEF_NONE || space->ncomp == 1,
+               "fs_assemble_vector: the SUPG source term is built for scalar spaces");
     if (space->ncomp == 1 && space->inc_cell.p && !(form->supg_pe > 0.0 && sv.mode != FS_COEF_NONE) && !getenv("FS_SOURCE_ATOMIC")) {
         // b was zeroed above unless add: the gather kernel adds to what is there either way
         hipLaunchKernelGGL(k_assemble_p1_source_gather<true>, dim3(fs_grid_for(space->n_slices * 64, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s,

@@ -506,7 +506,7 @@ int fs_p2p_check(hipStream_t s) {
     if (e) {
         FS_HIP(hipMemsetAsync(g_p2p_err, 0, sizeof(int), s));
         fs_set_error("peer-to-peer exchange: a neighbour's data did not arrive within FS_P2P_TIMEOUT_MS (peer process gone, or stores over hipIpc mappings not visible on this system) - results of this solve are invalid");
-        return FS_ERR_COMM;
+        return FS_ERR_P2P_TIMEOUT;
     }
     return FS_OK;
 }

@@ -44,6 +44,8 @@ extern "C" {
 #define FS_ERR_UNSUPPORTED (-4)
 #define FS_ERR_COMM (-5)      /* RCCL error */
 #define FS_ERR_NUMERIC (-6)   /* Krylov breakdown (non-SPD operator, NaN) */
+#define FS_ERR_P2P_TIMEOUT (-7) /* a wait of the peer-to-peer halo exchange timed out (FS_P2P_TIMEOUT_MS): the transport failed, not the solve;
+                                 * the host side turns the exchange of the space off on every rank and solves again over RCCL */
 
 typedef struct fs_mesh_s* fs_mesh_t;
 typedef struct fs_space_s* fs_space_t;
@@ -263,7 +265,8 @@ typedef struct fs_linear_form {
     fs_coef source;
     double vector_value[3];
     fs_coef div_coef;
-    fs_coef supg_velocity;   /* with supg_pe > 0: + int source * tau (v . grad q) dx (constant / per-cell sources) */
+    fs_coef supg_velocity;   /* with supg_pe > 0: + int source * tau (v . grad q) dx (constant, per-cell and nodal sources;
+                              * constant / per-cell velocity; nodal: exact for the source's P1 / P2 interpolant) */
     double supg_pe;
 } fs_linear_form;
 int fs_assemble_vector(fs_space_t space, const fs_linear_form* form, fs_vector_t b, int add);
@@ -422,7 +425,9 @@ int fs_amg_setup(fs_matrix_t A, int n_nullspace, const double* nullspace, const 
  * node, in the undecomposed space, of local owned node i.  Afterwards fs_amg_apply / fs_amg_solve smooth, restrict and prolong
  * level 0 on this rank's rows (ghost refresh before every fine product, the restricted right-hand side summed over the ranks)
  * and apply levels >= 1 as they are: the preconditioner - and the iteration count - of one GPU, with the fine-level work
- * divided by the number of ranks.  COLLECTIVE in its use (every rank attaches its part before the first solve). */
+ * divided by the number of ranks.  COLLECTIVE in its use (every rank attaches its part before the first solve).  A second call
+ * on a hierarchy that has its fine level attached swaps in A_local - a matrix on the SAME decomposed space holding the same
+ * operator (a hierarchy kept over several solves multiplies with the caller's current matrix, not the first one). */
 int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, int64_t n_owned_nodes, const int32_t* owned_global_nodes);
 int fs_amg_destroy(fs_amg_t amg);
 int fs_amg_info(fs_amg_t amg, int* n_levels, double* operator_complexity, double* grid_complexity, double* setup_ms);

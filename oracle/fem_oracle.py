@@ -940,14 +940,23 @@ def p1_supg_local(coords, cells, velocity, pe, advection_scale=0.0, mass_coef=0.
     return w[:, :, None] * (advection_scale * vg[:, None, :] * vol[:, None, None] + (0.25 * m * vol)[:, None, None])
 
 
-def assemble_p1_supg_source(coords, cells, velocity, pe, f):
-    """int f tau (v . grad phi_a) dx for a constant / per-cell source f."""
+def assemble_p1_supg_source(coords, cells, velocity, pe, f=None, f_nodal=None):
+    """int f tau (v . grad phi_a) dx for a constant / per-cell source f, or for the P1 interpolant of a source Function given by its
+    vertex values f_nodal (ScalarTransportSolver.py:213-226 with Tq of :259-276) - that one by the 4-point degree-2 rule."""
     detJ, g = p1_geometry(coords, cells)
     vol = np.abs(detJ) / 6.0
     w, _ = supg_weights(coords, cells, velocity, pe)
-    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
+    cells = np.asarray(cells, dtype=np.int64)
+    if f_nodal is not None:
+        fe = np.asarray(f_nodal, dtype=np.float64)[cells]                                          # [nc, 4]
+        a_, b_ = 0.5854101966249685, 0.1381966011250105
+        lam = np.full((4, 4), b_) + (a_ - b_) * np.eye(4)
+        mean = sum(0.25 * (fe @ lam[q]) for q in range(4))                                         # int S_h dx / |K|
+        ff = mean
+    else:
+        ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
     b = np.zeros(len(coords))
-    np.add.at(b, np.asarray(cells, dtype=np.int64).ravel(), (w * (ff * vol)[:, None]).ravel())
+    np.add.at(b, cells.ravel(), (w * (ff * vol)[:, None]).ravel())
     return b
 
 
@@ -1149,12 +1158,19 @@ def tri_supg_local(coords, cells, velocity, pe, advection_scale=0.0, mass_coef=0
     return w[:, :, None] * (advection_scale * vg[:, None, :] * area[:, None, None] + (m * area / 3.0)[:, None, None])
 
 
-def assemble_tri_supg_source(coords, cells, velocity, pe, f):
+def assemble_tri_supg_source(coords, cells, velocity, pe, f=None, f_nodal=None):
+    """2-D counterpart of assemble_p1_supg_source (f_nodal: vertex values of the source Function, 3-point edge-midpoint rule)."""
     area, _ = tri_geometry(coords, cells)
     w, _ = tri_supg_weights(coords, cells, velocity, pe)
-    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(area),))
+    cells = np.asarray(cells, dtype=np.int64)
+    if f_nodal is not None:
+        fe = np.asarray(f_nodal, dtype=np.float64)[cells]
+        lam = 0.5 * (1.0 - np.eye(3))
+        ff = sum((fe @ lam[q]) / 3.0 for q in range(3))
+    else:
+        ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(area),))
     b = np.zeros(len(coords))
-    np.add.at(b, np.asarray(cells, dtype=np.int64).ravel(), (w * (ff * area)[:, None]).ravel())
+    np.add.at(b, cells.ravel(), (w * (ff * area)[:, None]).ravel())
     return b
 
 
@@ -1742,16 +1758,23 @@ def p2_supg_system_local(coords, cells, velocity, pe, stiffness=0.0, advection_s
     return Ke
 
 
-def p2_supg_source_local(coords, cells, velocity, pe, f):
-    """be[a] = int f Tq_a dx for a constant / per-cell source f."""
+def p2_supg_source_local(coords, cells, velocity, pe, f=None, f_nodal=None, cell_dofs=None):
+    """be[a] = int f Tq_a dx for a constant / per-cell source f, or - f_nodal [n_dofs] with cell_dofs [nc, nd] - for the source
+    Function's CG2 interpolant  S_h = sum_k S_k phi_k  (ScalarTransportSolver.py:213-226: get_body_source_items returns whatever
+    translate_value made of settings['body_source'], :259-276: it is multiplied by Tq like every other term).  By quadrature
+    (degree 4 / 5: the integrand S_h (v . grad q_a) is cubic), independently of the kernels' closed-form moments."""
     cells, size, g, pts, wq, shape, edges = _p2_simplex_tools(coords, cells)
     tau, v = p2_supg_tau(coords, cells, velocity, pe)
-    ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
     be = np.zeros((len(cells), cells.shape[1] + len(edges)))
+    if f_nodal is not None:
+        Sk = np.asarray(f_nodal, dtype=np.float64)[np.asarray(cell_dofs, dtype=np.int64)]          # [nc, nd]
+    else:
+        ff = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(cells),))
     for lam, w in zip(pts, wq):
         phi, dphi = shape(np.asarray(lam))
         vg = np.einsum("ci,cai->ca", v, np.einsum("ak,cki->cai", dphi, g))
-        be += (w * size * ff)[:, None] * (phi[None, :] + tau[:, None] * vg)
+        fq = Sk @ phi if f_nodal is not None else ff
+        be += (w * size * fq)[:, None] * (phi[None, :] + tau[:, None] * vg)
     return be
 
 

@@ -316,6 +316,28 @@ for name, transient, body in (("navier_stokes_2d_steady", False, None), ("navier
         import traceback
         out[name] = {"reference_raises": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc().strip().splitlines()[-3].strip()}
 
+# (last, so that the auto-numbered symbols of the cases above keep their names)
+# non-Newtonian material WITH the coupled temperature: nu (1 + 0.1 p / p_ref)(1 - 0.2 T / T_ref) (CoupledNavierStokesSolver.py:199-203),
+# with a pressure outlet so that the viscosity of the boundary term (:401) is recorded as well
+st = ns_settings(False)
+st['solving_temperature'] = True
+st['material'] = {'density': 2.0, 'kinematic_viscosity': 0.01, 'specific_heat_capacity': 3.0, 'thermal_conductivity': 0.1, 'Newtonian': False}
+st['initial_values'] = {'velocity': (0, 0, 0), 'pressure': 1.0e5, 'temperature': 320}
+st['solver_settings']['reference_values'] = {'velocity': (1, 1, 1), 'pressure': 1.0e5, 'temperature': 300}
+st['boundary_conditions']['walls']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(350)})
+st['boundary_conditions']['lid']['values'].append({'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(300)})
+st['boundary_conditions']["outlet"] = {'boundary': AutoSubDomain(lambda x, on_boundary: on_boundary), 'boundary_id': 3,
+                                       'values': [{'variable': "pressure", 'type': 'Dirichlet', 'value': Constant(1.0e5)},
+                                                  # (the reference's thermal form reads bc['type'] of EVERY boundary: one without a
+                                                  # temperature entry is a KeyError there, ScalarTransportSolver.py:169)
+                                                  {'variable': 'temperature', 'type': 'Dirichlet', 'value': Constant(330)}]}
+try:
+    run("navier_stokes_non_newtonian_temperature", CoupledNavierStokesSolver.CoupledNavierStokesSolver(st))
+except Exception as e:
+    import traceback
+    out["navier_stokes_non_newtonian_temperature"] = {"reference_raises": "%s: %s" % (type(e).__name__, e),
+                                                      "where": traceback.format_exc().strip().splitlines()[-3].strip()}
+
 path = os.path.join(HERE, "reference_forms.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

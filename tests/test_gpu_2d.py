@@ -815,6 +815,17 @@ def test_p2_triangle_supg_kernels_match_oracle(gpu):
         gpu.assemble_vector(V, b, source=7.0, supg=(vel, 5.0))
         refb = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 5.0, 7.0))
         assert np.abs(b.get() - refb).max() <= 1e-13 * np.abs(refb).max() * 10
+        # nodal sources (round 5): a Function on the CG2 space, and - on the CG1 space of the same mesh - its vertex values
+        fn = rng.uniform(1.0, 3.0, n)
+        gpu.assemble_vector(V, b, source=("nodal", fn), supg=(vel, 5.0))
+        refn = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 5.0, f_nodal=fn, cell_dofs=cd))
+        assert np.abs(b.get() - refn).max() <= 1e-12 * np.abs(refn).max()
+        V1 = gpu.DeviceSpace(V.mesh, 1)
+        b1 = gpu.DeviceVector(V1.n_owned)
+        gpu.assemble_vector(V1, b1, source=("nodal", fn[:len(co)]), supg=(vel, 5.0))
+        ref1 = fo.assemble_tri_source(co, ce, f_nodal=fn[:len(co)]) + fo.assemble_tri_supg_source(co, ce, vel, 5.0, f_nodal=fn[:len(co)])
+        assert np.abs(b1.get() - ref1).max() <= 1e-12 * np.abs(ref1).max()
+        assert np.abs(fo.assemble_tri_supg_source(co, ce, vel, 5.0, f_nodal=fn[:len(co)])).max() > 1e-4 * np.abs(ref1).max()
         _, cell_edges, cnt = fo.tri_edge_numbering(ce)
         fc = np.array([(c, o) for c in range(len(ce)) for o in range(3) if cnt[cell_edges[c, o]] == 1]).reshape(-1, 2)
         A.assemble(stiffness=0.7)

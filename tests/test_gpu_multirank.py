@@ -37,8 +37,8 @@ def _run(world, case, tmp_path, **extra_env):
                                               (2, "default"), (3, "default"), (2, "p2p_breaks_mid_run"), (3, "p2p_breaks_mid_run")])
 def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, recurrence):
     """Both CG recurrences and both transports on several ranks: same solution as one GPU <= 1e-9, iteration count within +2.
-    Default since round 4: the single-reduction recurrence over the peer-to-peer exchange (set up and self-tested when the halo
-    plan is set); a transport that breaks in the middle of a run - every wait from the sixth receive on times out - is left by
+    Default: the single-reduction recurrence over RCCL (round 5: the peer-to-peer exchange is opt-in, FS_HALO_P2P=auto / 1, set up
+    and self-tested when the halo plan is set); a transport that breaks in the middle of a run - every wait from the sixth receive on times out - is left by
     all ranks together and the solve repeated over RCCL (backend._with_p2p_fallback): same field."""
     nx, ny, nz, axis = 9, 7, 23, 0
     co, ce = fo.box_mesh((0, 0, 0), (1.0, 0.8, 2.0), nx, ny, nz)
@@ -55,7 +55,7 @@ def test_box_slabs_over_ranks_equal_the_single_gpu_solve(gpu, tmp_path, world, r
     st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
     env = {"single_reduction": dict(FS_CG_PIPELINED="0", FS_HALO_P2P="0"), "pipelined": dict(FS_CG_PIPELINED="1", FS_HALO_P2P="0"),
            "pipelined_no_early_halo": dict(FS_CG_PIPELINED="1", FS_HALO_P2P="0", FS_HALO_EARLY="0"),
-           "default": {}, "p2p_breaks_mid_run": dict(FS_P2P_TEST="late:6", FS_P2P_TIMEOUT_MS="100"),
+           "default": {}, "p2p_breaks_mid_run": dict(FS_HALO_P2P="auto", FS_P2P_TEST="late:6", FS_P2P_TIMEOUT_MS="100"),
            # ghost refresh by stores into the neighbour PROCESS's memory (hipIpc) instead of send / recv: real on one GPU too
            "pipelined_p2p": dict(FS_HALO_P2P="1", FS_CG_PIPELINED="1"), "single_reduction_p2p": dict(FS_HALO_P2P="1"),
            # FS_P2P_FUSE: 0 = the separate send / receive / all-reduce kernels around a split product, 6 = the fused iteration with
@@ -88,8 +88,8 @@ def test_one_launch_iteration_on_a_decomposed_space(gpu, tmp_path, world, mode):
                       np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
     st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
     assert st["row_classes"] > 0 and st["iterations"] > 64
-    env = {"default": {}, "two_launch_kernels": dict(FS_CG_FUSED_P2P="0"),
-           "breaks_mid_run": dict(FS_P2P_TEST="late:6", FS_P2P_TIMEOUT_MS="100")}[mode]
+    env = {"default": dict(FS_HALO_P2P="auto"), "two_launch_kernels": dict(FS_HALO_P2P="auto", FS_CG_FUSED_P2P="0"),
+           "breaks_mid_run": dict(FS_HALO_P2P="auto", FS_P2P_TEST="late:6", FS_P2P_TIMEOUT_MS="100")}[mode]
     r = _run(world, "box", tmp_path, FS_TEST_BOX="%d,%d,%d,%d" % (nx, ny, nz, axis), **env)
     assert int(r["converged"]) == 1 and float(r["true_res"]) <= 2e-10 and float(r["true_res2"]) <= 2e-10
     assert abs(int(r["iterations"]) - st["iterations"]) <= 2

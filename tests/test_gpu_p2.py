@@ -244,6 +244,12 @@ def test_p2_advection_kernel_and_solver_class(gpu, data_dir):
             gpu.assemble_vector(V, b, source=("cell", fc), supg=(vel, 2.0))
             refb = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 2.0, fc))
             assert np.abs(b.get() - refb).max() <= 1e-12 * np.abs(refb).max()
+            # a NODAL source (a Function on the CG2 space): closed-form first moments in the kernel, degree-5 quadrature in the oracle
+            fn = rng.uniform(1.0, 3.0, n)
+            gpu.assemble_vector(V, b, source=("nodal", fn), supg=(vel, 2.0))
+            refn = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 2.0, f_nodal=fn, cell_dofs=cd))
+            plainn = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, 1e-300, f_nodal=fn, cell_dofs=cd))
+            assert np.abs(b.get() - refn).max() <= 1e-12 * np.abs(refn).max() and np.abs(refn - plainn).max() > 1e-3 * np.abs(refn).max()
             # ds terms: the cells behind the boundary facets (cell, opposite vertex)
             from oracle import ns_oracle as nso
             fcells = np.array(nso.boundary_facet_cells(nso.TaylorHood(co, ce), lambda x: True)).reshape(-1, 2)[::3]
@@ -392,11 +398,12 @@ def test_p2_temperature_dependent_conductivity(gpu):
     assert np.abs(T - lin).max() > 0.1                                     # the nonlinearity matters
 
 
-@pytest.mark.parametrize("transient", [False, True])
-def test_p2_supg_stabilised_convection_matches_oracle(gpu, transient):
+@pytest.mark.parametrize("transient,source", [(False, "constant"), (True, "constant"), (False, "field")])
+def test_p2_supg_stabilised_convection_matches_oracle(gpu, transient, source):
     """advection_settings 'SPUG' with fe_degree 2 (ScalarTransportSolver.py:259-270 is degree-agnostic; round 4): every test function
-    is q + tau (v . grad q) - diffusion (with the Hessian of q), advection, capacity, body source, HTC and flux boundary terms."""
-    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, near
+    is q + tau (v . grad q) - diffusion (with the Hessian of q), advection, capacity, body source, HTC and flux boundary terms.
+    source = field (round 5): an Expression body source, i.e. its CG2 interpolant times Tq (ScalarTransportSolver.py:213-226, 259-276)."""
+    from fenicssolver_amd.fem import UnitCubeMesh, FunctionSpace, AutoSubDomain, Constant, Expression, near
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     from oracle import ns_oracle as nso
     vel, pe, rho_cp, k = (0.8, -0.5, 0.3), 5.0, 2.0 * 3.0, 0.6
@@ -407,7 +414,8 @@ def test_p2_supg_stabilised_convection_matches_oracle(gpu, transient):
     bcs["cold"] = {'boundary': AutoSubDomain(lambda x: near(x[1], 0.0)), 'boundary_id': 2, 'type': 'HTC', 'value': Constant(100), 'ambient': Constant(300)}
     bcs["side"] = {'boundary': AutoSubDomain(lambda x: near(x[0], 1.0)), 'boundary_id': 3, 'type': 'heatFlux', 'value': Constant(36.0)}
     st = {'solver_name': 'x', 'mesh': None, 'function_space': Q, 'periodic_boundary': None, 'boundary_conditions': bcs,
-          'body_source': 7.0, 'initial_values': {'temperature': 300}, 'convective_velocity': Constant(vel),
+          'body_source': 7.0 if source == "constant" else Expression("7.0 + 30.0*x[0] - 20.0*x[1]*x[2]", degree=2),
+          'initial_values': {'temperature': 300}, 'convective_velocity': Constant(vel),
           'advection_settings': {'stabilization_method': 'SPUG', 'Pe': pe},
           'material': {'density': 2.0, 'specific_heat_capacity': 3.0, 'thermal_conductivity': k},
           'solver_settings': {'transient_settings': {'transient': transient, 'starting_time': 0, 'time_step': 0.1, 'ending_time': 0.3},
@@ -437,9 +445,13 @@ def test_p2_supg_stabilised_convection_matches_oracle(gpu, transient):
     R = fo.assemble_p2_facet_mass(co, edges, facets, fm, 2, 100.0)
     dA2, db2 = fo.p2_supg_facet_terms(co, ce, cdl, n, marked_cells(2), vel, pe, g=100.0 * 300.0, h=100.0)
     _, db3 = fo.p2_supg_facet_terms(co, ce, cdl, n, marked_cells(3), vel, pe, g=36.0)
-    load = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, pe, 7.0)) \
-        + facet_load(3, 36.0) + facet_load(2, 100.0 * 300.0) + db2 + db3
     X = Q.node_coordinates()
+    if source == "constant":
+        src = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, pe, 7.0))
+    else:
+        fn = 7.0 + 30.0 * X[:, 0] - 20.0 * X[:, 1] * X[:, 2]
+        src = fo.assemble_generic_vector(n, cd, fo.p2_supg_source_local(co, ce, vel, pe, f_nodal=fn, cell_dofs=cd))
+    load = src + facet_load(3, 36.0) + facet_load(2, 100.0 * 300.0) + db2 + db3
     top = np.nonzero(X[:, 1] == 1.0)[0]
     A = (A_op + R + dA2).tocsr()
     if not transient:

@@ -488,15 +488,17 @@ def test_point_sources(gpu):
     assert np.all(np.isfinite(T2)) and T2.max() > 360.0      # heated above the hot wall near the source
 
 
-@pytest.mark.parametrize("transient", [False, True])
-def test_supg_stabilised_convection_matches_oracle(gpu, transient):
+@pytest.mark.parametrize("transient,source", [(False, "constant"), (True, "constant"), (False, "field"), (True, "field")])
+def test_supg_stabilised_convection_matches_oracle(gpu, transient, source):
     """advection_settings = {'stabilization_method': 'SPUG', 'Pe': ...} (ScalarTransportSolver.py:259-270): every
-    test function is q + tau (v . grad q) - volume, source and boundary terms alike."""
-    from fenicssolver_amd.fem import Constant
+    test function is q + tau (v . grad q) - volume, source and boundary terms alike.  source = field (round 5): the body source is
+    an Expression - whatever get_body_source_items returns is multiplied by Tq (:213-226, 259-276) - i.e. its P1 interpolant."""
+    from fenicssolver_amd.fem import Constant, Expression
     from fenicssolver_amd.ScalarTransportSolver import ScalarTransportSolver
     from oracle import ns_oracle as nso
     vel, pe, rho_cp, k = (0.8, -0.5, 0.3), 5.0, 2.0 * 3.0, 0.6
-    s, m = _box_heat_settings(4, transient=transient, body_source=7.0)
+    body = 7.0 if source == "constant" else Expression("7.0 + 30.0*x[0] - 20.0*x[1]*x[2]", degree=1)
+    s, m = _box_heat_settings(4, transient=transient, body_source=body)
     s['material'] = {'density': 2.0, 'specific_heat_capacity': 3.0, 'thermal_conductivity': k}
     s['convective_velocity'] = Constant(vel)
     s['advection_settings'] = {'stabilization_method': 'SPUG', 'Pe': pe}
@@ -525,7 +527,13 @@ def test_supg_stabilised_convection_matches_oracle(gpu, transient):
     R = fo.assemble_p1_facet_mass(co, facets, fm, 2, 100.0)
     dA2, db2 = fo.supg_facet_terms(co, ce, marked_cells(2), vel, pe, g=100.0 * 300.0, h=100.0)
     _, db3 = fo.supg_facet_terms(co, ce, marked_cells(3), vel, pe, g=36.0)
-    load = fo.assemble_p1_source(co, ce, 7.0) + fo.assemble_p1_supg_source(co, ce, vel, pe, 7.0) \
+    if source == "constant":
+        src = fo.assemble_p1_source(co, ce, 7.0) + fo.assemble_p1_supg_source(co, ce, vel, pe, 7.0)
+    else:
+        fn = 7.0 + 30.0 * co[:, 0] - 20.0 * co[:, 1] * co[:, 2]
+        src = fo.assemble_p1_source(co, ce, f_nodal=fn) + fo.assemble_p1_supg_source(co, ce, vel, pe, f_nodal=fn)
+        assert np.abs(fo.assemble_p1_supg_source(co, ce, vel, pe, f_nodal=fn)).max() > 1e-4 * np.abs(src).max()     # not a no-op
+    load = src \
         + fo.assemble_p1_facet_load(co, facets, fm, 3, 36.0) + fo.assemble_p1_facet_load(co, facets, fm, 2, 100.0 * 300.0) + db2 + db3
     top = np.nonzero(co[:, 1] == 1.0)[0]
     if not transient:
@@ -546,7 +554,7 @@ def test_supg_stabilised_convection_matches_oracle(gpu, transient):
             t += dt
     assert np.abs(T - ref).max() <= 1e-8 * np.abs(ref).max()
     # the stabilisation changes the answer (it is not a no-op at this Peclet number)
-    s2, _ = _box_heat_settings(4, transient=transient, body_source=7.0)
+    s2, _ = _box_heat_settings(4, transient=transient, body_source=body)
     s2['material'] = dict(s['material'])
     s2['convective_velocity'] = Constant(vel)
     s2['boundary_conditions'] = s['boundary_conditions']
