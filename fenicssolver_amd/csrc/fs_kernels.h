@@ -35,6 +35,8 @@ __device__ __forceinline__ chunk_iter xcd_chunks(int64_t n_chunks) {
 //           workgroup's stores were acknowledged before it counted;
 //   reader: spins on the sequence number with system-scope loads, then reads the data with system-scope loads (the buffers are
 //           fine-grained allocations: nothing of them is held in a cache).
+// a word of pinned host memory the host polls (progress / status of a batch of launches): relaxed, system scope, no fence
+__device__ __forceinline__ void fs_host_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void fs_p2p_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double fs_p2p_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void fs_p2p_stores_done() {

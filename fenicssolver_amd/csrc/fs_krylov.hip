@@ -17,6 +17,7 @@
 // flight, so the stream never drains.
 #include "fs_common.h"
 #include "fs_kernels.h"
+#include <functional>
 #include <chrono>
 #include <string>
 #include <unordered_map>
@@ -436,10 +437,15 @@ __device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ 
 // One row's stored entries (DIA slice storage: value plane k, offset list of the row's piece of its slice), nonzero values only:
 // f(position, value), position = slot * nq + q for component q of an entry's nq = bs * bs values (block entry e, component q at
 // q * plane + e).  Returns false when an entry has no position in the plan.
+// sc (scalar operators only; may be null): the row is walked as D^-1/2 A D^-1/2 - every stored value v at column r + o becomes
+// (v sc[r]) sc[r + o], the expression and the bits of k_scale_copy - so that a matrix can be compared with the kept class table of
+// its scaled form WITHOUT writing the scaled copy first (the copy is 300 MB of traffic at 1 M rows, and on the row-dictionary path
+// nobody reads it).
 template <typename F>
 __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
                                               const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane,
-                                              const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f) {
+                                              const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f,
+                                              const double* __restrict__ sc = nullptr) {
     const int32_t sl = r >> 6, ln = r & 63;
     const int64_t base = slice_ptr[sl];
     const int width = (int)((slice_ptr[sl + 1] - base) >> 6);
@@ -467,6 +473,14 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
                 o[u] = op[k];
                 v[u] = vp[(int64_t)k * FS_SLICE];
             }
+            if (sc) {
+                const double sr = sc[r];
+                double scol[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) scol[u] = sc[v[u] != 0.0 ? r + o[u] : r];       // (a padded position has no column)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = v[u] * sr * scol[u];
+            }
             int slot[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -488,8 +502,9 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
     for (int k = 0; k < width && ok; ++k) {
         int slot = -2;          // not looked up yet
         for (int q = 0; q < nq; ++q) {
-            const double v = vp[(int64_t)k * FS_SLICE + (int64_t)q * plane];
+            double v = vp[(int64_t)k * FS_SLICE + (int64_t)q * plane];
             if (v == 0.0) continue;
+            if (sc) v = v * sc[r] * sc[r + op[k]];
             if (slot == -2) slot = dict_slot_of(pl, n_runs, RL, g, op[k]);
             if (slot < 0) { ok = false; break; }
             f(slot * nq + q, v);
@@ -607,7 +622,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
                                                           const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
                                                           const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
                                                           const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
-                                                          uint16_t* __restrict__ cls, int* info) {
+                                                          uint16_t* __restrict__ cls, int* info, const double* __restrict__ sc = nullptr) {
     const int lane = threadIdx.x & 63;
     int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -631,7 +646,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
             const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) {
                 ++nz;
                 diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
-            });
+            }, sc);
             bad += !fits || diff != 0 || nz != nnz[id];
         }
         // distinct classes among the item's rows (what its wave will have to hold in LDS)
@@ -1532,7 +1547,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
                                                            const double* __restrict__ part_in, double* __restrict__ part_out, int npart,
                                                            const double* __restrict__ ctrl, double* __restrict__ scal, int* __restrict__ status,
                                                            int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd,
-                                                           const double* __restrict__ sums) {
+                                                           const double* __restrict__ sums, int* __restrict__ mirror) {
+    // mirror (may be null): two words of PINNED HOST memory - [0] the status word once the recurrence has stopped, [1] the number of
+    // the iteration this launch is working on - written by one lane with relaxed system-scope stores (no fence: nothing is ordered
+    // against them).  The host enqueues the next launches from what it reads there (fs_krylov_solve) instead of copying the status
+    // word back behind every batch, and stops within a few launches of the end instead of a batch and a half after it.
     FS_STAMP(0);
     // The launch is latency-bound at the sizes it is used for (a wave has two work items at 1 M rows), and what it reads first was
     // written by the previous launch on other XCDs - every dependent load is a round trip to the Infinity Cache (1 - 2 us).  So
@@ -1646,23 +1665,21 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64
     const double gamma = sm[0], delta = sm[1], rho = sm[2];
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     if (leader) hist[iter] = rho;
-    if (rho <= thresh) {                        // every workgroup takes the same branch: the inputs are identical
-        if (leader) { status[1] = iter; status[0] = 1; }
-        return;
-    }
-    if (iter >= (int)it_max) {
-        if (leader) { status[1] = iter; status[0] = 3; }
-        return;
-    }
+    auto stop = [&](int code) {
+        if (leader) {
+            status[1] = iter; status[0] = code;
+            if (mirror) { fs_host_store(mirror + 1, iter); fs_host_store(mirror, code); }
+        }
+    };
+    if (rho <= thresh) { stop(1); return; }     // every workgroup takes the same branch: the inputs are identical
+    if (iter >= (int)it_max) { stop(3); return; }
     double beta, alpha;
-    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
+    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) { stop(2); return; }
     if (leader) {
         scal[2 * (iter & 1) + 0] = gamma;
         scal[2 * (iter & 1) + 1] = alpha;
         it_ctr[par ^ 1] = iter + 1;
+        if (mirror) fs_host_store(mirror + 1, iter + 1);
     }
     const double nalpha = -alpha;
     FS_STAMP(4);
@@ -2217,6 +2234,10 @@ static int g_spmv_unroll = 4;
 static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 static int g_cg_batch = 32;
+// one-launch iteration on one GPU: launches go out g_cg_sub at a time (one hipGraph) whenever the device - its progress is read from
+// pinned memory the kernel writes (krylov_ws::h_mirror) - has fewer than g_cg_ahead of them left to do; g_cg_mirror = 0: the batches
+// of g_cg_batch with the status word copied back behind each (round 4)
+static int g_cg_sub = 16, g_cg_ahead = 6, g_cg_mirror = 1;      // (tools/probes/cg_tail_probe.py: 6.80 -> 6.44 ms per solve at 1 M rows)
 static int g_cg_fuse_sums = 1;
 static int g_cg_graph = -1;      // -1: automatic (graphs, unless a profiler's tool library is in the process)
 static int g_update_blocks = 1024;  // (round 3, with the 16 us row-dictionary product at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 10.59 / 10.42 / 10.20 / 10.12 / 11.22 ms per step; 10 M rows: flat)
@@ -2249,6 +2270,14 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_row_dictionary = value != 0.0;
     } else if (!strcmp(name, "box_snap")) {
         fs_set_box_snap(value != 0.0);
+    } else if (!strcmp(name, "cg_sub")) {
+        FS_REQUIRE(value >= 2 && value <= 256 && ((int)value & 1) == 0, "cg_sub must be an even number in [2,256]");
+        g_cg_sub = (int)value;
+    } else if (!strcmp(name, "cg_ahead")) {
+        FS_REQUIRE(value >= 1 && value <= 4096, "cg_ahead must be in [1,4096]");
+        g_cg_ahead = (int)value;
+    } else if (!strcmp(name, "cg_mirror")) {
+        g_cg_mirror = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "cg_batch")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
         g_cg_batch = (int)value;
@@ -2597,7 +2626,11 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
 
 // Try to describe `val` (the scalar DIA matrix the solver is about to multiply with) by row classes; leaves g_dict.built_for =
 // val on success, nullptr otherwise.  One host synchronisation (16 bytes).  FS_SPMV_DICT=0 switches it off.
-static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
+// raw, sc (scalar operators, one GPU; may be null): val = D^-1/2 raw D^-1/2 has NOT been written yet.  The comparison with the kept
+// class table then walks raw and scales on the fly; only if that fails - or no table is kept - `materialize` writes val (k_scale_copy)
+// before anything reads it.  On the kept path val stays unwritten: it is the KEY of the permission (built_for), and every product of
+// the solve goes through the dictionary kernels (launch_spmv: whole-space launches of a space without a halo plan).
+static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, const double* raw, const double* sc, const std::function<void()>& materialize) {
     row_dict& D = g_dict;
     D.built_for = nullptr;
     fs_space_s* sp = A->space;
@@ -2643,7 +2676,8 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
         else {
             FS_CHECK(D.info.zero(s));
             hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                               val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
+                               raw ? raw : val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p,
+                               raw ? sc : nullptr);
             FS_KERNEL_CHECK();
             int h[4] = {0, 0, 0, 0};
             FS_CHECK(D.info.download(h, 4, s));
@@ -2663,6 +2697,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
         }
     }
     D.tables_space = 0;
+    materialize();                  // the classes are found from the scaled values themselves
     FS_CHECK(D.keys.zero(s));
     FS_CHECK(D.info.zero(s));
     FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
@@ -2691,6 +2726,18 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s) {
     D.tables_ncls = h[0];
     ++D.n_built;
     return FS_OK;
+}
+
+static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s, const double* raw = nullptr, const double* sc = nullptr,
+                      const std::function<void()>& scale_copy = nullptr) {
+    bool copied = raw == nullptr;
+    const auto materialize = [&]() {
+        if (!copied) { scale_copy(); copied = true; }
+    };
+    const int rc = dict_build_impl(A, val, s, raw, sc, materialize);
+    // every outcome but `the kept table describes this matrix` reads val: the streaming kernels, or a table just built from it
+    if (!(g_dict.built_for == val && g_dict.kept)) materialize();
+    return rc;
 }
 
 // `list` / `n_list`: multiply only these slices (the interior or the boundary slices of a decomposed space, in
@@ -3053,6 +3100,9 @@ struct krylov_ws {
     int64_t bicg_n = -1;
     dbuf<int> status;
     int* h_status = nullptr;  // pinned: 2 x 4 status ints (double-buffered polls) + [8] zero-diagonal count
+    int* h_mirror = nullptr;  // pinned, written by the iteration kernel's leader lane: [0] status once stopped, [1] iteration in progress
+    int* d_mirror = nullptr;  // ... its device address
+    bool mirror_ok = true;    // false once a wait on it timed out (stores not visible on this system): the copied status word again
     double* h_vals = nullptr; // pinned: the sums [0 .. 8) and the control block [8 .. 12) at the end of a pass
     hipEvent_t poll[2] = {nullptr, nullptr};
     static const int NSAMPLE = 64;
@@ -3100,6 +3150,11 @@ static int ws_prepare(krylov_ws& ws, int64_t n, int64_t nl, int max_iter) {
         FS_CHECK(ws.d_err.alloc(1));
         FS_HIP(hipHostMalloc((void**)&ws.h_status, 16 * sizeof(int), hipHostMallocDefault));     // ([12 .. 16): the status word at the end of a pass)
         FS_HIP(hipHostMalloc((void**)&ws.h_vals, 16 * sizeof(double), hipHostMallocDefault));
+        if (hipHostMalloc((void**)&ws.h_mirror, 16 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&ws.d_mirror, ws.h_mirror, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            ws.h_mirror = ws.d_mirror = nullptr;
+        }
         FS_HIP(hipEventCreateWithFlags(&ws.poll[0], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.poll[1], hipEventDisableTiming));
         FS_HIP(hipEventCreateWithFlags(&ws.ev_upd, hipEventDisableTiming));
@@ -3218,17 +3273,26 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         FS_HIP(hipMemcpyAsync(sc_local, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
         FS_CHECK(fs_halo_exchange_dev(sp, sc_local, s));
         const int g2 = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
+        const auto scale_copy1 = [&]() {
+            hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
+        };
+        // scalar operator on one GPU: the scaled copy is written only if somebody is going to read it - a matrix that the kept class
+        // table describes (verified on the fly-scaled values, dict_build) is multiplied from the table alone
+        static const bool lazy_env = !(getenv("FS_LAZY_SCALE_COPY") && getenv("FS_LAZY_SCALE_COPY")[0] == '0');
+        const bool lazy_copy = bs == 1 && !sp->halo.active && lazy_env;
         if (bs == 2)
             hipLaunchKernelGGL(k_scale_copy<2>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
-        else if (bs == 1)
-            hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
-        else
+        else if (bs == 1) {
+            if (!lazy_copy) scale_copy1();
+        } else
             hipLaunchKernelGGL(k_scale_copy<3>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
         hipLaunchKernelGGL(k_pointwise_mul, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, ws.dinv.p, b->d.p, n, ws.bhat.p);
         FS_KERNEL_CHECK();
         aval = ws.aval.p;
         if (bs == 1) {
-            FS_CHECK(dict_build(A, aval, s));       // a handful of distinct rows (uniform box, constant coefficient)?
+            // a handful of distinct rows (uniform box, constant coefficient)?
+            if (lazy_copy) FS_CHECK(dict_build(A, aval, s, A->val.p, sc_local, scale_copy1));
+            else FS_CHECK(dict_build(A, aval, s));
             sgrid = spmv_partials(sp, bs);          // (the row-dictionary product has its own launch geometry)
         }
     }
@@ -3269,7 +3333,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     static const int sample_every = getenv("FS_CG_SAMPLE_EVERY") ? std::max(1, atoi(getenv("FS_CG_SAMPLE_EVERY"))) : 16;
     static const char* upd_nt_env = getenv("FS_UPDATE_NT");
     const bool upd_nt = upd_nt_env ? upd_nt_env[0] == '1' : (int64_t)sp->n_dofs_owned * 72 > ((int64_t)192 << 20);   // five vectors exceed the caches
-    int total_iters = 0, n_samples = 0, n_pass = 0;
+    int total_iters = 0, n_samples = 0, n_pass = 0, n_launches = 0;
     bool fusedp_used = false;
     int h_status[4] = {0, 0, 0, 0};
     bool use_guess = opts->nonzero_guess != 0;
@@ -3426,8 +3490,37 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         if (fusedp) fusedp_used = true;
         const bool use_graph = ds && !bicg && !pipelined && graph_sized && !fused && !fusedp &&
                                ((fuse_sums && !sp->halo.active && bs == 1) || p2p_fuse);
+        // One-launch iteration on one GPU: the host follows the device through two words of pinned memory the kernel's leader lane
+        // writes (iteration in progress, status once stopped) and keeps between cg_ahead and cg_ahead + cg_sub launches enqueued.
+        // With batches of 32 and the status word copied back behind each, a solve of 293 iterations enqueued 352 launches - the
+        // 59 that returned on the status word cost 5.3 us each, 0.31 of a 6.8 ms solve - and ten in-stream copies.
+        static const int mirror_env = getenv("FS_CG_MIRROR") ? atoi(getenv("FS_CG_MIRROR")) : -1;
+        bool mirrored = fused && !fusedp && ws.d_mirror && ws.mirror_ok && (mirror_env >= 0 ? mirror_env != 0 : g_cg_mirror != 0);
+        int* const mirror_dev = mirrored ? ws.d_mirror : nullptr;
+        volatile int* const hm = ws.h_mirror;
+        if (mirrored) { hm[0] = 0; hm[1] = 0; }
+        const int bsz = mirrored ? g_cg_sub : batch;
+        int seen = 0;
+        auto t_seen = std::chrono::steady_clock::now();
         while (!finished) {
-            const int kend = (k + batch < max_iter + 1) ? k + batch : max_iter + 1;
+            if (mirrored && k > 0) {
+                if (hm[0] != 0) break;                  // the recurrence has stopped: what is enqueued returns on the status word
+                const int done = hm[1];
+                if (k - done > g_cg_ahead) {            // enough enqueued: wait for the device to get on
+                    if (done != seen) { seen = done; t_seen = std::chrono::steady_clock::now(); }
+                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_seen).count() > 2.0) {
+                        // no progress seen for two seconds: the kernel's stores do not reach this host memory while it runs.  The
+                        // copied status word from here on, for the rest of the process.
+                        FS_HIP(hipStreamSynchronize(s));
+                        ws.mirror_ok = false;
+                        mirrored = false;
+                        fprintf(stderr, "[libfsamd] CG progress words in pinned memory not updated by the device: polling the status word by copies\n");
+                    }
+                    continue;
+                }
+            }
+            const int kend = (k + bsz < max_iter + 1) ? k + bsz : max_iter + 1;
+            const int k_before = k;
             if (fused || fusedp) {
                 // launch k = update k + product k + 1; buffers [k & 1] are read, [(k + 1) & 1] written.  Decomposed space (fusedp):
                 // the exchange kernel goes first - it reduces the sums of the previous launch's partials over the ranks, stores the
@@ -3451,7 +3544,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
 #define FS_ITER_ARGS dim3(igrid), dim3(FS_BLOCK), lds, s, sp->n_nodes_local, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
                      reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.ncls, \
                      Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], igrid, \
-                     ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd(), ws.sums.p
+                     ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd(), ws.sums.p, mirror_dev
                     if (fusedp) {
                         launch_exchange(par);
                         hipLaunchKernelGGL((k_dict_cg_iter<3, true>), FS_ITER_ARGS);
@@ -3467,19 +3560,19 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                     launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
                 }
-                if (graph_sized && k >= batch && kend - k == batch && kend <= max_iter && (batch & 1) == 0 && (k & 1) == 0) {
+                if (graph_sized && k >= batch && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
                                            ws.ctrl.p, ws.scal.p, snd2[0].own_recv, red2[0].own_buf,
                                            fusedp ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation + 1) : nullptr};
-                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (fusedp ? 1 : 0), batch, igrid,
+                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (fusedp ? 1 : 0) + (mirror_dev ? 2 : 0), bsz, igrid,
                                               (int64_t)dict_map_xcd() + 16 * (int64_t)p2p_rows_cap,
                                               (int64_t)sp->n_dict_items, (int64_t)A->serial, (int64_t)sp->serial};
                     if (!ws.cgf_graph || memcmp(key, ws.cgf_key, sizeof(key)) || memcmp(key_i, ws.cgf_key_i, sizeof(key_i))) {
                         if (ws.cgf_graph) { (void)hipGraphExecDestroy(ws.cgf_graph); ws.cgf_graph = nullptr; }
                         hipGraph_t graph = nullptr;
                         FS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                        for (int i = 0; i < batch; ++i) launch_iter(i & 1);
+                        for (int i = 0; i < bsz; ++i) launch_iter(i & 1);
                         FS_HIP(hipStreamEndCapture(s, &graph));
                         FS_HIP(hipGraphInstantiate(&ws.cgf_graph, graph, nullptr, nullptr, 0));
                         (void)hipGraphDestroy(graph);
@@ -3706,14 +3799,17 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 }
             }
             FS_KERNEL_CHECK();
-            FS_HIP(hipMemcpyAsync(ws.h_status + 4 * slot, ws.status.p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            FS_HIP(hipEventRecord(ws.poll[slot], s));
-            if (pending >= 0) {
-                FS_HIP(hipEventSynchronize(ws.poll[pending]));
-                if (ws.h_status[4 * pending] != 0) finished = true;
+            n_launches += k - k_before;
+            if (!mirrored) {
+                FS_HIP(hipMemcpyAsync(ws.h_status + 4 * slot, ws.status.p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                FS_HIP(hipEventRecord(ws.poll[slot], s));
+                if (pending >= 0) {
+                    FS_HIP(hipEventSynchronize(ws.poll[pending]));
+                    if (ws.h_status[4 * pending] != 0) finished = true;
+                }
+                pending = slot;
+                slot ^= 1;
             }
-            pending = slot;
-            slot ^= 1;
             if (k > max_iter) finished = true;
         }
         if (sp->halo.begun) {          // the exchange started for a product that is not coming any more
@@ -3823,6 +3919,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         stats->row_classes = g_dict.built_for ? g_dict.ncls : 0;
         stats->fused_iteration = fusedp_used ? 2 : (fused ? 1 : 0);
         stats->classes_kept = g_dict.built_for && g_dict.kept ? 1 : 0;
+        stats->launches = n_launches;
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -1048,6 +1048,43 @@ def test_one_launch_cg_iteration_is_the_two_launch_iteration_bit_for_bit(gpu, n,
     assert np.abs(x1 - xo).max() <= 1e-7 * np.abs(xo).max()
 
 
+def test_host_follows_the_one_launch_iteration_through_pinned_progress_words(gpu):
+    """Round 5: the leader lane of k_dict_cg_iter writes the iteration in progress and - once the recurrence stops - the status word
+    into pinned host memory; the host keeps cg_ahead .. cg_ahead + cg_sub launches enqueued instead of batches of 32 with the status
+    word copied back behind each.  Same iterates, same histories, bit for bit, for several (cg_sub, cg_ahead); far fewer launches
+    behind the last iteration (fs_krylov_stats.launches); the iteration limit and a solve converged from the start behave alike.
+    And the class table kept from the first solve is compared with the later matrices WITHOUT the scaled copy being written
+    (FS_LAZY_SCALE_COPY: values scaled on the fly in k_dict_finish) - the solves above are that path from the second one on."""
+    n = 40
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    P, V, A, b = _box_system(gpu, mesh, n)
+    got = {}
+    try:
+        for mode in ((0, 16, 6), (1, 16, 6), (1, 2, 1), (1, 8, 40), (1, 64, 3)):
+            gpu.set_option("cg_mirror", mode[0]); gpu.set_option("cg_sub", mode[1]); gpu.set_option("cg_ahead", mode[2])
+            x = gpu.DeviceVector(V.n_local)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+            hist = np.array(gpu.krylov_history())
+            y = gpu.DeviceVector(V.n_local)
+            lim = gpu.krylov_solve(A, b, y, rtol=1e-14, max_iter=37)
+            z = gpu.DeviceVector(V.n_local)
+            zero = gpu.krylov_solve(A, b, z, rtol=1.0, max_iter=50)
+            got[mode] = (st, x.get()[:V.n_owned].copy(), hist, lim, y.get()[:V.n_owned].copy(), zero)
+    finally:
+        gpu.set_option("cg_mirror", 1); gpu.set_option("cg_sub", 16); gpu.set_option("cg_ahead", 6)
+    s0, x0, h0, l0, y0, z0 = got[(0, 16, 6)]
+    assert s0["fused_iteration"] == 1 and s0["converged"] == 1 and s0["iterations"] > 64 and s0["classes_kept"] == 0
+    assert s0["launches"] - s0["iterations"] >= 1 and got[(1, 16, 6)][0]["classes_kept"] == 1 and got[(0, 16, 6)][3]["classes_kept"] == 1
+    for mode, (st, x, h, lim, y, zero) in got.items():
+        assert st["fused_iteration"] == 1 and st["iterations"] == s0["iterations"] and st["converged"] == 1, mode
+        assert np.array_equal(h, h0) and np.array_equal(x, x0), mode
+        assert lim["iterations"] == 37 and lim["converged"] == 0 and np.array_equal(y, y0), mode
+        assert zero["iterations"] == 0 and zero["converged"] == 1, mode
+        if mode[0]:
+            assert 1 <= st["launches"] - st["iterations"] <= mode[1] + mode[2] + 1, (mode, st["launches"], st["iterations"])
+    assert got[(1, 16, 6)][0]["launches"] < s0["launches"]
+
+
 def test_one_launch_cg_iteration_stops_at_the_iteration_limit_like_the_two_launch_one(gpu):
     """max_iter below what the tolerance needs: both iterations stop after exactly max_iter steps with the same iterate (status 3
     path of k_dict_cg_iter: the launch that sees iter == limit only checks); and a solve that is converged from the start
