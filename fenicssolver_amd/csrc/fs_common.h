@@ -142,6 +142,9 @@ struct fs_mesh_s {
     // their differences carry rounding noise of 1e-16 that differs from cell to cell) - what lets the solver find the few
     // dozen distinct rows of such an operator (fs_krylov.hip, row dictionary).  0 = not a uniform box: nothing is snapped.
     double box_h[3] = {0.0, 0.0, 0.0};
+    // ... and, when this process holds the WHOLE box (one GPU), its cell counts: vertex v sits at (v % (nx + 1), ...), x fastest -
+    // what the solver's lattice order of a CG2 space on it is computed from (fs_lattice.hip).  0 = a slab, or not a box.
+    int64_t box_n[3] = {0, 0, 0};
 };
 
 // Peer-to-peer ghost refresh (opt-in, one node): every rank owns a fine-grained receive buffer + arrival flags that its
@@ -273,6 +276,17 @@ struct fs_space_s {
     dbuf<int32_t> dict_plans;
     int dict_slots = 0;
     int dict_run_len = 3;         // coefficient positions per run (2: CG2 spaces, where runs of three offsets are rare)
+    // hints for dict_structure_build (set by fs_lattice.hip for the lattice-ordered shadow of a CG2 box space): rows repeat their
+    // offset set with this period inside mesh lines of dict_line rows (0: unknown - segments are grown from nested sets), and a
+    // line is one segment whose plan is the union of its rows' sets
+    int dict_period = 1;
+    int64_t dict_line = 0;
+    int dict_runs = 8;            // runs per plan round (12: the lattice-ordered shadow - k_dict_spmv<.., 12>)
+    // the solver's lattice-ordered shadow of a scalar CG2 space on a uniform box (fs_lattice.hip): 0 not looked at yet, 1 built,
+    // -1 does not apply
+    struct fs_lattice_shadow* lattice = nullptr;
+    int lattice_state = 0;
+    ~fs_space_s();
     int64_t n_dict_items = -1;    // -1: not built yet, 0: the pattern does not lend itself to the form
     dbuf<int32_t> pair_list;      // [2 * n_pairs]
     dbuf<int32_t> pair_singles;   // [n_pair_singles]
@@ -321,6 +335,15 @@ static inline int fs_grid_for(int64_t work_items, int per_block = FS_BLOCK, int 
 }
 
 // ---- cross-TU internals ------------------------------------------------------------------
+// fs_lattice.hip
+struct fs_lattice_shadow;
+void fs_lattice_release(fs_lattice_shadow* L);
+int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out);
+int fs_lattice_enter(fs_lattice_shadow* L, fs_matrix_s* A, const fs_vector_s* b, const fs_vector_s* x, bool use_guess, fs_matrix_s** A_sh,
+                     fs_vector_s** b_sh, fs_vector_s** x_sh);
+int fs_lattice_leave(fs_lattice_shadow* L, const fs_space_s* sp, fs_vector_s* x);
+// fs_symbolic.hip: SELL-64 / DIA storage of a space from its CSR pattern (rowptr, colidx, n_nodes_owned, n_nodes_local set)
+int fs_space_build_storage(fs_space_s* sp, hipStream_t s);
 // fs_assemble.hip: box meshes snap their edge vectors to the grid spacing (fs_set_option "box_snap", FS_BOX_SNAP=0: off)
 void fs_set_box_snap(bool on);
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.

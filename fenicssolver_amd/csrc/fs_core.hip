@@ -553,6 +553,7 @@ extern "C" int fs_mesh_create_box(int64_t nx, int64_t ny, int64_t nz, const doub
     m->box_h[0] = (p1[0] - p0[0]) / (double)nx;
     m->box_h[1] = (p1[1] - p0[1]) / (double)ny;
     m->box_h[2] = (p1[2] - p0[2]) / (double)nz;
+    if (!d.has_lower && !d.has_upper) { m->box_n[0] = nx; m->box_n[1] = ny; m->box_n[2] = nz; }
     int rc = FS_OK;
     if ((rc = m->xyz.alloc(nv * 4)) != FS_OK || (rc = m->cells.alloc(nc * 4)) != FS_OK ||
         (rc = m->gid.alloc(nv)) != FS_OK) {

@@ -420,14 +420,28 @@ struct dict_plan_round {
     uint8_t pad[24];
 };
 static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round");
+// Rounds of TWELVE runs (fs_space_s::dict_runs = 12: the lattice-ordered shadow of a CG2 box space, fs_lattice.hip - three quarters
+// of its mesh lines have 11 runs + the z run, one round instead of two): the same 64 bytes, 12 starts + 12 lengths.  Code that
+// takes the number of runs per round at run time reads a round through these two:
+struct dict_plan_round12 {
+    int32_t start[12];
+    uint8_t len[12];
+    uint8_t pad[4];
+};
+static_assert(sizeof(dict_plan_round12) == 64, "one 64-byte scalar load per round");
+__host__ __device__ __forceinline__ int32_t dict_run_start(const dict_plan_round* __restrict__ pl, int NR, int g) {
+    return reinterpret_cast<const int32_t*>(pl + g / NR)[g % NR];
+}
+__host__ __device__ __forceinline__ int dict_run_len(const dict_plan_round* __restrict__ pl, int NR, int g) {
+    return (int)(reinterpret_cast<const uint8_t*>(pl + g / NR) + 4 * NR)[g % NR];
+}
 
 // Coefficient position (plan layout) of the stored entry with offset o, walking the runs of a plan in ascending order from run g on
 // (the entries of a row come in ascending offsets, as the runs do): -1 = the plan has no such offset.
-__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int RL, int& g, int32_t o) {
+__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int RL, int& g, int32_t o, int NR = 8) {
     while (g < n_runs) {
-        const dict_plan_round& pr = pl[g >> 3];
-        const int32_t st = pr.start[g & 7];
-        const int ln = pr.len[g & 7];
+        const int32_t st = dict_run_start(pl, NR, g);
+        const int ln = dict_run_len(pl, NR, g);
         if (ln > 0 && o < st + ln) return o >= st ? RL * g + (o - st) : -1;
         ++g;
     }
@@ -445,7 +459,7 @@ template <typename F>
 __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
                                               const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane,
                                               const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f,
-                                              const double* __restrict__ sc = nullptr) {
+                                              const double* __restrict__ sc = nullptr, int NR = 8) {
     const int32_t sl = r >> 6, ln = r & 63;
     const int64_t base = slice_ptr[sl];
     const int width = (int)((slice_ptr[sl + 1] - base) >> 6);
@@ -453,7 +467,7 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
     const int32_t* __restrict__ op = dia_off + dp + 1 + (ln >= dia_off[dp] ? width : 0);
     const double* __restrict__ vp = val + base + ln;
     bool ok = true;
-    if (n_runs == 8 && nq == 1) {
+    if (n_runs == 8 && NR == 8 && nq == 1) {
         // one-round plans of scalar operators (P1): the eight run starts and lengths are wave-uniform - in scalar registers, an
         // entry's position is found by comparing its offset with all of them - and the row is taken eight entries at a time,
         // offsets and values of a batch (and whatever f loads) in flight together; the walk below goes entry by entry, two loads
@@ -505,7 +519,7 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
             double v = vp[(int64_t)k * FS_SLICE + (int64_t)q * plane];
             if (v == 0.0) continue;
             if (sc) v = v * sc[r] * sc[r + op[k]];
-            if (slot == -2) slot = dict_slot_of(pl, n_runs, RL, g, op[k]);
+            if (slot == -2) slot = dict_slot_of(pl, n_runs, RL, g, op[k], NR);
             if (slot < 0) { ok = false; break; }
             f(slot * nq + q, v);
         }
@@ -529,7 +543,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
                                                           const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
                                                           const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
                                                           unsigned long long* keys, const unsigned long long* keys_cached, double* slot_vals,
-                                                          uint16_t* __restrict__ cls_slot, int* info) {
+                                                          uint16_t* __restrict__ cls_slot, int* info, int NR = 8) {
     const int lane = threadIdx.x & 63;
     int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -538,14 +552,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
         const int4 it = items[q];
         const int32_t first = it.x, nr = it.y & 0xffff;
         const dict_plan_round* __restrict__ pl = plans + it.z;
-        const int n_runs = 8 * it.w;
+        const int n_runs = NR * it.w;
         for (int half = 0; half < 2; ++half) {
             const int i = half * 64 + lane;
             const bool live = i < nr;
             const int32_t r = first + i;
             unsigned long long h = 1469598103934665603ull;
             bool fits = true;
-            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); });
+            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); }, nullptr, NR);
             if (!h) h = 1ull;
             if (live && !fits) atomicAdd(&info[2], 1);
             int my_slot = 0;
@@ -565,7 +579,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const
                             if (old == 0ull) {                  // this row is the representative of a new class
                                 if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 double* __restrict__ dst = slot_vals + (int64_t)slot * S;       // (zero-filled by the host before the launch)
-                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; });
+                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; }, nullptr, NR);
                                 break;
                             }
                         }
@@ -622,7 +636,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
                                                           const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
                                                           const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
                                                           const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
-                                                          uint16_t* __restrict__ cls, int* info, const double* __restrict__ sc = nullptr) {
+                                                          uint16_t* __restrict__ cls, int* info, const double* __restrict__ sc = nullptr, int NR = 8) {
     const int lane = threadIdx.x & 63;
     int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -631,7 +645,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
         const int4 it = items[q];
         const int32_t first = it.x, nr = it.y & 0xffff;
         const dict_plan_round* __restrict__ pl = plans + it.z;
-        const int n_runs = 8 * it.w;
+        const int n_runs = NR * it.w;
         int id2[2] = {-1, -1};
         for (int half = 0; half < 2; ++half) {
             const int i = half * 64 + lane;
@@ -646,7 +660,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const
             const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) {
                 ++nz;
                 diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
-            }, sc);
+            }, sc, NR);
             bad += !fits || diff != 0 || nz != nnz[id];
         }
         // distinct classes among the item's rows (what its wave will have to hold in LDS)
@@ -725,7 +739,8 @@ __device__ __forceinline__ void fs_wave_copy_pairs(double* __restrict__ lds, con
 // RL: longest run of the space's plans (coefficient positions per run): 3 on P1 Kuhn meshes (runs of 2, 2, 2, 3, 2, 2, 2), 2 on CG2
 // spaces, where 67 % of the runs are one offset long, 32 % two and 0.5 % three (those are cut in two): a third fewer fmas and LDS
 // reads on padded positions, one DPP shift per run instead of two.
-template <int DOTS, bool LDSD, int RL>
+// NR: runs per plan round (8; 12 on the lattice-ordered shadow of a CG2 box space: twelve 16-byte loads in flight per lane and round)
+template <int DOTS, bool LDSD, int RL, int NR = 8>
 __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
                                                         const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
                                                         const double* __restrict__ dict, int S, int C,
@@ -787,21 +802,21 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
         // [0, n_cols) (first / last rows of the vector) load the two values of a pair one by one, each clamped into x: a column
         // outside the vector has no entry, hence a zero coefficient, and every value inside it is the right one.
         const double* __restrict__ xr = x + r;
-        v2d A[8];
-        struct starts8 { int32_t v[8]; };
+        v2d A[NR];
+        struct starts8 { int32_t v[NR]; };
         auto read_starts = [&](const dict_plan_round* __restrict__ p) {       // (wave-uniform: one 32-byte scalar load)
             starts8 t;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t.v[j] = __builtin_amdgcn_readfirstlane(p->start[j]);
+            for (int j = 0; j < NR; ++j) t.v[j] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t*>(p)[j]);
             return t;
         };
-        auto load_round = [&](v2d (&buf)[8], const starts8& st) {
+        auto load_round = [&](v2d (&buf)[NR], const starts8& st) {
             if (!edge) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + st.v[j]);
+                for (int j = 0; j < NR; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + st.v[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < NR; ++j) {
                     const int32_t c = r + st.v[j];
                     buf[j].x = x[c < 0 ? 0 : (c > cmax ? cmax : c)];
                     buf[j].y = x[c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1)];
@@ -860,11 +875,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
         // (measured and not kept, CG2 n = 107, product 204 us: the next round's loads in flight while this one is multiplied - a
         // second register set, 138 VGPRs, 3 waves per SIMD: 270 us; only the terms a run's length calls for, by wave-uniform branches
         // - most CG2 runs are one or two offsets long - : 339 us, the branches keep the coefficient reads from being batched)
-        auto compute_round = [&](const v2d (&buf)[8], int rd) {
-            const double* __restrict__ w0 = v0 + 8 * RL * rd;
-            const double* __restrict__ w1 = v1 + 8 * RL * rd;
+        auto compute_round = [&](const v2d (&buf)[NR], int rd) {
+            const double* __restrict__ w0 = v0 + NR * RL * rd;
+            const double* __restrict__ w1 = v1 + NR * RL * rd;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NR; ++j) {
                 const double e0 = buf[j].x, e1 = buf[j].y;
                 const double e2 = fs_from_next_lane(buf[j].x);
                 a0 = fma(w0[RL * j], e0, a0);     a1 = fma(w1[RL * j], e1, a1);
@@ -2233,6 +2248,15 @@ static int g_spmv_blocks = 1024;
 static int g_spmv_unroll = 4;
 static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
+// Scalar CG2 operators on uniform boxes solved in the lattice order of the half grid (fs_lattice.hip): OFF by default - measured on
+// BASELINE configs[3] (9.94 M rows, tools/probes/p2_lattice_probe.py, round 5) the product takes 222 us with rounds of 8 runs, 272
+// with rounds of 12 (139 VGPRs, three waves per SIMD), 240 with the items regrouped by class, against 191 us in the space's own
+// numbering.  The rounds per work item do drop (3.4 -> 2.5 -> 1.5) but the time does not follow them: per row pair both orders
+// spend the same 54 coefficient positions (fma + LDS read each) on 29 stored entries - in lattice order because a line's plan is the
+// UNION of its two alternating row patterns (an x-edge row of 27 entries rides the 26 runs of its vertex neighbours).  The kernel
+// is bound by those instructions, not by dependent rounds.  Option "lattice_order" / FS_LATTICE=1 turn it on.
+static int g_lattice = getenv("FS_LATTICE") && getenv("FS_LATTICE")[0] == '1' ? 1 : 0;
+static inline bool bs_is_scalar_cg2(const fs_matrix_s* A) { return A->bs == 1 && A->space->degree == 2 && A->space->ncomp == 1; }
 static int g_cg_batch = 32;
 // one-launch iteration on one GPU: launches go out g_cg_sub at a time (one hipGraph) whenever the device - its progress is read from
 // pinned memory the kernel writes (krylov_ws::h_mirror) - has fewer than g_cg_ahead of them left to do; g_cg_mirror = 0: the batches
@@ -2276,6 +2300,8 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "cg_ahead")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_ahead must be in [1,4096]");
         g_cg_ahead = (int)value;
+    } else if (!strcmp(name, "lattice_order")) {
+        g_lattice = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "cg_mirror")) {
         g_cg_mirror = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "cg_batch")) {
@@ -2385,13 +2411,16 @@ static int dict_map_xcd();
 // ---- structure of the row-dictionary product: segments, work items, run plans (once per space) ---------------------------------
 // chg[r] = 1: the (col - row) offset set of row r differs from row r - 1's (compared through a 64-bit hash of both: a collision
 // merges two rows into one segment whose plan then misses an entry - caught by the verification of every row in dict_build)
-__global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, uint8_t* __restrict__ chg) {
+// period, line (fs_space_s::dict_period / dict_line): the rows of a mesh line of `line` rows repeat their sets with that period - a
+// row is compared with the row `period` before it, and the first `period` rows of every line count as changes.
+__global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, uint8_t* __restrict__ chg,
+                             int period = 1, int64_t line = 0) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; r < n_rows; r += stride) {
         unsigned long long h[2] = {0ull, 1ull};
         for (int w = 0; w < 2; ++w) {
-            const int64_t q = r - w;
+            const int64_t q = r - w * period;
             if (q < 0) break;
             const int32_t s0 = rowptr[q], s1 = rowptr[q + 1];
             unsigned long long hh = 1469598103934665603ull ^ (unsigned long long)(s1 - s0);
@@ -2401,7 +2430,7 @@ __global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr,
             }
             h[w] = hh;
         }
-        chg[r] = r == 0 || h[0] != h[1];
+        chg[r] = r < period || h[0] != h[1] || (line > 0 && r % line < period);
     }
 }
 // offsets of the listed rows, concatenated (ptr = exclusive scan of their lengths)
@@ -2443,7 +2472,8 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
     {
         dbuf<uint8_t> d_chg;
         FS_CHECK(d_chg.alloc(n));
-        hipLaunchKernelGGL(k_row_change, dim3(fs_grid_for(n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, d_chg.p);
+        hipLaunchKernelGGL(k_row_change, dim3(fs_grid_for(n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, d_chg.p,
+                           sp->dict_period, sp->dict_line);
         FS_KERNEL_CHECK();
         FS_CHECK(d_chg.download(chg.data(), n, s));
     }
@@ -2475,7 +2505,28 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
     // 3. segments: a row joins while its set is nested with the segment's list (which grows to the larger one)
     struct segment { int32_t first, end, list; };      // list = index of the change row whose offsets are the segment's list
     std::vector<segment> segs;
-    {
+    if (sp->dict_line > 0) {
+        // mesh lines of a known length whose rows alternate between sets (the lattice-ordered shadow of a CG2 box space): a line is
+        // one segment, its list the UNION of the sets of its change rows - appended to the lists as one more
+        const int64_t line = sp->dict_line;
+        int64_t i = 0;
+        std::vector<int32_t> uni, tmp;
+        for (int64_t a = 0; a < n; a += line) {
+            const int64_t e = std::min(a + line, n);
+            uni.clear();
+            for (; i < nc && crow[(size_t)i] < e; ++i) {
+                tmp.clear();
+                std::set_union(uni.begin(), uni.end(), coff.data() + cptr[(size_t)i], coff.data() + cptr[(size_t)i + 1], std::back_inserter(tmp));
+                uni.swap(tmp);
+            }
+            const int32_t id = (int32_t)clen.size();
+            coff.resize((size_t)cptr.back());          // (drop the padding element of an empty list array)
+            coff.insert(coff.end(), uni.begin(), uni.end());
+            clen.push_back((int32_t)uni.size());
+            cptr.push_back(cptr.back() + (int64_t)uni.size());
+            segs.push_back({(int32_t)a, (int32_t)e, id});
+        }
+    } else {
         auto set_of = [&](int64_t i) { return std::make_pair(coff.data() + cptr[(size_t)i], coff.data() + cptr[(size_t)i + 1]); };
         int64_t cur = 0;
         segs.push_back({0, 0, 0});
@@ -2489,6 +2540,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         }
         segs.back().end = (int32_t)n;
     }
+    const int NR = sp->dict_runs;       // runs per round: 8, or 12 for the lattice-ordered shadow of a CG2 box space
     // 4. run plans (identical lists share one) and items.  Runs of up to three consecutive offsets - or of up to two where longer
     // ones are rare (CG2: 0.5 % of the runs): a class row then has two coefficient positions per run instead of three
     int RL = 3;
@@ -2529,9 +2581,9 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
             for (int k = 0; k < w;) {
                 int len = 1;
                 while (k + len < w && len < RL && o[k + len] == o[k + len - 1] + 1) ++len;
-                if (slot == 8) { rounds.push_back(cur); memset(&cur, 0, sizeof(cur)); slot = 0; }
-                cur.start[slot] = o[k];
-                cur.len[slot] = (uint8_t)len;
+                if (slot == NR) { rounds.push_back(cur); memset(&cur, 0, sizeof(cur)); slot = 0; }
+                reinterpret_cast<int32_t*>(&cur)[slot] = o[k];                          // (dict_run_start / dict_run_len: NR starts, then NR lengths)
+                (reinterpret_cast<uint8_t*>(&cur) + 4 * NR)[slot] = (uint8_t)len;
                 pi.min_start = std::min(pi.min_start, o[k]);
                 pi.max_start = std::max(pi.max_start, o[k]);
                 ++slot;
@@ -2571,8 +2623,14 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         const plan_info& pi = seg_plan[g];
         // (a segment longer than one item is cut at multiples of 126 rows - even rows: the 16-byte accesses of w and d are aligned
         // there; a shorter one - a mesh line of a CG2 space - is one item wherever it starts)
+        // (a mesh line of known length - the lattice-ordered shadow -: equal pieces of an even number of rows, so that every lane's
+        // first row is an even point of the line)
+        const int32_t seg_len = segs[g].end - segs[g].first;
+        const int32_t pieces = (seg_len + FS_DICT_ITEM_ROWS - 1) / FS_DICT_ITEM_ROWS;
+        const int32_t piece = sp->dict_line > 0 ? (((seg_len + pieces - 1) / pieces + 1) & ~1) : 0;
         for (int32_t a = segs[g].first, e; a < segs[g].end; a = e) {
             e = segs[g].end - a <= FS_DICT_ITEM_ROWS ? segs[g].end : (a / FS_DICT_ITEM_ROWS + 1) * FS_DICT_ITEM_ROWS;
+            if (piece > 0) e = std::min(a + piece, segs[g].end);
             // (all 64 lanes load, also those past the item's last row: in range means in range for 128 rows)
             const bool edge = (int64_t)a + pi.min_start < 0 || (int64_t)a + 127 + pi.max_start > n_cols - 1;      // (64 lanes x 2 values)
             item it;
@@ -2585,6 +2643,21 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         }
     }
     if ((int64_t)all.size() * 8 > n) return give_up("segments of fewer than 8 rows");
+    if (sp->dict_line > 0) {
+        // Lattice order: consecutive mesh lines belong to different node classes, and a wave that takes them one after the other
+        // copies the class rows of every item into its LDS region again (six rows of 864 bytes, one dependent round trip each:
+        // measured 272 us per product at 10 M rows against 193 us in the space's own numbering).  Inside windows of 1024 items
+        // (about two and a half mesh planes at n = 107) the items are taken plan by plan and piece by piece: the four consecutive
+        // items of a wave are then the same piece of neighbouring lines of ONE class - same class rows, already in place.
+        const int64_t line = sp->dict_line;
+        constexpr size_t WINDOW = 1024;
+        for (size_t w0 = 0; w0 < all.size(); w0 += WINDOW)
+            std::sort(all.begin() + w0, all.begin() + std::min(w0 + WINDOW, all.size()), [line](const item& u, const item& v) {
+                if (u.v[2] != v.v[2]) return u.v[2] < v.v[2];
+                const int64_t pu = u.v[0] % line, pv = v.v[0] % line;
+                return pu != pv ? pu < pv : u.v[0] < v.v[0];
+            });
+    }
     if (!rank.empty()) {
         std::sort(all.begin(), all.end(), [](const item& u, const item& v) { return u.key < v.key; });
         // ... and inside windows of 2048 items (about what one XCD has in flight) by row number again: the lines of ONE node class
@@ -2608,7 +2681,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         // (the plans depend on the pattern only: a later build for new halo lists finds the same array in place)
         FS_CHECK(sp->dict_plans.alloc(std::max<int64_t>(plan_ints, 16)));
         FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(rounds.data()), plan_ints, s));
-        sp->dict_slots = 8 * RL * std::max(max_rounds, 1);
+        sp->dict_slots = NR * RL * std::max(max_rounds, 1);
         sp->dict_run_len = RL;
         FS_CHECK(upload_items(sp->dict_items, sp->n_dict_items, -1));
     }
@@ -2677,7 +2750,7 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
             FS_CHECK(D.info.zero(s));
             hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
                                raw ? raw : val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p,
-                               raw ? sc : nullptr);
+                               raw ? sc : nullptr, sp->dict_runs);
             FS_KERNEL_CHECK();
             int h[4] = {0, 0, 0, 0};
             FS_CHECK(D.info.download(h, 4, s));
@@ -2702,10 +2775,10 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
     FS_CHECK(D.info.zero(s));
     FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
     hipLaunchKernelGGL(k_dict_insert, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p);
+                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.keys.p, D.keys.p, D.slot_vals.p, D.cls_slot.p, D.info.p, sp->dict_runs);
     hipLaunchKernelGGL(k_dict_compact, dim3(1), dim3(1024), 0, s, D.keys.p, D.slot_vals.p, S, D.slot2cls.p, D.values.p, D.nnz.p);
     hipLaunchKernelGGL(k_dict_finish, dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_dict_items, items, plans, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p,
-                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p);
+                       val, nq, sp->sell_entries, S, sp->dict_run_len, D.slot2cls.p, D.values.p, D.nnz.p, D.cls_slot.p, D.cls.p, D.info.p, nullptr, sp->dict_runs);
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
@@ -2784,11 +2857,12 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             const size_t whole = (size_t)g_dict.ncls * g_dict.S * sizeof(double);
             const size_t per_wave = (size_t)(FS_BLOCK / 64) * g_dict.C * g_dict.S * sizeof(double);
             const bool rl2 = sp->dict_run_len == 2;
-            if (whole <= (size_t)FS_DICT_WHOLE_LDS_BYTES) {
+            if (whole <= (size_t)FS_DICT_WHOLE_LDS_BYTES && sp->dict_runs == 8) {
                 if (rl2) hipLaunchKernelGGL((k_dict_spmv<DOTS, true, 2>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
                 else hipLaunchKernelGGL((k_dict_spmv<DOTS, true, 3>), dim3(gd), dim3(FS_BLOCK), whole, s, FS_DICT_ARGS(g_dict.ncls));
             } else {
-                if (rl2) hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 2>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
+                if (sp->dict_runs == 12) hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 3, 12>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
+                else if (rl2) hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 2>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
                 else hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 3>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
             }
 #undef FS_DICT_ARGS
@@ -3188,6 +3262,26 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const int64_t n = sp->n_dofs_owned, nl = sp->n_dofs_local;
     FS_REQUIRE(b->d.n >= n && x->d.n >= n, "fs_krylov_solve: b/x shorter than the owned dofs (%lld)", (long long)n);
     hipStream_t s = fs_rt().stream;
+    // A scalar CG2 operator on a uniform box (one GPU) is solved in LATTICE order (fs_lattice.hip): values, b and x permuted into
+    // the solver's shadow of the space, the solve run there (this function again, on the shadow's handles), x permuted back.
+    if (bs_is_scalar_cg2(A) && g_lattice && sp->lattice_state >= 0) {
+        fs_lattice_shadow* L = nullptr;
+        FS_CHECK(fs_lattice_get(sp, &L));
+        if (L) {
+            const auto t0 = std::chrono::steady_clock::now();
+            fs_matrix_s* A2 = nullptr;
+            fs_vector_s *b2 = nullptr, *x2 = nullptr;
+            FS_CHECK(fs_lattice_enter(L, A, b, x, opts->nonzero_guess != 0, &A2, &b2, &x2));
+            FS_CHECK(fs_krylov_solve(A2, b2, x2, opts, stats));
+            FS_CHECK(fs_lattice_leave(L, sp, x));
+            FS_HIP(hipStreamSynchronize(s));
+            if (stats) {
+                stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                stats->lattice_order = 1;
+            }
+            return FS_OK;
+        }
+    }
     krylov_ws& ws = g_ws;
     FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
     if (sp->halo.begun) {              // left over from a solve that ended in an error
@@ -3305,7 +3399,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     const bool fused_common = ds && !pipelined && bs == 1 && fused_opt != 0 &&
                               g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
                               (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
-                              nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && (fused_opt > 0 || n <= fused_max_rows);
+                              nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && sp->dict_runs == 8 && (fused_opt > 0 || n <= fused_max_rows);
     const int igrid = fused_common ? spmv_partials_unsplit(sp, bs) : 0;        // workgroups (= dot partials) of the iteration kernel
     const bool fused_sized = fused_common && 3 * (int64_t)igrid * 2 <= (int64_t)ws.partials.n && igrid <= 4 * FS_BLOCK;
     const bool fused = fused_sized && fuse_sums && !sp->halo.active;

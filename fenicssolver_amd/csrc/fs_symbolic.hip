@@ -321,7 +321,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
                                                             int32_t* __restrict__ dia_cnt,
                                                             int32_t* __restrict__ tmp_off, int32_t* __restrict__ split_at,
                                                             int* __restrict__ max_w,
-                                                            int* __restrict__ n_dia, unsigned long long* __restrict__ dia_entries) {
+                                                            int* __restrict__ n_dia, unsigned long long* __restrict__ dia_entries,
+                                                            int64_t line = 0) {
+    // line > 0 (the lattice-ordered shadow of a CG2 box space, fs_lattice.hip): the rows come in mesh lines of that many, and the one
+    // place a slice can be split is where a line ends inside it (rows ALTERNATE between two patterns there: every row is a
+    // `candidate` of the search below, which tries the first dozen)
     const int lane = threadIdx.x & 63;
     int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -351,6 +355,10 @@ __global__ void __launch_bounds__(FS_BLOCK) k_slice_analyze(const int32_t* __res
                 const int64_t pf = __shfl_up(first, 1, 64);
                 const int pl = __shfl_up(len, 1, 64);
                 unsigned long long cand = __ballot(lane > 0 && r < n_rows && (first != pf || len != pl));
+                if (line > 0) {
+                    const int64_t to_end = line - (s * FS_SLICE) % line;          // rows of the slice before the next line starts
+                    cand = to_end < FS_SLICE ? (1ull << to_end) : 0ull;
+                }
                 int best = 0, best_w = FS_DIA_CAP + 1;
                 for (int t = 0; t < FS_SPLIT_TRIES && cand; ++t) {
                     const int sp = __ffsll((long long)cand) - 1;
@@ -899,6 +907,91 @@ __global__ void k_extra_pair_keys(const int32_t* __restrict__ pairs, int64_t n, 
     }
 }
 
+// Hybrid SELL-64 / DIA storage of a space from its CSR pattern (sp->rowptr / colidx over sp->n_nodes_owned rows, columns below
+// sp->n_nodes_local): slice_ptr, dia_ptr / dia_off, sell_col, the counters.  Step 4 of fs_space_create - and what the solver's
+// lattice-ordered shadow of a CG2 box operator is built with (fs_lattice.hip).
+int fs_space_build_storage(fs_space_s* sp, hipStream_t s) {
+    const int64_t n_rows = sp->n_nodes_owned;
+    const int64_t n_slices = (n_rows + FS_SLICE - 1) / FS_SLICE;
+    sp->n_slices = n_slices;
+    {
+        dbuf<int64_t> entries;
+        dbuf<int32_t> dia_cnt, dia_scan, tmp_off, split_at;
+        dbuf<int> d_max, d_ndia;
+        dbuf<unsigned long long> d_dia_entries;
+        FS_CHECK(entries.alloc(n_slices + 1));
+        FS_CHECK(entries.zero(s));
+        FS_CHECK(dia_cnt.alloc(n_slices + 1));
+        FS_CHECK(dia_cnt.zero(s));
+        FS_CHECK(dia_scan.alloc(n_slices + 1));
+        FS_CHECK(tmp_off.alloc(n_slices * 2 * FS_DIA_CAP));
+        FS_CHECK(split_at.alloc(n_slices));
+        FS_CHECK(d_dia_entries.alloc(1));
+        FS_CHECK(d_dia_entries.zero(s));
+        FS_CHECK(d_max.alloc(1));
+        FS_CHECK(d_max.zero(s));
+        FS_CHECK(d_ndia.alloc(1));
+        FS_CHECK(d_ndia.zero(s));
+        FS_CHECK(sp->slice_ptr.alloc(n_slices + 1));
+        FS_CHECK(sp->dia_ptr.alloc(n_slices));
+        const char* env = getenv("FS_DISABLE_DIA");
+        const char* env_split = getenv("FS_DISABLE_DIA_SPLIT");
+        // 0: SELL only, 1: whole-slice DIA only, 2: DIA with split slices (default)
+        const int allow_dia = (env && *env && *env != '0') ? 0 : ((env_split && *env_split && *env_split != '0') ? 1 : 2);
+        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64, FS_BLOCK, 1024)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, split_at.p, d_max.p, d_ndia.p, d_dia_entries.p, sp->dict_line);
+        FS_HIP(hipGetLastError());
+        size_t tmp_bytes = 0, t2 = 0;
+        FS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
+        FS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
+        if (t2 > tmp_bytes) tmp_bytes = t2;
+        dbuf<char> tmp;
+        FS_CHECK(tmp.alloc((int64_t)tmp_bytes + 16));
+        size_t tb = tmp_bytes;
+        FS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
+        tb = tmp_bytes;
+        FS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
+        int64_t total = 0;
+        int32_t total_off = 0;
+        int h_ndia = 0;
+        FS_HIP(hipMemcpyAsync(&total, sp->slice_ptr.p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        FS_HIP(hipMemcpyAsync(&total_off, dia_scan.p + n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        FS_CHECK(d_ndia.download(&h_ndia, 1, s));
+        FS_CHECK(d_max.download(&sp->max_row, 1, s));
+        sp->sell_entries = total;
+        sp->n_dia_slices = h_ndia;
+        unsigned long long h_dia_entries = 0;
+        FS_CHECK(d_dia_entries.download(&h_dia_entries, 1, s));
+        sp->dia_entries = (int64_t)h_dia_entries;
+        FS_CHECK(sp->dia_off.alloc((total_off > 0 ? total_off : 1) + 64));       // (+ 64: the row-dictionary product reads whole rounds of 16 offsets)
+        FS_CHECK(sp->dia_off.zero(s));
+        hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, split_at.p, sp->dia_ptr.p, sp->dia_off.p);
+        FS_HIP(hipGetLastError());
+        static const bool no_dedup = getenv("FS_DIA_DEDUP") && getenv("FS_DIA_DEDUP")[0] == '0';
+        if (h_ndia > 0 && !no_dedup) {       // identical offset lists -> one copy (see k_dia_dedup_insert)
+            dbuf<unsigned long long> keys;
+            dbuf<int32_t> rep, shared;
+            FS_CHECK(keys.alloc(FS_DEDUP_CAP));
+            FS_CHECK(rep.alloc(FS_DEDUP_CAP));
+            FS_CHECK(shared.alloc(n_slices));
+            FS_CHECK(keys.zero(s));
+            FS_HIP(hipMemsetAsync(rep.p, 0x7f, (size_t)FS_DEDUP_CAP * sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_dia_dedup_insert, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p);
+            hipLaunchKernelGGL(k_dia_dedup_adopt, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p, shared.p);
+            FS_HIP(hipGetLastError());
+            FS_HIP(hipMemcpyAsync(sp->dia_ptr.p, shared.p, (size_t)n_slices * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
+        FS_HIP(hipStreamSynchronize(s));
+    }
+    if (sp->sell_entries >= (int64_t)INT32_MAX) {
+        fs_set_error("fs_space_create: storage of %lld entries exceeds int32 slot indexing", (long long)sp->sell_entries);
+        return FS_ERR_UNSUPPORTED;
+    }
+    FS_CHECK(sp->sell_col.alloc(sp->sell_entries));
+    hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, sp->n_nodes_local, n_slices, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, sp->sell_col.p);
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+}
+
 static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, int64_t n_extra, const int32_t* extra_pairs,
                              fs_space_t* out);
 
@@ -1223,84 +1316,8 @@ static int space_create_impl(fs_mesh_t mesh, int family, int degree, int ncomp, 
         FS_SP_HIP(hipStreamSynchronize(s));
     }
     // 4. hybrid SELL-64 / DIA storage
-    const int64_t n_slices = (n_rows + FS_SLICE - 1) / FS_SLICE;
-    sp->n_slices = n_slices;
-    {
-        dbuf<int64_t> entries;
-        dbuf<int32_t> dia_cnt, dia_scan, tmp_off, split_at;
-        dbuf<int> d_max, d_ndia;
-        dbuf<unsigned long long> d_dia_entries;
-        FS_SP(entries.alloc(n_slices + 1));
-        FS_SP(entries.zero(s));
-        FS_SP(dia_cnt.alloc(n_slices + 1));
-        FS_SP(dia_cnt.zero(s));
-        FS_SP(dia_scan.alloc(n_slices + 1));
-        FS_SP(tmp_off.alloc(n_slices * 2 * FS_DIA_CAP));
-        FS_SP(split_at.alloc(n_slices));
-        FS_SP(d_dia_entries.alloc(1));
-        FS_SP(d_dia_entries.zero(s));
-        FS_SP(d_max.alloc(1));
-        FS_SP(d_max.zero(s));
-        FS_SP(d_ndia.alloc(1));
-        FS_SP(d_ndia.zero(s));
-        FS_SP(sp->slice_ptr.alloc(n_slices + 1));
-        FS_SP(sp->dia_ptr.alloc(n_slices));
-        const char* env = getenv("FS_DISABLE_DIA");
-        const char* env_split = getenv("FS_DISABLE_DIA_SPLIT");
-        // 0: SELL only, 1: whole-slice DIA only, 2: DIA with split slices (default)
-        const int allow_dia = (env && *env && *env != '0') ? 0 : ((env_split && *env_split && *env_split != '0') ? 1 : 2);
-        hipLaunchKernelGGL(k_slice_analyze, dim3(fs_grid_for(n_slices * 64, FS_BLOCK, 1024)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, n_slices, allow_dia, entries.p, dia_cnt.p, tmp_off.p, split_at.p, d_max.p, d_ndia.p, d_dia_entries.p);
-        FS_SP_HIP(hipGetLastError());
-        size_t tmp_bytes = 0, t2 = 0;
-        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
-        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
-        if (t2 > tmp_bytes) tmp_bytes = t2;
-        dbuf<char> tmp;
-        FS_SP(tmp.alloc((int64_t)tmp_bytes + 16));
-        size_t tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, entries.p, sp->slice_ptr.p, (int)(n_slices + 1), s));
-        tb = tmp_bytes;
-        FS_SP_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, dia_cnt.p, dia_scan.p, (int)(n_slices + 1), s));
-        int64_t total = 0;
-        int32_t total_off = 0;
-        int h_ndia = 0;
-        FS_SP_HIP(hipMemcpyAsync(&total, sp->slice_ptr.p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        FS_SP_HIP(hipMemcpyAsync(&total_off, dia_scan.p + n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        FS_SP(d_ndia.download(&h_ndia, 1, s));
-        FS_SP(d_max.download(&sp->max_row, 1, s));
-        sp->sell_entries = total;
-        sp->n_dia_slices = h_ndia;
-        unsigned long long h_dia_entries = 0;
-        FS_SP(d_dia_entries.download(&h_dia_entries, 1, s));
-        sp->dia_entries = (int64_t)h_dia_entries;
-        FS_SP(sp->dia_off.alloc((total_off > 0 ? total_off : 1) + 64));       // (+ 64: the row-dictionary product reads whole rounds of 16 offsets)
-        FS_SP(sp->dia_off.zero(s));
-        hipLaunchKernelGGL(k_dia_ptr, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, dia_cnt.p, dia_scan.p, n_slices, tmp_off.p, split_at.p, sp->dia_ptr.p, sp->dia_off.p);
-        FS_SP_HIP(hipGetLastError());
-        static const bool no_dedup = getenv("FS_DIA_DEDUP") && getenv("FS_DIA_DEDUP")[0] == '0';
-        if (h_ndia > 0 && !no_dedup) {       // identical offset lists -> one copy (see k_dia_dedup_insert)
-            dbuf<unsigned long long> keys;
-            dbuf<int32_t> rep, shared;
-            FS_SP(keys.alloc(FS_DEDUP_CAP));
-            FS_SP(rep.alloc(FS_DEDUP_CAP));
-            FS_SP(shared.alloc(n_slices));
-            FS_SP(keys.zero(s));
-            FS_SP_HIP(hipMemsetAsync(rep.p, 0x7f, (size_t)FS_DEDUP_CAP * sizeof(int32_t), s));
-            hipLaunchKernelGGL(k_dia_dedup_insert, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p);
-            hipLaunchKernelGGL(k_dia_dedup_adopt, dim3(fs_grid_for(n_slices)), dim3(FS_BLOCK), 0, s, n_slices, dia_cnt.p, sp->dia_ptr.p, sp->dia_off.p, keys.p, rep.p, shared.p);
-            FS_SP_HIP(hipGetLastError());
-            FS_SP_HIP(hipMemcpyAsync(sp->dia_ptr.p, shared.p, (size_t)n_slices * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        }
-        FS_SP_HIP(hipStreamSynchronize(s));
-    }
-    if (sp->sell_entries >= (int64_t)INT32_MAX) {
-        fs_set_error("fs_space_create: storage of %lld entries exceeds int32 slot indexing", (long long)sp->sell_entries);
-        delete sp;
-        return FS_ERR_UNSUPPORTED;
-    }
-    FS_SP(sp->sell_col.alloc(sp->sell_entries));
-    hipLaunchKernelGGL(k_fill_sell, dim3(fs_grid_for(n_slices * 64)), dim3(FS_BLOCK), 0, s, sp->rowptr.p, sp->colidx.p, n_rows, sp->n_nodes_local, n_slices, sp->slice_ptr.p, sp->dia_ptr.p, sp->dia_off.p, sp->sell_col.p);
-    FS_SP_HIP(hipGetLastError());
+    FS_SP(fs_space_build_storage(sp, s));
+    const int64_t n_slices = sp->n_slices;
     // processing order of the slices (SpMV, gather assembly).  CG2: by the vertex the slice's first node sits at, i.e.
     // the sweep order of the vertices with the edge classes interleaved (bits = -1).  Measured inside the CG solve on
     // MI355X (round 1): P2 10 M DOF 1071 us unordered, 703 us by vertex, 735-755 us in Morton order (4-7 bits per

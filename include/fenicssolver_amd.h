@@ -78,7 +78,8 @@ int fs_memory_trim(void);
 const char* fs_last_error(void);
 const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
- * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
+ * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll), "lattice_order" (0 / 1: scalar CG2 operators on uniform boxes solved in
+ * the lattice order of the half grid, fs_krylov_stats.lattice_order), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
  * through pinned host memory and the host keeps "cg_ahead" to "cg_ahead" + "cg_sub" launches enqueued, instead of batches of
  * "cg_batch" with the status word copied back behind each),
  * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
@@ -379,6 +380,8 @@ typedef struct fs_krylov_stats {
                              * compared with its old class, bit for bit, and none differed (a steady problem solved again, a
                              * transient one with a constant step: one pass over the values instead of three); 0: the classes
                              * were found from scratch (or the streaming kernels ran) */
+    int lattice_order;      /* 1: a scalar CG2 operator on a uniform box, solved in the solver's lattice order of the half grid (values,
+                             * b and x permuted in and out; the API numbering is untouched): option "lattice_order" */
     int launches;           /* iterations ENQUEUED over all passes (fs_krylov_solve): those behind the one that stopped the
                              * recurrence return on the status word - launches - iterations of them, a few microseconds each */
 } fs_krylov_stats;

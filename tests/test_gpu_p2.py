@@ -469,3 +469,47 @@ def test_p2_supg_stabilised_convection_matches_oracle(gpu, transient, source):
     st2['function_space'] = FunctionSpace(UnitCubeMesh(3, 3, 2), "CG", 2)
     T2 = ScalarTransportSolver(st2).solve().vector().array()
     assert np.abs(T - T2).max() > 1e-3                # the stabilisation is not a no-op at this Peclet number
+
+
+def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
+    """Option lattice_order (fs_lattice.hip, round 5): a scalar CG2 operator on a uniform box is permuted, inside the Krylov solve,
+    into the x-fastest order of the half grid (vertices and edge mid-points interleaved as they sit in space, one dummy row per mesh
+    line), solved there through the row-dictionary product with rounds of twelve runs, and permuted back - the API numbering is
+    untouched.  Same Krylov iteration count, same solution to rounding, also from a nonzero guess and for a non-symmetric operator
+    (BiCGStab); a box whose lines are shorter than a slice keeps the space's own numbering.  (Measured slower than the space's
+    numbering at 10 M rows - the option is off by default; this pins its arithmetic.)"""
+    import bench
+    n = 32
+    prob = bench.P2Problem(n, (0, n + 1), 2, 0, 1)
+    prob.A.assemble(stiffness=20.0)
+    prob.b.fill(0.0)
+    prob.A.apply_dirichlet(prob.b, prob.dofs, prob.vals, symmetric=True)
+    got = {}
+    try:
+        for lat in (0, 1):
+            gpu.set_option("lattice_order", lat)
+            x = gpu.DeviceVector(prob.V.n_owned)
+            st = gpu.krylov_solve(prob.A, prob.b, x, rtol=1e-10, max_iter=5000)
+            x0 = x.get().copy()
+            guess = x0 * (1.0 + 1e-3 * np.cos(np.arange(len(x0))))
+            x.set(guess)
+            st2 = gpu.krylov_solve(prob.A, prob.b, x, rtol=1e-10, max_iter=5000, nonzero_guess=True)
+            y = gpu.DeviceVector(prob.V.n_owned)
+            st3 = gpu.krylov_solve(prob.A, prob.b, y, rtol=1e-10, max_iter=5000, method="bicgstab")
+            got[lat] = (st, x0, st2, x.get().copy(), st3, y.get().copy())
+        small = bench.P2Problem(12, (0, 13), 2, 0, 1)          # 26 rows per line: no DIA slices in lattice order -> not used
+        small.A.assemble(stiffness=20.0)
+        small.b.fill(0.0)
+        small.A.apply_dirichlet(small.b, small.dofs, small.vals, symmetric=True)
+        st_small = gpu.krylov_solve(small.A, small.b, small.x, rtol=1e-10, max_iter=5000)
+    finally:
+        gpu.set_option("lattice_order", 0)
+    (s0, x0, r0, g0, b0, y0), (s1, x1, r1, g1, b1, y1) = got[0], got[1]
+    assert s0["lattice_order"] == 0 and s1["lattice_order"] == 1 and r1["lattice_order"] == 1 and b1["lattice_order"] == 1
+    assert s1["row_classes"] > 0 and s1["converged"] == 1 and abs(s1["iterations"] - s0["iterations"]) <= 1
+    scale = np.abs(x0).max()
+    assert np.abs(x1 - x0).max() <= 1e-9 * scale and np.abs(x1 - prob.exact_owned).max() <= 1e-6 * scale
+    assert r1["converged"] == 1 and abs(r1["iterations"] - r0["iterations"]) <= 2 and np.abs(g1 - g0).max() <= 1e-8 * scale
+    assert b1["converged"] == 1 and np.abs(y1 - y0).max() <= 1e-7 * scale
+    assert st_small["lattice_order"] == 0 and st_small["converged"] == 1
+    assert np.abs(small.x.get()[:small.n_owned] - small.exact_owned).max() <= 1e-6 * scale
