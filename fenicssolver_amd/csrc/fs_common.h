@@ -344,6 +344,7 @@ int fs_lattice_enter(fs_lattice_shadow* L, fs_matrix_s* A, const fs_vector_s* b,
 int fs_lattice_leave(fs_lattice_shadow* L, const fs_space_s* sp, fs_vector_s* x);
 // fs_symbolic.hip: SELL-64 / DIA storage of a space from its CSR pattern (rowptr, colidx, n_nodes_owned, n_nodes_local set)
 int fs_space_build_storage(fs_space_s* sp, hipStream_t s);
+int fs_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t count, hipStream_t s);
 // fs_assemble.hip: box meshes snap their edge vectors to the grid spacing (fs_set_option "box_snap", FS_BOX_SNAP=0: off)
 void fs_set_box_snap(bool on);
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.

@@ -1409,7 +1409,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
                                                                double* __restrict__ scal, int* __restrict__ status,
                                                                double* __restrict__ hist, double* __restrict__ r,
                                                                const double* __restrict__ w, double* __restrict__ p,
-                                                               double* __restrict__ sv, double* __restrict__ x) {
+                                                               double* __restrict__ sv, double* __restrict__ x, int* __restrict__ mirror = nullptr) {
+    // mirror (one GPU; may be null): the pinned progress words of k_dict_cg_iter - [0] status once stopped, [1] iteration in progress
     // (the status word is looked at AFTER the first trip's loads have gone out - everything a launch reads first was written by the
     // previous launch on other XCDs, and each dependent load is a round trip of about a microsecond)
     const int st0 = status[0];
@@ -1462,22 +1463,20 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
     }
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     if (leader) hist[iter] = rho;
-    if (rho <= thresh) {
-        if (leader) { status[1] = iter; status[0] = 1; }
-        return;
-    }
-    if (check_only) {
-        if (leader) { status[1] = iter; status[0] = 3; }
-        return;
-    }
+    auto stop = [&](int code) {
+        if (leader) {
+            status[1] = iter; status[0] = code;
+            if (mirror) { fs_host_store(mirror + 1, iter); fs_host_store(mirror, code); }
+        }
+    };
+    if (rho <= thresh) { stop(1); return; }
+    if (check_only) { stop(3); return; }
     double beta, alpha;
-    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
+    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) { stop(2); return; }
     if (leader) {
         scal[2 * (iter & 1) + 0] = gamma;
         scal[2 * (iter & 1) + 1] = alpha;
+        if (mirror) fs_host_store(mirror + 1, iter + 1);
     }
     // two strided elements per trip: ten 16-B loads in flight per lane (the kernel is latency-bound at 1 M DOF)
     bool prefetched = first_trip;
@@ -3282,8 +3281,20 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             return FS_OK;
         }
     }
+    // FS_SOLVE_TIMING=1: wall-clock laps of the phases of a solve on stderr (each lap synchronises the stream: a diagnostic, it
+    // changes what it measures; tools/probes/first_step_probe.py uses it to split the first solve of a process)
+    static const bool lap_on = getenv("FS_SOLVE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!lap_on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fs_krylov timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+        lap_t = now;
+    };
     krylov_ws& ws = g_ws;
     FS_CHECK(ws_prepare(ws, n, nl, opts->max_iter));
+    lap("workspace");
     if (sp->halo.begun) {              // left over from a solve that ended in an error
         FS_CHECK(fs_halo_end_dev(sp, fs_rt().stream));
         sp->halo.begun = false;
@@ -3361,6 +3372,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, pgrid, 1, ws.sums.p + 4, s));
     hipLaunchKernelGGL(k_set_threshold, dim3(1), dim3(64), 0, s, ws.sums.p + 4, opts->rtol, opts->atol, ws.ctrl.p);
     const double* aval = nullptr;
+    lap("diagonal, |b|, threshold");
     if (ds) {
         // the scaled system needs ghost scale factors too: refresh them through the halo
         double* sc_local = ws.sc_local.p;
@@ -3390,6 +3402,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             sgrid = spmv_partials(sp, bs);          // (the row-dictionary product has its own launch geometry)
         }
     }
+    lap("scaling + row classes");
     // One launch per iteration (k_dict_cg_iter) where the product is the row-dictionary kernel with the whole dictionary in LDS,
     // on one GPU.  Automatic mode: FS_CG_FUSED_MAX_ROWS rows at most (the neighbour values of three vectors instead of one have
     // to stay in the L2 of an XCD; measured crossover in DESIGN.md section 3).
@@ -3589,7 +3602,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // With batches of 32 and the status word copied back behind each, a solve of 293 iterations enqueued 352 launches - the
         // 59 that returned on the status word cost 5.3 us each, 0.31 of a 6.8 ms solve - and ten in-stream copies.
         static const int mirror_env = getenv("FS_CG_MIRROR") ? atoi(getenv("FS_CG_MIRROR")) : -1;
-        bool mirrored = fused && !fusedp && ws.d_mirror && ws.mirror_ok && (mirror_env >= 0 ? mirror_env != 0 : g_cg_mirror != 0);
+        // (the same for the two-launch iteration on one GPU - streaming products, row-dictionary products above 3 M rows -, whose
+        // update kernel writes the words: its batches of 32 left up to 59 x 2 launches behind the last iteration)
+        const bool two_launch_1gpu = use_graph && !p2p_fuse && fuse_sums && !sp->halo.active;
+        bool mirrored = ((fused && !fusedp) || two_launch_1gpu) && ws.d_mirror && ws.mirror_ok && (mirror_env >= 0 ? mirror_env != 0 : g_cg_mirror != 0);
         int* const mirror_dev = mirrored ? ws.d_mirror : nullptr;
         volatile int* const hm = ws.h_mirror;
         if (mirrored) { hm[0] = 0; hm[1] = 0; }
@@ -3691,7 +3707,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                 }
             }
-            if (use_graph && k >= batch && kend - k == batch && kend <= max_iter) {
+            if (use_graph && k >= batch && kend - k == bsz && kend <= max_iter) {
                 // everything the captured launches bake in: the vectors of the workspace, the operator's value and
                 // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
                 // and pool addresses are handed out again (another mesh with the same row count would otherwise replay
@@ -3710,15 +3726,15 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                                        p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? ((int64_t)g_dict.ncls * 256 + g_dict.S) * 256 + g_dict.C : 0;
-                const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, batch, fgrid, vgrid,
-                                          (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs),
+                const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, bsz, fgrid, vgrid,
+                                          (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs) + (mirror_dev ? 4 : 0),
                                           (int64_t)A->serial, (int64_t)sp->serial};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
                     if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
                     hipGraph_t graph = nullptr;
                     FS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                     int rc_cap = FS_OK;
-                    for (int i = 0; i < batch && rc_cap == FS_OK; ++i) {
+                    for (int i = 0; i < bsz && rc_cap == FS_OK; ++i) {
                         // iteration index (status[2]) and iteration limit (ctrl[2]) from the device: iter = -1
                         if (p2p_fuse) {
                             launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
@@ -3730,8 +3746,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             continue;
                         }
                         rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
                     }
                     const hipError_t e_end = hipStreamEndCapture(s, &graph);
                     FS_CHECK(rc_cap);
@@ -3859,8 +3875,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const int co = k == max_iter ? 1 : 0;
                     if (fuse_sums) {
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
                     } else {
                         FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 3, ws.sums.p, s));
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
@@ -3906,6 +3922,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             }
             if (k > max_iter) finished = true;
         }
+        lap("iterations of the pass");
         if (sp->halo.begun) {          // the exchange started for a product that is not coming any more
             FS_CHECK(fs_halo_end_dev(sp, s));
             sp->halo.begun = false;

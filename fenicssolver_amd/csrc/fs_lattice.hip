@@ -19,8 +19,6 @@
 // with one plan per node class (no union padding) would run on.
 #include "fs_common.h"
 
-#include <hipcub/hipcub.hpp>
-
 struct fs_lattice_shadow {
     fs_space_s* sp = nullptr;       // structure of P A P^T (pattern, SELL / DIA storage, dictionary hints); no mesh, no assembly tables
     fs_matrix_s* A = nullptr;       // its values
@@ -204,14 +202,7 @@ int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out) {
         (rc = written.alloc(n_sh)) != FS_OK || (rc = written.zero(s)) != FS_OK || (rc = sh->rowptr.alloc(n_sh + 1)) != FS_OK) return fail(rc);
     hipLaunchKernelGGL(k_lattice_row_lengths, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, L->perm.p, len.p);
     hipLaunchKernelGGL(k_lattice_dummy_lengths, dim3(fs_grid_for(n_sh)), dim3(FS_BLOCK), 0, s, n_sh, len.p, d_cnt.p);
-    {
-        size_t tb = 0;
-        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tb, len.p, sh->rowptr.p, (int)(n_sh + 1), s) != hipSuccess) return fail(FS_ERR_HIP);
-        dbuf<char> tmp;
-        if ((rc = tmp.alloc((int64_t)tb + 16)) != FS_OK) return fail(rc);
-        if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, len.p, sh->rowptr.p, (int)(n_sh + 1), s) != hipSuccess) return fail(FS_ERR_HIP);
-        if (hipStreamSynchronize(s) != hipSuccess) return fail(FS_ERR_HIP);
-    }
+    if ((rc = fs_scan_exclusive_i32(len.p, sh->rowptr.p, n_sh + 1, s)) != FS_OK) return fail(rc);
     int h_cnt[2] = {0, 0};
     int32_t h_nnz = 0;
     if ((rc = d_cnt.download(h_cnt, 2, s)) != FS_OK) return fail(rc);

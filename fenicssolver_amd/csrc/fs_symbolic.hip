@@ -907,6 +907,17 @@ __global__ void k_extra_pair_keys(const int32_t* __restrict__ pairs, int64_t n, 
     }
 }
 
+// out[i] = sum of in[0 .. i), count entries (the device scan of this file's code object, for translation units without one)
+int fs_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t count, hipStream_t s) {
+    size_t tb = 0;
+    FS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)count, s));
+    dbuf<char> tmp;
+    FS_CHECK(tmp.alloc((int64_t)tb + 16));
+    FS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)count, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 // Hybrid SELL-64 / DIA storage of a space from its CSR pattern (sp->rowptr / colidx over sp->n_nodes_owned rows, columns below
 // sp->n_nodes_local): slice_ptr, dia_ptr / dia_off, sell_col, the counters.  Step 4 of fs_space_create - and what the solver's
 // lattice-ordered shadow of a CG2 box operator is built with (fs_lattice.hip).
