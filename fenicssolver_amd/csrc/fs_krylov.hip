@@ -3054,6 +3054,81 @@ __global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, in
     }
 }
 
+// The same product with the ENTRIES of a slice dealt to the four waves (wave w takes entries w, w + 4, ...) instead of the block-rows:
+// a wave multiplies whole 4 x 4 blocks, so the four values of x behind a column are loaded once per entry instead of once per wave
+// and block-row - 16 + 2 load instructions per entry where the block-row kernel issues 4 x (4 + 2) - and the four partial sums of
+// every row meet in LDS (8 KB, two barriers per slice), added in wave order.  Round 5: the block-row kernel streamed the 1.45 GB of
+// the configs[4] operator at 3.8 TB/s, its texture-address units busy with the x gathers of all four waves.
+#ifndef FS_SPMV4_U
+#define FS_SPMV4_U 1      // (measured on the configs[4] operator: 1: 317 us, 2: 359 us; the block-row kernel: 388 us)
+#endif
+template <bool NT, bool TH>
+__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_ksplit(int64_t n_rows, int64_t n_cols, int64_t n_slices,
+                                                                const int64_t* __restrict__ slice_ptr,
+                                                                const int32_t* __restrict__ sell_col,
+                                                                const int32_t* __restrict__ dia_ptr,
+                                                                const int32_t* __restrict__ dia_off,
+                                                                const double* __restrict__ val, int64_t plane,
+                                                                const double* __restrict__ x, double* __restrict__ y,
+                                                                int64_t nvo, int64_t gv0, int64_t gv1) {
+    __shared__ double part[4][4][FS_SLICE];         // [wave][block-row][lane]
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t cmax = n_cols - 1;
+    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
+        const int64_t r = s * FS_SLICE + lane;
+        const bool edge_rows = TH && s * FS_SLICE >= nvo;         // block-row 3 of these nodes is the dummy identity row
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int32_t dp = dia_ptr[s];
+        const double* __restrict__ vp = val + base + lane;
+        const int32_t* __restrict__ cp = sell_col + base + lane;
+        const int split = dp >= 0 ? dia_off[dp] : FS_SLICE;
+        const int32_t* __restrict__ opa = dia_off + (dp >= 0 ? dp + 1 : 0);
+        const int32_t* __restrict__ opb = opa + (split < FS_SLICE ? width : 0);
+        const bool hi = lane >= split;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        // U entries of this wave in flight together (U x 18 loads per lane); an entry past the end repeats the last one with weight 0
+        constexpr int U = FS_SPMV4_U;
+        for (int k0 = w; k0 < width; k0 += 4 * U) {
+            double2 xa[U], xb[U];
+            double v[U][4][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + 4 * u < width;
+                const int k = live ? k0 + 4 * u : k0;
+                int64_t c = dp >= 0 ? r + (hi ? opb[k] : opa[k]) : (int64_t)fs_col_decode(cp[(int64_t)k * FS_SLICE]);
+                c = c < 0 ? 0 : (c > cmax ? cmax : c);
+                const bool pc = !TH || c < nvo || (c >= gv0 && c < gv1);          // the column node carries a pressure
+                xa[u] = reinterpret_cast<const double2*>(x)[2 * c];
+                xb[u] = reinterpret_cast<const double2*>(x)[2 * c + 1];
+                if (!live) { xa[u] = make_double2(0.0, 0.0); xb[u] = xa[u]; }
+                const double* __restrict__ ve = vp + (int64_t)k * FS_SLICE;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool row_on = live && !(edge_rows && i == 3);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) v[u][i][j] = row_on ? fs_ldv<NT>(&ve[(int64_t)(i * 4 + j) * plane]) : 0.0;
+                    v[u][i][3] = (row_on && pc) ? fs_ldv<NT>(&ve[(int64_t)(i * 4 + 3) * plane]) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += v[u][i][0] * xa[u].x + v[u][i][1] * xa[u].y + v[u][i][2] * xb[u].x + v[u][i][3] * xb[u].y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[w][i][lane] = acc[i];
+        __syncthreads();
+        if (r < n_rows) {
+            // wave w adds up block-row w
+            const double sum = ((part[0][w][lane] + part[1][w][lane]) + part[2][w][lane]) + part[3][w][lane];
+            y[r * 4 + w] = (edge_rows && w == 3) ? x[r * 4 + 3] : sum;
+        }
+        __syncthreads();
+    }
+}
+
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     if (A->bs == 4 && !getenv("FS_SPMV4_GENERIC")) {
         fs_space_s* sp = A->space;
@@ -3064,7 +3139,16 @@ int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
         const int64_t nvo = sp->mesh->n_owned, gv0 = sp->n_nodes_owned, gv1 = sp->n_nodes_owned + (sp->mesh->nv - sp->mesh->n_owned);
 #define FS_SPMV4_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, \
                       sp->dia_ptr.p, sp->dia_off.p, A->val.p, sp->sell_entries, x, y, nvo, gv0, gv1
-        if (spmv_nontemporal(sp, 4)) {
+        static const bool ksplit = !(getenv("FS_SPMV4_KSPLIT") && getenv("FS_SPMV4_KSPLIT")[0] == '0');
+        if (ksplit) {
+            if (spmv_nontemporal(sp, 4)) {
+                if (th) hipLaunchKernelGGL((k_sell_spmv4_ksplit<true, true>), FS_SPMV4_ARGS);
+                else hipLaunchKernelGGL((k_sell_spmv4_ksplit<true, false>), FS_SPMV4_ARGS);
+            } else {
+                if (th) hipLaunchKernelGGL((k_sell_spmv4_ksplit<false, true>), FS_SPMV4_ARGS);
+                else hipLaunchKernelGGL((k_sell_spmv4_ksplit<false, false>), FS_SPMV4_ARGS);
+            }
+        } else if (spmv_nontemporal(sp, 4)) {
             if (th) hipLaunchKernelGGL((k_sell_spmv4_rows<true, true>), FS_SPMV4_ARGS);
             else hipLaunchKernelGGL((k_sell_spmv4_rows<true, false>), FS_SPMV4_ARGS);
         } else {
