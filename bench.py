@@ -239,6 +239,50 @@ class P2Problem:
     step = Problem.step
 
 
+class P2FileOrderProblem:
+    """BASELINE configs[3]'s operator on the cube as a mesh FILE would deliver it (one GPU): vertices and cells randomly permuted,
+    uploaded through fs_mesh_create (renumber: through the library's locality order first, as fem.Mesh does for file meshes); CG2 space
+    on it - nothing for DIA slices or the row dictionary to find: the streaming SELL product every Gmsh / FreeCAD P2 case takes."""
+
+    pipelined = False
+
+    def __init__(self, n, axis, renumber, seed=0):
+        xyz, cells, _ = B.DeviceMesh.box(n, n, n).get()
+        nv = len(xyz)
+        rng = np.random.default_rng(seed)
+        new_of_old = rng.permutation(nv).astype(np.int64)
+        co = np.empty_like(xyz)
+        co[new_of_old] = xyz
+        ce = np.sort(new_of_old[cells], axis=1)[rng.permutation(len(cells))].astype(np.int32)
+        del cells
+        t0 = time.perf_counter()
+        if renumber:
+            self.mesh, vorder, _ = B.DeviceMesh.renumbered(co, ce)
+            co = co[vorder]                      # device vertex order
+        else:
+            self.mesh = B.DeviceMesh(co, ce)
+        B.synchronize()
+        t1 = time.perf_counter()
+        self.V = B.DeviceSpace(self.mesh, 1, degree=2)
+        B.synchronize()
+        t2 = time.perf_counter()
+        self.mesh_ms, self.symbolic_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        edges = self.V.edges().astype(np.int64)
+        cv = co[:, axis]
+        cm = 0.5 * (cv[edges[:, 0]] + cv[edges[:, 1]])
+        c = np.concatenate([cv, cm])             # node = vertex, then edge in the space's order (one GPU)
+        lo, hi = np.nonzero(c == 0.0)[0], np.nonzero(c == 1.0)[0]
+        self.dofs = np.concatenate([lo, hi]).astype(np.int32)
+        self.vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+        self.A = B.DeviceMatrix(self.V)
+        self.b = B.DeviceVector(self.V.n_owned)
+        self.x = B.DeviceVector(self.V.n_owned)
+        self.n_owned = self.V.n_owned
+        self.exact_owned = 350.0 - 50.0 * c
+
+    step = Problem.step
+
+
 def p2_global_dofs(n):
     return (n + 1) ** 3 + 3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3      # vertices + axis, face-diagonal and body-diagonal edges
 
@@ -400,11 +444,17 @@ def strong_leg(n, axis, rank, world, rtol, barrier, steps=3):
     return res
 
 
-def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="auto"):
-    """BASELINE configs[3]: P2 heat conduction, unit cube n (107 -> 9 938 375 DOF), z-slabs over the ranks."""
+def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="auto", mesh="structured"):
+    """BASELINE configs[3]: P2 heat conduction, unit cube n (107 -> 9 938 375 DOF), z-slabs over the ranks.
+    mesh = shuffled / renumbered (one GPU): the same cube in FILE order (P2FileOrderProblem)."""
     zplanes = partition.slab_ranges(n + 1, world)[rank]
     t0 = time.perf_counter()
-    prob = P2Problem(n, zplanes, axis, rank, world)
+    if mesh != "structured":
+        if world != 1:
+            sys.exit("bench.py --workload p2 --mesh %s is a one-GPU measurement" % mesh)
+        prob = P2FileOrderProblem(n, axis, renumber=mesh == "renumbered")
+    else:
+        prob = P2Problem(n, zplanes, axis, rank, world)
     setup_s = time.perf_counter() - t0
     name, trial = choose_recurrence(prob, rtol, world, recurrence, barrier)
     elapsed, asm_ms, st, name = timed_steps_with_fallback(prob, rtol, steps, barrier, name, trial, world, warmup)
@@ -414,7 +464,10 @@ def p2_leg(n, axis, rank, world, rtol, barrier, steps=2, warmup=1, recurrence="a
     n_dof = p2_global_dofs(n)
     k = kernel_rates(st, prob.V)
     return {"workload": "BASELINE configs[3]: P2 heat conduction, unit cube n=%d (%d DOF, %d tets), k=20, T=350/300 on the %s-faces, "
-                        "Jacobi-PCG rtol %g, %s" % (n, n_dof, 6 * n ** 3, "xyz"[axis], rtol, "1 GPU" if world == 1 else "%d z-slabs" % world),
+                        "Jacobi-PCG rtol %g, %s%s" % (n, n_dof, 6 * n ** 3, "xyz"[axis], rtol, "1 GPU" if world == 1 else "%d z-slabs" % world,
+                                                       "" if mesh == "structured" else "; mesh uploaded with RANDOMLY PERMUTED vertices and cells (%s)" % (
+                                                           "the library's locality renumbering on" if mesh == "renumbered" else "renumbering off")),
+            "mesh_ms": round(prob.mesh_ms, 2),
             "n_dof": n_dof, "dof_per_s": round(n_dof / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
             "assemble_ms": round(asm_ms, 4), "cg_iterations": st["iterations"], "true_rel_residual": st["true_rel_residual"],
             "ms_per_iteration": round((ms - asm_ms) / max(st["iterations"], 1), 5),
@@ -636,12 +689,12 @@ def main():
     if a.workload == "p2":      # BASELINE configs[3] as the timed leg: the fixed 9.94 M-DOF problem over the ranks (strong)
         n = a.n if a.n != 99 else 107
         axis = a.bc_axis if a.bc_axis is not None else 2
-        r = p2_leg(n, axis, rank, world, a.rtol, barrier, steps=a.steps, warmup=a.warmup, recurrence=a.recurrence)
+        r = p2_leg(n, axis, rank, world, a.rtol, barrier, steps=a.steps, warmup=a.warmup, recurrence=a.recurrence, mesh=a.mesh)
         if rank == 0:
             out = dict(base, value=r["dof_per_s"], steps=a.steps, warmup=a.warmup, ms_per_step=r["ms_per_step"], scaling="strong",
                        config={"workload": r["workload"], "n_dof": r["n_dof"], "n_cells": 6 * n ** 3, "parallelism": par,
                                "cg_iterations": r["cg_iterations"], "true_rel_residual": r["true_rel_residual"], "recurrence": r["recurrence"]},
-                       assemble_ms_per_step=r["assemble_ms"], symbolic_ms=r["symbolic_ms"],
+                       assemble_ms_per_step=r["assemble_ms"], symbolic_ms=r["symbolic_ms"], mesh_ms=r["mesh_ms"],
                        parity={"max_abs_error_vs_exact_profile": r["max_abs_error_vs_exact_profile"]})
             k = r["spmv"]
             hbm = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * k["rows_rank0"] > (256 << 20)

@@ -78,11 +78,13 @@ def kernel_stats():
     out = os.path.join(OUT, TAG + "_kernel_stats.csv")
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
-        # live_* exclude the no-op launches of a CG batch enqueued after convergence (< 10 % of the max)
+        # live_* exclude the no-op launches of a CG batch enqueued after convergence (< 35 % of the 90th percentile: a launch of the one-launch
+        # iteration that returns on the status word still takes 5 us of a live launch's 20)
         w.writerow(["phase", "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct_of_gpu_time",
                     "live_calls", "live_avg_us"])
         for (ph, k), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            live = [d for d in a[4] if d >= 0.1 * a[3]]
+            ref = sorted(a[4])[int(0.9 * (len(a[4]) - 1))]          # (90th percentile: one slow first launch must not define `live`)
+            live = [d for d in a[4] if d >= 0.35 * ref]
             w.writerow([ph, k, a[0], "%.1f" % (a[1] / 1e3), "%.3f" % (a[1] / a[0] / 1e3), "%.3f" % (a[2] / 1e3),
                         "%.3f" % (a[3] / 1e3), "%.2f" % (100 * a[1] / total), len(live),
                         "%.3f" % (sum(live) / len(live) / 1e3)])
