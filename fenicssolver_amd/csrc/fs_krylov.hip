@@ -3459,9 +3459,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     lap("diagonal, |b|, threshold");
     if (ds) {
         // the scaled system needs ghost scale factors too: refresh them through the halo
-        double* sc_local = ws.sc_local.p;
-        FS_HIP(hipMemcpyAsync(sc_local, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        FS_CHECK(fs_halo_exchange_dev(sp, sc_local, s));
+        // (no halo plan: no ghost entries - the factors are read where they are)
+        double* sc_local = sp->halo.active ? ws.sc_local.p : ws.dinv.p;
+        if (sp->halo.active) {
+            FS_HIP(hipMemcpyAsync(sc_local, ws.dinv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            FS_CHECK(fs_halo_exchange_dev(sp, sc_local, s));
+        }
         const int g2 = fs_grid_for(sp->n_slices * 64, FS_BLOCK, 8192);
         const auto scale_copy1 = [&]() {
             hipLaunchKernelGGL(k_scale_copy<1>, dim3(g2), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->sell_col.p, A->val.p, sp->sell_entries, sc_local, ws.aval.p);
@@ -3694,6 +3697,10 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         volatile int* const hm = ws.h_mirror;
         if (mirrored) { hm[0] = 0; hm[1] = 0; }
         const int bsz = mirrored ? g_cg_sub : batch;
+        // the launches that carry the event samples go out one by one before the graphs take over: the first 32 iterations (samples
+        // at iterations 1 and 17), or - with the progress words - the first 16 (samples at 1 and 9)
+        const int first_plain = mirrored ? std::min(batch, 16) : batch;
+        const int sample_step = mirrored ? std::min(sample_every, 8) : sample_every;
         int seen = 0;
         auto t_seen = std::chrono::steady_clock::now();
         while (!finished) {
@@ -3754,7 +3761,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                     launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
                 }
-                if (graph_sized && k >= batch && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
+                if (graph_sized && k >= first_plain && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
                                            ws.ctrl.p, ws.scal.p, snd2[0].own_recv, red2[0].own_buf,
@@ -3777,7 +3784,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     k = kend;
                 }
                 for (; k < kend; ++k) {
-                    const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
+                    const bool sample = (k % sample_step == 1 % sample_step) && n_samples < krylov_ws::NSAMPLE;
                     if (sample) {
                         ws.sample_iter[n_samples] = k;
                         FS_HIP(hipEventRecord(ws.ev[n_samples][0], s));
@@ -3791,7 +3798,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                 }
             }
-            if (use_graph && k >= batch && kend - k == bsz && kend <= max_iter) {
+            if (use_graph && k >= first_plain && kend - k == bsz && kend <= max_iter) {
                 // everything the captured launches bake in: the vectors of the workspace, the operator's value and
                 // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
                 // and pool addresses are handed out again (another mesh with the same row count would otherwise replay
@@ -3845,7 +3852,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 k = kend;
             }
             for (; k < kend; ++k) {
-                const bool sample = (k % sample_every == 1 % sample_every) && n_samples < krylov_ws::NSAMPLE;
+                const bool sample = (k % sample_step == 1 % sample_step) && n_samples < krylov_ws::NSAMPLE;
                 if (sample) ws.sample_iter[n_samples] = k;
                 if (bicg) {
                     const int co = k == max_iter ? 1 : 0;
