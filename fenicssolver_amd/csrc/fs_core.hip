@@ -199,12 +199,11 @@ extern "C" int fs_init(int device_id) {
     // seven eighths of the first sparsity pattern of a process.  FS_PRELOAD=0: load on first use, as the runtime does by itself.
     static const bool preload = !(getenv("FS_PRELOAD") && getenv("FS_PRELOAD")[0] == '0');
     if (preload) {
+        // (what every solve needs.  The AMG object - 4.7 MB, its own rocPRIM sorts and scans, 40 ms to load - and the saddle-point
+        // and communication objects are loaded by their first launch: a heat-conduction case never pays for them)
         fs_symbolic_preload();
         fs_assemble_preload();
         fs_krylov_preload();
-        fs_amg_preload();
-        fs_saddle_preload();
-        fs_comm_preload();
     }
     return FS_OK;
 }
