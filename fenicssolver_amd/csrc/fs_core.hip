@@ -1,5 +1,6 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
+#include <chrono>
 #include <atomic>
 #include <mutex>
 #include "fs_kernels.h"
@@ -201,9 +202,22 @@ extern "C" int fs_init(int device_id) {
     if (preload) {
         // (what every solve needs.  The AMG object - 4.7 MB, its own rocPRIM sorts and scans, 40 ms to load - and the saddle-point
         // and communication objects are loaded by their first launch: a heat-conduction case never pays for them)
+        static const bool init_timing = getenv("FS_INIT_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!init_timing) return;
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[fs_init timing] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
+        // (FS_INIT_TIMING=1, round 5, MI355X box: 40 ms the set-up object with its rocPRIM instantiations, 3 + 6 ms the other two - of
+        // 170 - 310 ms of fs_init, the rest being the HIP runtime's own start: hipGetDeviceCount 117 ms, the stream 20 ms)
         fs_symbolic_preload();
+        lap("set-up object (rocPRIM)");
         fs_assemble_preload();
+        lap("assembly object");
         fs_krylov_preload();
+        lap("Krylov object");
     }
     return FS_OK;
 }
