@@ -3680,6 +3680,12 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // same way; the RCCL iteration is not - ncclSend / ncclRecv / ncclAllReduce are host calls)
         // (automatic mode: every size - the launch gaps are 10 % of an iteration at 1 M rows and still 1.5 % at 10 M)
         const bool graph_sized = graph_mode != 0;
+        // The FIRST graph a process instantiates costs 9 ms (the runtime's graph machinery; later ones 0.1 ms), twelve times what the
+        // graphs save a 300-iteration solve at 1 M rows: the first solve of a process launches its iterations one by one - a
+        // one-shot run never pays, a time loop pays in its second step (tools/probes/first_step_probe.py; FS_CG_GRAPH=1 forces graphs)
+        static bool first_solve_done = false;
+        const bool graphs_allowed = first_solve_done || graph_mode > 0;
+        struct mark_done { bool& f; ~mark_done() { f = true; } } mark_first_solve{first_solve_done};
         const bool fusedp = fusedp_ok && p2p_fuse && !bicg;
         if (fusedp) fusedp_used = true;
         const bool use_graph = ds && !bicg && !pipelined && graph_sized && !fused && !fusedp &&
@@ -3761,7 +3767,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                     launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
                 }
-                if (graph_sized && k >= first_plain && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
+                if (graph_sized && graphs_allowed && k >= first_plain && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
                                            ws.ctrl.p, ws.scal.p, snd2[0].own_recv, red2[0].own_buf,
@@ -3798,7 +3804,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     }
                 }
             }
-            if (use_graph && k >= first_plain && kend - k == bsz && kend <= max_iter) {
+            if (use_graph && graphs_allowed && k >= first_plain && kend - k == bsz && kend <= max_iter) {
                 // everything the captured launches bake in: the vectors of the workspace, the operator's value and
                 // structure arrays - and the serial numbers of matrix and space, because a destroyed operator's heap
                 // and pool addresses are handed out again (another mesh with the same row count would otherwise replay
