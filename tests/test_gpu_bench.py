@@ -38,6 +38,8 @@ def test_default_command_prints_the_contract_line(gpu):
     assert 0.3 <= r["frac"] <= 1.0 and abs(r["achieved"] - r["required_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) <= 1e-3 * r["achieved"]
     assert r["csr_equivalent_GBps"] > r["achieved"] and 0.3 <= r["iteration"]["frac"] <= 1.0 and 0.5 <= r["update_kernel"]["frac"] <= 1.0
     assert d["one_shot_dof_per_s"] < d["value"] and r["one_shot"]["dof_per_s"] < r["dof_per_s"]
+    # the first step of the process is reported by itself, the cold figure includes fs_init
+    assert d["first_step_ms"] > d["ms_per_step"] and d["cold_one_shot_dof_per_s"] < d["one_shot_dof_per_s"] and d["init_ms"] > 0
     # the BASELINE operator has repeated rows: the line says so and carries the streaming kernel's roofline beside it
     assert "k_dict_spmv" in r["kernel"] and "note_row_dictionary" in r
     s = r["streaming_kernel"]
@@ -56,8 +58,12 @@ def test_default_command_prints_the_contract_line(gpu):
     (("--cells", "23", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-case"), "P1 Poisson"),
     (("--workload", "p2", "--cells", "15", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"), "configs[3]"),
     (("--cells", "15", "--mesh", "renumbered", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-case"), "RANDOMLY PERMUTED"),
+    (("--workload", "p2", "--cells", "11", "--mesh", "renumbered", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"), "RANDOMLY PERMUTED"),
+    (("--workload", "p2", "--cells", "11", "--mesh", "shuffled", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"), "renumbering off"),
 ])
 def test_side_workloads_print_a_line(gpu, args, expect):
     d = _bench(*args)
     assert expect in d["config"]["workload"] and d["value"] > 0 and d["config"]["true_rel_residual"] <= 1.1e-8
     assert "roofline" in d and d["n_gpus"] == 1
+    if "--workload" in args:       # the CG2 legs carry their own check: the linear profile is in the space
+        assert d["parity"]["max_abs_error_vs_exact_profile"] <= 1e-4
