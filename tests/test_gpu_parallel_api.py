@@ -39,7 +39,7 @@ def _periodic_subdomain(axis, length):
     return Periodic()
 
 
-def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip=False, periodic=None):
+def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip=False, periodic=None, source_field=False):
     """periodic: axis of a periodic_boundary (reference SolverBase.py:260-275) - 1: across the slabs a decomposition cuts (slave
     and master on one rank), 2: ALONG the decomposition axis (the first and the last rank become neighbours; the hot / HTC faces
     then move to x)."""
@@ -85,6 +85,9 @@ def _heat_case(n=5, transient=False, degree=1, supg=False, distributed=False, ip
     solver.material['conductivity'] = {'lower': {'subdomain_id': 1, 'value': 0.6},
                                        'upper': {'subdomain_id': 2, 'value': 6.0}}
     solver.body_source = {'heater': {'subdomain_id': 2, 'value': 50.0}}
+    if source_field:      # a body source given as an Expression: its nodal interpolant, also under the SUPG test function (round 5)
+        from fenicssolver_amd.fem import Expression
+        solver.body_source = Expression("50.0 + 30.0*x[0] - 20.0*x[1]*x[2]", degree=degree)
     return solver
 
 
@@ -251,7 +254,8 @@ CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=T
          "elasticity_fine": lambda: _elastic_case(fine=3), "elasticity_pfield": lambda: _elastic_case(pressure_field=True),
          "elasticity_p2_pfield": lambda: _elastic_case(degree=2, pressure_field=True),
          "heat_file": _file_mesh_case, "heat_file_p2": lambda: _file_mesh_case(2),
-         "heat_supg": lambda: _heat_case(supg=True), "heat_ip": lambda: _heat_case(ip=True), "heat_ip_cn": lambda: _heat_case(ip=True, transient=True),
+         "heat_supg": lambda: _heat_case(supg=True), "heat_supg_field": lambda: _heat_case(supg=True, source_field=True),
+         "heat_p2_supg_field": lambda: _heat_case(supg=True, source_field=True, degree=2), "heat_ip": lambda: _heat_case(ip=True), "heat_ip_cn": lambda: _heat_case(ip=True, transient=True),
          "heat_p2": _heat_p2_case, "elasticity_p2": _elastic_p2_case,
          # periodic_boundary under decomposition (round 4): slaves owned by their masters' rank, masters as extra ghosts
          "heat_periodic_y": lambda: _heat_case(periodic=1), "heat_periodic_z": lambda: _heat_case(periodic=2),
