@@ -33,6 +33,8 @@ struct bcsr {
     int64_t nnz = 0;                // blocks
     dbuf<int32_t> rowptr, col;
     dbuf<double> val;               // [nnz][br][bc]
+    dbuf<float> val32;              // the same rounded to fp32 (levels >= 1 and transfer operators of a finished hierarchy: what the
+                                    // V-cycle streams; the fp64 values stay for the set-up of the next level and for inspection)
 };
 
 struct amg_level {
@@ -45,6 +47,7 @@ struct amg_level {
     int64_t n_agg = 0;
     dbuf<int32_t> pt_ptr, pt_entry, pt_row;   // transpose index of P (entries sorted by column)
     dbuf<double> rt_val;  // R = P^T blocks [nb][bs] in pt order: the restriction streams them contiguously
+    dbuf<float> rt_val32; // rounded to fp32 (the SAME rounded numbers as P.val32: R stays the exact transpose of P)
     dbuf<double> dinv;    // [n]
     dbuf<uint8_t> ident;  // [n] scalar row has no off-diagonal value (eliminated Dirichlet dof)
     dbuf<double> B;       // near-null space [n][nb]
@@ -900,13 +903,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_grp(int64_t n, const int
     if (lg == 0 && row < n) y[row] = MODE ? b[row] - acc : acc;
 }
 
+template <typename T> struct fs_pair_of;
+template <> struct fs_pair_of<double> { typedef double2 type; };
+template <> struct fs_pair_of<float> { typedef float2 type; };
+
 // the same with one wave per NODE (block row) of a level with large blocks: the lanes stride over the contiguous values
 // of the block row (coalesced 8-byte loads; the per-scalar-row kernels read 48-byte pieces 288 bytes apart and lean on
 // the caches for the rest of the line: 3.5 TB/s on the 0.9 GB level-1 operator of configs[2]), every lane keeps BS
 // partial sums, butterfly reduction, lanes 0..BS-1 write
-template <int BS, int MODE>
+template <int BS, int MODE, typename VT = double>
 __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const int32_t* __restrict__ rp,
-                                                             const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                             const int32_t* __restrict__ ci, const VT* __restrict__ val,
                                                              const double* __restrict__ x, const double* __restrict__ b,
                                                              double* __restrict__ y) {
     constexpr int BB = BS * BS;
@@ -916,13 +923,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const i
     for (; i < nn; i += stride) {
         const int32_t e0 = rp[i];
         const int total = (rp[i + 1] - e0) * BB;
-        const double* row = val + (int64_t)e0 * BB;
+        const VT* row = val + (int64_t)e0 * BB;
         double acc[BS];
 #pragma unroll
         for (int r = 0; r < BS; ++r) acc[r] = 0.0;
-        if (BS % 2 == 0) {           // a lane takes one row of one block: BS/2 16-byte loads of values and of x
+        if (BS % 2 == 0) {           // a lane takes one row of one block: BS/2 16-byte (fp32 values: 8-byte) loads of values, BS/2 16-byte loads of x
             constexpr int HP = BS / 2;
-            const double2* row2 = reinterpret_cast<const double2*>(row);
+            typedef typename fs_pair_of<VT>::type VT2;
+            const VT2* row2 = reinterpret_cast<const VT2*>(row);
             const int parts = (rp[i + 1] - e0) * BS;
             for (int idx = lane; idx < parts; idx += 64) {
                 const int e = idx / BS, r = idx - e * BS;
@@ -930,8 +938,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const i
                 double v = 0.0;
 #pragma unroll
                 for (int h = 0; h < HP; ++h) {
-                    const double2 a = row2[(int64_t)idx * HP + h], xx = xv[h];
-                    v += a.x * xx.x + a.y * xx.y;
+                    const VT2 a = row2[(int64_t)idx * HP + h];
+                    const double2 xx = xv[h];
+                    v += (double)a.x * xx.x + (double)a.y * xx.y;
                 }
 #pragma unroll
                 for (int rr = 0; rr < BS; ++rr)
@@ -941,7 +950,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const i
             for (int idx = lane; idx < total; idx += 64) {
                 const int e = idx / BB, rem = idx - e * BB;
                 const int r = rem / BS, c = rem - r * BS;
-                const double v = row[idx] * x[(int64_t)ci[e0 + e] * BS + c];
+                const double v = (double)row[idx] * x[(int64_t)ci[e0 + e] * BS + c];
 #pragma unroll
                 for (int rr = 0; rr < BS; ++rr)
                     if (rr == r) acc[rr] += v;
@@ -977,9 +986,9 @@ __global__ void k_prolong_add(int64_t n_f, int br, int bc, const int32_t* __rest
 }
 
 // the same for a known block shape: 16 lanes per fine node stride over the values of its block row
-template <int BR, int BC>
+template <int BR, int BC, typename VT = double>
 __global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, const int32_t* __restrict__ rp,
-                                                              const int32_t* __restrict__ ci, const double* __restrict__ val,
+                                                              const int32_t* __restrict__ ci, const VT* __restrict__ val,
                                                               const double* __restrict__ xc, double* __restrict__ xf) {
     constexpr int BB = BR * BC;
     const int sub = threadIdx.x & 15;
@@ -988,13 +997,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, cons
     for (; i < nn_f; i += stride) {
         const int32_t e0 = rp[i];
         const int total = (rp[i + 1] - e0) * BB;
-        const double* row = val + (int64_t)e0 * BB;
+        const VT* row = val + (int64_t)e0 * BB;
         double acc[BR];
 #pragma unroll
         for (int r = 0; r < BR; ++r) acc[r] = 0.0;
-        if (BC % 2 == 0) {           // a lane takes one row of one block: BC/2 16-byte loads of values and of xc
+        if (BC % 2 == 0) {           // a lane takes one row of one block: BC/2 16-byte (fp32 values: 8-byte) loads of values, BC/2 16-byte loads of xc
             constexpr int HP = BC / 2;
-            const double2* row2 = reinterpret_cast<const double2*>(row);
+            typedef typename fs_pair_of<VT>::type VT2;
+            const VT2* row2 = reinterpret_cast<const VT2*>(row);
             const int parts = (rp[i + 1] - e0) * BR;
             for (int idx = sub; idx < parts; idx += 16) {
                 const int e = idx / BR, r = idx - e * BR;
@@ -1002,8 +1012,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, cons
                 double v = 0.0;
 #pragma unroll
                 for (int h = 0; h < HP; ++h) {
-                    const double2 a = row2[(int64_t)idx * HP + h], xx = xv[h];
-                    v += a.x * xx.x + a.y * xx.y;
+                    const VT2 a = row2[(int64_t)idx * HP + h];
+                    const double2 xx = xv[h];
+                    v += (double)a.x * xx.x + (double)a.y * xx.y;
                 }
 #pragma unroll
                 for (int rr = 0; rr < BR; ++rr)
@@ -1013,7 +1024,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_prolong_add_grp(int64_t nn_f, cons
             for (int idx = sub; idx < total; idx += 16) {
                 const int e = idx / BB, rem = idx - e * BB;
                 const int r = rem / BC, c = rem - r * BC;
-                const double v = row[idx] * xc[(int64_t)ci[e0 + e] * BC + c];
+                const double v = (double)row[idx] * xc[(int64_t)ci[e0 + e] * BC + c];
 #pragma unroll
                 for (int rr = 0; rr < BR; ++rr)
                     if (rr == r) acc[rr] += v;
@@ -1046,9 +1057,9 @@ __global__ void k_transpose_blocks(int64_t nq, int br, int bc, const int32_t* __
 
 // out = P^T rf : one wave per coarse node; lanes stride over the entries of the column (contiguous R blocks),
 // each lane accumulates its nb partial sums, fixed-order shuffle reduction
-template <int BR, int BC>
+template <int BR, int BC, typename VT = double>
 __global__ void __launch_bounds__(FS_BLOCK) k_restrict(int64_t nn_c, const int32_t* __restrict__ pt_ptr,
-                                                        const int32_t* __restrict__ pt_row, const double* __restrict__ rt,
+                                                        const int32_t* __restrict__ pt_row, const VT* __restrict__ rt,
                                                         const double* __restrict__ rf, double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     int64_t I = (int64_t)blockIdx.x * (FS_BLOCK / 64) + (threadIdx.x >> 6);
@@ -1063,13 +1074,14 @@ __global__ void __launch_bounds__(FS_BLOCK) k_restrict(int64_t nn_c, const int32
 #pragma unroll
             for (int r = 0; r < BR; ++r) rv[r] = rr[r];
             double blk[BR * BC];
-            if ((BR * BC) % 2 == 0) {     // blocks are 16-byte aligned
-                const double2* b2 = reinterpret_cast<const double2*>(rt + (int64_t)q * BR * BC);
+            if ((BR * BC) % 2 == 0) {     // blocks are 16-byte (fp32: 8-byte) aligned
+                typedef typename fs_pair_of<VT>::type VT2;
+                const VT2* b2 = reinterpret_cast<const VT2*>(rt + (int64_t)q * BR * BC);
 #pragma unroll
-                for (int h = 0; h < BR * BC / 2; ++h) { const double2 t = b2[h]; blk[2 * h] = t.x; blk[2 * h + 1] = t.y; }
+                for (int h = 0; h < BR * BC / 2; ++h) { const VT2 t = b2[h]; blk[2 * h] = (double)t.x; blk[2 * h + 1] = (double)t.y; }
             } else {
 #pragma unroll
-                for (int h = 0; h < BR * BC; ++h) blk[h] = rt[(int64_t)q * BR * BC + h];
+                for (int h = 0; h < BR * BC; ++h) blk[h] = (double)rt[(int64_t)q * BR * BC + h];
             }
 #pragma unroll
             for (int c = 0; c < BC; ++c)
@@ -1254,6 +1266,53 @@ static int spgemm(int64_t n_out, int64_t n_cols, int br, int bk, int bc, bool tr
     return FS_OK;
 }
 
+// ---- fp32 storage of what the V-cycle streams below the fine level ------------------------------------------------------------
+// The V-cycle is a PRECONDITIONER: CG outside works on the fp64 operator with fp64 vectors and stops on the fp64 residual.  Its
+// coarse operators (0.9 GB at level 1 of configs[2], four products per cycle) and its transfer operators are streamed once per
+// use and bound by HBM, so they are kept rounded to fp32 - half the bytes; vectors, diagonals, eigenvalue bounds and every
+// accumulation stay fp64 (a value is widened as it is loaded).  R is rounded from the same numbers as P (it stays P^T exactly) and a
+// symmetric A_l stays symmetric up to what the two summation orders of the Galerkin product differed by before rounding.
+// fs_set_option("amg_coarse_fp32", 0) / FS_AMG_FP32=0: fp64 storage throughout (round-4 behaviour).
+static int g_amg_fp32 = -1;
+void fs_amg_set_coarse_fp32(int on) { g_amg_fp32 = on ? 1 : 0; }
+static bool amg_fp32() {
+    if (g_amg_fp32 < 0) {
+        const char* e = getenv("FS_AMG_FP32");
+        g_amg_fp32 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_amg_fp32 != 0;
+}
+
+__global__ void k_round_to_f32(int64_t n, const double* __restrict__ src, float* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (float)src[i];
+}
+static int round_to_f32(const dbuf<double>& src, int64_t count, dbuf<float>& dst, hipStream_t s) {
+    FS_CHECK(dst.alloc(std::max<int64_t>(count, 1)));
+    if (count > 0) hipLaunchKernelGGL(k_round_to_f32, dim3(fs_grid_for(count, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, count, src.p, dst.p);
+    FS_KERNEL_CHECK();
+    return FS_OK;
+}
+// the level operator: only where the wave-per-node product (6 x 6 blocks) streams it
+static bool level_uses_node_waves(const amg_level* L) {
+    static const bool no_node = getenv("FS_AMG_NO_NODE_WAVES") != nullptr;
+    return !no_node && L->bs == 6 && L->nn > 0 && L->A.nnz >= 4 * L->nn;
+}
+static int level_operator_to_f32(amg_level* L, hipStream_t s) {
+    if (!amg_fp32() || !level_uses_node_waves(L)) return FS_OK;
+    return round_to_f32(L->A.val, L->A.nnz * 36, L->A.val32, s);
+}
+// the transfer operators of a level: the block shapes with a templated restriction / prolongation
+static int level_transfers_to_f32(amg_level* L, hipStream_t s) {
+    if (!amg_fp32() || L->P.nnz <= 0) return FS_OK;
+    if (!((L->P.br == 3 || L->P.br == 6) && L->P.bc == 6)) return FS_OK;
+    const int64_t count = L->P.nnz * L->P.br * L->P.bc;
+    FS_CHECK(round_to_f32(L->P.val, count, L->P.val32, s));
+    return round_to_f32(L->rt_val, count, L->rt_val32, s);
+}
+
+static int coarse_level_spmv(amg_level* L, const double* x, const double* b, double* y, int mode, hipStream_t s);
 static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, double* y, int mode, hipStream_t s) {
     amg_level* L = (l == 0 && M->dist0) ? M->dist0 : M->lv[l];
     if (l == 0) {
@@ -1262,12 +1321,21 @@ static int level_spmv(fs_amg_s* M, int l, const double* x, const double* b, doub
         hipLaunchKernelGGL(k_amg_sub, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, b, L->t.p, y);
         return FS_OK;
     }
+    return coarse_level_spmv(L, x, b, y, mode, s);
+}
+
+// y = A_l x (mode 0) or b - A_l x (mode 1) on the level's own block CSR
+static int coarse_level_spmv(amg_level* L, const double* x, const double* b, double* y, int mode, hipStream_t s) {
     // 6x6 blocks: a wave per node over the contiguous block row
-    static const bool no_node = getenv("FS_AMG_NO_NODE_WAVES") != nullptr;
-    if (!no_node && L->bs == 6 && L->nn > 0 && L->A.nnz >= 4 * L->nn) {
+    if (level_uses_node_waves(L)) {
         const int gg = fs_grid_for(L->nn * 64, FS_BLOCK, 1 << 20);
-        if (mode) hipLaunchKernelGGL((k_bcsr_spmv_node<6, 1>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
-        else hipLaunchKernelGGL((k_bcsr_spmv_node<6, 0>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
+        if (L->A.val32.p) {
+            if (mode) hipLaunchKernelGGL((k_bcsr_spmv_node<6, 1, float>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val32.p, x, b, y);
+            else hipLaunchKernelGGL((k_bcsr_spmv_node<6, 0, float>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val32.p, x, b, y);
+        } else {
+            if (mode) hipLaunchKernelGGL((k_bcsr_spmv_node<6, 1>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
+            else hipLaunchKernelGGL((k_bcsr_spmv_node<6, 0>), dim3(gg), dim3(FS_BLOCK), 0, s, L->nn, L->A.rowptr.p, L->A.col.p, L->A.val.p, x, b, y);
+        }
         return FS_OK;
     }
     // long rows on few nodes: 16 lanes per scalar row
@@ -1310,6 +1378,13 @@ static int bcsr_spmv_setup(amg_level* L, const double* x, double* y, hipStream_t
     return FS_OK;
 }
 
+// set-up products of a level >= 1: the product of the V-cycle where the level is one of 6 x 6 blocks (a wave per node over the
+// fp32 values: 15 power-iteration steps on level 1 of configs[2] 4.4 -> ms), else the per-row kernels above
+static int coarse_product(amg_level* L, const double* x, double* y, hipStream_t s) {
+    if (level_uses_node_waves(L)) return coarse_level_spmv(L, x, nullptr, y, 0, s);
+    return bcsr_spmv_setup(L, x, y, s);
+}
+
 static int dot_host(fs_amg_s* M, const double* x, const double* y, int64_t n, double* out, hipStream_t s) {
     const int g = fs_grid_for(n, FS_BLOCK, 1024);
     hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(FS_BLOCK), 0, s, x, y, n, M->partials.p);
@@ -1339,14 +1414,21 @@ static int estimate_lmax(fs_amg_s* M, amg_level* L, int steps, hipStream_t s) {
     const double growth = L->gersh > 1.0 ? L->gersh : 1.0;
     int safe = steps;
     while (safe > 1 && safe * log10(growth) > 250.0) --safe;
+    // the fine products through the row dictionary where the rows repeat (uniform boxes: 60 instead of 328 us at configs[2])
+    struct dict_guard { bool on = false; ~dict_guard() { if (on) fs_dict_end(); } } dict_scope;
+    static const bool lmax_dict = !(getenv("FS_AMG_LMAX_DICT") && getenv("FS_AMG_LMAX_DICT")[0] == '0');
+    if (fine && lmax_dict) {
+        dict_scope.on = true;
+        FS_CHECK(fs_dict_begin(M->fine, s));
+    }
     for (int it = 0; it + 1 < safe; ++it) {
         if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
-        else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
+        else FS_CHECK(coarse_product(L, v.p, w.p, s));
         hipLaunchKernelGGL(k_amg_scale_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, w.p, 1.0);
         std::swap(v.p, w.p);
     }
     if (fine) FS_CHECK(fs_spmv_dev(M->fine, v.p, w.p, s));
-    else FS_CHECK(bcsr_spmv_setup(L, v.p, w.p, s));
+    else FS_CHECK(coarse_product(L, v.p, w.p, s));
     double num = 0.0, den = 0.0;
     FS_CHECK(dot_host(M, v.p, w.p, L->n, &num, s));
     hipLaunchKernelGGL(k_amg_div_dinv, dim3(fs_grid_for(L->n)), dim3(FS_BLOCK), 0, s, L->n, L->dinv.p, v.p, w.p);
@@ -1511,6 +1593,7 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     amg_tick("  smoothed P");
     // transpose index of P
     FS_CHECK(build_p_transpose(L, nn, n_agg, bs, nb, s));
+    FS_CHECK(level_transfers_to_f32(L, s));
     amg_tick("  transpose");
     // A_c = P^T (A P)
     {
@@ -1524,6 +1607,7 @@ static int coarsen(fs_amg_s* M, amg_level* L, double theta, int eig_steps, amg_l
     amg_tick("  RAP");
     hipLaunchKernelGGL(k_fix_dead, dim3(fs_grid_for(n_agg)), dim3(FS_BLOCK), 0, s, (int64_t)n_agg, nb, C->A.rowptr.p, C->A.col.p, C->A.val.p);
     FS_KERNEL_CHECK();
+    FS_CHECK(level_operator_to_f32(C, s));
     FS_HIP(hipStreamSynchronize(s));
     *out = C;
     return FS_OK;
@@ -1761,6 +1845,7 @@ extern "C" int fs_amg_attach_distributed_fine(fs_amg_t M, fs_matrix_t A_local, i
     hipLaunchKernelGGL(k_sel_copy_rows, dim3(fs_grid_for(nn * 64, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, nn, sel.p, G->P.rowptr.p, G->P.col.p, G->P.val.p, bb,
                        D->P.rowptr.p, D->P.col.p, D->P.val.p);
     if ((rc = build_p_transpose(D, nn, G->n_agg, bs, nb, s)) != FS_OK) return fail(rc);
+    if (G->P.val32.p && (rc = level_transfers_to_f32(D, s)) != FS_OK) return fail(rc);     // the same storage as the replicated level 0
     // diagonal and work vectors of the local rows
     if ((rc = D->dinv.alloc(std::max<int64_t>(D->n, 1))) != FS_OK || (rc = D->r.alloc(std::max<int64_t>(D->n, 1))) != FS_OK ||
         (rc = D->d.alloc(std::max<int64_t>(D->n, 1))) != FS_OK || (rc = D->t.alloc(std::max<int64_t>(D->n, 1))) != FS_OK) return fail(rc);
@@ -1877,18 +1962,26 @@ static int vcycle(fs_amg_s* M, int l, double* x, const double* b, hipStream_t s)
     FS_CHECK(level_spmv(M, l, x, b, L->r.p, 1, s));
     {
         const int rg = fs_grid_for(C->nn, FS_BLOCK / 64, 16384);
+#define FS_RESTRICT_ARGS32 dim3(rg), dim3(FS_BLOCK), 0, s, C->nn, L->pt_ptr.p, L->pt_row.p, L->rt_val32.p, L->r.p, C->b.p
 #define FS_RESTRICT_ARGS dim3(rg), dim3(FS_BLOCK), 0, s, C->nn, L->pt_ptr.p, L->pt_row.p, L->rt_val.p, L->r.p, C->b.p
-        if (L->P.br == 1 && L->P.bc == 1) hipLaunchKernelGGL((k_restrict<1, 1>), FS_RESTRICT_ARGS);
+        if (L->rt_val32.p && L->P.br == 3 && L->P.bc == 6) hipLaunchKernelGGL((k_restrict<3, 6, float>), FS_RESTRICT_ARGS32);
+        else if (L->rt_val32.p && L->P.br == 6 && L->P.bc == 6) hipLaunchKernelGGL((k_restrict<6, 6, float>), FS_RESTRICT_ARGS32);
+        else if (L->P.br == 1 && L->P.bc == 1) hipLaunchKernelGGL((k_restrict<1, 1>), FS_RESTRICT_ARGS);
         else if (L->P.br == 3 && L->P.bc == 3) hipLaunchKernelGGL((k_restrict<3, 3>), FS_RESTRICT_ARGS);
         else if (L->P.br == 3 && L->P.bc == 6) hipLaunchKernelGGL((k_restrict<3, 6>), FS_RESTRICT_ARGS);
         else if (L->P.br == 6 && L->P.bc == 6) hipLaunchKernelGGL((k_restrict<6, 6>), FS_RESTRICT_ARGS);
         else { fs_set_error("AMG: restriction for %dx%d blocks is not built", L->P.br, L->P.bc); return FS_ERR_UNSUPPORTED; }
 #undef FS_RESTRICT_ARGS
+#undef FS_RESTRICT_ARGS32
     }
     // distributed fine level: every rank restricted its own rows; the coarse right-hand side is their sum, on every rank
     if (dist) FS_CHECK(fs_comm_allreduce_dev(C->b.p, (int)C->n, s));
     FS_CHECK(vcycle(M, l + 1, C->x.p, C->b.p, s));
-    if (L->P.br == 3 && L->P.bc == 6)
+    if (L->P.val32.p && L->P.br == 3 && L->P.bc == 6)
+        hipLaunchKernelGGL((k_prolong_add_grp<3, 6, float>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val32.p, C->x.p, x);
+    else if (L->P.val32.p && L->P.br == 6 && L->P.bc == 6)
+        hipLaunchKernelGGL((k_prolong_add_grp<6, 6, float>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val32.p, C->x.p, x);
+    else if (L->P.br == 3 && L->P.bc == 6)
         hipLaunchKernelGGL((k_prolong_add_grp<3, 6>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);
     else if (L->P.br == 6 && L->P.bc == 6)
         hipLaunchKernelGGL((k_prolong_add_grp<6, 6>), dim3(fs_grid_for(L->nn * 16, FS_BLOCK, 65536)), dim3(FS_BLOCK), 0, s, L->nn, L->P.rowptr.p, L->P.col.p, L->P.val.p, C->x.p, x);

@@ -382,6 +382,7 @@ void fs_comm_preload();
 int fs_dict_begin(fs_matrix_s* A, hipStream_t s);
 void fs_dict_end();
 int fs_dict_classes();
+void fs_amg_set_coarse_fp32(int on);   // fs_amg.hip: hierarchies built from now on keep their coarse / transfer operators in fp32 (1) or fp64 (0)
 // fs_krylov.hip: bare y = A x on the library stream, no halo exchange, no synchronisation.
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s);
 // fs_amg.hip: z = M r (one V-cycle) on device pointers, no synchronisation.

@@ -2303,6 +2303,8 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_lattice = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "cg_mirror")) {
         g_cg_mirror = value != 0.0 ? 1 : 0;
+    } else if (!strcmp(name, "amg_coarse_fp32")) {
+        fs_amg_set_coarse_fp32(value != 0.0);
     } else if (!strcmp(name, "cg_batch")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_batch must be in [1,4096]");
         g_cg_batch = (int)value;
