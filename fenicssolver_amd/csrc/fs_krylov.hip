@@ -932,6 +932,403 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
     }
 }
 
+// ---- the row-dictionary product on a LATTICE-ORDERED operator (fs_lattice.hip), x staged through LDS tiles ----------------------------
+// k_dict_spmv fetches x with one 16-byte global load per run and lane: 20 - 39 vector-memory instructions per work item on a CG2 operator,
+// whatever the numbering - the per-CU address path is what bounds it (0.17 of the HBM peak on BASELINE configs[3]).  In lattice order
+// (row = X + SX (Y + NY Z) on the half grid) every neighbour of a row lies within +-2 in each direction, so a workgroup of eight waves
+// takes a TILE of 128 x 4 x 4 rows and loads the (128 + 4) x 8 x 8 window of x around it into LDS with coalesced 16-byte loads (4.1 x
+// 8 B per row, from L2), the even and the odd X of a line side by side in two halves of the window.  A wave then takes the 64 rows of
+// ONE PARITY of a line (X = x0 + p, x0 + p + 2, ..): along a mesh line these are rows of one class (vertex rows, x-edge rows, ..), so
+// the class's row - a list of (coefficient, window offset), the nonzero positions of the plan layout in plan order - is WAVE-UNIFORM.
+// The wave loads it ahead of time (lane k: entry k), spreads it into its own LDS scratch and reads it back entry by entry as a
+// broadcast; x comes from the window at consecutive addresses (no bank conflicts); one fma per STORED entry - no padded positions.  Two
+// lines two planes apart (same parities: the same class) are multiplied together, one read of the list for both.  The order of a
+// row's terms is that of k_dict_spmv and of the streaming kernels: the same bits (option "lattice_check" compares every row).
+// Nothing is assumed about where classes change: a wave whose lanes are not of one class walks its DISTINCT classes one after the other
+// (lat_wave_rows: the lanes of the other classes masked, the lists through scalar loads - slow, correct).  What the geometry buys is
+// that this does not happen - EXCEPT at the ends of the lines: the first LT_LO and the last LT_HI rows of a line have classes of their
+// own (boundary rows, and - the operator is scaled with its diagonal - the rows coupled to them), nine of 216 columns at configs[3].
+// They are left out of the line waves and multiplied at the end of the kernel, every lane its own list, everything from global memory.
+// The lists come from the class rows and the plans (k_lat_table: one representative row per class; then EVERY row is checked: its
+// plan puts its class's coefficients at the offsets of that list, its X has the parity the list's window offsets were worked out for -
+// or the form is refused).
+// MEASURED (round 5, MI355X, configs[3], 9.98 M rows, profiles/r05_p2_lattice_tiles.txt): 158 us per product against 168 us for
+// k_dict_spmv in the space's numbering (both alone, no dots); inside the CG iteration, with the three dots, 207 against 190 us - the
+// end rows (4 % of the rows) take 35 us, the dots' strided loads of r another 25.  Steps on the way: per-lane lists from LDS (three LDS
+// reads per entry, loop lengths set by the vertex rows) 342 us; lists through scalar loads 689 us; lists handed out with v_readlane
+// 240 us (16 cycles per readlane); LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us.  Used where the lattice order
+// is (option "lattice_order", off by default).
+constexpr int LT_TX = 128, LT_TY = 4, LT_TZ = 4;
+constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity in a window line
+constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;
+constexpr int LT_WINH = LT_HX * LT_WY * LT_WZ;      // doubles of one parity half of the window
+constexpr int LT_WIN = 2 * LT_WINH;                 // 66 KB
+constexpr int LT_BLOCK = 512;                       // threads of a tile's workgroup (eight waves share one window)
+constexpr int LT_LO = 4, LT_HI = 5;                 // rows at the two ends of a line whose classes are their own: the boundary rows and - the operator is
+                                                    // scaled with its diagonal - the rows coupled to them (and the dummy row that makes a line even)
+constexpr int LT_ML = 72;                           // entries per class row (a CG2 vertex row of a Kuhn mesh has up to 65), padded to 8
+
+static int g_lt_dbg = 0;     // (FS_LATTICE_DEBUG times k_lattice_spmv once more without the rows at the ends of the lines: 1)
+struct lat_tables {
+    dbuf<int32_t> rep, cnt, off, rel;   // [ncls] representative row, [ncls] entries, [ncls][LT_ML] column offsets (verification) / window offsets
+    dbuf<double> coef;                  // [ncls][LT_ML]
+    dbuf<int> info;                     // [0] entries that do not fit / rows whose plan or parity disagrees
+    const double* built_for = nullptr;
+    uint64_t space_serial = 0;
+    int ncls = 0;
+    bool ok = false;
+};
+static lat_tables g_lat;
+
+__global__ void k_lat_rep(int64_t n, const uint16_t* __restrict__ cls, int32_t* __restrict__ rep) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < n; r += stride) {
+        const int c = cls[r];
+        if (__hip_atomic_load(&rep[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)r) atomicMin(&rep[c], (int32_t)r);
+    }
+}
+
+// BUILD: the representative row of every class writes the class's list from its item's plan; !BUILD: one lane per distinct class of
+// every item checks that the item's plan gives the same offsets, every row that its X has the parity of its class's representative
+// (or its list holds nothing but the diagonal)
+template <bool BUILD>
+__global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
+                                                        const uint16_t* __restrict__ cls, const int32_t* __restrict__ rep,
+                                                        const double* __restrict__ values, int S, int RL, int NR, int64_t SX, int64_t NY,
+                                                        int32_t* __restrict__ cnt, double* __restrict__ coef, int32_t* __restrict__ rel,
+                                                        int32_t* __restrict__ off, int* __restrict__ info) {
+    const int lane = threadIdx.x & 63;
+    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t plane = SX * NY;
+    int bad = 0;
+    for (; q < n_items; q += stride) {
+        const int4 it = items[q];
+        const int32_t first = it.x, nr = it.y & 0xffff;
+        const dict_plan_round* __restrict__ pl = plans + it.z;
+        const int n_runs = NR * it.w;
+        for (int half = 0; half < 2; ++half) {
+            const int i = half * 64 + lane;
+            const int32_t r = first + i;
+            const int c = i < nr ? (int)cls[r] : -1;
+            const int p = (int)((r % SX) & 1);
+            bool work;
+            if (BUILD) work = c >= 0 && rep[c] == r;
+            else {      // the first lane of every class among these 64 rows
+                if (c >= 0 && ((rep[c] % SX) & 1) != p && !(cnt[c] == 1 && off[(int64_t)c * LT_ML] == 0)) ++bad;
+                work = false;
+                unsigned long long todo = __ballot(c >= 0);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int cv = __shfl(c, leader, 64);
+                    if (lane == leader) work = true;
+                    todo &= ~__ballot(c == cv);
+                }
+            }
+            if (!work) continue;
+            const double* __restrict__ dv = values + (int64_t)c * S;
+            int k = 0;
+            const int have = BUILD ? 0 : cnt[c];
+            for (int g = 1; g < n_runs; ++g) {          // (run 0 is the z run: no coefficients)
+                const int32_t st = dict_run_start(pl, NR, g);
+                const int ln = dict_run_len(pl, NR, g);
+                for (int t = 0; t < ln; ++t) {
+                    const double v = RL * g + t < S ? dv[RL * g + t] : 0.0;
+                    if (v == 0.0) continue;
+                    const int32_t o = st + t;
+                    if (BUILD) {
+                        // o = dx + SX (dy + NY dz) with |dx|, |dy|, |dz| <= 2
+                        const int64_t dz = (o + (o >= 0 ? plane / 2 : -(plane / 2))) / plane;
+                        const int64_t rem = o - dz * plane;
+                        const int64_t dy = (rem + (rem >= 0 ? SX / 2 : -(SX / 2))) / SX;
+                        const int64_t dx = rem - dy * SX;
+                        const bool fits = k < LT_ML && dx >= -2 && dx <= 2 && dy >= -2 && dy <= 2 && dz >= -2 && dz <= 2;
+                        if (fits) {
+                            // window offset from the row's own position: the other parity's half for odd dx, floor((p + dx) / 2) along x
+                            const int pd = p + (int)dx, p2 = pd & 1, di = (pd - p2) / 2;
+                            coef[(int64_t)c * LT_ML + k] = v;
+                            off[(int64_t)c * LT_ML + k] = o;
+                            rel[(int64_t)c * LT_ML + k] = (p2 - p) * LT_WINH + di + LT_HX * ((int)dy + LT_WY * (int)dz);
+                        } else ++bad;
+                    } else if (k >= have || off[(int64_t)c * LT_ML + k] != o) ++bad;
+                    ++k;
+                }
+            }
+            if (BUILD) cnt[c] = k <= LT_ML ? k : LT_ML;
+            else if (k != have) ++bad;
+        }
+    }
+    if (bad) atomicAdd(&info[0], bad);
+}
+
+// the rows of a wave: the distinct classes of its lanes one after the other, the class's list through scalar loads
+__device__ __forceinline__ double lat_wave_rows(int c, int own, const double* __restrict__ win, const int32_t* __restrict__ tcnt,
+                                                const double* __restrict__ tcoef, const int32_t* __restrict__ trel) {
+    double a = 0.0;
+    unsigned long long todo = __ballot(c >= 0);
+    while (todo) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const int cm = __builtin_amdgcn_readlane(c, leader);
+        const bool mine = c == cm;
+        const int cn = __builtin_amdgcn_readfirstlane(tcnt[cm]);
+        const double* __restrict__ cp = tcoef + (int64_t)cm * LT_ML;
+        const int32_t* __restrict__ rp = trel + (int64_t)cm * LT_ML;
+        for (int k0 = 0; k0 < cn; k0 += 8) {        // (a list is padded to a multiple of 8 positions)
+            double cf[8], xv[8];
+            int32_t rl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cf[e] = cp[k0 + e];
+                rl[e] = k0 + e < cn ? rp[k0 + e] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = win[mine ? own + rl[e] : own];     // (another class's offsets may leave the window)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + e < cn && mine) a = fma(cf[e], xv[e], a);
+        }
+        todo &= ~__ballot(mine);
+    }
+    return a;
+}
+
+// the same for a wave whose lanes are ALL of one class (the rule): the list was loaded into registers ahead of time, entry k in lane k
+// (k + 64: second set); the wave spreads it into its own LDS scratch and every lane reads entry after entry from there - the same
+// address in all lanes, a broadcast (2 cycles on gfx950) - then x at its own position + the entry's offset, one fma.  (v_readlane
+// handed the entries out without LDS and took 16 cycles each: 220 instead of 110 us per product.)  The positions behind the end of a
+// list hold (0.0, 0): they add +0 * x[row].
+__device__ __forceinline__ double lat_wave_rows_uniform(int cn, int own, const double* __restrict__ win, double* __restrict__ sc, int* __restrict__ sr,
+                                                        double vc0, int vr0, double vc1, int vr1) {
+    const int lane = threadIdx.x & 63;
+    sc[lane] = vc0;
+    sr[lane] = vr0;
+    if (lane < LT_ML - 64) { sc[64 + lane] = vc1; sr[64 + lane] = vr1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a = 0.0;
+    for (int k0 = 0; k0 < cn; k0 += 8) {
+        double xv[8], cf[8];
+        int rl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = win[own + rl[e]];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
+    }
+    __builtin_amdgcn_wave_barrier();        // (the next line's list overwrites the scratch)
+    return a;
+}
+
+// ... and for TWO lines of the same class (lines two planes apart: same parities): one read of the list serves both rows of a lane, whose
+// two fma chains are independent
+__device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int own_b, const double* __restrict__ win, double* __restrict__ sc, int* __restrict__ sr,
+                                                       double vc0, int vr0, double vc1, int vr1, double& ra, double& rb) {
+    const int lane = threadIdx.x & 63;
+    sc[lane] = vc0;
+    sr[lane] = vr0;
+    if (lane < LT_ML - 64) { sc[64 + lane] = vc1; sr[64 + lane] = vr1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a = 0.0, b = 0.0;
+    for (int k0 = 0; k0 < cn; k0 += 8) {
+        double xa[8], xb[8], cf[8];
+        int rl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xa[e] = win[own_a + rl[e]]; xb[e] = win[own_b + rl[e]]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a = fma(cf[e], xa[e], a); b = fma(cf[e], xb[e], b); }
+    }
+    __builtin_amdgcn_wave_barrier();        // (the next line's list overwrites the scratch)
+    ra = a;
+    rb = b;
+}
+
+template <int DOTS>
+__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, int nxc, int nyt, int64_t SX, int64_t NY, int64_t NZ,
+                                                           const uint16_t* __restrict__ cls, const int32_t* __restrict__ tcnt,
+                                                           const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff,
+                                                           const double* __restrict__ x, double* __restrict__ y,
+                                                           const double* __restrict__ rvec, double* __restrict__ partials,
+                                                           int* __restrict__ status, int part_base, int part_stride, int bump, int dbg) {
+    const int st0 = DOTS ? status[0] : 0;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double win[];      // [2][LT_WZ][LT_WY][LT_HX]: even X, odd X
+    __shared__ double ldsw[LT_BLOCK / 64];
+    __shared__ double list_c[LT_BLOCK / 64][LT_ML];                   // a wave's scratch: the class list of the line it multiplies
+    __shared__ int list_r[LT_BLOCK / 64][LT_ML];
+    if (DOTS) {
+        if (st0 != 0) return;
+        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = SX * NY * NZ;
+    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
+    constexpr int NL = LT_TY * LT_TZ;               // lines of a tile
+    constexpr int NWV = LT_BLOCK / 64;              // waves
+    constexpr int U = 2 * NL / NWV;                 // (line, parity) pairs per wave
+    auto finish = [&](int64_t r, double a, double zi) {
+        y[r] = a;
+        if (DOTS && DOTS != 4) {
+            const double ri = rvec[r];
+            if (DOTS == 1) { d_rz += ri * zi; d_wz += a * zi; d_rr += ri * ri; }
+            else if (DOTS == 2) { d_rz += a * ri; d_wz += a * a; d_rr += ri * ri; }
+            else if (DOTS == 3) { d_rz += zi * zi; d_wz += a * zi; d_rr += ri * zi * zi; }
+        }
+    };
+    for (chunk_iter it = xcd_chunks(n_tiles); it.cur < it.end; it.cur += it.step) {
+        const int64_t tile = it.cur;
+        const int64_t xc = tile % nxc, yt = (tile / nxc) % nyt, zt = tile / ((int64_t)nxc * nyt);
+        const int64_t x0 = xc * LT_TX, y0 = yt * LT_TY, z0 = zt * LT_TZ;
+        // ---- the window of x: lines (y0 - 2 .. y0 + LT_TY + 1) x (z0 - 2 .. ) from X = x0 - 2 on, one 16-byte load per (even, odd)
+        // pair, all of a thread's loads in flight together; outside the lattice: zero
+        constexpr int NW = (LT_WINH + LT_BLOCK - 1) / LT_BLOCK;
+        v2d wv[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = u * LT_BLOCK + (int)threadIdx.x;
+            wv[u] = v2d{0.0, 0.0};
+            if (i < LT_WINH) {
+                const int xx = i % LT_HX, yy = (i / LT_HX) % LT_WY, zz = i / (LT_HX * LT_WY);
+                const int64_t Y = y0 - 2 + yy, Z = z0 - 2 + zz;
+                if (Y >= 0 && Y < NY && Z >= 0 && Z < NZ) {
+                    int64_t g = x0 - 2 + 2 * xx + SX * (Y + NY * Z);       // (even: SX and x0 are)
+                    g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);               // columns before / behind the vector carry no entry
+                    wv[u] = *reinterpret_cast<const v2d*>(x + g);
+                }
+            }
+        }
+        // ---- the rows of this thread: U line waves (line, parity); their class numbers, then the list of the wave's first class (lane k:
+        // entries k and k + 64), asked for before the window is waited for
+        int64_t r[U];
+        int c[U], own[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
+            const int64_t X = x0 + 2 * lane + p, Y = y0 + (line % LT_TY), Z = z0 + (line / LT_TY);
+            const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < NY && Z < NZ;
+            r[u] = in ? X + SX * (Y + NY * Z) : -1;
+            own[u] = p * LT_WINH + (lane + 1) + LT_HX * ((line % LT_TY) + 2 + LT_WY * ((line / LT_TY) + 2));
+            c[u] = in ? (int)cls[r[u]] : -1;
+        }
+        int cm[U], cn[U];
+        bool uni[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long live = __ballot(c[u] >= 0);
+            cm[u] = live ? __builtin_amdgcn_readlane(c[u], __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
+            uni[u] = __ballot(c[u] == cm[u]) == live;
+            cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
+        }
+        struct lat_list { double c0, c1; int r0, r1; };
+        auto load_list = [&](int cls_m) {
+            lat_list L;
+            const int64_t at = (int64_t)cls_m * LT_ML + lane;
+            L.c0 = tcoef[at];
+            L.r0 = trel[at];
+            L.c1 = tcoef[at + 64];          // (the tables are padded: no branch, so that the wait for a list is counted exactly)
+            L.r1 = trel[at + 64];
+            return L;
+        };
+        // lines u and u + U / 2 of a wave lie two planes apart (same parities in X, Y and Z: normally the same class): taken together
+        static_assert(LT_TZ == 4 && LT_TY == 4, "the pairing of lines below assumes 4 x 4 lines per tile");
+        lat_list cur = load_list(cm[0]);
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = u * LT_BLOCK + (int)threadIdx.x;
+            if (i < LT_WINH) { win[i] = wv[u].x; win[LT_WINH + i] = wv[u].y; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < U / 2; ++j) {
+            // lines j and j + U / 2 of this wave: the same (line % LT_TY), Z two apart
+            const int ua = j, ub = j + U / 2;
+            lat_list nxt = cur;
+            if (j + 1 < U / 2) nxt = load_list(cm[j + 1]);      // (in flight while these lines are multiplied)
+            const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
+            if (both) {
+                double ra, rb;
+                lat_wave_rows_uniform2(cn[ua], own[ua], own[ub], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
+                if (r[ua] >= 0) finish(r[ua], ra, win[own[ua]]);
+                if (r[ub] >= 0) finish(r[ub], rb, win[own[ub]]);
+            } else {
+                if (cn[ua] != 0) {
+                    double a;
+                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own[ua], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
+                    else a = lat_wave_rows(c[ua], own[ua], win, tcnt, tcoef, trel);
+                    if (r[ua] >= 0) finish(r[ua], a, win[own[ua]]);
+                }
+                if (cn[ub] != 0) {          // (its list was not asked for ahead of time: tiles where the class changes between the planes)
+                    double a;
+                    if (uni[ub]) {
+                        const lat_list lb = load_list(cm[ub]);
+                        a = lat_wave_rows_uniform(cn[ub], own[ub], win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
+                    } else a = lat_wave_rows(c[ub], own[ub], win, tcnt, tcoef, trel);
+                    if (r[ub] >= 0) finish(r[ub], a, win[own[ub]]);
+                }
+            }
+            cur = nxt;
+        }
+        __syncthreads();            // (the next tile overwrites the window)
+    }
+    // ---- the first LT_LO and the last LT_HI rows of every line (classes of their own): 64 consecutive Y of one column and plane per
+    // wave, every lane its own list; coefficients, offsets and x from global memory, eight entries in flight.  (Tried: waves of one Y
+    // parity - lists of one length - with the next eight pairs asked for ahead: 33 instead of 26 us.)
+    {
+        const int nyc = (int)((NY + 63) >> 6);
+        const int64_t n_tasks = (int64_t)(LT_LO + LT_HI) * NZ * nyc;
+        for (int64_t t = (int64_t)blockIdx.x * (LT_BLOCK / 64) + wave; t < n_tasks && !(dbg & 1); t += (int64_t)gridDim.x * (LT_BLOCK / 64)) {
+            const int col = (int)(t % (LT_LO + LT_HI));
+            const int64_t Z = (t / (LT_LO + LT_HI)) % NZ, Y = ((t / (LT_LO + LT_HI)) / NZ) * 64 + lane;
+            const int64_t X = col < LT_LO ? col : SX - (LT_LO + LT_HI) + col;
+            const bool in = Y < NY;
+            const int64_t rr = X + SX * ((in ? Y : 0) + NY * Z);
+            const int cc = (int)cls[rr];
+            int most = in ? tcnt[cc] : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int m2 = __shfl_xor(most, o, 64); most = m2 > most ? m2 : most; }
+            const double* __restrict__ cp = tcoef + (int64_t)cc * LT_ML;
+            const int32_t* __restrict__ op = toff + (int64_t)cc * LT_ML;
+            double a = 0.0;
+            for (int k0 = 0; k0 < most; k0 += 8) {       // (behind a list's end: (0.0, offset 0))
+                double cf[8], xv[8];
+                int32_t of[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cf[e] = cp[k0 + e]; of[e] = op[k0 + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = x[rr + of[e]];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
+            }
+            if (in) finish(rr, a, x[rr]);
+        }
+    }
+    if (DOTS && DOTS != 4) {
+        // (fixed order: shuffle reduction per wave, the waves' sums added in order by thread 0)
+        double t[3] = {d_rz, d_wz, d_rr};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double v = t[q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) ldsw[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double acc = 0.0;
+                for (int w = 0; w < LT_BLOCK / 64; ++w) acc += ldsw[w];
+                partials[q * part_stride + part_base + blockIdx.x] = acc;
+            }
+            __syncthreads();
+        }
+    }
+}
+static size_t lat_lds_bytes() { return (size_t)LT_WIN * 8; }
+
 // ---- the same product for 3 x 3 block rows (vector P1 spaces: the elasticity operator of a uniform box; the fine level of its AMG) --
 // A lane holds two consecutive NODES (six rows); a run's load is the six values x[3 (r + o)] .. x[3 (r + o) + 5] (three 16-byte
 // loads), the next two nodes come from the next lane; class rows are [position][9].  Per stored block the terms are added in the
@@ -2254,6 +2651,7 @@ static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 // spend the same 54 coefficient positions (fma + LDS read each) on 29 stored entries - in lattice order because a line's plan is the
 // UNION of its two alternating row patterns (an x-edge row of 27 entries rides the 26 runs of its vertex neighbours).  The kernel
 // is bound by those instructions, not by dependent rounds.  Option "lattice_order" / FS_LATTICE=1 turn it on.
+static int g_lat_check = getenv("FS_LATTICE_CHECK") && getenv("FS_LATTICE_CHECK")[0] == '1' ? 1 : 0;      // option "lattice_check"
 static int g_lattice = getenv("FS_LATTICE") && getenv("FS_LATTICE")[0] == '1' ? 1 : 0;
 static inline bool bs_is_scalar_cg2(const fs_matrix_s* A) { return A->bs == 1 && A->space->degree == 2 && A->space->ncomp == 1; }
 static int g_cg_batch = 32;
@@ -2299,6 +2697,8 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "cg_ahead")) {
         FS_REQUIRE(value >= 1 && value <= 4096, "cg_ahead must be in [1,4096]");
         g_cg_ahead = (int)value;
+    } else if (!strcmp(name, "lattice_check")) {
+        g_lat_check = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "lattice_order")) {
         g_lattice = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "cg_mirror")) {
@@ -2802,6 +3202,112 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
     return FS_OK;
 }
 
+template <int DOTS>
+static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
+                        int* status, hipStream_t s, const double* val_override = nullptr, const int32_t* list = nullptr, int64_t n_list = 0,
+                        int part_base = 0, int part_stride = 0, int bump = 1);
+__global__ void k_lat_fill(int64_t n, double* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long h = ((unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 31;
+        v[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+__global__ void k_lat_count_diff(int64_t n, const double* __restrict__ a, const double* __restrict__ b, int* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int c = 0;
+    for (; i < n; i += stride) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
+}
+
+// the lists of the tile product (k_lattice_spmv) for the dictionary just built on a lattice-ordered operator; g_lat.ok says whether
+// the product may be used (every class fits a list, every row's plan agrees with its class's list, no tile has too many classes)
+static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
+    fs_space_s* sp = A->space;
+    g_lat.ok = false;
+    g_lat.built_for = nullptr;
+    static const bool off = getenv("FS_LATTICE_TILES") && getenv("FS_LATTICE_TILES")[0] == '0';
+    if (off || sp->lat_ny <= 0 || A->bs != 1 || g_dict.built_for != val || g_dict.bs != 1 || g_dict.space_serial != sp->serial || sp->n_dict_items <= 0) return FS_OK;
+    const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz, n = SX * NY * NZ;
+    const int ncls = g_dict.ncls;
+    if (n != sp->n_nodes_owned || sp->n_nodes_local != sp->n_nodes_owned || NY < 6 || SX < 2 * (LT_LO + LT_HI) || (SX & 1) || ncls <= 0) return FS_OK;
+    if (g_lat.rep.n < ncls) {
+        FS_CHECK(g_lat.rep.alloc(ncls));
+        FS_CHECK(g_lat.cnt.alloc(ncls));
+        FS_CHECK(g_lat.off.alloc((int64_t)ncls * LT_ML + 64));
+        FS_CHECK(g_lat.rel.alloc((int64_t)ncls * LT_ML + 64));
+        FS_CHECK(g_lat.coef.alloc((int64_t)ncls * LT_ML + 64));
+    }
+    if (!g_lat.info.p) FS_CHECK(g_lat.info.alloc(4));
+    FS_HIP(hipMemsetAsync(g_lat.rep.p, 0x7f, (size_t)ncls * 4, s));
+    FS_CHECK(g_lat.cnt.zero(s));
+    FS_CHECK(g_lat.coef.zero(s));        // (the padded positions of a list are read, and multiplied with nothing)
+    FS_CHECK(g_lat.rel.zero(s));
+    FS_CHECK(g_lat.off.zero(s));
+    FS_CHECK(g_lat.info.zero(s));
+    hipLaunchKernelGGL(k_lat_rep, dim3(fs_grid_for(n, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n, g_dict.cls.p, g_lat.rep.p);
+    const int gi = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
+#define FS_LAT_TAB_ARGS dim3(gi), dim3(FS_BLOCK), 0, s, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
+                        reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_lat.rep.p, g_dict.values.p, g_dict.S, sp->dict_run_len, \
+                        sp->dict_runs, SX, NY, g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.info.p
+    hipLaunchKernelGGL(k_lat_table<true>, FS_LAT_TAB_ARGS);
+    hipLaunchKernelGGL(k_lat_table<false>, FS_LAT_TAB_ARGS);
+#undef FS_LAT_TAB_ARGS
+    FS_KERNEL_CHECK();
+    int h[4] = {0, 0, 0, 0};
+    FS_CHECK(g_lat.info.download(h, 1, s));
+    static const bool debug = getenv("FS_LATTICE_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[lattice tiles] %d classes, tiles of %d x %d x %d rows: %d entries / rows that do not fit\n", ncls, LT_TX, LT_TY, LT_TZ, h[0]);
+    g_lat.ok = h[0] == 0;
+    g_lat.built_for = val;
+    g_lat.space_serial = sp->serial;
+    g_lat.ncls = ncls;
+    if (g_lat.ok && g_lat_check) {
+        // option "lattice_check": the tile product against k_dict_spmv on a vector of pseudo-random numbers, every row, bit for bit
+        dbuf<double> xv, y1, y2;
+        FS_CHECK(xv.alloc(n + 2)); FS_CHECK(y1.alloc(n + 2)); FS_CHECK(y2.alloc(n + 2));
+        hipLaunchKernelGGL(k_lat_fill, dim3(fs_grid_for(n + 2, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n + 2, xv.p);
+        launch_spmv<0>(A, xv.p, y1.p, nullptr, nullptr, nullptr, s, val, nullptr, 0, 0, 0, 0);
+        g_lat.ok = false;
+        launch_spmv<0>(A, xv.p, y2.p, nullptr, nullptr, nullptr, s, val, nullptr, 0, 0, 0, 0);
+        g_lat.ok = true;
+        FS_CHECK(g_lat.info.zero(s));
+        hipLaunchKernelGGL(k_lat_count_diff, dim3(fs_grid_for(n, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n, y1.p, y2.p, g_lat.info.p);
+        FS_KERNEL_CHECK();
+        FS_CHECK(g_lat.info.download(h, 1, s));
+        if (debug) fprintf(stderr, "[lattice tiles] tile product against the work-item product: %d of %lld rows differ\n", h[0], (long long)n);
+        if (debug) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            const int variants[] = {0, 1, -1};
+            for (int v : variants) {
+                g_lt_dbg = v < 0 ? 0 : v;
+                if (v < 0) g_lat.ok = false;        // the work-item product
+                launch_spmv<0>(A, xv.p, y1.p, nullptr, nullptr, nullptr, s, val, nullptr, 0, 0, 0, 0);
+                (void)hipEventRecord(e0, s);
+                for (int it = 0; it < 10; ++it) launch_spmv<0>(A, xv.p, y1.p, nullptr, nullptr, nullptr, s, val, nullptr, 0, 0, 0, 0);
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                fprintf(stderr, "[lattice tiles]   %-44s %.1f us per product\n", v < 0 ? "work-item product (k_dict_spmv):" : (v == 0 ? "tile product:" : "tile product without the ends of the lines:"), ms * 100.0);
+            }
+            g_lt_dbg = 0;
+            g_lat.ok = true;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        if (h[0] != 0) {
+            g_lat.ok = false;
+            fs_set_error("lattice_check: the tile product differs from the work-item product on %d of %lld rows", h[0], (long long)n);
+            return FS_ERR_NUMERIC;
+        }
+    }
+    return FS_OK;
+}
+
 static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s, const double* raw = nullptr, const double* sc = nullptr,
                       const std::function<void()>& scale_copy = nullptr) {
     bool copied = raw == nullptr;
@@ -2811,6 +3317,7 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s, const do
     const int rc = dict_build_impl(A, val, s, raw, sc, materialize);
     // every outcome but `the kept table describes this matrix` reads val: the streaming kernels, or a table just built from it
     if (!(g_dict.built_for == val && g_dict.kept)) materialize();
+    if (rc == FS_OK && A->space->lat_ny > 0) FS_CHECK(lat_prepare(A, val, s));
     return rc;
 }
 
@@ -2818,8 +3325,8 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s, const do
 // processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
 static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double* rvec, double* partials,
-                        int* status, hipStream_t s, const double* val_override = nullptr,
-                        const int32_t* list = nullptr, int64_t n_list = 0, int part_base = 0, int part_stride = 0, int bump = 1) {
+                        int* status, hipStream_t s, const double* val_override,
+                        const int32_t* list, int64_t n_list, int part_base, int part_stride, int bump) {
     const double* mat_val = val_override ? val_override : A->val.p;
     fs_space_s* sp = A->space;
     const int64_t ns = list ? n_list : sp->n_slices;
@@ -2851,6 +3358,19 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             items = in ? h.items_interior.p : (list == h.boundary.p ? h.items_boundary.p : nullptr);
             n_items = in ? h.n_items_interior : h.n_items_boundary;
             gd = spmv_grid(ns, sp->n_slices);
+        }
+        if (!list && g_lat.ok && g_lat.built_for == mat_val && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls) {
+            // a lattice-ordered operator: tiles of 64 x 4 x 4 rows, x through LDS (k_lattice_spmv)
+            const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz;
+            const int nxc = (int)((SX + LT_TX - 1) / LT_TX), nyt = (int)((NY + LT_TY - 1) / LT_TY), nzt = (int)((NZ + LT_TZ - 1) / LT_TZ);
+            const size_t lds = lat_lds_bytes();
+            auto kern = k_lattice_spmv<DOTS>;
+            static bool attr_set = false;       // (one per instantiation)
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, (int64_t)nxc * nyt * nzt, nxc, nyt, SX, NY, NZ, g_dict.cls.p,
+                               g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
+                               g_lt_dbg);
+            return;
         }
         if (items && n_items >= 0) {
 #define FS_DICT_ARGS(CC) sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), \

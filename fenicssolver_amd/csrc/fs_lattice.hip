@@ -195,6 +195,8 @@ int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out) {
     sh->dict_period = 2;
     sh->dict_line = SX;
     sh->dict_runs = 12;
+    sh->lat_ny = (int)NY;
+    sh->lat_nz = (int)NZ;
     dbuf<int32_t> len;
     dbuf<int> d_cnt;
     dbuf<uint8_t> written;

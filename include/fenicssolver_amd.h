@@ -79,14 +79,19 @@ const char* fs_last_error(void);
 const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
  * (2/4/8/16 row entries in flight per lane), "cg_batch" (iterations per host poll), "lattice_order" (0 / 1: scalar CG2 operators on uniform boxes solved in
- * the lattice order of the half grid, fs_krylov_stats.lattice_order), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
+ * the lattice order of the half grid, fs_krylov_stats.lattice_order; the product of the two-launch iteration is then the tile product
+ * k_lattice_spmv), "lattice_check" (0 / 1: every solve in lattice order first compares the tile product with the work-item product on a
+ * vector of pseudo-random numbers, every row, bit for bit - a difference fails the solve with FS_ERR_NUMERIC), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
  * through pinned host memory and the host keeps "cg_ahead" to "cg_ahead" + "cg_sub" launches enqueued, instead of batches of
  * "cg_batch" with the status word copied back behind each),
  * "cg_fuse_sums" (0/1: sum the dot partials inside the update kernel on one GPU),
  * "update_blocks" (grid of the fused vector-update kernel), "cg_graph" (-1 / 0 / 1: CG batches as hipGraphs by size /
  * never / always), "cg_fused" (-1 / 0 / 1: ONE launch per CG iteration on row-dictionary operators - up to 3 M rows /
  * never / wherever it applies; fs_krylov_stats.fused_iteration), "row_dictionary" (0 / 1: allow the row-dictionary form of the product, fs_krylov_stats.row_classes),
- * "box_snap" (0 / 1: box meshes snap their edge vectors to the grid spacing so that equal stencils are equal bit for bit). */
+ * "box_snap" (0 / 1: box meshes snap their edge vectors to the grid spacing so that equal stencils are equal bit for bit),
+ * "amg_coarse_fp32" (1 / 0, default 1: hierarchies built from now on keep the 6 x 6-block coarse operators and the transfer operators
+ * the V-cycle streams rounded to fp32 - vectors, accumulation, the fine level and the CG outside stay fp64; fs_amg_level_get keeps
+ * returning the fp64 operators; FS_AMG_FP32=0 in the environment is the same switch). */
 int fs_set_option(const char* name, double value);
 /* Name, CU count and HBM bytes of the selected device. */
 int fs_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);

@@ -179,6 +179,47 @@ def test_amg_elasticity_rigid_body_modes(gpu, clamp):
     assert sj["iterations"] > 5 * st["iterations"]
 
 
+def test_fp32_storage_of_coarse_and_transfer_operators_leaves_the_solve_alone(gpu):
+    """The V-cycle streams its 6 x 6-block coarse operators and its transfer operators rounded to fp32 (fs_amg.hip: half the bytes
+    of what bounds it); vectors, accumulation and the CG outside stay fp64.  Held here: the preconditioner is still symmetric
+    positive definite (to the rounding of its stored numbers), the iteration count is that of fp64 storage +- 1, the solution the
+    oracle's, and the inspection hook keeps returning the fp64 Galerkin operators."""
+    V, A, b, Ab, bb, rbm = _elasticity(gpu, dims=(8, 3, 3))
+    ref = fo.solve_direct(Ab, bb)
+    n = V.n_owned
+    out = {}
+    try:
+        for fp32 in (0, 1):
+            gpu.set_option("amg_coarse_fp32", fp32)
+            amg = gpu.AMG(A, nullspace=rbm, coarse_size=60)
+            assert amg.level_info(1)["block_size"] == 6
+            _check_hierarchy(amg, Ab, rbm.T.copy(), 6)
+            x = gpu.DeviceVector(V.n_local)
+            st = amg.solve(b, x, rtol=1e-10)
+            assert st["converged"] == 1
+            assert np.abs(x.get()[:n] - ref).max() <= 1e-7 * np.abs(ref).max()
+            M = np.empty((n, n))
+            r = gpu.DeviceVector(n)
+            z = gpu.DeviceVector(V.n_local)
+            e = np.zeros(n)
+            for i in range(n):
+                e[:] = 0.0
+                e[i] = 1.0
+                r.set(e)
+                amg.apply(r, z)
+                M[:, i] = z.get()[:n]
+            out[fp32] = (st["iterations"], M)
+            amg.close()
+    finally:
+        gpu.set_option("amg_coarse_fp32", 1)
+    (it64, M64), (it32, M32) = out[0], out[1]
+    assert abs(it32 - it64) <= 1, (it64, it32)
+    assert np.abs(M64 - M64.T).max() <= 1e-10 * np.abs(M64).max()
+    assert np.abs(M32 - M32.T).max() <= 1e-6 * np.abs(M32).max()          # fp32 rounding of the two Galerkin summation orders
+    assert np.linalg.eigvalsh(0.5 * (M32 + M32.T)).min() > 0
+    assert 0 < np.abs(M32 - M64).max() <= 1e-5 * np.abs(M64).max()       # the storage IS different, by fp32 rounding only
+
+
 def test_amg_rejects_bad_input(gpu):
     from fenicssolver_amd._lib import BackendError
     V, A, b, Ab, bb = _poisson(gpu, 4)

@@ -477,7 +477,11 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
     line), solved there through the row-dictionary product with rounds of twelve runs, and permuted back - the API numbering is
     untouched.  Same Krylov iteration count, same solution to rounding, also from a nonzero guess and for a non-symmetric operator
     (BiCGStab); a box whose lines are shorter than a slice keeps the space's own numbering.  (Measured slower than the space's
-    numbering at 10 M rows - the option is off by default; this pins its arithmetic.)"""
+    numbering at 10 M rows - the option is off by default; this pins its arithmetic.)
+    In lattice order the product of the two-launch iteration is the TILE product (k_lattice_spmv: x through LDS windows, a wave per
+    line parity, class lists broadcast): option lattice_check has every solve compare it with the work-item product on a vector of
+    pseudo-random numbers, every row, bit for bit (a difference is an error of the solve); cg_fused = 0 keeps the two-launch iteration
+    at this size, so that the iterations themselves run on the tile product and its fused dots."""
     import bench
     n = 32
     prob = bench.P2Problem(n, (0, n + 1), 2, 0, 1)
@@ -486,8 +490,10 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
     prob.A.apply_dirichlet(prob.b, prob.dofs, prob.vals, symmetric=True)
     got = {}
     try:
-        for lat in (0, 1):
-            gpu.set_option("lattice_order", lat)
+        gpu.set_option("lattice_check", 1)
+        for lat in (0, 1, 2):
+            gpu.set_option("lattice_order", 1 if lat else 0)
+            gpu.set_option("cg_fused", 0 if lat == 2 else -1)
             x = gpu.DeviceVector(prob.V.n_owned)
             st = gpu.krylov_solve(prob.A, prob.b, x, rtol=1e-10, max_iter=5000)
             x0 = x.get().copy()
@@ -504,6 +510,12 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
         st_small = gpu.krylov_solve(small.A, small.b, small.x, rtol=1e-10, max_iter=5000)
     finally:
         gpu.set_option("lattice_order", 0)
+        gpu.set_option("lattice_check", 0)
+        gpu.set_option("cg_fused", -1)
+    (s2, x2, r2, g2, b2, y2) = got[2]           # the two-launch iteration on the tile product
+    assert s2["lattice_order"] == 1 and s2["fused_iteration"] == 0 and s2["converged"] == 1
+    assert abs(s2["iterations"] - got[0][0]["iterations"]) <= 1 and np.abs(x2 - got[0][1]).max() <= 1e-9 * np.abs(got[0][1]).max()
+    assert r2["converged"] == 1 and np.abs(g2 - got[0][3]).max() <= 1e-8 * np.abs(got[0][1]).max()
     (s0, x0, r0, g0, b0, y0), (s1, x1, r1, g1, b1, y1) = got[0], got[1]
     assert s0["lattice_order"] == 0 and s1["lattice_order"] == 1 and r1["lattice_order"] == 1 and b1["lattice_order"] == 1
     assert s1["row_classes"] > 0 and s1["converged"] == 1 and abs(s1["iterations"] - s0["iterations"]) <= 1
