@@ -1172,10 +1172,9 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
     constexpr int NL = LT_TY * LT_TZ;               // lines of a tile
     constexpr int NWV = LT_BLOCK / 64;              // waves
     constexpr int U = 2 * NL / NWV;                 // (line, parity) pairs per wave
-    auto finish = [&](int64_t r, double a, double zi) {
+    auto finish = [&](int64_t r, double a, double zi, double ri) {
         y[r] = a;
         if (DOTS && DOTS != 4) {
-            const double ri = rvec[r];
             if (DOTS == 1) { d_rz += ri * zi; d_wz += a * zi; d_rr += ri * ri; }
             else if (DOTS == 2) { d_rz += a * ri; d_wz += a * a; d_rr += ri * ri; }
             else if (DOTS == 3) { d_rz += zi * zi; d_wz += a * zi; d_rr += ri * zi * zi; }
@@ -1251,17 +1250,19 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             lat_list nxt = cur;
             if (j + 1 < U / 2) nxt = load_list(cm[j + 1]);      // (in flight while these lines are multiplied)
             const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
+            // (the residual entries of the fused dots: asked for now, needed behind the multiplication)
+            const double ria = (DOTS && DOTS != 4 && r[ua] >= 0) ? rvec[r[ua]] : 0.0, rib = (DOTS && DOTS != 4 && r[ub] >= 0) ? rvec[r[ub]] : 0.0;
             if (both) {
                 double ra, rb;
                 lat_wave_rows_uniform2(cn[ua], own[ua], own[ub], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
-                if (r[ua] >= 0) finish(r[ua], ra, win[own[ua]]);
-                if (r[ub] >= 0) finish(r[ub], rb, win[own[ub]]);
+                if (r[ua] >= 0) finish(r[ua], ra, win[own[ua]], ria);
+                if (r[ub] >= 0) finish(r[ub], rb, win[own[ub]], rib);
             } else {
                 if (cn[ua] != 0) {
                     double a;
                     if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own[ua], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
                     else a = lat_wave_rows(c[ua], own[ua], win, tcnt, tcoef, trel);
-                    if (r[ua] >= 0) finish(r[ua], a, win[own[ua]]);
+                    if (r[ua] >= 0) finish(r[ua], a, win[own[ua]], ria);
                 }
                 if (cn[ub] != 0) {          // (its list was not asked for ahead of time: tiles where the class changes between the planes)
                     double a;
@@ -1269,7 +1270,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                         const lat_list lb = load_list(cm[ub]);
                         a = lat_wave_rows_uniform(cn[ub], own[ub], win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
                     } else a = lat_wave_rows(c[ub], own[ub], win, tcnt, tcoef, trel);
-                    if (r[ub] >= 0) finish(r[ub], a, win[own[ub]]);
+                    if (r[ub] >= 0) finish(r[ub], a, win[own[ub]], rib);
                 }
             }
             cur = nxt;
@@ -1305,7 +1306,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
             }
-            if (in) finish(rr, a, x[rr]);
+            if (in) finish(rr, a, x[rr], (DOTS && DOTS != 4) ? rvec[rr] : 0.0);
         }
     }
     if (DOTS && DOTS != 4) {
