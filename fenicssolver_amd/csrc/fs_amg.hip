@@ -927,7 +927,29 @@ __global__ void __launch_bounds__(FS_BLOCK) k_bcsr_spmv_node(int64_t nn, const i
         double acc[BS];
 #pragma unroll
         for (int r = 0; r < BS; ++r) acc[r] = 0.0;
-        if (BS % 2 == 0) {           // a lane takes one row of one block: BS/2 16-byte (fp32 values: 8-byte) loads of values, BS/2 16-byte loads of x
+        if (BS == 6 && sizeof(VT) == 4) {
+            // fp32 values of 6 x 6 blocks: a lane takes TWO rows of one block - 48 bytes, three 16-byte loads (a row alone is three 8-byte
+            // loads: 110 us per level-1 product of configs[2], 4.1 TB/s) - and the block's six values of x once for both
+            const float4* row4 = reinterpret_cast<const float4*>(row);
+            const int parts = (rp[i + 1] - e0) * 3;
+            for (int idx = lane; idx < parts; idx += 64) {
+                const int e = idx / 3, r2 = idx - e * 3;
+                const double2* xv = reinterpret_cast<const double2*>(x + (int64_t)ci[e0 + e] * BS);
+                const float4 a0 = row4[(int64_t)idx * 3], a1 = row4[(int64_t)idx * 3 + 1], a2 = row4[(int64_t)idx * 3 + 2];
+                const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
+                // the terms of a row in the order of the one-row-per-lane form: pairs (0, 1), (2, 3), (4, 5)
+                double v0 = 0.0, v1 = 0.0;
+                v0 += (double)a0.x * x0.x + (double)a0.y * x0.y;
+                v0 += (double)a0.z * x1.x + (double)a0.w * x1.y;
+                v0 += (double)a1.x * x2.x + (double)a1.y * x2.y;
+                v1 += (double)a1.z * x0.x + (double)a1.w * x0.y;
+                v1 += (double)a2.x * x1.x + (double)a2.y * x1.y;
+                v1 += (double)a2.z * x2.x + (double)a2.w * x2.y;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if (rr == r2) { acc[2 * rr] += v0; acc[2 * rr + 1] += v1; }
+            }
+        } else if (BS % 2 == 0) {           // a lane takes one row of one block: BS/2 16-byte (fp32 values: 8-byte) loads of values, BS/2 16-byte loads of x
             constexpr int HP = BS / 2;
             typedef typename fs_pair_of<VT>::type VT2;
             const VT2* row2 = reinterpret_cast<const VT2*>(row);

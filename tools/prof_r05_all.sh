@@ -27,7 +27,9 @@ python $R/bench.py --workload th > $S/r05_th_bench_line.json 2>/dev/null
 python $R/bench.py --n 440 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-case > $S/r05_bench_line_n440_86M_dof.json 2>/dev/null
 python $R/tools/probes/rccl_self_halo_probe.py 99 all 2>&1 | grep -a "iteration\|refresh\|rows" > $S/r05_p2p_self_halo_timings.txt
 python $R/tools/probes/cg_tail_probe.py 99 0,16,6 1,16,6 2>&1 | tail -2 > $S/r05_cg_tail.txt
-python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | tail -5 > $S/r05_p2_lattice_order.txt
+FS_LATTICE_TILES=0 python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | tail -5 > $S/r05_p2_lattice_order.txt      # (the work-item product on the lattice order)
+bash $R/tools/probes/p2_lattice_tiles.sh > /dev/null 2>&1; cp $R/gpurun_out/r05_p2_lattice_tiles.txt $S/                    # (the tile product)
+hipcc --offload-arch=gfx950 -O3 $R/tools/probes/mfma_f64_probe.hip -o /tmp/mfma_f64_probe 2>/dev/null && /tmp/mfma_f64_probe > $S/r05_mfma_f64_probe.txt 2>&1
 (FS_SPMV4_KSPLIT=0 python $R/tools/probes/spmv4_probe.py; python $R/tools/probes/spmv4_probe.py) 2>&1 | grep -a "KSPLIT\|max" > $S/r05_spmv4_kernels.txt
 python $R/tools/probes/first_step_probe.py 2>&1 | tail -18 > $S/r05_first_step.txt
 bash $R/tools/shim_scale_check.sh > $S/r05_shim_scale_check.txt 2>&1
