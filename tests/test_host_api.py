@@ -150,6 +150,16 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fs_version()
 
 
+def test_every_tunable_is_documented_in_the_header():
+    """fs_set_option names its tunables in the library's source; the header is their only documentation."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "fenicssolver_amd", "csrc", "fs_krylov.hip")).read()
+    names = re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', src)
+    header = open(os.path.join(root, "include", "fenicssolver_amd.h")).read()
+    assert len(names) >= 15 and not [n for n in names if '"%s"' % n not in header]
+
+
 def test_product_fails_loudly_without_gpu(data_dir):
     from fenicssolver_amd import backend
     if backend.device_count() > 0:
