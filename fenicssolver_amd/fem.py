@@ -918,9 +918,9 @@ class FunctionSpace:
                 # a mesh in FILE order on one GPU: the same machinery with one part whose numbering is the locality order
                 root._device = self._make_parallel_device(root, backend, parallel, renumber=True)
             elif parallel.active():
-                if root._periodic is not None and (root._degree != 1 or facet_coupling or getattr(root._mesh, "_slab", None) is not None):
-                    raise SolverError("periodic_boundary (constrained_domain) under domain decomposition is built for P1 spaces on a "
-                                      "replicated host mesh (no interior-facet terms); CG2 / Taylor-Hood spaces: one GPU")
+                if root._periodic is not None and (facet_coupling or getattr(root._mesh, "_slab", None) is not None):
+                    raise SolverError("periodic_boundary (constrained_domain) under domain decomposition is built for P1 / P2 spaces on a "
+                                      "replicated host mesh (no interior-facet terms); BoxMesh(distributed=True): one GPU or the replicated box")
                 root._device = self._make_parallel_device(root, backend, parallel, facet_coupling=facet_coupling)
             else:
                 pairs = None
@@ -995,6 +995,11 @@ class FunctionSpace:
             pk = next((k for k in cache if len(k) == 4 and k[:3] == (rank, size, "periodic")), None)
             if pk is not None:
                 cache[(rank, size)] = cache[pk]
+            pk2 = next((k for k in cache if len(k) == 4 and k[:3] == (rank, size, "periodic_p2")), None)
+            if pk is None and pk2 is not None:       # (the part of a periodic CG2 space: its device mesh carries ORDER ids, its part extra cells)
+                o2, p2, oid2, dm2 = cache[pk2]
+                cache[(rank, size)] = (o2, p2, dm2)
+                cache[("p2_plan_args", rank, size)] = (oid2, pk2)
         if (rank, size) not in cache and size == 1 and FunctionSpace._wants_renumbering(root):
             # one part in locality order (a mesh FILE on one GPU): ordered, re-indexed and built on the device in one upload
             # (fs_mesh_create_renumbered; the numpy re-indexing of the general path below took 6.7 s at 10 M vertices)
@@ -1018,7 +1023,16 @@ class FunctionSpace:
                 ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
             root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
         else:
-            plan = partition.build_p2_plan(ce, owner, rank, part, ds.edges(), root.edge_nodes())
+            extra = cache.get(("p2_plan_args", rank, size))
+            if extra is None:
+                plan = partition.build_p2_plan(ce, owner, rank, part, ds.edges(), root.edge_nodes())
+            else:       # the part belongs to a periodic CG2 space of this mesh (see _make_parallel_periodic_p2_device)
+                sl_, ma_ = (np.asarray(a, dtype=np.int64) for a in cache[("p2_tied", rank, size)])
+                mo_ = np.full(mesh.num_vertices(), -1, dtype=np.int64)
+                mo_[sl_] = ma_
+                ce64_ = np.asarray(ce, dtype=np.int64)
+                plan = partition.build_p2_plan(ce, owner, rank, part, ds.edges(), root.edge_nodes(), order_id=extra[0],
+                                               part_cells_of=lambda q: partition._local_cell_mask(ce64_, owner, q, None, mo_))
             nc_ = root._ncomp
             if plan.n_owned_nodes * nc_ != ds.n_owned:
                 raise SolverError("internal error: host and device disagree on the owned P2 nodes")
@@ -1046,6 +1060,8 @@ class FunctionSpace:
         mesh = root._mesh
         co, ce = mesh.coordinates(), mesh.cells()
         sl, ma = (np.asarray(a, dtype=np.int64) for a in root._periodic)
+        if root._degree == 2:
+            return FunctionSpace._make_parallel_periodic_p2_device(root, backend, parallel, partition, rank, size, cache, co, ce, sl, ma)
         key = (rank, size, "periodic", hash(sl.tobytes()) ^ hash(ma.tobytes()))
         if key not in cache:
             axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
@@ -1061,6 +1077,57 @@ class FunctionSpace:
         if size > 1:
             ds.set_halo(part.neighbors, part.dof_send_lists(root._ncomp), [c * root._ncomp for c in part.recv_counts])
         root._localizer = parallel.Localizer(part, mesh.num_vertices(), root._ncomp)
+        return ds
+
+    @staticmethod
+    def _make_parallel_periodic_p2_device(root, backend, parallel, partition, rank, size, cache, co, ce, sl, ma):
+        """A CG2 space with a periodic constraint on several ranks (round 5).  As for P1 (above), and for the EDGE nodes:
+          * the master of a slave edge node is an edge node, and an edge exists on the device only inside a cell: a part also takes
+            the cells around the masters of its slave vertices (partition.build_local_part(tied_cells=True));
+          * an edge belongs to the owner of its end point of smaller id.  The device mesh is handed ORDER ids - a slave vertex right
+            behind its master, 2 fold(v) + is_slave(v) - instead of the vertex numbers, so that a slave edge and its master edge are
+            owned through corresponding end points, by one rank (a slave vertex already lives with its master);
+          * the pattern's extra couplings are given in node numbers, which the device space itself defines: it is built twice,
+            first without them (for its edge table), then with."""
+        mesh = root._mesh
+        nvg = mesh.num_vertices()
+        key = (rank, size, "periodic_p2", hash(sl.tobytes()) ^ hash(ma.tobytes()))
+        if key not in cache:
+            axis = int(np.argmax(co.max(axis=0) - co.min(axis=0)))
+            owner = np.array(partition.slab_owner(co, size, axis=axis))
+            owner[sl] = owner[ma]
+            part = partition.build_local_part(ce, owner, rank, tied=(sl, ma), tied_cells=True)
+            fold = np.arange(nvg, dtype=np.int64)
+            fold[sl] = ma
+            order_id = 2 * fold
+            order_id[sl] += 1
+            cache[key] = (owner, part, order_id, backend.DeviceMesh(co[part.l2g], part.cells, n_owned=part.n_owned, global_ids=order_id[part.l2g]))
+        owner, part, order_id, dm = cache[key]
+        cache[("p2_tied", rank, size)] = (sl, ma)
+        master_of = np.full(nvg, -1, dtype=np.int64)
+        master_of[sl] = ma
+        ce64 = np.asarray(ce, dtype=np.int64)
+        cells_of = lambda q: partition._local_cell_mask(ce64, owner, q, None, master_of)
+        nc_ = root._ncomp
+        probe = backend.DeviceSpace(dm, nc_, 2)                  # (edge table and node numbering: the same with the extra couplings)
+        plan = partition.build_p2_plan(ce, owner, rank, part, probe.edges(), root.edge_nodes(), order_id=order_id, part_cells_of=cells_of)
+        if plan.n_owned_nodes * nc_ != probe.n_owned:
+            raise SolverError("internal error: host and device disagree on the owned P2 nodes of a periodic space")
+        loc = parallel.Localizer(part, nvg, nc_, p2_plan=plan, n_global_nodes=root.num_nodes())
+        pairs = loc.g2l[root._periodic_couplings().astype(np.int64)]
+        pairs = pairs[(pairs >= 0).all(axis=1) & (pairs < plan.n_owned_nodes).any(axis=1)]
+        probe_edges = np.asarray(probe.edges()).copy()
+        probe.close()
+        ds = backend.DeviceSpace(dm, nc_, 2, coupled_pairs=pairs.astype(np.int32))
+        if not np.array_equal(np.asarray(ds.edges()), probe_edges):
+            raise SolverError("internal error: the extra couplings of a periodic space changed the device's edge numbering")
+        if size > 1:
+            def dof_lists(lists):
+                if nc_ == 1:
+                    return lists
+                return [(np.asarray(l, dtype=np.int64)[:, None] * nc_ + np.arange(nc_)[None, :]).reshape(-1).astype(np.int32) for l in lists]
+            ds.set_halo(plan.neighbors, dof_lists(plan.send_lists), [c * nc_ for c in plan.recv_counts], recv_lists=dof_lists(plan.recv_lists))
+        root._localizer = loc
         return ds
 
     @staticmethod

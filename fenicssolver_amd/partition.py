@@ -84,10 +84,13 @@ class LocalPart:
         return [(s[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel().astype(np.int32) for s in self.send_lists]
 
 
-def _local_cell_mask(cells, owner, q, face_pairs):
+def _local_cell_mask(cells, owner, q, face_pairs, master_cells_of=None):
     """Cells of rank q's part: those holding a q-owned vertex and - with face_pairs, the (cell, cell) pairs of the interior
     facets - their neighbours across a facet (the second layer interior-facet integrals need: a row of an owned vertex a takes
-    contributions from every facet of the cells around a, and the cell on the far side need not touch any owned vertex)."""
+    contributions from every facet of the cells around a, and the cell on the far side need not touch any owned vertex).
+    master_cells_of ([n_global] master vertex of every slave, -1 elsewhere; CG2 spaces with a periodic constraint): the cells
+    around the masters of the slave vertices of those cells as well - the master of a slave EDGE node is an edge node, and an edge
+    exists on the device only inside a cell (a P1 space makes do with the master vertex alone, without cells)."""
     m = (owner[cells] == q).any(axis=1)
     if face_pairs is not None:
         a, b = face_pairs[:, 0], face_pairs[:, 1]
@@ -95,6 +98,12 @@ def _local_cell_mask(cells, owner, q, face_pairs):
         m2[b[m[a]]] = True
         m2[a[m[b]]] = True
         m = m2
+    if master_cells_of is not None:
+        v = np.unique(cells[m])
+        ma = master_cells_of[v]
+        need = np.zeros(len(owner), dtype=bool)
+        need[ma[ma >= 0]] = True
+        m = m | need[cells].any(axis=1)
     return m
 
 
@@ -104,14 +113,14 @@ def _with_masters(verts, master_of):
     return np.union1d(verts, m[m >= 0])
 
 
-def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_pairs=None, tied=None):
+def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_pairs=None, tied=None, tied_cells=False):
     """vertex_rank / cell_rank (optional, [n_global] each): a locality order (backend.locality_order) - the owned vertices
     and the local cells are then numbered by it instead of by their global ids (the order a mesh file happens to have).
     face_pairs [nf,2] (optional, global cell ids of the two cells of every interior facet): two cell layers instead of one.
     tied (optional, (slaves, masters) global vertex ids of a periodic constraint; `owner` must give a slave its master's rank):
     the folded operator P^T A P moves every column of a slave onto its master, so a part holds the master of every slave among
     its vertices as well - as an extra ghost vertex without cells where the master is no mesh neighbour of anything local (the
-    far side of the domain)."""
+    far side of the domain).  tied_cells (CG2 spaces): the part also takes the CELLS around those masters (see _local_cell_mask)."""
     cells = np.asarray(cells, dtype=np.int64)
     owner = np.asarray(owner)
     if face_pairs is not None:
@@ -123,7 +132,8 @@ def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_
         master_of[np.asarray(tied[0], dtype=np.int64)] = np.asarray(tied[1], dtype=np.int64)
         if not np.array_equal(owner[np.asarray(tied[0], dtype=np.int64)], owner[np.asarray(tied[1], dtype=np.int64)]):
             raise ValueError("build_local_part: a tied (slave, master) pair must live on one rank")
-    keep = np.nonzero(_local_cell_mask(cells, owner, rank, face_pairs))[0]
+    mco = master_of if tied_cells else None
+    keep = np.nonzero(_local_cell_mask(cells, owner, rank, face_pairs, mco))[0]
     if cell_rank is not None:
         keep = keep[np.argsort(np.asarray(cell_rank)[keep], kind="stable")]
     lc = cells[keep]
@@ -153,7 +163,7 @@ def build_local_part(cells, owner, rank, vertex_rank=None, cell_rank=None, face_
         if not general:
             touch = cand[(owner[cand] == q).any(axis=1)]
         else:
-            touch = cells[_local_cell_mask(cells, owner, q, face_pairs)]
+            touch = cells[_local_cell_mask(cells, owner, q, face_pairs, mco)]
         v = np.unique(touch)
         if master_of is not None:
             v = _with_masters(v, master_of)
@@ -248,19 +258,26 @@ def _edge_keys(g0, g1, n_global):
     return lo.astype(np.int64) * n_global + hi
 
 
-def build_p2_plan(cells, owner, rank, part, local_edges, global_edges):
+def build_p2_plan(cells, owner, rank, part, local_edges, global_edges, order_id=None, part_cells_of=None):
     """cells [nc,4] / owner [nv]: the GLOBAL mesh and vertex owners; part: this rank's LocalPart; local_edges [ne,2]: the
     device's edge table in node order (local vertex ids, owned edges first); global_edges [ne_g,2]: the host's global
     edge-node table (FunctionSpace.edge_nodes()).  No communication: every rank derives both sides of each exchange
-    from the global mesh, ordered by (vertices by global id, then edges by (g0, g1))."""
+    from the global mesh, ordered by (vertices by global id, then edges by (g0, g1)).
+    order_id ([n_global], optional): the ids the DEVICE mesh was given as global ids (fs_mesh_set_global_ids) where they are not
+    the mesh's own - an edge belongs to the owner of its end point of smaller ORDER id (periodic CG2 spaces: a slave vertex is
+    ordered right behind its master, so that a slave edge and its master edge are owned through corresponding end points).
+    part_cells_of (rank -> boolean mask over the global cells, optional): the cells of another rank's part where they are not
+    just the cells around its vertices."""
     cells = np.asarray(cells, dtype=np.int64)
     owner = np.asarray(owner)
     n_global = len(owner)
+    oid = np.arange(n_global, dtype=np.int64) if order_id is None else np.asarray(order_id, dtype=np.int64)
     nv, nvo = part.n_local, part.n_owned
     le = np.asarray(local_edges, dtype=np.int64).reshape(-1, 2)
-    g0 = np.minimum(part.l2g[le[:, 0]], part.l2g[le[:, 1]])
-    g1 = np.maximum(part.l2g[le[:, 0]], part.l2g[le[:, 1]])
-    e_owner = owner[g0]
+    ga, gb = part.l2g[le[:, 0]], part.l2g[le[:, 1]]
+    g0 = np.minimum(ga, gb)
+    g1 = np.maximum(ga, gb)
+    e_owner = owner[np.where(oid[ga] < oid[gb], ga, gb)]
     neo = int((e_owner == rank).sum())
     if not (np.all(e_owner[:neo] == rank) and np.all(e_owner[neo:] != rank)):
         raise AssertionError("device edge table is not ordered owned-first")
@@ -289,11 +306,12 @@ def build_p2_plan(cells, owner, rank, part, local_edges, global_edges):
         ge = ge[np.argsort(lkey[ge])]
         recv_lists.append(np.concatenate([node_of_vertex[gv], node_of_edge[ge]]).astype(np.int32))
         # send: my vertices (LocalPart order) and my edges that live in a cell local to q
-        touch = mine_cells[(owner[mine_cells] == q).any(axis=1)]
+        touch = mine_cells[(owner[mine_cells] == q).any(axis=1)] if part_cells_of is None else cells[part_cells_of(q)]
         a = np.concatenate([touch[:, i] for i, _ in _TET_EDGES])
         b = np.concatenate([touch[:, j] for _, j in _TET_EDGES])
-        k = np.unique(_edge_keys(a, b, n_global))
-        k = k[owner[k // n_global] == rank]                      # owner = owner of the smaller global id
+        k, first = np.unique(_edge_keys(a, b, n_global), return_index=True)
+        a, b = a[first], b[first]
+        k = k[owner[np.where(oid[a] < oid[b], a, b)] == rank]   # owner = owner of the end point of smaller (order) id
         pos = lsort[np.searchsorted(lkey[lsort], k)]
         if not np.array_equal(lkey[pos], k):
             raise AssertionError("an edge to send is not a local edge")

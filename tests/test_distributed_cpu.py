@@ -275,3 +275,81 @@ def test_parts_of_a_periodic_space_hold_the_masters_of_their_slaves(world, axis)
             assert np.array_equal(pq.l2g[pq.send_lists[pq.neighbors.index(r)]], ghosts_from_q)
         assert off == part.n_local
     assert np.all(covered == 1)
+
+
+@pytest.mark.parametrize("world,axis", [(2, 2), (3, 2), (3, 1), (4, 0)])
+def test_periodic_cg2_parts_own_slave_and_master_edges_together(world, axis):
+    """Periodic constraints on CG2 spaces under decomposition (round 5; reference SolverBase.py:263-270 is degree-agnostic).  The
+    master of a slave EDGE node is an edge node: build_local_part(tied_cells=True) brings the cells around the masters of a part's
+    slave vertices, and with ORDER ids (a slave right behind its master) as the ids that decide who owns an edge, a slave edge and
+    its master edge are owned by one rank.  Held: every local slave node has its master in the part; slave and master edge nodes
+    have one owner; both sides of every exchange agree, node for node; the owned sets partition the nodes; and every cell pattern
+    coupling of the folded operator with an owned row is local."""
+    nx, ny, nz = 3, 3, 8
+    box = (1.0, 0.9, 2.4)
+    co, ce = fo.box_mesh((0, 0, 0), box, nx, ny, nz)
+    ce = ce.astype(np.int64)
+    nvg = len(co)
+    slaves = np.nonzero(np.isclose(co[:, axis], box[axis]))[0]
+    key = lambda idx: [tuple(np.round(np.delete(co[i], axis), 9)) for i in idx]
+    m0 = np.nonzero(np.isclose(co[:, axis], 0.0))[0]
+    lookup = {k: i for k, i in zip(key(m0), m0)}
+    masters = np.array([lookup[k] for k in key(slaves)])
+    cd, edges_g = fo.p2_cell_dofs(nvg, ce)
+    edges_g = np.asarray(edges_g, dtype=np.int64)
+    n_nodes = nvg + len(edges_g)
+    # node-level pairs: an edge whose end points fold onto another edge's is tied to it
+    fold_v = np.arange(nvg, dtype=np.int64)
+    fold_v[slaves] = masters
+    ekey = {tuple(sorted(e)): k for k, e in enumerate(edges_g.tolist())}
+    node_fold = np.arange(n_nodes, dtype=np.int64)
+    node_fold[slaves] = masters
+    for k, (a, b) in enumerate(edges_g.tolist()):
+        fa, fb = fold_v[a], fold_v[b]
+        if (fa, fb) != (a, b) and fa != fb and tuple(sorted((fa, fb))) in ekey:
+            node_fold[nvg + k] = nvg + ekey[tuple(sorted((fa, fb)))]
+    assert (node_fold[nvg:] != np.arange(nvg, n_nodes)).sum() > 0
+    owner = np.array(partition.slab_owner(co, world, axis=2))
+    owner[slaves] = owner[masters]
+    order_id = 2 * fold_v
+    order_id[slaves] += 1
+    master_of = np.full(nvg, -1, dtype=np.int64)
+    master_of[slaves] = masters
+    cells_of = lambda q: partition._local_cell_mask(ce, owner, q, None, master_of)
+    plans, parts = [], []
+    for r in range(world):
+        part = partition.build_local_part(ce, owner, r, tied=(slaves, masters), tied_cells=True)
+        assert np.array_equal(np.sort(part.cell_gids), np.nonzero(cells_of(r))[0])
+        # the device's edge table: unique local vertex pairs, owned first - an edge belongs to the owner of its end of smaller ORDER id
+        c = part.cells.astype(np.int64)
+        pairs = np.unique(np.concatenate([np.sort(c[:, [i, j]], axis=1) for i, j in partition._TET_EDGES]), axis=0)
+        oid = order_id[part.l2g[pairs]]
+        vmin = np.where(oid[:, 0] < oid[:, 1], pairs[:, 0], pairs[:, 1])
+        ghost = vmin >= part.n_owned
+        le = np.concatenate([pairs[~ghost], pairs[ghost]])
+        plans.append(partition.build_p2_plan(ce, owner, r, part, le, edges_g, order_id=order_id, part_cells_of=cells_of))
+        parts.append(part)
+    node_owner = np.full(n_nodes, -1)
+    for r, pl in enumerate(plans):
+        assert np.all(node_owner[pl.l2g_nodes[:pl.n_owned_nodes]] == -1)
+        node_owner[pl.l2g_nodes[:pl.n_owned_nodes]] = r
+    assert np.all(node_owner >= 0)                                         # the owned sets partition the nodes
+    assert np.array_equal(node_owner, node_owner[node_fold])               # a slave lives with its master - edges too
+    cells_nodes = cd.astype(np.int64)
+    for r, pl in enumerate(plans):
+        g2l = np.full(n_nodes, -1, dtype=np.int64)
+        g2l[pl.l2g_nodes] = np.arange(len(pl.l2g_nodes))
+        local = pl.l2g_nodes
+        assert (g2l[node_fold[local]] >= 0).all(), "a local slave node's master is not in the part of rank %d" % r
+        ghosts = np.concatenate(pl.recv_lists) if pl.recv_lists else np.zeros(0, dtype=np.int64)
+        assert sorted(ghosts.tolist()) == list(range(pl.n_owned_nodes, len(pl.l2g_nodes)))
+        for qi, q in enumerate(pl.neighbors):
+            back = plans[q].neighbors.index(r)
+            assert np.array_equal(plans[q].l2g_nodes[plans[q].send_lists[back]], pl.l2g_nodes[pl.recv_lists[qi]])
+            assert np.all(plans[q].send_lists[back] < plans[q].n_owned_nodes)
+        # folded pattern: rows fold(i), columns fold(j) for all (i, j) of a cell; those with an owned row must be local
+        rows = node_fold[np.repeat(cells_nodes, 10, axis=1).ravel()]
+        cols = node_fold[np.tile(cells_nodes, (1, 10)).ravel()]
+        mine = node_owner[rows] == r
+        assert (g2l[cols[mine]] >= 0).all(), "a folded row of rank %d couples with a node outside its part" % r
+

@@ -152,7 +152,8 @@ def test_vector_space_slabs_over_ranks(gpu, tmp_path, world, mode):
 @pytest.mark.parametrize("case,world", [("heat", 2), ("heat_cn", 2), ("elasticity", 2), ("heat_p2", 2), ("heat_p2", 3), ("heat_supg", 2),
                                         ("heat_supg_field", 2), ("heat_p2_supg_field", 2), ("heat_ip", 2), ("heat_ip", 3), ("elasticity_pfield", 2), ("elasticity_p2_pfield", 2),
                                         ("heat_periodic_y", 2), ("heat_periodic_z", 2), ("heat_periodic_z", 3), ("heat_periodic_z_cn", 2),
-                                        ("elasticity_periodic", 2), ("elasticity_periodic", 3)])
+                                        ("elasticity_periodic", 2), ("elasticity_periodic", 3),
+                                        ("heat_p2_periodic_y", 2), ("heat_p2_periodic_z", 2), ("heat_p2_periodic_z", 3), ("elasticity_p2_periodic", 2)])
 def test_solver_classes_under_several_ranks(gpu, tmp_path, case, world):
     _solver_classes_case(gpu, tmp_path, case, world)
 

@@ -260,7 +260,10 @@ CASES = {"heat": lambda: _heat_case(), "heat_cn": lambda: _heat_case(transient=T
          # periodic_boundary under decomposition (round 4): slaves owned by their masters' rank, masters as extra ghosts
          "heat_periodic_y": lambda: _heat_case(periodic=1), "heat_periodic_z": lambda: _heat_case(periodic=2),
          "heat_periodic_z_cn": lambda: _heat_case(periodic=2, transient=True),
-         "elasticity_periodic": lambda: _elastic_case(periodic=1)}
+         "elasticity_periodic": lambda: _elastic_case(periodic=1),
+         # ... and of CG2 spaces (round 5): the cells around the masters in the part, edges owned through order ids
+         "heat_p2_periodic_y": lambda: _heat_case(4, degree=2, periodic=1), "heat_p2_periodic_z": lambda: _heat_case(4, degree=2, periodic=2),
+         "elasticity_p2_periodic": lambda: _elastic_case(degree=2, periodic=1)}
 
 
 @pytest.mark.parametrize("case", sorted(CASES) + sorted(NS_CASES))
