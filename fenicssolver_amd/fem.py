@@ -918,9 +918,10 @@ class FunctionSpace:
                 # a mesh in FILE order on one GPU: the same machinery with one part whose numbering is the locality order
                 root._device = self._make_parallel_device(root, backend, parallel, renumber=True)
             elif parallel.active():
-                if root._periodic is not None and (facet_coupling or getattr(root._mesh, "_slab", None) is not None):
+                if root._periodic is not None and (facet_coupling or getattr(root._mesh, "_slab", None) is not None or root._ncomp == 4):
                     raise SolverError("periodic_boundary (constrained_domain) under domain decomposition is built for P1 / P2 spaces on a "
-                                      "replicated host mesh (no interior-facet terms); BoxMesh(distributed=True): one GPU or the replicated box")
+                                      "replicated host mesh (no interior-facet terms); Taylor-Hood spaces: one GPU; "
+                                      "BoxMesh(distributed=True): one GPU or the replicated box")
                 root._device = self._make_parallel_device(root, backend, parallel, facet_coupling=facet_coupling)
             else:
                 pairs = None
