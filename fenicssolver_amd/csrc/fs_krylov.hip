@@ -953,7 +953,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
 // plan puts its class's coefficients at the offsets of that list, its X has the parity the list's window offsets were worked out for -
 // or the form is refused).
 // MEASURED (round 5, MI355X, configs[3], 9.98 M rows, profiles/r05_p2_lattice_tiles.txt): 158 us per product against 168 us for
-// k_dict_spmv in the space's numbering (both alone, no dots); inside the CG iteration, with the three dots, 207 against 190 us - the
+// k_dict_spmv on the same lattice-ordered operator (both alone, no dots; with the dots 199 against 230 us); inside the CG iteration
+// 198 - 207 us against 190 us for k_dict_spmv in the SPACE'S numbering (222 - 272 us for it in lattice order) - the
 // end rows (4 % of the rows) take 35 us, the dots' strided loads of r another 25.  Steps on the way: per-lane lists from LDS (three LDS
 // reads per entry, loop lengths set by the vertex rows) 342 us; lists through scalar loads 689 us; lists handed out with v_readlane
 // 240 us (16 cycles per readlane); LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us.  Used where the lattice order
@@ -3294,10 +3295,41 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
                 (void)hipEventSynchronize(e1);
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, e0, e1);
-                fprintf(stderr, "[lattice tiles]   %-44s %.1f us per product\n", v < 0 ? "work-item product (k_dict_spmv):" : (v == 0 ? "tile product:" : "tile product without the ends of the lines:"), ms * 100.0);
+                fprintf(stderr, "[lattice tiles]   %-44s %.1f us per product\n", v < 0 ? "work-item product on this operator:" : (v == 0 ? "tile product:" : "tile product without the ends of the lines:"), ms * 100.0);
             }
             g_lt_dbg = 0;
             g_lat.ok = true;
+            // the same with the three fused dots, and with 1 GB streamed between the launches (x, y out of the caches as behind the
+            // update kernel of an iteration): per-launch events
+            if (getenv("FS_LATTICE_DEBUG")[0] == '2') {
+                dbuf<double> big, part, rv2;
+                dbuf<int> st;
+                const int64_t nbig = (int64_t)128 << 20;
+                if (big.alloc(nbig) == FS_OK && part.alloc(3 * 4096) == FS_OK && st.alloc(8) == FS_OK && rv2.alloc(n + 2) == FS_OK) {
+                    (void)st.zero(s);
+                    hipLaunchKernelGGL(k_lat_fill, dim3(fs_grid_for(n + 2, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n + 2, rv2.p);
+                    for (int tile = 1; tile >= 0; --tile)
+                        for (int dots = 0; dots <= 3; dots += 3)
+                            for (int cold = 0; cold <= 1; ++cold) {
+                                g_lat.ok = tile != 0;
+                                float total = 0.f;
+                                for (int it = 0; it < 6; ++it) {
+                                    if (cold) hipLaunchKernelGGL(k_lat_fill, dim3(4096), dim3(FS_BLOCK), 0, s, nbig, big.p);
+                                    (void)hipEventRecord(e0, s);
+                                    if (dots) launch_spmv<3>(A, xv.p, y1.p, rv2.p, part.p, st.p, s, val, nullptr, 0, 0, 0, 0);
+                                    else launch_spmv<0>(A, xv.p, y1.p, nullptr, nullptr, nullptr, s, val, nullptr, 0, 0, 0, 0);
+                                    (void)hipEventRecord(e1, s);
+                                    (void)hipEventSynchronize(e1);
+                                    float ms = 0.f;
+                                    (void)hipEventElapsedTime(&ms, e0, e1);
+                                    if (it) total += ms;
+                                }
+                                fprintf(stderr, "[lattice tiles]   %s, %s, %s: %.1f us\n", tile ? "tile product" : "work-item product on this operator", dots ? "three dots" : "no dots",
+                                        cold ? "caches streamed over" : "warm", total * 200.0);
+                            }
+                    g_lat.ok = true;
+                }
+            }
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
         if (h[0] != 0) {
