@@ -964,6 +964,7 @@ constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity
 constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;
 constexpr int LT_WINH = LT_HX * LT_WY * LT_WZ;      // doubles of one parity half of the window
 constexpr int LT_WIN = 2 * LT_WINH;                 // 66 KB
+constexpr int LT_B2 = 4;                            // entries per batch of the paired-lines loop
 constexpr int LT_BLOCK = 512;                       // threads of a tile's workgroup (eight waves share one window)
 constexpr int LT_LO = 4, LT_HI = 5;                 // rows at the two ends of a line whose classes are their own: the boundary rows and - the operator is
                                                     // scaled with its diagonal - the rows coupled to them (and the dummy row that makes a line even)
@@ -1075,18 +1076,18 @@ __device__ __forceinline__ double lat_wave_rows(int c, int own, const double* __
         const int cn = __builtin_amdgcn_readfirstlane(tcnt[cm]);
         const double* __restrict__ cp = tcoef + (int64_t)cm * LT_ML;
         const int32_t* __restrict__ rp = trel + (int64_t)cm * LT_ML;
-        for (int k0 = 0; k0 < cn; k0 += 8) {        // (a list is padded to a multiple of 8 positions)
-            double cf[8], xv[8];
-            int32_t rl[8];
+        for (int k0 = 0; k0 < cn; k0 += LT_B2) {        // (a list is padded to a multiple of 8 positions)
+            double cf[LT_B2], xv[LT_B2];
+            int32_t rl[LT_B2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < LT_B2; ++e) {
                 cf[e] = cp[k0 + e];
                 rl[e] = k0 + e < cn ? rp[k0 + e] : 0;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = win[mine ? own + rl[e] : own];     // (another class's offsets may leave the window)
+            for (int e = 0; e < LT_B2; ++e) xv[e] = win[mine ? own + rl[e] : own];     // (another class's offsets may leave the window)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int e = 0; e < LT_B2; ++e)
                 if (k0 + e < cn && mine) a = fma(cf[e], xv[e], a);
         }
         todo &= ~__ballot(mine);
@@ -1135,15 +1136,15 @@ __device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int ow
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double a = 0.0, b = 0.0;
-    for (int k0 = 0; k0 < cn; k0 += 8) {
-        double xa[8], xb[8], cf[8];
-        int rl[8];
+    for (int k0 = 0; k0 < cn; k0 += LT_B2) {       // (batches of four: eight cost 28 more registers and spills at four waves per SIMD)
+        double xa[LT_B2], xb[LT_B2], cf[LT_B2];
+        int rl[LT_B2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
+        for (int e = 0; e < LT_B2; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xa[e] = win[own_a + rl[e]]; xb[e] = win[own_b + rl[e]]; }
+        for (int e = 0; e < LT_B2; ++e) { xa[e] = win[own_a + rl[e]]; xb[e] = win[own_b + rl[e]]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a = fma(cf[e], xa[e], a); b = fma(cf[e], xb[e], b); }
+        for (int e = 0; e < LT_B2; ++e) { a = fma(cf[e], xa[e], a); b = fma(cf[e], xb[e], b); }
     }
     __builtin_amdgcn_wave_barrier();        // (the next line's list overwrites the scratch)
     ra = a;
@@ -1175,7 +1176,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
     constexpr int U = 2 * NL / NWV;                 // (line, parity) pairs per wave
     auto finish = [&](int64_t r, double a, double zi, double ri) {
         y[r] = a;
-        if (DOTS && DOTS != 4) {
+        if (DOTS && DOTS != 4 && !(dbg & 4)) {
             if (DOTS == 1) { d_rz += ri * zi; d_wz += a * zi; d_rr += ri * ri; }
             else if (DOTS == 2) { d_rz += a * ri; d_wz += a * a; d_rr += ri * ri; }
             else if (DOTS == 3) { d_rz += zi * zi; d_wz += a * zi; d_rr += ri * zi * zi; }
@@ -1191,7 +1192,11 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         v2d wv[NW];
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
-            const int i = u * LT_BLOCK + (int)threadIdx.x;
+            int i = u * LT_BLOCK + (int)threadIdx.x;
+            // (opaque to the compiler: it otherwise computes the nine window positions of a thread once, ahead of the tile loop, keeps
+            // them in scratch at four waves per SIMD, and waits for each reload with vmcnt(0) - that is, for the window load before it:
+            // nine round trips per tile instead of one, + 60 us per product in the instantiations with the dots)
+            asm volatile("" : "+v"(i));
             wv[u] = v2d{0.0, 0.0};
             if (i < LT_WINH) {
                 const int xx = i % LT_HX, yy = (i / LT_HX) % LT_WY, zz = i / (LT_HX * LT_WY);
@@ -1205,16 +1210,24 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         }
         // ---- the rows of this thread: U line waves (line, parity); their class numbers, then the list of the wave's first class (lane k:
         // entries k and k + 64), asked for before the window is waited for
-        int64_t r[U];
-        int c[U], own[U];
+        // (row numbers as 32-bit, a row's own window position recomputed where it is used: registers are what this kernel is short of)
+        int32_t r[U];
+        int c[U];
+        double ri[U];
+        auto own_of = [&](int u) {
+            const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
+            return p * LT_WINH + (lane + 1) + LT_HX * ((line % LT_TY) + 2 + LT_WY * ((line / LT_TY) + 2));
+        };
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
             const int64_t X = x0 + 2 * lane + p, Y = y0 + (line % LT_TY), Z = z0 + (line / LT_TY);
             const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < NY && Z < NZ;
-            r[u] = in ? X + SX * (Y + NY * Z) : -1;
-            own[u] = p * LT_WINH + (lane + 1) + LT_HX * ((line % LT_TY) + 2 + LT_WY * ((line / LT_TY) + 2));
+            r[u] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
             c[u] = in ? (int)cls[r[u]] : -1;
+            // (the residual entries of the fused dots: asked for HERE.  Asked for next to the multiplication, their wait - the youngest
+            // loads of the wave: vmcnt(0) - was also a wait for the previous lines' stores of y: + 60 us per product)
+            ri[u] = (DOTS && DOTS != 4 && in && !(dbg & 2)) ? rvec[r[u]] : 0.0;
         }
         int cm[U], cn[U];
         bool uni[U];
@@ -1251,27 +1264,26 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             lat_list nxt = cur;
             if (j + 1 < U / 2) nxt = load_list(cm[j + 1]);      // (in flight while these lines are multiplied)
             const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
-            // (the residual entries of the fused dots: asked for now, needed behind the multiplication)
-            const double ria = (DOTS && DOTS != 4 && r[ua] >= 0) ? rvec[r[ua]] : 0.0, rib = (DOTS && DOTS != 4 && r[ub] >= 0) ? rvec[r[ub]] : 0.0;
+            const double ria = ri[ua], rib = ri[ub];
             if (both) {
                 double ra, rb;
-                lat_wave_rows_uniform2(cn[ua], own[ua], own[ub], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
-                if (r[ua] >= 0) finish(r[ua], ra, win[own[ua]], ria);
-                if (r[ub] >= 0) finish(r[ub], rb, win[own[ub]], rib);
+                lat_wave_rows_uniform2(cn[ua], own_of(ua), own_of(ub), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
+                if (r[ua] >= 0) finish(r[ua], ra, win[own_of(ua)], ria);
+                if (r[ub] >= 0) finish(r[ub], rb, win[own_of(ub)], rib);
             } else {
                 if (cn[ua] != 0) {
                     double a;
-                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own[ua], win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
-                    else a = lat_wave_rows(c[ua], own[ua], win, tcnt, tcoef, trel);
-                    if (r[ua] >= 0) finish(r[ua], a, win[own[ua]], ria);
+                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_of(ua), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
+                    else a = lat_wave_rows(c[ua], own_of(ua), win, tcnt, tcoef, trel);
+                    if (r[ua] >= 0) finish(r[ua], a, win[own_of(ua)], ria);
                 }
                 if (cn[ub] != 0) {          // (its list was not asked for ahead of time: tiles where the class changes between the planes)
                     double a;
                     if (uni[ub]) {
                         const lat_list lb = load_list(cm[ub]);
-                        a = lat_wave_rows_uniform(cn[ub], own[ub], win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
-                    } else a = lat_wave_rows(c[ub], own[ub], win, tcnt, tcoef, trel);
-                    if (r[ub] >= 0) finish(r[ub], a, win[own[ub]], rib);
+                        a = lat_wave_rows_uniform(cn[ub], own_of(ub), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
+                    } else a = lat_wave_rows(c[ub], own_of(ub), win, tcnt, tcoef, trel);
+                    if (r[ub] >= 0) finish(r[ub], a, win[own_of(ub)], rib);
                 }
             }
             cur = nxt;
@@ -3308,9 +3320,12 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
                 if (big.alloc(nbig) == FS_OK && part.alloc(3 * 4096) == FS_OK && st.alloc(8) == FS_OK && rv2.alloc(n + 2) == FS_OK) {
                     (void)st.zero(s);
                     hipLaunchKernelGGL(k_lat_fill, dim3(fs_grid_for(n + 2, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n + 2, rv2.p);
-                    for (int tile = 1; tile >= 0; --tile)
+                    for (int tile = 3; tile >= 0; --tile)
                         for (int dots = 0; dots <= 3; dots += 3)
                             for (int cold = 0; cold <= 1; ++cold) {
+                                if (tile >= 2 && (!dots || cold)) continue;
+                                g_lt_dbg = tile == 3 ? 2 : (tile == 2 ? 4 : 0);
+                                if (tile >= 2) fprintf(stderr, "[lattice tiles]   (ablation %d: %s)\n", g_lt_dbg, g_lt_dbg == 2 ? "no loads of r" : "no dot accumulation");
                                 g_lat.ok = tile != 0;
                                 float total = 0.f;
                                 for (int it = 0; it < 6; ++it) {
