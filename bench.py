@@ -559,6 +559,11 @@ def kernel_name(V, st=None):
     if st is not None and st.get("fused_iteration", 0):          # fs_krylov.hip k_dict_cg_iter: one launch per CG iteration
         return ("k_dict_cg_iter<3> (ONE launch per CG iteration: update of iteration k + row-dictionary product of iteration k + 1, "
                 "%d distinct rows in LDS; the new residual on the neighbour columns recomputed from the old r, w, s)" % st["row_classes"])
+    if st is not None and st.get("lattice_order", 0) and st.get("row_classes", 0) > 0:
+        # fs_krylov.hip k_lattice_spmv: the solver's lattice-ordered shadow of a scalar CG2 box operator (fs_lattice.hip)
+        return ("k_lattice_spmv<3> (row-dictionary form in the solver's LATTICE order of the half grid: %d distinct rows; tiles of 128 x 4 x 4 rows, "
+                "x through LDS windows, a wave per line parity with its class's row broadcast from LDS; the rows at the ends of the mesh lines per lane)"
+                % st["row_classes"])
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
         # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
         # class rows are 24 doubles per round of the longest run plan: 1 round on P1, 5 on CG2 Kuhn meshes) / per-item class rows

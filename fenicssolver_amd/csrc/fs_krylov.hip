@@ -2666,7 +2666,8 @@ static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 // UNION of its two alternating row patterns (an x-edge row of 27 entries rides the 26 runs of its vertex neighbours).  The kernel
 // is bound by those instructions, not by dependent rounds.  Option "lattice_order" / FS_LATTICE=1 turn it on.
 static int g_lat_check = getenv("FS_LATTICE_CHECK") && getenv("FS_LATTICE_CHECK")[0] == '1' ? 1 : 0;      // option "lattice_check"
-static int g_lattice = getenv("FS_LATTICE") && getenv("FS_LATTICE")[0] == '1' ? 1 : 0;
+static int g_lattice = getenv("FS_LATTICE") ? (getenv("FS_LATTICE")[0] == '1' ? 1 : (getenv("FS_LATTICE")[0] == '0' ? 0 : -1)) : -1;
+constexpr int64_t FS_LATTICE_MIN_ROWS = 400000;     // automatic (-1): from here on (274 k rows: 36.4 against 35.2 us per iteration; 1.03 M: 52.6 against 98.8)
 static inline bool bs_is_scalar_cg2(const fs_matrix_s* A) { return A->bs == 1 && A->space->degree == 2 && A->space->ncomp == 1; }
 static int g_cg_batch = 32;
 // one-launch iteration on one GPU: launches go out g_cg_sub at a time (one hipGraph) whenever the device - its progress is read from
@@ -2714,7 +2715,7 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "lattice_check")) {
         g_lat_check = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "lattice_order")) {
-        g_lattice = value != 0.0 ? 1 : 0;
+        g_lattice = value < 0.0 ? -1 : (value != 0.0 ? 1 : 0);
     } else if (!strcmp(name, "cg_mirror")) {
         g_cg_mirror = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "amg_coarse_fp32")) {
@@ -3917,7 +3918,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
     hipStream_t s = fs_rt().stream;
     // A scalar CG2 operator on a uniform box (one GPU) is solved in LATTICE order (fs_lattice.hip): values, b and x permuted into
     // the solver's shadow of the space, the solve run there (this function again, on the shadow's handles), x permuted back.
-    if (bs_is_scalar_cg2(A) && g_lattice && sp->lattice_state >= 0) {
+    // Automatic (option "lattice_order" = -1, the default): from FS_LATTICE_MIN_ROWS rows on, and only as long as the shadow's solves
+    // run on the tile product (a shadow whose rows do not fit the tile form - lat_prepare - is given up after its first solve).
+    if (bs_is_scalar_cg2(A) && (g_lattice > 0 || (g_lattice < 0 && sp->n_nodes_owned >= FS_LATTICE_MIN_ROWS)) && sp->lattice_state >= 0) {
         fs_lattice_shadow* L = nullptr;
         FS_CHECK(fs_lattice_get(sp, &L));
         if (L) {
@@ -3927,6 +3930,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             FS_CHECK(fs_lattice_enter(L, A, b, x, opts->nonzero_guess != 0, &A2, &b2, &x2));
             FS_CHECK(fs_krylov_solve(A2, b2, x2, opts, stats));
             FS_CHECK(fs_lattice_leave(L, sp, x));
+            if (g_lattice < 0 && !(g_lat.ok && g_lat.space_serial == A2->space->serial)) sp->lattice_state = -1;
             FS_HIP(hipStreamSynchronize(s));
             if (stats) {
                 stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

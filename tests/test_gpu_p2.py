@@ -509,7 +509,7 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
         small.A.apply_dirichlet(small.b, small.dofs, small.vals, symmetric=True)
         st_small = gpu.krylov_solve(small.A, small.b, small.x, rtol=1e-10, max_iter=5000)
     finally:
-        gpu.set_option("lattice_order", 0)
+        gpu.set_option("lattice_order", -1)
         gpu.set_option("lattice_check", 0)
         gpu.set_option("cg_fused", -1)
     (s2, x2, r2, g2, b2, y2) = got[2]           # the two-launch iteration on the tile product
@@ -525,3 +525,36 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
     assert b1["converged"] == 1 and np.abs(y1 - y0).max() <= 1e-7 * scale
     assert st_small["lattice_order"] == 0 and st_small["converged"] == 1
     assert np.abs(small.x.get()[:small.n_owned] - small.exact_owned).max() <= 1e-6 * scale
+
+
+
+def test_large_cg2_boxes_are_solved_in_lattice_order_by_default(gpu):
+    """Automatic choice (option lattice_order = -1, the default since the tile product beat the work-item product of the space's own
+    numbering - DESIGN.md section 3): from 400 000 rows on a scalar CG2 box operator is solved in the solver's lattice order, smaller
+    ones in the space's numbering; the two give the same solve."""
+    import bench
+    n = 37                       # 75^3 = 421 875 rows
+    prob = bench.P2Problem(n, (0, n + 1), 2, 0, 1)
+    prob.A.assemble(stiffness=20.0)
+    prob.b.fill(0.0)
+    prob.A.apply_dirichlet(prob.b, prob.dofs, prob.vals, symmetric=True)
+    try:
+        gpu.set_option("lattice_check", 1)
+        x1 = gpu.DeviceVector(prob.V.n_owned)
+        s1 = gpu.krylov_solve(prob.A, prob.b, x1, rtol=1e-10, max_iter=5000)
+        gpu.set_option("lattice_order", 0)
+        x0 = gpu.DeviceVector(prob.V.n_owned)
+        s0 = gpu.krylov_solve(prob.A, prob.b, x0, rtol=1e-10, max_iter=5000)
+    finally:
+        gpu.set_option("lattice_order", -1)
+        gpu.set_option("lattice_check", 0)
+    assert s1["lattice_order"] == 1 and s1["row_classes"] > 0 and s1["converged"] == 1
+    assert s0["lattice_order"] == 0 and s0["converged"] == 1 and abs(s1["iterations"] - s0["iterations"]) <= 1
+    scale = np.abs(x0.get()).max()
+    assert np.abs(x1.get() - x0.get()).max() <= 1e-9 * scale
+    small = bench.P2Problem(24, (0, 25), 2, 0, 1)      # 49^3 = 117 649 rows: the space's own numbering
+    small.A.assemble(stiffness=20.0)
+    small.b.fill(0.0)
+    small.A.apply_dirichlet(small.b, small.dofs, small.vals, symmetric=True)
+    st = gpu.krylov_solve(small.A, small.b, small.x, rtol=1e-10, max_iter=5000)
+    assert st["lattice_order"] == 0 and st["converged"] == 1
