@@ -1188,24 +1188,26 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         const int64_t x0 = xc * LT_TX, y0 = yt * LT_TY, z0 = zt * LT_TZ;
         // ---- the window of x: lines (y0 - 2 .. y0 + LT_TY + 1) x (z0 - 2 .. ) from X = x0 - 2 on, one 16-byte load per (even, odd)
         // pair, all of a thread's loads in flight together; outside the lattice: zero
-        constexpr int NW = (LT_WINH + LT_BLOCK - 1) / LT_BLOCK;
+        // A wave takes LPW whole window lines: lane l the pair l + 1 of each (64 of the 66 pairs of a line, 1 KB per wave and load, the
+        // line's start and validity wave-uniform), and in one more load the 2 x LPW pairs at the ends of its lines.  (Dealing the
+        // window's pairs to the threads by index cost a division chain per load - which the compiler hoisted out of the tile loop
+        // into scratch, whose reloads it then waited for with vmcnt(0): every window load behind the one before it, + 60 us.)
+        constexpr int LPW = LT_WY * LT_WZ / NWV;        // window lines per wave
+        static_assert(LPW * NWV == LT_WY * LT_WZ && 2 * LPW <= 64 && LT_HX == 66, "window lines are dealt to the waves whole");
+        constexpr int NW = LPW + 1;
         v2d wv[NW];
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
-            int i = u * LT_BLOCK + (int)threadIdx.x;
-            // (opaque to the compiler: it otherwise computes the nine window positions of a thread once, ahead of the tile loop, keeps
-            // them in scratch at four waves per SIMD, and waits for each reload with vmcnt(0) - that is, for the window load before it:
-            // nine round trips per tile instead of one, + 60 us per product in the instantiations with the dots)
-            asm volatile("" : "+v"(i));
+            // u < LPW: line wave * LPW + u, pair lane + 1; u == LPW: lanes 0 .. 2 LPW - 1: line wave * LPW + (lane >> 1), pair 0 / 65
+            const int wline = wave * LPW + (u < LPW ? u : (lane >> 1) % LPW);
+            const int xx = u < LPW ? lane + 1 : ((lane & 1) ? LT_HX - 1 : 0);
+            const int yy = wline % LT_WY, zz = wline / LT_WY;
+            const int64_t Y = y0 - 2 + yy, Z = z0 - 2 + zz;
             wv[u] = v2d{0.0, 0.0};
-            if (i < LT_WINH) {
-                const int xx = i % LT_HX, yy = (i / LT_HX) % LT_WY, zz = i / (LT_HX * LT_WY);
-                const int64_t Y = y0 - 2 + yy, Z = z0 - 2 + zz;
-                if (Y >= 0 && Y < NY && Z >= 0 && Z < NZ) {
-                    int64_t g = x0 - 2 + 2 * xx + SX * (Y + NY * Z);       // (even: SX and x0 are)
-                    g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);               // columns before / behind the vector carry no entry
-                    wv[u] = *reinterpret_cast<const v2d*>(x + g);
-                }
+            if ((u < LPW || lane < 2 * LPW) && Y >= 0 && Y < NY && Z >= 0 && Z < NZ) {
+                int64_t g = x0 - 2 + 2 * xx + SX * (Y + NY * Z);       // (even: SX and x0 are)
+                g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);               // columns before / behind the vector carry no entry
+                wv[u] = *reinterpret_cast<const v2d*>(x + g);
             }
         }
         // ---- the rows of this thread: U line waves (line, parity); their class numbers, then the list of the wave's first class (lane k:
@@ -1253,8 +1255,10 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         lat_list cur = load_list(cm[0]);
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
-            const int i = u * LT_BLOCK + (int)threadIdx.x;
-            if (i < LT_WINH) { win[i] = wv[u].x; win[LT_WINH + i] = wv[u].y; }
+            const int wline = wave * LPW + (u < LPW ? u : (lane >> 1) % LPW);
+            const int xx = u < LPW ? lane + 1 : ((lane & 1) ? LT_HX - 1 : 0);
+            const int i = xx + LT_HX * wline;
+            if (u < LPW || lane < 2 * LPW) { win[i] = wv[u].x; win[LT_WINH + i] = wv[u].y; }
         }
         __syncthreads();
 #pragma unroll
