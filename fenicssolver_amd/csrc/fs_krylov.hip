@@ -952,13 +952,15 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
 // The lists come from the class rows and the plans (k_lat_table: one representative row per class; then EVERY row is checked: its
 // plan puts its class's coefficients at the offsets of that list, its X has the parity the list's window offsets were worked out for -
 // or the form is refused).
-// MEASURED (round 5, MI355X, configs[3], 9.98 M rows, profiles/r05_p2_lattice_tiles.txt): 158 us per product against 168 us for
-// k_dict_spmv on the same lattice-ordered operator (both alone, no dots; with the dots 199 against 230 us); inside the CG iteration
-// 198 - 207 us against 190 us for k_dict_spmv in the SPACE'S numbering (222 - 272 us for it in lattice order) - the
-// end rows (4 % of the rows) take 35 us, the dots' strided loads of r another 25.  Steps on the way: per-lane lists from LDS (three LDS
-// reads per entry, loop lengths set by the vertex rows) 342 us; lists through scalar loads 689 us; lists handed out with v_readlane
-// 240 us (16 cycles per readlane); LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us.  Used where the lattice order
-// is (option "lattice_order", off by default).
+// MEASURED (round 5, MI355X, configs[3], 9.98 M rows, profiles/r05_p2_lattice_tiles.txt): inside the CG iteration, with the three dots,
+// 155 us per product against 187 - 195 us for k_dict_spmv in the SPACE'S numbering and 222 - 272 us for it in lattice order; alone 134 us
+// without / 149 us with the dots (the work-item product on the same operator: 168 / 230 us).  Of the 134 us the rows at the ends of the
+// lines (4 % of the rows) take 30.  Steps on the way (all bit-identical): per-lane lists from LDS (three LDS reads per entry, loop lengths
+// set by the vertex rows) 342 us; lists through scalar loads 689 us; lists handed out with v_readlane 240 us (16 cycles per readlane);
+// LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us; batches of four entries (no spills in the loop) 137 us; and the
+// one that decided it: the compiler had hoisted every thread's nine window positions out of the tile loop into scratch and waited for
+// each reload with vmcnt(0) - for the window load before it -, nine round trips per tile instead of one: with the dots 197 -> 154 us;
+// whole window lines per wave (no division chains) 149 us.  Automatic from 400 000 rows on (option "lattice_order").
 constexpr int LT_TX = 128, LT_TY = 4, LT_TZ = 4;
 constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity in a window line
 constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;

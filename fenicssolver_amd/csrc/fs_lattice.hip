@@ -14,9 +14,11 @@
 // back: the matrix values through a precomputed entry map (one scattered copy per solve, 1 % of a 10 M-row solve), b and x through
 // the node permutation.  Everything structural is built once per space, on the device.
 //
-// MEASURED (round 5, MI355X, configs[3]): correct - same iterations, solutions equal to 1e-10 - and SLOWER: 222 - 272 us per product
-// against 191 us in the space's numbering (fs_krylov.hip, g_lattice).  Off by default; kept as the permutation machinery a kernel
-// with one plan per node class (no union padding) would run on.
+// MEASURED (round 5, MI355X, configs[3]): the WORK-ITEM product (k_dict_spmv) on this order is slower than on the space's numbering - 222 -
+// 272 us against 191 us -, the TILE product written for it (fs_krylov.hip, k_lattice_spmv: x through LDS windows, a wave per line parity,
+// class lists broadcast) is faster: 155 us, the iteration 282 against 297 us; at 1.03 M rows 52.6 against 98.8 us per iteration (there the
+// space's numbering gets no dictionary at all).  Automatic from 400 000 rows on (option "lattice_order" = -1), given up for a space whose
+// shadow does not fit the tile form.
 #include "fs_common.h"
 
 struct fs_lattice_shadow {
