@@ -966,6 +966,9 @@ constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity
 constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;
 constexpr int LT_WINH = LT_HX * LT_WY * LT_WZ;      // doubles of one parity half of the window
 constexpr int LT_WIN = 2 * LT_WINH;                 // 66 KB
+constexpr int CT_XW = 8, CT_Y = 128, CT_Z = 4;     // column tiles (the ends of the lines): X positions of the window, rows along Y, planes
+static_assert(2 * LT_HX * CT_XW * (CT_Z + 4) == LT_WIN && CT_Y / 2 + 2 == LT_HX, "a column tile's window is the tile window's LDS");
+constexpr int LT_LOY = 4, LT_HIY = 4;               // rows at the two ends of a COLUMN whose classes are their own (as LT_LO / LT_HI; no dummy row in Y)
 constexpr int LT_B2 = 4;                            // entries per batch of the paired-lines loop
 constexpr int LT_BLOCK = 512;                       // threads of a tile's workgroup (eight waves share one window)
 constexpr int LT_LO = 4, LT_HI = 5;                 // rows at the two ends of a line whose classes are their own: the boundary rows and - the operator is
@@ -975,6 +978,7 @@ constexpr int LT_ML = 72;                           // entries per class row (a 
 static int g_lt_dbg = 0;     // (FS_LATTICE_DEBUG times k_lattice_spmv once more without the rows at the ends of the lines: 1)
 struct lat_tables {
     dbuf<int32_t> rep, cnt, off, rel;   // [ncls] representative row, [ncls] entries, [ncls][LT_ML] column offsets (verification) / window offsets
+    dbuf<int32_t> relc;                 // [ncls][LT_ML] the offsets in the window of a COLUMN tile (the ends of the lines: lanes along Y)
     dbuf<double> coef;                  // [ncls][LT_ML]
     dbuf<int> info;                     // [0] entries that do not fit / rows whose plan or parity disagrees
     const double* built_for = nullptr;
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const i
                                                         const uint16_t* __restrict__ cls, const int32_t* __restrict__ rep,
                                                         const double* __restrict__ values, int S, int RL, int NR, int64_t SX, int64_t NY,
                                                         int32_t* __restrict__ cnt, double* __restrict__ coef, int32_t* __restrict__ rel,
-                                                        int32_t* __restrict__ off, int* __restrict__ info) {
+                                                        int32_t* __restrict__ off, int* __restrict__ info, int32_t* __restrict__ relc) {
     const int lane = threadIdx.x & 63;
     int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1016,11 +1020,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const i
             const int i = half * 64 + lane;
             const int32_t r = first + i;
             const int c = i < nr ? (int)cls[r] : -1;
-            const int p = (int)((r % SX) & 1);
+            const int p = (int)((r % SX) & 1), py = (int)(((r / SX) % NY) & 1);
             bool work;
             if (BUILD) work = c >= 0 && rep[c] == r;
             else {      // the first lane of every class among these 64 rows
-                if (c >= 0 && ((rep[c] % SX) & 1) != p && !(cnt[c] == 1 && off[(int64_t)c * LT_ML] == 0)) ++bad;
+                if (c >= 0 && (((rep[c] % SX) & 1) != p || (((rep[c] / SX) % NY) & 1) != py) && !(cnt[c] == 1 && off[(int64_t)c * LT_ML] == 0)) ++bad;
                 work = false;
                 unsigned long long todo = __ballot(c >= 0);
                 while (todo) {
@@ -1054,6 +1058,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const i
                             coef[(int64_t)c * LT_ML + k] = v;
                             off[(int64_t)c * LT_ML + k] = o;
                             rel[(int64_t)c * LT_ML + k] = (p2 - p) * LT_WINH + di + LT_HX * ((int)dy + LT_WY * (int)dz);
+                            // column tiles: the two halves hold the even / odd Y, a line of the window runs along Y
+                            const int qd = py + (int)dy, q2 = qd & 1, dj = (qd - q2) / 2;
+                            relc[(int64_t)c * LT_ML + k] = (q2 - py) * LT_WINH + dj + LT_HX * ((int)dx + CT_XW * (int)dz);
                         } else ++bad;
                     } else if (k >= have || off[(int64_t)c * LT_ML + k] != o) ++bad;
                     ++k;
@@ -1156,7 +1163,7 @@ __device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int ow
 template <int DOTS>
 __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, int nxc, int nyt, int64_t SX, int64_t NY, int64_t NZ,
                                                            const uint16_t* __restrict__ cls, const int32_t* __restrict__ tcnt,
-                                                           const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff,
+                                                           const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff, const int32_t* __restrict__ trelc,
                                                            const double* __restrict__ x, double* __restrict__ y,
                                                            const double* __restrict__ rvec, double* __restrict__ partials,
                                                            int* __restrict__ status, int part_base, int part_stride, int bump, int dbg) {
@@ -1184,6 +1191,153 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             else if (DOTS == 3) { d_rz += zi * zi; d_wz += a * zi; d_rr += ri * zi * zi; }
         }
     };
+    // ---- FIRST the corners: rows of the end columns within LT_LOY / LT_HIY of the ends of their column; every lane its own list, everything
+    // from global memory - a chain of dependent loads, 19 us for 0.2 % of the rows when it ran behind the tiles.  A wave: one column, eight
+    // planes x the eight rows.  Corners and column tiles go to the workgroups counted from the LAST: the tiles are dealt out from the
+    // first (xcd_chunks), so these have one tile less to do than the others.
+    {
+        const int nzb = (int)((NZ + 7) >> 3);
+        const int64_t n_tasks = (int64_t)(LT_LO + LT_HI) * nzb;
+        for (int64_t t = (int64_t)(gridDim.x - 1 - blockIdx.x) * NWV + wave; t < n_tasks && !(dbg & 9); t += (int64_t)gridDim.x * NWV) {
+            const int col = (int)(t % (LT_LO + LT_HI)), d = lane & 7;
+            const int64_t Z = (t / (LT_LO + LT_HI)) * 8 + (lane >> 3);
+            const int64_t Y = d < LT_LOY ? d : NY - (LT_LOY + LT_HIY) + d;
+            const int64_t X = col < LT_LO ? col : SX - (LT_LO + LT_HI) + col;
+            const bool in = Z < NZ;
+            const int64_t rr = X + SX * (Y + NY * (in ? Z : 0));
+            const int cc = (int)cls[rr];
+            int most = in ? tcnt[cc] : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int m2 = __shfl_xor(most, o, 64); most = m2 > most ? m2 : most; }
+            const double* __restrict__ cp = tcoef + (int64_t)cc * LT_ML;
+            const int32_t* __restrict__ op = toff + (int64_t)cc * LT_ML;
+            double a = 0.0;
+            for (int k0 = 0; k0 < most; k0 += 8) {       // (behind a list's end: (0.0, offset 0))
+                double cf[8], xv[8];
+                int32_t of[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cf[e] = cp[k0 + e]; of[e] = op[k0 + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = x[rr + of[e]];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
+            }
+            if (in) finish(rr, a, x[rr], (DOTS && DOTS != 4) ? rvec[rr] : 0.0);
+        }
+    }
+    // ---- the first LT_LO and the last LT_HI rows of every line (classes of their own): COLUMN tiles.  Along Y such a column is what a line
+    // is along X - rows of one class per parity -, so the same machinery runs with the roles of X and Y exchanged: a workgroup takes
+    // the end columns of one side x 128 Y x 4 Z, loads the window (8 X positions x 132 Y x 8 Z: the same 66 KB, even and odd Y in two
+    // halves, a line of the window along Y), a wave the 64 rows of one Y parity of one (column, plane), two planes two apart together.
+    // The rows at the ends of the COLUMNS (first / last four Y: classes of their own again, 0.2 % of the rows) follow per lane below.
+    const int nycc = (int)((NY + CT_Y - 1) / CT_Y), nzc = (int)((NZ + CT_Z - 1) / CT_Z);
+    const int64_t n_ct = (int64_t)2 * nycc * nzc;
+    for (int64_t ct = gridDim.x - 1 - blockIdx.x; ct < n_ct && !(dbg & 1); ct += gridDim.x) {
+        const int side = (int)(ct & 1);
+        const int64_t ycn = (ct >> 1) % nycc, zcn = (ct >> 1) / nycc;
+        const int64_t y0 = ycn * CT_Y, z0 = zcn * CT_Z;
+        const int64_t xw0 = side ? SX - CT_XW : 0;                  // X of window position 0
+        const int ncol = side ? LT_HI : LT_LO;
+        const int64_t col0 = side ? SX - LT_HI : 0;                 // first end column of this side
+        // window: wave w takes plane w; its items (Y line, pair of X positions): 132 x 4, four lanes a line's 64 bytes
+        constexpr int NIT = (2 * LT_HX * (CT_XW / 2) + 63) / 64;
+        v2d wv[NIT];
+        {
+            const int64_t Z = z0 - 2 + wave;
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int item = u * 64 + lane, yl = item >> 2, xp = item & 3;
+                const int64_t Y = y0 - 2 + yl;
+                wv[u] = v2d{0.0, 0.0};
+                if (yl < 2 * LT_HX && Y >= 0 && Y < NY && Z >= 0 && Z < NZ)
+                    wv[u] = *reinterpret_cast<const v2d*>(x + xw0 + 2 * xp + SX * (Y + NY * Z));
+            }
+        }
+        // pairs of column lines: q = (column, Y parity, plane pair): planes zl and zl + 2
+        const int npair = ncol * 4;
+        constexpr int UC = (LT_HI * 4 + NWV - 1) / NWV;
+        int32_t r[2 * UC];
+        int c[2 * UC];
+        double ri[2 * UC];
+        auto own_c = [&](int q, int half) {
+            const int col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
+            return py * LT_WINH + (lane + 1) + LT_HX * ((int)(col0 - xw0) + col + CT_XW * (zl + 2));
+        };
+#pragma unroll
+        for (int j = 0; j < UC; ++j)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int q = wave + NWV * j, col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
+                const int64_t X = col0 + col, Y = y0 + 2 * lane + py, Z = z0 + zl;
+                const bool in = q < npair && Y >= LT_LOY && Y <= NY - 1 - LT_HIY && Z < NZ;
+                r[2 * j + half] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
+                c[2 * j + half] = in ? (int)cls[r[2 * j + half]] : -1;
+                ri[2 * j + half] = (DOTS && DOTS != 4 && in) ? rvec[r[2 * j + half]] : 0.0;
+            }
+        int cm[2 * UC], cn[2 * UC];
+        bool uni[2 * UC];
+#pragma unroll
+        for (int u = 0; u < 2 * UC; ++u) {
+            const unsigned long long live = __ballot(c[u] >= 0);
+            cm[u] = live ? __builtin_amdgcn_readlane(c[u], __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
+            uni[u] = __ballot(c[u] == cm[u]) == live;
+            cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
+        }
+        struct lat_list { double c0, c1; int r0, r1; };
+        auto load_list = [&](int cls_m) {
+            lat_list L;
+            const int64_t at = (int64_t)cls_m * LT_ML + lane;
+            L.c0 = tcoef[at];
+            L.r0 = trelc[at];
+            L.c1 = tcoef[at + 64];
+            L.r1 = trelc[at + 64];
+            return L;
+        };
+        lat_list cur = load_list(cm[0]);
+        {
+            const int zz = wave;
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int item = u * 64 + lane, yl = item >> 2, xp = item & 3;
+                if (yl < 2 * LT_HX) {
+                    const int i = (yl & 1) * LT_WINH + (yl >> 1) + LT_HX * (2 * xp + CT_XW * zz);
+                    win[i] = wv[u].x;
+                    win[i + LT_HX] = wv[u].y;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < UC; ++j) {
+            const int ua = 2 * j, ub = 2 * j + 1, q = wave + NWV * j;
+            lat_list nxt = cur;
+            if (j + 1 < UC) nxt = load_list(cm[2 * (j + 1)]);
+            const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
+            if (both) {
+                double ra, rb;
+                lat_wave_rows_uniform2(cn[ua], own_c(q, 0), own_c(q, 1), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
+                if (r[ua] >= 0) finish(r[ua], ra, win[own_c(q, 0)], ri[ua]);
+                if (r[ub] >= 0) finish(r[ub], rb, win[own_c(q, 1)], ri[ub]);
+            } else {
+                if (cn[ua] != 0) {
+                    double a;
+                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_c(q, 0), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
+                    else a = lat_wave_rows(c[ua], own_c(q, 0), win, tcnt, tcoef, trelc);
+                    if (r[ua] >= 0) finish(r[ua], a, win[own_c(q, 0)], ri[ua]);
+                }
+                if (cn[ub] != 0) {
+                    double a;
+                    if (uni[ub]) {
+                        const lat_list lb = load_list(cm[ub]);
+                        a = lat_wave_rows_uniform(cn[ub], own_c(q, 1), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
+                    } else a = lat_wave_rows(c[ub], own_c(q, 1), win, tcnt, tcoef, trelc);
+                    if (r[ub] >= 0) finish(r[ub], a, win[own_c(q, 1)], ri[ub]);
+                }
+            }
+            cur = nxt;
+        }
+        __syncthreads();
+    }
     for (chunk_iter it = xcd_chunks(n_tiles); it.cur < it.end; it.cur += it.step) {
         const int64_t tile = it.cur;
         const int64_t xc = tile % nxc, yt = (tile / nxc) % nyt, zt = tile / ((int64_t)nxc * nyt);
@@ -1295,38 +1449,6 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             cur = nxt;
         }
         __syncthreads();            // (the next tile overwrites the window)
-    }
-    // ---- the first LT_LO and the last LT_HI rows of every line (classes of their own): 64 consecutive Y of one column and plane per
-    // wave, every lane its own list; coefficients, offsets and x from global memory, eight entries in flight.  (Tried: waves of one Y
-    // parity - lists of one length - with the next eight pairs asked for ahead: 33 instead of 26 us.)
-    {
-        const int nyc = (int)((NY + 63) >> 6);
-        const int64_t n_tasks = (int64_t)(LT_LO + LT_HI) * NZ * nyc;
-        for (int64_t t = (int64_t)blockIdx.x * (LT_BLOCK / 64) + wave; t < n_tasks && !(dbg & 1); t += (int64_t)gridDim.x * (LT_BLOCK / 64)) {
-            const int col = (int)(t % (LT_LO + LT_HI));
-            const int64_t Z = (t / (LT_LO + LT_HI)) % NZ, Y = ((t / (LT_LO + LT_HI)) / NZ) * 64 + lane;
-            const int64_t X = col < LT_LO ? col : SX - (LT_LO + LT_HI) + col;
-            const bool in = Y < NY;
-            const int64_t rr = X + SX * ((in ? Y : 0) + NY * Z);
-            const int cc = (int)cls[rr];
-            int most = in ? tcnt[cc] : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int m2 = __shfl_xor(most, o, 64); most = m2 > most ? m2 : most; }
-            const double* __restrict__ cp = tcoef + (int64_t)cc * LT_ML;
-            const int32_t* __restrict__ op = toff + (int64_t)cc * LT_ML;
-            double a = 0.0;
-            for (int k0 = 0; k0 < most; k0 += 8) {       // (behind a list's end: (0.0, offset 0))
-                double cf[8], xv[8];
-                int32_t of[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { cf[e] = cp[k0 + e]; of[e] = op[k0 + e]; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = x[rr + of[e]];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
-            }
-            if (in) finish(rr, a, x[rr], (DOTS && DOTS != 4) ? rvec[rr] : 0.0);
-        }
     }
     if (DOTS && DOTS != 4) {
         // (fixed order: shuffle reduction per wave, the waves' sums added in order by thread 0)
@@ -3254,12 +3376,13 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     if (off || sp->lat_ny <= 0 || A->bs != 1 || g_dict.built_for != val || g_dict.bs != 1 || g_dict.space_serial != sp->serial || sp->n_dict_items <= 0) return FS_OK;
     const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz, n = SX * NY * NZ;
     const int ncls = g_dict.ncls;
-    if (n != sp->n_nodes_owned || sp->n_nodes_local != sp->n_nodes_owned || NY < 6 || SX < 2 * (LT_LO + LT_HI) || (SX & 1) || ncls <= 0) return FS_OK;
+    if (n != sp->n_nodes_owned || sp->n_nodes_local != sp->n_nodes_owned || NY < 2 * (LT_LOY + LT_HIY) || SX < 2 * (LT_LO + LT_HI) || (SX & 1) || ncls <= 0) return FS_OK;
     if (g_lat.rep.n < ncls) {
         FS_CHECK(g_lat.rep.alloc(ncls));
         FS_CHECK(g_lat.cnt.alloc(ncls));
         FS_CHECK(g_lat.off.alloc((int64_t)ncls * LT_ML + 64));
         FS_CHECK(g_lat.rel.alloc((int64_t)ncls * LT_ML + 64));
+        FS_CHECK(g_lat.relc.alloc((int64_t)ncls * LT_ML + 64));
         FS_CHECK(g_lat.coef.alloc((int64_t)ncls * LT_ML + 64));
     }
     if (!g_lat.info.p) FS_CHECK(g_lat.info.alloc(4));
@@ -3267,13 +3390,14 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     FS_CHECK(g_lat.cnt.zero(s));
     FS_CHECK(g_lat.coef.zero(s));        // (the padded positions of a list are read, and multiplied with nothing)
     FS_CHECK(g_lat.rel.zero(s));
+    FS_CHECK(g_lat.relc.zero(s));
     FS_CHECK(g_lat.off.zero(s));
     FS_CHECK(g_lat.info.zero(s));
     hipLaunchKernelGGL(k_lat_rep, dim3(fs_grid_for(n, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n, g_dict.cls.p, g_lat.rep.p);
     const int gi = fs_grid_for(sp->n_dict_items * 64, FS_BLOCK, 4096);
 #define FS_LAT_TAB_ARGS dim3(gi), dim3(FS_BLOCK), 0, s, sp->n_dict_items, reinterpret_cast<const int4*>(sp->dict_items.p), \
                         reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_lat.rep.p, g_dict.values.p, g_dict.S, sp->dict_run_len, \
-                        sp->dict_runs, SX, NY, g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.info.p
+                        sp->dict_runs, SX, NY, g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.info.p, g_lat.relc.p
     hipLaunchKernelGGL(k_lat_table<true>, FS_LAT_TAB_ARGS);
     hipLaunchKernelGGL(k_lat_table<false>, FS_LAT_TAB_ARGS);
 #undef FS_LAT_TAB_ARGS
@@ -3303,7 +3427,7 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
         if (debug) {
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            const int variants[] = {0, 1, -1};
+            const int variants[] = {0, 8, 1, -1};
             for (int v : variants) {
                 g_lt_dbg = v < 0 ? 0 : v;
                 if (v < 0) g_lat.ok = false;        // the work-item product
@@ -3314,7 +3438,7 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
                 (void)hipEventSynchronize(e1);
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, e0, e1);
-                fprintf(stderr, "[lattice tiles]   %-44s %.1f us per product\n", v < 0 ? "work-item product on this operator:" : (v == 0 ? "tile product:" : "tile product without the ends of the lines:"), ms * 100.0);
+                fprintf(stderr, "[lattice tiles]   %-44s %.1f us per product\n", v < 0 ? "work-item product on this operator:" : (v == 0 ? "tile product:" : (v == 8 ? "tile product without the corner rows:" : "tile product without the ends of the lines:")), ms * 100.0);
             }
             g_lt_dbg = 0;
             g_lat.ok = true;
@@ -3423,7 +3547,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             static bool attr_set = false;       // (one per instantiation)
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
             hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, (int64_t)nxc * nyt * nzt, nxc, nyt, SX, NY, NZ, g_dict.cls.p,
-                               g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
+                               g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.relc.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
                                g_lt_dbg);
             return;
         }
