@@ -985,6 +985,8 @@ struct lat_tables {
     uint64_t space_serial = 0;
     int ncls = 0;
     bool ok = false;
+    bool tables_ok = false;             // the lists were built and every row fits them: for dictionary tables number dict_built of that space
+    int64_t dict_built = -1;
 };
 static lat_tables g_lat;
 
@@ -1161,7 +1163,7 @@ __device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int ow
 }
 
 template <int DOTS>
-__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, int nxc, int nyt, int64_t SX, int64_t NY, int64_t NZ,
+__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, int nxc, int tiles_z, int w_ys, int w_ye, int w_tiles, int64_t SX, int64_t NY, int64_t NZ,
                                                            const uint16_t* __restrict__ cls, const int32_t* __restrict__ tcnt,
                                                            const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff, const int32_t* __restrict__ trelc,
                                                            const double* __restrict__ x, double* __restrict__ y,
@@ -1339,9 +1341,30 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         __syncthreads();
     }
     for (chunk_iter it = xcd_chunks(n_tiles); it.cur < it.end; it.cur += it.step) {
-        const int64_t tile = it.cur;
-        const int64_t xc = tile % nxc, yt = (tile / nxc) % nyt, zt = tile / ((int64_t)nxc * nyt);
-        const int64_t x0 = xc * LT_TX, y0 = yt * LT_TY, z0 = zt * LT_TZ;
+        // A plane of tiles: the strips (four lines in Y) before w_ys and from w_ye on in tiles of their own, nxc to a strip; the strips
+        // w_ys .. w_ye - 1 - every line of theirs an interior line in Y - as ONE long line per line number: a tile takes 128 consecutive
+        // positions of it, wherever they start, and where it runs over the end of a line it goes on at the start of the line FOUR lines
+        // up (the same line number in the next strip: same parities, normally the same class; if not, the wave takes its classes one by
+        // one as anywhere).  The window and the rows wrap the same way, so a row's neighbours stay where its list expects them: the
+        // first and last rows of a line are not tile rows.  (SX = 216 at configs[3]: two tiles a strip with 88 of 128 positions used in
+        // the second become 87 tiles for 51 strips - 5 022 tiles instead of 5 832.)
+        const int tile_z = (int)(it.cur / tiles_z), tq = (int)(it.cur - (int64_t)tile_z * tiles_z);
+        const int w_first = w_ys * nxc;
+        int tx0, ty0;
+        bool wrap = false;
+        if (tq < w_first) { tx0 = (tq % nxc) * LT_TX; ty0 = (tq / nxc) * LT_TY; }
+        else if (tq < w_first + w_tiles) {
+            const int g0 = (tq - w_first) * LT_TX, yo = g0 / (int)SX;
+            tx0 = g0 - yo * (int)SX;
+            ty0 = (w_ys + yo) * LT_TY;
+            wrap = true;
+        } else {
+            const int q2 = tq - w_first - w_tiles;
+            tx0 = (q2 % nxc) * LT_TX;
+            ty0 = (w_ye + q2 / nxc) * LT_TY;
+        }
+        const int64_t x0 = tx0, y0 = ty0, z0 = (int64_t)tile_z * LT_TZ;
+        const int64_t ylim = wrap ? (int64_t)w_ye * LT_TY : NY;           // (rows behind the long line's end belong to the tiles of strip w_ye)
         // ---- the window of x: lines (y0 - 2 .. y0 + LT_TY + 1) x (z0 - 2 .. ) from X = x0 - 2 on, one 16-byte load per (even, odd)
         // pair, all of a thread's loads in flight together; outside the lattice: zero
         // A wave takes LPW whole window lines: lane l the pair l + 1 of each (64 of the 66 pairs of a line, 1 KB per wave and load, the
@@ -1358,10 +1381,12 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             const int wline = wave * LPW + (u < LPW ? u : (lane >> 1) % LPW);
             const int xx = u < LPW ? lane + 1 : ((lane & 1) ? LT_HX - 1 : 0);
             const int yy = wline % LT_WY, zz = wline / LT_WY;
-            const int64_t Y = y0 - 2 + yy, Z = z0 - 2 + zz;
+            int64_t Y = y0 - 2 + yy, Xw = x0 - 2 + 2 * xx;
+            const int64_t Z = z0 - 2 + zz;
+            if (wrap && Xw >= SX) { Xw -= SX; Y += LT_TY; }
             wv[u] = v2d{0.0, 0.0};
             if ((u < LPW || lane < 2 * LPW) && Y >= 0 && Y < NY && Z >= 0 && Z < NZ) {
-                int64_t g = x0 - 2 + 2 * xx + SX * (Y + NY * Z);       // (even: SX and x0 are)
+                int64_t g = Xw + SX * (Y + NY * Z);                    // (even: SX and x0 are)
                 g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);               // columns before / behind the vector carry no entry
                 wv[u] = *reinterpret_cast<const v2d*>(x + g);
             }
@@ -1379,8 +1404,10 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
-            const int64_t X = x0 + 2 * lane + p, Y = y0 + (line % LT_TY), Z = z0 + (line / LT_TY);
-            const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < NY && Z < NZ;
+            int64_t X = x0 + 2 * lane + p, Y = y0 + (line % LT_TY);
+            const int64_t Z = z0 + (line / LT_TY);
+            if (wrap && X >= SX) { X -= SX; Y += LT_TY; }
+            const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < ylim && Z < NZ;
             r[u] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
             c[u] = in ? (int)cls[r[u]] : -1;
             // (the residual entries of the fused dots: asked for HERE.  Asked for next to the multiplication, their wait - the youngest
@@ -3386,6 +3413,14 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
         FS_CHECK(g_lat.coef.alloc((int64_t)ncls * LT_ML + 64));
     }
     if (!g_lat.info.p) FS_CHECK(g_lat.info.alloc(4));
+    // A KEPT dictionary (dict_build_impl: every row of this matrix compared with its old class, bit for bit - same class numbers, same
+    // class rows) is the one these lists were made from and every row was checked against: nothing to do (configs[3]: 2.0 + 0.6 + 0.6 ms
+    // of kernels, six fills and a host round trip per solve).  n_built counts the table builds: a build in between makes the lists stale.
+    const bool lists_kept = g_dict.kept && g_lat.tables_ok && g_lat.space_serial == sp->serial && g_lat.ncls == ncls && g_lat.dict_built == g_dict.n_built;
+    int h[4] = {0, 0, 0, 0};
+    static const bool debug = getenv("FS_LATTICE_DEBUG") != nullptr;
+    if (!lists_kept) {
+    g_lat.tables_ok = false;
     FS_HIP(hipMemsetAsync(g_lat.rep.p, 0x7f, (size_t)ncls * 4, s));
     FS_CHECK(g_lat.cnt.zero(s));
     FS_CHECK(g_lat.coef.zero(s));        // (the padded positions of a list are read, and multiplied with nothing)
@@ -3402,11 +3437,12 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     hipLaunchKernelGGL(k_lat_table<false>, FS_LAT_TAB_ARGS);
 #undef FS_LAT_TAB_ARGS
     FS_KERNEL_CHECK();
-    int h[4] = {0, 0, 0, 0};
     FS_CHECK(g_lat.info.download(h, 1, s));
-    static const bool debug = getenv("FS_LATTICE_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[lattice tiles] %d classes, tiles of %d x %d x %d rows: %d entries / rows that do not fit\n", ncls, LT_TX, LT_TY, LT_TZ, h[0]);
-    g_lat.ok = h[0] == 0;
+    g_lat.tables_ok = h[0] == 0;
+    g_lat.dict_built = g_dict.n_built;
+    }
+    g_lat.ok = g_lat.tables_ok;
     g_lat.built_for = val;
     g_lat.space_serial = sp->serial;
     g_lat.ncls = ncls;
@@ -3480,6 +3516,7 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
         }
         if (h[0] != 0) {
             g_lat.ok = false;
+            g_lat.tables_ok = false;
             fs_set_error("lattice_check: the tile product differs from the work-item product on %d of %lld rows", h[0], (long long)n);
             return FS_ERR_NUMERIC;
         }
@@ -3542,11 +3579,20 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             // a lattice-ordered operator: tiles of 64 x 4 x 4 rows, x through LDS (k_lattice_spmv)
             const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz;
             const int nxc = (int)((SX + LT_TX - 1) / LT_TX), nyt = (int)((NY + LT_TY - 1) / LT_TY), nzt = (int)((NZ + LT_TZ - 1) / LT_TZ);
+            // the strips whose four lines are all interior lines in Y (LT_LOY .. NY - 1 - LT_HIY) as one long line, if that saves tiles
+            static const bool no_wrap = getenv("FS_LATTICE_WRAP") && getenv("FS_LATTICE_WRAP")[0] == '0';
+            int w_ys = (LT_LOY + LT_TY - 1) / LT_TY, w_ye = (int)((NY - LT_HIY) / LT_TY), w_tiles = 0;
+            if (!no_wrap && SX >= LT_TX + 8 && w_ye - w_ys >= 2 && (int64_t)(w_ye - w_ys) * SX < (int64_t)1 << 30) {
+                w_tiles = (int)(((int64_t)(w_ye - w_ys) * SX + LT_TX - 1) / LT_TX);
+                if (w_tiles >= (w_ye - w_ys) * nxc) w_tiles = 0;
+            }
+            if (!w_tiles) w_ys = w_ye = nyt;
+            const int tiles_z = w_ys * nxc + w_tiles + (nyt - w_ye) * nxc;
             const size_t lds = lat_lds_bytes();
             auto kern = k_lattice_spmv<DOTS>;
             static bool attr_set = false;       // (one per instantiation)
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-            hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, (int64_t)nxc * nyt * nzt, nxc, nyt, SX, NY, NZ, g_dict.cls.p,
+            hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, (int64_t)tiles_z * nzt, nxc, tiles_z, w_ys, w_ye, w_tiles, SX, NY, NZ, g_dict.cls.p,
                                g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.relc.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
                                g_lt_dbg);
             return;

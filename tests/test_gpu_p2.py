@@ -558,3 +558,42 @@ def test_large_cg2_boxes_are_solved_in_lattice_order_by_default(gpu):
     small.A.apply_dirichlet(small.b, small.dofs, small.vals, symmetric=True)
     st = gpu.krylov_solve(small.A, small.b, small.x, rtol=1e-10, max_iter=5000)
     assert st["lattice_order"] == 0 and st["converged"] == 1
+
+
+def test_tile_product_on_lines_longer_than_a_tile(gpu):
+    """k_lattice_spmv takes the strips of interior lines as one long line per line number once a mesh line is longer than a tile
+    (138 rows at n = 68: 35 tiles a plane instead of 64): a tile that runs over the end of a line goes on at the start of the line four
+    lines up, window and rows alike.  Option lattice_check compares every row of the tile product with the work-item product bit for
+    bit (a difference fails the solve); the solve agrees with the one in the space's own numbering, and a second solve on the same
+    matrix - its dictionary and with it the tile lists KEPT - gives the first one's iterations and solution exactly."""
+    import bench
+    n = 68                      # 137^3 = 2 571 353 rows, 138 to a line of the lattice order
+    prob = bench.P2Problem(n, (0, n + 1), 2, 0, 1)
+    prob.A.assemble(stiffness=20.0)
+    prob.b.fill(0.0)
+    prob.A.apply_dirichlet(prob.b, prob.dofs, prob.vals, symmetric=True)
+    try:
+        gpu.set_option("lattice_check", 1)
+        gpu.set_option("cg_fused", 0)
+        x1 = gpu.DeviceVector(prob.V.n_owned)
+        s1 = gpu.krylov_solve(prob.A, prob.b, x1, rtol=1e-10, max_iter=5000)
+        x2 = gpu.DeviceVector(prob.V.n_owned)
+        s2 = gpu.krylov_solve(prob.A, prob.b, x2, rtol=1e-10, max_iter=5000)
+        gpu.set_option("lattice_check", 0)
+        x3 = gpu.DeviceVector(prob.V.n_owned)
+        s3 = gpu.krylov_solve(prob.A, prob.b, x3, rtol=1e-10, max_iter=5000)
+        gpu.set_option("lattice_order", 0)
+        x0 = gpu.DeviceVector(prob.V.n_owned)
+        s0 = gpu.krylov_solve(prob.A, prob.b, x0, rtol=1e-10, max_iter=5000)
+    finally:
+        gpu.set_option("lattice_order", -1)
+        gpu.set_option("lattice_check", 0)
+        gpu.set_option("cg_fused", -1)
+    assert s1["lattice_order"] == 1 and s1["row_classes"] > 0 and s1["converged"] == 1 and s1["fused_iteration"] == 0
+    assert s0["lattice_order"] == 0 and s0["converged"] == 1 and abs(s1["iterations"] - s0["iterations"]) <= 1
+    scale = np.abs(x0.get()).max()
+    assert np.abs(x1.get() - x0.get()).max() <= 1e-9 * scale
+    assert np.abs(x1.get()[:prob.n_owned] - prob.exact_owned).max() <= 1e-6 * scale
+    for s, x in ((s2, x2), (s3, x3)):
+        assert s["lattice_order"] == 1 and s["classes_kept"] == 1 and s["iterations"] == s1["iterations"]
+        assert np.array_equal(x.get(), x1.get())
