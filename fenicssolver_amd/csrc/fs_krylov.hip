@@ -975,12 +975,64 @@ constexpr int LT_LO = 4, LT_HI = 5;                 // rows at the two ends of a
                                                     // scaled with its diagonal - the rows coupled to them (and the dummy row that makes a line even)
 constexpr int LT_ML = 72;                           // entries per class row (a CG2 vertex row of a Kuhn mesh has up to 65), padded to 8
 
+// the tiles of a plane of tiles (k_lattice_spmv's tile loop and k_lat_tile_table walk them the same way)
+struct lat_geom {
+    int64_t n_tiles;
+    int nxc, tiles_z, w_ys, w_ye, w_tiles;
+    int n_ct_wgs, n_extra, grid;        // workgroups 0 .. n_ct_wgs - 1: column tiles; .. n_extra - 1: corner rows; .. grid - 1: tiles
+};
+struct lat_tile {
+    int64_t x0, y0, z0, ylim;
+    bool wrap;
+};
+// A plane of tiles: the strips (four lines in Y) before w_ys and from w_ye on in tiles of their own, nxc to a strip; the strips
+// w_ys .. w_ye - 1 - every line of theirs an interior line in Y - as ONE long line per line number: a tile takes 128 consecutive
+// positions of it, wherever they start, and where it runs over the end of a line it goes on at the start of the line FOUR lines
+// up (the same line number in the next strip: same parities, normally the same class; if not, the wave takes its classes one by
+// one as anywhere).  The window and the rows wrap the same way, so a row's neighbours stay where its list expects them: the
+// first and last rows of a line are not tile rows.  (SX = 216 at configs[3]: two tiles a strip with 88 of 128 positions used in
+// the second become 87 tiles for 51 strips - 5 022 tiles instead of 5 832.)
+__device__ __forceinline__ lat_tile lat_tile_of(int64_t tile, const lat_geom& G, int64_t SX, int64_t NY) {
+    const int tile_z = (int)(tile / G.tiles_z), tq = (int)(tile - (int64_t)tile_z * G.tiles_z);
+    const int w_first = G.w_ys * G.nxc;
+    int tx0, ty0;
+    lat_tile T;
+    T.wrap = false;
+    if (tq < w_first) { tx0 = (tq % G.nxc) * LT_TX; ty0 = (tq / G.nxc) * LT_TY; }
+    else if (tq < w_first + G.w_tiles) {
+        const int g0 = (tq - w_first) * LT_TX, yo = g0 / (int)SX;
+        tx0 = g0 - yo * (int)SX;
+        ty0 = (G.w_ys + yo) * LT_TY;
+        T.wrap = true;
+    } else {
+        const int q2 = tq - w_first - G.w_tiles;
+        tx0 = (q2 % G.nxc) * LT_TX;
+        ty0 = (G.w_ye + q2 / G.nxc) * LT_TY;
+    }
+    T.x0 = tx0; T.y0 = ty0; T.z0 = (int64_t)tile_z * LT_TZ;
+    T.ylim = T.wrap ? (int64_t)G.w_ye * LT_TY : NY;           // (rows behind the long line's end belong to the tiles of strip w_ye)
+    return T;
+}
+// row u of a lane: wave w takes the (line, parity) pairs w, w + 8, ..; -1: not a tile row
+__device__ __forceinline__ int32_t lat_tile_row(const lat_tile& T, int u, int wave, int lane, int64_t SX, int64_t NY, int64_t NZ) {
+    const int wl = wave + (LT_BLOCK / 64) * u, line = wl >> 1, p = wl & 1;
+    int64_t X = T.x0 + 2 * lane + p, Y = T.y0 + (line % LT_TY);
+    const int64_t Z = T.z0 + (line / LT_TY);
+    if (T.wrap && X >= SX) { X -= SX; Y += LT_TY; }
+    const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < T.ylim && Z < NZ;
+    return in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
+}
+
+static const int g_lt_dbg_env = getenv("FS_LATTICE_BITS") ? atoi(getenv("FS_LATTICE_BITS")) : 0;      // (experiments: bits or-ed into the kernel's dbg argument)
 static int g_lt_dbg = 0;     // (FS_LATTICE_DEBUG times k_lattice_spmv once more without the rows at the ends of the lines: 1)
 struct lat_tables {
     dbuf<int32_t> rep, cnt, off, rel;   // [ncls] representative row, [ncls] entries, [ncls][LT_ML] column offsets (verification) / window offsets
     dbuf<int32_t> relc;                 // [ncls][LT_ML] the offsets in the window of a COLUMN tile (the ends of the lines: lanes along Y)
     dbuf<double> coef;                  // [ncls][LT_ML]
     dbuf<int> info;                     // [0] entries that do not fit / rows whose plan or parity disagrees
+    dbuf<uint32_t> tile_cls;            // [tile][wave][u]: the class of the wave's u-th line (bits 0 - 15), its entries (16 - 23), all live
+                                        // lanes of that class (24), any live lane (25): k_lat_tile_table
+    lat_geom geom = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double* built_for = nullptr;
     uint64_t space_serial = 0;
     int ncls = 0;
@@ -1075,6 +1127,25 @@ __global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const i
     if (bad) atomicAdd(&info[0], bad);
 }
 
+// what k_lattice_spmv needs to know about the four lines of a wave of a tile before it can ask for their lists: once per set of lists
+__global__ void __launch_bounds__(LT_BLOCK) k_lat_tile_table(lat_geom G, int64_t SX, int64_t NY, int64_t NZ, const uint16_t* __restrict__ cls,
+                                                              const int32_t* __restrict__ tcnt, uint32_t* __restrict__ tab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t tile = blockIdx.x; tile < G.n_tiles; tile += gridDim.x) {
+        const lat_tile T = lat_tile_of(tile, G, SX, NY);
+        for (int u = 0; u < 2 * LT_TY * LT_TZ / (LT_BLOCK / 64); ++u) {
+            const int32_t r = lat_tile_row(T, u, wave, lane, SX, NY, NZ);
+            const int c = r >= 0 ? (int)cls[r] : -1;
+            const unsigned long long live = __ballot(c >= 0);
+            const int cm = live ? __shfl(c, __ffsll((long long)live) - 1, 64) : 0;
+            const bool uni = __ballot(c == cm) == live;
+            const int cn = live ? tcnt[cm] : 0;
+            if (lane == 0)
+                tab[(tile * (LT_BLOCK / 64) + wave) * 4 + u] = (uint32_t)cm | ((uint32_t)cn << 16) | ((uint32_t)uni << 24) | ((uint32_t)(live != 0) << 25);
+        }
+    }
+}
+
 // the rows of a wave: the distinct classes of its lanes one after the other, the class's list through scalar loads
 __device__ __forceinline__ double lat_wave_rows(int c, int own, const double* __restrict__ win, const int32_t* __restrict__ tcnt,
                                                 const double* __restrict__ tcoef, const int32_t* __restrict__ trel) {
@@ -1163,7 +1234,7 @@ __device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int ow
 }
 
 template <int DOTS>
-__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, int nxc, int tiles_z, int w_ys, int w_ye, int w_tiles, int64_t SX, int64_t NY, int64_t NZ,
+__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(lat_geom G, const uint32_t* __restrict__ tile_cls, int64_t SX, int64_t NY, int64_t NZ,
                                                            const uint16_t* __restrict__ cls, const int32_t* __restrict__ tcnt,
                                                            const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff, const int32_t* __restrict__ trelc,
                                                            const double* __restrict__ x, double* __restrict__ y,
@@ -1200,7 +1271,8 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
     {
         const int nzb = (int)((NZ + 7) >> 3);
         const int64_t n_tasks = (int64_t)(LT_LO + LT_HI) * nzb;
-        for (int64_t t = (int64_t)(gridDim.x - 1 - blockIdx.x) * NWV + wave; t < n_tasks && !(dbg & 9); t += (int64_t)gridDim.x * NWV) {
+        const bool corner_wg = (int)blockIdx.x >= G.n_ct_wgs && (int)blockIdx.x < G.n_extra;
+        for (int64_t t = corner_wg ? (int64_t)((int)blockIdx.x - G.n_ct_wgs) * NWV + wave : n_tasks; t < n_tasks && !(dbg & 9); t += (int64_t)(G.n_extra - G.n_ct_wgs) * NWV) {
             const int col = (int)(t % (LT_LO + LT_HI)), d = lane & 7;
             const int64_t Z = (t / (LT_LO + LT_HI)) * 8 + (lane >> 3);
             const int64_t Y = d < LT_LOY ? d : NY - (LT_LOY + LT_HIY) + d;
@@ -1234,7 +1306,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
     // The rows at the ends of the COLUMNS (first / last four Y: classes of their own again, 0.2 % of the rows) follow per lane below.
     const int nycc = (int)((NY + CT_Y - 1) / CT_Y), nzc = (int)((NZ + CT_Z - 1) / CT_Z);
     const int64_t n_ct = (int64_t)2 * nycc * nzc;
-    for (int64_t ct = gridDim.x - 1 - blockIdx.x; ct < n_ct && !(dbg & 1); ct += gridDim.x) {
+    for (int64_t ct = (int)blockIdx.x < G.n_ct_wgs ? (int64_t)blockIdx.x : n_ct; ct < n_ct && !(dbg & 1); ct += G.n_ct_wgs) {
         const int side = (int)(ct & 1);
         const int64_t ycn = (ct >> 1) % nycc, zcn = (ct >> 1) / nycc;
         const int64_t y0 = ycn * CT_Y, z0 = zcn * CT_Z;
@@ -1242,25 +1314,42 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         const int ncol = side ? LT_HI : LT_LO;
         const int64_t col0 = side ? SX - LT_HI : 0;                 // first end column of this side
         // window: wave w takes plane w; its items (Y line, pair of X positions): 132 x 4, four lanes a line's 64 bytes
-        constexpr int NIT = (2 * LT_HX * (CT_XW / 2) + 63) / 64;
-        v2d wv[NIT];
+        // (three loads in flight per lane at a time, a real loop: all nine at once - 36 registers - had this part of the kernel spill, and a
+        // kernel with a private segment pays for it at EVERY launch, in front of the kernel where no event and no trace sees it: about 30 us
+        // per launch of the 2 296 workgroups here)
+        constexpr int NIT = (2 * LT_HX * (CT_XW / 2) + 63) / 64, NIH = 3;
+        static_assert(NIT % NIH == 0, "the window of a column tile is loaded in whole batches");
         {
             const int64_t Z = z0 - 2 + wave;
+#pragma unroll 1
+            for (int u0 = 0; u0 < NIT; u0 += NIH) {
+                v2d wv[NIH];
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int item = u * 64 + lane, yl = item >> 2, xp = item & 3;
-                const int64_t Y = y0 - 2 + yl;
-                wv[u] = v2d{0.0, 0.0};
-                if (yl < 2 * LT_HX && Y >= 0 && Y < NY && Z >= 0 && Z < NZ)
-                    wv[u] = *reinterpret_cast<const v2d*>(x + xw0 + 2 * xp + SX * (Y + NY * Z));
+                for (int u = 0; u < NIH; ++u) {
+                    const int item = (u0 + u) * 64 + lane, yl = item >> 2, xp = item & 3;
+                    const int64_t Y = y0 - 2 + yl;
+                    wv[u] = v2d{0.0, 0.0};
+                    if (yl < 2 * LT_HX && Y >= 0 && Y < NY && Z >= 0 && Z < NZ)
+                        wv[u] = *reinterpret_cast<const v2d*>(x + xw0 + 2 * xp + SX * (Y + NY * Z));
+                }
+#pragma unroll
+                for (int u = 0; u < NIH; ++u) {
+                    const int item = (u0 + u) * 64 + lane, yl = item >> 2, xp = item & 3;
+                    if (yl < 2 * LT_HX) {
+                        const int i = (yl & 1) * LT_WINH + (yl >> 1) + LT_HX * (2 * xp + CT_XW * wave);
+                        win[i] = wv[u].x;
+                        win[i + LT_HX] = wv[u].y;
+                    }
+                }
             }
         }
         // pairs of column lines: q = (column, Y parity, plane pair): planes zl and zl + 2
         const int npair = ncol * 4;
         constexpr int UC = (LT_HI * 4 + NWV - 1) / NWV;
         int32_t r[2 * UC];
-        int c[2 * UC];
         double ri[2 * UC];
+        int cm[2 * UC], cn[2 * UC];
+        bool uni[2 * UC];
         auto own_c = [&](int q, int half) {
             const int col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
             return py * LT_WINH + (lane + 1) + LT_HX * ((int)(col0 - xw0) + col + CT_XW * (zl + 2));
@@ -1272,19 +1361,16 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                 const int q = wave + NWV * j, col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
                 const int64_t X = col0 + col, Y = y0 + 2 * lane + py, Z = z0 + zl;
                 const bool in = q < npair && Y >= LT_LOY && Y <= NY - 1 - LT_HIY && Z < NZ;
-                r[2 * j + half] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
-                c[2 * j + half] = in ? (int)cls[r[2 * j + half]] : -1;
-                ri[2 * j + half] = (DOTS && DOTS != 4 && in) ? rvec[r[2 * j + half]] : 0.0;
+                const int u = 2 * j + half;
+                r[u] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
+                ri[u] = (DOTS && DOTS != 4 && in) ? rvec[r[u]] : 0.0;
+                const int c = in ? (int)cls[r[u]] : -1;        // (a lane's own class number is not kept: registers)
+                const unsigned long long live = __ballot(c >= 0);
+                cm[u] = live ? __builtin_amdgcn_readlane(c, __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
+                uni[u] = __ballot(c == cm[u]) == live;
+                cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
             }
-        int cm[2 * UC], cn[2 * UC];
-        bool uni[2 * UC];
-#pragma unroll
-        for (int u = 0; u < 2 * UC; ++u) {
-            const unsigned long long live = __ballot(c[u] >= 0);
-            cm[u] = live ? __builtin_amdgcn_readlane(c[u], __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
-            uni[u] = __ballot(c[u] == cm[u]) == live;
-            cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
-        }
+        auto cls_of = [&](int32_t row) { return row >= 0 ? (int)cls[row] : -1; };
         struct lat_list { double c0, c1; int r0, r1; };
         auto load_list = [&](int cls_m) {
             lat_list L;
@@ -1296,18 +1382,6 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             return L;
         };
         lat_list cur = load_list(cm[0]);
-        {
-            const int zz = wave;
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int item = u * 64 + lane, yl = item >> 2, xp = item & 3;
-                if (yl < 2 * LT_HX) {
-                    const int i = (yl & 1) * LT_WINH + (yl >> 1) + LT_HX * (2 * xp + CT_XW * zz);
-                    win[i] = wv[u].x;
-                    win[i + LT_HX] = wv[u].y;
-                }
-            }
-        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < UC; ++j) {
@@ -1324,7 +1398,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                 if (cn[ua] != 0) {
                     double a;
                     if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_c(q, 0), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
-                    else a = lat_wave_rows(c[ua], own_c(q, 0), win, tcnt, tcoef, trelc);
+                    else a = lat_wave_rows(cls_of(r[ua]), own_c(q, 0), win, tcnt, tcoef, trelc);
                     if (r[ua] >= 0) finish(r[ua], a, win[own_c(q, 0)], ri[ua]);
                 }
                 if (cn[ub] != 0) {
@@ -1332,7 +1406,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                     if (uni[ub]) {
                         const lat_list lb = load_list(cm[ub]);
                         a = lat_wave_rows_uniform(cn[ub], own_c(q, 1), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
-                    } else a = lat_wave_rows(c[ub], own_c(q, 1), win, tcnt, tcoef, trelc);
+                    } else a = lat_wave_rows(cls_of(r[ub]), own_c(q, 1), win, tcnt, tcoef, trelc);
                     if (r[ub] >= 0) finish(r[ub], a, win[own_c(q, 1)], ri[ub]);
                 }
             }
@@ -1340,31 +1414,23 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         }
         __syncthreads();
     }
-    for (chunk_iter it = xcd_chunks(n_tiles); it.cur < it.end; it.cur += it.step) {
-        // A plane of tiles: the strips (four lines in Y) before w_ys and from w_ye on in tiles of their own, nxc to a strip; the strips
-        // w_ys .. w_ye - 1 - every line of theirs an interior line in Y - as ONE long line per line number: a tile takes 128 consecutive
-        // positions of it, wherever they start, and where it runs over the end of a line it goes on at the start of the line FOUR lines
-        // up (the same line number in the next strip: same parities, normally the same class; if not, the wave takes its classes one by
-        // one as anywhere).  The window and the rows wrap the same way, so a row's neighbours stay where its list expects them: the
-        // first and last rows of a line are not tile rows.  (SX = 216 at configs[3]: two tiles a strip with 88 of 128 positions used in
-        // the second become 87 tiles for 51 strips - 5 022 tiles instead of 5 832.)
-        const int tile_z = (int)(it.cur / tiles_z), tq = (int)(it.cur - (int64_t)tile_z * tiles_z);
-        const int w_first = w_ys * nxc;
-        int tx0, ty0;
-        bool wrap = false;
-        if (tq < w_first) { tx0 = (tq % nxc) * LT_TX; ty0 = (tq / nxc) * LT_TY; }
-        else if (tq < w_first + w_tiles) {
-            const int g0 = (tq - w_first) * LT_TX, yo = g0 / (int)SX;
-            tx0 = g0 - yo * (int)SX;
-            ty0 = (w_ys + yo) * LT_TY;
-            wrap = true;
-        } else {
-            const int q2 = tq - w_first - w_tiles;
-            tx0 = (q2 % nxc) * LT_TX;
-            ty0 = (w_ye + q2 / nxc) * LT_TY;
-        }
-        const int64_t x0 = tx0, y0 = ty0, z0 = (int64_t)tile_z * LT_TZ;
-        const int64_t ylim = wrap ? (int64_t)w_ye * LT_TY : NY;           // (rows behind the long line's end belong to the tiles of strip w_ye)
+    // the tiles: the workgroups behind the first n_extra (a multiple of 8: workgroup b runs on XCD b mod 8), each XCD a contiguous eighth
+    chunk_iter it;
+    {
+        const int b = (int)blockIdx.x - G.n_extra, tg = G.grid - G.n_extra;
+        const int64_t per_xcd = (G.n_tiles + 7) >> 3, e = ((b & 7) + 1) * per_xcd;
+        it.step = tg >> 3;
+        it.cur = b >= 0 ? (b & 7) * per_xcd + (b >> 3) : G.n_tiles;
+        it.end = e < G.n_tiles ? e : G.n_tiles;
+    }
+    for (; it.cur < it.end; it.cur += it.step) {
+        const lat_tile T = lat_tile_of(it.cur, G, SX, NY);
+        const int64_t x0 = T.x0, y0 = T.y0, z0 = T.z0;
+        const bool wrap = T.wrap;
+        // the classes of this wave's four lines: one scalar load (k_lat_tile_table wrote them when the lists were made), asked for with
+        // the window - where the class numbers used to be read per lane, compared across the wave and their list lengths fetched, three
+        // dependent round trips before the first list could be asked for
+        const uint4 tc = *reinterpret_cast<const uint4*>(tile_cls + (it.cur * (LT_BLOCK / 64) + __builtin_amdgcn_readfirstlane(wave)) * 4);
         // ---- the window of x: lines (y0 - 2 .. y0 + LT_TY + 1) x (z0 - 2 .. ) from X = x0 - 2 on, one 16-byte load per (even, odd)
         // pair, all of a thread's loads in flight together; outside the lattice: zero
         // A wave takes LPW whole window lines: lane l the pair l + 1 of each (64 of the 66 pairs of a line, 1 KB per wave and load, the
@@ -1395,7 +1461,6 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         // entries k and k + 64), asked for before the window is waited for
         // (row numbers as 32-bit, a row's own window position recomputed where it is used: registers are what this kernel is short of)
         int32_t r[U];
-        int c[U];
         double ri[U];
         auto own_of = [&](int u) {
             const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
@@ -1403,25 +1468,21 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
         };
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
-            int64_t X = x0 + 2 * lane + p, Y = y0 + (line % LT_TY);
-            const int64_t Z = z0 + (line / LT_TY);
-            if (wrap && X >= SX) { X -= SX; Y += LT_TY; }
-            const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < ylim && Z < NZ;
-            r[u] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
-            c[u] = in ? (int)cls[r[u]] : -1;
+            r[u] = lat_tile_row(T, u, wave, lane, SX, NY, NZ);
+            const bool in = r[u] >= 0;
             // (the residual entries of the fused dots: asked for HERE.  Asked for next to the multiplication, their wait - the youngest
             // loads of the wave: vmcnt(0) - was also a wait for the previous lines' stores of y: + 60 us per product)
             ri[u] = (DOTS && DOTS != 4 && in && !(dbg & 2)) ? rvec[r[u]] : 0.0;
         }
         int cm[U], cn[U];
         bool uni[U];
+        static_assert(U == 4, "a wave's four lines in one 16-byte word of the tile table");
+        const uint32_t tcw[U] = {tc.x, tc.y, tc.z, tc.w};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned long long live = __ballot(c[u] >= 0);
-            cm[u] = live ? __builtin_amdgcn_readlane(c[u], __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
-            uni[u] = __ballot(c[u] == cm[u]) == live;
-            cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
+            cm[u] = (int)(tcw[u] & 0xffffu);
+            cn[u] = (tcw[u] >> 25) & 1u ? (int)((tcw[u] >> 16) & 0xffu) : 0;
+            uni[u] = (tcw[u] >> 24) & 1u;
         }
         struct lat_list { double c0, c1; int r0, r1; };
         auto load_list = [&](int cls_m) {
@@ -1433,6 +1494,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
             L.r1 = trel[at + 64];
             return L;
         };
+        auto cls_of = [&](int32_t row) { return row >= 0 ? (int)cls[row] : -1; };        // (a wave of several classes: per lane, when it comes to it)
         // lines u and u + U / 2 of a wave lie two planes apart (same parities in X, Y and Z: normally the same class): taken together
         static_assert(LT_TZ == 4 && LT_TY == 4, "the pairing of lines below assumes 4 x 4 lines per tile");
         lat_list cur = load_list(cm[0]);
@@ -1461,7 +1523,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                 if (cn[ua] != 0) {
                     double a;
                     if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_of(ua), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
-                    else a = lat_wave_rows(c[ua], own_of(ua), win, tcnt, tcoef, trel);
+                    else a = lat_wave_rows(cls_of(r[ua]), own_of(ua), win, tcnt, tcoef, trel);
                     if (r[ua] >= 0) finish(r[ua], a, win[own_of(ua)], ria);
                 }
                 if (cn[ub] != 0) {          // (its list was not asked for ahead of time: tiles where the class changes between the planes)
@@ -1469,7 +1531,7 @@ __global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(int64_t n_tiles, i
                     if (uni[ub]) {
                         const lat_list lb = load_list(cm[ub]);
                         a = lat_wave_rows_uniform(cn[ub], own_of(ub), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
-                    } else a = lat_wave_rows(c[ub], own_of(ub), win, tcnt, tcoef, trel);
+                    } else a = lat_wave_rows(cls_of(r[ub]), own_of(ub), win, tcnt, tcoef, trel);
                     if (r[ub] >= 0) finish(r[ub], a, win[own_of(ub)], rib);
                 }
             }
@@ -3395,6 +3457,40 @@ __global__ void k_lat_count_diff(int64_t n, const double* __restrict__ a, const 
 
 // the lists of the tile product (k_lattice_spmv) for the dictionary just built on a lattice-ordered operator; g_lat.ok says whether
 // the product may be used (every class fits a list, every row's plan agrees with its class's list, no tile has too many classes)
+static lat_geom lat_geometry(int64_t SX, int64_t NY, int64_t NZ) {
+    lat_geom G;
+    G.nxc = (int)((SX + LT_TX - 1) / LT_TX);
+    const int nyt = (int)((NY + LT_TY - 1) / LT_TY), nzt = (int)((NZ + LT_TZ - 1) / LT_TZ);
+    // the strips whose four lines are all interior lines in Y (LT_LOY .. NY - 1 - LT_HIY) as one long line, if that saves tiles
+    static const bool no_wrap = getenv("FS_LATTICE_WRAP") && getenv("FS_LATTICE_WRAP")[0] == '0';
+    G.w_ys = (LT_LOY + LT_TY - 1) / LT_TY;
+    G.w_ye = (int)((NY - LT_HIY) / LT_TY);
+    G.w_tiles = 0;
+    if (!no_wrap && SX >= LT_TX + 8 && G.w_ye - G.w_ys >= 2 && (int64_t)(G.w_ye - G.w_ys) * SX < (int64_t)1 << 30) {
+        G.w_tiles = (int)(((int64_t)(G.w_ye - G.w_ys) * SX + LT_TX - 1) / LT_TX);
+        if (G.w_tiles >= (G.w_ye - G.w_ys) * G.nxc) G.w_tiles = 0;
+    }
+    if (!G.w_tiles) G.w_ys = G.w_ye = nyt;
+    G.tiles_z = G.w_ys * G.nxc + G.w_tiles + (nyt - G.w_ye) * G.nxc;
+    G.n_tiles = (int64_t)G.tiles_z * nzt;
+    // Launch geometry.  The column tiles and the corner rows get workgroups of their own AT THE FRONT of the grid - they start first,
+    // and the dispatcher hands their slots to tile workgroups as they finish -, the tiles one workgroup per slot of the chip behind
+    // them (two workgroups of eight waves and 74 KB of LDS per CU: 512), each with its strided share of its XCD's tiles.  (Given to
+    // workgroups that also had their share of tiles - the first form - the column tiles sat on the critical path of the launch: with
+    // the three dots 31 us of 134 for 4 % of the rows.  Measured at configs[3], product alone / iteration of the solve, same box:
+    // 256 tile workgroups 127 / 278 us, 384: 123 / 273, 512: 100 / 237 - 248, 640: 116 / 266, 768: 102 / 240, 1024: 99 / 246,
+    // 2048: 98 / 248, 3072: 96 / 297 - the update kernel sums one partial per workgroup.)
+    static const int tile_wgs_env = getenv("FS_LATTICE_TILE_WGS") ? atoi(getenv("FS_LATTICE_TILE_WGS")) : 512;
+    const int64_t n_ct = (int64_t)2 * ((NY + CT_Y - 1) / CT_Y) * ((NZ + CT_Z - 1) / CT_Z);
+    const int64_t corner_wgs = ((int64_t)(LT_LO + LT_HI) * ((NZ + 7) >> 3) + (LT_BLOCK / 64) - 1) / (LT_BLOCK / 64);
+    G.n_ct_wgs = (int)std::min<int64_t>(n_ct, 1024);
+    G.n_extra = (int)((G.n_ct_wgs + std::min<int64_t>(corner_wgs, 256) + 7) & ~(int64_t)7);
+    int64_t tg = std::min<int64_t>(std::max<int64_t>(G.n_tiles, 8), std::max(tile_wgs_env, 8));
+    tg = std::min<int64_t>((tg + 7) & ~(int64_t)7, (FS_MAX_PARTIAL_BLOCKS - G.n_extra) & ~7);
+    G.grid = G.n_extra + (int)tg;
+    return G;
+}
+
 static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     fs_space_s* sp = A->space;
     g_lat.ok = false;
@@ -3436,6 +3532,11 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     hipLaunchKernelGGL(k_lat_table<true>, FS_LAT_TAB_ARGS);
     hipLaunchKernelGGL(k_lat_table<false>, FS_LAT_TAB_ARGS);
 #undef FS_LAT_TAB_ARGS
+    g_lat.geom = lat_geometry(SX, NY, NZ);
+    if (g_lat.geom.n_tiles >= ((int64_t)1 << 26) || ncls > 65535) return FS_OK;        // (cannot be: 32-bit rows, 16-bit classes)
+    if (g_lat.tile_cls.n < g_lat.geom.n_tiles * (LT_BLOCK / 64) * 4) FS_CHECK(g_lat.tile_cls.alloc(g_lat.geom.n_tiles * (LT_BLOCK / 64) * 4));
+    hipLaunchKernelGGL(k_lat_tile_table, dim3((unsigned)std::min<int64_t>(g_lat.geom.n_tiles, 4096)), dim3(LT_BLOCK), 0, s, g_lat.geom, SX, NY, NZ,
+                       g_dict.cls.p, g_lat.cnt.p, g_lat.tile_cls.p);
     FS_KERNEL_CHECK();
     FS_CHECK(g_lat.info.download(h, 1, s));
     if (debug) fprintf(stderr, "[lattice tiles] %d classes, tiles of %d x %d x %d rows: %d entries / rows that do not fit\n", ncls, LT_TX, LT_TY, LT_TZ, h[0]);
@@ -3487,12 +3588,12 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
                 if (big.alloc(nbig) == FS_OK && part.alloc(3 * 4096) == FS_OK && st.alloc(8) == FS_OK && rv2.alloc(n + 2) == FS_OK) {
                     (void)st.zero(s);
                     hipLaunchKernelGGL(k_lat_fill, dim3(fs_grid_for(n + 2, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n + 2, rv2.p);
-                    for (int tile = 3; tile >= 0; --tile)
+                    for (int tile = 5; tile >= 0; --tile)
                         for (int dots = 0; dots <= 3; dots += 3)
                             for (int cold = 0; cold <= 1; ++cold) {
                                 if (tile >= 2 && (!dots || cold)) continue;
-                                g_lt_dbg = tile == 3 ? 2 : (tile == 2 ? 4 : 0);
-                                if (tile >= 2) fprintf(stderr, "[lattice tiles]   (ablation %d: %s)\n", g_lt_dbg, g_lt_dbg == 2 ? "no loads of r" : "no dot accumulation");
+                                g_lt_dbg = tile == 5 ? 3 : (tile == 4 ? 1 : (tile == 3 ? 2 : (tile == 2 ? 4 : 0)));
+                                if (tile >= 2) fprintf(stderr, "[lattice tiles]   (ablation %d: %s)\n", g_lt_dbg, g_lt_dbg == 3 ? "no ends of the lines, no loads of r" : (g_lt_dbg == 1 ? "no ends of the lines" : (g_lt_dbg == 2 ? "no loads of r" : "no dot accumulation")));
                                 g_lat.ok = tile != 0;
                                 float total = 0.f;
                                 for (int it = 0; it < 6; ++it) {
@@ -3578,23 +3679,14 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
         if (!list && g_lat.ok && g_lat.built_for == mat_val && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls) {
             // a lattice-ordered operator: tiles of 64 x 4 x 4 rows, x through LDS (k_lattice_spmv)
             const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz;
-            const int nxc = (int)((SX + LT_TX - 1) / LT_TX), nyt = (int)((NY + LT_TY - 1) / LT_TY), nzt = (int)((NZ + LT_TZ - 1) / LT_TZ);
-            // the strips whose four lines are all interior lines in Y (LT_LOY .. NY - 1 - LT_HIY) as one long line, if that saves tiles
-            static const bool no_wrap = getenv("FS_LATTICE_WRAP") && getenv("FS_LATTICE_WRAP")[0] == '0';
-            int w_ys = (LT_LOY + LT_TY - 1) / LT_TY, w_ye = (int)((NY - LT_HIY) / LT_TY), w_tiles = 0;
-            if (!no_wrap && SX >= LT_TX + 8 && w_ye - w_ys >= 2 && (int64_t)(w_ye - w_ys) * SX < (int64_t)1 << 30) {
-                w_tiles = (int)(((int64_t)(w_ye - w_ys) * SX + LT_TX - 1) / LT_TX);
-                if (w_tiles >= (w_ye - w_ys) * nxc) w_tiles = 0;
-            }
-            if (!w_tiles) w_ys = w_ye = nyt;
-            const int tiles_z = w_ys * nxc + w_tiles + (nyt - w_ye) * nxc;
             const size_t lds = lat_lds_bytes();
             auto kern = k_lattice_spmv<DOTS>;
             static bool attr_set = false;       // (one per instantiation)
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-            hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, (int64_t)tiles_z * nzt, nxc, tiles_z, w_ys, w_ye, w_tiles, SX, NY, NZ, g_dict.cls.p,
+            gd = g_lat.geom.grid;              // (spmv_partials_unsplit says the same: the dot partials of this launch)
+            hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, g_lat.geom, g_lat.tile_cls.p, SX, NY, NZ, g_dict.cls.p,
                                g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.relc.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
-                               g_lt_dbg);
+                               g_lt_dbg | g_lt_dbg_env);
             return;
         }
         if (items && n_items >= 0) {
@@ -3681,7 +3773,11 @@ static int dict_grid(const fs_space_s* sp) {
     return (int)std::max<int64_t>(g, 8);
 }
 static int spmv_partials_unsplit(const fs_space_s* sp, int bs) {
-    if (bs == 1 && g_dict.built_for && g_dict.space_serial == sp->serial) return dict_grid(sp);
+    if (bs == 1 && g_dict.built_for && g_dict.space_serial == sp->serial) {
+        // (the tile product of a lattice-ordered operator has its own geometry: launch_spmv's condition)
+        if (g_lat.ok && g_lat.built_for == g_dict.built_for && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls && g_lat.geom.grid > 0) return g_lat.geom.grid;
+        return dict_grid(sp);
+    }
     if (bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
         return spmv_pair_grid(sp) + (sp->n_pair_singles ? spmv_grid(sp->n_pair_singles, sp->n_slices) : 0);
     return spmv_grid(sp->n_slices, sp->n_slices);

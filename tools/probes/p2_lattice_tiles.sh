@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 {
 echo "# FS_LATTICE_DEBUG=2 FS_LATTICE_CHECK=1 python tools/probes/p2_lattice_probe.py 107  (both products on the lattice-ordered operator: 10 launches back to back, then single launches with events)"
-FS_LATTICE_DEBUG=2 FS_LATTICE_CHECK=1 python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | grep -E "lattice tiles" | head -n 13
+FS_LATTICE_DEBUG=2 FS_LATTICE_CHECK=1 python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | grep -E "lattice tiles" | head -n 17
 echo "# python tools/probes/p2_lattice_probe.py 107  (inside the solve: product with the three dots, sampled with events)"
 python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | tail -n 5
 } > $R/gpurun_out/r05_p2_lattice_tiles.txt 2>&1
