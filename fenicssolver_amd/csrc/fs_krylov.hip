@@ -513,6 +513,40 @@ __device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restri
         return true;
     }
     int g = 1;                  // run 0 is the z run
+    if (nq == 1) {
+        // scalar operators with plans of several rounds (CG2; the lattice order's line plans): offsets, values and scale factors of
+        // eight entries in flight together, then the walk along the plan for the eight - the entry-by-entry loop below waits for two
+        // or three dependent loads per entry (configs[3]: 3.9 ms per solve for the comparison with the kept table)
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int32_t o[8];
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u < width ? k0 + u : width - 1;
+                o[u] = op[k];
+                v[u] = vp[(int64_t)k * FS_SLICE];
+            }
+            bool stored[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) stored[u] = k0 + u < width && v[u] != 0.0;
+            if (sc) {
+                const double sr = sc[r];
+                double scol[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) scol[u] = sc[stored[u] ? r + o[u] : r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = v[u] * sr * scol[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (stored[u]) {
+                    const int slot = dict_slot_of(pl, n_runs, RL, g, o[u], NR);
+                    if (slot < 0) return false;
+                    f(slot, v[u]);
+                }
+        }
+        return true;
+    }
     for (int k = 0; k < width && ok; ++k) {
         int slot = -2;          // not looked up yet
         for (int q = 0; q < nq; ++q) {

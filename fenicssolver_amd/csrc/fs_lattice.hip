@@ -26,6 +26,7 @@ struct fs_lattice_shadow {
     fs_matrix_s* A = nullptr;       // its values
     dbuf<int32_t> perm;             // [n nodes of the space] node -> shadow row
     dbuf<int32_t> emap;             // [sell_entries of the space] stored entry -> shadow entry (-1: padding)
+    dbuf<int32_t> imap;             // [sell_entries of the shadow] shadow entry -> stored entry of the space (-1: none): what the copy reads
     fs_vector_s b, x;
     int64_t n = 0;                  // shadow rows (dummies included)
     ~fs_lattice_shadow() {
@@ -145,12 +146,24 @@ __global__ void k_lattice_dummy_diag(int64_t n_sh, const uint8_t* __restrict__ w
     }
 }
 
-__global__ void k_lattice_copy_values(int64_t n_entries, const int32_t* __restrict__ emap, const double* __restrict__ val, double* __restrict__ val_sh) {
+// The values of the space's matrix into the shadow's storage, once per solve.  GATHER form (imap: shadow entry -> entry of the space's
+// storage, -1: padding or a dummy row's unit diagonal, left as they are): the writes are whole lines, and the reads of a slice are two
+// interleaved runs of consecutive rows (the vertex rows and the edge rows of a mesh line).  The scatter form it replaces (emap: entry
+// of the space -> shadow entry) wrote every second 8-byte word of a line: 3.1 ms per solve at configs[3].
+__global__ void k_lattice_copy_values(int64_t n_entries_sh, const int32_t* __restrict__ imap, const double* __restrict__ val, double* __restrict__ val_sh) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n_entries_sh; t += stride) {
+        const int32_t e = imap[t];
+        if (e >= 0) val_sh[t] = val[e];
+    }
+}
+__global__ void k_lattice_invert_map(int64_t n_entries, const int32_t* __restrict__ emap, int32_t* __restrict__ imap) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; e < n_entries; e += stride) {
         const int32_t t = emap[e];
-        if (t >= 0) val_sh[t] = val[e];
+        if (t >= 0) imap[t] = (int32_t)e;
     }
 }
 __global__ void k_lattice_scatter(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ v, double* __restrict__ v_sh) {
@@ -235,6 +248,9 @@ int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out) {
         (rc = L->b.d.alloc(n_sh)) != FS_OK || (rc = L->x.d.alloc(n_sh)) != FS_OK || (rc = L->b.d.zero(s)) != FS_OK || (rc = L->x.d.zero(s)) != FS_OK) return fail(rc);
     hipLaunchKernelGGL(k_lattice_entry_map, dim3(fs_grid_for(sp->n_slices * 64, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, sp->n_slices, n, sp->slice_ptr.p, sp->sell_col.p,
                        L->perm.p, sh->slice_ptr.p, sh->sell_col.p, L->emap.p, d_cnt.p + 1);
+    if ((rc = L->imap.alloc(sh->sell_entries)) != FS_OK) return fail(rc);
+    if (hipMemsetAsync(L->imap.p, 0xff, (size_t)sh->sell_entries * sizeof(int32_t), s) != hipSuccess) return fail(FS_ERR_HIP);
+    hipLaunchKernelGGL(k_lattice_invert_map, dim3(fs_grid_for(sp->sell_entries, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, sp->sell_entries, L->emap.p, L->imap.p);
     hipLaunchKernelGGL(k_lattice_dummy_diag, dim3(fs_grid_for(n_sh)), dim3(FS_BLOCK), 0, s, n_sh, written.p, sh->slice_ptr.p, sh->sell_col.p, L->A->val.p);
     if (hipGetLastError() != hipSuccess) return fail(FS_ERR_HIP);
     if ((rc = d_cnt.download(h_cnt, 2, s)) != FS_OK) return fail(rc);
@@ -259,7 +275,8 @@ int fs_lattice_enter(fs_lattice_shadow* L, fs_matrix_s* A, const fs_vector_s* b,
     hipStream_t s = fs_rt().stream;
     const fs_space_s* sp = A->space;
     const int64_t n = sp->n_nodes_owned;
-    hipLaunchKernelGGL(k_lattice_copy_values, dim3(fs_grid_for(sp->sell_entries, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, sp->sell_entries, L->emap.p, A->val.p, L->A->val.p);
+    const int64_t ne_sh = L->A->space->sell_entries;
+    hipLaunchKernelGGL(k_lattice_copy_values, dim3(fs_grid_for(ne_sh, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, ne_sh, L->imap.p, A->val.p, L->A->val.p);
     hipLaunchKernelGGL(k_lattice_scatter, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, n, L->perm.p, b->d.p, L->b.d.p);
     if (use_guess) hipLaunchKernelGGL(k_lattice_scatter, dim3(fs_grid_for(n)), dim3(FS_BLOCK), 0, s, n, L->perm.p, x->d.p, L->x.d.p);
     else FS_CHECK(L->x.d.zero(s));
