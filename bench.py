@@ -562,7 +562,8 @@ def kernel_name(V, st=None):
     if st is not None and st.get("lattice_order", 0) and st.get("row_classes", 0) > 0:
         # fs_krylov.hip k_lattice_spmv: the solver's lattice-ordered shadow of a scalar CG2 box operator (fs_lattice.hip)
         return ("k_lattice_spmv<3> (row-dictionary form in the solver's LATTICE order of the half grid: %d distinct rows; tiles of 128 x 4 x 4 rows, "
-                "x through LDS windows, a wave per line parity with its class's row broadcast from LDS; the rows at the ends of the mesh lines per lane)"
+                "x through LDS windows, a wave per line parity with its class's row broadcast from LDS; interior strips of lines as one long line; the rows at the "
+                "ends of the mesh lines in column tiles with lanes along Y, in workgroups of their own)"
                 % st["row_classes"])
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
         # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
