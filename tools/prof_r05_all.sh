@@ -29,6 +29,7 @@ python $R/tools/probes/rccl_self_halo_probe.py 99 all 2>&1 | grep -a "iteration\
 python $R/tools/probes/cg_tail_probe.py 99 0,16,6 1,16,6 2>&1 | tail -2 > $S/r05_cg_tail.txt
 FS_LATTICE_TILES=0 python $R/tools/probes/p2_lattice_probe.py 107 2>&1 | tail -5 > $S/r05_p2_lattice_order.txt      # (the work-item product on the lattice order)
 bash $R/tools/probes/p2_lattice_tiles.sh > /dev/null 2>&1; cp $R/gpurun_out/r05_p2_lattice_tiles.txt $S/                    # (the tile product)
+bash $R/tools/probes/exp_lattice_grid.sh "256 512 768 1024 2048" > /dev/null 2>&1; cp $R/gpurun_out/exp_var.txt $S/r05_p2_lattice_grid.txt      # (tile workgroups behind the column workgroups)
 hipcc --offload-arch=gfx950 -O3 $R/tools/probes/mfma_f64_probe.hip -o /tmp/mfma_f64_probe 2>/dev/null && /tmp/mfma_f64_probe > $S/r05_mfma_f64_probe.txt 2>&1
 (FS_SPMV4_KSPLIT=0 python $R/tools/probes/spmv4_probe.py; python $R/tools/probes/spmv4_probe.py) 2>&1 | grep -a "KSPLIT\|max" > $S/r05_spmv4_kernels.txt
 python $R/tools/probes/first_step_probe.py 2>&1 | tail -18 > $S/r05_first_step.txt
