@@ -597,3 +597,44 @@ def test_tile_product_on_lines_longer_than_a_tile(gpu):
     for s, x in ((s2, x2), (s3, x3)):
         assert s["lattice_order"] == 1 and s["classes_kept"] == 1 and s["iterations"] == s1["iterations"]
         assert np.array_equal(x.get(), x1.get())
+
+
+def test_tile_product_on_a_box_that_is_not_a_cube(gpu):
+    """The tile product on 70 x 26 x 18 cells (142 x 53 x 37 rows in lattice order: lines longer than a tile, a last strip of one
+    line, a last plane of tiles with one plane): every row against the work-item product bit for bit (lattice_check), the solve
+    against the one in the space's own numbering and against the exact linear profile along x."""
+    nx, ny, nz = 70, 26, 18
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    V = gpu.DeviceSpace(mesh, 1, degree=2)
+    xyz, cells, _ = mesh.get()
+    edges = V.edges().astype(np.int64)
+    nv = len(xyz)
+    cv = xyz[:, 0]
+    ce = 0.5 * (xyz[edges[:, 0], 0] + xyz[edges[:, 1], 0])
+    co = np.concatenate([cv, ce])
+    lo, hi = np.flatnonzero(co == 0.0), np.flatnonzero(co == 1.0)
+    dofs = np.concatenate([lo, hi]).astype(np.int32)
+    vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+    A = gpu.DeviceMatrix(V)
+    b = gpu.DeviceVector(V.n_owned)
+    A.assemble(stiffness=20.0)
+    b.fill(0.0)
+    A.apply_dirichlet(b, dofs, vals, symmetric=True)
+    got = {}
+    try:
+        gpu.set_option("lattice_check", 1)
+        gpu.set_option("cg_fused", 0)
+        for lat in (1, 0):
+            gpu.set_option("lattice_order", lat)
+            x = gpu.DeviceVector(V.n_owned)
+            got[lat] = (gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000), x.get().copy())
+    finally:
+        gpu.set_option("lattice_order", -1)
+        gpu.set_option("lattice_check", 0)
+        gpu.set_option("cg_fused", -1)
+    (s1, x1), (s0, x0) = got[1], got[0]
+    assert s1["lattice_order"] == 1 and s1["row_classes"] > 0 and s1["converged"] == 1 and s1["fused_iteration"] == 0
+    assert s0["lattice_order"] == 0 and s0["converged"] == 1 and abs(s1["iterations"] - s0["iterations"]) <= 1
+    scale = np.abs(x0).max()
+    assert np.abs(x1 - x0).max() <= 1e-9 * scale
+    assert np.abs(x1[:V.n_owned] - (350.0 - 50.0 * co[:V.n_owned])).max() <= 1e-6 * scale
