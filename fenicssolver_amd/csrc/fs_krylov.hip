@@ -982,7 +982,8 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
 // (lat_wave_rows: the lanes of the other classes masked, the lists through scalar loads - slow, correct).  What the geometry buys is
 // that this does not happen - EXCEPT at the ends of the lines: the first LT_LO and the last LT_HI rows of a line have classes of their
 // own (boundary rows, and - the operator is scaled with its diagonal - the rows coupled to them), nine of 216 columns at configs[3].
-// They are left out of the line waves and multiplied at the end of the kernel, every lane its own list, everything from global memory.
+// They are left out of the line waves: COLUMN tiles take them (the same machinery with X and Y exchanged, lanes along Y), in workgroups
+// of their own at the front of the grid; the few rows at the ends of the end columns per lane from global memory.
 // The lists come from the class rows and the plans (k_lat_table: one representative row per class; then EVERY row is checked: its
 // plan puts its class's coefficients at the offsets of that list, its X has the parity the list's window offsets were worked out for -
 // or the form is refused).
@@ -995,6 +996,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
 // one that decided it: the compiler had hoisted every thread's nine window positions out of the tile loop into scratch and waited for
 // each reload with vmcnt(0) - for the window load before it -, nine round trips per tile instead of one: with the dots 197 -> 154 us;
 // whole window lines per wave (no division chains) 149 us.  Automatic from 400 000 rows on (option "lattice_order").
+// Later in round 5 (DESIGN.md section 3 has the table): column tiles 150 us inside the iteration; interior strips as one long line
+// (lat_tile_of) 139; a wave's classes from the per-tile table (k_lat_tile_table) 133; column / corner workgroups at the front of the
+// grid, 512 tile workgroups, no private segment 120 us (105 - 115 in the trace; alone 99 us).
 constexpr int LT_TX = 128, LT_TY = 4, LT_TZ = 4;
 constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity in a window line
 constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;
@@ -3711,7 +3715,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             gd = spmv_grid(ns, sp->n_slices);
         }
         if (!list && g_lat.ok && g_lat.built_for == mat_val && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls) {
-            // a lattice-ordered operator: tiles of 64 x 4 x 4 rows, x through LDS (k_lattice_spmv)
+            // a lattice-ordered operator: tiles of 128 x 4 x 4 rows, x through LDS (k_lattice_spmv)
             const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz;
             const size_t lds = lat_lds_bytes();
             auto kern = k_lattice_spmv<DOTS>;
