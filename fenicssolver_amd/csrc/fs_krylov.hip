@@ -995,7 +995,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t 
 // LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us; batches of four entries (no spills in the loop) 137 us; and the
 // one that decided it: the compiler had hoisted every thread's nine window positions out of the tile loop into scratch and waited for
 // each reload with vmcnt(0) - for the window load before it -, nine round trips per tile instead of one: with the dots 197 -> 154 us;
-// whole window lines per wave (no division chains) 149 us.  Automatic from 400 000 rows on (option "lattice_order").
+// whole window lines per wave (no division chains) 149 us.  Automatic from 270 000 rows on (option "lattice_order").
 // Later in round 5 (DESIGN.md section 3 has the table): column tiles 150 us inside the iteration; interior strips as one long line
 // (lat_tile_of) 139; a wave's classes from the per-tile table (k_lat_tile_table) 133; column / corner workgroups at the front of the
 // grid, 512 tile workgroups, no private segment 120 us (105 - 115 in the trace; alone 99 us).
@@ -2922,7 +2922,8 @@ static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 // is bound by those instructions, not by dependent rounds.  Option "lattice_order" / FS_LATTICE=1 turn it on.
 static int g_lat_check = getenv("FS_LATTICE_CHECK") && getenv("FS_LATTICE_CHECK")[0] == '1' ? 1 : 0;      // option "lattice_check"
 static int g_lattice = getenv("FS_LATTICE") ? (getenv("FS_LATTICE")[0] == '1' ? 1 : (getenv("FS_LATTICE")[0] == '0' ? 0 : -1)) : -1;
-constexpr int64_t FS_LATTICE_MIN_ROWS = 400000;     // automatic (-1): from here on (274 k rows: 36.4 against 35.2 us per iteration; 1.03 M: 52.6 against 98.8)
+constexpr int64_t FS_LATTICE_MIN_ROWS = 270000;     // automatic (-1): from here on (us per iteration, lattice order against the space's: 250 k rows 29.0 / 26.2, 275 k: 26.4 / 34.9,
+                                                    // 300 k: 29.5 / 35.5, 1.03 M: 52.6 / 98.8 with the first tile kernel; it was 400 000 until the tile product got to 120 us at 10 M rows)
 static inline bool bs_is_scalar_cg2(const fs_matrix_s* A) { return A->bs == 1 && A->space->degree == 2 && A->space->ncomp == 1; }
 static int g_cg_batch = 32;
 // one-launch iteration on one GPU: launches go out g_cg_sub at a time (one hipGraph) whenever the device - its progress is read from

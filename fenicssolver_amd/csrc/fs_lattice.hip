@@ -17,7 +17,7 @@
 // MEASURED (round 5, MI355X, configs[3]): the WORK-ITEM product (k_dict_spmv) on this order is slower than on the space's numbering - 222 -
 // 272 us against 191 us -, the TILE product written for it (fs_krylov.hip, k_lattice_spmv: x through LDS windows, a wave per line parity,
 // class lists broadcast) is faster: 155 us, the iteration 282 against 297 us; at 1.03 M rows 52.6 against 98.8 us per iteration (there the
-// space's numbering gets no dictionary at all).  Automatic from 400 000 rows on (option "lattice_order" = -1), given up for a space whose
+// space's numbering gets no dictionary at all).  Automatic from 270 000 rows on (option "lattice_order" = -1; 400 000 before the tile product's second half of round 5), given up for a space whose
 // shadow does not fit the tile form.
 #include "fs_common.h"
 

@@ -79,7 +79,7 @@ const char* fs_last_error(void);
 const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
  * (2/4/8/16 row entries in flight per lane), "spmv_unroll4" (1/2/4: the same for 4 x 4 block rows), "cg_batch" (iterations per host poll), "lattice_order" (-1 / 0 / 1: scalar CG2 operators on uniform boxes solved in
- * the lattice order of the half grid, fs_krylov_stats.lattice_order - automatic = from 400 000 rows on, where the product is then the
+ * the lattice order of the half grid, fs_krylov_stats.lattice_order - automatic = from 270 000 rows on, where the product is then the
  * tile product k_lattice_spmv / never / wherever the order exists), "lattice_check" (0 / 1: every solve in lattice order first compares the tile product with the work-item product on a
  * vector of pseudo-random numbers, every row, bit for bit - a difference fails the solve with FS_ERR_NUMERIC), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
  * through pinned host memory and the host keeps "cg_ahead" to "cg_ahead" + "cg_sub" launches enqueued, instead of batches of

@@ -530,10 +530,10 @@ def test_cg2_box_operator_solved_in_lattice_order_gives_the_same_solve(gpu):
 
 def test_large_cg2_boxes_are_solved_in_lattice_order_by_default(gpu):
     """Automatic choice (option lattice_order = -1, the default since the tile product beat the work-item product of the space's own
-    numbering - DESIGN.md section 3): from 400 000 rows on a scalar CG2 box operator is solved in the solver's lattice order, smaller
+    numbering - DESIGN.md section 3): from 270 000 rows on a scalar CG2 box operator is solved in the solver's lattice order, smaller
     ones in the space's numbering; the two give the same solve."""
     import bench
-    n = 37                       # 75^3 = 421 875 rows
+    n = 32                       # 65^3 = 274 625 rows (n = 31, 250 047 rows, keeps the space's numbering: measured slower there)
     prob = bench.P2Problem(n, (0, n + 1), 2, 0, 1)
     prob.A.assemble(stiffness=20.0)
     prob.b.fill(0.0)
