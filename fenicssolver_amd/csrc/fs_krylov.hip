@@ -4154,7 +4154,7 @@ struct krylov_ws {
     // iteration index from the device).  Re-instantiated when anything it bakes in changes.
     dbuf<double> sg;            // s on the ghost rows, in arrival order (peer-to-peer iteration: a rank advances its ghost r, s itself)
     hipGraphExec_t cg_graph = nullptr;
-    const void* cg_key[24] = {};
+    const void* cg_key[32] = {};
     int64_t cg_key_i[8] = {};
     // one-launch iteration (k_dict_cg_iter): the second set of r, w, s (double-buffered by iteration parity), the iteration
     // counters of the device, its own captured batch
@@ -4699,13 +4699,21 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 const int fgrid = p2p_fuse ? spmv_partials_unsplit(sp, bs) : sgrid;
                 if (p2p_fuse) FS_CHECK(fs_p2p_exchange_args(sp, ws.partials.p, fgrid, ws.sums.p, &red, &snd));
                 const bool dict_on = g_dict.built_for && g_dict.built_for == aval;
-                const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
+                // (the tile product of a lattice-ordered operator bakes in the list tables, the tile table and the geometry of lat_prepare:
+                // those buffers grow - are allocated anew - when another space brings more classes or tiles)
+                const bool lat_on = dict_on && g_lat.ok && g_lat.built_for == aval && g_lat.space_serial == sp->serial;
+                const void* key[32] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
                                        ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf,
                                        dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
                                        dict_on ? (const void*)sp->dict_items.p : nullptr, p2p_fuse ? (const void*)ws.sg.p : nullptr,
                                        dict_on ? (const void*)sp->dict_plans.p : nullptr, dict_on ? (const void*)sp->halo.items_interior.p : nullptr,
                                        dict_on ? (const void*)sp->halo.items_boundary.p : nullptr,
-                                       p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr};
+                                       p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr,
+                                       lat_on ? (const void*)g_lat.tile_cls.p : nullptr, lat_on ? (const void*)g_lat.cnt.p : nullptr,
+                                       lat_on ? (const void*)g_lat.coef.p : nullptr, lat_on ? (const void*)g_lat.rel.p : nullptr,
+                                       lat_on ? (const void*)g_lat.off.p : nullptr, lat_on ? (const void*)g_lat.relc.p : nullptr,
+                                       lat_on ? reinterpret_cast<const void*>((uintptr_t)g_lat.geom.n_tiles) : nullptr,
+                                       lat_on ? reinterpret_cast<const void*>(((uintptr_t)g_lat.geom.grid << 32) | (uintptr_t)(uint32_t)g_lat.geom.w_tiles) : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? ((int64_t)g_dict.ncls * 256 + g_dict.S) * 256 + g_dict.C : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, bsz, fgrid, vgrid,

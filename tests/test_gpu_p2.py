@@ -638,3 +638,46 @@ def test_tile_product_on_a_box_that_is_not_a_cube(gpu):
     scale = np.abs(x0).max()
     assert np.abs(x1 - x0).max() <= 1e-9 * scale
     assert np.abs(x1[:V.n_owned] - (350.0 - 50.0 * co[:V.n_owned])).max() <= 1e-6 * scale
+
+
+def test_two_lattice_ordered_operators_solved_in_turn(gpu):
+    """The tile product's tables (class lists, per-tile class table, launch geometry) belong to the operator solved last: two CG2 box
+    operators of different shape solved in turn - each solve rebuilds them, re-captures its batch of launches on them (the tables are
+    part of the captured launches' identity), checks the tile product against the work-item product bit for bit - give, the second
+    time round, the first round's iterations and solutions exactly."""
+    import bench
+    cube = bench.P2Problem(32, (0, 33), 2, 0, 1)
+    cube.A.assemble(stiffness=20.0)
+    cube.b.fill(0.0)
+    cube.A.apply_dirichlet(cube.b, cube.dofs, cube.vals, symmetric=True)
+    mesh = gpu.DeviceMesh.box(70, 26, 18, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    V = gpu.DeviceSpace(mesh, 1, degree=2)
+    xyz, _, _ = mesh.get()
+    edges = V.edges().astype(np.int64)
+    co = np.concatenate([xyz[:, 0], 0.5 * (xyz[edges[:, 0], 0] + xyz[edges[:, 1], 0])])
+    lo, hi = np.flatnonzero(co == 0.0), np.flatnonzero(co == 1.0)
+    A = gpu.DeviceMatrix(V)
+    b = gpu.DeviceVector(V.n_owned)
+    A.assemble(stiffness=20.0)
+    b.fill(0.0)
+    A.apply_dirichlet(b, np.concatenate([lo, hi]).astype(np.int32), np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)]), symmetric=True)
+    runs = []
+    try:
+        gpu.set_option("lattice_check", 1)
+        gpu.set_option("lattice_order", 1)
+        gpu.set_option("cg_fused", 0)
+        for rnd in range(2):
+            for (AA, bb, nn) in ((cube.A, cube.b, cube.V.n_owned), (A, b, V.n_owned)):
+                x = gpu.DeviceVector(nn)
+                st = gpu.krylov_solve(AA, bb, x, rtol=1e-10, max_iter=5000)
+                runs.append((st, x.get().copy()))
+    finally:
+        gpu.set_option("lattice_order", -1)
+        gpu.set_option("lattice_check", 0)
+        gpu.set_option("cg_fused", -1)
+    for st, _ in runs:
+        assert st["lattice_order"] == 1 and st["converged"] == 1 and st["row_classes"] > 0
+    for k in (0, 1):
+        assert runs[k][0]["iterations"] == runs[k + 2][0]["iterations"] and np.array_equal(runs[k][1], runs[k + 2][1])
+    assert np.abs(runs[0][1][:cube.n_owned] - cube.exact_owned).max() <= 1e-6 * 350.0
+    assert np.abs(runs[1][1][:V.n_owned] - (350.0 - 50.0 * co[:V.n_owned])).max() <= 1e-6 * 350.0
