@@ -2075,7 +2075,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
                                                                double* __restrict__ scal, int* __restrict__ status,
                                                                double* __restrict__ hist, double* __restrict__ r,
                                                                const double* __restrict__ w, double* __restrict__ p,
-                                                               double* __restrict__ sv, double* __restrict__ x, int* __restrict__ mirror = nullptr) {
+                                                               double* __restrict__ sv, double* __restrict__ x, int* __restrict__ mirror = nullptr, int r_plain = 0) {
     // mirror (one GPU; may be null): the pinned progress words of k_dict_cg_iter - [0] status once stopped, [1] iteration in progress
     // (the status word is looked at AFTER the first trip's loads have gone out - everything a launch reads first was written by the
     // previous launch on other XCDs, and each dependent load is a round trip of about a microsecond)
@@ -2165,8 +2165,11 @@ __global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int it
         xb.x += alpha * pb.x;       xb.y += alpha * pb.y;
         ra.x -= alpha * sa.x;       ra.y -= alpha * sa.y;
         rb.x -= alpha * sb.x;       rb.y -= alpha * sb.y;
-        io::st(&p2[i], pa); io::st(&s2[i], sa); io::st(&x2[i], xa); io::st(&r2[i], ra);
-        io::st(&p2[j], pb); io::st(&s2[j], sb); io::st(&x2[j], xb); io::st(&r2[j], rb);
+        // (r_plain, bits: ordinary stores for r / p / s / x where the kernel otherwise streams its stores past the caches; g_upd_r_plain)
+        if (r_plain & 2) { p2[i] = pa; p2[j] = pb; } else { io::st(&p2[i], pa); io::st(&p2[j], pb); }
+        if (r_plain & 4) { s2[i] = sa; s2[j] = sb; } else { io::st(&s2[i], sa); io::st(&s2[j], sb); }
+        if (r_plain & 8) { x2[i] = xa; x2[j] = xb; } else { io::st(&x2[i], xa); io::st(&x2[j], xb); }
+        if (r_plain & 1) { r2[i] = ra; r2[j] = rb; } else { io::st(&r2[i], ra); io::st(&r2[j], rb); }
     }
     for (; i < n2; i += stride) {
         const double2 ww = w2[i];
@@ -2925,6 +2928,11 @@ static int g_lattice = getenv("FS_LATTICE") ? (getenv("FS_LATTICE")[0] == '1' ? 
 constexpr int64_t FS_LATTICE_MIN_ROWS = 270000;     // automatic (-1): from here on (us per iteration, lattice order against the space's: 250 k rows 29.0 / 26.2, 275 k: 26.4 / 34.9,
                                                     // 300 k: 29.5 / 35.5, 1.03 M: 52.6 / 98.8 with the first tile kernel; it was 400 000 until the tile product got to 120 us at 10 M rows)
 static inline bool bs_is_scalar_cg2(const fs_matrix_s* A) { return A->bs == 1 && A->space->degree == 2 && A->space->ncomp == 1; }
+// k_cg_update_scaled with non-temporal accesses (vectors larger than the caches): which of its stores are ORDINARY ones all the same -
+// bit 0: r, 1: p, 2: s, 3: x.  Measured (round 5, same box, A/B twice; tools/probes/exp_update_r_plain.sh), us per iteration at configs[3] /
+// the 10 M-DOF P1 cube / its streaming form: none 237 - 240 / 177 - 181 / 394 - 397; r: 228 - 236 / 169 - 174 / 365 - 389; r + p: 241 / 183 / 400;
+// r + s: 242 / 184 / 396; r + x: 245 / 180 / 389; all four: 258 / 194 / 427.  The residual is what the next product reads: default 1.
+static const int g_upd_r_plain = getenv("FS_UPDATE_R_PLAIN") ? atoi(getenv("FS_UPDATE_R_PLAIN")) : 1;
 static int g_cg_batch = 32;
 // one-launch iteration on one GPU: launches go out g_cg_sub at a time (one hipGraph) whenever the device - its progress is read from
 // pinned memory the kernel writes (krylov_ws::h_mirror) - has fewer than g_cg_ahead of them left to do; g_cg_mirror = 0: the batches
@@ -4736,8 +4744,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                             continue;
                         }
                         rc_cap = spmv_overlapped<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval);
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev, g_upd_r_plain);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, -1, 0, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev, g_upd_r_plain);
                     }
                     const hipError_t e_end = hipStreamEndCapture(s, &graph);
                     FS_CHECK(rc_cap);
@@ -4865,8 +4873,8 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                     const int co = k == max_iter ? 1 : 0;
                     if (fuse_sums) {
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
-                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
-                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev);
+                        if (upd_nt) hipLaunchKernelGGL((k_cg_update_scaled<true, true>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev, g_upd_r_plain);
+                        else hipLaunchKernelGGL((k_cg_update_scaled<true, false>), dim3(vgrid), dim3(FS_BLOCK), 0, s, n, k, co, ws.partials.p, sgrid, ws.sums.p, ws.ctrl.p, ws.scal.p, ws.status.p, hist_p, ws.z.p, ws.w.p, ws.p.p, ws.s.p, x->d.p, mirror_dev, g_upd_r_plain);
                     } else {
                         FS_CHECK(fs_comm_sum_allreduce_dev(ws.partials.p, sgrid, 3, ws.sums.p, s));
                         if (sample) FS_HIP(hipEventRecord(ws.ev[n_samples][2], s));
