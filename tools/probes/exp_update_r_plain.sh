@@ -1,3 +1,4 @@
+# k_cg_update_scaled: which stores of the non-temporal form are ordinary ones (FS_UPDATE_R_PLAIN bits: 1 r, 2 p, 4 s, 8 x; default 1): configs[3] and the default bench command
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for v in ${1:-0 1 3 5 9 15 1}; do
