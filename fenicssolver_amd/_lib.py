@@ -140,6 +140,7 @@ SIGNATURES = {
     "fs_krylov_history": (C.c_int, [c_f64p, C.c_int, C.POINTER(C.c_int)]),
     "fs_spmv_benchmark": (C.c_int, [_H, _H, _H, C.c_int, c_f64p]),
     "fs_spmv_dictionary": (C.c_int, [_H, _H, _H, C.POINTER(C.c_int)]),
+    "fs_last_product_kind": (C.c_int, []),
     "fs_amg_setup": (C.c_int, [_H, C.c_int, c_f64p, C.POINTER(fs_amg_opts), C.POINTER(_H)]),
     "fs_amg_attach_distributed_fine": (C.c_int, [_H, _H, c_i64, c_i32p]),
     "fs_amg_destroy": (C.c_int, [_H]),

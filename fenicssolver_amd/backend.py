@@ -805,5 +805,11 @@ def comm_benchmark(space, reps=200):
     return a.value, h.value
 
 
+def last_product_kind():
+    """Kernel family of the last product this process launched (fs_last_product_kind): 0 streaming, 1 row-dictionary work items,
+    2 lattice tiles (CG2 box), 3 marching windows (P1 box), 4 block-row dictionary."""
+    return int(L.load().fs_last_product_kind())
+
+
 def set_option(name, value):
     L.check(L.load().fs_set_option(name.encode(), float(value)), "fs_set_option")

@@ -282,6 +282,8 @@ struct fs_space_s {
     int dict_period = 1;
     int64_t dict_line = 0;
     int dict_runs = 8;            // runs per plan round (12: the lattice-ordered shadow - k_dict_spmv<.., 12>)
+    int32_t box_a = 0;            // > 0: the whole space is ONE segment with the offset list of a Kuhn-split box, box_a rows per mesh line and
+    int64_t box_b = 0;            // box_b rows per mesh plane (dict_structure_build): the marching-window product applies (fs_box.h)
     int lat_ny = 0, lat_nz = 0;   // lattice-ordered shadow: lines per plane, planes (row = x + dict_line * (y + lat_ny * z)); 0: not one
     // the solver's lattice-ordered shadow of a scalar CG2 space on a uniform box (fs_lattice.hip): 0 not looked at yet, 1 built,
     // -1 does not apply

@@ -17,6 +17,8 @@
 // flight, so the stream never drains.
 #include "fs_common.h"
 #include "fs_kernels.h"
+#define BOX_DC_AUX 2      // (fs_box.h: dot weights and class numbers are read once - streamed past the caches)
+#include "fs_box.h"
 #include <functional>
 #include <chrono>
 #include <string>
@@ -2943,6 +2945,10 @@ static int g_cg_graph = -1;      // -1: automatic (graphs, unless a profiler's t
 static int g_update_blocks = 1024;  // (round 3, with the 16 us row-dictionary product at 1 M rows: 256 / 512 / 768 / 1024 / 2048 workgroups: 10.59 / 10.42 / 10.20 / 10.12 / 11.22 ms per step; 10 M rows: flat)
 static int g_cg_fused = -1;      // one launch per CG iteration on row-dictionary operators: -1 automatic, 0 never, 1 wherever it applies
 static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
+// the marching-window product of P1 box operators (fs_box.h): option "box_spmv" (0: k_dict_spmv everywhere), from "box_min_rows" rows on
+static int g_last_product_kind = 0;      // fs_last_product_kind()
+static int g_box = getenv("FS_BOX_SPMV") ? atoi(getenv("FS_BOX_SPMV")) : 1;                    // option "box_spmv"
+static int64_t g_box_min_rows = getenv("FS_BOX_MIN_ROWS") ? atoll(getenv("FS_BOX_MIN_ROWS")) : 1500000;
 
 extern "C" int fs_set_option(const char* name, double value) {
     FS_REQUIRE(name, "fs_set_option: null name");
@@ -2966,6 +2972,11 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "update_blocks")) {
         FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
         g_update_blocks = (int)value;
+    } else if (!strcmp(name, "box_spmv")) {
+        g_box = value != 0.0;
+    } else if (!strcmp(name, "box_min_rows")) {
+        FS_REQUIRE(value >= 0, "box_min_rows must be >= 0");
+        g_box_min_rows = (int64_t)value;
     } else if (!strcmp(name, "row_dictionary")) {
         g_row_dictionary = value != 0.0;
     } else if (!strcmp(name, "box_snap")) {
@@ -3219,6 +3230,26 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
             cur = i;
         }
         segs.back().end = (int32_t)n;
+        // A few segments whose lists are all contained in the longest one (a P1 box: the first mesh line, the rest of the first
+        // plane, the first line of the second plane, everything else - the greedy pass above only ever grows a list by nesting)
+        // are ONE segment with that list: a row has zero coefficients where it has no entry, as the boundary rows inside the bulk
+        // segment already do, and the items whose loads could leave the vector are flagged `edge` below.  One plan for the whole
+        // space = one coefficient layout for every class row (k_box_spmv relies on it).
+        if (segs.size() > 1 && segs.size() <= 8) {
+            size_t big = 0;
+            for (size_t g = 1; g < segs.size(); ++g)
+                if (clen[(size_t)segs[g].list] > clen[(size_t)segs[big].list]) big = g;
+            const auto M = set_of(segs[big].list);
+            bool nested = true;
+            for (size_t g = 0; g < segs.size() && nested; ++g) {
+                const auto o = set_of(segs[g].list);
+                nested = std::includes(M.first, M.second, o.first, o.second);
+            }
+            if (nested) {
+                const int32_t list = segs[big].list;
+                segs.assign(1, segment{0, (int32_t)n, list});
+            }
+        }
     }
     const int NR = sp->dict_runs;       // runs per round: 8, or 12 for the lattice-ordered shadow of a CG2 box space
     // 4. run plans (identical lists share one) and items.  Runs of up to three consecutive offsets - or of up to two where longer
@@ -3363,6 +3394,13 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         FS_CHECK(sp->dict_plans.upload(reinterpret_cast<const int32_t*>(rounds.data()), plan_ints, s));
         sp->dict_slots = NR * RL * std::max(max_rounds, 1);
         sp->dict_run_len = RL;
+        // ONE segment with the offset list of a Kuhn-split box (P1 on fs_mesh_create_box / BoxMesh, one GPU): the marching-window
+        // product applies (fs_box.h, k_box_spmv)
+        sp->box_a = 0; sp->box_b = 0;
+        if (segs.size() == 1 && rounds.size() == 1 && NR == 8 && !h.active && n == n_cols) {
+            box_geom bg;
+            if (box_recognize(rounds[0].start, rounds[0].len, 8, n, RL, &bg)) { sp->box_a = bg.a; sp->box_b = bg.b; }
+        }
         FS_CHECK(upload_items(sp->dict_items, sp->n_dict_items, -1));
     }
     if (need_lists) {
@@ -3383,6 +3421,8 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
 // class table then walks raw and scales on the fly; only if that fails - or no table is kept - `materialize` writes val (k_scale_copy)
 // before anything reads it.  On the kept path val stays unwritten: it is the KEY of the permission (built_for), and every product of
 // the solve goes through the dictionary kernels (launch_spmv: whole-space launches of a space without a halo plan).
+struct box_plan_s;
+static const box_plan_s* box_plan_for(const fs_space_s* sp, int ncls);
 static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, const double* raw, const double* sc, const std::function<void()>& materialize) {
     row_dict& D = g_dict;
     D.built_for = nullptr;
@@ -3422,6 +3462,7 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
         D.built_for = val;
         D.space_serial = sp->serial;
         D.matrix_serial = A->serial;
+        if (A->bs == 1 && sp->dict_runs == 8 && sp->dict_run_len == 3) (void)box_plan_for(sp, ncls);     // (the launch plan of k_box_spmv: made here, outside any capture)
     };
     static const bool no_reuse = getenv("FS_DICT_REUSE") && getenv("FS_DICT_REUSE")[0] == '0';
     if (!no_reuse && D.tables_space == sp->serial && D.tables_bs == A->bs && D.tables_S == S && D.tables_ncls > 0) {
@@ -3685,6 +3726,76 @@ static int dict_build(fs_matrix_s* A, const double* val, hipStream_t s, const do
     return rc;
 }
 
+// ---- the marching-window product of a P1 box operator (fs_box.h) ------------------------------------------------------------------
+// Two launch shapes: mesh lines up to 320 rows - 6 compute waves x 2 rows per lane (patches of <= 768 rows, two workgroups per CU);
+// longer lines - 8 x 3 (<= 1536 rows, one workgroup per CU: the window's halo of 2 (a + 1) positions is paid per patch).  Measured
+// (tools/probes/box_spmv_probe.hip, profiles/r06_box_probe.txt): 10 M rows 51 us, 86 M rows 382 - 400 us inside an iteration-like
+// sequence, where a plain streaming kernel over the same 26 B/row takes 57 and 421.
+struct box_plan_s {
+    unsigned long long space_serial = 0;
+    int ncls = 0, shape = -1;       // shape 0: 6 x 2, 1: 8 x 3, -1: does not fit
+    box_geom g;
+    size_t lds = 0;
+};
+static box_plan_s g_box_plan;
+// (the kernels take up to 160 KB of dynamic LDS: the attribute is set for every instantiation when the first plan is made - by
+// dict_build, outside any stream capture - not at the launch, which may be a node of a CG batch being captured)
+template <int DOTS>
+static void box_set_lds_attribute() {
+    (void)hipFuncSetAttribute((const void*)k_box_spmv<DOTS, 6, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+    (void)hipFuncSetAttribute((const void*)k_box_spmv<DOTS, 8, 3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+}
+static void box_prepare_kernels() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    box_set_lds_attribute<0>(); box_set_lds_attribute<1>(); box_set_lds_attribute<2>(); box_set_lds_attribute<3>(); box_set_lds_attribute<4>();
+    (void)hipGetLastError();
+}
+static const box_plan_s* box_plan_for(const fs_space_s* sp, int ncls) {
+    if (!g_box || sp->box_a <= 0 || sp->n_nodes_owned < g_box_min_rows || sp->halo.active) return nullptr;
+    box_plan_s& B = g_box_plan;
+    if (B.space_serial != sp->serial || B.ncls != ncls) {
+        B.space_serial = sp->serial; B.ncls = ncls; B.shape = -1;
+        int32_t starts[8] = {0, (int32_t)-(sp->box_a + sp->box_b + 1), (int32_t)-(sp->box_b + 1), -(sp->box_a + 1), -1, sp->box_a, (int32_t)sp->box_b, (int32_t)(sp->box_a + sp->box_b)};
+        const uint8_t lens[8] = {0, 2, 2, 2, 3, 2, 2, 2};
+        box_geom g;
+        if (ncls * BOX_TERMS * 8 <= (24 << 10) && box_recognize(starts, lens, 8, sp->n_nodes_owned, 3, &g)) {
+            const int cus = fs_rt().compute_units > 0 ? fs_rt().compute_units : 256;
+            static const int shape_env = getenv("FS_BOX_SHAPE") ? atoi(getenv("FS_BOX_SHAPE")) : -1;
+            for (int shape = (shape_env >= 0 ? shape_env : (sp->box_a <= 320 ? 0 : 1)); shape <= 1; ++shape) {
+                const int cw = shape == 0 ? 6 : 8, rp = shape == 0 ? 2 : 3;
+                box_geom t = g;
+                t.S = sp->dict_slots;
+                box_cut(&t, cw * 64 * rp, cus, 1);
+                const size_t lds = box_lds_bytes(t, ncls, 2, true);
+                const int per_cu = (int)std::min<size_t>((size_t)(160 << 10) / (lds + 256), shape == 0 ? 2 : 1);
+                if (per_cu < 1 || (t.G + (t.dslot >> 7) + (t.cslot >> 9)) > 62) continue;
+                box_cut(&t, cw * 64 * rp, cus * per_cu, 1);
+                B.g = t; B.lds = box_lds_bytes(t, ncls, 2, true); B.shape = shape;
+                box_prepare_kernels();
+                break;
+            }
+        }
+        if (getenv("FS_KRYLOV_DEBUG"))
+            fprintf(stderr, "[fs_krylov] marching-window product: shape %d, a %d b %lld, patches %d x %d rows, %d chunks of %d planes, %d workgroups, %zu B of LDS\n",
+                    B.shape, sp->box_a, (long long)sp->box_b, B.g.P, B.g.L, B.g.ZC, B.g.nz, B.g.grid, B.lds);
+    }
+    return B.shape >= 0 ? &B : nullptr;
+}
+template <int DOTS>
+static void launch_box(const box_plan_s* B, const uint16_t* cls, const double* dict, int ncls, const double* x, double* y, const double* rvec,
+                       double* partials, int* status, int part_base, int part_stride, int bump, hipStream_t s) {
+    const box_geom& g = B->g;
+    if (B->shape == 0) {
+        auto kern = k_box_spmv<DOTS, 6, 2, 2, 2>;
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(8 * 64), B->lds, s, g, cls, dict, ncls, x, y, rvec, partials, status, part_base, part_stride ? part_stride : g.grid, bump);
+    } else {
+        auto kern = k_box_spmv<DOTS, 8, 3, 2, 2>;
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(10 * 64), B->lds, s, g, cls, dict, ncls, x, y, rvec, partials, status, part_base, part_stride ? part_stride : g.grid, bump);
+    }
+}
+
 // `list` / `n_list`: multiply only these slices (the interior or the boundary slices of a decomposed space, in
 // processing order); nullptr = all slices in the space's own order.
 template <int DOTS>
@@ -3707,6 +3818,7 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
         if (sp->dict_run_len == 2) hipLaunchKernelGGL((k_dict_spmv3<2>), FS_DICT3_ARGS);
         else hipLaunchKernelGGL((k_dict_spmv3<3>), FS_DICT3_ARGS);
 #undef FS_DICT3_ARGS
+        g_last_product_kind = 4;
         return;
     }
     if (A->bs == 1 && g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == mat_val && g_dict.matrix_serial == A->serial && g_dict.space_serial == sp->serial) {
@@ -3734,7 +3846,15 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             hipLaunchKernelGGL(kern, dim3(gd), dim3(LT_BLOCK), lds, s, g_lat.geom, g_lat.tile_cls.p, SX, NY, NZ, g_dict.cls.p,
                                g_lat.cnt.p, g_lat.coef.p, g_lat.rel.p, g_lat.off.p, g_lat.relc.p, x, y, rvec, partials, status, part_base, part_stride ? part_stride : gd, bump,
                                g_lt_dbg | g_lt_dbg_env);
+            g_last_product_kind = 2;
             return;
+        }
+        if (!list && sp->dict_runs == 8 && sp->dict_run_len == 3) {
+            if (const box_plan_s* B = box_plan_for(sp, g_dict.ncls)) {
+                launch_box<DOTS>(B, g_dict.cls.p, g_dict.values.p, g_dict.ncls, x, y, rvec, partials, status, part_base, part_stride, bump, s);
+                g_last_product_kind = 3;
+                return;
+            }
         }
         if (items && n_items >= 0) {
 #define FS_DICT_ARGS(CC) sp->n_nodes_local, n_items, reinterpret_cast<const int4*>(items), reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), \
@@ -3751,9 +3871,11 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
                 else hipLaunchKernelGGL((k_dict_spmv<DOTS, false, 3>), dim3(gd), dim3(FS_BLOCK), per_wave, s, FS_DICT_ARGS(g_dict.C));
             }
 #undef FS_DICT_ARGS
+            g_last_product_kind = 1;
             return;
         }
     }
+    g_last_product_kind = 0;
     const int grid = spmv_grid(ns, sp->n_slices);
     if (part_stride == 0) part_stride = grid;
 #define FS_SPMV_ARGS dim3(grid), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_nodes_local, ns, sp->slice_ptr.p, sp->sell_col.p, sp->dia_ptr.p, sp->dia_off.p, mat_val, sp->sell_entries, x, y, rvec, partials, status, order, part_base, part_stride, bump
@@ -3823,6 +3945,8 @@ static int spmv_partials_unsplit(const fs_space_s* sp, int bs) {
     if (bs == 1 && g_dict.built_for && g_dict.space_serial == sp->serial) {
         // (the tile product of a lattice-ordered operator has its own geometry: launch_spmv's condition)
         if (g_lat.ok && g_lat.built_for == g_dict.built_for && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls && g_lat.geom.grid > 0) return g_lat.geom.grid;
+        if (g_dict.bs == 1 && sp->dict_runs == 8 && sp->dict_run_len == 3)
+            if (const box_plan_s* B = box_plan_for(sp, g_dict.ncls)) return B->g.grid;      // (launch_spmv's condition)
         return dict_grid(sp);
     }
     if (bs == 1 && sp->n_pairs > 0 && spmv_use_pairs(sp, 1))
@@ -4060,6 +4184,8 @@ int fs_dict_begin(fs_matrix_s* A, hipStream_t s) {
 }
 void fs_dict_end() { g_dict.built_for = nullptr; }
 int fs_dict_classes() { return g_dict.built_for ? g_dict.ncls : 0; }
+
+extern "C" int fs_last_product_kind(void) { return g_last_product_kind; }
 
 extern "C" int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y) {
     FS_REQUIRE(A && x && y, "fs_spmv: null pointer");

@@ -408,6 +408,13 @@ int fs_spmv_benchmark(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int reps, dou
  * rows used, 0 = the rows do not repeat and the streaming product ran.  Both forms give the same bits as fs_spmv. */
 int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_classes);
 
+/* Which kernel the LAST product launched by this process went through (MatMult, SolverBase.py:663-670; a diagnostic - PETSc's
+ * analogue is the -log_view line of MatMult): 0 streaming SELL / DIA kernels, 1 row-dictionary work items (k_dict_spmv), 2 lattice
+ * tiles of a CG2 box (k_lattice_spmv), 3 marching windows of a P1 box (k_box_spmv, round 6: options "box_spmv" 1 / 0 and
+ * "box_min_rows", default 1 500 000), 4 block-row dictionary (k_dict_spmv3).  The one-launch iteration k_dict_cg_iter does not
+ * count as a product here. */
+int fs_last_product_kind(void);
+
 /* ---- smoothed-aggregation AMG (PETScPreconditioner("petsc_amg") + set_near_nullspace,
  *      SolverBase.py:643-672; Chebyshev/Jacobi level smoother as the PETScOptions there ask) ---- */
 

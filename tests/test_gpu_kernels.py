@@ -745,6 +745,87 @@ def test_row_dictionary_product_bits(gpu, dims, mass):
         xb.set(nxt)
 
 
+@pytest.mark.parametrize("dims,mass", [((20, 20, 20), 0.7), ((33, 33, 33), None), ((70, 9, 11), 0.3), ((7, 40, 5), None), ((130, 4, 3), 1.0),
+                                       ((215, 6, 5), None), ((40, 41, 30), 0.2), ((399, 3, 2), None)])
+def test_marching_window_product_bits(gpu, dims, mass):
+    """k_box_spmv (round 6: windows of x marching through the mesh planes of a P1 box, fs_box.h) = the streaming product = the
+    work-item dictionary product, BIT FOR BIT, over a chain of dependent products.  Shapes with even and odd rows per line / per
+    plane (the loader's 16-byte groups start at even indices: an odd plane stride shifts every other window by one), lines longer
+    than a patch, patches that end inside a line, chunks of one plane."""
+    nx, ny, nz = dims
+    mesh = gpu.DeviceMesh.box(nx, ny, nz)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=20.0, mass=mass)
+    rng = np.random.default_rng(6)
+    xs = [gpu.DeviceVector(V.n_local) for _ in range(3)]
+    ys = [gpu.DeviceVector(V.n_owned) for _ in range(3)]
+    x0 = rng.standard_normal(V.n_local)
+    for v in xs:
+        v.set(x0)
+    try:
+        gpu.set_option("box_min_rows", 0)
+        for it in range(8):
+            gpu.set_option("box_spmv", 1)
+            assert A.spmv_dictionary(xs[0], ys[0]) > 0
+            assert gpu.last_product_kind() == 3, "the marching-window product did not run"
+            gpu.set_option("box_spmv", 0)
+            assert A.spmv_dictionary(xs[1], ys[1]) > 0
+            assert gpu.last_product_kind() == 1
+            A.spmv(xs[2], ys[2])
+            a, b, c = (v.get() for v in ys)
+            assert np.array_equal(a, c), (it, np.abs(a - c).max(), int((a != c).sum()))
+            assert np.array_equal(b, c), (it, np.abs(b - c).max())
+            nxt = np.zeros(V.n_local)
+            nxt[:V.n_owned] = a / np.abs(a).max()
+            for v in xs:
+                v.set(nxt)
+    finally:
+        gpu.set_option("box_spmv", 1)
+        gpu.set_option("box_min_rows", 1500000)
+
+
+@pytest.mark.parametrize("method,scale", [("cg", True), ("cg", False), ("bicgstab", True)])
+def test_solves_through_the_marching_window_product(gpu, method, scale):
+    """CG on the scaled operator (three fused sums of the product: z.z, w.z, sum d z^2), CG without the scaling (r.z, w.z, r.r) and
+    BiCGStab (w.r, w.w, r.r; status word only) through k_box_spmv against the same solves through k_dict_spmv: same iteration
+    counts, solutions equal to rounding (the partial sums are added in another order: patches, not work items)."""
+    n = 47
+    mesh = gpu.DeviceMesh.box(n, n, n)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    nn = (n + 1) ** 3
+    idx = np.arange(nn)
+    dofs = idx[(idx // ((n + 1) ** 2) == 0) | (idx // ((n + 1) ** 2) == n)].astype(np.int32)
+    vals = np.where(dofs < (n + 1) ** 2, 350.0, 300.0)
+    res = {}
+    try:
+        gpu.set_option("box_min_rows", 0)
+        gpu.set_option("cg_fused", 0)
+        for box in (1, 0):
+            gpu.set_option("box_spmv", box)
+            A.assemble(stiffness=20.0, mass=0.3 if method == "bicgstab" else None)
+            b = gpu.DeviceVector(V.n_owned)
+            gpu.assemble_vector(V, b, source=1.0)
+            A.apply_dirichlet(b, dofs, vals, True)
+            x = gpu.DeviceVector(V.n_owned)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=3000, method=method, diagonal_scale=scale)
+            assert st["converged"] == 1, st
+            if method == "cg" and scale:
+                assert st["row_classes"] > 0, st
+            if st["row_classes"] > 0:           # (solves that do not take the dictionary form run the streaming kernels either way)
+                assert gpu.last_product_kind() == (3 if box else 1), (box, gpu.last_product_kind())
+            res[box] = (st, x.get())
+    finally:
+        gpu.set_option("box_spmv", 1)
+        gpu.set_option("box_min_rows", 1500000)
+        gpu.set_option("cg_fused", -1)
+    (s1, x1), (s0, x0) = res[1], res[0]
+    assert abs(s1["iterations"] - s0["iterations"]) <= (0 if method == "cg" else 2), (s1, s0)
+    assert np.abs(x1 - x0).max() <= 1e-9 * np.abs(x0).max()
+    assert s1["true_rel_residual"] <= 5e-10
+
+
 def test_block_row_dictionary_product_bits_and_the_amg_solve(gpu):
     """Vector P1 space on a uniform box (round 4): the 3 x 3 block rows of the elasticity operator repeat (33 classes at any size;
     the elasticity kernel snaps its edge vectors like the scalar ones) and the products of fs_amg_solve - four per V-cycle on the
