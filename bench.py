@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--th-n", type=int, default=43, help="cube of the configs[4] extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-case", action="store_true", help="skip the extra 10 M-DOF roofline measurement")
+    ap.add_argument("--no-cache-free-case", action="store_true",
+                    help="skip the 86 M-DOF cube (n = 440) behind the 10 M-DOF roofline measurement: the same kernels where the 256 MiB Infinity Cache cannot help")
     return ap.parse_args()
 
 
@@ -565,6 +567,14 @@ def kernel_name(V, st=None):
                 "x through LDS windows, a wave per line parity with its class's row broadcast from LDS; interior strips of lines as one long line; the rows at the "
                 "ends of the mesh lines in column tiles with lanes along Y, in workgroups of their own)"
                 % st["row_classes"])
+    if st is not None and st.get("row_classes", 0) > 0 and st.get("product_kind", 0) == 3:
+        # fs_box.h k_box_spmv (round 6): a P1 box from 1.5 M rows on - launch shape by the length of a mesh line (fs_krylov.hip box_plan_for)
+        nx = int(round(V.n_owned ** (1.0 / 3.0)))
+        shape = "6,2,2,2" if nx <= 320 else "8,3,2,2"
+        return ("k_box_spmv<3,%s> (row-dictionary form of a P1 box, %d distinct rows: windows of x MARCHING through the mesh planes in an "
+                "LDS ring filled by two loader waves with global_load_lds_dwordx4 two steps ahead, dot weights and class numbers through "
+                "LDS as well, partial sums of three planes' rows in registers, one resident window per workgroup; template arguments: "
+                "dot mode, compute waves, rows per lane, steps ahead, loader waves)" % (shape, st["row_classes"]))
     if st is not None and st.get("row_classes", 0) > 0:       # fs_krylov.hip dict_build(): a few distinct rows, coefficients in LDS
         # template arguments: dot mode, whole dictionary in every workgroup's LDS (<= 32 KB, fs_krylov.hip FS_DICT_WHOLE_LDS_BYTES;
         # class rows are 24 doubles per round of the longest run plan: 1 round on P1, 5 on CG2 Kuhn meshes) / per-item class rows
@@ -631,11 +641,11 @@ def iteration_rates(st, k, n_rows):
                                                           "required bytes of the product + 72 B/row of the update")}
 
 
-PROFILE_ROUND = "r05"          # the round whose committed PMC passes (profiles/<round>_pmc.json) belong to THIS tree's kernels
+PROFILE_ROUND = "r06"          # the round whose committed PMC passes (profiles/<round>_pmc.json) belong to THIS tree's kernels
 
 
 def committed_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round (profiles/r05_pmc.json;
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round (profiles/r06_pmc.json;
     collected on the same command in separate --pmc runs by tools/collect_profiles.sh).  Not measured in this run.  A missing file
     or key gives None: an older round's file describes an older kernel and is never used."""
     name = PROFILE_ROUND + "_pmc.json"
@@ -649,7 +659,8 @@ def committed_traffic(tag):
 
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["required_GBps"] / HBM_PEAK_GBS
-    what = (" (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
+    what = " (product fused with the 3 dot products of the diagonally scaled CG)" if "k_box_spmv" in k["kernel"] else (
+           " (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
             "LDS, work items of 126 rows - two per lane -, one 16-byte load per run of consecutive offsets; template arguments: dot mode, "
             "whole dictionary in LDS)") if k.get("row_classes", 0) > 0 else (
         " (hybrid SELL-64/DIA SpMV fused with the 3 dot products of the diagonally scaled CG; template arguments of k_sell_spmv: block "
@@ -909,6 +920,31 @@ def main():
                     B.set_option("row_dictionary", 1)
             out["roofline"] = r
             del big
+            if not a.no_cache_free_case:
+                # --- the same kernels at 85.8 M rows: 8.4 GB per iteration against 256 MiB of Infinity Cache (at 10 M rows the 988 MB
+                # of an iteration are 4 x the cache, and FETCH_SIZE counts its hits: VERDICT r5).  One first step + one timed step.
+                B.profile_marker(4)     # phase 4: the cache-free sibling
+                try:
+                    huge = Problem(440, 440, 440, (1.0, 1.0, 1.0), (0, 441), axis, 0, 1)
+                    huge.step(a.rtol)
+                    B.synchronize()
+                    t0 = time.perf_counter()
+                    st_h, asm_h = huge.step(a.rtol)
+                    B.synchronize()
+                    t_h = time.perf_counter() - t0
+                    k_h = kernel_rates(st_h, huge.V)
+                    r["cache_free_case"] = {
+                        "workload": "same path, unit cube n=440, %d DOF (%.2f GB required per product, %.2f GB per iteration)" % (
+                            huge.n_owned, k_h["required_bytes_per_launch"] / 1e9,
+                            (k_h["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * huge.n_owned) / 1e9),
+                        "kernel": k_h["kernel"].split(" (")[0], "avg_launch_ms": k_h["avg_launch_ms"],
+                        "required_bytes_per_launch": k_h["required_bytes_per_launch"], "achieved": k_h["required_GBps"],
+                        "frac": round(k_h["required_GBps"] / HBM_PEAK_GBS, 3), "dof_per_s": round(huge.n_owned / t_h, 1),
+                        "cg_iterations": st_h["iterations"], "assemble_ms": round(asm_h, 3), "solve_ms": round(st_h["solve_ms"], 3),
+                        "update_kernel": update_rates(st_h, huge.n_owned), "iteration": iteration_rates(st_h, k_h, huge.n_owned)}
+                    del huge
+                except Exception as e:          # (a box with less free memory must not cost the line)
+                    r["cache_free_case"] = {"error": repr(e)[:300]}
         # --- CPU baseline: the oracle's C restatement of the reference's CPU path, same workload ---
         if not a.no_cpu_baseline:
             from oracle import c_oracle

@@ -59,7 +59,7 @@ class fs_krylov_stats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("bnorm", C.c_double),
                 ("rel_residual", C.c_double), ("true_rel_residual", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms", C.c_double), ("update_ms", C.c_double), ("spmv_bytes", c_i64), ("row_classes", C.c_int),
-                ("fused_iteration", C.c_int), ("classes_kept", C.c_int), ("lattice_order", C.c_int), ("launches", C.c_int)]
+                ("fused_iteration", C.c_int), ("classes_kept", C.c_int), ("lattice_order", C.c_int), ("launches", C.c_int), ("product_kind", C.c_int)]
 
 
 class fs_ns_form(C.Structure):

@@ -5155,6 +5155,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         stats->fused_iteration = fusedp_used ? 2 : (fused ? 1 : 0);
         stats->classes_kept = g_dict.built_for && g_dict.kept ? 1 : 0;
         stats->launches = n_launches;
+        stats->product_kind = fused ? 1 : g_last_product_kind;
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -389,6 +389,8 @@ typedef struct fs_krylov_stats {
                              * b and x permuted in and out; the API numbering is untouched): option "lattice_order" */
     int launches;           /* iterations ENQUEUED over all passes (fs_krylov_solve): those behind the one that stopped the
                              * recurrence return on the status word - launches - iterations of them, a few microseconds each */
+    int product_kind;       /* kernel family of the solve's products (fs_last_product_kind): 0 streaming, 1 row-dictionary work items
+                             * (also inside the one-launch iteration), 2 lattice tiles, 3 marching windows of a P1 box, 4 block rows */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,

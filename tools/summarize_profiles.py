@@ -30,7 +30,7 @@ OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, 
 PHASES = ("init", "n99_1M_dof", "n215_10M_dof", "n215_10M_dof_streaming")
 N_DOF = {"n99_1M_dof": 100 ** 3, "n215_10M_dof": 216 ** 3, "n215_10M_dof_streaming": 216 ** 3}
 MARKER = "k_profile_marker"
-HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
+HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_box_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
 
 def short(name):
@@ -174,7 +174,9 @@ def main():
             if key is not None:
                 out["update_" + size] = int(hbm(key))
             continue
-        key = first(ph, "k_dict_spmv<3,")          # row-dictionary form of the product (dictionary in LDS / class rows per work item)
+        # row-dictionary form of the product: the marching-window kernel of P1 boxes (round 6), else the work-item kernel
+        # (dictionary in LDS / class rows per work item)
+        key = first(ph, "k_box_spmv<3,", "k_dict_spmv<3,")
         if key is not None:
             out["spmv_dict_" + size] = int(hbm(key))
             out["spmv_dict_" + size + "_kernel"] = key[1]
