@@ -473,6 +473,8 @@ class SolverBase():
         distributed; 'amg_decomposition': 'schwarz' selects the rank-local hierarchies).  The pressure Laplacian of the
         Navier-Stokes Schur complement is treated the same way (fs_saddle.hip)."""
         from . import backend, parallel
+        if getattr(self, '_amg_distributed_off', False):
+            A_local = None                  # a distribution fault was seen on this solver earlier: replicated from then on
         cached = getattr(self, '_amg_cache', None)
         tag = 'replicated' if A_local is None else 'distributed'
         if key is not None and cached is not None and cached[0] == (tag, key):
@@ -499,12 +501,18 @@ class SolverBase():
             stats = hierarchy.solve(b, x, rtol=rtol, max_iter=max_iter, norm=norm)
             stats.update({'amg_' + k: v for k, v in hierarchy.info().items()})
             stats['amg_reused'], stats['amg_decomposition'] = reused, 'distributed'
-            if stats['converged'] != 1 and stats['converged'] >= 0:
-                # The distributed fine level has not run on more than one physical GPU yet: a solve that
-                # does not reach its tolerance - the status is the same on every rank, it comes from reduced sums - is repeated
-                # with the replicated hierarchy of round 3 (no communication inside the solve) instead of being reported.
-                self.logger.warning('solve_amg: %d iterations with the distributed fine level without convergence; solving again replicated',
-                                    stats['iterations'])
+            true_r, rec_r = stats.get('true_rel_residual', 0.0), stats.get('rel_residual', 0.0)
+            faulty = not np.isfinite(true_r) or true_r > 100.0 * max(rec_r, rtol)
+            if (stats['converged'] != 1 and stats['converged'] >= 0 and faulty) or (stats['converged'] == 1 and not np.isfinite(true_r)):
+                # The distributed fine level has not run on more than one physical GPU yet.  EVIDENCE of a
+                # distribution fault - the true residual b - A x far from the recurrence residual, or not a number (the status and
+                # both residuals are the same on every rank: they come from reduced sums) - sends this solve and every later one
+                # of this solver to the replicated hierarchy of round 3 (no communication inside the solve).  A solve that merely
+                # stops at the user's maximum_iterations with consistent residuals is REPORTED as it is (the silent
+                # second solve doubled the cost of a hard problem and hid it behind a warning).
+                self.logger.warning('solve_amg: distributed fine level: true residual %.3g against recurrence residual %.3g after %d '
+                                    'iterations; replicated hierarchy from now on', true_r, rec_r, stats['iterations'])
+                self._amg_distributed_off = True
                 hierarchy.close()
                 self._amg_cache = None
                 x.fill(0.0)

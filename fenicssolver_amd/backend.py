@@ -543,9 +543,11 @@ def _with_p2p_fallback(spaces, solve, x_guess=None):
     """Run a solve over space(s) whose ghost refresh is the peer-to-peer exchange.  A wait of that transport that times out (peer
     process gone, stores over the mappings not visible on this system) fails the solve with FS_ERR_P2P_TIMEOUT on the rank that
     saw it.  The ranks then compare notes over RCCL proper (never over the transport in doubt) on THAT code only, and if any of
-    them saw it all of them turn the exchange of the space(s) off and solve again over RCCL send / recv.  Any other failure - a
-    Krylov breakdown, a zero diagonal, a bad argument - is not the transport's: it is raised as it is (after the agreement, so that
-    the ranks stay paired), nothing is turned off and nothing is repeated.  One small RCCL all-gather per solve, only while the
+    them saw it ALL of them turn the exchange of the space(s) off and solve again over RCCL send / recv - also a rank whose own
+    solve failed with another code (stale ghosts produce a breakdown as easily as a time-out; a rank that raised here would leave
+    the others alone in the collectives of the second solve).  When NO rank timed out, any failure - a Krylov breakdown, a zero
+    diagonal, a bad argument - is not the transport's: it is raised as it is (after the agreement, so that the ranks stay
+    paired), nothing is turned off and nothing is repeated.  One small RCCL all-gather per solve, only while the
     exchange is on: a rank can finish its last wait while a neighbour times out on its own, so success on this rank says nothing
     about the others."""
     if not isinstance(spaces, (list, tuple)):
@@ -575,8 +577,13 @@ def _with_p2p_fallback(spaces, solve, x_guess=None):
                                                   "on this rank" if timed_out else "on another rank")
     for sp in live:
         sp.enable_p2p_halo(False)
+    # Once ANY rank timed out, every local error of this solve is taken as a consequence of it (a rank whose neighbour's stores never
+    # arrived consumes stale ghosts or garbage sums and may fail with a breakdown instead of the time-out code): ALL ranks solve
+    # again over RCCL, so that nobody is left alone in a collective.  A genuine non-transport failure shows again in the
+    # second solve, on every rank alike, and is raised there.
     if err is not None and not timed_out:
-        raise err
+        logging.getLogger("fenicssolver_amd").warning("this rank's solve failed with %r while another rank's exchange timed out: "
+                                                      "treated as a consequence, solving again", err)
     if keep is not None:
         x_guess.copy_from(keep)
     return solve()

@@ -81,6 +81,14 @@ void* fs_pool_alloc(size_t bytes);   // nullptr (error message set) when the dev
 void fs_pool_free(void* p);
 void fs_pool_trim(size_t keep_bytes);   // give cached blocks back to the driver until at most keep_bytes stay
 void fs_pool_stats(size_t* live_bytes, size_t* cached_bytes);
+// Small host <-> device copies go through ONE pinned staging buffer of the library (FS_STAGING_BYTES, allocated by fs_init's helper
+// thread): a hipMemcpy between device and PAGEABLE host memory above a few KB makes the runtime pin the host pages first - 9 ms
+// for the 56 KB list of a structure build (round 6, tools/probes/first_step_probe.py), every time the pages are new.
+// Returns FS_OK / FS_ERR_HIP; synchronises the stream.  Larger copies: the runtime's own path (pinning pays there).
+constexpr size_t FS_STAGING_BYTES = 1 << 20;
+int fs_staged_copy(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s);
+void* fs_staging_lock();             // the buffer itself (device-accessible host memory) for a kernel's small result; nullptr: none, not locked
+void fs_staging_unlock();
 
 // ---- device buffer -------------------------------------------------------------
 template <typename T>
@@ -100,17 +108,11 @@ struct dbuf {
         return FS_OK;
     }
     int upload(const T* host, int64_t count, hipStream_t s) {
-        if (count) {
-            FS_HIP(hipMemcpyAsync(p, host, (size_t)count * sizeof(T), hipMemcpyHostToDevice, s));
-            FS_HIP(hipStreamSynchronize(s));
-        }
+        if (count) return fs_staged_copy(p, host, (size_t)count * sizeof(T), true, s);
         return FS_OK;
     }
     int download(T* host, int64_t count, hipStream_t s) const {
-        if (count) {
-            FS_HIP(hipMemcpyAsync(host, p, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, s));
-            FS_HIP(hipStreamSynchronize(s));
-        }
+        if (count) return fs_staged_copy(host, p, (size_t)count * sizeof(T), false, s);
         return FS_OK;
     }
     void release() {

@@ -1,5 +1,7 @@
 // Runtime, vectors and meshes of libfsamd.so (gfx950).
 #include "fs_common.h"
+#include <thread>
+#include <vector>
 #include <chrono>
 #include <atomic>
 #include <mutex>
@@ -46,6 +48,64 @@ block_pool& pool() {
 }
 }  // namespace
 
+// ---- pinned staging buffer of the small copies (fs_common.h) ----
+namespace {
+std::mutex g_staging_mu;
+void* g_staging = nullptr;          // FS_STAGING_BYTES of pinned host memory, or nullptr (then the runtime's own path)
+bool g_staging_tried = false;
+void* staging_buffer() {            // (g_staging_mu held)
+    if (!g_staging_tried) {
+        g_staging_tried = true;
+        static const bool off = getenv("FS_STAGING") && getenv("FS_STAGING")[0] == '0';
+        if (!off && hipHostMalloc(&g_staging, FS_STAGING_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_staging = nullptr;
+        }
+    }
+    return g_staging;
+}
+}  // namespace
+// the staging buffer itself, for kernels that write a small result straight into host memory (it is device-accessible): locked
+// until fs_staging_unlock; nullptr (and not locked) when there is none
+void* fs_staging_lock() {
+    g_staging_mu.lock();
+    void* st = staging_buffer();
+    if (!st) g_staging_mu.unlock();
+    return st;
+}
+void fs_staging_unlock() { g_staging_mu.unlock(); }
+void fs_staging_prepare() {
+    std::lock_guard<std::mutex> lock(g_staging_mu);
+    (void)staging_buffer();
+}
+int fs_staged_copy(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
+    if (bytes == 0) return FS_OK;
+    static const bool trace = getenv("FS_COPY_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct report {
+        const std::chrono::steady_clock::time_point t0; size_t bytes; bool to_device, on;
+        ~report() { if (on) fprintf(stderr, "[fs copy] %s %zu bytes %.3f ms\n", to_device ? "H2D" : "D2H", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    } rep{t0, bytes, to_device, trace};
+    if (bytes <= FS_STAGING_BYTES) {
+        std::lock_guard<std::mutex> lock(g_staging_mu);
+        if (void* st = staging_buffer()) {
+            if (to_device) {
+                memcpy(st, src, bytes);
+                FS_HIP(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+                FS_HIP(hipStreamSynchronize(s));
+            } else {
+                FS_HIP(hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, s));
+                FS_HIP(hipStreamSynchronize(s));
+                memcpy(dst, st, bytes);
+            }
+            return FS_OK;
+        }
+    }
+    FS_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    return FS_OK;
+}
+
 void fs_pool_trim(size_t keep_bytes) {
     block_pool& P = pool();
     std::lock_guard<std::recursive_mutex> lock(P.mu);
@@ -61,6 +121,7 @@ void fs_pool_trim(size_t keep_bytes) {
 void* fs_pool_alloc(size_t bytes) {
     block_pool& P = pool();
     if (bytes == 0) return nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;       // (kernels that read whole 16-byte groups - k_box_spmv's loaders - may touch the bytes behind an odd count)
     std::lock_guard<std::recursive_mutex> lock(P.mu);
     // the smallest idle block that holds the request and wastes at most a quarter of itself (small blocks: half)
     auto it = P.idle.lower_bound(bytes);
@@ -164,6 +225,10 @@ extern "C" int fs_device_count(int* count) {
     return FS_OK;
 }
 
+__global__ void k_profile_marker(int phase, int* sink);
+
+void fs_staging_prepare();
+
 extern "C" int fs_init(int device_id) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -212,12 +277,72 @@ extern "C" int fs_init(int device_id) {
         };
         // (FS_INIT_TIMING=1, round 5, MI355X box: 40 ms the set-up object with its rocPRIM instantiations, 3 + 6 ms the other two - of
         // 170 - 310 ms of fs_init, the rest being the HIP runtime's own start: hipGetDeviceCount 117 ms, the stream 20 ms)
+        // The runtime's own first-use costs, taken HERE, next to the code objects, on a helper thread (they sit in other parts of the
+        // runtime than the module loader): the first hipGraph a process instantiates (9 - 13 ms of graph machinery: the second step of
+        // a time loop used to pay them, the first one ran graph-free to dodge them) and the first pageable host-to-device /
+        // device-to-host copies (staging buffers, 8 ms each: the first apply_dirichlet of a process).  FS_WARM=0: not done.
+        static const bool warm = !(getenv("FS_WARM") && getenv("FS_WARM")[0] == '0');
+        std::thread warm_thread;
+        if (warm) {
+            hipStream_t main_stream = rt.stream;
+            warm_thread = std::thread([device_id, main_stream] {
+                if (hipSetDevice(device_id) != hipSuccess) return;
+                fs_staging_prepare();
+                hipStream_t ws = nullptr;
+                if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+                void* d = nullptr;
+                std::vector<char> h(1 << 16, 1);
+                if (hipMalloc(&d, FS_STAGING_BYTES) == hipSuccess) {
+                    (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, ws);
+                    (void)hipMemcpyAsync(h.data(), d, h.size(), hipMemcpyDeviceToHost, ws);
+                    (void)hipStreamSynchronize(ws);
+                    // (copies above 64 KB take another path of the runtime with a first-use cost of its own: 7 ms for the first
+                    // 120 KB device-to-host copy of a process, pinned destination or not)
+                    void* st = nullptr;
+                    {
+                        std::lock_guard<std::mutex> lock(g_staging_mu);
+                        st = staging_buffer();
+                    }
+                    if (getenv("FS_INIT_TIMING")) fprintf(stderr, "[fs_init timing] helper: staging buffer %p\n", st);
+                    if (st) {
+                        // (on the library's OWN stream - nobody else uses it while fs_init runs -: the cost is per stream)
+                        (void)hipMemcpyAsync(d, st, 120000, hipMemcpyHostToDevice, main_stream);
+                        (void)hipStreamSynchronize(main_stream);
+                        const auto tw = std::chrono::steady_clock::now();
+                        const hipError_t e1 = hipMemcpyAsync(st, d, 120000, hipMemcpyDeviceToHost, main_stream);
+                        const hipError_t e2 = hipStreamSynchronize(main_stream);
+                        if (getenv("FS_INIT_TIMING")) fprintf(stderr, "[fs_init timing] helper: first 120000-byte D2H on the library's stream %.3f ms (%d %d)\n",
+                                                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count(), (int)e1, (int)e2);
+                        (void)hipMemcpyAsync(d, st, FS_STAGING_BYTES, hipMemcpyHostToDevice, main_stream);
+                        (void)hipMemcpyAsync(st, d, FS_STAGING_BYTES, hipMemcpyDeviceToHost, main_stream);
+                        (void)hipStreamSynchronize(main_stream);
+                    }
+                }
+                hipGraph_t g = nullptr;
+                hipGraphExec_t ge = nullptr;
+                if (hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    k_profile_marker<<<1, 64, 0, ws>>>(-1, nullptr);
+                    k_profile_marker<<<1, 64, 0, ws>>>(-2, nullptr);
+                    if (hipStreamEndCapture(ws, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+                        (void)hipGraphLaunch(ge, ws);
+                        (void)hipStreamSynchronize(ws);
+                    }
+                }
+                if (ge) (void)hipGraphExecDestroy(ge);
+                if (g) (void)hipGraphDestroy(g);
+                if (d) (void)hipFree(d);
+                (void)hipStreamDestroy(ws);
+                (void)hipGetLastError();
+            });
+        }
         fs_symbolic_preload();
         lap("set-up object (rocPRIM)");
         fs_assemble_preload();
         lap("assembly object");
         fs_krylov_preload();
         lap("Krylov object");
+        if (warm_thread.joinable()) warm_thread.join();
+        lap("first graph + first copies (helper thread)");
     }
     return FS_OK;
 }

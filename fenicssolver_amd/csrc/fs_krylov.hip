@@ -1077,6 +1077,8 @@ struct lat_tables {
     uint64_t space_serial = 0;
     int ncls = 0;
     bool ok = false;
+    bool judged = false;                // lat_prepare looked at a matrix since the flag was last cleared (fs_krylov_solve: a solve that never
+                                        // builds a dictionary - BiCGStab, no diagonal scaling - says nothing about the tile form)
     bool tables_ok = false;             // the lists were built and every row fits them: for dictionary tables number dict_built of that space
     int64_t dict_built = -1;
 };
@@ -2918,7 +2920,7 @@ static int g_spmv_blocks = 1024;
 static int g_spmv_unroll = 4;
 static bool g_spmv_blocks_pinned = false, g_spmv_unroll_pinned = false;
 static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
-// Scalar CG2 operators on uniform boxes solved in the lattice order of the half grid (fs_lattice.hip): OFF by default - measured on
+// Scalar CG2 operators on uniform boxes solved in the lattice order of the half grid (fs_lattice.hip): automatic from FS_LATTICE_MIN_ROWS rows on (option "lattice_order" = -1; 0 = never, 1 = wherever the order exists) - measured on
 // BASELINE configs[3] (9.94 M rows, tools/probes/p2_lattice_probe.py, round 5) the product takes 222 us with rounds of 8 runs, 272
 // with rounds of 12 (139 VGPRs, three waves per SIMD), 240 with the items regrouped by class, against 191 us in the space's own
 // numbering.  The rounds per work item do drop (3.4 -> 2.5 -> 1.5) but the time does not follow them: per row pair both orders
@@ -3104,8 +3106,10 @@ static int dict_map_xcd();
 // merges two rows into one segment whose plan then misses an entry - caught by the verification of every row in dict_build)
 // period, line (fs_space_s::dict_period / dict_line): the rows of a mesh line of `line` rows repeat their sets with that period - a
 // row is compared with the row `period` before it, and the first `period` rows of every line count as changes.
-__global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, uint8_t* __restrict__ chg,
-                             int period = 1, int64_t line = 0) {
+// (round 6: the rows that change are APPENDED to a list - count in list_n[0], the first `cap` of them stored, in any order - instead of
+// a flag per row: the flags were n bytes to the host and a host loop over them, 9 of the 17 ms of the first solve of a process at 1 M rows)
+__global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, int32_t* __restrict__ list,
+                             unsigned long long* __restrict__ list_n, int64_t cap, int period = 1, int64_t line = 0) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; r < n_rows; r += stride) {
@@ -3121,7 +3125,19 @@ __global__ void k_row_change(int64_t n_rows, const int32_t* __restrict__ rowptr,
             }
             h[w] = hh;
         }
-        chg[r] = r < period || h[0] != h[1] || (line > 0 && r % line < period);
+        const bool chg = r < period || h[0] != h[1] || (line > 0 && r % line < period);
+        // one atomic per wave: the lanes with a changing row take consecutive places behind the wave's first
+        const unsigned long long m = __ballot(chg);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(list_n, (unsigned long long)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (chg) {
+                const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)at < cap) list[at] = (int32_t)r;
+            }
+        }
     }
 }
 // offsets of the listed rows, concatenated (ptr = exclusive scan of their lengths)
@@ -3158,20 +3174,50 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         return FS_OK;
     };
     if (n < 2 || !sp->rowptr.p || !sp->colidx.p) return give_up("no pattern");
+    static const bool lap_on = getenv("FS_SOLVE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!lap_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fs_krylov timing]     structure: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+        lap_t = now;
+    };
     // 1. rows whose offset set differs from the previous row's
-    std::vector<uint8_t> chg((size_t)n);
-    {
-        dbuf<uint8_t> d_chg;
-        FS_CHECK(d_chg.alloc(n));
-        hipLaunchKernelGGL(k_row_change, dim3(fs_grid_for(n, FS_BLOCK, 8192)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, d_chg.p,
-                           sp->dict_period, sp->dict_line);
-        FS_KERNEL_CHECK();
-        FS_CHECK(d_chg.download(chg.data(), n, s));
-    }
     std::vector<int32_t> crow;
-    for (int64_t r = 0; r < n; ++r)
-        if (chg[(size_t)r]) crow.push_back((int32_t)r);
-    const int64_t nc = (int64_t)crow.size();
+    int64_t nc = 0;
+    {
+        // The list goes straight into the library's pinned staging buffer when it fits (the kernel stores into host memory; the
+        // count stays on the device - one returning atomic per wave over the bus would cost more than the whole pass): the first
+        // device-to-host copy out of the freshly allocated list buffer took 7 - 9 ms of the first solve of a process (round 6,
+        // tools/probes/first_step_probe.py with FS_COPY_TRACE=1; the same copy a second time: 0.04 ms).
+        dbuf<unsigned long long> d_cnt;
+        FS_CHECK(d_cnt.alloc(1));
+        for (int pass = 0; pass < 2; ++pass) {
+            const int64_t cap_host = (int64_t)(FS_STAGING_BYTES / sizeof(int32_t));
+            void* st = pass == 0 ? fs_staging_lock() : nullptr;
+            struct unlock { void* st; ~unlock() { if (st) fs_staging_unlock(); } } guard{st};
+            dbuf<int32_t> d_list;
+            const int64_t cap = st ? cap_host : n / 2 + 1;
+            if (!st) FS_CHECK(d_list.alloc(cap));
+            FS_CHECK(d_cnt.zero(s));
+            // (the grid covers the rows once - whole waves, the ballot above needs every lane of a wave in the loop together)
+            hipLaunchKernelGGL(k_row_change, dim3(fs_grid_for(n, FS_BLOCK, 65535)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p,
+                               st ? reinterpret_cast<int32_t*>(st) : d_list.p, d_cnt.p, cap, sp->dict_period, sp->dict_line);
+            FS_KERNEL_CHECK();
+            unsigned long long h_cnt = 0;
+            FS_HIP(hipMemcpyAsync(&h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+            FS_HIP(hipStreamSynchronize(s));
+            nc = (int64_t)h_cnt;
+            if (nc * 2 > n) break;                   // an unstructured mesh: given up below
+            if (nc > cap) continue;                  // more rows than the staging buffer holds: once more, into a device list
+            crow.resize((size_t)nc);
+            if (st) memcpy(crow.data(), st, (size_t)nc * sizeof(int32_t));
+            else FS_CHECK(d_list.download(crow.data(), nc, s));
+            std::sort(crow.begin(), crow.end());
+            break;
+        }
+    }
+    lap("changing rows");
     if (nc * 2 > n) return give_up("rows change their offset set too often");     // (an unstructured mesh)
     // 2. ... and their offset lists
     std::vector<int32_t> clen((size_t)nc), coff;
@@ -3193,6 +3239,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         FS_KERNEL_CHECK();
         FS_CHECK(d_off.download(coff.data(), cptr[(size_t)nc], s));
     }
+    lap("their offset lists");
     // 3. segments: a row joins while its set is nested with the segment's list (which grows to the larger one)
     struct segment { int32_t first, end, list; };      // list = index of the change row whose offsets are the segment's list
     std::vector<segment> segs;
@@ -3271,6 +3318,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         if (n_long * 20 < n_runs3) RL = 2;
         static const char* rl_env = getenv("FS_DICT_RUN_LENGTH");
         if (rl_env && (rl_env[0] == '2' || rl_env[0] == '3')) RL = rl_env[0] - '0';
+        if (NR == 12) RL = 3;       // (the only instantiation of the work-item product for rounds of twelve runs is k_dict_spmv<.., 3, 12>: ADVICE r5)
     }
     std::vector<dict_plan_round> rounds;
     struct plan_info { int32_t first, rounds, min_start, max_start; };
@@ -3387,6 +3435,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         if (rc == FS_OK && !flat.empty()) rc = dst.upload(flat.data(), (int64_t)flat.size(), s);
         return rc;
     };
+    lap("segments, plans, items");
     const int64_t plan_ints = (int64_t)rounds.size() * 16;
     if (need_space) {
         // (the plans depend on the pattern only: a later build for new halo lists finds the same array in place)
@@ -3408,6 +3457,7 @@ static int dict_structure_build(fs_space_s* sp, hipStream_t s) {
         FS_CHECK(upload_items(h.items_boundary, h.n_items_boundary, 1));
     }
     FS_HIP(hipStreamSynchronize(s));
+    lap("uploads");
     if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
         fprintf(stderr, "[fs_krylov] row-dictionary work items: %lld for the space (%.1f rows each), interior %lld, boundary %lld; %d coefficient positions per class row\n",
                 (long long)sp->n_dict_items, sp->n_dict_items ? (double)n / sp->n_dict_items : 0.0, (long long)h.n_items_interior,
@@ -3433,7 +3483,17 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
     // on the AMG-PCG solve of the cantilever: 91 k DOF 6.5 -> 9.5 ms, 683 k DOF 14.0 -> 12.4 ms, 5.1 M DOF 100 -> 61 ms)
     static const int64_t min_nodes3 = getenv("FS_DICT3_MIN_NODES") ? atoll(getenv("FS_DICT3_MIN_NODES")) : 150000;      // (tests lower it)
     if (A->bs == 3 && sp->n_nodes_owned < min_nodes3) return FS_OK;
+    static const bool lap_on = getenv("FS_SOLVE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!lap_on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fs_krylov timing]   dictionary: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+        lap_t = now;
+    };
     FS_CHECK(dict_structure_build(sp, s));
+    lap("structure");
     if (sp->n_dict_items <= 0) return FS_OK;
     const int nq = A->bs * A->bs;               // values per stored entry (3 x 3 blocks of a vector space: the class rows are [position][9])
     const int S = sp->dict_slots * nq;
@@ -3491,7 +3551,9 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
         }
     }
     D.tables_space = 0;
+    lap("tables allocated");
     materialize();                  // the classes are found from the scaled values themselves
+    lap("scaled copy");
     FS_CHECK(D.keys.zero(s));
     FS_CHECK(D.info.zero(s));
     FS_HIP(hipMemsetAsync(D.slot_vals.p, 0, (size_t)FS_DICT_CAP * S * sizeof(double), s));
@@ -3503,6 +3565,7 @@ static int dict_build_impl(fs_matrix_s* A, const double* val, hipStream_t s, con
     FS_KERNEL_CHECK();
     int h[4] = {0, 0, 0, 0};
     FS_CHECK(D.info.download(h, 4, s));
+    lap("classes found + verified");
     const bool ok = usable(h, h[0]);
     if (getenv("FS_KRYLOV_DEBUG"))
         fprintf(stderr, "[fs_krylov] row dictionary: %d distinct rows of %d positions among %lld, %d mismatches, at most %d classes per item -> %s\n", h[0], S,
@@ -3582,6 +3645,7 @@ static lat_geom lat_geometry(int64_t SX, int64_t NY, int64_t NZ) {
 static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     fs_space_s* sp = A->space;
     g_lat.ok = false;
+    g_lat.judged = true;
     g_lat.built_for = nullptr;
     static const bool off = getenv("FS_LATTICE_TILES") && getenv("FS_LATTICE_TILES")[0] == '0';
     if (off || sp->lat_ny <= 0 || A->bs != 1 || g_dict.built_for != val || g_dict.bs != 1 || g_dict.space_serial != sp->serial || sp->n_dict_items <= 0) return FS_OK;
@@ -4373,10 +4437,21 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
             fs_matrix_s* A2 = nullptr;
             fs_vector_s *b2 = nullptr, *x2 = nullptr;
             FS_CHECK(fs_lattice_enter(L, A, b, x, opts->nonzero_guess != 0, &A2, &b2, &x2));
+            // (the shadow matrix has ONE serial and holds another operator's values on every call: the dictionary's marker `these rows
+            // do not repeat`, keyed on the serial, must not outlive the matrix it was set for - ADVICE r5)
+            if (g_dict.gave_up_on == A2->serial) g_dict.gave_up_on = 0;
+            g_lat.ok = false;           // (decided by THIS solve: a flag left by an earlier solve on another space says nothing)
+            g_lat.judged = false;
             FS_CHECK(fs_krylov_solve(A2, b2, x2, opts, stats));
             FS_CHECK(fs_lattice_leave(L, sp, x));
-            if (g_lattice < 0 && !(g_lat.ok && g_lat.space_serial == A2->space->serial)) sp->lattice_state = -1;
             FS_HIP(hipStreamSynchronize(s));
+            if (g_lattice < 0 && g_lat.judged && !(g_lat.ok && g_lat.space_serial == A2->space->serial)) {
+                // the shadow's rows do not fit the tile form: the space's own numbering from now on, and the shadow (a second copy of
+                // the operator's structure and values: several GB at configs[3]) is given back
+                sp->lattice_state = -1;
+                fs_lattice_release(sp->lattice);
+                sp->lattice = nullptr;
+            }
             if (stats) {
                 stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 stats->lattice_order = 1;
@@ -4702,7 +4777,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         // The FIRST graph a process instantiates costs 9 ms (the runtime's graph machinery; later ones 0.1 ms), twelve times what the
         // graphs save a 300-iteration solve at 1 M rows: the first solve of a process launches its iterations one by one - a
         // one-shot run never pays, a time loop pays in its second step (tools/probes/first_step_probe.py; FS_CG_GRAPH=1 forces graphs)
-        static bool first_solve_done = false;
+        // (round 6: fs_init instantiates a two-node graph on a helper thread while the code objects load - the machinery is paid for
+        // there, and the first solve of a process goes out in graphs like every other; FS_WARM=0 restores the old rule)
+        static bool first_solve_done = !(getenv("FS_WARM") && getenv("FS_WARM")[0] == '0');
         const bool graphs_allowed = first_solve_done || graph_mode > 0;
         struct mark_done { bool& f; ~mark_done() { f = true; } } mark_first_solve{first_solve_done};
         const bool fusedp = fusedp_ok && p2p_fuse && !bicg;

@@ -258,6 +258,7 @@ int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out) {
         fs_set_error("fs_lattice: internal error, %d stored entries have no place in the lattice-ordered pattern", h_cnt[1]);
         return fail(FS_ERR_INVALID);
     }
+    L->emap.release();          // (read by k_lattice_invert_map only, which the download above has waited for: sell_entries int32s)
     L->n = n_sh;
     if (getenv("FS_KRYLOV_DEBUG") || getenv("FS_SPACE_DEBUG"))
         fprintf(stderr, "[fs_lattice] space %llu: %lld CG2 nodes on the half grid %lld x %lld x %lld (+ %lld dummy rows), %lld stored entries (space: %lld)\n",

@@ -41,7 +41,11 @@ def test_default_command_prints_the_contract_line(gpu):
     # the first step of the process is reported by itself, the cold figure includes fs_init
     assert d["first_step_ms"] > d["ms_per_step"] and d["cold_one_shot_dof_per_s"] < d["one_shot_dof_per_s"] and d["init_ms"] > 0
     # the BASELINE operator has repeated rows: the line says so and carries the streaming kernel's roofline beside it
-    assert "k_dict_spmv" in r["kernel"] and "note_row_dictionary" in r
+    assert ("k_box_spmv" in r["kernel"] or "k_dict_spmv" in r["kernel"]) and "note_row_dictionary" in r
+    # ... and the same kernels where the Infinity Cache cannot help (85.8 M rows), beside the 10 M-row fractions
+    cf = r["cache_free_case"]
+    assert "error" not in cf, cf
+    assert cf["required_bytes_per_launch"] == 26 * 441 ** 3 and 0.3 <= cf["frac"] <= 1.0 and 0.3 <= cf["iteration"]["frac"] <= 1.0
     s = r["streaming_kernel"]
     assert "k_dia_pair_spmv" in s["kernel"] and 0.5 <= s["frac"] <= 1.0 and s["cg_iterations"] == r["cg_iterations"] == 451
     # the step workload itself (1 M rows, cache-resident): ONE launch per CG iteration, priced on the 90 B/row that launch moves

@@ -759,3 +759,50 @@ def test_one_launch_iteration_kernel_keeps_four_waves_per_simd(tmp_path):
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
         assert occ >= 4 and vgprs <= 128 and spill == 0, (vgprs, spill, occ)
     assert seen >= 1
+
+
+def test_p2p_fallback_keeps_the_ranks_paired(monkeypatch):
+    """once ANY rank reports the time-out of the peer-to-peer exchange every rank solves again over RCCL - also a rank
+    whose own solve failed with a different error (stale ghosts make a breakdown as easily as a time-out); a failure nobody's
+    transport caused is raised as it is, nothing switched off, nothing repeated."""
+    from fenicssolver_amd import backend as B, _lib as L
+
+    class Space:
+        _p2p = True
+        off = 0
+
+        def enable_p2p_halo(self, on):
+            self.off += not on
+
+    def err(rc):
+        e = L.BackendError("x")
+        e.rc = rc
+        return e
+
+    monkeypatch.setattr(B, "_comm_up", True)
+    # this rank: breakdown; another rank: time-out -> switched off, solved again, no exception
+    monkeypatch.setattr(B, "comm_allgather", lambda v, n: [v[0], 1.0])
+    sp, calls = Space(), []
+
+    def solve_a():
+        calls.append(1)
+        if len(calls) == 1:
+            raise err(L.FS_ERR_NUMERIC)
+    B._with_p2p_fallback(sp, solve_a)
+    assert len(calls) == 2 and sp.off == 1
+    # nobody timed out: the local error is raised, nothing repeated
+    monkeypatch.setattr(B, "comm_allgather", lambda v, n: [v[0], 0.0])
+    sp, calls = Space(), []
+
+    def solve_b():
+        calls.append(1)
+        raise err(L.FS_ERR_NUMERIC)
+    with pytest.raises(L.BackendError):
+        B._with_p2p_fallback(sp, solve_b)
+    assert len(calls) == 1 and sp.off == 0
+    # a failure that is not the transport's shows again in the second solve and is raised there
+    monkeypatch.setattr(B, "comm_allgather", lambda v, n: [v[0], 1.0])
+    sp, calls = Space(), []
+    with pytest.raises(L.BackendError):
+        B._with_p2p_fallback(sp, solve_b)
+    assert len(calls) == 2 and sp.off == 1
