@@ -112,10 +112,29 @@ class ScalarTransportSolver(SolverBase):
         elif self.scalar_name in self._COEFFICIENT_RULES[kind]:
             c = self._COEFFICIENT_RULES[kind][self.scalar_name](m, self)
         elif kind == 'conductivity':
+            # conductivity = diffusivity * capacity (ScalarTransportSolver.py:119-121).  Either factor may be a python function of
+            # T (:88-91, :106-109): the product then is one - the reference calls both factors WITHOUT the field here and fails on a
+            # function that uses its argument; evaluated at the current field instead
+            from inspect import isfunction
+            d_raw, c_raw = self._raw_coefficient('diffusivity'), self._raw_coefficient('capacity')
+            if isfunction(d_raw) or isfunction(c_raw):
+                d_fn = d_raw if isfunction(d_raw) else (lambda Tv, v=self.get_material_value(d_raw): v)
+                c_fn = c_raw if isfunction(c_raw) else (lambda Tv, v=self.get_material_value(c_raw): v)
+                self._derived_conductivity_fn = lambda Tv: d_fn(Tv) * c_fn(Tv)
+                return self._finish_material(self._derived_conductivity_fn, T)
             c = self.diffusivity() * self.capacity()
         else:
             raise SolverError('material {} property is not found for {}'.format(kind, self.scalar_name))
         return self._finish_material(c, T)
+
+    def _raw_coefficient(self, kind):
+        """The material entry a coefficient comes from, before any evaluation (a number, a Constant, a field, a function of T)."""
+        m = self.material
+        if kind in m:
+            return m[kind]
+        if self.scalar_name in self._COEFFICIENT_RULES[kind]:
+            return self._COEFFICIENT_RULES[kind][self.scalar_name](m, self)
+        raise SolverError('material {} property is not found for {}'.format(kind, self.scalar_name))
 
     def capacity(self, T=None):
         return self._coefficient('capacity', T)
@@ -248,7 +267,9 @@ class ScalarTransportSolver(SolverBase):
     # ------------------------------------------------------------------ boundary conditions
     def update_boundary_conditions(self, time_iter_, T, Tq, ds):
         """-> (Dirichlet bcs, list of FacetLoad / FacetRobin)  (ScalarTransportSolver.py:142-211)"""
-        capacity = self.capacity(T)
+        # (a capacity that is a python function of T is evaluated on the current field - generate_form leaves it in _material_field; the
+        # boundary terms that scale with the capacity, Neumann / Robin gradients, then refuse it: _scalar_capacity)
+        capacity = self.capacity(T if isinstance(T, Function) else getattr(self, '_material_field', None))
         bcs = []
         integrals_N = []
         self._point_sources = []
@@ -363,8 +384,14 @@ class ScalarTransportSolver(SolverBase):
         kraw = self.material.get('conductivity', self.material.get('thermal_conductivity'))
         if isfunction(kraw):
             F.conductivity_fn = kraw
-        if self.nonlinear_material and F.conductivity_fn is None:
-            raise SolverError('only the conductivity may depend on the temperature on the GPU back end')
+        elif getattr(self, '_derived_conductivity_fn', None) is not None and 'conductivity' not in self.material and \
+                self.scalar_name not in self._COEFFICIENT_RULES['conductivity']:
+            F.conductivity_fn = self._derived_conductivity_fn      # diffusivity(T) * capacity(T)
+        # a capacity that depends on T (a python function, ScalarTransportSolver.py:88-91): the transient term
+        # (1/dt) (T - T_prev) c(T) q dx is re-evaluated at every Newton iterate, cell by cell at the mean of the vertex values, like k(T)
+        craw = self.material.get('capacity')
+        if isfunction(craw):
+            F.capacity_fn = craw
 
         if self.transient_settings['transient']:
             F.transient = True
@@ -382,6 +409,7 @@ class ScalarTransportSolver(SolverBase):
             F.advection = (velocity, self._scalar_capacity(self._volume_coefficient(capacity, 'capacity')))
             F.symmetric = False
 
+        self._material_field = T_current
         bcs, integrals_N = self.update_boundary_conditions(time_iter_, T, T_test, Measure("ds", subdomain_data=self.boundary_facets))
         for item in integrals_N:
             (F.robin if isinstance(item, forms.FacetRobin) else F.facet_loads).append(item)
@@ -420,6 +448,7 @@ class ScalarTransportSolver(SolverBase):
 
     def refresh_nonlinear_form(self, F, T):
         """Re-evaluate the temperature-dependent coefficients of F at the Newton iterate T."""
+        self._refresh_capacity(F, T)
         if F.conductivity_fn is not None and self.function_space.degree() == 2:
             # P2 iterate: k(T_h) at the 14 points of the degree-5 rule, where the integrand k grad T . grad q is evaluated
             # (exact for a conductivity that is linear in T, e.g. examples/test_heat_transfer.py:53)
@@ -440,6 +469,12 @@ class ScalarTransportSolver(SolverBase):
             Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)
             F.conductivity = forms.VolumeCoefficient(
                 "cell", np.broadcast_to(np.asarray(F.conductivity_fn(Tbar), dtype=np.float64), Tbar.shape).copy())
+
+    def _refresh_capacity(self, F, T):
+        if getattr(F, 'capacity_fn', None) is not None and F.transient:
+            Tbar = T.vertex_values()[self.mesh.cells().astype(np.int64)].mean(axis=1)
+            F.capacity = forms.VolumeCoefficient(
+                "cell", np.broadcast_to(np.asarray(F.capacity_fn(Tbar), dtype=np.float64), Tbar.shape).copy())
 
     def solve_form(self, F, T_current, bcs):
         if self.nonlinear:

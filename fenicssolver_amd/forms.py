@@ -98,6 +98,7 @@ class ScalarForm:
         # (ScalarTransportSolver.py:338-350, 361-376) and material callables re-evaluated every iteration
         self.radiation = None         # (m, T_ambient)
         self.conductivity_fn = None   # callable(T array) -> k
+        self.capacity_fn = None       # callable(T array) -> volumetric capacity (transient term; re-evaluated per Newton iterate)
         self.nonlinear = False
 
     def describe(self):
