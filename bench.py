@@ -510,6 +510,37 @@ def th_leg(n, n_steps, rank, world):
     w = solver.solve()
     parallel.barrier()
     t2 = parallel.max_over_ranks(time.perf_counter() - t1)
+    # the dominant kernel of the configuration - the 4 x 4-block product of the FGMRES iterations, k_sell_spmv4_ksplit - timed on the
+    # Jacobian of the last Newton step (fs_spmv_benchmark: HIP events around back-to-back launches on the library's stream), against
+    # the bytes its storage form has to move: the LIVE value planes (a pressure column / row exists for vertex nodes only: 16 values
+    # of a vertex-vertex block, 12 of vertex-edge and edge-vertex, 9 of edge-edge), 4 B of column index per block, x read and
+    # y written (4 doubles per node each)
+    spmv4 = None
+    try:
+        ctx = getattr(solver, '_ns_ctx', None)
+        if world == 1 and ctx is not None:
+            J = ctx['J']
+            Vd = J.space
+            xb, yb = B.DeviceVector(Vd.n_local * 4), B.DeviceVector(Vd.n_owned * 4)
+            xb.fill(1.0)
+            ms4 = J.spmv_benchmark(xb, yb, reps=30)
+            fsp = solver.function_space
+            cn = (fsp.cell_nodes() if hasattr(fsp, 'cell_nodes') else fsp.velocity_space().cell_nodes()).astype(np.int64)
+            if cn.shape[1] != 10:
+                cn = None
+            live = None
+            if cn is not None:
+                nn = int(cn.max()) + 1
+                nvx = mesh.num_vertices()
+                keys = np.unique((cn[:, :, None] * nn + cn[:, None, :]).ravel())
+                rv, cv = (keys // nn) < nvx, (keys % nn) < nvx
+                n_vv, n_ve, n_ev, n_ee = int((rv & cv).sum()), int((rv & ~cv).sum()), int((~rv & cv).sum()), int((~rv & ~cv).sum())
+                live = 8 * (16 * n_vv + 12 * (n_ve + n_ev) + 9 * n_ee) + 4 * len(keys) + 64 * nn
+            spmv4 = {"kernel": "k_sell_spmv4_ksplit<true,true> (4 x 4-block Taylor-Hood product: the entries of a slice dealt to the four waves)",
+                     "avg_launch_ms": round(ms4, 5), "required_bytes_per_launch": live,
+                     "stored_bytes": int(Vd.spmv_matrix_bytes)}
+    except Exception as e:          # (the measurement must not cost the line)
+        spmv4 = {"error": repr(e)[:200]}
     W4 = w.vector().array().reshape(-1, 4)
     nv = mesh.num_vertices()
     n_local_nodes = len(W4)
@@ -526,7 +557,7 @@ def th_leg(n, n_steps, rank, world):
             "dof_per_s": round(n_dof * solver.current_step / t2, 1), "setup_s": round(t1 - t0, 2),
             "newton_residuals_last_step": [float(v) for v in solver.newton_history],
             "krylov_iterations_last_step": int(solver.newton_krylov_iterations),
-            "max_speed": speed, "pressure_range": [p_lo, p_hi], "host_nodes_rank0": n_local_nodes}
+            "max_speed": speed, "pressure_range": [p_lo, p_hi], "host_nodes_rank0": n_local_nodes, "spmv4": spmv4}
 
 
 class Watchdog:
@@ -657,6 +688,24 @@ def committed_traffic(tag):
     return (v, "profiles/" + name) if v is not None else (None, None)
 
 
+def committed_kernel_traffic(case, prefixes):
+    """HBM bytes per launch of a side workload's product kernel from THIS round's committed counter passes
+    (profiles/<round>_<case>_pmc_raw.json, tools/pmc_average.py: mean FETCH_SIZE / WRITE_SIZE in KiB over all launches of the traced
+    run, the no-op launches behind convergence included): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 - the read side doubled by the gfx950
+    rule the default command's calibration confirms."""
+    name = "%s_%s_pmc_raw.json" % (PROFILE_ROUND, case)
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    for pre in prefixes:
+        for kname, v in d.items():
+            if kname.startswith(pre) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                return int((2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024), "profiles/" + name
+    return None, None
+
+
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["required_GBps"] / HBM_PEAK_GBS
     what = " (product fused with the 3 dot products of the diagonally scaled CG)" if "k_box_spmv" in k["kernel"] else (
@@ -715,7 +764,10 @@ def main():
                        parity={"max_abs_error_vs_exact_profile": r["max_abs_error_vs_exact_profile"]})
             k = r["spmv"]
             hbm = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * k["rows_rank0"] > (256 << 20)
-            out["roofline"] = dict(make_roofline(k, "rank 0's part of the step workload", None, None),
+            traffic, src = (None, None)
+            if world == 1 and a.mesh == "structured" and n == 107:
+                traffic, src = committed_kernel_traffic("p2", ("k_lattice_spmv<3", "k_dict_spmv<3"))
+            out["roofline"] = dict(make_roofline(k, "rank 0's part of the step workload", traffic, src),
                                    update_kernel=r["update"], iteration=r["iteration"])
             out["roofline"]["kernel"] = k["kernel"] + " (product of the CG2 operator fused with the 3 CG dot products)"
             if not hbm:
@@ -734,6 +786,19 @@ def main():
                        detail={k: r[k] for k in ("newton_residuals_last_step", "krylov_iterations_last_step", "max_speed", "pressure_range", "setup_s")},
                        roofline={"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                  "note": "kernel rates of this configuration: profiles/*_ns_kernel_stats.csv (rocprofv3 of tools/prof_ns.sh)"})
+            k4 = r.get("spmv4") or {}
+            if k4.get("required_bytes_per_launch") and k4.get("avg_launch_ms", 0) > 0:
+                gbps = k4["required_bytes_per_launch"] / k4["avg_launch_ms"] / 1e6
+                out["roofline"].update(kernel=k4["kernel"], achieved=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBS, 3),
+                                       avg_launch_ms=k4["avg_launch_ms"], required_bytes_per_launch=k4["required_bytes_per_launch"],
+                                       stored_bytes=k4["stored_bytes"],
+                                       required_bytes_model="live value planes of the 4 x 4 blocks (16 / 12 / 9 of 16 by node kinds) + 4 B of column "
+                                                            "index per block + 64 B per node (x read, y written)",
+                                       note="the dominant kernel of the FGMRES iterations timed by fs_spmv_benchmark (HIP events, 30 back-to-back "
+                                            "launches on the Jacobian of the last Newton step) after the timed steps; shares of the other kernels: "
+                                            "profiles/*_ns_kernel_stats.csv")
+            elif k4:
+                out["roofline"]["spmv4"] = k4
             print(json.dumps(out))
         parallel.barrier()
         parallel.finalize()
