@@ -71,22 +71,51 @@ __global__ void k_lattice_dummy_lengths(int64_t n_sh, int32_t* __restrict__ len,
     if (c) atomicAdd(n_dummy, c);
 }
 
-// the permuted columns of every row, ascending (insertion sort in place: a row has at most 65 entries); dummy rows: their diagonal
-__global__ void k_lattice_fill_rows(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const int32_t* __restrict__ perm,
-                                    const int32_t* __restrict__ rowptr_sh, int32_t* __restrict__ col_sh, uint8_t* __restrict__ written) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// the permuted columns of every row, ascending; dummy rows: their diagonal.
+// A WAVE per row (round 6; the first form - a thread per row, insertion sort in place in global memory, up to 65 x 65 / 4 dependent
+// read-modify-writes - took 56 ms in one launch at configs[3], 0.6 of a steady step): a lane takes up to two of the row's entries,
+// the wave's entries sit in LDS, and an entry's place is the number of entries smaller than it (the columns of a row are distinct:
+// perm is a bijection).  Rows of more than 128 entries (none on a tetrahedral CG2 space) are sorted by one lane as before.
+__global__ void __launch_bounds__(FS_BLOCK) k_lattice_fill_rows(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ rowptr_sh,
+                                                               int32_t* __restrict__ col_sh, uint8_t* __restrict__ written) {
+    __shared__ int32_t buf[FS_BLOCK / 64][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (; r < n_rows; r += stride) {
         const int32_t p = perm[r];
         int32_t* __restrict__ o = col_sh + rowptr_sh[p];
         const int32_t s0 = rowptr[r], w = rowptr[r + 1] - s0;
-        for (int k = 0; k < w; ++k) {
-            const int32_t c = perm[colidx[s0 + k]];
-            int j = k;
-            while (j > 0 && o[j - 1] > c) { o[j] = o[j - 1]; --j; }
-            o[j] = c;
+        if (w > 128) {
+            if (lane == 0) {
+                for (int k = 0; k < w; ++k) {
+                    const int32_t c = perm[colidx[s0 + k]];
+                    int j = k;
+                    while (j > 0 && o[j - 1] > c) { o[j] = o[j - 1]; --j; }
+                    o[j] = c;
+                }
+                written[p] = 1;
+            }
+            continue;
         }
-        written[p] = 1;
+        const int32_t c0 = lane < w ? perm[colidx[s0 + lane]] : 0x7fffffff;
+        const int32_t c1 = lane + 64 < w ? perm[colidx[s0 + 64 + lane]] : 0x7fffffff;
+        buf[wave][lane] = c0;
+        buf[wave][64 + lane] = c1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int k0 = 0, k1 = 0;
+        for (int k = 0; k < w; ++k) {
+            const int32_t v = buf[wave][k];         // (the same address in every lane: a broadcast)
+            k0 += v < c0;
+            k1 += v < c1;
+        }
+        if (lane < w) o[k0] = c0;
+        if (lane + 64 < w) o[k1] = c1;
+        if (lane == 0) written[p] = 1;
+        __builtin_amdgcn_wave_barrier();            // (the next row's entries overwrite these)
     }
 }
 __global__ void k_lattice_fill_dummies(int64_t n_sh, const int32_t* __restrict__ rowptr_sh, const uint8_t* __restrict__ written, int32_t* __restrict__ col_sh) {
@@ -232,7 +261,7 @@ int fs_lattice_get(fs_space_s* sp, fs_lattice_shadow** out) {
     }
     sh->nnz_nodes = h_nnz;
     if ((rc = sh->colidx.alloc(h_nnz)) != FS_OK) return fail(rc);
-    hipLaunchKernelGGL(k_lattice_fill_rows, dim3(fs_grid_for(n, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, L->perm.p, sh->rowptr.p, sh->colidx.p, written.p);
+    hipLaunchKernelGGL(k_lattice_fill_rows, dim3(fs_grid_for(n * 64, FS_BLOCK, 16384)), dim3(FS_BLOCK), 0, s, n, sp->rowptr.p, sp->colidx.p, L->perm.p, sh->rowptr.p, sh->colidx.p, written.p);
     hipLaunchKernelGGL(k_lattice_fill_dummies, dim3(fs_grid_for(n_sh)), dim3(FS_BLOCK), 0, s, n_sh, sh->rowptr.p, written.p, sh->colidx.p);
     if (hipGetLastError() != hipSuccess) return fail(FS_ERR_HIP);
     if ((rc = fs_space_build_storage(sh, s)) != FS_OK) return fail(rc);
