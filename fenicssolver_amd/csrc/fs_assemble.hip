@@ -65,6 +65,8 @@ __device__ __forceinline__ tet_geom tet_geometry_snapped(const double (&x0)[3], 
 __device__ __forceinline__ tet_geom tet_geometry_box(const double* __restrict__ xyz4, const int32_t (&v)[4], const box_snap& bx);
 static int g_box_snap = -1;          // -1: not set (environment FS_BOX_SNAP, default on)
 void fs_set_box_snap(bool on) { g_box_snap = on; }
+static int g_box_assembly = -1;      // -1: not set (environment FS_BOX_ASSEMBLY, default on): option "box_assembly"
+void fs_set_box_assembly(bool on) { g_box_assembly = on; }
 static box_snap make_box_snap(const fs_mesh_s* m) {
     static const bool env_off = getenv("FS_BOX_SNAP") && getenv("FS_BOX_SNAP")[0] == '0';
     const bool off = g_box_snap < 0 ? env_off : g_box_snap == 0;
@@ -363,6 +365,111 @@ __global__ void __launch_bounds__(FS_BLOCK) __attribute__((amdgpu_waves_per_eu(3
         if (APPLY) {
             if (s * FS_SLICE + lane < n_rows) val[s * FS_SLICE + lane] = yacc;
             continue;
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
+    }
+}
+
+// ---- scalar P1 on a BOX mesh: the row-gather assembly without the geometry (round 6) ------------------------------------------------
+// k_assemble_p1_scalar_gather recomputes a tetrahedron's four gradients for every (row, cell) incidence - 24 x about 170 vector
+// instructions, three coordinate gathers and a cell record per incidence: 2.26 ms at 10 M rows, 0.13 of the HBM peak on its 240 B/row,
+// counter traffic 2.8 x the required bytes.  On a mesh made by fs_mesh_create_box the SNAPPED edge vectors of a cell
+// are a function of its TYPE alone (cell c of a hexahedron is type c % 6: k_box_cells) and so are |det J| and the products g_a . g_b:
+// 6 types x 4 row vertices x (|det J|, four products) - 120 doubles, computed once per mesh by k_box_ref_rows with the very calls and
+// expressions of the general kernel (same rotation of the row's vertex to local index 0, same tet_geometry_snapped, same sum), hence
+// the same bits (tests/test_gpu_kernels.py::test_box_assembly_fast_path_bits compares every stored value).  Per incidence: the record
+// (cell, positions: 8 B), the type's five numbers from LDS, the coefficient, four products.  Constant or per-cell scalar stiffness
+// and mass coefficients; everything else (tensor conductivities, advection, SUPG, the matrix-free apply) stays with the general kernel.
+__global__ void k_box_ref_rows(const int32_t* __restrict__ cells, const double* __restrict__ xyz4, const box_snap bx, double* __restrict__ ref) {
+    const int i = threadIdx.x;
+    if (i >= 24) return;
+    const int ty = i >> 2, a = i & 3;
+    const int4 v4 = reinterpret_cast<const int4*>(cells)[ty];
+    int32_t vv[4];
+    vv[0] = a == 0 ? v4.x : a == 1 ? v4.y : a == 2 ? v4.z : v4.w;
+    vv[1] = a == 0 ? v4.y : a == 1 ? v4.z : a == 2 ? v4.w : v4.x;
+    vv[2] = a == 0 ? v4.z : a == 1 ? v4.w : a == 2 ? v4.x : v4.y;
+    vv[3] = a == 0 ? v4.w : a == 1 ? v4.x : a == 2 ? v4.y : v4.z;
+    double x0[3], x1[3], x2[3], x3[3];
+    load_vertex(xyz4, vv[0], x0);
+    load_vertex(xyz4, vv[1], x1);
+    load_vertex(xyz4, vv[2], x2);
+    load_vertex(xyz4, vv[3], x3);
+    const tet_geom t = tet_geometry_snapped(x0, x1, x2, x3, bx);
+    ref[5 * i] = t.adet;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ref[5 * i + 1 + b] = t.g[0][0] * t.g[b][0] + t.g[0][1] * t.g[b][1] + t.g[0][2] * t.g[b][2];
+}
+
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p1_box_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr, const int64_t* __restrict__ inc_slice_ptr,
+    const int32_t* __restrict__ inc_cell, const uint32_t* __restrict__ inc_pos, const double* __restrict__ ref,
+    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order, int acc_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [max_row][blockDim.x], then the 120 reference numbers
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    double* __restrict__ rf = lds_acc + acc_doubles;
+    if (tid < 120) rf[tid] = ref[tid];
+    __syncthreads();
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t q0 = it.cur * wpb + wave;
+        if (q0 >= n_slices) continue;
+        const int64_t s = order ? order[q0] : q0;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        constexpr int PF = 8;
+        for (int j0 = 0; j0 < iwidth; j0 += PF) {
+            int32_t qc[PF];
+            uint32_t pc[PF];
+            double kk[PF], mv[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 + u;
+                qc[u] = j < iwidth ? inc_cell[ibase + (int64_t)j * FS_SLICE + lane] : -1;
+                pc[u] = j < iwidth ? inc_pos[ibase + (int64_t)j * FS_SLICE + lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int c = qc[u] >= 0 ? qc[u] >> 2 : 0;
+                kk[u] = kc.mode == FS_COEF_CONST ? kc.value : (kc.mode == FS_COEF_CELL ? kc.data[c] : 0.0);
+                mv[u] = mc.mode == FS_COEF_CONST ? mc.value : (mc.mode == FS_COEF_CELL ? mc.data[c] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int32_t q = qc[u];
+                if (q < 0) continue;
+                const uint32_t packed = pc[u];
+                const int c = q >> 2, a = q & 3;
+                const uint32_t prot = a == 0 ? packed : ((packed >> (8 * a)) | (packed << (32 - 8 * a)));
+                const double* __restrict__ R = rf + 5 * (4 * (c % 6) + a);
+                const double adet = R[0];
+                const double vol = adet * (1.0 / 6.0);
+                const double w = kk[u] * vol;
+                double row[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) row[b] = w * R[1 + b];
+                if (mc.mode != FS_COEF_NONE) {
+                    const double mm = mv[u] * adet * (1.0 / 120.0);
+                    row[0] += 2.0 * mm;
+                    row[1] += mm;
+                    row[2] += mm;
+                    row[3] += mm;
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int k = (prot >> (8 * b)) & 255;
+                    lds_acc[k * bd + tid] += row[b];
+                }
+            }
         }
         for (int k = 0; k < width; ++k) {
             const int64_t e = base + (int64_t)k * FS_SLICE + lane;
@@ -2562,7 +2669,25 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;  // multiple of 8: XCD map
-        if (add)
+        // a mesh made by fs_mesh_create_box, snapped geometry, scalar coefficients, no advection: the geometry-free form
+        static const bool box_env_off = getenv("FS_BOX_ASSEMBLY") && getenv("FS_BOX_ASSEMBLY")[0] == '0';
+        const bool box_fast_off = g_box_assembly < 0 ? box_env_off : g_box_assembly == 0;
+        const box_snap bxs = make_box_snap(m);
+        if (!box_fast_off && bxs.h[0] > 0.0 && m->nc >= 6 && ac.mode == FS_COEF_NONE && bd == FS_BLOCK &&
+            (kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL) &&
+            (mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL) && lds + 120 * sizeof(double) <= 64 * 1024) {
+            if (!m->box_ref.p) {
+                FS_CHECK(const_cast<fs_mesh_s*>(m)->box_ref.alloc(120));
+                hipLaunchKernelGGL(k_box_ref_rows, dim3(1), dim3(64), 0, s, m->cells.p, m->xyz.p, bxs, m->box_ref.p);
+            }
+            const int accd = sp->max_row * bd;
+            if (add)
+                hipLaunchKernelGGL(k_assemble_p1_box_gather<true>, dim3(g), dim3(bd), lds + 120 * sizeof(double), s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                                   sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->box_ref.p, kc, mc, A->val.p, sp->slice_order.p, accd);
+            else
+                hipLaunchKernelGGL(k_assemble_p1_box_gather<false>, dim3(g), dim3(bd), lds + 120 * sizeof(double), s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                                   sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->box_ref.p, kc, mc, A->val.p, sp->slice_order.p, accd);
+        } else if (add)
             hipLaunchKernelGGL(k_assemble_p1_scalar_gather<1>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p, make_box_snap(m));
         else
             hipLaunchKernelGGL(k_assemble_p1_scalar_gather<0>, dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale, form->supg_pe, A->val.p, sp->slice_order.p, make_box_snap(m));

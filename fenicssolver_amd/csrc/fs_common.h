@@ -147,6 +147,10 @@ struct fs_mesh_s {
     // ... and, when this process holds the WHOLE box (one GPU), its cell counts: vertex v sits at (v % (nx + 1), ...), x fastest -
     // what the solver's lattice order of a CG2 space on it is computed from (fs_lattice.hip).  0 = a slab, or not a box.
     int64_t box_n[3] = {0, 0, 0};
+    // reference rows of the P1 stiffness / mass matrix of a box mesh's six cell types (fs_assemble.hip, k_assemble_p1_box_gather):
+    // [6 types][4 row vertices][5] = (|det J|, g_row . g_b for the row's rotated local vertices b = 0 .. 3), computed on the first
+    // hexahedron with the SNAPPED geometry every cell of that type has bit for bit.  Empty until the first assembly that uses it.
+    dbuf<double> box_ref;
 };
 
 // Peer-to-peer ghost refresh (opt-in, one node): every rank owns a fine-grained receive buffer + arrival flags that its
@@ -352,6 +356,7 @@ int fs_space_build_storage(fs_space_s* sp, hipStream_t s);
 int fs_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t count, hipStream_t s);
 // fs_assemble.hip: box meshes snap their edge vectors to the grid spacing (fs_set_option "box_snap", FS_BOX_SNAP=0: off)
 void fs_set_box_snap(bool on);
+void fs_set_box_assembly(bool on);   // fs_assemble.hip: the geometry-free P1 assembly of box meshes (option "box_assembly")
 // RCCL (fs_comm.hip): in-stream collectives on device buffers; no-ops on one rank.
 int fs_comm_allreduce_dev(double* d_inout, int n, hipStream_t s);
 // sums over all ranks of the per-workgroup partials [nv][npart] (the k_sum_partials order) -> out[nv]: one kernel when the

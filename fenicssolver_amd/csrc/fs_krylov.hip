@@ -2983,6 +2983,8 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_row_dictionary = value != 0.0;
     } else if (!strcmp(name, "box_snap")) {
         fs_set_box_snap(value != 0.0);
+    } else if (!strcmp(name, "box_assembly")) {
+        fs_set_box_assembly(value != 0.0);
     } else if (!strcmp(name, "cg_sub")) {
         FS_REQUIRE(value >= 2 && value <= 256 && ((int)value & 1) == 0, "cg_sub must be an even number in [2,256]");
         g_cg_sub = (int)value;

@@ -1075,6 +1075,42 @@ def test_box_assembly_is_translation_invariant_and_matches_the_oracle(gpu):
     assert len(rows) == (n - 1) ** 3 and len(np.unique(vals, axis=0)) == 1
 
 
+@pytest.mark.parametrize("dims,p1", [((12, 12, 12), (1.0, 0.7, 1.3)), ((33, 5, 9), (2.0, 1.0, 1.0)), ((7, 40, 5), (1.0, 1.0, 1.0))])
+def test_box_assembly_fast_path_bits(gpu, dims, p1):
+    """k_assemble_p1_box_gather (round 6: the P1 scalar assembly of a box mesh from the reference rows of its six cell types) writes
+    the values of the general row-gather kernel BIT FOR BIT: constant and per-cell stiffness, with and without a mass term, A = and
+    A += forms.  Option "box_assembly" switches between the two."""
+    nx, ny, nz = dims
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), p1)
+    V = gpu.DeviceSpace(mesh, 1)
+    rng = np.random.default_rng(3)
+    kcell = 1.0 + rng.random(6 * nx * ny * nz)
+    mcell = 0.5 + rng.random(6 * nx * ny * nz)
+    got = {}
+    try:
+        for fast in (1, 0):
+            gpu.set_option("box_assembly", fast)
+            out = []
+            for kw in (dict(stiffness=20.0), dict(stiffness=20.0, mass=2.0), dict(stiffness=("cell", kcell)),
+                       dict(stiffness=("cell", kcell), mass=("cell", mcell))):
+                A = gpu.DeviceMatrix(V)
+                A.assemble(**kw)
+                out.append(A.to_csr()[2].copy())
+                A.assemble(add=True, **kw)              # A += the same form
+                out.append(A.to_csr()[2].copy())
+            got[fast] = out
+    finally:
+        gpu.set_option("box_assembly", 1)
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()))
+    co, ce = fo.box_mesh((0, 0, 0), p1, nx, ny, nz)
+    A = gpu.DeviceMatrix(V)
+    A.assemble(stiffness=("cell", kcell), mass=2.0)
+    rp, ci, va, shape = A.to_csr()
+    Ao = fo.assemble_p1_scalar(co, ce, k=kcell, mass_coef=2.0)
+    assert abs(sp.csr_matrix((va, ci, rp), shape=shape) - Ao).max() <= 1e-12 * abs(Ao).max()
+
+
 def test_row_dictionary_buffers_may_move_between_solves(gpu):
     """The captured CG batches bake the dictionary's buffers in: a larger space in between re-allocates them, and the batches of the
     first space must be captured again (they are keyed on those buffers) - same solution before and after."""
