@@ -705,6 +705,112 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     }
 }
 
+// ---- scalar CG2 on a BOX mesh without the geometry (round 6; see k_assemble_p1_box_gather) ------------------------------------------
+// Reference per (cell type, local dof a): the cell volume and the ten sums over the four quadrature points of
+// 0.25 grad phi_a . grad phi_b - the loop of the general kernel's symmetric instantiation, verbatim - 660 doubles per mesh.
+__global__ void k_box_ref_rows_p2(const int32_t* __restrict__ cells, const double* __restrict__ xyz4, const box_snap bx, double* __restrict__ ref) {
+    const int i = threadIdx.x;
+    if (i >= 60) return;
+    const int ty = i / 10, a = i - 10 * ty;
+    const int4 c4 = reinterpret_cast<const int4*>(cells)[ty];
+    const int32_t vv[4] = {c4.x, c4.y, c4.z, c4.w};
+    const tet_geom t = tet_geometry_box(xyz4, vv, bx);
+    const double vol = t.adet * (1.0 / 6.0);
+    double row[10];
+#pragma unroll
+    for (int b = 0; b < 10; ++b) row[b] = 0.0;
+#pragma unroll
+    for (int qp = 0; qp < 4; ++qp) {
+        const double lam[4] = {FS_P2_QP[qp][0], FS_P2_QP[qp][1], FS_P2_QP[qp][2], FS_P2_QP[qp][3]};
+        double gp[10][3];
+        p2_basis_grads(t, lam, gp);
+        double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < 10; ++b)
+            if (b == a) { ga[0] = gp[b][0]; ga[1] = gp[b][1]; ga[2] = gp[b][2]; }
+#pragma unroll
+        for (int b = 0; b < 10; ++b) row[b] += 0.25 * (ga[0] * gp[b][0] + ga[1] * gp[b][1] + ga[2] * gp[b][2]);
+    }
+    ref[11 * i] = vol;
+#pragma unroll
+    for (int b = 0; b < 10; ++b) ref[11 * i + 1 + b] = row[b];
+}
+
+template <bool ADD>
+__global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_box_gather(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr, const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries,
+    const int32_t* __restrict__ inc_cell, const uint32_t* __restrict__ inc_pos, const double* __restrict__ ref,
+    coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order, int acc_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [max_row][blockDim.x], then the 660 reference numbers
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
+    double* __restrict__ rf = lds_acc + acc_doubles;
+    for (int i = tid; i < 660; i += bd) rf[i] = ref[i];
+    __syncthreads();
+    const int64_t n_chunks = (n_slices + wpb - 1) / wpb;
+    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
+        const int64_t q0 = it.cur * wpb + wave;
+        if (q0 >= n_slices) continue;
+        const int64_t s = order ? order[q0] : q0;
+        const int64_t base = slice_ptr[s];
+        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+        const int64_t ibase = inc_slice_ptr[s];
+        const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
+        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        constexpr int PF = 4;
+        for (int j0 = 0; j0 < iwidth; j0 += PF) {
+            int32_t qc[PF];
+            uint32_t pc[PF][3];
+            double kk[PF], mv[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 + u;
+                const int64_t e = ibase + (int64_t)j * FS_SLICE + lane;
+                qc[u] = j < iwidth ? inc_cell[e] : -1;
+#pragma unroll
+                for (int w = 0; w < 3; ++w) pc[u][w] = j < iwidth ? inc_pos[w * inc_entries + e] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int c = qc[u] >= 0 ? qc[u] / 10 : 0;
+                kk[u] = kc.mode == FS_COEF_CONST ? kc.value : (kc.mode == FS_COEF_CELL ? kc.data[c] : 0.0);
+                mv[u] = mc.mode == FS_COEF_CONST ? mc.value : (mc.mode == FS_COEF_CELL ? mc.data[c] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int32_t q = qc[u];
+                if (q < 0) continue;
+                const int c = q / 10, a = q - 10 * c;
+                const double* __restrict__ R = rf + 11 * (10 * (c % 6) + a);
+                const double vol = R[0];
+                double row[10];
+#pragma unroll
+                for (int b = 0; b < 10; ++b) row[b] = 0.0;
+                if (kc.mode != FS_COEF_NONE) {
+                    const double w = kk[u] * vol;
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] = R[1 + b] * w;
+                }
+                if (mc.mode != FS_COEF_NONE) {
+                    const double mm = mv[u] * vol * (1.0 / 420.0);
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) row[b] += mm * FS_P2_MASS420[a][b];
+                }
+#pragma unroll
+                for (int b = 0; b < 10; ++b) {
+                    const int k = (pc[u][b >> 2] >> (8 * (b & 3))) & 255;
+                    lds_acc[k * bd + tid] += row[b];
+                }
+            }
+        }
+        for (int k = 0; k < width; ++k) {
+            const int64_t e = base + (int64_t)k * FS_SLICE + lane;
+            const double x = lds_acc[k * bd + tid];
+            val[e] = ADD ? val[e] + x : x;
+        }
+    }
+}
+
 // P2 load vector: int f phi_a dx; constant / per-cell f: V * (-1/20 vertex, 1/5 edge); nodal (P2) f: M_e f_e
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_source(const int32_t* __restrict__ cell_dofs,
                                                                  const int32_t* __restrict__ cells,
@@ -2644,7 +2750,25 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
         FS_REQUIRE(lds <= 64 * 1024, "fs_assemble_matrix: rows of %d entries exceed the LDS accumulator", sp->max_row);
         const int wpb = bd / 64;
         const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
-        if (ac3.mode != FS_COEF_NONE || kc.mode == FS_COEF_CELL_QP) {
+        static const bool box_env_off2 = getenv("FS_BOX_ASSEMBLY") && getenv("FS_BOX_ASSEMBLY")[0] == '0';
+        const bool box_fast_off2 = g_box_assembly < 0 ? box_env_off2 : g_box_assembly == 0;
+        const box_snap bxs2 = make_box_snap(m);
+        if (!box_fast_off2 && bxs2.h[0] > 0.0 && m->nc >= 6 && ac3.mode == FS_COEF_NONE &&
+            (kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL) &&
+            (mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL) && lds + 660 * sizeof(double) <= 64 * 1024) {
+            // a mesh made by fs_mesh_create_box: the geometry-free form (k_assemble_p2_box_gather)
+            if (!m->box_ref2.p) {
+                FS_CHECK(m->box_ref2.alloc(660));
+                hipLaunchKernelGGL(k_box_ref_rows_p2, dim3(1), dim3(64), 0, s, m->cells.p, m->xyz.p, bxs2, m->box_ref2.p);
+            }
+            const int accd = sp->max_row * bd;
+            if (add)
+                hipLaunchKernelGGL(k_assemble_p2_box_gather<true>, dim3(g), dim3(bd), lds + 660 * sizeof(double), s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                                   sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->box_ref2.p, kc, mc, A->val.p, sp->slice_order.p, accd);
+            else
+                hipLaunchKernelGGL(k_assemble_p2_box_gather<false>, dim3(g), dim3(bd), lds + 660 * sizeof(double), s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                                   sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->box_ref2.p, kc, mc, A->val.p, sp->slice_order.p, accd);
+        } else if (ac3.mode != FS_COEF_NONE || kc.mode == FS_COEF_CELL_QP) {
             if (add)
                 hipLaunchKernelGGL((k_assemble_p2_scalar_gather<true, true>), dim3(g), dim3(bd), lds, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p, sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, A->val.p, sp->slice_order.p, make_box_snap(m), ac3, form->advection_scale, form->supg_pe);
             else
@@ -2677,7 +2801,7 @@ extern "C" int fs_assemble_matrix(fs_matrix_t A, const fs_bilinear_form* form, i
             (kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL) &&
             (mc.mode == FS_COEF_NONE || mc.mode == FS_COEF_CONST || mc.mode == FS_COEF_CELL) && lds + 120 * sizeof(double) <= 64 * 1024) {
             if (!m->box_ref.p) {
-                FS_CHECK(const_cast<fs_mesh_s*>(m)->box_ref.alloc(120));
+                FS_CHECK(m->box_ref.alloc(120));
                 hipLaunchKernelGGL(k_box_ref_rows, dim3(1), dim3(64), 0, s, m->cells.p, m->xyz.p, bxs, m->box_ref.p);
             }
             const int accd = sp->max_row * bd;

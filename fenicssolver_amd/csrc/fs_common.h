@@ -151,6 +151,8 @@ struct fs_mesh_s {
     // [6 types][4 row vertices][5] = (|det J|, g_row . g_b for the row's rotated local vertices b = 0 .. 3), computed on the first
     // hexahedron with the SNAPPED geometry every cell of that type has bit for bit.  Empty until the first assembly that uses it.
     dbuf<double> box_ref;
+    // the same for CG2 (k_assemble_p2_box_gather): [6 types][10 local dofs][11] = (volume, the row's ten quadrature sums of grad phi_a . grad phi_b)
+    dbuf<double> box_ref2;
 };
 
 // Peer-to-peer ghost refresh (opt-in, one node): every rank owns a fine-grained receive buffer + arrival flags that its

@@ -1111,6 +1111,33 @@ def test_box_assembly_fast_path_bits(gpu, dims, p1):
     assert abs(sp.csr_matrix((va, ci, rp), shape=shape) - Ao).max() <= 1e-12 * abs(Ao).max()
 
 
+@pytest.mark.parametrize("dims,p1", [((8, 8, 8), (1.0, 0.7, 1.3)), ((17, 4, 6), (2.0, 1.0, 1.0))])
+def test_box_assembly_fast_path_bits_cg2(gpu, dims, p1):
+    """k_assemble_p2_box_gather against the general CG2 row-gather kernel, bit for bit (constant / per-cell stiffness, mass, A +=)."""
+    nx, ny, nz = dims
+    mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), p1)
+    V = gpu.DeviceSpace(mesh, 1, degree=2)
+    rng = np.random.default_rng(4)
+    kcell = 1.0 + rng.random(6 * nx * ny * nz)
+    mcell = 0.5 + rng.random(6 * nx * ny * nz)
+    got = {}
+    try:
+        for fast in (1, 0):
+            gpu.set_option("box_assembly", fast)
+            out = []
+            for kw in (dict(stiffness=20.0), dict(stiffness=20.0, mass=2.0), dict(stiffness=("cell", kcell), mass=("cell", mcell)), dict(mass=3.0)):
+                A = gpu.DeviceMatrix(V)
+                A.assemble(**kw)
+                out.append(A.to_csr()[2].copy())
+                A.assemble(add=True, **kw)
+                out.append(A.to_csr()[2].copy())
+            got[fast] = out
+    finally:
+        gpu.set_option("box_assembly", 1)
+    for a, b in zip(got[1], got[0]):
+        assert np.abs(a).max() > 0 and np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()))
+
+
 def test_row_dictionary_buffers_may_move_between_solves(gpu):
     """The captured CG batches bake the dictionary's buffers in: a larger space in between re-allocates them, and the batches of the
     first space must be captured again (they are keyed on those buffers) - same solution before and after."""
