@@ -30,1710 +30,13 @@
 #define FS_BLOCK_ROUND 3      // 3x3 blocks per round of the vector-space product (measured: see DESIGN.md section 3)
 #endif
 
-// ---- SELL-64 SpMV, optionally fused with the three CG dot products -------------------------
-// One round of N entries of a scalar row: all 2N loads are issued before the first FMA, so the latency of a
-// round is one memory round trip whatever N is.  The remainder of a row (width % UNROLL entries) goes through
-// the same code with N = remainder (compile-time if-chain) instead of a serial tail loop - on the 15-wide
-// rows of a P1 Kuhn mesh a serial tail is 3 of the 6 round trips at UNROLL = 4.
-// NT: matrix values and column indices are read once per product; when the matrix is larger than the caches
-// (Infinity Cache 256 MB) a non-temporal load keeps them from evicting the x window out of L2 (measured on MI355X,
-// 10 M DOF: P1 310 -> 290 us, P2 1095 -> 1016 us; at 1 M DOF, where the matrix stays cache-resident between
-// iterations, the hint costs 25 %, so it is chosen by size).
-template <bool NT, typename T>
-__device__ __forceinline__ T fs_ldv(const T* p) {
-    return NT ? __builtin_nontemporal_load(p) : *p;
-}
-// op / op2: the offset lists of the two pieces of a DIA slice (fs_symbolic.hip, "SPLIT slices"; op2 == op when the slice is
-// not split), hi: this lane belongs to the second piece - two scalar loads and one select per entry, no column stream
-template <int N, bool NT>
-__device__ __forceinline__ void dia_round(const double* __restrict__ vp, const int32_t* __restrict__ op, const int32_t* __restrict__ op2,
-                                          bool hi, int k, int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
-    double v[N], xv[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = fs_ldv<NT>(&vp[(int64_t)(k + u) * FS_SLICE]);
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        int32_t c = r + (hi ? op2[k + u] : op[k + u]);
-        c = c < 0 ? 0 : (c > cmax ? cmax : c);
-        xv[u] = x[c];
-    }
-#pragma unroll
-    for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
-}
-template <int N, bool NT>
-__device__ __forceinline__ void sell_round(const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
-                                           const double* __restrict__ x, double& acc) {
-    int32_t c[N];
-    double v[N], xv[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) c[u] = fs_col_decode(fs_ldv<NT>(&cp[(int64_t)(k + u) * FS_SLICE]));
-#pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = fs_ldv<NT>(&vp[(int64_t)(k + u) * FS_SLICE]);
-#pragma unroll
-    for (int u = 0; u < N; ++u) xv[u] = x[c[u]];
-#pragma unroll
-    for (int u = 0; u < N; ++u) acc += v[u] * xv[u];
-}
-template <int N, bool NT>
-struct row_tail {
-    static __device__ __forceinline__ void dia(int rem, const double* __restrict__ vp, const int32_t* __restrict__ op,
-                                               const int32_t* __restrict__ op2, bool hi, int k,
-                                               int32_t r, int32_t cmax, const double* __restrict__ x, double& acc) {
-        if (rem == N) dia_round<N, NT>(vp, op, op2, hi, k, r, cmax, x, acc);
-        else row_tail<N - 1, NT>::dia(rem, vp, op, op2, hi, k, r, cmax, x, acc);
-    }
-    static __device__ __forceinline__ void sell(int rem, const double* __restrict__ vp, const int32_t* __restrict__ cp, int k,
-                                                const double* __restrict__ x, double& acc) {
-        if (rem == N) sell_round<N, NT>(vp, cp, k, x, acc);
-        else row_tail<N - 1, NT>::sell(rem, vp, cp, k, x, acc);
-    }
-};
-template <bool NT>
-struct row_tail<0, NT> {
-    static __device__ __forceinline__ void dia(int, const double*, const int32_t*, const int32_t*, bool, int, int32_t, int32_t, const double*, double&) {}
-    static __device__ __forceinline__ void sell(int, const double*, const int32_t*, int, const double*, double&) {}
-};
+#include "fs_krylov_stream.inc"      // the streaming products: hybrid SELL-64 / DIA kernels (k_sell_spmv, k_dia_pair_spmv)
 
-// One round of R block entries (BS x BS values each, vector spaces): all R * (BS*BS + BS) loads are issued before the first FMA,
-// as the scalar rounds above do - the serial loop it replaces had the 12 loads of ONE 3x3 block in flight per lane and was
-// latency-bound (fine-level product of the elasticity AMG, configs[2]).
-template <int BS, int R, bool NT>
-__device__ __forceinline__ void block_round(const double* __restrict__ vp, int64_t plane, const int64_t (&c)[R], int k,
-                                            const double* __restrict__ x, double (&acc)[BS]) {
-    double v[R][BS * BS], xv[R][BS];
-#pragma unroll
-    for (int u = 0; u < R; ++u)
-#pragma unroll
-        for (int q = 0; q < BS * BS; ++q) v[u][q] = fs_ldv<NT>(&vp[(int64_t)q * plane + (int64_t)(k + u) * FS_SLICE]);
-#pragma unroll
-    for (int u = 0; u < R; ++u)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) xv[u][j] = x[c[u] * BS + j];
-#pragma unroll
-    for (int u = 0; u < R; ++u)
-#pragma unroll
-        for (int j = 0; j < BS; ++j)
-#pragma unroll
-            for (int i = 0; i < BS; ++i) acc[i] += v[u][i * BS + j] * xv[u][j];
-}
+#include "fs_krylov_dict.inc"      // the row-dictionary form of scalar DIA operators: plans, class tables (k_dict_insert / compact / finish), the work-item product k_dict_spmv
 
-template <int BS, int DOTS, int UNROLL, bool NT = false>
-__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv(int64_t n_rows, int64_t n_cols, int64_t n_slices,
-                                                        const int64_t* __restrict__ slice_ptr,
-                                                        const int32_t* __restrict__ sell_col,
-                                                        const int32_t* __restrict__ dia_ptr,
-                                                        const int32_t* __restrict__ dia_off,
-                                                        const double* __restrict__ val, int64_t plane,
-                                                        const double* __restrict__ x, double* __restrict__ y,
-                                                        const double* __restrict__ rvec,
-                                                        double* __restrict__ partials,
-                                                        int* __restrict__ status,
-                                                        const int32_t* __restrict__ order,
-                                                        int part_base, int part_stride, int bump) {
-    // part_base / part_stride: where this launch's per-workgroup dot partials go (partials[j*stride + base + wg]);
-    // a product split into an interior and a boundary launch fills one array of stride = both grids
-    // DOTS == 4: no dot products, but the launch is gated by the status word like the fused ones (the product of the
-    // pipelined CG, whose dots are computed by its update kernel)
-    if (DOTS) {
-        if (status[0] != 0) return;  // converged earlier: the remaining launches of the batch are no-ops
-        // status[2] = number of in-loop products launched so far: the update kernel of a captured batch (hipGraph: same
-        // arguments every iteration) reads its iteration index from it.  Nobody else touches the word while we run.
-        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;
-    }
-    __shared__ double lds4[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    const int64_t n_chunks = (n_slices + 3) >> 2;
-    const int32_t cmax = (int32_t)(n_cols - 1);
-    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
-        const int64_t q = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
-        if (q >= n_slices) continue;
-        const int64_t s = order ? __builtin_amdgcn_readfirstlane(order[q]) : q;      // fs_space_s::slice_order
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-        const int32_t dp = dia_ptr[s];              // wave-uniform: >= 0 selects the DIA form
-        const int64_t r = s * FS_SLICE + lane;
-        const bool live = r < n_rows;
-        const int32_t* __restrict__ cp = sell_col + base + lane;
-        const double* __restrict__ vp = val + base + lane;
-        double zi[BS], ri[BS], acc[BS];
-        // operands of the fused dots are requested up front so their latency hides under the row loop
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-            zi[i] = 0.0;
-            ri[i] = 0.0;
-            acc[i] = 0.0;
-            if (DOTS && DOTS != 4 && live) {
-                if (DOTS == 1 || DOTS == 3) zi[i] = x[r * BS + i];
-                ri[i] = rvec[r * BS + i];
-            }
-        }
-        if (dp >= 0) {
-            // DIA slice: column = row + offset[k] (one scalar per entry row), so the x gather of the wave
-            // is one contiguous 512-B read and no column index is streamed.  Entries a row does not have
-            // hold the value 0 and read a clamped, valid address.
-            const int split = dia_off[dp];                                  // rows [split, 64) use the second offset list
-            const int32_t* __restrict__ op = dia_off + dp + 1;
-            const int32_t* __restrict__ op2 = op + (split < FS_SLICE ? width : 0);
-            const bool hi = lane >= split;
-            int k = 0;
-            if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) dia_round<UNROLL, NT>(vp, op, op2, hi, k, (int32_t)r, cmax, x, acc[0]);
-                row_tail<UNROLL - 1, NT>::dia(width - k, vp, op, op2, hi, k, (int32_t)r, cmax, x, acc[0]);
-                k = width;
-            }
-            if (BS > 1) {
-                constexpr int R = BS == 3 ? FS_BLOCK_ROUND : 2;
-                for (; k + R <= width; k += R) {
-                    int64_t c[R];
-#pragma unroll
-                    for (int u = 0; u < R; ++u) {
-                        c[u] = r + (hi ? op2[k + u] : op[k + u]);
-                        c[u] = c[u] < 0 ? 0 : (c[u] > cmax ? cmax : c[u]);
-                    }
-                    block_round<BS, R, NT>(vp, plane, c, k, x, acc);
-                }
-            }
-            for (; k < width; ++k) {
-                int64_t c = r + (hi ? op2[k] : op[k]);
-                c = c < 0 ? 0 : (c > cmax ? cmax : c);
-#pragma unroll
-                for (int j = 0; j < BS; ++j) {
-                    const double xj = x[c * BS + j];
-#pragma unroll
-                    for (int i = 0; i < BS; ++i) acc[i] += fs_ldv<NT>(&vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE]) * xj;
-                }
-            }
-        } else {
-            int k = 0;
-            if (BS == 1) {
-                for (; k + UNROLL <= width; k += UNROLL) sell_round<UNROLL, NT>(vp, cp, k, x, acc[0]);
-                row_tail<UNROLL - 1, NT>::sell(width - k, vp, cp, k, x, acc[0]);
-                k = width;
-            }
-            if (BS > 1) {
-                constexpr int R = BS == 3 ? FS_BLOCK_ROUND : 2;
-                for (; k + R <= width; k += R) {
-                    int64_t c[R];
-#pragma unroll
-                    for (int u = 0; u < R; ++u) c[u] = fs_col_decode(fs_ldv<NT>(&cp[(int64_t)(k + u) * FS_SLICE]));
-                    block_round<BS, R, NT>(vp, plane, c, k, x, acc);
-                }
-            }
-            for (; k < width; ++k) {
-                const int64_t c = fs_col_decode(cp[(int64_t)k * FS_SLICE]);
-#pragma unroll
-                for (int j = 0; j < BS; ++j) {
-                    const double xj = x[c * BS + j];
-#pragma unroll
-                    for (int i = 0; i < BS; ++i) acc[i] += fs_ldv<NT>(&vp[(int64_t)(i * BS + j) * plane + (int64_t)k * FS_SLICE]) * xj;
-                }
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < BS; ++i) {
-                y[r * BS + i] = acc[i];
-                if (DOTS == 1) {          // CG: r.z, w.z, r.r
-                    d_rz += ri[i] * zi[i];
-                    d_wz += acc[i] * zi[i];
-                    d_rr += ri[i] * ri[i];
-                } else if (DOTS == 2) {   // generic: w.u, w.w, u.u with u = rvec
-                    d_rz += acc[i] * ri[i];
-                    d_wz += acc[i] * acc[i];
-                    d_rr += ri[i] * ri[i];
-                } else if (DOTS == 3) {   // diagonally scaled CG (z == r): r.r, w.r, sum d r^2 with d = rvec
-                    d_rz += zi[i] * zi[i];
-                    d_wz += acc[i] * zi[i];
-                    d_rr += ri[i] * zi[i] * zi[i];
-                }
-            }
-        }
-    }
-    if (DOTS && DOTS != 4) {
-        const double t0 = fs_block_sum(d_rz, lds4);
-        const double t1 = fs_block_sum(d_wz, lds4);
-        const double t2 = fs_block_sum(d_rr, lds4);
-        if (threadIdx.x == 0) {
-            partials[part_base + blockIdx.x] = t0;
-            partials[part_stride + part_base + blockIdx.x] = t1;
-            partials[2 * part_stride + part_base + blockIdx.x] = t2;
-        }
-    }
-}
+#include "fs_krylov_lattice.inc"      // the tile product of a lattice-ordered CG2 box operator (k_lattice_spmv) and its tables
 
-// ---- DIA slices, two rows per lane ------------------------------------------------------------------------------------
-// PMC on the one-row-per-lane kernel at 10 M DOF (round 2: TA busy 70 %, 31 % of the wave cycles issue stalls, time
-// proportional to the L1 accesses and insensitive to the HBM byte count) says the per-CU address / L1 path is the limit,
-// not HBM.  This kernel halves the vector-memory instructions per row: a wave takes TWO slices with the same offset list
-// (lanes 0-31 the first, 32-63 the second), every lane two consecutive rows, so the value planes are read as 16-byte
-// lane loads, and inside a run of consecutive offsets (..., o, o+1, ...) the x value a lane needs for its second row at
-// offset o is the one it needs for its first row at offset o+1: one new 8-byte load per further offset of a run.
-// P1 Kuhn mesh (15 offsets in 7 runs): 15 + 22 + 2 loads per two rows instead of 64.
-// Pairs are formed on the host (fs_space_s::pair_list: consecutive slices in processing order, both DIA, both complete,
-// identical offset lists); everything else goes through k_sell_spmv as before.  Same per-row summation order.
-template <int DOTS, bool NT>
-__global__ void __launch_bounds__(FS_BLOCK) k_dia_pair_spmv(int64_t n_cols, int64_t n_pairs, const int32_t* __restrict__ pairs,
-                                                            const int64_t* __restrict__ slice_ptr,
-                                                            const int32_t* __restrict__ dia_ptr,
-                                                            const int32_t* __restrict__ dia_off,
-                                                            const double* __restrict__ val,
-                                                            const double* __restrict__ x, double* __restrict__ y,
-                                                            const double* __restrict__ rvec,
-                                                            double* __restrict__ partials,
-                                                            int* __restrict__ status, int part_base, int part_stride, int bump) {
-    if (DOTS) {
-        if (status[0] != 0) return;
-        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
-    }
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    __shared__ double lds4[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, l2 = (lane & 31) * 2;
-    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    const int64_t n_chunks = (n_pairs + 3) >> 2;
-    const int32_t cmax = (int32_t)(n_cols - 1);
-    constexpr int U = 16;
-    for (chunk_iter it = xcd_chunks(n_chunks); it.cur < it.end; it.cur += it.step) {
-        const int64_t q = __builtin_amdgcn_readfirstlane((int)(it.cur * 4 + wave));
-        if (q >= n_pairs) continue;
-        const int32_t sa = __builtin_amdgcn_readfirstlane(pairs[2 * q]), sb = __builtin_amdgcn_readfirstlane(pairs[2 * q + 1]);
-        const int64_t s = half ? sb : sa;
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[sa + 1] - slice_ptr[sa]) >> 6);       // same for both slices of a pair
-        const int32_t* __restrict__ op = dia_off + dia_ptr[sa] + 1;               // the shared offset list (pairs are never split slices)
-        const int32_t r = (int32_t)(s * FS_SLICE + l2);
-        const double* __restrict__ vp = val + base + l2;
-        v2d zi = {0.0, 0.0}, ri = {0.0, 0.0};
-        if (DOTS && DOTS != 4) {
-            if (DOTS == 1 || DOTS == 3) zi = *reinterpret_cast<const v2d*>(&x[r]);
-            ri = *reinterpret_cast<const v2d*>(&rvec[r]);
-        }
-        double a0 = 0.0, a1 = 0.0, prev_hi = 0.0;
-        int32_t prev_o = INT32_MIN;
-        for (int k0 = 0; k0 < width; k0 += U) {
-            v2d t[U];
-            double lo[U], hi[U];
-            bool cont[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k0 + u < width) t[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(&vp[(int64_t)(k0 + u) * FS_SLICE]))
-                                              : *reinterpret_cast<const v2d*>(&vp[(int64_t)(k0 + u) * FS_SLICE]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k0 + u < width) {
-                    const int32_t o = op[k0 + u];
-                    cont[u] = o == (u == 0 ? prev_o : op[k0 + u - 1]) + 1;     // wave-uniform
-                    int32_t c1 = r + o + 1;
-                    c1 = c1 < 0 ? 0 : (c1 > cmax ? cmax : c1);
-                    hi[u] = x[c1];
-                    if (!cont[u]) {
-                        int32_t c0 = r + o;
-                        c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
-                        lo[u] = x[c0];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k0 + u < width) {
-                    const double l = cont[u] ? (u == 0 ? prev_hi : hi[u - 1]) : lo[u];
-                    a0 += t[u].x * l;
-                    a1 += t[u].y * hi[u];
-                }
-            }
-            const int last = (width - k0 < U ? width - k0 : U) - 1;
-            prev_o = op[k0 + last];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (u == last) prev_hi = hi[u];
-        }
-        v2d out;
-        out.x = a0; out.y = a1;
-        *reinterpret_cast<v2d*>(&y[r]) = out;
-        if (DOTS == 1) {
-            d_rz += ri.x * zi.x + ri.y * zi.y;
-            d_wz += a0 * zi.x + a1 * zi.y;
-            d_rr += ri.x * ri.x + ri.y * ri.y;
-        } else if (DOTS == 2) {
-            d_rz += a0 * ri.x + a1 * ri.y;
-            d_wz += a0 * a0 + a1 * a1;
-            d_rr += ri.x * ri.x + ri.y * ri.y;
-        } else if (DOTS == 3) {
-            d_rz += zi.x * zi.x + zi.y * zi.y;
-            d_wz += a0 * zi.x + a1 * zi.y;
-            d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
-        }
-    }
-    if (DOTS && DOTS != 4) {
-        const double t0 = fs_block_sum(d_rz, lds4);
-        const double t1 = fs_block_sum(d_wz, lds4);
-        const double t2 = fs_block_sum(d_rr, lds4);
-        if (threadIdx.x == 0) {
-            partials[part_base + blockIdx.x] = t0;
-            partials[part_stride + part_base + blockIdx.x] = t1;
-            partials[2 * part_stride + part_base + blockIdx.x] = t2;
-        }
-    }
-}
-
-
-// ---- row-dictionary form of a scalar DIA matrix ---------------------------------------------------------------------------------
-// On a uniform box mesh with constant coefficients (BASELINE configs[0] / [1] / [3]: BoxMesh, k = 20) the assembled operator has a
-// few dozen (P1) to a few hundred (CG2) DISTINCT rows - interior, the 26 kinds of boundary position, the rows next to Dirichlet
-// faces - each repeated bit for bit (the box assembly snaps its edge vectors to the grid spacing, fs_assemble.hip, so that rows are
-// translation-invariant).  The product then does not have to stream 8 B per entry: every row carries a 2-byte class number and
-// the distinct coefficient rows are fetched per work item.  Built per solve from the values the solver is about to multiply with,
-// every row verified bit for bit against its class, so it is lossless and needs no knowledge of where the matrix came from.
-//
-// Round 4: the product is organised by ROWS, not by the 64-row slices of the value storage it no longer reads.
-//   * SEGMENTS (once per space, dict_structure_build): maximal runs of consecutive rows whose (col - row) offset sets are nested in
-//     one list - on a box mesh a mesh line (CG2: 107 / 108 rows, every line its own list because the edge classes are numbered with
-//     different line lengths) or, where all lines share one list (P1), the whole mesh.  Cut into WORK ITEMS of <= 128 rows.
-//   * the segment's offset list is cut into RUNS of up to three consecutive offsets (o, o + 1, o + 2).  A lane holds TWO consecutive
-//     rows; for a run starting at o its rows need x[r + o .. r + o + 3]: ONE 16-byte load x[r + o], x[r + o + 1] per lane, the
-//     other two values are the NEXT lane's load (DPP wave shift, no LDS); lane 63 has no rows of its own - an item is 126 rows -
-//     and loads what lane 62 needs (tests/test_gpu_kernels.py multiplies chains of dependent vectors bit for bit against the
-//     streaming product).  3.5 vector-memory instructions per row on the Kuhn stencil
-//     instead of the 19 of round 3, whose per-CU address path - not HBM - was the limit (0.27 of the peak on 26 B/row).
-//   * a RUN PLAN per segment: rounds of 8 runs (start offset, length); slot 0 of round 0 is the run (0; no coefficients) whose
-//     load IS z = x[r], x[r + 1] for the fused dots.  A class row holds its coefficients IN PLAN LAYOUT, [round][run][3], zero where
-//     a run is shorter or the row has no such entry: the kernel reads them at fixed positions.  Ascending offsets = the storage
-//     order of the streaming kernels, one fma each: same summation order, same bits (the extra terms add +0 * x).
-//   * per item, the distinct classes of its rows (a mesh line: interior + the two ends) are copied into the wave's own LDS
-//     region (sized for the item with the most classes, counted when the classes are found; at most 64 KB per workgroup) - the
-//     dictionary itself may have any size (CG2: 350 KB).
-//   * items whose loads could leave [0, n_cols) (first / last mesh plane) gather their four values per run one by one, clamped.
-// Measured (tools/probes/dict_pair_probe.hip and profiles/r04_*): P1, 10 M rows: 123 -> 64 us.
-constexpr int FS_DICT_CAP = 8192;       // hash slots
-constexpr int FS_DICT_MAX = 4096;       // distinct rows accepted
-constexpr int FS_DICT_ITEM_ROWS = 126;  // rows per work item: two per lane for lanes 0 .. 62; lane 63 only loads (its pair is what lane 62
-                                        // needs from `the next lane`: no separate tail loads)
-constexpr int FS_DICT_WHOLE_LDS_BYTES = 32 << 10;   // a dictionary up to this size is held whole by every workgroup
-constexpr int FS_DICT_LDS_BYTES = 64 << 10;   // per workgroup: 4 waves x (most distinct classes of any item) x (doubles per class row)
-constexpr int FS_DICT_ITEMS_PER_WAVE = 4;   // consecutive items a wave takes when it fetches class rows per item
-constexpr int FS_DICT3_RUNS = 4;          // runs whose loads the block-row kernel has in flight at a time
-constexpr int FS_DICT_MAX_ROUNDS = 8;   // rounds of 8 runs per plan (192 coefficient positions)
-
-struct dict_plan_round {
-    int32_t start[8];       // first offset of each run (0 for an empty slot: a harmless load of x[r], x[r + 1])
-    uint8_t len[8];         // 0 .. 3
-    uint8_t pad[24];
-};
-static_assert(sizeof(dict_plan_round) == 64, "one 64-byte scalar load per round");
-// Rounds of TWELVE runs (fs_space_s::dict_runs = 12: the lattice-ordered shadow of a CG2 box space, fs_lattice.hip - three quarters
-// of its mesh lines have 11 runs + the z run, one round instead of two): the same 64 bytes, 12 starts + 12 lengths.  Code that
-// takes the number of runs per round at run time reads a round through these two:
-struct dict_plan_round12 {
-    int32_t start[12];
-    uint8_t len[12];
-    uint8_t pad[4];
-};
-static_assert(sizeof(dict_plan_round12) == 64, "one 64-byte scalar load per round");
-__host__ __device__ __forceinline__ int32_t dict_run_start(const dict_plan_round* __restrict__ pl, int NR, int g) {
-    return reinterpret_cast<const int32_t*>(pl + g / NR)[g % NR];
-}
-__host__ __device__ __forceinline__ int dict_run_len(const dict_plan_round* __restrict__ pl, int NR, int g) {
-    return (int)(reinterpret_cast<const uint8_t*>(pl + g / NR) + 4 * NR)[g % NR];
-}
-
-// Coefficient position (plan layout) of the stored entry with offset o, walking the runs of a plan in ascending order from run g on
-// (the entries of a row come in ascending offsets, as the runs do): -1 = the plan has no such offset.
-__device__ __forceinline__ int dict_slot_of(const dict_plan_round* __restrict__ pl, int n_runs, int RL, int& g, int32_t o, int NR = 8) {
-    while (g < n_runs) {
-        const int32_t st = dict_run_start(pl, NR, g);
-        const int ln = dict_run_len(pl, NR, g);
-        if (ln > 0 && o < st + ln) return o >= st ? RL * g + (o - st) : -1;
-        ++g;
-    }
-    return -1;
-}
-
-// One row's stored entries (DIA slice storage: value plane k, offset list of the row's piece of its slice), nonzero values only:
-// f(position, value), position = slot * nq + q for component q of an entry's nq = bs * bs values (block entry e, component q at
-// q * plane + e).  Returns false when an entry has no position in the plan.
-// sc (scalar operators only; may be null): the row is walked as D^-1/2 A D^-1/2 - every stored value v at column r + o becomes
-// (v sc[r]) sc[r + o], the expression and the bits of k_scale_copy - so that a matrix can be compared with the kept class table of
-// its scaled form WITHOUT writing the scaled copy first (the copy is 300 MB of traffic at 1 M rows, and on the row-dictionary path
-// nobody reads it).
-template <typename F>
-__device__ __forceinline__ bool dict_walk_row(int32_t r, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                              const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane,
-                                              const dict_plan_round* __restrict__ pl, int n_runs, int RL, F f,
-                                              const double* __restrict__ sc = nullptr, int NR = 8) {
-    const int32_t sl = r >> 6, ln = r & 63;
-    const int64_t base = slice_ptr[sl];
-    const int width = (int)((slice_ptr[sl + 1] - base) >> 6);
-    const int32_t dp = dia_ptr[sl];
-    const int32_t* __restrict__ op = dia_off + dp + 1 + (ln >= dia_off[dp] ? width : 0);
-    const double* __restrict__ vp = val + base + ln;
-    bool ok = true;
-    if (n_runs == 8 && NR == 8 && nq == 1) {
-        // one-round plans of scalar operators (P1): the eight run starts and lengths are wave-uniform - in scalar registers, an
-        // entry's position is found by comparing its offset with all of them - and the row is taken eight entries at a time,
-        // offsets and values of a batch (and whatever f loads) in flight together; the walk below goes entry by entry, two loads
-        // and a branch per step of the plan, each waited for
-        int32_t st[8], le[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            st[j] = __builtin_amdgcn_readfirstlane(pl->start[j]);
-            le[j] = __builtin_amdgcn_readfirstlane((int)pl->len[j]);
-        }
-        for (int k0 = 0; k0 < width; k0 += 8) {
-            int32_t o[8];
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u < width ? k0 + u : width - 1;        // (clamped: the loads of a short batch stay inside the row)
-                o[u] = op[k];
-                v[u] = vp[(int64_t)k * FS_SLICE];
-            }
-            if (sc) {
-                const double sr = sc[r];
-                double scol[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) scol[u] = sc[v[u] != 0.0 ? r + o[u] : r];       // (a padded position has no column)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = v[u] * sr * scol[u];
-            }
-            int slot[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                slot[u] = -1;
-#pragma unroll
-                for (int j = 1; j < 8; ++j)              // (run 0 is the z run: no coefficients)
-                    if (le[j] > 0 && o[u] >= st[j] && o[u] < st[j] + le[j]) slot[u] = RL * j + (o[u] - st[j]);
-                if (k0 + u >= width || v[u] == 0.0) slot[u] = -3;         // nothing stored there
-                if (slot[u] == -1) ok = false;                           // a value outside the plan
-            }
-            if (!ok) return false;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (slot[u] >= 0) f(slot[u], v[u]);
-        }
-        return true;
-    }
-    int g = 1;                  // run 0 is the z run
-    if (nq == 1) {
-        // scalar operators with plans of several rounds (CG2; the lattice order's line plans): offsets, values and scale factors of
-        // eight entries in flight together, then the walk along the plan for the eight - the entry-by-entry loop below waits for two
-        // or three dependent loads per entry (configs[3]: 3.9 ms per solve for the comparison with the kept table)
-        for (int k0 = 0; k0 < width; k0 += 8) {
-            int32_t o[8];
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u < width ? k0 + u : width - 1;
-                o[u] = op[k];
-                v[u] = vp[(int64_t)k * FS_SLICE];
-            }
-            bool stored[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) stored[u] = k0 + u < width && v[u] != 0.0;
-            if (sc) {
-                const double sr = sc[r];
-                double scol[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) scol[u] = sc[stored[u] ? r + o[u] : r];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = v[u] * sr * scol[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (stored[u]) {
-                    const int slot = dict_slot_of(pl, n_runs, RL, g, o[u], NR);
-                    if (slot < 0) return false;
-                    f(slot, v[u]);
-                }
-        }
-        return true;
-    }
-    for (int k = 0; k < width && ok; ++k) {
-        int slot = -2;          // not looked up yet
-        for (int q = 0; q < nq; ++q) {
-            double v = vp[(int64_t)k * FS_SLICE + (int64_t)q * plane];
-            if (v == 0.0) continue;
-            if (sc) v = v * sc[r] * sc[r + op[k]];
-            if (slot == -2) slot = dict_slot_of(pl, n_runs, RL, g, op[k], NR);
-            if (slot < 0) { ok = false; break; }
-            f(slot * nq + q, v);
-        }
-    }
-    return ok;
-}
-
-__device__ __forceinline__ unsigned long long dict_mix(unsigned long long h, int slot, double v) {
-    h = (h ^ (unsigned long long)__double_as_longlong(v)) * 1099511628211ull;
-    h = (h ^ (unsigned long long)(unsigned)slot) * 1099511628211ull;
-    return h ^ (h >> 29);
-}
-
-// info[0] = classes found, info[1] = 1: gave up (too many classes), info[2] = rows that differ from their class or do not fit their
-// plan (verification), info[3] = most distinct classes in any item
-// Nearly all rows of such an operator carry the SAME hash, so the table is hit where it hurts: the lanes of a wave are first grouped
-// by hash (a wave of interior rows is one group) and only the group's first lane goes to memory, and it looks at the slot with an
-// ordinary cached load before any atomic (a slot goes from 0 to its final key once: a key seen there is final, a stale 0 merely
-// sends the lane to the compare-and-swap, which returns the truth).
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_insert(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
-                                                          const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
-                                                          unsigned long long* keys, const unsigned long long* keys_cached, double* slot_vals,
-                                                          uint16_t* __restrict__ cls_slot, int* info, int NR = 8) {
-    const int lane = threadIdx.x & 63;
-    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (; q < n_items; q += stride) {
-        if (__hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-        const int4 it = items[q];
-        const int32_t first = it.x, nr = it.y & 0xffff;
-        const dict_plan_round* __restrict__ pl = plans + it.z;
-        const int n_runs = NR * it.w;
-        for (int half = 0; half < 2; ++half) {
-            const int i = half * 64 + lane;
-            const bool live = i < nr;
-            const int32_t r = first + i;
-            unsigned long long h = 1469598103934665603ull;
-            bool fits = true;
-            if (live) fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) { h = dict_mix(h, slot, v); }, nullptr, NR);
-            if (!h) h = 1ull;
-            if (live && !fits) atomicAdd(&info[2], 1);
-            int my_slot = 0;
-            unsigned long long todo = __ballot(live);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const unsigned long long hl = ((unsigned long long)(unsigned)__shfl((int)(h >> 32), leader, 64) << 32) |
-                                              (unsigned long long)(unsigned)__shfl((int)(h & 0xffffffffull), leader, 64);
-                const bool mine = live && h == hl;
-                int slot = (int)(hl & (FS_DICT_CAP - 1));
-                if (lane == leader) {
-                    for (int probe = 0; probe < FS_DICT_CAP; ++probe) {
-                        unsigned long long old = keys_cached[slot];
-                        if (old != hl) {
-                            old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, hl);
-                            if (old == 0ull) {                  // this row is the representative of a new class
-                                if (atomicAdd(&info[0], 1) >= FS_DICT_MAX) __hip_atomic_store(&info[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                double* __restrict__ dst = slot_vals + (int64_t)slot * S;       // (zero-filled by the host before the launch)
-                                (void)dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int sl2, double v) { if (sl2 < S) dst[sl2] = v; }, nullptr, NR);
-                                break;
-                            }
-                        }
-                        if (old == hl) break;
-                        slot = (slot + 1) & (FS_DICT_CAP - 1);
-                    }
-                }
-                slot = __shfl(slot, leader, 64);
-                if (mine) my_slot = slot;
-                todo &= ~__ballot(mine);
-            }
-            if (live) cls_slot[r] = (uint16_t)my_slot;
-        }
-    }
-}
-
-// number the occupied slots; values[id][S] = the class rows in plan layout, nnz[id] = their nonzero positions
-__global__ void __launch_bounds__(1024) k_dict_compact(const unsigned long long* __restrict__ keys, const double* __restrict__ slot_vals,
-                                                       int S, int32_t* __restrict__ slot2cls, double* __restrict__ values, int32_t* __restrict__ nnz) {
-    constexpr int PER = FS_DICT_CAP / 1024;       // consecutive slots per thread
-    __shared__ int cnt[1024];
-    const int t = threadIdx.x;
-    int mine = 0;
-    for (int q = 0; q < PER; ++q) mine += keys[t * PER + q] != 0ull;
-    cnt[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan
-        const int v = t >= off ? cnt[t - off] : 0;
-        __syncthreads();
-        cnt[t] += v;
-        __syncthreads();
-    }
-    int id = cnt[t] - mine;
-    for (int q = 0; q < PER; ++q) {
-        const int slot = t * PER + q;
-        const bool used = keys[slot] != 0ull;
-        slot2cls[slot] = used ? id : -1;
-        if (used && id < FS_DICT_MAX) {
-            int nz = 0;
-            for (int k = 0; k < S; ++k) {
-                const double v = slot_vals[(int64_t)slot * S + k];
-                values[(int64_t)id * S + k] = v;
-                nz += v != 0.0;
-            }
-            nnz[id] = nz;
-        }
-        id += used;
-    }
-}
-
-// class numbers; EVERY row against its class, bit for bit (a hash collision ends here); the distinct classes of every item counted
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_finish(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
-                                                          const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ dia_ptr,
-                                                          const int32_t* __restrict__ dia_off, const double* __restrict__ val, int nq, int64_t plane, int S, int RL,
-                                                          const int32_t* __restrict__ slot2cls, const double* __restrict__ values,
-                                                          const int32_t* __restrict__ nnz, const uint16_t* __restrict__ cls_slot,
-                                                          uint16_t* __restrict__ cls, int* info, const double* __restrict__ sc = nullptr, int NR = 8) {
-    const int lane = threadIdx.x & 63;
-    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    int bad = 0, crowded = 0;       // (crowded: most distinct classes of an item so far)
-    for (; q < n_items; q += stride) {
-        const int4 it = items[q];
-        const int32_t first = it.x, nr = it.y & 0xffff;
-        const dict_plan_round* __restrict__ pl = plans + it.z;
-        const int n_runs = NR * it.w;
-        int id2[2] = {-1, -1};
-        for (int half = 0; half < 2; ++half) {
-            const int i = half * 64 + lane;
-            if (i >= nr) continue;
-            const int32_t r = first + i;
-            const int id = slot2cls[cls_slot[r]];
-            cls[r] = (uint16_t)(id < 0 ? 0 : id);
-            if (id < 0 || id >= FS_DICT_MAX) { ++bad; continue; }
-            id2[half] = id;
-            const double* __restrict__ dv = values + (int64_t)id * S;
-            int nz = 0, diff = 0;
-            const bool fits = dict_walk_row(r, slice_ptr, dia_ptr, dia_off, val, nq, plane, pl, n_runs, RL, [&](int slot, double v) {
-                ++nz;
-                diff += slot >= S || __double_as_longlong(v) != __double_as_longlong(dv[slot < S ? slot : 0]);
-            }, sc, NR);
-            bad += !fits || diff != 0 || nz != nnz[id];
-        }
-        // distinct classes among the item's rows (what its wave will have to hold in LDS)
-        int distinct = 0;
-        unsigned long long m0 = __ballot(id2[0] >= 0), m1 = __ballot(id2[1] >= 0);
-        while (m0 | m1) {
-            const bool from0 = m0 != 0ull;
-            const int src = __ffsll((long long)(from0 ? m0 : m1)) - 1;
-            const int cv = __shfl(from0 ? id2[0] : id2[1], src, 64);
-            m0 &= ~__ballot(id2[0] == cv);
-            m1 &= ~__ballot(id2[1] == cv);
-            ++distinct;
-        }
-        crowded = distinct > crowded ? distinct : crowded;
-    }
-    if (bad) atomicAdd(&info[2], bad);
-    // (a look before the atomic: nearly every wave holds the same maximum, and 8 000 atomics on one address were most of this
-    // kernel's time at 1 M rows)
-    if (crowded && lane == 0 && crowded > __hip_atomic_load(&info[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[3], crowded);
-}
-
-// the next lane's value (DPP wave shift, no LDS); lane 63, which has no next lane, owns no rows
-__device__ __forceinline__ double fs_from_next_lane(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// n doubles (n even, both 16-byte aligned) global -> LDS by the whole workgroup: batches of four 16-byte loads per thread, all four
-// in flight before the first LDS store (the plain loop `for i: lds[i] = g[i]` compiles to one load - wait - store per trip:
-// eight dependent round trips for the 15 KB dictionary of a P1 box, about 4 us at the head of every launch)
-__device__ __forceinline__ void fs_fill_lds(double* __restrict__ lds, const double* __restrict__ g, int n) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const int n2 = n >> 1;
-    const v2d* __restrict__ g2 = reinterpret_cast<const v2d*>(g);
-    v2d* __restrict__ l2 = reinterpret_cast<v2d*>(lds);
-    for (int base = 0; base < n2; base += 4 * FS_BLOCK) {
-        v2d t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * FS_BLOCK + (int)threadIdx.x;
-            t[u] = g2[i < n2 ? i : n2 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * FS_BLOCK + (int)threadIdx.x;
-            if (i < n2) l2[i] = t[u];
-        }
-    }
-}
-
-// the same by ONE wave (a class row of n2 16-byte pairs into the wave's LDS region): four loads in flight per lane and batch
-__device__ __forceinline__ void fs_wave_copy_pairs(double* __restrict__ lds, const double* __restrict__ g, int n2, int lane) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const v2d* __restrict__ g2 = reinterpret_cast<const v2d*>(g);
-    v2d* __restrict__ l2 = reinterpret_cast<v2d*>(lds);
-    for (int base = 0; base < n2; base += 256) {
-        v2d t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * 64 + lane;
-            t[u] = g2[i < n2 ? i : n2 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * 64 + lane;
-            if (i < n2) l2[i] = t[u];
-        }
-    }
-}
-
-// item: x = first row, y = rows (1 .. 126) | edge << 16, z = first plan round, w = rounds.  S = doubles per class row (8 RL per round
-// of the longest plan of the space), C = class rows a wave's LDS region holds.  Dynamic LDS: 4 waves x C x S doubles.
-// LDSD: the whole dictionary fits the workgroup's LDS (P1: 78 class rows of 24 doubles) - loaded once per workgroup, a row's
-// coefficients sit at class * S; otherwise (CG2: 361 rows of 120) each item's classes are copied into its wave's region.
-// RL: longest run of the space's plans (coefficient positions per run): 3 on P1 Kuhn meshes (runs of 2, 2, 2, 3, 2, 2, 2), 2 on CG2
-// spaces, where 67 % of the runs are one offset long, 32 % two and 0.5 % three (those are cut in two): a third fewer fmas and LDS
-// reads on padded positions, one DPP shift per run instead of two.
-// NR: runs per plan round (8; 12 on the lattice-ordered shadow of a CG2 box space: twelve 16-byte loads in flight per lane and round)
-template <int DOTS, bool LDSD, int RL, int NR = 8>
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
-                                                        const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
-                                                        const double* __restrict__ dict, int S, int C,
-                                                        const double* __restrict__ x, double* __restrict__ y,
-                                                        const double* __restrict__ rvec, double* __restrict__ partials,
-                                                        int* __restrict__ status, int part_base, int part_stride, int bump, int map_xcd) {
-    // (the status word is asked for now and looked at after the dictionary's loads have gone out: one round trip instead of two)
-    const int st0 = DOTS ? status[0] : 0;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ __attribute__((aligned(16))) double sdict[];
-    __shared__ double lds4[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    double* __restrict__ wl = LDSD ? sdict : sdict + (int64_t)wave * C * S;
-    if (LDSD) fs_fill_lds(sdict, dict, C * S);      // (C = number of classes here)
-    if (DOTS) {
-        if (st0 != 0) return;
-        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
-    }
-    if (LDSD) __syncthreads();
-    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    // A wave takes K CONSECUTIVE items of a chunk of 4 K: with per-item class rows (!LDSD) neighbouring mesh lines hold the same
-    // classes, and a class row already in the wave's region (tagv: lane k knows which class slot k holds) is not fetched again.
-    constexpr int K = LDSD ? 1 : FS_DICT_ITEMS_PER_WAVE;
-    const int64_t n_chunks = (n_items + 4 * K - 1) / (4 * K);
-    const int32_t cmax = (int32_t)(n_cols - 1);
-    chunk_iter it = xcd_chunks(n_chunks);
-    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
-    int tagv = -1, rr = 0;
-    const unsigned long long cmask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
-    for (; it.cur < it.end; it.cur += it.step)
-    for (int kk = 0; kk < K; ++kk) {
-        const int64_t q = (it.cur * 4 + wave) * K + kk;
-        if (q >= n_items) break;
-        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
-        const int32_t first = __builtin_amdgcn_readfirstlane(ds.x);
-        const int nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
-        const int edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
-        const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
-        const int rounds = __builtin_amdgcn_readfirstlane(ds.w);
-        const int32_t r = first + 2 * lane;
-        const bool ok0 = 2 * lane < nr, ok1 = 2 * lane + 1 < nr;
-        v2d ri = {0.0, 0.0};
-        if (DOTS && DOTS != 4) {
-            if (ok1) ri = *reinterpret_cast<const v2du*>(&rvec[r]);
-            else if (ok0) ri.x = rvec[r];
-        }
-        int c0 = -1, c1 = -1;
-        if ((first & 1) == 0) {        // (wave-uniform) the two class numbers of a lane in one 4-byte load (the array is padded)
-            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
-            if (ok0) c0 = (int)(two & 0xffffu);
-            if (ok1) c1 = (int)(two >> 16);
-        } else {
-            if (ok0) c0 = (int)cls[r];
-            if (ok1) c1 = (int)cls[r + 1];
-        }
-        // the x values of the first round are asked for before anything waits for the class numbers.  Items whose accesses could leave
-        // [0, n_cols) (first / last rows of the vector) load the two values of a pair one by one, each clamped into x: a column
-        // outside the vector has no entry, hence a zero coefficient, and every value inside it is the right one.
-        const double* __restrict__ xr = x + r;
-        v2d A[NR];
-        struct starts8 { int32_t v[NR]; };
-        auto read_starts = [&](const dict_plan_round* __restrict__ p) {       // (wave-uniform: one 32-byte scalar load)
-            starts8 t;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) t.v[j] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t*>(p)[j]);
-            return t;
-        };
-        auto load_round = [&](v2d (&buf)[NR], const starts8& st) {
-            if (!edge) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) buf[j] = *reinterpret_cast<const v2du*>(xr + st.v[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    const int32_t c = r + st.v[j];
-                    buf[j].x = x[c < 0 ? 0 : (c > cmax ? cmax : c)];
-                    buf[j].y = x[c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1)];
-                }
-            }
-        };
-        load_round(A, read_starts(pl));
-        // (per-item class rows = CG2: the run starts of a plan are the line's own - 20 MB of plans streamed once per product - and
-        // the NEXT round's are asked for a round ahead, so that a round's loads wait for one memory round trip, not two: 196 ->
-        // 187 us.  It costs 20 VGPRs (the compiler forms the next round's addresses early): not done where the dictionary sits whole
-        // in LDS - P1, one round -, which it took from 6 to 4 waves per SIMD, 68 -> 78 us)
-        starts8 st_next = read_starts(pl + ((!LDSD && rounds > 1) ? 1 : 0));
-        int b0 = 0, b1 = 0;
-        if (LDSD) {
-            b0 = ok0 ? c0 * S : 0;
-            b1 = ok1 ? c1 * S : 0;
-        } else {
-            // ---- the classes of this item's rows -> the wave's LDS region (C slots), unless they are there already ----
-            unsigned long long inuse = 0ull;
-            bool copied = false;
-            unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
-            while (m0 | m1) {
-                const bool from0 = m0 != 0ull;
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(from0 ? m0 : m1)) - 1);
-                const int cv = __builtin_amdgcn_readlane(from0 ? c0 : c1, src);
-                const unsigned long long hit = __ballot(tagv == cv) & cmask;
-                int slot;
-                if (hit) slot = __ffsll((long long)hit) - 1;
-                else {
-                    // victim: the first slot from the round-robin pointer on that this item does not use (there is one: C is the
-                    // largest number of classes any item has)
-                    const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
-                    slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
-                    rr = slot + 1 == C ? 0 : slot + 1;
-                    fs_wave_copy_pairs(wl + slot * S, dict + (int64_t)cv * S, S >> 1, lane);
-                    if (lane == slot) tagv = cv;
-                    copied = true;
-                }
-                inuse |= 1ull << slot;
-                const bool h0 = c0 == cv, h1 = c1 == cv;
-                if (h0) b0 = slot * S;
-                if (h1) b1 = slot * S;
-                m0 &= ~__ballot(h0);
-                m1 &= ~__ballot(h1);
-            }
-            if (copied) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-        const double* __restrict__ v0 = wl + b0;
-        const double* __restrict__ v1 = wl + b1;
-        double a0 = 0.0, a1 = 0.0;
-        v2d zi = {0.0, 0.0};
-        // (measured and not kept, CG2 n = 107, product 204 us: the next round's loads in flight while this one is multiplied - a
-        // second register set, 138 VGPRs, 3 waves per SIMD: 270 us; only the terms a run's length calls for, by wave-uniform branches
-        // - most CG2 runs are one or two offsets long - : 339 us, the branches keep the coefficient reads from being batched)
-        auto compute_round = [&](const v2d (&buf)[NR], int rd) {
-            const double* __restrict__ w0 = v0 + NR * RL * rd;
-            const double* __restrict__ w1 = v1 + NR * RL * rd;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const double e0 = buf[j].x, e1 = buf[j].y;
-                const double e2 = fs_from_next_lane(buf[j].x);
-                a0 = fma(w0[RL * j], e0, a0);     a1 = fma(w1[RL * j], e1, a1);
-                a0 = fma(w0[RL * j + 1], e1, a0); a1 = fma(w1[RL * j + 1], e2, a1);
-                if (RL == 3) {
-                    const double e3 = fs_from_next_lane(buf[j].y);
-                    a0 = fma(w0[RL * j + 2], e2, a0); a1 = fma(w1[RL * j + 2], e3, a1);
-                }
-                // (the coefficient positions are compile-time constants: left alone the compiler reads all 48 of a round
-                // ahead of the first fma - 150 VGPRs, 3 waves per SIMD; a compiler barrier per run keeps it at the run's six)
-                asm volatile("" ::: "memory");
-            }
-        };
-        for (int rd = 0; rd < rounds; ++rd) {
-            if (rd > 0) {
-                if (LDSD) load_round(A, read_starts(pl + rd));
-                else {
-                    load_round(A, st_next);
-                    st_next = read_starts(pl + (rd + 1 < rounds ? rd + 1 : rd));
-                }
-            }
-            compute_round(A, rd);
-            if (rd == 0) zi = A[0];
-        }
-        if (ok1) {
-            v2d out;
-            out.x = a0; out.y = a1;
-            *reinterpret_cast<v2du*>(&y[r]) = out;
-        } else if (ok0) y[r] = a0;
-        if (!ok0) { a0 = 0.0; zi.x = 0.0; }
-        if (!ok1) { a1 = 0.0; zi.y = 0.0; }
-        if (DOTS == 1) {
-            d_rz += ri.x * zi.x + ri.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * ri.x + ri.y * ri.y;
-        } else if (DOTS == 2) {
-            d_rz += a0 * ri.x + a1 * ri.y; d_wz += a0 * a0 + a1 * a1; d_rr += ri.x * ri.x + ri.y * ri.y;
-        } else if (DOTS == 3) {
-            d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += ri.x * zi.x * zi.x + ri.y * zi.y * zi.y;
-        }
-        if (!LDSD) __builtin_amdgcn_wave_barrier();            // (the next item's class rows may overwrite this one's)
-    }
-    if (DOTS && DOTS != 4) {
-        const double t0 = fs_block_sum(d_rz, lds4);
-        const double t1 = fs_block_sum(d_wz, lds4);
-        const double t2 = fs_block_sum(d_rr, lds4);
-        if (threadIdx.x == 0) {
-            partials[part_base + blockIdx.x] = t0;
-            partials[part_stride + part_base + blockIdx.x] = t1;
-            partials[2 * part_stride + part_base + blockIdx.x] = t2;
-        }
-    }
-}
-
-// ---- the row-dictionary product on a LATTICE-ORDERED operator (fs_lattice.hip), x staged through LDS tiles ----------------------------
-// k_dict_spmv fetches x with one 16-byte global load per run and lane: 20 - 39 vector-memory instructions per work item on a CG2 operator,
-// whatever the numbering - the per-CU address path is what bounds it (0.17 of the HBM peak on BASELINE configs[3]).  In lattice order
-// (row = X + SX (Y + NY Z) on the half grid) every neighbour of a row lies within +-2 in each direction, so a workgroup of eight waves
-// takes a TILE of 128 x 4 x 4 rows and loads the (128 + 4) x 8 x 8 window of x around it into LDS with coalesced 16-byte loads (4.1 x
-// 8 B per row, from L2), the even and the odd X of a line side by side in two halves of the window.  A wave then takes the 64 rows of
-// ONE PARITY of a line (X = x0 + p, x0 + p + 2, ..): along a mesh line these are rows of one class (vertex rows, x-edge rows, ..), so
-// the class's row - a list of (coefficient, window offset), the nonzero positions of the plan layout in plan order - is WAVE-UNIFORM.
-// The wave loads it ahead of time (lane k: entry k), spreads it into its own LDS scratch and reads it back entry by entry as a
-// broadcast; x comes from the window at consecutive addresses (no bank conflicts); one fma per STORED entry - no padded positions.  Two
-// lines two planes apart (same parities: the same class) are multiplied together, one read of the list for both.  The order of a
-// row's terms is that of k_dict_spmv and of the streaming kernels: the same bits (option "lattice_check" compares every row).
-// Nothing is assumed about where classes change: a wave whose lanes are not of one class walks its DISTINCT classes one after the other
-// (lat_wave_rows: the lanes of the other classes masked, the lists through scalar loads - slow, correct).  What the geometry buys is
-// that this does not happen - EXCEPT at the ends of the lines: the first LT_LO and the last LT_HI rows of a line have classes of their
-// own (boundary rows, and - the operator is scaled with its diagonal - the rows coupled to them), nine of 216 columns at configs[3].
-// They are left out of the line waves: COLUMN tiles take them (the same machinery with X and Y exchanged, lanes along Y), in workgroups
-// of their own at the front of the grid; the few rows at the ends of the end columns per lane from global memory.
-// The lists come from the class rows and the plans (k_lat_table: one representative row per class; then EVERY row is checked: its
-// plan puts its class's coefficients at the offsets of that list, its X has the parity the list's window offsets were worked out for -
-// or the form is refused).
-// MEASURED (round 5, MI355X, configs[3], 9.98 M rows, profiles/r05_p2_lattice_tiles.txt): inside the CG iteration, with the three dots,
-// 155 us per product against 187 - 195 us for k_dict_spmv in the SPACE'S numbering and 222 - 272 us for it in lattice order; alone 134 us
-// without / 149 us with the dots (the work-item product on the same operator: 168 / 230 us).  Of the 134 us the rows at the ends of the
-// lines (4 % of the rows) take 30.  Steps on the way (all bit-identical): per-lane lists from LDS (three LDS reads per entry, loop lengths
-// set by the vertex rows) 342 us; lists through scalar loads 689 us; lists handed out with v_readlane 240 us (16 cycles per readlane);
-// LDS broadcast 184 us; paired lines 167 us; eight waves per tile 158 us; batches of four entries (no spills in the loop) 137 us; and the
-// one that decided it: the compiler had hoisted every thread's nine window positions out of the tile loop into scratch and waited for
-// each reload with vmcnt(0) - for the window load before it -, nine round trips per tile instead of one: with the dots 197 -> 154 us;
-// whole window lines per wave (no division chains) 149 us.  Automatic from 270 000 rows on (option "lattice_order").
-// Later in round 5 (DESIGN.md section 3 has the table): column tiles 150 us inside the iteration; interior strips as one long line
-// (lat_tile_of) 139; a wave's classes from the per-tile table (k_lat_tile_table) 133; column / corner workgroups at the front of the
-// grid, 512 tile workgroups, no private segment 120 us (105 - 115 in the trace; alone 99 us).
-constexpr int LT_TX = 128, LT_TY = 4, LT_TZ = 4;
-constexpr int LT_HX = LT_TX / 2 + 2;                // x positions of one parity in a window line
-constexpr int LT_WY = LT_TY + 4, LT_WZ = LT_TZ + 4;
-constexpr int LT_WINH = LT_HX * LT_WY * LT_WZ;      // doubles of one parity half of the window
-constexpr int LT_WIN = 2 * LT_WINH;                 // 66 KB
-constexpr int CT_XW = 8, CT_Y = 128, CT_Z = 4;     // column tiles (the ends of the lines): X positions of the window, rows along Y, planes
-static_assert(2 * LT_HX * CT_XW * (CT_Z + 4) == LT_WIN && CT_Y / 2 + 2 == LT_HX, "a column tile's window is the tile window's LDS");
-constexpr int LT_LOY = 4, LT_HIY = 4;               // rows at the two ends of a COLUMN whose classes are their own (as LT_LO / LT_HI; no dummy row in Y)
-constexpr int LT_B2 = 4;                            // entries per batch of the paired-lines loop
-constexpr int LT_BLOCK = 512;                       // threads of a tile's workgroup (eight waves share one window)
-constexpr int LT_LO = 4, LT_HI = 5;                 // rows at the two ends of a line whose classes are their own: the boundary rows and - the operator is
-                                                    // scaled with its diagonal - the rows coupled to them (and the dummy row that makes a line even)
-constexpr int LT_ML = 72;                           // entries per class row (a CG2 vertex row of a Kuhn mesh has up to 65), padded to 8
-
-// the tiles of a plane of tiles (k_lattice_spmv's tile loop and k_lat_tile_table walk them the same way)
-struct lat_geom {
-    int64_t n_tiles;
-    int nxc, tiles_z, w_ys, w_ye, w_tiles;
-    int n_ct_wgs, n_extra, grid;        // workgroups 0 .. n_ct_wgs - 1: column tiles; .. n_extra - 1: corner rows; .. grid - 1: tiles
-};
-struct lat_tile {
-    int64_t x0, y0, z0, ylim;
-    bool wrap;
-};
-// A plane of tiles: the strips (four lines in Y) before w_ys and from w_ye on in tiles of their own, nxc to a strip; the strips
-// w_ys .. w_ye - 1 - every line of theirs an interior line in Y - as ONE long line per line number: a tile takes 128 consecutive
-// positions of it, wherever they start, and where it runs over the end of a line it goes on at the start of the line FOUR lines
-// up (the same line number in the next strip: same parities, normally the same class; if not, the wave takes its classes one by
-// one as anywhere).  The window and the rows wrap the same way, so a row's neighbours stay where its list expects them: the
-// first and last rows of a line are not tile rows.  (SX = 216 at configs[3]: two tiles a strip with 88 of 128 positions used in
-// the second become 87 tiles for 51 strips - 5 022 tiles instead of 5 832.)
-__device__ __forceinline__ lat_tile lat_tile_of(int64_t tile, const lat_geom& G, int64_t SX, int64_t NY) {
-    const int tile_z = (int)(tile / G.tiles_z), tq = (int)(tile - (int64_t)tile_z * G.tiles_z);
-    const int w_first = G.w_ys * G.nxc;
-    int tx0, ty0;
-    lat_tile T;
-    T.wrap = false;
-    if (tq < w_first) { tx0 = (tq % G.nxc) * LT_TX; ty0 = (tq / G.nxc) * LT_TY; }
-    else if (tq < w_first + G.w_tiles) {
-        const int g0 = (tq - w_first) * LT_TX, yo = g0 / (int)SX;
-        tx0 = g0 - yo * (int)SX;
-        ty0 = (G.w_ys + yo) * LT_TY;
-        T.wrap = true;
-    } else {
-        const int q2 = tq - w_first - G.w_tiles;
-        tx0 = (q2 % G.nxc) * LT_TX;
-        ty0 = (G.w_ye + q2 / G.nxc) * LT_TY;
-    }
-    T.x0 = tx0; T.y0 = ty0; T.z0 = (int64_t)tile_z * LT_TZ;
-    T.ylim = T.wrap ? (int64_t)G.w_ye * LT_TY : NY;           // (rows behind the long line's end belong to the tiles of strip w_ye)
-    return T;
-}
-// row u of a lane: wave w takes the (line, parity) pairs w, w + 8, ..; -1: not a tile row
-__device__ __forceinline__ int32_t lat_tile_row(const lat_tile& T, int u, int wave, int lane, int64_t SX, int64_t NY, int64_t NZ) {
-    const int wl = wave + (LT_BLOCK / 64) * u, line = wl >> 1, p = wl & 1;
-    int64_t X = T.x0 + 2 * lane + p, Y = T.y0 + (line % LT_TY);
-    const int64_t Z = T.z0 + (line / LT_TY);
-    if (T.wrap && X >= SX) { X -= SX; Y += LT_TY; }
-    const bool in = X >= LT_LO && X <= SX - 1 - LT_HI && Y < T.ylim && Z < NZ;
-    return in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
-}
-
-static const int g_lt_dbg_env = getenv("FS_LATTICE_BITS") ? atoi(getenv("FS_LATTICE_BITS")) : 0;      // (experiments: bits or-ed into the kernel's dbg argument)
-static int g_lt_dbg = 0;     // (FS_LATTICE_DEBUG times k_lattice_spmv once more without the rows at the ends of the lines: 1)
-struct lat_tables {
-    dbuf<int32_t> rep, cnt, off, rel;   // [ncls] representative row, [ncls] entries, [ncls][LT_ML] column offsets (verification) / window offsets
-    dbuf<int32_t> relc;                 // [ncls][LT_ML] the offsets in the window of a COLUMN tile (the ends of the lines: lanes along Y)
-    dbuf<double> coef;                  // [ncls][LT_ML]
-    dbuf<int> info;                     // [0] entries that do not fit / rows whose plan or parity disagrees
-    dbuf<uint32_t> tile_cls;            // [tile][wave][u]: the class of the wave's u-th line (bits 0 - 15), its entries (16 - 23), all live
-                                        // lanes of that class (24), any live lane (25): k_lat_tile_table
-    lat_geom geom = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double* built_for = nullptr;
-    uint64_t space_serial = 0;
-    int ncls = 0;
-    bool ok = false;
-    bool judged = false;                // lat_prepare looked at a matrix since the flag was last cleared (fs_krylov_solve: a solve that never
-                                        // builds a dictionary - BiCGStab, no diagonal scaling - says nothing about the tile form)
-    bool tables_ok = false;             // the lists were built and every row fits them: for dictionary tables number dict_built of that space
-    int64_t dict_built = -1;
-};
-static lat_tables g_lat;
-
-__global__ void k_lat_rep(int64_t n, const uint16_t* __restrict__ cls, int32_t* __restrict__ rep) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; r < n; r += stride) {
-        const int c = cls[r];
-        if (__hip_atomic_load(&rep[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)r) atomicMin(&rep[c], (int32_t)r);
-    }
-}
-
-// BUILD: the representative row of every class writes the class's list from its item's plan; !BUILD: one lane per distinct class of
-// every item checks that the item's plan gives the same offsets, every row that its X has the parity of its class's representative
-// (or its list holds nothing but the diagonal)
-template <bool BUILD>
-__global__ void __launch_bounds__(FS_BLOCK) k_lat_table(int64_t n_items, const int4* __restrict__ items, const dict_plan_round* __restrict__ plans,
-                                                        const uint16_t* __restrict__ cls, const int32_t* __restrict__ rep,
-                                                        const double* __restrict__ values, int S, int RL, int NR, int64_t SX, int64_t NY,
-                                                        int32_t* __restrict__ cnt, double* __restrict__ coef, int32_t* __restrict__ rel,
-                                                        int32_t* __restrict__ off, int* __restrict__ info, int32_t* __restrict__ relc) {
-    const int lane = threadIdx.x & 63;
-    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t plane = SX * NY;
-    int bad = 0;
-    for (; q < n_items; q += stride) {
-        const int4 it = items[q];
-        const int32_t first = it.x, nr = it.y & 0xffff;
-        const dict_plan_round* __restrict__ pl = plans + it.z;
-        const int n_runs = NR * it.w;
-        for (int half = 0; half < 2; ++half) {
-            const int i = half * 64 + lane;
-            const int32_t r = first + i;
-            const int c = i < nr ? (int)cls[r] : -1;
-            const int p = (int)((r % SX) & 1), py = (int)(((r / SX) % NY) & 1);
-            bool work;
-            if (BUILD) work = c >= 0 && rep[c] == r;
-            else {      // the first lane of every class among these 64 rows
-                if (c >= 0 && (((rep[c] % SX) & 1) != p || (((rep[c] / SX) % NY) & 1) != py) && !(cnt[c] == 1 && off[(int64_t)c * LT_ML] == 0)) ++bad;
-                work = false;
-                unsigned long long todo = __ballot(c >= 0);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int cv = __shfl(c, leader, 64);
-                    if (lane == leader) work = true;
-                    todo &= ~__ballot(c == cv);
-                }
-            }
-            if (!work) continue;
-            const double* __restrict__ dv = values + (int64_t)c * S;
-            int k = 0;
-            const int have = BUILD ? 0 : cnt[c];
-            for (int g = 1; g < n_runs; ++g) {          // (run 0 is the z run: no coefficients)
-                const int32_t st = dict_run_start(pl, NR, g);
-                const int ln = dict_run_len(pl, NR, g);
-                for (int t = 0; t < ln; ++t) {
-                    const double v = RL * g + t < S ? dv[RL * g + t] : 0.0;
-                    if (v == 0.0) continue;
-                    const int32_t o = st + t;
-                    if (BUILD) {
-                        // o = dx + SX (dy + NY dz) with |dx|, |dy|, |dz| <= 2
-                        const int64_t dz = (o + (o >= 0 ? plane / 2 : -(plane / 2))) / plane;
-                        const int64_t rem = o - dz * plane;
-                        const int64_t dy = (rem + (rem >= 0 ? SX / 2 : -(SX / 2))) / SX;
-                        const int64_t dx = rem - dy * SX;
-                        const bool fits = k < LT_ML && dx >= -2 && dx <= 2 && dy >= -2 && dy <= 2 && dz >= -2 && dz <= 2;
-                        if (fits) {
-                            // window offset from the row's own position: the other parity's half for odd dx, floor((p + dx) / 2) along x
-                            const int pd = p + (int)dx, p2 = pd & 1, di = (pd - p2) / 2;
-                            coef[(int64_t)c * LT_ML + k] = v;
-                            off[(int64_t)c * LT_ML + k] = o;
-                            rel[(int64_t)c * LT_ML + k] = (p2 - p) * LT_WINH + di + LT_HX * ((int)dy + LT_WY * (int)dz);
-                            // column tiles: the two halves hold the even / odd Y, a line of the window runs along Y
-                            const int qd = py + (int)dy, q2 = qd & 1, dj = (qd - q2) / 2;
-                            relc[(int64_t)c * LT_ML + k] = (q2 - py) * LT_WINH + dj + LT_HX * ((int)dx + CT_XW * (int)dz);
-                        } else ++bad;
-                    } else if (k >= have || off[(int64_t)c * LT_ML + k] != o) ++bad;
-                    ++k;
-                }
-            }
-            if (BUILD) cnt[c] = k <= LT_ML ? k : LT_ML;
-            else if (k != have) ++bad;
-        }
-    }
-    if (bad) atomicAdd(&info[0], bad);
-}
-
-// what k_lattice_spmv needs to know about the four lines of a wave of a tile before it can ask for their lists: once per set of lists
-__global__ void __launch_bounds__(LT_BLOCK) k_lat_tile_table(lat_geom G, int64_t SX, int64_t NY, int64_t NZ, const uint16_t* __restrict__ cls,
-                                                              const int32_t* __restrict__ tcnt, uint32_t* __restrict__ tab) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t tile = blockIdx.x; tile < G.n_tiles; tile += gridDim.x) {
-        const lat_tile T = lat_tile_of(tile, G, SX, NY);
-        for (int u = 0; u < 2 * LT_TY * LT_TZ / (LT_BLOCK / 64); ++u) {
-            const int32_t r = lat_tile_row(T, u, wave, lane, SX, NY, NZ);
-            const int c = r >= 0 ? (int)cls[r] : -1;
-            const unsigned long long live = __ballot(c >= 0);
-            const int cm = live ? __shfl(c, __ffsll((long long)live) - 1, 64) : 0;
-            const bool uni = __ballot(c == cm) == live;
-            const int cn = live ? tcnt[cm] : 0;
-            if (lane == 0)
-                tab[(tile * (LT_BLOCK / 64) + wave) * 4 + u] = (uint32_t)cm | ((uint32_t)cn << 16) | ((uint32_t)uni << 24) | ((uint32_t)(live != 0) << 25);
-        }
-    }
-}
-
-// the rows of a wave: the distinct classes of its lanes one after the other, the class's list through scalar loads
-__device__ __forceinline__ double lat_wave_rows(int c, int own, const double* __restrict__ win, const int32_t* __restrict__ tcnt,
-                                                const double* __restrict__ tcoef, const int32_t* __restrict__ trel) {
-    double a = 0.0;
-    unsigned long long todo = __ballot(c >= 0);
-    while (todo) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        const int cm = __builtin_amdgcn_readlane(c, leader);
-        const bool mine = c == cm;
-        const int cn = __builtin_amdgcn_readfirstlane(tcnt[cm]);
-        const double* __restrict__ cp = tcoef + (int64_t)cm * LT_ML;
-        const int32_t* __restrict__ rp = trel + (int64_t)cm * LT_ML;
-        for (int k0 = 0; k0 < cn; k0 += LT_B2) {        // (a list is padded to a multiple of 8 positions)
-            double cf[LT_B2], xv[LT_B2];
-            int32_t rl[LT_B2];
-#pragma unroll
-            for (int e = 0; e < LT_B2; ++e) {
-                cf[e] = cp[k0 + e];
-                rl[e] = k0 + e < cn ? rp[k0 + e] : 0;
-            }
-#pragma unroll
-            for (int e = 0; e < LT_B2; ++e) xv[e] = win[mine ? own + rl[e] : own];     // (another class's offsets may leave the window)
-#pragma unroll
-            for (int e = 0; e < LT_B2; ++e)
-                if (k0 + e < cn && mine) a = fma(cf[e], xv[e], a);
-        }
-        todo &= ~__ballot(mine);
-    }
-    return a;
-}
-
-// the same for a wave whose lanes are ALL of one class (the rule): the list was loaded into registers ahead of time, entry k in lane k
-// (k + 64: second set); the wave spreads it into its own LDS scratch and every lane reads entry after entry from there - the same
-// address in all lanes, a broadcast (2 cycles on gfx950) - then x at its own position + the entry's offset, one fma.  (v_readlane
-// handed the entries out without LDS and took 16 cycles each: 220 instead of 110 us per product.)  The positions behind the end of a
-// list hold (0.0, 0): they add +0 * x[row].
-__device__ __forceinline__ double lat_wave_rows_uniform(int cn, int own, const double* __restrict__ win, double* __restrict__ sc, int* __restrict__ sr,
-                                                        double vc0, int vr0, double vc1, int vr1) {
-    const int lane = threadIdx.x & 63;
-    sc[lane] = vc0;
-    sr[lane] = vr0;
-    if (lane < LT_ML - 64) { sc[64 + lane] = vc1; sr[64 + lane] = vr1; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double a = 0.0;
-    for (int k0 = 0; k0 < cn; k0 += 8) {
-        double xv[8], cf[8];
-        int rl[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = win[own + rl[e]];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
-    }
-    __builtin_amdgcn_wave_barrier();        // (the next line's list overwrites the scratch)
-    return a;
-}
-
-// ... and for TWO lines of the same class (lines two planes apart: same parities): one read of the list serves both rows of a lane, whose
-// two fma chains are independent
-__device__ __forceinline__ void lat_wave_rows_uniform2(int cn, int own_a, int own_b, const double* __restrict__ win, double* __restrict__ sc, int* __restrict__ sr,
-                                                       double vc0, int vr0, double vc1, int vr1, double& ra, double& rb) {
-    const int lane = threadIdx.x & 63;
-    sc[lane] = vc0;
-    sr[lane] = vr0;
-    if (lane < LT_ML - 64) { sc[64 + lane] = vc1; sr[64 + lane] = vr1; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double a = 0.0, b = 0.0;
-    for (int k0 = 0; k0 < cn; k0 += LT_B2) {       // (batches of four: eight cost 28 more registers and spills at four waves per SIMD)
-        double xa[LT_B2], xb[LT_B2], cf[LT_B2];
-        int rl[LT_B2];
-#pragma unroll
-        for (int e = 0; e < LT_B2; ++e) { cf[e] = sc[k0 + e]; rl[e] = sr[k0 + e]; }
-#pragma unroll
-        for (int e = 0; e < LT_B2; ++e) { xa[e] = win[own_a + rl[e]]; xb[e] = win[own_b + rl[e]]; }
-#pragma unroll
-        for (int e = 0; e < LT_B2; ++e) { a = fma(cf[e], xa[e], a); b = fma(cf[e], xb[e], b); }
-    }
-    __builtin_amdgcn_wave_barrier();        // (the next line's list overwrites the scratch)
-    ra = a;
-    rb = b;
-}
-
-template <int DOTS>
-__global__ void __launch_bounds__(LT_BLOCK, 4) k_lattice_spmv(lat_geom G, const uint32_t* __restrict__ tile_cls, int64_t SX, int64_t NY, int64_t NZ,
-                                                           const uint16_t* __restrict__ cls, const int32_t* __restrict__ tcnt,
-                                                           const double* __restrict__ tcoef, const int32_t* __restrict__ trel, const int32_t* __restrict__ toff, const int32_t* __restrict__ trelc,
-                                                           const double* __restrict__ x, double* __restrict__ y,
-                                                           const double* __restrict__ rvec, double* __restrict__ partials,
-                                                           int* __restrict__ status, int part_base, int part_stride, int bump, int dbg) {
-    const int st0 = DOTS ? status[0] : 0;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    extern __shared__ __attribute__((aligned(16))) double win[];      // [2][LT_WZ][LT_WY][LT_HX]: even X, odd X
-    __shared__ double ldsw[LT_BLOCK / 64];
-    __shared__ double list_c[LT_BLOCK / 64][LT_ML];                   // a wave's scratch: the class list of the line it multiplies
-    __shared__ int list_r[LT_BLOCK / 64][LT_ML];
-    if (DOTS) {
-        if (st0 != 0) return;
-        if (bump && blockIdx.x == 0 && threadIdx.x == 0) status[2] += 1;      // see k_sell_spmv
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n = SX * NY * NZ;
-    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    constexpr int NL = LT_TY * LT_TZ;               // lines of a tile
-    constexpr int NWV = LT_BLOCK / 64;              // waves
-    constexpr int U = 2 * NL / NWV;                 // (line, parity) pairs per wave
-    auto finish = [&](int64_t r, double a, double zi, double ri) {
-        y[r] = a;
-        if (DOTS && DOTS != 4 && !(dbg & 4)) {
-            if (DOTS == 1) { d_rz += ri * zi; d_wz += a * zi; d_rr += ri * ri; }
-            else if (DOTS == 2) { d_rz += a * ri; d_wz += a * a; d_rr += ri * ri; }
-            else if (DOTS == 3) { d_rz += zi * zi; d_wz += a * zi; d_rr += ri * zi * zi; }
-        }
-    };
-    // ---- FIRST the corners: rows of the end columns within LT_LOY / LT_HIY of the ends of their column; every lane its own list, everything
-    // from global memory - a chain of dependent loads, 19 us for 0.2 % of the rows when it ran behind the tiles.  A wave: one column, eight
-    // planes x the eight rows.  Corners and column tiles go to the workgroups counted from the LAST: the tiles are dealt out from the
-    // first (xcd_chunks), so these have one tile less to do than the others.
-    {
-        const int nzb = (int)((NZ + 7) >> 3);
-        const int64_t n_tasks = (int64_t)(LT_LO + LT_HI) * nzb;
-        const bool corner_wg = (int)blockIdx.x >= G.n_ct_wgs && (int)blockIdx.x < G.n_extra;
-        for (int64_t t = corner_wg ? (int64_t)((int)blockIdx.x - G.n_ct_wgs) * NWV + wave : n_tasks; t < n_tasks && !(dbg & 9); t += (int64_t)(G.n_extra - G.n_ct_wgs) * NWV) {
-            const int col = (int)(t % (LT_LO + LT_HI)), d = lane & 7;
-            const int64_t Z = (t / (LT_LO + LT_HI)) * 8 + (lane >> 3);
-            const int64_t Y = d < LT_LOY ? d : NY - (LT_LOY + LT_HIY) + d;
-            const int64_t X = col < LT_LO ? col : SX - (LT_LO + LT_HI) + col;
-            const bool in = Z < NZ;
-            const int64_t rr = X + SX * (Y + NY * (in ? Z : 0));
-            const int cc = (int)cls[rr];
-            int most = in ? tcnt[cc] : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int m2 = __shfl_xor(most, o, 64); most = m2 > most ? m2 : most; }
-            const double* __restrict__ cp = tcoef + (int64_t)cc * LT_ML;
-            const int32_t* __restrict__ op = toff + (int64_t)cc * LT_ML;
-            double a = 0.0;
-            for (int k0 = 0; k0 < most; k0 += 8) {       // (behind a list's end: (0.0, offset 0))
-                double cf[8], xv[8];
-                int32_t of[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { cf[e] = cp[k0 + e]; of[e] = op[k0 + e]; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = x[rr + of[e]];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fma(cf[e], xv[e], a);
-            }
-            if (in) finish(rr, a, x[rr], (DOTS && DOTS != 4) ? rvec[rr] : 0.0);
-        }
-    }
-    // ---- the first LT_LO and the last LT_HI rows of every line (classes of their own): COLUMN tiles.  Along Y such a column is what a line
-    // is along X - rows of one class per parity -, so the same machinery runs with the roles of X and Y exchanged: a workgroup takes
-    // the end columns of one side x 128 Y x 4 Z, loads the window (8 X positions x 132 Y x 8 Z: the same 66 KB, even and odd Y in two
-    // halves, a line of the window along Y), a wave the 64 rows of one Y parity of one (column, plane), two planes two apart together.
-    // The rows at the ends of the COLUMNS (first / last four Y: classes of their own again, 0.2 % of the rows) follow per lane below.
-    const int nycc = (int)((NY + CT_Y - 1) / CT_Y), nzc = (int)((NZ + CT_Z - 1) / CT_Z);
-    const int64_t n_ct = (int64_t)2 * nycc * nzc;
-    for (int64_t ct = (int)blockIdx.x < G.n_ct_wgs ? (int64_t)blockIdx.x : n_ct; ct < n_ct && !(dbg & 1); ct += G.n_ct_wgs) {
-        const int side = (int)(ct & 1);
-        const int64_t ycn = (ct >> 1) % nycc, zcn = (ct >> 1) / nycc;
-        const int64_t y0 = ycn * CT_Y, z0 = zcn * CT_Z;
-        const int64_t xw0 = side ? SX - CT_XW : 0;                  // X of window position 0
-        const int ncol = side ? LT_HI : LT_LO;
-        const int64_t col0 = side ? SX - LT_HI : 0;                 // first end column of this side
-        // window: wave w takes plane w; its items (Y line, pair of X positions): 132 x 4, four lanes a line's 64 bytes
-        // (three loads in flight per lane at a time, a real loop: all nine at once - 36 registers - had this part of the kernel spill, and a
-        // kernel with a private segment pays for it at EVERY launch, in front of the kernel where no event and no trace sees it: about 30 us
-        // per launch of the 2 296 workgroups here)
-        constexpr int NIT = (2 * LT_HX * (CT_XW / 2) + 63) / 64, NIH = 3;
-        static_assert(NIT % NIH == 0, "the window of a column tile is loaded in whole batches");
-        {
-            const int64_t Z = z0 - 2 + wave;
-#pragma unroll 1
-            for (int u0 = 0; u0 < NIT; u0 += NIH) {
-                v2d wv[NIH];
-#pragma unroll
-                for (int u = 0; u < NIH; ++u) {
-                    const int item = (u0 + u) * 64 + lane, yl = item >> 2, xp = item & 3;
-                    const int64_t Y = y0 - 2 + yl;
-                    wv[u] = v2d{0.0, 0.0};
-                    if (yl < 2 * LT_HX && Y >= 0 && Y < NY && Z >= 0 && Z < NZ)
-                        wv[u] = *reinterpret_cast<const v2d*>(x + xw0 + 2 * xp + SX * (Y + NY * Z));
-                }
-#pragma unroll
-                for (int u = 0; u < NIH; ++u) {
-                    const int item = (u0 + u) * 64 + lane, yl = item >> 2, xp = item & 3;
-                    if (yl < 2 * LT_HX) {
-                        const int i = (yl & 1) * LT_WINH + (yl >> 1) + LT_HX * (2 * xp + CT_XW * wave);
-                        win[i] = wv[u].x;
-                        win[i + LT_HX] = wv[u].y;
-                    }
-                }
-            }
-        }
-        // pairs of column lines: q = (column, Y parity, plane pair): planes zl and zl + 2
-        const int npair = ncol * 4;
-        constexpr int UC = (LT_HI * 4 + NWV - 1) / NWV;
-        int32_t r[2 * UC];
-        double ri[2 * UC];
-        int cm[2 * UC], cn[2 * UC];
-        bool uni[2 * UC];
-        auto own_c = [&](int q, int half) {
-            const int col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
-            return py * LT_WINH + (lane + 1) + LT_HX * ((int)(col0 - xw0) + col + CT_XW * (zl + 2));
-        };
-#pragma unroll
-        for (int j = 0; j < UC; ++j)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int q = wave + NWV * j, col = q >> 2, py = (q >> 1) & 1, zl = (q & 1) + 2 * half;
-                const int64_t X = col0 + col, Y = y0 + 2 * lane + py, Z = z0 + zl;
-                const bool in = q < npair && Y >= LT_LOY && Y <= NY - 1 - LT_HIY && Z < NZ;
-                const int u = 2 * j + half;
-                r[u] = in ? (int32_t)(X + SX * (Y + NY * Z)) : -1;
-                ri[u] = (DOTS && DOTS != 4 && in) ? rvec[r[u]] : 0.0;
-                const int c = in ? (int)cls[r[u]] : -1;        // (a lane's own class number is not kept: registers)
-                const unsigned long long live = __ballot(c >= 0);
-                cm[u] = live ? __builtin_amdgcn_readlane(c, __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1)) : 0;
-                uni[u] = __ballot(c == cm[u]) == live;
-                cn[u] = live ? __builtin_amdgcn_readfirstlane(tcnt[cm[u]]) : 0;
-            }
-        auto cls_of = [&](int32_t row) { return row >= 0 ? (int)cls[row] : -1; };
-        struct lat_list { double c0, c1; int r0, r1; };
-        auto load_list = [&](int cls_m) {
-            lat_list L;
-            const int64_t at = (int64_t)cls_m * LT_ML + lane;
-            L.c0 = tcoef[at];
-            L.r0 = trelc[at];
-            L.c1 = tcoef[at + 64];
-            L.r1 = trelc[at + 64];
-            return L;
-        };
-        lat_list cur = load_list(cm[0]);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < UC; ++j) {
-            const int ua = 2 * j, ub = 2 * j + 1, q = wave + NWV * j;
-            lat_list nxt = cur;
-            if (j + 1 < UC) nxt = load_list(cm[2 * (j + 1)]);
-            const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
-            if (both) {
-                double ra, rb;
-                lat_wave_rows_uniform2(cn[ua], own_c(q, 0), own_c(q, 1), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
-                if (r[ua] >= 0) finish(r[ua], ra, win[own_c(q, 0)], ri[ua]);
-                if (r[ub] >= 0) finish(r[ub], rb, win[own_c(q, 1)], ri[ub]);
-            } else {
-                if (cn[ua] != 0) {
-                    double a;
-                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_c(q, 0), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
-                    else a = lat_wave_rows(cls_of(r[ua]), own_c(q, 0), win, tcnt, tcoef, trelc);
-                    if (r[ua] >= 0) finish(r[ua], a, win[own_c(q, 0)], ri[ua]);
-                }
-                if (cn[ub] != 0) {
-                    double a;
-                    if (uni[ub]) {
-                        const lat_list lb = load_list(cm[ub]);
-                        a = lat_wave_rows_uniform(cn[ub], own_c(q, 1), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
-                    } else a = lat_wave_rows(cls_of(r[ub]), own_c(q, 1), win, tcnt, tcoef, trelc);
-                    if (r[ub] >= 0) finish(r[ub], a, win[own_c(q, 1)], ri[ub]);
-                }
-            }
-            cur = nxt;
-        }
-        __syncthreads();
-    }
-    // the tiles: the workgroups behind the first n_extra (a multiple of 8: workgroup b runs on XCD b mod 8), each XCD a contiguous eighth
-    chunk_iter it;
-    {
-        const int b = (int)blockIdx.x - G.n_extra, tg = G.grid - G.n_extra;
-        const int64_t per_xcd = (G.n_tiles + 7) >> 3, e = ((b & 7) + 1) * per_xcd;
-        it.step = tg >> 3;
-        it.cur = b >= 0 ? (b & 7) * per_xcd + (b >> 3) : G.n_tiles;
-        it.end = e < G.n_tiles ? e : G.n_tiles;
-    }
-    for (; it.cur < it.end; it.cur += it.step) {
-        const lat_tile T = lat_tile_of(it.cur, G, SX, NY);
-        const int64_t x0 = T.x0, y0 = T.y0, z0 = T.z0;
-        const bool wrap = T.wrap;
-        // the classes of this wave's four lines: one scalar load (k_lat_tile_table wrote them when the lists were made), asked for with
-        // the window - where the class numbers used to be read per lane, compared across the wave and their list lengths fetched, three
-        // dependent round trips before the first list could be asked for
-        const uint4 tc = *reinterpret_cast<const uint4*>(tile_cls + (it.cur * (LT_BLOCK / 64) + __builtin_amdgcn_readfirstlane(wave)) * 4);
-        // ---- the window of x: lines (y0 - 2 .. y0 + LT_TY + 1) x (z0 - 2 .. ) from X = x0 - 2 on, one 16-byte load per (even, odd)
-        // pair, all of a thread's loads in flight together; outside the lattice: zero
-        // A wave takes LPW whole window lines: lane l the pair l + 1 of each (64 of the 66 pairs of a line, 1 KB per wave and load, the
-        // line's start and validity wave-uniform), and in one more load the 2 x LPW pairs at the ends of its lines.  (Dealing the
-        // window's pairs to the threads by index cost a division chain per load - which the compiler hoisted out of the tile loop
-        // into scratch, whose reloads it then waited for with vmcnt(0): every window load behind the one before it, + 60 us.)
-        constexpr int LPW = LT_WY * LT_WZ / NWV;        // window lines per wave
-        static_assert(LPW * NWV == LT_WY * LT_WZ && 2 * LPW <= 64 && LT_HX == 66, "window lines are dealt to the waves whole");
-        constexpr int NW = LPW + 1;
-        v2d wv[NW];
-#pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            // u < LPW: line wave * LPW + u, pair lane + 1; u == LPW: lanes 0 .. 2 LPW - 1: line wave * LPW + (lane >> 1), pair 0 / 65
-            const int wline = wave * LPW + (u < LPW ? u : (lane >> 1) % LPW);
-            const int xx = u < LPW ? lane + 1 : ((lane & 1) ? LT_HX - 1 : 0);
-            const int yy = wline % LT_WY, zz = wline / LT_WY;
-            int64_t Y = y0 - 2 + yy, Xw = x0 - 2 + 2 * xx;
-            const int64_t Z = z0 - 2 + zz;
-            if (wrap && Xw >= SX) { Xw -= SX; Y += LT_TY; }
-            wv[u] = v2d{0.0, 0.0};
-            if ((u < LPW || lane < 2 * LPW) && Y >= 0 && Y < NY && Z >= 0 && Z < NZ) {
-                int64_t g = Xw + SX * (Y + NY * Z);                    // (even: SX and x0 are)
-                g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);               // columns before / behind the vector carry no entry
-                wv[u] = *reinterpret_cast<const v2d*>(x + g);
-            }
-        }
-        // ---- the rows of this thread: U line waves (line, parity); their class numbers, then the list of the wave's first class (lane k:
-        // entries k and k + 64), asked for before the window is waited for
-        // (row numbers as 32-bit, a row's own window position recomputed where it is used: registers are what this kernel is short of)
-        int32_t r[U];
-        double ri[U];
-        auto own_of = [&](int u) {
-            const int wl = wave + NWV * u, line = wl >> 1, p = wl & 1;
-            return p * LT_WINH + (lane + 1) + LT_HX * ((line % LT_TY) + 2 + LT_WY * ((line / LT_TY) + 2));
-        };
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            r[u] = lat_tile_row(T, u, wave, lane, SX, NY, NZ);
-            const bool in = r[u] >= 0;
-            // (the residual entries of the fused dots: asked for HERE.  Asked for next to the multiplication, their wait - the youngest
-            // loads of the wave: vmcnt(0) - was also a wait for the previous lines' stores of y: + 60 us per product)
-            ri[u] = (DOTS && DOTS != 4 && in && !(dbg & 2)) ? rvec[r[u]] : 0.0;
-        }
-        int cm[U], cn[U];
-        bool uni[U];
-        static_assert(U == 4, "a wave's four lines in one 16-byte word of the tile table");
-        const uint32_t tcw[U] = {tc.x, tc.y, tc.z, tc.w};
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cm[u] = (int)(tcw[u] & 0xffffu);
-            cn[u] = (tcw[u] >> 25) & 1u ? (int)((tcw[u] >> 16) & 0xffu) : 0;
-            uni[u] = (tcw[u] >> 24) & 1u;
-        }
-        struct lat_list { double c0, c1; int r0, r1; };
-        auto load_list = [&](int cls_m) {
-            lat_list L;
-            const int64_t at = (int64_t)cls_m * LT_ML + lane;
-            L.c0 = tcoef[at];
-            L.r0 = trel[at];
-            L.c1 = tcoef[at + 64];          // (the tables are padded: no branch, so that the wait for a list is counted exactly)
-            L.r1 = trel[at + 64];
-            return L;
-        };
-        auto cls_of = [&](int32_t row) { return row >= 0 ? (int)cls[row] : -1; };        // (a wave of several classes: per lane, when it comes to it)
-        // lines u and u + U / 2 of a wave lie two planes apart (same parities in X, Y and Z: normally the same class): taken together
-        static_assert(LT_TZ == 4 && LT_TY == 4, "the pairing of lines below assumes 4 x 4 lines per tile");
-        lat_list cur = load_list(cm[0]);
-#pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            const int wline = wave * LPW + (u < LPW ? u : (lane >> 1) % LPW);
-            const int xx = u < LPW ? lane + 1 : ((lane & 1) ? LT_HX - 1 : 0);
-            const int i = xx + LT_HX * wline;
-            if (u < LPW || lane < 2 * LPW) { win[i] = wv[u].x; win[LT_WINH + i] = wv[u].y; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < U / 2; ++j) {
-            // lines j and j + U / 2 of this wave: the same (line % LT_TY), Z two apart
-            const int ua = j, ub = j + U / 2;
-            lat_list nxt = cur;
-            if (j + 1 < U / 2) nxt = load_list(cm[j + 1]);      // (in flight while these lines are multiplied)
-            const bool both = uni[ua] && uni[ub] && cm[ua] == cm[ub] && cn[ua] != 0 && cn[ub] != 0;
-            const double ria = ri[ua], rib = ri[ub];
-            if (both) {
-                double ra, rb;
-                lat_wave_rows_uniform2(cn[ua], own_of(ua), own_of(ub), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1, ra, rb);
-                if (r[ua] >= 0) finish(r[ua], ra, win[own_of(ua)], ria);
-                if (r[ub] >= 0) finish(r[ub], rb, win[own_of(ub)], rib);
-            } else {
-                if (cn[ua] != 0) {
-                    double a;
-                    if (uni[ua]) a = lat_wave_rows_uniform(cn[ua], own_of(ua), win, list_c[wave], list_r[wave], cur.c0, cur.r0, cur.c1, cur.r1);
-                    else a = lat_wave_rows(cls_of(r[ua]), own_of(ua), win, tcnt, tcoef, trel);
-                    if (r[ua] >= 0) finish(r[ua], a, win[own_of(ua)], ria);
-                }
-                if (cn[ub] != 0) {          // (its list was not asked for ahead of time: tiles where the class changes between the planes)
-                    double a;
-                    if (uni[ub]) {
-                        const lat_list lb = load_list(cm[ub]);
-                        a = lat_wave_rows_uniform(cn[ub], own_of(ub), win, list_c[wave], list_r[wave], lb.c0, lb.r0, lb.c1, lb.r1);
-                    } else a = lat_wave_rows(cls_of(r[ub]), own_of(ub), win, tcnt, tcoef, trel);
-                    if (r[ub] >= 0) finish(r[ub], a, win[own_of(ub)], rib);
-                }
-            }
-            cur = nxt;
-        }
-        __syncthreads();            // (the next tile overwrites the window)
-    }
-    if (DOTS && DOTS != 4) {
-        // (fixed order: shuffle reduction per wave, the waves' sums added in order by thread 0)
-        double t[3] = {d_rz, d_wz, d_rr};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double v = t[q];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) ldsw[wave] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double acc = 0.0;
-                for (int w = 0; w < LT_BLOCK / 64; ++w) acc += ldsw[w];
-                partials[q * part_stride + part_base + blockIdx.x] = acc;
-            }
-            __syncthreads();
-        }
-    }
-}
-static size_t lat_lds_bytes() { return (size_t)LT_WIN * 8; }
-
-// ---- the same product for 3 x 3 block rows (vector P1 spaces: the elasticity operator of a uniform box; the fine level of its AMG) --
-// A lane holds two consecutive NODES (six rows); a run's load is the six values x[3 (r + o)] .. x[3 (r + o) + 5] (three 16-byte
-// loads), the next two nodes come from the next lane; class rows are [position][9].  Per stored block the terms are added in the
-// streaming kernel's order (k_sell_spmv<3, ..>: column component outer, row component inner): same bits.  Rounds are taken in two
-// halves of four runs (a round's 48 doubles of x per lane would not leave room for anything else).  No fused dots: this is the
-// product of fs_spmv_dev - the AMG V-cycle's fine level and its CG.
-template <int RL>
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_spmv3(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
-                                                         const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
-                                                         const double* __restrict__ dict, int S, int C,
-                                                         const double* __restrict__ x, double* __restrict__ y, int map_xcd) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ __attribute__((aligned(16))) double sdict[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    double* __restrict__ wl = sdict + (int64_t)wave * C * S;
-    constexpr int K = FS_DICT_ITEMS_PER_WAVE;
-    const int64_t n_chunks = (n_items + 4 * K - 1) / (4 * K);
-    const int32_t cmax = (int32_t)(n_cols - 1);
-    chunk_iter it = xcd_chunks(n_chunks);
-    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
-    int tagv = -1, rr = 0;
-    const unsigned long long cmask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
-    for (; it.cur < it.end; it.cur += it.step)
-    for (int kk = 0; kk < K; ++kk) {
-        const int64_t q = (it.cur * 4 + wave) * K + kk;
-        if (q >= n_items) break;
-        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
-        const int32_t first = __builtin_amdgcn_readfirstlane(ds.x);
-        const int nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
-        const int edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
-        const dict_plan_round* __restrict__ pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
-        const int rounds = __builtin_amdgcn_readfirstlane(ds.w);
-        const int32_t r = first + 2 * lane;
-        const bool ok0 = 2 * lane < nr, ok1 = 2 * lane + 1 < nr;
-        const int c0 = ok0 ? (int)cls[r] : -1, c1 = ok1 ? (int)cls[r + 1] : -1;
-        // ---- the classes of this item's nodes -> the wave's LDS region, unless they are there already (k_dict_spmv) ----
-        int b0 = 0, b1 = 0;
-        {
-            unsigned long long inuse = 0ull;
-            bool copied = false;
-            unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
-            while (m0 | m1) {
-                const bool from0 = m0 != 0ull;
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)(from0 ? m0 : m1)) - 1);
-                const int cv = __builtin_amdgcn_readlane(from0 ? c0 : c1, src);
-                const unsigned long long hit = __ballot(tagv == cv) & cmask;
-                int slot;
-                if (hit) slot = __ffsll((long long)hit) - 1;
-                else {
-                    const unsigned long long freeb = ~inuse & cmask, ahead = freeb & ~((1ull << rr) - 1ull);
-                    slot = __ffsll((long long)(ahead ? ahead : freeb)) - 1;
-                    rr = slot + 1 == C ? 0 : slot + 1;
-                    fs_wave_copy_pairs(wl + slot * S, dict + (int64_t)cv * S, S >> 1, lane);
-                    if (lane == slot) tagv = cv;
-                    copied = true;
-                }
-                inuse |= 1ull << slot;
-                const bool h0 = c0 == cv, h1 = c1 == cv;
-                if (h0) b0 = slot * S;
-                if (h1) b1 = slot * S;
-                m0 &= ~__ballot(h0);
-                m1 &= ~__ballot(h1);
-            }
-            if (copied) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-        const double* __restrict__ v0 = wl + b0;
-        const double* __restrict__ v1 = wl + b1;
-        double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
-        for (int rd = 0; rd < rounds; ++rd) {
-            const dict_plan_round* __restrict__ p = pl + rd;
-#pragma unroll 1
-            for (int h4 = 0; h4 < 8; h4 += FS_DICT3_RUNS) {
-                v2d A[FS_DICT3_RUNS][3];
-                if (!edge) {
-#pragma unroll
-                    for (int j = 0; j < FS_DICT3_RUNS; ++j) {
-                        const double* __restrict__ xp = x + 3 * ((int64_t)r + p->start[h4 + j]);
-                        A[j][0] = *reinterpret_cast<const v2du*>(xp);
-                        A[j][1] = *reinterpret_cast<const v2du*>(xp + 2);
-                        A[j][2] = *reinterpret_cast<const v2du*>(xp + 4);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < FS_DICT3_RUNS; ++j) {
-                        int32_t ca = r + p->start[h4 + j], cb = ca + 1;
-                        ca = ca < 0 ? 0 : (ca > cmax ? cmax : ca);
-                        cb = cb < 0 ? 0 : (cb > cmax ? cmax : cb);
-                        const double* __restrict__ pa = x + 3 * (int64_t)ca;
-                        const double* __restrict__ pb = x + 3 * (int64_t)cb;
-                        A[j][0].x = pa[0]; A[j][0].y = pa[1]; A[j][1].x = pa[2];
-                        A[j][1].y = pb[0]; A[j][2].x = pb[1]; A[j][2].y = pb[2];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < FS_DICT3_RUNS; ++j) {
-                    const double e0[3] = {A[j][0].x, A[j][0].y, A[j][1].x}, e1[3] = {A[j][1].y, A[j][2].x, A[j][2].y};
-                    const double* __restrict__ w0 = v0 + (8 * RL * rd + RL * (h4 + j)) * 9;
-                    const double* __restrict__ w1 = v1 + (8 * RL * rd + RL * (h4 + j)) * 9;
-                    // (a compiler barrier after every 3 x 3 block: left alone the compiler reads a run's 54 coefficients - and the next
-                    // runs' - ahead of the first fma: 256 VGPRs and spills, one wave per SIMD, 219 us)
-                    auto block_terms = [&](const double* __restrict__ cb, const double (&e)[3], double (&acc)[3]) {
-#pragma unroll
-                        for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) acc[i] = fma(cb[i * 3 + jj], e[jj], acc[i]);
-                        asm volatile("" ::: "memory");
-                    };
-                    block_terms(w0, e0, a0);      block_terms(w1, e1, a1);
-                    const double e2[3] = {fs_from_next_lane(e0[0]), fs_from_next_lane(e0[1]), fs_from_next_lane(e0[2])};
-                    block_terms(w0 + 9, e1, a0);  block_terms(w1 + 9, e2, a1);
-                    if (RL == 3) {
-                        const double e3[3] = {fs_from_next_lane(e1[0]), fs_from_next_lane(e1[1]), fs_from_next_lane(e1[2])};
-                        block_terms(w0 + 18, e2, a0); block_terms(w1 + 18, e3, a1);
-                    }
-                }
-            }
-        }
-        double* __restrict__ yp = y + 3 * (int64_t)r;
-        if (ok1) {
-            v2d o0, o1, o2;
-            o0.x = a0[0]; o0.y = a0[1]; o1.x = a0[2]; o1.y = a1[0]; o2.x = a1[1]; o2.y = a1[2];
-            *reinterpret_cast<v2du*>(yp) = o0; *reinterpret_cast<v2du*>(yp + 2) = o1; *reinterpret_cast<v2du*>(yp + 4) = o2;
-        } else if (ok0) { yp[0] = a0[0]; yp[1] = a0[1]; yp[2] = a0[2]; }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
+#include "fs_krylov_dict3.inc"      // the row-dictionary product of 3 x 3 block rows (k_dict_spmv3)
 
 struct row_dict {
     dbuf<uint16_t> cls, cls_slot;
@@ -1766,1153 +69,7 @@ struct row_dict_scope {
     ~row_dict_scope() { g_dict.built_for = nullptr; }
 };
 
-// ---- CG scalar state on the device ---------------------------------------------------------
-// sums[0..2] = gamma=r.z, delta=w.z, rho=r.r of the current iteration (globally reduced)
-// ctrl[0] = threshold on rho (max(rtol^2 b.b, atol^2)), ctrl[1] = b.b, ctrl[2] = max_iter (read by the update kernels of a
-// captured batch, so that one instantiated graph serves solves with different iteration limits)
-// scal[2][2] = (gamma, alpha) of the previous iteration, double-buffered by iteration parity
-// status[0] = 0 running / 1 converged / 2 breakdown / 3 max_iter, status[1] = iterations
-__global__ void k_set_threshold(const double* __restrict__ bb, double rtol, double atol, double* __restrict__ ctrl) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double t = rtol * rtol * bb[0];
-        ctrl[0] = fmax(t, atol * atol);
-        ctrl[1] = bb[0];
-    }
-}
-__global__ void k_set_iteration_limit(double* __restrict__ ctrl, int max_iter) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctrl[2] = (double)max_iter;
-}
-
-// FUSED: every workgroup first sums the SpMV's per-WG partials itself (same fixed order as
-// k_sum_partials, so all workgroups obtain bit-identical gamma/delta/rho) - saves one launch per
-// iteration on a single GPU; with a communicator the sums come from the all-reduced `sums`.
-// alpha, beta of the single-reduction recurrences from the reduced sums and the previous iteration's (gamma, alpha).  ONE definition
-// for every kernel that needs them - the update kernels, the peer-to-peer exchange kernel that advances the ghost rows of r and
-// s on its own, the pipelined recurrence: the ghost copies stay bit-identical to the owner's rows only if all of them apply the
-// same bits.  false: not SPD / NaN.
-__device__ __forceinline__ bool cg_scalars_from(int iter, double gamma, double delta, double rho, double gamma_old, double alpha_old,
-                                                 double& alpha, double& beta) {
-    beta = 0.0;
-    if (iter == 0) {
-        alpha = gamma / delta;
-    } else {
-        beta = gamma / gamma_old;
-        alpha = gamma / (delta - beta * gamma / alpha_old);
-    }
-    return (alpha > 0.0) && (alpha < 1e300) && (rho == rho);
-}
-__device__ __forceinline__ bool cg_scalars(int iter, double gamma, double delta, double rho, const double* __restrict__ scal,
-                                            double& alpha, double& beta) {
-    double gamma_old = 0.0, alpha_old = 0.0;
-    if (iter != 0) {
-        gamma_old = scal[2 * ((iter - 1) & 1) + 0];
-        alpha_old = scal[2 * ((iter - 1) & 1) + 1];
-    }
-    return cg_scalars_from(iter, gamma, delta, rho, gamma_old, alpha_old, alpha, beta);
-}
-
-template <bool FUSED>
-__global__ void __launch_bounds__(FS_BLOCK) k_cg_update(int64_t n, int iter, int check_only,
-                                                        const double* __restrict__ partials, int npart,
-                                                        const double* __restrict__ sums,
-                                                        const double* __restrict__ ctrl, double* __restrict__ scal,
-                                                        int* __restrict__ status, double* __restrict__ hist,
-                                                        const double* __restrict__ dinv, double* z,
-                                                        const double* __restrict__ w, double* __restrict__ p,
-                                                        double* __restrict__ sv, double* __restrict__ x,
-                                                        double* __restrict__ r) {
-    if (status[0] != 0) return;
-    double gamma, delta, rho;
-    if (FUSED) {
-        __shared__ double lds4[4];
-        __shared__ double sh[3];
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int i = threadIdx.x; i < npart; i += FS_BLOCK) {
-            a0 += partials[i];
-            a1 += partials[npart + i];
-            a2 += partials[2 * npart + i];
-        }
-        const double t0 = fs_block_sum(a0, lds4);
-        const double t1 = fs_block_sum(a1, lds4);
-        const double t2 = fs_block_sum(a2, lds4);
-        if (threadIdx.x == 0) { sh[0] = t0; sh[1] = t1; sh[2] = t2; }
-        __syncthreads();
-        gamma = sh[0]; delta = sh[1]; rho = sh[2];
-    } else {
-        gamma = sums[0]; delta = sums[1]; rho = sums[2];
-    }
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    if (leader) hist[iter] = rho;
-    if (rho <= ctrl[0]) {  // every workgroup takes the same branch: inputs are identical
-        if (leader) { status[1] = iter; status[0] = 1; }
-        return;
-    }
-    if (check_only) {
-        if (leader) { status[1] = iter; status[0] = 3; }
-        return;
-    }
-    double beta, alpha;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {  // not SPD / NaN
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
-    if (leader) {
-        scal[2 * (iter & 1) + 0] = gamma;
-        scal[2 * (iter & 1) + 1] = alpha;
-    }
-    // 16-B vectorised body; n even part as double2, tail scalar
-    const int64_t n2 = n >> 1;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    double2* z2 = reinterpret_cast<double2*>(z);  // read and written in place: no restrict
-    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
-    const double2* __restrict__ d2 = reinterpret_cast<const double2*>(dinv);
-    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
-    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
-    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
-    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
-    for (; i < n2; i += stride) {
-        const double2 zz = z2[i], ww = w2[i], dd = d2[i];
-        double2 pp = p2[i], ss = s2[i], xx = x2[i], rr = r2[i];
-        pp.x = zz.x + beta * pp.x;  pp.y = zz.y + beta * pp.y;
-        ss.x = ww.x + beta * ss.x;  ss.y = ww.y + beta * ss.y;
-        xx.x += alpha * pp.x;       xx.y += alpha * pp.y;
-        rr.x -= alpha * ss.x;       rr.y -= alpha * ss.y;
-        p2[i] = pp; s2[i] = ss; x2[i] = xx; r2[i] = rr;
-        double2 zn; zn.x = dd.x * rr.x; zn.y = dd.y * rr.y;
-        z2[i] = zn;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t t = n - 1;
-        const double pp = z[t] + beta * p[t];
-        const double ss = w[t] + beta * sv[t];
-        p[t] = pp; sv[t] = ss;
-        x[t] += alpha * pp;
-        const double rr = r[t] - alpha * ss;
-        r[t] = rr;
-        z[t] = dinv[t] * rr;
-    }
-}
-
-// ---- BiCGStab (non-symmetric operators: advection, ScalarTransportSolver.py:305-311) --------------
-// Right-preconditioned (Jacobi) BiCGStab, PETSc KSPBCGS.  Per iteration: two fused SpMV+dots launches and
-// three fused vector kernels; rho/alpha/omega, the threshold and the status word live on the device,
-// exactly as for CG.  bscal = {rho[parity 0], rho[parity 1], alpha, omega}.
-template <int NS>
-__device__ __forceinline__ void wg_sum_partials(const double* __restrict__ partials, int npart, double (&out)[NS]) {
-    __shared__ double lds4[4];
-    __shared__ double sh[NS];
-    double a[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = 0.0;
-    // four trips at a time, their 4 NS loads in flight together (the plain loop waits for every trip's loads before the next
-    // trip's go out: four dependent round trips for 1024 partials, and the partials were written by the previous launch on other
-    // XCDs - about 0.7 us each); a thread's partials are still added in ascending index: same bits
-    for (int i0 = threadIdx.x; i0 < npart; i0 += 4 * FS_BLOCK) {
-        double v[4][NS];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = i0 + t * FS_BLOCK;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) v[t][j] = partials[(int64_t)j * npart + (i < npart ? i : npart - 1)];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (i0 + t * FS_BLOCK < npart) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) a[j] += v[t][j];
-            }
-    }
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const double t = fs_block_sum(a[j], lds4);
-        if (threadIdx.x == 0) sh[j] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NS; ++j) out[j] = sh[j];
-}
-
-static __global__ void __launch_bounds__(FS_BLOCK) k_dot2_partial(const double* __restrict__ a, const double* __restrict__ b,
-                                                                  const double* __restrict__ c, const double* __restrict__ d,
-                                                                  int64_t n, double* __restrict__ partial) {
-    __shared__ double lds4[4];
-    double s0 = 0.0, s1 = 0.0;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        s0 += a[i] * b[i];
-        s1 += c[i] * d[i];
-    }
-    const double t0 = fs_block_sum(s0, lds4);
-    const double t1 = fs_block_sum(s1, lds4);
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = t0;
-        partial[gridDim.x + blockIdx.x] = t1;
-    }
-}
-
-// K1: (rho_new = rhat.r, rr = r.r) -> convergence test, beta, p = r + beta (p - omega v), y = D^-1 p
-template <bool FUSED>
-__global__ void __launch_bounds__(FS_BLOCK) k_bicg_p(int64_t n, int iter, int check_only,
-                                                     const double* __restrict__ partials, int npart,
-                                                     const double* __restrict__ sums, const double* __restrict__ ctrl,
-                                                     double* __restrict__ bscal, int* __restrict__ status,
-                                                     double* __restrict__ hist, const double* __restrict__ dinv,
-                                                     const double* __restrict__ r, double* __restrict__ p,
-                                                     const double* __restrict__ v, double* __restrict__ y) {
-    if (status[0] != 0) return;
-    double sm[2];
-    if (FUSED) wg_sum_partials<2>(partials, npart, sm);
-    else { sm[0] = sums[0]; sm[1] = sums[1]; }
-    const double rho_new = sm[0], rr = sm[1];
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    if (leader) hist[iter] = rr;
-    if (rr <= ctrl[0]) {
-        if (leader) { status[1] = iter; status[0] = 1; }
-        return;
-    }
-    if (check_only) {
-        if (leader) { status[1] = iter; status[0] = 3; }
-        return;
-    }
-    double beta = 0.0, omega = 0.0;
-    if (iter > 0) {
-        const double rho_old = bscal[(iter - 1) & 1];
-        const double alpha = bscal[2];
-        omega = bscal[3];
-        beta = (rho_new / rho_old) * (alpha / omega);
-    }
-    if (!(rho_new == rho_new) || rho_new == 0.0 || !(beta == beta) || !(fabs(beta) < 1e300)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
-    if (leader) bscal[iter & 1] = rho_new;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const double pn = iter == 0 ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
-        p[i] = pn;
-        y[i] = dinv[i] * pn;
-    }
-}
-
-// K3: alpha = rho / (rhat.v); s = r - alpha v; z = D^-1 s
-template <bool FUSED>
-__global__ void __launch_bounds__(FS_BLOCK) k_bicg_s(int64_t n, int iter, const double* __restrict__ partials,
-                                                     int npart, const double* __restrict__ sums,
-                                                     double* __restrict__ bscal, int* __restrict__ status,
-                                                     const double* __restrict__ dinv, const double* __restrict__ r,
-                                                     const double* __restrict__ v, double* __restrict__ sv,
-                                                     double* __restrict__ z) {
-    if (status[0] != 0) return;
-    double sm[1];
-    if (FUSED) wg_sum_partials<1>(partials, npart, sm);
-    else sm[0] = sums[0];
-    const double rv = sm[0];
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    const double alpha = bscal[iter & 1] / rv;
-    if (rv == 0.0 || !(alpha == alpha) || !(fabs(alpha) < 1e300)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
-    if (leader) bscal[2] = alpha;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const double si = r[i] - alpha * v[i];
-        sv[i] = si;
-        z[i] = dinv[i] * si;
-    }
-}
-
-// K5: omega = (t.s)/(t.t); x += alpha y + omega z; r = s - omega t; partial dots (rhat.r, r.r)
-template <bool FUSED>
-__global__ void __launch_bounds__(FS_BLOCK) k_bicg_x(int64_t n, int iter, const double* __restrict__ partials,
-                                                     int npart, const double* __restrict__ sums,
-                                                     double* __restrict__ bscal, int* __restrict__ status,
-                                                     double* __restrict__ x, const double* __restrict__ y,
-                                                     const double* __restrict__ z, double* __restrict__ r,
-                                                     const double* __restrict__ sv, const double* __restrict__ t,
-                                                     const double* __restrict__ rhat, double* __restrict__ pout) {
-    if (status[0] != 0) return;
-    double sm[2];
-    if (FUSED) wg_sum_partials<2>(partials, npart, sm);
-    else { sm[0] = sums[0]; sm[1] = sums[1]; }
-    const double ts = sm[0], tt = sm[1];
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    const double omega = tt > 0.0 ? ts / tt : 0.0;   // t = 0 only when s = 0: x + alpha y is already exact
-    const double alpha = bscal[2];
-    if (!(omega == omega)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
-    if (leader) bscal[3] = omega;
-    __shared__ double lds4b[4];
-    double d0 = 0.0, d1 = 0.0;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        x[i] += alpha * y[i] + omega * z[i];
-        const double ri = sv[i] - omega * t[i];
-        r[i] = ri;
-        d0 += rhat[i] * ri;
-        d1 += ri * ri;
-    }
-    const double t0 = fs_block_sum(d0, lds4b);
-    const double t1 = fs_block_sum(d1, lds4b);
-    if (threadIdx.x == 0) {
-        pout[blockIdx.x] = t0;
-        pout[gridDim.x + blockIdx.x] = t1;
-    }
-}
-
-// ---- CG on the symmetrically scaled system  D^-1/2 A D^-1/2 (PETSc KSPSetDiagonalScale) ------------
-// Jacobi-PCG on A is unpreconditioned CG on the scaled operator, for which z == r: the update kernel
-// drops the z and D^-1 streams (72 instead of 96 B/DOF per iteration).  rho stays the UNSCALED ||r||^2
-// (sum d r^2, computed in the SpMV), so the stopping test is unchanged.
-template <bool FUSED, bool NT = false>
-__global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled(int64_t n, int iter, int check_only,
-                                                               const double* __restrict__ partials, int npart,
-                                                               const double* __restrict__ sums,
-                                                               const double* __restrict__ ctrl,
-                                                               double* __restrict__ scal, int* __restrict__ status,
-                                                               double* __restrict__ hist, double* __restrict__ r,
-                                                               const double* __restrict__ w, double* __restrict__ p,
-                                                               double* __restrict__ sv, double* __restrict__ x, int* __restrict__ mirror = nullptr, int r_plain = 0) {
-    // mirror (one GPU; may be null): the pinned progress words of k_dict_cg_iter - [0] status once stopped, [1] iteration in progress
-    // (the status word is looked at AFTER the first trip's loads have gone out - everything a launch reads first was written by the
-    // previous launch on other XCDs, and each dependent load is a round trip of about a microsecond)
-    const int st0 = status[0];
-    const int st2 = status[2];
-    const double it_max = ctrl[2], thresh = ctrl[0];
-    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];      // (gamma, alpha) of the two iteration parities
-    // NT (vectors larger than the caches, 10 M DOF): non-temporal loads and stores - the probe in tools/probes streams
-    // 7.2 instead of 6.4 TB/s that way
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    struct io {
-        static __device__ __forceinline__ double2 ld(const double2* q) {
-            if (NT) { const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)); return make_double2(t.x, t.y); }
-            return *q;
-        }
-        static __device__ __forceinline__ void st(double2* q, const double2& v) {
-            if (NT) { v2d t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(q)); }
-            else *q = v;
-        }
-    };
-    const int64_t n2 = n >> 1;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
-    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
-    double2* __restrict__ s2 = reinterpret_cast<double2*>(sv);
-    double2* __restrict__ x2 = reinterpret_cast<double2*>(x);
-    double2* __restrict__ r2 = reinterpret_cast<double2*>(r);
-    // the operands of the first trip are requested BEFORE the sums are reduced (at 1 M rows a thread makes two trips and the
-    // kernel is latency-bound: the reduction of 3 x 1024 partials and the ten loads of the trip used to be two round trips in a row)
-    const bool first_trip = i + stride < n2;
-    double2 wa0 = {0.0, 0.0}, wb0 = wa0, pa0 = wa0, sa0 = wa0, xa0 = wa0, ra0 = wa0, pb0 = wa0, sb0 = wa0, xb0 = wa0, rb0 = wa0;
-    if (first_trip) {
-        const int64_t j = i + stride;
-        wa0 = io::ld(&w2[i]); wb0 = io::ld(&w2[j]);
-        pa0 = io::ld(&p2[i]); sa0 = io::ld(&s2[i]); xa0 = io::ld(&x2[i]); ra0 = io::ld(&r2[i]);
-        pb0 = io::ld(&p2[j]); sb0 = io::ld(&s2[j]); xb0 = io::ld(&x2[j]); rb0 = io::ld(&r2[j]);
-    }
-    if (st0 != 0) return;
-    if (iter < 0) {                 // captured batch: the index of the product that preceded this launch
-        iter = st2 - 1;
-        check_only = iter >= (int)it_max ? 1 : 0;
-    }
-    double gamma, delta, rho;
-    if (FUSED) {
-        double sm[3];
-        wg_sum_partials<3>(partials, npart, sm);
-        gamma = sm[0]; delta = sm[1]; rho = sm[2];
-    } else {
-        gamma = sums[0]; delta = sums[1]; rho = sums[2];
-    }
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    if (leader) hist[iter] = rho;
-    auto stop = [&](int code) {
-        if (leader) {
-            status[1] = iter; status[0] = code;
-            if (mirror) { fs_host_store(mirror + 1, iter); fs_host_store(mirror, code); }
-        }
-    };
-    if (rho <= thresh) { stop(1); return; }
-    if (check_only) { stop(3); return; }
-    double beta, alpha;
-    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) { stop(2); return; }
-    if (leader) {
-        scal[2 * (iter & 1) + 0] = gamma;
-        scal[2 * (iter & 1) + 1] = alpha;
-        if (mirror) fs_host_store(mirror + 1, iter + 1);
-    }
-    // two strided elements per trip: ten 16-B loads in flight per lane (the kernel is latency-bound at 1 M DOF)
-    bool prefetched = first_trip;
-    for (; i + stride < n2; i += 2 * stride) {
-        const int64_t j = i + stride;
-        double2 wa, wb, pa, sa, xa, ra, pb, sb, xb, rb;
-        if (prefetched) {
-            wa = wa0; wb = wb0; pa = pa0; sa = sa0; xa = xa0; ra = ra0; pb = pb0; sb = sb0; xb = xb0; rb = rb0;
-            prefetched = false;
-        } else {
-            wa = io::ld(&w2[i]); wb = io::ld(&w2[j]);
-            pa = io::ld(&p2[i]); sa = io::ld(&s2[i]); xa = io::ld(&x2[i]); ra = io::ld(&r2[i]);
-            pb = io::ld(&p2[j]); sb = io::ld(&s2[j]); xb = io::ld(&x2[j]); rb = io::ld(&r2[j]);
-        }
-        pa.x = ra.x + beta * pa.x;  pa.y = ra.y + beta * pa.y;
-        pb.x = rb.x + beta * pb.x;  pb.y = rb.y + beta * pb.y;
-        sa.x = wa.x + beta * sa.x;  sa.y = wa.y + beta * sa.y;
-        sb.x = wb.x + beta * sb.x;  sb.y = wb.y + beta * sb.y;
-        xa.x += alpha * pa.x;       xa.y += alpha * pa.y;
-        xb.x += alpha * pb.x;       xb.y += alpha * pb.y;
-        ra.x -= alpha * sa.x;       ra.y -= alpha * sa.y;
-        rb.x -= alpha * sb.x;       rb.y -= alpha * sb.y;
-        // (r_plain, bits: ordinary stores for r / p / s / x where the kernel otherwise streams its stores past the caches; g_upd_r_plain)
-        if (r_plain & 2) { p2[i] = pa; p2[j] = pb; } else { io::st(&p2[i], pa); io::st(&p2[j], pb); }
-        if (r_plain & 4) { s2[i] = sa; s2[j] = sb; } else { io::st(&s2[i], sa); io::st(&s2[j], sb); }
-        if (r_plain & 8) { x2[i] = xa; x2[j] = xb; } else { io::st(&x2[i], xa); io::st(&x2[j], xb); }
-        if (r_plain & 1) { r2[i] = ra; r2[j] = rb; } else { io::st(&r2[i], ra); io::st(&r2[j], rb); }
-    }
-    for (; i < n2; i += stride) {
-        const double2 ww = w2[i];
-        double2 pp = p2[i], ss = s2[i], xx = x2[i], rr = r2[i];
-        pp.x = rr.x + beta * pp.x;  pp.y = rr.y + beta * pp.y;
-        ss.x = ww.x + beta * ss.x;  ss.y = ww.y + beta * ss.y;
-        xx.x += alpha * pp.x;       xx.y += alpha * pp.y;
-        rr.x -= alpha * ss.x;       rr.y -= alpha * ss.y;
-        p2[i] = pp; s2[i] = ss; x2[i] = xx; r2[i] = rr;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t t = n - 1;
-        const double pp = r[t] + beta * p[t];
-        const double ss = w[t] + beta * sv[t];
-        p[t] = pp; sv[t] = ss;
-        x[t] += alpha * pp;
-        r[t] -= alpha * ss;
-    }
-}
-
-// ---- ONE launch per CG iteration (row-dictionary operators, one GPU) ------------------------------------------------------------
-// Launch k does the update of iteration k AND the product of iteration k + 1:
-//      s_k = w_k + beta_k s_{k-1};   r_{k+1} = r_k - alpha_k s_k;   p_k = r_k + beta_k p_{k-1};   x_{k+1} = x_k + alpha_k p_k
-//      w_{k+1} = A r_{k+1}   with the three sums (r.r, w.r, sum d r^2) of the new pair
-// The product needs r_{k+1} on the NEIGHBOUR rows, which other workgroups own: instead of waiting for them (a device-wide barrier
-// costs 8 us on the 8 XCDs of gfx950, DESIGN history) every lane recomputes r_{k+1}[j] = r_k[j] - alpha (w_k[j] + beta s_{k-1}[j])
-// for the columns its runs touch - the same two fmas the owner applies, hence the same bits - from the OLD r, w, s, which are
-// read-only during the launch: r, w, s are double-buffered by iteration parity, p and x are row-local and stay in place.  alpha_k,
-// beta_k come from the dot partials launch k - 1 left (summed by every workgroup, as k_cg_update_scaled does).
-// Per row: reads r, w, s (neighbour values from L1 / L2), p, x, d, the 2-byte class; writes r, w, s, p, x = 90 B instead of the
-// 98 B and two launches of k_dict_spmv + k_cg_update_scaled; 3 x 3.5 vector loads per row for the runs instead of 3.5.
-// The iteration number travels on the device (it_ctr[par] read by everybody, it_ctr[par ^ 1] = iter + 1 written by one lane) so
-// that a captured batch replays with constant arguments; par = parity of the launch = which buffers are `old`.
-// Whole dictionary in LDS only (P1 boxes: the operators whose iteration is launch-bound).
-// Measured on MI355X (tools/probes/fused_iter_probe.py, hipGraph batches): 1 M rows: 27.4 us per iteration against 29.9 us for
-// the two launches, iterates BIT-IDENTICAL (the same fmas on the same operands, the same partial-sum geometry); 10 M rows: 285 us
-// against 187 us - with ONE neighbour vector instead of three (timing ablation, wrong numerics) still 220 us: the row-local
-// streams (5 loads, 5 stores per row) reach 4.1 TB/s inside an item-by-item kernel against the 6.5 TB/s of the grid-stride update
-// kernel, and three vectors x three mesh planes no longer fit the 4 MB L2 of an XCD.  Hence automatic only where the vectors
-// stay in the Infinity Cache (FS_CG_FUSED_MAX_ROWS, default 3 M rows).
-#ifdef FS_ITER_TIMING
-__device__ long long g_iter_dbg[8 * 4096];
-#define FS_STAMP(k) do { if (threadIdx.x == 0 && it_ctr[par] == 100) g_iter_dbg[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
-#else
-#define FS_STAMP(k) do { } while (0)
-#endif
-// COMM: a decomposed space - the three sums come reduced over the ranks from `sums` (k_cg_p2p_exchange<true> before this launch put
-// them there, stored the neighbours' w into the ghost rows of w_in and advanced the ghost rows of r_out / s_out); the neighbour
-// columns of an item may then be ghost columns: n_cols counts them.
-template <int RL, bool COMM>
-__global__ void __launch_bounds__(FS_BLOCK) k_dict_cg_iter(int64_t n_cols, int64_t n_items, const int4* __restrict__ items,
-                                                           const dict_plan_round* __restrict__ plans, const uint16_t* __restrict__ cls,
-                                                           const double* __restrict__ dict, int S, int C,
-                                                           const double* __restrict__ r_in, const double* __restrict__ w_in,
-                                                           const double* __restrict__ s_in, double* __restrict__ r_out,
-                                                           double* __restrict__ w_out, double* __restrict__ s_out,
-                                                           double* __restrict__ pv, double* __restrict__ xv, const double* __restrict__ dvec,
-                                                           const double* __restrict__ part_in, double* __restrict__ part_out, int npart,
-                                                           const double* __restrict__ ctrl, double* __restrict__ scal, int* __restrict__ status,
-                                                           int* __restrict__ it_ctr, int par, double* __restrict__ hist, int map_xcd,
-                                                           const double* __restrict__ sums, int* __restrict__ mirror) {
-    // mirror (may be null): two words of PINNED HOST memory - [0] the status word once the recurrence has stopped, [1] the number of
-    // the iteration this launch is working on - written by one lane with relaxed system-scope stores (no fence: nothing is ordered
-    // against them).  The host enqueues the next launches from what it reads there (fs_krylov_solve) instead of copying the status
-    // word back behind every batch, and stops within a few launches of the end instead of a batch and a half after it.
-    FS_STAMP(0);
-    // The launch is latency-bound at the sizes it is used for (a wave has two work items at 1 M rows), and what it reads first was
-    // written by the previous launch on other XCDs - every dependent load is a round trip to the Infinity Cache (1 - 2 us).  So
-    // everything the prologue needs goes out BEFORE anything is waited for: status word, iteration number, threshold, both parities
-    // of the previous (gamma, alpha), the twelve dot partials of this thread, the first item's header -> run starts -> first
-    // twelve run loads, the dictionary.  (Timeline of the first version, tools/probes: 8.8 of 22.7 us were the prologue.)
-    const int st0 = status[0];
-    const int iter = it_ctr[par];
-    const double thresh = ctrl[0], it_max = ctrl[2];
-    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];
-    double pl[3][4];
-    double sum_g = 0.0, sum_d = 0.0, sum_r = 0.0;
-    if (COMM) { sum_g = sums[0]; sum_d = sums[1]; sum_r = sums[2]; }
-    else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = threadIdx.x + t * FS_BLOCK;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) pl[j][t] = part_in[(int64_t)j * npart + (i < npart ? i : npart - 1)];      // (no branch: twelve loads in flight)
-        }
-    }
-    FS_STAMP(1);
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));
-    extern __shared__ __attribute__((aligned(16))) double sdict[];
-    __shared__ double lds34[3][4];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t n_chunks = (n_items + 3) / 4;
-    const int32_t cmax = (int32_t)(n_cols - 1);
-    chunk_iter it = xcd_chunks(n_chunks);
-    if (!map_xcd) { it.cur = blockIdx.x; it.step = gridDim.x; it.end = n_chunks; }
-    struct item_hdr { int32_t first; int nr, edge, rounds; const dict_plan_round* pl; };
-    auto decode = [&](int64_t q) {
-        const int4 ds = items[__builtin_amdgcn_readfirstlane((int)q)];
-        item_hdr H;
-        H.first = __builtin_amdgcn_readfirstlane(ds.x);
-        H.nr = __builtin_amdgcn_readfirstlane(ds.y) & 0xffff;
-        H.edge = __builtin_amdgcn_readfirstlane(ds.y) >> 16;
-        H.pl = plans + __builtin_amdgcn_readfirstlane(ds.z);
-        H.rounds = __builtin_amdgcn_readfirstlane(ds.w);
-        return H;
-    };
-    // loads of runs [4 h, 4 h + 4) of round rd: scalar base (vector + run start) + one 32-bit byte offset per lane - the `saddr` form
-    // of the load, no 64-bit address arithmetic or address registers per load (rows < 2^29)
-    auto load_half = [&](const item_hdr& H, int rd, int h, uint32_t boff, v2d (&A)[4], v2d (&Wb)[4], v2d (&Sb)[4]) {
-        // (measured and not kept: run starts that need no load - kernel arguments for the plan most items have, or a per-item copy beside
-        // the header - and the next item's header asked for an item ahead: with nothing left between header and run loads the
-        // compiler schedules 164 - 177 VGPRs (and spills SGPRs into them), two or three waves per SIMD instead of four, and the
-        // launch gets slower: 22.9 against 19.0 us at 1 M rows)
-        int32_t sts[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sts[j] = __builtin_amdgcn_readfirstlane(H.pl[rd].start[4 * h + j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t st = sts[j];
-            A[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(r_in + st) + boff);
-            Wb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(w_in + st) + boff);
-            Sb[j] = *reinterpret_cast<const v2du*>(reinterpret_cast<const char*>(s_in + st) + boff);
-        }
-    };
-    auto load_own = [&](const item_hdr& H, v2d& pp, v2d& xx, v2d& dd) {
-        const int32_t r = H.first + 2 * lane;
-        pp = xx = dd = v2d{0.0, 0.0};
-        if (2 * lane + 1 < H.nr) {
-            pp = *reinterpret_cast<const v2du*>(&pv[r]);
-            xx = *reinterpret_cast<const v2du*>(&xv[r]);
-            dd = *reinterpret_cast<const v2du*>(&dvec[r]);
-        } else if (2 * lane < H.nr) { pp.x = pv[r]; xx.x = xv[r]; dd.x = dvec[r]; }
-    };
-    // Nothing the first item LOADS depends on alpha, beta: its first twelve run loads and its row-local operands are asked for
-    // before the partial sums are reduced (a wave has about two items at 1 M rows; 35.3 -> 27.4 us per iteration with 1024 workgroups)
-    item_hdr H0 = {};
-    v2d PA[4], PW[4], PS[4], Ppp = {0.0, 0.0}, Pxx = {0.0, 0.0}, Pdd = {0.0, 0.0};
-    const bool have0 = it.cur < it.end && it.cur * 4 + wave < n_items;
-    if (have0) {
-        H0 = decode(it.cur * 4 + wave);
-        if (!H0.edge) load_half(H0, 0, 0, (uint32_t)(H0.first + 2 * lane) * 8u, PA, PW, PS);
-        load_own(H0, Ppp, Pxx, Pdd);
-    }
-    FS_STAMP(2);
-    fs_fill_lds(sdict, dict, C * S);             // (visible after the barrier of the sum below)
-    if (st0 != 0) return;
-    // the three sums of the previous launch's partials, in the order of wg_sum_partials / fs_block_sum (same bits as the update
-    // kernel of the two-launch iteration computes), with ONE barrier: a thread's partials in ascending index, the wave's by the
-    // shuffle tree, the four waves as (0 + 1) + (2 + 3) by every thread
-    double sm[3];
-    if (COMM) {
-        sm[0] = sum_g; sm[1] = sum_d; sm[2] = sum_r;
-        __syncthreads();                        // (the dictionary is in LDS)
-    } else {                                    // (npart <= 4 x 256: the host launches this kernel with at most 1024 workgroups)
-        double a[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if ((int)threadIdx.x + t * FS_BLOCK < npart) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) a[j] += pl[j][t];
-            }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a[j] += __shfl_down(a[j], off, 64);
-            if (lane == 0) lds34[j][wave] = a[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 3; ++j) sm[j] = (lds34[j][0] + lds34[j][1]) + (lds34[j][2] + lds34[j][3]);
-        __syncthreads();                        // (lds34 is written again at the end)
-    }
-    FS_STAMP(3);
-    const double gamma = sm[0], delta = sm[1], rho = sm[2];
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    if (leader) hist[iter] = rho;
-    auto stop = [&](int code) {
-        if (leader) {
-            status[1] = iter; status[0] = code;
-            if (mirror) { fs_host_store(mirror + 1, iter); fs_host_store(mirror, code); }
-        }
-    };
-    if (rho <= thresh) { stop(1); return; }     // every workgroup takes the same branch: the inputs are identical
-    if (iter >= (int)it_max) { stop(3); return; }
-    double beta, alpha;
-    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) { stop(2); return; }
-    if (leader) {
-        scal[2 * (iter & 1) + 0] = gamma;
-        scal[2 * (iter & 1) + 1] = alpha;
-        it_ctr[par ^ 1] = iter + 1;
-        if (mirror) fs_host_store(mirror + 1, iter + 1);
-    }
-    const double nalpha = -alpha;
-    FS_STAMP(4);
-    double d_rz = 0.0, d_wz = 0.0, d_rr = 0.0;
-    // PRE: this item's first half round and row-local operands were loaded before the prologue
-    auto do_item = [&](const item_hdr& H, auto pre_tag) {
-        constexpr bool PRE = decltype(pre_tag)::value;
-        const int32_t r = H.first + 2 * lane;
-        const bool ok0 = 2 * lane < H.nr, ok1 = 2 * lane + 1 < H.nr;
-        int c0 = -1, c1 = -1;
-        if ((H.first & 1) == 0) {
-            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cls[r]);
-            if (ok0) c0 = (int)(two & 0xffffu);
-            if (ok1) c1 = (int)(two >> 16);
-        } else {
-            if (ok0) c0 = (int)cls[r];
-            if (ok1) c1 = (int)cls[r + 1];
-        }
-        v2d sn0 = {0.0, 0.0}, ro0 = {0.0, 0.0};
-        v2d pp, xx, dd;
-        if (PRE) { pp = Ppp; xx = Pxx; dd = Pdd; }
-        else load_own(H, pp, xx, dd);
-        const double* __restrict__ v0 = sdict + (ok0 ? c0 * S : 0);
-        const double* __restrict__ v1 = sdict + (ok1 ? c1 * S : 0);
-        double a0 = 0.0, a1 = 0.0;
-        v2d zi = {0.0, 0.0};
-        // one run: its terms in ascending offsets, one fma each (the order and the bits of k_dict_spmv)
-        auto run_terms = [&](v2d rn, const double* __restrict__ w0, const double* __restrict__ w1) {
-            const double e0 = rn.x, e1 = rn.y;
-            const double e2 = fs_from_next_lane(rn.x);
-            a0 = fma(w0[0], e0, a0); a1 = fma(w1[0], e1, a1);
-            a0 = fma(w0[1], e1, a0); a1 = fma(w1[1], e2, a1);
-            if (RL == 3) {
-                const double e3 = fs_from_next_lane(rn.y);
-                a0 = fma(w0[2], e2, a0); a1 = fma(w1[2], e3, a1);
-            }
-        };
-        if (!H.edge) {
-            const uint32_t boff = (uint32_t)r * 8u;
-            for (int rd = 0; rd < H.rounds; ++rd) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    v2d A[4], Wb[4], Sb[4];
-                    if (PRE && h == 0) {
-                        if (rd == 0) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { A[j] = PA[j]; Wb[j] = PW[j]; Sb[j] = PS[j]; }
-                        } else load_half(H, rd, h, boff, A, Wb, Sb);
-                    } else load_half(H, rd, h, boff, A, Wb, Sb);
-                    // the new r on these columns: r - alpha (w + beta s), two fmas per value - the owner's operations, the owner's bits
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v2d sn;
-                        sn.x = fma(beta, Sb[j].x, Wb[j].x); sn.y = fma(beta, Sb[j].y, Wb[j].y);
-                        if (h == 0 && j == 0 && rd == 0) { sn0 = sn; ro0 = A[0]; }
-                        A[j].x = fma(nalpha, sn.x, A[j].x); A[j].y = fma(nalpha, sn.y, A[j].y);
-                    }
-                    if (h == 0 && rd == 0) zi = A[0];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        run_terms(A[j], v0 + RL * (8 * rd + 4 * h + j), v1 + RL * (8 * rd + 4 * h + j));
-                        asm volatile("" ::: "memory");
-                    }
-                }
-            }
-        } else {
-            // items whose loads could leave [0, n_cols) (first / last mesh plane; 1.4 % of the rows at 10 M): run by run, each value
-            // clamped into the vector (a column outside it has a zero coefficient)
-            const int n_runs = 8 * H.rounds;
-#pragma unroll 1
-            for (int g = 0; g < n_runs; ++g) {
-                const int32_t c = r + __builtin_amdgcn_readfirstlane(H.pl[g >> 3].start[g & 7]);
-                const int32_t ca = c < 0 ? 0 : (c > cmax ? cmax : c), cb = c + 1 < 0 ? 0 : (c + 1 > cmax ? cmax : c + 1);
-                v2d rn, sn;
-                sn.x = fma(beta, s_in[ca], w_in[ca]); sn.y = fma(beta, s_in[cb], w_in[cb]);
-                const double ra = r_in[ca], rb = r_in[cb];
-                if (g == 0) { sn0 = sn; ro0.x = ra; ro0.y = rb; }
-                rn.x = fma(nalpha, sn.x, ra); rn.y = fma(nalpha, sn.y, rb);
-                if (g == 0) zi = rn;
-                run_terms(rn, v0 + RL * g, v1 + RL * g);
-            }
-        }
-        // own rows: p, x, and the new s, r, w
-        v2d pn, xn;
-        pn.x = fma(beta, pp.x, ro0.x); pn.y = fma(beta, pp.y, ro0.y);
-        xn.x = fma(alpha, pn.x, xx.x); xn.y = fma(alpha, pn.y, xx.y);
-        if (ok1) {
-            v2d out;
-            out.x = a0; out.y = a1;
-            *reinterpret_cast<v2du*>(&w_out[r]) = out;
-            *reinterpret_cast<v2du*>(&r_out[r]) = zi;
-            *reinterpret_cast<v2du*>(&s_out[r]) = sn0;
-            *reinterpret_cast<v2du*>(&pv[r]) = pn;
-            *reinterpret_cast<v2du*>(&xv[r]) = xn;
-        } else if (ok0) {
-            w_out[r] = a0; r_out[r] = zi.x; s_out[r] = sn0.x; pv[r] = pn.x; xv[r] = xn.x;
-        }
-        if (!ok0) { a0 = 0.0; zi.x = 0.0; }
-        if (!ok1) { a1 = 0.0; zi.y = 0.0; }
-        d_rz += zi.x * zi.x + zi.y * zi.y; d_wz += a0 * zi.x + a1 * zi.y; d_rr += dd.x * zi.x * zi.x + dd.y * zi.y * zi.y;
-    };
-    if (have0) {
-        do_item(H0, std::true_type{});
-        it.cur += it.step;
-    }
-    FS_STAMP(5);
-    for (; it.cur < it.end; it.cur += it.step) {
-        const int64_t q = it.cur * 4 + wave;
-        if (q >= n_items) break;
-        do_item(decode(q), std::false_type{});
-    }
-    FS_STAMP(6);
-    // this workgroup's three dot partials: fs_block_sum's order (shuffle tree, then (0 + 1) + (2 + 3)), one barrier for the three
-    double dsum[3] = {d_rz, d_wz, d_rr};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dsum[j] += __shfl_down(dsum[j], off, 64);
-        if (lane == 0) lds34[j][wave] = dsum[j];
-    }
-    __syncthreads();
-    FS_STAMP(7);
-    if (threadIdx.x < 3) part_out[(int64_t)threadIdx.x * npart + blockIdx.x] =
-        (lds34[threadIdx.x][0] + lds34[threadIdx.x][1]) + (lds34[threadIdx.x][2] + lds34[threadIdx.x][3]);
-}
-
-// The same update on the rows [0, a) and [b, n) only - the rows a slab sends to its neighbours - so that the halo
-// exchange of the new r can start before the bulk of the update and the interior product are even launched (several
-// GPUs: sums from the all-reduce).  No side effects: status, history and the scalars are written by the launch on the
-// remaining rows, which comes later in the stream and takes the same decisions from the same inputs.
-__global__ void __launch_bounds__(FS_BLOCK) k_cg_update_scaled_rows(int64_t a, int64_t b, int64_t n, int iter, int check_only,
-                                                                    const double* __restrict__ sums, const double* __restrict__ ctrl,
-                                                                    const double* __restrict__ scal, const int* __restrict__ status,
-                                                                    double* __restrict__ r, const double* __restrict__ w,
-                                                                    double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x) {
-    if (status[0] != 0) return;
-    const double gamma = sums[0], delta = sums[1], rho = sums[2];
-    if (rho <= ctrl[0] || check_only) return;
-    double beta, alpha;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
-    const int64_t total = a + (n - b);
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < total; t += stride) {
-        const int64_t i = t < a ? t : b + (t - a);
-        const double pp = r[i] + beta * p[i];
-        const double ss = w[i] + beta * sv[i];
-        p[i] = pp; sv[i] = ss;
-        x[i] += alpha * pp;
-        r[i] -= alpha * ss;
-    }
-}
-
-// ---- the exchange kernel of the peer-to-peer iteration (fs_comm.hip: hipIpc-mapped buffers; protocol in fs_kernels.h) -----------
-// Everything of a CG iteration that crosses GPUs, in ONE launch between the product and the update.  What travels is w = A r on
-// the rows some neighbour needs - known as soon as the product is through, with no dependence on the sums - and NOT the new
-// residual: a rank advances the ghost copies of r and s itself (s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g are row-local and it
-// knows alpha, beta), with the operations the owner's update kernel applies to the same rows.
-//   1. every workgroup stores its share of w[send rows] straight into the neighbours' receive buffers, the last one through
-//      publishes the sequence number of the exchange at every neighbour;
-//   2. (meanwhile on the wire) every workgroup sums the product's dot partials itself (same bits everywhere); workgroup 0
-//      stores the three sums into slot [me] of the other ranks' all-reduce buffers; every workgroup waits for the other ranks'
-//      sums and adds all up in rank order; workgroup 0 leaves the result in `sums` for the update kernel that follows;
-//   3. every workgroup waits for the neighbours' sequence numbers and advances its share of the ghost rows with the received w.
-// (No workgroup waits before its own stores are counted, so two ranks never wait for each other.)  Any halo plan (send lists
-// need not be contiguous, ghosts may be scattered), any block size: rows are dofs here.  Gated by the status word; steps 1 and
-// 2 always run together, step 3 only if the iteration goes on - decided from the reduced sums, hence alike on every rank.
-// PP: the exchange of the ONE-LAUNCH iteration on a decomposed space (k_dict_cg_iter<3, true> follows): r, w, s are double-buffered by
-// iteration parity and that kernel recomputes the new residual on its neighbour columns - ghost columns included - from the OLD r, w,
-// s.  So the received w goes into the ghost rows of the current w (pp.w_cur), and the ghost rows of s and r are advanced from the
-// current buffers into the next ones (pp.s_cur -> pp.s_nxt, pp.r_cur -> pp.r_nxt): the two fmas of the owner.  The iteration number
-// comes from it_ctr[par] (written by the previous iteration kernel).
-struct fs_pp_ghosts {
-    double* w_cur;
-    const double* s_cur;
-    double* s_nxt;
-    const double* r_cur;
-    double* r_nxt;
-    const int* it_ctr;
-    int par;
-};
-template <bool PP>
-__global__ void __launch_bounds__(FS_BLOCK) k_cg_p2p_exchange(int iter, int check_only, const double* __restrict__ ctrl,
-                                                              const double* __restrict__ scal, const int* __restrict__ status,
-                                                              double* r, const double* __restrict__ w, double* __restrict__ s_ghost,
-                                                              const fs_p2p_rowsred red, const fs_p2p_sendrows snd, const fs_pp_ghosts pp) {
-    // (every scalar the launch needs is asked for before the first of them is looked at: each was written by the previous launch,
-    // a dependent load is a round trip of about a microsecond, and this kernel sits on the critical path of every iteration)
-    const int st0 = status[0], st2 = status[2];
-    const double it_max = ctrl[2], thresh = ctrl[0];
-    const double sc_g0 = scal[0], sc_a0 = scal[1], sc_g1 = scal[2], sc_a1 = scal[3];
-    // sequence numbers of THIS exchange: one past the last executed ones (fs_comm.hip); read by every workgroup at its start,
-    // advanced by the last workgroup through each part
-    const unsigned long long rseq = *red.d_seq + 1ull, hseq = *snd.d_seq + 1ull;
-    const int it_dev = PP ? pp.it_ctr[pp.par] : 0;
-    if (st0 != 0) return;
-    if (PP) {
-        iter = it_dev;
-        check_only = iter >= (int)it_max ? 1 : 0;
-    } else if (iter < 0) {          // captured batch: the index of the product that preceded this launch
-        iter = st2 - 1;
-        check_only = iter >= (int)it_max ? 1 : 0;
-    }
-    const int rslot = (int)(rseq & 1ull), hslot = (int)(hseq & 1ull);
-    const int64_t e_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int t = threadIdx.x;
-    // 1. w on the interface rows -> the neighbours
-    for (int64_t e = e_first; e < snd.total_send; e += stride) {
-        const double wv = w[snd.send_idx[e]];
-        int j = 0;
-        while (j + 1 < snd.nn && e >= snd.peers[j + 1].send_offset) ++j;
-        const fs_p2p_peer q = snd.peers[j];
-        fs_p2p_store(q.recv + (int64_t)hslot * q.peer_total + q.recv_offset + (e - q.send_offset), wv);
-    }
-    fs_p2p_stores_done();
-    __syncthreads();
-    if (t == 0 && atomicAdd(snd.counter, 1u) == gridDim.x - 1) {
-        __hip_atomic_store(snd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(snd.d_seq, hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int j = 0; j < snd.nn; ++j) {
-            const fs_p2p_peer q = snd.peers[j];
-            fs_p2p_publish(q.flags + (int64_t)hslot * q.peer_nn + q.peer_slot, hseq);
-        }
-    }
-    // 2. the sums of all ranks
-    double sm[3];
-    wg_sum_partials<3>(red.partials, red.npart, sm);
-    if (blockIdx.x == 0 && t < red.nr && t != red.me) {
-        double* dst = red.peer_buf[t] + ((int64_t)rslot * red.nr + red.me) * 8;
-        fs_p2p_store(dst, sm[0]); fs_p2p_store(dst + 1, sm[1]); fs_p2p_store(dst + 2, sm[2]);
-        fs_p2p_stores_done();
-        fs_p2p_publish(red.peer_flags[t] + (int64_t)rslot * red.nr + red.me, rseq);
-    }
-    if (t < red.nr && t != red.me) fs_p2p_wait(red.own_flags + (int64_t)rslot * red.nr + t, rseq, red.timeout, red.err);
-    __syncthreads();
-    __shared__ double tot[3];
-    if (t < 3) {
-        double a = 0.0;
-        for (int q = 0; q < red.nr; ++q)
-            a += q == red.me ? sm[t] : fs_p2p_load(red.own_buf + ((int64_t)rslot * red.nr + q) * 8 + t);
-        tot[t] = a;
-        if (blockIdx.x == 0) red.sums_out[t] = a;
-    }
-    if (t == 0 && atomicAdd(red.counter, 1u) == gridDim.x - 1) {          // every workgroup has read d_seq and the other ranks' sums
-        __hip_atomic_store(red.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(red.d_seq, rseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const double gamma = tot[0], delta = tot[1], rho = tot[2];
-    if (rho <= thresh || check_only) return;
-    double beta, alpha;
-    if (!cg_scalars_from(iter, gamma, delta, rho, ((iter - 1) & 1) ? sc_g1 : sc_g0, ((iter - 1) & 1) ? sc_a1 : sc_a0, alpha, beta)) return;
-    // 3. ghost rows: s_g <- w_g + beta s_g, r_g <- r_g - alpha s_g (the two lines of the update kernel)
-    if (t < snd.nn) fs_p2p_wait(snd.own_flags + (int64_t)hslot * snd.nn + t, hseq, snd.timeout, snd.err);
-    __syncthreads();
-    const double* own_recv = snd.own_recv + (int64_t)hslot * snd.recv_stride;
-    for (int64_t k = e_first; k < snd.total_recv; k += stride) {
-        const int64_t gi = snd.recv_idx ? (int64_t)snd.recv_idx[k] : snd.n_owned + k;
-        if (PP) {
-            const double wv = fs_p2p_load(own_recv + k);
-            pp.w_cur[gi] = wv;
-            const double ss = fma(beta, pp.s_cur[gi], wv);
-            pp.s_nxt[gi] = ss;
-            pp.r_nxt[gi] = fma(-alpha, ss, pp.r_cur[gi]);
-        } else {
-            const double ss = fs_p2p_load(own_recv + k) + beta * s_ghost[k];
-            s_ghost[k] = ss;
-            r[gi] -= alpha * ss;
-        }
-    }
-}
-
-// ---- pipelined CG (Ghysels & Vanroose, Parallel Computing 40 (2014)) on the scaled system --------------------------
-// The single-reduction recurrence above still has the global sums between the product and the update: on several GPUs the
-// 3-double all-reduce (latency, not bandwidth) is paid in full every iteration.  The pipelined recurrence carries two more
-// vectors (w = A r, z = A s) so that the sums of iteration i - (r.r, w.r, sum d r^2) of r_i, w_i - are known BEFORE the
-// product n_i = A w_i starts and are reduced while it runs:
-//      beta = gamma_i / gamma_{i-1},  alpha = gamma_i / (delta_i - beta gamma_i / alpha_{i-1})
-//      z = n + beta z;  s = w + beta s;  p = r + beta p;   x += alpha p;  r -= alpha s;  w -= alpha z
-// In exact arithmetic the iterates are those of CG.  The update kernel computes the sums of the NEW r, w as it writes
-// them (per-workgroup partials, double-buffered by iteration parity because the next launch reads one set while it writes
-// the other).  112 instead of 72 B/DOF of vector traffic per iteration: it only pays where a collective is hidden.
-// Rows [m0, m1) are updated by this launch; rows [0, m0) and [m1, n) - what a slab sends to its neighbours - were already
-// updated by k_pcg_update_rows (so that their exchange could start) and only enter the sums here.
-template <bool FUSED, bool NT>
-__global__ void __launch_bounds__(FS_BLOCK) k_pcg_update(int64_t n, int64_t m0, int64_t m1, int iter, int check_only,
-                                                         double* __restrict__ partials, int npart,
-                                                         const double* __restrict__ sums, const double* __restrict__ ctrl,
-                                                         double* __restrict__ scal, int* __restrict__ status,
-                                                         double* __restrict__ hist, const double* __restrict__ dvec,
-                                                         double* __restrict__ r, double* __restrict__ w,
-                                                         const double* __restrict__ nv, double* __restrict__ p,
-                                                         double* __restrict__ sv, double* __restrict__ z,
-                                                         double* __restrict__ x) {
-    if (status[0] != 0) return;
-    double gamma, delta, rho;
-    if (FUSED) {
-        double sm[3];
-        wg_sum_partials<3>(partials + (int64_t)(iter & 1) * 3 * npart, npart, sm);
-        gamma = sm[0]; delta = sm[1]; rho = sm[2];
-    } else {
-        gamma = sums[0]; delta = sums[1]; rho = sums[2];
-    }
-    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-    if (leader) hist[iter] = rho;
-    if (rho <= ctrl[0]) {
-        if (leader) { status[1] = iter; status[0] = 1; }
-        return;
-    }
-    if (check_only) {
-        if (leader) { status[1] = iter; status[0] = 3; }
-        return;
-    }
-    double alpha, beta;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) {
-        if (leader) { status[1] = iter; status[0] = 2; }
-        return;
-    }
-    if (leader) {
-        scal[2 * (iter & 1) + 0] = gamma;
-        scal[2 * (iter & 1) + 1] = alpha;
-    }
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    struct io {
-        static __device__ __forceinline__ v2d ld(const double* q) {
-            return NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q)) : *reinterpret_cast<const v2d*>(q);
-        }
-        static __device__ __forceinline__ void st(double* q, const v2d& v) {
-            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(q));
-            else *reinterpret_cast<v2d*>(q) = v;
-        }
-    };
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t npair = (m1 - m0) >> 1;              // m0 is even
-    for (int64_t q = tid; q < npair; q += stride) {
-        const int64_t i = m0 + 2 * q;
-        const v2d nn = io::ld(nv + i), dd = io::ld(dvec + i);
-        v2d zz = io::ld(z + i), ss = io::ld(sv + i), pp = io::ld(p + i), ww = io::ld(w + i), rr = io::ld(r + i), xx = io::ld(x + i);
-        zz = nn + beta * zz;
-        ss = ww + beta * ss;
-        pp = rr + beta * pp;
-        xx += alpha * pp;
-        rr -= alpha * ss;
-        ww -= alpha * zz;
-        io::st(z + i, zz); io::st(sv + i, ss); io::st(p + i, pp); io::st(x + i, xx); io::st(r + i, rr); io::st(w + i, ww);
-        a0 += rr.x * rr.x + rr.y * rr.y;
-        a1 += ww.x * rr.x + ww.y * rr.y;
-        a2 += dd.x * rr.x * rr.x + dd.y * rr.y * rr.y;
-    }
-    if (((m1 - m0) & 1) && tid == 0) {
-        const int64_t i = m1 - 1;
-        const double zz = nv[i] + beta * z[i], ss = w[i] + beta * sv[i], pp = r[i] + beta * p[i];
-        z[i] = zz; sv[i] = ss; p[i] = pp;
-        x[i] += alpha * pp;
-        const double rr = r[i] - alpha * ss, ww = w[i] - alpha * zz;
-        r[i] = rr; w[i] = ww;
-        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
-    }
-    // rows already updated by k_pcg_update_rows
-    const int64_t extra = m0 + (n - m1);
-    for (int64_t t = tid; t < extra; t += stride) {
-        const int64_t i = t < m0 ? t : m1 + (t - m0);
-        const double rr = r[i], ww = w[i];
-        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
-    }
-    __shared__ double lds4[4];
-    const double t0 = fs_block_sum(a0, lds4);
-    const double t1 = fs_block_sum(a1, lds4);
-    const double t2 = fs_block_sum(a2, lds4);
-    if (threadIdx.x == 0) {
-        double* out = partials + (int64_t)((iter + 1) & 1) * 3 * npart;
-        out[blockIdx.x] = t0;
-        out[npart + blockIdx.x] = t1;
-        out[2 * npart + blockIdx.x] = t2;
-    }
-}
-
-// The pipelined update on the rows [0, a) and [b, n) only (sums from the all-reduce): no side effects, the launch on
-// the remaining rows takes the same decisions from the same inputs and writes status / history / scalars.
-__global__ void __launch_bounds__(FS_BLOCK) k_pcg_update_rows(int64_t a, int64_t b, int64_t n, int iter, int check_only,
-                                                              const double* __restrict__ sums, const double* __restrict__ ctrl,
-                                                              const double* __restrict__ scal, const int* __restrict__ status,
-                                                              double* __restrict__ r, double* __restrict__ w,
-                                                              const double* __restrict__ nv, double* __restrict__ p,
-                                                              double* __restrict__ sv, double* __restrict__ z, double* __restrict__ x) {
-    if (status[0] != 0) return;
-    const double gamma = sums[0], delta = sums[1], rho = sums[2];
-    if (rho <= ctrl[0] || check_only) return;
-    double alpha, beta;
-    if (!cg_scalars(iter, gamma, delta, rho, scal, alpha, beta)) return;
-    const int64_t total = a + (n - b);
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < total; t += stride) {
-        const int64_t i = t < a ? t : b + (t - a);
-        const double zz = nv[i] + beta * z[i], ss = w[i] + beta * sv[i], pp = r[i] + beta * p[i];
-        z[i] = zz; sv[i] = ss; p[i] = pp;
-        x[i] += alpha * pp;
-        r[i] -= alpha * ss;
-        w[i] -= alpha * zz;
-    }
-}
-
-// sums of the first iterate of a pass: partials (parity 0) of (r.r, w.r, sum d r^2)
-__global__ void __launch_bounds__(FS_BLOCK) k_pcg_dots(int64_t n, const double* __restrict__ r, const double* __restrict__ w,
-                                                       const double* __restrict__ dvec, double* __restrict__ partials, int npart) {
-    __shared__ double lds4[4];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const double rr = r[i], ww = w[i];
-        a0 += rr * rr; a1 += ww * rr; a2 += dvec[i] * rr * rr;
-    }
-    const double t0 = fs_block_sum(a0, lds4);
-    const double t1 = fs_block_sum(a1, lds4);
-    const double t2 = fs_block_sum(a2, lds4);
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x] = t0;
-        partials[npart + blockIdx.x] = t1;
-        partials[2 * npart + blockIdx.x] = t2;
-    }
-}
-
-// aval = D^-1/2 A D^-1/2 (copy; the caller's matrix is left untouched), sc = 1/sqrt(diag)
-template <int BS>
-__global__ void __launch_bounds__(FS_BLOCK) k_scale_copy(int64_t n_rows, int64_t n_slices,
-                                                         const int64_t* __restrict__ slice_ptr,
-                                                         const int32_t* __restrict__ sell_col,
-                                                         const double* __restrict__ val, int64_t plane,
-                                                         const double* __restrict__ sc, double* __restrict__ aval) {
-    const int lane = threadIdx.x & 63;
-    int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (; s < n_slices; s += stride) {
-        const int64_t r = s * FS_SLICE + lane;
-        const int64_t base = slice_ptr[s] + lane;
-        const int width = (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 6);
-        for (int k = 0; k < width; ++k) {
-            const int64_t e = base + (int64_t)k * FS_SLICE;
-            const int32_t c = sell_col[e];
-#pragma unroll
-            for (int i = 0; i < BS; ++i)
-#pragma unroll
-                for (int j = 0; j < BS; ++j) {
-                    const int64_t idx = (int64_t)(i * BS + j) * plane + e;
-                    aval[idx] = (c >= 0 && r < n_rows) ? val[idx] * sc[r * BS + i] * sc[(int64_t)c * BS + j] : 0.0;
-                }
-        }
-    }
-}
-
-__global__ void k_pointwise_div(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
-                                double* __restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = a[i] / b[i];
-}
-
-// partial of sum d (b - w)^2 ; optionally r = b - w
-__global__ void __launch_bounds__(FS_BLOCK) k_residual_scaled(const double* __restrict__ b, const double* __restrict__ w,
-                                                              const double* __restrict__ d, int64_t n,
-                                                              double* __restrict__ r, double* __restrict__ partial) {
-    __shared__ double lds4[4];
-    double acc = 0.0;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const double x = b[i] - w[i];
-        if (r) r[i] = x;
-        acc += d[i] * x * x;
-    }
-    const double t = fs_block_sum(acc, lds4);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-template <int BS>
-__global__ void k_extract_dinv(int64_t n_rows, const int64_t* __restrict__ slice_ptr,
-                               const int32_t* __restrict__ sell_col, const double* __restrict__ val, int64_t plane,
-                               int jacobi, double* __restrict__ dinv, int* __restrict__ err,
-                               double* __restrict__ dvec = nullptr) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; r < n_rows; r += stride) {
-        const int64_t sp0 = slice_ptr[r >> 6];
-        const int width = (int)((slice_ptr[(r >> 6) + 1] - sp0) >> 6);
-        const int64_t base = sp0 + (r & 63);
-        int kd = -1;
-        for (int k = 0; k < width; ++k)
-            if (sell_col[base + (int64_t)k * FS_SLICE] == r) { kd = k; break; }
-        for (int i = 0; i < BS; ++i) {
-            double d = 1.0;
-            if (jacobi) {
-                d = kd >= 0 ? val[(int64_t)(i * BS + i) * plane + base + (int64_t)kd * FS_SLICE] : 0.0;
-                if (!(d != 0.0) || (jacobi == 2 && !(d > 0.0))) { atomicAdd(err, 1); d = 1.0; }
-                if (dvec) dvec[r * BS + i] = d;
-                d = jacobi == 2 ? 1.0 / sqrt(d) : 1.0 / d;
-            }
-            dinv[r * BS + i] = d;
-        }
-    }
-}
-
-__global__ void k_pointwise_mul(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
-                                double* __restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = a[i] * b[i];
-}
-
-// r = b - w ; partial of r.r
-__global__ void __launch_bounds__(FS_BLOCK) k_residual(const double* __restrict__ b, const double* __restrict__ w,
-                                                       int64_t n, double* __restrict__ r,
-                                                       double* __restrict__ partial) {
-    __shared__ double lds4[4];
-    double acc = 0.0;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const double d = b[i] - w[i];
-        if (r) r[i] = d;
-        acc += d * d;
-    }
-    const double t = fs_block_sum(acc, lds4);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-// up to four vectors zeroed by ONE launch (the start of a CG pass: p, s, z and x - four memsets of 8 MB each at 1 M rows were four
-// launches with their gaps)
-__global__ void __launch_bounds__(FS_BLOCK) k_zero4(double* __restrict__ a, int64_t na, double* __restrict__ b, int64_t nb,
-                                                    double* __restrict__ c, int64_t nc, double* __restrict__ d, int64_t nd) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    double* const ptr[4] = {a, b, c, d};
-    const int64_t len[4] = {na, nb, nc, nd};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        double* __restrict__ v = ptr[q];
-        const int64_t n2 = len[q] >> 1;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) reinterpret_cast<v2d*>(v)[i] = v2d{0.0, 0.0};
-        if ((len[q] & 1) && blockIdx.x == 0 && threadIdx.x == 0) v[len[q] - 1] = 0.0;
-    }
-}
+#include "fs_krylov_iter.inc"      // the Krylov iterations' device side: CG / BiCGStab / pipelined CG update kernels, the one-launch iteration k_dict_cg_iter, the peer-to-peer exchange kernel
 
 // ---- host side --------------------------------------------------------------------------------
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
@@ -4051,163 +1208,7 @@ static int spmv_overlapped(fs_matrix_s* A, double* x, double* y, const double* r
     return FS_OK;
 }
 
-// y = A x for 4x4-block matrices (Taylor-Hood): one workgroup per slice, wave i computes block-row i.  A slice of a
-// CG2 pattern holds 30-65 entries of 16 planes each; giving every block-row its own wave quarters the serial
-// chain of a wave and quadruples the loads in flight (the generic kernel walks all 16 planes in one wave).
-// TH: the matrix is a Taylor-Hood operator (fs_assemble_navier_stokes).  Only vertex nodes carry a pressure, so
-//   - plane (i, 3) - the pressure-gradient column - is structurally zero wherever the COLUMN node is an edge node: its
-//     load is predicated on the column being a vertex ([0, nvo) or the ghost vertices [gv0, gv1));
-//   - block-row 3 of an EDGE node is the dummy identity row: slices that lie entirely behind the vertex rows copy x.
-// 16 planes of 8 B per stored block shrink to about 10 on average: the FGMRES iteration of configs[4] went from 1.02 to 0.90 ms.
-template <bool NT, bool TH>
-__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_rows(int64_t n_rows, int64_t n_cols, int64_t n_slices,
-                                                              const int64_t* __restrict__ slice_ptr,
-                                                              const int32_t* __restrict__ sell_col,
-                                                              const int32_t* __restrict__ dia_ptr,
-                                                              const int32_t* __restrict__ dia_off,
-                                                              const double* __restrict__ val, int64_t plane,
-                                                              const double* __restrict__ x, double* __restrict__ y,
-                                                              int64_t nvo, int64_t gv0, int64_t gv1) {
-    const int lane = threadIdx.x & 63;
-    const int i = threadIdx.x >> 6;          // block-row of this wave
-    const int64_t cmax = n_cols - 1;
-    // Slices are dealt round-robin (consecutive slices to different XCDs).  Measured on the configs[4] matrix: 443-490 us,
-    // with or without the spatial order of the slices; 567 us for XCD-contiguous eighths of the ordered slices and
-    // 878 us for contiguous eighths of the rows (vertex rows are 65 blocks wide, edge rows 20-30: unbalanced)
-    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
-        const int64_t r = s * FS_SLICE + lane;
-        if (TH && i == 3 && s * FS_SLICE >= nvo) {       // dummy pressure rows of edge nodes
-            if (r < n_rows) y[r * 4 + 3] = x[r * 4 + 3];
-            continue;
-        }
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-        const int32_t dp = dia_ptr[s];
-        const double* __restrict__ vp = val + (int64_t)(i * 4) * plane + base + lane;
-        const int32_t* __restrict__ cp = sell_col + base + lane;
-        // DIA slice: [split][list A][list B if split < 64] (fs_symbolic.hip, "SPLIT slices"); this lane's list
-        const int split = dp >= 0 ? dia_off[dp] : FS_SLICE;
-        const int32_t* __restrict__ opa = dia_off + (dp >= 0 ? dp + 1 : 0);
-        const int32_t* __restrict__ opb = opa + (split < FS_SLICE ? width : 0);
-        const bool hi = lane >= split;
-        double acc = 0.0;
-        int k = 0;
-        constexpr int U = 4;       // entries per round (2: 391 us, 4: 374 us, 8: 476 us on the configs[4] matrix - register pressure)
-        for (; k + U <= width; k += U) {
-            int64_t c[U];
-            bool pv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (dp >= 0) {
-                    c[u] = r + (hi ? opb[k + u] : opa[k + u]);
-                    c[u] = c[u] < 0 ? 0 : (c[u] > cmax ? cmax : c[u]);
-                } else {
-                    c[u] = fs_col_decode(cp[(int64_t)(k + u) * FS_SLICE]);
-                }
-                pv[u] = !TH || c[u] < nvo || (c[u] >= gv0 && c[u] < gv1);
-            }
-            double v[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) v[u][j] = fs_ldv<NT>(&vp[(int64_t)j * plane + (int64_t)(k + u) * FS_SLICE]);
-                v[u][3] = pv[u] ? fs_ldv<NT>(&vp[(int64_t)3 * plane + (int64_t)(k + u) * FS_SLICE]) : 0.0;
-            }
-            double2 xa[U], xb[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xa[u] = reinterpret_cast<const double2*>(x)[2 * c[u]];
-                xb[u] = reinterpret_cast<const double2*>(x)[2 * c[u] + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc += v[u][0] * xa[u].x + v[u][1] * xa[u].y + v[u][2] * xb[u].x + v[u][3] * xb[u].y;
-        }
-        for (; k < width; ++k) {
-            int64_t c = dp >= 0 ? r + (hi ? opb[k] : opa[k]) : (int64_t)fs_col_decode(cp[(int64_t)k * FS_SLICE]);
-            c = c < 0 ? 0 : (c > cmax ? cmax : c);
-            const bool pc = !TH || c < nvo || (c >= gv0 && c < gv1);
-            const double2 xa = reinterpret_cast<const double2*>(x)[2 * c], xb = reinterpret_cast<const double2*>(x)[2 * c + 1];
-            acc += vp[(int64_t)k * FS_SLICE] * xa.x + vp[plane + (int64_t)k * FS_SLICE] * xa.y +
-                   vp[2 * plane + (int64_t)k * FS_SLICE] * xb.x + (pc ? vp[3 * plane + (int64_t)k * FS_SLICE] : 0.0) * xb.y;
-        }
-        if (r < n_rows) y[r * 4 + i] = acc;
-    }
-}
-
-// The same product with the ENTRIES of a slice dealt to the four waves (wave w takes entries w, w + 4, ...) instead of the block-rows:
-// a wave multiplies whole 4 x 4 blocks, so the four values of x behind a column are loaded once per entry instead of once per wave
-// and block-row - 16 + 2 load instructions per entry where the block-row kernel issues 4 x (4 + 2) - and the four partial sums of
-// every row meet in LDS (8 KB, two barriers per slice), added in wave order.  Round 5: the block-row kernel streamed the 1.45 GB of
-// the configs[4] operator at 3.8 TB/s, its texture-address units busy with the x gathers of all four waves.
-#ifndef FS_SPMV4_U
-#define FS_SPMV4_U 1      // (measured on the configs[4] operator: 1: 317 us, 2: 359 us; the block-row kernel: 388 us)
-#endif
-template <bool NT, bool TH>
-__global__ void __launch_bounds__(FS_BLOCK) k_sell_spmv4_ksplit(int64_t n_rows, int64_t n_cols, int64_t n_slices,
-                                                                const int64_t* __restrict__ slice_ptr,
-                                                                const int32_t* __restrict__ sell_col,
-                                                                const int32_t* __restrict__ dia_ptr,
-                                                                const int32_t* __restrict__ dia_off,
-                                                                const double* __restrict__ val, int64_t plane,
-                                                                const double* __restrict__ x, double* __restrict__ y,
-                                                                int64_t nvo, int64_t gv0, int64_t gv1) {
-    __shared__ double part[4][4][FS_SLICE];         // [wave][block-row][lane]
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int64_t cmax = n_cols - 1;
-    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
-        const int64_t r = s * FS_SLICE + lane;
-        const bool edge_rows = TH && s * FS_SLICE >= nvo;         // block-row 3 of these nodes is the dummy identity row
-        const int64_t base = slice_ptr[s];
-        const int width = (int)((slice_ptr[s + 1] - base) >> 6);
-        const int32_t dp = dia_ptr[s];
-        const double* __restrict__ vp = val + base + lane;
-        const int32_t* __restrict__ cp = sell_col + base + lane;
-        const int split = dp >= 0 ? dia_off[dp] : FS_SLICE;
-        const int32_t* __restrict__ opa = dia_off + (dp >= 0 ? dp + 1 : 0);
-        const int32_t* __restrict__ opb = opa + (split < FS_SLICE ? width : 0);
-        const bool hi = lane >= split;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        // U entries of this wave in flight together (U x 18 loads per lane); an entry past the end repeats the last one with weight 0
-        constexpr int U = FS_SPMV4_U;
-        for (int k0 = w; k0 < width; k0 += 4 * U) {
-            double2 xa[U], xb[U];
-            double v[U][4][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = k0 + 4 * u < width;
-                const int k = live ? k0 + 4 * u : k0;
-                int64_t c = dp >= 0 ? r + (hi ? opb[k] : opa[k]) : (int64_t)fs_col_decode(cp[(int64_t)k * FS_SLICE]);
-                c = c < 0 ? 0 : (c > cmax ? cmax : c);
-                const bool pc = !TH || c < nvo || (c >= gv0 && c < gv1);          // the column node carries a pressure
-                xa[u] = reinterpret_cast<const double2*>(x)[2 * c];
-                xb[u] = reinterpret_cast<const double2*>(x)[2 * c + 1];
-                if (!live) { xa[u] = make_double2(0.0, 0.0); xb[u] = xa[u]; }
-                const double* __restrict__ ve = vp + (int64_t)k * FS_SLICE;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool row_on = live && !(edge_rows && i == 3);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) v[u][i][j] = row_on ? fs_ldv<NT>(&ve[(int64_t)(i * 4 + j) * plane]) : 0.0;
-                    v[u][i][3] = (row_on && pc) ? fs_ldv<NT>(&ve[(int64_t)(i * 4 + 3) * plane]) : 0.0;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] += v[u][i][0] * xa[u].x + v[u][i][1] * xa[u].y + v[u][i][2] * xb[u].x + v[u][i][3] * xb[u].y;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[w][i][lane] = acc[i];
-        __syncthreads();
-        if (r < n_rows) {
-            // wave w adds up block-row w
-            const double sum = ((part[0][w][lane] + part[1][w][lane]) + part[2][w][lane]) + part[3][w][lane];
-            y[r * 4 + w] = (edge_rows && w == 3) ? x[r * 4 + 3] : sum;
-        }
-        __syncthreads();
-    }
-}
+#include "fs_krylov_block4.inc"      // the product of 4 x 4-block Taylor-Hood operators (k_sell_spmv4_rows, k_sell_spmv4_ksplit)
 
 int fs_spmv_dev(fs_matrix_s* A, const double* x, double* y, hipStream_t s) {
     if (A->bs == 4 && !getenv("FS_SPMV4_GENERIC")) {
