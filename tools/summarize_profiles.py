@@ -183,7 +183,7 @@ def main():
         key = first(ph, "k_dict_cg_iter<3")         # the one-launch CG iteration (update k + product k + 1; up to 3 M rows)
         if key is not None:
             out["cg_iter_" + size] = int(hbm(key))
-        key = first(ph, "k_assemble_p1_scalar_gather")
+        key = first(ph, "k_assemble_p1_box_gather", "k_assemble_p1_scalar_gather")      # (box meshes: the geometry-free form, round 6)
         if key is not None:
             out["assemble_" + size] = int(hbm(key))
     json.dump(out, open(os.path.join(OUT, TAG + "_pmc.json"), "w"), indent=1)
