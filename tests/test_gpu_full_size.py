@@ -71,6 +71,27 @@ def test_config2_family_10m_dof_hbm_resident(gpu):
         assert V.n_dia_slices == V.n_slices             # every slice of the Kuhn cube is stored in DIA form
     zc = np.repeat(np.arange(n + 1) / n, (n + 1) ** 2)
     assert np.abs(x.get() - (350.0 - 50.0 * zc)).max() <= 2e-3
+    # round 6: the solve's products went through the marching-window kernel (launch shape 6 x 2: mesh lines of 216 rows) ...
+    assert st["row_classes"] > 0 and st["product_kind"] == 3
+    _marching_windows_equal_work_items(gpu, V, A)
+
+
+def _marching_windows_equal_work_items(gpu, V, A):
+    """... and k_box_spmv = k_dict_spmv BIT FOR BIT on the assembled, Dirichlet-constrained operator at this size (the production launch
+    geometry: hundreds of patches x chunks of planes), on a vector of pseudo-random numbers."""
+    rng = np.random.default_rng(11)
+    xv = gpu.DeviceVector(V.n_local)
+    xv.set(rng.standard_normal(V.n_local))
+    ya, yb = gpu.DeviceVector(V.n_owned), gpu.DeviceVector(V.n_owned)
+    try:
+        gpu.set_option("box_spmv", 1)
+        assert A.spmv_dictionary(xv, ya) > 0 and gpu.last_product_kind() == 3
+        gpu.set_option("box_spmv", 0)
+        assert A.spmv_dictionary(xv, yb) > 0 and gpu.last_product_kind() == 1
+    finally:
+        gpu.set_option("box_spmv", 1)
+    a, b = ya.get(), yb.get()
+    assert np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()))
 
 
 def test_largest_single_gpu_p1_problem_86m_dof(gpu):
@@ -86,6 +107,9 @@ def test_largest_single_gpu_p1_problem_86m_dof(gpu):
     zmean = T.reshape(n + 1, P).mean(axis=1)
     assert np.abs(zmean - (350.0 - 50.0 * np.arange(n + 1) / n)).max() <= 5e-3     # linear in z, plane by plane
     assert T.min() >= 300.0 - 1e-6 and T.max() <= 350.0 + 1e-6                       # discrete maximum principle
+    # (launch shape 8 x 3 of the marching-window product: mesh lines of 441 rows, an ODD number of rows per plane)
+    assert st["product_kind"] == 3
+    _marching_windows_equal_work_items(gpu, V, A)
     del A, x, V, mesh
     gpu.trim_memory()
     big = gpu.DeviceMesh.box(480, 480, 480)                                           # 663 M tets: 4 nc >= 2^31
