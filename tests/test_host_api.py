@@ -806,3 +806,20 @@ def test_p2p_fallback_keeps_the_ranks_paired(monkeypatch):
     with pytest.raises(L.BackendError):
         B._with_p2p_fallback(sp, solve_b)
     assert len(calls) == 2 and sp.off == 1
+
+
+def test_marching_window_launch_planning(tmp_path):
+    """fs_box.h: box_recognize / box_cut / box_lds_bytes over 3 000 box shapes (even and odd strides, lines shorter and longer than a
+    patch, one plane per chunk): patches tile the plane, every plane sits in exactly one chunk, every unit is taken by exactly one
+    workgroup of the kernel's own loop, the window slots hold every position a step reads - compiled with hipcc, run on the CPU."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    exe = str(tmp_path / "box_plan_check")
+    p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "fenicssolver_amd", "csrc"),
+                        "-o", exe, os.path.join(ROOT, "tests", "cpp", "box_plan_check.cpp")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120).stdout.decode()
+    assert out.startswith("ok "), out
