@@ -337,7 +337,8 @@ def _bilinear_form(keep, stiffness=None, mass=None, lame=None, advection=None, a
 
 
 def apply_operator(space, x, y, stiffness=None, mass=None, advection=None, advection_scale=1.0, supg_pe=0.0, reps=0):
-    """Matrix-free y = K(form) x on a scalar CG1 space over tetrahedra (no matrix is formed, no Dirichlet rows).
+    """Matrix-free y = K(form) x on a scalar CG1 or CG2 space over tetrahedra (no matrix is formed, no Dirichlet rows; CG2: constant
+    or per-cell scalar coefficients, no advection).
     reps > 1: also returns the mean milliseconds of reps products timed with HIP events."""
     keep = []
     f = _bilinear_form(keep, stiffness, mass, None, advection, advection_scale, supg_pe)

@@ -538,13 +538,16 @@ __device__ __constant__ double FS_TET14_QW[14] = {
 
 // ADV: + scale * int phi_a (v . grad phi_b) dx with a constant or per-cell velocity (inner(velocity, grad(T))*Tq*capacity*dx,
 // ScalarTransportSolver.py:305-311, with fe_degree 2); a separate instantiation, the symmetric kernel keeps its registers
-template <bool ADD, bool ADV = false>
+// APPLY (round 6, fs_operator_apply on CG2 spaces): the matrix-free product val[row] = (form x)[row] - the same walk with the row of
+// the local matrix multiplied into the x values of the cell's ten nodes (cell_dofs) instead of stored; no LDS accumulator.
+template <bool ADD, bool ADV = false, bool APPLY = false>
 __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ inc_slice_ptr, int64_t inc_entries, const int32_t* __restrict__ inc_cell,
     const uint32_t* __restrict__ inc_pos, const int32_t* __restrict__ cells, const double* __restrict__ xyz4,
     coef_dev kc, coef_dev mc, double* __restrict__ val, const int32_t* __restrict__ order, const box_snap bx,
-    coef_dev ac = coef_dev(), double ascale = 0.0, double supg_pe = 0.0) {
+    coef_dev ac = coef_dev(), double ascale = 0.0, double supg_pe = 0.0,
+    const int32_t* __restrict__ cell_dofs = nullptr, const double* __restrict__ xvec = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [width][blockDim.x]
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, wpb = bd >> 6;
@@ -557,7 +560,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
         const int width = (int)((slice_ptr[s + 1] - base) >> 6);
         const int64_t ibase = inc_slice_ptr[s];
         const int iwidth = (int)((inc_slice_ptr[s + 1] - ibase) >> 6);
-        for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        if (!APPLY)
+            for (int k = 0; k < width; ++k) lds_acc[k * bd + tid] = 0.0;
+        double yacc = 0.0;
         // loads issued ahead of their use, as in the P1 kernel: the records of the next group while this one is worked on,
         // the cell records of a group before its first coordinate load
         constexpr int PF = 4;
@@ -690,12 +695,21 @@ __global__ void __launch_bounds__(FS_BLOCK) k_assemble_p2_scalar_gather(
                     for (int b = 0; b < 10; ++b) row[b] += w * (vx * gp[b][0] + vy * gp[b][1] + vz * gp[b][2]) + wm * pb[b];
                 }
             }
+            if (APPLY) {
 #pragma unroll
-            for (int b = 0; b < 10; ++b) {
-                const int k = (pw[b >> 2] >> (8 * (b & 3))) & 255;
-                lds_acc[k * bd + tid] += row[b];
+                for (int b = 0; b < 10; ++b) yacc += row[b] * xvec[cell_dofs[(int64_t)c * 10 + b]];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 10; ++b) {
+                    const int k = (pw[b >> 2] >> (8 * (b & 3))) & 255;
+                    lds_acc[k * bd + tid] += row[b];
+                }
             }
           }
+        }
+        if (APPLY) {
+            if (s * FS_SLICE + lane < n_rows) val[s * FS_SLICE + lane] = yacc;
+            continue;
         }
         for (int k = 0; k < width; ++k) {
             const int64_t e = base + (int64_t)k * FS_SLICE + lane;
@@ -3232,8 +3246,8 @@ extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_
     FS_REQUIRE(V && form && x && y, "fs_operator_apply: null pointer");
     fs_space_s* sp = V;
     fs_mesh_s* m = sp->mesh;
-    FS_REQUIRE(m->tdim == 3 && sp->degree == 1 && sp->ncomp == 1 && sp->inc_cell.p,
-               "fs_operator_apply: built for scalar CG1 spaces on tetrahedra");
+    FS_REQUIRE(m->tdim == 3 && (sp->degree == 1 || sp->degree == 2) && sp->ncomp == 1 && sp->inc_cell.p,
+               "fs_operator_apply: built for scalar CG1 / CG2 spaces on tetrahedra");
     FS_REQUIRE(x->d.n >= sp->n_dofs_local && y->d.n >= sp->n_dofs_owned && x != y, "fs_operator_apply: vector too short (or x is y)");
     hipStream_t s = fs_rt().stream;
     dbuf<double> kstore, mstore, astore;
@@ -3247,10 +3261,19 @@ extern "C" int fs_operator_apply(fs_space_t V, const fs_bilinear_form* form, fs_
                "fs_operator_apply: coefficients must be constant or per cell");
     const int wpb = FS_BLOCK / 64;
     const int g = (fs_grid_for((sp->n_slices + wpb - 1) / wpb, 1, 8192) + 7) & ~7;
+    if (sp->degree == 2) {
+        FS_REQUIRE(sp->cell_dofs && ac.mode == FS_COEF_NONE && (kc.mode == FS_COEF_NONE || kc.mode == FS_COEF_CONST || kc.mode == FS_COEF_CELL),
+                   "fs_operator_apply: CG2 spaces take constant or per-cell scalar coefficients and no advection");
+    }
     auto go = [&]() {
-        hipLaunchKernelGGL(k_assemble_p1_scalar_gather<2>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
-                           sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale,
-                           form->supg_pe, y->d.p, sp->slice_order.p, make_box_snap(m), x->d.p);
+        if (sp->degree == 2)
+            hipLaunchKernelGGL((k_assemble_p2_scalar_gather<false, false, true>), dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                               sp->inc_slice_ptr.p, sp->inc_entries, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, y->d.p, sp->slice_order.p,
+                               make_box_snap(m), coef_dev(), 0.0, 0.0, sp->cell_dofs, x->d.p);
+        else
+            hipLaunchKernelGGL(k_assemble_p1_scalar_gather<2>, dim3(g), dim3(FS_BLOCK), 0, s, sp->n_nodes_owned, sp->n_slices, sp->slice_ptr.p,
+                               sp->inc_slice_ptr.p, sp->inc_cell.p, sp->inc_pos.p, m->cells.p, m->xyz.p, kc, mc, ac, form->advection_scale,
+                               form->supg_pe, y->d.p, sp->slice_order.p, make_box_snap(m), x->d.p);
     };
     go();
     if (reps > 1 && ms_per_launch) {      // HIP events around reps further launches on the library's stream

@@ -330,7 +330,7 @@ int fs_apply_dirichlet(fs_matrix_t A, fs_vector_t b, int64_t n, const int32_t* d
  * attached and a communicator up, ghosts of x are refreshed first. */
 int fs_spmv(fs_matrix_t A, fs_vector_t x, fs_vector_t y);
 
-/* Matrix-free product y = K(form) x on a scalar CG1 space over tetrahedra (what `assemble(a)` followed by MatMult
+/* Matrix-free product y = K(form) x on a scalar CG1 or (round 6: constant / per-cell scalar coefficients, no advection) CG2 space over tetrahedra (what `assemble(a)` followed by MatMult
  * would give, SolverBase.py:586-590, without forming the matrix): the row-gather assembly walk with every local row
  * multiplied into x.  No Dirichlet rows (callers mask); x must carry current ghost values.  reps > 1 with
  * ms_per_launch != NULL additionally times reps launches with HIP events (mean milliseconds per product). */
