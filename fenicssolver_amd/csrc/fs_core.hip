@@ -336,6 +336,8 @@ extern "C" int fs_init(int device_id) {
                 (void)hipGetLastError();
             });
         }
+        // (measured and not kept, round 6: the three objects on three threads - the runtime's loader takes them one after the other
+        // whoever asks: 49 + 11.5 ms, and the helper thread's first graph then queues behind them, 12 ms more)
         fs_symbolic_preload();
         lap("set-up object (rocPRIM)");
         fs_assemble_preload();
