@@ -17,8 +17,6 @@
 // flight, so the stream never drains.
 #include "fs_common.h"
 #include "fs_kernels.h"
-#define BOX_DC_AUX 2      // (fs_box.h: dot weights and class numbers are read once - streamed past the caches)
-#include "fs_box.h"
 #include <functional>
 #include <chrono>
 #include <string>
@@ -71,6 +69,10 @@ struct row_dict_scope {
 
 #include "fs_krylov_iter.inc"      // the Krylov iterations' device side: CG / BiCGStab / pipelined CG update kernels, the one-launch iteration k_dict_cg_iter, the peer-to-peer exchange kernel
 
+#define BOX_DC_AUX 2      // (fs_box.h: dot weights and class numbers are read once - streamed past the caches)
+#include "fs_box.h"                // the marching-window product of P1 box operators (k_box_spmv) and its launch planning
+#include "fs_krylov_boxiter.inc"   // ... and the one-launch CG iteration in the same form (k_box_cg_iter)
+
 // ---- host side --------------------------------------------------------------------------------
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
 static int g_spmv_blocks = 1024;
@@ -106,6 +108,13 @@ static int g_cg_fused = -1;      // one launch per CG iteration on row-dictionar
 static int g_row_dictionary = 1; // row-dictionary product where the operator allows it (0: always the streaming kernels)
 // the marching-window product of P1 box operators (fs_box.h): option "box_spmv" (0: k_dict_spmv everywhere), from "box_min_rows" rows on
 static int g_last_product_kind = 0;      // fs_last_product_kind()
+// (OPT-IN: measured on MI355X, tools/probes/fused_iter_probe.py - 1 M rows 25.1 us per iteration two steps ahead / 29.5 one step ahead
+// against 21.5 for k_dict_cg_iter; 3 M rows 50.2 against 50.8; 4.9 M rows 85 against 92 - 97 for the two launches; 10 M rows 208 against 170:
+// a marching step costs 1.5 - 2 us whatever it moves - 31 global_load_lds issues per round on two loader waves, three dependent LDS round
+// trips, a barrier -, which long marches over HBM-resident data amortise and the ten steps of a cache-resident launch do not)
+static int g_box_iter = getenv("FS_BOX_ITER") ? atoi(getenv("FS_BOX_ITER")) : 0;                    // option "box_iter"
+static int g_box_iter_ahead = getenv("FS_BOX_ITER_AHEAD") ? atoi(getenv("FS_BOX_ITER_AHEAD")) : 2;
+static int64_t g_box_iter_min_rows = getenv("FS_BOX_ITER_MIN_ROWS") ? atoll(getenv("FS_BOX_ITER_MIN_ROWS")) : 400000;
 static int g_box = getenv("FS_BOX_SPMV") ? atoi(getenv("FS_BOX_SPMV")) : 1;                    // option "box_spmv"
 static int64_t g_box_min_rows = getenv("FS_BOX_MIN_ROWS") ? atoll(getenv("FS_BOX_MIN_ROWS")) : 1500000;
 
@@ -131,6 +140,11 @@ extern "C" int fs_set_option(const char* name, double value) {
     } else if (!strcmp(name, "update_blocks")) {
         FS_REQUIRE(value >= 1 && value <= 65535, "update_blocks must be in [1,65535]");
         g_update_blocks = (int)value;
+    } else if (!strcmp(name, "box_iter")) {
+        g_box_iter = value != 0.0;
+    } else if (!strcmp(name, "box_iter_min_rows")) {
+        FS_REQUIRE(value >= 0, "box_iter_min_rows must be >= 0");
+        g_box_iter_min_rows = (int64_t)value;
     } else if (!strcmp(name, "box_spmv")) {
         g_box = value != 0.0;
     } else if (!strcmp(name, "box_min_rows")) {
@@ -1006,6 +1020,58 @@ static const box_plan_s* box_plan_for(const fs_space_s* sp, int ncls) {
     }
     return B.shape >= 0 ? &B : nullptr;
 }
+// launch plan of the one-launch iteration in marching-window form (k_box_cg_iter): patches of <= 512 rows (4 compute waves x 2 rows per
+// lane + 2 loaders); the loaders one step ahead with two workgroups per CU, or two steps ahead with one (option "box_iter_ahead").
+// The same geometry serves product 0 of the solve (k_box_spmv<3, 6, 2, 2, 2>: its patches may be anything up to 768 rows).
+struct box_iter_plan_s {
+    unsigned long long space_serial = 0;
+    int ncls = 0, ahead = 0, ok = 0;
+    box_geom g;
+    size_t lds = 0, lds_product = 0;
+};
+static box_iter_plan_s g_box_iter_plan;
+static const box_iter_plan_s* box_iter_plan_for(const fs_space_s* sp, int ncls) {
+    if (!g_box_iter || !g_box || sp->box_a <= 0 || sp->n_nodes_owned < g_box_iter_min_rows || sp->halo.active) return nullptr;
+    box_iter_plan_s& B = g_box_iter_plan;
+    const int D = g_box_iter_ahead == 2 ? 2 : 1;
+    if (B.space_serial != sp->serial || B.ncls != ncls || B.ahead != D) {
+        B.space_serial = sp->serial; B.ncls = ncls; B.ahead = D; B.ok = 0;
+        int32_t starts[8] = {0, (int32_t)-(sp->box_a + sp->box_b + 1), (int32_t)-(sp->box_b + 1), -(sp->box_a + 1), -1, sp->box_a, (int32_t)sp->box_b, (int32_t)(sp->box_a + sp->box_b)};
+        const uint8_t lens[8] = {0, 2, 2, 2, 3, 2, 2, 2};
+        box_geom g;
+        if (ncls * BOX_TERMS * 8 <= (24 << 10) && box_recognize(starts, lens, 8, sp->n_nodes_owned, 3, &g)) {
+            const int cus = fs_rt().compute_units > 0 ? fs_rt().compute_units : 256;
+            g.S = sp->dict_slots;
+            box_geom t = g;
+            box_cut(&t, 512, cus, 1);
+            size_t lds = box_iter_lds_bytes(t, ncls, D);
+            const int per_cu = (int)std::min<size_t>((size_t)(160 << 10) / (lds + 256), 2);
+            if (per_cu >= 1 && 3 * t.G * (D - 1) <= 62 && (3 * (t.dslot >> 7) + (t.cslot >> 9)) * (D - 1) <= 62) {
+                t = g;
+                box_cut(&t, 512, cus * per_cu, 1);
+                B.g = t;
+                B.lds = box_iter_lds_bytes(t, ncls, D);
+                B.lds_product = box_lds_bytes(t, ncls, 2, true);
+                B.ok = t.grid <= 1024 && B.lds_product <= (size_t)(160 << 10);
+                if (B.ok) {
+                    box_prepare_kernels();
+                    static bool attr = false;
+                    if (!attr) {
+                        attr = true;
+                        (void)hipFuncSetAttribute((const void*)k_box_cg_iter<4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                        (void)hipFuncSetAttribute((const void*)k_box_cg_iter<4, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+        }
+        if (getenv("FS_KRYLOV_DEBUG"))
+            fprintf(stderr, "[fs_krylov] marching-window iteration: ok %d, %d step(s) ahead, patches %d x %d rows, %d chunks of %d planes, %d workgroups, %zu B of LDS\n",
+                    B.ok, D, B.g.P, B.g.L, B.g.ZC, B.g.nz, B.g.grid, B.lds);
+    }
+    return B.ok ? &B : nullptr;
+}
+
 template <int DOTS>
 static void launch_box(const box_plan_s* B, const uint16_t* cls, const double* dict, int ncls, const double* x, double* y, const double* rvec,
                        double* partials, int* status, int part_base, int part_stride, int bump, hipStream_t s) {
@@ -1597,7 +1663,9 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                               g_dict.bs == 1 && g_dict.built_for && g_dict.built_for == aval && sp->n_dict_items > 0 &&
                               (size_t)g_dict.ncls * g_dict.S * sizeof(double) <= (size_t)FS_DICT_WHOLE_LDS_BYTES &&
                               nl < ((int64_t)1 << 29) && sp->dict_run_len == 3 && sp->dict_runs == 8 && (fused_opt > 0 || n <= fused_max_rows);
-    const int igrid = fused_common ? spmv_partials_unsplit(sp, bs) : 0;        // workgroups (= dot partials) of the iteration kernel
+    // (round 6) P1 boxes from 400 k rows on: the iteration in marching-window form (k_box_cg_iter), with its own launch geometry
+    const box_iter_plan_s* BI = (fused_common && !sp->halo.active && fuse_sums) ? box_iter_plan_for(sp, g_dict.ncls) : nullptr;
+    const int igrid = fused_common ? (BI ? BI->g.grid : spmv_partials_unsplit(sp, bs)) : 0;        // workgroups (= dot partials) of the iteration kernel
     const bool fused_sized = fused_common && 3 * (int64_t)igrid * 2 <= (int64_t)ws.partials.n && igrid <= 4 * FS_BLOCK;
     const bool fused = fused_sized && fuse_sums && !sp->halo.active;
     // a decomposed space: the same kernel after the peer-to-peer exchange kernel (two launches per iteration instead of three) - where
@@ -1851,7 +1919,13 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                      reinterpret_cast<const dict_plan_round*>(sp->dict_plans.p), g_dict.cls.p, g_dict.values.p, g_dict.S, g_dict.ncls, \
                      Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], igrid, \
                      ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, dict_map_xcd(), ws.sums.p, mirror_dev
-                    if (fusedp) {
+                    if (BI && !fusedp) {
+#define FS_BOX_ITER_ARGS dim3(igrid), dim3(6 * 64), BI->lds, s, BI->g, g_dict.cls.p, g_dict.values.p, g_dict.ncls, Z[par], W[par], SV[par], Z[par ^ 1], W[par ^ 1], \
+                         SV[par ^ 1], ws.p.p, x->d.p, ws.dvec.p, PT[par], PT[par ^ 1], igrid, ws.ctrl.p, ws.scal.p, ws.status.p, ws.it_ctr.p, par, hist_p, mirror_dev
+                        if (BI->ahead == 2) hipLaunchKernelGGL((k_box_cg_iter<4, 2, 2, 2>), FS_BOX_ITER_ARGS);
+                        else hipLaunchKernelGGL((k_box_cg_iter<4, 2, 1, 2>), FS_BOX_ITER_ARGS);
+#undef FS_BOX_ITER_ARGS
+                    } else if (fusedp) {
                         launch_exchange(par);
                         hipLaunchKernelGGL((k_dict_cg_iter<3, true>), FS_ITER_ARGS);
                     } else hipLaunchKernelGGL((k_dict_cg_iter<3, false>), FS_ITER_ARGS);
@@ -1864,14 +1938,21 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                         FS_CHECK(fs_halo_exchange_dev(sp, ws.z.p, s));
                         p2p_ghosts_in = true;
                     }
-                    launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
+                    if (BI && !fusedp) {
+                        // (the product kernel on the ITERATION's patches and chunks: one dot partial per workgroup of either kernel)
+                        box_plan_s P0;
+                        P0.g = BI->g; P0.lds = BI->lds_product; P0.shape = 0;
+                        launch_box<3>(&P0, g_dict.cls.p, g_dict.values.p, g_dict.ncls, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, 0, igrid, 1, s);
+                        g_last_product_kind = 3;
+                    } else
+                        launch_spmv<3>(A, ws.z.p, ws.w.p, ws.dvec.p, ws.partials.p, ws.status.p, s, aval, nullptr, 0, 0, 0, 0);
                 }
                 if (graph_sized && graphs_allowed && k >= first_plain && kend - k == bsz && kend <= max_iter && (bsz & 1) == 0 && (k & 1) == 0) {
                     const void* key[24] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p, ws.dvec.p, ws.p.p, ws.s.p,
                                            ws.z2.p, ws.w2.p, ws.s2.p, ws.it_ctr.p, g_dict.cls.p, g_dict.values.p, sp->dict_items.p, sp->dict_plans.p,
                                            ws.ctrl.p, ws.scal.p, snd2[0].own_recv, red2[0].own_buf,
                                            fusedp ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation + 1) : nullptr};
-                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (fusedp ? 1 : 0) + (mirror_dev ? 2 : 0), bsz, igrid,
+                    const int64_t key_i[8] = {n, ((int64_t)g_dict.ncls * 256 + g_dict.S) * 4 + (fusedp ? 1 : 0) + (mirror_dev ? 2 : 0), bsz + 4096 * (BI ? BI->ahead : 0), igrid,
                                               (int64_t)dict_map_xcd() + 16 * (int64_t)p2p_rows_cap,
                                               (int64_t)sp->n_dict_items, (int64_t)A->serial, (int64_t)sp->serial};
                     if (!ws.cgf_graph || memcmp(key, ws.cgf_key, sizeof(key)) || memcmp(key_i, ws.cgf_key_i, sizeof(key_i))) {
@@ -2235,7 +2316,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
         stats->fused_iteration = fusedp_used ? 2 : (fused ? 1 : 0);
         stats->classes_kept = g_dict.built_for && g_dict.kept ? 1 : 0;
         stats->launches = n_launches;
-        stats->product_kind = fused ? 1 : g_last_product_kind;
+        stats->product_kind = fused ? (BI ? 3 : 1) : g_last_product_kind;
         if (fused) stats->update_ms = 0.0;       // (spmv_ms is the whole iteration: one launch)
     }
     if (h_status[0] == 2) {

@@ -91,6 +91,8 @@ const char* fs_version(void);
  * "box_snap" (0 / 1: box meshes snap their edge vectors to the grid spacing so that equal stencils are equal bit for bit),
  * "box_assembly" (1 / 0: scalar CG1 operators on fs_mesh_create_box meshes are assembled from the reference rows of the six cell types instead of
  * per-incidence geometry - the same bits), "box_spmv" (1 / 0) and "box_min_rows" (default 1 500 000): the marching-window product k_box_spmv,
+ * "box_iter" (0 / 1, default 0: opt-in) and "box_iter_min_rows" (default 400 000): the one-launch CG iteration of P1 box operators in marching-window
+ * form (k_box_cg_iter; iterates equal to the other forms to rounding, not bit for bit; measured slower than k_dict_cg_iter up to 3 M rows),
  * "amg_coarse_fp32" (1 / 0, default 1: hierarchies built from now on keep the 6 x 6-block coarse operators and the transfer operators
  * the V-cycle streams rounded to fp32 - vectors, accumulation, the fine level and the CG outside stay fp64; fs_amg_level_get keeps
  * returning the fp64 operators; FS_AMG_FP32=0 in the environment is the same switch). */

@@ -851,6 +851,43 @@ def test_solves_through_the_marching_window_product(gpu, method, scale):
     assert s1["true_rel_residual"] <= 5e-10
 
 
+@pytest.mark.parametrize("dims,ahead", [((47, 47, 47), None), ((40, 41, 30), None), ((99, 20, 12), None)])
+def test_one_launch_iteration_in_marching_window_form(gpu, dims, ahead):
+    """k_box_cg_iter (option "box_iter", opt-in: fs_krylov_boxiter.inc) - update k + product k + 1 of a P1 box operator with the windows
+    of r, w, s through an LDS ring - against k_dict_cg_iter on the same solve: same iteration count, solutions equal to rounding
+    (the dot partials have another geometry), true residual at the tolerance; shapes with odd and even strides."""
+    nx, ny, nz = dims
+    mesh = gpu.DeviceMesh.box(nx, ny, nz)
+    V = gpu.DeviceSpace(mesh, 1)
+    A = gpu.DeviceMatrix(V)
+    nn = (nx + 1) * (ny + 1)
+    dofs = np.concatenate([np.arange(nn), np.arange(nz * nn, (nz + 1) * nn)]).astype(np.int32)
+    vals = np.concatenate([np.full(nn, 350.0), np.full(nn, 300.0)])
+    res = {}
+    try:
+        gpu.set_option("box_iter_min_rows", 0)
+        gpu.set_option("cg_fused", 1)
+        for on in (1, 0):
+            gpu.set_option("box_iter", on)
+            A.assemble(stiffness=20.0)
+            b = gpu.DeviceVector(V.n_owned)
+            gpu.assemble_vector(V, b, source=1.0)
+            A.apply_dirichlet(b, dofs, vals, True)
+            x = gpu.DeviceVector(V.n_owned)
+            st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=3000)
+            assert st["converged"] == 1 and st["fused_iteration"] == 1 and st["row_classes"] > 0, st
+            assert st["product_kind"] == (3 if on else 1), st          # (3: the marching-window form ran)
+            res[on] = (st, x.get())
+    finally:
+        gpu.set_option("box_iter", 0)
+        gpu.set_option("box_iter_min_rows", 400000)
+        gpu.set_option("cg_fused", -1)
+    (s1, x1), (s0, x0) = res[1], res[0]
+    assert s1["iterations"] == s0["iterations"], (s1, s0)
+    assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
+    assert s1["true_rel_residual"] <= 2e-10
+
+
 def test_block_row_dictionary_product_bits_and_the_amg_solve(gpu):
     """Vector P1 space on a uniform box (round 4): the 3 x 3 block rows of the elasticity operator repeat (33 classes at any size;
     the elasticity kernel snaps its edge vectors like the scalar ones) and the products of fs_amg_solve - four per V-cycle on the
