@@ -1021,11 +1021,15 @@ def main():
             cal = time.perf_counter() - t0
             n_cpu = n if cal * (n / 32.0) ** 4 < 60.0 else 49
             ref = c_oracle.heat_box_solve(n_cpu, n_cpu, n_cpu, axis=axis, rtol=a.rtol)
+            # (the host cores of a box are shared and the figure moved by 1.5 x between leases, VERDICT r5: the faster of two passes)
+            ref2 = c_oracle.heat_box_solve(n_cpu, n_cpu, n_cpu, axis=axis, rtol=a.rtol)
+            if ref2["t_assemble"] + ref2["t_solve"] < ref["t_assemble"] + ref["t_solve"]:
+                ref = ref2
             cpu_s = ref["t_assemble"] + ref["t_solve"]
             scale = np.abs(ref["x"]).max()
             out["cpu_baseline"] = {
                 "value": round((n_cpu + 1) ** 3 / cpu_s, 1), "unit": "DOF/s", "cores": ref["threads"], "kind": "port",
-                "sample": "%s once (n=%d: assemble %.3f s + %d PCG iterations %.3f s; "
+                "sample": "%s, the faster of two passes (n=%d: assemble %.3f s + %d PCG iterations %.3f s; "
                           "pattern build %.2f s excluded as on the GPU)" % (
                               "the full step workload" if n_cpu == n else "a smaller cube of the same family",
                               n_cpu, ref["t_assemble"], ref["iterations"], ref["t_solve"], ref["t_symbolic"]),
