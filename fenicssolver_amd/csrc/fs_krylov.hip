@@ -32,7 +32,10 @@
 
 #include "fs_krylov_dict.inc"      // the row-dictionary form of scalar DIA operators: plans, class tables (k_dict_insert / compact / finish), the work-item product k_dict_spmv
 
-#include "fs_krylov_lattice.inc"      // the tile product of a lattice-ordered CG2 box operator (k_lattice_spmv) and its tables
+#define BOX_DC_AUX 2      // (fs_box.h: dot weights and class numbers are read once - streamed past the caches)
+#include "fs_box.h"                // the marching-window product of P1 box operators (k_box_spmv) and its launch planning
+#include "fs_latmarch.h"            // the marching-window product of CG2 box operators in lattice order (lm_march) and its tables
+#include "fs_krylov_lattice.inc"      // the tile product of a lattice-ordered CG2 box operator (k_lattice_spmv), its tables, k_lat_march
 
 #include "fs_krylov_dict3.inc"      // the row-dictionary product of 3 x 3 block rows (k_dict_spmv3)
 
@@ -69,9 +72,7 @@ struct row_dict_scope {
 
 #include "fs_krylov_iter.inc"      // the Krylov iterations' device side: CG / BiCGStab / pipelined CG update kernels, the one-launch iteration k_dict_cg_iter, the peer-to-peer exchange kernel
 
-#define BOX_DC_AUX 2      // (fs_box.h: dot weights and class numbers are read once - streamed past the caches)
-#include "fs_box.h"                // the marching-window product of P1 box operators (k_box_spmv) and its launch planning
-#include "fs_krylov_boxiter.inc"   // ... and the one-launch CG iteration in the same form (k_box_cg_iter)
+#include "fs_krylov_boxiter.inc"   // the one-launch CG iteration of P1 box operators in marching-window form (k_box_cg_iter)
 
 // ---- host side --------------------------------------------------------------------------------
 // tunables (fs_set_option): persistent grid size and row-loop unroll of the SpMV
@@ -87,6 +88,7 @@ static int g_spmv_unroll4 = 2;   // 4x4-block matrices (Taylor-Hood)
 // UNION of its two alternating row patterns (an x-edge row of 27 entries rides the 26 runs of its vertex neighbours).  The kernel
 // is bound by those instructions, not by dependent rounds.  Option "lattice_order" / FS_LATTICE=1 turn it on.
 static int g_lat_check = getenv("FS_LATTICE_CHECK") && getenv("FS_LATTICE_CHECK")[0] == '1' ? 1 : 0;      // option "lattice_check"
+static int g_lat_march = getenv("FS_LATTICE_MARCH") ? atoi(getenv("FS_LATTICE_MARCH")) : 1;       // option "lattice_march": k_lat_march (fs_latmarch.h) where its tables can be built; 0: the tile product
 static int g_lattice = getenv("FS_LATTICE") ? (getenv("FS_LATTICE")[0] == '1' ? 1 : (getenv("FS_LATTICE")[0] == '0' ? 0 : -1)) : -1;
 constexpr int64_t FS_LATTICE_MIN_ROWS = 270000;     // automatic (-1): from here on (us per iteration, lattice order against the space's: 250 k rows 29.0 / 26.2, 275 k: 26.4 / 34.9,
                                                     // 300 k: 29.5 / 35.5, 1.03 M: 52.6 / 98.8 with the first tile kernel; it was 400 000 until the tile product got to 120 us at 10 M rows)
@@ -164,6 +166,9 @@ extern "C" int fs_set_option(const char* name, double value) {
         g_cg_ahead = (int)value;
     } else if (!strcmp(name, "lattice_check")) {
         g_lat_check = value != 0.0 ? 1 : 0;
+    } else if (!strcmp(name, "lattice_march")) {
+        if (g_lat_march != (value != 0.0 ? 1 : 0)) g_lat.tables_ok = false;       // (the tables of either form are made with the lists: lat_prepare)
+        g_lat_march = value != 0.0 ? 1 : 0;
     } else if (!strcmp(name, "lattice_order")) {
         g_lattice = value < 0.0 ? -1 : (value != 0.0 ? 1 : 0);
     } else if (!strcmp(name, "cg_mirror")) {
@@ -779,6 +784,70 @@ __global__ void k_lat_count_diff(int64_t n, const double* __restrict__ a, const 
     if (c) atomicAdd(out, c);
 }
 
+// ---- the marching-window product of a lattice-ordered CG2 box operator (fs_latmarch.h, k_lat_march) -----------------------------------
+// One workgroup per CU: seven line waves - a wave a line of the patch - and a loader; the rings (window, step lists, dot weights:
+// three slots each, the loaders two steps ahead) take up to 150 KB of LDS.  Lines of up to 64 or 128 pairs (RP = 1, 2 pieces).
+// Its tables (coefficient rows by stencil position, the row numbers of the lines, the step lists) are built - and every class, every
+// line checked against what the kernel assumes - by lat_prepare behind the lists of the tile product; an operator that does not fit
+// (an entry outside its parity's stencil, a line whose interior rows are of several classes) keeps the tile product.
+struct lat_march_s {
+    dbuf<int32_t> used;         // [ncls 8]
+    dbuf<double> coefS;         // [ncls 8 + 1][LM_CS]; the last row: zeros
+    dbuf<uint32_t> lc;          // [NY][LZ]: row numbers of the lines
+    dbuf<int32_t> tab, rep, num;            // the hash table over the tuples, a tuple's first-come twin, its list number
+    dbuf<int32_t> sl_line;      // [NS2][NYP]: list numbers
+    dbuf<double> SL;            // [lists][LM_SL]
+    int n_lists = 0;
+    lm_geom g = {};
+    size_t lds = 0;
+    bool ok = false;            // the tables describe the dictionary g_lat's lists were made for
+};
+static lat_march_s g_lm;
+template <int DOTS>
+static void lm_set_lds_attribute() {
+    (void)hipFuncSetAttribute((const void*)k_lat_march<DOTS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 << 10);
+    (void)hipFuncSetAttribute((const void*)k_lat_march<DOTS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 << 10);
+}
+static void lm_prepare_kernels() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    lm_set_lds_attribute<0>(); lm_set_lds_attribute<1>(); lm_set_lds_attribute<2>(); lm_set_lds_attribute<3>(); lm_set_lds_attribute<4>();
+    (void)hipGetLastError();
+}
+// the launch plan for a lattice; false: no shape fits
+static bool lm_plan(int64_t SX, int64_t NY, int64_t NZ, lm_geom* out, size_t* lds_out) {
+    const int cus = fs_rt().compute_units > 0 ? fs_rt().compute_units : 256;
+    const int nh = (int)((SX / 2 + 63) / 64);
+    if (nh < 1 || nh > 2 || SX * NY * (NZ + 8) >= ((int64_t)1 << 31)) return false;
+    static const int py_env = getenv("FS_LATTICE_MARCH_PY") ? atoi(getenv("FS_LATTICE_MARCH_PY")) : 0;
+    int py = LM_LW;
+    if (py_env >= 1 && py_env <= py) py = py_env;
+    for (; py >= 1; --py) {
+        lm_geom g;
+        lm_cut(&g, SX, NY, NZ, py, cus);
+        const size_t lds = std::max(lm_lds_bytes(g, 2, true), lat_lds_bytes());
+        if (lds > (size_t)(152 << 10) || g.G + g.Gd > 62) continue;
+        *out = g; *lds_out = lds;
+        return true;
+    }
+    return false;
+}
+template <int DOTS>
+static void launch_lat_march(const double* x, double* y, const double* rvec, double* partials, int* status, int part_base, int part_stride, int bump, hipStream_t s) {
+    const lm_geom& g = g_lm.g;
+    const lat_geom& G = g_lat.geom;
+    const size_t lds = std::max(lm_lds_bytes(g, 2, DOTS == 1 || DOTS == 2 || DOTS == 3), lat_lds_bytes());
+    static const int lm_dbg = getenv("FS_LM_DBG") ? atoi(getenv("FS_LM_DBG")) : 0;       // (experiments: 1 no ends of the lines, 2 no line waves, 4 no loads)
+    const int grid = G.n_extra + g.grid;
+#define FS_LM_ARGS dim3(grid), dim3(LM_WAVES * 64), lds, s, G, g, g_dict.cls.p, g_lat.cnt.p, g_lat.coef.p, g_lat.off.p, g_lat.relc.p, g_lm.SL.p, g_lm.sl_line.p, x, y, rvec, partials, \
+                   status, part_base, part_stride ? part_stride : grid, bump, lm_dbg
+    if (g.NH == 1) hipLaunchKernelGGL((k_lat_march<DOTS, 1>), FS_LM_ARGS);
+    else hipLaunchKernelGGL((k_lat_march<DOTS, 2>), FS_LM_ARGS);
+#undef FS_LM_ARGS
+}
+static int lm_grid() { return g_lat.geom.n_extra + g_lm.g.grid; }
+
 // the lists of the tile product (k_lattice_spmv) for the dictionary just built on a lattice-ordered operator; g_lat.ok says whether
 // the product may be used (every class fits a list, every row's plan agrees with its class's list, no tile has too many classes)
 static lat_geom lat_geometry(int64_t SX, int64_t NY, int64_t NZ) {
@@ -863,10 +932,51 @@ static int lat_prepare(fs_matrix_s* A, const double* val, hipStream_t s) {
     hipLaunchKernelGGL(k_lat_tile_table, dim3((unsigned)std::min<int64_t>(g_lat.geom.n_tiles, 4096)), dim3(LT_BLOCK), 0, s, g_lat.geom, SX, NY, NZ,
                        g_dict.cls.p, g_lat.cnt.p, g_lat.tile_cls.p);
     FS_KERNEL_CHECK();
-    FS_CHECK(g_lat.info.download(h, 1, s));
+    // the tables of the marching-window product (fs_latmarch.h): coefficient rows by stencil position for every (class, parity class)
+    // that occurs, the row numbers of the lines, the step lists; info[1]: entries outside their parity's stencil, info[2]: interior
+    // rows of a line that are not of the line's class, info[3]: step lists
+    g_lm.ok = false;
+    bool lm_tried = false;
+    int64_t n_tuples = 0;
+    if (g_lat_march && ncls * 8 + 1 <= 65535 && lm_plan(SX, NY, NZ, &g_lm.g, &g_lm.lds)) {
+        lm_tried = true;
+        const lm_geom& mg = g_lm.g;
+        n_tuples = (int64_t)NY * mg.NS2;
+        int64_t tab_n = 1024;
+        while (tab_n < 2 * n_tuples) tab_n *= 2;
+        if (g_lm.used.n < (int64_t)ncls * 8) { FS_CHECK(g_lm.used.alloc((int64_t)ncls * 8)); FS_CHECK(g_lm.coefS.alloc(((int64_t)ncls * 8 + 1) * LM_CS)); }
+        if (g_lm.lc.n < (int64_t)NY * mg.LZ) FS_CHECK(g_lm.lc.alloc((int64_t)NY * mg.LZ));
+        if (g_lm.rep.n < n_tuples) { FS_CHECK(g_lm.rep.alloc(n_tuples)); FS_CHECK(g_lm.num.alloc(n_tuples)); }
+        if (g_lm.sl_line.n < (int64_t)mg.NYP * mg.NS2) FS_CHECK(g_lm.sl_line.alloc((int64_t)mg.NYP * mg.NS2));
+        if (g_lm.tab.n != tab_n) FS_CHECK(g_lm.tab.alloc(tab_n));
+        FS_CHECK(g_lm.used.zero(s));
+        FS_CHECK(g_lm.coefS.zero(s));
+        FS_CHECK(g_lm.sl_line.zero(s));
+        FS_HIP(hipMemsetAsync(g_lm.tab.p, 0xff, (size_t)tab_n * 4, s));
+        hipLaunchKernelGGL(k_lm_used, dim3(fs_grid_for(n, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n, SX, NY, g_dict.cls.p, g_lm.used.p);
+        hipLaunchKernelGGL(k_lm_coef, dim3((ncls * 8 + 63) / 64), dim3(64), 0, s, ncls, SX, NY, g_lm.used.p, g_lat.cnt.p, g_lat.off.p, g_lat.coef.p, LT_ML, g_lm.coefS.p, g_lat.info.p);
+        hipLaunchKernelGGL(k_lm_lines, dim3(fs_grid_for((int64_t)NY * mg.LZ * 64, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, mg, ncls * 8, g_dict.cls.p, g_lm.lc.p, g_lat.info.p);
+        hipLaunchKernelGGL(k_lm_dedupe, dim3(fs_grid_for(n_tuples, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, mg, n_tuples, g_lm.lc.p, g_lm.tab.p, (uint32_t)(tab_n - 1), g_lm.rep.p);
+        hipLaunchKernelGGL(k_lm_number, dim3(fs_grid_for(n_tuples, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, n_tuples, g_lm.rep.p, g_lm.num.p, g_lat.info.p);
+        FS_KERNEL_CHECK();
+        lm_prepare_kernels();
+    }
+    FS_CHECK(g_lat.info.download(h, 4, s));
     if (debug) fprintf(stderr, "[lattice tiles] %d classes, tiles of %d x %d x %d rows: %d entries / rows that do not fit\n", ncls, LT_TX, LT_TY, LT_TZ, h[0]);
     g_lat.tables_ok = h[0] == 0;
     g_lat.dict_built = g_dict.n_built;
+    g_lm.ok = lm_tried && h[0] == 0 && h[1] == 0 && h[2] == 0 && h[3] > 0;
+    if (g_lm.ok) {
+        const lm_geom& mg = g_lm.g;
+        g_lm.n_lists = h[3];
+        if (g_lm.SL.n < (int64_t)h[3] * LM_SL + 64) FS_CHECK(g_lm.SL.alloc((int64_t)h[3] * LM_SL + 64));
+        hipLaunchKernelGGL(k_lm_fill, dim3(fs_grid_for(n_tuples, FS_BLOCK, 4096)), dim3(FS_BLOCK), 0, s, mg, n_tuples, g_lm.lc.p, g_lm.rep.p, g_lm.num.p, g_lm.coefS.p,
+                           g_lm.sl_line.p, g_lm.SL.p, h[3]);
+        FS_KERNEL_CHECK();
+    }
+    if (debug || getenv("FS_KRYLOV_DEBUG"))
+        fprintf(stderr, "[lattice march] %s: %d entries outside their stencil, %d interior rows not of their line's class, %d step lists; patches of %d lines, %d x %d units, %d workgroups, %zu B of LDS\n",
+                g_lm.ok ? "on" : (lm_tried ? "refused" : "off"), h[1], h[2], h[3], g_lm.g.PY, g_lm.g.NP, g_lm.g.ZC, g_lm.g.grid, g_lm.lds);
     }
     g_lat.ok = g_lat.tables_ok;
     g_lat.built_for = val;
@@ -1125,6 +1235,12 @@ static void launch_spmv(fs_matrix_s* A, const double* x, double* y, const double
             gd = spmv_grid(ns, sp->n_slices);
         }
         if (!list && g_lat.ok && g_lat.built_for == mat_val && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls) {
+            if (g_lm.ok && g_lat_march) {
+                // ... in marching-window form (k_lat_march)
+                launch_lat_march<DOTS>(x, y, rvec, partials, status, part_base, part_stride, bump, s);
+                g_last_product_kind = 5;
+                return;
+            }
             // a lattice-ordered operator: tiles of 128 x 4 x 4 rows, x through LDS (k_lattice_spmv)
             const int64_t SX = sp->dict_line, NY = sp->lat_ny, NZ = sp->lat_nz;
             const size_t lds = lat_lds_bytes();
@@ -1233,7 +1349,8 @@ static int dict_grid(const fs_space_s* sp) {
 static int spmv_partials_unsplit(const fs_space_s* sp, int bs) {
     if (bs == 1 && g_dict.built_for && g_dict.space_serial == sp->serial) {
         // (the tile product of a lattice-ordered operator has its own geometry: launch_spmv's condition)
-        if (g_lat.ok && g_lat.built_for == g_dict.built_for && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls && g_lat.geom.grid > 0) return g_lat.geom.grid;
+        if (g_lat.ok && g_lat.built_for == g_dict.built_for && g_lat.space_serial == sp->serial && g_lat.ncls == g_dict.ncls && g_lat.geom.grid > 0)
+            return g_lm.ok && g_lat_march ? lm_grid() : g_lat.geom.grid;
         if (g_dict.bs == 1 && sp->dict_runs == 8 && sp->dict_run_len == 3)
             if (const box_plan_s* B = box_plan_for(sp, g_dict.ncls)) return B->g.grid;      // (launch_spmv's condition)
         return dict_grid(sp);
@@ -1997,6 +2114,7 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                 // (the tile product of a lattice-ordered operator bakes in the list tables, the tile table and the geometry of lat_prepare:
                 // those buffers grow - are allocated anew - when another space brings more classes or tiles)
                 const bool lat_on = dict_on && g_lat.ok && g_lat.built_for == aval && g_lat.space_serial == sp->serial;
+                const bool lm_on = lat_on && g_lm.ok && g_lat_march;          // (k_lat_march bakes in its own tables and geometry)
                 const void* key[32] = {A, aval, x->d.p, hist_p, ws.z.p, ws.w.p, ws.partials.p, ws.status.p,
                                        ws.dvec.p, ws.p.p, ws.s.p, sp->sell_col.p, snd.own_recv, snd.peers, red.own_buf, red.peer_buf,
                                        dict_on ? (const void*)g_dict.cls.p : nullptr, dict_on ? (const void*)g_dict.values.p : nullptr,
@@ -2004,15 +2122,15 @@ extern "C" int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, cons
                                        dict_on ? (const void*)sp->dict_plans.p : nullptr, dict_on ? (const void*)sp->halo.items_interior.p : nullptr,
                                        dict_on ? (const void*)sp->halo.items_boundary.p : nullptr,
                                        p2p_fuse ? reinterpret_cast<const void*>((uintptr_t)sp->halo.p2p.generation) : nullptr,
-                                       lat_on ? (const void*)g_lat.tile_cls.p : nullptr, lat_on ? (const void*)g_lat.cnt.p : nullptr,
-                                       lat_on ? (const void*)g_lat.coef.p : nullptr, lat_on ? (const void*)g_lat.rel.p : nullptr,
+                                       lat_on ? (lm_on ? (const void*)g_lm.sl_line.p : (const void*)g_lat.tile_cls.p) : nullptr, lat_on ? (const void*)g_lat.cnt.p : nullptr,
+                                       lat_on ? (const void*)g_lat.coef.p : nullptr, lat_on ? (lm_on ? (const void*)g_lm.SL.p : (const void*)g_lat.rel.p) : nullptr,
                                        lat_on ? (const void*)g_lat.off.p : nullptr, lat_on ? (const void*)g_lat.relc.p : nullptr,
                                        lat_on ? reinterpret_cast<const void*>((uintptr_t)g_lat.geom.n_tiles) : nullptr,
                                        lat_on ? reinterpret_cast<const void*>(((uintptr_t)g_lat.geom.grid << 32) | (uintptr_t)(uint32_t)g_lat.geom.w_tiles) : nullptr};
                 // (+ whether the product is the row-dictionary kernel, with the class count and width its launch bakes in)
                 const int64_t dict_sig = dict_on ? ((int64_t)g_dict.ncls * 256 + g_dict.S) * 256 + g_dict.C : 0;
                 const int64_t key_i[8] = {n, (p2p_fuse ? (int64_t)p2p_rows_cap + 1 : 0) + 1024 * dict_sig, bsz, fgrid, vgrid,
-                                          (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs) + (mirror_dev ? 4 : 0),
+                                          (int64_t)upd_nt * 2 + (int64_t)spmv_nontemporal(sp, bs) + (mirror_dev ? 4 : 0) + (lm_on ? 8 + 16 * (int64_t)g_lm.g.PY + 1024 * (int64_t)g_lm.g.ZC : 0),
                                           (int64_t)A->serial, (int64_t)sp->serial};
                 if (!ws.cg_graph || memcmp(key, ws.cg_key, sizeof(key)) || memcmp(key_i, ws.cg_key_i, sizeof(key_i))) {
                     if (ws.cg_graph) { (void)hipGraphExecDestroy(ws.cg_graph); ws.cg_graph = nullptr; }
