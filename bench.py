@@ -592,6 +592,14 @@ def kernel_name(V, st=None):
     if st is not None and st.get("fused_iteration", 0):          # fs_krylov.hip k_dict_cg_iter: one launch per CG iteration
         return ("k_dict_cg_iter<3> (ONE launch per CG iteration: update of iteration k + row-dictionary product of iteration k + 1, "
                 "%d distinct rows in LDS; the new residual on the neighbour columns recomputed from the old r, w, s)" % st["row_classes"])
+    if st is not None and st.get("lattice_order", 0) and st.get("row_classes", 0) > 0 and st.get("product_kind", 0) == 5:
+        # fs_latmarch.h / fs_krylov_lattice.inc k_lat_march (round 6): the lattice-ordered shadow in marching-window form
+        return ("k_lat_march<3,%d> (row-dictionary form in the solver's LATTICE order of the half grid, %d distinct rows: windows of x MARCHING "
+                "through the lattice planes in an LDS ring filled by a loader wave with global_load_lds_dwordx4 two steps ahead; the loop "
+                "structure compile-time - eight parity stencils -, a wave per line with the partial sums of five planes' rows in registers, "
+                "the coefficients of a (line, step) one contiguous step list through scalar loads; the rows at the ends of the mesh lines "
+                "in column tiles with lanes along Y, in workgroups of their own at the front of the same launch; template arguments: dot "
+                "mode, 64-pair pieces of a line)" % (2 if round((V.n_owned) ** (1.0 / 3.0)) + 1 > 128 else 1, st["row_classes"]))
     if st is not None and st.get("lattice_order", 0) and st.get("row_classes", 0) > 0:
         # fs_krylov.hip k_lattice_spmv: the solver's lattice-ordered shadow of a scalar CG2 box operator (fs_lattice.hip)
         return ("k_lattice_spmv<3> (row-dictionary form in the solver's LATTICE order of the half grid: %d distinct rows; tiles of 128 x 4 x 4 rows, "
@@ -708,7 +716,7 @@ def committed_kernel_traffic(case, prefixes):
 
 def make_roofline(k, workload, traffic, traffic_source):
     frac = k["required_GBps"] / HBM_PEAK_GBS
-    what = " (product fused with the 3 dot products of the diagonally scaled CG)" if "k_box_spmv" in k["kernel"] else (
+    what = " (product fused with the 3 dot products of the diagonally scaled CG)" if ("k_box_spmv" in k["kernel"] or "k_lat_march" in k["kernel"]) else (
            " (DIA product fused with the 3 dot products of the diagonally scaled CG, values from a dictionary of the distinct rows in "
             "LDS, work items of 126 rows - two per lane -, one 16-byte load per run of consecutive offsets; template arguments: dot mode, "
             "whole dictionary in LDS)") if k.get("row_classes", 0) > 0 else (
@@ -766,7 +774,7 @@ def main():
             hbm = k["required_bytes_per_launch"] + UPDATE_BYTES_PER_DOF * k["rows_rank0"] > (256 << 20)
             traffic, src = (None, None)
             if world == 1 and a.mesh == "structured" and n == 107:
-                traffic, src = committed_kernel_traffic("p2", ("k_lattice_spmv<3", "k_dict_spmv<3"))
+                traffic, src = committed_kernel_traffic("p2", ("k_lat_march<3", "k_lattice_spmv<3", "k_dict_spmv<3"))
             out["roofline"] = dict(make_roofline(k, "rank 0's part of the step workload", traffic, src),
                                    update_kernel=r["update"], iteration=r["iteration"])
             out["roofline"]["kernel"] = k["kernel"] + " (product of the CG2 operator fused with the 3 CG dot products)"

@@ -815,7 +815,7 @@ def comm_benchmark(space, reps=200):
 
 def last_product_kind():
     """Kernel family of the last product this process launched (fs_last_product_kind): 0 streaming, 1 row-dictionary work items,
-    2 lattice tiles (CG2 box), 3 marching windows (P1 box), 4 block-row dictionary."""
+    2 lattice tiles (CG2 box), 3 marching windows (P1 box), 4 block-row dictionary, 5 marching windows (CG2 box in lattice order)."""
     return int(L.load().fs_last_product_kind())
 
 

@@ -826,8 +826,8 @@ static bool lm_plan(int64_t SX, int64_t NY, int64_t NZ, lm_geom* out, size_t* ld
     for (; py >= 1; --py) {
         lm_geom g;
         lm_cut(&g, SX, NY, NZ, py, cus);
-        const size_t lds = std::max(lm_lds_bytes(g, 2, true), lat_lds_bytes());
-        if (lds > (size_t)(152 << 10) || g.G + g.Gd > 62) continue;
+        const size_t lds = std::max(lm_lds_bytes(g, LM_D, true), lat_lds_bytes());
+        if (lds > (size_t)(152 << 10) || (LM_D - 1) * (g.G + g.Gd) > 62) continue;
         *out = g; *lds_out = lds;
         return true;
     }
@@ -837,7 +837,7 @@ template <int DOTS>
 static void launch_lat_march(const double* x, double* y, const double* rvec, double* partials, int* status, int part_base, int part_stride, int bump, hipStream_t s) {
     const lm_geom& g = g_lm.g;
     const lat_geom& G = g_lat.geom;
-    const size_t lds = std::max(lm_lds_bytes(g, 2, DOTS == 1 || DOTS == 2 || DOTS == 3), lat_lds_bytes());
+    const size_t lds = std::max(lm_lds_bytes(g, LM_D, DOTS == 1 || DOTS == 2 || DOTS == 3), lat_lds_bytes());
     static const int lm_dbg = getenv("FS_LM_DBG") ? atoi(getenv("FS_LM_DBG")) : 0;       // (experiments: 1 no ends of the lines, 2 no line waves, 4 no loads)
     const int grid = G.n_extra + g.grid;
 #define FS_LM_ARGS dim3(grid), dim3(LM_WAVES * 64), lds, s, G, g, g_dict.cls.p, g_lat.cnt.p, g_lat.coef.p, g_lat.off.p, g_lat.relc.p, g_lm.SL.p, g_lm.sl_line.p, x, y, rvec, partials, \

@@ -23,20 +23,35 @@
 // The window comes in as (even X, odd X) pairs: a lane reads the up to 15 pairs around its own with ds_read_b128 (conflict-free at
 // one pair per lane), 6 - 15 reads for 36 - 82 fmas per lane and step.
 // COEFFICIENTS.  What a (line, step) multiplies with is a STEP LIST: the 36 - 82 coefficients of the five rows in flight of both
-// columns, in the order the step uses them.  The lists are made once per dictionary (k_lm_dedupe .. k_lm_fill: a few hundred
-// distinct ones - the interior of the box has four); the LOADER brings the lists of the patch's lines into LDS with the window
-// (one 672-byte piece per line and step), and a line wave reads coefficient p of its line at a compile-time offset, the same
-// address in all lanes: an LDS broadcast.  (First form: scalar loads from per-class coefficient rows into SGPRs - thirteen
-// s_waitcnt lgkmcnt(0) per line task, each a scalar-cache round trip in front of a handful of fmas: 3 400 cycles per task and step
-// where the fmas take 230.)
-// A wave takes a LINE of the patch - all its pieces of 64 pairs against one stream of the line's list: a coefficient read serves
-// 2 x (pieces) fmas.
+// columns, contiguous, in the order the step uses them (window line by window line, so that a lane holds two lines of the window at a
+// time, not five).  The lists are made once per dictionary (k_lm_lines .. k_lm_fill: a few hundred distinct ones - the interior of the
+// box has four) and read through SCALAR loads: the list of a (line, step) is wave-uniform, a coefficient an SGPR operand of the fmas.
+// A wave takes a LINE of the patch - all its pieces of 64 pairs against one stream of the line's list: a coefficient serves 2 x
+// (pieces) fmas.
 // The ENDS of the lines (X < LM_LO, X > SX - 1 - LM_HI: boundary rows, the rows coupled to them, the dummy row that makes a line
 // even) have classes of their own - 4 % of the rows at configs[3].  They stay with the code of the tile product (lat_line_ends,
-// fs_krylov_lattice.inc: column tiles, lanes along Y), in workgroups of their own at the front of the grid of the same launch.
-// (Tried: end waves in every workgroup, a lane an end pair with its own step list from global memory - 44 - 106 us per product on
-// their own, a round trip per chunk of coefficients and no registers to ask further ahead.)
-// LOADER waves bring window, dot weights and step lists with global_load_lds_dwordx4, D steps ahead (fs_box.h: exact vmcnt counts).
+// fs_krylov_lattice.inc: column tiles, lanes along Y), in workgroups of their own at the front of the grid of the same launch
+// (k_lat_march, fs_krylov_lattice.inc).
+// A LOADER wave brings window and dot weights with global_load_lds_dwordx4, LM_D steps ahead (fs_box.h: exact vmcnt counts).
+//
+// MEASURED (round 6, MI355X, configs[3], 9.98 M rows; tools/probes/run_latmarch_abl.sh, profiles/r06_p2_latmarch.txt): inside the CG
+// iteration 80 - 85 us per product against 115 - 120 for k_lattice_spmv; alone, warm, 70 us without / 83 with the dots (tile product
+// 96 / 96).  The loads alone (no arithmetic) take 30 / 46 us, the line waves alone 56 / 66, the ends of the lines 12: what bounds
+// the kernel is the instruction stream of a line wave - 2 700 - 3 800 cycles per step where its fmas take 460 (cycle counters around
+// barrier and step).  Steps on the way, all bit-identical:
+//  * coefficients through scalar loads from per-class rows (ten rows a step, thirteen s_waitcnt lgkmcnt(0) per line task, a task a
+//    half line), end waves in every workgroup with per-lane lists from global memory: 75 us alone / 96 with the dots; the roles of
+//    the waves as branches INSIDE the loop over the units had hipcc's s_waitcnt insertion carry the end wave's pending vector loads
+//    into the line waves - a vmcnt(0), a wait for the stores of y, in front of every task: roles outside the loop 71 / 84;
+//  * step lists staged in LDS by the loader, read as broadcasts: ds_read_b64 pairs up into ds_read2_b64 (half rate), the volatile
+//    form is not scheduled ahead of its fma (a round trip per coefficient), 16-byte pairs in chunks streamed two or three ahead:
+//    line waves alone 50 - 72 us - an LDS round trip per chunk and no registers to ask further ahead;
+//  * end waves (two per workgroup, a lane an end pair, its list from global memory): 44 - 106 us on their own;
+//  * a wave per line and eight waves (ten spilled at 168 registers), ends by the column tiles of the tile product: 67 / 84;
+//  * the list lane-distributed in two registers, a coefficient handed out with two v_readlane_b32 (4 cycles each, tools/probes/
+//    readlane_probe.hip) - no memory round trip for coefficients at all: line waves alone 61 us, no better: not the loads of the
+//    coefficients, the whole stream (register moves that rotate the five partial sums, hazards, two waves a SIMD) is what a step costs;
+//  * loader three steps ahead: no change.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -45,10 +60,11 @@
 #include "fs_box.h"
 #include "fs_cg2_stencil.h"
 
-constexpr int LM_LO = 4, LM_HI = 5;     // rows at the two ends of a line that the end waves take (as LT_LO / LT_HI of the tile product)
+constexpr int LM_LO = 4, LM_HI = 5;     // rows at the two ends of a line that lat_line_ends takes (LT_LO / LT_HI of the tile product)
 constexpr int LM_ZPAD = 4;              // planes of padding (the zero row) on either side of the per-line row number tables
 constexpr int LM_SL = 84;               // doubles per step list (82 at most: a vertex line's even plane), 42 16-byte pairs
 constexpr int LM_LW = 7;                // line waves of a workgroup: patches of up to LM_LW lines
+constexpr int LM_D = 2;                 // steps the loader runs ahead (LM_D + 1 slots of window and dot weights)
 constexpr int LM_WAVES = LM_LW + 1;     // + the loader (eight waves: 256 registers a lane - ten waves spilled at 168)
 
 struct lm_geom {
@@ -61,7 +77,6 @@ struct lm_geom {
     int32_t ZC;                 // chunks of planes
     int32_t slot, G;            // doubles per window slot (a multiple of 128), 1 KiB pieces
     int32_t dslot, Gd;          // ... per dot-weight slot
-    int32_t cslot;              // doubles per step-list slot = PY LM_SL
     int32_t LZ;                 // entries per line of the row number tables = NZ + 2 LM_ZPAD
     int32_t NS2;                // steps a line has = NZ + 4 (window planes -2 .. NZ + 1)
     int32_t NYP;                // lines per step of sl_line = NY + LM_LW (a patch's numbers are read LM_LW at a time)
@@ -70,8 +85,6 @@ struct lm_geom {
 
 typedef double lm_v2d __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) lm_v2d* lm_lds_pairs;
-typedef const __attribute__((address_space(3))) double* lm_lds_doubles;
-typedef const lm_v2d* lm_glb_pairs;
 
 template <class F, int... I>
 __device__ __forceinline__ void lm_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
@@ -115,9 +128,8 @@ __host__ __device__ constexpr lm_variant_t lm_make_variant(int py, int jzb) {
 }
 constexpr lm_variant_t LM_VAR[2][2] = {{lm_make_variant(0, 0), lm_make_variant(0, 1)}, {lm_make_variant(1, 0), lm_make_variant(1, 1)}};
 static_assert(LM_VAR[0][0].len <= LM_SL && LM_VAR[0][1].len <= LM_SL && LM_VAR[1][0].len <= LM_SL && LM_VAR[1][1].len <= LM_SL, "step lists fit");
-// a 16-byte pair of a list or of the window, kept where it is written: list and window are STREAMED - chunk c + AHEAD of the list
-// asked for in front of the fmas of chunk c, window line dy + 1 when the fmas of line dy begin - with exact in-order s_waitcnt counts
-// (hipcc hoists plain loads: the whole list plus the window, 220 registers, spilled)
+// a 16-byte pair of the window, read where it is written: the window is STREAMED - line dy + 1 asked for when the fmas of line dy
+// begin - with in-order s_waitcnt counts (hipcc hoists plain loads: the whole window at once, 120 registers with two pieces)
 __device__ __forceinline__ lm_v2d lm_pair(lm_lds_pairs p, int j) { return *(const volatile __attribute__((address_space(3))) lm_v2d*)(p + j); }
 
 // One step of a line: its RP pieces of 64 pairs (a lane: pair lane of each piece, the two columns of the pair) against ONE stream of
@@ -347,7 +359,6 @@ static inline void lm_cut(lm_geom* g, int64_t SX, int64_t NY, int64_t NZ, int PY
     g->slot = g->G * 128;
     g->Gd = (int32_t)(((int64_t)PY * SX + 127) / 128);
     g->dslot = g->Gd * 128;
-    g->cslot = PY * LM_SL;
     g->LZ = (int32_t)NZ + 2 * LM_ZPAD;
     g->NS2 = (int32_t)NZ + 4;
     g->NYP = (int32_t)NY + LM_LW;

@@ -80,7 +80,9 @@ const char* fs_version(void);
 /* Tunables: "spmv_blocks" (persistent SpMV grid, multiple of 8), "spmv_unroll"
  * (2/4/8/16 row entries in flight per lane), "spmv_unroll4" (1/2/4: the same for 4 x 4 block rows), "cg_batch" (iterations per host poll), "lattice_order" (-1 / 0 / 1: scalar CG2 operators on uniform boxes solved in
  * the lattice order of the half grid, fs_krylov_stats.lattice_order - automatic = from 270 000 rows on, where the product is then the
- * tile product k_lattice_spmv / never / wherever the order exists), "lattice_check" (0 / 1: every solve in lattice order first compares the tile product with the work-item product on a
+ * marching-window product k_lat_march or the tile product k_lattice_spmv / never / wherever the order exists), "lattice_march" (1 / 0, round 6: k_lat_march where
+ * its tables can be built - every class inside its parity's compile-time stencil, every mesh line of one class per parity away from its ends - / the tile product; the same bits),
+ * "lattice_check" (0 / 1: every solve in lattice order first compares that product with the work-item product on a
  * vector of pseudo-random numbers, every row, bit for bit - a difference fails the solve with FS_ERR_NUMERIC), "cg_mirror" (0 / 1: the one-launch iteration reports its progress
  * through pinned host memory and the host keeps "cg_ahead" to "cg_ahead" + "cg_sub" launches enqueued, instead of batches of
  * "cg_batch" with the status word copied back behind each),
@@ -394,7 +396,8 @@ typedef struct fs_krylov_stats {
     int launches;           /* iterations ENQUEUED over all passes (fs_krylov_solve): those behind the one that stopped the
                              * recurrence return on the status word - launches - iterations of them, a few microseconds each */
     int product_kind;       /* kernel family of the solve's products (fs_last_product_kind): 0 streaming, 1 row-dictionary work items
-                             * (also inside the one-launch iteration), 2 lattice tiles, 3 marching windows of a P1 box, 4 block rows */
+                             * (also inside the one-launch iteration), 2 lattice tiles, 3 marching windows of a P1 box, 4 block rows,
+                             * 5 marching windows of a CG2 box in lattice order */
 } fs_krylov_stats;
 
 int fs_krylov_solve(fs_matrix_t A, fs_vector_t b, fs_vector_t x, const fs_krylov_opts* opts,
@@ -417,8 +420,8 @@ int fs_spmv_dictionary(fs_matrix_t A, fs_vector_t x, fs_vector_t y, int* row_cla
 /* Which kernel the LAST product launched by this process went through (MatMult, SolverBase.py:663-670; a diagnostic - PETSc's
  * analogue is the -log_view line of MatMult): 0 streaming SELL / DIA kernels, 1 row-dictionary work items (k_dict_spmv), 2 lattice
  * tiles of a CG2 box (k_lattice_spmv), 3 marching windows of a P1 box (k_box_spmv, round 6: options "box_spmv" 1 / 0 and
- * "box_min_rows", default 1 500 000), 4 block-row dictionary (k_dict_spmv3).  The one-launch iteration k_dict_cg_iter does not
- * count as a product here. */
+ * "box_min_rows", default 1 500 000), 4 block-row dictionary (k_dict_spmv3), 5 marching windows of a CG2 box in lattice order
+ * (k_lat_march, round 6: option "lattice_march" 1 / 0).  The one-launch iteration k_dict_cg_iter does not count as a product here. */
 int fs_last_product_kind(void);
 
 /* ---- smoothed-aggregation AMG (PETScPreconditioner("petsc_amg") + set_near_nullspace,

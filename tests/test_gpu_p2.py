@@ -681,3 +681,51 @@ def test_two_lattice_ordered_operators_solved_in_turn(gpu):
         assert runs[k][0]["iterations"] == runs[k + 2][0]["iterations"] and np.array_equal(runs[k][1], runs[k + 2][1])
     assert np.abs(runs[0][1][:cube.n_owned] - cube.exact_owned).max() <= 1e-6 * 350.0
     assert np.abs(runs[1][1][:V.n_owned] - (350.0 - 50.0 * co[:V.n_owned])).max() <= 1e-6 * 350.0
+
+
+def test_marching_window_product_of_cg2_boxes_against_the_tile_product(gpu):
+    """k_lat_march (fs_latmarch.h, round 6): in the solver's lattice order the product of a scalar CG2 box operator marches LDS
+    windows through the lattice planes - loop structure from the compile-time parity stencils (fs_cg2_stencil.h), a wave per mesh line,
+    the coefficients of a (line, step) one contiguous step list, the ends of the lines by the column tiles of the tile product in the
+    same launch.  Option lattice_march = 0 keeps the tile product k_lattice_spmv.  Both against the work-item product bit for bit
+    on every row (lattice_check: a difference fails the solve), the solves against each other and against the exact profile: a box of
+    142 x 53 x 37 lattice rows (lines of two 64-pair pieces, a last patch of four lines, chunks of planes of unequal length), one of
+    83 x 57 x 45 (lines of a single piece, Dirichlet values on the faces across the mesh lines' direction: the classes change along
+    the march) and a cube of 137 rows a side."""
+    out = {}
+    boxes = {"142 x 53 x 37": (70, 26, 18, 0), "83 x 57 x 45": (41, 28, 22, 2), "137^3": (68, 68, 68, 1)}
+    try:
+        gpu.set_option("lattice_check", 1)
+        gpu.set_option("lattice_order", 1)
+        gpu.set_option("cg_fused", 0)
+        for name, (nx, ny, nz, axis) in boxes.items():
+            mesh = gpu.DeviceMesh.box(nx, ny, nz, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+            V = gpu.DeviceSpace(mesh, 1, degree=2)
+            xyz, cells, _ = mesh.get()
+            edges = V.edges().astype(np.int64)
+            co = np.concatenate([xyz[:, axis], 0.5 * (xyz[edges[:, 0], axis] + xyz[edges[:, 1], axis])])
+            lo, hi = np.flatnonzero(co == 0.0), np.flatnonzero(co == 1.0)
+            dofs = np.concatenate([lo, hi]).astype(np.int32)
+            vals = np.concatenate([np.full(len(lo), 350.0), np.full(len(hi), 300.0)])
+            A = gpu.DeviceMatrix(V)
+            b = gpu.DeviceVector(V.n_owned)
+            A.assemble(stiffness=20.0)
+            b.fill(0.0)
+            A.apply_dirichlet(b, dofs, vals, symmetric=True)
+            for march in (1, 0):
+                gpu.set_option("lattice_march", march)
+                x = gpu.DeviceVector(V.n_owned)
+                st = gpu.krylov_solve(A, b, x, rtol=1e-10, max_iter=5000)
+                out[(name, march)] = (st, x.get()[:V.n_owned].copy(), 350.0 - 50.0 * co[:V.n_owned])
+    finally:
+        gpu.set_option("lattice_march", 1)
+        gpu.set_option("lattice_order", -1)
+        gpu.set_option("lattice_check", 0)
+        gpu.set_option("cg_fused", -1)
+    for name in boxes:
+        (s1, x1, exact), (s0, x0, _) = out[(name, 1)], out[(name, 0)]
+        assert s1["product_kind"] == 5 and s0["product_kind"] == 2, (name, s1["product_kind"], s0["product_kind"])
+        assert s1["lattice_order"] == 1 and s0["lattice_order"] == 1 and s1["converged"] == 1 and s0["converged"] == 1, name
+        assert abs(s1["iterations"] - s0["iterations"]) <= 1, name
+        scale = np.abs(x0).max()
+        assert np.abs(x1 - x0).max() <= 1e-9 * scale and np.abs(x1 - exact).max() <= 1e-6 * scale, name

@@ -823,3 +823,19 @@ def test_marching_window_launch_planning(tmp_path):
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120).stdout.decode()
     assert out.startswith("ok "), out
+
+
+def test_cg2_stencil_tables_are_what_the_generator_writes(tmp_path):
+    """fs_cg2_stencil.h (the compile-time loop structure of k_lat_march, fs_latmarch.h) is generated from the oracle's Kuhn box mesh and
+    CG2 dof map (tools/gen_cg2_stencil.py): the committed header is byte for byte what the generator writes, eight parity classes of
+    65 / 27 / 19 entries, 28.75 on average - the stored entries per row of a CG2 operator on a Kuhn mesh."""
+    import subprocess, sys
+    out = tmp_path / "fs_cg2_stencil.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_cg2_stencil.py"), str(out)], check=True, capture_output=True, timeout=300)
+    with open(os.path.join(ROOT, "fenicssolver_amd", "csrc", "fs_cg2_stencil.h")) as fh:
+        committed = fh.read()
+    assert out.read_text() == committed
+    import re
+    counts = [int(v) for v in re.search(r"LM_CNT\[8\] = \{([^}]*)\}", committed).group(1).split(",")]
+    assert sorted(counts) == [19, 19, 19, 27, 27, 27, 27, 65] and sum(counts) / 8.0 == 28.75
+

@@ -30,7 +30,7 @@ OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, 
 PHASES = ("init", "n99_1M_dof", "n215_10M_dof", "n215_10M_dof_streaming")
 N_DOF = {"n99_1M_dof": 100 ** 3, "n215_10M_dof": 216 ** 3, "n215_10M_dof_streaming": 216 ** 3}
 MARKER = "k_profile_marker"
-HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_box_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
+HOT = ("k_sell_spmv", "k_dia_pair_spmv", "k_dict_spmv", "k_box_spmv", "k_lat_march", "k_lattice_spmv", "k_dict_cg_iter", "k_cg_update", "k_assemble", "k_dot", "k_dirichlet", "k_residual", "k_sum_partials")
 
 
 def short(name):
