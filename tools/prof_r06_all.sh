@@ -25,6 +25,7 @@ timeout 600 bash $R/tools/prof_ns.sh > $R/gpurun_out/prof_ns_r06.log 2>&1
 timeout 120 python $R/tools/kernel_stats_csv.py $R/gpurun_out/prof_ns $S/r06_ns_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python tools/config5_probe.py 43 2" 2>&1 | tail -1
 rm -rf $R/gpurun_out/prof_amg $R/gpurun_out/prof_ns $R/gpurun_out/prof
 timeout 300 python $R/bench.py --workload p2 --steps 3 --warmup 1 > $S/r06_p2_bench_line.json 2>/dev/null
+(cd $R && DBGS="0 1 3 5 7" timeout 900 bash tools/probes/run_latmarch_abl.sh > /dev/null 2>&1; timeout 600 bash tools/probes/run_latmarch_iter.sh > /dev/null 2>&1; bash tools/probes/latmarch_report.sh > $S/r06_p2_latmarch.txt)      # (k_lat_march with parts switched off, the solve with either product)
 timeout 300 python $R/bench.py --workload th > $S/r06_th_bench_line.json 2>/dev/null
 timeout 300 python $R/bench.py --cells 215 --mesh renumbered --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-case > $S/r06_sell_unstructured_renumbered_bench_line.json 2>/dev/null
 timeout 400 bash $R/tools/probes/run_box_probe.sh "216 441" > /dev/null 2>&1; cp $R/gpurun_out/box_probe.txt $S/r06_box_probe.txt
