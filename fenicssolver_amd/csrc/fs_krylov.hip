@@ -785,7 +785,7 @@ __global__ void k_lat_count_diff(int64_t n, const double* __restrict__ a, const 
 }
 
 // ---- the marching-window product of a lattice-ordered CG2 box operator (fs_latmarch.h, k_lat_march) -----------------------------------
-// One workgroup per CU: seven line waves - a wave a line of the patch - and a loader; the rings (window, step lists, dot weights:
+// One workgroup per CU: eleven line waves - a wave a line of the patch - and a loader (three waves a SIMD); the rings (window, step lists, dot weights:
 // three slots each, the loaders two steps ahead) take up to 150 KB of LDS.  Lines of up to 64 or 128 pairs (RP = 1, 2 pieces).
 // Its tables (coefficient rows by stencil position, the row numbers of the lines, the step lists) are built - and every class, every
 // line checked against what the kernel assumes - by lat_prepare behind the lists of the tile product; an operator that does not fit

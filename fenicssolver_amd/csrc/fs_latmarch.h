@@ -35,8 +35,9 @@
 // A LOADER wave brings window and dot weights with global_load_lds_dwordx4, LM_D steps ahead (fs_box.h: exact vmcnt counts).
 //
 // MEASURED (round 6, MI355X, configs[3], 9.98 M rows; tools/probes/run_latmarch_abl.sh, profiles/r06_p2_latmarch.txt): inside the CG
-// iteration 80 - 85 us per product against 115 - 120 for k_lattice_spmv; alone, warm, 70 us without / 83 with the dots (tile product
-// 96 / 96).  The loads alone (no arithmetic) take 30 / 46 us, the line waves alone 56 / 66, the ends of the lines 12: what bounds
+// iteration 76 - 79 us per product against 114 - 120 for k_lattice_spmv; alone, warm, 61 us without / 79 with the dots (tile product
+// 96 / 96).  The loads alone (no arithmetic) take 28 / 43 us, the line waves alone 50 / 63 (seven line waves: 56 / 66), the ends of the
+// lines 12: what bounds
 // the kernel is the instruction stream of a line wave - 2 700 - 3 800 cycles per step where its fmas take 460 (cycle counters around
 // barrier and step).  Steps on the way, all bit-identical:
 //  * coefficients through scalar loads from per-class rows (ten rows a step, thirteen s_waitcnt lgkmcnt(0) per line task, a task a
@@ -51,7 +52,10 @@
 //  * the list lane-distributed in two registers, a coefficient handed out with two v_readlane_b32 (4 cycles each, tools/probes/
 //    readlane_probe.hip) - no memory round trip for coefficients at all: line waves alone 61 us, no better: not the loads of the
 //    coefficients, the whole stream (register moves that rotate the five partial sums, hazards, two waves a SIMD) is what a step costs;
-//  * loader three steps ahead: no change;
+//  * loader three steps ahead: no change; dot weights with the default cache policy instead of nt: the update kernel behind the
+//    product 98 -> 117 us;
+//  * eleven line waves + the loader (twelve waves, three a SIMD, 168 registers allowed, 153 used) instead of seven + one: fewer steps
+//    per wave (30.6 -> 21.4), less window halo (1.57 -> 1.36 x): 80 - 85 -> 76 - 79 us inside the iteration - kept;
 //  * the steps two to a loop turn with the parities as template constants (no four-way branch, no registers where branches meet):
 //    eight copies of the step, 602 SGPRs spilled, 100 us inside the iteration.
 #pragma once
@@ -65,9 +69,12 @@
 constexpr int LM_LO = 4, LM_HI = 5;     // rows at the two ends of a line that lat_line_ends takes (LT_LO / LT_HI of the tile product)
 constexpr int LM_ZPAD = 4;              // planes of padding (the zero row) on either side of the per-line row number tables
 constexpr int LM_SL = 84;               // doubles per step list (82 at most: a vertex line's even plane), 42 16-byte pairs
-constexpr int LM_LW = 7;                // line waves of a workgroup: patches of up to LM_LW lines
+constexpr int LM_LW = 11;               // line waves of a workgroup: patches of up to LM_LW lines
+#ifndef LM_DC_AUX
+#define LM_DC_AUX 2             // cache policy of the dot weights (read once): 2 = nt (0: the update kernel behind the product 98 -> 117 us)
+#endif
 constexpr int LM_D = 2;                 // steps the loader runs ahead (LM_D + 1 slots of window and dot weights)
-constexpr int LM_WAVES = LM_LW + 1;     // + the loader (eight waves: 256 registers a lane - ten waves spilled at 168)
+constexpr int LM_WAVES = LM_LW + 1;     // + the loader (twelve waves: three a SIMD, 168 registers a lane)
 
 struct lm_geom {
     int64_t n;                  // rows
@@ -259,7 +266,7 @@ __device__ __forceinline__ void lm_march(const lm_geom& g, int wg, int n_wg, con
                 const int sl = st % NS;
                 const int64_t jz = z0 - 2 + st;
                 if (do_x) pieces(x, (jz * NY + Y0 - 2) * SX - 2, ring + sl * g.slot, g.G, std::integral_constant<int, 0>());
-                if (do_d && has_d(st)) pieces(rvec, ((jz - 2) * NY + Y0) * SX, dring + sl * g.dslot, g.Gd, std::integral_constant<int, BOX_DC_AUX>());
+                if (do_d && has_d(st)) pieces(rvec, ((jz - 2) * NY + Y0) * SX, dring + sl * g.dslot, g.Gd, std::integral_constant<int, LM_DC_AUX>());
             };
             for (int r = -D; r < 0; ++r) issue_round(r);
             for (int st = 0; st < steps; ++st) {
