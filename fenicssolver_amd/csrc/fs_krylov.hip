@@ -786,7 +786,8 @@ __global__ void k_lat_count_diff(int64_t n, const double* __restrict__ a, const 
 
 // ---- the marching-window product of a lattice-ordered CG2 box operator (fs_latmarch.h, k_lat_march) -----------------------------------
 // One workgroup per CU: eleven line waves - a wave a line of the patch - and a loader (three waves a SIMD); the rings (window, step lists, dot weights:
-// three slots each, the loaders two steps ahead) take up to 150 KB of LDS.  Lines of up to 64 or 128 pairs (RP = 1, 2 pieces).
+// three slots each, the loaders two steps ahead) take up to 150 KB of LDS.  A wave takes one or two 64-pair pieces of a line (RP), lines
+// of more than 128 pairs several waves.
 // Its tables (coefficient rows by stencil position, the row numbers of the lines, the step lists) are built - and every class, every
 // line checked against what the kernel assumes - by lat_prepare behind the lists of the tile product; an operator that does not fit
 // (an entry outside its parity's stencil, a line whose interior rows are of several classes) keeps the tile product.
@@ -819,9 +820,10 @@ static void lm_prepare_kernels() {
 static bool lm_plan(int64_t SX, int64_t NY, int64_t NZ, lm_geom* out, size_t* lds_out) {
     const int cus = fs_rt().compute_units > 0 ? fs_rt().compute_units : 256;
     const int nh = (int)((SX / 2 + 63) / 64);
-    if (nh < 1 || nh > 2 || SX * NY * (NZ + 8) >= ((int64_t)1 << 31)) return false;
+    if (nh < 1 || nh > 2 * LM_LW || SX * NY * (NZ + 8) >= ((int64_t)1 << 31)) return false;
     static const int py_env = getenv("FS_LATTICE_MARCH_PY") ? atoi(getenv("FS_LATTICE_MARCH_PY")) : 0;
-    int py = LM_LW;
+    int py = LM_LW / ((nh + 1) / 2);         // (a wave takes two pieces of a line)
+    if (py < 1) return false;
     if (py_env >= 1 && py_env <= py) py = py_env;
     for (; py >= 1; --py) {
         lm_geom g;

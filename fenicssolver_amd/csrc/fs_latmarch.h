@@ -26,8 +26,8 @@
 // columns, contiguous, in the order the step uses them (window line by window line, so that a lane holds two lines of the window at a
 // time, not five).  The lists are made once per dictionary (k_lm_lines .. k_lm_fill: a few hundred distinct ones - the interior of the
 // box has four) and read through SCALAR loads: the list of a (line, step) is wave-uniform, a coefficient an SGPR operand of the fmas.
-// A wave takes a LINE of the patch - all its pieces of 64 pairs against one stream of the line's list: a coefficient serves 2 x
-// (pieces) fmas.
+// A wave takes a LINE of the patch - up to two pieces of 64 pairs against one stream of the line's list: a coefficient serves 2 x
+// (pieces) fmas; a line of more than 128 pairs takes several waves (27 M rows, lines of 302: 222 us against 341 for the tile product).
 // The ENDS of the lines (X < LM_LO, X > SX - 1 - LM_HI: boundary rows, the rows coupled to them, the dummy row that makes a line
 // even) have classes of their own - 4 % of the rows at configs[3].  They stay with the code of the tile product (lat_line_ends,
 // fs_krylov_lattice.inc: column tiles, lanes along Y), in workgroups of their own at the front of the grid of the same launch
@@ -81,6 +81,7 @@ struct lm_geom {
     int32_t SX, NY, NZ;         // the lattice (SX even)
     int32_t HP;                 // pairs per line = SX / 2
     int32_t NH;                 // 64-pair pieces of a line
+    int32_t WPL;                // waves per line: a wave takes up to two pieces
     int32_t PY;                 // lines per patch
     int32_t NP;                 // patches per plane
     int32_t ZC;                 // chunks of planes
@@ -203,7 +204,7 @@ __device__ __forceinline__ void lm_line_step(const lm_lds_pairs (&Wc)[RP], int h
 
 
 // The interior of the lines (X = LM_LO .. SX - 1 - LM_HI) of the units of workgroup wg of n_wg.  DOTS as k_box_spmv.  A workgroup:
-// LM_LW line waves - wave w takes line w of the patch, its RP = NH pieces of 64 pairs - and a loader wave; D: steps the loaders
+// LM_LW line waves - a wave takes RP <= 2 pieces of 64 pairs of a line of the patch, WPL waves a line - and a loader wave; D: steps the loaders
 // run ahead (D + 1 slots each).  SL[list][LM_SL]: the step lists; sl_line[(jz + 2) NYP + Y]: the list of line Y at window plane jz.
 // lds: the dynamic LDS (lm_lds_bytes).  The dot sums of a lane are added to d_rz, d_wz, d_rr.
 template <int DOTS, int RP, int D>
@@ -289,7 +290,7 @@ __device__ __forceinline__ void lm_march(const lm_geom& g, int wg, int n_wg, con
                 for (int k = 0; k < 4; ++k) AE[i][k] = AO[i][k] = 0.0;
                 zE[i][0] = zE[i][1] = zO[i][0] = zO[i][1] = 0.0;
             }
-            const int il = wave, Y = Y0 + il;
+            const int il = wave / g.WPL, piece0 = (wave - il * g.WPL) * RP, Y = Y0 + il;     // (a line of more than two pieces: several waves)
             const bool live = Y < NY;                // (uniform)
             // (the number of the line's list: asked for a step ahead)
             const int32_t* __restrict__ idp = sl_line + (int64_t)z0 * g.NYP + (live ? Y : NY - 1);       // (step st: window plane z0 - 2 + st, entry jz + 2)
@@ -308,7 +309,7 @@ __device__ __forceinline__ void lm_march(const lm_geom& g, int wg, int n_wg, con
                 int lq[RP];
 #pragma unroll
                 for (int i = 0; i < RP; ++i) {
-                    const int lp = i * 64 + lane;
+                    const int lp = (piece0 + i) * 64 + lane;
                     lq[i] = lp < HP ? lp : HP - 1;
                     Wc[i] = W + lq[i];
                 }
@@ -321,7 +322,7 @@ __device__ __forceinline__ void lm_march(const lm_geom& g, int wg, int n_wg, con
 #pragma unroll
                 for (int i = 0; i < RP; ++i) {
                     if (fin) {
-                        const int lp = i * 64 + lane, X = 2 * lp;
+                        const int lp = (piece0 + i) * 64 + lane, X = 2 * lp;
                         const bool stE = lp < HP && X >= LM_LO && X <= SX - 1 - LM_HI, stO = lp < HP && X + 1 >= LM_LO && X + 1 <= SX - 1 - LM_HI;
                         const int64_t row = ((int64_t)(jz - 2) * NY + Y) * SX + X;
                         lm_v2d ri = lm_v2d{0.0, 0.0};
@@ -351,7 +352,7 @@ __device__ __forceinline__ void lm_march(const lm_geom& g, int wg, int n_wg, con
     }
     };
     if (wave >= LM_LW) run(std::integral_constant<int, 0>());
-    else if (wave >= g.PY) run(std::integral_constant<int, 2>());
+    else if (wave >= g.PY * g.WPL) run(std::integral_constant<int, 2>());
     else run(std::integral_constant<int, 1>());
 }
 
@@ -361,6 +362,7 @@ static inline void lm_cut(lm_geom* g, int64_t SX, int64_t NY, int64_t NZ, int PY
     g->SX = (int32_t)SX; g->NY = (int32_t)NY; g->NZ = (int32_t)NZ;
     g->HP = (int32_t)(SX / 2);
     g->NH = (g->HP + 63) / 64;
+    g->WPL = (g->NH + 1) / 2;
     g->PY = PY;
     g->NP = (int32_t)((NY + PY - 1) / PY);
     const int64_t need = (int64_t)(PY + 4) * SX + 4;            // (a pair in front of the first line, one behind the last)

@@ -691,9 +691,9 @@ def test_marching_window_product_of_cg2_boxes_against_the_tile_product(gpu):
     on every row (lattice_check: a difference fails the solve), the solves against each other and against the exact profile: a box of
     142 x 53 x 37 lattice rows (lines of two 64-pair pieces, a last patch of four lines, chunks of planes of unequal length), one of
     83 x 57 x 45 (lines of a single piece, Dirichlet values on the faces across the mesh lines' direction: the classes change along
-    the march) and a cube of 137 rows a side."""
+    the march), a cube of 137 rows a side, and a box with lines of three pieces (262 rows: two waves a line)."""
     out = {}
-    boxes = {"142 x 53 x 37": (70, 26, 18, 0), "83 x 57 x 45": (41, 28, 22, 2), "137^3": (68, 68, 68, 1)}
+    boxes = {"142 x 53 x 37": (70, 26, 18, 0), "83 x 57 x 45": (41, 28, 22, 2), "137^3": (68, 68, 68, 1), "262 x 17 x 17": (130, 8, 8, 1)}
     try:
         gpu.set_option("lattice_check", 1)
         gpu.set_option("lattice_order", 1)
